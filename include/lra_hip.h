@@ -1,0 +1,72 @@
+/* include/lra_hip.h -- C ABI of liblra_hip.so: the MI355X (gfx950) replacement for the
+ * per-read alignment hot path of ChaissonLab/LRA (MapRead.h:153-263 and what it calls).
+ *
+ * The reference has no FFI seam: every stage is a C++ function template #included into
+ * lra.cpp.  Each entry point below replaces ONE of those functions for a whole BATCH of
+ * reads / sub-problems (the GPU needs thousands at once), and cites the reference
+ * function it replaces.  A maintainer binds them from MapRead.h as shown in
+ * INTEGRATION.md.
+ *
+ * Conventions
+ *   - plain C types only; no torch / STL types cross the boundary;
+ *   - pointers named d_* are DEVICE (HBM) pointers, h_* are host pointers;
+ *   - every call is asynchronous on the context's HIP stream (lra_ctx_set_stream) unless
+ *     it says "synchronous"; the caller synchronises the stream before reading results;
+ *   - return value: 0 = ok, negative = error (lra_ctx_last_error gives the text); the
+ *     library never calls exit() (the reference exit(1)s, lra.cpp:623-640);
+ *   - per-item `status` words report conditions that are undefined behaviour or an
+ *     endless loop in the reference (so no parity is defined for them).
+ */
+#ifndef LRA_HIP_H_
+#define LRA_HIP_H_
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct lra_ctx lra_ctx;
+
+#define LRA_OK 0
+#define LRA_ERR_INVALID (-1)
+#define LRA_ERR_HIP (-2)
+#define LRA_ERR_NOMEM (-3)
+
+/* per-item status bits */
+#define LRA_ST_OOB_SLOT 1      /* reference would index outside its matrices            */
+#define LRA_ST_NO_TERMINATION 2 /* reference trace back would loop forever              */
+#define LRA_ST_RANGE 4         /* problem too large for the 32-bit device score range   */
+#define LRA_ST_CAPACITY 8      /* caller-provided output capacity exceeded              */
+
+/* ---- context ---------------------------------------------------------------------- */
+int lra_ctx_create(int device_id, lra_ctx** out);
+void lra_ctx_destroy(lra_ctx* ctx);
+/* stream = a hipStream_t (NULL = the default stream).  All later calls launch on it. */
+int lra_ctx_set_stream(lra_ctx* ctx, void* stream);
+const char* lra_ctx_last_error(lra_ctx* ctx);
+/* ABI version of the loaded library (tests check it against this header). */
+int lra_abi_version(void);
+#define LRA_ABI_VERSION 1
+
+/* ---- a12: banded one-gap seed-extension DP ------------------------------------------
+ * Replaces   int AffineOneGapAlign(string& qSeq, int qLen, string& tSeq, int tLen,
+ *                                  int m, int mm, int indel, int k, Alignment& aln,
+ *                                  AffineAlignBuffers& b)          (AffineOneGapAlign.h:157)
+ * for n independent (q,t,k) problems.  Sequences are ASCII bytes inside one device
+ * buffer d_seq; problem p uses d_seq[q_off[p] .. +q_len[p]) and d_seq[t_off[p] .. +t_len[p]).
+ * Outputs per problem: the returned score; the gapless blocks the reference appends to
+ * aln.blocks, as (qPos,tPos,length) int32 triples written at d_blocks + 3*d_block_off[p]
+ * (capacity d_block_off[p+1]-d_block_off[p] triples; min(q_len,t_len)+1 always suffices);
+ * their count; a status word (bits above).                                              */
+int lra_affine_one_gap_align_batch(lra_ctx* ctx, int n, const char* d_seq,
+                                   const uint64_t* d_q_off, const int32_t* d_q_len,
+                                   const uint64_t* d_t_off, const int32_t* d_t_len,
+                                   const int32_t* d_k, int m, int mm, int indel,
+                                   int32_t* d_score, int32_t* d_nblocks, int32_t* d_blocks,
+                                   const uint64_t* d_block_off, int32_t* d_status);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* LRA_HIP_H_ */

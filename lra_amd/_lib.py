@@ -1,0 +1,50 @@
+"""ctypes loader for liblra_hip.so (the HIP kernels + C ABI).  Fails loudly if absent."""
+import ctypes as C
+import os
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB = None
+ABI_VERSION = 1
+
+
+class LraError(RuntimeError):
+    pass
+
+
+def library_path():
+    return os.path.join(HERE, "liblra_hip.so")
+
+
+# name -> (restype, argtypes); every symbol include/lra_hip.h declares
+_u64p = C.POINTER(C.c_uint64)
+_i32p = C.POINTER(C.c_int32)
+_vp = C.c_void_p
+SYMBOLS = {
+    "lra_abi_version": (C.c_int, []),
+    "lra_ctx_create": (C.c_int, [C.c_int, C.POINTER(_vp)]),
+    "lra_ctx_destroy": (None, [_vp]),
+    "lra_ctx_set_stream": (C.c_int, [_vp, _vp]),
+    "lra_ctx_last_error": (C.c_char_p, [_vp]),
+    "lra_affine_one_gap_align_batch": (C.c_int, [_vp, C.c_int, _vp, _vp, _vp, _vp, _vp, _vp, C.c_int, C.c_int,
+                                                  C.c_int, _vp, _vp, _vp, _vp, _vp]),
+}
+
+
+def load_library():
+    """Load liblra_hip.so; raise LraError if it has not been built (no fallback exists)."""
+    global _LIB
+    if _LIB is not None:
+        return _LIB
+    path = library_path()
+    if not os.path.exists(path):
+        raise LraError("liblra_hip.so is not built (%s). Run `python -c 'import __graft_entry__ as g; g.build()'` "
+                       "-- lra_amd has no CPU fallback." % path)
+    lib = C.CDLL(path)
+    for name, (res, args) in SYMBOLS.items():
+        fn = getattr(lib, name)  # AttributeError if the symbol is missing
+        fn.restype = res
+        fn.argtypes = args
+    if lib.lra_abi_version() != ABI_VERSION:
+        raise LraError("liblra_hip.so ABI %d != expected %d" % (lib.lra_abi_version(), ABI_VERSION))
+    _LIB = lib
+    return lib

@@ -1,0 +1,46 @@
+"""Device context: owns an lra_ctx bound to one GPU and to torch's current stream."""
+import ctypes as C
+
+import torch
+
+from ._lib import LraError, load_library
+
+
+class Context:
+    """One per process / GPU.  torch is used only for device memory and streams."""
+
+    def __init__(self, device=0):
+        if not torch.cuda.is_available():
+            raise LraError("no GPU visible: lra_amd runs only on an MI355X (there is no CPU fallback)")
+        self.lib = load_library()
+        self.device = torch.device("cuda", device)
+        h = C.c_void_p()
+        rc = self.lib.lra_ctx_create(device, C.byref(h))
+        if rc != 0:
+            raise LraError("lra_ctx_create failed (%d)" % rc)
+        self.h = h
+        self.bind_stream()
+
+    def bind_stream(self, stream=None):
+        s = stream if stream is not None else torch.cuda.current_stream(self.device)
+        self.check(self.lib.lra_ctx_set_stream(self.h, C.c_void_p(s.cuda_stream)))
+
+    def check(self, rc):
+        if rc != 0:
+            raise LraError("liblra_hip error %d: %s" % (rc, self.lib.lra_ctx_last_error(self.h).decode()))
+
+    def close(self):
+        if self.h:
+            self.lib.lra_ctx_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+def ptr(t):
+    """Device pointer of a torch tensor as c_void_p (None -> NULL)."""
+    return C.c_void_p(0 if t is None else t.data_ptr())

@@ -1,0 +1,429 @@
+// lra_amd/csrc/aog.hip -- batched banded one-gap seed-extension DP for gfx950.
+//
+// Replaces AffineOneGapAlign (reference: AffineOneGapAlign.h:157-649) for a batch of
+// independent (q, t, k) problems: a banded linear-gap global DP filled from (0,0)
+// ("prefix" band) and, when the length difference exceeds the band ("alignTop",
+// :194-203), a second band anchored at (qLen,tLen) ("suffix") joined to the first by
+// one free long gap chosen through per-row / per-column running maxima (:347-360).
+//
+// MI355X mapping
+//   * one 64-lane wavefront owns one problem; its two flat score/arrow matrices, the
+//     per-diagonal maxima and the 2-bit sequence codes live in that wave's LDS slice
+//     (classes A: <= 10 KB, 4 waves per workgroup; B: <= 64 KB, 1 wave per workgroup),
+//     or in an HBM scratch slot for the rare larger problem (class C);
+//   * the band is swept by ANTI-DIAGONALS: the <= k+1 cells of one anti-diagonal are
+//     independent, one lane each; consecutive sweeps are ordered by wavefront-local
+//     fences only (no s_barrier: the waves of a workgroup run different problems);
+//   * the per-row / per-column maxima (ties: last row resp. first column, as the
+//     reference's >= / > updates give) are taken after the sweep, one lane per row/column;
+//   * trace back is a serial walk by lane 0 over 1-byte arrows; blocks are emitted in
+//     walk order and reversed cooperatively.
+//   Scores are int32 with MISSING = -2^30 (the reference uses INT_MIN in 64-bit cells,
+//   :29,:146); every decision compares values whose offsets from MISSING stay below
+//   2^28 (checked per problem), so all orderings and equalities are preserved, and the
+//   returned score is mapped back to the reference's 32-bit truncation.
+//   Slot arithmetic (:12-27) is kept exactly: the suffix matrix is addressed through a
+//   shifted origin and some out-of-band neighbour reads land on other rows' slots.
+#include "common.h"
+
+namespace {
+
+constexpr int MISS = -(1 << 30);
+enum { A_DONE = 0, A_LEFT = 1, A_DOWN = 2, A_DIAG = 3, A_BORDER = 4, A_GAPLEFT = 5, A_GAPDOWN = 6 };
+
+constexpr int CLASS_A_BYTES = 10 * 1024;  // per wave, 4 waves per workgroup
+constexpr int CLASS_B_BYTES = 64 * 1024;  // per wave, 1 wave per workgroup
+
+__device__ __forceinline__ int code_n(unsigned char c) {  // SeqUtils.h:42-75 (seqMapN)
+  if (c < 8) return c & 3;
+  switch (c) {
+    case 'A': case 'a': return 0;
+    case 'C': case 'c': return 1;
+    case 'G': case 'g': return 2;
+    case 'T': case 't': return 3;
+    default: return 4;
+  }
+}
+
+struct Geo {
+  int qLen, tLen, diag, k, R, qB, tB;
+  bool top;
+  int n;  // slots per matrix
+};
+
+__device__ __forceinline__ bool make_geo(int qLen, int tLen, int k0, Geo& g) {
+  g.qLen = qLen; g.tLen = tLen;
+  g.diag = max(1, min(qLen, tLen));                 // :162
+  int k = min(g.diag, k0);                          // :194
+  g.top = true;
+  if (g.diag + 2 * k >= max(qLen, tLen)) { k *= 2; g.top = false; }  // :196-203
+  g.k = k;
+  g.R = 2 * k + 3;                                  // :207-209
+  long n = (long)(3 + k + g.diag) * g.R;            // :210
+  g.qB = min(g.diag + k, qLen + 1);                 // :309-310
+  g.tB = min(g.diag + k, tLen + 1);
+  if (n > (1L << 28)) { g.n = 0; return false; }
+  g.n = (int)n;
+  return true;
+}
+
+__host__ __device__ __forceinline__ long align4(long x) { return (x + 3) & ~3L; }
+
+// bytes of working memory one problem needs (same carve order as carve())
+__device__ __forceinline__ long need_bytes(const Geo& g) {
+  long mats = g.top ? 2 : 1;
+  return mats * 4L * g.n + 16L * (g.diag + 1) + mats * align4(g.n) + align4(g.qLen + 1) + align4(g.tLen + 1);
+}
+
+struct Work {
+  int* sPre; int* sSuf; int* loMax; int* loIdx; int* upMax; int* upIdx;
+  signed char* pPre; signed char* pSuf; unsigned char* qc; unsigned char* tc;
+};
+
+template <typename BytePtr>
+__device__ __forceinline__ Work carve(BytePtr base, const Geo& g) {
+  Work w;
+  auto* p = base;
+  w.sPre = (int*)p; p += 4L * g.n;
+  w.sSuf = (int*)p; if (g.top) p += 4L * g.n;
+  w.loMax = (int*)p; p += 4L * (g.diag + 1);
+  w.loIdx = (int*)p; p += 4L * (g.diag + 1);
+  w.upMax = (int*)p; p += 4L * (g.diag + 1);
+  w.upIdx = (int*)p; p += 4L * (g.diag + 1);
+  w.pPre = (signed char*)p; p += align4(g.n);
+  w.pSuf = (signed char*)p; if (g.top) p += align4(g.n);
+  w.qc = (unsigned char*)p; p += align4(g.qLen + 1);
+  w.tc = (unsigned char*)p;
+  return w;
+}
+
+// Orders this wave's earlier LDS / global writes before its later reads.  Workgroup-scope
+// fences lower to s_waitcnt only (no barrier, no cache maintenance): one wave's memory
+// instructions are serviced in order by its CU's LDS and L1.
+__device__ __forceinline__ void wave_sync() {
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+}
+
+struct Problem {
+  const char* q; const char* t;
+  int qLen, tLen, k0, m, mm, indel;
+};
+
+template <typename BytePtr>
+__device__ __forceinline__ void solve(int lane, const Problem& pr, const Geo& g, BytePtr mem, int* out_score,
+                      int* out_nb, int* blocks, long cap, int* out_status) {
+  const int qLen = g.qLen, tLen = g.tLen, k = g.k, R = g.R, diag = g.diag, n = g.n;
+  const int m = pr.m, mm = pr.mm, indel = pr.indel;
+  Work w = carve(mem, g);
+  int status = 0;
+  auto PI = [&](int i, int j) { return j * R + (i - j) + k + 1; };  // :12-17
+  auto inb = [&](int s) { return s >= 0 && s < n; };
+#define PSET(slot, sc, ar)                                                         \
+  do { int s__ = (slot); if (inb(s__)) { w.sPre[s__] = (sc); w.pPre[s__] = (ar); } else status |= LRA_ST_OOB_SLOT; } while (0)
+#define SSET(slot, sc, ar)                                                         \
+  do { int s__ = (slot); if (inb(s__)) { w.sSuf[s__] = (sc); w.pSuf[s__] = (ar); } else status |= LRA_ST_OOB_SLOT; } while (0)
+
+  // ---- codes + clear (:173-219)
+  for (int x = lane; x <= qLen; x += 64) w.qc[x] = x ? code_n((unsigned char)pr.q[x - 1]) : 0;
+  for (int x = lane; x <= tLen; x += 64) w.tc[x] = x ? code_n((unsigned char)pr.t[x - 1]) : 0;
+  for (int x = lane; x < n; x += 64) { w.sPre[x] = MISS; w.pPre[x] = -1; }
+  if (g.top)
+    for (int x = lane; x < n; x += 64) { w.sSuf[x] = MISS; w.pSuf[x] = -1; }
+  for (int x = lane; x <= diag; x += 64) { w.loMax[x] = MISS; w.loIdx[x] = 0; w.upMax[x] = MISS; w.upIdx[x] = 0; }
+  wave_sync();
+  // ---- prefix boundary (:229-241), then rails (:248-306); the rails overwrite (0,k+1)
+  for (int i = 1 + lane; i < k + 1; i += 64) PSET(PI(i, 0), indel * i, A_LEFT);
+  for (int j = 1 + lane; j <= k + 1; j += 64) PSET(PI(0, j), indel * j, A_DOWN);
+  if (lane == 0) PSET(PI(0, 0), 0, A_DONE);
+  wave_sync();
+  if (qLen >= tLen) {
+    for (int i = lane; i <= diag - k - 1; i += 64) PSET(PI(i, i + k + 1), MISS, A_BORDER);
+    for (int i = 1 + lane; i < diag + k - 1; i += 64) PSET(PI(i + k + 1, i), MISS, A_BORDER);
+  }
+  if (qLen <= tLen) {
+    for (int j = lane; j < diag - 1; j += 64) PSET(PI(j + k + 1, j), MISS, A_BORDER);
+    for (int j = 1 + lane; j < diag + k; j += 64) PSET(PI(j - k - 1, j), MISS, A_BORDER);
+  }
+  wave_sync();
+  // ---- prefix fill by anti-diagonals s = i + j (:313-339)
+  const int qB = g.qB, tB = g.tB;
+  for (int s = 2; s <= (qB - 1) + (tB - 1); s++) {
+    int jlo = max(1, max(s - qB + 1, (s - k + 1) >> 1));   // ceil((s-k)/2), s-k may be < 0
+    if (s - k < 0) jlo = max(1, s - qB + 1);
+    int jhi = min(tB - 1, min(s - 1, (s + k) >> 1));
+    for (int j = jlo + lane; j <= jhi; j += 64) {
+      int i = s - j;
+      int sIns = w.sPre[PI(i - 1, j)] + indel;
+      int sDel = w.sPre[PI(i, j - 1)] + indel;
+      int sMat = w.sPre[PI(i - 1, j - 1)] + (w.qc[i] == w.tc[j] ? m : mm);
+      int best = max(sIns, max(sDel, sMat));
+      int ar = (best == sIns) ? A_LEFT : (best == sDel) ? A_DOWN : A_DIAG;   // :331-339
+      int slot = PI(i, j);
+      w.sPre[slot] = best;
+      w.pPre[slot] = (signed char)ar;
+    }
+    wave_sync();
+  }
+
+  int ti, tj;        // trace-back cursor
+  int result;
+  long nb = 0;       // blocks written (walk order)
+  const long iter_cap = 4L * (qLen + tLen + 8);
+  // A block is a maximal run of diagonal arrows; (i,j) after the run is its start.
+  int run = 0;
+  auto flush = [&](int i_after, int j_after) {
+    if (run > 0) {
+      if (nb < cap) { blocks[3 * nb] = i_after; blocks[3 * nb + 1] = j_after; blocks[3 * nb + 2] = run; }
+      else status |= LRA_ST_CAPACITY;
+      nb++;
+      run = 0;
+    }
+  };
+
+  if (g.top) {
+    // ---- per-row / per-column maxima of the prefix band (:347-360)
+    //   loMax[j] = max over rows i < qLen-k of column j, ties -> LARGEST i   (>=)
+    //   upMax[i] = max over columns j < tLen of row i (i <= diag), ties -> SMALLEST j (>)
+    for (int j = 1 + lane; j < tB && j <= diag; j += 64) {
+      int bm = MISS, bi = 0;
+      int ihi = min(qB, j + k + 1);
+      for (int i = max(1, j - k); i < ihi && i < qLen - k; i++) {
+        int v = w.sPre[PI(i, j)];
+        if (v >= bm) { bm = v; bi = i; }
+      }
+      w.loMax[j] = bm; w.loIdx[j] = bi;
+    }
+    for (int i = 1 + lane; i <= diag && i < qB; i += 64) {
+      int bm = MISS, bj = 0;
+      int jhi = min(tB - 1, i + k);
+      for (int j = max(1, i - k); j <= jhi && j < tLen; j++) {
+        int v = w.sPre[PI(i, j)];
+        if (v > bm) { bm = v; bj = j; }
+      }
+      w.upMax[i] = bm; w.upIdx[i] = bj;
+    }
+    if (lane == 0) {
+      if (qLen >= tLen) { w.loMax[0] = 0; w.loIdx[0] = 0; }   // :275-276
+      if (qLen <= tLen) { w.upMax[0] = 0; w.upIdx[0] = 0; }   // :300-301
+    }
+    wave_sync();
+    // ---- suffix boundary (:409-467), loop by loop in the reference's order
+    const int qStart = max(0, qLen - diag), qEnd = qLen + 1;
+    const int tStart = max(0, tLen - diag);
+    const int tLow = max(0, tLen - diag - k - 1 - 1);
+    const int qLow = max(0, qLen - diag - k - 1);
+    const int tEnd = tLen + 1;
+    auto SI = [&](int ii, int jj) {                               // :19-27
+      int a = ii - qLow, b = jj - tLow;
+      return b * R + (a - b) + k + 1;
+    };
+    if (qLen >= tLen) {
+      for (int i = qLow + lane; i < qStart + k + 1; i += 64) SSET(SI(i, 0), w.loMax[0], A_GAPLEFT);
+      wave_sync();
+      for (int j = 1 + lane; j <= diag; j += 64) SSET(SI(qLow + j - 1, j), w.loMax[j], A_GAPLEFT);
+      wave_sync();
+      for (int j = tStart + 1 + lane; j < tEnd - k; j += 64) SSET(SI(qStart + (j - tStart - 1) + k + 1, j), MISS, A_BORDER);
+      wave_sync();
+    }
+    if (qLen <= tLen) {
+      for (int j = tLow + lane; j < tStart + k + 2; j += 64) SSET(SI(qStart, j), w.upMax[0], A_GAPDOWN);
+      wave_sync();
+      for (int j = tStart + 1 + lane; j < tEnd; j += 64) {
+        int i = qStart + 1 + (j - tStart - 1);
+        SSET(SI(i, j - k - 1), (i <= diag ? w.upMax[i] : MISS), A_GAPDOWN);
+      }
+      wave_sync();
+      for (int j = tStart + lane; j < tEnd - k - 1; j += 64) SSET(SI(qStart + (j - tStart), j + k + 1), MISS, A_BORDER);
+      wave_sync();
+    }
+    // ---- suffix fill by anti-diagonals (:474-518).  Row j holds rows
+    //      i in [max(qLow+1, j+c0-k), min(qLen, j+c0+k)],  c0 = qStart + diag - tLen.
+    const int c0 = qStart + diag - tLen;
+    const bool qLong = qLen >= tLen;
+    for (int s = (qLow + 1) + (tLow + 1); s <= qLen + tLen; s++) {
+      int num = s - c0 - k;
+      int jlo = (num >= 0) ? ((num + 1) >> 1) : -((-num) >> 1);           // ceil(num/2)
+      jlo = max(jlo, max(tLow + 1, s - qLen));
+      int num2 = s - c0 + k;
+      int jhi = (num2 >= 0) ? (num2 >> 1) : -((-num2 + 1) >> 1);          // floor(num2/2)
+      jhi = min(jhi, min(tLen, s - qLow - 1));
+      for (int j = jlo + lane; j <= jhi; j += 64) {
+        int i = s - j;
+        int delClose = MISS, insClose = MISS;
+        if (qLong) delClose = (j <= diag) ? w.loMax[j] : MISS;
+        else insClose = (i <= diag) ? w.upMax[i] : MISS;
+        int a = SI(i - 1, j), b = SI(i, j - 1), c = SI(i - 1, j - 1);
+        if (!inb(a) || !inb(b) || !inb(c)) { status |= LRA_ST_OOB_SLOT; continue; }
+        int sIns = w.sSuf[a] + indel;
+        int sDel = w.sSuf[b] + indel;
+        int sMat = w.sSuf[c] + (w.qc[i] == w.tc[j] ? m : mm);
+        int best = max(delClose, max(insClose, max(sIns, max(sDel, sMat))));
+        int ar = (best == sIns) ? A_LEFT : (best == sDel) ? A_DOWN : (best == sMat) ? A_DIAG
+                 : (best == delClose) ? A_GAPLEFT : A_GAPDOWN;              // :502-516
+        SSET(SI(i, j), best, (signed char)ar);
+      }
+      wave_sync();
+    }
+    // ---- suffix trace back (:523-580), lane 0
+    ti = qLen; tj = tLen;
+    int s0 = SI(ti, tj);
+    int arrow = inb(s0) ? w.pSuf[s0] : -1;
+    result = inb(s0) ? w.sSuf[s0] : MISS;
+    if (lane == 0) {
+      long it = 0;
+      while (arrow != A_DONE && arrow != A_GAPDOWN && arrow != A_GAPLEFT && ti >= 0 && tj >= 0) {
+        if (++it > iter_cap) { status |= LRA_ST_NO_TERMINATION; break; }
+        if (arrow == A_DIAG) { run++; ti--; tj--; }
+        else if (arrow == A_LEFT) { flush(ti, tj); ti--; }
+        else if (arrow == A_DOWN) { flush(ti, tj); tj--; }
+        else { status |= LRA_ST_NO_TERMINATION; break; }   // border / unset arrow: endless in the reference
+        if (ti >= 0 && tj >= 0) { int sl = SI(ti, tj); arrow = inb(sl) ? w.pSuf[sl] : -1; if (!inb(sl)) status |= LRA_ST_OOB_SLOT; }
+      }
+      flush(ti, tj);
+      if (arrow == A_GAPDOWN && ti >= 0 && ti <= diag) tj = w.upIdx[ti];      // :568-574
+      else if (arrow == A_GAPLEFT && tj >= 0 && tj <= diag) ti = w.loIdx[tj]; // :575-580
+    }
+  } else {                                                                    // :582-586
+    ti = qB - 1; tj = tB - 1;
+    result = w.sPre[PI(ti, tj)];
+  }
+  // ---- prefix trace back (:589-629), lane 0
+  if (lane == 0) {
+    int arrow = (ti >= 0 && tj >= 0 && inb(PI(ti, tj))) ? w.pPre[PI(ti, tj)] : A_DONE;
+    long it = 0;
+    while (arrow != A_BORDER && arrow != A_DONE && ti >= 0 && tj >= 0) {
+      if (++it > iter_cap) { status |= LRA_ST_NO_TERMINATION; break; }
+      if (arrow == A_DIAG) { run++; ti--; tj--; }
+      else if (arrow == A_LEFT) { flush(ti, tj); ti--; }
+      else if (arrow == A_DOWN) { flush(ti, tj); tj--; }
+      else { if (arrow != A_GAPLEFT && arrow != A_GAPDOWN) status |= LRA_ST_NO_TERMINATION; break; }
+      if (ti < 0 || tj < 0) break;
+      arrow = w.pPre[PI(ti, tj)];
+    }
+    flush(ti, tj);
+  }
+#undef PSET
+#undef SSET
+  // ---- publish: blocks were written in walk (reverse) order with absolute matrix
+  //      coordinates; alignment order is the reverse, relative to where the walk ended.
+  nb = __shfl(nb, 0);
+  int fi = __shfl(ti, 0), fj = __shfl(tj, 0);
+  wave_sync();
+  long nw = min(nb, cap);
+  for (long x = lane; x < (nw + 1) / 2; x += 64) {
+    long y = nw - 1 - x;
+    int a0 = blocks[3 * x], a1 = blocks[3 * x + 1], a2 = blocks[3 * x + 2];
+    int b0 = blocks[3 * y], b1 = blocks[3 * y + 1], b2 = blocks[3 * y + 2];
+    blocks[3 * x] = b0 - fi; blocks[3 * x + 1] = b1 - fj; blocks[3 * x + 2] = b2;
+    if (y != x) { blocks[3 * y] = a0 - fi; blocks[3 * y + 1] = a1 - fj; blocks[3 * y + 2] = a2; }
+  }
+  // status bits raised by any lane
+  for (int off = 32; off > 0; off >>= 1) status |= __shfl_xor(status, off);
+  if (lane == 0) {
+    // map the device score domain back to the reference's (int)(long) truncation
+    int r = result;
+    if (r < -(1 << 29)) r = (int)(unsigned int)((long)INT_MIN + ((long)r - (long)MISS));
+    *out_score = r;
+    *out_nb = (int)nb;
+    *out_status = status;
+  }
+}
+
+struct BatchArgs {
+  int n;
+  const char* seq;
+  const uint64_t* q_off; const int32_t* q_len; const uint64_t* t_off; const int32_t* t_len;
+  const int32_t* k;
+  int m, mm, indel;
+  int32_t* score; int32_t* nblocks; int32_t* blocks; const uint64_t* block_off; int32_t* status;
+  // work lists built by classify(): counts[3], lists 3 x n
+  int* counts; int* lists;
+  char* gscratch; long gslot_bytes; int gslots;
+};
+
+__device__ __forceinline__ bool load_problem(const BatchArgs& a, int p, Problem& pr, Geo& g, int& range_ok) {
+  pr.q = a.seq + a.q_off[p]; pr.t = a.seq + a.t_off[p];
+  pr.qLen = a.q_len[p]; pr.tLen = a.t_len[p]; pr.k0 = a.k[p];
+  pr.m = a.m; pr.mm = a.mm; pr.indel = a.indel;
+  bool ok = pr.qLen >= 0 && pr.tLen >= 0 && pr.k0 >= 1 && make_geo(pr.qLen, pr.tLen, pr.k0, g);
+  long mx = max(abs(a.m), max(abs(a.mm), abs(a.indel)));
+  range_ok = ok && ((long)(pr.qLen + pr.tLen + 16) * (mx + 1) < (1L << 28));
+  return range_ok;
+}
+
+__global__ void aog_classify(BatchArgs a) {
+  int p = blockIdx.x * blockDim.x + threadIdx.x;
+  if (p >= a.n) return;
+  Problem pr; Geo g; int ok;
+  if (!load_problem(a, p, pr, g, ok)) {
+    a.score[p] = 0; a.nblocks[p] = 0; a.status[p] = LRA_ST_RANGE;
+    return;
+  }
+  long need = need_bytes(g);
+  int cls = need <= CLASS_A_BYTES ? 0 : need <= CLASS_B_BYTES ? 1 : 2;
+  if (cls == 2 && need > a.gslot_bytes) { a.score[p] = 0; a.nblocks[p] = 0; a.status[p] = LRA_ST_RANGE; return; }
+  int pos = atomicAdd(&a.counts[cls], 1);
+  a.lists[(long)cls * a.n + pos] = p;
+}
+
+template <int CLS>
+__global__ void __launch_bounds__(CLS == 0 ? 256 : 64) aog_kernel(BatchArgs a) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int lane = threadIdx.x & 63;
+  const int wave_in_wg = threadIdx.x >> 6;
+  const int waves_per_wg = blockDim.x >> 6;
+  const int wave = blockIdx.x * waves_per_wg + wave_in_wg;
+  const int nwaves = gridDim.x * waves_per_wg;
+  const int count = a.counts[CLS];
+  for (int x = wave; x < count; x += nwaves) {
+    int p = a.lists[(long)CLS * a.n + x];
+    Problem pr; Geo g; int ok;
+    load_problem(a, p, pr, g, ok);
+    long cap = (long)(a.block_off[p + 1] - a.block_off[p]);
+    int* blk = a.blocks + 3 * a.block_off[p];
+    if (CLS == 0) solve(lane, pr, g, smem + wave_in_wg * CLASS_A_BYTES, &a.score[p], &a.nblocks[p], blk, cap, &a.status[p]);
+    else if (CLS == 1) solve(lane, pr, g, smem, &a.score[p], &a.nblocks[p], blk, cap, &a.status[p]);
+    else solve(lane, pr, g, a.gscratch + (long)(wave % a.gslots) * a.gslot_bytes, &a.score[p], &a.nblocks[p], blk, cap, &a.status[p]);
+    wave_sync();
+  }
+}
+
+}  // namespace
+
+extern "C" int lra_affine_one_gap_align_batch(lra_ctx* ctx, int n, const char* d_seq,
+                                              const uint64_t* d_q_off, const int32_t* d_q_len,
+                                              const uint64_t* d_t_off, const int32_t* d_t_len,
+                                              const int32_t* d_k, int m, int mm, int indel,
+                                              int32_t* d_score, int32_t* d_nblocks, int32_t* d_blocks,
+                                              const uint64_t* d_block_off, int32_t* d_status) {
+  if (!ctx) return LRA_ERR_INVALID;
+  if (n < 0) return lra_set_err(ctx, LRA_ERR_INVALID, "n < 0");
+  if (n == 0) return LRA_OK;
+  LRA_HIP_CHECK(ctx, hipSetDevice(ctx->device));
+  BatchArgs a;
+  a.n = n; a.seq = d_seq; a.q_off = d_q_off; a.q_len = d_q_len; a.t_off = d_t_off; a.t_len = d_t_len;
+  a.k = d_k; a.m = m; a.mm = mm; a.indel = indel;
+  a.score = d_score; a.nblocks = d_nblocks; a.blocks = d_blocks; a.block_off = d_block_off; a.status = d_status;
+  // scratch slot 0: counts[4] + lists[3n];  slot 1: class-C HBM work slots
+  size_t list_bytes = 16 + sizeof(int) * 3 * (size_t)n;
+  char* s0 = (char*)lra_scratch(ctx, 0, list_bytes);
+  if (!s0) return LRA_ERR_NOMEM;
+  a.counts = (int*)s0; a.lists = (int*)(s0 + 16);
+  a.gslots = ctx->num_cu * 2;
+  a.gslot_bytes = 8L << 20;  // 8 MiB per slot: e.g. 1.5 kb x 1.5 kb at k = 60, or 5 kb x 5 kb at k = 15
+  a.gscratch = (char*)lra_scratch(ctx, 1, (size_t)a.gslots * a.gslot_bytes);
+  if (!a.gscratch) return LRA_ERR_NOMEM;
+  LRA_HIP_CHECK(ctx, hipMemsetAsync(a.counts, 0, 16, ctx->stream));
+  hipLaunchKernelGGL(aog_classify, dim3((n + 255) / 256), dim3(256), 0, ctx->stream, a);
+  int wgA = min((n + 3) / 4, ctx->num_cu * 5);
+  int wgB = min(n, ctx->num_cu * 2);
+  int wgC = min(n, a.gslots);
+  hipLaunchKernelGGL(aog_kernel<0>, dim3(wgA), dim3(256), 4 * CLASS_A_BYTES, ctx->stream, a);
+  LRA_HIP_CHECK(ctx, hipFuncSetAttribute((const void*)aog_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, CLASS_B_BYTES));
+  hipLaunchKernelGGL(aog_kernel<1>, dim3(wgB), dim3(64), CLASS_B_BYTES, ctx->stream, a);
+  hipLaunchKernelGGL(aog_kernel<2>, dim3(wgC), dim3(64), 0, ctx->stream, a);
+  LRA_HIP_CHECK(ctx, hipGetLastError());
+  return LRA_OK;
+}
