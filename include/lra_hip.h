@@ -49,6 +49,62 @@ const char* lra_ctx_last_error(lra_ctx* ctx);
 int lra_abi_version(void);
 #define LRA_ABI_VERSION 1
 
+/* Convenience for hosts without their own HIP binding: synchronous device->host copy on the
+ * context's stream (a C++ host would call hipMemcpy itself).                                */
+int lra_copy_to_host(lra_ctx* ctx, void* h_dst, const void* d_src, uint64_t bytes);
+
+/* Per-kernel device timing (HIP events on the context's stream around every kernel the
+ * library launches).  Off by default.  lra_ctx_timing_get synchronises the stream and returns
+ * the accumulated milliseconds and launch count of the named kernel since the last reset
+ * (names: see DESIGN.md "kernels"); returns LRA_ERR_INVALID for an unknown name.            */
+int lra_ctx_timing_enable(lra_ctx* ctx, int on);
+int lra_ctx_timing_reset(lra_ctx* ctx);
+int lra_ctx_timing_get(lra_ctx* ctx, const char* name, double* total_ms, int* launches);
+
+/* ---- reference data (replicated per GPU) ---------------------------------------------
+ * Genome: the concatenated upper-case chromosome bytes, chromosome c at global offset
+ * header.pos[c] (Genome.h:59-68, Genome::Read :115-138 upper-cases).  Replaces the role of
+ * Genome::seqs / GlobalIndexToSeq (Genome.h:106-112) for the device side.  Synchronous copy. */
+int lra_ctx_load_genome(lra_ctx* ctx, const char* h_seq, uint64_t len);
+/* Global minimizer index = the payload of `ref.mms` (MMIndex.h:402-424): n GenomeTuples
+ * sorted by (t & 2^63-1), passed as two host arrays (t, pos).  Replaces `genomemm`
+ * (MapRead.h:153).  Synchronous copy.                                                       */
+int lra_ctx_load_global_index(lra_ctx* ctx, const uint64_t* h_key, const uint32_t* h_pos, uint64_t n);
+
+/* ---- a1-a4: tier-1 seeding of a read batch ---------------------------------------------
+ * Replaces, per read (MapRead.h:169-203):
+ *   StoreMinimizers<GenomeTuple,Tuple>(read.seq, read.length, k, w, readmm, true)  MinCount.h:8
+ *   sort(readmm.begin(), readmm.end())                                            MapRead.h:185
+ *   CompareLists<GenomeTuple,Tuple>(readmm, genomemm, allMatches, opts, true)     CompareLists.h:9
+ *   SeparateMatchesByStrand(read, genome, k, allMatches, forMatches, revMatches)  MapRead.h:109
+ * Input: n_reads upper-case ASCII reads concatenated in d_seq, read r = bytes
+ * [d_read_off[r], d_read_off[r+1]).  k = opts.globalK, w = opts.globalW,
+ * max_freq = opts.globalMaxFreq.
+ * Output (device arrays owned by the context, valid until the next lra_seed_batch call on
+ * it; CSR by read):
+ *   d_mm_*     readmm after the sort (t with the strand flag in bit 63, pos)
+ *   d_match_*  allMatches in the reference's order: (index into the read's readmm,
+ *              index into the global index) per pair
+ *   d_sep_*    forMatches then revMatches of each read (read pos, genome pos of each pair),
+ *              d_n_forward[r] = forMatches.size()
+ * Synchronous: returns after the results are complete (two host round trips size the
+ * outputs).                                                                                */
+typedef struct lra_seed_result {
+  int32_t n_reads;
+  uint64_t n_minimizers, n_matches;
+  const uint64_t* d_mm_off;    /* [n_reads+1] */
+  const uint64_t* d_mm_key;    /* [n_minimizers] */
+  const uint32_t* d_mm_pos;    /* [n_minimizers] */
+  const uint64_t* d_match_off; /* [n_reads+1] */
+  const uint32_t* d_match_qi;  /* [n_matches] */
+  const uint32_t* d_match_ti;  /* [n_matches] */
+  const uint32_t* d_n_forward; /* [n_reads] */
+  const uint32_t* d_sep_qpos;  /* [n_matches] */
+  const uint32_t* d_sep_tpos;  /* [n_matches] */
+} lra_seed_result;
+int lra_seed_batch(lra_ctx* ctx, int n_reads, const char* d_seq, const uint64_t* d_read_off, int k, int w,
+                   int max_freq, lra_seed_result* out);
+
 /* ---- a12: banded one-gap seed-extension DP ------------------------------------------
  * Replaces   int AffineOneGapAlign(string& qSeq, int qLen, string& tSeq, int tLen,
  *                                  int m, int mm, int indel, int k, Alignment& aln,

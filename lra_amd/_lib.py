@@ -25,6 +25,13 @@ SYMBOLS = {
     "lra_ctx_destroy": (None, [_vp]),
     "lra_ctx_set_stream": (C.c_int, [_vp, _vp]),
     "lra_ctx_last_error": (C.c_char_p, [_vp]),
+    "lra_copy_to_host": (C.c_int, [_vp, _vp, _vp, C.c_uint64]),
+    "lra_ctx_timing_enable": (C.c_int, [_vp, C.c_int]),
+    "lra_ctx_timing_reset": (C.c_int, [_vp]),
+    "lra_ctx_timing_get": (C.c_int, [_vp, C.c_char_p, C.POINTER(C.c_double), C.POINTER(C.c_int)]),
+    "lra_ctx_load_genome": (C.c_int, [_vp, _vp, C.c_uint64]),
+    "lra_ctx_load_global_index": (C.c_int, [_vp, _vp, _vp, C.c_uint64]),
+    "lra_seed_batch": (C.c_int, [_vp, C.c_int, _vp, _vp, C.c_int, C.c_int, C.c_int, _vp]),
     "lra_affine_one_gap_align_batch": (C.c_int, [_vp, C.c_int, _vp, _vp, _vp, _vp, _vp, _vp, C.c_int, C.c_int,
                                                   C.c_int, _vp, _vp, _vp, _vp, _vp]),
 }
@@ -35,6 +42,10 @@ def load_library():
     global _LIB
     if _LIB is not None:
         return _LIB
+    # torch (device memory / streams plumbing) bundles its own HIP runtime; it must be the one
+    # already mapped when liblra_hip.so resolves libamdhip64, so both share one runtime
+    # instance (device pointers and streams cross the boundary).
+    import torch  # noqa: F401
     path = library_path()
     if not os.path.exists(path):
         raise LraError("liblra_hip.so is not built (%s). Run `python -c 'import __graft_entry__ as g; g.build()'` "

@@ -29,6 +29,26 @@ class Context:
         if rc != 0:
             raise LraError("liblra_hip error %d: %s" % (rc, self.lib.lra_ctx_last_error(self.h).decode()))
 
+    def to_host(self, dev_ptr, count, dtype):
+        """Copy `count` items of numpy `dtype` from a raw device pointer into a new numpy array."""
+        import numpy as np
+        out = np.empty(int(count), dtype=dtype)
+        if count:
+            self.check(self.lib.lra_copy_to_host(self.h, C.c_void_p(out.ctypes.data), C.c_void_p(dev_ptr), C.c_uint64(out.nbytes)))
+        return out
+
+    def timing(self, on=True):
+        self.check(self.lib.lra_ctx_timing_enable(self.h, 1 if on else 0))
+
+    def timing_reset(self):
+        self.check(self.lib.lra_ctx_timing_reset(self.h))
+
+    def timing_get(self, name):
+        """(total_ms, launches) of the named kernel since the last reset; (0.0, 0) if it never ran."""
+        ms, n = C.c_double(0), C.c_int(0)
+        rc = self.lib.lra_ctx_timing_get(self.h, name.encode(), C.byref(ms), C.byref(n))
+        return (ms.value, n.value) if rc == 0 else (0.0, 0)
+
     def close(self):
         if self.h:
             self.lib.lra_ctx_destroy(self.h)

@@ -420,10 +420,16 @@ extern "C" int lra_affine_one_gap_align_batch(lra_ctx* ctx, int n, const char* d
   int wgA = min((n + 3) / 4, ctx->num_cu * 5);
   int wgB = min(n, ctx->num_cu * 2);
   int wgC = min(n, a.gslots);
+  lra_time_begin(ctx, "aog_lds_small");
   hipLaunchKernelGGL(aog_kernel<0>, dim3(wgA), dim3(256), 4 * CLASS_A_BYTES, ctx->stream, a);
+  lra_time_end(ctx);
   LRA_HIP_CHECK(ctx, hipFuncSetAttribute((const void*)aog_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, CLASS_B_BYTES));
+  lra_time_begin(ctx, "aog_lds_large");
   hipLaunchKernelGGL(aog_kernel<1>, dim3(wgB), dim3(64), CLASS_B_BYTES, ctx->stream, a);
+  lra_time_end(ctx);
+  lra_time_begin(ctx, "aog_hbm");
   hipLaunchKernelGGL(aog_kernel<2>, dim3(wgC), dim3(64), 0, ctx->stream, a);
+  lra_time_end(ctx);
   LRA_HIP_CHECK(ctx, hipGetLastError());
   return LRA_OK;
 }

@@ -4,7 +4,12 @@
 #include <stdint.h>
 #include <stdio.h>
 #include <string>
+#include <string.h>
+#include <vector>
 #include "../../include/lra_hip.h"
+
+struct lra_seed_state;
+struct lra_time_rec { const char* name; hipEvent_t a, b; };
 
 struct lra_ctx {
   int device = 0;
@@ -14,7 +19,16 @@ struct lra_ctx {
   void* scratch[4] = {nullptr, nullptr, nullptr, nullptr};
   size_t scratch_bytes[4] = {0, 0, 0, 0};
   int num_cu = 256;
+  lra_seed_state* seed = nullptr;
+  // kernel timing
+  bool timing = false;
+  std::vector<lra_time_rec> recs;
+  std::vector<hipEvent_t> free_events;
 };
+
+void lra_time_begin(lra_ctx* ctx, const char* name);
+void lra_time_end(lra_ctx* ctx);
+void lra_seed_free(lra_ctx* ctx);
 
 int lra_set_err(lra_ctx* ctx, int code, const char* fmt, ...);
 // returns a device buffer of >= bytes (slot 0..3), growing it if needed (synchronises the

@@ -54,6 +54,9 @@ extern "C" void lra_ctx_destroy(lra_ctx* ctx) {
   (void)hipStreamSynchronize(ctx->stream);
   for (int i = 0; i < 4; i++)
     if (ctx->scratch[i]) (void)hipFree(ctx->scratch[i]);
+  lra_seed_free(ctx);
+  for (auto& r : ctx->recs) { (void)hipEventDestroy(r.a); (void)hipEventDestroy(r.b); }
+  for (auto e : ctx->free_events) (void)hipEventDestroy(e);
   delete ctx;
 }
 
@@ -64,3 +67,59 @@ extern "C" int lra_ctx_set_stream(lra_ctx* ctx, void* stream) {
 }
 
 extern "C" const char* lra_ctx_last_error(lra_ctx* ctx) { return ctx ? ctx->err.c_str() : "null ctx"; }
+
+// ---- per-kernel timing ------------------------------------------------------------------
+static hipEvent_t get_event(lra_ctx* ctx) {
+  if (!ctx->free_events.empty()) { hipEvent_t e = ctx->free_events.back(); ctx->free_events.pop_back(); return e; }
+  hipEvent_t e;
+  (void)hipEventCreate(&e);
+  return e;
+}
+
+void lra_time_begin(lra_ctx* ctx, const char* name) {
+  if (!ctx->timing) return;
+  lra_time_rec r{name, get_event(ctx), get_event(ctx)};
+  (void)hipEventRecord(r.a, ctx->stream);
+  ctx->recs.push_back(r);
+}
+
+void lra_time_end(lra_ctx* ctx) {
+  if (!ctx->timing || ctx->recs.empty()) return;
+  (void)hipEventRecord(ctx->recs.back().b, ctx->stream);
+}
+
+extern "C" int lra_ctx_timing_enable(lra_ctx* ctx, int on) {
+  if (!ctx) return LRA_ERR_INVALID;
+  ctx->timing = on != 0;
+  return LRA_OK;
+}
+
+extern "C" int lra_ctx_timing_reset(lra_ctx* ctx) {
+  if (!ctx) return LRA_ERR_INVALID;
+  (void)hipStreamSynchronize(ctx->stream);
+  for (auto& r : ctx->recs) { ctx->free_events.push_back(r.a); ctx->free_events.push_back(r.b); }
+  ctx->recs.clear();
+  return LRA_OK;
+}
+
+extern "C" int lra_ctx_timing_get(lra_ctx* ctx, const char* name, double* total_ms, int* launches) {
+  if (!ctx || !name) return LRA_ERR_INVALID;
+  LRA_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+  double tot = 0; int n = 0;
+  for (auto& r : ctx->recs)
+    if (strcmp(r.name, name) == 0) {
+      float ms = 0;
+      if (hipEventElapsedTime(&ms, r.a, r.b) == hipSuccess) { tot += ms; n++; }
+    }
+  if (total_ms) *total_ms = tot;
+  if (launches) *launches = n;
+  return n ? LRA_OK : lra_set_err(ctx, LRA_ERR_INVALID, "no timing records for kernel '%s'", name);
+}
+
+extern "C" int lra_copy_to_host(lra_ctx* ctx, void* h_dst, const void* d_src, uint64_t bytes) {
+  if (!ctx) return LRA_ERR_INVALID;
+  if (bytes == 0) return LRA_OK;
+  LRA_HIP_CHECK(ctx, hipMemcpyAsync(h_dst, d_src, bytes, hipMemcpyDeviceToHost, ctx->stream));
+  LRA_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+  return LRA_OK;
+}

@@ -1,0 +1,575 @@
+// lra_amd/csrc/seed.hip -- tier-1 seeding of a read batch on gfx950.
+//
+// Replaces, for a whole batch of reads resident in HBM, the first stages of MapRead
+// (reference: MapRead.h:169-203):
+//   a1  StoreMinimizers<GenomeTuple,Tuple>(read, globalK, globalW)        MinCount.h:8-179
+//   a2  sort(readmm.begin(), readmm.end())                                MapRead.h:185
+//   a3  CompareLists<GenomeTuple,Tuple>(readmm, genomemm, allMatches)     CompareLists.h:9-146
+//   a4  SeparateMatchesByStrand(read, genome, k, allMatches, for, rev)    MapRead.h:109-150
+//
+// Layout in HBM (structure of arrays, CSR by read):
+//   reads    : uint8 seq[], uint64 read_off[n+1]
+//   minimizers: uint64 mm_key[] (strand in bit 63, TupleOps.h:68), uint32 mm_pos[], uint64 mm_off[n+1]
+//   index    : uint64 idx_key[] sorted by (key & 2^63-1), uint32 idx_pos[]   (the .mms payload, MMIndex.h:416)
+//   matches  : uint32 match_qi[] (index into the read's sorted minimizers), uint32 match_ti[]
+//              (index into the global index), uint64 match_off[n+1], in the reference's
+//              discovery order; then per read forward-strand matches first, reverse after:
+//              uint32 sep_qpos[], sep_tpos[], uint32 n_forward[n].
+//
+// Why these stages are emulated step by step instead of re-derived: their outputs depend
+// on implementation details -- the unmasked first-window comparison and ring-index
+// tie-break of the minimizer scan, the permutation libstdc++'s introsort leaves among
+// equal keys (MapRead.h:185 sorts with a non-total order), and CompareLists' alternating
+// two-ended walk with raw-key run skipping (which re-emits or drops pairs depending on
+// that permutation).  Parallelism is across reads (one lane per read for the serial
+// state machines) and across query tuples (one lane per tuple for the index searches,
+// which are the HBM-heavy part).
+#include "common.h"
+
+namespace {
+
+constexpr uint64_t FOR_MASK = ~(1ULL << 63);  // lra.cpp:1008-1012
+constexpr uint64_t REV_MASK = (1ULL << 63);
+constexpr int MAX_W = 32;
+
+__device__ __forceinline__ int code_n(unsigned char c) {  // SeqUtils.h:42 (seqMapN)
+  if (c < 8) return c & 3;
+  switch (c) {
+    case 'A': case 'a': return 0;
+    case 'C': case 'c': return 1;
+    case 'G': case 'g': return 2;
+    case 'T': case 't': return 3;
+    default: return 4;
+  }
+}
+__device__ __forceinline__ uint64_t code2(unsigned char c) {  // SeqUtils.h:7 (seqMap)
+  int v = code_n(c);
+  return v > 3 ? 0 : (uint64_t)v;
+}
+
+// ------------------------------------------------------------------------------------ a1
+// One lane per read; the state machine of MinCount.h:8-179 verbatim in behaviour.
+// EMIT=false only counts.  The w-entry ring lives in LDS, lane-interleaved.
+template <bool EMIT>
+__global__ void __launch_bounds__(64) sketch_kernel(int n_reads, const unsigned char* __restrict__ seq_all,
+                                                    const uint64_t* __restrict__ read_off, int k, int w,
+                                                    const uint64_t* __restrict__ mm_off, uint64_t* __restrict__ mm_key,
+                                                    uint32_t* __restrict__ mm_pos, uint32_t* __restrict__ counts) {
+  __shared__ uint64_t ringT[MAX_W * 64];
+  __shared__ uint32_t ringP[MAX_W * 64];
+  const int lane = threadIdx.x;
+  const int r = blockIdx.x * 64 + lane;
+  if (r >= n_reads) return;
+  const unsigned char* seq = seq_all + read_off[r];
+  const uint32_t seqLen = (uint32_t)(read_off[r + 1] - read_off[r]);
+  uint64_t* okey = EMIT ? mm_key + mm_off[r] : nullptr;
+  uint32_t* opos = EMIT ? mm_pos + mm_off[r] : nullptr;
+  uint32_t n = 0;
+#define SK_EMIT(T_, P_) do { if (EMIT) { okey[n] = (T_); opos[n] = (P_); } n++; } while (0)
+#define SK_DONE() do { if (!EMIT) counts[r] = n; return; } while (0)
+  const int span = w + k - 1;                                          // :17
+  if (seqLen < (uint32_t)k || seqLen < (uint32_t)span) SK_DONE();      // :12,:26
+  const uint64_t kmask = (k >= 32) ? ~0ULL : ((1ULL << (2 * k)) - 1);
+  long nvStart = 0, nvEnd = 0;
+  bool valid = false;
+  auto find_valid = [&]() -> bool {                                    // :27-41 / :117-131
+    valid = false;
+    while ((uint32_t)nvStart < seqLen - (uint32_t)span && !valid) {
+      valid = true;
+      for (long x = nvStart; valid && x < nvStart + span; x++)
+        if (code_n(seq[x]) > 3) { nvStart = x + 1; valid = false; }
+    }
+    return valid;
+  };
+  if (!find_valid()) SK_DONE();
+  nvEnd = nvStart + span;
+  uint64_t cur = 0, rc = 0;
+  for (int p = 0; p < k; p++) cur = (cur << 2) + code2(seq[p]);        // StoreTuple TupleOps.h:104
+  {
+    uint64_t a = cur;                                                  // TupleRC TupleOps.h:125
+    for (int i = 0; i < k; i++) { rc = (rc << 2) + ((~a) & 3ULL); a >>= 2; }
+  }
+  auto canon = [&]() -> uint64_t {
+    return ((cur & FOR_MASK) < (rc & FOR_MASK)) ? (cur & FOR_MASK) : (rc | REV_MASK);
+  };
+  auto shift = [&](uint32_t at) {                                      // TupleOps.h:114-123
+    uint64_t c = code2(seq[at]);
+    cur = ((cur << 2) & kmask) + c;
+    rc = (rc >> 2) + (((~c) & 3ULL) << (2 * ((uint64_t)k - 1)));
+  };
+  uint64_t actT = canon();
+  uint32_t actP = 0;
+  ringT[0 * 64 + lane] = actT; ringP[0 * 64 + lane] = 0;
+  uint32_t p;
+  const uint32_t nk = seqLen - k + 1;
+  for (p = 1; p < (uint32_t)w && p < nk; p++) {                        // :77-96
+    shift(p + k - 1);
+    uint64_t c = canon();
+    if (c < actT) { actT = c; actP = p; }                              // unmasked compare (:91)
+    ringT[(p % w) * 64 + lane] = c; ringP[(p % w) * 64 + lane] = p;
+  }
+  if (nvEnd == span) SK_EMIT(actT, actP);                              // :100-102
+  uint32_t slot = (uint32_t)w % (uint32_t)w;                           // p % w, advanced incrementally
+  for (p = w; p < nk; p++) {                                           // :105-178
+    if (nvEnd == (long)(p + k - 1)) {
+      if (code_n(seq[p + k - 1]) <= 3) nvEnd++;
+      else {
+        nvStart = p + k;
+        if (!find_valid()) SK_DONE();
+        nvEnd = nvStart + span;
+      }
+    }
+    shift(p + k - 1);
+    uint64_t c = canon();
+    ringT[slot * 64 + lane] = c; ringP[slot * 64 + lane] = p;
+    if (++slot == (uint32_t)w) slot = 0;
+    if (p - w >= actP) {                                               // :148-162 re-scan, ring order
+      actT = ringT[lane]; actP = ringP[lane];
+      for (int j = 1; j < w; j++) {
+        uint64_t t = ringT[j * 64 + lane];
+        if ((t & FOR_MASK) < (actT & FOR_MASK)) { actT = t; actP = ringP[j * 64 + lane]; }
+      }
+      if (nvEnd == (long)(p + k)) SK_EMIT(actT, actP);
+    } else if ((c & FOR_MASK) < (actT & FOR_MASK)) {                   // :164-173
+      actT = c; actP = p;
+      if (nvEnd == (long)(p + k)) SK_EMIT(actT, actP);
+    }
+  }
+  SK_DONE();
+#undef SK_EMIT
+#undef SK_DONE
+}
+
+// ------------------------------------------------------------------------------------ a2
+// libstdc++ std::sort (bits/stl_algo.h: __introsort_loop + __final_insertion_sort, threshold
+// 16, median-of-three to first, unguarded Hoare partition, heap-sort fall-back) restated on
+// (key,pos) pairs with the reference's masked comparison (TupleOps.h:76).  The permutation of
+// equal keys it leaves is what MapRead.h:185 produces, and CompareLists depends on it.
+struct SortSeg {
+  uint64_t* k; uint32_t* p;
+  __device__ __forceinline__ bool lt(long a, long b) const { return (k[a] & FOR_MASK) < (k[b] & FOR_MASK); }
+  __device__ __forceinline__ void swap(long a, long b) {
+    uint64_t tk = k[a]; k[a] = k[b]; k[b] = tk;
+    uint32_t tp = p[a]; p[a] = p[b]; p[b] = tp;
+  }
+  __device__ __forceinline__ void mv(long dst, long src) { k[dst] = k[src]; p[dst] = p[src]; }
+};
+
+__device__ void adjust_heap(SortSeg& s, long first, long hole, long len, uint64_t vk, uint32_t vp) {
+  const long top = hole;
+  long child = hole;
+  while (child < (len - 1) / 2) {
+    child = 2 * (child + 1);
+    if (s.lt(first + child, first + (child - 1))) child--;
+    s.mv(first + hole, first + child);
+    hole = child;
+  }
+  if ((len & 1) == 0 && child == (len - 2) / 2) {
+    child = 2 * (child + 1);
+    s.mv(first + hole, first + (child - 1));
+    hole = child - 1;
+  }
+  long parent = (hole - 1) / 2;                                        // __push_heap
+  while (hole > top && (s.k[first + parent] & FOR_MASK) < (vk & FOR_MASK)) {
+    s.mv(first + hole, first + parent);
+    hole = parent;
+    parent = (hole - 1) / 2;
+  }
+  s.k[first + hole] = vk; s.p[first + hole] = vp;
+}
+
+__device__ void heap_sort(SortSeg& s, long first, long last) {         // __partial_sort(first,last,last)
+  long len = last - first;
+  if (len >= 2) {                                                      // __make_heap
+    long parent = (len - 2) / 2;
+    while (true) {
+      uint64_t vk = s.k[first + parent]; uint32_t vp = s.p[first + parent];
+      adjust_heap(s, first, parent, len, vk, vp);
+      if (parent == 0) break;
+      parent--;
+    }
+  }
+  while (last - first > 1) {                                           // __sort_heap / __pop_heap
+    --last;
+    uint64_t vk = s.k[last]; uint32_t vp = s.p[last];
+    s.mv(last, first);
+    adjust_heap(s, first, 0, last - first, vk, vp);
+  }
+}
+
+__device__ __forceinline__ void unguarded_linear_insert(SortSeg& s, long last) {
+  uint64_t vk = s.k[last]; uint32_t vp = s.p[last];
+  long next = last - 1;
+  while ((vk & FOR_MASK) < (s.k[next] & FOR_MASK)) { s.mv(last, next); last = next; --next; }
+  s.k[last] = vk; s.p[last] = vp;
+}
+
+__device__ void insertion_sort(SortSeg& s, long first, long last) {
+  if (first == last) return;
+  for (long i = first + 1; i != last; ++i) {
+    if (s.lt(i, first)) {
+      uint64_t vk = s.k[i]; uint32_t vp = s.p[i];
+      for (long x = i; x > first; --x) s.mv(x, x - 1);                 // move_backward
+      s.k[first] = vk; s.p[first] = vp;
+    } else unguarded_linear_insert(s, i);
+  }
+}
+
+__global__ void __launch_bounds__(64) sort_kernel(int n_reads, const uint64_t* __restrict__ mm_off, uint64_t* mm_key, uint32_t* mm_pos) {
+  const int r = blockIdx.x * 64 + threadIdx.x;
+  if (r >= n_reads) return;
+  SortSeg s{mm_key + mm_off[r], mm_pos + mm_off[r]};
+  const long n = (long)(mm_off[r + 1] - mm_off[r]);
+  if (n < 2) return;
+  // __introsort_loop with an explicit stack (segments are disjoint, so their order is free)
+  int sp = 0;
+  long stF[64], stL[64]; int stD[64];
+  int lg = 63 - __clzll((unsigned long long)n);
+  stF[0] = 0; stL[0] = n; stD[0] = 2 * lg; sp = 1;
+  while (sp > 0) {
+    --sp;
+    long first = stF[sp], last = stL[sp]; int depth = stD[sp];
+    while (last - first > 16) {
+      if (depth == 0) { heap_sort(s, first, last); break; }
+      --depth;
+      long mid = first + (last - first) / 2;
+      long a = first + 1, b = mid, c = last - 1;                       // __move_median_to_first
+      if (s.lt(a, b)) {
+        if (s.lt(b, c)) s.swap(first, b);
+        else if (s.lt(a, c)) s.swap(first, c);
+        else s.swap(first, a);
+      } else if (s.lt(a, c)) s.swap(first, a);
+      else if (s.lt(b, c)) s.swap(first, c);
+      else s.swap(first, b);
+      long f = first + 1, l = last;                                    // __unguarded_partition
+      const uint64_t pv = s.k[first] & FOR_MASK;
+      while (true) {
+        while ((s.k[f] & FOR_MASK) < pv) ++f;
+        --l;
+        while (pv < (s.k[l] & FOR_MASK)) --l;
+        if (!(f < l)) break;
+        s.swap(f, l);
+        ++f;
+      }
+      if (sp < 64) { stF[sp] = f; stL[sp] = last; stD[sp] = depth; sp++; }
+      last = f;
+    }
+  }
+  if (n > 16) {                                                        // __final_insertion_sort
+    insertion_sort(s, 0, 16);
+    for (long i = 16; i != n; ++i) unguarded_linear_insert(s, i);
+  } else insertion_sort(s, 0, n);
+}
+
+// ------------------------------------------------------------------------------------ a3
+// (i) per query tuple: global lower/upper bound of its masked key in the index.  Because the
+// index is sorted by masked key, lower_bound over any sub-range [ts,te) is the global bound
+// clamped to [ts,te] -- so the serial walk of CompareLists needs no searches of its own.
+__global__ void bounds_kernel(uint64_t total, const uint64_t* __restrict__ mm_key, const uint64_t* __restrict__ idx_key,
+                              uint64_t n_idx, uint32_t* __restrict__ lb, uint32_t* __restrict__ ub) {
+  uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= total) return;
+  const uint64_t q = mm_key[i] & FOR_MASK;
+  uint64_t lo = 0, hi = n_idx;
+  while (lo < hi) { uint64_t mid = lo + ((hi - lo) >> 1); if ((idx_key[mid] & FOR_MASK) < q) lo = mid + 1; else hi = mid; }
+  lb[i] = (uint32_t)lo;
+  hi = n_idx;                                                          // upper bound starts from lo
+  while (lo < hi) { uint64_t mid = lo + ((hi - lo) >> 1); if (!(q < (idx_key[mid] & FOR_MASK))) lo = mid + 1; else hi = mid; }
+  ub[i] = (uint32_t)lo;
+}
+
+// (ii) the alternating two-ended walk of CompareLists.h:43-143, one lane per read.
+template <bool EMIT>
+__global__ void __launch_bounds__(64) compare_kernel(int n_reads, const uint64_t* __restrict__ mm_off, const uint64_t* __restrict__ mm_key,
+                                                     const uint32_t* __restrict__ lbA, const uint32_t* __restrict__ ubA,
+                                                     const uint64_t* __restrict__ idx_key, long n_idx, long maxFreq,
+                                                     const uint64_t* __restrict__ match_off, uint32_t* __restrict__ match_qi,
+                                                     uint32_t* __restrict__ match_ti, uint64_t* __restrict__ counts) {
+  const int r = blockIdx.x * 64 + threadIdx.x;
+  if (r >= n_reads) return;
+  const uint64_t* qk = mm_key + mm_off[r];
+  const uint32_t* LB = lbA + mm_off[r];
+  const uint32_t* UB = ubA + mm_off[r];
+  const long nq = (long)(mm_off[r + 1] - mm_off[r]);
+  const long nt = n_idx;
+  uint32_t* oq = EMIT ? match_qi + match_off[r] : nullptr;
+  uint32_t* ot = EMIT ? match_ti + match_off[r] : nullptr;
+  uint64_t n = 0;
+  const uint64_t M = FOR_MASK;
+#define Qm(i) (qk[(i)] & M)
+#define Tm(i) (idx_key[(i)] & M)
+  if (nq != 0 && nt != 0) {                                            // :27-30
+    long qs = 0, qe = nq - 1, ts = 0, te = nt;
+    do {
+      while (qs <= qe && Qm(qs) < Tm(ts)) qs++;                        // :47-49
+      if (qs >= qe) break;                                             // :51-53
+      uint64_t startGap = Qm(qs) - Tm(ts);
+      while (qe > qs && te > ts && Qm(qe) > Tm(te - 1)) qe--;          // :63-65
+      uint64_t endGap = Tm(te - 1) - Qm(qe);
+      if (startGap == 0 || (startGap & M) > (endGap & M)) {            // :69
+        const long tsOrig = ts, qsOrig = qs;
+        long lo = (long)LB[qs];                                        // lower_bound on [ts,te)  (:76)
+        ts = lo < ts ? ts : (lo > te ? te : lo);
+        if (ts < te && Tm(ts) == Qm(qs)) {
+          const uint32_t tsStart = (uint32_t)ts;
+          uint32_t tsi = (uint32_t)ts;
+          { long e = (long)UB[qs]; e = e > te ? te : e; if (e > (long)tsi) tsi = (uint32_t)e; }   // end of the equal run inside [ts,te)
+          const uint32_t qsStart = (uint32_t)qs;
+          while (qs < qe && Qm(qs + 1) == Qm(qs)) qs++;
+          if (qs - (long)qsStart < maxFreq) {
+            for (uint32_t ti = tsStart; ti != tsi; ti++)
+              for (uint32_t qi = qsStart; (long)qi <= qs; qi++) {
+                if (EMIT) { oq[n] = qi; ot[n] = ti; }
+                n++;
+              }
+          }
+        }
+        { const uint64_t raw = idx_key[tsOrig]; while (ts < te && idx_key[ts] == raw) ts++; }   // :101
+        { const uint64_t raw = qk[qsOrig]; while (qs < qe && qk[qs] == raw) qs++; }             // :102
+      } else {
+        if (te != nt && Tm(te - 1) == Qm(qe)) {                        // :112-114
+        } else {                                                       // upper_bound on [ts,te) (:116-118)
+          long hi = (long)UB[qe];
+          te = hi < ts ? ts : (hi > te ? te : hi);
+        }
+        const uint32_t teStart = (uint32_t)te;
+        uint32_t tei = (uint32_t)te;
+        if ((long)tei > ts && Tm(tei - 1) == Qm(qe)) {                 // start of the equal run inside [ts,te)
+          long b = (long)LB[qe]; b = b < ts ? ts : b;
+          tei = (uint32_t)b;
+        }
+        if (tei < teStart && teStart > 0) {
+          const uint32_t qeStart = (uint32_t)qe;
+          while (qe > qs && Qm(qe) == Qm(qe - 1)) qe--;
+          if ((long)qeStart - qe < maxFreq) {
+            for (uint32_t ti = tei; ti < teStart; ti++)
+              for (uint32_t qi = (uint32_t)qe; qi <= qeStart; qi++) {
+                if (EMIT) { oq[n] = qi; ot[n] = ti; }
+                n++;
+              }
+          }
+        }
+        te = tei;
+      }
+    } while (qs < qe && ts < te);
+  }
+#undef Qm
+#undef Tm
+  if (!EMIT) counts[r] = n;
+}
+
+// ------------------------------------------------------------------------------------ a4
+// One wave per read: strand flag per match (k-byte compare of read vs genome), then a stable
+// partition (forward first) with ballot/popcount prefix sums.
+__global__ void __launch_bounds__(64) strand_kernel(int n_reads, const unsigned char* __restrict__ seq_all, const uint64_t* __restrict__ read_off,
+                                                    const unsigned char* __restrict__ genome, int k,
+                                                    const uint64_t* __restrict__ mm_off, const uint32_t* __restrict__ mm_pos,
+                                                    const uint32_t* __restrict__ idx_pos,
+                                                    const uint64_t* __restrict__ match_off, const uint32_t* __restrict__ match_qi,
+                                                    const uint32_t* __restrict__ match_ti, uint32_t* __restrict__ sep_qpos,
+                                                    uint32_t* __restrict__ sep_tpos, uint32_t* __restrict__ n_forward) {
+  const int lane = threadIdx.x;
+  for (int r = blockIdx.x; r < n_reads; r += gridDim.x) {
+    const unsigned char* read = seq_all + read_off[r];
+    const uint32_t* qpos_of = mm_pos + mm_off[r];
+    const uint64_t m0 = match_off[r], m1 = match_off[r + 1];
+    // pass 1: count forward matches
+    uint64_t nf = 0;
+    for (uint64_t base = m0; base < m1; base += 64) {
+      uint64_t i = base + lane;
+      bool fwd = false;
+      if (i < m1) {
+        const unsigned char* a = read + qpos_of[match_qi[i]];
+        const unsigned char* b = genome + idx_pos[match_ti[i]];
+        fwd = true;
+        for (int x = 0; x < k; x++) if (a[x] != b[x]) { fwd = false; break; }
+      }
+      nf += __popcll(__ballot(fwd));
+    }
+    if (lane == 0) n_forward[r] = (uint32_t)nf;
+    // pass 2: stable partition
+    uint64_t fcur = m0, rcur = m0 + nf;
+    for (uint64_t base = m0; base < m1; base += 64) {
+      uint64_t i = base + lane;
+      bool in = i < m1, fwd = false;
+      uint32_t qp = 0, tp = 0;
+      if (in) {
+        qp = qpos_of[match_qi[i]]; tp = idx_pos[match_ti[i]];
+        const unsigned char* a = read + qp;
+        const unsigned char* b = genome + tp;
+        fwd = true;
+        for (int x = 0; x < k; x++) if (a[x] != b[x]) { fwd = false; break; }
+      }
+      unsigned long long mf = __ballot(in && fwd), mr = __ballot(in && !fwd);
+      unsigned long long below = (lane == 0) ? 0ULL : (~0ULL >> (64 - lane));
+      if (in) {
+        uint64_t dst = fwd ? fcur + __popcll(mf & below) : rcur + __popcll(mr & below);
+        sep_qpos[dst] = qp; sep_tpos[dst] = tp;
+      }
+      fcur += __popcll(mf); rcur += __popcll(mr);
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------ scans
+// exclusive scan of n (<= a few million) counts into n+1 offsets; one workgroup.
+template <typename CT>
+__global__ void __launch_bounds__(1024) scan_kernel(long n, const CT* __restrict__ counts, uint64_t* __restrict__ off) {
+  __shared__ uint64_t part[1024];
+  const int t = threadIdx.x;
+  const long per = (n + 1023) / 1024;
+  const long lo = (long)t * per, hi = (lo + per < n) ? lo + per : n;
+  uint64_t s = 0;
+  for (long i = lo; i < hi; i++) s += (uint64_t)counts[i];
+  part[t] = s;
+  __syncthreads();
+  for (int d = 1; d < 1024; d <<= 1) {
+    uint64_t v = (t >= d) ? part[t - d] : 0;
+    __syncthreads();
+    part[t] += v;
+    __syncthreads();
+  }
+  uint64_t run = (t == 0) ? 0 : part[t - 1];
+  for (long i = lo; i < hi; i++) { off[i] = run; run += (uint64_t)counts[i]; }
+  if (t == 1023) off[n] = part[1023];
+}
+
+}  // namespace
+
+// ======================================================================================
+struct lra_seed_state {
+  unsigned char* genome = nullptr; uint64_t genome_len = 0;
+  uint64_t* idx_key = nullptr; uint32_t* idx_pos = nullptr; uint64_t n_idx = 0;
+  // batch buffers (grown on demand)
+  uint32_t* counts32 = nullptr; uint64_t* counts64 = nullptr; uint64_t* mm_off = nullptr; uint64_t* match_off = nullptr;
+  uint32_t* n_forward = nullptr; size_t cap_reads = 0;
+  uint64_t* mm_key = nullptr; uint32_t* mm_pos = nullptr; uint32_t* lb = nullptr; uint32_t* ub = nullptr; size_t cap_mm = 0;
+  uint32_t* match_qi = nullptr; uint32_t* match_ti = nullptr; uint32_t* sep_qpos = nullptr; uint32_t* sep_tpos = nullptr; size_t cap_match = 0;
+};
+
+static lra_seed_state* seed_state(lra_ctx* ctx) {
+  if (!ctx->seed) ctx->seed = new lra_seed_state();
+  return ctx->seed;
+}
+
+template <typename T>
+static bool regrow(T*& p, size_t n) {
+  if (p) (void)hipFree(p);
+  p = nullptr;
+  return hipMalloc((void**)&p, n * sizeof(T) + 64) == hipSuccess;
+}
+
+void lra_seed_free(lra_ctx* ctx) {
+  lra_seed_state* s = ctx->seed;
+  if (!s) return;
+  void* ptrs[] = {s->genome, s->idx_key, s->idx_pos, s->counts32, s->counts64, s->mm_off, s->match_off, s->n_forward,
+                  s->mm_key, s->mm_pos, s->lb, s->ub, s->match_qi, s->match_ti, s->sep_qpos, s->sep_tpos};
+  for (void* p : ptrs) if (p) (void)hipFree(p);
+  delete s;
+  ctx->seed = nullptr;
+}
+
+extern "C" int lra_ctx_load_genome(lra_ctx* ctx, const char* h_seq, uint64_t len) {
+  if (!ctx || (!h_seq && len)) return LRA_ERR_INVALID;
+  LRA_HIP_CHECK(ctx, hipSetDevice(ctx->device));
+  lra_seed_state* s = seed_state(ctx);
+  if (!regrow(s->genome, len + 64)) return lra_set_err(ctx, LRA_ERR_NOMEM, "genome alloc");
+  s->genome_len = len;
+  LRA_HIP_CHECK(ctx, hipMemcpy(s->genome, h_seq, len, hipMemcpyHostToDevice));
+  LRA_HIP_CHECK(ctx, hipMemset(s->genome + len, 0, 64));
+  return LRA_OK;
+}
+
+extern "C" int lra_ctx_load_global_index(lra_ctx* ctx, const uint64_t* h_key, const uint32_t* h_pos, uint64_t n) {
+  if (!ctx || n >= (1ULL << 32)) return LRA_ERR_INVALID;
+  LRA_HIP_CHECK(ctx, hipSetDevice(ctx->device));
+  lra_seed_state* s = seed_state(ctx);
+  if (!regrow(s->idx_key, n + 1) || !regrow(s->idx_pos, n + 1)) return lra_set_err(ctx, LRA_ERR_NOMEM, "index alloc");
+  s->n_idx = n;
+  LRA_HIP_CHECK(ctx, hipMemcpy(s->idx_key, h_key, n * 8, hipMemcpyHostToDevice));
+  LRA_HIP_CHECK(ctx, hipMemcpy(s->idx_pos, h_pos, n * 4, hipMemcpyHostToDevice));
+  return LRA_OK;
+}
+
+extern "C" int lra_seed_batch(lra_ctx* ctx, int n_reads, const char* d_seq, const uint64_t* d_read_off, int k, int w,
+                              int max_freq, lra_seed_result* out) {
+  if (!ctx || !out || n_reads < 0) return LRA_ERR_INVALID;
+  if (k < 1 || k > 32 || w < 1 || w > MAX_W) return lra_set_err(ctx, LRA_ERR_INVALID, "k must be 1..32 and w 1..%d", MAX_W);
+  lra_seed_state* s = seed_state(ctx);
+  if (!s->genome || !s->idx_key) return lra_set_err(ctx, LRA_ERR_INVALID, "load genome and global index first");
+  LRA_HIP_CHECK(ctx, hipSetDevice(ctx->device));
+  hipStream_t st = ctx->stream;
+  memset(out, 0, sizeof(*out));
+  out->n_reads = n_reads;
+  if (n_reads == 0) return LRA_OK;
+  if ((size_t)n_reads > s->cap_reads) {
+    LRA_HIP_CHECK(ctx, hipStreamSynchronize(st));
+    size_t c = (size_t)n_reads + n_reads / 4 + 64;
+    if (!regrow(s->counts32, c) || !regrow(s->counts64, c) || !regrow(s->mm_off, c + 1) || !regrow(s->match_off, c + 1) ||
+        !regrow(s->n_forward, c))
+      return lra_set_err(ctx, LRA_ERR_NOMEM, "per-read arrays");
+    s->cap_reads = c;
+  }
+  const unsigned char* seq = (const unsigned char*)d_seq;
+  const int nb = (n_reads + 63) / 64;
+  // ---- a1: count, scan, emit
+  lra_time_begin(ctx, "sketch_count");
+  hipLaunchKernelGGL(sketch_kernel<false>, dim3(nb), dim3(64), 0, st, n_reads, seq, d_read_off, k, w, (const uint64_t*)nullptr,
+                     (uint64_t*)nullptr, (uint32_t*)nullptr, s->counts32);
+  lra_time_end(ctx);
+  hipLaunchKernelGGL(scan_kernel<uint32_t>, dim3(1), dim3(1024), 0, st, (long)n_reads, s->counts32, s->mm_off);
+  uint64_t total_mm = 0;
+  LRA_HIP_CHECK(ctx, hipMemcpyAsync(&total_mm, s->mm_off + n_reads, 8, hipMemcpyDeviceToHost, st));
+  LRA_HIP_CHECK(ctx, hipStreamSynchronize(st));
+  if (total_mm >= (1ULL << 32)) return lra_set_err(ctx, LRA_ERR_INVALID, "batch too large: %llu minimizers", (unsigned long long)total_mm);
+  if (total_mm > s->cap_mm) {
+    size_t c = total_mm + total_mm / 4 + 1024;
+    if (!regrow(s->mm_key, c) || !regrow(s->mm_pos, c) || !regrow(s->lb, c) || !regrow(s->ub, c))
+      return lra_set_err(ctx, LRA_ERR_NOMEM, "minimizer arrays");
+    s->cap_mm = c;
+  }
+  lra_time_begin(ctx, "sketch_emit");
+  hipLaunchKernelGGL(sketch_kernel<true>, dim3(nb), dim3(64), 0, st, n_reads, seq, d_read_off, k, w, s->mm_off, s->mm_key, s->mm_pos,
+                     (uint32_t*)nullptr);
+  lra_time_end(ctx);
+  // ---- a2
+  lra_time_begin(ctx, "sort");
+  hipLaunchKernelGGL(sort_kernel, dim3(nb), dim3(64), 0, st, n_reads, s->mm_off, s->mm_key, s->mm_pos);
+  lra_time_end(ctx);
+  // ---- a3
+  if (total_mm) {
+    lra_time_begin(ctx, "index_bounds");
+    hipLaunchKernelGGL(bounds_kernel, dim3((unsigned)((total_mm + 255) / 256)), dim3(256), 0, st, total_mm, s->mm_key, s->idx_key, s->n_idx,
+                       s->lb, s->ub);
+    lra_time_end(ctx);
+  }
+  lra_time_begin(ctx, "compare_count");
+  hipLaunchKernelGGL(compare_kernel<false>, dim3(nb), dim3(64), 0, st, n_reads, s->mm_off, s->mm_key, s->lb, s->ub, s->idx_key,
+                     (long)s->n_idx, (long)max_freq, (const uint64_t*)nullptr, (uint32_t*)nullptr, (uint32_t*)nullptr, s->counts64);
+  lra_time_end(ctx);
+  hipLaunchKernelGGL(scan_kernel<uint64_t>, dim3(1), dim3(1024), 0, st, (long)n_reads, s->counts64, s->match_off);
+  uint64_t total_m = 0;
+  LRA_HIP_CHECK(ctx, hipMemcpyAsync(&total_m, s->match_off + n_reads, 8, hipMemcpyDeviceToHost, st));
+  LRA_HIP_CHECK(ctx, hipStreamSynchronize(st));
+  if (total_m > s->cap_match) {
+    size_t c = total_m + total_m / 4 + 1024;
+    if (!regrow(s->match_qi, c) || !regrow(s->match_ti, c) || !regrow(s->sep_qpos, c) || !regrow(s->sep_tpos, c))
+      return lra_set_err(ctx, LRA_ERR_NOMEM, "match arrays (%llu matches)", (unsigned long long)total_m);
+    s->cap_match = c;
+  }
+  lra_time_begin(ctx, "compare_emit");
+  hipLaunchKernelGGL(compare_kernel<true>, dim3(nb), dim3(64), 0, st, n_reads, s->mm_off, s->mm_key, s->lb, s->ub, s->idx_key,
+                     (long)s->n_idx, (long)max_freq, s->match_off, s->match_qi, s->match_ti, (uint64_t*)nullptr);
+  lra_time_end(ctx);
+  // ---- a4
+  lra_time_begin(ctx, "strand");
+  hipLaunchKernelGGL(strand_kernel, dim3(n_reads < 4096 ? n_reads : 4096), dim3(64), 0, st, n_reads, seq, d_read_off, s->genome, k, s->mm_off,
+                     s->mm_pos, s->idx_pos, s->match_off, s->match_qi, s->match_ti, s->sep_qpos, s->sep_tpos, s->n_forward);
+  lra_time_end(ctx);
+  LRA_HIP_CHECK(ctx, hipGetLastError());
+  out->n_minimizers = total_mm; out->n_matches = total_m;
+  out->d_mm_off = s->mm_off; out->d_mm_key = s->mm_key; out->d_mm_pos = s->mm_pos;
+  out->d_match_off = s->match_off; out->d_match_qi = s->match_qi; out->d_match_ti = s->match_ti;
+  out->d_n_forward = s->n_forward; out->d_sep_qpos = s->sep_qpos; out->d_sep_tpos = s->sep_tpos;
+  return LRA_OK;
+}

@@ -1,0 +1,63 @@
+"""Host-side mirror of the tier-1 seeding stages of MapRead (reference: MapRead.h:169-203):
+StoreMinimizers -> sort -> CompareLists -> SeparateMatchesByStrand, for a batch of reads."""
+import ctypes as C
+
+import numpy as np
+import torch
+
+from .context import Context, ptr
+
+
+class SeedResult(C.Structure):
+    _fields_ = [("n_reads", C.c_int32), ("n_minimizers", C.c_uint64), ("n_matches", C.c_uint64),
+                ("d_mm_off", C.c_void_p), ("d_mm_key", C.c_void_p), ("d_mm_pos", C.c_void_p),
+                ("d_match_off", C.c_void_p), ("d_match_qi", C.c_void_p), ("d_match_ti", C.c_void_p),
+                ("d_n_forward", C.c_void_p), ("d_sep_qpos", C.c_void_p), ("d_sep_tpos", C.c_void_p)]
+
+
+def load_reference(ctx: Context, genome_u8, idx_key, idx_pos):
+    """Replicate genome bytes and the global minimizer index (`.mms` payload) into this GPU's HBM."""
+    g = np.ascontiguousarray(genome_u8, dtype=np.uint8)
+    k = np.ascontiguousarray(idx_key).view(np.uint64)
+    p = np.ascontiguousarray(idx_pos, dtype=np.uint32)
+    assert len(k) == len(p)
+    ctx.check(ctx.lib.lra_ctx_load_genome(ctx.h, C.c_void_p(g.ctypes.data), C.c_uint64(len(g))))
+    ctx.check(ctx.lib.lra_ctx_load_global_index(ctx.h, C.c_void_p(k.ctypes.data), C.c_void_p(p.ctypes.data), C.c_uint64(len(k))))
+
+
+class ReadBatch:
+    """Reads resident in HBM: concatenated upper-case bytes + CSR offsets."""
+
+    def __init__(self, ctx: Context, reads):
+        lens = np.fromiter((len(r) for r in reads), dtype=np.int64, count=len(reads))
+        off = np.zeros(len(reads) + 1, dtype=np.int64)
+        off[1:] = np.cumsum(lens)
+        buf = np.frombuffer(b"".join(bytes(r) for r in reads), dtype=np.uint8) if off[-1] else np.zeros(0, np.uint8)
+        self.n = len(reads)
+        self.total_bases = int(off[-1])
+        self.seq = torch.from_numpy(np.concatenate([buf, np.zeros(64, np.uint8)])).to(ctx.device)
+        self.off = torch.from_numpy(off).to(ctx.device)
+        self.off_h = off
+
+
+def seed_batch(ctx: Context, batch: ReadBatch, k, w, max_freq):
+    """Run a1-a4 on the batch; returns the SeedResult struct (device pointers owned by ctx)."""
+    res = SeedResult()
+    ctx.check(ctx.lib.lra_seed_batch(ctx.h, batch.n, ptr(batch.seq), ptr(batch.off), k, w, max_freq, C.byref(res)))
+    return res
+
+
+def fetch(ctx: Context, res: SeedResult):
+    """Copy a SeedResult to host numpy arrays (dict)."""
+    n = res.n_reads
+    return {
+        "mm_off": ctx.to_host(res.d_mm_off, n + 1, np.uint64),
+        "mm_key": ctx.to_host(res.d_mm_key, res.n_minimizers, np.uint64),
+        "mm_pos": ctx.to_host(res.d_mm_pos, res.n_minimizers, np.uint32),
+        "match_off": ctx.to_host(res.d_match_off, n + 1, np.uint64),
+        "match_qi": ctx.to_host(res.d_match_qi, res.n_matches, np.uint32),
+        "match_ti": ctx.to_host(res.d_match_ti, res.n_matches, np.uint32),
+        "n_forward": ctx.to_host(res.d_n_forward, n, np.uint32),
+        "sep_qpos": ctx.to_host(res.d_sep_qpos, res.n_matches, np.uint32),
+        "sep_tpos": ctx.to_host(res.d_sep_tpos, res.n_matches, np.uint32),
+    }

@@ -47,3 +47,47 @@ def affine_one_gap_align(q: bytes, t: bytes, m, mm, indel, k, cap=4096):
     n = nb.value
     assert n <= cap
     return score, blocks[:3 * n].reshape(n, 3).copy(), st.value
+
+
+def store_minimizers(seq: bytes, k, w):
+    L = lib()
+    cap = max(1, len(seq))
+    keys = np.zeros(cap, dtype=np.uint64)
+    pos = np.zeros(cap, dtype=np.uint32)
+    L.oracle_store_minimizers.restype = C.c_long
+    n = L.oracle_store_minimizers(C.c_char_p(seq), C.c_uint32(len(seq)), k, w, _p(keys, C.c_uint64), _p(pos, C.c_uint32), C.c_long(cap))
+    assert n <= cap
+    return keys[:n].copy(), pos[:n].copy()
+
+
+def sort_minimizers(keys, pos):
+    L = lib()
+    keys = np.ascontiguousarray(keys, dtype=np.uint64).copy()
+    pos = np.ascontiguousarray(pos, dtype=np.uint32).copy()
+    L.oracle_sort_minimizers(_p(keys, C.c_uint64), _p(pos, C.c_uint32), C.c_long(len(keys)))
+    return keys, pos
+
+
+def compare_lists(qk, qp, tk, tp, max_freq, max_diag=0, min_diag=0, cap=None):
+    L = lib()
+    qk = np.ascontiguousarray(qk, dtype=np.uint64); qp = np.ascontiguousarray(qp, dtype=np.uint32)
+    tk = np.ascontiguousarray(tk, dtype=np.uint64); tp = np.ascontiguousarray(tp, dtype=np.uint32)
+    L.oracle_compare_lists.restype = C.c_long
+    args = lambda oq, ot, c: (_p(qk, C.c_uint64), _p(qp, C.c_uint32), C.c_long(len(qk)), _p(tk, C.c_uint64), _p(tp, C.c_uint32),
+                              C.c_long(len(tk)), C.c_long(max_freq), C.c_int64(max_diag), C.c_int64(min_diag), oq, ot, C.c_long(c))
+    dummy = np.zeros(1, dtype=np.uint32)
+    n = L.oracle_compare_lists(*args(_p(dummy, C.c_uint32), _p(dummy, C.c_uint32), 0))
+    oq = np.zeros(max(1, n), dtype=np.uint32); ot = np.zeros(max(1, n), dtype=np.uint32)
+    n2 = L.oracle_compare_lists(*args(_p(oq, C.c_uint32), _p(ot, C.c_uint32), n))
+    assert n2 == n
+    return oq[:n], ot[:n]
+
+
+def separate_strand(read: bytes, genome, k, qpos, tpos):
+    L = lib()
+    qpos = np.ascontiguousarray(qpos, dtype=np.uint32); tpos = np.ascontiguousarray(tpos, dtype=np.uint32)
+    strand = np.zeros(max(1, len(qpos)), dtype=np.uint8)
+    g = genome if isinstance(genome, bytes) else genome.tobytes()
+    L.oracle_separate_strand.restype = C.c_long
+    L.oracle_separate_strand(C.c_char_p(read), C.c_char_p(g), k, _p(qpos, C.c_uint32), _p(tpos, C.c_uint32), C.c_long(len(qpos)), _p(strand, C.c_uint8))
+    return strand[:len(qpos)]
