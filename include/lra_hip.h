@@ -109,18 +109,45 @@ int lra_seed_batch(lra_ctx* ctx, int n_reads, const char* d_seq, const uint64_t*
  * Replaces   int AffineOneGapAlign(string& qSeq, int qLen, string& tSeq, int tLen,
  *                                  int m, int mm, int indel, int k, Alignment& aln,
  *                                  AffineAlignBuffers& b)          (AffineOneGapAlign.h:157)
- * for n independent (q,t,k) problems.  Sequences are ASCII bytes inside one device
- * buffer d_seq; problem p uses d_seq[q_off[p] .. +q_len[p]) and d_seq[t_off[p] .. +t_len[p]).
+ * for n independent (q,t,k) problems.  Sequences are ASCII bytes inside device buffers
+ * d_qseq / d_tseq (may be the same buffer); problem p uses d_qseq[q_off[p] .. +q_len[p]) and
+ * d_tseq[t_off[p] .. +t_len[p]).
  * Outputs per problem: the returned score; the gapless blocks the reference appends to
  * aln.blocks, as (qPos,tPos,length) int32 triples written at d_blocks + 3*d_block_off[p]
  * (capacity d_block_off[p+1]-d_block_off[p] triples; min(q_len,t_len)+1 always suffices);
  * their count; a status word (bits above).                                              */
-int lra_affine_one_gap_align_batch(lra_ctx* ctx, int n, const char* d_seq,
+int lra_affine_one_gap_align_batch(lra_ctx* ctx, int n, const char* d_qseq, const char* d_tseq,
                                    const uint64_t* d_q_off, const int32_t* d_q_len,
                                    const uint64_t* d_t_off, const int32_t* d_t_len,
                                    const int32_t* d_k, int m, int mm, int indel,
                                    int32_t* d_score, int32_t* d_nblocks, int32_t* d_blocks,
                                    const uint64_t* d_block_off, int32_t* d_status);
+
+/* ---- a14: banded 3-state affine indel refinement ----------------------------------------
+ * Replaces   void IndelRefineAlignment(Read& read, Genome& genome, Alignment& alignment,
+ *                                      const Options& opts, IndelRefineBuffers& buffers,
+ *                                      bool endAlign = false)            (IndelRefine.h:53)
+ * for n_aln alignments.  Alignment a: its gapless blocks alignment.blocks as (qPos,tPos,length)
+ * int32 triples d_blocks_in[3*d_block_off[a] .. 3*d_block_off[a+1]) (absolute read / chromosome
+ * coordinates); alignment.read = the read strand it is on = d_qseq + d_q_off[a] of length
+ * d_q_len[a] (read.length); genome.seqs[alignment.chromIndex] = d_tseq + d_t_off[a] of length
+ * d_t_len[a] (genome.lengths[chromIndex]).  refine_band = opts.refineBand (2..64), match /
+ * mismatch / indel = opts.localMatch / localMismatch / localIndel, end_align as the argument.
+ * Output: the refined alignment.blocks of every alignment (CSR, device arrays owned by the
+ * context, valid until the next call), a status word per alignment (bits above; LRA_ST_RANGE
+ * also flags a row window wider than 64 cells, not supported yet).  Synchronous.            */
+typedef struct lra_refine_result {
+  int32_t n_aln;
+  uint64_t n_blocks, n_segments, n_rows, n_cells, n_aog;
+  const uint64_t* d_block_off;   /* [n_aln+1] */
+  const int32_t* d_blocks;       /* [3*n_blocks] */
+  const int32_t* d_status;       /* [n_aln] */
+} lra_refine_result;
+int lra_indel_refine_batch(lra_ctx* ctx, int n_aln, const int32_t* d_blocks_in, const uint64_t* d_block_off,
+                           uint64_t n_blocks_in, const char* d_qseq, const uint64_t* d_q_off,
+                           const int32_t* d_q_len, const char* d_tseq, const uint64_t* d_t_off,
+                           const int64_t* d_t_len, int refine_band, int match, int mismatch, int indel,
+                           int end_align, lra_refine_result* out);
 
 #ifdef __cplusplus
 }

@@ -47,7 +47,7 @@ class AogBatch:
         """Launch the batch on the context's stream (asynchronous)."""
         c = self.ctx
         c.check(c.lib.lra_affine_one_gap_align_batch(
-            c.h, self.n, ptr(self.seq), ptr(self.q_off), ptr(self.q_len), ptr(self.t_off), ptr(self.t_len),
+            c.h, self.n, ptr(self.seq), ptr(self.seq), ptr(self.q_off), ptr(self.q_len), ptr(self.t_off), ptr(self.t_len),
             ptr(self.k), self.m, self.mm, self.indel, ptr(self.score), ptr(self.nblocks), ptr(self.blocks),
             ptr(self.block_off), ptr(self.status)))
 

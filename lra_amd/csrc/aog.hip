@@ -210,7 +210,7 @@ __device__ __forceinline__ void solve(int lane, const Problem& pr, const Geo& g,
     }
     wave_sync();
     // ---- suffix boundary (:409-467), loop by loop in the reference's order
-    const int qStart = max(0, qLen - diag), qEnd = qLen + 1;
+    const int qStart = max(0, qLen - diag);
     const int tStart = max(0, tLen - diag);
     const int tLow = max(0, tLen - diag - k - 1 - 1);
     const int qLow = max(0, qLen - diag - k - 1);
@@ -333,7 +333,7 @@ __device__ __forceinline__ void solve(int lane, const Problem& pr, const Geo& g,
 
 struct BatchArgs {
   int n;
-  const char* seq;
+  const char* qseq; const char* tseq;
   const uint64_t* q_off; const int32_t* q_len; const uint64_t* t_off; const int32_t* t_len;
   const int32_t* k;
   int m, mm, indel;
@@ -344,7 +344,7 @@ struct BatchArgs {
 };
 
 __device__ __forceinline__ bool load_problem(const BatchArgs& a, int p, Problem& pr, Geo& g, int& range_ok) {
-  pr.q = a.seq + a.q_off[p]; pr.t = a.seq + a.t_off[p];
+  pr.q = a.qseq + a.q_off[p]; pr.t = a.tseq + a.t_off[p];
   pr.qLen = a.q_len[p]; pr.tLen = a.t_len[p]; pr.k0 = a.k[p];
   pr.m = a.m; pr.mm = a.mm; pr.indel = a.indel;
   bool ok = pr.qLen >= 0 && pr.tLen >= 0 && pr.k0 >= 1 && make_geo(pr.qLen, pr.tLen, pr.k0, g);
@@ -392,18 +392,16 @@ __global__ void __launch_bounds__(CLS == 0 ? 256 : 64) aog_kernel(BatchArgs a) {
 
 }  // namespace
 
-extern "C" int lra_affine_one_gap_align_batch(lra_ctx* ctx, int n, const char* d_seq,
-                                              const uint64_t* d_q_off, const int32_t* d_q_len,
-                                              const uint64_t* d_t_off, const int32_t* d_t_len,
-                                              const int32_t* d_k, int m, int mm, int indel,
-                                              int32_t* d_score, int32_t* d_nblocks, int32_t* d_blocks,
-                                              const uint64_t* d_block_off, int32_t* d_status) {
+int lra_aog_launch_device(lra_ctx* ctx, int n, const char* d_qseq, const char* d_tseq, const uint64_t* d_q_off,
+                          const int32_t* d_q_len, const uint64_t* d_t_off, const int32_t* d_t_len, const int32_t* d_k,
+                          int m, int mm, int indel, int32_t* d_score, int32_t* d_nblocks, int32_t* d_blocks,
+                          const uint64_t* d_block_off, int32_t* d_status) {
   if (!ctx) return LRA_ERR_INVALID;
   if (n < 0) return lra_set_err(ctx, LRA_ERR_INVALID, "n < 0");
   if (n == 0) return LRA_OK;
   LRA_HIP_CHECK(ctx, hipSetDevice(ctx->device));
   BatchArgs a;
-  a.n = n; a.seq = d_seq; a.q_off = d_q_off; a.q_len = d_q_len; a.t_off = d_t_off; a.t_len = d_t_len;
+  a.n = n; a.qseq = d_qseq; a.tseq = d_tseq; a.q_off = d_q_off; a.q_len = d_q_len; a.t_off = d_t_off; a.t_len = d_t_len;
   a.k = d_k; a.m = m; a.mm = mm; a.indel = indel;
   a.score = d_score; a.nblocks = d_nblocks; a.blocks = d_blocks; a.block_off = d_block_off; a.status = d_status;
   // scratch slot 0: counts[4] + lists[3n];  slot 1: class-C HBM work slots
@@ -432,4 +430,14 @@ extern "C" int lra_affine_one_gap_align_batch(lra_ctx* ctx, int n, const char* d
   lra_time_end(ctx);
   LRA_HIP_CHECK(ctx, hipGetLastError());
   return LRA_OK;
+}
+
+extern "C" int lra_affine_one_gap_align_batch(lra_ctx* ctx, int n, const char* d_qseq, const char* d_tseq,
+                                              const uint64_t* d_q_off, const int32_t* d_q_len,
+                                              const uint64_t* d_t_off, const int32_t* d_t_len,
+                                              const int32_t* d_k, int m, int mm, int indel,
+                                              int32_t* d_score, int32_t* d_nblocks, int32_t* d_blocks,
+                                              const uint64_t* d_block_off, int32_t* d_status) {
+  return lra_aog_launch_device(ctx, n, d_qseq, d_tseq, d_q_off, d_q_len, d_t_off, d_t_len, d_k, m, mm, indel, d_score, d_nblocks,
+                               d_blocks, d_block_off, d_status);
 }

@@ -20,6 +20,8 @@ struct lra_ctx {
   size_t scratch_bytes[4] = {0, 0, 0, 0};
   int num_cu = 256;
   lra_seed_state* seed = nullptr;
+  void* aux = nullptr; size_t aux_bytes = 0;          // AffineOneGapAlign blocks of refine fallbacks
+  void* out_buf = nullptr; size_t out_bytes = 0;      // refined blocks handed back to the caller
   // kernel timing
   bool timing = false;
   std::vector<lra_time_rec> recs;

@@ -55,6 +55,8 @@ extern "C" void lra_ctx_destroy(lra_ctx* ctx) {
   for (int i = 0; i < 4; i++)
     if (ctx->scratch[i]) (void)hipFree(ctx->scratch[i]);
   lra_seed_free(ctx);
+  if (ctx->aux) (void)hipFree(ctx->aux);
+  if (ctx->out_buf) (void)hipFree(ctx->out_buf);
   for (auto& r : ctx->recs) { (void)hipEventDestroy(r.a); (void)hipEventDestroy(r.b); }
   for (auto e : ctx->free_events) (void)hipEventDestroy(e);
   delete ctx;

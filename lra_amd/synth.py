@@ -70,6 +70,41 @@ def simulate_read(rng, genome, length, err, mix, rev):
     return out, start, length, int(rev)
 
 
+def simulate_read_with_blocks(rng, genome, length, err, mix):
+    """Forward-strand read plus its TRUE alignment as gapless blocks (qPos, tPos, len) in absolute
+    read / genome coordinates (substitutions stay inside blocks; an insertion puts one extra read
+    base after its reference base; a deletion skips the reference base)."""
+    n = len(genome)
+    length = int(max(50, min(length, n - 1)))
+    start = int(rng.integers(0, n - length))
+    src = genome[start:start + length]
+    r = rng.random(length)
+    ps, pi, pd = (err * m / sum(mix) for m in mix)
+    sub = r < ps
+    ins = (r >= ps) & (r < ps + pi)
+    dele = (r >= ps + pi) & (r < ps + pi + pd)
+    dele[0] = dele[-1] = False
+    ins[-1] = False
+    base = src.copy()
+    base[sub] = BASES[(CODE[src[sub]] + rng.integers(1, 4, size=int(sub.sum()))) % 4]
+    counts = np.ones(length, dtype=np.int64)
+    counts[ins] = 2
+    counts[dele] = 0
+    out = np.repeat(base, counts)
+    ends = np.cumsum(counts)
+    out[ends[ins] - 1] = BASES[rng.integers(0, 4, size=int(ins.sum()))]
+    qpos = ends - counts                      # read index of each reference base (if kept)
+    keep = ~dele
+    # a block breaks after an insertion and around deletions
+    idx = np.nonzero(keep)[0]
+    brk = np.ones(len(idx), dtype=bool)
+    brk[1:] = (np.diff(idx) != 1) | ins[idx[:-1]]
+    starts = np.nonzero(brk)[0]
+    lens = np.diff(np.append(starts, len(idx)))
+    blocks = np.stack([qpos[idx[starts]], idx[starts] + start, lens], axis=1).astype(np.int32)
+    return out, blocks
+
+
 def simulate_reads(genome, n_reads, mean_len, sd_len, err, mix=(30, 35, 35), seed=3, rev_frac=0.5):
     rng = np.random.default_rng(seed)
     reads, truth = [], []

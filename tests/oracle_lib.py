@@ -91,3 +91,19 @@ def separate_strand(read: bytes, genome, k, qpos, tpos):
     L.oracle_separate_strand.restype = C.c_long
     L.oracle_separate_strand(C.c_char_p(read), C.c_char_p(g), k, _p(qpos, C.c_uint32), _p(tpos, C.c_uint32), C.c_long(len(qpos)), _p(strand, C.c_uint8))
     return strand[:len(qpos)]
+
+
+def indel_refine(blocks, q_seq: bytes, t_seq: bytes, refine_band, match, mismatch, indel, end_align=False, read_len=None, chrom_len=None):
+    """blocks: (n,3) int32 (qPos,tPos,len).  Returns (refined (m,3) int32, status)."""
+    L = lib()
+    b = np.ascontiguousarray(np.asarray(blocks, dtype=np.int32).reshape(-1, 3))
+    n = len(b)
+    cap = int(b[:, 2].sum() + 2 * n + 64 + (b[-1, 1] + b[-1, 2] - b[0, 1] if n else 0) + (b[-1, 0] + b[-1, 2] - b[0, 0] if n else 0))
+    out = np.zeros(3 * cap, dtype=np.int32)
+    st = C.c_int(0)
+    L.oracle_indel_refine.restype = C.c_long
+    m = L.oracle_indel_refine(_p(b, C.c_int), C.c_long(n), C.c_char_p(q_seq), C.c_long(len(q_seq) if read_len is None else read_len),
+                              C.c_char_p(t_seq), C.c_long(len(t_seq) if chrom_len is None else chrom_len), refine_band, match, mismatch,
+                              indel, 1 if end_align else 0, _p(out, C.c_int), C.c_long(cap), C.byref(st))
+    assert m <= cap, (m, cap)
+    return out[:3 * m].reshape(m, 3).copy(), st.value
