@@ -1,0 +1,233 @@
+#!/usr/bin/env python
+"""bench.py -- throughput of the MI355X hot path on synthetic long reads.
+
+One "step" = one pass of the GPU-resident hot-path stages over one batch of reads already in HBM:
+  a1-a4  tier-1 seeding   (StoreMinimizers -> sort -> CompareLists -> SeparateMatchesByStrand)
+  a12    AffineOneGapAlign on the between-anchor gaps of every read
+  a14    IndelRefineAlignment over every read's block list
+The chaining stages between them (a5-a11, a13: clustering, sparse DP, local refinement glue) are
+NOT built yet, so the a12/a14 inputs are derived from the simulator's true alignment (anchors =
+true gapless blocks >= 12 bp; the gaps between them go to a12; a perturbed block list goes to
+a14).  `config.stages` says so; the number is the throughput of the stages listed, not of a
+whole `lra align`.
+
+Contract: python bench.py --gpus N --steps K --warmup W  -> rank 0 prints ONE JSON line.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+
+def build_workload(args, rank):
+    from lra_amd import synth
+    t0 = time.time()
+    genome = synth.make_genome(int(args.genome_mb * 1e6), seed=1, repeat_frac=0.25)
+    idx_key, idx_pos = synth.build_global_index(genome, args.k, args.w, 150)
+    rng = np.random.default_rng(1000 + rank)                 # each rank owns its own shard of reads
+    reads, truth = [], []
+    for _ in range(args.reads):
+        L = int(max(1000, rng.normal(args.read_len, args.read_len / 10)))
+        r, b = synth.simulate_read_with_blocks(rng, genome, L, args.err, (30, 35, 35))
+        reads.append(r)
+        truth.append(b)
+    # a12 problems: gaps between consecutive anchors (true blocks >= 12 bp)
+    aq, at, ak = [], [], []
+    gbytes = genome
+    for r, b in zip(reads, truth):
+        anc = b[b[:, 2] >= 12]
+        for i in range(len(anc) - 1):
+            qs, qe = anc[i, 0] + anc[i, 2], anc[i + 1, 0]
+            ts, te = anc[i, 1] + anc[i, 2], anc[i + 1, 1]
+            if qe - qs <= 0 and te - ts <= 0:
+                continue
+            aq.append(r[qs:qe].tobytes()); at.append(gbytes[ts:te].tobytes())
+            ak.append(min(abs(int(qe - qs) - int(te - ts)) * 2 + 1, 15))   # LocalRefineAlignment.h:101-115
+    # a14 input: truth blocks with some removed / trimmed (what seed extension hands over)
+    rblocks = []
+    for b in truth:
+        keep = rng.random(len(b)) > 0.15
+        keep[0] = keep[-1] = True
+        bb = b[keep].copy()
+        trim = (bb[:, 2] > 6) & (rng.random(len(bb)) < 0.3)
+        a = rng.integers(0, 3, size=len(bb)) * trim
+        z = rng.integers(0, 3, size=len(bb)) * trim
+        bb[:, 0] += a; bb[:, 1] += a; bb[:, 2] -= (a + z)
+        rblocks.append(bb[bb[:, 2] > 0])
+    return dict(genome=genome, idx_key=idx_key, idx_pos=idx_pos, reads=reads, truth=truth, aq=aq, at=at, ak=ak,
+                rblocks=rblocks, gen_s=time.time() - t0)
+
+
+def cpu_baseline(wl, args, budget_s=20.0):
+    """The oracle (CPU restatement) timed single-threaded on a bounded sample of the same workload."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import oracle_lib as O
+    O.lib()
+    g = wl["genome"].tobytes() + b"\0" * 64
+    t0 = time.time()
+    bases = 0
+    n = 0
+    gap_i = 0
+    for r, tb, rb in zip(wl["reads"], wl["truth"], wl["rblocks"]):
+        rbytes = r.tobytes()
+        keys, pos = O.store_minimizers(rbytes, args.k, args.w)
+        sk, sp = O.sort_minimizers(keys, pos)
+        qi, ti = O.compare_lists(sk, sp, wl["idx_key"], wl["idx_pos"], args.max_freq)
+        O.separate_strand(rbytes, g, args.k, sp[qi], wl["idx_pos"][ti])
+        anc = tb[tb[:, 2] >= 12]
+        for i in range(len(anc) - 1):
+            if gap_i < len(wl["aq"]):
+                O.affine_one_gap_align(wl["aq"][gap_i], wl["at"][gap_i], 4, -1, -2, wl["ak"][gap_i])
+                gap_i += 1
+        O.indel_refine(rb, rbytes, g, args.refine_band, 4, -1, -2)
+        bases += len(r)
+        n += 1
+        if time.time() - t0 > budget_s:
+            break
+    dt = time.time() - t0
+    return {"value": bases / dt / 1e9, "unit": "Gbp/s", "cores": 1, "kind": "port",
+            "sample": "%d reads (%d bp) of the same batch through the oracle's a1-a4, a12, a14 in %.1f s, 1 thread "
+                      "(python ctypes call overhead included)" % (n, bases, dt)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--genome-mb", type=float, default=float(os.environ.get("LRA_BENCH_GENOME_MB", 64)))
+    ap.add_argument("--reads", type=int, default=int(os.environ.get("LRA_BENCH_READS", 1024)), help="reads per GPU per step")
+    ap.add_argument("--read-len", type=int, default=30000)
+    ap.add_argument("--err", type=float, default=0.10)
+    ap.add_argument("--k", type=int, default=17)          # -ONT: globalK 17, globalW 10 (lra.cpp:386-431)
+    ap.add_argument("--w", type=int, default=10)
+    ap.add_argument("--max-freq", type=int, default=150)
+    ap.add_argument("--refine-band", type=int, default=7)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+    dev_index = local_rank if world > 1 else 0
+    torch.cuda.set_device(dev_index)
+
+    from lra_amd.context import Context
+    from lra_amd import seed, align, refine, parallel
+
+    wl = build_workload(args, rank)
+    ctx = Context(dev_index)
+    seed.load_reference(ctx, wl["genome"], wl["idx_key"], wl["idx_pos"])
+    rbatch = seed.ReadBatch(ctx, [r.tobytes() for r in wl["reads"]])
+    abatch = align.AogBatch(ctx, wl["aq"], wl["at"], wl["ak"], 4, -1, -2)       # -ONT localMatch/Mismatch/Indel
+    gdev = torch.from_numpy(np.concatenate([wl["genome"], np.zeros(64, np.uint8)])).to(ctx.device)
+    lens = np.array([len(r) for r in wl["reads"]], dtype=np.int64)
+    fbatch = refine.RefineBatch(ctx, wl["rblocks"], rbatch.seq, rbatch.off_h[:-1], lens.astype(np.int32), gdev,
+                                np.zeros(len(lens), np.int64), np.full(len(lens), len(wl["genome"]), np.int64))
+    total_bases = int(lens.sum())
+
+    stats = {}
+
+    def step():
+        sres = seed.seed_batch(ctx, rbatch, args.k, args.w, args.max_freq)
+        abatch.run()
+        fres = refine.indel_refine_batch(ctx, fbatch, args.refine_band, 4, -1, -2)
+        # the one exchange step: refined block records -> rank 0
+        rec = ctx.to_tensor(fres.d_blocks, 3 * fres.n_blocks, torch.int32)
+        parallel.gather_records(rec, dst=0)
+        stats.update(n_mm=sres.n_minimizers, n_match=sres.n_matches, n_cells=fres.n_cells, n_rows=fres.n_rows,
+                     n_seg=fres.n_segments, n_blocks=fres.n_blocks, n_aog=fres.n_aog)
+
+    def sync():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    ctx.timing(True)
+    ctx.timing_reset()
+    sync()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    sync()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        tt = torch.tensor([dt], dtype=torch.float64, device=ctx.device)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dt = float(tt.item())
+        tb = torch.tensor([total_bases], dtype=torch.int64, device=ctx.device)
+        dist.all_reduce(tb, op=dist.ReduceOp.SUM)
+        job_bases = int(tb.item())
+        nreads = args.reads * world
+    else:
+        job_bases = total_bases
+        nreads = args.reads
+
+    kernels = ["sketch_count", "sketch_emit", "sort", "index_bounds", "compare_count", "compare_emit", "strand",
+               "aog_lds_small", "aog_lds_large", "aog_hbm", "ir_segment", "ir_band", "ir_fill", "ir_trace_count", "ir_trace_emit"]
+    ktimes = {k: ctx.timing_get(k) for k in kernels}
+    ctx.timing(False)
+    if rank == 0:
+        ms_step = dt / args.steps * 1e3
+        gbps = job_bases * args.steps / dt / 1e9
+        dom = max(ktimes, key=lambda k: ktimes[k][0])
+        dom_ms, dom_n = ktimes[dom]
+        avg_ms = dom_ms / max(dom_n, 1)
+        # algorithmic bytes per launch of the dominant kernel (DESIGN.md "kernels" gives the per-unit figures)
+        L = total_bases
+        alg = {
+            "ir_fill": 1 * stats["n_cells"] + 12 * stats["n_rows"] + 2 * stats["n_rows"],        # 1 B arrow/cell + row windows + both sequences
+            "ir_band": 12 * stats["n_rows"] + 12 * stats["n_blocks"],
+            "ir_trace_count": 1 * stats["n_cells"] + 12 * stats["n_rows"],
+            "ir_trace_emit": 1 * stats["n_cells"] + 12 * stats["n_rows"] + 12 * stats["n_blocks"],
+            "sort": 2 * 12 * stats["n_mm"],
+            "index_bounds": stats["n_mm"] * (12 + 64 + 8),
+            "compare_count": stats["n_mm"] * (8 + 8 + 64),
+            "compare_emit": stats["n_mm"] * (8 + 8 + 64) + 8 * stats["n_match"],
+            "sketch_count": L, "sketch_emit": L + 12 * stats["n_mm"],
+            "strand": stats["n_match"] * (8 + 8 + 2 * args.k),
+            "aog_lds_small": sum(len(a) + len(b) for a, b in zip(wl["aq"], wl["at"])) + 12 * len(wl["aq"]),
+        }.get(dom, 0)
+        achieved = alg / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
+        out = {
+            "metric": "aligned Gbp/s (hot-path stages a1-a4 + a12 + a14), 30 kb ONT-like reads", "value": gbps, "unit": "Gbp/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_step, "higher_is_better": True,
+            "scaling": "weak", "vs_baseline": None, "dtype": "int32", "data": "synthetic",
+            "reads_per_s": nreads * args.steps / dt,
+            "config": {"workload": "synthetic %g Mb chromosome (chr20-sized, BASELINE configs[1] reference) + %d reads/GPU of N(%d, 10%%) bp, %g%% "
+                                   "error 30:35:35 (BASELINE configs[2] -ONT read profile; full GRCh38 not generated in round 1)"
+                                   % (args.genome_mb, args.reads, args.read_len, args.err * 100),
+                       "preset": "-ONT (k=%d w=%d maxFreq=%d refineBand=%d match/mismatch/indel=4/-1/-2)" % (args.k, args.w, args.max_freq, args.refine_band),
+                       "stages": "a1-a4 on the reads; a12 on between-anchor gaps and a14 on block lists derived from the simulator's truth "
+                                 "(a5-a11,a13 chaining stages not built yet: NOT a whole `lra align`)",
+                       "parallelism": "reads sharded by ordinal, 1 process/GPU; RCCL gather of block records to rank 0",
+                       "per_step": {k: int(v) for k, v in stats.items()}},
+            "kernel_ms_per_step": {k: round(v[0] / args.steps, 4) for k, v in ktimes.items() if v[1]},
+            "roofline": {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": 8000.0, "unit": "GB/s", "frac": achieved / 8000.0,
+                         "traffic": None, "avg_launch_ms": avg_ms, "algorithmic_bytes_per_launch": alg},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(wl, args)
+        out["setup_s"] = round(wl["gen_s"], 1)
+        print(json.dumps(out))
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -53,6 +53,10 @@ int lra_abi_version(void);
  * context's stream (a C++ host would call hipMemcpy itself).                                */
 int lra_copy_to_host(lra_ctx* ctx, void* h_dst, const void* d_src, uint64_t bytes);
 
+/* Asynchronous device->device copy on the context's stream (e.g. out of context-owned result
+ * arrays into caller-owned memory before the next call recycles them).                        */
+int lra_copy_device(lra_ctx* ctx, void* d_dst, const void* d_src, uint64_t bytes);
+
 /* Per-kernel device timing (HIP events on the context's stream around every kernel the
  * library launches).  Off by default.  lra_ctx_timing_get synchronises the stream and returns
  * the accumulated milliseconds and launch count of the named kernel since the last reset

@@ -26,6 +26,7 @@ SYMBOLS = {
     "lra_ctx_set_stream": (C.c_int, [_vp, _vp]),
     "lra_ctx_last_error": (C.c_char_p, [_vp]),
     "lra_copy_to_host": (C.c_int, [_vp, _vp, _vp, C.c_uint64]),
+    "lra_copy_device": (C.c_int, [_vp, _vp, _vp, C.c_uint64]),
     "lra_ctx_timing_enable": (C.c_int, [_vp, C.c_int]),
     "lra_ctx_timing_reset": (C.c_int, [_vp]),
     "lra_ctx_timing_get": (C.c_int, [_vp, C.c_char_p, C.POINTER(C.c_double), C.POINTER(C.c_int)]),

@@ -37,6 +37,13 @@ class Context:
             self.check(self.lib.lra_copy_to_host(self.h, C.c_void_p(out.ctypes.data), C.c_void_p(dev_ptr), C.c_uint64(out.nbytes)))
         return out
 
+    def to_tensor(self, dev_ptr, count, dtype):
+        """Copy `count` items from a raw device pointer into a new torch tensor on this GPU (async on the stream)."""
+        out = torch.empty(int(count), dtype=dtype, device=self.device)
+        if count:
+            self.check(self.lib.lra_copy_device(self.h, C.c_void_p(out.data_ptr()), C.c_void_p(dev_ptr), C.c_uint64(out.numel() * out.element_size())))
+        return out
+
     def timing(self, on=True):
         self.check(self.lib.lra_ctx_timing_enable(self.h, 1 if on else 0))
 

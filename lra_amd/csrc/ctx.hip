@@ -125,3 +125,10 @@ extern "C" int lra_copy_to_host(lra_ctx* ctx, void* h_dst, const void* d_src, ui
   LRA_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
   return LRA_OK;
 }
+
+extern "C" int lra_copy_device(lra_ctx* ctx, void* d_dst, const void* d_src, uint64_t bytes) {
+  if (!ctx) return LRA_ERR_INVALID;
+  if (bytes == 0) return LRA_OK;
+  LRA_HIP_CHECK(ctx, hipMemcpyAsync(d_dst, d_src, bytes, hipMemcpyDeviceToDevice, ctx->stream));
+  return LRA_OK;
+}
