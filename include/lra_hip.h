@@ -109,6 +109,12 @@ typedef struct lra_seed_result {
 int lra_seed_batch(lra_ctx* ctx, int n_reads, const char* d_seq, const uint64_t* d_read_off, int k, int w,
                    int max_freq, lra_seed_result* out);
 
+/* a2 alone: sorts each list [d_off[i], d_off[i+1]) of (key,pos) tuples IN PLACE exactly as
+ * `std::sort(readmm.begin(), readmm.end())` (MapRead.h:185, libstdc++ introsort with
+ * GenomeTuple::operator<, TupleOps.h:76) would, including the order it leaves equal keys in.
+ * Asynchronous.                                                                               */
+int lra_sort_minimizers_batch(lra_ctx* ctx, int n_lists, const uint64_t* d_off, uint64_t* d_key, uint32_t* d_pos);
+
 /* ---- a12: banded one-gap seed-extension DP ------------------------------------------
  * Replaces   int AffineOneGapAlign(string& qSeq, int qLen, string& tSeq, int tLen,
  *                                  int m, int mm, int indel, int k, Alignment& aln,

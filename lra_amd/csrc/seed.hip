@@ -31,6 +31,7 @@ namespace {
 constexpr uint64_t FOR_MASK = ~(1ULL << 63);  // lra.cpp:1008-1012
 constexpr uint64_t REV_MASK = (1ULL << 63);
 constexpr int MAX_W = 32;
+constexpr int SORT_CAP = 9000;   // tuples per read the LDS sort holds (16 B each + tables <= 160 KiB)
 
 __device__ __forceinline__ int code_n(unsigned char c) {  // SeqUtils.h:42 (seqMapN)
   if (c < 8) return c & 3;
@@ -215,9 +216,11 @@ __device__ void insertion_sort(SortSeg& s, long first, long last) {
   }
 }
 
-__global__ void __launch_bounds__(64) sort_kernel(int n_reads, const uint64_t* __restrict__ mm_off, uint64_t* mm_key, uint32_t* mm_pos) {
+__global__ void __launch_bounds__(64) sort_kernel(int n_reads, const uint64_t* __restrict__ mm_off, uint64_t* mm_key, uint32_t* mm_pos,
+                                                  const int* __restrict__ only_flagged) {
   const int r = blockIdx.x * 64 + threadIdx.x;
   if (r >= n_reads) return;
+  if (only_flagged && !only_flagged[r]) return;
   SortSeg s{mm_key + mm_off[r], mm_pos + mm_off[r]};
   const long n = (long)(mm_off[r + 1] - mm_off[r]);
   if (n < 2) return;
@@ -259,6 +262,247 @@ __global__ void __launch_bounds__(64) sort_kernel(int n_reads, const uint64_t* _
     insertion_sort(s, 0, 16);
     for (long i = 16; i != n; ++i) unguarded_linear_insert(s, i);
   } else insertion_sort(s, 0, n);
+}
+
+// ---- a2, fast path: the same std::sort, one 256-thread workgroup per read, data in LDS.
+// Two facts make introsort data-parallel without changing its result:
+//  (1) the segments the loop recurses into are disjoint, so they can be processed level by
+//      level, all segments of a level at once;
+//  (2) libstdc++'s unguarded Hoare partition of [first+1,last) around *first is a closed form:
+//      with a_1<a_2<... the positions holding x >= pivot (ascending) and b_1>b_2>... those
+//      holding x <= pivot (descending), it swaps (a_i,b_i) for i <= m = #{i: a_i < b_i} and
+//      returns cut = min(a_{m+1}, b_m).  Ranks come from prefix counts, swaps are independent.
+// The final insertion sort is stable, and the <=16-element leftovers are mutually ordered, so
+// it equals a stable insertion sort of every leftover block on its own.
+constexpr int SORT_NT = 256;
+constexpr unsigned short S_NONE = 0xFFFF;
+
+struct LdsSeg {                     // (key, original index) pairs in LDS
+  uint64_t* k; unsigned short* p;
+  __device__ __forceinline__ bool lt(int a, int b) const { return (k[a] & FOR_MASK) < (k[b] & FOR_MASK); }
+  __device__ __forceinline__ void swap(int a, int b) {
+    uint64_t tk = k[a]; k[a] = k[b]; k[b] = tk;
+    unsigned short tp = p[a]; p[a] = p[b]; p[b] = tp;
+  }
+  __device__ __forceinline__ void mv(int dst, int src) { k[dst] = k[src]; p[dst] = p[src]; }
+};
+
+__device__ void lds_adjust_heap(LdsSeg& s, int first, int hole, int len, uint64_t vk, unsigned short vp) {
+  const int top = hole;
+  int child = hole;
+  while (child < (len - 1) / 2) {
+    child = 2 * (child + 1);
+    if (s.lt(first + child, first + (child - 1))) child--;
+    s.mv(first + hole, first + child);
+    hole = child;
+  }
+  if ((len & 1) == 0 && child == (len - 2) / 2) {
+    child = 2 * (child + 1);
+    s.mv(first + hole, first + (child - 1));
+    hole = child - 1;
+  }
+  int parent = (hole - 1) / 2;
+  while (hole > top && (s.k[first + parent] & FOR_MASK) < (vk & FOR_MASK)) {
+    s.mv(first + hole, first + parent);
+    hole = parent;
+    parent = (hole - 1) / 2;
+  }
+  s.k[first + hole] = vk; s.p[first + hole] = vp;
+}
+
+__device__ void lds_heap_sort(LdsSeg& s, int first, int last) {
+  int len = last - first;
+  if (len >= 2) {
+    int parent = (len - 2) / 2;
+    while (true) {
+      uint64_t vk = s.k[first + parent]; unsigned short vp = s.p[first + parent];
+      lds_adjust_heap(s, first, parent, len, vk, vp);
+      if (parent == 0) break;
+      parent--;
+    }
+  }
+  while (last - first > 1) {
+    --last;
+    uint64_t vk = s.k[last]; unsigned short vp = s.p[last];
+    s.mv(last, first);
+    lds_adjust_heap(s, first, 0, last - first, vk, vp);
+  }
+}
+
+__device__ void lds_insertion_sort(LdsSeg& s, int first, int last) {   // == __insertion_sort on an isolated block
+  for (int i = first + 1; i < last; ++i) {
+    uint64_t vk = s.k[i]; unsigned short vp = s.p[i];
+    int j = i;
+    while (j > first && (vk & FOR_MASK) < (s.k[j - 1] & FOR_MASK)) { s.mv(j, j - 1); --j; }
+    s.k[j] = vk; s.p[j] = vp;
+  }
+}
+
+__global__ void __launch_bounds__(SORT_NT) sort_wg_kernel(int n_reads, const uint64_t* __restrict__ mm_off, uint64_t* mm_key, uint32_t* mm_pos,
+                                                        uint32_t* tscratch, int cap, int* __restrict__ fallback) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int maxseg = cap / 16 + 8;
+  uint64_t* key = (uint64_t*)smem;
+  unsigned short* idx = (unsigned short*)(key + cap);
+  unsigned short* seg = idx + cap;
+  unsigned short* pa = seg + cap;
+  unsigned short* pb = pa + cap;
+  unsigned short* sF = pb + cap;            // segment tables (current)
+  unsigned short* sL = sF + maxseg;
+  unsigned short* sD = sL + maxseg;
+  unsigned short* nF = sD + maxseg;         // next level
+  unsigned short* nL = nF + maxseg;
+  unsigned short* nD = nL + maxseg;
+  unsigned short* sCut = nD + maxseg;
+  unsigned short* sLid = sCut + maxseg;
+  unsigned short* sRid = sLid + maxseg;
+  unsigned short* sM = sRid + maxseg;
+  unsigned int* startBits = (unsigned int*)(sM + maxseg + (maxseg & 1));   // leftover-block start markers, cap/32+1 words
+  __shared__ int cnt[4];                    // nseg, nnext
+  __shared__ unsigned int waveTot[8];
+  uint32_t* t32 = tscratch + (size_t)blockIdx.x * (size_t)(cap + 64);
+  LdsSeg S{key, idx};
+  for (int r = blockIdx.x; r < n_reads; r += gridDim.x) {
+    const long base = (long)mm_off[r];
+    const int n = (int)(mm_off[r + 1] - mm_off[r]);
+    if (n < 2) continue;
+    if (n > cap) { if (tid == 0) fallback[r] = 1; continue; }
+    __syncthreads();
+    for (int p = tid; p < n; p += SORT_NT) { key[p] = mm_key[base + p]; idx[p] = (unsigned short)p; seg[p] = 0; }
+    for (int x = tid; x < cap / 32 + 1; x += SORT_NT) startBits[x] = 0;
+    if (tid == 0) {
+      if (n > 16) { sF[0] = 0; sL[0] = (unsigned short)n; sD[0] = (unsigned short)(2 * (31 - __clz(n))); cnt[0] = 1; }
+      else cnt[0] = 0;
+      cnt[1] = 0;
+    }
+    __syncthreads();
+    if (tid == 0) startBits[0] = 1u;
+    int nseg = cnt[0];
+    while (nseg > 0) {
+      // (a) depth check / median of three -> pivot at `first`
+      for (int s = tid; s < nseg; s += SORT_NT) {
+        const int first = sF[s], last = sL[s];
+        sM[s] = 0;
+        if (sD[s] == 0) { lds_heap_sort(S, first, last); sM[s] = S_NONE; continue; }
+        sD[s] = sD[s] - 1;
+        const int a = first + 1, b = first + (last - first) / 2, c = last - 1;
+        if (S.lt(a, b)) {
+          if (S.lt(b, c)) S.swap(first, b);
+          else if (S.lt(a, c)) S.swap(first, c);
+          else S.swap(first, a);
+        } else if (S.lt(a, c)) S.swap(first, a);
+        else if (S.lt(b, c)) S.swap(first, c);
+        else S.swap(first, b);
+      }
+      __syncthreads();
+      // (b) exclusive prefix counts of the two stopper flags over all positions (wave w owns a
+      //     contiguous range; ballots give in-row ranks)
+      const int rows = (n + 63) / 64, rpw = (rows + 3) / 4;
+      const int r0 = wave * rpw, r1 = min(rows, r0 + rpw);
+      auto flags = [&](int p, bool& A, bool& B) {
+        A = false; B = false;
+        if (p < n) {
+          const unsigned short sg = seg[p];
+          if (sg != S_NONE && sM[sg] != S_NONE && p != sF[sg]) {
+            const uint64_t piv = key[sF[sg]] & FOR_MASK, km = key[p] & FOR_MASK;
+            A = km >= piv; B = km <= piv;
+          }
+        }
+      };
+      unsigned int totA = 0, totB = 0;
+      for (int rw = r0; rw < r1; rw++) {
+        bool A, B; flags(rw * 64 + lane, A, B);
+        totA += __popcll(__ballot(A)); totB += __popcll(__ballot(B));
+      }
+      if (lane == 0) { waveTot[wave] = totA; waveTot[4 + wave] = totB; }
+      __syncthreads();
+      unsigned int baseA = 0, baseB = 0;
+      for (int w = 0; w < wave; w++) { baseA += waveTot[w]; baseB += waveTot[4 + w]; }
+      const unsigned long long below = (lane == 0) ? 0ULL : (~0ULL >> (64 - lane));
+      for (int rw = r0; rw < r1; rw++) {
+        const int p = rw * 64 + lane;
+        bool A, B; flags(p, A, B);
+        const unsigned long long mA = __ballot(A), mB = __ballot(B);
+        if (p <= n) t32[p] = ((baseA + __popcll(mA & below)) & 0xFFFF) | ((baseB + __popcll(mB & below)) << 16);
+        baseA += __popcll(mA); baseB += __popcll(mB);
+      }
+      if (wave == 3 && lane == 0 && (n & 63) == 0) t32[n] = (baseA & 0xFFFF) | (baseB << 16);   // prefix at n when n is a row boundary
+      __syncthreads();
+      // (c) scatter stopper positions: pa ascending, pb descending, both stored from first+1
+      for (int p = tid; p < n; p += SORT_NT) {
+        bool A, B; flags(p, A, B);
+        if (A || B) {
+          const int sg = seg[p], b0 = sF[sg] + 1;
+          const unsigned int t = t32[p], tb = t32[b0], te = t32[sL[sg]];
+          if (A) pa[b0 + (((t & 0xFFFF) - (tb & 0xFFFF)) & 0xFFFF)] = (unsigned short)p;
+          if (B) pb[b0 + (((te >> 16) - (t >> 16) - 1) & 0xFFFF)] = (unsigned short)p;
+        }
+      }
+      __syncthreads();
+      // (d) m = number of leading pairs with a_i < b_i
+      for (int p = tid; p < n; p += SORT_NT) {
+        const unsigned short sg = seg[p];
+        if (sg == S_NONE || sM[sg] == S_NONE) continue;
+        const int b0 = sF[sg] + 1, i = p - b0;
+        if (i < 0) continue;
+        const unsigned int tb = t32[b0], te = t32[sL[sg]];
+        const int nA = ((te & 0xFFFF) - (tb & 0xFFFF)) & 0xFFFF, nB = ((te >> 16) - (tb >> 16)) & 0xFFFF;
+        const int lim = min(nA, nB);
+        if (i < lim && pa[b0 + i] < pb[b0 + i] && !(i + 1 < lim && pa[b0 + i + 1] < pb[b0 + i + 1])) sM[sg] = (unsigned short)(i + 1);
+      }
+      __syncthreads();
+      // (e) the swaps
+      for (int p = tid; p < n; p += SORT_NT) {
+        const unsigned short sg = seg[p];
+        if (sg == S_NONE || sM[sg] == S_NONE) continue;
+        const int b0 = sF[sg] + 1, i = p - b0;
+        if (i >= 0 && i < sM[sg]) S.swap(pa[b0 + i], pb[b0 + i]);
+      }
+      __syncthreads();
+      // (f) cut -> children
+      for (int s = tid; s < nseg; s += SORT_NT) {
+        const int first = sF[s], last = sL[s];
+        if (sM[s] == S_NONE) { sCut[s] = (unsigned short)last; sLid[s] = S_NONE; sRid[s] = S_NONE; continue; }   // heap sorted: finished
+        const int b0 = first + 1, m = sM[s];
+        const unsigned int tb = t32[b0], te = t32[last];
+        const int nA = ((te & 0xFFFF) - (tb & 0xFFFF)) & 0xFFFF;
+        int cut = 0x7fffffff;
+        if (m < nA) cut = pa[b0 + m];
+        if (m >= 1) cut = min(cut, (int)pb[b0 + m - 1]);
+        sCut[s] = (unsigned short)cut;
+        unsigned short lid = S_NONE, rid = S_NONE;
+        if (cut - first > 16) { int x = atomicAdd(&cnt[1], 1); nF[x] = (unsigned short)first; nL[x] = (unsigned short)cut; nD[x] = sD[s]; lid = (unsigned short)x; }
+        if (last - cut > 16) { int x = atomicAdd(&cnt[1], 1); nF[x] = (unsigned short)cut; nL[x] = (unsigned short)last; nD[x] = sD[s]; rid = (unsigned short)x; }
+        atomicOr(&startBits[cut >> 5], 1u << (cut & 31));
+        sLid[s] = lid; sRid[s] = rid;
+      }
+      __syncthreads();
+      // (g) relabel elements, swap tables
+      for (int p = tid; p < n; p += SORT_NT) {
+        const unsigned short sg = seg[p];
+        if (sg != S_NONE) seg[p] = (p < sCut[sg]) ? sLid[sg] : sRid[sg];
+      }
+      nseg = cnt[1];
+      __syncthreads();
+      for (int s = tid; s < nseg; s += SORT_NT) { sF[s] = nF[s]; sL[s] = nL[s]; sD[s] = nD[s]; }
+      if (tid == 0) cnt[1] = 0;
+      __syncthreads();
+    }
+    // final insertion sort of every leftover block (blocks start at the marked positions)
+    for (int p = tid; p < n; p += SORT_NT) {
+      if ((startBits[p >> 5] >> (p & 31)) & 1u) {
+        int q = p + 1;
+        while (q < n && !((startBits[q >> 5] >> (q & 31)) & 1u)) q++;
+        lds_insertion_sort(S, p, q);
+      }
+    }
+    __syncthreads();
+    uint32_t* tmp = (uint32_t*)pa;            // pa|pb = 4*cap bytes
+    for (int p = tid; p < n; p += SORT_NT) tmp[p] = mm_pos[base + idx[p]];
+    __syncthreads();
+    for (int p = tid; p < n; p += SORT_NT) { mm_key[base + p] = key[p]; mm_pos[base + p] = tmp[p]; }
+  }
 }
 
 // ------------------------------------------------------------------------------------ a3
@@ -491,6 +735,37 @@ extern "C" int lra_ctx_load_global_index(lra_ctx* ctx, const uint64_t* h_key, co
   return LRA_OK;
 }
 
+static int launch_sort(lra_ctx* ctx, int n_reads, const uint64_t* mm_off, uint64_t* mm_key, uint32_t* mm_pos) {
+  hipStream_t st = ctx->stream;
+  const int nb = (n_reads + 63) / 64;
+  const int cap = SORT_CAP;
+  const int maxseg = cap / 16 + 8;
+  const size_t lds = (size_t)cap * 16 + (size_t)maxseg * 20 + 8 + (size_t)(cap / 32 + 2) * 4;
+  const int grid = n_reads < ctx->num_cu ? n_reads : ctx->num_cu;
+  uint32_t* tscr = (uint32_t*)lra_scratch(ctx, 0, (size_t)grid * (cap + 64) * 4 + (size_t)n_reads * 4);
+  if (!tscr) return LRA_ERR_NOMEM;
+  int* flags = (int*)(tscr + (size_t)grid * (cap + 64));
+  LRA_HIP_CHECK(ctx, hipMemsetAsync(flags, 0, (size_t)n_reads * 4, st));
+  LRA_HIP_CHECK(ctx, hipFuncSetAttribute((const void*)sort_wg_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  lra_time_begin(ctx, "sort");
+  hipLaunchKernelGGL(sort_wg_kernel, dim3(grid), dim3(SORT_NT), lds, st, n_reads, mm_off, mm_key, mm_pos, tscr, cap, flags);
+  lra_time_end(ctx);
+  lra_time_begin(ctx, "sort_fallback");
+  hipLaunchKernelGGL(sort_kernel, dim3(nb), dim3(64), 0, st, n_reads, mm_off, mm_key, mm_pos, (const int*)flags);
+  lra_time_end(ctx);
+  return LRA_OK;
+}
+
+extern "C" int lra_sort_minimizers_batch(lra_ctx* ctx, int n_lists, const uint64_t* d_off, uint64_t* d_key, uint32_t* d_pos) {
+  if (!ctx || n_lists < 0) return LRA_ERR_INVALID;
+  if (n_lists == 0) return LRA_OK;
+  LRA_HIP_CHECK(ctx, hipSetDevice(ctx->device));
+  int rc = launch_sort(ctx, n_lists, d_off, d_key, d_pos);
+  if (rc) return rc;
+  LRA_HIP_CHECK(ctx, hipGetLastError());
+  return LRA_OK;
+}
+
 extern "C" int lra_seed_batch(lra_ctx* ctx, int n_reads, const char* d_seq, const uint64_t* d_read_off, int k, int w,
                               int max_freq, lra_seed_result* out) {
   if (!ctx || !out || n_reads < 0) return LRA_ERR_INVALID;
@@ -533,9 +808,7 @@ extern "C" int lra_seed_batch(lra_ctx* ctx, int n_reads, const char* d_seq, cons
                      (uint32_t*)nullptr);
   lra_time_end(ctx);
   // ---- a2
-  lra_time_begin(ctx, "sort");
-  hipLaunchKernelGGL(sort_kernel, dim3(nb), dim3(64), 0, st, n_reads, s->mm_off, s->mm_key, s->mm_pos);
-  lra_time_end(ctx);
+  { int rc = launch_sort(ctx, n_reads, s->mm_off, s->mm_key, s->mm_pos); if (rc) return rc; }
   // ---- a3
   if (total_mm) {
     lra_time_begin(ctx, "index_bounds");

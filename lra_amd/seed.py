@@ -61,3 +61,21 @@ def fetch(ctx: Context, res: SeedResult):
         "sep_qpos": ctx.to_host(res.d_sep_qpos, res.n_matches, np.uint32),
         "sep_tpos": ctx.to_host(res.d_sep_tpos, res.n_matches, np.uint32),
     }
+
+
+def sort_minimizers_batch(ctx: Context, keys_list, pos_list):
+    """a2 alone (std::sort emulation) on a list of (keys uint64, pos uint32) arrays; returns sorted copies."""
+    n = len(keys_list)
+    lens = np.array([len(k) for k in keys_list], dtype=np.int64)
+    off = np.zeros(n + 1, dtype=np.int64)
+    off[1:] = np.cumsum(lens)
+    K = np.concatenate([np.asarray(k, dtype=np.uint64) for k in keys_list] + [np.zeros(1, np.uint64)])
+    P = np.concatenate([np.asarray(p, dtype=np.uint32) for p in pos_list] + [np.zeros(1, np.uint32)])
+    dk = torch.from_numpy(K.view(np.int64)).to(ctx.device)
+    dp = torch.from_numpy(P.view(np.int32)).to(ctx.device)
+    do = torch.from_numpy(off).to(ctx.device)
+    ctx.check(ctx.lib.lra_sort_minimizers_batch(ctx.h, n, ptr(do), ptr(dk), ptr(dp)))
+    torch.cuda.synchronize(ctx.device)
+    K2 = dk.cpu().numpy().view(np.uint64)
+    P2 = dp.cpu().numpy().view(np.uint32)
+    return [(K2[off[i]:off[i + 1]].copy(), P2[off[i]:off[i + 1]].copy()) for i in range(n)]

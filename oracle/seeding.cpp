@@ -195,3 +195,26 @@ extern "C" long oracle_separate_strand(const char* read, const char* genome, int
   }
   return nf;
 }
+
+// ---- test input generator: McIlroy's "antiquicksort" adversary run against libstdc++'s
+// std::sort, yielding a key assignment that drives introsort to its depth limit (so the
+// heap-sort fall-back is exercised).  vals_out[i] = key of element i.
+namespace {
+struct Adversary {
+  std::vector<int> val; int gas, nsolid = 0, candidate = 0;
+  bool less(int x, int y) {
+    if (val[x] == gas && val[y] == gas) { if (x == candidate) val[x] = nsolid++; else val[y] = nsolid++; }
+    if (val[x] == gas) candidate = x; else if (val[y] == gas) candidate = y;
+    return val[x] < val[y];
+  }
+};
+}
+extern "C" void oracle_antiqsort(int n, uint64_t* vals_out) {
+  Adversary a;
+  a.gas = n;
+  a.val.assign(n, n);
+  std::vector<int> ptr(n);
+  for (int i = 0; i < n; i++) ptr[i] = i;
+  std::sort(ptr.begin(), ptr.end(), [&](int x, int y) { return a.less(x, y); });
+  for (int i = 0; i < n; i++) vals_out[i] = (uint64_t)a.val[i];
+}

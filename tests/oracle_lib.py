@@ -107,3 +107,10 @@ def indel_refine(blocks, q_seq: bytes, t_seq: bytes, refine_band, match, mismatc
                               indel, 1 if end_align else 0, _p(out, C.c_int), C.c_long(cap), C.byref(st))
     assert m <= cap, (m, cap)
     return out[:3 * m].reshape(m, 3).copy(), st.value
+
+
+def antiqsort_keys(n):
+    L = lib()
+    out = np.zeros(n, dtype=np.uint64)
+    L.oracle_antiqsort(n, _p(out, C.c_uint64))
+    return out

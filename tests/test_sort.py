@@ -1,0 +1,40 @@
+"""a2: the device std::sort emulation must reproduce libstdc++'s permutation exactly (ties included)."""
+import numpy as np
+import pytest
+
+
+def _cases():
+    rng = np.random.default_rng(17)
+    cs = []
+    for n in [0, 1, 2, 3, 15, 16, 17, 18, 33, 64, 65, 100, 257, 1000, 4097, 6000, 8999, 9000, 9001, 12000]:
+        for ks in [2, 5, 50, 1 << 40]:
+            k = rng.integers(0, ks, size=n).astype(np.uint64)
+            k |= (rng.integers(0, 2, size=n).astype(np.uint64) << np.uint64(63))     # strand flag: ignored by the comparison
+            cs.append(k)
+    for n in [500, 6000]:
+        cs.append(np.arange(n, dtype=np.uint64))                      # sorted
+        cs.append(np.arange(n, dtype=np.uint64)[::-1].copy())         # reversed
+        cs.append(np.zeros(n, dtype=np.uint64))                       # all equal
+        cs.append(np.concatenate([np.arange(n // 2), np.arange(n // 2)[::-1]]).astype(np.uint64))   # organ pipe
+    return cs
+
+
+def test_oracle_sort_is_std_sort_and_adversary_hits_depth_limit(oracle):
+    k = oracle.antiqsort_keys(5000)
+    assert k.max() <= 5000 and len(np.unique(k)) > 4000
+    sk, sp = oracle.sort_minimizers(k, np.arange(5000, dtype=np.uint32))
+    assert np.all(np.diff(sk.astype(np.int64)) >= 0) and sorted(sp.tolist()) == list(range(5000))
+
+
+@pytest.mark.gpu
+def test_hip_sort_matches_std_sort(ctx, oracle):
+    from lra_amd import seed
+    cs = _cases()
+    for n in [300, 3000, 7000]:
+        cs.append(oracle.antiqsort_keys(n))                           # forces the heap-sort fall-back
+    pos = [np.arange(len(k), dtype=np.uint32) for k in cs]
+    got = seed.sort_minimizers_batch(ctx, cs, pos)
+    for i, (k, p) in enumerate(zip(cs, pos)):
+        ek, ep = oracle.sort_minimizers(k, p)
+        assert np.array_equal(got[i][0], ek), (i, len(k))
+        assert np.array_equal(got[i][1], ep), (i, len(k))
