@@ -25,74 +25,64 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 
-def build_workload(args, rank):
-    from lra_amd import synth
+def build_workload(args, rank, device):
+    """Everything is generated on the GPU with bulk tensor ops (seconds), seeded per rank."""
+    import torch
+    from lra_amd import synth_torch as st
     t0 = time.time()
-    genome = synth.make_genome(int(args.genome_mb * 1e6), seed=1, repeat_frac=0.25)
-    idx_key, idx_pos = synth.build_global_index(genome, args.k, args.w, 150)
-    rng = np.random.default_rng(1000 + rank)                 # each rank owns its own shard of reads
-    reads, truth = [], []
-    for _ in range(args.reads):
-        L = int(max(1000, rng.normal(args.read_len, args.read_len / 10)))
-        r, b = synth.simulate_read_with_blocks(rng, genome, L, args.err, (30, 35, 35))
-        reads.append(r)
-        truth.append(b)
-    # a12 problems: gaps between consecutive anchors (true blocks >= 12 bp)
-    aq, at, ak = [], [], []
-    gbytes = genome
-    for r, b in zip(reads, truth):
-        anc = b[b[:, 2] >= 12]
-        for i in range(len(anc) - 1):
-            qs, qe = anc[i, 0] + anc[i, 2], anc[i + 1, 0]
-            ts, te = anc[i, 1] + anc[i, 2], anc[i + 1, 1]
-            if qe - qs <= 0 and te - ts <= 0:
-                continue
-            aq.append(r[qs:qe].tobytes()); at.append(gbytes[ts:te].tobytes())
-            ak.append(min(abs(int(qe - qs) - int(te - ts)) * 2 + 1, 15))   # LocalRefineAlignment.h:101-115
-    # a14 input: truth blocks with some removed / trimmed (what seed extension hands over)
-    rblocks = []
-    for b in truth:
-        keep = rng.random(len(b)) > 0.15
-        keep[0] = keep[-1] = True
-        bb = b[keep].copy()
-        trim = (bb[:, 2] > 6) & (rng.random(len(bb)) < 0.3)
-        a = rng.integers(0, 3, size=len(bb)) * trim
-        z = rng.integers(0, 3, size=len(bb)) * trim
-        bb[:, 0] += a; bb[:, 1] += a; bb[:, 2] -= (a + z)
-        rblocks.append(bb[bb[:, 2] > 0])
-    return dict(genome=genome, idx_key=idx_key, idx_pos=idx_pos, reads=reads, truth=truth, aq=aq, at=at, ak=ak,
-                rblocks=rblocks, gen_s=time.time() - t0)
+    genome = st.make_genome(int(args.genome_mb * 1e6), 1, device)
+    idx_key, idx_pos = st.build_global_index(genome, args.k, args.w, 150)
+    sim = st.simulate_batch(genome, args.reads, args.read_len, args.read_len / 10, args.err, (30, 35, 35), 1000 + rank)
+    pad = torch.zeros(64, dtype=torch.uint8, device=device)
+    strands = torch.cat([sim["seq"], pad])                                   # the strand every alignment lies on
+    g2 = torch.Generator(device=device).manual_seed(77 + rank)
+    rev = torch.rand(args.reads, generator=g2, device=device) < 0.5
+    reads = torch.cat([st.revcomp_some(sim["seq"], sim["off"], rev), pad])   # what the sequencer gave us (half reverse strand)
+    gaps = st.gap_problems(sim)
+    rblocks, rboff = st.perturbed_blocks(sim, 5 + rank)
+    torch.cuda.synchronize()
+    return dict(genome=genome, idx_key=idx_key, idx_pos=idx_pos, sim=sim, strands=strands, reads=reads, gaps=gaps,
+                rblocks=rblocks, rboff=rboff, gen_s=time.time() - t0)
 
 
-def cpu_baseline(wl, args, budget_s=20.0):
+def cpu_baseline(wl, args, budget_s=20.0, max_reads=64):
     """The oracle (CPU restatement) timed single-threaded on a bounded sample of the same workload."""
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import oracle_lib as O
     O.lib()
-    g = wl["genome"].tobytes() + b"\0" * 64
+    S = min(max_reads, args.reads)
+    sim = wl["sim"]
+    off = sim["off"][:S + 1].cpu().numpy()
+    reads = wl["reads"][:int(off[-1])].cpu().numpy()
+    strands = wl["strands"][:int(off[-1])].cpu().numpy()
+    g = wl["genome"].cpu().numpy().tobytes() + b"\0" * 64
+    gp = {k: v.cpu().numpy() for k, v in wl["gaps"].items()}
+    rb = wl["rblocks"].cpu().numpy(); rbo = wl["rboff"][:S + 1].cpu().numpy()
+    gsel = np.nonzero(gp["rid"] < S)[0]
+    gptr = 0
     t0 = time.time()
     bases = 0
     n = 0
-    gap_i = 0
-    for r, tb, rb in zip(wl["reads"], wl["truth"], wl["rblocks"]):
-        rbytes = r.tobytes()
+    for r in range(S):
+        rbytes = reads[off[r]:off[r + 1]].tobytes()
+        sbytes = strands[off[r]:off[r + 1]].tobytes()
         keys, pos = O.store_minimizers(rbytes, args.k, args.w)
         sk, sp = O.sort_minimizers(keys, pos)
         qi, ti = O.compare_lists(sk, sp, wl["idx_key"], wl["idx_pos"], args.max_freq)
         O.separate_strand(rbytes, g, args.k, sp[qi], wl["idx_pos"][ti])
-        anc = tb[tb[:, 2] >= 12]
-        for i in range(len(anc) - 1):
-            if gap_i < len(wl["aq"]):
-                O.affine_one_gap_align(wl["aq"][gap_i], wl["at"][gap_i], 4, -1, -2, wl["ak"][gap_i])
-                gap_i += 1
-        O.indel_refine(rb, rbytes, g, args.refine_band, 4, -1, -2)
-        bases += len(r)
+        while gptr < len(gsel) and gp["rid"][gsel[gptr]] == r:
+            i = gsel[gptr]
+            qo = int(gp["q_off"][i] - off[r]); to = int(gp["t_off"][i])
+            O.affine_one_gap_align(sbytes[qo:qo + int(gp["q_len"][i])], g[to:to + int(gp["t_len"][i])], 4, -1, -2, int(gp["k"][i]))
+            gptr += 1
+        O.indel_refine(rb[rbo[r]:rbo[r + 1]], sbytes, g, args.refine_band, 4, -1, -2)
+        bases += len(rbytes)
         n += 1
         if time.time() - t0 > budget_s:
             break
     dt = time.time() - t0
     return {"value": bases / dt / 1e9, "unit": "Gbp/s", "cores": 1, "kind": "port",
-            "sample": "%d reads (%d bp) of the same batch through the oracle's a1-a4, a12, a14 in %.1f s, 1 thread "
+            "sample": "first %d reads (%d bp) of the same batch through the oracle's a1-a4, a12, a14 in %.1f s, 1 thread "
                       "(python ctypes call overhead included)" % (n, bases, dt)}
 
 
@@ -102,7 +92,7 @@ def main():
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--genome-mb", type=float, default=float(os.environ.get("LRA_BENCH_GENOME_MB", 64)))
-    ap.add_argument("--reads", type=int, default=int(os.environ.get("LRA_BENCH_READS", 1024)), help="reads per GPU per step")
+    ap.add_argument("--reads", type=int, default=int(os.environ.get("LRA_BENCH_READS", 8192)), help="reads per GPU per step")
     ap.add_argument("--read-len", type=int, default=30000)
     ap.add_argument("--err", type=float, default=0.10)
     ap.add_argument("--k", type=int, default=17)          # -ONT: globalK 17, globalW 10 (lra.cpp:386-431)
@@ -127,16 +117,22 @@ def main():
     from lra_amd.context import Context
     from lra_amd import seed, align, refine, parallel
 
-    wl = build_workload(args, rank)
     ctx = Context(dev_index)
-    seed.load_reference(ctx, wl["genome"], wl["idx_key"], wl["idx_pos"])
-    rbatch = seed.ReadBatch(ctx, [r.tobytes() for r in wl["reads"]])
-    abatch = align.AogBatch(ctx, wl["aq"], wl["at"], wl["ak"], 4, -1, -2)       # -ONT localMatch/Mismatch/Indel
-    gdev = torch.from_numpy(np.concatenate([wl["genome"], np.zeros(64, np.uint8)])).to(ctx.device)
-    lens = np.array([len(r) for r in wl["reads"]], dtype=np.int64)
-    fbatch = refine.RefineBatch(ctx, wl["rblocks"], rbatch.seq, rbatch.off_h[:-1], lens.astype(np.int32), gdev,
-                                np.zeros(len(lens), np.int64), np.full(len(lens), len(wl["genome"]), np.int64))
+    wl = build_workload(args, rank, ctx.device)
+    seed.load_reference(ctx, wl["genome"].cpu().numpy(), wl["idx_key"], wl["idx_pos"])
+    sim = wl["sim"]
+    rbatch = seed.read_batch_from_device(ctx, wl["reads"], sim["off"])
+    gp = wl["gaps"]
+    gdev = torch.cat([wl["genome"], torch.zeros(64, dtype=torch.uint8, device=ctx.device)])
+    abatch = align.AogBatch.from_device(ctx, wl["strands"], gdev, gp["q_off"], gp["q_len"], gp["t_off"], gp["t_len"], gp["k"], 4, -1, -2)   # -ONT scores
+    lens = (sim["off"][1:] - sim["off"][:-1])
+    nR = args.reads
+    fbatch = refine.refine_batch_from_device(ctx, wl["rblocks"], wl["rboff"], wl["strands"], sim["off"][:-1], lens,
+                                             gdev, torch.zeros(nR, dtype=torch.int64, device=ctx.device),
+                                             torch.full((nR,), int(wl["genome"].numel()), dtype=torch.int64, device=ctx.device))
     total_bases = int(lens.sum())
+    n_gap_bytes = int(gp["q_len"].sum() + gp["t_len"].sum())
+    n_gaps = int(gp["k"].numel())
 
     stats = {}
 
@@ -177,7 +173,7 @@ def main():
         job_bases = total_bases
         nreads = args.reads
 
-    kernels = ["sketch_count", "sketch_emit", "sort", "index_bounds", "compare_count", "compare_emit", "strand",
+    kernels = ["sketch_count", "sketch_serial", "sketch_emit", "sort", "sort_fallback", "index_bounds", "compare", "strand",
                "aog_lds_small", "aog_lds_large", "aog_hbm", "ir_segment", "ir_band", "ir_fill", "ir_trace_count", "ir_trace_emit"]
     ktimes = {k: ctx.timing_get(k) for k in kernels}
     ctx.timing(False)
@@ -196,11 +192,11 @@ def main():
             "ir_trace_emit": 1 * stats["n_cells"] + 12 * stats["n_rows"] + 12 * stats["n_blocks"],
             "sort": 2 * 12 * stats["n_mm"],
             "index_bounds": stats["n_mm"] * (12 + 64 + 8),
-            "compare_count": stats["n_mm"] * (8 + 8 + 64),
-            "compare_emit": stats["n_mm"] * (8 + 8 + 64) + 8 * stats["n_match"],
+            "compare": stats["n_mm"] * (8 + 8 + 64) + 8 * stats["n_match"],
             "sketch_count": L, "sketch_emit": L + 12 * stats["n_mm"],
             "strand": stats["n_match"] * (8 + 8 + 2 * args.k),
-            "aog_lds_small": sum(len(a) + len(b) for a, b in zip(wl["aq"], wl["at"])) + 12 * len(wl["aq"]),
+            "aog_lds_small": n_gap_bytes + 12 * n_gaps,
+            "ir_segment": 12 * stats["n_blocks"],
         }.get(dom, 0)
         achieved = alg / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
         out = {

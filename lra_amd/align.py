@@ -43,17 +43,39 @@ class AogBatch:
         self.status = torch.empty(n, dtype=torch.int32, device=dev)
         self.blocks = torch.empty(max(1, int(boff[-1])) * 3, dtype=torch.int32, device=dev)
 
+    @classmethod
+    def from_device(cls, ctx, qseq, tseq, q_off, q_len, t_off, t_len, k, m, mm, indel):
+        """Problems described by device tensors: offsets into the device buffers qseq / tseq."""
+        self = cls.__new__(cls)
+        self.ctx, self.n, self.m, self.mm, self.indel = ctx, int(q_off.numel()), m, mm, indel
+        self.seq, self.tseq = qseq, tseq
+        self.q_off, self.t_off = q_off.to(torch.int64).contiguous(), t_off.to(torch.int64).contiguous()
+        self.q_len, self.t_len = q_len.to(torch.int32).contiguous(), t_len.to(torch.int32).contiguous()
+        self.k = k.to(torch.int32).contiguous()
+        cap = torch.minimum(self.q_len, self.t_len).to(torch.int64) + 1
+        boff = torch.zeros(self.n + 1, dtype=torch.int64, device=ctx.device)
+        boff[1:] = torch.cumsum(cap, 0)
+        self.block_off = boff
+        self.block_off_h = None
+        self.score = torch.empty(self.n, dtype=torch.int32, device=ctx.device)
+        self.nblocks = torch.empty(self.n, dtype=torch.int32, device=ctx.device)
+        self.status = torch.empty(self.n, dtype=torch.int32, device=ctx.device)
+        self.blocks = torch.empty(max(1, int(boff[-1])) * 3, dtype=torch.int32, device=ctx.device)
+        return self
+
     def run(self):
         """Launch the batch on the context's stream (asynchronous)."""
         c = self.ctx
         c.check(c.lib.lra_affine_one_gap_align_batch(
-            c.h, self.n, ptr(self.seq), ptr(self.seq), ptr(self.q_off), ptr(self.q_len), ptr(self.t_off), ptr(self.t_len),
+            c.h, self.n, ptr(self.seq), ptr(getattr(self, "tseq", self.seq)), ptr(self.q_off), ptr(self.q_len), ptr(self.t_off), ptr(self.t_len),
             ptr(self.k), self.m, self.mm, self.indel, ptr(self.score), ptr(self.nblocks), ptr(self.blocks),
             ptr(self.block_off), ptr(self.status)))
 
     def results(self):
         """Synchronise and return (scores, list of (nb,3) block arrays, status) on the host."""
         torch.cuda.synchronize(self.ctx.device)
+        if self.block_off_h is None:
+            self.block_off_h = self.block_off.cpu().numpy()
         score = self.score.cpu().numpy()
         nb = self.nblocks.cpu().numpy()
         st = self.status.cpu().numpy()

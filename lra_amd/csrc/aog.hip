@@ -354,18 +354,30 @@ __device__ __forceinline__ bool load_problem(const BatchArgs& a, int p, Problem&
 }
 
 __global__ void aog_classify(BatchArgs a) {
-  int p = blockIdx.x * blockDim.x + threadIdx.x;
-  if (p >= a.n) return;
-  Problem pr; Geo g; int ok;
-  if (!load_problem(a, p, pr, g, ok)) {
-    a.score[p] = 0; a.nblocks[p] = 0; a.status[p] = LRA_ST_RANGE;
-    return;
+  const int p = blockIdx.x * blockDim.x + threadIdx.x;
+  const int lane = threadIdx.x & 63;
+  int cls = -1;
+  if (p < a.n) {
+    Problem pr; Geo g; int ok;
+    if (!load_problem(a, p, pr, g, ok)) {
+      a.score[p] = 0; a.nblocks[p] = 0; a.status[p] = LRA_ST_RANGE;
+    } else {
+      long need = need_bytes(g);
+      cls = need <= CLASS_A_BYTES ? 0 : need <= CLASS_B_BYTES ? 1 : 2;
+      if (cls == 2 && need > a.gslot_bytes) { a.score[p] = 0; a.nblocks[p] = 0; a.status[p] = LRA_ST_RANGE; cls = -1; }
+    }
   }
-  long need = need_bytes(g);
-  int cls = need <= CLASS_A_BYTES ? 0 : need <= CLASS_B_BYTES ? 1 : 2;
-  if (cls == 2 && need > a.gslot_bytes) { a.score[p] = 0; a.nblocks[p] = 0; a.status[p] = LRA_ST_RANGE; return; }
-  int pos = atomicAdd(&a.counts[cls], 1);
-  a.lists[(long)cls * a.n + pos] = p;
+  // one atomic per wave and class
+  const unsigned long long below = (lane == 0) ? 0ULL : (~0ULL >> (64 - lane));
+  for (int c = 0; c < 3; c++) {
+    const unsigned long long m = __ballot(cls == c);
+    if (!m) continue;
+    int base = 0;
+    const int leader = __ffsll((long long)m) - 1;
+    if (lane == leader) base = atomicAdd(&a.counts[c], __popcll(m));
+    base = __shfl(base, leader);
+    if (cls == c) a.lists[(long)c * a.n + base + __popcll(m & below)] = p;
+  }
 }
 
 template <int CLS>

@@ -55,12 +55,14 @@ template <bool EMIT>
 __global__ void __launch_bounds__(64) sketch_kernel(int n_reads, const unsigned char* __restrict__ seq_all,
                                                     const uint64_t* __restrict__ read_off, int k, int w,
                                                     const uint64_t* __restrict__ mm_off, uint64_t* __restrict__ mm_key,
-                                                    uint32_t* __restrict__ mm_pos, uint32_t* __restrict__ counts) {
+                                                    uint32_t* __restrict__ mm_pos, uint32_t* __restrict__ counts,
+                                                    const int* __restrict__ only_flagged) {
   __shared__ uint64_t ringT[MAX_W * 64];
   __shared__ uint32_t ringP[MAX_W * 64];
   const int lane = threadIdx.x;
   const int r = blockIdx.x * 64 + lane;
   if (r >= n_reads) return;
+  if (only_flagged && !only_flagged[r]) return;
   const unsigned char* seq = seq_all + read_off[r];
   const uint32_t seqLen = (uint32_t)(read_off[r + 1] - read_off[r]);
   uint64_t* okey = EMIT ? mm_key + mm_off[r] : nullptr;
@@ -139,6 +141,150 @@ __global__ void __launch_bounds__(64) sketch_kernel(int n_reads, const unsigned 
   SK_DONE();
 #undef SK_EMIT
 #undef SK_DONE
+}
+
+// ---- a1, fast path: one WAVE per read (reads without non-ACGT bytes; the others are flagged
+// for the serial kernel above).  64 positions per tile:
+//   * 2-bit codes of the tile are packed with two ballots; every lane cuts its own k-mer out of
+//     the packed words and derives forward / reverse-complement keys with bit tricks;
+//   * the serial state of MinCount.h is only "which position is the active minimizer".  After
+//     position 2w-1 the active one is always a minimum (by masked key) of the current window
+//     (every element that entered after the first window was compared against it on entry), so
+//       act(p) = p                      if key[p] <  min of the previous window
+//              = ring-order argmin(p)   if act(p-1) just left the window      (:148-154)
+//              = act(p-1)               otherwise,
+//     and a tuple is emitted in the first two cases (:155-172).  Wherever the window minimum is
+//     unique act(p) is that position regardless of history, so lanes resolve independently and
+//     only lanes inside a run of tied minima are walked in order;
+//   * positions below 2w (first window chosen with the UNMASKED comparison, :91) are replayed
+//     literally by the whole wave on uniform values.
+__device__ __forceinline__ uint64_t spread32(uint64_t x) {
+  x = (x | (x << 16)) & 0x0000FFFF0000FFFFULL;
+  x = (x | (x << 8)) & 0x00FF00FF00FF00FFULL;
+  x = (x | (x << 4)) & 0x0F0F0F0F0F0F0F0FULL;
+  x = (x | (x << 2)) & 0x3333333333333333ULL;
+  x = (x | (x << 1)) & 0x5555555555555555ULL;
+  return x;
+}
+
+template <bool EMIT>
+__global__ void __launch_bounds__(64) sketch_wave_kernel(int n_reads, const unsigned char* __restrict__ seq_all,
+                                                         const uint64_t* __restrict__ read_off, int k, int w,
+                                                         const uint64_t* __restrict__ mm_off, uint64_t* __restrict__ mm_key,
+                                                         uint32_t* __restrict__ mm_pos, uint32_t* __restrict__ counts, int* flagN) {
+  __shared__ uint64_t kbuf[128];
+  const int lane = threadIdx.x;
+  const uint64_t kbits = (k >= 32) ? 0xFFFFFFFFULL : ((1ULL << k) - 1);
+  const uint64_t mask2k = (k >= 32) ? ~0ULL : ((1ULL << (2 * k)) - 1);
+  const unsigned long long below = (lane == 0) ? 0ULL : (~0ULL >> (64 - lane));
+  for (int r = blockIdx.x; r < n_reads; r += gridDim.x) {
+    if (EMIT && flagN[r]) continue;
+    const unsigned char* seq = seq_all + read_off[r];
+    const uint32_t seqLen = (uint32_t)(read_off[r + 1] - read_off[r]);
+    uint64_t* okey = EMIT ? mm_key + mm_off[r] : nullptr;
+    uint32_t* opos = EMIT ? mm_pos + mm_off[r] : nullptr;
+    uint32_t nout = 0;
+    const int span = w + k - 1;
+    if (seqLen < (uint32_t)k || seqLen <= (uint32_t)span) { if (!EMIT && lane == 0) { counts[r] = 0; flagN[r] = 0; } continue; }   // :12,:26-27
+    const uint32_t nk = seqLen - k + 1;
+    const uint32_t P0 = min((uint32_t)(2 * w), nk);
+    bool hasN = false;
+    uint64_t carry_m = 0; uint32_t carry_act = 0;
+    for (uint32_t B = 0; B < nk; B += 64) {
+      // ---- keys of positions B..B+63
+      const uint32_t p = B + lane;
+      int c0 = 0, c1 = 0;
+      if (p < seqLen) { int c = code_n(seq[p]); hasN |= c > 3; c0 = c & 3; }
+      if (lane < k - 1 && p + 64 < seqLen) { int c = code_n(seq[p + 64]); hasN |= c > 3; c1 = c > 3 ? 0 : c; }
+      const unsigned long long b0 = __ballot(c0 & 1), b1 = __ballot(c0 & 2), t0 = __ballot(c1 & 1), t1 = __ballot(c1 & 2);
+      uint64_t x0 = b0 >> lane, x1 = b1 >> lane;
+      if (lane) { x0 |= t0 << (64 - lane); x1 |= t1 << (64 - lane); }
+      x0 &= kbits; x1 &= kbits;
+      const uint64_t LE = spread32(x0) | (spread32(x1) << 1);
+      const uint64_t rc = (~LE) & mask2k;
+      uint64_t v = __brevll(LE);
+      v = ((v >> 1) & 0x5555555555555555ULL) | ((v & 0x5555555555555555ULL) << 1);
+      const uint64_t fwd = (k >= 32) ? v : (v >> (64 - 2 * k));
+      const uint64_t key = ((fwd & FOR_MASK) < (rc & FOR_MASK)) ? (fwd & FOR_MASK) : (rc | REV_MASK);   // :60-61
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+      kbuf[p & 127] = key;
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+      __builtin_amdgcn_wave_barrier();
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+      if (B == 0) {
+        // ---- literal replay of positions 0..P0-1 on uniform values (all lanes identical)
+        uint64_t actT = kbuf[0]; uint32_t actP = 0;
+        for (uint32_t q = 1; q < (uint32_t)w && q < nk; q++) { uint64_t c = kbuf[q]; if (c < actT) { actT = c; actP = q; } }   // :77-96
+        if (lane == 0 && EMIT) { okey[nout] = actT; opos[nout] = actP; }                                                       // :100-102
+        nout++;
+        for (uint32_t q = w; q < P0; q++) {                                                                                  // :105-178
+          const uint64_t c = kbuf[q];
+          bool em = false;
+          if (q - w >= actP) {
+            // ring slot j holds the newest position == j (mod w)
+            uint64_t bt = 0; uint32_t bp = 0;
+            for (int j = 0; j < w; j++) {
+              uint32_t x = q - ((q - (uint32_t)j) % (uint32_t)w);
+              uint64_t t = kbuf[x];
+              if (j == 0 || (t & FOR_MASK) < (bt & FOR_MASK)) { bt = t; bp = x; }
+            }
+            actT = bt; actP = bp; em = true;
+          } else if ((c & FOR_MASK) < (actT & FOR_MASK)) { actT = c; actP = q; em = true; }
+          if (em) { if (lane == 0 && EMIT) { okey[nout] = actT; opos[nout] = actP; } nout++; }
+        }
+        carry_m = actT & FOR_MASK; carry_act = actP;
+      }
+      // ---- positions >= P0 of this tile, in parallel
+      const bool live = p >= P0 && p < nk;
+      uint64_t bk = key & FOR_MASK; uint32_t bpos = p; int br = (int)(p % (uint32_t)w), cnt = 1;
+      if (live) {
+        int rx = br;
+        for (int d = 1; d < w; d++) {
+          rx = (rx == 0) ? w - 1 : rx - 1;
+          const uint32_t x = p - d;
+          const uint64_t kx = kbuf[x & 127] & FOR_MASK;
+          if (kx < bk) { bk = kx; bpos = x; br = rx; cnt = 1; }
+          else if (kx == bk) { cnt++; if (rx < br) { br = rx; bpos = x; } }
+        }
+      }
+      // min of the previous window = lane-1's window min (lane 0: carried over)
+      uint64_t mprev = __shfl_up(bk, 1);
+      const bool prevLive = lane > 0 && (p - 1) >= P0;
+      if (!prevLive) mprev = carry_m;           // first live lane of the read, or lane 0 of a later tile
+      const bool strictNew = live && (key & FOR_MASK) < mprev;
+      uint32_t A = (cnt == 1 || strictNew) ? (strictNew ? p : bpos) : 0xFFFFFFFFu;
+      // resolve lanes whose window minimum is tied, in order
+      unsigned long long unk = __ballot(live && A == 0xFFFFFFFFu);
+      while (unk) {
+        const int l = __ffsll((long long)unk) - 1;
+        unk &= unk - 1;
+        uint32_t pa = __shfl(A, (l + 63) & 63);
+        const uint32_t pl = B + l;
+        if (l == 0 || pl - 1 < P0) pa = carry_act;
+        const uint32_t posR = __shfl(bpos, l);
+        const uint32_t a = (pa == pl - w) ? posR : pa;
+        if (lane == l) A = a;
+      }
+      uint32_t prevA = __shfl_up(A, 1);
+      if (!prevLive) prevA = carry_act;
+      const bool em = live && (prevA == p - (uint32_t)w || strictNew);
+      const unsigned long long me = __ballot(em);
+      if (EMIT && em) {
+        const uint32_t o = nout + __popcll(me & below);
+        okey[o] = kbuf[A & 127]; opos[o] = A;
+      }
+      nout += __popcll(me);
+      // carries: state after the last live position of this tile
+      const unsigned long long ml = __ballot(live);
+      if (ml) {
+        const int last = 63 - __clzll((long long)ml);
+        carry_m = __shfl(bk, last); carry_act = __shfl(A, last);
+      }
+      __builtin_amdgcn_wave_barrier();
+    }
+    const bool anyN = __ballot(hasN) != 0;
+    if (!EMIT && lane == 0) { counts[r] = nout; flagN[r] = anyN ? 1 : 0; }
+  }
 }
 
 // ------------------------------------------------------------------------------------ a2
@@ -522,8 +668,20 @@ __global__ void bounds_kernel(uint64_t total, const uint64_t* __restrict__ mm_ke
   ub[i] = (uint32_t)lo;
 }
 
+// per-read upper bound on emitted pairs: a (query tuple, index tuple) pair with equal keys can be
+// emitted by a front step, re-emitted once by the raw-key quirk (:101-102), and once by a back step
+__global__ void __launch_bounds__(64) match_capacity_kernel(int n_reads, const uint64_t* __restrict__ mm_off, const uint32_t* __restrict__ lb,
+                                                            const uint32_t* __restrict__ ub, uint64_t* __restrict__ cap) {
+  const int lane = threadIdx.x;
+  for (int r = blockIdx.x; r < n_reads; r += gridDim.x) {
+    uint64_t sum = 0;
+    for (uint64_t i = mm_off[r] + lane; i < mm_off[r + 1]; i += 64) sum += (uint64_t)(ub[i] - lb[i]);
+    for (int off = 32; off > 0; off >>= 1) sum += __shfl_xor(sum, off);
+    if (lane == 0) cap[r] = 3 * sum;
+  }
+}
+
 // (ii) the alternating two-ended walk of CompareLists.h:43-143, one lane per read.
-template <bool EMIT>
 __global__ void __launch_bounds__(64) compare_kernel(int n_reads, const uint64_t* __restrict__ mm_off, const uint64_t* __restrict__ mm_key,
                                                      const uint32_t* __restrict__ lbA, const uint32_t* __restrict__ ubA,
                                                      const uint64_t* __restrict__ idx_key, long n_idx, long maxFreq,
@@ -536,8 +694,10 @@ __global__ void __launch_bounds__(64) compare_kernel(int n_reads, const uint64_t
   const uint32_t* UB = ubA + mm_off[r];
   const long nq = (long)(mm_off[r + 1] - mm_off[r]);
   const long nt = n_idx;
-  uint32_t* oq = EMIT ? match_qi + match_off[r] : nullptr;
-  uint32_t* ot = EMIT ? match_ti + match_off[r] : nullptr;
+  constexpr bool EMIT = true;
+  uint32_t* oq = match_qi + match_off[r];
+  uint32_t* ot = match_ti + match_off[r];
+  const uint64_t room = match_off[r + 1] - match_off[r];
   uint64_t n = 0;
   const uint64_t M = FOR_MASK;
 #define Qm(i) (qk[(i)] & M)
@@ -563,7 +723,7 @@ __global__ void __launch_bounds__(64) compare_kernel(int n_reads, const uint64_t
           if (qs - (long)qsStart < maxFreq) {
             for (uint32_t ti = tsStart; ti != tsi; ti++)
               for (uint32_t qi = qsStart; (long)qi <= qs; qi++) {
-                if (EMIT) { oq[n] = qi; ot[n] = ti; }
+                if (EMIT && n < room) { oq[n] = qi; ot[n] = ti; }
                 n++;
               }
           }
@@ -588,7 +748,7 @@ __global__ void __launch_bounds__(64) compare_kernel(int n_reads, const uint64_t
           if ((long)qeStart - qe < maxFreq) {
             for (uint32_t ti = tei; ti < teStart; ti++)
               for (uint32_t qi = (uint32_t)qe; qi <= qeStart; qi++) {
-                if (EMIT) { oq[n] = qi; ot[n] = ti; }
+                if (EMIT && n < room) { oq[n] = qi; ot[n] = ti; }
                 n++;
               }
           }
@@ -599,7 +759,7 @@ __global__ void __launch_bounds__(64) compare_kernel(int n_reads, const uint64_t
   }
 #undef Qm
 #undef Tm
-  if (!EMIT) counts[r] = n;
+  counts[r] = n;
 }
 
 // ------------------------------------------------------------------------------------ a4
@@ -609,14 +769,20 @@ __global__ void __launch_bounds__(64) strand_kernel(int n_reads, const unsigned 
                                                     const unsigned char* __restrict__ genome, int k,
                                                     const uint64_t* __restrict__ mm_off, const uint32_t* __restrict__ mm_pos,
                                                     const uint32_t* __restrict__ idx_pos,
-                                                    const uint64_t* __restrict__ match_off, const uint32_t* __restrict__ match_qi,
-                                                    const uint32_t* __restrict__ match_ti, uint32_t* __restrict__ sep_qpos,
+                                                    const uint64_t* __restrict__ match_off, const uint64_t* __restrict__ src_off,
+                                                    const uint32_t* __restrict__ src_qi, const uint32_t* __restrict__ src_ti,
+                                                    uint32_t* __restrict__ match_qi, uint32_t* __restrict__ match_ti, uint32_t* __restrict__ sep_qpos,
                                                     uint32_t* __restrict__ sep_tpos, uint32_t* __restrict__ n_forward) {
   const int lane = threadIdx.x;
   for (int r = blockIdx.x; r < n_reads; r += gridDim.x) {
     const unsigned char* read = seq_all + read_off[r];
     const uint32_t* qpos_of = mm_pos + mm_off[r];
     const uint64_t m0 = match_off[r], m1 = match_off[r + 1];
+    // pass 0: compact the pairs out of the capacity-spaced walk buffer
+    for (uint64_t i = m0 + lane; i < m1; i += 64) { match_qi[i] = src_qi[src_off[r] + (i - m0)]; match_ti[i] = src_ti[src_off[r] + (i - m0)]; }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
     // pass 1: count forward matches
     uint64_t nf = 0;
     for (uint64_t base = m0; base < m1; base += 64) {
@@ -689,6 +855,7 @@ struct lra_seed_state {
   uint32_t* n_forward = nullptr; size_t cap_reads = 0;
   uint64_t* mm_key = nullptr; uint32_t* mm_pos = nullptr; uint32_t* lb = nullptr; uint32_t* ub = nullptr; size_t cap_mm = 0;
   uint32_t* match_qi = nullptr; uint32_t* match_ti = nullptr; uint32_t* sep_qpos = nullptr; uint32_t* sep_tpos = nullptr; size_t cap_match = 0;
+  uint32_t* tmp_qi = nullptr; uint32_t* tmp_ti = nullptr; size_t cap_tmp = 0; uint64_t* cap_cnt = nullptr; uint64_t* cap_off = nullptr;
 };
 
 static lra_seed_state* seed_state(lra_ctx* ctx) {
@@ -707,7 +874,7 @@ void lra_seed_free(lra_ctx* ctx) {
   lra_seed_state* s = ctx->seed;
   if (!s) return;
   void* ptrs[] = {s->genome, s->idx_key, s->idx_pos, s->counts32, s->counts64, s->mm_off, s->match_off, s->n_forward,
-                  s->mm_key, s->mm_pos, s->lb, s->ub, s->match_qi, s->match_ti, s->sep_qpos, s->sep_tpos};
+                  s->mm_key, s->mm_pos, s->lb, s->ub, s->match_qi, s->match_ti, s->sep_qpos, s->sep_tpos, s->tmp_qi, s->tmp_ti, s->cap_cnt, s->cap_off};
   for (void* p : ptrs) if (p) (void)hipFree(p);
   delete s;
   ctx->seed = nullptr;
@@ -781,16 +948,22 @@ extern "C" int lra_seed_batch(lra_ctx* ctx, int n_reads, const char* d_seq, cons
     LRA_HIP_CHECK(ctx, hipStreamSynchronize(st));
     size_t c = (size_t)n_reads + n_reads / 4 + 64;
     if (!regrow(s->counts32, c) || !regrow(s->counts64, c) || !regrow(s->mm_off, c + 1) || !regrow(s->match_off, c + 1) ||
-        !regrow(s->n_forward, c))
+        !regrow(s->n_forward, c) || !regrow(s->cap_cnt, c) || !regrow(s->cap_off, c + 1))
       return lra_set_err(ctx, LRA_ERR_NOMEM, "per-read arrays");
     s->cap_reads = c;
   }
   const unsigned char* seq = (const unsigned char*)d_seq;
   const int nb = (n_reads + 63) / 64;
   // ---- a1: count, scan, emit
+  const int gridW = n_reads < ctx->num_cu * 32 ? n_reads : ctx->num_cu * 32;
+  int* flagN = (int*)s->n_forward;   // reused before a4 writes it
   lra_time_begin(ctx, "sketch_count");
+  hipLaunchKernelGGL(sketch_wave_kernel<false>, dim3(gridW), dim3(64), 0, st, n_reads, seq, d_read_off, k, w, (const uint64_t*)nullptr,
+                     (uint64_t*)nullptr, (uint32_t*)nullptr, s->counts32, flagN);
+  lra_time_end(ctx);
+  lra_time_begin(ctx, "sketch_serial");
   hipLaunchKernelGGL(sketch_kernel<false>, dim3(nb), dim3(64), 0, st, n_reads, seq, d_read_off, k, w, (const uint64_t*)nullptr,
-                     (uint64_t*)nullptr, (uint32_t*)nullptr, s->counts32);
+                     (uint64_t*)nullptr, (uint32_t*)nullptr, s->counts32, (const int*)flagN);
   lra_time_end(ctx);
   hipLaunchKernelGGL(scan_kernel<uint32_t>, dim3(1), dim3(1024), 0, st, (long)n_reads, s->counts32, s->mm_off);
   uint64_t total_mm = 0;
@@ -804,8 +977,12 @@ extern "C" int lra_seed_batch(lra_ctx* ctx, int n_reads, const char* d_seq, cons
     s->cap_mm = c;
   }
   lra_time_begin(ctx, "sketch_emit");
+  hipLaunchKernelGGL(sketch_wave_kernel<true>, dim3(gridW), dim3(64), 0, st, n_reads, seq, d_read_off, k, w, s->mm_off, s->mm_key, s->mm_pos,
+                     (uint32_t*)nullptr, flagN);
+  lra_time_end(ctx);
+  lra_time_begin(ctx, "sketch_serial");
   hipLaunchKernelGGL(sketch_kernel<true>, dim3(nb), dim3(64), 0, st, n_reads, seq, d_read_off, k, w, s->mm_off, s->mm_key, s->mm_pos,
-                     (uint32_t*)nullptr);
+                     (uint32_t*)nullptr, (const int*)flagN);
   lra_time_end(ctx);
   // ---- a2
   { int rc = launch_sort(ctx, n_reads, s->mm_off, s->mm_key, s->mm_pos); if (rc) return rc; }
@@ -816,28 +993,35 @@ extern "C" int lra_seed_batch(lra_ctx* ctx, int n_reads, const char* d_seq, cons
                        s->lb, s->ub);
     lra_time_end(ctx);
   }
-  lra_time_begin(ctx, "compare_count");
-  hipLaunchKernelGGL(compare_kernel<false>, dim3(nb), dim3(64), 0, st, n_reads, s->mm_off, s->mm_key, s->lb, s->ub, s->idx_key,
-                     (long)s->n_idx, (long)max_freq, (const uint64_t*)nullptr, (uint32_t*)nullptr, (uint32_t*)nullptr, s->counts64);
+  hipLaunchKernelGGL(match_capacity_kernel, dim3(gridW), dim3(64), 0, st, n_reads, s->mm_off, s->lb, s->ub, s->cap_cnt);
+  hipLaunchKernelGGL(scan_kernel<uint64_t>, dim3(1), dim3(1024), 0, st, (long)n_reads, s->cap_cnt, s->cap_off);
+  uint64_t total_cap = 0;
+  LRA_HIP_CHECK(ctx, hipMemcpyAsync(&total_cap, s->cap_off + n_reads, 8, hipMemcpyDeviceToHost, st));
+  LRA_HIP_CHECK(ctx, hipStreamSynchronize(st));
+  if (total_cap > s->cap_tmp) {
+    size_t c = total_cap + total_cap / 4 + 1024;
+    if (!regrow(s->tmp_qi, c) || !regrow(s->tmp_ti, c)) return lra_set_err(ctx, LRA_ERR_NOMEM, "match walk buffers (%llu)", (unsigned long long)total_cap);
+    s->cap_tmp = c;
+  }
+  lra_time_begin(ctx, "compare");
+  hipLaunchKernelGGL(compare_kernel, dim3(nb), dim3(64), 0, st, n_reads, s->mm_off, s->mm_key, s->lb, s->ub, s->idx_key,
+                     (long)s->n_idx, (long)max_freq, s->cap_off, s->tmp_qi, s->tmp_ti, s->counts64);
   lra_time_end(ctx);
   hipLaunchKernelGGL(scan_kernel<uint64_t>, dim3(1), dim3(1024), 0, st, (long)n_reads, s->counts64, s->match_off);
   uint64_t total_m = 0;
   LRA_HIP_CHECK(ctx, hipMemcpyAsync(&total_m, s->match_off + n_reads, 8, hipMemcpyDeviceToHost, st));
   LRA_HIP_CHECK(ctx, hipStreamSynchronize(st));
+  if (total_m > total_cap) return lra_set_err(ctx, LRA_ERR_INVALID, "match capacity bound violated (%llu > %llu)", (unsigned long long)total_m, (unsigned long long)total_cap);
   if (total_m > s->cap_match) {
     size_t c = total_m + total_m / 4 + 1024;
     if (!regrow(s->match_qi, c) || !regrow(s->match_ti, c) || !regrow(s->sep_qpos, c) || !regrow(s->sep_tpos, c))
       return lra_set_err(ctx, LRA_ERR_NOMEM, "match arrays (%llu matches)", (unsigned long long)total_m);
     s->cap_match = c;
   }
-  lra_time_begin(ctx, "compare_emit");
-  hipLaunchKernelGGL(compare_kernel<true>, dim3(nb), dim3(64), 0, st, n_reads, s->mm_off, s->mm_key, s->lb, s->ub, s->idx_key,
-                     (long)s->n_idx, (long)max_freq, s->match_off, s->match_qi, s->match_ti, (uint64_t*)nullptr);
-  lra_time_end(ctx);
   // ---- a4
   lra_time_begin(ctx, "strand");
   hipLaunchKernelGGL(strand_kernel, dim3(n_reads < 4096 ? n_reads : 4096), dim3(64), 0, st, n_reads, seq, d_read_off, s->genome, k, s->mm_off,
-                     s->mm_pos, s->idx_pos, s->match_off, s->match_qi, s->match_ti, s->sep_qpos, s->sep_tpos, s->n_forward);
+                     s->mm_pos, s->idx_pos, s->match_off, s->cap_off, s->tmp_qi, s->tmp_ti, s->match_qi, s->match_ti, s->sep_qpos, s->sep_tpos, s->n_forward);
   lra_time_end(ctx);
   LRA_HIP_CHECK(ctx, hipGetLastError());
   out->n_minimizers = total_mm; out->n_matches = total_m;

@@ -35,6 +35,19 @@ class RefineBatch:
         self.t_len = torch.from_numpy(np.asarray(t_len, dtype=np.int64)).to(dev)
 
 
+def refine_batch_from_device(ctx, blocks, block_off, q_seq, q_off, q_len, t_seq, t_off, t_len):
+    """RefineBatch whose inputs already are device tensors (blocks int32 [nb,3], CSR offsets int64)."""
+    b = RefineBatch.__new__(RefineBatch)
+    b.ctx, b.n = ctx, int(block_off.numel()) - 1
+    b.n_blocks_in = int(blocks.shape[0])
+    b.blocks = blocks.to(torch.int32).contiguous().reshape(-1)
+    b.block_off = block_off.to(torch.int64).contiguous()
+    b.q_seq, b.t_seq = q_seq, t_seq
+    b.q_off, b.q_len = q_off.to(torch.int64).contiguous(), q_len.to(torch.int32).contiguous()
+    b.t_off, b.t_len = t_off.to(torch.int64).contiguous(), t_len.to(torch.int64).contiguous()
+    return b
+
+
 def indel_refine_batch(ctx: Context, b: RefineBatch, refine_band, match, mismatch, indel, end_align=False):
     res = RefineResult()
     ctx.check(ctx.lib.lra_indel_refine_batch(ctx.h, b.n, ptr(b.blocks), ptr(b.block_off), C.c_uint64(b.n_blocks_in), ptr(b.q_seq),

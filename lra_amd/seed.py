@@ -40,6 +40,16 @@ class ReadBatch:
         self.off_h = off
 
 
+def read_batch_from_device(ctx, seq, off):
+    """ReadBatch over device tensors (seq uint8 with >= 64 bytes of padding after the last read, off int64 [n+1])."""
+    b = ReadBatch.__new__(ReadBatch)
+    b.n = int(off.numel()) - 1
+    b.seq, b.off = seq, off.to(torch.int64).contiguous()
+    b.off_h = None
+    b.total_bases = int(off[-1])
+    return b
+
+
 def seed_batch(ctx: Context, batch: ReadBatch, k, w, max_freq):
     """Run a1-a4 on the batch; returns the SeedResult struct (device pointers owned by ctx)."""
     res = SeedResult()
