@@ -45,7 +45,7 @@ def build_workload(args, rank, device):
                 rblocks=rblocks, rboff=rboff, gen_s=time.time() - t0)
 
 
-def cpu_baseline(wl, args, budget_s=20.0, max_reads=64):
+def cpu_baseline(wl, args, budget_s=20.0, max_reads=768):
     """The oracle (CPU restatement) timed single-threaded on a bounded sample of the same workload."""
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import oracle_lib as O
