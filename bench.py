@@ -174,7 +174,7 @@ def main():
         nreads = args.reads
 
     kernels = ["sketch_count", "sketch_serial", "sketch_emit", "sort", "sort_fallback", "index_bounds", "compare", "strand",
-               "aog_lds_small", "aog_lds_large", "aog_hbm", "ir_segment", "ir_band", "ir_fill", "ir_trace_count", "ir_trace_emit"]
+               "aog_lds_tiny", "aog_lds_small", "aog_lds_large", "aog_hbm", "ir_segment", "ir_band", "ir_fill", "ir_trace", "ir_gather"]
     ktimes = {k: ctx.timing_get(k) for k in kernels}
     ctx.timing(False)
     if rank == 0:
@@ -186,16 +186,16 @@ def main():
         # algorithmic bytes per launch of the dominant kernel (DESIGN.md "kernels" gives the per-unit figures)
         L = total_bases
         alg = {
-            "ir_fill": 1 * stats["n_cells"] + 12 * stats["n_rows"] + 2 * stats["n_rows"],        # 1 B arrow/cell + row windows + both sequences
-            "ir_band": 12 * stats["n_rows"] + 12 * stats["n_blocks"],
-            "ir_trace_count": 1 * stats["n_cells"] + 12 * stats["n_rows"],
-            "ir_trace_emit": 1 * stats["n_cells"] + 12 * stats["n_rows"] + 12 * stats["n_blocks"],
+            "ir_fill": 1 * stats["n_cells"] + 16 * stats["n_rows"] + 1 * stats["n_rows"],        # 1 B arrow/cell + row windows + both sequences
+            "ir_band": 16 * stats["n_rows"] + 12 * stats["n_blocks"],
+            "ir_trace": 1 * stats["n_rows"] + 16 * stats["n_rows"] + 12 * stats["n_blocks"],   # ~1 arrow + 1 row record per row walked
             "sort": 2 * 12 * stats["n_mm"],
             "index_bounds": stats["n_mm"] * (12 + 64 + 8),
             "compare": stats["n_mm"] * (8 + 8 + 64) + 8 * stats["n_match"],
             "sketch_count": L, "sketch_emit": L + 12 * stats["n_mm"],
             "strand": stats["n_match"] * (8 + 8 + 2 * args.k),
             "aog_lds_small": n_gap_bytes + 12 * n_gaps,
+            "aog_lds_tiny": n_gap_bytes + 12 * n_gaps,
             "ir_segment": 12 * stats["n_blocks"],
         }.get(dom, 0)
         achieved = alg / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0

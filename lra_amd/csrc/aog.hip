@@ -33,6 +33,7 @@ enum { A_DONE = 0, A_LEFT = 1, A_DOWN = 2, A_DIAG = 3, A_BORDER = 4, A_GAPLEFT =
 
 constexpr int CLASS_A_BYTES = 10 * 1024;  // per wave, 4 waves per workgroup
 constexpr int CLASS_B_BYTES = 64 * 1024;  // per wave, 1 wave per workgroup
+constexpr int CLASS_S_BYTES = 2560;       // per 16-lane group: 4 problems per wave, 16 per workgroup (anti-diagonals <= 16 cells)
 
 __device__ __forceinline__ int code_n(unsigned char c) {  // SeqUtils.h:42-75 (seqMapN)
   if (c < 8) return c & 3;
@@ -48,7 +49,8 @@ __device__ __forceinline__ int code_n(unsigned char c) {  // SeqUtils.h:42-75 (s
 struct Geo {
   int qLen, tLen, diag, k, R, qB, tB;
   bool top;
-  int n;  // slots per matrix
+  int n;      // slots per matrix in the reference (bounds checks)
+  int nUsed;  // prefix-matrix slots that can ever be read back: rows j < tB when only the prefix band is used
 };
 
 __device__ __forceinline__ bool make_geo(int qLen, int tLen, int k0, Geo& g) {
@@ -62,8 +64,9 @@ __device__ __forceinline__ bool make_geo(int qLen, int tLen, int k0, Geo& g) {
   long n = (long)(3 + k + g.diag) * g.R;            // :210
   g.qB = min(g.diag + k, qLen + 1);                 // :309-310
   g.tB = min(g.diag + k, tLen + 1);
-  if (n > (1L << 28)) { g.n = 0; return false; }
+  if (n > (1L << 28)) { g.n = 0; g.nUsed = 0; return false; }
   g.n = (int)n;
+  g.nUsed = g.top ? g.n : min(g.n, g.tB * g.R);
   return true;
 }
 
@@ -71,8 +74,8 @@ __host__ __device__ __forceinline__ long align4(long x) { return (x + 3) & ~3L; 
 
 // bytes of working memory one problem needs (same carve order as carve())
 __device__ __forceinline__ long need_bytes(const Geo& g) {
-  long mats = g.top ? 2 : 1;
-  return mats * 4L * g.n + 16L * (g.diag + 1) + mats * align4(g.n) + align4(g.qLen + 1) + align4(g.tLen + 1);
+  long suf = g.top ? (4L * g.n + align4(g.n)) : 0;
+  return 4L * g.nUsed + align4(g.nUsed) + suf + 16L * (g.diag + 1) + align4(g.qLen + 1) + align4(g.tLen + 1);
 }
 
 struct Work {
@@ -84,13 +87,13 @@ template <typename BytePtr>
 __device__ __forceinline__ Work carve(BytePtr base, const Geo& g) {
   Work w;
   auto* p = base;
-  w.sPre = (int*)p; p += 4L * g.n;
+  w.sPre = (int*)p; p += 4L * g.nUsed;
   w.sSuf = (int*)p; if (g.top) p += 4L * g.n;
   w.loMax = (int*)p; p += 4L * (g.diag + 1);
   w.loIdx = (int*)p; p += 4L * (g.diag + 1);
   w.upMax = (int*)p; p += 4L * (g.diag + 1);
   w.upIdx = (int*)p; p += 4L * (g.diag + 1);
-  w.pPre = (signed char*)p; p += align4(g.n);
+  w.pPre = (signed char*)p; p += align4(g.nUsed);
   w.pSuf = (signed char*)p; if (g.top) p += align4(g.n);
   w.qc = (unsigned char*)p; p += align4(g.qLen + 1);
   w.tc = (unsigned char*)p;
@@ -111,40 +114,41 @@ struct Problem {
   int qLen, tLen, k0, m, mm, indel;
 };
 
-template <typename BytePtr>
-__device__ __forceinline__ void solve(int lane, const Problem& pr, const Geo& g, BytePtr mem, int* out_score,
+template <int G, typename BytePtr>
+__device__ __forceinline__ void solve(int wlane, const Problem& pr, const Geo& g, BytePtr mem, int* out_score,
                       int* out_nb, int* blocks, long cap, int* out_status) {
-  const int qLen = g.qLen, tLen = g.tLen, k = g.k, R = g.R, diag = g.diag, n = g.n;
+  const int qLen = g.qLen, tLen = g.tLen, k = g.k, R = g.R, diag = g.diag, n = g.n, nUsed = g.nUsed;
   const int m = pr.m, mm = pr.mm, indel = pr.indel;
+  const int lane = wlane & (G - 1), gbase = wlane - lane;   // G lanes work on this problem
   Work w = carve(mem, g);
   int status = 0;
   auto PI = [&](int i, int j) { return j * R + (i - j) + k + 1; };  // :12-17
   auto inb = [&](int s) { return s >= 0 && s < n; };
 #define PSET(slot, sc, ar)                                                         \
-  do { int s__ = (slot); if (inb(s__)) { w.sPre[s__] = (sc); w.pPre[s__] = (ar); } else status |= LRA_ST_OOB_SLOT; } while (0)
+  do { int s__ = (slot); if (inb(s__)) { if (s__ < nUsed) { w.sPre[s__] = (sc); w.pPre[s__] = (ar); } } else status |= LRA_ST_OOB_SLOT; } while (0)
 #define SSET(slot, sc, ar)                                                         \
   do { int s__ = (slot); if (inb(s__)) { w.sSuf[s__] = (sc); w.pSuf[s__] = (ar); } else status |= LRA_ST_OOB_SLOT; } while (0)
 
   // ---- codes + clear (:173-219)
-  for (int x = lane; x <= qLen; x += 64) w.qc[x] = x ? code_n((unsigned char)pr.q[x - 1]) : 0;
-  for (int x = lane; x <= tLen; x += 64) w.tc[x] = x ? code_n((unsigned char)pr.t[x - 1]) : 0;
-  for (int x = lane; x < n; x += 64) { w.sPre[x] = MISS; w.pPre[x] = -1; }
+  for (int x = lane; x <= qLen; x += G) w.qc[x] = x ? code_n((unsigned char)pr.q[x - 1]) : 0;
+  for (int x = lane; x <= tLen; x += G) w.tc[x] = x ? code_n((unsigned char)pr.t[x - 1]) : 0;
+  for (int x = lane; x < nUsed; x += G) { w.sPre[x] = MISS; w.pPre[x] = -1; }
   if (g.top)
-    for (int x = lane; x < n; x += 64) { w.sSuf[x] = MISS; w.pSuf[x] = -1; }
-  for (int x = lane; x <= diag; x += 64) { w.loMax[x] = MISS; w.loIdx[x] = 0; w.upMax[x] = MISS; w.upIdx[x] = 0; }
+    for (int x = lane; x < n; x += G) { w.sSuf[x] = MISS; w.pSuf[x] = -1; }
+  for (int x = lane; x <= diag; x += G) { w.loMax[x] = MISS; w.loIdx[x] = 0; w.upMax[x] = MISS; w.upIdx[x] = 0; }
   wave_sync();
   // ---- prefix boundary (:229-241), then rails (:248-306); the rails overwrite (0,k+1)
-  for (int i = 1 + lane; i < k + 1; i += 64) PSET(PI(i, 0), indel * i, A_LEFT);
-  for (int j = 1 + lane; j <= k + 1; j += 64) PSET(PI(0, j), indel * j, A_DOWN);
+  for (int i = 1 + lane; i < k + 1; i += G) PSET(PI(i, 0), indel * i, A_LEFT);
+  for (int j = 1 + lane; j <= k + 1; j += G) PSET(PI(0, j), indel * j, A_DOWN);
   if (lane == 0) PSET(PI(0, 0), 0, A_DONE);
   wave_sync();
   if (qLen >= tLen) {
-    for (int i = lane; i <= diag - k - 1; i += 64) PSET(PI(i, i + k + 1), MISS, A_BORDER);
-    for (int i = 1 + lane; i < diag + k - 1; i += 64) PSET(PI(i + k + 1, i), MISS, A_BORDER);
+    for (int i = lane; i <= diag - k - 1; i += G) PSET(PI(i, i + k + 1), MISS, A_BORDER);
+    for (int i = 1 + lane; i < diag + k - 1; i += G) PSET(PI(i + k + 1, i), MISS, A_BORDER);
   }
   if (qLen <= tLen) {
-    for (int j = lane; j < diag - 1; j += 64) PSET(PI(j + k + 1, j), MISS, A_BORDER);
-    for (int j = 1 + lane; j < diag + k; j += 64) PSET(PI(j - k - 1, j), MISS, A_BORDER);
+    for (int j = lane; j < diag - 1; j += G) PSET(PI(j + k + 1, j), MISS, A_BORDER);
+    for (int j = 1 + lane; j < diag + k; j += G) PSET(PI(j - k - 1, j), MISS, A_BORDER);
   }
   wave_sync();
   // ---- prefix fill by anti-diagonals s = i + j (:313-339)
@@ -153,7 +157,7 @@ __device__ __forceinline__ void solve(int lane, const Problem& pr, const Geo& g,
     int jlo = max(1, max(s - qB + 1, (s - k + 1) >> 1));   // ceil((s-k)/2), s-k may be < 0
     if (s - k < 0) jlo = max(1, s - qB + 1);
     int jhi = min(tB - 1, min(s - 1, (s + k) >> 1));
-    for (int j = jlo + lane; j <= jhi; j += 64) {
+    for (int j = jlo + lane; j <= jhi; j += G) {
       int i = s - j;
       int sIns = w.sPre[PI(i - 1, j)] + indel;
       int sDel = w.sPre[PI(i, j - 1)] + indel;
@@ -186,7 +190,7 @@ __device__ __forceinline__ void solve(int lane, const Problem& pr, const Geo& g,
     // ---- per-row / per-column maxima of the prefix band (:347-360)
     //   loMax[j] = max over rows i < qLen-k of column j, ties -> LARGEST i   (>=)
     //   upMax[i] = max over columns j < tLen of row i (i <= diag), ties -> SMALLEST j (>)
-    for (int j = 1 + lane; j < tB && j <= diag; j += 64) {
+    for (int j = 1 + lane; j < tB && j <= diag; j += G) {
       int bm = MISS, bi = 0;
       int ihi = min(qB, j + k + 1);
       for (int i = max(1, j - k); i < ihi && i < qLen - k; i++) {
@@ -195,7 +199,7 @@ __device__ __forceinline__ void solve(int lane, const Problem& pr, const Geo& g,
       }
       w.loMax[j] = bm; w.loIdx[j] = bi;
     }
-    for (int i = 1 + lane; i <= diag && i < qB; i += 64) {
+    for (int i = 1 + lane; i <= diag && i < qB; i += G) {
       int bm = MISS, bj = 0;
       int jhi = min(tB - 1, i + k);
       for (int j = max(1, i - k); j <= jhi && j < tLen; j++) {
@@ -220,22 +224,22 @@ __device__ __forceinline__ void solve(int lane, const Problem& pr, const Geo& g,
       return b * R + (a - b) + k + 1;
     };
     if (qLen >= tLen) {
-      for (int i = qLow + lane; i < qStart + k + 1; i += 64) SSET(SI(i, 0), w.loMax[0], A_GAPLEFT);
+      for (int i = qLow + lane; i < qStart + k + 1; i += G) SSET(SI(i, 0), w.loMax[0], A_GAPLEFT);
       wave_sync();
-      for (int j = 1 + lane; j <= diag; j += 64) SSET(SI(qLow + j - 1, j), w.loMax[j], A_GAPLEFT);
+      for (int j = 1 + lane; j <= diag; j += G) SSET(SI(qLow + j - 1, j), w.loMax[j], A_GAPLEFT);
       wave_sync();
-      for (int j = tStart + 1 + lane; j < tEnd - k; j += 64) SSET(SI(qStart + (j - tStart - 1) + k + 1, j), MISS, A_BORDER);
+      for (int j = tStart + 1 + lane; j < tEnd - k; j += G) SSET(SI(qStart + (j - tStart - 1) + k + 1, j), MISS, A_BORDER);
       wave_sync();
     }
     if (qLen <= tLen) {
-      for (int j = tLow + lane; j < tStart + k + 2; j += 64) SSET(SI(qStart, j), w.upMax[0], A_GAPDOWN);
+      for (int j = tLow + lane; j < tStart + k + 2; j += G) SSET(SI(qStart, j), w.upMax[0], A_GAPDOWN);
       wave_sync();
-      for (int j = tStart + 1 + lane; j < tEnd; j += 64) {
+      for (int j = tStart + 1 + lane; j < tEnd; j += G) {
         int i = qStart + 1 + (j - tStart - 1);
         SSET(SI(i, j - k - 1), (i <= diag ? w.upMax[i] : MISS), A_GAPDOWN);
       }
       wave_sync();
-      for (int j = tStart + lane; j < tEnd - k - 1; j += 64) SSET(SI(qStart + (j - tStart), j + k + 1), MISS, A_BORDER);
+      for (int j = tStart + lane; j < tEnd - k - 1; j += G) SSET(SI(qStart + (j - tStart), j + k + 1), MISS, A_BORDER);
       wave_sync();
     }
     // ---- suffix fill by anti-diagonals (:474-518).  Row j holds rows
@@ -249,7 +253,7 @@ __device__ __forceinline__ void solve(int lane, const Problem& pr, const Geo& g,
       int num2 = s - c0 + k;
       int jhi = (num2 >= 0) ? (num2 >> 1) : -((-num2 + 1) >> 1);          // floor(num2/2)
       jhi = min(jhi, min(tLen, s - qLow - 1));
-      for (int j = jlo + lane; j <= jhi; j += 64) {
+      for (int j = jlo + lane; j <= jhi; j += G) {
         int i = s - j;
         int delClose = MISS, insClose = MISS;
         if (qLong) delClose = (j <= diag) ? w.loMax[j] : MISS;
@@ -308,11 +312,11 @@ __device__ __forceinline__ void solve(int lane, const Problem& pr, const Geo& g,
 #undef SSET
   // ---- publish: blocks were written in walk (reverse) order with absolute matrix
   //      coordinates; alignment order is the reverse, relative to where the walk ended.
-  nb = __shfl(nb, 0);
-  int fi = __shfl(ti, 0), fj = __shfl(tj, 0);
+  nb = __shfl(nb, gbase);
+  int fi = __shfl(ti, gbase), fj = __shfl(tj, gbase);
   wave_sync();
   long nw = min(nb, cap);
-  for (long x = lane; x < (nw + 1) / 2; x += 64) {
+  for (long x = lane; x < (nw + 1) / 2; x += G) {
     long y = nw - 1 - x;
     int a0 = blocks[3 * x], a1 = blocks[3 * x + 1], a2 = blocks[3 * x + 2];
     int b0 = blocks[3 * y], b1 = blocks[3 * y + 1], b2 = blocks[3 * y + 2];
@@ -320,7 +324,7 @@ __device__ __forceinline__ void solve(int lane, const Problem& pr, const Geo& g,
     if (y != x) { blocks[3 * y] = a0 - fi; blocks[3 * y + 1] = a1 - fj; blocks[3 * y + 2] = a2; }
   }
   // status bits raised by any lane
-  for (int off = 32; off > 0; off >>= 1) status |= __shfl_xor(status, off);
+  for (int off = G / 2; off > 0; off >>= 1) status |= __shfl_xor(status, off);
   if (lane == 0) {
     // map the device score domain back to the reference's (int)(long) truncation
     int r = result;
@@ -364,12 +368,13 @@ __global__ void aog_classify(BatchArgs a) {
     } else {
       long need = need_bytes(g);
       cls = need <= CLASS_A_BYTES ? 0 : need <= CLASS_B_BYTES ? 1 : 2;
+      if (need <= CLASS_S_BYTES && g.k + 1 <= 16) cls = 3;
       if (cls == 2 && need > a.gslot_bytes) { a.score[p] = 0; a.nblocks[p] = 0; a.status[p] = LRA_ST_RANGE; cls = -1; }
     }
   }
   // one atomic per wave and class
   const unsigned long long below = (lane == 0) ? 0ULL : (~0ULL >> (64 - lane));
-  for (int c = 0; c < 3; c++) {
+  for (int c = 0; c < 4; c++) {
     const unsigned long long m = __ballot(cls == c);
     if (!m) continue;
     int base = 0;
@@ -381,23 +386,26 @@ __global__ void aog_classify(BatchArgs a) {
 }
 
 template <int CLS>
-__global__ void __launch_bounds__(CLS == 0 ? 256 : 64) aog_kernel(BatchArgs a) {
+__global__ void __launch_bounds__((CLS == 0 || CLS == 3) ? 256 : 64) aog_kernel(BatchArgs a) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
+  constexpr int G = (CLS == 3) ? 16 : 64;
+  constexpr int GPW = 64 / G;
   const int lane = threadIdx.x & 63;
   const int wave_in_wg = threadIdx.x >> 6;
   const int waves_per_wg = blockDim.x >> 6;
-  const int wave = blockIdx.x * waves_per_wg + wave_in_wg;
-  const int nwaves = gridDim.x * waves_per_wg;
+  const int group = (blockIdx.x * waves_per_wg + wave_in_wg) * GPW + lane / G;
+  const int ngroups = gridDim.x * waves_per_wg * GPW;
   const int count = a.counts[CLS];
-  for (int x = wave; x < count; x += nwaves) {
+  for (int x = group; x < count; x += ngroups) {
     int p = a.lists[(long)CLS * a.n + x];
     Problem pr; Geo g; int ok;
     load_problem(a, p, pr, g, ok);
     long cap = (long)(a.block_off[p + 1] - a.block_off[p]);
     int* blk = a.blocks + 3 * a.block_off[p];
-    if (CLS == 0) solve(lane, pr, g, smem + wave_in_wg * CLASS_A_BYTES, &a.score[p], &a.nblocks[p], blk, cap, &a.status[p]);
-    else if (CLS == 1) solve(lane, pr, g, smem, &a.score[p], &a.nblocks[p], blk, cap, &a.status[p]);
-    else solve(lane, pr, g, a.gscratch + (long)(wave % a.gslots) * a.gslot_bytes, &a.score[p], &a.nblocks[p], blk, cap, &a.status[p]);
+    if (CLS == 3) solve<16>(lane, pr, g, smem + (wave_in_wg * GPW + lane / G) * CLASS_S_BYTES, &a.score[p], &a.nblocks[p], blk, cap, &a.status[p]);
+    else if (CLS == 0) solve<64>(lane, pr, g, smem + wave_in_wg * CLASS_A_BYTES, &a.score[p], &a.nblocks[p], blk, cap, &a.status[p]);
+    else if (CLS == 1) solve<64>(lane, pr, g, smem, &a.score[p], &a.nblocks[p], blk, cap, &a.status[p]);
+    else solve<64>(lane, pr, g, a.gscratch + (long)(group % a.gslots) * a.gslot_bytes, &a.score[p], &a.nblocks[p], blk, cap, &a.status[p]);
     wave_sync();
   }
 }
@@ -417,7 +425,7 @@ int lra_aog_launch_device(lra_ctx* ctx, int n, const char* d_qseq, const char* d
   a.k = d_k; a.m = m; a.mm = mm; a.indel = indel;
   a.score = d_score; a.nblocks = d_nblocks; a.blocks = d_blocks; a.block_off = d_block_off; a.status = d_status;
   // scratch slot 0: counts[4] + lists[3n];  slot 1: class-C HBM work slots
-  size_t list_bytes = 16 + sizeof(int) * 3 * (size_t)n;
+  size_t list_bytes = 16 + sizeof(int) * 4 * (size_t)n;
   char* s0 = (char*)lra_scratch(ctx, 0, list_bytes);
   if (!s0) return LRA_ERR_NOMEM;
   a.counts = (int*)s0; a.lists = (int*)(s0 + 16);
@@ -430,6 +438,9 @@ int lra_aog_launch_device(lra_ctx* ctx, int n, const char* d_qseq, const char* d
   int wgA = min((n + 3) / 4, ctx->num_cu * 5);
   int wgB = min(n, ctx->num_cu * 2);
   int wgC = min(n, a.gslots);
+  lra_time_begin(ctx, "aog_lds_tiny");
+  hipLaunchKernelGGL(aog_kernel<3>, dim3(min((n + 15) / 16, ctx->num_cu * 8)), dim3(256), 16 * CLASS_S_BYTES, ctx->stream, a);
+  lra_time_end(ctx);
   lra_time_begin(ctx, "aog_lds_small");
   hipLaunchKernelGGL(aog_kernel<0>, dim3(wgA), dim3(256), 4 * CLASS_A_BYTES, ctx->stream, a);
   lra_time_end(ctx);

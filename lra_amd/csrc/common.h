@@ -21,7 +21,10 @@ struct lra_ctx {
   int num_cu = 256;
   lra_seed_state* seed = nullptr;
   void* aux = nullptr; size_t aux_bytes = 0;          // AffineOneGapAlign blocks of refine fallbacks
-  void* out_buf = nullptr; size_t out_bytes = 0;      // refined blocks handed back to the caller
+  void* out_buf = nullptr; size_t out_bytes = 0;
+  uint64_t* scan_tmp = nullptr;
+  void* gbuf[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};   // growable result / work buffers (lra_ensure)
+  size_t gbytes[6] = {0, 0, 0, 0, 0, 0};                       // tile sums of lra_exclusive_scan      // refined blocks handed back to the caller
   // kernel timing
   bool timing = false;
   std::vector<lra_time_rec> recs;
@@ -36,6 +39,8 @@ int lra_set_err(lra_ctx* ctx, int code, const char* fmt, ...);
 // returns a device buffer of >= bytes (slot 0..3), growing it if needed (synchronises the
 // stream before freeing the old one)
 void* lra_scratch(lra_ctx* ctx, int slot, size_t bytes);
+// growable buffer `idx` of at least `bytes` (contents NOT preserved on growth)
+void* lra_ensure(lra_ctx* ctx, int idx, size_t bytes);
 
 #define LRA_HIP_CHECK(ctx, call)                                                         \
   do {                                                                                   \

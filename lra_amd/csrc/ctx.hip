@@ -31,6 +31,16 @@ void* lra_scratch(lra_ctx* ctx, int slot, size_t bytes) {
   return p;
 }
 
+void* lra_ensure(lra_ctx* ctx, int idx, size_t bytes) {
+  if (ctx->gbuf[idx] && ctx->gbytes[idx] >= bytes) return ctx->gbuf[idx];
+  if (ctx->gbuf[idx]) { (void)hipStreamSynchronize(ctx->stream); (void)hipFree(ctx->gbuf[idx]); ctx->gbuf[idx] = nullptr; ctx->gbytes[idx] = 0; }
+  size_t want = bytes + bytes / 4 + 4096;
+  void* p = nullptr;
+  if (hipMalloc(&p, want) != hipSuccess) { lra_set_err(ctx, LRA_ERR_NOMEM, "hipMalloc(%zu) failed", want); return nullptr; }
+  ctx->gbuf[idx] = p; ctx->gbytes[idx] = want;
+  return p;
+}
+
 extern "C" int lra_abi_version(void) { return LRA_ABI_VERSION; }
 
 extern "C" int lra_ctx_create(int device_id, lra_ctx** out) {
@@ -57,6 +67,8 @@ extern "C" void lra_ctx_destroy(lra_ctx* ctx) {
   lra_seed_free(ctx);
   if (ctx->aux) (void)hipFree(ctx->aux);
   if (ctx->out_buf) (void)hipFree(ctx->out_buf);
+  if (ctx->scan_tmp) (void)hipFree(ctx->scan_tmp);
+  for (int i = 0; i < 6; i++) if (ctx->gbuf[i]) (void)hipFree(ctx->gbuf[i]);
   for (auto& r : ctx->recs) { (void)hipEventDestroy(r.a); (void)hipEventDestroy(r.b); }
   for (auto e : ctx->free_events) (void)hipEventDestroy(e);
   delete ctx;

@@ -34,6 +34,7 @@
 // exactly (integers, no rounding).  The arrows are then chosen by the reference's equality
 // cascade (:583-616) from the true candidate values, so ties resolve identically.
 #include "common.h"
+#include "scan.h"
 #include <algorithm>
 
 int lra_aog_launch_device(lra_ctx* ctx, int n, const char* d_qseq, const char* d_tseq, const uint64_t* d_q_off,
@@ -46,7 +47,6 @@ namespace {
 constexpr int BAD = -999999999;       // IndelRefine.h:368
 constexpr int NEG = -2000000000;      // "no candidate" sentinel, below every reachable score
 enum { C_DIAG = 0, C_LEFT = 1, C_DOWN = 2, C_BOUND = 3, C_DELCLOSE = 4, C_INSCLOSE = 5, C_DONE = 6 };
-constexpr int RING = 128;
 
 __device__ __forceinline__ void wave_sync() {
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
@@ -177,224 +177,244 @@ __global__ void __launch_bounds__(64) ir_segment(IRArgs A) {
 }
 
 // ---------------------------------------------------------------------------------- band
+struct __attribute__((aligned(16))) Row { int S, E; unsigned int C; int T; };   // window [S,E], cell offset in segment, target base
+
 struct BandArgs {
   uint64_t n_seg;
-  const int32_t* s_aln; const int32_t* s_kind; const int32_t* s_qStart; const int32_t* s_qEnd;
+  const int32_t* s_aln; const int32_t* s_kind; const int32_t* s_qStart; const int32_t* s_qEnd; const int32_t* s_tStart;
   const int32_t* s_b0; const int32_t* s_b1; const int32_t* s_first; const int32_t* s_lastLen;
   const uint64_t* s_rows; const uint64_t* s_row_off;
   const int32_t* ab; const uint64_t* block_off;
+  const char* tseq; const uint64_t* t_off;
   int k;
-  int32_t* rowS; int32_t* rowE; uint32_t* rowC;     // per row: window start / end (absolute q), cell offset in segment
-  uint64_t* s_cells; int32_t* s_status;
+  Row* rows;
+  uint64_t* s_cells; int32_t* s_status; int32_t* s_width; uint64_t* s_tmpcap;
 };
 
-__global__ void __launch_bounds__(64) ir_band(BandArgs B) {
-  __shared__ int ringS[RING], ringE[RING];
+// One LANE per segment: the row-window construction of IndelRefine.h:220-333 replayed event by
+// event.  Only the 2k rows around the current target row can still change; they live in a
+// per-lane ring in LDS (lane-interleaved, conflict-free), finished rows stream out to HBM.
+template <int RS>
+__global__ void __launch_bounds__(64) ir_band_lane(BandArgs B) {
+  __shared__ int ringS[RS * 64], ringE[RS * 64];
   const int lane = threadIdx.x;
-  for (uint64_t s = blockIdx.x; s < B.n_seg; s += gridDim.x) {
-    if (B.s_kind[s] != 0) { if (lane == 0) { B.s_cells[s] = 0; B.s_status[s] = 0; } continue; }
-    const long tLen = (long)B.s_rows[s];
-    const int a = B.s_aln[s];
-    const int32_t* ab = B.ab + 3 * (B.block_off[a] + 2 * (uint64_t)a);
-    const long b0 = B.s_b0[s], b1 = B.s_b1[s];
-    const long qStart = B.s_qStart[s], qEnd = B.s_qEnd[s];
-    const int k = B.k;
-    int32_t* gS = B.rowS + B.s_row_off[s];
-    int32_t* gE = B.rowE + B.s_row_off[s];
-    uint32_t* gC = B.rowC + B.s_row_off[s];
-    int status = 0;
-    for (int x = lane; x < RING; x += 64) { ringS[x] = -1; ringE[x] = -1; }
-    wave_sync();
-    auto blk = [&](long b, long& q, long& t, long& l) {
-      if (b == b0) { q = B.s_first[3 * s]; t = B.s_first[3 * s + 1]; l = B.s_first[3 * s + 2]; }
-      else { q = ab[3 * b]; t = ab[3 * b + 1]; l = (b == b1) ? B.s_lastLen[s] : ab[3 * b + 2]; }
-    };
-    auto flush = [&](long r) {   // row r can no longer change: write it out and recycle its slot
-      if (lane == 0 && r >= 0 && r < tLen) { gS[r] = ringS[r & (RING - 1)]; gE[r] = ringE[r & (RING - 1)]; ringS[r & (RING - 1)] = -1; ringE[r & (RING - 1)] = -1; }
-    };
-    long q, t, l;
-    blk(b0, q, t, l);
-    long tOff = 0;
-    for (long b = b0; b <= b1 && !(status & 1); b++) {                  // :232-315
-      long bq, bt, bl;
-      blk(b, bq, bt, bl);
-      int bqGap = 0, btGap = 0;
-      long blockLength = bl;
-      if (b < b1) {
-        long nq2, nt2, nl2;
-        blk(b + 1, nq2, nt2, nl2);
-        bqGap = (int)(nq2 - (bq + bl)); btGap = (int)(nt2 - (bt + bl));
-        if (bqGap > 0 && btGap > 0) { int c = min(bqGap, btGap); bqGap -= c; btGap -= c; blockLength += c; }
+  const uint64_t s = (uint64_t)blockIdx.x * 64 + lane;
+  if (s >= B.n_seg) return;
+  if (B.s_kind[s] != 0) { B.s_cells[s] = 0; B.s_status[s] = 0; B.s_width[s] = 0; B.s_tmpcap[s] = 0; return; }
+  const long tLen = (long)B.s_rows[s];
+  const int a = B.s_aln[s];
+  const int32_t* ab = B.ab + 3 * (B.block_off[a] + 2 * (uint64_t)a);
+  const long b0 = B.s_b0[s], b1 = B.s_b1[s];
+  const long qStart = B.s_qStart[s], qEnd = B.s_qEnd[s];
+  const int k = B.k;
+  Row* rows = B.rows + B.s_row_off[s];
+  int status = 0;
+#define RG(arr, r) arr[(int)((r) & (RS - 1)) * 64 + lane]
+  for (int x = 0; x < RS; x++) { ringS[x * 64 + lane] = -1; ringE[x * 64 + lane] = -1; }
+  const int32_t fq = B.s_first[3 * s], ft = B.s_first[3 * s + 1], fl = B.s_first[3 * s + 2], lastLen = B.s_lastLen[s];
+  auto blk = [&](long b, long& q, long& t, long& l) {
+    if (b == b0) { q = fq; t = ft; l = fl; }
+    else { q = ab[3 * b]; t = ab[3 * b + 1]; l = (b == b1) ? lastLen : ab[3 * b + 2]; }
+  };
+  auto flush = [&](long r) {   // row r can no longer change: write it out and recycle its slot
+    if (r >= 0 && r < tLen) { int2 v; v.x = RG(ringS, r); v.y = RG(ringE, r); *(int2*)&rows[r] = v; RG(ringS, r) = -1; RG(ringE, r) = -1; }
+  };
+  long q = fq;
+  long tOff = 0;
+  long bq = fq, bt = ft, bl = fl;
+  for (long b = b0; b <= b1 && !(status & 1); b++) {                    // :232-315
+    int bqGap = 0, btGap = 0;
+    long blockLength = bl;
+    long nq2 = 0, nt2 = 0, nl2 = 0;
+    if (b < b1) {
+      blk(b + 1, nq2, nt2, nl2);
+      bqGap = (int)(nq2 - (bq + bl)); btGap = (int)(nt2 - (bt + bl));
+      if (bqGap > 0 && btGap > 0) { int c = min(bqGap, btGap); bqGap -= c; btGap -= c; blockLength += c; }
+    }
+    for (long bi = 0; bi < blockLength; bi++) {                         // :252-283
+      if (tOff >= tLen) { status |= 1; break; }
+      {
+        int lo = (int)max(q - k, qStart);
+        int cs = RG(ringS, tOff), ce = RG(ringE, tOff);
+        RG(ringS, tOff) = (cs == -1) ? lo : min(cs, lo);
+        if (ce == -1 || ce < q + k) RG(ringE, tOff) = (int)min(qEnd - 1, q + k);
       }
-      for (long bi = 0; bi < blockLength; bi++) {                       // :252-283
+      for (int ki = 0; ki < k; ki++) {
+        if (tOff - ki >= 0) { if (RG(ringE, tOff - ki) < q) RG(ringE, tOff - ki) = (int)q; }
+        if (tOff + ki < tLen) { int v = RG(ringS, tOff + ki); if (v == -1 || v > q) RG(ringS, tOff + ki) = (int)q; }
+      }
+      tOff++; q++;
+      flush(tOff - k);
+    }
+    if (bqGap > btGap) {                                                // :287-305
+      for (int qi = 0; qi < bqGap; qi++, q++)
+        for (int ki = 0; ki < k; ki++) {
+          if (tOff - ki >= 0 && tOff - ki < tLen) { if (RG(ringE, tOff - ki) < q) RG(ringE, tOff - ki) = (int)q; }
+          if (tOff + ki < tLen) { int v = RG(ringS, tOff + ki); if (v == 0 || v > q) RG(ringS, tOff + ki) = (int)q; }   // (sic) == 0
+        }
+    }
+    if (btGap > bqGap) {                                                // :306-314
+      for (int ti = 0; ti < btGap; ti++) {
         if (tOff >= tLen) { status |= 1; break; }
-        const int slot = (int)(tOff & (RING - 1));
-        if (lane == 0) {
-          int lo = (int)max(q - k, qStart);
-          ringS[slot] = (ringS[slot] == -1) ? lo : min(ringS[slot], lo);
-          if (ringE[slot] == -1 || ringE[slot] < q + k) ringE[slot] = (int)min(qEnd - 1, q + k);
-        }
-        wave_sync();
-        if (lane < k) {
-          if (tOff - lane >= 0) { int sl = (int)((tOff - lane) & (RING - 1)); if (ringE[sl] < q) ringE[sl] = (int)q; }
-          if (tOff + lane < tLen) { int sl = (int)((tOff + lane) & (RING - 1)); if (ringS[sl] == -1 || ringS[sl] > q) ringS[sl] = (int)q; }
-        }
-        wave_sync();
-        tOff++; q++; t++;
+        RG(ringS, tOff) = (int)max(q - k, qStart); RG(ringE, tOff) = (int)min(qEnd - 1, q + k);
+        tOff++;
         flush(tOff - k);
       }
-      if (bqGap > btGap) {                                              // :287-305
-        for (int qi = 0; qi < bqGap; qi++, q++) {
-          if (lane < k) {
-            if (tOff - lane >= 0 && tOff - lane < tLen) { int sl = (int)((tOff - lane) & (RING - 1)); if (ringE[sl] < q) ringE[sl] = (int)q; }
-            if (tOff + lane < tLen) { int sl = (int)((tOff + lane) & (RING - 1)); if (ringS[sl] == 0 || ringS[sl] > q) ringS[sl] = (int)q; }   // (sic) == 0
-          }
-          wave_sync();
-        }
-      }
-      if (btGap > bqGap) {                                              // :306-314
-        for (int ti = 0; ti < btGap; ti++) {
-          if (tOff >= tLen) { status |= 1; break; }
-          if (lane == 0) { int sl = (int)(tOff & (RING - 1)); ringS[sl] = (int)max(q - k, qStart); ringE[sl] = (int)min(qEnd - 1, q + k); }
-          wave_sync();
-          tOff++; t++;
-          flush(tOff - k);
-        }
-      }
     }
-    wave_sync();
-    for (long r = max(0L, tOff - k + 1); r < tLen; r++) flush(r);
-    wave_sync();
-    // ---- :318-322 suffix minimum of qS (back to front, 64 rows at a time)
-    int carry = 0x7fffffff;
-    for (long base = ((tLen - 1) / 64) * 64; base >= 0; base -= 64) {
-      long r = base + lane;
-      int v = (r < tLen) ? gS[r] : 0x7fffffff;
-      for (int d = 1; d < 64; d <<= 1) { int o = __shfl_down(v, d); if (lane + d < 64) v = min(v, o); }
-      v = min(v, carry);
-      if (r < tLen) gS[r] = v;
-      carry = __shfl(v, 0);
+    bq = nq2; bt = nt2; bl = nl2;
+  }
+  for (long r = max(0L, tOff - k + 1); r < tLen; r++) flush(r);
+#undef RG
+  if (tOff != tLen) status |= 1;
+  unsigned long long cells = 0;
+  int width = 0;
+  if (!status) {
+    // :318-322 suffix minimum of qS
+    int run = rows[tLen - 1].S;
+    for (long r = tLen - 2; r >= 0; r--) { int v = rows[r].S; if (run < v) rows[r].S = run; else run = v; }
+    // :323-328 prefix maximum of qE, cell offsets (+ the target base of the row)
+    const unsigned char* tb = (const unsigned char*)B.tseq + B.t_off[a] + B.s_tStart[s];
+    int runE = -0x7fffffff;
+    for (long r = 0; r < tLen; r++) {
+      Row w = rows[r];
+      runE = max(runE, w.E);
+      w.E = runE;
+      int len = w.E - w.S + 1;
+      if (len < 1 || w.S < 0) status |= 1;
+      else if (len > 64) status |= 4;
+      width = max(width, len);
+      w.C = (unsigned int)cells; w.T = tb[r];
+      rows[r] = w;
+      cells += (unsigned long long)max(len, 0);
     }
-    // ---- :323-328 prefix maximum of qE, row lengths, cell offsets
-    int carryE = -0x7fffffff;
-    unsigned long long cells = 0;
-    for (long base = 0; base < tLen; base += 64) {
-      long r = base + lane;
-      int e = (r < tLen) ? gE[r] : -0x7fffffff;
-      for (int d = 1; d < 64; d <<= 1) { int o = __shfl_up(e, d); if (lane >= d) e = max(e, o); }
-      e = max(e, carryE);
-      carryE = __shfl(e, 63);
-      int len = 0;
-      if (r < tLen) {
-        gE[r] = e;
-        len = e - gS[r] + 1;
-        if (len < 1 || len > 64 || gS[r] < 0) status |= (len > 64 ? 4 : 1);
-      }
-      unsigned int incl = (unsigned int)max(len, 0);
-      for (int d = 1; d < 64; d <<= 1) { unsigned int o = __shfl_up(incl, d); if (lane >= d) incl += o; }
-      if (r < tLen) gC[r] = (uint32_t)(cells + incl - (unsigned int)max(len, 0));
-      cells += __shfl(incl, 63);
-    }
-    for (int off = 32; off > 0; off >>= 1) status |= __shfl_xor(status, off);
-    if (tOff != tLen) status |= 1;
-    if (lane == 0) { B.s_cells[s] = (status ? 0 : cells); B.s_status[s] = status; }
-    wave_sync();
+  }
+  B.s_cells[s] = status ? 0 : cells;
+  B.s_status[s] = status;
+  B.s_width[s] = status ? 0 : width;
+  B.s_tmpcap[s] = status ? 0 : (uint64_t)(tLen + (qEnd - qStart) + 2);
+}
+
+// width classes for ir_fill: 16 / 32 / 64 lanes per segment
+__global__ void ir_classify(uint64_t n_seg, const int32_t* __restrict__ s_kind, const int32_t* __restrict__ s_status, const int32_t* __restrict__ s_width,
+                            int* counts, uint32_t* lists) {
+  const uint64_t s = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int lane = threadIdx.x & 63;
+  int cls = -1;
+  if (s < n_seg && s_kind[s] == 0 && s_status[s] == 0) { int w = s_width[s]; cls = w <= 16 ? 0 : w <= 32 ? 1 : 2; }
+  const unsigned long long below = (lane == 0) ? 0ULL : (~0ULL >> (64 - lane));
+  for (int c = 0; c < 3; c++) {
+    const unsigned long long m = __ballot(cls == c);
+    if (!m) continue;
+    int base = 0;
+    const int leader = __ffsll((long long)m) - 1;
+    if (lane == leader) base = atomicAdd(&counts[c], __popcll(m));
+    base = __shfl(base, leader);
+    if (cls == c) lists[(uint64_t)c * n_seg + base + __popcll(m & below)] = (uint32_t)s;
   }
 }
 
 // ---------------------------------------------------------------------------------- fill
 struct FillArgs {
   uint64_t n_seg;
-  const int32_t* s_aln; const int32_t* s_kind; const int32_t* s_tStart; const uint64_t* s_rows; const uint64_t* s_row_off;
-  const uint64_t* s_cells; const uint64_t* s_cell_off; const int32_t* s_status;
-  const int32_t* rowS; const int32_t* rowE; const uint32_t* rowC;
-  const char* qseq; const uint64_t* q_off; const char* tseq; const uint64_t* t_off;
+  const int32_t* s_aln; const uint64_t* s_rows; const uint64_t* s_row_off; const uint64_t* s_cell_off;
+  const Row* rows;
+  const char* qseq; const uint64_t* q_off;
   int match, mismatch, g;
   unsigned char* path;
+  const int* counts; const uint32_t* lists;
 };
 
 __device__ __forceinline__ bool is_bound(long row, int c, int len) { return c == len - 1 || (row > 0 && c == 0); }
 
+// G lanes per segment (G = 16, 32 or 64 by the segment's widest row), 64/G segments per wave.
+// Each group sweeps its own segment row by row: one lane per cell, previous row in registers.
+template <int G>
 __global__ void __launch_bounds__(64) ir_fill(FillArgs F) {
+  constexpr int GP = 64 / G;
+  constexpr int CLS = (G == 16) ? 0 : (G == 32) ? 1 : 2;
   const int lane = threadIdx.x;
+  const int c = lane % G, gbase = lane - c;
   const int g = F.g, go = 2 * F.g + 1;
-  for (uint64_t s = blockIdx.x; s < F.n_seg; s += gridDim.x) {
-    if (F.s_kind[s] != 0 || F.s_status[s] != 0) continue;
-    const long tLen = (long)F.s_rows[s];
-    const int a = F.s_aln[s];
-    const int32_t* gS = F.rowS + F.s_row_off[s];
-    const int32_t* gE = F.rowE + F.s_row_off[s];
-    const uint32_t* gC = F.rowC + F.s_row_off[s];
-    const unsigned char* qb = (const unsigned char*)F.qseq + F.q_off[a];
-    const unsigned char* tb = (const unsigned char*)F.tseq + F.t_off[a] + F.s_tStart[s];
-    unsigned char* P = F.path + F.s_cell_off[s];
-    // 64-row chunk of per-row data, one row per lane
-    int cS = 0, cE = 0; unsigned int cC = 0; int cT = 0;
-    auto load_chunk = [&](long base) {
-      long r = base + lane;
-      if (r < tLen) { cS = gS[r]; cE = gE[r]; cC = gC[r]; cT = tb[r]; }
-    };
-    load_chunk(0);
-    // ---- row 0 (:407-431)
-    int S = __shfl(cS, 0), E = __shfl(cE, 0);
-    unsigned int C0 = __shfl(cC, 0);
-    int len = E - S + 1;
-    int prevM, prevD;
-    {
-      const bool last = (lane == len - 1) && (tLen > 1);
-      prevM = last ? BAD : (lane == 0 ? 0 : lane * g);
-      prevD = BAD;
-      int code = last ? C_BOUND : (lane == 0 ? C_DONE : C_LEFT);
-      if (lane < len) P[C0 + lane] = (unsigned char)code;
+  const long count = F.counts[CLS];
+  const uint32_t* list = F.lists + (uint64_t)CLS * F.n_seg;
+  const long stride = (long)gridDim.x * GP;
+  long x = (long)blockIdx.x * GP + lane / G;
+  // per-group state (identical on the G lanes of a group)
+  long ti = -1, tLen = 0;
+  const Row* rows = nullptr; const unsigned char* qb = nullptr; unsigned char* P = nullptr;
+  long chunkBase = 0;
+  Row chunk; chunk.S = chunk.E = chunk.T = 0; chunk.C = 0;
+  int prevM = BAD, prevD = BAD, prevS = 0, prevLen = 0;
+  bool done = false;
+  while (true) {
+    if (!done && ti < 0) {
+      if (x < count) {
+        const uint64_t s = list[x];
+        x += stride;
+        const int a = F.s_aln[s];
+        tLen = (long)F.s_rows[s];
+        rows = F.rows + F.s_row_off[s];
+        qb = (const unsigned char*)F.qseq + F.q_off[a];
+        P = F.path + F.s_cell_off[s];
+        ti = 0; chunkBase = 0;
+        if (c < tLen) chunk = rows[c];
+      } else done = true;
     }
-    int prevS = S, prevLen = len;
-    for (long ti = 1; ti < tLen; ti++) {                                // :438-622
-      if ((ti & 63) == 0) load_chunk(ti);
-      const int src = (int)(ti & 63);
-      S = __shfl(cS, src); E = __shfl(cE, src);
-      const unsigned int C = __shfl(cC, src);
-      const int tch = __shfl(cT, src);
-      len = E - S + 1;
-      const int off = S - prevS;
-      const bool lastRow = (ti == tLen - 1);
-      const int c = lane;
-      const bool interior = c >= 1 && (lastRow ? c <= len - 1 : c <= len - 2);
-      const int srcA = c + off, srcD = srcA - 1;
-      const bool aboveIn = srcA <= prevLen - 1;                          // qE[ti-1] >= q   (:491,:548,:567)
-      const int aM = __shfl(prevM, srcA & 63), aD = __shfl(prevD, srcA & 63), dM = __shfl(prevM, srcD & 63);
-      const bool okA = aboveIn && !is_bound(ti - 1, srcA, prevLen);
-      const bool okD = aboveIn && srcD >= 0 && !is_bound(ti - 1, srcD, prevLen);
-      const int dOpen = okA ? aM + go : BAD, dExt = okA ? aD : BAD;      // :491-502 (gapExtend = 0)
-      const int Dv = max(dOpen, dExt);
-      const int delOpen = (Dv == dOpen) ? 1 : 0;                         // :504-516
-      int qch = 0;
-      if (interior) qch = qb[S + c];
-      const int mS = okD ? dM + (tch == qch ? F.match : F.mismatch) : BAD;   // :548-563
-      const int dS = okA ? aM + g : BAD;                                     // :567-574
-      const int V = interior ? max(mS, max(dS, Dv)) : NEG;
-      int W = V;                                                         // inclusive prefix max of V
-      for (int d = 1; d < 64; d <<= 1) { int o = __shfl_up(W, d); if (lane >= d) W = max(W, o); }
-      int Wm1 = __shfl_up(W, 1), Vm1 = __shfl_up(V, 1);
-      if (lane == 0) { Wm1 = NEG; Vm1 = NEG; }
-      const int Iv = max(BAD, go + Wm1);
-      int M = max(max(BAD, V), max(Vm1 + g, go + Wm1));
-      if (!interior) M = BAD;
-      int Mleft = __shfl_up(M, 1);
-      if (c <= 1) Mleft = BAD;                                           // the row's left boundary cell (:413-418)
-      const int iOpen = Mleft + go;                                      // :523
-      const int insOpen = (Iv == iOpen) ? 1 : 0;                         // :528-540
-      const int iS = Mleft + g;                                          // :565
-      int code;
-      if (!interior) code = C_BOUND;
-      else if (M == mS) code = C_DIAG;                                   // :583-616
-      else if (M == iS) code = C_LEFT;
-      else if (M == dS) code = C_DOWN;
-      else if (M == Dv) code = C_DELCLOSE;
-      else code = C_INSCLOSE;
-      if (c < len) P[C + c] = (unsigned char)(code | (delOpen << 3) | (insOpen << 4));
-      prevM = M;
-      prevD = interior ? Dv : BAD;
-      prevS = S; prevLen = len;
+    if (__ballot(!done) == 0ULL) break;
+    if (!done && ti - chunkBase == G) { chunkBase = ti; if (ti + c < tLen) chunk = rows[ti + c]; }
+    const int src = gbase + (int)((ti - chunkBase) & (G - 1));
+    const int S = __shfl(chunk.S, src), E = __shfl(chunk.E, src), tch = __shfl(chunk.T, src);
+    const unsigned int C = __shfl(chunk.C, src);
+    const int len = E - S + 1;
+    const bool lastRow = (ti == tLen - 1);
+    const int off = S - prevS;
+    const bool interior = c >= 1 && (lastRow ? c <= len - 1 : c <= len - 2);
+    const int srcA = c + off, srcD = srcA - 1;
+    const bool aboveIn = srcA <= prevLen - 1;                            // qE[ti-1] >= q   (:491,:548,:567)
+    const int aM = __shfl(prevM, gbase + (srcA & (G - 1))), aD = __shfl(prevD, gbase + (srcA & (G - 1)));
+    const int dM = __shfl(prevM, gbase + (srcD & (G - 1)));
+    const bool okA = aboveIn && !is_bound(ti - 1, srcA, prevLen);
+    const bool okD = aboveIn && srcD >= 0 && !is_bound(ti - 1, srcD, prevLen);
+    const int dOpen = okA ? aM + go : BAD, dExt = okA ? aD : BAD;        // :491-502 (gapExtend = 0)
+    const int Dv = max(dOpen, dExt);
+    const int delOpen = (Dv == dOpen) ? 1 : 0;                           // :504-516
+    int qch = 0;
+    if (!done && ti > 0 && interior) qch = qb[S + c];
+    const int mS = okD ? dM + (tch == qch ? F.match : F.mismatch) : BAD; // :548-563
+    const int dS = okA ? aM + g : BAD;                                   // :567-574
+    const int V = interior ? max(mS, max(dS, Dv)) : NEG;
+    int W = V;                                                           // inclusive prefix max of V inside the group
+    for (int d = 1; d < G; d <<= 1) { int o = __shfl_up(W, d); if (c >= d) W = max(W, o); }
+    int Wm1 = __shfl_up(W, 1), Vm1 = __shfl_up(V, 1);
+    if (c == 0) { Wm1 = NEG; Vm1 = NEG; }
+    const int Iv = max(BAD, go + Wm1);
+    int M = max(max(BAD, V), max(Vm1 + g, go + Wm1));
+    if (!interior) M = BAD;
+    int Mleft = __shfl_up(M, 1);
+    if (c <= 1) Mleft = BAD;                                             // the row's left boundary cell (:413-418)
+    const int iOpen = Mleft + go;                                        // :523
+    const int insOpen = (Iv == iOpen) ? 1 : 0;                           // :528-540
+    const int iS = Mleft + g;                                            // :565
+    int code;
+    if (!interior) code = C_BOUND;
+    else if (M == mS) code = C_DIAG;                                     // :583-616
+    else if (M == iS) code = C_LEFT;
+    else if (M == dS) code = C_DOWN;
+    else if (M == Dv) code = C_DELCLOSE;
+    else code = C_INSCLOSE;
+    int outM = M, outD = interior ? Dv : BAD;
+    unsigned char outB = (unsigned char)(code | (delOpen << 3) | (insOpen << 4));
+    if (ti == 0) {                                                       // :407-431 first row
+      const bool last0 = (c == len - 1) && (tLen > 1);
+      outM = last0 ? BAD : (c == 0 ? 0 : c * g);
+      outD = BAD;
+      outB = (unsigned char)(last0 ? C_BOUND : (c == 0 ? C_DONE : C_LEFT));
+    }
+    if (!done) {
+      if (c < len) P[C + c] = outB;
+      prevM = outM; prevD = outD; prevS = S; prevLen = len;
+      ti++;
+      if (ti == tLen) ti = -1;
     }
   }
 }
@@ -402,119 +422,94 @@ __global__ void __launch_bounds__(64) ir_fill(FillArgs F) {
 // ---------------------------------------------------------------------------------- trace
 struct TraceArgs {
   uint64_t n_seg;
-  const int32_t* s_kind; const int32_t* s_qStart; const int32_t* s_tStart; const uint64_t* s_rows; const uint64_t* s_row_off;
+  const int32_t* s_kind; const int32_t* s_tStart; const uint64_t* s_rows; const uint64_t* s_row_off;
   const uint64_t* s_cells; const uint64_t* s_cell_off; int32_t* s_status;
-  const int32_t* rowS; const int32_t* rowE; const uint32_t* rowC;
+  const Row* rows;
   const unsigned char* path;
-  uint32_t* s_nblk; uint32_t* s_nq; uint32_t* s_nt;   // count pass outputs: blocks, q consumed, t consumed
-  const uint64_t* s_out_off; int32_t* out_blocks;     // emit pass
+  uint32_t* s_nblk;
+  const uint64_t* s_tmp_off; int32_t* tmp_blocks;     // blocks in walk order (back to front), forward coordinates
 };
 
-template <bool EMIT>
-__global__ void __launch_bounds__(64) ir_trace(TraceArgs T) {
-  __shared__ int lS[64], lLen[64];
-  __shared__ unsigned int lC[64];
-  __shared__ unsigned char lP[64 * 64];
-  const int lane = threadIdx.x;
-  for (uint64_t s = blockIdx.x; s < T.n_seg; s += gridDim.x) {
-    if (T.s_kind[s] != 0) continue;
-    if (T.s_status[s] != 0) { if (!EMIT && lane == 0) { T.s_nblk[s] = 0; T.s_nq[s] = 0; T.s_nt[s] = 0; } continue; }
-    const long tLen = (long)T.s_rows[s];
-    const int32_t* gS = T.rowS + T.s_row_off[s];
-    const int32_t* gE = T.rowE + T.s_row_off[s];
-    const uint32_t* gC = T.rowC + T.s_row_off[s];
-    const unsigned char* P = T.path + T.s_cell_off[s];
-    // walk state (meaningful on lane 0, broadcast at chunk boundaries): row ti, absolute read
-    // position qa of the current cell, current matrix
-    int ti = (int)(tLen - 1);
-    int qa = gE[tLen - 1];                    // last cell of the matrix (:629)
-    int mat = 0;                              // 0 match, 1 del, 2 ins
-    int done = 0, bad = 0;
-    // block assembly back to front: positions are forward coordinates
-    unsigned int nblk = 0, nD = 0, nL = 0, nU = 0;
-    long q = 0, t = 0;
-    long outIdx = 0;
-    int32_t* ob = nullptr;
-    if (EMIT) {
-      q = (long)T.s_qStart[s] + T.s_nq[s]; t = (long)T.s_tStart[s] + T.s_nt[s];
-      outIdx = (long)T.s_nblk[s] - 1;
-      ob = T.out_blocks + 3 * T.s_out_off[s];
-    }
-    int curKind = -1, pending = 0;
-    long dlen = 0;
-    long steps = 0;
-    const long step_cap = 4 * (long)T.s_cells[s] + 64;
-    auto emit_block = [&]() {
-      if (EMIT) { if (outIdx >= 0) { ob[3 * outIdx] = (int)q; ob[3 * outIdx + 1] = (int)t; ob[3 * outIdx + 2] = (int)dlen; } outIdx--; }
-      nblk++;
-    };
-    // The forward parse (:718-745) is: [diag run][one run of left OR of down] -> one block.  Seen
-    // back to front: every gap run closes the block whose diag run (possibly empty) precedes it,
-    // and a trailing diag run is a block of its own.
-    auto op = [&](int kind) {                 // kind: 0 diag, 1 left, 2 down
-      if (kind != curKind) {
-        if (curKind == -1 && kind == 0) { pending = 1; dlen = 0; }
-        if (kind != 0) {
-          if (pending) emit_block();
-          pending = 1; dlen = 0;
-        }
-        curKind = kind;
+// One LANE per segment: the trace back of IndelRefine.h:626-674 and the path -> blocks parse of
+// :718-745 fused.  Walking back from the last cell, the forward position before the ops consumed so
+// far is known from the cell coordinates, so blocks come out (in reverse order) with their final
+// coordinates in one pass.  The forward parse is: [diag run][one run of left OR of down] -> one
+// block; seen back to front every gap run closes the block whose (possibly empty) diag run precedes
+// it, and a trailing diag run is a block of its own.
+__global__ void __launch_bounds__(64) ir_trace_lane(TraceArgs T) {
+  const uint64_t s = (uint64_t)blockIdx.x * 64 + threadIdx.x;
+  if (s >= T.n_seg) return;
+  if (T.s_kind[s] != 0) return;
+  if (T.s_status[s] != 0) { T.s_nblk[s] = 0; return; }
+  const long tLen = (long)T.s_rows[s];
+  const Row* rows = T.rows + T.s_row_off[s];
+  const unsigned char* P = T.path + T.s_cell_off[s];
+  int32_t* ob = T.tmp_blocks + 3 * T.s_tmp_off[s];
+  const long cap = (long)(T.s_tmp_off[s + 1] - T.s_tmp_off[s]);
+  long ti = tLen - 1;
+  Row rw = rows[ti];
+  int qa = rw.E;                              // last cell of the matrix (:629)
+  int mat = 0;                                // 0 match, 1 del, 2 ins
+  int bad = 0;
+  long nblk = 0;
+  long q = (long)rw.E + 1, t = (long)T.s_tStart[s] + tLen;   // forward position after the whole path
+  int curKind = -1, pending = 0;
+  long dlen = 0;
+  long steps = 0;
+  const long step_cap = 4 * (long)T.s_cells[s] + 64;
+  auto emit_block = [&]() {
+    if (nblk < cap) { ob[3 * nblk] = (int)q; ob[3 * nblk + 1] = (int)t; ob[3 * nblk + 2] = (int)dlen; } else bad = 1;
+    nblk++;
+  };
+  auto op = [&](int kind) {                   // kind: 0 diag, 1 left, 2 down
+    if (kind != curKind) {
+      if (curKind == -1 && kind == 0) { pending = 1; dlen = 0; }
+      if (kind != 0) {
+        if (pending) emit_block();
+        pending = 1; dlen = 0;
       }
-      if (kind == 0) { dlen++; q--; t--; nD++; }
-      else if (kind == 1) { q--; nL++; }
-      else { t--; nU++; }
-    };
-    while (!done) {
-      // stage rows [lo, hi] = [max(0, ti-63), ti]
-      const int hi = ti, lo = max(0, ti - 63);
-      wave_sync();
-      {
-        int r = lo + lane;
-        if (r <= hi) { lS[lane] = gS[r]; lC[lane] = gC[r]; lLen[lane] = gE[r] - gS[r] + 1; }
-      }
-      wave_sync();
-      const unsigned int cbase = lC[0];
-      const unsigned int cend = lC[hi - lo] + (unsigned int)lLen[hi - lo];
-      for (unsigned int x = cbase + lane; x < cend; x += 64) lP[x - cbase] = P[x];
-      wave_sync();
-      if (lane == 0) {
-        while (ti >= lo) {
-          const int ri = ti - lo;
-          const int c = qa - lS[ri];
-          if (c < 0 || c >= lLen[ri]) { bad = 1; done = 1; break; }
-          if (ti == 0 && c == 0) { done = 1; break; }                   // flat index 0 (:631)
-          if (++steps > step_cap) { bad = 1; done = 1; break; }
-          const unsigned char pb = lP[lC[ri] - cbase + c];
-          if (mat == 0) {                                               // :632-648
-            const int code = pb & 7;
-            if (code == C_DELCLOSE) mat = 1;
-            else if (code == C_INSCLOSE) mat = 2;
-            else if (code == C_DIAG) { op(0); ti--; qa--; }
-            else if (code == C_LEFT) { op(1); qa--; }
-            else if (code == C_DOWN) { op(2); ti--; }
-            else { bad = 1; done = 1; break; }                          // boundary arrow: endless loop in the reference
-          } else if (mat == 1) {                                        // :649-659
-            op(2);
-            mat = ((pb >> 3) & 1) ? 0 : 1;
-            ti--;
-          } else {                                                      // :660-671
-            op(1);
-            mat = ((pb >> 4) & 1) ? 0 : 2;
-            qa--;
-          }
-        }
-        if (ti < 0) { bad = 1; done = 1; }
-      }
-      ti = __shfl(ti, 0); qa = __shfl(qa, 0); done = __shfl(done, 0);
+      curKind = kind;
     }
-    if (lane == 0) {
-      op(0);                                                            // the aligned first base (:674)
-      if (pending) emit_block();
-      if (bad) T.s_status[s] |= 2;
-      if (!EMIT) { T.s_nblk[s] = bad ? 0 : nblk; T.s_nq[s] = nD + nL; T.s_nt[s] = nD + nU; }
+    if (kind == 0) { dlen++; q--; t--; }
+    else if (kind == 1) q--;
+    else t--;
+  };
+  while (true) {
+    const int c = qa - rw.S;
+    if (c < 0 || c > rw.E - rw.S) { bad = 1; break; }
+    if (ti == 0 && c == 0) break;                                       // flat index 0 (:631)
+    if (++steps > step_cap) { bad = 1; break; }
+    const unsigned char pb = P[rw.C + c];
+    long nti = ti;
+    if (mat == 0) {                                                     // :632-648
+      const int code = pb & 7;
+      if (code == C_DELCLOSE) mat = 1;
+      else if (code == C_INSCLOSE) mat = 2;
+      else if (code == C_DIAG) { op(0); nti = ti - 1; qa--; }
+      else if (code == C_LEFT) { op(1); qa--; }
+      else if (code == C_DOWN) { op(2); nti = ti - 1; }
+      else { bad = 1; break; }                                          // boundary arrow: endless loop in the reference
+    } else if (mat == 1) {                                              // :649-659
+      op(2);
+      mat = ((pb >> 3) & 1) ? 0 : 1;
+      nti = ti - 1;
+    } else {                                                            // :660-671
+      op(1);
+      mat = ((pb >> 4) & 1) ? 0 : 2;
+      qa--;
     }
-    wave_sync();
+    if (nti != ti) {
+      if (nti < 0) { bad = 1; break; }
+      ti = nti;
+      rw = rows[ti];
+    }
   }
+  if (!bad) {
+    op(0);                                                              // the aligned first base (:674)
+    if (pending) emit_block();
+  }
+  if (bad) T.s_status[s] |= 2;
+  T.s_nblk[s] = bad ? 0 : (uint32_t)nblk;
 }
 
 // ---------------------------------------------------------------------------------- gather
@@ -524,6 +519,7 @@ struct GatherArgs {
   const uint64_t* seg_off;            // per alignment
   const int32_t* s_kind; const int32_t* s_qStart; const int32_t* s_tStart; const uint32_t* s_aog_idx;
   const int32_t* aog_blocks; const uint64_t* aog_block_off; const int32_t* aog_nblocks;
+  const int32_t* tmp_blocks; const uint64_t* s_tmp_off; const uint32_t* s_nblk;
   int32_t* out_blocks;
 };
 
@@ -547,7 +543,15 @@ __global__ void __launch_bounds__(64) ir_gather(GatherArgs G) {
       continue;
     }
     uint64_t s = G.seg_off[G.i_aln[i]] + (uint64_t)G.i_data[3 * i];
-    if (G.s_kind[s] == 0) continue;                                     // DP segments were written in place by ir_trace
+    if (G.s_kind[s] == 0) {                                             // DP segment: the walk left its blocks back to front
+      const int32_t* src = G.tmp_blocks + 3 * G.s_tmp_off[s];
+      const int n = (int)G.s_nblk[s];
+      for (int x = lane; x < n; x += 64) {
+        const int y = n - 1 - x;
+        out[3 * x] = src[3 * y]; out[3 * x + 1] = src[3 * y + 1]; out[3 * x + 2] = src[3 * y + 2];
+      }
+      continue;
+    }
     const uint32_t p = G.s_aog_idx[s];
     const int32_t* src = G.aog_blocks + 3 * G.aog_block_off[p];
     const int n = G.aog_nblocks[p];
@@ -602,26 +606,6 @@ __global__ void ir_aog_setup(uint64_t n_seg, const int32_t* s_kind, const int32_
   p_cap[p] = (uint32_t)(min(p_q_len[p], p_t_len[p]) + 1);
 }
 
-template <typename CT>
-__global__ void __launch_bounds__(1024) scan_kernel(long n, const CT* __restrict__ counts, uint64_t* __restrict__ off) {
-  __shared__ uint64_t part[1024];
-  const int t = threadIdx.x;
-  const long per = (n + 1023) / 1024;
-  const long lo = min((long)t * per, n), hi = min(lo + per, n);
-  uint64_t s = 0;
-  for (long i = lo; i < hi; i++) s += (uint64_t)counts[i];
-  part[t] = s;
-  __syncthreads();
-  for (int d = 1; d < 1024; d <<= 1) {
-    uint64_t v = (t >= d) ? part[t - d] : 0;
-    __syncthreads();
-    part[t] += v;
-    __syncthreads();
-  }
-  uint64_t run = (t == 0) ? 0 : part[t - 1];
-  for (long i = lo; i < hi; i++) { off[i] = run; run += (uint64_t)counts[i]; }
-  if (t == 1023) off[n] = part[1023];
-}
 
 // simple device bump allocator over one scratch arena (slot 2), 256-byte aligned
 struct Arena {
@@ -639,7 +623,7 @@ struct Arena {
 
 template <typename CT>
 static void scan(lra_ctx* ctx, long n, const CT* c, uint64_t* off) {
-  hipLaunchKernelGGL(scan_kernel<CT>, dim3(1), dim3(1024), 0, ctx->stream, n, c, off);
+  (void)lra_exclusive_scan<CT>(ctx, n, c, off);
 }
 
 static int d2h(lra_ctx* ctx, void* dst, const void* src, size_t bytes) {
@@ -660,20 +644,20 @@ extern "C" int lra_indel_refine_batch(lra_ctx* ctx, int n_aln, const int32_t* d_
   LRA_HIP_CHECK(ctx, hipSetDevice(ctx->device));
   hipStream_t st = ctx->stream;
   const size_t nA = (size_t)n_aln, nBk = (size_t)n_blocks_in + 2 * nA;   // augmented blocks
-  // ---- arena A (slot 2): everything whose size is bounded by the input
+  // ---- arena A (scratch slot 2): everything whose size is bounded by the input
+  const size_t capSeg = nBk, capItem = 2 * nBk + nA;
   size_t needA = 0;
   auto add = [&](size_t n, size_t sz) { needA += ((n * sz + 255) & ~(size_t)255); };
-  add(nA, 4); add(nA, 4); add(nA, 4); add(nA + 1, 8); add(nA + 1, 8);                 // a_nseg a_nitem a_status seg_off item_off
-  add(3 * nBk, 4);                                                                    // ab
-  const size_t capSeg = nBk, capItem = 2 * nBk + nA;
-  add(capSeg, 4); add(capSeg, 4); add(capSeg, 4); add(capSeg, 4); add(capSeg, 4); add(capSeg, 4); add(capSeg, 4); add(capSeg, 4);
-  add(3 * capSeg, 4); add(capSeg, 4); add(capSeg, 8); add(capSeg, 4);                 // first lastLen rows isAog
-  add(capSeg + 1, 8); add(capSeg + 1, 8); add(capSeg, 8); add(capSeg + 1, 8); add(capSeg, 4);   // row_off aog_off cells cell_off status
-  add(capSeg, 4); add(capSeg, 4); add(capSeg, 4); add(capSeg, 4); add(capSeg + 1, 8);           // nblk nq nt aog_idx out_off(seg)
-  add(capItem, 4); add(3 * capItem, 4); add(capItem, 4); add(capItem, 4); add(capItem + 1, 8);  // i_kind i_data i_aln i_count i_out_off
-  add(capSeg, 8); add(capSeg, 4); add(capSeg, 8); add(capSeg, 4); add(capSeg, 4); add(capSeg, 4); add(capSeg + 1, 8);   // aog problem arrays
-  add(capSeg, 4); add(capSeg, 4); add(capSeg, 4);                                               // aog score nblocks status
-  add(nA + 1, 8);                                                                               // out block_off per alignment
+  add(nA, 4); add(nA, 4); add(nA, 4); add(nA + 1, 8); add(nA + 1, 8); add(3 * nBk, 4);
+  for (int i = 0; i < 8; i++) add(capSeg, 4);
+  add(3 * capSeg, 4); add(capSeg, 4); add(capSeg, 8); add(capSeg, 4);
+  add(capSeg + 1, 8); add(capSeg + 1, 8); add(capSeg, 8); add(capSeg + 1, 8); add(capSeg, 4);
+  add(capSeg, 4); add(capSeg, 4); add(capSeg, 8); add(capSeg + 1, 8); add(capSeg, 4); add(capSeg + 1, 8);
+  add(3 * capSeg, 4); add(16, 4);
+  add(capItem, 4); add(3 * capItem, 4); add(capItem, 4); add(capItem, 4); add(capItem + 1, 8);
+  add(capSeg, 8); add(capSeg, 4); add(capSeg, 8); add(capSeg, 4); add(capSeg, 4); add(capSeg, 4); add(capSeg + 1, 8);
+  add(capSeg, 4); add(capSeg, 4); add(capSeg, 4);
+  add(nA + 1, 8);
   char* baseA = (char*)lra_scratch(ctx, 2, needA + 4096);
   if (!baseA) return LRA_ERR_NOMEM;
   Arena ar{baseA, needA + 4096, 0};
@@ -690,8 +674,9 @@ extern "C" int lra_indel_refine_batch(lra_ctx* ctx, int n_aln, const int32_t* d_
   A.s_first = ar.get<int32_t>(3 * capSeg); A.s_lastLen = ar.get<int32_t>(capSeg); A.s_rows = ar.get<uint64_t>(capSeg); A.s_isAog = ar.get<uint32_t>(capSeg);
   uint64_t* s_row_off = ar.get<uint64_t>(capSeg + 1); uint64_t* s_aog_off = ar.get<uint64_t>(capSeg + 1);
   uint64_t* s_cells = ar.get<uint64_t>(capSeg); uint64_t* s_cell_off = ar.get<uint64_t>(capSeg + 1); int32_t* s_status = ar.get<int32_t>(capSeg);
-  uint32_t* s_nblk = ar.get<uint32_t>(capSeg); uint32_t* s_nq = ar.get<uint32_t>(capSeg); uint32_t* s_nt = ar.get<uint32_t>(capSeg);
-  uint32_t* s_aog_idx = ar.get<uint32_t>(capSeg); uint64_t* s_out_off = ar.get<uint64_t>(capSeg + 1);
+  uint32_t* s_nblk = ar.get<uint32_t>(capSeg); int32_t* s_width = ar.get<int32_t>(capSeg); uint64_t* s_tmpcap = ar.get<uint64_t>(capSeg);
+  uint64_t* s_tmp_off = ar.get<uint64_t>(capSeg + 1); uint32_t* s_aog_idx = ar.get<uint32_t>(capSeg); uint64_t* s_out_off = ar.get<uint64_t>(capSeg + 1);
+  uint32_t* fill_lists = ar.get<uint32_t>(3 * capSeg); int* fill_counts = ar.get<int>(16);
   A.i_kind = ar.get<int32_t>(capItem); A.i_data = ar.get<int32_t>(3 * capItem);
   int32_t* i_aln = ar.get<int32_t>(capItem); uint32_t* i_count = ar.get<uint32_t>(capItem); uint64_t* i_out_off = ar.get<uint64_t>(capItem + 1);
   uint64_t* p_q_off = ar.get<uint64_t>(capSeg); int32_t* p_q_len = ar.get<int32_t>(capSeg); uint64_t* p_t_off = ar.get<uint64_t>(capSeg);
@@ -714,64 +699,58 @@ extern "C" int lra_indel_refine_batch(lra_ctx* ctx, int n_aln, const int32_t* d_
   if (n_seg > capSeg || n_item > capItem) return lra_set_err(ctx, LRA_ERR_INVALID, "segment accounting");
   hipLaunchKernelGGL(ir_item_aln, dim3((n_aln + 255) / 256), dim3(256), 0, st, n_aln, item_off, i_aln);
   uint64_t n_rows = 0, n_aog = 0, n_cells = 0;
-  int32_t* rowS = nullptr; int32_t* rowE = nullptr; uint32_t* rowC = nullptr;
+  const int32_t* tmp_blocks = nullptr;
   if (n_seg) {
     scan(ctx, (long)n_seg, A.s_rows, s_row_off);
     scan(ctx, (long)n_seg, A.s_isAog, s_aog_off);
     if (d2h(ctx, &n_rows, s_row_off + n_seg, 8) || d2h(ctx, &n_aog, s_aog_off + n_seg, 8)) return LRA_ERR_HIP;
-    // ---- arena B (slot 3): rows, then cells
-    size_t rowBytes = ((n_rows * 4 + 255) & ~(size_t)255);
-    char* baseB = (char*)lra_scratch(ctx, 3, 3 * rowBytes + 4096);
-    if (!baseB) return LRA_ERR_NOMEM;
-    rowS = (int32_t*)baseB; rowE = (int32_t*)(baseB + rowBytes); rowC = (uint32_t*)(baseB + 2 * rowBytes);
+    Row* rows = (Row*)lra_ensure(ctx, 0, (n_rows + 1) * sizeof(Row));
+    if (!rows) return LRA_ERR_NOMEM;
     BandArgs B;
-    B.n_seg = n_seg; B.s_aln = A.s_aln; B.s_kind = A.s_kind; B.s_qStart = A.s_qStart; B.s_qEnd = A.s_qEnd; B.s_b0 = A.s_b0; B.s_b1 = A.s_b1;
-    B.s_first = A.s_first; B.s_lastLen = A.s_lastLen; B.s_rows = A.s_rows; B.s_row_off = s_row_off; B.ab = A.ab; B.block_off = d_block_off;
-    B.k = refine_band; B.rowS = rowS; B.rowE = rowE; B.rowC = rowC; B.s_cells = s_cells; B.s_status = s_status;
-    const unsigned gridW = (unsigned)std::min<uint64_t>(n_seg, (uint64_t)ctx->num_cu * 32);
+    B.n_seg = n_seg; B.s_aln = A.s_aln; B.s_kind = A.s_kind; B.s_qStart = A.s_qStart; B.s_qEnd = A.s_qEnd; B.s_tStart = A.s_tStart;
+    B.s_b0 = A.s_b0; B.s_b1 = A.s_b1; B.s_first = A.s_first; B.s_lastLen = A.s_lastLen; B.s_rows = A.s_rows; B.s_row_off = s_row_off;
+    B.ab = A.ab; B.block_off = d_block_off; B.tseq = d_tseq; B.t_off = d_t_off; B.k = refine_band; B.rows = rows;
+    B.s_cells = s_cells; B.s_status = s_status; B.s_width = s_width; B.s_tmpcap = s_tmpcap;
+    const unsigned gridL = (unsigned)((n_seg + 63) / 64);
     lra_time_begin(ctx, "ir_band");
-    hipLaunchKernelGGL(ir_band, dim3(gridW), dim3(64), 0, st, B);
+    if (refine_band <= 8) hipLaunchKernelGGL(ir_band_lane<16>, dim3(gridL), dim3(64), 0, st, B);
+    else if (refine_band <= 32) hipLaunchKernelGGL(ir_band_lane<64>, dim3(gridL), dim3(64), 0, st, B);
+    else hipLaunchKernelGGL(ir_band_lane<128>, dim3(gridL), dim3(64), 0, st, B);
     lra_time_end(ctx);
     scan(ctx, (long)n_seg, s_cells, s_cell_off);
-    if (d2h(ctx, &n_cells, s_cell_off + n_seg, 8)) return LRA_ERR_HIP;
-    // path bytes live after the row arrays; re-fetch the arena in case it must grow
-    size_t needB = 3 * rowBytes + n_cells + 4096;
-    if (needB > ctx->scratch_bytes[3]) {
-      // grow while keeping the row arrays: allocate new, copy, free old
-      void* nb = nullptr;
-      size_t want = needB + needB / 4;
-      if (hipMalloc(&nb, want) != hipSuccess) return lra_set_err(ctx, LRA_ERR_NOMEM, "trace-back arena (%zu bytes)", want);
-      LRA_HIP_CHECK(ctx, hipMemcpyAsync(nb, baseB, 3 * rowBytes, hipMemcpyDeviceToDevice, st));
-      LRA_HIP_CHECK(ctx, hipStreamSynchronize(st));
-      (void)hipFree(ctx->scratch[3]);
-      ctx->scratch[3] = nb; ctx->scratch_bytes[3] = want;
-      baseB = (char*)nb;
-      rowS = (int32_t*)baseB; rowE = (int32_t*)(baseB + rowBytes); rowC = (uint32_t*)(baseB + 2 * rowBytes);
-    }
-    unsigned char* path = (unsigned char*)(baseB + 3 * rowBytes);
+    scan(ctx, (long)n_seg, s_tmpcap, s_tmp_off);
+    uint64_t n_tmp = 0;
+    if (d2h(ctx, &n_cells, s_cell_off + n_seg, 8) || d2h(ctx, &n_tmp, s_tmp_off + n_seg, 8)) return LRA_ERR_HIP;
+    unsigned char* path = (unsigned char*)lra_ensure(ctx, 1, n_cells + 256);
+    int32_t* tmpb = (int32_t*)lra_ensure(ctx, 2, (n_tmp + 1) * 12);
+    if (!path || !tmpb) return LRA_ERR_NOMEM;
+    tmp_blocks = tmpb;
+    LRA_HIP_CHECK(ctx, hipMemsetAsync(fill_counts, 0, 64, st));
+    hipLaunchKernelGGL(ir_classify, dim3((unsigned)((n_seg + 255) / 256)), dim3(256), 0, st, n_seg, A.s_kind, s_status, s_width, fill_counts, fill_lists);
     FillArgs F;
-    F.n_seg = n_seg; F.s_aln = A.s_aln; F.s_kind = A.s_kind; F.s_tStart = A.s_tStart; F.s_rows = A.s_rows; F.s_row_off = s_row_off;
-    F.s_cells = s_cells; F.s_cell_off = s_cell_off; F.s_status = s_status; F.rowS = rowS; F.rowE = rowE; F.rowC = rowC;
-    F.qseq = d_qseq; F.q_off = d_q_off; F.tseq = d_tseq; F.t_off = d_t_off; F.match = match; F.mismatch = mismatch; F.g = indel; F.path = path;
+    F.n_seg = n_seg; F.s_aln = A.s_aln; F.s_rows = A.s_rows; F.s_row_off = s_row_off; F.s_cell_off = s_cell_off; F.rows = rows;
+    F.qseq = d_qseq; F.q_off = d_q_off; F.match = match; F.mismatch = mismatch; F.g = indel; F.path = path;
+    F.counts = fill_counts; F.lists = fill_lists;
+    const unsigned cap_grid = (unsigned)ctx->num_cu * 32;
     lra_time_begin(ctx, "ir_fill");
-    hipLaunchKernelGGL(ir_fill, dim3(gridW), dim3(64), 0, st, F);
+    hipLaunchKernelGGL(ir_fill<16>, dim3((unsigned)std::min<uint64_t>((n_seg + 3) / 4, cap_grid)), dim3(64), 0, st, F);
+    hipLaunchKernelGGL(ir_fill<32>, dim3((unsigned)std::min<uint64_t>((n_seg + 1) / 2, cap_grid)), dim3(64), 0, st, F);
+    hipLaunchKernelGGL(ir_fill<64>, dim3((unsigned)std::min<uint64_t>(n_seg, cap_grid)), dim3(64), 0, st, F);
     lra_time_end(ctx);
     TraceArgs T;
-    T.n_seg = n_seg; T.s_kind = A.s_kind; T.s_qStart = A.s_qStart; T.s_tStart = A.s_tStart; T.s_rows = A.s_rows; T.s_row_off = s_row_off;
-    T.s_cells = s_cells; T.s_cell_off = s_cell_off; T.s_status = s_status; T.rowS = rowS; T.rowE = rowE; T.rowC = rowC; T.path = path;
-    T.s_nblk = s_nblk; T.s_nq = s_nq; T.s_nt = s_nt; T.s_out_off = nullptr; T.out_blocks = nullptr;
-    lra_time_begin(ctx, "ir_trace_count");
-    hipLaunchKernelGGL(ir_trace<false>, dim3(gridW), dim3(64), 0, st, T);
+    T.n_seg = n_seg; T.s_kind = A.s_kind; T.s_tStart = A.s_tStart; T.s_rows = A.s_rows; T.s_row_off = s_row_off;
+    T.s_cells = s_cells; T.s_cell_off = s_cell_off; T.s_status = s_status; T.rows = rows; T.path = path;
+    T.s_nblk = s_nblk; T.s_tmp_off = s_tmp_off; T.tmp_blocks = tmpb;
+    lra_time_begin(ctx, "ir_trace");
+    hipLaunchKernelGGL(ir_trace_lane, dim3(gridL), dim3(64), 0, st, T);
     lra_time_end(ctx);
     // ---- short segments -> AffineOneGapAlign (:344-357)
-    int32_t* aog_blocks = nullptr;
     if (n_aog) {
       hipLaunchKernelGGL(ir_aog_setup, dim3((unsigned)((n_seg + 255) / 256)), dim3(256), 0, st, n_seg, A.s_kind, A.s_aln, s_aog_off, A.s_qStart,
                          A.s_tStart, A.s_qEnd, A.s_tEnd, d_q_off, d_t_off, refine_band, s_aog_idx, p_q_off, p_q_len, p_t_off, p_t_len, p_k, p_cap);
       scan(ctx, (long)n_aog, p_cap, p_block_off);
       uint64_t aog_cap = 0;
       if (d2h(ctx, &aog_cap, p_block_off + n_aog, 8)) return LRA_ERR_HIP;
-      // AOG uses scratch slots 0/1; its blocks go to the tail of arena A's slot? use a dedicated hipMalloc-backed buffer in ctx
       if (aog_cap * 12 + 64 > ctx->aux_bytes) {
         if (ctx->aux) (void)hipFree(ctx->aux);
         ctx->aux = nullptr; ctx->aux_bytes = 0;
@@ -779,18 +758,14 @@ extern "C" int lra_indel_refine_batch(lra_ctx* ctx, int n_aln, const int32_t* d_
         if (hipMalloc(&ctx->aux, want) != hipSuccess) return lra_set_err(ctx, LRA_ERR_NOMEM, "aog block buffer");
         ctx->aux_bytes = want;
       }
-      aog_blocks = (int32_t*)ctx->aux;
       int rc = lra_aog_launch_device(ctx, (int)n_aog, d_qseq, d_tseq, p_q_off, p_q_len, p_t_off, p_t_len, p_k, match, mismatch, indel, p_score,
-                                     p_nblocks, aog_blocks, p_block_off, p_status);
+                                     p_nblocks, (int32_t*)ctx->aux, p_block_off, p_status);
       if (rc) return rc;
     }
-    // ---- output sizing
-    hipLaunchKernelGGL(ir_item_counts, dim3((unsigned)((n_item + 255) / 256)), dim3(256), 0, st, n_item, A.i_kind, A.i_data, i_aln, seg_off, A.s_kind,
-                       s_nblk, s_aog_idx, p_nblocks, i_count);
-  } else {
-    hipLaunchKernelGGL(ir_item_counts, dim3((unsigned)((n_item + 255) / 256)), dim3(256), 0, st, n_item, A.i_kind, A.i_data, i_aln, seg_off, A.s_kind,
-                       s_nblk, s_aog_idx, p_nblocks, i_count);
   }
+  // ---- output sizing and assembly
+  hipLaunchKernelGGL(ir_item_counts, dim3((unsigned)((n_item + 255) / 256)), dim3(256), 0, st, n_item, A.i_kind, A.i_data, i_aln, seg_off, A.s_kind,
+                     s_nblk, s_aog_idx, p_nblocks, i_count);
   scan(ctx, (long)n_item, i_count, i_out_off);
   uint64_t n_out = 0;
   if (d2h(ctx, &n_out, i_out_off + n_item, 8)) return LRA_ERR_HIP;
@@ -802,26 +777,16 @@ extern "C" int lra_indel_refine_batch(lra_ctx* ctx, int n_aln, const int32_t* d_
     ctx->out_bytes = want;
   }
   int32_t* out_blocks = (int32_t*)ctx->out_buf;
-  // per-alignment offsets = out offset of its first item; per-segment out offset = its item's
   hipLaunchKernelGGL(ir_finalize_offsets, dim3((unsigned)((std::max<uint64_t>(n_item, nA + 1) + 255) / 256)), dim3(256), 0, st, n_aln, n_item, item_off,
                      i_out_off, A.i_kind, A.i_data, i_aln, seg_off, s_out_off, out_block_off);
-  if (n_seg) {
-    TraceArgs T;
-    T.n_seg = n_seg; T.s_kind = A.s_kind; T.s_qStart = A.s_qStart; T.s_tStart = A.s_tStart; T.s_rows = A.s_rows; T.s_row_off = s_row_off;
-    T.s_cells = s_cells; T.s_cell_off = s_cell_off; T.s_status = s_status; T.rowS = rowS; T.rowE = rowE; T.rowC = rowC;
-    T.path = (unsigned char*)((char*)ctx->scratch[3] + 3 * ((n_rows * 4 + 255) & ~(size_t)255));
-    T.s_nblk = s_nblk; T.s_nq = s_nq; T.s_nt = s_nt; T.s_out_off = s_out_off; T.out_blocks = out_blocks;
-    const unsigned gridW = (unsigned)std::min<uint64_t>(n_seg, (uint64_t)ctx->num_cu * 32);
-    lra_time_begin(ctx, "ir_trace_emit");
-    hipLaunchKernelGGL(ir_trace<true>, dim3(gridW), dim3(64), 0, st, T);
-    lra_time_end(ctx);
-  }
   GatherArgs G;
   G.n_item = n_item; G.i_kind = A.i_kind; G.i_data = A.i_data; G.i_aln = i_aln; G.i_out_off = i_out_off; G.seg_off = seg_off;
   G.s_kind = A.s_kind; G.s_qStart = A.s_qStart; G.s_tStart = A.s_tStart; G.s_aog_idx = s_aog_idx;
-  G.aog_blocks = (const int32_t*)ctx->aux; G.aog_block_off = p_block_off; G.aog_nblocks = p_nblocks; G.out_blocks = out_blocks;
-  if (n_item) hipLaunchKernelGGL(ir_gather, dim3((unsigned)std::min<uint64_t>(n_item, 65535)), dim3(64), 0, st, G);
-  // per-alignment status = OR over its segments
+  G.aog_blocks = (const int32_t*)ctx->aux; G.aog_block_off = p_block_off; G.aog_nblocks = p_nblocks;
+  G.tmp_blocks = tmp_blocks; G.s_tmp_off = s_tmp_off; G.s_nblk = s_nblk; G.out_blocks = out_blocks;
+  lra_time_begin(ctx, "ir_gather");
+  if (n_item) hipLaunchKernelGGL(ir_gather, dim3((unsigned)std::min<uint64_t>(n_item, 65535 * 4)), dim3(64), 0, st, G);
+  lra_time_end(ctx);
   hipLaunchKernelGGL(ir_aln_status, dim3((n_aln + 255) / 256), dim3(256), 0, st, n_aln, seg_off, A.s_kind, s_status, s_aog_idx, p_status, A.a_status);
   LRA_HIP_CHECK(ctx, hipGetLastError());
   LRA_HIP_CHECK(ctx, hipStreamSynchronize(st));

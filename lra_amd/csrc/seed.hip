@@ -25,6 +25,7 @@
 // state machines) and across query tuples (one lane per tuple for the index searches,
 // which are the HBM-heavy part).
 #include "common.h"
+#include "scan.h"
 
 namespace {
 
@@ -420,7 +421,8 @@ __global__ void __launch_bounds__(64) sort_kernel(int n_reads, const uint64_t* _
 //      returns cut = min(a_{m+1}, b_m).  Ranks come from prefix counts, swaps are independent.
 // The final insertion sort is stable, and the <=16-element leftovers are mutually ordered, so
 // it equals a stable insertion sort of every leftover block on its own.
-constexpr int SORT_NT = 256;
+constexpr int SORT_NT = 1024;
+constexpr int SORT_NW = SORT_NT / 64;
 constexpr unsigned short S_NONE = 0xFFFF;
 
 struct LdsSeg {                     // (key, original index) pairs in LDS
@@ -506,7 +508,7 @@ __global__ void __launch_bounds__(SORT_NT) sort_wg_kernel(int n_reads, const uin
   unsigned short* sM = sRid + maxseg;
   unsigned int* startBits = (unsigned int*)(sM + maxseg + (maxseg & 1));   // leftover-block start markers, cap/32+1 words
   __shared__ int cnt[4];                    // nseg, nnext
-  __shared__ unsigned int waveTot[8];
+  __shared__ unsigned int waveTot[2 * SORT_NW];
   uint32_t* t32 = tscratch + (size_t)blockIdx.x * (size_t)(cap + 64);
   LdsSeg S{key, idx};
   for (int r = blockIdx.x; r < n_reads; r += gridDim.x) {
@@ -544,7 +546,7 @@ __global__ void __launch_bounds__(SORT_NT) sort_wg_kernel(int n_reads, const uin
       __syncthreads();
       // (b) exclusive prefix counts of the two stopper flags over all positions (wave w owns a
       //     contiguous range; ballots give in-row ranks)
-      const int rows = (n + 63) / 64, rpw = (rows + 3) / 4;
+      const int rows = (n + 63) / 64, rpw = (rows + SORT_NW - 1) / SORT_NW;
       const int r0 = wave * rpw, r1 = min(rows, r0 + rpw);
       auto flags = [&](int p, bool& A, bool& B) {
         A = false; B = false;
@@ -561,10 +563,10 @@ __global__ void __launch_bounds__(SORT_NT) sort_wg_kernel(int n_reads, const uin
         bool A, B; flags(rw * 64 + lane, A, B);
         totA += __popcll(__ballot(A)); totB += __popcll(__ballot(B));
       }
-      if (lane == 0) { waveTot[wave] = totA; waveTot[4 + wave] = totB; }
+      if (lane == 0) { waveTot[wave] = totA; waveTot[SORT_NW + wave] = totB; }
       __syncthreads();
       unsigned int baseA = 0, baseB = 0;
-      for (int w = 0; w < wave; w++) { baseA += waveTot[w]; baseB += waveTot[4 + w]; }
+      for (int w = 0; w < wave; w++) { baseA += waveTot[w]; baseB += waveTot[SORT_NW + w]; }
       const unsigned long long below = (lane == 0) ? 0ULL : (~0ULL >> (64 - lane));
       for (int rw = r0; rw < r1; rw++) {
         const int p = rw * 64 + lane;
@@ -573,7 +575,7 @@ __global__ void __launch_bounds__(SORT_NT) sort_wg_kernel(int n_reads, const uin
         if (p <= n) t32[p] = ((baseA + __popcll(mA & below)) & 0xFFFF) | ((baseB + __popcll(mB & below)) << 16);
         baseA += __popcll(mA); baseB += __popcll(mB);
       }
-      if (wave == 3 && lane == 0 && (n & 63) == 0) t32[n] = (baseA & 0xFFFF) | (baseB << 16);   // prefix at n when n is a row boundary
+      if (wave == SORT_NW - 1 && lane == 0 && (n & 63) == 0) t32[n] = (baseA & 0xFFFF) | (baseB << 16);   // prefix at n when n is a row boundary
       __syncthreads();
       // (c) scatter stopper positions: pa ascending, pb descending, both stored from first+1
       for (int p = tid; p < n; p += SORT_NT) {
@@ -655,17 +657,41 @@ __global__ void __launch_bounds__(SORT_NT) sort_wg_kernel(int n_reads, const uin
 // (i) per query tuple: global lower/upper bound of its masked key in the index.  Because the
 // index is sorted by masked key, lower_bound over any sub-range [ts,te) is the global bound
 // clamped to [ts,te] -- so the serial walk of CompareLists needs no searches of its own.
+// A bucket directory over the top bits of the masked key (built once at index load) confines each
+// search to a handful of entries: dir[b] = first index whose (key >> shift) >= b.
+__global__ void dir_build_kernel(uint32_t nbuckets, int shift, const uint64_t* __restrict__ idx_key, uint64_t n_idx, uint32_t* __restrict__ dir) {
+  uint64_t b = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (b > nbuckets) return;
+  if (b == nbuckets) { dir[b] = (uint32_t)n_idx; return; }
+  const uint64_t q = b << shift;
+  uint64_t lo = 0, hi = n_idx;
+  while (lo < hi) { uint64_t mid = lo + ((hi - lo) >> 1); if ((idx_key[mid] & FOR_MASK) < q) lo = mid + 1; else hi = mid; }
+  dir[b] = (uint32_t)lo;
+}
+
+// Also hands the walk the index keys it will look at when it lands on these bounds (T[lb], T[lb-1],
+// T[ub-1]), so the serial walk itself makes no dependent loads from the index.
 __global__ void bounds_kernel(uint64_t total, const uint64_t* __restrict__ mm_key, const uint64_t* __restrict__ idx_key,
-                              uint64_t n_idx, uint32_t* __restrict__ lb, uint32_t* __restrict__ ub) {
+                              uint64_t n_idx, const uint32_t* __restrict__ dir, uint32_t nbuckets, int shift,
+                              uint32_t* __restrict__ lb, uint32_t* __restrict__ ub, uint64_t* __restrict__ tk_lb,
+                              uint64_t* __restrict__ tk_lbm1, uint64_t* __restrict__ tk_ubm1) {
   uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= total) return;
   const uint64_t q = mm_key[i] & FOR_MASK;
-  uint64_t lo = 0, hi = n_idx;
+  uint64_t bkt = q >> shift;
+  if (bkt >= nbuckets) bkt = nbuckets - 1;
+  uint64_t lo = dir[bkt], hi = dir[bkt + 1];
+  if (bkt == nbuckets - 1) hi = n_idx;
+  const uint64_t hi0 = hi;
   while (lo < hi) { uint64_t mid = lo + ((hi - lo) >> 1); if ((idx_key[mid] & FOR_MASK) < q) lo = mid + 1; else hi = mid; }
-  lb[i] = (uint32_t)lo;
-  hi = n_idx;                                                          // upper bound starts from lo
+  const uint64_t l = lo;
+  hi = hi0;
   while (lo < hi) { uint64_t mid = lo + ((hi - lo) >> 1); if (!(q < (idx_key[mid] & FOR_MASK))) lo = mid + 1; else hi = mid; }
-  ub[i] = (uint32_t)lo;
+  const uint64_t u = lo;
+  lb[i] = (uint32_t)l; ub[i] = (uint32_t)u;
+  tk_lb[i] = (l < n_idx) ? idx_key[l] : 0;
+  tk_lbm1[i] = (l > 0) ? idx_key[l - 1] : 0;
+  tk_ubm1[i] = (u > 0) ? idx_key[u - 1] : 0;
 }
 
 // per-read upper bound on emitted pairs: a (query tuple, index tuple) pair with equal keys can be
@@ -681,9 +707,13 @@ __global__ void __launch_bounds__(64) match_capacity_kernel(int n_reads, const u
   }
 }
 
-// (ii) the alternating two-ended walk of CompareLists.h:43-143, one lane per read.
+// (ii) the alternating two-ended walk of CompareLists.h:43-143, one lane per read.  T[ts] and
+// T[te-1] live in registers and are refreshed from the prefetched neighbourhood arrays whenever
+// ts / te jump to a bound; only the raw-key run skip (:101) still reads the index itself.
 __global__ void __launch_bounds__(64) compare_kernel(int n_reads, const uint64_t* __restrict__ mm_off, const uint64_t* __restrict__ mm_key,
                                                      const uint32_t* __restrict__ lbA, const uint32_t* __restrict__ ubA,
+                                                     const uint64_t* __restrict__ tkLbA, const uint64_t* __restrict__ tkLbm1A,
+                                                     const uint64_t* __restrict__ tkUbm1A,
                                                      const uint64_t* __restrict__ idx_key, long n_idx, long maxFreq,
                                                      const uint64_t* __restrict__ match_off, uint32_t* __restrict__ match_qi,
                                                      uint32_t* __restrict__ match_ti, uint64_t* __restrict__ counts) {
@@ -692,55 +722,69 @@ __global__ void __launch_bounds__(64) compare_kernel(int n_reads, const uint64_t
   const uint64_t* qk = mm_key + mm_off[r];
   const uint32_t* LB = lbA + mm_off[r];
   const uint32_t* UB = ubA + mm_off[r];
+  const uint64_t* TKLB = tkLbA + mm_off[r];
+  const uint64_t* TKLBM1 = tkLbm1A + mm_off[r];
+  const uint64_t* TKUBM1 = tkUbm1A + mm_off[r];
   const long nq = (long)(mm_off[r + 1] - mm_off[r]);
   const long nt = n_idx;
-  constexpr bool EMIT = true;
   uint32_t* oq = match_qi + match_off[r];
   uint32_t* ot = match_ti + match_off[r];
   const uint64_t room = match_off[r + 1] - match_off[r];
   uint64_t n = 0;
   const uint64_t M = FOR_MASK;
 #define Qm(i) (qk[(i)] & M)
-#define Tm(i) (idx_key[(i)] & M)
   if (nq != 0 && nt != 0) {                                            // :27-30
     long qs = 0, qe = nq - 1, ts = 0, te = nt;
+    uint64_t Tts = idx_key[0], Tte1 = idx_key[nt - 1];                 // raw T[ts], T[te-1]
     do {
-      while (qs <= qe && Qm(qs) < Tm(ts)) qs++;                        // :47-49
+      while (qs <= qe && Qm(qs) < (Tts & M)) qs++;                     // :47-49
       if (qs >= qe) break;                                             // :51-53
-      uint64_t startGap = Qm(qs) - Tm(ts);
-      while (qe > qs && te > ts && Qm(qe) > Tm(te - 1)) qe--;          // :63-65
-      uint64_t endGap = Tm(te - 1) - Qm(qe);
+      const uint64_t Qs = Qm(qs);
+      uint64_t startGap = Qs - (Tts & M);
+      while (qe > qs && te > ts && Qm(qe) > (Tte1 & M)) qe--;          // :63-65
+      const uint64_t Qe = Qm(qe);
+      uint64_t endGap = (Tte1 & M) - Qe;
       if (startGap == 0 || (startGap & M) > (endGap & M)) {            // :69
         const long tsOrig = ts, qsOrig = qs;
-        long lo = (long)LB[qs];                                        // lower_bound on [ts,te)  (:76)
-        ts = lo < ts ? ts : (lo > te ? te : lo);
-        if (ts < te && Tm(ts) == Qm(qs)) {
+        const uint64_t rawOrig = Tts;
+        const long lo = (long)LB[qs];                                  // lower_bound on [ts,te)  (:76)
+        if (lo > ts) {
+          if (lo >= te) ts = te;
+          else { ts = lo; Tts = TKLB[qs]; }
+        }
+        if (ts < te && (Tts & M) == Qs) {
           const uint32_t tsStart = (uint32_t)ts;
           uint32_t tsi = (uint32_t)ts;
           { long e = (long)UB[qs]; e = e > te ? te : e; if (e > (long)tsi) tsi = (uint32_t)e; }   // end of the equal run inside [ts,te)
           const uint32_t qsStart = (uint32_t)qs;
-          while (qs < qe && Qm(qs + 1) == Qm(qs)) qs++;
+          while (qs < qe && Qm(qs + 1) == Qs) qs++;
           if (qs - (long)qsStart < maxFreq) {
             for (uint32_t ti = tsStart; ti != tsi; ti++)
               for (uint32_t qi = qsStart; (long)qi <= qs; qi++) {
-                if (EMIT && n < room) { oq[n] = qi; ot[n] = ti; }
+                if (n < room) { oq[n] = qi; ot[n] = ti; }
                 n++;
               }
           }
         }
-        { const uint64_t raw = idx_key[tsOrig]; while (ts < te && idx_key[ts] == raw) ts++; }   // :101
+        if (ts == tsOrig) {                                            // :101 (a jump lands on a different key: no skip)
+          while (ts < te && Tts == rawOrig) { ts++; if (ts < nt) Tts = idx_key[ts]; }
+        }
         { const uint64_t raw = qk[qsOrig]; while (qs < qe && qk[qs] == raw) qs++; }             // :102
       } else {
-        if (te != nt && Tm(te - 1) == Qm(qe)) {                        // :112-114
+        if (te != nt && (Tte1 & M) == Qe) {                            // :112-114
         } else {                                                       // upper_bound on [ts,te) (:116-118)
-          long hi = (long)UB[qe];
-          te = hi < ts ? ts : (hi > te ? te : hi);
+          const long hi = (long)UB[qe];
+          if (hi < te) {
+            if (hi <= ts) te = ts;
+            else { te = hi; Tte1 = TKUBM1[qe]; }
+          }
         }
         const uint32_t teStart = (uint32_t)te;
         uint32_t tei = (uint32_t)te;
-        if ((long)tei > ts && Tm(tei - 1) == Qm(qe)) {                 // start of the equal run inside [ts,te)
-          long b = (long)LB[qe]; b = b < ts ? ts : b;
-          tei = (uint32_t)b;
+        if ((long)tei > ts && (Tte1 & M) == Qe) {                      // start of the equal run inside [ts,te)
+          long b = (long)LB[qe];
+          if (b <= ts) tei = (uint32_t)ts;
+          else { tei = (uint32_t)b; Tte1 = TKLBM1[qe]; }
         }
         if (tei < teStart && teStart > 0) {
           const uint32_t qeStart = (uint32_t)qe;
@@ -748,7 +792,7 @@ __global__ void __launch_bounds__(64) compare_kernel(int n_reads, const uint64_t
           if ((long)qeStart - qe < maxFreq) {
             for (uint32_t ti = tei; ti < teStart; ti++)
               for (uint32_t qi = (uint32_t)qe; qi <= qeStart; qi++) {
-                if (EMIT && n < room) { oq[n] = qi; ot[n] = ti; }
+                if (n < room) { oq[n] = qi; ot[n] = ti; }
                 n++;
               }
           }
@@ -758,7 +802,6 @@ __global__ void __launch_bounds__(64) compare_kernel(int n_reads, const uint64_t
     } while (qs < qe && ts < te);
   }
 #undef Qm
-#undef Tm
   counts[r] = n;
 }
 
@@ -823,26 +866,6 @@ __global__ void __launch_bounds__(64) strand_kernel(int n_reads, const unsigned 
 
 // ------------------------------------------------------------------------------------ scans
 // exclusive scan of n (<= a few million) counts into n+1 offsets; one workgroup.
-template <typename CT>
-__global__ void __launch_bounds__(1024) scan_kernel(long n, const CT* __restrict__ counts, uint64_t* __restrict__ off) {
-  __shared__ uint64_t part[1024];
-  const int t = threadIdx.x;
-  const long per = (n + 1023) / 1024;
-  const long lo = (long)t * per, hi = (lo + per < n) ? lo + per : n;
-  uint64_t s = 0;
-  for (long i = lo; i < hi; i++) s += (uint64_t)counts[i];
-  part[t] = s;
-  __syncthreads();
-  for (int d = 1; d < 1024; d <<= 1) {
-    uint64_t v = (t >= d) ? part[t - d] : 0;
-    __syncthreads();
-    part[t] += v;
-    __syncthreads();
-  }
-  uint64_t run = (t == 0) ? 0 : part[t - 1];
-  for (long i = lo; i < hi; i++) { off[i] = run; run += (uint64_t)counts[i]; }
-  if (t == 1023) off[n] = part[1023];
-}
 
 }  // namespace
 
@@ -854,6 +877,8 @@ struct lra_seed_state {
   uint32_t* counts32 = nullptr; uint64_t* counts64 = nullptr; uint64_t* mm_off = nullptr; uint64_t* match_off = nullptr;
   uint32_t* n_forward = nullptr; size_t cap_reads = 0;
   uint64_t* mm_key = nullptr; uint32_t* mm_pos = nullptr; uint32_t* lb = nullptr; uint32_t* ub = nullptr; size_t cap_mm = 0;
+  uint64_t* tk_lb = nullptr; uint64_t* tk_lbm1 = nullptr; uint64_t* tk_ubm1 = nullptr;
+  uint32_t* dir = nullptr; uint32_t nbuckets = 0; int dir_shift = 0;
   uint32_t* match_qi = nullptr; uint32_t* match_ti = nullptr; uint32_t* sep_qpos = nullptr; uint32_t* sep_tpos = nullptr; size_t cap_match = 0;
   uint32_t* tmp_qi = nullptr; uint32_t* tmp_ti = nullptr; size_t cap_tmp = 0; uint64_t* cap_cnt = nullptr; uint64_t* cap_off = nullptr;
 };
@@ -874,7 +899,7 @@ void lra_seed_free(lra_ctx* ctx) {
   lra_seed_state* s = ctx->seed;
   if (!s) return;
   void* ptrs[] = {s->genome, s->idx_key, s->idx_pos, s->counts32, s->counts64, s->mm_off, s->match_off, s->n_forward,
-                  s->mm_key, s->mm_pos, s->lb, s->ub, s->match_qi, s->match_ti, s->sep_qpos, s->sep_tpos, s->tmp_qi, s->tmp_ti, s->cap_cnt, s->cap_off};
+                  s->mm_key, s->mm_pos, s->lb, s->ub, s->match_qi, s->match_ti, s->sep_qpos, s->sep_tpos, s->tmp_qi, s->tmp_ti, s->cap_cnt, s->cap_off, s->tk_lb, s->tk_lbm1, s->tk_ubm1, s->dir};
   for (void* p : ptrs) if (p) (void)hipFree(p);
   delete s;
   ctx->seed = nullptr;
@@ -899,6 +924,17 @@ extern "C" int lra_ctx_load_global_index(lra_ctx* ctx, const uint64_t* h_key, co
   s->n_idx = n;
   LRA_HIP_CHECK(ctx, hipMemcpy(s->idx_key, h_key, n * 8, hipMemcpyHostToDevice));
   LRA_HIP_CHECK(ctx, hipMemcpy(s->idx_pos, h_pos, n * 4, hipMemcpyHostToDevice));
+  // bucket directory: ~2 buckets per entry, on the top bits of the largest masked key
+  int dbits = 1;
+  while ((1ULL << dbits) < 2 * n && dbits < 27) dbits++;
+  const uint64_t maxkey = n ? (h_key[n - 1] & FOR_MASK) : 0;
+  int kbits = 1;
+  while (kbits < 63 && (maxkey >> kbits)) kbits++;
+  s->dir_shift = kbits > dbits ? kbits - dbits : 0;
+  s->nbuckets = (uint32_t)((maxkey >> s->dir_shift) + 1);
+  if (!regrow(s->dir, (size_t)s->nbuckets + 2)) return lra_set_err(ctx, LRA_ERR_NOMEM, "index directory");
+  hipLaunchKernelGGL(dir_build_kernel, dim3((s->nbuckets + 256) / 256), dim3(256), 0, ctx->stream, s->nbuckets, s->dir_shift, s->idx_key, n, s->dir);
+  LRA_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
   return LRA_OK;
 }
 
@@ -965,14 +1001,15 @@ extern "C" int lra_seed_batch(lra_ctx* ctx, int n_reads, const char* d_seq, cons
   hipLaunchKernelGGL(sketch_kernel<false>, dim3(nb), dim3(64), 0, st, n_reads, seq, d_read_off, k, w, (const uint64_t*)nullptr,
                      (uint64_t*)nullptr, (uint32_t*)nullptr, s->counts32, (const int*)flagN);
   lra_time_end(ctx);
-  hipLaunchKernelGGL(scan_kernel<uint32_t>, dim3(1), dim3(1024), 0, st, (long)n_reads, s->counts32, s->mm_off);
+  if (lra_exclusive_scan<uint32_t>(ctx, (long)n_reads, s->counts32, s->mm_off)) return LRA_ERR_HIP;
   uint64_t total_mm = 0;
   LRA_HIP_CHECK(ctx, hipMemcpyAsync(&total_mm, s->mm_off + n_reads, 8, hipMemcpyDeviceToHost, st));
   LRA_HIP_CHECK(ctx, hipStreamSynchronize(st));
   if (total_mm >= (1ULL << 32)) return lra_set_err(ctx, LRA_ERR_INVALID, "batch too large: %llu minimizers", (unsigned long long)total_mm);
   if (total_mm > s->cap_mm) {
     size_t c = total_mm + total_mm / 4 + 1024;
-    if (!regrow(s->mm_key, c) || !regrow(s->mm_pos, c) || !regrow(s->lb, c) || !regrow(s->ub, c))
+    if (!regrow(s->mm_key, c) || !regrow(s->mm_pos, c) || !regrow(s->lb, c) || !regrow(s->ub, c) || !regrow(s->tk_lb, c) ||
+        !regrow(s->tk_lbm1, c) || !regrow(s->tk_ubm1, c))
       return lra_set_err(ctx, LRA_ERR_NOMEM, "minimizer arrays");
     s->cap_mm = c;
   }
@@ -990,11 +1027,11 @@ extern "C" int lra_seed_batch(lra_ctx* ctx, int n_reads, const char* d_seq, cons
   if (total_mm) {
     lra_time_begin(ctx, "index_bounds");
     hipLaunchKernelGGL(bounds_kernel, dim3((unsigned)((total_mm + 255) / 256)), dim3(256), 0, st, total_mm, s->mm_key, s->idx_key, s->n_idx,
-                       s->lb, s->ub);
+                       s->dir, s->nbuckets, s->dir_shift, s->lb, s->ub, s->tk_lb, s->tk_lbm1, s->tk_ubm1);
     lra_time_end(ctx);
   }
   hipLaunchKernelGGL(match_capacity_kernel, dim3(gridW), dim3(64), 0, st, n_reads, s->mm_off, s->lb, s->ub, s->cap_cnt);
-  hipLaunchKernelGGL(scan_kernel<uint64_t>, dim3(1), dim3(1024), 0, st, (long)n_reads, s->cap_cnt, s->cap_off);
+  if (lra_exclusive_scan<uint64_t>(ctx, (long)n_reads, s->cap_cnt, s->cap_off)) return LRA_ERR_HIP;
   uint64_t total_cap = 0;
   LRA_HIP_CHECK(ctx, hipMemcpyAsync(&total_cap, s->cap_off + n_reads, 8, hipMemcpyDeviceToHost, st));
   LRA_HIP_CHECK(ctx, hipStreamSynchronize(st));
@@ -1004,10 +1041,10 @@ extern "C" int lra_seed_batch(lra_ctx* ctx, int n_reads, const char* d_seq, cons
     s->cap_tmp = c;
   }
   lra_time_begin(ctx, "compare");
-  hipLaunchKernelGGL(compare_kernel, dim3(nb), dim3(64), 0, st, n_reads, s->mm_off, s->mm_key, s->lb, s->ub, s->idx_key,
+  hipLaunchKernelGGL(compare_kernel, dim3(nb), dim3(64), 0, st, n_reads, s->mm_off, s->mm_key, s->lb, s->ub, s->tk_lb, s->tk_lbm1, s->tk_ubm1, s->idx_key,
                      (long)s->n_idx, (long)max_freq, s->cap_off, s->tmp_qi, s->tmp_ti, s->counts64);
   lra_time_end(ctx);
-  hipLaunchKernelGGL(scan_kernel<uint64_t>, dim3(1), dim3(1024), 0, st, (long)n_reads, s->counts64, s->match_off);
+  if (lra_exclusive_scan<uint64_t>(ctx, (long)n_reads, s->counts64, s->match_off)) return LRA_ERR_HIP;
   uint64_t total_m = 0;
   LRA_HIP_CHECK(ctx, hipMemcpyAsync(&total_m, s->match_off + n_reads, 8, hipMemcpyDeviceToHost, st));
   LRA_HIP_CHECK(ctx, hipStreamSynchronize(st));
