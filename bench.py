@@ -92,7 +92,7 @@ def main():
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--genome-mb", type=float, default=float(os.environ.get("LRA_BENCH_GENOME_MB", 64)))
-    ap.add_argument("--reads", type=int, default=int(os.environ.get("LRA_BENCH_READS", 8192)), help="reads per GPU per step")
+    ap.add_argument("--reads", type=int, default=int(os.environ.get("LRA_BENCH_READS", 32768)), help="reads per GPU per step")
     ap.add_argument("--read-len", type=int, default=30000)
     ap.add_argument("--err", type=float, default=0.10)
     ap.add_argument("--k", type=int, default=17)          # -ONT: globalK 17, globalW 10 (lra.cpp:386-431)

@@ -115,6 +115,34 @@ int lra_seed_batch(lra_ctx* ctx, int n_reads, const char* d_seq, const uint64_t*
  * Asynchronous.                                                                               */
 int lra_sort_minimizers_batch(lra_ctx* ctx, int n_lists, const uint64_t* d_off, uint64_t* d_key, uint32_t* d_pos);
 
+/* ---- a5: match cleaning + diagonal clusters ----------------------------------------------
+ * Replaces, per read and strand,   CleanMatches(Matches, clusters, genome, read, opts, timing, ma_strand)
+ * (Clustering.h:1840) in the configuration every preset uses (opts.ExtractDiagonalFromClean, lra.cpp:268-431):
+ * DiagonalSort / AntiDiagonalSort (Sorting.h:50,113) -> CleanOffDiagonal (Clustering.h:566-798, incl.
+ * AVGfreq :550 and SecondRoundCleanOffDiagonal :802-868) -> one Cluster per surviving diagonal run
+ * (SetClusterBoundariesFromMatches :308, chromIndex = header.Find(tStart) Genome.h:20).
+ * Input: the forMatches / revMatches of lra_seed_batch (the context's current seed result).
+ * Output (device arrays owned by the context, CSR by read; forward-strand clusters first, as
+ * MapRead_lowacc builds `clusters`, Map_lowacc.h:77-78):
+ *   clusters: per cluster start/end into the cleaned match arrays, q/t box, strand, chromIndex, anchorfreq
+ *   cl_qpos / cl_tpos: the cleaned, diagonal-sorted matches (genome coordinates)                */
+typedef struct lra_clean_opts {
+  int32_t globalK, cleanMaxDiag, minDiagCluster, bypassClustering, cleanClustersize;
+  int32_t SecondCleanMinDiagCluster, SecondCleanMaxDiag, punish_anchorfreq, anchorPerlength;
+} lra_clean_opts;
+typedef struct lra_cluster_result {
+  int32_t n_reads;
+  uint64_t n_clusters, n_matches;
+  const uint64_t* d_cluster_off;  /* [n_reads+1] */
+  const uint64_t* d_c_start;      /* [n_clusters] first match of the cluster (index into d_cl_*) */
+  const uint64_t* d_c_end;        /* [n_clusters] one past its last match */
+  const uint32_t* d_c_qStart; const uint32_t* d_c_qEnd; const uint32_t* d_c_tStart; const uint32_t* d_c_tEnd;
+  const int32_t* d_c_strand; const int32_t* d_c_chrom; const float* d_c_anchorfreq;
+  const uint32_t* d_cl_qpos; const uint32_t* d_cl_tpos;   /* [n_matches] */
+} lra_cluster_result;
+int lra_clean_matches_batch(lra_ctx* ctx, const lra_clean_opts* opts, const uint64_t* h_chrom_pos, int n_chrom,
+                            lra_cluster_result* out);
+
 /* ---- a12: banded one-gap seed-extension DP ------------------------------------------
  * Replaces   int AffineOneGapAlign(string& qSeq, int qLen, string& tSeq, int tLen,
  *                                  int m, int mm, int indel, int k, Alignment& aln,

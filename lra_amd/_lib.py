@@ -34,6 +34,7 @@ SYMBOLS = {
     "lra_ctx_load_global_index": (C.c_int, [_vp, _vp, _vp, C.c_uint64]),
     "lra_sort_minimizers_batch": (C.c_int, [_vp, C.c_int, _vp, _vp, _vp]),
     "lra_seed_batch": (C.c_int, [_vp, C.c_int, _vp, _vp, C.c_int, C.c_int, C.c_int, _vp]),
+    "lra_clean_matches_batch": (C.c_int, [_vp, _vp, _vp, C.c_int, _vp]),
     "lra_indel_refine_batch": (C.c_int, [_vp, C.c_int, _vp, _vp, C.c_uint64, _vp, _vp, _vp, _vp, _vp, _vp, C.c_int, C.c_int,
                                           C.c_int, C.c_int, C.c_int, _vp]),
     "lra_affine_one_gap_align_batch": (C.c_int, [_vp, C.c_int, _vp, _vp, _vp, _vp, _vp, _vp, _vp, C.c_int, C.c_int,

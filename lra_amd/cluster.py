@@ -1,0 +1,37 @@
+"""Host-side mirror of CleanMatches (reference: Clustering.h:1840) for the current seed result of a context."""
+import ctypes as C
+
+import numpy as np
+
+from .context import Context
+
+
+class CleanOpts(C.Structure):
+    _fields_ = [(n, C.c_int32) for n in ("globalK", "cleanMaxDiag", "minDiagCluster", "bypassClustering", "cleanClustersize",
+                                         "SecondCleanMinDiagCluster", "SecondCleanMaxDiag", "punish_anchorfreq", "anchorPerlength")]
+
+
+class ClusterResult(C.Structure):
+    _fields_ = [("n_reads", C.c_int32), ("n_clusters", C.c_uint64), ("n_matches", C.c_uint64), ("d_cluster_off", C.c_void_p),
+                ("d_c_start", C.c_void_p), ("d_c_end", C.c_void_p), ("d_c_qStart", C.c_void_p), ("d_c_qEnd", C.c_void_p),
+                ("d_c_tStart", C.c_void_p), ("d_c_tEnd", C.c_void_p), ("d_c_strand", C.c_void_p), ("d_c_chrom", C.c_void_p),
+                ("d_c_anchorfreq", C.c_void_p), ("d_cl_qpos", C.c_void_p), ("d_cl_tpos", C.c_void_p)]
+
+
+def clean_matches_batch(ctx: Context, opts: CleanOpts, chrom_pos):
+    """chrom_pos = genome.header.pos (cumulative chromosome starts, n_chrom+1 entries)."""
+    cp = np.ascontiguousarray(chrom_pos, dtype=np.uint64)
+    res = ClusterResult()
+    ctx.check(ctx.lib.lra_clean_matches_batch(ctx.h, C.byref(opts), C.c_void_p(cp.ctypes.data), len(cp) - 1, C.byref(res)))
+    return res
+
+
+def fetch(ctx: Context, res: ClusterResult):
+    n, nc, nm = res.n_reads, res.n_clusters, res.n_matches
+    return {"cluster_off": ctx.to_host(res.d_cluster_off, n + 1, np.uint64),
+            "start": ctx.to_host(res.d_c_start, nc, np.uint64), "end": ctx.to_host(res.d_c_end, nc, np.uint64),
+            "qStart": ctx.to_host(res.d_c_qStart, nc, np.uint32), "qEnd": ctx.to_host(res.d_c_qEnd, nc, np.uint32),
+            "tStart": ctx.to_host(res.d_c_tStart, nc, np.uint32), "tEnd": ctx.to_host(res.d_c_tEnd, nc, np.uint32),
+            "strand": ctx.to_host(res.d_c_strand, nc, np.int32), "chrom": ctx.to_host(res.d_c_chrom, nc, np.int32),
+            "freq": ctx.to_host(res.d_c_anchorfreq, nc, np.float32),
+            "cl_qpos": ctx.to_host(res.d_cl_qpos, nm, np.uint32), "cl_tpos": ctx.to_host(res.d_cl_tpos, nm, np.uint32)}

@@ -815,7 +815,8 @@ __global__ void __launch_bounds__(64) strand_kernel(int n_reads, const unsigned 
                                                     const uint64_t* __restrict__ match_off, const uint64_t* __restrict__ src_off,
                                                     const uint32_t* __restrict__ src_qi, const uint32_t* __restrict__ src_ti,
                                                     uint32_t* __restrict__ match_qi, uint32_t* __restrict__ match_ti, uint32_t* __restrict__ sep_qpos,
-                                                    uint32_t* __restrict__ sep_tpos, uint32_t* __restrict__ n_forward) {
+                                                    uint32_t* __restrict__ sep_tpos, uint32_t* __restrict__ n_forward,
+                                                    const uint64_t* __restrict__ mm_key, uint64_t* __restrict__ sep_qkey) {
   const int lane = threadIdx.x;
   for (int r = blockIdx.x; r < n_reads; r += gridDim.x) {
     const unsigned char* read = seq_all + read_off[r];
@@ -846,8 +847,9 @@ __global__ void __launch_bounds__(64) strand_kernel(int n_reads, const unsigned 
       uint64_t i = base + lane;
       bool in = i < m1, fwd = false;
       uint32_t qp = 0, tp = 0;
+      uint64_t qk = 0;
       if (in) {
-        qp = qpos_of[match_qi[i]]; tp = idx_pos[match_ti[i]];
+        qp = qpos_of[match_qi[i]]; tp = idx_pos[match_ti[i]]; qk = mm_key[mm_off[r] + match_qi[i]];
         const unsigned char* a = read + qp;
         const unsigned char* b = genome + tp;
         fwd = true;
@@ -857,7 +859,7 @@ __global__ void __launch_bounds__(64) strand_kernel(int n_reads, const unsigned 
       unsigned long long below = (lane == 0) ? 0ULL : (~0ULL >> (64 - lane));
       if (in) {
         uint64_t dst = fwd ? fcur + __popcll(mf & below) : rcur + __popcll(mr & below);
-        sep_qpos[dst] = qp; sep_tpos[dst] = tp;
+        sep_qpos[dst] = qp; sep_tpos[dst] = tp; sep_qkey[dst] = qk;
       }
       fcur += __popcll(mf); rcur += __popcll(mr);
     }
@@ -870,18 +872,7 @@ __global__ void __launch_bounds__(64) strand_kernel(int n_reads, const unsigned 
 }  // namespace
 
 // ======================================================================================
-struct lra_seed_state {
-  unsigned char* genome = nullptr; uint64_t genome_len = 0;
-  uint64_t* idx_key = nullptr; uint32_t* idx_pos = nullptr; uint64_t n_idx = 0;
-  // batch buffers (grown on demand)
-  uint32_t* counts32 = nullptr; uint64_t* counts64 = nullptr; uint64_t* mm_off = nullptr; uint64_t* match_off = nullptr;
-  uint32_t* n_forward = nullptr; size_t cap_reads = 0;
-  uint64_t* mm_key = nullptr; uint32_t* mm_pos = nullptr; uint32_t* lb = nullptr; uint32_t* ub = nullptr; size_t cap_mm = 0;
-  uint64_t* tk_lb = nullptr; uint64_t* tk_lbm1 = nullptr; uint64_t* tk_ubm1 = nullptr;
-  uint32_t* dir = nullptr; uint32_t nbuckets = 0; int dir_shift = 0;
-  uint32_t* match_qi = nullptr; uint32_t* match_ti = nullptr; uint32_t* sep_qpos = nullptr; uint32_t* sep_tpos = nullptr; size_t cap_match = 0;
-  uint32_t* tmp_qi = nullptr; uint32_t* tmp_ti = nullptr; size_t cap_tmp = 0; uint64_t* cap_cnt = nullptr; uint64_t* cap_off = nullptr;
-};
+#include "seed_state.h"
 
 static lra_seed_state* seed_state(lra_ctx* ctx) {
   if (!ctx->seed) ctx->seed = new lra_seed_state();
@@ -899,7 +890,7 @@ void lra_seed_free(lra_ctx* ctx) {
   lra_seed_state* s = ctx->seed;
   if (!s) return;
   void* ptrs[] = {s->genome, s->idx_key, s->idx_pos, s->counts32, s->counts64, s->mm_off, s->match_off, s->n_forward,
-                  s->mm_key, s->mm_pos, s->lb, s->ub, s->match_qi, s->match_ti, s->sep_qpos, s->sep_tpos, s->tmp_qi, s->tmp_ti, s->cap_cnt, s->cap_off, s->tk_lb, s->tk_lbm1, s->tk_ubm1, s->dir};
+                  s->mm_key, s->mm_pos, s->lb, s->ub, s->match_qi, s->match_ti, s->sep_qpos, s->sep_tpos, s->tmp_qi, s->tmp_ti, s->cap_cnt, s->cap_off, s->tk_lb, s->tk_lbm1, s->tk_ubm1, s->dir, s->sep_qkey};
   for (void* p : ptrs) if (p) (void)hipFree(p);
   delete s;
   ctx->seed = nullptr;
@@ -1051,16 +1042,17 @@ extern "C" int lra_seed_batch(lra_ctx* ctx, int n_reads, const char* d_seq, cons
   if (total_m > total_cap) return lra_set_err(ctx, LRA_ERR_INVALID, "match capacity bound violated (%llu > %llu)", (unsigned long long)total_m, (unsigned long long)total_cap);
   if (total_m > s->cap_match) {
     size_t c = total_m + total_m / 4 + 1024;
-    if (!regrow(s->match_qi, c) || !regrow(s->match_ti, c) || !regrow(s->sep_qpos, c) || !regrow(s->sep_tpos, c))
+    if (!regrow(s->match_qi, c) || !regrow(s->match_ti, c) || !regrow(s->sep_qpos, c) || !regrow(s->sep_tpos, c) || !regrow(s->sep_qkey, c))
       return lra_set_err(ctx, LRA_ERR_NOMEM, "match arrays (%llu matches)", (unsigned long long)total_m);
     s->cap_match = c;
   }
   // ---- a4
   lra_time_begin(ctx, "strand");
   hipLaunchKernelGGL(strand_kernel, dim3(n_reads < 4096 ? n_reads : 4096), dim3(64), 0, st, n_reads, seq, d_read_off, s->genome, k, s->mm_off,
-                     s->mm_pos, s->idx_pos, s->match_off, s->cap_off, s->tmp_qi, s->tmp_ti, s->match_qi, s->match_ti, s->sep_qpos, s->sep_tpos, s->n_forward);
+                     s->mm_pos, s->idx_pos, s->match_off, s->cap_off, s->tmp_qi, s->tmp_ti, s->match_qi, s->match_ti, s->sep_qpos, s->sep_tpos, s->n_forward, s->mm_key, s->sep_qkey);
   lra_time_end(ctx);
   LRA_HIP_CHECK(ctx, hipGetLastError());
+  s->last_n_reads = n_reads; s->last_n_matches = total_m;
   out->n_minimizers = total_mm; out->n_matches = total_m;
   out->d_mm_off = s->mm_off; out->d_mm_key = s->mm_key; out->d_mm_pos = s->mm_pos;
   out->d_match_off = s->match_off; out->d_match_qi = s->match_qi; out->d_match_ti = s->match_ti;

@@ -1,0 +1,18 @@
+// lra_amd/csrc/seed_state.h -- device-resident state shared by the seeding (seed.hip) and clustering (cluster.hip) stages.
+#pragma once
+#include "common.h"
+
+struct lra_seed_state {
+  unsigned char* genome = nullptr; uint64_t genome_len = 0;
+  uint64_t* idx_key = nullptr; uint32_t* idx_pos = nullptr; uint64_t n_idx = 0;
+  // batch buffers (grown on demand)
+  uint32_t* counts32 = nullptr; uint64_t* counts64 = nullptr; uint64_t* mm_off = nullptr; uint64_t* match_off = nullptr;
+  uint32_t* n_forward = nullptr; size_t cap_reads = 0;
+  uint64_t* mm_key = nullptr; uint32_t* mm_pos = nullptr; uint32_t* lb = nullptr; uint32_t* ub = nullptr; size_t cap_mm = 0;
+  uint64_t* tk_lb = nullptr; uint64_t* tk_lbm1 = nullptr; uint64_t* tk_ubm1 = nullptr;
+  uint32_t* dir = nullptr; uint32_t nbuckets = 0; int dir_shift = 0;
+  uint32_t* match_qi = nullptr; uint32_t* match_ti = nullptr; uint32_t* sep_qpos = nullptr; uint32_t* sep_tpos = nullptr; uint64_t* sep_qkey = nullptr; size_t cap_match = 0;
+  int last_n_reads = 0; uint64_t last_n_matches = 0;   // shape of the current seed result (inputs of the clean stage)
+  uint32_t* tmp_qi = nullptr; uint32_t* tmp_ti = nullptr; size_t cap_tmp = 0; uint64_t* cap_cnt = nullptr; uint64_t* cap_off = nullptr;
+};
+

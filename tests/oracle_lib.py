@@ -114,3 +114,42 @@ def antiqsort_keys(n):
     out = np.zeros(n, dtype=np.uint64)
     L.oracle_antiqsort(n, _p(out, C.c_uint64))
     return out
+
+
+class CleanOpts(C.Structure):
+    _fields_ = [(n, C.c_int32) for n in ("globalK", "cleanMaxDiag", "minDiagCluster", "bypassClustering", "cleanClustersize",
+                                         "SecondCleanMinDiagCluster", "SecondCleanMaxDiag", "punish_anchorfreq", "anchorPerlength")]
+
+
+# (lra.cpp:268-431) the fields CleanMatches reads, per preset
+CLEAN_PRESETS = {
+    "ONT": dict(globalK=17, cleanMaxDiag=200, minDiagCluster=3, bypassClustering=1, cleanClustersize=100,
+                SecondCleanMinDiagCluster=10, SecondCleanMaxDiag=100, punish_anchorfreq=5, anchorPerlength=5),
+    "CLR": dict(globalK=15, cleanMaxDiag=200, minDiagCluster=3, bypassClustering=1, cleanClustersize=100,
+                SecondCleanMinDiagCluster=10, SecondCleanMaxDiag=120, punish_anchorfreq=5, anchorPerlength=5),
+    "CCS": dict(globalK=17, cleanMaxDiag=150, minDiagCluster=10, bypassClustering=0, cleanClustersize=100,
+                SecondCleanMinDiagCluster=30, SecondCleanMaxDiag=100, punish_anchorfreq=10, anchorPerlength=10),
+}
+
+
+def clean_matches(qpos, tpos, qkey, strand, opts: "CleanOpts", chrom_pos):
+    """One strand of one read.  Returns (out_q, out_t, clusters dict of arrays)."""
+    L = lib()
+    n = len(qpos)
+    qpos = np.ascontiguousarray(qpos, dtype=np.uint32); tpos = np.ascontiguousarray(tpos, dtype=np.uint32)
+    qkey = np.ascontiguousarray(qkey, dtype=np.uint64)
+    cp = np.ascontiguousarray(chrom_pos, dtype=np.uint64)
+    cap = max(1, n)
+    oq = np.zeros(cap, np.uint32); ot = np.zeros(cap, np.uint32)
+    cs = np.zeros(cap, np.int64); ce = np.zeros(cap, np.int64)
+    qs = np.zeros(cap, np.uint32); qe = np.zeros(cap, np.uint32); ts = np.zeros(cap, np.uint32); te = np.zeros(cap, np.uint32)
+    ch = np.zeros(cap, np.int32); fr = np.zeros(cap, np.float32)
+    nclean = C.c_long(0)
+    L.oracle_clean_matches.restype = C.c_long
+    ncl = L.oracle_clean_matches(_p(qpos, C.c_uint32), _p(tpos, C.c_uint32), _p(qkey, C.c_uint64), C.c_long(n), int(strand), C.byref(opts),
+                                 _p(cp, C.c_uint64), len(cp) - 1, _p(oq, C.c_uint32), _p(ot, C.c_uint32), C.byref(nclean),
+                                 _p(cs, C.c_long), _p(ce, C.c_long), _p(qs, C.c_uint32), _p(qe, C.c_uint32), _p(ts, C.c_uint32),
+                                 _p(te, C.c_uint32), _p(ch, C.c_int), _p(fr, C.c_float))
+    k = nclean.value
+    return oq[:k].copy(), ot[:k].copy(), dict(start=cs[:ncl].copy(), end=ce[:ncl].copy(), qStart=qs[:ncl].copy(), qEnd=qe[:ncl].copy(),
+                                              tStart=ts[:ncl].copy(), tEnd=te[:ncl].copy(), chrom=ch[:ncl].copy(), freq=fr[:ncl].copy())
