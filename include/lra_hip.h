@@ -143,6 +143,23 @@ typedef struct lra_cluster_result {
 int lra_clean_matches_batch(lra_ctx* ctx, const lra_clean_opts* opts, const uint64_t* h_chrom_pos, int n_chrom,
                             lra_cluster_result* out);
 
+/* ---- a7: linear extension of the cleaned clusters ------------------------------------------
+ * Replaces, per cluster of the context's current lra_clean_matches_batch result,
+ *   LinearExtend(&clusters[d].matches, ext.matches, ext.matchesLengths, opts, genome, read,
+ *                chromIndex, strand, 1, opts.globalK)            (LinearExtend.h:658-716, Checkbp :50-85)
+ *   DecideCoordinates(ext, strand, chromIndex, anchorfreq)        (LinearExtend.h:105-128)
+ * as MapRead_lowacc does (Map_lowacc.h:131-137; chromosome offsets handled inside).  d_seq/d_read_off:
+ * the reads of the batch (as given to lra_seed_batch).  Output: per cluster its extended anchors
+ * (read pos, genome pos, length) at [d_e_start[c], d_e_start[c] + d_e_count[c]) and its new box.    */
+typedef struct lra_extend_result {
+  uint64_t n_clusters, n_anchors_cap;
+  const uint64_t* d_e_start;      /* [n_clusters] */
+  const uint32_t* d_e_count;      /* [n_clusters] */
+  const uint32_t* d_e_qpos; const uint32_t* d_e_tpos; const int32_t* d_e_len;   /* [n_anchors_cap] */
+  const uint32_t* d_box;          /* [4*n_clusters] qStart,qEnd,tStart,tEnd */
+} lra_extend_result;
+int lra_linear_extend_batch(lra_ctx* ctx, int K, const char* d_seq, const uint64_t* d_read_off, lra_extend_result* out);
+
 /* ---- a12: banded one-gap seed-extension DP ------------------------------------------
  * Replaces   int AffineOneGapAlign(string& qSeq, int qLen, string& tSeq, int tLen,
  *                                  int m, int mm, int indel, int k, Alignment& aln,

@@ -35,3 +35,23 @@ def fetch(ctx: Context, res: ClusterResult):
             "strand": ctx.to_host(res.d_c_strand, nc, np.int32), "chrom": ctx.to_host(res.d_c_chrom, nc, np.int32),
             "freq": ctx.to_host(res.d_c_anchorfreq, nc, np.float32),
             "cl_qpos": ctx.to_host(res.d_cl_qpos, nm, np.uint32), "cl_tpos": ctx.to_host(res.d_cl_tpos, nm, np.uint32)}
+
+
+class ExtendResult(C.Structure):
+    _fields_ = [("n_clusters", C.c_uint64), ("n_anchors_cap", C.c_uint64), ("d_e_start", C.c_void_p), ("d_e_count", C.c_void_p),
+                ("d_e_qpos", C.c_void_p), ("d_e_tpos", C.c_void_p), ("d_e_len", C.c_void_p), ("d_box", C.c_void_p)]
+
+
+def linear_extend_batch(ctx: Context, K, read_batch):
+    """LinearExtend + DecideCoordinates over the context's current clusters (reads = the seeded ReadBatch)."""
+    from .context import ptr
+    res = ExtendResult()
+    ctx.check(ctx.lib.lra_linear_extend_batch(ctx.h, int(K), ptr(read_batch.seq), ptr(read_batch.off), C.byref(res)))
+    return res
+
+
+def fetch_extend(ctx: Context, res: ExtendResult):
+    nc, nm = res.n_clusters, res.n_anchors_cap
+    return {"e_start": ctx.to_host(res.d_e_start, nc, np.uint64), "e_count": ctx.to_host(res.d_e_count, nc, np.uint32),
+            "e_qpos": ctx.to_host(res.d_e_qpos, nm, np.uint32), "e_tpos": ctx.to_host(res.d_e_tpos, nm, np.uint32),
+            "e_len": ctx.to_host(res.d_e_len, nm, np.int32), "box": ctx.to_host(res.d_box, 4 * nc, np.uint32).reshape(-1, 4)}

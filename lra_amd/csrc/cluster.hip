@@ -17,6 +17,7 @@
 #include <cstdlib>
 #include "seed_state.h"
 #include "scan.h"
+#include <algorithm>
 #include <rocprim/rocprim.hpp>
 
 namespace {
@@ -338,5 +339,139 @@ extern "C" int lra_clean_matches_batch(lra_ctx* ctx, const lra_clean_opts* opts,
   out->d_c_qStart = C.o_qs; out->d_c_qEnd = C.o_qe; out->d_c_tStart = C.o_ts; out->d_c_tEnd = C.o_te;
   out->d_c_strand = C.o_strand; out->d_c_chrom = C.o_chrom; out->d_c_anchorfreq = C.o_freq;
   out->d_cl_qpos = A.cl_q; out->d_cl_tpos = A.cl_t;
+  if (!ctx->clus) ctx->clus = new lra_cluster_state();
+  lra_cluster_state* cs = ctx->clus;
+  cs->n_reads = n_reads; cs->n_clusters = ncl; cs->n_matches = nm;
+  cs->cluster_off = C.cluster_off; cs->c_start = C.o_start; cs->c_end = C.o_end; cs->c_strand = C.o_strand; cs->c_chrom = C.o_chrom;
+  cs->cl_q = A.cl_q; cs->cl_t = A.cl_t; cs->chrom_pos = d_chrom; cs->n_chrom = n_chrom;
+  return LRA_OK;
+}
+
+void lra_cluster_free(lra_ctx* ctx) { delete ctx->clus; ctx->clus = nullptr; }
+
+// ======================================================================================== a7
+namespace {
+
+struct ExtArgs {
+  uint64_t n_clusters; int n_reads; int K;
+  const uint64_t* cluster_off; const uint64_t* c_start; const uint64_t* c_end; const int* c_strand; const int* c_chrom;
+  const uint32_t* cl_q; const uint32_t* cl_t; const uint64_t* chrom_pos;
+  const unsigned char* genome; const unsigned char* seq; const uint64_t* read_off;
+  int* c_read;
+  uint32_t* e_q; uint32_t* e_t; int* e_len; uint32_t* e_count; uint32_t* box;
+};
+
+__global__ void cluster_read_map(int n_reads, const uint64_t* cluster_off, int* c_read) {
+  int r = blockIdx.x * blockDim.x + threadIdx.x;
+  if (r >= n_reads) return;
+  for (uint64_t c = cluster_off[r]; c < cluster_off[r + 1]; c++) c_read[c] = r;
+}
+
+// One wave per cluster.  Whether two consecutive matches fuse (same diagonal and either overlapping
+// or joined by an exact-match walk, Checkbp) depends on that pair alone, so every pair is tested by
+// its own lane; the extended anchors are the stretches between the break points.
+__global__ void __launch_bounds__(64) linear_extend_kernel(ExtArgs A) {
+  const int lane = threadIdx.x;
+  const unsigned long long below = (lane == 0) ? 0ULL : (~0ULL >> (64 - lane));
+  const uint32_t K = (uint32_t)A.K;
+  for (uint64_t x = blockIdx.x; x < A.n_clusters; x += gridDim.x) {
+    const uint64_t s = A.c_start[x], e = A.c_end[x];
+    const int strand = A.c_strand[x], chrom = A.c_chrom[x], r = A.c_read[x];
+    const uint64_t coff = A.chrom_pos[chrom];
+    const uint32_t chromLen = (uint32_t)(A.chrom_pos[chrom + 1] - coff);
+    const unsigned char* G = A.genome + coff;
+    const unsigned char* R = A.seq + A.read_off[r];
+    const uint32_t readLen = (uint32_t)(A.read_off[r + 1] - A.read_off[r]);
+    uint64_t m = s;                     // start of the open stretch
+    uint32_t nout = 0;
+    uint32_t bqS = 0xFFFFFFFFu, bqE = 0, btS = 0xFFFFFFFFu, btE = 0;
+    auto put = [&](uint32_t idx, uint32_t q, uint32_t t, int len) {
+      A.e_q[s + idx] = q; A.e_t[s + idx] = t + (uint32_t)coff; A.e_len[s + idx] = len;
+      bqS = min(bqS, q); bqE = max(bqE, q + (uint32_t)len); btS = min(btS, t + (uint32_t)coff); btE = max(btE, t + (uint32_t)coff + (uint32_t)len);
+    };
+    for (uint64_t base = s; base < e; base += 64) {
+      const uint64_t i = base + lane;
+      bool brk = false, ext = false;
+      uint32_t qe = 0, te = 0, qp = 0, tp = 0;
+      if (i > s && i < e) {
+        const uint32_t q1 = A.cl_q[i - 1], t1 = A.cl_t[i - 1] - (uint32_t)coff, q2 = A.cl_q[i], t2 = A.cl_t[i] - (uint32_t)coff;
+        qp = q1; tp = t1;
+        const int64_t d1 = strand == 0 ? (int64_t)q1 - (int64_t)t1 : (int64_t)q1 + (int64_t)t1;
+        const int64_t d2 = strand == 0 ? (int64_t)q2 - (int64_t)t2 : (int64_t)q2 + (int64_t)t2;
+        if (d1 != d2) brk = true;                                              // :702-707
+        else if (q2 >= q1 + K) {                                                // :681-699
+          uint32_t curQ = q1 + K, curT;
+          if (strand == 0) {                                                    // Checkbp :50-85
+            curT = min(chromLen, t1 + K);
+            const uint32_t nextT = min(chromLen, t2);
+            while (curQ < readLen && curT < chromLen && q2 > curQ && nextT > curT && G[curT] == R[curQ]) { curQ++; curT++; }
+            if (!(curQ == q2 && curT == t2)) { brk = true; ext = true; }
+          } else {
+            curT = min(chromLen - 1, t1 - 1);
+            const uint32_t nextT = min(chromLen - 1, t2 + K - 1);
+            while (curQ < readLen && q2 > curQ && nextT < curT && G[curT] == R[curQ]) { curQ++; curT--; }
+            if (!(curQ == q2 && curT == t2 + K - 1)) { brk = true; ext = true; }
+          }
+          qe = curQ; te = curT;
+        }
+      }
+      const unsigned long long mb = __ballot(brk);
+      if (brk) {
+        // the stretch this break closes starts at the previous break of the chunk, or at the carried m
+        const unsigned long long prevb = mb & below;
+        const uint64_t ms = prevb ? base + (63 - __clzll((long long)prevb)) : m;
+        const uint32_t qm = A.cl_q[ms], tm = A.cl_t[ms] - (uint32_t)coff;
+        const uint32_t idx = nout + __popcll(prevb);
+        if (ext) put(idx, qm, strand == 0 ? tm : te + 1, (int)(qe - qm));
+        else put(idx, qm, strand == 0 ? tm : tp, (int)(qp + K - qm));
+      }
+      if (mb) { m = base + (63 - __clzll((long long)mb)); nout += __popcll(mb); }
+    }
+    if (e > s) {                                                               // :710-714 the last stretch
+      if (lane == 0) {
+        const uint32_t qm = A.cl_q[m], tm = A.cl_t[m] - (uint32_t)coff;
+        const uint32_t ql = A.cl_q[e - 1], tl = A.cl_t[e - 1] - (uint32_t)coff;
+        put(nout, qm, strand == 0 ? tm : tl, (int)(ql + K - qm));
+      }
+      nout++;
+    }
+    for (int off = 32; off > 0; off >>= 1) {
+      bqS = min(bqS, (uint32_t)__shfl_xor(bqS, off)); bqE = max(bqE, (uint32_t)__shfl_xor(bqE, off));
+      btS = min(btS, (uint32_t)__shfl_xor(btS, off)); btE = max(btE, (uint32_t)__shfl_xor(btE, off));
+    }
+    if (lane == 0) { A.e_count[x] = nout; A.box[4 * x] = bqS; A.box[4 * x + 1] = bqE; A.box[4 * x + 2] = btS; A.box[4 * x + 3] = btE; }
+  }
+}
+
+}  // namespace
+
+extern "C" int lra_linear_extend_batch(lra_ctx* ctx, int K, const char* d_seq, const uint64_t* d_read_off, lra_extend_result* out) {
+  if (!ctx || !out || K < 1) return LRA_ERR_INVALID;
+  lra_cluster_state* cs = ctx->clus;
+  if (!cs || !ctx->seed || !ctx->seed->genome) return lra_set_err(ctx, LRA_ERR_INVALID, "run lra_clean_matches_batch first");
+  memset(out, 0, sizeof(*out));
+  LRA_HIP_CHECK(ctx, hipSetDevice(ctx->device));
+  hipStream_t st = ctx->stream;
+  const size_t NM = (size_t)cs->n_matches + 64, NC = (size_t)cs->n_clusters + 8;
+  auto sz = [](size_t n, size_t e) { return (n * e + 255) & ~(size_t)255; };
+  char* w = (char*)lra_scratch(ctx, 3, sz(NM, 4) * 3 + sz(NC, 4) * 2 + sz(4 * NC, 4) + 4096);
+  if (!w) return LRA_ERR_NOMEM;
+  ExtArgs A;
+  A.n_clusters = cs->n_clusters; A.n_reads = cs->n_reads; A.K = K;
+  A.cluster_off = cs->cluster_off; A.c_start = cs->c_start; A.c_end = cs->c_end; A.c_strand = cs->c_strand; A.c_chrom = cs->c_chrom;
+  A.cl_q = cs->cl_q; A.cl_t = cs->cl_t; A.chrom_pos = cs->chrom_pos;
+  A.genome = ctx->seed->genome; A.seq = (const unsigned char*)d_seq; A.read_off = d_read_off;
+  A.e_q = carve<uint32_t>(w, NM); A.e_t = carve<uint32_t>(w, NM); A.e_len = carve<int>(w, NM);
+  A.e_count = carve<uint32_t>(w, NC); A.c_read = carve<int>(w, NC); A.box = carve<uint32_t>(w, 4 * NC);
+  if (cs->n_clusters) {
+    hipLaunchKernelGGL(cluster_read_map, dim3((cs->n_reads + 255) / 256), dim3(256), 0, st, cs->n_reads, cs->cluster_off, A.c_read);
+    lra_time_begin(ctx, "linear_extend");
+    hipLaunchKernelGGL(linear_extend_kernel, dim3((unsigned)std::min<uint64_t>(cs->n_clusters, (uint64_t)ctx->num_cu * 32)), dim3(64), 0, st, A);
+    lra_time_end(ctx);
+  }
+  LRA_HIP_CHECK(ctx, hipGetLastError());
+  LRA_HIP_CHECK(ctx, hipStreamSynchronize(st));
+  out->n_clusters = cs->n_clusters; out->n_anchors_cap = cs->n_matches;
+  out->d_e_start = cs->c_start; out->d_e_count = A.e_count; out->d_e_qpos = A.e_q; out->d_e_tpos = A.e_t; out->d_e_len = A.e_len; out->d_box = A.box;
   return LRA_OK;
 }

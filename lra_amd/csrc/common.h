@@ -9,6 +9,7 @@
 #include "../../include/lra_hip.h"
 
 struct lra_seed_state;
+struct lra_cluster_state;
 struct lra_time_rec { const char* name; hipEvent_t a, b; };
 
 struct lra_ctx {
@@ -20,6 +21,7 @@ struct lra_ctx {
   size_t scratch_bytes[4] = {0, 0, 0, 0};
   int num_cu = 256;
   lra_seed_state* seed = nullptr;
+  lra_cluster_state* clus = nullptr;
   void* aux = nullptr; size_t aux_bytes = 0;          // AffineOneGapAlign blocks of refine fallbacks
   void* out_buf = nullptr; size_t out_bytes = 0;
   uint64_t* scan_tmp = nullptr;
@@ -34,6 +36,7 @@ struct lra_ctx {
 void lra_time_begin(lra_ctx* ctx, const char* name);
 void lra_time_end(lra_ctx* ctx);
 void lra_seed_free(lra_ctx* ctx);
+void lra_cluster_free(lra_ctx* ctx);
 
 int lra_set_err(lra_ctx* ctx, int code, const char* fmt, ...);
 // returns a device buffer of >= bytes (slot 0..3), growing it if needed (synchronises the

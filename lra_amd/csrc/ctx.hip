@@ -65,6 +65,7 @@ extern "C" void lra_ctx_destroy(lra_ctx* ctx) {
   for (int i = 0; i < 4; i++)
     if (ctx->scratch[i]) (void)hipFree(ctx->scratch[i]);
   lra_seed_free(ctx);
+  lra_cluster_free(ctx);
   if (ctx->aux) (void)hipFree(ctx->aux);
   if (ctx->out_buf) (void)hipFree(ctx->out_buf);
   if (ctx->scan_tmp) (void)hipFree(ctx->scan_tmp);

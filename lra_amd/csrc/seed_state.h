@@ -16,3 +16,12 @@ struct lra_seed_state {
   uint32_t* tmp_qi = nullptr; uint32_t* tmp_ti = nullptr; size_t cap_tmp = 0; uint64_t* cap_cnt = nullptr; uint64_t* cap_off = nullptr;
 };
 
+
+// current cluster result (cluster.hip), inputs of the linear-extension stage
+struct lra_cluster_state {
+  int n_reads = 0; uint64_t n_clusters = 0, n_matches = 0;
+  const uint64_t* cluster_off = nullptr; const uint64_t* c_start = nullptr; const uint64_t* c_end = nullptr;
+  const int* c_strand = nullptr; const int* c_chrom = nullptr;
+  const uint32_t* cl_q = nullptr; const uint32_t* cl_t = nullptr;
+  const uint64_t* chrom_pos = nullptr; int n_chrom = 0;
+};

@@ -153,3 +153,15 @@ def clean_matches(qpos, tpos, qkey, strand, opts: "CleanOpts", chrom_pos):
     k = nclean.value
     return oq[:k].copy(), ot[:k].copy(), dict(start=cs[:ncl].copy(), end=ce[:ncl].copy(), qStart=qs[:ncl].copy(), qEnd=qe[:ncl].copy(),
                                               tStart=ts[:ncl].copy(), tEnd=te[:ncl].copy(), chrom=ch[:ncl].copy(), freq=fr[:ncl].copy())
+
+
+def linear_extend(q, t, strand, K, read: bytes, chrom: bytes):
+    """Pair-version LinearExtend + DecideCoordinates for one cluster (t chromosome-relative)."""
+    L = lib()
+    q = np.ascontiguousarray(q, dtype=np.uint32); t = np.ascontiguousarray(t, dtype=np.uint32)
+    n = len(q)
+    eq = np.zeros(max(1, n), np.uint32); et = np.zeros(max(1, n), np.uint32); el = np.zeros(max(1, n), np.int32); box = np.zeros(4, np.uint32)
+    L.oracle_linear_extend.restype = C.c_long
+    ne = L.oracle_linear_extend(_p(q, C.c_uint32), _p(t, C.c_uint32), C.c_long(n), int(strand), int(K), C.c_char_p(read), C.c_uint32(len(read)),
+                                C.c_char_p(chrom), C.c_uint32(len(chrom)), _p(eq, C.c_uint32), _p(et, C.c_uint32), _p(el, C.c_int), _p(box, C.c_uint32))
+    return eq[:ne].copy(), et[:ne].copy(), el[:ne].copy(), box

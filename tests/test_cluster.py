@@ -73,3 +73,34 @@ def test_hip_clean_matches_oracle(ctx, oracle, preset, k, w, mf, err):
             assert got == e, (r, x)
         total += len(exp)
     assert total > 50
+    # ---- a7: LinearExtend + DecideCoordinates on those clusters
+    eres = cluster.linear_extend_batch(ctx, k, batch)
+    eo = cluster.fetch_extend(ctx, eres)
+    cp = np.asarray(chrom_pos, dtype=np.int64)
+    n_ext = 0
+    for r, read in enumerate(reads):
+        rb = read.tobytes()
+        for x in range(int(out["cluster_off"][r]), int(out["cluster_off"][r + 1])):
+            a, b = int(out["start"][x]), int(out["end"][x])
+            ch = int(out["chrom"][x]); off = int(cp[ch])
+            chrom = genome[off:int(cp[ch + 1])].tobytes()
+            eq, et, el, box = oracle.linear_extend(out["cl_qpos"][a:b], out["cl_tpos"][a:b] - np.uint32(off), int(out["strand"][x]), k, rb, chrom)
+            es, ec = int(eo["e_start"][x]), int(eo["e_count"][x])
+            assert ec == len(eq), (r, x, ec, len(eq))
+            assert np.array_equal(eo["e_qpos"][es:es + ec], eq) and np.array_equal(eo["e_tpos"][es:es + ec], et + np.uint32(off))
+            assert np.array_equal(eo["e_len"][es:es + ec], el)
+            assert eo["box"][x].tolist() == [int(box[0]), int(box[1]), int(box[2]) + off, int(box[3]) + off]
+            n_ext += ec
+    assert n_ext > 50
+
+
+def test_oracle_linear_extend_sanity(oracle):
+    g = synth.make_genome(5000, seed=3).tobytes()
+    read = g[1000:1400]
+    # three 17-mers on one diagonal, exact matches in between -> one anchor covering all; then a diagonal change
+    q = [0, 40, 120, 200]; t = [1000, 1040, 1120, 1210]
+    eq, et, el, box = oracle.linear_extend(q, t, 0, 17, read, g)
+    assert eq.tolist() == [0, 200] and et.tolist() == [1000, 1210] and el.tolist() == [137, 17]
+    assert box.tolist() == [0, 217, 1000, 1227]
+    assert len(oracle.linear_extend([], [], 0, 17, read, g)[0]) == 0
+    assert oracle.linear_extend([5], [1005], 0, 17, read, g)[2].tolist() == [17]
