@@ -204,6 +204,31 @@ int lra_indel_refine_batch(lra_ctx* ctx, int n_aln, const int32_t* d_blocks_in, 
                            const int64_t* d_t_len, int refine_band, int match, int mismatch, int indel,
                            int end_align, lra_refine_result* out);
 
+/* ---- a16: alignment statistics + CIGAR ---------------------------------------------------
+ * Replaces   void Alignment::CalculateStatistics(const Options&, ostream*, const vector<float>& LookUpTable)
+ * (Alignment.h:513-531 = CreateAlignmentStrings :247 + AlignStringsToCigar :414, opts.showmm) for
+ * n_aln alignments given as blocks (same conventions as lra_indel_refine_batch; d_t_off is the
+ * chromosome start).  h_lookup = the reference's LookUpTable (LogLookUpTable.h: logf(1), logf(6), ...,
+ * 2001 floats, computed by the HOST libm so the float value matches the reference bit for bit).
+ * Output per alignment: 18 int32 counters in the order
+ *   nm nmm nins ndel tdel tins nSmallDel nMedDel nLargeDel nSmallIns nMedIns nLargeIns preClip sufClip qStart qEnd tStart tEnd
+ * named after the reference's MEMBERS after the call (so nins counts deletion runs and ndel insertion
+ * runs), the float `value` (NV), and the CIGAR as runs (length << 4 | op,
+ * op 0 '=', 1 'X', 2 'I', 3 'D'), CSR by alignment.  Counters are this call's increments of a fresh
+ * Alignment (the reference never resets tdel/tins/nSmall*).  Synchronous.                          */
+typedef struct lra_stats_result {
+  int32_t n_aln;
+  uint64_t n_runs;
+  const int32_t* d_counts;    /* [18*n_aln] */
+  const float* d_value;       /* [n_aln] */
+  const uint64_t* d_run_off;  /* [n_aln+1] */
+  const uint32_t* d_runs;     /* [n_runs] */
+} lra_stats_result;
+int lra_calculate_statistics_batch(lra_ctx* ctx, int n_aln, const int32_t* d_blocks, const uint64_t* d_block_off,
+                                   const char* d_qseq, const uint64_t* d_q_off, const int32_t* d_q_len,
+                                   const char* d_tseq, const uint64_t* d_t_off, const float* h_lookup, int n_lookup,
+                                   lra_stats_result* out);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,173 @@
+// lra_amd/csrc/stats.hip -- a16: alignment statistics and CIGAR runs for a batch of alignments (gfx950).
+//
+// Replaces Alignment::CalculateStatistics (reference: Alignment.h:513-531): CreateAlignmentStrings
+// (:247-331) + AlignStringsToCigar (:414-504, opts.showmm).  The reference materialises three
+// alignment strings and re-parses them; here the column stream is generated on the fly from the
+// blocks: one wave per alignment, 64 aligned pairs per step compared at once (ballot of the
+// mismatch flags), runs cut out of the 64-bit masks with count-trailing-zeros, and the counters and
+// the float value accumulated run by run in the reference's order (so the float additions round
+// identically; the log table is the caller's, i.e. the host libm's logf, LogLookUpTable.h:9-15).
+#include "common.h"
+#include "scan.h"
+
+namespace {
+
+__device__ __forceinline__ int code2(unsigned char c) {   // seqMap (SeqUtils.h:7): non-ACGT -> 0
+  switch (c) {
+    case 1: case 5: case 'C': case 'c': return 1;
+    case 2: case 6: case 'G': case 'g': return 2;
+    case 3: case 7: case 'T': case 't': return 3;
+    default: return 0;
+  }
+}
+
+struct StatArgs {
+  int n_aln;
+  const int32_t* blocks; const uint64_t* block_off;
+  const unsigned char* qseq; const uint64_t* q_off; const int32_t* q_len;
+  const unsigned char* tseq; const uint64_t* t_off;
+  const float* lut;
+  int32_t* counts; float* value; uint32_t* n_runs;
+  const uint64_t* run_off; uint32_t* runs;
+};
+
+template <bool EMIT>
+__global__ void __launch_bounds__(64) stats_kernel(StatArgs A) {
+  const int lane = threadIdx.x;
+  for (int a = blockIdx.x; a < A.n_aln; a += gridDim.x) {
+    const long nb = (long)(A.block_off[a + 1] - A.block_off[a]);
+    const int32_t* B = A.blocks + 3 * A.block_off[a];
+    const unsigned char* R = A.qseq + A.q_off[a];
+    const unsigned char* G = A.tseq + A.t_off[a];
+    uint32_t* out = EMIT ? A.runs + A.run_off[a] : nullptr;
+    int nm = 0, nmm = 0, nD = 0, nI = 0, tdel = 0, tins = 0, sD = 0, mD = 0, lD = 0, sI = 0, mI = 0, lI = 0;
+    float value = 0;
+    uint32_t nr = 0;
+    int curType = -1; long curLen = 0;
+    auto close_run = [&]() {                                             // one CIGAR run (:419-501)
+      if (curType < 0 || curLen == 0) return;
+      const long len = curLen;
+      if (EMIT && lane == 0) out[nr] = (uint32_t)(len << 4) | (uint32_t)curType;
+      nr++;
+      if (curType == 0) { nm += (int)len; value += (float)len; }
+      else if (curType == 1) { nmm += (int)len; value -= (float)len; }
+      else {
+        float pen;
+        bool small = len <= 20;
+        if (len <= 20) pen = 0;
+        else if (len <= 10001) pen = -3.0f * A.lut[(int)((len - 1) / 5)] - 1;
+        else if (len <= 100001) pen = -1000;
+        else pen = -2000;
+        if (curType == 3) {                                              // 'D' :447-470
+          tdel += (int)len; nD++;
+          if (len <= 10) sD++;
+          if (len > 10 && len < 50) mD++; else if (len > 50) lD++;
+        } else {                                                         // 'I' :472-499
+          tins += (int)len; nI++;
+          if (len <= 10) sI++;
+          if (len > 10 && len < 50) mI++; else if (len > 50) lI++;
+          if (small) sI++;
+        }
+        if (small) value -= (float)len; else value += pen;
+      }
+    };
+    auto feed = [&](int type, long len) {                                // append `len` columns of one type
+      if (len <= 0) return;
+      if (type == curType) curLen += len;
+      else { close_run(); curType = type; curLen = len; }
+    };
+    auto pairs = [&](long q, long t, long len) {                         // aligned pairs: '=' / 'X' by base code
+      for (long off = 0; off < len; off += 64) {
+        const int cnt = (int)min(64L, len - off);
+        bool x = false;
+        if (lane < cnt) x = code2(R[q + off + lane]) != code2(G[t + off + lane]);
+        const unsigned long long mx = __ballot(x);
+        int pos = 0;
+        while (pos < cnt) {
+          const int cur = (int)((mx >> pos) & 1ULL);
+          unsigned long long y = (cur ? ~mx : mx) >> pos;               // first column of the other kind
+          int run = y ? __ffsll((long long)y) - 1 : 64;
+          run = min(run, cnt - pos);
+          feed(cur, run);
+          pos += run;
+        }
+      }
+    };
+    if (nb > 0) {
+      long q = B[0], t = B[1];
+      for (long b = 0; b < nb; b++) {                                    // :261-330
+        const long L = B[3 * b + 2];
+        pairs(q, t, L);
+        q += L; t += L;
+        if (b == nb - 1) continue;
+        long qg = (long)B[3 * (b + 1)] - B[3 * b] - L, tg = (long)B[3 * (b + 1) + 1] - B[3 * b + 1] - L;
+        if (qg > 0 || tg > 0) {
+          const long common = qg > tg ? tg : qg;
+          tg -= common; qg -= common;
+          feed(2, qg); q += max(qg, 0L);
+          feed(3, tg); t += max(tg, 0L);
+          if (common > 0) { pairs(q, t, common); q += common; t += common; }
+        }
+      }
+      close_run();
+    }
+    if (lane == 0) {
+      if (!EMIT) {
+        int32_t* o = A.counts + 18 * (long)a;
+        o[0] = nm; o[1] = nmm; o[2] = nD; o[3] = nI; o[4] = tdel; o[5] = tins; o[6] = sD; o[7] = mD; o[8] = lD; o[9] = sI; o[10] = mI; o[11] = lI;
+        if (nb > 0) {
+          const long last = nb - 1;
+          o[12] = B[0]; o[13] = A.q_len[a] - B[3 * last] - B[3 * last + 2];
+          o[14] = B[0]; o[15] = B[3 * last] + B[3 * last + 2]; o[16] = B[1]; o[17] = B[3 * last + 1] + B[3 * last + 2];
+        } else { for (int x = 12; x < 18; x++) o[x] = 0; }
+        A.value[a] = value;
+        A.n_runs[a] = nr;
+      }
+    }
+  }
+}
+
+}  // namespace
+
+extern "C" int lra_calculate_statistics_batch(lra_ctx* ctx, int n_aln, const int32_t* d_blocks, const uint64_t* d_block_off,
+                                              const char* d_qseq, const uint64_t* d_q_off, const int32_t* d_q_len, const char* d_tseq,
+                                              const uint64_t* d_t_off, const float* h_lookup, int n_lookup, lra_stats_result* out) {
+  if (!ctx || !out || n_aln < 0 || !h_lookup || n_lookup < 2001) return LRA_ERR_INVALID;
+  memset(out, 0, sizeof(*out));
+  out->n_aln = n_aln;
+  if (n_aln == 0) return LRA_OK;
+  LRA_HIP_CHECK(ctx, hipSetDevice(ctx->device));
+  hipStream_t st = ctx->stream;
+  const size_t nA = (size_t)n_aln;
+  auto sz = [](size_t n, size_t e) { return (n * e + 255) & ~(size_t)255; };
+  char* w = (char*)lra_scratch(ctx, 2, sz(18 * nA, 4) + sz(nA, 4) * 2 + sz(nA + 1, 8) + sz((size_t)n_lookup, 4) + 4096);
+  if (!w) return LRA_ERR_NOMEM;
+  StatArgs A;
+  A.n_aln = n_aln; A.blocks = d_blocks; A.block_off = d_block_off;
+  A.qseq = (const unsigned char*)d_qseq; A.q_off = d_q_off; A.q_len = d_q_len; A.tseq = (const unsigned char*)d_tseq; A.t_off = d_t_off;
+  A.counts = (int32_t*)w; w += sz(18 * nA, 4);
+  A.value = (float*)w; w += sz(nA, 4);
+  A.n_runs = (uint32_t*)w; w += sz(nA, 4);
+  uint64_t* run_off = (uint64_t*)w; w += sz(nA + 1, 8);
+  float* lut = (float*)w;
+  A.lut = lut; A.run_off = run_off; A.runs = nullptr;
+  LRA_HIP_CHECK(ctx, hipMemcpyAsync(lut, h_lookup, (size_t)n_lookup * 4, hipMemcpyHostToDevice, st));
+  const int grid = n_aln < ctx->num_cu * 32 ? n_aln : ctx->num_cu * 32;
+  lra_time_begin(ctx, "stats");
+  hipLaunchKernelGGL(stats_kernel<false>, dim3(grid), dim3(64), 0, st, A);
+  lra_time_end(ctx);
+  if (lra_exclusive_scan<uint32_t>(ctx, (long)n_aln, A.n_runs, run_off)) return LRA_ERR_HIP;
+  uint64_t total = 0;
+  LRA_HIP_CHECK(ctx, hipMemcpyAsync(&total, run_off + n_aln, 8, hipMemcpyDeviceToHost, st));
+  LRA_HIP_CHECK(ctx, hipStreamSynchronize(st));
+  uint32_t* runs = (uint32_t*)lra_scratch(ctx, 3, (total + 1) * 4);
+  if (!runs) return LRA_ERR_NOMEM;
+  A.runs = runs;
+  lra_time_begin(ctx, "stats_cigar");
+  hipLaunchKernelGGL(stats_kernel<true>, dim3(grid), dim3(64), 0, st, A);
+  lra_time_end(ctx);
+  LRA_HIP_CHECK(ctx, hipGetLastError());
+  LRA_HIP_CHECK(ctx, hipStreamSynchronize(st));
+  out->n_runs = total; out->d_counts = A.counts; out->d_value = A.value; out->d_run_off = run_off; out->d_runs = runs;
+  return LRA_OK;
+}

@@ -61,3 +61,31 @@ def fetch(ctx: Context, res: RefineResult):
     blocks = ctx.to_host(res.d_blocks, 3 * res.n_blocks, np.int32).reshape(-1, 3)
     status = ctx.to_host(res.d_status, res.n_aln, np.int32)
     return [blocks[int(off[a]):int(off[a + 1])] for a in range(res.n_aln)], status
+
+
+class StatsResult(C.Structure):
+    _fields_ = [("n_aln", C.c_int32), ("n_runs", C.c_uint64), ("d_counts", C.c_void_p), ("d_value", C.c_void_p),
+                ("d_run_off", C.c_void_p), ("d_runs", C.c_void_p)]
+
+
+STAT_NAMES = ["nm", "nmm", "nins", "ndel", "tdel", "tins", "nSmallDel", "nMedDel", "nLargeDel", "nSmallIns", "nMedIns", "nLargeIns",
+              "preClip", "sufClip", "qStart", "qEnd", "tStart", "tEnd"]
+
+
+def calculate_statistics_batch(ctx: Context, b: RefineBatch, lookup_table):
+    """Alignment::CalculateStatistics over the alignments of a RefineBatch-shaped input (blocks + sequences).
+    lookup_table: float32[2001] = logf(1), logf(6), ... from the host libm."""
+    lut = np.ascontiguousarray(lookup_table, dtype=np.float32)
+    res = StatsResult()
+    ctx.check(ctx.lib.lra_calculate_statistics_batch(ctx.h, b.n, ptr(b.blocks), ptr(b.block_off), ptr(b.q_seq), ptr(b.q_off), ptr(b.q_len),
+                                                     ptr(b.t_seq), ptr(b.t_off), C.c_void_p(lut.ctypes.data), len(lut), C.byref(res)))
+    return res
+
+
+def fetch_stats(ctx: Context, res: StatsResult):
+    counts = ctx.to_host(res.d_counts, 18 * res.n_aln, np.int32).reshape(-1, 18)
+    value = ctx.to_host(res.d_value, res.n_aln, np.float32)
+    off = ctx.to_host(res.d_run_off, res.n_aln + 1, np.uint64)
+    runs = ctx.to_host(res.d_runs, res.n_runs, np.uint32)
+    cigars = ["".join("%d%s" % (r >> 4, "=XID"[r & 15]) for r in runs[int(off[a]):int(off[a + 1])]) for a in range(res.n_aln)]
+    return counts, value, cigars

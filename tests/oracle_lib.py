@@ -165,3 +165,44 @@ def linear_extend(q, t, strand, K, read: bytes, chrom: bytes):
     ne = L.oracle_linear_extend(_p(q, C.c_uint32), _p(t, C.c_uint32), C.c_long(n), int(strand), int(K), C.c_char_p(read), C.c_uint32(len(read)),
                                 C.c_char_p(chrom), C.c_uint32(len(chrom)), _p(eq, C.c_uint32), _p(et, C.c_uint32), _p(el, C.c_int), _p(box, C.c_uint32))
     return eq[:ne].copy(), et[:ne].copy(), el[:ne].copy(), box
+
+
+_LUT = None
+
+
+def log_lookup_table():
+    """LookUpTable of the reference (LogLookUpTable.h:9-15): logf(i) for i = 1, 6, ..., 10001, float32 (host libm)."""
+    global _LUT
+    if _LUT is None:
+        import math
+        import struct
+        vals = []
+        libm = C.CDLL("libm.so.6")
+        libm.logf.restype = C.c_float
+        libm.logf.argtypes = [C.c_float]
+        for i in range(1, 10002, 5):
+            vals.append(libm.logf(float(i)))
+        _LUT = np.array(vals, dtype=np.float32)
+    return _LUT
+
+
+STAT_NAMES = ["nm", "nmm", "nins", "ndel", "tdel", "tins", "nSmallDel", "nMedDel", "nLargeDel", "nSmallIns", "nMedIns", "nLargeIns",
+              "preClip", "sufClip", "qStart", "qEnd", "tStart", "tEnd"]
+
+
+def calculate_statistics(blocks, read: bytes, genome: bytes):
+    """Returns (counts dict, value float32, runs uint32 array (len<<4|op), cigar string)."""
+    L = lib()
+    b = np.ascontiguousarray(np.asarray(blocks, dtype=np.int32).reshape(-1, 3))
+    lut = log_lookup_table()
+    counts = np.zeros(18, dtype=np.int64)
+    val = C.c_float(0)
+    cap = int(b[:, 2].sum() * 2 + 4 * len(b) + 16) if len(b) else 1
+    runs = np.zeros(cap, dtype=np.uint32)
+    L.oracle_calculate_statistics.restype = C.c_long
+    n = L.oracle_calculate_statistics(_p(b, C.c_int), C.c_long(len(b)), C.c_char_p(read), C.c_long(len(read)), C.c_char_p(genome),
+                                      _p(lut, C.c_float), _p(counts, C.c_long), C.byref(val), _p(runs, C.c_uint32), C.c_long(cap))
+    assert n <= cap
+    runs = runs[:n].copy()
+    cigar = "".join("%d%s" % (r >> 4, "=XID"[r & 15]) for r in runs)
+    return dict(zip(STAT_NAMES, counts.tolist())), np.float32(val.value), runs, cigar
