@@ -70,4 +70,8 @@ class Context:
 
 def ptr(t):
     """Device pointer of a torch tensor as c_void_p (None -> NULL)."""
-    return C.c_void_p(0 if t is None else t.data_ptr())
+    if t is None:
+        return C.c_void_p(0)
+    if isinstance(t, int):
+        return C.c_void_p(t)            # already a raw device address (context-owned result array)
+    return C.c_void_p(t.data_ptr())

@@ -28,36 +28,36 @@ struct StatArgs {
   const unsigned char* tseq; const uint64_t* t_off;
   const float* lut;
   int32_t* counts; float* value; uint32_t* n_runs;
-  const uint64_t* run_off; uint32_t* runs;
+  const uint64_t* cap_off; uint32_t* runs;      // runs at capacity offsets (<= aligned columns per alignment)
 };
 
-template <bool EMIT>
+// Value bookkeeping: '=' / 'X' runs and gaps <= 20 add integers; as long as no long gap (a log-table
+// term, :462/:491) has been added the float `value` is an exact integer, so those contributions can
+// be summed in any order (ival) -- whole 64-column chunks at a time.  From the first long gap on
+// every run is applied to the float in the reference's order.
 __global__ void __launch_bounds__(64) stats_kernel(StatArgs A) {
   const int lane = threadIdx.x;
+  const unsigned long long below = (lane == 0) ? 0ULL : (~0ULL >> (64 - lane));
   for (int a = blockIdx.x; a < A.n_aln; a += gridDim.x) {
     const long nb = (long)(A.block_off[a + 1] - A.block_off[a]);
     const int32_t* B = A.blocks + 3 * A.block_off[a];
     const unsigned char* R = A.qseq + A.q_off[a];
     const unsigned char* G = A.tseq + A.t_off[a];
-    uint32_t* out = EMIT ? A.runs + A.run_off[a] : nullptr;
+    uint32_t* out = A.runs + A.cap_off[a];
     int nm = 0, nmm = 0, nD = 0, nI = 0, tdel = 0, tins = 0, sD = 0, mD = 0, lD = 0, sI = 0, mI = 0, lI = 0;
-    float value = 0;
+    long ival = 0; float value = 0; bool frac = false;
     uint32_t nr = 0;
     int curType = -1; long curLen = 0;
+    auto addv = [&](long x) { if (!frac) ival += x; else value += (float)x; };   // x integer: +len or -len
     auto close_run = [&]() {                                             // one CIGAR run (:419-501)
       if (curType < 0 || curLen == 0) return;
       const long len = curLen;
-      if (EMIT && lane == 0) out[nr] = (uint32_t)(len << 4) | (uint32_t)curType;
+      if (lane == 0) out[nr] = (uint32_t)(len << 4) | (uint32_t)curType;
       nr++;
-      if (curType == 0) { nm += (int)len; value += (float)len; }
-      else if (curType == 1) { nmm += (int)len; value -= (float)len; }
+      if (curType == 0) { nm += (int)len; addv(len); }
+      else if (curType == 1) { nmm += (int)len; addv(-len); }
       else {
-        float pen;
-        bool small = len <= 20;
-        if (len <= 20) pen = 0;
-        else if (len <= 10001) pen = -3.0f * A.lut[(int)((len - 1) / 5)] - 1;
-        else if (len <= 100001) pen = -1000;
-        else pen = -2000;
+        const bool small = len <= 20;
         if (curType == 3) {                                              // 'D' :447-470
           tdel += (int)len; nD++;
           if (len <= 10) sD++;
@@ -68,7 +68,15 @@ __global__ void __launch_bounds__(64) stats_kernel(StatArgs A) {
           if (len > 10 && len < 50) mI++; else if (len > 50) lI++;
           if (small) sI++;
         }
-        if (small) value -= (float)len; else value += pen;
+        if (small) addv(-len);
+        else {
+          if (!frac) { value = (float)ival; frac = true; }
+          float pen;
+          if (len <= 10001) pen = -3.0f * A.lut[(int)((len - 1) / 5)] - 1;
+          else if (len <= 100001) pen = -1000;
+          else pen = -2000;
+          value += pen;
+        }
       }
     };
     auto feed = [&](int type, long len) {                                // append `len` columns of one type
@@ -81,16 +89,38 @@ __global__ void __launch_bounds__(64) stats_kernel(StatArgs A) {
         const int cnt = (int)min(64L, len - off);
         bool x = false;
         if (lane < cnt) x = code2(R[q + off + lane]) != code2(G[t + off + lane]);
-        const unsigned long long mx = __ballot(x);
-        int pos = 0;
-        while (pos < cnt) {
-          const int cur = (int)((mx >> pos) & 1ULL);
-          unsigned long long y = (cur ? ~mx : mx) >> pos;               // first column of the other kind
-          int run = y ? __ffsll((long long)y) - 1 : 64;
-          run = min(run, cnt - pos);
-          feed(cur, run);
-          pos += run;
+        const unsigned long long valid = cnt == 64 ? ~0ULL : ((1ULL << cnt) - 1);
+        const unsigned long long mx = __ballot(x) & valid;
+        // run starts inside the chunk: column c > 0 whose kind differs from column c-1
+        const unsigned long long starts = ((mx ^ (mx << 1)) & valid) & ~1ULL;
+        if (!starts) { feed((int)(mx & 1ULL), cnt); continue; }          // the whole chunk is one kind
+        const int firstStart = __ffsll((long long)starts) - 1, lastStart = 63 - __clzll((long long)starts);
+        feed((int)(mx & 1ULL), firstStart);                              // head: continues the open run
+        close_run();
+        // interior runs [start_i, start_{i+1}): every run-start lane writes its own run
+        const int nInner = __popcll(starts) - 1;
+        if ((starts >> lane) & 1ULL && lane != lastStart) {
+          const unsigned long long later = starts & ~(below | (1ULL << lane));
+          const int nxt = __ffsll((long long)later) - 1;
+          out[nr + __popcll(starts & below)] = (uint32_t)((nxt - lane) << 4) | (uint32_t)((mx >> lane) & 1ULL);
         }
+        if (nInner > 0) {
+          const unsigned long long inner = ((1ULL << lastStart) - 1) & ~((1ULL << firstStart) - 1);   // columns [firstStart, lastStart)
+          const int nx = __popcll(mx & inner), ne = __popcll(inner) - nx;
+          nm += ne; nmm += nx;
+          if (!frac) ival += ne - nx;
+          else {                                                          // rare: apply in order
+            unsigned long long st2 = starts & ~(1ULL << lastStart);
+            while (st2) {
+              const int c0 = __ffsll((long long)st2) - 1; st2 &= st2 - 1;
+              const unsigned long long later = starts & ~((1ULL << c0) | ((1ULL << c0) - 1));
+              const int c1 = __ffsll((long long)later) - 1;
+              value += ((mx >> c0) & 1ULL) ? -(float)(c1 - c0) : (float)(c1 - c0);
+            }
+          }
+          nr += nInner;
+        }
+        curType = (int)((mx >> lastStart) & 1ULL); curLen = cnt - lastStart;   // tail: stays open
       }
     };
     if (nb > 0) {
@@ -112,18 +142,34 @@ __global__ void __launch_bounds__(64) stats_kernel(StatArgs A) {
       close_run();
     }
     if (lane == 0) {
-      if (!EMIT) {
-        int32_t* o = A.counts + 18 * (long)a;
-        o[0] = nm; o[1] = nmm; o[2] = nD; o[3] = nI; o[4] = tdel; o[5] = tins; o[6] = sD; o[7] = mD; o[8] = lD; o[9] = sI; o[10] = mI; o[11] = lI;
-        if (nb > 0) {
-          const long last = nb - 1;
-          o[12] = B[0]; o[13] = A.q_len[a] - B[3 * last] - B[3 * last + 2];
-          o[14] = B[0]; o[15] = B[3 * last] + B[3 * last + 2]; o[16] = B[1]; o[17] = B[3 * last + 1] + B[3 * last + 2];
-        } else { for (int x = 12; x < 18; x++) o[x] = 0; }
-        A.value[a] = value;
-        A.n_runs[a] = nr;
-      }
+      int32_t* o = A.counts + 18 * (long)a;
+      o[0] = nm; o[1] = nmm; o[2] = nD; o[3] = nI; o[4] = tdel; o[5] = tins; o[6] = sD; o[7] = mD; o[8] = lD; o[9] = sI; o[10] = mI; o[11] = lI;
+      if (nb > 0) {
+        const long last = nb - 1;
+        o[12] = B[0]; o[13] = A.q_len[a] - B[3 * last] - B[3 * last + 2];
+        o[14] = B[0]; o[15] = B[3 * last] + B[3 * last + 2]; o[16] = B[1]; o[17] = B[3 * last + 1] + B[3 * last + 2];
+      } else { for (int x = 12; x < 18; x++) o[x] = 0; }
+      A.value[a] = frac ? value : (float)ival;
+      A.n_runs[a] = nr;
     }
+  }
+}
+
+// capacity per alignment = aligned columns + 2 (every run has >= 1 column)
+__global__ void stats_capacity(int n_aln, const int32_t* blocks, const uint64_t* block_off, uint64_t* cap) {
+  int a = blockIdx.x * blockDim.x + threadIdx.x;
+  if (a >= n_aln) return;
+  const uint64_t b0 = block_off[a], b1 = block_off[a + 1];
+  if (b1 == b0) { cap[a] = 1; return; }
+  const int32_t* f = blocks + 3 * b0; const int32_t* l = blocks + 3 * (b1 - 1);
+  const long qs = (long)l[0] + l[2] - f[0], ts = (long)l[1] + l[2] - f[1];
+  cap[a] = (uint64_t)(max(qs, 0L) + max(ts, 0L) + 2);
+}
+
+__global__ void __launch_bounds__(64) stats_compact(int n_aln, const uint64_t* cap_off, const uint64_t* run_off, const uint32_t* src, uint32_t* dst) {
+  for (int a = blockIdx.x; a < n_aln; a += gridDim.x) {
+    const uint64_t s = cap_off[a], d = run_off[a], n = run_off[a + 1] - d;
+    for (uint64_t x = threadIdx.x; x < n; x += 64) dst[d + x] = src[s + x];
   }
 }
 
@@ -140,7 +186,7 @@ extern "C" int lra_calculate_statistics_batch(lra_ctx* ctx, int n_aln, const int
   hipStream_t st = ctx->stream;
   const size_t nA = (size_t)n_aln;
   auto sz = [](size_t n, size_t e) { return (n * e + 255) & ~(size_t)255; };
-  char* w = (char*)lra_scratch(ctx, 2, sz(18 * nA, 4) + sz(nA, 4) * 2 + sz(nA + 1, 8) + sz((size_t)n_lookup, 4) + 4096);
+  char* w = (char*)lra_scratch(ctx, 2, sz(18 * nA, 4) + sz(nA, 4) * 2 + sz(nA + 1, 8) * 2 + sz(nA, 8) + sz((size_t)n_lookup, 4) + 4096);
   if (!w) return LRA_ERR_NOMEM;
   StatArgs A;
   A.n_aln = n_aln; A.blocks = d_blocks; A.block_off = d_block_off;
@@ -149,12 +195,22 @@ extern "C" int lra_calculate_statistics_batch(lra_ctx* ctx, int n_aln, const int
   A.value = (float*)w; w += sz(nA, 4);
   A.n_runs = (uint32_t*)w; w += sz(nA, 4);
   uint64_t* run_off = (uint64_t*)w; w += sz(nA + 1, 8);
+  uint64_t* cap_off = (uint64_t*)w; w += sz(nA + 1, 8);
+  uint64_t* cap = (uint64_t*)w; w += sz(nA, 8);
   float* lut = (float*)w;
-  A.lut = lut; A.run_off = run_off; A.runs = nullptr;
+  A.lut = lut; A.cap_off = cap_off;
   LRA_HIP_CHECK(ctx, hipMemcpyAsync(lut, h_lookup, (size_t)n_lookup * 4, hipMemcpyHostToDevice, st));
+  hipLaunchKernelGGL(stats_capacity, dim3((n_aln + 255) / 256), dim3(256), 0, st, n_aln, d_blocks, d_block_off, cap);
+  if (lra_exclusive_scan<uint64_t>(ctx, (long)n_aln, cap, cap_off)) return LRA_ERR_HIP;
+  uint64_t total_cap = 0;
+  LRA_HIP_CHECK(ctx, hipMemcpyAsync(&total_cap, cap_off + n_aln, 8, hipMemcpyDeviceToHost, st));
+  LRA_HIP_CHECK(ctx, hipStreamSynchronize(st));
+  uint32_t* tmp = (uint32_t*)lra_ensure(ctx, 2, (total_cap + 1) * 4);      // shares the refine stage's temporary block buffer slot
+  if (!tmp) return LRA_ERR_NOMEM;
+  A.runs = tmp;
   const int grid = n_aln < ctx->num_cu * 32 ? n_aln : ctx->num_cu * 32;
   lra_time_begin(ctx, "stats");
-  hipLaunchKernelGGL(stats_kernel<false>, dim3(grid), dim3(64), 0, st, A);
+  hipLaunchKernelGGL(stats_kernel, dim3(grid), dim3(64), 0, st, A);
   lra_time_end(ctx);
   if (lra_exclusive_scan<uint32_t>(ctx, (long)n_aln, A.n_runs, run_off)) return LRA_ERR_HIP;
   uint64_t total = 0;
@@ -162,9 +218,8 @@ extern "C" int lra_calculate_statistics_batch(lra_ctx* ctx, int n_aln, const int
   LRA_HIP_CHECK(ctx, hipStreamSynchronize(st));
   uint32_t* runs = (uint32_t*)lra_scratch(ctx, 3, (total + 1) * 4);
   if (!runs) return LRA_ERR_NOMEM;
-  A.runs = runs;
   lra_time_begin(ctx, "stats_cigar");
-  hipLaunchKernelGGL(stats_kernel<true>, dim3(grid), dim3(64), 0, st, A);
+  hipLaunchKernelGGL(stats_compact, dim3(grid), dim3(64), 0, st, n_aln, cap_off, run_off, tmp, runs);
   lra_time_end(ctx);
   LRA_HIP_CHECK(ctx, hipGetLastError());
   LRA_HIP_CHECK(ctx, hipStreamSynchronize(st));

@@ -89,3 +89,12 @@ def fetch_stats(ctx: Context, res: StatsResult):
     runs = ctx.to_host(res.d_runs, res.n_runs, np.uint32)
     cigars = ["".join("%d%s" % (r >> 4, "=XID"[r & 15]) for r in runs[int(off[a]):int(off[a + 1])]) for a in range(res.n_aln)]
     return counts, value, cigars
+
+
+def stats_of_refined(ctx: Context, b: RefineBatch, rres: RefineResult, lookup_table):
+    """CalculateStatistics straight on the (context-owned) output of indel_refine_batch, no copies."""
+    v = RefineBatch.__new__(RefineBatch)
+    v.ctx, v.n, v.n_blocks_in = ctx, b.n, int(rres.n_blocks)
+    v.blocks, v.block_off = int(rres.d_blocks), int(rres.d_block_off)
+    v.q_seq, v.q_off, v.q_len, v.t_seq, v.t_off, v.t_len = b.q_seq, b.q_off, b.q_len, b.t_seq, b.t_off, b.t_len
+    return calculate_statistics_batch(ctx, v, lookup_table)
