@@ -160,6 +160,37 @@ typedef struct lra_extend_result {
 } lra_extend_result;
 int lra_linear_extend_batch(lra_ctx* ctx, int K, const char* d_seq, const uint64_t* d_read_off, lra_extend_result* out);
 
+/* ---- a10: tier-2 (local) minimizer index and lookups ----------------------------------------
+ * lra_local_index_batch replaces  LocalIndex::IndexSeq(char* seq, int seqLen)  (MMIndex.h:200-245) for
+ * n_seqs sequences (read strands, Map_lowacc.h:246-250; or chromosomes = LocalIndex::IndexFile, the
+ * `.gli` payload): per `window` bases the non-canonical (w,k) minimizers (MinCount.h:182), sorted by
+ * k-mer with std::sort (MMIndex.h:219) and thinned by RemoveFrequent(maxFreq) (MMIndex.h:69).
+ * LocalTuple = uint32  t | pos << 20  (TupleOps.h:20-25; pos relative to the window start).
+ * Two-call protocol: call with d_out_buf = NULL to get bytes_needed, allocate, call again; the
+ * result then lives in the caller's buffer:  d_win_off[n_seqs+1] (first window of each sequence),
+ * d_tuple_bnd[n_windows+1] (tupleBoundaries), d_tuples[n_tuples].  Synchronous.
+ *
+ * lra_local_compare_batch replaces  CompareLists<LocalTuple,SmallTuple>(qBegin,qEnd,tBegin,tEnd,result,
+ * opts,false,maxDiagNum,minDiagNum)  (CompareLists.h:9) for n_tasks (query list, target list) pairs
+ * given as index ranges into two tuple arrays; max_freq = opts.localMaxFreq; per-task diagonal bounds
+ * (NULL = unbounded; the filter applies only when both are non-zero, CompareLists.h:87).  Output: the
+ * emitted pairs as absolute indices into the two tuple arrays, CSR by task, in the reference's order
+ * (context-owned, valid until the next call).  Synchronous.                                        */
+typedef struct lra_local_index_result {
+  int32_t n_seqs;
+  uint64_t n_windows, n_tuples, bytes_needed;
+  const uint64_t* d_win_off; const uint64_t* d_tuple_bnd; const uint32_t* d_tuples;
+} lra_local_index_result;
+int lra_local_index_batch(lra_ctx* ctx, int n_seqs, const char* d_seq, const uint64_t* d_seq_off, int k, int w, int window,
+                          int max_freq, void* d_out_buf, uint64_t out_buf_bytes, lra_local_index_result* out);
+typedef struct lra_local_pairs_result {
+  uint64_t n_tasks, n_pairs;
+  const uint64_t* d_pair_off; const uint32_t* d_pair_qi; const uint32_t* d_pair_ti;
+} lra_local_pairs_result;
+int lra_local_compare_batch(lra_ctx* ctx, uint64_t n_tasks, const uint32_t* d_q_tuples, const uint64_t* d_q_lo, const uint64_t* d_q_hi,
+                            const uint32_t* d_t_tuples, const uint64_t* d_t_lo, const uint64_t* d_t_hi, int max_freq,
+                            const int64_t* d_max_diag, const int64_t* d_min_diag, lra_local_pairs_result* out);
+
 /* ---- a12: banded one-gap seed-extension DP ------------------------------------------
  * Replaces   int AffineOneGapAlign(string& qSeq, int qLen, string& tSeq, int tLen,
  *                                  int m, int mm, int indel, int k, Alignment& aln,

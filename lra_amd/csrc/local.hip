@@ -1,0 +1,411 @@
+// lra_amd/csrc/local.hip -- tier-2 (local) minimizer index and lookups on gfx950.
+//
+//   lra_local_index_batch     LocalIndex::IndexSeq (MMIndex.h:200-245): per 256-base window the
+//                             non-canonical (w,k)-minimizers (StoreMinimizers_noncanonical,
+//                             MinCount.h:182-338), std::sort by k-mer (MMIndex.h:219), RemoveFrequent
+//                             (MMIndex.h:69-84).  Used for reads (both strands, Map_lowacc.h:246-250) and
+//                             for genomes (LocalIndex::IndexFile, MMIndex.h:247-254 = the `.gli` payload).
+//   lra_local_compare_batch   CompareLists<LocalTuple,SmallTuple> with Global=false and a diagonal band
+//                             (CompareLists.h:9-146) over (read-window list, genome-window list) tasks,
+//                             the lookup Refine_splitchain / REFINEclusters perform (ChainRefine.h:384,
+//                             ClusterRefine.h:50).
+// A LocalTuple is the word  t | pos << 20  (TupleOps.h:20-25).  Windows hold ~40-80 tuples, so every
+// window / task is one lane: 7.7 M windows per 32 k-read batch keep the chip full.
+#include "common.h"
+#include "scan.h"
+#include <algorithm>
+
+namespace {
+
+constexpr uint32_t TMASK = 0xFFFFF;
+__device__ __forceinline__ uint32_t T_(uint32_t v) { return v & TMASK; }
+__device__ __forceinline__ uint32_t P_(uint32_t v) { return v >> 20; }
+
+__device__ __forceinline__ int code_n(unsigned char c) {
+  if (c < 8) return c & 3;
+  switch (c) {
+    case 'A': case 'a': return 0;
+    case 'C': case 'c': return 1;
+    case 'G': case 'g': return 2;
+    case 'T': case 't': return 3;
+    default: return 4;
+  }
+}
+__device__ __forceinline__ uint32_t code2(unsigned char c) { int v = code_n(c); return v > 3 ? 0u : (uint32_t)v; }
+
+constexpr int MAXW = 16;
+
+// window -> (sequence, start, length)
+__global__ void window_map(int n_seqs, const uint64_t* __restrict__ seq_off, int window, const uint64_t* __restrict__ win_off,
+                           uint32_t* __restrict__ w_seq, uint64_t* __restrict__ w_start, uint32_t* __restrict__ w_len) {
+  int s = blockIdx.x * blockDim.x + threadIdx.x;
+  if (s >= n_seqs) return;
+  const uint64_t a = seq_off[s], L = seq_off[s + 1] - a;
+  uint64_t wi = win_off[s];
+  for (uint64_t p = 0; p < L; p += window, wi++) { w_seq[wi] = s; w_start[wi] = a + p; w_len[wi] = (uint32_t)std::min<uint64_t>((uint64_t)window, L - p); }
+}
+__global__ void window_count(int n_seqs, const uint64_t* __restrict__ seq_off, int window, uint32_t* __restrict__ nwin) {
+  int s = blockIdx.x * blockDim.x + threadIdx.x;
+  if (s >= n_seqs) return;
+  const uint64_t L = seq_off[s + 1] - seq_off[s];
+  nwin[s] = (uint32_t)(L / window + (L % window != 0 ? 1 : 0));        // MMIndex.h:201-206
+}
+
+// StoreMinimizers_noncanonical for one window per lane.  EMIT=false counts.
+template <bool EMIT>
+__global__ void __launch_bounds__(64) local_sketch(uint64_t n_win, const unsigned char* __restrict__ seq_all, const uint64_t* __restrict__ w_start,
+                                                   const uint32_t* __restrict__ w_len, int k, int w, const uint64_t* __restrict__ raw_off,
+                                                   uint32_t* __restrict__ raw, uint32_t* __restrict__ counts) {
+  __shared__ uint32_t ringT[MAXW * 64], ringP[MAXW * 64];
+  const int lane = threadIdx.x;
+  const uint64_t wi = (uint64_t)blockIdx.x * 64 + lane;
+  if (wi >= n_win) return;
+  const unsigned char* seq = seq_all + w_start[wi];
+  const uint32_t seqLen = w_len[wi];
+  uint32_t* out = EMIT ? raw + raw_off[wi] : nullptr;
+  uint32_t n = 0;
+#define LS_EMIT(T__, P__) do { if (EMIT) out[n] = ((T__) & TMASK) | (((P__) & 0xFFFu) << 20); n++; } while (0)
+#define LS_DONE() do { if (!EMIT) counts[wi] = n; return; } while (0)
+  const int span = w + k - 1;
+  if (seqLen < (uint32_t)k || seqLen < (uint32_t)span) LS_DONE();        // :186,:199
+  const uint32_t kmask = (k >= 16) ? 0xFFFFFFFFu : ((1u << (2 * k)) - 1);
+  long nvStart = 0, nvEnd = 0;
+  bool valid = false;
+  auto find_valid = [&]() -> bool {                                      // :200-214
+    valid = false;
+    while ((uint32_t)nvStart < seqLen - (uint32_t)span && !valid) {
+      valid = true;
+      for (long x = nvStart; valid && x < nvStart + span; x++)
+        if (code_n(seq[x]) > 3) { nvStart = x + 1; valid = false; }
+    }
+    return valid;
+  };
+  if (!find_valid()) LS_DONE();
+  nvEnd = nvStart + span;
+  uint32_t cur = 0;
+  for (int p = 0; p < k; p++) cur = ((cur << 2) + code2(seq[p])) & TMASK;
+  auto shift = [&](uint32_t at) { cur = ((((cur << 2) & TMASK) & kmask) + code2(seq[at])) & TMASK; };
+  uint32_t actT = cur, actP = 0;
+  ringT[lane] = actT; ringP[lane] = 0;
+  uint32_t p;
+  const uint32_t nk = seqLen - k + 1;
+  for (p = 1; p < (uint32_t)w && p < nk; p++) {                          // :251-270
+    shift(p + k - 1);
+    if (cur < actT) { actT = cur; actP = p; }
+    ringT[(p % w) * 64 + lane] = cur; ringP[(p % w) * 64 + lane] = p;
+  }
+  if (nvEnd == span) LS_EMIT(actT, actP);
+  for (p = w; p < nk; p++) {                                             // :276-337
+    shift(p + k - 1);
+    if (nvEnd == (long)(p + k - 1)) {
+      if (code_n(seq[p + k - 1]) <= 3) nvEnd++;
+      else {
+        nvStart = p + k;
+        if (!find_valid()) LS_DONE();
+        nvEnd = nvStart + span;
+      }
+    }
+    ringT[(p % w) * 64 + lane] = cur; ringP[(p % w) * 64 + lane] = p;
+    if (p - w >= actP) {
+      actT = ringT[lane]; actP = ringP[lane];
+      for (int j = 1; j < w; j++) { uint32_t t = ringT[j * 64 + lane]; if (t < actT) { actT = t; actP = ringP[j * 64 + lane]; } }
+      if (nvEnd == (long)(p + k)) LS_EMIT(actT, actP);
+    } else if (cur < actT) {
+      actT = cur; actP = p;
+      if (nvEnd == (long)(p + k)) LS_EMIT(actT, actP);
+    }
+  }
+  LS_DONE();
+#undef LS_EMIT
+#undef LS_DONE
+}
+
+// ---- libstdc++ std::sort on a list of LocalTuple words (comparison on t only), one lane per list
+__device__ __forceinline__ bool wlt(uint32_t a, uint32_t b) { return T_(a) < T_(b); }
+
+__device__ void w_adjust_heap(uint32_t* v, long first, long hole, long len, uint32_t val) {
+  const long top = hole;
+  long child = hole;
+  while (child < (len - 1) / 2) {
+    child = 2 * (child + 1);
+    if (wlt(v[first + child], v[first + child - 1])) child--;
+    v[first + hole] = v[first + child];
+    hole = child;
+  }
+  if ((len & 1) == 0 && child == (len - 2) / 2) {
+    child = 2 * (child + 1);
+    v[first + hole] = v[first + child - 1];
+    hole = child - 1;
+  }
+  long parent = (hole - 1) / 2;
+  while (hole > top && wlt(v[first + parent], val)) { v[first + hole] = v[first + parent]; hole = parent; parent = (hole - 1) / 2; }
+  v[first + hole] = val;
+}
+
+__device__ void w_std_sort(uint32_t* v, long n) {
+  if (n < 2) return;
+  long stF[40], stL[40]; int stD[40];
+  int sp = 0;
+  stF[0] = 0; stL[0] = n; stD[0] = 2 * (63 - __clzll((unsigned long long)n)); sp = 1;
+  while (sp > 0) {
+    --sp;
+    long first = stF[sp], last = stL[sp]; int depth = stD[sp];
+    while (last - first > 16) {
+      if (depth == 0) {                                                  // __partial_sort(first,last,last)
+        long len = last - first;
+        for (long parent = (len - 2) / 2;; parent--) { w_adjust_heap(v, first, parent, len, v[first + parent]); if (parent == 0) break; }
+        long l2 = last;
+        while (l2 - first > 1) { --l2; uint32_t val = v[l2]; v[l2] = v[first]; w_adjust_heap(v, first, 0, l2 - first, val); }
+        break;
+      }
+      --depth;
+      const long a = first + 1, b = first + (last - first) / 2, c = last - 1;
+      auto sw = [&](long x, long y) { uint32_t t = v[x]; v[x] = v[y]; v[y] = t; };
+      if (wlt(v[a], v[b])) { if (wlt(v[b], v[c])) sw(first, b); else if (wlt(v[a], v[c])) sw(first, c); else sw(first, a); }
+      else if (wlt(v[a], v[c])) sw(first, a);
+      else if (wlt(v[b], v[c])) sw(first, c);
+      else sw(first, b);
+      long f = first + 1, l = last;
+      const uint32_t pv = v[first];
+      while (true) {
+        while (wlt(v[f], pv)) ++f;
+        --l;
+        while (wlt(pv, v[l])) --l;
+        if (!(f < l)) break;
+        sw(f, l);
+        ++f;
+      }
+      if (sp < 40) { stF[sp] = f; stL[sp] = last; stD[sp] = depth; sp++; }
+      last = f;
+    }
+  }
+  auto ins = [&](long first, long last) {                                // __insertion_sort
+    for (long i = first + 1; i < last; ++i) {
+      uint32_t val = v[i];
+      if (wlt(val, v[first])) { for (long x = i; x > first; --x) v[x] = v[x - 1]; v[first] = val; }
+      else { long j = i; while (wlt(val, v[j - 1])) { v[j] = v[j - 1]; --j; } v[j] = val; }
+    }
+  };
+  if (n > 16) {
+    ins(0, 16);
+    for (long i = 16; i < n; ++i) { uint32_t val = v[i]; long j = i; while (wlt(val, v[j - 1])) { v[j] = v[j - 1]; --j; } v[j] = val; }
+  } else ins(0, n);
+}
+
+// sort + RemoveFrequent in place; counts[wi] = surviving tuples
+__global__ void __launch_bounds__(64) local_sort_filter(uint64_t n_win, const uint64_t* __restrict__ raw_off, uint32_t* raw, int maxFreq, uint32_t* __restrict__ counts) {
+  const uint64_t wi = (uint64_t)blockIdx.x * 64 + threadIdx.x;
+  if (wi >= n_win) return;
+  uint32_t* v = raw + raw_off[wi];
+  const long n = (long)(raw_off[wi + 1] - raw_off[wi]);
+  w_std_sort(v, n);                                                      // MMIndex.h:219
+  long c = 0, x = 0;                                                     // RemoveFrequent MMIndex.h:69-84
+  while (x < n) {
+    long ne = x;
+    while (ne < n && T_(v[ne]) == T_(v[x])) ne++;
+    if (ne - x < maxFreq) for (long y = x; y < ne; y++) v[c++] = v[y];
+    x = ne;
+  }
+  counts[wi] = (uint32_t)c;
+}
+
+__global__ void __launch_bounds__(64) local_compact(uint64_t n_win, const uint64_t* __restrict__ raw_off, const uint32_t* __restrict__ raw,
+                                                    const uint64_t* __restrict__ bnd, uint32_t* __restrict__ out) {
+  const uint64_t wi = (uint64_t)blockIdx.x * 64 + threadIdx.x;
+  if (wi >= n_win) return;
+  const uint32_t* s = raw + raw_off[wi];
+  uint32_t* d = out + bnd[wi];
+  const long n = (long)(bnd[wi + 1] - bnd[wi]);
+  for (long x = 0; x < n; x++) d[x] = s[x];
+}
+
+// ---- CompareLists<LocalTuple,SmallTuple>, one lane per task
+struct CmpArgs {
+  uint64_t n_tasks;
+  const uint32_t* q; const uint64_t* q_lo; const uint64_t* q_hi;
+  const uint32_t* t; const uint64_t* t_lo; const uint64_t* t_hi;
+  long maxFreq; const int64_t* maxDiag; const int64_t* minDiag;
+  const uint64_t* out_off; uint32_t* out_qi; uint32_t* out_ti; uint32_t* counts;
+};
+
+template <bool EMIT>
+__global__ void __launch_bounds__(64) local_compare(CmpArgs A) {
+  const uint64_t x = (uint64_t)blockIdx.x * 64 + threadIdx.x;
+  if (x >= A.n_tasks) return;
+  const uint32_t* q = A.q + A.q_lo[x]; const uint32_t* t = A.t + A.t_lo[x];
+  const long nq = (long)(A.q_hi[x] - A.q_lo[x]), nt = (long)(A.t_hi[x] - A.t_lo[x]);
+  const int64_t maxDiag = A.maxDiag ? A.maxDiag[x] : 0, minDiag = A.minDiag ? A.minDiag[x] : 0;
+  const long maxFreq = A.maxFreq;
+  uint32_t* oq = EMIT ? A.out_qi + A.out_off[x] : nullptr; uint32_t* ot = EMIT ? A.out_ti + A.out_off[x] : nullptr;
+  uint32_t n = 0;
+  auto emit = [&](long qi, long ti) {                                    // :87-97
+    if (maxDiag != 0 && minDiag != 0) {
+      const int64_t d = (int64_t)P_(t[ti]) - (int64_t)P_(q[qi]);
+      if (!(d <= maxDiag && d >= minDiag)) return;
+    }
+    if (EMIT) { oq[n] = (uint32_t)(A.q_lo[x] + qi); ot[n] = (uint32_t)(A.t_lo[x] + ti); }
+    n++;
+  };
+#define Q(i) T_(q[(i)])
+#define TT(i) T_(t[(i)])
+  if (nq != 0 && nt != 0) {
+    long qs = 0, qe = nq - 1, ts = 0, te = nt;
+    do {
+      while (qs <= qe && Q(qs) < TT(ts)) qs++;
+      if (qs >= qe) break;
+      const uint32_t startGap = (Q(qs) - TT(ts)) & TMASK;
+      while (qe > qs && te > ts && Q(qe) > TT(te - 1)) qe--;
+      const uint32_t endGap = (TT(te - 1) - Q(qe)) & TMASK;
+      if (startGap == 0 || startGap > endGap) {
+        const long tsOrig = ts, qsOrig = qs;
+        long lo = ts, hi = te;
+        while (lo < hi) { long mid = lo + (hi - lo) / 2; if (TT(mid) < Q(qs)) lo = mid + 1; else hi = mid; }
+        ts = lo;
+        if (ts < te && TT(ts) == Q(qs)) {
+          long tsi = ts;
+          while (tsi != te && Q(qs) == TT(tsi)) tsi++;
+          const long qsStart = qs;
+          while (qs < qe && Q(qs + 1) == Q(qs)) qs++;
+          if (qs - qsStart < maxFreq)
+            for (long ti = ts; ti != tsi; ti++)
+              for (long qi = qsStart; qi <= qs; qi++) emit(qi, ti);
+        }
+        { const uint32_t raw = TT(tsOrig); while (ts < te && TT(ts) == raw) ts++; }
+        { const uint32_t raw = Q(qsOrig); while (qs < qe && Q(qs) == raw) qs++; }
+      } else {
+        if (te != nt && TT(te - 1) == Q(qe)) {
+        } else {
+          long lo = ts, hi = te;
+          while (lo < hi) { long mid = lo + (hi - lo) / 2; if (!(Q(qe) < TT(mid))) lo = mid + 1; else hi = mid; }
+          te = lo;
+        }
+        const long teStart = te;
+        long tei = te;
+        while (tei > ts && TT(tei - 1) == Q(qe)) tei--;
+        if (tei < teStart && teStart > 0) {
+          const long qeStart = qe;
+          while (qe > qs && Q(qe) == Q(qe - 1)) qe--;
+          if (qeStart - qe < maxFreq)
+            for (long ti = tei; ti < teStart; ti++)
+              for (long qi = qe; qi <= qeStart; qi++) emit(qi, ti);
+        }
+        te = tei;
+      }
+    } while (qs < qe && ts < te);
+  }
+#undef Q
+#undef TT
+  if (!EMIT) A.counts[x] = n;
+}
+
+template <typename T>
+static T* carve(char*& p, size_t n) { T* r = (T*)p; p += (n * sizeof(T) + 255) & ~(size_t)255; return r; }
+static int d2h8(lra_ctx* ctx, uint64_t* dst, const uint64_t* src) {
+  LRA_HIP_CHECK(ctx, hipMemcpyAsync(dst, src, 8, hipMemcpyDeviceToHost, ctx->stream));
+  LRA_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+  return LRA_OK;
+}
+
+}  // namespace
+
+extern "C" int lra_local_index_batch(lra_ctx* ctx, int n_seqs, const char* d_seq, const uint64_t* d_seq_off, int k, int w, int window,
+                                     int max_freq, void* d_out_buf, uint64_t out_buf_bytes, lra_local_index_result* out) {
+  if (!ctx || !out || n_seqs < 0) return LRA_ERR_INVALID;
+  if (k < 1 || k > 10 || w < 1 || w > MAXW || window < w + k || window > 4096)
+    return lra_set_err(ctx, LRA_ERR_INVALID, "need 1<=k<=10 (20-bit LocalTuple), 1<=w<=%d, w+k<=window<=4096", MAXW);
+  memset(out, 0, sizeof(*out));
+  if (n_seqs == 0) return LRA_OK;
+  LRA_HIP_CHECK(ctx, hipSetDevice(ctx->device));
+  hipStream_t st = ctx->stream;
+  auto sz = [](size_t n, size_t e) { return (n * e + 255) & ~(size_t)255; };
+  // pass 0: windows per sequence
+  char* w0 = (char*)lra_scratch(ctx, 0, sz((size_t)n_seqs + 1, 4) + sz((size_t)n_seqs + 1, 8) + 4096);
+  if (!w0) return LRA_ERR_NOMEM;
+  uint32_t* nwin = carve<uint32_t>(w0, (size_t)n_seqs + 1);
+  uint64_t* win_off = carve<uint64_t>(w0, (size_t)n_seqs + 1);
+  hipLaunchKernelGGL(window_count, dim3((n_seqs + 255) / 256), dim3(256), 0, st, n_seqs, d_seq_off, window, nwin);
+  if (lra_exclusive_scan<uint32_t>(ctx, (long)n_seqs, nwin, win_off)) return LRA_ERR_HIP;
+  uint64_t n_win = 0;
+  if (d2h8(ctx, &n_win, win_off + n_seqs)) return LRA_ERR_HIP;
+  // per-window arrays
+  const size_t NW = (size_t)n_win + 2;
+  char* w1 = (char*)lra_scratch(ctx, 1, sz(NW, 4) * 3 + sz(NW, 8) * 3 + 4096);
+  if (!w1) return LRA_ERR_NOMEM;
+  uint32_t* w_seq = carve<uint32_t>(w1, NW); uint32_t* w_len = carve<uint32_t>(w1, NW); uint32_t* cnt = carve<uint32_t>(w1, NW);
+  uint64_t* w_start = carve<uint64_t>(w1, NW); uint64_t* raw_off = carve<uint64_t>(w1, NW); uint64_t* bnd_tmp = carve<uint64_t>(w1, NW);
+  const unsigned char* seq = (const unsigned char*)d_seq;
+  const unsigned gw = (unsigned)((n_win + 63) / 64);
+  uint64_t n_raw = 0, n_tup = 0;
+  if (n_win) {
+    hipLaunchKernelGGL(window_map, dim3((n_seqs + 255) / 256), dim3(256), 0, st, n_seqs, d_seq_off, window, win_off, w_seq, w_start, w_len);
+    lra_time_begin(ctx, "local_sketch");
+    hipLaunchKernelGGL(local_sketch<false>, dim3(gw), dim3(64), 0, st, n_win, seq, w_start, w_len, k, w, (const uint64_t*)nullptr, (uint32_t*)nullptr, cnt);
+    lra_time_end(ctx);
+    if (lra_exclusive_scan<uint32_t>(ctx, (long)n_win, cnt, raw_off)) return LRA_ERR_HIP;
+    if (d2h8(ctx, &n_raw, raw_off + n_win)) return LRA_ERR_HIP;
+  }
+  uint32_t* raw = (uint32_t*)lra_scratch(ctx, 2, (n_raw + 1) * 4);
+  if (!raw) return LRA_ERR_NOMEM;
+  if (n_win) {
+    lra_time_begin(ctx, "local_sketch");
+    hipLaunchKernelGGL(local_sketch<true>, dim3(gw), dim3(64), 0, st, n_win, seq, w_start, w_len, k, w, raw_off, raw, (uint32_t*)nullptr);
+    lra_time_end(ctx);
+    lra_time_begin(ctx, "local_sort_filter");
+    hipLaunchKernelGGL(local_sort_filter, dim3(gw), dim3(64), 0, st, n_win, raw_off, raw, max_freq, cnt);
+    lra_time_end(ctx);
+    if (lra_exclusive_scan<uint32_t>(ctx, (long)n_win, cnt, bnd_tmp)) return LRA_ERR_HIP;
+    if (d2h8(ctx, &n_tup, bnd_tmp + n_win)) return LRA_ERR_HIP;
+  }
+  // results live in the caller's buffer: [win_off: n_seqs+1 u64][bnd: n_win+1 u64][tuples: n_tup u32]
+  const uint64_t need = sz((size_t)n_seqs + 1, 8) + sz(NW, 8) + sz((size_t)n_tup + 1, 4);
+  out->n_seqs = n_seqs; out->n_windows = n_win; out->n_tuples = n_tup; out->bytes_needed = need;
+  if (!d_out_buf || out_buf_bytes < need) return LRA_OK;                   // sizing call: the caller allocates and calls again
+  char* ob = (char*)d_out_buf;
+  uint64_t* o_win = carve<uint64_t>(ob, (size_t)n_seqs + 1); uint64_t* o_bnd = carve<uint64_t>(ob, NW); uint32_t* o_tup = carve<uint32_t>(ob, (size_t)n_tup + 1);
+  LRA_HIP_CHECK(ctx, hipMemcpyAsync(o_win, win_off, ((size_t)n_seqs + 1) * 8, hipMemcpyDeviceToDevice, st));
+  if (n_win) {
+    LRA_HIP_CHECK(ctx, hipMemcpyAsync(o_bnd, bnd_tmp, ((size_t)n_win + 1) * 8, hipMemcpyDeviceToDevice, st));
+    hipLaunchKernelGGL(local_compact, dim3(gw), dim3(64), 0, st, n_win, raw_off, raw, bnd_tmp, o_tup);
+  }
+  LRA_HIP_CHECK(ctx, hipGetLastError());
+  LRA_HIP_CHECK(ctx, hipStreamSynchronize(st));
+  out->d_win_off = o_win; out->d_tuple_bnd = o_bnd; out->d_tuples = o_tup;
+  return LRA_OK;
+}
+
+extern "C" int lra_local_compare_batch(lra_ctx* ctx, uint64_t n_tasks, const uint32_t* d_q_tuples, const uint64_t* d_q_lo, const uint64_t* d_q_hi,
+                                       const uint32_t* d_t_tuples, const uint64_t* d_t_lo, const uint64_t* d_t_hi, int max_freq,
+                                       const int64_t* d_max_diag, const int64_t* d_min_diag, lra_local_pairs_result* out) {
+  if (!ctx || !out) return LRA_ERR_INVALID;
+  memset(out, 0, sizeof(*out));
+  out->n_tasks = n_tasks;
+  if (n_tasks == 0) return LRA_OK;
+  LRA_HIP_CHECK(ctx, hipSetDevice(ctx->device));
+  hipStream_t st = ctx->stream;
+  auto sz = [](size_t n, size_t e) { return (n * e + 255) & ~(size_t)255; };
+  char* w = (char*)lra_scratch(ctx, 0, sz(n_tasks + 1, 4) + sz(n_tasks + 1, 8) + 4096);
+  if (!w) return LRA_ERR_NOMEM;
+  CmpArgs A;
+  A.n_tasks = n_tasks; A.q = d_q_tuples; A.q_lo = d_q_lo; A.q_hi = d_q_hi; A.t = d_t_tuples; A.t_lo = d_t_lo; A.t_hi = d_t_hi;
+  A.maxFreq = max_freq; A.maxDiag = d_max_diag; A.minDiag = d_min_diag;
+  A.counts = carve<uint32_t>(w, n_tasks + 1);
+  uint64_t* off = carve<uint64_t>(w, n_tasks + 1);
+  A.out_off = off; A.out_qi = nullptr; A.out_ti = nullptr;
+  const unsigned g = (unsigned)((n_tasks + 63) / 64);
+  lra_time_begin(ctx, "local_compare");
+  hipLaunchKernelGGL(local_compare<false>, dim3(g), dim3(64), 0, st, A);
+  lra_time_end(ctx);
+  if (lra_exclusive_scan<uint32_t>(ctx, (long)n_tasks, A.counts, off)) return LRA_ERR_HIP;
+  uint64_t total = 0;
+  if (d2h8(ctx, &total, off + n_tasks)) return LRA_ERR_HIP;
+  char* r = (char*)lra_scratch(ctx, 1, sz(total + 1, 4) * 2 + 4096);
+  if (!r) return LRA_ERR_NOMEM;
+  A.out_qi = carve<uint32_t>(r, total + 1); A.out_ti = carve<uint32_t>(r, total + 1);
+  lra_time_begin(ctx, "local_compare");
+  hipLaunchKernelGGL(local_compare<true>, dim3(g), dim3(64), 0, st, A);
+  lra_time_end(ctx);
+  LRA_HIP_CHECK(ctx, hipGetLastError());
+  LRA_HIP_CHECK(ctx, hipStreamSynchronize(st));
+  out->n_pairs = total; out->d_pair_off = off; out->d_pair_qi = A.out_qi; out->d_pair_ti = A.out_ti;
+  return LRA_OK;
+}

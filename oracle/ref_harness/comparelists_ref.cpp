@@ -17,12 +17,36 @@ using namespace std;
 #include "TupleOps.h"
 #include "CompareLists.h"
 
+// mode 1 (first token "L"): CompareLists<LocalTuple,SmallTuple> with Global=false and a diagonal band:
+//   L nq nt maxFreq maxDiag minDiag   then nq + nt lines "t pos"   ->  "n qi0 ti0 ..." (list indices)
+static void local_mode() {
+  long nq, nt, maxFreq, maxDiag, minDiag;
+  cin >> nq >> nt >> maxFreq >> maxDiag >> minDiag;
+  vector<LocalTuple> q(nq), t(nt);
+  for (long i = 0; i < nq; i++) { unsigned a, b; cin >> a >> b; q[i].t = a; q[i].pos = b; }
+  for (long i = 0; i < nt; i++) { unsigned a, b; cin >> a >> b; t[i].t = a; t[i].pos = b; }
+  Options opts;
+  opts.localMaxFreq = maxFreq;
+  vector<pair<LocalTuple, LocalTuple> > res;
+  // identify emitted tuples by address-free keys: (t,pos) may repeat, so tag pos with the index
+  CompareLists<LocalTuple, SmallTuple>(q.begin(), q.end(), t.begin(), t.end(), res, opts, false, maxDiag, minDiag, false);
+  cout << res.size();
+  for (auto& r : res) cout << " " << r.first.t << " " << r.first.pos << " " << r.second.t << " " << r.second.pos;
+  cout << "\n";
+}
+
 int main() {
+  LocalTuple::for_mask_s = 0xFFFFF;   // as InitStatic (lra.cpp:1013-1017)
+  LocalTuple::rev_mask_s = 0;
   Tuple mask = 1;
   GenomeTuple::for_mask_s = ~(mask << 63);   // as InitStatic (lra.cpp:1008-1012)
   GenomeTuple::rev_mask_s = (mask << 63);
   long nq, nt, maxFreq; int sortq;
-  while (cin >> nq >> nt >> maxFreq >> sortq) {
+  string tok;
+  while (cin >> tok) {
+    if (tok == "L") { local_mode(); continue; }
+    nq = stol(tok);
+    cin >> nt >> maxFreq >> sortq;
     vector<GenomeTuple> q(nq), t(nt);
     for (long i = 0; i < nq; i++) { unsigned long long a; unsigned int b; cin >> a >> b; q[i].t = a; q[i].pos = b; }
     for (long i = 0; i < nt; i++) { unsigned long long a; unsigned int b; cin >> a >> b; t[i].t = a; t[i].pos = b; }

@@ -206,3 +206,42 @@ def calculate_statistics(blocks, read: bytes, genome: bytes):
     runs = runs[:n].copy()
     cigar = "".join("%d%s" % (r >> 4, "=XID"[r & 15]) for r in runs)
     return dict(zip(STAT_NAMES, counts.tolist())), np.float32(val.value), runs, cigar
+
+
+def pack_local(t, pos):
+    """LocalTuple words  t | pos << 20  (TupleOps.h:20-25)."""
+    return (np.asarray(t, dtype=np.uint32) & np.uint32(0xFFFFF)) | (np.asarray(pos, dtype=np.uint32) << np.uint32(20))
+
+
+def store_minimizers_noncanonical(seq: bytes, k, w):
+    L = lib()
+    cap = max(1, len(seq))
+    out = np.zeros(cap, dtype=np.uint32)
+    L.oracle_store_minimizers_noncanonical.restype = C.c_long
+    n = L.oracle_store_minimizers_noncanonical(C.c_char_p(seq), C.c_uint32(len(seq)), k, w, _p(out, C.c_uint32), C.c_long(cap))
+    return out[:n].copy()
+
+
+def local_index_seq(seq: bytes, k, w, window, max_freq):
+    """LocalIndex::IndexSeq: (tuples uint32, boundaries uint64[nWindows+1])."""
+    L = lib()
+    nwin = (len(seq) + window - 1) // window
+    cap = max(1, len(seq))
+    tup = np.zeros(cap, dtype=np.uint32)
+    bnd = np.zeros(nwin + 1, dtype=np.uint64)
+    L.oracle_local_index_seq.restype = C.c_long
+    n = L.oracle_local_index_seq(C.c_char_p(seq), C.c_long(len(seq)), k, w, window, max_freq, _p(tup, C.c_uint32), C.c_long(cap), _p(bnd, C.c_uint64))
+    assert n == nwin
+    return tup[:int(bnd[-1])].copy(), bnd
+
+
+def compare_lists_local(q, t, max_freq, max_diag=0, min_diag=0):
+    L = lib()
+    q = np.ascontiguousarray(q, dtype=np.uint32); t = np.ascontiguousarray(t, dtype=np.uint32)
+    cap = max(1, 3 * len(q) * max(1, len(t)))
+    oq = np.zeros(cap, np.uint32); ot = np.zeros(cap, np.uint32)
+    L.oracle_compare_lists_local.restype = C.c_long
+    n = L.oracle_compare_lists_local(_p(q, C.c_uint32), C.c_long(len(q)), _p(t, C.c_uint32), C.c_long(len(t)), C.c_long(max_freq),
+                                     C.c_int64(max_diag), C.c_int64(min_diag), _p(oq, C.c_uint32), _p(ot, C.c_uint32), C.c_long(cap))
+    assert n <= cap
+    return oq[:n].copy(), ot[:n].copy()

@@ -1,0 +1,139 @@
+"""a10 tier-2 primitives: oracle vs reference golden (CPU) and HIP vs oracle (GPU)."""
+import json
+import os
+
+import numpy as np
+import pytest
+
+from lra_amd import synth
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+GOLD = json.load(open(os.path.join(HERE, "golden", "local_compare_golden.json")))["cases"]
+
+
+def test_oracle_local_compare_matches_reference_golden(oracle):
+    for c in GOLD:
+        q = np.array(c["q"], dtype=np.uint32).reshape(-1, 2); t = np.array(c["t"], dtype=np.uint32).reshape(-1, 2)
+        oq, ot = oracle.compare_lists_local(oracle.pack_local(q[:, 0], q[:, 1]), oracle.pack_local(t[:, 0], t[:, 1]), c["maxFreq"], c["maxDiag"], c["minDiag"])
+        got = []
+        for a, b in zip(oq, ot):
+            got += [int(q[a, 0]), int(q[a, 1]), int(t[b, 0]), int(t[b, 1])]
+        assert got == c["pairs"]
+
+
+def test_oracle_local_index_sanity(oracle):
+    g = synth.make_genome(3000, seed=6)
+    tup, bnd = oracle.local_index_seq(g.tobytes(), 10, 5, 256, 15)
+    assert len(bnd) == 13 and bnd[-1] == len(tup) and len(tup) > 300
+    ck = np.zeros(len(g) - 9, dtype=np.int64)
+    for i in range(10):
+        ck = (ck << 2) | synth.CODE[g[i:i + len(ck)]]
+    for wi in range(12):
+        seg = tup[int(bnd[wi]):int(bnd[wi + 1])]
+        t = seg & 0xFFFFF; p = seg >> 20
+        assert np.all(np.diff(t.astype(np.int64)) >= 0)                      # sorted by k-mer
+        assert np.all(ck[wi * 256 + p] == t)                                 # the k-mer at that window position
+    assert len(oracle.local_index_seq(b"ACGTACGTAC", 10, 5, 256, 15)[0]) == 0
+    poly = oracle.local_index_seq(b"A" * 600, 10, 5, 256, 15)[0]
+    assert len(poly) < 40                                                    # RemoveFrequent drops the repeated k-mer
+
+
+def _seqs():
+    rng = np.random.default_rng(77)
+    g = synth.make_genome(40000, seed=8, repeat_frac=0.3)
+    seqs = [g[i * 3000:i * 3000 + int(rng.integers(200, 3000))].copy() for i in range(12)]
+    seqs += [np.frombuffer(b"", np.uint8), np.frombuffer(b"ACGTACGTACGTAC", np.uint8), np.frombuffer(b"N" * 700, np.uint8),
+             np.concatenate([g[100:400], np.frombuffer(b"NNN", np.uint8), g[400:900]]), np.tile(np.frombuffer(b"ACG", np.uint8), 300),
+             g[5000:5256].copy(), g[6000:6257].copy()]
+    return g, seqs
+
+
+def _device_seqs(ctx, seqs):
+    import torch
+    lens = np.array([len(s) for s in seqs], dtype=np.int64)
+    off = np.zeros(len(seqs) + 1, dtype=np.int64); off[1:] = np.cumsum(lens)
+    buf = np.concatenate(list(seqs) + [np.zeros(64, np.uint8)])
+    return torch.from_numpy(buf).to(ctx.device), torch.from_numpy(off).to(ctx.device)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("k,w,window,mf", [(10, 5, 256, 15), (7, 5, 256, 30), (10, 5, 128, 5)])
+def test_hip_local_index_matches_oracle(ctx, oracle, k, w, window, mf):
+    from lra_amd import local
+    g, seqs = _seqs()
+    sd, od = _device_seqs(ctx, seqs)
+    li = local.LocalIndex(ctx, sd, od, k, w, window, mf)
+    win_off, bnd, tup = li.fetch()
+    total = 0
+    for i, s in enumerate(seqs):
+        et, eb = oracle.local_index_seq(s.tobytes(), k, w, window, mf)
+        w0, w1 = int(win_off[i]), int(win_off[i + 1])
+        assert w1 - w0 == len(eb) - 1, i
+        got_b = bnd[w0:w1 + 1] - bnd[w0]
+        assert np.array_equal(got_b, eb), i
+        assert np.array_equal(tup[int(bnd[w0]):int(bnd[w1])], et), i
+        total += len(et)
+    assert total > 1000
+
+
+@pytest.mark.gpu
+def test_hip_local_compare_matches_golden_and_oracle(ctx, oracle):
+    import torch
+    from lra_amd import local
+    # (i) the reference golden lists, through a fake index object holding raw tuple arrays
+    class Raw:
+        pass
+    qs, ts, ql, qh, tl, th, mxd, mnd = [], [], [], [], [], [], [], []
+    qo = to = 0
+    by_mf = {}
+    for c in GOLD:
+        by_mf.setdefault(c["maxFreq"], []).append(c)
+    for mf, cs in by_mf.items():
+        qs, ts, ql, qh, tl, th, mxd, mnd = [], [], [], [], [], [], [], []
+        qo = to = 0
+        for c in cs:
+            q = np.array(c["q"], dtype=np.uint32).reshape(-1, 2); t = np.array(c["t"], dtype=np.uint32).reshape(-1, 2)
+            qs.append(oracle.pack_local(q[:, 0], q[:, 1])); ts.append(oracle.pack_local(t[:, 0], t[:, 1]))
+            ql.append(qo); qo += len(q); qh.append(qo); tl.append(to); to += len(t); th.append(to)
+            mxd.append(c["maxDiag"]); mnd.append(c["minDiag"])
+        qa = np.concatenate(qs + [np.zeros(1, np.uint32)]); ta = np.concatenate(ts + [np.zeros(1, np.uint32)])
+        A, B = Raw(), Raw()
+        A.t_ = torch.from_numpy(qa.view(np.int32)).to(ctx.device); B.t_ = torch.from_numpy(ta.view(np.int32)).to(ctx.device)
+        A.res = local.LocalIndexResult(); B.res = local.LocalIndexResult()
+        A.res.d_tuples = A.t_.data_ptr(); B.res.d_tuples = B.t_.data_ptr()
+        off, pqi, pti = local.local_compare_batch(ctx, A, ql, qh, B, tl, th, mf, mxd, mnd)
+        for i, c in enumerate(cs):
+            got = []
+            for a, b in zip(pqi[int(off[i]):int(off[i + 1])], pti[int(off[i]):int(off[i + 1])]):
+                got += [int(qa[a] & 0xFFFFF), int(qa[a] >> 20), int(ta[b] & 0xFFFFF), int(ta[b] >> 20)]
+            assert got == c["pairs"], (mf, i)
+    # (ii) real windows: read windows against the genome windows they overlap
+    g = synth.make_genome(60000, seed=9, repeat_frac=0.3)
+    rng = np.random.default_rng(3)
+    reads = []
+    for i in range(10):
+        s = int(rng.integers(0, 50000))
+        r = g[s:s + 5000].copy()
+        mut = rng.random(len(r)) < 0.08
+        r[mut] = synth.BASES[rng.integers(0, 4, size=int(mut.sum()))]
+        reads.append((s, r))
+    gd, god = _device_seqs(ctx, [g])
+    rd, rod = _device_seqs(ctx, [r for _, r in reads])
+    gi = local.LocalIndex(ctx, gd, god); ri = local.LocalIndex(ctx, rd, rod)
+    gw, gb, gt = gi.fetch(); rw, rb, rt = ri.fetch()
+    ql, qh, tl, th = [], [], [], []
+    for i, (s, r) in enumerate(reads):
+        for wloc in range(int(rw[i + 1] - rw[i])):
+            wq = int(rw[i]) + wloc
+            gwin = (s + wloc * 256) // 256
+            for gwx in (gwin, gwin + 1):
+                if gwx < len(gb) - 1:
+                    ql.append(int(rb[wq])); qh.append(int(rb[wq + 1])); tl.append(int(gb[gwx])); th.append(int(gb[gwx + 1]))
+    off, pqi, pti = local.local_compare_batch(ctx, ri, ql, qh, gi, tl, th, 15)
+    npairs = 0
+    for x in range(len(ql)):
+        eq, et = oracle.compare_lists_local(rt[ql[x]:qh[x]], gt[tl[x]:th[x]], 15)
+        a, b = int(off[x]), int(off[x + 1])
+        assert np.array_equal(pqi[a:b], eq + np.uint32(ql[x])) and np.array_equal(pti[a:b], et + np.uint32(tl[x])), x
+        npairs += b - a
+    assert npairs > 500
