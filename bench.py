@@ -5,6 +5,8 @@ One "step" = one pass of the GPU-resident hot-path stages over one batch of read
   a1-a4  tier-1 seeding   (StoreMinimizers -> sort -> CompareLists -> SeparateMatchesByStrand)
   a5     CleanMatches      (diagonal sort, CleanOffDiagonal, clusters) on those matches
   a7     LinearExtend + DecideCoordinates on those clusters
+  a10    tier-2 primitives: CreateRC, LocalIndex::IndexSeq of both strands, and CompareLists<LocalTuple> of every read
+         window against the two genome windows at its true locus
   a12    AffineOneGapAlign on the between-anchor gaps of every read
   a14    IndelRefineAlignment over every read's block list
   a16    CalculateStatistics (CIGAR runs, NM/NX/ND/NI/TD/TI counters, NV) on the refined blocks
@@ -44,7 +46,7 @@ def build_workload(args, rank, device):
     gaps = st.gap_problems(sim)
     rblocks, rboff = st.perturbed_blocks(sim, 5 + rank)
     torch.cuda.synchronize()
-    return dict(genome=genome, idx_key=idx_key, idx_pos=idx_pos, sim=sim, strands=strands, reads=reads, gaps=gaps,
+    return dict(genome=genome, idx_key=idx_key, idx_pos=idx_pos, sim=sim, strands=strands, reads=reads, gaps=gaps, rev=rev,
                 rblocks=rblocks, rboff=rboff, gen_s=time.time() - t0)
 
 
@@ -146,6 +148,22 @@ def main():
     fbatch = refine.refine_batch_from_device(ctx, wl["rblocks"], wl["rboff"], wl["strands"], sim["off"][:-1], lens,
                                              gdev, torch.zeros(nR, dtype=torch.int64, device=ctx.device),
                                              torch.full((nR,), int(wl["genome"].numel()), dtype=torch.int64, device=ctx.device))
+    # a10 inputs: genome local index (the `.gli` payload, built once) and, per read window, the two genome
+    # windows at its true locus (what Refine_splitchain looks up, ChainRefine.h:384-576)
+    from lra_amd import local
+    g_off = torch.tensor([0, int(wl["genome"].numel())], dtype=torch.int64, device=ctx.device)
+    gli = local.LocalIndex(ctx, gdev, g_off, 10, 5, 256, 15)
+    gbnd = gli.bnd_tensor()
+    nwin_r = (lens + 255) // 256
+    rwin_off = torch.zeros(nR + 1, dtype=torch.int64, device=ctx.device); rwin_off[1:] = torch.cumsum(nwin_r, 0)
+    rid_w = torch.repeat_interleave(torch.arange(nR, device=ctx.device), nwin_r)
+    wloc = torch.arange(int(rwin_off[-1]), device=ctx.device) - rwin_off[rid_w]
+    rstart = sim["blocks"][sim["block_off"][:-1], 1].long()                     # true genome start of every read
+    gwin0 = torch.clamp((rstart[rid_w] + wloc * 256) // 256, max=gli.n_windows - 2)
+    is_rev = wl["rev"][rid_w]
+    task_q = torch.cat([torch.arange(int(rwin_off[-1]), device=ctx.device)] * 2)
+    task_g = torch.cat([gwin0, gwin0 + 1])
+    task_rev = torch.cat([is_rev, is_rev])
     total_bases = int(lens.sum())
     n_gap_bytes = int(gp["q_len"].sum() + gp["t_len"].sum())
     n_gaps = int(gp["k"].numel())
@@ -156,6 +174,15 @@ def main():
         sres = seed.seed_batch(ctx, rbatch, args.k, args.w, args.max_freq)
         cres = cluster.clean_matches_batch(ctx, copts, [0, int(wl["genome"].numel())])
         eres = cluster.linear_extend_batch(ctx, args.k, rbatch)
+        rc = seed.create_rc(ctx, rbatch)
+        li_f = local.LocalIndex(ctx, rbatch.seq, rbatch.off, 10, 5, 256, 15)      # forwardIndex.IndexSeq(read.seq)  (Map_lowacc.h:249)
+        li_r = local.LocalIndex(ctx, rc, rbatch.off, 10, 5, 256, 15)              # reverseIndex.IndexSeq(readRC)    (Map_lowacc.h:250)
+        npairs = 0
+        for li, sel in ((li_f, ~task_rev), (li_r, task_rev)):                     # the strand whose RC equals the genome-oriented read
+            qb = li.bnd_tensor()
+            tq, tg = task_q[sel], task_g[sel]
+            pres = local.local_compare_batch(ctx, li, qb[tq], qb[tq + 1], gli, gbnd[tg], gbnd[tg + 1], 15, fetch=False)
+            npairs += pres.n_pairs
         abatch.run()
         fres = refine.indel_refine_batch(ctx, fbatch, args.refine_band, 4, -1, -2)
         tres = refine.stats_of_refined(ctx, fbatch, fres, lut)
@@ -163,7 +190,8 @@ def main():
         rec = ctx.to_tensor(fres.d_blocks, 3 * fres.n_blocks, torch.int32)
         parallel.gather_records(rec, dst=0)
         stats.update(n_mm=sres.n_minimizers, n_match=sres.n_matches, n_cells=fres.n_cells, n_rows=fres.n_rows,
-                     n_seg=fres.n_segments, n_blocks=fres.n_blocks, n_aog=fres.n_aog, n_clusters=cres.n_clusters, n_cigar_runs=tres.n_runs)
+                     n_seg=fres.n_segments, n_blocks=fres.n_blocks, n_aog=fres.n_aog, n_clusters=cres.n_clusters, n_cigar_runs=tres.n_runs, n_local_tuples=li_f.n_tuples + li_r.n_tuples,
+                     n_local_tasks=int(task_q.numel()), n_local_pairs=npairs)
 
     def sync():
         if world > 1:
@@ -193,7 +221,7 @@ def main():
         nreads = args.reads
 
     kernels = ["sketch_count", "sketch_serial", "sketch_emit", "sort", "sort_fallback", "index_bounds", "compare", "strand",
-               "aog_lds_tiny", "aog_lds_small", "aog_lds_large", "aog_hbm", "ir_segment", "ir_band", "ir_fill", "ir_trace", "ir_gather", "clean_sort", "clean", "linear_extend", "stats", "stats_cigar"]
+               "aog_lds_tiny", "aog_lds_small", "aog_lds_large", "aog_hbm", "ir_segment", "ir_band", "ir_fill", "ir_trace", "ir_gather", "clean_sort", "clean", "linear_extend", "stats", "stats_cigar", "create_rc", "local_sketch", "local_sort_filter", "local_compare"]
     ktimes = {k: ctx.timing_get(k) for k in kernels}
     ctx.timing(False)
     if rank == 0:
@@ -219,7 +247,7 @@ def main():
         }.get(dom, 0)
         achieved = alg / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
         out = {
-            "metric": "aligned Gbp/s (hot-path stages a1-a5, a7, a12, a14, a16), 30 kb ONT-like reads", "value": gbps, "unit": "Gbp/s",
+            "metric": "aligned Gbp/s (hot-path stages a1-a5, a7, a10 primitives, a12, a14, a16), 30 kb ONT-like reads", "value": gbps, "unit": "Gbp/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_step, "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "int32", "data": "synthetic",
             "reads_per_s": nreads * args.steps / dt,

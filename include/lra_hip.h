@@ -109,6 +109,10 @@ typedef struct lra_seed_result {
 int lra_seed_batch(lra_ctx* ctx, int n_reads, const char* d_seq, const uint64_t* d_read_off, int k, int w,
                    int max_freq, lra_seed_result* out);
 
+/* CreateRC (SeqUtils.h:151): reverse complement of every read of the batch into d_rc (same offsets);
+ * bytes other than ACGTacgtn become 'N' (RevCompNuc, SeqUtils.h:112).  Asynchronous.            */
+int lra_create_rc_batch(lra_ctx* ctx, int n_reads, const char* d_seq, const uint64_t* d_read_off, char* d_rc);
+
 /* a2 alone: sorts each list [d_off[i], d_off[i+1]) of (key,pos) tuples IN PLACE exactly as
  * `std::sort(readmm.begin(), readmm.end())` (MapRead.h:185, libstdc++ introsort with
  * GenomeTuple::operator<, TupleOps.h:76) would, including the order it leaves equal keys in.
@@ -166,9 +170,9 @@ int lra_linear_extend_batch(lra_ctx* ctx, int K, const char* d_seq, const uint64
  * `.gli` payload): per `window` bases the non-canonical (w,k) minimizers (MinCount.h:182), sorted by
  * k-mer with std::sort (MMIndex.h:219) and thinned by RemoveFrequent(maxFreq) (MMIndex.h:69).
  * LocalTuple = uint32  t | pos << 20  (TupleOps.h:20-25; pos relative to the window start).
- * Two-call protocol: call with d_out_buf = NULL to get bytes_needed, allocate, call again; the
- * result then lives in the caller's buffer:  d_win_off[n_seqs+1] (first window of each sequence),
- * d_tuple_bnd[n_windows+1] (tupleBoundaries), d_tuples[n_tuples].  Synchronous.
+ * Result (one context-owned allocation of `bytes` bytes starting at d_base, valid until the next call;
+ * copy it with lra_copy_device to keep several indexes alive): d_win_off[n_seqs+1] (first window of
+ * each sequence), d_tuple_bnd[n_windows+1] (tupleBoundaries), d_tuples[n_tuples].  Synchronous.
  *
  * lra_local_compare_batch replaces  CompareLists<LocalTuple,SmallTuple>(qBegin,qEnd,tBegin,tEnd,result,
  * opts,false,maxDiagNum,minDiagNum)  (CompareLists.h:9) for n_tasks (query list, target list) pairs
@@ -178,11 +182,12 @@ int lra_linear_extend_batch(lra_ctx* ctx, int K, const char* d_seq, const uint64
  * (context-owned, valid until the next call).  Synchronous.                                        */
 typedef struct lra_local_index_result {
   int32_t n_seqs;
-  uint64_t n_windows, n_tuples, bytes_needed;
+  uint64_t n_windows, n_tuples, bytes;
+  const void* d_base;
   const uint64_t* d_win_off; const uint64_t* d_tuple_bnd; const uint32_t* d_tuples;
 } lra_local_index_result;
 int lra_local_index_batch(lra_ctx* ctx, int n_seqs, const char* d_seq, const uint64_t* d_seq_off, int k, int w, int window,
-                          int max_freq, void* d_out_buf, uint64_t out_buf_bytes, lra_local_index_result* out);
+                          int max_freq, lra_local_index_result* out);
 typedef struct lra_local_pairs_result {
   uint64_t n_tasks, n_pairs;
   const uint64_t* d_pair_off; const uint32_t* d_pair_qi; const uint32_t* d_pair_ti;

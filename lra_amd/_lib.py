@@ -32,12 +32,13 @@ SYMBOLS = {
     "lra_ctx_timing_get": (C.c_int, [_vp, C.c_char_p, C.POINTER(C.c_double), C.POINTER(C.c_int)]),
     "lra_ctx_load_genome": (C.c_int, [_vp, _vp, C.c_uint64]),
     "lra_ctx_load_global_index": (C.c_int, [_vp, _vp, _vp, C.c_uint64]),
+    "lra_create_rc_batch": (C.c_int, [_vp, C.c_int, _vp, _vp, _vp]),
     "lra_sort_minimizers_batch": (C.c_int, [_vp, C.c_int, _vp, _vp, _vp]),
     "lra_seed_batch": (C.c_int, [_vp, C.c_int, _vp, _vp, C.c_int, C.c_int, C.c_int, _vp]),
     "lra_clean_matches_batch": (C.c_int, [_vp, _vp, _vp, C.c_int, _vp]),
     "lra_linear_extend_batch": (C.c_int, [_vp, C.c_int, _vp, _vp, _vp]),
     "lra_calculate_statistics_batch": (C.c_int, [_vp, C.c_int, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, C.c_int, _vp]),
-    "lra_local_index_batch": (C.c_int, [_vp, C.c_int, _vp, _vp, C.c_int, C.c_int, C.c_int, C.c_int, _vp, C.c_uint64, _vp]),
+    "lra_local_index_batch": (C.c_int, [_vp, C.c_int, _vp, _vp, C.c_int, C.c_int, C.c_int, C.c_int, _vp]),
     "lra_local_compare_batch": (C.c_int, [_vp, C.c_uint64, _vp, _vp, _vp, _vp, _vp, _vp, C.c_int, _vp, _vp, _vp]),
     "lra_indel_refine_batch": (C.c_int, [_vp, C.c_int, _vp, _vp, C.c_uint64, _vp, _vp, _vp, _vp, _vp, _vp, C.c_int, C.c_int,
                                           C.c_int, C.c_int, C.c_int, _vp]),

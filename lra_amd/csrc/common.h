@@ -25,8 +25,8 @@ struct lra_ctx {
   void* aux = nullptr; size_t aux_bytes = 0;          // AffineOneGapAlign blocks of refine fallbacks
   void* out_buf = nullptr; size_t out_bytes = 0;
   uint64_t* scan_tmp = nullptr;
-  void* gbuf[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};   // growable result / work buffers (lra_ensure)
-  size_t gbytes[6] = {0, 0, 0, 0, 0, 0};                       // tile sums of lra_exclusive_scan      // refined blocks handed back to the caller
+  void* gbuf[10] = {};   // growable result / work buffers (lra_ensure)
+  size_t gbytes[10] = {};                       // tile sums of lra_exclusive_scan      // refined blocks handed back to the caller
   // kernel timing
   bool timing = false;
   std::vector<lra_time_rec> recs;

@@ -309,7 +309,7 @@ static int d2h8(lra_ctx* ctx, uint64_t* dst, const uint64_t* src) {
 }  // namespace
 
 extern "C" int lra_local_index_batch(lra_ctx* ctx, int n_seqs, const char* d_seq, const uint64_t* d_seq_off, int k, int w, int window,
-                                     int max_freq, void* d_out_buf, uint64_t out_buf_bytes, lra_local_index_result* out) {
+                                     int max_freq, lra_local_index_result* out) {
   if (!ctx || !out || n_seqs < 0) return LRA_ERR_INVALID;
   if (k < 1 || k > 10 || w < 1 || w > MAXW || window < w + k || window > 4096)
     return lra_set_err(ctx, LRA_ERR_INVALID, "need 1<=k<=10 (20-bit LocalTuple), 1<=w<=%d, w+k<=window<=4096", MAXW);
@@ -356,11 +356,12 @@ extern "C" int lra_local_index_batch(lra_ctx* ctx, int n_seqs, const char* d_seq
     if (lra_exclusive_scan<uint32_t>(ctx, (long)n_win, cnt, bnd_tmp)) return LRA_ERR_HIP;
     if (d2h8(ctx, &n_tup, bnd_tmp + n_win)) return LRA_ERR_HIP;
   }
-  // results live in the caller's buffer: [win_off: n_seqs+1 u64][bnd: n_win+1 u64][tuples: n_tup u32]
+  // results: [win_off: n_seqs+1 u64][bnd: n_win+1 u64][tuples: n_tup u32] in a context-owned buffer
   const uint64_t need = sz((size_t)n_seqs + 1, 8) + sz(NW, 8) + sz((size_t)n_tup + 1, 4);
-  out->n_seqs = n_seqs; out->n_windows = n_win; out->n_tuples = n_tup; out->bytes_needed = need;
-  if (!d_out_buf || out_buf_bytes < need) return LRA_OK;                   // sizing call: the caller allocates and calls again
-  char* ob = (char*)d_out_buf;
+  out->n_seqs = n_seqs; out->n_windows = n_win; out->n_tuples = n_tup; out->bytes = need;
+  char* ob = (char*)lra_ensure(ctx, 6, need + 256);
+  if (!ob) return LRA_ERR_NOMEM;
+  out->d_base = ob;
   uint64_t* o_win = carve<uint64_t>(ob, (size_t)n_seqs + 1); uint64_t* o_bnd = carve<uint64_t>(ob, NW); uint32_t* o_tup = carve<uint32_t>(ob, (size_t)n_tup + 1);
   LRA_HIP_CHECK(ctx, hipMemcpyAsync(o_win, win_off, ((size_t)n_seqs + 1) * 8, hipMemcpyDeviceToDevice, st));
   if (n_win) {

@@ -929,6 +929,38 @@ extern "C" int lra_ctx_load_global_index(lra_ctx* ctx, const uint64_t* h_key, co
   return LRA_OK;
 }
 
+// CreateRC (SeqUtils.h:151-158, RevCompNuc :112-146): dest[l-i-1] = complement(seq[i]); anything that is
+// not one of ACGTacgtn becomes 'N'.
+__global__ void create_rc_kernel(int n_reads, const unsigned char* __restrict__ seq, const uint64_t* __restrict__ off, unsigned char* __restrict__ dst) {
+  const int lane = threadIdx.x & 63;
+  const int wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, nw = (gridDim.x * blockDim.x) >> 6;
+  for (int r = wave; r < n_reads; r += nw) {
+    const uint64_t a = off[r], L = off[r + 1] - a;
+    for (uint64_t i = lane; i < L; i += 64) {
+      const unsigned char c = seq[a + i];
+      unsigned char o = 'N';
+      switch (c) {
+        case 'A': o = 'T'; break; case 'C': o = 'G'; break; case 'G': o = 'C'; break; case 'T': o = 'A'; break;
+        case 'a': o = 't'; break; case 'c': o = 'g'; break; case 'g': o = 'c'; break; case 't': o = 'a'; break;
+        case 'n': o = 'n'; break;
+        default: break;
+      }
+      dst[a + L - 1 - i] = o;
+    }
+  }
+}
+
+extern "C" int lra_create_rc_batch(lra_ctx* ctx, int n_reads, const char* d_seq, const uint64_t* d_read_off, char* d_rc) {
+  if (!ctx || n_reads < 0) return LRA_ERR_INVALID;
+  if (n_reads == 0) return LRA_OK;
+  LRA_HIP_CHECK(ctx, hipSetDevice(ctx->device));
+  lra_time_begin(ctx, "create_rc");
+  hipLaunchKernelGGL(create_rc_kernel, dim3(ctx->num_cu * 8), dim3(256), 0, ctx->stream, n_reads, (const unsigned char*)d_seq, d_read_off, (unsigned char*)d_rc);
+  lra_time_end(ctx);
+  LRA_HIP_CHECK(ctx, hipGetLastError());
+  return LRA_OK;
+}
+
 static int launch_sort(lra_ctx* ctx, int n_reads, const uint64_t* mm_off, uint64_t* mm_key, uint32_t* mm_pos) {
   hipStream_t st = ctx->stream;
   const int nb = (n_reads + 63) / 64;

@@ -89,3 +89,10 @@ def sort_minimizers_batch(ctx: Context, keys_list, pos_list):
     K2 = dk.cpu().numpy().view(np.uint64)
     P2 = dp.cpu().numpy().view(np.uint32)
     return [(K2[off[i]:off[i + 1]].copy(), P2[off[i]:off[i + 1]].copy()) for i in range(n)]
+
+
+def create_rc(ctx: Context, batch: ReadBatch):
+    """CreateRC for every read of the batch: returns a device tensor laid out like batch.seq."""
+    rc = torch.zeros_like(batch.seq)
+    ctx.check(ctx.lib.lra_create_rc_batch(ctx.h, batch.n, ptr(batch.seq), ptr(batch.off), ptr(rc)))
+    return rc

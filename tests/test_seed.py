@@ -120,3 +120,15 @@ def test_hip_seed_repeats_and_ties(ctx, oracle):
     reads.append(np.tile(np.frombuffer(b"AC", dtype=np.uint8), 300))
     n = _check_batch(ctx, oracle, genome, reads, 11, 5, 8, index_max_freq=400)
     assert n > 100
+
+
+@pytest.mark.gpu
+def test_hip_create_rc(ctx):
+    from lra_amd import seed
+    reads = [b"ACGTNacgtnXY", b"", b"A", b"GATTACA" * 50]
+    b = seed.ReadBatch(ctx, reads)
+    rc = seed.create_rc(ctx, b).cpu().numpy()
+    comp = {ord(a): ord(c) for a, c in zip("ACGTacgtn", "TGCAtgcan")}
+    for i, r in enumerate(reads):
+        exp = bytes(comp.get(c, ord("N")) for c in reversed(r))
+        assert rc[int(b.off_h[i]):int(b.off_h[i + 1])].tobytes() == exp
