@@ -51,17 +51,39 @@ __global__ void window_count(int n_seqs, const uint64_t* __restrict__ seq_off, i
   nwin[s] = (uint32_t)(L / window + (L % window != 0 ? 1 : 0));        // MMIndex.h:201-206
 }
 
-// StoreMinimizers_noncanonical for one window per lane.  EMIT=false counts.
+// StoreMinimizers_noncanonical for one window per lane.  EMIT=false counts.  The 64 windows of a wave
+// are first copied into LDS with coalesced loads (lane-private rows of WSTRIDE bytes, an odd number of
+// dwords apart so the per-lane byte reads spread over the banks): the serial scan then never touches
+// HBM (the unstaged version fetched ~40x the sequence bytes because 64 private streams thrash L1).
+constexpr int WMAX = 256;            // staged window length; longer windows read from HBM directly
+constexpr int WSTRIDE = WMAX + 4;
 template <bool EMIT>
 __global__ void __launch_bounds__(64) local_sketch(uint64_t n_win, const unsigned char* __restrict__ seq_all, const uint64_t* __restrict__ w_start,
                                                    const uint32_t* __restrict__ w_len, int k, int w, const uint64_t* __restrict__ raw_off,
                                                    uint32_t* __restrict__ raw, uint32_t* __restrict__ counts) {
   __shared__ uint32_t ringT[MAXW * 64], ringP[MAXW * 64];
+  __shared__ unsigned char stage[64 * WSTRIDE];
   const int lane = threadIdx.x;
-  const uint64_t wi = (uint64_t)blockIdx.x * 64 + lane;
+  const uint64_t w0 = (uint64_t)blockIdx.x * 64;
+  const uint64_t wi = w0 + lane;
+  // cooperative staging of the wave's windows
+  for (int x = 0; x < 64; x++) {
+    const uint64_t wx = w0 + x;
+    if (wx >= n_win) break;
+    const uint32_t L = w_len[wx];
+    if (L > WMAX) continue;
+    const unsigned char* src = seq_all + w_start[wx];
+    for (uint32_t p = lane; p < L; p += 64) stage[x * WSTRIDE + p] = src[p];
+  }
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
   if (wi >= n_win) return;
-  const unsigned char* seq = seq_all + w_start[wi];
   const uint32_t seqLen = w_len[wi];
+  const bool staged = seqLen <= WMAX;
+  const unsigned char* gseq = seq_all + w_start[wi];
+  const unsigned char* lseq = stage + lane * WSTRIDE;
+  auto SEQ = [&](uint32_t p) -> unsigned char { return staged ? lseq[p] : gseq[p]; };
   uint32_t* out = EMIT ? raw + raw_off[wi] : nullptr;
   uint32_t n = 0;
 #define LS_EMIT(T__, P__) do { if (EMIT) out[n] = ((T__) & TMASK) | (((P__) & 0xFFFu) << 20); n++; } while (0)
@@ -76,15 +98,15 @@ __global__ void __launch_bounds__(64) local_sketch(uint64_t n_win, const unsigne
     while ((uint32_t)nvStart < seqLen - (uint32_t)span && !valid) {
       valid = true;
       for (long x = nvStart; valid && x < nvStart + span; x++)
-        if (code_n(seq[x]) > 3) { nvStart = x + 1; valid = false; }
+        if (code_n(SEQ((uint32_t)x)) > 3) { nvStart = x + 1; valid = false; }
     }
     return valid;
   };
   if (!find_valid()) LS_DONE();
   nvEnd = nvStart + span;
   uint32_t cur = 0;
-  for (int p = 0; p < k; p++) cur = ((cur << 2) + code2(seq[p])) & TMASK;
-  auto shift = [&](uint32_t at) { cur = ((((cur << 2) & TMASK) & kmask) + code2(seq[at])) & TMASK; };
+  for (int p = 0; p < k; p++) cur = ((cur << 2) + code2(SEQ(p))) & TMASK;
+  auto shift = [&](uint32_t at) { cur = ((((cur << 2) & TMASK) & kmask) + code2(SEQ(at))) & TMASK; };
   uint32_t actT = cur, actP = 0;
   ringT[lane] = actT; ringP[lane] = 0;
   uint32_t p;
@@ -95,17 +117,19 @@ __global__ void __launch_bounds__(64) local_sketch(uint64_t n_win, const unsigne
     ringT[(p % w) * 64 + lane] = cur; ringP[(p % w) * 64 + lane] = p;
   }
   if (nvEnd == span) LS_EMIT(actT, actP);
+  uint32_t slot = 0;                                                     // p % w for p = w
   for (p = w; p < nk; p++) {                                             // :276-337
     shift(p + k - 1);
     if (nvEnd == (long)(p + k - 1)) {
-      if (code_n(seq[p + k - 1]) <= 3) nvEnd++;
+      if (code_n(SEQ(p + k - 1)) <= 3) nvEnd++;
       else {
         nvStart = p + k;
         if (!find_valid()) LS_DONE();
         nvEnd = nvStart + span;
       }
     }
-    ringT[(p % w) * 64 + lane] = cur; ringP[(p % w) * 64 + lane] = p;
+    ringT[slot * 64 + lane] = cur; ringP[slot * 64 + lane] = p;
+    if (++slot == (uint32_t)w) slot = 0;
     if (p - w >= actP) {
       actT = ringT[lane]; actP = ringP[lane];
       for (int j = 1; j < w; j++) { uint32_t t = ringT[j * 64 + lane]; if (t < actT) { actT = t; actP = ringP[j * 64 + lane]; } }
@@ -192,21 +216,54 @@ __device__ void w_std_sort(uint32_t* v, long n) {
   } else ins(0, n);
 }
 
-// sort + RemoveFrequent in place; counts[wi] = surviving tuples
+// sort + RemoveFrequent in place; counts[wi] = surviving tuples.  Lists of <= LCAP tuples are sorted in a
+// lane-private LDS row (copied in and out with coalesced accesses); longer ones in HBM.
+constexpr int LCAP = 160;
+constexpr int LSTRIDE = LCAP + 1;
 __global__ void __launch_bounds__(64) local_sort_filter(uint64_t n_win, const uint64_t* __restrict__ raw_off, uint32_t* raw, int maxFreq, uint32_t* __restrict__ counts) {
-  const uint64_t wi = (uint64_t)blockIdx.x * 64 + threadIdx.x;
-  if (wi >= n_win) return;
-  uint32_t* v = raw + raw_off[wi];
-  const long n = (long)(raw_off[wi + 1] - raw_off[wi]);
-  w_std_sort(v, n);                                                      // MMIndex.h:219
-  long c = 0, x = 0;                                                     // RemoveFrequent MMIndex.h:69-84
-  while (x < n) {
-    long ne = x;
-    while (ne < n && T_(v[ne]) == T_(v[x])) ne++;
-    if (ne - x < maxFreq) for (long y = x; y < ne; y++) v[c++] = v[y];
-    x = ne;
+  __shared__ uint32_t stage[64 * LSTRIDE];
+  const int lane = threadIdx.x;
+  const uint64_t w0 = (uint64_t)blockIdx.x * 64;
+  const uint64_t wi = w0 + lane;
+  for (int x = 0; x < 64; x++) {
+    const uint64_t wx = w0 + x;
+    if (wx >= n_win) break;
+    const uint64_t a = raw_off[wx], n = raw_off[wx + 1] - a;
+    if (n > LCAP) continue;
+    for (uint32_t p = lane; p < n; p += 64) stage[x * LSTRIDE + p] = raw[a + p];
   }
-  counts[wi] = (uint32_t)c;
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+  long n = 0, c = 0;
+  bool staged = false;
+  if (wi < n_win) {
+    n = (long)(raw_off[wi + 1] - raw_off[wi]);
+    staged = n <= LCAP;
+    uint32_t* v = staged ? stage + lane * LSTRIDE : raw + raw_off[wi];
+    w_std_sort(v, n);                                                    // MMIndex.h:219
+    long x = 0;                                                          // RemoveFrequent MMIndex.h:69-84
+    while (x < n) {
+      long ne = x;
+      while (ne < n && T_(v[ne]) == T_(v[x])) ne++;
+      if (ne - x < maxFreq) for (long y = x; y < ne; y++) v[c++] = v[y];
+      x = ne;
+    }
+    counts[wi] = (uint32_t)c;
+  }
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+  // write the surviving tuples back (coalesced, one window at a time)
+  for (int x = 0; x < 64; x++) {
+    const uint64_t wx = w0 + x;
+    if (wx >= n_win) break;
+    const long cx = __shfl((int)c, x);
+    const bool sx = __shfl((int)staged, x) != 0;
+    if (!sx) continue;
+    const uint64_t a = raw_off[wx];
+    for (long p = lane; p < cx; p += 64) raw[a + p] = stage[x * LSTRIDE + p];
+  }
 }
 
 __global__ void __launch_bounds__(64) local_compact(uint64_t n_win, const uint64_t* __restrict__ raw_off, const uint32_t* __restrict__ raw,
@@ -228,12 +285,29 @@ struct CmpArgs {
   const uint64_t* out_off; uint32_t* out_qi; uint32_t* out_ti; uint32_t* counts;
 };
 
+constexpr int QCAP = 96, TCAP = 160, CSTRIDE = QCAP + TCAP + 1;   // lane-private LDS row: query list then target list
 template <bool EMIT>
 __global__ void __launch_bounds__(64) local_compare(CmpArgs A) {
-  const uint64_t x = (uint64_t)blockIdx.x * 64 + threadIdx.x;
+  __shared__ uint32_t stage[64 * CSTRIDE];
+  const int lane = threadIdx.x;
+  const uint64_t x0 = (uint64_t)blockIdx.x * 64;
+  for (int i = 0; i < 64; i++) {                                         // coalesced staging, one task at a time
+    const uint64_t xi = x0 + i;
+    if (xi >= A.n_tasks) break;
+    const uint64_t qa = A.q_lo[xi], qn = A.q_hi[xi] - qa, ta = A.t_lo[xi], tn = A.t_hi[xi] - ta;
+    if (qn > QCAP || tn > TCAP) continue;
+    for (uint32_t p = lane; p < qn; p += 64) stage[i * CSTRIDE + p] = A.q[qa + p];
+    for (uint32_t p = lane; p < tn; p += 64) stage[i * CSTRIDE + QCAP + p] = A.t[ta + p];
+  }
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+  const uint64_t x = x0 + lane;
   if (x >= A.n_tasks) return;
-  const uint32_t* q = A.q + A.q_lo[x]; const uint32_t* t = A.t + A.t_lo[x];
   const long nq = (long)(A.q_hi[x] - A.q_lo[x]), nt = (long)(A.t_hi[x] - A.t_lo[x]);
+  const bool staged = nq <= QCAP && nt <= TCAP;
+  const uint32_t* q = staged ? stage + lane * CSTRIDE : A.q + A.q_lo[x];
+  const uint32_t* t = staged ? stage + lane * CSTRIDE + QCAP : A.t + A.t_lo[x];
   const int64_t maxDiag = A.maxDiag ? A.maxDiag[x] : 0, minDiag = A.minDiag ? A.minDiag[x] : 0;
   const long maxFreq = A.maxFreq;
   uint32_t* oq = EMIT ? A.out_qi + A.out_off[x] : nullptr; uint32_t* ot = EMIT ? A.out_ti + A.out_off[x] : nullptr;
