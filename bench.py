@@ -183,6 +183,9 @@ def main():
             tq, tg = task_q[sel], task_g[sel]
             pres = local.local_compare_batch(ctx, li, qb[tq], qb[tq + 1], gli, gbnd[tg], gbnd[tg + 1], 15, fetch=False)
             npairs += pres.n_pairs
+            if "n_local_task_words" not in stats or stats.get("_lw_done", 0) < 2:
+                stats["n_local_task_words"] = stats.get("n_local_task_words", 0) + int((qb[tq + 1] - qb[tq]).sum() + (gbnd[tg + 1] - gbnd[tg]).sum())
+                stats["_lw_done"] = stats.get("_lw_done", 0) + 1
         abatch.run()
         fres = refine.indel_refine_batch(ctx, fbatch, args.refine_band, 4, -1, -2)
         tres = refine.stats_of_refined(ctx, fbatch, fres, lut)
@@ -241,6 +244,11 @@ def main():
             "compare": stats["n_mm"] * (8 + 8 + 64) + 8 * stats["n_match"],
             "sketch_count": L, "sketch_emit": L + 12 * stats["n_mm"],
             "strand": stats["n_match"] * (8 + 8 + 2 * args.k),
+            "local_compare": 4 * stats.get("n_local_task_words", 0) // 2 + 8 * stats.get("n_local_pairs", 0) // 2,   # per launch (count / emit, two strands)
+            "local_sort_filter": 2 * 4 * stats.get("n_local_tuples", 0) // 2,
+            "local_sketch": 2 * L // 2 + 4 * stats.get("n_local_tuples", 0) // 2,
+            "stats": 2 * L + 12 * stats["n_blocks"] + 4 * stats.get("n_cigar_runs", 0),
+            "clean": 16 * stats["n_match"] * 3,
             "aog_lds_small": n_gap_bytes + 12 * n_gaps,
             "aog_lds_tiny": n_gap_bytes + 12 * n_gaps,
             "ir_segment": 12 * stats["n_blocks"],
@@ -258,7 +266,7 @@ def main():
                        "stages": "a1-a5,a7 chained on the reads; a12 on between-anchor gaps and a14 on block lists derived from the simulator's truth, "
                                  "a16 on a14's output (a8-a11,a13 chaining stages not built yet: NOT a whole `lra align`)",
                        "parallelism": "reads sharded by ordinal, 1 process/GPU; RCCL gather of block records to rank 0",
-                       "per_step": {k: int(v) for k, v in stats.items()}},
+                       "per_step": {k: int(v) for k, v in stats.items() if not k.startswith("_")}},
             "kernel_ms_per_step": {k: round(v[0] / args.steps, 4) for k, v in ktimes.items() if v[1]},
             "roofline": {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": 8000.0, "unit": "GB/s", "frac": achieved / 8000.0,
                          "traffic": None, "avg_launch_ms": avg_ms, "algorithmic_bytes_per_launch": alg},
