@@ -245,3 +245,89 @@ def compare_lists_local(q, t, max_freq, max_diag=0, min_diag=0):
                                      C.c_int64(max_diag), C.c_int64(min_diag), _p(oq, C.c_uint32), _p(ot, C.c_uint32), C.c_long(cap))
     assert n <= cap
     return oq[:n].copy(), ot[:n].copy()
+
+
+# ---- sparse DP (a8) -----------------------------------------------------------------------------------------------
+class SdpOpts(C.Structure):
+    _fields_ = [("rate", C.c_float), ("NumAln", C.c_int), ("alnthres", C.c_float), ("readLen", C.c_int),
+                ("gapopen", C.c_float), ("gapextend", C.c_float), ("gaproot", C.c_float),
+                ("gapCeiling1", C.c_int), ("gapCeiling2", C.c_int)]
+
+
+# -ONT preset (lra.cpp:388-420) + Options.h defaults
+SDP_ONT = dict(rate=20.0, NumAln=2, alnthres=0.7, gapopen=7.0, gapextend=10.0, gaproot=1.5, gapCeiling1=1500, gapCeiling2=3000)
+
+
+def sdp_opts(read_len, **kw):
+    d = dict(SDP_ONT); d.update(kw)
+    return SdpOpts(d["rate"], d["NumAln"], d["alnthres"], int(read_len), d["gapopen"], d["gapextend"], d["gaproot"],
+                   d["gapCeiling1"], d["gapCeiling2"])
+
+
+def sdp_divide_dump(q, t, ind, inv, want_text=False):
+    """(length, fnv1a hash[, text]) of the canonical decomposition text."""
+    L = lib()
+    q = np.ascontiguousarray(q, np.uint32); t = np.ascontiguousarray(t, np.uint32)
+    ind = np.ascontiguousarray(ind, np.uint8); inv = np.ascontiguousarray(inv, np.uint8)
+    h = C.c_uint64(0)
+    L.oracle_sdp_divide_dump.restype = C.c_long
+    n = L.oracle_sdp_divide_dump(C.c_long(len(q)), _p(q, C.c_uint32), _p(t, C.c_uint32), _p(ind, C.c_uint8), _p(inv, C.c_uint8),
+                                 C.byref(h), None, C.c_long(0))
+    if not want_text:
+        return n, h.value
+    buf = C.create_string_buffer(n + 1)
+    L.oracle_sdp_divide_dump(C.c_long(len(q)), _p(q, C.c_uint32), _p(t, C.c_uint32), _p(ind, C.c_uint8), _p(inv, C.c_uint8),
+                             C.byref(h), buf, C.c_long(n + 1))
+    return n, h.value, buf.value.decode()
+
+
+def sdp_pwl(params, xs):
+    """params = (intercept, scalar, root, g1, g2) -> (pwl bits, w bits, slope bits[25], inter bits[25])"""
+    L = lib()
+    xs = np.ascontiguousarray(xs, np.int64)
+    a = np.zeros(len(xs), np.float32); b = np.zeros(len(xs), np.float32)
+    s = np.zeros(25, np.float32); i = np.zeros(25, np.float32)
+    L.oracle_sdp_pwl(C.c_float(params[0]), C.c_float(params[1]), C.c_float(params[2]), C.c_int(params[3]), C.c_int(params[4]),
+                     C.c_long(len(xs)), _p(xs, C.c_long), _p(a, C.c_float), _p(b, C.c_float), _p(s, C.c_float), _p(i, C.c_float))
+    return a.view(np.uint32), b.view(np.uint32), s.view(np.uint32), i.view(np.uint32)
+
+
+def sdp_maximization_script(params, Di, Ei, ops):
+    """ops: list of (op, a, value_bits).  -> (outputs, final Block pairs)"""
+    L = lib()
+    Di = np.ascontiguousarray(Di, np.int64); Ei = np.ascontiguousarray(Ei, np.int64)
+    op = np.ascontiguousarray([o[0] for o in ops], np.int32)
+    a = np.ascontiguousarray([o[1] for o in ops], np.int64)
+    v = np.ascontiguousarray([o[2] for o in ops], np.uint32).view(np.float32)
+    out = np.zeros(max(1, len(ops)), np.int64)
+    blk = np.zeros(2 * (len(Di) + len(ops) + 8) * 2, np.int64)
+    nb = C.c_long(0)
+    L.oracle_sdp_maximization_script.restype = C.c_long
+    n = L.oracle_sdp_maximization_script(C.c_long(len(Di)), _p(Di, C.c_long), C.c_long(len(Ei)), _p(Ei, C.c_long), C.c_long(len(ops)),
+                                         _p(op, C.c_int), _p(a, C.c_long), _p(v, C.c_float), C.c_float(params[0]), C.c_float(params[1]),
+                                         C.c_float(params[2]), C.c_int(params[3]), C.c_int(params[4]), _p(out, C.c_long), _p(blk, C.c_long),
+                                         C.byref(nb))
+    return out[:n].copy(), blk[:2 * nb.value].copy()
+
+
+def sdp_chain(cluster_off, cluster_strand, q, t, length, opts: "SdpOpts"):
+    """SDP#A on one read's extended clusters -> dict(val, prev_sub, prev_ind, flags, chains=[dict(frags, link, box, value)])."""
+    L = lib()
+    off = np.ascontiguousarray(cluster_off, np.int32); st = np.ascontiguousarray(cluster_strand, np.uint8)
+    q = np.ascontiguousarray(q, np.uint32); t = np.ascontiguousarray(t, np.uint32); ln = np.ascontiguousarray(length, np.int32)
+    n = len(q); nc = len(st)
+    assert len(off) == nc + 1 and (nc == 0 or off[-1] == n)
+    val = np.zeros(max(1, n), np.float32); ps = np.zeros(max(1, n), np.int64); pi = np.zeros(max(1, n), np.int64)
+    fl = np.zeros(max(1, n), np.uint8)
+    mc = max(1, opts.NumAln)
+    coff = np.zeros(mc + 1, np.int32); cf = np.zeros(max(1, n), np.uint32); cl = np.zeros(max(1, n), np.uint8)
+    box = np.zeros(4 * mc, np.uint32); cv = np.zeros(mc, np.float32)
+    L.oracle_sdp_chain.restype = C.c_int
+    r = L.oracle_sdp_chain(C.c_int(nc), _p(off, C.c_int), _p(st, C.c_uint8), _p(q, C.c_uint32), _p(t, C.c_uint32), _p(ln, C.c_int),
+                           C.byref(opts), _p(val, C.c_float), _p(ps, C.c_long), _p(pi, C.c_long), _p(fl, C.c_uint8), C.c_int(mc),
+                           _p(coff, C.c_int), _p(cf, C.c_uint32), _p(cl, C.c_uint8), _p(box, C.c_uint32), _p(cv, C.c_float))
+    chains = []
+    for c in range(max(r, 0)):
+        a, b = coff[c], coff[c + 1]
+        chains.append(dict(frags=cf[a:b].copy(), link=cl[a:b - 1].copy(), box=box[4 * c:4 * c + 4].copy(), value=float(cv[c])))
+    return dict(status=r, val=val[:n], prev_sub=ps[:n], prev_ind=pi[:n], flags=fl[:n], chains=chains)
