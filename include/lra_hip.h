@@ -164,6 +164,46 @@ typedef struct lra_extend_result {
 } lra_extend_result;
 int lra_linear_extend_batch(lra_ctx* ctx, int K, const char* d_seq, const uint64_t* d_read_off, lra_extend_result* out);
 
+/* ---- a8: sparse dynamic programming over the extended anchors ("SDP#A") -------------------------
+ * Replaces, per read,   SparseDP(ext_clusters, chains, optsSDP, LookUpTable, read, match_rate)
+ * (SparseDP.h:2139-2279 as called from Map_lowacc.h:188): insertPointsPair (:79), the SortByRowOp / SortByColOp
+ * std::sorts (:2171-2174, libstdc++ permutation of tied points included), GetRowInfo / GetColInfo, the four
+ * decompositions DivideSubProbBy{Row,Col}{1,2}, ProcessPoint<Cluster> (:1015) with Maximization /
+ * FindValueInBlock / PWL_w (SubRountine.h), PassValueToD1/D2 (:140,:226), the Fragment_valueOrder sort,
+ * TraceBack (:1351) and DecidePrimaryChains (:1658).  InitPWL(gapopen, gapextend, gaproot, gapCeiling1,
+ * gapCeiling2) (lra.cpp:648) is evaluated on the host with the host libm, as the reference does at start-up.
+ * Input: clusters CSR by read (d_cluster_off[n_reads+1]); per cluster its anchors
+ * [d_c_start[c], d_c_start[c] + d_c_count[c]) in d_q/d_t/d_len (read pos, GLOBAL genome pos, length -- the layout
+ * lra_linear_extend_batch produces) and its strand; read lengths from d_read_off; match_rate per read
+ * (d_rate, NULL = opts->rate for every read; Map_lowacc.h:185-186 uses 3 for reads with a repetitive cluster).
+ * Output (context-owned, valid until the next call): per read up to opts->NumAln chains in slots
+ * [r*NumAln, r*NumAln + d_n_chains[r]); slot s: anchors d_chain_cluster/anchor/link[d_chain_start[s] .. + d_chain_len[s])
+ * in trace-back order (last anchor first; cluster = index within the read, anchor = index within the cluster,
+ * link[i] = 1 if the step to the next listed anchor is an inversion link), box = QStart,QEnd,TStart,TEnd,
+ * value = FirstSDPValue.  d_frag_off[n_reads+1] / d_frag_val: every anchor's final DP value in cluster order.
+ * d_status[r]: LRA_ST_CAPACITY if a work buffer bound was hit, LRA_ST_OOB_SLOT if the reference would read outside
+ * its arrays (the read then has no chains).  Synchronous.                                              */
+typedef struct lra_sdp_opts {
+  float rate; int32_t NumAln; float alnthres;
+  float gapopen, gapextend, gaproot; int32_t gapCeiling1, gapCeiling2;
+} lra_sdp_opts;
+typedef struct lra_chain_result {
+  int32_t n_reads, num_aln;
+  uint64_t n_frags, n_points, n_subproblem_entries;
+  const uint32_t* d_n_chains;       /* [n_reads] */
+  const uint64_t* d_chain_start;    /* [n_reads*num_aln] */
+  const uint32_t* d_chain_len;      /* [n_reads*num_aln] */
+  const uint32_t* d_chain_box;      /* [4*n_reads*num_aln] */
+  const float* d_chain_value;       /* [n_reads*num_aln] */
+  const uint32_t* d_chain_cluster; const uint32_t* d_chain_anchor; const uint8_t* d_chain_link;   /* [n_frags] */
+  const uint64_t* d_frag_off;       /* [n_reads+1] */
+  const float* d_frag_val;          /* [n_frags] */
+  const uint32_t* d_status;         /* [n_reads] */
+} lra_chain_result;
+int lra_sparse_dp_batch(lra_ctx* ctx, int n_reads, const uint64_t* d_cluster_off, const uint64_t* d_c_start, const uint32_t* d_c_count,
+                        const int32_t* d_c_strand, const uint32_t* d_q, const uint32_t* d_t, const int32_t* d_len,
+                        const uint64_t* d_read_off, const float* d_rate, const lra_sdp_opts* opts, lra_chain_result* out);
+
 /* ---- a10: tier-2 (local) minimizer index and lookups ----------------------------------------
  * lra_local_index_batch replaces  LocalIndex::IndexSeq(char* seq, int seqLen)  (MMIndex.h:200-245) for
  * n_seqs sequences (read strands, Map_lowacc.h:246-250; or chromosomes = LocalIndex::IndexFile, the

@@ -25,9 +25,10 @@ struct lra_ctx {
   void* aux = nullptr; size_t aux_bytes = 0;          // AffineOneGapAlign blocks of refine fallbacks
   void* out_buf = nullptr; size_t out_bytes = 0;
   uint64_t* scan_tmp = nullptr;
-  void* gbuf[10] = {};   // growable result / work buffers (lra_ensure)
-  size_t gbytes[10] = {};                       // tile sums of lra_exclusive_scan      // refined blocks handed back to the caller
+  void* gbuf[16] = {};   // growable result / work buffers (lra_ensure)
+  size_t gbytes[16] = {};
   // kernel timing
+  const char* sort_tag = "sort"; const char* sort_fb_tag = "sort_fallback";   // timing names of the exact-sort kernels (sdp.hip retags them)
   bool timing = false;
   std::vector<lra_time_rec> recs;
   std::vector<hipEvent_t> free_events;

@@ -1,0 +1,890 @@
+// lra_amd/csrc/sdp.hip -- SURVEY §8a row a8: the first sparse dynamic program of the low-accuracy path (SDP#A),
+// SparseDP(vector<Cluster>&, vector<UltimateChain>&, ...) (SparseDP.h:2139-2279, called at Map_lowacc.h:188), for a
+// whole batch of reads.  gfx950 only.
+//
+// What the reference does per read: every anchor becomes a start/end point pair per orientation family
+// (insertPointsPair :79), the points are std::sort'ed by row and by column, four divide-and-conquer decompositions
+// (DivideSubProbBy{Row,Col}{1,2}) build a tree of sub-problems holding the distinct diagonals of the end points of
+// one half (Di) and of the start points of the other half (Ei); ProcessPoint (:1015) then walks the points in row
+// order: a start point queries every sub-problem on its root-to-leaf paths (Maximization / FindValueInBlock, a
+// candidate-list structure over the PWL gap cost, SubRountine.h:270-345), an end point deposits the anchor's value
+// in them (PassValueToD*).  The result depends on the order of all these steps (values deposited after a
+// candidate was consumed stay invisible, `last` moves backwards, slots are overwritten), so it is reproduced
+// literally; what is re-designed is how it is laid out and scheduled:
+//
+//  * points, sorts: one thread per cluster writes the points; the two std::sorts are the library's libstdc++-exact
+//    workgroup sort (seed.hip) on packed 63-bit keys (q,t,ind / t,q,ind) -- the permutation of tied points is part
+//    of the result because it fixes the processing order;
+//  * decompositions: the sub-problem numbering is internal to the reference (prev_sub is only an index), so the trees
+//    are built level by level instead of depth first: per family the points are kept sorted by diagonal and stably
+//    partitioned by half at every level (prefix sums), which yields every node's sorted distinct Di/Ei at once;
+//    Db/Eb have closed forms (counts of smaller diagonals), and every (point, level) gets its sub-problem and its
+//    index in Di/Ei recorded -- the Lower_Bound searches of ProcessPoint/PassValueToD* disappear;
+//  * ProcessPoint: one half wave (32 lanes) per read; lane (family pair, level) owns the sub-problems of that level,
+//    so the <= 32 sub-problems a point touches advance concurrently and no sub-problem is ever touched by two
+//    lanes; the ordered `<` update of Value[ii] becomes a (max value, first in order) reduction;
+//  * TraceBack / DecidePrimaryChains: one lane per read after the exact sort of the values.
+//
+// Roofline: integer/float bookkeeping with dependent loads, HBM-nominal; algorithmic bytes per read =
+// 44 B per sub-problem entry + 16 B per (point, level) visit record.
+#include "common.h"
+#include "scan.h"
+#include <algorithm>
+#include <cmath>
+
+namespace {
+
+constexpr int LV = 16;                    // levels per decomposition (lines per read <= 32768)
+constexpr uint32_t NONE = 0xFFFFFFFFu;
+constexpr int MAXALN = 16;
+
+__device__ __forceinline__ void wave_sync() {
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+}
+__device__ __forceinline__ int wave_incl_scan(int v, int lane) {
+  for (int d = 1; d < 64; d <<= 1) { int o = __shfl_up(v, d); if (lane >= d) v += o; }
+  return v;
+}
+
+struct PwlTab { long long stops[25]; float slope[25], inter[25]; int c1, c2; };
+
+struct Node {            // one full sub-problem (SubProblem.h:15-37), 48 bytes
+  uint32_t dBase;        // entry index of Di[0] within the read's entry arrays; Ei[0] at dBase + nD
+  uint32_t nD, nE;
+  int32_t now, last;
+  uint32_t sTop, nBlk;   // sizes of S_1 and Block
+  uint32_t stkOff, blkOff, stkCap, blkCap;
+  uint32_t pad;
+};
+
+// ---- counting / point generation ------------------------------------------------------------------------------------
+__global__ void k_cluster_counts(uint64_t nc, const uint32_t* __restrict__ c_count, uint32_t* fragCnt, uint32_t* ptCnt) {
+  uint64_t c = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= nc) return;
+  uint32_t n = c_count[c];
+  fragCnt[c] = n;
+  ptCnt[c] = 2 * n + 2 * (n == 0 ? 0 : n == 1 ? 1 : 2);     // SparseDP.h:2159-2166: first and last anchor get the other family's pair too
+}
+
+__global__ void k_read_offsets(int n_reads, const uint64_t* __restrict__ cluster_off, const uint64_t* __restrict__ clusFragOff,
+                               const uint64_t* __restrict__ clusPtOff, uint64_t* fragOff, uint64_t* ptOff, uint32_t* clusRead,
+                               uint32_t* status, uint32_t* nChains) {
+  int r = blockIdx.x * blockDim.x + threadIdx.x;
+  if (r > n_reads) return;
+  fragOff[r] = clusFragOff[cluster_off[r]];
+  ptOff[r] = clusPtOff[cluster_off[r]];
+  if (r < n_reads) {
+    for (uint64_t c = cluster_off[r]; c < cluster_off[r + 1]; c++) clusRead[c] = r;
+    status[r] = 0; nChains[r] = 0;
+  }
+}
+
+struct PtArgs {
+  uint64_t nc;
+  const uint64_t* cluster_off; const uint64_t* c_start; const uint32_t* c_count; const int32_t* c_strand;
+  const uint32_t* q; const uint32_t* t; const int32_t* len;
+  const uint32_t* clusRead; const uint64_t* clusFragOff; const uint64_t* clusPtOff; const uint64_t* fragOff; const uint64_t* ptOff;
+  const float* rate_in; float rate;
+  uint32_t* fq; uint32_t* ft; int32_t* flen; uint32_t* fcl; uint32_t* fai; float* fval; uint32_t* fprevNode; uint32_t* fprevInd; uint8_t* fflags;
+  uint8_t* used;
+  uint64_t* key1; uint32_t* pay1; uint32_t* iq; uint32_t* it; uint8_t* ifl; uint32_t* ifr; uint32_t* ptRead;
+};
+
+// one thread per cluster: anchors -> compact fragment arrays + points in insertion order (SparseDP.h:2152-2169)
+__global__ void k_points(PtArgs a) {
+  uint64_t c = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= a.nc) return;
+  const uint32_t r = a.clusRead[c];
+  const uint32_t n = a.c_count[c];
+  const uint64_t src = a.c_start[c];
+  const int strand = a.c_strand[c];
+  uint64_t g = a.clusFragOff[c], p = a.clusPtOff[c];
+  const uint64_t f0 = a.fragOff[r], p0 = a.ptOff[r];
+  const uint32_t cl = (uint32_t)(c - a.cluster_off[r]);
+  const float rate = a.rate_in ? a.rate_in[r] : a.rate;
+  for (uint32_t i = 0; i < n; i++, g++) {
+    const uint32_t q = a.q[src + i], t = a.t[src + i];
+    const int len = a.len[src + i];
+    const uint32_t lf = (uint32_t)(g - f0);
+    a.fq[g] = q; a.ft[g] = t; a.flen[g] = len; a.fcl[g] = cl; a.fai[g] = i;
+    a.fval[g] = len * rate;                                            // Value[ii].val = matchesLengths * rate (:2206)
+    a.fprevNode[g] = NONE; a.fprevInd[g] = NONE; a.fflags[g] = 3; a.used[g] = 0;
+    const bool edge = (i == 0 || i == n - 1);
+    for (int rep = 0; rep < (edge ? 2 : 1); rep++) {
+      const int pair = (strand == 0) ? rep : 1 - rep;                  // forward cluster: s1/e1 first; reverse: s2/e2 first
+      uint32_t sq, st, eq, et;
+      if (pair == 0) { sq = q; st = t; eq = q + len; et = t + len; }   // insertPointsPair :79-137
+      else { sq = q; st = t + len; eq = q + len; et = t; }
+      const uint8_t inv = pair == 0 ? 1 : 0;
+      for (int e = 0; e < 2; e++, p++) {
+        const uint32_t pq = e ? eq : sq, pt = e ? et : st;
+        const uint8_t ind = e ? 0 : 1;
+        a.key1[p] = ((uint64_t)pq << 33) | ((uint64_t)pt << 1) | ind; // SortByRowOp: q, t, ind (Sorting.h:226)
+        a.pay1[p] = (uint32_t)(p - p0);
+        a.iq[p] = pq; a.it[p] = pt; a.ifl[p] = (uint8_t)(ind | (inv << 1)); a.ifr[p] = lf; a.ptRead[p] = r;
+      }
+    }
+  }
+}
+
+// after the row sort: gather the point attributes into H1 order, build the column-sort and diagonal-sort keys
+__global__ void k_gather(uint64_t np, const uint32_t* __restrict__ ptRead, const uint64_t* __restrict__ ptOff, const uint32_t* __restrict__ pay1,
+                         const uint32_t* __restrict__ iq, const uint32_t* __restrict__ it, const uint8_t* __restrict__ ifl,
+                         const uint32_t* __restrict__ ifr, uint32_t* hq, uint32_t* ht, uint8_t* hfl, uint32_t* hfr, uint64_t* key2,
+                         uint32_t* pay2, uint64_t* key3, uint32_t* pay3) {
+  uint64_t p = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (p >= np) return;
+  const uint64_t p0 = ptOff[ptRead[p]];
+  const uint64_t s = p0 + pay1[p];
+  const uint32_t q = iq[s], t = it[s];
+  const uint8_t fl = ifl[s];
+  hq[p] = q; ht[p] = t; hfl[p] = fl; hfr[p] = ifr[s];
+  key2[p] = ((uint64_t)t << 31) | ((uint64_t)q << 1) | (fl & 1);       // SortByColOp: t, q, ind (Sorting.h:241)
+  pay2[p] = (uint32_t)(p - p0);
+  const int inv = (fl >> 1) & 1, ind = fl & 1;
+  const uint64_t cls = (uint64_t)((inv ? 0 : 2) + (ind ? 0 : 1));      // 0: s1, 1: e1, 2: s2, 3: e2
+  const uint64_t dg = inv ? (uint64_t)((int64_t)t - (int64_t)q + (1LL << 32)) : (uint64_t)t + q;
+  key3[p] = (cls << 40) | dg;
+  pay3[p] = (uint32_t)(p - p0);
+}
+
+// ---- decompositions ---------------------------------------------------------------------------------------------------
+struct BuildArgs {
+  int r0, n;                                 // reads [r0, r0 + n)
+  const uint64_t* ptOff;
+  const uint32_t* hq; const uint32_t* ht; const uint8_t* hfl; const uint32_t* h2; const uint64_t* key3; const uint32_t* pay3;
+  uint32_t* scratch;                         // 28 words per point + 64 per read
+  uint32_t* cntEntries; uint32_t* cntNodes; uint32_t* cntD;   // [n] (count pass out)
+  const uint64_t* entOff; const uint64_t* nodeOff; const uint64_t* dOff;   // [n+1] (emit pass in)
+  int64_t* A_val; int32_t* A_b; float* A_v; uint32_t* A_p; int2* stk; Node* nodes;
+  uint2* visit;                              // [(points of the chunk) * 2 * LV]
+  uint32_t* status;
+};
+
+template <bool EMIT>
+__global__ void __launch_bounds__(64) sdp_build(BuildArgs a) {
+  const int rr = blockIdx.x, r = a.r0 + rr, lane = threadIdx.x;
+  const uint64_t p0 = a.ptOff[r], pc0 = a.ptOff[a.r0];
+  const int P = (int)(a.ptOff[r + 1] - p0);
+  if (P == 0) { if (!EMIT && lane == 0) { a.cntEntries[rr] = 0; a.cntNodes[rr] = 0; a.cntD[rr] = 0; } return; }
+  const uint32_t* hq = a.hq + p0; const uint32_t* ht = a.ht + p0; const uint32_t* h2 = a.h2 + p0;
+  const uint64_t* key3 = a.key3 + p0; const uint32_t* pay3 = a.pay3 + p0;
+  uint32_t* S = a.scratch + 28 * (p0 - pc0) + 64 * (uint64_t)rr;
+  const int NCAP = P + 2;
+  uint32_t* rowOf = S; uint32_t* colOf = rowOf + P;
+  uint32_t* lp = colOf + P;                 // [2][P]
+  uint32_t* ln = lp + 2 * P;                // [2][P]: [0] node index of the element, [1] temporary 2k+side
+  uint32_t* pf = ln + 2 * P;                // [P+1]
+  uint32_t* ph = pf + P + 1;                // [P+1]
+  uint32_t* tbl = ph + P + 1;               // [2][6][NCAP]
+  uint32_t* tmp = tbl + 12 * NCAP;          // [8][NCAP]
+#define TB(c, f, k) tbl[((c) * 6 + (f)) * NCAP + (k)]
+#define TM(f, k) tmp[(f) * NCAP + (k)]
+  enum { F_LS, F_LE, F_SB, F_SE, F_EB, F_EE };
+  enum { T_C1S, T_C1E, T_ND, T_NE, T_CH0, T_CH1, T_BASE, T_GID };
+  // rows (GetRowInfo) and columns (GetColInfo): index of the distinct q / t of every point
+  int R = 0, C = 0;
+  for (int i0 = 0; i0 < P; i0 += 64) {
+    const int i = i0 + lane;
+    const int head = (i < P) && (i == 0 || hq[i] != hq[i - 1]);
+    const int inc = wave_incl_scan(head, lane);
+    if (i < P) rowOf[i] = R + inc - 1;
+    R += __shfl(inc, 63);
+  }
+  for (int i0 = 0; i0 < P; i0 += 64) {
+    const int i = i0 + lane;
+    const int head = (i < P) && (i == 0 || ht[h2[i]] != ht[h2[i - 1]]);
+    const int inc = wave_incl_scan(head, lane);
+    if (i < P) colOf[h2[i]] = C + inc - 1;
+    C += __shfl(inc, 63);
+  }
+  // class boundaries in the diagonal-sorted list
+  int cOff[5];
+  {
+    int c0 = 0, c1 = 0, c2 = 0, c3 = 0;
+    for (int i = lane; i < P; i += 64) { const int cl = (int)(key3[i] >> 40); c0 += cl == 0; c1 += cl == 1; c2 += cl == 2; c3 += cl == 3; }
+    for (int o = 32; o > 0; o >>= 1) { c0 += __shfl_xor(c0, o); c1 += __shfl_xor(c1, o); c2 += __shfl_xor(c2, o); c3 += __shfl_xor(c3, o); }
+    cOff[0] = 0; cOff[1] = c0; cOff[2] = c0 + c1; cOff[3] = c0 + c1 + c2; cOff[4] = P;
+  }
+  wave_sync();
+  uint32_t nEntries = 0, nNodesTot = 0, sumD = 0;
+  uint64_t eOff = 0, nOff = 0, dOff = 0;
+  if (EMIT) { eOff = a.entOff[rr]; nOff = a.nodeOff[rr]; dOff = a.dOff[rr]; }
+  const uint64_t stkBase = 2 * dOff + 4 * nOff;   // the stack pairs of this read start here (Block pairs: 2 * eOff + 8 * nOff)
+  bool overflow = false;
+  for (int fam = 0; fam < 4; fam++) {
+    // family switches (DivideSubBy{Row1,Col1,Row2,Col2}.h): R1, C1, R2, C2
+    const bool col = fam & 1, back = fam >= 2, desc = (fam == 1 || fam == 2), swapped = (fam == 3);
+    const uint32_t* lineOf = col ? colOf : rowOf;
+    const int nLines = col ? C : R;
+    const int sc = back ? 2 : 0;
+    const int nS = cOff[sc + 1] - cOff[sc], nEn = cOff[sc + 2] - cOff[sc + 1], Pf = nS + nEn;
+    if (nS == 0 || nEn == 0) continue;
+    const int fam2 = fam & 1;
+    const int dSide = swapped ? 1 : 0, eSide = swapped ? 0 : 1;
+    for (int i = lane; i < Pf; i += 64) { lp[i] = pay3[cOff[sc] + i]; ln[i] = 0; }
+    if (lane == 0) { TB(0, F_LS, 0) = 0; TB(0, F_LE, 0) = nLines; TB(0, F_SB, 0) = 0; TB(0, F_SE, 0) = nS; TB(0, F_EB, 0) = nS; TB(0, F_EE, 0) = Pf; }
+    int nNodes = 1, cur = 0;
+    wave_sync();
+    for (int level = 0; nNodes > 0; level++) {
+      if (level >= LV) { overflow = true; break; }
+      const int nxt = cur ^ 1;
+      uint32_t* lpc = lp + cur * P; uint32_t* lpn = lp + nxt * P;
+      // A: which elements go to the first half of their node's lines; exclusive prefix in pf
+      {
+        int carry = 0;
+        for (int i0 = 0; i0 < Pf; i0 += 64) {
+          const int i = i0 + lane;
+          int f = 0;
+          if (i < Pf) {
+            const uint32_t k = ln[i];
+            if (k != NONE) {
+              const uint32_t s = TB(cur, F_LS, k), e = TB(cur, F_LE, k);
+              f = (e - s > 1) ? (lineOf[lpc[i]] < ((s + e) >> 1)) : 1;
+            }
+          }
+          const int inc = wave_incl_scan(f, lane);
+          if (i < Pf) pf[i] = carry + inc - f;
+          carry += __shfl(inc, 63);
+        }
+        if (lane == 0) pf[Pf] = carry;
+      }
+      wave_sync();
+      for (int k = lane; k < nNodes; k += 64) {
+        TM(T_C1S, k) = pf[TB(cur, F_SE, k)] - pf[TB(cur, F_SB, k)];
+        TM(T_C1E, k) = pf[TB(cur, F_EE, k)] - pf[TB(cur, F_EB, k)];
+      }
+      wave_sync();
+      // C: stable partition of every node's two segments
+      for (int i = lane; i < Pf; i += 64) {
+        const uint32_t k = ln[i];
+        if (k == NONE) { ln[P + i] = NONE; continue; }
+        const bool isS = i < nS;
+        const uint32_t sb = isS ? TB(cur, F_SB, k) : TB(cur, F_EB, k);
+        const uint32_t c1 = isS ? TM(T_C1S, k) : TM(T_C1E, k);
+        const uint32_t rank1 = pf[i] - pf[sb];
+        const uint32_t first = pf[i + 1] - pf[i];
+        const uint32_t np_ = first ? sb + rank1 : sb + c1 + ((uint32_t)i - sb - rank1);
+        lpn[np_] = lpc[i];
+        ln[P + np_] = 2 * k + (first ? 0 : 1);
+      }
+      wave_sync();
+      // D: heads of the distinct diagonals inside the D segment (ends) / E segment (starts); exclusive prefix in ph
+      {
+        int carry = 0;
+        for (int j0 = 0; j0 < Pf; j0 += 64) {
+          const int j = j0 + lane;
+          int head = 0;
+          if (j < Pf) {
+            const uint32_t k2 = ln[P + j];
+            if (k2 != NONE) {
+              const uint32_t k = k2 >> 1, side = k2 & 1;
+              const bool isS = j < nS;
+              const bool leaf = TB(cur, F_LE, k) - TB(cur, F_LS, k) == 1;
+              const bool in = leaf || (int)side == (isS ? eSide : dSide);
+              if (in) {
+                uint32_t beg = isS ? TB(cur, F_SB, k) : TB(cur, F_EB, k);
+                if (!leaf && side == 1) beg += isS ? TM(T_C1S, k) : TM(T_C1E, k);
+                if ((uint32_t)j == beg) head = 1;
+                else {
+                  const uint32_t a0 = lpn[j], a1 = lpn[j - 1];
+                  const int64_t d0 = back ? (int64_t)ht[a0] + hq[a0] : (int64_t)ht[a0] - hq[a0];
+                  const int64_t d1 = back ? (int64_t)ht[a1] + hq[a1] : (int64_t)ht[a1] - hq[a1];
+                  head = d0 != d1;
+                }
+              }
+            }
+          }
+          const int inc = wave_incl_scan(head, lane);
+          if (j < Pf) ph[j] = carry + inc - head;
+          carry += __shfl(inc, 63);
+        }
+        if (lane == 0) ph[Pf] = carry;
+      }
+      wave_sync();
+      // E: per node: sizes, fullness, children, next level's table
+      int nNext = 0;
+      for (int k0 = 0; k0 < nNodes; k0 += 64) {
+        const int k = k0 + lane;
+        uint32_t nD = 0, nE = 0, act0 = 0, act1 = 0, full = 0;
+        uint32_t ls = 0, le = 0, sb = 0, se = 0, eb = 0, ee = 0, c1S = 0, c1E = 0;
+        bool leaf = false;
+        if (k < nNodes) {
+          ls = TB(cur, F_LS, k); le = TB(cur, F_LE, k); sb = TB(cur, F_SB, k); se = TB(cur, F_SE, k); eb = TB(cur, F_EB, k); ee = TB(cur, F_EE, k);
+          c1S = TM(T_C1S, k); c1E = TM(T_C1E, k);
+          leaf = le - ls == 1;
+          uint32_t dB, dE, eB, eE;
+          if (leaf) { dB = eb; dE = ee; eB = sb; eE = se; }
+          else {
+            dB = dSide == 0 ? eb : eb + c1E; dE = dSide == 0 ? eb + c1E : ee;
+            eB = eSide == 0 ? sb : sb + c1S; eE = eSide == 0 ? sb + c1S : se;
+          }
+          nD = ph[dE] - ph[dB]; nE = ph[eE] - ph[eB];
+          full = nD > 0 && nE > 0;
+          if (!leaf) {                                                   // DivideSubProbBy*: which halves are explored
+            const bool goD = nD > 0, goE = nE > 0;                       // both empty: none; only Di: D half; only Ei: E half; else both
+            if (dSide == 0) { act0 = goD; act1 = goE; } else { act1 = goD; act0 = goE; }
+          }
+        }
+        const int incF = wave_incl_scan((int)full, lane), incEnt = wave_incl_scan((int)(full ? nD + nE : 0), lane),
+                  incD = wave_incl_scan((int)(full ? nD : 0), lane), incC = wave_incl_scan((int)(act0 + act1), lane);
+        if (k < nNodes) {
+          const uint32_t gid = nNodesTot + incF - full, base = nEntries + incEnt - (full ? nD + nE : 0), dpre = sumD + incD - (full ? nD : 0);
+          TM(T_ND, k) = nD; TM(T_NE, k) = nE; TM(T_GID, k) = full ? gid : NONE; TM(T_BASE, k) = base;
+          uint32_t ci = nNext + incC - (act0 + act1);
+          const uint32_t med = (ls + le) >> 1;
+          TM(T_CH0, k) = NONE; TM(T_CH1, k) = NONE;
+          if (act0) { TM(T_CH0, k) = ci; TB(nxt, F_LS, ci) = ls; TB(nxt, F_LE, ci) = med; TB(nxt, F_SB, ci) = sb; TB(nxt, F_SE, ci) = sb + c1S;
+                      TB(nxt, F_EB, ci) = eb; TB(nxt, F_EE, ci) = eb + c1E; ci++; }
+          if (act1) { TM(T_CH1, k) = ci; TB(nxt, F_LS, ci) = med; TB(nxt, F_LE, ci) = le; TB(nxt, F_SB, ci) = sb + c1S; TB(nxt, F_SE, ci) = se;
+                      TB(nxt, F_EB, ci) = eb + c1E; TB(nxt, F_EE, ci) = ee; }
+          if (EMIT && full) {
+            Node nd;
+            nd.dBase = base; nd.nD = nD; nd.nE = nE; nd.now = 0; nd.last = -1; nd.sTop = 1; nd.nBlk = 0;
+            nd.stkOff = 2 * dpre + 4 * gid; nd.stkCap = 2 * nD + 4; nd.blkOff = 2 * base + 8 * gid; nd.blkCap = 2 * (nD + nE) + 8; nd.pad = (uint32_t)fam;
+            a.nodes[nOff + gid] = nd;
+            a.stk[stkBase + nd.stkOff] = make_int2(-1, (int)nE + 1);     // dummy pair (DivideSubByRow1.h:470)
+          }
+        }
+        nNodesTot += __shfl(incF, 63); nEntries += __shfl(incEnt, 63); sumD += __shfl(incD, 63); nNext += __shfl(incC, 63);
+      }
+      wave_sync();
+      // F: node index of every element for the next level; emit Di / Ei and the visit records
+      for (int j = lane; j < Pf; j += 64) {
+        const uint32_t k2 = ln[P + j];
+        if (k2 == NONE) { ln[j] = NONE; continue; }
+        const uint32_t k = k2 >> 1, side = k2 & 1;
+        const bool leaf = TB(cur, F_LE, k) - TB(cur, F_LS, k) == 1;
+        ln[j] = leaf ? NONE : (side == 0 ? TM(T_CH0, k) : TM(T_CH1, k));
+        if (EMIT) {
+          const uint32_t gid = TM(T_GID, k);
+          const bool isS = j < nS;
+          const bool in = leaf || (int)side == (isS ? eSide : dSide);
+          if (in && gid != NONE) {
+            uint32_t beg = isS ? TB(cur, F_SB, k) : TB(cur, F_EB, k);
+            if (!leaf && side == 1) beg += isS ? TM(T_C1S, k) : TM(T_C1E, k);
+            const uint32_t head = ph[j + 1] - ph[j];
+            const uint32_t grp = ph[j] - ph[beg] + head - 1;
+            const uint32_t n = isS ? TM(T_NE, k) : TM(T_ND, k);
+            const uint32_t idx = desc ? n - 1 - grp : grp;
+            const uint32_t ent = TM(T_BASE, k) + (isS ? TM(T_ND, k) + idx : idx);
+            const uint32_t pos = lpn[j];
+            if (head) a.A_val[eOff + ent] = back ? (int64_t)ht[pos] + hq[pos] : (int64_t)ht[pos] - hq[pos];
+            a.visit[((p0 - pc0) + pos) * (2 * LV) + fam2 * LV + level] = make_uint2(gid, idx);
+          }
+        }
+      }
+      wave_sync();
+      // G: Db / Eb in closed form (Decide_Eb_Db_*), values and back pointers zeroed
+      if (EMIT) {
+        for (int j = lane; j < Pf; j += 64) {
+          const uint32_t k2 = ln[P + j];
+          if (k2 == NONE) continue;
+          const uint32_t k = k2 >> 1, side = k2 & 1;
+          const uint32_t gid = TM(T_GID, k);
+          if (gid == NONE || ph[j + 1] == ph[j]) continue;
+          const bool isS = j < nS;
+          const bool leaf = TB(cur, F_LE, k) - TB(cur, F_LS, k) == 1;
+          if (!(leaf || (int)side == (isS ? eSide : dSide))) continue;
+          uint32_t beg = isS ? TB(cur, F_SB, k) : TB(cur, F_EB, k);
+          if (!leaf && side == 1) beg += isS ? TM(T_C1S, k) : TM(T_C1E, k);
+          const uint32_t nD = TM(T_ND, k), nE = TM(T_NE, k), base = TM(T_BASE, k);
+          const uint32_t grp = ph[j] - ph[beg];
+          const uint32_t n = isS ? nE : nD;
+          const uint32_t idx = desc ? n - 1 - grp : grp;
+          const uint32_t ent = base + (isS ? nD + idx : idx);
+          const int64_t x = a.A_val[eOff + ent];
+          const int64_t* opp = a.A_val + eOff + base + (isS ? 0 : nD);
+          const uint32_t m = isS ? nD : nE;
+          uint32_t lo = 0, cnt = m;
+          // D entry: asc  #{Ei < x}   desc #{Ei >= x};   E entry: asc #{Di <= x}   desc #{Di > x}
+          while (cnt > 0) {
+            const uint32_t step = cnt >> 1, it = lo + step;
+            const int64_t v = opp[it];
+            const bool go = isS ? (desc ? v > x : v <= x) : (desc ? v >= x : v < x);
+            if (go) { lo = it + 1; cnt -= step + 1; } else cnt = step;
+          }
+          a.A_b[eOff + ent] = isS ? (int32_t)lo - 1 : (lo == m ? -1 : (int32_t)lo);
+          a.A_v[eOff + ent] = 0.f; a.A_p[eOff + ent] = 0;
+        }
+      }
+      nNodes = nNext; cur = nxt;
+      wave_sync();
+    }
+  }
+  if (lane == 0) {
+    if (!EMIT) { a.cntEntries[rr] = nEntries; a.cntNodes[rr] = nNodesTot; a.cntD[rr] = sumD; }
+    if (overflow) atomicOr(&a.status[r], (uint32_t)LRA_ST_CAPACITY);
+  }
+#undef TB
+#undef TM
+}
+
+// ---- ProcessPoint -----------------------------------------------------------------------------------------------------
+struct ProcArgs {
+  int r0, n;
+  const uint64_t* ptOff; const uint64_t* fragOff;
+  const uint32_t* hq; const uint32_t* ht; const uint8_t* hfl; const uint32_t* hfr;
+  const int32_t* flen; float* fval; uint32_t* fprevNode; uint32_t* fprevInd; uint8_t* fflags;
+  const float* rate_in; float rate;
+  const uint64_t* entOff; const uint64_t* nodeOff; const uint64_t* dOff;
+  int64_t* A_val; int32_t* A_b; float* A_v; uint32_t* A_p; int2* stk; int2* blk; Node* nodes;
+  const uint2* visit;
+  uint32_t* status;
+  PwlTab pwl;
+};
+
+struct Sub {               // one lane's view of a sub-problem
+  const int64_t* Di; const int64_t* Ei; float* Dv; const int32_t* Db; int2* S; int2* B;
+  int nD, nE, sTop, nBlk, sCap, bCap;
+  uint32_t st;
+};
+
+__device__ __forceinline__ float pwl_w(const long long* stops, const float* slope, const float* inter, int c1, int c2, long long i, long long j) {
+  long long x = (j > i ? j - i : i - j) + 1;                            // w(): labs(j - i) + 1   SubRountine.h:123
+  if (x == 1) return 0.f;
+  long long pen;
+  if (x <= 2) pen = 0;                                                  // PWL_w :101 (minX = 2)
+  else {
+    int lo = 0, cnt = 24;                                               // upper_bound(&STOPS[0], &STOPS[24], x)
+    while (cnt > 0) { const int step = cnt >> 1, it = lo + step; if (!(x < stops[it])) { lo = it + 1; cnt -= step + 1; } else cnt = step; }
+    pen = (long long)(slope[lo - 1] * (float)x + inter[lo - 1]);
+    if (pen >= c1 && pen < c2) pen = c1;
+    else if (pen > c2) pen = c2;
+  }
+  return -(float)pen;
+}
+
+#define W(i, j) pwl_w(s_stops, s_slope, s_inter, c1, c2, (i), (j))
+#define SPUSH(v) do { if (s.sTop < s.sCap) s.S[s.sTop] = (v); else s.st |= LRA_ST_CAPACITY; s.sTop++; } while (0)
+#define BPUSH(v) do { if (s.nBlk < s.bCap) s.B[s.nBlk] = (v); else s.st |= LRA_ST_CAPACITY; s.nBlk++; } while (0)
+#define STOP() (s.S[min(s.sTop, s.sCap) - 1])
+
+// Maximization (SubRountine.h:270-345), `last` .. `now` of the sub-problem; returns false if a bound was hit
+__device__ bool maximization(Sub& s, int last, int now, const long long* s_stops, const float* s_slope, const float* s_inter, int c1, int c2) {
+  const int m = s.nD, n = s.nE;
+  for (int i = last + 1; i <= now; ++i) {
+    const int db = s.Db[i];
+    if (db == -1) break;
+    if (STOP().y == n + 1) { BPUSH(make_int2(-1, db)); SPUSH(make_int2(i, n)); }
+    while (s.sTop > 1 && db >= STOP().y) { BPUSH(STOP()); s.sTop--; }
+    if (s.st) return false;
+    const int l = STOP().x;
+    if (l < 0) { s.st |= LRA_ST_OOB_SLOT; return false; }
+    const float dvi = s.Dv[i];
+    const long long di = s.Di[i], edb = s.Ei[db];
+    if (dvi + W(di, edb) > s.Dv[l] + W(s.Di[l], edb)) {
+      if (db < STOP().y && s.nBlk > 0 && db > s.B[min(s.nBlk, s.bCap) - 1].y) BPUSH(make_int2(STOP().x, db));
+      int2 cur = STOP(), prev = cur;
+      while (s.sTop > 0) {
+        if (cur.x < 0 || cur.y < 1) { s.st |= LRA_ST_OOB_SLOT; return false; }
+        const long long e = s.Ei[cur.y - 1];
+        if (!(dvi + W(di, e) > s.Dv[cur.x] + W(s.Di[cur.x], e))) break;
+        s.sTop--;
+        prev = cur;
+        if (s.sTop == 0) { s.st |= LRA_ST_OOB_SLOT; return false; }
+        cur = STOP();
+        if (cur.y == n + 1) break;
+      }
+      // FindBoundary(prev.second, cur.second, i, cur.first) :239-263
+      unsigned first = (unsigned)prev.y;
+      if (cur.x != -1) {
+        unsigned count = (unsigned)cur.y - first;
+        const float dvb = s.Dv[cur.x];
+        const long long dib = s.Di[cur.x];
+        while (count > 0) {
+          const unsigned step = count / 2, it = first + step;
+          const long long e = s.Ei[it];
+          if (dvi + W(di, e) > dvb + W(dib, e)) { first = it + 1; count -= step + 1; } else count = step;
+        }
+      } else first = (unsigned)n;
+      SPUSH(make_int2(i, (int)first));
+    }
+    if (s.st) return false;
+  }
+  if (now == m - 1) { while (s.sTop > 0 && STOP().y != n + 1) { BPUSH(STOP()); s.sTop--; } }
+  else { const int dbn = s.Db[now + 1]; while (s.sTop > 0 && dbn >= STOP().y) { BPUSH(STOP()); s.sTop--; } }
+  return s.st == 0 && s.sTop > 0;
+}
+
+__global__ void __launch_bounds__(64) sdp_process(ProcArgs a) {
+  __shared__ long long s_stops[25];
+  __shared__ float s_slope[25], s_inter[25];
+  const int lane = threadIdx.x, gl = lane & 31, grp = lane >> 5;
+  if (lane < 25) { s_stops[lane] = a.pwl.stops[lane]; s_slope[lane] = a.pwl.slope[lane]; s_inter[lane] = a.pwl.inter[lane]; }
+  __syncthreads();
+  const int c1 = a.pwl.c1, c2 = a.pwl.c2;
+  const int rr = blockIdx.x * 2 + grp;
+  const bool have = rr < a.n;
+  const int r = a.r0 + (have ? rr : 0);
+  const uint64_t p0 = a.ptOff[r], pc0 = a.ptOff[a.r0], f0 = a.fragOff[r];
+  const int P = have ? (int)(a.ptOff[r + 1] - p0) : 0;
+  const int Pmax = max(P, __shfl_xor(P, 32));
+  const float rate = a.rate_in ? a.rate_in[r] : a.rate;
+  const int fam2 = gl >> 4, level = gl & 15;
+  const uint64_t eOff = have ? a.entOff[rr] : 0, nOff = have ? a.nodeOff[rr] : 0, dOffR = have ? a.dOff[rr] : 0;
+  int2* stkR = a.stk + 2 * dOffR + 4 * nOff;
+  int2* blkR = a.blk + 2 * eOff + 8 * nOff;
+  uint32_t bad = 0;
+  for (int i = 0; i < Pmax; i++) {
+    const bool on = i < P && !bad;
+    float ev = -1.f;
+    uint32_t vnode = NONE, vi1 = 0;
+    uint32_t lf = 0;
+    int ind = 0, inv = 0;
+    if (on) {
+      const uint8_t fl = a.hfl[p0 + i];
+      lf = a.hfr[p0 + i];
+      ind = fl & 1; inv = (fl >> 1) & 1;
+      const uint2 v = a.visit[((p0 - pc0) + i) * (2 * LV) + gl];
+      if (v.x != NONE) {
+        Node* nd = a.nodes + nOff + v.x;
+        const uint32_t dB = nd->dBase, nD = nd->nD, nE = nd->nE;
+        if (ind == 0) {                                                  // PassValueToD1/D2 (SparseDP.h:140-310)
+          const float val = a.fval[f0 + lf];
+          float* dv = a.A_v + eOff + dB + v.y;
+          if (*dv < val) { *dv = val; a.A_p[eOff + dB + v.y] = lf; }
+        } else {                                                         // ProcessPoint, start point (:1025-1060)
+          const int i1 = (int)v.y;
+          const int ebv = a.A_b[eOff + dB + nD + i1];
+          if (ebv != -1) {
+            Sub s;
+            s.Di = a.A_val + eOff + dB; s.Ei = s.Di + nD; s.Dv = a.A_v + eOff + dB; s.Db = a.A_b + eOff + dB;
+            s.S = stkR + nd->stkOff; s.B = blkR + nd->blkOff; s.nD = (int)nD; s.nE = (int)nE; s.sTop = (int)nd->sTop; s.nBlk = (int)nd->nBlk;
+            s.sCap = (int)nd->stkCap; s.bCap = (int)nd->blkCap; s.st = 0;
+            const bool ok = maximization(s, nd->last, ebv, s_stops, s_slope, s_inter, c1, c2);
+            nd->now = ebv; nd->last = ebv; nd->sTop = (uint32_t)s.sTop; nd->nBlk = (uint32_t)s.nBlk;
+            if (!ok || s.nBlk == 0) bad |= s.st ? s.st : LRA_ST_OOB_SLOT;
+            else {
+              // FindValueInBlock :224-236
+              int i2;
+              const int2 bb = s.B[s.nBlk - 1], top = s.S[s.sTop - 1];
+              if (i1 >= bb.y && i1 < top.y) i2 = top.x;
+              else {
+                int lo = 0, cnt = s.nBlk;                               // UPPERbound :205-221
+                while (cnt > 0) { const int step = cnt >> 1, it = lo + step; if (i1 >= s.B[it].y) { lo = it + 1; cnt -= step + 1; } else cnt = step; }
+                i2 = lo < s.nBlk ? s.B[lo].x : -1;
+              }
+              if (i2 < 0 || i2 >= (int)nD) bad |= LRA_ST_OOB_SLOT;
+              else {
+                ev = s.Dv[i2] + W(s.Di[i2], s.Ei[i1]) + rate * a.flen[f0 + lf];
+                a.A_v[eOff + dB + nD + i1] = ev;                         // Ev[i1], Ep[i1]
+                a.A_p[eOff + dB + nD + i1] = (uint32_t)i2;
+                vnode = v.x; vi1 = (uint32_t)i1;
+              }
+            }
+          }
+        }
+      }
+    }
+    // Value[ii]: the visits are applied in the order R-family deepest level first, then C-family; `val < Ev` keeps the
+    // first visit that reaches the maximum (:1045-1051)
+    bad |= __shfl_xor(bad, 16); bad |= __shfl_xor(bad, 8); bad |= __shfl_xor(bad, 4); bad |= __shfl_xor(bad, 2); bad |= __shfl_xor(bad, 1);
+    if (ind == 1 && i < P) {
+      const int ord = fam2 * 16 + (15 - level);
+      float bv = ev; int bo = vnode != NONE ? ord : 64;
+      for (int o = 16; o > 0; o >>= 1) {
+        const float ov = __shfl_xor(bv, o); const int oo = __shfl_xor(bo, o);
+        if (ov > bv || (ov == bv && oo < bo)) { bv = ov; bo = oo; }
+      }
+      if (vnode != NONE && bo == ord && !bad) {
+        if (a.fval[f0 + lf] < bv) {
+          a.fval[f0 + lf] = bv; a.fprevNode[f0 + lf] = vnode; a.fprevInd[f0 + lf] = vi1;
+          a.fflags[f0 + lf] = (uint8_t)((fam2 == 0 ? 1 : 0) | (inv ? 2 : 0));     // bit0 prev (row family), bit1 inv
+        }
+      }
+    }
+    wave_sync();
+  }
+  if (have && gl == 0 && bad) atomicOr(&a.status[r], bad);
+}
+
+// ---- value order, TraceBack, DecidePrimaryChains ------------------------------------------------------------------------
+__global__ void k_valkeys(uint64_t f0, uint64_t n, const float* __restrict__ fval, const uint32_t* __restrict__ fragRead,
+                          const uint64_t* __restrict__ fragOff, uint64_t* okey, uint32_t* opay) {
+  uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const uint64_t g = f0 + i;
+  okey[g] = (uint64_t)(0xFFFFFFFFu - __float_as_uint(fval[g]));         // Fragment_valueOrder: value descending (values are >= 0)
+  opay[g] = (uint32_t)(g - fragOff[fragRead[g]]);
+}
+
+__global__ void k_frag_read(int n_reads, const uint64_t* __restrict__ fragOff, uint32_t* fragRead) {
+  int r = blockIdx.x;
+  for (uint64_t g = fragOff[r] + threadIdx.x; g < fragOff[r + 1]; g += blockDim.x) fragRead[g] = r;
+}
+
+struct TraceArgs {
+  int r0, n, numAln; float alnthres;
+  const uint64_t* fragOff; const uint64_t* read_off;
+  const uint32_t* fq; const uint32_t* ft; const int32_t* flen; const uint32_t* fcl; const uint32_t* fai;
+  const float* fval; const uint32_t* fprevNode; const uint32_t* fprevInd; const uint8_t* fflags; const uint32_t* opay;
+  uint8_t* used;
+  const uint64_t* entOff; const uint64_t* nodeOff; const uint32_t* A_p; const Node* nodes;
+  uint32_t* nChains; uint64_t* chainStart; uint32_t* chainLen; uint32_t* chainBox; float* chainValue;
+  uint32_t* ccl; uint32_t* can; uint8_t* clink;
+  const uint32_t* status;
+};
+
+__global__ void __launch_bounds__(64) sdp_trace(TraceArgs a) {
+  const int rr = blockIdx.x * 64 + threadIdx.x;
+  if (rr >= a.n) return;
+  const int r = a.r0 + rr;
+  const uint64_t f0 = a.fragOff[r];
+  const int total = (int)(a.fragOff[r + 1] - f0);
+  a.nChains[r] = 0;
+  if (total == 0 || a.status[r]) return;
+  const uint64_t eOff = a.entOff[rr], nOff = a.nodeOff[rr];
+  const int readLen = (int)(a.read_off[r + 1] - a.read_off[r]);
+  const float thres = a.alnthres * a.fval[f0 + a.opay[f0]];
+  int nCh = 0, fv = 0;
+  uint64_t out = f0;                                                     // chains are written back to back into the read's fragment range
+  uint32_t c0TS = 0, c0TE = 0;
+  while (nCh < a.numAln && fv < total && a.fval[f0 + a.opay[f0 + fv]] >= thres) {
+    uint32_t i = a.opay[f0 + fv];
+    const float firstVal = a.fval[f0 + i];
+    // TraceBack with `used` (:1351-1438); the chain is written at out.. and rolled back if it runs into a used anchor
+    uint32_t len = 0;
+    bool abandoned = false;
+    if (a.used[f0 + i] == 0) {
+      a.ccl[out] = i; len = 1; a.used[f0 + i] = 1;
+      uint32_t pn = a.fprevNode[f0 + i], pi = a.fprevInd[f0 + i];
+      while (pn != NONE && pi != NONE) {
+        const Node nd = a.nodes[nOff + pn];
+        const uint32_t ind = a.A_p[eOff + nd.dBase + nd.nD + pi];       // Ep[prev_ind]
+        const uint32_t nx = a.A_p[eOff + nd.dBase + ind];               // Dp[ind]
+        if (a.used[f0 + nx] == 0) { a.clink[out + len - 1] = (a.fflags[f0 + i] & 2) ? 0 : 1; i = nx; }
+        else { abandoned = true; break; }
+        pn = a.fprevNode[f0 + i]; pi = a.fprevInd[f0 + i];
+        if (a.used[f0 + i] == 0) { a.ccl[out + len] = i; len++; a.used[f0 + i] = 1; }
+        else { abandoned = true; break; }
+      }
+      if (abandoned) { for (uint32_t k = 0; k < len; k++) a.used[f0 + a.ccl[out + k]] = 0; len = 0; }
+    }
+    if (len != 0) {
+      uint32_t f = a.ccl[out], l = a.ccl[out + len - 1];
+      uint32_t QEnd = a.fq[f0 + f] + a.flen[f0 + f], QStart = a.fq[f0 + l], TEnd = a.ft[f0 + f] + a.flen[f0 + f], TStart = a.ft[f0 + l];
+      for (uint32_t k = 0; k < len; k++) {
+        f = a.ccl[out + k];
+        QEnd = max(QEnd, a.fq[f0 + f] + (uint32_t)a.flen[f0 + f]);
+        QStart = min(QStart, a.fq[f0 + f]);
+        TStart = min(TStart, a.ft[f0 + f]);
+        TEnd = min(TEnd, a.ft[f0 + f] + (uint32_t)a.flen[f0 + f]);       // min, as the reference has it (:1694)
+      }
+      if (len >= 3 && QEnd > QStart && (double)((float)(QEnd - QStart) / readLen) > 0.005 && QEnd - QStart >= 200) {
+        bool push = false;
+        if (nCh == 0) push = true;
+        else {                                                           // chains[0].OverlapsOnT(TStart, TEnd, 0.05f)  Chain.h:261
+          int ovp = 0;
+          if (TStart >= c0TS && TStart < c0TE) ovp = (int)(min(TEnd, c0TE) - TStart);
+          else if (TEnd > c0TS && TEnd <= c0TE) ovp = (int)(TEnd - max(TStart, c0TS));
+          else if (TStart < c0TS && TEnd > c0TE) ovp = (int)(c0TE - c0TS);
+          const float denomA = (float)(c0TE - c0TS);
+          push = (ovp / denomA <= 0.05f);
+        }
+        if (push) {
+          const int slot = r * a.numAln + nCh;
+          a.chainStart[slot] = out; a.chainLen[slot] = len; a.chainValue[slot] = firstVal;
+          a.chainBox[4 * slot] = QStart; a.chainBox[4 * slot + 1] = QEnd; a.chainBox[4 * slot + 2] = TStart; a.chainBox[4 * slot + 3] = TEnd;
+          a.clink[out + len - 1] = 0;
+          if (nCh == 0) { c0TS = TStart; c0TE = TEnd; }
+          nCh++;
+          out += len;
+        }
+      } else break;
+    }
+    fv++;
+  }
+  // local fragment index -> (cluster, anchor)
+  for (uint64_t k = f0; k < out; k++) { const uint32_t lf = a.ccl[k]; a.can[k] = a.fai[f0 + lf]; a.ccl[k] = a.fcl[f0 + lf]; }
+  a.nChains[r] = (uint32_t)nCh;
+}
+
+inline size_t sz(size_t n, size_t elem) { return (n * elem + 255) / 256 * 256; }
+
+}  // namespace
+
+extern "C" int lra_sparse_dp_batch(lra_ctx* ctx, int n_reads, const uint64_t* d_cluster_off, const uint64_t* d_c_start, const uint32_t* d_c_count,
+                                   const int32_t* d_c_strand, const uint32_t* d_q, const uint32_t* d_t, const int32_t* d_len,
+                                   const uint64_t* d_read_off, const float* d_rate, const lra_sdp_opts* opts, lra_chain_result* out) {
+  if (!ctx || !out || !opts || n_reads < 0) return LRA_ERR_INVALID;
+  if (opts->NumAln < 1 || opts->NumAln > MAXALN) return lra_set_err(ctx, LRA_ERR_INVALID, "NumAln must be 1..%d", MAXALN);
+  memset(out, 0, sizeof *out);
+  out->n_reads = n_reads; out->num_aln = opts->NumAln;
+  if (n_reads == 0) return LRA_OK;
+  LRA_HIP_CHECK(ctx, hipSetDevice(ctx->device));
+  hipStream_t st = ctx->stream;
+  const size_t n1 = (size_t)n_reads + 1;
+  // InitPWL on the host (SubRountine.h:43-99), host libm as in the reference
+  PwlTab pw;
+  {
+    static const long long stv[25] = {0,    5,    10,   20,   40,   80,    100,   200,   300,   500,   1000,  2000, 3000,
+                                      4000, 5000, 6000, 7000, 8000, 9000, 15000, 20000, 30000, 40000, 50000, 100000};
+    float intercept = opts->gapopen, scalar = opts->gapextend, root = opts->gaproot, vals[25];
+    for (int i = 0; i < 25; i++) { pw.stops[i] = stv[i]; pw.slope[i] = 0; pw.inter[i] = 0; }
+    vals[0] = 0;
+    for (int i = 1; i < 25; i++) { if (i <= 2) intercept = 0; vals[i] = intercept + scalar * std::pow((float)stv[i], 1 / root); }
+    for (int i = 0; i < 24; i++) {
+      float slope = (vals[i + 1] - vals[i]) / (stv[i + 1] - stv[i]);
+      if (stv[i] <= 10) { pw.slope[i] = 0; pw.inter[i] = 0; }
+      else { pw.slope[i] = slope; pw.inter[i] = vals[i] - stv[i] * slope + intercept; }
+    }
+    pw.c1 = opts->gapCeiling1; pw.c2 = opts->gapCeiling2;
+  }
+  std::vector<uint64_t> h_off(n1);
+  LRA_HIP_CHECK(ctx, hipMemcpyAsync(h_off.data(), d_cluster_off, n1 * 8, hipMemcpyDeviceToHost, st));
+  LRA_HIP_CHECK(ctx, hipStreamSynchronize(st));
+  const uint64_t NC = h_off[n_reads];
+  // ---- batch-level buffers: clusters and reads
+  const size_t nslot = (size_t)n_reads * opts->NumAln;
+  size_t needA = sz(NC + 1, 4) * 3 + sz(NC + 2, 8) * 2 + sz(n1, 8) * 2 + sz(n1, 4) * 2 + sz(nslot, 8) + sz(nslot, 4) * 2 + sz(4 * nslot, 4) + 4096;
+  char* wa = (char*)lra_ensure(ctx, 7, needA);
+  if (!wa) return LRA_ERR_NOMEM;
+  auto take = [](char*& w, size_t n, size_t e) { char* p = w; w += sz(n, e); return p; };
+  uint32_t* clusFragCnt = (uint32_t*)take(wa, NC + 1, 4); uint32_t* clusPtCnt = (uint32_t*)take(wa, NC + 1, 4); uint32_t* clusRead = (uint32_t*)take(wa, NC + 1, 4);
+  uint64_t* clusFragOff = (uint64_t*)take(wa, NC + 2, 8); uint64_t* clusPtOff = (uint64_t*)take(wa, NC + 2, 8);
+  uint64_t* fragOff = (uint64_t*)take(wa, n1, 8); uint64_t* ptOff = (uint64_t*)take(wa, n1, 8);
+  uint32_t* status = (uint32_t*)take(wa, n1, 4); uint32_t* nChains = (uint32_t*)take(wa, n1, 4);
+  uint64_t* chainStart = (uint64_t*)take(wa, nslot, 8); uint32_t* chainLen = (uint32_t*)take(wa, nslot, 4); float* chainValue = (float*)take(wa, nslot, 4);
+  uint32_t* chainBox = (uint32_t*)take(wa, 4 * nslot, 4);
+  LRA_HIP_CHECK(ctx, hipMemsetAsync(chainLen, 0, nslot * 4, st));
+  if (NC > 0) {
+    lra_time_begin(ctx, "sdp_points");
+    hipLaunchKernelGGL(k_cluster_counts, dim3((unsigned)((NC + 255) / 256)), dim3(256), 0, st, NC, d_c_count, clusFragCnt, clusPtCnt);
+    lra_time_end(ctx);
+  }
+  { int rc = lra_exclusive_scan<uint32_t>(ctx, (long)NC, clusFragCnt, clusFragOff); if (rc) return rc; }
+  { int rc = lra_exclusive_scan<uint32_t>(ctx, (long)NC, clusPtCnt, clusPtOff); if (rc) return rc; }
+  hipLaunchKernelGGL(k_read_offsets, dim3((unsigned)((n1 + 255) / 256)), dim3(256), 0, st, n_reads, d_cluster_off, clusFragOff, clusPtOff, fragOff, ptOff,
+                     clusRead, status, nChains);
+  std::vector<uint64_t> h_frag(n1), h_pt(n1);
+  LRA_HIP_CHECK(ctx, hipMemcpyAsync(h_frag.data(), fragOff, n1 * 8, hipMemcpyDeviceToHost, st));
+  LRA_HIP_CHECK(ctx, hipMemcpyAsync(h_pt.data(), ptOff, n1 * 8, hipMemcpyDeviceToHost, st));
+  LRA_HIP_CHECK(ctx, hipStreamSynchronize(st));
+  const uint64_t NF = h_frag[n_reads], NP = h_pt[n_reads];
+  out->n_frags = NF; out->n_points = NP;
+  // ---- fragments
+  size_t needF = sz(NF + 1, 4) * 10 + sz(NF + 1, 1) * 3 + sz(NF + 1, 8) + 4096;
+  char* wf = (char*)lra_ensure(ctx, 8, needF);
+  if (!wf) return LRA_ERR_NOMEM;
+  uint32_t* fq = (uint32_t*)take(wf, NF + 1, 4); uint32_t* ft = (uint32_t*)take(wf, NF + 1, 4); int32_t* flen = (int32_t*)take(wf, NF + 1, 4);
+  uint32_t* fcl = (uint32_t*)take(wf, NF + 1, 4); uint32_t* fai = (uint32_t*)take(wf, NF + 1, 4); float* fval = (float*)take(wf, NF + 1, 4);
+  uint32_t* fprevNode = (uint32_t*)take(wf, NF + 1, 4); uint32_t* fprevInd = (uint32_t*)take(wf, NF + 1, 4);
+  uint32_t* ccl = (uint32_t*)take(wf, NF + 1, 4); uint32_t* can = (uint32_t*)take(wf, NF + 1, 4);
+  uint8_t* fflags = (uint8_t*)take(wf, NF + 1, 1); uint8_t* used = (uint8_t*)take(wf, NF + 1, 1); uint8_t* clink = (uint8_t*)take(wf, NF + 1, 1);
+  uint64_t* okey = (uint64_t*)take(wf, NF + 1, 8);
+  // ---- points
+  size_t needP = sz(NP + 1, 8) * 3 + sz(NP + 1, 4) * 11 + sz(NP + 1, 1) * 2 + sz(NF + 1, 4) * 2 + 4096;
+  char* wp = (char*)lra_ensure(ctx, 9, needP);
+  if (!wp) return LRA_ERR_NOMEM;
+  uint64_t* key1 = (uint64_t*)take(wp, NP + 1, 8); uint64_t* key2 = (uint64_t*)take(wp, NP + 1, 8); uint64_t* key3 = (uint64_t*)take(wp, NP + 1, 8);
+  uint32_t* pay1 = (uint32_t*)take(wp, NP + 1, 4); uint32_t* pay2 = (uint32_t*)take(wp, NP + 1, 4); uint32_t* pay3 = (uint32_t*)take(wp, NP + 1, 4);
+  uint32_t* iq = (uint32_t*)take(wp, NP + 1, 4); uint32_t* it = (uint32_t*)take(wp, NP + 1, 4); uint32_t* ifr = (uint32_t*)take(wp, NP + 1, 4);
+  uint32_t* ptRead = (uint32_t*)take(wp, NP + 1, 4);
+  uint32_t* hq = (uint32_t*)take(wp, NP + 1, 4); uint32_t* ht = (uint32_t*)take(wp, NP + 1, 4); uint32_t* hfr = (uint32_t*)take(wp, NP + 1, 4);
+  uint32_t* spare = (uint32_t*)take(wp, NP + 1, 4); (void)spare;
+  uint8_t* ifl = (uint8_t*)take(wp, NP + 1, 1); uint8_t* hfl = (uint8_t*)take(wp, NP + 1, 1);
+  uint32_t* opay = (uint32_t*)take(wp, NF + 1, 4); uint32_t* fragRead = (uint32_t*)take(wp, NF + 1, 4);
+  out->d_n_chains = nChains; out->d_chain_start = chainStart; out->d_chain_len = chainLen; out->d_chain_box = chainBox; out->d_chain_value = chainValue;
+  out->d_chain_cluster = ccl; out->d_chain_anchor = can; out->d_chain_link = clink; out->d_frag_off = fragOff; out->d_frag_val = fval; out->d_status = status;
+  if (NF == 0) { LRA_HIP_CHECK(ctx, hipStreamSynchronize(st)); return LRA_OK; }
+  {
+    PtArgs pa;
+    pa.nc = NC; pa.cluster_off = d_cluster_off; pa.c_start = d_c_start; pa.c_count = d_c_count; pa.c_strand = d_c_strand; pa.q = d_q; pa.t = d_t; pa.len = d_len;
+    pa.clusRead = clusRead; pa.clusFragOff = clusFragOff; pa.clusPtOff = clusPtOff; pa.fragOff = fragOff; pa.ptOff = ptOff; pa.rate_in = d_rate; pa.rate = opts->rate;
+    pa.fq = fq; pa.ft = ft; pa.flen = flen; pa.fcl = fcl; pa.fai = fai; pa.fval = fval; pa.fprevNode = fprevNode; pa.fprevInd = fprevInd; pa.fflags = fflags; pa.used = used;
+    pa.key1 = key1; pa.pay1 = pay1; pa.iq = iq; pa.it = it; pa.ifl = ifl; pa.ifr = ifr; pa.ptRead = ptRead;
+    lra_time_begin(ctx, "sdp_points");
+    hipLaunchKernelGGL(k_points, dim3((unsigned)((NC + 127) / 128)), dim3(128), 0, st, pa);
+    hipLaunchKernelGGL(k_frag_read, dim3(n_reads), dim3(64), 0, st, n_reads, fragOff, fragRead);
+    lra_time_end(ctx);
+  }
+  struct Retag { lra_ctx* c; Retag(lra_ctx* x) : c(x) { c->sort_tag = "sdp_sort"; c->sort_fb_tag = "sdp_sort_fallback"; } ~Retag() { c->sort_tag = "sort"; c->sort_fb_tag = "sort_fallback"; } } retag(ctx);
+  { int rc = lra_sort_minimizers_batch(ctx, n_reads, ptOff, key1, pay1); if (rc) return rc; }       // sort(H1, SortByRowOp)  :2171
+  lra_time_begin(ctx, "sdp_points");
+  hipLaunchKernelGGL(k_gather, dim3((unsigned)((NP + 255) / 256)), dim3(256), 0, st, NP, ptRead, ptOff, pay1, iq, it, ifl, ifr, hq, ht, hfl, hfr, key2, pay2,
+                     key3, pay3);
+  lra_time_end(ctx);
+  { int rc = lra_sort_minimizers_batch(ctx, n_reads, ptOff, key2, pay2); if (rc) return rc; }       // sort(H2, SortByColOp)  :2174
+  { int rc = lra_sort_minimizers_batch(ctx, n_reads, ptOff, key3, pay3); if (rc) return rc; }       // diagonal order per point class
+  LRA_HIP_CHECK(ctx, hipGetLastError());
+  // ---- chunks of reads: decompositions, ProcessPoint, trace
+  const uint64_t chunkPts = 24u << 20;
+  uint64_t totalEntries = 0;
+  for (int r0 = 0; r0 < n_reads;) {
+    int r1 = r0 + 1;
+    while (r1 < n_reads && h_pt[r1 + 1] - h_pt[r0] <= chunkPts) r1++;
+    const int nr = r1 - r0;
+    const uint64_t cp = h_pt[r1] - h_pt[r0];
+    if (cp == 0) { r0 = r1; continue; }
+    const size_t nr1 = (size_t)nr + 1;
+    size_t needS = sz(28 * cp + 64 * (size_t)nr + 64, 4) + sz(nr1, 4) * 3 + sz(nr1 + 1, 8) * 3 + 4096;
+    char* ws = (char*)lra_ensure(ctx, 10, needS);
+    if (!ws) return LRA_ERR_NOMEM;
+    uint32_t* scratch = (uint32_t*)take(ws, 28 * cp + 64 * (size_t)nr + 64, 4);
+    uint32_t* cntE = (uint32_t*)take(ws, nr1, 4); uint32_t* cntN = (uint32_t*)take(ws, nr1, 4); uint32_t* cntD = (uint32_t*)take(ws, nr1, 4);
+    uint64_t* entOff = (uint64_t*)take(ws, nr1 + 1, 8); uint64_t* nodeOff = (uint64_t*)take(ws, nr1 + 1, 8); uint64_t* dOff = (uint64_t*)take(ws, nr1 + 1, 8);
+    uint2* visit = (uint2*)lra_ensure(ctx, 11, cp * 2 * LV * sizeof(uint2) + 256);
+    if (!visit) return LRA_ERR_NOMEM;
+    LRA_HIP_CHECK(ctx, hipMemsetAsync(visit, 0xFF, cp * 2 * LV * sizeof(uint2), st));
+    BuildArgs ba;
+    memset(&ba, 0, sizeof ba);
+    ba.r0 = r0; ba.n = nr; ba.ptOff = ptOff; ba.hq = hq; ba.ht = ht; ba.hfl = hfl; ba.h2 = pay2; ba.key3 = key3; ba.pay3 = pay3; ba.scratch = scratch;
+    ba.cntEntries = cntE; ba.cntNodes = cntN; ba.cntD = cntD; ba.visit = visit; ba.status = status;
+    lra_time_begin(ctx, "sdp_build_count");
+    hipLaunchKernelGGL(sdp_build<false>, dim3(nr), dim3(64), 0, st, ba);
+    lra_time_end(ctx);
+    { int rc = lra_exclusive_scan<uint32_t>(ctx, nr, cntE, entOff); if (rc) return rc; }
+    { int rc = lra_exclusive_scan<uint32_t>(ctx, nr, cntN, nodeOff); if (rc) return rc; }
+    { int rc = lra_exclusive_scan<uint32_t>(ctx, nr, cntD, dOff); if (rc) return rc; }
+    uint64_t tot[3];
+    LRA_HIP_CHECK(ctx, hipMemcpyAsync(&tot[0], entOff + nr, 8, hipMemcpyDeviceToHost, st));
+    LRA_HIP_CHECK(ctx, hipMemcpyAsync(&tot[1], nodeOff + nr, 8, hipMemcpyDeviceToHost, st));
+    LRA_HIP_CHECK(ctx, hipMemcpyAsync(&tot[2], dOff + nr, 8, hipMemcpyDeviceToHost, st));
+    LRA_HIP_CHECK(ctx, hipStreamSynchronize(st));
+    const uint64_t E = tot[0], N = tot[1], D = tot[2];
+    totalEntries += E;
+    const uint64_t nStk = 2 * D + 4 * N + 8, nBlk = 2 * E + 8 * N + 8;
+    size_t needAr = sz(E + 1, 8) + sz(E + 1, 4) * 3 + sz(nStk, 8) + sz(nBlk, 8) + sz(N + 1, sizeof(Node)) + 4096;
+    char* war = (char*)lra_ensure(ctx, 12, needAr);
+    if (!war) return LRA_ERR_NOMEM;
+    int64_t* A_val = (int64_t*)take(war, E + 1, 8); int32_t* A_b = (int32_t*)take(war, E + 1, 4); float* A_v = (float*)take(war, E + 1, 4);
+    uint32_t* A_p = (uint32_t*)take(war, E + 1, 4); int2* stk = (int2*)take(war, nStk, 8); int2* blk = (int2*)take(war, nBlk, 8);
+    Node* nodes = (Node*)take(war, N + 1, sizeof(Node));
+    ba.entOff = entOff; ba.nodeOff = nodeOff; ba.dOff = dOff; ba.A_val = A_val; ba.A_b = A_b; ba.A_v = A_v; ba.A_p = A_p; ba.stk = stk; ba.nodes = nodes;
+    lra_time_begin(ctx, "sdp_build");
+    hipLaunchKernelGGL(sdp_build<true>, dim3(nr), dim3(64), 0, st, ba);
+    lra_time_end(ctx);
+    ProcArgs pa;
+    pa.r0 = r0; pa.n = nr; pa.ptOff = ptOff; pa.fragOff = fragOff; pa.hq = hq; pa.ht = ht; pa.hfl = hfl; pa.hfr = hfr; pa.flen = flen; pa.fval = fval;
+    pa.fprevNode = fprevNode; pa.fprevInd = fprevInd; pa.fflags = fflags; pa.rate_in = d_rate; pa.rate = opts->rate; pa.entOff = entOff; pa.nodeOff = nodeOff;
+    pa.dOff = dOff; pa.A_val = A_val; pa.A_b = A_b; pa.A_v = A_v; pa.A_p = A_p; pa.stk = stk; pa.blk = blk; pa.nodes = nodes; pa.visit = visit; pa.status = status;
+    pa.pwl = pw;
+    lra_time_begin(ctx, "sdp_process");
+    hipLaunchKernelGGL(sdp_process, dim3((nr + 1) / 2), dim3(64), 0, st, pa);
+    lra_time_end(ctx);
+    const uint64_t cf0 = h_frag[r0], cfn = h_frag[r1] - h_frag[r0];
+    if (cfn > 0) {
+      lra_time_begin(ctx, "sdp_trace");
+      hipLaunchKernelGGL(k_valkeys, dim3((unsigned)((cfn + 255) / 256)), dim3(256), 0, st, cf0, cfn, fval, fragRead, fragOff, okey, opay);
+      lra_time_end(ctx);
+      { int rc = lra_sort_minimizers_batch(ctx, nr, fragOff + r0, okey, opay); if (rc) return rc; }   // Fragment_valueOrder::Sort (Fragment_Info.h:88)
+      TraceArgs ta;
+      ta.r0 = r0; ta.n = nr; ta.numAln = opts->NumAln; ta.alnthres = opts->alnthres; ta.fragOff = fragOff; ta.read_off = d_read_off; ta.fq = fq; ta.ft = ft;
+      ta.flen = flen; ta.fcl = fcl; ta.fai = fai; ta.fval = fval; ta.fprevNode = fprevNode; ta.fprevInd = fprevInd; ta.fflags = fflags; ta.opay = opay; ta.used = used;
+      ta.entOff = entOff; ta.nodeOff = nodeOff; ta.A_p = A_p; ta.nodes = nodes; ta.nChains = nChains; ta.chainStart = chainStart; ta.chainLen = chainLen;
+      ta.chainBox = chainBox; ta.chainValue = chainValue; ta.ccl = ccl; ta.can = can; ta.clink = clink; ta.status = status;
+      lra_time_begin(ctx, "sdp_trace");
+      hipLaunchKernelGGL(sdp_trace, dim3((nr + 63) / 64), dim3(64), 0, st, ta);
+      lra_time_end(ctx);
+    }
+    LRA_HIP_CHECK(ctx, hipGetLastError());
+    r0 = r1;
+  }
+  out->n_subproblem_entries = totalEntries;
+  LRA_HIP_CHECK(ctx, hipStreamSynchronize(st));
+  LRA_HIP_CHECK(ctx, hipGetLastError());
+  return LRA_OK;
+}

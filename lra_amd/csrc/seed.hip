@@ -973,10 +973,10 @@ static int launch_sort(lra_ctx* ctx, int n_reads, const uint64_t* mm_off, uint64
   int* flags = (int*)(tscr + (size_t)grid * (cap + 64));
   LRA_HIP_CHECK(ctx, hipMemsetAsync(flags, 0, (size_t)n_reads * 4, st));
   LRA_HIP_CHECK(ctx, hipFuncSetAttribute((const void*)sort_wg_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-  lra_time_begin(ctx, "sort");
+  lra_time_begin(ctx, ctx->sort_tag);
   hipLaunchKernelGGL(sort_wg_kernel, dim3(grid), dim3(SORT_NT), lds, st, n_reads, mm_off, mm_key, mm_pos, tscr, cap, flags);
   lra_time_end(ctx);
-  lra_time_begin(ctx, "sort_fallback");
+  lra_time_begin(ctx, ctx->sort_fb_tag);
   hipLaunchKernelGGL(sort_kernel, dim3(nb), dim3(64), 0, st, n_reads, mm_off, mm_key, mm_pos, (const int*)flags);
   lra_time_end(ctx);
   return LRA_OK;

@@ -48,3 +48,147 @@ def test_oracle_maximization_matches_reference(gold):
         assert ok.mean() > 0.99
         if ok.all():
             assert blk.tolist() == c["block"]
+
+
+# ---------------------------------------------------------------- GPU: HIP SDP#A vs. oracle ---------------------------
+def _random_clusters(rng, n_clusters, per_cluster, span, ties):
+    offs = [0]; strands = []; Q = []; T = []; L = []
+    for c in range(n_clusters):
+        strand = int(rng.random() < 0.4)
+        q = int(rng.integers(0, span)); t = int(rng.integers(0, span)) + (span if strand else 0)
+        m = int(rng.integers(1, per_cluster + 1))
+        for i in range(m):
+            ln = int(rng.choice([1, 2, 3])) if ties else int(rng.choice([17, 17, 20, 30, 60, 150]))
+            Q.append(q); T.append(t); L.append(ln)
+            step = int(rng.integers(0, 3)) if ties else int(rng.integers(0, 200))
+            q += ln + step
+            if strand:
+                t = max(0, t - ln - (int(rng.integers(0, 3)) if ties else int(rng.integers(0, 200))))
+            else:
+                t += ln + (int(rng.integers(0, 3)) if ties else int(rng.integers(0, 200)))
+        strands.append(strand); offs.append(len(Q))
+    return (np.array(offs, np.int32), np.array(strands, np.uint8), np.array(Q, np.uint32), np.array(T, np.uint32), np.array(L, np.int32))
+
+
+def _run_hip(ctx, reads_in, read_lens, opts_kw):
+    """reads_in: list of (cluster_off, strands, q, t, len) per read -> fetched result dict"""
+    import torch
+    from lra_amd import chain
+    dev = ctx.device
+    coff = [0]; cstart = []; ccount = []; cstrand = []; Q = []; T = []; L = []
+    pad = 0
+    for (offs, st, q, t, ln) in reads_in:
+        for c in range(len(st)):
+            a, b = int(offs[c]), int(offs[c + 1])
+            Q.extend([7] * pad); T.extend([9] * pad); L.extend([1] * pad)          # gaps between clusters, as lra_linear_extend_batch leaves them
+            cstart.append(len(Q)); ccount.append(b - a); cstrand.append(int(st[c]))
+            Q.extend(q[a:b].tolist()); T.extend(t[a:b].tolist()); L.extend(ln[a:b].tolist())
+            pad = (pad + 1) % 3
+        coff.append(len(cstart))
+    roff = np.concatenate([[0], np.cumsum(read_lens)]).astype(np.int64)
+    tt = lambda a, dt: torch.tensor(np.asarray(a, dtype=dt), device=dev)
+    d = dict(cluster_off=tt(coff, np.int64), c_start=tt(cstart if cstart else [0], np.int64), c_count=tt(ccount if ccount else [0], np.int32),
+             c_strand=tt(cstrand if cstrand else [0], np.int32), q=tt(Q if Q else [0], np.int64).to(torch.int32),
+             t=tt(T if T else [0], np.int64).to(torch.int32), ln=tt(L if L else [0], np.int32), roff=tt(roff, np.int64))
+    res = chain.sparse_dp_batch(ctx, len(reads_in), d["cluster_off"], d["c_start"], d["c_count"], d["c_strand"], d["q"], d["t"], d["ln"], d["roff"],
+                                chain.sdp_opts(**opts_kw))
+    return res, chain.fetch(ctx, res)
+
+
+def _compare(out, num_aln, reads_in, read_lens, opts_kw):
+    n_ok = 0
+    for r, (offs, st, q, t, ln) in enumerate(reads_in):
+        exp = O.sdp_chain(offs, st, q, t, ln, O.sdp_opts(read_lens[r], **opts_kw))
+        if exp["status"] < 0:
+            assert out["status"][r] != 0, r
+            continue
+        assert out["status"][r] == 0, (r, out["status"][r])
+        f0, f1 = int(out["frag_off"][r]), int(out["frag_off"][r + 1])
+        assert f1 - f0 == len(q)
+        assert np.array_equal(out["frag_val"][f0:f1].view(np.uint32), exp["val"].view(np.uint32)), r
+        assert int(out["n_chains"][r]) == len(exp["chains"]), (r, out["n_chains"][r], len(exp["chains"]))
+        for c, ch in enumerate(exp["chains"]):
+            s = r * num_aln + c
+            a = int(out["chain_start"][s]); m = int(out["chain_len"][s])
+            assert m == len(ch["frags"]), (r, c)
+            cl = np.searchsorted(offs, ch["frags"], side="right") - 1
+            assert np.array_equal(out["chain_cluster"][a:a + m], cl), (r, c)
+            assert np.array_equal(out["chain_anchor"][a:a + m], ch["frags"] - offs[cl]), (r, c)
+            assert np.array_equal(out["chain_link"][a:a + m - 1], ch["link"]), (r, c)
+            assert out["chain_box"][s].tolist() == ch["box"].tolist(), (r, c)
+            assert np.float32(out["chain_value"][s]) == np.float32(ch["value"]), (r, c)
+            n_ok += 1
+    return n_ok
+
+
+@pytest.mark.gpu
+def test_hip_sdp_random_clusters(ctx):
+    rng = np.random.default_rng(77)
+    reads_in = []
+    for k in range(160):
+        if k < 40: reads_in.append(_random_clusters(rng, int(rng.integers(1, 4)), 3, 12, True))        # heavy coordinate ties
+        elif k < 80: reads_in.append(_random_clusters(rng, int(rng.integers(1, 5)), 6, 40, True))
+        elif k < 140: reads_in.append(_random_clusters(rng, int(rng.integers(1, 8)), 12, 3000, False))
+        else: reads_in.append(_random_clusters(rng, int(rng.integers(4, 30)), 40, 30000, False))
+    reads_in.insert(5, (np.array([0], np.int32), np.zeros(0, np.uint8), np.zeros(0, np.uint32), np.zeros(0, np.uint32), np.zeros(0, np.int32)))   # read without clusters
+    reads_in.insert(9, (np.array([0, 1], np.int32), np.array([1], np.uint8), np.array([5], np.uint32), np.array([100], np.uint32), np.array([17], np.int32)))
+    read_lens = [max(300, int(q.max()) + 200) if len(q) else 300 for (_, _, q, _, _) in reads_in]
+    for kw in (dict(), dict(NumAln=3, alnthres=0.3, rate=3.0), dict(gapopen=4.0, gapextend=20.0, gapCeiling1=3000, gapCeiling2=5000, rate=1.0)):
+        res, out = _run_hip(ctx, reads_in, read_lens, kw)
+        n = _compare(out, res.num_aln, reads_in, read_lens, kw)
+        assert n > 40
+
+
+@pytest.mark.gpu
+def test_hip_sdp_on_oracle_pipeline_reads(ctx):
+    """30 kb ONT-like reads through the oracle's a1-a7, then SDP#A on the GPU vs. the oracle"""
+    from lra_amd import synth
+    from sdp_inputs import oracle_ext_clusters
+    genome = synth.make_genome(1_500_000, seed=12, repeat_frac=0.3)
+    ik, ip = synth.build_global_index(genome, 17, 10, 150)
+    reads, truth = synth.simulate_reads(genome, 10, 20000, 6000, 0.10, seed=4)
+    reads_in = [oracle_ext_clusters(O, r.tobytes(), genome, ik, ip) for r in reads]
+    read_lens = [len(r) for r in reads]
+    res, out = _run_hip(ctx, reads_in, read_lens, {})
+    assert _compare(out, res.num_aln, reads_in, read_lens, {}) >= 8
+    # the primary chain lies on the simulated locus
+    for r, (s0, L, strand) in enumerate(truth):
+        if out["n_chains"][r]:
+            box = out["chain_box"][r * res.num_aln]
+            assert box[2] >= s0 - 200 and box[2] <= s0 + L + 200
+
+
+@pytest.mark.gpu
+def test_hip_sdp_chained_after_hip_extend(ctx, oracle):
+    """seed -> clean -> extend -> SDP#A all on the GPU; the oracle's SDP on the GPU's own extended anchors must agree"""
+    from lra_amd import synth, seed, cluster, chain
+    genome = synth.make_genome(600_000, seed=31, repeat_frac=0.4, n_families=3)
+    ik, ip = synth.build_global_index(genome, 17, 10, 100)
+    reads, truth = synth.simulate_reads(genome, 40, 12000, 4000, 0.10, seed=9)
+    reads += [np.frombuffer(b"ACGT" * 5, dtype=np.uint8)]
+    seed.load_reference(ctx, genome, ik, ip)
+    batch = seed.ReadBatch(ctx, [r.tobytes() for r in reads])
+    seed.seed_batch(ctx, batch, 17, 10, 150)
+    po = dict(oracle.CLEAN_PRESETS["ONT"]); po["globalK"] = 17
+    cres = cluster.clean_matches_batch(ctx, cluster.CleanOpts(**po), [0, len(genome)])
+    eres = cluster.linear_extend_batch(ctx, 17, batch)
+    co = cluster.fetch(ctx, cres); eo = cluster.fetch_extend(ctx, eres)
+    res = chain.sparse_dp_batch(ctx, len(reads), cres.d_cluster_off, eres.d_e_start, eres.d_e_count, cres.d_c_strand, eres.d_e_qpos, eres.d_e_tpos,
+                                eres.d_e_len, batch.off, chain.sdp_opts())
+    out = chain.fetch(ctx, res)
+    reads_in = []
+    for r in range(len(reads)):
+        offs = [0]; st = []; Q = []; T = []; L = []
+        for x in range(int(co["cluster_off"][r]), int(co["cluster_off"][r + 1])):
+            a, n = int(eo["e_start"][x]), int(eo["e_count"][x])
+            Q.extend(eo["e_qpos"][a:a + n].tolist()); T.extend(eo["e_tpos"][a:a + n].tolist()); L.extend(eo["e_len"][a:a + n].tolist())
+            st.append(int(co["strand"][x])); offs.append(len(Q))
+        reads_in.append((np.array(offs, np.int32), np.array(st, np.uint8), np.array(Q, np.uint32), np.array(T, np.uint32), np.array(L, np.int32)))
+    read_lens = [len(r) for r in reads]
+    assert _compare(out, res.num_aln, reads_in, read_lens, {}) >= 30
+    hit = 0
+    for r, (s0, L, strand) in enumerate(truth):
+        if out["n_chains"][r]:
+            box = out["chain_box"][r * res.num_aln]
+            hit += int(box[2] >= s0 - 300 and box[2] <= s0 + L + 300)
+    assert hit >= 35
