@@ -50,13 +50,13 @@ __device__ __forceinline__ int wave_incl_scan(int v, int lane) {
 
 struct PwlTab { long long stops[25]; float slope[25], inter[25]; int c1, c2; };
 
-struct Node {            // one full sub-problem (SubProblem.h:15-37), 48 bytes
-  uint32_t dBase;        // entry index of Di[0] within the read's entry arrays; Ei[0] at dBase + nD
+struct Ent { long long val; int b; float v; };   // one Di / Ei slot: diagonal, Db / Eb, Dv / Ev   (16 bytes)
+struct Node {            // one full sub-problem (SubProblem.h:15-37), 32 bytes
+  uint32_t dBase;        // entry index of Di[0] within the read's entries; Ei[0] at dBase + nD
   uint32_t nD, nE;
-  int32_t now, last;
+  int32_t last;
   uint32_t sTop, nBlk;   // sizes of S_1 and Block
-  uint32_t stkOff, blkOff, stkCap, blkCap;
-  uint32_t pad;
+  uint32_t stkOff, blkOff;   // capacities: stack 2 nD + 4 pairs, Block 2 (nD + nE) + 8 pairs
 };
 
 // ---- counting / point generation ------------------------------------------------------------------------------------
@@ -88,7 +88,7 @@ struct PtArgs {
   const uint32_t* clusRead; const uint64_t* clusFragOff; const uint64_t* clusPtOff; const uint64_t* fragOff; const uint64_t* ptOff;
   const float* rate_in; float rate;
   uint32_t* fq; uint32_t* ft; int32_t* flen; uint32_t* fcl; uint32_t* fai; float* fval; uint32_t* fprevNode; uint32_t* fprevInd; uint8_t* fflags;
-  uint8_t* used;
+  uint8_t* used; unsigned long long* fkey; uint32_t* fspos; uint32_t* fSpos2;
   uint64_t* key1; uint32_t* pay1; uint32_t* iq; uint32_t* it; uint8_t* ifl; uint32_t* ifr; uint32_t* ptRead;
 };
 
@@ -111,6 +111,8 @@ __global__ void k_points(PtArgs a) {
     a.fq[g] = q; a.ft[g] = t; a.flen[g] = len; a.fcl[g] = cl; a.fai[g] = i;
     a.fval[g] = len * rate;                                            // Value[ii].val = matchesLengths * rate (:2206)
     a.fprevNode[g] = NONE; a.fprevInd[g] = NONE; a.fflags[g] = 3; a.used[g] = 0;
+    a.fkey[g] = ((unsigned long long)__float_as_uint(len * rate) << 32) | 0xFFFFFFFFull;   // (value, no predecessor)
+    a.fspos[g] = 0; a.fSpos2[2 * g] = NONE; a.fSpos2[2 * g + 1] = NONE;
     const bool edge = (i == 0 || i == n - 1);
     for (int rep = 0; rep < (edge ? 2 : 1); rep++) {
       const int pair = (strand == 0) ? rep : 1 - rep;                  // forward cluster: s1/e1 first; reverse: s2/e2 first
@@ -133,7 +135,7 @@ __global__ void k_points(PtArgs a) {
 __global__ void k_gather(uint64_t np, const uint32_t* __restrict__ ptRead, const uint64_t* __restrict__ ptOff, const uint32_t* __restrict__ pay1,
                          const uint32_t* __restrict__ iq, const uint32_t* __restrict__ it, const uint8_t* __restrict__ ifl,
                          const uint32_t* __restrict__ ifr, uint32_t* hq, uint32_t* ht, uint8_t* hfl, uint32_t* hfr, uint64_t* key2,
-                         uint32_t* pay2, uint64_t* key3, uint32_t* pay3) {
+                         uint32_t* pay2, uint64_t* key3, uint32_t* pay3, const uint64_t* __restrict__ fragOff, uint32_t* fspos, uint32_t* fSpos2) {
   uint64_t p = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (p >= np) return;
   const uint64_t p0 = ptOff[ptRead[p]];
@@ -148,6 +150,11 @@ __global__ void k_gather(uint64_t np, const uint32_t* __restrict__ ptRead, const
   const uint64_t dg = inv ? (uint64_t)((int64_t)t - (int64_t)q + (1LL << 32)) : (uint64_t)t + q;
   key3[p] = (cls << 40) | dg;
   pay3[p] = (uint32_t)(p - p0);
+  if (ind) {                                                            // where the fragment's start points sit in H1
+    const uint64_t g = fragOff[ptRead[p]] + ifr[s];
+    atomicMax(&fspos[g], (uint32_t)(p - p0));
+    fSpos2[2 * g + (inv ? 0 : 1)] = (uint32_t)(p - p0);
+  }
 }
 
 // ---- decompositions ---------------------------------------------------------------------------------------------------
@@ -156,9 +163,9 @@ struct BuildArgs {
   const uint64_t* ptOff;
   const uint32_t* hq; const uint32_t* ht; const uint8_t* hfl; const uint32_t* h2; const uint64_t* key3; const uint32_t* pay3;
   uint32_t* scratch;                         // 28 words per point + 64 per read
-  uint32_t* cntEntries; uint32_t* cntNodes; uint32_t* cntD;   // [n] (count pass out)
+  uint32_t* cntEntries; uint32_t* cntNodes; uint32_t* cntD; uint32_t* cntV;   // [n] (count pass out)
   const uint64_t* entOff; const uint64_t* nodeOff; const uint64_t* dOff;   // [n+1] (emit pass in)
-  int64_t* A_val; int32_t* A_b; float* A_v; uint32_t* A_p; int2* stk; Node* nodes;
+  Ent* ent; uint32_t* A_p; int2* stk; Node* nodes;
   uint2* visit;                              // [(points of the chunk) * 2 * LV]
   uint32_t* status;
 };
@@ -168,7 +175,7 @@ __global__ void __launch_bounds__(64) sdp_build(BuildArgs a) {
   const int rr = blockIdx.x, r = a.r0 + rr, lane = threadIdx.x;
   const uint64_t p0 = a.ptOff[r], pc0 = a.ptOff[a.r0];
   const int P = (int)(a.ptOff[r + 1] - p0);
-  if (P == 0) { if (!EMIT && lane == 0) { a.cntEntries[rr] = 0; a.cntNodes[rr] = 0; a.cntD[rr] = 0; } return; }
+  if (P == 0) { if (!EMIT && lane == 0) { a.cntEntries[rr] = 0; a.cntNodes[rr] = 0; a.cntD[rr] = 0; a.cntV[rr] = 0; } return; }
   const uint32_t* hq = a.hq + p0; const uint32_t* ht = a.ht + p0; const uint32_t* h2 = a.h2 + p0;
   const uint64_t* key3 = a.key3 + p0; const uint32_t* pay3 = a.pay3 + p0;
   uint32_t* S = a.scratch + 28 * (p0 - pc0) + 64 * (uint64_t)rr;
@@ -209,7 +216,7 @@ __global__ void __launch_bounds__(64) sdp_build(BuildArgs a) {
     cOff[0] = 0; cOff[1] = c0; cOff[2] = c0 + c1; cOff[3] = c0 + c1 + c2; cOff[4] = P;
   }
   wave_sync();
-  uint32_t nEntries = 0, nNodesTot = 0, sumD = 0;
+  uint32_t nEntries = 0, nNodesTot = 0, sumD = 0, nVisits = 0;
   uint64_t eOff = 0, nOff = 0, dOff = 0;
   if (EMIT) { eOff = a.entOff[rr]; nOff = a.nodeOff[rr]; dOff = a.dOff[rr]; }
   const uint64_t stkBase = 2 * dOff + 4 * nOff;   // the stack pairs of this read start here (Block pairs: 2 * eOff + 8 * nOff)
@@ -342,8 +349,8 @@ __global__ void __launch_bounds__(64) sdp_build(BuildArgs a) {
                       TB(nxt, F_EB, ci) = eb + c1E; TB(nxt, F_EE, ci) = ee; }
           if (EMIT && full) {
             Node nd;
-            nd.dBase = base; nd.nD = nD; nd.nE = nE; nd.now = 0; nd.last = -1; nd.sTop = 1; nd.nBlk = 0;
-            nd.stkOff = 2 * dpre + 4 * gid; nd.stkCap = 2 * nD + 4; nd.blkOff = 2 * base + 8 * gid; nd.blkCap = 2 * (nD + nE) + 8; nd.pad = (uint32_t)fam;
+            nd.dBase = base; nd.nD = nD; nd.nE = nE; nd.last = -1; nd.sTop = 1; nd.nBlk = 0;
+            nd.stkOff = 2 * dpre + 4 * gid; nd.blkOff = 2 * base + 8 * gid;
             a.nodes[nOff + gid] = nd;
             a.stk[stkBase + nd.stkOff] = make_int2(-1, (int)nE + 1);     // dummy pair (DivideSubByRow1.h:470)
           }
@@ -358,21 +365,24 @@ __global__ void __launch_bounds__(64) sdp_build(BuildArgs a) {
         const uint32_t k = k2 >> 1, side = k2 & 1;
         const bool leaf = TB(cur, F_LE, k) - TB(cur, F_LS, k) == 1;
         ln[j] = leaf ? NONE : (side == 0 ? TM(T_CH0, k) : TM(T_CH1, k));
-        if (EMIT) {
+        {
           const uint32_t gid = TM(T_GID, k);
           const bool isS = j < nS;
           const bool in = leaf || (int)side == (isS ? eSide : dSide);
           if (in && gid != NONE) {
-            uint32_t beg = isS ? TB(cur, F_SB, k) : TB(cur, F_EB, k);
-            if (!leaf && side == 1) beg += isS ? TM(T_C1S, k) : TM(T_C1E, k);
-            const uint32_t head = ph[j + 1] - ph[j];
-            const uint32_t grp = ph[j] - ph[beg] + head - 1;
-            const uint32_t n = isS ? TM(T_NE, k) : TM(T_ND, k);
-            const uint32_t idx = desc ? n - 1 - grp : grp;
-            const uint32_t ent = TM(T_BASE, k) + (isS ? TM(T_ND, k) + idx : idx);
-            const uint32_t pos = lpn[j];
-            if (head) a.A_val[eOff + ent] = back ? (int64_t)ht[pos] + hq[pos] : (int64_t)ht[pos] - hq[pos];
-            a.visit[((p0 - pc0) + pos) * (2 * LV) + fam2 * LV + level] = make_uint2(gid, idx);
+            if (!EMIT) nVisits++;
+            else {
+              uint32_t beg = isS ? TB(cur, F_SB, k) : TB(cur, F_EB, k);
+              if (!leaf && side == 1) beg += isS ? TM(T_C1S, k) : TM(T_C1E, k);
+              const uint32_t head = ph[j + 1] - ph[j];
+              const uint32_t grp = ph[j] - ph[beg] + head - 1;
+              const uint32_t n = isS ? TM(T_NE, k) : TM(T_ND, k);
+              const uint32_t idx = desc ? n - 1 - grp : grp;
+              const uint32_t ent = TM(T_BASE, k) + (isS ? TM(T_ND, k) + idx : idx);
+              const uint32_t pos = lpn[j];
+              if (head) a.ent[eOff + ent].val = back ? (int64_t)ht[pos] + hq[pos] : (int64_t)ht[pos] - hq[pos];
+              a.visit[((p0 - pc0) + pos) * (2 * LV) + fam2 * LV + level] = make_uint2(gid, idx);
+            }
           }
         }
       }
@@ -395,27 +405,28 @@ __global__ void __launch_bounds__(64) sdp_build(BuildArgs a) {
           const uint32_t n = isS ? nE : nD;
           const uint32_t idx = desc ? n - 1 - grp : grp;
           const uint32_t ent = base + (isS ? nD + idx : idx);
-          const int64_t x = a.A_val[eOff + ent];
-          const int64_t* opp = a.A_val + eOff + base + (isS ? 0 : nD);
+          const long long x = a.ent[eOff + ent].val;
+          const Ent* opp = a.ent + eOff + base + (isS ? 0 : nD);
           const uint32_t m = isS ? nD : nE;
           uint32_t lo = 0, cnt = m;
           // D entry: asc  #{Ei < x}   desc #{Ei >= x};   E entry: asc #{Di <= x}   desc #{Di > x}
           while (cnt > 0) {
             const uint32_t step = cnt >> 1, it = lo + step;
-            const int64_t v = opp[it];
+            const long long v = opp[it].val;
             const bool go = isS ? (desc ? v > x : v <= x) : (desc ? v >= x : v < x);
             if (go) { lo = it + 1; cnt -= step + 1; } else cnt = step;
           }
-          a.A_b[eOff + ent] = isS ? (int32_t)lo - 1 : (lo == m ? -1 : (int32_t)lo);
-          a.A_v[eOff + ent] = 0.f; a.A_p[eOff + ent] = 0;
+          a.ent[eOff + ent].b = isS ? (int32_t)lo - 1 : (lo == m ? -1 : (int32_t)lo);
+          a.ent[eOff + ent].v = 0.f; a.A_p[eOff + ent] = 0;
         }
       }
       nNodes = nNext; cur = nxt;
       wave_sync();
     }
   }
+  for (int o = 32; o > 0; o >>= 1) nVisits += __shfl_xor(nVisits, o);
   if (lane == 0) {
-    if (!EMIT) { a.cntEntries[rr] = nEntries; a.cntNodes[rr] = nNodesTot; a.cntD[rr] = sumD; }
+    if (!EMIT) { a.cntEntries[rr] = nEntries; a.cntNodes[rr] = nNodesTot; a.cntD[rr] = sumD; a.cntV[rr] = nVisits; }
     if (overflow) atomicOr(&a.status[r], (uint32_t)LRA_ST_CAPACITY);
   }
 #undef TB
@@ -426,179 +437,250 @@ __global__ void __launch_bounds__(64) sdp_build(BuildArgs a) {
 struct ProcArgs {
   int r0, n;
   const uint64_t* ptOff; const uint64_t* fragOff;
-  const uint32_t* hq; const uint32_t* ht; const uint8_t* hfl; const uint32_t* hfr;
+  const uint8_t* hfl; const uint32_t* hfr;
   const int32_t* flen; float* fval; uint32_t* fprevNode; uint32_t* fprevInd; uint8_t* fflags;
   const float* rate_in; float rate;
   const uint64_t* entOff; const uint64_t* nodeOff; const uint64_t* dOff;
-  int64_t* A_val; int32_t* A_b; float* A_v; uint32_t* A_p; int2* stk; int2* blk; Node* nodes;
+  Ent* ent; uint32_t* A_p; int2* stk; int2* blk; Node* nodes;
   const uint2* visit;
   uint32_t* status;
   PwlTab pwl;
 };
 
-struct Sub {               // one lane's view of a sub-problem
-  const int64_t* Di; const int64_t* Ei; float* Dv; const int32_t* Db; int2* S; int2* B;
-  int nD, nE, sTop, nBlk, sCap, bCap;
-  uint32_t st;
-};
-
-__device__ __forceinline__ float pwl_w(const long long* stops, const float* slope, const float* inter, int c1, int c2, long long i, long long j) {
-  long long x = (j > i ? j - i : i - j) + 1;                            // w(): labs(j - i) + 1   SubRountine.h:123
-  if (x == 1) return 0.f;
-  long long pen;
-  if (x <= 2) pen = 0;                                                  // PWL_w :101 (minX = 2)
-  else {
-    int lo = 0, cnt = 24;                                               // upper_bound(&STOPS[0], &STOPS[24], x)
-    while (cnt > 0) { const int step = cnt >> 1, it = lo + step; if (!(x < stops[it])) { lo = it + 1; cnt -= step + 1; } else cnt = step; }
-    pen = (long long)(slope[lo - 1] * (float)x + inter[lo - 1]);
-    if (pen >= c1 && pen < c2) pen = c1;
-    else if (pen > c2) pen = c2;
-  }
+// w(i, j) = -PWL_w(|j - i| + 1)   (SubRountine.h:101-129).  upper_bound over STOPS[0..24) as a count of constants <= x.
+__device__ __forceinline__ float pwl_w(const float* slope, const float* inter, int c1, int c2, long long i, long long j) {
+  const long long x = (j > i ? j - i : i - j) + 1;
+  if (x <= 2) return x == 1 ? 0.f : -0.f;
+  const int xs = x > 0x7fffffffLL ? 0x7fffffff : (int)x;
+  const int b = 1 + (xs >= 5) + (xs >= 10) + (xs >= 20) + (xs >= 40) + (xs >= 80) + (xs >= 100) + (xs >= 200) + (xs >= 300) + (xs >= 500) + (xs >= 1000) +
+                (xs >= 2000) + (xs >= 3000) + (xs >= 4000) + (xs >= 5000) + (xs >= 6000) + (xs >= 7000) + (xs >= 8000) + (xs >= 9000) + (xs >= 15000) +
+                (xs >= 20000) + (xs >= 30000) + (xs >= 40000) + (xs >= 50000);
+  long long pen = (long long)(slope[b - 1] * (float)x + inter[b - 1]);
+  if (pen >= c1 && pen < c2) pen = c1;
+  else if (pen > c2) pen = c2;
   return -(float)pen;
 }
 
-#define W(i, j) pwl_w(s_stops, s_slope, s_inter, c1, c2, (i), (j))
-#define SPUSH(v) do { if (s.sTop < s.sCap) s.S[s.sTop] = (v); else s.st |= LRA_ST_CAPACITY; s.sTop++; } while (0)
-#define BPUSH(v) do { if (s.nBlk < s.bCap) s.B[s.nBlk] = (v); else s.st |= LRA_ST_CAPACITY; s.nBlk++; } while (0)
-#define STOP() (s.S[min(s.sTop, s.sCap) - 1])
-
-// Maximization (SubRountine.h:270-345), `last` .. `now` of the sub-problem; returns false if a bound was hit
-__device__ bool maximization(Sub& s, int last, int now, const long long* s_stops, const float* s_slope, const float* s_inter, int c1, int c2) {
-  const int m = s.nD, n = s.nE;
-  for (int i = last + 1; i <= now; ++i) {
-    const int db = s.Db[i];
-    if (db == -1) break;
-    if (STOP().y == n + 1) { BPUSH(make_int2(-1, db)); SPUSH(make_int2(i, n)); }
-    while (s.sTop > 1 && db >= STOP().y) { BPUSH(STOP()); s.sTop--; }
-    if (s.st) return false;
-    const int l = STOP().x;
-    if (l < 0) { s.st |= LRA_ST_OOB_SLOT; return false; }
-    const float dvi = s.Dv[i];
-    const long long di = s.Di[i], edb = s.Ei[db];
-    if (dvi + W(di, edb) > s.Dv[l] + W(s.Di[l], edb)) {
-      if (db < STOP().y && s.nBlk > 0 && db > s.B[min(s.nBlk, s.bCap) - 1].y) BPUSH(make_int2(STOP().x, db));
-      int2 cur = STOP(), prev = cur;
-      while (s.sTop > 0) {
-        if (cur.x < 0 || cur.y < 1) { s.st |= LRA_ST_OOB_SLOT; return false; }
-        const long long e = s.Ei[cur.y - 1];
-        if (!(dvi + W(di, e) > s.Dv[cur.x] + W(s.Di[cur.x], e))) break;
-        s.sTop--;
-        prev = cur;
-        if (s.sTop == 0) { s.st |= LRA_ST_OOB_SLOT; return false; }
-        cur = STOP();
-        if (cur.y == n + 1) break;
-      }
-      // FindBoundary(prev.second, cur.second, i, cur.first) :239-263
-      unsigned first = (unsigned)prev.y;
-      if (cur.x != -1) {
-        unsigned count = (unsigned)cur.y - first;
-        const float dvb = s.Dv[cur.x];
-        const long long dib = s.Di[cur.x];
-        while (count > 0) {
-          const unsigned step = count / 2, it = first + step;
-          const long long e = s.Ei[it];
-          if (dvi + W(di, e) > dvb + W(dib, e)) { first = it + 1; count -= step + 1; } else count = step;
-        }
-      } else first = (unsigned)n;
-      SPUSH(make_int2(i, (int)first));
-    }
-    if (s.st) return false;
-  }
-  if (now == m - 1) { while (s.sTop > 0 && STOP().y != n + 1) { BPUSH(STOP()); s.sTop--; } }
-  else { const int dbn = s.Db[now + 1]; while (s.sTop > 0 && dbn >= STOP().y) { BPUSH(STOP()); s.sTop--; } }
-  return s.st == 0 && s.sTop > 0;
+__device__ __forceinline__ int rl_i(int v, int src) { return __builtin_amdgcn_readlane(v, src); }           // src must be wave-uniform
+__device__ __forceinline__ float rl_f(float v, int src) { return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), src)); }
+__device__ __forceinline__ long long rl_ll(long long v, int src) {
+  const unsigned lo = (unsigned)__builtin_amdgcn_readlane((int)(v & 0xffffffffLL), src), hi = (unsigned)__builtin_amdgcn_readlane((int)(v >> 32), src);
+  return (long long)(((unsigned long long)hi << 32) | lo);
+}
+__device__ __forceinline__ long long shfl_ll(long long v, int src) {
+  const int lo = __shfl((int)(v & 0xffffffffLL), src), hi = __shfl((int)(v >> 32), src);
+  return (long long)(((unsigned long long)(unsigned)hi << 32) | (unsigned)lo);
 }
 
-__global__ void __launch_bounds__(64) sdp_process(ProcArgs a) {
-  __shared__ long long s_stops[25];
-  __shared__ float s_slope[25], s_inter[25];
-  const int lane = threadIdx.x, gl = lane & 31, grp = lane >> 5;
-  if (lane < 25) { s_stops[lane] = a.pwl.stops[lane]; s_slope[lane] = a.pwl.slope[lane]; s_inter[lane] = a.pwl.inter[lane]; }
-  __syncthreads();
-  const int c1 = a.pwl.c1, c2 = a.pwl.c2;
-  const int rr = blockIdx.x * 2 + grp;
-  const bool have = rr < a.n;
-  const int r = a.r0 + (have ? rr : 0);
-  const uint64_t p0 = a.ptOff[r], pc0 = a.ptOff[a.r0], f0 = a.fragOff[r];
-  const int P = have ? (int)(a.ptOff[r + 1] - p0) : 0;
-  const int Pmax = max(P, __shfl_xor(P, 32));
-  const float rate = a.rate_in ? a.rate_in[r] : a.rate;
-  const int fam2 = gl >> 4, level = gl & 15;
-  const uint64_t eOff = have ? a.entOff[rr] : 0, nOff = have ? a.nodeOff[rr] : 0, dOffR = have ? a.dOff[rr] : 0;
-  int2* stkR = a.stk + 2 * dOffR + 4 * nOff;
-  int2* blkR = a.blk + 2 * eOff + 8 * nOff;
-  uint32_t bad = 0;
-  for (int i = 0; i < Pmax; i++) {
-    const bool on = i < P && !bad;
-    float ev = -1.f;
-    uint32_t vnode = NONE, vi1 = 0;
-    uint32_t lf = 0;
-    int ind = 0, inv = 0;
-    if (on) {
-      const uint8_t fl = a.hfl[p0 + i];
-      lf = a.hfr[p0 + i];
-      ind = fl & 1; inv = (fl >> 1) & 1;
-      const uint2 v = a.visit[((p0 - pc0) + i) * (2 * LV) + gl];
-      if (v.x != NONE) {
-        Node* nd = a.nodes + nOff + v.x;
-        const uint32_t dB = nd->dBase, nD = nd->nD, nE = nd->nE;
-        if (ind == 0) {                                                  // PassValueToD1/D2 (SparseDP.h:140-310)
-          const float val = a.fval[f0 + lf];
-          float* dv = a.A_v + eOff + dB + v.y;
-          if (*dv < val) { *dv = val; a.A_p[eOff + dB + v.y] = lf; }
-        } else {                                                         // ProcessPoint, start point (:1025-1060)
-          const int i1 = (int)v.y;
-          const int ebv = a.A_b[eOff + dB + nD + i1];
-          if (ebv != -1) {
-            Sub s;
-            s.Di = a.A_val + eOff + dB; s.Ei = s.Di + nD; s.Dv = a.A_v + eOff + dB; s.Db = a.A_b + eOff + dB;
-            s.S = stkR + nd->stkOff; s.B = blkR + nd->blkOff; s.nD = (int)nD; s.nE = (int)nE; s.sTop = (int)nd->sTop; s.nBlk = (int)nd->nBlk;
-            s.sCap = (int)nd->stkCap; s.bCap = (int)nd->blkCap; s.st = 0;
-            const bool ok = maximization(s, nd->last, ebv, s_stops, s_slope, s_inter, c1, c2);
-            nd->now = ebv; nd->last = ebv; nd->sTop = (uint32_t)s.sTop; nd->nBlk = (uint32_t)s.nBlk;
-            if (!ok || s.nBlk == 0) bad |= s.st ? s.st : LRA_ST_OOB_SLOT;
-            else {
-              // FindValueInBlock :224-236
-              int i2;
-              const int2 bb = s.B[s.nBlk - 1], top = s.S[s.sTop - 1];
-              if (i1 >= bb.y && i1 < top.y) i2 = top.x;
-              else {
-                int lo = 0, cnt = s.nBlk;                               // UPPERbound :205-221
-                while (cnt > 0) { const int step = cnt >> 1, it = lo + step; if (i1 >= s.B[it].y) { lo = it + 1; cnt -= step + 1; } else cnt = step; }
-                i2 = lo < s.nBlk ? s.B[lo].x : -1;
-              }
-              if (i2 < 0 || i2 >= (int)nD) bad |= LRA_ST_OOB_SLOT;
-              else {
-                ev = s.Dv[i2] + W(s.Di[i2], s.Ei[i1]) + rate * a.flen[f0 + lf];
-                a.A_v[eOff + dB + nD + i1] = ev;                         // Ev[i1], Ep[i1]
-                a.A_p[eOff + dB + nD + i1] = (uint32_t)i2;
-                vnode = v.x; vi1 = (uint32_t)i1;
-              }
-            }
-          }
-        }
+// The literal binary search  `while (count > 0) { step = count / 2; it = first + step; if (pred(it)) { first = it + 1; count -= step + 1; }
+// else count = step; }`  (FindBoundary :245-254, UPPERbound :209-219), six levels per memory round: lane t = 1..63 evaluates the
+// predicate at the probe the search would make after taking the decisions spelled by t's bits; the wave then walks the 63 answers.
+template <typename Pred>
+__device__ __forceinline__ unsigned coop_search(unsigned first, unsigned count, int lane, Pred pred) {
+  while (count > 0) {
+    unsigned f = first, c = count;
+    bool valid = lane >= 1;
+    if (valid) {
+      const int depth = 31 - __clz(lane);
+      for (int d = depth - 1; d >= 0; --d) {
+        if (c == 0) { valid = false; break; }
+        const unsigned step = c / 2, it = f + step;
+        if ((lane >> d) & 1) { f = it + 1; c -= step + 1; } else c = step;
       }
     }
-    // Value[ii]: the visits are applied in the order R-family deepest level first, then C-family; `val < Ev` keeps the
-    // first visit that reaches the maximum (:1045-1051)
-    bad |= __shfl_xor(bad, 16); bad |= __shfl_xor(bad, 8); bad |= __shfl_xor(bad, 4); bad |= __shfl_xor(bad, 2); bad |= __shfl_xor(bad, 1);
-    if (ind == 1 && i < P) {
-      const int ord = fam2 * 16 + (15 - level);
-      float bv = ev; int bo = vnode != NONE ? ord : 64;
-      for (int o = 16; o > 0; o >>= 1) {
-        const float ov = __shfl_xor(bv, o); const int oo = __shfl_xor(bo, o);
-        if (ov > bv || (ov == bv && oo < bo)) { bv = ov; bo = oo; }
+    const bool p = (valid && c > 0) ? pred(f + c / 2) : false;
+    const unsigned long long m = __ballot(p);
+    unsigned t = 1;
+    while (t < 64 && count > 0) {
+      const unsigned step = count / 2, it = first + step;
+      const unsigned bit = (unsigned)((m >> t) & 1);
+      if (bit) { first = it + 1; count -= step + 1; } else count = step;
+      t = 2 * t + bit;
+    }
+  }
+  return first;
+}
+
+// One wave per read.  The points are walked in H1 order (ProcessPoint :1015-1171); lane (family pair, level) < 32 owns the
+// sub-problem the point touches on that level.  End points (PassValueToD*) are one independent update per lane.  For a start
+// point the lanes whose sub-problem has a usable Eb take turns as owner of a wave-cooperative Maximization (:270-345): the
+// owner's state is broadcast, all lanes run the (sequential) candidate-list loop in lock step (every lane issues the same stack /
+// Block stores, so each sees its own) with the next 64 Di / Dv / Db and
+// Ei[Db] prefetched one per lane, and the two binary searches (FindBoundary, FindValueInBlock's UPPERbound) probe six levels
+// per memory round.  Value[ii] is then the (max value, first in visit order) reduction the ordered `val < Ev` updates compute.
+__global__ void __launch_bounds__(64) sdp_process(ProcArgs a) {
+  __shared__ float s_slope[25], s_inter[25];
+  const int lane = threadIdx.x;
+  if (lane < 25) { s_slope[lane] = a.pwl.slope[lane]; s_inter[lane] = a.pwl.inter[lane]; }
+  __syncthreads();
+  const int c1 = a.pwl.c1, c2 = a.pwl.c2;
+#define W(i, j) pwl_w(s_slope, s_inter, c1, c2, (i), (j))
+  const int rr = blockIdx.x, r = a.r0 + rr;
+  const uint64_t p0 = a.ptOff[r], pc0 = a.ptOff[a.r0], f0 = a.fragOff[r];
+  const int P = (int)(a.ptOff[r + 1] - p0);
+  const float rate = a.rate_in ? a.rate_in[r] : a.rate;
+  const uint64_t eOff = a.entOff[rr], nOff = a.nodeOff[rr], dOffR = a.dOff[rr];
+  Ent* ent = a.ent + eOff;
+  uint32_t* Ap = a.A_p + eOff;
+  Node* nodes = a.nodes + nOff;
+  int2* stkR = a.stk + 2 * dOffR + 4 * nOff;
+  int2* blkR = a.blk + 2 * eOff + 8 * nOff;
+  const int fam2 = (lane >> 4) & 1, level = lane & 15;
+  uint32_t bad = 0;
+  for (int pi = 0; pi < P && !bad; pi++) {
+    const uint8_t fl = a.hfl[p0 + pi];
+    const uint32_t lf = a.hfr[p0 + pi];
+    const int ind = fl & 1, inv = (fl >> 1) & 1;
+    uint2 v = make_uint2(NONE, 0);
+    if (lane < 2 * LV) v = a.visit[((p0 - pc0) + pi) * (2 * LV) + lane];
+    if (ind == 0) {                                                      // PassValueToD1/D2 (SparseDP.h:140-310)
+      if (v.x != NONE) {
+        const float val = a.fval[f0 + lf];
+        const uint32_t e = nodes[v.x].dBase + v.y;
+        if (ent[e].v < val) { ent[e].v = val; Ap[e] = lf; }
       }
-      if (vnode != NONE && bo == ord && !bad) {
-        if (a.fval[f0 + lf] < bv) {
-          a.fval[f0 + lf] = bv; a.fprevNode[f0 + lf] = vnode; a.fprevInd[f0 + lf] = vi1;
-          a.fflags[f0 + lf] = (uint8_t)((fam2 == 0 ? 1 : 0) | (inv ? 2 : 0));     // bit0 prev (row family), bit1 inv
+    } else {                                                             // start point (:1025-1060)
+      // phase 0, every lane for its own sub-problem: descriptor, Eb[i1], stack top, last Block pair, Db[now + 1]
+      Node nd; nd.dBase = 0; nd.nD = 0; nd.nE = 0; nd.last = -1; nd.sTop = 0; nd.nBlk = 0; nd.stkOff = 0; nd.blkOff = 0;
+      int now = -1;
+      long long ei1 = 0;
+      if (v.x != NONE) { nd = nodes[v.x]; const Ent e = ent[nd.dBase + nd.nD + v.y]; now = e.b; ei1 = e.val; }
+      const bool need = now != -1;
+      const int m = (int)nd.nD, n = (int)nd.nE, i1 = (int)v.y;
+      int sTop = (int)nd.sTop, nBlk = (int)nd.nBlk;
+      int2* S = stkR + nd.stkOff; int2* B = blkR + nd.blkOff;
+      const int bCap = 2 * (m + n) + 8;
+      const Ent* D = ent + nd.dBase;
+      int2 top = make_int2(0, 0), lastB = make_int2(0, 0);
+      int dbn = 0;
+      uint32_t st = 0;
+      if (need) { top = S[sTop - 1]; if (nBlk > 0) lastB = B[nBlk - 1]; if (now != m - 1) dbn = D[now + 1].b; }
+      // phase 1, one owner at a time, the whole wave: the insertions  for (i = last + 1; i <= now; ++i)  of Maximization :275-328
+      unsigned long long todo = __ballot(need && now > nd.last);
+      while (todo) {
+        const int owner = __ffsll((long long)todo) - 1;
+        todo &= todo - 1;
+        const Ent* oD = ent + (uint32_t)rl_i((int)nd.dBase, owner);
+        const int on = rl_i(n, owner), om = rl_i(m, owner);
+        const Ent* oE = oD + om;
+        const int olast = rl_i(nd.last, owner), onow = rl_i(now, owner);
+        int oTop = rl_i(sTop, owner), oBlk = rl_i(nBlk, owner);
+        int2* oS = stkR + (uint32_t)rl_i((int)nd.stkOff, owner);
+        int2* oB = blkR + (uint32_t)rl_i((int)nd.blkOff, owner);
+        const int oSCap = 2 * om + 4, oBCap = 2 * (om + on) + 8;
+        int2 otop = make_int2(rl_i(top.x, owner), rl_i(top.y, owner)), olastB = make_int2(rl_i(lastB.x, owner), rl_i(lastB.y, owner));
+        uint32_t ost = 0;
+        bool topD = false; float tDv = 0; long long tDi = 0;
+#define SPUSH(val_) do { const int2 v__ = (val_); if (oTop < oSCap) oS[oTop] = v__; else ost |= LRA_ST_CAPACITY; oTop++; } while (0)
+#define BPUSH(val_) do { const int2 v__ = (val_); if (oBlk < oBCap) oB[oBlk] = v__; else ost |= LRA_ST_CAPACITY; oBlk++; olastB = v__; } while (0)
+        bool stop = false;
+        for (int i0 = olast + 1; i0 <= onow && !stop && !ost; i0 += 64) {
+          const int j = i0 + lane;
+          Ent dj; dj.val = 0; dj.b = -1; dj.v = 0;
+          long long ej = 0;
+          if (j <= onow) { dj = oD[j]; if (dj.b != -1) ej = oE[dj.b].val; }
+          const int nb = min(64, onow - i0 + 1);
+          int t = 0;
+          while (t < nb && !ost) {
+            // iterations that neither stop, pop nor beat the top candidate change nothing: every lane tests its own candidate
+            // against the current top and the wave jumps to the first one that does something
+            if (otop.y != on + 1) {
+              if (otop.x < 0) { ost |= LRA_ST_OOB_SLOT; break; }
+              if (!topD) { const Ent e = oD[otop.x]; tDv = e.v; tDi = e.val; topD = true; }
+              bool evt = false;
+              if (lane >= t && lane < nb)
+                evt = dj.b == -1 || (oTop > 1 && dj.b >= otop.y) || (dj.v + W(dj.val, ej) > tDv + W(tDi, ej));
+              const unsigned long long em = __ballot(evt);
+              if (!em) break;
+              t = __ffsll((long long)em) - 1;
+            }
+            const int i = i0 + t;
+            const int db = rl_i(dj.b, t);
+            if (db == -1) { stop = true; break; }                         // :277
+            const long long di = rl_ll(dj.val, t), edb = rl_ll(ej, t);
+            const float dvi = rl_f(dj.v, t);
+            if (otop.y == on + 1) { BPUSH(make_int2(-1, db)); SPUSH(make_int2(i, on)); otop = make_int2(i, on); tDv = dvi; tDi = di; topD = true; }   // :280-285
+            while (oTop > 1 && db >= otop.y) { BPUSH(otop); oTop--; otop = oS[oTop - 1]; topD = false; }                                         // :286-290
+            if (otop.x < 0) { ost |= LRA_ST_OOB_SLOT; break; }
+            if (!topD) { const Ent e = oD[otop.x]; tDv = e.v; tDi = e.val; topD = true; }
+            if (dvi + W(di, edb) > tDv + W(tDi, edb)) {                   // :292
+              if (db < otop.y && oBlk > 0 && db > olastB.y) BPUSH(make_int2(otop.x, db));
+              int2 cur = otop; float cDv = tDv; long long cDi = tDi; int prevY = cur.y;
+              while (oTop > 0) {                                          // :299-306
+                if (cur.x < 0 || cur.y < 1) { ost |= LRA_ST_OOB_SLOT; break; }
+                const long long e = oE[cur.y - 1].val;
+                if (!(dvi + W(di, e) > cDv + W(cDi, e))) break;
+                oTop--; prevY = cur.y;
+                if (oTop == 0) { ost |= LRA_ST_OOB_SLOT; break; }
+                cur = oS[oTop - 1];
+                if (cur.y == on + 1) break;
+                if (cur.x < 0) { ost |= LRA_ST_OOB_SLOT; break; }
+                const Ent ce = oD[cur.x]; cDv = ce.v; cDi = ce.val;
+              }
+              if (ost) break;
+              unsigned h;                                                 // FindBoundary :239-263
+              if (cur.x != -1) {
+                const float dvb = cDv; const long long dib = cDi;
+                h = coop_search((unsigned)prevY, (unsigned)cur.y - (unsigned)prevY, lane,
+                                [&](unsigned it) { const long long e = oE[it].val; return dvi + W(di, e) > dvb + W(dib, e); });
+              } else h = (unsigned)on;
+              SPUSH(make_int2(i, (int)h)); otop = make_int2(i, (int)h); tDv = dvi; tDi = di; topD = true;
+            }
+            t++;
+          }
+        }
+#undef SPUSH
+#undef BPUSH
+        if (lane == owner) { sTop = oTop; nBlk = oBlk; top = otop; lastB = olastB; st |= ost; }
+      }
+      // phase 2, every lane for its own sub-problem: the flush of Maximization :330-343, FindValueInBlock :224-236, Ev / Ep
+      float ev = -1.f;
+      bool got = false;
+      if (need && !st) {
+        if (now == m - 1) { while (sTop > 1 && top.y != n + 1) { if (nBlk < bCap) B[nBlk] = top; else st |= LRA_ST_CAPACITY; nBlk++; lastB = top; sTop--; top = S[sTop - 1]; } }
+        else { while (sTop > 1 && dbn >= top.y) { if (nBlk < bCap) B[nBlk] = top; else st |= LRA_ST_CAPACITY; nBlk++; lastB = top; sTop--; top = S[sTop - 1]; } }
+        int i2 = -1;
+        if (!st && nBlk > 0) {
+          if (i1 >= lastB.y && i1 < top.y) i2 = top.x;
+          else {
+            int lo = 0, cnt = nBlk;                                       // UPPERbound :205-221
+            while (cnt > 0) { const int step = cnt >> 1, it = lo + step; if (i1 >= B[it].y) { lo = it + 1; cnt -= step + 1; } else cnt = step; }
+            if (lo < nBlk) i2 = B[lo].x;
+          }
+        }
+        if (st || i2 < 0 || i2 >= m) st |= st ? st : LRA_ST_OOB_SLOT;
+        else {
+          const Ent d2 = D[i2];
+          ev = d2.v + W(d2.val, ei1) + rate * a.flen[f0 + lf];            // :1040
+          got = true;
+          ent[nd.dBase + nd.nD + i1].v = ev; Ap[nd.dBase + nd.nD + i1] = (uint32_t)i2;   // Ev[i1], Ep[i1]
+          Node* np = nodes + v.x;
+          np->last = now; np->sTop = (uint32_t)sTop; np->nBlk = (uint32_t)nBlk;
+        }
+      }
+      const uint32_t myI1 = v.y;
+      for (int o = 32; o > 0; o >>= 1) st |= __shfl_xor(st, o);
+      bad |= st;
+      // Value[ii]: visits apply in the order R family deepest level first, then C family; `val < Ev` keeps the first maximum
+      if (!bad) {
+        const int ord = fam2 * 16 + (15 - level);
+        float bv = got ? ev : -1.f; int bo = got ? ord : 64;
+        for (int o = 32; o > 0; o >>= 1) {
+          const float ov = __shfl_xor(bv, o); const int oo = __shfl_xor(bo, o);
+          if (ov > bv || (ov == bv && oo < bo)) { bv = ov; bo = oo; }
+        }
+        if (got && bo == ord) {
+          if (a.fval[f0 + lf] < bv) {
+            a.fval[f0 + lf] = bv; a.fprevNode[f0 + lf] = v.x; a.fprevInd[f0 + lf] = myI1;
+            a.fflags[f0 + lf] = (uint8_t)((fam2 == 0 ? 1 : 0) | (inv ? 2 : 0));   // bit0 prev (row family), bit1 inv
+          }
         }
       }
     }
     wave_sync();
   }
-  if (have && gl == 0 && bad) atomicOr(&a.status[r], bad);
+  if (lane == 0 && bad) atomicOr(&a.status[r], bad);
+#undef W
 }
 
 // ---- value order, TraceBack, DecidePrimaryChains ------------------------------------------------------------------------
@@ -766,7 +848,7 @@ extern "C" int lra_sparse_dp_batch(lra_ctx* ctx, int n_reads, const uint64_t* d_
   const uint64_t NF = h_frag[n_reads], NP = h_pt[n_reads];
   out->n_frags = NF; out->n_points = NP;
   // ---- fragments
-  size_t needF = sz(NF + 1, 4) * 10 + sz(NF + 1, 1) * 3 + sz(NF + 1, 8) + 4096;
+  size_t needF = sz(NF + 1, 4) * 11 + sz(2 * NF + 2, 4) + sz(NF + 1, 1) * 3 + sz(NF + 1, 8) * 2 + 4096;
   char* wf = (char*)lra_ensure(ctx, 8, needF);
   if (!wf) return LRA_ERR_NOMEM;
   uint32_t* fq = (uint32_t*)take(wf, NF + 1, 4); uint32_t* ft = (uint32_t*)take(wf, NF + 1, 4); int32_t* flen = (int32_t*)take(wf, NF + 1, 4);
@@ -774,7 +856,8 @@ extern "C" int lra_sparse_dp_batch(lra_ctx* ctx, int n_reads, const uint64_t* d_
   uint32_t* fprevNode = (uint32_t*)take(wf, NF + 1, 4); uint32_t* fprevInd = (uint32_t*)take(wf, NF + 1, 4);
   uint32_t* ccl = (uint32_t*)take(wf, NF + 1, 4); uint32_t* can = (uint32_t*)take(wf, NF + 1, 4);
   uint8_t* fflags = (uint8_t*)take(wf, NF + 1, 1); uint8_t* used = (uint8_t*)take(wf, NF + 1, 1); uint8_t* clink = (uint8_t*)take(wf, NF + 1, 1);
-  uint64_t* okey = (uint64_t*)take(wf, NF + 1, 8);
+  uint64_t* okey = (uint64_t*)take(wf, NF + 1, 8); unsigned long long* fkey = (unsigned long long*)take(wf, NF + 1, 8);
+  uint32_t* fspos = (uint32_t*)take(wf, NF + 1, 4); uint32_t* fSpos2 = (uint32_t*)take(wf, 2 * NF + 2, 4);
   // ---- points
   size_t needP = sz(NP + 1, 8) * 3 + sz(NP + 1, 4) * 11 + sz(NP + 1, 1) * 2 + sz(NF + 1, 4) * 2 + 4096;
   char* wp = (char*)lra_ensure(ctx, 9, needP);
@@ -795,6 +878,7 @@ extern "C" int lra_sparse_dp_batch(lra_ctx* ctx, int n_reads, const uint64_t* d_
     pa.nc = NC; pa.cluster_off = d_cluster_off; pa.c_start = d_c_start; pa.c_count = d_c_count; pa.c_strand = d_c_strand; pa.q = d_q; pa.t = d_t; pa.len = d_len;
     pa.clusRead = clusRead; pa.clusFragOff = clusFragOff; pa.clusPtOff = clusPtOff; pa.fragOff = fragOff; pa.ptOff = ptOff; pa.rate_in = d_rate; pa.rate = opts->rate;
     pa.fq = fq; pa.ft = ft; pa.flen = flen; pa.fcl = fcl; pa.fai = fai; pa.fval = fval; pa.fprevNode = fprevNode; pa.fprevInd = fprevInd; pa.fflags = fflags; pa.used = used;
+    pa.fkey = fkey; pa.fspos = fspos; pa.fSpos2 = fSpos2;
     pa.key1 = key1; pa.pay1 = pay1; pa.iq = iq; pa.it = it; pa.ifl = ifl; pa.ifr = ifr; pa.ptRead = ptRead;
     lra_time_begin(ctx, "sdp_points");
     hipLaunchKernelGGL(k_points, dim3((unsigned)((NC + 127) / 128)), dim3(128), 0, st, pa);
@@ -805,7 +889,7 @@ extern "C" int lra_sparse_dp_batch(lra_ctx* ctx, int n_reads, const uint64_t* d_
   { int rc = lra_sort_minimizers_batch(ctx, n_reads, ptOff, key1, pay1); if (rc) return rc; }       // sort(H1, SortByRowOp)  :2171
   lra_time_begin(ctx, "sdp_points");
   hipLaunchKernelGGL(k_gather, dim3((unsigned)((NP + 255) / 256)), dim3(256), 0, st, NP, ptRead, ptOff, pay1, iq, it, ifl, ifr, hq, ht, hfl, hfr, key2, pay2,
-                     key3, pay3);
+                     key3, pay3, fragOff, fspos, fSpos2);
   lra_time_end(ctx);
   { int rc = lra_sort_minimizers_batch(ctx, n_reads, ptOff, key2, pay2); if (rc) return rc; }       // sort(H2, SortByColOp)  :2174
   { int rc = lra_sort_minimizers_batch(ctx, n_reads, ptOff, key3, pay3); if (rc) return rc; }       // diagonal order per point class
@@ -820,11 +904,12 @@ extern "C" int lra_sparse_dp_batch(lra_ctx* ctx, int n_reads, const uint64_t* d_
     const uint64_t cp = h_pt[r1] - h_pt[r0];
     if (cp == 0) { r0 = r1; continue; }
     const size_t nr1 = (size_t)nr + 1;
-    size_t needS = sz(28 * cp + 64 * (size_t)nr + 64, 4) + sz(nr1, 4) * 3 + sz(nr1 + 1, 8) * 3 + 4096;
+    size_t needS = sz(28 * cp + 64 * (size_t)nr + 64, 4) + sz(nr1, 4) * 4 + sz(nr1 + 1, 8) * 4 + sz(33 * nr1, 4) + 4096;
     char* ws = (char*)lra_ensure(ctx, 10, needS);
     if (!ws) return LRA_ERR_NOMEM;
     uint32_t* scratch = (uint32_t*)take(ws, 28 * cp + 64 * (size_t)nr + 64, 4);
     uint32_t* cntE = (uint32_t*)take(ws, nr1, 4); uint32_t* cntN = (uint32_t*)take(ws, nr1, 4); uint32_t* cntD = (uint32_t*)take(ws, nr1, 4);
+    uint32_t* cntV = (uint32_t*)take(ws, nr1, 4); uint64_t* visOff = (uint64_t*)take(ws, nr1 + 1, 8); uint32_t* laneOff = (uint32_t*)take(ws, 33 * nr1, 4); (void)laneOff;
     uint64_t* entOff = (uint64_t*)take(ws, nr1 + 1, 8); uint64_t* nodeOff = (uint64_t*)take(ws, nr1 + 1, 8); uint64_t* dOff = (uint64_t*)take(ws, nr1 + 1, 8);
     uint2* visit = (uint2*)lra_ensure(ctx, 11, cp * 2 * LV * sizeof(uint2) + 256);
     if (!visit) return LRA_ERR_NOMEM;
@@ -832,38 +917,39 @@ extern "C" int lra_sparse_dp_batch(lra_ctx* ctx, int n_reads, const uint64_t* d_
     BuildArgs ba;
     memset(&ba, 0, sizeof ba);
     ba.r0 = r0; ba.n = nr; ba.ptOff = ptOff; ba.hq = hq; ba.ht = ht; ba.hfl = hfl; ba.h2 = pay2; ba.key3 = key3; ba.pay3 = pay3; ba.scratch = scratch;
-    ba.cntEntries = cntE; ba.cntNodes = cntN; ba.cntD = cntD; ba.visit = visit; ba.status = status;
+    ba.cntEntries = cntE; ba.cntNodes = cntN; ba.cntD = cntD; ba.cntV = cntV; ba.visit = visit; ba.status = status;
     lra_time_begin(ctx, "sdp_build_count");
     hipLaunchKernelGGL(sdp_build<false>, dim3(nr), dim3(64), 0, st, ba);
     lra_time_end(ctx);
     { int rc = lra_exclusive_scan<uint32_t>(ctx, nr, cntE, entOff); if (rc) return rc; }
     { int rc = lra_exclusive_scan<uint32_t>(ctx, nr, cntN, nodeOff); if (rc) return rc; }
     { int rc = lra_exclusive_scan<uint32_t>(ctx, nr, cntD, dOff); if (rc) return rc; }
-    uint64_t tot[3];
+    { int rc = lra_exclusive_scan<uint32_t>(ctx, nr, cntV, visOff); if (rc) return rc; }
+    uint64_t tot[4];
     LRA_HIP_CHECK(ctx, hipMemcpyAsync(&tot[0], entOff + nr, 8, hipMemcpyDeviceToHost, st));
     LRA_HIP_CHECK(ctx, hipMemcpyAsync(&tot[1], nodeOff + nr, 8, hipMemcpyDeviceToHost, st));
     LRA_HIP_CHECK(ctx, hipMemcpyAsync(&tot[2], dOff + nr, 8, hipMemcpyDeviceToHost, st));
+    LRA_HIP_CHECK(ctx, hipMemcpyAsync(&tot[3], visOff + nr, 8, hipMemcpyDeviceToHost, st));
     LRA_HIP_CHECK(ctx, hipStreamSynchronize(st));
-    const uint64_t E = tot[0], N = tot[1], D = tot[2];
+    const uint64_t E = tot[0], N = tot[1], D = tot[2], V = tot[3];
     totalEntries += E;
     const uint64_t nStk = 2 * D + 4 * N + 8, nBlk = 2 * E + 8 * N + 8;
-    size_t needAr = sz(E + 1, 8) + sz(E + 1, 4) * 3 + sz(nStk, 8) + sz(nBlk, 8) + sz(N + 1, sizeof(Node)) + 4096;
+    size_t needAr = sz(E + 1, sizeof(Ent)) + sz(E + 1, 4) + sz(nStk, 8) + sz(nBlk, 8) + sz(N + 1, sizeof(Node)) + sz(V + 1, 16) + 4096;
     char* war = (char*)lra_ensure(ctx, 12, needAr);
     if (!war) return LRA_ERR_NOMEM;
-    int64_t* A_val = (int64_t*)take(war, E + 1, 8); int32_t* A_b = (int32_t*)take(war, E + 1, 4); float* A_v = (float*)take(war, E + 1, 4);
+    Ent* ent = (Ent*)take(war, E + 1, sizeof(Ent));
     uint32_t* A_p = (uint32_t*)take(war, E + 1, 4); int2* stk = (int2*)take(war, nStk, 8); int2* blk = (int2*)take(war, nBlk, 8);
-    Node* nodes = (Node*)take(war, N + 1, sizeof(Node));
-    ba.entOff = entOff; ba.nodeOff = nodeOff; ba.dOff = dOff; ba.A_val = A_val; ba.A_b = A_b; ba.A_v = A_v; ba.A_p = A_p; ba.stk = stk; ba.nodes = nodes;
+    Node* nodes = (Node*)take(war, N + 1, sizeof(Node)); uint4* queue = (uint4*)take(war, V + 1, 16); (void)queue;
+    ba.entOff = entOff; ba.nodeOff = nodeOff; ba.dOff = dOff; ba.ent = ent; ba.A_p = A_p; ba.stk = stk; ba.nodes = nodes;
     lra_time_begin(ctx, "sdp_build");
     hipLaunchKernelGGL(sdp_build<true>, dim3(nr), dim3(64), 0, st, ba);
     lra_time_end(ctx);
     ProcArgs pa;
-    pa.r0 = r0; pa.n = nr; pa.ptOff = ptOff; pa.fragOff = fragOff; pa.hq = hq; pa.ht = ht; pa.hfl = hfl; pa.hfr = hfr; pa.flen = flen; pa.fval = fval;
+    pa.r0 = r0; pa.n = nr; pa.ptOff = ptOff; pa.fragOff = fragOff; pa.hfl = hfl; pa.hfr = hfr; pa.flen = flen; pa.fval = fval;
     pa.fprevNode = fprevNode; pa.fprevInd = fprevInd; pa.fflags = fflags; pa.rate_in = d_rate; pa.rate = opts->rate; pa.entOff = entOff; pa.nodeOff = nodeOff;
-    pa.dOff = dOff; pa.A_val = A_val; pa.A_b = A_b; pa.A_v = A_v; pa.A_p = A_p; pa.stk = stk; pa.blk = blk; pa.nodes = nodes; pa.visit = visit; pa.status = status;
-    pa.pwl = pw;
+    pa.dOff = dOff; pa.ent = ent; pa.A_p = A_p; pa.stk = stk; pa.blk = blk; pa.nodes = nodes; pa.visit = visit; pa.status = status; pa.pwl = pw;
     lra_time_begin(ctx, "sdp_process");
-    hipLaunchKernelGGL(sdp_process, dim3((nr + 1) / 2), dim3(64), 0, st, pa);
+    hipLaunchKernelGGL(sdp_process, dim3(nr), dim3(64), 0, st, pa);
     lra_time_end(ctx);
     const uint64_t cf0 = h_frag[r0], cfn = h_frag[r1] - h_frag[r0];
     if (cfn > 0) {
