@@ -59,6 +59,40 @@ struct Node {            // one full sub-problem (SubProblem.h:15-37), 32 bytes
   uint32_t stkOff, blkOff;   // capacities: stack 2 nD + 4 pairs, Block 2 (nD + nE) + 8 pairs
 };
 
+// Everything ProcessPoint touches for one read lies in one contiguous block (sections 256-byte aligned): a wave's working set is a
+// couple of megabytes in one place instead of six arrays gigabytes apart (TLB reach).
+struct ReadArena { uint64_t base; uint32_t entOff, apOff, stkOff, blkOff, visOff, pad; };   // byte offsets from base; nodes at 0
+
+__device__ __host__ inline uint32_t al256(uint64_t x) { return (uint32_t)((x + 255) & ~(uint64_t)255); }
+
+__global__ void k_arena_sizes(int n, int r0, const uint64_t* __restrict__ ptOff, const uint32_t* __restrict__ cntE, const uint32_t* __restrict__ cntN,
+                              const uint32_t* __restrict__ cntD, ReadArena* ra, uint64_t* bytes) {
+  int rr = blockIdx.x * blockDim.x + threadIdx.x;
+  if (rr >= n) return;
+  const uint64_t E = cntE[rr], N = cntN[rr], D = cntD[rr], P = ptOff[r0 + rr + 1] - ptOff[r0 + rr];
+  ReadArena a;
+  a.base = 0; a.pad = 0;
+  uint64_t o = al256(N * sizeof(Node));
+  a.entOff = (uint32_t)o; o = al256(o + E * sizeof(Ent));
+  a.apOff = (uint32_t)o; o = al256(o + E * 4);
+  a.stkOff = (uint32_t)o; o = al256(o + (2 * D + 4 * N + 2) * 8);
+  a.blkOff = (uint32_t)o; o = al256(o + (2 * E + 8 * N + 2) * 8);
+  a.visOff = (uint32_t)o; o = al256(o + P * 2 * LV * sizeof(uint2));
+  ra[rr] = a;
+  bytes[rr] = o;
+}
+__global__ void k_arena_bases(int n, const uint64_t* __restrict__ byteOff, ReadArena* ra) {
+  int rr = blockIdx.x * blockDim.x + threadIdx.x;
+  if (rr < n) ra[rr].base = byteOff[rr];
+}
+__global__ void k_visit_clear(const ReadArena* __restrict__ ra, const uint64_t* __restrict__ byteOff, char* arena) {
+  const int rr = blockIdx.x;
+  const uint64_t lo = ra[rr].base + ra[rr].visOff, hi = byteOff[rr + 1];
+  uint4* p = (uint4*)(arena + lo);
+  const uint64_t n = (hi - lo) / 16;
+  for (uint64_t i = threadIdx.x; i < n; i += blockDim.x) p[i] = make_uint4(NONE, NONE, NONE, NONE);
+}
+
 // ---- counting / point generation ------------------------------------------------------------------------------------
 __global__ void k_cluster_counts(uint64_t nc, const uint32_t* __restrict__ c_count, uint32_t* fragCnt, uint32_t* ptCnt) {
   uint64_t c = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -164,14 +198,12 @@ struct BuildArgs {
   const uint32_t* hq; const uint32_t* ht; const uint8_t* hfl; const uint32_t* h2; const uint64_t* key3; const uint32_t* pay3;
   uint32_t* scratch;                         // 28 words per point + 64 per read
   uint32_t* cntEntries; uint32_t* cntNodes; uint32_t* cntD; uint32_t* cntV;   // [n] (count pass out)
-  const uint64_t* entOff; const uint64_t* nodeOff; const uint64_t* dOff;   // [n+1] (emit pass in)
-  Ent* ent; uint32_t* A_p; int2* stk; Node* nodes;
-  uint2* visit;                              // [(points of the chunk) * 2 * LV]
+  const ReadArena* ra; char* arena;          // emit pass: per-read blocks
   uint32_t* status;
 };
 
 template <bool EMIT>
-__global__ void __launch_bounds__(64) sdp_build(BuildArgs a) {
+__global__ void __launch_bounds__(64, 8) sdp_build(BuildArgs a) {
   const int rr = blockIdx.x, r = a.r0 + rr, lane = threadIdx.x;
   const uint64_t p0 = a.ptOff[r], pc0 = a.ptOff[a.r0];
   const int P = (int)(a.ptOff[r + 1] - p0);
@@ -217,9 +249,12 @@ __global__ void __launch_bounds__(64) sdp_build(BuildArgs a) {
   }
   wave_sync();
   uint32_t nEntries = 0, nNodesTot = 0, sumD = 0, nVisits = 0;
-  uint64_t eOff = 0, nOff = 0, dOff = 0;
-  if (EMIT) { eOff = a.entOff[rr]; nOff = a.nodeOff[rr]; dOff = a.dOff[rr]; }
-  const uint64_t stkBase = 2 * dOff + 4 * nOff;   // the stack pairs of this read start here (Block pairs: 2 * eOff + 8 * nOff)
+  Node* nodesR = nullptr; Ent* entR = nullptr; uint32_t* apR = nullptr; int2* stkR = nullptr; uint2* visR = nullptr;
+  if (EMIT) {
+    const ReadArena A = a.ra[rr];
+    char* b = a.arena + A.base;
+    nodesR = (Node*)b; entR = (Ent*)(b + A.entOff); apR = (uint32_t*)(b + A.apOff); stkR = (int2*)(b + A.stkOff); visR = (uint2*)(b + A.visOff);
+  }
   bool overflow = false;
   for (int fam = 0; fam < 4; fam++) {
     // family switches (DivideSubBy{Row1,Col1,Row2,Col2}.h): R1, C1, R2, C2
@@ -351,8 +386,8 @@ __global__ void __launch_bounds__(64) sdp_build(BuildArgs a) {
             Node nd;
             nd.dBase = base; nd.nD = nD; nd.nE = nE; nd.last = -1; nd.sTop = 1; nd.nBlk = 0;
             nd.stkOff = 2 * dpre + 4 * gid; nd.blkOff = 2 * base + 8 * gid;
-            a.nodes[nOff + gid] = nd;
-            a.stk[stkBase + nd.stkOff] = make_int2(-1, (int)nE + 1);     // dummy pair (DivideSubByRow1.h:470)
+            nodesR[gid] = nd;
+            stkR[nd.stkOff] = make_int2(-1, (int)nE + 1);     // dummy pair (DivideSubByRow1.h:470)
           }
         }
         nNodesTot += __shfl(incF, 63); nEntries += __shfl(incEnt, 63); sumD += __shfl(incD, 63); nNext += __shfl(incC, 63);
@@ -380,8 +415,8 @@ __global__ void __launch_bounds__(64) sdp_build(BuildArgs a) {
               const uint32_t idx = desc ? n - 1 - grp : grp;
               const uint32_t ent = TM(T_BASE, k) + (isS ? TM(T_ND, k) + idx : idx);
               const uint32_t pos = lpn[j];
-              if (head) a.ent[eOff + ent].val = back ? (int64_t)ht[pos] + hq[pos] : (int64_t)ht[pos] - hq[pos];
-              a.visit[((p0 - pc0) + pos) * (2 * LV) + fam2 * LV + level] = make_uint2(gid, idx);
+              if (head) entR[ent].val = back ? (int64_t)ht[pos] + hq[pos] : (int64_t)ht[pos] - hq[pos];
+              visR[(uint64_t)pos * (2 * LV) + fam2 * LV + level] = make_uint2(gid, idx);
             }
           }
         }
@@ -405,8 +440,8 @@ __global__ void __launch_bounds__(64) sdp_build(BuildArgs a) {
           const uint32_t n = isS ? nE : nD;
           const uint32_t idx = desc ? n - 1 - grp : grp;
           const uint32_t ent = base + (isS ? nD + idx : idx);
-          const long long x = a.ent[eOff + ent].val;
-          const Ent* opp = a.ent + eOff + base + (isS ? 0 : nD);
+          const long long x = entR[ent].val;
+          const Ent* opp = entR + base + (isS ? 0 : nD);
           const uint32_t m = isS ? nD : nE;
           uint32_t lo = 0, cnt = m;
           // D entry: asc  #{Ei < x}   desc #{Ei >= x};   E entry: asc #{Di <= x}   desc #{Di > x}
@@ -416,8 +451,22 @@ __global__ void __launch_bounds__(64) sdp_build(BuildArgs a) {
             const bool go = isS ? (desc ? v > x : v <= x) : (desc ? v >= x : v < x);
             if (go) { lo = it + 1; cnt -= step + 1; } else cnt = step;
           }
-          a.ent[eOff + ent].b = isS ? (int32_t)lo - 1 : (lo == m ? -1 : (int32_t)lo);
-          a.ent[eOff + ent].v = 0.f; a.A_p[eOff + ent] = 0;
+          entR[ent].b = isS ? (int32_t)lo - 1 : (lo == m ? -1 : (int32_t)lo);
+          float v0 = 0.f;
+          if (isS && lo >= 1 && lo < nD) {
+            // Ev[] is written but never read by the reference (only Ep is); the slot holds Db[Eb + 1], which the flush at the end of
+            // Maximization (:337) needs, so that ProcessPoint gets it with the same load as Eb
+            const long long xd = entR[base + lo].val;                       // Di[Eb + 1]
+            const Ent* ei = entR + base + nD;
+            uint32_t l2 = 0, c2 = nE;
+            while (c2 > 0) {
+              const uint32_t step = c2 >> 1, it = l2 + step;
+              const long long vv = ei[it].val;
+              if (desc ? vv >= xd : vv < xd) { l2 = it + 1; c2 -= step + 1; } else c2 = step;
+            }
+            v0 = __int_as_float(l2 == nE ? -1 : (int)l2);
+          }
+          entR[ent].v = v0; apR[ent] = 0;
         }
       }
       nNodes = nNext; cur = nxt;
@@ -440,9 +489,7 @@ struct ProcArgs {
   const uint8_t* hfl; const uint32_t* hfr;
   const int32_t* flen; float* fval; uint32_t* fprevNode; uint32_t* fprevInd; uint8_t* fflags;
   const float* rate_in; float rate;
-  const uint64_t* entOff; const uint64_t* nodeOff; const uint64_t* dOff;
-  Ent* ent; uint32_t* A_p; int2* stk; int2* blk; Node* nodes;
-  const uint2* visit;
+  const ReadArena* ra; char* arena;
   uint32_t* status;
   PwlTab pwl;
 };
@@ -516,45 +563,61 @@ __global__ void __launch_bounds__(64) sdp_process(ProcArgs a) {
   const int c1 = a.pwl.c1, c2 = a.pwl.c2;
 #define W(i, j) pwl_w(s_slope, s_inter, c1, c2, (i), (j))
   const int rr = blockIdx.x, r = a.r0 + rr;
-  const uint64_t p0 = a.ptOff[r], pc0 = a.ptOff[a.r0], f0 = a.fragOff[r];
+  const uint64_t p0 = a.ptOff[r], f0 = a.fragOff[r];
   const int P = (int)(a.ptOff[r + 1] - p0);
   const float rate = a.rate_in ? a.rate_in[r] : a.rate;
-  const uint64_t eOff = a.entOff[rr], nOff = a.nodeOff[rr], dOffR = a.dOff[rr];
-  Ent* ent = a.ent + eOff;
-  uint32_t* Ap = a.A_p + eOff;
-  Node* nodes = a.nodes + nOff;
-  int2* stkR = a.stk + 2 * dOffR + 4 * nOff;
-  int2* blkR = a.blk + 2 * eOff + 8 * nOff;
+  const ReadArena A = a.ra[rr];
+  char* ab = a.arena + A.base;
+  Node* nodes = (Node*)ab;
+  Ent* ent = (Ent*)(ab + A.entOff);
+  uint32_t* Ap = (uint32_t*)(ab + A.apOff);
+  int2* stkR = (int2*)(ab + A.stkOff);
+  int2* blkR = (int2*)(ab + A.blkOff);
+  const uint2* visR = (const uint2*)(ab + A.visOff);
   const int fam2 = (lane >> 4) & 1, level = lane & 15;
   uint32_t bad = 0;
+  // per-lane cache of the sub-problem this lane touched last (descriptor, stack top, last Block pair): consecutive points mostly
+  // stay in the same sub-problem on the upper levels
+  Node cn; cn.dBase = 0; cn.nD = 0; cn.nE = 0; cn.last = -1; cn.sTop = 0; cn.nBlk = 0; cn.stkOff = 0; cn.blkOff = 0;
+  uint32_t cId = NONE;
+  int2 cTop = make_int2(0, 0), cLastB = make_int2(0, 0);
+  bool cTopOk = false;
+  uint8_t flN = P > 0 ? a.hfl[p0] : 0;
+  uint32_t lfN = P > 0 ? a.hfr[p0] : 0;
+  uint2 vN = make_uint2(NONE, 0);
+  if (P > 0 && lane < 2 * LV) vN = visR[lane];
   for (int pi = 0; pi < P && !bad; pi++) {
-    const uint8_t fl = a.hfl[p0 + pi];
-    const uint32_t lf = a.hfr[p0 + pi];
+    const uint8_t fl = flN;
+    const uint32_t lf = lfN;
+    const uint2 v = vN;
+    if (pi + 1 < P) {                                                    // next point's row, in flight while this one is processed
+      flN = a.hfl[p0 + pi + 1]; lfN = a.hfr[p0 + pi + 1];
+      if (lane < 2 * LV) vN = visR[(uint64_t)(pi + 1) * (2 * LV) + lane];
+    }
     const int ind = fl & 1, inv = (fl >> 1) & 1;
-    uint2 v = make_uint2(NONE, 0);
-    if (lane < 2 * LV) v = a.visit[((p0 - pc0) + pi) * (2 * LV) + lane];
+    if (v.x != NONE && v.x != cId) { cn = nodes[v.x]; cId = v.x; cTopOk = false; }
     if (ind == 0) {                                                      // PassValueToD1/D2 (SparseDP.h:140-310)
       if (v.x != NONE) {
         const float val = a.fval[f0 + lf];
-        const uint32_t e = nodes[v.x].dBase + v.y;
+        const uint32_t e = cn.dBase + v.y;
         if (ent[e].v < val) { ent[e].v = val; Ap[e] = lf; }
       }
     } else {                                                             // start point (:1025-1060)
-      // phase 0, every lane for its own sub-problem: descriptor, Eb[i1], stack top, last Block pair, Db[now + 1]
-      Node nd; nd.dBase = 0; nd.nD = 0; nd.nE = 0; nd.last = -1; nd.sTop = 0; nd.nBlk = 0; nd.stkOff = 0; nd.blkOff = 0;
-      int now = -1;
+      // phase 0, every lane for its own sub-problem: Eb[i1] (+ Db[Eb + 1]), stack top, last Block pair
+      Node nd = cn;
+      if (v.x == NONE) { nd.dBase = 0; nd.nD = 0; nd.nE = 0; nd.last = -1; nd.sTop = 0; nd.nBlk = 0; nd.stkOff = 0; nd.blkOff = 0; }
+      int now = -1, dbn = 0;
       long long ei1 = 0;
-      if (v.x != NONE) { nd = nodes[v.x]; const Ent e = ent[nd.dBase + nd.nD + v.y]; now = e.b; ei1 = e.val; }
+      if (v.x != NONE) { const Ent e = ent[nd.dBase + nd.nD + v.y]; now = e.b; ei1 = e.val; dbn = __float_as_int(e.v); }
       const bool need = now != -1;
       const int m = (int)nd.nD, n = (int)nd.nE, i1 = (int)v.y;
       int sTop = (int)nd.sTop, nBlk = (int)nd.nBlk;
       int2* S = stkR + nd.stkOff; int2* B = blkR + nd.blkOff;
       const int bCap = 2 * (m + n) + 8;
       const Ent* D = ent + nd.dBase;
-      int2 top = make_int2(0, 0), lastB = make_int2(0, 0);
-      int dbn = 0;
+      int2 top = cTop, lastB = cLastB;
       uint32_t st = 0;
-      if (need) { top = S[sTop - 1]; if (nBlk > 0) lastB = B[nBlk - 1]; if (now != m - 1) dbn = D[now + 1].b; }
+      if (need && !cTopOk) { top = S[sTop - 1]; lastB = nBlk > 0 ? B[nBlk - 1] : make_int2(0, 0); }
       // phase 1, one owner at a time, the whole wave: the insertions  for (i = last + 1; i <= now; ++i)  of Maximization :275-328
       unsigned long long todo = __ballot(need && now > nd.last);
       while (todo) {
@@ -643,8 +706,19 @@ __global__ void __launch_bounds__(64) sdp_process(ProcArgs a) {
         if (!st && nBlk > 0) {
           if (i1 >= lastB.y && i1 < top.y) i2 = top.x;
           else {
-            int lo = 0, cnt = nBlk;                                       // UPPERbound :205-221
-            while (cnt > 0) { const int step = cnt >> 1, it = lo + step; if (i1 >= B[it].y) { lo = it + 1; cnt -= step + 1; } else cnt = step; }
+            int lo = 0, cnt = nBlk;                                       // UPPERbound :205-221, two levels per memory round
+            while (cnt > 0) {
+              const int step = cnt >> 1, it = lo + step;
+              const int cntT = cnt - step - 1, itT = it + 1 + (cntT >> 1), itF = lo + (step >> 1);
+              const int yM = B[it].y, yT = cntT > 0 ? B[itT].y : 0, yF = step > 0 ? B[itF].y : 0;
+              if (i1 >= yM) {
+                lo = it + 1; cnt = cntT;
+                if (cnt > 0) { const int s2 = cnt >> 1; if (i1 >= yT) { lo = itT + 1; cnt -= s2 + 1; } else cnt = s2; }
+              } else {
+                cnt = step;
+                if (cnt > 0) { const int s2 = cnt >> 1; if (i1 >= yF) { lo = itF + 1; cnt -= s2 + 1; } else cnt = s2; }
+              }
+            }
             if (lo < nBlk) i2 = B[lo].x;
           }
         }
@@ -653,9 +727,10 @@ __global__ void __launch_bounds__(64) sdp_process(ProcArgs a) {
           const Ent d2 = D[i2];
           ev = d2.v + W(d2.val, ei1) + rate * a.flen[f0 + lf];            // :1040
           got = true;
-          ent[nd.dBase + nd.nD + i1].v = ev; Ap[nd.dBase + nd.nD + i1] = (uint32_t)i2;   // Ev[i1], Ep[i1]
+          Ap[nd.dBase + nd.nD + i1] = (uint32_t)i2;                       // Ep[i1] (Ev[i1] is never read again)
           Node* np = nodes + v.x;
           np->last = now; np->sTop = (uint32_t)sTop; np->nBlk = (uint32_t)nBlk;
+          cn.last = now; cn.sTop = (uint32_t)sTop; cn.nBlk = (uint32_t)nBlk; cTop = top; cLastB = lastB; cTopOk = true;
         }
       }
       const uint32_t myI1 = v.y;
@@ -704,7 +779,7 @@ struct TraceArgs {
   const uint32_t* fq; const uint32_t* ft; const int32_t* flen; const uint32_t* fcl; const uint32_t* fai;
   const float* fval; const uint32_t* fprevNode; const uint32_t* fprevInd; const uint8_t* fflags; const uint32_t* opay;
   uint8_t* used;
-  const uint64_t* entOff; const uint64_t* nodeOff; const uint32_t* A_p; const Node* nodes;
+  const ReadArena* ra; const char* arena;
   uint32_t* nChains; uint64_t* chainStart; uint32_t* chainLen; uint32_t* chainBox; float* chainValue;
   uint32_t* ccl; uint32_t* can; uint8_t* clink;
   const uint32_t* status;
@@ -718,7 +793,9 @@ __global__ void __launch_bounds__(64) sdp_trace(TraceArgs a) {
   const int total = (int)(a.fragOff[r + 1] - f0);
   a.nChains[r] = 0;
   if (total == 0 || a.status[r]) return;
-  const uint64_t eOff = a.entOff[rr], nOff = a.nodeOff[rr];
+  const ReadArena A = a.ra[rr];
+  const Node* nodesR = (const Node*)(a.arena + A.base);
+  const uint32_t* apR = (const uint32_t*)(a.arena + A.base + A.apOff);
   const int readLen = (int)(a.read_off[r + 1] - a.read_off[r]);
   const float thres = a.alnthres * a.fval[f0 + a.opay[f0]];
   int nCh = 0, fv = 0;
@@ -734,9 +811,9 @@ __global__ void __launch_bounds__(64) sdp_trace(TraceArgs a) {
       a.ccl[out] = i; len = 1; a.used[f0 + i] = 1;
       uint32_t pn = a.fprevNode[f0 + i], pi = a.fprevInd[f0 + i];
       while (pn != NONE && pi != NONE) {
-        const Node nd = a.nodes[nOff + pn];
-        const uint32_t ind = a.A_p[eOff + nd.dBase + nd.nD + pi];       // Ep[prev_ind]
-        const uint32_t nx = a.A_p[eOff + nd.dBase + ind];               // Dp[ind]
+        const Node nd = nodesR[pn];
+        const uint32_t ind = apR[nd.dBase + nd.nD + pi];                // Ep[prev_ind]
+        const uint32_t nx = apR[nd.dBase + ind];                        // Dp[ind]
         if (a.used[f0 + nx] == 0) { a.clink[out + len - 1] = (a.fflags[f0 + i] & 2) ? 0 : 1; i = nx; }
         else { abandoned = true; break; }
         pn = a.fprevNode[f0 + i]; pi = a.fprevInd[f0 + i];
@@ -904,50 +981,41 @@ extern "C" int lra_sparse_dp_batch(lra_ctx* ctx, int n_reads, const uint64_t* d_
     const uint64_t cp = h_pt[r1] - h_pt[r0];
     if (cp == 0) { r0 = r1; continue; }
     const size_t nr1 = (size_t)nr + 1;
-    size_t needS = sz(28 * cp + 64 * (size_t)nr + 64, 4) + sz(nr1, 4) * 4 + sz(nr1 + 1, 8) * 4 + sz(33 * nr1, 4) + 4096;
+    size_t needS = sz(28 * cp + 64 * (size_t)nr + 64, 4) + sz(nr1, 4) * 4 + sz(nr1 + 1, 8) * 3 + sz(nr1, sizeof(ReadArena)) + 4096;
     char* ws = (char*)lra_ensure(ctx, 10, needS);
     if (!ws) return LRA_ERR_NOMEM;
     uint32_t* scratch = (uint32_t*)take(ws, 28 * cp + 64 * (size_t)nr + 64, 4);
     uint32_t* cntE = (uint32_t*)take(ws, nr1, 4); uint32_t* cntN = (uint32_t*)take(ws, nr1, 4); uint32_t* cntD = (uint32_t*)take(ws, nr1, 4);
-    uint32_t* cntV = (uint32_t*)take(ws, nr1, 4); uint64_t* visOff = (uint64_t*)take(ws, nr1 + 1, 8); uint32_t* laneOff = (uint32_t*)take(ws, 33 * nr1, 4); (void)laneOff;
-    uint64_t* entOff = (uint64_t*)take(ws, nr1 + 1, 8); uint64_t* nodeOff = (uint64_t*)take(ws, nr1 + 1, 8); uint64_t* dOff = (uint64_t*)take(ws, nr1 + 1, 8);
-    uint2* visit = (uint2*)lra_ensure(ctx, 11, cp * 2 * LV * sizeof(uint2) + 256);
-    if (!visit) return LRA_ERR_NOMEM;
-    LRA_HIP_CHECK(ctx, hipMemsetAsync(visit, 0xFF, cp * 2 * LV * sizeof(uint2), st));
+    uint32_t* cntV = (uint32_t*)take(ws, nr1, 4);
+    uint64_t* entOff = (uint64_t*)take(ws, nr1 + 1, 8); uint64_t* bytes = (uint64_t*)take(ws, nr1 + 1, 8); uint64_t* byteOff = (uint64_t*)take(ws, nr1 + 1, 8);
+    ReadArena* ra = (ReadArena*)take(ws, nr1, sizeof(ReadArena));
     BuildArgs ba;
     memset(&ba, 0, sizeof ba);
     ba.r0 = r0; ba.n = nr; ba.ptOff = ptOff; ba.hq = hq; ba.ht = ht; ba.hfl = hfl; ba.h2 = pay2; ba.key3 = key3; ba.pay3 = pay3; ba.scratch = scratch;
-    ba.cntEntries = cntE; ba.cntNodes = cntN; ba.cntD = cntD; ba.cntV = cntV; ba.visit = visit; ba.status = status;
+    ba.cntEntries = cntE; ba.cntNodes = cntN; ba.cntD = cntD; ba.cntV = cntV; ba.status = status;
     lra_time_begin(ctx, "sdp_build_count");
     hipLaunchKernelGGL(sdp_build<false>, dim3(nr), dim3(64), 0, st, ba);
+    hipLaunchKernelGGL(k_arena_sizes, dim3((nr + 255) / 256), dim3(256), 0, st, nr, r0, ptOff, cntE, cntN, cntD, ra, bytes);
     lra_time_end(ctx);
     { int rc = lra_exclusive_scan<uint32_t>(ctx, nr, cntE, entOff); if (rc) return rc; }
-    { int rc = lra_exclusive_scan<uint32_t>(ctx, nr, cntN, nodeOff); if (rc) return rc; }
-    { int rc = lra_exclusive_scan<uint32_t>(ctx, nr, cntD, dOff); if (rc) return rc; }
-    { int rc = lra_exclusive_scan<uint32_t>(ctx, nr, cntV, visOff); if (rc) return rc; }
-    uint64_t tot[4];
+    { int rc = lra_exclusive_scan<uint64_t>(ctx, nr, bytes, byteOff); if (rc) return rc; }
+    uint64_t tot[2];
     LRA_HIP_CHECK(ctx, hipMemcpyAsync(&tot[0], entOff + nr, 8, hipMemcpyDeviceToHost, st));
-    LRA_HIP_CHECK(ctx, hipMemcpyAsync(&tot[1], nodeOff + nr, 8, hipMemcpyDeviceToHost, st));
-    LRA_HIP_CHECK(ctx, hipMemcpyAsync(&tot[2], dOff + nr, 8, hipMemcpyDeviceToHost, st));
-    LRA_HIP_CHECK(ctx, hipMemcpyAsync(&tot[3], visOff + nr, 8, hipMemcpyDeviceToHost, st));
+    LRA_HIP_CHECK(ctx, hipMemcpyAsync(&tot[1], byteOff + nr, 8, hipMemcpyDeviceToHost, st));
     LRA_HIP_CHECK(ctx, hipStreamSynchronize(st));
-    const uint64_t E = tot[0], N = tot[1], D = tot[2], V = tot[3];
-    totalEntries += E;
-    const uint64_t nStk = 2 * D + 4 * N + 8, nBlk = 2 * E + 8 * N + 8;
-    size_t needAr = sz(E + 1, sizeof(Ent)) + sz(E + 1, 4) + sz(nStk, 8) + sz(nBlk, 8) + sz(N + 1, sizeof(Node)) + sz(V + 1, 16) + 4096;
-    char* war = (char*)lra_ensure(ctx, 12, needAr);
-    if (!war) return LRA_ERR_NOMEM;
-    Ent* ent = (Ent*)take(war, E + 1, sizeof(Ent));
-    uint32_t* A_p = (uint32_t*)take(war, E + 1, 4); int2* stk = (int2*)take(war, nStk, 8); int2* blk = (int2*)take(war, nBlk, 8);
-    Node* nodes = (Node*)take(war, N + 1, sizeof(Node)); uint4* queue = (uint4*)take(war, V + 1, 16); (void)queue;
-    ba.entOff = entOff; ba.nodeOff = nodeOff; ba.dOff = dOff; ba.ent = ent; ba.A_p = A_p; ba.stk = stk; ba.nodes = nodes;
+    totalEntries += tot[0];
+    char* arena = (char*)lra_ensure(ctx, 12, tot[1] + 4096);
+    if (!arena) return LRA_ERR_NOMEM;
+    hipLaunchKernelGGL(k_arena_bases, dim3((nr + 255) / 256), dim3(256), 0, st, nr, byteOff, ra);
     lra_time_begin(ctx, "sdp_build");
+    hipLaunchKernelGGL(k_visit_clear, dim3(nr), dim3(256), 0, st, ra, byteOff, arena);
+    ba.ra = ra; ba.arena = arena;
     hipLaunchKernelGGL(sdp_build<true>, dim3(nr), dim3(64), 0, st, ba);
     lra_time_end(ctx);
     ProcArgs pa;
     pa.r0 = r0; pa.n = nr; pa.ptOff = ptOff; pa.fragOff = fragOff; pa.hfl = hfl; pa.hfr = hfr; pa.flen = flen; pa.fval = fval;
-    pa.fprevNode = fprevNode; pa.fprevInd = fprevInd; pa.fflags = fflags; pa.rate_in = d_rate; pa.rate = opts->rate; pa.entOff = entOff; pa.nodeOff = nodeOff;
-    pa.dOff = dOff; pa.ent = ent; pa.A_p = A_p; pa.stk = stk; pa.blk = blk; pa.nodes = nodes; pa.visit = visit; pa.status = status; pa.pwl = pw;
+    pa.fprevNode = fprevNode; pa.fprevInd = fprevInd; pa.fflags = fflags; pa.rate_in = d_rate; pa.rate = opts->rate; pa.ra = ra; pa.arena = arena;
+    pa.status = status; pa.pwl = pw;
     lra_time_begin(ctx, "sdp_process");
     hipLaunchKernelGGL(sdp_process, dim3(nr), dim3(64), 0, st, pa);
     lra_time_end(ctx);
@@ -960,7 +1028,7 @@ extern "C" int lra_sparse_dp_batch(lra_ctx* ctx, int n_reads, const uint64_t* d_
       TraceArgs ta;
       ta.r0 = r0; ta.n = nr; ta.numAln = opts->NumAln; ta.alnthres = opts->alnthres; ta.fragOff = fragOff; ta.read_off = d_read_off; ta.fq = fq; ta.ft = ft;
       ta.flen = flen; ta.fcl = fcl; ta.fai = fai; ta.fval = fval; ta.fprevNode = fprevNode; ta.fprevInd = fprevInd; ta.fflags = fflags; ta.opay = opay; ta.used = used;
-      ta.entOff = entOff; ta.nodeOff = nodeOff; ta.A_p = A_p; ta.nodes = nodes; ta.nChains = nChains; ta.chainStart = chainStart; ta.chainLen = chainLen;
+      ta.ra = ra; ta.arena = arena; ta.nChains = nChains; ta.chainStart = chainStart; ta.chainLen = chainLen;
       ta.chainBox = chainBox; ta.chainValue = chainValue; ta.ccl = ccl; ta.can = can; ta.clink = clink; ta.status = status;
       lra_time_begin(ctx, "sdp_trace");
       hipLaunchKernelGGL(sdp_trace, dim3((nr + 63) / 64), dim3(64), 0, st, ta);
