@@ -77,12 +77,16 @@ def cpu_baseline(wl, args, budget_s=20.0, max_reads=768):
         sk, sp = O.sort_minimizers(keys, pos)
         qi, ti = O.compare_lists(sk, sp, wl["idx_key"], wl["idx_pos"], args.max_freq)
         st = O.separate_strand(rbytes, g, args.k, sp[qi], wl["idx_pos"][ti])
+        offs = [0]; cst = []; Q = []; T = []; Ln = []
         for strand in (0, 1):
             sel = st == strand
             oq, ot, cl = O.clean_matches(sp[qi][sel], wl["idx_pos"][ti][sel], sk[qi][sel], strand, oopts, [0, len(g) - 64])
             for ci in range(len(cl["start"])):
                 a, b = int(cl["start"][ci]), int(cl["end"][ci])
-                O.linear_extend(oq[a:b], ot[a:b], strand, args.k, rbytes, g)
+                eq, et, el, _ = O.linear_extend(oq[a:b], ot[a:b], strand, args.k, rbytes, g)
+                Q.append(eq); T.append(et); Ln.append(el); cst.append(strand); offs.append(offs[-1] + len(eq))
+        if cst:
+            O.sdp_chain(offs, cst, np.concatenate(Q), np.concatenate(T), np.concatenate(Ln), O.sdp_opts(len(rbytes)))
         while gptr < len(gsel) and gp["rid"][gsel[gptr]] == r:
             i = gsel[gptr]
             qo = int(gp["q_off"][i] - off[r]); to = int(gp["t_off"][i])
@@ -96,7 +100,7 @@ def cpu_baseline(wl, args, budget_s=20.0, max_reads=768):
             break
     dt = time.time() - t0
     return {"value": bases / dt / 1e9, "unit": "Gbp/s", "cores": 1, "kind": "port",
-            "sample": "first %d reads (%d bp) of the same batch through the oracle's a1-a4, a12, a14 in %.1f s, 1 thread "
+            "sample": "first %d reads (%d bp) of the same batch through the oracle's a1-a5, a7, a8, a12, a14, a16 in %.1f s, 1 thread "
                       "(python ctypes call overhead included)" % (n, bases, dt)}
 
 
@@ -241,9 +245,10 @@ def main():
         dom = max(ktimes, key=lambda k: ktimes[k][0])
         dom_ms, dom_n = ktimes[dom]
         avg_ms = dom_ms / max(dom_n, 1)
-        # algorithmic bytes per launch of the dominant kernel (DESIGN.md "kernels" gives the per-unit figures)
+        launches_per_step = max(dom_n, 1) / args.steps
+        # algorithmic bytes PER STEP of the dominant kernel, all its launches together (DESIGN.md section 3 gives the per-unit figures)
         L = total_bases
-        alg = {
+        alg_step = {
             "ir_fill": 1 * stats["n_cells"] + 16 * stats["n_rows"] + 1 * stats["n_rows"],        # 1 B arrow/cell + row windows + both sequences
             "ir_band": 16 * stats["n_rows"] + 12 * stats["n_blocks"],
             "ir_trace": 1 * stats["n_rows"] + 16 * stats["n_rows"] + 12 * stats["n_blocks"],   # ~1 arrow + 1 row record per row walked
@@ -252,19 +257,22 @@ def main():
             "compare": stats["n_mm"] * (8 + 8 + 64) + 8 * stats["n_match"],
             "sketch_count": L, "sketch_emit": L + 12 * stats["n_mm"],
             "strand": stats["n_match"] * (8 + 8 + 2 * args.k),
-            "local_compare": 4 * stats.get("n_local_task_words", 0) // 2 + 8 * stats.get("n_local_pairs", 0) // 2,   # per launch (count / emit, two strands)
-            "local_sort_filter": 2 * 4 * stats.get("n_local_tuples", 0) // 2,
-            "local_sketch": 2 * L // 2 + 4 * stats.get("n_local_tuples", 0) // 2,
+            "local_compare": 2 * 4 * stats.get("n_local_task_words", 0) + 8 * stats.get("n_local_pairs", 0),   # count + emit passes, both strands
+            "local_sort_filter": 2 * 4 * stats.get("n_local_tuples", 0),
+            "local_sketch": 2 * 2 * L + 4 * stats.get("n_local_tuples", 0),
             "stats": 2 * L + 12 * stats["n_blocks"] + 4 * stats.get("n_cigar_runs", 0),
             "clean": 16 * stats["n_match"] * 3,
             "aog_lds_small": n_gap_bytes + 12 * n_gaps,
             "aog_lds_tiny": n_gap_bytes + 12 * n_gaps,
             "ir_segment": 12 * stats["n_blocks"],
-            # a8: 44 B per sub-problem entry (Di/Ei 8, Db/Eb 4, value 4, back pointer 4, stack 8, Block 16) + 16 B per (point, level) visit record
-            "sdp_process": 44 * stats.get("n_sdp_entries", 0) + 16 * stats.get("n_sdp_entries", 0) + 13 * stats.get("n_sdp_points", 0),
-            "sdp_build": 28 * stats.get("n_sdp_entries", 0) + 16 * stats.get("n_sdp_entries", 0) + 13 * stats.get("n_sdp_points", 0),
-            "sdp_sort": 3 * 2 * 12 * stats.get("n_sdp_points", 0) // 4,
+            # a8: 44 B per sub-problem entry (Di/Ei + Db/Eb + value 16, back pointer 4, stack 8, Block 16) + the 256 B visit row and 13 B
+            # of coordinates per point
+            "sdp_process": 44 * stats.get("n_sdp_entries", 0) + 269 * stats.get("n_sdp_points", 0),
+            "sdp_build": 20 * stats.get("n_sdp_entries", 0) + 269 * stats.get("n_sdp_points", 0),
+            "sdp_build_count": 13 * stats.get("n_sdp_points", 0),
+            "sdp_sort": 4 * 2 * 12 * stats.get("n_sdp_points", 0),
         }.get(dom, 0)
+        alg = alg_step / launches_per_step
         achieved = alg / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
         out = {
             "metric": "aligned Gbp/s (hot-path stages a1-a5, a7, a8 SDP#A, a10 primitives, a12, a14, a16), 30 kb ONT-like reads", "value": gbps, "unit": "Gbp/s",
