@@ -6,12 +6,13 @@ One "step" = one pass of the GPU-resident hot-path stages over one batch of read
   a5     CleanMatches      (diagonal sort, CleanOffDiagonal, clusters) on those matches
   a7     LinearExtend + DecideCoordinates on those clusters
   a8     SparseDP (SDP#A): the primary chain(s) of every read over those anchors
+  a9     RemoveSpuriousJump, SPLITChain, RemoveSpuriousSplitChain on those chains
   a10    tier-2 primitives: CreateRC, LocalIndex::IndexSeq of both strands, and CompareLists<LocalTuple> of every read
          window against the two genome windows at its true locus
   a12    AffineOneGapAlign on the between-anchor gaps of every read
   a14    IndelRefineAlignment over every read's block list
   a16    CalculateStatistics (CIGAR runs, NM/NX/ND/NI/TD/TI counters, NV) on the refined blocks
-The stages between a8 and a12 (a9-a11, a13: chain filters, tier-2 lookup glue, local refinement glue) are
+The stages between a9 and a12 (a10 lookup glue, a11, a13: tier-2 refinement of the split chains, local refinement glue) are
 NOT built yet, so the a12/a14 inputs are derived from the simulator's true alignment (anchors =
 true gapless blocks >= 12 bp; the gaps between them go to a12; a perturbed block list goes to
 a14).  `config.stages` says so; the number is the throughput of the stages listed, not of a
@@ -183,6 +184,8 @@ def main():
         # a8: SDP#A over the extended anchors of every read (Map_lowacc.h:185-188)
         chres = chain.sparse_dp_batch(ctx, nR, cres.d_cluster_off, eres.d_e_start, eres.d_e_count, cres.d_c_strand, eres.d_e_qpos, eres.d_e_tpos,
                                       eres.d_e_len, rbatch.off, sdp_opts)
+        # a9: RemoveSpuriousJump + SPLITChain + RemoveSpuriousSplitChain on every chain (Map_lowacc.h:189-256)
+        spres = chain.split_chains_batch(ctx, chres, [0, int(wl["genome"].numel())])
         rc = seed.create_rc(ctx, rbatch)
         li_f = local.LocalIndex(ctx, rbatch.seq, rbatch.off, 10, 5, 256, 15)      # forwardIndex.IndexSeq(read.seq)  (Map_lowacc.h:249)
         li_r = local.LocalIndex(ctx, rc, rbatch.off, 10, 5, 256, 15)              # reverseIndex.IndexSeq(readRC)    (Map_lowacc.h:250)
@@ -236,7 +239,7 @@ def main():
 
     kernels = ["sketch_count", "sketch_serial", "sketch_emit", "sort", "sort_fallback", "index_bounds", "compare", "strand",
                "aog_lds_tiny", "aog_lds_small", "aog_lds_large", "aog_hbm", "ir_segment", "ir_band", "ir_fill", "ir_trace", "ir_gather", "clean_sort", "clean", "linear_extend", "stats", "stats_cigar", "create_rc", "local_sketch", "local_sort_filter", "local_compare",
-               "sdp_points", "sdp_sort", "sdp_sort_fallback", "sdp_build_count", "sdp_build", "sdp_process", "sdp_trace"]
+               "chain_split", "sdp_points", "sdp_sort", "sdp_sort_fallback", "sdp_build_count", "sdp_build", "sdp_process", "sdp_trace"]
     ktimes = {k: ctx.timing_get(k) for k in kernels}
     ctx.timing(False)
     if rank == 0:
@@ -275,7 +278,7 @@ def main():
         alg = alg_step / launches_per_step
         achieved = alg / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
         out = {
-            "metric": "aligned Gbp/s (hot-path stages a1-a5, a7, a8 SDP#A, a10 primitives, a12, a14, a16), 30 kb ONT-like reads", "value": gbps, "unit": "Gbp/s",
+            "metric": "aligned Gbp/s (hot-path stages a1-a5, a7, a8 SDP#A, a9 split, a10 primitives, a12, a14, a16), 30 kb ONT-like reads", "value": gbps, "unit": "Gbp/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_step, "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "int32", "data": "synthetic",
             "reads_per_s": nreads * args.steps / dt,
@@ -283,8 +286,8 @@ def main():
                                    "error 30:35:35 (BASELINE configs[2] -ONT read profile; full GRCh38 not generated in round 1)"
                                    % (args.genome_mb, args.reads, args.read_len, args.err * 100),
                        "preset": "-ONT (k=%d w=%d maxFreq=%d refineBand=%d match/mismatch/indel=4/-1/-2)" % (args.k, args.w, args.max_freq, args.refine_band),
-                       "stages": "a1-a5,a7,a8(SDP#A) chained on the reads; a12 on between-anchor gaps and a14 on block lists derived from the simulator's truth, "
-                                 "a16 on a14's output (a9-a11,a13 chain post-processing / refinement glue not built yet: NOT a whole `lra align`)",
+                       "stages": "a1-a5,a7,a8(SDP#A),a9(chain split) chained on the reads; a12 on between-anchor gaps and a14 on block lists derived from the simulator's truth, "
+                                 "a16 on a14's output (a10 lookup glue, a11, a13 refinement glue not built yet: NOT a whole `lra align`)",
                        "parallelism": "reads sharded by ordinal, 1 process/GPU; RCCL gather of block records to rank 0",
                        "per_step": {k: int(v) for k, v in stats.items() if not k.startswith("_")}},
             "kernel_ms_per_step": {k: round(v[0] / args.steps, 4) for k, v in ktimes.items() if v[1]},

@@ -181,11 +181,17 @@ int lra_linear_extend_batch(lra_ctx* ctx, int K, const char* d_seq, const uint64
  * in trace-back order (last anchor first; cluster = index within the read, anchor = index within the cluster,
  * link[i] = 1 if the step to the next listed anchor is an inversion link), box = QStart,QEnd,TStart,TEnd,
  * value = FirstSDPValue.  d_frag_off[n_reads+1] / d_frag_val: every anchor's final DP value in cluster order.
+ * mode LRA_SDP_SINGLE_CLUSTER replaces  SparseDP(ClusterIndex, extend_clusters, ultimatechain, smallOpts, LookUpTable, read)
+ * (SparseDP.h:2287-2438, called at Map_lowacc.h:535): every "read" is one cluster job, anchors get only their own family's point pair,
+ * rate = opts.second_anchorbonus, and the one chain is the plain TraceBack (:1521) from the first anchor of maximal value (no box).
  * d_status[r]: LRA_ST_CAPACITY if a work buffer bound was hit, LRA_ST_OOB_SLOT if the reference would read outside
  * its arrays (the read then has no chains).  Synchronous.                                              */
+#define LRA_SDP_CLUSTERS 0
+#define LRA_SDP_SINGLE_CLUSTER 1
 typedef struct lra_sdp_opts {
   float rate; int32_t NumAln; float alnthres;
   float gapopen, gapextend, gaproot; int32_t gapCeiling1, gapCeiling2;
+  int32_t mode;   /* LRA_SDP_CLUSTERS (0) or LRA_SDP_SINGLE_CLUSTER (1) */
 } lra_sdp_opts;
 typedef struct lra_chain_result {
   int32_t n_reads, num_aln;
@@ -196,6 +202,7 @@ typedef struct lra_chain_result {
   const uint32_t* d_chain_box;      /* [4*n_reads*num_aln] */
   const float* d_chain_value;       /* [n_reads*num_aln] */
   const uint32_t* d_chain_cluster; const uint32_t* d_chain_anchor; const uint8_t* d_chain_link;   /* [n_frags] */
+  const uint32_t* d_chain_q; const uint32_t* d_chain_t; const int32_t* d_chain_alen; const uint8_t* d_chain_strand;   /* [n_frags] the anchors themselves (q, t, length, strand of the cluster) */
   const uint64_t* d_frag_off;       /* [n_reads+1] */
   const float* d_frag_val;          /* [n_frags] */
   const uint32_t* d_status;         /* [n_reads] */
@@ -203,6 +210,33 @@ typedef struct lra_chain_result {
 int lra_sparse_dp_batch(lra_ctx* ctx, int n_reads, const uint64_t* d_cluster_off, const uint64_t* d_c_start, const uint32_t* d_c_count,
                         const int32_t* d_c_strand, const uint32_t* d_q, const uint32_t* d_t, const int32_t* d_len,
                         const uint64_t* d_read_off, const float* d_rate, const lra_sdp_opts* opts, lra_chain_result* out);
+
+/* ---- a9 (low-accuracy path): chain filters and chain splitting -------------------------------------------
+ * Replaces, per chain of an lra_sparse_dp_batch result (mode LRA_SDP_CLUSTERS), what MapRead_lowacc does before tier-2 refinement:
+ *   RemoveSpuriousJump<UltimateChain>(chains[p])                                   Chain.h:897-957   (Map_lowacc.h:189-192)
+ *   SPLITChain(genome, read, chains[p], spchain, spchain_link, opts)               Mapping_ultility.h:385-441 (push_new :349,
+ *     SplitChain::CHROMIndex Chain.h:386, MergeSplitchainINS Mapping_ultility.h:172)
+ *   RemoveSpuriousSplitChain(spchain, spchain_link)                                Map_lowacc.h:38-66
+ * h_chrom_pos = genome.header.pos (n_chrom + 1 entries).  Output (context-owned), all arrays indexed like the chain arrays: chain
+ * slot s occupies [d_chain_start[s], + d_chain_len[s]):
+ *   d_keep[i]            1 if anchor i of the chain survives RemoveSpuriousJump; d_n_kept[s]; d_link[.. + n_kept-1) the filtered links
+ *   d_n_split[s]         number of split chains; split k of slot s lives at index x = d_chain_start[s] + k of the per-split arrays:
+ *   d_sp_beg[x], d_sp_len[x]   its anchors = d_sp_idx[d_chain_start[s] + beg .. + len) (indices into the FILTERED chain, in the
+ *                        order SPLITChain leaves them: forward-strand pieces reversed), d_sp_link alongside (len-1 used)
+ *   d_sp_type[x] ('N','T','I'), d_sp_strand[x], d_sp_chrom[x], d_sp_box[4x..] (QStart,QEnd,TStart,TEnd)
+ *   d_ci_beg[x], d_ci_len[x]   SplitChain::ClusterIndex = d_ci_idx[d_chain_start[s] + beg .. + len)
+ *   d_split_link[d_chain_start[s] + k], k < d_n_split_link[s]     spchain_link
+ *   d_status[s]          LRA_ST_OOB_SLOT if the reference would read outside its arrays (the slot then has no splits).  Synchronous. */
+typedef struct lra_split_result {
+  uint64_t n_slots, n_frags;
+  const uint8_t* d_keep; const uint32_t* d_n_kept; const uint8_t* d_link;
+  const uint32_t* d_n_split; const uint32_t* d_sp_beg; const uint32_t* d_sp_len; const uint32_t* d_sp_idx; const uint8_t* d_sp_link;
+  const uint8_t* d_sp_type; const uint8_t* d_sp_strand; const int32_t* d_sp_chrom; const uint32_t* d_sp_box;
+  const uint32_t* d_ci_beg; const uint32_t* d_ci_len; const uint32_t* d_ci_idx;
+  const uint8_t* d_split_link; const uint32_t* d_n_split_link; const uint32_t* d_status;
+} lra_split_result;
+int lra_split_chains_batch(lra_ctx* ctx, const lra_chain_result* chains, const uint64_t* h_chrom_pos, int n_chrom, int splitdist,
+                           int bypass_clustering, lra_split_result* out);
 
 /* ---- a10: tier-2 (local) minimizer index and lookups ----------------------------------------
  * lra_local_index_batch replaces  LocalIndex::IndexSeq(char* seq, int seqLen)  (MMIndex.h:200-245) for

@@ -8,23 +8,24 @@ from .context import Context, ptr
 
 class SdpOpts(C.Structure):
     _fields_ = [("rate", C.c_float), ("NumAln", C.c_int32), ("alnthres", C.c_float), ("gapopen", C.c_float), ("gapextend", C.c_float),
-                ("gaproot", C.c_float), ("gapCeiling1", C.c_int32), ("gapCeiling2", C.c_int32)]
+                ("gaproot", C.c_float), ("gapCeiling1", C.c_int32), ("gapCeiling2", C.c_int32), ("mode", C.c_int32)]
 
 
 # -ONT preset (lra.cpp:388-420; alnthres: Options.h:198)
-ONT = dict(rate=20.0, NumAln=2, alnthres=0.7, gapopen=7.0, gapextend=10.0, gaproot=1.5, gapCeiling1=1500, gapCeiling2=3000)
+ONT = dict(rate=20.0, NumAln=2, alnthres=0.7, gapopen=7.0, gapextend=10.0, gaproot=1.5, gapCeiling1=1500, gapCeiling2=3000, mode=0)
 
 
 def sdp_opts(**kw):
     d = dict(ONT); d.update(kw)
-    return SdpOpts(d["rate"], d["NumAln"], d["alnthres"], d["gapopen"], d["gapextend"], d["gaproot"], d["gapCeiling1"], d["gapCeiling2"])
+    return SdpOpts(d["rate"], d["NumAln"], d["alnthres"], d["gapopen"], d["gapextend"], d["gaproot"], d["gapCeiling1"], d["gapCeiling2"], d["mode"])
 
 
 class ChainResult(C.Structure):
     _fields_ = [("n_reads", C.c_int32), ("num_aln", C.c_int32), ("n_frags", C.c_uint64), ("n_points", C.c_uint64),
                 ("n_subproblem_entries", C.c_uint64), ("d_n_chains", C.c_void_p), ("d_chain_start", C.c_void_p), ("d_chain_len", C.c_void_p),
                 ("d_chain_box", C.c_void_p), ("d_chain_value", C.c_void_p), ("d_chain_cluster", C.c_void_p), ("d_chain_anchor", C.c_void_p),
-                ("d_chain_link", C.c_void_p), ("d_frag_off", C.c_void_p), ("d_frag_val", C.c_void_p), ("d_status", C.c_void_p)]
+                ("d_chain_link", C.c_void_p), ("d_chain_q", C.c_void_p), ("d_chain_t", C.c_void_p), ("d_chain_alen", C.c_void_p),
+                ("d_chain_strand", C.c_void_p), ("d_frag_off", C.c_void_p), ("d_frag_val", C.c_void_p), ("d_status", C.c_void_p)]
 
 
 def sparse_dp_batch(ctx: Context, n_reads, cluster_off, c_start, c_count, c_strand, q, t, length, read_off, opts: SdpOpts, rate=None):
@@ -41,5 +42,34 @@ def fetch(ctx: Context, res: ChainResult):
             "chain_len": ctx.to_host(res.d_chain_len, n * na, np.uint32), "chain_box": ctx.to_host(res.d_chain_box, 4 * n * na, np.uint32).reshape(-1, 4),
             "chain_value": ctx.to_host(res.d_chain_value, n * na, np.float32), "chain_cluster": ctx.to_host(res.d_chain_cluster, nf, np.uint32),
             "chain_anchor": ctx.to_host(res.d_chain_anchor, nf, np.uint32), "chain_link": ctx.to_host(res.d_chain_link, nf, np.uint8),
+            "chain_q": ctx.to_host(res.d_chain_q, nf, np.uint32), "chain_t": ctx.to_host(res.d_chain_t, nf, np.uint32),
+            "chain_alen": ctx.to_host(res.d_chain_alen, nf, np.int32), "chain_strand": ctx.to_host(res.d_chain_strand, nf, np.uint8),
             "frag_off": ctx.to_host(res.d_frag_off, n + 1, np.uint64), "frag_val": ctx.to_host(res.d_frag_val, nf, np.float32),
             "status": ctx.to_host(res.d_status, n, np.uint32)}
+
+
+class SplitResult(C.Structure):
+    _fields_ = [("n_slots", C.c_uint64), ("n_frags", C.c_uint64)] + [(n, C.c_void_p) for n in (
+        "d_keep", "d_n_kept", "d_link", "d_n_split", "d_sp_beg", "d_sp_len", "d_sp_idx", "d_sp_link", "d_sp_type", "d_sp_strand", "d_sp_chrom",
+        "d_sp_box", "d_ci_beg", "d_ci_len", "d_ci_idx", "d_split_link", "d_n_split_link", "d_status")]
+
+
+def split_chains_batch(ctx: Context, chains: ChainResult, chrom_pos, splitdist=50000, bypass=1):
+    """RemoveSpuriousJump + SPLITChain + RemoveSpuriousSplitChain (Map_lowacc.h:189-256) on every chain of an SDP#A result."""
+    cp = np.ascontiguousarray(chrom_pos, dtype=np.uint64)
+    res = SplitResult()
+    ctx.check(ctx.lib.lra_split_chains_batch(ctx.h, C.byref(chains), C.c_void_p(cp.ctypes.data), len(cp) - 1, int(splitdist), int(bypass), C.byref(res)))
+    return res
+
+
+def fetch_split(ctx: Context, res: SplitResult):
+    ns, nf = res.n_slots, res.n_frags
+    u8, u32 = np.uint8, np.uint32
+    return {"keep": ctx.to_host(res.d_keep, nf, u8), "n_kept": ctx.to_host(res.d_n_kept, ns, u32), "link": ctx.to_host(res.d_link, nf, u8),
+            "n_split": ctx.to_host(res.d_n_split, ns, u32), "sp_beg": ctx.to_host(res.d_sp_beg, nf, u32), "sp_len": ctx.to_host(res.d_sp_len, nf, u32),
+            "sp_idx": ctx.to_host(res.d_sp_idx, nf, u32), "sp_link": ctx.to_host(res.d_sp_link, nf, u8), "sp_type": ctx.to_host(res.d_sp_type, nf, u8),
+            "sp_strand": ctx.to_host(res.d_sp_strand, nf, u8), "sp_chrom": ctx.to_host(res.d_sp_chrom, nf, np.int32),
+            "sp_box": ctx.to_host(res.d_sp_box, 4 * nf, u32).reshape(-1, 4), "ci_beg": ctx.to_host(res.d_ci_beg, nf, u32),
+            "ci_len": ctx.to_host(res.d_ci_len, nf, u32), "ci_idx": ctx.to_host(res.d_ci_idx, nf, u32),
+            "split_link": ctx.to_host(res.d_split_link, nf, u8), "n_split_link": ctx.to_host(res.d_n_split_link, ns, u32),
+            "status": ctx.to_host(res.d_status, ns, u32)}

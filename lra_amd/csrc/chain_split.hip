@@ -1,0 +1,254 @@
+// lra_amd/csrc/chain_split.hip -- SURVEY §8a row a9 (low-accuracy path): what MapRead_lowacc does to every chain of the first
+// sparse DP before tier-2 refinement (Map_lowacc.h:189-192, :252-256), for all chains of a batch.  gfx950 only.
+//   RemoveSpuriousJump<UltimateChain>     Chain.h:897-957
+//   SPLITChain                            Mapping_ultility.h:385-441 (push_new :349-383, SplitChain::CHROMIndex Chain.h:386-394,
+//                                         GenomeHeader::Find Genome.h:20-32, UltimateChain::diag Chain.h:243-246)
+//   MergeSplitchainINS                    Mapping_ultility.h:172-262
+//   RemoveSpuriousSplitChain              Map_lowacc.h:38-66
+// Mapping: one lane per chain slot; these are short serial scans (a chain has a few hundred anchors, a read one or two chains), far
+// below every other stage -- the point of having them on the device is that the chain never leaves HBM between the sparse DP and the
+// refinement stages.  A split chain is a run [a, b) of the filtered chain; MergeSplitchainINS concatenates runs, kept as a linked list
+// and laid out at the end.  Algorithmic bytes: 21 B per chain anchor in, ~14 B out.
+#include "common.h"
+#include <algorithm>
+
+namespace {
+
+constexpr uint32_t NONE = 0xFFFFFFFFu;
+
+struct SplitArgs {
+  uint64_t n_slots;
+  const uint64_t* chainStart; const uint32_t* chainLen; const uint32_t* nChains; int numAln;
+  const uint32_t* cq; const uint32_t* ct; const int32_t* clen; const uint8_t* cstrand; const uint32_t* ccl; const uint8_t* clink;
+  const uint64_t* pos; int npos; int splitdist, bypass;
+  // outputs
+  uint8_t* keep; uint32_t* nKept; uint8_t* link;
+  uint32_t* nSplit; uint32_t* spBeg; uint32_t* spLen; uint32_t* spIdx; uint8_t* spLink; uint8_t* spType; uint8_t* spStrand; int32_t* spChrom; uint32_t* spBox;
+  uint32_t* ciBeg; uint32_t* ciLen; uint32_t* ciIdx; uint8_t* splitLink; uint32_t* nSplitLink; uint32_t* status;
+  // scratch, indexed like the chain arrays
+  uint32_t* fidx;      // filtered position -> original position
+  uint32_t* runA; uint32_t* runB; uint32_t* runNext; uint32_t* curInd; uint8_t* keepS; uint8_t* spl0;
+};
+
+__device__ int header_find(const uint64_t* pos, int npos, uint64_t query, bool& ub) {   // Genome.h:20-32
+  if (npos > 0 && query == pos[0]) return 0;
+  int lo = 0, cnt = npos;
+  while (cnt > 0) { const int step = cnt >> 1; if (pos[lo + step] < query) { lo += step + 1; cnt -= step + 1; } else cnt = step; }
+  if (lo == npos) { ub = true; return lo - 1; }
+  if (query == pos[lo]) return lo;
+  return lo - 1;
+}
+
+__global__ void __launch_bounds__(64) split_kernel(SplitArgs a) {
+  const uint64_t s = (uint64_t)blockIdx.x * 64 + threadIdx.x;
+  if (s >= a.n_slots) return;
+  a.nKept[s] = 0; a.nSplit[s] = 0; a.nSplitLink[s] = 0; a.status[s] = 0;
+  const uint32_t r = (uint32_t)(s / a.numAln), c = (uint32_t)(s % a.numAln);
+  if (c >= a.nChains[r]) return;
+  const uint64_t base = a.chainStart[s];
+  const int n = (int)a.chainLen[s];
+  if (n == 0) return;
+  const uint32_t* Q = a.cq + base; const uint32_t* T = a.ct + base; const int32_t* Ln = a.clen + base;
+  const uint8_t* St = a.cstrand + base; const uint32_t* Cl = a.ccl + base; const uint8_t* Lk = a.clink + base;
+  uint8_t* keep = a.keep + base; uint8_t* link = a.link + base; uint32_t* fidx = a.fidx + base;
+  // ---- RemoveSpuriousJump :897-957.  Only adjacent SVs one anchor apart matter, so one pass with the previous SV suffices.
+  for (int i = 0; i < n; i++) keep[i] = 1;
+  if (n >= 2) {
+    int pSV = 0, pPos = -1; bool have = false;
+    for (int i = 1; i < n; i++) {
+      int sv = 0; bool is = false;
+      if (St[i] == St[i - 1]) {
+        int Gap;
+        if (St[i] == 0) Gap = (int)(((long long)T[i] - (long long)Q[i]) - ((long long)T[i - 1] - (long long)Q[i - 1]));
+        else Gap = (int)((long long)(uint32_t)(Q[i] + (uint32_t)Ln[i] + T[i]) - (long long)(uint32_t)(Q[i - 1] + (uint32_t)Ln[i - 1] + T[i - 1]));
+        if (abs(Gap) > 100) { sv = Gap; is = true; }
+      } else { sv = 0; is = true; }
+      if (is) {
+        if (have && ((sv >= 0) != (pSV >= 0)) && sv != 0 && pSV != 0 && i - pPos == 1 && Ln[pPos] < 50) keep[pPos] = 0;
+        pSV = sv; pPos = i; have = true;
+      }
+    }
+  }
+  int N = 0;
+  for (int i = 0; i < n; i++)
+    if (keep[i]) { fidx[N] = (uint32_t)i; if (N >= 1) link[N - 1] = Lk[i - 1]; N++; }
+  a.nKept[s] = (uint32_t)N;
+#define FQ(i) Q[fidx[i]]
+#define FT(i) T[fidx[i]]
+#define FL(i) Ln[fidx[i]]
+#define FS(i) St[fidx[i]]
+#define FQE(i) (Q[fidx[i]] + (uint32_t)Ln[fidx[i]])
+#define FTE(i) (T[fidx[i]] + (uint32_t)Ln[fidx[i]])
+  // ---- SPLITChain :385-441; split k = run [runA, runB) of the filtered chain
+  uint32_t* runA = a.runA + base; uint32_t* runB = a.runB + base; uint32_t* runNext = a.runNext + base;
+  uint8_t* spType = a.spType + base; uint8_t* spStrand = a.spStrand + base; int32_t* spChrom = a.spChrom + base; uint32_t* spBox = a.spBox + 4 * base;
+  uint8_t* spl = a.spl0 + base;
+  bool ub = false;
+  int ns = 0, nl = 0;
+  int runStart = 0;
+  auto push_new = [&](int from, int to) -> bool {                        // :349-383; the run is [from, to)
+    const uint32_t QStart = FQ(to - 1), QEnd = FQE(from);
+    uint32_t TStart, TEnd;
+    if (FS(from) == 0) { TStart = FT(to - 1); TEnd = FTE(from); } else { TStart = FT(from); TEnd = FTE(to - 1); }
+    const int first = header_find(a.pos, a.npos, (uint64_t)TStart + 1, ub), last = header_find(a.pos, a.npos, (uint64_t)TEnd, ub);
+    if (first != last) return false;
+    runA[ns] = (uint32_t)from; runB[ns] = (uint32_t)to; runNext[ns] = NONE; spType[ns] = 'N'; spStrand[ns] = FS(from); spChrom[ns] = first;
+    spBox[4 * ns] = QStart; spBox[4 * ns + 1] = QEnd; spBox[4 * ns + 2] = TStart; spBox[4 * ns + 3] = TEnd;
+    ns++;
+    return true;
+  };
+  for (int im = 0; im < N - 1; im++) {
+    const int cur = im + 1, prev = im;
+    const int qdist = (int)(FQ(prev) - FQE(cur));
+    const int tdist = (FT(prev) > FTE(cur)) ? (int)(FT(prev) - FTE(cur)) : (int)(FTE(cur) - FT(prev));
+    const int dist = min(qdist, tdist);
+    const long long dc = FS(cur) == 1 ? (long long)FQE(cur) + (long long)FT(cur) : (long long)FT(cur) - (long long)FQ(cur);   // Chain.h:243
+    const long long dp = FS(prev) == 1 ? (long long)FQE(prev) + (long long)FT(prev) : (long long)FT(prev) - (long long)FQ(prev);
+    const long long dd = dc > dp ? dc - dp : dp - dc;
+    if (FS(cur) == FS(prev) && dist >= 1000 && (double)dd <= ceil(0.15 * (double)dist)) {
+      if (push_new(runStart, cur)) { spl[nl++] = 0; spType[ns - 1] = 'N'; }
+      runStart = cur;
+    } else if (FT(cur) > FTE(prev) + (uint32_t)a.splitdist || FTE(cur) + (uint32_t)a.splitdist < FT(prev)) {
+      if (push_new(runStart, cur)) { spl[nl++] = 0; spType[ns - 1] = 'T'; }
+      runStart = cur;
+    } else if (FS(cur) != FS(prev)) {
+      if (push_new(runStart, cur)) { spType[ns - 1] = 'I'; spl[nl++] = 1; }
+      runStart = cur;
+    }
+  }
+  if (N > 0) push_new(runStart, N);
+  // ---- MergeSplitchainINS :172-262
+  uint8_t* keepS = a.keepS + base;
+  for (int k = 0; k < ns; k++) keepS[k] = 1;
+  if (ns >= 3) {
+    uint32_t* curInd = a.curInd + base;
+    for (int k = 0; k < ns; k++) curInd[k] = (uint32_t)k;
+    bool change = false;
+    int i0 = 0;
+    while (i0 + 3 <= ns) {
+      const int cc = (int)curInd[i0];
+      if (spType[cc] != 'T') { i0++; continue; }
+      int nn = (int)curInd[i0 + 2];
+      while (nn < ns) {
+        const long long cTS = spBox[4 * cc + 2], nTE = spBox[4 * nn + 3];
+        const long long tdist = cTS > nTE ? cTS - nTE : nTE - cTS;
+        if (tdist > 1500 || spStrand[cc] != spStrand[nn] || spChrom[cc] != spChrom[nn]) { nn++; continue; }
+        change = true;
+        uint32_t tail = (uint32_t)cc;                                     // append nn's runs behind cc's
+        while (runNext[tail] != NONE) tail = runNext[tail];
+        runNext[tail] = (uint32_t)nn;
+        spBox[4 * cc] = min(spBox[4 * cc], spBox[4 * nn]); spBox[4 * cc + 2] = min(spBox[4 * cc + 2], spBox[4 * nn + 2]);
+        spBox[4 * cc + 1] = max(spBox[4 * cc + 1], spBox[4 * nn + 1]); spBox[4 * cc + 3] = max(spBox[4 * cc + 3], spBox[4 * nn + 3]);
+        spType[cc] = spType[nn];
+        curInd[nn] = curInd[cc];
+        keepS[nn] = 0;
+        break;
+      }
+      i0 = nn;
+    }
+    if (change) {
+      int rcount = 0;
+      for (int k = 0; k < ns; k++) rcount += keepS[k];
+      for (int x = nl; x < rcount - 1; x++) spl[x] = 0;                  // vector<bool>::resize fills with false
+      nl = rcount - 1;
+      if (a.bypass) { int x = 0; for (int k = 0; k < ns; k++) if (keepS[k]) { if (x > 0) spl[x - 1] = spType[k] == 'I'; x++; } }
+    }
+  }
+  // ---- RemoveSpuriousSplitChain  Map_lowacc.h:38-66  (sizes of the merged pieces), then lay the survivors out
+  int total = 0;
+  for (int k = 0; k < ns; k++) if (keepS[k]) { for (uint32_t x = (uint32_t)k; x != NONE; x = runNext[x]) total += (int)(runB[x] - runA[x]); }
+  const int filter = max((int)floorf(0.02f * (float)total), 2), filterDI = max((int)floorf(0.03f * (float)total), 2);
+  uint32_t* spBeg = a.spBeg + base; uint32_t* spLen = a.spLen + base; uint32_t* spIdx = a.spIdx + base; uint8_t* spLink = a.spLink + base;
+  uint32_t* ciBeg = a.ciBeg + base; uint32_t* ciLen = a.ciLen + base; uint32_t* ciIdx = a.ciIdx + base; uint8_t* splitLink = a.splitLink + base;
+  int outK = 0, o = 0, co = 0, idx = 0;                                    // idx: position among the kept (merged) pieces
+  for (int k = 0; k < ns && !ub; k++) {
+    if (!keepS[k]) continue;
+    int sz = 0;
+    for (uint32_t x = (uint32_t)k; x != NONE; x = runNext[x]) sz += (int)(runB[x] - runA[x]);
+    bool rm = sz < min(filter, 2);
+    if (idx > 0) {
+      if (idx - 1 >= nl) { ub = true; break; }
+      if (spl[idx - 1] == 1 && sz < min(filterDI, 4)) rm = true;
+    }
+    if (!rm) {
+      // sptc in SPLITChain's order; link[j] joins sptc[j] and sptc[j+1] (0 across a merge); forward pieces are reversed at the end (:436)
+      const int beg = o;
+      for (uint32_t x = (uint32_t)k; x != NONE; x = runNext[x]) {
+        for (uint32_t p = runA[x]; p < runB[x]; p++) {
+          spIdx[o] = p;
+          if (o > beg) spLink[o - 1] = (p == runA[x]) ? (uint8_t)0 : link[p - 1];   // 0 across a merge (:205)
+          o++;
+        }
+      }
+      // ClusterIndex: consecutive-distinct clusters along the piece (push_new :352-356, merge :226-236)
+      const int cbeg = co;
+      for (uint32_t x = (uint32_t)k; x != NONE; x = runNext[x]) {
+        if (x != (uint32_t)k && !a.bypass) break;
+        for (uint32_t p = runA[x]; p < runB[x]; p++) { const uint32_t cl = Cl[fidx[p]]; if (co == cbeg || ciIdx[co - 1] != cl) ciIdx[co++] = cl; }
+      }
+      if (spStrand[k] == 0) {
+        for (int x = beg, y = o - 1; x < y; x++, y--) { const uint32_t tv = spIdx[x]; spIdx[x] = spIdx[y]; spIdx[y] = tv; }
+        for (int x = beg, y = o - 2; x < y; x++, y--) { const uint8_t tv = spLink[x]; spLink[x] = spLink[y]; spLink[y] = tv; }
+      }
+      spBeg[outK] = (uint32_t)beg; spLen[outK] = (uint32_t)(o - beg); ciBeg[outK] = (uint32_t)cbeg; ciLen[outK] = (uint32_t)(co - cbeg);
+      // per-split attributes move from slot k to slot outK (outK <= k)
+      spType[outK] = spType[k]; spStrand[outK] = spStrand[k]; spChrom[outK] = spChrom[k];
+      spBox[4 * outK] = spBox[4 * k]; spBox[4 * outK + 1] = spBox[4 * k + 1]; spBox[4 * outK + 2] = spBox[4 * k + 2]; spBox[4 * outK + 3] = spBox[4 * k + 3];
+      if (outK > 1) splitLink[outK - 1] = spl[idx - 1];
+      else if (outK == 1) splitLink[0] = spl[0];                          // `if (c > 1)` in the reference: slot 0 keeps spchain_link[0]
+      outK++;
+    }
+    idx++;
+  }
+  if (ub) { a.status[s] = LRA_ST_OOB_SLOT; return; }
+  a.nSplit[s] = (uint32_t)outK;
+  a.nSplitLink[s] = outK > 1 ? (uint32_t)(outK - 1) : 0;
+#undef FQ
+#undef FT
+#undef FL
+#undef FS
+#undef FQE
+#undef FTE
+}
+
+inline size_t sz(size_t n, size_t e) { return (n * e + 255) / 256 * 256; }
+
+}  // namespace
+
+extern "C" int lra_split_chains_batch(lra_ctx* ctx, const lra_chain_result* ch, const uint64_t* h_chrom_pos, int n_chrom, int splitdist,
+                                      int bypass_clustering, lra_split_result* out) {
+  if (!ctx || !ch || !out || !h_chrom_pos || n_chrom < 1) return LRA_ERR_INVALID;
+  memset(out, 0, sizeof *out);
+  LRA_HIP_CHECK(ctx, hipSetDevice(ctx->device));
+  hipStream_t st = ctx->stream;
+  const uint64_t slots = (uint64_t)ch->n_reads * ch->num_aln, NF = ch->n_frags;
+  out->n_slots = slots; out->n_frags = NF;
+  if (slots == 0) return LRA_OK;
+  const size_t npos = (size_t)n_chrom + 1;
+  size_t need = sz(NF + 1, 1) * 8 + sz(NF + 1, 4) * 12 + sz(4 * NF + 4, 4) + sz(slots + 1, 4) * 4 + sz(npos, 8) + 4096;
+  char* w = (char*)lra_ensure(ctx, 13, need);
+  if (!w) return LRA_ERR_NOMEM;
+  auto take = [](char*& p, size_t n, size_t e) { char* r = p; p += sz(n, e); return r; };
+  SplitArgs a;
+  a.n_slots = slots; a.chainStart = ch->d_chain_start; a.chainLen = ch->d_chain_len; a.nChains = ch->d_n_chains; a.numAln = ch->num_aln;
+  a.cq = ch->d_chain_q; a.ct = ch->d_chain_t; a.clen = ch->d_chain_alen; a.cstrand = ch->d_chain_strand; a.ccl = ch->d_chain_cluster; a.clink = ch->d_chain_link;
+  uint64_t* dpos = (uint64_t*)take(w, npos, 8);
+  a.pos = dpos; a.npos = (int)npos; a.splitdist = splitdist; a.bypass = bypass_clustering;
+  a.keep = (uint8_t*)take(w, NF + 1, 1); a.link = (uint8_t*)take(w, NF + 1, 1); a.spLink = (uint8_t*)take(w, NF + 1, 1); a.spType = (uint8_t*)take(w, NF + 1, 1);
+  a.spStrand = (uint8_t*)take(w, NF + 1, 1); a.splitLink = (uint8_t*)take(w, NF + 1, 1); a.keepS = (uint8_t*)take(w, NF + 1, 1); a.spl0 = (uint8_t*)take(w, NF + 1, 1);
+  a.spBeg = (uint32_t*)take(w, NF + 1, 4); a.spLen = (uint32_t*)take(w, NF + 1, 4); a.spIdx = (uint32_t*)take(w, NF + 1, 4); a.spChrom = (int32_t*)take(w, NF + 1, 4);
+  a.ciBeg = (uint32_t*)take(w, NF + 1, 4); a.ciLen = (uint32_t*)take(w, NF + 1, 4); a.ciIdx = (uint32_t*)take(w, NF + 1, 4); a.fidx = (uint32_t*)take(w, NF + 1, 4);
+  a.runA = (uint32_t*)take(w, NF + 1, 4); a.runB = (uint32_t*)take(w, NF + 1, 4); a.runNext = (uint32_t*)take(w, NF + 1, 4); a.curInd = (uint32_t*)take(w, NF + 1, 4);
+  a.spBox = (uint32_t*)take(w, 4 * NF + 4, 4);
+  a.nKept = (uint32_t*)take(w, slots + 1, 4); a.nSplit = (uint32_t*)take(w, slots + 1, 4); a.nSplitLink = (uint32_t*)take(w, slots + 1, 4); a.status = (uint32_t*)take(w, slots + 1, 4);
+  LRA_HIP_CHECK(ctx, hipMemcpyAsync(dpos, h_chrom_pos, npos * 8, hipMemcpyHostToDevice, st));
+  lra_time_begin(ctx, "chain_split");
+  hipLaunchKernelGGL(split_kernel, dim3((unsigned)((slots + 63) / 64)), dim3(64), 0, st, a);
+  lra_time_end(ctx);
+  LRA_HIP_CHECK(ctx, hipStreamSynchronize(st));
+  LRA_HIP_CHECK(ctx, hipGetLastError());
+  out->d_keep = a.keep; out->d_n_kept = a.nKept; out->d_link = a.link; out->d_n_split = a.nSplit; out->d_sp_beg = a.spBeg; out->d_sp_len = a.spLen;
+  out->d_sp_idx = a.spIdx; out->d_sp_link = a.spLink; out->d_sp_type = a.spType; out->d_sp_strand = a.spStrand; out->d_sp_chrom = a.spChrom; out->d_sp_box = a.spBox;
+  out->d_ci_beg = a.ciBeg; out->d_ci_len = a.ciLen; out->d_ci_idx = a.ciIdx; out->d_split_link = a.splitLink; out->d_n_split_link = a.nSplitLink; out->d_status = a.status;
+  return LRA_OK;
+}

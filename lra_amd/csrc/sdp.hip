@@ -94,12 +94,12 @@ __global__ void k_visit_clear(const ReadArena* __restrict__ ra, const uint64_t* 
 }
 
 // ---- counting / point generation ------------------------------------------------------------------------------------
-__global__ void k_cluster_counts(uint64_t nc, const uint32_t* __restrict__ c_count, uint32_t* fragCnt, uint32_t* ptCnt) {
+__global__ void k_cluster_counts(uint64_t nc, const uint32_t* __restrict__ c_count, uint32_t* fragCnt, uint32_t* ptCnt, int single) {
   uint64_t c = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (c >= nc) return;
   uint32_t n = c_count[c];
   fragCnt[c] = n;
-  ptCnt[c] = 2 * n + 2 * (n == 0 ? 0 : n == 1 ? 1 : 2);     // SparseDP.h:2159-2166: first and last anchor get the other family's pair too
+  ptCnt[c] = 2 * n + (single ? 0 : 2 * (n == 0 ? 0 : n == 1 ? 1 : 2));     // SparseDP.h:2159-2166: first and last anchor get the other family's pair too
 }
 
 __global__ void k_read_offsets(int n_reads, const uint64_t* __restrict__ cluster_off, const uint64_t* __restrict__ clusFragOff,
@@ -120,9 +120,9 @@ struct PtArgs {
   const uint64_t* cluster_off; const uint64_t* c_start; const uint32_t* c_count; const int32_t* c_strand;
   const uint32_t* q; const uint32_t* t; const int32_t* len;
   const uint32_t* clusRead; const uint64_t* clusFragOff; const uint64_t* clusPtOff; const uint64_t* fragOff; const uint64_t* ptOff;
-  const float* rate_in; float rate;
+  const float* rate_in; float rate; int single;
   uint32_t* fq; uint32_t* ft; int32_t* flen; uint32_t* fcl; uint32_t* fai; float* fval; uint32_t* fprevNode; uint32_t* fprevInd; uint8_t* fflags;
-  uint8_t* used; unsigned long long* fkey; uint32_t* fspos; uint32_t* fSpos2;
+  uint8_t* used; uint8_t* fstrand; unsigned long long* fkey; uint32_t* fspos; uint32_t* fSpos2;
   uint64_t* key1; uint32_t* pay1; uint32_t* iq; uint32_t* it; uint8_t* ifl; uint32_t* ifr; uint32_t* ptRead;
 };
 
@@ -144,10 +144,10 @@ __global__ void k_points(PtArgs a) {
     const uint32_t lf = (uint32_t)(g - f0);
     a.fq[g] = q; a.ft[g] = t; a.flen[g] = len; a.fcl[g] = cl; a.fai[g] = i;
     a.fval[g] = len * rate;                                            // Value[ii].val = matchesLengths * rate (:2206)
-    a.fprevNode[g] = NONE; a.fprevInd[g] = NONE; a.fflags[g] = 3; a.used[g] = 0;
+    a.fprevNode[g] = NONE; a.fprevInd[g] = NONE; a.fflags[g] = 3; a.used[g] = 0; a.fstrand[g] = (uint8_t)(strand != 0);
     a.fkey[g] = ((unsigned long long)__float_as_uint(len * rate) << 32) | 0xFFFFFFFFull;   // (value, no predecessor)
     a.fspos[g] = 0; a.fSpos2[2 * g] = NONE; a.fSpos2[2 * g + 1] = NONE;
-    const bool edge = (i == 0 || i == n - 1);
+    const bool edge = !a.single && (i == 0 || i == n - 1);                 // the single-cluster SDP (SparseDP.h:2296-2305) inserts one pair only
     for (int rep = 0; rep < (edge ? 2 : 1); rep++) {
       const int pair = (strand == 0) ? rep : 1 - rep;                  // forward cluster: s1/e1 first; reverse: s2/e2 first
       uint32_t sq, st, eq, et;
@@ -774,14 +774,14 @@ __global__ void k_frag_read(int n_reads, const uint64_t* __restrict__ fragOff, u
 }
 
 struct TraceArgs {
-  int r0, n, numAln; float alnthres;
+  int r0, n, numAln, single; float alnthres;
   const uint64_t* fragOff; const uint64_t* read_off;
   const uint32_t* fq; const uint32_t* ft; const int32_t* flen; const uint32_t* fcl; const uint32_t* fai;
   const float* fval; const uint32_t* fprevNode; const uint32_t* fprevInd; const uint8_t* fflags; const uint32_t* opay;
   uint8_t* used;
   const ReadArena* ra; const char* arena;
   uint32_t* nChains; uint64_t* chainStart; uint32_t* chainLen; uint32_t* chainBox; float* chainValue;
-  uint32_t* ccl; uint32_t* can; uint8_t* clink;
+  uint32_t* ccl; uint32_t* can; uint8_t* clink; uint32_t* cq; uint32_t* ct; int32_t* clen; uint8_t* cstrand; const uint8_t* fstrand;
   const uint32_t* status;
 };
 
@@ -796,6 +796,32 @@ __global__ void __launch_bounds__(64) sdp_trace(TraceArgs a) {
   const ReadArena A = a.ra[rr];
   const Node* nodesR = (const Node*)(a.arena + A.base);
   const uint32_t* apR = (const uint32_t*)(a.arena + A.base + A.apOff);
+  if (a.single) {                                                        // SparseDP.h:2417-2434: first anchor of maximal value, plain TraceBack :1521
+    float maxv = 0; uint32_t i = 0;
+    for (int l = 0; l < total; l++) if (a.fval[f0 + l] > maxv) { maxv = a.fval[f0 + l]; i = l; }
+    uint32_t len = 0;
+    uint32_t pn = a.fprevNode[f0 + i], pi = a.fprevInd[f0 + i];
+    a.ccl[f0] = i; len = 1;
+    while (pn != NONE && pi != NONE && len < (uint32_t)total) {
+      const Node nd = nodesR[pn];
+      const uint32_t ind = apR[nd.dBase + nd.nD + pi];
+      a.clink[f0 + len - 1] = (a.fflags[f0 + i] & 2) ? 0 : 1;
+      i = apR[nd.dBase + ind];
+      pn = a.fprevNode[f0 + i]; pi = a.fprevInd[f0 + i];
+      a.ccl[f0 + len] = i; len++;
+    }
+    a.clink[f0 + len - 1] = 0;
+    const int slot = r * a.numAln;
+    a.chainStart[slot] = f0; a.chainLen[slot] = len; a.chainValue[slot] = maxv;
+    a.chainBox[4 * slot] = 0; a.chainBox[4 * slot + 1] = 0; a.chainBox[4 * slot + 2] = 0; a.chainBox[4 * slot + 3] = 0;
+    for (uint64_t k = f0; k < f0 + len; k++) {
+      const uint32_t lf = a.ccl[k];
+      a.cq[k] = a.fq[f0 + lf]; a.ct[k] = a.ft[f0 + lf]; a.clen[k] = a.flen[f0 + lf]; a.cstrand[k] = a.fstrand[f0 + lf];
+      a.can[k] = a.fai[f0 + lf]; a.ccl[k] = a.fcl[f0 + lf];
+    }
+    a.nChains[r] = 1;
+    return;
+  }
   const int readLen = (int)(a.read_off[r + 1] - a.read_off[r]);
   const float thres = a.alnthres * a.fval[f0 + a.opay[f0]];
   int nCh = 0, fv = 0;
@@ -857,7 +883,11 @@ __global__ void __launch_bounds__(64) sdp_trace(TraceArgs a) {
     fv++;
   }
   // local fragment index -> (cluster, anchor)
-  for (uint64_t k = f0; k < out; k++) { const uint32_t lf = a.ccl[k]; a.can[k] = a.fai[f0 + lf]; a.ccl[k] = a.fcl[f0 + lf]; }
+  for (uint64_t k = f0; k < out; k++) {
+    const uint32_t lf = a.ccl[k];
+    a.cq[k] = a.fq[f0 + lf]; a.ct[k] = a.ft[f0 + lf]; a.clen[k] = a.flen[f0 + lf]; a.cstrand[k] = a.fstrand[f0 + lf];
+    a.can[k] = a.fai[f0 + lf]; a.ccl[k] = a.fcl[f0 + lf];
+  }
   a.nChains[r] = (uint32_t)nCh;
 }
 
@@ -911,7 +941,7 @@ extern "C" int lra_sparse_dp_batch(lra_ctx* ctx, int n_reads, const uint64_t* d_
   LRA_HIP_CHECK(ctx, hipMemsetAsync(chainLen, 0, nslot * 4, st));
   if (NC > 0) {
     lra_time_begin(ctx, "sdp_points");
-    hipLaunchKernelGGL(k_cluster_counts, dim3((unsigned)((NC + 255) / 256)), dim3(256), 0, st, NC, d_c_count, clusFragCnt, clusPtCnt);
+    hipLaunchKernelGGL(k_cluster_counts, dim3((unsigned)((NC + 255) / 256)), dim3(256), 0, st, NC, d_c_count, clusFragCnt, clusPtCnt, opts->mode == LRA_SDP_SINGLE_CLUSTER);
     lra_time_end(ctx);
   }
   { int rc = lra_exclusive_scan<uint32_t>(ctx, (long)NC, clusFragCnt, clusFragOff); if (rc) return rc; }
@@ -925,7 +955,7 @@ extern "C" int lra_sparse_dp_batch(lra_ctx* ctx, int n_reads, const uint64_t* d_
   const uint64_t NF = h_frag[n_reads], NP = h_pt[n_reads];
   out->n_frags = NF; out->n_points = NP;
   // ---- fragments
-  size_t needF = sz(NF + 1, 4) * 11 + sz(2 * NF + 2, 4) + sz(NF + 1, 1) * 3 + sz(NF + 1, 8) * 2 + 4096;
+  size_t needF = sz(NF + 1, 4) * 14 + sz(2 * NF + 2, 4) + sz(NF + 1, 1) * 5 + sz(NF + 1, 8) * 2 + 4096;
   char* wf = (char*)lra_ensure(ctx, 8, needF);
   if (!wf) return LRA_ERR_NOMEM;
   uint32_t* fq = (uint32_t*)take(wf, NF + 1, 4); uint32_t* ft = (uint32_t*)take(wf, NF + 1, 4); int32_t* flen = (int32_t*)take(wf, NF + 1, 4);
@@ -933,6 +963,8 @@ extern "C" int lra_sparse_dp_batch(lra_ctx* ctx, int n_reads, const uint64_t* d_
   uint32_t* fprevNode = (uint32_t*)take(wf, NF + 1, 4); uint32_t* fprevInd = (uint32_t*)take(wf, NF + 1, 4);
   uint32_t* ccl = (uint32_t*)take(wf, NF + 1, 4); uint32_t* can = (uint32_t*)take(wf, NF + 1, 4);
   uint8_t* fflags = (uint8_t*)take(wf, NF + 1, 1); uint8_t* used = (uint8_t*)take(wf, NF + 1, 1); uint8_t* clink = (uint8_t*)take(wf, NF + 1, 1);
+  uint8_t* fstrand = (uint8_t*)take(wf, NF + 1, 1); uint8_t* cstrand = (uint8_t*)take(wf, NF + 1, 1);
+  uint32_t* cq = (uint32_t*)take(wf, NF + 1, 4); uint32_t* ct = (uint32_t*)take(wf, NF + 1, 4); int32_t* clen = (int32_t*)take(wf, NF + 1, 4);
   uint64_t* okey = (uint64_t*)take(wf, NF + 1, 8); unsigned long long* fkey = (unsigned long long*)take(wf, NF + 1, 8);
   uint32_t* fspos = (uint32_t*)take(wf, NF + 1, 4); uint32_t* fSpos2 = (uint32_t*)take(wf, 2 * NF + 2, 4);
   // ---- points
@@ -948,13 +980,14 @@ extern "C" int lra_sparse_dp_batch(lra_ctx* ctx, int n_reads, const uint64_t* d_
   uint8_t* ifl = (uint8_t*)take(wp, NP + 1, 1); uint8_t* hfl = (uint8_t*)take(wp, NP + 1, 1);
   uint32_t* opay = (uint32_t*)take(wp, NF + 1, 4); uint32_t* fragRead = (uint32_t*)take(wp, NF + 1, 4);
   out->d_n_chains = nChains; out->d_chain_start = chainStart; out->d_chain_len = chainLen; out->d_chain_box = chainBox; out->d_chain_value = chainValue;
-  out->d_chain_cluster = ccl; out->d_chain_anchor = can; out->d_chain_link = clink; out->d_frag_off = fragOff; out->d_frag_val = fval; out->d_status = status;
+  out->d_chain_cluster = ccl; out->d_chain_anchor = can; out->d_chain_link = clink; out->d_chain_q = cq; out->d_chain_t = ct; out->d_chain_alen = clen;
+  out->d_chain_strand = cstrand; out->d_frag_off = fragOff; out->d_frag_val = fval; out->d_status = status;
   if (NF == 0) { LRA_HIP_CHECK(ctx, hipStreamSynchronize(st)); return LRA_OK; }
   {
     PtArgs pa;
     pa.nc = NC; pa.cluster_off = d_cluster_off; pa.c_start = d_c_start; pa.c_count = d_c_count; pa.c_strand = d_c_strand; pa.q = d_q; pa.t = d_t; pa.len = d_len;
-    pa.clusRead = clusRead; pa.clusFragOff = clusFragOff; pa.clusPtOff = clusPtOff; pa.fragOff = fragOff; pa.ptOff = ptOff; pa.rate_in = d_rate; pa.rate = opts->rate;
-    pa.fq = fq; pa.ft = ft; pa.flen = flen; pa.fcl = fcl; pa.fai = fai; pa.fval = fval; pa.fprevNode = fprevNode; pa.fprevInd = fprevInd; pa.fflags = fflags; pa.used = used;
+    pa.clusRead = clusRead; pa.clusFragOff = clusFragOff; pa.clusPtOff = clusPtOff; pa.fragOff = fragOff; pa.ptOff = ptOff; pa.rate_in = d_rate; pa.rate = opts->rate; pa.single = opts->mode == LRA_SDP_SINGLE_CLUSTER;
+    pa.fq = fq; pa.ft = ft; pa.flen = flen; pa.fcl = fcl; pa.fai = fai; pa.fval = fval; pa.fprevNode = fprevNode; pa.fprevInd = fprevInd; pa.fflags = fflags; pa.used = used; pa.fstrand = fstrand;
     pa.fkey = fkey; pa.fspos = fspos; pa.fSpos2 = fSpos2;
     pa.key1 = key1; pa.pay1 = pay1; pa.iq = iq; pa.it = it; pa.ifl = ifl; pa.ifr = ifr; pa.ptRead = ptRead;
     lra_time_begin(ctx, "sdp_points");
@@ -1026,10 +1059,11 @@ extern "C" int lra_sparse_dp_batch(lra_ctx* ctx, int n_reads, const uint64_t* d_
       lra_time_end(ctx);
       { int rc = lra_sort_minimizers_batch(ctx, nr, fragOff + r0, okey, opay); if (rc) return rc; }   // Fragment_valueOrder::Sort (Fragment_Info.h:88)
       TraceArgs ta;
-      ta.r0 = r0; ta.n = nr; ta.numAln = opts->NumAln; ta.alnthres = opts->alnthres; ta.fragOff = fragOff; ta.read_off = d_read_off; ta.fq = fq; ta.ft = ft;
+      ta.r0 = r0; ta.n = nr; ta.numAln = opts->NumAln; ta.single = opts->mode == LRA_SDP_SINGLE_CLUSTER; ta.alnthres = opts->alnthres; ta.fragOff = fragOff; ta.read_off = d_read_off; ta.fq = fq; ta.ft = ft;
       ta.flen = flen; ta.fcl = fcl; ta.fai = fai; ta.fval = fval; ta.fprevNode = fprevNode; ta.fprevInd = fprevInd; ta.fflags = fflags; ta.opay = opay; ta.used = used;
       ta.ra = ra; ta.arena = arena; ta.nChains = nChains; ta.chainStart = chainStart; ta.chainLen = chainLen;
       ta.chainBox = chainBox; ta.chainValue = chainValue; ta.ccl = ccl; ta.can = can; ta.clink = clink; ta.status = status;
+      ta.cq = cq; ta.ct = ct; ta.clen = clen; ta.cstrand = cstrand; ta.fstrand = fstrand;
       lra_time_begin(ctx, "sdp_trace");
       hipLaunchKernelGGL(sdp_trace, dim3((nr + 63) / 64), dim3(64), 0, st, ta);
       lra_time_end(ctx);

@@ -1,0 +1,221 @@
+// oracle/chain_split.cpp -- TEST INFRASTRUCTURE ONLY (see oracle_common.h).
+//
+// CPU restatement of what MapRead_lowacc does to every chain of the first sparse DP before tier-2 refinement
+// (Map_lowacc.h:189-192, :252-256):
+//   RemoveSpuriousJump<UltimateChain>                          Chain.h:897-957
+//   SPLITChain(genome, read, chain, spchain, spchain_link)     Mapping_ultility.h:385-441, push_new :349-383,
+//     SplitChain::CHROMIndex Chain.h:386-394 (GenomeHeader::Find Genome.h:20-32), UltimateChain::diag Chain.h:243-246
+//   MergeSplitchainINS                                         Mapping_ultility.h:172-262
+//   RemoveSpuriousSplitChain                                   Map_lowacc.h:38-66
+// Parity status: PARITY UNPINNED -- Chain.h / Mapping_ultility.h include Genome.h (htslib); restated from the source text.
+#include "oracle_common.h"
+#include <algorithm>
+#include <cmath>
+#include <cstdlib>
+#include <numeric>
+#include <vector>
+
+namespace {
+
+struct Anchor { uint32_t q, t; int len; int strand; int cluster; };   // one chain element with its cluster's strand (0 forward)
+
+struct Split {
+  std::vector<int> sptc;
+  std::vector<bool> link;
+  uint32_t QStart = 0, QEnd = 0, TStart = 0, TEnd = 0;
+  int chromIndex = 0;
+  bool Strand = 0;
+  std::vector<int> ClusterIndex;
+  char type = 'N';
+};
+
+int header_find(const uint64_t* pos, int npos, uint64_t query, bool& ub) {   // Genome.h:20-32
+  if (npos > 0 && query == pos[0]) return 0;
+  const uint64_t* it = std::lower_bound(pos, pos + npos, query);
+  int i = (int)(it - pos);
+  if (i == npos) { ub = true; return i - 1; }
+  if (query == *it) return i;
+  return i - 1;
+}
+
+inline bool sgn(int x) { return x >= 0; }                               // sign() Clustering.h:544
+
+}  // namespace
+
+// In: one chain in trace-back order (anchor i: q, t(global), len, strand of its cluster, cluster index) with its link bits
+// (n - 1 of them); the chromosome table pos[0..npos) (genome.header.pos).  splitdist = opts.splitdist, bypass = opts.bypassClustering.
+// Out: keep[i] (RemoveSpuriousJump), link of the filtered chain; the split chains as CSR over indices INTO THE FILTERED CHAIN
+// (spOff[nSplit+1], spIdx), per split: type char, Strand, chromIndex, box (QStart,QEnd,TStart,TEnd), link bits CSR-aligned with spIdx
+// (entry k links spIdx[k] to spIdx[k+1]), ClusterIndex CSR (ciOff, ciIdx); splitLink[nSplit-1].  Returns nSplit, or -1 if the reference
+// would read outside its arrays.
+extern "C" int oracle_split_chain(int n, const uint32_t* q, const uint32_t* t, const int* len, const uint8_t* strand, const int* cluster,
+                                  const uint8_t* link, const uint64_t* pos, int npos, int splitdist, int bypass, uint8_t* keep, int* nKept,
+                                  uint8_t* linkOut, int* spOff, int* spIdx, uint8_t* spLink, char* spType, uint8_t* spStrand, int* spChrom,
+                                  uint32_t* spBox, int* ciOff, int* ciIdx, uint8_t* splitLink, int* nSplitLink) {
+  std::vector<Anchor> ch(n);
+  for (int i = 0; i < n; i++) ch[i] = Anchor{q[i], t[i], len[i], (int)strand[i], cluster[i]};
+  std::vector<bool> lk(link, link + (n > 0 ? n - 1 : 0));
+  auto qS = [&](int i) { return ch[i].q; };
+  auto tS = [&](int i) { return ch[i].t; };
+  auto qE = [&](int i) { return ch[i].q + (uint32_t)ch[i].len; };
+  auto tE = [&](int i) { return ch[i].t + (uint32_t)ch[i].len; };
+  // ---- RemoveSpuriousJump :897-957
+  std::vector<bool> remove(n, false);
+  if (n >= 2) {
+    std::vector<int> SV, SVpos;
+    for (int c = 1; c < n; c++) {
+      if (ch[c].strand == ch[c - 1].strand) {
+        int Gap;
+        if (ch[c].strand == 0) Gap = (int)(((long)tS(c) - (long)qS(c)) - ((long)tS(c - 1) - (long)qS(c - 1)));
+        else Gap = (int)((long)(qE(c) + tS(c)) - (long)(qE(c - 1) + tS(c - 1)));     // 32-bit sums, as written
+        if (std::abs(Gap) > 100) { SV.push_back(Gap); SVpos.push_back(c); }
+      } else { SVpos.push_back(c); SV.push_back(0); }
+    }
+    for (size_t c = 1; c < SV.size(); c++) {
+      if (remove[SVpos[c - 1]] == 0 && sgn(SV[c]) != sgn(SV[c - 1]) && SV[c] != 0 && SV[c - 1] != 0 && SVpos[c] - SVpos[c - 1] == 1)
+        for (int i = SVpos[c - 1]; i < SVpos[c]; i++) if (ch[i].len < 50) remove[i] = true;
+    }
+    int m = 0;
+    for (int i = 0; i < n; i++)
+      if (!remove[i]) {
+        ch[m] = ch[i];
+        if (!lk.empty() && m >= 1) lk[m - 1] = lk[i - 1];
+        m++;
+      }
+    ch.resize(m);
+    if (!lk.empty()) lk.resize(m - 1);
+  }
+  for (int i = 0; i < n; i++) keep[i] = !remove[i];
+  const int N = (int)ch.size();
+  *nKept = N;
+  for (size_t i = 0; i < lk.size(); i++) linkOut[i] = lk[i];
+  // ---- SPLITChain :385-441
+  bool ub = false;
+  std::vector<Split> sp;
+  std::vector<bool> spl;
+  auto diag = [&](int i) -> long { return ch[i].strand == 1 ? (long)qE(i) + (long)tS(i) : (long)tS(i) - (long)qS(i); };   // Chain.h:243
+  std::vector<int> onec;
+  std::vector<bool> olk;
+  auto push_new = [&](int cur) -> bool {                                 // :349-383
+    Split s;
+    s.sptc = onec; s.link = olk; s.Strand = ch[onec[0]].strand; s.type = 'N';
+    s.ClusterIndex.push_back(ch[onec[0]].cluster);
+    for (size_t c = 1; c < onec.size(); c++) if (ch[onec[c]].cluster != s.ClusterIndex.back()) s.ClusterIndex.push_back(ch[onec[c]].cluster);
+    s.QStart = qS(onec.back()); s.QEnd = qE(onec[0]);
+    if (ch[onec[0]].strand == 0) { s.TStart = tS(onec.back()); s.TEnd = tE(onec[0]); }
+    else { s.TStart = tS(onec[0]); s.TEnd = tE(onec.back()); }
+    int first = header_find(pos, npos, (uint64_t)s.TStart + 1, ub), last = header_find(pos, npos, (uint64_t)s.TEnd, ub);   // CHROMIndex
+    onec.clear(); olk.clear(); onec.push_back(cur);
+    if (first != last) return false;
+    s.chromIndex = first;
+    sp.push_back(s);
+    return true;
+  };
+  if (N == 0) { *nSplitLink = 0; spOff[0] = 0; ciOff[0] = 0; return 0; }
+  onec.push_back(0);
+  int im = 0, cur = 0, prev = 0;
+  while (im < N - 1) {
+    cur = im + 1; prev = im;
+    int qdist = (int)(qS(prev) - qE(cur));
+    int tdist = (tS(prev) > tE(cur)) ? (int)(tS(prev) - tE(cur)) : (int)(tE(cur) - tS(prev));
+    int dist = std::min(qdist, tdist);
+    if (ch[cur].strand == ch[prev].strand && dist >= 1000 && std::labs(diag(cur) - diag(prev)) <= std::ceil(0.15 * dist)) {
+      if (push_new(cur)) { spl.push_back(0); sp.back().type = 'N'; }
+    } else if (tS(cur) > tE(prev) + (uint32_t)splitdist || tE(cur) + (uint32_t)splitdist < tS(prev)) {
+      if (push_new(cur)) { spl.push_back(0); sp.back().type = 'T'; }
+    } else if (ch[cur].strand != ch[prev].strand) {
+      if (push_new(cur)) { sp.back().type = 'I'; spl.push_back(1); }
+    } else { onec.push_back(cur); olk.push_back(lk[im]); }
+    im++;
+  }
+  if (!onec.empty()) push_new(cur);
+  // ---- MergeSplitchainINS :172-262
+  if (sp.size() >= 3) {
+    std::vector<int> cur_ind(sp.size());
+    std::iota(cur_ind.begin(), cur_ind.end(), 0);
+    std::vector<bool> keepS(sp.size(), true);
+    bool change = false;
+    size_t i0 = 0;
+    while (i0 + 3 <= sp.size()) {
+      int c = cur_ind[i0];
+      if (sp[c].type != 'T') { i0++; continue; }
+      size_t nn = (size_t)cur_ind[i0 + 2];
+      while (nn < sp.size()) {
+        long tdist = (sp[c].TStart > sp[nn].TEnd) ? ((long)sp[c].TStart - (long)sp[nn].TEnd) : ((long)sp[nn].TEnd - (long)sp[c].TStart);
+        if (tdist > 1500) { nn++; continue; }
+        if (sp[c].Strand != sp[nn].Strand) { nn++; continue; }
+        if (sp[c].chromIndex != sp[nn].chromIndex) { nn++; continue; }
+        change = true;
+        int t1 = (int)sp[c].sptc.size(), tt = t1 + (int)sp[nn].sptc.size();
+        sp[c].sptc.resize(tt); sp[c].link.resize(tt - 1);
+        for (int s = t1; s < tt; s++) {
+          sp[c].sptc[s] = sp[nn].sptc[s - t1];
+          if (s == t1) sp[c].link[s - 1] = 0;
+          else sp[c].link[s - 1] = sp[nn].link[s - t1 - 1];
+          sp[c].QStart = std::min(sp[c].QStart, sp[nn].QStart); sp[c].TStart = std::min(sp[c].TStart, sp[nn].TStart);
+          sp[c].QEnd = std::max(sp[c].QEnd, sp[nn].QEnd); sp[c].TEnd = std::max(sp[c].TEnd, sp[nn].TEnd);
+          sp[c].type = sp[nn].type;
+        }
+        if (bypass) {
+          int pv = sp[c].ClusterIndex.back();
+          for (size_t s = 0; s < sp[nn].ClusterIndex.size(); s++) {
+            int cu = sp[nn].ClusterIndex[s];
+            if (pv != cu) { sp[c].ClusterIndex.push_back(cu); pv = cu; }
+          }
+        }
+        cur_ind[nn] = cur_ind[c];
+        keepS[nn] = false;
+        break;
+      }
+      i0 = nn;
+    }
+    if (change) {
+      size_t r = 0;
+      for (size_t s = 0; s < sp.size(); s++) if (keepS[s]) { if (r != s) sp[r] = sp[s]; r++; }
+      sp.resize(r);
+      spl.resize(r - 1);
+      if (bypass) for (size_t k = 1; k < sp.size(); k++) spl[k - 1] = sp[k].type == 'I';
+    }
+  }
+  for (auto& s : sp)                                                     // :436-441
+    if (s.Strand == 0) { std::reverse(s.sptc.begin(), s.sptc.end()); std::reverse(s.link.begin(), s.link.end()); }
+  // ---- RemoveSpuriousSplitChain  Map_lowacc.h:38-66
+  {
+    int total = 0;
+    for (auto& s : sp) total += (int)s.sptc.size();
+    int filter = std::max((int)std::floor(0.02f * (float)total), 2);
+    int filterDI = std::max((int)std::floor(0.03f * (float)total), 2);
+    std::vector<bool> rm(sp.size(), 0);
+    for (size_t i = 0; i < sp.size(); i++) {
+      if ((int)sp[i].sptc.size() < std::min(filter, 2)) rm[i] = 1;
+      if (i > 0) {
+        if (i - 1 >= spl.size()) { ub = true; break; }
+        if (spl[i - 1] == 1 && (int)sp[i].sptc.size() < std::min(filterDI, 4)) rm[i] = 1;
+      }
+    }
+    if (ub) return -1;
+    size_t c = 0;
+    for (size_t i = 0; i < rm.size(); i++)
+      if (!rm[i]) {
+        if (c != i) sp[c] = sp[i];
+        if (c > 1) spl[c - 1] = spl[i - 1];
+        c++;
+      }
+    sp.resize(c);
+    if (c > 1) spl.resize(c - 1); else spl.clear();
+  }
+  if (ub) return -1;
+  int o = 0, co = 0;
+  for (size_t k = 0; k < sp.size(); k++) {
+    spOff[k] = o; ciOff[k] = co;
+    for (size_t x = 0; x < sp[k].sptc.size(); x++) { spIdx[o + x] = sp[k].sptc[x]; spLink[o + x] = x < sp[k].link.size() ? (uint8_t)sp[k].link[x] : 0; }
+    o += (int)sp[k].sptc.size();
+    for (int x : sp[k].ClusterIndex) ciIdx[co++] = x;
+    spType[k] = sp[k].type; spStrand[k] = sp[k].Strand; spChrom[k] = sp[k].chromIndex;
+    spBox[4 * k] = sp[k].QStart; spBox[4 * k + 1] = sp[k].QEnd; spBox[4 * k + 2] = sp[k].TStart; spBox[4 * k + 3] = sp[k].TEnd;
+  }
+  spOff[sp.size()] = o; ciOff[sp.size()] = co;
+  *nSplitLink = (int)spl.size();
+  for (size_t k = 0; k < spl.size(); k++) splitLink[k] = spl[k];
+  return (int)sp.size();
+}

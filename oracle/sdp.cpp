@@ -476,6 +476,7 @@ struct oracle_sdp_opts {
   int readLen;         // read.length
   float gapopen, gapextend, gaproot;   // InitPWL arguments (lra.cpp:648)
   int gapCeiling1, gapCeiling2;
+  int mode;            // 0: SDP#A (:2139);  1: the single-cluster SparseDP (:2287-2438): one point pair per anchor, first maximum, plain TraceBack
 };
 
 // SDP#A over the extended clusters of one read.  Fragments are the clusters' matches, concatenated in cluster order
@@ -496,7 +497,7 @@ extern "C" int oracle_sdp_chain(int nClusters, const int* clusterOff, const uint
     int ms = clusterOff[cm], sz = clusterOff[cm + 1] - ms;
     for (int i = 0; i < sz; i++) {
       int g = ms + i;
-      bool edge = (i == 0 || i == sz - 1);
+      bool edge = o->mode == 0 && (i == 0 || i == sz - 1);
       if (clusterStrand[cm] == 0) {
         insert_pair(c.H1, g, q[g], t[g], len[g], cm, 0, 1);
         if (edge) insert_pair(c.H1, g, q[g], t[g], len[g], cm, 1, 1);
@@ -578,6 +579,26 @@ extern "C" int oracle_sdp_chain(int nClusters, const int* clusterOff, const uint
     if (fragPrevSub) fragPrevSub[i] = V[i].prev_sub;
     if (fragPrevInd) fragPrevInd[i] = V[i].prev_ind;
     if (fragFlags) fragFlags[i] = (uint8_t)((V[i].prev ? 1 : 0) | (V[i].inv ? 2 : 0));
+  }
+  if (o->mode == 1) {                                                     // :2417-2434
+    float max_value = 0; unsigned int max_pos = 0;
+    for (int l = 0; l < total; l++) if (V[l].val > max_value) { max_value = V[l].val; max_pos = l; }
+    unsigned int i = max_pos;                                             // TraceBack :1521-1565
+    long ps = V[i].prev_sub, pi = V[i].prev_ind;
+    int n = 0;
+    chainFrag[n++] = i;
+    while (ps != -1 && pi != -1 && n < total) {
+      int fam = (V[i].inv ? 0 : 2) + (V[i].prev ? 0 : 1);
+      Sub& s = c.subs[fam][ps];
+      chainLink[n - 1] = V[i].inv ? 0 : 1;
+      i = s.Dp[s.Ep[pi]];
+      ps = V[i].prev_sub; pi = V[i].prev_ind;
+      chainFrag[n++] = i;
+    }
+    chainLink[n - 1] = 0;
+    chainOff[1] = n; chainValue[0] = max_value;
+    chainBox[0] = chainBox[1] = chainBox[2] = chainBox[3] = 0;
+    return 1;
   }
   // DecidePrimaryChains :1658-1760
   std::vector<int> order(total);

@@ -251,17 +251,17 @@ def compare_lists_local(q, t, max_freq, max_diag=0, min_diag=0):
 class SdpOpts(C.Structure):
     _fields_ = [("rate", C.c_float), ("NumAln", C.c_int), ("alnthres", C.c_float), ("readLen", C.c_int),
                 ("gapopen", C.c_float), ("gapextend", C.c_float), ("gaproot", C.c_float),
-                ("gapCeiling1", C.c_int), ("gapCeiling2", C.c_int)]
+                ("gapCeiling1", C.c_int), ("gapCeiling2", C.c_int), ("mode", C.c_int)]
 
 
 # -ONT preset (lra.cpp:388-420) + Options.h defaults
-SDP_ONT = dict(rate=20.0, NumAln=2, alnthres=0.7, gapopen=7.0, gapextend=10.0, gaproot=1.5, gapCeiling1=1500, gapCeiling2=3000)
+SDP_ONT = dict(rate=20.0, NumAln=2, alnthres=0.7, gapopen=7.0, gapextend=10.0, gaproot=1.5, gapCeiling1=1500, gapCeiling2=3000, mode=0)
 
 
 def sdp_opts(read_len, **kw):
     d = dict(SDP_ONT); d.update(kw)
     return SdpOpts(d["rate"], d["NumAln"], d["alnthres"], int(read_len), d["gapopen"], d["gapextend"], d["gaproot"],
-                   d["gapCeiling1"], d["gapCeiling2"])
+                   d["gapCeiling1"], d["gapCeiling2"], d["mode"])
 
 
 def sdp_divide_dump(q, t, ind, inv, want_text=False):
@@ -331,3 +331,32 @@ def sdp_chain(cluster_off, cluster_strand, q, t, length, opts: "SdpOpts"):
         a, b = coff[c], coff[c + 1]
         chains.append(dict(frags=cf[a:b].copy(), link=cl[a:b - 1].copy(), box=box[4 * c:4 * c + 4].copy(), value=float(cv[c])))
     return dict(status=r, val=val[:n], prev_sub=ps[:n], prev_ind=pi[:n], flags=fl[:n], chains=chains)
+
+
+# ---- chain post-filters + SPLITChain (a9, low-accuracy path) ----------------------------------------------------------
+def split_chain(q, t, length, strand, cluster, link, chrom_pos, splitdist=50000, bypass=1):
+    """One chain (trace-back order) -> dict(keep, link, splits=[dict(idx, link, type, strand, chrom, box, clusters)], split_link) or None (UB)."""
+    L = lib()
+    q = np.ascontiguousarray(q, np.uint32); t = np.ascontiguousarray(t, np.uint32); ln = np.ascontiguousarray(length, np.int32)
+    st = np.ascontiguousarray(strand, np.uint8); cl = np.ascontiguousarray(cluster, np.int32); lk = np.ascontiguousarray(link, np.uint8)
+    pos = np.ascontiguousarray(chrom_pos, np.uint64)
+    n = len(q)
+    m = max(1, n)
+    keep = np.zeros(m, np.uint8); nk = C.c_int(0); lo = np.zeros(m, np.uint8)
+    spOff = np.zeros(m + 2, np.int32); spIdx = np.zeros(m, np.int32); spLink = np.zeros(m, np.uint8); spType = np.zeros(m + 1, np.int8)
+    spStrand = np.zeros(m + 1, np.uint8); spChrom = np.zeros(m + 1, np.int32); spBox = np.zeros(4 * (m + 1), np.uint32)
+    ciOff = np.zeros(m + 2, np.int32); ciIdx = np.zeros(m, np.int32); sl = np.zeros(m + 1, np.uint8); nsl = C.c_int(0)
+    L.oracle_split_chain.restype = C.c_int
+    r = L.oracle_split_chain(C.c_int(n), _p(q, C.c_uint32), _p(t, C.c_uint32), _p(ln, C.c_int), _p(st, C.c_uint8), _p(cl, C.c_int), _p(lk, C.c_uint8),
+                             _p(pos, C.c_uint64), C.c_int(len(pos)), C.c_int(splitdist), C.c_int(bypass), _p(keep, C.c_uint8), C.byref(nk),
+                             _p(lo, C.c_uint8), _p(spOff, C.c_int), _p(spIdx, C.c_int), _p(spLink, C.c_uint8), spType.ctypes.data_as(C.c_char_p),
+                             _p(spStrand, C.c_uint8), _p(spChrom, C.c_int), _p(spBox, C.c_uint32), _p(ciOff, C.c_int), _p(ciIdx, C.c_int),
+                             _p(sl, C.c_uint8), C.byref(nsl))
+    if r < 0:
+        return None
+    splits = []
+    for k in range(r):
+        a, b = spOff[k], spOff[k + 1]
+        splits.append(dict(idx=spIdx[a:b].copy(), link=spLink[a:b - 1].copy() if b > a else spLink[0:0].copy(), type=chr(spType[k]), strand=int(spStrand[k]),
+                           chrom=int(spChrom[k]), box=spBox[4 * k:4 * k + 4].copy(), clusters=ciIdx[ciOff[k]:ciOff[k + 1]].copy()))
+    return dict(keep=keep[:n].copy(), n_kept=nk.value, link=lo[:max(nk.value - 1, 0)].copy(), splits=splits, split_link=sl[:nsl.value].copy())

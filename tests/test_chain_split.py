@@ -1,0 +1,112 @@
+"""a9 (low-accuracy path): RemoveSpuriousJump + SPLITChain + MergeSplitchainINS + RemoveSpuriousSplitChain.
+Oracle sanity on CPU (parity unpinned: Chain.h / Mapping_ultility.h need htslib); HIP vs oracle on the GPU."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+import oracle_lib as O
+
+CHROM = [0, 3_000_000, 6_000_000]
+
+
+def _random_chain(rng, n, kind):
+    """anchors in trace-back order (q descending)"""
+    q = 200_000; t = int(rng.integers(1_000_000, 2_000_000)); strand = int(rng.random() < 0.3)
+    t_home = t
+    Q = []; T = []; L = []; S = []; CL = []; LK = []
+    cl = 0
+    for i in range(n):
+        ln = int(rng.choice([17, 20, 30, 45, 60, 120]))
+        Q.append(q); T.append(t); L.append(ln); S.append(strand); CL.append(cl)
+        if i < n - 1: LK.append(int(rng.random() < 0.1))
+        u = rng.random()
+        q -= ln + int(rng.integers(0, 150))
+        step = ln + int(rng.integers(0, 150))
+        if kind >= 1 and u < 0.08:                       # diagonal jump > 100 (an SV), often paired with the opposite one right after
+            step += int(rng.choice([-400, -150, 150, 400, 900]))
+        if kind >= 2 and u > 0.93:                       # far jump and maybe back (translocation-like), or a strand flip
+            v = rng.random()
+            if v < 0.4: t = t + int(rng.choice([-1, 1])) * int(rng.integers(60_000, 400_000)); cl += 1
+            elif v < 0.7: t = t_home - (200_000 - q) + int(rng.integers(-800, 800)); cl += 1
+            else: strand ^= 1; cl += 1
+        if kind >= 3 and u > 0.985: t = 3_000_000 - int(rng.integers(0, 60)); cl += 1   # straddle the chromosome boundary
+        if kind >= 1 and 0.5 < u < 0.53: q -= int(rng.integers(1000, 5000)); step += int(rng.integers(1000, 5000))   # long collinear gap
+        t = t - step if strand == 0 else t + step
+        t = max(1, min(t, 5_999_000))
+        if rng.random() < 0.2: cl += 1
+    return (np.array(Q, np.uint32), np.array(T, np.uint32), np.array(L, np.int32), np.array(S, np.uint8), np.array(CL, np.int32), np.array(LK, np.uint8))
+
+
+def test_oracle_split_sanity():
+    # one forward chain on a diagonal, a 80 kb jump, five more anchors: a 'T' piece and an 'N' piece, forward pieces listed first-to-last
+    q = []; t = []
+    qq = 5000; tt = 1_000_000
+    for i in range(10): q.append(qq); t.append(tt); qq -= 100; tt -= 100
+    tt -= 80000
+    for i in range(5): q.append(qq); t.append(tt); qq -= 100; tt -= 100
+    n = len(q)
+    r = O.split_chain(q, t, [30] * n, [0] * n, [0] * 10 + [1] * 5, [0] * (n - 1), [0, 50_000_000])
+    assert r["n_kept"] == n and [s["type"] for s in r["splits"]] == ["T", "N"]
+    assert r["splits"][0]["idx"].tolist() == list(range(9, -1, -1)) and r["splits"][1]["clusters"].tolist() == [1]
+    assert r["split_link"].tolist() == [0]
+    # paired opposite jumps one anchor apart: the short anchor between them goes (RemoveSpuriousJump)
+    q = [1000, 900, 800, 700, 600]; t = [5000, 4900, 4500, 4700, 4600]
+    r = O.split_chain(q, t, [20] * 5, [0] * 5, [0] * 5, [0] * 4, [0, 50_000_000])
+    assert r["keep"].tolist() == [1, 1, 0, 1, 1]
+
+
+@pytest.mark.gpu
+def test_hip_split_chains_oracle(ctx):
+    import torch
+    from lra_amd import chain
+    rng = np.random.default_rng(3)
+    num_aln = 2
+    chains = []
+    for k in range(400):
+        chains.append(_random_chain(rng, int(rng.integers(1, 120)), kind=k % 4))
+    n_reads = len(chains) // num_aln
+    # fake lra_chain_result: slot s = chains[s]
+    start = [0]
+    for c in chains: start.append(start[-1] + len(c[0]))
+    cat = lambda j, dt: np.concatenate([c[j] for c in chains]).astype(dt)
+    link = np.concatenate([np.concatenate([c[5], [0]]) for c in chains]).astype(np.uint8)
+    dev = ctx.device
+    tt = lambda a: torch.tensor(a, device=dev)
+    bufs = dict(n_chains=tt(np.full(n_reads, num_aln, np.int32)), start=tt(np.array(start[:-1], np.int64)), length=tt(np.array([len(c[0]) for c in chains], np.int32)),
+                q=tt(cat(0, np.int64)).to(torch.int32), t=tt(cat(1, np.int64)).to(torch.int32), ln=tt(cat(2, np.int32)), st=tt(cat(3, np.uint8)), cl=tt(cat(4, np.int32)), lk=tt(link))
+    res = chain.ChainResult()
+    res.n_reads = n_reads; res.num_aln = num_aln; res.n_frags = start[-1]
+    res.d_n_chains = bufs["n_chains"].data_ptr(); res.d_chain_start = bufs["start"].data_ptr(); res.d_chain_len = bufs["length"].data_ptr()
+    res.d_chain_q = bufs["q"].data_ptr(); res.d_chain_t = bufs["t"].data_ptr(); res.d_chain_alen = bufs["ln"].data_ptr(); res.d_chain_strand = bufs["st"].data_ptr()
+    res.d_chain_cluster = bufs["cl"].data_ptr(); res.d_chain_link = bufs["lk"].data_ptr()
+    for splitdist, bypass in ((50000, 1), (50000, 0)):
+        sres = chain.split_chains_batch(ctx, res, CHROM, splitdist, bypass)
+        out = chain.fetch_split(ctx, sres)
+        n_t = n_i = n_merge = 0
+        for s, c in enumerate(chains):
+            exp = O.split_chain(c[0], c[1], c[2], c[3], c[4], c[5], CHROM, splitdist, bypass)
+            b = start[s]
+            if exp is None:
+                assert out["status"][s] != 0
+                continue
+            assert out["status"][s] == 0, s
+            n = len(c[0])
+            assert out["keep"][b:b + n].tolist() == exp["keep"].tolist(), s
+            assert out["n_kept"][s] == exp["n_kept"]
+            assert out["link"][b:b + max(exp["n_kept"] - 1, 0)].tolist() == exp["link"].tolist(), s
+            assert out["n_split"][s] == len(exp["splits"]), (s, out["n_split"][s], len(exp["splits"]))
+            for k, e in enumerate(exp["splits"]):
+                x = b + k
+                a0, m = b + int(out["sp_beg"][x]), int(out["sp_len"][x])
+                assert out["sp_idx"][a0:a0 + m].tolist() == e["idx"].tolist(), (s, k)
+                assert out["sp_link"][a0:a0 + m - 1].tolist() == e["link"].tolist(), (s, k)
+                assert chr(out["sp_type"][x]) == e["type"] and out["sp_strand"][x] == e["strand"] and out["sp_chrom"][x] == e["chrom"], (s, k)
+                assert out["sp_box"][x].tolist() == e["box"].tolist(), (s, k)
+                c0, cm = b + int(out["ci_beg"][x]), int(out["ci_len"][x])
+                assert out["ci_idx"][c0:c0 + cm].tolist() == e["clusters"].tolist(), (s, k)
+                n_t += e["type"] == "T"; n_i += e["type"] == "I"
+                n_merge += int(np.any(np.abs(np.diff(e["idx"].astype(np.int64))) > 1))
+            assert out["n_split_link"][s] == len(exp["split_link"])
+            assert out["split_link"][b:b + len(exp["split_link"])].tolist() == exp["split_link"].tolist(), s
+        assert n_t > 10 and n_i > 10 and n_merge > 0, (n_t, n_i, n_merge)

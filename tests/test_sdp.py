@@ -140,6 +140,21 @@ def test_hip_sdp_random_clusters(ctx):
 
 
 @pytest.mark.gpu
+def test_hip_sdp_single_cluster_mode(ctx):
+    """SparseDP(ClusterIndex, ...) (SparseDP.h:2287, Map_lowacc.h:535): one cluster per job, first maximum, plain trace back"""
+    rng = np.random.default_rng(5)
+    jobs = []
+    for k in range(120):
+        ties = k < 40
+        offs, st, q, t, ln = _random_clusters(rng, 1, int(rng.integers(1, 60)), 12 if ties else 5000, ties)
+        jobs.append((offs, st, q, t, ln))
+    read_lens = [1000] * len(jobs)
+    kw = dict(mode=1, NumAln=1, rate=6.0)                                 # second_anchorbonus of the -ONT / -CLR presets
+    res, out = _run_hip(ctx, jobs, read_lens, kw)
+    assert _compare(out, res.num_aln, jobs, read_lens, kw) == len(jobs)
+
+
+@pytest.mark.gpu
 def test_hip_sdp_on_oracle_pipeline_reads(ctx):
     """30 kb ONT-like reads through the oracle's a1-a7, then SDP#A on the GPU vs. the oracle"""
     from lra_amd import synth
