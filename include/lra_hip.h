@@ -339,6 +339,30 @@ int lra_calculate_statistics_batch(lra_ctx* ctx, int n_aln, const int32_t* d_blo
                                    const char* d_tseq, const uint64_t* d_t_off, const float* h_lookup, int n_lookup,
                                    lra_stats_result* out);
 
+/* ---- a17: SAM / PAF / BED records (host code, no device work) ------------------------------------------
+ * Byte-for-byte the text of  Alignment::PrintSAM (Alignment.h:658-808), SimplePrintSAM (:811-905), PrintPAF (:600-656) and
+ * PrintBed (:591-598) for alignments described by plain records (the fields those functions read).  Tags in the reference's order:
+ * SAM  NM MM NX ND TD NI TI NV AS AO N0 RT TP SD ME LD SI MI LI [SA];  simple SAM  RT NM NX ND TD NI TI N0 NV AS AO;
+ * PAF  OR NM NX ND TD NI TI SD ME LD SI MI LI N0 NV AS TP [NA] [RT] [CG].  opts.printMD is not supported (the MD string needs the
+ * alignment strings).  n_blocks == 0 prints the unaligned record.  lra_format_sam prints segment `as` of the group and lists the other
+ * segments, last to first, in SA:Z.  passthrough: the text appended when opts.passthroughtag is set (NULL otherwise).
+ * Output: at most cap bytes into out (no terminator); *len = bytes needed.  Returns LRA_ERR_INVALID if cap < *len.            */
+typedef struct lra_aln_record {
+  const char* read_name; const char* read; const char* qual;   /* qual: NULL, "*" or read_len quality characters (NUL-terminated) */
+  int32_t read_len;
+  const char* chrom; uint32_t genome_len;                      /* Alignment::chrom, genomeLen */
+  const char* cigar;
+  uint32_t flag; int32_t strand; uint32_t mapqv; int32_t supplementary, typeofaln;
+  uint32_t q_start, q_end, t_start, t_end; int32_t pre_clip, suf_clip;
+  int32_t nm, nmm, nins, ndel, tdel, tins, nSmallDel, nMedDel, nLargeDel, nSmallIns, nMedIns, nLargeIns;
+  float value; int32_t order, NumOfAnchors0, NumOfAnchors1, runtime;
+  int32_t n_blocks; uint32_t first_block_qpos, last_block_qend;   /* blocks[0].qPos and blocks[last].qPos + length (hard-clipped substrings) */
+} lra_aln_record;
+int lra_format_sam(const lra_aln_record* group, int n_group, int as, int hard_clip, const char* passthrough, char* out, uint64_t cap, uint64_t* len);
+int lra_format_sam_simple(const lra_aln_record* rec, int hard_clip, const char* passthrough, char* out, uint64_t cap, uint64_t* len);
+int lra_format_paf(const lra_aln_record* rec, int print_cigar, char* out, uint64_t cap, uint64_t* len);
+int lra_format_bed(const lra_aln_record* rec, char* out, uint64_t cap, uint64_t* len);
+
 #ifdef __cplusplus
 }
 #endif

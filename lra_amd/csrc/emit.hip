@@ -1,0 +1,133 @@
+// lra_amd/csrc/emit.hip -- SURVEY §8a row a17: the text records.  Host code only (iostream formatting with the same libstdc++ the
+// reference uses, so `float` fields print identically); kept in the library so that a caller holding device results gets the
+// reference's exact SAM / PAF / BED lines without linking the reference's Alignment class.
+//   Alignment::PrintBed :591-598, PrintPAF :600-656, PrintSAM :658-808, SimplePrintSAM :811-905   (Alignment.h)
+#include "common.h"
+#include <sstream>
+#include <string>
+#include <string.h>
+
+namespace {
+
+int deliver(const std::string& s, char* out, uint64_t cap, uint64_t* len) {
+  if (len) *len = s.size();
+  if (!out || cap < s.size()) return LRA_ERR_INVALID;
+  memcpy(out, s.data(), s.size());
+  return LRA_OK;
+}
+
+const char* tp_of(int typeofaln) { return typeofaln == 0 ? "P" : typeofaln == 1 ? "S" : "I"; }
+
+void clipped_cigar(std::ostream& o, const lra_aln_record& r, char clipOp) {
+  if (r.pre_clip > 0) o << r.pre_clip << clipOp;
+  o << (r.cigar ? r.cigar : "");
+  if (r.suf_clip > 0) o << r.suf_clip << clipOp;
+}
+
+void unaligned_record(std::ostream& o, const lra_aln_record& r) {      // :663-681, :815-833
+  o << "4\t*\t0\t0\t*\t*\t0\t0\t";
+  o.write(r.read, r.read_len);
+  o << "\t";
+  if (r.qual == nullptr) o << "*";
+  else o << std::string(r.qual, (size_t)r.read_len);
+}
+
+}  // namespace
+
+extern "C" int lra_format_bed(const lra_aln_record* r, char* out, uint64_t cap, uint64_t* len) {
+  if (!r) return LRA_ERR_INVALID;
+  std::ostringstream o;
+  o << r->chrom << "\t" << r->t_start << "\t" << r->t_end << "\t" << (int)(unsigned char)r->mapqv << "\t" << r->read_name << "\t" << r->read_len << "\t"
+    << r->q_start << "\t" << r->q_end << "\t" << r->nm << "\t" << r->nmm << "\t" << r->nins << "\t" << r->ndel << "\t" << r->value << "\t" << r->flag << "\t"
+    << r->NumOfAnchors1 << "\t" << r->NumOfAnchors1 / (float)r->read_len << std::endl;
+  return deliver(o.str(), out, cap, len);
+}
+
+extern "C" int lra_format_paf(const lra_aln_record* r, int print_cigar, char* out, uint64_t cap, uint64_t* len) {
+  if (!r) return LRA_ERR_INVALID;
+  std::ostringstream o;
+  const char strandChar = r->strand == 1 ? '-' : '+';
+  o << r->read_name << "\t" << r->read_len << "\t";
+  if (r->strand == 0) o << r->q_start << "\t" << r->q_end << "\t";
+  else o << (uint32_t)((uint32_t)r->read_len - r->q_end) << "\t" << (uint32_t)((uint32_t)r->read_len - r->q_start) << "\t";
+  o << strandChar << "\t" << r->chrom << "\t" << r->genome_len << "\t" << r->t_start << "\t" << r->t_end << "\t" << r->nm << "\t"
+    << r->nm + r->nmm + r->ndel + r->nins << "\t" << (int)(unsigned char)r->mapqv;
+  o << "\tOR:i:" << r->order << "\tNM:i:" << r->nmm + r->ndel + r->nins << "\tNX:i:" << r->nmm << "\tND:i:" << r->ndel << "\tTD:i:" << r->tdel
+    << "\tNI:i:" << r->nins << "\tTI:i:" << r->tins << "\tSD:i:" << r->nSmallDel << "\tME:i:" << r->nMedDel << "\tLD:i:" << r->nLargeDel
+    << "\tSI:i:" << r->nSmallIns << "\tMI:i:" << r->nMedIns << "\tLI:i:" << r->nLargeIns << "\tN0:i:" << r->NumOfAnchors0 << "\tNV:f:" << r->value
+    << "\tAS:i:" << (int)r->value << "\tTP:A:" << tp_of(r->typeofaln);
+  if (r->NumOfAnchors1 > 0) o << "\tNA:i:" << r->NumOfAnchors1;
+  if (r->runtime > 0) o << "\tRT:i:" << r->runtime;
+  if (print_cigar) { o << "\tCG:z:"; clipped_cigar(o, *r, 'S'); }
+  o << std::endl;
+  return deliver(o.str(), out, cap, len);
+}
+
+extern "C" int lra_format_sam(const lra_aln_record* g, int n_group, int as, int hard_clip, const char* passthrough, char* out, uint64_t cap,
+                              uint64_t* len) {
+  if (!g || n_group < 1 || as < 0 || as >= n_group) return LRA_ERR_INVALID;
+  const lra_aln_record& r = g[as];
+  std::ostringstream o;
+  o << r.read_name << "\t";
+  if (r.n_blocks == 0) unaligned_record(o, r);
+  else {
+    o << (unsigned int)r.flag << "\t" << r.chrom << "\t" << (uint32_t)(r.t_start + 1) << "\t" << (unsigned int)(unsigned char)r.mapqv << "\t";
+    clipped_cigar(o, r, (r.supplementary && hard_clip) ? 'H' : 'S');
+    o << "\t*\t0\t" << (uint32_t)(r.t_end - r.t_start) << "\t";
+    if (!r.supplementary) o.write(r.read, r.read_len);
+    else if (hard_clip) o.write(r.read + r.q_start, (std::streamsize)(r.q_end - r.q_start));
+    else o.write(r.read, r.read_len);
+    std::string qualStr;
+    if (r.qual == nullptr || r.qual[0] == '*') qualStr = "*";
+    else if (r.supplementary && hard_clip) qualStr = std::string(std::string(r.qual), r.first_block_qpos, r.last_block_qend - r.first_block_qpos);
+    else qualStr.assign(r.qual, (size_t)r.read_len);
+    o << "\t";
+    if (r.qual == nullptr) o << "*"; else o << qualStr;
+    o << "\tNM:i:" << r.nmm + r.ndel + r.nins << "\tMM:i:" << r.nmm + r.ndel + r.nins << "\tNX:i:" << r.nmm << "\tND:i:" << r.ndel << "\tTD:i:" << r.tdel
+      << "\tNI:i:" << r.nins << "\tTI:i:" << r.tins << "\tNV:f:" << r.value << "\tAS:i:" << (int)r.value << "\tAO:i:" << r.order
+      << "\tN0:i:" << r.NumOfAnchors0 << "\tRT:i:" << r.runtime << "\tTP:A:" << tp_of(r.typeofaln)
+      << "\tSD:i:" << r.nSmallDel << "\tME:i:" << r.nMedDel << "\tLD:i:" << r.nLargeDel << "\tSI:i:" << r.nSmallIns << "\tMI:i:" << r.nMedIns
+      << "\tLI:i:" << r.nLargeIns;
+    if (n_group > 1) o << "\tSA:Z:";
+    for (int ag = n_group - 1; ag >= 0; ag--) {
+      if (ag == as) continue;
+      o << g[ag].chrom << "," << (uint32_t)(g[ag].t_start + 1) << "," << (g[ag].strand == 0 ? "+" : "-") << ",";
+      clipped_cigar(o, g[ag], 'S');
+      o << "," << (unsigned int)(unsigned char)g[ag].mapqv << "," << (int)g[ag].nm << ";";
+    }
+  }
+  if (passthrough) o << "\t" << passthrough;
+  o << std::endl;
+  return deliver(o.str(), out, cap, len);
+}
+
+extern "C" int lra_format_sam_simple(const lra_aln_record* rp, int hard_clip, const char* passthrough, char* out, uint64_t cap, uint64_t* len) {
+  if (!rp) return LRA_ERR_INVALID;
+  const lra_aln_record& r = *rp;
+  std::ostringstream o;
+  o << r.read_name << "\t";
+  if (r.n_blocks == 0) unaligned_record(o, r);
+  else {
+    o << (unsigned int)r.flag << "\t" << r.chrom << "\t" << (uint32_t)(r.t_start + 1) << "\t" << (unsigned int)(unsigned char)r.mapqv << "\t";
+    clipped_cigar(o, r, hard_clip ? 'H' : 'S');
+    o << "\t*\t0\t" << (uint32_t)(r.t_end - r.t_start) << "\t";
+    std::string qualStr;
+    if (hard_clip) {
+      o << std::string(r.read + r.first_block_qpos, r.last_block_qend - r.first_block_qpos);
+      if (r.qual != nullptr && strncmp(r.qual, "*", 1) != 0) qualStr = std::string(r.qual + r.first_block_qpos, r.last_block_qend - r.first_block_qpos);
+      else qualStr = "*";
+    } else {
+      o << std::string(r.read, (size_t)r.read_len);
+      if (r.qual == nullptr || r.qual[0] == '*') qualStr = "*";       // the reference dereferences qual here; NULL never reaches it
+      else qualStr.assign(r.qual, (size_t)r.read_len);
+    }
+    o << "\t";
+    if (r.qual == nullptr) o << "*"; else o << qualStr;
+    o << "\tRT:i:" << r.runtime << "\tNM:i:" << r.nmm + r.ndel + r.nins << "\tNX:i:" << r.nmm << "\tND:i:" << r.ndel << "\tTD:i:" << r.tdel
+      << "\tNI:i:" << r.nins << "\tTI:i:" << r.tins << "\tN0:i:" << r.NumOfAnchors0 << "\tNV:f:" << r.value << "\tAS:i:" << (int)r.value
+      << "\tAO:i:" << r.order;
+  }
+  if (passthrough) o << "\t" << passthrough;
+  o << std::endl;
+  return deliver(o.str(), out, cap, len);
+}
