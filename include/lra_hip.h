@@ -270,6 +270,26 @@ int lra_local_compare_batch(lra_ctx* ctx, uint64_t n_tasks, const uint32_t* d_q_
                             const uint32_t* d_t_tuples, const uint64_t* d_t_lo, const uint64_t* d_t_hi, int max_freq,
                             const int64_t* d_max_diag, const int64_t* d_min_diag, lra_local_pairs_result* out);
 
+/* ---- a11: anchors inside one gap ------------------------------------------------------------------------
+ * Replaces   float RefineSpace(int K, int W, int refineSpaceDiag, bool consider_str, GenomePairs& EndPairs, const Options& opts,
+ *                              Genome&, Read&, char* strands[2], int& ChromIndex, GenomePos qe, GenomePos qs, GenomePos te, GenomePos ts,
+ *                              bool st, GenomePos lrts = 0, GenomePos lrlength = 0)                     (ClusterRefine.h:242-325)
+ * for n gaps.  Gap p: query = d_qseq[q_off .. + q_len) (= strands[st] + qs, q_len = qe - qs), target = d_tseq[t_off .. + t_len)
+ * (= genome.seqs[ChromIndex] + (ts - lrts), t_len = te - ts + lrlength), t_span = te - (ts - lrts) (GenomePos arithmetic, used for the
+ * diagonal band), K / W / diag = refineSpaceDiag per gap, q_add = qs, t_add = ts - lrts, flip_len = read.length if (consider_str and
+ * st == 1) else 0.  match / mismatch / indel = opts.localMatch / localMismatch / localIndel, max_freq = opts.localMaxFreq of the
+ * Options the caller passes (CompareLists with Global = false).  Output (context-owned): EndPairs as (first.pos, second.pos) CSR by gap,
+ * in the reference's order; identity (the return value: matching bases / min(span) when both spans are < 1000, else -1); status (the
+ * AffineOneGapAlign status bits, LRA_ST_RANGE for W > 32).  Synchronous.                                                      */
+typedef struct lra_refine_space_result {
+  uint64_t n_problems, n_pairs, n_small;
+  const uint64_t* d_pair_off; const uint32_t* d_pair_q; const uint32_t* d_pair_t; const float* d_identity; const uint32_t* d_status;
+} lra_refine_space_result;
+int lra_refine_space_batch(lra_ctx* ctx, int n, const char* d_qseq, const uint64_t* d_q_off, const int32_t* d_q_len, const char* d_tseq,
+                           const uint64_t* d_t_off, const int32_t* d_t_len, const uint32_t* d_t_span, const int32_t* d_K, const int32_t* d_W,
+                           const int32_t* d_diag, const uint32_t* d_q_add, const uint32_t* d_t_add, const uint32_t* d_flip_len, int match,
+                           int mismatch, int indel, int max_freq, lra_refine_space_result* out);
+
 /* ---- a12: banded one-gap seed-extension DP ------------------------------------------
  * Replaces   int AffineOneGapAlign(string& qSeq, int qLen, string& tSeq, int tLen,
  *                                  int m, int mm, int indel, int k, Alignment& aln,

@@ -1,0 +1,351 @@
+// lra_amd/csrc/refine_space.hip -- SURVEY §8a row a11, the gap-seeding function RefineSpace (ClusterRefine.h:242-325) for a batch
+// of (read span x genome span) gaps.  gfx950 only.
+//   both spans < 1000:  AffineOneGapAlign(query, ref, localMatch, localMismatch, localIndel, 30) (aog.hip), then the exact K-mers every
+//                       K bases of its blocks and identity = matching bases / min(span)                      :262-292
+//   otherwise:          StoreMinimizers_noncanonical<GenomeTuple,Tuple> (MinCount.h:182-338) of both spans, std::sort (the library's
+//                       libstdc++-exact sort), CompareLists<GenomeTuple,Tuple> with the diagonal band        :305-311
+//   then "+= qs", "+= ts - lrts" and the reverse-strand flip                                                  :313-323
+// Mapping: the short-gap branch (the common one: gaps between chained anchors) is the batched AffineOneGapAlign plus one lane per gap
+// for the K-mer scan; the long-gap branch runs one lane per (gap, side) for the sketch and one lane per gap for the list walk --
+// literal serial code, it is rare and bounded by refineSpaceDist.  Algorithmic bytes: qLen + tLen + 12 per block + 8 per pair.
+#include "common.h"
+#include "scan.h"
+#include <algorithm>
+
+int lra_aog_launch_device(lra_ctx* ctx, int n, const char* d_qseq, const char* d_tseq, const uint64_t* d_q_off, const int32_t* d_q_len,
+                          const uint64_t* d_t_off, const int32_t* d_t_len, const int32_t* d_k, int m, int mm, int indel, int32_t* d_score,
+                          int32_t* d_nblocks, int32_t* d_blocks, const uint64_t* d_block_off, int32_t* d_status);
+
+namespace {
+
+constexpr uint64_t FOR_MASK = 0x7FFFFFFFFFFFFFFFULL;
+constexpr int MAX_W = 32;
+
+__device__ __forceinline__ int code_n(unsigned char c) {                 // seqMapN (SeqUtils.h:42-75)
+  if (c < 8) return c & 3;
+  switch (c) { case 'A': case 'a': return 0; case 'C': case 'c': return 1; case 'G': case 'g': return 2; case 'T': case 't': return 3; default: return 4; }
+}
+__device__ __forceinline__ int code(unsigned char c) { const int v = code_n(c); return v > 3 ? 0 : v; }   // seqMap
+
+struct RsArgs {
+  int n;
+  const char* qseq; const char* tseq; const uint64_t* q_off; const int32_t* q_len; const uint64_t* t_off; const int32_t* t_len;
+  const uint32_t* t_span; const int32_t* K; const int32_t* W; const int32_t* diag; const uint32_t* q_add; const uint32_t* t_add; const uint32_t* flip;
+  long maxFreq;
+  // classification
+  uint32_t* isSmall; uint64_t* smallPos; uint32_t* smallIdx; uint32_t* largeIdx;   // smallPos: exclusive scan of isSmall
+  // small branch (compact, indexed by position among the small ones)
+  uint64_t* sq_off; int32_t* sq_len; uint64_t* st_off; int32_t* st_len; int32_t* sk; uint32_t* bcap; const uint64_t* boff;
+  const int32_t* nblocks; const int32_t* blocks; const int32_t* aogStatus;
+  // large branch: lists 2*j (target), 2*j+1 (query) of large problem j
+  uint32_t* lcnt; const uint64_t* loff; uint64_t* lkey; uint32_t* lpos;
+  // output
+  uint32_t* cnt; const uint64_t* pair_off; uint32_t* outQ; uint32_t* outT; float* identity; uint32_t* status;
+};
+
+__global__ void rs_classify(RsArgs a) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= a.n) return;
+  a.isSmall[i] = (a.q_len[i] < 1000 && a.t_len[i] < 1000) ? 1u : 0u;   // querySeq.size() < 1000 and refSeq.size() < 1000  :262
+  a.status[i] = 0; a.identity[i] = -1.f; a.cnt[i] = 0;
+}
+
+__global__ void rs_split(RsArgs a) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= a.n) return;
+  const uint64_t sp = a.smallPos[i];
+  if (a.isSmall[i]) {
+    a.smallIdx[sp] = (uint32_t)i;
+    a.sq_off[sp] = a.q_off[i]; a.sq_len[sp] = a.q_len[i]; a.st_off[sp] = a.t_off[i]; a.st_len[sp] = a.t_len[i]; a.sk[sp] = 30;
+    a.bcap[sp] = (uint32_t)(a.q_len[i] + a.t_len[i] + 8);
+  } else a.largeIdx[(uint64_t)i - sp] = (uint32_t)i;
+}
+
+// short gaps: matching bases and exact K-mers of the AffineOneGapAlign blocks (:265-291)
+template <bool EMIT>
+__global__ void rs_small(RsArgs a, int nSmall) {
+  const int s = blockIdx.x * blockDim.x + threadIdx.x;
+  if (s >= nSmall) return;
+  const uint32_t i = a.smallIdx[s];
+  const char* q = a.qseq + a.q_off[i]; const char* t = a.tseq + a.t_off[i];
+  const int K = a.K[i];
+  const int32_t* B = a.blocks + 3 * a.boff[s];
+  const int nb = a.nblocks[s];
+  int nMatch = 0; uint32_t np = 0;
+  const uint64_t o = EMIT ? a.pair_off[i] : 0;
+  const uint32_t qAdd = a.q_add[i], tAdd = a.t_add[i], flip = a.flip[i];
+  for (int b = 0; b < nb; b++) {
+    const int bq = B[3 * b], bt = B[3 * b + 1], bl = B[3 * b + 2];
+    if (!EMIT) for (int x = 0; x < bl; x++) nMatch += q[bq + x] == t[bt + x];
+    if (bl > K)
+      for (int bp = 0; bp + K < bl; bp += K) {
+        bool mis = false;
+        for (int x = 0; x < K; x++) if (t[bt + bp + x] != q[bq + bp + x]) { mis = true; break; }
+        if (!mis) {
+          if (EMIT) { uint32_t pq = (uint32_t)(bq + bp) + qAdd; if (flip) pq = flip - pq - (uint32_t)K; a.outQ[o + np] = pq; a.outT[o + np] = (uint32_t)(bt + bp) + tAdd; }
+          np++;
+        }
+      }
+  }
+  if (!EMIT) {
+    a.cnt[i] = np;
+    a.identity[i] = nMatch / (float)min(a.q_len[i], a.t_len[i]);
+    if (a.aogStatus[s]) a.status[i] |= (uint32_t)a.aogStatus[s];
+  }
+}
+
+// long gaps: StoreMinimizers_noncanonical<GenomeTuple,Tuple>(seq, seqLen, K, W, out, false)   MinCount.h:182-338
+template <bool EMIT>
+__global__ void rs_sketch(RsArgs a, int nLarge) {
+  const int l = blockIdx.x * blockDim.x + threadIdx.x;
+  if (l >= 2 * nLarge) return;
+  const uint32_t i = a.largeIdx[l >> 1];
+  const bool isQ = l & 1;
+  const unsigned char* seq = (const unsigned char*)(isQ ? a.qseq + a.q_off[i] : a.tseq + a.t_off[i]);
+  const uint32_t seqLen = (uint32_t)(isQ ? a.q_len[i] : a.t_len[i]);
+  const int k = a.K[i], w = a.W[i];
+  uint32_t n = 0;
+  const uint64_t o = EMIT ? a.loff[l] : 0;
+  auto emit = [&](uint64_t t, uint32_t p) { if (EMIT) { a.lkey[o + n] = t; a.lpos[o + n] = p; } n++; };
+  auto done = [&]() { if (!EMIT) a.lcnt[l] = n; };
+  if (w > MAX_W || w < 1 || k < 1 || k > 31) { if (!EMIT) { a.lcnt[l] = 0; atomicOr(&a.status[i], (uint32_t)LRA_ST_RANGE); } return; }
+  if (seqLen < (uint32_t)k) { done(); return; }
+  const int span = w + k - 1;
+  if (seqLen < (uint32_t)span) { done(); return; }
+  uint64_t mask = 0;
+  for (int x = 0; x < k; x++) { mask <<= 2; mask += 3; }
+  long nvStart = 0, nvEnd = 0;
+  auto find_valid = [&]() -> bool {
+    bool valid = false;
+    while ((uint32_t)nvStart < seqLen - (uint32_t)span && !valid) {
+      valid = true;
+      for (long x = nvStart; valid && x < nvStart + span; x++) if (code_n(seq[x]) > 3) { nvStart = x + 1; valid = false; }
+    }
+    return valid;
+  };
+  if (!find_valid()) { done(); return; }
+  nvEnd = nvStart + span;
+  uint64_t cur = 0;
+  for (int p = 0; p < k; p++) { cur <<= 2; cur += (uint64_t)code(seq[p]); }
+  uint64_t ringT[MAX_W]; uint32_t ringP[MAX_W];
+  uint64_t actT = cur; uint32_t actP = 0;
+  ringT[0] = actT; ringP[0] = 0;
+  uint32_t p;
+  for (p = 1; p < (uint32_t)w && p < seqLen - k + 1; p++) {
+    cur = ((cur << 2) & mask) + (uint64_t)code(seq[p + k - 1]);
+    const uint64_t c = cur & FOR_MASK;
+    if (c < actT) { actT = c; actP = p; }
+    ringT[p % w] = c; ringP[p % w] = p;
+  }
+  if (nvEnd == span) emit(actT, actP);
+  for (p = w; p < seqLen - k + 1; p++) {
+    cur = ((cur << 2) & mask) + (uint64_t)code(seq[p + k - 1]);
+    const uint64_t c = cur & FOR_MASK;
+    if (nvEnd == (long)(p + k - 1)) {
+      if (code_n(seq[p + k - 1]) <= 3) nvEnd++;
+      else {
+        nvStart = p + k;
+        if (!find_valid()) { done(); return; }
+        nvEnd = nvStart + span;
+      }
+    }
+    ringT[p % w] = c; ringP[p % w] = p;
+    if (p - w >= actP) {
+      actT = ringT[0]; actP = ringP[0];
+      for (int j = 1; j < w; j++) if ((ringT[j] & FOR_MASK) < (actT & FOR_MASK)) { actT = ringT[j]; actP = ringP[j]; }
+      if (nvEnd == (long)(p + k)) emit(actT, actP);
+    } else if ((c & FOR_MASK) < (actT & FOR_MASK)) {
+      actT = c; actP = p;
+      if (nvEnd == (long)(p + k)) emit(actT, actP);
+    }
+  }
+  done();
+}
+
+// long gaps: CompareLists<GenomeTuple,Tuple>(query, target, ..., Global = false, maxDiagNum, minDiagNum, canonical = false)  CompareLists.h:9-146
+template <bool EMIT>
+__global__ void rs_compare(RsArgs a, int nLarge) {
+  const int j = blockIdx.x * blockDim.x + threadIdx.x;
+  if (j >= nLarge) return;
+  const uint32_t i = a.largeIdx[j];
+  const uint64_t* tk = a.lkey + a.loff[2 * j]; const uint32_t* tp = a.lpos + a.loff[2 * j];
+  const uint64_t* qk = a.lkey + a.loff[2 * j + 1]; const uint32_t* qp = a.lpos + a.loff[2 * j + 1];
+  const long nt = (long)(a.loff[2 * j + 1] - a.loff[2 * j]), nq = (long)(a.loff[2 * j + 2] - a.loff[2 * j + 1]);
+  const long long diag2 = (long long)a.t_span[i] - (long long)(uint32_t)a.q_len[i];
+  const long long minDiag = min(0LL, diag2) - a.diag[i], maxDiag = max(0LL, diag2) + a.diag[i];
+  const long maxFreq = a.maxFreq;
+  const int K = a.K[i];
+  const uint32_t qAdd = a.q_add[i], tAdd = a.t_add[i], flip = a.flip[i];
+  uint32_t n = 0;
+  const uint64_t o = EMIT ? a.pair_off[i] : 0;
+  auto emit = [&](long qi, long ti) {
+    if (maxDiag != 0 && minDiag != 0) {                                  // :87
+      const long long d = (long long)tp[ti] - (long long)qp[qi];
+      if (!(d <= maxDiag && d >= minDiag)) return;
+    }
+    if (EMIT) { uint32_t pq = qp[qi] + qAdd; if (flip) pq = flip - pq - (uint32_t)K; a.outQ[o + n] = pq; a.outT[o + n] = tp[ti] + tAdd; }
+    n++;
+  };
+#define Qk(x) (qk[x] & FOR_MASK)
+#define Tk(x) (tk[x] & FOR_MASK)
+  if (nq > 0 && nt > 0) {
+    long qs = 0, qe = nq - 1, ts = 0, te = nt;
+    do {
+      while (qs <= qe && Qk(qs) < Tk(ts)) qs++;                          // :47-49
+      if (qs >= qe) break;                                               // :51-53
+      const uint64_t startGap = Qk(qs) - Tk(ts);
+      while (qe > qs && te > ts && Qk(qe) > Tk(te - 1)) qe--;
+      const uint64_t endGap = Tk(te - 1) - Qk(qe);
+      if (startGap == 0 || (startGap & FOR_MASK) > (endGap & FOR_MASK)) {
+        const long tsOrig = ts, qsOrig = qs;
+        long lo = ts, hi = te;
+        while (lo < hi) { const long mid = lo + (hi - lo) / 2; if (Tk(mid) < Qk(qs)) lo = mid + 1; else hi = mid; }
+        ts = lo;
+        if (ts < te && Tk(ts) == Qk(qs)) {
+          const long tsStart = ts; long tsi = ts;
+          while (tsi != te && Qk(qs) == Tk(tsi)) tsi++;
+          const long qsStart = qs;
+          while (qs < qe && Qk(qs + 1) == Qk(qs)) qs++;
+          for (long ti = tsStart; ti != tsi; ti++)
+            if (qs - qsStart < maxFreq)
+              for (long qi = qsStart; qi <= qs; qi++) emit(qi, ti);
+        }
+        while (ts < te && tk[ts] == tk[tsOrig]) ts++;                    // :101 raw compare
+        while (qs < qe && qk[qs] == qk[qsOrig]) qs++;                    // :102
+      } else {
+        if (te != nt && Tk(te - 1) == Qk(qe)) {
+        } else {
+          long lo = ts, hi = te;
+          while (lo < hi) { const long mid = lo + (hi - lo) / 2; if (!(Qk(qe) < Tk(mid))) lo = mid + 1; else hi = mid; }
+          te = lo;
+        }
+        const long teStart = te; long tei = te;
+        while (tei > ts && Tk(tei - 1) == Qk(qe)) tei--;
+        if (tei < teStart && teStart > 0) {
+          const long qeStart = qe;
+          while (qe > qs && Qk(qe) == Qk(qe - 1)) qe--;
+          for (long ti = tei; ti < teStart; ti++)
+            if (qeStart - qe < maxFreq)
+              for (long qi = qe; qi <= qeStart; qi++) emit(qi, ti);
+        }
+        te = tei;
+      }
+    } while (qs < qe && ts < te);
+  }
+#undef Qk
+#undef Tk
+  if (!EMIT) a.cnt[i] = n;
+}
+
+inline size_t sz(size_t n, size_t e) { return (n * e + 255) / 256 * 256; }
+
+}  // namespace
+
+extern "C" int lra_refine_space_batch(lra_ctx* ctx, int n, const char* d_qseq, const uint64_t* d_q_off, const int32_t* d_q_len, const char* d_tseq,
+                                      const uint64_t* d_t_off, const int32_t* d_t_len, const uint32_t* d_t_span, const int32_t* d_K, const int32_t* d_W,
+                                      const int32_t* d_diag, const uint32_t* d_q_add, const uint32_t* d_t_add, const uint32_t* d_flip_len, int match,
+                                      int mismatch, int indel, int max_freq, lra_refine_space_result* out) {
+  if (!ctx || !out || n < 0) return LRA_ERR_INVALID;
+  memset(out, 0, sizeof *out);
+  out->n_problems = (uint64_t)n;
+  if (n == 0) return LRA_OK;
+  LRA_HIP_CHECK(ctx, hipSetDevice(ctx->device));
+  hipStream_t st = ctx->stream;
+  const size_t n1 = (size_t)n + 2;
+  auto take = [](char*& p, size_t cnt, size_t e) { char* r = p; p += sz(cnt, e); return r; };
+  size_t needW = sz(n1, 4) * 8 + sz(n1, 8) * 6 + sz(2 * n1, 4) + sz(2 * n1 + 2, 8) + 4096;
+  char* w = (char*)lra_ensure(ctx, 14, needW);
+  if (!w) return LRA_ERR_NOMEM;
+  RsArgs a;
+  memset(&a, 0, sizeof a);
+  a.n = n; a.qseq = d_qseq; a.tseq = d_tseq; a.q_off = d_q_off; a.q_len = d_q_len; a.t_off = d_t_off; a.t_len = d_t_len; a.t_span = d_t_span; a.K = d_K; a.W = d_W;
+  a.diag = d_diag; a.q_add = d_q_add; a.t_add = d_t_add; a.flip = d_flip_len; a.maxFreq = max_freq;
+  a.isSmall = (uint32_t*)take(w, n1, 4); a.smallIdx = (uint32_t*)take(w, n1, 4); a.largeIdx = (uint32_t*)take(w, n1, 4); a.sq_len = (int32_t*)take(w, n1, 4);
+  a.st_len = (int32_t*)take(w, n1, 4); a.sk = (int32_t*)take(w, n1, 4); a.bcap = (uint32_t*)take(w, n1, 4); a.cnt = (uint32_t*)take(w, n1, 4);
+  a.smallPos = (uint64_t*)take(w, n1, 8); a.sq_off = (uint64_t*)take(w, n1, 8); a.st_off = (uint64_t*)take(w, n1, 8);
+  uint64_t* boff = (uint64_t*)take(w, n1, 8); uint64_t* pair_off = (uint64_t*)take(w, n1, 8); uint64_t* spare8 = (uint64_t*)take(w, n1, 8); (void)spare8;
+  a.lcnt = (uint32_t*)take(w, 2 * n1, 4); uint64_t* loff = (uint64_t*)take(w, 2 * n1 + 2, 8);
+  // results that outlive the call
+  size_t needR = sz(n1, 8) + sz(n1, 4) * 2 + 4096;
+  const unsigned g = (unsigned)((n + 255) / 256);
+  float* identity; uint32_t* status; uint64_t* pairOffOut;
+  {
+    char* r0 = (char*)lra_ensure(ctx, 15, needR);
+    if (!r0) return LRA_ERR_NOMEM;
+    pairOffOut = (uint64_t*)take(r0, n1, 8); identity = (float*)take(r0, n1, 4); status = (uint32_t*)take(r0, n1, 4);
+  }
+  a.identity = identity; a.status = status;
+  lra_time_begin(ctx, "refine_space");
+  hipLaunchKernelGGL(rs_classify, dim3(g), dim3(256), 0, st, a);
+  lra_time_end(ctx);
+  { int rc = lra_exclusive_scan<uint32_t>(ctx, n, a.isSmall, a.smallPos); if (rc) return rc; }
+  uint64_t nSmall64 = 0;
+  LRA_HIP_CHECK(ctx, hipMemcpyAsync(&nSmall64, a.smallPos + n, 8, hipMemcpyDeviceToHost, st));
+  LRA_HIP_CHECK(ctx, hipStreamSynchronize(st));
+  const int nSmall = (int)nSmall64, nLarge = n - nSmall;
+  hipLaunchKernelGGL(rs_split, dim3(g), dim3(256), 0, st, a);
+  // ---- short gaps
+  int32_t* blocks = nullptr;
+  if (nSmall > 0) {
+    { int rc = lra_exclusive_scan<uint32_t>(ctx, nSmall, a.bcap, boff); if (rc) return rc; }
+    uint64_t totalCap = 0;
+    LRA_HIP_CHECK(ctx, hipMemcpyAsync(&totalCap, boff + nSmall, 8, hipMemcpyDeviceToHost, st));
+    LRA_HIP_CHECK(ctx, hipStreamSynchronize(st));
+    size_t needB = sz(3 * totalCap + 3, 4) + sz((size_t)nSmall + 1, 4) * 3 + 4096;
+    char* wb = (char*)lra_ensure(ctx, 16, needB);
+    if (!wb) return LRA_ERR_NOMEM;
+    blocks = (int32_t*)take(wb, 3 * totalCap + 3, 4);
+    int32_t* score = (int32_t*)take(wb, (size_t)nSmall + 1, 4); int32_t* nblocks = (int32_t*)take(wb, (size_t)nSmall + 1, 4);
+    int32_t* ast = (int32_t*)take(wb, (size_t)nSmall + 1, 4);
+    int rc = lra_aog_launch_device(ctx, nSmall, d_qseq, d_tseq, a.sq_off, a.sq_len, a.st_off, a.st_len, a.sk, match, mismatch, indel, score, nblocks, blocks,
+                                   boff, ast);
+    if (rc) return rc;
+    a.boff = boff; a.nblocks = nblocks; a.blocks = blocks; a.aogStatus = ast;
+    lra_time_begin(ctx, "refine_space");
+    hipLaunchKernelGGL(rs_small<false>, dim3((nSmall + 63) / 64), dim3(64), 0, st, a, nSmall);
+    lra_time_end(ctx);
+  }
+  // ---- long gaps
+  if (nLarge > 0) {
+    lra_time_begin(ctx, "refine_space_long");
+    hipLaunchKernelGGL(rs_sketch<false>, dim3((2 * nLarge + 63) / 64), dim3(64), 0, st, a, nLarge);
+    lra_time_end(ctx);
+    { int rc = lra_exclusive_scan<uint32_t>(ctx, 2 * nLarge, a.lcnt, loff); if (rc) return rc; }
+    uint64_t totalMm = 0;
+    LRA_HIP_CHECK(ctx, hipMemcpyAsync(&totalMm, loff + 2 * nLarge, 8, hipMemcpyDeviceToHost, st));
+    LRA_HIP_CHECK(ctx, hipStreamSynchronize(st));
+    char* wl = (char*)lra_ensure(ctx, 17, sz(totalMm + 1, 8) + sz(totalMm + 1, 4) + 4096);
+    if (!wl) return LRA_ERR_NOMEM;
+    a.lkey = (uint64_t*)take(wl, totalMm + 1, 8); a.lpos = (uint32_t*)take(wl, totalMm + 1, 4); a.loff = loff;
+    lra_time_begin(ctx, "refine_space_long");
+    hipLaunchKernelGGL(rs_sketch<true>, dim3((2 * nLarge + 63) / 64), dim3(64), 0, st, a, nLarge);
+    lra_time_end(ctx);
+    { int rc = lra_sort_minimizers_batch(ctx, 2 * nLarge, loff, a.lkey, a.lpos); if (rc) return rc; }   // sort(EndGenomeTup), sort(EndReadTup)  :306,:308
+    lra_time_begin(ctx, "refine_space_long");
+    hipLaunchKernelGGL(rs_compare<false>, dim3((nLarge + 63) / 64), dim3(64), 0, st, a, nLarge);
+    lra_time_end(ctx);
+  }
+  // ---- pairs
+  { int rc = lra_exclusive_scan<uint32_t>(ctx, n, a.cnt, pair_off); if (rc) return rc; }
+  uint64_t nPairs = 0;
+  LRA_HIP_CHECK(ctx, hipMemcpyAsync(&nPairs, pair_off + n, 8, hipMemcpyDeviceToHost, st));
+  LRA_HIP_CHECK(ctx, hipStreamSynchronize(st));
+  char* r = (char*)lra_ensure(ctx, 11, sz(nPairs + 1, 4) * 2 + 4096);
+  if (!r) return LRA_ERR_NOMEM;
+  uint32_t* outQ = (uint32_t*)take(r, nPairs + 1, 4); uint32_t* outT = (uint32_t*)take(r, nPairs + 1, 4);
+  LRA_HIP_CHECK(ctx, hipMemcpyAsync(pairOffOut, pair_off, ((size_t)n + 1) * 8, hipMemcpyDeviceToDevice, st));
+  a.pair_off = pairOffOut; a.outQ = outQ; a.outT = outT;
+  lra_time_begin(ctx, "refine_space");
+  if (nSmall > 0) hipLaunchKernelGGL(rs_small<true>, dim3((nSmall + 63) / 64), dim3(64), 0, st, a, nSmall);
+  lra_time_end(ctx);
+  if (nLarge > 0) {
+    lra_time_begin(ctx, "refine_space_long");
+    hipLaunchKernelGGL(rs_compare<true>, dim3((nLarge + 63) / 64), dim3(64), 0, st, a, nLarge);
+    lra_time_end(ctx);
+  }
+  LRA_HIP_CHECK(ctx, hipStreamSynchronize(st));
+  LRA_HIP_CHECK(ctx, hipGetLastError());
+  out->n_pairs = nPairs; out->n_small = (uint64_t)nSmall; out->d_pair_off = pairOffOut; out->d_pair_q = outQ; out->d_pair_t = outT; out->d_identity = identity;
+  out->d_status = status;
+  return LRA_OK;
+}

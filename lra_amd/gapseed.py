@@ -1,0 +1,28 @@
+"""Host-side mirror of RefineSpace (reference: ClusterRefine.h:242-325) for a batch of gaps."""
+import ctypes as C
+
+import numpy as np
+
+from .context import Context, ptr
+
+
+class RefineSpaceResult(C.Structure):
+    _fields_ = [("n_problems", C.c_uint64), ("n_pairs", C.c_uint64), ("n_small", C.c_uint64), ("d_pair_off", C.c_void_p), ("d_pair_q", C.c_void_p),
+                ("d_pair_t", C.c_void_p), ("d_identity", C.c_void_p), ("d_status", C.c_void_p)]
+
+
+def refine_space_batch(ctx: Context, n, qseq, q_off, q_len, tseq, t_off, t_len, t_span, K, W, diag, q_add, t_add, flip_len, match=4, mismatch=-1,
+                       indel=-2, max_freq=15):
+    """All array arguments are device tensors (see include/lra_hip.h)."""
+    res = RefineSpaceResult()
+    ctx.check(ctx.lib.lra_refine_space_batch(ctx.h, int(n), ptr(qseq), ptr(q_off), ptr(q_len), ptr(tseq), ptr(t_off), ptr(t_len), ptr(t_span), ptr(K),
+                                             ptr(W), ptr(diag), ptr(q_add), ptr(t_add), ptr(flip_len), int(match), int(mismatch), int(indel),
+                                             int(max_freq), C.byref(res)))
+    return res
+
+
+def fetch(ctx: Context, res: RefineSpaceResult):
+    n, m = res.n_problems, res.n_pairs
+    return {"pair_off": ctx.to_host(res.d_pair_off, n + 1, np.uint64), "pair_q": ctx.to_host(res.d_pair_q, m, np.uint32),
+            "pair_t": ctx.to_host(res.d_pair_t, m, np.uint32), "identity": ctx.to_host(res.d_identity, n, np.float32),
+            "status": ctx.to_host(res.d_status, n, np.uint32)}

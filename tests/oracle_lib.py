@@ -360,3 +360,28 @@ def split_chain(q, t, length, strand, cluster, link, chrom_pos, splitdist=50000,
         splits.append(dict(idx=spIdx[a:b].copy(), link=spLink[a:b - 1].copy() if b > a else spLink[0:0].copy(), type=chr(spType[k]), strand=int(spStrand[k]),
                            chrom=int(spChrom[k]), box=spBox[4 * k:4 * k + 4].copy(), clusters=ciIdx[ciOff[k]:ciOff[k + 1]].copy()))
     return dict(keep=keep[:n].copy(), n_kept=nk.value, link=lo[:max(nk.value - 1, 0)].copy(), splits=splits, split_link=sl[:nsl.value].copy())
+
+
+# ---- RefineSpace (a11) ------------------------------------------------------------------------------------------------
+def store_minimizers_noncanonical64(seq: bytes, k, w):
+    L = lib()
+    cap = len(seq) + 1
+    keys = np.zeros(cap, np.uint64); pos = np.zeros(cap, np.uint32)
+    L.oracle_store_minimizers_noncanonical64.restype = C.c_long
+    n = L.oracle_store_minimizers_noncanonical64(C.c_char_p(seq), C.c_uint32(len(seq)), int(k), int(w), _p(keys, C.c_uint64), _p(pos, C.c_uint32), C.c_long(cap))
+    return keys[:n].copy(), pos[:n].copy()
+
+
+def refine_space(q: bytes, t: bytes, t_span, K, W, diag, match=4, mismatch=-1, indel=-2, max_freq=15, q_add=0, t_add=0, flip_len=0):
+    """-> (pairs_q, pairs_t, identity)"""
+    L = lib()
+    cap = 4 * (len(q) + len(t)) + 64
+    while True:
+        oq = np.zeros(cap, np.uint32); ot = np.zeros(cap, np.uint32); ident = C.c_float(0)
+        L.oracle_refine_space.restype = C.c_long
+        n = L.oracle_refine_space(C.c_char_p(q), len(q), C.c_char_p(t), len(t), C.c_uint32(t_span), int(K), int(W), int(diag), int(match), int(mismatch),
+                                  int(indel), C.c_long(max_freq), C.c_uint32(q_add), C.c_uint32(t_add), C.c_uint32(flip_len), _p(oq, C.c_uint32),
+                                  _p(ot, C.c_uint32), C.c_long(cap), C.byref(ident))
+        if n <= cap:
+            return oq[:n].copy(), ot[:n].copy(), ident.value
+        cap = n

@@ -1,0 +1,76 @@
+"""a11 RefineSpace (ClusterRefine.h:242-325): oracle sanity on CPU (its pieces are pinned elsewhere; the glue is unpinned), HIP vs oracle on the GPU."""
+import numpy as np
+import pytest
+
+import oracle_lib as O
+from lra_amd import synth
+
+
+def _gap(rng, genome, qlen, err, with_n=False):
+    s0 = int(rng.integers(1000, len(genome) - 40000))
+    tlen = int(qlen * rng.uniform(0.85, 1.15)) + int(rng.integers(0, 40))
+    t = genome[s0:s0 + tlen].copy()
+    q = synth.mutate(genome[s0:s0 + qlen], err, rng) if hasattr(synth, "mutate") else None
+    if q is None:
+        q = genome[s0:s0 + qlen].copy()
+        m = rng.random(len(q)) < err
+        q[m] = rng.choice(np.frombuffer(b"ACGT", np.uint8), int(m.sum()))
+    if with_n and len(q) > 50:
+        q[10:13] = ord("N")
+    return q.tobytes(), t.tobytes()
+
+
+def test_oracle_refine_space_sanity():
+    rng = np.random.default_rng(2)
+    genome = synth.make_genome(200000, seed=5)
+    q, t = _gap(rng, genome, 400, 0.0)
+    oq, ot, ident = O.refine_space(q, t, len(t), 10, 5, 30)
+    assert ident > 0.99 and len(oq) > 20 and np.all(oq == ot)                   # identical sequences: K-mers on the main diagonal
+    q, t = _gap(rng, genome, 3000, 0.05)
+    oq, ot, ident = O.refine_space(q, t, len(t), 9, 5, 60, q_add=100, t_add=7000)
+    assert ident == -1 and len(oq) > 30
+    d = ot.astype(np.int64) - 7000 - (oq.astype(np.int64) - 100)
+    assert np.all(np.abs(d) <= abs(len(t) - len(q)) + 60)                        # inside the diagonal band
+    k1, p1 = O.store_minimizers_noncanonical64(b"ACGT" * 3, 6, 5)
+    assert len(k1) >= 1
+    assert len(O.store_minimizers_noncanonical64(b"ACG", 6, 5)[0]) == 0
+
+
+@pytest.mark.gpu
+def test_hip_refine_space_oracle(ctx):
+    import torch
+    from lra_amd import gapseed
+    rng = np.random.default_rng(11)
+    genome = synth.make_genome(400000, seed=8, repeat_frac=0.3)
+    probs = []
+    for i in range(300):
+        kind = i % 6
+        qlen = int(rng.choice([8, 31, 60, 200, 600, 990])) if kind < 4 else int(rng.choice([1000, 1500, 4000, 12000]))
+        q, t = _gap(rng, genome, qlen, float(rng.choice([0.0, 0.03, 0.12])), with_n=(i % 17 == 0))
+        if kind == 3: t = t[: max(5, len(t) // 3)]                                   # very unequal spans
+        K = int(rng.choice([6, 9, 12])); W = int(rng.choice([3, 5]))
+        flip = int(rng.choice([0, 0, 50000]))
+        probs.append(dict(q=q, t=t, t_span=len(t) - int(rng.integers(0, 3)), K=K, W=W, diag=int(rng.choice([30, 60, 200])), q_add=int(rng.integers(0, 30000)),
+                          t_add=int(rng.integers(0, 1 << 30)), flip=flip))
+    qcat = b"".join(p["q"] for p in probs); tcat = b"".join(p["t"] for p in probs)
+    qoff = np.cumsum([0] + [len(p["q"]) for p in probs])[:-1]; toff = np.cumsum([0] + [len(p["t"]) for p in probs])[:-1]
+    dev = ctx.device
+    T = lambda a, dt: torch.tensor(np.asarray(a, dtype=dt), device=dev)
+    dq = torch.tensor(np.frombuffer(qcat + b"\0" * 64, np.uint8).copy(), device=dev); dt_ = torch.tensor(np.frombuffer(tcat + b"\0" * 64, np.uint8).copy(), device=dev)
+    args = [T(qoff, np.int64), T([len(p["q"]) for p in probs], np.int32)]
+    res = gapseed.refine_space_batch(ctx, len(probs), dq, args[0], args[1], dt_, T(toff, np.int64), T([len(p["t"]) for p in probs], np.int32),
+                                     T([p["t_span"] for p in probs], np.int64).to(torch.int32), T([p["K"] for p in probs], np.int32),
+                                     T([p["W"] for p in probs], np.int32), T([p["diag"] for p in probs], np.int32),
+                                     T([p["q_add"] for p in probs], np.int64).to(torch.int32), T([p["t_add"] for p in probs], np.int64).to(torch.int32),
+                                     T([p["flip"] for p in probs], np.int64).to(torch.int32), 4, -1, -2, 15)
+    out = gapseed.fetch(ctx, res)
+    assert 0 < res.n_small < len(probs)
+    total = 0
+    for i, p in enumerate(probs):
+        eq, et, ident = O.refine_space(p["q"], p["t"], p["t_span"], p["K"], p["W"], p["diag"], 4, -1, -2, 15, p["q_add"], p["t_add"], p["flip"])
+        a, b = int(out["pair_off"][i]), int(out["pair_off"][i + 1])
+        assert b - a == len(eq), (i, b - a, len(eq))
+        assert np.array_equal(out["pair_q"][a:b], eq) and np.array_equal(out["pair_t"][a:b], et), i
+        assert np.float32(out["identity"][i]).view(np.uint32) == np.float32(ident).view(np.uint32), (i, out["identity"][i], ident)
+        total += len(eq)
+    assert total > 1000
