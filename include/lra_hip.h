@@ -308,6 +308,24 @@ int lra_affine_one_gap_align_batch(lra_ctx* ctx, int n, const char* d_qseq, cons
                                    int32_t* d_score, int32_t* d_nblocks, int32_t* d_blocks,
                                    const uint64_t* d_block_off, int32_t* d_status);
 
+/* ---- a13 (DP leaf): the alignment between two consecutive chain anchors -------------------------------------
+ * Replaces   RefineByLinearAlignment(btc_curReadEnd, btc_curGenomeEnd, btc_nextReadStart, btc_nextGenomeStart, str, chromIndex,
+ *                                    alignment, read, genome, strands, ...)                    (LocalRefineAlignment.h:141-185)
+ * = SetMatchAndGaps (:93) + RefineSubstrings (:127) + AlignSubstrings (:100) for n anchor pairs: if min(nextReadStart - curReadEnd + 1,
+ * nextGenomeStart - curGenomeEnd + 1) > 0 and (opts.refineLevel & REF_DP), AffineOneGapAlign on strands[str][curReadEnd, nextReadStart)
+ * x genome.seqs[chromIndex][curGenomeEnd, nextGenomeStart) with band min(2 * |qLen - tLen| + 1, opts.localBand); its blocks, shifted by
+ * (curReadEnd, curGenomeEnd), are what the reference appends to alignment->blocks.  d_q_base[p] / d_t_base[p]: offset of strands[str] /
+ * genome.seqs[chromIndex] inside d_qseq / d_tseq.  Output (context-owned): blocks CSR by pair (qPos,tPos,length), score, status
+ * (AffineOneGapAlign bits; LRA_ST_RANGE if a span is negative).  Synchronous.                                                  */
+typedef struct lra_between_result {
+  uint64_t n_gaps, n_blocks;
+  const uint64_t* d_block_off; const int32_t* d_blocks; const int32_t* d_score; const uint32_t* d_status;
+} lra_between_result;
+int lra_between_anchors_batch(lra_ctx* ctx, int n, const char* d_qseq, const uint64_t* d_q_base, const uint32_t* d_cur_read_end,
+                              const uint32_t* d_next_read_start, const char* d_tseq, const uint64_t* d_t_base, const uint32_t* d_cur_genome_end,
+                              const uint32_t* d_next_genome_start, int match, int mismatch, int indel, int local_band, int refine_dp,
+                              lra_between_result* out);
+
 /* ---- a14: banded 3-state affine indel refinement ----------------------------------------
  * Replaces   void IndelRefineAlignment(Read& read, Genome& genome, Alignment& alignment,
  *                                      const Options& opts, IndelRefineBuffers& buffers,

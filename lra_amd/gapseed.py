@@ -26,3 +26,24 @@ def fetch(ctx: Context, res: RefineSpaceResult):
     return {"pair_off": ctx.to_host(res.d_pair_off, n + 1, np.uint64), "pair_q": ctx.to_host(res.d_pair_q, m, np.uint32),
             "pair_t": ctx.to_host(res.d_pair_t, m, np.uint32), "identity": ctx.to_host(res.d_identity, n, np.float32),
             "status": ctx.to_host(res.d_status, n, np.uint32)}
+
+
+class BetweenResult(C.Structure):
+    _fields_ = [("n_gaps", C.c_uint64), ("n_blocks", C.c_uint64), ("d_block_off", C.c_void_p), ("d_blocks", C.c_void_p), ("d_score", C.c_void_p),
+                ("d_status", C.c_void_p)]
+
+
+def between_anchors_batch(ctx: Context, n, qseq, q_base, cur_read_end, next_read_start, tseq, t_base, cur_genome_end, next_genome_start, match=4, mismatch=-1,
+                          indel=-2, local_band=15, refine_dp=1):
+    """RefineByLinearAlignment (LocalRefineAlignment.h:141) for n anchor pairs; array arguments are device tensors."""
+    res = BetweenResult()
+    ctx.check(ctx.lib.lra_between_anchors_batch(ctx.h, int(n), ptr(qseq), ptr(q_base), ptr(cur_read_end), ptr(next_read_start), ptr(tseq), ptr(t_base),
+                                                ptr(cur_genome_end), ptr(next_genome_start), int(match), int(mismatch), int(indel), int(local_band),
+                                                int(refine_dp), C.byref(res)))
+    return res
+
+
+def fetch_between(ctx: Context, res: BetweenResult):
+    n, m = res.n_gaps, res.n_blocks
+    return {"block_off": ctx.to_host(res.d_block_off, n + 1, np.uint64), "blocks": ctx.to_host(res.d_blocks, 3 * m, np.int32).reshape(-1, 3),
+            "score": ctx.to_host(res.d_score, n, np.int32), "status": ctx.to_host(res.d_status, n, np.uint32)}

@@ -126,3 +126,22 @@ extern "C" long oracle_refine_space(const char* q, int qLen, const char* t, int 
   }
   return n;
 }
+
+// RefineByLinearAlignment (LocalRefineAlignment.h:141-185): the blocks appended to alignment->blocks for one anchor pair.
+// q = strands[str], t = genome.seqs[chromIndex] (whole sequences); returns the number of blocks, -1 if a span is negative
+// (std::string of negative length in the reference).
+extern "C" int oracle_between_anchors(const char* q, const char* t, uint32_t curReadEnd, uint32_t nextReadStart, uint32_t curGenomeEnd,
+                                      uint32_t nextGenomeStart, int match, int mismatch, int indel, int localBand, int refineDp, int* blocks, int cap,
+                                      int* score) {
+  const int m = (int)std::min(nextReadStart - curReadEnd + 1u, nextGenomeStart - curGenomeEnd + 1u);   // SetMatchAndGaps :93-98
+  *score = 0;
+  if (!(m > 0) || !refineDp) return 0;
+  const int qLen = (int)(nextReadStart - curReadEnd), tLen = (int)(nextGenomeStart - curGenomeEnd);      // AlignSubstrings :103-104
+  if (qLen < 0 || tLen < 0) return -1;
+  const int drift = std::abs(qLen - tLen);
+  int nb = 0, st = 0;
+  *score = oracle_affine_one_gap_align(q + curReadEnd, qLen, t + curGenomeEnd, tLen, match, mismatch, indel, std::min(drift * 2 + 1, localBand), blocks,
+                                       cap, &nb, &st);
+  for (int b = 0; b < nb && b < cap; b++) { blocks[3 * b] += (int)curReadEnd; blocks[3 * b + 1] += (int)curGenomeEnd; }   // RefineSubstrings :134-138
+  return nb;
+}

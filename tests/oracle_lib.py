@@ -385,3 +385,18 @@ def refine_space(q: bytes, t: bytes, t_span, K, W, diag, match=4, mismatch=-1, i
         if n <= cap:
             return oq[:n].copy(), ot[:n].copy(), ident.value
         cap = n
+
+
+def between_anchors(q: bytes, t: bytes, cur_read_end, next_read_start, cur_genome_end, next_genome_start, match=4, mismatch=-1, indel=-2, local_band=15,
+                    refine_dp=1):
+    """RefineByLinearAlignment for one anchor pair -> (blocks [n,3], score) or None (negative span)."""
+    L = lib()
+    cap = max(8, min(len(q), len(t)) + 8)
+    blocks = np.zeros(3 * cap, np.int32); score = C.c_int(0)
+    L.oracle_between_anchors.restype = C.c_int
+    n = L.oracle_between_anchors(C.c_char_p(q), C.c_char_p(t), C.c_uint32(cur_read_end), C.c_uint32(next_read_start), C.c_uint32(cur_genome_end),
+                                 C.c_uint32(next_genome_start), int(match), int(mismatch), int(indel), int(local_band), int(refine_dp),
+                                 _p(blocks, C.c_int), cap, C.byref(score))
+    if n < 0:
+        return None
+    return blocks[:3 * n].reshape(n, 3).copy(), score.value

@@ -74,3 +74,46 @@ def test_hip_refine_space_oracle(ctx):
         assert np.float32(out["identity"][i]).view(np.uint32) == np.float32(ident).view(np.uint32), (i, out["identity"][i], ident)
         total += len(eq)
     assert total > 1000
+
+
+@pytest.mark.gpu
+def test_hip_between_anchors_oracle(ctx):
+    """a13 DP leaf: RefineByLinearAlignment (LocalRefineAlignment.h:141-185) for consecutive anchor pairs"""
+    import torch
+    from lra_amd import gapseed
+    rng = np.random.default_rng(4)
+    genome = synth.make_genome(300000, seed=6)
+    reads, truth = synth.simulate_reads(genome, 6, 8000, 500, 0.10, seed=2)
+    g = genome.tobytes()
+    roff = np.cumsum([0] + [len(r) for r in reads])
+    rcat = b"".join(r.tobytes() for r in reads)
+    Q = []; cases = []
+    for i in range(600):
+        r = int(rng.integers(0, len(reads))); s0 = truth[r][0]; L = len(reads[r])
+        qs = int(rng.integers(0, L - 400)); ql = int(rng.choice([0, 0, 1, 5, 30, 120, 350]))
+        ts = s0 + qs + int(rng.integers(-20, 20)); tl = max(0, ql + int(rng.choice([0, 0, -3, 4, 25, -ql, 60])))
+        qe, te = qs + ql, ts + tl
+        if i % 41 == 0: qe = qs - 1                     # m == 0: nothing aligned
+        if i % 53 == 0: qe = max(0, qs - 5)             # negative span: the reference builds a string of negative length
+        cases.append((r, qs, qe, ts, te))
+    dev = ctx.device
+    T = lambda a, dt: torch.tensor(np.asarray(a, dtype=dt), device=dev)
+    dq = torch.tensor(np.frombuffer(rcat + b"\0" * 64, np.uint8).copy(), device=dev); dg = torch.tensor(np.frombuffer(g + b"\0" * 64, np.uint8).copy(), device=dev)
+    for refine_dp in (1, 0):
+        res = gapseed.between_anchors_batch(ctx, len(cases), dq, T([roff[c[0]] for c in cases], np.int64), T([c[1] for c in cases], np.int64).to(torch.int32),
+                                            T([c[2] for c in cases], np.int64).to(torch.int32), dg, T([0] * len(cases), np.int64),
+                                            T([c[3] for c in cases], np.int64).to(torch.int32), T([c[4] for c in cases], np.int64).to(torch.int32),
+                                            4, -1, -2, 15, refine_dp)
+        out = gapseed.fetch_between(ctx, res)
+        nb = 0
+        for i, (r, qs, qe, ts, te) in enumerate(cases):
+            exp = O.between_anchors(reads[r].tobytes(), g, qs, qe, ts, te, 4, -1, -2, 15, refine_dp)
+            a, b = int(out["block_off"][i]), int(out["block_off"][i + 1])
+            if exp is None:
+                assert out["status"][i] != 0 and b == a
+                continue
+            assert out["status"][i] == 0, i
+            assert np.array_equal(out["blocks"][a:b], exp[0]), (i, qs, qe, ts, te)
+            if len(exp[0]): assert out["score"][i] == exp[1], i
+            nb += b - a
+        assert (nb > 500) == bool(refine_dp)
