@@ -184,6 +184,8 @@ int lra_linear_extend_batch(lra_ctx* ctx, int K, const char* d_seq, const uint64
  * mode LRA_SDP_SINGLE_CLUSTER replaces  SparseDP(ClusterIndex, extend_clusters, ultimatechain, smallOpts, LookUpTable, read)
  * (SparseDP.h:2287-2438, called at Map_lowacc.h:535): every "read" is one cluster job, anchors get only their own family's point pair,
  * rate = opts.second_anchorbonus, and the one chain is the plain TraceBack (:1521) from the first anchor of maximal value (no box).
+ * The same mode with several clusters per job is  SparseDP(SplitChain& inputChain, vector<Cluster_SameDiag*>&, FinalChain&, ...)
+ * (SparseDP.h:1766-1955, LocalRefineAlignment.h:563): pass the clusters of inputChain in order, anchors = (GetqStart, GettStart, length).
  * d_status[r]: LRA_ST_CAPACITY if a work buffer bound was hit, LRA_ST_OOB_SLOT if the reference would read outside
  * its arrays (the read then has no chains).  Synchronous.                                              */
 #define LRA_SDP_CLUSTERS 0

@@ -149,6 +149,11 @@ def test_hip_sdp_single_cluster_mode(ctx):
         offs, st, q, t, ln = _random_clusters(rng, 1, int(rng.integers(1, 60)), 12 if ties else 5000, ties)
         jobs.append((offs, st, q, t, ln))
     read_lens = [1000] * len(jobs)
+    # SparseDP(SplitChain&, vector<Cluster_SameDiag*>&, FinalChain&, ...) (SparseDP.h:1766, LocalRefineAlignment.h:563) is the same
+    # engine over the several clusters of a split chain: one point pair per anchor by its cluster's strand, first maximum, plain trace back
+    for k in range(60):
+        jobs.append(_random_clusters(rng, int(rng.integers(2, 7)), 25, 4000, False))
+    read_lens = [1000] * len(jobs)
     kw = dict(mode=1, NumAln=1, rate=6.0)                                 # second_anchorbonus of the -ONT / -CLR presets
     res, out = _run_hip(ctx, jobs, read_lens, kw)
     assert _compare(out, res.num_aln, jobs, read_lens, kw) == len(jobs)
