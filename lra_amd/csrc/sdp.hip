@@ -34,7 +34,7 @@
 
 namespace {
 
-constexpr int LV = 16;                    // levels per decomposition (lines per read <= 32768)
+constexpr int LV = 18;                    // levels per decomposition (distinct rows / columns per read <= 131072); 2 * LV lanes own them
 constexpr uint32_t NONE = 0xFFFFFFFFu;
 constexpr int MAXALN = 16;
 
@@ -61,35 +61,38 @@ struct Node {            // one full sub-problem (SubProblem.h:15-37), 32 bytes
 
 // Everything ProcessPoint touches for one read lies in one contiguous block (sections 256-byte aligned): a wave's working set is a
 // couple of megabytes in one place instead of six arrays gigabytes apart (TLB reach).
-struct ReadArena { uint64_t base; uint32_t entOff, apOff, stkOff, blkOff, visOff, pad; };   // byte offsets from base; nodes at 0
+struct ReadArena { uint64_t base; uint32_t entOff, apOff, stkOff, blkOff, visOff, capShift; };   // base: device address; byte offsets from it; nodes at 0
+// capShift: the candidate stack and Block of a sub-problem have (2 nD + 4) << capShift and (2 (nD + nE) + 8) << capShift slots.  Re-inserted
+// candidates (`last` moving backwards) can outgrow any fixed multiple, so reads that hit the bound are re-run with capShift 3, then 6.
 
 __device__ __host__ inline uint32_t al256(uint64_t x) { return (uint32_t)((x + 255) & ~(uint64_t)255); }
 
 __global__ void k_arena_sizes(int n, int r0, const uint64_t* __restrict__ ptOff, const uint32_t* __restrict__ cntE, const uint32_t* __restrict__ cntN,
-                              const uint32_t* __restrict__ cntD, ReadArena* ra, uint64_t* bytes) {
-  int rr = blockIdx.x * blockDim.x + threadIdx.x;
-  if (rr >= n) return;
+                              const uint32_t* __restrict__ cntD, ReadArena* ra, uint64_t* bytes, const uint32_t* __restrict__ order, int shift) {
+  int b = blockIdx.x * blockDim.x + threadIdx.x;
+  if (b >= n) return;
+  const int rr = (int)order[b];
   const uint64_t E = cntE[rr], N = cntN[rr], D = cntD[rr], P = ptOff[r0 + rr + 1] - ptOff[r0 + rr];
   ReadArena a;
-  a.base = 0; a.pad = 0;
+  a.base = 0; a.capShift = (uint32_t)shift;
   uint64_t o = al256(N * sizeof(Node));
   a.entOff = (uint32_t)o; o = al256(o + E * sizeof(Ent));
   a.apOff = (uint32_t)o; o = al256(o + E * 4);
-  a.stkOff = (uint32_t)o; o = al256(o + (2 * D + 4 * N + 2) * 8);
-  a.blkOff = (uint32_t)o; o = al256(o + (2 * E + 8 * N + 2) * 8);
+  a.stkOff = (uint32_t)o; o = al256(o + (((2 * D + 4 * N) << shift) + 2) * 8);
+  a.blkOff = (uint32_t)o; o = al256(o + (((2 * E + 8 * N) << shift) + 2) * 8);
   a.visOff = (uint32_t)o; o = al256(o + P * 2 * LV * sizeof(uint2));
   ra[rr] = a;
-  bytes[rr] = o;
+  bytes[b] = o;
 }
-__global__ void k_arena_bases(int n, const uint64_t* __restrict__ byteOff, ReadArena* ra) {
-  int rr = blockIdx.x * blockDim.x + threadIdx.x;
-  if (rr < n) ra[rr].base = byteOff[rr];
+__global__ void k_arena_bases(int n, const uint64_t* __restrict__ byteOff, ReadArena* ra, const uint32_t* __restrict__ order, char* arena) {
+  int b = blockIdx.x * blockDim.x + threadIdx.x;
+  if (b < n) ra[order[b]].base = (uint64_t)(uintptr_t)(arena + byteOff[b]);
 }
-__global__ void k_visit_clear(const ReadArena* __restrict__ ra, const uint64_t* __restrict__ byteOff, char* arena) {
-  const int rr = blockIdx.x;
-  const uint64_t lo = ra[rr].base + ra[rr].visOff, hi = byteOff[rr + 1];
-  uint4* p = (uint4*)(arena + lo);
-  const uint64_t n = (hi - lo) / 16;
+__global__ void k_visit_clear(const ReadArena* __restrict__ ra, const uint64_t* __restrict__ byteOff, const uint32_t* __restrict__ order) {
+  const int b = blockIdx.x;
+  const ReadArena A = ra[order[b]];
+  uint4* p = (uint4*)((char*)(uintptr_t)A.base + A.visOff);
+  const uint64_t n = (byteOff[b + 1] - byteOff[b] - A.visOff) / 16;
   for (uint64_t i = threadIdx.x; i < n; i += blockDim.x) p[i] = make_uint4(NONE, NONE, NONE, NONE);
 }
 
@@ -191,20 +194,31 @@ __global__ void k_gather(uint64_t np, const uint32_t* __restrict__ ptRead, const
   }
 }
 
+// before a read is re-run with larger stacks: Value[] back to its initial state (SparseDP.h:2206), status cleared
+__global__ void k_reset_frags(int r0, const uint32_t* __restrict__ order, const uint64_t* __restrict__ fragOff, const int32_t* __restrict__ flen,
+                              const float* __restrict__ rate_in, float rate, float* fval, uint32_t* fprevNode, uint32_t* fprevInd, uint8_t* fflags,
+                              uint32_t* status) {
+  const int r = r0 + (int)order[blockIdx.x];
+  const float rt = rate_in ? rate_in[r] : rate;
+  for (uint64_t g = fragOff[r] + threadIdx.x; g < fragOff[r + 1]; g += blockDim.x) { fval[g] = flen[g] * rt; fprevNode[g] = NONE; fprevInd[g] = NONE; fflags[g] = 3; }
+  if (threadIdx.x == 0) status[r] = 0;
+}
+
 // ---- decompositions ---------------------------------------------------------------------------------------------------
 struct BuildArgs {
   int r0, n;                                 // reads [r0, r0 + n)
+  const uint32_t* order;                     // block b works on read r0 + order[b] (largest first: the longest waves start first)
   const uint64_t* ptOff;
   const uint32_t* hq; const uint32_t* ht; const uint8_t* hfl; const uint32_t* h2; const uint64_t* key3; const uint32_t* pay3;
   uint32_t* scratch;                         // 28 words per point + 64 per read
   uint32_t* cntEntries; uint32_t* cntNodes; uint32_t* cntD; uint32_t* cntV;   // [n] (count pass out)
-  const ReadArena* ra; char* arena;          // emit pass: per-read blocks
+  const ReadArena* ra;                       // emit pass: per-read blocks
   uint32_t* status;
 };
 
 template <bool EMIT>
 __global__ void __launch_bounds__(64, 8) sdp_build(BuildArgs a) {
-  const int rr = blockIdx.x, r = a.r0 + rr, lane = threadIdx.x;
+  const int rr = (int)a.order[blockIdx.x], r = a.r0 + rr, lane = threadIdx.x;
   const uint64_t p0 = a.ptOff[r], pc0 = a.ptOff[a.r0];
   const int P = (int)(a.ptOff[r + 1] - p0);
   if (P == 0) { if (!EMIT && lane == 0) { a.cntEntries[rr] = 0; a.cntNodes[rr] = 0; a.cntD[rr] = 0; a.cntV[rr] = 0; } return; }
@@ -250,9 +264,11 @@ __global__ void __launch_bounds__(64, 8) sdp_build(BuildArgs a) {
   wave_sync();
   uint32_t nEntries = 0, nNodesTot = 0, sumD = 0, nVisits = 0;
   Node* nodesR = nullptr; Ent* entR = nullptr; uint32_t* apR = nullptr; int2* stkR = nullptr; uint2* visR = nullptr;
+  int capShift = 0;
   if (EMIT) {
     const ReadArena A = a.ra[rr];
-    char* b = a.arena + A.base;
+    char* b = (char*)(uintptr_t)A.base;
+    capShift = (int)A.capShift;
     nodesR = (Node*)b; entR = (Ent*)(b + A.entOff); apR = (uint32_t*)(b + A.apOff); stkR = (int2*)(b + A.stkOff); visR = (uint2*)(b + A.visOff);
   }
   bool overflow = false;
@@ -385,7 +401,7 @@ __global__ void __launch_bounds__(64, 8) sdp_build(BuildArgs a) {
           if (EMIT && full) {
             Node nd;
             nd.dBase = base; nd.nD = nD; nd.nE = nE; nd.last = -1; nd.sTop = 1; nd.nBlk = 0;
-            nd.stkOff = 2 * dpre + 4 * gid; nd.blkOff = 2 * base + 8 * gid;
+            nd.stkOff = (2 * dpre + 4 * gid) << capShift; nd.blkOff = (2 * base + 8 * gid) << capShift;
             nodesR[gid] = nd;
             stkR[nd.stkOff] = make_int2(-1, (int)nE + 1);     // dummy pair (DivideSubByRow1.h:470)
           }
@@ -476,7 +492,7 @@ __global__ void __launch_bounds__(64, 8) sdp_build(BuildArgs a) {
   for (int o = 32; o > 0; o >>= 1) nVisits += __shfl_xor(nVisits, o);
   if (lane == 0) {
     if (!EMIT) { a.cntEntries[rr] = nEntries; a.cntNodes[rr] = nNodesTot; a.cntD[rr] = sumD; a.cntV[rr] = nVisits; }
-    if (overflow) atomicOr(&a.status[r], (uint32_t)LRA_ST_CAPACITY);
+    if (overflow) atomicOr(&a.status[r], (uint32_t)LRA_ST_RANGE);             // more than 2^(LV-1) distinct rows / columns
   }
 #undef TB
 #undef TM
@@ -485,11 +501,12 @@ __global__ void __launch_bounds__(64, 8) sdp_build(BuildArgs a) {
 // ---- ProcessPoint -----------------------------------------------------------------------------------------------------
 struct ProcArgs {
   int r0, n;
+  const uint32_t* order;
   const uint64_t* ptOff; const uint64_t* fragOff;
   const uint8_t* hfl; const uint32_t* hfr;
   const int32_t* flen; float* fval; uint32_t* fprevNode; uint32_t* fprevInd; uint8_t* fflags;
   const float* rate_in; float rate;
-  const ReadArena* ra; char* arena;
+  const ReadArena* ra;
   uint32_t* status;
   PwlTab pwl;
 };
@@ -562,19 +579,20 @@ __global__ void __launch_bounds__(64) sdp_process(ProcArgs a) {
   __syncthreads();
   const int c1 = a.pwl.c1, c2 = a.pwl.c2;
 #define W(i, j) pwl_w(s_slope, s_inter, c1, c2, (i), (j))
-  const int rr = blockIdx.x, r = a.r0 + rr;
+  const int rr = (int)a.order[blockIdx.x], r = a.r0 + rr;
   const uint64_t p0 = a.ptOff[r], f0 = a.fragOff[r];
   const int P = (int)(a.ptOff[r + 1] - p0);
   const float rate = a.rate_in ? a.rate_in[r] : a.rate;
   const ReadArena A = a.ra[rr];
-  char* ab = a.arena + A.base;
+  char* ab = (char*)(uintptr_t)A.base;
+  const int capShift = (int)A.capShift;
   Node* nodes = (Node*)ab;
   Ent* ent = (Ent*)(ab + A.entOff);
   uint32_t* Ap = (uint32_t*)(ab + A.apOff);
   int2* stkR = (int2*)(ab + A.stkOff);
   int2* blkR = (int2*)(ab + A.blkOff);
   const uint2* visR = (const uint2*)(ab + A.visOff);
-  const int fam2 = (lane >> 4) & 1, level = lane & 15;
+  const int fam2 = lane < LV ? 0 : 1, level = lane < LV ? lane : lane - LV;   // lanes >= 2 * LV have no visits
   uint32_t bad = 0;
   // per-lane cache of the sub-problem this lane touched last (descriptor, stack top, last Block pair): consecutive points mostly
   // stay in the same sub-problem on the upper levels
@@ -613,13 +631,64 @@ __global__ void __launch_bounds__(64) sdp_process(ProcArgs a) {
       const int m = (int)nd.nD, n = (int)nd.nE, i1 = (int)v.y;
       int sTop = (int)nd.sTop, nBlk = (int)nd.nBlk;
       int2* S = stkR + nd.stkOff; int2* B = blkR + nd.blkOff;
-      const int bCap = 2 * (m + n) + 8;
+      const int bCap = (2 * (m + n) + 8) << capShift;
       const Ent* D = ent + nd.dBase;
       int2 top = cTop, lastB = cLastB;
       uint32_t st = 0;
       if (need && !cTopOk) { top = S[sTop - 1]; lastB = nBlk > 0 ? B[nBlk - 1] : make_int2(0, 0); }
-      // phase 1, one owner at a time, the whole wave: the insertions  for (i = last + 1; i <= now; ++i)  of Maximization :275-328
-      unsigned long long todo = __ballot(need && now > nd.last);
+      // phase 1a, every lane for itself: short insertion runs (most queries advance `now` by a few candidates only) -- the same loop
+      // as below, literal and lane-local, all lanes at once
+      const int LOCAL_MAX = 6;
+      const bool small = need && now > nd.last && now - nd.last <= LOCAL_MAX;
+      if (small) {
+        const Ent* E = D + nd.nD;
+        const int sCap = (2 * m + 4) << capShift;
+        bool topD = false; float tDv = 0; long long tDi = 0;
+#define SPUSHL(val_) do { const int2 v__ = (val_); if (sTop < sCap) S[sTop] = v__; else st |= LRA_ST_CAPACITY; sTop++; } while (0)
+#define BPUSHL(val_) do { const int2 v__ = (val_); if (nBlk < bCap) B[nBlk] = v__; else st |= LRA_ST_CAPACITY; nBlk++; lastB = v__; } while (0)
+        for (int i = nd.last + 1; i <= now && !st; ++i) {
+          const Ent di_ = D[i];
+          const int db = di_.b;
+          if (db == -1) break;
+          const long long di = di_.val; const float dvi = di_.v;
+          const long long edb = E[db].val;
+          if (top.y == n + 1) { BPUSHL(make_int2(-1, db)); SPUSHL(make_int2(i, n)); top = make_int2(i, n); tDv = dvi; tDi = di; topD = true; }
+          while (sTop > 1 && db >= top.y) { BPUSHL(top); sTop--; top = S[sTop - 1]; topD = false; }
+          if (top.x < 0) { st |= LRA_ST_OOB_SLOT; break; }
+          if (!topD) { const Ent e = D[top.x]; tDv = e.v; tDi = e.val; topD = true; }
+          if (dvi + W(di, edb) > tDv + W(tDi, edb)) {
+            if (db < top.y && nBlk > 0 && db > lastB.y) BPUSHL(make_int2(top.x, db));
+            int2 cur = top; float cDv = tDv; long long cDi = tDi; int prevY = cur.y;
+            while (sTop > 0) {
+              if (cur.x < 0 || cur.y < 1) { st |= LRA_ST_OOB_SLOT; break; }
+              const long long e = E[cur.y - 1].val;
+              if (!(dvi + W(di, e) > cDv + W(cDi, e))) break;
+              sTop--; prevY = cur.y;
+              if (sTop == 0) { st |= LRA_ST_OOB_SLOT; break; }
+              cur = S[sTop - 1];
+              if (cur.y == n + 1) break;
+              if (cur.x < 0) { st |= LRA_ST_OOB_SLOT; break; }
+              const Ent ce = D[cur.x]; cDv = ce.v; cDi = ce.val;
+            }
+            if (st) break;
+            unsigned first = (unsigned)n;                                 // FindBoundary :239-263
+            if (cur.x != -1) {
+              first = (unsigned)prevY;
+              unsigned count = (unsigned)cur.y - first;
+              while (count > 0) {
+                const unsigned step = count / 2, it = first + step;
+                const long long e = E[it].val;
+                if (dvi + W(di, e) > cDv + W(cDi, e)) { first = it + 1; count -= step + 1; } else count = step;
+              }
+            }
+            SPUSHL(make_int2(i, (int)first)); top = make_int2(i, (int)first); tDv = dvi; tDi = di; topD = true;
+          }
+        }
+#undef SPUSHL
+#undef BPUSHL
+      }
+      // phase 1b, one owner at a time, the whole wave: long insertion runs  for (i = last + 1; i <= now; ++i)  of Maximization :275-328
+      unsigned long long todo = __ballot(need && now > nd.last && !small);
       while (todo) {
         const int owner = __ffsll((long long)todo) - 1;
         todo &= todo - 1;
@@ -630,7 +699,7 @@ __global__ void __launch_bounds__(64) sdp_process(ProcArgs a) {
         int oTop = rl_i(sTop, owner), oBlk = rl_i(nBlk, owner);
         int2* oS = stkR + (uint32_t)rl_i((int)nd.stkOff, owner);
         int2* oB = blkR + (uint32_t)rl_i((int)nd.blkOff, owner);
-        const int oSCap = 2 * om + 4, oBCap = 2 * (om + on) + 8;
+        const int oSCap = (2 * om + 4) << capShift, oBCap = (2 * (om + on) + 8) << capShift;
         int2 otop = make_int2(rl_i(top.x, owner), rl_i(top.y, owner)), olastB = make_int2(rl_i(lastB.x, owner), rl_i(lastB.y, owner));
         uint32_t ost = 0;
         bool topD = false; float tDv = 0; long long tDi = 0;
@@ -738,7 +807,7 @@ __global__ void __launch_bounds__(64) sdp_process(ProcArgs a) {
       bad |= st;
       // Value[ii]: visits apply in the order R family deepest level first, then C family; `val < Ev` keeps the first maximum
       if (!bad) {
-        const int ord = fam2 * 16 + (15 - level);
+        const int ord = fam2 * LV + (LV - 1 - level);
         float bv = got ? ev : -1.f; int bo = got ? ord : 64;
         for (int o = 32; o > 0; o >>= 1) {
           const float ov = __shfl_xor(bv, o); const int oo = __shfl_xor(bo, o);
@@ -779,7 +848,7 @@ struct TraceArgs {
   const uint32_t* fq; const uint32_t* ft; const int32_t* flen; const uint32_t* fcl; const uint32_t* fai;
   const float* fval; const uint32_t* fprevNode; const uint32_t* fprevInd; const uint8_t* fflags; const uint32_t* opay;
   uint8_t* used;
-  const ReadArena* ra; const char* arena;
+  const ReadArena* ra;
   uint32_t* nChains; uint64_t* chainStart; uint32_t* chainLen; uint32_t* chainBox; float* chainValue;
   uint32_t* ccl; uint32_t* can; uint8_t* clink; uint32_t* cq; uint32_t* ct; int32_t* clen; uint8_t* cstrand; const uint8_t* fstrand;
   const uint32_t* status;
@@ -794,8 +863,8 @@ __global__ void __launch_bounds__(64) sdp_trace(TraceArgs a) {
   a.nChains[r] = 0;
   if (total == 0 || a.status[r]) return;
   const ReadArena A = a.ra[rr];
-  const Node* nodesR = (const Node*)(a.arena + A.base);
-  const uint32_t* apR = (const uint32_t*)(a.arena + A.base + A.apOff);
+  const Node* nodesR = (const Node*)(uintptr_t)A.base;
+  const uint32_t* apR = (const uint32_t*)((const char*)(uintptr_t)A.base + A.apOff);
   if (a.single) {                                                        // SparseDP.h:2417-2434: first anchor of maximal value, plain TraceBack :1521
     float maxv = 0; uint32_t i = 0;
     for (int l = 0; l < total; l++) if (a.fval[f0 + l] > maxv) { maxv = a.fval[f0 + l]; i = l; }
@@ -1005,7 +1074,9 @@ extern "C" int lra_sparse_dp_batch(lra_ctx* ctx, int n_reads, const uint64_t* d_
   { int rc = lra_sort_minimizers_batch(ctx, n_reads, ptOff, key3, pay3); if (rc) return rc; }       // diagonal order per point class
   LRA_HIP_CHECK(ctx, hipGetLastError());
   // ---- chunks of reads: decompositions, ProcessPoint, trace
-  const uint64_t chunkPts = 24u << 20;
+  // one chunk if it fits: the kernels' duration is set by the longest read once the chip is no longer full, so few large launches
+  // beat many small ones (32768 reads: 4 chunks of 8192 took 4 x 105 ms in sdp_process)
+  const uint64_t chunkPts = 44ull << 20;      // ~36 GB of arenas per chunk; a 32768-read batch of 30 kb reads is two chunks
   uint64_t totalEntries = 0;
   for (int r0 = 0; r0 < n_reads;) {
     int r1 = r0 + 1;
@@ -1014,44 +1085,78 @@ extern "C" int lra_sparse_dp_batch(lra_ctx* ctx, int n_reads, const uint64_t* d_
     const uint64_t cp = h_pt[r1] - h_pt[r0];
     if (cp == 0) { r0 = r1; continue; }
     const size_t nr1 = (size_t)nr + 1;
-    size_t needS = sz(28 * cp + 64 * (size_t)nr + 64, 4) + sz(nr1, 4) * 4 + sz(nr1 + 1, 8) * 3 + sz(nr1, sizeof(ReadArena)) + 4096;
+    size_t needS = sz(28 * cp + 64 * (size_t)nr + 64, 4) + sz(nr1, 4) * 6 + sz(nr1 + 1, 8) * 3 + sz(nr1, sizeof(ReadArena)) + 4096;
     char* ws = (char*)lra_ensure(ctx, 10, needS);
     if (!ws) return LRA_ERR_NOMEM;
     uint32_t* scratch = (uint32_t*)take(ws, 28 * cp + 64 * (size_t)nr + 64, 4);
     uint32_t* cntE = (uint32_t*)take(ws, nr1, 4); uint32_t* cntN = (uint32_t*)take(ws, nr1, 4); uint32_t* cntD = (uint32_t*)take(ws, nr1, 4);
-    uint32_t* cntV = (uint32_t*)take(ws, nr1, 4);
+    uint32_t* cntV = (uint32_t*)take(ws, nr1, 4); uint32_t* order = (uint32_t*)take(ws, nr1, 4); uint32_t* order2 = (uint32_t*)take(ws, nr1, 4);
+    std::vector<uint32_t> h_orderAll, h_prev;
+    {
+      std::vector<uint32_t> h_order(nr);
+      for (int i = 0; i < nr; i++) h_order[i] = (uint32_t)i;
+      std::sort(h_order.begin(), h_order.end(), [&](uint32_t x, uint32_t y) {
+        const uint64_t px = h_pt[r0 + x + 1] - h_pt[r0 + x], py = h_pt[r0 + y + 1] - h_pt[r0 + y];
+        return px != py ? px > py : x < y;
+      });
+      LRA_HIP_CHECK(ctx, hipMemcpyAsync(order, h_order.data(), (size_t)nr * 4, hipMemcpyHostToDevice, st));
+      LRA_HIP_CHECK(ctx, hipStreamSynchronize(st));
+      h_orderAll = h_order;
+    }
     uint64_t* entOff = (uint64_t*)take(ws, nr1 + 1, 8); uint64_t* bytes = (uint64_t*)take(ws, nr1 + 1, 8); uint64_t* byteOff = (uint64_t*)take(ws, nr1 + 1, 8);
     ReadArena* ra = (ReadArena*)take(ws, nr1, sizeof(ReadArena));
     BuildArgs ba;
     memset(&ba, 0, sizeof ba);
     ba.r0 = r0; ba.n = nr; ba.ptOff = ptOff; ba.hq = hq; ba.ht = ht; ba.hfl = hfl; ba.h2 = pay2; ba.key3 = key3; ba.pay3 = pay3; ba.scratch = scratch;
-    ba.cntEntries = cntE; ba.cntNodes = cntN; ba.cntD = cntD; ba.cntV = cntV; ba.status = status;
+    ba.cntEntries = cntE; ba.cntNodes = cntN; ba.cntD = cntD; ba.cntV = cntV; ba.status = status; ba.order = order;
     lra_time_begin(ctx, "sdp_build_count");
     hipLaunchKernelGGL(sdp_build<false>, dim3(nr), dim3(64), 0, st, ba);
-    hipLaunchKernelGGL(k_arena_sizes, dim3((nr + 255) / 256), dim3(256), 0, st, nr, r0, ptOff, cntE, cntN, cntD, ra, bytes);
     lra_time_end(ctx);
     { int rc = lra_exclusive_scan<uint32_t>(ctx, nr, cntE, entOff); if (rc) return rc; }
-    { int rc = lra_exclusive_scan<uint64_t>(ctx, nr, bytes, byteOff); if (rc) return rc; }
-    uint64_t tot[2];
-    LRA_HIP_CHECK(ctx, hipMemcpyAsync(&tot[0], entOff + nr, 8, hipMemcpyDeviceToHost, st));
-    LRA_HIP_CHECK(ctx, hipMemcpyAsync(&tot[1], byteOff + nr, 8, hipMemcpyDeviceToHost, st));
-    LRA_HIP_CHECK(ctx, hipStreamSynchronize(st));
-    totalEntries += tot[0];
-    char* arena = (char*)lra_ensure(ctx, 12, tot[1] + 4096);
-    if (!arena) return LRA_ERR_NOMEM;
-    hipLaunchKernelGGL(k_arena_bases, dim3((nr + 255) / 256), dim3(256), 0, st, nr, byteOff, ra);
-    lra_time_begin(ctx, "sdp_build");
-    hipLaunchKernelGGL(k_visit_clear, dim3(nr), dim3(256), 0, st, ra, byteOff, arena);
-    ba.ra = ra; ba.arena = arena;
-    hipLaunchKernelGGL(sdp_build<true>, dim3(nr), dim3(64), 0, st, ba);
-    lra_time_end(ctx);
-    ProcArgs pa;
-    pa.r0 = r0; pa.n = nr; pa.ptOff = ptOff; pa.fragOff = fragOff; pa.hfl = hfl; pa.hfr = hfr; pa.flen = flen; pa.fval = fval;
-    pa.fprevNode = fprevNode; pa.fprevInd = fprevInd; pa.fflags = fflags; pa.rate_in = d_rate; pa.rate = opts->rate; pa.ra = ra; pa.arena = arena;
-    pa.status = status; pa.pwl = pw;
-    lra_time_begin(ctx, "sdp_process");
-    hipLaunchKernelGGL(sdp_process, dim3(nr), dim3(64), 0, st, pa);
-    lra_time_end(ctx);
+    uint64_t totE = 0;
+    LRA_HIP_CHECK(ctx, hipMemcpyAsync(&totE, entOff + nr, 8, hipMemcpyDeviceToHost, st));
+    // attempt 0: all reads of the chunk; attempts 1, 2: the reads whose candidate stack / Block outgrew its slots, with 8x / 64x the slots
+    std::vector<uint32_t> h_status(nr), h_sub;
+    uint32_t* subOrder = order;
+    int nsub = nr;
+    for (int att = 0; att < 3 && nsub > 0; att++) {
+      const int shift = 3 * att;
+      const int slot = att == 0 ? 12 : 21 + att;
+      hipLaunchKernelGGL(k_arena_sizes, dim3((nsub + 255) / 256), dim3(256), 0, st, nsub, r0, ptOff, cntE, cntN, cntD, ra, bytes, subOrder, shift);
+      { int rc = lra_exclusive_scan<uint64_t>(ctx, nsub, bytes, byteOff); if (rc) return rc; }
+      uint64_t totB = 0;
+      LRA_HIP_CHECK(ctx, hipMemcpyAsync(&totB, byteOff + nsub, 8, hipMemcpyDeviceToHost, st));
+      LRA_HIP_CHECK(ctx, hipStreamSynchronize(st));
+      if (att == 0) totalEntries += totE;
+      char* arena = (char*)lra_ensure(ctx, slot, totB + 4096);
+      if (!arena) return LRA_ERR_NOMEM;
+      hipLaunchKernelGGL(k_arena_bases, dim3((nsub + 255) / 256), dim3(256), 0, st, nsub, byteOff, ra, subOrder, arena);
+      lra_time_begin(ctx, "sdp_build");
+      hipLaunchKernelGGL(k_visit_clear, dim3(nsub), dim3(256), 0, st, ra, byteOff, subOrder);
+      ba.ra = ra; ba.order = subOrder;
+      hipLaunchKernelGGL(sdp_build<true>, dim3(nsub), dim3(64), 0, st, ba);
+      lra_time_end(ctx);
+      if (att > 0)
+        hipLaunchKernelGGL(k_reset_frags, dim3(nsub), dim3(64), 0, st, r0, subOrder, fragOff, flen, d_rate, opts->rate, fval, fprevNode, fprevInd, fflags, status);
+      ProcArgs pa;
+      pa.r0 = r0; pa.n = nsub; pa.order = subOrder; pa.ptOff = ptOff; pa.fragOff = fragOff; pa.hfl = hfl; pa.hfr = hfr; pa.flen = flen; pa.fval = fval;
+      pa.fprevNode = fprevNode; pa.fprevInd = fprevInd; pa.fflags = fflags; pa.rate_in = d_rate; pa.rate = opts->rate; pa.ra = ra;
+      pa.status = status; pa.pwl = pw;
+      lra_time_begin(ctx, "sdp_process");
+      hipLaunchKernelGGL(sdp_process, dim3(nsub), dim3(64), 0, st, pa);
+      lra_time_end(ctx);
+      if (att == 2) break;
+      LRA_HIP_CHECK(ctx, hipMemcpyAsync(h_status.data(), status + r0, (size_t)nr * 4, hipMemcpyDeviceToHost, st));
+      LRA_HIP_CHECK(ctx, hipStreamSynchronize(st));
+      h_sub.clear();
+      for (int i = 0; i < nsub; i++) { const uint32_t rr = att == 0 ? h_orderAll[i] : h_prev[i]; if (h_status[rr] & LRA_ST_CAPACITY) h_sub.push_back(rr); }
+      nsub = (int)h_sub.size();
+      if (nsub == 0) break;
+      h_prev = h_sub;
+      LRA_HIP_CHECK(ctx, hipMemcpyAsync(order2, h_sub.data(), (size_t)nsub * 4, hipMemcpyHostToDevice, st));
+      LRA_HIP_CHECK(ctx, hipStreamSynchronize(st));
+      subOrder = order2;
+    }
     const uint64_t cf0 = h_frag[r0], cfn = h_frag[r1] - h_frag[r0];
     if (cfn > 0) {
       lra_time_begin(ctx, "sdp_trace");
@@ -1061,7 +1166,7 @@ extern "C" int lra_sparse_dp_batch(lra_ctx* ctx, int n_reads, const uint64_t* d_
       TraceArgs ta;
       ta.r0 = r0; ta.n = nr; ta.numAln = opts->NumAln; ta.single = opts->mode == LRA_SDP_SINGLE_CLUSTER; ta.alnthres = opts->alnthres; ta.fragOff = fragOff; ta.read_off = d_read_off; ta.fq = fq; ta.ft = ft;
       ta.flen = flen; ta.fcl = fcl; ta.fai = fai; ta.fval = fval; ta.fprevNode = fprevNode; ta.fprevInd = fprevInd; ta.fflags = fflags; ta.opay = opay; ta.used = used;
-      ta.ra = ra; ta.arena = arena; ta.nChains = nChains; ta.chainStart = chainStart; ta.chainLen = chainLen;
+      ta.ra = ra; ta.nChains = nChains; ta.chainStart = chainStart; ta.chainLen = chainLen;
       ta.chainBox = chainBox; ta.chainValue = chainValue; ta.ccl = ccl; ta.can = can; ta.clink = clink; ta.status = status;
       ta.cq = cq; ta.ct = ct; ta.clen = clen; ta.cstrand = cstrand; ta.fstrand = fstrand;
       lra_time_begin(ctx, "sdp_trace");

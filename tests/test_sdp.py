@@ -212,3 +212,57 @@ def test_hip_sdp_chained_after_hip_extend(ctx, oracle):
             box = out["chain_box"][r * res.num_aln]
             hit += int(box[2] >= s0 - 300 and box[2] <= s0 + L + 300)
     assert hit >= 35
+
+
+@pytest.mark.gpu
+def test_hip_sdp_bench_workload_flags_and_sample(ctx, oracle):
+    """bench-like reads (30 kb, 10 % error, repeats in a 16 Mb genome): every read the kernel flags must be one where the reference itself
+    reads outside its arrays (oracle status -1), never a work-buffer bound; a sample of the others must match the oracle."""
+    import torch
+    from lra_amd import synth_torch as st, seed, cluster, chain
+    dev = ctx.device
+    genome = st.make_genome(16_000_000, 1, dev)
+    ik, ip = st.build_global_index(genome, 17, 10, 150)
+    sim = st.simulate_batch(genome, 1024, 30000, 3000, 0.10, (30, 35, 35), 77)
+    pad = torch.zeros(64, dtype=torch.uint8, device=dev)
+    reads = torch.cat([sim["seq"], pad])
+    seed.load_reference(ctx, genome.cpu().numpy(), ik, ip)
+    rb = seed.read_batch_from_device(ctx, reads, sim["off"])
+    seed.seed_batch(ctx, rb, 17, 10, 150)
+    po = dict(oracle.CLEAN_PRESETS["ONT"]); po["globalK"] = 17
+    cres = cluster.clean_matches_batch(ctx, cluster.CleanOpts(**po), [0, int(genome.numel())])
+    eres = cluster.linear_extend_batch(ctx, 17, rb)
+    res = chain.sparse_dp_batch(ctx, 1024, cres.d_cluster_off, eres.d_e_start, eres.d_e_count, cres.d_c_strand, eres.d_e_qpos, eres.d_e_tpos, eres.d_e_len,
+                                rb.off, chain.sdp_opts())
+    out = chain.fetch(ctx, res)
+    co = cluster.fetch(ctx, cres); eo = cluster.fetch_extend(ctx, eres)
+    off = sim["off"].cpu().numpy()
+    flagged = np.nonzero(out["status"])[0].tolist()
+    sample = sorted(set(flagged + list(range(0, 1024, 37))))
+    reads_in = {}
+    for r in sample:
+        offs = [0]; stv = []; Q = []; T = []; L = []
+        for x in range(int(co["cluster_off"][r]), int(co["cluster_off"][r + 1])):
+            a, n = int(eo["e_start"][x]), int(eo["e_count"][x])
+            Q.extend(eo["e_qpos"][a:a + n].tolist()); T.extend(eo["e_tpos"][a:a + n].tolist()); L.extend(eo["e_len"][a:a + n].tolist())
+            stv.append(int(co["strand"][x])); offs.append(len(Q))
+        reads_in[r] = (np.array(offs, np.int32), np.array(stv, np.uint8), np.array(Q, np.uint32), np.array(T, np.uint32), np.array(L, np.int32))
+    n_ok = 0
+    for r in sample:
+        offs, stv, q, t, ln = reads_in[r]
+        exp = O.sdp_chain(offs, stv, q, t, ln, O.sdp_opts(int(off[r + 1] - off[r])))
+        if out["status"][r] != 0:
+            assert out["status"][r] & 8 == 0, (r, "work-buffer bound hit", out["status"][r])
+            assert exp["status"] < 0, (r, out["status"][r])
+            continue
+        assert exp["status"] >= 0, r
+        f0, f1 = int(out["frag_off"][r]), int(out["frag_off"][r + 1])
+        assert np.array_equal(out["frag_val"][f0:f1].view(np.uint32), exp["val"].view(np.uint32)), r
+        assert int(out["n_chains"][r]) == len(exp["chains"]), r
+        for c, ch in enumerate(exp["chains"]):
+            s = r * res.num_aln + c
+            a = int(out["chain_start"][s]); m = int(out["chain_len"][s])
+            cl = np.searchsorted(offs, ch["frags"], side="right") - 1
+            assert m == len(ch["frags"]) and np.array_equal(out["chain_cluster"][a:a + m], cl) and np.array_equal(out["chain_anchor"][a:a + m], ch["frags"] - offs[cl]), (r, c)
+        n_ok += 1
+    assert n_ok >= 20
