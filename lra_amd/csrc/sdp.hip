@@ -51,19 +51,21 @@ __device__ __forceinline__ int wave_incl_scan(int v, int lane) {
 struct PwlTab { long long stops[25]; float slope[25], inter[25]; int c1, c2; };
 
 struct Ent { long long val; int b; float v; };   // one Di / Ei slot: diagonal, Db / Eb, Dv / Ev   (16 bytes)
-struct Node {            // one full sub-problem (SubProblem.h:15-37), 32 bytes
+struct Node {            // one full sub-problem (SubProblem.h:15-37), 40 bytes
   uint32_t dBase;        // entry index of Di[0] within the read's entries; Ei[0] at dBase + nD
   uint32_t nD, nE;
   int32_t last;
   uint32_t sTop, nBlk;   // sizes of S_1 and Block
-  uint32_t stkOff, blkOff;   // capacities: stack 2 nD + 4 pairs, Block 2 (nD + nE) + 8 pairs
+  uint32_t stkOff, blkOff;   // where they live, in pairs from the read's pair area (stacks, Blocks, then the growth pool)
+  uint32_t stkCap, blkCap;   // their current capacities: 2 nD + 4 and 2 (nD + nE) + 8 pairs to begin with, doubled from the pool on demand
 };
 
 // Everything ProcessPoint touches for one read lies in one contiguous block (sections 256-byte aligned): a wave's working set is a
 // couple of megabytes in one place instead of six arrays gigabytes apart (TLB reach).
-struct ReadArena { uint64_t base; uint32_t entOff, apOff, stkOff, blkOff, visOff, capShift; };   // base: device address; byte offsets from it; nodes at 0
-// capShift: the candidate stack and Block of a sub-problem have (2 nD + 4) << capShift and (2 (nD + nE) + 8) << capShift slots.  Re-inserted
-// candidates (`last` moving backwards) can outgrow any fixed multiple, so reads that hit the bound are re-run with capShift 3, then 6.
+struct ReadArena { uint64_t base; uint32_t entOff, apOff, stkOff, visOff, blkPair, poolPair, poolPairs, pad; };   // base: device address; byte offsets; nodes at 0
+// The pair area at stkOff holds the candidate stacks, then (from pair index blkPair) the Block lists, then (from poolPair) a pool of
+// poolPairs pairs.  Re-inserted candidates (`last` moving backwards) let a stack / Block outgrow any fixed multiple of its sub-problem, so
+// they start at 2 nD + 4 / 2 (nD + nE) + 8 pairs and double out of the pool when full; a read that exhausts its pool is re-run with 8x, 64x.
 
 __device__ __host__ inline uint32_t al256(uint64_t x) { return (uint32_t)((x + 255) & ~(uint64_t)255); }
 
@@ -74,12 +76,13 @@ __global__ void k_arena_sizes(int n, int r0, const uint64_t* __restrict__ ptOff,
   const int rr = (int)order[b];
   const uint64_t E = cntE[rr], N = cntN[rr], D = cntD[rr], P = ptOff[r0 + rr + 1] - ptOff[r0 + rr];
   ReadArena a;
-  a.base = 0; a.capShift = (uint32_t)shift;
+  a.base = 0; a.pad = 0;
   uint64_t o = al256(N * sizeof(Node));
   a.entOff = (uint32_t)o; o = al256(o + E * sizeof(Ent));
   a.apOff = (uint32_t)o; o = al256(o + E * 4);
-  a.stkOff = (uint32_t)o; o = al256(o + (((2 * D + 4 * N) << shift) + 2) * 8);
-  a.blkOff = (uint32_t)o; o = al256(o + (((2 * E + 8 * N) << shift) + 2) * 8);
+  const uint64_t stkPairs = 2 * D + 4 * N + 2, blkPairs = 2 * E + 8 * N + 2, poolPairs = (2 * E + 4096) << shift;
+  a.stkOff = (uint32_t)o; a.blkPair = (uint32_t)stkPairs; a.poolPair = (uint32_t)(stkPairs + blkPairs); a.poolPairs = (uint32_t)poolPairs;
+  o = al256(o + (stkPairs + blkPairs + poolPairs) * 8);
   a.visOff = (uint32_t)o; o = al256(o + P * 2 * LV * sizeof(uint2));
   ra[rr] = a;
   bytes[b] = o;
@@ -264,11 +267,11 @@ __global__ void __launch_bounds__(64, 8) sdp_build(BuildArgs a) {
   wave_sync();
   uint32_t nEntries = 0, nNodesTot = 0, sumD = 0, nVisits = 0;
   Node* nodesR = nullptr; Ent* entR = nullptr; uint32_t* apR = nullptr; int2* stkR = nullptr; uint2* visR = nullptr;
-  int capShift = 0;
+  uint32_t blkPair = 0;
   if (EMIT) {
     const ReadArena A = a.ra[rr];
     char* b = (char*)(uintptr_t)A.base;
-    capShift = (int)A.capShift;
+    blkPair = A.blkPair;
     nodesR = (Node*)b; entR = (Ent*)(b + A.entOff); apR = (uint32_t*)(b + A.apOff); stkR = (int2*)(b + A.stkOff); visR = (uint2*)(b + A.visOff);
   }
   bool overflow = false;
@@ -401,7 +404,7 @@ __global__ void __launch_bounds__(64, 8) sdp_build(BuildArgs a) {
           if (EMIT && full) {
             Node nd;
             nd.dBase = base; nd.nD = nD; nd.nE = nE; nd.last = -1; nd.sTop = 1; nd.nBlk = 0;
-            nd.stkOff = (2 * dpre + 4 * gid) << capShift; nd.blkOff = (2 * base + 8 * gid) << capShift;
+            nd.stkOff = 2 * dpre + 4 * gid; nd.blkOff = blkPair + 2 * base + 8 * gid; nd.stkCap = 2 * nD + 4; nd.blkCap = 2 * (nD + nE) + 8;
             nodesR[gid] = nd;
             stkR[nd.stkOff] = make_int2(-1, (int)nE + 1);     // dummy pair (DivideSubByRow1.h:470)
           }
@@ -506,7 +509,7 @@ struct ProcArgs {
   const uint8_t* hfl; const uint32_t* hfr;
   const int32_t* flen; float* fval; uint32_t* fprevNode; uint32_t* fprevInd; uint8_t* fflags;
   const float* rate_in; float rate;
-  const ReadArena* ra;
+  const ReadArena* ra; uint32_t* poolUsed;
   uint32_t* status;
   PwlTab pwl;
 };
@@ -565,6 +568,29 @@ __device__ __forceinline__ unsigned coop_search(unsigned first, unsigned count, 
   return first;
 }
 
+// a stack / Block that is full moves to twice the room in the read's pool (the old room is abandoned)
+__device__ bool grow_pairs(int2* pairs, uint32_t& off, int& cap, int used, uint32_t* poolUsed, uint32_t poolPair, uint32_t poolPairs) {
+  const uint32_t ncap = 2u * (uint32_t)cap;
+  const uint32_t at = atomicAdd(poolUsed, ncap);
+  if (at + ncap > poolPairs) return false;
+  int2* dst = pairs + poolPair + at; const int2* src = pairs + off;
+  for (int k = 0; k < used && k < cap; k++) dst[k] = src[k];
+  off = poolPair + at; cap = (int)ncap;
+  return true;
+}
+__device__ bool coop_grow_pairs(int2* pairs, uint32_t& off, int& cap, int used, uint32_t* poolUsed, uint32_t poolPair, uint32_t poolPairs, int lane) {
+  const uint32_t ncap = 2u * (uint32_t)cap;
+  uint32_t at = 0;
+  if (lane == 0) at = atomicAdd(poolUsed, ncap);
+  at = (uint32_t)__builtin_amdgcn_readfirstlane((int)at);
+  if (at + ncap > poolPairs) return false;
+  int2* dst = pairs + poolPair + at; const int2* src = pairs + off;
+  for (int k = lane; k < used && k < cap; k += 64) dst[k] = src[k];
+  wave_sync();
+  off = poolPair + at; cap = (int)ncap;
+  return true;
+}
+
 // One wave per read.  The points are walked in H1 order (ProcessPoint :1015-1171); lane (family pair, level) < 32 owns the
 // sub-problem the point touches on that level.  End points (PassValueToD*) are one independent update per lane.  For a start
 // point the lanes whose sub-problem has a usable Eb take turns as owner of a wave-cooperative Maximization (:270-345): the
@@ -585,18 +611,18 @@ __global__ void __launch_bounds__(64) sdp_process(ProcArgs a) {
   const float rate = a.rate_in ? a.rate_in[r] : a.rate;
   const ReadArena A = a.ra[rr];
   char* ab = (char*)(uintptr_t)A.base;
-  const int capShift = (int)A.capShift;
   Node* nodes = (Node*)ab;
   Ent* ent = (Ent*)(ab + A.entOff);
   uint32_t* Ap = (uint32_t*)(ab + A.apOff);
-  int2* stkR = (int2*)(ab + A.stkOff);
-  int2* blkR = (int2*)(ab + A.blkOff);
+  int2* pairs = (int2*)(ab + A.stkOff);                                  // stacks, Blocks and the growth pool of this read
+  const uint32_t poolPair = A.poolPair, poolPairs = A.poolPairs;
+  uint32_t* poolUsed = a.poolUsed + rr;
   const uint2* visR = (const uint2*)(ab + A.visOff);
   const int fam2 = lane < LV ? 0 : 1, level = lane < LV ? lane : lane - LV;   // lanes >= 2 * LV have no visits
   uint32_t bad = 0;
   // per-lane cache of the sub-problem this lane touched last (descriptor, stack top, last Block pair): consecutive points mostly
   // stay in the same sub-problem on the upper levels
-  Node cn; cn.dBase = 0; cn.nD = 0; cn.nE = 0; cn.last = -1; cn.sTop = 0; cn.nBlk = 0; cn.stkOff = 0; cn.blkOff = 0;
+  Node cn; cn.dBase = 0; cn.nD = 0; cn.nE = 0; cn.last = -1; cn.sTop = 0; cn.nBlk = 0; cn.stkOff = 0; cn.blkOff = 0; cn.stkCap = 0; cn.blkCap = 0;
   uint32_t cId = NONE;
   int2 cTop = make_int2(0, 0), cLastB = make_int2(0, 0);
   bool cTopOk = false;
@@ -623,15 +649,16 @@ __global__ void __launch_bounds__(64) sdp_process(ProcArgs a) {
     } else {                                                             // start point (:1025-1060)
       // phase 0, every lane for its own sub-problem: Eb[i1] (+ Db[Eb + 1]), stack top, last Block pair
       Node nd = cn;
-      if (v.x == NONE) { nd.dBase = 0; nd.nD = 0; nd.nE = 0; nd.last = -1; nd.sTop = 0; nd.nBlk = 0; nd.stkOff = 0; nd.blkOff = 0; }
+      if (v.x == NONE) { nd.dBase = 0; nd.nD = 0; nd.nE = 0; nd.last = -1; nd.sTop = 0; nd.nBlk = 0; nd.stkOff = 0; nd.blkOff = 0; nd.stkCap = 0; nd.blkCap = 0; }
       int now = -1, dbn = 0;
       long long ei1 = 0;
       if (v.x != NONE) { const Ent e = ent[nd.dBase + nd.nD + v.y]; now = e.b; ei1 = e.val; dbn = __float_as_int(e.v); }
       const bool need = now != -1;
       const int m = (int)nd.nD, n = (int)nd.nE, i1 = (int)v.y;
       int sTop = (int)nd.sTop, nBlk = (int)nd.nBlk;
-      int2* S = stkR + nd.stkOff; int2* B = blkR + nd.blkOff;
-      const int bCap = (2 * (m + n) + 8) << capShift;
+      uint32_t stkOff = nd.stkOff, blkOff = nd.blkOff;
+      int2* S = pairs + stkOff; int2* B = pairs + blkOff;
+      int sCap = (int)nd.stkCap, bCap = (int)nd.blkCap;
       const Ent* D = ent + nd.dBase;
       int2 top = cTop, lastB = cLastB;
       uint32_t st = 0;
@@ -642,10 +669,11 @@ __global__ void __launch_bounds__(64) sdp_process(ProcArgs a) {
       const bool small = need && now > nd.last && now - nd.last <= LOCAL_MAX;
       if (small) {
         const Ent* E = D + nd.nD;
-        const int sCap = (2 * m + 4) << capShift;
         bool topD = false; float tDv = 0; long long tDi = 0;
-#define SPUSHL(val_) do { const int2 v__ = (val_); if (sTop < sCap) S[sTop] = v__; else st |= LRA_ST_CAPACITY; sTop++; } while (0)
-#define BPUSHL(val_) do { const int2 v__ = (val_); if (nBlk < bCap) B[nBlk] = v__; else st |= LRA_ST_CAPACITY; nBlk++; lastB = v__; } while (0)
+#define SPUSHL(val_) do { const int2 v__ = (val_); if (sTop >= sCap) { if (grow_pairs(pairs, stkOff, sCap, sTop, poolUsed, poolPair, poolPairs)) S = pairs + stkOff; else st |= LRA_ST_CAPACITY; } \
+                          if (sTop < sCap) S[sTop] = v__; sTop++; } while (0)
+#define BPUSHL(val_) do { const int2 v__ = (val_); if (nBlk >= bCap) { if (grow_pairs(pairs, blkOff, bCap, nBlk, poolUsed, poolPair, poolPairs)) B = pairs + blkOff; else st |= LRA_ST_CAPACITY; } \
+                          if (nBlk < bCap) B[nBlk] = v__; nBlk++; lastB = v__; } while (0)
         for (int i = nd.last + 1; i <= now && !st; ++i) {
           const Ent di_ = D[i];
           const int db = di_.b;
@@ -697,14 +725,16 @@ __global__ void __launch_bounds__(64) sdp_process(ProcArgs a) {
         const Ent* oE = oD + om;
         const int olast = rl_i(nd.last, owner), onow = rl_i(now, owner);
         int oTop = rl_i(sTop, owner), oBlk = rl_i(nBlk, owner);
-        int2* oS = stkR + (uint32_t)rl_i((int)nd.stkOff, owner);
-        int2* oB = blkR + (uint32_t)rl_i((int)nd.blkOff, owner);
-        const int oSCap = (2 * om + 4) << capShift, oBCap = (2 * (om + on) + 8) << capShift;
+        uint32_t oStkOff = (uint32_t)rl_i((int)stkOff, owner), oBlkOff = (uint32_t)rl_i((int)blkOff, owner);
+        int2* oS = pairs + oStkOff; int2* oB = pairs + oBlkOff;
+        int oSCap = rl_i(sCap, owner), oBCap = rl_i(bCap, owner);
         int2 otop = make_int2(rl_i(top.x, owner), rl_i(top.y, owner)), olastB = make_int2(rl_i(lastB.x, owner), rl_i(lastB.y, owner));
         uint32_t ost = 0;
         bool topD = false; float tDv = 0; long long tDi = 0;
-#define SPUSH(val_) do { const int2 v__ = (val_); if (oTop < oSCap) oS[oTop] = v__; else ost |= LRA_ST_CAPACITY; oTop++; } while (0)
-#define BPUSH(val_) do { const int2 v__ = (val_); if (oBlk < oBCap) oB[oBlk] = v__; else ost |= LRA_ST_CAPACITY; oBlk++; olastB = v__; } while (0)
+#define SPUSH(val_) do { const int2 v__ = (val_); if (oTop >= oSCap) { if (coop_grow_pairs(pairs, oStkOff, oSCap, oTop, poolUsed, poolPair, poolPairs, lane)) oS = pairs + oStkOff; else ost |= LRA_ST_CAPACITY; } \
+                         if (oTop < oSCap) oS[oTop] = v__; oTop++; } while (0)
+#define BPUSH(val_) do { const int2 v__ = (val_); if (oBlk >= oBCap) { if (coop_grow_pairs(pairs, oBlkOff, oBCap, oBlk, poolUsed, poolPair, poolPairs, lane)) oB = pairs + oBlkOff; else ost |= LRA_ST_CAPACITY; } \
+                         if (oBlk < oBCap) oB[oBlk] = v__; oBlk++; olastB = v__; } while (0)
         bool stop = false;
         for (int i0 = olast + 1; i0 <= onow && !stop && !ost; i0 += 64) {
           const int j = i0 + lane;
@@ -763,14 +793,17 @@ __global__ void __launch_bounds__(64) sdp_process(ProcArgs a) {
         }
 #undef SPUSH
 #undef BPUSH
-        if (lane == owner) { sTop = oTop; nBlk = oBlk; top = otop; lastB = olastB; st |= ost; }
+        if (lane == owner) { sTop = oTop; nBlk = oBlk; top = otop; lastB = olastB; st |= ost; stkOff = oStkOff; blkOff = oBlkOff; sCap = oSCap; bCap = oBCap; S = oS; B = oB; }
       }
       // phase 2, every lane for its own sub-problem: the flush of Maximization :330-343, FindValueInBlock :224-236, Ev / Ep
       float ev = -1.f;
       bool got = false;
       if (need && !st) {
-        if (now == m - 1) { while (sTop > 1 && top.y != n + 1) { if (nBlk < bCap) B[nBlk] = top; else st |= LRA_ST_CAPACITY; nBlk++; lastB = top; sTop--; top = S[sTop - 1]; } }
-        else { while (sTop > 1 && dbn >= top.y) { if (nBlk < bCap) B[nBlk] = top; else st |= LRA_ST_CAPACITY; nBlk++; lastB = top; sTop--; top = S[sTop - 1]; } }
+#define BPUSH2(val_) do { const int2 v__ = (val_); if (nBlk >= bCap) { if (grow_pairs(pairs, blkOff, bCap, nBlk, poolUsed, poolPair, poolPairs)) B = pairs + blkOff; else st |= LRA_ST_CAPACITY; } \
+                          if (nBlk < bCap) B[nBlk] = v__; nBlk++; lastB = v__; } while (0)
+        if (now == m - 1) { while (sTop > 1 && top.y != n + 1 && !st) { BPUSH2(top); sTop--; top = S[sTop - 1]; } }
+        else { while (sTop > 1 && dbn >= top.y && !st) { BPUSH2(top); sTop--; top = S[sTop - 1]; } }
+#undef BPUSH2
         int i2 = -1;
         if (!st && nBlk > 0) {
           if (i1 >= lastB.y && i1 < top.y) i2 = top.x;
@@ -799,7 +832,10 @@ __global__ void __launch_bounds__(64) sdp_process(ProcArgs a) {
           Ap[nd.dBase + nd.nD + i1] = (uint32_t)i2;                       // Ep[i1] (Ev[i1] is never read again)
           Node* np = nodes + v.x;
           np->last = now; np->sTop = (uint32_t)sTop; np->nBlk = (uint32_t)nBlk;
-          cn.last = now; cn.sTop = (uint32_t)sTop; cn.nBlk = (uint32_t)nBlk; cTop = top; cLastB = lastB; cTopOk = true;
+          if (stkOff != nd.stkOff) { np->stkOff = stkOff; np->stkCap = (uint32_t)sCap; }
+          if (blkOff != nd.blkOff) { np->blkOff = blkOff; np->blkCap = (uint32_t)bCap; }
+          cn.last = now; cn.sTop = (uint32_t)sTop; cn.nBlk = (uint32_t)nBlk; cn.stkOff = stkOff; cn.blkOff = blkOff; cn.stkCap = (uint32_t)sCap; cn.blkCap = (uint32_t)bCap;
+          cTop = top; cLastB = lastB; cTopOk = true;
         }
       }
       const uint32_t myI1 = v.y;
@@ -1085,12 +1121,12 @@ extern "C" int lra_sparse_dp_batch(lra_ctx* ctx, int n_reads, const uint64_t* d_
     const uint64_t cp = h_pt[r1] - h_pt[r0];
     if (cp == 0) { r0 = r1; continue; }
     const size_t nr1 = (size_t)nr + 1;
-    size_t needS = sz(28 * cp + 64 * (size_t)nr + 64, 4) + sz(nr1, 4) * 6 + sz(nr1 + 1, 8) * 3 + sz(nr1, sizeof(ReadArena)) + 4096;
+    size_t needS = sz(28 * cp + 64 * (size_t)nr + 64, 4) + sz(nr1, 4) * 7 + sz(nr1 + 1, 8) * 3 + sz(nr1, sizeof(ReadArena)) + 4096;
     char* ws = (char*)lra_ensure(ctx, 10, needS);
     if (!ws) return LRA_ERR_NOMEM;
     uint32_t* scratch = (uint32_t*)take(ws, 28 * cp + 64 * (size_t)nr + 64, 4);
     uint32_t* cntE = (uint32_t*)take(ws, nr1, 4); uint32_t* cntN = (uint32_t*)take(ws, nr1, 4); uint32_t* cntD = (uint32_t*)take(ws, nr1, 4);
-    uint32_t* cntV = (uint32_t*)take(ws, nr1, 4); uint32_t* order = (uint32_t*)take(ws, nr1, 4); uint32_t* order2 = (uint32_t*)take(ws, nr1, 4);
+    uint32_t* cntV = (uint32_t*)take(ws, nr1, 4); uint32_t* order = (uint32_t*)take(ws, nr1, 4); uint32_t* order2 = (uint32_t*)take(ws, nr1, 4); uint32_t* poolUsed = (uint32_t*)take(ws, nr1, 4);
     std::vector<uint32_t> h_orderAll, h_prev;
     {
       std::vector<uint32_t> h_order(nr);
@@ -1141,7 +1177,8 @@ extern "C" int lra_sparse_dp_batch(lra_ctx* ctx, int n_reads, const uint64_t* d_
       ProcArgs pa;
       pa.r0 = r0; pa.n = nsub; pa.order = subOrder; pa.ptOff = ptOff; pa.fragOff = fragOff; pa.hfl = hfl; pa.hfr = hfr; pa.flen = flen; pa.fval = fval;
       pa.fprevNode = fprevNode; pa.fprevInd = fprevInd; pa.fflags = fflags; pa.rate_in = d_rate; pa.rate = opts->rate; pa.ra = ra;
-      pa.status = status; pa.pwl = pw;
+      pa.status = status; pa.pwl = pw; pa.poolUsed = poolUsed;
+      LRA_HIP_CHECK(ctx, hipMemsetAsync(poolUsed, 0, (size_t)nr * 4, st));
       lra_time_begin(ctx, "sdp_process");
       hipLaunchKernelGGL(sdp_process, dim3(nsub), dim3(64), 0, st, pa);
       lra_time_end(ctx);
