@@ -31,6 +31,9 @@
 #include "scan.h"
 #include <algorithm>
 #include <cmath>
+#include <cstring>
+#include <cstdlib>
+#include <rocprim/rocprim.hpp>
 
 namespace {
 
@@ -1107,7 +1110,20 @@ extern "C" int lra_sparse_dp_batch(lra_ctx* ctx, int n_reads, const uint64_t* d_
                      key3, pay3, fragOff, fspos, fSpos2);
   lra_time_end(ctx);
   { int rc = lra_sort_minimizers_batch(ctx, n_reads, ptOff, key2, pay2); if (rc) return rc; }       // sort(H2, SortByColOp)  :2174
-  { int rc = lra_sort_minimizers_batch(ctx, n_reads, ptOff, key3, pay3); if (rc) return rc; }       // diagonal order per point class
+  // diagonal order per point class: any sorted order serves (ties are the same diagonal), so this one is a segmented radix sort -- the
+  // exact introsort degenerates on the long runs of equal diagonals.  Sorted into the (now free) key1 / pay1 buffers.
+  {
+    size_t temp_bytes = 0;
+    (void)rocprim::segmented_radix_sort_pairs(nullptr, temp_bytes, (uint64_t*)nullptr, (uint64_t*)nullptr, (uint32_t*)nullptr, (uint32_t*)nullptr,
+                                              (unsigned int)NP, (unsigned int)n_reads, (uint64_t*)nullptr, (uint64_t*)nullptr, 0, 42, st);
+    void* temp = lra_scratch(ctx, 2, temp_bytes + 256);
+    if (!temp) return LRA_ERR_NOMEM;
+    lra_time_begin(ctx, "sdp_sort");
+    hipError_t e = rocprim::segmented_radix_sort_pairs(temp, temp_bytes, key3, key1, pay3, pay1, (unsigned int)NP, (unsigned int)n_reads, ptOff, ptOff + 1,
+                                                       0, 42, st);
+    lra_time_end(ctx);
+    if (e != hipSuccess) return lra_set_err(ctx, LRA_ERR_HIP, "segmented sort: %s", hipGetErrorString(e));
+  }
   LRA_HIP_CHECK(ctx, hipGetLastError());
   // ---- chunks of reads: decompositions, ProcessPoint, trace
   // one chunk if it fits: the kernels' duration is set by the longest read once the chip is no longer full, so few large launches
@@ -1143,7 +1159,7 @@ extern "C" int lra_sparse_dp_batch(lra_ctx* ctx, int n_reads, const uint64_t* d_
     ReadArena* ra = (ReadArena*)take(ws, nr1, sizeof(ReadArena));
     BuildArgs ba;
     memset(&ba, 0, sizeof ba);
-    ba.r0 = r0; ba.n = nr; ba.ptOff = ptOff; ba.hq = hq; ba.ht = ht; ba.hfl = hfl; ba.h2 = pay2; ba.key3 = key3; ba.pay3 = pay3; ba.scratch = scratch;
+    ba.r0 = r0; ba.n = nr; ba.ptOff = ptOff; ba.hq = hq; ba.ht = ht; ba.hfl = hfl; ba.h2 = pay2; ba.key3 = key1; ba.pay3 = pay1; ba.scratch = scratch;
     ba.cntEntries = cntE; ba.cntNodes = cntN; ba.cntD = cntD; ba.cntV = cntV; ba.status = status; ba.order = order;
     lra_time_begin(ctx, "sdp_build_count");
     hipLaunchKernelGGL(sdp_build<false>, dim3(nr), dim3(64), 0, st, ba);
