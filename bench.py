@@ -277,6 +277,14 @@ def main():
         }.get(dom, 0)
         alg = alg_step / launches_per_step
         achieved = alg / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
+        # HBM traffic per launch: from the committed PMC pass (profiles/pmc_latest.json) when it was taken on launches of the same size
+        traffic = None
+        try:
+            pmc = json.load(open(os.path.join(ROOT, "profiles", "pmc_latest.json")))["kernels"].get(dom)
+            if pmc and abs(pmc["reads_per_launch"] - args.reads / launches_per_step) < 1:
+                traffic = pmc["fetch_bytes_per_launch"]
+        except (OSError, ValueError, KeyError):
+            pass
         out = {
             "metric": "aligned Gbp/s (hot-path stages a1-a5, a7, a8 SDP#A, a9 split, a10 primitives, a12, a14, a16), 30 kb ONT-like reads", "value": gbps, "unit": "Gbp/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_step, "higher_is_better": True,
@@ -292,7 +300,7 @@ def main():
                        "per_step": {k: int(v) for k, v in stats.items() if not k.startswith("_")}},
             "kernel_ms_per_step": {k: round(v[0] / args.steps, 4) for k, v in ktimes.items() if v[1]},
             "roofline": {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": 8000.0, "unit": "GB/s", "frac": achieved / 8000.0,
-                         "traffic": None, "avg_launch_ms": avg_ms, "algorithmic_bytes_per_launch": alg},
+                         "traffic": traffic, "avg_launch_ms": avg_ms, "algorithmic_bytes_per_launch": alg},
         }
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(wl, args)
