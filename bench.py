@@ -48,6 +48,7 @@ def build_workload(args, rank, device):
     gaps = st.gap_problems(sim)
     rblocks, rboff = st.perturbed_blocks(sim, 5 + rank)
     torch.cuda.synchronize()
+    torch.cuda.empty_cache()                                                 # hand the generator's temporaries back: the stages need the room
     return dict(genome=genome, idx_key=idx_key, idx_pos=idx_pos, sim=sim, strands=strands, reads=reads, gaps=gaps, rev=rev,
                 rblocks=rblocks, rboff=rboff, gen_s=time.time() - t0)
 

@@ -1127,8 +1127,9 @@ extern "C" int lra_sparse_dp_batch(lra_ctx* ctx, int n_reads, const uint64_t* d_
   LRA_HIP_CHECK(ctx, hipGetLastError());
   // ---- chunks of reads: decompositions, ProcessPoint, trace
   // one chunk if it fits: the kernels' duration is set by the longest read once the chip is no longer full, so few large launches
-  // beat many small ones (32768 reads: 4 chunks of 8192 took 4 x 105 ms in sdp_process)
-  const uint64_t chunkPts = 44ull << 20;      // ~36 GB of arenas per chunk; a 32768-read batch of 30 kb reads is two chunks
+  // beat many small ones (32768 reads, sdp_process: 4 chunks 420 ms, 2 chunks 255 ms, 1 chunk 187 ms)
+  uint64_t chunkPts = 96ull << 20;            // ~75 GB of arenas per chunk: a 32768-read batch of 30 kb reads (80 M points) is one chunk
+  if (const char* e = getenv("LRA_SDP_CHUNK_MPOINTS")) { const long v = atol(e); if (v > 0) chunkPts = (uint64_t)v << 20; }   // tuning knob
   uint64_t totalEntries = 0;
   for (int r0 = 0; r0 < n_reads;) {
     int r1 = r0 + 1;
