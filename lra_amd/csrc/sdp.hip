@@ -216,7 +216,7 @@ struct BuildArgs {
   const uint32_t* order;                     // block b works on read r0 + order[b] (largest first: the longest waves start first)
   const uint64_t* ptOff;
   const uint32_t* hq; const uint32_t* ht; const uint8_t* hfl; const uint32_t* h2; const uint64_t* key3; const uint32_t* pay3;
-  uint32_t* scratch;                         // 28 words per point + 64 per read
+  uint32_t* scratch;                         // 34 words per point + 64 per read
   uint32_t* cntEntries; uint32_t* cntNodes; uint32_t* cntD; uint32_t* cntV;   // [n] (count pass out)
   const ReadArena* ra;                       // emit pass: per-read blocks
   uint32_t* status;
@@ -230,7 +230,7 @@ __global__ void __launch_bounds__(64, 8) sdp_build(BuildArgs a) {
   if (P == 0) { if (!EMIT && lane == 0) { a.cntEntries[rr] = 0; a.cntNodes[rr] = 0; a.cntD[rr] = 0; a.cntV[rr] = 0; } return; }
   const uint32_t* hq = a.hq + p0; const uint32_t* ht = a.ht + p0; const uint32_t* h2 = a.h2 + p0;
   const uint64_t* key3 = a.key3 + p0; const uint32_t* pay3 = a.pay3 + p0;
-  uint32_t* S = a.scratch + 28 * (p0 - pc0) + 64 * (uint64_t)rr;
+  uint32_t* S = a.scratch + 34 * (p0 - pc0) + 64 * (uint64_t)rr;
   const int NCAP = P + 2;
   uint32_t* rowOf = S; uint32_t* colOf = rowOf + P;
   uint32_t* lp = colOf + P;                 // [2][P]
@@ -239,6 +239,8 @@ __global__ void __launch_bounds__(64, 8) sdp_build(BuildArgs a) {
   uint32_t* ph = pf + P + 1;                // [P+1]
   uint32_t* tbl = ph + P + 1;               // [2][6][NCAP]
   uint32_t* tmp = tbl + 12 * NCAP;          // [8][NCAP]
+  uint32_t* ll = tmp + 8 * NCAP;            // [2][P]  line (row / column index) of the element: travels with it, no gathers per level
+  long long* ld = (long long*)(ll + 2 * P);  // [2][P]  its diagonal (word offset 30 P + 42 from S: even, so 8-byte aligned)
 #define TB(c, f, k) tbl[((c) * 6 + (f)) * NCAP + (k)]
 #define TM(f, k) tmp[(f) * NCAP + (k)]
   enum { F_LS, F_LE, F_SB, F_SE, F_EB, F_EE };
@@ -288,7 +290,11 @@ __global__ void __launch_bounds__(64, 8) sdp_build(BuildArgs a) {
     if (nS == 0 || nEn == 0) continue;
     const int fam2 = fam & 1;
     const int dSide = swapped ? 1 : 0, eSide = swapped ? 0 : 1;
-    for (int i = lane; i < Pf; i += 64) { lp[i] = pay3[cOff[sc] + i]; ln[i] = 0; }
+    for (int i = lane; i < Pf; i += 64) {
+      const uint32_t pos = pay3[cOff[sc] + i];
+      lp[i] = pos; ln[i] = 0; ll[i] = lineOf[pos];
+      ld[i] = back ? (long long)ht[pos] + hq[pos] : (long long)ht[pos] - hq[pos];
+    }
     if (lane == 0) { TB(0, F_LS, 0) = 0; TB(0, F_LE, 0) = nLines; TB(0, F_SB, 0) = 0; TB(0, F_SE, 0) = nS; TB(0, F_EB, 0) = nS; TB(0, F_EE, 0) = Pf; }
     int nNodes = 1, cur = 0;
     wave_sync();
@@ -296,6 +302,8 @@ __global__ void __launch_bounds__(64, 8) sdp_build(BuildArgs a) {
       if (level >= LV) { overflow = true; break; }
       const int nxt = cur ^ 1;
       uint32_t* lpc = lp + cur * P; uint32_t* lpn = lp + nxt * P;
+      uint32_t* llc = ll + cur * P; uint32_t* lln = ll + nxt * P;
+      long long* ldc = ld + (size_t)cur * P; long long* ldn = ld + (size_t)nxt * P;
       // A: which elements go to the first half of their node's lines; exclusive prefix in pf
       {
         int carry = 0;
@@ -306,7 +314,7 @@ __global__ void __launch_bounds__(64, 8) sdp_build(BuildArgs a) {
             const uint32_t k = ln[i];
             if (k != NONE) {
               const uint32_t s = TB(cur, F_LS, k), e = TB(cur, F_LE, k);
-              f = (e - s > 1) ? (lineOf[lpc[i]] < ((s + e) >> 1)) : 1;
+              f = (e - s > 1) ? (llc[i] < ((s + e) >> 1)) : 1;
             }
           }
           const int inc = wave_incl_scan(f, lane);
@@ -331,7 +339,7 @@ __global__ void __launch_bounds__(64, 8) sdp_build(BuildArgs a) {
         const uint32_t rank1 = pf[i] - pf[sb];
         const uint32_t first = pf[i + 1] - pf[i];
         const uint32_t np_ = first ? sb + rank1 : sb + c1 + ((uint32_t)i - sb - rank1);
-        lpn[np_] = lpc[i];
+        lpn[np_] = lpc[i]; lln[np_] = llc[i]; ldn[np_] = ldc[i];
         ln[P + np_] = 2 * k + (first ? 0 : 1);
       }
       wave_sync();
@@ -353,10 +361,7 @@ __global__ void __launch_bounds__(64, 8) sdp_build(BuildArgs a) {
                 if (!leaf && side == 1) beg += isS ? TM(T_C1S, k) : TM(T_C1E, k);
                 if ((uint32_t)j == beg) head = 1;
                 else {
-                  const uint32_t a0 = lpn[j], a1 = lpn[j - 1];
-                  const int64_t d0 = back ? (int64_t)ht[a0] + hq[a0] : (int64_t)ht[a0] - hq[a0];
-                  const int64_t d1 = back ? (int64_t)ht[a1] + hq[a1] : (int64_t)ht[a1] - hq[a1];
-                  head = d0 != d1;
+                  head = ldn[j] != ldn[j - 1];
                 }
               }
             }
@@ -437,7 +442,7 @@ __global__ void __launch_bounds__(64, 8) sdp_build(BuildArgs a) {
               const uint32_t idx = desc ? n - 1 - grp : grp;
               const uint32_t ent = TM(T_BASE, k) + (isS ? TM(T_ND, k) + idx : idx);
               const uint32_t pos = lpn[j];
-              if (head) entR[ent].val = back ? (int64_t)ht[pos] + hq[pos] : (int64_t)ht[pos] - hq[pos];
+              if (head) entR[ent].val = ldn[j];
               visR[(uint64_t)pos * (2 * LV) + fam2 * LV + level] = make_uint2(gid, idx);
             }
           }
@@ -1138,10 +1143,10 @@ extern "C" int lra_sparse_dp_batch(lra_ctx* ctx, int n_reads, const uint64_t* d_
     const uint64_t cp = h_pt[r1] - h_pt[r0];
     if (cp == 0) { r0 = r1; continue; }
     const size_t nr1 = (size_t)nr + 1;
-    size_t needS = sz(28 * cp + 64 * (size_t)nr + 64, 4) + sz(nr1, 4) * 7 + sz(nr1 + 1, 8) * 3 + sz(nr1, sizeof(ReadArena)) + 4096;
+    size_t needS = sz(34 * cp + 64 * (size_t)nr + 64, 4) + sz(nr1, 4) * 7 + sz(nr1 + 1, 8) * 3 + sz(nr1, sizeof(ReadArena)) + 4096;
     char* ws = (char*)lra_ensure(ctx, 10, needS);
     if (!ws) return LRA_ERR_NOMEM;
-    uint32_t* scratch = (uint32_t*)take(ws, 28 * cp + 64 * (size_t)nr + 64, 4);
+    uint32_t* scratch = (uint32_t*)take(ws, 34 * cp + 64 * (size_t)nr + 64, 4);
     uint32_t* cntE = (uint32_t*)take(ws, nr1, 4); uint32_t* cntN = (uint32_t*)take(ws, nr1, 4); uint32_t* cntD = (uint32_t*)take(ws, nr1, 4);
     uint32_t* cntV = (uint32_t*)take(ws, nr1, 4); uint32_t* order = (uint32_t*)take(ws, nr1, 4); uint32_t* order2 = (uint32_t*)take(ws, nr1, 4); uint32_t* poolUsed = (uint32_t*)take(ws, nr1, 4);
     std::vector<uint32_t> h_orderAll, h_prev;
