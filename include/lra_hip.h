@@ -379,6 +379,25 @@ int lra_calculate_statistics_batch(lra_ctx* ctx, int n_aln, const int32_t* d_blo
                                    const char* d_tseq, const uint64_t* d_t_off, const float* h_lookup, int n_lookup,
                                    lra_stats_result* out);
 
+/* ---- a15: junctions of split alignments ---------------------------------------------------------------------
+ * Replaces   RefineBreakpoint(read, genome, leftAln, rightAln, opts)   (RefineBreakpoint.h:210-466; Map_lowacc.h:592, Map_highacc.h:725)
+ * for n junctions: if the read bases between the two segments (in forward read coordinates) number 1..499, both segments are extended into
+ * the gap by a full DP (RSdp: match 2, mismatch -2, gap -4), cut where the summed score is best, and the new blocks are glued on
+ * (PrependBlocks / AppendBlocks).  Per junction and side: the segment's blocks (CSR, (qPos,tPos,length) triples), its strand, the offset
+ * of Alignment::read (the read strand it is aligned on) in d_seq, the offset and length of its chromosome in d_genome; d_read_len.
+ * Output (context-owned): the two block lists after the call, at d_*_blocks + 3 * d_*_off[j] with d_*_n[j] blocks each; status bit
+ * 0x10000 = refined, LRA_ST_OOB_SLOT = the reference would read outside the read / chromosome (lists unchanged).  Synchronous.   */
+typedef struct lra_breakpoint_result {
+  uint64_t n_junctions;
+  const int32_t* d_l_blocks; const uint64_t* d_l_off; const int32_t* d_l_n;
+  const int32_t* d_r_blocks; const uint64_t* d_r_off; const int32_t* d_r_n;
+  const uint32_t* d_status;
+} lra_breakpoint_result;
+int lra_refine_breakpoint_batch(lra_ctx* ctx, int n, const int32_t* d_read_len, const char* d_seq, const char* d_genome, const int32_t* d_l_blocks,
+                                const uint64_t* d_l_off, const int32_t* d_l_strand, const uint64_t* d_l_read_off, const uint64_t* d_l_chrom_off,
+                                const int32_t* d_l_chrom_len, const int32_t* d_r_blocks, const uint64_t* d_r_off, const int32_t* d_r_strand,
+                                const uint64_t* d_r_read_off, const uint64_t* d_r_chrom_off, const int32_t* d_r_chrom_len, lra_breakpoint_result* out);
+
 /* ---- a17: SAM / PAF / BED records (host code, no device work) ------------------------------------------
  * Byte-for-byte the text of  Alignment::PrintSAM (Alignment.h:658-808), SimplePrintSAM (:811-905), PrintPAF (:600-656) and
  * PrintBed (:591-598) for alignments described by plain records (the fields those functions read).  Tags in the reference's order:

@@ -47,3 +47,26 @@ def fetch_between(ctx: Context, res: BetweenResult):
     n, m = res.n_gaps, res.n_blocks
     return {"block_off": ctx.to_host(res.d_block_off, n + 1, np.uint64), "blocks": ctx.to_host(res.d_blocks, 3 * m, np.int32).reshape(-1, 3),
             "score": ctx.to_host(res.d_score, n, np.int32), "status": ctx.to_host(res.d_status, n, np.uint32)}
+
+
+class BreakpointResult(C.Structure):
+    _fields_ = [("n_junctions", C.c_uint64), ("d_l_blocks", C.c_void_p), ("d_l_off", C.c_void_p), ("d_l_n", C.c_void_p), ("d_r_blocks", C.c_void_p),
+                ("d_r_off", C.c_void_p), ("d_r_n", C.c_void_p), ("d_status", C.c_void_p)]
+
+
+def refine_breakpoint_batch(ctx: Context, n, read_len, seq, genome, l_blocks, l_off, l_strand, l_read_off, l_chrom_off, l_chrom_len, r_blocks, r_off,
+                            r_strand, r_read_off, r_chrom_off, r_chrom_len):
+    """RefineBreakpoint (RefineBreakpoint.h:210) for n junctions; array arguments are device tensors."""
+    res = BreakpointResult()
+    ctx.check(ctx.lib.lra_refine_breakpoint_batch(ctx.h, int(n), ptr(read_len), ptr(seq), ptr(genome), ptr(l_blocks), ptr(l_off), ptr(l_strand),
+                                                  ptr(l_read_off), ptr(l_chrom_off), ptr(l_chrom_len), ptr(r_blocks), ptr(r_off), ptr(r_strand),
+                                                  ptr(r_read_off), ptr(r_chrom_off), ptr(r_chrom_len), C.byref(res)))
+    return res
+
+
+def fetch_breakpoint(ctx: Context, res: BreakpointResult, l_total_cap, r_total_cap):
+    n = res.n_junctions
+    return {"l_off": ctx.to_host(res.d_l_off, n + 1, np.uint64), "l_n": ctx.to_host(res.d_l_n, n, np.int32),
+            "l_blocks": ctx.to_host(res.d_l_blocks, 3 * l_total_cap, np.int32).reshape(-1, 3),
+            "r_off": ctx.to_host(res.d_r_off, n + 1, np.uint64), "r_n": ctx.to_host(res.d_r_n, n, np.int32),
+            "r_blocks": ctx.to_host(res.d_r_blocks, 3 * r_total_cap, np.int32).reshape(-1, 3), "status": ctx.to_host(res.d_status, n, np.uint32)}

@@ -400,3 +400,17 @@ def between_anchors(q: bytes, t: bytes, cur_read_end, next_read_start, cur_genom
     if n < 0:
         return None
     return blocks[:3 * n].reshape(n, 3).copy(), score.value
+
+
+# ---- RefineBreakpoint (a15) -------------------------------------------------------------------------------------------
+def refine_breakpoint(read_len, l_blocks, l_strand, l_read: bytes, l_chrom: bytes, r_blocks, r_strand, r_read: bytes, r_chrom: bytes):
+    """-> (ret, left blocks [n,3], right blocks [n,3]); ret 1 refined, 0 untouched, -1 the reference reads outside its inputs"""
+    L = lib()
+    lb = np.ascontiguousarray(l_blocks, np.int32).reshape(-1); rb = np.ascontiguousarray(r_blocks, np.int32).reshape(-1)
+    nl, nr = len(lb) // 3, len(rb) // 3
+    lo = np.zeros(3 * (nl + 502), np.int32); ro = np.zeros(3 * (nr + 502), np.int32); nlo = C.c_int(0); nro = C.c_int(0)
+    L.oracle_refine_breakpoint.restype = C.c_int
+    ret = L.oracle_refine_breakpoint(int(read_len), _p(lb, C.c_int), nl, int(l_strand), C.c_char_p(l_read), C.c_char_p(l_chrom), len(l_chrom),
+                                     _p(rb, C.c_int), nr, int(r_strand), C.c_char_p(r_read), C.c_char_p(r_chrom), len(r_chrom),
+                                     _p(lo, C.c_int), C.byref(nlo), _p(ro, C.c_int), C.byref(nro))
+    return ret, lo[:3 * nlo.value].reshape(-1, 3).copy(), ro[:3 * nro.value].reshape(-1, 3).copy()

@@ -117,3 +117,71 @@ def test_hip_between_anchors_oracle(ctx):
             if len(exp[0]): assert out["score"][i] == exp[1], i
             nb += b - a
         assert (nb > 500) == bool(refine_dp)
+
+
+def _junction(rng, read_len, chrom_len, seq_f, seq_r):
+    """two segments with a gap of `span` forward read bases between them; any strand combination; a few blocks each"""
+    span = int(rng.choice([1, 2, 7, 40, 180, 350, 499, 500, 700]))
+    flqe = int(rng.integers(700, 1200)); frqs = flqe + span
+    ls, rs = int(rng.integers(0, 2)), int(rng.integers(0, 2))
+
+    def blocks(q0, t0, n, back):
+        out = []; q, t = q0, t0
+        for _ in range(n):
+            ln = int(rng.integers(5, 60))
+            if back: q -= ln; t -= ln
+            out.append([q, t, ln])
+            if not back: q += ln; t += ln
+            g = int(rng.integers(0, 4))
+            if back: q -= g; t -= int(rng.integers(0, 4))
+            else: q += g; t += int(rng.integers(0, 4))
+        return sorted(out)
+    # left segment ends (forward coordinates) at flqe
+    lt = int(rng.choice([rng.integers(2000, chrom_len - 2000), chrom_len - int(rng.integers(0, 300)), int(rng.integers(100, 400))]))
+    if ls == 0: L = blocks(flqe, lt, int(rng.integers(1, 4)), True)                       # its last block ends at q = flqe
+    else: L = blocks(read_len - flqe, lt, int(rng.integers(1, 4)), False)                 # reverse strand: GetQStart = readLen - flqe
+    rt = int(rng.choice([rng.integers(2000, chrom_len - 2000), int(rng.integers(0, 300)), chrom_len - int(rng.integers(100, 400))]))
+    if rs == 0: R = blocks(frqs, rt, int(rng.integers(1, 4)), False)                      # starts at q = frqs
+    else: R = blocks(read_len - frqs, rt, int(rng.integers(1, 4)), True)                  # reverse strand: GetQEnd = readLen - frqs
+    ok = all(b[0] >= 0 and b[1] >= 0 and b[0] + b[2] <= read_len and b[1] + b[2] <= chrom_len for b in L + R)
+    return (L, ls, R, rs) if ok else None
+
+
+@pytest.mark.gpu
+def test_hip_refine_breakpoint_oracle(ctx):
+    import torch
+    from lra_amd import gapseed
+    rng = np.random.default_rng(21)
+    read_len, chrom_len = 3000, 20000
+    alpha = np.frombuffer(b"AACCGT", np.uint8)                               # skewed alphabet: chance matches make the DP paths non-trivial
+    seq_f = rng.choice(alpha, read_len).astype(np.uint8).tobytes(); seq_r = rng.choice(alpha, read_len).astype(np.uint8).tobytes()
+    chrom = rng.choice(alpha, chrom_len).astype(np.uint8).tobytes()
+    juncs = []
+    while len(juncs) < 120:
+        j = _junction(rng, read_len, chrom_len, seq_f, seq_r)
+        if j: juncs.append(j)
+    dev = ctx.device
+    T = lambda a, dt: torch.tensor(np.asarray(a, dtype=dt), device=dev)
+    seq = torch.tensor(np.frombuffer(seq_f + seq_r + b"\0" * 64, np.uint8).copy(), device=dev)
+    gen = torch.tensor(np.frombuffer(chrom + b"\0" * 64, np.uint8).copy(), device=dev)
+    lcat = np.array([b for j in juncs for b in j[0]], np.int32); rcat = np.array([b for j in juncs for b in j[2]], np.int32)
+    loff = np.cumsum([0] + [len(j[0]) for j in juncs]); roff = np.cumsum([0] + [len(j[2]) for j in juncs])
+    n = len(juncs)
+    res = gapseed.refine_breakpoint_batch(ctx, n, T([read_len] * n, np.int32), seq, gen, T(lcat.reshape(-1), np.int32), T(loff, np.int64),
+                                          T([j[1] for j in juncs], np.int32), T([j[1] * read_len for j in juncs], np.int64), T([0] * n, np.int64),
+                                          T([chrom_len] * n, np.int32), T(rcat.reshape(-1), np.int32), T(roff, np.int64), T([j[3] for j in juncs], np.int32),
+                                          T([j[3] * read_len for j in juncs], np.int64), T([0] * n, np.int64), T([chrom_len] * n, np.int32))
+    out = gapseed.fetch_breakpoint(ctx, res, int(loff[-1]) + 502 * n, int(roff[-1]) + 502 * n)
+    refined = 0
+    for i, (L, ls, R, rs) in enumerate(juncs):
+        ret, el, er = O.refine_breakpoint(read_len, L, ls, seq_r if ls else seq_f, chrom, R, rs, seq_r if rs else seq_f, chrom)
+        a, b = int(out["l_off"][i]), int(out["r_off"][i])
+        gl = out["l_blocks"][a:a + int(out["l_n"][i])]; gr = out["r_blocks"][b:b + int(out["r_n"][i])]
+        if ret < 0:
+            assert out["status"][i] & 1, i
+            continue
+        assert np.array_equal(gl, el), (i, ls, rs, gl.tolist(), el.tolist())
+        assert np.array_equal(gr, er), (i, ls, rs)
+        assert bool(out["status"][i] & 0x10000) == (ret == 1), i
+        refined += ret == 1
+    assert refined > 40
