@@ -20,13 +20,15 @@
 //    partitioned by half at every level (prefix sums), which yields every node's sorted distinct Di/Ei at once;
 //    Db/Eb have closed forms (counts of smaller diagonals), and every (point, level) gets its sub-problem and its
 //    index in Di/Ei recorded -- the Lower_Bound searches of ProcessPoint/PassValueToD* disappear;
-//  * ProcessPoint: one half wave (32 lanes) per read; lane (family pair, level) owns the sub-problems of that level,
-//    so the <= 32 sub-problems a point touches advance concurrently and no sub-problem is ever touched by two
-//    lanes; the ordered `<` update of Value[ii] becomes a (max value, first in order) reduction;
+//  * ProcessPoint: one wave per read; lane (family pair, level) < 2 * LV owns the sub-problems of that level, so the sub-problems a
+//    point touches advance concurrently and none is ever touched by two lanes; short candidate insertions run per lane, long ones
+//    wave-cooperatively (prefetched candidates, iterations that change nothing skipped with a ballot, six-level probes in the
+//    boundary search); the ordered `<` update of Value[ii] becomes a (max value, first in order) reduction; stacks / Block lists that
+//    fill up double out of a per-read pool;
 //  * TraceBack / DecidePrimaryChains: one lane per read after the exact sort of the values.
 //
-// Roofline: integer/float bookkeeping with dependent loads, HBM-nominal; algorithmic bytes per read =
-// 44 B per sub-problem entry + 16 B per (point, level) visit record.
+// Roofline: integer/float bookkeeping with dependent loads, HBM-nominal; algorithmic bytes = 44 B per sub-problem entry + 269 B per
+// point (visit row + coordinates).  A launch lasts as long as its largest reads: one chunk per batch, largest first.
 #include "common.h"
 #include "scan.h"
 #include <algorithm>
@@ -131,7 +133,7 @@ struct PtArgs {
   const uint32_t* clusRead; const uint64_t* clusFragOff; const uint64_t* clusPtOff; const uint64_t* fragOff; const uint64_t* ptOff;
   const float* rate_in; float rate; int single;
   uint32_t* fq; uint32_t* ft; int32_t* flen; uint32_t* fcl; uint32_t* fai; float* fval; uint32_t* fprevNode; uint32_t* fprevInd; uint8_t* fflags;
-  uint8_t* used; uint8_t* fstrand; unsigned long long* fkey; uint32_t* fspos; uint32_t* fSpos2;
+  uint8_t* used; uint8_t* fstrand;
   uint64_t* key1; uint32_t* pay1; uint32_t* iq; uint32_t* it; uint8_t* ifl; uint32_t* ifr; uint32_t* ptRead;
 };
 
@@ -154,8 +156,6 @@ __global__ void k_points(PtArgs a) {
     a.fq[g] = q; a.ft[g] = t; a.flen[g] = len; a.fcl[g] = cl; a.fai[g] = i;
     a.fval[g] = len * rate;                                            // Value[ii].val = matchesLengths * rate (:2206)
     a.fprevNode[g] = NONE; a.fprevInd[g] = NONE; a.fflags[g] = 3; a.used[g] = 0; a.fstrand[g] = (uint8_t)(strand != 0);
-    a.fkey[g] = ((unsigned long long)__float_as_uint(len * rate) << 32) | 0xFFFFFFFFull;   // (value, no predecessor)
-    a.fspos[g] = 0; a.fSpos2[2 * g] = NONE; a.fSpos2[2 * g + 1] = NONE;
     const bool edge = !a.single && (i == 0 || i == n - 1);                 // the single-cluster SDP (SparseDP.h:2296-2305) inserts one pair only
     for (int rep = 0; rep < (edge ? 2 : 1); rep++) {
       const int pair = (strand == 0) ? rep : 1 - rep;                  // forward cluster: s1/e1 first; reverse: s2/e2 first
@@ -178,7 +178,7 @@ __global__ void k_points(PtArgs a) {
 __global__ void k_gather(uint64_t np, const uint32_t* __restrict__ ptRead, const uint64_t* __restrict__ ptOff, const uint32_t* __restrict__ pay1,
                          const uint32_t* __restrict__ iq, const uint32_t* __restrict__ it, const uint8_t* __restrict__ ifl,
                          const uint32_t* __restrict__ ifr, uint32_t* hq, uint32_t* ht, uint8_t* hfl, uint32_t* hfr, uint64_t* key2,
-                         uint32_t* pay2, uint64_t* key3, uint32_t* pay3, const uint64_t* __restrict__ fragOff, uint32_t* fspos, uint32_t* fSpos2) {
+                         uint32_t* pay2, uint64_t* key3, uint32_t* pay3) {
   uint64_t p = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (p >= np) return;
   const uint64_t p0 = ptOff[ptRead[p]];
@@ -193,11 +193,6 @@ __global__ void k_gather(uint64_t np, const uint32_t* __restrict__ ptRead, const
   const uint64_t dg = inv ? (uint64_t)((int64_t)t - (int64_t)q + (1LL << 32)) : (uint64_t)t + q;
   key3[p] = (cls << 40) | dg;
   pay3[p] = (uint32_t)(p - p0);
-  if (ind) {                                                            // where the fragment's start points sit in H1
-    const uint64_t g = fragOff[ptRead[p]] + ifr[s];
-    atomicMax(&fspos[g], (uint32_t)(p - p0));
-    fSpos2[2 * g + (inv ? 0 : 1)] = (uint32_t)(p - p0);
-  }
 }
 
 // before a read is re-run with larger stacks: Value[] back to its initial state (SparseDP.h:2206), status cleared
@@ -1078,8 +1073,7 @@ extern "C" int lra_sparse_dp_batch(lra_ctx* ctx, int n_reads, const uint64_t* d_
   uint8_t* fflags = (uint8_t*)take(wf, NF + 1, 1); uint8_t* used = (uint8_t*)take(wf, NF + 1, 1); uint8_t* clink = (uint8_t*)take(wf, NF + 1, 1);
   uint8_t* fstrand = (uint8_t*)take(wf, NF + 1, 1); uint8_t* cstrand = (uint8_t*)take(wf, NF + 1, 1);
   uint32_t* cq = (uint32_t*)take(wf, NF + 1, 4); uint32_t* ct = (uint32_t*)take(wf, NF + 1, 4); int32_t* clen = (int32_t*)take(wf, NF + 1, 4);
-  uint64_t* okey = (uint64_t*)take(wf, NF + 1, 8); unsigned long long* fkey = (unsigned long long*)take(wf, NF + 1, 8);
-  uint32_t* fspos = (uint32_t*)take(wf, NF + 1, 4); uint32_t* fSpos2 = (uint32_t*)take(wf, 2 * NF + 2, 4);
+  uint64_t* okey = (uint64_t*)take(wf, NF + 1, 8);
   // ---- points
   size_t needP = sz(NP + 1, 8) * 3 + sz(NP + 1, 4) * 11 + sz(NP + 1, 1) * 2 + sz(NF + 1, 4) * 2 + 4096;
   char* wp = (char*)lra_ensure(ctx, 9, needP);
@@ -1101,7 +1095,6 @@ extern "C" int lra_sparse_dp_batch(lra_ctx* ctx, int n_reads, const uint64_t* d_
     pa.nc = NC; pa.cluster_off = d_cluster_off; pa.c_start = d_c_start; pa.c_count = d_c_count; pa.c_strand = d_c_strand; pa.q = d_q; pa.t = d_t; pa.len = d_len;
     pa.clusRead = clusRead; pa.clusFragOff = clusFragOff; pa.clusPtOff = clusPtOff; pa.fragOff = fragOff; pa.ptOff = ptOff; pa.rate_in = d_rate; pa.rate = opts->rate; pa.single = opts->mode == LRA_SDP_SINGLE_CLUSTER;
     pa.fq = fq; pa.ft = ft; pa.flen = flen; pa.fcl = fcl; pa.fai = fai; pa.fval = fval; pa.fprevNode = fprevNode; pa.fprevInd = fprevInd; pa.fflags = fflags; pa.used = used; pa.fstrand = fstrand;
-    pa.fkey = fkey; pa.fspos = fspos; pa.fSpos2 = fSpos2;
     pa.key1 = key1; pa.pay1 = pay1; pa.iq = iq; pa.it = it; pa.ifl = ifl; pa.ifr = ifr; pa.ptRead = ptRead;
     lra_time_begin(ctx, "sdp_points");
     hipLaunchKernelGGL(k_points, dim3((unsigned)((NC + 127) / 128)), dim3(128), 0, st, pa);
@@ -1112,7 +1105,7 @@ extern "C" int lra_sparse_dp_batch(lra_ctx* ctx, int n_reads, const uint64_t* d_
   { int rc = lra_sort_minimizers_batch(ctx, n_reads, ptOff, key1, pay1); if (rc) return rc; }       // sort(H1, SortByRowOp)  :2171
   lra_time_begin(ctx, "sdp_points");
   hipLaunchKernelGGL(k_gather, dim3((unsigned)((NP + 255) / 256)), dim3(256), 0, st, NP, ptRead, ptOff, pay1, iq, it, ifl, ifr, hq, ht, hfl, hfr, key2, pay2,
-                     key3, pay3, fragOff, fspos, fSpos2);
+                     key3, pay3);
   lra_time_end(ctx);
   { int rc = lra_sort_minimizers_batch(ctx, n_reads, ptOff, key2, pay2); if (rc) return rc; }       // sort(H2, SortByColOp)  :2174
   // diagonal order per point class: any sorted order serves (ties are the same diagonal), so this one is a segmented radix sort -- the
