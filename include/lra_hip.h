@@ -240,6 +240,21 @@ typedef struct lra_split_result {
 int lra_split_chains_batch(lra_ctx* ctx, const lra_chain_result* chains, const uint64_t* h_chrom_pos, int n_chrom, int splitdist,
                            int bypass_clustering, lra_split_result* out);
 
+/* The chain filters of Chain.h on arbitrary chains (CSR d_off[n_chains+1] over anchors given by read pos, genome pos, length, strand of the
+ * cluster, trace-back order; d_link[i] = link bit between anchor i and i+1 of the same chain, NULL if the chain type has none), applied in
+ * the order h_ops[0..n_ops):  1 RemoveSmallPairedIndels (:546)   2 RemovePairedIndels (:607)   3 the same with refineEnds = false
+ * 4 RemoveSpuriousAnchors (:828; leaves `link` longer than the chain, as the reference does)   8 RemoveSpuriousJump (:897).
+ * Map_lowacc.h:538-539 = {2, 4};  LocalRefineAlignment.h:567-571 = {1, 2 (or 3), 4}.
+ * Output (context-owned; shares its buffer with lra_split_chains_batch): d_keep per anchor, d_n_kept per chain, the surviving links
+ * d_link[d_off[c] .. + d_n_link[c]).  Synchronous.                                                                               */
+typedef struct lra_filter_result {
+  uint64_t n_chains, n_anchors;
+  const uint8_t* d_keep; const uint32_t* d_n_kept; const uint8_t* d_link; const uint32_t* d_n_link;
+} lra_filter_result;
+int lra_filter_chains_batch(lra_ctx* ctx, uint64_t n_chains, const uint64_t* d_off, uint64_t n_anchors, const uint32_t* d_q, const uint32_t* d_t,
+                            const int32_t* d_len, const uint8_t* d_strand, const uint8_t* d_link, const int32_t* h_ops, int n_ops,
+                            lra_filter_result* out);
+
 /* ---- a10: tier-2 (local) minimizer index and lookups ----------------------------------------
  * lra_local_index_batch replaces  LocalIndex::IndexSeq(char* seq, int seqLen)  (MMIndex.h:200-245) for
  * n_seqs sequences (read strands, Map_lowacc.h:246-250; or chromosomes = LocalIndex::IndexFile, the

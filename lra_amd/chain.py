@@ -73,3 +73,23 @@ def fetch_split(ctx: Context, res: SplitResult):
             "ci_len": ctx.to_host(res.d_ci_len, nf, u32), "ci_idx": ctx.to_host(res.d_ci_idx, nf, u32),
             "split_link": ctx.to_host(res.d_split_link, nf, u8), "n_split_link": ctx.to_host(res.d_n_split_link, ns, u32),
             "status": ctx.to_host(res.d_status, ns, u32)}
+
+
+class FilterResult(C.Structure):
+    _fields_ = [("n_chains", C.c_uint64), ("n_anchors", C.c_uint64), ("d_keep", C.c_void_p), ("d_n_kept", C.c_void_p), ("d_link", C.c_void_p),
+                ("d_n_link", C.c_void_p)]
+
+
+def filter_chains_batch(ctx: Context, n_chains, off, n_anchors, q, t, length, strand, link, ops):
+    """Chain.h filters (ops: 1 RemoveSmallPairedIndels, 2/3 RemovePairedIndels with/without refineEnds, 4 RemoveSpuriousAnchors,
+    8 RemoveSpuriousJump) on CSR chains; array arguments are device tensors, link may be None."""
+    o = np.ascontiguousarray(ops, dtype=np.int32)
+    res = FilterResult()
+    ctx.check(ctx.lib.lra_filter_chains_batch(ctx.h, C.c_uint64(n_chains), ptr(off), C.c_uint64(n_anchors), ptr(q), ptr(t), ptr(length), ptr(strand),
+                                              ptr(link) if link is not None else None, C.c_void_p(o.ctypes.data), len(o), C.byref(res)))
+    return res
+
+
+def fetch_filter(ctx: Context, res: FilterResult):
+    return {"keep": ctx.to_host(res.d_keep, res.n_anchors, np.uint8), "n_kept": ctx.to_host(res.d_n_kept, res.n_chains, np.uint32),
+            "link": ctx.to_host(res.d_link, res.n_anchors, np.uint8), "n_link": ctx.to_host(res.d_n_link, res.n_chains, np.uint32)}

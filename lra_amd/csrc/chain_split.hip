@@ -211,6 +211,117 @@ __global__ void __launch_bounds__(64) split_kernel(SplitArgs a) {
 #undef FTE
 }
 
+// ---- the chain filters of Chain.h on arbitrary chains: RemoveSmallPairedIndels :546 (op 1), RemovePairedIndels :607 (op 2; op 3 with
+// refineEnds = false), RemoveSpuriousAnchors :828 (op 4, leaves `link` alone), RemoveSpuriousJump :897 (op 8), in the order given.
+// One lane per chain; every filter is two streaming passes (the reference's SV list is only ever compared with its previous entry).
+struct FilterArgs {
+  uint64_t n; const uint64_t* off; const uint32_t* q; const uint32_t* t; const int32_t* len; const uint8_t* strand; const uint8_t* link;
+  int ops[8]; int nOps;
+  uint8_t* keep; uint32_t* nKept; uint8_t* linkOut; uint32_t* nLink; uint32_t* idx; uint8_t* rm;
+};
+
+__global__ void __launch_bounds__(64) filter_kernel(FilterArgs a) {
+  const uint64_t c0 = (uint64_t)blockIdx.x * 64 + threadIdx.x;
+  if (c0 >= a.n) return;
+  const uint64_t base = a.off[c0];
+  const int n = (int)(a.off[c0 + 1] - base);
+  const uint32_t* Q = a.q + base; const uint32_t* T = a.t + base; const int32_t* Ln = a.len + base; const uint8_t* St = a.strand + base;
+  uint8_t* keep = a.keep + base; uint8_t* lk = a.linkOut + base; uint32_t* idx = a.idx + base; uint8_t* rm = a.rm + base;
+  int N = n;
+  int nl = (a.link && n > 0) ? n - 1 : 0;
+  const bool hasLink = a.link != nullptr && nl > 0;
+  for (int i = 0; i < n; i++) idx[i] = (uint32_t)i;
+  for (int i = 0; i < nl; i++) lk[i] = a.link[base + i];
+#define XQ(i) Q[idx[i]]
+#define XT(i) T[idx[i]]
+#define XL(i) Ln[idx[i]]
+#define XS(i) St[idx[i]]
+#define XQE(i) (Q[idx[i]] + (uint32_t)Ln[idx[i]])
+#define XTE(i) (T[idx[i]] + (uint32_t)Ln[idx[i]])
+  for (int oi = 0; oi < a.nOps; oi++) {
+    const int op = a.ops[oi];
+    if (N < 2) continue;
+    for (int i = 0; i < N; i++) rm[i] = 0;
+    auto gap_of = [&](int c) -> int {
+      if (XS(c) == 0) return (int)(((long long)XT(c) - (long long)XQ(c)) - ((long long)XT(c - 1) - (long long)XQ(c - 1)));
+      return (int)((long long)(uint32_t)(XQE(c) + XT(c)) - (long long)(uint32_t)(XQE(c - 1) + XT(c - 1)));
+    };
+    auto dists = [&](int c, long long& tDist, long long& qDist) {         // Chain.h:617-630
+      if (XT(c) > XTE(c - 1)) tDist = (uint32_t)(XT(c) - XTE(c - 1)); else tDist = (uint32_t)(XT(c - 1) - XTE(c));
+      if (XQ(c) > XQE(c - 1)) qDist = (uint32_t)(XQ(c) - XTE(c - 1)); else qDist = (uint32_t)(XQ(c - 1) - XQE(c));
+    };
+    float meanDist = 0, sdDist = 0;
+    const bool refineEnds = op == 2;
+    if (refineEnds) {
+      // `totDistSq += dist*dist` overflows `long` when a distance wrapped around 2^32 (the q distance mixes in tEnd); the reference binary
+      // (x86-64, two's complement wrap, signed conversion) then sees a negative sum, a NaN deviation and calls every distance invalid.
+      long long totalDist = 0; unsigned long long totDistSqU = 0;
+      for (int c = 1; c < N; c++) { long long tD, qD; dists(c, tD, qD); const long long d = min(tD, qD); totDistSqU += (unsigned long long)d * (unsigned long long)d; totalDist += d; }
+      const long long totDistSq = (long long)totDistSqU;
+      const float nDist = (float)(N - 1);
+      meanDist = (float)totalDist / nDist;
+      const float varDist = (float)totDistSq / nDist - meanDist * meanDist;
+      sdDist = __fsqrt_rn(varDist);
+    }
+    int pSV = 0, pPos = -1; bool have = false;
+    for (int c = 1; c < N; c++) {
+      int sv = 0; bool is = false;
+      if (XS(c) == XS(c - 1)) {
+        const int Gap = gap_of(c), ag = abs(Gap);
+        const bool in = op == 1 ? (ag > 5 && ag <= 50) : op == 8 ? ag > 100 : op == 4 ? ag >= 500 : ag > 30;
+        if (in) { sv = Gap; is = true; }
+      } else { sv = 0; is = true; }
+      if (!is) continue;
+      if (have) {
+        const bool opp = ((sv >= 0) != (pSV >= 0)) && sv != 0 && pSV != 0;
+        if (op == 1) { if (opp && abs(sv + pSV) <= 20 && c - pPos < 3) for (int i = pPos; i < c; i++) if (XL(i) <= 50) rm[i] = 1; }
+        else if (op == 8) { if (rm[pPos] == 0 && opp && c - pPos == 1) for (int i = pPos; i < c; i++) if (XL(i) < 50) rm[i] = 1; }
+        else if (op == 4) {
+          if (sv != 0 && pSV != 0 && c - pPos <= 10) {
+            bool check = false;
+            for (int b = pPos; b < c; b++) if (XL(b) >= 50) { check = true; break; }
+            if (!check) for (int i = pPos; i < c; i++) if (XL(i) < 50) rm[i] = 1;
+          }
+        } else {
+          if (opp && abs(sv) >= 300 && abs(pSV) >= 300 && c - pPos < 3) for (int i = pPos; i < c; i++) if (XL(i) < 100) rm[i] = 1;
+          if (opp && abs(sv + pSV) < 100 && c - pPos < 3) for (int i = pPos; i < c; i++) if (XL(i) < 100) rm[i] = 1;
+        }
+      }
+      pSV = sv; pPos = c; have = true;
+    }
+    if (refineEnds) {
+      int firstValid = -1, lastValid = -1;
+      for (int c = 1; c < N; c++) {
+        long long tD, qD; dists(c, tD, qD);
+        const int dist = (int)min(tD, qD);
+        if ((float)dist < meanDist + 4 * sdDist) { if (firstValid == -1) firstValid = c - 1; lastValid = c; }
+      }
+      if (lastValid == -1 || firstValid == -1) for (int i = 0; i < N; i++) if (XL(i) < 100) rm[i] = 1;
+      if (firstValid > 0 && firstValid < 3) for (int i = 0; i < firstValid; i++) if (XL(i) < 100) rm[i] = 1;
+      if (lastValid + 1 <= N && N - lastValid < 3) for (int i = lastValid + 1; i < N; i++) if (XL(i) < 100) rm[i] = 1;
+    }
+    const bool touchLink = op != 4;
+    int m = 0;
+    for (int i = 0; i < N; i++)
+      if (!rm[i]) {
+        idx[m] = idx[i];
+        if (touchLink && hasLink && nl > 0 && m >= 1) lk[m - 1] = lk[i - 1];
+        m++;
+      }
+    N = m;
+    if (touchLink && hasLink && nl > 0) { if (op == 2 || op == 3) { if (m > 0) nl = m - 1; } else nl = m - 1; }
+  }
+  for (int i = 0; i < n; i++) keep[i] = 0;
+  for (int i = 0; i < N; i++) keep[idx[i]] = 1;
+  a.nKept[c0] = (uint32_t)N; a.nLink[c0] = (uint32_t)nl;
+#undef XQ
+#undef XT
+#undef XL
+#undef XS
+#undef XQE
+#undef XTE
+}
+
 inline size_t sz(size_t n, size_t e) { return (n * e + 255) / 256 * 256; }
 
 }  // namespace
@@ -250,5 +361,32 @@ extern "C" int lra_split_chains_batch(lra_ctx* ctx, const lra_chain_result* ch, 
   out->d_keep = a.keep; out->d_n_kept = a.nKept; out->d_link = a.link; out->d_n_split = a.nSplit; out->d_sp_beg = a.spBeg; out->d_sp_len = a.spLen;
   out->d_sp_idx = a.spIdx; out->d_sp_link = a.spLink; out->d_sp_type = a.spType; out->d_sp_strand = a.spStrand; out->d_sp_chrom = a.spChrom; out->d_sp_box = a.spBox;
   out->d_ci_beg = a.ciBeg; out->d_ci_len = a.ciLen; out->d_ci_idx = a.ciIdx; out->d_split_link = a.splitLink; out->d_n_split_link = a.nSplitLink; out->d_status = a.status;
+  return LRA_OK;
+}
+
+extern "C" int lra_filter_chains_batch(lra_ctx* ctx, uint64_t n_chains, const uint64_t* d_off, uint64_t n_anchors, const uint32_t* d_q, const uint32_t* d_t,
+                                       const int32_t* d_len, const uint8_t* d_strand, const uint8_t* d_link, const int32_t* h_ops, int n_ops,
+                                       lra_filter_result* out) {
+  if (!ctx || !out || !h_ops || n_ops < 0 || n_ops > 8) return LRA_ERR_INVALID;
+  for (int i = 0; i < n_ops; i++) if (h_ops[i] != 1 && h_ops[i] != 2 && h_ops[i] != 3 && h_ops[i] != 4 && h_ops[i] != 8) return lra_set_err(ctx, LRA_ERR_INVALID, "unknown chain filter %d", h_ops[i]);
+  memset(out, 0, sizeof *out);
+  out->n_chains = n_chains; out->n_anchors = n_anchors;
+  if (n_chains == 0) return LRA_OK;
+  LRA_HIP_CHECK(ctx, hipSetDevice(ctx->device));
+  hipStream_t st = ctx->stream;
+  auto take = [](char*& p, size_t n, size_t e) { char* r = p; p += sz(n, e); return r; };
+  char* w = (char*)lra_ensure(ctx, 13, sz(n_anchors + 1, 1) * 3 + sz(n_anchors + 1, 4) + sz(n_chains + 1, 4) * 2 + 4096);
+  if (!w) return LRA_ERR_NOMEM;
+  FilterArgs a;
+  a.n = n_chains; a.off = d_off; a.q = d_q; a.t = d_t; a.len = d_len; a.strand = d_strand; a.link = d_link; a.nOps = n_ops;
+  for (int i = 0; i < 8; i++) a.ops[i] = i < n_ops ? h_ops[i] : 0;
+  a.keep = (uint8_t*)take(w, n_anchors + 1, 1); a.linkOut = (uint8_t*)take(w, n_anchors + 1, 1); a.rm = (uint8_t*)take(w, n_anchors + 1, 1);
+  a.idx = (uint32_t*)take(w, n_anchors + 1, 4); a.nKept = (uint32_t*)take(w, n_chains + 1, 4); a.nLink = (uint32_t*)take(w, n_chains + 1, 4);
+  lra_time_begin(ctx, "chain_filter");
+  hipLaunchKernelGGL(filter_kernel, dim3((unsigned)((n_chains + 63) / 64)), dim3(64), 0, st, a);
+  lra_time_end(ctx);
+  LRA_HIP_CHECK(ctx, hipStreamSynchronize(st));
+  LRA_HIP_CHECK(ctx, hipGetLastError());
+  out->d_keep = a.keep; out->d_n_kept = a.nKept; out->d_link = a.linkOut; out->d_n_link = a.nLink;
   return LRA_OK;
 }

@@ -219,3 +219,110 @@ extern "C" int oracle_split_chain(int n, const uint32_t* q, const uint32_t* t, c
   for (size_t k = 0; k < spl.size(); k++) splitLink[k] = spl[k];
   return (int)sp.size();
 }
+
+// ---- the other chain filters of Chain.h, applied in the order given by ops[] to one chain (trace-back order) -------------------
+//   op 1  RemoveSmallPairedIndels :546-603     op 2  RemovePairedIndels(chain, refineEnds) :607-741 (op 3 = with refineEnds false)
+//   op 4  RemoveSpuriousAnchors :828-890 (does not touch `link`)     op 8  RemoveSpuriousJump :897-957
+// Map_lowacc.h:538-539 applies {2, 4} to the chain of the second sparse DP; LocalRefineAlignment.h:567-571 {1, 2 or 3, 4}.
+// Out: keep[] over the ORIGINAL anchors, the surviving links (linkOut, *nLink of them: RemoveSpuriousAnchors leaves the vector longer than
+// the chain, as the reference does).  Returns the number of surviving anchors.
+extern "C" int oracle_filter_chain(int n, const uint32_t* q, const uint32_t* t, const int* len, const uint8_t* strand, const uint8_t* link, int hasLink,
+                                   const int* ops, int nOps, uint8_t* keep, uint8_t* linkOut, int* nLink) {
+  struct A { uint32_t q, t; int len; int strand; int orig; };
+  std::vector<A> ch(n);
+  for (int i = 0; i < n; i++) ch[i] = A{q[i], t[i], len[i], (int)strand[i], i};
+  std::vector<bool> lk;
+  if (hasLink) lk.assign(link, link + (n > 0 ? n - 1 : 0));
+  auto qS = [&](int i) { return ch[i].q; };
+  auto tS = [&](int i) { return ch[i].t; };
+  auto qE = [&](int i) { return ch[i].q + (uint32_t)ch[i].len; };
+  auto tE = [&](int i) { return ch[i].t + (uint32_t)ch[i].len; };
+  auto gap_of = [&](int c) -> int {
+    if (ch[c].strand == 0) return (int)(((long)tS(c) - (long)qS(c)) - ((long)tS(c - 1) - (long)qS(c - 1)));
+    return (int)((long)(qE(c) + tS(c)) - (long)(qE(c - 1) + tS(c - 1)));
+  };
+  for (int oi = 0; oi < nOps; oi++) {
+    const int op = ops[oi];
+    const int N = (int)ch.size();
+    if (N < 2) continue;
+    std::vector<bool> remove(N, false);
+    std::vector<int> SV, SVpos;
+    bool touchLink = true;
+    if (op == 1 || op == 8) {
+      for (int c = 1; c < N; c++) {
+        if (ch[c].strand == ch[c - 1].strand) {
+          int Gap = gap_of(c);
+          bool in = op == 1 ? (std::abs(Gap) > 5 && std::abs(Gap) <= 50) : (std::abs(Gap) > 100);
+          if (in) { SV.push_back(Gap); SVpos.push_back(c); }
+        } else { SVpos.push_back(c); SV.push_back(0); }
+      }
+      for (size_t c = 1; c < SV.size(); c++) {
+        if (op == 1) {
+          if (sgn(SV[c]) != sgn(SV[c - 1]) && SV[c] != 0 && SV[c - 1] != 0 && std::abs(SV[c] + SV[c - 1]) <= 20 && SVpos[c] - SVpos[c - 1] < 3)
+            for (int i = SVpos[c - 1]; i < SVpos[c]; i++) if (ch[i].len <= 50) remove[i] = true;
+        } else if (remove[SVpos[c - 1]] == 0 && sgn(SV[c]) != sgn(SV[c - 1]) && SV[c] != 0 && SV[c - 1] != 0 && SVpos[c] - SVpos[c - 1] == 1)
+          for (int i = SVpos[c - 1]; i < SVpos[c]; i++) if (ch[i].len < 50) remove[i] = true;
+      }
+    } else if (op == 2 || op == 3) {
+      const bool refineEnds = op == 2;
+      long totalDist = 0; unsigned long totDistSqU = 0;                      // dist*dist wraps like the reference binary's `long` does
+      auto dists = [&](int c, long& tDist, long& qDist) {                  // :617-630 (GenomePos arithmetic; the q distance mixes in tEnd, as written)
+        if (tS(c) > tE(c - 1)) tDist = tS(c) - tE(c - 1); else tDist = tS(c - 1) - tE(c);
+        if (qS(c) > qE(c - 1)) qDist = qS(c) - tE(c - 1); else qDist = qS(c - 1) - qE(c);
+      };
+      for (int c = 1; c < N; c++) {
+        if (refineEnds) { long tD, qD; dists(c, tD, qD); long dist = std::min(tD, qD); totDistSqU += (unsigned long)dist * (unsigned long)dist; totalDist += dist; }
+        if (ch[c].strand == ch[c - 1].strand) { int Gap = gap_of(c); if (std::abs(Gap) > 30) { SV.push_back(Gap); SVpos.push_back(c); } }
+        else { SVpos.push_back(c); SV.push_back(0); }
+      }
+      const long totDistSq = (long)totDistSqU;
+      float nDist = N - 1;
+      float meanDist = totalDist / nDist;
+      float varDist = totDistSq / float(nDist) - meanDist * meanDist;
+      float sdDist = std::sqrt(varDist);
+      int firstValid = -1, lastValid = -1;
+      for (size_t c = 1; c < SV.size(); c++) {
+        if (sgn(SV[c]) != sgn(SV[c - 1]) && SV[c] != 0 && SV[c - 1] != 0 && std::abs(SV[c]) >= 300 && std::abs(SV[c - 1]) >= 300 && SVpos[c] - SVpos[c - 1] < 3)
+          for (int i = SVpos[c - 1]; i < SVpos[c]; i++) if (ch[i].len < 100) remove[i] = true;
+        if (sgn(SV[c]) != sgn(SV[c - 1]) && SV[c] != 0 && SV[c - 1] != 0 && std::abs(SV[c] + SV[c - 1]) < 100 && SVpos[c] - SVpos[c - 1] < 3)
+          for (int i = SVpos[c - 1]; i < SVpos[c]; i++) if (ch[i].len < 100) remove[i] = true;
+      }
+      if (refineEnds) {
+        for (int c = 1; c < N; c++) {
+          long tD, qD; dists(c, tD, qD);
+          int dist = (int)std::min(tD, qD);
+          if (dist < meanDist + 4 * sdDist) { if (firstValid == -1) firstValid = c - 1; lastValid = c; }
+        }
+        if (lastValid == -1 || firstValid == -1) for (int i = 0; i < N; i++) if (ch[i].len < 100) remove[i] = true;
+        if (firstValid > 0 && firstValid < 3) for (int i = 0; i < firstValid; i++) if (ch[i].len < 100) remove[i] = true;
+        if (lastValid + 1 <= N && N - lastValid < 3) for (int i = lastValid + 1; i < N; i++) if (ch[i].len < 100) remove[i] = true;
+      }
+    } else if (op == 4) {
+      touchLink = false;
+      for (int c = 1; c < N; c++) {
+        if (ch[c].strand == ch[c - 1].strand) { int Gap = gap_of(c); if (std::abs(Gap) >= 500) { SV.push_back(Gap); SVpos.push_back(c); } }
+        else { SVpos.push_back(c); SV.push_back(0); }
+      }
+      for (size_t c = 1; c < SV.size(); c++)
+        if (SV[c] != 0 && SV[c - 1] != 0 && SVpos[c] - SVpos[c - 1] <= 10) {
+          bool check = false;
+          for (int b = SVpos[c - 1]; b < SVpos[c]; b++) if (ch[b].len >= 50) { check = true; break; }
+          if (!check) for (int i = SVpos[c - 1]; i < SVpos[c]; i++) if (ch[i].len < 50) remove[i] = true;
+        }
+    }
+    int m = 0;
+    for (int i = 0; i < N; i++)
+      if (!remove[i]) {
+        ch[m] = ch[i];
+        if (touchLink && !lk.empty() && m >= 1) lk[m - 1] = lk[i - 1];
+        m++;
+      }
+    ch.resize(m);
+    if (touchLink && !lk.empty()) { if (op == 2 || op == 3) { if (m > 0) lk.resize(m - 1); } else lk.resize(m - 1); }
+  }
+  for (int i = 0; i < n; i++) keep[i] = 0;
+  for (auto& a : ch) keep[a.orig] = 1;
+  *nLink = (int)lk.size();
+  for (size_t i = 0; i < lk.size(); i++) linkOut[i] = lk[i];
+  return (int)ch.size();
+}

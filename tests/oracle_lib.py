@@ -414,3 +414,20 @@ def refine_breakpoint(read_len, l_blocks, l_strand, l_read: bytes, l_chrom: byte
                                      _p(rb, C.c_int), nr, int(r_strand), C.c_char_p(r_read), C.c_char_p(r_chrom), len(r_chrom),
                                      _p(lo, C.c_int), C.byref(nlo), _p(ro, C.c_int), C.byref(nro))
     return ret, lo[:3 * nlo.value].reshape(-1, 3).copy(), ro[:3 * nro.value].reshape(-1, 3).copy()
+
+
+def filter_chain(q, t, length, strand, link, ops):
+    """Chain.h filters in the given order (1 small paired indels, 2/3 paired indels with/without refineEnds, 4 spurious anchors, 8 spurious jump).
+    link=None for chain types without links.  -> (keep, surviving links)"""
+    L = lib()
+    q = np.ascontiguousarray(q, np.uint32); t = np.ascontiguousarray(t, np.uint32); ln = np.ascontiguousarray(length, np.int32)
+    st = np.ascontiguousarray(strand, np.uint8)
+    n = len(q)
+    has = link is not None
+    lk = np.ascontiguousarray(link if has else np.zeros(max(n - 1, 0)), np.uint8)
+    ops = np.ascontiguousarray(ops, np.int32)
+    keep = np.zeros(max(1, n), np.uint8); lo = np.zeros(max(1, n), np.uint8); nl = C.c_int(0)
+    L.oracle_filter_chain.restype = C.c_int
+    L.oracle_filter_chain(C.c_int(n), _p(q, C.c_uint32), _p(t, C.c_uint32), _p(ln, C.c_int), _p(st, C.c_uint8), _p(lk, C.c_uint8), C.c_int(int(has)),
+                          _p(ops, C.c_int), C.c_int(len(ops)), _p(keep, C.c_uint8), _p(lo, C.c_uint8), C.byref(nl))
+    return keep[:n].copy(), lo[:nl.value].copy()

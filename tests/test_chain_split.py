@@ -110,3 +110,61 @@ def test_hip_split_chains_oracle(ctx):
             assert out["n_split_link"][s] == len(exp["split_link"])
             assert out["split_link"][b:b + len(exp["split_link"])].tolist() == exp["split_link"].tolist(), s
         assert n_t > 10 and n_i > 10 and n_merge > 0, (n_t, n_i, n_merge)
+
+
+def _indel_chain(rng, n):
+    """a chain with small / large paired diagonal jumps, short and long anchors, the odd strand flip and far end anchors"""
+    q = 300_000; t = int(rng.integers(1_000_000, 2_000_000)); strand = int(rng.random() < 0.3)
+    Q = []; T = []; L = []; S = []; LK = []
+    pend = 0
+    for i in range(n):
+        ln = int(rng.choice([17, 20, 30, 45, 60, 99, 100, 150]))
+        Q.append(q); T.append(t); L.append(ln); S.append(strand)
+        if i < n - 1: LK.append(int(rng.random() < 0.15))
+        q -= ln + int(rng.integers(0, 120))
+        step = ln + int(rng.integers(0, 120))
+        u = rng.random()
+        if pend and rng.random() < 0.7: step -= pend + int(rng.integers(-25, 25)); pend = 0      # the opposite jump shortly after
+        elif u < 0.12: pend = int(rng.choice([8, 20, 45, 60, 90, 320, 600, 900])) * int(rng.choice([-1, 1])); step += pend
+        if u > 0.985: strand ^= 1
+        if i in (0, 1, n - 3, n - 2) and rng.random() < 0.3: step += int(rng.integers(20_000, 90_000))   # far-away chain ends (refineEnds)
+        t = t - step if strand == 0 else t + step
+        t = max(1000, min(t, 5_000_000))
+    return (np.array(Q, np.uint32), np.array(T, np.uint32), np.array(L, np.int32), np.array(S, np.uint8), np.array(LK, np.uint8))
+
+
+def test_oracle_filter_chain_sanity():
+    # +400 / -400 diagonal jumps two anchors apart: RemovePairedIndels drops the short anchors in between; no link -> no link out
+    q = [1000, 900, 800, 700, 600, 500]; t = [5000, 4900, 5200, 5100, 4600, 4500]
+    keep, lk = O.filter_chain(q, t, [20] * 6, [0] * 6, None, [3])
+    assert keep.tolist() == [1, 1, 0, 0, 1, 1] and len(lk) == 0
+    keep, lk = O.filter_chain(q, t, [20, 20, 150, 20, 20, 20], [0] * 6, [0, 1, 0, 1, 0], [3])
+    assert keep.tolist() == [1, 1, 1, 0, 1, 1] and lk.tolist() == [0, 1, 1, 0]
+
+
+@pytest.mark.gpu
+def test_hip_filter_chains_oracle(ctx):
+    import torch
+    from lra_amd import chain
+    rng = np.random.default_rng(12)
+    chains = [_indel_chain(rng, int(rng.integers(1, 90))) for _ in range(300)]
+    off = np.cumsum([0] + [len(c[0]) for c in chains])
+    cat = lambda j, dt: np.concatenate([c[j] for c in chains]).astype(dt)
+    link = np.concatenate([np.concatenate([c[4], [0]]) for c in chains]).astype(np.uint8)
+    dev = ctx.device
+    tt = lambda a: torch.tensor(a, device=dev)
+    d = dict(off=tt(off.astype(np.int64)), q=tt(cat(0, np.int64)).to(torch.int32), t=tt(cat(1, np.int64)).to(torch.int32), ln=tt(cat(2, np.int32)),
+             st=tt(cat(3, np.uint8)), lk=tt(link))
+    removed = 0
+    for ops, with_link in (([2, 4], True), ([1, 2, 4], False), ([1, 3, 4], True), ([8], True), ([4, 8, 1], True), ([2], True)):
+        res = chain.filter_chains_batch(ctx, len(chains), d["off"], int(off[-1]), d["q"], d["t"], d["ln"], d["st"], d["lk"] if with_link else None, ops)
+        out = chain.fetch_filter(ctx, res)
+        for i, c in enumerate(chains):
+            keep, lk = O.filter_chain(c[0], c[1], c[2], c[3], c[4] if with_link else None, ops)
+            a, b = int(off[i]), int(off[i + 1])
+            assert out["keep"][a:b].tolist() == keep.tolist(), (ops, i)
+            assert out["n_kept"][i] == keep.sum()
+            assert out["n_link"][i] == len(lk), (ops, i, out["n_link"][i], len(lk))
+            assert out["link"][a:a + len(lk)].tolist() == lk.tolist(), (ops, i)
+            removed += int((keep == 0).sum())
+    assert removed > 300
