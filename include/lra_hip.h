@@ -194,6 +194,7 @@ typedef struct lra_sdp_opts {
   float rate; int32_t NumAln; float alnthres;
   float gapopen, gapextend, gaproot; int32_t gapCeiling1, gapCeiling2;
   int32_t mode;   /* LRA_SDP_CLUSTERS (0) or LRA_SDP_SINGLE_CLUSTER (1) */
+  int32_t globalK; /* Options::globalK; read by lra_sparse_dp_boxes_batch only (value threshold, SparseDP.h:1592) */
 } lra_sdp_opts;
 typedef struct lra_chain_result {
   int32_t n_reads, num_aln;
@@ -208,10 +209,46 @@ typedef struct lra_chain_result {
   const uint64_t* d_frag_off;       /* [n_reads+1] */
   const float* d_frag_val;          /* [n_frags] */
   const uint32_t* d_status;         /* [n_reads] */
+  const int32_t* d_chain_num_anchors; /* [n_reads*num_aln] CHain::NumOfAnchors0 (lra_sparse_dp_boxes_batch; NULL otherwise) */
 } lra_chain_result;
 int lra_sparse_dp_batch(lra_ctx* ctx, int n_reads, const uint64_t* d_cluster_off, const uint64_t* d_c_start, const uint32_t* d_c_count,
                         const int32_t* d_c_strand, const uint32_t* d_q, const uint32_t* d_t, const int32_t* d_len,
                         const uint64_t* d_read_off, const float* d_rate, const lra_sdp_opts* opts, lra_chain_result* out);
+
+/* The high-accuracy overload SparseDP(vector<Cluster>& splitclusters, vector<Primary_chain>&, opts, LookUpTable, read,
+ * rate) (SparseDP.h:1956-2135, called at Map_highacc.h:229): every box contributes the four points s1 (qStart+1, tStart+1), e1 (qEnd-1,
+ * tEnd-1), s2 (qStart+1, tEnd-1), e2 (qEnd-1, tStart+1) in that insertion order, weighs Val*rate (ProcessPoint :313), and chains are
+ * chosen by DecidePrimaryChains :1587-1655: value threshold max(alnthres*best, best - 130*globalK), TraceBack with `used`, box by
+ * min/max over the chain, read-span fraction > 0.005, at most NumAln chains (they are Primary_chains[0].chains).
+ * Box i of read r is d_box_off[r] + i: (d_qs, d_qe, d_ts, d_te, d_strand 0 = forward, d_val = Cluster::Val, d_num_anchors =
+ * Cluster::NumofAnchors0, may be NULL).  opts->rate (or d_rate[r]) is the caller's `rate` (Map_highacc.h:227-228); opts->mode is
+ * ignored.  Result as lra_sparse_dp_batch: d_chain_cluster = box index within the read, d_chain_q/t = (qStart, tStart),
+ * d_chain_alen = Val, d_chain_anchor = 0, plus d_chain_num_anchors (ComputeNumOfAnchors :1577).                         */
+int lra_sparse_dp_boxes_batch(lra_ctx* ctx, int n_reads, const uint64_t* d_box_off, const uint32_t* d_qs, const uint32_t* d_qe,
+                              const uint32_t* d_ts, const uint32_t* d_te, const int32_t* d_strand, const int32_t* d_val,
+                              const int32_t* d_num_anchors, const uint64_t* d_read_off, const float* d_rate, const lra_sdp_opts* opts,
+                              lra_chain_result* out);
+
+/* ---- a6 (high-accuracy path): SplitClusters + DecideSplitClustersValue -----------------------------------
+ * Replaces, for every read of a batch, SplitClusters(clusters, splitclusters, read, opts) (SplitClusters.h:63-171, IntervalSet :18-60)
+ * and DecideSplitClustersValue(clusters, splitclusters, opts, read) (:176-249) as called at Map_highacc.h:153-155.
+ * Cluster c of read r is d_cluster_off[r] + c: box (d_qs, d_qe, d_ts, d_te), d_strand (0 = forward), d_anchorfreq; its matches' read
+ * positions (matches[i].first.pos, in the cluster's own CartesianSort order) are d_match_q[d_match_off[c] .. d_match_off[c+1]).
+ * contig = (opts.readType == Options::contig) (only then are sparse clusters kept whole), K = opts.globalK.
+ * Output (context-owned): split clusters of read r = [d_split_off[r], d_split_off[r+1]) of d_qs.. in the reference's push order (whole
+ * clusters first, then pieces cluster by cluster): box, strand, d_coarse (index of the original within the read), d_val (Cluster::Val),
+ * d_num_anchors (NumofAnchors0), d_read; per original cluster d_cluster_val (Cluster::Val) and d_cluster_split (Cluster::split).
+ * The arrays feed lra_sparse_dp_boxes_batch unchanged.  Synchronous.                                                              */
+typedef struct lra_split_clusters_result {
+  int32_t n_reads; uint64_t n_clusters, n_split;
+  const uint64_t* d_split_off;                 /* [n_reads+1] */
+  const uint32_t* d_qs; const uint32_t* d_qe; const uint32_t* d_ts; const uint32_t* d_te;   /* [n_split] */
+  const int32_t* d_strand; const int32_t* d_coarse; const int32_t* d_val; const int32_t* d_num_anchors; const uint32_t* d_read;   /* [n_split] */
+  const int32_t* d_cluster_val; const uint8_t* d_cluster_split;   /* [n_clusters] */
+} lra_split_clusters_result;
+int lra_split_clusters_batch(lra_ctx* ctx, int n_reads, const uint64_t* d_cluster_off, const uint32_t* d_qs, const uint32_t* d_qe,
+                             const uint32_t* d_ts, const uint32_t* d_te, const int32_t* d_strand, const float* d_anchorfreq,
+                             const uint64_t* d_match_off, const uint32_t* d_match_q, int contig, int K, lra_split_clusters_result* out);
 
 /* ---- a9 (low-accuracy path): chain filters and chain splitting -------------------------------------------
  * Replaces, per chain of an lra_sparse_dp_batch result (mode LRA_SDP_CLUSTERS), what MapRead_lowacc does before tier-2 refinement:

@@ -8,16 +8,18 @@ from .context import Context, ptr
 
 class SdpOpts(C.Structure):
     _fields_ = [("rate", C.c_float), ("NumAln", C.c_int32), ("alnthres", C.c_float), ("gapopen", C.c_float), ("gapextend", C.c_float),
-                ("gaproot", C.c_float), ("gapCeiling1", C.c_int32), ("gapCeiling2", C.c_int32), ("mode", C.c_int32)]
+                ("gaproot", C.c_float), ("gapCeiling1", C.c_int32), ("gapCeiling2", C.c_int32), ("mode", C.c_int32),
+                ("globalK", C.c_int32)]
 
 
 # -ONT preset (lra.cpp:388-420; alnthres: Options.h:198)
-ONT = dict(rate=20.0, NumAln=2, alnthres=0.7, gapopen=7.0, gapextend=10.0, gaproot=1.5, gapCeiling1=1500, gapCeiling2=3000, mode=0)
+ONT = dict(rate=20.0, NumAln=2, alnthres=0.7, gapopen=7.0, gapextend=10.0, gaproot=1.5, gapCeiling1=1500, gapCeiling2=3000, mode=0, globalK=17)
 
 
 def sdp_opts(**kw):
     d = dict(ONT); d.update(kw)
-    return SdpOpts(d["rate"], d["NumAln"], d["alnthres"], d["gapopen"], d["gapextend"], d["gaproot"], d["gapCeiling1"], d["gapCeiling2"], d["mode"])
+    return SdpOpts(d["rate"], d["NumAln"], d["alnthres"], d["gapopen"], d["gapextend"], d["gaproot"], d["gapCeiling1"], d["gapCeiling2"], d["mode"],
+                   d["globalK"])
 
 
 class ChainResult(C.Structure):
@@ -25,7 +27,8 @@ class ChainResult(C.Structure):
                 ("n_subproblem_entries", C.c_uint64), ("d_n_chains", C.c_void_p), ("d_chain_start", C.c_void_p), ("d_chain_len", C.c_void_p),
                 ("d_chain_box", C.c_void_p), ("d_chain_value", C.c_void_p), ("d_chain_cluster", C.c_void_p), ("d_chain_anchor", C.c_void_p),
                 ("d_chain_link", C.c_void_p), ("d_chain_q", C.c_void_p), ("d_chain_t", C.c_void_p), ("d_chain_alen", C.c_void_p),
-                ("d_chain_strand", C.c_void_p), ("d_frag_off", C.c_void_p), ("d_frag_val", C.c_void_p), ("d_status", C.c_void_p)]
+                ("d_chain_strand", C.c_void_p), ("d_frag_off", C.c_void_p), ("d_frag_val", C.c_void_p), ("d_status", C.c_void_p),
+                ("d_chain_num_anchors", C.c_void_p)]
 
 
 def sparse_dp_batch(ctx: Context, n_reads, cluster_off, c_start, c_count, c_strand, q, t, length, read_off, opts: SdpOpts, rate=None):
@@ -36,9 +39,19 @@ def sparse_dp_batch(ctx: Context, n_reads, cluster_off, c_start, c_count, c_stra
     return res
 
 
+def sparse_dp_boxes_batch(ctx: Context, n_reads, box_off, qs, qe, ts, te, strand, val, num_anchors, read_off, opts: SdpOpts, rate=None):
+    """The high-accuracy SparseDP over split-cluster boxes (SparseDP.h:1956); array arguments are device tensors (see include/lra_hip.h)."""
+    res = ChainResult()
+    ctx.check(ctx.lib.lra_sparse_dp_boxes_batch(ctx.h, int(n_reads), ptr(box_off), ptr(qs), ptr(qe), ptr(ts), ptr(te), ptr(strand), ptr(val),
+                                                ptr(num_anchors) if num_anchors is not None else None, ptr(read_off),
+                                                ptr(rate) if rate is not None else None, C.byref(opts), C.byref(res)))
+    return res
+
+
 def fetch(ctx: Context, res: ChainResult):
     n, na, nf = res.n_reads, res.num_aln, res.n_frags
-    return {"n_chains": ctx.to_host(res.d_n_chains, n, np.uint32), "chain_start": ctx.to_host(res.d_chain_start, n * na, np.uint64),
+    extra = {"chain_num_anchors": ctx.to_host(res.d_chain_num_anchors, n * na, np.int32)} if res.d_chain_num_anchors else {}
+    return {**extra, "n_chains": ctx.to_host(res.d_n_chains, n, np.uint32), "chain_start": ctx.to_host(res.d_chain_start, n * na, np.uint64),
             "chain_len": ctx.to_host(res.d_chain_len, n * na, np.uint32), "chain_box": ctx.to_host(res.d_chain_box, 4 * n * na, np.uint32).reshape(-1, 4),
             "chain_value": ctx.to_host(res.d_chain_value, n * na, np.float32), "chain_cluster": ctx.to_host(res.d_chain_cluster, nf, np.uint32),
             "chain_anchor": ctx.to_host(res.d_chain_anchor, nf, np.uint32), "chain_link": ctx.to_host(res.d_chain_link, nf, np.uint8),
@@ -93,3 +106,27 @@ def filter_chains_batch(ctx: Context, n_chains, off, n_anchors, q, t, length, st
 def fetch_filter(ctx: Context, res: FilterResult):
     return {"keep": ctx.to_host(res.d_keep, res.n_anchors, np.uint8), "n_kept": ctx.to_host(res.d_n_kept, res.n_chains, np.uint32),
             "link": ctx.to_host(res.d_link, res.n_anchors, np.uint8), "n_link": ctx.to_host(res.d_n_link, res.n_chains, np.uint32)}
+
+
+class SplitClustersResult(C.Structure):
+    _fields_ = [("n_reads", C.c_int32), ("n_clusters", C.c_uint64), ("n_split", C.c_uint64)] + [(n, C.c_void_p) for n in (
+        "d_split_off", "d_qs", "d_qe", "d_ts", "d_te", "d_strand", "d_coarse", "d_val", "d_num_anchors", "d_read", "d_cluster_val",
+        "d_cluster_split")]
+
+
+def split_clusters_batch(ctx: Context, n_reads, cluster_off, qs, qe, ts, te, strand, anchorfreq, match_off, match_q, contig=False, K=17):
+    """SplitClusters + DecideSplitClustersValue (SplitClusters.h:63,176; high-accuracy path) for a batch; device tensors in."""
+    res = SplitClustersResult()
+    ctx.check(ctx.lib.lra_split_clusters_batch(ctx.h, int(n_reads), ptr(cluster_off), ptr(qs), ptr(qe), ptr(ts), ptr(te), ptr(strand), ptr(anchorfreq),
+                                               ptr(match_off), ptr(match_q), 1 if contig else 0, int(K), C.byref(res)))
+    return res
+
+
+def fetch_split_clusters(ctx: Context, res: SplitClustersResult):
+    n, ns, nc = res.n_reads, res.n_split, res.n_clusters
+    d = {"split_off": ctx.to_host(res.d_split_off, n + 1, np.uint64), "cluster_val": ctx.to_host(res.d_cluster_val, nc, np.int32),
+         "cluster_split": ctx.to_host(res.d_cluster_split, nc, np.uint8)}
+    for k, dt in (("qs", np.uint32), ("qe", np.uint32), ("ts", np.uint32), ("te", np.uint32), ("strand", np.int32), ("coarse", np.int32),
+                  ("val", np.int32), ("num_anchors", np.int32), ("read", np.uint32)):
+        d[k] = ctx.to_host(getattr(res, "d_" + k), ns, dt)
+    return d

@@ -108,6 +108,7 @@ __global__ void k_visit_clear(const ReadArena* __restrict__ ra, const uint64_t* 
 __global__ void k_cluster_counts(uint64_t nc, const uint32_t* __restrict__ c_count, uint32_t* fragCnt, uint32_t* ptCnt, int single) {
   uint64_t c = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (c >= nc) return;
+  if (!c_count) { fragCnt[c] = 1; ptCnt[c] = 4; return; }                  // box mode (SparseDP.h:1959-2018): s1 e1 s2 e2 for every box
   uint32_t n = c_count[c];
   fragCnt[c] = n;
   ptCnt[c] = 2 * n + (single ? 0 : 2 * (n == 0 ? 0 : n == 1 ? 1 : 2));     // SparseDP.h:2159-2166: first and last anchor get the other family's pair too
@@ -134,6 +135,7 @@ struct PtArgs {
   const float* rate_in; float rate; int single;
   uint32_t* fq; uint32_t* ft; int32_t* flen; uint32_t* fcl; uint32_t* fai; float* fval; uint32_t* fprevNode; uint32_t* fprevInd; uint8_t* fflags;
   uint8_t* used; uint8_t* fstrand;
+  const uint32_t* qe; const uint32_t* te; uint32_t* fqe; uint32_t* fte;   // box mode only
   uint64_t* key1; uint32_t* pay1; uint32_t* iq; uint32_t* it; uint8_t* ifl; uint32_t* ifr; uint32_t* ptRead;
 };
 
@@ -142,13 +144,30 @@ __global__ void k_points(PtArgs a) {
   uint64_t c = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (c >= a.nc) return;
   const uint32_t r = a.clusRead[c];
-  const uint32_t n = a.c_count[c];
-  const uint64_t src = a.c_start[c];
   const int strand = a.c_strand[c];
   uint64_t g = a.clusFragOff[c], p = a.clusPtOff[c];
   const uint64_t f0 = a.fragOff[r], p0 = a.ptOff[r];
   const uint32_t cl = (uint32_t)(c - a.cluster_off[r]);
   const float rate = a.rate_in ? a.rate_in[r] : a.rate;
+  if (a.qe) {                                                          // box mode: the split cluster c is the fragment (SparseDP.h:1959-2018)
+    const uint32_t qs = a.q[c], ts = a.t[c], qe = a.qe[c], te = a.te[c];
+    const int val = a.len[c];
+    a.fq[g] = qs; a.ft[g] = ts; a.fqe[g] = qe; a.fte[g] = te; a.flen[g] = val; a.fcl[g] = cl; a.fai[g] = 0;
+    a.fval[g] = val * rate;                                            // Value[ii].val = FragInput[ii].Val*rate (:2084)
+    a.fprevNode[g] = NONE; a.fprevInd[g] = NONE; a.fflags[g] = 3; a.used[g] = 0; a.fstrand[g] = (uint8_t)(strand != 0);
+    const uint32_t lf = (uint32_t)(g - f0);
+    for (int k = 0; k < 4; k++, p++) {                                 // s1 (qs+1,ts+1)  e1 (qe-1,te-1)  s2 (qs+1,te-1)  e2 (qe-1,ts+1)
+      const uint8_t ind = (k & 1) ? 0 : 1, inv = k < 2 ? 1 : 0;
+      const uint32_t pq = ind ? qs + 1 : qe - 1;
+      const uint32_t pt = (k == 0 || k == 3) ? ts + 1 : te - 1;
+      a.key1[p] = ((uint64_t)pq << 33) | ((uint64_t)pt << 1) | ind;
+      a.pay1[p] = (uint32_t)(p - p0);
+      a.iq[p] = pq; a.it[p] = pt; a.ifl[p] = (uint8_t)(ind | (inv << 1)); a.ifr[p] = lf; a.ptRead[p] = r;
+    }
+    return;
+  }
+  const uint32_t n = a.c_count[c];
+  const uint64_t src = a.c_start[c];
   for (uint32_t i = 0; i < n; i++, g++) {
     const uint32_t q = a.q[src + i], t = a.t[src + i];
     const int len = a.len[src + i];
@@ -883,6 +902,7 @@ __global__ void k_frag_read(int n_reads, const uint64_t* __restrict__ fragOff, u
 
 struct TraceArgs {
   int r0, n, numAln, single; float alnthres;
+  int boxes, globalK; const uint32_t* fqe; const uint32_t* fte; const int32_t* numAnchors; int32_t* chainNum;   // box mode (DecidePrimaryChains :1587)
   const uint64_t* fragOff; const uint64_t* read_off;
   const uint32_t* fq; const uint32_t* ft; const int32_t* flen; const uint32_t* fcl; const uint32_t* fai;
   const float* fval; const uint32_t* fprevNode; const uint32_t* fprevInd; const uint8_t* fflags; const uint32_t* opay;
@@ -931,11 +951,12 @@ __global__ void __launch_bounds__(64) sdp_trace(TraceArgs a) {
     return;
   }
   const int readLen = (int)(a.read_off[r + 1] - a.read_off[r]);
-  const float thres = a.alnthres * a.fval[f0 + a.opay[f0]];
+  const float best = a.fval[f0 + a.opay[f0]];
+  const float thres = a.boxes ? fmaxf(a.alnthres * best, best - (float)(130 * a.globalK)) : a.alnthres * best;   // :1592 / :1663
   int nCh = 0, fv = 0;
   uint64_t out = f0;                                                     // chains are written back to back into the read's fragment range
   uint32_t c0TS = 0, c0TE = 0;
-  while (nCh < a.numAln && fv < total && a.fval[f0 + a.opay[f0 + fv]] >= thres) {
+  while ((a.boxes || nCh < a.numAln) && fv < total && a.fval[f0 + a.opay[f0 + fv]] >= thres) {
     uint32_t i = a.opay[f0 + fv];
     const float firstVal = a.fval[f0 + i];
     // TraceBack with `used` (:1351-1438); the chain is written at out.. and rolled back if it runs into a used anchor
@@ -956,7 +977,26 @@ __global__ void __launch_bounds__(64) sdp_trace(TraceArgs a) {
       }
       if (abandoned) { for (uint32_t k = 0; k < len; k++) a.used[f0 + a.ccl[out + k]] = 0; len = 0; }
     }
-    if (len != 0) {
+    if (len != 0 && a.boxes) {                                           // :1607-1650
+      uint32_t f = a.ccl[out], l = a.ccl[out + len - 1];
+      uint32_t QEnd = a.fqe[f0 + f], TEnd = a.fte[f0 + f], QStart = a.fq[f0 + l], TStart = a.ft[f0 + l];
+      int na = 0;
+      for (uint32_t k = 0; k < len; k++) {
+        f = a.ccl[out + k];
+        QEnd = max(QEnd, a.fqe[f0 + f]); TEnd = max(TEnd, a.fte[f0 + f]);
+        QStart = min(QStart, a.fq[f0 + f]); TStart = min(TStart, a.ft[f0 + f]);
+        if (a.numAnchors) na += a.numAnchors[f0 + f];                    // ComputeNumOfAnchors :1577
+      }
+      if ((double)((float)(QEnd - QStart) / readLen) > 0.005) {
+        if (nCh >= a.numAln) break;
+        const int slot = r * a.numAln + nCh;
+        a.chainStart[slot] = out; a.chainLen[slot] = len; a.chainValue[slot] = firstVal; a.chainNum[slot] = na;
+        a.chainBox[4 * slot] = QStart; a.chainBox[4 * slot + 1] = QEnd; a.chainBox[4 * slot + 2] = TStart; a.chainBox[4 * slot + 3] = TEnd;
+        a.clink[out + len - 1] = 0;
+        nCh++;
+        out += len;
+      } else break;
+    } else if (len != 0) {
       uint32_t f = a.ccl[out], l = a.ccl[out + len - 1];
       uint32_t QEnd = a.fq[f0 + f] + a.flen[f0 + f], QStart = a.fq[f0 + l], TEnd = a.ft[f0 + f] + a.flen[f0 + f], TStart = a.ft[f0 + l];
       for (uint32_t k = 0; k < len; k++) {
@@ -1001,11 +1041,12 @@ __global__ void __launch_bounds__(64) sdp_trace(TraceArgs a) {
 
 inline size_t sz(size_t n, size_t elem) { return (n * elem + 255) / 256 * 256; }
 
-}  // namespace
-
-extern "C" int lra_sparse_dp_batch(lra_ctx* ctx, int n_reads, const uint64_t* d_cluster_off, const uint64_t* d_c_start, const uint32_t* d_c_count,
-                                   const int32_t* d_c_strand, const uint32_t* d_q, const uint32_t* d_t, const int32_t* d_len,
-                                   const uint64_t* d_read_off, const float* d_rate, const lra_sdp_opts* opts, lra_chain_result* out) {
+// Box mode (d_qe != null): clusters are the fragments; d_c_start / d_c_count are null, d_q/d_t/d_qe/d_te/d_len(=Val)/d_c_strand are per box.
+int sdp_run(lra_ctx* ctx, int n_reads, const uint64_t* d_cluster_off, const uint64_t* d_c_start, const uint32_t* d_c_count,
+            const int32_t* d_c_strand, const uint32_t* d_q, const uint32_t* d_t, const int32_t* d_len, const uint64_t* d_read_off,
+            const float* d_rate, const lra_sdp_opts* opts, lra_chain_result* out, const uint32_t* d_qe, const uint32_t* d_te,
+            const int32_t* d_num_anchors) {
+  const bool boxes = d_qe != nullptr;
   if (!ctx || !out || !opts || n_reads < 0) return LRA_ERR_INVALID;
   if (opts->NumAln < 1 || opts->NumAln > MAXALN) return lra_set_err(ctx, LRA_ERR_INVALID, "NumAln must be 1..%d", MAXALN);
   memset(out, 0, sizeof *out);
@@ -1036,7 +1077,7 @@ extern "C" int lra_sparse_dp_batch(lra_ctx* ctx, int n_reads, const uint64_t* d_
   const uint64_t NC = h_off[n_reads];
   // ---- batch-level buffers: clusters and reads
   const size_t nslot = (size_t)n_reads * opts->NumAln;
-  size_t needA = sz(NC + 1, 4) * 3 + sz(NC + 2, 8) * 2 + sz(n1, 8) * 2 + sz(n1, 4) * 2 + sz(nslot, 8) + sz(nslot, 4) * 2 + sz(4 * nslot, 4) + 4096;
+  size_t needA = sz(NC + 1, 4) * 3 + sz(NC + 2, 8) * 2 + sz(n1, 8) * 2 + sz(n1, 4) * 2 + sz(nslot, 8) + sz(nslot, 4) * 3 + sz(4 * nslot, 4) + 4096;
   char* wa = (char*)lra_ensure(ctx, 7, needA);
   if (!wa) return LRA_ERR_NOMEM;
   auto take = [](char*& w, size_t n, size_t e) { char* p = w; w += sz(n, e); return p; };
@@ -1046,10 +1087,12 @@ extern "C" int lra_sparse_dp_batch(lra_ctx* ctx, int n_reads, const uint64_t* d_
   uint32_t* status = (uint32_t*)take(wa, n1, 4); uint32_t* nChains = (uint32_t*)take(wa, n1, 4);
   uint64_t* chainStart = (uint64_t*)take(wa, nslot, 8); uint32_t* chainLen = (uint32_t*)take(wa, nslot, 4); float* chainValue = (float*)take(wa, nslot, 4);
   uint32_t* chainBox = (uint32_t*)take(wa, 4 * nslot, 4);
+  int32_t* chainNum = (int32_t*)take(wa, nslot, 4);
   LRA_HIP_CHECK(ctx, hipMemsetAsync(chainLen, 0, nslot * 4, st));
   if (NC > 0) {
     lra_time_begin(ctx, "sdp_points");
-    hipLaunchKernelGGL(k_cluster_counts, dim3((unsigned)((NC + 255) / 256)), dim3(256), 0, st, NC, d_c_count, clusFragCnt, clusPtCnt, opts->mode == LRA_SDP_SINGLE_CLUSTER);
+    hipLaunchKernelGGL(k_cluster_counts, dim3((unsigned)((NC + 255) / 256)), dim3(256), 0, st, NC, boxes ? nullptr : d_c_count, clusFragCnt, clusPtCnt,
+                       opts->mode == LRA_SDP_SINGLE_CLUSTER);
     lra_time_end(ctx);
   }
   { int rc = lra_exclusive_scan<uint32_t>(ctx, (long)NC, clusFragCnt, clusFragOff); if (rc) return rc; }
@@ -1063,7 +1106,7 @@ extern "C" int lra_sparse_dp_batch(lra_ctx* ctx, int n_reads, const uint64_t* d_
   const uint64_t NF = h_frag[n_reads], NP = h_pt[n_reads];
   out->n_frags = NF; out->n_points = NP;
   // ---- fragments
-  size_t needF = sz(NF + 1, 4) * 14 + sz(2 * NF + 2, 4) + sz(NF + 1, 1) * 5 + sz(NF + 1, 8) * 2 + 4096;
+  size_t needF = sz(NF + 1, 4) * 16 + sz(2 * NF + 2, 4) + sz(NF + 1, 1) * 5 + sz(NF + 1, 8) * 2 + 4096;
   char* wf = (char*)lra_ensure(ctx, 8, needF);
   if (!wf) return LRA_ERR_NOMEM;
   uint32_t* fq = (uint32_t*)take(wf, NF + 1, 4); uint32_t* ft = (uint32_t*)take(wf, NF + 1, 4); int32_t* flen = (int32_t*)take(wf, NF + 1, 4);
@@ -1074,6 +1117,7 @@ extern "C" int lra_sparse_dp_batch(lra_ctx* ctx, int n_reads, const uint64_t* d_
   uint8_t* fstrand = (uint8_t*)take(wf, NF + 1, 1); uint8_t* cstrand = (uint8_t*)take(wf, NF + 1, 1);
   uint32_t* cq = (uint32_t*)take(wf, NF + 1, 4); uint32_t* ct = (uint32_t*)take(wf, NF + 1, 4); int32_t* clen = (int32_t*)take(wf, NF + 1, 4);
   uint64_t* okey = (uint64_t*)take(wf, NF + 1, 8);
+  uint32_t* fqe = (uint32_t*)take(wf, NF + 1, 4); uint32_t* fte = (uint32_t*)take(wf, NF + 1, 4);
   // ---- points
   size_t needP = sz(NP + 1, 8) * 3 + sz(NP + 1, 4) * 11 + sz(NP + 1, 1) * 2 + sz(NF + 1, 4) * 2 + 4096;
   char* wp = (char*)lra_ensure(ctx, 9, needP);
@@ -1089,12 +1133,14 @@ extern "C" int lra_sparse_dp_batch(lra_ctx* ctx, int n_reads, const uint64_t* d_
   out->d_n_chains = nChains; out->d_chain_start = chainStart; out->d_chain_len = chainLen; out->d_chain_box = chainBox; out->d_chain_value = chainValue;
   out->d_chain_cluster = ccl; out->d_chain_anchor = can; out->d_chain_link = clink; out->d_chain_q = cq; out->d_chain_t = ct; out->d_chain_alen = clen;
   out->d_chain_strand = cstrand; out->d_frag_off = fragOff; out->d_frag_val = fval; out->d_status = status;
+  out->d_chain_num_anchors = boxes ? chainNum : nullptr;
   if (NF == 0) { LRA_HIP_CHECK(ctx, hipStreamSynchronize(st)); return LRA_OK; }
   {
     PtArgs pa;
     pa.nc = NC; pa.cluster_off = d_cluster_off; pa.c_start = d_c_start; pa.c_count = d_c_count; pa.c_strand = d_c_strand; pa.q = d_q; pa.t = d_t; pa.len = d_len;
     pa.clusRead = clusRead; pa.clusFragOff = clusFragOff; pa.clusPtOff = clusPtOff; pa.fragOff = fragOff; pa.ptOff = ptOff; pa.rate_in = d_rate; pa.rate = opts->rate; pa.single = opts->mode == LRA_SDP_SINGLE_CLUSTER;
     pa.fq = fq; pa.ft = ft; pa.flen = flen; pa.fcl = fcl; pa.fai = fai; pa.fval = fval; pa.fprevNode = fprevNode; pa.fprevInd = fprevInd; pa.fflags = fflags; pa.used = used; pa.fstrand = fstrand;
+    pa.qe = d_qe; pa.te = d_te; pa.fqe = fqe; pa.fte = fte;
     pa.key1 = key1; pa.pay1 = pay1; pa.iq = iq; pa.it = it; pa.ifl = ifl; pa.ifr = ifr; pa.ptRead = ptRead;
     lra_time_begin(ctx, "sdp_points");
     hipLaunchKernelGGL(k_points, dim3((unsigned)((NC + 127) / 128)), dim3(128), 0, st, pa);
@@ -1221,6 +1267,7 @@ extern "C" int lra_sparse_dp_batch(lra_ctx* ctx, int n_reads, const uint64_t* d_
       ta.ra = ra; ta.nChains = nChains; ta.chainStart = chainStart; ta.chainLen = chainLen;
       ta.chainBox = chainBox; ta.chainValue = chainValue; ta.ccl = ccl; ta.can = can; ta.clink = clink; ta.status = status;
       ta.cq = cq; ta.ct = ct; ta.clen = clen; ta.cstrand = cstrand; ta.fstrand = fstrand;
+      ta.boxes = boxes; ta.globalK = opts->globalK; ta.fqe = fqe; ta.fte = fte; ta.numAnchors = d_num_anchors; ta.chainNum = chainNum;
       lra_time_begin(ctx, "sdp_trace");
       hipLaunchKernelGGL(sdp_trace, dim3((nr + 63) / 64), dim3(64), 0, st, ta);
       lra_time_end(ctx);
@@ -1232,4 +1279,23 @@ extern "C" int lra_sparse_dp_batch(lra_ctx* ctx, int n_reads, const uint64_t* d_
   LRA_HIP_CHECK(ctx, hipStreamSynchronize(st));
   LRA_HIP_CHECK(ctx, hipGetLastError());
   return LRA_OK;
+}
+
+}  // namespace
+
+extern "C" int lra_sparse_dp_batch(lra_ctx* ctx, int n_reads, const uint64_t* d_cluster_off, const uint64_t* d_c_start, const uint32_t* d_c_count,
+                                   const int32_t* d_c_strand, const uint32_t* d_q, const uint32_t* d_t, const int32_t* d_len,
+                                   const uint64_t* d_read_off, const float* d_rate, const lra_sdp_opts* opts, lra_chain_result* out) {
+  if (opts && opts->mode != LRA_SDP_CLUSTERS && opts->mode != LRA_SDP_SINGLE_CLUSTER) return lra_set_err(ctx, LRA_ERR_INVALID, "mode must be 0 or 1");
+  return sdp_run(ctx, n_reads, d_cluster_off, d_c_start, d_c_count, d_c_strand, d_q, d_t, d_len, d_read_off, d_rate, opts, out, nullptr, nullptr, nullptr);
+}
+
+extern "C" int lra_sparse_dp_boxes_batch(lra_ctx* ctx, int n_reads, const uint64_t* d_box_off, const uint32_t* d_qs, const uint32_t* d_qe,
+                                         const uint32_t* d_ts, const uint32_t* d_te, const int32_t* d_strand, const int32_t* d_val,
+                                         const int32_t* d_num_anchors, const uint64_t* d_read_off, const float* d_rate, const lra_sdp_opts* opts,
+                                         lra_chain_result* out) {
+  if (!opts || !d_qe || !d_te) return LRA_ERR_INVALID;
+  lra_sdp_opts o = *opts;
+  o.mode = LRA_SDP_CLUSTERS;                                             // chain decision of the box mode is selected by d_qe
+  return sdp_run(ctx, n_reads, d_box_off, nullptr, nullptr, d_strand, d_qs, d_ts, d_val, d_read_off, d_rate, &o, out, d_qe, d_te, d_num_anchors);
 }

@@ -477,6 +477,8 @@ struct oracle_sdp_opts {
   float gapopen, gapextend, gaproot;   // InitPWL arguments (lra.cpp:648)
   int gapCeiling1, gapCeiling2;
   int mode;            // 0: SDP#A (:2139);  1: the single-cluster SparseDP (:2287-2438): one point pair per anchor, first maximum, plain TraceBack
+                       // 2: the high-accuracy SparseDP over split-cluster boxes (:1956-2135), through oracle_sdp_chain_boxes only
+  int globalK;         // Options::globalK (mode 2: the value threshold of DecidePrimaryChains :1592)
 };
 
 // SDP#A over the extended clusters of one read.  Fragments are the clusters' matches, concatenated in cluster order
@@ -484,16 +486,27 @@ struct oracle_sdp_opts {
 // Outputs: per fragment val / prev_sub / prev_ind / flags (bit0 prev, bit1 inv); chains as CSR (chainOff[nChains+1]) of global
 // fragment indices in trace-back order (last anchor first) with link bits (chainLink[chainOff[c] + s], s < len-1), boxes
 // (QStart,QEnd,TStart,TEnd) and FirstSDPValue.  Returns the number of chains, or -1 on undefined behaviour in the reference.
-extern "C" int oracle_sdp_chain(int nClusters, const int* clusterOff, const uint8_t* clusterStrand, const uint32_t* q, const uint32_t* t,
-                                const int* len, const oracle_sdp_opts* o, float* fragVal, long* fragPrevSub, long* fragPrevInd,
-                                uint8_t* fragFlags, int maxChains, int* chainOff, uint32_t* chainFrag, uint8_t* chainLink, uint32_t* chainBox,
-                                float* chainValue) {
-  int total = nClusters > 0 ? clusterOff[nClusters] : 0;
+static int sdp_chain_impl(int nClusters, const int* clusterOff, const uint8_t* clusterStrand, const uint32_t* q, const uint32_t* t,
+                          const int* len, const oracle_sdp_opts* o, float* fragVal, long* fragPrevSub, long* fragPrevInd,
+                          uint8_t* fragFlags, int maxChains, int* chainOff, uint32_t* chainFrag, uint8_t* chainLink, uint32_t* chainBox,
+                          float* chainValue, const uint32_t* qe, const uint32_t* te, const int* numAnchors, int* chainNumAnchors) {
+  int total = nClusters > 0 ? (o->mode == 2 ? nClusters : clusterOff[nClusters]) : 0;
   chainOff[0] = 0;
   if (total == 0) return 0;
   Ctx c;
   c.pwl.init(o->gapopen, o->gapextend, o->gaproot, o->gapCeiling1, o->gapCeiling2);
-  for (int cm = 0; cm < nClusters; cm++) {                                  // :2152-2169
+  if (o->mode == 2) {                                                       // :1959-2018: four points per box, s1 e1 s2 e2
+    for (int i = 0; i < total; i++) {
+      const int orient = clusterStrand[i] == 0 ? 1 : 0;
+      Pt p;
+      p.frag = i; p.cluster = i; p.orient = orient;
+      p.ind = 1; p.inv = 1; p.q = q[i] + 1; p.t = t[i] + 1; c.H1.push_back(p);
+      p.ind = 0; p.inv = 1; p.q = qe[i] - 1; p.t = te[i] - 1; c.H1.push_back(p);
+      p.ind = 1; p.inv = 0; p.q = q[i] + 1; p.t = te[i] - 1; c.H1.push_back(p);
+      p.ind = 0; p.inv = 0; p.q = qe[i] - 1; p.t = t[i] + 1; c.H1.push_back(p);
+    }
+  }
+  for (int cm = 0; o->mode != 2 && cm < nClusters; cm++) {                  // :2152-2169
     int ms = clusterOff[cm], sz = clusterOff[cm + 1] - ms;
     for (int i = 0; i < sz; i++) {
       int g = ms + i;
@@ -600,7 +613,7 @@ extern "C" int oracle_sdp_chain(int nClusters, const int* clusterOff, const uint
     chainBox[0] = chainBox[1] = chainBox[2] = chainBox[3] = 0;
     return 1;
   }
-  // DecidePrimaryChains :1658-1760
+  // DecidePrimaryChains :1658-1760 (modes 0) / :1587-1655 (mode 2)
   std::vector<int> order(total);
   std::iota(order.begin(), order.end(), 0);
   {
@@ -609,6 +622,54 @@ extern "C" int oracle_sdp_chain(int nClusters, const int* clusterOff, const uint
     std::sort(order.begin(), order.end(), [&fv](int a, int b) { return fv[a] > fv[b]; });   // Fragment_valueOrder::Sort
   }
   std::vector<bool> used(total, 0);
+  if (o->mode == 2) {
+    const float best = V[order[0]].val;
+    const float value_thres = std::max(o->alnthres * best, best - 130 * o->globalK);
+    int nChains = 0, fv = 0;
+    while (fv < total && V[order[fv]].val >= value_thres) {
+      unsigned int i = order[fv];
+      std::vector<unsigned int> chain;
+      std::vector<bool> link;
+      long ps = V[i].prev_sub, pi = V[i].prev_ind;                        // TraceBack with `used` :1351-1438
+      if (used[i] == 0) {
+        chain.push_back(i); used[i] = 1;
+        auto abandon = [&]() { for (unsigned int x : chain) used[x] = 0; chain.clear(); link.clear(); };
+        while (ps != -1 && pi != -1) {
+          int fam = (V[i].inv ? 0 : 2) + (V[i].prev ? 0 : 1);
+          Sub& s = c.subs[fam][ps];
+          unsigned int nx = s.Dp[s.Ep[pi]];
+          if (used[nx] == 0) { link.push_back(V[i].inv ? 0 : 1); i = nx; }
+          else { abandon(); break; }
+          ps = V[i].prev_sub; pi = V[i].prev_ind;
+          if (used[i] == 0) { chain.push_back(i); used[i] = 1; }
+          else { abandon(); break; }
+        }
+      }
+      if (!chain.empty()) {
+        uint32_t qEnd = qe[chain[0]], tEnd = te[chain[0]], qStart = q[chain.back()], tStart = t[chain.back()];
+        for (size_t k = 0; k < chain.size(); k++) {
+          qEnd = std::max(qe[chain[k]], qEnd); tEnd = std::max(te[chain[k]], tEnd);
+          qStart = std::min(q[chain[k]], qStart); tStart = std::min(t[chain[k]], tStart);
+        }
+        if (((float)(qEnd - qStart) / o->readLen) > 0.005) {
+          if (nChains >= o->NumAln || nChains >= maxChains) break;       // :1636-1645 (the first one opens Primary_chains[0])
+          int na = 0;
+          for (unsigned int x : chain) na += numAnchors ? numAnchors[x] : 0;   // ComputeNumOfAnchors :1577
+          int off = chainOff[nChains];
+          for (size_t k = 0; k < chain.size(); k++) chainFrag[off + k] = chain[k];
+          for (size_t k = 0; k < link.size(); k++) chainLink[off + k] = link[k];
+          if (chain.size() > link.size()) chainLink[off + link.size()] = 0;
+          chainBox[4 * nChains] = qStart; chainBox[4 * nChains + 1] = qEnd; chainBox[4 * nChains + 2] = tStart; chainBox[4 * nChains + 3] = tEnd;
+          chainValue[nChains] = V[order[fv]].val;
+          if (chainNumAnchors) chainNumAnchors[nChains] = na;
+          nChains++;
+          chainOff[nChains] = off + (int)chain.size();
+        } else break;
+      }
+      fv++;
+    }
+    return nChains;
+  }
   float thres = o->alnthres * V[order[0]].val;
   int nChains = 0, fv = 0;
   uint32_t c0TS = 0, c0TE = 0;
@@ -671,4 +732,26 @@ extern "C" int oracle_sdp_chain(int nClusters, const int* clusterOff, const uint
     fv++;
   }
   return nChains;
+}
+
+extern "C" int oracle_sdp_chain(int nClusters, const int* clusterOff, const uint8_t* clusterStrand, const uint32_t* q, const uint32_t* t,
+                                const int* len, const oracle_sdp_opts* o, float* fragVal, long* fragPrevSub, long* fragPrevInd,
+                                uint8_t* fragFlags, int maxChains, int* chainOff, uint32_t* chainFrag, uint8_t* chainLink, uint32_t* chainBox,
+                                float* chainValue) {
+  if (o->mode == 2) return -1;
+  return sdp_chain_impl(nClusters, clusterOff, clusterStrand, q, t, len, o, fragVal, fragPrevSub, fragPrevInd, fragFlags, maxChains, chainOff,
+                        chainFrag, chainLink, chainBox, chainValue, nullptr, nullptr, nullptr, nullptr);
+}
+
+// The high-accuracy SparseDP (SparseDP.h:1956-2135, Map_highacc.h:229) over one read's split clusters: box i = (qs, qe, ts, te,
+// strand, Val, NumofAnchors0); o->rate is the caller's `rate` (:227-228), o->mode is taken as 2.  Chains come back as for
+// oracle_sdp_chain (indices are box indices), plus Num_Anchors per chain.
+extern "C" int oracle_sdp_chain_boxes(int nBoxes, const uint32_t* qs, const uint32_t* qe, const uint32_t* ts, const uint32_t* te,
+                                      const uint8_t* strand, const int* val, const int* numAnchors, const oracle_sdp_opts* o, float* fragVal,
+                                      long* fragPrevSub, long* fragPrevInd, uint8_t* fragFlags, int maxChains, int* chainOff, uint32_t* chainFrag,
+                                      uint8_t* chainLink, uint32_t* chainBox, float* chainValue, int* chainNumAnchors) {
+  oracle_sdp_opts o2 = *o;
+  o2.mode = 2;
+  return sdp_chain_impl(nBoxes, nullptr, strand, qs, ts, val, &o2, fragVal, fragPrevSub, fragPrevInd, fragFlags, maxChains, chainOff, chainFrag,
+                        chainLink, chainBox, chainValue, qe, te, numAnchors, chainNumAnchors);
 }

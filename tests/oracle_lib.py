@@ -251,17 +251,18 @@ def compare_lists_local(q, t, max_freq, max_diag=0, min_diag=0):
 class SdpOpts(C.Structure):
     _fields_ = [("rate", C.c_float), ("NumAln", C.c_int), ("alnthres", C.c_float), ("readLen", C.c_int),
                 ("gapopen", C.c_float), ("gapextend", C.c_float), ("gaproot", C.c_float),
-                ("gapCeiling1", C.c_int), ("gapCeiling2", C.c_int), ("mode", C.c_int)]
+                ("gapCeiling1", C.c_int), ("gapCeiling2", C.c_int), ("mode", C.c_int), ("globalK", C.c_int)]
 
 
 # -ONT preset (lra.cpp:388-420) + Options.h defaults
-SDP_ONT = dict(rate=20.0, NumAln=2, alnthres=0.7, gapopen=7.0, gapextend=10.0, gaproot=1.5, gapCeiling1=1500, gapCeiling2=3000, mode=0)
+SDP_ONT = dict(rate=20.0, NumAln=2, alnthres=0.7, gapopen=7.0, gapextend=10.0, gaproot=1.5, gapCeiling1=1500, gapCeiling2=3000, mode=0,
+               globalK=17)
 
 
 def sdp_opts(read_len, **kw):
     d = dict(SDP_ONT); d.update(kw)
     return SdpOpts(d["rate"], d["NumAln"], d["alnthres"], int(read_len), d["gapopen"], d["gapextend"], d["gaproot"],
-                   d["gapCeiling1"], d["gapCeiling2"], d["mode"])
+                   d["gapCeiling1"], d["gapCeiling2"], d["mode"], d["globalK"])
 
 
 def sdp_divide_dump(q, t, ind, inv, want_text=False):
@@ -331,6 +332,53 @@ def sdp_chain(cluster_off, cluster_strand, q, t, length, opts: "SdpOpts"):
         a, b = coff[c], coff[c + 1]
         chains.append(dict(frags=cf[a:b].copy(), link=cl[a:b - 1].copy(), box=box[4 * c:4 * c + 4].copy(), value=float(cv[c])))
     return dict(status=r, val=val[:n], prev_sub=ps[:n], prev_ind=pi[:n], flags=fl[:n], chains=chains)
+
+
+def sdp_chain_boxes(qs, qe, ts, te, strand, val, num_anchors, opts: "SdpOpts"):
+    """The high-accuracy SparseDP (SparseDP.h:1956) on one read's split clusters -> as sdp_chain, chains carry num_anchors."""
+    L = lib()
+    qs = np.ascontiguousarray(qs, np.uint32); qe = np.ascontiguousarray(qe, np.uint32); ts = np.ascontiguousarray(ts, np.uint32)
+    te = np.ascontiguousarray(te, np.uint32); st = np.ascontiguousarray(strand, np.uint8); vl = np.ascontiguousarray(val, np.int32)
+    na = np.ascontiguousarray(num_anchors, np.int32)
+    n = len(qs)
+    val_o = np.zeros(max(1, n), np.float32); ps = np.zeros(max(1, n), np.int64); pi = np.zeros(max(1, n), np.int64)
+    fl = np.zeros(max(1, n), np.uint8)
+    mc = max(1, opts.NumAln)
+    coff = np.zeros(mc + 1, np.int32); cf = np.zeros(max(1, n), np.uint32); cl = np.zeros(max(1, n), np.uint8)
+    box = np.zeros(4 * mc, np.uint32); cv = np.zeros(mc, np.float32); cn = np.zeros(mc, np.int32)
+    L.oracle_sdp_chain_boxes.restype = C.c_int
+    r = L.oracle_sdp_chain_boxes(C.c_int(n), _p(qs, C.c_uint32), _p(qe, C.c_uint32), _p(ts, C.c_uint32), _p(te, C.c_uint32), _p(st, C.c_uint8),
+                                 _p(vl, C.c_int), _p(na, C.c_int), C.byref(opts), _p(val_o, C.c_float), _p(ps, C.c_long), _p(pi, C.c_long),
+                                 _p(fl, C.c_uint8), C.c_int(mc), _p(coff, C.c_int), _p(cf, C.c_uint32), _p(cl, C.c_uint8), _p(box, C.c_uint32),
+                                 _p(cv, C.c_float), _p(cn, C.c_int))
+    chains = []
+    for c in range(max(r, 0)):
+        a, b = coff[c], coff[c + 1]
+        chains.append(dict(frags=cf[a:b].copy(), link=cl[a:b - 1].copy(), box=box[4 * c:4 * c + 4].copy(), value=float(cv[c]),
+                           num_anchors=int(cn[c])))
+    return dict(status=r, val=val_o[:n], prev_sub=ps[:n], prev_ind=pi[:n], flags=fl[:n], chains=chains)
+
+
+def split_clusters(qs, qe, ts, te, strand, anchorfreq, match_off, match_q, contig=False, K=17):
+    """SplitClusters + DecideSplitClustersValue (SplitClusters.h:63,176) on one read -> dict(cluster_val, cluster_split, qs, qe, ts, te,
+    strand, coarse, val, num)."""
+    L = lib()
+    qs = np.ascontiguousarray(qs, np.uint32); qe = np.ascontiguousarray(qe, np.uint32); ts = np.ascontiguousarray(ts, np.uint32)
+    te = np.ascontiguousarray(te, np.uint32); st = np.ascontiguousarray(strand, np.uint8); af = np.ascontiguousarray(anchorfreq, np.float32)
+    mo = np.ascontiguousarray(match_off, np.int32); mq = np.ascontiguousarray(match_q, np.uint32)
+    n = len(qs)
+    cap = 8 * n * n + 16
+    cv = np.zeros(max(1, n), np.int32); cs = np.zeros(max(1, n), np.uint8)
+    o = [np.zeros(cap, np.uint32) for _ in range(4)]
+    ost = np.zeros(cap, np.uint8); oc = np.zeros(cap, np.int32); ov = np.zeros(cap, np.int32); on = np.zeros(cap, np.int32)
+    L.oracle_split_clusters.restype = C.c_int
+    r = L.oracle_split_clusters(C.c_int(n), _p(qs, C.c_uint32), _p(qe, C.c_uint32), _p(ts, C.c_uint32), _p(te, C.c_uint32), _p(st, C.c_uint8),
+                                _p(af, C.c_float), _p(mo, C.c_int), _p(mq, C.c_uint32), C.c_int(1 if contig else 0), C.c_int(K),
+                                _p(cv, C.c_int), _p(cs, C.c_uint8), C.c_int(cap), _p(o[0], C.c_uint32), _p(o[1], C.c_uint32),
+                                _p(o[2], C.c_uint32), _p(o[3], C.c_uint32), _p(ost, C.c_uint8), _p(oc, C.c_int), _p(ov, C.c_int), _p(on, C.c_int))
+    assert r >= 0, r
+    return dict(cluster_val=cv[:n].copy(), cluster_split=cs[:n].copy(), qs=o[0][:r].copy(), qe=o[1][:r].copy(), ts=o[2][:r].copy(),
+                te=o[3][:r].copy(), strand=ost[:r].copy(), coarse=oc[:r].copy(), val=ov[:r].copy(), num=on[:r].copy())
 
 
 # ---- chain post-filters + SPLITChain (a9, low-accuracy path) ----------------------------------------------------------

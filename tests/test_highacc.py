@@ -1,0 +1,139 @@
+"""a6 + the high-accuracy SparseDP overload (SparseDP.h:1956): SplitClusters / DecideSplitClustersValue and the sparse DP over the
+resulting boxes.  Oracle sanity on CPU (parity unpinned: SplitClusters.h needs Cluster from Clustering.h -> htslib; the SDP engine's
+components are pinned in test_sdp.py); HIP vs oracle on the GPU."""
+import numpy as np
+import pytest
+
+import oracle_lib as O
+
+K = 17
+
+
+def _random_read(rng, n, read_len, tight):
+    """n cluster boxes on a read; tight => many shared / near coordinates so cuts coincide and ties appear in the cut order"""
+    qs = []; qe = []; ts = []; te = []; st = []; af = []; moff = [0]; mq = []
+    grid = 50 if tight else 1
+    for _ in range(n):
+        lq = int(rng.integers(20, min(6000, read_len - 10)))
+        a = int(rng.integers(0, read_len - lq)) // grid * grid
+        b = a + max(4, lq // grid * grid)
+        slope = rng.choice([1.0, 1.0, 0.97, 1.04, 0.5, 2.0])
+        lt = max(4, int((b - a) * slope) // grid * grid)
+        c = int(rng.integers(1000, 200_000)) // grid * grid
+        qs.append(a); qe.append(b); ts.append(c); te.append(c + lt); st.append(int(rng.random() < 0.4)); af.append(float(rng.choice([1.0, 2.5, 3.0, 4.0, 5.0, 6.5])))
+        m = int(rng.integers(0, 40))
+        pos = np.sort(rng.integers(a, max(a + 1, b - K), size=m)) if m else np.zeros(0, np.int64)
+        mq.extend(pos.tolist()); moff.append(len(mq))
+    return (np.array(qs, np.uint32), np.array(qe, np.uint32), np.array(ts, np.uint32), np.array(te, np.uint32), np.array(st, np.uint8),
+            np.array(af, np.float32), np.array(moff, np.int32), np.array(mq, np.uint32))
+
+
+def test_oracle_split_clusters_sanity():
+    # one forward cluster alone: no cut coordinate strictly inside it -> itself; Val = covered read bases, NumofAnchors0 = all matches
+    r = O.split_clusters([0], [100], [1000], [1100], [0], [1.0], [0, 3], [0, 10, 50])
+    assert r["qs"].tolist() == [0] and r["qe"].tolist() == [100] and r["ts"].tolist() == [1000] and r["te"].tolist() == [1100]
+    assert r["cluster_val"].tolist() == [44] and r["val"].tolist() == [44] and r["num"].tolist() == [3]
+    # two overlapping forward clusters cut each other on q
+    r = O.split_clusters([0, 50], [100, 150], [1000, 2000], [1100, 2100], [0, 0], [1.0, 1.0], [0, 2, 4], [10, 60, 70, 120])
+    assert list(zip(r["qs"].tolist(), r["qe"].tolist(), r["ts"].tolist(), r["te"].tolist())) == [
+        (0, 50, 1000, 1050), (50, 100, 1050, 1100), (50, 100, 2000, 2050), (100, 150, 2050, 2100)]
+    assert r["coarse"].tolist() == [0, 0, 1, 1] and r["num"].tolist() == [1, 1, 1, 1]
+    assert r["cluster_val"].tolist() == [34, 34] and r["val"].tolist() == [17, 17, 17, 17]
+    # a reverse cluster: pieces run down the anti-diagonal
+    r = O.split_clusters([0, 40], [100, 60], [1000, 5000], [1100, 5020], [1, 0], [1.0, 1.0], [0, 0, 0], [])
+    got = list(zip(r["qs"].tolist(), r["qe"].tolist(), r["ts"].tolist(), r["te"].tolist(), r["strand"].tolist()))
+    assert got[:3] == [(0, 40, 1060, 1100, 1), (40, 60, 1040, 1060, 1), (60, 100, 1000, 1040, 1)]
+    # contig reads keep frequent clusters whole, and list them first
+    r = O.split_clusters([0, 50], [100, 150], [1000, 2000], [1100, 2100], [0, 0], [2.0, 6.5], [0, 0, 0], [], contig=True)
+    assert r["cluster_split"].tolist() == [1, 0] and r["coarse"].tolist()[0] == 1 and (r["qs"][0], r["qe"][0]) == (50, 150)
+
+
+def test_oracle_sdp_boxes_sanity():
+    # three collinear forward boxes chain into one; the value is the sum of Val*rate minus nothing (diagonal gaps <= 2 are free)
+    qs = [0, 100, 200]; qe = [100, 200, 300]; ts = [1000, 1100, 1200]; te = [1100, 1200, 1300]
+    r = O.sdp_chain_boxes(qs, qe, ts, te, [0, 0, 0], [50, 60, 70], [5, 6, 7], O.sdp_opts(10000, rate=2.0))
+    assert r["status"] == 1 and r["chains"][0]["frags"].tolist() == [2, 1, 0] and r["chains"][0]["num_anchors"] == 18
+    assert r["chains"][0]["value"] == 2.0 * 180 and r["chains"][0]["box"].tolist() == [0, 300, 1000, 1300]
+
+
+def _hip_split(ctx, reads, contig):
+    import torch
+    from lra_amd import chain
+    dev = ctx.device
+    coff = np.concatenate([[0], np.cumsum([len(r[0]) for r in reads])]).astype(np.int64)
+    cat = lambda i, dt: np.concatenate([r[i] for r in reads]).astype(dt) if reads else np.zeros(0, dt)
+    moff = [0]
+    for r in reads:
+        base = moff[-1]
+        moff.extend((base + r[6][1:].astype(np.int64)).tolist())
+    tt = lambda a: torch.tensor(a, device=dev)
+    pad = lambda a: a if len(a) else np.zeros(1, a.dtype)
+    d = dict(coff=tt(coff), qs=tt(pad(cat(0, np.int64)).astype(np.int32)), qe=tt(pad(cat(1, np.int64)).astype(np.int32)),
+             ts=tt(pad(cat(2, np.int64)).astype(np.int32)), te=tt(pad(cat(3, np.int64)).astype(np.int32)), st=tt(pad(cat(4, np.int32))),
+             af=tt(pad(cat(5, np.float32))), moff=tt(np.array(moff, np.int64)), mq=tt(pad(cat(7, np.int64)).astype(np.int32)))
+    res = chain.split_clusters_batch(ctx, len(reads), d["coff"], d["qs"], d["qe"], d["ts"], d["te"], d["st"], d["af"], d["moff"], d["mq"], contig=contig, K=K)
+    return res, chain.fetch_split_clusters(ctx, res), coff, d
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("contig", [False, True])
+def test_hip_split_clusters_and_boxes_sdp_oracle(ctx, contig):
+    import torch
+    from lra_amd import chain
+    rng = np.random.default_rng(77 + int(contig))
+    reads = []; lens = []
+    for i in range(160):
+        L = int(rng.integers(3000, 40000))
+        n = int(rng.choice([0, 1, 2, 5, 12, 30, 70])) if i % 7 else 0
+        reads.append(_random_read(rng, n, L, tight=(i % 3 == 0)) if n else tuple(np.zeros(0, dt) for dt in (np.uint32,) * 4 + (np.uint8, np.float32)) + (np.zeros(1, np.int32), np.zeros(0, np.uint32)))
+        lens.append(L)
+    res, out, coff, d = _hip_split(ctx, reads, contig)
+    n_pieces = 0
+    exp_all = []
+    for r, rd in enumerate(reads):
+        exp = O.split_clusters(*rd, contig=contig, K=K)
+        exp_all.append(exp)
+        a, b = int(out["split_off"][r]), int(out["split_off"][r + 1])
+        assert b - a == len(exp["qs"]), (r, b - a, len(exp["qs"]))
+        for k in ("qs", "qe", "ts", "te", "strand", "coarse", "val"):
+            assert np.array_equal(out[k][a:b].astype(np.int64), exp[k].astype(np.int64)), (r, k)
+        assert np.array_equal(out["num_anchors"][a:b], exp["num"]), r
+        assert np.all(out["read"][a:b] == r)
+        c0, c1 = int(coff[r]), int(coff[r + 1])
+        assert np.array_equal(out["cluster_val"][c0:c1], exp["cluster_val"]) and np.array_equal(out["cluster_split"][c0:c1], exp["cluster_split"]), r
+        n_pieces += b - a
+    assert n_pieces > 3000
+    # the sparse DP over the boxes, straight from the device arrays of the split
+    roff = torch.tensor(np.concatenate([[0], np.cumsum(lens)]).astype(np.int64), device=ctx.device)
+    for kw in (dict(rate=1.0, NumAln=3), dict(rate=0.5, NumAln=1, alnthres=0.3)):
+        opts = chain.sdp_opts(globalK=K, **kw)
+        cres = chain.sparse_dp_boxes_batch(ctx, len(reads), res.d_split_off, res.d_qs, res.d_qe, res.d_ts, res.d_te, res.d_strand, res.d_val,
+                                           res.d_num_anchors, roff, opts)
+        co = chain.fetch(ctx, cres)
+        na = opts.NumAln
+        n_chains = 0
+        for r, exp_s in enumerate(exp_all):
+            if len(exp_s["qs"]) == 0:
+                assert co["n_chains"][r] == 0
+                continue
+            exp = O.sdp_chain_boxes(exp_s["qs"], exp_s["qe"], exp_s["ts"], exp_s["te"], exp_s["strand"], exp_s["val"], exp_s["num"],
+                                    O.sdp_opts(lens[r], globalK=K, **kw))
+            if exp["status"] < 0:
+                assert co["status"][r] != 0, r
+                continue
+            assert co["status"][r] == 0, (r, co["status"][r])
+            f0, f1 = int(co["frag_off"][r]), int(co["frag_off"][r + 1])
+            assert f1 - f0 == len(exp_s["qs"])
+            assert np.array_equal(co["frag_val"][f0:f1].view(np.uint32), exp["val"].view(np.uint32)), r
+            assert int(co["n_chains"][r]) == len(exp["chains"]), (r, co["n_chains"][r], len(exp["chains"]))
+            for c, ch in enumerate(exp["chains"]):
+                s = r * na + c
+                a = int(co["chain_start"][s]); ln = int(co["chain_len"][s])
+                assert ln == len(ch["frags"]), (r, c)
+                assert np.array_equal(co["chain_cluster"][a:a + ln], ch["frags"]), (r, c)
+                assert np.array_equal(co["chain_link"][a:a + ln - 1], ch["link"]), (r, c)
+                assert np.array_equal(co["chain_box"][s], ch["box"]), (r, c)
+                assert np.float32(co["chain_value"][s]).view(np.uint32) == np.float32(ch["value"]).view(np.uint32)
+                assert int(co["chain_num_anchors"][s]) == ch["num_anchors"]
+                n_chains += 1
+        assert n_chains > 100
