@@ -186,6 +186,8 @@ int lra_linear_extend_batch(lra_ctx* ctx, int K, const char* d_seq, const uint64
  * rate = opts.second_anchorbonus, and the one chain is the plain TraceBack (:1521) from the first anchor of maximal value (no box).
  * The same mode with several clusters per job is  SparseDP(SplitChain& inputChain, vector<Cluster_SameDiag*>&, FinalChain&, ...)
  * (SparseDP.h:1766-1955, LocalRefineAlignment.h:563): pass the clusters of inputChain in order, anchors = (GetqStart, GettStart, length).
+ * SparseDP_ForwardOnly (SparseDP_Forward.h:312-450, called at LocalRefineAlignment.h:378) is this mode on one forward-strand cluster
+ * per job with rate = (float)rate: the same points, weights, first-maximum rule and trace back.
  * d_status[r]: LRA_ST_CAPACITY if a work buffer bound was hit, LRA_ST_OOB_SLOT if the reference would read outside
  * its arrays (the read then has no chains).  Synchronous.                                              */
 #define LRA_SDP_CLUSTERS 0
