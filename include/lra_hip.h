@@ -275,6 +275,7 @@ typedef struct lra_split_result {
   const uint8_t* d_sp_type; const uint8_t* d_sp_strand; const int32_t* d_sp_chrom; const uint32_t* d_sp_box;
   const uint32_t* d_ci_beg; const uint32_t* d_ci_len; const uint32_t* d_ci_idx;
   const uint8_t* d_split_link; const uint32_t* d_n_split_link; const uint32_t* d_status;
+  const uint32_t* d_fidx;   /* [n_frags] position in the filtered chain -> position in the chain (both relative to d_chain_start[s]) */
 } lra_split_result;
 int lra_split_chains_batch(lra_ctx* ctx, const lra_chain_result* chains, const uint64_t* h_chrom_pos, int n_chrom, int splitdist,
                            int bypass_clustering, lra_split_result* out);
@@ -325,6 +326,36 @@ typedef struct lra_local_pairs_result {
 int lra_local_compare_batch(lra_ctx* ctx, uint64_t n_tasks, const uint32_t* d_q_tuples, const uint64_t* d_q_lo, const uint64_t* d_q_hi,
                             const uint32_t* d_t_tuples, const uint64_t* d_t_lo, const uint64_t* d_t_hi, int max_freq,
                             const int64_t* d_max_diag, const int64_t* d_min_diag, lra_local_pairs_result* out);
+
+/* Refine_splitchain(splitchains, chain, refinedclusters, clusters, genome, read, glIndex, localIndexes, smallOpts, opts)
+ * (ChainRefine.h:384-576, called at Map_lowacc.h:294) for every split chain of an lra_split_chains_batch result: the walk over the
+ * genome local-index windows under the split chain (LocalIndex::LookupIndex MMIndex.h:175, GenomeHeader::GetNextOffset Genome.h:43),
+ * with the extended clusters of the split chain brought to chromosome coordinates on their own strand (SwapStrand ClusterRefine.h:24,
+ * K = opts.globalK), CompareLists<LocalTuple,SmallTuple> of every (read window, genome window) it meets, AppendValues
+ * (TupleOps.h:159-195), SwapStrand of reverse results (K = smallOpts.globalK), SetClusterBoundariesFromMatches (Clustering.h:308) and
+ * refineEffiency.
+ * read_index: ONE lra_local_index_batch result over 2*n_reads sequences, the reads forward then their reverse complements
+ * (forwardIndex / reverseIndex, Map_lowacc.h:246-250), built with window = opts->local_window.  Genome local index (`.gli` payload):
+ * d_g_seq_off[n_g_windows+1] = glIndex.seqOffsets, d_g_tuple_bnd = tupleBoundaries, d_g_tuples = minimizers.
+ * opts: window = smallOpts.window, smallK = smallOpts.globalK, K = opts.globalK, limitrefine = opts.limitrefine, max_freq =
+ * smallOpts.localMaxFreq, local_window = glIndex.localIndexWindow.
+ * UNDEFINED IN THE REFERENCE: with limitrefine (the default) the upper diagonal bound of every window starts from an uninitialised
+ * variable (ChainRefine.h:468 `miniMaxDiag = miniMaxDiag;`); here it starts from the first anchor's diagonal like the lower bound.
+ * Output (context-owned), indexed like the split arrays (split k of slot s at x = d_chain_start[s] + k): refinedclusters[k].matches =
+ * (d_match_q, d_match_t)[d_match_off[x] .. d_match_off[x+1]) (t relative to the chromosome), d_box[4x..] = qStart,qEnd,tStart,tEnd,
+ * d_eff[x] = refineEffiency, d_status[x] (LRA_ST_OOB_SLOT where the reference would index outside an array; no matches then).
+ * strand / coarse / chromIndex of the refined cluster are the split chain's Strand / k / chromIndex.  Synchronous.            */
+typedef struct lra_rsc_opts { int32_t window, smallK, K, limitrefine, max_freq, local_window; } lra_rsc_opts;
+typedef struct lra_refined_result {
+  uint64_t n_frags, n_tasks, n_pairs, n_matches;
+  const uint64_t* d_match_off;               /* [n_frags+1] */
+  const uint32_t* d_match_q; const uint32_t* d_match_t;   /* [n_matches] */
+  const uint32_t* d_box; const float* d_eff; const uint32_t* d_status;   /* [4*n_frags], [n_frags], [n_frags] */
+} lra_refined_result;
+int lra_refine_splitchain_batch(lra_ctx* ctx, const lra_chain_result* chains, const lra_split_result* split, const uint64_t* d_read_off,
+                                const uint64_t* h_chrom_pos, int n_chrom, const lra_local_index_result* read_index, uint64_t n_g_windows,
+                                const uint64_t* d_g_seq_off, const uint64_t* d_g_tuple_bnd, const uint32_t* d_g_tuples,
+                                const lra_rsc_opts* opts, lra_refined_result* out);
 
 /* ---- a11: anchors inside one gap ------------------------------------------------------------------------
  * Replaces   float RefineSpace(int K, int W, int refineSpaceDiag, bool consider_str, GenomePairs& EndPairs, const Options& opts,

@@ -64,7 +64,7 @@ def fetch(ctx: Context, res: ChainResult):
 class SplitResult(C.Structure):
     _fields_ = [("n_slots", C.c_uint64), ("n_frags", C.c_uint64)] + [(n, C.c_void_p) for n in (
         "d_keep", "d_n_kept", "d_link", "d_n_split", "d_sp_beg", "d_sp_len", "d_sp_idx", "d_sp_link", "d_sp_type", "d_sp_strand", "d_sp_chrom",
-        "d_sp_box", "d_ci_beg", "d_ci_len", "d_ci_idx", "d_split_link", "d_n_split_link", "d_status")]
+        "d_sp_box", "d_ci_beg", "d_ci_len", "d_ci_idx", "d_split_link", "d_n_split_link", "d_status", "d_fidx")]
 
 
 def split_chains_batch(ctx: Context, chains: ChainResult, chrom_pos, splitdist=50000, bypass=1):
@@ -130,3 +130,32 @@ def fetch_split_clusters(ctx: Context, res: SplitClustersResult):
                   ("val", np.int32), ("num_anchors", np.int32), ("read", np.uint32)):
         d[k] = ctx.to_host(getattr(res, "d_" + k), ns, dt)
     return d
+
+
+class RscOpts(C.Structure):
+    _fields_ = [(n, C.c_int32) for n in ("window", "smallK", "K", "limitrefine", "max_freq", "local_window")]
+
+
+class RefinedResult(C.Structure):
+    _fields_ = [("n_frags", C.c_uint64), ("n_tasks", C.c_uint64), ("n_pairs", C.c_uint64), ("n_matches", C.c_uint64)] + [
+        (n, C.c_void_p) for n in ("d_match_off", "d_match_q", "d_match_t", "d_box", "d_eff", "d_status")]
+
+
+def refine_splitchain_batch(ctx: Context, chains: ChainResult, split: SplitResult, read_off, chrom_pos, read_index, g_seq_off, g_index,
+                            window=100, smallK=10, K=17, limitrefine=True, max_freq=15):
+    """Refine_splitchain (ChainRefine.h:384) for every split chain.  read_index: local.LocalIndex over the reads forward then reverse
+    complemented; g_index: local.LocalIndex of the genome, g_seq_off its seqOffsets as a device int64 tensor."""
+    cp = np.ascontiguousarray(chrom_pos, dtype=np.uint64)
+    o = RscOpts(int(window), int(smallK), int(K), 1 if limitrefine else 0, int(max_freq), int(g_index.window))
+    res = RefinedResult()
+    ctx.check(ctx.lib.lra_refine_splitchain_batch(ctx.h, C.byref(chains), C.byref(split), ptr(read_off), C.c_void_p(cp.ctypes.data), len(cp) - 1,
+                                                  C.byref(read_index.res), C.c_uint64(g_index.n_windows), ptr(g_seq_off),
+                                                  C.c_void_p(g_index.res.d_tuple_bnd), C.c_void_p(g_index.res.d_tuples), C.byref(o), C.byref(res)))
+    return res
+
+
+def fetch_refined(ctx: Context, res: RefinedResult):
+    nf = res.n_frags
+    return {"match_off": ctx.to_host(res.d_match_off, nf + 1, np.uint64), "match_q": ctx.to_host(res.d_match_q, res.n_matches, np.uint32),
+            "match_t": ctx.to_host(res.d_match_t, res.n_matches, np.uint32), "box": ctx.to_host(res.d_box, 4 * nf, np.uint32).reshape(-1, 4),
+            "eff": ctx.to_host(res.d_eff, nf, np.float32), "status": ctx.to_host(res.d_status, nf, np.uint32)}

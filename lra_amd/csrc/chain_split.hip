@@ -361,6 +361,7 @@ extern "C" int lra_split_chains_batch(lra_ctx* ctx, const lra_chain_result* ch, 
   out->d_keep = a.keep; out->d_n_kept = a.nKept; out->d_link = a.link; out->d_n_split = a.nSplit; out->d_sp_beg = a.spBeg; out->d_sp_len = a.spLen;
   out->d_sp_idx = a.spIdx; out->d_sp_link = a.spLink; out->d_sp_type = a.spType; out->d_sp_strand = a.spStrand; out->d_sp_chrom = a.spChrom; out->d_sp_box = a.spBox;
   out->d_ci_beg = a.ciBeg; out->d_ci_len = a.ciLen; out->d_ci_idx = a.ciIdx; out->d_split_link = a.splitLink; out->d_n_split_link = a.nSplitLink; out->d_status = a.status;
+  out->d_fidx = a.fidx;
   return LRA_OK;
 }
 

@@ -381,6 +381,38 @@ def split_clusters(qs, qe, ts, te, strand, anchorfreq, match_off, match_q, conti
                 te=o[3][:r].copy(), strand=ost[:r].copy(), coarse=oc[:r].copy(), val=ov[:r].copy(), num=on[:r].copy())
 
 
+class RscOpts(C.Structure):
+    _fields_ = [(n, C.c_int) for n in ("window", "smallK", "K", "limitrefine", "maxFreq")]
+
+
+def refine_splitchain(q, t, length, cluster, cstrand, sptc, box, strand, chrom, ci, chrom_pos, read_len, q_index, g_index,
+                      window=100, smallK=10, K=17, limitrefine=True, max_freq=15):
+    """Refine_splitchain (ChainRefine.h:384) for one split chain.  q_index / g_index = (seqOffsets, tupleBoundaries, tuples) of the read's
+    index on the split chain's strand / of the genome.  -> dict(q, t, box, eff) or None when the reference reads outside an array."""
+    L = lib()
+    q = np.ascontiguousarray(q, np.uint32); t = np.ascontiguousarray(t, np.uint32); ln = np.ascontiguousarray(length, np.int32)
+    cl = np.ascontiguousarray(cluster, np.int32); cs = np.ascontiguousarray(cstrand, np.uint8); sp = np.ascontiguousarray(sptc, np.int32)
+    bx = np.ascontiguousarray(box, np.uint32); cia = np.ascontiguousarray(ci, np.int32); pos = np.ascontiguousarray(chrom_pos, np.uint64)
+    qs, qb, qt = (np.ascontiguousarray(q_index[0], np.uint64), np.ascontiguousarray(q_index[1], np.uint64), np.ascontiguousarray(q_index[2], np.uint32))
+    gs, gb, gt = (np.ascontiguousarray(g_index[0], np.uint64), np.ascontiguousarray(g_index[1], np.uint64), np.ascontiguousarray(g_index[2], np.uint32))
+    o = RscOpts(window, smallK, K, 1 if limitrefine else 0, max_freq)
+    cap = 1 << 16
+    while True:
+        oq = np.zeros(cap, np.uint32); ot = np.zeros(cap, np.uint32); ob = np.zeros(4, np.uint32); eff = C.c_float(0)
+        L.oracle_refine_splitchain.restype = C.c_long
+        n = L.oracle_refine_splitchain(C.c_int(len(q)), _p(q, C.c_uint32), _p(t, C.c_uint32), _p(ln, C.c_int), _p(cl, C.c_int), _p(cs, C.c_uint8),
+                                       C.c_int(len(sp)), _p(sp, C.c_int), _p(bx, C.c_uint32), C.c_int(int(strand)), C.c_int(int(chrom)),
+                                       C.c_int(len(cia)), _p(cia, C.c_int), _p(pos, C.c_uint64), C.c_int(len(pos) - 1), C.c_uint32(int(read_len)),
+                                       C.c_long(len(qs) - 1), _p(qs, C.c_uint64), _p(qb, C.c_uint64), _p(qt, C.c_uint32), C.c_long(len(gs) - 1),
+                                       _p(gs, C.c_uint64), _p(gb, C.c_uint64), _p(gt, C.c_uint32), C.byref(o), C.c_long(cap), _p(oq, C.c_uint32),
+                                       _p(ot, C.c_uint32), _p(ob, C.c_uint32), C.byref(eff))
+        if n < 0:
+            return None
+        if n <= cap:
+            return dict(q=oq[:n].copy(), t=ot[:n].copy(), box=ob.copy(), eff=np.float32(eff.value))
+        cap = int(n)
+
+
 # ---- chain post-filters + SPLITChain (a9, low-accuracy path) ----------------------------------------------------------
 def split_chain(q, t, length, strand, cluster, link, chrom_pos, splitdist=50000, bypass=1):
     """One chain (trace-back order) -> dict(keep, link, splits=[dict(idx, link, type, strand, chrom, box, clusters)], split_link) or None (UB)."""

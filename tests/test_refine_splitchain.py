@@ -1,0 +1,133 @@
+"""a10 glue: Refine_splitchain (ChainRefine.h:384-576).  The whole low-accuracy front end runs on the GPU (seed -> clean -> extend ->
+SDP#A -> SPLITChain), then lra_refine_splitchain_batch; the oracle restates Refine_splitchain per split chain on the GPU's own chains.
+Parity unpinned (ChainRefine.h needs htslib headers); with limitrefine the reference reads an uninitialised bound (see the oracle file)."""
+import numpy as np
+import pytest
+
+import oracle_lib as O
+
+K = 17
+
+
+def _seq_offsets(starts, total, window):
+    """LocalIndex::seqOffsets of sequences starting at `starts` (MMIndex.h:200-245): window ends, restarting at each sequence"""
+    out = [0]
+    ends = list(starts[1:]) + [total]
+    for s, e in zip(starts, ends):
+        p = s
+        while p < e:
+            p = min(p + window, e)
+            out.append(p)
+    return np.array(out, np.uint64)
+
+
+def test_oracle_refine_splitchain_sanity():
+    # one forward anchor chain on the diagonal t = q + 1000 of a random sequence: every refined match must lie within 100 of that
+    # diagonal and inside the split chain's box, in chromosome coordinates
+    rng = np.random.default_rng(5)
+    genome = rng.integers(0, 4, 6000).astype(np.uint8)
+    g = np.frombuffer(b"ACGT", np.uint8)[genome]
+    read = g[1000:3000].copy()
+    gt, gb = O.local_index_seq(g.tobytes(), 10, 5, 256, 15)
+    qt, qb = O.local_index_seq(read.tobytes(), 10, 5, 256, 15)
+    gso = _seq_offsets([0], len(g), 256); qso = _seq_offsets([0], len(read), 256)
+    q = np.arange(1900, 0, -100, dtype=np.uint32); t = q + 1000                       # trace-back order
+    n = len(q)
+    sptc = np.arange(n - 1, -1, -1)                                                   # forward split chains list anchors first-to-last
+    box = [int(q.min()), int(q.max()) + 20, int(t.min()), int(t.max()) + 20]
+    r = O.refine_splitchain(q, t, [20] * n, [0] * n, [0] * n, sptc, box, 0, 0, [0], [0, len(g)], len(read), (qso, qb, qt), (gso, gb, gt))
+    assert r is not None and len(r["q"]) > 50
+    d = r["t"].astype(np.int64) - r["q"].astype(np.int64)
+    assert np.all(np.abs(d - 1000) <= 100) and np.all(r["q"] >= box[0]) and np.all(r["q"] < box[1]) and np.all(r["t"] >= box[2]) and np.all(r["t"] < box[3])
+    assert np.sum(d == 1000) > 40 and r["box"][0] == r["q"].min() and r["box"][1] == r["q"].max() + 10
+    r2 = O.refine_splitchain(q, t, [20] * n, [0] * n, [0] * n, sptc, box, 0, 0, [0], [0, len(g)], len(read), (qso, qb, qt), (gso, gb, gt), limitrefine=False)
+    assert np.all(np.abs(r2["t"].astype(np.int64) - r2["q"].astype(np.int64) - 1000) <= 50) and len(r2["q"]) <= len(r["q"])
+
+
+@pytest.mark.gpu
+def test_hip_refine_splitchain_oracle(ctx, oracle):
+    import torch
+    from lra_amd import synth, seed, cluster, chain, local
+    dev = ctx.device
+    genome = synth.make_genome(600_000, seed=41, repeat_frac=0.3, n_families=3)
+    CH = [0, 299_900, 600_000]                                                        # two chromosomes; the second does not start on a window edge
+    ik, ip = synth.build_global_index(genome, K, 10, 100)
+    reads, truth = synth.simulate_reads(genome, 36, 9000, 3000, 0.10, seed=19)
+    # chimeric reads: two loci far apart, the second half possibly reverse-complemented -> several split chains, 'T' / 'I' pieces
+    rng = np.random.default_rng(8)
+    for j in range(8):
+        a = int(rng.integers(10_000, 250_000)); b = int(rng.integers(330_000, 560_000))
+        ra = synth.simulate_read(rng, genome[a:a + 5000], 4000, 0.08, (30, 35, 35), False)[0]
+        rb = synth.simulate_read(rng, genome[b:b + 5000], 4000, 0.08, (30, 35, 35), bool(j & 1))[0]
+        reads.append(np.concatenate([ra, rb]))
+    # reads hugging the chromosome ends (the walk then runs into the last windows)
+    reads.append(genome[599_000:600_000].copy()); reads.append(genome[299_000:299_900].copy()); reads.append(genome[0:1500].copy())
+    reads.append(np.frombuffer(b"ACGT" * 5, dtype=np.uint8))
+    n = len(reads)
+    seed.load_reference(ctx, genome, ik, ip)
+    batch = seed.ReadBatch(ctx, [r.tobytes() for r in reads])
+    seed.seed_batch(ctx, batch, K, 10, 150)
+    po = dict(oracle.CLEAN_PRESETS["ONT"]); po["globalK"] = K
+    cres = cluster.clean_matches_batch(ctx, cluster.CleanOpts(**po), CH)
+    eres = cluster.linear_extend_batch(ctx, K, batch)
+    chres = chain.sparse_dp_batch(ctx, n, cres.d_cluster_off, eres.d_e_start, eres.d_e_count, cres.d_c_strand, eres.d_e_qpos, eres.d_e_tpos,
+                                  eres.d_e_len, batch.off, chain.sdp_opts())
+    co = chain.fetch(ctx, chres)
+    # the chain arrays are reused by later SDP calls: keep our own copies alive for the split / refine stages
+    spres = chain.split_chains_batch(ctx, chres, CH)
+    so = chain.fetch_split(ctx, spres)
+    fidx = ctx.to_host(spres.d_fidx, spres.n_frags, np.uint32)
+    # local indexes: genome (two sequences), reads forward + reverse complement in one index
+    gdev = torch.from_numpy(np.concatenate([genome, np.zeros(64, np.uint8)])).to(dev)
+    gli = local.LocalIndex(ctx, gdev, torch.tensor(CH, dtype=torch.int64, device=dev), 10, 5, 256, 15)
+    rc = seed.create_rc(ctx, batch)
+    tot = int(batch.off[-1])
+    both = torch.cat([batch.seq[:tot], rc[:tot], torch.zeros(64, dtype=torch.uint8, device=dev)])
+    off2 = torch.cat([batch.off, batch.off[1:] + tot])
+    rli = local.LocalIndex(ctx, both, off2, 10, 5, 256, 15)
+    gso = _seq_offsets(CH[:-1], CH[-1], 256)
+    assert len(gso) == gli.n_windows + 1
+    gso_d = torch.from_numpy(gso.astype(np.int64)).to(dev)
+    g_win, g_bnd, g_tup = gli.fetch()
+    r_win, r_bnd, r_tup = rli.fetch()
+    lens = [len(r) for r in reads]
+    na = chres.num_aln
+    for limit in (True, False):
+        res = chain.refine_splitchain_batch(ctx, chres, spres, batch.off, CH, rli, gso_d, gli, window=100, smallK=10, K=K, limitrefine=limit, max_freq=15)
+        out = chain.fetch_refined(ctx, res)
+        n_checked = n_rev = n_matches = n_multi = 0
+        for r in range(n):
+            for c in range(int(co["n_chains"][r])):
+                s = r * na + c
+                if so["status"][s]:
+                    continue
+                b = int(co["chain_start"][s]); ln = int(co["chain_len"][s])
+                keep = so["keep"][b:b + ln].astype(bool)
+                sel = np.nonzero(keep)[0]
+                assert np.array_equal(fidx[b:b + len(sel)], sel)
+                q = co["chain_q"][b:b + ln][sel]; t = co["chain_t"][b:b + ln][sel]; al = co["chain_alen"][b:b + ln][sel]
+                cl = co["chain_cluster"][b:b + ln][sel]; cst = co["chain_strand"][b:b + ln][sel]
+                nsp = int(so["n_split"][s])
+                n_multi += nsp > 1
+                for k in range(nsp):
+                    x = b + k
+                    a0, m = b + int(so["sp_beg"][x]), int(so["sp_len"][x])
+                    sptc = so["sp_idx"][a0:a0 + m]
+                    c0, cm = b + int(so["ci_beg"][x]), int(so["ci_len"][x])
+                    strand = int(so["sp_strand"][x])
+                    w0, w1 = int(r_win[strand * n + r]), int(r_win[strand * n + r + 1])
+                    q_index = (_seq_offsets([0], lens[r], 256), r_bnd[w0:w1 + 1] - r_bnd[w0], r_tup[int(r_bnd[w0]):int(r_bnd[w1])])
+                    exp = O.refine_splitchain(q, t, al, cl, cst, sptc, so["sp_box"][x], strand, int(so["sp_chrom"][x]), so["ci_idx"][c0:c0 + cm], CH, lens[r],
+                                              q_index, (gso, g_bnd, g_tup), window=100, smallK=10, K=K, limitrefine=limit, max_freq=15)
+                    m0, m1 = int(out["match_off"][x]), int(out["match_off"][x + 1])
+                    if exp is None:
+                        assert out["status"][x] != 0 and m1 == m0, (r, c, k)
+                        continue
+                    assert out["status"][x] == 0, (r, c, k, out["status"][x])
+                    assert m1 - m0 == len(exp["q"]), (r, c, k, m1 - m0, len(exp["q"]))
+                    assert np.array_equal(out["match_q"][m0:m1], exp["q"]) and np.array_equal(out["match_t"][m0:m1], exp["t"]), (r, c, k)
+                    if m1 > m0:
+                        assert np.array_equal(out["box"][x], exp["box"]), (r, c, k)
+                        assert out["eff"][x].view(np.uint32) == exp["eff"].view(np.uint32), (r, c, k)
+                    n_checked += 1; n_rev += strand; n_matches += m1 - m0
+        assert n_checked >= 40 and n_rev >= 10 and n_matches > 20000 and n_multi >= 4, (n_checked, n_rev, n_matches, n_multi)
