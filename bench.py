@@ -7,12 +7,12 @@ One "step" = one pass of the GPU-resident hot-path stages over one batch of read
   a7     LinearExtend + DecideCoordinates on those clusters
   a8     SparseDP (SDP#A): the primary chain(s) of every read over those anchors
   a9     RemoveSpuriousJump, SPLITChain, RemoveSpuriousSplitChain on those chains
-  a10    tier-2 primitives: CreateRC, LocalIndex::IndexSeq of both strands, and CompareLists<LocalTuple> of every read
-         window against the two genome windows at its true locus
+  a10    tier-2 lookup: CreateRC, LocalIndex::IndexSeq of both strands, Refine_splitchain on every split chain of a9 (the window
+         walk, CompareLists<LocalTuple> of every (read window, genome window) it meets, AppendValues, boundaries)
   a12    AffineOneGapAlign on the between-anchor gaps of every read
   a14    IndelRefineAlignment over every read's block list
   a16    CalculateStatistics (CIGAR runs, NM/NX/ND/NI/TD/TI counters, NV) on the refined blocks
-The stages between a9 and a12 (a10 lookup glue, a11, a13: tier-2 refinement of the split chains, local refinement glue) are
+The stages between a10 and a12 (a11 callers, the second sparse DP's inputs, a13: local refinement glue) are
 NOT built yet, so the a12/a14 inputs are derived from the simulator's true alignment (anchors =
 true gapless blocks >= 12 bp; the gaps between them go to a12; a perturbed block list goes to
 a14).  `config.stages` says so; the number is the throughput of the stages listed, not of a
@@ -156,22 +156,17 @@ def main():
     fbatch = refine.refine_batch_from_device(ctx, wl["rblocks"], wl["rboff"], wl["strands"], sim["off"][:-1], lens,
                                              gdev, torch.zeros(nR, dtype=torch.int64, device=ctx.device),
                                              torch.full((nR,), int(wl["genome"].numel()), dtype=torch.int64, device=ctx.device))
-    # a10 inputs: genome local index (the `.gli` payload, built once) and, per read window, the two genome
-    # windows at its true locus (what Refine_splitchain looks up, ChainRefine.h:384-576)
+    # a10 inputs: genome local index (the `.gli` payload, built once: tuples, tupleBoundaries, seqOffsets) and one buffer holding
+    # the reads forward followed by their reverse complements (forwardIndex / reverseIndex, Map_lowacc.h:246-250)
     from lra_amd import local
-    g_off = torch.tensor([0, int(wl["genome"].numel())], dtype=torch.int64, device=ctx.device)
+    G = int(wl["genome"].numel())
+    g_off = torch.tensor([0, G], dtype=torch.int64, device=ctx.device)
     gli = local.LocalIndex(ctx, gdev, g_off, 10, 5, 256, 15)
-    gbnd = gli.bnd_tensor()
-    nwin_r = (lens + 255) // 256
-    rwin_off = torch.zeros(nR + 1, dtype=torch.int64, device=ctx.device); rwin_off[1:] = torch.cumsum(nwin_r, 0)
-    rid_w = torch.repeat_interleave(torch.arange(nR, device=ctx.device), nwin_r)
-    wloc = torch.arange(int(rwin_off[-1]), device=ctx.device) - rwin_off[rid_w]
-    rstart = sim["blocks"][sim["block_off"][:-1], 1].long()                     # true genome start of every read
-    gwin0 = torch.clamp((rstart[rid_w] + wloc * 256) // 256, max=gli.n_windows - 2)
-    is_rev = wl["rev"][rid_w]
-    task_q = torch.cat([torch.arange(int(rwin_off[-1]), device=ctx.device)] * 2)
-    task_g = torch.cat([gwin0, gwin0 + 1])
-    task_rev = torch.cat([is_rev, is_rev])
+    gso = torch.cat([torch.arange(0, G, 256, dtype=torch.int64, device=ctx.device), torch.tensor([G], dtype=torch.int64, device=ctx.device)])
+    tot = int(sim["off"][-1])
+    both = torch.zeros(2 * tot + 64, dtype=torch.uint8, device=ctx.device)
+    both[:tot] = rbatch.seq[:tot]
+    off2 = torch.cat([rbatch.off, rbatch.off[1:] + tot]).contiguous()
     total_bases = int(lens.sum())
     n_gap_bytes = int(gp["q_len"].sum() + gp["t_len"].sum())
     n_gaps = int(gp["k"].numel())
@@ -187,18 +182,13 @@ def main():
                                       eres.d_e_len, rbatch.off, sdp_opts)
         # a9: RemoveSpuriousJump + SPLITChain + RemoveSpuriousSplitChain on every chain (Map_lowacc.h:189-256)
         spres = chain.split_chains_batch(ctx, chres, [0, int(wl["genome"].numel())])
-        rc = seed.create_rc(ctx, rbatch)
-        li_f = local.LocalIndex(ctx, rbatch.seq, rbatch.off, 10, 5, 256, 15)      # forwardIndex.IndexSeq(read.seq)  (Map_lowacc.h:249)
-        li_r = local.LocalIndex(ctx, rc, rbatch.off, 10, 5, 256, 15)              # reverseIndex.IndexSeq(readRC)    (Map_lowacc.h:250)
-        npairs = 0
-        for li, sel in ((li_f, ~task_rev), (li_r, task_rev)):                     # the strand whose RC equals the genome-oriented read
-            qb = li.bnd_tensor()
-            tq, tg = task_q[sel], task_g[sel]
-            pres = local.local_compare_batch(ctx, li, qb[tq], qb[tq + 1], gli, gbnd[tg], gbnd[tg + 1], 15, fetch=False)
-            npairs += pres.n_pairs
-            if "n_local_task_words" not in stats or stats.get("_lw_done", 0) < 2:
-                stats["n_local_task_words"] = stats.get("n_local_task_words", 0) + int((qb[tq + 1] - qb[tq]).sum() + (gbnd[tg + 1] - gbnd[tg]).sum())
-                stats["_lw_done"] = stats.get("_lw_done", 0) + 1
+        # a10: CreateRC, LocalIndex::IndexSeq of both strands, Refine_splitchain on every split chain (Map_lowacc.h:246-294)
+        ctx.check(ctx.lib.lra_create_rc_batch(ctx.h, rbatch.n, C.c_void_p(rbatch.seq.data_ptr()), C.c_void_p(rbatch.off.data_ptr()), C.c_void_p(both.data_ptr() + tot)))
+        rli = local.LocalIndex(ctx, both, off2, 10, 5, 256, 15)
+        rres = chain.refine_splitchain_batch(ctx, chres, spres, rbatch.off, [0, G], rli, gso, gli, window=100, smallK=10, K=args.k, limitrefine=True, max_freq=15)
+        if "n_local_task_words" not in stats and rres.n_tasks:
+            t4 = [ctx.to_tensor(p_, rres.n_tasks, torch.int64) for p_ in (rres.d_task_q_lo, rres.d_task_q_hi, rres.d_task_t_lo, rres.d_task_t_hi)]
+            stats["n_local_task_words"] = int((t4[1] - t4[0]).sum() + (t4[3] - t4[2]).sum())
         abatch.run()
         fres = refine.indel_refine_batch(ctx, fbatch, args.refine_band, 4, -1, -2)
         tres = refine.stats_of_refined(ctx, fbatch, fres, lut)
@@ -206,8 +196,8 @@ def main():
         rec = ctx.to_tensor(fres.d_blocks, 3 * fres.n_blocks, torch.int32)
         parallel.gather_records(rec, dst=0)
         stats.update(n_mm=sres.n_minimizers, n_match=sres.n_matches, n_cells=fres.n_cells, n_rows=fres.n_rows,
-                     n_seg=fres.n_segments, n_blocks=fres.n_blocks, n_aog=fres.n_aog, n_clusters=cres.n_clusters, n_cigar_runs=tres.n_runs, n_local_tuples=li_f.n_tuples + li_r.n_tuples,
-                     n_local_tasks=int(task_q.numel()), n_local_pairs=npairs,
+                     n_seg=fres.n_segments, n_blocks=fres.n_blocks, n_aog=fres.n_aog, n_clusters=cres.n_clusters, n_cigar_runs=tres.n_runs, n_local_tuples=rli.n_tuples,
+                     n_local_tasks=rres.n_tasks, n_local_pairs=rres.n_pairs, n_refined_matches=rres.n_matches,
                      n_sdp_anchors=chres.n_frags, n_sdp_points=chres.n_points, n_sdp_entries=chres.n_subproblem_entries)
         stats["_chres"] = chres
 
@@ -240,7 +230,7 @@ def main():
 
     kernels = ["sketch_count", "sketch_serial", "sketch_emit", "sort", "sort_fallback", "index_bounds", "compare", "strand",
                "aog_lds_tiny", "aog_lds_small", "aog_lds_large", "aog_hbm", "ir_segment", "ir_band", "ir_fill", "ir_trace", "ir_gather", "clean_sort", "clean", "linear_extend", "stats", "stats_cigar", "create_rc", "local_sketch", "local_sort_filter", "local_compare",
-               "chain_split", "sdp_points", "sdp_sort", "sdp_sort_fallback", "sdp_build_count", "sdp_build", "sdp_process", "sdp_trace"]
+               "rsc_tasks", "rsc_filter", "chain_split", "sdp_points", "sdp_sort", "sdp_sort_fallback", "sdp_build_count", "sdp_build", "sdp_process", "sdp_trace"]
     ktimes = {k: ctx.timing_get(k) for k in kernels}
     ctx.timing(False)
     if rank == 0:
@@ -263,6 +253,8 @@ def main():
             "strand": stats["n_match"] * (8 + 8 + 2 * args.k),
             "local_compare": 2 * 4 * stats.get("n_local_task_words", 0) + 8 * stats.get("n_local_pairs", 0),   # count + emit passes, both strands
             "local_sort_filter": 2 * 4 * stats.get("n_local_tuples", 0),
+            "rsc_tasks": 2 * (21 * stats.get("n_sdp_anchors", 0) + 36 * stats.get("n_local_tasks", 0)),
+            "rsc_filter": 2 * 8 * stats.get("n_local_pairs", 0) + 8 * stats.get("n_refined_matches", 0),
             "local_sketch": 2 * 2 * L + 4 * stats.get("n_local_tuples", 0),
             "stats": 2 * L + 12 * stats["n_blocks"] + 4 * stats.get("n_cigar_runs", 0),
             "clean": 16 * stats["n_match"] * 3,
@@ -287,7 +279,7 @@ def main():
         except (OSError, ValueError, KeyError):
             pass
         out = {
-            "metric": "aligned Gbp/s (hot-path stages a1-a5, a7, a8 SDP#A, a9 split, a10 primitives, a12, a14, a16), 30 kb ONT-like reads", "value": gbps, "unit": "Gbp/s",
+            "metric": "aligned Gbp/s (hot-path stages a1-a5, a7, a8 SDP#A, a9 split, a10 Refine_splitchain, a12, a14, a16), 30 kb ONT-like reads", "value": gbps, "unit": "Gbp/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_step, "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "int32", "data": "synthetic",
             "reads_per_s": nreads * args.steps / dt,
@@ -295,8 +287,8 @@ def main():
                                    "error 30:35:35 (BASELINE configs[2] -ONT read profile; full GRCh38 not generated in round 1)"
                                    % (args.genome_mb, args.reads, args.read_len, args.err * 100),
                        "preset": "-ONT (k=%d w=%d maxFreq=%d refineBand=%d match/mismatch/indel=4/-1/-2)" % (args.k, args.w, args.max_freq, args.refine_band),
-                       "stages": "a1-a5,a7,a8(SDP#A),a9(chain split) chained on the reads; a12 on between-anchor gaps and a14 on block lists derived from the simulator's truth, "
-                                 "a16 on a14's output (a10 lookup glue, a11, a13 refinement glue not built yet: NOT a whole `lra align`)",
+                       "stages": "a1-a5,a7,a8(SDP#A),a9(chain split),a10(Refine_splitchain) chained on the reads; a12 on between-anchor gaps and a14 on block lists derived from "
+                                 "the simulator's truth, a16 on a14's output (a11 callers, a13 refinement glue not built yet: NOT a whole `lra align`)",
                        "parallelism": "reads sharded by ordinal, 1 process/GPU; RCCL gather of block records to rank 0",
                        "per_step": {k: int(v) for k, v in stats.items() if not k.startswith("_")}},
             "kernel_ms_per_step": {k: round(v[0] / args.steps, 4) for k, v in ktimes.items() if v[1]},

@@ -351,6 +351,7 @@ typedef struct lra_refined_result {
   const uint64_t* d_match_off;               /* [n_frags+1] */
   const uint32_t* d_match_q; const uint32_t* d_match_t;   /* [n_matches] */
   const uint32_t* d_box; const float* d_eff; const uint32_t* d_status;   /* [4*n_frags], [n_frags], [n_frags] */
+  const uint64_t* d_task_q_lo; const uint64_t* d_task_q_hi; const uint64_t* d_task_t_lo; const uint64_t* d_task_t_hi;   /* [n_tasks] the CompareLists calls, as tuple ranges */
 } lra_refined_result;
 int lra_refine_splitchain_batch(lra_ctx* ctx, const lra_chain_result* chains, const lra_split_result* split, const uint64_t* d_read_off,
                                 const uint64_t* h_chrom_pos, int n_chrom, const lra_local_index_result* read_index, uint64_t n_g_windows,

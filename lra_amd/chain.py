@@ -138,7 +138,8 @@ class RscOpts(C.Structure):
 
 class RefinedResult(C.Structure):
     _fields_ = [("n_frags", C.c_uint64), ("n_tasks", C.c_uint64), ("n_pairs", C.c_uint64), ("n_matches", C.c_uint64)] + [
-        (n, C.c_void_p) for n in ("d_match_off", "d_match_q", "d_match_t", "d_box", "d_eff", "d_status")]
+        (n, C.c_void_p) for n in ("d_match_off", "d_match_q", "d_match_t", "d_box", "d_eff", "d_status", "d_task_q_lo", "d_task_q_hi", "d_task_t_lo",
+                                  "d_task_t_hi")]
 
 
 def refine_splitchain_batch(ctx: Context, chains: ChainResult, split: SplitResult, read_off, chrom_pos, read_index, g_seq_off, g_index,

@@ -337,6 +337,7 @@ extern "C" int lra_refine_splitchain_batch(lra_ctx* ctx, const lra_chain_result*
     LRA_HIP_CHECK(ctx, hipMemsetAsync(outOff, 0, 16, st));
   }
   out->n_matches = NM; out->d_match_q = oq; out->d_match_t = ot;
+  out->d_task_q_lo = a.qLo; out->d_task_q_hi = a.qHi; out->d_task_t_lo = a.tLo; out->d_task_t_hi = a.tHi;
   f.oq = oq; f.ot = ot;
   lra_time_begin(ctx, "rsc_filter");
   hipLaunchKernelGGL(rsc_match_off, dim3((unsigned)((NF + 2 + 255) / 256)), dim3(256), 0, st, f);
