@@ -46,6 +46,10 @@ void* lra_scratch(lra_ctx* ctx, int slot, size_t bytes);
 // growable buffer `idx` of at least `bytes` (contents NOT preserved on growth)
 void* lra_ensure(lra_ctx* ctx, int idx, size_t bytes);
 
+// seed.hip: std::sort-identical segmented sort of (key, payload) lists whose keys rarely repeat inside a list
+int lra_sort_mostly_unique_batch(lra_ctx* ctx, int n_lists, const uint64_t* d_off, uint64_t total, uint64_t* d_key, uint32_t* d_pos,
+                                 uint64_t* tmp_key, uint32_t* tmp_pos, int end_bit);
+
 #define LRA_HIP_CHECK(ctx, call)                                                         \
   do {                                                                                   \
     hipError_t e__ = (call);                                                             \

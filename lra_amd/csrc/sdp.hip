@@ -1148,12 +1148,13 @@ int sdp_run(lra_ctx* ctx, int n_reads, const uint64_t* d_cluster_off, const uint
     lra_time_end(ctx);
   }
   struct Retag { lra_ctx* c; Retag(lra_ctx* x) : c(x) { c->sort_tag = "sdp_sort"; c->sort_fb_tag = "sdp_sort_fallback"; } ~Retag() { c->sort_tag = "sort"; c->sort_fb_tag = "sort_fallback"; } } retag(ctx);
-  { int rc = lra_sort_minimizers_batch(ctx, n_reads, ptOff, key1, pay1); if (rc) return rc; }       // sort(H1, SortByRowOp)  :2171
+  // the two point orders: (q, t, ind) / (t, q, ind) keys repeat only where two anchors share a corner, so the radix path takes nearly all lists
+  { int rc = lra_sort_mostly_unique_batch(ctx, n_reads, ptOff, NP, key1, pay1, key3, pay3, 64); if (rc) return rc; }   // sort(H1, SortByRowOp)  :2171
   lra_time_begin(ctx, "sdp_points");
   hipLaunchKernelGGL(k_gather, dim3((unsigned)((NP + 255) / 256)), dim3(256), 0, st, NP, ptRead, ptOff, pay1, iq, it, ifl, ifr, hq, ht, hfl, hfr, key2, pay2,
                      key3, pay3);
   lra_time_end(ctx);
-  { int rc = lra_sort_minimizers_batch(ctx, n_reads, ptOff, key2, pay2); if (rc) return rc; }       // sort(H2, SortByColOp)  :2174
+  { int rc = lra_sort_mostly_unique_batch(ctx, n_reads, ptOff, NP, key2, pay2, key1, pay1, 63); if (rc) return rc; }   // sort(H2, SortByColOp)  :2174
   // diagonal order per point class: any sorted order serves (ties are the same diagonal), so this one is a segmented radix sort -- the
   // exact introsort degenerates on the long runs of equal diagonals.  Sorted into the (now free) key1 / pay1 buffers.
   {

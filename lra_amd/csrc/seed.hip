@@ -25,6 +25,7 @@
 // state machines) and across query tuples (one lane per tuple for the index searches,
 // which are the HBM-heavy part).
 #include "common.h"
+#include <rocprim/rocprim.hpp>
 #include "scan.h"
 
 namespace {
@@ -487,7 +488,8 @@ __device__ void lds_insertion_sort(LdsSeg& s, int first, int last) {   // == __i
 }
 
 __global__ void __launch_bounds__(SORT_NT) sort_wg_kernel(int n_reads, const uint64_t* __restrict__ mm_off, uint64_t* mm_key, uint32_t* mm_pos,
-                                                        uint32_t* tscratch, int cap, int* __restrict__ fallback) {
+                                                        uint32_t* tscratch, int cap, int* __restrict__ fallback,
+                                                        const int* __restrict__ only) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int maxseg = cap / 16 + 8;
@@ -515,6 +517,7 @@ __global__ void __launch_bounds__(SORT_NT) sort_wg_kernel(int n_reads, const uin
     const long base = (long)mm_off[r];
     const int n = (int)(mm_off[r + 1] - mm_off[r]);
     if (n < 2) continue;
+    if (only && !only[r]) continue;
     if (n > cap) { if (tid == 0) fallback[r] = 1; continue; }
     __syncthreads();
     for (int p = tid; p < n; p += SORT_NT) { key[p] = mm_key[base + p]; idx[p] = (unsigned short)p; seg[p] = 0; }
@@ -961,7 +964,7 @@ extern "C" int lra_create_rc_batch(lra_ctx* ctx, int n_reads, const char* d_seq,
   return LRA_OK;
 }
 
-static int launch_sort(lra_ctx* ctx, int n_reads, const uint64_t* mm_off, uint64_t* mm_key, uint32_t* mm_pos) {
+static int launch_sort(lra_ctx* ctx, int n_reads, const uint64_t* mm_off, uint64_t* mm_key, uint32_t* mm_pos, const int* only = nullptr) {
   hipStream_t st = ctx->stream;
   const int nb = (n_reads + 63) / 64;
   const int cap = SORT_CAP;
@@ -974,11 +977,51 @@ static int launch_sort(lra_ctx* ctx, int n_reads, const uint64_t* mm_off, uint64
   LRA_HIP_CHECK(ctx, hipMemsetAsync(flags, 0, (size_t)n_reads * 4, st));
   LRA_HIP_CHECK(ctx, hipFuncSetAttribute((const void*)sort_wg_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
   lra_time_begin(ctx, ctx->sort_tag);
-  hipLaunchKernelGGL(sort_wg_kernel, dim3(grid), dim3(SORT_NT), lds, st, n_reads, mm_off, mm_key, mm_pos, tscr, cap, flags);
+  hipLaunchKernelGGL(sort_wg_kernel, dim3(grid), dim3(SORT_NT), lds, st, n_reads, mm_off, mm_key, mm_pos, tscr, cap, flags, only);
   lra_time_end(ctx);
   lra_time_begin(ctx, ctx->sort_fb_tag);
   hipLaunchKernelGGL(sort_kernel, dim3(nb), dim3(64), 0, st, n_reads, mm_off, mm_key, mm_pos, (const int*)flags);
   lra_time_end(ctx);
+  return LRA_OK;
+}
+
+// A list whose keys are all different has only one sorted order, so any sort reproduces std::sort on it.  Lists are radix-sorted into
+// (tmp_key, tmp_pos); one block per list then looks for two equal neighbours: without any, the sorted list is copied over the input,
+// with one the input is left alone and the list is marked for the exact sort.
+__global__ void __launch_bounds__(256) sort_adopt_kernel(int n_lists, const uint64_t* __restrict__ off, uint64_t* key, uint32_t* pos,
+                                                         const uint64_t* __restrict__ tkey, const uint32_t* __restrict__ tpos, int* ties) {
+  const int r = blockIdx.x;
+  const uint64_t b = off[r], e = off[r + 1];
+  int tie = 0;
+  for (uint64_t i = b + threadIdx.x; i + 1 < e; i += 256) tie |= tkey[i] == tkey[i + 1];
+  tie = __syncthreads_or(tie);
+  if (tie) { if (threadIdx.x == 0) ties[r] = 1; return; }
+  if (threadIdx.x == 0) ties[r] = 0;
+  for (uint64_t i = b + threadIdx.x; i < e; i += 256) { key[i] = tkey[i]; pos[i] = tpos[i]; }
+}
+
+// Same result as lra_sort_minimizers_batch, for keys that rarely repeat within a list (the sparse DP's point orders): keys below
+// 2^end_bit, `total` = d_off[n_lists], (tmp_key, tmp_pos) = scratch of the same size as the input.
+int lra_sort_mostly_unique_batch(lra_ctx* ctx, int n_lists, const uint64_t* d_off, uint64_t total, uint64_t* d_key, uint32_t* d_pos,
+                                 uint64_t* tmp_key, uint32_t* tmp_pos, int end_bit) {
+  if (n_lists == 0 || total == 0) return LRA_OK;
+  hipStream_t st = ctx->stream;
+  size_t temp_bytes = 0;
+  (void)rocprim::segmented_radix_sort_pairs(nullptr, temp_bytes, (uint64_t*)nullptr, (uint64_t*)nullptr, (uint32_t*)nullptr, (uint32_t*)nullptr,
+                                            (unsigned int)total, (unsigned int)n_lists, (uint64_t*)nullptr, (uint64_t*)nullptr, 0, end_bit, st);
+  char* temp = (char*)lra_scratch(ctx, 2, temp_bytes + 256 + (size_t)n_lists * 4);
+  if (!temp) return LRA_ERR_NOMEM;
+  int* ties = (int*)(temp + ((temp_bytes + 255) & ~(size_t)255));
+  lra_time_begin(ctx, ctx->sort_tag);
+  hipError_t e = rocprim::segmented_radix_sort_pairs(temp, temp_bytes, d_key, tmp_key, d_pos, tmp_pos, (unsigned int)total, (unsigned int)n_lists, d_off,
+                                                     d_off + 1, 0, end_bit, st);
+  if (e != hipSuccess) { lra_time_end(ctx); return lra_set_err(ctx, LRA_ERR_HIP, "segmented sort: %s", hipGetErrorString(e)); }
+  hipLaunchKernelGGL(sort_adopt_kernel, dim3(n_lists), dim3(256), 0, st, n_lists, d_off, d_key, d_pos, (const uint64_t*)tmp_key, (const uint32_t*)tmp_pos, ties);
+  lra_time_end(ctx);
+  // lra_scratch slot 0 is launch_sort's own; the ties mask lives in slot 2 and stays valid through it
+  int rc = launch_sort(ctx, n_lists, d_off, d_key, d_pos, ties);
+  if (rc) return rc;
+  LRA_HIP_CHECK(ctx, hipGetLastError());
   return LRA_OK;
 }
 
