@@ -220,49 +220,46 @@ __device__ void w_std_sort(uint32_t* v, long n) {
 // lane-private LDS row (copied in and out with coalesced accesses); longer ones in HBM.
 constexpr int LCAP = 160;
 constexpr int LSTRIDE = LCAP + 1;
-__global__ void __launch_bounds__(64) local_sort_filter(uint64_t n_win, const uint64_t* __restrict__ raw_off, uint32_t* raw, int maxFreq, uint32_t* __restrict__ counts) {
+constexpr int STAGE_NT = 256;                                           // 4 waves stage a block's 64 lists (memory parallelism), wave 0 works on them
+__global__ void __launch_bounds__(STAGE_NT) local_sort_filter(uint64_t n_win, const uint64_t* __restrict__ raw_off, uint32_t* raw, int maxFreq, uint32_t* __restrict__ counts) {
   __shared__ uint32_t stage[64 * LSTRIDE];
-  const int lane = threadIdx.x;
+  __shared__ uint32_t kept[64];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const uint64_t w0 = (uint64_t)blockIdx.x * 64;
   const uint64_t wi = w0 + lane;
-  for (int x = 0; x < 64; x++) {
-    const uint64_t wx = w0 + x;
-    if (wx >= n_win) break;
-    const uint64_t a = raw_off[wx], n = raw_off[wx + 1] - a;
+  const uint64_t myA = wi < n_win ? raw_off[wi] : 0, myN = wi < n_win ? raw_off[wi + 1] - myA : 0;
+#pragma unroll 4
+  for (int x = wave; x < 64; x += STAGE_NT / 64) {
+    const uint64_t a = __shfl(myA, x), n = __shfl(myN, x);
     if (n > LCAP) continue;
     for (uint32_t p = lane; p < n; p += 64) stage[x * LSTRIDE + p] = raw[a + p];
   }
-  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-  __builtin_amdgcn_wave_barrier();
-  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-  long n = 0, c = 0;
-  bool staged = false;
-  if (wi < n_win) {
-    n = (long)(raw_off[wi + 1] - raw_off[wi]);
-    staged = n <= LCAP;
-    uint32_t* v = staged ? stage + lane * LSTRIDE : raw + raw_off[wi];
-    w_std_sort(v, n);                                                    // MMIndex.h:219
-    long x = 0;                                                          // RemoveFrequent MMIndex.h:69-84
-    while (x < n) {
-      long ne = x;
-      while (ne < n && T_(v[ne]) == T_(v[x])) ne++;
-      if (ne - x < maxFreq) for (long y = x; y < ne; y++) v[c++] = v[y];
-      x = ne;
+  __syncthreads();
+  if (wave == 0) {
+    long c = 0;
+    if (wi < n_win) {
+      const long n = (long)myN;
+      const bool staged = n <= LCAP;
+      uint32_t* v = staged ? stage + lane * LSTRIDE : raw + myA;
+      w_std_sort(v, n);                                                  // MMIndex.h:219
+      long x = 0;                                                        // RemoveFrequent MMIndex.h:69-84
+      while (x < n) {
+        long ne = x;
+        while (ne < n && T_(v[ne]) == T_(v[x])) ne++;
+        if (ne - x < maxFreq) for (long y = x; y < ne; y++) v[c++] = v[y];
+        x = ne;
+      }
+      counts[wi] = (uint32_t)c;
     }
-    counts[wi] = (uint32_t)c;
+    kept[lane] = (uint32_t)c;
   }
-  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-  __builtin_amdgcn_wave_barrier();
-  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-  // write the surviving tuples back (coalesced, one window at a time)
-  for (int x = 0; x < 64; x++) {
-    const uint64_t wx = w0 + x;
-    if (wx >= n_win) break;
-    const long cx = __shfl((int)c, x);
-    const bool sx = __shfl((int)staged, x) != 0;
-    if (!sx) continue;
-    const uint64_t a = raw_off[wx];
-    for (long p = lane; p < cx; p += 64) raw[a + p] = stage[x * LSTRIDE + p];
+  __syncthreads();
+  // write the surviving tuples back (coalesced, one window per wave at a time)
+  for (int x = wave; x < 64; x += STAGE_NT / 64) {
+    const uint64_t a = __shfl(myA, x), n = __shfl(myN, x);
+    if (w0 + x >= n_win || n > LCAP) continue;
+    const uint32_t cx = kept[x];
+    for (uint32_t p = lane; p < cx; p += 64) raw[a + p] = stage[x * LSTRIDE + p];
   }
 }
 
@@ -287,27 +284,27 @@ struct CmpArgs {
 
 constexpr int QCAP = 96, TCAP = 160, CSTRIDE = QCAP + TCAP + 1;   // lane-private LDS row: query list then target list
 template <bool EMIT>
-__global__ void __launch_bounds__(64) local_compare(CmpArgs A) {
+__global__ void __launch_bounds__(STAGE_NT) local_compare(CmpArgs A) {
   __shared__ uint32_t stage[64 * CSTRIDE];
-  const int lane = threadIdx.x;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const uint64_t x0 = (uint64_t)blockIdx.x * 64;
-  for (int i = 0; i < 64; i++) {                                         // coalesced staging, one task at a time
-    const uint64_t xi = x0 + i;
-    if (xi >= A.n_tasks) break;
-    const uint64_t qa = A.q_lo[xi], qn = A.q_hi[xi] - qa, ta = A.t_lo[xi], tn = A.t_hi[xi] - ta;
+  const uint64_t x = x0 + lane;
+  const bool live = x < A.n_tasks;
+  const uint64_t myQa = live ? A.q_lo[x] : 0, myTa = live ? A.t_lo[x] : 0;
+  const uint64_t myQn = live ? A.q_hi[x] - myQa : 0, myTn = live ? A.t_hi[x] - myTa : 0;
+#pragma unroll 4
+  for (int i = wave; i < 64; i += STAGE_NT / 64) {                       // coalesced staging, one task per wave at a time
+    const uint64_t qa = __shfl(myQa, i), qn = __shfl(myQn, i), ta = __shfl(myTa, i), tn = __shfl(myTn, i);
     if (qn > QCAP || tn > TCAP) continue;
     for (uint32_t p = lane; p < qn; p += 64) stage[i * CSTRIDE + p] = A.q[qa + p];
     for (uint32_t p = lane; p < tn; p += 64) stage[i * CSTRIDE + QCAP + p] = A.t[ta + p];
   }
-  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-  __builtin_amdgcn_wave_barrier();
-  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-  const uint64_t x = x0 + lane;
-  if (x >= A.n_tasks) return;
-  const long nq = (long)(A.q_hi[x] - A.q_lo[x]), nt = (long)(A.t_hi[x] - A.t_lo[x]);
+  __syncthreads();
+  if (wave != 0 || !live) return;
+  const long nq = (long)myQn, nt = (long)myTn;
   const bool staged = nq <= QCAP && nt <= TCAP;
-  const uint32_t* q = staged ? stage + lane * CSTRIDE : A.q + A.q_lo[x];
-  const uint32_t* t = staged ? stage + lane * CSTRIDE + QCAP : A.t + A.t_lo[x];
+  const uint32_t* q = staged ? stage + lane * CSTRIDE : A.q + myQa;
+  const uint32_t* t = staged ? stage + lane * CSTRIDE + QCAP : A.t + myTa;
   const int64_t maxDiag = A.maxDiag ? A.maxDiag[x] : 0, minDiag = A.minDiag ? A.minDiag[x] : 0;
   const long maxFreq = A.maxFreq;
   uint32_t* oq = EMIT ? A.out_qi + A.out_off[x] : nullptr; uint32_t* ot = EMIT ? A.out_ti + A.out_off[x] : nullptr;
@@ -425,7 +422,7 @@ extern "C" int lra_local_index_batch(lra_ctx* ctx, int n_seqs, const char* d_seq
     hipLaunchKernelGGL(local_sketch<true>, dim3(gw), dim3(64), 0, st, n_win, seq, w_start, w_len, k, w, raw_off, raw, (uint32_t*)nullptr);
     lra_time_end(ctx);
     lra_time_begin(ctx, "local_sort_filter");
-    hipLaunchKernelGGL(local_sort_filter, dim3(gw), dim3(64), 0, st, n_win, raw_off, raw, max_freq, cnt);
+    hipLaunchKernelGGL(local_sort_filter, dim3(gw), dim3(STAGE_NT), 0, st, n_win, raw_off, raw, max_freq, cnt);
     lra_time_end(ctx);
     if (lra_exclusive_scan<uint32_t>(ctx, (long)n_win, cnt, bnd_tmp)) return LRA_ERR_HIP;
     if (d2h8(ctx, &n_tup, bnd_tmp + n_win)) return LRA_ERR_HIP;
@@ -468,7 +465,7 @@ extern "C" int lra_local_compare_batch(lra_ctx* ctx, uint64_t n_tasks, const uin
   A.out_off = off; A.out_qi = nullptr; A.out_ti = nullptr;
   const unsigned g = (unsigned)((n_tasks + 63) / 64);
   lra_time_begin(ctx, "local_compare");
-  hipLaunchKernelGGL(local_compare<false>, dim3(g), dim3(64), 0, st, A);
+  hipLaunchKernelGGL(local_compare<false>, dim3(g), dim3(STAGE_NT), 0, st, A);
   lra_time_end(ctx);
   if (lra_exclusive_scan<uint32_t>(ctx, (long)n_tasks, A.counts, off)) return LRA_ERR_HIP;
   uint64_t total = 0;
@@ -477,7 +474,7 @@ extern "C" int lra_local_compare_batch(lra_ctx* ctx, uint64_t n_tasks, const uin
   if (!r) return LRA_ERR_NOMEM;
   A.out_qi = carve<uint32_t>(r, total + 1); A.out_ti = carve<uint32_t>(r, total + 1);
   lra_time_begin(ctx, "local_compare");
-  hipLaunchKernelGGL(local_compare<true>, dim3(g), dim3(64), 0, st, A);
+  hipLaunchKernelGGL(local_compare<true>, dim3(g), dim3(STAGE_NT), 0, st, A);
   lra_time_end(ctx);
   LRA_HIP_CHECK(ctx, hipGetLastError());
   LRA_HIP_CHECK(ctx, hipStreamSynchronize(st));
