@@ -378,6 +378,29 @@ int lra_refine_space_batch(lra_ctx* ctx, int n, const char* d_qseq, const uint64
                            const int32_t* d_diag, const uint32_t* d_q_add, const uint32_t* d_t_add, const uint32_t* d_flip_len, int match,
                            int mismatch, int indel, int max_freq, lra_refine_space_result* out);
 
+/* Refine_Btwnsplitchain(spchain, refined_clusters, RevBtwnCluster, tracerev, genome, read, smallOpts, strands, spchain_link)
+ * (ChainRefine.h:579-754, called at Map_lowacc.h:362) for every chain of the batch: for each pair of neighbouring refined clusters the
+ * case analysis of :587-660 (plain gap, INV, DUP) and RefineBtwnSpace_AppendCloseCluster (:59-121; append_to_closetcluster :22-56) /
+ * RefineBtwnSpace (ClusterRefine.h:327-430) on the one or two spaces, then the spaces beyond the first and the last split chain
+ * (:684-753), each RefineSpace call going through lra_refine_space_batch.  Gaps of one chain are taken in order (a gap reads the boxes
+ * the previous one may have moved): the batch advances in rounds, one gap index per round.
+ * refined = the lra_refine_splitchain_batch result of the same chains / split; d_strands = the reads forward, then (at byte rc_base)
+ * their reverse complements, laid out by d_read_off; d_genome = all chromosomes back to back (h_chrom_pos).  opts = the Options the
+ * reference passes (smallOpts): K / W = globalK / globalW, refineSpaceDist, anchorstoosparse, localMatch / localMismatch / localIndel,
+ * max_freq = localMaxFreq.  Read types -ONT / -CLR only (the others leave refineSpaceDiag uninitialised, ChainRefine.h:68-71).
+ * Output (context-owned), indexed like the split arrays: the refined clusters after the call -- matches (base matches first, then every
+ * appended run in the reference's order), box, refineEffiency, refinespace flag.  RevBtwnCluster / tracerev are dead in the reference
+ * (their consumer is commented out, Map_lowacc.h:363-370) and are not produced.  Synchronous.                                    */
+typedef struct lra_btwn_opts { int32_t K, W, refineSpaceDist; float anchorstoosparse; int32_t match, mismatch, indel, max_freq; } lra_btwn_opts;
+typedef struct lra_btwn_result {
+  uint64_t n_frags, n_matches, n_problems, n_pairs; uint32_t n_rounds;
+  const uint64_t* d_match_off; const uint32_t* d_match_q; const uint32_t* d_match_t;
+  const uint32_t* d_box; const float* d_eff; const uint8_t* d_refinespace;
+} lra_btwn_result;
+int lra_refine_btwn_splitchain_batch(lra_ctx* ctx, const lra_chain_result* chains, const lra_split_result* split, const lra_refined_result* refined,
+                                     const uint64_t* d_read_off, const char* d_strands, uint64_t rc_base, const char* d_genome,
+                                     const uint64_t* h_chrom_pos, int n_chrom, const lra_btwn_opts* opts, lra_btwn_result* out);
+
 /* ---- a12: banded one-gap seed-extension DP ------------------------------------------
  * Replaces   int AffineOneGapAlign(string& qSeq, int qLen, string& tSeq, int tLen,
  *                                  int m, int mm, int indel, int k, Alignment& aln,

@@ -160,3 +160,32 @@ def fetch_refined(ctx: Context, res: RefinedResult):
     return {"match_off": ctx.to_host(res.d_match_off, nf + 1, np.uint64), "match_q": ctx.to_host(res.d_match_q, res.n_matches, np.uint32),
             "match_t": ctx.to_host(res.d_match_t, res.n_matches, np.uint32), "box": ctx.to_host(res.d_box, 4 * nf, np.uint32).reshape(-1, 4),
             "eff": ctx.to_host(res.d_eff, nf, np.float32), "status": ctx.to_host(res.d_status, nf, np.uint32)}
+
+
+class BtwnOpts(C.Structure):
+    _fields_ = [("K", C.c_int32), ("W", C.c_int32), ("refineSpaceDist", C.c_int32), ("anchorstoosparse", C.c_float), ("match", C.c_int32),
+                ("mismatch", C.c_int32), ("indel", C.c_int32), ("max_freq", C.c_int32)]
+
+
+class BtwnResult(C.Structure):
+    _fields_ = [("n_frags", C.c_uint64), ("n_matches", C.c_uint64), ("n_problems", C.c_uint64), ("n_pairs", C.c_uint64), ("n_rounds", C.c_uint32)] + [
+        (n, C.c_void_p) for n in ("d_match_off", "d_match_q", "d_match_t", "d_box", "d_eff", "d_refinespace")]
+
+
+def refine_btwn_splitchain_batch(ctx: Context, chains: ChainResult, split: SplitResult, refined: RefinedResult, read_off, strands, rc_base, genome,
+                                 chrom_pos, K=10, W=5, refineSpaceDist=10000, anchorstoosparse=0.01, match=4, mismatch=-1, indel=-2, max_freq=15):
+    """Refine_Btwnsplitchain (ChainRefine.h:579) for every chain; strands = reads forward then reverse complemented (device uint8)."""
+    cp = np.ascontiguousarray(chrom_pos, dtype=np.uint64)
+    o = BtwnOpts(int(K), int(W), int(refineSpaceDist), float(anchorstoosparse), int(match), int(mismatch), int(indel), int(max_freq))
+    res = BtwnResult()
+    ctx.check(ctx.lib.lra_refine_btwn_splitchain_batch(ctx.h, C.byref(chains), C.byref(split), C.byref(refined), ptr(read_off), ptr(strands),
+                                                       C.c_uint64(int(rc_base)), ptr(genome), C.c_void_p(cp.ctypes.data), len(cp) - 1, C.byref(o),
+                                                       C.byref(res)))
+    return res
+
+
+def fetch_btwn(ctx: Context, res: BtwnResult):
+    nf = res.n_frags
+    return {"match_off": ctx.to_host(res.d_match_off, nf + 1, np.uint64), "match_q": ctx.to_host(res.d_match_q, res.n_matches, np.uint32),
+            "match_t": ctx.to_host(res.d_match_t, res.n_matches, np.uint32), "box": ctx.to_host(res.d_box, 4 * nf, np.uint32).reshape(-1, 4),
+            "eff": ctx.to_host(res.d_eff, nf, np.float32), "refinespace": ctx.to_host(res.d_refinespace, nf, np.uint8)}

@@ -25,8 +25,8 @@ struct lra_ctx {
   void* aux = nullptr; size_t aux_bytes = 0;          // AffineOneGapAlign blocks of refine fallbacks
   void* out_buf = nullptr; size_t out_bytes = 0;
   uint64_t* scan_tmp = nullptr;
-  void* gbuf[32] = {};   // growable result / work buffers (lra_ensure)
-  size_t gbytes[32] = {};
+  void* gbuf[40] = {};   // growable result / work buffers (lra_ensure)
+  size_t gbytes[40] = {};
   // kernel timing
   const char* sort_tag = "sort"; const char* sort_fb_tag = "sort_fallback";   // timing names of the exact-sort kernels (sdp.hip retags them)
   bool timing = false;

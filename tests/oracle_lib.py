@@ -413,6 +413,35 @@ def refine_splitchain(q, t, length, cluster, cstrand, sptc, box, strand, chrom, 
         cap = int(n)
 
 
+class BtwnOpts(C.Structure):
+    _fields_ = [("K", C.c_int), ("W", C.c_int), ("refineSpaceDist", C.c_int), ("anchorstoosparse", C.c_float), ("match", C.c_int),
+                ("mismatch", C.c_int), ("indel", C.c_int), ("maxFreq", C.c_int)]
+
+
+def refine_btwn_splitchain(match_off, mq, mt, box, strand, chrom, link, fwd: bytes, rc: bytes, genome: bytes, chrom_pos, K=10, W=5,
+                           refineSpaceDist=10000, anchorstoosparse=0.01, match=4, mismatch=-1, indel=-2, max_freq=15):
+    """Refine_Btwnsplitchain (ChainRefine.h:579) on one chain's refined clusters -> dict(off, q, t, box, refinespace, n_rev) or None (UB)."""
+    L = lib()
+    mo = np.ascontiguousarray(match_off, np.int32); mq = np.ascontiguousarray(mq, np.uint32); mt = np.ascontiguousarray(mt, np.uint32)
+    bx = np.ascontiguousarray(box, np.uint32).reshape(-1); st = np.ascontiguousarray(strand, np.uint8); chv = np.ascontiguousarray(chrom, np.int32)
+    lk = np.ascontiguousarray(link, np.uint8); pos = np.ascontiguousarray(chrom_pos, np.uint64)
+    nsp = len(st)
+    o = BtwnOpts(K, W, refineSpaceDist, anchorstoosparse, match, mismatch, indel, max_freq)
+    cap = len(mq) + 4 * len(fwd) + 1024
+    oo = np.zeros(nsp + 1, np.int32); oq = np.zeros(cap, np.uint32); ot = np.zeros(cap, np.uint32); ob = np.zeros(4 * max(1, nsp), np.uint32)
+    orf = np.zeros(max(1, nsp), np.uint8); nrev = C.c_int(0)
+    if len(lk) == 0: lk = np.zeros(1, np.uint8)
+    L.oracle_refine_btwn_splitchain.restype = C.c_long
+    n = L.oracle_refine_btwn_splitchain(C.c_int(nsp), _p(mo, C.c_int), _p(mq, C.c_uint32), _p(mt, C.c_uint32), _p(bx, C.c_uint32), _p(st, C.c_uint8),
+                                        _p(chv, C.c_int), _p(lk, C.c_uint8), C.c_char_p(fwd), C.c_char_p(rc), C.c_uint32(len(fwd)), C.c_char_p(genome),
+                                        _p(pos, C.c_uint64), C.c_int(len(pos) - 1), C.byref(o), C.c_long(cap), _p(oo, C.c_int), _p(oq, C.c_uint32),
+                                        _p(ot, C.c_uint32), _p(ob, C.c_uint32), _p(orf, C.c_uint8), C.byref(nrev))
+    if n < 0:
+        return None
+    assert n <= cap
+    return dict(off=oo.copy(), q=oq[:n].copy(), t=ot[:n].copy(), box=ob.reshape(-1, 4)[:nsp].copy(), refinespace=orf[:nsp].copy(), n_rev=nrev.value)
+
+
 # ---- chain post-filters + SPLITChain (a9, low-accuracy path) ----------------------------------------------------------
 def split_chain(q, t, length, strand, cluster, link, chrom_pos, splitdist=50000, bypass=1):
     """One chain (trace-back order) -> dict(keep, link, splits=[dict(idx, link, type, strand, chrom, box, clusters)], split_link) or None (UB)."""

@@ -44,8 +44,7 @@ def test_oracle_refine_splitchain_sanity():
     assert np.all(np.abs(r2["t"].astype(np.int64) - r2["q"].astype(np.int64) - 1000) <= 50) and len(r2["q"]) <= len(r["q"])
 
 
-@pytest.mark.gpu
-def test_hip_refine_splitchain_oracle(ctx, oracle):
+def _front_end(ctx, oracle):
     import torch
     from lra_amd import synth, seed, cluster, chain, local
     dev = ctx.device
@@ -60,6 +59,18 @@ def test_hip_refine_splitchain_oracle(ctx, oracle):
         ra = synth.simulate_read(rng, genome[a:a + 5000], 4000, 0.08, (30, 35, 35), False)[0]
         rb = synth.simulate_read(rng, genome[b:b + 5000], 4000, 0.08, (30, 35, 35), bool(j & 1))[0]
         reads.append(np.concatenate([ra, rb]))
+    # an inversion inside a read (forward, reverse-complemented middle, forward) and a 6 kb deletion: neighbouring split chains with a
+    # space between them that Refine_Btwnsplitchain seeds (the INV / two-block and the plain branches)
+    for j in range(4):
+        a = int(rng.integers(20_000, 250_000))
+        A_ = synth.simulate_read(rng, genome[a:a + 4001], 4000, 0.06, (30, 35, 35), False)[0]
+        B_ = synth.simulate_read(rng, genome[a + 4000:a + 6501], 2500, 0.06, (30, 35, 35), True)[0]
+        C_ = synth.simulate_read(rng, genome[a + 6500:a + 10501], 4000, 0.06, (30, 35, 35), False)[0]
+        reads.append(np.concatenate([A_, B_, C_]))
+        b = int(rng.integers(320_000, 560_000))
+        D_ = synth.simulate_read(rng, genome[b:b + 4001], 4000, 0.06, (30, 35, 35), False)[0]
+        E_ = synth.simulate_read(rng, genome[b + 10_000:b + 14_001], 4000, 0.06, (30, 35, 35), False)[0]
+        reads.append(np.concatenate([D_, E_]) if j & 1 else synth.revcomp(np.concatenate([D_, E_])))
     # reads hugging the chromosome ends (the walk then runs into the last windows)
     reads.append(genome[599_000:600_000].copy()); reads.append(genome[299_000:299_900].copy()); reads.append(genome[0:1500].copy())
     reads.append(np.frombuffer(b"ACGT" * 5, dtype=np.uint8))
@@ -74,7 +85,7 @@ def test_hip_refine_splitchain_oracle(ctx, oracle):
                                   eres.d_e_len, batch.off, chain.sdp_opts())
     co = chain.fetch(ctx, chres)
     # the chain arrays are reused by later SDP calls: keep our own copies alive for the split / refine stages
-    spres = chain.split_chains_batch(ctx, chres, CH)
+    spres = chain.split_chains_batch(ctx, chres, CH, 5000, 1)                       # splitdist 5000: the 6 kb deletions split their chains
     so = chain.fetch_split(ctx, spres)
     fidx = ctx.to_host(spres.d_fidx, spres.n_frags, np.uint32)
     # local indexes: genome (two sequences), reads forward + reverse complement in one index
@@ -92,6 +103,15 @@ def test_hip_refine_splitchain_oracle(ctx, oracle):
     r_win, r_bnd, r_tup = rli.fetch()
     lens = [len(r) for r in reads]
     na = chres.num_aln
+    return dict(**{k: v for k, v in locals().items() if k not in ("ctx", "oracle")})
+
+
+@pytest.mark.gpu
+def test_hip_refine_splitchain_oracle(ctx, oracle):
+    from lra_amd import chain
+    P = _front_end(ctx, oracle)
+    chres, spres, batch, CH, rli, gso_d, gli, co, so, fidx, n, na, lens = (P[k] for k in ("chres", "spres", "batch", "CH", "rli", "gso_d", "gli", "co", "so", "fidx", "n", "na", "lens"))
+    r_win, r_bnd, r_tup, gso, g_bnd, g_tup = (P[k] for k in ("r_win", "r_bnd", "r_tup", "gso", "g_bnd", "g_tup"))
     for limit in (True, False):
         res = chain.refine_splitchain_batch(ctx, chres, spres, batch.off, CH, rli, gso_d, gli, window=100, smallK=10, K=K, limitrefine=limit, max_freq=15)
         out = chain.fetch_refined(ctx, res)
@@ -131,3 +151,50 @@ def test_hip_refine_splitchain_oracle(ctx, oracle):
                         assert out["eff"][x].view(np.uint32) == exp["eff"].view(np.uint32), (r, c, k)
                     n_checked += 1; n_rev += strand; n_matches += m1 - m0
         assert n_checked >= 40 and n_rev >= 10 and n_matches > 20000 and n_multi >= 4, (n_checked, n_rev, n_matches, n_multi)
+
+
+@pytest.mark.gpu
+def test_hip_refine_btwn_splitchain_oracle(ctx, oracle):
+    """a11 callers: Refine_Btwnsplitchain on the refined clusters the GPU produced, against the oracle chain by chain"""
+    from lra_amd import chain, synth
+    P = _front_end(ctx, oracle)
+    chres, spres, batch, CH, rli, gso_d, gli, co, so, n, na, reads, genome, both, tot, gdev = (P[k] for k in (
+        "chres", "spres", "batch", "CH", "rli", "gso_d", "gli", "co", "so", "n", "na", "reads", "genome", "both", "tot", "gdev"))
+    rres = chain.refine_splitchain_batch(ctx, chres, spres, batch.off, CH, rli, gso_d, gli, window=100, smallK=10, K=K, limitrefine=True, max_freq=15)
+    ro = chain.fetch_refined(ctx, rres)
+    gbytes = genome.tobytes()
+    for rsd, sparse in ((10000, 0.01), (10000, 0.2)):                    # the second threshold pushes results through the sparse (grouping) branch
+        bres = chain.refine_btwn_splitchain_batch(ctx, chres, spres, rres, batch.off, both, tot, gdev, CH, K=10, W=5, refineSpaceDist=rsd,
+                                                  anchorstoosparse=sparse, match=4, mismatch=-1, indel=-2, max_freq=15)
+        bo = chain.fetch_btwn(ctx, bres)
+        assert bres.n_problems > 40 and bres.n_rounds >= 4, (bres.n_problems, bres.n_rounds)
+        n_chains = n_grown = n_multi = n_added = 0
+        for r in range(n):
+            fwd = reads[r].tobytes(); rc = synth.revcomp(reads[r]).tobytes()
+            for c in range(int(co["n_chains"][r])):
+                s = r * na + c
+                if so["status"][s]:
+                    continue
+                b = int(co["chain_start"][s]); nsp = int(so["n_split"][s])
+                if nsp == 0:
+                    continue
+                offs = [0]; mq = []; mt = []
+                for k in range(nsp):
+                    m0, m1 = int(ro["match_off"][b + k]), int(ro["match_off"][b + k + 1])
+                    mq.extend(ro["match_q"][m0:m1].tolist()); mt.extend(ro["match_t"][m0:m1].tolist()); offs.append(len(mq))
+                exp = O.refine_btwn_splitchain(offs, mq, mt, ro["box"][b:b + nsp], so["sp_strand"][b:b + nsp], so["sp_chrom"][b:b + nsp],
+                                               so["split_link"][b:b + max(nsp - 1, 0)], fwd, rc, gbytes, CH, K=10, W=5, refineSpaceDist=rsd,
+                                               anchorstoosparse=sparse, match=4, mismatch=-1, indel=-2, max_freq=15)
+                assert exp is not None
+                for k in range(nsp):
+                    x = b + k
+                    m0, m1 = int(bo["match_off"][x]), int(bo["match_off"][x + 1])
+                    e0, e1 = int(exp["off"][k]), int(exp["off"][k + 1])
+                    assert m1 - m0 == e1 - e0, (r, c, k, m1 - m0, e1 - e0)
+                    assert np.array_equal(bo["match_q"][m0:m1], exp["q"][e0:e1]) and np.array_equal(bo["match_t"][m0:m1], exp["t"][e0:e1]), (r, c, k)
+                    assert np.array_equal(bo["box"][x], exp["box"][k]), (r, c, k)
+                    assert bo["refinespace"][x] == exp["refinespace"][k], (r, c, k)
+                    grown = (m1 - m0) - (offs[k + 1] - offs[k])
+                    n_grown += grown > 0; n_added += grown
+                n_chains += 1; n_multi += nsp > 1
+        assert n_chains >= 40 and n_multi >= 8 and n_grown >= 20 and n_added > 130, (n_chains, n_multi, n_grown, n_added)
