@@ -84,13 +84,19 @@ __global__ void __launch_bounds__(64) stats_kernel(StatArgs A) {
       if (type == curType) curLen += len;
       else { close_run(); curType = type; curLen = len; }
     };
-    auto pairs = [&](long q, long t, long len) {                         // aligned pairs: '=' / 'X' by base code
+    // the first 64 columns of the next block are fetched while the current block is worked on (blocks are ~16 bp on noisy reads, so
+    // without this every block costs a full dependent-load latency)
+    auto pairs = [&](long q, long t, long len, bool usePre, unsigned long long pm) {   // aligned pairs: '=' / 'X' by base code
       for (long off = 0; off < len; off += 64) {
         const int cnt = (int)min(64L, len - off);
-        bool x = false;
-        if (lane < cnt) x = code2(R[q + off + lane]) != code2(G[t + off + lane]);
         const unsigned long long valid = cnt == 64 ? ~0ULL : ((1ULL << cnt) - 1);
-        const unsigned long long mx = __ballot(x) & valid;
+        unsigned long long mx;
+        if (off == 0 && usePre) mx = pm & valid;
+        else {
+          bool x = false;
+          if (lane < cnt) x = code2(R[q + off + lane]) != code2(G[t + off + lane]);
+          mx = __ballot(x) & valid;
+        }
         // run starts inside the chunk: column c > 0 whose kind differs from column c-1
         const unsigned long long starts = ((mx ^ (mx << 1)) & valid) & ~1ULL;
         if (!starts) { feed((int)(mx & 1ULL), cnt); continue; }          // the whole chunk is one kind
@@ -125,19 +131,45 @@ __global__ void __launch_bounds__(64) stats_kernel(StatArgs A) {
     };
     if (nb > 0) {
       long q = B[0], t = B[1];
+      // block table: 64 blocks per load, handed out by shuffles.  Each lane also compares the first 64 columns of its block, so the
+      // per-block loop below touches no memory for blocks of up to 64 columns (a noisy read's blocks are ~16 bp: one dependent HBM
+      // round trip per block otherwise)
+      int tq = 0, tt = 0, tl = 0; unsigned long long tm = 0; long tbase = -64;
+      auto blk = [&](long b, int& bq, int& bt, int& bl, unsigned long long& bm) {
+        if (b >= tbase + 64 || b < tbase) {
+          tbase = b;
+          const long i = b + lane;
+          tm = 0;
+          if (i < nb) {
+            tq = B[3 * i]; tt = B[3 * i + 1]; tl = B[3 * i + 2];
+            const int c1 = min(tl, 64);
+            const unsigned char* rp = R + tq; const unsigned char* gp = G + tt;
+#pragma unroll 8
+            for (int c = 0; c < c1; c++) tm |= (unsigned long long)(code2(rp[c]) != code2(gp[c])) << c;
+          }
+        }
+        const int k = (int)(b - tbase);
+        bq = __shfl(tq, k); bt = __shfl(tt, k); bl = __shfl(tl, k); bm = __shfl(tm, k);
+      };
+      int cq, ct, cl; unsigned long long cm;
+      blk(0, cq, ct, cl, cm);
       for (long b = 0; b < nb; b++) {                                    // :261-330
-        const long L = B[3 * b + 2];
-        pairs(q, t, L);
+        const long L = cl;
+        int nq = 0, nt = 0, nl = 0; unsigned long long nm2 = 0;
+        const bool hasNext = b + 1 < nb;
+        if (hasNext) blk(b + 1, nq, nt, nl, nm2);
+        pairs(q, t, L, q == cq && t == ct, cm);
         q += L; t += L;
-        if (b == nb - 1) continue;
-        long qg = (long)B[3 * (b + 1)] - B[3 * b] - L, tg = (long)B[3 * (b + 1) + 1] - B[3 * b + 1] - L;
+        if (!hasNext) continue;
+        long qg = (long)nq - cq - L, tg = (long)nt - ct - L;
         if (qg > 0 || tg > 0) {
           const long common = qg > tg ? tg : qg;
           tg -= common; qg -= common;
           feed(2, qg); q += max(qg, 0L);
           feed(3, tg); t += max(tg, 0L);
-          if (common > 0) { pairs(q, t, common); q += common; t += common; }
+          if (common > 0) { pairs(q, t, common, false, 0); q += common; t += common; }
         }
+        cq = nq; ct = nt; cl = nl; cm = nm2;
       }
       close_run();
     }
