@@ -401,6 +401,32 @@ int lra_refine_btwn_splitchain_batch(lra_ctx* ctx, const lra_chain_result* chain
                                      const uint64_t* d_read_off, const char* d_strands, uint64_t rc_base, const char* d_genome,
                                      const uint64_t* h_chrom_pos, int n_chrom, const lra_btwn_opts* opts, lra_btwn_result* out);
 
+/* What MapRead_lowacc does with the refined clusters of every chain before the second sparse DP (Map_lowacc.h:440-476):
+ *   MergeChain(Refined_Clusters, mergeinfo, merge_spcluster, spcluster)                         ChainRefine.h:767-802
+ *   LinearExtend(&Refined_Clusters[cI]->matches, extend_clusters[r].matches, .matchesLengths, smallOpts, genome, read, chromIndex,
+ *                st, 0, smallOpts.globalK) for every member of a merged cluster                     LinearExtend.h:658-716
+ *   DecideCoordinates(extend_clusters[r], st, chromIndex, anchorfreq)                             LinearExtend.h:105-127
+ *   TrimOverlappedAnchors(extend_clusters, 0)                                                     LinearExtend.h:574-649
+ * refined = the lra_refine_btwn_splitchain_batch result; d_seq = the reads (forward), d_genome = all chromosomes; K = smallOpts.globalK.
+ * Output (context-owned): merged cluster g of chain slot s is d_slot_group_off[s] + g; it covers the refined clusters (dense index
+ * d_cluster_base[s] + k for split chain k) d_group_first[g] .. d_group_last[g]; its anchors are (d_q, d_t chromosome-relative, d_len)
+ * [d_anchor_off[g], + d_count[g]); d_box[4g..] / d_strand / d_chrom as DecideCoordinates leaves them.
+ * The second sparse DP (Map_lowacc.h:535) is lra_sparse_dp_batch in mode LRA_SDP_SINGLE_CLUSTER with n_reads = n_groups,
+ * d_cluster_off = d_iota, d_c_start = d_anchor_off, d_c_count = d_count, d_c_strand = d_strand, d_q / d_t / d_len.  Synchronous.   */
+typedef struct lra_merge_result {
+  uint64_t n_slots, n_groups, n_anchors;
+  const uint64_t* d_slot_group_off;   /* [n_slots+1] */
+  const uint64_t* d_cluster_base;     /* [n_slots+1] */
+  const uint32_t* d_group_slot; const uint32_t* d_group_first; const uint32_t* d_group_last;   /* [n_groups] */
+  const uint64_t* d_anchor_off;       /* [n_groups+1] */
+  const uint32_t* d_count;            /* [n_groups] */
+  const uint32_t* d_q; const uint32_t* d_t; const int32_t* d_len;   /* [n_anchors] */
+  const uint32_t* d_box; const int32_t* d_strand; const int32_t* d_chrom;   /* [4*n_groups], [n_groups] */
+  const uint64_t* d_iota;             /* [n_groups+1] 0, 1, 2, ... */
+} lra_merge_result;
+int lra_merge_extend_batch(lra_ctx* ctx, const lra_chain_result* chains, const lra_split_result* split, const lra_btwn_result* refined, const char* d_seq,
+                           const uint64_t* d_read_off, const char* d_genome, const uint64_t* h_chrom_pos, int n_chrom, int K, lra_merge_result* out);
+
 /* ---- a12: banded one-gap seed-extension DP ------------------------------------------
  * Replaces   int AffineOneGapAlign(string& qSeq, int qLen, string& tSeq, int tLen,
  *                                  int m, int mm, int indel, int k, Alignment& aln,

@@ -50,6 +50,7 @@ SYMBOLS = {
     "lra_split_clusters_batch": (C.c_int, [_vp, C.c_int, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, C.c_int, C.c_int, _vp]),
     "lra_refine_splitchain_batch": (C.c_int, [_vp, _vp, _vp, _vp, _vp, C.c_int, _vp, C.c_uint64, _vp, _vp, _vp, _vp, _vp]),
     "lra_refine_btwn_splitchain_batch": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, C.c_uint64, _vp, _vp, C.c_int, _vp, _vp]),
+    "lra_merge_extend_batch": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, C.c_int, C.c_int, _vp]),
     "lra_filter_chains_batch": (C.c_int, [_vp, C.c_uint64, _vp, C.c_uint64, _vp, _vp, _vp, _vp, _vp, _vp, C.c_int, _vp]),
     "lra_calculate_statistics_batch": (C.c_int, [_vp, C.c_int, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, C.c_int, _vp]),
     "lra_local_index_batch": (C.c_int, [_vp, C.c_int, _vp, _vp, C.c_int, C.c_int, C.c_int, C.c_int, _vp]),

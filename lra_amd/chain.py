@@ -189,3 +189,28 @@ def fetch_btwn(ctx: Context, res: BtwnResult):
     return {"match_off": ctx.to_host(res.d_match_off, nf + 1, np.uint64), "match_q": ctx.to_host(res.d_match_q, res.n_matches, np.uint32),
             "match_t": ctx.to_host(res.d_match_t, res.n_matches, np.uint32), "box": ctx.to_host(res.d_box, 4 * nf, np.uint32).reshape(-1, 4),
             "eff": ctx.to_host(res.d_eff, nf, np.float32), "refinespace": ctx.to_host(res.d_refinespace, nf, np.uint8)}
+
+
+class MergeResult(C.Structure):
+    _fields_ = [("n_slots", C.c_uint64), ("n_groups", C.c_uint64), ("n_anchors", C.c_uint64)] + [(n, C.c_void_p) for n in (
+        "d_slot_group_off", "d_cluster_base", "d_group_slot", "d_group_first", "d_group_last", "d_anchor_off", "d_count", "d_q", "d_t", "d_len", "d_box",
+        "d_strand", "d_chrom", "d_iota")]
+
+
+def merge_extend_batch(ctx: Context, chains: ChainResult, split: SplitResult, refined: BtwnResult, seq, read_off, genome, chrom_pos, K=10):
+    """MergeChain + LinearExtend + DecideCoordinates + TrimOverlappedAnchors (Map_lowacc.h:440-476) for every chain."""
+    cp = np.ascontiguousarray(chrom_pos, dtype=np.uint64)
+    res = MergeResult()
+    ctx.check(ctx.lib.lra_merge_extend_batch(ctx.h, C.byref(chains), C.byref(split), C.byref(refined), ptr(seq), ptr(read_off), ptr(genome),
+                                             C.c_void_p(cp.ctypes.data), len(cp) - 1, int(K), C.byref(res)))
+    return res
+
+
+def fetch_merge(ctx: Context, res: MergeResult):
+    ns, ng, na = res.n_slots, res.n_groups, res.n_anchors
+    return {"slot_group_off": ctx.to_host(res.d_slot_group_off, ns + 1, np.uint64), "cluster_base": ctx.to_host(res.d_cluster_base, ns + 1, np.uint64),
+            "group_first": ctx.to_host(res.d_group_first, ng, np.uint32), "group_last": ctx.to_host(res.d_group_last, ng, np.uint32),
+            "anchor_off": ctx.to_host(res.d_anchor_off, ng + 1, np.uint64), "count": ctx.to_host(res.d_count, ng, np.uint32),
+            "q": ctx.to_host(res.d_q, na, np.uint32), "t": ctx.to_host(res.d_t, na, np.uint32), "len": ctx.to_host(res.d_len, na, np.int32),
+            "box": ctx.to_host(res.d_box, 4 * ng, np.uint32).reshape(-1, 4), "strand": ctx.to_host(res.d_strand, ng, np.int32),
+            "chrom": ctx.to_host(res.d_chrom, ng, np.int32)}

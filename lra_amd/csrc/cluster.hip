@@ -445,6 +445,22 @@ __global__ void __launch_bounds__(64) linear_extend_kernel(ExtArgs A) {
 
 }  // namespace
 
+// the pair-version LinearExtend on caller-supplied cluster arrays (merge_extend.hip: the refined clusters before the second sparse DP)
+int lra_launch_linear_extend(lra_ctx* ctx, uint64_t n_clusters, int K, const uint64_t* c_start, const uint64_t* c_end, const int* c_strand, const int* c_chrom,
+                             int* c_read, const uint32_t* cl_q, const uint32_t* cl_t, const uint64_t* d_chrom_pos, const unsigned char* genome,
+                             const unsigned char* seq, const uint64_t* read_off, uint32_t* e_q, uint32_t* e_t, int* e_len, uint32_t* e_count, uint32_t* box) {
+  if (n_clusters == 0) return LRA_OK;
+  ExtArgs A;
+  memset(&A, 0, sizeof A);
+  A.n_clusters = n_clusters; A.K = K; A.c_start = c_start; A.c_end = c_end; A.c_strand = c_strand; A.c_chrom = c_chrom; A.c_read = c_read;
+  A.cl_q = cl_q; A.cl_t = cl_t; A.chrom_pos = d_chrom_pos; A.genome = genome; A.seq = seq; A.read_off = read_off;
+  A.e_q = e_q; A.e_t = e_t; A.e_len = e_len; A.e_count = e_count; A.box = box;
+  lra_time_begin(ctx, "linear_extend");
+  hipLaunchKernelGGL(linear_extend_kernel, dim3((unsigned)std::min<uint64_t>(n_clusters, (uint64_t)ctx->num_cu * 32)), dim3(64), 0, ctx->stream, A);
+  lra_time_end(ctx);
+  return LRA_OK;
+}
+
 extern "C" int lra_linear_extend_batch(lra_ctx* ctx, int K, const char* d_seq, const uint64_t* d_read_off, lra_extend_result* out) {
   if (!ctx || !out || K < 1) return LRA_ERR_INVALID;
   lra_cluster_state* cs = ctx->clus;

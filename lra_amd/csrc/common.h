@@ -50,6 +50,11 @@ void* lra_ensure(lra_ctx* ctx, int idx, size_t bytes);
 int lra_sort_mostly_unique_batch(lra_ctx* ctx, int n_lists, const uint64_t* d_off, uint64_t total, uint64_t* d_key, uint32_t* d_pos,
                                  uint64_t* tmp_key, uint32_t* tmp_pos, int end_bit);
 
+// cluster.hip: LinearExtend (pair version, LinearExtend.h:658) + DecideCoordinates box on caller-supplied clusters of diagonal-sorted matches
+int lra_launch_linear_extend(lra_ctx* ctx, uint64_t n_clusters, int K, const uint64_t* c_start, const uint64_t* c_end, const int* c_strand, const int* c_chrom,
+                             int* c_read, const uint32_t* cl_q, const uint32_t* cl_t, const uint64_t* d_chrom_pos, const unsigned char* genome,
+                             const unsigned char* seq, const uint64_t* read_off, uint32_t* e_q, uint32_t* e_t, int* e_len, uint32_t* e_count, uint32_t* box);
+
 #define LRA_HIP_CHECK(ctx, call)                                                         \
   do {                                                                                   \
     hipError_t e__ = (call);                                                             \

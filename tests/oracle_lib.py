@@ -442,6 +442,27 @@ def refine_btwn_splitchain(match_off, mq, mt, box, strand, chrom, link, fwd: byt
     return dict(off=oo.copy(), q=oq[:n].copy(), t=ot[:n].copy(), box=ob.reshape(-1, 4)[:nsp].copy(), refinespace=orf[:nsp].copy(), n_rev=nrev.value)
 
 
+def merge_extend(match_off, mq, mt, box, strand, chrom, read: bytes, genome: bytes, chrom_pos, K=10):
+    """MergeChain + LinearExtend + DecideCoordinates + TrimOverlappedAnchors on one chain's refined clusters ->
+    dict(member, anchor_off, q, t, len, box, strand, chrom)."""
+    L = lib()
+    mo = np.ascontiguousarray(match_off, np.int32); mq = np.ascontiguousarray(mq, np.uint32); mt = np.ascontiguousarray(mt, np.uint32)
+    bx = np.ascontiguousarray(box, np.uint32).reshape(-1); st = np.ascontiguousarray(strand, np.uint8); chv = np.ascontiguousarray(chrom, np.int32)
+    pos = np.ascontiguousarray(chrom_pos, np.uint64)
+    nsp = len(st)
+    cap = len(mq) + 8
+    gm = np.zeros(nsp + 2, np.int32); ao = np.zeros(nsp + 2, np.int32); aq = np.zeros(cap, np.uint32); at = np.zeros(cap, np.uint32); al = np.zeros(cap, np.int32)
+    gb = np.zeros(4 * (nsp + 1), np.uint32); gs = np.zeros(nsp + 1, np.uint8); gc = np.zeros(nsp + 1, np.int32)
+    L.oracle_merge_extend.restype = C.c_int
+    ng = L.oracle_merge_extend(C.c_int(nsp), _p(mo, C.c_int), _p(mq, C.c_uint32), _p(mt, C.c_uint32), _p(bx, C.c_uint32), _p(st, C.c_uint8), _p(chv, C.c_int),
+                               C.c_char_p(read), C.c_uint32(len(read)), C.c_char_p(genome), _p(pos, C.c_uint64), C.c_int(K), C.c_long(cap), _p(gm, C.c_int),
+                               _p(ao, C.c_int), _p(aq, C.c_uint32), _p(at, C.c_uint32), _p(al, C.c_int), _p(gb, C.c_uint32), _p(gs, C.c_uint8), _p(gc, C.c_int))
+    assert ng >= 0
+    n = int(ao[ng])
+    return dict(member=gm[:ng + 1].copy(), anchor_off=ao[:ng + 1].copy(), q=aq[:n].copy(), t=at[:n].copy(), len=al[:n].copy(),
+                box=gb.reshape(-1, 4)[:ng].copy(), strand=gs[:ng].copy(), chrom=gc[:ng].copy())
+
+
 # ---- chain post-filters + SPLITChain (a9, low-accuracy path) ----------------------------------------------------------
 def split_chain(q, t, length, strand, cluster, link, chrom_pos, splitdist=50000, bypass=1):
     """One chain (trace-back order) -> dict(keep, link, splits=[dict(idx, link, type, strand, chrom, box, clusters)], split_link) or None (UB)."""

@@ -198,3 +198,69 @@ def test_hip_refine_btwn_splitchain_oracle(ctx, oracle):
                     n_grown += grown > 0; n_added += grown
                 n_chains += 1; n_multi += nsp > 1
         assert n_chains >= 40 and n_multi >= 8 and n_grown >= 20 and n_added > 130, (n_chains, n_multi, n_grown, n_added)
+
+
+@pytest.mark.gpu
+def test_hip_merge_extend_and_second_sdp_oracle(ctx, oracle):
+    """MergeChain + LinearExtend + DecideCoordinates + TrimOverlappedAnchors on the GPU's refined clusters, then the second sparse DP
+    (single-cluster mode) straight from the device arrays, both against the oracle"""
+    from lra_amd import chain
+    P = _front_end(ctx, oracle)
+    chres, spres, batch, CH, rli, gso_d, gli, co, so, n, na, reads, genome, both, tot, gdev = (P[k] for k in (
+        "chres", "spres", "batch", "CH", "rli", "gso_d", "gli", "co", "so", "n", "na", "reads", "genome", "both", "tot", "gdev"))
+    rres = chain.refine_splitchain_batch(ctx, chres, spres, batch.off, CH, rli, gso_d, gli, window=100, smallK=10, K=K, limitrefine=True, max_freq=15)
+    bres = chain.refine_btwn_splitchain_batch(ctx, chres, spres, rres, batch.off, both, tot, gdev, CH, K=10, W=5)
+    bo = chain.fetch_btwn(ctx, bres)
+    mres = chain.merge_extend_batch(ctx, chres, spres, bres, batch.seq, batch.off, gdev, CH, K=10)
+    mo = chain.fetch_merge(ctx, mres)
+    gbytes = genome.tobytes()
+    n_groups = n_merged = n_trim = n_anchors = 0
+    exp_groups = {}
+    for r in range(n):
+        for c in range(int(co["n_chains"][r])):
+            s = r * na + c
+            g0, g1 = int(mo["slot_group_off"][s]), int(mo["slot_group_off"][s + 1])
+            if so["status"][s] or int(so["n_split"][s]) == 0:
+                assert g1 == g0
+                continue
+            b = int(co["chain_start"][s]); nsp = int(so["n_split"][s])
+            offs = [0]; mq = []; mt = []
+            for k in range(nsp):
+                m0, m1 = int(bo["match_off"][b + k]), int(bo["match_off"][b + k + 1])
+                mq.extend(bo["match_q"][m0:m1].tolist()); mt.extend(bo["match_t"][m0:m1].tolist()); offs.append(len(mq))
+            exp = O.merge_extend(offs, mq, mt, bo["box"][b:b + nsp], so["sp_strand"][b:b + nsp], so["sp_chrom"][b:b + nsp], reads[r].tobytes(), gbytes, CH, K=10)
+            ng = len(exp["member"]) - 1
+            assert g1 - g0 == ng, (r, c, g1 - g0, ng)
+            cb = int(mo["cluster_base"][s])
+            for g in range(ng):
+                G = g0 + g
+                assert int(mo["group_first"][G]) - cb == (exp["member"][g] if g else 0) and int(mo["group_last"][G]) - cb == exp["member"][g + 1] - 1
+                a0, cnt = int(mo["anchor_off"][G]), int(mo["count"][G])
+                e0, e1 = int(exp["anchor_off"][g]), int(exp["anchor_off"][g + 1])
+                assert cnt == e1 - e0, (r, c, g)
+                assert np.array_equal(mo["q"][a0:a0 + cnt], exp["q"][e0:e1]) and np.array_equal(mo["t"][a0:a0 + cnt], exp["t"][e0:e1]), (r, c, g)
+                assert np.array_equal(mo["len"][a0:a0 + cnt], exp["len"][e0:e1]), (r, c, g)
+                assert np.array_equal(mo["box"][G], exp["box"][g]) and mo["strand"][G] == exp["strand"][g] and mo["chrom"][G] == exp["chrom"][g], (r, c, g)
+                exp_groups[G] = (exp["q"][e0:e1], exp["t"][e0:e1], exp["len"][e0:e1], int(exp["strand"][g]))
+                n_groups += 1; n_merged += int(exp["member"][g + 1] - (exp["member"][g] if g else 0) > 1); n_anchors += cnt
+    assert n_groups >= 40 and n_anchors > 5000, (n_groups, n_merged, n_anchors)
+    # the second sparse DP (Map_lowacc.h:535) on the merged clusters, fed from the device arrays
+    opts = chain.sdp_opts(mode=1, rate=1.0)
+    cres2 = chain.sparse_dp_batch(ctx, int(mres.n_groups), mres.d_iota, mres.d_anchor_off, mres.d_count, mres.d_strand, mres.d_q, mres.d_t, mres.d_len,
+                                  mres.d_iota, opts)
+    c2 = chain.fetch(ctx, cres2)
+    n2 = 0
+    for G, (q, t, ln, st) in exp_groups.items():
+        if len(q) == 0:
+            continue
+        exp = O.sdp_chain([0, len(q)], [st], q, t, ln, O.sdp_opts(1000, mode=1, rate=1.0))
+        if exp["status"] < 0:
+            assert c2["status"][G] != 0
+            continue
+        assert c2["status"][G] == 0
+        f0 = int(c2["frag_off"][G])
+        assert np.array_equal(c2["frag_val"][f0:f0 + len(q)].view(np.uint32), exp["val"].view(np.uint32)), G
+        a = int(c2["chain_start"][G * cres2.num_aln]); m = int(c2["chain_len"][G * cres2.num_aln])
+        assert m == len(exp["chains"][0]["frags"]) and np.array_equal(c2["chain_anchor"][a:a + m], exp["chains"][0]["frags"]), G
+        n2 += 1
+    assert n2 >= 40
