@@ -12,7 +12,9 @@ One "step" = one pass of the GPU-resident hot-path stages over one batch of read
   a12    AffineOneGapAlign on the between-anchor gaps of every read
   a14    IndelRefineAlignment over every read's block list
   a16    CalculateStatistics (CIGAR runs, NM/NX/ND/NI/TD/TI counters, NV) on the refined blocks
-The stages between a10 and a12 (a11 callers, the second sparse DP's inputs, a13: local refinement glue) are
+  a11    Refine_Btwnsplitchain (RefineSpace on the spaces between / beyond the refined clusters), then MergeChain, the second
+         LinearExtend + TrimOverlappedAnchors and the second sparse DP on every merged cluster (Map_lowacc.h:362-540)
+The stage between the second sparse DP and a12/a14 (a13: LocalRefineAlignment's chain walk) is
 NOT built yet, so the a12/a14 inputs are derived from the simulator's true alignment (anchors =
 true gapless blocks >= 12 bp; the gaps between them go to a12; a perturbed block list goes to
 a14).  `config.stages` says so; the number is the throughput of the stages listed, not of a
@@ -137,6 +139,7 @@ def main():
     from lra_amd.context import Context
     from lra_amd import seed, align, refine, parallel, cluster, chain
     sdp_opts = chain.sdp_opts()
+    sdp2_opts = chain.sdp_opts(mode=1, rate=2.0)          # SparseDP :2287 with opts.second_anchorbonus (Options.h:221)
     import ctypes as C
     libm = C.CDLL("libm.so.6"); libm.logf.restype = C.c_float; libm.logf.argtypes = [C.c_float]
     lut = np.array([libm.logf(float(i)) for i in range(1, 10002, 5)], dtype=np.float32)      # LogLookUpTable.h:9-15
@@ -186,6 +189,14 @@ def main():
         ctx.check(ctx.lib.lra_create_rc_batch(ctx.h, rbatch.n, C.c_void_p(rbatch.seq.data_ptr()), C.c_void_p(rbatch.off.data_ptr()), C.c_void_p(both.data_ptr() + tot)))
         rli = local.LocalIndex(ctx, both, off2, 10, 5, 256, 15)
         rres = chain.refine_splitchain_batch(ctx, chres, spres, rbatch.off, [0, G], rli, gso, gli, window=100, smallK=10, K=args.k, limitrefine=True, max_freq=15)
+        # a11 callers, a9 MergeChain, a7 second pass, a8 second sparse DP + its filters (Map_lowacc.h:362-540)
+        bres = chain.refine_btwn_splitchain_batch(ctx, chres, spres, rres, rbatch.off, both, tot, gdev, [0, G], K=10, W=5, refineSpaceDist=30000,
+                                                  anchorstoosparse=0.005, match=4, mismatch=-1, indel=-2, max_freq=15)
+        mres = chain.merge_extend_batch(ctx, chres, spres, bres, rbatch.seq, rbatch.off, gdev, [0, G], K=10)
+        ch2 = chain.sparse_dp_batch(ctx, int(mres.n_groups), mres.d_iota, mres.d_anchor_off, mres.d_count, mres.d_strand, mres.d_q, mres.d_t, mres.d_len,
+                                    mres.d_iota, sdp2_opts)
+        stats.update(n_btwn_problems=bres.n_problems, n_btwn_rounds=bres.n_rounds, n_refined_after_btwn=bres.n_matches, n_merged_clusters=mres.n_groups,
+                     n_sdp2_anchors=mres.n_anchors, n_sdp2_entries=ch2.n_subproblem_entries)
         if "n_local_task_words" not in stats and rres.n_tasks:
             t4 = [ctx.to_tensor(p_, rres.n_tasks, torch.int64) for p_ in (rres.d_task_q_lo, rres.d_task_q_hi, rres.d_task_t_lo, rres.d_task_t_hi)]
             stats["n_local_task_words"] = int((t4[1] - t4[0]).sum() + (t4[3] - t4[2]).sum())
@@ -230,7 +241,7 @@ def main():
 
     kernels = ["sketch_count", "sketch_serial", "sketch_emit", "sort", "sort_fallback", "index_bounds", "compare", "strand",
                "aog_lds_tiny", "aog_lds_small", "aog_lds_large", "aog_hbm", "ir_segment", "ir_band", "ir_fill", "ir_trace", "ir_gather", "clean_sort", "clean", "linear_extend", "stats", "stats_cigar", "create_rc", "local_sketch", "local_sort_filter", "local_compare",
-               "rsc_tasks", "rsc_filter", "chain_split", "sdp_points", "sdp_sort", "sdp_sort_fallback", "sdp_build_count", "sdp_build", "sdp_process", "sdp_trace"]
+               "rsc_tasks", "rsc_filter", "refine_space", "refine_space_long", "btwn_plan", "btwn_apply", "merge_extend", "chain_split", "sdp_points", "sdp_sort", "sdp_sort_fallback", "sdp_build_count", "sdp_build", "sdp_process", "sdp_trace"]
     ktimes = {k: ctx.timing_get(k) for k in kernels}
     ctx.timing(False)
     if rank == 0:
@@ -242,6 +253,8 @@ def main():
         launches_per_step = max(dom_n, 1) / args.steps
         # algorithmic bytes PER STEP of the dominant kernel, all its launches together (DESIGN.md section 3 gives the per-unit figures)
         L = total_bases
+        sdp_entries = stats.get("n_sdp_entries", 0) + stats.get("n_sdp2_entries", 0)
+        sdp_points = stats.get("n_sdp_points", 0) + 2 * stats.get("n_sdp2_anchors", 0)
         alg_step = {
             "ir_fill": 1 * stats["n_cells"] + 16 * stats["n_rows"] + 1 * stats["n_rows"],        # 1 B arrow/cell + row windows + both sequences
             "ir_band": 16 * stats["n_rows"] + 12 * stats["n_blocks"],
@@ -263,10 +276,11 @@ def main():
             "ir_segment": 12 * stats["n_blocks"],
             # a8: 44 B per sub-problem entry (Di/Ei + Db/Eb + value 16, back pointer 4, stack 8, Block 16) + the 256 B visit row and 13 B
             # of coordinates per point
-            "sdp_process": 44 * stats.get("n_sdp_entries", 0) + 269 * stats.get("n_sdp_points", 0),
-            "sdp_build": 20 * stats.get("n_sdp_entries", 0) + 269 * stats.get("n_sdp_points", 0),
-            "sdp_build_count": 13 * stats.get("n_sdp_points", 0),
-            "sdp_sort": 4 * 2 * 12 * stats.get("n_sdp_points", 0),
+            # (both sparse DPs of the step: SDP#A and the per-merged-cluster one, whose anchors give two points each)
+            "sdp_process": 44 * sdp_entries + 269 * sdp_points,
+            "sdp_build": 20 * sdp_entries + 269 * sdp_points,
+            "sdp_build_count": 13 * sdp_points,
+            "sdp_sort": 4 * 2 * 12 * sdp_points,
         }.get(dom, 0)
         alg = alg_step / launches_per_step
         achieved = alg / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
@@ -279,7 +293,7 @@ def main():
         except (OSError, ValueError, KeyError):
             pass
         out = {
-            "metric": "aligned Gbp/s (hot-path stages a1-a5, a7, a8 SDP#A, a9 split, a10 Refine_splitchain, a12, a14, a16), 30 kb ONT-like reads", "value": gbps, "unit": "Gbp/s",
+            "metric": "aligned Gbp/s (hot-path stages a1-a5, a7, a8 SDP#A, a9 split + MergeChain, a10 Refine_splitchain, a11 Refine_Btwnsplitchain, a7/a8 second pass, a12, a14, a16), 30 kb ONT-like reads", "value": gbps, "unit": "Gbp/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_step, "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "int32", "data": "synthetic",
             "reads_per_s": nreads * args.steps / dt,
@@ -287,8 +301,9 @@ def main():
                                    "error 30:35:35 (BASELINE configs[2] -ONT read profile; full GRCh38 not generated in round 1)"
                                    % (args.genome_mb, args.reads, args.read_len, args.err * 100),
                        "preset": "-ONT (k=%d w=%d maxFreq=%d refineBand=%d match/mismatch/indel=4/-1/-2)" % (args.k, args.w, args.max_freq, args.refine_band),
-                       "stages": "a1-a5,a7,a8(SDP#A),a9(chain split),a10(Refine_splitchain) chained on the reads; a12 on between-anchor gaps and a14 on block lists derived from "
-                                 "the simulator's truth, a16 on a14's output (a11 callers, a13 refinement glue not built yet: NOT a whole `lra align`)",
+                       "stages": "a1-a5,a7,a8(SDP#A),a9(chain split),a10(Refine_splitchain),a11(Refine_Btwnsplitchain),a9(MergeChain),a7(second LinearExtend+Trim),a8(second "
+                                 "SDP) chained on the reads = MapRead_lowacc up to Map_lowacc.h:540; a12 on between-anchor gaps and a14 on block lists derived "
+                                 "from the simulator's truth, a16 on a14's output (a13 LocalRefineAlignment glue not built yet: NOT a whole `lra align`)",
                        "parallelism": "reads sharded by ordinal, 1 process/GPU; RCCL gather of block records to rank 0",
                        "per_step": {k: int(v) for k, v in stats.items() if not k.startswith("_")}},
             "kernel_ms_per_step": {k: round(v[0] / args.steps, 4) for k, v in ktimes.items() if v[1]},

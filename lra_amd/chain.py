@@ -12,8 +12,8 @@ class SdpOpts(C.Structure):
                 ("globalK", C.c_int32)]
 
 
-# -ONT preset (lra.cpp:388-420; alnthres: Options.h:198)
-ONT = dict(rate=20.0, NumAln=2, alnthres=0.7, gapopen=7.0, gapextend=10.0, gaproot=1.5, gapCeiling1=1500, gapCeiling2=3000, mode=0, globalK=17)
+# -ONT preset (lra.cpp:388-420; alnthres 0.65: lra.cpp:429)
+ONT = dict(rate=20.0, NumAln=2, alnthres=0.65, gapopen=7.0, gapextend=10.0, gaproot=1.5, gapCeiling1=1500, gapCeiling2=3000, mode=0, globalK=17)
 
 
 def sdp_opts(**kw):

@@ -255,7 +255,7 @@ class SdpOpts(C.Structure):
 
 
 # -ONT preset (lra.cpp:388-420) + Options.h defaults
-SDP_ONT = dict(rate=20.0, NumAln=2, alnthres=0.7, gapopen=7.0, gapextend=10.0, gaproot=1.5, gapCeiling1=1500, gapCeiling2=3000, mode=0,
+SDP_ONT = dict(rate=20.0, NumAln=2, alnthres=0.65, gapopen=7.0, gapextend=10.0, gaproot=1.5, gapCeiling1=1500, gapCeiling2=3000, mode=0,
                globalK=17)
 
 
