@@ -551,11 +551,31 @@ typedef struct lra_aln_record {
   int32_t nm, nmm, nins, ndel, tdel, tins, nSmallDel, nMedDel, nLargeDel, nSmallIns, nMedIns, nLargeIns;
   float value; int32_t order, NumOfAnchors0, NumOfAnchors1, runtime;
   int32_t n_blocks; uint32_t first_block_qpos, last_block_qend;   /* blocks[0].qPos and blocks[last].qPos + length (hard-clipped substrings) */
+  int32_t is_secondary;                                        /* Alignment::ISsecondary (read by lra_group_alignments, not printed) */
 } lra_aln_record;
 int lra_format_sam(const lra_aln_record* group, int n_group, int as, int hard_clip, const char* passthrough, char* out, uint64_t cap, uint64_t* len);
 int lra_format_sam_simple(const lra_aln_record* rec, int hard_clip, const char* passthrough, char* out, uint64_t cap, uint64_t* len);
 int lra_format_paf(const lra_aln_record* rec, int print_cigar, char* out, uint64_t cap, uint64_t* len);
 int lra_format_bed(const lra_aln_record* rec, char* out, uint64_t cap, uint64_t* len);
+
+/* ---- a16 / a17: a read's alignments between CalculateStatistics and the text records (host code) -------------------------------
+ * lra_group_alignments  = SegAlignmentGroup::SetFromSegAlignment (Alignment.h:944-983) for n_groups alignments whose segment records are
+ *                         recs[seg_off[g] .. seg_off[g+1]) (SegAlignment order): sums, flags (REVERSE, SUPPLEMENTARY), ISsecondary.
+ * lra_order_alignments  = AlignmentsOrder::Update (:1021-1046; operator() :1048, std::sort): index[old_end..n_groups) ordered by
+ *                         (value, NumOfAnchors0) descending, first primary, others secondary (SECONDARY flag, typeofaln 2 unless 3).
+ * lra_simple_mapqv      = SimpleMapQV (Mapping_ultility.h:497-595), opts.bypassClustering / readType == clr / == ont / globalK.
+ * lra_output_read       = OUTPUT (:453-493) and output_unaligned (:445-451): formats 's' (PrintSAM), 'b' (PrintBed), 'p' / 'P' (PrintPAF
+ *                         without / with CIGAR); sets Alignment::order; two-call convention of the lra_format_* functions.             */
+typedef struct lra_aln_group {
+  int32_t first, count;
+  uint32_t q_start, q_end, t_start, t_end; int32_t nm, nmm, ndel, nins; int32_t is_secondary; float value; int32_t NumOfAnchors0, NumOfAnchors1;
+} lra_aln_group;
+int lra_group_alignments(lra_aln_record* recs, const int32_t* seg_off, int n_groups, lra_aln_group* groups);
+int lra_order_alignments(lra_aln_group* groups, int n_groups, lra_aln_record* recs, int32_t* index, int old_end);
+int lra_simple_mapqv(const lra_aln_group* groups, const int32_t* index, int n_groups, lra_aln_record* recs, int bypass_clustering, int is_clr, int is_ont,
+                     int globalK);
+int lra_output_read(const lra_aln_group* groups, const int32_t* index, int n_groups, lra_aln_record* recs, int print_num_aln, char format, int hard_clip,
+                    const char* passthrough, int read_unaligned, const lra_aln_record* unaligned_rec, char* out, uint64_t cap, uint64_t* len);
 
 #ifdef __cplusplus
 }
