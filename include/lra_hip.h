@@ -557,6 +557,9 @@ int lra_format_sam(const lra_aln_record* group, int n_group, int as, int hard_cl
 int lra_format_sam_simple(const lra_aln_record* rec, int hard_clip, const char* passthrough, char* out, uint64_t cap, uint64_t* len);
 int lra_format_paf(const lra_aln_record* rec, int print_cigar, char* out, uint64_t cap, uint64_t* len);
 int lra_format_bed(const lra_aln_record* rec, char* out, uint64_t cap, uint64_t* len);
+/* "@PG\tID:lra\tPN:lra\tVN:<version>\tCL:<command_line>" (lra.cpp:665-671) + one "@SQ\tSN:..\tLN:.." per chromosome (Genome.h:85-89) */
+int lra_format_sam_header(const char* version, const char* command_line, const char* const* chrom_names, const uint64_t* chrom_pos, int n_chrom,
+                          char* out, uint64_t cap, uint64_t* len);
 
 /* ---- a16 / a17: a read's alignments between CalculateStatistics and the text records (host code) -------------------------------
  * lra_group_alignments  = SegAlignmentGroup::SetFromSegAlignment (Alignment.h:944-983) for n_groups alignments whose segment records are

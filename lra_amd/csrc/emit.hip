@@ -131,3 +131,14 @@ extern "C" int lra_format_sam_simple(const lra_aln_record* rp, int hard_clip, co
   o << std::endl;
   return deliver(o.str(), out, cap, len);
 }
+
+// The SAM header lra writes before the first record: "@PG" (lra.cpp:665-671) and GenomeHeader::WriteSAMHeader (Genome.h:85-89).
+// command_line = "lra align" followed by the argv words as lra.cpp:667-670 joins them; version = lraVersion (lra.cpp:36).
+extern "C" int lra_format_sam_header(const char* version, const char* command_line, const char* const* chrom_names, const uint64_t* chrom_pos, int n_chrom,
+                                     char* out, uint64_t cap, uint64_t* len) {
+  if (!version || !command_line || n_chrom < 0 || (n_chrom > 0 && (!chrom_names || !chrom_pos))) return LRA_ERR_INVALID;
+  std::ostringstream o;
+  o << "@PG\tID:lra\tPN:lra\tVN:" << version << "\tCL:" << command_line << std::endl;
+  for (int i = 0; i < n_chrom; i++) o << "@SQ\tSN:" << chrom_names[i] << "\tLN:" << chrom_pos[i + 1] - chrom_pos[i] << std::endl;
+  return deliver(o.str(), out, cap, len);
+}
