@@ -895,6 +895,26 @@ __global__ void k_valkeys(uint64_t f0, uint64_t n, const float* __restrict__ fva
   opay[g] = (uint32_t)(g - fragOff[fragRead[g]]);
 }
 
+// TraceBack's step Dp[Ep[prev_ind]] of sub-problem prev_sub, resolved for every fragment at once (the chain walk then chases one pointer
+// per anchor instead of four dependent loads); taken after ProcessPoint has finished, as the reference's trace back reads it
+__global__ void k_pred(uint64_t f0, uint64_t n, int r0, const uint32_t* __restrict__ fragRead, const uint32_t* __restrict__ fprevNode,
+                       const uint32_t* __restrict__ fprevInd, const uint32_t* __restrict__ status, const ReadArena* __restrict__ ra, uint32_t* fpred) {
+  uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const uint64_t g = f0 + i;
+  const uint32_t r = fragRead[g];
+  uint32_t pred = NONE;
+  const uint32_t pn = fprevNode[g], pi = fprevInd[g];
+  if (!status[r] && pn != NONE && pi != NONE) {
+    const ReadArena A = ra[(int)r - r0];
+    const Node* nodesR = (const Node*)(uintptr_t)A.base;
+    const uint32_t* apR = (const uint32_t*)((const char*)(uintptr_t)A.base + A.apOff);
+    const Node nd = nodesR[pn];
+    pred = apR[nd.dBase + apR[nd.dBase + nd.nD + pi]];
+  }
+  fpred[g] = pred;
+}
+
 __global__ void k_frag_read(int n_reads, const uint64_t* __restrict__ fragOff, uint32_t* fragRead) {
   int r = blockIdx.x;
   for (uint64_t g = fragOff[r] + threadIdx.x; g < fragOff[r + 1]; g += blockDim.x) fragRead[g] = r;
@@ -905,7 +925,7 @@ struct TraceArgs {
   int boxes, globalK; const uint32_t* fqe; const uint32_t* fte; const int32_t* numAnchors; int32_t* chainNum;   // box mode (DecidePrimaryChains :1587)
   const uint64_t* fragOff; const uint64_t* read_off;
   const uint32_t* fq; const uint32_t* ft; const int32_t* flen; const uint32_t* fcl; const uint32_t* fai;
-  const float* fval; const uint32_t* fprevNode; const uint32_t* fprevInd; const uint8_t* fflags; const uint32_t* opay;
+  const float* fval; const uint32_t* fpred; const uint8_t* fflags; const uint32_t* opay;
   uint8_t* used;
   const ReadArena* ra;
   uint32_t* nChains; uint64_t* chainStart; uint32_t* chainLen; uint32_t* chainBox; float* chainValue;
@@ -921,21 +941,15 @@ __global__ void __launch_bounds__(64) sdp_trace(TraceArgs a) {
   const int total = (int)(a.fragOff[r + 1] - f0);
   a.nChains[r] = 0;
   if (total == 0 || a.status[r]) return;
-  const ReadArena A = a.ra[rr];
-  const Node* nodesR = (const Node*)(uintptr_t)A.base;
-  const uint32_t* apR = (const uint32_t*)((const char*)(uintptr_t)A.base + A.apOff);
   if (a.single) {                                                        // SparseDP.h:2417-2434: first anchor of maximal value, plain TraceBack :1521
     float maxv = 0; uint32_t i = 0;
     for (int l = 0; l < total; l++) if (a.fval[f0 + l] > maxv) { maxv = a.fval[f0 + l]; i = l; }
     uint32_t len = 0;
-    uint32_t pn = a.fprevNode[f0 + i], pi = a.fprevInd[f0 + i];
     a.ccl[f0] = i; len = 1;
-    while (pn != NONE && pi != NONE && len < (uint32_t)total) {
-      const Node nd = nodesR[pn];
-      const uint32_t ind = apR[nd.dBase + nd.nD + pi];
+    uint32_t nx;
+    while ((nx = a.fpred[f0 + i]) != NONE && len < (uint32_t)total) {
       a.clink[f0 + len - 1] = (a.fflags[f0 + i] & 2) ? 0 : 1;
-      i = apR[nd.dBase + ind];
-      pn = a.fprevNode[f0 + i]; pi = a.fprevInd[f0 + i];
+      i = nx;
       a.ccl[f0 + len] = i; len++;
     }
     a.clink[f0 + len - 1] = 0;
@@ -964,16 +978,11 @@ __global__ void __launch_bounds__(64) sdp_trace(TraceArgs a) {
     bool abandoned = false;
     if (a.used[f0 + i] == 0) {
       a.ccl[out] = i; len = 1; a.used[f0 + i] = 1;
-      uint32_t pn = a.fprevNode[f0 + i], pi = a.fprevInd[f0 + i];
-      while (pn != NONE && pi != NONE) {
-        const Node nd = nodesR[pn];
-        const uint32_t ind = apR[nd.dBase + nd.nD + pi];                // Ep[prev_ind]
-        const uint32_t nx = apR[nd.dBase + ind];                        // Dp[ind]
+      uint32_t nx;
+      while ((nx = a.fpred[f0 + i]) != NONE) {                          // Dp[Ep[prev_ind]] of sub-problem prev_sub (k_pred)
         if (a.used[f0 + nx] == 0) { a.clink[out + len - 1] = (a.fflags[f0 + i] & 2) ? 0 : 1; i = nx; }
         else { abandoned = true; break; }
-        pn = a.fprevNode[f0 + i]; pi = a.fprevInd[f0 + i];
-        if (a.used[f0 + i] == 0) { a.ccl[out + len] = i; len++; a.used[f0 + i] = 1; }
-        else { abandoned = true; break; }
+        a.ccl[out + len] = i; len++; a.used[f0 + i] = 1;                 // (the reference tests used[i] again here: it has just seen it clear)
       }
       if (abandoned) { for (uint32_t k = 0; k < len; k++) a.used[f0 + a.ccl[out + k]] = 0; len = 0; }
     }
@@ -1127,7 +1136,7 @@ int sdp_run(lra_ctx* ctx, int n_reads, const uint64_t* d_cluster_off, const uint
   uint32_t* iq = (uint32_t*)take(wp, NP + 1, 4); uint32_t* it = (uint32_t*)take(wp, NP + 1, 4); uint32_t* ifr = (uint32_t*)take(wp, NP + 1, 4);
   uint32_t* ptRead = (uint32_t*)take(wp, NP + 1, 4);
   uint32_t* hq = (uint32_t*)take(wp, NP + 1, 4); uint32_t* ht = (uint32_t*)take(wp, NP + 1, 4); uint32_t* hfr = (uint32_t*)take(wp, NP + 1, 4);
-  uint32_t* spare = (uint32_t*)take(wp, NP + 1, 4); (void)spare;
+  uint32_t* spare = (uint32_t*)take(wp, NP + 1, 4);          // TraceBack's predecessor per fragment (k_pred)
   uint8_t* ifl = (uint8_t*)take(wp, NP + 1, 1); uint8_t* hfl = (uint8_t*)take(wp, NP + 1, 1);
   uint32_t* opay = (uint32_t*)take(wp, NF + 1, 4); uint32_t* fragRead = (uint32_t*)take(wp, NF + 1, 4);
   out->d_n_chains = nChains; out->d_chain_start = chainStart; out->d_chain_len = chainLen; out->d_chain_box = chainBox; out->d_chain_value = chainValue;
@@ -1260,11 +1269,13 @@ int sdp_run(lra_ctx* ctx, int n_reads, const uint64_t* d_cluster_off, const uint
     if (cfn > 0) {
       lra_time_begin(ctx, "sdp_trace");
       hipLaunchKernelGGL(k_valkeys, dim3((unsigned)((cfn + 255) / 256)), dim3(256), 0, st, cf0, cfn, fval, fragRead, fragOff, okey, opay);
+      hipLaunchKernelGGL(k_pred, dim3((unsigned)((cfn + 255) / 256)), dim3(256), 0, st, cf0, cfn, r0, (const uint32_t*)fragRead, (const uint32_t*)fprevNode,
+                         (const uint32_t*)fprevInd, (const uint32_t*)status, (const ReadArena*)ra, spare);
       lra_time_end(ctx);
       { int rc = lra_sort_minimizers_batch(ctx, nr, fragOff + r0, okey, opay); if (rc) return rc; }   // Fragment_valueOrder::Sort (Fragment_Info.h:88)
       TraceArgs ta;
       ta.r0 = r0; ta.n = nr; ta.numAln = opts->NumAln; ta.single = opts->mode == LRA_SDP_SINGLE_CLUSTER; ta.alnthres = opts->alnthres; ta.fragOff = fragOff; ta.read_off = d_read_off; ta.fq = fq; ta.ft = ft;
-      ta.flen = flen; ta.fcl = fcl; ta.fai = fai; ta.fval = fval; ta.fprevNode = fprevNode; ta.fprevInd = fprevInd; ta.fflags = fflags; ta.opay = opay; ta.used = used;
+      ta.flen = flen; ta.fcl = fcl; ta.fai = fai; ta.fval = fval; ta.fpred = spare; ta.fflags = fflags; ta.opay = opay; ta.used = used;
       ta.ra = ra; ta.nChains = nChains; ta.chainStart = chainStart; ta.chainLen = chainLen;
       ta.chainBox = chainBox; ta.chainValue = chainValue; ta.ccl = ccl; ta.can = can; ta.clink = clink; ta.status = status;
       ta.cq = cq; ta.ct = ct; ta.clen = clen; ta.cstrand = cstrand; ta.fstrand = fstrand;
