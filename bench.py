@@ -34,21 +34,28 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 
-def build_workload(args, rank, device):
-    """Everything is generated on the GPU with bulk tensor ops (seconds), seeded per rank."""
+def build_reference(args, device):
+    """Genome + global index, generated on the GPU with bulk tensor ops (seconds)."""
+    from lra_amd import synth_torch as st
+    genome = st.make_genome(int(args.genome_mb * 1e6), 1, device)
+    idx_key, idx_pos = st.build_global_index(genome, args.k, args.w, 150)
+    return genome, idx_key, idx_pos
+
+
+def build_workload(args, rank, device, ref, n_reads, lane):
+    """One lane's reads (seeded per rank and lane) and the truth-derived inputs of the stages behind a13."""
     import torch
     from lra_amd import synth_torch as st
     t0 = time.time()
-    genome = st.make_genome(int(args.genome_mb * 1e6), 1, device)
-    idx_key, idx_pos = st.build_global_index(genome, args.k, args.w, 150)
-    sim = st.simulate_batch(genome, args.reads, args.read_len, args.read_len / 10, args.err, (30, 35, 35), 1000 + rank)
+    genome, idx_key, idx_pos = ref
+    sim = st.simulate_batch(genome, n_reads, args.read_len, args.read_len / 10, args.err, (30, 35, 35), 1000 + rank + 7919 * lane)
     pad = torch.zeros(64, dtype=torch.uint8, device=device)
     strands = torch.cat([sim["seq"], pad])                                   # the strand every alignment lies on
-    g2 = torch.Generator(device=device).manual_seed(77 + rank)
-    rev = torch.rand(args.reads, generator=g2, device=device) < 0.5
+    g2 = torch.Generator(device=device).manual_seed(77 + rank + 7919 * lane)
+    rev = torch.rand(n_reads, generator=g2, device=device) < 0.5
     reads = torch.cat([st.revcomp_some(sim["seq"], sim["off"], rev), pad])   # what the sequencer gave us (half reverse strand)
     gaps = st.gap_problems(sim)
-    rblocks, rboff = st.perturbed_blocks(sim, 5 + rank)
+    rblocks, rboff = st.perturbed_blocks(sim, 5 + rank + 7919 * lane)
     torch.cuda.synchronize()
     torch.cuda.empty_cache()                                                 # hand the generator's temporaries back: the stages need the room
     return dict(genome=genome, idx_key=idx_key, idx_pos=idx_pos, sim=sim, strands=strands, reads=reads, gaps=gaps, rev=rev,
@@ -60,7 +67,7 @@ def cpu_baseline(wl, args, budget_s=20.0, max_reads=768):
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import oracle_lib as O
     O.lib()
-    S = min(max_reads, args.reads)
+    S = min(max_reads, int(wl["sim"]["off"].numel()) - 1)
     sim = wl["sim"]
     off = sim["off"][:S + 1].cpu().numpy()
     reads = wl["reads"][:int(off[-1])].cpu().numpy()
@@ -122,6 +129,9 @@ def main():
     ap.add_argument("--max-freq", type=int, default=150)
     ap.add_argument("--refine-band", type=int, default=7)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--lanes", type=int, default=int(os.environ.get("LRA_BENCH_LANES", 2)),
+                    help="the batch is cut into this many sub-batches, each driven by its own context and HIP stream from its own host thread, so "
+                         "that the serial tails of one sub-batch's kernels overlap the other's work")
     args = ap.parse_args()
 
     import torch
@@ -146,71 +156,115 @@ def main():
     copts = cluster.CleanOpts(globalK=17, cleanMaxDiag=200, minDiagCluster=3, bypassClustering=1, cleanClustersize=100,
                               SecondCleanMinDiagCluster=10, SecondCleanMaxDiag=100, punish_anchorfreq=5, anchorPerlength=5)   # -ONT
 
-    ctx = Context(dev_index)
-    wl = build_workload(args, rank, ctx.device)
-    seed.load_reference(ctx, wl["genome"].cpu().numpy(), wl["idx_key"], wl["idx_pos"])
-    sim = wl["sim"]
-    rbatch = seed.read_batch_from_device(ctx, wl["reads"], sim["off"])
-    gp = wl["gaps"]
-    gdev = torch.cat([wl["genome"], torch.zeros(64, dtype=torch.uint8, device=ctx.device)])
-    abatch = align.AogBatch.from_device(ctx, wl["strands"], gdev, gp["q_off"], gp["q_len"], gp["t_off"], gp["t_len"], gp["k"], 4, -1, -2)   # -ONT scores
-    lens = (sim["off"][1:] - sim["off"][:-1])
-    nR = args.reads
-    fbatch = refine.refine_batch_from_device(ctx, wl["rblocks"], wl["rboff"], wl["strands"], sim["off"][:-1], lens,
-                                             gdev, torch.zeros(nR, dtype=torch.int64, device=ctx.device),
-                                             torch.full((nR,), int(wl["genome"].numel()), dtype=torch.int64, device=ctx.device))
-    # a10 inputs: genome local index (the `.gli` payload, built once: tuples, tupleBoundaries, seqOffsets) and one buffer holding
-    # the reads forward followed by their reverse complements (forwardIndex / reverseIndex, Map_lowacc.h:246-250)
-    from lra_amd import local
-    G = int(wl["genome"].numel())
-    g_off = torch.tensor([0, G], dtype=torch.int64, device=ctx.device)
-    gli = local.LocalIndex(ctx, gdev, g_off, 10, 5, 256, 15)
-    gso = torch.cat([torch.arange(0, G, 256, dtype=torch.int64, device=ctx.device), torch.tensor([G], dtype=torch.int64, device=ctx.device)])
-    tot = int(sim["off"][-1])
-    both = torch.zeros(2 * tot + 64, dtype=torch.uint8, device=ctx.device)
-    both[:tot] = rbatch.seq[:tot]
-    off2 = torch.cat([rbatch.off, rbatch.off[1:] + tot]).contiguous()
-    total_bases = int(lens.sum())
-    n_gap_bytes = int(gp["q_len"].sum() + gp["t_len"].sum())
-    n_gaps = int(gp["k"].numel())
+    import threading
+    errors = []
 
-    stats = {}
+    def make_lane(lane, n_reads, ref):
+        """One sub-batch: its own context (buffers + HIP stream) and its reads; returns (ctx, step, stats, constants)."""
+        stream = torch.cuda.Stream(device=dev_index) if args.lanes > 1 else None
+        ctx = Context(dev_index)
+        if stream is not None:
+            ctx.bind_stream(stream)
+        wl = build_workload(args, rank, ctx.device, ref, n_reads, lane)
+        seed.load_reference(ctx, wl["genome"].cpu().numpy(), wl["idx_key"], wl["idx_pos"])
+        sim = wl["sim"]
+        rbatch = seed.read_batch_from_device(ctx, wl["reads"], sim["off"])
+        gp = wl["gaps"]
+        gdev = torch.cat([wl["genome"], torch.zeros(64, dtype=torch.uint8, device=ctx.device)])
+        abatch = align.AogBatch.from_device(ctx, wl["strands"], gdev, gp["q_off"], gp["q_len"], gp["t_off"], gp["t_len"], gp["k"], 4, -1, -2)   # -ONT scores
+        lens = (sim["off"][1:] - sim["off"][:-1])
+        nR = n_reads
+        fbatch = refine.refine_batch_from_device(ctx, wl["rblocks"], wl["rboff"], wl["strands"], sim["off"][:-1], lens,
+                                                 gdev, torch.zeros(nR, dtype=torch.int64, device=ctx.device),
+                                                 torch.full((nR,), int(wl["genome"].numel()), dtype=torch.int64, device=ctx.device))
+        # a10 inputs: genome local index (the `.gli` payload, built once: tuples, tupleBoundaries, seqOffsets) and one buffer holding
+        # the reads forward followed by their reverse complements (forwardIndex / reverseIndex, Map_lowacc.h:246-250)
+        from lra_amd import local
+        G = int(wl["genome"].numel())
+        g_off = torch.tensor([0, G], dtype=torch.int64, device=ctx.device)
+        gli = local.LocalIndex(ctx, gdev, g_off, 10, 5, 256, 15)
+        gso = torch.cat([torch.arange(0, G, 256, dtype=torch.int64, device=ctx.device), torch.tensor([G], dtype=torch.int64, device=ctx.device)])
+        tot = int(sim["off"][-1])
+        both = torch.zeros(2 * tot + 64, dtype=torch.uint8, device=ctx.device)
+        both[:tot] = rbatch.seq[:tot]
+        off2 = torch.cat([rbatch.off, rbatch.off[1:] + tot]).contiguous()
+        total_bases = int(lens.sum())
+        n_gap_bytes = int(gp["q_len"].sum() + gp["t_len"].sum())
+        n_gaps = int(gp["k"].numel())
+
+        stats = {}
+        out_rec = [None]
+
+        def step():
+            sres = seed.seed_batch(ctx, rbatch, args.k, args.w, args.max_freq)
+            cres = cluster.clean_matches_batch(ctx, copts, [0, int(wl["genome"].numel())])
+            eres = cluster.linear_extend_batch(ctx, args.k, rbatch)
+            # a8: SDP#A over the extended anchors of every read (Map_lowacc.h:185-188)
+            chres = chain.sparse_dp_batch(ctx, nR, cres.d_cluster_off, eres.d_e_start, eres.d_e_count, cres.d_c_strand, eres.d_e_qpos, eres.d_e_tpos,
+                                          eres.d_e_len, rbatch.off, sdp_opts)
+            # a9: RemoveSpuriousJump + SPLITChain + RemoveSpuriousSplitChain on every chain (Map_lowacc.h:189-256)
+            spres = chain.split_chains_batch(ctx, chres, [0, int(wl["genome"].numel())])
+            # a10: CreateRC, LocalIndex::IndexSeq of both strands, Refine_splitchain on every split chain (Map_lowacc.h:246-294)
+            ctx.check(ctx.lib.lra_create_rc_batch(ctx.h, rbatch.n, C.c_void_p(rbatch.seq.data_ptr()), C.c_void_p(rbatch.off.data_ptr()), C.c_void_p(both.data_ptr() + tot)))
+            rli = local.LocalIndex(ctx, both, off2, 10, 5, 256, 15)
+            rres = chain.refine_splitchain_batch(ctx, chres, spres, rbatch.off, [0, G], rli, gso, gli, window=100, smallK=10, K=args.k, limitrefine=True, max_freq=15)
+            # a11 callers, a9 MergeChain, a7 second pass, a8 second sparse DP + its filters (Map_lowacc.h:362-540)
+            bres = chain.refine_btwn_splitchain_batch(ctx, chres, spres, rres, rbatch.off, both, tot, gdev, [0, G], K=10, W=5, refineSpaceDist=30000,
+                                                      anchorstoosparse=0.005, match=4, mismatch=-1, indel=-2, max_freq=15)
+            mres = chain.merge_extend_batch(ctx, chres, spres, bres, rbatch.seq, rbatch.off, gdev, [0, G], K=10)
+            ch2 = chain.sparse_dp_batch(ctx, int(mres.n_groups), mres.d_iota, mres.d_anchor_off, mres.d_count, mres.d_strand, mres.d_q, mres.d_t, mres.d_len,
+                                        mres.d_iota, sdp2_opts)
+            stats.update(n_btwn_problems=bres.n_problems, n_btwn_rounds=bres.n_rounds, n_refined_after_btwn=bres.n_matches, n_merged_clusters=mres.n_groups,
+                         n_sdp2_anchors=mres.n_anchors, n_sdp2_entries=ch2.n_subproblem_entries)
+            if "n_local_task_words" not in stats and rres.n_tasks:
+                t4 = [ctx.to_tensor(p_, rres.n_tasks, torch.int64) for p_ in (rres.d_task_q_lo, rres.d_task_q_hi, rres.d_task_t_lo, rres.d_task_t_hi)]
+                stats["n_local_task_words"] = int((t4[1] - t4[0]).sum() + (t4[3] - t4[2]).sum())
+            abatch.run()
+            fres = refine.indel_refine_batch(ctx, fbatch, args.refine_band, 4, -1, -2)
+            tres = refine.stats_of_refined(ctx, fbatch, fres, lut)
+            # the one exchange step: refined block records -> rank 0
+            rec = ctx.to_tensor(fres.d_blocks, 3 * fres.n_blocks, torch.int32)
+            out_rec[0] = rec
+            stats.update(n_mm=sres.n_minimizers, n_match=sres.n_matches, n_cells=fres.n_cells, n_rows=fres.n_rows,
+                         n_seg=fres.n_segments, n_blocks=fres.n_blocks, n_aog=fres.n_aog, n_clusters=cres.n_clusters, n_cigar_runs=tres.n_runs, n_local_tuples=rli.n_tuples,
+                         n_local_tasks=rres.n_tasks, n_local_pairs=rres.n_pairs, n_refined_matches=rres.n_matches,
+                         n_sdp_anchors=chres.n_frags, n_sdp_points=chres.n_points, n_sdp_entries=chres.n_subproblem_entries)
+
+
+        def run_step():
+            try:
+                torch.cuda.set_device(dev_index)                         # the current device is per host thread
+                if stream is not None:
+                    with torch.cuda.stream(stream):
+                        step()
+                else:
+                    step()
+            except BaseException as e:                                   # surfaced by the caller: a thread's exception would vanish otherwise
+                errors.append(e)
+        return dict(ctx=ctx, step=run_step, stats=stats, wl=wl, total_bases=total_bases, n_gap_bytes=n_gap_bytes, n_gaps=n_gaps, out_rec=out_rec)
+
+    ref = build_reference(args, torch.device("cuda", dev_index))
+    per_lane = [args.reads // args.lanes + (1 if i < args.reads % args.lanes else 0) for i in range(args.lanes)]
+    lanes = [make_lane(i, per_lane[i], ref) for i in range(args.lanes)]
+    ctx = lanes[0]["ctx"]
+    wl = lanes[0]["wl"]
+    torch.cuda.synchronize()
+    total_bases = sum(l["total_bases"] for l in lanes)
+    n_gap_bytes = sum(l["n_gap_bytes"] for l in lanes); n_gaps = sum(l["n_gaps"] for l in lanes)
 
     def step():
-        sres = seed.seed_batch(ctx, rbatch, args.k, args.w, args.max_freq)
-        cres = cluster.clean_matches_batch(ctx, copts, [0, int(wl["genome"].numel())])
-        eres = cluster.linear_extend_batch(ctx, args.k, rbatch)
-        # a8: SDP#A over the extended anchors of every read (Map_lowacc.h:185-188)
-        chres = chain.sparse_dp_batch(ctx, nR, cres.d_cluster_off, eres.d_e_start, eres.d_e_count, cres.d_c_strand, eres.d_e_qpos, eres.d_e_tpos,
-                                      eres.d_e_len, rbatch.off, sdp_opts)
-        # a9: RemoveSpuriousJump + SPLITChain + RemoveSpuriousSplitChain on every chain (Map_lowacc.h:189-256)
-        spres = chain.split_chains_batch(ctx, chres, [0, int(wl["genome"].numel())])
-        # a10: CreateRC, LocalIndex::IndexSeq of both strands, Refine_splitchain on every split chain (Map_lowacc.h:246-294)
-        ctx.check(ctx.lib.lra_create_rc_batch(ctx.h, rbatch.n, C.c_void_p(rbatch.seq.data_ptr()), C.c_void_p(rbatch.off.data_ptr()), C.c_void_p(both.data_ptr() + tot)))
-        rli = local.LocalIndex(ctx, both, off2, 10, 5, 256, 15)
-        rres = chain.refine_splitchain_batch(ctx, chres, spres, rbatch.off, [0, G], rli, gso, gli, window=100, smallK=10, K=args.k, limitrefine=True, max_freq=15)
-        # a11 callers, a9 MergeChain, a7 second pass, a8 second sparse DP + its filters (Map_lowacc.h:362-540)
-        bres = chain.refine_btwn_splitchain_batch(ctx, chres, spres, rres, rbatch.off, both, tot, gdev, [0, G], K=10, W=5, refineSpaceDist=30000,
-                                                  anchorstoosparse=0.005, match=4, mismatch=-1, indel=-2, max_freq=15)
-        mres = chain.merge_extend_batch(ctx, chres, spres, bres, rbatch.seq, rbatch.off, gdev, [0, G], K=10)
-        ch2 = chain.sparse_dp_batch(ctx, int(mres.n_groups), mres.d_iota, mres.d_anchor_off, mres.d_count, mres.d_strand, mres.d_q, mres.d_t, mres.d_len,
-                                    mres.d_iota, sdp2_opts)
-        stats.update(n_btwn_problems=bres.n_problems, n_btwn_rounds=bres.n_rounds, n_refined_after_btwn=bres.n_matches, n_merged_clusters=mres.n_groups,
-                     n_sdp2_anchors=mres.n_anchors, n_sdp2_entries=ch2.n_subproblem_entries)
-        if "n_local_task_words" not in stats and rres.n_tasks:
-            t4 = [ctx.to_tensor(p_, rres.n_tasks, torch.int64) for p_ in (rres.d_task_q_lo, rres.d_task_q_hi, rres.d_task_t_lo, rres.d_task_t_hi)]
-            stats["n_local_task_words"] = int((t4[1] - t4[0]).sum() + (t4[3] - t4[2]).sum())
-        abatch.run()
-        fres = refine.indel_refine_batch(ctx, fbatch, args.refine_band, 4, -1, -2)
-        tres = refine.stats_of_refined(ctx, fbatch, fres, lut)
+        if len(lanes) == 1:
+            lanes[0]["step"]()
+        else:
+            ths = [threading.Thread(target=l["step"]) for l in lanes]
+            for t in ths: t.start()
+            for t in ths: t.join()
+        if errors:
+            raise errors[0]
+        torch.cuda.synchronize()
         # the one exchange step: refined block records -> rank 0
-        rec = ctx.to_tensor(fres.d_blocks, 3 * fres.n_blocks, torch.int32)
+        rec = torch.cat([l["out_rec"][0] for l in lanes]) if len(lanes) > 1 else lanes[0]["out_rec"][0]
         parallel.gather_records(rec, dst=0)
-        stats.update(n_mm=sres.n_minimizers, n_match=sres.n_matches, n_cells=fres.n_cells, n_rows=fres.n_rows,
-                     n_seg=fres.n_segments, n_blocks=fres.n_blocks, n_aog=fres.n_aog, n_clusters=cres.n_clusters, n_cigar_runs=tres.n_runs, n_local_tuples=rli.n_tuples,
-                     n_local_tasks=rres.n_tasks, n_local_pairs=rres.n_pairs, n_refined_matches=rres.n_matches,
-                     n_sdp_anchors=chres.n_frags, n_sdp_points=chres.n_points, n_sdp_entries=chres.n_subproblem_entries)
-        stats["_chres"] = chres
 
     def sync():
         if world > 1:
@@ -219,8 +273,9 @@ def main():
 
     for _ in range(args.warmup):
         step()
-    ctx.timing(True)
-    ctx.timing_reset()
+    for l in lanes:
+        l["ctx"].timing(True)
+        l["ctx"].timing_reset()
     sync()
     t0 = time.perf_counter()
     for _ in range(args.steps):
@@ -242,8 +297,16 @@ def main():
     kernels = ["sketch_count", "sketch_serial", "sketch_emit", "sort", "sort_fallback", "index_bounds", "compare", "strand",
                "aog_lds_tiny", "aog_lds_small", "aog_lds_large", "aog_hbm", "ir_segment", "ir_band", "ir_fill", "ir_trace", "ir_gather", "clean_sort", "clean", "linear_extend", "stats", "stats_cigar", "create_rc", "local_sketch", "local_sort_filter", "local_compare",
                "rsc_tasks", "rsc_filter", "refine_space", "refine_space_long", "btwn_plan", "btwn_apply", "merge_extend", "chain_split", "sdp_points", "sdp_sort", "sdp_sort_fallback", "sdp_build_count", "sdp_build", "sdp_process", "sdp_trace"]
-    ktimes = {k: ctx.timing_get(k) for k in kernels}
-    ctx.timing(False)
+    ktimes = {}
+    for k in kernels:
+        tt_ = [l["ctx"].timing_get(k) for l in lanes]
+        ktimes[k] = (sum(x[0] for x in tt_), sum(x[1] for x in tt_))
+    for l in lanes:
+        l["ctx"].timing(False)
+    stats = {}
+    for l in lanes:
+        for k, v in l["stats"].items():
+            stats[k] = stats.get(k, 0) + v if isinstance(v, (int, float)) else v
     if rank == 0:
         ms_step = dt / args.steps * 1e3
         gbps = job_bases * args.steps / dt / 1e9
@@ -304,7 +367,7 @@ def main():
                        "stages": "a1-a5,a7,a8(SDP#A),a9(chain split),a10(Refine_splitchain),a11(Refine_Btwnsplitchain),a9(MergeChain),a7(second LinearExtend+Trim),a8(second "
                                  "SDP) chained on the reads = MapRead_lowacc up to Map_lowacc.h:540; a12 on between-anchor gaps and a14 on block lists derived "
                                  "from the simulator's truth, a16 on a14's output (a13 LocalRefineAlignment glue not built yet: NOT a whole `lra align`)",
-                       "parallelism": "reads sharded by ordinal, 1 process/GPU; RCCL gather of block records to rank 0",
+                       "parallelism": "reads sharded by ordinal, 1 process/GPU, %d sub-batches per process on their own HIP streams; RCCL gather of block records to rank 0" % args.lanes,
                        "per_step": {k: int(v) for k, v in stats.items() if not k.startswith("_")}},
             "kernel_ms_per_step": {k: round(v[0] / args.steps, 4) for k, v in ktimes.items() if v[1]},
             "roofline": {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": 8000.0, "unit": "GB/s", "frac": achieved / 8000.0,
