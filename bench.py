@@ -129,7 +129,7 @@ def main():
     ap.add_argument("--max-freq", type=int, default=150)
     ap.add_argument("--refine-band", type=int, default=7)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--lanes", type=int, default=int(os.environ.get("LRA_BENCH_LANES", 2)),
+    ap.add_argument("--lanes", type=int, default=int(os.environ.get("LRA_BENCH_LANES", 1)),
                     help="the batch is cut into this many sub-batches, each driven by its own context and HIP stream from its own host thread, so "
                          "that the serial tails of one sub-batch's kernels overlap the other's work")
     args = ap.parse_args()
