@@ -264,3 +264,130 @@ def test_hip_merge_extend_and_second_sdp_oracle(ctx, oracle):
         assert m == len(exp["chains"][0]["frags"]) and np.array_equal(c2["chain_anchor"][a:a + m], exp["chains"][0]["frags"]), G
         n2 += 1
     assert n2 >= 40
+
+
+@pytest.mark.gpu
+def test_hip_lowacc_chain_bench_like_sample(ctx, oracle):
+    """bench-like reads (30 kb, 10 % error, 16 Mb genome with repeats) through the whole chained low-accuracy front end on the GPU
+    (seed -> ... -> second sparse DP's inputs); a sample of reads is checked stage by stage against the oracle, every read against
+    size-independent properties (matches inside their boxes, anchors inside merged boxes, CSR consistency)."""
+    import torch
+    from lra_amd import synth_torch as st, seed, cluster, chain, local
+    dev = ctx.device
+    NR = 384
+    genome = st.make_genome(16_000_000, 1, dev)
+    ik, ip = st.build_global_index(genome, K, 10, 150)
+    sim = st.simulate_batch(genome, NR, 30000, 3000, 0.10, (30, 35, 35), 99)
+    pad = torch.zeros(64, dtype=torch.uint8, device=dev)
+    g2 = torch.Generator(device=dev).manual_seed(5)
+    rev = torch.rand(NR, generator=g2, device=dev) < 0.5
+    reads = torch.cat([st.revcomp_some(sim["seq"], sim["off"], rev), pad])
+    G = int(genome.numel())
+    CH = [0, G]
+    seed.load_reference(ctx, genome.cpu().numpy(), ik, ip)
+    rb = seed.read_batch_from_device(ctx, reads, sim["off"])
+    seed.seed_batch(ctx, rb, K, 10, 150)
+    po = dict(oracle.CLEAN_PRESETS["ONT"]); po["globalK"] = K
+    cres = cluster.clean_matches_batch(ctx, cluster.CleanOpts(**po), CH)
+    eres = cluster.linear_extend_batch(ctx, K, rb)
+    chres = chain.sparse_dp_batch(ctx, NR, cres.d_cluster_off, eres.d_e_start, eres.d_e_count, cres.d_c_strand, eres.d_e_qpos, eres.d_e_tpos, eres.d_e_len,
+                                  rb.off, chain.sdp_opts())
+    co = chain.fetch(ctx, chres)
+    spres = chain.split_chains_batch(ctx, chres, CH)
+    so = chain.fetch_split(ctx, spres)
+    gdev = torch.cat([genome, pad])
+    gli = local.LocalIndex(ctx, gdev, torch.tensor(CH, dtype=torch.int64, device=dev), 10, 5, 256, 15)
+    tot = int(rb.off[-1])
+    both = torch.zeros(2 * tot + 64, dtype=torch.uint8, device=dev)
+    both[:tot] = rb.seq[:tot]
+    both[tot:2 * tot] = seed.create_rc(ctx, rb)[:tot]
+    off2 = torch.cat([rb.off, rb.off[1:] + tot]).contiguous()
+    rli = local.LocalIndex(ctx, both, off2, 10, 5, 256, 15)
+    gso = _seq_offsets([0], G, 256)
+    gso_d = torch.from_numpy(gso.astype(np.int64)).to(dev)
+    rres = chain.refine_splitchain_batch(ctx, chres, spres, rb.off, CH, rli, gso_d, gli, window=100, smallK=10, K=K, limitrefine=True, max_freq=15)
+    ro = chain.fetch_refined(ctx, rres)
+    bres = chain.refine_btwn_splitchain_batch(ctx, chres, spres, rres, rb.off, both, tot, gdev, CH, K=10, W=5, refineSpaceDist=30000, anchorstoosparse=0.005)
+    bo = chain.fetch_btwn(ctx, bres)
+    mres = chain.merge_extend_batch(ctx, chres, spres, bres, rb.seq, rb.off, gdev, CH, K=10)
+    mo = chain.fetch_merge(ctx, mres)
+    ch2 = chain.sparse_dp_batch(ctx, int(mres.n_groups), mres.d_iota, mres.d_anchor_off, mres.d_count, mres.d_strand, mres.d_q, mres.d_t, mres.d_len,
+                                mres.d_iota, chain.sdp_opts(mode=1, rate=2.0))
+    c2 = chain.fetch(ctx, ch2)
+    na = chres.num_aln
+    off = sim["off"].cpu().numpy()
+    # ---- properties on every read
+    assert int(ro["match_off"][-1]) == rres.n_matches and np.all(np.diff(ro["match_off"].astype(np.int64)) >= 0)
+    assert int(bo["match_off"][-1]) == bres.n_matches and np.all(bo["match_off"].astype(np.int64) >= ro["match_off"].astype(np.int64))
+    assert int(mo["anchor_off"][-1]) == mres.n_anchors
+    n_with = 0
+    for r in range(NR):
+        L = int(off[r + 1] - off[r])
+        for c in range(int(co["n_chains"][r])):
+            s = r * na + c
+            if so["status"][s]:
+                continue
+            b = int(co["chain_start"][s])
+            for k in range(int(so["n_split"][s])):
+                x = b + k
+                m0, m1 = int(bo["match_off"][x]), int(bo["match_off"][x + 1])
+                if m1 == m0:
+                    continue
+                q = bo["match_q"][m0:m1]; t = bo["match_t"][m0:m1]; bx = bo["box"][x]
+                assert q.min() == bx[0] and q.max() + 10 == bx[1] and t.min() == bx[2] and t.max() + 10 == bx[3], (r, c, k)
+                assert bx[1] <= L and bx[3] <= G
+                n_with += 1
+            for g in range(int(mo["slot_group_off"][s]), int(mo["slot_group_off"][s + 1])):
+                a0, cnt = int(mo["anchor_off"][g]), int(mo["count"][g])
+                if cnt:
+                    assert int(c2["status"][g]) == 0 and int(c2["n_chains"][g]) == 1
+    assert n_with >= NR // 2
+    # ---- stage-by-stage parity on a sample of reads
+    g_win, g_bnd, g_tup = gli.fetch()
+    r_win, r_bnd, r_tup = rli.fetch()
+    gbytes = genome.cpu().numpy().tobytes()
+    reads_h = reads.cpu().numpy()
+    n_checked = 0
+    for r in range(0, NR, 24):
+        L = int(off[r + 1] - off[r])
+        rd = reads_h[int(off[r]):int(off[r + 1])]
+        from lra_amd import synth
+        fwd = rd.tobytes(); rc = synth.revcomp(rd).tobytes()
+        for c in range(int(co["n_chains"][r])):
+            s = r * na + c
+            if so["status"][s] or int(so["n_split"][s]) == 0:
+                continue
+            b = int(co["chain_start"][s]); ln = int(co["chain_len"][s]); nsp = int(so["n_split"][s])
+            sel = np.nonzero(so["keep"][b:b + ln])[0]
+            q = co["chain_q"][b:b + ln][sel]; t = co["chain_t"][b:b + ln][sel]; al = co["chain_alen"][b:b + ln][sel]
+            cl = co["chain_cluster"][b:b + ln][sel]; cst = co["chain_strand"][b:b + ln][sel]
+            offs = [0]; mq = []; mt = []
+            for k in range(nsp):
+                x = b + k
+                a0, m = b + int(so["sp_beg"][x]), int(so["sp_len"][x])
+                c0, cm = b + int(so["ci_beg"][x]), int(so["ci_len"][x])
+                strand = int(so["sp_strand"][x])
+                w0, w1 = int(r_win[strand * NR + r]), int(r_win[strand * NR + r + 1])
+                q_index = (_seq_offsets([0], L, 256), r_bnd[w0:w1 + 1] - r_bnd[w0], r_tup[int(r_bnd[w0]):int(r_bnd[w1])])
+                exp = O.refine_splitchain(q, t, al, cl, cst, so["sp_idx"][a0:a0 + m], so["sp_box"][x], strand, int(so["sp_chrom"][x]), so["ci_idx"][c0:c0 + cm], CH, L,
+                                          q_index, (gso, g_bnd, g_tup), window=100, smallK=10, K=K, limitrefine=True, max_freq=15)
+                m0, m1 = int(ro["match_off"][x]), int(ro["match_off"][x + 1])
+                assert exp is not None and np.array_equal(ro["match_q"][m0:m1], exp["q"]) and np.array_equal(ro["match_t"][m0:m1], exp["t"]), (r, c, k)
+                mq.extend(exp["q"].tolist()); mt.extend(exp["t"].tolist()); offs.append(len(mq))
+            expb = O.refine_btwn_splitchain(offs, mq, mt, ro["box"][b:b + nsp], so["sp_strand"][b:b + nsp], so["sp_chrom"][b:b + nsp],
+                                            so["split_link"][b:b + max(nsp - 1, 0)], fwd, rc, gbytes, CH, K=10, W=5, refineSpaceDist=30000, anchorstoosparse=0.005)
+            assert expb is not None
+            for k in range(nsp):
+                x = b + k
+                m0, m1 = int(bo["match_off"][x]), int(bo["match_off"][x + 1]); e0, e1 = int(expb["off"][k]), int(expb["off"][k + 1])
+                assert np.array_equal(bo["match_q"][m0:m1], expb["q"][e0:e1]) and np.array_equal(bo["match_t"][m0:m1], expb["t"][e0:e1]), (r, c, k)
+                assert np.array_equal(bo["box"][x], expb["box"][k])
+            expm = O.merge_extend(expb["off"], expb["q"], expb["t"], expb["box"], so["sp_strand"][b:b + nsp], so["sp_chrom"][b:b + nsp], fwd, gbytes, CH, K=10)
+            g0 = int(mo["slot_group_off"][s])
+            assert int(mo["slot_group_off"][s + 1]) - g0 == len(expm["member"]) - 1
+            for g in range(len(expm["member"]) - 1):
+                a0, cnt = int(mo["anchor_off"][g0 + g]), int(mo["count"][g0 + g]); e0, e1 = int(expm["anchor_off"][g]), int(expm["anchor_off"][g + 1])
+                assert cnt == e1 - e0 and np.array_equal(mo["q"][a0:a0 + cnt], expm["q"][e0:e1]) and np.array_equal(mo["t"][a0:a0 + cnt], expm["t"][e0:e1])
+                assert np.array_equal(mo["len"][a0:a0 + cnt], expm["len"][e0:e1]) and np.array_equal(mo["box"][g0 + g], expm["box"][g])
+            n_checked += 1
+    assert n_checked >= 12
