@@ -552,6 +552,7 @@ typedef struct lra_aln_record {
   float value; int32_t order, NumOfAnchors0, NumOfAnchors1, runtime;
   int32_t n_blocks; uint32_t first_block_qpos, last_block_qend;   /* blocks[0].qPos and blocks[last].qPos + length (hard-clipped substrings) */
   int32_t is_secondary;                                        /* Alignment::ISsecondary (read by lra_group_alignments, not printed) */
+  const char* md;                                              /* NULL, or the MD:Z value (opts.printMD; lra_md_string) */
 } lra_aln_record;
 int lra_format_sam(const lra_aln_record* group, int n_group, int as, int hard_clip, const char* passthrough, char* out, uint64_t cap, uint64_t* len);
 int lra_format_sam_simple(const lra_aln_record* rec, int hard_clip, const char* passthrough, char* out, uint64_t cap, uint64_t* len);
@@ -560,6 +561,14 @@ int lra_format_bed(const lra_aln_record* rec, char* out, uint64_t cap, uint64_t*
 /* "@PG\tID:lra\tPN:lra\tVN:<version>\tCL:<command_line>" (lra.cpp:665-671) + one "@SQ\tSN:..\tLN:.." per chromosome (Genome.h:85-89) */
 int lra_format_sam_header(const char* version, const char* command_line, const char* const* chrom_names, const uint64_t* chrom_pos, int n_chrom,
                           char* out, uint64_t cap, uint64_t* len);
+
+/* Alignment strings and what is printed from them (host code): CreateAlignmentStrings (Alignment.h:247-331), AlignmentStringsToMD (:204-245,
+ * the MD:Z value PrintSAM adds with opts.printMD), PrintPairwise (:564-589, print format "a").  Two-call convention as above.             */
+int lra_alignment_strings(const char* query, const char* text, const int32_t* blocks, int n_blocks, char* q_out, char* a_out, char* t_out, uint64_t cap,
+                          uint64_t* len, uint32_t* ref_len);
+int lra_md_string(const char* query_str, const char* ref_str, uint64_t n, char* out, uint64_t cap, uint64_t* len);
+int lra_format_pairwise(const char* read_name, const char* chrom, int n_blocks, int first_q, int first_t, uint32_t ref_len, const char* query_str,
+                        const char* align_str, const char* ref_str, uint64_t n, char* out, uint64_t cap, uint64_t* len);
 
 /* ---- a16 / a17: a read's alignments between CalculateStatistics and the text records (host code) -------------------------------
  * lra_group_alignments  = SegAlignmentGroup::SetFromSegAlignment (Alignment.h:944-983) for n_groups alignments whose segment records are

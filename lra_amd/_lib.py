@@ -52,6 +52,10 @@ SYMBOLS = {
     "lra_refine_btwn_splitchain_batch": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, C.c_uint64, _vp, _vp, C.c_int, _vp, _vp]),
     "lra_merge_extend_batch": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, C.c_int, C.c_int, _vp]),
     "lra_format_sam_header": (C.c_int, [C.c_char_p, C.c_char_p, _vp, _vp, C.c_int, _vp, C.c_uint64, _vp]),
+    "lra_alignment_strings": (C.c_int, [C.c_char_p, C.c_char_p, _vp, C.c_int, _vp, _vp, _vp, C.c_uint64, _vp, _vp]),
+    "lra_md_string": (C.c_int, [C.c_char_p, C.c_char_p, C.c_uint64, _vp, C.c_uint64, _vp]),
+    "lra_format_pairwise": (C.c_int, [C.c_char_p, C.c_char_p, C.c_int, C.c_int, C.c_int, C.c_uint32, C.c_char_p, C.c_char_p, C.c_char_p, C.c_uint64, _vp,
+                                      C.c_uint64, _vp]),
     "lra_group_alignments": (C.c_int, [_vp, _vp, C.c_int, _vp]),
     "lra_order_alignments": (C.c_int, [_vp, C.c_int, _vp, _vp, C.c_int]),
     "lra_simple_mapqv": (C.c_int, [_vp, _vp, C.c_int, _vp, C.c_int, C.c_int, C.c_int, C.c_int]),

@@ -3,6 +3,7 @@
 // reference's exact SAM / PAF / BED lines without linking the reference's Alignment class.
 //   Alignment::PrintBed :591-598, PrintPAF :600-656, PrintSAM :658-808, SimplePrintSAM :811-905   (Alignment.h)
 #include "common.h"
+#include <algorithm>
 #include <sstream>
 #include <string>
 #include <string.h>
@@ -88,6 +89,7 @@ extern "C" int lra_format_sam(const lra_aln_record* g, int n_group, int as, int 
       << "\tN0:i:" << r.NumOfAnchors0 << "\tRT:i:" << r.runtime << "\tTP:A:" << tp_of(r.typeofaln)
       << "\tSD:i:" << r.nSmallDel << "\tME:i:" << r.nMedDel << "\tLD:i:" << r.nLargeDel << "\tSI:i:" << r.nSmallIns << "\tMI:i:" << r.nMedIns
       << "\tLI:i:" << r.nLargeIns;
+    if (r.md) o << "\tMD:Z:" << r.md;                                    // opts.printMD (:763-767); the string comes from lra_md_string
     if (n_group > 1) o << "\tSA:Z:";
     for (int ag = n_group - 1; ag >= 0; ag--) {
       if (ag == as) continue;
@@ -140,5 +142,103 @@ extern "C" int lra_format_sam_header(const char* version, const char* command_li
   std::ostringstream o;
   o << "@PG\tID:lra\tPN:lra\tVN:" << version << "\tCL:" << command_line << std::endl;
   for (int i = 0; i < n_chrom; i++) o << "@SQ\tSN:" << chrom_names[i] << "\tLN:" << chrom_pos[i + 1] - chrom_pos[i] << std::endl;
+  return deliver(o.str(), out, cap, len);
+}
+
+// ---- alignment strings, MD, pairwise view (Alignment.h:204-245, :247-331, :564-589): host code over one alignment's blocks -------
+namespace {
+int seq_map(unsigned char c) {                                           // seqMap (SeqUtils.h:7-40): non-ACGT -> 0
+  switch (c) {
+    case 1: case 5: case 'C': case 'c': return 1;
+    case 2: case 6: case 'G': case 'g': return 2;
+    case 3: case 7: case 'T': case 't': return 3;
+    default: return 0;
+  }
+}
+void alignment_strings(const char* query, const char* text, const int32_t* B, int nb, std::string& qs, std::string& as, std::string& ts, uint32_t& refLen) {
+  qs.clear(); as.clear(); ts.clear(); refLen = 0;
+  if (nb == 0) return;
+  uint32_t q = (uint32_t)B[0], t = (uint32_t)B[1];
+  auto pair = [&]() { qs.push_back(query[q]); ts.push_back(text[t]); as.push_back(seq_map((unsigned char)query[q]) != seq_map((unsigned char)text[t]) ? '*' : '|'); q++; t++; };
+  for (int b = 0; b < nb; b++) {
+    for (int bl = 0; bl < B[3 * b + 2]; bl++) pair();
+    if (b == nb - 1) continue;
+    int queryGapLen = B[3 * (b + 1)] - B[3 * b] - B[3 * b + 2], textGapLen = B[3 * (b + 1) + 1] - B[3 * b + 1] - B[3 * b + 2];
+    if (queryGapLen > 0 || textGapLen > 0) {
+      int commonGapLen = queryGapLen;
+      if (queryGapLen > textGapLen) commonGapLen = textGapLen;
+      textGapLen -= commonGapLen; queryGapLen -= commonGapLen;
+      for (int g = 0; g < queryGapLen; g++, q++) { ts.push_back('-'); as.push_back(' '); qs.push_back(query[q]); }
+      for (int g = 0; g < textGapLen; g++, t++) { ts.push_back(text[t]); as.push_back(' '); qs.push_back('-'); }
+      for (int g = 0; g < commonGapLen; g++) pair();
+    }
+  }
+  refLen = t - 0;                                                        // refLen = t - refStart with refStart = 0 (:330)
+}
+}  // namespace
+
+// CreateAlignmentStrings (:247-331): blocks = (qPos, tPos, length) triples; the three strings have the same length *len (each buffer
+// needs cap >= *len; call once with NULL buffers for the length).  *ref_len = Alignment::refLen as the reference leaves it.
+extern "C" int lra_alignment_strings(const char* query, const char* text, const int32_t* blocks, int n_blocks, char* q_out, char* a_out, char* t_out,
+                                     uint64_t cap, uint64_t* len, uint32_t* ref_len) {
+  if (!query || !text || n_blocks < 0 || (n_blocks > 0 && !blocks)) return LRA_ERR_INVALID;
+  std::string qs, as, ts; uint32_t rl = 0;
+  alignment_strings(query, text, blocks, n_blocks, qs, as, ts, rl);
+  if (len) *len = qs.size();
+  if (ref_len) *ref_len = rl;
+  if (!q_out || !a_out || !t_out || cap < qs.size()) return qs.empty() ? LRA_OK : LRA_ERR_INVALID;
+  memcpy(q_out, qs.data(), qs.size()); memcpy(a_out, as.data(), as.size()); memcpy(t_out, ts.data(), ts.size());
+  return LRA_OK;
+}
+
+// AlignmentStringsToMD (:204-245), literally (including what it does at the end of the strings: std::string's terminator is read)
+extern "C" int lra_md_string(const char* query_str, const char* ref_str, uint64_t n, char* out, uint64_t cap, uint64_t* len) {
+  if (!query_str || !ref_str) return LRA_ERR_INVALID;
+  std::string query(query_str, (size_t)n), text(ref_str, (size_t)n);
+  for (size_t i = 0; i < query.size(); i++) query[i] = (char)toupper(query[i]);
+  for (size_t i = 0; i < text.size(); i++) text[i] = (char)toupper(text[i]);
+  std::ostringstream md;
+  const std::string& cq = query; const std::string& ct = text;           // const operator[]: [size()] is the terminator
+  int s = 0;
+  while (s < (int)text.size()) {
+    int i = s, match = 0;
+    while ((i < (int)text.size() && ct[i] == cq[i]) || ct[i] == '-') { if (ct[i] == cq[i]) match++; i++; }
+    md << match;
+    s = i;
+    if (ct[i] != cq[i] && ct[i] != '-' && cq[i] != '-') { i++; md << text.substr(s, 1); }
+    else if (ct[i] != '-' && cq[i] == '-') {
+      while (i < (int)text.size() && ct[i] != '-' && cq[i] == '-') i++;
+      md << "^" << text.substr(s, i - s);
+    }
+    while (i < (int)text.size() && ct[i] == '-' && cq[i] == '=') i++;
+    s = i;
+  }
+  return deliver(md.str(), out, cap, len);
+}
+
+// PrintPairwise (:564-589): the 50-column view; first_q / first_t = blocks[0].qPos / tPos (GetQStart / GetTStart), ref_len = refLen
+extern "C" int lra_format_pairwise(const char* read_name, const char* chrom, int n_blocks, int first_q, int first_t, uint32_t ref_len, const char* query_str,
+                                   const char* align_str, const char* ref_str, uint64_t n, char* out, uint64_t cap, uint64_t* len) {
+  if (!read_name || !chrom || !query_str || !align_str || !ref_str) return LRA_ERR_INVALID;
+  const std::string queryString(query_str, (size_t)n), alignString(align_str, (size_t)n), refString(ref_str, (size_t)n);
+  std::ostringstream o;
+  int i = 0, q = 0, t = 0;
+  o << read_name << std::endl;
+  if (n_blocks > 0) o << "Interval:\t" << chrom << ":" << first_t << "-" << (uint32_t)first_t + ref_len << std::endl;
+  const int gq = n_blocks > 0 ? first_q : 0, gt = n_blocks > 0 ? first_t : 0;
+  while (i < (int)queryString.size()) {
+    const int end = std::min((int)queryString.size(), i + 50);
+    const std::string qsub = queryString.substr(i, end - i);
+    o.width(10);
+    o << q + gq << " q: " << qsub << std::endl;
+    q += (int)(qsub.size() - std::count(qsub.begin(), qsub.end(), '-'));
+    o << "              " << alignString.substr(i, end - i) << std::endl;
+    const std::string tsub = refString.substr(i, end - i);
+    o.width(10);
+    o << t + gt << " t: " << tsub << std::endl;
+    t += (int)(tsub.size() - std::count(tsub.begin(), tsub.end(), '-'));
+    o << std::endl;
+    i = end;
+  }
   return deliver(o.str(), out, cap, len);
 }
