@@ -38,6 +38,7 @@ typedef struct lra_ctx lra_ctx;
 #define LRA_ST_NO_TERMINATION 2 /* reference trace back would loop forever              */
 #define LRA_ST_RANGE 4         /* problem too large for the 32-bit device score range   */
 #define LRA_ST_CAPACITY 8      /* caller-provided output capacity exceeded              */
+#define LRA_ST_REJECTED 16     /* the reference drops the item itself (e.g. a cluster spanning two chromosomes) */
 
 /* ---- context ---------------------------------------------------------------------- */
 int lra_ctx_create(int device_id, lra_ctx** out);
@@ -357,6 +358,24 @@ int lra_refine_splitchain_batch(lra_ctx* ctx, const lra_chain_result* chains, co
                                 const uint64_t* h_chrom_pos, int n_chrom, const lra_local_index_result* read_index, uint64_t n_g_windows,
                                 const uint64_t* d_g_seq_off, const uint64_t* d_g_tuple_bnd, const uint32_t* d_g_tuples,
                                 const lra_rsc_opts* opts, lra_refined_result* out);
+
+/* REFINEclusters(clusters, refinedclusters, genome, read, glIndex, localIndexes, smallOpts, opts) (ClusterRefine.h:50-240, called at
+ * Map_highacc.h:429-447): the cluster-wise twin of Refine_splitchain on the high-accuracy path.  Cluster c of read r is d_cluster_off[r] + c:
+ * its matches are (d_q, d_t genome-wide)[d_c_start[c] .. + d_c_count[c]) (n_matches_cap = the extent of those arrays), its box d_qs/d_qe/
+ * d_ts/d_te (genome-wide t), d_c_strand.  read_index / genome index / opts as for lra_refine_splitchain_batch (limitrefine unused).
+ * Output (context-owned, shares buffers with lra_refine_splitchain_batch): per cluster d_chrom (Cluster::CHROMIndex), d_status
+ * (LRA_ST_REJECTED: the cluster spans two chromosomes and is cleared, :61-65; LRA_ST_OOB_SLOT), refined matches CSR (t relative to the
+ * chromosome), box, refineEffiency.  strand / coarse (-1) / refinespace (0) are the caller's.  Synchronous.                          */
+typedef struct lra_refined_clusters_result {
+  uint64_t n_clusters, n_tasks, n_pairs, n_matches;
+  const uint64_t* d_match_off; const uint32_t* d_match_q; const uint32_t* d_match_t;
+  const uint32_t* d_box; const float* d_eff; const uint32_t* d_status; const int32_t* d_chrom;
+} lra_refined_clusters_result;
+int lra_refine_clusters_batch(lra_ctx* ctx, int n_reads, const uint64_t* d_cluster_off, const uint64_t* d_c_start, const uint32_t* d_c_count,
+                              const int32_t* d_c_strand, const uint32_t* d_qs, const uint32_t* d_qe, const uint32_t* d_ts, const uint32_t* d_te,
+                              const uint32_t* d_q, const uint32_t* d_t, uint64_t n_matches_cap, const uint64_t* d_read_off, const uint64_t* h_chrom_pos,
+                              int n_chrom, const lra_local_index_result* read_index, uint64_t n_g_windows, const uint64_t* d_g_seq_off,
+                              const uint64_t* d_g_tuple_bnd, const uint32_t* d_g_tuples, const lra_rsc_opts* opts, lra_refined_clusters_result* out);
 
 /* ---- a11: anchors inside one gap ------------------------------------------------------------------------
  * Replaces   float RefineSpace(int K, int W, int refineSpaceDiag, bool consider_str, GenomePairs& EndPairs, const Options& opts,

@@ -60,6 +60,7 @@ SYMBOLS = {
     "lra_order_alignments": (C.c_int, [_vp, C.c_int, _vp, _vp, C.c_int]),
     "lra_simple_mapqv": (C.c_int, [_vp, _vp, C.c_int, _vp, C.c_int, C.c_int, C.c_int, C.c_int]),
     "lra_output_read": (C.c_int, [_vp, _vp, C.c_int, _vp, C.c_int, C.c_char, C.c_int, C.c_char_p, C.c_int, _vp, _vp, C.c_uint64, _vp]),
+    "lra_refine_clusters_batch": (C.c_int, [_vp, C.c_int] + [_vp] * 10 + [C.c_uint64, _vp, _vp, C.c_int, _vp, C.c_uint64, _vp, _vp, _vp, _vp, _vp]),
     "lra_filter_chains_batch": (C.c_int, [_vp, C.c_uint64, _vp, C.c_uint64, _vp, _vp, _vp, _vp, _vp, _vp, C.c_int, _vp]),
     "lra_calculate_statistics_batch": (C.c_int, [_vp, C.c_int, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, C.c_int, _vp]),
     "lra_local_index_batch": (C.c_int, [_vp, C.c_int, _vp, _vp, C.c_int, C.c_int, C.c_int, C.c_int, _vp]),

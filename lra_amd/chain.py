@@ -214,3 +214,28 @@ def fetch_merge(ctx: Context, res: MergeResult):
             "q": ctx.to_host(res.d_q, na, np.uint32), "t": ctx.to_host(res.d_t, na, np.uint32), "len": ctx.to_host(res.d_len, na, np.int32),
             "box": ctx.to_host(res.d_box, 4 * ng, np.uint32).reshape(-1, 4), "strand": ctx.to_host(res.d_strand, ng, np.int32),
             "chrom": ctx.to_host(res.d_chrom, ng, np.int32)}
+
+
+class RefinedClustersResult(C.Structure):
+    _fields_ = [("n_clusters", C.c_uint64), ("n_tasks", C.c_uint64), ("n_pairs", C.c_uint64), ("n_matches", C.c_uint64)] + [
+        (n, C.c_void_p) for n in ("d_match_off", "d_match_q", "d_match_t", "d_box", "d_eff", "d_status", "d_chrom")]
+
+
+def refine_clusters_batch(ctx: Context, n_reads, cluster_off, c_start, c_count, c_strand, qs, qe, ts, te, q, t, n_matches_cap, read_off, chrom_pos, read_index,
+                          g_seq_off, g_index, window=100, smallK=10, K=17, max_freq=15):
+    """REFINEclusters (ClusterRefine.h:50) for every cluster; array arguments are device tensors or raw device addresses."""
+    cp = np.ascontiguousarray(chrom_pos, dtype=np.uint64)
+    o = RscOpts(int(window), int(smallK), int(K), 0, int(max_freq), int(g_index.window))
+    res = RefinedClustersResult()
+    ctx.check(ctx.lib.lra_refine_clusters_batch(ctx.h, int(n_reads), ptr(cluster_off), ptr(c_start), ptr(c_count), ptr(c_strand), ptr(qs), ptr(qe), ptr(ts), ptr(te),
+                                                ptr(q), ptr(t), C.c_uint64(int(n_matches_cap)), ptr(read_off), C.c_void_p(cp.ctypes.data), len(cp) - 1,
+                                                C.byref(read_index.res), C.c_uint64(g_index.n_windows), ptr(g_seq_off), C.c_void_p(g_index.res.d_tuple_bnd),
+                                                C.c_void_p(g_index.res.d_tuples), C.byref(o), C.byref(res)))
+    return res
+
+
+def fetch_refined_clusters(ctx: Context, res: RefinedClustersResult):
+    nc = res.n_clusters
+    return {"match_off": ctx.to_host(res.d_match_off, nc + 1, np.uint64), "match_q": ctx.to_host(res.d_match_q, res.n_matches, np.uint32),
+            "match_t": ctx.to_host(res.d_match_t, res.n_matches, np.uint32), "box": ctx.to_host(res.d_box, 4 * nc, np.uint32).reshape(-1, 4),
+            "eff": ctx.to_host(res.d_eff, nc, np.float32), "status": ctx.to_host(res.d_status, nc, np.uint32), "chrom": ctx.to_host(res.d_chrom, nc, np.int32)}

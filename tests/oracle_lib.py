@@ -463,6 +463,35 @@ def merge_extend(match_off, mq, mt, box, strand, chrom, read: bytes, genome: byt
                 box=gb.reshape(-1, 4)[:ng].copy(), strand=gs[:ng].copy(), chrom=gc[:ng].copy())
 
 
+class RclOpts(C.Structure):
+    _fields_ = [(n, C.c_int) for n in ("window", "smallK", "K", "maxFreq")]
+
+
+def refine_cluster(mq, mt, box, strand, chrom_pos, read_len, q_index, g_index, window=100, smallK=10, K=17, max_freq=15):
+    """REFINEclusters (ClusterRefine.h:50) for one cluster -> dict(q, t, box, eff, chrom), "rejected" (CHROMIndex) or None (UB)."""
+    L = lib()
+    mq = np.ascontiguousarray(mq, np.uint32); mt = np.ascontiguousarray(mt, np.uint32); bx = np.ascontiguousarray(box, np.uint32)
+    pos = np.ascontiguousarray(chrom_pos, np.uint64)
+    qs, qb, qt = (np.ascontiguousarray(q_index[0], np.uint64), np.ascontiguousarray(q_index[1], np.uint64), np.ascontiguousarray(q_index[2], np.uint32))
+    gs, gb, gt = (np.ascontiguousarray(g_index[0], np.uint64), np.ascontiguousarray(g_index[1], np.uint64), np.ascontiguousarray(g_index[2], np.uint32))
+    o = RclOpts(window, smallK, K, max_freq)
+    cap = 1 << 16
+    while True:
+        oq = np.zeros(cap, np.uint32); ot = np.zeros(cap, np.uint32); ob = np.zeros(4, np.uint32); eff = C.c_float(0); ch = C.c_int(0)
+        L.oracle_refine_cluster.restype = C.c_long
+        n = L.oracle_refine_cluster(C.c_int(len(mq)), _p(mq, C.c_uint32), _p(mt, C.c_uint32), _p(bx, C.c_uint32), C.c_int(int(strand)), _p(pos, C.c_uint64),
+                                    C.c_int(len(pos) - 1), C.c_uint32(int(read_len)), C.c_long(len(qs) - 1), _p(qs, C.c_uint64), _p(qb, C.c_uint64),
+                                    _p(qt, C.c_uint32), C.c_long(len(gs) - 1), _p(gs, C.c_uint64), _p(gb, C.c_uint64), _p(gt, C.c_uint32), C.byref(o),
+                                    C.c_long(cap), C.byref(ch), _p(oq, C.c_uint32), _p(ot, C.c_uint32), _p(ob, C.c_uint32), C.byref(eff))
+        if n == -2:
+            return "rejected"
+        if n < 0:
+            return None
+        if n <= cap:
+            return dict(q=oq[:n].copy(), t=ot[:n].copy(), box=ob.copy(), eff=np.float32(eff.value), chrom=ch.value)
+        cap = int(n)
+
+
 # ---- chain post-filters + SPLITChain (a9, low-accuracy path) ----------------------------------------------------------
 def split_chain(q, t, length, strand, cluster, link, chrom_pos, splitdist=50000, bypass=1):
     """One chain (trace-back order) -> dict(keep, link, splits=[dict(idx, link, type, strand, chrom, box, clusters)], split_link) or None (UB)."""

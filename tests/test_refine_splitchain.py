@@ -391,3 +391,52 @@ def test_hip_lowacc_chain_bench_like_sample(ctx, oracle):
                 assert np.array_equal(mo["len"][a0:a0 + cnt], expm["len"][e0:e1]) and np.array_equal(mo["box"][g0 + g], expm["box"][g])
             n_checked += 1
     assert n_checked >= 12
+
+
+@pytest.mark.gpu
+def test_hip_refine_clusters_oracle(ctx, oracle):
+    """REFINEclusters (high-accuracy path) on the clusters the GPU's CleanMatches produced (two chromosomes; a few clusters are made to span
+    the chromosome boundary so that CHROMIndex rejects them), against the oracle cluster by cluster"""
+    import torch
+    from lra_amd import chain, cluster
+    P = _front_end(ctx, oracle)
+    cres, batch, CH, rli, gso_d, gli, n, lens = (P[k] for k in ("cres", "batch", "CH", "rli", "gso_d", "gli", "n", "lens"))
+    r_win, r_bnd, r_tup, gso, g_bnd, g_tup = (P[k] for k in ("r_win", "r_bnd", "r_tup", "gso", "g_bnd", "g_tup"))
+    co = cluster.fetch(ctx, cres)
+    nc = int(cres.n_clusters)
+    dev = ctx.device
+    cnt = (co["end"] - co["start"]).astype(np.int32)
+    ts = co["tStart"].copy(); te = co["tEnd"].copy()
+    rej = [c for c in range(nc) if ts[c] < CH[1] < te[c] + 4000][:3]                # stretch a few boxes across the chromosome boundary
+    for c in rej: te[c] = max(te[c], CH[1] + 50)
+    tt = lambda a, dt: torch.from_numpy(np.ascontiguousarray(a, dtype=dt)).to(dev)
+    d_cnt = tt(cnt, np.int32); d_ts = tt(ts.astype(np.int32), np.int32); d_te = tt(te.astype(np.int32), np.int32)
+    res = chain.refine_clusters_batch(ctx, n, cres.d_cluster_off, cres.d_c_start, d_cnt, cres.d_c_strand, cres.d_c_qStart, cres.d_c_qEnd, d_ts, d_te,
+                                      cres.d_cl_qpos, cres.d_cl_tpos, int(cres.n_matches), batch.off, CH, rli, gso_d, gli, window=100, smallK=10, K=K, max_freq=15)
+    out = chain.fetch_refined_clusters(ctx, res)
+    coff = co["cluster_off"]
+    n_ok = n_rev = n_rej = n_matches = 0
+    for r in range(n):
+        for c in range(int(coff[r]), int(coff[r + 1])):
+            a, b = int(co["start"][c]), int(co["end"][c])
+            strand = int(co["strand"][c])
+            w0, w1 = int(r_win[strand * n + r]), int(r_win[strand * n + r + 1])
+            q_index = (_seq_offsets([0], lens[r], 256), r_bnd[w0:w1 + 1] - r_bnd[w0], r_tup[int(r_bnd[w0]):int(r_bnd[w1])])
+            exp = O.refine_cluster(co["cl_qpos"][a:b], co["cl_tpos"][a:b], [co["qStart"][c], co["qEnd"][c], ts[c], te[c]], strand, CH, lens[r], q_index,
+                                   (gso, g_bnd, g_tup), window=100, smallK=10, K=K, max_freq=15)
+            m0, m1 = int(out["match_off"][c]), int(out["match_off"][c + 1])
+            if exp == "rejected":
+                assert out["status"][c] == 16 and m1 == m0, c
+                n_rej += 1
+                continue
+            if exp is None:
+                assert out["status"][c] == 1 and m1 == m0, c
+                continue
+            assert out["status"][c] == 0, (c, out["status"][c])
+            assert m1 - m0 == len(exp["q"]), (c, m1 - m0, len(exp["q"]))
+            assert np.array_equal(out["match_q"][m0:m1], exp["q"]) and np.array_equal(out["match_t"][m0:m1], exp["t"]), c
+            assert out["chrom"][c] == exp["chrom"]
+            if m1 > m0:
+                assert np.array_equal(out["box"][c], exp["box"]) and out["eff"][c].view(np.uint32) == exp["eff"].view(np.uint32), c
+            n_ok += 1; n_rev += strand; n_matches += m1 - m0
+    assert n_ok >= 100 and n_rev >= 20 and n_matches > 20000, (n_ok, n_rev, n_rej, n_matches)
