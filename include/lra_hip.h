@@ -284,6 +284,7 @@ int lra_split_chains_batch(lra_ctx* ctx, const lra_chain_result* chains, const u
 /* The chain filters of Chain.h on arbitrary chains (CSR d_off[n_chains+1] over anchors given by read pos, genome pos, length, strand of the
  * cluster, trace-back order; d_link[i] = link bit between anchor i and i+1 of the same chain, NULL if the chain type has none), applied in
  * the order h_ops[0..n_ops):  1 RemoveSmallPairedIndels (:546)   2 RemovePairedIndels (:607)   3 the same with refineEnds = false
+ *   5 RemovePairedIndels(GenomePairs&, chain, lengths) (:753-811; strand and link are not read)
  * 4 RemoveSpuriousAnchors (:828; leaves `link` longer than the chain, as the reference does)   8 RemoveSpuriousJump (:897).
  * Map_lowacc.h:538-539 = {2, 4};  LocalRefineAlignment.h:567-571 = {1, 2 (or 3), 4}.
  * Output (context-owned; shares its buffer with lra_split_chains_batch): d_keep per anchor, d_n_kept per chain, the surviving links
@@ -443,6 +444,9 @@ typedef struct lra_merge_result {
   const uint32_t* d_box; const int32_t* d_strand; const int32_t* d_chrom;   /* [4*n_groups], [n_groups] */
   const uint64_t* d_iota;             /* [n_groups+1] 0, 1, 2, ... */
 } lra_merge_result;
+/* TrimOverlappedAnchors(GenomePairs&, vector<int>&) (LinearExtend.h:722-780; used at LocalRefineAlignment.h:371): n_lists anchor lists in CSR
+ * d_off, lengths trimmed in place.  Synchronous.                                                                                          */
+int lra_trim_anchor_pairs_batch(lra_ctx* ctx, uint64_t n_lists, const uint64_t* d_off, uint64_t n_anchors, uint32_t* d_q, uint32_t* d_t, int32_t* d_len);
 int lra_merge_extend_batch(lra_ctx* ctx, const lra_chain_result* chains, const lra_split_result* split, const lra_btwn_result* refined, const char* d_seq,
                            const uint64_t* d_read_off, const char* d_genome, const uint64_t* h_chrom_pos, int n_chrom, int K, lra_merge_result* out);
 

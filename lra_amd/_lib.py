@@ -50,6 +50,7 @@ SYMBOLS = {
     "lra_split_clusters_batch": (C.c_int, [_vp, C.c_int, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, C.c_int, C.c_int, _vp]),
     "lra_refine_splitchain_batch": (C.c_int, [_vp, _vp, _vp, _vp, _vp, C.c_int, _vp, C.c_uint64, _vp, _vp, _vp, _vp, _vp]),
     "lra_refine_btwn_splitchain_batch": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, C.c_uint64, _vp, _vp, C.c_int, _vp, _vp]),
+    "lra_trim_anchor_pairs_batch": (C.c_int, [_vp, C.c_uint64, _vp, C.c_uint64, _vp, _vp, _vp]),
     "lra_merge_extend_batch": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, C.c_int, C.c_int, _vp]),
     "lra_format_sam_header": (C.c_int, [C.c_char_p, C.c_char_p, _vp, _vp, C.c_int, _vp, C.c_uint64, _vp]),
     "lra_alignment_strings": (C.c_int, [C.c_char_p, C.c_char_p, _vp, C.c_int, _vp, _vp, _vp, C.c_uint64, _vp, _vp]),

@@ -264,7 +264,27 @@ __global__ void __launch_bounds__(64) filter_kernel(FilterArgs a) {
       sdDist = __fsqrt_rn(varDist);
     }
     int pSV = 0, pPos = -1; bool have = false;
-    for (int c = 1; c < N; c++) {
+    if (op == 5) {                                                       // RemovePairedIndels(GenomePairs&, chain, lengths)  Chain.h:753-811
+      int pG = 0;
+      for (int c = 1; c < N; c++) {
+        const int Gap = (int)(((long long)XT(c) - (long long)XQ(c)) - ((long long)XT(c - 1) - (long long)XQ(c - 1)));
+        if (abs(Gap) <= 30) continue;
+        const int sv = Gap, g = (int)XT(c);
+        if (have) {
+          const int blink = max(abs(sv), abs(pSV));
+          const bool pos = sv >= 0, differ = (sv >= 0) != (pSV >= 0);
+          const int lim = max(2 * blink, 1000);
+          const int dIns = abs(g - pG), dDel = abs(g - sv - pG);
+          bool hit = false;
+          if (differ && abs(sv + pSV) < 600 && abs(sv) != 0 && pSV != 0) hit = (pos && dIns < lim) || (!pos && dDel < lim);
+          else if (differ && sv != 0 && pSV != 0 && ((pos && dIns < 500) || (!pos && dDel < 500))) hit = true;
+          else if (!differ && sv != 0 && pSV != 0) hit = (pos && dIns < lim) || (!pos && dDel < lim);
+          if (hit) for (int i = pPos; i < c; i++) if (XL(i) < 100) rm[i] = 1;
+        }
+        pSV = sv; pPos = c; pG = g; have = true;
+      }
+    }
+    for (int c = 1; c < N && op != 5; c++) {
       int sv = 0; bool is = false;
       if (XS(c) == XS(c - 1)) {
         const int Gap = gap_of(c), ag = abs(Gap);
@@ -300,7 +320,7 @@ __global__ void __launch_bounds__(64) filter_kernel(FilterArgs a) {
       if (firstValid > 0 && firstValid < 3) for (int i = 0; i < firstValid; i++) if (XL(i) < 100) rm[i] = 1;
       if (lastValid + 1 <= N && N - lastValid < 3) for (int i = lastValid + 1; i < N; i++) if (XL(i) < 100) rm[i] = 1;
     }
-    const bool touchLink = op != 4;
+    const bool touchLink = op != 4 && op != 5;
     int m = 0;
     for (int i = 0; i < N; i++)
       if (!rm[i]) {
@@ -369,7 +389,7 @@ extern "C" int lra_filter_chains_batch(lra_ctx* ctx, uint64_t n_chains, const ui
                                        const int32_t* d_len, const uint8_t* d_strand, const uint8_t* d_link, const int32_t* h_ops, int n_ops,
                                        lra_filter_result* out) {
   if (!ctx || !out || !h_ops || n_ops < 0 || n_ops > 8) return LRA_ERR_INVALID;
-  for (int i = 0; i < n_ops; i++) if (h_ops[i] != 1 && h_ops[i] != 2 && h_ops[i] != 3 && h_ops[i] != 4 && h_ops[i] != 8) return lra_set_err(ctx, LRA_ERR_INVALID, "unknown chain filter %d", h_ops[i]);
+  for (int i = 0; i < n_ops; i++) if (h_ops[i] != 1 && h_ops[i] != 2 && h_ops[i] != 3 && h_ops[i] != 4 && h_ops[i] != 5 && h_ops[i] != 8) return lra_set_err(ctx, LRA_ERR_INVALID, "unknown chain filter %d", h_ops[i]);
   memset(out, 0, sizeof *out);
   out->n_chains = n_chains; out->n_anchors = n_anchors;
   if (n_chains == 0) return LRA_OK;

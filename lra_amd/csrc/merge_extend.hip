@@ -141,16 +141,18 @@ struct LongLess {                                                        // Long
 };
 
 // TrimOverlappedAnchors LinearExtend.h:574-649, one lane per merged cluster
-__global__ void me_trim(uint64_t ng, MeArgs a) {
+// (the GenomePairs version :722-780 is the same walk with strand 0 and long = 50: gstrand == NULL, minLen = 50)
+__global__ void me_trim(uint64_t ng, const uint64_t* __restrict__ anchorOff, uint32_t* aq, uint32_t* at, int32_t* alen, const int32_t* __restrict__ gstrand,
+                        uint64_t* scratch, int minLen) {
   const uint64_t g = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (g >= ng) return;
-  const uint64_t b = a.anchorOff[g];
-  const uint32_t n = (uint32_t)(a.anchorOff[g + 1] - b);
-  uint32_t* Q = a.aq + b; uint32_t* T = a.at + b; int32_t* L = a.alen + b;
-  uint64_t* idx = a.scratch + b;
-  const int S = a.gstrand[g];
+  const uint64_t b = anchorOff[g];
+  const uint32_t n = (uint32_t)(anchorOff[g + 1] - b);
+  uint32_t* Q = aq + b; uint32_t* T = at + b; int32_t* L = alen + b;
+  uint64_t* idx = scratch + b;
+  const int S = gstrand ? gstrand[g] : 0;
   uint32_t m = 0;
-  for (uint32_t i = 0; i < n; i++) if (L[i] >= 40) idx[m++] = i;
+  for (uint32_t i = 0; i < n; i++) if (L[i] >= minLen) idx[m++] = i;
   LongLess lt{Q, T, L, S};
   lra_std_sort::std_sort(idx, (long)m, lt);
   for (uint32_t ln = 1; ln < m; ln++) {
@@ -260,7 +262,7 @@ extern "C" int lra_merge_extend_batch(lra_ctx* ctx, const lra_chain_result* ch, 
   a.aq = (uint32_t*)take(wa, NA + 1, 4); a.at = (uint32_t*)take(wa, NA + 1, 4); a.alen = (int32_t*)take(wa, NA + 1, 4);
   lra_time_begin(ctx, "merge_extend");
   hipLaunchKernelGGL(me_concat, dim3((unsigned)std::min<uint64_t>(NG, (uint64_t)ctx->num_cu * 32)), dim3(64), 0, st, NG, a);
-  hipLaunchKernelGGL(me_trim, dim3((unsigned)((NG + 63) / 64)), dim3(64), 0, st, NG, a);
+  hipLaunchKernelGGL(me_trim, dim3((unsigned)((NG + 63) / 64)), dim3(64), 0, st, NG, (const uint64_t*)anchorOff, a.aq, a.at, a.alen, (const int32_t*)a.gstrand, a.scratch, 40);
   hipLaunchKernelGGL(me_iota, dim3((unsigned)((NG + 256) / 256)), dim3(256), 0, st, NG, iota);
   lra_time_end(ctx);
   LRA_HIP_CHECK(ctx, hipStreamSynchronize(st));
@@ -268,5 +270,21 @@ extern "C" int lra_merge_extend_batch(lra_ctx* ctx, const lra_chain_result* ch, 
   out->n_anchors = NA; out->d_anchor_off = anchorOff; out->d_count = a.gSize; out->d_q = a.aq; out->d_t = a.at; out->d_len = a.alen; out->d_box = a.gbox;
   out->d_strand = a.gstrand; out->d_chrom = a.gchrom; out->d_group_slot = a.gSlot; out->d_group_first = a.gFirst; out->d_group_last = a.gLast; out->d_cluster_base = clBase;
   out->d_iota = iota;
+  return LRA_OK;
+}
+
+// TrimOverlappedAnchors(GenomePairs& ExtendPairs, vector<int>& ExtendPairsMatchesLengths) (LinearExtend.h:722-780) on n_lists anchor lists
+// (CSR d_off; lengths are modified in place).  Used inside RefinedAlignmentbtwnAnchors (LocalRefineAlignment.h:371).
+extern "C" int lra_trim_anchor_pairs_batch(lra_ctx* ctx, uint64_t n_lists, const uint64_t* d_off, uint64_t n_anchors, uint32_t* d_q, uint32_t* d_t, int32_t* d_len) {
+  if (!ctx) return LRA_ERR_INVALID;
+  if (n_lists == 0 || n_anchors == 0) return LRA_OK;
+  LRA_HIP_CHECK(ctx, hipSetDevice(ctx->device));
+  uint64_t* scratch = (uint64_t*)lra_scratch(ctx, 2, (n_anchors + 1) * 8);
+  if (!scratch) return LRA_ERR_NOMEM;
+  lra_time_begin(ctx, "merge_extend");
+  hipLaunchKernelGGL(me_trim, dim3((unsigned)((n_lists + 63) / 64)), dim3(64), 0, ctx->stream, n_lists, d_off, d_q, d_t, d_len, (const int32_t*)nullptr, scratch, 50);
+  lra_time_end(ctx);
+  LRA_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+  LRA_HIP_CHECK(ctx, hipGetLastError());
   return LRA_OK;
 }

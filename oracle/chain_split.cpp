@@ -297,6 +297,29 @@ extern "C" int oracle_filter_chain(int n, const uint32_t* q, const uint32_t* t, 
         if (firstValid > 0 && firstValid < 3) for (int i = 0; i < firstValid; i++) if (ch[i].len < 100) remove[i] = true;
         if (lastValid + 1 <= N && N - lastValid < 3) for (int i = lastValid + 1; i < N; i++) if (ch[i].len < 100) remove[i] = true;
       }
+    } else if (op == 5) {                                                  // RemovePairedIndels(GenomePairs&, chain, lengths)  Chain.h:753-811
+      touchLink = false;
+      std::vector<int> SVgenome;
+      for (int c = 1; c < N; c++) {
+        int Gap = (int)(((long)tS(c) - (long)qS(c)) - ((long)tS(c - 1) - (long)qS(c - 1)));
+        if (std::abs(Gap) > 30) { SV.push_back(Gap); SVgenome.push_back((int)tS(c)); SVpos.push_back(c); }
+      }
+      auto sg = [](int x) { return x >= 0; };
+      for (size_t c = 1; c < SV.size(); c++) {
+        int blink = std::max(std::abs(SV[c]), std::abs(SV[c - 1]));
+        if (sg(SV[c]) != sg(SV[c - 1]) && std::abs(SV[c] + SV[c - 1]) < 600 && std::abs(SV[c]) != 0 && SV[c - 1] != 0) {
+          if ((sg(SV[c]) == true && std::abs(SVgenome[c] - SVgenome[c - 1]) < std::max(2 * blink, 1000)) ||
+              (sg(SV[c]) == false && std::abs(SVgenome[c] - SV[c] - SVgenome[c - 1]) < std::max(2 * blink, 1000)))
+            for (int i = SVpos[c - 1]; i < SVpos[c]; i++) if (ch[i].len < 100) remove[i] = true;
+        } else if (sg(SV[c]) != sg(SV[c - 1]) && SV[c] != 0 && SV[c - 1] != 0 &&
+                   ((sg(SV[c]) == true && std::abs(SVgenome[c] - SVgenome[c - 1]) < 500) || (sg(SV[c]) == false && std::abs(SVgenome[c] - SV[c] - SVgenome[c - 1]) < 500))) {
+          for (int i = SVpos[c - 1]; i < SVpos[c]; i++) if (ch[i].len < 100) remove[i] = true;
+        } else if (sg(SV[c]) == sg(SV[c - 1]) && SV[c] != 0 && SV[c - 1] != 0) {
+          if ((sg(SV[c]) == true && std::abs(SVgenome[c] - SVgenome[c - 1]) < std::max(2 * blink, 1000)) ||
+              (sg(SV[c]) == false && std::abs(SVgenome[c] - SV[c] - SVgenome[c - 1]) < std::max(2 * blink, 1000)))
+            for (int i = SVpos[c - 1]; i < SVpos[c]; i++) if (ch[i].len < 100) remove[i] = true;
+        }
+      }
     } else if (op == 4) {
       touchLink = false;
       for (int c = 1; c < N; c++) {

@@ -105,3 +105,17 @@ extern "C" int oracle_merge_extend(int nsp, const int* matchOff, const uint32_t*
   }
   return (int)groups.size();
 }
+
+// TrimOverlappedAnchors(GenomePairs&, vector<int>&) LinearExtend.h:722-780: one list, lengths modified in place
+extern "C" void oracle_trim_anchor_pairs(int n, const uint32_t* Q, const uint32_t* T, int* L) {
+  std::vector<int> idx;
+  for (int i = 0; i < n; i++) if (L[i] >= 50) idx.push_back(i);
+  std::sort(idx.begin(), idx.end(), [&](int i, int j) { if (Q[i] != Q[j]) return Q[i] < Q[j]; return T[i] < T[j]; });   // LongAnchors, strand 0
+  for (size_t ln = 1; ln < idx.size(); ln++) {
+    const int prev = idx[ln - 1], cur = idx[ln];
+    int overlap_r = 0, overlap_g = 0;
+    if (Q[cur] < Q[prev] + L[prev] && Q[cur] >= Q[prev] + L[prev] - 30) overlap_r = (int)(Q[prev] + L[prev] - Q[cur]);
+    if (T[cur] < T[prev] + L[prev] && T[cur] >= T[prev] + L[prev] - 30) overlap_g = (int)(T[prev] + L[prev] - T[cur]);
+    if (overlap_r > 0 || overlap_g > 0) L[prev] -= std::max(overlap_r, overlap_g) + 1;
+  }
+}

@@ -156,7 +156,7 @@ def test_hip_filter_chains_oracle(ctx):
     d = dict(off=tt(off.astype(np.int64)), q=tt(cat(0, np.int64)).to(torch.int32), t=tt(cat(1, np.int64)).to(torch.int32), ln=tt(cat(2, np.int32)),
              st=tt(cat(3, np.uint8)), lk=tt(link))
     removed = 0
-    for ops, with_link in (([2, 4], True), ([1, 2, 4], False), ([1, 3, 4], True), ([8], True), ([4, 8, 1], True), ([2], True)):
+    for ops, with_link in (([2, 4], True), ([1, 2, 4], False), ([1, 3, 4], True), ([8], True), ([4, 8, 1], True), ([2], True), ([5], False), ([5, 4], True)):
         res = chain.filter_chains_batch(ctx, len(chains), d["off"], int(off[-1]), d["q"], d["t"], d["ln"], d["st"], d["lk"] if with_link else None, ops)
         out = chain.fetch_filter(ctx, res)
         for i, c in enumerate(chains):
@@ -168,3 +168,40 @@ def test_hip_filter_chains_oracle(ctx):
             assert out["link"][a:a + len(lk)].tolist() == lk.tolist(), (ops, i)
             removed += int((keep == 0).sum())
     assert removed > 300
+
+
+@pytest.mark.gpu
+def test_hip_trim_anchor_pairs_oracle(ctx):
+    """TrimOverlappedAnchors(GenomePairs&, lengths) LinearExtend.h:722: lists of anchors, some long ones overlapping by up to 30 on either axis,
+    equal (q, t) keys with different lengths included (the tie the exact std::sort decides)"""
+    import ctypes as C
+    import torch
+    rng = np.random.default_rng(4)
+    lists = []
+    for _ in range(200):
+        n = int(rng.integers(0, 60))
+        q = 100; t = 5000; Q = []; T = []; L = []
+        for i in range(n):
+            ln = int(rng.choice([12, 30, 49, 50, 51, 80, 140]))
+            Q.append(q); T.append(t); L.append(ln)
+            if rng.random() < 0.1: Q.append(q); T.append(t); L.append(int(rng.choice([50, 75])))          # same corner, another length
+            q += ln + int(rng.choice([-25, -10, -1, 0, 3, 40])); t += ln + int(rng.choice([-30, -12, 0, 5, 60]))
+        p = rng.permutation(len(Q))
+        lists.append((np.array(Q, np.uint32)[p], np.array(T, np.uint32)[p], np.array(L, np.int32)[p]))
+    off = np.cumsum([0] + [len(l[0]) for l in lists]).astype(np.int64)
+    dev = ctx.device
+    cat = lambda j, dt: torch.from_numpy(np.concatenate([l[j] for l in lists]).astype(dt)).to(dev)
+    dq = cat(0, np.int64).to(torch.int32); dt_ = cat(1, np.int64).to(torch.int32); dl = cat(2, np.int32)
+    doff = torch.from_numpy(off).to(dev)
+    ctx.check(ctx.lib.lra_trim_anchor_pairs_batch(ctx.h, C.c_uint64(len(lists)), C.c_void_p(doff.data_ptr()), C.c_uint64(int(off[-1])), C.c_void_p(dq.data_ptr()),
+                                                  C.c_void_p(dt_.data_ptr()), C.c_void_p(dl.data_ptr())))
+    got = dl.cpu().numpy()
+    L_ = O.lib()
+    changed = 0
+    for i, (Q, T, Ln) in enumerate(lists):
+        e = Ln.copy()
+        Qc = np.ascontiguousarray(Q); Tc = np.ascontiguousarray(T)
+        L_.oracle_trim_anchor_pairs(C.c_int(len(Q)), Qc.ctypes.data_as(C.POINTER(C.c_uint32)), Tc.ctypes.data_as(C.POINTER(C.c_uint32)), e.ctypes.data_as(C.POINTER(C.c_int)))
+        assert np.array_equal(got[off[i]:off[i + 1]], e), i
+        changed += int((e != Ln).sum())
+    assert changed > 100
