@@ -397,6 +397,11 @@ int lra_refine_space_batch(lra_ctx* ctx, int n, const char* d_qseq, const uint64
                            const uint64_t* d_t_off, const int32_t* d_t_len, const uint32_t* d_t_span, const int32_t* d_K, const int32_t* d_W,
                            const int32_t* d_diag, const uint32_t* d_q_add, const uint32_t* d_t_add, const uint32_t* d_flip_len, int match,
                            int mismatch, int indel, int max_freq, lra_refine_space_result* out);
+/* the same with opts.localMaxFreq given per gap (d_max_freq[n]) */
+int lra_refine_space_batch_mf(lra_ctx* ctx, int n, const char* d_qseq, const uint64_t* d_q_off, const int32_t* d_q_len, const char* d_tseq,
+                              const uint64_t* d_t_off, const int32_t* d_t_len, const uint32_t* d_t_span, const int32_t* d_K, const int32_t* d_W,
+                              const int32_t* d_diag, const uint32_t* d_q_add, const uint32_t* d_t_add, const uint32_t* d_flip_len, int match,
+                              int mismatch, int indel, const int32_t* d_max_freq, lra_refine_space_result* out);
 
 /* Refine_Btwnsplitchain(spchain, refined_clusters, RevBtwnCluster, tracerev, genome, read, smallOpts, strands, spchain_link)
  * (ChainRefine.h:579-754, called at Map_lowacc.h:362) for every chain of the batch: for each pair of neighbouring refined clusters the
@@ -485,6 +490,34 @@ int lra_between_anchors_batch(lra_ctx* ctx, int n, const char* d_qseq, const uin
                               const uint32_t* d_next_read_start, const char* d_tseq, const uint64_t* d_t_base, const uint32_t* d_cur_genome_end,
                               const uint32_t* d_next_genome_start, int match, int mismatch, int indel, int local_band, int refine_dp,
                               lra_between_result* out);
+
+/* ---- a13: the chain walk that turns the second sparse DP's chains into alignments ------------------------------------------------
+ * Replaces   LocalRefineAlignment(ultimatechains, ext_clusters, alignments, smallOpts, LookUpTable, read, strands, h, genome, LSC, tinyOpts,
+ *                                 buff, svsigstrm)                                   (LocalRefineAlignment.h:885-1029, Map_lowacc.h:576)
+ * including RefinedAlignmentbtwnAnchors (:203-550) for n_jobs primary chains.  Job j (primary chain h = d_job_h[j] of read d_job_read[j]) has
+ * the chains d_job_chain_off[j] .. d_job_chain_off[j+1] (ultimatechains[st], after RemovePairedIndels / RemoveSpuriousAnchors); chain c has
+ * the anchors d_chain_anchor_off[c] .. (q on the forward read, t chromosome-relative, length; chain order = trace-back order), its cluster's
+ * strand and chromIndex, FirstSDPValue, NumOfAnchors0, NumOfAnchors1.  d_strands = the reads forward, then (at rc_base) reverse complemented.
+ * opts = tinyOpts: localW / globalW / localMaxFreq on entry, localMatch / localMismatch / localIndel / localBand, RefineBySDP, readType
+ * (is_ont: clr / ont vs contig / ccs), and the PWL parameters of the sparse DP.
+ * Output (context-owned): the SegAlignments each job pushes, in order: alignments d_job_aln_off[j] .. d_job_aln_off[j+1], each with strand,
+ * Supplymentary, ISsecondary, NumOfAnchors0 / 1, chromIndex, value and its blocks (qPos, tPos, length) d_block_off[a] .. d_block_off[a+1].
+ * d_status[j] != 0: the reference would read outside an array on that job.  Synchronous.                                             */
+typedef struct lra_lra_opts {
+  int32_t localW, globalW, localMaxFreq, match, mismatch, indel, localBand, refineBySDP, isOnt;
+  float gapopen, gapextend, gaproot; int32_t gapCeiling1, gapCeiling2;
+} lra_lra_opts;
+typedef struct lra_alignments_result {
+  uint64_t n_jobs, n_alignments, n_blocks, n_big, n_inner_jobs;
+  const uint64_t* d_job_aln_off;
+  const int32_t* d_strand; const int32_t* d_supp; const int32_t* d_secondary; const int32_t* d_n0; const int32_t* d_n1; const int32_t* d_chrom; const float* d_value;
+  const uint64_t* d_block_off; const int32_t* d_blocks; const uint32_t* d_status;
+} lra_alignments_result;
+int lra_local_refine_batch(lra_ctx* ctx, uint64_t n_jobs, const uint64_t* d_job_chain_off, const uint32_t* d_job_read, const int32_t* d_job_h, uint64_t n_chains,
+                           const uint64_t* d_chain_anchor_off, const int32_t* d_chain_strand, const int32_t* d_chain_chrom, const float* d_chain_value,
+                           const int32_t* d_chain_n0, const int32_t* d_chain_n1, uint64_t n_anchors, const uint32_t* d_q, const uint32_t* d_t, const int32_t* d_len,
+                           const uint64_t* d_read_off, const char* d_strands, uint64_t rc_base, const char* d_genome, const uint64_t* h_chrom_pos, int n_chrom,
+                           const lra_lra_opts* opts, lra_alignments_result* out);
 
 /* ---- a14: banded 3-state affine indel refinement ----------------------------------------
  * Replaces   void IndelRefineAlignment(Read& read, Genome& genome, Alignment& alignment,

@@ -44,6 +44,7 @@ SYMBOLS = {
     "lra_format_paf": (C.c_int, [_vp, C.c_int, _vp, C.c_uint64, _vp]),
     "lra_format_bed": (C.c_int, [_vp, _vp, C.c_uint64, _vp]),
     "lra_refine_space_batch": (C.c_int, [_vp, C.c_int] + [_vp] * 13 + [C.c_int] * 4 + [_vp]),
+    "lra_refine_space_batch_mf": (C.c_int, [_vp, C.c_int] + [_vp] * 13 + [C.c_int] * 3 + [_vp, _vp]),
     "lra_between_anchors_batch": (C.c_int, [_vp, C.c_int] + [_vp] * 8 + [C.c_int] * 5 + [_vp]),
     "lra_refine_breakpoint_batch": (C.c_int, [_vp, C.c_int] + [_vp] * 16),
     "lra_sparse_dp_boxes_batch": (C.c_int, [_vp, C.c_int, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
@@ -62,6 +63,8 @@ SYMBOLS = {
     "lra_simple_mapqv": (C.c_int, [_vp, _vp, C.c_int, _vp, C.c_int, C.c_int, C.c_int, C.c_int]),
     "lra_output_read": (C.c_int, [_vp, _vp, C.c_int, _vp, C.c_int, C.c_char, C.c_int, C.c_char_p, C.c_int, _vp, _vp, C.c_uint64, _vp]),
     "lra_refine_clusters_batch": (C.c_int, [_vp, C.c_int] + [_vp] * 10 + [C.c_uint64, _vp, _vp, C.c_int, _vp, C.c_uint64, _vp, _vp, _vp, _vp, _vp]),
+    "lra_local_refine_batch": (C.c_int, [_vp, C.c_uint64, _vp, _vp, _vp, C.c_uint64, _vp, _vp, _vp, _vp, _vp, _vp, C.c_uint64, _vp, _vp, _vp, _vp, _vp, C.c_uint64, _vp, _vp,
+                                         C.c_int, _vp, _vp]),
     "lra_filter_chains_batch": (C.c_int, [_vp, C.c_uint64, _vp, C.c_uint64, _vp, _vp, _vp, _vp, _vp, _vp, C.c_int, _vp]),
     "lra_calculate_statistics_batch": (C.c_int, [_vp, C.c_int, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, C.c_int, _vp]),
     "lra_local_index_batch": (C.c_int, [_vp, C.c_int, _vp, _vp, C.c_int, C.c_int, C.c_int, C.c_int, _vp]),

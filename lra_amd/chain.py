@@ -239,3 +239,41 @@ def fetch_refined_clusters(ctx: Context, res: RefinedClustersResult):
     return {"match_off": ctx.to_host(res.d_match_off, nc + 1, np.uint64), "match_q": ctx.to_host(res.d_match_q, res.n_matches, np.uint32),
             "match_t": ctx.to_host(res.d_match_t, res.n_matches, np.uint32), "box": ctx.to_host(res.d_box, 4 * nc, np.uint32).reshape(-1, 4),
             "eff": ctx.to_host(res.d_eff, nc, np.float32), "status": ctx.to_host(res.d_status, nc, np.uint32), "chrom": ctx.to_host(res.d_chrom, nc, np.int32)}
+
+
+class LraOpts(C.Structure):
+    _fields_ = [(n, C.c_int32) for n in ("localW", "globalW", "localMaxFreq", "match", "mismatch", "indel", "localBand", "refineBySDP", "isOnt")] + [
+        ("gapopen", C.c_float), ("gapextend", C.c_float), ("gaproot", C.c_float), ("gapCeiling1", C.c_int32), ("gapCeiling2", C.c_int32)]
+
+
+ONT_LRA = dict(localW=5, globalW=5, localMaxFreq=15, match=4, mismatch=-1, indel=-2, localBand=15, refineBySDP=1, isOnt=1, gapopen=7.0, gapextend=10.0, gaproot=1.5,
+               gapCeiling1=1500, gapCeiling2=3000)
+
+
+class AlignmentsResult(C.Structure):
+    _fields_ = [("n_jobs", C.c_uint64), ("n_alignments", C.c_uint64), ("n_blocks", C.c_uint64), ("n_big", C.c_uint64), ("n_inner_jobs", C.c_uint64)] + [
+        (n, C.c_void_p) for n in ("d_job_aln_off", "d_strand", "d_supp", "d_secondary", "d_n0", "d_n1", "d_chrom", "d_value", "d_block_off", "d_blocks", "d_status")]
+
+
+def local_refine_batch(ctx: Context, job_chain_off, job_read, job_h, chain_anchor_off, chain_strand, chain_chrom, chain_value, chain_n0, chain_n1, q, t, length,
+                       read_off, strands, rc_base, genome, chrom_pos, **kw):
+    """LocalRefineAlignment (LocalRefineAlignment.h:885) for every primary chain; array arguments are device tensors."""
+    cp = np.ascontiguousarray(chrom_pos, dtype=np.uint64)
+    d = dict(ONT_LRA); d.update(kw)
+    o = LraOpts(*[d[n] for n, _ in LraOpts._fields_])
+    res = AlignmentsResult()
+    nj, nc, na = int(job_read.numel()), int(chain_strand.numel()), int(q.numel())
+    ctx.check(ctx.lib.lra_local_refine_batch(ctx.h, C.c_uint64(nj), ptr(job_chain_off), ptr(job_read), ptr(job_h), C.c_uint64(nc), ptr(chain_anchor_off), ptr(chain_strand),
+                                             ptr(chain_chrom), ptr(chain_value), ptr(chain_n0), ptr(chain_n1), C.c_uint64(na), ptr(q), ptr(t), ptr(length), ptr(read_off),
+                                             ptr(strands), C.c_uint64(int(rc_base)), ptr(genome), C.c_void_p(cp.ctypes.data), len(cp) - 1, C.byref(o), C.byref(res)))
+    return res
+
+
+def fetch_alignments(ctx: Context, res: AlignmentsResult):
+    nj, na, nb = res.n_jobs, res.n_alignments, res.n_blocks
+    d = {"job_aln_off": ctx.to_host(res.d_job_aln_off, nj + 1, np.uint64), "block_off": ctx.to_host(res.d_block_off, na + 1, np.uint64),
+         "blocks": ctx.to_host(res.d_blocks, 3 * nb, np.int32).reshape(-1, 3), "value": ctx.to_host(res.d_value, na, np.float32),
+         "status": ctx.to_host(res.d_status, nj, np.uint32)}
+    for k in ("strand", "supp", "secondary", "n0", "n1", "chrom"):
+        d[k] = ctx.to_host(getattr(res, "d_" + k), na, np.int32)
+    return d

@@ -357,7 +357,7 @@ struct ExtArgs {
   const uint64_t* cluster_off; const uint64_t* c_start; const uint64_t* c_end; const int* c_strand; const int* c_chrom;
   const uint32_t* cl_q; const uint32_t* cl_t; const uint64_t* chrom_pos;
   const unsigned char* genome; const unsigned char* seq; const uint64_t* read_off;
-  int* c_read;
+  int* c_read; const int* c_K;             // per-cluster K when non-null (the gap seeds of RefinedAlignmentbtwnAnchors use 9 or 12)
   uint32_t* e_q; uint32_t* e_t; int* e_len; uint32_t* e_count; uint32_t* box;
 };
 
@@ -373,8 +373,8 @@ __global__ void cluster_read_map(int n_reads, const uint64_t* cluster_off, int* 
 __global__ void __launch_bounds__(64) linear_extend_kernel(ExtArgs A) {
   const int lane = threadIdx.x;
   const unsigned long long below = (lane == 0) ? 0ULL : (~0ULL >> (64 - lane));
-  const uint32_t K = (uint32_t)A.K;
   for (uint64_t x = blockIdx.x; x < A.n_clusters; x += gridDim.x) {
+    const uint32_t K = (uint32_t)(A.c_K ? A.c_K[x] : A.K);
     const uint64_t s = A.c_start[x], e = A.c_end[x];
     const int strand = A.c_strand[x], chrom = A.c_chrom[x], r = A.c_read[x];
     const uint64_t coff = A.chrom_pos[chrom];
@@ -448,13 +448,14 @@ __global__ void __launch_bounds__(64) linear_extend_kernel(ExtArgs A) {
 // the pair-version LinearExtend on caller-supplied cluster arrays (merge_extend.hip: the refined clusters before the second sparse DP)
 int lra_launch_linear_extend(lra_ctx* ctx, uint64_t n_clusters, int K, const uint64_t* c_start, const uint64_t* c_end, const int* c_strand, const int* c_chrom,
                              int* c_read, const uint32_t* cl_q, const uint32_t* cl_t, const uint64_t* d_chrom_pos, const unsigned char* genome,
-                             const unsigned char* seq, const uint64_t* read_off, uint32_t* e_q, uint32_t* e_t, int* e_len, uint32_t* e_count, uint32_t* box) {
+                             const unsigned char* seq, const uint64_t* read_off, uint32_t* e_q, uint32_t* e_t, int* e_len, uint32_t* e_count, uint32_t* box,
+                             const int* c_K) {
   if (n_clusters == 0) return LRA_OK;
   ExtArgs A;
   memset(&A, 0, sizeof A);
   A.n_clusters = n_clusters; A.K = K; A.c_start = c_start; A.c_end = c_end; A.c_strand = c_strand; A.c_chrom = c_chrom; A.c_read = c_read;
   A.cl_q = cl_q; A.cl_t = cl_t; A.chrom_pos = d_chrom_pos; A.genome = genome; A.seq = seq; A.read_off = read_off;
-  A.e_q = e_q; A.e_t = e_t; A.e_len = e_len; A.e_count = e_count; A.box = box;
+  A.e_q = e_q; A.e_t = e_t; A.e_len = e_len; A.e_count = e_count; A.box = box; A.c_K = c_K;
   lra_time_begin(ctx, "linear_extend");
   hipLaunchKernelGGL(linear_extend_kernel, dim3((unsigned)std::min<uint64_t>(n_clusters, (uint64_t)ctx->num_cu * 32)), dim3(64), 0, ctx->stream, A);
   lra_time_end(ctx);
@@ -473,7 +474,7 @@ extern "C" int lra_linear_extend_batch(lra_ctx* ctx, int K, const char* d_seq, c
   char* w = (char*)lra_scratch(ctx, 3, sz(NM, 4) * 3 + sz(NC, 4) * 2 + sz(4 * NC, 4) + 4096);
   if (!w) return LRA_ERR_NOMEM;
   ExtArgs A;
-  A.n_clusters = cs->n_clusters; A.n_reads = cs->n_reads; A.K = K;
+  A.n_clusters = cs->n_clusters; A.n_reads = cs->n_reads; A.K = K; A.c_K = nullptr;
   A.cluster_off = cs->cluster_off; A.c_start = cs->c_start; A.c_end = cs->c_end; A.c_strand = cs->c_strand; A.c_chrom = cs->c_chrom;
   A.cl_q = cs->cl_q; A.cl_t = cs->cl_t; A.chrom_pos = cs->chrom_pos;
   A.genome = ctx->seed->genome; A.seq = (const unsigned char*)d_seq; A.read_off = d_read_off;

@@ -25,8 +25,8 @@ struct lra_ctx {
   void* aux = nullptr; size_t aux_bytes = 0;          // AffineOneGapAlign blocks of refine fallbacks
   void* out_buf = nullptr; size_t out_bytes = 0;
   uint64_t* scan_tmp = nullptr;
-  void* gbuf[40] = {};   // growable result / work buffers (lra_ensure)
-  size_t gbytes[40] = {};
+  void* gbuf[56] = {};   // growable result / work buffers (lra_ensure)
+  size_t gbytes[56] = {};
   // kernel timing
   const char* sort_tag = "sort"; const char* sort_fb_tag = "sort_fallback";   // timing names of the exact-sort kernels (sdp.hip retags them)
   bool timing = false;
@@ -53,7 +53,8 @@ int lra_sort_mostly_unique_batch(lra_ctx* ctx, int n_lists, const uint64_t* d_of
 // cluster.hip: LinearExtend (pair version, LinearExtend.h:658) + DecideCoordinates box on caller-supplied clusters of diagonal-sorted matches
 int lra_launch_linear_extend(lra_ctx* ctx, uint64_t n_clusters, int K, const uint64_t* c_start, const uint64_t* c_end, const int* c_strand, const int* c_chrom,
                              int* c_read, const uint32_t* cl_q, const uint32_t* cl_t, const uint64_t* d_chrom_pos, const unsigned char* genome,
-                             const unsigned char* seq, const uint64_t* read_off, uint32_t* e_q, uint32_t* e_t, int* e_len, uint32_t* e_count, uint32_t* box);
+                             const unsigned char* seq, const uint64_t* read_off, uint32_t* e_q, uint32_t* e_t, int* e_len, uint32_t* e_count, uint32_t* box,
+                             const int* c_K = nullptr);
 
 #define LRA_HIP_CHECK(ctx, call)                                                         \
   do {                                                                                   \

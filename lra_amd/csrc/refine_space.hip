@@ -31,7 +31,7 @@ struct RsArgs {
   int n;
   const char* qseq; const char* tseq; const uint64_t* q_off; const int32_t* q_len; const uint64_t* t_off; const int32_t* t_len;
   const uint32_t* t_span; const int32_t* K; const int32_t* W; const int32_t* diag; const uint32_t* q_add; const uint32_t* t_add; const uint32_t* flip;
-  long maxFreq;
+  long maxFreq; const int32_t* maxFreqArr;   // per-problem localMaxFreq when non-null
   // classification
   uint32_t* isSmall; uint64_t* smallPos; uint32_t* smallIdx; uint32_t* largeIdx;   // smallPos: exclusive scan of isSmall
   // small branch (compact, indexed by position among the small ones)
@@ -173,7 +173,7 @@ __global__ void rs_compare(RsArgs a, int nLarge) {
   const long nt = (long)(a.loff[2 * j + 1] - a.loff[2 * j]), nq = (long)(a.loff[2 * j + 2] - a.loff[2 * j + 1]);
   const long long diag2 = (long long)a.t_span[i] - (long long)(uint32_t)a.q_len[i];
   const long long minDiag = min(0LL, diag2) - a.diag[i], maxDiag = max(0LL, diag2) + a.diag[i];
-  const long maxFreq = a.maxFreq;
+  const long maxFreq = a.maxFreqArr ? (long)a.maxFreqArr[i] : a.maxFreq;
   const int K = a.K[i];
   const uint32_t qAdd = a.q_add[i], tAdd = a.t_add[i], flip = a.flip[i];
   uint32_t n = 0;
@@ -241,10 +241,10 @@ inline size_t sz(size_t n, size_t e) { return (n * e + 255) / 256 * 256; }
 
 }  // namespace
 
-extern "C" int lra_refine_space_batch(lra_ctx* ctx, int n, const char* d_qseq, const uint64_t* d_q_off, const int32_t* d_q_len, const char* d_tseq,
-                                      const uint64_t* d_t_off, const int32_t* d_t_len, const uint32_t* d_t_span, const int32_t* d_K, const int32_t* d_W,
-                                      const int32_t* d_diag, const uint32_t* d_q_add, const uint32_t* d_t_add, const uint32_t* d_flip_len, int match,
-                                      int mismatch, int indel, int max_freq, lra_refine_space_result* out) {
+static int refine_space_impl(lra_ctx* ctx, int n, const char* d_qseq, const uint64_t* d_q_off, const int32_t* d_q_len, const char* d_tseq,
+                             const uint64_t* d_t_off, const int32_t* d_t_len, const uint32_t* d_t_span, const int32_t* d_K, const int32_t* d_W,
+                             const int32_t* d_diag, const uint32_t* d_q_add, const uint32_t* d_t_add, const uint32_t* d_flip_len, int match,
+                             int mismatch, int indel, int max_freq, const int32_t* d_max_freq, lra_refine_space_result* out) {
   if (!ctx || !out || n < 0) return LRA_ERR_INVALID;
   memset(out, 0, sizeof *out);
   out->n_problems = (uint64_t)n;
@@ -259,7 +259,7 @@ extern "C" int lra_refine_space_batch(lra_ctx* ctx, int n, const char* d_qseq, c
   RsArgs a;
   memset(&a, 0, sizeof a);
   a.n = n; a.qseq = d_qseq; a.tseq = d_tseq; a.q_off = d_q_off; a.q_len = d_q_len; a.t_off = d_t_off; a.t_len = d_t_len; a.t_span = d_t_span; a.K = d_K; a.W = d_W;
-  a.diag = d_diag; a.q_add = d_q_add; a.t_add = d_t_add; a.flip = d_flip_len; a.maxFreq = max_freq;
+  a.diag = d_diag; a.q_add = d_q_add; a.t_add = d_t_add; a.flip = d_flip_len; a.maxFreq = max_freq; a.maxFreqArr = d_max_freq;
   a.isSmall = (uint32_t*)take(w, n1, 4); a.smallIdx = (uint32_t*)take(w, n1, 4); a.largeIdx = (uint32_t*)take(w, n1, 4); a.sq_len = (int32_t*)take(w, n1, 4);
   a.st_len = (int32_t*)take(w, n1, 4); a.sk = (int32_t*)take(w, n1, 4); a.bcap = (uint32_t*)take(w, n1, 4); a.cnt = (uint32_t*)take(w, n1, 4);
   a.smallPos = (uint64_t*)take(w, n1, 8); a.sq_off = (uint64_t*)take(w, n1, 8); a.st_off = (uint64_t*)take(w, n1, 8);
@@ -348,4 +348,22 @@ extern "C" int lra_refine_space_batch(lra_ctx* ctx, int n, const char* d_qseq, c
   out->n_pairs = nPairs; out->n_small = (uint64_t)nSmall; out->d_pair_off = pairOffOut; out->d_pair_q = outQ; out->d_pair_t = outT; out->d_identity = identity;
   out->d_status = status;
   return LRA_OK;
+}
+
+extern "C" int lra_refine_space_batch(lra_ctx* ctx, int n, const char* d_qseq, const uint64_t* d_q_off, const int32_t* d_q_len, const char* d_tseq,
+                                      const uint64_t* d_t_off, const int32_t* d_t_len, const uint32_t* d_t_span, const int32_t* d_K, const int32_t* d_W,
+                                      const int32_t* d_diag, const uint32_t* d_q_add, const uint32_t* d_t_add, const uint32_t* d_flip_len, int match,
+                                      int mismatch, int indel, int max_freq, lra_refine_space_result* out) {
+  return refine_space_impl(ctx, n, d_qseq, d_q_off, d_q_len, d_tseq, d_t_off, d_t_len, d_t_span, d_K, d_W, d_diag, d_q_add, d_t_add, d_flip_len, match, mismatch,
+                           indel, max_freq, nullptr, out);
+}
+
+// the same with opts.localMaxFreq per problem (RefinedAlignmentbtwnAnchors raises it to 50 for spaces under 500, LocalRefineAlignment.h:272-277)
+extern "C" int lra_refine_space_batch_mf(lra_ctx* ctx, int n, const char* d_qseq, const uint64_t* d_q_off, const int32_t* d_q_len, const char* d_tseq,
+                                         const uint64_t* d_t_off, const int32_t* d_t_len, const uint32_t* d_t_span, const int32_t* d_K, const int32_t* d_W,
+                                         const int32_t* d_diag, const uint32_t* d_q_add, const uint32_t* d_t_add, const uint32_t* d_flip_len, int match,
+                                         int mismatch, int indel, const int32_t* d_max_freq, lra_refine_space_result* out) {
+  if (!d_max_freq) return LRA_ERR_INVALID;
+  return refine_space_impl(ctx, n, d_qseq, d_q_off, d_q_len, d_tseq, d_t_off, d_t_len, d_t_span, d_K, d_W, d_diag, d_q_add, d_t_add, d_flip_len, match, mismatch,
+                           indel, 0, d_max_freq, out);
 }

@@ -492,6 +492,41 @@ def refine_cluster(mq, mt, box, strand, chrom_pos, read_len, q_index, g_index, w
         cap = int(n)
 
 
+class LraOpts(C.Structure):
+    _fields_ = [(n, C.c_int) for n in ("localW", "globalW", "localMaxFreq", "match", "mismatch", "indel", "localBand", "refineBySDP", "isOnt")] + [
+        ("gapopen", C.c_float), ("gapextend", C.c_float), ("gaproot", C.c_float), ("gapCeiling1", C.c_int), ("gapCeiling2", C.c_int)]
+
+
+def local_refine_alignment(chain_off, aq, at, alen, chain_strand, chain_chrom, first_sdp, n0, n1, h, fwd: bytes, rc: bytes, genome: bytes, chrom_pos, **kw):
+    """LocalRefineAlignment (LocalRefineAlignment.h:885) for one primary chain -> list of dict(strand, supp, secondary, n0, n1, value, chrom, blocks) or None (UB)."""
+    L = lib()
+    d = dict(localW=5, globalW=5, localMaxFreq=15, match=4, mismatch=-1, indel=-2, localBand=15, refineBySDP=1, isOnt=1, gapopen=7.0, gapextend=10.0, gaproot=1.5,
+             gapCeiling1=1500, gapCeiling2=3000)
+    d.update(kw)
+    o = LraOpts(*[d[n] for n, _ in LraOpts._fields_])
+    co = np.ascontiguousarray(chain_off, np.int32); aq = np.ascontiguousarray(aq, np.uint32); at = np.ascontiguousarray(at, np.uint32); al = np.ascontiguousarray(alen, np.int32)
+    cs = np.ascontiguousarray(chain_strand, np.uint8); cc = np.ascontiguousarray(chain_chrom, np.int32); fs = np.ascontiguousarray(first_sdp, np.float32)
+    a0 = np.ascontiguousarray(n0, np.int32); a1 = np.ascontiguousarray(n1, np.int32); pos = np.ascontiguousarray(chrom_pos, np.uint64)
+    nch = len(cs)
+    sizes = np.diff(co)
+    lsc = int(np.argmax(sizes)) if nch else 0                              # LargestSplitChain: first maximum
+    max_seg = 4 * len(aq) + 8; cap = 4 * (len(aq) + len(fwd)) + 64
+    seg = [np.zeros(max_seg, np.int32) for _ in range(5)]; sv = np.zeros(max_seg, np.float32); sc = np.zeros(max_seg, np.int32)
+    sbo = np.zeros(max_seg + 1, np.int32); blk = np.zeros(3 * cap, np.int32)
+    L.oracle_local_refine_alignment.restype = C.c_int
+    n = L.oracle_local_refine_alignment(C.c_int(nch), _p(co, C.c_int), _p(aq, C.c_uint32), _p(at, C.c_uint32), _p(al, C.c_int), _p(cs, C.c_uint8), _p(cc, C.c_int),
+                                        _p(fs, C.c_float), _p(a0, C.c_int), _p(a1, C.c_int), C.c_int(lsc), C.c_int(int(h)), C.c_char_p(fwd), C.c_char_p(rc),
+                                        C.c_uint32(len(fwd)), C.c_char_p(genome), _p(pos, C.c_uint64), C.byref(o), C.c_int(max_seg), _p(seg[0], C.c_int),
+                                        _p(seg[1], C.c_int), _p(seg[2], C.c_int), _p(seg[3], C.c_int), _p(seg[4], C.c_int), _p(sv, C.c_float), _p(sc, C.c_int),
+                                        _p(sbo, C.c_int), _p(blk, C.c_int), C.c_long(cap))
+    if n == -1:
+        return None
+    assert n >= 0, n
+    B = blk.reshape(-1, 3)
+    return [dict(strand=int(seg[0][i]), supp=int(seg[1][i]), secondary=int(seg[2][i]), n0=int(seg[3][i]), n1=int(seg[4][i]), value=float(sv[i]), chrom=int(sc[i]),
+                 blocks=B[sbo[i]:sbo[i + 1]].copy()) for i in range(n)]
+
+
 # ---- chain post-filters + SPLITChain (a9, low-accuracy path) ----------------------------------------------------------
 def split_chain(q, t, length, strand, cluster, link, chrom_pos, splitdist=50000, bypass=1):
     """One chain (trace-back order) -> dict(keep, link, splits=[dict(idx, link, type, strand, chrom, box, clusters)], split_link) or None (UB)."""

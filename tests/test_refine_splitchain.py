@@ -440,3 +440,90 @@ def test_hip_refine_clusters_oracle(ctx, oracle):
                 assert np.array_equal(out["box"][c], exp["box"]) and out["eff"][c].view(np.uint32) == exp["eff"].view(np.uint32), c
             n_ok += 1; n_rev += strand; n_matches += m1 - m0
     assert n_ok >= 100 and n_rev >= 20 and n_matches > 20000, (n_ok, n_rev, n_rej, n_matches)
+
+
+def _second_sdp_chains(ctx, oracle, P):
+    """front end -> ... -> second sparse DP + its filters; returns everything the a13 test needs (jobs = chain slots)"""
+    import torch
+    from lra_amd import chain
+    chres, spres, batch, CH, rli, gso_d, gli, co, so, n, na, both, tot, gdev = (P[k] for k in (
+        "chres", "spres", "batch", "CH", "rli", "gso_d", "gli", "co", "so", "n", "na", "both", "tot", "gdev"))
+    rres = chain.refine_splitchain_batch(ctx, chres, spres, batch.off, CH, rli, gso_d, gli, window=100, smallK=10, K=K, limitrefine=True, max_freq=15)
+    bres = chain.refine_btwn_splitchain_batch(ctx, chres, spres, rres, batch.off, both, tot, gdev, CH, K=10, W=5)
+    mres = chain.merge_extend_batch(ctx, chres, spres, bres, batch.seq, batch.off, gdev, CH, K=10)
+    mo = chain.fetch_merge(ctx, mres)
+    cres2 = chain.sparse_dp_batch(ctx, int(mres.n_groups), mres.d_iota, mres.d_anchor_off, mres.d_count, mres.d_strand, mres.d_q, mres.d_t, mres.d_len,
+                                  mres.d_iota, chain.sdp_opts(mode=1, rate=2.0))
+    c2 = chain.fetch(ctx, cres2)
+    jobs = []                                                              # (read, h, [chains]) with chain = (q, t, len, strand, chrom, value)
+    for r in range(n):
+        for c in range(int(co["n_chains"][r])):
+            s = r * na + c
+            chains = []
+            for G in range(int(mo["slot_group_off"][s]), int(mo["slot_group_off"][s + 1])):
+                cnt = int(mo["count"][G])
+                if cnt == 0 or c2["status"][G] or int(c2["n_chains"][G]) == 0:
+                    continue
+                a0 = int(mo["anchor_off"][G])
+                cs_ = int(c2["chain_start"][G * cres2.num_aln]); m = int(c2["chain_len"][G * cres2.num_aln])
+                idx = c2["chain_anchor"][cs_:cs_ + m].astype(np.int64)
+                q = mo["q"][a0 + idx]; t = mo["t"][a0 + idx]; ln = mo["len"][a0 + idx]
+                st = int(mo["strand"][G])
+                keep, _ = O.filter_chain(q, t, ln, [st] * m, None, [2, 4])    # RemovePairedIndels + RemoveSpuriousAnchors (Map_lowacc.h:538-539)
+                kb = keep.astype(bool)
+                chains.append((q[kb], t[kb], ln[kb], st, int(mo["chrom"][G]), float(c2["chain_value"][G * cres2.num_aln])))
+            if chains:
+                jobs.append((r, c, chains))
+    return jobs
+
+
+@pytest.mark.gpu
+def test_hip_local_refine_alignment_oracle(ctx, oracle):
+    """a13: LocalRefineAlignment + RefinedAlignmentbtwnAnchors on the chains of the second sparse DP (reads with inversions, deletions, junk
+    insertions so that large spaces, breaks and inverted seeds occur), against the oracle job by job"""
+    import torch
+    from lra_amd import chain, synth
+    P = _front_end(ctx, oracle)
+    jobs = _second_sdp_chains(ctx, oracle, P)
+    reads, genome, batch, both, tot, gdev, CH = (P[k] for k in ("reads", "genome", "batch", "both", "tot", "gdev", "CH"))
+    dev = ctx.device
+    jco = [0]; jr = []; jh = []; cao = [0]; cs = []; cc = []; cv = []; c0 = []; c1 = []; Q = []; T = []; Ln = []
+    for (r, h, chains) in jobs:
+        for (q, t, ln, st, ch, val) in chains:
+            Q.extend(q.tolist()); T.extend(t.tolist()); Ln.extend(ln.tolist()); cao.append(len(Q)); cs.append(st); cc.append(ch); cv.append(val); c0.append(len(q)); c1.append(7)
+        jco.append(len(cs)); jr.append(r); jh.append(h)
+    tt = lambda a, dt: torch.from_numpy(np.ascontiguousarray(a, dtype=dt)).to(dev)
+    res = chain.local_refine_batch(ctx, tt(jco, np.int64), tt(jr, np.int32), tt(jh, np.int32), tt(cao, np.int64), tt(cs, np.int32), tt(cc, np.int32), tt(cv, np.float32),
+                                   tt(c0, np.int32), tt(c1, np.int32), tt(Q, np.int64).to(torch.int32), tt(T, np.int64).to(torch.int32), tt(Ln, np.int32), batch.off, both, tot,
+                                   gdev, CH)
+    out = chain.fetch_alignments(ctx, res)
+    gbytes = genome.tobytes()
+    n_jobs = n_aln = n_events = n_blocks = 0
+    ci = 0
+    for ji, (r, h, chains) in enumerate(jobs):
+        fwd = reads[r].tobytes(); rc = synth.revcomp(reads[r]).tobytes()
+        off = [0]; aq = []; at = []; al = []
+        for (q, t, ln, st, ch, val) in chains:
+            aq.extend(q.tolist()); at.extend(t.tolist()); al.extend(ln.tolist()); off.append(len(aq))
+        nch = len(chains)
+        exp = O.local_refine_alignment(off, aq, at, al, [x[3] for x in chains], [x[4] for x in chains], [x[5] for x in chains], c0[ci:ci + nch], c1[ci:ci + nch], h, fwd, rc,
+                                       gbytes, CH)
+        ci += nch
+        a0, a1 = int(out["job_aln_off"][ji]), int(out["job_aln_off"][ji + 1])
+        if exp is None:
+            assert out["status"][ji] != 0, ji
+            continue
+        assert out["status"][ji] == 0, (ji, out["status"][ji])
+        assert a1 - a0 == len(exp), (ji, a1 - a0, len(exp))
+        for k, e in enumerate(exp):
+            x = a0 + k
+            for f in ("strand", "supp", "secondary", "n0", "n1", "chrom"):
+                assert int(out[f][x]) == e[f], (ji, k, f, int(out[f][x]), e[f])
+            assert np.float32(out["value"][x]).view(np.uint32) == np.float32(e["value"]).view(np.uint32), (ji, k)
+            b0, b1 = int(out["block_off"][x]), int(out["block_off"][x + 1])
+            assert b1 - b0 == len(e["blocks"]), (ji, k, b1 - b0, len(e["blocks"]))
+            assert np.array_equal(out["blocks"][b0:b1], e["blocks"]), (ji, k)
+            n_blocks += b1 - b0
+        n_jobs += 1; n_aln += len(exp); n_events += len(exp) - sum(1 for c_ in chains if len(c_[0]) > 1)
+    print("a13 stats: jobs %d alignments %d events %d blocks %d large spaces %d seed-set jobs %d" % (n_jobs, n_aln, n_events, n_blocks, res.n_big, res.n_inner_jobs))
+    assert n_jobs >= 40 and n_blocks > 10000 and res.n_big >= 5, (n_jobs, n_aln, n_events, n_blocks, res.n_big, res.n_inner_jobs)
