@@ -12,6 +12,8 @@
 #include "oracle_common.h"
 #include <algorithm>
 #include <cmath>
+#include <cstdio>
+#include <cstdlib>
 #include <utility>
 #include <vector>
 
@@ -104,6 +106,7 @@ void between_anchors(Env& E, int cur, int next, int str, int inv_str, int chrom,
     if (E.bad) return;
     const int minDist = (int)std::min(rd, gd);
     bool useRev = false;
+    if (getenv("ORACLE_DEBUG")) fprintf(stderr, "big space: rd %ld gd %ld K %d nF %zu id %f minRatio %f blocks %zu\n", rd, gd, K, fq.size(), identity, minRatio, alns.back().blocks.size() / 3);
     if ((fq.size() / (float)minDist) < minRatio && alns.back().blocks.size() / 3 >= 5 && identity < 0.8) {   // try the other strand
       const uint32_t temp = curReadEnd;
       curReadEnd = L - nextReadStart; nextReadStart = L - temp;

@@ -527,3 +527,81 @@ def test_hip_local_refine_alignment_oracle(ctx, oracle):
         n_jobs += 1; n_aln += len(exp); n_events += len(exp) - sum(1 for c_ in chains if len(c_[0]) > 1)
     print("a13 stats: jobs %d alignments %d events %d blocks %d large spaces %d seed-set jobs %d" % (n_jobs, n_aln, n_events, n_blocks, res.n_big, res.n_inner_jobs))
     assert n_jobs >= 40 and n_blocks > 10000 and res.n_big >= 5, (n_jobs, n_aln, n_events, n_blocks, res.n_big, res.n_inner_jobs)
+
+
+@pytest.mark.gpu
+def test_hip_local_refine_events_oracle(ctx):
+    """a13 on crafted chains: an inverted stretch between two anchors (inverted seeds -> an inversion alignment), junk of 800 / 400 bases on both
+    sides (no seed on either strand -> the alignment breaks; the K = 9 / maxFreq 50 branch), mutated stretches (forward seeds -> the inner
+    chain), on both strands, near the start of a chain (fewer than 5 blocks: no inversion is tried) and later"""
+    import torch
+    from lra_amd import chain, synth, seed
+    rng = np.random.default_rng(123)
+    genome = synth.make_genome(400_000, seed=77, repeat_frac=0.1, n_families=2)
+    ALPH = np.frombuffer(b"ACGT", np.uint8)
+    CH = [0, 180_000, 400_000]
+    reads = []; jobs = []
+    for j in range(40):
+        kind = j % 5; rev = (j // 5) % 2; early = (j // 10) % 2
+        chrom = int(rng.integers(0, 2))
+        a = CH[chrom] + int(rng.integers(5_000, 150_000))
+        Lr = 5000
+        seg = genome[a:a + Lr].copy()
+        e0 = 150 if early else 2200                                       # where the event sits (read-strand coordinate of the alignment)
+        span = {0: 1500, 1: 1500, 2: 400, 3: 900, 4: 0}[kind]                  # >= 1000 on both sides: the minimizer path of RefineSpace, no chance seeds
+        if kind == 0: seg[e0:e0 + span] = synth.revcomp(genome[a + e0:a + e0 + span])                 # inversion
+        elif kind in (1, 2): seg[e0:e0 + span] = ALPH[rng.integers(0, 4, span)]                          # junk on both sides
+        elif kind == 3:                                                                                  # 12 % substitutions: seeds survive
+            m_ = rng.random(span) < 0.12
+            seg[e0:e0 + span][m_] = ALPH[rng.integers(0, 4, int(m_.sum()))]
+        # anchors: exact 40-mers every 55 bases outside the event, in the alignment's own (read-strand) coordinates
+        anchors = [(x, x, 40) for x in range(20, Lr - 60, 55) if x + 40 <= e0 - 45 or x >= e0 + span + 45]
+        if span: anchors += [(e0 - 40, e0 - 40, 40), (e0 + span, e0 + span, 40)]     # anchors flush with the event: the space is the event itself
+        read = synth.revcomp(seg) if rev else seg
+        reads.append(read)
+        L = len(read)
+        chrom_off = CH[chrom]
+        ch = []
+        for (qr, tr, ln) in sorted(anchors, reverse=True):               # chain order: highest forward q first
+            t = a + tr - chrom_off
+            q = L - qr - ln if rev else qr
+            ch.append((q, t, ln))
+        if rev: ch = ch[::-1]                                              # strand 1: descending forward q = ascending strand coordinate
+        ch = sorted(ch, key=lambda x: -x[0])
+        jobs.append((j, int(early), [(np.array([c[0] for c in ch], np.uint32), np.array([c[1] for c in ch], np.uint32), np.array([c[2] for c in ch], np.int32), rev, chrom,
+                                      float(100 + j))]))
+    batch = seed.ReadBatch(ctx, [r.tobytes() for r in reads])
+    dev = ctx.device
+    tot = int(batch.off[-1])
+    both = torch.zeros(2 * tot + 64, dtype=torch.uint8, device=dev)
+    both[:tot] = batch.seq[:tot]; both[tot:2 * tot] = seed.create_rc(ctx, batch)[:tot]
+    gdev = torch.from_numpy(np.concatenate([genome, np.zeros(64, np.uint8)])).to(dev)
+    jco = [0]; jr = []; jh = []; cao = [0]; cs = []; cc = []; cv = []; c0 = []; c1 = []; Q = []; T = []; Ln = []
+    for (r, h, chains) in jobs:
+        for (q, t, ln, st, chm, val) in chains:
+            Q.extend(q.tolist()); T.extend(t.tolist()); Ln.extend(ln.tolist()); cao.append(len(Q)); cs.append(st); cc.append(chm); cv.append(val); c0.append(len(q)); c1.append(3)
+        jco.append(len(cs)); jr.append(r); jh.append(h)
+    tt = lambda a_, dt: torch.from_numpy(np.ascontiguousarray(a_, dtype=dt)).to(dev)
+    res = chain.local_refine_batch(ctx, tt(jco, np.int64), tt(jr, np.int32), tt(jh, np.int32), tt(cao, np.int64), tt(cs, np.int32), tt(cc, np.int32), tt(cv, np.float32),
+                                   tt(c0, np.int32), tt(c1, np.int32), tt(Q, np.int64).to(torch.int32), tt(T, np.int64).to(torch.int32), tt(Ln, np.int32), batch.off, both, tot,
+                                   gdev, CH)
+    out = chain.fetch_alignments(ctx, res)
+    gbytes = genome.tobytes()
+    n_inv = n_multi = 0
+    for ji, (r, h, chains) in enumerate(jobs):
+        q, t, ln, st, chm, val = chains[0]
+        exp = O.local_refine_alignment([0, len(q)], q, t, ln, [st], [chm], [val], [len(q)], [3], h, reads[r].tobytes(), synth.revcomp(reads[r]).tobytes(), gbytes, CH)
+        a0, a1 = int(out["job_aln_off"][ji]), int(out["job_aln_off"][ji + 1])
+        assert exp is not None and out["status"][ji] == 0, ji
+        assert a1 - a0 == len(exp), (ji, ji % 5, a1 - a0, len(exp))
+        for k, e in enumerate(exp):
+            x = a0 + k
+            for f in ("strand", "supp", "secondary", "n0", "n1", "chrom"):
+                assert int(out[f][x]) == e[f], (ji, k, f, int(out[f][x]), e[f])
+            assert np.float32(out["value"][x]).view(np.uint32) == np.float32(e["value"]).view(np.uint32), (ji, k)
+            b0, b1 = int(out["block_off"][x]), int(out["block_off"][x + 1])
+            assert b1 - b0 == len(e["blocks"]) and np.array_equal(out["blocks"][b0:b1], e["blocks"]), (ji, k)
+            n_inv += e["strand"] != st
+        n_multi += len(exp) > 1
+    print("a13 events: jobs with several alignments %d, inverted alignments %d, large spaces %d, seed-set jobs %d" % (n_multi, n_inv, res.n_big, res.n_inner_jobs))
+    assert n_multi >= 8 and n_inv >= 2 and res.n_big >= 24
