@@ -519,6 +519,20 @@ int lra_local_refine_batch(lra_ctx* ctx, uint64_t n_jobs, const uint64_t* d_job_
                            const uint64_t* d_read_off, const char* d_strands, uint64_t rc_base, const char* d_genome, const uint64_t* h_chrom_pos, int n_chrom,
                            const lra_lra_opts* opts, lra_alignments_result* out);
 
+/* From the second sparse DP to lra_local_refine_batch (Map_lowacc.h:530-540, :575): `second` = lra_sparse_dp_batch in single-cluster mode over the
+ * merged clusters of `merge`; its chains are filtered (RemovePairedIndels<UltimateChain>, RemoveSpuriousAnchors) and grouped per primary chain.
+ * job = chain slot of the first sparse DP (read = slot / num_aln, h = slot % num_aln; d_slot_n0[slot] = chains[p].NumOfAnchors0 kept by the caller, the
+ * first DP's result arrays being overwritten by the second; may be NULL), chains = its merged clusters.  Output (context-owned) = the array
+ * arguments of lra_local_refine_batch.  Synchronous.                                                                                         */
+typedef struct lra_local_refine_inputs {
+  uint64_t n_jobs, n_chains, n_anchors;
+  const uint64_t* d_job_chain_off; const uint32_t* d_job_read; const int32_t* d_job_h;
+  const uint64_t* d_chain_anchor_off; const int32_t* d_chain_strand; const int32_t* d_chain_chrom; const float* d_chain_value; const int32_t* d_chain_n0;
+  const int32_t* d_chain_n1; const uint32_t* d_q; const uint32_t* d_t; const int32_t* d_len;
+} lra_local_refine_inputs;
+int lra_local_refine_inputs_batch(lra_ctx* ctx, int num_aln, const uint32_t* d_slot_n0, const lra_merge_result* merge, const lra_chain_result* second,
+                                  lra_local_refine_inputs* out);
+
 /* ---- a14: banded 3-state affine indel refinement ----------------------------------------
  * Replaces   void IndelRefineAlignment(Read& read, Genome& genome, Alignment& alignment,
  *                                      const Options& opts, IndelRefineBuffers& buffers,

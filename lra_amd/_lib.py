@@ -65,6 +65,7 @@ SYMBOLS = {
     "lra_refine_clusters_batch": (C.c_int, [_vp, C.c_int] + [_vp] * 10 + [C.c_uint64, _vp, _vp, C.c_int, _vp, C.c_uint64, _vp, _vp, _vp, _vp, _vp]),
     "lra_local_refine_batch": (C.c_int, [_vp, C.c_uint64, _vp, _vp, _vp, C.c_uint64, _vp, _vp, _vp, _vp, _vp, _vp, C.c_uint64, _vp, _vp, _vp, _vp, _vp, C.c_uint64, _vp, _vp,
                                          C.c_int, _vp, _vp]),
+    "lra_local_refine_inputs_batch": (C.c_int, [_vp, C.c_int, _vp, _vp, _vp, _vp]),
     "lra_filter_chains_batch": (C.c_int, [_vp, C.c_uint64, _vp, C.c_uint64, _vp, _vp, _vp, _vp, _vp, _vp, C.c_int, _vp]),
     "lra_calculate_statistics_batch": (C.c_int, [_vp, C.c_int, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, C.c_int, _vp]),
     "lra_local_index_batch": (C.c_int, [_vp, C.c_int, _vp, _vp, C.c_int, C.c_int, C.c_int, C.c_int, _vp]),

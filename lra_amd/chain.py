@@ -277,3 +277,24 @@ def fetch_alignments(ctx: Context, res: AlignmentsResult):
     for k in ("strand", "supp", "secondary", "n0", "n1", "chrom"):
         d[k] = ctx.to_host(getattr(res, "d_" + k), na, np.int32)
     return d
+
+
+class LocalRefineInputs(C.Structure):
+    _fields_ = [("n_jobs", C.c_uint64), ("n_chains", C.c_uint64), ("n_anchors", C.c_uint64)] + [(n, C.c_void_p) for n in (
+        "d_job_chain_off", "d_job_read", "d_job_h", "d_chain_anchor_off", "d_chain_strand", "d_chain_chrom", "d_chain_value", "d_chain_n0", "d_chain_n1", "d_q", "d_t", "d_len")]
+
+
+def local_refine_from_sdp(ctx: Context, num_aln, slot_n0, merge: MergeResult, second: ChainResult, read_off, strands, rc_base, genome, chrom_pos, **kw):
+    """Filters of the second sparse DP + LocalRefineAlignment for every primary chain, without leaving the device (Map_lowacc.h:530-576)."""
+    inp = LocalRefineInputs()
+    ctx.check(ctx.lib.lra_local_refine_inputs_batch(ctx.h, int(num_aln), ptr(slot_n0) if slot_n0 is not None else None, C.byref(merge), C.byref(second), C.byref(inp)))
+    cp = np.ascontiguousarray(chrom_pos, dtype=np.uint64)
+    d = dict(ONT_LRA); d.update(kw)
+    o = LraOpts(*[d[n] for n, _ in LraOpts._fields_])
+    res = AlignmentsResult()
+    v = C.c_void_p
+    ctx.check(ctx.lib.lra_local_refine_batch(ctx.h, C.c_uint64(inp.n_jobs), v(inp.d_job_chain_off), v(inp.d_job_read), v(inp.d_job_h), C.c_uint64(inp.n_chains),
+                                             v(inp.d_chain_anchor_off), v(inp.d_chain_strand), v(inp.d_chain_chrom), v(inp.d_chain_value), v(inp.d_chain_n0),
+                                             v(inp.d_chain_n1), C.c_uint64(inp.n_anchors), v(inp.d_q), v(inp.d_t), v(inp.d_len), ptr(read_off), ptr(strands),
+                                             C.c_uint64(int(rc_base)), ptr(genome), C.c_void_p(cp.ctypes.data), len(cp) - 1, C.byref(o), C.byref(res)))
+    return inp, res

@@ -20,6 +20,10 @@
 #include <algorithm>
 #include <vector>
 
+#include <cstdio>
+#include <cstdlib>
+#define LR_DBG(...) do { if (getenv("LRA_DEBUG")) { (void)hipStreamSynchronize(ctx->stream); fprintf(stderr, __VA_ARGS__); fprintf(stderr, " [%s]\n", hipGetErrorString(hipGetLastError())); } } while (0)
+
 namespace {
 
 constexpr uint32_t NONE = 0xFFFFFFFFu;
@@ -463,6 +467,7 @@ extern "C" int lra_local_refine_batch(lra_ctx* ctx, uint64_t n_jobs, const uint6
   LRA_HIP_CHECK(ctx, hipMemcpyAsync(&nDir, dirId + NA, 8, hipMemcpyDeviceToHost, st));
   LRA_HIP_CHECK(ctx, hipMemcpyAsync(&nBig, bigId + NA, 8, hipMemcpyDeviceToHost, st));
   LRA_HIP_CHECK(ctx, hipStreamSynchronize(st));
+  LR_DBG("classified: NA %llu nDir %llu nBig %llu", (unsigned long long)NA, (unsigned long long)nDir, (unsigned long long)nBig);
   a.nBig = nBig; out->n_big = nBig;
   // ---- 2: direct pairs
   uint64_t d1Blocks = 0;
@@ -543,6 +548,7 @@ extern "C" int lra_local_refine_batch(lra_ctx* ctx, uint64_t n_jobs, const uint6
     LRA_HIP_CHECK(ctx, hipMemcpyAsync(&nJ, jobId + 2 * nBig, 8, hipMemcpyDeviceToHost, st));
     LRA_HIP_CHECK(ctx, hipStreamSynchronize(st));
   }
+  LR_DBG("spaces done: nF %llu nRev %llu nR %llu nJ %llu", (unsigned long long)nF, (unsigned long long)nRev, (unsigned long long)nR, (unsigned long long)nJ);
   a.nJ = nJ; out->n_inner_jobs = nJ;
   // ---- 6: seed-set jobs
   char* wj = (char*)lra_ensure(ctx, 47, sz(nJ + 2, 4) * 12 + sz(nJ + 2, 8) * 7 + sz(nJ + 2, 1) * 2 + 4096);
@@ -610,6 +616,7 @@ extern "C" int lra_local_refine_batch(lra_ctx* ctx, uint64_t n_jobs, const uint6
     LRA_HIP_CHECK(ctx, hipMemcpyAsync(&nJobProb, pOff + nJ, 8, hipMemcpyDeviceToHost, st));
     LRA_HIP_CHECK(ctx, hipStreamSynchronize(st));
   } else LRA_HIP_CHECK(ctx, hipMemsetAsync(pOff, 0, 16, st));
+  LR_DBG("jobs done: nJobProb %llu", (unsigned long long)nJobProb);
   a.nJobProb = nJobProb;
   if (nBig) {
     hipLaunchKernelGGL(lr_whole, grid(nBig), dim3(256), 0, st, a, 0);
@@ -634,6 +641,7 @@ extern "C" int lra_local_refine_batch(lra_ctx* ctx, uint64_t n_jobs, const uint6
       a.d2Off = b2.d_block_off; a.d2Blk = b2.d_blocks;
     }
   }
+  LR_DBG("second AOG done: nP2 %llu", (unsigned long long)nP2);
   // ---- 8: the walk
   lra_time_begin(ctx, "local_refine");
   hipLaunchKernelGGL(lr_walk<0>, grid(NJ0), dim3(256), 0, st, a);
@@ -644,6 +652,7 @@ extern "C" int lra_local_refine_batch(lra_ctx* ctx, uint64_t n_jobs, const uint6
   LRA_HIP_CHECK(ctx, hipMemcpyAsync(&nAln, alnOff + NJ0, 8, hipMemcpyDeviceToHost, st));
   LRA_HIP_CHECK(ctx, hipMemcpyAsync(&nBlk, blkOff + NJ0, 8, hipMemcpyDeviceToHost, st));
   LRA_HIP_CHECK(ctx, hipStreamSynchronize(st));
+  LR_DBG("walk counted: nAln %llu nBlk %llu", (unsigned long long)nAln, (unsigned long long)nBlk);
   char* wo = (char*)lra_ensure(ctx, 51, sz(nAln + 2, 4) * 7 + sz(nAln + 2, 8) + sz(3 * nBlk + 3, 4) + 4096);
   if (!wo) return LRA_ERR_NOMEM;
   Carver co{wo};
@@ -659,5 +668,106 @@ extern "C" int lra_local_refine_batch(lra_ctx* ctx, uint64_t n_jobs, const uint6
   out->n_alignments = nAln; out->n_blocks = nBlk; out->d_job_aln_off = alnOff; out->d_strand = a.oStrand; out->d_supp = a.oSupp; out->d_secondary = a.oSec; out->d_n0 = a.oN0;
   out->d_n1 = a.oN1; out->d_chrom = a.oChrom; out->d_value = a.oValue; out->d_block_off = a.oBlockOff; out->d_blocks = a.oBlocks; out->d_status = a.status;
   (void)nR;
+  return LRA_OK;
+}
+
+// ---- from the second sparse DP to the inputs of lra_local_refine_batch (Map_lowacc.h:530-540) ------------------------------------------------
+namespace {
+
+// (the second sparse DP's result has num_aln slots per merged cluster; its one chain is in the first)
+__global__ void pi_len(uint64_t ng, int na2, const uint32_t* __restrict__ nChains, const uint32_t* __restrict__ chainLen, const uint32_t* __restrict__ status, uint32_t* len) {
+  const uint64_t g = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (g < ng) len[g] = (status[g] || nChains[g] == 0) ? 0 : chainLen[g * na2];
+}
+__global__ void __launch_bounds__(64) pi_gather(uint64_t ng, int na2, const uint64_t* __restrict__ off, const uint64_t* __restrict__ chainStart, const uint32_t* __restrict__ cq,
+                                                const uint32_t* __restrict__ ct, const int32_t* __restrict__ cl, const int32_t* __restrict__ gstrand, uint32_t* q, uint32_t* t,
+                                                int32_t* l, uint8_t* s) {
+  for (uint64_t g = blockIdx.x; g < ng; g += gridDim.x) {
+    const uint64_t o = off[g], b = chainStart[g * na2];
+    const uint32_t n = (uint32_t)(off[g + 1] - o);
+    for (uint32_t i = threadIdx.x; i < n; i += 64) { q[o + i] = cq[b + i]; t[o + i] = ct[b + i]; l[o + i] = cl[b + i]; s[o + i] = (uint8_t)(gstrand[g] != 0); }
+  }
+}
+__global__ void __launch_bounds__(64) pi_kept(uint64_t ng, const uint64_t* __restrict__ off, const uint64_t* __restrict__ koff, const uint8_t* __restrict__ keep,
+                                              const uint32_t* __restrict__ q, const uint32_t* __restrict__ t, const int32_t* __restrict__ l, uint32_t* oq, uint32_t* ot, int32_t* ol) {
+  const int lane = threadIdx.x;
+  for (uint64_t g = blockIdx.x; g < ng; g += gridDim.x) {
+    const uint64_t o = off[g];
+    const uint32_t n = (uint32_t)(off[g + 1] - o);
+    uint64_t w = koff[g];
+    for (uint32_t b0 = 0; b0 < n; b0 += 64) {
+      const uint32_t i = b0 + lane;
+      const bool k = i < n && keep[o + i];
+      const unsigned long long m = __ballot(k);
+      if (k) { const uint64_t d = w + __popcll(m & ((1ull << lane) - 1)); oq[d] = q[o + i]; ot[d] = t[o + i]; ol[d] = l[o + i]; }
+      w += __popcll(m);
+    }
+  }
+}
+__global__ void pi_jobs(uint64_t nslots, int numAln, const uint32_t* __restrict__ firstLen, uint32_t* jobRead, int32_t* jobH) {
+  const uint64_t s = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  (void)firstLen;
+  if (s < nslots) { jobRead[s] = (uint32_t)(s / numAln); jobH[s] = (int32_t)(s % numAln); }
+}
+__global__ void pi_chains(uint64_t ng, int na2, const uint32_t* __restrict__ gslot, const uint32_t* __restrict__ firstLen, const uint32_t* __restrict__ len, const float* __restrict__ val,
+                          int32_t* n0, int32_t* n1, float* v) {
+  const uint64_t g = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (g < ng) { n0[g] = firstLen ? (int32_t)firstLen[gslot[g]] : 0; n1[g] = (int32_t)len[g]; v[g] = val[g * na2]; }
+}
+
+}  // namespace
+
+// Map_lowacc.h:530-540 + :575: the chains of the per-merged-cluster sparse DP (`second`, single-cluster mode over lra_merge_extend_batch's output)
+// go through RemovePairedIndels<UltimateChain> and RemoveSpuriousAnchors (lra_filter_chains_batch ops {2, 4}) and become the ultimatechains of
+// their primary chain: job = chain slot of the first sparse DP, chains = its merged clusters in order.  FirstSDPValue = the second DP's best
+// value (:2427), NumOfAnchors1 = its chain length (:2430); NumOfAnchors0 = d_slot_n0[slot] (chains[p].NumOfAnchors0 of the first sparse DP, whose
+// result arrays the second one has overwritten by now: the caller keeps what it needs; NULL = 0; it only feeds MAPQ).
+extern "C" int lra_local_refine_inputs_batch(lra_ctx* ctx, int num_aln, const uint32_t* d_slot_n0, const lra_merge_result* mg, const lra_chain_result* second,
+                                             lra_local_refine_inputs* out) {
+  if (!ctx || num_aln < 1 || !mg || !second || !out) return LRA_ERR_INVALID;
+  memset(out, 0, sizeof *out);
+  LRA_HIP_CHECK(ctx, hipSetDevice(ctx->device));
+  hipStream_t st = ctx->stream;
+  const uint64_t NG = mg->n_groups, slots = mg->n_slots;
+  out->n_jobs = slots; out->n_chains = NG;
+  if (slots == 0) return LRA_OK;
+  auto grid = [](uint64_t n) { return dim3((unsigned)((n + 255) / 256)); };
+  char* w = (char*)lra_ensure(ctx, 52, sz(NG + 2, 4) * 3 + sz(NG + 2, 8) * 2 + sz(NG + 2, 4) + sz(slots + 2, 4) * 2 + 4096);
+  if (!w) return LRA_ERR_NOMEM;
+  Carver c{w};
+  uint32_t* len = c.take<uint32_t>(NG + 2); int32_t* n0 = c.take<int32_t>(NG + 2); int32_t* n1 = c.take<int32_t>(NG + 2); float* val = c.take<float>(NG + 2);
+  uint64_t* off = c.take<uint64_t>(NG + 2); uint64_t* koff = c.take<uint64_t>(NG + 2);
+  uint32_t* jobRead = c.take<uint32_t>(slots + 2); int32_t* jobH = c.take<int32_t>(slots + 2);
+  hipLaunchKernelGGL(pi_jobs, grid(slots), dim3(256), 0, st, slots, num_aln, d_slot_n0, jobRead, jobH);
+  out->d_job_chain_off = mg->d_slot_group_off; out->d_job_read = jobRead; out->d_job_h = jobH; out->d_chain_strand = mg->d_strand; out->d_chain_chrom = mg->d_chrom;
+  out->d_chain_value = val; out->d_chain_n0 = n0; out->d_chain_n1 = n1; out->d_chain_anchor_off = koff;
+  if (NG == 0) { LRA_HIP_CHECK(ctx, hipMemsetAsync(koff, 0, 16, st)); LRA_HIP_CHECK(ctx, hipStreamSynchronize(st)); return LRA_OK; }
+  hipLaunchKernelGGL(pi_len, grid(NG), dim3(256), 0, st, NG, (int)second->num_aln, second->d_n_chains, second->d_chain_len, second->d_status, len);
+  { int rc = lra_exclusive_scan<uint32_t>(ctx, (long)NG, len, off); if (rc) return rc; }
+  uint64_t NA2 = 0;
+  LRA_HIP_CHECK(ctx, hipMemcpyAsync(&NA2, off + NG, 8, hipMemcpyDeviceToHost, st));
+  LRA_HIP_CHECK(ctx, hipStreamSynchronize(st));
+  char* wa = (char*)lra_ensure(ctx, 53, sz(NA2 + 1, 4) * 6 + sz(NA2 + 1, 1) + 4096);
+  if (!wa) return LRA_ERR_NOMEM;
+  Carver ca{wa};
+  uint32_t* q = ca.take<uint32_t>(NA2 + 1); uint32_t* t = ca.take<uint32_t>(NA2 + 1); int32_t* l = ca.take<int32_t>(NA2 + 1);
+  uint32_t* oq = ca.take<uint32_t>(NA2 + 1); uint32_t* ot = ca.take<uint32_t>(NA2 + 1); int32_t* ol = ca.take<int32_t>(NA2 + 1); uint8_t* s8 = ca.take<uint8_t>(NA2 + 1);
+  const unsigned gw = (unsigned)std::min<uint64_t>(NG, (uint64_t)ctx->num_cu * 32);
+  hipLaunchKernelGGL(pi_gather, dim3(gw), dim3(64), 0, st, NG, (int)second->num_aln, (const uint64_t*)off, second->d_chain_start, second->d_chain_q, second->d_chain_t, second->d_chain_alen,
+                     mg->d_strand, q, t, l, s8);
+  hipLaunchKernelGGL(pi_chains, grid(NG), dim3(256), 0, st, NG, (int)second->num_aln, mg->d_group_slot, d_slot_n0, (const uint32_t*)len, second->d_chain_value, n0, n1, val);
+  LR_DBG("inputs: NG %llu NA2 %llu", (unsigned long long)NG, (unsigned long long)NA2);
+  lra_filter_result fr;
+  const int ops[2] = {2, 4};
+  { int rc = lra_filter_chains_batch(ctx, NG, off, NA2, q, t, l, s8, nullptr, ops, 2, &fr); if (rc) return rc; }
+  { int rc = lra_exclusive_scan<uint32_t>(ctx, (long)NG, fr.d_n_kept, koff); if (rc) return rc; }
+  uint64_t NK = 0;
+  LRA_HIP_CHECK(ctx, hipMemcpyAsync(&NK, koff + NG, 8, hipMemcpyDeviceToHost, st));
+  LRA_HIP_CHECK(ctx, hipStreamSynchronize(st));
+  LR_DBG("filtered: NK %llu", (unsigned long long)NK);
+  hipLaunchKernelGGL(pi_kept, dim3(gw), dim3(64), 0, st, NG, (const uint64_t*)off, (const uint64_t*)koff, fr.d_keep, (const uint32_t*)q, (const uint32_t*)t, (const int32_t*)l, oq, ot, ol);
+  LRA_HIP_CHECK(ctx, hipStreamSynchronize(st));
+  LRA_HIP_CHECK(ctx, hipGetLastError());
+  out->n_anchors = NK; out->d_q = oq; out->d_t = ot; out->d_len = ol;
   return LRA_OK;
 }

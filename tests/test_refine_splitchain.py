@@ -471,9 +471,10 @@ def _second_sdp_chains(ctx, oracle, P):
                 st = int(mo["strand"][G])
                 keep, _ = O.filter_chain(q, t, ln, [st] * m, None, [2, 4])    # RemovePairedIndels + RemoveSpuriousAnchors (Map_lowacc.h:538-539)
                 kb = keep.astype(bool)
-                chains.append((q[kb], t[kb], ln[kb], st, int(mo["chrom"][G]), float(c2["chain_value"][G * cres2.num_aln])))
+                chains.append((q[kb], t[kb], ln[kb], st, int(mo["chrom"][G]), float(c2["chain_value"][G * cres2.num_aln]), m))
             if chains:
                 jobs.append((r, c, chains))
+    P["_mres"] = mres; P["_cres2"] = cres2; P["_mo"] = mo
     return jobs
 
 
@@ -489,7 +490,7 @@ def test_hip_local_refine_alignment_oracle(ctx, oracle):
     dev = ctx.device
     jco = [0]; jr = []; jh = []; cao = [0]; cs = []; cc = []; cv = []; c0 = []; c1 = []; Q = []; T = []; Ln = []
     for (r, h, chains) in jobs:
-        for (q, t, ln, st, ch, val) in chains:
+        for (q, t, ln, st, ch, val, _m) in chains:
             Q.extend(q.tolist()); T.extend(t.tolist()); Ln.extend(ln.tolist()); cao.append(len(Q)); cs.append(st); cc.append(ch); cv.append(val); c0.append(len(q)); c1.append(7)
         jco.append(len(cs)); jr.append(r); jh.append(h)
     tt = lambda a, dt: torch.from_numpy(np.ascontiguousarray(a, dtype=dt)).to(dev)
@@ -503,7 +504,7 @@ def test_hip_local_refine_alignment_oracle(ctx, oracle):
     for ji, (r, h, chains) in enumerate(jobs):
         fwd = reads[r].tobytes(); rc = synth.revcomp(reads[r]).tobytes()
         off = [0]; aq = []; at = []; al = []
-        for (q, t, ln, st, ch, val) in chains:
+        for (q, t, ln, st, ch, val, _m) in chains:
             aq.extend(q.tolist()); at.extend(t.tolist()); al.extend(ln.tolist()); off.append(len(aq))
         nch = len(chains)
         exp = O.local_refine_alignment(off, aq, at, al, [x[3] for x in chains], [x[4] for x in chains], [x[5] for x in chains], c0[ci:ci + nch], c1[ci:ci + nch], h, fwd, rc,
@@ -605,3 +606,44 @@ def test_hip_local_refine_events_oracle(ctx):
         n_multi += len(exp) > 1
     print("a13 events: jobs with several alignments %d, inverted alignments %d, large spaces %d, seed-set jobs %d" % (n_multi, n_inv, res.n_big, res.n_inner_jobs))
     assert n_multi >= 8 and n_inv >= 2 and res.n_big >= 24
+
+
+@pytest.mark.gpu
+def test_hip_local_refine_from_sdp_on_device(ctx, oracle):
+    """the same walk fed on the device: second sparse DP -> filters {2, 4} -> job / chain arrays (lra_local_refine_inputs_batch) -> a13, no host
+    round trip; checked against the oracle with the host-built chains"""
+    import torch
+    from lra_amd import chain, synth
+    P = _front_end(ctx, oracle)
+    co, na, n = P["co"], P["na"], P["n"]
+    slot_n0 = torch.from_numpy(co["chain_len"].astype(np.int32)).to(ctx.device)          # kept before the second sparse DP reuses the result buffers
+    jobs = _second_sdp_chains(ctx, oracle, P)
+    reads, genome, batch, both, tot, gdev, CH = (P[k] for k in ("reads", "genome", "batch", "both", "tot", "gdev", "CH"))
+    inp, res = chain.local_refine_from_sdp(ctx, na, slot_n0, P["_mres"], P["_cres2"], batch.off, both, tot, gdev, CH)
+    out = chain.fetch_alignments(ctx, res)
+    assert int(res.n_jobs) == n * na
+    gbytes = genome.tobytes()
+    by_slot = {r * na + h: chains for (r, h, chains) in jobs}
+    n_checked = 0
+    for s in range(n * na):
+        a0, a1 = int(out["job_aln_off"][s]), int(out["job_aln_off"][s + 1])
+        chains = by_slot.get(s)
+        if chains is None:
+            assert a1 == a0, s
+            continue
+        r, h = s // na, s % na
+        # the device keeps empty / unchained merged clusters as empty chains: they only shift LSC's index, never its choice (size 0 never wins)
+        off = [0]; aq = []; at = []; al = []
+        for (q, t, ln, st, ch, val, m) in chains:
+            aq.extend(q.tolist()); at.extend(t.tolist()); al.extend(ln.tolist()); off.append(len(aq))
+        exp = O.local_refine_alignment(off, aq, at, al, [x[3] for x in chains], [x[4] for x in chains], [x[5] for x in chains], [int(co["chain_len"][s])] * len(chains),
+                                       [x[6] for x in chains], h, reads[r].tobytes(), synth.revcomp(reads[r]).tobytes(), gbytes, CH)
+        assert exp is not None and out["status"][s] == 0 and a1 - a0 == len(exp), (s, a1 - a0, None if exp is None else len(exp))
+        for k, e in enumerate(exp):
+            x = a0 + k
+            for f in ("strand", "secondary", "n0", "n1", "chrom"):
+                assert int(out[f][x]) == e[f], (s, k, f, int(out[f][x]), e[f])
+            b0, b1 = int(out["block_off"][x]), int(out["block_off"][x + 1])
+            assert b1 - b0 == len(e["blocks"]) and np.array_equal(out["blocks"][b0:b1], e["blocks"]), (s, k)
+        n_checked += 1
+    assert n_checked >= 40
