@@ -1,24 +1,15 @@
 #!/usr/bin/env python
 """bench.py -- throughput of the MI355X hot path on synthetic long reads.
 
-One "step" = one pass of the GPU-resident hot-path stages over one batch of reads already in HBM:
+One "step" = MapRead_lowacc (the -ONT / -CLR path of `lra align`) over one batch of reads already in HBM, every stage consuming what the previous one
+produced on the device:
   a1-a4  tier-1 seeding   (StoreMinimizers -> sort -> CompareLists -> SeparateMatchesByStrand)
-  a5     CleanMatches      (diagonal sort, CleanOffDiagonal, clusters) on those matches
-  a7     LinearExtend + DecideCoordinates on those clusters
-  a8     SparseDP (SDP#A): the primary chain(s) of every read over those anchors
-  a9     RemoveSpuriousJump, SPLITChain, RemoveSpuriousSplitChain on those chains
-  a10    tier-2 lookup: CreateRC, LocalIndex::IndexSeq of both strands, Refine_splitchain on every split chain of a9 (the window
-         walk, CompareLists<LocalTuple> of every (read window, genome window) it meets, AppendValues, boundaries)
-  a12    AffineOneGapAlign on the between-anchor gaps of every read
-  a14    IndelRefineAlignment over every read's block list
-  a16    CalculateStatistics (CIGAR runs, NM/NX/ND/NI/TD/TI counters, NV) on the refined blocks
-  a11    Refine_Btwnsplitchain (RefineSpace on the spaces between / beyond the refined clusters), then MergeChain, the second
-         LinearExtend + TrimOverlappedAnchors and the second sparse DP on every merged cluster (Map_lowacc.h:362-540)
-The stage between the second sparse DP and a12/a14 (a13: LocalRefineAlignment's chain walk) is
-NOT built yet, so the a12/a14 inputs are derived from the simulator's true alignment (anchors =
-true gapless blocks >= 12 bp; the gaps between them go to a12; a perturbed block list goes to
-a14).  `config.stages` says so; the number is the throughput of the stages listed, not of a
-whole `lra align`.
+  a5     CleanMatches;  a7 LinearExtend + DecideCoordinates;  a8 SparseDP (SDP#A)
+  a9     chain filters, SPLITChain;  a10 CreateRC, LocalIndex::IndexSeq of both strands, Refine_splitchain
+  a11    Refine_Btwnsplitchain;  a9 MergeChain;  a7 second LinearExtend + TrimOverlappedAnchors;  a8 the per-merged-cluster sparse DP + its filters
+  a13    LocalRefineAlignment (incl. a12 AffineOneGapAlign between anchors, RefineSpace + inner sparse DP on large spaces)
+  a14    IndelRefineAlignment on those alignments;  a16 CalculateStatistics (CIGAR runs, NM/NX/ND/NI/TD/TI counters, NV)
+Not in the step: RefineBreakpoint (built, off by default in lra), the per-read MAPQ / ordering / SAM text (host code, built).
 
 Contract: python bench.py --gpus N --steps K --warmup W  -> rank 0 prints ONE JSON line.
 """
@@ -171,12 +162,8 @@ def main():
         rbatch = seed.read_batch_from_device(ctx, wl["reads"], sim["off"])
         gp = wl["gaps"]
         gdev = torch.cat([wl["genome"], torch.zeros(64, dtype=torch.uint8, device=ctx.device)])
-        abatch = align.AogBatch.from_device(ctx, wl["strands"], gdev, gp["q_off"], gp["q_len"], gp["t_off"], gp["t_len"], gp["k"], 4, -1, -2)   # -ONT scores
         lens = (sim["off"][1:] - sim["off"][:-1])
         nR = n_reads
-        fbatch = refine.refine_batch_from_device(ctx, wl["rblocks"], wl["rboff"], wl["strands"], sim["off"][:-1], lens,
-                                                 gdev, torch.zeros(nR, dtype=torch.int64, device=ctx.device),
-                                                 torch.full((nR,), int(wl["genome"].numel()), dtype=torch.int64, device=ctx.device))
         # a10 inputs: genome local index (the `.gli` payload, built once: tuples, tupleBoundaries, seqOffsets) and one buffer holding
         # the reads forward followed by their reverse complements (forwardIndex / reverseIndex, Map_lowacc.h:246-250)
         from lra_amd import local
@@ -202,6 +189,8 @@ def main():
             # a8: SDP#A over the extended anchors of every read (Map_lowacc.h:185-188)
             chres = chain.sparse_dp_batch(ctx, nR, cres.d_cluster_off, eres.d_e_start, eres.d_e_count, cres.d_c_strand, eres.d_e_qpos, eres.d_e_tpos,
                                           eres.d_e_len, rbatch.off, sdp_opts)
+            num_aln = int(chres.num_aln)
+            slot_n0 = ctx.to_tensor(chres.d_chain_len, nR * num_aln, torch.int32)          # chains[p].NumOfAnchors0 for a13 (the second sparse DP reuses these buffers)
             # a9: RemoveSpuriousJump + SPLITChain + RemoveSpuriousSplitChain on every chain (Map_lowacc.h:189-256)
             spres = chain.split_chains_batch(ctx, chres, [0, int(wl["genome"].numel())])
             # a10: CreateRC, LocalIndex::IndexSeq of both strands, Refine_splitchain on every split chain (Map_lowacc.h:246-294)
@@ -219,9 +208,19 @@ def main():
             if "n_local_task_words" not in stats and rres.n_tasks:
                 t4 = [ctx.to_tensor(p_, rres.n_tasks, torch.int64) for p_ in (rres.d_task_q_lo, rres.d_task_q_hi, rres.d_task_t_lo, rres.d_task_t_hi)]
                 stats["n_local_task_words"] = int((t4[1] - t4[0]).sum() + (t4[3] - t4[2]).sum())
-            abatch.run()
-            fres = refine.indel_refine_batch(ctx, fbatch, args.refine_band, 4, -1, -2)
-            tres = refine.stats_of_refined(ctx, fbatch, fres, lut)
+            # a13: filters of the second sparse DP + LocalRefineAlignment: the chains become alignments (blocks) (Map_lowacc.h:538-576)
+            inp, ares = chain.local_refine_from_sdp(ctx, num_aln, slot_n0, mres, ch2, rbatch.off, both, tot, gdev, [0, G])
+            # a14 + a16 on those alignments: IndelRefineAlignment, CalculateStatistics (Map_lowacc.h:582-597)
+            nA = int(ares.n_alignments)
+            aoff = ctx.to_tensor(ares.d_job_aln_off, int(ares.n_jobs) + 1, torch.int64)
+            aln_read = torch.repeat_interleave(torch.arange(int(ares.n_jobs), device=ctx.device), aoff[1:] - aoff[:-1]) // num_aln
+            a_strand = ctx.to_tensor(ares.d_strand, nA, torch.int32).to(torch.int64)
+            fb = refine.refine_batch_from_device(ctx, ctx.to_tensor(ares.d_blocks, 3 * int(ares.n_blocks), torch.int32).view(-1, 3),
+                                                 ctx.to_tensor(ares.d_block_off, nA + 1, torch.int64), both, rbatch.off[aln_read] + a_strand * tot, lens[aln_read],
+                                                 gdev, torch.zeros(nA, dtype=torch.int64, device=ctx.device), torch.full((nA,), G, dtype=torch.int64, device=ctx.device))
+            fres = refine.indel_refine_batch(ctx, fb, args.refine_band, 4, -1, -2)
+            tres = refine.stats_of_refined(ctx, fb, fres, lut)
+            stats.update(n_alignments=nA, n_a13_blocks=int(ares.n_blocks), n_large_spaces=int(ares.n_big))
             # the one exchange step: refined block records -> rank 0
             rec = ctx.to_tensor(fres.d_blocks, 3 * fres.n_blocks, torch.int32)
             out_rec[0] = rec
@@ -296,7 +295,7 @@ def main():
 
     kernels = ["sketch_count", "sketch_serial", "sketch_emit", "sort", "sort_fallback", "index_bounds", "compare", "strand",
                "aog_lds_tiny", "aog_lds_small", "aog_lds_large", "aog_hbm", "ir_segment", "ir_band", "ir_fill", "ir_trace", "ir_gather", "clean_sort", "clean", "linear_extend", "stats", "stats_cigar", "create_rc", "local_sketch", "local_sort_filter", "local_compare",
-               "rsc_tasks", "rsc_filter", "refine_space", "refine_space_long", "btwn_plan", "btwn_apply", "merge_extend", "chain_split", "sdp_points", "sdp_sort", "sdp_sort_fallback", "sdp_build_count", "sdp_build", "sdp_process", "sdp_trace"]
+               "rsc_tasks", "rsc_filter", "refine_space", "refine_space_long", "btwn_plan", "btwn_apply", "merge_extend", "between_anchors", "local_refine", "chain_split", "sdp_points", "sdp_sort", "sdp_sort_fallback", "sdp_build_count", "sdp_build", "sdp_process", "sdp_trace"]
     ktimes = {}
     for k in kernels:
         tt_ = [l["ctx"].timing_get(k) for l in lanes]
@@ -356,7 +355,7 @@ def main():
         except (OSError, ValueError, KeyError):
             pass
         out = {
-            "metric": "aligned Gbp/s (hot-path stages a1-a5, a7, a8 SDP#A, a9 split + MergeChain, a10 Refine_splitchain, a11 Refine_Btwnsplitchain, a7/a8 second pass, a12, a14, a16), 30 kb ONT-like reads", "value": gbps, "unit": "Gbp/s",
+            "metric": "aligned Gbp/s (hot-path stages a1-a5, a7, a8 SDP#A, a9 split + MergeChain, a10 Refine_splitchain, a11 Refine_Btwnsplitchain, a7/a8 second pass, a13 LocalRefineAlignment incl. a12, a14, a16 = MapRead_lowacc), 30 kb ONT-like reads", "value": gbps, "unit": "Gbp/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_step, "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "int32", "data": "synthetic",
             "reads_per_s": nreads * args.steps / dt,
@@ -364,9 +363,10 @@ def main():
                                    "error 30:35:35 (BASELINE configs[2] -ONT read profile; full GRCh38 not generated in round 1)"
                                    % (args.genome_mb, args.reads, args.read_len, args.err * 100),
                        "preset": "-ONT (k=%d w=%d maxFreq=%d refineBand=%d match/mismatch/indel=4/-1/-2)" % (args.k, args.w, args.max_freq, args.refine_band),
-                       "stages": "a1-a5,a7,a8(SDP#A),a9(chain split),a10(Refine_splitchain),a11(Refine_Btwnsplitchain),a9(MergeChain),a7(second LinearExtend+Trim),a8(second "
-                                 "SDP) chained on the reads = MapRead_lowacc up to Map_lowacc.h:540; a12 on between-anchor gaps and a14 on block lists derived "
-                                 "from the simulator's truth, a16 on a14's output (a13 LocalRefineAlignment glue not built yet: NOT a whole `lra align`)",
+                       "stages": "MapRead_lowacc chained on the reads, every stage on the alignments the previous one produced: a1-a5, a7, a8 (SDP#A), a9 (chain filters, SPLITChain), "
+                                 "a10 (Refine_splitchain), a11 (Refine_Btwnsplitchain), a9 (MergeChain), a7 (second LinearExtend + Trim), a8 (second SDP + filters), a13 "
+                                 "(LocalRefineAlignment incl. a12 AffineOneGapAlign between anchors), a14 (IndelRefineAlignment), a16 (CalculateStatistics).  Not in the step: "
+                                 "RefineBreakpoint (a15, built; off by default in lra), MAPQ / ordering / SAM text (a16-a17 host code, built)",
                        "parallelism": "reads sharded by ordinal, 1 process/GPU, %d sub-batches per process on their own HIP streams; RCCL gather of block records to rank 0" % args.lanes,
                        "per_step": {k: int(v) for k, v in stats.items() if not k.startswith("_")}},
             "kernel_ms_per_step": {k: round(v[0] / args.steps, 4) for k, v in ktimes.items() if v[1]},
