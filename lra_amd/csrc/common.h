@@ -28,6 +28,7 @@ struct lra_ctx {
   void* gbuf[56] = {};   // growable result / work buffers (lra_ensure)
   size_t gbytes[56] = {};
   // kernel timing
+  bool sdp_inner = false;                    // local_refine.hip: its small inner sparse DP is timed under "sdp_inner_*"
   const char* sort_tag = "sort"; const char* sort_fb_tag = "sort_fallback";   // timing names of the exact-sort kernels (sdp.hip retags them)
   bool timing = false;
   std::vector<lra_time_rec> recs;

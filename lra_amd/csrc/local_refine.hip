@@ -609,7 +609,10 @@ extern "C" int lra_local_refine_batch(lra_ctx* ctx, uint64_t n_jobs, const uint6
     memset(&so, 0, sizeof so);
     so.rate = 2.0f; so.NumAln = 1; so.alnthres = 0; so.gapopen = opts->gapopen; so.gapextend = opts->gapextend; so.gaproot = opts->gaproot; so.gapCeiling1 = opts->gapCeiling1;
     so.gapCeiling2 = opts->gapCeiling2; so.mode = LRA_SDP_SINGLE_CLUSTER; so.globalK = 0;
-    { int rc = lra_sparse_dp_batch(ctx, (int)nJ, iota, xOff, a.xCnt, zeros, a.xq, a.xt, a.xl, iota, nullptr, &so, &sdp); if (rc) return rc; }
+    ctx->sdp_inner = true;
+    const int rcS = lra_sparse_dp_batch(ctx, (int)nJ, iota, xOff, a.xCnt, zeros, a.xq, a.xt, a.xl, iota, nullptr, &so, &sdp);
+    ctx->sdp_inner = false;
+    if (rcS) return rcS;
     a.sStart = sdp.d_chain_start; a.sLen = sdp.d_chain_len; a.sAnchor = sdp.d_chain_anchor; a.sValue = sdp.d_chain_value; a.sStatus = sdp.d_status;
     hipLaunchKernelGGL(lr_inner_plan<0>, grid(nJ), dim3(256), 0, st, a);
     { int rc = lra_exclusive_scan<uint32_t>(ctx, (long)nJ, a.pCnt, pOff); if (rc) return rc; }

@@ -1099,7 +1099,7 @@ int sdp_run(lra_ctx* ctx, int n_reads, const uint64_t* d_cluster_off, const uint
   int32_t* chainNum = (int32_t*)take(wa, nslot, 4);
   LRA_HIP_CHECK(ctx, hipMemsetAsync(chainLen, 0, nslot * 4, st));
   if (NC > 0) {
-    lra_time_begin(ctx, "sdp_points");
+    lra_time_begin(ctx, ctx->sdp_inner ? "sdp_inner_points" : "sdp_points");
     hipLaunchKernelGGL(k_cluster_counts, dim3((unsigned)((NC + 255) / 256)), dim3(256), 0, st, NC, boxes ? nullptr : d_c_count, clusFragCnt, clusPtCnt,
                        opts->mode == LRA_SDP_SINGLE_CLUSTER);
     lra_time_end(ctx);
@@ -1151,15 +1151,15 @@ int sdp_run(lra_ctx* ctx, int n_reads, const uint64_t* d_cluster_off, const uint
     pa.fq = fq; pa.ft = ft; pa.flen = flen; pa.fcl = fcl; pa.fai = fai; pa.fval = fval; pa.fprevNode = fprevNode; pa.fprevInd = fprevInd; pa.fflags = fflags; pa.used = used; pa.fstrand = fstrand;
     pa.qe = d_qe; pa.te = d_te; pa.fqe = fqe; pa.fte = fte;
     pa.key1 = key1; pa.pay1 = pay1; pa.iq = iq; pa.it = it; pa.ifl = ifl; pa.ifr = ifr; pa.ptRead = ptRead;
-    lra_time_begin(ctx, "sdp_points");
+    lra_time_begin(ctx, ctx->sdp_inner ? "sdp_inner_points" : "sdp_points");
     hipLaunchKernelGGL(k_points, dim3((unsigned)((NC + 127) / 128)), dim3(128), 0, st, pa);
     hipLaunchKernelGGL(k_frag_read, dim3(n_reads), dim3(64), 0, st, n_reads, fragOff, fragRead);
     lra_time_end(ctx);
   }
-  struct Retag { lra_ctx* c; Retag(lra_ctx* x) : c(x) { c->sort_tag = "sdp_sort"; c->sort_fb_tag = "sdp_sort_fallback"; } ~Retag() { c->sort_tag = "sort"; c->sort_fb_tag = "sort_fallback"; } } retag(ctx);
+  struct Retag { lra_ctx* c; Retag(lra_ctx* x) : c(x) { c->sort_tag = c->sdp_inner ? "sdp_inner_sort" : "sdp_sort"; c->sort_fb_tag = c->sdp_inner ? "sdp_inner_sort_fallback" : "sdp_sort_fallback"; } ~Retag() { c->sort_tag = "sort"; c->sort_fb_tag = "sort_fallback"; } } retag(ctx);
   // the two point orders: (q, t, ind) / (t, q, ind) keys repeat only where two anchors share a corner, so the radix path takes nearly all lists
   { int rc = lra_sort_mostly_unique_batch(ctx, n_reads, ptOff, NP, key1, pay1, key3, pay3, 64); if (rc) return rc; }   // sort(H1, SortByRowOp)  :2171
-  lra_time_begin(ctx, "sdp_points");
+  lra_time_begin(ctx, ctx->sdp_inner ? "sdp_inner_points" : "sdp_points");
   hipLaunchKernelGGL(k_gather, dim3((unsigned)((NP + 255) / 256)), dim3(256), 0, st, NP, ptRead, ptOff, pay1, iq, it, ifl, ifr, hq, ht, hfl, hfr, key2, pay2,
                      key3, pay3);
   lra_time_end(ctx);
@@ -1172,7 +1172,7 @@ int sdp_run(lra_ctx* ctx, int n_reads, const uint64_t* d_cluster_off, const uint
                                               (unsigned int)NP, (unsigned int)n_reads, (uint64_t*)nullptr, (uint64_t*)nullptr, 0, 42, st);
     void* temp = lra_scratch(ctx, 2, temp_bytes + 256);
     if (!temp) return LRA_ERR_NOMEM;
-    lra_time_begin(ctx, "sdp_sort");
+    lra_time_begin(ctx, ctx->sdp_inner ? "sdp_inner_sort" : "sdp_sort");
     hipError_t e = rocprim::segmented_radix_sort_pairs(temp, temp_bytes, key3, key1, pay3, pay1, (unsigned int)NP, (unsigned int)n_reads, ptOff, ptOff + 1,
                                                        0, 42, st);
     lra_time_end(ctx);
@@ -1216,7 +1216,7 @@ int sdp_run(lra_ctx* ctx, int n_reads, const uint64_t* d_cluster_off, const uint
     memset(&ba, 0, sizeof ba);
     ba.r0 = r0; ba.n = nr; ba.ptOff = ptOff; ba.hq = hq; ba.ht = ht; ba.hfl = hfl; ba.h2 = pay2; ba.key3 = key1; ba.pay3 = pay1; ba.scratch = scratch;
     ba.cntEntries = cntE; ba.cntNodes = cntN; ba.cntD = cntD; ba.cntV = cntV; ba.status = status; ba.order = order;
-    lra_time_begin(ctx, "sdp_build_count");
+    lra_time_begin(ctx, ctx->sdp_inner ? "sdp_inner_build_count" : "sdp_build_count");
     hipLaunchKernelGGL(sdp_build<false>, dim3(nr), dim3(64), 0, st, ba);
     lra_time_end(ctx);
     { int rc = lra_exclusive_scan<uint32_t>(ctx, nr, cntE, entOff); if (rc) return rc; }
@@ -1238,7 +1238,7 @@ int sdp_run(lra_ctx* ctx, int n_reads, const uint64_t* d_cluster_off, const uint
       char* arena = (char*)lra_ensure(ctx, slot, totB + 4096);
       if (!arena) return LRA_ERR_NOMEM;
       hipLaunchKernelGGL(k_arena_bases, dim3((nsub + 255) / 256), dim3(256), 0, st, nsub, byteOff, ra, subOrder, arena);
-      lra_time_begin(ctx, "sdp_build");
+      lra_time_begin(ctx, ctx->sdp_inner ? "sdp_inner_build" : "sdp_build");
       hipLaunchKernelGGL(k_visit_clear, dim3(nsub), dim3(256), 0, st, ra, byteOff, subOrder);
       ba.ra = ra; ba.order = subOrder;
       hipLaunchKernelGGL(sdp_build<true>, dim3(nsub), dim3(64), 0, st, ba);
@@ -1250,7 +1250,7 @@ int sdp_run(lra_ctx* ctx, int n_reads, const uint64_t* d_cluster_off, const uint
       pa.fprevNode = fprevNode; pa.fprevInd = fprevInd; pa.fflags = fflags; pa.rate_in = d_rate; pa.rate = opts->rate; pa.ra = ra;
       pa.status = status; pa.pwl = pw; pa.poolUsed = poolUsed;
       LRA_HIP_CHECK(ctx, hipMemsetAsync(poolUsed, 0, (size_t)nr * 4, st));
-      lra_time_begin(ctx, "sdp_process");
+      lra_time_begin(ctx, ctx->sdp_inner ? "sdp_inner_process" : "sdp_process");
       hipLaunchKernelGGL(sdp_process, dim3(nsub), dim3(64), 0, st, pa);
       lra_time_end(ctx);
       if (att == 2) break;
@@ -1267,7 +1267,7 @@ int sdp_run(lra_ctx* ctx, int n_reads, const uint64_t* d_cluster_off, const uint
     }
     const uint64_t cf0 = h_frag[r0], cfn = h_frag[r1] - h_frag[r0];
     if (cfn > 0) {
-      lra_time_begin(ctx, "sdp_trace");
+      lra_time_begin(ctx, ctx->sdp_inner ? "sdp_inner_trace" : "sdp_trace");
       hipLaunchKernelGGL(k_valkeys, dim3((unsigned)((cfn + 255) / 256)), dim3(256), 0, st, cf0, cfn, fval, fragRead, fragOff, okey, opay);
       hipLaunchKernelGGL(k_pred, dim3((unsigned)((cfn + 255) / 256)), dim3(256), 0, st, cf0, cfn, r0, (const uint32_t*)fragRead, (const uint32_t*)fprevNode,
                          (const uint32_t*)fprevInd, (const uint32_t*)status, (const ReadArena*)ra, spare);
@@ -1280,7 +1280,7 @@ int sdp_run(lra_ctx* ctx, int n_reads, const uint64_t* d_cluster_off, const uint
       ta.chainBox = chainBox; ta.chainValue = chainValue; ta.ccl = ccl; ta.can = can; ta.clink = clink; ta.status = status;
       ta.cq = cq; ta.ct = ct; ta.clen = clen; ta.cstrand = cstrand; ta.fstrand = fstrand;
       ta.boxes = boxes; ta.globalK = opts->globalK; ta.fqe = fqe; ta.fte = fte; ta.numAnchors = d_num_anchors; ta.chainNum = chainNum;
-      lra_time_begin(ctx, "sdp_trace");
+      lra_time_begin(ctx, ctx->sdp_inner ? "sdp_inner_trace" : "sdp_trace");
       hipLaunchKernelGGL(sdp_trace, dim3((nr + 63) / 64), dim3(64), 0, st, ta);
       lra_time_end(ctx);
     }
