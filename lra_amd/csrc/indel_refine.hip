@@ -36,6 +36,7 @@
 #include "common.h"
 #include "scan.h"
 #include <algorithm>
+#include <stdlib.h>
 
 int lra_aog_launch_device(lra_ctx* ctx, int n, const char* d_qseq, const char* d_tseq, const uint64_t* d_q_off,
                           const int32_t* d_q_len, const uint64_t* d_t_off, const int32_t* d_t_len, const int32_t* d_k,
@@ -179,8 +180,10 @@ __global__ void __launch_bounds__(64) ir_segment(IRArgs A) {
 // ---------------------------------------------------------------------------------- band
 struct __attribute__((aligned(16))) Row { int S, E; unsigned int C; int T; };   // window [S,E], cell offset in segment, target base
 
+constexpr int CB = 32;                // blocks per band chunk
+
 struct BandArgs {
-  uint64_t n_seg;
+  uint64_t n_seg, n_task;
   const int32_t* s_aln; const int32_t* s_kind; const int32_t* s_qStart; const int32_t* s_qEnd; const int32_t* s_tStart;
   const int32_t* s_b0; const int32_t* s_b1; const int32_t* s_first; const int32_t* s_lastLen;
   const uint64_t* s_rows; const uint64_t* s_row_off;
@@ -189,49 +192,142 @@ struct BandArgs {
   int k;
   Row* rows;
   uint64_t* s_cells; int32_t* s_status; int32_t* s_width; uint64_t* s_tmpcap;
+  uint32_t* s_nchunk; const uint64_t* chunk_off; uint32_t* task_seg; int32_t* chunkT; int32_t* chunkQ;
 };
 
-// One LANE per segment: the row-window construction of IndelRefine.h:220-333 replayed event by
-// event.  Only the 2k rows around the current target row can still change; they live in a
-// per-lane ring in LDS (lane-interleaved, conflict-free), finished rows stream out to HBM.
+// The block view of a segment: block b0 is the (possibly trimmed) first block, block b1 carries
+// the trimmed last length (IndelRefine.h:178-211).
+struct SegBlocks {
+  const int32_t* ab; long b0, b1; int fq, ft, fl, lastLen;
+  __device__ __forceinline__ void get(long b, long& q, long& t, long& l) const {
+    if (b == b0) { q = fq; t = ft; l = fl; }
+    else { q = ab[3 * b]; t = ab[3 * b + 1]; l = (b == b1) ? lastLen : ab[3 * b + 2]; }
+  }
+};
+__device__ __forceinline__ SegBlocks seg_blocks(const BandArgs& B, uint64_t s) {
+  SegBlocks v;
+  const int a = B.s_aln[s];
+  v.ab = B.ab + 3 * (B.block_off[a] + 2 * (uint64_t)a);
+  v.b0 = B.s_b0[s]; v.b1 = B.s_b1[s];
+  v.fq = B.s_first[3 * s]; v.ft = B.s_first[3 * s + 1]; v.fl = B.s_first[3 * s + 2]; v.lastLen = B.s_lastLen[s];
+  return v;
+}
+// What one iteration of the block loop (:232-315) consumes: the gaps to the next block after the
+// shared diagonal part `c` is moved into the block (:243-250), the target rows and the query
+// positions the iteration advances by.
+struct BlockStep { int bqGap, btGap; long blockLength, rows, advq; };
+__device__ __forceinline__ BlockStep block_step(const SegBlocks& sb, long b, long bq, long bt, long bl, long& nq2, long& nt2, long& nl2) {
+  BlockStep st; st.bqGap = 0; st.btGap = 0; st.blockLength = bl; nq2 = nt2 = nl2 = 0;
+  if (b < sb.b1) {
+    sb.get(b + 1, nq2, nt2, nl2);
+    st.bqGap = (int)(nq2 - (bq + bl)); st.btGap = (int)(nt2 - (bt + bl));
+    if (st.bqGap > 0 && st.btGap > 0) { int c = min(st.bqGap, st.btGap); st.bqGap -= c; st.btGap -= c; st.blockLength += c; }
+  }
+  const long body = st.blockLength > 0 ? st.blockLength : 0;
+  st.rows = body + (st.btGap > st.bqGap && st.btGap > 0 ? st.btGap : 0);
+  st.advq = body + (st.bqGap > st.btGap && st.bqGap > 0 ? st.bqGap : 0);
+  return st;
+}
+
+// chunks per segment: CB blocks each (0 for the AffineOneGapAlign segments)
+__global__ void ir_band_nchunk(BandArgs B) {
+  const uint64_t s = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (s >= B.n_seg) return;
+  B.s_nchunk[s] = (B.s_kind[s] != 0) ? 0u : (uint32_t)((B.s_b1[s] - B.s_b0[s] + 1 + CB - 1) / CB);
+}
+__global__ void ir_band_tasks(BandArgs B) {
+  const uint64_t s = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (s >= B.n_seg) return;
+  const uint64_t lo = B.chunk_off[s], hi = B.chunk_off[s + 1];
+  for (uint64_t x = lo; x < hi; x++) B.task_seg[x] = (uint32_t)s;
+  if (hi - lo <= 1) B.s_status[s] = 0;
+}
+
+// One WAVE per multi-chunk segment: the row / query position at which every chunk of CB blocks
+// starts (a prefix sum over the block steps), and whether the replay would run off the segment
+// (tOff reaches tLen early, or ends short of it, :253,:308 -> status 1): every step consumes
+// rows >= 0, so that happens exactly when the steps do not add up to tLen.
+__global__ void __launch_bounds__(64) ir_band_prep(BandArgs B) {
+  const uint64_t s = blockIdx.x;
+  const int lane = threadIdx.x;
+  const uint64_t co = B.chunk_off[s];
+  if (B.chunk_off[s + 1] - co <= 1) return;
+  const SegBlocks sb = seg_blocks(B, s);
+  const long nb = sb.b1 - sb.b0 + 1;
+  long long carryT = 0, carryQ = 0;
+  for (long base = 0; base < nb; base += 64) {
+    const long i = base + lane;
+    long long r = 0, q = 0;
+    if (i < nb) {
+      long bq, bt, bl, nq2, nt2, nl2;
+      sb.get(sb.b0 + i, bq, bt, bl);
+      const BlockStep st = block_step(sb, sb.b0 + i, bq, bt, bl, nq2, nt2, nl2);
+      r = st.rows; q = st.advq;
+    }
+    long long ir = r, iq = q;
+    for (int d = 1; d < 64; d <<= 1) {
+      long long orr = __shfl_up(ir, d), oq = __shfl_up(iq, d);
+      if (lane >= d) { ir += orr; iq += oq; }
+    }
+    if (i < nb && i > 0 && (i % CB) == 0) {
+      B.chunkT[co + i / CB] = (int32_t)(carryT + ir - r);
+      B.chunkQ[co + i / CB] = (int32_t)(sb.fq + carryQ + iq - q);
+    }
+    carryT += __shfl(ir, 63); carryQ += __shfl(iq, 63);
+  }
+  if (lane == 0) B.s_status[s] = (carryT != (long long)B.s_rows[s]) ? 1 : 0;
+}
+
+// One LANE per chunk of CB blocks: the row-window construction of IndelRefine.h:220-333 replayed
+// event by event.  Only the 2k rows around the current target row can still change; they live in a
+// per-lane ring in LDS (lane-interleaved, conflict-free), finished rows stream out to HBM.  An
+// event at row t touches rows t-k+1 .. t+k-1 only and rows do not interact, so a chunk that starts
+// at row T0 reproduces the state of rows >= T0-k+1 exactly by replaying, on an empty ring, from
+// any block that starts at or before row T0-2k+1; it walks the previous chunk's blocks
+// arithmetically up to that block, and owns (writes) the rows it retires from T0-k+1 on.
 template <int RS>
-__global__ void __launch_bounds__(64) ir_band_lane(BandArgs B) {
+__global__ void __launch_bounds__(64) ir_band_chunk(BandArgs B) {
   __shared__ int ringS[RS * 64], ringE[RS * 64];
   const int lane = threadIdx.x;
-  const uint64_t s = (uint64_t)blockIdx.x * 64 + lane;
-  if (s >= B.n_seg) return;
-  if (B.s_kind[s] != 0) { B.s_cells[s] = 0; B.s_status[s] = 0; B.s_width[s] = 0; B.s_tmpcap[s] = 0; return; }
+  const uint64_t x = (uint64_t)blockIdx.x * 64 + lane;
+  if (x >= B.n_task) return;
+  const uint64_t s = B.task_seg[x];
+  const uint64_t co = B.chunk_off[s];
+  const long c = (long)(x - co), nch = (long)(B.chunk_off[s + 1] - co);
+  const bool multi = nch > 1, lastChunk = (c == nch - 1);
+  if (multi && B.s_status[s] != 0) return;
   const long tLen = (long)B.s_rows[s];
-  const int a = B.s_aln[s];
-  const int32_t* ab = B.ab + 3 * (B.block_off[a] + 2 * (uint64_t)a);
-  const long b0 = B.s_b0[s], b1 = B.s_b1[s];
+  const SegBlocks sb = seg_blocks(B, s);
   const long qStart = B.s_qStart[s], qEnd = B.s_qEnd[s];
   const int k = B.k;
   Row* rows = B.rows + B.s_row_off[s];
   int status = 0;
 #define RG(arr, r) arr[(int)((r) & (RS - 1)) * 64 + lane]
-  for (int x = 0; x < RS; x++) { ringS[x * 64 + lane] = -1; ringE[x * 64 + lane] = -1; }
-  const int32_t fq = B.s_first[3 * s], ft = B.s_first[3 * s + 1], fl = B.s_first[3 * s + 2], lastLen = B.s_lastLen[s];
-  auto blk = [&](long b, long& q, long& t, long& l) {
-    if (b == b0) { q = fq; t = ft; l = fl; }
-    else { q = ab[3 * b]; t = ab[3 * b + 1]; l = (b == b1) ? lastLen : ab[3 * b + 2]; }
-  };
+  for (int z = 0; z < RS; z++) { ringS[z * 64 + lane] = -1; ringE[z * 64 + lane] = -1; }
+  const long bFirst = sb.b0 + c * CB, bLast = min(sb.b1, bFirst + CB - 1);
+  const long T0 = c > 0 ? B.chunkT[co + c] : 0;
+  long from = c;
+  while (from > 0) { from--; if (from == 0 || T0 - B.chunkT[co + from] >= 2 * (long)k - 1) break; }
+  const long ownLo = c > 0 ? T0 - k + 1 : 0, thr = T0 - 2 * (long)k + 1;
+  long q = from > 0 ? B.chunkQ[co + from] : sb.fq;
+  long tOff = from > 0 ? B.chunkT[co + from] : 0;
   auto flush = [&](long r) {   // row r can no longer change: write it out and recycle its slot
-    if (r >= 0 && r < tLen) { int2 v; v.x = RG(ringS, r); v.y = RG(ringE, r); *(int2*)&rows[r] = v; RG(ringS, r) = -1; RG(ringE, r) = -1; }
-  };
-  long q = fq;
-  long tOff = 0;
-  long bq = fq, bt = ft, bl = fl;
-  for (long b = b0; b <= b1 && !(status & 1); b++) {                    // :232-315
-    int bqGap = 0, btGap = 0;
-    long blockLength = bl;
-    long nq2 = 0, nt2 = 0, nl2 = 0;
-    if (b < b1) {
-      blk(b + 1, nq2, nt2, nl2);
-      bqGap = (int)(nq2 - (bq + bl)); btGap = (int)(nt2 - (bt + bl));
-      if (bqGap > 0 && btGap > 0) { int c = min(bqGap, btGap); bqGap -= c; btGap -= c; blockLength += c; }
+    if (r >= 0 && r < tLen) {
+      if (r >= ownLo) { int2 v; v.x = RG(ringS, r); v.y = RG(ringE, r); *(int2*)&rows[r] = v; }
+      RG(ringS, r) = -1; RG(ringE, r) = -1;
     }
-    for (long bi = 0; bi < blockLength; bi++) {                         // :252-283
+  };
+  long bq, bt, bl;
+  sb.get(sb.b0 + from * CB, bq, bt, bl);
+  bool live = (c == 0);
+  for (long b = sb.b0 + from * CB; b <= bLast && !(status & 1); b++) {  // :232-315
+    long nq2, nt2, nl2;
+    const BlockStep st = block_step(sb, b, bq, bt, bl, nq2, nt2, nl2);
+    if (!live) {
+      if (b < bFirst && tOff + st.rows <= thr) { tOff += st.rows; q += st.advq; bq = nq2; bt = nt2; bl = nl2; continue; }
+      live = true;
+    }
+    for (long bi = 0; bi < st.blockLength; bi++) {                      // :252-283
       if (tOff >= tLen) { status |= 1; break; }
       {
         int lo = (int)max(q - k, qStart);
@@ -246,15 +342,15 @@ __global__ void __launch_bounds__(64) ir_band_lane(BandArgs B) {
       tOff++; q++;
       flush(tOff - k);
     }
-    if (bqGap > btGap) {                                                // :287-305
-      for (int qi = 0; qi < bqGap; qi++, q++)
+    if (st.bqGap > st.btGap) {                                          // :287-305
+      for (int qi = 0; qi < st.bqGap; qi++, q++)
         for (int ki = 0; ki < k; ki++) {
           if (tOff - ki >= 0 && tOff - ki < tLen) { if (RG(ringE, tOff - ki) < q) RG(ringE, tOff - ki) = (int)q; }
           if (tOff + ki < tLen) { int v = RG(ringS, tOff + ki); if (v == 0 || v > q) RG(ringS, tOff + ki) = (int)q; }   // (sic) == 0
         }
     }
-    if (btGap > bqGap) {                                                // :306-314
-      for (int ti = 0; ti < btGap; ti++) {
+    if (st.btGap > st.bqGap) {                                          // :306-314
+      for (int ti = 0; ti < st.btGap; ti++) {
         if (tOff >= tLen) { status |= 1; break; }
         RG(ringS, tOff) = (int)max(q - k, qStart); RG(ringE, tOff) = (int)min(qEnd - 1, q + k);
         tOff++;
@@ -263,35 +359,64 @@ __global__ void __launch_bounds__(64) ir_band_lane(BandArgs B) {
     }
     bq = nq2; bt = nt2; bl = nl2;
   }
-  for (long r = max(0L, tOff - k + 1); r < tLen; r++) flush(r);
+  if (lastChunk) for (long r = max(0L, tOff - k + 1); r < tLen; r++) flush(r);
 #undef RG
-  if (tOff != tLen) status |= 1;
+  if (!multi) { if (tOff != tLen) status |= 1; B.s_status[s] = status; }
+}
+
+// One WAVE per segment: the suffix minimum of qS (:318-322), then the prefix maximum of qE, the
+// window checks and the cell offsets (:323-328, + the target base of the row), 64 rows a step.
+__global__ void __launch_bounds__(64) ir_band_scan(BandArgs B) {
+  const uint64_t s = blockIdx.x;
+  const int lane = threadIdx.x;
+  if (B.s_kind[s] != 0) { if (lane == 0) { B.s_cells[s] = 0; B.s_status[s] = 0; B.s_width[s] = 0; B.s_tmpcap[s] = 0; } return; }
+  int status = B.s_status[s];
+  const long tLen = (long)B.s_rows[s];
+  Row* rows = B.rows + B.s_row_off[s];
   unsigned long long cells = 0;
   int width = 0;
-  if (!status) {
-    // :318-322 suffix minimum of qS
-    int run = rows[tLen - 1].S;
-    for (long r = tLen - 2; r >= 0; r--) { int v = rows[r].S; if (run < v) rows[r].S = run; else run = v; }
-    // :323-328 prefix maximum of qE, cell offsets (+ the target base of the row)
+  if (!status && tLen > 0) {
+    int run = 0x7fffffff;
+    for (long base = ((tLen - 1) / 64) * 64; base >= 0; base -= 64) {
+      const long r = base + lane;
+      const int own = (r < tLen) ? rows[r].S : 0x7fffffff;
+      int v = own;
+      for (int d = 1; d < 64; d <<= 1) { int o = __shfl_down(v, d); if (lane + d < 64) v = min(v, o); }
+      v = min(v, run);
+      if (r < tLen && v != own) rows[r].S = v;
+      run = __shfl(v, 0);
+    }
+    const int a = B.s_aln[s];
     const unsigned char* tb = (const unsigned char*)B.tseq + B.t_off[a] + B.s_tStart[s];
     int runE = -0x7fffffff;
-    for (long r = 0; r < tLen; r++) {
-      Row w = rows[r];
-      runE = max(runE, w.E);
-      w.E = runE;
-      int len = w.E - w.S + 1;
-      if (len < 1 || w.S < 0) status |= 1;
-      else if (len > 64) status |= 4;
-      width = max(width, len);
-      w.C = (unsigned int)cells; w.T = tb[r];
-      rows[r] = w;
-      cells += (unsigned long long)max(len, 0);
+    for (long base = 0; base < tLen; base += 64) {
+      const long r = base + lane;
+      Row w; w.S = 0; w.E = -0x7fffffff; w.C = 0; w.T = 0;
+      if (r < tLen) w = rows[r];
+      int e = w.E;
+      for (int d = 1; d < 64; d <<= 1) { int o = __shfl_up(e, d); if (lane >= d) e = max(e, o); }
+      e = max(e, runE);
+      runE = __shfl(e, 63);
+      int len = (r < tLen) ? e - w.S + 1 : 0;
+      if (r < tLen) {
+        if (len < 1 || w.S < 0) status |= 1;
+        else if (len > 64) status |= 4;
+        width = max(width, len);
+      }
+      const unsigned long long l = (unsigned long long)max(len, 0);
+      unsigned long long inc = l;
+      for (int d = 1; d < 64; d <<= 1) { unsigned long long o = __shfl_up(inc, d); if (lane >= d) inc += o; }
+      if (r < tLen) { w.E = e; w.C = (unsigned int)(cells + inc - l); w.T = tb[r]; rows[r] = w; }
+      cells += __shfl(inc, 63);
     }
+    for (int o = 32; o > 0; o >>= 1) { status |= __shfl_xor(status, o); width = max(width, __shfl_xor(width, o)); }
   }
-  B.s_cells[s] = status ? 0 : cells;
-  B.s_status[s] = status;
-  B.s_width[s] = status ? 0 : width;
-  B.s_tmpcap[s] = status ? 0 : (uint64_t)(tLen + (qEnd - qStart) + 2);
+  if (lane == 0) {
+    B.s_cells[s] = status ? 0 : cells;
+    B.s_status[s] = status;
+    B.s_width[s] = status ? 0 : width;
+    B.s_tmpcap[s] = status ? 0 : (uint64_t)(tLen + ((long)B.s_qEnd[s] - B.s_qStart[s]) + 2);
+  }
 }
 
 // width classes for ir_fill: 16 / 32 / 64 lanes per segment
@@ -658,6 +783,7 @@ extern "C" int lra_indel_refine_batch(lra_ctx* ctx, int n_aln, const int32_t* d_
   add(capSeg, 8); add(capSeg, 4); add(capSeg, 8); add(capSeg, 4); add(capSeg, 4); add(capSeg, 4); add(capSeg + 1, 8);
   add(capSeg, 4); add(capSeg, 4); add(capSeg, 4);
   add(nA + 1, 8);
+  add(capSeg, 4); add(capSeg + 1, 8);
   char* baseA = (char*)lra_scratch(ctx, 2, needA + 4096);
   if (!baseA) return LRA_ERR_NOMEM;
   Arena ar{baseA, needA + 4096, 0};
@@ -684,7 +810,8 @@ extern "C" int lra_indel_refine_batch(lra_ctx* ctx, int n_aln, const int32_t* d_
   uint64_t* p_block_off = ar.get<uint64_t>(capSeg + 1);
   int32_t* p_score = ar.get<int32_t>(capSeg); int32_t* p_nblocks = ar.get<int32_t>(capSeg); int32_t* p_status = ar.get<int32_t>(capSeg);
   uint64_t* out_block_off = ar.get<uint64_t>(nA + 1);
-  if (!out_block_off) return lra_set_err(ctx, LRA_ERR_NOMEM, "arena accounting");
+  uint32_t* s_nchunk = ar.get<uint32_t>(capSeg); uint64_t* chunk_off = ar.get<uint64_t>(capSeg + 1);
+  if (!out_block_off || !chunk_off) return lra_set_err(ctx, LRA_ERR_NOMEM, "arena accounting");
 
   const int nbA = (n_aln + 63) / 64;
   // ---- segments: count, scan, emit
@@ -712,10 +839,26 @@ extern "C" int lra_indel_refine_batch(lra_ctx* ctx, int n_aln, const int32_t* d_
     B.ab = A.ab; B.block_off = d_block_off; B.tseq = d_tseq; B.t_off = d_t_off; B.k = refine_band; B.rows = rows;
     B.s_cells = s_cells; B.s_status = s_status; B.s_width = s_width; B.s_tmpcap = s_tmpcap;
     const unsigned gridL = (unsigned)((n_seg + 63) / 64);
+    const unsigned gridS = (unsigned)((n_seg + 255) / 256);
     lra_time_begin(ctx, "ir_band");
-    if (refine_band <= 8) hipLaunchKernelGGL(ir_band_lane<16>, dim3(gridL), dim3(64), 0, st, B);
-    else if (refine_band <= 32) hipLaunchKernelGGL(ir_band_lane<64>, dim3(gridL), dim3(64), 0, st, B);
-    else hipLaunchKernelGGL(ir_band_lane<128>, dim3(gridL), dim3(64), 0, st, B);
+    B.s_nchunk = s_nchunk; B.chunk_off = chunk_off; B.n_task = 0; B.task_seg = nullptr; B.chunkT = nullptr; B.chunkQ = nullptr;
+    hipLaunchKernelGGL(ir_band_nchunk, dim3(gridS), dim3(256), 0, st, B);
+    scan(ctx, (long)n_seg, s_nchunk, chunk_off);
+    uint64_t n_task = 0;
+    if (d2h(ctx, &n_task, chunk_off + n_seg, 8)) return LRA_ERR_HIP;
+    uint32_t* task_seg = (uint32_t*)lra_ensure(ctx, 54, (n_task + 1) * 4);
+    int32_t* chunk_tq = (int32_t*)lra_ensure(ctx, 55, (n_task + 1) * 8);
+    if (!task_seg || !chunk_tq) return LRA_ERR_NOMEM;
+    B.n_task = n_task; B.task_seg = task_seg; B.chunkT = chunk_tq; B.chunkQ = chunk_tq + n_task + 1;
+    hipLaunchKernelGGL(ir_band_tasks, dim3(gridS), dim3(256), 0, st, B);
+    hipLaunchKernelGGL(ir_band_prep, dim3((unsigned)n_seg), dim3(64), 0, st, B);
+    if (n_task) {
+      const unsigned gridT = (unsigned)((n_task + 63) / 64);
+      if (refine_band <= 8) hipLaunchKernelGGL(ir_band_chunk<16>, dim3(gridT), dim3(64), 0, st, B);
+      else if (refine_band <= 32) hipLaunchKernelGGL(ir_band_chunk<64>, dim3(gridT), dim3(64), 0, st, B);
+      else hipLaunchKernelGGL(ir_band_chunk<128>, dim3(gridT), dim3(64), 0, st, B);
+    }
+    hipLaunchKernelGGL(ir_band_scan, dim3((unsigned)n_seg), dim3(64), 0, st, B);
     lra_time_end(ctx);
     scan(ctx, (long)n_seg, s_cells, s_cell_off);
     scan(ctx, (long)n_seg, s_tmpcap, s_tmp_off);
@@ -732,6 +875,12 @@ extern "C" int lra_indel_refine_batch(lra_ctx* ctx, int n_aln, const int32_t* d_
     F.qseq = d_qseq; F.q_off = d_q_off; F.match = match; F.mismatch = mismatch; F.g = indel; F.path = path;
     F.counts = fill_counts; F.lists = fill_lists;
     const unsigned cap_grid = (unsigned)ctx->num_cu * 32;
+    if (getenv("LRA_IR_DBG")) {
+      int hc[3] = {0, 0, 0};
+      if (d2h(ctx, hc, fill_counts, 12)) return LRA_ERR_HIP;
+      fprintf(stderr, "[ir] n_seg %llu n_rows %llu n_cells %llu n_task %llu fill classes 16/32/64: %d %d %d\n", (unsigned long long)n_seg,
+              (unsigned long long)n_rows, (unsigned long long)n_cells, (unsigned long long)n_task, hc[0], hc[1], hc[2]);
+    }
     lra_time_begin(ctx, "ir_fill");
     hipLaunchKernelGGL(ir_fill<16>, dim3((unsigned)std::min<uint64_t>((n_seg + 3) / 4, cap_grid)), dim3(64), 0, st, F);
     hipLaunchKernelGGL(ir_fill<32>, dim3((unsigned)std::min<uint64_t>((n_seg + 1) / 2, cap_grid)), dim3(64), 0, st, F);

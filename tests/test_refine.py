@@ -19,14 +19,14 @@ def perturb(rng, blocks, drop=0.15, trim=0.3):
     return b[b[:, 2] > 0]
 
 
-def make_cases(seed, n, mean_len, err, mix, genome):
+def make_cases(seed, n, mean_len, err, mix, genome, drop=0.15, trim=0.3):
     rng = np.random.default_rng(seed)
     reads, blocks = [], []
     for i in range(n):
         L = int(max(200, rng.normal(mean_len, mean_len / 4)))
         r, b = synth.simulate_read_with_blocks(rng, genome, L, err, mix)
         reads.append(r)
-        blocks.append(perturb(rng, b))
+        blocks.append(perturb(rng, b, drop, trim))
     return reads, blocks
 
 
@@ -95,3 +95,37 @@ def test_hip_refine_matches_oracle(ctx, oracle, band, par, err, mix, mean_len, n
         assert st == 0
         assert status[i] == 0, (i, status[i])
         assert np.array_equal(got[i], exp), (i, len(got[i]), len(exp))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("band,err,mean_len,n,odd", [(7, 0.10, 6000, 24, 0.0), (7, 0.12, 20000, 6, 0.02), (20, 0.10, 8000, 8, 0.01)])
+def test_hip_refine_long_segments(ctx, oracle, band, err, mean_len, n, odd):
+    """What LocalRefineAlignment hands over: every gap is small, so one segment spans hundreds of
+    blocks (the chunked window construction).  `odd` > 0 also pulls some blocks' query start back
+    (overlapping query coordinates, a drifting query cursor in IndelRefine.h:287-314) and some
+    target starts back (the row count no longer adds up -> the alignment is rejected)."""
+    genome = synth.make_genome(300000, seed=22)
+    reads, blocks = make_cases(7 + band, n, mean_len, err, (30, 35, 35), genome, drop=0.0, trim=0.5)
+    rng = np.random.default_rng(5)
+    if odd:
+        # the drifting cursor widens the last rows past the segment's query end: keep the alignment
+        # clear of the read end so that those cells are still inside the read (both sides then see
+        # the same bases; past the read the reference reads whatever follows in memory)
+        blocks = [b[b[:, 0] + b[:, 2] < len(r) - 64].copy() for r, b in zip(reads, blocks)]
+        for b in blocks:
+            m = rng.random(len(b)) < odd
+            m[0] = False
+            b[m, 0] -= rng.integers(1, 3, size=int(m.sum())).astype(b.dtype)
+        b = blocks[-1]
+        b[len(b) // 2, 1] -= 8
+    (got, status), res = _run_gpu(ctx, genome, reads, blocks, band, (4, -1, -2))
+    assert res.n_rows / max(res.n_segments, 1) > 500
+    g = genome.tobytes()
+    n_ok = 0
+    for i, (r, b) in enumerate(zip(reads, blocks)):
+        exp, st = oracle.indel_refine(b, r.tobytes(), g, band, 4, -1, -2)
+        assert (status[i] != 0) == (st != 0), (i, status[i], st)
+        if st == 0:
+            n_ok += 1
+            assert np.array_equal(got[i], exp), (i, len(got[i]), len(exp))
+    assert n_ok >= n // 2
