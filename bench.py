@@ -138,97 +138,37 @@ def main():
     torch.cuda.set_device(dev_index)
 
     from lra_amd.context import Context
-    from lra_amd import seed, align, refine, parallel, cluster, chain
-    sdp_opts = chain.sdp_opts()
-    sdp2_opts = chain.sdp_opts(mode=1, rate=2.0)          # SparseDP :2287 with opts.second_anchorbonus (Options.h:221)
-    import ctypes as C
-    libm = C.CDLL("libm.so.6"); libm.logf.restype = C.c_float; libm.logf.argtypes = [C.c_float]
-    lut = np.array([libm.logf(float(i)) for i in range(1, 10002, 5)], dtype=np.float32)      # LogLookUpTable.h:9-15
-    copts = cluster.CleanOpts(globalK=17, cleanMaxDiag=200, minDiagCluster=3, bypassClustering=1, cleanClustersize=100,
-                              SecondCleanMinDiagCluster=10, SecondCleanMaxDiag=100, punish_anchorfreq=5, anchorPerlength=5)   # -ONT
+    from lra_amd import seed, parallel, mapread
+    mopts = mapread.LowAccOptions(globalK=args.k, globalW=args.w, globalMaxFreq=args.max_freq, refineBand=args.refine_band)   # -ONT
 
     import threading
     errors = []
 
     def make_lane(lane, n_reads, ref):
-        """One sub-batch: its own context (buffers + HIP stream) and its reads; returns (ctx, step, stats, constants)."""
+        """One sub-batch: its own context (buffers + HIP stream), mapper and reads; returns (ctx, step, stats, constants)."""
         stream = torch.cuda.Stream(device=dev_index) if args.lanes > 1 else None
         ctx = Context(dev_index)
         if stream is not None:
             ctx.bind_stream(stream)
         wl = build_workload(args, rank, ctx.device, ref, n_reads, lane)
-        seed.load_reference(ctx, wl["genome"].cpu().numpy(), wl["idx_key"], wl["idx_pos"])
+        G = int(wl["genome"].numel())
+        # the reference side, built once: global index, genome, the genome's local index (.gli)
+        mapper = mapread.LowAccMapper(ctx, wl["genome"], wl["idx_key"], wl["idx_pos"], [b"chr1"], [0, G], mopts)
         sim = wl["sim"]
         rbatch = seed.read_batch_from_device(ctx, wl["reads"], sim["off"])
         gp = wl["gaps"]
-        gdev = torch.cat([wl["genome"], torch.zeros(64, dtype=torch.uint8, device=ctx.device)])
         lens = (sim["off"][1:] - sim["off"][:-1])
-        nR = n_reads
-        # a10 inputs: genome local index (the `.gli` payload, built once: tuples, tupleBoundaries, seqOffsets) and one buffer holding
-        # the reads forward followed by their reverse complements (forwardIndex / reverseIndex, Map_lowacc.h:246-250)
-        from lra_amd import local
-        G = int(wl["genome"].numel())
-        g_off = torch.tensor([0, G], dtype=torch.int64, device=ctx.device)
-        gli = local.LocalIndex(ctx, gdev, g_off, 10, 5, 256, 15)
-        gso = torch.cat([torch.arange(0, G, 256, dtype=torch.int64, device=ctx.device), torch.tensor([G], dtype=torch.int64, device=ctx.device)])
-        tot = int(sim["off"][-1])
-        both = torch.zeros(2 * tot + 64, dtype=torch.uint8, device=ctx.device)
-        both[:tot] = rbatch.seq[:tot]
-        off2 = torch.cat([rbatch.off, rbatch.off[1:] + tot]).contiguous()
         total_bases = int(lens.sum())
         n_gap_bytes = int(gp["q_len"].sum() + gp["t_len"].sum())
         n_gaps = int(gp["k"].numel())
 
-        stats = {}
+        stats = mapper.stats
         out_rec = [None]
 
         def step():
-            sres = seed.seed_batch(ctx, rbatch, args.k, args.w, args.max_freq)
-            cres = cluster.clean_matches_batch(ctx, copts, [0, int(wl["genome"].numel())])
-            eres = cluster.linear_extend_batch(ctx, args.k, rbatch)
-            # a8: SDP#A over the extended anchors of every read (Map_lowacc.h:185-188)
-            chres = chain.sparse_dp_batch(ctx, nR, cres.d_cluster_off, eres.d_e_start, eres.d_e_count, cres.d_c_strand, eres.d_e_qpos, eres.d_e_tpos,
-                                          eres.d_e_len, rbatch.off, sdp_opts)
-            num_aln = int(chres.num_aln)
-            slot_n0 = ctx.to_tensor(chres.d_chain_len, nR * num_aln, torch.int32)          # chains[p].NumOfAnchors0 for a13 (the second sparse DP reuses these buffers)
-            # a9: RemoveSpuriousJump + SPLITChain + RemoveSpuriousSplitChain on every chain (Map_lowacc.h:189-256)
-            spres = chain.split_chains_batch(ctx, chres, [0, int(wl["genome"].numel())])
-            # a10: CreateRC, LocalIndex::IndexSeq of both strands, Refine_splitchain on every split chain (Map_lowacc.h:246-294)
-            ctx.check(ctx.lib.lra_create_rc_batch(ctx.h, rbatch.n, C.c_void_p(rbatch.seq.data_ptr()), C.c_void_p(rbatch.off.data_ptr()), C.c_void_p(both.data_ptr() + tot)))
-            rli = local.LocalIndex(ctx, both, off2, 10, 5, 256, 15)
-            rres = chain.refine_splitchain_batch(ctx, chres, spres, rbatch.off, [0, G], rli, gso, gli, window=100, smallK=10, K=args.k, limitrefine=True, max_freq=15)
-            # a11 callers, a9 MergeChain, a7 second pass, a8 second sparse DP + its filters (Map_lowacc.h:362-540)
-            bres = chain.refine_btwn_splitchain_batch(ctx, chres, spres, rres, rbatch.off, both, tot, gdev, [0, G], K=10, W=5, refineSpaceDist=30000,
-                                                      anchorstoosparse=0.005, match=4, mismatch=-1, indel=-2, max_freq=15)
-            mres = chain.merge_extend_batch(ctx, chres, spres, bres, rbatch.seq, rbatch.off, gdev, [0, G], K=10)
-            ch2 = chain.sparse_dp_batch(ctx, int(mres.n_groups), mres.d_iota, mres.d_anchor_off, mres.d_count, mres.d_strand, mres.d_q, mres.d_t, mres.d_len,
-                                        mres.d_iota, sdp2_opts)
-            stats.update(n_btwn_problems=bres.n_problems, n_btwn_rounds=bres.n_rounds, n_refined_after_btwn=bres.n_matches, n_merged_clusters=mres.n_groups,
-                         n_sdp2_anchors=mres.n_anchors, n_sdp2_entries=ch2.n_subproblem_entries)
-            if "n_local_task_words" not in stats and rres.n_tasks:
-                t4 = [ctx.to_tensor(p_, rres.n_tasks, torch.int64) for p_ in (rres.d_task_q_lo, rres.d_task_q_hi, rres.d_task_t_lo, rres.d_task_t_hi)]
-                stats["n_local_task_words"] = int((t4[1] - t4[0]).sum() + (t4[3] - t4[2]).sum())
-            # a13: filters of the second sparse DP + LocalRefineAlignment: the chains become alignments (blocks) (Map_lowacc.h:538-576)
-            inp, ares = chain.local_refine_from_sdp(ctx, num_aln, slot_n0, mres, ch2, rbatch.off, both, tot, gdev, [0, G])
-            # a14 + a16 on those alignments: IndelRefineAlignment, CalculateStatistics (Map_lowacc.h:582-597)
-            nA = int(ares.n_alignments)
-            aoff = ctx.to_tensor(ares.d_job_aln_off, int(ares.n_jobs) + 1, torch.int64)
-            aln_read = torch.repeat_interleave(torch.arange(int(ares.n_jobs), device=ctx.device), aoff[1:] - aoff[:-1]) // num_aln
-            a_strand = ctx.to_tensor(ares.d_strand, nA, torch.int32).to(torch.int64)
-            fb = refine.refine_batch_from_device(ctx, ctx.to_tensor(ares.d_blocks, 3 * int(ares.n_blocks), torch.int32).view(-1, 3),
-                                                 ctx.to_tensor(ares.d_block_off, nA + 1, torch.int64), both, rbatch.off[aln_read] + a_strand * tot, lens[aln_read],
-                                                 gdev, torch.zeros(nA, dtype=torch.int64, device=ctx.device), torch.full((nA,), G, dtype=torch.int64, device=ctx.device))
-            fres = refine.indel_refine_batch(ctx, fb, args.refine_band, 4, -1, -2)
-            tres = refine.stats_of_refined(ctx, fb, fres, lut)
-            stats.update(n_alignments=nA, n_a13_blocks=int(ares.n_blocks), n_large_spaces=int(ares.n_big))
-            # the one exchange step: refined block records -> rank 0
-            rec = ctx.to_tensor(fres.d_blocks, 3 * fres.n_blocks, torch.int32)
-            out_rec[0] = rec
-            stats.update(n_mm=sres.n_minimizers, n_match=sres.n_matches, n_cells=fres.n_cells, n_rows=fres.n_rows,
-                         n_seg=fres.n_segments, n_blocks=fres.n_blocks, n_aog=fres.n_aog, n_clusters=cres.n_clusters, n_cigar_runs=tres.n_runs, n_local_tuples=rli.n_tuples,
-                         n_local_tasks=rres.n_tasks, n_local_pairs=rres.n_pairs, n_refined_matches=rres.n_matches,
-                         n_sdp_anchors=chres.n_frags, n_sdp_points=chres.n_points, n_sdp_entries=chres.n_subproblem_entries)
-
+            # MapRead_lowacc for the whole batch: a1-a5, a7-a11, a13, a14, a16 (lra_amd/mapread.py lists the calls)
+            res = mapper.align(rbatch)
+            out_rec[0] = res.block_records                               # the one exchange step: refined block records -> rank 0
 
         def run_step():
             try:
@@ -295,7 +235,7 @@ def main():
 
     kernels = ["sketch_count", "sketch_serial", "sketch_emit", "sort", "sort_fallback", "index_bounds", "compare", "strand",
                "aog_lds_tiny", "aog_lds_small", "aog_lds_large", "aog_hbm", "ir_segment", "ir_band", "ir_fill", "ir_trace", "ir_gather", "clean_sort", "clean", "linear_extend", "stats", "stats_cigar", "create_rc", "local_sketch", "local_sort_filter", "local_compare",
-               "rsc_tasks", "rsc_filter", "refine_space", "refine_space_long", "btwn_plan", "btwn_apply", "merge_extend", "between_anchors", "local_refine", "sdp_inner_points", "sdp_inner_sort", "sdp_inner_build_count", "sdp_inner_build", "sdp_inner_process", "sdp_inner_trace", "chain_split", "sdp_points", "sdp_sort", "sdp_sort_fallback", "sdp_build_count", "sdp_build", "sdp_process", "sdp_trace"]
+               "rsc_tasks", "rsc_filter", "refine_space", "rs_long_sketch", "rs_long_compare", "btwn_plan", "btwn_apply", "merge_extend", "between_anchors", "local_refine", "sdp_inner_points", "sdp_inner_sort", "sdp_inner_build_count", "sdp_inner_build", "sdp_inner_process", "sdp_inner_trace", "chain_split", "sdp_points", "sdp_sort", "sdp_sort_fallback", "sdp_build_count", "sdp_build", "sdp_process", "sdp_trace"]
     ktimes = {}
     for k in kernels:
         tt_ = [l["ctx"].timing_get(k) for l in lanes]

@@ -443,7 +443,7 @@ struct FillArgs {
   uint64_t n_seg;
   const int32_t* s_aln; const uint64_t* s_rows; const uint64_t* s_row_off; const uint64_t* s_cell_off;
   const Row* rows;
-  const char* qseq; const uint64_t* q_off;
+  const char* qseq; const uint64_t* q_off; const int32_t* q_len;
   int match, mismatch, g;
   unsigned char* path;
   const int* counts; const uint32_t* lists;
@@ -451,8 +451,26 @@ struct FillArgs {
 
 __device__ __forceinline__ bool is_bound(long row, int c, int len) { return c == len - 1 || (row > 0 && c == 0); }
 
+// Cross-lane moves on the VALU (DPP), no LDS round trip.  shr1: lane i takes lane i-1 of the wave
+// (lane 0 takes `fill`).  scan_max<G>: inclusive prefix maximum inside aligned groups of G lanes
+// (row_shr inside the 16-lane rows, then row_bcast 15 / 31 carry the row totals forward).
+__device__ __forceinline__ int shr1(int x, int fill) { return __builtin_amdgcn_update_dpp(fill, x, 0x138, 0xf, 0xf, false); }
+template <int G>
+__device__ __forceinline__ int scan_max(int w) {
+  w = max(w, __builtin_amdgcn_update_dpp(NEG, w, 0x111, 0xf, 0xf, false));
+  w = max(w, __builtin_amdgcn_update_dpp(NEG, w, 0x112, 0xf, 0xf, false));
+  w = max(w, __builtin_amdgcn_update_dpp(NEG, w, 0x114, 0xf, 0xf, false));
+  w = max(w, __builtin_amdgcn_update_dpp(NEG, w, 0x118, 0xf, 0xf, false));
+  if (G >= 32) w = max(w, __builtin_amdgcn_update_dpp(NEG, w, 0x142, 0xa, 0xf, false));
+  if (G >= 64) w = max(w, __builtin_amdgcn_update_dpp(NEG, w, 0x143, 0xc, 0xf, false));
+  return w;
+}
+
 // G lanes per segment (G = 16, 32 or 64 by the segment's widest row), 64/G segments per wave.
 // Each group sweeps its own segment row by row: one lane per cell, previous row in registers.
+// The query bases of the rows come from a sliding register window (2G bases + G prefetched), the
+// row descriptors from a register chunk of G rows; the only per-row memory traffic is the row of
+// arrows going out.
 template <int G>
 __global__ void __launch_bounds__(64) ir_fill(FillArgs F) {
   constexpr int GP = 64 / G;
@@ -467,10 +485,12 @@ __global__ void __launch_bounds__(64) ir_fill(FillArgs F) {
   // per-group state (identical on the G lanes of a group)
   long ti = -1, tLen = 0;
   const Row* rows = nullptr; const unsigned char* qb = nullptr; unsigned char* P = nullptr;
-  long chunkBase = 0;
+  long chunkBase = 0, qLast = 0;
   Row chunk; chunk.S = chunk.E = chunk.T = 0; chunk.C = 0;
+  int W0 = 0, qlo = 0, qhi = 0, qnext = 0;
   int prevM = BAD, prevD = BAD, prevS = 0, prevLen = 0;
   bool done = false;
+  auto ldq = [&](long idx) -> int { return qb[idx < qLast ? idx : qLast]; };   // past the read: its last base (the reference reads out of range there)
   while (true) {
     if (!done && ti < 0) {
       if (x < count) {
@@ -480,9 +500,12 @@ __global__ void __launch_bounds__(64) ir_fill(FillArgs F) {
         tLen = (long)F.s_rows[s];
         rows = F.rows + F.s_row_off[s];
         qb = (const unsigned char*)F.qseq + F.q_off[a];
+        qLast = (long)F.q_len[a] - 1;
         P = F.path + F.s_cell_off[s];
         ti = 0; chunkBase = 0;
         if (c < tLen) chunk = rows[c];
+        W0 = rows[0].S;
+        qlo = ldq((long)W0 + c); qhi = ldq((long)W0 + G + c); qnext = ldq((long)W0 + 2 * G + c);
       } else done = true;
     }
     if (__ballot(!done) == 0ULL) break;
@@ -490,6 +513,10 @@ __global__ void __launch_bounds__(64) ir_fill(FillArgs F) {
     const int src = gbase + (int)((ti - chunkBase) & (G - 1));
     const int S = __shfl(chunk.S, src), E = __shfl(chunk.E, src), tch = __shfl(chunk.T, src);
     const unsigned int C = __shfl(chunk.C, src);
+    while (!done && S - W0 >= G) { W0 += G; qlo = qhi; qhi = qnext; qnext = ldq((long)W0 + 2 * G + c); }
+    const int j = S - W0 + c;                                           // 0 .. 2G-1
+    const int q1 = __shfl(qlo, gbase + (j & (G - 1))), q2 = __shfl(qhi, gbase + (j & (G - 1)));
+    const int qch = (j < G) ? q1 : q2;
     const int len = E - S + 1;
     const bool lastRow = (ti == tLen - 1);
     const int off = S - prevS;
@@ -497,25 +524,22 @@ __global__ void __launch_bounds__(64) ir_fill(FillArgs F) {
     const int srcA = c + off, srcD = srcA - 1;
     const bool aboveIn = srcA <= prevLen - 1;                            // qE[ti-1] >= q   (:491,:548,:567)
     const int aM = __shfl(prevM, gbase + (srcA & (G - 1))), aD = __shfl(prevD, gbase + (srcA & (G - 1)));
-    const int dM = __shfl(prevM, gbase + (srcD & (G - 1)));
+    const int dM = shr1(aM, BAD);                                        // prevM[srcD]: only read by interior cells (c >= 1)
     const bool okA = aboveIn && !is_bound(ti - 1, srcA, prevLen);
     const bool okD = aboveIn && srcD >= 0 && !is_bound(ti - 1, srcD, prevLen);
     const int dOpen = okA ? aM + go : BAD, dExt = okA ? aD : BAD;        // :491-502 (gapExtend = 0)
     const int Dv = max(dOpen, dExt);
     const int delOpen = (Dv == dOpen) ? 1 : 0;                           // :504-516
-    int qch = 0;
-    if (!done && ti > 0 && interior) qch = qb[S + c];
     const int mS = okD ? dM + (tch == qch ? F.match : F.mismatch) : BAD; // :548-563
     const int dS = okA ? aM + g : BAD;                                   // :567-574
     const int V = interior ? max(mS, max(dS, Dv)) : NEG;
-    int W = V;                                                           // inclusive prefix max of V inside the group
-    for (int d = 1; d < G; d <<= 1) { int o = __shfl_up(W, d); if (c >= d) W = max(W, o); }
-    int Wm1 = __shfl_up(W, 1), Vm1 = __shfl_up(V, 1);
+    const int W = scan_max<G>(V);                                        // inclusive prefix max of V inside the group
+    int Wm1 = shr1(W, NEG), Vm1 = shr1(V, NEG);
     if (c == 0) { Wm1 = NEG; Vm1 = NEG; }
     const int Iv = max(BAD, go + Wm1);
     int M = max(max(BAD, V), max(Vm1 + g, go + Wm1));
     if (!interior) M = BAD;
-    int Mleft = __shfl_up(M, 1);
+    int Mleft = shr1(M, BAD);
     if (c <= 1) Mleft = BAD;                                             // the row's left boundary cell (:413-418)
     const int iOpen = Mleft + go;                                        // :523
     const int insOpen = (Iv == iOpen) ? 1 : 0;                           // :528-540
@@ -872,7 +896,7 @@ extern "C" int lra_indel_refine_batch(lra_ctx* ctx, int n_aln, const int32_t* d_
     hipLaunchKernelGGL(ir_classify, dim3((unsigned)((n_seg + 255) / 256)), dim3(256), 0, st, n_seg, A.s_kind, s_status, s_width, fill_counts, fill_lists);
     FillArgs F;
     F.n_seg = n_seg; F.s_aln = A.s_aln; F.s_rows = A.s_rows; F.s_row_off = s_row_off; F.s_cell_off = s_cell_off; F.rows = rows;
-    F.qseq = d_qseq; F.q_off = d_q_off; F.match = match; F.mismatch = mismatch; F.g = indel; F.path = path;
+    F.qseq = d_qseq; F.q_off = d_q_off; F.q_len = d_q_len; F.match = match; F.mismatch = mismatch; F.g = indel; F.path = path;
     F.counts = fill_counts; F.lists = fill_lists;
     const unsigned cap_grid = (unsigned)ctx->num_cu * 32;
     if (getenv("LRA_IR_DBG")) {

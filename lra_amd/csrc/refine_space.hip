@@ -9,6 +9,7 @@
 // for the K-mer scan; the long-gap branch runs one lane per (gap, side) for the sketch and one lane per gap for the list walk --
 // literal serial code, it is rare and bounded by refineSpaceDist.  Algorithmic bytes: qLen + tLen + 12 per block + 8 per pair.
 #include "common.h"
+#include <stdlib.h>
 #include "scan.h"
 #include <algorithm>
 
@@ -95,20 +96,45 @@ __global__ void rs_small(RsArgs a, int nSmall) {
 }
 
 // long gaps: StoreMinimizers_noncanonical<GenomeTuple,Tuple>(seq, seqLen, K, W, out, false)   MinCount.h:182-338
+// One WAVE per (gap, side): the scan is a serial state machine, so every lane runs it on the same (uniform) values and lane 0 writes;
+// what the wave buys is the memory system -- the bases come through a 1 KB tile in LDS that the 64 lanes refill together, and the
+// w-entry ring lives in LDS instead of per-lane scratch, so no step waits on HBM.
+constexpr int SK_TILE = 1024, SK_BACK = 256;
+__device__ __forceinline__ void rs_wave_sync() {
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+}
 template <bool EMIT>
-__global__ void rs_sketch(RsArgs a, int nLarge) {
-  const int l = blockIdx.x * blockDim.x + threadIdx.x;
+__global__ void __launch_bounds__(64) rs_sketch(RsArgs a, int nLarge) {
+  __shared__ unsigned char tile[SK_TILE];
+  __shared__ uint64_t ringT[MAX_W];
+  __shared__ uint32_t ringP[MAX_W];
+  const int l = blockIdx.x, lane = threadIdx.x;
   if (l >= 2 * nLarge) return;
   const uint32_t i = a.largeIdx[l >> 1];
   const bool isQ = l & 1;
-  const unsigned char* seq = (const unsigned char*)(isQ ? a.qseq + a.q_off[i] : a.tseq + a.t_off[i]);
+  const unsigned char* gseq = (const unsigned char*)(isQ ? a.qseq + a.q_off[i] : a.tseq + a.t_off[i]);
   const uint32_t seqLen = (uint32_t)(isQ ? a.q_len[i] : a.t_len[i]);
+  long tileBase = -(long)SK_TILE - 1;
+  auto at = [&](long x) -> unsigned char {                               // seq[x], x uniform over the wave
+    if (x < tileBase || x >= tileBase + SK_TILE) {
+      rs_wave_sync();
+      tileBase = x > SK_BACK ? ((x - SK_BACK) & ~15L) : 0;
+      for (int o = lane * 16; o < SK_TILE; o += 64 * 16)
+        for (int b = 0; b < 16; b++) { const long g = tileBase + o + b; tile[o + b] = g < (long)seqLen ? gseq[g] : 0; }
+      rs_wave_sync();
+    }
+    return tile[x - tileBase];
+  };
+  struct SeqView { decltype(at)& f; __device__ unsigned char operator[](long x) const { return f(x); } };
+  SeqView seq{at};
   const int k = a.K[i], w = a.W[i];
   uint32_t n = 0;
   const uint64_t o = EMIT ? a.loff[l] : 0;
-  auto emit = [&](uint64_t t, uint32_t p) { if (EMIT) { a.lkey[o + n] = t; a.lpos[o + n] = p; } n++; };
-  auto done = [&]() { if (!EMIT) a.lcnt[l] = n; };
-  if (w > MAX_W || w < 1 || k < 1 || k > 31) { if (!EMIT) { a.lcnt[l] = 0; atomicOr(&a.status[i], (uint32_t)LRA_ST_RANGE); } return; }
+  auto emit = [&](uint64_t t, uint32_t p) { if (EMIT && lane == 0) { a.lkey[o + n] = t; a.lpos[o + n] = p; } n++; };
+  auto done = [&]() { if (!EMIT && lane == 0) a.lcnt[l] = n; };
+  if (w > MAX_W || w < 1 || k < 1 || k > 31) { if (!EMIT && lane == 0) { a.lcnt[l] = 0; atomicOr(&a.status[i], (uint32_t)LRA_ST_RANGE); } return; }
   if (seqLen < (uint32_t)k) { done(); return; }
   const int span = w + k - 1;
   if (seqLen < (uint32_t)span) { done(); return; }
@@ -127,7 +153,6 @@ __global__ void rs_sketch(RsArgs a, int nLarge) {
   nvEnd = nvStart + span;
   uint64_t cur = 0;
   for (int p = 0; p < k; p++) { cur <<= 2; cur += (uint64_t)code(seq[p]); }
-  uint64_t ringT[MAX_W]; uint32_t ringP[MAX_W];
   uint64_t actT = cur; uint32_t actP = 0;
   ringT[0] = actT; ringP[0] = 0;
   uint32_t p;
@@ -163,14 +188,23 @@ __global__ void rs_sketch(RsArgs a, int nLarge) {
 }
 
 // long gaps: CompareLists<GenomeTuple,Tuple>(query, target, ..., Global = false, maxDiagNum, minDiagNum, canonical = false)  CompareLists.h:9-146
+// One WAVE per gap, the walk on uniform values as in rs_sketch; the two sorted key lists are staged in LDS (when they fit) so that the
+// searches and run scans of the walk never wait on HBM.  Lane 0 writes the pairs.
+constexpr int CMP_LDS_KEYS = 7168;                                        // 56 KB of keys per workgroup
 template <bool EMIT>
-__global__ void rs_compare(RsArgs a, int nLarge) {
-  const int j = blockIdx.x * blockDim.x + threadIdx.x;
+__global__ void __launch_bounds__(64) rs_compare(RsArgs a, int nLarge) {
+  __shared__ uint64_t skeys[CMP_LDS_KEYS];
+  const int j = blockIdx.x, lane = threadIdx.x;
   if (j >= nLarge) return;
   const uint32_t i = a.largeIdx[j];
   const uint64_t* tk = a.lkey + a.loff[2 * j]; const uint32_t* tp = a.lpos + a.loff[2 * j];
   const uint64_t* qk = a.lkey + a.loff[2 * j + 1]; const uint32_t* qp = a.lpos + a.loff[2 * j + 1];
   const long nt = (long)(a.loff[2 * j + 1] - a.loff[2 * j]), nq = (long)(a.loff[2 * j + 2] - a.loff[2 * j + 1]);
+  if (nt + nq <= CMP_LDS_KEYS) {                                          // the two lists are adjacent in lkey: one copy
+    for (long x = lane; x < nt + nq; x += 64) skeys[x] = tk[x];
+    rs_wave_sync();
+    tk = skeys; qk = skeys + nt;
+  }
   const long long diag2 = (long long)a.t_span[i] - (long long)(uint32_t)a.q_len[i];
   const long long minDiag = min(0LL, diag2) - a.diag[i], maxDiag = max(0LL, diag2) + a.diag[i];
   const long maxFreq = a.maxFreqArr ? (long)a.maxFreqArr[i] : a.maxFreq;
@@ -183,7 +217,7 @@ __global__ void rs_compare(RsArgs a, int nLarge) {
       const long long d = (long long)tp[ti] - (long long)qp[qi];
       if (!(d <= maxDiag && d >= minDiag)) return;
     }
-    if (EMIT) { uint32_t pq = qp[qi] + qAdd; if (flip) pq = flip - pq - (uint32_t)K; a.outQ[o + n] = pq; a.outT[o + n] = tp[ti] + tAdd; }
+    if (EMIT && lane == 0) { uint32_t pq = qp[qi] + qAdd; if (flip) pq = flip - pq - (uint32_t)K; a.outQ[o + n] = pq; a.outT[o + n] = tp[ti] + tAdd; }
     n++;
   };
 #define Qk(x) (qk[x] & FOR_MASK)
@@ -234,7 +268,7 @@ __global__ void rs_compare(RsArgs a, int nLarge) {
   }
 #undef Qk
 #undef Tk
-  if (!EMIT) a.cnt[i] = n;
+  if (!EMIT && lane == 0) a.cnt[i] = n;
 }
 
 inline size_t sz(size_t n, size_t e) { return (n * e + 255) / 256 * 256; }
@@ -307,22 +341,23 @@ static int refine_space_impl(lra_ctx* ctx, int n, const char* d_qseq, const uint
   }
   // ---- long gaps
   if (nLarge > 0) {
-    lra_time_begin(ctx, "refine_space_long");
-    hipLaunchKernelGGL(rs_sketch<false>, dim3((2 * nLarge + 63) / 64), dim3(64), 0, st, a, nLarge);
+    lra_time_begin(ctx, "rs_long_sketch");
+    hipLaunchKernelGGL(rs_sketch<false>, dim3(2 * nLarge), dim3(64), 0, st, a, nLarge);
     lra_time_end(ctx);
     { int rc = lra_exclusive_scan<uint32_t>(ctx, 2 * nLarge, a.lcnt, loff); if (rc) return rc; }
     uint64_t totalMm = 0;
     LRA_HIP_CHECK(ctx, hipMemcpyAsync(&totalMm, loff + 2 * nLarge, 8, hipMemcpyDeviceToHost, st));
     LRA_HIP_CHECK(ctx, hipStreamSynchronize(st));
+    if (getenv("LRA_RS_DBG")) fprintf(stderr, "[rs] n %d nLarge %d minimizers %llu\n", n, nLarge, (unsigned long long)totalMm);
     char* wl = (char*)lra_ensure(ctx, 17, sz(totalMm + 1, 8) + sz(totalMm + 1, 4) + 4096);
     if (!wl) return LRA_ERR_NOMEM;
     a.lkey = (uint64_t*)take(wl, totalMm + 1, 8); a.lpos = (uint32_t*)take(wl, totalMm + 1, 4); a.loff = loff;
-    lra_time_begin(ctx, "refine_space_long");
-    hipLaunchKernelGGL(rs_sketch<true>, dim3((2 * nLarge + 63) / 64), dim3(64), 0, st, a, nLarge);
+    lra_time_begin(ctx, "rs_long_sketch");
+    hipLaunchKernelGGL(rs_sketch<true>, dim3(2 * nLarge), dim3(64), 0, st, a, nLarge);
     lra_time_end(ctx);
     { int rc = lra_sort_minimizers_batch(ctx, 2 * nLarge, loff, a.lkey, a.lpos); if (rc) return rc; }   // sort(EndGenomeTup), sort(EndReadTup)  :306,:308
-    lra_time_begin(ctx, "refine_space_long");
-    hipLaunchKernelGGL(rs_compare<false>, dim3((nLarge + 63) / 64), dim3(64), 0, st, a, nLarge);
+    lra_time_begin(ctx, "rs_long_compare");
+    hipLaunchKernelGGL(rs_compare<false>, dim3(nLarge), dim3(64), 0, st, a, nLarge);
     lra_time_end(ctx);
   }
   // ---- pairs
@@ -339,8 +374,8 @@ static int refine_space_impl(lra_ctx* ctx, int n, const char* d_qseq, const uint
   if (nSmall > 0) hipLaunchKernelGGL(rs_small<true>, dim3((nSmall + 63) / 64), dim3(64), 0, st, a, nSmall);
   lra_time_end(ctx);
   if (nLarge > 0) {
-    lra_time_begin(ctx, "refine_space_long");
-    hipLaunchKernelGGL(rs_compare<true>, dim3((nLarge + 63) / 64), dim3(64), 0, st, a, nLarge);
+    lra_time_begin(ctx, "rs_long_compare");
+    hipLaunchKernelGGL(rs_compare<true>, dim3(nLarge), dim3(64), 0, st, a, nLarge);
     lra_time_end(ctx);
   }
   LRA_HIP_CHECK(ctx, hipStreamSynchronize(st));

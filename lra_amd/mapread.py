@@ -1,0 +1,233 @@
+"""MapRead_lowacc for a batch of reads (reference: Map_lowacc.h:33-640, called from MapRead, MapRead.h:169-263): every stage between the
+read bases and the alignments' statistics runs on the device through the C-ABI library, one batched call per stage; the per-read record
+bookkeeping behind CalculateStatistics (SetFromSegAlignment, AlignmentsOrder, SimpleMapQV, OUTPUT) is the library's host code.
+
+    mapper = LowAccMapper(ctx, genome, idx_key, idx_pos, ["chr1", ...], [0, ..., G])     # once per reference
+    res = mapper.align(seed.ReadBatch(ctx, reads))                                       # device work, results stay in HBM
+    sam = mapper.records(res, names, reads)                                              # one text record group per read
+
+Stage order and the reference lines each call replaces:
+    a1-a4  seed_batch               StoreMinimizers, sort, CompareLists, SeparateMatchesByStrand        MapRead.h:169-203
+    a5     clean_matches_batch      CleanMatches per strand                                              Map_lowacc.h:60-150
+    a7     linear_extend_batch      LinearExtend of every cluster                                        Map_lowacc.h:160-184
+    a8     sparse_dp_batch          SparseDP over the clusters of the read (primary chains)             Map_lowacc.h:185-188
+    a9     split_chains_batch       RemoveSpuriousJump, SPLITChain, RemoveSpuriousSplitChain             Map_lowacc.h:189-245
+    a10    LocalIndex, refine_splitchain_batch, refine_btwn_splitchain_batch                             Map_lowacc.h:246-410
+    a9/a7  merge_extend_batch       MergeChain, LinearExtend (second pass), TrimOverlappedAnchors        Map_lowacc.h:411-520
+    a8     sparse_dp_batch          SparseDP on the merged clusters (ultimate chains)                    Map_lowacc.h:521-540
+    a13    local_refine_from_sdp    RemovePairedIndels / RemoveSpuriousAnchors, LocalRefineAlignment     Map_lowacc.h:541-576
+    a14    indel_refine_batch       IndelRefineAlignment                                                 Map_lowacc.h:582-585
+    a16    stats_of_refined         CalculateStatistics                                                  Map_lowacc.h:597-599
+    a16/17 records                  SetFromSegAlignment, AlignmentsOrder::Update, SimpleMapQV, OUTPUT    Map_lowacc.h:600-618
+"""
+import ctypes as C
+from dataclasses import dataclass
+
+import numpy as np
+import torch
+
+from . import chain, cluster, emit, local, refine, seed
+from .context import Context
+
+
+@dataclass
+class LowAccOptions:
+    """The -ONT preset (lra.cpp:386-431 over the defaults of Options.h:127-230)."""
+    globalK: int = 17
+    globalW: int = 10
+    globalMaxFreq: int = 150
+    localK: int = 10
+    localW: int = 5
+    localMaxFreq: int = 15
+    localIndexWindow: int = 256
+    refineBand: int = 7
+    localMatch: int = 4
+    localMismatch: int = -1
+    localIndel: int = -2
+    refineSpaceDist: int = 30000
+    anchorstoosparse: float = 0.005
+    splitdist: int = 50000            # Options.h:191
+    window: int = 100                 # smallOpts.window (Map_lowacc.h:40)
+    second_anchorbonus: float = 2.0
+    bypassClustering: bool = True
+    read_type: str = "ont"
+    hardClip: bool = True
+    PrintNumAln: int = 1
+    printFormat: str = "s"
+
+
+def seq_offsets(chrom_pos, window):
+    """LocalIndex::seqOffsets of the genome (MMIndex.h:200-245): window ends, restarting at each sequence."""
+    out = [0]
+    for s, e in zip(chrom_pos[:-1], chrom_pos[1:]):
+        p = int(s)
+        while p < e:
+            p = min(p + window, int(e))
+            out.append(p)
+    return np.array(out, np.int64)
+
+
+def _log_lookup_table():
+    """LogLookUpTable.h:9-15 -- logf from the host libm, as the reference builds it."""
+    libm = C.CDLL("libm.so.6")
+    libm.logf.restype = C.c_float
+    libm.logf.argtypes = [C.c_float]
+    return np.array([libm.logf(float(i)) for i in range(1, 10002, 5)], dtype=np.float32)
+
+
+class MapBatchResult:
+    """What align() leaves in HBM for one batch (context-owned buffers: valid until the next align() on the same context)."""
+    pass
+
+
+class LowAccMapper:
+    def __init__(self, ctx: Context, genome, idx_key, idx_pos, chrom_names, chrom_pos, opts: LowAccOptions = None):
+        """genome: uint8 bases of all sequences back to back (numpy or device tensor); idx_key / idx_pos: the global minimizer index (the
+        .mms payload, MMIndex.h:416); chrom_pos: n_chrom + 1 start offsets (Genome::header.pos)."""
+        self.ctx = ctx
+        self.opts = opts or LowAccOptions()
+        o = self.opts
+        dev = ctx.device
+        g = genome if torch.is_tensor(genome) else torch.from_numpy(np.ascontiguousarray(genome, dtype=np.uint8))
+        self.G = int(g.numel())
+        self.chrom_pos = [int(x) for x in chrom_pos]
+        assert self.chrom_pos[0] == 0 and self.chrom_pos[-1] == self.G
+        self.chrom_names = [n if isinstance(n, bytes) else str(n).encode() for n in chrom_names]
+        seed.load_reference(ctx, g.cpu().numpy(), idx_key, idx_pos)
+        self.gdev = torch.cat([g.to(dev), torch.zeros(64, dtype=torch.uint8, device=dev)])
+        self.g_off = torch.tensor(self.chrom_pos, dtype=torch.int64, device=dev)
+        # the genome's local index (the .gli payload): built once
+        self.gli = local.LocalIndex(ctx, self.gdev, self.g_off, o.localK, o.localW, o.localIndexWindow, o.localMaxFreq)
+        self.gso = torch.from_numpy(seq_offsets(self.chrom_pos, o.localIndexWindow)).to(dev)
+        self.lut = _log_lookup_table()
+        self.sdp_opts = chain.sdp_opts()
+        self.sdp2_opts = chain.sdp_opts(mode=1, rate=o.second_anchorbonus)      # SparseDP :2287 with opts.second_anchorbonus (Options.h:221)
+        self.clean_opts = cluster.CleanOpts(globalK=o.globalK, cleanMaxDiag=200, minDiagCluster=3, bypassClustering=int(o.bypassClustering),
+                                            cleanClustersize=100, SecondCleanMinDiagCluster=10, SecondCleanMaxDiag=100, punish_anchorfreq=5,
+                                            anchorPerlength=5)
+        self.stats = {}
+
+    # ------------------------------------------------------------------------------------------------------------------ device stages
+    def align(self, rbatch) -> MapBatchResult:
+        ctx, o, st = self.ctx, self.opts, self.stats
+        CH, G, gdev = self.chrom_pos, self.G, self.gdev
+        nR = rbatch.n
+        tot = int(rbatch.total_bases)
+        lens = rbatch.off[1:] - rbatch.off[:-1]
+        sres = seed.seed_batch(ctx, rbatch, o.globalK, o.globalW, o.globalMaxFreq)
+        cres = cluster.clean_matches_batch(ctx, self.clean_opts, CH)
+        eres = cluster.linear_extend_batch(ctx, o.globalK, rbatch)
+        chres = chain.sparse_dp_batch(ctx, nR, cres.d_cluster_off, eres.d_e_start, eres.d_e_count, cres.d_c_strand, eres.d_e_qpos, eres.d_e_tpos,
+                                      eres.d_e_len, rbatch.off, self.sdp_opts)
+        num_aln = int(chres.num_aln)
+        # chains[p].NumOfAnchors0 for a13 (the second sparse DP reuses the first one's buffers)
+        slot_n0 = ctx.to_tensor(chres.d_chain_len, nR * num_aln, torch.int32) if nR * num_aln else None
+        spres = chain.split_chains_batch(ctx, chres, CH, o.splitdist)
+        # the reads forward, then reverse complemented, in one buffer (forwardIndex / reverseIndex, Map_lowacc.h:246-250)
+        both = torch.zeros(2 * tot + 64, dtype=torch.uint8, device=ctx.device)
+        both[:tot] = rbatch.seq[:tot]
+        ctx.check(ctx.lib.lra_create_rc_batch(ctx.h, nR, C.c_void_p(rbatch.seq.data_ptr()), C.c_void_p(rbatch.off.data_ptr()), C.c_void_p(both.data_ptr() + tot)))
+        off2 = torch.cat([rbatch.off, rbatch.off[1:] + tot]).contiguous()
+        rli = local.LocalIndex(ctx, both, off2, o.localK, o.localW, o.localIndexWindow, o.localMaxFreq)
+        rres = chain.refine_splitchain_batch(ctx, chres, spres, rbatch.off, CH, rli, self.gso, self.gli, window=o.window, smallK=o.localK, K=o.globalK,
+                                             limitrefine=True, max_freq=o.localMaxFreq)
+        bres = chain.refine_btwn_splitchain_batch(ctx, chres, spres, rres, rbatch.off, both, tot, gdev, CH, K=o.localK, W=o.localW,
+                                                  refineSpaceDist=o.refineSpaceDist, anchorstoosparse=o.anchorstoosparse, match=o.localMatch,
+                                                  mismatch=o.localMismatch, indel=o.localIndel, max_freq=o.localMaxFreq)
+        mres = chain.merge_extend_batch(ctx, chres, spres, bres, rbatch.seq, rbatch.off, gdev, CH, K=o.localK)
+        ch2 = chain.sparse_dp_batch(ctx, int(mres.n_groups), mres.d_iota, mres.d_anchor_off, mres.d_count, mres.d_strand, mres.d_q, mres.d_t, mres.d_len,
+                                    mres.d_iota, self.sdp2_opts)
+        st.update(n_btwn_problems=bres.n_problems, n_btwn_rounds=bres.n_rounds, n_refined_after_btwn=bres.n_matches, n_merged_clusters=mres.n_groups,
+                  n_sdp2_anchors=mres.n_anchors, n_sdp2_entries=ch2.n_subproblem_entries)
+        if "n_local_task_words" not in st and rres.n_tasks:
+            t4 = [ctx.to_tensor(p_, rres.n_tasks, torch.int64) for p_ in (rres.d_task_q_lo, rres.d_task_q_hi, rres.d_task_t_lo, rres.d_task_t_hi)]
+            st["n_local_task_words"] = int((t4[1] - t4[0]).sum() + (t4[3] - t4[2]).sum())
+        inp, ares = chain.local_refine_from_sdp(ctx, num_aln, slot_n0, mres, ch2, rbatch.off, both, tot, gdev, CH)
+        nA, nJ = int(ares.n_alignments), int(ares.n_jobs)
+        aoff = ctx.to_tensor(ares.d_job_aln_off, nJ + 1, torch.int64)
+        aln_job = torch.repeat_interleave(torch.arange(nJ, device=ctx.device), aoff[1:] - aoff[:-1])
+        aln_read = aln_job // max(num_aln, 1)
+        a_strand = ctx.to_tensor(ares.d_strand, nA, torch.int32).to(torch.int64)
+        a_chrom = ctx.to_tensor(ares.d_chrom, nA, torch.int32).to(torch.int64)
+        fb = refine.refine_batch_from_device(ctx, ctx.to_tensor(ares.d_blocks, 3 * int(ares.n_blocks), torch.int32).view(-1, 3),
+                                             ctx.to_tensor(ares.d_block_off, nA + 1, torch.int64), both, rbatch.off[aln_read] + a_strand * tot, lens[aln_read],
+                                             gdev, self.g_off[a_chrom], self.g_off[a_chrom + 1] - self.g_off[a_chrom])
+        fres = refine.indel_refine_batch(ctx, fb, o.refineBand, o.localMatch, o.localMismatch, o.localIndel)
+        tres = refine.stats_of_refined(ctx, fb, fres, self.lut)
+        st.update(n_alignments=nA, n_a13_blocks=int(ares.n_blocks), n_large_spaces=int(ares.n_big),
+                  n_mm=sres.n_minimizers, n_match=sres.n_matches, n_cells=fres.n_cells, n_rows=fres.n_rows,
+                  n_seg=fres.n_segments, n_blocks=fres.n_blocks, n_aog=fres.n_aog, n_clusters=cres.n_clusters, n_cigar_runs=tres.n_runs, n_local_tuples=rli.n_tuples,
+                  n_local_tasks=rres.n_tasks, n_local_pairs=rres.n_pairs, n_refined_matches=rres.n_matches,
+                  n_sdp_anchors=chres.n_frags, n_sdp_points=chres.n_points, n_sdp_entries=chres.n_subproblem_entries)
+        r = MapBatchResult()
+        r.n_reads, r.num_aln, r.n_alignments, r.n_jobs = nR, num_aln, nA, nJ
+        r.alignments, r.refined, r.stat = ares, fres, tres
+        r.aln_job, r.aln_read, r.job_aln_off = aln_job, aln_read, aoff
+        r.refine_batch, r.strands, r.rc_base = fb, both, tot
+        # the refined block triples: what a rank hands to the gather step
+        r.block_records = ctx.to_tensor(fres.d_blocks, 3 * fres.n_blocks, torch.int32)
+        return r
+
+    # ------------------------------------------------------------------------------------------------------------------ records
+    def records(self, res: MapBatchResult, names, reads, quals=None, passthrough=None):
+        """Per read: SetFromSegAlignment -> AlignmentsOrder::Update -> SimpleMapQV -> OUTPUT (Map_lowacc.h:600-618), or output_unaligned
+        when its first primary chain produced no alignment (:578-581, :604-607).  names / reads / quals: per-read bytes.  Returns one bytes
+        object per read in opts.printFormat ('s' SAM, 'p' / 'P' PAF, 'b' BED)."""
+        ctx, o = self.ctx, self.opts
+        nA, na = res.n_alignments, max(res.num_aln, 1)
+        counts, value, cigars = refine.fetch_stats(ctx, res.stat)
+        al = chain.fetch_alignments(ctx, res.alignments)
+        ir_status = ctx.to_host(res.refined.d_status, nA, np.int32) if nA else np.zeros(0, np.int32)
+        rb_off = ctx.to_host(res.refined.d_block_off, nA + 1, np.uint64) if nA else np.zeros(1, np.uint64)
+        rblocks = ctx.to_host(res.refined.d_blocks, 3 * int(res.refined.n_blocks), np.int32).reshape(-1, 3) if nA else np.zeros((0, 3), np.int32)
+        jo = al["job_aln_off"].astype(np.int64)
+        ix = {n: i for i, n in enumerate(refine.STAT_NAMES)}
+        out = []
+        for r in range(res.n_reads):
+            name = names[r] if isinstance(names[r], bytes) else str(names[r]).encode()
+            rd = bytes(reads[r])
+            ql = None if quals is None else quals[r]
+            recs, seg_off = [], [0]
+            unaligned = int(jo[r * na + 1] - jo[r * na]) == 0 if res.n_jobs else True                   # p == 0 left no SegAlignment (:578)
+            if not unaligned:
+                for p in range(na):
+                    j = r * na + p
+                    if jo[j + 1] == jo[j]:
+                        # the reference pushes an empty SegAlignmentGroup for such a chain and carries on; it holds no record
+                        continue
+                    for a in range(int(jo[j]), int(jo[j + 1])):
+                        c = counts[a]
+                        rec = emit.AlnRecord()
+                        rec.read_name, rec.read, rec.qual, rec.read_len = name, rd, ql, len(rd)
+                        ci = int(al["chrom"][a])
+                        rec.chrom = self.chrom_names[ci]
+                        rec.genome_len = self.chrom_pos[ci + 1] - self.chrom_pos[ci]
+                        rec.cigar = cigars[a].encode()
+                        rec.flag, rec.strand, rec.mapqv = 0, int(al["strand"][a]), 0
+                        rec.supplementary, rec.typeofaln, rec.is_secondary = int(al["supp"][a]), 0, int(al["secondary"][a])
+                        rec.q_start, rec.q_end, rec.t_start, rec.t_end = (int(c[ix[k]]) for k in ("qStart", "qEnd", "tStart", "tEnd"))
+                        rec.pre_clip, rec.suf_clip = int(c[ix["preClip"]]), int(c[ix["sufClip"]])
+                        for k in ("nm", "nmm", "nins", "ndel", "tdel", "tins", "nSmallDel", "nMedDel", "nLargeDel", "nSmallIns", "nMedIns", "nLargeIns"):
+                            setattr(rec, k, int(c[ix[k]]))
+                        rec.value, rec.order, rec.runtime = float(al["value"][a]), 0, 0
+                        rec.NumOfAnchors0, rec.NumOfAnchors1 = int(al["n0"][a]), int(al["n1"][a])
+                        b = rblocks[int(rb_off[a]):int(rb_off[a + 1])]
+                        rec.n_blocks = len(b)
+                        rec.first_block_qpos = int(b[0, 0]) if len(b) else 0
+                        rec.last_block_qend = int(b[-1, 0] + b[-1, 2]) if len(b) else 0
+                        recs.append(rec)
+                    seg_off.append(len(recs))
+            if unaligned or not recs:
+                un = emit.AlnRecord()
+                un.read_name, un.read, un.qual, un.read_len = name, rd, ql, len(rd)
+                text, _, _, _ = emit.finish_read([], [0], fmt=o.printFormat, unaligned=un)
+            else:
+                text, _, _, _ = emit.finish_read(recs, seg_off, bypass_clustering=o.bypassClustering, read_type=o.read_type, globalK=o.globalK,
+                                                 print_num_aln=o.PrintNumAln, fmt=o.printFormat, hard_clip=o.hardClip, passthrough=passthrough)
+            out.append(text)
+        return out
+
+    def sam_header(self, version=b"lra_amd", command_line=b""):
+        names = (C.c_char_p * len(self.chrom_names))(*self.chrom_names)
+        pos = (C.c_uint64 * len(self.chrom_pos))(*self.chrom_pos)
+        return emit._call("lra_format_sam_header", version, command_line, names, pos, len(self.chrom_names))
