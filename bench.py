@@ -166,9 +166,9 @@ def main():
         out_rec = [None]
 
         def step():
-            # MapRead_lowacc for the whole batch: a1-a5, a7-a11, a13, a14, a16 (lra_amd/mapread.py lists the calls)
+            # MapRead_lowacc for the whole batch behind the C boundary (lra_map_reads_lowacc_batch): a1-a5, a7-a11, a13, a14, a16
             res = mapper.align(rbatch)
-            out_rec[0] = res.block_records                               # the one exchange step: refined block records -> rank 0
+            out_rec[0] = mapper.block_records(res)                       # the one exchange step: refined block records -> rank 0
 
         def run_step():
             try:

@@ -659,6 +659,64 @@ int lra_simple_mapqv(const lra_aln_group* groups, const int32_t* index, int n_gr
 int lra_output_read(const lra_aln_group* groups, const int32_t* index, int n_groups, lra_aln_record* recs, int print_num_aln, char format, int hard_clip,
                     const char* passthrough, int read_unaligned, const lra_aln_record* unaligned_rec, char* out, uint64_t cap, uint64_t* len);
 
+/* ---- the path behind one call: MapRead_lowacc for a batch of reads -----------------------------------------------------------------
+ * Replaces   int MapRead_lowacc(const vector<float>& LookUpTable, Read& read, Genome& genome, vector<GenomeTuple>& genomemm, LocalIndex& glIndex,
+ *                               const Options& opts, ostream* output, ostream* svsigstrm, Timing& timing, IndelRefineBuffers&, pthread_mutex_t*)
+ *            (Map_lowacc.h:33-640), which MapRead (MapRead.h:153-263) enters for the low-accuracy presets (-ONT, -CLR), called by the MapReads
+ *            worker (lra.cpp:117) and the serial loop (lra.cpp:721) once per read.
+ * The reference side (shared, read-only in the reference too) is loaded once per context:
+ *   lra_ctx_load_genome        genome.seqs back to back                                  (Genome.h:122-137)
+ *   lra_ctx_load_chromosomes   genome.header.pos, n_chrom + 1 cumulative starts          (Genome.h:60-83)
+ *   lra_ctx_load_global_index  genomemm, the .mms payload                                (MMIndex.h:416)
+ *   lra_ctx_build_local_index  glIndex: LocalIndex::IndexSeq of every chromosome on the device (the .gli payload; MMIndex.h:200-254)
+ * lra_map_reads_lowacc_batch aligns n_reads reads (d_seq: upper-case bases back to back, >= 64 bytes of padding behind the last read;
+ * d_read_off: n_reads + 1 offsets; total_bases = d_read_off[n_reads]) and leaves, in context-owned buffers valid until the next call:
+ *   job j = read j / num_aln, primary chain j % num_aln (the loop over chains, Map_lowacc.h:232); its SegAlignments are alignments
+ *   d_job_aln_off[j] .. d_job_aln_off[j+1] (empty when the chain produced none); per alignment: read, strand, Supplymentary, ISsecondary,
+ *   NumOfAnchors0 / 1, chromIndex, FirstSDPValue (value before CalculateStatistics), the refined blocks (IndelRefineAlignment),
+ *   CalculateStatistics' 18 counters (order of lra_calculate_statistics_batch), NV value and CIGAR runs ((length << 4) | op, op in =XID).
+ *   d_job_status[j] != 0 / d_refine_status[a] != 0: the reference would read outside an array there (see the stage headers).
+ * lra_map_records is the per-read tail (SetFromSegAlignment, AlignmentsOrder::Update, SimpleMapQV, OUTPUT / output_unaligned,
+ * Map_lowacc.h:600-618) on the host: text of all reads in input order, two-call convention; rec_off (nullable): n_reads + 1 offsets of
+ * each read's records inside the text.  names / reads / quals (nullable, or NULL / "*" entries) / read_len: per read, host.            */
+#define LRA_READ_ONT 0
+#define LRA_READ_CLR 1
+#define LRA_READ_CCS 2
+#define LRA_READ_CONTIG 3
+typedef struct lra_map_opts {
+  int32_t globalK, globalW, globalMaxFreq;
+  int32_t localK, localW, localMaxFreq, localIndexWindow;
+  int32_t refineBand, localMatch, localMismatch, localIndel, localBand;
+  int32_t refineSpaceDist; float anchorstoosparse; int32_t splitdist, window;
+  float second_anchorbonus; int32_t bypassClustering, skipBandedRefine;
+  lra_clean_opts clean; lra_sdp_opts sdp;
+  int32_t readType, hardClip, PrintNumAln, printFormat;   /* printFormat: 's' SAM, 'p' / 'P' PAF, 'b' BED */
+} lra_map_opts;
+typedef struct lra_map_counters {
+  uint64_t n_minimizers, n_matches, n_clusters, n_sdp_anchors, n_sdp_points, n_sdp_entries, n_local_tuples, n_local_tasks, n_local_task_words, n_local_pairs, n_refined_matches,
+           n_btwn_problems, n_btwn_rounds, n_refined_after_btwn, n_merged_clusters, n_sdp2_anchors, n_sdp2_entries, n_a13_blocks, n_large_spaces, n_segments,
+           n_rows, n_cells, n_aog;
+} lra_map_counters;
+typedef struct lra_map_result {
+  int32_t n_reads, num_aln;
+  uint64_t n_jobs, n_alignments, n_blocks, n_runs;
+  const uint64_t* d_job_aln_off; const uint32_t* d_job_status;
+  const uint32_t* d_aln_read; const int32_t* d_strand; const int32_t* d_supp; const int32_t* d_secondary; const int32_t* d_n0; const int32_t* d_n1;
+  const int32_t* d_chrom; const float* d_first_sdp_value;
+  const uint64_t* d_block_off; const int32_t* d_blocks; const int32_t* d_refine_status;
+  const int32_t* d_counts; const float* d_value; const uint64_t* d_run_off; const uint32_t* d_runs;
+  const char* d_strands; uint64_t rc_base;                 /* the reads forward, then (at rc_base) reverse complemented */
+  lra_map_counters counters;
+} lra_map_result;
+void lra_map_opts_preset_ont(lra_map_opts* opts);          /* -ONT: lra.cpp:386-431 over Options.h:127-230 */
+int lra_ctx_load_chromosomes(lra_ctx* ctx, const uint64_t* h_chrom_pos, int n_chrom);
+int lra_ctx_build_local_index(lra_ctx* ctx, int k, int w, int window, int max_freq);
+int lra_map_reads_lowacc_batch(lra_ctx* ctx, int n_reads, const char* d_seq, const uint64_t* d_read_off, uint64_t total_bases, const lra_map_opts* opts,
+                               lra_map_result* out);
+int lra_map_records(lra_ctx* ctx, const lra_map_result* res, const lra_map_opts* opts, const char* const* names, const char* const* reads,
+                    const char* const* quals, const int32_t* read_len, const char* const* chrom_names, const char* passthrough, char* out, uint64_t cap,
+                    uint64_t* len, uint64_t* rec_off);
+
 #ifdef __cplusplus
 }
 #endif

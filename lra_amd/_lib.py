@@ -66,6 +66,11 @@ SYMBOLS = {
     "lra_local_refine_batch": (C.c_int, [_vp, C.c_uint64, _vp, _vp, _vp, C.c_uint64, _vp, _vp, _vp, _vp, _vp, _vp, C.c_uint64, _vp, _vp, _vp, _vp, _vp, C.c_uint64, _vp, _vp,
                                          C.c_int, _vp, _vp]),
     "lra_local_refine_inputs_batch": (C.c_int, [_vp, C.c_int, _vp, _vp, _vp, _vp]),
+    "lra_map_opts_preset_ont": (None, [_vp]),
+    "lra_ctx_load_chromosomes": (C.c_int, [_vp, _vp, C.c_int]),
+    "lra_ctx_build_local_index": (C.c_int, [_vp, C.c_int, C.c_int, C.c_int, C.c_int]),
+    "lra_map_reads_lowacc_batch": (C.c_int, [_vp, C.c_int, _vp, _vp, C.c_uint64, _vp, _vp]),
+    "lra_map_records": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, C.c_char_p, _vp, C.c_uint64, _vp, _vp]),
     "lra_filter_chains_batch": (C.c_int, [_vp, C.c_uint64, _vp, C.c_uint64, _vp, _vp, _vp, _vp, _vp, _vp, C.c_int, _vp]),
     "lra_calculate_statistics_batch": (C.c_int, [_vp, C.c_int, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, C.c_int, _vp]),
     "lra_local_index_batch": (C.c_int, [_vp, C.c_int, _vp, _vp, C.c_int, C.c_int, C.c_int, C.c_int, _vp]),

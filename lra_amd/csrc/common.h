@@ -10,6 +10,7 @@
 
 struct lra_seed_state;
 struct lra_cluster_state;
+struct lra_map_state;
 struct lra_time_rec { const char* name; hipEvent_t a, b; };
 
 struct lra_ctx {
@@ -22,11 +23,12 @@ struct lra_ctx {
   int num_cu = 256;
   lra_seed_state* seed = nullptr;
   lra_cluster_state* clus = nullptr;
+  lra_map_state* map = nullptr;                       // mapread.hip: chromosome table, the genome's local index
   void* aux = nullptr; size_t aux_bytes = 0;          // AffineOneGapAlign blocks of refine fallbacks
   void* out_buf = nullptr; size_t out_bytes = 0;
   uint64_t* scan_tmp = nullptr;
-  void* gbuf[56] = {};   // growable result / work buffers (lra_ensure)
-  size_t gbytes[56] = {};
+  void* gbuf[64] = {};   // growable result / work buffers (lra_ensure)
+  size_t gbytes[64] = {};
   // kernel timing
   bool sdp_inner = false;                    // local_refine.hip: its small inner sparse DP is timed under "sdp_inner_*"
   const char* sort_tag = "sort"; const char* sort_fb_tag = "sort_fallback";   // timing names of the exact-sort kernels (sdp.hip retags them)
@@ -39,6 +41,7 @@ void lra_time_begin(lra_ctx* ctx, const char* name);
 void lra_time_end(lra_ctx* ctx);
 void lra_seed_free(lra_ctx* ctx);
 void lra_cluster_free(lra_ctx* ctx);
+void lra_map_free(lra_ctx* ctx);
 
 int lra_set_err(lra_ctx* ctx, int code, const char* fmt, ...);
 // returns a device buffer of >= bytes (slot 0..3), growing it if needed (synchronises the

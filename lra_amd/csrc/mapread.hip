@@ -1,0 +1,356 @@
+// lra_amd/csrc/mapread.hip -- the drop-in boundary of the path: MapRead_lowacc for a batch of reads behind ONE call (gfx950 only).
+//
+// Replaces, for n_reads reads at a time, the body of
+//     int MapRead_lowacc(LookUpTable, Read&, Genome&, genomemm, glIndex, opts, output, svsigstrm, timing, indelRefineBuffers, semaphore)
+// (reference: Map_lowacc.h:33-640, entered from MapRead, MapRead.h:169-263) between "the read's bases" and "its alignments with their
+// statistics" (lra_map_reads_lowacc_batch), and the per-read tail SetFromSegAlignment / AlignmentsOrder::Update / SimpleMapQV / OUTPUT
+// (Map_lowacc.h:600-618; lra_map_records).  The stages are the library's own batched entry points, called in the reference's order; the
+// only work done here is the glue the reference does with std::vector moves: keeping NumOfAnchors0 of the first sparse DP, building the
+// forward + reverse-complement read buffer, and addressing every alignment's strand / chromosome for IndelRefineAlignment and
+// CalculateStatistics.
+#include "common.h"
+#include "seed_state.h"
+#include <math.h>
+#include <stdlib.h>
+#include <algorithm>
+
+struct lra_map_state {
+  std::vector<uint64_t> chrom_pos;                 // Genome::header.pos, n_chrom + 1 entries
+  uint64_t* d_chrom_pos = nullptr;
+  void* gli_buf = nullptr; lra_local_index_result gli{};   // the genome's LocalIndex (the .gli payload), built on the device
+  uint64_t* d_gso = nullptr; uint64_t n_gwin = 0;  // its seqOffsets
+  int gli_window = 0;
+  std::vector<float> lut;                          // LogLookUpTable.h:9-15
+};
+
+void lra_map_free(lra_ctx* ctx) {
+  lra_map_state* m = ctx->map;
+  if (!m) return;
+  if (m->d_chrom_pos) (void)hipFree(m->d_chrom_pos);
+  if (m->gli_buf) (void)hipFree(m->gli_buf);
+  if (m->d_gso) (void)hipFree(m->d_gso);
+  delete m;
+  ctx->map = nullptr;
+}
+
+namespace {
+
+lra_map_state* map_state(lra_ctx* ctx) {
+  if (!ctx->map) ctx->map = new lra_map_state();
+  return ctx->map;
+}
+
+__global__ void k_add_off(int n, const uint64_t* __restrict__ off, uint64_t add, uint64_t* __restrict__ out) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i <= n) out[i] = off[i];                       // [0..n]: the reads forward
+  if (i >= 1 && i <= n) out[n + i] = off[i] + add;   // [n+1..2n]: their reverse complements
+}
+
+// per alignment: which read, where its strand's bases start, where its chromosome starts and how long it is
+__global__ void k_aln_address(uint64_t n_jobs, int num_aln, const uint64_t* __restrict__ job_aln_off, const int32_t* __restrict__ strand,
+                              const int32_t* __restrict__ chrom, const uint64_t* __restrict__ read_off, uint64_t rc_base,
+                              const uint64_t* __restrict__ chrom_pos, uint32_t* __restrict__ aln_read, uint64_t* __restrict__ q_off,
+                              int32_t* __restrict__ q_len, uint64_t* __restrict__ t_off, int64_t* __restrict__ t_len) {
+  const uint64_t j = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (j >= n_jobs) return;
+  const uint32_t r = (uint32_t)(j / (uint64_t)num_aln);
+  for (uint64_t a = job_aln_off[j]; a < job_aln_off[j + 1]; a++) {
+    aln_read[a] = r;
+    q_off[a] = read_off[r] + (strand[a] ? rc_base : 0);
+    q_len[a] = (int32_t)(read_off[r + 1] - read_off[r]);
+    const int c = chrom[a];
+    t_off[a] = chrom_pos[c];
+    t_len[a] = (int64_t)(chrom_pos[c + 1] - chrom_pos[c]);
+  }
+}
+
+// tuple words the local compare stage reads (the algorithmic bytes of local_compare): sum over tasks of both list lengths
+__global__ void k_task_words(uint64_t n, const uint64_t* __restrict__ qlo, const uint64_t* __restrict__ qhi, const uint64_t* __restrict__ tlo,
+                             const uint64_t* __restrict__ thi, unsigned long long* sum) {
+  unsigned long long v = 0;
+  for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x) v += (qhi[i] - qlo[i]) + (thi[i] - tlo[i]);
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+  if ((threadIdx.x & 63) == 0 && v) atomicAdd(sum, v);
+}
+
+}  // namespace
+
+extern "C" void lra_map_opts_preset_ont(lra_map_opts* o) {
+  if (!o) return;
+  memset(o, 0, sizeof *o);
+  // -ONT (lra.cpp:386-431) over the defaults of Options.h:127-230
+  o->globalK = 17; o->globalW = 10; o->globalMaxFreq = 150;
+  o->localK = 10; o->localW = 5; o->localMaxFreq = 15; o->localIndexWindow = 256;
+  o->refineBand = 7; o->localMatch = 4; o->localMismatch = -1; o->localIndel = -2; o->localBand = 15;
+  o->refineSpaceDist = 30000; o->anchorstoosparse = 0.005f; o->splitdist = 50000; o->window = 100;
+  o->second_anchorbonus = 2.0f; o->bypassClustering = 1; o->skipBandedRefine = 0;
+  o->clean.globalK = 17; o->clean.cleanMaxDiag = 200; o->clean.minDiagCluster = 3; o->clean.bypassClustering = 1; o->clean.cleanClustersize = 100;
+  o->clean.SecondCleanMinDiagCluster = 10; o->clean.SecondCleanMaxDiag = 100; o->clean.punish_anchorfreq = 5; o->clean.anchorPerlength = 5;
+  o->sdp.rate = 20.0f; o->sdp.NumAln = 2; o->sdp.alnthres = 0.65f; o->sdp.gapopen = 7.0f; o->sdp.gapextend = 10.0f; o->sdp.gaproot = 1.5f;
+  o->sdp.gapCeiling1 = 1500; o->sdp.gapCeiling2 = 3000; o->sdp.mode = 0; o->sdp.globalK = 17;
+  o->readType = LRA_READ_ONT; o->hardClip = 1; o->PrintNumAln = 1; o->printFormat = 's';
+}
+
+extern "C" int lra_ctx_load_chromosomes(lra_ctx* ctx, const uint64_t* h_chrom_pos, int n_chrom) {
+  if (!ctx || !h_chrom_pos || n_chrom < 1) return LRA_ERR_INVALID;
+  LRA_HIP_CHECK(ctx, hipSetDevice(ctx->device));
+  lra_map_state* m = map_state(ctx);
+  m->chrom_pos.assign(h_chrom_pos, h_chrom_pos + n_chrom + 1);
+  if (m->d_chrom_pos) (void)hipFree(m->d_chrom_pos);
+  LRA_HIP_CHECK(ctx, hipMalloc((void**)&m->d_chrom_pos, (size_t)(n_chrom + 1) * 8));
+  LRA_HIP_CHECK(ctx, hipMemcpy(m->d_chrom_pos, h_chrom_pos, (size_t)(n_chrom + 1) * 8, hipMemcpyHostToDevice));
+  if (m->lut.empty()) for (int i = 1; i < 10002; i += 5) m->lut.push_back(logf((float)i));   // LogLookUpTable.h:9-15
+  return LRA_OK;
+}
+
+extern "C" int lra_ctx_build_local_index(lra_ctx* ctx, int k, int w, int window, int max_freq) {
+  if (!ctx || !ctx->map || ctx->map->chrom_pos.size() < 2) return ctx ? lra_set_err(ctx, LRA_ERR_INVALID, "load the chromosome table first") : LRA_ERR_INVALID;
+  if (!ctx->seed || !ctx->seed->genome) return lra_set_err(ctx, LRA_ERR_INVALID, "load the genome first");
+  LRA_HIP_CHECK(ctx, hipSetDevice(ctx->device));
+  lra_map_state* m = ctx->map;
+  const int n_chrom = (int)m->chrom_pos.size() - 1;
+  if (m->chrom_pos[n_chrom] != ctx->seed->genome_len) return lra_set_err(ctx, LRA_ERR_INVALID, "chromosome table does not cover the genome");
+  lra_local_index_result r;
+  int rc = lra_local_index_batch(ctx, n_chrom, (const char*)ctx->seed->genome, m->d_chrom_pos, k, w, window, max_freq, &r);
+  if (rc) return rc;
+  // the result lives in a context buffer the reads' index will reuse: keep a copy
+  if (m->gli_buf) (void)hipFree(m->gli_buf);
+  LRA_HIP_CHECK(ctx, hipMalloc(&m->gli_buf, r.bytes + 256));
+  LRA_HIP_CHECK(ctx, hipMemcpyAsync(m->gli_buf, r.d_base, r.bytes, hipMemcpyDeviceToDevice, ctx->stream));
+  LRA_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+  m->gli = r;
+  const char* ob = (const char*)r.d_base; char* nb = (char*)m->gli_buf;
+  m->gli.d_base = nb;
+  m->gli.d_win_off = (const uint64_t*)(nb + ((const char*)r.d_win_off - ob));
+  m->gli.d_tuple_bnd = (const uint64_t*)(nb + ((const char*)r.d_tuple_bnd - ob));
+  m->gli.d_tuples = (const uint32_t*)(nb + ((const char*)r.d_tuples - ob));
+  m->gli_window = window;
+  // LocalIndex::seqOffsets (MMIndex.h:200-245): window ends, restarting at each sequence
+  std::vector<uint64_t> gso; gso.push_back(0);
+  for (int c = 0; c < n_chrom; c++)
+    for (uint64_t p = m->chrom_pos[c]; p < m->chrom_pos[c + 1];) { p = std::min<uint64_t>(p + (uint64_t)window, m->chrom_pos[c + 1]); gso.push_back(p); }
+  if (gso.size() != r.n_windows + 1) return lra_set_err(ctx, LRA_ERR_INVALID, "local index window count mismatch");
+  if (m->d_gso) (void)hipFree(m->d_gso);
+  LRA_HIP_CHECK(ctx, hipMalloc((void**)&m->d_gso, gso.size() * 8));
+  LRA_HIP_CHECK(ctx, hipMemcpy(m->d_gso, gso.data(), gso.size() * 8, hipMemcpyHostToDevice));
+  m->n_gwin = r.n_windows;
+  return LRA_OK;
+}
+
+extern "C" int lra_map_reads_lowacc_batch(lra_ctx* ctx, int n_reads, const char* d_seq, const uint64_t* d_read_off, uint64_t total_bases,
+                                          const lra_map_opts* o, lra_map_result* out) {
+  if (!ctx || !o || !out || n_reads < 0) return LRA_ERR_INVALID;
+  memset(out, 0, sizeof *out);
+  lra_map_state* m = ctx->map;
+  if (!m || !m->gli_buf || !ctx->seed || !ctx->seed->genome || !ctx->seed->idx_key)
+    return lra_set_err(ctx, LRA_ERR_INVALID, "reference not loaded (genome, global index, chromosome table, local index)");
+  if (m->gli_window != o->localIndexWindow) return lra_set_err(ctx, LRA_ERR_INVALID, "local index built with another window");
+  out->n_reads = n_reads;
+  if (n_reads == 0) return LRA_OK;
+  LRA_HIP_CHECK(ctx, hipSetDevice(ctx->device));
+  hipStream_t st = ctx->stream;
+  const uint64_t* CH = m->chrom_pos.data();
+  const int nCh = (int)m->chrom_pos.size() - 1;
+  const char* genome = (const char*)ctx->seed->genome;
+  const uint64_t tot = total_bases;
+  int rc;
+  // a1-a4
+  lra_seed_result sres;
+  if ((rc = lra_seed_batch(ctx, n_reads, d_seq, d_read_off, o->globalK, o->globalW, o->globalMaxFreq, &sres))) return rc;
+  // a5, a7
+  lra_cluster_result cres;
+  if ((rc = lra_clean_matches_batch(ctx, &o->clean, CH, nCh, &cres))) return rc;
+  lra_extend_result eres;
+  if ((rc = lra_linear_extend_batch(ctx, o->globalK, d_seq, d_read_off, &eres))) return rc;
+  // a8: the primary chains (Map_lowacc.h:185-188)
+  lra_chain_result chres;
+  if ((rc = lra_sparse_dp_batch(ctx, n_reads, cres.d_cluster_off, eres.d_e_start, eres.d_e_count, cres.d_c_strand, eres.d_e_qpos, eres.d_e_tpos, eres.d_e_len,
+                                d_read_off, nullptr, &o->sdp, &chres))) return rc;
+  const int num_aln = chres.num_aln;
+  const uint64_t n_slots = (uint64_t)n_reads * (uint64_t)num_aln;
+  // chains[p].NumOfAnchors0 (the second sparse DP reuses the first one's buffers)
+  uint32_t* slot_n0 = (uint32_t*)lra_ensure(ctx, 56, (n_slots + 1) * 4);
+  if (!slot_n0) return LRA_ERR_NOMEM;
+  LRA_HIP_CHECK(ctx, hipMemcpyAsync(slot_n0, chres.d_chain_len, n_slots * 4, hipMemcpyDeviceToDevice, st));
+  // a9
+  lra_split_result spres;
+  if ((rc = lra_split_chains_batch(ctx, &chres, CH, nCh, o->splitdist, o->bypassClustering, &spres))) return rc;
+  // a10: the reads forward, then reverse complemented, in one buffer + its local index (Map_lowacc.h:246-250)
+  char* both = (char*)lra_ensure(ctx, 57, 2 * tot + 64);
+  uint64_t* off2 = (uint64_t*)lra_ensure(ctx, 58, (2 * (size_t)n_reads + 2) * 8);
+  if (!both || !off2) return LRA_ERR_NOMEM;
+  LRA_HIP_CHECK(ctx, hipMemcpyAsync(both, d_seq, tot, hipMemcpyDeviceToDevice, st));
+  LRA_HIP_CHECK(ctx, hipMemsetAsync(both + 2 * tot, 0, 64, st));
+  if ((rc = lra_create_rc_batch(ctx, n_reads, d_seq, d_read_off, both + tot))) return rc;
+  hipLaunchKernelGGL(k_add_off, dim3((n_reads + 256) / 256), dim3(256), 0, st, n_reads, d_read_off, tot, off2);
+  lra_local_index_result rli;
+  if ((rc = lra_local_index_batch(ctx, 2 * n_reads, both, off2, o->localK, o->localW, o->localIndexWindow, o->localMaxFreq, &rli))) return rc;
+  lra_rsc_opts ro; ro.window = o->window; ro.smallK = o->localK; ro.K = o->globalK; ro.limitrefine = 1; ro.max_freq = o->localMaxFreq; ro.local_window = o->localIndexWindow;
+  lra_refined_result rres;
+  if ((rc = lra_refine_splitchain_batch(ctx, &chres, &spres, d_read_off, CH, nCh, &rli, m->n_gwin, m->d_gso, m->gli.d_tuple_bnd, m->gli.d_tuples, &ro, &rres))) return rc;
+  uint64_t task_words = 0;
+  if (rres.n_tasks) {
+    unsigned long long* d_sum = (unsigned long long*)lra_scratch(ctx, 3, 256);
+    if (!d_sum) return LRA_ERR_NOMEM;
+    LRA_HIP_CHECK(ctx, hipMemsetAsync(d_sum, 0, 8, st));
+    hipLaunchKernelGGL(k_task_words, dim3((unsigned)std::min<uint64_t>((rres.n_tasks + 255) / 256, 1024)), dim3(256), 0, st, rres.n_tasks, rres.d_task_q_lo,
+                       rres.d_task_q_hi, rres.d_task_t_lo, rres.d_task_t_hi, d_sum);
+    LRA_HIP_CHECK(ctx, hipMemcpyAsync(&task_words, d_sum, 8, hipMemcpyDeviceToHost, st));
+    LRA_HIP_CHECK(ctx, hipStreamSynchronize(st));
+  }
+  // a11 callers
+  lra_btwn_opts bo; bo.K = o->localK; bo.W = o->localW; bo.refineSpaceDist = o->refineSpaceDist; bo.anchorstoosparse = o->anchorstoosparse;
+  bo.match = o->localMatch; bo.mismatch = o->localMismatch; bo.indel = o->localIndel; bo.max_freq = o->localMaxFreq;
+  lra_btwn_result bres;
+  if ((rc = lra_refine_btwn_splitchain_batch(ctx, &chres, &spres, &rres, d_read_off, both, tot, genome, CH, nCh, &bo, &bres))) return rc;
+  // a9 MergeChain, a7 second pass, a8 second sparse DP (Map_lowacc.h:411-540)
+  lra_merge_result mres;
+  if ((rc = lra_merge_extend_batch(ctx, &chres, &spres, &bres, d_seq, d_read_off, genome, CH, nCh, o->localK, &mres))) return rc;
+  lra_sdp_opts s2 = o->sdp; s2.mode = 1; s2.rate = o->second_anchorbonus;      // SparseDP :2287 with opts.second_anchorbonus (Options.h:221)
+  lra_chain_result ch2;
+  if ((rc = lra_sparse_dp_batch(ctx, (int)mres.n_groups, mres.d_iota, mres.d_anchor_off, mres.d_count, mres.d_strand, mres.d_q, mres.d_t, mres.d_len, mres.d_iota,
+                                nullptr, &s2, &ch2))) return rc;
+  // a13
+  lra_local_refine_inputs inp;
+  if ((rc = lra_local_refine_inputs_batch(ctx, num_aln, slot_n0, &mres, &ch2, &inp))) return rc;
+  lra_lra_opts lo; lo.localW = o->localW; lo.globalW = o->localW; lo.localMaxFreq = o->localMaxFreq; lo.match = o->localMatch; lo.mismatch = o->localMismatch;
+  lo.indel = o->localIndel; lo.localBand = o->localBand; lo.refineBySDP = 1; lo.isOnt = (o->readType == LRA_READ_ONT || o->readType == LRA_READ_CLR) ? 1 : 0;
+  lo.gapopen = o->sdp.gapopen; lo.gapextend = o->sdp.gapextend; lo.gaproot = o->sdp.gaproot; lo.gapCeiling1 = o->sdp.gapCeiling1; lo.gapCeiling2 = o->sdp.gapCeiling2;
+  lra_alignments_result ares;
+  if ((rc = lra_local_refine_batch(ctx, inp.n_jobs, inp.d_job_chain_off, inp.d_job_read, inp.d_job_h, inp.n_chains, inp.d_chain_anchor_off, inp.d_chain_strand,
+                                   inp.d_chain_chrom, inp.d_chain_value, inp.d_chain_n0, inp.d_chain_n1, inp.n_anchors, inp.d_q, inp.d_t, inp.d_len, d_read_off,
+                                   both, tot, genome, CH, nCh, &lo, &ares))) return rc;
+  const uint64_t nA = ares.n_alignments, nJ = ares.n_jobs;
+  // a14, a16 on every SegAlignment (Map_lowacc.h:582-599)
+  uint32_t* aln_read = (uint32_t*)lra_ensure(ctx, 59, (nA + 1) * 4);
+  uint64_t* q_off = (uint64_t*)lra_ensure(ctx, 60, (nA + 1) * 8);
+  int32_t* q_len = (int32_t*)lra_ensure(ctx, 61, (nA + 1) * 4);
+  uint64_t* t_off = (uint64_t*)lra_ensure(ctx, 62, (nA + 1) * 8);
+  int64_t* t_len = (int64_t*)lra_ensure(ctx, 63, (nA + 1) * 8);
+  if (!aln_read || !q_off || !q_len || !t_off || !t_len) return LRA_ERR_NOMEM;
+  if (nJ) hipLaunchKernelGGL(k_aln_address, dim3((unsigned)((nJ + 255) / 256)), dim3(256), 0, st, nJ, num_aln, ares.d_job_aln_off, ares.d_strand, ares.d_chrom,
+                             d_read_off, tot, m->d_chrom_pos, aln_read, q_off, q_len, t_off, t_len);
+  lra_refine_result fres; memset(&fres, 0, sizeof fres);
+  lra_stats_result tres; memset(&tres, 0, sizeof tres);
+  if (nA) {
+    if (o->skipBandedRefine) {
+      fres.n_aln = (int)nA; fres.n_blocks = ares.n_blocks; fres.d_block_off = ares.d_block_off; fres.d_blocks = ares.d_blocks; fres.d_status = nullptr;
+    } else if ((rc = lra_indel_refine_batch(ctx, (int)nA, ares.d_blocks, ares.d_block_off, ares.n_blocks, both, q_off, q_len, genome, t_off, t_len, o->refineBand,
+                                            o->localMatch, o->localMismatch, o->localIndel, 0, &fres))) return rc;
+    if ((rc = lra_calculate_statistics_batch(ctx, (int)nA, fres.d_blocks, fres.d_block_off, both, q_off, q_len, genome, t_off, m->lut.data(), (int)m->lut.size(), &tres)))
+      return rc;
+  }
+  LRA_HIP_CHECK(ctx, hipStreamSynchronize(st));
+  LRA_HIP_CHECK(ctx, hipGetLastError());
+  out->num_aln = num_aln; out->n_jobs = nJ; out->n_alignments = nA; out->n_blocks = fres.n_blocks; out->n_runs = tres.n_runs;
+  out->d_job_aln_off = ares.d_job_aln_off; out->d_job_status = ares.d_status;
+  out->d_aln_read = aln_read; out->d_strand = ares.d_strand; out->d_supp = ares.d_supp; out->d_secondary = ares.d_secondary; out->d_n0 = ares.d_n0; out->d_n1 = ares.d_n1;
+  out->d_chrom = ares.d_chrom; out->d_first_sdp_value = ares.d_value;
+  out->d_block_off = fres.d_block_off; out->d_blocks = fres.d_blocks; out->d_refine_status = fres.d_status;
+  out->d_counts = tres.d_counts; out->d_value = tres.d_value; out->d_run_off = tres.d_run_off; out->d_runs = tres.d_runs;
+  out->d_strands = both; out->rc_base = tot;
+  // counters of the batch (what bench.py prices the roofline with)
+  lra_map_counters& c = out->counters;
+  c.n_minimizers = sres.n_minimizers; c.n_matches = sres.n_matches; c.n_clusters = cres.n_clusters; c.n_sdp_anchors = chres.n_frags; c.n_sdp_points = chres.n_points;
+  c.n_sdp_entries = chres.n_subproblem_entries; c.n_local_tuples = rli.n_tuples; c.n_local_tasks = rres.n_tasks; c.n_local_task_words = task_words; c.n_local_pairs = rres.n_pairs;
+  c.n_refined_matches = rres.n_matches; c.n_btwn_problems = bres.n_problems; c.n_btwn_rounds = bres.n_rounds; c.n_refined_after_btwn = bres.n_matches;
+  c.n_merged_clusters = mres.n_groups; c.n_sdp2_anchors = mres.n_anchors; c.n_sdp2_entries = ch2.n_subproblem_entries; c.n_a13_blocks = ares.n_blocks;
+  c.n_large_spaces = ares.n_big; c.n_segments = fres.n_segments; c.n_rows = fres.n_rows; c.n_cells = fres.n_cells; c.n_aog = fres.n_aog;
+  return LRA_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------------------- records (host)
+namespace {
+template <typename T>
+int fetch(lra_ctx* ctx, std::vector<T>& v, const T* d, size_t n) {
+  v.resize(n);
+  if (n && d) LRA_HIP_CHECK(ctx, hipMemcpy(v.data(), d, n * sizeof(T), hipMemcpyDeviceToHost));
+  return LRA_OK;
+}
+}  // namespace
+
+extern "C" int lra_map_records(lra_ctx* ctx, const lra_map_result* res, const lra_map_opts* o, const char* const* names, const char* const* reads,
+                               const char* const* quals, const int32_t* read_len, const char* const* chrom_names, const char* passthrough, char* out,
+                               uint64_t cap, uint64_t* len, uint64_t* rec_off) {
+  if (!ctx || !res || !o || !names || !reads || !read_len || !chrom_names || !len) return LRA_ERR_INVALID;
+  lra_map_state* m = ctx->map;
+  if (!m) return LRA_ERR_INVALID;
+  LRA_HIP_CHECK(ctx, hipSetDevice(ctx->device));
+  const size_t nA = res->n_alignments, nJ = res->n_jobs;
+  const int na = std::max(res->num_aln, 1);
+  std::vector<uint64_t> jo, boff, roff; std::vector<int32_t> strand, supp, sec, n0, n1, chrom, counts, blocks; std::vector<float> fval; std::vector<uint32_t> runs;
+  int rc;
+  if ((rc = fetch(ctx, jo, res->d_job_aln_off, nJ ? nJ + 1 : 0)) || (rc = fetch(ctx, strand, res->d_strand, nA)) || (rc = fetch(ctx, supp, res->d_supp, nA)) ||
+      (rc = fetch(ctx, sec, res->d_secondary, nA)) || (rc = fetch(ctx, n0, res->d_n0, nA)) || (rc = fetch(ctx, n1, res->d_n1, nA)) ||
+      (rc = fetch(ctx, chrom, res->d_chrom, nA)) || (rc = fetch(ctx, fval, res->d_first_sdp_value, nA)) || (rc = fetch(ctx, counts, res->d_counts, 18 * nA)) ||
+      (rc = fetch(ctx, boff, res->d_block_off, nA ? nA + 1 : 0)) || (rc = fetch(ctx, blocks, res->d_blocks, 3 * (size_t)res->n_blocks)) ||
+      (rc = fetch(ctx, roff, res->d_run_off, nA ? nA + 1 : 0)) || (rc = fetch(ctx, runs, res->d_runs, (size_t)res->n_runs)))
+    return rc;
+  std::string text;
+  std::vector<std::string> cigars;
+  std::vector<lra_aln_record> recs;
+  std::vector<int32_t> seg_off, index;
+  std::vector<lra_aln_group> groups;
+  std::vector<char> buf;
+  char tmp[32];
+  for (int r = 0; r < res->n_reads; r++) {
+    if (rec_off) rec_off[r] = text.size();
+    recs.clear(); cigars.clear(); seg_off.assign(1, 0);
+    const bool unaligned = nJ == 0 || jo[(size_t)r * na + 1] == jo[(size_t)r * na];     // p == 0 left no SegAlignment (Map_lowacc.h:578-581)
+    if (!unaligned) {
+      size_t total = 0;
+      for (int p = 0; p < na; p++) total += (size_t)(jo[(size_t)r * na + p + 1] - jo[(size_t)r * na + p]);
+      cigars.reserve(total);                                              // the records keep pointers into these strings
+      for (int p = 0; p < na; p++) {
+        const size_t j = (size_t)r * na + p;
+        if (jo[j + 1] == jo[j]) continue;
+        for (uint64_t a = jo[j]; a < jo[j + 1]; a++) {
+          std::string cg;
+          for (uint64_t x = roff[a]; x < roff[a + 1]; x++) { snprintf(tmp, sizeof tmp, "%u%c", runs[x] >> 4, "=XID"[runs[x] & 15]); cg += tmp; }
+          cigars.push_back(std::move(cg));
+          const int32_t* c = &counts[18 * a];
+          lra_aln_record rec; memset(&rec, 0, sizeof rec);
+          rec.read_name = names[r]; rec.read = reads[r]; rec.qual = quals ? quals[r] : nullptr; rec.read_len = read_len[r];
+          rec.chrom = chrom_names[chrom[a]]; rec.genome_len = (uint32_t)(m->chrom_pos[chrom[a] + 1] - m->chrom_pos[chrom[a]]);
+          rec.cigar = cigars.back().c_str();
+          rec.strand = strand[a]; rec.supplementary = supp[a]; rec.is_secondary = sec[a];
+          rec.nm = c[0]; rec.nmm = c[1]; rec.nins = c[2]; rec.ndel = c[3]; rec.tdel = c[4]; rec.tins = c[5]; rec.nSmallDel = c[6]; rec.nMedDel = c[7]; rec.nLargeDel = c[8];
+          rec.nSmallIns = c[9]; rec.nMedIns = c[10]; rec.nLargeIns = c[11]; rec.pre_clip = c[12]; rec.suf_clip = c[13];
+          rec.q_start = (uint32_t)c[14]; rec.q_end = (uint32_t)c[15]; rec.t_start = (uint32_t)c[16]; rec.t_end = (uint32_t)c[17];
+          rec.value = fval[a]; rec.NumOfAnchors0 = n0[a]; rec.NumOfAnchors1 = n1[a];
+          const uint64_t b0 = boff[a], b1 = boff[a + 1];
+          rec.n_blocks = (int32_t)(b1 - b0);
+          rec.first_block_qpos = b1 > b0 ? (uint32_t)blocks[3 * b0] : 0;
+          rec.last_block_qend = b1 > b0 ? (uint32_t)(blocks[3 * (b1 - 1)] + blocks[3 * (b1 - 1) + 2]) : 0;
+          recs.push_back(rec);
+        }
+        seg_off.push_back((int32_t)recs.size());
+      }
+    }
+    uint64_t need = 0;
+    if (unaligned || recs.empty()) {
+      lra_aln_record un; memset(&un, 0, sizeof un);
+      un.read_name = names[r]; un.read = reads[r]; un.qual = quals ? quals[r] : nullptr; un.read_len = read_len[r];
+      lra_output_read(nullptr, nullptr, 0, nullptr, o->PrintNumAln, (char)o->printFormat, o->hardClip, passthrough, 1, &un, nullptr, 0, &need);
+      buf.resize(need + 1);
+      if ((rc = lra_output_read(nullptr, nullptr, 0, nullptr, o->PrintNumAln, (char)o->printFormat, o->hardClip, passthrough, 1, &un, buf.data(), need, &need))) return rc;
+    } else {
+      const int n = (int)seg_off.size() - 1;
+      groups.assign(n, lra_aln_group()); index.assign(n, 0);
+      if ((rc = lra_group_alignments(recs.data(), seg_off.data(), n, groups.data())) || (rc = lra_order_alignments(groups.data(), n, recs.data(), index.data(), 0)) ||
+          (rc = lra_simple_mapqv(groups.data(), index.data(), n, recs.data(), o->bypassClustering, o->readType == LRA_READ_CLR, o->readType == LRA_READ_ONT, o->globalK)))
+        return rc;
+      lra_output_read(groups.data(), index.data(), n, recs.data(), o->PrintNumAln, (char)o->printFormat, o->hardClip, passthrough, 0, nullptr, nullptr, 0, &need);
+      buf.resize(need + 1);
+      if ((rc = lra_output_read(groups.data(), index.data(), n, recs.data(), o->PrintNumAln, (char)o->printFormat, o->hardClip, passthrough, 0, nullptr, buf.data(), need,
+                                &need))) return rc;
+    }
+    text.append(buf.data(), need);
+  }
+  if (rec_off) rec_off[res->n_reads] = text.size();
+  *len = text.size();
+  if (!out) return LRA_OK;
+  if (cap < text.size()) return LRA_ERR_INVALID;
+  memcpy(out, text.data(), text.size());
+  return LRA_OK;
+}

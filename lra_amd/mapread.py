@@ -1,6 +1,9 @@
-"""MapRead_lowacc for a batch of reads (reference: Map_lowacc.h:33-640, called from MapRead, MapRead.h:169-263): every stage between the
-read bases and the alignments' statistics runs on the device through the C-ABI library, one batched call per stage; the per-read record
-bookkeeping behind CalculateStatistics (SetFromSegAlignment, AlignmentsOrder, SimpleMapQV, OUTPUT) is the library's host code.
+"""MapRead_lowacc for a batch of reads (reference: Map_lowacc.h:33-640, called from MapRead, MapRead.h:169-263).
+
+The drop-in boundary is the C ABI: lra_map_reads_lowacc_batch (every stage between the read bases and the alignments' statistics, on the
+device) and lra_map_records (SetFromSegAlignment, AlignmentsOrder, SimpleMapQV, OUTPUT on the host) in lra_amd/csrc/mapread.hip;
+LowAccMapper.align / .records are thin ctypes wrappers over them.  align_staged / records_staged drive the same stages one library call at
+a time from Python -- the form the stage-by-stage parity tests hook into; both forms must give identical results (tests/test_mapread.py).
 
     mapper = LowAccMapper(ctx, genome, idx_key, idx_pos, ["chr1", ...], [0, ..., G])     # once per reference
     res = mapper.align(seed.ReadBatch(ctx, reads))                                       # device work, results stay in HBM
@@ -75,6 +78,35 @@ def _log_lookup_table():
     return np.array([libm.logf(float(i)) for i in range(1, 10002, 5)], dtype=np.float32)
 
 
+class MapOpts(C.Structure):
+    """lra_map_opts (include/lra_hip.h)"""
+    _fields_ = ([(n, C.c_int32) for n in ("globalK", "globalW", "globalMaxFreq", "localK", "localW", "localMaxFreq", "localIndexWindow", "refineBand",
+                                          "localMatch", "localMismatch", "localIndel", "localBand", "refineSpaceDist")] +
+                [("anchorstoosparse", C.c_float), ("splitdist", C.c_int32), ("window", C.c_int32), ("second_anchorbonus", C.c_float),
+                 ("bypassClustering", C.c_int32), ("skipBandedRefine", C.c_int32), ("clean", cluster.CleanOpts), ("sdp", chain.SdpOpts)] +
+                [(n, C.c_int32) for n in ("readType", "hardClip", "PrintNumAln", "printFormat")])
+
+
+class MapCounters(C.Structure):
+    _fields_ = [(n, C.c_uint64) for n in ("n_minimizers", "n_matches", "n_clusters", "n_sdp_anchors", "n_sdp_points", "n_sdp_entries", "n_local_tuples",
+                                          "n_local_tasks", "n_local_task_words", "n_local_pairs", "n_refined_matches", "n_btwn_problems", "n_btwn_rounds", "n_refined_after_btwn",
+                                          "n_merged_clusters", "n_sdp2_anchors", "n_sdp2_entries", "n_a13_blocks", "n_large_spaces", "n_segments", "n_rows",
+                                          "n_cells", "n_aog")]
+
+
+class MapResult(C.Structure):
+    """lra_map_result (include/lra_hip.h)"""
+    _fields_ = ([("n_reads", C.c_int32), ("num_aln", C.c_int32), ("n_jobs", C.c_uint64), ("n_alignments", C.c_uint64), ("n_blocks", C.c_uint64),
+                 ("n_runs", C.c_uint64)] +
+                [(n, C.c_void_p) for n in ("d_job_aln_off", "d_job_status", "d_aln_read", "d_strand", "d_supp", "d_secondary", "d_n0", "d_n1", "d_chrom",
+                                           "d_first_sdp_value", "d_block_off", "d_blocks", "d_refine_status", "d_counts", "d_value", "d_run_off", "d_runs",
+                                           "d_strands")] +
+                [("rc_base", C.c_uint64), ("counters", MapCounters)])
+
+
+READ_TYPES = {"ont": 0, "clr": 1, "ccs": 2, "contig": 3}
+
+
 class MapBatchResult:
     """What align() leaves in HBM for one batch (context-owned buffers: valid until the next align() on the same context)."""
     pass
@@ -94,10 +126,13 @@ class LowAccMapper:
         assert self.chrom_pos[0] == 0 and self.chrom_pos[-1] == self.G
         self.chrom_names = [n if isinstance(n, bytes) else str(n).encode() for n in chrom_names]
         seed.load_reference(ctx, g.cpu().numpy(), idx_key, idx_pos)
+        cp = (C.c_uint64 * len(self.chrom_pos))(*self.chrom_pos)
+        ctx.check(ctx.lib.lra_ctx_load_chromosomes(ctx.h, cp, len(self.chrom_pos) - 1))
+        ctx.check(ctx.lib.lra_ctx_build_local_index(ctx.h, o.localK, o.localW, o.localIndexWindow, o.localMaxFreq))
+        self.copts = self._c_opts()
         self.gdev = torch.cat([g.to(dev), torch.zeros(64, dtype=torch.uint8, device=dev)])
         self.g_off = torch.tensor(self.chrom_pos, dtype=torch.int64, device=dev)
-        # the genome's local index (the .gli payload): built once
-        self.gli = local.LocalIndex(ctx, self.gdev, self.g_off, o.localK, o.localW, o.localIndexWindow, o.localMaxFreq)
+        self._gli = None
         self.gso = torch.from_numpy(seq_offsets(self.chrom_pos, o.localIndexWindow)).to(dev)
         self.lut = _log_lookup_table()
         self.sdp_opts = chain.sdp_opts()
@@ -107,8 +142,64 @@ class LowAccMapper:
                                             anchorPerlength=5)
         self.stats = {}
 
-    # ------------------------------------------------------------------------------------------------------------------ device stages
-    def align(self, rbatch) -> MapBatchResult:
+    @property
+    def gli(self):
+        """The genome's local index as a Python-side object (align_staged only; the C boundary keeps its own in the context)."""
+        if self._gli is None:
+            o = self.opts
+            self._gli = local.LocalIndex(self.ctx, self.gdev, self.g_off, o.localK, o.localW, o.localIndexWindow, o.localMaxFreq)
+        return self._gli
+
+    def _c_opts(self):
+        o = self.opts
+        m = MapOpts()
+        self.ctx.lib.lra_map_opts_preset_ont(C.byref(m))
+        for n in ("globalK", "globalW", "globalMaxFreq", "localK", "localW", "localMaxFreq", "localIndexWindow", "refineBand", "localMatch", "localMismatch",
+                  "localIndel", "refineSpaceDist", "anchorstoosparse", "splitdist", "window", "second_anchorbonus"):
+            setattr(m, n, getattr(o, n))
+        m.bypassClustering = int(o.bypassClustering)
+        m.clean.globalK = o.globalK; m.clean.bypassClustering = int(o.bypassClustering); m.sdp.globalK = o.globalK
+        m.readType = READ_TYPES[o.read_type]; m.hardClip = int(o.hardClip); m.PrintNumAln = o.PrintNumAln; m.printFormat = ord(o.printFormat)
+        return m
+
+    # ------------------------------------------------------------------------------------------------------------------ the C boundary
+    def align(self, rbatch) -> MapResult:
+        """lra_map_reads_lowacc_batch: the whole device side in one library call."""
+        ctx = self.ctx
+        res = MapResult()
+        ctx.check(ctx.lib.lra_map_reads_lowacc_batch(ctx.h, rbatch.n, C.c_void_p(rbatch.seq.data_ptr()), C.c_void_p(rbatch.off.data_ptr()),
+                                                     C.c_uint64(int(rbatch.total_bases)), C.byref(self.copts), C.byref(res)))
+        c = res.counters
+        self.stats.update({n: int(getattr(c, n)) for n, _ in MapCounters._fields_})
+        self.stats.update(n_alignments=int(res.n_alignments), n_blocks=int(res.n_blocks), n_cigar_runs=int(res.n_runs),
+                          n_mm=int(c.n_minimizers), n_match=int(c.n_matches), n_seg=int(c.n_segments))
+        return res
+
+    def block_records(self, res: MapResult):
+        """The refined block triples of a batch as a device tensor (what a rank hands to the gather step)."""
+        return self.ctx.to_tensor(res.d_blocks, 3 * int(res.n_blocks), torch.int32)
+
+    def records(self, res: MapResult, names, reads, quals=None, passthrough=None):
+        """lra_map_records: one bytes object per read in opts.printFormat."""
+        ctx = self.ctx
+        n = int(res.n_reads)
+        enc = lambda x: x if isinstance(x, bytes) else str(x).encode()
+        nm = [enc(x) for x in names]; rd = [bytes(x) for x in reads]
+        a_names = (C.c_char_p * n)(*nm); a_reads = (C.c_char_p * n)(*rd)
+        a_quals = (C.c_char_p * n)(*[None if q is None else bytes(q) for q in quals]) if quals is not None else None
+        a_len = (C.c_int32 * n)(*[len(x) for x in rd])
+        a_chr = (C.c_char_p * len(self.chrom_names))(*self.chrom_names)
+        ln = C.c_uint64(0)
+        roff = (C.c_uint64 * (n + 1))()
+        args = (ctx.h, C.byref(res), C.byref(self.copts), a_names, a_reads, a_quals, a_len, a_chr, passthrough)
+        ctx.check(ctx.lib.lra_map_records(*args, None, C.c_uint64(0), C.byref(ln), roff))
+        buf = C.create_string_buffer(ln.value + 1)
+        ctx.check(ctx.lib.lra_map_records(*args, buf, C.c_uint64(ln.value), C.byref(ln), roff))
+        raw = buf.raw
+        return [raw[roff[i]:roff[i + 1]] for i in range(n)]
+
+    # ------------------------------------------------------------------------------------------------------------------ the same, stage by stage
+    def align_staged(self, rbatch) -> MapBatchResult:
         ctx, o, st = self.ctx, self.opts, self.stats
         CH, G, gdev = self.chrom_pos, self.G, self.gdev
         nR = rbatch.n
@@ -169,7 +260,7 @@ class LowAccMapper:
         return r
 
     # ------------------------------------------------------------------------------------------------------------------ records
-    def records(self, res: MapBatchResult, names, reads, quals=None, passthrough=None):
+    def records_staged(self, res: MapBatchResult, names, reads, quals=None, passthrough=None):
         """Per read: SetFromSegAlignment -> AlignmentsOrder::Update -> SimpleMapQV -> OUTPUT (Map_lowacc.h:600-618), or output_unaligned
         when its first primary chain produced no alignment (:578-581, :604-607).  names / reads / quals: per-read bytes.  Returns one bytes
         object per read in opts.printFormat ('s' SAM, 'p' / 'P' PAF, 'b' BED)."""

@@ -32,9 +32,20 @@ def test_map_reads_to_sam(ctx):
     reads.append(np.concatenate([a, b])); truth.append("chimera")
     mapper = mapread.LowAccMapper(ctx, genome, ik, ip, names, CH, o)
     batch = seed.ReadBatch(ctx, [r.tobytes() for r in reads])
-    res = mapper.align(batch)
     rnames = [b"read%d" % i for i in range(len(reads))]
+    # the same stages driven one library call at a time (what the stage parity tests hook into) ...
+    sres = mapper.align_staged(batch)
+    staged = mapper.records_staged(sres, rnames, [r.tobytes() for r in reads])
+    staged_blocks = sres.block_records.cpu().numpy()
+    # ... and behind the C boundary: one call for the device side, one for the records
+    res = mapper.align(batch)
+    assert np.array_equal(mapper.block_records(res).cpu().numpy(), staged_blocks)
     texts = mapper.records(res, rnames, [r.tobytes() for r in reads])
+    assert texts == staged
+    for fmt in "pPb":
+        mapper.opts.printFormat = fmt; mapper.copts = mapper._c_opts()
+        assert mapper.records(res, rnames, [r.tobytes() for r in reads]) == mapper.records_staged(sres, rnames, [r.tobytes() for r in reads]), fmt
+    mapper.opts.printFormat = "s"; mapper.copts = mapper._c_opts()
     assert len(texts) == len(reads)
     hdr = mapper.sam_header(b"test", b"lra align")
     assert hdr.count(b"@SQ") == 2 and b"SN:chrB\tLN:450000" in hdr
