@@ -237,6 +237,12 @@ extern "C" int lra_map_reads_lowacc_batch(lra_ctx* ctx, int n_reads, const char*
       fres.n_aln = (int)nA; fres.n_blocks = ares.n_blocks; fres.d_block_off = ares.d_block_off; fres.d_blocks = ares.d_blocks; fres.d_status = nullptr;
     } else if ((rc = lra_indel_refine_batch(ctx, (int)nA, ares.d_blocks, ares.d_block_off, ares.n_blocks, both, q_off, q_len, genome, t_off, t_len, o->refineBand,
                                             o->localMatch, o->localMismatch, o->localIndel, 0, &fres))) return rc;
+    if (fres.d_status) {                                                  // the refine stage's status array lives in scratch the next stage reuses
+      int32_t* keep = (int32_t*)lra_ensure(ctx, 64, (nA + 1) * 4);
+      if (!keep) return LRA_ERR_NOMEM;
+      LRA_HIP_CHECK(ctx, hipMemcpyAsync(keep, fres.d_status, nA * 4, hipMemcpyDeviceToDevice, st));
+      fres.d_status = keep;
+    }
     if ((rc = lra_calculate_statistics_batch(ctx, (int)nA, fres.d_blocks, fres.d_block_off, both, q_off, q_len, genome, t_off, m->lut.data(), (int)m->lut.size(), &tres)))
       return rc;
   }

@@ -244,6 +244,7 @@ class LowAccMapper:
                                              ctx.to_tensor(ares.d_block_off, nA + 1, torch.int64), both, rbatch.off[aln_read] + a_strand * tot, lens[aln_read],
                                              gdev, self.g_off[a_chrom], self.g_off[a_chrom + 1] - self.g_off[a_chrom])
         fres = refine.indel_refine_batch(ctx, fb, o.refineBand, o.localMatch, o.localMismatch, o.localIndel)
+        refine_status = ctx.to_tensor(fres.d_status, nA, torch.int32)      # lives in scratch the next stage reuses
         tres = refine.stats_of_refined(ctx, fb, fres, self.lut)
         st.update(n_alignments=nA, n_a13_blocks=int(ares.n_blocks), n_large_spaces=int(ares.n_big),
                   n_mm=sres.n_minimizers, n_match=sres.n_matches, n_cells=fres.n_cells, n_rows=fres.n_rows,
@@ -252,7 +253,7 @@ class LowAccMapper:
                   n_sdp_anchors=chres.n_frags, n_sdp_points=chres.n_points, n_sdp_entries=chres.n_subproblem_entries)
         r = MapBatchResult()
         r.n_reads, r.num_aln, r.n_alignments, r.n_jobs = nR, num_aln, nA, nJ
-        r.alignments, r.refined, r.stat = ares, fres, tres
+        r.alignments, r.refined, r.stat, r.refine_status = ares, fres, tres, refine_status
         r.aln_job, r.aln_read, r.job_aln_off = aln_job, aln_read, aoff
         r.refine_batch, r.strands, r.rc_base = fb, both, tot
         # the refined block triples: what a rank hands to the gather step
@@ -268,7 +269,6 @@ class LowAccMapper:
         nA, na = res.n_alignments, max(res.num_aln, 1)
         counts, value, cigars = refine.fetch_stats(ctx, res.stat)
         al = chain.fetch_alignments(ctx, res.alignments)
-        ir_status = ctx.to_host(res.refined.d_status, nA, np.int32) if nA else np.zeros(0, np.int32)
         rb_off = ctx.to_host(res.refined.d_block_off, nA + 1, np.uint64) if nA else np.zeros(1, np.uint64)
         rblocks = ctx.to_host(res.refined.d_blocks, 3 * int(res.refined.n_blocks), np.int32).reshape(-1, 3) if nA else np.zeros((0, 3), np.int32)
         jo = al["job_aln_off"].astype(np.int64)
