@@ -53,57 +53,36 @@ def build_workload(args, rank, device, ref, n_reads, lane):
                 rblocks=rblocks, rboff=rboff, gen_s=time.time() - t0)
 
 
-def cpu_baseline(wl, args, budget_s=20.0, max_reads=768):
-    """The oracle (CPU restatement) timed single-threaded on a bounded sample of the same workload."""
+def cpu_baseline(wl, args, mapper, budget_s=20.0, max_reads=768):
+    """The oracle (CPU restatement) timed single-threaded on a bounded sample of the same workload: MapRead_lowacc read by read through
+    tests/oracle_pipeline.py, the same stages in the same order as the GPU step (its alignments equal the GPU's: tests/test_mapread.py)."""
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import oracle_lib as O
+    import oracle_pipeline as OP
     O.lib()
-    S = min(max_reads, int(wl["sim"]["off"].numel()) - 1)
     sim = wl["sim"]
+    S = min(max_reads, int(sim["off"].numel()) - 1)
     off = sim["off"][:S + 1].cpu().numpy()
     reads = wl["reads"][:int(off[-1])].cpu().numpy()
-    strands = wl["strands"][:int(off[-1])].cpu().numpy()
     g = wl["genome"].cpu().numpy().tobytes() + b"\0" * 64
-    gp = {k: v.cpu().numpy() for k, v in wl["gaps"].items()}
-    rb = wl["rblocks"].cpu().numpy(); rbo = wl["rboff"][:S + 1].cpu().numpy()
-    gsel = np.nonzero(gp["rid"] < S)[0]
-    oopts = O.CleanOpts(**O.CLEAN_PRESETS["ONT"])
-    gptr = 0
+    # the reference side (read-only, built once in the reference too): the genome's local index
+    g_win, g_bnd, g_tup = mapper.gli.fetch()
+    g_index = (OP.seq_offsets(len(g) - 64, mapper.opts.localIndexWindow), g_bnd, g_tup)
+    opts = dict(globalK=args.k, globalW=args.w, globalMaxFreq=args.max_freq, refineBand=args.refine_band)
     t0 = time.time()
-    bases = 0
-    n = 0
+    bases = n = n_aln = 0
     for r in range(S):
         rbytes = reads[off[r]:off[r + 1]].tobytes()
-        sbytes = strands[off[r]:off[r + 1]].tobytes()
-        keys, pos = O.store_minimizers(rbytes, args.k, args.w)
-        sk, sp = O.sort_minimizers(keys, pos)
-        qi, ti = O.compare_lists(sk, sp, wl["idx_key"], wl["idx_pos"], args.max_freq)
-        st = O.separate_strand(rbytes, g, args.k, sp[qi], wl["idx_pos"][ti])
-        offs = [0]; cst = []; Q = []; T = []; Ln = []
-        for strand in (0, 1):
-            sel = st == strand
-            oq, ot, cl = O.clean_matches(sp[qi][sel], wl["idx_pos"][ti][sel], sk[qi][sel], strand, oopts, [0, len(g) - 64])
-            for ci in range(len(cl["start"])):
-                a, b = int(cl["start"][ci]), int(cl["end"][ci])
-                eq, et, el, _ = O.linear_extend(oq[a:b], ot[a:b], strand, args.k, rbytes, g)
-                Q.append(eq); T.append(et); Ln.append(el); cst.append(strand); offs.append(offs[-1] + len(eq))
-        if cst:
-            O.sdp_chain(offs, cst, np.concatenate(Q), np.concatenate(T), np.concatenate(Ln), O.sdp_opts(len(rbytes)))
-        while gptr < len(gsel) and gp["rid"][gsel[gptr]] == r:
-            i = gsel[gptr]
-            qo = int(gp["q_off"][i] - off[r]); to = int(gp["t_off"][i])
-            O.affine_one_gap_align(sbytes[qo:qo + int(gp["q_len"][i])], g[to:to + int(gp["t_len"][i])], 4, -1, -2, int(gp["k"][i]))
-            gptr += 1
-        refined, _ = O.indel_refine(rb[rbo[r]:rbo[r + 1]], sbytes, g, args.refine_band, 4, -1, -2)
-        O.calculate_statistics(refined, sbytes, g)
+        alns, _ = OP.map_read_lowacc(rbytes, g, wl["idx_key"], wl["idx_pos"], g_index, opts)
+        n_aln += sum(len(x) for x in alns)
         bases += len(rbytes)
         n += 1
         if time.time() - t0 > budget_s:
             break
     dt = time.time() - t0
     return {"value": bases / dt / 1e9, "unit": "Gbp/s", "cores": 1, "kind": "port",
-            "sample": "first %d reads (%d bp) of the same batch through the oracle's a1-a5, a7, a8, a12, a14, a16 in %.1f s, 1 thread "
-                      "(python ctypes call overhead included)" % (n, bases, dt)}
+            "sample": "first %d reads (%d bp, %d alignments) of the same batch through the oracle's MapRead_lowacc (a1-a5, a7-a11, a13 incl. a12, a14, a16: "
+                      "the stages of the GPU step, tests/oracle_pipeline.py) in %.1f s, 1 thread (python ctypes call overhead included)" % (n, bases, n_aln, dt)}
 
 
 def main():
@@ -180,7 +159,7 @@ def main():
                     step()
             except BaseException as e:                                   # surfaced by the caller: a thread's exception would vanish otherwise
                 errors.append(e)
-        return dict(ctx=ctx, step=run_step, stats=stats, wl=wl, total_bases=total_bases, n_gap_bytes=n_gap_bytes, n_gaps=n_gaps, out_rec=out_rec)
+        return dict(ctx=ctx, step=run_step, stats=stats, wl=wl, mapper=mapper, total_bases=total_bases, n_gap_bytes=n_gap_bytes, n_gaps=n_gaps, out_rec=out_rec)
 
     ref = build_reference(args, torch.device("cuda", dev_index))
     per_lane = [args.reads // args.lanes + (1 if i < args.reads % args.lanes else 0) for i in range(args.lanes)]
@@ -314,7 +293,7 @@ def main():
                          "traffic": traffic, "avg_launch_ms": avg_ms, "algorithmic_bytes_per_launch": alg},
         }
         if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(wl, args)
+            out["cpu_baseline"] = cpu_baseline(wl, args, lanes[0]["mapper"])
         out["setup_s"] = round(wl["gen_s"], 1)
         print(json.dumps(out))
     if world > 1:

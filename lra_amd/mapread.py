@@ -175,6 +175,23 @@ class LowAccMapper:
                           n_mm=int(c.n_minimizers), n_match=int(c.n_matches), n_seg=int(c.n_segments))
         return res
 
+    def fetch(self, res: MapResult):
+        """Host copies of a batch result: per job the alignment range, per alignment its fields, refined blocks, counters, NV and CIGAR."""
+        ctx = self.ctx
+        nA, nJ = int(res.n_alignments), int(res.n_jobs)
+        d = {"job_aln_off": ctx.to_host(res.d_job_aln_off, nJ + 1, np.uint64) if nJ else np.zeros(1, np.uint64),
+             "job_status": ctx.to_host(res.d_job_status, nJ, np.uint32) if nJ else np.zeros(0, np.uint32)}
+        for k, dt in (("aln_read", np.uint32), ("strand", np.int32), ("supp", np.int32), ("secondary", np.int32), ("n0", np.int32), ("n1", np.int32),
+                      ("chrom", np.int32), ("first_sdp_value", np.float32), ("refine_status", np.int32), ("value", np.float32)):
+            p_ = getattr(res, "d_" + k)
+            d[k] = ctx.to_host(p_, nA, dt) if nA and p_ else np.zeros(nA, dt)
+        d["block_off"] = ctx.to_host(res.d_block_off, nA + 1, np.uint64) if nA else np.zeros(1, np.uint64)
+        d["blocks"] = ctx.to_host(res.d_blocks, 3 * int(res.n_blocks), np.int32).reshape(-1, 3) if nA else np.zeros((0, 3), np.int32)
+        d["counts"] = ctx.to_host(res.d_counts, 18 * nA, np.int32).reshape(-1, 18) if nA else np.zeros((0, 18), np.int32)
+        d["run_off"] = ctx.to_host(res.d_run_off, nA + 1, np.uint64) if nA else np.zeros(1, np.uint64)
+        d["runs"] = ctx.to_host(res.d_runs, int(res.n_runs), np.uint32) if nA else np.zeros(0, np.uint32)
+        return d
+
     def block_records(self, res: MapResult):
         """The refined block triples of a batch as a device tensor (what a rank hands to the gather step)."""
         return self.ctx.to_tensor(res.d_blocks, 3 * int(res.n_blocks), torch.int32)

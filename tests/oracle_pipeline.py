@@ -1,0 +1,132 @@
+"""MapRead_lowacc for ONE read composed from the oracle's stage functions only (test infrastructure: used by tests/ and by bench.py's
+cpu_baseline leg, never by the product).  It follows Map_lowacc.h:33-599 stage by stage exactly as lra_amd/csrc/mapread.hip chains the
+device stages, so its alignments must equal the GPU path's (tests/test_mapread.py) and its run time is the CPU cost of the same work.
+Single-chromosome genomes only (the oracle's LinearExtend / IndelRefine take the chromosome's bytes)."""
+import numpy as np
+
+import oracle_lib as O
+
+ONT = dict(globalK=17, globalW=10, globalMaxFreq=150, localK=10, localW=5, localMaxFreq=15, localIndexWindow=256, refineBand=7, match=4, mismatch=-1,
+           indel=-2, refineSpaceDist=30000, anchorstoosparse=0.005, splitdist=50000, window=100, second_anchorbonus=2.0)
+
+_COMP = np.zeros(256, np.uint8)
+for a, b in zip(b"ACGTNacgtn", b"TGCANtgcan"):
+    _COMP[a] = b
+
+
+def revcomp_bytes(s: bytes) -> bytes:
+    return _COMP[np.frombuffer(s, np.uint8)][::-1].tobytes()
+
+
+def seq_offsets(n, window):
+    return np.array(list(range(0, n, window)) + [n], np.uint64) if n else np.zeros(1, np.uint64)
+
+
+def map_read_lowacc(read: bytes, genome: bytes, idx_key, idx_pos, g_index, opts=None, clean_opts=None, stats=True):
+    """-> (alignments, unaligned).  alignments: list over primary chains p of lists of dict(strand, supp, secondary, n0, n1, value, chrom,
+    a13_blocks, blocks (after IndelRefineAlignment), refine_status[, counts, nv, cigar]).  genome: the chromosome's bases (+ padding);
+    g_index = (seqOffsets, tupleBoundaries, tuples) of the genome's local index."""
+    o = dict(ONT)
+    if opts:
+        o.update(opts)
+    G = len(genome.rstrip(b"\0"))
+    CH = [0, G]
+    L = len(read)
+    K = o["globalK"]
+    co = clean_opts or O.CleanOpts(**dict(O.CLEAN_PRESETS["ONT"], globalK=K))
+    # a1-a4 (MapRead.h:169-203)
+    keys, pos = O.store_minimizers(read, K, o["globalW"])
+    sk, sp = O.sort_minimizers(keys, pos)
+    qi, ti = O.compare_lists(sk, sp, idx_key, idx_pos, o["globalMaxFreq"])
+    st = O.separate_strand(read, genome, K, sp[qi], idx_pos[ti])
+    # a5, a7 (Map_lowacc.h:60-184)
+    offs = [0]; cst = []; Q = []; T = []; Ln = []
+    for strand in (0, 1):
+        sel = st == strand
+        oq, ot, cl = O.clean_matches(sp[qi][sel], idx_pos[ti][sel], sk[qi][sel], strand, co, CH)
+        for ci in range(len(cl["start"])):
+            a, b = int(cl["start"][ci]), int(cl["end"][ci])
+            eq, et, el, _ = O.linear_extend(oq[a:b], ot[a:b], strand, K, read, genome)
+            Q.append(eq); T.append(et); Ln.append(el); cst.append(strand); offs.append(offs[-1] + len(eq))
+    if not cst:
+        return [], True
+    Q = np.concatenate(Q); T = np.concatenate(T); Ln = np.concatenate(Ln)
+    # a8: primary chains (Map_lowacc.h:185-188)
+    first = O.sdp_chain(offs, cst, Q, T, Ln, O.sdp_opts(L))
+    if first["status"] < 0 or not first["chains"]:
+        return [], True
+    offs_a = np.asarray(offs)
+    fwd = read; rc = revcomp_bytes(read)
+    q_index = [None, None]
+    alignments = []
+    for p, ch in enumerate(first["chains"]):
+        fr = ch["frags"].astype(np.int64)
+        cl_of = np.searchsorted(offs_a, fr, side="right") - 1
+        cstrand = np.asarray(cst, np.uint8)[cl_of]
+        # a9 (Map_lowacc.h:189-245)
+        sc = O.split_chain(Q[fr], T[fr], Ln[fr], cstrand, cl_of, ch["link"], CH, o["splitdist"], 1)
+        if sc is None:
+            alignments.append([]);
+            if p == 0: return alignments, True
+            continue
+        kb = sc["keep"].astype(bool)
+        q, t, al, cl, cs_ = Q[fr][kb], T[fr][kb], Ln[fr][kb], cl_of[kb], cstrand[kb]
+        nsp = len(sc["splits"])
+        segs = []
+        if nsp:
+            # a10 (Map_lowacc.h:246-294)
+            moff = [0]; mq = []; mt = []; boxes = []; ok = True
+            for s in sc["splits"]:
+                sd = s["strand"]
+                if q_index[sd] is None:
+                    tup, bnd = O.local_index_seq(fwd if sd == 0 else rc, o["localK"], o["localW"], o["localIndexWindow"], o["localMaxFreq"])
+                    q_index[sd] = (seq_offsets(L, o["localIndexWindow"]), bnd, tup)
+                rs = O.refine_splitchain(q, t, al, cl, cs_, s["idx"], s["box"], sd, s["chrom"], s["clusters"], CH, L, q_index[sd], g_index,
+                                         window=o["window"], smallK=o["localK"], K=K, limitrefine=True, max_freq=o["localMaxFreq"])
+                if rs is None:
+                    ok = False
+                    break
+                mq.extend(rs["q"].tolist()); mt.extend(rs["t"].tolist()); moff.append(len(mq)); boxes.append(rs["box"])
+            if ok:
+                strands = [s["strand"] for s in sc["splits"]]; chroms = [s["chrom"] for s in sc["splits"]]
+                # a11 callers, MergeChain, second LinearExtend + Trim (Map_lowacc.h:362-476)
+                eb = O.refine_btwn_splitchain(moff, mq, mt, np.array(boxes, np.uint32).reshape(-1, 4), strands, chroms, sc["split_link"], fwd, rc, genome, CH,
+                                              K=o["localK"], W=o["localW"], refineSpaceDist=o["refineSpaceDist"], anchorstoosparse=o["anchorstoosparse"],
+                                              match=o["match"], mismatch=o["mismatch"], indel=o["indel"], max_freq=o["localMaxFreq"])
+                if eb is not None:
+                    em = O.merge_extend(eb["off"], eb["q"], eb["t"], eb["box"], strands, chroms, fwd, genome, CH, K=o["localK"])
+                    # second sparse DP + RemovePairedIndels / RemoveSpuriousAnchors (Map_lowacc.h:521-540)
+                    chains = []
+                    for g in range(len(em["member"]) - 1):
+                        a0, a1 = int(em["anchor_off"][g]), int(em["anchor_off"][g + 1])
+                        if a1 == a0:
+                            continue
+                        sg = int(em["strand"][g])
+                        e2 = O.sdp_chain([0, a1 - a0], [sg], em["q"][a0:a1], em["t"][a0:a1], em["len"][a0:a1], O.sdp_opts(L, mode=1, rate=o["second_anchorbonus"]))
+                        if e2["status"] < 0 or not e2["chains"]:
+                            continue
+                        ix = e2["chains"][0]["frags"].astype(np.int64)
+                        cq, ct, cln = em["q"][a0:a1][ix], em["t"][a0:a1][ix], em["len"][a0:a1][ix]
+                        keep, _ = O.filter_chain(cq, ct, cln, [sg] * len(ix), None, [2, 4])
+                        k2 = keep.astype(bool)
+                        chains.append((cq[k2], ct[k2], cln[k2], sg, int(em["chrom"][g]), e2["chains"][0]["value"], len(ix)))
+                    if chains:
+                        # a13 (Map_lowacc.h:576)
+                        off = [0]; aq = []; at = []; aln = []
+                        for c in chains:
+                            aq.extend(c[0].tolist()); at.extend(c[1].tolist()); aln.extend(c[2].tolist()); off.append(len(aq))
+                        segs = O.local_refine_alignment(off, aq, at, aln, [c[3] for c in chains], [c[4] for c in chains], [c[5] for c in chains],
+                                                        [len(fr)] * len(chains), [c[6] for c in chains], p, fwd, rc, genome, CH) or []
+        out = []
+        for s in segs:
+            sb = fwd if s["strand"] == 0 else rc
+            # a14, a16 (Map_lowacc.h:582-599)
+            refined, rst = O.indel_refine(s["blocks"], sb, genome, o["refineBand"], o["match"], o["mismatch"], o["indel"])
+            d = dict(s, a13_blocks=s["blocks"], blocks=refined, refine_status=rst)
+            if stats and rst == 0 and len(refined):
+                d["stats"] = O.calculate_statistics(refined, sb, genome)
+            out.append(d)
+        alignments.append(out)
+        if p == 0 and not out:
+            return alignments, True                                        # Map_lowacc.h:578-581
+    return alignments, False

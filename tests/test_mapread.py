@@ -78,3 +78,48 @@ def test_map_reads_to_sam(ctx):
         assert "NM" in tags
     n_sim = sum(1 for t in truth if isinstance(t, tuple))
     assert n_right >= 0.9 * n_sim, (n_right, n_sim)
+
+
+@pytest.mark.gpu
+def test_map_reads_match_oracle_pipeline(ctx, oracle):
+    """The C boundary against the oracle's stage functions composed on the CPU (tests/oracle_pipeline.py): every SegAlignment of every
+    primary chain -- strand, Supplymentary, NumOfAnchors0/1, FirstSDPValue, the refined blocks -- bit for bit, on plain reads, reads with a
+    deletion / an inversion / a translocated half, and a read that cannot align."""
+    import oracle_pipeline as OP
+    from lra_amd import seed, mapread
+    genome = synth.make_genome(500_000, seed=31, repeat_frac=0.25, n_families=3)
+    o = mapread.LowAccOptions()
+    ik, ip = synth.build_global_index(genome, o.globalK, o.globalW, 100)
+    reads, truth = synth.simulate_reads(genome, 10, 8000, 2500, 0.10, seed=11)
+    rng = np.random.default_rng(2)
+    sim = lambda a, n, rev=False, err=0.08: synth.simulate_read(rng, genome[a:a + n + 1], n, err, (30, 35, 35), rev)[0]
+    reads.append(np.concatenate([sim(50_000, 4000), sim(60_000, 4000)]))                       # 6 kb deletion
+    reads.append(np.concatenate([sim(150_000, 4000), sim(154_000, 2500, True), sim(156_500, 4000)]))   # inversion
+    reads.append(np.concatenate([sim(250_000, 4500), sim(400_000, 4500, True)]))               # translocation, second half reversed
+    reads.append(synth.revcomp(np.concatenate([sim(300_000, 3000), sim(303_200, 3000)])))      # 200 bp deletion, read on the reverse strand
+    reads.append(np.frombuffer(b"ACGT", dtype=np.uint8)[rng.integers(0, 4, 2500)].copy())      # junk
+    mapper = mapread.LowAccMapper(ctx, genome, ik, ip, [b"chr1"], [0, len(genome)], o)
+    res = mapper.align(seed.ReadBatch(ctx, [r.tobytes() for r in reads]))
+    out = mapper.fetch(res)
+    na = int(res.num_aln)
+    g_win, g_bnd, g_tup = mapper.gli.fetch()
+    g_index = (OP.seq_offsets(len(genome), 256), g_bnd, g_tup)
+    gbytes = genome.tobytes() + b"\0" * 64
+    n_seg = n_supp = n_rev = n_multi = 0
+    for r, rd in enumerate(reads):
+        exp, unaligned = OP.map_read_lowacc(rd.tobytes(), gbytes, ik, ip, g_index)
+        for p in range(na):
+            a0, a1 = int(out["job_aln_off"][r * na + p]), int(out["job_aln_off"][r * na + p + 1])
+            e = exp[p] if p < len(exp) else []
+            assert a1 - a0 == len(e), (r, p, a1 - a0, len(e))
+            for a, s in zip(range(a0, a1), e):
+                assert (out["strand"][a], out["supp"][a], out["n0"][a], out["n1"][a], out["chrom"][a]) == (s["strand"], s["supp"], s["n0"], s["n1"], s["chrom"]), (r, p, a)
+                assert np.float32(out["first_sdp_value"][a]).view(np.uint32) == np.float32(s["value"]).view(np.uint32), (r, p, a)
+                assert out["refine_status"][a] == s["refine_status"] == 0, (r, p, a)
+                b = out["blocks"][int(out["block_off"][a]):int(out["block_off"][a + 1])]
+                assert np.array_equal(b, s["blocks"]), (r, p, a, len(b), len(s["blocks"]))
+                n_seg += 1; n_supp += int(s["supp"]); n_rev += int(s["strand"])
+            n_multi += len(e) > 1
+        if unaligned:
+            assert out["job_aln_off"][r * na + 1] == out["job_aln_off"][r * na], r
+    assert n_seg >= len(reads) - 1 and n_supp >= 2 and n_rev >= 3 and n_multi >= 2, (n_seg, n_supp, n_rev, n_multi)
