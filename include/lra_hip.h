@@ -709,6 +709,7 @@ typedef struct lra_map_result {
   lra_map_counters counters;
 } lra_map_result;
 void lra_map_opts_preset_ont(lra_map_opts* opts);          /* -ONT: lra.cpp:386-431 over Options.h:127-230 */
+void lra_map_opts_preset_clr(lra_map_opts* opts);          /* -CLR: lra.cpp:341-386 */
 int lra_ctx_load_chromosomes(lra_ctx* ctx, const uint64_t* h_chrom_pos, int n_chrom);
 int lra_ctx_build_local_index(lra_ctx* ctx, int k, int w, int window, int max_freq);
 int lra_map_reads_lowacc_batch(lra_ctx* ctx, int n_reads, const char* d_seq, const uint64_t* d_read_off, uint64_t total_bases, const lra_map_opts* opts,

@@ -67,6 +67,7 @@ SYMBOLS = {
                                          C.c_int, _vp, _vp]),
     "lra_local_refine_inputs_batch": (C.c_int, [_vp, C.c_int, _vp, _vp, _vp, _vp]),
     "lra_map_opts_preset_ont": (None, [_vp]),
+    "lra_map_opts_preset_clr": (None, [_vp]),
     "lra_ctx_load_chromosomes": (C.c_int, [_vp, _vp, C.c_int]),
     "lra_ctx_build_local_index": (C.c_int, [_vp, C.c_int, C.c_int, C.c_int, C.c_int]),
     "lra_map_reads_lowacc_batch": (C.c_int, [_vp, C.c_int, _vp, _vp, C.c_uint64, _vp, _vp]),

@@ -91,6 +91,16 @@ extern "C" void lra_map_opts_preset_ont(lra_map_opts* o) {
   o->readType = LRA_READ_ONT; o->hardClip = 1; o->PrintNumAln = 1; o->printFormat = 's';
 }
 
+extern "C" void lra_map_opts_preset_clr(lra_map_opts* o) {
+  if (!o) return;
+  lra_map_opts_preset_ont(o);
+  // -CLR (lra.cpp:341-386): what differs from -ONT on this path
+  o->globalK = 15; o->globalMaxFreq = 250; o->refineBand = 20; o->second_anchorbonus = 6.0f;
+  o->clean.globalK = 15; o->clean.SecondCleanMaxDiag = 120;
+  o->sdp.rate = 15.0f; o->sdp.alnthres = 0.50f; o->sdp.globalK = 15;
+  o->readType = LRA_READ_CLR;
+}
+
 extern "C" int lra_ctx_load_chromosomes(lra_ctx* ctx, const uint64_t* h_chrom_pos, int n_chrom) {
   if (!ctx || !h_chrom_pos || n_chrom < 1) return LRA_ERR_INVALID;
   LRA_HIP_CHECK(ctx, hipSetDevice(ctx->device));

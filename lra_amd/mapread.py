@@ -51,12 +51,23 @@ class LowAccOptions:
     anchorstoosparse: float = 0.005
     splitdist: int = 50000            # Options.h:191
     window: int = 100                 # smallOpts.window (Map_lowacc.h:40)
+    initial_anchorbonus: float = 20.0
     second_anchorbonus: float = 2.0
+    alnthres: float = 0.65
+    SecondCleanMaxDiag: int = 100
     bypassClustering: bool = True
     read_type: str = "ont"
     hardClip: bool = True
     PrintNumAln: int = 1
     printFormat: str = "s"
+
+
+def clr_options(**kw):
+    """The -CLR preset (lra.cpp:341-386): what differs from -ONT on this path."""
+    d = dict(globalK=15, globalMaxFreq=250, refineBand=20, initial_anchorbonus=15.0, second_anchorbonus=6.0, alnthres=0.50, SecondCleanMaxDiag=120,
+             read_type="clr")
+    d.update(kw)
+    return LowAccOptions(**d)
 
 
 def seq_offsets(chrom_pos, window):
@@ -135,10 +146,10 @@ class LowAccMapper:
         self._gli = None
         self.gso = torch.from_numpy(seq_offsets(self.chrom_pos, o.localIndexWindow)).to(dev)
         self.lut = _log_lookup_table()
-        self.sdp_opts = chain.sdp_opts()
-        self.sdp2_opts = chain.sdp_opts(mode=1, rate=o.second_anchorbonus)      # SparseDP :2287 with opts.second_anchorbonus (Options.h:221)
+        self.sdp_opts = chain.sdp_opts(rate=o.initial_anchorbonus, alnthres=o.alnthres, globalK=o.globalK)
+        self.sdp2_opts = chain.sdp_opts(mode=1, rate=o.second_anchorbonus, alnthres=o.alnthres, globalK=o.globalK)   # SparseDP :2287, opts.second_anchorbonus
         self.clean_opts = cluster.CleanOpts(globalK=o.globalK, cleanMaxDiag=200, minDiagCluster=3, bypassClustering=int(o.bypassClustering),
-                                            cleanClustersize=100, SecondCleanMinDiagCluster=10, SecondCleanMaxDiag=100, punish_anchorfreq=5,
+                                            cleanClustersize=100, SecondCleanMinDiagCluster=10, SecondCleanMaxDiag=o.SecondCleanMaxDiag, punish_anchorfreq=5,
                                             anchorPerlength=5)
         self.stats = {}
 
@@ -158,7 +169,8 @@ class LowAccMapper:
                   "localIndel", "refineSpaceDist", "anchorstoosparse", "splitdist", "window", "second_anchorbonus"):
             setattr(m, n, getattr(o, n))
         m.bypassClustering = int(o.bypassClustering)
-        m.clean.globalK = o.globalK; m.clean.bypassClustering = int(o.bypassClustering); m.sdp.globalK = o.globalK
+        m.clean.globalK = o.globalK; m.clean.bypassClustering = int(o.bypassClustering); m.clean.SecondCleanMaxDiag = o.SecondCleanMaxDiag
+        m.sdp.globalK = o.globalK; m.sdp.rate = o.initial_anchorbonus; m.sdp.alnthres = o.alnthres
         m.readType = READ_TYPES[o.read_type]; m.hardClip = int(o.hardClip); m.PrintNumAln = o.PrintNumAln; m.printFormat = ord(o.printFormat)
         return m
 

@@ -7,7 +7,9 @@ import numpy as np
 import oracle_lib as O
 
 ONT = dict(globalK=17, globalW=10, globalMaxFreq=150, localK=10, localW=5, localMaxFreq=15, localIndexWindow=256, refineBand=7, match=4, mismatch=-1,
-           indel=-2, refineSpaceDist=30000, anchorstoosparse=0.005, splitdist=50000, window=100, second_anchorbonus=2.0)
+           indel=-2, refineSpaceDist=30000, anchorstoosparse=0.005, splitdist=50000, window=100, initial_anchorbonus=20.0, second_anchorbonus=2.0,
+           alnthres=0.65, SecondCleanMaxDiag=100)
+CLR = dict(ONT, globalK=15, globalMaxFreq=250, refineBand=20, initial_anchorbonus=15.0, second_anchorbonus=6.0, alnthres=0.50, SecondCleanMaxDiag=120)
 
 _COMP = np.zeros(256, np.uint8)
 for a, b in zip(b"ACGTNacgtn", b"TGCANtgcan"):
@@ -33,7 +35,8 @@ def map_read_lowacc(read: bytes, genome: bytes, idx_key, idx_pos, g_index, opts=
     CH = [0, G]
     L = len(read)
     K = o["globalK"]
-    co = clean_opts or O.CleanOpts(**dict(O.CLEAN_PRESETS["ONT"], globalK=K))
+    co = clean_opts or O.CleanOpts(**dict(O.CLEAN_PRESETS["ONT"], globalK=K, SecondCleanMaxDiag=o["SecondCleanMaxDiag"]))
+    sdp_kw = dict(alnthres=o["alnthres"], globalK=K)
     # a1-a4 (MapRead.h:169-203)
     keys, pos = O.store_minimizers(read, K, o["globalW"])
     sk, sp = O.sort_minimizers(keys, pos)
@@ -52,7 +55,7 @@ def map_read_lowacc(read: bytes, genome: bytes, idx_key, idx_pos, g_index, opts=
         return [], True
     Q = np.concatenate(Q); T = np.concatenate(T); Ln = np.concatenate(Ln)
     # a8: primary chains (Map_lowacc.h:185-188)
-    first = O.sdp_chain(offs, cst, Q, T, Ln, O.sdp_opts(L))
+    first = O.sdp_chain(offs, cst, Q, T, Ln, O.sdp_opts(L, rate=o["initial_anchorbonus"], **sdp_kw))
     if first["status"] < 0 or not first["chains"]:
         return [], True
     offs_a = np.asarray(offs)
@@ -102,7 +105,7 @@ def map_read_lowacc(read: bytes, genome: bytes, idx_key, idx_pos, g_index, opts=
                         if a1 == a0:
                             continue
                         sg = int(em["strand"][g])
-                        e2 = O.sdp_chain([0, a1 - a0], [sg], em["q"][a0:a1], em["t"][a0:a1], em["len"][a0:a1], O.sdp_opts(L, mode=1, rate=o["second_anchorbonus"]))
+                        e2 = O.sdp_chain([0, a1 - a0], [sg], em["q"][a0:a1], em["t"][a0:a1], em["len"][a0:a1], O.sdp_opts(L, mode=1, rate=o["second_anchorbonus"], **sdp_kw))
                         if e2["status"] < 0 or not e2["chains"]:
                             continue
                         ix = e2["chains"][0]["frags"].astype(np.int64)

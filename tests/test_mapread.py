@@ -81,18 +81,21 @@ def test_map_reads_to_sam(ctx):
 
 
 @pytest.mark.gpu
-def test_map_reads_match_oracle_pipeline(ctx, oracle):
+@pytest.mark.parametrize("preset", ["ont", "clr"])
+def test_map_reads_match_oracle_pipeline(ctx, oracle, preset):
     """The C boundary against the oracle's stage functions composed on the CPU (tests/oracle_pipeline.py): every SegAlignment of every
     primary chain -- strand, Supplymentary, NumOfAnchors0/1, FirstSDPValue, the refined blocks -- bit for bit, on plain reads, reads with a
     deletion / an inversion / a translocated half, and a read that cannot align."""
     import oracle_pipeline as OP
     from lra_amd import seed, mapread
     genome = synth.make_genome(500_000, seed=31, repeat_frac=0.25, n_families=3)
-    o = mapread.LowAccOptions()
+    o = mapread.LowAccOptions() if preset == "ont" else mapread.clr_options()
+    oo = OP.ONT if preset == "ont" else OP.CLR
+    err, mix = (0.10, (30, 35, 35)) if preset == "ont" else (0.15, (20, 30, 50))
     ik, ip = synth.build_global_index(genome, o.globalK, o.globalW, 100)
-    reads, truth = synth.simulate_reads(genome, 10, 8000, 2500, 0.10, seed=11)
+    reads, truth = synth.simulate_reads(genome, 10, 8000, 2500, err, mix, seed=11)
     rng = np.random.default_rng(2)
-    sim = lambda a, n, rev=False, err=0.08: synth.simulate_read(rng, genome[a:a + n + 1], n, err, (30, 35, 35), rev)[0]
+    sim = lambda a, n, rev=False: synth.simulate_read(rng, genome[a:a + n + 1], n, err * 0.8, mix, rev)[0]
     reads.append(np.concatenate([sim(50_000, 4000), sim(60_000, 4000)]))                       # 6 kb deletion
     reads.append(np.concatenate([sim(150_000, 4000), sim(154_000, 2500, True), sim(156_500, 4000)]))   # inversion
     reads.append(np.concatenate([sim(250_000, 4500), sim(400_000, 4500, True)]))               # translocation, second half reversed
@@ -107,7 +110,7 @@ def test_map_reads_match_oracle_pipeline(ctx, oracle):
     gbytes = genome.tobytes() + b"\0" * 64
     n_seg = n_supp = n_rev = n_multi = 0
     for r, rd in enumerate(reads):
-        exp, unaligned = OP.map_read_lowacc(rd.tobytes(), gbytes, ik, ip, g_index)
+        exp, unaligned = OP.map_read_lowacc(rd.tobytes(), gbytes, ik, ip, g_index, oo)
         for p in range(na):
             a0, a1 = int(out["job_aln_off"][r * na + p]), int(out["job_aln_off"][r * na + p + 1])
             e = exp[p] if p < len(exp) else []
