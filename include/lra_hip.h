@@ -321,6 +321,10 @@ typedef struct lra_local_index_result {
 } lra_local_index_result;
 int lra_local_index_batch(lra_ctx* ctx, int n_seqs, const char* d_seq, const uint64_t* d_seq_off, int k, int w, int window,
                           int max_freq, lra_local_index_result* out);
+/* The same with sequences switched off: d_active[s] == 0 leaves sequence s's windows in place (the window numbering is unchanged) but empty.
+ * MapRead_lowacc indexes both strands of every read (Map_lowacc.h:249-250) and then only looks up the strands its split chains lie on.       */
+int lra_local_index_masked_batch(lra_ctx* ctx, int n_seqs, const char* d_seq, const uint64_t* d_seq_off, const uint8_t* d_active, int k, int w,
+                                 int window, int max_freq, lra_local_index_result* out);
 typedef struct lra_local_pairs_result {
   uint64_t n_tasks, n_pairs;
   const uint64_t* d_pair_off; const uint32_t* d_pair_qi; const uint32_t* d_pair_ti;

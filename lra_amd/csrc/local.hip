@@ -36,13 +36,15 @@ __device__ __forceinline__ uint32_t code2(unsigned char c) { int v = code_n(c); 
 constexpr int MAXW = 16;
 
 // window -> (sequence, start, length)
+// (sequences masked out keep their windows -- the window numbering is part of the index -- but with length 0: no tuples)
 __global__ void window_map(int n_seqs, const uint64_t* __restrict__ seq_off, int window, const uint64_t* __restrict__ win_off,
-                           uint32_t* __restrict__ w_seq, uint64_t* __restrict__ w_start, uint32_t* __restrict__ w_len) {
+                           const uint8_t* __restrict__ active, uint32_t* __restrict__ w_seq, uint64_t* __restrict__ w_start, uint32_t* __restrict__ w_len) {
   int s = blockIdx.x * blockDim.x + threadIdx.x;
   if (s >= n_seqs) return;
   const uint64_t a = seq_off[s], L = seq_off[s + 1] - a;
+  const bool on = !active || active[s];
   uint64_t wi = win_off[s];
-  for (uint64_t p = 0; p < L; p += window, wi++) { w_seq[wi] = s; w_start[wi] = a + p; w_len[wi] = (uint32_t)std::min<uint64_t>((uint64_t)window, L - p); }
+  for (uint64_t p = 0; p < L; p += window, wi++) { w_seq[wi] = s; w_start[wi] = a + p; w_len[wi] = on ? (uint32_t)std::min<uint64_t>((uint64_t)window, L - p) : 0u; }
 }
 __global__ void window_count(int n_seqs, const uint64_t* __restrict__ seq_off, int window, uint32_t* __restrict__ nwin) {
   int s = blockIdx.x * blockDim.x + threadIdx.x;
@@ -381,6 +383,11 @@ static int d2h8(lra_ctx* ctx, uint64_t* dst, const uint64_t* src) {
 
 extern "C" int lra_local_index_batch(lra_ctx* ctx, int n_seqs, const char* d_seq, const uint64_t* d_seq_off, int k, int w, int window,
                                      int max_freq, lra_local_index_result* out) {
+  return lra_local_index_masked_batch(ctx, n_seqs, d_seq, d_seq_off, nullptr, k, w, window, max_freq, out);
+}
+
+extern "C" int lra_local_index_masked_batch(lra_ctx* ctx, int n_seqs, const char* d_seq, const uint64_t* d_seq_off, const uint8_t* d_active, int k, int w,
+                                            int window, int max_freq, lra_local_index_result* out) {
   if (!ctx || !out || n_seqs < 0) return LRA_ERR_INVALID;
   if (k < 1 || k > 10 || w < 1 || w > MAXW || window < w + k || window > 4096)
     return lra_set_err(ctx, LRA_ERR_INVALID, "need 1<=k<=10 (20-bit LocalTuple), 1<=w<=%d, w+k<=window<=4096", MAXW);
@@ -408,7 +415,7 @@ extern "C" int lra_local_index_batch(lra_ctx* ctx, int n_seqs, const char* d_seq
   const unsigned gw = (unsigned)((n_win + 63) / 64);
   uint64_t n_raw = 0, n_tup = 0;
   if (n_win) {
-    hipLaunchKernelGGL(window_map, dim3((n_seqs + 255) / 256), dim3(256), 0, st, n_seqs, d_seq_off, window, win_off, w_seq, w_start, w_len);
+    hipLaunchKernelGGL(window_map, dim3((n_seqs + 255) / 256), dim3(256), 0, st, n_seqs, d_seq_off, window, win_off, d_active, w_seq, w_start, w_len);
     lra_time_begin(ctx, "local_sketch");
     hipLaunchKernelGGL(local_sketch<false>, dim3(gw), dim3(64), 0, st, n_win, seq, w_start, w_len, k, w, (const uint64_t*)nullptr, (uint32_t*)nullptr, cnt);
     lra_time_end(ctx);

@@ -64,6 +64,15 @@ __global__ void k_aln_address(uint64_t n_jobs, int num_aln, const uint64_t* __re
   }
 }
 
+// which (strand, read) sequences of the forward + reverse-complement buffer Refine_splitchain will look up: those a split chain lies on
+__global__ void k_mark_strands(uint64_t n_slots, int num_aln, int n_reads, const uint32_t* __restrict__ n_split, const uint64_t* __restrict__ chain_start,
+                               const uint8_t* __restrict__ sp_strand, const uint32_t* __restrict__ status, uint8_t* __restrict__ active) {
+  const uint64_t s = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (s >= n_slots || status[s]) return;
+  const uint32_t r = (uint32_t)(s / (uint64_t)num_aln);
+  for (uint32_t k = 0; k < n_split[s]; k++) active[(sp_strand[chain_start[s] + k] ? n_reads : 0) + r] = 1;
+}
+
 // tuple words the local compare stage reads (the algorithmic bytes of local_compare): sum over tasks of both list lengths
 __global__ void k_task_words(uint64_t n, const uint64_t* __restrict__ qlo, const uint64_t* __restrict__ qhi, const uint64_t* __restrict__ tlo,
                              const uint64_t* __restrict__ thi, unsigned long long* sum) {
@@ -193,8 +202,14 @@ extern "C" int lra_map_reads_lowacc_batch(lra_ctx* ctx, int n_reads, const char*
   LRA_HIP_CHECK(ctx, hipMemsetAsync(both + 2 * tot, 0, 64, st));
   if ((rc = lra_create_rc_batch(ctx, n_reads, d_seq, d_read_off, both + tot))) return rc;
   hipLaunchKernelGGL(k_add_off, dim3((n_reads + 256) / 256), dim3(256), 0, st, n_reads, d_read_off, tot, off2);
+  // the reference indexes both strands of every read; only the strands with a split chain are ever looked up, so only those get tuples
+  uint8_t* active = (uint8_t*)lra_ensure(ctx, 65, 2 * (size_t)n_reads + 64);
+  if (!active) return LRA_ERR_NOMEM;
+  LRA_HIP_CHECK(ctx, hipMemsetAsync(active, 0, 2 * (size_t)n_reads, st));
+  hipLaunchKernelGGL(k_mark_strands, dim3((unsigned)((n_slots + 255) / 256)), dim3(256), 0, st, n_slots, num_aln, n_reads, spres.d_n_split, chres.d_chain_start,
+                     spres.d_sp_strand, spres.d_status, active);
   lra_local_index_result rli;
-  if ((rc = lra_local_index_batch(ctx, 2 * n_reads, both, off2, o->localK, o->localW, o->localIndexWindow, o->localMaxFreq, &rli))) return rc;
+  if ((rc = lra_local_index_masked_batch(ctx, 2 * n_reads, both, off2, active, o->localK, o->localW, o->localIndexWindow, o->localMaxFreq, &rli))) return rc;
   lra_rsc_opts ro; ro.window = o->window; ro.smallK = o->localK; ro.K = o->globalK; ro.limitrefine = 1; ro.max_freq = o->localMaxFreq; ro.local_window = o->localIndexWindow;
   lra_refined_result rres;
   if ((rc = lra_refine_splitchain_batch(ctx, &chres, &spres, d_read_off, CH, nCh, &rli, m->n_gwin, m->d_gso, m->gli.d_tuple_bnd, m->gli.d_tuples, &ro, &rres))) return rc;
