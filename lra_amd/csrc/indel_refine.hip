@@ -585,8 +585,12 @@ struct TraceArgs {
 // coordinates in one pass.  The forward parse is: [diag run][one run of left OR of down] -> one
 // block; seen back to front every gap run closes the block whose (possibly empty) diag run precedes
 // it, and a trailing diag run is a block of its own.
+// The walk is a chain of dependent loads; TRACE_LANES < 64 active lanes per wave spread a batch of few, long segments over more waves
+// (more SIMDs busy, fewer distinct cache lines per load instruction).
+constexpr int TRACE_LANES = 16;
 __global__ void __launch_bounds__(64) ir_trace_lane(TraceArgs T) {
-  const uint64_t s = (uint64_t)blockIdx.x * 64 + threadIdx.x;
+  if (threadIdx.x >= TRACE_LANES) return;
+  const uint64_t s = (uint64_t)blockIdx.x * TRACE_LANES + threadIdx.x;
   if (s >= T.n_seg) return;
   if (T.s_kind[s] != 0) return;
   if (T.s_status[s] != 0) { T.s_nblk[s] = 0; return; }
@@ -915,7 +919,7 @@ extern "C" int lra_indel_refine_batch(lra_ctx* ctx, int n_aln, const int32_t* d_
     T.s_cells = s_cells; T.s_cell_off = s_cell_off; T.s_status = s_status; T.rows = rows; T.path = path;
     T.s_nblk = s_nblk; T.s_tmp_off = s_tmp_off; T.tmp_blocks = tmpb;
     lra_time_begin(ctx, "ir_trace");
-    hipLaunchKernelGGL(ir_trace_lane, dim3(gridL), dim3(64), 0, st, T);
+    hipLaunchKernelGGL(ir_trace_lane, dim3((unsigned)((n_seg + TRACE_LANES - 1) / TRACE_LANES)), dim3(64), 0, st, T);
     lra_time_end(ctx);
     // ---- short segments -> AffineOneGapAlign (:344-357)
     if (n_aog) {
