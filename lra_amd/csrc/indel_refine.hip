@@ -419,22 +419,32 @@ __global__ void __launch_bounds__(64) ir_band_scan(BandArgs B) {
   }
 }
 
-// width classes for ir_fill: 16 / 32 / 64 lanes per segment
+// Work lists of ir_fill: width class (16 / 32 / 64 lanes per segment by the segment's widest row) x length bucket (log2 of the row
+// count, longest first), so that the lane groups of a wave sweep segments of similar length and the long ones start first.  Bin =
+// class * 32 + (31 - log2 rows).  EMIT = false counts the bins, EMIT = true places the segments (cursor = bin start offsets).
+constexpr int FILL_BINS = 96;
+template <bool EMIT>
 __global__ void ir_classify(uint64_t n_seg, const int32_t* __restrict__ s_kind, const int32_t* __restrict__ s_status, const int32_t* __restrict__ s_width,
-                            int* counts, uint32_t* lists) {
+                            const uint64_t* __restrict__ s_rows, int* bins, uint32_t* list) {
   const uint64_t s = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
   const int lane = threadIdx.x & 63;
-  int cls = -1;
-  if (s < n_seg && s_kind[s] == 0 && s_status[s] == 0) { int w = s_width[s]; cls = w <= 16 ? 0 : w <= 32 ? 1 : 2; }
+  int bin = -1;
+  if (s < n_seg && s_kind[s] == 0 && s_status[s] == 0) {
+    const int w = s_width[s];
+    const uint32_t r = (uint32_t)min((unsigned long long)s_rows[s], 0x7fffffffULL);
+    bin = (w <= 16 ? 0 : w <= 32 ? 1 : 2) * 32 + (r ? __clz(r) : 31);
+  }
   const unsigned long long below = (lane == 0) ? 0ULL : (~0ULL >> (64 - lane));
-  for (int c = 0; c < 3; c++) {
-    const unsigned long long m = __ballot(cls == c);
-    if (!m) continue;
+  unsigned long long todo = __ballot(bin >= 0);
+  while (todo) {
+    const int leader = __ffsll((long long)todo) - 1;
+    const int b = __shfl(bin, leader);
+    const unsigned long long m = __ballot(bin == b);
     int base = 0;
-    const int leader = __ffsll((long long)m) - 1;
-    if (lane == leader) base = atomicAdd(&counts[c], __popcll(m));
+    if (lane == leader) base = atomicAdd(&bins[b], __popcll(m));
     base = __shfl(base, leader);
-    if (cls == c) lists[(uint64_t)c * n_seg + base + __popcll(m & below)] = (uint32_t)s;
+    if (EMIT && bin == b) list[base + __popcll(m & below)] = (uint32_t)s;
+    todo &= ~m;
   }
 }
 
@@ -446,7 +456,7 @@ struct FillArgs {
   const char* qseq; const uint64_t* q_off; const int32_t* q_len;
   int match, mismatch, g;
   unsigned char* path;
-  const int* counts; const uint32_t* lists;
+  const uint32_t* list; int* cursor;      // work list (class-major, long segments first); cursor[cls] = next entry, class cls ends at cursor[4 + cls]
 };
 
 __device__ __forceinline__ bool is_bound(long row, int c, int len) { return c == len - 1 || (row > 0 && c == 0); }
@@ -478,10 +488,8 @@ __global__ void __launch_bounds__(64) ir_fill(FillArgs F) {
   const int lane = threadIdx.x;
   const int c = lane % G, gbase = lane - c;
   const int g = F.g, go = 2 * F.g + 1;
-  const long count = F.counts[CLS];
-  const uint32_t* list = F.lists + (uint64_t)CLS * F.n_seg;
-  const long stride = (long)gridDim.x * GP;
-  long x = (long)blockIdx.x * GP + lane / G;
+  const long listEnd = F.cursor[4 + CLS];
+  const uint32_t* list = F.list;
   // per-group state (identical on the G lanes of a group)
   long ti = -1, tLen = 0;
   const Row* rows = nullptr; const unsigned char* qb = nullptr; unsigned char* P = nullptr;
@@ -493,9 +501,11 @@ __global__ void __launch_bounds__(64) ir_fill(FillArgs F) {
   auto ldq = [&](long idx) -> int { return qb[idx < qLast ? idx : qLast]; };   // past the read: its last base (the reference reads out of range there)
   while (true) {
     if (!done && ti < 0) {
-      if (x < count) {
+      long x = 0;
+      if (c == 0) x = atomicAdd(&F.cursor[CLS], 1);                       // the group's next segment: whichever is next in the list
+      x = __shfl(x, gbase);
+      if (x < listEnd) {
         const uint64_t s = list[x];
-        x += stride;
         const int a = F.s_aln[s];
         tLen = (long)F.s_rows[s];
         rows = F.rows + F.s_row_off[s];
@@ -806,7 +816,7 @@ extern "C" int lra_indel_refine_batch(lra_ctx* ctx, int n_aln, const int32_t* d_
   add(3 * capSeg, 4); add(capSeg, 4); add(capSeg, 8); add(capSeg, 4);
   add(capSeg + 1, 8); add(capSeg + 1, 8); add(capSeg, 8); add(capSeg + 1, 8); add(capSeg, 4);
   add(capSeg, 4); add(capSeg, 4); add(capSeg, 8); add(capSeg + 1, 8); add(capSeg, 4); add(capSeg + 1, 8);
-  add(3 * capSeg, 4); add(16, 4);
+  add(3 * capSeg, 4); add(FILL_BINS + 16, 4);
   add(capItem, 4); add(3 * capItem, 4); add(capItem, 4); add(capItem, 4); add(capItem + 1, 8);
   add(capSeg, 8); add(capSeg, 4); add(capSeg, 8); add(capSeg, 4); add(capSeg, 4); add(capSeg, 4); add(capSeg + 1, 8);
   add(capSeg, 4); add(capSeg, 4); add(capSeg, 4);
@@ -830,7 +840,7 @@ extern "C" int lra_indel_refine_batch(lra_ctx* ctx, int n_aln, const int32_t* d_
   uint64_t* s_cells = ar.get<uint64_t>(capSeg); uint64_t* s_cell_off = ar.get<uint64_t>(capSeg + 1); int32_t* s_status = ar.get<int32_t>(capSeg);
   uint32_t* s_nblk = ar.get<uint32_t>(capSeg); int32_t* s_width = ar.get<int32_t>(capSeg); uint64_t* s_tmpcap = ar.get<uint64_t>(capSeg);
   uint64_t* s_tmp_off = ar.get<uint64_t>(capSeg + 1); uint32_t* s_aog_idx = ar.get<uint32_t>(capSeg); uint64_t* s_out_off = ar.get<uint64_t>(capSeg + 1);
-  uint32_t* fill_lists = ar.get<uint32_t>(3 * capSeg); int* fill_counts = ar.get<int>(16);
+  uint32_t* fill_lists = ar.get<uint32_t>(3 * capSeg); int* fill_counts = ar.get<int>(FILL_BINS + 16);
   A.i_kind = ar.get<int32_t>(capItem); A.i_data = ar.get<int32_t>(3 * capItem);
   int32_t* i_aln = ar.get<int32_t>(capItem); uint32_t* i_count = ar.get<uint32_t>(capItem); uint64_t* i_out_off = ar.get<uint64_t>(capItem + 1);
   uint64_t* p_q_off = ar.get<uint64_t>(capSeg); int32_t* p_q_len = ar.get<int32_t>(capSeg); uint64_t* p_t_off = ar.get<uint64_t>(capSeg);
@@ -896,23 +906,30 @@ extern "C" int lra_indel_refine_batch(lra_ctx* ctx, int n_aln, const int32_t* d_
     int32_t* tmpb = (int32_t*)lra_ensure(ctx, 2, (n_tmp + 1) * 12);
     if (!path || !tmpb) return LRA_ERR_NOMEM;
     tmp_blocks = tmpb;
-    LRA_HIP_CHECK(ctx, hipMemsetAsync(fill_counts, 0, 64, st));
-    hipLaunchKernelGGL(ir_classify, dim3((unsigned)((n_seg + 255) / 256)), dim3(256), 0, st, n_seg, A.s_kind, s_status, s_width, fill_counts, fill_lists);
+    int h_bins[FILL_BINS], h_start[FILL_BINS], h_cursor[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    LRA_HIP_CHECK(ctx, hipMemsetAsync(fill_counts, 0, FILL_BINS * 4, st));
+    hipLaunchKernelGGL(ir_classify<false>, dim3((unsigned)((n_seg + 255) / 256)), dim3(256), 0, st, n_seg, A.s_kind, s_status, s_width, A.s_rows, fill_counts, fill_lists);
+    if (d2h(ctx, h_bins, fill_counts, FILL_BINS * 4)) return LRA_ERR_HIP;
+    { int run = 0; for (int b = 0; b < FILL_BINS; b++) { h_start[b] = run; run += h_bins[b]; if ((b & 31) == 0) h_cursor[b / 32] = h_start[b]; if ((b & 31) == 31) h_cursor[4 + b / 32] = run; } }
+    LRA_HIP_CHECK(ctx, hipMemcpyAsync(fill_counts, h_start, FILL_BINS * 4, hipMemcpyHostToDevice, st));
+    hipLaunchKernelGGL(ir_classify<true>, dim3((unsigned)((n_seg + 255) / 256)), dim3(256), 0, st, n_seg, A.s_kind, s_status, s_width, A.s_rows, fill_counts, fill_lists);
+    int* fill_cursor = fill_counts + FILL_BINS;
+    LRA_HIP_CHECK(ctx, hipMemcpyAsync(fill_cursor, h_cursor, 32, hipMemcpyHostToDevice, st));
     FillArgs F;
     F.n_seg = n_seg; F.s_aln = A.s_aln; F.s_rows = A.s_rows; F.s_row_off = s_row_off; F.s_cell_off = s_cell_off; F.rows = rows;
     F.qseq = d_qseq; F.q_off = d_q_off; F.q_len = d_q_len; F.match = match; F.mismatch = mismatch; F.g = indel; F.path = path;
-    F.counts = fill_counts; F.lists = fill_lists;
+    F.list = fill_lists; F.cursor = fill_cursor;
     const unsigned cap_grid = (unsigned)ctx->num_cu * 32;
     if (getenv("LRA_IR_DBG")) {
-      int hc[3] = {0, 0, 0};
-      if (d2h(ctx, hc, fill_counts, 12)) return LRA_ERR_HIP;
+      const int hc[3] = {h_cursor[4] - h_cursor[0], h_cursor[5] - h_cursor[1], h_cursor[6] - h_cursor[2]};
       fprintf(stderr, "[ir] n_seg %llu n_rows %llu n_cells %llu n_task %llu fill classes 16/32/64: %d %d %d\n", (unsigned long long)n_seg,
               (unsigned long long)n_rows, (unsigned long long)n_cells, (unsigned long long)n_task, hc[0], hc[1], hc[2]);
     }
     lra_time_begin(ctx, "ir_fill");
-    hipLaunchKernelGGL(ir_fill<16>, dim3((unsigned)std::min<uint64_t>((n_seg + 3) / 4, cap_grid)), dim3(64), 0, st, F);
-    hipLaunchKernelGGL(ir_fill<32>, dim3((unsigned)std::min<uint64_t>((n_seg + 1) / 2, cap_grid)), dim3(64), 0, st, F);
-    hipLaunchKernelGGL(ir_fill<64>, dim3((unsigned)std::min<uint64_t>(n_seg, cap_grid)), dim3(64), 0, st, F);
+    const uint64_t n16 = (uint64_t)(h_cursor[4] - h_cursor[0]), n32 = (uint64_t)(h_cursor[5] - h_cursor[1]), n64 = (uint64_t)(h_cursor[6] - h_cursor[2]);
+    if (n16) hipLaunchKernelGGL(ir_fill<16>, dim3((unsigned)std::min<uint64_t>((n16 + 3) / 4, cap_grid)), dim3(64), 0, st, F);
+    if (n32) hipLaunchKernelGGL(ir_fill<32>, dim3((unsigned)std::min<uint64_t>((n32 + 1) / 2, cap_grid)), dim3(64), 0, st, F);
+    if (n64) hipLaunchKernelGGL(ir_fill<64>, dim3((unsigned)std::min<uint64_t>(n64, cap_grid)), dim3(64), 0, st, F);
     lra_time_end(ctx);
     TraceArgs T;
     T.n_seg = n_seg; T.s_kind = A.s_kind; T.s_tStart = A.s_tStart; T.s_rows = A.s_rows; T.s_row_off = s_row_off;
