@@ -133,8 +133,8 @@ __global__ void __launch_bounds__(64) rs_sketch(RsArgs a, int nLarge) {
   uint32_t n = 0;
   const uint64_t o = EMIT ? a.loff[l] : 0;
   auto emit = [&](uint64_t t, uint32_t p) { if (EMIT && lane == 0) { a.lkey[o + n] = t; a.lpos[o + n] = p; } n++; };
-  auto done = [&]() { if (!EMIT && lane == 0) a.lcnt[l] = n; };
-  if (w > MAX_W || w < 1 || k < 1 || k > 31) { if (!EMIT && lane == 0) { a.lcnt[l] = 0; atomicOr(&a.status[i], (uint32_t)LRA_ST_RANGE); } return; }
+  auto done = [&]() { if (lane == 0) a.lcnt[l] = n; };
+  if (w > MAX_W || w < 1 || k < 1 || k > 31) { if (lane == 0) { a.lcnt[l] = 0; atomicOr(&a.status[i], (uint32_t)LRA_ST_RANGE); } return; }
   if (seqLen < (uint32_t)k) { done(); return; }
   const int span = w + k - 1;
   if (seqLen < (uint32_t)span) { done(); return; }
@@ -185,6 +185,24 @@ __global__ void __launch_bounds__(64) rs_sketch(RsArgs a, int nLarge) {
     }
   }
   done();
+}
+
+// capacity of list l in the single-pass sketch: every k-mer position could be emitted
+__global__ void rs_caps(RsArgs a, int nLarge, uint32_t* cap) {
+  const int l = blockIdx.x * blockDim.x + threadIdx.x;
+  if (l >= 2 * nLarge) return;
+  const uint32_t i = a.largeIdx[l >> 1];
+  const long len = (l & 1) ? a.q_len[i] : a.t_len[i];
+  const long k = a.K[i];
+  cap[l] = (uint32_t)(len >= k && k >= 1 ? len - k + 1 : 0);
+}
+// one wave per list: raw (capacity-spaced) tuples -> the CSR lists
+__global__ void __launch_bounds__(64) rs_compact(int nLists, const uint64_t* __restrict__ capOff, const uint64_t* __restrict__ loff, const uint64_t* __restrict__ rk,
+                                                  const uint32_t* __restrict__ rp, uint64_t* __restrict__ lkey, uint32_t* __restrict__ lpos) {
+  const int l = blockIdx.x;
+  if (l >= nLists) return;
+  const uint64_t s = capOff[l], d = loff[l], n = loff[l + 1] - d;
+  for (uint64_t x = threadIdx.x; x < n; x += 64) { lkey[d + x] = rk[s + x]; lpos[d + x] = rp[s + x]; }
 }
 
 // long gaps: CompareLists<GenomeTuple,Tuple>(query, target, ..., Global = false, maxDiagNum, minDiagNum, canonical = false)  CompareLists.h:9-146
@@ -287,7 +305,7 @@ static int refine_space_impl(lra_ctx* ctx, int n, const char* d_qseq, const uint
   hipStream_t st = ctx->stream;
   const size_t n1 = (size_t)n + 2;
   auto take = [](char*& p, size_t cnt, size_t e) { char* r = p; p += sz(cnt, e); return r; };
-  size_t needW = sz(n1, 4) * 8 + sz(n1, 8) * 6 + sz(2 * n1, 4) + sz(2 * n1 + 2, 8) + 4096;
+  size_t needW = sz(n1, 4) * 8 + sz(n1, 8) * 6 + 2 * (sz(2 * n1, 4) + sz(2 * n1 + 2, 8)) + 4096;
   char* w = (char*)lra_ensure(ctx, 14, needW);
   if (!w) return LRA_ERR_NOMEM;
   RsArgs a;
@@ -341,8 +359,19 @@ static int refine_space_impl(lra_ctx* ctx, int n, const char* d_qseq, const uint
   }
   // ---- long gaps
   if (nLarge > 0) {
+    // one serial pass per list into capacity-spaced slots (a list cannot hold more tuples than k-mer positions), then a parallel compaction
+    uint32_t* lcap = (uint32_t*)take(w, 2 * n1, 4); uint64_t* capOff = (uint64_t*)take(w, 2 * n1 + 2, 8);
+    hipLaunchKernelGGL(rs_caps, dim3((2 * nLarge + 255) / 256), dim3(256), 0, st, a, nLarge, lcap);
+    { int rc = lra_exclusive_scan<uint32_t>(ctx, 2 * nLarge, lcap, capOff); if (rc) return rc; }
+    uint64_t totalCap = 0;
+    LRA_HIP_CHECK(ctx, hipMemcpyAsync(&totalCap, capOff + 2 * nLarge, 8, hipMemcpyDeviceToHost, st));
+    LRA_HIP_CHECK(ctx, hipStreamSynchronize(st));
+    char* wr = (char*)lra_ensure(ctx, 66, sz(totalCap + 1, 8) + sz(totalCap + 1, 4) + 4096);
+    if (!wr) return LRA_ERR_NOMEM;
+    uint64_t* rawKey = (uint64_t*)take(wr, totalCap + 1, 8); uint32_t* rawPos = (uint32_t*)take(wr, totalCap + 1, 4);
+    a.lkey = rawKey; a.lpos = rawPos; a.loff = capOff;
     lra_time_begin(ctx, "rs_long_sketch");
-    hipLaunchKernelGGL(rs_sketch<false>, dim3(2 * nLarge), dim3(64), 0, st, a, nLarge);
+    hipLaunchKernelGGL(rs_sketch<true>, dim3(2 * nLarge), dim3(64), 0, st, a, nLarge);
     lra_time_end(ctx);
     { int rc = lra_exclusive_scan<uint32_t>(ctx, 2 * nLarge, a.lcnt, loff); if (rc) return rc; }
     uint64_t totalMm = 0;
@@ -352,9 +381,7 @@ static int refine_space_impl(lra_ctx* ctx, int n, const char* d_qseq, const uint
     char* wl = (char*)lra_ensure(ctx, 17, sz(totalMm + 1, 8) + sz(totalMm + 1, 4) + 4096);
     if (!wl) return LRA_ERR_NOMEM;
     a.lkey = (uint64_t*)take(wl, totalMm + 1, 8); a.lpos = (uint32_t*)take(wl, totalMm + 1, 4); a.loff = loff;
-    lra_time_begin(ctx, "rs_long_sketch");
-    hipLaunchKernelGGL(rs_sketch<true>, dim3(2 * nLarge), dim3(64), 0, st, a, nLarge);
-    lra_time_end(ctx);
+    hipLaunchKernelGGL(rs_compact, dim3(2 * nLarge), dim3(64), 0, st, 2 * nLarge, capOff, loff, rawKey, rawPos, a.lkey, a.lpos);
     { int rc = lra_sort_minimizers_batch(ctx, 2 * nLarge, loff, a.lkey, a.lpos); if (rc) return rc; }   // sort(EndGenomeTup), sort(EndReadTup)  :306,:308
     lra_time_begin(ctx, "rs_long_compare");
     hipLaunchKernelGGL(rs_compare<false>, dim3(nLarge), dim3(64), 0, st, a, nLarge);
