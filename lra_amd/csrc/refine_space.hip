@@ -40,6 +40,7 @@ struct RsArgs {
   const int32_t* nblocks; const int32_t* blocks; const int32_t* aogStatus;
   // large branch: lists 2*j (target), 2*j+1 (query) of large problem j
   uint32_t* lcnt; const uint64_t* loff; uint64_t* lkey; uint32_t* lpos;
+  int4* rects; uint32_t* nrect;              // the (target run x query run) rectangles the list walk emits, per large problem
   // output
   uint32_t* cnt; const uint64_t* pair_off; uint32_t* outQ; uint32_t* outT; float* identity; uint32_t* status;
 };
@@ -207,9 +208,22 @@ __global__ void __launch_bounds__(64) rs_compact(int nLists, const uint64_t* __r
 
 // long gaps: CompareLists<GenomeTuple,Tuple>(query, target, ..., Global = false, maxDiagNum, minDiagNum, canonical = false)  CompareLists.h:9-146
 // One WAVE per gap, the walk on uniform values as in rs_sketch; the two sorted key lists are staged in LDS (when they fit) so that the
-// searches and run scans of the walk never wait on HBM.  Lane 0 writes the pairs.
+// searches and run scans of the walk never wait on HBM.  The walk runs once: every emission of the reference is a rectangle (a run of
+// equal target keys x a run of equal query keys, target-major); the walk records the rectangle and counts its cells that pass the
+// diagonal band with all lanes, rs_emit then writes the pairs of all rectangles in the same order.
 constexpr int CMP_LDS_KEYS = 7168;                                        // 56 KB of keys per workgroup
-template <bool EMIT>
+struct RsBand { long long minDiag, maxDiag; };
+__device__ __forceinline__ RsBand rs_band(const RsArgs& a, uint32_t i) {
+  const long long diag2 = (long long)a.t_span[i] - (long long)(uint32_t)a.q_len[i];
+  return RsBand{min(0LL, diag2) - a.diag[i], max(0LL, diag2) + a.diag[i]};
+}
+__device__ __forceinline__ bool rs_pass(const RsBand& bd, const uint32_t* tp, const uint32_t* qp, long qi, long ti) {
+  if (bd.maxDiag != 0 && bd.minDiag != 0) {                              // :87
+    const long long d = (long long)tp[ti] - (long long)qp[qi];
+    if (!(d <= bd.maxDiag && d >= bd.minDiag)) return false;
+  }
+  return true;
+}
 __global__ void __launch_bounds__(64) rs_compare(RsArgs a, int nLarge) {
   __shared__ uint64_t skeys[CMP_LDS_KEYS];
   const int j = blockIdx.x, lane = threadIdx.x;
@@ -223,20 +237,20 @@ __global__ void __launch_bounds__(64) rs_compare(RsArgs a, int nLarge) {
     rs_wave_sync();
     tk = skeys; qk = skeys + nt;
   }
-  const long long diag2 = (long long)a.t_span[i] - (long long)(uint32_t)a.q_len[i];
-  const long long minDiag = min(0LL, diag2) - a.diag[i], maxDiag = max(0LL, diag2) + a.diag[i];
+  const RsBand bd = rs_band(a, i);
   const long maxFreq = a.maxFreqArr ? (long)a.maxFreqArr[i] : a.maxFreq;
-  const int K = a.K[i];
-  const uint32_t qAdd = a.q_add[i], tAdd = a.t_add[i], flip = a.flip[i];
-  uint32_t n = 0;
-  const uint64_t o = EMIT ? a.pair_off[i] : 0;
-  auto emit = [&](long qi, long ti) {
-    if (maxDiag != 0 && minDiag != 0) {                                  // :87
-      const long long d = (long long)tp[ti] - (long long)qp[qi];
-      if (!(d <= maxDiag && d >= minDiag)) return;
-    }
-    if (EMIT && lane == 0) { uint32_t pq = qp[qi] + qAdd; if (flip) pq = flip - pq - (uint32_t)K; a.outQ[o + n] = pq; a.outT[o + n] = tp[ti] + tAdd; }
-    n++;
+  int4* rects = a.rects + a.loff[2 * j] + 2 * (uint64_t)j;               // nt + nq + 2 slots: every iteration of the walk emits at most one
+  const long rcap = nt + nq + 2;
+  uint32_t n = 0, nrect = 0;
+  auto rect = [&](long t0, long t1, long q0, long q1) {                   // ti in [t0, t1), qi in [q0, q1]
+    if (nrect < rcap) { if (lane == 0) rects[nrect] = make_int4((int)t0, (int)t1, (int)q0, (int)q1); }
+    else if (lane == 0) atomicOr(&a.status[i], (uint32_t)LRA_ST_CAPACITY);
+    nrect++;
+    const long w = q1 - q0 + 1, cells = (t1 - t0) * w;
+    uint32_t c = 0;
+    for (long x = lane; x < cells; x += 64) c += rs_pass(bd, tp, qp, q0 + x % w, t0 + x / w) ? 1u : 0u;
+    for (int o = 32; o > 0; o >>= 1) c += __shfl_xor(c, o);
+    n += c;
   };
 #define Qk(x) (qk[x] & FOR_MASK)
 #define Tk(x) (tk[x] & FOR_MASK)
@@ -258,9 +272,7 @@ __global__ void __launch_bounds__(64) rs_compare(RsArgs a, int nLarge) {
           while (tsi != te && Qk(qs) == Tk(tsi)) tsi++;
           const long qsStart = qs;
           while (qs < qe && Qk(qs + 1) == Qk(qs)) qs++;
-          for (long ti = tsStart; ti != tsi; ti++)
-            if (qs - qsStart < maxFreq)
-              for (long qi = qsStart; qi <= qs; qi++) emit(qi, ti);
+          if (qs - qsStart < maxFreq && tsi > tsStart) rect(tsStart, tsi, qsStart, qs);   // for ti .. if (..) for qi .. emit(qi, ti)
         }
         while (ts < te && tk[ts] == tk[tsOrig]) ts++;                    // :101 raw compare
         while (qs < qe && qk[qs] == qk[qsOrig]) qs++;                    // :102
@@ -276,9 +288,7 @@ __global__ void __launch_bounds__(64) rs_compare(RsArgs a, int nLarge) {
         if (tei < teStart && teStart > 0) {
           const long qeStart = qe;
           while (qe > qs && Qk(qe) == Qk(qe - 1)) qe--;
-          for (long ti = tei; ti < teStart; ti++)
-            if (qeStart - qe < maxFreq)
-              for (long qi = qe; qi <= qeStart; qi++) emit(qi, ti);
+          if (qeStart - qe < maxFreq) rect(tei, teStart, qe, qeStart);
         }
         te = tei;
       }
@@ -286,7 +296,40 @@ __global__ void __launch_bounds__(64) rs_compare(RsArgs a, int nLarge) {
   }
 #undef Qk
 #undef Tk
-  if (!EMIT && lane == 0) a.cnt[i] = n;
+  if (lane == 0) { a.cnt[i] = n; a.nrect[j] = nrect < rcap ? nrect : (uint32_t)rcap; }
+}
+
+// the pairs of the recorded rectangles, in the reference's order (rectangle by rectangle, target-major)
+__global__ void __launch_bounds__(64) rs_emit(RsArgs a, int nLarge) {
+  const int j = blockIdx.x, lane = threadIdx.x;
+  if (j >= nLarge) return;
+  const uint32_t i = a.largeIdx[j];
+  const uint32_t* tp = a.lpos + a.loff[2 * j]; const uint32_t* qp = a.lpos + a.loff[2 * j + 1];
+  const RsBand bd = rs_band(a, i);
+  const int K = a.K[i];
+  const uint32_t qAdd = a.q_add[i], tAdd = a.t_add[i], flip = a.flip[i];
+  const int4* rects = a.rects + a.loff[2 * j] + 2 * (uint64_t)j;
+  const uint32_t nrect = a.nrect[j];
+  const uint64_t o = a.pair_off[i];
+  const unsigned long long below = (lane == 0) ? 0ULL : (~0ULL >> (64 - lane));
+  uint32_t n = 0;
+  for (uint32_t r = 0; r < nrect; r++) {
+    const int4 R = rects[r];
+    const long w = (long)R.w - R.z + 1, cells = ((long)R.y - R.x) * w;
+    for (long base = 0; base < cells; base += 64) {
+      const long x = base + lane;
+      const long qi = R.z + x % w, ti = R.x + x / w;
+      const bool ok = x < cells && rs_pass(bd, tp, qp, qi, ti);
+      const unsigned long long m = __ballot(ok);
+      if (ok) {
+        uint32_t pq = qp[qi] + qAdd;
+        if (flip) pq = flip - pq - (uint32_t)K;
+        const uint64_t at = o + n + __popcll(m & below);
+        a.outQ[at] = pq; a.outT[at] = tp[ti] + tAdd;
+      }
+      n += (uint32_t)__popcll(m);
+    }
+  }
 }
 
 inline size_t sz(size_t n, size_t e) { return (n * e + 255) / 256 * 256; }
@@ -378,13 +421,14 @@ static int refine_space_impl(lra_ctx* ctx, int n, const char* d_qseq, const uint
     LRA_HIP_CHECK(ctx, hipMemcpyAsync(&totalMm, loff + 2 * nLarge, 8, hipMemcpyDeviceToHost, st));
     LRA_HIP_CHECK(ctx, hipStreamSynchronize(st));
     if (getenv("LRA_RS_DBG")) fprintf(stderr, "[rs] n %d nLarge %d minimizers %llu\n", n, nLarge, (unsigned long long)totalMm);
-    char* wl = (char*)lra_ensure(ctx, 17, sz(totalMm + 1, 8) + sz(totalMm + 1, 4) + 4096);
+    char* wl = (char*)lra_ensure(ctx, 17, sz(totalMm + 1, 8) + sz(totalMm + 1, 4) + sz(totalMm + 2 * (size_t)nLarge + 4, 16) + sz((size_t)nLarge + 1, 4) + 4096);
     if (!wl) return LRA_ERR_NOMEM;
     a.lkey = (uint64_t*)take(wl, totalMm + 1, 8); a.lpos = (uint32_t*)take(wl, totalMm + 1, 4); a.loff = loff;
+    a.rects = (int4*)take(wl, totalMm + 2 * (size_t)nLarge + 4, 16); a.nrect = (uint32_t*)take(wl, (size_t)nLarge + 1, 4);
     hipLaunchKernelGGL(rs_compact, dim3(2 * nLarge), dim3(64), 0, st, 2 * nLarge, capOff, loff, rawKey, rawPos, a.lkey, a.lpos);
     { int rc = lra_sort_minimizers_batch(ctx, 2 * nLarge, loff, a.lkey, a.lpos); if (rc) return rc; }   // sort(EndGenomeTup), sort(EndReadTup)  :306,:308
     lra_time_begin(ctx, "rs_long_compare");
-    hipLaunchKernelGGL(rs_compare<false>, dim3(nLarge), dim3(64), 0, st, a, nLarge);
+    hipLaunchKernelGGL(rs_compare, dim3(nLarge), dim3(64), 0, st, a, nLarge);
     lra_time_end(ctx);
   }
   // ---- pairs
@@ -402,7 +446,7 @@ static int refine_space_impl(lra_ctx* ctx, int n, const char* d_qseq, const uint
   lra_time_end(ctx);
   if (nLarge > 0) {
     lra_time_begin(ctx, "rs_long_compare");
-    hipLaunchKernelGGL(rs_compare<true>, dim3(nLarge), dim3(64), 0, st, a, nLarge);
+    hipLaunchKernelGGL(rs_emit, dim3(nLarge), dim3(64), 0, st, a, nLarge);
     lra_time_end(ctx);
   }
   LRA_HIP_CHECK(ctx, hipStreamSynchronize(st));
