@@ -59,10 +59,12 @@ __global__ void window_count(int n_seqs, const uint64_t* __restrict__ seq_off, i
 // HBM (the unstaged version fetched ~40x the sequence bytes because 64 private streams thrash L1).
 constexpr int WMAX = 256;            // staged window length; longer windows read from HBM directly
 constexpr int WSTRIDE = WMAX + 4;
-template <bool EMIT>
+// One pass: window wi writes its tuples at raw + wi * stride (stride = window - k + 1 slots: a window cannot emit more tuples than it has
+// k-mer positions) and its count; the sort / filter and the compaction read the slab through (wi * stride, counts[wi]).
 __global__ void __launch_bounds__(64) local_sketch(uint64_t n_win, const unsigned char* __restrict__ seq_all, const uint64_t* __restrict__ w_start,
-                                                   const uint32_t* __restrict__ w_len, int k, int w, const uint64_t* __restrict__ raw_off,
+                                                   const uint32_t* __restrict__ w_len, int k, int w, uint64_t stride,
                                                    uint32_t* __restrict__ raw, uint32_t* __restrict__ counts) {
+  constexpr bool EMIT = true;
   __shared__ uint32_t ringT[MAXW * 64], ringP[MAXW * 64];
   __shared__ unsigned char stage[64 * WSTRIDE];
   const int lane = threadIdx.x;
@@ -86,10 +88,10 @@ __global__ void __launch_bounds__(64) local_sketch(uint64_t n_win, const unsigne
   const unsigned char* gseq = seq_all + w_start[wi];
   const unsigned char* lseq = stage + lane * WSTRIDE;
   auto SEQ = [&](uint32_t p) -> unsigned char { return staged ? lseq[p] : gseq[p]; };
-  uint32_t* out = EMIT ? raw + raw_off[wi] : nullptr;
+  uint32_t* out = raw + wi * stride;
   uint32_t n = 0;
 #define LS_EMIT(T__, P__) do { if (EMIT) out[n] = ((T__) & TMASK) | (((P__) & 0xFFFu) << 20); n++; } while (0)
-#define LS_DONE() do { if (!EMIT) counts[wi] = n; return; } while (0)
+#define LS_DONE() do { counts[wi] = n; return; } while (0)
   const int span = w + k - 1;
   if (seqLen < (uint32_t)k || seqLen < (uint32_t)span) LS_DONE();        // :186,:199
   const uint32_t kmask = (k >= 16) ? 0xFFFFFFFFu : ((1u << (2 * k)) - 1);
@@ -223,13 +225,13 @@ __device__ void w_std_sort(uint32_t* v, long n) {
 constexpr int LCAP = 160;
 constexpr int LSTRIDE = LCAP + 1;
 constexpr int STAGE_NT = 256;                                           // 4 waves stage a block's 64 lists (memory parallelism), wave 0 works on them
-__global__ void __launch_bounds__(STAGE_NT) local_sort_filter(uint64_t n_win, const uint64_t* __restrict__ raw_off, uint32_t* raw, int maxFreq, uint32_t* __restrict__ counts) {
+__global__ void __launch_bounds__(STAGE_NT) local_sort_filter(uint64_t n_win, uint64_t stride, uint32_t* raw, int maxFreq, uint32_t* counts) {
   __shared__ uint32_t stage[64 * LSTRIDE];
   __shared__ uint32_t kept[64];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const uint64_t w0 = (uint64_t)blockIdx.x * 64;
   const uint64_t wi = w0 + lane;
-  const uint64_t myA = wi < n_win ? raw_off[wi] : 0, myN = wi < n_win ? raw_off[wi + 1] - myA : 0;
+  const uint64_t myA = wi * stride, myN = wi < n_win ? counts[wi] : 0;       // raw count in, filtered count out
 #pragma unroll 4
   for (int x = wave; x < 64; x += STAGE_NT / 64) {
     const uint64_t a = __shfl(myA, x), n = __shfl(myN, x);
@@ -265,11 +267,11 @@ __global__ void __launch_bounds__(STAGE_NT) local_sort_filter(uint64_t n_win, co
   }
 }
 
-__global__ void __launch_bounds__(64) local_compact(uint64_t n_win, const uint64_t* __restrict__ raw_off, const uint32_t* __restrict__ raw,
+__global__ void __launch_bounds__(64) local_compact(uint64_t n_win, uint64_t stride, const uint32_t* __restrict__ raw,
                                                     const uint64_t* __restrict__ bnd, uint32_t* __restrict__ out) {
   const uint64_t wi = (uint64_t)blockIdx.x * 64 + threadIdx.x;
   if (wi >= n_win) return;
-  const uint32_t* s = raw + raw_off[wi];
+  const uint32_t* s = raw + wi * stride;
   uint32_t* d = out + bnd[wi];
   const long n = (long)(bnd[wi + 1] - bnd[wi]);
   for (long x = 0; x < n; x++) d[x] = s[x];
@@ -410,26 +412,20 @@ extern "C" int lra_local_index_masked_batch(lra_ctx* ctx, int n_seqs, const char
   char* w1 = (char*)lra_scratch(ctx, 1, sz(NW, 4) * 3 + sz(NW, 8) * 3 + 4096);
   if (!w1) return LRA_ERR_NOMEM;
   uint32_t* w_seq = carve<uint32_t>(w1, NW); uint32_t* w_len = carve<uint32_t>(w1, NW); uint32_t* cnt = carve<uint32_t>(w1, NW);
-  uint64_t* w_start = carve<uint64_t>(w1, NW); uint64_t* raw_off = carve<uint64_t>(w1, NW); uint64_t* bnd_tmp = carve<uint64_t>(w1, NW);
+  uint64_t* w_start = carve<uint64_t>(w1, NW); uint64_t* spare_ = carve<uint64_t>(w1, NW); (void)spare_; uint64_t* bnd_tmp = carve<uint64_t>(w1, NW);
   const unsigned char* seq = (const unsigned char*)d_seq;
   const unsigned gw = (unsigned)((n_win + 63) / 64);
-  uint64_t n_raw = 0, n_tup = 0;
+  uint64_t n_tup = 0;
+  const uint64_t stride = (uint64_t)(window - k + 1);
+  uint32_t* raw = (uint32_t*)lra_scratch(ctx, 2, ((size_t)n_win * stride + 64) * 4);
+  if (!raw) return LRA_ERR_NOMEM;
   if (n_win) {
     hipLaunchKernelGGL(window_map, dim3((n_seqs + 255) / 256), dim3(256), 0, st, n_seqs, d_seq_off, window, win_off, d_active, w_seq, w_start, w_len);
     lra_time_begin(ctx, "local_sketch");
-    hipLaunchKernelGGL(local_sketch<false>, dim3(gw), dim3(64), 0, st, n_win, seq, w_start, w_len, k, w, (const uint64_t*)nullptr, (uint32_t*)nullptr, cnt);
-    lra_time_end(ctx);
-    if (lra_exclusive_scan<uint32_t>(ctx, (long)n_win, cnt, raw_off)) return LRA_ERR_HIP;
-    if (d2h8(ctx, &n_raw, raw_off + n_win)) return LRA_ERR_HIP;
-  }
-  uint32_t* raw = (uint32_t*)lra_scratch(ctx, 2, (n_raw + 1) * 4);
-  if (!raw) return LRA_ERR_NOMEM;
-  if (n_win) {
-    lra_time_begin(ctx, "local_sketch");
-    hipLaunchKernelGGL(local_sketch<true>, dim3(gw), dim3(64), 0, st, n_win, seq, w_start, w_len, k, w, raw_off, raw, (uint32_t*)nullptr);
+    hipLaunchKernelGGL(local_sketch, dim3(gw), dim3(64), 0, st, n_win, seq, w_start, w_len, k, w, stride, raw, cnt);
     lra_time_end(ctx);
     lra_time_begin(ctx, "local_sort_filter");
-    hipLaunchKernelGGL(local_sort_filter, dim3(gw), dim3(STAGE_NT), 0, st, n_win, raw_off, raw, max_freq, cnt);
+    hipLaunchKernelGGL(local_sort_filter, dim3(gw), dim3(STAGE_NT), 0, st, n_win, stride, raw, max_freq, cnt);
     lra_time_end(ctx);
     if (lra_exclusive_scan<uint32_t>(ctx, (long)n_win, cnt, bnd_tmp)) return LRA_ERR_HIP;
     if (d2h8(ctx, &n_tup, bnd_tmp + n_win)) return LRA_ERR_HIP;
@@ -444,7 +440,7 @@ extern "C" int lra_local_index_masked_batch(lra_ctx* ctx, int n_seqs, const char
   LRA_HIP_CHECK(ctx, hipMemcpyAsync(o_win, win_off, ((size_t)n_seqs + 1) * 8, hipMemcpyDeviceToDevice, st));
   if (n_win) {
     LRA_HIP_CHECK(ctx, hipMemcpyAsync(o_bnd, bnd_tmp, ((size_t)n_win + 1) * 8, hipMemcpyDeviceToDevice, st));
-    hipLaunchKernelGGL(local_compact, dim3(gw), dim3(64), 0, st, n_win, raw_off, raw, bnd_tmp, o_tup);
+    hipLaunchKernelGGL(local_compact, dim3(gw), dim3(64), 0, st, n_win, stride, raw, bnd_tmp, o_tup);
   }
   LRA_HIP_CHECK(ctx, hipGetLastError());
   LRA_HIP_CHECK(ctx, hipStreamSynchronize(st));
