@@ -126,3 +126,31 @@ def test_map_reads_match_oracle_pipeline(ctx, oracle, preset):
         if unaligned:
             assert out["job_aln_off"][r * na + 1] == out["job_aln_off"][r * na], r
     assert n_seg >= len(reads) - 1 and n_supp >= 2 and n_rev >= 3 and n_multi >= 2, (n_seg, n_supp, n_rev, n_multi)
+
+
+def test_oracle_pipeline_sanity(oracle):
+    """The oracle's MapRead_lowacc composition on the CPU: simulated reads come back at their locus with a plausible alignment (the
+    checker itself; the GPU path is compared with it above)."""
+    import oracle_lib as O
+    import oracle_pipeline as OP
+    genome = synth.make_genome(300_000, seed=13, repeat_frac=0.2, n_families=2)
+    ik, ip = synth.build_global_index(genome, 17, 10, 100)
+    tup, bnd = O.local_index_seq(genome.tobytes(), 10, 5, 256, 15)
+    g_index = (OP.seq_offsets(len(genome), 256), bnd, tup)
+    gbytes = genome.tobytes() + b"\0" * 64
+    reads, truth = synth.simulate_reads(genome, 5, 6000, 1500, 0.10, seed=4)
+    rng = np.random.default_rng(1)
+    reads.append(np.frombuffer(b"ACGT", dtype=np.uint8)[rng.integers(0, 4, 2000)].copy()); truth.append(None)
+    for rd, tr in zip(reads, truth):
+        alns, unaligned = OP.map_read_lowacc(rd.tobytes(), gbytes, ik, ip, g_index)
+        if tr is None:
+            assert unaligned
+            continue
+        s, l, st = tr
+        assert not unaligned and len(alns[0]) >= 1
+        a = alns[0][0]
+        b = a["blocks"]
+        assert a["strand"] == st and a["refine_status"] == 0
+        assert abs(int(b[0, 1]) - s) < 300 and abs(int(b[-1, 1] + b[-1, 2]) - (s + l)) < 300
+        assert b[:, 2].sum() > 0.7 * len(rd)
+        assert np.all(b[:-1, 0] + b[:-1, 2] <= b[1:, 0]) and np.all(b[:-1, 1] + b[:-1, 2] <= b[1:, 1])
