@@ -663,6 +663,19 @@ int lra_simple_mapqv(const lra_aln_group* groups, const int32_t* index, int n_gr
 int lra_output_read(const lra_aln_group* groups, const int32_t* index, int n_groups, lra_aln_record* recs, int print_num_aln, char format, int hard_clip,
                     const char* passthrough, int read_unaligned, const lra_aln_record* unaligned_rec, char* out, uint64_t cap, uint64_t* len);
 
+/* ---- a7 (high-accuracy path): MergeMatchesSameDiag -----------------------------------------------------------------------------------
+ * Replaces   MergeMatchesSameDiag(extend_clusters, samediag_clusters, opts)                    (LinearExtend.h:795-829, Map_highacc.h:642)
+ * for n_clusters extended clusters: cluster c has the anchors d_anchor_off[c] .. d_anchor_off[c+1] (read pos, chromosome pos, length,
+ * Cluster::overlap flag, in the cluster's order) and its strand.  Output: Cluster_SameDiag::start / end of cluster c =
+ * d_start / d_end [d_group_off[c] .. d_group_off[c+1]) (anchor indices relative to the cluster); d_status[c] = LRA_ST_OOB_SLOT for an
+ * empty cluster (the reference reads matches[0]).  Synchronous.                                                                        */
+typedef struct lra_same_diag_result {
+  uint64_t n_clusters, n_groups;
+  const uint64_t* d_group_off; const uint32_t* d_start; const uint32_t* d_end; const uint32_t* d_status;
+} lra_same_diag_result;
+int lra_merge_same_diag_batch(lra_ctx* ctx, uint64_t n_clusters, const uint64_t* d_anchor_off, const uint32_t* d_q, const uint32_t* d_t,
+                              const int32_t* d_len, const uint8_t* d_overlap, const int32_t* d_strand, int merge_dist, lra_same_diag_result* out);
+
 /* ---- the path behind one call: MapRead_lowacc for a batch of reads -----------------------------------------------------------------
  * Replaces   int MapRead_lowacc(const vector<float>& LookUpTable, Read& read, Genome& genome, vector<GenomeTuple>& genomemm, LocalIndex& glIndex,
  *                               const Options& opts, ostream* output, ostream* svsigstrm, Timing& timing, IndelRefineBuffers&, pthread_mutex_t*)

@@ -298,3 +298,22 @@ def local_refine_from_sdp(ctx: Context, num_aln, slot_n0, merge: MergeResult, se
                                              v(inp.d_chain_n1), C.c_uint64(inp.n_anchors), v(inp.d_q), v(inp.d_t), v(inp.d_len), ptr(read_off), ptr(strands),
                                              C.c_uint64(int(rc_base)), ptr(genome), C.c_void_p(cp.ctypes.data), len(cp) - 1, C.byref(o), C.byref(res)))
     return inp, res
+
+
+class SameDiagResult(C.Structure):
+    _fields_ = [("n_clusters", C.c_uint64), ("n_groups", C.c_uint64)] + [(n, C.c_void_p) for n in ("d_group_off", "d_start", "d_end", "d_status")]
+
+
+def merge_same_diag_batch(ctx: Context, anchor_off, q, t, length, overlap, strand, merge_dist=100):
+    """MergeMatchesSameDiag (LinearExtend.h:795, high-accuracy path) for a batch of extended clusters; device tensors in."""
+    res = SameDiagResult()
+    n = int(strand.numel())
+    ctx.check(ctx.lib.lra_merge_same_diag_batch(ctx.h, C.c_uint64(n), ptr(anchor_off), ptr(q), ptr(t), ptr(length), ptr(overlap), ptr(strand), int(merge_dist),
+                                                C.byref(res)))
+    return res
+
+
+def fetch_same_diag(ctx: Context, res: SameDiagResult):
+    n, ng = int(res.n_clusters), int(res.n_groups)
+    return {"group_off": ctx.to_host(res.d_group_off, n + 1, np.uint64), "start": ctx.to_host(res.d_start, ng, np.uint32),
+            "end": ctx.to_host(res.d_end, ng, np.uint32), "status": ctx.to_host(res.d_status, n, np.uint32)}

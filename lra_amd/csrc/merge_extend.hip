@@ -288,3 +288,90 @@ extern "C" int lra_trim_anchor_pairs_batch(lra_ctx* ctx, uint64_t n_lists, const
   LRA_HIP_CHECK(ctx, hipGetLastError());
   return LRA_OK;
 }
+
+
+// ---------------------------------------------------------------------------------------------------------------- MergeMatchesSameDiag
+// LinearExtend.h:795-829 (Map_highacc.h:642): whether anchor q opens a new Cluster_SameDiag entry depends on the pair (q - 1, q) alone, so
+// every anchor tests its own pair and the entries are the stretches between the heads: one wave per cluster, count then emit.
+namespace {
+struct SdArgs {
+  uint64_t n_clusters;
+  const uint64_t* a_off; const uint32_t* q; const uint32_t* t; const int32_t* len; const uint8_t* overlap; const int32_t* strand;
+  int merge_dist;
+  uint32_t* cnt; const uint64_t* g_off; uint32_t* g_start; uint32_t* g_end; uint32_t* status;
+};
+__device__ __forceinline__ bool sd_head(const SdArgs& a, uint64_t base, long i, int strand) {   // does anchor i (>= 1) start a new entry?
+  const uint64_t x = base + i, p = x - 1;
+  const long dq = strand == 0 ? (long)a.t[x] - (long)a.q[x] : (long)a.q[x] + (long)a.t[x] + a.len[x];
+  const long dp = strand == 0 ? (long)a.t[p] - (long)a.q[p] : (long)a.q[p] + (long)a.t[p] + a.len[p];
+  const uint32_t prevEnd = a.q[p] + (uint32_t)a.len[p];
+  const long gap = labs((long)a.q[x] - ((long)a.q[p] + a.len[p]));
+  return !(a.overlap[p] == 0 && a.overlap[x] == 0 && dp == dq && prevEnd < a.q[x] && gap <= a.merge_dist);
+}
+template <bool EMIT>
+__global__ void __launch_bounds__(64) sd_kernel(SdArgs a) {
+  const uint64_t c = blockIdx.x;
+  const int lane = threadIdx.x;
+  if (c >= a.n_clusters) return;
+  const uint64_t base = a.a_off[c];
+  const long n = (long)(a.a_off[c + 1] - base);
+  if (n <= 0) { if (!EMIT && lane == 0) { a.cnt[c] = 0; a.status[c] = LRA_ST_OOB_SLOT; } return; }   // the reference reads matches[0]
+  const int strand = a.strand[c];
+  const unsigned long long below = (lane == 0) ? 0ULL : (~0ULL >> (64 - lane));
+  uint32_t ng = 0;
+  const uint64_t go = EMIT ? a.g_off[c] : 0;
+  for (long i0 = 0; i0 < n; i0 += 64) {
+    const long i = i0 + lane;
+    const bool head = i < n && (i == 0 || sd_head(a, base, i, strand));
+    const unsigned long long m = __ballot(head);
+    if (EMIT && head) {
+      const uint32_t g = ng + (uint32_t)__popcll(m & below);
+      a.g_start[go + g] = (uint32_t)i;
+      if (g > 0) a.g_end[go + g - 1] = (uint32_t)i;                      // the previous entry ends where this one starts
+    }
+    ng += (uint32_t)__popcll(m);
+  }
+  if (lane == 0) {
+    if (EMIT) a.g_end[go + ng - 1] = (uint32_t)n;
+    else { a.cnt[c] = ng; a.status[c] = 0; }
+  }
+}
+}  // namespace
+
+extern "C" int lra_merge_same_diag_batch(lra_ctx* ctx, uint64_t n_clusters, const uint64_t* d_anchor_off, const uint32_t* d_q, const uint32_t* d_t,
+                                         const int32_t* d_len, const uint8_t* d_overlap, const int32_t* d_strand, int merge_dist,
+                                         lra_same_diag_result* out) {
+  if (!ctx || !out) return LRA_ERR_INVALID;
+  memset(out, 0, sizeof *out);
+  out->n_clusters = n_clusters;
+  if (n_clusters == 0) return LRA_OK;
+  LRA_HIP_CHECK(ctx, hipSetDevice(ctx->device));
+  hipStream_t st = ctx->stream;
+  const size_t n1 = (size_t)n_clusters + 2;
+  char* w = (char*)lra_ensure(ctx, 67, ((n1 * 4 + 255) & ~(size_t)255) * 2 + ((n1 * 8 + 255) & ~(size_t)255) + 4096);
+  if (!w) return LRA_ERR_NOMEM;
+  uint32_t* cnt = (uint32_t*)w; w += (n1 * 4 + 255) & ~(size_t)255;
+  uint32_t* status = (uint32_t*)w; w += (n1 * 4 + 255) & ~(size_t)255;
+  uint64_t* g_off = (uint64_t*)w;
+  SdArgs a; memset(&a, 0, sizeof a);
+  a.n_clusters = n_clusters; a.a_off = d_anchor_off; a.q = d_q; a.t = d_t; a.len = d_len; a.overlap = d_overlap; a.strand = d_strand; a.merge_dist = merge_dist;
+  a.cnt = cnt; a.status = status;
+  lra_time_begin(ctx, "merge_same_diag");
+  hipLaunchKernelGGL(sd_kernel<false>, dim3((unsigned)n_clusters), dim3(64), 0, st, a);
+  lra_time_end(ctx);
+  { int rc = lra_exclusive_scan<uint32_t>(ctx, (long)n_clusters, cnt, g_off); if (rc) return rc; }
+  uint64_t ng = 0;
+  LRA_HIP_CHECK(ctx, hipMemcpyAsync(&ng, g_off + n_clusters, 8, hipMemcpyDeviceToHost, st));
+  LRA_HIP_CHECK(ctx, hipStreamSynchronize(st));
+  uint32_t* gs = (uint32_t*)lra_ensure(ctx, 68, (ng + 1) * 8 + 512);
+  if (!gs) return LRA_ERR_NOMEM;
+  uint32_t* ge = gs + ((ng + 64) & ~(uint64_t)63);
+  a.g_off = g_off; a.g_start = gs; a.g_end = ge;
+  lra_time_begin(ctx, "merge_same_diag");
+  hipLaunchKernelGGL(sd_kernel<true>, dim3((unsigned)n_clusters), dim3(64), 0, st, a);
+  lra_time_end(ctx);
+  LRA_HIP_CHECK(ctx, hipStreamSynchronize(st));
+  LRA_HIP_CHECK(ctx, hipGetLastError());
+  out->n_groups = ng; out->d_group_off = g_off; out->d_start = gs; out->d_end = ge; out->d_status = status;
+  return LRA_OK;
+}

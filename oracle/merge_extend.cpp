@@ -119,3 +119,26 @@ extern "C" void oracle_trim_anchor_pairs(int n, const uint32_t* Q, const uint32_
     if (overlap_r > 0 || overlap_g > 0) L[prev] -= std::max(overlap_r, overlap_g) + 1;
   }
 }
+
+// MergeMatchesSameDiag (LinearExtend.h:795-829; Map_highacc.h:642): consecutive anchors of one extended cluster that lie on the same
+// diagonal, carry no overlap flag, follow each other on the read and are at most merge_dist apart fall into one Cluster_SameDiag entry.
+// GetDiag (Clustering.h:886-889), GapDifference (:539-542).  Returns the number of entries (start / end = anchor index ranges), -1 for an
+// empty cluster (the reference reads matches[0] of it).
+extern "C" int oracle_merge_same_diag(int n, const uint32_t* Q, const uint32_t* T, const int* L, const uint8_t* overlap, int strand, int merge_dist,
+                                      int* start, int* end) {
+  if (n <= 0) return -1;
+  auto diag = [&](int i) -> long { return strand == 0 ? (long)T[i] - (long)Q[i] : (long)Q[i] + (long)T[i] + L[i]; };
+  int ng = 0;
+  start[ng] = 0; end[ng] = 1; ng++;
+  long prev_diag = diag(0);
+  uint32_t prev_qEnd = Q[0] + (uint32_t)L[0];
+  for (int q = 1; q < n; q++) {
+    const long cur_diag = diag(q);
+    const long gap = labs((long)Q[q] - ((long)Q[q - 1] + L[q - 1]));
+    if (overlap[q - 1] == 0 && overlap[q] == 0 && prev_diag == cur_diag && prev_qEnd < Q[q] && gap <= merge_dist) end[ng - 1] = q + 1;
+    else { start[ng] = q; end[ng] = q + 1; ng++; }
+    prev_qEnd = Q[q] + (uint32_t)L[q];
+    prev_diag = cur_diag;
+  }
+  return ng;
+}

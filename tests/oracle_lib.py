@@ -625,3 +625,18 @@ def filter_chain(q, t, length, strand, link, ops):
     L.oracle_filter_chain(C.c_int(n), _p(q, C.c_uint32), _p(t, C.c_uint32), _p(ln, C.c_int), _p(st, C.c_uint8), _p(lk, C.c_uint8), C.c_int(int(has)),
                           _p(ops, C.c_int), C.c_int(len(ops)), _p(keep, C.c_uint8), _p(lo, C.c_uint8), C.byref(nl))
     return keep[:n].copy(), lo[:nl.value].copy()
+
+
+def merge_same_diag(q, t, length, overlap, strand, merge_dist=100):
+    """MergeMatchesSameDiag (LinearExtend.h:795) on one extended cluster -> (start, end) anchor index ranges, or None for an empty cluster."""
+    L = lib()
+    q = np.ascontiguousarray(q, np.uint32); t = np.ascontiguousarray(t, np.uint32); ln = np.ascontiguousarray(length, np.int32)
+    ov = np.ascontiguousarray(overlap, np.uint8)
+    n = len(q)
+    st = np.zeros(max(1, n), np.int32); en = np.zeros(max(1, n), np.int32)
+    L.oracle_merge_same_diag.restype = C.c_int
+    ng = L.oracle_merge_same_diag(C.c_int(n), _p(q, C.c_uint32), _p(t, C.c_uint32), _p(ln, C.c_int), _p(ov, C.c_uint8), C.c_int(int(strand)), C.c_int(int(merge_dist)),
+                                  _p(st, C.c_int), _p(en, C.c_int))
+    if ng < 0:
+        return None
+    return st[:ng].copy(), en[:ng].copy()

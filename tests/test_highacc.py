@@ -137,3 +137,60 @@ def test_hip_split_clusters_and_boxes_sdp_oracle(ctx, contig):
                 assert int(co["chain_num_anchors"][s]) == ch["num_anchors"]
                 n_chains += 1
         assert n_chains > 100
+
+
+def _same_diag_clusters(rng, n_clusters):
+    """extended clusters as LinearExtend leaves them: runs of anchors on one diagonal (some adjacent, some far apart), diagonal jumps,
+    overlap flags, both strands; an empty cluster"""
+    Q, T, L, OV, ST, off = [], [], [], [], [], [0]
+    for c in range(n_clusters):
+        strand = int(rng.integers(0, 2))
+        n = int(rng.integers(1, 200)) if c != 3 else 0
+        q = int(rng.integers(0, 1000)); t = int(rng.integers(5000, 100000))
+        for i in range(n):
+            ln = int(rng.integers(10, 60))
+            Q.append(q); L.append(ln); OV.append(int(rng.random() < 0.08))
+            T.append(t if strand == 0 else t - ln)                    # reverse strand: q + t + len constant along a diagonal
+            kind = rng.random()
+            gap = int(rng.integers(1, 30)) if kind < 0.6 else int(rng.integers(90, 130)) if kind < 0.75 else 0 if kind < 0.8 else int(rng.integers(1, 30))
+            q += ln + gap
+            t = t + (ln + gap) if strand == 0 else t - (ln + gap)
+            if kind >= 0.8:
+                t += int(rng.integers(-3, 4))                          # leave the diagonal
+        ST.append(strand); off.append(len(Q))
+    return (np.array(Q, np.uint32), np.array(T, np.int64).astype(np.uint32), np.array(L, np.int32), np.array(OV, np.uint8), np.array(ST, np.int32),
+            np.array(off, np.int64))
+
+
+def test_oracle_merge_same_diag_sanity(oracle):
+    # three anchors on one forward diagonal 20 apart, then a jump: two entries; an overlap flag splits; a far anchor (> merge_dist) splits
+    q = [0, 40, 80, 200]; t = [1000, 1040, 1080, 1300]; ln = [20, 20, 20, 20]
+    assert [x.tolist() for x in oracle.merge_same_diag(q, t, ln, [0, 0, 0, 0], 0)] == [[0, 3], [3, 4]]
+    assert [x.tolist() for x in oracle.merge_same_diag(q, t, ln, [0, 1, 0, 0], 0)] == [[0, 1, 2, 3], [1, 2, 3, 4]]
+    assert [x.tolist() for x in oracle.merge_same_diag([0, 200], [1000, 1200], [20, 20], [0, 0], 0)] == [[0, 1], [1, 2]]
+    assert [x.tolist() for x in oracle.merge_same_diag([0, 40], [1040, 1000], [20, 20], [0, 0], 1)] == [[0], [2]]      # q + t + len equal
+    assert oracle.merge_same_diag([], [], [], [], 0) is None
+
+
+@pytest.mark.gpu
+def test_hip_merge_same_diag_oracle(ctx, oracle):
+    import torch
+    from lra_amd import chain
+    rng = np.random.default_rng(12)
+    Q, T, L, OV, ST, off = _same_diag_clusters(rng, 300)
+    dev = ctx.device
+    tt = lambda a: torch.from_numpy(a).to(dev)
+    res = chain.merge_same_diag_batch(ctx, tt(off), tt(Q), tt(T), tt(L), tt(OV), tt(ST), 100)
+    out = chain.fetch_same_diag(ctx, res)
+    n_merged = n_groups = 0
+    for c in range(len(ST)):
+        a, b = int(off[c]), int(off[c + 1])
+        exp = oracle.merge_same_diag(Q[a:b], T[a:b], L[a:b], OV[a:b], int(ST[c]), 100)
+        g0, g1 = int(out["group_off"][c]), int(out["group_off"][c + 1])
+        if exp is None:
+            assert out["status"][c] != 0 and g1 == g0
+            continue
+        assert out["status"][c] == 0
+        assert out["start"][g0:g1].tolist() == exp[0].tolist() and out["end"][g0:g1].tolist() == exp[1].tolist(), c
+        n_groups += g1 - g0; n_merged += int(np.sum(exp[1] - exp[0] > 1))
+    assert n_groups > 5000 and n_merged > 2000, (n_groups, n_merged)
