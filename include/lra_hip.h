@@ -676,6 +676,21 @@ typedef struct lra_same_diag_result {
 int lra_merge_same_diag_batch(lra_ctx* ctx, uint64_t n_clusters, const uint64_t* d_anchor_off, const uint32_t* d_q, const uint32_t* d_t,
                               const int32_t* d_len, const uint8_t* d_overlap, const int32_t* d_strand, int merge_dist, lra_same_diag_result* out);
 
+/* ---- a9 (high-accuracy path): switchindex ---------------------------------------------------------------------------------------------
+ * Replaces   switchindex(splitclusters, Primary_chains, clusters, genome, read)                (Mapping_ultility.h:39-168, Map_highacc.h:274)
+ * for n_chains chains (every CHain of every Primary_chain of every read): chain c = d_ch[d_chain_off[c] .. d_chain_off[c+1]) (split-cluster
+ * indices relative to its read, as lra_sparse_dp_boxes_batch returns them) with d_n_link[c] link bits at d_link[d_chain_off[c] ..];
+ * d_split_base[c] / d_cluster_base[c] = where its read's split clusters (d_coarse) / clusters (d_cl_qs, d_cl_qe = Cluster::qStart, qEnd)
+ * begin; n_total = d_chain_off[n_chains].  Output (context-owned, same offsets): the rewritten chain d_ch[d_chain_off[c] .. + d_n[c]) of
+ * cluster indices and d_n_link[c] links; d_status[c] = LRA_ST_OOB_SLOT where the reference would index past a vector.  Synchronous.     */
+typedef struct lra_switchindex_result {
+  uint64_t n_chains;
+  const uint32_t* d_ch; const uint8_t* d_link; const uint32_t* d_n; const uint32_t* d_n_link; const uint32_t* d_status;
+} lra_switchindex_result;
+int lra_switchindex_batch(lra_ctx* ctx, uint64_t n_chains, const uint64_t* d_chain_off, const uint32_t* d_ch, const uint8_t* d_link,
+                          const uint32_t* d_n_link, const uint64_t* d_split_base, const uint64_t* d_cluster_base, const int32_t* d_coarse,
+                          const uint32_t* d_cl_qs, const uint32_t* d_cl_qe, uint64_t n_total, lra_switchindex_result* out);
+
 /* ---- the path behind one call: MapRead_lowacc for a batch of reads -----------------------------------------------------------------
  * Replaces   int MapRead_lowacc(const vector<float>& LookUpTable, Read& read, Genome& genome, vector<GenomeTuple>& genomemm, LocalIndex& glIndex,
  *                               const Options& opts, ostream* output, ostream* svsigstrm, Timing& timing, IndelRefineBuffers&, pthread_mutex_t*)

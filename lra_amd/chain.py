@@ -317,3 +317,22 @@ def fetch_same_diag(ctx: Context, res: SameDiagResult):
     n, ng = int(res.n_clusters), int(res.n_groups)
     return {"group_off": ctx.to_host(res.d_group_off, n + 1, np.uint64), "start": ctx.to_host(res.d_start, ng, np.uint32),
             "end": ctx.to_host(res.d_end, ng, np.uint32), "status": ctx.to_host(res.d_status, n, np.uint32)}
+
+
+class SwitchIndexResult(C.Structure):
+    _fields_ = [("n_chains", C.c_uint64)] + [(n, C.c_void_p) for n in ("d_ch", "d_link", "d_n", "d_n_link", "d_status")]
+
+
+def switchindex_batch(ctx: Context, chain_off, ch, link, n_link, split_base, cluster_base, coarse, cl_qs, cl_qe):
+    """switchindex (Mapping_ultility.h:39, high-accuracy path) for a batch of chains; device tensors in."""
+    res = SwitchIndexResult()
+    n = int(chain_off.numel()) - 1
+    ctx.check(ctx.lib.lra_switchindex_batch(ctx.h, C.c_uint64(n), ptr(chain_off), ptr(ch), ptr(link), ptr(n_link), ptr(split_base), ptr(cluster_base), ptr(coarse),
+                                            ptr(cl_qs), ptr(cl_qe), C.c_uint64(int(chain_off[-1])), C.byref(res)))
+    return res
+
+
+def fetch_switchindex(ctx: Context, res: SwitchIndexResult, n_total):
+    n = int(res.n_chains)
+    return {"ch": ctx.to_host(res.d_ch, n_total, np.uint32), "link": ctx.to_host(res.d_link, n_total, np.uint8), "n": ctx.to_host(res.d_n, n, np.uint32),
+            "n_link": ctx.to_host(res.d_n_link, n, np.uint32), "status": ctx.to_host(res.d_status, n, np.uint32)}

@@ -351,3 +351,116 @@ extern "C" int lra_split_clusters_batch(lra_ctx* ctx, int n_reads, const uint64_
   LRA_HIP_CHECK(ctx, hipGetLastError());
   return LRA_OK;
 }
+
+
+// ---------------------------------------------------------------------------------------------------------------- switchindex
+// Mapping_ultility.h:39-168 (Map_highacc.h:274): the chains of the box-fragment sparse DP are lists of split clusters; map them back to the
+// clusters they were cut from, drop the links between pieces of one cluster, merge repeats (adjacent ones by std::unique, spread ones by
+// keeping the first occurrence and skipping to behind the last), and drop clusters whose read interval lies inside their predecessor's.
+// Chains are short lists rewritten in place by data-dependent steps: one lane per chain.
+namespace {
+struct SwArgs {
+  uint64_t n_chains;
+  const uint64_t* off; const uint32_t* ch; const uint8_t* link; const uint32_t* n_link;
+  const uint64_t* sp_base; const uint64_t* cl_base; const int32_t* coarse; const uint32_t* cl_qs; const uint32_t* cl_qe;
+  uint32_t* o_ch; uint8_t* o_link; uint32_t* o_n; uint32_t* o_nlink; uint32_t* status;
+  uint32_t* t_ch; uint8_t* t_link; uint32_t* iv_s; uint32_t* iv_e;
+};
+__global__ void sw_kernel(SwArgs a) {
+  const uint64_t c = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= a.n_chains) return;
+  const uint64_t b = a.off[c];
+  long n = (long)(a.off[c + 1] - b);
+  long nl = a.n_link[c];
+  uint32_t* A = a.o_ch + b; uint8_t* L = a.o_link + b;
+  uint32_t* TA = a.t_ch + b; uint8_t* TL = a.t_link + b; uint32_t* IS = a.iv_s + b; uint32_t* IE = a.iv_e + b;
+  const int32_t* coarse = a.coarse + a.sp_base[c];
+  const uint32_t* qs = a.cl_qs + a.cl_base[c]; const uint32_t* qe = a.cl_qe + a.cl_base[c];
+  auto fail = [&]() { a.status[c] = LRA_ST_OOB_SLOT; a.o_n[c] = 0; a.o_nlink[c] = 0; };
+  for (long i = 0; i < n; i++) A[i] = (uint32_t)coarse[a.ch[b + i]];                                    // :42-48
+  for (long i = 0; i < nl; i++) L[i] = a.link[b + i];
+  if (nl > 0) {                                                                                         // :52-69
+    for (long i = 1; i < n; i++) if (A[i] == A[i - 1] && i - 1 >= nl) { fail(); return; }
+    long sm = 0;
+    for (long i = 0; i < nl; i++) { const bool rm = (i + 1 < n) && A[i + 1] == A[i]; if (!rm) { L[sm] = L[i]; sm++; } }
+    nl = sm;
+  }
+  { long m = 0; for (long i = 0; i < n; i++) if (i == 0 || A[i] != A[m - 1]) A[m++] = A[i]; n = m; }     // std::unique :73-80
+  if (n > 0) {                                                                                          // :84-143
+    long niv = 0;
+    for (long i = 0; i < n; i++) {
+      bool first = true;
+      for (long j = 0; j < i; j++) if (A[j] == A[i]) { first = false; break; }
+      if (!first) continue;
+      long last = i;
+      for (long j = i + 1; j < n; j++) if (A[j] == A[i]) last = j;
+      if (last + 1 > i + 1) { IS[niv] = (uint32_t)i; IE[niv] = (uint32_t)(last + 1); niv++; }
+    }
+    long m = 0, ml = 0, ste = 0, nc = 0;
+    while (ste < niv) {
+      while (nc <= (long)IS[ste]) {
+        TA[m++] = A[nc];
+        if (m > 1) { if (nc - 1 < 0 || nc - 1 >= nl) { fail(); return; } TL[ml++] = L[nc - 1]; }
+        nc++;
+      }
+      nc = (long)IE[ste];
+      ste++;
+    }
+    while (nc < n) {
+      TA[m++] = A[nc];
+      if (m > 1) { if (nc - 1 < 0 || nc - 1 >= nl) { fail(); return; } TL[ml++] = L[nc - 1]; }
+      nc++;
+    }
+    for (long i = 0; i < m; i++) A[i] = TA[i];
+    for (long i = 0; i < ml; i++) L[i] = TL[i];
+    n = m; nl = ml;
+  }
+  {                                                                                                     // :147-166
+    long sc = 0;
+    bool prevRemoved = false;
+    uint32_t prevCluster = 0;
+    for (long i = 0; i < n; i++) {
+      const uint32_t cr = A[i];
+      bool rem = false;
+      if (i >= 1 && !prevRemoved && qs[cr] >= qs[prevCluster] && qe[cr] <= qe[prevCluster]) rem = true;
+      prevRemoved = rem; prevCluster = cr;                               // cremove[c - 1] and ch[c - 1] of the next step (ch is compacted afterwards)
+      if (!rem) {
+        A[sc] = cr;
+        if (sc >= 1) { if (i - 1 >= nl || sc - 1 >= nl) { fail(); return; } L[sc - 1] = L[i - 1]; }
+        sc++;
+      }
+    }
+    if (sc - 1 < 0) { fail(); return; }
+    n = sc; nl = sc - 1;
+  }
+  a.o_n[c] = (uint32_t)n; a.o_nlink[c] = (uint32_t)nl; a.status[c] = 0;
+}
+}  // namespace
+
+extern "C" int lra_switchindex_batch(lra_ctx* ctx, uint64_t n_chains, const uint64_t* d_chain_off, const uint32_t* d_ch, const uint8_t* d_link,
+                                     const uint32_t* d_n_link, const uint64_t* d_split_base, const uint64_t* d_cluster_base, const int32_t* d_coarse,
+                                     const uint32_t* d_cl_qs, const uint32_t* d_cl_qe, uint64_t n_total, lra_switchindex_result* out) {
+  if (!ctx || !out) return LRA_ERR_INVALID;
+  memset(out, 0, sizeof *out);
+  out->n_chains = n_chains;
+  if (n_chains == 0) return LRA_OK;
+  LRA_HIP_CHECK(ctx, hipSetDevice(ctx->device));
+  hipStream_t st = ctx->stream;
+  auto al = [](size_t x) { return (x + 255) & ~(size_t)255; };
+  const size_t N = (size_t)n_total + 1, C1 = (size_t)n_chains + 1;
+  char* w = (char*)lra_ensure(ctx, 69, al(N * 4) * 4 + al(N) * 2 + al(C1 * 4) * 3 + 4096);
+  if (!w) return LRA_ERR_NOMEM;
+  SwArgs a; memset(&a, 0, sizeof a);
+  a.n_chains = n_chains; a.off = d_chain_off; a.ch = d_ch; a.link = d_link; a.n_link = d_n_link; a.sp_base = d_split_base; a.cl_base = d_cluster_base;
+  a.coarse = d_coarse; a.cl_qs = d_cl_qs; a.cl_qe = d_cl_qe;
+  a.o_ch = (uint32_t*)w; w += al(N * 4); a.t_ch = (uint32_t*)w; w += al(N * 4); a.iv_s = (uint32_t*)w; w += al(N * 4); a.iv_e = (uint32_t*)w; w += al(N * 4);
+  a.o_link = (uint8_t*)w; w += al(N); a.t_link = (uint8_t*)w; w += al(N);
+  a.o_n = (uint32_t*)w; w += al(C1 * 4); a.o_nlink = (uint32_t*)w; w += al(C1 * 4); a.status = (uint32_t*)w;
+  lra_time_begin(ctx, "switchindex");
+  hipLaunchKernelGGL(sw_kernel, dim3((unsigned)((n_chains + 63) / 64)), dim3(64), 0, st, a);
+  lra_time_end(ctx);
+  LRA_HIP_CHECK(ctx, hipStreamSynchronize(st));
+  LRA_HIP_CHECK(ctx, hipGetLastError());
+  out->d_ch = a.o_ch; out->d_link = a.o_link; out->d_n = a.o_n; out->d_n_link = a.o_nlink; out->d_status = a.status;
+  return LRA_OK;
+}

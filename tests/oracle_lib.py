@@ -640,3 +640,19 @@ def merge_same_diag(q, t, length, overlap, strand, merge_dist=100):
     if ng < 0:
         return None
     return st[:ng].copy(), en[:ng].copy()
+
+
+def switchindex(ch, link, coarse, cl_qs, cl_qe):
+    """switchindex (Mapping_ultility.h:39) on one chain -> (ch, link) or None where the reference reads outside an array."""
+    L = lib()
+    ch = np.ascontiguousarray(ch, np.uint32); lk = np.ascontiguousarray(link, np.uint8)
+    co = np.ascontiguousarray(coarse, np.int32); qs = np.ascontiguousarray(cl_qs, np.uint32); qe = np.ascontiguousarray(cl_qe, np.uint32)
+    n = len(ch)
+    oc = np.zeros(max(1, n), np.uint32); ol = np.zeros(max(1, n), np.uint8); nl = C.c_int(0)
+    lk_in = lk if len(lk) else np.zeros(1, np.uint8)
+    L.oracle_switchindex.restype = C.c_int
+    r = L.oracle_switchindex(C.c_int(n), _p(ch if n else np.zeros(1, np.uint32), C.c_uint32), C.c_int(len(lk)), _p(lk_in, C.c_uint8), _p(co, C.c_int), _p(qs, C.c_uint32),
+                             _p(qe, C.c_uint32), _p(oc, C.c_uint32), _p(ol, C.c_uint8), C.byref(nl))
+    if r < 0:
+        return None
+    return oc[:r].copy(), ol[:nl.value].copy()

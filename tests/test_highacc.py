@@ -194,3 +194,62 @@ def test_hip_merge_same_diag_oracle(ctx, oracle):
         assert out["start"][g0:g1].tolist() == exp[0].tolist() and out["end"][g0:g1].tolist() == exp[1].tolist(), c
         n_groups += g1 - g0; n_merged += int(np.sum(exp[1] - exp[0] > 1))
     assert n_groups > 5000 and n_merged > 2000, (n_groups, n_merged)
+
+
+def test_oracle_switchindex_sanity(oracle):
+    co = np.arange(200); qs = np.arange(200) * 100; qe = qs + 50
+    ch, lk = oracle.switchindex([22, 125, 19, 125, 16, 17, 125, 57, 125], [0] * 8, co, qs, qe)          # the reference's own example (:82)
+    assert ch.tolist() == [22, 125] and lk.tolist() == [0]
+    ch, lk = oracle.switchindex([5, 5, 6, 6, 7], [1, 0, 1, 0], co, qs, qe)                               # links inside one cluster go
+    assert ch.tolist() == [5, 6, 7] and lk.tolist() == [0, 0]
+    qe2 = qe.copy(); qe2[3] = qs[4] + 60                                                                 # cluster 4 inside cluster 3 on the read
+    qs2 = qs.copy(); qs2[4] = qs2[3] + 10
+    ch, lk = oracle.switchindex([3, 4, 9], [1, 0], co, qs2, qe2)
+    assert ch.tolist() == [3, 9] and lk.tolist() == [0]
+
+
+@pytest.mark.gpu
+def test_hip_switchindex_oracle(ctx, oracle):
+    import torch
+    from lra_amd import chain
+    rng = np.random.default_rng(21)
+    n_reads = 60
+    ch_all, lk_all, off, nlk, spb, clb, coarse_all, qs_all, qe_all = [], [], [0], [], [], [], [], [], []
+    per_chain = []
+    for r in range(n_reads):
+        ncl = int(rng.integers(2, 12)); nsp = int(rng.integers(ncl, 5 * ncl))
+        coarse = np.sort(rng.integers(0, ncl, nsp)).astype(np.int32)                      # split clusters in cluster order
+        s = np.sort(rng.integers(0, 20000, ncl)); e = s + rng.integers(50, 3000, ncl)
+        for j in range(1, ncl):
+            if rng.random() < 0.3:
+                s[j] = s[j - 1] + 5; e[j] = e[j - 1] - 1                                  # nested on the read
+        sp0, cl0 = len(coarse_all), len(qs_all)
+        coarse_all.extend(coarse.tolist()); qs_all.extend(s.tolist()); qe_all.extend(e.tolist())
+        for h in range(int(rng.integers(1, 4))):
+            n = int(rng.integers(1, 40))
+            ch = rng.integers(0, nsp, n)
+            if rng.random() < 0.5:
+                ch = np.sort(ch)[::-1]                                                     # colinear-looking chain: adjacent repeats
+            has_link = rng.random() < 0.85
+            lk = rng.integers(0, 2, n - 1) if has_link else np.zeros(0, np.int64)
+            ch_all.extend(ch.tolist()); lk_all.extend(lk.tolist() + [0] * (n - len(lk))); off.append(len(ch_all)); nlk.append(len(lk))
+            spb.append(sp0); clb.append(cl0)
+            per_chain.append((ch.copy(), lk.copy(), coarse, s, e))
+    dev = ctx.device
+    T = lambda a, dt: torch.from_numpy(np.asarray(a, dt)).to(dev)
+    res = chain.switchindex_batch(ctx, T(off, np.int64), T(ch_all, np.uint32), T(lk_all, np.uint8), T(nlk, np.uint32), T(spb, np.int64), T(clb, np.int64),
+                                  T(coarse_all, np.int32), T(qs_all, np.uint32), T(qe_all, np.uint32))
+    out = chain.fetch_switchindex(ctx, res, len(ch_all))
+    n_short = n_ub = 0
+    for c, (ch, lk, coarse, s, e) in enumerate(per_chain):
+        exp = oracle.switchindex(ch, lk, coarse, s, e)
+        if exp is None:
+            assert out["status"][c] != 0, c
+            n_ub += 1
+            continue
+        assert out["status"][c] == 0, c
+        b = off[c]
+        assert out["ch"][b:b + int(out["n"][c])].tolist() == exp[0].tolist(), c
+        assert out["link"][b:b + int(out["n_link"][c])].tolist() == exp[1].tolist(), c
+        n_short += len(exp[0]) < len(ch)
+    assert n_short > 40 and len(per_chain) > 100, (n_short, n_ub, len(per_chain))
