@@ -154,3 +154,38 @@ def test_oracle_pipeline_sanity(oracle):
         assert abs(int(b[0, 1]) - s) < 300 and abs(int(b[-1, 1] + b[-1, 2]) - (s + l)) < 300
         assert b[:, 2].sum() > 0.7 * len(rd)
         assert np.all(b[:-1, 0] + b[:-1, 2] <= b[1:, 0]) and np.all(b[:-1, 1] + b[:-1, 2] <= b[1:, 1])
+
+
+@pytest.mark.gpu
+def test_map_reads_edge_batches(ctx, oracle):
+    """Batches the path must survive: nothing alignable at all (no alignment arrays downstream), reads shorter than a k-mer / a window, an
+    empty read between real ones, a single read; every read still gets its record (flag 4 when unaligned), aligned ones match the oracle."""
+    import oracle_pipeline as OP
+    from lra_amd import seed, mapread
+    genome = synth.make_genome(200_000, seed=9, repeat_frac=0.1, n_families=2)
+    o = mapread.LowAccOptions()
+    ik, ip = synth.build_global_index(genome, o.globalK, o.globalW, 100)
+    mapper = mapread.LowAccMapper(ctx, genome, ik, ip, [b"chr1"], [0, len(genome)], o)
+    rng = np.random.default_rng(7)
+    junk = lambda n: np.frombuffer(b"ACGT", dtype=np.uint8)[rng.integers(0, 4, n)].copy()
+    good = synth.simulate_read(rng, genome[20_000:25_001], 5000, 0.10, (30, 35, 35), False)[0]
+    g_win, g_bnd, g_tup = mapper.gli.fetch()
+    g_index = (OP.seq_offsets(len(genome), 256), g_bnd, g_tup)
+    gbytes = genome.tobytes() + b"\0" * 64
+    for reads in ([junk(1500), junk(300)], [junk(12), good, np.zeros(0, np.uint8), junk(40), genome[100:120].copy()], [good]):
+        batch = seed.ReadBatch(ctx, [r.tobytes() for r in reads])
+        res = mapper.align(batch)
+        out = mapper.fetch(res)
+        texts = mapper.records(res, [b"r%d" % i for i in range(len(reads))], [r.tobytes() for r in reads])
+        na = max(int(res.num_aln), 1)
+        for i, (rd, txt) in enumerate(zip(reads, texts)):
+            exp, unaligned = OP.map_read_lowacc(rd.tobytes(), gbytes, ik, ip, g_index) if len(rd) else ([], True)
+            f = txt.decode().split("\n")[0].split("\t")
+            assert f[0] == "r%d" % i
+            n_gpu = int(out["job_aln_off"][i * na + 1] - out["job_aln_off"][i * na]) if int(res.n_jobs) else 0
+            assert (n_gpu == 0) == unaligned, (i, n_gpu, unaligned)
+            assert bool(int(f[1]) & 4) == unaligned, (i, f[1])
+            if not unaligned:
+                a = int(out["job_aln_off"][i * na])
+                b = out["blocks"][int(out["block_off"][a]):int(out["block_off"][a + 1])]
+                assert np.array_equal(b, exp[0][0]["blocks"]), i
