@@ -13,7 +13,14 @@
 #include <math.h>
 #include <stdlib.h>
 #include <algorithm>
+#include <thread>
 
+struct lra_map_sig {                             // what a text of lra_map_records was made from
+  const void* blocks = nullptr; const void* runs = nullptr; int32_t n_reads = 0; uint64_t n_aln = 0; int32_t fmt = 0, pna = 0, hard = 0; const char* pass = nullptr;
+  bool operator==(const lra_map_sig& o) const {
+    return blocks == o.blocks && runs == o.runs && n_reads == o.n_reads && n_aln == o.n_aln && fmt == o.fmt && pna == o.pna && hard == o.hard && pass == o.pass;
+  }
+};
 struct lra_map_state {
   std::vector<uint64_t> chrom_pos;                 // Genome::header.pos, n_chrom + 1 entries
   uint64_t* d_chrom_pos = nullptr;
@@ -21,6 +28,7 @@ struct lra_map_state {
   uint64_t* d_gso = nullptr; uint64_t n_gwin = 0;  // its seqOffsets
   int gli_window = 0;
   std::vector<float> lut;                          // LogLookUpTable.h:9-15
+  std::string last_text; std::vector<uint64_t> last_off; lra_map_sig last_sig;   // lra_map_records: sizing call -> filling call
 };
 
 void lra_map_free(lra_ctx* ctx) {
@@ -306,6 +314,15 @@ extern "C" int lra_map_records(lra_ctx* ctx, const lra_map_result* res, const lr
   if (!ctx || !res || !o || !names || !reads || !read_len || !chrom_names || !len) return LRA_ERR_INVALID;
   lra_map_state* m = ctx->map;
   if (!m) return LRA_ERR_INVALID;
+  // two-call convention: the sizing call keeps its text, the filling call for the same result and format hands it over
+  const lra_map_sig sig{res->d_blocks, res->d_runs, res->n_reads, res->n_alignments, o->printFormat, o->PrintNumAln, o->hardClip, passthrough};
+  if (out && m->last_sig == sig && !m->last_text.empty() && cap >= m->last_text.size()) {
+    memcpy(out, m->last_text.data(), m->last_text.size());
+    *len = m->last_text.size();
+    if (rec_off) memcpy(rec_off, m->last_off.data(), m->last_off.size() * 8);
+    std::string().swap(m->last_text); m->last_sig = lra_map_sig{};
+    return LRA_OK;
+  }
   LRA_HIP_CHECK(ctx, hipSetDevice(ctx->device));
   const size_t nA = res->n_alignments, nJ = res->n_jobs;
   const int na = std::max(res->num_aln, 1);
@@ -317,71 +334,119 @@ extern "C" int lra_map_records(lra_ctx* ctx, const lra_map_result* res, const lr
       (rc = fetch(ctx, boff, res->d_block_off, nA ? nA + 1 : 0)) || (rc = fetch(ctx, blocks, res->d_blocks, 3 * (size_t)res->n_blocks)) ||
       (rc = fetch(ctx, roff, res->d_run_off, nA ? nA + 1 : 0)) || (rc = fetch(ctx, runs, res->d_runs, (size_t)res->n_runs)))
     return rc;
-  std::string text;
-  std::vector<std::string> cigars;
-  std::vector<lra_aln_record> recs;
-  std::vector<int32_t> seg_off, index;
-  std::vector<lra_aln_group> groups;
-  std::vector<char> buf;
-  char tmp[32];
-  for (int r = 0; r < res->n_reads; r++) {
-    if (rec_off) rec_off[r] = text.size();
-    recs.clear(); cigars.clear(); seg_off.assign(1, 0);
-    const bool unaligned = nJ == 0 || jo[(size_t)r * na + 1] == jo[(size_t)r * na];     // p == 0 left no SegAlignment (Map_lowacc.h:578-581)
-    if (!unaligned) {
-      size_t total = 0;
-      for (int p = 0; p < na; p++) total += (size_t)(jo[(size_t)r * na + p + 1] - jo[(size_t)r * na + p]);
-      cigars.reserve(total);                                              // the records keep pointers into these strings
-      for (int p = 0; p < na; p++) {
-        const size_t j = (size_t)r * na + p;
-        if (jo[j + 1] == jo[j]) continue;
-        for (uint64_t a = jo[j]; a < jo[j + 1]; a++) {
-          std::string cg;
-          for (uint64_t x = roff[a]; x < roff[a + 1]; x++) { snprintf(tmp, sizeof tmp, "%u%c", runs[x] >> 4, "=XID"[runs[x] & 15]); cg += tmp; }
-          cigars.push_back(std::move(cg));
-          const int32_t* c = &counts[18 * a];
-          lra_aln_record rec; memset(&rec, 0, sizeof rec);
-          rec.read_name = names[r]; rec.read = reads[r]; rec.qual = quals ? quals[r] : nullptr; rec.read_len = read_len[r];
-          rec.chrom = chrom_names[chrom[a]]; rec.genome_len = (uint32_t)(m->chrom_pos[chrom[a] + 1] - m->chrom_pos[chrom[a]]);
-          rec.cigar = cigars.back().c_str();
-          rec.strand = strand[a]; rec.supplementary = supp[a]; rec.is_secondary = sec[a];
-          rec.nm = c[0]; rec.nmm = c[1]; rec.nins = c[2]; rec.ndel = c[3]; rec.tdel = c[4]; rec.tins = c[5]; rec.nSmallDel = c[6]; rec.nMedDel = c[7]; rec.nLargeDel = c[8];
-          rec.nSmallIns = c[9]; rec.nMedIns = c[10]; rec.nLargeIns = c[11]; rec.pre_clip = c[12]; rec.suf_clip = c[13];
-          rec.q_start = (uint32_t)c[14]; rec.q_end = (uint32_t)c[15]; rec.t_start = (uint32_t)c[16]; rec.t_end = (uint32_t)c[17];
-          rec.value = fval[a]; rec.NumOfAnchors0 = n0[a]; rec.NumOfAnchors1 = n1[a];
-          const uint64_t b0 = boff[a], b1 = boff[a + 1];
-          rec.n_blocks = (int32_t)(b1 - b0);
-          rec.first_block_qpos = b1 > b0 ? (uint32_t)blocks[3 * b0] : 0;
-          rec.last_block_qend = b1 > b0 ? (uint32_t)(blocks[3 * (b1 - 1)] + blocks[3 * (b1 - 1) + 2]) : 0;
-          recs.push_back(rec);
+  // every read is independent: host threads take contiguous ranges of reads, each builds its own text; ranges are joined in read order
+  const int n_reads = res->n_reads;
+  unsigned hw = std::thread::hardware_concurrency();
+  int T = (int)std::min<unsigned>(hw ? hw : 1u, 16u);
+  T = std::max(1, std::min(T, n_reads / 32 + 1));
+  if (const char* e = getenv("LRA_RECORD_THREADS")) T = std::max(1, atoi(e));
+  std::vector<std::string> part(T);
+  std::vector<std::vector<uint64_t>> plen(T);
+  std::vector<int> prc(T, LRA_OK);
+  auto work = [&](int tix) {
+    const int lo = (int)((long)n_reads * tix / T), hi = (int)((long)n_reads * (tix + 1) / T);
+    std::string& text = part[tix];
+    std::vector<std::string> cigars;
+    std::vector<lra_aln_record> recs;
+    std::vector<int32_t> seg_off, index;
+    std::vector<lra_aln_group> groups;
+    std::vector<char> buf;
+    int rc = LRA_OK;
+    for (int r = lo; r < hi; r++) {
+      recs.clear(); cigars.clear(); seg_off.assign(1, 0);
+      const bool unaligned = nJ == 0 || jo[(size_t)r * na + 1] == jo[(size_t)r * na];     // p == 0 left no SegAlignment (Map_lowacc.h:578-581)
+      if (!unaligned) {
+        size_t total = 0;
+        for (int p = 0; p < na; p++) total += (size_t)(jo[(size_t)r * na + p + 1] - jo[(size_t)r * na + p]);
+        cigars.reserve(total);                                            // the records keep pointers into these strings
+        for (int p = 0; p < na; p++) {
+          const size_t j = (size_t)r * na + p;
+          if (jo[j + 1] == jo[j]) continue;
+          for (uint64_t a = jo[j]; a < jo[j + 1]; a++) {
+            std::string cg;
+            cg.reserve((size_t)(roff[a + 1] - roff[a]) * 4 + 8);
+            for (uint64_t x = roff[a]; x < roff[a + 1]; x++) {
+              char tmp[12]; int k = 11;
+              uint32_t v = runs[x] >> 4;
+              tmp[k] = "=XID"[runs[x] & 15];
+              do { tmp[--k] = (char)('0' + v % 10); v /= 10; } while (v);
+              cg.append(tmp + k, (size_t)(12 - k));
+            }
+            cigars.push_back(std::move(cg));
+            const int32_t* c = &counts[18 * a];
+            lra_aln_record rec; memset(&rec, 0, sizeof rec);
+            rec.read_name = names[r]; rec.read = reads[r]; rec.qual = quals ? quals[r] : nullptr; rec.read_len = read_len[r];
+            rec.chrom = chrom_names[chrom[a]]; rec.genome_len = (uint32_t)(m->chrom_pos[chrom[a] + 1] - m->chrom_pos[chrom[a]]);
+            rec.cigar = cigars.back().c_str();
+            rec.strand = strand[a]; rec.supplementary = supp[a]; rec.is_secondary = sec[a];
+            rec.nm = c[0]; rec.nmm = c[1]; rec.nins = c[2]; rec.ndel = c[3]; rec.tdel = c[4]; rec.tins = c[5]; rec.nSmallDel = c[6]; rec.nMedDel = c[7]; rec.nLargeDel = c[8];
+            rec.nSmallIns = c[9]; rec.nMedIns = c[10]; rec.nLargeIns = c[11]; rec.pre_clip = c[12]; rec.suf_clip = c[13];
+            rec.q_start = (uint32_t)c[14]; rec.q_end = (uint32_t)c[15]; rec.t_start = (uint32_t)c[16]; rec.t_end = (uint32_t)c[17];
+            rec.value = fval[a]; rec.NumOfAnchors0 = n0[a]; rec.NumOfAnchors1 = n1[a];
+            const uint64_t b0 = boff[a], b1 = boff[a + 1];
+            rec.n_blocks = (int32_t)(b1 - b0);
+            rec.first_block_qpos = b1 > b0 ? (uint32_t)blocks[3 * b0] : 0;
+            rec.last_block_qend = b1 > b0 ? (uint32_t)(blocks[3 * (b1 - 1)] + blocks[3 * (b1 - 1) + 2]) : 0;
+            recs.push_back(rec);
+          }
+          seg_off.push_back((int32_t)recs.size());
         }
-        seg_off.push_back((int32_t)recs.size());
       }
+      uint64_t need = 0;
+      if (unaligned || recs.empty()) {
+        lra_aln_record un; memset(&un, 0, sizeof un);
+        un.read_name = names[r]; un.read = reads[r]; un.qual = quals ? quals[r] : nullptr; un.read_len = read_len[r];
+        lra_output_read(nullptr, nullptr, 0, nullptr, o->PrintNumAln, (char)o->printFormat, o->hardClip, passthrough, 1, &un, nullptr, 0, &need);
+        buf.resize(need + 1);
+        if ((rc = lra_output_read(nullptr, nullptr, 0, nullptr, o->PrintNumAln, (char)o->printFormat, o->hardClip, passthrough, 1, &un, buf.data(), need, &need))) break;
+      } else {
+        const int n = (int)seg_off.size() - 1;
+        groups.assign(n, lra_aln_group()); index.assign(n, 0);
+        if ((rc = lra_group_alignments(recs.data(), seg_off.data(), n, groups.data())) || (rc = lra_order_alignments(groups.data(), n, recs.data(), index.data(), 0)) ||
+            (rc = lra_simple_mapqv(groups.data(), index.data(), n, recs.data(), o->bypassClustering, o->readType == LRA_READ_CLR, o->readType == LRA_READ_ONT, o->globalK)))
+          break;
+        lra_output_read(groups.data(), index.data(), n, recs.data(), o->PrintNumAln, (char)o->printFormat, o->hardClip, passthrough, 0, nullptr, nullptr, 0, &need);
+        buf.resize(need + 1);
+        if ((rc = lra_output_read(groups.data(), index.data(), n, recs.data(), o->PrintNumAln, (char)o->printFormat, o->hardClip, passthrough, 0, nullptr, buf.data(), need,
+                                  &need))) break;
+      }
+      text.append(buf.data(), need);
+      plen[tix].push_back(need);
     }
-    uint64_t need = 0;
-    if (unaligned || recs.empty()) {
-      lra_aln_record un; memset(&un, 0, sizeof un);
-      un.read_name = names[r]; un.read = reads[r]; un.qual = quals ? quals[r] : nullptr; un.read_len = read_len[r];
-      lra_output_read(nullptr, nullptr, 0, nullptr, o->PrintNumAln, (char)o->printFormat, o->hardClip, passthrough, 1, &un, nullptr, 0, &need);
-      buf.resize(need + 1);
-      if ((rc = lra_output_read(nullptr, nullptr, 0, nullptr, o->PrintNumAln, (char)o->printFormat, o->hardClip, passthrough, 1, &un, buf.data(), need, &need))) return rc;
-    } else {
-      const int n = (int)seg_off.size() - 1;
-      groups.assign(n, lra_aln_group()); index.assign(n, 0);
-      if ((rc = lra_group_alignments(recs.data(), seg_off.data(), n, groups.data())) || (rc = lra_order_alignments(groups.data(), n, recs.data(), index.data(), 0)) ||
-          (rc = lra_simple_mapqv(groups.data(), index.data(), n, recs.data(), o->bypassClustering, o->readType == LRA_READ_CLR, o->readType == LRA_READ_ONT, o->globalK)))
-        return rc;
-      lra_output_read(groups.data(), index.data(), n, recs.data(), o->PrintNumAln, (char)o->printFormat, o->hardClip, passthrough, 0, nullptr, nullptr, 0, &need);
-      buf.resize(need + 1);
-      if ((rc = lra_output_read(groups.data(), index.data(), n, recs.data(), o->PrintNumAln, (char)o->printFormat, o->hardClip, passthrough, 0, nullptr, buf.data(), need,
-                                &need))) return rc;
-    }
-    text.append(buf.data(), need);
+    prc[tix] = rc;
+  };
+  if (T == 1) work(0);
+  else {
+    std::vector<std::thread> th;
+    for (int t = 0; t < T; t++) th.emplace_back(work, t);
+    for (auto& x : th) x.join();
   }
+  for (int t = 0; t < T; t++) if (prc[t]) return prc[t];
+  std::string& text = m->last_text;
+  text.clear();
+  { size_t tot = 0; for (auto& x : part) tot += x.size(); text.reserve(tot); }
+  {
+    int r = 0;
+    uint64_t at = 0;
+    for (int t = 0; t < T; t++) {
+      for (uint64_t l : plen[t]) { if (rec_off) rec_off[r] = at; at += l; r++; }
+      text += part[t];
+      std::string().swap(part[t]);
+    }
+  }
+  m->last_sig = sig;
   if (rec_off) rec_off[res->n_reads] = text.size();
   *len = text.size();
-  if (!out) return LRA_OK;
+  if (!out) {                                                            // sizing call: remember the offsets too
+    m->last_off.assign((size_t)res->n_reads + 1, 0);
+    uint64_t at = 0; size_t r = 0;
+    for (int t = 0; t < T; t++) for (uint64_t l : plen[t]) { m->last_off[r++] = at; at += l; }
+    m->last_off[res->n_reads] = at;
+    return LRA_OK;
+  }
+  m->last_sig = lra_map_sig{};
   if (cap < text.size()) return LRA_ERR_INVALID;
   memcpy(out, text.data(), text.size());
+  std::string().swap(m->last_text);
   return LRA_OK;
 }
