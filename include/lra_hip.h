@@ -720,7 +720,7 @@ typedef struct lra_map_opts {
   int32_t localK, localW, localMaxFreq, localIndexWindow;
   int32_t refineBand, localMatch, localMismatch, localIndel, localBand;
   int32_t refineSpaceDist; float anchorstoosparse; int32_t splitdist, window;
-  float second_anchorbonus; int32_t bypassClustering, skipBandedRefine;
+  float second_anchorbonus; int32_t bypassClustering, skipBandedRefine, refineBreakpoint;   /* refineBreakpoint: --refineBreakpoints (lra.cpp:262) */
   lra_clean_opts clean; lra_sdp_opts sdp;
   int32_t readType, hardClip, PrintNumAln, printFormat;   /* printFormat: 's' SAM, 'p' / 'P' PAF, 'b' BED */
 } lra_map_opts;

@@ -10,6 +10,7 @@
 // CalculateStatistics.
 #include "common.h"
 #include "seed_state.h"
+#include "scan.h"
 #include <math.h>
 #include <stdlib.h>
 #include <algorithm>
@@ -79,6 +80,56 @@ __global__ void k_mark_strands(uint64_t n_slots, int num_aln, int n_reads, const
   if (s >= n_slots || status[s]) return;
   const uint32_t r = (uint32_t)(s / (uint64_t)num_aln);
   for (uint32_t k = 0; k < n_split[s]; k++) active[(sp_strand[chain_start[s] + k] ? n_reads : 0) + r] = 1;
+}
+
+// ---- RefineBreakpoint between consecutive SegAlignments of a job (Map_lowacc.h:586-596), one round per junction index
+__global__ void k_bp_params(int n, const uint32_t* __restrict__ jl, const uint32_t* __restrict__ jr, const uint64_t* __restrict__ boff,
+                            const int32_t* __restrict__ strand, const uint64_t* __restrict__ q_off, const int32_t* __restrict__ q_len,
+                            const uint64_t* __restrict__ t_off, const int64_t* __restrict__ t_len, uint32_t* l_cnt, uint32_t* r_cnt, int32_t* read_len,
+                            int32_t* l_strand, uint64_t* l_read, uint64_t* l_coff, int32_t* l_clen, int32_t* r_strand, uint64_t* r_read, uint64_t* r_coff,
+                            int32_t* r_clen) {
+  const int j = blockIdx.x * blockDim.x + threadIdx.x;
+  if (j >= n) return;
+  const uint32_t a = jl[j], b = jr[j];
+  l_cnt[j] = (uint32_t)(boff[a + 1] - boff[a]); r_cnt[j] = (uint32_t)(boff[b + 1] - boff[b]);
+  read_len[j] = q_len[a];
+  l_strand[j] = strand[a]; l_read[j] = q_off[a]; l_coff[j] = t_off[a]; l_clen[j] = (int32_t)t_len[a];
+  r_strand[j] = strand[b]; r_read[j] = q_off[b]; r_coff[j] = t_off[b]; r_clen[j] = (int32_t)t_len[b];
+}
+__global__ void __launch_bounds__(64) k_bp_gather(int n, const uint32_t* __restrict__ jl, const uint32_t* __restrict__ jr, const uint64_t* __restrict__ boff,
+                                                  const int32_t* __restrict__ blocks, const uint64_t* __restrict__ l_off, const uint64_t* __restrict__ r_off,
+                                                  int32_t* l_blocks, int32_t* r_blocks) {
+  const int j = blockIdx.x >> 1, side = blockIdx.x & 1;
+  if (j >= n) return;
+  const uint32_t a = side ? jr[j] : jl[j];
+  const int32_t* s = blocks + 3 * boff[a];
+  int32_t* d = side ? r_blocks + 3 * r_off[j] : l_blocks + 3 * l_off[j];
+  const uint64_t w = 3 * (boff[a + 1] - boff[a]);
+  for (uint64_t x = threadIdx.x; x < w; x += 64) d[x] = s[x];
+}
+__global__ void k_bp_counts(uint64_t nA, const uint64_t* __restrict__ boff, uint32_t* cnt, int32_t* touched) {
+  const uint64_t a = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (a >= nA) return;
+  cnt[a] = (uint32_t)(boff[a + 1] - boff[a]); touched[a] = -1;
+}
+__global__ void k_bp_touch(int n, const uint32_t* __restrict__ jl, const uint32_t* __restrict__ jr, const int32_t* __restrict__ l_n, const int32_t* __restrict__ r_n,
+                           uint32_t* cnt, int32_t* touched) {
+  const int j = blockIdx.x * blockDim.x + threadIdx.x;
+  if (j >= n) return;
+  cnt[jl[j]] = (uint32_t)l_n[j]; touched[jl[j]] = 2 * j;
+  cnt[jr[j]] = (uint32_t)r_n[j]; touched[jr[j]] = 2 * j + 1;
+}
+__global__ void __launch_bounds__(64) k_bp_scatter(uint64_t nA, const uint64_t* __restrict__ old_off, const int32_t* __restrict__ old_blocks,
+                                                   const uint64_t* __restrict__ new_off, const int32_t* __restrict__ touched, const int32_t* __restrict__ l_blocks,
+                                                   const uint64_t* __restrict__ l_off, const int32_t* __restrict__ r_blocks, const uint64_t* __restrict__ r_off,
+                                                   int32_t* new_blocks) {
+  const uint64_t a = blockIdx.x;
+  if (a >= nA) return;
+  const int32_t tch = touched[a];
+  const int32_t* s = tch < 0 ? old_blocks + 3 * old_off[a] : (tch & 1) ? r_blocks + 3 * r_off[tch >> 1] : l_blocks + 3 * l_off[tch >> 1];
+  int32_t* d = new_blocks + 3 * new_off[a];
+  const uint64_t w = 3 * (new_off[a + 1] - new_off[a]);
+  for (uint64_t x = threadIdx.x; x < w; x += 64) d[x] = s[x];
 }
 
 // tuple words the local compare stage reads (the algorithmic bytes of local_compare): sum over tasks of both list lengths
@@ -161,6 +212,71 @@ extern "C" int lra_ctx_build_local_index(lra_ctx* ctx, int k, int w, int window,
   LRA_HIP_CHECK(ctx, hipMalloc((void**)&m->d_gso, gso.size() * 8));
   LRA_HIP_CHECK(ctx, hipMemcpy(m->d_gso, gso.data(), gso.size() * 8, hipMemcpyHostToDevice));
   m->n_gwin = r.n_windows;
+  return LRA_OK;
+}
+
+// RefineBreakpoint(read, genome, *SegAlignment[s], *SegAlignment[s-1], opts) for s = 1, 2, ... of every job: round k runs junction k of all
+// jobs that have one (segment k is "left", segment k - 1 -- already refined against k - 2 in the round before -- is "right").
+static int refine_breakpoints(lra_ctx* ctx, uint64_t nJ, uint64_t nA, const uint64_t* d_job_aln_off, const int32_t* d_strand, const uint64_t* q_off, const int32_t* q_len,
+                              const uint64_t* t_off, const int64_t* t_len, const char* strands, const char* genome, lra_refine_result* fres) {
+  hipStream_t st = ctx->stream;
+  std::vector<uint64_t> jo(nJ + 1);
+  LRA_HIP_CHECK(ctx, hipMemcpyAsync(jo.data(), d_job_aln_off, (nJ + 1) * 8, hipMemcpyDeviceToHost, st));
+  LRA_HIP_CHECK(ctx, hipStreamSynchronize(st));
+  uint64_t max_seg = 0;
+  for (uint64_t j = 0; j < nJ; j++) max_seg = std::max(max_seg, jo[j + 1] - jo[j]);
+  const int32_t* cur_blocks = fres->d_blocks; const uint64_t* cur_off = fres->d_block_off;
+  uint64_t n_blocks = fres->n_blocks;
+  auto al = [](size_t x) { return (x + 255) & ~(size_t)255; };
+  for (uint64_t k = 1; k < max_seg; k++) {
+    std::vector<uint32_t> hl, hr;
+    for (uint64_t j = 0; j < nJ; j++) if (jo[j + 1] - jo[j] > k) { hl.push_back((uint32_t)(jo[j] + k)); hr.push_back((uint32_t)(jo[j] + k - 1)); }
+    const int n = (int)hl.size();
+    if (!n) break;
+    const size_t n1 = (size_t)n + 2;
+    char* w = (char*)lra_ensure(ctx, 72, al(n1 * 4) * 9 + al(n1 * 8) * 6 + al((nA + 2) * 4) * 2 + al((nA + 2) * 8) + 4096);
+    if (!w) return LRA_ERR_NOMEM;
+    auto take = [&](size_t bytes) { char* r = w; w += al(bytes); return r; };
+    uint32_t* jl = (uint32_t*)take(n1 * 4); uint32_t* jr = (uint32_t*)take(n1 * 4); uint32_t* l_cnt = (uint32_t*)take(n1 * 4); uint32_t* r_cnt = (uint32_t*)take(n1 * 4);
+    int32_t* read_len = (int32_t*)take(n1 * 4); int32_t* l_strand = (int32_t*)take(n1 * 4); int32_t* r_strand = (int32_t*)take(n1 * 4);
+    int32_t* l_clen = (int32_t*)take(n1 * 4); int32_t* r_clen = (int32_t*)take(n1 * 4);
+    uint64_t* l_read = (uint64_t*)take(n1 * 8); uint64_t* r_read = (uint64_t*)take(n1 * 8); uint64_t* l_coff = (uint64_t*)take(n1 * 8); uint64_t* r_coff = (uint64_t*)take(n1 * 8);
+    uint64_t* l_off = (uint64_t*)take(n1 * 8); uint64_t* r_off = (uint64_t*)take(n1 * 8);
+    uint32_t* cnt = (uint32_t*)take((nA + 2) * 4); int32_t* touched = (int32_t*)take((nA + 2) * 4); uint64_t* new_off_tmp = (uint64_t*)take((nA + 2) * 8);
+    LRA_HIP_CHECK(ctx, hipMemcpyAsync(jl, hl.data(), (size_t)n * 4, hipMemcpyHostToDevice, st));
+    LRA_HIP_CHECK(ctx, hipMemcpyAsync(jr, hr.data(), (size_t)n * 4, hipMemcpyHostToDevice, st));
+    hipLaunchKernelGGL(k_bp_params, dim3((n + 255) / 256), dim3(256), 0, st, n, jl, jr, cur_off, d_strand, q_off, q_len, t_off, t_len, l_cnt, r_cnt, read_len, l_strand,
+                       l_read, l_coff, l_clen, r_strand, r_read, r_coff, r_clen);
+    int rc;
+    if ((rc = lra_exclusive_scan<uint32_t>(ctx, n, l_cnt, l_off)) || (rc = lra_exclusive_scan<uint32_t>(ctx, n, r_cnt, r_off))) return rc;
+    uint64_t tl = 0, tr = 0;
+    LRA_HIP_CHECK(ctx, hipMemcpyAsync(&tl, l_off + n, 8, hipMemcpyDeviceToHost, st));
+    LRA_HIP_CHECK(ctx, hipMemcpyAsync(&tr, r_off + n, 8, hipMemcpyDeviceToHost, st));
+    LRA_HIP_CHECK(ctx, hipStreamSynchronize(st));
+    int32_t* lb = (int32_t*)lra_ensure(ctx, 73, al((tl + 1) * 12) + al((tr + 1) * 12) + 512);
+    if (!lb) return LRA_ERR_NOMEM;
+    int32_t* rb = (int32_t*)((char*)lb + al((tl + 1) * 12));
+    hipLaunchKernelGGL(k_bp_gather, dim3(2 * n), dim3(64), 0, st, n, jl, jr, cur_off, cur_blocks, l_off, r_off, lb, rb);
+    lra_breakpoint_result br;
+    if ((rc = lra_refine_breakpoint_batch(ctx, n, read_len, strands, genome, lb, l_off, l_strand, l_read, l_coff, l_clen, rb, r_off, r_strand, r_read, r_coff, r_clen, &br)))
+      return rc;
+    hipLaunchKernelGGL(k_bp_counts, dim3((unsigned)((nA + 255) / 256)), dim3(256), 0, st, nA, cur_off, cnt, touched);
+    hipLaunchKernelGGL(k_bp_touch, dim3((n + 255) / 256), dim3(256), 0, st, n, jl, jr, br.d_l_n, br.d_r_n, cnt, touched);
+    if ((rc = lra_exclusive_scan<uint32_t>(ctx, (long)nA, cnt, new_off_tmp))) return rc;
+    uint64_t nb = 0;
+    LRA_HIP_CHECK(ctx, hipMemcpyAsync(&nb, new_off_tmp + nA, 8, hipMemcpyDeviceToHost, st));
+    LRA_HIP_CHECK(ctx, hipStreamSynchronize(st));
+    const int slot = 74 + (int)(k & 1);                                   // ping-pong: the other slot may hold the current blocks
+    char* nbuf = (char*)lra_ensure(ctx, slot, al((nb + 1) * 12) + al((nA + 2) * 8) + 512);
+    if (!nbuf) return LRA_ERR_NOMEM;
+    int32_t* new_blocks = (int32_t*)nbuf; uint64_t* new_off = (uint64_t*)(nbuf + al((nb + 1) * 12));
+    LRA_HIP_CHECK(ctx, hipMemcpyAsync(new_off, new_off_tmp, (nA + 1) * 8, hipMemcpyDeviceToDevice, st));
+    hipLaunchKernelGGL(k_bp_scatter, dim3((unsigned)nA), dim3(64), 0, st, nA, cur_off, cur_blocks, new_off, touched, br.d_l_blocks, br.d_l_off, br.d_r_blocks, br.d_r_off,
+                       new_blocks);
+    LRA_HIP_CHECK(ctx, hipStreamSynchronize(st));
+    cur_blocks = new_blocks; cur_off = new_off; n_blocks = nb;
+  }
+  fres->d_blocks = cur_blocks; fres->d_block_off = cur_off; fres->n_blocks = n_blocks;
   return LRA_OK;
 }
 
@@ -276,6 +392,7 @@ extern "C" int lra_map_reads_lowacc_batch(lra_ctx* ctx, int n_reads, const char*
       LRA_HIP_CHECK(ctx, hipMemcpyAsync(keep, fres.d_status, nA * 4, hipMemcpyDeviceToDevice, st));
       fres.d_status = keep;
     }
+    if (o->refineBreakpoint && (rc = refine_breakpoints(ctx, nJ, nA, ares.d_job_aln_off, ares.d_strand, q_off, q_len, t_off, t_len, both, genome, &fres))) return rc;
     if ((rc = lra_calculate_statistics_batch(ctx, (int)nA, fres.d_blocks, fres.d_block_off, both, q_off, q_len, genome, t_off, m->lut.data(), (int)m->lut.size(), &tres)))
       return rc;
   }

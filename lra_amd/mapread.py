@@ -56,6 +56,7 @@ class LowAccOptions:
     alnthres: float = 0.65
     SecondCleanMaxDiag: int = 100
     bypassClustering: bool = True
+    refineBreakpoint: bool = False     # --refineBreakpoints (lra.cpp:262)
     read_type: str = "ont"
     hardClip: bool = True
     PrintNumAln: int = 1
@@ -94,7 +95,7 @@ class MapOpts(C.Structure):
     _fields_ = ([(n, C.c_int32) for n in ("globalK", "globalW", "globalMaxFreq", "localK", "localW", "localMaxFreq", "localIndexWindow", "refineBand",
                                           "localMatch", "localMismatch", "localIndel", "localBand", "refineSpaceDist")] +
                 [("anchorstoosparse", C.c_float), ("splitdist", C.c_int32), ("window", C.c_int32), ("second_anchorbonus", C.c_float),
-                 ("bypassClustering", C.c_int32), ("skipBandedRefine", C.c_int32), ("clean", cluster.CleanOpts), ("sdp", chain.SdpOpts)] +
+                 ("bypassClustering", C.c_int32), ("skipBandedRefine", C.c_int32), ("refineBreakpoint", C.c_int32), ("clean", cluster.CleanOpts), ("sdp", chain.SdpOpts)] +
                 [(n, C.c_int32) for n in ("readType", "hardClip", "PrintNumAln", "printFormat")])
 
 
@@ -168,7 +169,7 @@ class LowAccMapper:
         for n in ("globalK", "globalW", "globalMaxFreq", "localK", "localW", "localMaxFreq", "localIndexWindow", "refineBand", "localMatch", "localMismatch",
                   "localIndel", "refineSpaceDist", "anchorstoosparse", "splitdist", "window", "second_anchorbonus"):
             setattr(m, n, getattr(o, n))
-        m.bypassClustering = int(o.bypassClustering)
+        m.bypassClustering = int(o.bypassClustering); m.refineBreakpoint = int(o.refineBreakpoint)
         m.clean.globalK = o.globalK; m.clean.bypassClustering = int(o.bypassClustering); m.clean.SecondCleanMaxDiag = o.SecondCleanMaxDiag
         m.sdp.globalK = o.globalK; m.sdp.rate = o.initial_anchorbonus; m.sdp.alnthres = o.alnthres
         m.readType = READ_TYPES[o.read_type]; m.hardClip = int(o.hardClip); m.PrintNumAln = o.PrintNumAln; m.printFormat = ord(o.printFormat)

@@ -8,7 +8,7 @@ import oracle_lib as O
 
 ONT = dict(globalK=17, globalW=10, globalMaxFreq=150, localK=10, localW=5, localMaxFreq=15, localIndexWindow=256, refineBand=7, match=4, mismatch=-1,
            indel=-2, refineSpaceDist=30000, anchorstoosparse=0.005, splitdist=50000, window=100, initial_anchorbonus=20.0, second_anchorbonus=2.0,
-           alnthres=0.65, SecondCleanMaxDiag=100)
+           alnthres=0.65, SecondCleanMaxDiag=100, refineBreakpoint=False)
 CLR = dict(ONT, globalK=15, globalMaxFreq=250, refineBand=20, initial_anchorbonus=15.0, second_anchorbonus=6.0, alnthres=0.50, SecondCleanMaxDiag=120)
 
 _COMP = np.zeros(256, np.uint8)
@@ -123,12 +123,20 @@ def map_read_lowacc(read: bytes, genome: bytes, idx_key, idx_pos, g_index, opts=
         out = []
         for s in segs:
             sb = fwd if s["strand"] == 0 else rc
-            # a14, a16 (Map_lowacc.h:582-599)
+            # a14 (Map_lowacc.h:582-585)
             refined, rst = O.indel_refine(s["blocks"], sb, genome, o["refineBand"], o["match"], o["mismatch"], o["indel"])
-            d = dict(s, a13_blocks=s["blocks"], blocks=refined, refine_status=rst)
-            if stats and rst == 0 and len(refined):
-                d["stats"] = O.calculate_statistics(refined, sb, genome)
-            out.append(d)
+            out.append(dict(s, a13_blocks=s["blocks"], blocks=refined, refine_status=rst))
+        if o["refineBreakpoint"]:                                          # a15 (Map_lowacc.h:586-596): segments come right to left on the read
+            for si in range(1, len(out)):
+                l, r = out[si], out[si - 1]
+                ret, lb, rb = O.refine_breakpoint(L, l["blocks"], l["strand"], fwd if l["strand"] == 0 else rc, genome[:G], r["blocks"], r["strand"],
+                                                  fwd if r["strand"] == 0 else rc, genome[:G])
+                if ret >= 0:
+                    l["blocks"], r["blocks"] = lb, rb
+                l["breakpoint"] = ret
+        for d in out:                                                      # a16 (Map_lowacc.h:597-599)
+            if stats and d["refine_status"] == 0 and len(d["blocks"]):
+                d["stats"] = O.calculate_statistics(d["blocks"], fwd if d["strand"] == 0 else rc, genome)
         alignments.append(out)
         if p == 0 and not out:
             return alignments, True                                        # Map_lowacc.h:578-581

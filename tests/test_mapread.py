@@ -81,7 +81,7 @@ def test_map_reads_to_sam(ctx):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("preset", ["ont", "clr"])
+@pytest.mark.parametrize("preset", ["ont", "clr", "ont-bp"])
 def test_map_reads_match_oracle_pipeline(ctx, oracle, preset):
     """The C boundary against the oracle's stage functions composed on the CPU (tests/oracle_pipeline.py): every SegAlignment of every
     primary chain -- strand, Supplymentary, NumOfAnchors0/1, FirstSDPValue, the refined blocks -- bit for bit, on plain reads, reads with a
@@ -89,9 +89,9 @@ def test_map_reads_match_oracle_pipeline(ctx, oracle, preset):
     import oracle_pipeline as OP
     from lra_amd import seed, mapread
     genome = synth.make_genome(500_000, seed=31, repeat_frac=0.25, n_families=3)
-    o = mapread.LowAccOptions() if preset == "ont" else mapread.clr_options()
-    oo = OP.ONT if preset == "ont" else OP.CLR
-    err, mix = (0.10, (30, 35, 35)) if preset == "ont" else (0.15, (20, 30, 50))
+    o = mapread.clr_options() if preset == "clr" else mapread.LowAccOptions(refineBreakpoint=(preset == "ont-bp"))     # ont-bp: --refineBreakpoints
+    oo = OP.CLR if preset == "clr" else dict(OP.ONT, refineBreakpoint=(preset == "ont-bp"))
+    err, mix = (0.15, (20, 30, 50)) if preset == "clr" else (0.10, (30, 35, 35))
     ik, ip = synth.build_global_index(genome, o.globalK, o.globalW, 100)
     reads, truth = synth.simulate_reads(genome, 10, 8000, 2500, err, mix, seed=11)
     rng = np.random.default_rng(2)
@@ -108,7 +108,7 @@ def test_map_reads_match_oracle_pipeline(ctx, oracle, preset):
     g_win, g_bnd, g_tup = mapper.gli.fetch()
     g_index = (OP.seq_offsets(len(genome), 256), g_bnd, g_tup)
     gbytes = genome.tobytes() + b"\0" * 64
-    n_seg = n_supp = n_rev = n_multi = 0
+    n_seg = n_supp = n_rev = n_multi = n_bp = 0
     for r, rd in enumerate(reads):
         exp, unaligned = OP.map_read_lowacc(rd.tobytes(), gbytes, ik, ip, g_index, oo)
         for p in range(na):
@@ -121,11 +121,12 @@ def test_map_reads_match_oracle_pipeline(ctx, oracle, preset):
                 assert out["refine_status"][a] == s["refine_status"] == 0, (r, p, a)
                 b = out["blocks"][int(out["block_off"][a]):int(out["block_off"][a + 1])]
                 assert np.array_equal(b, s["blocks"]), (r, p, a, len(b), len(s["blocks"]))
-                n_seg += 1; n_supp += int(s["supp"]); n_rev += int(s["strand"])
+                n_seg += 1; n_supp += int(s["supp"]); n_rev += int(s["strand"]); n_bp += int(s.get("breakpoint", 0) == 1)
             n_multi += len(e) > 1
         if unaligned:
             assert out["job_aln_off"][r * na + 1] == out["job_aln_off"][r * na], r
     assert n_seg >= len(reads) - 1 and n_supp >= 2 and n_rev >= 3 and n_multi >= 2, (n_seg, n_supp, n_rev, n_multi)
+    assert preset != "ont-bp" or n_bp >= 1, n_bp
 
 
 def test_oracle_pipeline_sanity(oracle):
