@@ -108,8 +108,10 @@ __device__ void second_round(const CleanArgs& A, uint64_t base, const uint32_t* 
   }
 }
 
+constexpr int CLEAN_LANES = 16;
 __global__ void __launch_bounds__(64) clean_kernel(CleanArgs A) {
-  const long seg = (long)blockIdx.x * 64 + threadIdx.x;
+  if (threadIdx.x >= CLEAN_LANES) return;                                // serial scans with dependent loads: fewer lanes per wave, more waves
+  const long seg = (long)blockIdx.x * CLEAN_LANES + threadIdx.x;
   if (seg >= 2L * A.n_reads) return;
   const int r = (int)(seg >> 1), strand = (int)(seg & 1);
   const uint64_t m0 = A.match_off[r], mf = m0 + A.n_forward[r], m1 = A.match_off[r + 1];
@@ -314,7 +316,7 @@ extern "C" int lra_clean_matches_batch(lra_ctx* ctx, const lra_clean_opts* opts,
   lra_time_end(ctx);
   // ---- clean
   lra_time_begin(ctx, "clean");
-  hipLaunchKernelGGL(clean_kernel, dim3((2 * n_reads + 63) / 64), dim3(64), 0, st, A);
+  hipLaunchKernelGGL(clean_kernel, dim3((2 * n_reads + CLEAN_LANES - 1) / CLEAN_LANES), dim3(64), 0, st, A);
   lra_time_end(ctx);
   if (lra_exclusive_scan<uint32_t>(ctx, 2L * n_reads, A.seg_ncl, seg_coff)) return LRA_ERR_HIP;
   uint64_t ncl = 0;

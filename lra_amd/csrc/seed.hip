@@ -713,6 +713,7 @@ __global__ void __launch_bounds__(64) match_capacity_kernel(int n_reads, const u
 // (ii) the alternating two-ended walk of CompareLists.h:43-143, one lane per read.  T[ts] and
 // T[te-1] live in registers and are refreshed from the prefetched neighbourhood arrays whenever
 // ts / te jump to a bound; only the raw-key run skip (:101) still reads the index itself.
+constexpr int FLAT_LANES = 16;
 __global__ void __launch_bounds__(64) compare_kernel(int n_reads, const uint64_t* __restrict__ mm_off, const uint64_t* __restrict__ mm_key,
                                                      const uint32_t* __restrict__ lbA, const uint32_t* __restrict__ ubA,
                                                      const uint64_t* __restrict__ tkLbA, const uint64_t* __restrict__ tkLbm1A,
@@ -720,7 +721,8 @@ __global__ void __launch_bounds__(64) compare_kernel(int n_reads, const uint64_t
                                                      const uint64_t* __restrict__ idx_key, long n_idx, long maxFreq,
                                                      const uint64_t* __restrict__ match_off, uint32_t* __restrict__ match_qi,
                                                      uint32_t* __restrict__ match_ti, uint64_t* __restrict__ counts) {
-  const int r = blockIdx.x * 64 + threadIdx.x;
+  if (threadIdx.x >= FLAT_LANES) return;                                 // a chain of dependent loads per read: fewer lanes per wave, more waves
+  const int r = blockIdx.x * FLAT_LANES + threadIdx.x;
   if (r >= n_reads) return;
   const uint64_t* qk = mm_key + mm_off[r];
   const uint32_t* LB = lbA + mm_off[r];
@@ -1107,7 +1109,7 @@ extern "C" int lra_seed_batch(lra_ctx* ctx, int n_reads, const char* d_seq, cons
     s->cap_tmp = c;
   }
   lra_time_begin(ctx, "compare");
-  hipLaunchKernelGGL(compare_kernel, dim3(nb), dim3(64), 0, st, n_reads, s->mm_off, s->mm_key, s->lb, s->ub, s->tk_lb, s->tk_lbm1, s->tk_ubm1, s->idx_key,
+  hipLaunchKernelGGL(compare_kernel, dim3((n_reads + FLAT_LANES - 1) / FLAT_LANES), dim3(64), 0, st, n_reads, s->mm_off, s->mm_key, s->lb, s->ub, s->tk_lb, s->tk_lbm1, s->tk_ubm1, s->idx_key,
                      (long)s->n_idx, (long)max_freq, s->cap_off, s->tmp_qi, s->tmp_ti, s->counts64);
   lra_time_end(ctx);
   if (lra_exclusive_scan<uint64_t>(ctx, (long)n_reads, s->counts64, s->match_off)) return LRA_ERR_HIP;
