@@ -77,9 +77,11 @@ struct IRArgs {
 // The grouping loop of IndelRefine.h:79-211 / :761-767.  Only blocks[startBlock] and
 // blocks[endBlock] are ever modified by the reference, and only the "alt" remainder survives
 // an iteration, so one override record replaces the in-place edits.
+constexpr int SEG_LANES = 16;             // one lane per alignment walks its blocks: fewer lanes per wave, more waves
 template <bool EMIT>
 __global__ void __launch_bounds__(64) ir_segment(IRArgs A) {
-  const int a = blockIdx.x * 64 + threadIdx.x;
+  if (threadIdx.x >= SEG_LANES) return;
+  const int a = blockIdx.x * SEG_LANES + threadIdx.x;
   if (a >= A.n_aln) return;
   const long nIn = (long)(A.block_off[a + 1] - A.block_off[a]);
   const int32_t* bin = A.blocks_in + 3 * A.block_off[a];
@@ -851,7 +853,7 @@ extern "C" int lra_indel_refine_batch(lra_ctx* ctx, int n_aln, const int32_t* d_
   uint32_t* s_nchunk = ar.get<uint32_t>(capSeg); uint64_t* chunk_off = ar.get<uint64_t>(capSeg + 1);
   if (!out_block_off || !chunk_off) return lra_set_err(ctx, LRA_ERR_NOMEM, "arena accounting");
 
-  const int nbA = (n_aln + 63) / 64;
+  const int nbA = (n_aln + SEG_LANES - 1) / SEG_LANES;
   // ---- segments: count, scan, emit
   lra_time_begin(ctx, "ir_segment");
   hipLaunchKernelGGL(ir_segment<false>, dim3(nbA), dim3(64), 0, st, A);

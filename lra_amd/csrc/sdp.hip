@@ -933,8 +933,10 @@ struct TraceArgs {
   const uint32_t* status;
 };
 
+constexpr int TRACE_LANES = 16;           // a serial walk with dependent loads per read: fewer lanes per wave, more waves
 __global__ void __launch_bounds__(64) sdp_trace(TraceArgs a) {
-  const int rr = blockIdx.x * 64 + threadIdx.x;
+  if (threadIdx.x >= TRACE_LANES) return;
+  const int rr = blockIdx.x * TRACE_LANES + threadIdx.x;
   if (rr >= a.n) return;
   const int r = a.r0 + rr;
   const uint64_t f0 = a.fragOff[r];
@@ -1281,7 +1283,7 @@ int sdp_run(lra_ctx* ctx, int n_reads, const uint64_t* d_cluster_off, const uint
       ta.cq = cq; ta.ct = ct; ta.clen = clen; ta.cstrand = cstrand; ta.fstrand = fstrand;
       ta.boxes = boxes; ta.globalK = opts->globalK; ta.fqe = fqe; ta.fte = fte; ta.numAnchors = d_num_anchors; ta.chainNum = chainNum;
       lra_time_begin(ctx, ctx->sdp_inner ? "sdp_inner_trace" : "sdp_trace");
-      hipLaunchKernelGGL(sdp_trace, dim3((nr + 63) / 64), dim3(64), 0, st, ta);
+      hipLaunchKernelGGL(sdp_trace, dim3((nr + TRACE_LANES - 1) / TRACE_LANES), dim3(64), 0, st, ta);
       lra_time_end(ctx);
     }
     LRA_HIP_CHECK(ctx, hipGetLastError());
