@@ -33,7 +33,6 @@ enum { A_DONE = 0, A_LEFT = 1, A_DOWN = 2, A_DIAG = 3, A_BORDER = 4, A_GAPLEFT =
 
 constexpr int CLASS_A_BYTES = 10 * 1024;  // per wave, 4 waves per workgroup
 constexpr int CLASS_B_BYTES = 64 * 1024;  // per wave, 1 wave per workgroup
-constexpr int CLASS_A0_BYTES = 5 * 1024;   // per wave, 8 waves per workgroup
 constexpr int CLASS_M1_BYTES = 20 * 1024; // the same with a smaller LDS request: 8 / 5 problems per CU instead of 2
 constexpr int CLASS_M2_BYTES = 32 * 1024;
 constexpr int CLASS_S_BYTES = 2560;       // per 16-lane group: 4 problems per wave, 16 per workgroup (anti-diagonals <= 16 cells)
@@ -371,13 +370,14 @@ __global__ void aog_classify(BatchArgs a) {
     } else {
       long need = need_bytes(g);
       cls = need <= CLASS_A_BYTES ? 0 : need <= CLASS_M1_BYTES ? 4 : need <= CLASS_M2_BYTES ? 5 : need <= CLASS_B_BYTES ? 1 : 2;
+      if (g.k + 1 <= 32) cls = cls == 0 ? 7 : cls == 4 ? 8 : cls == 5 ? 9 : cls;                              // anti-diagonals of at most 32 cells: two problems per wave
       if (need <= CLASS_S_BYTES && g.k + 1 <= 16) cls = 3;
       if (cls == 2 && need > a.gslot_bytes) { a.score[p] = 0; a.nblocks[p] = 0; a.status[p] = LRA_ST_RANGE; cls = -1; }
     }
   }
   // one atomic per wave and class
   const unsigned long long below = (lane == 0) ? 0ULL : (~0ULL >> (64 - lane));
-  for (int c = 0; c < 7; c++) {
+  for (int c = 0; c < 10; c++) {
     const unsigned long long m = __ballot(cls == c);
     if (!m) continue;
     int base = 0;
@@ -389,9 +389,9 @@ __global__ void aog_classify(BatchArgs a) {
 }
 
 template <int CLS>
-__global__ void __launch_bounds__(CLS == 6 ? 512 : (CLS == 0 || CLS == 3) ? 256 : 64) aog_kernel(BatchArgs a) {
+__global__ void __launch_bounds__((CLS == 0 || CLS == 3 || CLS == 7) ? 256 : 64) aog_kernel(BatchArgs a) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  constexpr int G = (CLS == 3) ? 16 : 64;
+  constexpr int G = (CLS == 3) ? 16 : (CLS >= 7) ? 32 : 64;
   constexpr int GPW = 64 / G;
   const int lane = threadIdx.x & 63;
   const int wave_in_wg = threadIdx.x >> 6;
@@ -406,7 +406,9 @@ __global__ void __launch_bounds__(CLS == 6 ? 512 : (CLS == 0 || CLS == 3) ? 256 
     long cap = (long)(a.block_off[p + 1] - a.block_off[p]);
     int* blk = a.blocks + 3 * a.block_off[p];
     if (CLS == 3) solve<16>(lane, pr, g, smem + (wave_in_wg * GPW + lane / G) * CLASS_S_BYTES, &a.score[p], &a.nblocks[p], blk, cap, &a.status[p]);
-    else if (CLS == 6) solve<64>(lane, pr, g, smem + wave_in_wg * CLASS_A0_BYTES, &a.score[p], &a.nblocks[p], blk, cap, &a.status[p]);
+    else if (CLS == 8) solve<32>(lane, pr, g, smem + (lane / G) * CLASS_M1_BYTES, &a.score[p], &a.nblocks[p], blk, cap, &a.status[p]);
+    else if (CLS == 9) solve<32>(lane, pr, g, smem + (lane / G) * CLASS_M2_BYTES, &a.score[p], &a.nblocks[p], blk, cap, &a.status[p]);
+    else if (CLS == 7) solve<32>(lane, pr, g, smem + (wave_in_wg * GPW + lane / G) * CLASS_A_BYTES, &a.score[p], &a.nblocks[p], blk, cap, &a.status[p]);
     else if (CLS == 0) solve<64>(lane, pr, g, smem + wave_in_wg * CLASS_A_BYTES, &a.score[p], &a.nblocks[p], blk, cap, &a.status[p]);
     else if (CLS == 1 || CLS == 4 || CLS == 5) solve<64>(lane, pr, g, smem, &a.score[p], &a.nblocks[p], blk, cap, &a.status[p]);
     else solve<64>(lane, pr, g, a.gscratch + (long)(group % a.gslots) * a.gslot_bytes, &a.score[p], &a.nblocks[p], blk, cap, &a.status[p]);
@@ -428,16 +430,16 @@ int lra_aog_launch_device(lra_ctx* ctx, int n, const char* d_qseq, const char* d
   a.n = n; a.qseq = d_qseq; a.tseq = d_tseq; a.q_off = d_q_off; a.q_len = d_q_len; a.t_off = d_t_off; a.t_len = d_t_len;
   a.k = d_k; a.m = m; a.mm = mm; a.indel = indel;
   a.score = d_score; a.nblocks = d_nblocks; a.blocks = d_blocks; a.block_off = d_block_off; a.status = d_status;
-  // scratch slot 0: counts[8] + lists[7n];  slot 1: class-C HBM work slots
-  size_t list_bytes = 32 + sizeof(int) * 7 * (size_t)n;
+  // scratch slot 0: counts[16] + lists[10n];  slot 1: class-C HBM work slots
+  size_t list_bytes = 64 + sizeof(int) * 10 * (size_t)n;
   char* s0 = (char*)lra_scratch(ctx, 0, list_bytes);
   if (!s0) return LRA_ERR_NOMEM;
-  a.counts = (int*)s0; a.lists = (int*)(s0 + 32);
+  a.counts = (int*)s0; a.lists = (int*)(s0 + 64);
   a.gslots = ctx->num_cu * 4;
   a.gslot_bytes = 8L << 20;  // 8 MiB per slot: e.g. 1.5 kb x 1.5 kb at k = 60, or 5 kb x 5 kb at k = 15
   a.gscratch = (char*)lra_scratch(ctx, 1, (size_t)a.gslots * a.gslot_bytes);
   if (!a.gscratch) return LRA_ERR_NOMEM;
-  LRA_HIP_CHECK(ctx, hipMemsetAsync(a.counts, 0, 32, ctx->stream));
+  LRA_HIP_CHECK(ctx, hipMemsetAsync(a.counts, 0, 64, ctx->stream));
   hipLaunchKernelGGL(aog_classify, dim3((n + 255) / 256), dim3(256), 0, ctx->stream, a);
   int wgA = min((n + 3) / 4, ctx->num_cu * 5);
   int wgB = min(n, ctx->num_cu * 2);
@@ -445,11 +447,16 @@ int lra_aog_launch_device(lra_ctx* ctx, int n, const char* d_qseq, const char* d
   lra_time_begin(ctx, "aog_lds_tiny");
   hipLaunchKernelGGL(aog_kernel<3>, dim3(min((n + 15) / 16, ctx->num_cu * 8)), dim3(256), 16 * CLASS_S_BYTES, ctx->stream, a);
   lra_time_end(ctx);
+  LRA_HIP_CHECK(ctx, hipFuncSetAttribute((const void*)aog_kernel<7>, hipFuncAttributeMaxDynamicSharedMemorySize, 8 * CLASS_A_BYTES));
   lra_time_begin(ctx, "aog_lds_small");
+  hipLaunchKernelGGL(aog_kernel<7>, dim3(min((n + 7) / 8, ctx->num_cu * 2)), dim3(256), 8 * CLASS_A_BYTES, ctx->stream, a);
   hipLaunchKernelGGL(aog_kernel<0>, dim3(wgA), dim3(256), 4 * CLASS_A_BYTES, ctx->stream, a);
   lra_time_end(ctx);
   LRA_HIP_CHECK(ctx, hipFuncSetAttribute((const void*)aog_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, CLASS_B_BYTES));
+  LRA_HIP_CHECK(ctx, hipFuncSetAttribute((const void*)aog_kernel<9>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * CLASS_M2_BYTES));
   lra_time_begin(ctx, "aog_lds_medium");
+  hipLaunchKernelGGL(aog_kernel<8>, dim3(min((n + 1) / 2, ctx->num_cu * 4)), dim3(64), 2 * CLASS_M1_BYTES, ctx->stream, a);
+  hipLaunchKernelGGL(aog_kernel<9>, dim3(min((n + 1) / 2, ctx->num_cu * 2)), dim3(64), 2 * CLASS_M2_BYTES, ctx->stream, a);
   hipLaunchKernelGGL(aog_kernel<4>, dim3(min(n, ctx->num_cu * 8)), dim3(64), CLASS_M1_BYTES, ctx->stream, a);
   hipLaunchKernelGGL(aog_kernel<5>, dim3(min(n, ctx->num_cu * 5)), dim3(64), CLASS_M2_BYTES, ctx->stream, a);
   lra_time_end(ctx);
