@@ -292,10 +292,10 @@ __global__ void __launch_bounds__(STAGE_NT) local_compare(CmpArgs A) {
   __shared__ uint32_t stage[64 * CSTRIDE];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const uint64_t x0 = (uint64_t)blockIdx.x * 64;
-  const uint64_t x = x0 + lane;
-  const bool live = x < A.n_tasks;
-  const uint64_t myQa = live ? A.q_lo[x] : 0, myTa = live ? A.t_lo[x] : 0;
-  const uint64_t myQn = live ? A.q_hi[x] - myQa : 0, myTn = live ? A.t_hi[x] - myTa : 0;
+  const uint64_t xl = x0 + lane;
+  const bool live = xl < A.n_tasks;
+  const uint64_t myQa = live ? A.q_lo[xl] : 0, myTa = live ? A.t_lo[xl] : 0;
+  const uint64_t myQn = live ? A.q_hi[xl] - myQa : 0, myTn = live ? A.t_hi[xl] - myTa : 0;
 #pragma unroll 4
   for (int i = wave; i < 64; i += STAGE_NT / 64) {                       // coalesced staging, one task per wave at a time
     const uint64_t qa = __shfl(myQa, i), qn = __shfl(myQn, i), ta = __shfl(myTa, i), tn = __shfl(myTn, i);
@@ -304,11 +304,17 @@ __global__ void __launch_bounds__(STAGE_NT) local_compare(CmpArgs A) {
     for (uint32_t p = lane; p < tn; p += 64) stage[i * CSTRIDE + QCAP + p] = A.t[ta + p];
   }
   __syncthreads();
-  if (wave != 0 || !live) return;
-  const long nq = (long)myQn, nt = (long)myTn;
+  // the walks diverge from task to task: every wave of the block takes 16 of its 64 tasks (16 active lanes), so the four SIMDs of the CU
+  // work on the block's lists at once and a wave only waits for the longest of 16 walks
+  constexpr int TPW = 64 / (STAGE_NT / 64);
+  const int slot = wave * TPW + lane;                                    // the task (and its LDS row) this lane walks
+  const uint64_t sQa = __shfl(myQa, slot & 63), sTa = __shfl(myTa, slot & 63), sQn = __shfl(myQn, slot & 63), sTn = __shfl(myTn, slot & 63);
+  if (lane >= TPW || x0 + slot >= A.n_tasks) return;
+  const uint64_t x = x0 + slot;
+  const long nq = (long)sQn, nt = (long)sTn;
   const bool staged = nq <= QCAP && nt <= TCAP;
-  const uint32_t* q = staged ? stage + lane * CSTRIDE : A.q + myQa;
-  const uint32_t* t = staged ? stage + lane * CSTRIDE + QCAP : A.t + myTa;
+  const uint32_t* q = staged ? stage + slot * CSTRIDE : A.q + sQa;
+  const uint32_t* t = staged ? stage + slot * CSTRIDE + QCAP : A.t + sTa;
   const int64_t maxDiag = A.maxDiag ? A.maxDiag[x] : 0, minDiag = A.minDiag ? A.minDiag[x] : 0;
   const long maxFreq = A.maxFreq;
   uint32_t* oq = EMIT ? A.out_qi + A.out_off[x] : nullptr; uint32_t* ot = EMIT ? A.out_ti + A.out_off[x] : nullptr;
