@@ -13,7 +13,8 @@ ap.add_argument("--reads", type=int, default=8192)
 a = ap.parse_args()
 args = argparse.Namespace(genome_mb=64, reads=a.reads, read_len=30000, err=0.10, k=17, w=10, max_freq=150, refine_band=7)
 dev = torch.device("cuda", 0)
-wl = bench.build_workload(args, 0, dev)
+ref = bench.build_reference(args, dev)
+wl = bench.build_workload(args, 0, dev, ref, a.reads, 0)
 ctx = Context(0)
 seed.load_reference(ctx, wl["genome"].cpu().numpy(), wl["idx_key"], wl["idx_pos"])
 rb = seed.read_batch_from_device(ctx, wl["reads"], wl["sim"]["off"])
