@@ -42,6 +42,14 @@ def test_map_reads_to_sam(ctx):
     assert np.array_equal(mapper.block_records(res).cpu().numpy(), staged_blocks)
     texts = mapper.records(res, rnames, [r.tobytes() for r in reads])
     assert texts == staged
+    import os
+    os.environ["LRA_RECORD_THREADS"] = "1"                                  # one host thread or many: the same text
+    try:
+        assert mapper.records(res, rnames, [r.tobytes() for r in reads]) == texts
+        os.environ["LRA_RECORD_THREADS"] = "7"
+        assert mapper.records(res, rnames, [r.tobytes() for r in reads]) == texts
+    finally:
+        del os.environ["LRA_RECORD_THREADS"]
     for fmt in "pPb":
         mapper.opts.printFormat = fmt; mapper.copts = mapper._c_opts()
         assert mapper.records(res, rnames, [r.tobytes() for r in reads]) == mapper.records_staged(sres, rnames, [r.tobytes() for r in reads]), fmt
