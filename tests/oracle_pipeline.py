@@ -1,7 +1,7 @@
 """MapRead_lowacc for ONE read composed from the oracle's stage functions only (test infrastructure: used by tests/ and by bench.py's
 cpu_baseline leg, never by the product).  It follows Map_lowacc.h:33-599 stage by stage exactly as lra_amd/csrc/mapread.hip chains the
 device stages, so its alignments must equal the GPU path's (tests/test_mapread.py) and its run time is the CPU cost of the same work.
-Single-chromosome genomes only (the oracle's LinearExtend / IndelRefine take the chromosome's bytes)."""
+chrom_pos (Genome::header.pos) defaults to one chromosome; the stages that take a chromosome's bytes get the slice."""
 import numpy as np
 
 import oracle_lib as O
@@ -24,15 +24,16 @@ def seq_offsets(n, window):
     return np.array(list(range(0, n, window)) + [n], np.uint64) if n else np.zeros(1, np.uint64)
 
 
-def map_read_lowacc(read: bytes, genome: bytes, idx_key, idx_pos, g_index, opts=None, clean_opts=None, stats=True):
+def map_read_lowacc(read: bytes, genome: bytes, idx_key, idx_pos, g_index, opts=None, clean_opts=None, stats=True, chrom_pos=None):
     """-> (alignments, unaligned).  alignments: list over primary chains p of lists of dict(strand, supp, secondary, n0, n1, value, chrom,
     a13_blocks, blocks (after IndelRefineAlignment), refine_status[, counts, nv, cigar]).  genome: the chromosome's bases (+ padding);
     g_index = (seqOffsets, tupleBoundaries, tuples) of the genome's local index."""
     o = dict(ONT)
     if opts:
         o.update(opts)
-    G = len(genome.rstrip(b"\0"))
-    CH = [0, G]
+    G = len(genome.rstrip(b"\0")) if chrom_pos is None else int(chrom_pos[-1])
+    CH = [0, G] if chrom_pos is None else [int(x) for x in chrom_pos]
+    chrom_bytes = lambda c: genome[CH[c]:CH[c + 1]]
     L = len(read)
     K = o["globalK"]
     co = clean_opts or O.CleanOpts(**dict(O.CLEAN_PRESETS["ONT"], globalK=K, SecondCleanMaxDiag=o["SecondCleanMaxDiag"]))
@@ -49,8 +50,9 @@ def map_read_lowacc(read: bytes, genome: bytes, idx_key, idx_pos, g_index, opts=
         oq, ot, cl = O.clean_matches(sp[qi][sel], idx_pos[ti][sel], sk[qi][sel], strand, co, CH)
         for ci in range(len(cl["start"])):
             a, b = int(cl["start"][ci]), int(cl["end"][ci])
-            eq, et, el, _ = O.linear_extend(oq[a:b], ot[a:b], strand, K, read, genome)
-            Q.append(eq); T.append(et); Ln.append(el); cst.append(strand); offs.append(offs[-1] + len(eq))
+            c = int(cl["chrom"][ci]); off = np.uint32(CH[c])
+            eq, et, el, _ = O.linear_extend(oq[a:b], ot[a:b] - off, strand, K, read, chrom_bytes(c))
+            Q.append(eq); T.append(et + off); Ln.append(el); cst.append(strand); offs.append(offs[-1] + len(eq))
     if not cst:
         return [], True
     Q = np.concatenate(Q); T = np.concatenate(T); Ln = np.concatenate(Ln)
@@ -124,19 +126,19 @@ def map_read_lowacc(read: bytes, genome: bytes, idx_key, idx_pos, g_index, opts=
         for s in segs:
             sb = fwd if s["strand"] == 0 else rc
             # a14 (Map_lowacc.h:582-585)
-            refined, rst = O.indel_refine(s["blocks"], sb, genome, o["refineBand"], o["match"], o["mismatch"], o["indel"])
+            refined, rst = O.indel_refine(s["blocks"], sb, chrom_bytes(s["chrom"]) + b"\0" * 64, o["refineBand"], o["match"], o["mismatch"], o["indel"])
             out.append(dict(s, a13_blocks=s["blocks"], blocks=refined, refine_status=rst))
         if o["refineBreakpoint"]:                                          # a15 (Map_lowacc.h:586-596): segments come right to left on the read
             for si in range(1, len(out)):
                 l, r = out[si], out[si - 1]
-                ret, lb, rb = O.refine_breakpoint(L, l["blocks"], l["strand"], fwd if l["strand"] == 0 else rc, genome[:G], r["blocks"], r["strand"],
-                                                  fwd if r["strand"] == 0 else rc, genome[:G])
+                ret, lb, rb = O.refine_breakpoint(L, l["blocks"], l["strand"], fwd if l["strand"] == 0 else rc, chrom_bytes(l["chrom"]), r["blocks"], r["strand"],
+                                                  fwd if r["strand"] == 0 else rc, chrom_bytes(r["chrom"]))
                 if ret >= 0:
                     l["blocks"], r["blocks"] = lb, rb
                 l["breakpoint"] = ret
         for d in out:                                                      # a16 (Map_lowacc.h:597-599)
             if stats and d["refine_status"] == 0 and len(d["blocks"]):
-                d["stats"] = O.calculate_statistics(d["blocks"], fwd if d["strand"] == 0 else rc, genome)
+                d["stats"] = O.calculate_statistics(d["blocks"], fwd if d["strand"] == 0 else rc, chrom_bytes(d["chrom"]) + b"\0" * 64)
         alignments.append(out)
         if p == 0 and not out:
             return alignments, True                                        # Map_lowacc.h:578-581

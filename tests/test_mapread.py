@@ -89,7 +89,7 @@ def test_map_reads_to_sam(ctx):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("preset", ["ont", "clr", "ont-bp"])
+@pytest.mark.parametrize("preset", ["ont", "clr", "ont-bp", "ont-2chr"])
 def test_map_reads_match_oracle_pipeline(ctx, oracle, preset):
     """The C boundary against the oracle's stage functions composed on the CPU (tests/oracle_pipeline.py): every SegAlignment of every
     primary chain -- strand, Supplymentary, NumOfAnchors0/1, FirstSDPValue, the refined blocks -- bit for bit, on plain reads, reads with a
@@ -109,16 +109,17 @@ def test_map_reads_match_oracle_pipeline(ctx, oracle, preset):
     reads.append(np.concatenate([sim(250_000, 4500), sim(400_000, 4500, True)]))               # translocation, second half reversed
     reads.append(synth.revcomp(np.concatenate([sim(300_000, 3000), sim(303_200, 3000)])))      # 200 bp deletion, read on the reverse strand
     reads.append(np.frombuffer(b"ACGT", dtype=np.uint8)[rng.integers(0, 4, 2500)].copy())      # junk
-    mapper = mapread.LowAccMapper(ctx, genome, ik, ip, [b"chr1"], [0, len(genome)], o)
+    CH = [0, 200_100, len(genome)] if preset == "ont-2chr" else [0, len(genome)]      # two chromosomes: the deletion / inversion reads lie in the first, the translocation spans both
+    mapper = mapread.LowAccMapper(ctx, genome, ik, ip, [b"chr%d" % (i + 1) for i in range(len(CH) - 1)], CH, o)
     res = mapper.align(seed.ReadBatch(ctx, [r.tobytes() for r in reads]))
     out = mapper.fetch(res)
     na = int(res.num_aln)
     g_win, g_bnd, g_tup = mapper.gli.fetch()
-    g_index = (OP.seq_offsets(len(genome), 256), g_bnd, g_tup)
+    g_index = (mapread.seq_offsets(CH, 256).astype(np.uint64), g_bnd, g_tup)
     gbytes = genome.tobytes() + b"\0" * 64
     n_seg = n_supp = n_rev = n_multi = n_bp = 0
     for r, rd in enumerate(reads):
-        exp, unaligned = OP.map_read_lowacc(rd.tobytes(), gbytes, ik, ip, g_index, oo)
+        exp, unaligned = OP.map_read_lowacc(rd.tobytes(), gbytes, ik, ip, g_index, oo, chrom_pos=CH)
         for p in range(na):
             a0, a1 = int(out["job_aln_off"][r * na + p]), int(out["job_aln_off"][r * na + p + 1])
             e = exp[p] if p < len(exp) else []
