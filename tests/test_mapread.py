@@ -94,8 +94,10 @@ def test_map_reads_match_oracle_pipeline(ctx, oracle, preset):
     """The C boundary against the oracle's stage functions composed on the CPU (tests/oracle_pipeline.py): every SegAlignment of every
     primary chain -- strand, Supplymentary, NumOfAnchors0/1, FirstSDPValue, the refined blocks -- bit for bit, on plain reads, reads with a
     deletion / an inversion / a translocated half, and a read that cannot align."""
+    import oracle_lib
     import oracle_pipeline as OP
     from lra_amd import seed, mapread
+    O_STAT_NAMES = oracle_lib.STAT_NAMES
     genome = synth.make_genome(500_000, seed=31, repeat_frac=0.25, n_families=3)
     o = mapread.clr_options() if preset == "clr" else mapread.LowAccOptions(refineBreakpoint=(preset == "ont-bp"))     # ont-bp: --refineBreakpoints
     oo = OP.CLR if preset == "clr" else dict(OP.ONT, refineBreakpoint=(preset == "ont-bp"))
@@ -130,6 +132,10 @@ def test_map_reads_match_oracle_pipeline(ctx, oracle, preset):
                 assert out["refine_status"][a] == s["refine_status"] == 0, (r, p, a)
                 b = out["blocks"][int(out["block_off"][a]):int(out["block_off"][a + 1])]
                 assert np.array_equal(b, s["blocks"]), (r, p, a, len(b), len(s["blocks"]))
+                ec, ev, eruns, _ = s["stats"]                                                  # CalculateStatistics: counters, NV bits, CIGAR runs
+                assert out["counts"][a].tolist() == [ec[k] for k in O_STAT_NAMES], (r, p, a)
+                assert np.float32(out["value"][a]).view(np.uint32) == np.float32(ev).view(np.uint32), (r, p, a)
+                assert np.array_equal(out["runs"][int(out["run_off"][a]):int(out["run_off"][a + 1])], eruns), (r, p, a)
                 n_seg += 1; n_supp += int(s["supp"]); n_rev += int(s["strand"]); n_bp += int(s.get("breakpoint", 0) == 1)
             n_multi += len(e) > 1
         if unaligned:
