@@ -205,3 +205,64 @@ def test_map_reads_edge_batches(ctx, oracle):
                 a = int(out["job_aln_off"][i * na])
                 b = out["blocks"][int(out["block_off"][a]):int(out["block_off"][a + 1])]
                 assert np.array_equal(b, exp[0][0]["blocks"]), i
+
+
+@pytest.mark.gpu
+def test_map_reads_bench_like_properties(ctx, oracle):
+    """The bench's read profile (30 kb, 10 % error, half of the reads reverse-complemented) on a 16 Mb genome through the C boundary:
+    size-independent properties on every read (aligned at the locus it was drawn from, blocks colinear and inside the read / chromosome,
+    CIGAR runs consistent with the blocks and the counters), and a sample compared with the oracle pipeline bit for bit."""
+    import torch
+    import oracle_pipeline as OP
+    from lra_amd import synth_torch as st, seed, mapread
+    dev = ctx.device
+    NR = 512
+    genome = st.make_genome(16_000_000, 1, dev)
+    o = mapread.LowAccOptions()
+    ik, ip = st.build_global_index(genome, o.globalK, o.globalW, 150)
+    sim = st.simulate_batch(genome, NR, 30000, 3000, 0.10, (30, 35, 35), 1234)
+    pad = torch.zeros(64, dtype=torch.uint8, device=dev)
+    g2 = torch.Generator(device=dev).manual_seed(8)
+    rev = torch.rand(NR, generator=g2, device=dev) < 0.5
+    reads = torch.cat([st.revcomp_some(sim["seq"], sim["off"], rev), pad])
+    G = int(genome.numel())
+    mapper = mapread.LowAccMapper(ctx, genome, ik, ip, [b"chr1"], [0, G], o)
+    res = mapper.align(seed.read_batch_from_device(ctx, reads, sim["off"]))
+    out = mapper.fetch(res)
+    na = int(res.num_aln)
+    off = sim["off"].cpu().numpy(); rev_h = rev.cpu().numpy()
+    tb = sim["blocks"].cpu().numpy(); tbo = sim["block_off"].cpu().numpy()
+    n_primary = 0
+    for r in range(NR):
+        L = int(off[r + 1] - off[r])
+        a0, a1 = int(out["job_aln_off"][r * na]), int(out["job_aln_off"][r * na + 1])
+        if a1 == a0:
+            continue
+        a = a0
+        b = out["blocks"][int(out["block_off"][a]):int(out["block_off"][a + 1])].astype(np.int64)
+        assert len(b) and out["refine_status"][a] == 0
+        assert np.all(b[:, 2] >= 0) and np.all(b[:-1, 0] + b[:-1, 2] <= b[1:, 0]) and np.all(b[:-1, 1] + b[:-1, 2] <= b[1:, 1]), r
+        assert b[0, 0] >= 0 and b[-1, 0] + b[-1, 2] <= L and b[-1, 1] + b[-1, 2] <= G, r
+        assert int(out["strand"][a]) == int(rev_h[r]), r
+        t0 = int(tb[tbo[r], 1]); t1 = int(tb[tbo[r + 1] - 1, 1] + tb[tbo[r + 1] - 1, 2])          # the locus the read was drawn from
+        if a1 - a0 == 1:
+            assert abs(int(b[0, 1]) - t0) < 500 and abs(int(b[-1, 1] + b[-1, 2]) - t1) < 500, (r, int(b[0, 1]), t0)
+            n_primary += 1
+        runs = out["runs"][int(out["run_off"][a]):int(out["run_off"][a + 1])].astype(np.int64)
+        ln, op = runs >> 4, runs & 15
+        c = out["counts"][a]
+        assert ln[op <= 1].sum() == b[:, 2].sum() and ln[op == 0].sum() == c[0] and ln[op == 1].sum() == c[1], r       # '=' + 'X' columns = block bases
+        assert ln[op <= 2].sum() == b[-1, 0] + b[-1, 2] - b[0, 0] and ln[(op <= 1) | (op == 3)].sum() == b[-1, 1] + b[-1, 2] - b[0, 1], r
+    assert n_primary >= 0.97 * NR, n_primary
+    g_win, g_bnd, g_tup = mapper.gli.fetch()
+    g_index = (OP.seq_offsets(G, 256), g_bnd, g_tup)
+    gbytes = genome.cpu().numpy().tobytes() + b"\0" * 64
+    reads_h = reads.cpu().numpy()
+    for r in range(0, NR, 64):
+        exp, unaligned = OP.map_read_lowacc(reads_h[int(off[r]):int(off[r + 1])].tobytes(), gbytes, ik, ip, g_index)
+        for p in range(na):
+            a0, a1 = int(out["job_aln_off"][r * na + p]), int(out["job_aln_off"][r * na + p + 1])
+            e = exp[p] if p < len(exp) else []
+            assert a1 - a0 == len(e), (r, p)
+            for a, s in zip(range(a0, a1), e):
+                assert np.array_equal(out["blocks"][int(out["block_off"][a]):int(out["block_off"][a + 1])], s["blocks"]), (r, p)
