@@ -456,6 +456,11 @@ typedef struct lra_merge_result {
 /* TrimOverlappedAnchors(GenomePairs&, vector<int>&) (LinearExtend.h:722-780; used at LocalRefineAlignment.h:371): n_lists anchor lists in CSR
  * d_off, lengths trimmed in place.  Synchronous.                                                                                          */
 int lra_trim_anchor_pairs_batch(lra_ctx* ctx, uint64_t n_lists, const uint64_t* d_off, uint64_t n_anchors, uint32_t* d_q, uint32_t* d_t, int32_t* d_len);
+/* TrimOverlappedAnchors(vector<Cluster>& extCluster, int start) (LinearExtend.h:574-649; LinearExtend_chain :783, Map_lowacc.h:476): the cluster
+ * version -- long anchors are those of 40 bases or more, a reverse-strand cluster (d_strand[c] == 1) is walked by read end and has the
+ * read start of the trimmed anchor moved; read positions and lengths are changed in place.  Synchronous.                                    */
+int lra_trim_overlapped_anchors_batch(lra_ctx* ctx, uint64_t n_clusters, const uint64_t* d_off, uint64_t n_anchors, const int32_t* d_strand,
+                                      uint32_t* d_q, uint32_t* d_t, int32_t* d_len);
 int lra_merge_extend_batch(lra_ctx* ctx, const lra_chain_result* chains, const lra_split_result* split, const lra_btwn_result* refined, const char* d_seq,
                            const uint64_t* d_read_off, const char* d_genome, const uint64_t* h_chrom_pos, int n_chrom, int K, lra_merge_result* out);
 

@@ -289,6 +289,22 @@ extern "C" int lra_trim_anchor_pairs_batch(lra_ctx* ctx, uint64_t n_lists, const
   return LRA_OK;
 }
 
+// TrimOverlappedAnchors(vector<Cluster>&, start) (LinearExtend.h:574-649; LinearExtend_chain :783-793, Map_lowacc.h:476): the same walk per
+// extended cluster with its strand (long anchors >= 40; reverse clusters are sorted by read end and have their read start moved)
+extern "C" int lra_trim_overlapped_anchors_batch(lra_ctx* ctx, uint64_t n_clusters, const uint64_t* d_off, uint64_t n_anchors, const int32_t* d_strand,
+                                                 uint32_t* d_q, uint32_t* d_t, int32_t* d_len) {
+  if (!ctx || (n_clusters && !d_strand)) return LRA_ERR_INVALID;
+  if (n_clusters == 0 || n_anchors == 0) return LRA_OK;
+  LRA_HIP_CHECK(ctx, hipSetDevice(ctx->device));
+  uint64_t* scratch = (uint64_t*)lra_scratch(ctx, 2, (n_anchors + 1) * 8);
+  if (!scratch) return LRA_ERR_NOMEM;
+  lra_time_begin(ctx, "merge_extend");
+  hipLaunchKernelGGL(me_trim, dim3((unsigned)((n_clusters + 63) / 64)), dim3(64), 0, ctx->stream, n_clusters, d_off, d_q, d_t, d_len, d_strand, scratch, 40);
+  lra_time_end(ctx);
+  LRA_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+  LRA_HIP_CHECK(ctx, hipGetLastError());
+  return LRA_OK;
+}
 
 // ---------------------------------------------------------------------------------------------------------------- MergeMatchesSameDiag
 // LinearExtend.h:795-829 (Map_highacc.h:642): whether anchor q opens a new Cluster_SameDiag entry depends on the pair (q - 1, q) alone, so

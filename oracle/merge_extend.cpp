@@ -106,6 +106,32 @@ extern "C" int oracle_merge_extend(int nsp, const int* matchOff, const uint32_t*
   return (int)groups.size();
 }
 
+// TrimOverlappedAnchors(vector<Cluster>&, start) LinearExtend.h:574-649 on one extended cluster: read positions / lengths modified in place
+extern "C" void oracle_trim_overlapped_anchors(int n, uint32_t* Q, const uint32_t* T, int* L, int S) {
+  std::vector<int> idx;
+  for (int i = 0; i < n; i++) if (L[i] >= 40) idx.push_back(i);
+  std::sort(idx.begin(), idx.end(), [&](int i, int j) {                  // LongAnchors::operator() :26-43
+    if (S == 0) { if (Q[i] != Q[j]) return Q[i] < Q[j]; return T[i] < T[j]; }
+    if (Q[i] + L[i] != Q[j] + L[j]) return Q[i] + L[i] > Q[j] + L[j];
+    return T[i] < T[j];
+  });
+  for (size_t ln = 1; ln < idx.size(); ln++) {
+    const int prev = idx[ln - 1], cur = idx[ln];
+    int overlap_r = 0, overlap_g = 0;
+    if (S == 0) {
+      if (Q[cur] < Q[prev] + L[prev] && Q[cur] >= Q[prev] + L[prev] - 30) overlap_r = (int)(Q[prev] + L[prev] - Q[cur]);
+    } else {
+      if (Q[cur] + L[cur] > Q[prev] && Q[cur] + L[cur] <= Q[prev] + 30) overlap_r = (int)(Q[cur] + L[cur] - Q[prev]);
+    }
+    if (T[cur] < T[prev] + L[prev] && T[cur] >= T[prev] + L[prev] - 30) overlap_g = (int)(T[prev] + L[prev] - T[cur]);
+    if (overlap_r > 0 || overlap_g > 0) {
+      const int overlap = std::max(overlap_r, overlap_g);
+      if (S == 1) Q[prev] += overlap + 1;
+      L[prev] -= overlap + 1;
+    }
+  }
+}
+
 // TrimOverlappedAnchors(GenomePairs&, vector<int>&) LinearExtend.h:722-780: one list, lengths modified in place
 extern "C" void oracle_trim_anchor_pairs(int n, const uint32_t* Q, const uint32_t* T, int* L) {
   std::vector<int> idx;

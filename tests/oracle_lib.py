@@ -656,3 +656,12 @@ def switchindex(ch, link, coarse, cl_qs, cl_qe):
     if r < 0:
         return None
     return oc[:r].copy(), ol[:nl.value].copy()
+
+
+def trim_overlapped_anchors(q, t, length, strand):
+    """TrimOverlappedAnchors(vector<Cluster>&, start) (LinearExtend.h:574) on one extended cluster -> (q, length) after trimming."""
+    L = lib()
+    q = np.ascontiguousarray(q, np.uint32).copy(); t = np.ascontiguousarray(t, np.uint32); ln = np.ascontiguousarray(length, np.int32).copy()
+    if len(q):
+        L.oracle_trim_overlapped_anchors(C.c_int(len(q)), _p(q, C.c_uint32), _p(t, C.c_uint32), _p(ln, C.c_int), C.c_int(int(strand)))
+    return q, ln

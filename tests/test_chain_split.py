@@ -205,3 +205,38 @@ def test_hip_trim_anchor_pairs_oracle(ctx):
         assert np.array_equal(got[off[i]:off[i + 1]], e), i
         changed += int((e != Ln).sum())
     assert changed > 100
+
+
+@pytest.mark.gpu
+def test_hip_trim_overlapped_anchors_clusters(ctx, oracle):
+    """the cluster version of TrimOverlappedAnchors (LinearExtend.h:574): both strands, long anchors overlapping by 1..30 on the read and / or
+    the genome, short anchors in between, ties in the sort key"""
+    import torch
+    rng = np.random.default_rng(17)
+    Q, T, L, off, ST = [], [], [], [0], []
+    for c in range(400):
+        strand = int(rng.integers(0, 2)); n = int(rng.integers(0, 60))
+        q = int(rng.integers(0, 500)); t = int(rng.integers(1000, 50000))
+        qs, ts, ls = [], [], []
+        for i in range(n):
+            ln = int(rng.integers(10, 120))
+            qs.append(q); ts.append(t); ls.append(ln)
+            step_q = ln + int(rng.integers(-30, 40)); step_t = ln + int(rng.integers(-30, 40))
+            q += max(step_q, 1); t += max(step_t, 1)
+        if strand:                                                        # reverse clusters run right to left on the read
+            top = q + 200
+            qs = [top - a - b for a, b in zip(qs, ls)]
+        Q += qs; T += ts; L += ls; ST.append(strand); off.append(len(Q))
+    dev = ctx.device
+    dq = torch.tensor(np.array(Q, np.uint32).astype(np.int64), dtype=torch.int64, device=dev).to(torch.int32)
+    dq = torch.from_numpy(np.array(Q, np.uint32)).to(dev); dt = torch.from_numpy(np.array(T, np.uint32)).to(dev); dl = torch.from_numpy(np.array(L, np.int32)).to(dev)
+    doff = torch.from_numpy(np.array(off, np.int64)).to(dev); dst = torch.from_numpy(np.array(ST, np.int32)).to(dev)
+    ctx.check(ctx.lib.lra_trim_overlapped_anchors_batch(ctx.h, len(ST), doff.data_ptr(), len(Q), dst.data_ptr(), dq.data_ptr(), dt.data_ptr(), dl.data_ptr()))
+    gq = dq.cpu().numpy(); gl = dl.cpu().numpy()
+    n_trim = 0
+    for c in range(len(ST)):
+        a, b = off[c], off[c + 1]
+        eq, el = oracle.trim_overlapped_anchors(Q[a:b], T[a:b], L[a:b], ST[c])
+        assert np.array_equal(gq[a:b], eq) and np.array_equal(gl[a:b], el), c
+        n_trim += int(np.sum(el != np.array(L[a:b], np.int32)))
+    assert n_trim > 300, n_trim
