@@ -681,6 +681,20 @@ typedef struct lra_same_diag_result {
 int lra_merge_same_diag_batch(lra_ctx* ctx, uint64_t n_clusters, const uint64_t* d_anchor_off, const uint32_t* d_q, const uint32_t* d_t,
                               const int32_t* d_len, const uint8_t* d_overlap, const int32_t* d_strand, int merge_dist, lra_same_diag_result* out);
 
+/* ---- a13 helper (high-accuracy path): SwitchToOriginalAnchors ------------------------------------------------------------------------
+ * Replaces   SwitchToOriginalAnchors(finalchain, ultimatechain, ExtendClusters, extend_clusters)      (LocalRefineAlignment.h:187-199, :576)
+ * for n_chains chains over Cluster_SameDiag entries: chain c = elements d_chain_off[c] .. d_chain_off[c+1], element i = entry d_elem_entry[i]
+ * of cluster d_elem_cluster[i] (FinalChain::chain / ClusterNum); same_diag = the lra_merge_same_diag_batch result the entries refer to;
+ * d_coarse[cluster] = Cluster_SameDiag::coarse.  Output: per chain the original anchors (index inside their cluster, entry by entry from its
+ * last anchor to its first) and their ClusterIndex, at d_chain_off[c] .. d_chain_off[c+1] of the result.  Synchronous.                   */
+typedef struct lra_original_anchors_result {
+  uint64_t n_chains, n_anchors;
+  const uint64_t* d_chain_off; const uint32_t* d_anchor; const int32_t* d_cluster;
+} lra_original_anchors_result;
+int lra_switch_to_original_anchors_batch(lra_ctx* ctx, uint64_t n_chains, const uint64_t* d_chain_off, uint64_t n_elems, const int32_t* d_elem_cluster,
+                                         const uint32_t* d_elem_entry, const lra_same_diag_result* same_diag, const int32_t* d_coarse,
+                                         lra_original_anchors_result* out);
+
 /* ---- a9 (high-accuracy path): switchindex ---------------------------------------------------------------------------------------------
  * Replaces   switchindex(splitclusters, Primary_chains, clusters, genome, read)                (Mapping_ultility.h:39-168, Map_highacc.h:274)
  * for n_chains chains (every CHain of every Primary_chain of every read): chain c = d_ch[d_chain_off[c] .. d_chain_off[c+1]) (split-cluster

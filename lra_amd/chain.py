@@ -336,3 +336,15 @@ def fetch_switchindex(ctx: Context, res: SwitchIndexResult, n_total):
     n = int(res.n_chains)
     return {"ch": ctx.to_host(res.d_ch, n_total, np.uint32), "link": ctx.to_host(res.d_link, n_total, np.uint8), "n": ctx.to_host(res.d_n, n, np.uint32),
             "n_link": ctx.to_host(res.d_n_link, n, np.uint32), "status": ctx.to_host(res.d_status, n, np.uint32)}
+
+
+class OriginalAnchorsResult(C.Structure):
+    _fields_ = [("n_chains", C.c_uint64), ("n_anchors", C.c_uint64)] + [(n, C.c_void_p) for n in ("d_chain_off", "d_anchor", "d_cluster")]
+
+
+def switch_to_original_anchors_batch(ctx: Context, chain_off, elem_cluster, elem_entry, same_diag: SameDiagResult, coarse):
+    """SwitchToOriginalAnchors (LocalRefineAlignment.h:187, high-accuracy path) for a batch of chains over Cluster_SameDiag entries."""
+    res = OriginalAnchorsResult()
+    ctx.check(ctx.lib.lra_switch_to_original_anchors_batch(ctx.h, C.c_uint64(int(chain_off.numel()) - 1), ptr(chain_off), C.c_uint64(int(elem_cluster.numel())),
+                                                           ptr(elem_cluster), ptr(elem_entry), C.byref(same_diag), ptr(coarse), C.byref(res)))
+    return res

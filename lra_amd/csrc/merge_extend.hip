@@ -177,6 +177,11 @@ __global__ void me_iota(uint64_t n, uint64_t* out) {
   if (i <= n) out[i] = i;
 }
 
+__global__ void me_gather_off(uint64_t n, const uint64_t* idx, const uint64_t* src, uint64_t* out) {
+  const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i <= n) out[i] = src[idx[i]];
+}
+
 inline size_t sz(size_t n, size_t e) { return (n * e + 255) / 256 * 256; }
 
 }  // namespace
@@ -389,5 +394,69 @@ extern "C" int lra_merge_same_diag_batch(lra_ctx* ctx, uint64_t n_clusters, cons
   LRA_HIP_CHECK(ctx, hipStreamSynchronize(st));
   LRA_HIP_CHECK(ctx, hipGetLastError());
   out->n_groups = ng; out->d_group_off = g_off; out->d_start = gs; out->d_end = ge; out->d_status = status;
+  return LRA_OK;
+}
+
+
+// ---------------------------------------------------------------------------------------------------------------- SwitchToOriginalAnchors
+// LocalRefineAlignment.h:187-199 (:576): the chain of the SplitChain sparse DP runs over Cluster_SameDiag entries; put the original anchors
+// back (entry k of cluster c -> anchors end[k]-1 .. start[k], ClusterIndex = coarse).  Count, scan, one wave per chain element to emit.
+namespace {
+struct SoArgs {
+  uint64_t n_elems;
+  const int32_t* e_cluster; const uint32_t* e_entry; const uint64_t* g_off; const uint32_t* start; const uint32_t* end; const int32_t* coarse;
+  uint32_t* cnt; const uint64_t* out_off; uint32_t* out_anchor; int32_t* out_cluster;
+};
+__global__ void so_count(SoArgs a) {
+  const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= a.n_elems) return;
+  const uint64_t g = a.g_off[a.e_cluster[i]] + a.e_entry[i];
+  a.cnt[i] = a.end[g] > a.start[g] ? a.end[g] - a.start[g] : 0u;
+}
+__global__ void __launch_bounds__(64) so_emit(SoArgs a) {
+  const uint64_t i = blockIdx.x;
+  if (i >= a.n_elems) return;
+  const int c = a.e_cluster[i];
+  const uint64_t g = a.g_off[c] + a.e_entry[i];
+  const uint32_t s = a.start[g], e = a.end[g];
+  const uint64_t o = a.out_off[i];
+  const int co = a.coarse[c];
+  for (uint32_t x = threadIdx.x; s + x < e; x += 64) { a.out_anchor[o + x] = e - 1 - x; a.out_cluster[o + x] = co; }
+}
+}  // namespace
+
+extern "C" int lra_switch_to_original_anchors_batch(lra_ctx* ctx, uint64_t n_chains, const uint64_t* d_chain_off, uint64_t n_elems, const int32_t* d_elem_cluster,
+                                                    const uint32_t* d_elem_entry, const lra_same_diag_result* same_diag, const int32_t* d_coarse,
+                                                    lra_original_anchors_result* out) {
+  if (!ctx || !out || !same_diag) return LRA_ERR_INVALID;
+  memset(out, 0, sizeof *out);
+  out->n_chains = n_chains;
+  if (n_chains == 0 || n_elems == 0) return LRA_OK;
+  LRA_HIP_CHECK(ctx, hipSetDevice(ctx->device));
+  hipStream_t st = ctx->stream;
+  auto al = [](size_t x) { return (x + 255) & ~(size_t)255; };
+  char* w = (char*)lra_ensure(ctx, 76, al((n_elems + 2) * 4) + al((n_elems + 2) * 8) + al((n_chains + 2) * 8) + 4096);
+  if (!w) return LRA_ERR_NOMEM;
+  SoArgs a; memset(&a, 0, sizeof a);
+  a.n_elems = n_elems; a.e_cluster = d_elem_cluster; a.e_entry = d_elem_entry; a.g_off = same_diag->d_group_off; a.start = same_diag->d_start; a.end = same_diag->d_end;
+  a.coarse = d_coarse;
+  a.cnt = (uint32_t*)w; w += al((n_elems + 2) * 4);
+  uint64_t* e_off = (uint64_t*)w; w += al((n_elems + 2) * 8);
+  uint64_t* c_off = (uint64_t*)w;
+  hipLaunchKernelGGL(so_count, dim3((unsigned)((n_elems + 255) / 256)), dim3(256), 0, st, a);
+  { int rc = lra_exclusive_scan<uint32_t>(ctx, (long)n_elems, a.cnt, e_off); if (rc) return rc; }
+  uint64_t total = 0;
+  LRA_HIP_CHECK(ctx, hipMemcpyAsync(&total, e_off + n_elems, 8, hipMemcpyDeviceToHost, st));
+  LRA_HIP_CHECK(ctx, hipStreamSynchronize(st));
+  uint32_t* oa = (uint32_t*)lra_ensure(ctx, 77, al((total + 1) * 4) * 2 + 512);
+  if (!oa) return LRA_ERR_NOMEM;
+  int32_t* oc = (int32_t*)((char*)oa + al((total + 1) * 4));
+  a.out_off = e_off; a.out_anchor = oa; a.out_cluster = oc;
+  hipLaunchKernelGGL(so_emit, dim3((unsigned)n_elems), dim3(64), 0, st, a);
+  // chain c's anchors start where its first element's do
+  hipLaunchKernelGGL(me_gather_off, dim3((unsigned)((n_chains + 256) / 256)), dim3(256), 0, st, n_chains, d_chain_off, (const uint64_t*)e_off, c_off);
+  LRA_HIP_CHECK(ctx, hipStreamSynchronize(st));
+  LRA_HIP_CHECK(ctx, hipGetLastError());
+  out->n_anchors = total; out->d_chain_off = c_off; out->d_anchor = oa; out->d_cluster = oc;
   return LRA_OK;
 }

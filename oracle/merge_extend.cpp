@@ -168,3 +168,17 @@ extern "C" int oracle_merge_same_diag(int n, const uint32_t* Q, const uint32_t* 
   }
   return ng;
 }
+
+// SwitchToOriginalAnchors (LocalRefineAlignment.h:187-199; called at :576): a chain over Cluster_SameDiag entries -> the chain over the
+// original anchors of the extended clusters: entry k of cluster c becomes its anchors end[k]-1 .. start[k] (descending), ClusterIndex = coarse.
+// chain_cluster[i] / chain_entry[i]: prev.ClusterNum(i) / prev.chain[i]; group_off / start / end: the MergeMatchesSameDiag result.
+extern "C" long oracle_switch_to_original_anchors(int n, const int* chain_cluster, const uint32_t* chain_entry, const uint64_t* group_off, const uint32_t* start,
+                                                  const uint32_t* end, const int* coarse, uint32_t* out_anchor, int* out_cluster) {
+  long m = 0;
+  for (int i = 0; i < n; i++) {
+    const int c = chain_cluster[i];
+    const uint64_t g = group_off[c] + chain_entry[i];
+    for (long j = (long)end[g] - 1; j >= (long)start[g]; j--) { out_anchor[m] = (uint32_t)j; out_cluster[m] = coarse[c]; m++; }
+  }
+  return m;
+}

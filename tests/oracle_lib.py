@@ -665,3 +665,17 @@ def trim_overlapped_anchors(q, t, length, strand):
     if len(q):
         L.oracle_trim_overlapped_anchors(C.c_int(len(q)), _p(q, C.c_uint32), _p(t, C.c_uint32), _p(ln, C.c_int), C.c_int(int(strand)))
     return q, ln
+
+
+def switch_to_original_anchors(chain_cluster, chain_entry, group_off, start, end, coarse):
+    """SwitchToOriginalAnchors (LocalRefineAlignment.h:187) for one chain -> (anchor index within its cluster, ClusterIndex) arrays."""
+    L = lib()
+    cc = np.ascontiguousarray(chain_cluster, np.int32); ce = np.ascontiguousarray(chain_entry, np.uint32)
+    go = np.ascontiguousarray(group_off, np.uint64); st = np.ascontiguousarray(start, np.uint32); en = np.ascontiguousarray(end, np.uint32)
+    co = np.ascontiguousarray(coarse, np.int32)
+    cap = int(sum(int(en[int(go[c]) + int(k)]) - int(st[int(go[c]) + int(k)]) for c, k in zip(cc, ce))) + 1
+    oa = np.zeros(cap, np.uint32); oc = np.zeros(cap, np.int32)
+    L.oracle_switch_to_original_anchors.restype = C.c_long
+    m = L.oracle_switch_to_original_anchors(C.c_int(len(cc)), _p(cc if len(cc) else np.zeros(1, np.int32), C.c_int), _p(ce if len(ce) else np.zeros(1, np.uint32), C.c_uint32),
+                                            _p(go, C.c_uint64), _p(st, C.c_uint32), _p(en, C.c_uint32), _p(co, C.c_int), _p(oa, C.c_uint32), _p(oc, C.c_int))
+    return oa[:m].copy(), oc[:m].copy()

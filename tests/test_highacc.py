@@ -194,6 +194,25 @@ def test_hip_merge_same_diag_oracle(ctx, oracle):
         assert out["start"][g0:g1].tolist() == exp[0].tolist() and out["end"][g0:g1].tolist() == exp[1].tolist(), c
         n_groups += g1 - g0; n_merged += int(np.sum(exp[1] - exp[0] > 1))
     assert n_groups > 5000 and n_merged > 2000, (n_groups, n_merged)
+    # SwitchToOriginalAnchors (LocalRefineAlignment.h:187): chains over those entries back to the original anchors
+    chains = []
+    for _ in range(200):
+        m = int(rng.integers(0, 40))
+        cl = rng.integers(0, len(ST), m)
+        cl = cl[np.array([off[c + 1] > off[c] for c in cl], bool)] if m else cl
+        ent = np.array([int(rng.integers(0, int(out["group_off"][c + 1] - out["group_off"][c]))) for c in cl], np.uint32)
+        chains.append((cl.astype(np.int32), ent))
+    coff = np.cumsum([0] + [len(c[0]) for c in chains]).astype(np.int64)
+    ecl = np.concatenate([c[0] for c in chains]).astype(np.int32); een = np.concatenate([c[1] for c in chains]).astype(np.uint32)
+    coarse = rng.integers(0, 50, len(ST)).astype(np.int32)
+    r2 = chain.switch_to_original_anchors_batch(ctx, tt(coff), tt(ecl), tt(een), res, tt(coarse))
+    o_off = ctx.to_host(r2.d_chain_off, len(chains) + 1, np.uint64); o_a = ctx.to_host(r2.d_anchor, int(r2.n_anchors), np.uint32)
+    o_c = ctx.to_host(r2.d_cluster, int(r2.n_anchors), np.int32)
+    for i, (cl, ent) in enumerate(chains):
+        ea, ec = oracle.switch_to_original_anchors(cl, ent, out["group_off"], out["start"], out["end"], coarse)
+        a0, a1 = int(o_off[i]), int(o_off[i + 1])
+        assert np.array_equal(o_a[a0:a1], ea) and np.array_equal(o_c[a0:a1], ec), i
+    assert int(r2.n_anchors) > 3000
 
 
 def test_oracle_switchindex_sanity(oracle):
