@@ -632,6 +632,9 @@ typedef struct lra_aln_record {
   int32_t n_blocks; uint32_t first_block_qpos, last_block_qend;   /* blocks[0].qPos and blocks[last].qPos + length (hard-clipped substrings) */
   int32_t is_secondary;                                        /* Alignment::ISsecondary (read by lra_group_alignments, not printed) */
   const char* md;                                              /* NULL, or the MD:Z value (opts.printMD; lra_md_string) */
+  /* print format 'a' (PrintPairwise) only, NULL otherwise: the blocks, Alignment::read (the read on the alignment's strand) and a pointer p
+   * with p[tPos] = chromosome base tPos for every tPos the blocks cover */
+  const int32_t* blocks; const char* strand_read; const char* chrom_text;
 } lra_aln_record;
 int lra_format_sam(const lra_aln_record* group, int n_group, int as, int hard_clip, const char* passthrough, char* out, uint64_t cap, uint64_t* len);
 int lra_format_sam_simple(const lra_aln_record* rec, int hard_clip, const char* passthrough, char* out, uint64_t cap, uint64_t* len);
@@ -656,7 +659,8 @@ int lra_format_pairwise(const char* read_name, const char* chrom, int n_blocks, 
  *                         (value, NumOfAnchors0) descending, first primary, others secondary (SECONDARY flag, typeofaln 2 unless 3).
  * lra_simple_mapqv      = SimpleMapQV (Mapping_ultility.h:497-595), opts.bypassClustering / readType == clr / == ont / globalK.
  * lra_output_read       = OUTPUT (:453-493) and output_unaligned (:445-451): formats 's' (PrintSAM), 'b' (PrintBed), 'p' / 'P' (PrintPAF
- *                         without / with CIGAR); sets Alignment::order; two-call convention of the lra_format_* functions.             */
+ *                         without / with CIGAR), 'a' (PrintPairwise; needs the records' blocks / strand_read / chrom_text); sets Alignment::order;
+ *                         two-call convention of the lra_format_* functions.                                                             */
 typedef struct lra_aln_group {
   int32_t first, count;
   uint32_t q_start, q_end, t_start, t_end; int32_t nm, nmm, ndel, nins; int32_t is_secondary; float value; int32_t NumOfAnchors0, NumOfAnchors1;
@@ -741,7 +745,7 @@ typedef struct lra_map_opts {
   int32_t refineSpaceDist; float anchorstoosparse; int32_t splitdist, window;
   float second_anchorbonus; int32_t bypassClustering, skipBandedRefine, refineBreakpoint;   /* refineBreakpoint: --refineBreakpoints (lra.cpp:262) */
   lra_clean_opts clean; lra_sdp_opts sdp;
-  int32_t readType, hardClip, PrintNumAln, printFormat;   /* printFormat: 's' SAM, 'p' / 'P' PAF, 'b' BED */
+  int32_t readType, hardClip, PrintNumAln, printFormat;   /* printFormat: 's' SAM, 'p' / 'P' PAF, 'b' BED, 'a' pairwise (PrintPairwise) */
 } lra_map_opts;
 typedef struct lra_map_counters {
   uint64_t n_minimizers, n_matches, n_clusters, n_sdp_anchors, n_sdp_points, n_sdp_entries, n_local_tuples, n_local_tasks, n_local_task_words, n_local_pairs, n_refined_matches,

@@ -451,6 +451,22 @@ extern "C" int lra_map_records(lra_ctx* ctx, const lra_map_result* res, const lr
       (rc = fetch(ctx, boff, res->d_block_off, nA ? nA + 1 : 0)) || (rc = fetch(ctx, blocks, res->d_blocks, 3 * (size_t)res->n_blocks)) ||
       (rc = fetch(ctx, roff, res->d_run_off, nA ? nA + 1 : 0)) || (rc = fetch(ctx, runs, res->d_runs, (size_t)res->n_runs)))
     return rc;
+  // print format 'a': the pairwise text needs the chromosome bases under every alignment and the read on its strand
+  const bool pairwise = o->printFormat == 'a';
+  std::vector<std::string> segText;
+  std::vector<uint32_t> segStart;
+  if (pairwise) {
+    if (!ctx->seed || !ctx->seed->genome) return lra_set_err(ctx, LRA_ERR_INVALID, "genome not loaded");
+    segText.resize(nA); segStart.assign(nA, 0);
+    for (size_t a = 0; a < nA; a++) {
+      const uint64_t b0 = boff[a], b1 = boff[a + 1];
+      if (b1 == b0) continue;
+      const uint32_t t0 = (uint32_t)blocks[3 * b0 + 1], t1 = (uint32_t)(blocks[3 * (b1 - 1) + 1] + blocks[3 * (b1 - 1) + 2]);
+      segStart[a] = t0;
+      segText[a].resize((size_t)(t1 - t0) + 1);
+      LRA_HIP_CHECK(ctx, hipMemcpy(&segText[a][0], ctx->seed->genome + m->chrom_pos[chrom[a]] + t0, t1 - t0, hipMemcpyDeviceToHost));
+    }
+  }
   // every read is independent: host threads take contiguous ranges of reads, each builds its own text; ranges are joined in read order
   const int n_reads = res->n_reads;
   unsigned hw = std::thread::hardware_concurrency();
@@ -468,9 +484,10 @@ extern "C" int lra_map_records(lra_ctx* ctx, const lra_map_result* res, const lr
     std::vector<int32_t> seg_off, index;
     std::vector<lra_aln_group> groups;
     std::vector<char> buf;
+    std::string rcRead;
     int rc = LRA_OK;
     for (int r = lo; r < hi; r++) {
-      recs.clear(); cigars.clear(); seg_off.assign(1, 0);
+      recs.clear(); cigars.clear(); seg_off.assign(1, 0); rcRead.clear();
       const bool unaligned = nJ == 0 || jo[(size_t)r * na + 1] == jo[(size_t)r * na];     // p == 0 left no SegAlignment (Map_lowacc.h:578-581)
       if (!unaligned) {
         size_t total = 0;
@@ -504,6 +521,19 @@ extern "C" int lra_map_records(lra_ctx* ctx, const lra_map_result* res, const lr
             rec.n_blocks = (int32_t)(b1 - b0);
             rec.first_block_qpos = b1 > b0 ? (uint32_t)blocks[3 * b0] : 0;
             rec.last_block_qend = b1 > b0 ? (uint32_t)(blocks[3 * (b1 - 1)] + blocks[3 * (b1 - 1) + 2]) : 0;
+            if (pairwise) {
+              if (strand[a] && rcRead.empty()) {                          // CreateRC (SeqUtils.h:151)
+                const int L = read_len[r];
+                rcRead.resize((size_t)L);
+                for (int x = 0; x < L; x++) {
+                  const char ch = reads[r][L - 1 - x];
+                  rcRead[x] = ch == 'A' ? 'T' : ch == 'C' ? 'G' : ch == 'G' ? 'C' : ch == 'T' ? 'A' : ch == 'a' ? 't' : ch == 'c' ? 'g' : ch == 'g' ? 'c' : ch == 't' ? 'a' : ch == 'n' ? 'n' : 'N';
+                }
+              }
+              rec.blocks = &blocks[3 * b0];
+              rec.strand_read = strand[a] ? rcRead.c_str() : reads[r];
+              rec.chrom_text = segText[a].data() - segStart[a];           // chrom_text[tPos] for the covered tPos only
+            }
             recs.push_back(rec);
           }
           seg_off.push_back((int32_t)recs.size());

@@ -160,6 +160,18 @@ extern "C" int lra_output_read(const lra_aln_group* groups, const int32_t* index
         if (format == 'b') rc = call([&](char* o, uint64_t c, uint64_t* l) { return lra_format_bed(&S[s], o, c, l); });
         else if (format == 's') rc = call([&](char* o, uint64_t c, uint64_t* l) { return lra_format_sam(S, G.count, s, hard_clip, passthrough, o, c, l); });
         else if (format == 'p' || format == 'P') rc = call([&](char* o, uint64_t c, uint64_t* l) { return lra_format_paf(&S[s], format == 'P', o, c, l); });
+        else if (format == 'a') {                                         // PrintPairwise (Alignment.h:564-589) on CreateAlignmentStrings' strings
+          const lra_aln_record& R = S[s];
+          if (!R.blocks || !R.strand_read || !R.chrom_text) return LRA_ERR_INVALID;
+          uint64_t n = 0; uint32_t refLen = 0;
+          lra_alignment_strings(R.strand_read, R.chrom_text, R.blocks, R.n_blocks, nullptr, nullptr, nullptr, 0, &n, &refLen);
+          std::vector<char> qs((size_t)n + 1), as((size_t)n + 1), ts((size_t)n + 1);
+          rc = lra_alignment_strings(R.strand_read, R.chrom_text, R.blocks, R.n_blocks, qs.data(), as.data(), ts.data(), n, &n, &refLen);
+          if (!rc) rc = call([&](char* o, uint64_t c, uint64_t* l) {
+            return lra_format_pairwise(R.read_name, R.chrom, R.n_blocks, R.n_blocks ? R.blocks[0] : 0, R.n_blocks ? R.blocks[1] : 0, refLen, qs.data(), as.data(),
+                                       ts.data(), n, o, c, l);
+          });
+        }
         else return LRA_ERR_INVALID;
         if (rc) return rc;
       }

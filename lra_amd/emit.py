@@ -11,7 +11,7 @@ class AlnRecord(C.Structure):
                  ("t_end", C.c_uint32), ("pre_clip", C.c_int32), ("suf_clip", C.c_int32)] +
                 [(n, C.c_int32) for n in ("nm", "nmm", "nins", "ndel", "tdel", "tins", "nSmallDel", "nMedDel", "nLargeDel", "nSmallIns", "nMedIns", "nLargeIns")] +
                 [("value", C.c_float), ("order", C.c_int32), ("NumOfAnchors0", C.c_int32), ("NumOfAnchors1", C.c_int32), ("runtime", C.c_int32),
-                 ("n_blocks", C.c_int32), ("first_block_qpos", C.c_uint32), ("last_block_qend", C.c_uint32), ("is_secondary", C.c_int32), ("md", C.c_char_p)])
+                 ("n_blocks", C.c_int32), ("first_block_qpos", C.c_uint32), ("last_block_qend", C.c_uint32), ("is_secondary", C.c_int32), ("md", C.c_char_p), ("blocks", C.c_void_p), ("strand_read", C.c_char_p), ("chrom_text", C.c_void_p)])
 
 
 class AlnGroup(C.Structure):

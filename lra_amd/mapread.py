@@ -294,7 +294,7 @@ class LowAccMapper:
     def records_staged(self, res: MapBatchResult, names, reads, quals=None, passthrough=None):
         """Per read: SetFromSegAlignment -> AlignmentsOrder::Update -> SimpleMapQV -> OUTPUT (Map_lowacc.h:600-618), or output_unaligned
         when its first primary chain produced no alignment (:578-581, :604-607).  names / reads / quals: per-read bytes.  Returns one bytes
-        object per read in opts.printFormat ('s' SAM, 'p' / 'P' PAF, 'b' BED)."""
+        object per read in opts.printFormat ('s' SAM, 'p' / 'P' PAF, 'b' BED; 'a' pairwise only through records())."""
         ctx, o = self.ctx, self.opts
         nA, na = res.n_alignments, max(res.num_aln, 1)
         counts, value, cigars = refine.fetch_stats(ctx, res.stat)

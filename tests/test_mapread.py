@@ -53,6 +53,42 @@ def test_map_reads_to_sam(ctx):
     for fmt in "pPb":
         mapper.opts.printFormat = fmt; mapper.copts = mapper._c_opts()
         assert mapper.records(res, rnames, [r.tobytes() for r in reads]) == mapper.records_staged(sres, rnames, [r.tobytes() for r in reads]), fmt
+    # print format "a": PrintPairwise of every printed SegAlignment, against the strings built here from the fetched blocks
+    import ctypes as C
+    from lra_amd._lib import load_library
+    lib = load_library()
+    mapper.opts.printFormat = "a"; mapper.copts = mapper._c_opts()
+    pw = mapper.records(res, rnames, [r.tobytes() for r in reads])
+    fo = mapper.fetch(res)
+    na_ = int(res.num_aln)
+    n_pw = 0
+    for i, rd in enumerate(reads):
+        j = i * na_
+        a0, a1 = int(fo["job_aln_off"][j]), int(fo["job_aln_off"][j + 1])                       # PrintNumAln = 1: the best group = the first job here
+        if a1 == a0:
+            assert pw[i] == b""
+            continue
+        if sum(int(fo["job_aln_off"][i * na_ + p + 1] - fo["job_aln_off"][i * na_ + p]) > 0 for p in range(na_)) > 1:
+            continue                                                                              # several candidate groups: ordering tested elsewhere
+        exp = b""
+        for a in range(a1 - 1, a0 - 1, -1):                                                     # segments are printed last to first
+            b = np.ascontiguousarray(fo["blocks"][int(fo["block_off"][a]):int(fo["block_off"][a + 1])], np.int32)
+            sread = rd.tobytes() if fo["strand"][a] == 0 else synth.revcomp(rd).tobytes()
+            ci = int(fo["chrom"][a]); text = genome[CH[ci]:CH[ci + 1]].tobytes()
+            n = C.c_uint64(0); rl = C.c_uint32(0)
+            bp = b.ctypes.data_as(C.c_void_p)
+            lib.lra_alignment_strings(sread, text, bp, len(b), None, None, None, C.c_uint64(0), C.byref(n), C.byref(rl))
+            qb = C.create_string_buffer(n.value + 1); ab = C.create_string_buffer(n.value + 1); tb = C.create_string_buffer(n.value + 1)
+            assert lib.lra_alignment_strings(sread, text, bp, len(b), qb, ab, tb, n, C.byref(n), C.byref(rl)) == 0
+            p_ = C.c_uint64(0)
+            args = (rnames[i], names[ci], len(b), int(b[0, 0]), int(b[0, 1]), rl, qb.raw[:n.value], ab.raw[:n.value], tb.raw[:n.value], n)
+            lib.lra_format_pairwise(*args, None, C.c_uint64(0), C.byref(p_))
+            pb = C.create_string_buffer(p_.value + 1)
+            assert lib.lra_format_pairwise(*args, pb, p_, C.byref(p_)) == 0
+            exp += pb.raw[:p_.value]
+        assert pw[i] == exp, i
+        n_pw += 1
+    assert n_pw >= 20
     mapper.opts.printFormat = "s"; mapper.copts = mapper._c_opts()
     assert len(texts) == len(reads)
     hdr = mapper.sam_header(b"test", b"lra align")
