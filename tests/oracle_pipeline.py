@@ -11,6 +11,7 @@ ONT = dict(globalK=17, globalW=10, globalMaxFreq=150, localK=10, localW=5, local
            alnthres=0.65, SecondCleanMaxDiag=100, refineBreakpoint=False)
 CLR = dict(ONT, globalK=15, globalMaxFreq=250, refineBand=20, initial_anchorbonus=15.0, second_anchorbonus=6.0, alnthres=0.50, SecondCleanMaxDiag=120)
 
+_CHROM_CACHE = {}
 _COMP = np.zeros(256, np.uint8)
 for a, b in zip(b"ACGTNacgtn", b"TGCANtgcan"):
     _COMP[a] = b
@@ -33,7 +34,16 @@ def map_read_lowacc(read: bytes, genome: bytes, idx_key, idx_pos, g_index, opts=
         o.update(opts)
     G = len(genome.rstrip(b"\0")) if chrom_pos is None else int(chrom_pos[-1])
     CH = [0, G] if chrom_pos is None else [int(x) for x in chrom_pos]
-    chrom_bytes = lambda c: genome[CH[c]:CH[c + 1]]
+    def chrom_bytes(c, padded=True):                                      # the chromosome's bases, sliced once per genome object (exact, or + 64 bytes of padding)
+        key = (id(genome), len(genome), tuple(CH))
+        if _CHROM_CACHE.get("key") != key:
+            _CHROM_CACHE.clear(); _CHROM_CACHE["key"] = key
+        if (c, padded) not in _CHROM_CACHE:
+            if padded:
+                _CHROM_CACHE[(c, padded)] = genome if (len(CH) == 2 and len(genome) >= G + 64) else genome[CH[c]:CH[c + 1]] + b"\0" * 64
+            else:
+                _CHROM_CACHE[(c, padded)] = genome if (len(CH) == 2 and len(genome) == G) else genome[CH[c]:CH[c + 1]]
+        return _CHROM_CACHE[(c, padded)]
     L = len(read)
     K = o["globalK"]
     co = clean_opts or O.CleanOpts(**dict(O.CLEAN_PRESETS["ONT"], globalK=K, SecondCleanMaxDiag=o["SecondCleanMaxDiag"]))
@@ -51,7 +61,7 @@ def map_read_lowacc(read: bytes, genome: bytes, idx_key, idx_pos, g_index, opts=
         for ci in range(len(cl["start"])):
             a, b = int(cl["start"][ci]), int(cl["end"][ci])
             c = int(cl["chrom"][ci]); off = np.uint32(CH[c])
-            eq, et, el, _ = O.linear_extend(oq[a:b], ot[a:b] - off, strand, K, read, chrom_bytes(c))
+            eq, et, el, _ = O.linear_extend(oq[a:b], ot[a:b] - off, strand, K, read, chrom_bytes(c, False))
             Q.append(eq); T.append(et + off); Ln.append(el); cst.append(strand); offs.append(offs[-1] + len(eq))
     if not cst:
         return [], True
@@ -126,19 +136,19 @@ def map_read_lowacc(read: bytes, genome: bytes, idx_key, idx_pos, g_index, opts=
         for s in segs:
             sb = fwd if s["strand"] == 0 else rc
             # a14 (Map_lowacc.h:582-585)
-            refined, rst = O.indel_refine(s["blocks"], sb, chrom_bytes(s["chrom"]) + b"\0" * 64, o["refineBand"], o["match"], o["mismatch"], o["indel"])
+            refined, rst = O.indel_refine(s["blocks"], sb, chrom_bytes(s["chrom"]), o["refineBand"], o["match"], o["mismatch"], o["indel"])
             out.append(dict(s, a13_blocks=s["blocks"], blocks=refined, refine_status=rst))
         if o["refineBreakpoint"]:                                          # a15 (Map_lowacc.h:586-596): segments come right to left on the read
             for si in range(1, len(out)):
                 l, r = out[si], out[si - 1]
-                ret, lb, rb = O.refine_breakpoint(L, l["blocks"], l["strand"], fwd if l["strand"] == 0 else rc, chrom_bytes(l["chrom"]), r["blocks"], r["strand"],
-                                                  fwd if r["strand"] == 0 else rc, chrom_bytes(r["chrom"]))
+                ret, lb, rb = O.refine_breakpoint(L, l["blocks"], l["strand"], fwd if l["strand"] == 0 else rc, chrom_bytes(l["chrom"], False), r["blocks"], r["strand"],
+                                                  fwd if r["strand"] == 0 else rc, chrom_bytes(r["chrom"], False))
                 if ret >= 0:
                     l["blocks"], r["blocks"] = lb, rb
                 l["breakpoint"] = ret
         for d in out:                                                      # a16 (Map_lowacc.h:597-599)
             if stats and d["refine_status"] == 0 and len(d["blocks"]):
-                d["stats"] = O.calculate_statistics(d["blocks"], fwd if d["strand"] == 0 else rc, chrom_bytes(d["chrom"]) + b"\0" * 64)
+                d["stats"] = O.calculate_statistics(d["blocks"], fwd if d["strand"] == 0 else rc, chrom_bytes(d["chrom"]))
         alignments.append(out)
         if p == 0 and not out:
             return alignments, True                                        # Map_lowacc.h:578-581
