@@ -685,6 +685,27 @@ typedef struct lra_same_diag_result {
 int lra_merge_same_diag_batch(lra_ctx* ctx, uint64_t n_clusters, const uint64_t* d_anchor_off, const uint32_t* d_q, const uint32_t* d_t,
                               const int32_t* d_len, const uint8_t* d_overlap, const int32_t* d_strand, int merge_dist, lra_same_diag_result* out);
 
+/* ---- a11 (high-accuracy path): RefineBtwnSpace --------------------------------------------------------------------------------------
+ * Replaces   int RefineBtwnSpace(int K, int W, vector<Cluster>& RevBtwnCluster, bool twoblocks, Cluster* cluster, const Options& opts, Genome&, Read&,
+ *                                char* strands[2], GenomePos qe, GenomePos qs, GenomePos te, GenomePos ts, bool st, GenomePos lrts = 0,
+ *                                GenomePos lrlength = 0)                                   (ClusterRefine.h:331-432; caller RefineBtwnClusters_chain :433)
+ * for n spaces, up to the vector insert + SetClusterBoundariesFromMatches it ends with (the caller owns the clusters): per space the read it
+ * belongs to, cluster->chromIndex, qs / qe / ts / te (t relative to the chromosome) and st as the caller passes them, twoblocks, lrts / lrlength
+ * (NULL = 0).  read_type = LRA_READ_* (opts.readType picks refineSpaceDiag), anchorstoosparse / match / mismatch / indel / max_freq =
+ * opts.anchorstoosparse / localMatch / localMismatch / localIndel / localMaxFreq.  Output per space: d_decision 0 nothing (:371), 1 the
+ * pairs go into the cluster (:363-369), 3 the same after the reverse strand was tried (:415-421: anchorfreq = 1 too), 2 the pairs form a
+ * new RevBtwnCluster on the other strand (:422-431, the reference returns 1); the pairs (CSR), refine efficiencies eff / reff (-1 when the
+ * reverse strand was not tried).  Synchronous.                                                                                           */
+typedef struct lra_btwn_space_result {
+  uint64_t n, n_pairs, n_reverse_tried;
+  const uint64_t* d_pair_off; const uint32_t* d_pair_q; const uint32_t* d_pair_t; const int32_t* d_decision; const float* d_eff; const float* d_reff;
+} lra_btwn_space_result;
+int lra_refine_btwn_space_batch(lra_ctx* ctx, int n, const uint32_t* d_qs, const uint32_t* d_qe, const uint32_t* d_ts, const uint32_t* d_te, const int32_t* d_st,
+                                const uint8_t* d_twoblocks, const uint32_t* d_read, const int32_t* d_chrom, const uint32_t* d_lrts, const uint32_t* d_lrlength,
+                                const uint64_t* d_read_off, const char* d_strands, uint64_t rc_base, const char* d_genome, const uint64_t* h_chrom_pos, int n_chrom,
+                                int K, int W, int read_type, float anchorstoosparse, int match, int mismatch, int indel, int max_freq,
+                                lra_btwn_space_result* out);
+
 /* ---- a13 helper (high-accuracy path): SwitchToOriginalAnchors ------------------------------------------------------------------------
  * Replaces   SwitchToOriginalAnchors(finalchain, ultimatechain, ExtendClusters, extend_clusters)      (LocalRefineAlignment.h:187-199, :576)
  * for n_chains chains over Cluster_SameDiag entries: chain c = elements d_chain_off[c] .. d_chain_off[c+1], element i = entry d_elem_entry[i]

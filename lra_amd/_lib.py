@@ -68,6 +68,7 @@ SYMBOLS = {
     "lra_local_refine_inputs_batch": (C.c_int, [_vp, C.c_int, _vp, _vp, _vp, _vp]),
     "lra_trim_overlapped_anchors_batch": (C.c_int, [_vp, C.c_uint64, _vp, C.c_uint64, _vp, _vp, _vp, _vp]),
     "lra_switch_to_original_anchors_batch": (C.c_int, [_vp, C.c_uint64, _vp, C.c_uint64, _vp, _vp, _vp, _vp, _vp]),
+    "lra_refine_btwn_space_batch": (C.c_int, [_vp, C.c_int] + [_vp] * 12 + [C.c_uint64, _vp, _vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, C.c_int, C.c_int, C.c_int, C.c_int, _vp]),
     "lra_merge_same_diag_batch": (C.c_int, [_vp, C.c_uint64, _vp, _vp, _vp, _vp, _vp, _vp, C.c_int, _vp]),
     "lra_switchindex_batch": (C.c_int, [_vp, C.c_uint64] + [_vp] * 9 + [C.c_uint64, _vp]),
     "lra_map_opts_preset_ont": (None, [_vp]),

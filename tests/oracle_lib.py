@@ -679,3 +679,18 @@ def switch_to_original_anchors(chain_cluster, chain_entry, group_off, start, end
     m = L.oracle_switch_to_original_anchors(C.c_int(len(cc)), _p(cc if len(cc) else np.zeros(1, np.int32), C.c_int), _p(ce if len(ce) else np.zeros(1, np.uint32), C.c_uint32),
                                             _p(go, C.c_uint64), _p(st, C.c_uint32), _p(en, C.c_uint32), _p(co, C.c_int), _p(oa, C.c_uint32), _p(oc, C.c_int))
     return oa[:m].copy(), oc[:m].copy()
+
+
+def refine_btwn_space(fwd: bytes, rc: bytes, chrom: bytes, qe, qs, te, ts, st, twoblocks, K=10, W=5, read_type=0, anchorstoosparse=0.005, match=4, mismatch=-1, indel=-2,
+                      max_freq=15, lrts=0, lrlength=0):
+    """RefineBtwnSpace (ClusterRefine.h:331) on one space -> (decision, pairs_q, pairs_t, eff, reff)"""
+    L = lib()
+    cap = 4 * ((qe - qs) + (te - ts + lrlength)) + 64
+    oq = np.zeros(cap, np.uint32); ot = np.zeros(cap, np.uint32); n = C.c_long(0); eff = C.c_float(0); reff = C.c_float(0)
+    L.oracle_refine_btwn_space.restype = C.c_int
+    d = L.oracle_refine_btwn_space(int(K), int(W), int(twoblocks), int(read_type), C.c_float(anchorstoosparse), int(match), int(mismatch), int(indel), C.c_long(max_freq),
+                                   C.c_char_p(fwd), C.c_char_p(rc), C.c_uint32(len(fwd)), C.c_char_p(chrom), C.c_uint32(qe), C.c_uint32(qs), C.c_uint32(te), C.c_uint32(ts),
+                                   int(st), C.c_uint32(lrts), C.c_uint32(lrlength), _p(oq, C.c_uint32), _p(ot, C.c_uint32), C.c_long(cap), C.byref(n), C.byref(eff),
+                                   C.byref(reff))
+    assert n.value <= cap
+    return d, oq[:n.value].copy(), ot[:n.value].copy(), np.float32(eff.value), np.float32(reff.value)

@@ -272,3 +272,69 @@ def test_hip_switchindex_oracle(ctx, oracle):
         assert out["link"][b:b + int(out["n_link"][c])].tolist() == exp[1].tolist(), c
         n_short += len(exp[0]) < len(ch)
     assert n_short > 40 and len(per_chain) > 100, (n_short, n_ub, len(per_chain))
+
+
+@pytest.mark.gpu
+def test_hip_refine_btwn_space_oracle(ctx, oracle):
+    """RefineBtwnSpace (ClusterRefine.h:331): spaces at the true locus (dense on the read's strand), at the locus of the reverse complement (dense
+    only on the other strand -> RevBtwnCluster), at unrelated loci (nothing / sparse either way), two-block spaces, short (< 1 kb: the
+    AffineOneGapAlign branch of RefineSpace) and long ones, both presets of refineSpaceDiag"""
+    import ctypes as C
+    import torch
+    from lra_amd import seed, synth
+    rng = np.random.default_rng(33)
+    genome = synth.make_genome(300_000, seed=14, repeat_frac=0.1, n_families=2)
+    CH = [0, 120_000, 300_000]
+    reads, locus = [], []
+    for i in range(6):
+        a = int(rng.integers(5_000, 100_000)) if i % 2 == 0 else int(rng.integers(130_000, 280_000))
+        rev = bool(i & 1)
+        reads.append(synth.simulate_read(rng, genome[a:a + 9001], 9000, 0.08, (30, 35, 35), rev)[0]); locus.append((a, rev))
+    batch = seed.ReadBatch(ctx, [r.tobytes() for r in reads])
+    tot = int(batch.off[-1])
+    rcb = seed.create_rc(ctx, batch)
+    both = torch.cat([batch.seq[:tot], rcb[:tot], torch.zeros(64, dtype=torch.uint8, device=ctx.device)])
+    gdev = torch.from_numpy(np.concatenate([genome, np.zeros(64, np.uint8)])).to(ctx.device)
+    P = []
+    for k in range(240):
+        r = int(rng.integers(0, len(reads))); a, rev = locus[r]; L = len(reads[r])
+        ci = 0 if a < CH[1] else 1
+        span = int(rng.integers(300, 900)) if k % 3 == 0 else int(rng.integers(1100, 4000))
+        q0 = int(rng.integers(0, L - span))
+        st = int(rev) if k % 4 else 1 - int(rev)                          # mostly the strand the read lies on; sometimes the wrong one
+        # the space in the orientation the caller passes it: forward read coordinates for st 0, and the flip of that for st 1 is done inside
+        qs, qe = q0, q0 + span
+        # genome interval under that read interval (read drawn forward from a, or reverse-complemented)
+        g0 = a + (q0 if not rev else L - (q0 + span))
+        kind = k % 5
+        t0 = g0 - CH[ci] + int(rng.integers(-20, 20)) if kind else int(rng.integers(1000, CH[ci + 1] - CH[ci] - 5000))
+        t0 = max(0, min(t0, CH[ci + 1] - CH[ci] - span - 64))
+        tlen = span + int(rng.integers(-40, 40))
+        P.append((r, ci, qs, qe, t0, t0 + tlen, st, int(k % 7 == 0)))
+    dev = ctx.device
+    T = lambda a, dt: torch.from_numpy(np.asarray(a, dt)).to(dev)
+    cols = list(zip(*P))
+    for read_type, sparse in ((0, 0.005), (3, 0.05)):
+        res = (C.c_uint64 * 3)()
+        class R(C.Structure):
+            _fields_ = [("n", C.c_uint64), ("n_pairs", C.c_uint64), ("n_rev", C.c_uint64)] + [(x, C.c_void_p) for x in ("off", "q", "t", "dec", "eff", "reff")]
+        out = R()
+        cp = (C.c_uint64 * len(CH))(*CH)
+        args = [T(cols[2], np.uint32), T(cols[3], np.uint32), T(cols[4], np.uint32), T(cols[5], np.uint32), T(cols[6], np.int32), T(cols[7], np.uint8), T(cols[0], np.uint32),
+                T(cols[1], np.int32)]
+        ctx.check(ctx.lib.lra_refine_btwn_space_batch(ctx.h, len(P), *[x.data_ptr() for x in args], None, None, batch.off.data_ptr(), both.data_ptr(), C.c_uint64(tot),
+                                                      gdev.data_ptr(), cp, len(CH) - 1, 10, 5, read_type, C.c_float(sparse), 4, -1, -2, 15, C.byref(out)))
+        n = len(P)
+        off = ctx.to_host(out.off, n + 1, np.uint64); pq = ctx.to_host(out.q, int(out.n_pairs), np.uint32); pt = ctx.to_host(out.t, int(out.n_pairs), np.uint32)
+        dec = ctx.to_host(out.dec, n, np.int32); eff = ctx.to_host(out.eff, n, np.float32); reff = ctx.to_host(out.reff, n, np.float32)
+        seen = set()
+        for i, (r, ci, qs, qe, ts, te, st, two) in enumerate(P):
+            fwd = reads[r].tobytes(); rc = synth.revcomp(reads[r]).tobytes()
+            chrom = genome[CH[ci]:CH[ci + 1]].tobytes() + b"\0" * 64
+            ed, eq, et, eeff, ereff = oracle.refine_btwn_space(fwd, rc, chrom, qe, qs, te, ts, st, two, K=10, W=5, read_type=read_type, anchorstoosparse=sparse)
+            assert dec[i] == ed, (i, dec[i], ed)
+            assert eff[i].view(np.uint32) == eeff.view(np.uint32) and reff[i].view(np.uint32) == ereff.view(np.uint32), i
+            a0, a1 = int(off[i]), int(off[i + 1])
+            assert np.array_equal(pq[a0:a1], eq) and np.array_equal(pt[a0:a1], et), (i, ed, a1 - a0, len(eq))
+            seen.add(int(ed))
+        assert seen == {0, 1, 2, 3}, seen
