@@ -295,6 +295,9 @@ def main():
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(wl, args, lanes[0]["mapper"])
         out["setup_s"] = round(wl["gen_s"], 1)
+        free_b, total_b = torch.cuda.mem_get_info(dev_index)
+        out["hbm_used_gb"] = round((total_b - free_b) / 1e9, 1)               # everything resident at the end of the run: reference, reads, work buffers
+        out["hbm_torch_reserved_gb"] = round(torch.cuda.memory_reserved(dev_index) / 1e9, 1)   # of which torch's allocator (workload + gathered records)
         print(json.dumps(out))
     if world > 1:
         dist.barrier()

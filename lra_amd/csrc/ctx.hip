@@ -20,7 +20,7 @@ void* lra_scratch(lra_ctx* ctx, int slot, size_t bytes) {
     ctx->scratch[slot] = nullptr;
     ctx->scratch_bytes[slot] = 0;
   }
-  size_t want = bytes + bytes / 4 + 4096;
+  size_t want = bytes + (bytes > (size_t(256) << 20) ? bytes / 16 : bytes / 4) + 4096;   // growth slack: 25 %, 6 % for large buffers
   void* p = nullptr;
   if (hipMalloc(&p, want) != hipSuccess) {
     lra_set_err(ctx, LRA_ERR_NOMEM, "hipMalloc(%zu) failed", want);
@@ -34,7 +34,7 @@ void* lra_scratch(lra_ctx* ctx, int slot, size_t bytes) {
 void* lra_ensure(lra_ctx* ctx, int idx, size_t bytes) {
   if (ctx->gbuf[idx] && ctx->gbytes[idx] >= bytes) return ctx->gbuf[idx];
   if (ctx->gbuf[idx]) { (void)hipStreamSynchronize(ctx->stream); (void)hipFree(ctx->gbuf[idx]); ctx->gbuf[idx] = nullptr; ctx->gbytes[idx] = 0; }
-  size_t want = bytes + (bytes > (size_t(4) << 30) ? bytes / 32 : bytes / 4) + 4096;   // growth slack: 25 %, 3 % for multi-GB buffers
+  size_t want = bytes + (bytes > (size_t(4) << 30) ? bytes / 32 : bytes > (size_t(256) << 20) ? bytes / 16 : bytes / 4) + 4096;   // growth slack: 25 %, 6 % from 256 MB, 3 % for multi-GB buffers
   void* p = nullptr;
   if (hipMalloc(&p, want) != hipSuccess) { lra_set_err(ctx, LRA_ERR_NOMEM, "hipMalloc(%zu) failed", want); return nullptr; }
   ctx->gbuf[idx] = p; ctx->gbytes[idx] = want;

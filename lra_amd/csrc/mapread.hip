@@ -405,6 +405,12 @@ extern "C" int lra_map_reads_lowacc_batch(lra_ctx* ctx, int n_reads, const char*
   out->d_block_off = fres.d_block_off; out->d_blocks = fres.d_blocks; out->d_refine_status = fres.d_status;
   out->d_counts = tres.d_counts; out->d_value = tres.d_value; out->d_run_off = tres.d_run_off; out->d_runs = tres.d_runs;
   out->d_strands = both; out->rc_base = tot;
+  if (getenv("LRA_MEM_DBG")) {
+    size_t tot = 0;
+    for (int i = 0; i < 80; i++) { tot += ctx->gbytes[i]; if (ctx->gbytes[i] > (size_t(1) << 30)) fprintf(stderr, "[mem] gbuf %d %.1f GB\n", i, ctx->gbytes[i] / 1e9); }
+    for (int i = 0; i < 4; i++) { tot += ctx->scratch_bytes[i]; fprintf(stderr, "[mem] scratch %d %.1f GB\n", i, ctx->scratch_bytes[i] / 1e9); }
+    fprintf(stderr, "[mem] aux %.1f out %.1f GB total %.1f GB\n", ctx->aux_bytes / 1e9, ctx->out_bytes / 1e9, (tot + ctx->aux_bytes + ctx->out_bytes) / 1e9);
+  }
   // counters of the batch (what bench.py prices the roofline with)
   lra_map_counters& c = out->counters;
   c.n_minimizers = sres.n_minimizers; c.n_matches = sres.n_matches; c.n_clusters = cres.n_clusters; c.n_sdp_anchors = chres.n_frags; c.n_sdp_points = chres.n_points;
