@@ -809,11 +809,33 @@ extern "C" int lra_indel_refine_batch(lra_ctx* ctx, int n_aln, const int32_t* d_
   LRA_HIP_CHECK(ctx, hipSetDevice(ctx->device));
   hipStream_t st = ctx->stream;
   const size_t nA = (size_t)n_aln, nBk = (size_t)n_blocks_in + 2 * nA;   // augmented blocks
-  // ---- arena A (scratch slot 2): everything whose size is bounded by the input
-  const size_t capSeg = nBk, capItem = 2 * nBk + nA;
+  // ---- per-alignment arrays (they outlive the call: status, block offsets), then the segment / item counts
+  const size_t perAln = ((nA * 4 + 255) & ~(size_t)255) * 3 + (((nA + 1) * 8 + 255) & ~(size_t)255) * 3;
+  char* baseP = (char*)lra_ensure(ctx, 70, perAln + 4096);
+  if (!baseP) return LRA_ERR_NOMEM;
+  Arena ap{baseP, perAln + 4096, 0};
+  IRArgs A;
+  memset(&A, 0, sizeof A);
+  A.n_aln = n_aln; A.blocks_in = d_blocks_in; A.block_off = d_block_off;
+  A.qseq = d_qseq; A.q_off = d_q_off; A.q_len = d_q_len; A.tseq = d_tseq; A.t_off = d_t_off; A.t_len = d_t_len;
+  A.k = refine_band; A.match = match; A.mismatch = mismatch; A.indel = indel; A.endAlign = end_align;
+  A.a_nseg = ap.get<uint32_t>(nA); A.a_nitem = ap.get<uint32_t>(nA); A.a_status = ap.get<int32_t>(nA);
+  uint64_t* seg_off = ap.get<uint64_t>(nA + 1); uint64_t* item_off = ap.get<uint64_t>(nA + 1); uint64_t* out_block_off = ap.get<uint64_t>(nA + 1);
+  if (!out_block_off) return lra_set_err(ctx, LRA_ERR_NOMEM, "arena accounting");
+  A.seg_off = seg_off; A.item_off = item_off;
+  const int nbA = (n_aln + SEG_LANES - 1) / SEG_LANES;
+  lra_time_begin(ctx, "ir_segment");
+  hipLaunchKernelGGL(ir_segment<false>, dim3(nbA), dim3(64), 0, st, A);
+  lra_time_end(ctx);
+  scan(ctx, (long)n_aln, A.a_nseg, seg_off);
+  scan(ctx, (long)n_aln, A.a_nitem, item_off);
+  uint64_t n_seg = 0, n_item = 0;
+  if (d2h(ctx, &n_seg, seg_off + n_aln, 8) || d2h(ctx, &n_item, item_off + n_aln, 8)) return LRA_ERR_HIP;
+  // ---- arena A (scratch slot 2): the per-segment / per-item arrays, sized by the counts
+  const size_t capSeg = (size_t)n_seg + 1, capItem = (size_t)n_item + 1;
   size_t needA = 0;
   auto add = [&](size_t n, size_t sz) { needA += ((n * sz + 255) & ~(size_t)255); };
-  add(nA, 4); add(nA, 4); add(nA, 4); add(nA + 1, 8); add(nA + 1, 8); add(3 * nBk, 4);
+  add(3 * nBk, 4);
   for (int i = 0; i < 8; i++) add(capSeg, 4);
   add(3 * capSeg, 4); add(capSeg, 4); add(capSeg, 8); add(capSeg, 4);
   add(capSeg + 1, 8); add(capSeg + 1, 8); add(capSeg, 8); add(capSeg + 1, 8); add(capSeg, 4);
@@ -822,18 +844,10 @@ extern "C" int lra_indel_refine_batch(lra_ctx* ctx, int n_aln, const int32_t* d_
   add(capItem, 4); add(3 * capItem, 4); add(capItem, 4); add(capItem, 4); add(capItem + 1, 8);
   add(capSeg, 8); add(capSeg, 4); add(capSeg, 8); add(capSeg, 4); add(capSeg, 4); add(capSeg, 4); add(capSeg + 1, 8);
   add(capSeg, 4); add(capSeg, 4); add(capSeg, 4);
-  add(nA + 1, 8);
   add(capSeg, 4); add(capSeg + 1, 8);
   char* baseA = (char*)lra_scratch(ctx, 2, needA + 4096);
   if (!baseA) return LRA_ERR_NOMEM;
   Arena ar{baseA, needA + 4096, 0};
-  IRArgs A;
-  A.n_aln = n_aln; A.blocks_in = d_blocks_in; A.block_off = d_block_off;
-  A.qseq = d_qseq; A.q_off = d_q_off; A.q_len = d_q_len; A.tseq = d_tseq; A.t_off = d_t_off; A.t_len = d_t_len;
-  A.k = refine_band; A.match = match; A.mismatch = mismatch; A.indel = indel; A.endAlign = end_align;
-  A.a_nseg = ar.get<uint32_t>(nA); A.a_nitem = ar.get<uint32_t>(nA); A.a_status = ar.get<int32_t>(nA);
-  uint64_t* seg_off = ar.get<uint64_t>(nA + 1); uint64_t* item_off = ar.get<uint64_t>(nA + 1);
-  A.seg_off = seg_off; A.item_off = item_off;
   A.ab = ar.get<int32_t>(3 * nBk);
   A.s_aln = ar.get<int32_t>(capSeg); A.s_kind = ar.get<int32_t>(capSeg); A.s_qStart = ar.get<int32_t>(capSeg); A.s_tStart = ar.get<int32_t>(capSeg);
   A.s_qEnd = ar.get<int32_t>(capSeg); A.s_tEnd = ar.get<int32_t>(capSeg); A.s_b0 = ar.get<int32_t>(capSeg); A.s_b1 = ar.get<int32_t>(capSeg);
@@ -849,21 +863,12 @@ extern "C" int lra_indel_refine_batch(lra_ctx* ctx, int n_aln, const int32_t* d_
   int32_t* p_t_len = ar.get<int32_t>(capSeg); int32_t* p_k = ar.get<int32_t>(capSeg); uint32_t* p_cap = ar.get<uint32_t>(capSeg);
   uint64_t* p_block_off = ar.get<uint64_t>(capSeg + 1);
   int32_t* p_score = ar.get<int32_t>(capSeg); int32_t* p_nblocks = ar.get<int32_t>(capSeg); int32_t* p_status = ar.get<int32_t>(capSeg);
-  uint64_t* out_block_off = ar.get<uint64_t>(nA + 1);
   uint32_t* s_nchunk = ar.get<uint32_t>(capSeg); uint64_t* chunk_off = ar.get<uint64_t>(capSeg + 1);
-  if (!out_block_off || !chunk_off) return lra_set_err(ctx, LRA_ERR_NOMEM, "arena accounting");
-
-  const int nbA = (n_aln + SEG_LANES - 1) / SEG_LANES;
-  // ---- segments: count, scan, emit
+  if (!chunk_off) return lra_set_err(ctx, LRA_ERR_NOMEM, "arena accounting");
+  // ---- segments: emit
   lra_time_begin(ctx, "ir_segment");
-  hipLaunchKernelGGL(ir_segment<false>, dim3(nbA), dim3(64), 0, st, A);
-  scan(ctx, (long)n_aln, A.a_nseg, seg_off);
-  scan(ctx, (long)n_aln, A.a_nitem, item_off);
   hipLaunchKernelGGL(ir_segment<true>, dim3(nbA), dim3(64), 0, st, A);
   lra_time_end(ctx);
-  uint64_t n_seg = 0, n_item = 0;
-  if (d2h(ctx, &n_seg, seg_off + n_aln, 8) || d2h(ctx, &n_item, item_off + n_aln, 8)) return LRA_ERR_HIP;
-  if (n_seg > capSeg || n_item > capItem) return lra_set_err(ctx, LRA_ERR_INVALID, "segment accounting");
   hipLaunchKernelGGL(ir_item_aln, dim3((n_aln + 255) / 256), dim3(256), 0, st, n_aln, item_off, i_aln);
   uint64_t n_rows = 0, n_aog = 0, n_cells = 0;
   const int32_t* tmp_blocks = nullptr;
