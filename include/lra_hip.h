@@ -147,6 +147,10 @@ typedef struct lra_cluster_result {
 } lra_cluster_result;
 int lra_clean_matches_batch(lra_ctx* ctx, const lra_clean_opts* opts, const uint64_t* h_chrom_pos, int n_chrom,
                             lra_cluster_result* out);
+/* The anchor bonus of the first sparse DP per read (Map_lowacc.h:86-89, :184-185): 3 for a read that has a cluster with anchorfreq in
+ * (1, 2] and at least 500 matches ("repetitivecluster"), opts.initial_anchorbonus otherwise.  *d_rate: [n_reads] floats, context-owned;
+ * pass it as d_rate to lra_sparse_dp_batch.  Asynchronous on the context's stream.                                                    */
+int lra_match_rate_batch(lra_ctx* ctx, const lra_cluster_result* clusters, float initial_anchorbonus, const float** d_rate);
 
 /* ---- a7: linear extension of the cleaned clusters ------------------------------------------
  * Replaces, per cluster of the context's current lra_clean_matches_batch result,
@@ -777,6 +781,8 @@ typedef struct lra_map_result {
   int32_t n_reads, num_aln;
   uint64_t n_jobs, n_alignments, n_blocks, n_runs;
   const uint64_t* d_job_aln_off; const uint32_t* d_job_status;
+  const uint8_t* d_job_reached;     /* [n_jobs] 1: primary chain p reached Map_lowacc.h:574 (its SegAlignmentGroup exists, possibly empty) */
+  const uint32_t* d_read_status;    /* [n_reads] OR of every stage's LRA_ST_* bits for the read; non-zero = not bit-identical, no record is emitted */
   const uint32_t* d_aln_read; const int32_t* d_strand; const int32_t* d_supp; const int32_t* d_secondary; const int32_t* d_n0; const int32_t* d_n1;
   const int32_t* d_chrom; const float* d_first_sdp_value;
   const uint64_t* d_block_off; const int32_t* d_blocks; const int32_t* d_refine_status;

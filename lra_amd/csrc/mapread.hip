@@ -55,6 +55,48 @@ __global__ void k_add_off(int n, const uint64_t* __restrict__ off, uint64_t add,
   if (i >= 1 && i <= n) out[n + i] = off[i] + add;   // [n+1..2n]: their reverse complements
 }
 
+// Map_lowacc.h:86-89, :184-185: a read with a cluster of anchorfreq in (1, 2] and >= 500 matches runs its first sparse DP with anchor bonus 3
+// instead of opts.initial_anchorbonus.  One wave per read over its clusters.
+__global__ void __launch_bounds__(64) k_match_rate(int n_reads, const uint64_t* __restrict__ cluster_off, const uint64_t* __restrict__ c_start,
+                                                   const uint64_t* __restrict__ c_end, const float* __restrict__ anchorfreq, float rate, float* __restrict__ out) {
+  const int r = blockIdx.x;
+  if (r >= n_reads) return;
+  bool rep = false;
+  for (uint64_t c = cluster_off[r] + threadIdx.x; c < cluster_off[r + 1]; c += 64) {
+    const float f = anchorfreq[c];
+    if (f > 1.0f && f <= 2.0f && c_end[c] - c_start[c] >= 500) rep = true;
+  }
+  const bool any = __ballot(rep) != 0;
+  if (threadIdx.x == 0) out[r] = any ? 3.0f : rate;
+}
+
+// ---- per-read status word: the OR of every stage's per-item status (LRA_ST_* bits), so that no flagged item is emitted as an ordinary record
+__global__ void k_or_status_div(uint64_t n, const uint32_t* __restrict__ status, int div, uint32_t* __restrict__ read_status) {
+  const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n && status[i]) atomicOr(&read_status[i / (uint64_t)div], status[i]);
+}
+__global__ void k_or_status_idx(uint64_t n, const uint32_t* __restrict__ status, const uint32_t* __restrict__ idx, int div, uint32_t* __restrict__ read_status) {
+  const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n && status[i]) atomicOr(&read_status[idx[i] / (uint32_t)div], status[i]);
+}
+__global__ void k_or_status_csr(uint64_t n_slots, const uint64_t* __restrict__ base, const uint32_t* __restrict__ status, int div, uint32_t* __restrict__ read_status) {
+  const uint64_t s = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (s >= n_slots) return;
+  uint32_t v = 0;
+  for (uint64_t c = base[s]; c < base[s + 1]; c++) v |= status[c];
+  if (v) atomicOr(&read_status[s / (uint64_t)div], v);
+}
+// Which primary chains p reach `alignments.resize(alignments.size() + 1)` (Map_lowacc.h:574): the chain exists, SPLITChain +
+// RemoveSpuriousSplitChain left a split chain (:263-267) and the refined clusters hold at least one match (:486-491).  A chain that
+// does not ends the loop over p (p > 0: break) or the read (p == 0: unaligned); one that does adds a SegAlignmentGroup even when
+// LocalRefineAlignment then produces no SegAlignment.
+__global__ void k_job_reached(uint64_t n_slots, const uint32_t* __restrict__ n_split, const uint32_t* __restrict__ sp_status, const uint64_t* __restrict__ cluster_base,
+                              const uint64_t* __restrict__ match_off, uint8_t* __restrict__ reached) {
+  const uint64_t s = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (s >= n_slots) return;
+  reached[s] = (!sp_status[s] && n_split[s] > 0 && match_off[cluster_base[s + 1]] > match_off[cluster_base[s]]) ? 1 : 0;
+}
+
 // per alignment: which read, where its strand's bases start, where its chromosome starts and how long it is
 __global__ void k_aln_address(uint64_t n_jobs, int num_aln, const uint64_t* __restrict__ job_aln_off, const int32_t* __restrict__ strand,
                               const int32_t* __restrict__ chrom, const uint64_t* __restrict__ read_off, uint64_t rc_base,
@@ -280,6 +322,19 @@ static int refine_breakpoints(lra_ctx* ctx, uint64_t nJ, uint64_t nA, const uint
   return LRA_OK;
 }
 
+extern "C" int lra_match_rate_batch(lra_ctx* ctx, const lra_cluster_result* clusters, float initial_anchorbonus, const float** d_rate) {
+  if (!ctx || !clusters || !d_rate) return LRA_ERR_INVALID;
+  *d_rate = nullptr;
+  const int n_reads = clusters->n_reads;
+  float* rate = (float*)lra_ensure(ctx, 12, ((size_t)n_reads + 1) * 4);
+  if (!rate) return LRA_ERR_NOMEM;
+  LRA_HIP_CHECK(ctx, hipSetDevice(ctx->device));
+  if (n_reads) hipLaunchKernelGGL(k_match_rate, dim3(n_reads), dim3(64), 0, ctx->stream, n_reads, clusters->d_cluster_off, clusters->d_c_start, clusters->d_c_end,
+                                  clusters->d_c_anchorfreq, initial_anchorbonus, rate);
+  *d_rate = rate;
+  return LRA_OK;
+}
+
 extern "C" int lra_map_reads_lowacc_batch(lra_ctx* ctx, int n_reads, const char* d_seq, const uint64_t* d_read_off, uint64_t total_bases,
                                           const lra_map_opts* o, lra_map_result* out) {
   if (!ctx || !o || !out || n_reads < 0) return LRA_ERR_INVALID;
@@ -289,9 +344,14 @@ extern "C" int lra_map_reads_lowacc_batch(lra_ctx* ctx, int n_reads, const char*
     return lra_set_err(ctx, LRA_ERR_INVALID, "reference not loaded (genome, global index, chromosome table, local index)");
   if (m->gli_window != o->localIndexWindow) return lra_set_err(ctx, LRA_ERR_INVALID, "local index built with another window");
   out->n_reads = n_reads;
+  std::string().swap(m->last_text); m->last_sig = lra_map_sig{};         // a sizing call of lra_map_records for an earlier batch is void now
   if (n_reads == 0) return LRA_OK;
   LRA_HIP_CHECK(ctx, hipSetDevice(ctx->device));
   hipStream_t st = ctx->stream;
+  auto grid = [](uint64_t n) { return dim3((unsigned)((n + 255) / 256)); };
+  uint32_t* read_status = (uint32_t*)lra_ensure(ctx, 22, ((size_t)n_reads + 1) * 4);
+  if (!read_status) return LRA_ERR_NOMEM;
+  LRA_HIP_CHECK(ctx, hipMemsetAsync(read_status, 0, (size_t)n_reads * 4, st));
   const uint64_t* CH = m->chrom_pos.data();
   const int nCh = (int)m->chrom_pos.size() - 1;
   const char* genome = (const char*)ctx->seed->genome;
@@ -305,12 +365,15 @@ extern "C" int lra_map_reads_lowacc_batch(lra_ctx* ctx, int n_reads, const char*
   if ((rc = lra_clean_matches_batch(ctx, &o->clean, CH, nCh, &cres))) return rc;
   lra_extend_result eres;
   if ((rc = lra_linear_extend_batch(ctx, o->globalK, d_seq, d_read_off, &eres))) return rc;
-  // a8: the primary chains (Map_lowacc.h:185-188)
+  // a8: the primary chains (Map_lowacc.h:184-188); match_rate = 3 for reads with a repetitive cluster (:86-89)
+  const float* match_rate = nullptr;
+  if ((rc = lra_match_rate_batch(ctx, &cres, o->sdp.rate, &match_rate))) return rc;
   lra_chain_result chres;
   if ((rc = lra_sparse_dp_batch(ctx, n_reads, cres.d_cluster_off, eres.d_e_start, eres.d_e_count, cres.d_c_strand, eres.d_e_qpos, eres.d_e_tpos, eres.d_e_len,
-                                d_read_off, nullptr, &o->sdp, &chres))) return rc;
+                                d_read_off, match_rate, &o->sdp, &chres))) return rc;
   const int num_aln = chres.num_aln;
   const uint64_t n_slots = (uint64_t)n_reads * (uint64_t)num_aln;
+  hipLaunchKernelGGL(k_or_status_div, grid(n_reads), dim3(256), 0, st, (uint64_t)n_reads, chres.d_status, 1, read_status);
   // chains[p].NumOfAnchors0 (the second sparse DP reuses the first one's buffers)
   uint32_t* slot_n0 = (uint32_t*)lra_ensure(ctx, 56, (n_slots + 1) * 4);
   if (!slot_n0) return LRA_ERR_NOMEM;
@@ -318,6 +381,7 @@ extern "C" int lra_map_reads_lowacc_batch(lra_ctx* ctx, int n_reads, const char*
   // a9
   lra_split_result spres;
   if ((rc = lra_split_chains_batch(ctx, &chres, CH, nCh, o->splitdist, o->bypassClustering, &spres))) return rc;
+  hipLaunchKernelGGL(k_or_status_div, grid(n_slots), dim3(256), 0, st, n_slots, spres.d_status, num_aln, read_status);
   // a10: the reads forward, then reverse complemented, in one buffer + its local index (Map_lowacc.h:246-250)
   char* both = (char*)lra_ensure(ctx, 57, 2 * tot + 64);
   uint64_t* off2 = (uint64_t*)lra_ensure(ctx, 58, (2 * (size_t)n_reads + 2) * 8);
@@ -355,10 +419,15 @@ extern "C" int lra_map_reads_lowacc_batch(lra_ctx* ctx, int n_reads, const char*
   // a9 MergeChain, a7 second pass, a8 second sparse DP (Map_lowacc.h:411-540)
   lra_merge_result mres;
   if ((rc = lra_merge_extend_batch(ctx, &chres, &spres, &bres, d_seq, d_read_off, genome, CH, nCh, o->localK, &mres))) return rc;
+  uint8_t* job_reached = (uint8_t*)lra_ensure(ctx, 23, n_slots + 64);
+  if (!job_reached) return LRA_ERR_NOMEM;
+  hipLaunchKernelGGL(k_job_reached, grid(n_slots), dim3(256), 0, st, n_slots, spres.d_n_split, spres.d_status, mres.d_cluster_base, bres.d_match_off, job_reached);
+  if (rres.n_frags) hipLaunchKernelGGL(k_or_status_csr, grid(n_slots), dim3(256), 0, st, n_slots, mres.d_cluster_base, rres.d_status, num_aln, read_status);
   lra_sdp_opts s2 = o->sdp; s2.mode = 1; s2.rate = o->second_anchorbonus;      // SparseDP :2287 with opts.second_anchorbonus (Options.h:221)
   lra_chain_result ch2;
   if ((rc = lra_sparse_dp_batch(ctx, (int)mres.n_groups, mres.d_iota, mres.d_anchor_off, mres.d_count, mres.d_strand, mres.d_q, mres.d_t, mres.d_len, mres.d_iota,
                                 nullptr, &s2, &ch2))) return rc;
+  if (mres.n_groups) hipLaunchKernelGGL(k_or_status_idx, grid(mres.n_groups), dim3(256), 0, st, mres.n_groups, ch2.d_status, mres.d_group_slot, num_aln, read_status);
   // a13
   lra_local_refine_inputs inp;
   if ((rc = lra_local_refine_inputs_batch(ctx, num_aln, slot_n0, &mres, &ch2, &inp))) return rc;
@@ -370,6 +439,7 @@ extern "C" int lra_map_reads_lowacc_batch(lra_ctx* ctx, int n_reads, const char*
                                    inp.d_chain_chrom, inp.d_chain_value, inp.d_chain_n0, inp.d_chain_n1, inp.n_anchors, inp.d_q, inp.d_t, inp.d_len, d_read_off,
                                    both, tot, genome, CH, nCh, &lo, &ares))) return rc;
   const uint64_t nA = ares.n_alignments, nJ = ares.n_jobs;
+  if (nJ) hipLaunchKernelGGL(k_or_status_div, grid(nJ), dim3(256), 0, st, nJ, ares.d_status, num_aln, read_status);
   // a14, a16 on every SegAlignment (Map_lowacc.h:582-599)
   uint32_t* aln_read = (uint32_t*)lra_ensure(ctx, 59, (nA + 1) * 4);
   uint64_t* q_off = (uint64_t*)lra_ensure(ctx, 60, (nA + 1) * 8);
@@ -391,6 +461,7 @@ extern "C" int lra_map_reads_lowacc_batch(lra_ctx* ctx, int n_reads, const char*
       if (!keep) return LRA_ERR_NOMEM;
       LRA_HIP_CHECK(ctx, hipMemcpyAsync(keep, fres.d_status, nA * 4, hipMemcpyDeviceToDevice, st));
       fres.d_status = keep;
+      hipLaunchKernelGGL(k_or_status_idx, grid(nA), dim3(256), 0, st, nA, (const uint32_t*)keep, aln_read, 1, read_status);
     }
     if (o->refineBreakpoint && (rc = refine_breakpoints(ctx, nJ, nA, ares.d_job_aln_off, ares.d_strand, q_off, q_len, t_off, t_len, both, genome, &fres))) return rc;
     if ((rc = lra_calculate_statistics_batch(ctx, (int)nA, fres.d_blocks, fres.d_block_off, both, q_off, q_len, genome, t_off, m->lut.data(), (int)m->lut.size(), &tres)))
@@ -399,7 +470,7 @@ extern "C" int lra_map_reads_lowacc_batch(lra_ctx* ctx, int n_reads, const char*
   LRA_HIP_CHECK(ctx, hipStreamSynchronize(st));
   LRA_HIP_CHECK(ctx, hipGetLastError());
   out->num_aln = num_aln; out->n_jobs = nJ; out->n_alignments = nA; out->n_blocks = fres.n_blocks; out->n_runs = tres.n_runs;
-  out->d_job_aln_off = ares.d_job_aln_off; out->d_job_status = ares.d_status;
+  out->d_job_aln_off = ares.d_job_aln_off; out->d_job_status = ares.d_status; out->d_job_reached = job_reached; out->d_read_status = read_status;
   out->d_aln_read = aln_read; out->d_strand = ares.d_strand; out->d_supp = ares.d_supp; out->d_secondary = ares.d_secondary; out->d_n0 = ares.d_n0; out->d_n1 = ares.d_n1;
   out->d_chrom = ares.d_chrom; out->d_first_sdp_value = ares.d_value;
   out->d_block_off = fres.d_block_off; out->d_blocks = fres.d_blocks; out->d_refine_status = fres.d_status;
@@ -449,9 +520,11 @@ extern "C" int lra_map_records(lra_ctx* ctx, const lra_map_result* res, const lr
   LRA_HIP_CHECK(ctx, hipSetDevice(ctx->device));
   const size_t nA = res->n_alignments, nJ = res->n_jobs;
   const int na = std::max(res->num_aln, 1);
-  std::vector<uint64_t> jo, boff, roff; std::vector<int32_t> strand, supp, sec, n0, n1, chrom, counts, blocks; std::vector<float> fval; std::vector<uint32_t> runs;
+  std::vector<uint64_t> jo, boff, roff; std::vector<int32_t> strand, supp, sec, n0, n1, chrom, counts, blocks; std::vector<float> fval; std::vector<uint32_t> runs, rstat;
+  std::vector<uint8_t> reached;
   int rc;
-  if ((rc = fetch(ctx, jo, res->d_job_aln_off, nJ ? nJ + 1 : 0)) || (rc = fetch(ctx, strand, res->d_strand, nA)) || (rc = fetch(ctx, supp, res->d_supp, nA)) ||
+  if ((rc = fetch(ctx, reached, res->d_job_reached, res->d_job_reached ? nJ : 0)) || (rc = fetch(ctx, rstat, res->d_read_status, res->d_read_status ? (size_t)res->n_reads : 0)) ||
+      (rc = fetch(ctx, jo, res->d_job_aln_off, nJ ? nJ + 1 : 0)) || (rc = fetch(ctx, strand, res->d_strand, nA)) || (rc = fetch(ctx, supp, res->d_supp, nA)) ||
       (rc = fetch(ctx, sec, res->d_secondary, nA)) || (rc = fetch(ctx, n0, res->d_n0, nA)) || (rc = fetch(ctx, n1, res->d_n1, nA)) ||
       (rc = fetch(ctx, chrom, res->d_chrom, nA)) || (rc = fetch(ctx, fval, res->d_first_sdp_value, nA)) || (rc = fetch(ctx, counts, res->d_counts, 18 * nA)) ||
       (rc = fetch(ctx, boff, res->d_block_off, nA ? nA + 1 : 0)) || (rc = fetch(ctx, blocks, res->d_blocks, 3 * (size_t)res->n_blocks)) ||
@@ -494,6 +567,7 @@ extern "C" int lra_map_records(lra_ctx* ctx, const lra_map_result* res, const lr
     int rc = LRA_OK;
     for (int r = lo; r < hi; r++) {
       recs.clear(); cigars.clear(); seg_off.assign(1, 0); rcRead.clear();
+      if (!rstat.empty() && rstat[r]) { plen[tix].push_back(0); continue; }   // flagged read: no record (the caller routes it elsewhere; lra_map_flagged_reads)
       const bool unaligned = nJ == 0 || jo[(size_t)r * na + 1] == jo[(size_t)r * na];     // p == 0 left no SegAlignment (Map_lowacc.h:578-581)
       if (!unaligned) {
         size_t total = 0;
@@ -501,7 +575,8 @@ extern "C" int lra_map_records(lra_ctx* ctx, const lra_map_result* res, const lr
         cigars.reserve(total);                                            // the records keep pointers into these strings
         for (int p = 0; p < na; p++) {
           const size_t j = (size_t)r * na + p;
-          if (jo[j + 1] == jo[j]) continue;
+          // a chain that never reaches :574 ends the loop over p (:267, :491); one that does keeps its (possibly empty) group (:574-600)
+          if (!reached.empty() ? !reached[j] : jo[j + 1] == jo[j]) break;
           for (uint64_t a = jo[j]; a < jo[j + 1]; a++) {
             std::string cg;
             cg.reserve((size_t)(roff[a + 1] - roff[a]) * 4 + 8);
@@ -556,7 +631,8 @@ extern "C" int lra_map_records(lra_ctx* ctx, const lra_map_result* res, const lr
         const int n = (int)seg_off.size() - 1;
         groups.assign(n, lra_aln_group()); index.assign(n, 0);
         if ((rc = lra_group_alignments(recs.data(), seg_off.data(), n, groups.data())) || (rc = lra_order_alignments(groups.data(), n, recs.data(), index.data(), 0)) ||
-            (rc = lra_simple_mapqv(groups.data(), index.data(), n, recs.data(), o->bypassClustering, o->readType == LRA_READ_CLR, o->readType == LRA_READ_ONT, o->globalK)))
+            (rc = lra_simple_mapqv(groups.data(), index.data(), n, recs.data(), o->bypassClustering, o->readType == LRA_READ_CLR, o->readType == LRA_READ_ONT,
+                                   o->localK)))                         // SimpleMapQV(alignmentsOrder, read, smallOpts): smallOpts.globalK = glIndex.k (Map_lowacc.h:233, :610)
           break;
         lra_output_read(groups.data(), index.data(), n, recs.data(), o->PrintNumAln, (char)o->printFormat, o->hardClip, passthrough, 0, nullptr, nullptr, 0, &need);
         buf.resize(need + 1);

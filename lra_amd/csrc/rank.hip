@@ -13,6 +13,9 @@
 
 namespace {
 const unsigned READ_REVERSE = 0x10, READ_SECONDARY = 0x100, READ_SUPPLEMENTARY = 0x800;   // Alignment.h:17-19
+// (int) of a float as the reference binary performs it (x86-64 cvttss2si): NaN and values outside int's range give INT_MIN.  SimpleMapQV
+// reaches this with y = NumOfAnchors0 / 0 when the second group is empty (a primary chain that produced no SegAlignment, Map_lowacc.h:574).
+inline int f2i(float v) { return (v != v || v >= 2147483648.0f || v < -2147483648.0f) ? (int)0x80000000 : (int)v; }
 }
 
 // SetFromSegAlignment :944-983 for group g over recs[seg_off[g] .. seg_off[g+1]); `g` must come zero-initialised the way the
@@ -97,8 +100,8 @@ extern "C" int lra_simple_mapqv(const lra_aln_group* groups, const int32_t* inde
         const float pen_cm_1 = pen(a), identity = ident(a);
         const float l = a.value > 3 ? logf(a.value / globalK) : 0;
         long mapq;
-        if (!bypass_clustering) mapq = (int)(pen_cm_1 * q_coef * l * identity);
-        else mapq = (int)(pen_cm_1 * q_coef * identity);
+        if (!bypass_clustering) mapq = f2i(pen_cm_1 * q_coef * l * identity);
+        else mapq = f2i(pen_cm_1 * q_coef * identity);
         mapq = mapq > 0 ? mapq : 0;
         a.mapqv = (unsigned char)(mapq < 60 ? mapq : 60);
       }
@@ -116,9 +119,9 @@ extern "C" int lra_simple_mapqv(const lra_aln_group* groups, const int32_t* inde
         const float l = a.value > 3 ? logf(a.value / globalK) : 0;
         identity = identity < 1 ? identity : 1;
         long mapq;
-        if (x >= 0.990f) mapq = (int)(pen_cm_1 * (1.0f - x) * y * identity);
-        else if (!bypass_clustering) mapq = (int)(pen_cm_1 * q_coef * (1.0f - x) * l * y * identity);
-        else mapq = (int)(pen_cm_1 * q_coef * (1.0f - x) * y * identity);
+        if (x >= 0.990f) mapq = f2i(pen_cm_1 * (1.0f - x) * y * identity);
+        else if (!bypass_clustering) mapq = f2i(pen_cm_1 * q_coef * (1.0f - x) * l * y * identity);
+        else mapq = f2i(pen_cm_1 * q_coef * (1.0f - x) * y * identity);
         mapq -= (int)(4.343f * logf(len) + .499f);
         mapq = mapq > 0 ? mapq : 0;
         a.mapqv = (unsigned char)(mapq < 60 ? mapq : 60);

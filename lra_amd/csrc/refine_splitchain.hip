@@ -11,7 +11,9 @@
 // AppendValues' diagonal / box test, again count then emit, so the matches of a split chain come out contiguous and in the reference's
 // order.  (4) rsc_finish, one wave per chain slot: SwapStrand on reverse split chains, box and refineEffiency by wave reduction.
 // UNDEFINED BEHAVIOUR IN THE REFERENCE: with opts.limitrefine (the default) the per-window upper diagonal bound starts from an
-// uninitialised variable (ChainRefine.h:468).  It is started here from the first anchor's diagonal, like the lower bound beside it.
+// uninitialised variable (ChainRefine.h:468, `miniMaxDiag = miniMaxDiag;`).  What the reference binary does with it was measured
+// (SURVEY.md H2): the stale stack slot holds a pointer-sized value that only grows, i.e. there is NO upper diagonal bound; only
+// miniMinDiag - 100 filters (AppendValues, TupleOps.h:168).  That is what is implemented: the upper bound is 2^60.
 // Algorithmic bytes: 21 B per chain anchor, 36 B per task, 8 B per candidate pair in, 8 B per kept match out.
 #include "common.h"
 #include "scan.h"
@@ -112,16 +114,17 @@ __global__ void __launch_bounds__(64) rsc_tasks(RscArgs a) {
       if (matchStart >= m) continue;
       if (matchEnd == matchStart) continue;
       uint32_t readStart = qS(matchStart), readEnd = qS(matchEnd - 1);
-      int64_t miniMin = (int64_t)tS(matchStart) - (int64_t)qS(matchStart), miniMax = miniMin;
+      int64_t miniMin = (int64_t)tS(matchStart) - (int64_t)qS(matchStart);
+      const int64_t miniMax = (int64_t)1 << 60;                            // no upper bound: see the header
       for (int mi = matchStart; mi < matchEnd; mi++) {
         const uint32_t q0 = qS(mi), q1 = q0 + (uint32_t)a.clen[AN(mi)];
         if (q0 < readStart) readStart = q0;
         if (q1 > readEnd) readEnd = q1;
         const int64_t d = (int64_t)tS(mi) - (int64_t)q0;
-        miniMin = min(miniMin, d); miniMax = max(miniMax, d);
+        miniMin = min(miniMin, d);
       }
       if (readStart == readEnd) { if (lsi > ls && readStart > 0) readStart = 0; }   // prev_readEnd is 0 here (:452, :461)
-      miniMin -= 100; miniMax += 100;
+      miniMin -= 100;
       const uint32_t sow = 500;
       if (lsi == ls) readStart = (readStart < sow) ? 0 : readStart - sow;
       if (lsi == le) readEnd = (readEnd + sow > readLen) ? readLen : readEnd + sow;

@@ -110,7 +110,7 @@ class MapResult(C.Structure):
     """lra_map_result (include/lra_hip.h)"""
     _fields_ = ([("n_reads", C.c_int32), ("num_aln", C.c_int32), ("n_jobs", C.c_uint64), ("n_alignments", C.c_uint64), ("n_blocks", C.c_uint64),
                  ("n_runs", C.c_uint64)] +
-                [(n, C.c_void_p) for n in ("d_job_aln_off", "d_job_status", "d_aln_read", "d_strand", "d_supp", "d_secondary", "d_n0", "d_n1", "d_chrom",
+                [(n, C.c_void_p) for n in ("d_job_aln_off", "d_job_status", "d_job_reached", "d_read_status", "d_aln_read", "d_strand", "d_supp", "d_secondary", "d_n0", "d_n1", "d_chrom",
                                            "d_first_sdp_value", "d_block_off", "d_blocks", "d_refine_status", "d_counts", "d_value", "d_run_off", "d_runs",
                                            "d_strands")] +
                 [("rc_base", C.c_uint64), ("counters", MapCounters)])
@@ -193,7 +193,9 @@ class LowAccMapper:
         ctx = self.ctx
         nA, nJ = int(res.n_alignments), int(res.n_jobs)
         d = {"job_aln_off": ctx.to_host(res.d_job_aln_off, nJ + 1, np.uint64) if nJ else np.zeros(1, np.uint64),
-             "job_status": ctx.to_host(res.d_job_status, nJ, np.uint32) if nJ else np.zeros(0, np.uint32)}
+             "job_status": ctx.to_host(res.d_job_status, nJ, np.uint32) if nJ else np.zeros(0, np.uint32),
+             "job_reached": ctx.to_host(res.d_job_reached, nJ, np.uint8) if nJ else np.zeros(0, np.uint8),
+             "read_status": ctx.to_host(res.d_read_status, int(res.n_reads), np.uint32) if int(res.n_reads) else np.zeros(0, np.uint32)}
         for k, dt in (("aln_read", np.uint32), ("strand", np.int32), ("supp", np.int32), ("secondary", np.int32), ("n0", np.int32), ("n1", np.int32),
                       ("chrom", np.int32), ("first_sdp_value", np.float32), ("refine_status", np.int32), ("value", np.float32)):
             p_ = getattr(res, "d_" + k)
@@ -238,8 +240,11 @@ class LowAccMapper:
         sres = seed.seed_batch(ctx, rbatch, o.globalK, o.globalW, o.globalMaxFreq)
         cres = cluster.clean_matches_batch(ctx, self.clean_opts, CH)
         eres = cluster.linear_extend_batch(ctx, o.globalK, rbatch)
+        # match_rate = 3 for a read with a repetitive cluster (Map_lowacc.h:86-89, :184-185)
+        rate = C.c_void_p()
+        ctx.check(ctx.lib.lra_match_rate_batch(ctx.h, C.byref(cres), C.c_float(o.initial_anchorbonus), C.byref(rate)))
         chres = chain.sparse_dp_batch(ctx, nR, cres.d_cluster_off, eres.d_e_start, eres.d_e_count, cres.d_c_strand, eres.d_e_qpos, eres.d_e_tpos,
-                                      eres.d_e_len, rbatch.off, self.sdp_opts)
+                                      eres.d_e_len, rbatch.off, self.sdp_opts, rate=rate.value)
         num_aln = int(chres.num_aln)
         # chains[p].NumOfAnchors0 for a13 (the second sparse DP reuses the first one's buffers)
         slot_n0 = ctx.to_tensor(chres.d_chain_len, nR * num_aln, torch.int32) if nR * num_aln else None
@@ -263,6 +268,16 @@ class LowAccMapper:
         if "n_local_task_words" not in st and rres.n_tasks:
             t4 = [ctx.to_tensor(p_, rres.n_tasks, torch.int64) for p_ in (rres.d_task_q_lo, rres.d_task_q_hi, rres.d_task_t_lo, rres.d_task_t_hi)]
             st["n_local_task_words"] = int((t4[1] - t4[0]).sum() + (t4[3] - t4[2]).sum())
+        # which primary chains reach Map_lowacc.h:574 (split chains left, refined clusters not all empty)
+        n_slots = nR * num_aln
+        if n_slots:
+            nsp = ctx.to_tensor(spres.d_n_split, n_slots, torch.int32)
+            spst = ctx.to_tensor(spres.d_status, n_slots, torch.int32)
+            cbase = ctx.to_tensor(mres.d_cluster_base, n_slots + 1, torch.int64)
+            moff = ctx.to_tensor(bres.d_match_off, int(bres.n_frags) + 1, torch.int64)
+            job_reached = ((spst == 0) & (nsp > 0) & (moff[cbase[1:]] > moff[cbase[:-1]])).cpu().numpy()
+        else:
+            job_reached = np.zeros(0, bool)
         inp, ares = chain.local_refine_from_sdp(ctx, num_aln, slot_n0, mres, ch2, rbatch.off, both, tot, gdev, CH)
         nA, nJ = int(ares.n_alignments), int(ares.n_jobs)
         aoff = ctx.to_tensor(ares.d_job_aln_off, nJ + 1, torch.int64)
@@ -284,7 +299,7 @@ class LowAccMapper:
         r = MapBatchResult()
         r.n_reads, r.num_aln, r.n_alignments, r.n_jobs = nR, num_aln, nA, nJ
         r.alignments, r.refined, r.stat, r.refine_status = ares, fres, tres, refine_status
-        r.aln_job, r.aln_read, r.job_aln_off = aln_job, aln_read, aoff
+        r.aln_job, r.aln_read, r.job_aln_off, r.job_reached = aln_job, aln_read, aoff, job_reached
         r.refine_batch, r.strands, r.rc_base = fb, both, tot
         # the refined block triples: what a rank hands to the gather step
         r.block_records = ctx.to_tensor(fres.d_blocks, 3 * fres.n_blocks, torch.int32)
@@ -313,9 +328,9 @@ class LowAccMapper:
             if not unaligned:
                 for p in range(na):
                     j = r * na + p
-                    if jo[j + 1] == jo[j]:
-                        # the reference pushes an empty SegAlignmentGroup for such a chain and carries on; it holds no record
-                        continue
+                    if not res.job_reached[j]:
+                        break                                                  # Map_lowacc.h:267, :491: the loop over p ends
+                    # (a chain that reaches :574 keeps its SegAlignmentGroup even when it is empty)
                     for a in range(int(jo[j]), int(jo[j + 1])):
                         c = counts[a]
                         rec = emit.AlnRecord()
@@ -343,7 +358,7 @@ class LowAccMapper:
                 un.read_name, un.read, un.qual, un.read_len = name, rd, ql, len(rd)
                 text, _, _, _ = emit.finish_read([], [0], fmt=o.printFormat, unaligned=un)
             else:
-                text, _, _, _ = emit.finish_read(recs, seg_off, bypass_clustering=o.bypassClustering, read_type=o.read_type, globalK=o.globalK,
+                text, _, _, _ = emit.finish_read(recs, seg_off, bypass_clustering=o.bypassClustering, read_type=o.read_type, globalK=o.localK,
                                                  print_num_aln=o.PrintNumAln, fmt=o.printFormat, hard_clip=o.hardClip, passthrough=passthrough)
             out.append(text)
         return out

@@ -11,10 +11,10 @@
 // Parity status: PARITY UNPINNED -- ChainRefine.h needs Genome.h / Clustering.h (htslib); restated from the source text.
 //
 // UNDEFINED BEHAVIOUR IN THE REFERENCE (default options): with opts.limitrefine (Options.h:234, true unless --skiplimitrefine) the upper
-// diagonal bound of every genome window starts from `miniMaxDiag = miniMaxDiag;` (ChainRefine.h:468), an uninitialised long.  The lower
-// bound next to it starts from the first anchor's diagonal; this restatement (and the kernel) starts the upper bound the same way,
-// which is what the loop that follows computes whenever the garbage is not larger than the true maximum.  limitrefine = 0 is fully
-// defined by the source and is restated literally.
+// diagonal bound of every genome window starts from `miniMaxDiag = miniMaxDiag;` (ChainRefine.h:468), an uninitialised long.  SURVEY.md
+// H2 measured what the reference binary does: the stale slot holds a pointer-sized value, so there is no upper diagonal bound at all
+// (`1L<<60` reproduced the binary on 400/400 reads; "as intended" initialisation changed 13/200 -ONT records).  This restatement and
+// the kernel implement the measured behaviour: +infinity.  limitrefine = 0 is fully defined by the source and is restated literally.
 #include "oracle_common.h"
 #include <algorithm>
 #include <vector>
@@ -115,12 +115,13 @@ extern "C" long oracle_refine_splitchain(int n, const uint32_t* q, const uint32_
     int64_t miniMinDiag = 0, miniMaxDiag = 0;
     if (o->limitrefine) {
       miniMinDiag = (int64_t)tS(matchStart) - (int64_t)qS(matchStart);
-      miniMaxDiag = miniMinDiag;                                          // see the header: uninitialised in the reference
-      for (int mi = matchStart; mi < matchEnd; mi++) {
+      // :468 `miniMaxDiag = miniMaxDiag;` reads an uninitialised local.  What the reference binary does (measured on
+      // x86-64 Linux, -O0 and -O2, -t 1 and -t 8): the stale stack slot holds a pointer-sized value (~9.4e13) that only grows, so
+      // there is NO upper diagonal bound when limitrefine is on -- only miniMinDiag - 100 filters.  Hard-coded as +infinity.
+      miniMaxDiag = (int64_t)1 << 60;
+      for (int mi = matchStart; mi < matchEnd; mi++)
         miniMinDiag = std::min(miniMinDiag, (int64_t)tS(mi) - (int64_t)qS(mi));
-        miniMaxDiag = std::max(miniMaxDiag, (int64_t)tS(mi) - (int64_t)qS(mi));
-      }
-      miniMinDiag -= 100; miniMaxDiag += 100;
+      miniMinDiag -= 100;
     }
     const int sow = 500;
     if (lsi == ls) readStart = (readStart < (uint32_t)sow) ? 0 : readStart - sow;

@@ -12,6 +12,7 @@ ONT = dict(globalK=17, globalW=10, globalMaxFreq=150, localK=10, localW=5, local
 CLR = dict(ONT, globalK=15, globalMaxFreq=250, refineBand=20, initial_anchorbonus=15.0, second_anchorbonus=6.0, alnthres=0.50, SecondCleanMaxDiag=120)
 
 _CHROM_CACHE = {}
+TRACE = {}                                                                # what the last map_read_lowacc call decided (match_rate, ...): for tests
 _COMP = np.zeros(256, np.uint8)
 for a, b in zip(b"ACGTNacgtn", b"TGCANtgcan"):
     _COMP[a] = b
@@ -55,11 +56,14 @@ def map_read_lowacc(read: bytes, genome: bytes, idx_key, idx_pos, g_index, opts=
     st = O.separate_strand(read, genome, K, sp[qi], idx_pos[ti])
     # a5, a7 (Map_lowacc.h:60-184)
     offs = [0]; cst = []; Q = []; T = []; Ln = []
+    repetitive = False                                                    # Map_lowacc.h:86-89
     for strand in (0, 1):
         sel = st == strand
         oq, ot, cl = O.clean_matches(sp[qi][sel], idx_pos[ti][sel], sk[qi][sel], strand, co, CH)
         for ci in range(len(cl["start"])):
             a, b = int(cl["start"][ci]), int(cl["end"][ci])
+            if 1.0 < float(cl["freq"][ci]) <= 2.0 and b - a >= 500:
+                repetitive = True
             c = int(cl["chrom"][ci]); off = np.uint32(CH[c])
             eq, et, el, _ = O.linear_extend(oq[a:b], ot[a:b] - off, strand, K, read, chrom_bytes(c, False))
             Q.append(eq); T.append(et + off); Ln.append(el); cst.append(strand); offs.append(offs[-1] + len(eq))
@@ -67,7 +71,9 @@ def map_read_lowacc(read: bytes, genome: bytes, idx_key, idx_pos, g_index, opts=
         return [], True
     Q = np.concatenate(Q); T = np.concatenate(T); Ln = np.concatenate(Ln)
     # a8: primary chains (Map_lowacc.h:185-188)
-    first = O.sdp_chain(offs, cst, Q, T, Ln, O.sdp_opts(L, rate=o["initial_anchorbonus"], **sdp_kw))
+    match_rate = 3.0 if repetitive else o["initial_anchorbonus"]          # Map_lowacc.h:184-185
+    TRACE["match_rate"] = match_rate
+    first = O.sdp_chain(offs, cst, Q, T, Ln, O.sdp_opts(L, rate=match_rate, **sdp_kw))
     if first["status"] < 0 or not first["chains"]:
         return [], True
     offs_a = np.asarray(offs)
@@ -80,14 +86,14 @@ def map_read_lowacc(read: bytes, genome: bytes, idx_key, idx_pos, g_index, opts=
         cstrand = np.asarray(cst, np.uint8)[cl_of]
         # a9 (Map_lowacc.h:189-245)
         sc = O.split_chain(Q[fr], T[fr], Ln[fr], cstrand, cl_of, ch["link"], CH, o["splitdist"], 1)
-        if sc is None:
-            alignments.append([]);
-            if p == 0: return alignments, True
-            continue
+        if sc is None or not len(sc["splits"]):                           # Map_lowacc.h:263-267: p == 0 -> unaligned, p > 0 -> break
+            if p == 0: return [[]], True
+            break
         kb = sc["keep"].astype(bool)
         q, t, al, cl, cs_ = Q[fr][kb], T[fr][kb], Ln[fr][kb], cl_of[kb], cstrand[kb]
         nsp = len(sc["splits"])
         segs = []
+        reached = False                                                   # does p get to `alignments.resize(alignments.size() + 1)` (:574)?
         if nsp:
             # a10 (Map_lowacc.h:246-294)
             moff = [0]; mq = []; mt = []; boxes = []; ok = True
@@ -108,7 +114,8 @@ def map_read_lowacc(read: bytes, genome: bytes, idx_key, idx_pos, g_index, opts=
                 eb = O.refine_btwn_splitchain(moff, mq, mt, np.array(boxes, np.uint32).reshape(-1, 4), strands, chroms, sc["split_link"], fwd, rc, genome, CH,
                                               K=o["localK"], W=o["localW"], refineSpaceDist=o["refineSpaceDist"], anchorstoosparse=o["anchorstoosparse"],
                                               match=o["match"], mismatch=o["mismatch"], indel=o["indel"], max_freq=o["localMaxFreq"])
-                if eb is not None:
+                if eb is not None and len(eb["q"]) > 0:                    # SizeRefinedClusters > 0 (:486-491)
+                    reached = True
                     em = O.merge_extend(eb["off"], eb["q"], eb["t"], eb["box"], strands, chroms, fwd, genome, CH, K=o["localK"])
                     # second sparse DP + RemovePairedIndels / RemoveSpuriousAnchors (Map_lowacc.h:521-540)
                     chains = []
@@ -132,6 +139,9 @@ def map_read_lowacc(read: bytes, genome: bytes, idx_key, idx_pos, g_index, opts=
                             aq.extend(c[0].tolist()); at.extend(c[1].tolist()); aln.extend(c[2].tolist()); off.append(len(aq))
                         segs = O.local_refine_alignment(off, aq, at, aln, [c[3] for c in chains], [c[4] for c in chains], [c[5] for c in chains],
                                                         [len(fr)] * len(chains), [c[6] for c in chains], p, fwd, rc, genome, CH) or []
+        if not reached:                                                   # :486-491 (or a stage hit undefined behaviour)
+            if p == 0: return [[]], True
+            break
         out = []
         for s in segs:
             sb = fwd if s["strand"] == 0 else rc

@@ -125,7 +125,7 @@ def test_map_reads_to_sam(ctx):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("preset", ["ont", "clr", "ont-bp", "ont-2chr"])
+@pytest.mark.parametrize("preset", ["ont", "clr", "ont-bp", "ont-2chr", "ont-rep"])
 def test_map_reads_match_oracle_pipeline(ctx, oracle, preset):
     """The C boundary against the oracle's stage functions composed on the CPU (tests/oracle_pipeline.py): every SegAlignment of every
     primary chain -- strand, Supplymentary, NumOfAnchors0/1, FirstSDPValue, the refined blocks -- bit for bit, on plain reads, reads with a
@@ -148,6 +148,17 @@ def test_map_reads_match_oracle_pipeline(ctx, oracle, preset):
     reads.append(synth.revcomp(np.concatenate([sim(300_000, 3000), sim(303_200, 3000)])))      # 200 bp deletion, read on the reverse strand
     reads.append(np.frombuffer(b"ACGT", dtype=np.uint8)[rng.integers(0, 4, 2500)].copy())      # junk
     CH = [0, 200_100, len(genome)] if preset == "ont-2chr" else [0, len(genome)]      # two chromosomes: the deletion / inversion reads lie in the first, the translocation spans both
+    if preset == "ont-rep":
+        # low-error 18 kb reads (>= 500 anchors per cluster) inside and outside a segmental duplication (24 kb, 0.5 % diverged): the first
+        # sparse DP runs with anchor bonus 3 where a cluster's anchorfreq lies in (1, 2] (Map_lowacc.h:86-89, :184-185), else with 20
+        genome = genome.copy()
+        dup = genome[100_000:124_000].copy()
+        flip = rng.random(len(dup)) < 0.005
+        dup[flip] = np.frombuffer(b"CGTA", np.uint8)[np.searchsorted(np.frombuffer(b"ACGT", np.uint8), dup[flip])]     # A->C, C->G, G->T, T->A
+        genome[330_000:354_000] = dup
+        ik, ip = synth.build_global_index(genome, o.globalK, o.globalW, 100)
+        for a0 in (101_000, 104_000, 332_000, 336_000, 200_000, 420_000):
+            reads.append(synth.simulate_read(rng, genome[a0:a0 + 18_001], 18_000, 0.02, mix, a0 == 104_000)[0])
     mapper = mapread.LowAccMapper(ctx, genome, ik, ip, [b"chr%d" % (i + 1) for i in range(len(CH) - 1)], CH, o)
     res = mapper.align(seed.ReadBatch(ctx, [r.tobytes() for r in reads]))
     out = mapper.fetch(res)
@@ -156,12 +167,17 @@ def test_map_reads_match_oracle_pipeline(ctx, oracle, preset):
     g_index = (mapread.seq_offsets(CH, 256).astype(np.uint64), g_bnd, g_tup)
     gbytes = genome.tobytes() + b"\0" * 64
     n_seg = n_supp = n_rev = n_multi = n_bp = 0
+    rates = []
     for r, rd in enumerate(reads):
         exp, unaligned = OP.map_read_lowacc(rd.tobytes(), gbytes, ik, ip, g_index, oo, chrom_pos=CH)
+        rates.append(OP.TRACE.get("match_rate"))
+        assert out["read_status"][r] == 0, (r, out["read_status"][r])
         for p in range(na):
             a0, a1 = int(out["job_aln_off"][r * na + p]), int(out["job_aln_off"][r * na + p + 1])
             e = exp[p] if p < len(exp) else []
             assert a1 - a0 == len(e), (r, p, a1 - a0, len(e))
+            if p > 0 or not unaligned:                                                        # which chains reach Map_lowacc.h:574
+                assert bool(out["job_reached"][r * na + p]) == (p < len(exp)), (r, p, len(exp))
             for a, s in zip(range(a0, a1), e):
                 assert (out["strand"][a], out["supp"][a], out["n0"][a], out["n1"][a], out["chrom"][a]) == (s["strand"], s["supp"], s["n0"], s["n1"], s["chrom"]), (r, p, a)
                 assert np.float32(out["first_sdp_value"][a]).view(np.uint32) == np.float32(s["value"]).view(np.uint32), (r, p, a)
@@ -178,6 +194,20 @@ def test_map_reads_match_oracle_pipeline(ctx, oracle, preset):
             assert out["job_aln_off"][r * na + 1] == out["job_aln_off"][r * na], r
     assert n_seg >= len(reads) - 1 and n_supp >= 2 and n_rev >= 3 and n_multi >= 2, (n_seg, n_supp, n_rev, n_multi)
     assert preset != "ont-bp" or n_bp >= 1, n_bp
+    if preset == "ont-rep":
+        # anchorfreq = matches / distinct read k-mers of a diagonal run (AVGfreq, Clustering.h:550): one repeated k-mer among >= 500 anchors
+        # puts a low-error read just above 1 (bonus 3), the reads inside the duplication just above 2 (bonus 20), 10 % error reads have
+        # fewer than 500 anchors per cluster (bonus 20).  Both values must occur, and the device computes the same rates.
+        assert 3.0 in rates and 20.0 in rates, rates
+        import ctypes as C
+        from lra_amd import cluster
+        batch = seed.ReadBatch(ctx, [r.tobytes() for r in reads])
+        seed.seed_batch(ctx, batch, o.globalK, o.globalW, o.globalMaxFreq)
+        cres = cluster.clean_matches_batch(ctx, mapper.clean_opts, CH)
+        d_rate = C.c_void_p()
+        ctx.check(ctx.lib.lra_match_rate_batch(ctx.h, C.byref(cres), C.c_float(o.initial_anchorbonus), C.byref(d_rate)))
+        got = ctx.to_host(d_rate.value, len(reads), np.float32)
+        assert got.tolist() == [float(x) if x is not None else 20.0 for x in rates], (got.tolist(), rates)
 
 
 def test_oracle_pipeline_sanity(oracle):

@@ -1,6 +1,7 @@
 """a10 glue: Refine_splitchain (ChainRefine.h:384-576).  The whole low-accuracy front end runs on the GPU (seed -> clean -> extend ->
 SDP#A -> SPLITChain), then lra_refine_splitchain_batch; the oracle restates Refine_splitchain per split chain on the GPU's own chains.
-Parity unpinned (ChainRefine.h needs htslib headers); with limitrefine the reference reads an uninitialised bound (see the oracle file)."""
+Parity unpinned (ChainRefine.h needs htslib headers); with limitrefine the reference reads an uninitialised upper bound: implemented as
+the binary's measured behaviour, no upper bound (see the oracle file)."""
 import numpy as np
 import pytest
 
@@ -22,8 +23,9 @@ def _seq_offsets(starts, total, window):
 
 
 def test_oracle_refine_splitchain_sanity():
-    # one forward anchor chain on the diagonal t = q + 1000 of a random sequence: every refined match must lie within 100 of that
-    # diagonal and inside the split chain's box, in chromosome coordinates
+    # one forward anchor chain on the diagonal t = q + 1000 of a random sequence: every refined match must lie no more than 100 below
+    # that diagonal (there is no upper bound with limitrefine: ChainRefine.h:468) and inside the split chain's box, in
+    # chromosome coordinates
     rng = np.random.default_rng(5)
     genome = rng.integers(0, 4, 6000).astype(np.uint8)
     g = np.frombuffer(b"ACGT", np.uint8)[genome]
@@ -38,10 +40,21 @@ def test_oracle_refine_splitchain_sanity():
     r = O.refine_splitchain(q, t, [20] * n, [0] * n, [0] * n, sptc, box, 0, 0, [0], [0, len(g)], len(read), (qso, qb, qt), (gso, gb, gt))
     assert r is not None and len(r["q"]) > 50
     d = r["t"].astype(np.int64) - r["q"].astype(np.int64)
-    assert np.all(np.abs(d - 1000) <= 100) and np.all(r["q"] >= box[0]) and np.all(r["q"] < box[1]) and np.all(r["t"] >= box[2]) and np.all(r["t"] < box[3])
+    assert np.all(d - 1000 >= -100) and np.all(r["q"] >= box[0]) and np.all(r["q"] < box[1]) and np.all(r["t"] >= box[2]) and np.all(r["t"] < box[3])
     assert np.sum(d == 1000) > 40 and r["box"][0] == r["q"].min() and r["box"][1] == r["q"].max() + 10
     r2 = O.refine_splitchain(q, t, [20] * n, [0] * n, [0] * n, sptc, box, 0, 0, [0], [0, len(g)], len(read), (qso, qb, qt), (gso, gb, gt), limitrefine=False)
     assert np.all(np.abs(r2["t"].astype(np.int64) - r2["q"].astype(np.int64) - 1000) <= 50) and len(r2["q"]) <= len(r["q"])
+    # a stretch of the read copied from 140 bases further along the genome (diagonal 1140, inside the same genome / read windows as the
+    # anchors around it): kept with limitrefine (no upper bound), dropped without it (maxDiagNum = 1050), and a stretch 140 bases
+    # further back (diagonal 860) is dropped by both (lower bounds 900 / 950)
+    read2 = read.copy(); read2[560:700] = g[1700:1840]; read2[1100:1240] = g[1960:2100]
+    qt2, qb2 = O.local_index_seq(read2.tobytes(), 10, 5, 256, 15)
+    r3 = O.refine_splitchain(q, t, [20] * n, [0] * n, [0] * n, sptc, box, 0, 0, [0], [0, len(g)], len(read), (qso, qb2, qt2), (gso, gb, gt))
+    d3 = r3["t"].astype(np.int64) - r3["q"].astype(np.int64)
+    assert np.sum(d3 == 1140) > 5 and np.sum(d3 == 860) == 0 and np.all(d3 >= 900)
+    r4 = O.refine_splitchain(q, t, [20] * n, [0] * n, [0] * n, sptc, box, 0, 0, [0], [0, len(g)], len(read), (qso, qb2, qt2), (gso, gb, gt), limitrefine=False)
+    d4 = r4["t"].astype(np.int64) - r4["q"].astype(np.int64)
+    assert np.sum(d4 == 1140) == 0 and np.sum(d4 == 860) == 0
 
 
 def _front_end(ctx, oracle):
