@@ -75,6 +75,38 @@ int lra_ctx_load_genome(lra_ctx* ctx, const char* h_seq, uint64_t len);
  * sorted by (t & 2^63-1), passed as two host arrays (t, pos).  Replaces `genomemm`
  * (MapRead.h:153).  Synchronous copy.                                                       */
 int lra_ctx_load_global_index(lra_ctx* ctx, const uint64_t* h_key, const uint32_t* h_pos, uint64_t n);
+/* The same two from device memory / built on the device:
+ *   lra_ctx_load_genome_device  copies len bytes from a device buffer.
+ *   lra_ctx_build_global_index  `lra index` on the loaded genome: StoreIndex (MMIndex.h:286-400) -- per chromosome
+ *       StoreMinimizers<GenomeTuple,Tuple>(seq, len, k, w) (MinCount.h:8-179), sort by masked key, keys occurring more than
+ *       max_freq (opts.globalMaxFreq) times dropped, then at most n_per_window (opts.NumOfminimizersPerWindow) entries per window of
+ *       winsize (opts.globalWinsize) bases in CountSort's order (:258-283: frequency ascending, sorted position descending) -- and
+ *       installs the result as the context's global index.  Index-time presets (lra.cpp:884-911): -ONT / -CCS 17, 10, 150, 15, 1;
+ *       -CLR 15, 10, 250, 12, 1; -CONTIG 19, 10, 30, 20, 1.  h_chrom_pos: n_chrom + 1 cumulative starts (Genome::header.pos).
+ *       The entries and their key order are StoreIndex's; equal keys keep their emission order (the reference: libstdc++'s std::sort
+ *       permutation), which also decides between two equal-key candidates inside one window.  *status = LRA_ST_OOB_SLOT when the
+ *       reference would index winCount out of range (:359-366).  Synchronous.
+ *   lra_ctx_global_index        the context's index as device arrays (for lra_write_mms after a copy to the host).                 */
+int lra_ctx_load_genome_device(lra_ctx* ctx, const char* d_seq, uint64_t len);
+int lra_ctx_build_global_index(lra_ctx* ctx, const uint64_t* h_chrom_pos, int n_chrom, int k, int w, int max_freq, int winsize, int n_per_window,
+                               uint64_t* n_minimizers, uint64_t* n_index, int* status);
+int lra_ctx_global_index(lra_ctx* ctx, const uint64_t** d_key, const uint32_t** d_pos, uint64_t* n);
+/* Index files (host arrays, host I/O), byte layouts of the reference:
+ *   .mms  WriteIndex / ReadIndex (MMIndex.h:402-424; Header::Write / Read Genome.h:59-84): int64 n; int32 globalK; int32 nChrom; per
+ *         chromosome int32 nameLen + name bytes; uint64 pos[nChrom + 1]; n GenomeTuples of 16 bytes {uint64 t; uint32 pos; 4 bytes of
+ *         padding (zeros here)}.  lra_read_mms: first call with key == NULL returns *n, *globalK, *n_chrom, *names_len (bytes for the
+ *         names, each NUL-terminated); the second call fills names, chrom_pos[n_chrom + 1], key[n], pos[n].
+ *   .gli  LocalIndex::Write / Read (MMIndex.h:138-173): int32 k, w, localIndexWindow, nRegions = n_windows + 1; uint64 seqOffsets[nRegions];
+ *         uint64 tupleBoundaries[nRegions]; uint64 nMin; nMin LocalTuples (uint32: t in the low 20 bits, pos in the high 12).
+ *         lra_read_gli: first call with seq_offsets == NULL returns the sizes.                                                          */
+int lra_write_mms(const char* path, int globalK, const char* const* chrom_names, const uint64_t* chrom_pos, int n_chrom, const uint64_t* key,
+                  const uint32_t* pos, uint64_t n);
+int lra_read_mms(const char* path, int* globalK, uint64_t* n, int* n_chrom, uint64_t* names_len, char* names, uint64_t* chrom_pos, uint64_t* key,
+                 uint32_t* pos);
+int lra_write_gli(const char* path, int k, int w, int window, uint64_t n_windows, const uint64_t* seq_offsets, const uint64_t* tuple_bnd,
+                  const uint32_t* tuples);
+int lra_read_gli(const char* path, int* k, int* w, int* window, uint64_t* n_windows, uint64_t* n_tuples, uint64_t* seq_offsets, uint64_t* tuple_bnd,
+                 uint32_t* tuples);
 
 /* ---- a1-a4: tier-1 seeding of a read batch ---------------------------------------------
  * Replaces, per read (MapRead.h:169-203):

@@ -32,6 +32,13 @@ SYMBOLS = {
     "lra_ctx_timing_get": (C.c_int, [_vp, C.c_char_p, C.POINTER(C.c_double), C.POINTER(C.c_int)]),
     "lra_ctx_load_genome": (C.c_int, [_vp, _vp, C.c_uint64]),
     "lra_ctx_load_global_index": (C.c_int, [_vp, _vp, _vp, C.c_uint64]),
+    "lra_ctx_load_genome_device": (C.c_int, [_vp, _vp, C.c_uint64]),
+    "lra_ctx_build_global_index": (C.c_int, [_vp, _vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _vp, _vp, _vp]),
+    "lra_ctx_global_index": (C.c_int, [_vp, _vp, _vp, _vp]),
+    "lra_write_mms": (C.c_int, [C.c_char_p, C.c_int, _vp, _vp, C.c_int, _vp, _vp, C.c_uint64]),
+    "lra_read_mms": (C.c_int, [C.c_char_p, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "lra_write_gli": (C.c_int, [C.c_char_p, C.c_int, C.c_int, C.c_int, C.c_uint64, _vp, _vp, _vp]),
+    "lra_read_gli": (C.c_int, [C.c_char_p, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "lra_create_rc_batch": (C.c_int, [_vp, C.c_int, _vp, _vp, _vp]),
     "lra_sort_minimizers_batch": (C.c_int, [_vp, C.c_int, _vp, _vp, _vp]),
     "lra_seed_batch": (C.c_int, [_vp, C.c_int, _vp, _vp, C.c_int, C.c_int, C.c_int, _vp]),

@@ -27,8 +27,8 @@ struct lra_ctx {
   void* aux = nullptr; size_t aux_bytes = 0;          // AffineOneGapAlign blocks of refine fallbacks
   void* out_buf = nullptr; size_t out_bytes = 0;
   uint64_t* scan_tmp = nullptr;
-  void* gbuf[80] = {};   // growable result / work buffers (lra_ensure)
-  size_t gbytes[80] = {};
+  void* gbuf[192] = {};   // growable result / work buffers (lra_ensure)
+  size_t gbytes[192] = {};
   // kernel timing
   bool sdp_inner = false;                    // local_refine.hip: its small inner sparse DP is timed under "sdp_inner_*"
   const char* sort_tag = "sort"; const char* sort_fb_tag = "sort_fallback";   // timing names of the exact-sort kernels (sdp.hip retags them)

@@ -70,7 +70,7 @@ extern "C" void lra_ctx_destroy(lra_ctx* ctx) {
   if (ctx->aux) (void)hipFree(ctx->aux);
   if (ctx->out_buf) (void)hipFree(ctx->out_buf);
   if (ctx->scan_tmp) (void)hipFree(ctx->scan_tmp);
-  for (int i = 0; i < 80; i++) if (ctx->gbuf[i]) (void)hipFree(ctx->gbuf[i]);
+  for (int i = 0; i < 192; i++) if (ctx->gbuf[i]) (void)hipFree(ctx->gbuf[i]);
   for (auto& r : ctx->recs) { (void)hipEventDestroy(r.a); (void)hipEventDestroy(r.b); }
   for (auto e : ctx->free_events) (void)hipEventDestroy(e);
   delete ctx;

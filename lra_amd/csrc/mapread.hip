@@ -79,22 +79,30 @@ __global__ void k_or_status_idx(uint64_t n, const uint32_t* __restrict__ status,
   const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i < n && status[i]) atomicOr(&read_status[idx[i] / (uint32_t)div], status[i]);
 }
-__global__ void k_or_status_csr(uint64_t n_slots, const uint64_t* __restrict__ base, const uint32_t* __restrict__ status, int div, uint32_t* __restrict__ read_status) {
+// per-split arrays live at chain_start[s] + k, k < n_split[s] (the split / refined-cluster numbering of chain_split.hip, refine_splitchain.hip, refine_btwn.hip)
+__global__ void k_or_status_split(uint64_t n_slots, int num_aln, const uint32_t* __restrict__ n_chains, const uint64_t* __restrict__ chain_start,
+                                  const uint32_t* __restrict__ n_split, const uint32_t* __restrict__ sp_status, const uint32_t* __restrict__ status,
+                                  uint32_t* __restrict__ read_status) {
   const uint64_t s = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (s >= n_slots) return;
+  const uint64_t r = s / (uint64_t)num_aln;
+  if ((uint32_t)(s % (uint64_t)num_aln) >= n_chains[r] || sp_status[s]) return;
   uint32_t v = 0;
-  for (uint64_t c = base[s]; c < base[s + 1]; c++) v |= status[c];
-  if (v) atomicOr(&read_status[s / (uint64_t)div], v);
+  for (uint64_t c = chain_start[s]; c < chain_start[s] + n_split[s]; c++) v |= status[c];
+  if (v) atomicOr(&read_status[r], v);
 }
 // Which primary chains p reach `alignments.resize(alignments.size() + 1)` (Map_lowacc.h:574): the chain exists, SPLITChain +
 // RemoveSpuriousSplitChain left a split chain (:263-267) and the refined clusters hold at least one match (:486-491).  A chain that
 // does not ends the loop over p (p > 0: break) or the read (p == 0: unaligned); one that does adds a SegAlignmentGroup even when
 // LocalRefineAlignment then produces no SegAlignment.
-__global__ void k_job_reached(uint64_t n_slots, const uint32_t* __restrict__ n_split, const uint32_t* __restrict__ sp_status, const uint64_t* __restrict__ cluster_base,
-                              const uint64_t* __restrict__ match_off, uint8_t* __restrict__ reached) {
+__global__ void k_job_reached(uint64_t n_slots, int num_aln, const uint32_t* __restrict__ n_chains, const uint64_t* __restrict__ chain_start,
+                              const uint32_t* __restrict__ n_split, const uint32_t* __restrict__ sp_status, const uint64_t* __restrict__ match_off,
+                              uint8_t* __restrict__ reached) {
   const uint64_t s = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (s >= n_slots) return;
-  reached[s] = (!sp_status[s] && n_split[s] > 0 && match_off[cluster_base[s + 1]] > match_off[cluster_base[s]]) ? 1 : 0;
+  bool ok = (uint32_t)(s % (uint64_t)num_aln) < n_chains[s / (uint64_t)num_aln] && !sp_status[s] && n_split[s] > 0;
+  if (ok) { const uint64_t cs = chain_start[s]; ok = match_off[cs + n_split[s]] > match_off[cs]; }
+  reached[s] = ok ? 1 : 0;
 }
 
 // per alignment: which read, where its strand's bases start, where its chromosome starts and how long it is
@@ -326,7 +334,7 @@ extern "C" int lra_match_rate_batch(lra_ctx* ctx, const lra_cluster_result* clus
   if (!ctx || !clusters || !d_rate) return LRA_ERR_INVALID;
   *d_rate = nullptr;
   const int n_reads = clusters->n_reads;
-  float* rate = (float*)lra_ensure(ctx, 12, ((size_t)n_reads + 1) * 4);
+  float* rate = (float*)lra_ensure(ctx, 80, ((size_t)n_reads + 1) * 4);
   if (!rate) return LRA_ERR_NOMEM;
   LRA_HIP_CHECK(ctx, hipSetDevice(ctx->device));
   if (n_reads) hipLaunchKernelGGL(k_match_rate, dim3(n_reads), dim3(64), 0, ctx->stream, n_reads, clusters->d_cluster_off, clusters->d_c_start, clusters->d_c_end,
@@ -349,7 +357,7 @@ extern "C" int lra_map_reads_lowacc_batch(lra_ctx* ctx, int n_reads, const char*
   LRA_HIP_CHECK(ctx, hipSetDevice(ctx->device));
   hipStream_t st = ctx->stream;
   auto grid = [](uint64_t n) { return dim3((unsigned)((n + 255) / 256)); };
-  uint32_t* read_status = (uint32_t*)lra_ensure(ctx, 22, ((size_t)n_reads + 1) * 4);
+  uint32_t* read_status = (uint32_t*)lra_ensure(ctx, 81, ((size_t)n_reads + 1) * 4);
   if (!read_status) return LRA_ERR_NOMEM;
   LRA_HIP_CHECK(ctx, hipMemsetAsync(read_status, 0, (size_t)n_reads * 4, st));
   const uint64_t* CH = m->chrom_pos.data();
@@ -419,10 +427,12 @@ extern "C" int lra_map_reads_lowacc_batch(lra_ctx* ctx, int n_reads, const char*
   // a9 MergeChain, a7 second pass, a8 second sparse DP (Map_lowacc.h:411-540)
   lra_merge_result mres;
   if ((rc = lra_merge_extend_batch(ctx, &chres, &spres, &bres, d_seq, d_read_off, genome, CH, nCh, o->localK, &mres))) return rc;
-  uint8_t* job_reached = (uint8_t*)lra_ensure(ctx, 23, n_slots + 64);
+  uint8_t* job_reached = (uint8_t*)lra_ensure(ctx, 82, n_slots + 64);
   if (!job_reached) return LRA_ERR_NOMEM;
-  hipLaunchKernelGGL(k_job_reached, grid(n_slots), dim3(256), 0, st, n_slots, spres.d_n_split, spres.d_status, mres.d_cluster_base, bres.d_match_off, job_reached);
-  if (rres.n_frags) hipLaunchKernelGGL(k_or_status_csr, grid(n_slots), dim3(256), 0, st, n_slots, mres.d_cluster_base, rres.d_status, num_aln, read_status);
+  hipLaunchKernelGGL(k_job_reached, grid(n_slots), dim3(256), 0, st, n_slots, num_aln, chres.d_n_chains, chres.d_chain_start, spres.d_n_split, spres.d_status,
+                     bres.d_match_off, job_reached);
+  if (rres.n_frags) hipLaunchKernelGGL(k_or_status_split, grid(n_slots), dim3(256), 0, st, n_slots, num_aln, chres.d_n_chains, chres.d_chain_start, spres.d_n_split,
+                                       spres.d_status, rres.d_status, read_status);
   lra_sdp_opts s2 = o->sdp; s2.mode = 1; s2.rate = o->second_anchorbonus;      // SparseDP :2287 with opts.second_anchorbonus (Options.h:221)
   lra_chain_result ch2;
   if ((rc = lra_sparse_dp_batch(ctx, (int)mres.n_groups, mres.d_iota, mres.d_anchor_off, mres.d_count, mres.d_strand, mres.d_q, mres.d_t, mres.d_len, mres.d_iota,
@@ -478,7 +488,7 @@ extern "C" int lra_map_reads_lowacc_batch(lra_ctx* ctx, int n_reads, const char*
   out->d_strands = both; out->rc_base = tot;
   if (getenv("LRA_MEM_DBG")) {
     size_t tot = 0;
-    for (int i = 0; i < 80; i++) { tot += ctx->gbytes[i]; if (ctx->gbytes[i] > (size_t(1) << 30)) fprintf(stderr, "[mem] gbuf %d %.1f GB\n", i, ctx->gbytes[i] / 1e9); }
+    for (int i = 0; i < 192; i++) { tot += ctx->gbytes[i]; if (ctx->gbytes[i] > (size_t(1) << 30)) fprintf(stderr, "[mem] gbuf %d %.1f GB\n", i, ctx->gbytes[i] / 1e9); }
     for (int i = 0; i < 4; i++) { tot += ctx->scratch_bytes[i]; fprintf(stderr, "[mem] scratch %d %.1f GB\n", i, ctx->scratch_bytes[i] / 1e9); }
     fprintf(stderr, "[mem] aux %.1f out %.1f GB total %.1f GB\n", ctx->aux_bytes / 1e9, ctx->out_bytes / 1e9, (tot + ctx->aux_bytes + ctx->out_bytes) / 1e9);
   }

@@ -912,24 +912,60 @@ extern "C" int lra_ctx_load_genome(lra_ctx* ctx, const char* h_seq, uint64_t len
   return LRA_OK;
 }
 
-extern "C" int lra_ctx_load_global_index(lra_ctx* ctx, const uint64_t* h_key, const uint32_t* h_pos, uint64_t n) {
-  if (!ctx || n >= (1ULL << 32)) return LRA_ERR_INVALID;
-  LRA_HIP_CHECK(ctx, hipSetDevice(ctx->device));
+// adopts device arrays (hipMalloc'ed, n + 1 entries at least) as the context's global index and builds the bucket directory over the key's top bits
+int lra_seed_install_index(lra_ctx* ctx, uint64_t* d_key, uint32_t* d_pos, uint64_t n) {
   lra_seed_state* s = seed_state(ctx);
-  if (!regrow(s->idx_key, n + 1) || !regrow(s->idx_pos, n + 1)) return lra_set_err(ctx, LRA_ERR_NOMEM, "index alloc");
-  s->n_idx = n;
-  LRA_HIP_CHECK(ctx, hipMemcpy(s->idx_key, h_key, n * 8, hipMemcpyHostToDevice));
-  LRA_HIP_CHECK(ctx, hipMemcpy(s->idx_pos, h_pos, n * 4, hipMemcpyHostToDevice));
+  if (s->idx_key) (void)hipFree(s->idx_key);
+  if (s->idx_pos) (void)hipFree(s->idx_pos);
+  s->idx_key = d_key; s->idx_pos = d_pos; s->n_idx = n;
+  if (!d_key || !d_pos) {
+    s->idx_key = nullptr; s->idx_pos = nullptr; s->n_idx = 0;
+    if (!regrow(s->idx_key, 2) || !regrow(s->idx_pos, 2)) return lra_set_err(ctx, LRA_ERR_NOMEM, "index alloc");
+    n = 0;
+  }
   // bucket directory: ~2 buckets per entry, on the top bits of the largest masked key
   int dbits = 1;
   while ((1ULL << dbits) < 2 * n && dbits < 27) dbits++;
-  const uint64_t maxkey = n ? (h_key[n - 1] & FOR_MASK) : 0;
+  uint64_t maxkey = 0;
+  if (n) { LRA_HIP_CHECK(ctx, hipMemcpy(&maxkey, s->idx_key + n - 1, 8, hipMemcpyDeviceToHost)); maxkey &= FOR_MASK; }
   int kbits = 1;
   while (kbits < 63 && (maxkey >> kbits)) kbits++;
   s->dir_shift = kbits > dbits ? kbits - dbits : 0;
   s->nbuckets = (uint32_t)((maxkey >> s->dir_shift) + 1);
   if (!regrow(s->dir, (size_t)s->nbuckets + 2)) return lra_set_err(ctx, LRA_ERR_NOMEM, "index directory");
   hipLaunchKernelGGL(dir_build_kernel, dim3((s->nbuckets + 256) / 256), dim3(256), 0, ctx->stream, s->nbuckets, s->dir_shift, s->idx_key, n, s->dir);
+  LRA_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+  return LRA_OK;
+}
+
+extern "C" int lra_ctx_load_global_index(lra_ctx* ctx, const uint64_t* h_key, const uint32_t* h_pos, uint64_t n) {
+  if (!ctx || n >= (1ULL << 32)) return LRA_ERR_INVALID;
+  LRA_HIP_CHECK(ctx, hipSetDevice(ctx->device));
+  uint64_t* dk = nullptr; uint32_t* dp = nullptr;
+  if (!regrow(dk, n + 1) || !regrow(dp, n + 1)) { if (dk) (void)hipFree(dk); return lra_set_err(ctx, LRA_ERR_NOMEM, "index alloc"); }
+  LRA_HIP_CHECK(ctx, hipMemcpy(dk, h_key, n * 8, hipMemcpyHostToDevice));
+  LRA_HIP_CHECK(ctx, hipMemcpy(dp, h_pos, n * 4, hipMemcpyHostToDevice));
+  return lra_seed_install_index(ctx, dk, dp, n);
+}
+
+// the context's global index (device arrays; the .mms payload as two columns)
+extern "C" int lra_ctx_global_index(lra_ctx* ctx, const uint64_t** d_key, const uint32_t** d_pos, uint64_t* n) {
+  if (!ctx || !ctx->seed || !n) return LRA_ERR_INVALID;
+  if (d_key) *d_key = ctx->seed->idx_key;
+  if (d_pos) *d_pos = ctx->seed->idx_pos;
+  *n = ctx->seed->n_idx;
+  return LRA_OK;
+}
+
+// the genome from a device buffer (copied: the context owns its reference data)
+extern "C" int lra_ctx_load_genome_device(lra_ctx* ctx, const char* d_seq, uint64_t len) {
+  if (!ctx || (!d_seq && len)) return LRA_ERR_INVALID;
+  LRA_HIP_CHECK(ctx, hipSetDevice(ctx->device));
+  lra_seed_state* s = seed_state(ctx);
+  if (!regrow(s->genome, len + 64)) return lra_set_err(ctx, LRA_ERR_NOMEM, "genome alloc");
+  s->genome_len = len;
+  LRA_HIP_CHECK(ctx, hipMemcpyAsync(s->genome, d_seq, len, hipMemcpyDeviceToDevice, ctx->stream));
+  LRA_HIP_CHECK(ctx, hipMemsetAsync(s->genome + len, 0, 64, ctx->stream));
   LRA_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
   return LRA_OK;
 }

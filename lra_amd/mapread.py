@@ -261,6 +261,21 @@ class LowAccMapper:
                                                   refineSpaceDist=o.refineSpaceDist, anchorstoosparse=o.anchorstoosparse, match=o.localMatch,
                                                   mismatch=o.localMismatch, indel=o.localIndel, max_freq=o.localMaxFreq)
         mres = chain.merge_extend_batch(ctx, chres, spres, bres, rbatch.seq, rbatch.off, gdev, CH, K=o.localK)
+        # which primary chains reach Map_lowacc.h:574 (split chains left, refined clusters not all empty); before the second sparse DP, which
+        # reuses the first one's result arrays
+        n_slots = nR * num_aln
+        if n_slots:
+            nsp = ctx.to_tensor(spres.d_n_split, n_slots, torch.int32).to(torch.int64)
+            spst = ctx.to_tensor(spres.d_status, n_slots, torch.int32)
+            cs = ctx.to_tensor(chres.d_chain_start, n_slots, torch.int64)
+            nch = ctx.to_tensor(chres.d_n_chains, nR, torch.int32).to(torch.int64)
+            exists = (torch.arange(n_slots, device=ctx.device) % num_aln) < torch.repeat_interleave(nch, num_aln)
+            moff = ctx.to_tensor(bres.d_match_off, int(bres.n_frags) + 1, torch.int64)
+            ok = exists & (spst == 0) & (nsp > 0)
+            cs = torch.where(ok, cs, torch.zeros_like(cs)); nsp = torch.where(ok, nsp, torch.zeros_like(nsp))
+            job_reached = (ok & (moff[cs + nsp] > moff[cs])).cpu().numpy()
+        else:
+            job_reached = np.zeros(0, bool)
         ch2 = chain.sparse_dp_batch(ctx, int(mres.n_groups), mres.d_iota, mres.d_anchor_off, mres.d_count, mres.d_strand, mres.d_q, mres.d_t, mres.d_len,
                                     mres.d_iota, self.sdp2_opts)
         st.update(n_btwn_problems=bres.n_problems, n_btwn_rounds=bres.n_rounds, n_refined_after_btwn=bres.n_matches, n_merged_clusters=mres.n_groups,
@@ -268,16 +283,6 @@ class LowAccMapper:
         if "n_local_task_words" not in st and rres.n_tasks:
             t4 = [ctx.to_tensor(p_, rres.n_tasks, torch.int64) for p_ in (rres.d_task_q_lo, rres.d_task_q_hi, rres.d_task_t_lo, rres.d_task_t_hi)]
             st["n_local_task_words"] = int((t4[1] - t4[0]).sum() + (t4[3] - t4[2]).sum())
-        # which primary chains reach Map_lowacc.h:574 (split chains left, refined clusters not all empty)
-        n_slots = nR * num_aln
-        if n_slots:
-            nsp = ctx.to_tensor(spres.d_n_split, n_slots, torch.int32)
-            spst = ctx.to_tensor(spres.d_status, n_slots, torch.int32)
-            cbase = ctx.to_tensor(mres.d_cluster_base, n_slots + 1, torch.int64)
-            moff = ctx.to_tensor(bres.d_match_off, int(bres.n_frags) + 1, torch.int64)
-            job_reached = ((spst == 0) & (nsp > 0) & (moff[cbase[1:]] > moff[cbase[:-1]])).cpu().numpy()
-        else:
-            job_reached = np.zeros(0, bool)
         inp, ares = chain.local_refine_from_sdp(ctx, num_aln, slot_n0, mres, ch2, rbatch.off, both, tot, gdev, CH)
         nA, nJ = int(ares.n_alignments), int(ares.n_jobs)
         aoff = ctx.to_tensor(ares.d_job_aln_off, nJ + 1, torch.int64)

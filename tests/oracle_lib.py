@@ -155,6 +155,21 @@ def clean_matches(qpos, tpos, qkey, strand, opts: "CleanOpts", chrom_pos):
                                               tStart=ts[:ncl].copy(), tEnd=te[:ncl].copy(), chrom=ch[:ncl].copy(), freq=fr[:ncl].copy())
 
 
+def store_index(genome: bytes, chrom_pos, k=17, w=10, max_freq=150, winsize=15, n_per_window=1, stable=False):
+    """StoreIndex (MMIndex.h:286-400) -> (key uint64[], pos uint32[], status).  stable: equal keys keep their emission order (the device builder's
+    order); False = the reference's std::sort."""
+    L = lib()
+    cp = np.ascontiguousarray(chrom_pos, dtype=np.uint64)
+    L.oracle_store_index.restype = C.c_long
+    st = C.c_int(0)
+    args = (C.c_char_p(genome), _p(cp, C.c_uint64), len(cp) - 1, int(k), int(w), int(max_freq), int(winsize), int(n_per_window), 1 if stable else 0)
+    n = L.oracle_store_index(*args, None, None, C.c_long(0), C.byref(st))
+    key = np.zeros(max(1, n), np.uint64); pos = np.zeros(max(1, n), np.uint32)
+    n2 = L.oracle_store_index(*args, _p(key, C.c_uint64), _p(pos, C.c_uint32), C.c_long(n), C.byref(st))
+    assert n2 == n
+    return key[:n].copy(), pos[:n].copy(), st.value
+
+
 def linear_extend(q, t, strand, K, read: bytes, chrom: bytes):
     """Pair-version LinearExtend + DecideCoordinates for one cluster (t chromosome-relative)."""
     L = lib()
