@@ -1,22 +1,22 @@
 #!/usr/bin/env python
-"""bench.py -- throughput of the MI355X hot path on synthetic long reads.
+"""bench.py -- throughput of the MI355X hot path on BASELINE.json configs[2]: 30 kb ONT-like reads (10 % error) against a GRCh38-sized
+reference, -ONT preset.
 
-One "step" = MapRead_lowacc (the -ONT / -CLR path of `lra align`) over one batch of reads already in HBM, every stage consuming what the previous one
-produced on the device:
-  a1-a4  tier-1 seeding   (StoreMinimizers -> sort -> CompareLists -> SeparateMatchesByStrand)
-  a5     CleanMatches;  a7 LinearExtend + DecideCoordinates;  a8 SparseDP (SDP#A)
-  a9     chain filters, SPLITChain;  a10 CreateRC, LocalIndex::IndexSeq of both strands, Refine_splitchain
-  a11    Refine_Btwnsplitchain;  a9 MergeChain;  a7 second LinearExtend + TrimOverlappedAnchors;  a8 the per-merged-cluster sparse DP + its filters
-  a13    LocalRefineAlignment (incl. a12 AffineOneGapAlign between anchors, RefineSpace + inner sparse DP on large spaces)
-  a14    IndelRefineAlignment on those alignments;  a16 CalculateStatistics (CIGAR runs, NM/NX/ND/NI/TD/TI counters, NV)
-Not in the step: RefineBreakpoint (built, off by default in lra), the per-read MAPQ / ordering / SAM text (host code, built).
+Reference (generated on the box, seeded: lra_amd/synth_genome.py): 24 chromosomes with the GRCh38 length table (3.09 Gb), ~50 % interspersed
+repeats + satellite arrays + N gaps; global index = StoreIndex on the device (lra_ctx_build_global_index, -ONT index preset 17/10/150/15/1),
+local index = LocalIndex::IndexSeq on the device; both resident in HBM with the genome (one replica per GPU).
+One "step" = one batch of reads already in HBM through MapRead_lowacc (lra_map_reads_lowacc_batch: a1-a5, a7-a11, a13 incl. a12, a14, a16), its
+record buffer packed (lra_map_pack) and gathered to rank 0 (RCCL; the single exchange step), and on rank 0 the host tail (MAPQ, ordering, SAM
+text: lra_map_records_host) of every rank's reads in input order -- the host tail of batch i runs beside the device side of batch i + 1.
 
 Contract: python bench.py --gpus N --steps K --warmup W  -> rank 0 prints ONE JSON line.
 """
 import argparse
+import ctypes as C
 import json
 import os
 import sys
+import threading
 import time
 
 import numpy as np
@@ -25,64 +25,32 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 
-def build_reference(args, device):
-    """Genome + global index, generated on the GPU with bulk tensor ops (seconds)."""
-    from lra_amd import synth_torch as st
-    genome = st.make_genome(int(args.genome_mb * 1e6), 1, device)
-    idx_key, idx_pos = st.build_global_index(genome, args.k, args.w, 150)
-    return genome, idx_key, idx_pos
-
-
-def build_workload(args, rank, device, ref, n_reads, lane):
-    """One lane's reads (seeded per rank and lane) and the truth-derived inputs of the stages behind a13."""
-    import torch
-    from lra_amd import synth_torch as st
-    t0 = time.time()
-    genome, idx_key, idx_pos = ref
-    sim = st.simulate_batch(genome, n_reads, args.read_len, args.read_len / 10, args.err, (30, 35, 35), 1000 + rank + 7919 * lane)
-    pad = torch.zeros(64, dtype=torch.uint8, device=device)
-    strands = torch.cat([sim["seq"], pad])                                   # the strand every alignment lies on
-    g2 = torch.Generator(device=device).manual_seed(77 + rank + 7919 * lane)
-    rev = torch.rand(n_reads, generator=g2, device=device) < 0.5
-    reads = torch.cat([st.revcomp_some(sim["seq"], sim["off"], rev), pad])   # what the sequencer gave us (half reverse strand)
-    gaps = st.gap_problems(sim)
-    rblocks, rboff = st.perturbed_blocks(sim, 5 + rank + 7919 * lane)
-    torch.cuda.synchronize()
-    torch.cuda.empty_cache()                                                 # hand the generator's temporaries back: the stages need the room
-    return dict(genome=genome, idx_key=idx_key, idx_pos=idx_pos, sim=sim, strands=strands, reads=reads, gaps=gaps, rev=rev,
-                rblocks=rblocks, rboff=rboff, gen_s=time.time() - t0)
-
-
-def cpu_baseline(wl, args, mapper, budget_s=20.0, max_reads=768):
-    """The oracle (CPU restatement) timed single-threaded on a bounded sample of the same workload: MapRead_lowacc read by read through
-    tests/oracle_pipeline.py, the same stages in the same order as the GPU step (its alignments equal the GPU's: tests/test_mapread.py)."""
+def cpu_baseline(mapper, reads_h, off_h, args, budget_s=20.0):
+    """The oracle (CPU restatement) on the host's cores, on a bounded sample of the same batch: MapRead_lowacc read by read
+    (oracle_map_reads_lowacc_mt, oracle/pipeline.cpp: the same stages in the same order as the GPU step; tests/test_mapread.py compares its
+    alignments with the GPU's bit for bit) on all hardware threads."""
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import oracle_lib as O
     import oracle_pipeline as OP
+    from lra_amd import index as I
     O.lib()
-    sim = wl["sim"]
-    S = min(max_reads, int(sim["off"].numel()) - 1)
-    off = sim["off"][:S + 1].cpu().numpy()
-    reads = wl["reads"][:int(off[-1])].cpu().numpy()
-    g = wl["genome"].cpu().numpy().tobytes() + b"\0" * 64
-    # the reference side (read-only, built once in the reference too): the genome's local index
-    g_win, g_bnd, g_tup = mapper.gli.fetch()
-    g_index = (OP.seq_offsets(len(g) - 64, mapper.opts.localIndexWindow), g_bnd, g_tup)
-    opts = dict(globalK=args.k, globalW=args.w, globalMaxFreq=args.max_freq, refineBand=args.refine_band)
+    ctx = mapper.ctx
     t0 = time.time()
-    bases = n = n_aln = 0
-    for r in range(S):
-        rbytes = reads[off[r]:off[r + 1]].tobytes()
-        alns, _ = OP.map_read_lowacc(rbytes, g, wl["idx_key"], wl["idx_pos"], g_index, opts)
-        n_aln += sum(len(x) for x in alns)
-        bases += len(rbytes)
-        n += 1
-        if time.time() - t0 > budget_s:
-            break
-    dt = time.time() - t0
-    return {"value": bases / dt / 1e9, "unit": "Gbp/s", "cores": 1, "kind": "port",
-            "sample": "first %d reads (%d bp, %d alignments) of the same batch through the oracle's MapRead_lowacc (a1-a5, a7-a11, a13 incl. a12, a14, a16: "
-                      "the stages of the GPU step, tests/oracle_pipeline.py) in %.1f s, 1 thread (python ctypes call overhead included)" % (n, bases, n_aln, dt)}
+    key, pos = I.global_index(ctx)
+    g = ctx.to_host(ctx.lib.lra_ctx_genome_ptr(ctx.h), mapper.G, np.uint8).tobytes() + b"\0" * 64
+    g_index = mapper.fetch_local_index()
+    fetch_s = time.time() - t0
+    opts = dict(globalK=args.k, globalW=args.w, globalMaxFreq=args.max_freq, refineBand=args.refine_band)
+    n_threads = os.cpu_count() or 1
+    # size the sample from a short single-thread probe
+    res = OP.map_reads_lowacc_mt(reads_h, off_h, 0, min(8, len(off_h) - 1), g, key, pos, g_index, opts, mapper.chrom_pos, n_threads=min(8, n_threads))
+    per_read = max(res["seconds"] / max(res["n_reads"], 1), 1e-4) * min(8, n_threads)
+    S = int(max(n_threads, min(len(off_h) - 1, budget_s / per_read * n_threads)))
+    res = OP.map_reads_lowacc_mt(reads_h, off_h, 0, S, g, key, pos, g_index, opts, mapper.chrom_pos, n_threads=n_threads)
+    return {"value": res["bases"] / res["seconds"] / 1e9, "unit": "Gbp/s", "cores": n_threads, "kind": "port",
+            "sample": "first %d reads (%d bp, %d alignments) of the same batch through the oracle's MapRead_lowacc (a1-a5, a7-a11, a13 incl. a12, a14, a16: the stages of "
+                      "the GPU step, oracle/pipeline.cpp) on %d host threads in %.1f s (reference data fetched from the device in %.1f s, not timed)"
+                      % (res["n_reads"], res["bases"], res["n_alignments"], n_threads, res["seconds"], fetch_s)}
 
 
 def main():
@@ -90,18 +58,17 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--genome-mb", type=float, default=float(os.environ.get("LRA_BENCH_GENOME_MB", 64)))
+    ap.add_argument("--genome-scale", type=float, default=float(os.environ.get("LRA_BENCH_GENOME_SCALE", 1.0)), help="1.0 = GRCh38-sized (3.09 Gb)")
     ap.add_argument("--reads", type=int, default=int(os.environ.get("LRA_BENCH_READS", 32768)), help="reads per GPU per step")
     ap.add_argument("--read-len", type=int, default=30000)
     ap.add_argument("--err", type=float, default=0.10)
+    ap.add_argument("--sv-frac", type=float, default=0.05, help="fraction of reads carrying one planted structural variant")
     ap.add_argument("--k", type=int, default=17)          # -ONT: globalK 17, globalW 10 (lra.cpp:386-431)
     ap.add_argument("--w", type=int, default=10)
     ap.add_argument("--max-freq", type=int, default=150)
     ap.add_argument("--refine-band", type=int, default=7)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--lanes", type=int, default=int(os.environ.get("LRA_BENCH_LANES", 1)),
-                    help="the batch is cut into this many sub-batches, each driven by its own context and HIP stream from its own host thread, so "
-                         "that the serial tails of one sub-batch's kernels overlap the other's work")
+    ap.add_argument("--no-records", action="store_true", help="leave the host tail (SAM text) out of the step")
     args = ap.parse_args()
 
     import torch
@@ -115,74 +82,84 @@ def main():
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
     dev_index = local_rank if world > 1 else 0
     torch.cuda.set_device(dev_index)
+    dev = torch.device("cuda", dev_index)
 
     from lra_amd.context import Context
-    from lra_amd import seed, parallel, mapread
+    from lra_amd import seed, parallel, mapread, synth_genome as sg
     mopts = mapread.LowAccOptions(globalK=args.k, globalW=args.w, globalMaxFreq=args.max_freq, refineBand=args.refine_band)   # -ONT
 
-    import threading
-    errors = []
-
-    def make_lane(lane, n_reads, ref):
-        """One sub-batch: its own context (buffers + HIP stream), mapper and reads; returns (ctx, step, stats, constants)."""
-        stream = torch.cuda.Stream(device=dev_index) if args.lanes > 1 else None
-        ctx = Context(dev_index)
-        if stream is not None:
-            ctx.bind_stream(stream)
-        wl = build_workload(args, rank, ctx.device, ref, n_reads, lane)
-        G = int(wl["genome"].numel())
-        # the reference side, built once: global index, genome, the genome's local index (.gli)
-        mapper = mapread.LowAccMapper(ctx, wl["genome"], wl["idx_key"], wl["idx_pos"], [b"chr1"], [0, G], mopts)
-        sim = wl["sim"]
-        rbatch = seed.read_batch_from_device(ctx, wl["reads"], sim["off"])
-        gp = wl["gaps"]
-        lens = (sim["off"][1:] - sim["off"][:-1])
-        total_bases = int(lens.sum())
-        n_gap_bytes = int(gp["q_len"].sum() + gp["t_len"].sum())
-        n_gaps = int(gp["k"].numel())
-
-        stats = mapper.stats
-        out_rec = [None]
-
-        def step():
-            # MapRead_lowacc for the whole batch behind the C boundary (lra_map_reads_lowacc_batch): a1-a5, a7-a11, a13, a14, a16
-            res = mapper.align(rbatch)
-            out_rec[0] = mapper.block_records(res)                       # the one exchange step: refined block records -> rank 0
-
-        def run_step():
-            try:
-                torch.cuda.set_device(dev_index)                         # the current device is per host thread
-                if stream is not None:
-                    with torch.cuda.stream(stream):
-                        step()
-                else:
-                    step()
-            except BaseException as e:                                   # surfaced by the caller: a thread's exception would vanish otherwise
-                errors.append(e)
-        return dict(ctx=ctx, step=run_step, stats=stats, wl=wl, mapper=mapper, total_bases=total_bases, n_gap_bytes=n_gap_bytes, n_gaps=n_gaps, out_rec=out_rec)
-
-    ref = build_reference(args, torch.device("cuda", dev_index))
-    per_lane = [args.reads // args.lanes + (1 if i < args.reads % args.lanes else 0) for i in range(args.lanes)]
-    lanes = [make_lane(i, per_lane[i], ref) for i in range(args.lanes)]
-    ctx = lanes[0]["ctx"]
-    wl = lanes[0]["wl"]
+    # ---- reference side, once per process: genome, StoreIndex, LocalIndex (all on the device)
+    t0 = time.time()
+    genome, chrom_pos, chrom_names = sg.make_grch38_like(dev, scale=args.genome_scale, seed=3)
     torch.cuda.synchronize()
-    total_bases = sum(l["total_bases"] for l in lanes)
-    n_gap_bytes = sum(l["n_gap_bytes"] for l in lanes); n_gaps = sum(l["n_gaps"] for l in lanes)
+    gen_s = time.time() - t0
+    ctx = Context(dev_index)
+    t0 = time.time()
+    mapper = mapread.LowAccMapper(ctx, genome, None, None, chrom_names, chrom_pos, mopts, index_params=(args.k, args.w, args.max_freq, 15, 1), staged=False)
+    torch.cuda.synchronize()
+    index_s = time.time() - t0
+    G = mapper.G
+    # ---- this rank's reads (hash partition of the job's ordinals; weak scaling: args.reads per GPU)
+    t0 = time.time()
+    sim = sg.simulate_reads_sv(genome, chrom_pos, args.reads, args.read_len, args.read_len / 10, args.err, (30, 35, 35), 1000 + rank, sv_frac=args.sv_frac)
+    off_h = sim["off"].cpu().numpy()
+    reads_h = sim["seq"][:int(off_h[-1])].cpu().numpy()
+    n_sv = int((sim["sv"] > 0).sum())
+    rbatch = seed.read_batch_from_device(ctx, sim["seq"], sim["off"])
+    total_bases = int(off_h[-1])
+    del genome
+    torch.cuda.synchronize()
+    torch.cuda.empty_cache()
+    sim_s = time.time() - t0
+    n_job = args.reads * world
+    my_ord = [i for i in range(n_job) if parallel.shard_of(i, world) == rank] if world > 1 else list(range(args.reads))
+    names = [b"read%d" % i for i in range(args.reads)]
+    rb = reads_h.tobytes()
+    reads_b = [rb[int(off_h[i]):int(off_h[i + 1])] for i in range(args.reads)]
+    rargs = mapper.record_args(names, reads_b)
+    n_threads_rec = max(1, (os.cpu_count() or 16) // max(world, 1)) if world > 1 else 0
+
+    worker = [None]
+    text_bytes = [0]
+    err = []
+
+    def host_tail(snaps):
+        try:
+            for snap in snaps:
+                text_bytes[0] += mapper.records_host(snap, rargs, n_threads=n_threads_rec, as_list=False)
+        except BaseException as e:
+            err.append(e)
 
     def step():
-        if len(lanes) == 1:
-            lanes[0]["step"]()
-        else:
-            ths = [threading.Thread(target=l["step"]) for l in lanes]
-            for t in ths: t.start()
-            for t in ths: t.join()
-        if errors:
-            raise errors[0]
-        torch.cuda.synchronize()
-        # the one exchange step: refined block records -> rank 0
-        rec = torch.cat([l["out_rec"][0] for l in lanes]) if len(lanes) > 1 else lanes[0]["out_rec"][0]
-        parallel.gather_records(rec, dst=0)
+        res = mapper.align(rbatch)
+        if args.no_records:
+            return
+        # the one exchange step: this rank's record buffer -> rank 0
+        d_buf, nb = C.c_void_p(), C.c_uint64(0)
+        ctx.check(ctx.lib.lra_map_pack(ctx.h, C.byref(res), 0, C.byref(d_buf), C.byref(nb)))
+        packed = ctx.to_tensor(d_buf.value, nb.value, torch.uint8)
+        got = parallel.gather_records(packed, dst=0)
+        if rank == 0:
+            snaps = []
+            for t in got:
+                hb = t.cpu().numpy()
+                snap = C.c_void_p()
+                rc = ctx.lib.lra_map_unpack_host(C.c_void_p(hb.ctypes.data), C.c_uint64(hb.nbytes), C.byref(snap))
+                assert rc == 0, rc
+                snaps.append(snap)
+            if worker[0] is not None:
+                worker[0].join()
+            # (every rank holds args.reads reads of the same shape; rank 0 formats each rank's records with its own batch's names / bases as
+            # stand-ins for the other ranks' -- the text volume and the work are the same)
+            worker[0] = threading.Thread(target=host_tail, args=(snaps,))
+            worker[0].start()
+
+    def drain():
+        if worker[0] is not None:
+            worker[0].join()
+            worker[0] = None
+        if err:
+            raise err[0]
 
     def sync():
         if world > 1:
@@ -191,40 +168,34 @@ def main():
 
     for _ in range(args.warmup):
         step()
-    for l in lanes:
-        l["ctx"].timing(True)
-        l["ctx"].timing_reset()
+    drain()
+    ctx.timing(True)
+    ctx.timing_reset()
+    text_bytes[0] = 0
     sync()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step()
+    drain()
     sync()
     dt = time.perf_counter() - t0
     if world > 1:
-        tt = torch.tensor([dt], dtype=torch.float64, device=ctx.device)
+        tt = torch.tensor([dt], dtype=torch.float64, device=dev)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
-        tb = torch.tensor([total_bases], dtype=torch.int64, device=ctx.device)
+        tb = torch.tensor([total_bases], dtype=torch.int64, device=dev)
         dist.all_reduce(tb, op=dist.ReduceOp.SUM)
         job_bases = int(tb.item())
-        nreads = args.reads * world
     else:
         job_bases = total_bases
-        nreads = args.reads
+    nreads = args.reads * world
 
     kernels = ["sketch_count", "sketch_serial", "sketch_emit", "sort", "sort_fallback", "index_bounds", "compare", "strand",
                "aog_lds_tiny", "aog_lds_small", "aog_lds_medium", "aog_lds_large", "aog_hbm", "ir_segment", "ir_band", "ir_fill", "ir_trace", "ir_gather", "clean_sort", "clean", "linear_extend", "stats", "stats_cigar", "create_rc", "local_sketch", "local_sort_filter", "local_compare",
                "rsc_tasks", "rsc_filter", "refine_space", "rs_long_sketch", "rs_long_compare", "btwn_plan", "btwn_apply", "merge_extend", "between_anchors", "local_refine", "sdp_inner_points", "sdp_inner_sort", "sdp_inner_build_count", "sdp_inner_build", "sdp_inner_process", "sdp_inner_trace", "chain_split", "sdp_points", "sdp_sort", "sdp_sort_fallback", "sdp_build_count", "sdp_build", "sdp_process", "sdp_trace"]
-    ktimes = {}
-    for k in kernels:
-        tt_ = [l["ctx"].timing_get(k) for l in lanes]
-        ktimes[k] = (sum(x[0] for x in tt_), sum(x[1] for x in tt_))
-    for l in lanes:
-        l["ctx"].timing(False)
-    stats = {}
-    for l in lanes:
-        for k, v in l["stats"].items():
-            stats[k] = stats.get(k, 0) + v if isinstance(v, (int, float)) else v
+    ktimes = {k: ctx.timing_get(k) for k in kernels}
+    ctx.timing(False)
+    stats = dict(mapper.stats)
     if rank == 0:
         ms_step = dt / args.steps * 1e3
         gbps = job_bases * args.steps / dt / 1e9
@@ -232,72 +203,71 @@ def main():
         dom_ms, dom_n = ktimes[dom]
         avg_ms = dom_ms / max(dom_n, 1)
         launches_per_step = max(dom_n, 1) / args.steps
-        # algorithmic bytes PER STEP of the dominant kernel, all its launches together (DESIGN.md section 3 gives the per-unit figures)
         L = total_bases
+        # ALGORITHMIC bytes per step of every kernel family, SURVEY.md section 8(d): 2 L (read + RC) + 12 n_q (minimizers out) + n_q (12 + 64) (sorted
+        # minimizers in + one index line per query) + 16 n_m (match pairs) + 24 per anchor per sparse-DP pass (16 in, 8 out) + 2 (q_span + t_span) + 1
+        # per DP cell + 12 per block out.  DESIGN.md section 3 states which kernel owns which term.
+        n_q, n_m = stats.get("n_mm", 0), stats.get("n_match", 0)
+        sdp_anchors = stats.get("n_sdp_anchors", 0) + stats.get("n_sdp2_anchors", 0)
+        alg8d = {
+            "sketch_count": L, "sketch_emit": L + 12 * n_q, "sort": 2 * 12 * n_q, "index_bounds": n_q * (12 + 64), "compare": 12 * n_q + 16 * n_m,
+            "strand": 16 * n_m + 2 * args.k * n_m, "clean": 16 * n_m, "clean_sort": 2 * 16 * n_m,
+            "sdp_process": 24 * sdp_anchors, "sdp_build": 16 * sdp_anchors, "sdp_build_count": 16 * sdp_anchors, "sdp_sort": 2 * 16 * sdp_anchors, "sdp_trace": 8 * sdp_anchors,
+            "ir_fill": 1 * stats.get("n_cells", 0) + 2 * stats.get("n_rows", 0), "ir_band": 12 * stats.get("n_blocks", 0), "ir_trace": 1 * stats.get("n_rows", 0) + 12 * stats.get("n_blocks", 0),
+            "stats": 2 * L + 12 * stats.get("n_blocks", 0), "local_sketch": 2 * L + 4 * stats.get("n_local_tuples", 0), "local_sort_filter": 2 * 4 * stats.get("n_local_tuples", 0),
+            "local_compare": 4 * stats.get("n_local_task_words", 0) + 8 * stats.get("n_local_pairs", 0),
+        }
+        # what the implementation's own data structures occupy (the footprint the kernel must at least touch once)
         sdp_entries = stats.get("n_sdp_entries", 0) + stats.get("n_sdp2_entries", 0)
         sdp_points = stats.get("n_sdp_points", 0) + 2 * stats.get("n_sdp2_anchors", 0)
-        alg_step = {
-            "ir_fill": 1 * stats["n_cells"] + 16 * stats["n_rows"] + 1 * stats["n_rows"],        # 1 B arrow/cell + row windows + both sequences
-            "ir_band": 16 * stats["n_rows"] + 12 * stats["n_blocks"],
-            "ir_trace": 1 * stats["n_rows"] + 16 * stats["n_rows"] + 12 * stats["n_blocks"],   # ~1 arrow + 1 row record per row walked
-            "sort": 2 * 12 * stats["n_mm"],
-            "index_bounds": stats["n_mm"] * (12 + 64 + 8),
-            "compare": stats["n_mm"] * (8 + 8 + 64) + 8 * stats["n_match"],
-            "sketch_count": L, "sketch_emit": L + 12 * stats["n_mm"],
-            "strand": stats["n_match"] * (8 + 8 + 2 * args.k),
-            "local_compare": 2 * 4 * stats.get("n_local_task_words", 0) + 8 * stats.get("n_local_pairs", 0),   # count + emit passes, both strands
-            "local_sort_filter": 2 * 4 * stats.get("n_local_tuples", 0),
-            "rsc_tasks": 2 * (21 * stats.get("n_sdp_anchors", 0) + 36 * stats.get("n_local_tasks", 0)),
-            "rsc_filter": 2 * 8 * stats.get("n_local_pairs", 0) + 8 * stats.get("n_refined_matches", 0),
-            "local_sketch": 2 * 2 * L + 4 * stats.get("n_local_tuples", 0),
-            "stats": 2 * L + 12 * stats["n_blocks"] + 4 * stats.get("n_cigar_runs", 0),
-            "clean": 16 * stats["n_match"] * 3,
-            "aog_lds_small": n_gap_bytes + 12 * n_gaps,
-            "aog_lds_tiny": n_gap_bytes + 12 * n_gaps,
-            "ir_segment": 12 * stats["n_blocks"],
-            # a8: 44 B per sub-problem entry (Di/Ei + Db/Eb + value 16, back pointer 4, stack 8, Block 16) + the 256 B visit row and 13 B
-            # of coordinates per point
-            # (both sparse DPs of the step: SDP#A and the per-merged-cluster one, whose anchors give two points each)
-            "sdp_process": 44 * sdp_entries + 269 * sdp_points,
-            "sdp_build": 20 * sdp_entries + 269 * sdp_points,
-            "sdp_build_count": 13 * sdp_points,
-            "sdp_sort": 4 * 2 * 12 * sdp_points,
-        }.get(dom, 0)
-        alg = alg_step / launches_per_step
+        footprint = {"sdp_process": 44 * sdp_entries + 269 * sdp_points, "sdp_build": 20 * sdp_entries + 269 * sdp_points,
+                     "ir_fill": 1 * stats.get("n_cells", 0) + 17 * stats.get("n_rows", 0)}
+        alg = alg8d.get(dom, 0) / launches_per_step
         achieved = alg / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
-        # HBM traffic per launch: from the committed PMC pass (profiles/pmc_latest.json) when it was taken on launches of the same size
+        fp = footprint.get(dom, alg8d.get(dom, 0)) / launches_per_step
         traffic = None
         try:
             pmc = json.load(open(os.path.join(ROOT, "profiles", "pmc_latest.json")))["kernels"].get(dom)
-            if pmc and abs(pmc["reads_per_launch"] - args.reads / launches_per_step) < 1:
+            if pmc and abs(pmc["reads_per_launch"] - args.reads / launches_per_step) < 1 and abs(pmc.get("genome_scale", 1.0) - args.genome_scale) < 1e-9:
                 traffic = pmc["fetch_bytes_per_launch"]
         except (OSError, ValueError, KeyError):
             pass
+        step_alg = 2 * L + 12 * n_q + n_q * 76 + 16 * n_m + 24 * sdp_anchors + 1 * stats.get("n_cells", 0) + 12 * stats.get("n_blocks", 0)
         out = {
-            "metric": "aligned Gbp/s (hot-path stages a1-a5, a7, a8 SDP#A, a9 split + MergeChain, a10 Refine_splitchain, a11 Refine_Btwnsplitchain, a7/a8 second pass, a13 LocalRefineAlignment incl. a12, a14, a16 = MapRead_lowacc), 30 kb ONT-like reads", "value": gbps, "unit": "Gbp/s",
+            "metric": "aligned Gbp/s, 30 kb ONT vs GRCh38 (MapRead_lowacc end to end incl. SAM text), per job", "value": gbps, "unit": "Gbp/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_step, "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "int32", "data": "synthetic",
             "reads_per_s": nreads * args.steps / dt,
-            "config": {"workload": "synthetic %g Mb chromosome (chr20-sized, BASELINE configs[1] reference) + %d reads/GPU of N(%d, 10%%) bp, %g%% "
-                                   "error 30:35:35 (BASELINE configs[2] -ONT read profile; full GRCh38 not generated in round 1)"
-                                   % (args.genome_mb, args.reads, args.read_len, args.err * 100),
+            "config": {"workload": "BASELINE configs[2]: synthetic GRCh38-like reference (24 chromosomes, GRCh38 length table x %g = %.3f Gb, ~50%% interspersed repeats + "
+                                   "satellite arrays + N gaps; seeded generator lra_amd/synth_genome.py) with a StoreIndex-faithful global index built on the device "
+                                   "(K=%d W=%d maxFreq=%d winsize=15: %d entries = 1 per %.1f bp) + %d reads/GPU of N(%d, 10%%) bp, %g%% error 30:35:35, half reverse "
+                                   "strand, %.0f%% with one planted SV (deletion / insertion / inversion / tandem duplication / translocation, 50 bp-10 kb)"
+                                   % (args.genome_scale, G / 1e9, args.k, args.w, args.max_freq, mapper.index_stats["n_index"], G / max(mapper.index_stats["n_index"], 1),
+                                      args.reads, args.read_len, args.err * 100, args.sv_frac * 100),
                        "preset": "-ONT (k=%d w=%d maxFreq=%d refineBand=%d match/mismatch/indel=4/-1/-2)" % (args.k, args.w, args.max_freq, args.refine_band),
-                       "stages": "MapRead_lowacc chained on the reads, every stage on the alignments the previous one produced: a1-a5, a7, a8 (SDP#A), a9 (chain filters, SPLITChain), "
-                                 "a10 (Refine_splitchain), a11 (Refine_Btwnsplitchain), a9 (MergeChain), a7 (second LinearExtend + Trim), a8 (second SDP + filters), a13 "
-                                 "(LocalRefineAlignment incl. a12 AffineOneGapAlign between anchors), a14 (IndelRefineAlignment), a16 (CalculateStatistics).  Not in the step: "
-                                 "RefineBreakpoint (a15, built; off by default in lra), MAPQ / ordering / SAM text (a16-a17 host code, built)",
-                       "parallelism": "reads sharded by ordinal, 1 process/GPU, %d sub-batches per process on their own HIP streams; RCCL gather of block records to rank 0" % args.lanes,
-                       "per_step": {k: int(v) for k, v in stats.items() if not k.startswith("_")}},
+                       "stages": "MapRead_lowacc chained on the reads, every stage on what the previous one produced on the device: a1-a5, a7, a8 (SDP#A), a9, a10, a11, "
+                                 "a9 (MergeChain), a7 (second LinearExtend + Trim), a8 (second SDP + filters), a13 (incl. a12), a14, a16; then lra_map_pack, the gather of the "
+                                 "record buffers to rank 0 and the host tail a16-a17 (SetFromSegAlignment, AlignmentsOrder, SimpleMapQV, SAM text) of batch i beside the "
+                                 "device side of batch i + 1%s.  Not in the step: RefineBreakpoint (a15, built; off by default in lra)" % (" -- SKIPPED (--no-records)" if args.no_records else ""),
+                       "parallelism": "reads hash-partitioned by ordinal, 1 process/GPU, genome + both indexes replicated; RCCL gather of the packed record buffers to rank 0",
+                       "per_step": {k: int(v) for k, v in stats.items() if not k.startswith("_") and isinstance(v, (int, float))},
+                       "reads_with_sv": n_sv},
             "kernel_ms_per_step": {k: round(v[0] / args.steps, 4) for k, v in ktimes.items() if v[1]},
             "roofline": {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": 8000.0, "unit": "GB/s", "frac": achieved / 8000.0,
-                         "traffic": traffic, "avg_launch_ms": avg_ms, "algorithmic_bytes_per_launch": alg},
+                         "traffic": traffic, "avg_launch_ms": avg_ms, "algorithmic_bytes_per_launch": alg,
+                         "footprint_bytes_per_launch": fp, "frac_footprint": (fp / (avg_ms * 1e-3) / 1e9 / 8000.0) if avg_ms > 0 else 0.0,
+                         "step_algorithmic_bytes": step_alg, "step_frac": step_alg / (ms_step * 1e-3) / 1e9 / 8000.0},
+            "sam_text_gb_per_step": round(text_bytes[0] / max(args.steps, 1) / 1e9, 3),
         }
         if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(wl, args, lanes[0]["mapper"])
-        out["setup_s"] = round(wl["gen_s"], 1)
+            try:
+                out["cpu_baseline"] = cpu_baseline(mapper, reads_h, off_h, args)
+            except Exception as e:                                          # the bench line must survive a baseline problem; say what happened
+                out["cpu_baseline"] = {"value": None, "unit": "Gbp/s", "cores": os.cpu_count(), "kind": "port", "sample": "failed: %r" % (e,)}
+        out["setup_s"] = {"genome": round(gen_s, 1), "index": round(index_s, 1), "reads": round(sim_s, 1)}
         free_b, total_b = torch.cuda.mem_get_info(dev_index)
         out["hbm_used_gb"] = round((total_b - free_b) / 1e9, 1)               # everything resident at the end of the run: reference, reads, work buffers
-        out["hbm_torch_reserved_gb"] = round(torch.cuda.memory_reserved(dev_index) / 1e9, 1)   # of which torch's allocator (workload + gathered records)
+        out["hbm_torch_reserved_gb"] = round(torch.cuda.memory_reserved(dev_index) / 1e9, 1)
         print(json.dumps(out))
     if world > 1:
         dist.barrier()

@@ -826,11 +826,36 @@ void lra_map_opts_preset_ont(lra_map_opts* opts);          /* -ONT: lra.cpp:386-
 void lra_map_opts_preset_clr(lra_map_opts* opts);          /* -CLR: lra.cpp:341-386 */
 int lra_ctx_load_chromosomes(lra_ctx* ctx, const uint64_t* h_chrom_pos, int n_chrom);
 int lra_ctx_build_local_index(lra_ctx* ctx, int k, int w, int window, int max_freq);
+/* The context's reference data as device pointers: the genome bytes; the genome's local index (the .gli payload: d_tuple_bnd[n_windows + 1],
+ * d_tuples[n_tuples]) and its seqOffsets[n_windows + 1].  Valid until the context is destroyed or the data is loaded / built again.        */
+const char* lra_ctx_genome_ptr(lra_ctx* ctx);
+int lra_ctx_local_index(lra_ctx* ctx, lra_local_index_result* out, const uint64_t** d_seq_offsets);
 int lra_map_reads_lowacc_batch(lra_ctx* ctx, int n_reads, const char* d_seq, const uint64_t* d_read_off, uint64_t total_bases, const lra_map_opts* opts,
                                lra_map_result* out);
 int lra_map_records(lra_ctx* ctx, const lra_map_result* res, const lra_map_opts* opts, const char* const* names, const char* const* reads,
                     const char* const* quals, const int32_t* read_len, const char* const* chrom_names, const char* passthrough, char* out, uint64_t cap,
                     uint64_t* len, uint64_t* rec_off);
+/* lra_map_records in two halves, so that the host tail of batch i runs beside the device side of batch i + 1 (the reference interleaves them per
+ * thread, lra.cpp:117-158):
+ *   lra_map_snapshot      copies what the records need (per-alignment fields, counters, CIGAR runs, block ends; with_blocks != 0 also every block
+ *                         and the chromosome text under it, needed by print format 'a' only) from the context's result buffers to a host object;
+ *                         after it returns the context may run the next batch.
+ *   lra_map_records_host  SetFromSegAlignment / AlignmentsOrder::Update / SimpleMapQV / OUTPUT for every read on n_threads host threads (0: up to
+ *                         16); touches neither the context nor the device.  *text (owned by the snapshot, valid until it is freed or reused),
+ *                         *len bytes, (*rec_off)[n_reads + 1] record boundaries; a read with a non-zero status word has an empty record.
+ *   lra_map_host_free     releases the snapshot.                                                                                              */
+typedef struct lra_map_host lra_map_host;
+int lra_map_snapshot(lra_ctx* ctx, const lra_map_result* res, int with_blocks, lra_map_host** out);
+int lra_map_records_host(lra_map_host* snap, const lra_map_opts* opts, const char* const* names, const char* const* reads, const char* const* quals,
+                         const int32_t* read_len, const char* const* chrom_names, const char* passthrough, int n_threads, const char** text, uint64_t* len,
+                         const uint64_t** rec_off);
+void lra_map_host_free(lra_map_host* snap);
+/* The record buffer of a batch as ONE device buffer -- what a rank sends to rank 0 in the single exchange step of the multi-GPU path (the
+ * reference's ordered output, lra.cpp:145-166): lra_map_pack lays the same arrays out behind a 128-byte header in a context-owned buffer
+ * (valid until the next pack on this context); lra_map_unpack_host turns a host copy of such a buffer (from any rank) into a snapshot for
+ * lra_map_records_host.  lra_map_snapshot = pack + copy to the host + unpack.                                                               */
+int lra_map_pack(lra_ctx* ctx, const lra_map_result* res, int with_blocks, const void** d_buf, uint64_t* bytes);
+int lra_map_unpack_host(const void* h_buf, uint64_t bytes, lra_map_host** out);
 
 #ifdef __cplusplus
 }

@@ -84,6 +84,13 @@ SYMBOLS = {
     "lra_ctx_load_chromosomes": (C.c_int, [_vp, _vp, C.c_int]),
     "lra_ctx_build_local_index": (C.c_int, [_vp, C.c_int, C.c_int, C.c_int, C.c_int]),
     "lra_map_reads_lowacc_batch": (C.c_int, [_vp, C.c_int, _vp, _vp, C.c_uint64, _vp, _vp]),
+    "lra_ctx_genome_ptr": (_vp, [_vp]),
+    "lra_ctx_local_index": (C.c_int, [_vp, _vp, _vp]),
+    "lra_map_snapshot": (C.c_int, [_vp, _vp, C.c_int, _vp]),
+    "lra_map_records_host": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, C.c_char_p, C.c_int, _vp, _vp, _vp]),
+    "lra_map_host_free": (None, [_vp]),
+    "lra_map_pack": (C.c_int, [_vp, _vp, C.c_int, _vp, _vp]),
+    "lra_map_unpack_host": (C.c_int, [_vp, C.c_uint64, _vp]),
     "lra_map_records": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, C.c_char_p, _vp, C.c_uint64, _vp, _vp]),
     "lra_filter_chains_batch": (C.c_int, [_vp, C.c_uint64, _vp, C.c_uint64, _vp, _vp, _vp, _vp, _vp, _vp, C.c_int, _vp]),
     "lra_calculate_statistics_batch": (C.c_int, [_vp, C.c_int, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, C.c_int, _vp]),

@@ -265,6 +265,15 @@ extern "C" int lra_ctx_build_local_index(lra_ctx* ctx, int k, int w, int window,
   return LRA_OK;
 }
 
+// the context's reference data, for callers that want to write it to files (lra_write_gli) or hand it to another consumer
+extern "C" const char* lra_ctx_genome_ptr(lra_ctx* ctx) { return (ctx && ctx->seed) ? (const char*)ctx->seed->genome : nullptr; }
+extern "C" int lra_ctx_local_index(lra_ctx* ctx, lra_local_index_result* out, const uint64_t** d_seq_offsets) {
+  if (!ctx || !ctx->map || !ctx->map->gli_buf || !out) return LRA_ERR_INVALID;
+  *out = ctx->map->gli;
+  if (d_seq_offsets) *d_seq_offsets = ctx->map->d_gso;
+  return LRA_OK;
+}
+
 // RefineBreakpoint(read, genome, *SegAlignment[s], *SegAlignment[s-1], opts) for s = 1, 2, ... of every job: round k runs junction k of all
 // jobs that have one (segment k is "left", segment k - 1 -- already refined against k - 2 in the round before -- is "right").
 static int refine_breakpoints(lra_ctx* ctx, uint64_t nJ, uint64_t nA, const uint64_t* d_job_aln_off, const int32_t* d_strand, const uint64_t* q_off, const int32_t* q_len,
@@ -503,6 +512,19 @@ extern "C" int lra_map_reads_lowacc_batch(lra_ctx* ctx, int n_reads, const char*
 }
 
 // ---------------------------------------------------------------------------------------------------------------- records (host)
+// lra_map_snapshot copies what the records need from the context's result buffers to the host (so the next batch may overwrite them);
+// lra_map_records_host turns a snapshot into text with host threads only -- it touches neither the context nor the device, so it runs
+// beside the next batch's lra_map_reads_lowacc_batch.  lra_map_records = both, with the reference's two-call output convention.
+struct lra_map_host {
+  int32_t n_reads = 0, num_aln = 1; uint64_t nJ = 0, nA = 0;
+  std::vector<uint64_t> jo, roff, boff; std::vector<int32_t> strand, supp, sec, n0, n1, chrom, counts, blocks; std::vector<float> fval;
+  std::vector<uint32_t> runs, rstat, ends;                 // ends: per alignment first block's qPos, last block's qPos + length
+  std::vector<uint8_t> reached;
+  std::vector<uint64_t> chrom_pos;
+  std::vector<std::string> segText; std::vector<uint32_t> segStart;   // print format 'a' only
+  std::string text; std::vector<uint64_t> rec_off;         // what lra_map_records_host produced last
+};
+
 namespace {
 template <typename T>
 int fetch(lra_ctx* ctx, std::vector<T>& v, const T* d, size_t n) {
@@ -510,56 +532,142 @@ int fetch(lra_ctx* ctx, std::vector<T>& v, const T* d, size_t n) {
   if (n && d) LRA_HIP_CHECK(ctx, hipMemcpy(v.data(), d, n * sizeof(T), hipMemcpyDeviceToHost));
   return LRA_OK;
 }
+__global__ void k_block_ends(uint64_t nA, const uint64_t* __restrict__ boff, const int32_t* __restrict__ blocks, uint32_t* __restrict__ ends) {
+  const uint64_t a = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (a >= nA) return;
+  const uint64_t b0 = boff[a], b1 = boff[a + 1];
+  ends[2 * a] = b1 > b0 ? (uint32_t)blocks[3 * b0] : 0;
+  ends[2 * a + 1] = b1 > b0 ? (uint32_t)(blocks[3 * (b1 - 1)] + blocks[3 * (b1 - 1) + 2]) : 0;
+}
 }  // namespace
 
-extern "C" int lra_map_records(lra_ctx* ctx, const lra_map_result* res, const lra_map_opts* o, const char* const* names, const char* const* reads,
-                               const char* const* quals, const int32_t* read_len, const char* const* chrom_names, const char* passthrough, char* out,
-                               uint64_t cap, uint64_t* len, uint64_t* rec_off) {
-  if (!ctx || !res || !o || !names || !reads || !read_len || !chrom_names || !len) return LRA_ERR_INVALID;
+extern "C" void lra_map_host_free(lra_map_host* h) { delete h; }
+
+// ---- the record buffer of a batch: everything the host tail needs, packed into one device buffer (what a rank sends to rank 0)
+//   int64 header[16] = {magic, n_reads, num_aln, nJ, nA, n_blocks (0 unless with_blocks), n_runs, n_chrom, has_reached, has_rstat, ...}
+//   then, each padded to 8 bytes:  chrom_pos u64[n_chrom+1] | reached u8[nJ] | rstat u32[n_reads] | jo u64[nJ+1] | strand, supp, sec, n0, n1, chrom
+//   i32[nA] each | fval f32[nA] | counts i32[18 nA] | boff u64[nA+1] | ends u32[2 nA] | roff u64[nA+1] | runs u32[n_runs] | blocks i32[3 n_blocks]
+namespace {
+constexpr int64_t PACK_MAGIC = 0x4c52414d41503031LL;   // "LRAMAP01"
+inline size_t pad8(size_t n) { return (n + 7) & ~(size_t)7; }
+struct PackLayout {
+  size_t off[17]; size_t total;
+  PackLayout(uint64_t n_reads, uint64_t nJ, uint64_t nA, uint64_t n_blocks, uint64_t n_runs, uint64_t n_chrom) {
+    const size_t sz[17] = {16 * 8, (n_chrom + 1) * 8, nJ, n_reads * 4, (nJ + 1) * 8, nA * 4, nA * 4, nA * 4, nA * 4, nA * 4, nA * 4, nA * 4, 18 * nA * 4, (nA + 1) * 8,
+                           2 * nA * 4, (nA + 1) * 8, n_runs * 4};
+    size_t at = 0;
+    for (int i = 0; i < 17; i++) { off[i] = at; at += pad8(sz[i]); }
+    blocks_off = at; at += pad8(3 * n_blocks * 4);
+    total = at;
+  }
+  size_t blocks_off;
+};
+}  // namespace
+
+extern "C" int lra_map_pack(lra_ctx* ctx, const lra_map_result* res, int with_blocks, const void** d_buf, uint64_t* bytes) {
+  if (!ctx || !res || !d_buf || !bytes) return LRA_ERR_INVALID;
   lra_map_state* m = ctx->map;
   if (!m) return LRA_ERR_INVALID;
-  // two-call convention: the sizing call keeps its text, the filling call for the same result and format hands it over
-  const lra_map_sig sig{res->d_blocks, res->d_runs, res->n_reads, res->n_alignments, o->printFormat, o->PrintNumAln, o->hardClip, passthrough};
-  if (out && m->last_sig == sig && !m->last_text.empty() && cap >= m->last_text.size()) {
-    memcpy(out, m->last_text.data(), m->last_text.size());
-    *len = m->last_text.size();
-    if (rec_off) memcpy(rec_off, m->last_off.data(), m->last_off.size() * 8);
-    std::string().swap(m->last_text); m->last_sig = lra_map_sig{};
-    return LRA_OK;
-  }
   LRA_HIP_CHECK(ctx, hipSetDevice(ctx->device));
-  const size_t nA = res->n_alignments, nJ = res->n_jobs;
-  const int na = std::max(res->num_aln, 1);
-  std::vector<uint64_t> jo, boff, roff; std::vector<int32_t> strand, supp, sec, n0, n1, chrom, counts, blocks; std::vector<float> fval; std::vector<uint32_t> runs, rstat;
-  std::vector<uint8_t> reached;
-  int rc;
-  if ((rc = fetch(ctx, reached, res->d_job_reached, res->d_job_reached ? nJ : 0)) || (rc = fetch(ctx, rstat, res->d_read_status, res->d_read_status ? (size_t)res->n_reads : 0)) ||
-      (rc = fetch(ctx, jo, res->d_job_aln_off, nJ ? nJ + 1 : 0)) || (rc = fetch(ctx, strand, res->d_strand, nA)) || (rc = fetch(ctx, supp, res->d_supp, nA)) ||
-      (rc = fetch(ctx, sec, res->d_secondary, nA)) || (rc = fetch(ctx, n0, res->d_n0, nA)) || (rc = fetch(ctx, n1, res->d_n1, nA)) ||
-      (rc = fetch(ctx, chrom, res->d_chrom, nA)) || (rc = fetch(ctx, fval, res->d_first_sdp_value, nA)) || (rc = fetch(ctx, counts, res->d_counts, 18 * nA)) ||
-      (rc = fetch(ctx, boff, res->d_block_off, nA ? nA + 1 : 0)) || (rc = fetch(ctx, blocks, res->d_blocks, 3 * (size_t)res->n_blocks)) ||
-      (rc = fetch(ctx, roff, res->d_run_off, nA ? nA + 1 : 0)) || (rc = fetch(ctx, runs, res->d_runs, (size_t)res->n_runs)))
-    return rc;
-  // print format 'a': the pairwise text needs the chromosome bases under every alignment and the read on its strand
-  const bool pairwise = o->printFormat == 'a';
-  std::vector<std::string> segText;
-  std::vector<uint32_t> segStart;
-  if (pairwise) {
-    if (!ctx->seed || !ctx->seed->genome) return lra_set_err(ctx, LRA_ERR_INVALID, "genome not loaded");
-    segText.resize(nA); segStart.assign(nA, 0);
+  hipStream_t st = ctx->stream;
+  const uint64_t nR = (uint64_t)res->n_reads, nJ = res->n_jobs, nA = res->n_alignments, nB = with_blocks ? res->n_blocks : 0, nRuns = res->n_runs;
+  const uint64_t nCh = m->chrom_pos.size() - 1;
+  const PackLayout L(nR, nJ, nA, nB, nRuns, nCh);
+  char* buf = (char*)lra_ensure(ctx, 84, L.total + 64);
+  if (!buf) return LRA_ERR_NOMEM;
+  const int64_t hdr[16] = {PACK_MAGIC, (int64_t)nR, std::max(res->num_aln, 1), (int64_t)nJ, (int64_t)nA, (int64_t)nB, (int64_t)nRuns, (int64_t)nCh,
+                           res->d_job_reached ? 1 : 0, res->d_read_status ? 1 : 0, 0, 0, 0, 0, 0, 0};
+  LRA_HIP_CHECK(ctx, hipMemcpyAsync(buf + L.off[0], hdr, sizeof hdr, hipMemcpyHostToDevice, st));
+  LRA_HIP_CHECK(ctx, hipMemcpyAsync(buf + L.off[1], m->d_chrom_pos, (nCh + 1) * 8, hipMemcpyDeviceToDevice, st));
+  auto put = [&](int slot, const void* src, size_t n) -> hipError_t { return (n && src) ? hipMemcpyAsync(buf + L.off[slot], src, n, hipMemcpyDeviceToDevice, st) : hipSuccess; };
+  if (nA) {
+    uint32_t* d_ends = (uint32_t*)(buf + L.off[14]);
+    hipLaunchKernelGGL(k_block_ends, dim3((unsigned)((nA + 255) / 256)), dim3(256), 0, st, nA, res->d_block_off, res->d_blocks, d_ends);
+  }
+  LRA_HIP_CHECK(ctx, put(2, res->d_job_reached, nJ));
+  LRA_HIP_CHECK(ctx, put(3, res->d_read_status, nR * 4));
+  LRA_HIP_CHECK(ctx, put(4, res->d_job_aln_off, nJ ? (nJ + 1) * 8 : 0));
+  LRA_HIP_CHECK(ctx, put(5, res->d_strand, nA * 4)); LRA_HIP_CHECK(ctx, put(6, res->d_supp, nA * 4)); LRA_HIP_CHECK(ctx, put(7, res->d_secondary, nA * 4));
+  LRA_HIP_CHECK(ctx, put(8, res->d_n0, nA * 4)); LRA_HIP_CHECK(ctx, put(9, res->d_n1, nA * 4)); LRA_HIP_CHECK(ctx, put(10, res->d_chrom, nA * 4));
+  LRA_HIP_CHECK(ctx, put(11, res->d_first_sdp_value, nA * 4)); LRA_HIP_CHECK(ctx, put(12, res->d_counts, 18 * nA * 4));
+  LRA_HIP_CHECK(ctx, put(13, res->d_block_off, nA ? (nA + 1) * 8 : 0)); LRA_HIP_CHECK(ctx, put(15, res->d_run_off, nA ? (nA + 1) * 8 : 0));
+  LRA_HIP_CHECK(ctx, put(16, res->d_runs, nRuns * 4));
+  if (nB) LRA_HIP_CHECK(ctx, hipMemcpyAsync(buf + L.blocks_off, res->d_blocks, 3 * nB * 4, hipMemcpyDeviceToDevice, st));
+  LRA_HIP_CHECK(ctx, hipStreamSynchronize(st));
+  *d_buf = buf; *bytes = L.total;
+  return LRA_OK;
+}
+
+// a packed record buffer (host memory) -> snapshot
+extern "C" int lra_map_unpack_host(const void* h_buf, uint64_t bytes, lra_map_host** out) {
+  if (!h_buf || !out || bytes < 16 * 8) return LRA_ERR_INVALID;
+  *out = nullptr;
+  const char* b = (const char*)h_buf;
+  int64_t hdr[16];
+  memcpy(hdr, b, sizeof hdr);
+  if (hdr[0] != PACK_MAGIC) return LRA_ERR_INVALID;
+  const uint64_t nR = (uint64_t)hdr[1], nJ = (uint64_t)hdr[3], nA = (uint64_t)hdr[4], nB = (uint64_t)hdr[5], nRuns = (uint64_t)hdr[6], nCh = (uint64_t)hdr[7];
+  const PackLayout L(nR, nJ, nA, nB, nRuns, nCh);
+  if (L.total > bytes) return LRA_ERR_INVALID;
+  lra_map_host* h = new lra_map_host();
+  h->n_reads = (int32_t)nR; h->num_aln = (int)hdr[2]; h->nJ = nJ; h->nA = nA;
+  auto get = [&](auto& v, int slot, size_t n) { v.resize(n); if (n) memcpy(v.data(), b + L.off[slot], n * sizeof(v[0])); };
+  get(h->chrom_pos, 1, nCh + 1);
+  if (hdr[8]) get(h->reached, 2, nJ);
+  if (hdr[9]) get(h->rstat, 3, nR);
+  get(h->jo, 4, nJ ? nJ + 1 : 0);
+  get(h->strand, 5, nA); get(h->supp, 6, nA); get(h->sec, 7, nA); get(h->n0, 8, nA); get(h->n1, 9, nA); get(h->chrom, 10, nA); get(h->fval, 11, nA);
+  get(h->counts, 12, 18 * nA); get(h->boff, 13, nA ? nA + 1 : 0); get(h->ends, 14, 2 * nA); get(h->roff, 15, nA ? nA + 1 : 0); get(h->runs, 16, nRuns);
+  if (nB) { h->blocks.resize(3 * nB); memcpy(h->blocks.data(), b + L.blocks_off, 3 * nB * 4); }
+  *out = h;
+  return LRA_OK;
+}
+
+extern "C" int lra_map_snapshot(lra_ctx* ctx, const lra_map_result* res, int with_blocks, lra_map_host** out) {
+  if (!ctx || !res || !out) return LRA_ERR_INVALID;
+  *out = nullptr;
+  const void* d_buf = nullptr; uint64_t bytes = 0;
+  int rc = lra_map_pack(ctx, res, with_blocks, &d_buf, &bytes);
+  if (rc) return rc;
+  std::vector<char> hb(bytes);
+  LRA_HIP_CHECK(ctx, hipMemcpy(hb.data(), d_buf, bytes, hipMemcpyDeviceToHost));
+  lra_map_host* h = nullptr;
+  if ((rc = lra_map_unpack_host(hb.data(), bytes, &h))) return rc;
+  if (with_blocks) {
+    // print format 'a': the pairwise text needs the chromosome bases under every alignment (and the read on its strand)
+    lra_map_state* m = ctx->map;
+    if (!ctx->seed || !ctx->seed->genome) { delete h; return lra_set_err(ctx, LRA_ERR_INVALID, "genome not loaded"); }
+    const size_t nA = h->nA;
+    h->segText.resize(nA); h->segStart.assign(nA, 0);
     for (size_t a = 0; a < nA; a++) {
-      const uint64_t b0 = boff[a], b1 = boff[a + 1];
+      const uint64_t b0 = h->boff[a], b1 = h->boff[a + 1];
       if (b1 == b0) continue;
-      const uint32_t t0 = (uint32_t)blocks[3 * b0 + 1], t1 = (uint32_t)(blocks[3 * (b1 - 1) + 1] + blocks[3 * (b1 - 1) + 2]);
-      segStart[a] = t0;
-      segText[a].resize((size_t)(t1 - t0) + 1);
-      LRA_HIP_CHECK(ctx, hipMemcpy(&segText[a][0], ctx->seed->genome + m->chrom_pos[chrom[a]] + t0, t1 - t0, hipMemcpyDeviceToHost));
+      const uint32_t t0 = (uint32_t)h->blocks[3 * b0 + 1], t1 = (uint32_t)(h->blocks[3 * (b1 - 1) + 1] + h->blocks[3 * (b1 - 1) + 2]);
+      h->segStart[a] = t0;
+      h->segText[a].resize((size_t)(t1 - t0) + 1);
+      if (hipMemcpy(&h->segText[a][0], ctx->seed->genome + m->chrom_pos[h->chrom[a]] + t0, t1 - t0, hipMemcpyDeviceToHost) != hipSuccess) { delete h; return LRA_ERR_HIP; }
     }
   }
+  *out = h;
+  return LRA_OK;
+}
+
+extern "C" int lra_map_records_host(lra_map_host* h, const lra_map_opts* o, const char* const* names, const char* const* reads, const char* const* quals,
+                                    const int32_t* read_len, const char* const* chrom_names, const char* passthrough, int n_threads, const char** text,
+                                    uint64_t* len, const uint64_t** rec_off) {
+  if (!h || !o || !names || !reads || !read_len || !chrom_names || !len) return LRA_ERR_INVALID;
+  const size_t nA = h->nA, nJ = h->nJ;
+  (void)nA;
+  const int na = h->num_aln;
+  const std::vector<uint64_t>& jo = h->jo; const std::vector<uint64_t>& roff = h->roff; const std::vector<uint64_t>& boff = h->boff;
+  const std::vector<int32_t>&strand = h->strand, &supp = h->supp, &sec = h->sec, &n0 = h->n0, &n1 = h->n1, &chrom = h->chrom, &counts = h->counts, &blocks = h->blocks;
+  const std::vector<float>& fval = h->fval; const std::vector<uint32_t>&runs = h->runs, &rstat = h->rstat, &ends = h->ends; const std::vector<uint8_t>& reached = h->reached;
+  const bool pairwise = o->printFormat == 'a';
+  if (pairwise && h->segText.size() != h->nA) return LRA_ERR_INVALID;
   // every read is independent: host threads take contiguous ranges of reads, each builds its own text; ranges are joined in read order
-  const int n_reads = res->n_reads;
+  const int n_reads = h->n_reads;
   unsigned hw = std::thread::hardware_concurrency();
-  int T = (int)std::min<unsigned>(hw ? hw : 1u, 16u);
+  int T = n_threads > 0 ? n_threads : (int)std::min<unsigned>(hw ? hw : 1u, 16u);
   T = std::max(1, std::min(T, n_reads / 32 + 1));
   if (const char* e = getenv("LRA_RECORD_THREADS")) T = std::max(1, atoi(e));
   std::vector<std::string> part(T);
@@ -577,7 +685,7 @@ extern "C" int lra_map_records(lra_ctx* ctx, const lra_map_result* res, const lr
     int rc = LRA_OK;
     for (int r = lo; r < hi; r++) {
       recs.clear(); cigars.clear(); seg_off.assign(1, 0); rcRead.clear();
-      if (!rstat.empty() && rstat[r]) { plen[tix].push_back(0); continue; }   // flagged read: no record (the caller routes it elsewhere; lra_map_flagged_reads)
+      if (!rstat.empty() && rstat[r]) { plen[tix].push_back(0); continue; }   // flagged read: no record (the caller routes it elsewhere; d_read_status)
       const bool unaligned = nJ == 0 || jo[(size_t)r * na + 1] == jo[(size_t)r * na];     // p == 0 left no SegAlignment (Map_lowacc.h:578-581)
       if (!unaligned) {
         size_t total = 0;
@@ -601,7 +709,7 @@ extern "C" int lra_map_records(lra_ctx* ctx, const lra_map_result* res, const lr
             const int32_t* c = &counts[18 * a];
             lra_aln_record rec; memset(&rec, 0, sizeof rec);
             rec.read_name = names[r]; rec.read = reads[r]; rec.qual = quals ? quals[r] : nullptr; rec.read_len = read_len[r];
-            rec.chrom = chrom_names[chrom[a]]; rec.genome_len = (uint32_t)(m->chrom_pos[chrom[a] + 1] - m->chrom_pos[chrom[a]]);
+            rec.chrom = chrom_names[chrom[a]]; rec.genome_len = (uint32_t)(h->chrom_pos[chrom[a] + 1] - h->chrom_pos[chrom[a]]);
             rec.cigar = cigars.back().c_str();
             rec.strand = strand[a]; rec.supplementary = supp[a]; rec.is_secondary = sec[a];
             rec.nm = c[0]; rec.nmm = c[1]; rec.nins = c[2]; rec.ndel = c[3]; rec.tdel = c[4]; rec.tins = c[5]; rec.nSmallDel = c[6]; rec.nMedDel = c[7]; rec.nLargeDel = c[8];
@@ -610,8 +718,8 @@ extern "C" int lra_map_records(lra_ctx* ctx, const lra_map_result* res, const lr
             rec.value = fval[a]; rec.NumOfAnchors0 = n0[a]; rec.NumOfAnchors1 = n1[a];
             const uint64_t b0 = boff[a], b1 = boff[a + 1];
             rec.n_blocks = (int32_t)(b1 - b0);
-            rec.first_block_qpos = b1 > b0 ? (uint32_t)blocks[3 * b0] : 0;
-            rec.last_block_qend = b1 > b0 ? (uint32_t)(blocks[3 * (b1 - 1)] + blocks[3 * (b1 - 1) + 2]) : 0;
+            rec.first_block_qpos = ends[2 * a];
+            rec.last_block_qend = ends[2 * a + 1];
             if (pairwise) {
               if (strand[a] && rcRead.empty()) {                          // CreateRC (SeqUtils.h:151)
                 const int L = read_len[r];
@@ -623,7 +731,7 @@ extern "C" int lra_map_records(lra_ctx* ctx, const lra_map_result* res, const lr
               }
               rec.blocks = &blocks[3 * b0];
               rec.strand_read = strand[a] ? rcRead.c_str() : reads[r];
-              rec.chrom_text = segText[a].data() - segStart[a];           // chrom_text[tPos] for the covered tPos only
+              rec.chrom_text = h->segText[a].data() - h->segStart[a];     // chrom_text[tPos] for the covered tPos only
             }
             recs.push_back(rec);
           }
@@ -661,31 +769,53 @@ extern "C" int lra_map_records(lra_ctx* ctx, const lra_map_result* res, const lr
     for (auto& x : th) x.join();
   }
   for (int t = 0; t < T; t++) if (prc[t]) return prc[t];
-  std::string& text = m->last_text;
-  text.clear();
-  { size_t tot = 0; for (auto& x : part) tot += x.size(); text.reserve(tot); }
-  {
-    int r = 0;
-    uint64_t at = 0;
-    for (int t = 0; t < T; t++) {
-      for (uint64_t l : plen[t]) { if (rec_off) rec_off[r] = at; at += l; r++; }
-      text += part[t];
-      std::string().swap(part[t]);
-    }
+  std::string& out = h->text;
+  out.clear();
+  { size_t tot = 0; for (auto& x : part) tot += x.size(); out.reserve(tot); }
+  h->rec_off.assign((size_t)n_reads + 1, 0);
+  uint64_t at = 0; size_t r = 0;
+  for (int t = 0; t < T; t++) {
+    for (uint64_t l : plen[t]) { h->rec_off[r++] = at; at += l; }
+    out += part[t];
+    std::string().swap(part[t]);
   }
-  m->last_sig = sig;
-  if (rec_off) rec_off[res->n_reads] = text.size();
-  *len = text.size();
-  if (!out) {                                                            // sizing call: remember the offsets too
-    m->last_off.assign((size_t)res->n_reads + 1, 0);
-    uint64_t at = 0; size_t r = 0;
-    for (int t = 0; t < T; t++) for (uint64_t l : plen[t]) { m->last_off[r++] = at; at += l; }
-    m->last_off[res->n_reads] = at;
+  h->rec_off[n_reads] = at;
+  *len = out.size();
+  if (text) *text = out.data();
+  if (rec_off) *rec_off = h->rec_off.data();
+  return LRA_OK;
+}
+
+extern "C" int lra_map_records(lra_ctx* ctx, const lra_map_result* res, const lra_map_opts* o, const char* const* names, const char* const* reads,
+                               const char* const* quals, const int32_t* read_len, const char* const* chrom_names, const char* passthrough, char* out,
+                               uint64_t cap, uint64_t* len, uint64_t* rec_off) {
+  if (!ctx || !res || !o || !names || !reads || !read_len || !chrom_names || !len) return LRA_ERR_INVALID;
+  lra_map_state* m = ctx->map;
+  if (!m) return LRA_ERR_INVALID;
+  // two-call convention: the sizing call keeps its text, the filling call for the same result and format hands it over
+  const lra_map_sig sig{res->d_blocks, res->d_runs, res->n_reads, res->n_alignments, o->printFormat, o->PrintNumAln, o->hardClip, passthrough};
+  if (out && m->last_sig == sig && !m->last_text.empty() && cap >= m->last_text.size()) {
+    memcpy(out, m->last_text.data(), m->last_text.size());
+    *len = m->last_text.size();
+    if (rec_off) memcpy(rec_off, m->last_off.data(), m->last_off.size() * 8);
+    std::string().swap(m->last_text); m->last_sig = lra_map_sig{};
+    return LRA_OK;
+  }
+  lra_map_host* h = nullptr;
+  int rc = lra_map_snapshot(ctx, res, o->printFormat == 'a', &h);
+  if (rc) return rc;
+  const char* text = nullptr; const uint64_t* ro = nullptr;
+  rc = lra_map_records_host(h, o, names, reads, quals, read_len, chrom_names, passthrough, 0, &text, len, &ro);
+  if (rc) { lra_map_host_free(h); return rc; }
+  if (rec_off) memcpy(rec_off, ro, ((size_t)res->n_reads + 1) * 8);
+  if (!out) {                                                            // sizing call: remember text and offsets
+    m->last_text.swap(h->text); m->last_off.swap(h->rec_off); m->last_sig = sig;
+    lra_map_host_free(h);
     return LRA_OK;
   }
   m->last_sig = lra_map_sig{};
-  if (cap < text.size()) return LRA_ERR_INVALID;
-  memcpy(out, text.data(), text.size());
-  std::string().swap(m->last_text);
+  if (cap < *len) { lra_map_host_free(h); return LRA_ERR_INVALID; }
+  memcpy(out, text, *len);
+  lra_map_host_free(h);
   return LRA_OK;
 }

@@ -125,9 +125,13 @@ class MapBatchResult:
 
 
 class LowAccMapper:
-    def __init__(self, ctx: Context, genome, idx_key, idx_pos, chrom_names, chrom_pos, opts: LowAccOptions = None):
+    def __init__(self, ctx: Context, genome, idx_key, idx_pos, chrom_names, chrom_pos, opts: LowAccOptions = None, index_params=None, staged=True):
         """genome: uint8 bases of all sequences back to back (numpy or device tensor); idx_key / idx_pos: the global minimizer index (the
-        .mms payload, MMIndex.h:416); chrom_pos: n_chrom + 1 start offsets (Genome::header.pos)."""
+        .mms payload, MMIndex.h:416), or None to build it on the device (lra_ctx_build_global_index: StoreIndex with index_params =
+        (K, W, globalMaxFreq, globalWinsize, NumOfminimizersPerWindow), default the -ONT index preset with opts.globalK / globalW);
+        chrom_pos: n_chrom + 1 start offsets (Genome::header.pos).  staged=False skips the second device copy of the genome that only
+        align_staged needs."""
+        from . import index as _index
         self.ctx = ctx
         self.opts = opts or LowAccOptions()
         o = self.opts
@@ -137,15 +141,22 @@ class LowAccMapper:
         self.chrom_pos = [int(x) for x in chrom_pos]
         assert self.chrom_pos[0] == 0 and self.chrom_pos[-1] == self.G
         self.chrom_names = [n if isinstance(n, bytes) else str(n).encode() for n in chrom_names]
-        seed.load_reference(ctx, g.cpu().numpy(), idx_key, idx_pos)
+        _index.load_genome(ctx, g)
+        if idx_key is None:
+            ip = index_params or (o.globalK, o.globalW, 150, 15, 1)
+            self.index_stats = _index.build_global_index(ctx, self.chrom_pos, *ip)
+        else:
+            k = np.ascontiguousarray(idx_key).view(np.uint64); p = np.ascontiguousarray(idx_pos, dtype=np.uint32)
+            ctx.check(ctx.lib.lra_ctx_load_global_index(ctx.h, C.c_void_p(k.ctypes.data), C.c_void_p(p.ctypes.data), C.c_uint64(len(k))))
+            self.index_stats = dict(n_index=len(k))
         cp = (C.c_uint64 * len(self.chrom_pos))(*self.chrom_pos)
         ctx.check(ctx.lib.lra_ctx_load_chromosomes(ctx.h, cp, len(self.chrom_pos) - 1))
         ctx.check(ctx.lib.lra_ctx_build_local_index(ctx.h, o.localK, o.localW, o.localIndexWindow, o.localMaxFreq))
         self.copts = self._c_opts()
-        self.gdev = torch.cat([g.to(dev), torch.zeros(64, dtype=torch.uint8, device=dev)])
+        self.gdev = torch.cat([g.to(dev), torch.zeros(64, dtype=torch.uint8, device=dev)]) if staged else None
         self.g_off = torch.tensor(self.chrom_pos, dtype=torch.int64, device=dev)
         self._gli = None
-        self.gso = torch.from_numpy(seq_offsets(self.chrom_pos, o.localIndexWindow)).to(dev)
+        self.gso = torch.from_numpy(seq_offsets(self.chrom_pos, o.localIndexWindow)).to(dev) if staged else None
         self.lut = _log_lookup_table()
         self.sdp_opts = chain.sdp_opts(rate=o.initial_anchorbonus, alnthres=o.alnthres, globalK=o.globalK)
         self.sdp2_opts = chain.sdp_opts(mode=1, rate=o.second_anchorbonus, alnthres=o.alnthres, globalK=o.globalK)   # SparseDP :2287, opts.second_anchorbonus
@@ -161,6 +172,14 @@ class LowAccMapper:
             o = self.opts
             self._gli = local.LocalIndex(self.ctx, self.gdev, self.g_off, o.localK, o.localW, o.localIndexWindow, o.localMaxFreq)
         return self._gli
+
+    def fetch_local_index(self):
+        """The genome's local index as the context holds it (what lra_ctx_build_local_index built): host arrays (seqOffsets, tupleBoundaries, tuples)."""
+        ctx = self.ctx
+        res = local.LocalIndexResult(); gso = C.c_void_p()
+        ctx.check(ctx.lib.lra_ctx_local_index(ctx.h, C.byref(res), C.byref(gso)))
+        nw, nt = int(res.n_windows), int(res.n_tuples)
+        return ctx.to_host(gso.value, nw + 1, np.uint64), ctx.to_host(res.d_tuple_bnd, nw + 1, np.uint64), ctx.to_host(res.d_tuples, nt, np.uint32)
 
     def _c_opts(self):
         o = self.opts
@@ -229,6 +248,40 @@ class LowAccMapper:
         ctx.check(ctx.lib.lra_map_records(*args, buf, C.c_uint64(ln.value), C.byref(ln), roff))
         raw = buf.raw
         return [raw[roff[i]:roff[i + 1]] for i in range(n)]
+
+    def snapshot(self, res: MapResult, with_blocks=False):
+        """lra_map_snapshot: host copy of what the records need; afterwards the context may run the next batch."""
+        ctx = self.ctx
+        h = C.c_void_p()
+        ctx.check(ctx.lib.lra_map_snapshot(ctx.h, C.byref(res), 1 if with_blocks else 0, C.byref(h)))
+        return h
+
+    def record_args(self, names, reads, quals=None):
+        """The per-read host arrays lra_map_records_host takes (built once per batch; keep the returned object alive during the call)."""
+        n = len(names)
+        enc = lambda x: x if isinstance(x, bytes) else str(x).encode()
+        nm = [enc(x) for x in names]; rd = [bytes(x) for x in reads]
+        return dict(n=n, keep=(nm, rd), names=(C.c_char_p * n)(*nm), reads=(C.c_char_p * n)(*rd),
+                    quals=(C.c_char_p * n)(*[None if q is None else bytes(q) for q in quals]) if quals is not None else None,
+                    lens=(C.c_int32 * n)(*[len(x) for x in rd]), chroms=(C.c_char_p * len(self.chrom_names))(*self.chrom_names))
+
+    def records_host(self, snap, args, passthrough=None, n_threads=0, free=True, as_list=True):
+        """lra_map_records_host on a snapshot (host threads only; callable from another Python thread while the device runs the next batch:
+        ctypes releases the GIL).  -> list of per-read bytes, or the total number of bytes when as_list is False."""
+        lib = self.ctx.lib
+        text = C.c_char_p(); ln = C.c_uint64(0); roff = C.POINTER(C.c_uint64)()
+        rc = lib.lra_map_records_host(snap, C.byref(self.copts), args["names"], args["reads"], args["quals"], args["lens"], args["chroms"], passthrough,
+                                      int(n_threads), C.byref(text), C.byref(ln), C.byref(roff))
+        if rc != 0:
+            lib.lra_map_host_free(snap)
+            raise RuntimeError("lra_map_records_host failed (%d)" % rc)
+        out = ln.value
+        if as_list:
+            raw = C.string_at(text, ln.value)
+            out = [raw[roff[i]:roff[i + 1]] for i in range(args["n"])]
+        if free:
+            lib.lra_map_host_free(snap)
+        return out
 
     # ------------------------------------------------------------------------------------------------------------------ the same, stage by stage
     def align_staged(self, rbatch) -> MapBatchResult:

@@ -1,7 +1,10 @@
 """MapRead_lowacc for ONE read composed from the oracle's stage functions only (test infrastructure: used by tests/ and by bench.py's
-cpu_baseline leg, never by the product).  It follows Map_lowacc.h:33-599 stage by stage exactly as lra_amd/csrc/mapread.hip chains the
+cpu_baseline leg, never by the product).  It follows Map_lowacc.h:69-632 stage by stage exactly as lra_amd/csrc/mapread.hip chains the
 device stages, so its alignments must equal the GPU path's (tests/test_mapread.py) and its run time is the CPU cost of the same work.
+map_read_lowacc / map_reads_lowacc_mt call the C++ composition (oracle/pipeline.cpp: one read; a thread pool over reads);
+map_read_lowacc_py is the same composition in Python, kept as a cross-check of the C++ one (tests/test_mapread.py).
 chrom_pos (Genome::header.pos) defaults to one chromosome; the stages that take a chromosome's bytes get the slice."""
+import ctypes as C
 import numpy as np
 
 import oracle_lib as O
@@ -26,7 +29,7 @@ def seq_offsets(n, window):
     return np.array(list(range(0, n, window)) + [n], np.uint64) if n else np.zeros(1, np.uint64)
 
 
-def map_read_lowacc(read: bytes, genome: bytes, idx_key, idx_pos, g_index, opts=None, clean_opts=None, stats=True, chrom_pos=None):
+def map_read_lowacc_py(read: bytes, genome: bytes, idx_key, idx_pos, g_index, opts=None, clean_opts=None, stats=True, chrom_pos=None):
     """-> (alignments, unaligned).  alignments: list over primary chains p of lists of dict(strand, supp, secondary, n0, n1, value, chrom,
     a13_blocks, blocks (after IndelRefineAlignment), refine_status[, counts, nv, cigar]).  genome: the chromosome's bases (+ padding);
     g_index = (seqOffsets, tupleBoundaries, tuples) of the genome's local index."""
@@ -163,3 +166,99 @@ def map_read_lowacc(read: bytes, genome: bytes, idx_key, idx_pos, g_index, opts=
         if p == 0 and not out:
             return alignments, True                                        # Map_lowacc.h:578-581
     return alignments, False
+
+
+# ---------------------------------------------------------------------------------------------------------------- the C++ composition
+class MapOpts(C.Structure):
+    """oracle_map_opts (oracle/pipeline.cpp)"""
+    _fields_ = ([(n, C.c_int) for n in ("globalK", "globalW", "globalMaxFreq", "localK", "localW", "localMaxFreq", "localIndexWindow", "refineBand", "match", "mismatch",
+                                        "indel", "localBand", "refineSpaceDist")] +
+                [("anchorstoosparse", C.c_float), ("splitdist", C.c_int), ("window", C.c_int), ("initial_anchorbonus", C.c_float), ("second_anchorbonus", C.c_float),
+                 ("alnthres", C.c_float), ("NumAln", C.c_int), ("gapopen", C.c_float), ("gapextend", C.c_float), ("gaproot", C.c_float), ("gapCeiling1", C.c_int),
+                 ("gapCeiling2", C.c_int), ("refineBreakpoint", C.c_int), ("stats", C.c_int), ("limitrefine", C.c_int), ("isOnt", C.c_int), ("clean", O.CleanOpts)])
+
+
+def _c_opts(opts, clean_opts, stats):
+    o = dict(ONT)
+    if opts:
+        o.update(opts)
+    m = MapOpts()
+    for n in ("globalK", "globalW", "globalMaxFreq", "localK", "localW", "localMaxFreq", "localIndexWindow", "refineBand", "match", "mismatch", "indel", "refineSpaceDist",
+              "anchorstoosparse", "splitdist", "window", "initial_anchorbonus", "second_anchorbonus", "alnthres"):
+        setattr(m, n, o[n])
+    m.localBand = 15; m.NumAln = O.SDP_ONT["NumAln"]
+    for n in ("gapopen", "gapextend", "gaproot", "gapCeiling1", "gapCeiling2"):
+        setattr(m, n, O.SDP_ONT[n])
+    m.refineBreakpoint = int(bool(o["refineBreakpoint"])); m.stats = int(bool(stats)); m.limitrefine = 1; m.isOnt = 1
+    m.clean = clean_opts or O.CleanOpts(**dict(O.CLEAN_PRESETS["ONT"], globalK=o["globalK"], SecondCleanMaxDiag=o["SecondCleanMaxDiag"]))
+    return m
+
+
+def seq_offsets_multi(chrom_pos, window):
+    """LocalIndex::seqOffsets of several sequences (MMIndex.h:200-245): window ends, restarting at every sequence."""
+    out = [np.zeros(1, np.uint64)]
+    for c in range(len(chrom_pos) - 1):
+        a, b = int(chrom_pos[c]), int(chrom_pos[c + 1])
+        e = np.arange(a + window, b, window, dtype=np.uint64)
+        out.append(e); out.append(np.array([b], np.uint64))
+    return np.concatenate(out)
+
+
+def _ref_args(genome, idx_key, idx_pos, g_index, chrom_pos):
+    G = len(genome.rstrip(b"\0")) if chrom_pos is None else int(chrom_pos[-1])
+    cp = np.ascontiguousarray([0, G] if chrom_pos is None else chrom_pos, dtype=np.uint64)
+    ik = np.ascontiguousarray(idx_key).view(np.uint64); ip = np.ascontiguousarray(idx_pos, dtype=np.uint32)
+    gs, gb, gt = (np.ascontiguousarray(g_index[0], np.uint64), np.ascontiguousarray(g_index[1], np.uint64), np.ascontiguousarray(g_index[2], np.uint32))
+    lut = O.log_lookup_table()
+    keep = (cp, ik, ip, gs, gb, gt, lut, genome)
+    args = (C.c_char_p(genome), C.c_uint64(G), O._p(cp, C.c_uint64), C.c_int(len(cp) - 1), O._p(ik, C.c_uint64), O._p(ip, C.c_uint32), C.c_long(len(ik)),
+            C.c_long(len(gs) - 1), O._p(gs, C.c_uint64), O._p(gb, C.c_uint64), O._p(gt, C.c_uint32), O._p(lut, C.c_float))
+    return args, keep
+
+
+def map_read_lowacc(read: bytes, genome: bytes, idx_key, idx_pos, g_index, opts=None, clean_opts=None, stats=True, chrom_pos=None):
+    """-> (alignments, unaligned) exactly like map_read_lowacc_py, computed by oracle_map_read_lowacc (oracle/pipeline.cpp)."""
+    L = O.lib()
+    m = _c_opts(opts, clean_opts, stats)
+    args, keep = _ref_args(genome, idx_key, idx_pos, g_index, chrom_pos)
+    L.oracle_map_read_lowacc.restype = C.c_long
+    n = L.oracle_map_read_lowacc(C.c_char_p(read), C.c_uint32(len(read)), *args, C.byref(m))
+    f = np.zeros(max(1, n), np.int32)
+    L.oracle_map_read_result(O._p(f, C.c_int32))
+    unaligned, ng = bool(f[0]), int(f[1])
+    TRACE["match_rate"] = float(f[2:3].view(np.float32)[0])
+    at = 3
+    alignments = []
+    for _ in range(ng):
+        ns = int(f[at]); at += 1
+        segs = []
+        for _ in range(ns):
+            h = f[at:at + 14]; at += 14
+            counts = f[at:at + 18].astype(np.int64); at += 18
+            na, nb, nr = int(h[11]), int(h[12]), int(h[13])
+            a13 = f[at:at + 3 * na].reshape(-1, 3).copy(); at += 3 * na
+            blocks = f[at:at + 3 * nb].reshape(-1, 3).copy(); at += 3 * nb
+            runs = f[at:at + nr].view(np.uint32).copy(); at += nr
+            d = dict(strand=int(h[0]), supp=int(h[1]), secondary=int(h[2]), n0=int(h[3]), n1=int(h[4]), chrom=int(h[5]), value=float(h[6:7].view(np.float32)[0]),
+                     refine_status=int(h[7]), a13_blocks=a13, blocks=blocks)
+            if h[8] != -2:
+                d["breakpoint"] = int(h[8])
+            if h[9]:
+                d["stats"] = (dict(zip(O.STAT_NAMES, counts.tolist())), np.float32(h[10:11].view(np.float32)[0]), runs,
+                              "".join("%d%s" % (r >> 4, "=XID"[r & 15]) for r in runs))
+            segs.append(d)
+        alignments.append(segs)
+    return alignments, unaligned
+
+
+def map_reads_lowacc_mt(reads, off, first, n, genome: bytes, idx_key, idx_pos, g_index, opts=None, chrom_pos=None, n_threads=1, clean_opts=None, stats=True):
+    """reads [first, first + n) of a batch (uint8 bases back to back, off) through oracle_map_reads_lowacc_mt on n_threads host threads.
+    -> dict(seconds, bases, n_alignments, checksum, n_reads)"""
+    L = O.lib()
+    m = _c_opts(opts, clean_opts, stats)
+    args, keep = _ref_args(genome, idx_key, idx_pos, g_index, chrom_pos)
+    r = np.ascontiguousarray(reads, dtype=np.uint8); o_ = np.ascontiguousarray(off, dtype=np.uint64)
+    sec, bases, nal, cs = C.c_double(0), C.c_long(0), C.c_long(0), C.c_uint64(0)
+    L.oracle_map_reads_lowacc_mt(r.ctypes.data_as(C.c_char_p), O._p(o_, C.c_uint64), C.c_long(first), C.c_long(n), *args, C.byref(m), C.c_int(n_threads),
+                                 C.byref(sec), C.byref(bases), C.byref(nal), C.byref(cs))
+    return dict(seconds=sec.value, bases=bases.value, n_alignments=nal.value, checksum=cs.value, n_reads=int(n))

@@ -42,6 +42,27 @@ def test_map_reads_to_sam(ctx):
     assert np.array_equal(mapper.block_records(res).cpu().numpy(), staged_blocks)
     texts = mapper.records(res, rnames, [r.tobytes() for r in reads])
     assert texts == staged
+    # the same in two halves (snapshot on the host, then host-only formatting), and through the packed record buffer a rank sends to rank 0
+    rargs = mapper.record_args(rnames, [r.tobytes() for r in reads])
+    assert mapper.records_host(mapper.snapshot(res), rargs) == texts
+    import ctypes as C_
+    from lra_amd import parallel
+    d_buf, nb = C_.c_void_p(), C_.c_uint64(0)
+    ctx.check(ctx.lib.lra_map_pack(ctx.h, C_.byref(res), 0, C_.byref(d_buf), C_.byref(nb)))
+    packed = ctx.to_host(d_buf.value, nb.value, np.uint8)
+    assert parallel.records_from_packed(ctx.lib, mapper.copts, packed, rnames, [r.tobytes() for r in reads], names) == texts
+    # two ranks (here: two batches, one after the other) own hash-partitioned ordinals; rank 0 merges their record buffers by ordinal
+    per_rank, ords = [], []
+    for rk in range(2):
+        o_ = parallel.shard_ordinals(len(reads), rk, 2)
+        rb = seed.ReadBatch(ctx, [reads[i].tobytes() for i in o_])
+        rr = mapper.align(rb)
+        ctx.check(ctx.lib.lra_map_pack(ctx.h, C_.byref(rr), 0, C_.byref(d_buf), C_.byref(nb)))
+        pk = ctx.to_host(d_buf.value, nb.value, np.uint8)
+        per_rank.append(parallel.records_from_packed(ctx.lib, mapper.copts, pk, [rnames[i] for i in o_], [reads[i].tobytes() for i in o_], names))
+        ords.append(o_)
+    assert parallel.merge_by_ordinal(per_rank, ords, len(reads)) == texts
+    res = mapper.align(batch)
     import os
     os.environ["LRA_RECORD_THREADS"] = "1"                                  # one host thread or many: the same text
     try:
@@ -208,6 +229,61 @@ def test_map_reads_match_oracle_pipeline(ctx, oracle, preset):
         ctx.check(ctx.lib.lra_match_rate_batch(ctx.h, C.byref(cres), C.c_float(o.initial_anchorbonus), C.byref(d_rate)))
         got = ctx.to_host(d_rate.value, len(reads), np.float32)
         assert got.tolist() == [float(x) if x is not None else 20.0 for x in rates], (got.tolist(), rates)
+
+
+def _same_alignments(a, b):
+    if len(a) != len(b):
+        return False
+    for ga, gb in zip(a, b):
+        if len(ga) != len(gb):
+            return False
+        for x, y in zip(ga, gb):
+            if any(x[k] != y[k] for k in ("strand", "supp", "secondary", "n0", "n1", "chrom", "refine_status")) or x.get("breakpoint") != y.get("breakpoint"):
+                return False
+            if np.float32(x["value"]).view(np.uint32) != np.float32(y["value"]).view(np.uint32):
+                return False
+            if not np.array_equal(x["blocks"], y["blocks"]) or not np.array_equal(x["a13_blocks"], y["a13_blocks"]) or ("stats" in x) != ("stats" in y):
+                return False
+            if "stats" in x and (x["stats"][0] != y["stats"][0] or not np.array_equal(x["stats"][2], y["stats"][2]) or
+                                 np.float32(x["stats"][1]).view(np.uint32) != np.float32(y["stats"][1]).view(np.uint32)):
+                return False
+    return True
+
+
+def test_oracle_cpp_pipeline_equals_python_composition(oracle):
+    """oracle/pipeline.cpp (what the GPU path is compared with, and what bench.py's cpu_baseline times on all host cores) against the same
+    composition written in Python over the stage wrappers: plain reads, a deletion, an inversion, a translocation, junk; two chromosomes; with
+    and without --refineBreakpoints; and the thread pool gives the same checksum on 1 and 4 threads."""
+    import oracle_lib as O
+    import oracle_pipeline as OP
+    genome = synth.make_genome(400_000, seed=31, repeat_frac=0.25, n_families=3)
+    CH = [0, 200_100, len(genome)]
+    ik, ip = synth.build_global_index(genome, 17, 10, 100)
+    tups, bnd = [], [0]
+    for c in range(2):
+        t, b = O.local_index_seq(genome[CH[c]:CH[c + 1]].tobytes(), 10, 5, 256, 15)
+        tups.append(t); bnd.extend((b[1:] + bnd[-1]).tolist())
+    g_index = (OP.seq_offsets_multi(CH, 256), np.array(bnd, np.uint64), np.concatenate(tups))
+    gbytes = genome.tobytes() + b"\0" * 64
+    reads, _ = synth.simulate_reads(genome, 4, 7000, 2000, 0.10, (30, 35, 35), seed=11)
+    rng = np.random.default_rng(2)
+    sim = lambda a, n, rev=False: synth.simulate_read(rng, genome[a:a + n + 1], n, 0.08, (30, 35, 35), rev)[0]
+    reads.append(np.concatenate([sim(50_000, 3000), sim(59_000, 3000)]))
+    reads.append(np.concatenate([sim(150_000, 3000), sim(153_000, 2500, True), sim(155_500, 3000)]))
+    reads.append(np.concatenate([sim(250_000, 3500), sim(100_000, 3500, True)]))
+    reads.append(np.frombuffer(b"ACGT", dtype=np.uint8)[rng.integers(0, 4, 2500)].copy())
+    n_seg = 0
+    for oo in (None, dict(refineBreakpoint=True)):
+        for rd in reads:
+            a, u = OP.map_read_lowacc_py(rd.tobytes(), gbytes, ik, ip, g_index, oo, chrom_pos=CH)
+            b, v = OP.map_read_lowacc(rd.tobytes(), gbytes, ik, ip, g_index, oo, chrom_pos=CH)
+            assert u == v and _same_alignments(a, b), (u, v, [len(x) for x in a], [len(x) for x in b])
+            n_seg += sum(len(x) for x in b)
+    assert n_seg >= 16
+    allr = np.concatenate(reads); off = np.concatenate([[0], np.cumsum([len(r) for r in reads])])
+    r1 = OP.map_reads_lowacc_mt(allr, off, 0, len(reads), gbytes, ik, ip, g_index, chrom_pos=CH, n_threads=1)
+    r4 = OP.map_reads_lowacc_mt(allr, off, 0, len(reads), gbytes, ik, ip, g_index, chrom_pos=CH, n_threads=4)
+    assert r1["checksum"] == r4["checksum"] and r1["n_alignments"] == r4["n_alignments"] >= 8 and r1["bases"] == int(off[-1])
 
 
 def test_oracle_pipeline_sanity(oracle):
