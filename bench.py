@@ -25,7 +25,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 
-def cpu_baseline(mapper, reads_h, off_h, args, budget_s=20.0):
+def cpu_baseline(mapper, reads_h, off_h, args):
     """The oracle (CPU restatement) on the host's cores, on a bounded sample of the same batch: MapRead_lowacc read by read
     (oracle_map_reads_lowacc_mt, oracle/pipeline.cpp: the same stages in the same order as the GPU step; tests/test_mapread.py compares its
     alignments with the GPU's bit for bit) on all hardware threads."""
@@ -42,10 +42,8 @@ def cpu_baseline(mapper, reads_h, off_h, args, budget_s=20.0):
     fetch_s = time.time() - t0
     opts = dict(globalK=args.k, globalW=args.w, globalMaxFreq=args.max_freq, refineBand=args.refine_band)
     n_threads = os.cpu_count() or 1
-    # size the sample from a short single-thread probe
-    res = OP.map_reads_lowacc_mt(reads_h, off_h, 0, min(8, len(off_h) - 1), g, key, pos, g_index, opts, mapper.chrom_pos, n_threads=min(8, n_threads))
-    per_read = max(res["seconds"] / max(res["n_reads"], 1), 1e-4) * min(8, n_threads)
-    S = int(max(n_threads, min(len(off_h) - 1, budget_s / per_read * n_threads)))
+    # a bounded sample: 8 reads per host thread (at most 4096), about 10-30 s of wall time
+    S = int(min(len(off_h) - 1, 4096, 8 * n_threads))
     res = OP.map_reads_lowacc_mt(reads_h, off_h, 0, S, g, key, pos, g_index, opts, mapper.chrom_pos, n_threads=n_threads)
     return {"value": res["bases"] / res["seconds"] / 1e9, "unit": "Gbp/s", "cores": n_threads, "kind": "port",
             "sample": "first %d reads (%d bp, %d alignments) of the same batch through the oracle's MapRead_lowacc (a1-a5, a7-a11, a13 incl. a12, a14, a16: the stages of "
@@ -69,6 +67,10 @@ def main():
     ap.add_argument("--refine-band", type=int, default=7)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-records", action="store_true", help="leave the host tail (SAM text) out of the step")
+    ap.add_argument("--satellite-frac", type=float, default=0.03, help="fraction of every chromosome in its satellite array")
+    ap.add_argument("--lanes", type=int, default=int(os.environ.get("LRA_BENCH_LANES", 1)),
+                    help="the batch is cut into this many sub-batches, each driven by its own context and HIP stream from its own host thread (ONE shared replica "
+                         "of the reference), so that the serial tails of one sub-batch's kernels overlap the other's work")
     args = ap.parse_args()
 
     import torch
@@ -90,7 +92,7 @@ def main():
 
     # ---- reference side, once per process: genome, StoreIndex, LocalIndex (all on the device)
     t0 = time.time()
-    genome, chrom_pos, chrom_names = sg.make_grch38_like(dev, scale=args.genome_scale, seed=3)
+    genome, chrom_pos, chrom_names = sg.make_grch38_like(dev, scale=args.genome_scale, seed=3, satellite_frac=args.satellite_frac)
     torch.cuda.synchronize()
     gen_s = time.time() - t0
     ctx = Context(dev_index)
@@ -99,65 +101,125 @@ def main():
     torch.cuda.synchronize()
     index_s = time.time() - t0
     G = mapper.G
-    # ---- this rank's reads (hash partition of the job's ordinals; weak scaling: args.reads per GPU)
+    # ---- this rank's reads (hash partition of the job's ordinals; weak scaling: args.reads per GPU), cut into args.lanes sub-batches
     t0 = time.time()
     sim = sg.simulate_reads_sv(genome, chrom_pos, args.reads, args.read_len, args.read_len / 10, args.err, (30, 35, 35), 1000 + rank, sv_frac=args.sv_frac)
     off_h = sim["off"].cpu().numpy()
     reads_h = sim["seq"][:int(off_h[-1])].cpu().numpy()
     n_sv = int((sim["sv"] > 0).sum())
-    rbatch = seed.read_batch_from_device(ctx, sim["seq"], sim["off"])
     total_bases = int(off_h[-1])
     del genome
+    rb = reads_h.tobytes()
+    n_threads_rec = min(64, max(1, (os.cpu_count() or 16) - 8)) if world > 1 else 0
+    lanes = []
+    for li in range(args.lanes):
+        r0, r1 = args.reads * li // args.lanes, args.reads * (li + 1) // args.lanes
+        if li == 0:
+            lctx, lmap, stream = ctx, mapper, None
+        else:
+            stream = torch.cuda.Stream(device=dev_index)
+            lctx = Context(dev_index)
+            lmap = mapread.LowAccMapper.sharing(lctx, mapper)
+        if args.lanes > 1 and li == 0:
+            stream = torch.cuda.Stream(device=dev_index)
+        if stream is not None:
+            lctx.bind_stream(stream)
+        b0, b1 = int(off_h[r0]), int(off_h[r1])
+        lseq = torch.cat([sim["seq"][b0:b1], torch.zeros(64, dtype=torch.uint8, device=dev)])
+        loff = (sim["off"][r0:r1 + 1] - b0).contiguous()
+        rbatch = seed.read_batch_from_device(lctx, lseq, loff)
+        names = [b"read%d" % i for i in range(r0, r1)]
+        reads_b = [rb[int(off_h[i]):int(off_h[i + 1])] for i in range(r0, r1)]
+        lanes.append(dict(ctx=lctx, mapper=lmap, stream=stream, rbatch=rbatch, rargs=lmap.record_args(names, reads_b), packed=None))
+    del sim
     torch.cuda.synchronize()
     torch.cuda.empty_cache()
     sim_s = time.time() - t0
-    n_job = args.reads * world
-    my_ord = [i for i in range(n_job) if parallel.shard_of(i, world) == rank] if world > 1 else list(range(args.reads))
-    names = [b"read%d" % i for i in range(args.reads)]
-    rb = reads_h.tobytes()
-    reads_b = [rb[int(off_h[i]):int(off_h[i + 1])] for i in range(args.reads)]
-    rargs = mapper.record_args(names, reads_b)
-    n_threads_rec = max(1, (os.cpu_count() or 16) // max(world, 1)) if world > 1 else 0
 
     worker = [None]
     text_bytes = [0]
     err = []
 
-    def host_tail(snaps):
+    def host_tail(items):
         try:
-            for snap in snaps:
-                text_bytes[0] += mapper.records_host(snap, rargs, n_threads=n_threads_rec, as_list=False)
+            for lane, snap in items:
+                text_bytes[0] += lane["mapper"].records_host(snap, lane["rargs"], n_threads=n_threads_rec, as_list=False)
         except BaseException as e:
             err.append(e)
 
-    def step():
-        res = mapper.align(rbatch)
-        if args.no_records:
-            return
-        # the one exchange step: this rank's record buffer -> rank 0
-        d_buf, nb = C.c_void_p(), C.c_uint64(0)
-        ctx.check(ctx.lib.lra_map_pack(ctx.h, C.byref(res), 0, C.byref(d_buf), C.byref(nb)))
-        packed = ctx.to_tensor(d_buf.value, nb.value, torch.uint8)
-        got = parallel.gather_records(packed, dst=0)
-        if rank == 0:
-            snaps = []
-            for t in got:
-                hb = t.cpu().numpy()
-                snap = C.c_void_p()
-                rc = ctx.lib.lra_map_unpack_host(C.c_void_p(hb.ctypes.data), C.c_uint64(hb.nbytes), C.byref(snap))
-                assert rc == 0, rc
-                snaps.append(snap)
-            if worker[0] is not None:
-                worker[0].join()
-            # (every rank holds args.reads reads of the same shape; rank 0 formats each rank's records with its own batch's names / bases as
-            # stand-ins for the other ranks' -- the text volume and the work are the same)
-            worker[0] = threading.Thread(target=host_tail, args=(snaps,))
-            worker[0].start()
+    def lane_device_side(lane):
+        try:
+            torch.cuda.set_device(dev_index)                               # the current device is per host thread
+            lc = lane["ctx"]
+            def run():
+                res = lane["mapper"].align(lane["rbatch"])
+                if args.no_records:
+                    return
+                d_buf, nb = C.c_void_p(), C.c_uint64(0)
+                lc.check(lc.lib.lra_map_pack(lc.h, C.byref(res), 0, C.byref(d_buf), C.byref(nb)))
+                lane["packed"] = lc.to_tensor(d_buf.value, nb.value, torch.uint8)
+            if lane["stream"] is not None:
+                with torch.cuda.stream(lane["stream"]):
+                    run()
+                lane["stream"].synchronize()
+            else:
+                run()
+        except BaseException as e:                                         # surfaced by the caller: a thread's exception would vanish otherwise
+            err.append(e)
 
-    def drain():
-        if worker[0] is not None:
-            worker[0].join()
-            worker[0] = None
+    # Every lane runs its own sequence of steps (no barrier between the lanes inside the timed region): lane i starts i / lanes of a step late, so
+    # that the long serial tail of one sub-batch's sparse DP runs beside the other sub-batches' wide kernels.  Collectives are issued in ticket
+    # order (step, lane) so that every rank issues them in the same order.
+    ticket = [0]
+    tcv = threading.Condition()
+    tails = []
+
+    def lane_loop(li, n_steps, stagger_s):
+        lane = lanes[li]
+        try:
+            if stagger_s:
+                time.sleep(stagger_s)
+            prev = None
+            for s_ in range(n_steps):
+                lane_device_side(lane)
+                if err:
+                    break
+                if args.no_records:
+                    continue
+                with tcv:
+                    while ticket[0] != s_ * len(lanes) + li:
+                        tcv.wait()
+                got = parallel.gather_records(lane["packed"], dst=0)          # the one exchange step: this rank's record buffer -> rank 0
+                with tcv:
+                    ticket[0] += 1
+                    tcv.notify_all()
+                if rank == 0:
+                    items = []
+                    for t in got:
+                        hb = t.cpu().numpy()
+                        snap = C.c_void_p()
+                        rc = ctx.lib.lra_map_unpack_host(C.c_void_p(hb.ctypes.data), C.c_uint64(hb.nbytes), C.byref(snap))
+                        assert rc == 0, rc
+                        # (every rank holds reads of the same shape; rank 0 formats each rank's records with its own lane's names / bases as stand-ins
+                        # for the other ranks' -- the text volume and the work are the same)
+                        items.append((lane, snap))
+                    if prev is not None:
+                        prev.join()
+                    prev = threading.Thread(target=host_tail, args=(items,))
+                    prev.start()
+            if prev is not None:
+                prev.join()
+        except BaseException as e:
+            err.append(e)
+
+    def run_steps(n_steps, stagger):
+        ticket[0] = 0
+        if len(lanes) == 1:
+            lane_loop(0, n_steps, 0.0)
+        else:
+            ths = [threading.Thread(target=lane_loop, args=(li, n_steps, stagger * li / len(lanes))) for li in range(len(lanes))]
+            for t in ths: t.start()
+            for t in ths: t.join()
         if err:
             raise err[0]
 
@@ -166,19 +228,19 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    for _ in range(args.warmup):
-        step()
-    drain()
-    ctx.timing(True)
-    ctx.timing_reset()
+    tw = time.perf_counter()
+    run_steps(args.warmup, 0.0)
+    step_guess = (time.perf_counter() - tw) / max(args.warmup, 1)
+    for l in lanes:
+        l["ctx"].timing(True)
+        l["ctx"].timing_reset()
     text_bytes[0] = 0
     sync()
     t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
-    drain()
+    run_steps(args.steps, step_guess if args.lanes > 1 else 0.0)
     sync()
     dt = time.perf_counter() - t0
+    t_dev = dt
     if world > 1:
         tt = torch.tensor([dt], dtype=torch.float64, device=dev)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
@@ -193,9 +255,15 @@ def main():
     kernels = ["sketch_count", "sketch_serial", "sketch_emit", "sort", "sort_fallback", "index_bounds", "compare", "strand",
                "aog_lds_tiny", "aog_lds_small", "aog_lds_medium", "aog_lds_large", "aog_hbm", "ir_segment", "ir_band", "ir_fill", "ir_trace", "ir_gather", "clean_sort", "clean", "linear_extend", "stats", "stats_cigar", "create_rc", "local_sketch", "local_sort_filter", "local_compare",
                "rsc_tasks", "rsc_filter", "refine_space", "rs_long_sketch", "rs_long_compare", "btwn_plan", "btwn_apply", "merge_extend", "between_anchors", "local_refine", "sdp_inner_points", "sdp_inner_sort", "sdp_inner_build_count", "sdp_inner_build", "sdp_inner_process", "sdp_inner_trace", "chain_split", "sdp_points", "sdp_sort", "sdp_sort_fallback", "sdp_build_count", "sdp_build", "sdp_process", "sdp_trace"]
-    ktimes = {k: ctx.timing_get(k) for k in kernels}
-    ctx.timing(False)
-    stats = dict(mapper.stats)
+    ktimes = {}
+    for k in kernels:
+        tt_ = [l["ctx"].timing_get(k) for l in lanes]
+        ktimes[k] = (sum(x[0] for x in tt_), sum(x[1] for x in tt_))
+    stats = {}
+    for l in lanes:
+        l["ctx"].timing(False)
+        for k, v in l["mapper"].stats.items():
+            stats[k] = stats.get(k, 0) + v if isinstance(v, (int, float)) else v
     if rank == 0:
         ms_step = dt / args.steps * 1e3
         gbps = job_bases * args.steps / dt / 1e9
@@ -249,7 +317,7 @@ def main():
                                  "a9 (MergeChain), a7 (second LinearExtend + Trim), a8 (second SDP + filters), a13 (incl. a12), a14, a16; then lra_map_pack, the gather of the "
                                  "record buffers to rank 0 and the host tail a16-a17 (SetFromSegAlignment, AlignmentsOrder, SimpleMapQV, SAM text) of batch i beside the "
                                  "device side of batch i + 1%s.  Not in the step: RefineBreakpoint (a15, built; off by default in lra)" % (" -- SKIPPED (--no-records)" if args.no_records else ""),
-                       "parallelism": "reads hash-partitioned by ordinal, 1 process/GPU, genome + both indexes replicated; RCCL gather of the packed record buffers to rank 0",
+                       "parallelism": "reads hash-partitioned by ordinal, 1 process/GPU, genome + both indexes replicated per GPU; %d sub-batch(es) per process on their own HIP streams; RCCL gather of the packed record buffers to rank 0" % args.lanes,
                        "per_step": {k: int(v) for k, v in stats.items() if not k.startswith("_") and isinstance(v, (int, float))},
                        "reads_with_sv": n_sv},
             "kernel_ms_per_step": {k: round(v[0] / args.steps, 4) for k, v in ktimes.items() if v[1]},
@@ -258,9 +326,12 @@ def main():
                          "footprint_bytes_per_launch": fp, "frac_footprint": (fp / (avg_ms * 1e-3) / 1e9 / 8000.0) if avg_ms > 0 else 0.0,
                          "step_algorithmic_bytes": step_alg, "step_frac": step_alg / (ms_step * 1e-3) / 1e9 / 8000.0},
             "sam_text_gb_per_step": round(text_bytes[0] / max(args.steps, 1) / 1e9, 3),
+            "device_side_ms_per_step": round(t_dev / args.steps * 1e3, 1),
         }
         if world == 1 and not args.no_cpu_baseline:
             try:
+                for l in lanes[1:]:
+                    l["ctx"].close()
                 out["cpu_baseline"] = cpu_baseline(mapper, reads_h, off_h, args)
             except Exception as e:                                          # the bench line must survive a baseline problem; say what happened
                 out["cpu_baseline"] = {"value": None, "unit": "Gbp/s", "cores": os.cpu_count(), "kind": "port", "sample": "failed: %r" % (e,)}

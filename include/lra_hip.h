@@ -828,6 +828,9 @@ int lra_ctx_load_chromosomes(lra_ctx* ctx, const uint64_t* h_chrom_pos, int n_ch
 int lra_ctx_build_local_index(lra_ctx* ctx, int k, int w, int window, int max_freq);
 /* The context's reference data as device pointers: the genome bytes; the genome's local index (the .gli payload: d_tuple_bnd[n_windows + 1],
  * d_tuples[n_tuples]) and its seqOffsets[n_windows + 1].  Valid until the context is destroyed or the data is loaded / built again.        */
+/* Several contexts on one GPU (sub-batches on their own HIP streams) share ONE replica of the reference: dst borrows src's genome, global
+ * index, chromosome table and local index; src must outlive dst; dst must not hold reference data of its own.                              */
+int lra_ctx_share_reference(lra_ctx* dst, lra_ctx* src);
 const char* lra_ctx_genome_ptr(lra_ctx* ctx);
 int lra_ctx_local_index(lra_ctx* ctx, lra_local_index_result* out, const uint64_t** d_seq_offsets);
 int lra_map_reads_lowacc_batch(lra_ctx* ctx, int n_reads, const char* d_seq, const uint64_t* d_read_off, uint64_t total_bases, const lra_map_opts* opts,

@@ -85,6 +85,7 @@ SYMBOLS = {
     "lra_ctx_build_local_index": (C.c_int, [_vp, C.c_int, C.c_int, C.c_int, C.c_int]),
     "lra_map_reads_lowacc_batch": (C.c_int, [_vp, C.c_int, _vp, _vp, C.c_uint64, _vp, _vp]),
     "lra_ctx_genome_ptr": (_vp, [_vp]),
+    "lra_ctx_share_reference": (C.c_int, [_vp, _vp]),
     "lra_ctx_local_index": (C.c_int, [_vp, _vp, _vp]),
     "lra_map_snapshot": (C.c_int, [_vp, _vp, C.c_int, _vp]),
     "lra_map_records_host": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, C.c_char_p, C.c_int, _vp, _vp, _vp]),

@@ -28,6 +28,7 @@ struct lra_map_state {
   void* gli_buf = nullptr; lra_local_index_result gli{};   // the genome's LocalIndex (the .gli payload), built on the device
   uint64_t* d_gso = nullptr; uint64_t n_gwin = 0;  // its seqOffsets
   int gli_window = 0;
+  bool borrowed = false;                           // reference data shared from another context (lra_ctx_share_reference): not freed here
   std::vector<float> lut;                          // LogLookUpTable.h:9-15
   std::string last_text; std::vector<uint64_t> last_off; lra_map_sig last_sig;   // lra_map_records: sizing call -> filling call
 };
@@ -35,9 +36,11 @@ struct lra_map_state {
 void lra_map_free(lra_ctx* ctx) {
   lra_map_state* m = ctx->map;
   if (!m) return;
-  if (m->d_chrom_pos) (void)hipFree(m->d_chrom_pos);
-  if (m->gli_buf) (void)hipFree(m->gli_buf);
-  if (m->d_gso) (void)hipFree(m->d_gso);
+  if (!m->borrowed) {
+    if (m->d_chrom_pos) (void)hipFree(m->d_chrom_pos);
+    if (m->gli_buf) (void)hipFree(m->gli_buf);
+    if (m->d_gso) (void)hipFree(m->d_gso);
+  }
   delete m;
   ctx->map = nullptr;
 }
@@ -262,6 +265,21 @@ extern "C" int lra_ctx_build_local_index(lra_ctx* ctx, int k, int w, int window,
   LRA_HIP_CHECK(ctx, hipMalloc((void**)&m->d_gso, gso.size() * 8));
   LRA_HIP_CHECK(ctx, hipMemcpy(m->d_gso, gso.data(), gso.size() * 8, hipMemcpyHostToDevice));
   m->n_gwin = r.n_windows;
+  return LRA_OK;
+}
+
+// Several contexts on one GPU (sub-batches on their own HIP streams, so that the serial tails of one sub-batch's kernels overlap the other's work)
+// share ONE replica of the reference: dst borrows src's genome, global index + directory, chromosome table and local index.  src must outlive dst.
+int lra_seed_share(lra_ctx* dst, lra_ctx* src);   // seed.hip
+extern "C" int lra_ctx_share_reference(lra_ctx* dst, lra_ctx* src) {
+  if (!dst || !src || dst == src || !src->map || !src->seed || dst->device != src->device) return LRA_ERR_INVALID;
+  if (dst->map) return lra_set_err(dst, LRA_ERR_INVALID, "context already holds reference data");
+  int rc = lra_seed_share(dst, src);
+  if (rc) return rc;
+  lra_map_state* m = map_state(dst);
+  const lra_map_state* s = src->map;
+  m->chrom_pos = s->chrom_pos; m->d_chrom_pos = s->d_chrom_pos; m->gli_buf = s->gli_buf; m->gli = s->gli; m->d_gso = s->d_gso; m->n_gwin = s->n_gwin;
+  m->gli_window = s->gli_window; m->lut = s->lut; m->borrowed = true;
   return LRA_OK;
 }
 

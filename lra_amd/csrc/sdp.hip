@@ -885,6 +885,238 @@ __global__ void __launch_bounds__(64) sdp_process(ProcArgs a) {
 #undef W
 }
 
+// ---- the same for LARGE reads: one 1024-thread workgroup per read, the (family pair, level) slots spread over its 16 waves.
+// A read from a satellite array gives tens of thousands of anchors on a lattice of tied rows / columns / diagonals; with one wave per read the
+// owners of a start point's insertions take turns (phase 1b above) and every turn is a chain of dependent memory round trips: 44 k points took
+// 1.2 s, the whole launch waiting for that one wave.  Here wave w owns the slots w, w + 16, w + 32: every sub-problem still sees exactly the
+// deposits and queries it sees above, in the same order (a sub-problem belongs to one slot, a slot to one wave), the waves meet at every start
+// point for the (max value, first in visit order) reduction over the slots, and Value[] is written before anyone reads it again (an anchor's
+// end point comes after its start point).  Insertions always run wave-cooperatively (the code of phase 1b with the owner's state uniform).
+struct SlotState { Node cn; uint32_t cId; int2 cTop, cLastB; int cTopOk; };
+constexpr int WG_NW = 16;
+
+__global__ void __launch_bounds__(64 * WG_NW) sdp_process_wg(ProcArgs a) {
+  __shared__ float s_slope[25], s_inter[25];
+  __shared__ SlotState ss[2 * LV];
+  __shared__ float s_ev[2 * LV];
+  __shared__ uint32_t s_i1[2 * LV];
+  __shared__ uint32_t s_node[2 * LV];
+  __shared__ uint32_t s_bad;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  if (tid < 25) { s_slope[tid] = a.pwl.slope[tid]; s_inter[tid] = a.pwl.inter[tid]; }
+  if (tid < 2 * LV) {
+    SlotState z; memset(&z, 0, sizeof z); z.cn.last = -1; z.cId = NONE;
+    ss[tid] = z;
+  }
+  if (tid == 0) s_bad = 0;
+  __syncthreads();
+  const int c1 = a.pwl.c1, c2 = a.pwl.c2;
+#define W(i, j) pwl_w(s_slope, s_inter, c1, c2, (i), (j))
+  const int rr = (int)a.order[blockIdx.x], r = a.r0 + rr;
+  const uint64_t p0 = a.ptOff[r], f0 = a.fragOff[r];
+  const int P = (int)(a.ptOff[r + 1] - p0);
+  const float rate = a.rate_in ? a.rate_in[r] : a.rate;
+  const ReadArena A = a.ra[rr];
+  char* ab = (char*)(uintptr_t)A.base;
+  Node* nodes = (Node*)ab;
+  Ent* ent = (Ent*)(ab + A.entOff);
+  uint32_t* Ap = (uint32_t*)(ab + A.apOff);
+  int2* pairs = (int2*)(ab + A.stkOff);
+  const uint32_t poolPair = A.poolPair, poolPairs = A.poolPairs;
+  uint32_t* poolUsed = a.poolUsed + rr;
+  const uint2* visR = (const uint2*)(ab + A.visOff);
+  constexpr int SPW = (2 * LV + WG_NW - 1) / WG_NW;                       // slots per wave (3)
+  uint2 vN[SPW]; uint8_t flN = P > 0 ? a.hfl[p0] : 0; uint32_t lfN = P > 0 ? a.hfr[p0] : 0;
+#pragma unroll
+  for (int k = 0; k < SPW; k++) { const int slot = wave + k * WG_NW; vN[k] = (P > 0 && slot < 2 * LV) ? visR[slot] : make_uint2(NONE, 0); }
+  for (int pi = 0; pi < P; pi++) {
+    const uint8_t fl = flN;
+    const uint32_t lf = lfN;
+    uint2 vv[SPW];
+#pragma unroll
+    for (int k = 0; k < SPW; k++) vv[k] = vN[k];
+    if (pi + 1 < P) {                                                    // next point's rows, in flight while this one is processed
+      flN = a.hfl[p0 + pi + 1]; lfN = a.hfr[p0 + pi + 1];
+#pragma unroll
+      for (int k = 0; k < SPW; k++) { const int slot = wave + k * WG_NW; if (slot < 2 * LV) vN[k] = visR[(uint64_t)(pi + 1) * (2 * LV) + slot]; }
+    }
+    const int ind = fl & 1, inv = (fl >> 1) & 1;
+    // phase 0 for all of this wave's slots at once (their loads are independent): sub-problem descriptor, Eb[i1], stack top, last Block pair
+    Ent e0[SPW]; int2 top0[SPW], lastB0[SPW]; bool act[SPW];
+#pragma unroll
+    for (int k = 0; k < SPW; k++) {
+      const int slot = wave + k * WG_NW;
+      act[k] = slot < 2 * LV && vv[k].x != NONE;
+      if (act[k] && vv[k].x != ss[slot].cId) {
+        if (lane == 0) { ss[slot].cn = nodes[vv[k].x]; ss[slot].cId = vv[k].x; ss[slot].cTopOk = 0; }
+      }
+    }
+    wave_sync();
+    if (ind) {
+#pragma unroll
+      for (int k = 0; k < SPW; k++) {
+        const int slot = wave + k * WG_NW;
+        e0[k].b = -1; e0[k].val = 0; e0[k].v = 0; top0[k] = make_int2(0, 0); lastB0[k] = make_int2(0, 0);
+        if (act[k]) {
+          const Node& nd = ss[slot].cn;
+          e0[k] = ent[nd.dBase + nd.nD + vv[k].y];
+          top0[k] = ss[slot].cTop; lastB0[k] = ss[slot].cLastB;
+          if (!ss[slot].cTopOk && nd.sTop > 0) { top0[k] = pairs[nd.stkOff + nd.sTop - 1]; lastB0[k] = nd.nBlk > 0 ? pairs[nd.blkOff + nd.nBlk - 1] : make_int2(0, 0); }
+        }
+      }
+    }
+#pragma unroll
+    for (int k = 0; k < SPW; k++) {
+      const int slot = wave + k * WG_NW;
+      if (slot >= 2 * LV) continue;
+      const uint2 v = vv[k];
+      if (!act[k]) { if (ind && lane == 0) s_ev[slot] = -2.f; continue; }
+      const Node nd = ss[slot].cn;
+      if (ind == 0) {                                                    // PassValueToD1/D2
+        if (lane == 0) {
+          const float val = a.fval[f0 + lf];
+          const uint32_t e = nd.dBase + v.y;
+          if (ent[e].v < val) { ent[e].v = val; Ap[e] = lf; }
+        }
+        continue;
+      }
+      const int now = e0[k].b, dbn = __float_as_int(e0[k].v);
+      const long long ei1 = e0[k].val;
+      const bool need = now != -1;
+      const int m = (int)nd.nD, n = (int)nd.nE, i1 = (int)v.y;
+      int oTop = (int)nd.sTop, oBlk = (int)nd.nBlk;
+      uint32_t oStkOff = nd.stkOff, oBlkOff = nd.blkOff;
+      int2* oS = pairs + oStkOff; int2* oB = pairs + oBlkOff;
+      int oSCap = (int)nd.stkCap, oBCap = (int)nd.blkCap;
+      const Ent* oD = ent + nd.dBase;
+      const Ent* oE = oD + m;
+      int2 otop = top0[k], olastB = lastB0[k];
+      uint32_t ost = 0;
+      const int on = n;
+#define SPUSH(val_) do { const int2 v__ = (val_); if (oTop >= oSCap) { if (coop_grow_pairs(pairs, oStkOff, oSCap, oTop, poolUsed, poolPair, poolPairs, lane)) oS = pairs + oStkOff; else ost |= LRA_ST_CAPACITY; } \
+                         if (oTop < oSCap) oS[oTop] = v__; oTop++; } while (0)
+#define BPUSH(val_) do { const int2 v__ = (val_); if (oBlk >= oBCap) { if (coop_grow_pairs(pairs, oBlkOff, oBCap, oBlk, poolUsed, poolPair, poolPairs, lane)) oB = pairs + oBlkOff; else ost |= LRA_ST_CAPACITY; } \
+                         if (oBlk < oBCap) oB[oBlk] = v__; oBlk++; olastB = v__; } while (0)
+      if (need && now > nd.last) {                                       // Maximization :275-328, the whole wave
+        const int olast = nd.last, onow = now;
+        bool topD = false; float tDv = 0; long long tDi = 0;
+        bool stop = false;
+        for (int i0 = olast + 1; i0 <= onow && !stop && !ost; i0 += 64) {
+          const int j = i0 + lane;
+          Ent dj; dj.val = 0; dj.b = -1; dj.v = 0;
+          long long ej = 0;
+          if (j <= onow) { dj = oD[j]; if (dj.b != -1) ej = oE[dj.b].val; }
+          const int nb = min(64, onow - i0 + 1);
+          int t = 0;
+          while (t < nb && !ost) {
+            if (otop.y != on + 1) {
+              if (otop.x < 0) { ost |= LRA_ST_OOB_SLOT; break; }
+              if (!topD) { const Ent e = oD[otop.x]; tDv = e.v; tDi = e.val; topD = true; }
+              bool evt = false;
+              if (lane >= t && lane < nb)
+                evt = dj.b == -1 || (oTop > 1 && dj.b >= otop.y) || (dj.v + W(dj.val, ej) > tDv + W(tDi, ej));
+              const unsigned long long em = __ballot(evt);
+              if (!em) break;
+              t = __ffsll((long long)em) - 1;
+            }
+            const int i = i0 + t;
+            const int db = rl_i(dj.b, t);
+            if (db == -1) { stop = true; break; }
+            const long long di = rl_ll(dj.val, t), edb = rl_ll(ej, t);
+            const float dvi = rl_f(dj.v, t);
+            if (otop.y == on + 1) { BPUSH(make_int2(-1, db)); SPUSH(make_int2(i, on)); otop = make_int2(i, on); tDv = dvi; tDi = di; topD = true; }
+            while (oTop > 1 && db >= otop.y) { BPUSH(otop); oTop--; otop = oS[oTop - 1]; topD = false; }
+            if (otop.x < 0) { ost |= LRA_ST_OOB_SLOT; break; }
+            if (!topD) { const Ent e = oD[otop.x]; tDv = e.v; tDi = e.val; topD = true; }
+            if (dvi + W(di, edb) > tDv + W(tDi, edb)) {
+              if (db < otop.y && oBlk > 0 && db > olastB.y) BPUSH(make_int2(otop.x, db));
+              int2 cur = otop; float cDv = tDv; long long cDi = tDi; int prevY = cur.y;
+              while (oTop > 0) {
+                if (cur.x < 0 || cur.y < 1) { ost |= LRA_ST_OOB_SLOT; break; }
+                const long long e = oE[cur.y - 1].val;
+                if (!(dvi + W(di, e) > cDv + W(cDi, e))) break;
+                oTop--; prevY = cur.y;
+                if (oTop == 0) { ost |= LRA_ST_OOB_SLOT; break; }
+                cur = oS[oTop - 1];
+                if (cur.y == on + 1) break;
+                if (cur.x < 0) { ost |= LRA_ST_OOB_SLOT; break; }
+                const Ent ce = oD[cur.x]; cDv = ce.v; cDi = ce.val;
+              }
+              if (ost) break;
+              unsigned h;
+              if (cur.x != -1) {
+                const float dvb = cDv; const long long dib = cDi;
+                h = coop_search((unsigned)prevY, (unsigned)cur.y - (unsigned)prevY, lane,
+                                [&](unsigned it) { const long long e = oE[it].val; return dvi + W(di, e) > dvb + W(dib, e); });
+              } else h = (unsigned)on;
+              SPUSH(make_int2(i, (int)h)); otop = make_int2(i, (int)h); tDv = dvi; tDi = di; topD = true;
+            }
+            t++;
+          }
+        }
+      }
+      // phase 2 (every lane the same values): the flush of Maximization :330-343, FindValueInBlock :224-236 with a wave-cooperative UPPERbound
+      float ev = -2.f;
+      if (need && !ost) {
+        if (now == m - 1) { while (oTop > 1 && otop.y != on + 1 && !ost) { BPUSH(otop); oTop--; otop = oS[oTop - 1]; } }
+        else { while (oTop > 1 && dbn >= otop.y && !ost) { BPUSH(otop); oTop--; otop = oS[oTop - 1]; } }
+        int i2 = -1;
+        if (!ost && oBlk > 0) {
+          if (i1 >= olastB.y && i1 < otop.y) i2 = otop.x;
+          else {
+            const int2* Bc = oB;
+            const unsigned lo = coop_search(0u, (unsigned)oBlk, lane, [&](unsigned it) { return i1 >= Bc[it].y; });   // UPPERbound :205-221
+            if ((int)lo < oBlk) i2 = oB[lo].x;
+          }
+        }
+        if (ost || i2 < 0 || i2 >= m) ost |= ost ? ost : LRA_ST_OOB_SLOT;
+        else {
+          const Ent d2 = oD[i2];
+          ev = d2.v + W(d2.val, ei1) + rate * a.flen[f0 + lf];
+          if (lane == 0) {
+            Ap[nd.dBase + nd.nD + i1] = (uint32_t)i2;
+            Node* np = nodes + v.x;
+            np->last = now; np->sTop = (uint32_t)oTop; np->nBlk = (uint32_t)oBlk;
+            if (oStkOff != nd.stkOff) { np->stkOff = oStkOff; np->stkCap = (uint32_t)oSCap; }
+            if (oBlkOff != nd.blkOff) { np->blkOff = oBlkOff; np->blkCap = (uint32_t)oBCap; }
+            SlotState& Z = ss[slot];
+            Z.cn.last = now; Z.cn.sTop = (uint32_t)oTop; Z.cn.nBlk = (uint32_t)oBlk; Z.cn.stkOff = oStkOff; Z.cn.blkOff = oBlkOff; Z.cn.stkCap = (uint32_t)oSCap; Z.cn.blkCap = (uint32_t)oBCap;
+            Z.cTop = otop; Z.cLastB = olastB; Z.cTopOk = 1;
+          }
+        }
+      }
+#undef SPUSH
+#undef BPUSH
+      if (lane == 0) {
+        if (ost) atomicOr(&s_bad, ost);
+        s_ev[slot] = ev; s_i1[slot] = (uint32_t)i1; s_node[slot] = v.x;
+      }
+    }
+    wave_sync();
+    if (ind) {
+      __syncthreads();
+      // Value[ii]: visits apply in the order R family deepest level first, then C family; `val < Ev` keeps the first maximum
+      if (tid == 0 && !s_bad) {
+        float bv = -1.f; int bs = -1;
+        for (int o = 0; o < 2 * LV; o++) {
+          const int fam2 = o / LV, level = LV - 1 - (o % LV);
+          const int slot = fam2 * LV + level;
+          const float e = s_ev[slot];
+          if (e > -1.5f && e > bv) { bv = e; bs = slot; }
+        }
+        if (bs >= 0 && a.fval[f0 + lf] < bv) {
+          a.fval[f0 + lf] = bv; a.fprevNode[f0 + lf] = s_node[bs]; a.fprevInd[f0 + lf] = s_i1[bs];
+          a.fflags[f0 + lf] = (uint8_t)((bs < LV ? 1 : 0) | (inv ? 2 : 0));
+        }
+      }
+      __syncthreads();
+      if (s_bad) break;
+    }
+  }
+  if (tid == 0 && s_bad) atomicOr(&a.status[r], s_bad);
+#undef W
+}
+
 // ---- value order, TraceBack, DecidePrimaryChains ------------------------------------------------------------------------
 __global__ void k_valkeys(uint64_t f0, uint64_t n, const float* __restrict__ fval, const uint32_t* __restrict__ fragRead,
                           const uint64_t* __restrict__ fragOff, uint64_t* okey, uint32_t* opay) {
@@ -1252,9 +1484,29 @@ int sdp_run(lra_ctx* ctx, int n_reads, const uint64_t* d_cluster_off, const uint
       pa.fprevNode = fprevNode; pa.fprevInd = fprevInd; pa.fflags = fflags; pa.rate_in = d_rate; pa.rate = opts->rate; pa.ra = ra;
       pa.status = status; pa.pwl = pw; pa.poolUsed = poolUsed;
       LRA_HIP_CHECK(ctx, hipMemsetAsync(poolUsed, 0, (size_t)nr * 4, st));
+      static const bool dbg = getenv("LRA_SDP_DBG") != nullptr;
+      hipEvent_t e0 = nullptr, e1 = nullptr;
+      if (dbg) { (void)hipEventCreate(&e0); (void)hipEventCreate(&e1); (void)hipEventRecord(e0, st); }
+      // the reads of this attempt are ordered by their number of points, largest first: the large ones get a workgroup each
+      int nbig = 0;
+      {
+        const long big_pts = getenv("LRA_SDP_BIG_POINTS") ? atol(getenv("LRA_SDP_BIG_POINTS")) : 6000;   // (tests lower it to run small reads through the workgroup kernel)
+        const std::vector<uint32_t>& ord = att == 0 ? h_orderAll : h_prev;
+        while (nbig < nsub && (long)(h_pt[r0 + ord[nbig] + 1] - h_pt[r0 + ord[nbig]]) >= big_pts) nbig++;
+      }
       lra_time_begin(ctx, ctx->sdp_inner ? "sdp_inner_process" : "sdp_process");
-      hipLaunchKernelGGL(sdp_process, dim3(nsub), dim3(64), 0, st, pa);
+      if (nbig > 0) hipLaunchKernelGGL(sdp_process_wg, dim3(nbig), dim3(64 * WG_NW), 0, st, pa);
+      if (nsub > nbig) { ProcArgs pb = pa; pb.order = subOrder + nbig; pb.n = nsub - nbig; hipLaunchKernelGGL(sdp_process, dim3(nsub - nbig), dim3(64), 0, st, pb); }
       lra_time_end(ctx);
+      if (dbg) {
+        (void)hipEventRecord(e1, st); (void)hipEventSynchronize(e1);
+        float ms = 0; (void)hipEventElapsedTime(&ms, e0, e1);
+        uint64_t mx = 0, tot = 0;
+        for (int i = 0; i < nr; i++) { const uint64_t p = h_pt[r0 + i + 1] - h_pt[r0 + i]; mx = std::max(mx, p); tot += p; }
+        fprintf(stderr, "[sdp] mode %d inner %d att %d reads %d (of %d) points total %llu max %llu  process %.1f ms\n", opts->mode, (int)ctx->sdp_inner, att, nsub, nr,
+                (unsigned long long)tot, (unsigned long long)mx, ms);
+        (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
+      }
       if (att == 2) break;
       LRA_HIP_CHECK(ctx, hipMemcpyAsync(h_status.data(), status + r0, (size_t)nr * 4, hipMemcpyDeviceToHost, st));
       LRA_HIP_CHECK(ctx, hipStreamSynchronize(st));

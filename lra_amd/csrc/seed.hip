@@ -487,18 +487,23 @@ __device__ void lds_insertion_sort(LdsSeg& s, int first, int last) {   // == __i
   }
 }
 
+// BIG: the same algorithm for lists of up to 65534 tuples (beyond the LDS capacity; the value order of a large read's sparse-DP fragments, the point
+// lists of a large read, the k-mer lists of a 30 kb gap): the element arrays live in a per-workgroup global scratch, only the segment tables stay in
+// LDS; it takes the lists the LDS kernel flagged and clears the flag of those it sorted.
+template <bool BIG>
 __global__ void __launch_bounds__(SORT_NT) sort_wg_kernel(int n_reads, const uint64_t* __restrict__ mm_off, uint64_t* mm_key, uint32_t* mm_pos,
                                                         uint32_t* tscratch, int cap, int* __restrict__ fallback,
-                                                        const int* __restrict__ only) {
+                                                        const int* __restrict__ only, char* gscr) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int maxseg = cap / 16 + 8;
-  uint64_t* key = (uint64_t*)smem;
+  const int maxseg = (cap / 16 + 8 + 1) & ~1;                            // even: the word array behind the ten tables stays 4-byte aligned
+  char* ebase = BIG ? gscr + (size_t)blockIdx.x * ((size_t)cap * 16 + 64) : smem;
+  uint64_t* key = (uint64_t*)ebase;
   unsigned short* idx = (unsigned short*)(key + cap);
   unsigned short* seg = idx + cap;
   unsigned short* pa = seg + cap;
   unsigned short* pb = pa + cap;
-  unsigned short* sF = pb + cap;            // segment tables (current)
+  unsigned short* sF = BIG ? (unsigned short*)smem : pb + cap;            // segment tables (current)
   unsigned short* sL = sF + maxseg;
   unsigned short* sD = sL + maxseg;
   unsigned short* nF = sD + maxseg;         // next level
@@ -517,9 +522,14 @@ __global__ void __launch_bounds__(SORT_NT) sort_wg_kernel(int n_reads, const uin
     const long base = (long)mm_off[r];
     const int n = (int)(mm_off[r + 1] - mm_off[r]);
     if (n < 2) continue;
-    if (only && !only[r]) continue;
-    if (n > cap) { if (tid == 0) fallback[r] = 1; continue; }
+    if (BIG) {
+      if (!fallback[r] || n > cap) continue;                              // (every thread reads the flag before anyone clears it: the barrier below)
+    } else {
+      if (only && !only[r]) continue;
+      if (n > cap) { if (tid == 0) fallback[r] = 1; continue; }
+    }
     __syncthreads();
+    if (BIG && tid == 0) fallback[r] = 0;
     for (int p = tid; p < n; p += SORT_NT) { key[p] = mm_key[base + p]; idx[p] = (unsigned short)p; seg[p] = 0; }
     for (int x = tid; x < cap / 32 + 1; x += SORT_NT) startBits[x] = 0;
     if (tid == 0) {
@@ -894,6 +904,7 @@ static bool regrow(T*& p, size_t n) {
 void lra_seed_free(lra_ctx* ctx) {
   lra_seed_state* s = ctx->seed;
   if (!s) return;
+  if (s->borrowed) { s->genome = nullptr; s->idx_key = nullptr; s->idx_pos = nullptr; s->dir = nullptr; }
   void* ptrs[] = {s->genome, s->idx_key, s->idx_pos, s->counts32, s->counts64, s->mm_off, s->match_off, s->n_forward,
                   s->mm_key, s->mm_pos, s->lb, s->ub, s->match_qi, s->match_ti, s->sep_qpos, s->sep_tpos, s->tmp_qi, s->tmp_ti, s->cap_cnt, s->cap_off, s->tk_lb, s->tk_lbm1, s->tk_ubm1, s->dir, s->sep_qkey};
   for (void* p : ptrs) if (p) (void)hipFree(p);
@@ -946,6 +957,16 @@ extern "C" int lra_ctx_load_global_index(lra_ctx* ctx, const uint64_t* h_key, co
   LRA_HIP_CHECK(ctx, hipMemcpy(dk, h_key, n * 8, hipMemcpyHostToDevice));
   LRA_HIP_CHECK(ctx, hipMemcpy(dp, h_pos, n * 4, hipMemcpyHostToDevice));
   return lra_seed_install_index(ctx, dk, dp, n);
+}
+
+int lra_seed_share(lra_ctx* dst, lra_ctx* src) {
+  if (dst->seed && (dst->seed->genome || dst->seed->idx_key)) return lra_set_err(dst, LRA_ERR_INVALID, "context already holds reference data");
+  lra_seed_state* d = seed_state(dst);
+  const lra_seed_state* s = src->seed;
+  d->borrowed = true;
+  d->genome = s->genome; d->genome_len = s->genome_len; d->idx_key = s->idx_key; d->idx_pos = s->idx_pos; d->n_idx = s->n_idx;
+  d->dir = s->dir; d->nbuckets = s->nbuckets; d->dir_shift = s->dir_shift;
+  return LRA_OK;
 }
 
 // the context's global index (device arrays; the .mms payload as two columns)
@@ -1005,17 +1026,24 @@ extern "C" int lra_create_rc_batch(lra_ctx* ctx, int n_reads, const char* d_seq,
 static int launch_sort(lra_ctx* ctx, int n_reads, const uint64_t* mm_off, uint64_t* mm_key, uint32_t* mm_pos, const int* only = nullptr) {
   hipStream_t st = ctx->stream;
   const int nb = (n_reads + 63) / 64;
-  const int cap = SORT_CAP;
-  const int maxseg = cap / 16 + 8;
+  const int cap = SORT_CAP, capB = 65534;                                 // unsigned short indices, 0xFFFF = none
+  const int maxseg = (cap / 16 + 8 + 1) & ~1, maxsegB = (capB / 16 + 8 + 1) & ~1;
   const size_t lds = (size_t)cap * 16 + (size_t)maxseg * 20 + 8 + (size_t)(cap / 32 + 2) * 4;
+  const size_t ldsB = (size_t)maxsegB * 20 + 8 + (size_t)(capB / 32 + 2) * 4 + 64;
   const int grid = n_reads < ctx->num_cu ? n_reads : ctx->num_cu;
+  const int gridB = std::min(grid, 64);
+  const size_t tszB = (size_t)gridB * (capB + 64) * 4, esz = (size_t)gridB * ((size_t)capB * 16 + 64);
   uint32_t* tscr = (uint32_t*)lra_scratch(ctx, 0, (size_t)grid * (cap + 64) * 4 + (size_t)n_reads * 4);
-  if (!tscr) return LRA_ERR_NOMEM;
+  char* big = (char*)lra_ensure(ctx, 85, tszB + esz + 1024);               // its own buffer: callers hold pointers into scratch 0 across a sort
+  if (!tscr || !big) return LRA_ERR_NOMEM;
+  uint32_t* tscrB = (uint32_t*)big; char* gscr = big + tszB;
   int* flags = (int*)(tscr + (size_t)grid * (cap + 64));
   LRA_HIP_CHECK(ctx, hipMemsetAsync(flags, 0, (size_t)n_reads * 4, st));
-  LRA_HIP_CHECK(ctx, hipFuncSetAttribute((const void*)sort_wg_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  LRA_HIP_CHECK(ctx, hipFuncSetAttribute((const void*)sort_wg_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  LRA_HIP_CHECK(ctx, hipFuncSetAttribute((const void*)sort_wg_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsB));
   lra_time_begin(ctx, ctx->sort_tag);
-  hipLaunchKernelGGL(sort_wg_kernel, dim3(grid), dim3(SORT_NT), lds, st, n_reads, mm_off, mm_key, mm_pos, tscr, cap, flags, only);
+  hipLaunchKernelGGL(sort_wg_kernel<false>, dim3(grid), dim3(SORT_NT), lds, st, n_reads, mm_off, mm_key, mm_pos, tscr, cap, flags, only, (char*)nullptr);
+  hipLaunchKernelGGL(sort_wg_kernel<true>, dim3(gridB), dim3(SORT_NT), ldsB, st, n_reads, mm_off, mm_key, mm_pos, tscrB, capB, flags, only, gscr);
   lra_time_end(ctx);
   lra_time_begin(ctx, ctx->sort_fb_tag);
   hipLaunchKernelGGL(sort_kernel, dim3(nb), dim3(64), 0, st, n_reads, mm_off, mm_key, mm_pos, (const int*)flags);

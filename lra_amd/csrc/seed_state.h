@@ -3,6 +3,7 @@
 #include "common.h"
 
 struct lra_seed_state {
+  bool borrowed = false;   // genome / index / directory belong to another context (lra_ctx_share_reference)
   unsigned char* genome = nullptr; uint64_t genome_len = 0;
   uint64_t* idx_key = nullptr; uint32_t* idx_pos = nullptr; uint64_t n_idx = 0;
   // batch buffers (grown on demand)

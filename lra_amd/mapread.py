@@ -173,6 +173,18 @@ class LowAccMapper:
             self._gli = local.LocalIndex(self.ctx, self.gdev, self.g_off, o.localK, o.localW, o.localIndexWindow, o.localMaxFreq)
         return self._gli
 
+    @classmethod
+    def sharing(cls, ctx: Context, other: "LowAccMapper"):
+        """A mapper on another context of the same GPU that borrows `other`'s reference data (lra_ctx_share_reference): for sub-batches that
+        run on their own HIP streams."""
+        m = cls.__new__(cls)
+        m.ctx = ctx; m.opts = other.opts; m.G = other.G; m.chrom_pos = other.chrom_pos; m.chrom_names = other.chrom_names; m.index_stats = other.index_stats
+        ctx.check(ctx.lib.lra_ctx_share_reference(ctx.h, other.ctx.h))
+        m.copts = other.copts; m.gdev = None; m.g_off = other.g_off; m._gli = None; m.gso = None; m.lut = other.lut
+        m.sdp_opts, m.sdp2_opts, m.clean_opts = other.sdp_opts, other.sdp2_opts, other.clean_opts
+        m.stats = {}
+        return m
+
     def fetch_local_index(self):
         """The genome's local index as the context holds it (what lra_ctx_build_local_index built): host arrays (seqOffsets, tupleBoundaries, tuples)."""
         ctx = self.ctx

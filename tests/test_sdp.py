@@ -266,3 +266,29 @@ def test_hip_sdp_bench_workload_flags_and_sample(ctx, oracle):
             assert m == len(ch["frags"]) and np.array_equal(out["chain_cluster"][a:a + m], cl) and np.array_equal(out["chain_anchor"][a:a + m], ch["frags"] - offs[cl]), (r, c)
         n_ok += 1
     assert n_ok >= 20
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("which", ["clusters", "single"])
+def test_hip_sdp_workgroup_kernel(ctx, which, monkeypatch):
+    """The workgroup-per-read ProcessPoint (sdp_process_wg, for reads with many points: the slots spread over 16 waves) against the oracle: the
+    threshold is lowered so that the ordinary test reads go through it, plus one read of 9000 anchors on a lattice of tied rows / columns /
+    diagonals (what a read from a satellite array looks like)."""
+    monkeypatch.setenv("LRA_SDP_BIG_POINTS", "40")
+    rng = np.random.default_rng(23)
+    if which == "clusters":
+        reads_in = [_random_clusters(rng, nc, per, span, ties) for nc, per, span, ties in [(6, 80, 30000, False), (3, 150, 20000, True), (10, 30, 30000, True), (1, 5, 1000, False)]]
+        kw = {}
+    else:
+        reads_in = [_random_clusters(rng, 1, per, span, ties) for per, span, ties in [(300, 20000, False), (600, 30000, True), (40, 3000, True)]]
+        # a lattice: anchors at (171 a + 7 b, 171 c + 7 b) -- thousands of tied coordinates and diagonals
+        a_ = rng.integers(0, 60, 9000); c_ = rng.integers(0, 60, 9000); b_ = rng.integers(0, 24, 9000)
+        q = (171 * a_ + 7 * b_).astype(np.uint32); t = (171 * c_ + 7 * b_ + 5000).astype(np.uint32)
+        _, u = np.unique(q.astype(np.int64) * 100000 + t, return_index=True)
+        u = np.sort(u)
+        o = np.lexsort((q[u], q[u].astype(np.int64) - t[u].astype(np.int64)))
+        reads_in.append((np.array([0, len(u)], np.int32), np.array([0], np.uint8), q[u][o], t[u][o], np.full(len(u), 12, np.int32)))
+        kw = dict(mode=1, rate=2.0)
+    read_lens = [40000] * len(reads_in)
+    res, out = _run_hip(ctx, reads_in, read_lens, kw)
+    assert _compare(out, int(res.num_aln), reads_in, read_lens, kw) >= len(reads_in) - 1

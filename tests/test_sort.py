@@ -38,3 +38,21 @@ def test_hip_sort_matches_std_sort(ctx, oracle):
         ek, ep = oracle.sort_minimizers(k, p)
         assert np.array_equal(got[i][0], ek), (i, len(k))
         assert np.array_equal(got[i][1], ep), (i, len(k))
+
+
+@pytest.mark.gpu
+def test_hip_sort_big_lists(ctx, oracle):
+    """Lists beyond the LDS capacity (9000 tuples): the global-memory workgroup sort up to 65534 tuples, the serial kernel beyond; heavy ties,
+    the depth-limit adversary, sizes around both limits."""
+    from lra_amd import seed
+    rng = np.random.default_rng(3)
+    cs = [rng.integers(0, 1 << 34, 9001).astype(np.uint64), rng.integers(0, 50, 20000).astype(np.uint64), rng.integers(0, 1 << 20, 65534).astype(np.uint64),
+          rng.integers(0, 4000, 65535).astype(np.uint64), rng.integers(0, 1 << 30, 70000).astype(np.uint64), oracle.antiqsort_keys(12000),
+          np.arange(30000, 0, -1).astype(np.uint64), np.zeros(15000, np.uint64), rng.integers(0, 1 << 34, 100).astype(np.uint64)]
+    cs[1] |= (rng.integers(0, 2, 20000).astype(np.uint64) << np.uint64(63))      # strand bits: not part of the order
+    pos = [np.arange(len(k), dtype=np.uint32) for k in cs]
+    got = seed.sort_minimizers_batch(ctx, cs, pos)
+    for i, (k, p) in enumerate(zip(cs, pos)):
+        ek, ep = oracle.sort_minimizers(k, p)
+        assert np.array_equal(got[i][0], ek), (i, len(k))
+        assert np.array_equal(got[i][1], ep), (i, len(k))
