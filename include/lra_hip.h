@@ -184,6 +184,30 @@ int lra_clean_matches_batch(lra_ctx* ctx, const lra_clean_opts* opts, const uint
  * pass it as d_rate to lra_sparse_dp_batch.  Asynchronous on the context's stream.                                                    */
 int lra_match_rate_batch(lra_ctx* ctx, const lra_cluster_result* clusters, float initial_anchorbonus, const float** d_rate);
 
+/* ---- a5 (high-accuracy path): MatchesToFineClusters -----------------------------------------------------------------------------------
+ * Replaces   MatchesToFineClusters(forMatches, clusters, ...); MatchesToFineClusters(revMatches, clusters, ..., 1)   (Clustering.h:1555-1680,
+ *            Map_highacc.h:41-42)
+ * behind lra_clean_matches_batch run with the high-accuracy options (bypassClustering = 0: its clusters are the rough clusters of
+ * CleanOffDiagonal): CartesianSort of every rough cluster, SplitRoughClustersWithGaps (:1358-1432), StoreFineClusters (:892-1331) for both
+ * strands of every read, sharing the read's `clusters` vector as the reference does.  opts: Options::globalK, RoughClustermaxGap, maxDiag,
+ * maxGap, minClusterSize, minUniqueStretchNum, minUniqueStretchDist (presets lra.cpp:268-340).
+ * Output (context-owned): fine clusters CSR by read (d_cluster_off), their matches CSR by cluster (d_match_off over d_q / d_t, genome
+ * coordinates), box {qStart, qEnd, tStart, tEnd}, strand, chromIndex, anchorfreq; d_status[r] = LRA_ST_OOB_SLOT where the reference reads
+ * clusters.back() of an empty vector (:1305; the read then has no clusters).  Synchronous.                                               */
+typedef struct lra_fine_opts { int32_t globalK, RoughClustermaxGap, maxDiag, maxGap, minClusterSize, minUniqueStretchNum, minUniqueStretchDist; } lra_fine_opts;
+typedef struct lra_fine_result {
+  int32_t n_reads;
+  uint64_t n_clusters, n_matches;
+  const uint64_t* d_cluster_off;   /* [n_reads+1] */
+  const uint64_t* d_match_off;     /* [n_clusters+1] */
+  const uint32_t* d_q; const uint32_t* d_t;   /* [n_matches] */
+  const uint32_t* d_box;           /* [4*n_clusters] */
+  const int32_t* d_strand; const int32_t* d_chrom; const float* d_anchorfreq;   /* [n_clusters] */
+  const uint32_t* d_status;        /* [n_reads] */
+} lra_fine_result;
+int lra_fine_clusters_batch(lra_ctx* ctx, const lra_cluster_result* rough, const lra_fine_opts* opts, const uint64_t* h_chrom_pos, int n_chrom,
+                            lra_fine_result* out);
+
 /* ---- a7: linear extension of the cleaned clusters ------------------------------------------
  * Replaces, per cluster of the context's current lra_clean_matches_batch result,
  *   LinearExtend(&clusters[d].matches, ext.matches, ext.matchesLengths, opts, genome, read,

@@ -55,3 +55,34 @@ def fetch_extend(ctx: Context, res: ExtendResult):
     return {"e_start": ctx.to_host(res.d_e_start, nc, np.uint64), "e_count": ctx.to_host(res.d_e_count, nc, np.uint32),
             "e_qpos": ctx.to_host(res.d_e_qpos, nm, np.uint32), "e_tpos": ctx.to_host(res.d_e_tpos, nm, np.uint32),
             "e_len": ctx.to_host(res.d_e_len, nm, np.int32), "box": ctx.to_host(res.d_box, 4 * nc, np.uint32).reshape(-1, 4)}
+
+
+class FineOpts(C.Structure):
+    """lra_fine_opts: Options::globalK, RoughClustermaxGap, maxDiag, maxGap, minClusterSize, minUniqueStretchNum, minUniqueStretchDist"""
+    _fields_ = [(n, C.c_int32) for n in ("globalK", "RoughClustermaxGap", "maxDiag", "maxGap", "minClusterSize", "minUniqueStretchNum", "minUniqueStretchDist")]
+
+
+class FineResult(C.Structure):
+    _fields_ = [("n_reads", C.c_int32), ("n_clusters", C.c_uint64), ("n_matches", C.c_uint64)] + [
+        (n, C.c_void_p) for n in ("d_cluster_off", "d_match_off", "d_q", "d_t", "d_box", "d_strand", "d_chrom", "d_anchorfreq", "d_status")]
+
+
+# lra.cpp:268-340 over Options.h:123-240
+FINE_PRESETS = {"CCS": dict(globalK=17, RoughClustermaxGap=500, maxDiag=500, maxGap=400, minClusterSize=10, minUniqueStretchNum=1, minUniqueStretchDist=50),
+                "CONTIG": dict(globalK=19, RoughClustermaxGap=500, maxDiag=100, maxGap=500, minClusterSize=10, minUniqueStretchNum=1, minUniqueStretchDist=50)}
+
+
+def fine_clusters_batch(ctx: Context, rough: ClusterResult, opts: FineOpts, chrom_pos):
+    """MatchesToFineClusters behind clean_matches_batch (run with bypassClustering = 0)."""
+    cp = np.ascontiguousarray(chrom_pos, dtype=np.uint64)
+    res = FineResult()
+    ctx.check(ctx.lib.lra_fine_clusters_batch(ctx.h, C.byref(rough), C.byref(opts), C.c_void_p(cp.ctypes.data), len(cp) - 1, C.byref(res)))
+    return res
+
+
+def fetch_fine(ctx: Context, res: FineResult):
+    n, nc, nm = int(res.n_reads), int(res.n_clusters), int(res.n_matches)
+    return dict(cluster_off=ctx.to_host(res.d_cluster_off, n + 1, np.uint64), match_off=ctx.to_host(res.d_match_off, nc + 1, np.uint64) if nc else np.zeros(1, np.uint64),
+                q=ctx.to_host(res.d_q, nm, np.uint32), t=ctx.to_host(res.d_t, nm, np.uint32), box=ctx.to_host(res.d_box, 4 * nc, np.uint32).reshape(-1, 4),
+                strand=ctx.to_host(res.d_strand, nc, np.int32), chrom=ctx.to_host(res.d_chrom, nc, np.int32), freq=ctx.to_host(res.d_anchorfreq, nc, np.float32),
+                status=ctx.to_host(res.d_status, n, np.uint32))

@@ -155,6 +155,27 @@ def clean_matches(qpos, tpos, qkey, strand, opts: "CleanOpts", chrom_pos):
                                               tStart=ts[:ncl].copy(), tEnd=te[:ncl].copy(), chrom=ch[:ncl].copy(), freq=fr[:ncl].copy())
 
 
+class FineOpts(C.Structure):
+    _fields_ = [(n, C.c_int) for n in ("globalK", "RoughClustermaxGap", "maxDiag", "maxGap", "minClusterSize", "minUniqueStretchNum", "minUniqueStretchDist")]
+
+
+def matches_to_fine_clusters(qpos, tpos, qkey, n_forward, clean_opts: "CleanOpts", fine_opts: "FineOpts", chrom_pos):
+    """Both strands of one read (forward matches first) -> (dict(off, q, t, box, strand, chrom, freq), status)"""
+    L = lib()
+    qpos = np.ascontiguousarray(qpos, np.uint32); tpos = np.ascontiguousarray(tpos, np.uint32); qkey = np.ascontiguousarray(qkey, np.uint64)
+    cp = np.ascontiguousarray(chrom_pos, np.uint64)
+    n = len(qpos); cap = max(1, n)
+    oq = np.zeros(cap, np.uint32); ot = np.zeros(cap, np.uint32); off = np.zeros(cap + 1, np.int64); box = np.zeros(4 * cap, np.uint32)
+    st = np.zeros(cap, np.int32); ch = np.zeros(cap, np.int32); fr = np.zeros(cap, np.float32); nm = C.c_long(0); status = C.c_int(0)
+    L.oracle_matches_to_fine_clusters.restype = C.c_long
+    nc = L.oracle_matches_to_fine_clusters(_p(qpos, C.c_uint32), _p(tpos, C.c_uint32), _p(qkey, C.c_uint64), C.c_long(n), C.c_long(int(n_forward)), C.byref(clean_opts),
+                                           C.byref(fine_opts), _p(cp, C.c_uint64), len(cp) - 1, C.c_long(cap), C.c_long(cap), _p(oq, C.c_uint32), _p(ot, C.c_uint32),
+                                           _p(off, C.c_long), _p(box, C.c_uint32), _p(st, C.c_int), _p(ch, C.c_int), _p(fr, C.c_float), C.byref(nm), C.byref(status))
+    assert nc >= 0
+    m = nm.value
+    return dict(off=off[:nc + 1].copy(), q=oq[:m].copy(), t=ot[:m].copy(), box=box.reshape(-1, 4)[:nc].copy(), strand=st[:nc].copy(), chrom=ch[:nc].copy(), freq=fr[:nc].copy()), status.value
+
+
 def store_index(genome: bytes, chrom_pos, k=17, w=10, max_freq=150, winsize=15, n_per_window=1, stable=False):
     """StoreIndex (MMIndex.h:286-400) -> (key uint64[], pos uint32[], status).  stable: equal keys keep their emission order (the device builder's
     order); False = the reference's std::sort."""
