@@ -225,6 +225,29 @@ typedef struct lra_extend_result {
 } lra_extend_result;
 int lra_linear_extend_batch(lra_ctx* ctx, int K, const char* d_seq, const uint64_t* d_read_off, lra_extend_result* out);
 
+/* ---- a7 (high-accuracy path): the cluster version of LinearExtend ---------------------------------------------------------------------
+ * Replaces   LinearExtend_chain(chain, ExtendClusters, RefinedClusters, smallOpts, genome, read, start, overlap, skiprepetitive, K)
+ *            (LinearExtend.h:783-792) = LinearExtend(vector<Cluster*>, vector<Cluster>&, chain, ...) (:136-352; CheckOverlap :88, Checkbp :50,
+ *            DecideCoordinates :105) + TrimOverlappedAnchors(ExtendClusters, start) (:574-649), called at Map_highacc.h:580 for every chain.
+ * Item i = one element of one chain: the refined cluster d_item_cluster[i], its neighbours on the chain d_item_prev[i] / d_item_next[i]
+ * (cluster indices, -1 at the ends), the read d_item_read[i].  Refined clusters: matches CSR d_match_off over d_mq / d_mt (t relative to the
+ * cluster's chromosome; SORTED IN PLACE by diagonal / anti-diagonal as the reference does, :201-210), d_box {qStart, qEnd, tStart, tEnd} (t
+ * relative), d_strand, d_chrom, d_anchorfreq.  d_seq / d_read_off: the reads (forward); d_genome: all chromosomes.
+ * Output (context-owned): per item its anchors d_anchor_off[i] .. d_anchor_off[i+1] (read pos, chromosome pos, length, Cluster::overlap flag),
+ * and what DecideCoordinates leaves: box, strand (-1 for an element without matches: the Cluster() default), chromIndex, anchorfreq.
+ * trim != 0 applies TrimOverlappedAnchors to every item's list.  Synchronous.                                                              */
+typedef struct lra_ext_clusters_result {
+  uint64_t n_items, n_anchors;
+  const uint64_t* d_anchor_off;    /* [n_items+1] */
+  const uint32_t* d_q; const uint32_t* d_t; const int32_t* d_len; const uint8_t* d_overlap;   /* [n_anchors] */
+  const uint32_t* d_box; const int32_t* d_strand; const int32_t* d_chrom; const float* d_anchorfreq;   /* [4*n_items], [n_items] */
+} lra_ext_clusters_result;
+int lra_linear_extend_clusters_batch(lra_ctx* ctx, uint64_t n_items, const uint32_t* d_item_cluster, const int32_t* d_item_prev, const int32_t* d_item_next,
+                                     const uint32_t* d_item_read, uint64_t n_clusters, const uint64_t* d_match_off, uint64_t n_matches, uint32_t* d_mq, uint32_t* d_mt,
+                                     const uint32_t* d_box, const int32_t* d_strand, const int32_t* d_chrom, const float* d_anchorfreq, const char* d_seq,
+                                     const uint64_t* d_read_off, const char* d_genome, const uint64_t* h_chrom_pos, int n_chrom, int skiprepetitive, int K, int trim,
+                                     lra_ext_clusters_result* out);
+
 /* ---- a8: sparse dynamic programming over the extended anchors ("SDP#A") -------------------------
  * Replaces, per read,   SparseDP(ext_clusters, chains, optsSDP, LookUpTable, read, match_rate)
  * (SparseDP.h:2139-2279 as called from Map_lowacc.h:188): insertPointsPair (:79), the SortByRowOp / SortByColOp

@@ -86,3 +86,28 @@ def fetch_fine(ctx: Context, res: FineResult):
                 q=ctx.to_host(res.d_q, nm, np.uint32), t=ctx.to_host(res.d_t, nm, np.uint32), box=ctx.to_host(res.d_box, 4 * nc, np.uint32).reshape(-1, 4),
                 strand=ctx.to_host(res.d_strand, nc, np.int32), chrom=ctx.to_host(res.d_chrom, nc, np.int32), freq=ctx.to_host(res.d_anchorfreq, nc, np.float32),
                 status=ctx.to_host(res.d_status, n, np.uint32))
+
+
+class ExtClustersResult(C.Structure):
+    _fields_ = [("n_items", C.c_uint64), ("n_anchors", C.c_uint64)] + [
+        (n, C.c_void_p) for n in ("d_anchor_off", "d_q", "d_t", "d_len", "d_overlap", "d_box", "d_strand", "d_chrom", "d_anchorfreq")]
+
+
+def linear_extend_clusters_batch(ctx: Context, item_cluster, item_prev, item_next, item_read, match_off, mq, mt, box, strand, chrom, freq, read_batch, genome_dev, chrom_pos,
+                                 skiprepetitive=True, K=17, trim=True):
+    """LinearExtend_chain (cluster version of LinearExtend + TrimOverlappedAnchors) for chain elements; array arguments are device tensors."""
+    from .context import ptr
+    cp = np.ascontiguousarray(chrom_pos, dtype=np.uint64)
+    res = ExtClustersResult()
+    ctx.check(ctx.lib.lra_linear_extend_clusters_batch(ctx.h, C.c_uint64(int(item_cluster.numel())), ptr(item_cluster), ptr(item_prev), ptr(item_next), ptr(item_read),
+                                                       C.c_uint64(int(strand.numel())), ptr(match_off), C.c_uint64(int(mq.numel())), ptr(mq), ptr(mt), ptr(box), ptr(strand),
+                                                       ptr(chrom), ptr(freq), ptr(read_batch.seq), ptr(read_batch.off), ptr(genome_dev), C.c_void_p(cp.ctypes.data), len(cp) - 1,
+                                                       1 if skiprepetitive else 0, int(K), 1 if trim else 0, C.byref(res)))
+    return res
+
+
+def fetch_ext_clusters(ctx: Context, res: ExtClustersResult):
+    n, na = int(res.n_items), int(res.n_anchors)
+    return dict(off=ctx.to_host(res.d_anchor_off, n + 1, np.uint64), q=ctx.to_host(res.d_q, na, np.uint32), t=ctx.to_host(res.d_t, na, np.uint32),
+                len=ctx.to_host(res.d_len, na, np.int32), overlap=ctx.to_host(res.d_overlap, na, np.uint8), box=ctx.to_host(res.d_box, 4 * n, np.uint32).reshape(-1, 4),
+                strand=ctx.to_host(res.d_strand, n, np.int32), chrom=ctx.to_host(res.d_chrom, n, np.int32), freq=ctx.to_host(res.d_anchorfreq, n, np.float32))

@@ -155,6 +155,28 @@ def clean_matches(qpos, tpos, qkey, strand, opts: "CleanOpts", chrom_pos):
                                               tStart=ts[:ncl].copy(), tEnd=te[:ncl].copy(), chrom=ch[:ncl].copy(), freq=fr[:ncl].copy())
 
 
+def linear_extend_cluster(q, t, strand, box, prev_box, next_box, anchorfreq, read: bytes, chrom: bytes, K=17, skiprepetitive=True, trim=False):
+    """One chain element of the cluster version of LinearExtend (LinearExtend.h:136-352); t relative to the chromosome.
+    -> dict(q, t, len, overlap, box, sorted_q, sorted_t)"""
+    L = lib()
+    q = np.ascontiguousarray(q, np.uint32).copy(); t = np.ascontiguousarray(t, np.uint32).copy()
+    n = len(q)
+    bx = np.ascontiguousarray(box, np.uint32)
+    pb = np.ascontiguousarray(prev_box, np.uint32) if prev_box is not None else None
+    nb = np.ascontiguousarray(next_box, np.uint32) if next_box is not None else None
+    eq = np.zeros(max(1, n), np.uint32); et = np.zeros(max(1, n), np.uint32); el = np.zeros(max(1, n), np.int32); eo = np.zeros(max(1, n), np.uint8)
+    ob = np.zeros(4, np.uint32); nov = C.c_int(0)
+    L.oracle_linear_extend_cluster.restype = C.c_long
+    ne = L.oracle_linear_extend_cluster(C.c_long(n), _p(q, C.c_uint32), _p(t, C.c_uint32), int(strand), _p(bx, C.c_uint32), _p(pb, C.c_uint32) if pb is not None else None,
+                                        _p(nb, C.c_uint32) if nb is not None else None, C.c_float(float(anchorfreq)), 1 if skiprepetitive else 0, int(K), C.c_char_p(read),
+                                        C.c_uint32(len(read)), C.c_char_p(chrom), C.c_uint32(len(chrom)), _p(eq, C.c_uint32), _p(et, C.c_uint32), _p(el, C.c_int),
+                                        _p(eo, C.c_uint8), _p(ob, C.c_uint32), C.byref(nov))
+    eq, et, el, eo = eq[:ne].copy(), et[:ne].copy(), el[:ne].copy(), eo[:ne].copy()
+    if trim and ne:
+        L.oracle_trim_overlapped_anchors(C.c_int(ne), _p(eq, C.c_uint32), _p(et, C.c_uint32), _p(el, C.c_int), C.c_int(int(strand)))
+    return dict(q=eq, t=et, len=el, overlap=eo, box=ob, sorted_q=q, sorted_t=t, n_overlap=nov.value)
+
+
 class FineOpts(C.Structure):
     _fields_ = [(n, C.c_int) for n in ("globalK", "RoughClustermaxGap", "maxDiag", "maxGap", "minClusterSize", "minUniqueStretchNum", "minUniqueStretchDist")]
 

@@ -122,3 +122,74 @@ def test_hip_fine_clusters_oracle(ctx, oracle, preset):
             n_cl += 1; n_rev += int(exp["strand"][c])
         n_multi += (c1 - c0) > 1
     assert n_cl >= len(reads) - 2 and n_rev >= 2 and n_multi >= 2, (n_cl, n_rev, n_multi)
+
+
+def _fine_clusters_on_gpu(ctx, preset="CCS", seed_=11, err=0.01):
+    """The a5 stage on the GPU for a set of reads: (genome, CH, reads, batch, fetched fine clusters)"""
+    from lra_amd import seed, cluster, index as I
+    g = _genome_with_repeats(seed_)
+    CH = [0, 250_000, len(g)]
+    K = FINE[preset]["globalK"]
+    I.load_genome(ctx, g)
+    I.build_global_index(ctx, CH, K, 10, 150, 15, 1)
+    rng = np.random.default_rng(5)
+    reads = _reads(g, rng, err=err)
+    batch = seed.ReadBatch(ctx, [r.tobytes() for r in reads])
+    seed.seed_batch(ctx, batch, K, 10, 150)
+    cl = dict(CLEAN["CONTIG" if preset == "CONTIG" else "CCS"], globalK=K)
+    rough = cluster.clean_matches_batch(ctx, cluster.CleanOpts(**cl), CH)
+    res = cluster.fine_clusters_batch(ctx, rough, cluster.FineOpts(**FINE[preset]), CH)
+    return g, CH, reads, batch, cluster.fetch_fine(ctx, res), K
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("skip", [True, False])
+def test_hip_linear_extend_clusters_oracle(ctx, oracle, skip):
+    """a7, cluster version: every fine cluster of every read as an element of a chain (the read's clusters in order of their read start), plus
+    clusters cut into two overlapping halves so that the neighbours' box coordinates fall inside a cluster (the CheckOverlap branches)."""
+    import torch
+    from lra_amd import cluster
+    g, CH, reads, batch, fc, K = _fine_clusters_on_gpu(ctx)
+    dev = ctx.device
+    # refined clusters = the fine clusters with t relative to their chromosome, and halves of the large ones
+    cl = []   # (read, q, t, strand, chrom, freq)
+    for r in range(len(reads)):
+        for c in range(int(fc["cluster_off"][r]), int(fc["cluster_off"][r + 1])):
+            a, b = int(fc["match_off"][c]), int(fc["match_off"][c + 1])
+            q = fc["q"][a:b]; t = fc["t"][a:b] - np.uint32(CH[int(fc["chrom"][c])])
+            cl.append((r, q, t, int(fc["strand"][c]), int(fc["chrom"][c]), float(fc["freq"][c])))
+            if b - a >= 40:
+                o = np.argsort(q, kind="stable"); h = len(o) * 6 // 10
+                cl.append((r, q[o[:h]], t[o[:h]], int(fc["strand"][c]), int(fc["chrom"][c]), 1.0))
+                cl.append((r, q[o[-h:]], t[o[-h:]], int(fc["strand"][c]), int(fc["chrom"][c]), 1.05))
+    box = np.array([[q.min(), q.max() + K, t.min(), t.max() + K] for _, q, t, *_ in cl], np.uint32)
+    # chains: per read, its clusters ordered by qStart
+    items = []
+    for r in range(len(reads)):
+        ids = [i for i, c in enumerate(cl) if c[0] == r]
+        ids.sort(key=lambda i: (int(box[i][0]), i))
+        for k, i in enumerate(ids):
+            items.append((i, ids[k - 1] if k > 0 else -1, ids[k + 1] if k + 1 < len(ids) else -1, r))
+    moff = np.concatenate([[0], np.cumsum([len(c[1]) for c in cl])]).astype(np.int64)
+    tt = lambda a, dt: torch.from_numpy(np.ascontiguousarray(a, dtype=dt)).to(dev)
+    d_mq = tt(np.concatenate([c[1] for c in cl]), np.uint32).view(torch.int32) if False else tt(np.concatenate([c[1] for c in cl]).astype(np.int64), np.int64).to(torch.int32)
+    d_mt = tt(np.concatenate([c[2] for c in cl]).astype(np.int64), np.int64).to(torch.int32)
+    gdev = torch.from_numpy(np.concatenate([g, np.zeros(64, np.uint8)])).to(dev)
+    res = cluster.linear_extend_clusters_batch(ctx, tt([x[0] for x in items], np.int32), tt([x[1] for x in items], np.int32), tt([x[2] for x in items], np.int32),
+                                               tt([x[3] for x in items], np.int32), tt(moff, np.int64), d_mq, d_mt, tt(box.astype(np.int64), np.int64).to(torch.int32).view(-1),
+                                               tt([c[3] for c in cl], np.int32), tt([c[4] for c in cl], np.int32), tt([c[5] for c in cl], np.float32), batch, gdev, CH,
+                                               skiprepetitive=skip, K=K, trim=True)
+    out = cluster.fetch_ext_clusters(ctx, res)
+    sq = d_mq.cpu().numpy().view(np.uint32); stt = d_mt.cpu().numpy().view(np.uint32)
+    n_ovl = n_rev = 0
+    for k, (i, pv, nx, r) in enumerate(items):
+        _, q, t, st, ci, fr = cl[i]
+        exp = O.linear_extend_cluster(q, t, st, box[i], box[pv] if pv >= 0 else None, box[nx] if nx >= 0 else None, fr, reads[r].tobytes(), g[CH[ci]:CH[ci + 1]].tobytes(),
+                                      K=K, skiprepetitive=skip, trim=True)
+        a, b = int(out["off"][k]), int(out["off"][k + 1])
+        assert np.array_equal(sq[moff[i]:moff[i + 1]], exp["sorted_q"]) and np.array_equal(stt[moff[i]:moff[i + 1]], exp["sorted_t"]), k
+        assert np.array_equal(out["q"][a:b], exp["q"]) and np.array_equal(out["t"][a:b], exp["t"]) and np.array_equal(out["len"][a:b], exp["len"]), k
+        assert np.array_equal(out["overlap"][a:b], exp["overlap"]), k
+        assert out["box"][k].tolist() == exp["box"].tolist() and out["strand"][k] == st and out["chrom"][k] == ci, k
+        n_ovl += int(exp["overlap"].sum()); n_rev += st
+    assert len(items) >= 25 and n_rev >= 3 and (n_ovl >= 5) == skip, (len(items), n_rev, n_ovl)
