@@ -789,6 +789,27 @@ int lra_refine_btwn_space_batch(lra_ctx* ctx, int n, const uint32_t* d_qs, const
                                 int K, int W, int read_type, float anchorstoosparse, int match, int mismatch, int indel, int max_freq,
                                 lra_btwn_space_result* out);
 
+/* ---- a11 (high-accuracy path): RefineBtwnClusters_chain -------------------------------------------------------------------------------
+ * Replaces   for every chain (p, h) of a read, in order: RefineBtwnClusters_chain(K, W, Primary_chains, RefinedClusters, RevBtwnCluster, tracerev,
+ *            genome, read, smallOpts, p, h, strands)                               (ClusterRefine.h:433-614, Map_highacc.h:513-518)
+ * Reads: d_read_chain_off[n_reads+1] over the chains (a read's chains in the reference's order); chain x = cluster indices
+ * d_ch[d_chain_off[x] .. d_chain_off[x+1]) in the chain's order (ch[0] nearest the read's end).  Clusters (the RefinedClusters of the batch): matches
+ * CSR d_match_off over d_mq / d_mt (t relative to the chromosome), d_box {qStart, qEnd, tStart, tEnd} = SetClusterBoundariesFromMatches of those
+ * matches for K (UPDATED IN PLACE), d_strand, d_chrom, d_anchorfreq (UPDATED IN PLACE: 1 where RefineBtwnSpace decided on the cluster's own
+ * strand after trying both, :414-419).  K / W: what the caller passes on (Map_highacc.h:466-468); read_type, anchorstoosparse, match, mismatch,
+ * indel, max_freq as lra_refine_btwn_space_batch.  d_strands: the reads forward, then (at rc_base) reverse complemented.
+ * Output (context-owned): every cluster's matches with the refined spaces' pairs appended in the reference's order (CSR), Cluster::refinespace.
+ * Synchronous.                                                                                                                              */
+typedef struct lra_btwn_clusters_result {
+  uint64_t n_clusters, n_matches, n_problems, n_pairs_added; uint32_t n_rounds;
+  const uint64_t* d_match_off; const uint32_t* d_q; const uint32_t* d_t; const uint8_t* d_refinespace;
+} lra_btwn_clusters_result;
+int lra_refine_btwn_clusters_batch(lra_ctx* ctx, int n_reads, const uint64_t* d_read_chain_off, uint64_t n_chains, const uint64_t* d_chain_off, const uint32_t* d_ch,
+                                   uint64_t n_clusters, const uint64_t* d_match_off, uint64_t n_matches, const uint32_t* d_mq, const uint32_t* d_mt, uint32_t* d_box,
+                                   const int32_t* d_strand, const int32_t* d_chrom, float* d_anchorfreq, const uint64_t* d_read_off, const char* d_strands, uint64_t rc_base,
+                                   const char* d_genome, const uint64_t* h_chrom_pos, int n_chrom, int K, int W, int read_type, float anchorstoosparse, int match, int mismatch,
+                                   int indel, int max_freq, lra_btwn_clusters_result* out);
+
 /* ---- a13 helper (high-accuracy path): SwitchToOriginalAnchors ------------------------------------------------------------------------
  * Replaces   SwitchToOriginalAnchors(finalchain, ultimatechain, ExtendClusters, extend_clusters)      (LocalRefineAlignment.h:187-199, :576)
  * for n_chains chains over Cluster_SameDiag entries: chain c = elements d_chain_off[c] .. d_chain_off[c+1], element i = entry d_elem_entry[i]

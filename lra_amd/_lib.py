@@ -45,6 +45,8 @@ SYMBOLS = {
     "lra_clean_matches_batch": (C.c_int, [_vp, _vp, _vp, C.c_int, _vp]),
     "lra_match_rate_batch": (C.c_int, [_vp, _vp, C.c_float, _vp]),
     "lra_fine_clusters_batch": (C.c_int, [_vp, _vp, _vp, _vp, C.c_int, _vp]),
+    "lra_refine_btwn_clusters_batch": (C.c_int, [_vp, C.c_int, _vp, C.c_uint64, _vp, _vp, C.c_uint64, _vp, C.c_uint64, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, C.c_uint64, _vp, _vp,
+                                                C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, C.c_int, C.c_int, C.c_int, C.c_int, _vp]),
     "lra_linear_extend_clusters_batch": (C.c_int, [_vp, C.c_uint64, _vp, _vp, _vp, _vp, C.c_uint64, _vp, C.c_uint64, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp,
                                                   C.c_int, C.c_int, C.c_int, C.c_int, _vp]),
     "lra_linear_extend_batch": (C.c_int, [_vp, C.c_int, _vp, _vp, _vp]),

@@ -111,3 +111,21 @@ def fetch_ext_clusters(ctx: Context, res: ExtClustersResult):
     return dict(off=ctx.to_host(res.d_anchor_off, n + 1, np.uint64), q=ctx.to_host(res.d_q, na, np.uint32), t=ctx.to_host(res.d_t, na, np.uint32),
                 len=ctx.to_host(res.d_len, na, np.int32), overlap=ctx.to_host(res.d_overlap, na, np.uint8), box=ctx.to_host(res.d_box, 4 * n, np.uint32).reshape(-1, 4),
                 strand=ctx.to_host(res.d_strand, n, np.int32), chrom=ctx.to_host(res.d_chrom, n, np.int32), freq=ctx.to_host(res.d_anchorfreq, n, np.float32))
+
+
+class BtwnClustersResult(C.Structure):
+    _fields_ = [("n_clusters", C.c_uint64), ("n_matches", C.c_uint64), ("n_problems", C.c_uint64), ("n_pairs_added", C.c_uint64), ("n_rounds", C.c_uint32)] + [
+        (n, C.c_void_p) for n in ("d_match_off", "d_q", "d_t", "d_refinespace")]
+
+
+def refine_btwn_clusters_batch(ctx: Context, read_chain_off, chain_off, ch, match_off, mq, mt, box, strand, chrom, freq, read_off, strands, rc_base, genome_dev, chrom_pos,
+                               K=17, W=10, read_type=2, anchorstoosparse=0.005, match=4, mismatch=-3, indel=-4, max_freq=15):
+    """RefineBtwnClusters_chain over the chains of a batch (box and freq are updated in place); array arguments are device tensors."""
+    from .context import ptr
+    cp = np.ascontiguousarray(chrom_pos, dtype=np.uint64)
+    res = BtwnClustersResult()
+    ctx.check(ctx.lib.lra_refine_btwn_clusters_batch(ctx.h, int(read_chain_off.numel()) - 1, ptr(read_chain_off), C.c_uint64(int(chain_off.numel()) - 1), ptr(chain_off), ptr(ch),
+                                                     C.c_uint64(int(strand.numel())), ptr(match_off), C.c_uint64(int(mq.numel())), ptr(mq), ptr(mt), ptr(box), ptr(strand), ptr(chrom),
+                                                     ptr(freq), ptr(read_off), ptr(strands), C.c_uint64(int(rc_base)), ptr(genome_dev), C.c_void_p(cp.ctypes.data), len(cp) - 1,
+                                                     int(K), int(W), int(read_type), C.c_float(anchorstoosparse), int(match), int(mismatch), int(indel), int(max_freq), C.byref(res)))
+    return res

@@ -177,6 +177,27 @@ def linear_extend_cluster(q, t, strand, box, prev_box, next_box, anchorfreq, rea
     return dict(q=eq, t=et, len=el, overlap=eo, box=ob, sorted_q=q, sorted_t=t, n_overlap=nov.value)
 
 
+def refine_btwn_clusters_chains(match_off, mq, mt, box, strand, chrom, freq, chain_off, ch, fwd: bytes, rc: bytes, genome: bytes, chrom_pos, K=17, W=10, read_type=2,
+                                anchorstoosparse=0.005, match=4, mismatch=-3, indel=-4, max_freq=15):
+    """RefineBtwnClusters_chain over all chains of one read (ClusterRefine.h:433) -> dict(off, q, t, box, freq, refinespace)"""
+    L = lib()
+    mo = np.ascontiguousarray(match_off, np.int32); mq = np.ascontiguousarray(mq, np.uint32); mt = np.ascontiguousarray(mt, np.uint32)
+    bx = np.ascontiguousarray(box, np.uint32).reshape(-1).copy(); st = np.ascontiguousarray(strand, np.uint8); chv = np.ascontiguousarray(chrom, np.int32)
+    fr = np.ascontiguousarray(freq, np.float32).copy(); co = np.ascontiguousarray(chain_off, np.int32); chn = np.ascontiguousarray(ch if len(ch) else [0], np.int32)
+    pos = np.ascontiguousarray(chrom_pos, np.uint64)
+    ncl = len(st)
+    rs = np.zeros(max(1, ncl), np.uint8); oo = np.zeros(ncl + 1, np.int32)
+    cap = len(mq) + 8 * len(fwd) + 1024
+    oq = np.zeros(cap, np.uint32); ot = np.zeros(cap, np.uint32)
+    L.oracle_refine_btwn_clusters_chains.restype = C.c_long
+    n = L.oracle_refine_btwn_clusters_chains(C.c_int(ncl), _p(mo, C.c_int), _p(mq, C.c_uint32), _p(mt, C.c_uint32), _p(bx, C.c_uint32), _p(st, C.c_uint8), _p(chv, C.c_int),
+                                             _p(fr, C.c_float), _p(rs, C.c_uint8), C.c_int(len(co) - 1), _p(co, C.c_int), _p(chn, C.c_int), int(K), int(W), int(read_type),
+                                             C.c_float(anchorstoosparse), int(match), int(mismatch), int(indel), C.c_long(max_freq), C.c_char_p(fwd), C.c_char_p(rc),
+                                             C.c_uint32(len(fwd)), C.c_char_p(genome), _p(pos, C.c_uint64), C.c_long(cap), _p(oo, C.c_int), _p(oq, C.c_uint32), _p(ot, C.c_uint32))
+    assert 0 <= n <= cap
+    return dict(off=oo, q=oq[:n].copy(), t=ot[:n].copy(), box=bx.reshape(-1, 4), freq=fr, refinespace=rs[:ncl])
+
+
 class FineOpts(C.Structure):
     _fields_ = [(n, C.c_int) for n in ("globalK", "RoughClustermaxGap", "maxDiag", "maxGap", "minClusterSize", "minUniqueStretchNum", "minUniqueStretchDist")]
 

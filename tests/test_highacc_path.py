@@ -193,3 +193,85 @@ def test_hip_linear_extend_clusters_oracle(ctx, oracle, skip):
         assert out["box"][k].tolist() == exp["box"].tolist() and out["strand"][k] == st and out["chrom"][k] == ci, k
         n_ovl += int(exp["overlap"].sum()); n_rev += st
     assert len(items) >= 25 and n_rev >= 3 and (n_ovl >= 5) == skip, (len(items), n_rev, n_ovl)
+
+
+def _both_strands(ctx, batch):
+    """the reads forward, then reverse complemented, in one device buffer (what the drivers build once per batch)"""
+    import ctypes as C_
+    import torch
+    tot = int(batch.total_bases)
+    both = torch.zeros(2 * tot + 64, dtype=torch.uint8, device=ctx.device)
+    both[:tot] = batch.seq[:tot]
+    ctx.check(ctx.lib.lra_create_rc_batch(ctx.h, batch.n, C_.c_void_p(batch.seq.data_ptr()), C_.c_void_p(batch.off.data_ptr()), C_.c_void_p(both.data_ptr() + tot)))
+    return both, tot
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("read_type", [2, 3, 0])
+def test_hip_refine_btwn_clusters_oracle(ctx, oracle, read_type):
+    """a11 caller, high-accuracy path: RefineBtwnClusters_chain over chains made of the GPU's own fine clusters (a read's clusters by descending read
+    start; reads with several clusters also get a second chain that shares a cluster with the first): the appended pairs, the boxes as the
+    serial walk leaves them, refinespace and anchorfreq, for -CCS, -CONTIG and a low-accuracy read type (other refineSpaceDiag)."""
+    import torch
+    from lra_amd import cluster
+    g, CH, reads, batch, fc0, K = _fine_clusters_on_gpu(ctx, err=0.02)
+    dev = ctx.device
+    # the clusters of the test: the fine clusters, the large ones cut into a head and a tail with the middle third removed (a space RefineBtwnSpace refills)
+    pieces = []
+    for r in range(len(reads)):
+        for c in range(int(fc0["cluster_off"][r]), int(fc0["cluster_off"][r + 1])):
+            a, b = int(fc0["match_off"][c]), int(fc0["match_off"][c + 1])
+            q = fc0["q"][a:b]; t = fc0["t"][a:b] - np.uint32(CH[int(fc0["chrom"][c])])
+            meta = (r, int(fc0["strand"][c]), int(fc0["chrom"][c]), float(fc0["freq"][c]))
+            if b - a >= 60:
+                o = np.argsort(q, kind="stable"); h = len(o) // 3
+                pieces.append((q[o[:h]], t[o[:h]]) + meta); pieces.append((q[o[-h:]], t[o[-h:]]) + meta)
+            else:
+                pieces.append((q, t) + meta)
+    nC = len(pieces)
+    fc = dict(q=np.concatenate([x[0] for x in pieces]), strand=np.array([x[3] for x in pieces], np.int32), chrom=np.array([x[4] for x in pieces], np.int32),
+              freq=np.array([x[5] for x in pieces], np.float32), match_off=np.concatenate([[0], np.cumsum([len(x[0]) for x in pieces])]).astype(np.int64),
+              cluster_off=np.searchsorted(np.array([x[2] for x in pieces]), np.arange(len(reads) + 1)).astype(np.int64))
+    rel_t = np.concatenate([x[1] for x in pieces])
+    box = np.array([[x[0].min(), x[0].max() + K, x[1].min(), x[1].max() + K] for x in pieces], np.int64)
+    chain_off = [0]; ch = []; read_chain_off = [0]
+    for r in range(len(reads)):
+        ids = list(range(int(fc["cluster_off"][r]), int(fc["cluster_off"][r + 1])))
+        ids.sort(key=lambda i: -int(box[i][0]))
+        if ids:
+            ch.extend(ids); chain_off.append(len(ch))
+            if len(ids) >= 2:
+                ch.extend(ids[1:]); chain_off.append(len(ch))
+        read_chain_off.append(len(chain_off) - 1)
+    tt = lambda a, dt: torch.from_numpy(np.ascontiguousarray(a, dtype=dt)).to(dev)
+    both, tot = _both_strands(ctx, batch)
+    gdev = torch.from_numpy(np.concatenate([g, np.zeros(64, np.uint8)])).to(dev)
+    d_box = tt(box, np.int64).to(torch.int32).view(-1).contiguous(); d_freq = tt(fc["freq"], np.float32)
+    res = cluster.refine_btwn_clusters_batch(ctx, tt(read_chain_off, np.int64), tt(chain_off, np.int64), tt(ch if ch else [0], np.int32), tt(fc["match_off"].astype(np.int64), np.int64),
+                                             tt(fc["q"].astype(np.int64), np.int64).to(torch.int32), tt(rel_t.astype(np.int64), np.int64).to(torch.int32), d_box,
+                                             tt(fc["strand"], np.int32), tt(fc["chrom"], np.int32), d_freq, batch.off, both, tot, gdev, CH, K=K, W=10, read_type=read_type)
+    moff = ctx.to_host(res.d_match_off, nC + 1, np.uint64).astype(np.int64)
+    oq = ctx.to_host(res.d_q, int(res.n_matches), np.uint32); ot = ctx.to_host(res.d_t, int(res.n_matches), np.uint32)
+    rs = ctx.to_host(res.d_refinespace, nC, np.uint8)
+    nbox = d_box.cpu().numpy().view(np.uint32).reshape(-1, 4); nfreq = d_freq.cpu().numpy()
+    gb = g.tobytes() + b"\0" * 64
+    n_added = n_ref = 0
+    for r in range(len(reads)):
+        c0, c1 = int(fc["cluster_off"][r]), int(fc["cluster_off"][r + 1])
+        if c1 == c0:
+            continue
+        m0 = int(fc["match_off"][c0])
+        x0, x1 = read_chain_off[r], read_chain_off[r + 1]
+        co = [chain_off[x] - chain_off[x0] for x in range(x0, x1 + 1)]
+        chn = [i - c0 for i in ch[chain_off[x0]:chain_off[x1]]]
+        rd = reads[r].tobytes()
+        exp = O.refine_btwn_clusters_chains(fc["match_off"][c0:c1 + 1].astype(np.int64) - m0, fc["q"][m0:int(fc["match_off"][c1])], rel_t[m0:int(fc["match_off"][c1])], box[c0:c1],
+                                            fc["strand"][c0:c1], fc["chrom"][c0:c1], fc["freq"][c0:c1], co, chn, rd, synth.revcomp(reads[r]).tobytes(), gb, CH, K=K, W=10,
+                                            read_type=read_type)
+        for c in range(c1 - c0):
+            a, b = int(moff[c0 + c]), int(moff[c0 + c + 1]); ea, eb = int(exp["off"][c]), int(exp["off"][c + 1])
+            assert np.array_equal(oq[a:b], exp["q"][ea:eb]) and np.array_equal(ot[a:b], exp["t"][ea:eb]), (r, c, b - a, eb - ea)
+            assert nbox[c0 + c].tolist() == exp["box"][c].tolist() and rs[c0 + c] == exp["refinespace"][c], (r, c)
+            assert np.float32(nfreq[c0 + c]).view(np.uint32) == np.float32(exp["freq"][c]).view(np.uint32), (r, c)
+            n_added += (eb - ea) - int(fc["match_off"][c0 + c + 1] - fc["match_off"][c0 + c]); n_ref += int(exp["refinespace"][c])
+    assert int(res.n_pairs_added) == n_added and n_ref >= 3 and n_added >= 100 and int(res.n_rounds) >= 2, (int(res.n_pairs_added), n_added, n_ref, int(res.n_rounds))
