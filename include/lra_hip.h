@@ -810,6 +810,23 @@ int lra_refine_btwn_clusters_batch(lra_ctx* ctx, int n_reads, const uint64_t* d_
                                    const char* d_genome, const uint64_t* h_chrom_pos, int n_chrom, int K, int W, int read_type, float anchorstoosparse, int match, int mismatch,
                                    int indel, int max_freq, lra_btwn_clusters_result* out);
 
+/* ---- a9 (high-accuracy path): SPLITChain over merged clusters -----------------------------------------------------------------------------
+ * Replaces   SPLITChain(read, ExtendClusters, splitchains, Primary_chains[p].chains[h].link, smallOpts)   (Mapping_ultility.h:266-346, Map_highacc.h:706)
+ * including MergeSplitchainINS (:172-262) and LargestSplitChain_dist (Chain.h:974-985, Map_highacc.h:707) for n_jobs chains.  Job j = the
+ * Cluster_SameDiag elements d_job_off[j] .. d_job_off[j+1] (strand 0 = forward, chromIndex, box = qStart, qEnd, tStart, tEnd with t relative to
+ * the chromosome) and the link bits d_link[d_link_off[j] ..] (entry im joins elements im and im + 1).  splitdist = opts.splitdist.
+ * Output (context-owned): pieces of job j = d_job_piece_off[j] .. d_job_piece_off[j+1]; piece p = the elements d_sptc[d_piece_off[p] ..
+ * d_piece_off[p+1]) (indices inside the job, in SplitChain::sptc order), its type ('T' 'D' 'I' 'N'), Strand, box (QStart, QEnd, TStart, TEnd);
+ * d_job_lsc[j] = LSC.  The reference leaves chromIndex of a chain's last piece indeterminate (Chain.h:350-360): it compares unequal to
+ * every other piece's here.  Synchronous.                                                                                                  */
+typedef struct lra_hsplit_result {
+  uint64_t n_jobs, n_pieces, n_elems;
+  const uint64_t* d_job_piece_off; const uint64_t* d_piece_off; const uint32_t* d_sptc; const uint8_t* d_piece_type; const uint8_t* d_piece_strand;
+  const uint32_t* d_piece_box; const uint32_t* d_piece_job; const uint32_t* d_job_lsc;
+} lra_hsplit_result;
+int lra_split_chains_highacc_batch(lra_ctx* ctx, uint64_t n_jobs, const uint64_t* d_job_off, uint64_t n_elems, const int32_t* d_strand, const int32_t* d_chrom,
+                                   const uint32_t* d_box, const uint64_t* d_link_off, const uint8_t* d_link, int splitdist, lra_hsplit_result* out);
+
 /* ---- a13 helper (high-accuracy path): SwitchToOriginalAnchors ------------------------------------------------------------------------
  * Replaces   SwitchToOriginalAnchors(finalchain, ultimatechain, ExtendClusters, extend_clusters)      (LocalRefineAlignment.h:187-199, :576)
  * for n_chains chains over Cluster_SameDiag entries: chain c = elements d_chain_off[c] .. d_chain_off[c+1], element i = entry d_elem_entry[i]

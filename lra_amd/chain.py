@@ -348,3 +348,24 @@ def switch_to_original_anchors_batch(ctx: Context, chain_off, elem_cluster, elem
     ctx.check(ctx.lib.lra_switch_to_original_anchors_batch(ctx.h, C.c_uint64(int(chain_off.numel()) - 1), ptr(chain_off), C.c_uint64(int(elem_cluster.numel())),
                                                            ptr(elem_cluster), ptr(elem_entry), C.byref(same_diag), ptr(coarse), C.byref(res)))
     return res
+
+
+class HSplitResult(C.Structure):
+    _fields_ = [("n_jobs", C.c_uint64), ("n_pieces", C.c_uint64), ("n_elems", C.c_uint64)] + [(n, C.c_void_p) for n in (
+        "d_job_piece_off", "d_piece_off", "d_sptc", "d_piece_type", "d_piece_strand", "d_piece_box", "d_piece_job", "d_job_lsc")]
+
+
+def split_chains_highacc_batch(ctx: Context, job_off, strand, chrom, box, link_off, link, splitdist=100000):
+    """High-accuracy SPLITChain + MergeSplitchainINS + LargestSplitChain_dist over chains of merged clusters; array arguments are device tensors."""
+    res = HSplitResult()
+    ctx.check(ctx.lib.lra_split_chains_highacc_batch(ctx.h, C.c_uint64(int(job_off.numel()) - 1), ptr(job_off), C.c_uint64(int(strand.numel())), ptr(strand), ptr(chrom),
+                                                     ptr(box), ptr(link_off), ptr(link), int(splitdist), C.byref(res)))
+    return res
+
+
+def fetch_hsplit(ctx: Context, res: HSplitResult):
+    nj, npc, ne = res.n_jobs, res.n_pieces, res.n_elems
+    return {"job_piece_off": ctx.to_host(res.d_job_piece_off, nj + 1, np.uint64), "piece_off": ctx.to_host(res.d_piece_off, npc + 1, np.uint64),
+            "sptc": ctx.to_host(res.d_sptc, ne, np.uint32), "type": ctx.to_host(res.d_piece_type, npc, np.uint8), "strand": ctx.to_host(res.d_piece_strand, npc, np.uint8),
+            "box": ctx.to_host(res.d_piece_box, 4 * npc, np.uint32).reshape(-1, 4), "job": ctx.to_host(res.d_piece_job, npc, np.uint32),
+            "lsc": ctx.to_host(res.d_job_lsc, nj, np.uint32)}

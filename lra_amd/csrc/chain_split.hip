@@ -10,6 +10,7 @@
 // refinement stages.  A split chain is a run [a, b) of the filtered chain; MergeSplitchainINS concatenates runs, kept as a linked list
 // and laid out at the end.  Algorithmic bytes: 21 B per chain anchor in, ~14 B out.
 #include "common.h"
+#include "scan.h"
 #include <algorithm>
 
 namespace {
@@ -409,5 +410,154 @@ extern "C" int lra_filter_chains_batch(lra_ctx* ctx, uint64_t n_chains, const ui
   LRA_HIP_CHECK(ctx, hipStreamSynchronize(st));
   LRA_HIP_CHECK(ctx, hipGetLastError());
   out->d_keep = a.keep; out->d_n_kept = a.nKept; out->d_link = a.linkOut; out->d_n_link = a.nLink;
+  return LRA_OK;
+}
+
+// ---- a9, high-accuracy path: SPLITChain over Cluster_SameDiag elements (Mapping_ultility.h:266-346) + MergeSplitchainINS (:172-262) +
+// LargestSplitChain_dist (Chain.h:974-985), one lane per chain.  A piece is a run [a, b) of the chain, merges are a linked list of runs.  The last
+// piece's chromIndex is indeterminate in the reference (never assigned, Chain.h:350-360): -1 here, so that it equals no other piece's.
+namespace {
+
+struct HSplitArgs {
+  uint64_t nJobs;
+  const uint64_t* jobOff; const uint64_t* linkOff; const uint8_t* link;
+  const int32_t* strand; const int32_t* chrom; const uint32_t* box; int splitdist;
+  uint32_t* nSplit; uint32_t* lsc; uint32_t* spLen; uint32_t* spIdx; uint8_t* spType; uint8_t* spStrand; uint32_t* spBox;
+  uint32_t* runA; uint32_t* runB; uint32_t* runNext; uint32_t* curInd; uint8_t* keepS; int32_t* spChrom; uint8_t* ty0; uint8_t* st0; uint32_t* bx0;
+};
+
+__global__ void __launch_bounds__(64) hsplit_kernel(HSplitArgs a) {
+  const uint64_t j = (uint64_t)blockIdx.x * 64 + threadIdx.x;
+  if (j >= a.nJobs) return;
+  const uint64_t base = a.jobOff[j];
+  const int n = (int)(a.jobOff[j + 1] - base);
+  a.nSplit[j] = 0; a.lsc[j] = 0;
+  if (n == 0) return;
+  const int32_t* St = a.strand + base; const int32_t* Ch = a.chrom + base; const uint32_t* B = a.box + 4 * base;
+  const uint8_t* Lk = a.link + a.linkOff[j];
+  uint32_t* runA = a.runA + base; uint32_t* runB = a.runB + base; uint32_t* runNext = a.runNext + base; uint32_t* curInd = a.curInd + base;
+  uint8_t* keepS = a.keepS + base; int32_t* spChrom = a.spChrom + base; uint8_t* ty = a.ty0 + base; uint8_t* sd = a.st0 + base; uint32_t* bx = a.bx0 + 4 * base;
+  auto ovl = [&](int x, int y) -> float {                                 // x->OverlaprateOnGenome(y)  Clustering.h:397-406
+    const uint32_t xs = B[4 * x + 2], xe = B[4 * x + 3], ys = B[4 * y + 2], ye = B[4 * y + 3];
+    if (xe <= ys || ye <= xs) return 0.f;
+    const int ovp = (int)(min(xe, ye) - max(xs, ys));
+    return __fdiv_rn((float)ovp, (float)(xe - xs));
+  };
+  int ns = 0, runStart = 0;
+  auto push = [&](int from, int to, char type, int chromIndex, int strand) {
+    runA[ns] = (uint32_t)from; runB[ns] = (uint32_t)to; runNext[ns] = NONE; ty[ns] = (uint8_t)type; spChrom[ns] = chromIndex; sd[ns] = (uint8_t)strand;
+    uint32_t qs = B[4 * from], qe = B[4 * from + 1], ts = B[4 * from + 2], te = B[4 * from + 3];
+    for (int v = from + 1; v < to; v++) { qs = min(qs, B[4 * v]); qe = max(qe, B[4 * v + 1]); ts = min(ts, B[4 * v + 2]); te = max(te, B[4 * v + 3]); }
+    bx[4 * ns] = qs; bx[4 * ns + 1] = qe; bx[4 * ns + 2] = ts; bx[4 * ns + 3] = te;
+    ns++;
+  };
+  for (int im = 0; im < n - 1; im++) {
+    const int cur = im + 1, prev = im;
+    const bool rep = ((Lk[im] == 1 && St[cur] == 0 && St[prev] == 0) || (Lk[im] == 0 && St[cur] == 1 && St[prev] == 1)) && (double)ovl(prev, cur) >= 0.6 &&
+                     (double)ovl(cur, prev) >= 0.6;
+    char type = 0;
+    if (B[4 * cur + 2] > B[4 * prev + 3] + (uint32_t)a.splitdist || B[4 * cur + 3] + (uint32_t)a.splitdist < B[4 * prev + 2] || Ch[cur] != Ch[prev]) type = 'T';
+    else if (rep) type = 'D';
+    else if ((St[cur] == 0 && St[prev] == 1) || (St[cur] == 1 && St[prev] == 0)) type = 'I';
+    if (type) { push(runStart, cur, type, Ch[cur], St[prev]); runStart = cur; }
+  }
+  push(runStart, n, 'N', -1, St[n - 1]);
+  for (int k = 0; k < ns; k++) keepS[k] = 1;
+  if (ns >= 3) {                                                          // MergeSplitchainINS :172-262
+    for (int k = 0; k < ns; k++) curInd[k] = (uint32_t)k;
+    int i0 = 0;
+    while (i0 + 3 <= ns) {
+      const int cc = (int)curInd[i0];
+      if (ty[cc] != 'T') { i0++; continue; }
+      int nn = (int)curInd[i0 + 2];
+      while (nn < ns) {
+        const long long cTS = bx[4 * cc + 2], nTE = bx[4 * nn + 3];
+        const long long tdist = cTS > nTE ? cTS - nTE : nTE - cTS;
+        if (tdist > 1500 || sd[cc] != sd[nn] || spChrom[cc] != spChrom[nn]) { nn++; continue; }
+        uint32_t tail = (uint32_t)cc;
+        while (runNext[tail] != NONE) tail = runNext[tail];
+        runNext[tail] = (uint32_t)nn;
+        bx[4 * cc] = min(bx[4 * cc], bx[4 * nn]); bx[4 * cc + 2] = min(bx[4 * cc + 2], bx[4 * nn + 2]);
+        bx[4 * cc + 1] = max(bx[4 * cc + 1], bx[4 * nn + 1]); bx[4 * cc + 3] = max(bx[4 * cc + 3], bx[4 * nn + 3]);
+        ty[cc] = ty[nn];
+        curInd[nn] = curInd[cc];
+        keepS[nn] = 0;
+        break;
+      }
+      i0 = nn;
+    }
+  }
+  uint32_t* spLen = a.spLen + base; uint32_t* spIdx = a.spIdx + base; uint8_t* spType = a.spType + base; uint8_t* spStrand = a.spStrand + base; uint32_t* spBox = a.spBox + 4 * base;
+  int outK = 0, o = 0, maxi = 0, maxi_d = 0;
+  for (int k = 0; k < ns; k++) {
+    if (!keepS[k]) continue;
+    const int beg = o;
+    for (uint32_t x = (uint32_t)k; x != NONE; x = runNext[x]) for (uint32_t v = runA[x]; v < runB[x]; v++) spIdx[o++] = v;
+    spLen[outK] = (uint32_t)(o - beg); spType[outK] = ty[k]; spStrand[outK] = sd[k];
+    const uint32_t qs = bx[4 * k], qe = bx[4 * k + 1];
+    spBox[4 * outK] = qs; spBox[4 * outK + 1] = qe; spBox[4 * outK + 2] = bx[4 * k + 2]; spBox[4 * outK + 3] = bx[4 * k + 3];
+    const int d = qe > qs ? (int)(qe - qs) : 0;                           // LargestSplitChain_dist
+    if (outK == 0) maxi_d = d; else if (d > maxi_d) { maxi = outK; maxi_d = d; }
+    outK++;
+  }
+  a.nSplit[j] = (uint32_t)outK; a.lsc[j] = (uint32_t)maxi;
+}
+
+// CSR of the pieces over all jobs: piece p of job j gets its length, attributes and the offset of its elements
+__global__ void hsplit_lay(uint64_t nJobs, const uint64_t* jobOff, const uint64_t* jobPieceOff, const uint32_t* spLen, const uint8_t* spType, const uint8_t* spStrand,
+                           const uint32_t* spBox, uint64_t* pieceOff, uint8_t* oType, uint8_t* oStrand, uint32_t* oBox, uint32_t* pieceJob, uint64_t nPieces, uint64_t nElems) {
+  const uint64_t j = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (j == 0) pieceOff[nPieces] = nElems;
+  if (j >= nJobs) return;
+  const uint64_t base = jobOff[j], p0 = jobPieceOff[j];
+  const int np = (int)(jobPieceOff[j + 1] - p0);
+  uint64_t o = base;
+  for (int k = 0; k < np; k++) {
+    pieceOff[p0 + k] = o; o += spLen[base + k]; oType[p0 + k] = spType[base + k]; oStrand[p0 + k] = spStrand[base + k]; pieceJob[p0 + k] = (uint32_t)j;
+    for (int x = 0; x < 4; x++) oBox[4 * (p0 + k) + x] = spBox[4 * (base + k) + x];
+  }
+}
+
+}  // namespace
+
+extern "C" int lra_split_chains_highacc_batch(lra_ctx* ctx, uint64_t n_jobs, const uint64_t* d_job_off, uint64_t n_elems, const int32_t* d_strand, const int32_t* d_chrom,
+                                              const uint32_t* d_box, const uint64_t* d_link_off, const uint8_t* d_link, int splitdist, lra_hsplit_result* out) {
+  if (!ctx || !out) return LRA_ERR_INVALID;
+  memset(out, 0, sizeof *out);
+  out->n_jobs = n_jobs;
+  if (n_jobs == 0) return LRA_OK;
+  LRA_HIP_CHECK(ctx, hipSetDevice(ctx->device));
+  hipStream_t st = ctx->stream;
+  const uint64_t NE = n_elems;
+  size_t need = sz(NE + 1, 4) * 8 + sz(NE + 1, 1) * 7 + sz(4 * NE + 4, 4) * 3 + sz(n_jobs + 2, 4) * 2 + sz(n_jobs + 2, 8) + sz(NE + 2, 8) + 4096;
+  char* w = (char*)lra_ensure(ctx, 93, need);
+  if (!w) return LRA_ERR_NOMEM;
+  auto take = [](char*& p, size_t n, size_t e) { char* r = p; p += sz(n, e); return r; };
+  HSplitArgs a;
+  a.nJobs = n_jobs; a.jobOff = d_job_off; a.linkOff = d_link_off; a.link = d_link; a.strand = d_strand; a.chrom = d_chrom; a.box = d_box; a.splitdist = splitdist;
+  a.nSplit = (uint32_t*)take(w, n_jobs + 2, 4); a.lsc = (uint32_t*)take(w, n_jobs + 2, 4);
+  uint64_t* jobPieceOff = (uint64_t*)take(w, n_jobs + 2, 8);
+  a.spLen = (uint32_t*)take(w, NE + 1, 4); a.spIdx = (uint32_t*)take(w, NE + 1, 4); a.runA = (uint32_t*)take(w, NE + 1, 4); a.runB = (uint32_t*)take(w, NE + 1, 4);
+  a.runNext = (uint32_t*)take(w, NE + 1, 4); a.curInd = (uint32_t*)take(w, NE + 1, 4); a.spChrom = (int32_t*)take(w, NE + 1, 4);
+  uint32_t* pieceJob = (uint32_t*)take(w, NE + 1, 4);
+  a.spType = (uint8_t*)take(w, NE + 1, 1); a.spStrand = (uint8_t*)take(w, NE + 1, 1); a.keepS = (uint8_t*)take(w, NE + 1, 1); a.ty0 = (uint8_t*)take(w, NE + 1, 1);
+  a.st0 = (uint8_t*)take(w, NE + 1, 1);
+  uint8_t* oType = (uint8_t*)take(w, NE + 1, 1); uint8_t* oStrand = (uint8_t*)take(w, NE + 1, 1);
+  a.spBox = (uint32_t*)take(w, 4 * NE + 4, 4); a.bx0 = (uint32_t*)take(w, 4 * NE + 4, 4);
+  uint32_t* oBox = (uint32_t*)take(w, 4 * NE + 4, 4);
+  uint64_t* pieceOff = (uint64_t*)take(w, NE + 2, 8);
+  lra_time_begin(ctx, "chain_split_highacc");
+  hipLaunchKernelGGL(hsplit_kernel, dim3((unsigned)((n_jobs + 63) / 64)), dim3(64), 0, st, a);
+  lra_time_end(ctx);
+  { int rc = lra_exclusive_scan<uint32_t>(ctx, (long)n_jobs, a.nSplit, jobPieceOff); if (rc) return rc; }
+  uint64_t nPieces = 0;
+  LRA_HIP_CHECK(ctx, hipMemcpyAsync(&nPieces, jobPieceOff + n_jobs, 8, hipMemcpyDeviceToHost, st));
+  LRA_HIP_CHECK(ctx, hipStreamSynchronize(st));
+  hipLaunchKernelGGL(hsplit_lay, dim3((unsigned)((n_jobs + 255) / 256)), dim3(256), 0, st, n_jobs, d_job_off, (const uint64_t*)jobPieceOff, (const uint32_t*)a.spLen,
+                     (const uint8_t*)a.spType, (const uint8_t*)a.spStrand, (const uint32_t*)a.spBox, pieceOff, oType, oStrand, oBox, pieceJob, nPieces, NE);
+  LRA_HIP_CHECK(ctx, hipStreamSynchronize(st));
+  LRA_HIP_CHECK(ctx, hipGetLastError());
+  out->n_pieces = nPieces; out->n_elems = NE; out->d_job_piece_off = jobPieceOff; out->d_piece_off = pieceOff; out->d_sptc = a.spIdx; out->d_piece_type = oType;
+  out->d_piece_strand = oStrand; out->d_piece_box = oBox; out->d_piece_job = pieceJob; out->d_job_lsc = a.lsc;
   return LRA_OK;
 }

@@ -349,3 +349,94 @@ extern "C" int oracle_filter_chain(int n, const uint32_t* q, const uint32_t* t, 
   for (size_t i = 0; i < lk.size(); i++) linkOut[i] = lk[i];
   return (int)ch.size();
 }
+
+// ---- the high-accuracy overload  SPLITChain(read, vector<Cluster_SameDiag*>& ExtendClusters, splitchains, link, opts)
+// (Mapping_ultility.h:266-346, called at Map_highacc.h:706) + MergeSplitchainINS (:172-262, bypassClustering == 0 on this path) +
+// LargestSplitChain_dist (Chain.h:974-985, Map_highacc.h:707).  Element v of the chain is a Cluster_SameDiag: strand, chromIndex, box
+// (qStart, qEnd, tStart, tEnd; t chromosome-relative); link = Primary_chains[p].chains[h].link.  OverlaprateOnGenome: Clustering.h:397-406.
+// The reference never sets chromIndex of the LAST piece (SplitChain's constructors leave it indeterminate, Chain.h:350-360; pieces pushed in the
+// loop get ExtendClusters[cur]->chromIndex, :291/:299/:308): it is restated as -1, a chromosome no other piece has.  PARITY UNPINNED.
+// Out: pieces as CSR over v (spOff, spIdx) in the pieces' final order, per piece type / Strand / box(QStart,QEnd,TStart,TEnd), *lsc.  Returns the piece count.
+extern "C" int oracle_split_chain_highacc(int n, const uint8_t* strand, const int* chrom, const uint32_t* box, const uint8_t* link, int splitdist, int* spOff,
+                                          int* spIdx, char* spType, uint8_t* spStrand, uint32_t* spBox, int* lsc) {
+  struct P { std::vector<int> sptc; uint32_t QS = 0, QE = 0, TS = 0, TE = 0; int chromIndex = -1; bool Strand = 0; char type = 'N'; };
+  std::vector<P> sp;
+  auto qS = [&](int i) { return box[4 * i]; }; auto qE = [&](int i) { return box[4 * i + 1]; };
+  auto tS = [&](int i) { return box[4 * i + 2]; }; auto tE = [&](int i) { return box[4 * i + 3]; };
+  auto ovl = [&](int a, int b) -> float {                                 // a->OverlaprateOnGenome(b)
+    if (tE(a) <= tS(b) || tE(b) <= tS(a)) return 0;
+    const int ovp = (int)(std::min(tE(a), tE(b)) - std::max(tS(a), tS(b)));
+    const float denomA = (float)(tE(a) - tS(a));
+    return ovp / denomA;
+  };
+  *lsc = 0; spOff[0] = 0;
+  if (n == 0) return 0;
+  std::vector<int> onec{0};
+  int im = 0, cur = 0, prev = 0;
+  auto cut = [&](char type) {
+    P p; p.sptc = onec; p.chromIndex = chrom[cur]; p.type = type; p.Strand = strand[prev];
+    sp.push_back(p); onec.clear(); onec.push_back(cur);
+  };
+  while (im < n - 1) {
+    cur = im + 1; prev = im;
+    bool rep_map = 0;
+    if (((link[im] == 1 && strand[cur] == 0 && strand[prev] == 0) || (link[im] == 0 && strand[cur] == 1 && strand[prev] == 1)) && ovl(prev, cur) >= 0.6 &&
+        ovl(cur, prev) >= 0.6)
+      rep_map = 1;
+    if (tS(cur) > tE(prev) + (uint32_t)splitdist || tE(cur) + (uint32_t)splitdist < tS(prev) || chrom[cur] != chrom[prev]) cut('T');
+    else if (rep_map) cut('D');
+    else if (strand[cur] != strand[prev]) cut('I');
+    else onec.push_back(cur);
+    im++;
+  }
+  if (!onec.empty()) { P p; p.sptc = onec; p.type = 'N'; p.Strand = strand[n - 1]; sp.push_back(p); }
+  for (auto& p : sp) {
+    p.QS = qS(p.sptc[0]); p.QE = qE(p.sptc[0]); p.TS = tS(p.sptc[0]); p.TE = tE(p.sptc[0]);
+    for (size_t k = 1; k < p.sptc.size(); k++) {
+      p.QS = std::min(p.QS, qS(p.sptc[k])); p.QE = std::max(p.QE, qE(p.sptc[k])); p.TS = std::min(p.TS, tS(p.sptc[k])); p.TE = std::max(p.TE, tE(p.sptc[k]));
+    }
+  }
+  if (sp.size() >= 3) {                                                    // MergeSplitchainINS :172-262
+    std::vector<int> cur_ind(sp.size());
+    std::iota(cur_ind.begin(), cur_ind.end(), 0);
+    std::vector<bool> keepS(sp.size(), true);
+    bool change = false;
+    size_t i0 = 0;
+    while (i0 + 3 <= sp.size()) {
+      const int c = cur_ind[i0];
+      if (sp[c].type != 'T') { i0++; continue; }
+      size_t nn = (size_t)cur_ind[i0 + 2];
+      while (nn < sp.size()) {
+        const long tdist = (sp[c].TS > sp[nn].TE) ? ((long)sp[c].TS - (long)sp[nn].TE) : ((long)sp[nn].TE - (long)sp[c].TS);
+        if (tdist > 1500 || sp[c].Strand != sp[nn].Strand || sp[c].chromIndex != sp[nn].chromIndex) { nn++; continue; }
+        change = true;
+        sp[c].sptc.insert(sp[c].sptc.end(), sp[nn].sptc.begin(), sp[nn].sptc.end());
+        sp[c].QS = std::min(sp[c].QS, sp[nn].QS); sp[c].TS = std::min(sp[c].TS, sp[nn].TS);
+        sp[c].QE = std::max(sp[c].QE, sp[nn].QE); sp[c].TE = std::max(sp[c].TE, sp[nn].TE);
+        sp[c].type = sp[nn].type;
+        cur_ind[nn] = cur_ind[c];
+        keepS[nn] = false;
+        break;
+      }
+      i0 = nn;
+    }
+    if (change) {
+      size_t r = 0;
+      for (size_t s = 0; s < sp.size(); s++) if (keepS[s]) { if (r != s) sp[r] = sp[s]; r++; }
+      sp.resize(r);
+    }
+  }
+  int o = 0;
+  for (size_t k = 0; k < sp.size(); k++) {
+    for (int v : sp[k].sptc) spIdx[o++] = v;
+    spOff[k + 1] = o; spType[k] = sp[k].type; spStrand[k] = sp[k].Strand;
+    spBox[4 * k] = sp[k].QS; spBox[4 * k + 1] = sp[k].QE; spBox[4 * k + 2] = sp[k].TS; spBox[4 * k + 3] = sp[k].TE;
+  }
+  int maxi = 0, maxi_d = sp[0].QE > sp[0].QS ? (int)(sp[0].QE - sp[0].QS) : 0;    // LargestSplitChain_dist
+  for (size_t mi = 1; mi < sp.size(); mi++) {
+    const int d = sp[mi].QE > sp[mi].QS ? (int)(sp[mi].QE - sp[mi].QS) : 0;
+    if (d > maxi_d) { maxi = (int)mi; maxi_d = d; }
+  }
+  *lsc = maxi;
+  return (int)sp.size();
+}

@@ -198,6 +198,19 @@ def refine_btwn_clusters_chains(match_off, mq, mt, box, strand, chrom, freq, cha
     return dict(off=oo, q=oq[:n].copy(), t=ot[:n].copy(), box=bx.reshape(-1, 4), freq=fr, refinespace=rs[:ncl])
 
 
+def split_chain_highacc(strand, chrom, box, link, splitdist=100000):
+    """High-accuracy SPLITChain + MergeSplitchainINS + LargestSplitChain_dist (Mapping_ultility.h:266-346) -> dict(off, idx, type, strand, box, lsc)"""
+    L = lib()
+    n = len(strand)
+    st = np.ascontiguousarray(strand, np.uint8); ch = np.ascontiguousarray(chrom, np.int32); bx = np.ascontiguousarray(box, np.uint32).reshape(-1)
+    lk = np.ascontiguousarray(np.concatenate([np.asarray(link, np.uint8), np.zeros(1, np.uint8)]))
+    off = np.zeros(n + 2, np.int32); idx = np.zeros(n + 1, np.int32); ty = np.zeros(n + 1, np.uint8); ss = np.zeros(n + 1, np.uint8); ob = np.zeros(4 * n + 4, np.uint32)
+    lsc = C.c_int(0)
+    k = L.oracle_split_chain_highacc(n, _p(st, C.c_uint8), _p(ch, C.c_int), _p(bx, C.c_uint32), _p(lk, C.c_uint8), int(splitdist), _p(off, C.c_int), _p(idx, C.c_int),
+                                     ty.ctypes.data_as(C.c_char_p), _p(ss, C.c_uint8), _p(ob, C.c_uint32), C.byref(lsc))
+    return dict(off=off[:k + 1], idx=idx[:off[k]], type=ty[:k], strand=ss[:k], box=ob[:4 * k].reshape(-1, 4), lsc=lsc.value)
+
+
 class FineOpts(C.Structure):
     _fields_ = [(n, C.c_int) for n in ("globalK", "RoughClustermaxGap", "maxDiag", "maxGap", "minClusterSize", "minUniqueStretchNum", "minUniqueStretchDist")]
 

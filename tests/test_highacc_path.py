@@ -275,3 +275,71 @@ def test_hip_refine_btwn_clusters_oracle(ctx, oracle, read_type):
             assert np.float32(nfreq[c0 + c]).view(np.uint32) == np.float32(exp["freq"][c]).view(np.uint32), (r, c)
             n_added += (eb - ea) - int(fc["match_off"][c0 + c + 1] - fc["match_off"][c0 + c]); n_ref += int(exp["refinespace"][c])
     assert int(res.n_pairs_added) == n_added and n_ref >= 3 and n_added >= 100 and int(res.n_rounds) >= 2, (int(res.n_pairs_added), n_added, n_ref, int(res.n_rounds))
+
+
+def _random_cluster_chains(rng, n_jobs):
+    """chains of merged clusters with every SPLITChain branch: far jumps, other chromosomes, inversions, duplicated target ranges, and the
+    A / insert / A' pattern MergeSplitchainINS joins."""
+    jobs = []
+    for j in range(n_jobs):
+        n = int(rng.integers(1, 14)) if j % 7 else int(rng.integers(1, 3))
+        strand = []; chrom = []; box = []; link = []
+        t = int(rng.integers(200000, 400000)); q = 100; st = int(rng.integers(0, 2)); ci = int(rng.integers(0, 3))
+        for v in range(n):
+            ln = int(rng.integers(200, 3000))
+            mode = rng.integers(0, 10)
+            if v and mode == 0: t += int(rng.integers(150000, 300000))
+            elif v and mode == 1: ci = (ci + 1) % 3
+            elif v and mode == 2: st ^= 1
+            elif v and mode == 3: t -= int(ln * rng.uniform(0.7, 1.0))             # repeated target range
+            elif v and mode == 4 and len(box) >= 2: t = box[-2][2] - ln - int(rng.integers(0, 1400)); ci = chrom[-2]; st = strand[-2]   # back next to the piece before the insert
+            strand.append(st); chrom.append(ci); box.append([q, q + ln, max(0, t), max(0, t) + ln])
+            q += ln + int(rng.integers(0, 50)); t = max(0, t) + ln + int(rng.integers(0, 60))
+            if v: link.append(int(rng.integers(0, 2)))
+        jobs.append((strand, chrom, box, link))
+    return jobs
+
+
+@pytest.mark.gpu
+def test_hip_split_chains_highacc_oracle(ctx, oracle):
+    """a9, high-accuracy SPLITChain: pieces, their order after MergeSplitchainINS, types, boxes and LSC for 400 random chains of merged clusters"""
+    import torch
+    from lra_amd import chain
+    rng = np.random.default_rng(23)
+    jobs = _random_cluster_chains(rng, 400)
+    dev = ctx.device
+    job_off = np.concatenate([[0], np.cumsum([len(j[0]) for j in jobs])]).astype(np.uint64)
+    link_off = np.concatenate([[0], np.cumsum([len(j[3]) for j in jobs])]).astype(np.uint64)
+    tt = lambda a, dt: torch.from_numpy(np.ascontiguousarray(a, dtype=dt)).to(dev)
+    cat = lambda k, dt: np.concatenate([np.asarray(j[k], dt).reshape(-1) for j in jobs] + [np.zeros(4, dt)])
+    res = chain.split_chains_highacc_batch(ctx, tt(job_off.astype(np.int64), np.int64), tt(cat(0, np.int32)[:-4], np.int32), tt(cat(1, np.int32), np.int32),
+                                           tt(cat(2, np.int64), np.int64).to(torch.int32), tt(link_off.astype(np.int64), np.int64), tt(cat(3, np.uint8), np.uint8))
+    out = chain.fetch_hsplit(ctx, res)
+    kinds = set(); merged = 0
+    for j, (strand, chrom, box, link) in enumerate(jobs):
+        exp = O.split_chain_highacc(strand, chrom, box, link)
+        p0, p1 = int(out["job_piece_off"][j]), int(out["job_piece_off"][j + 1])
+        assert p1 - p0 == len(exp["type"]), j
+        assert int(out["lsc"][j]) == exp["lsc"], j
+        for k in range(p1 - p0):
+            a, b = int(out["piece_off"][p0 + k]) - int(job_off[j]), int(out["piece_off"][p0 + k + 1]) - int(job_off[j])
+            got = out["sptc"][int(job_off[j]) + a:int(job_off[j]) + b].tolist(); want = exp["idx"][exp["off"][k]:exp["off"][k + 1]].tolist()
+            assert got == want, (j, k)
+            assert out["type"][p0 + k] == exp["type"][k] and out["strand"][p0 + k] == exp["strand"][k] and out["box"][p0 + k].tolist() == exp["box"][k].tolist(), (j, k)
+            assert int(out["job"][p0 + k]) == j
+            kinds.add(chr(int(exp["type"][k])))
+            merged += int(any(want[i + 1] != want[i] + 1 for i in range(len(want) - 1)))
+    assert kinds >= {"T", "D", "I", "N"} and merged >= 3, (kinds, merged)
+
+
+def test_oracle_split_chain_highacc_sanity(oracle):
+    """hand-made chains: an insert from another chromosome between two collinear pieces is bridged only when the far piece is not the chain's last one"""
+    # chains run from the read's end to its start: A, a far insert X, A' (continues A on the target), B far away
+    box = [[3000, 4000, 52000, 53000], [2500, 3000, 400000, 400500], [1500, 2500, 51000, 52000]]
+    r = O.split_chain_highacc([0, 0, 0], [0, 0, 0], box, [0, 0])
+    assert [chr(int(x)) for x in r["type"]] == ["T", "T", "N"] and r["idx"].tolist() == [0, 1, 2]     # A' is the last piece: chromIndex indeterminate, never bridged
+    box2 = box + [[0, 1000, 900000, 901000]]
+    r = O.split_chain_highacc([0, 0, 0, 0], [0, 0, 0, 0], box2, [0, 0, 0])
+    assert r["idx"].tolist() == [0, 2, 1, 3] and r["off"].tolist() == [0, 2, 3, 4] and r["lsc"] == 0 and [chr(int(x)) for x in r["type"]] == ["T", "T", "N"], r
+    r = O.split_chain_highacc([0, 1, 0], [0, 0, 0], [[0, 500, 1000, 1500], [500, 900, 1500, 1900], [900, 2000, 1900, 3000]], [0, 0])
+    assert [chr(int(x)) for x in r["type"]] == ["I", "I", "N"] and r["lsc"] == 2
