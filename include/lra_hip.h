@@ -39,6 +39,7 @@ typedef struct lra_ctx lra_ctx;
 #define LRA_ST_RANGE 4         /* problem too large for the 32-bit device score range   */
 #define LRA_ST_CAPACITY 8      /* caller-provided output capacity exceeded              */
 #define LRA_ST_REJECTED 16     /* the reference drops the item itself (e.g. a cluster spanning two chromosomes) */
+#define LRA_ST_UNSUPPORTED 32  /* the read takes a branch of the reference this library has not built (it gets no record) */
 
 /* ---- context ---------------------------------------------------------------------- */
 int lra_ctx_create(int device_id, lra_ctx** out);
@@ -379,6 +380,12 @@ typedef struct lra_filter_result {
 int lra_filter_chains_batch(lra_ctx* ctx, uint64_t n_chains, const uint64_t* d_off, uint64_t n_anchors, const uint32_t* d_q, const uint32_t* d_t,
                             const int32_t* d_len, const uint8_t* d_strand, const uint8_t* d_link, const int32_t* h_ops, int n_ops,
                             lra_filter_result* out);
+/* The same with the chain's qEnd(i) given explicitly (d_qend[i]; NULL = q + length): FinalChain::qEnd is Cluster_SameDiag::GetqEnd
+ * (Clustering.h:378-380), the merged entry's length added to its LAST anchor's read position; the high-accuracy LocalRefineAlignment
+ * (LocalRefineAlignment.h:567-571) filters such chains.                                                                              */
+int lra_filter_chains_ex_batch(lra_ctx* ctx, uint64_t n_chains, const uint64_t* d_off, uint64_t n_anchors, const uint32_t* d_q, const uint32_t* d_t,
+                               const int32_t* d_len, const uint32_t* d_qend, const uint8_t* d_strand, const uint8_t* d_link, const int32_t* h_ops, int n_ops,
+                               lra_filter_result* out);
 
 /* ---- a10: tier-2 (local) minimizer index and lookups ----------------------------------------
  * lra_local_index_batch replaces  LocalIndex::IndexSeq(char* seq, int seqLen)  (MMIndex.h:200-245) for
@@ -610,6 +617,17 @@ int lra_local_refine_batch(lra_ctx* ctx, uint64_t n_jobs, const uint64_t* d_job_
                            const int32_t* d_chain_n0, const int32_t* d_chain_n1, uint64_t n_anchors, const uint32_t* d_q, const uint32_t* d_t, const int32_t* d_len,
                            const uint64_t* d_read_off, const char* d_strands, uint64_t rc_base, const char* d_genome, const uint64_t* h_chrom_pos, int n_chrom,
                            const lra_lra_opts* opts, lra_alignments_result* out);
+
+/* The walk of the high-accuracy overload  LocalRefineAlignment(Primary_chains, splitchains, ExtendClusters, alignments, smallOpts, LookUpTable, read, strands,
+ * p, h, genome, LSC, tinyOpts, buff, svsigstrm, extend_clusters, false)  (LocalRefineAlignment.h:577-766, Map_highacc.h:708) behind its sparse DP, filters and
+ * SwitchToOriginalAnchors (:563-576): as lra_local_refine_batch, except that chain st of a job is splitchains[st] (pass empty chains for pieces whose
+ * ultimatechain is empty), a chain of one anchor still makes an alignment (:579), Supplymentary = (st != d_job_lsc[job]), d_chain_value /
+ * d_chain_n0 = Primary_chains[p].chains[h].value / NumOfAnchors0, d_chain_n1 = the chain's size.                                              */
+int lra_local_refine_highacc_batch(lra_ctx* ctx, uint64_t n_jobs, const uint64_t* d_job_chain_off, const uint32_t* d_job_read, const int32_t* d_job_h,
+                                   const uint32_t* d_job_lsc, uint64_t n_chains, const uint64_t* d_chain_anchor_off, const int32_t* d_chain_strand,
+                                   const int32_t* d_chain_chrom, const float* d_chain_value, const int32_t* d_chain_n0, const int32_t* d_chain_n1, uint64_t n_anchors,
+                                   const uint32_t* d_q, const uint32_t* d_t, const int32_t* d_len, const uint64_t* d_read_off, const char* d_strands, uint64_t rc_base,
+                                   const char* d_genome, const uint64_t* h_chrom_pos, int n_chrom, const lra_lra_opts* opts, lra_alignments_result* out);
 
 /* From the second sparse DP to lra_local_refine_batch (Map_lowacc.h:530-540, :575): `second` = lra_sparse_dp_batch in single-cluster mode over the
  * merged clusters of `merge`; its chains are filtered (RemovePairedIndels<UltimateChain>, RemoveSpuriousAnchors) and grouped per primary chain.
@@ -888,6 +906,7 @@ typedef struct lra_map_opts {
   float second_anchorbonus; int32_t bypassClustering, skipBandedRefine, refineBreakpoint;   /* refineBreakpoint: --refineBreakpoints (lra.cpp:262) */
   lra_clean_opts clean; lra_sdp_opts sdp;
   int32_t readType, hardClip, PrintNumAln, printFormat;   /* printFormat: 's' SAM, 'p' / 'P' PAF, 'b' BED, 'a' pairwise (PrintPairwise) */
+  lra_fine_opts fine; int32_t merge_dist;                 /* high-accuracy path only: MatchesToFineClusters, MergeMatchesSameDiag */
 } lra_map_opts;
 typedef struct lra_map_counters {
   uint64_t n_minimizers, n_matches, n_clusters, n_sdp_anchors, n_sdp_points, n_sdp_entries, n_local_tuples, n_local_tasks, n_local_task_words, n_local_pairs, n_refined_matches,
@@ -920,6 +939,17 @@ const char* lra_ctx_genome_ptr(lra_ctx* ctx);
 int lra_ctx_local_index(lra_ctx* ctx, lra_local_index_result* out, const uint64_t** d_seq_offsets);
 int lra_map_reads_lowacc_batch(lra_ctx* ctx, int n_reads, const char* d_seq, const uint64_t* d_read_off, uint64_t total_bases, const lra_map_opts* opts,
                                lra_map_result* out);
+/* The same boundary for the high-accuracy presets: MapRead_highacc (Map_highacc.h:37-798) behind MapRead (MapRead.h:169-239), which the reference enters
+ * when opts.bypassClustering == 0 (-CCS, -CONTIG).  Arguments and result as lra_map_reads_lowacc_batch; job j = read j / num_aln, chain h = j % num_aln of
+ * Primary_chains[0] (num_aln = opts.NumAln); d_job_reached[j] = the chain has clusters and got its SegAlignmentGroup (:697-699); d_first_sdp_value =
+ * Primary_chains[0].chains[h].value.  The counters of CalculateStatistics are what the reference's two calls (:721, :731) leave: tdel, tins and the six size
+ * classes accumulate over both.  Needs the genome, the chromosome table and the global index (no local index).  A -CCS read that takes the REFINEclusters
+ * branch (:413-447) comes back with LRA_ST_UNSUPPORTED in d_read_status.  lra_map_records / lra_map_snapshot / lra_map_pack serve both paths
+ * (opts.bypassClustering tells the record stage which tail to follow).                                                                          */
+void lra_map_opts_preset_ccs(lra_map_opts* opts);          /* -CCS: lra.cpp:306-340 */
+void lra_map_opts_preset_contig(lra_map_opts* opts);       /* -CONTIG: lra.cpp:268-305 */
+int lra_map_reads_highacc_batch(lra_ctx* ctx, int n_reads, const char* d_seq, const uint64_t* d_read_off, uint64_t total_bases, const lra_map_opts* opts,
+                                lra_map_result* out);
 int lra_map_records(lra_ctx* ctx, const lra_map_result* res, const lra_map_opts* opts, const char* const* names, const char* const* reads,
                     const char* const* quals, const int32_t* read_len, const char* const* chrom_names, const char* passthrough, char* out, uint64_t cap,
                     uint64_t* len, uint64_t* rec_off);

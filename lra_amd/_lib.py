@@ -77,6 +77,8 @@ SYMBOLS = {
     "lra_simple_mapqv": (C.c_int, [_vp, _vp, C.c_int, _vp, C.c_int, C.c_int, C.c_int, C.c_int]),
     "lra_output_read": (C.c_int, [_vp, _vp, C.c_int, _vp, C.c_int, C.c_char, C.c_int, C.c_char_p, C.c_int, _vp, _vp, C.c_uint64, _vp]),
     "lra_refine_clusters_batch": (C.c_int, [_vp, C.c_int] + [_vp] * 10 + [C.c_uint64, _vp, _vp, C.c_int, _vp, C.c_uint64, _vp, _vp, _vp, _vp, _vp]),
+    "lra_local_refine_highacc_batch": (C.c_int, [_vp, C.c_uint64, _vp, _vp, _vp, _vp, C.c_uint64, _vp, _vp, _vp, _vp, _vp, _vp, C.c_uint64, _vp, _vp, _vp, _vp, _vp, C.c_uint64,
+                                                 _vp, _vp, C.c_int, _vp, _vp]),
     "lra_local_refine_batch": (C.c_int, [_vp, C.c_uint64, _vp, _vp, _vp, C.c_uint64, _vp, _vp, _vp, _vp, _vp, _vp, C.c_uint64, _vp, _vp, _vp, _vp, _vp, C.c_uint64, _vp, _vp,
                                          C.c_int, _vp, _vp]),
     "lra_local_refine_inputs_batch": (C.c_int, [_vp, C.c_int, _vp, _vp, _vp, _vp]),
@@ -86,10 +88,13 @@ SYMBOLS = {
     "lra_merge_same_diag_batch": (C.c_int, [_vp, C.c_uint64, _vp, _vp, _vp, _vp, _vp, _vp, C.c_int, _vp]),
     "lra_switchindex_batch": (C.c_int, [_vp, C.c_uint64] + [_vp] * 9 + [C.c_uint64, _vp]),
     "lra_map_opts_preset_ont": (None, [_vp]),
+    "lra_map_opts_preset_ccs": (None, [_vp]),
+    "lra_map_opts_preset_contig": (None, [_vp]),
     "lra_map_opts_preset_clr": (None, [_vp]),
     "lra_ctx_load_chromosomes": (C.c_int, [_vp, _vp, C.c_int]),
     "lra_ctx_build_local_index": (C.c_int, [_vp, C.c_int, C.c_int, C.c_int, C.c_int]),
     "lra_map_reads_lowacc_batch": (C.c_int, [_vp, C.c_int, _vp, _vp, C.c_uint64, _vp, _vp]),
+    "lra_map_reads_highacc_batch": (C.c_int, [_vp, C.c_int, _vp, _vp, C.c_uint64, _vp, _vp]),
     "lra_ctx_genome_ptr": (_vp, [_vp]),
     "lra_ctx_share_reference": (C.c_int, [_vp, _vp]),
     "lra_ctx_local_index": (C.c_int, [_vp, _vp, _vp]),
@@ -100,6 +105,7 @@ SYMBOLS = {
     "lra_map_unpack_host": (C.c_int, [_vp, C.c_uint64, _vp]),
     "lra_map_records": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, C.c_char_p, _vp, C.c_uint64, _vp, _vp]),
     "lra_filter_chains_batch": (C.c_int, [_vp, C.c_uint64, _vp, C.c_uint64, _vp, _vp, _vp, _vp, _vp, _vp, C.c_int, _vp]),
+    "lra_filter_chains_ex_batch": (C.c_int, [_vp, C.c_uint64, _vp, C.c_uint64, _vp, _vp, _vp, _vp, _vp, _vp, _vp, C.c_int, _vp]),
     "lra_calculate_statistics_batch": (C.c_int, [_vp, C.c_int, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, C.c_int, _vp]),
     "lra_local_index_batch": (C.c_int, [_vp, C.c_int, _vp, _vp, C.c_int, C.c_int, C.c_int, C.c_int, _vp]),
     "lra_local_index_masked_batch": (C.c_int, [_vp, C.c_int, _vp, _vp, _vp, C.c_int, C.c_int, C.c_int, C.c_int, _vp]),

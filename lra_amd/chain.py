@@ -93,13 +93,14 @@ class FilterResult(C.Structure):
                 ("d_n_link", C.c_void_p)]
 
 
-def filter_chains_batch(ctx: Context, n_chains, off, n_anchors, q, t, length, strand, link, ops):
+def filter_chains_batch(ctx: Context, n_chains, off, n_anchors, q, t, length, strand, link, ops, qend=None):
     """Chain.h filters (ops: 1 RemoveSmallPairedIndels, 2/3 RemovePairedIndels with/without refineEnds, 4 RemoveSpuriousAnchors,
     8 RemoveSpuriousJump) on CSR chains; array arguments are device tensors, link may be None."""
     o = np.ascontiguousarray(ops, dtype=np.int32)
     res = FilterResult()
-    ctx.check(ctx.lib.lra_filter_chains_batch(ctx.h, C.c_uint64(n_chains), ptr(off), C.c_uint64(n_anchors), ptr(q), ptr(t), ptr(length), ptr(strand),
-                                              ptr(link) if link is not None else None, C.c_void_p(o.ctypes.data), len(o), C.byref(res)))
+    ctx.check(ctx.lib.lra_filter_chains_ex_batch(ctx.h, C.c_uint64(n_chains), ptr(off), C.c_uint64(n_anchors), ptr(q), ptr(t), ptr(length),
+                                                 ptr(qend) if qend is not None else None, ptr(strand), ptr(link) if link is not None else None,
+                                                 C.c_void_p(o.ctypes.data), len(o), C.byref(res)))
     return res
 
 

@@ -216,7 +216,7 @@ __global__ void __launch_bounds__(64) split_kernel(SplitArgs a) {
 // refineEnds = false), RemoveSpuriousAnchors :828 (op 4, leaves `link` alone), RemoveSpuriousJump :897 (op 8), in the order given.
 // One lane per chain; every filter is two streaming passes (the reference's SV list is only ever compared with its previous entry).
 struct FilterArgs {
-  uint64_t n; const uint64_t* off; const uint32_t* q; const uint32_t* t; const int32_t* len; const uint8_t* strand; const uint8_t* link;
+  uint64_t n; const uint64_t* off; const uint32_t* q; const uint32_t* t; const int32_t* len; const uint8_t* strand; const uint8_t* link; const uint32_t* qend;
   int ops[8]; int nOps;
   uint8_t* keep; uint32_t* nKept; uint8_t* linkOut; uint32_t* nLink; uint32_t* idx; uint8_t* rm;
 };
@@ -227,6 +227,7 @@ __global__ void __launch_bounds__(64) filter_kernel(FilterArgs a) {
   const uint64_t base = a.off[c0];
   const int n = (int)(a.off[c0 + 1] - base);
   const uint32_t* Q = a.q + base; const uint32_t* T = a.t + base; const int32_t* Ln = a.len + base; const uint8_t* St = a.strand + base;
+  const uint32_t* QE = a.qend ? a.qend + base : nullptr;   // FinalChain::qEnd is not qStart + length (Clustering.h:378-380)
   uint8_t* keep = a.keep + base; uint8_t* lk = a.linkOut + base; uint32_t* idx = a.idx + base; uint8_t* rm = a.rm + base;
   int N = n;
   int nl = (a.link && n > 0) ? n - 1 : 0;
@@ -237,7 +238,7 @@ __global__ void __launch_bounds__(64) filter_kernel(FilterArgs a) {
 #define XT(i) T[idx[i]]
 #define XL(i) Ln[idx[i]]
 #define XS(i) St[idx[i]]
-#define XQE(i) (Q[idx[i]] + (uint32_t)Ln[idx[i]])
+#define XQE(i) (QE ? QE[idx[i]] : Q[idx[i]] + (uint32_t)Ln[idx[i]])
 #define XTE(i) (T[idx[i]] + (uint32_t)Ln[idx[i]])
   for (int oi = 0; oi < a.nOps; oi++) {
     const int op = a.ops[oi];
@@ -386,9 +387,17 @@ extern "C" int lra_split_chains_batch(lra_ctx* ctx, const lra_chain_result* ch, 
   return LRA_OK;
 }
 
+extern "C" int lra_filter_chains_ex_batch(lra_ctx* ctx, uint64_t n_chains, const uint64_t* d_off, uint64_t n_anchors, const uint32_t* d_q, const uint32_t* d_t,
+                                          const int32_t* d_len, const uint32_t* d_qend, const uint8_t* d_strand, const uint8_t* d_link, const int32_t* h_ops, int n_ops,
+                                          lra_filter_result* out);
 extern "C" int lra_filter_chains_batch(lra_ctx* ctx, uint64_t n_chains, const uint64_t* d_off, uint64_t n_anchors, const uint32_t* d_q, const uint32_t* d_t,
                                        const int32_t* d_len, const uint8_t* d_strand, const uint8_t* d_link, const int32_t* h_ops, int n_ops,
                                        lra_filter_result* out) {
+  return lra_filter_chains_ex_batch(ctx, n_chains, d_off, n_anchors, d_q, d_t, d_len, nullptr, d_strand, d_link, h_ops, n_ops, out);
+}
+extern "C" int lra_filter_chains_ex_batch(lra_ctx* ctx, uint64_t n_chains, const uint64_t* d_off, uint64_t n_anchors, const uint32_t* d_q, const uint32_t* d_t,
+                                          const int32_t* d_len, const uint32_t* d_qend, const uint8_t* d_strand, const uint8_t* d_link, const int32_t* h_ops, int n_ops,
+                                          lra_filter_result* out) {
   if (!ctx || !out || !h_ops || n_ops < 0 || n_ops > 8) return LRA_ERR_INVALID;
   for (int i = 0; i < n_ops; i++) if (h_ops[i] != 1 && h_ops[i] != 2 && h_ops[i] != 3 && h_ops[i] != 4 && h_ops[i] != 5 && h_ops[i] != 8) return lra_set_err(ctx, LRA_ERR_INVALID, "unknown chain filter %d", h_ops[i]);
   memset(out, 0, sizeof *out);
@@ -400,7 +409,7 @@ extern "C" int lra_filter_chains_batch(lra_ctx* ctx, uint64_t n_chains, const ui
   char* w = (char*)lra_ensure(ctx, 13, sz(n_anchors + 1, 1) * 3 + sz(n_anchors + 1, 4) + sz(n_chains + 1, 4) * 2 + 4096);
   if (!w) return LRA_ERR_NOMEM;
   FilterArgs a;
-  a.n = n_chains; a.off = d_off; a.q = d_q; a.t = d_t; a.len = d_len; a.strand = d_strand; a.link = d_link; a.nOps = n_ops;
+  a.n = n_chains; a.off = d_off; a.q = d_q; a.t = d_t; a.len = d_len; a.strand = d_strand; a.link = d_link; a.qend = d_qend; a.nOps = n_ops;
   for (int i = 0; i < 8; i++) a.ops[i] = i < n_ops ? h_ops[i] : 0;
   a.keep = (uint8_t*)take(w, n_anchors + 1, 1); a.linkOut = (uint8_t*)take(w, n_anchors + 1, 1); a.rm = (uint8_t*)take(w, n_anchors + 1, 1);
   a.idx = (uint32_t*)take(w, n_anchors + 1, 4); a.nKept = (uint32_t*)take(w, n_chains + 1, 4); a.nLink = (uint32_t*)take(w, n_chains + 1, 4);

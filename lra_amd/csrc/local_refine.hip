@@ -36,6 +36,7 @@ struct LrArgs {
   const uint32_t* AQ; const uint32_t* AT; const int32_t* AL;
   const uint64_t* read_off; uint64_t rcBase; const uint64_t* pos;
   lra_lra_opts o;
+  const uint32_t* jobLSC; int minAnchors;   // high-accuracy overload (:552): LSC given by the caller, chains of one anchor are walked too
   // per chain / anchor
   uint32_t* chainJob; uint32_t* anchChain;
   uint8_t* type; uint32_t* cre; uint32_t* nrs; uint32_t* cge; uint32_t* ngs; uint32_t* isDir; uint32_t* isBig; const uint64_t* dirId; const uint64_t* bigId;
@@ -337,7 +338,8 @@ __global__ void lr_walk(LrArgs a) {
   const uint32_t L = (uint32_t)(a.read_off[r + 1] - a.read_off[r]);
   const int h = a.jobH[job];
   uint64_t LSC = 0;                                                       // LargestSplitChain Chain.h:963-971
-  for (uint64_t c = c0 + 1; c < c1; c++) if (a.aOff[c + 1] - a.aOff[c] > a.aOff[c0 + LSC + 1] - a.aOff[c0 + LSC]) LSC = c - c0;
+  if (a.jobLSC) LSC = a.jobLSC[job];
+  else for (uint64_t c = c0 + 1; c < c1; c++) if (a.aOff[c + 1] - a.aOff[c] > a.aOff[c0 + LSC + 1] - a.aOff[c0 + LSC]) LSC = c - c0;
   uint32_t nAln = 0; uint64_t nBlk = 0;
   uint64_t ai = PASS ? a.alnOff[job] : 0, bi = PASS ? a.blkOff[job] : 0;   // next alignment / block slot
   uint64_t curBlocks = 0;                                                 // blocks of the alignment being built
@@ -363,7 +365,7 @@ __global__ void lr_walk(LrArgs a) {
   for (uint64_t c = c0; c < c1; c++) {
     const uint64_t a0 = a.aOff[c];
     const int m = (int)(a.aOff[c + 1] - a0);
-    if (m <= 1) continue;
+    if (m < a.minAnchors) continue;
     const int str = a.cStrand[c] != 0, inv_str = !str, chrom = a.cChrom[c];
     const int n0 = a.cN0[c];
     const float val = a.cValue[c];
@@ -422,11 +424,38 @@ struct Carver {
 
 }  // namespace
 
+static int local_refine_impl(lra_ctx* ctx, uint64_t n_jobs, const uint64_t* d_job_chain_off, const uint32_t* d_job_read, const int32_t* d_job_h,
+                             uint64_t n_chains, const uint64_t* d_chain_anchor_off, const int32_t* d_chain_strand, const int32_t* d_chain_chrom,
+                             const float* d_chain_value, const int32_t* d_chain_n0, const int32_t* d_chain_n1, uint64_t n_anchors, const uint32_t* d_q,
+                             const uint32_t* d_t, const int32_t* d_len, const uint64_t* d_read_off, const char* d_strands, uint64_t rc_base,
+                             const char* d_genome, const uint64_t* h_chrom_pos, int n_chrom, const lra_lra_opts* opts, const uint32_t* d_job_lsc, int min_anchors,
+                             lra_alignments_result* out);
 extern "C" int lra_local_refine_batch(lra_ctx* ctx, uint64_t n_jobs, const uint64_t* d_job_chain_off, const uint32_t* d_job_read, const int32_t* d_job_h,
                                       uint64_t n_chains, const uint64_t* d_chain_anchor_off, const int32_t* d_chain_strand, const int32_t* d_chain_chrom,
                                       const float* d_chain_value, const int32_t* d_chain_n0, const int32_t* d_chain_n1, uint64_t n_anchors, const uint32_t* d_q,
                                       const uint32_t* d_t, const int32_t* d_len, const uint64_t* d_read_off, const char* d_strands, uint64_t rc_base,
                                       const char* d_genome, const uint64_t* h_chrom_pos, int n_chrom, const lra_lra_opts* opts, lra_alignments_result* out) {
+  return local_refine_impl(ctx, n_jobs, d_job_chain_off, d_job_read, d_job_h, n_chains, d_chain_anchor_off, d_chain_strand, d_chain_chrom, d_chain_value, d_chain_n0,
+                           d_chain_n1, n_anchors, d_q, d_t, d_len, d_read_off, d_strands, rc_base, d_genome, h_chrom_pos, n_chrom, opts, nullptr, 2, out);
+}
+// The walk of the high-accuracy overload (LocalRefineAlignment.h:577-766): the same, except that a chain of ONE anchor still makes an alignment
+// (`if (ultimatechain.size() == 0) continue`, :579), and Supplymentary is `st != LSC` with the caller's LSC = LargestSplitChain_dist (Map_highacc.h:707).
+extern "C" int lra_local_refine_highacc_batch(lra_ctx* ctx, uint64_t n_jobs, const uint64_t* d_job_chain_off, const uint32_t* d_job_read, const int32_t* d_job_h,
+                                              const uint32_t* d_job_lsc, uint64_t n_chains, const uint64_t* d_chain_anchor_off, const int32_t* d_chain_strand,
+                                              const int32_t* d_chain_chrom, const float* d_chain_value, const int32_t* d_chain_n0, const int32_t* d_chain_n1,
+                                              uint64_t n_anchors, const uint32_t* d_q, const uint32_t* d_t, const int32_t* d_len, const uint64_t* d_read_off,
+                                              const char* d_strands, uint64_t rc_base, const char* d_genome, const uint64_t* h_chrom_pos, int n_chrom,
+                                              const lra_lra_opts* opts, lra_alignments_result* out) {
+  if (!d_job_lsc) return LRA_ERR_INVALID;
+  return local_refine_impl(ctx, n_jobs, d_job_chain_off, d_job_read, d_job_h, n_chains, d_chain_anchor_off, d_chain_strand, d_chain_chrom, d_chain_value, d_chain_n0,
+                           d_chain_n1, n_anchors, d_q, d_t, d_len, d_read_off, d_strands, rc_base, d_genome, h_chrom_pos, n_chrom, opts, d_job_lsc, 1, out);
+}
+static int local_refine_impl(lra_ctx* ctx, uint64_t n_jobs, const uint64_t* d_job_chain_off, const uint32_t* d_job_read, const int32_t* d_job_h,
+                             uint64_t n_chains, const uint64_t* d_chain_anchor_off, const int32_t* d_chain_strand, const int32_t* d_chain_chrom,
+                             const float* d_chain_value, const int32_t* d_chain_n0, const int32_t* d_chain_n1, uint64_t n_anchors, const uint32_t* d_q,
+                             const uint32_t* d_t, const int32_t* d_len, const uint64_t* d_read_off, const char* d_strands, uint64_t rc_base,
+                             const char* d_genome, const uint64_t* h_chrom_pos, int n_chrom, const lra_lra_opts* opts, const uint32_t* d_job_lsc, int min_anchors,
+                             lra_alignments_result* out) {
   if (!ctx || !out || !opts || !h_chrom_pos || n_chrom < 1) return LRA_ERR_INVALID;
   memset(out, 0, sizeof *out);
   out->n_jobs = n_jobs;
@@ -440,7 +469,7 @@ extern "C" int lra_local_refine_batch(lra_ctx* ctx, uint64_t n_jobs, const uint6
   memset(&a, 0, sizeof a);
   a.nJobs = NJ0; a.nChains = NC; a.nAnch = NA; a.jobChainOff = d_job_chain_off; a.jobRead = d_job_read; a.jobH = d_job_h; a.aOff = d_chain_anchor_off;
   a.cStrand = d_chain_strand; a.cChrom = d_chain_chrom; a.cValue = d_chain_value; a.cN0 = d_chain_n0; a.cN1 = d_chain_n1; a.AQ = d_q; a.AT = d_t; a.AL = d_len;
-  a.read_off = d_read_off; a.rcBase = rc_base; a.o = *opts;
+  a.read_off = d_read_off; a.rcBase = rc_base; a.o = *opts; a.jobLSC = d_job_lsc; a.minAnchors = min_anchors;
   // ---- per chain / anchor state
   char* w0 = (char*)lra_ensure(ctx, 40, sz(npos, 8) + sz(NC + 1, 4) + sz(NA + 1, 4) * 7 + sz(NA + 1, 1) + sz(NA + 2, 8) * 2 + sz(NJ0 + 2, 4) * 3 + sz(NJ0 + 2, 8) * 2 + 4096);
   if (!w0) return LRA_ERR_NOMEM;

@@ -11,27 +11,11 @@
 #include "common.h"
 #include "seed_state.h"
 #include "scan.h"
+#include "map_state.h"
 #include <math.h>
 #include <stdlib.h>
 #include <algorithm>
 #include <thread>
-
-struct lra_map_sig {                             // what a text of lra_map_records was made from
-  const void* blocks = nullptr; const void* runs = nullptr; int32_t n_reads = 0; uint64_t n_aln = 0; int32_t fmt = 0, pna = 0, hard = 0; const char* pass = nullptr;
-  bool operator==(const lra_map_sig& o) const {
-    return blocks == o.blocks && runs == o.runs && n_reads == o.n_reads && n_aln == o.n_aln && fmt == o.fmt && pna == o.pna && hard == o.hard && pass == o.pass;
-  }
-};
-struct lra_map_state {
-  std::vector<uint64_t> chrom_pos;                 // Genome::header.pos, n_chrom + 1 entries
-  uint64_t* d_chrom_pos = nullptr;
-  void* gli_buf = nullptr; lra_local_index_result gli{};   // the genome's LocalIndex (the .gli payload), built on the device
-  uint64_t* d_gso = nullptr; uint64_t n_gwin = 0;  // its seqOffsets
-  int gli_window = 0;
-  bool borrowed = false;                           // reference data shared from another context (lra_ctx_share_reference): not freed here
-  std::vector<float> lut;                          // LogLookUpTable.h:9-15
-  std::string last_text; std::vector<uint64_t> last_off; lra_map_sig last_sig;   // lra_map_records: sizing call -> filling call
-};
 
 void lra_map_free(lra_ctx* ctx) {
   lra_map_state* m = ctx->map;
@@ -294,7 +278,7 @@ extern "C" int lra_ctx_local_index(lra_ctx* ctx, lra_local_index_result* out, co
 
 // RefineBreakpoint(read, genome, *SegAlignment[s], *SegAlignment[s-1], opts) for s = 1, 2, ... of every job: round k runs junction k of all
 // jobs that have one (segment k is "left", segment k - 1 -- already refined against k - 2 in the round before -- is "right").
-static int refine_breakpoints(lra_ctx* ctx, uint64_t nJ, uint64_t nA, const uint64_t* d_job_aln_off, const int32_t* d_strand, const uint64_t* q_off, const int32_t* q_len,
+int lra_refine_breakpoints(lra_ctx* ctx, uint64_t nJ, uint64_t nA, const uint64_t* d_job_aln_off, const int32_t* d_strand, const uint64_t* q_off, const int32_t* q_len,
                               const uint64_t* t_off, const int64_t* t_len, const char* strands, const char* genome, lra_refine_result* fres) {
   hipStream_t st = ctx->stream;
   std::vector<uint64_t> jo(nJ + 1);
@@ -500,7 +484,7 @@ extern "C" int lra_map_reads_lowacc_batch(lra_ctx* ctx, int n_reads, const char*
       fres.d_status = keep;
       hipLaunchKernelGGL(k_or_status_idx, grid(nA), dim3(256), 0, st, nA, (const uint32_t*)keep, aln_read, 1, read_status);
     }
-    if (o->refineBreakpoint && (rc = refine_breakpoints(ctx, nJ, nA, ares.d_job_aln_off, ares.d_strand, q_off, q_len, t_off, t_len, both, genome, &fres))) return rc;
+    if (o->refineBreakpoint && (rc = lra_refine_breakpoints(ctx, nJ, nA, ares.d_job_aln_off, ares.d_strand, q_off, q_len, t_off, t_len, both, genome, &fres))) return rc;
     if ((rc = lra_calculate_statistics_batch(ctx, (int)nA, fres.d_blocks, fres.d_block_off, both, q_off, q_len, genome, t_off, m->lut.data(), (int)m->lut.size(), &tres)))
       return rc;
   }
@@ -681,6 +665,7 @@ extern "C" int lra_map_records_host(lra_map_host* h, const lra_map_opts* o, cons
   const std::vector<int32_t>&strand = h->strand, &supp = h->supp, &sec = h->sec, &n0 = h->n0, &n1 = h->n1, &chrom = h->chrom, &counts = h->counts, &blocks = h->blocks;
   const std::vector<float>& fval = h->fval; const std::vector<uint32_t>&runs = h->runs, &rstat = h->rstat, &ends = h->ends; const std::vector<uint8_t>& reached = h->reached;
   const bool pairwise = o->printFormat == 'a';
+  const bool hi = !o->bypassClustering;                                   // MapRead_highacc's tail (Map_highacc.h:733-789)
   if (pairwise && h->segText.size() != h->nA) return LRA_ERR_INVALID;
   // every read is independent: host threads take contiguous ranges of reads, each builds its own text; ranges are joined in read order
   const int n_reads = h->n_reads;
@@ -704,7 +689,10 @@ extern "C" int lra_map_records_host(lra_map_host* h, const lra_map_opts* o, cons
     for (int r = lo; r < hi; r++) {
       recs.clear(); cigars.clear(); seg_off.assign(1, 0); rcRead.clear();
       if (!rstat.empty() && rstat[r]) { plen[tix].push_back(0); continue; }   // flagged read: no record (the caller routes it elsewhere; d_read_status)
-      const bool unaligned = nJ == 0 || jo[(size_t)r * na + 1] == jo[(size_t)r * na];     // p == 0 left no SegAlignment (Map_lowacc.h:578-581)
+      // low-accuracy path: p == 0 left no SegAlignment (Map_lowacc.h:578-581); high-accuracy path: read.unaligned or alignments.size() == 0
+      // (Map_highacc.h:778-781) = no chain of the read got its SegAlignmentGroup
+      bool unaligned = nJ == 0 || jo[(size_t)r * na + 1] == jo[(size_t)r * na];
+      if (hi && nJ) { unaligned = true; for (int p = 0; p < na; p++) if (!reached.empty() && reached[(size_t)r * na + p]) unaligned = false; }
       if (!unaligned) {
         size_t total = 0;
         for (int p = 0; p < na; p++) total += (size_t)(jo[(size_t)r * na + p + 1] - jo[(size_t)r * na + p]);
@@ -712,7 +700,8 @@ extern "C" int lra_map_records_host(lra_map_host* h, const lra_map_opts* o, cons
         for (int p = 0; p < na; p++) {
           const size_t j = (size_t)r * na + p;
           // a chain that never reaches :574 ends the loop over p (:267, :491); one that does keeps its (possibly empty) group (:574-600)
-          if (!reached.empty() ? !reached[j] : jo[j + 1] == jo[j]) break;
+          // (on the high-accuracy path a chain without clusters is skipped, Map_highacc.h:697, and the loop goes on)
+          if (!reached.empty() ? !reached[j] : jo[j + 1] == jo[j]) { if (hi) continue; break; }
           for (uint64_t a = jo[j]; a < jo[j + 1]; a++) {
             std::string cg;
             cg.reserve((size_t)(roff[a + 1] - roff[a]) * 4 + 8);
@@ -757,7 +746,8 @@ extern "C" int lra_map_records_host(lra_map_host* h, const lra_map_opts* o, cons
         }
       }
       uint64_t need = 0;
-      if (unaligned || recs.empty()) {
+      if (hi && !unaligned && recs.empty()) need = 0;                     // OUTPUT prints nothing: groups exist, the first has no segment, read.unaligned == 0 (Mapping_ultility.h:467-492)
+      else if (unaligned || recs.empty()) {
         lra_aln_record un; memset(&un, 0, sizeof un);
         un.read_name = names[r]; un.read = reads[r]; un.qual = quals ? quals[r] : nullptr; un.read_len = read_len[r];
         lra_output_read(nullptr, nullptr, 0, nullptr, o->PrintNumAln, (char)o->printFormat, o->hardClip, passthrough, 1, &un, nullptr, 0, &need);
@@ -768,7 +758,7 @@ extern "C" int lra_map_records_host(lra_map_host* h, const lra_map_opts* o, cons
         groups.assign(n, lra_aln_group()); index.assign(n, 0);
         if ((rc = lra_group_alignments(recs.data(), seg_off.data(), n, groups.data())) || (rc = lra_order_alignments(groups.data(), n, recs.data(), index.data(), 0)) ||
             (rc = lra_simple_mapqv(groups.data(), index.data(), n, recs.data(), o->bypassClustering, o->readType == LRA_READ_CLR, o->readType == LRA_READ_ONT,
-                                   o->localK)))                         // SimpleMapQV(alignmentsOrder, read, smallOpts): smallOpts.globalK = glIndex.k (Map_lowacc.h:233, :610)
+                                   hi ? o->globalK : o->localK)))                         // SimpleMapQV(alignmentsOrder, read, smallOpts): smallOpts.globalK = glIndex.k (Map_lowacc.h:233, :610); = opts.globalK on the high-accuracy path (Map_highacc.h:402, :736)
           break;
         lra_output_read(groups.data(), index.data(), n, recs.data(), o->PrintNumAln, (char)o->printFormat, o->hardClip, passthrough, 0, nullptr, nullptr, 0, &need);
         buf.resize(need + 1);

@@ -96,7 +96,7 @@ class MapOpts(C.Structure):
                                           "localMatch", "localMismatch", "localIndel", "localBand", "refineSpaceDist")] +
                 [("anchorstoosparse", C.c_float), ("splitdist", C.c_int32), ("window", C.c_int32), ("second_anchorbonus", C.c_float),
                  ("bypassClustering", C.c_int32), ("skipBandedRefine", C.c_int32), ("refineBreakpoint", C.c_int32), ("clean", cluster.CleanOpts), ("sdp", chain.SdpOpts)] +
-                [(n, C.c_int32) for n in ("readType", "hardClip", "PrintNumAln", "printFormat")])
+                [(n, C.c_int32) for n in ("readType", "hardClip", "PrintNumAln", "printFormat")] + [("fine", cluster.FineOpts), ("merge_dist", C.c_int32)])
 
 
 class MapCounters(C.Structure):
@@ -437,3 +437,52 @@ class LowAccMapper:
         names = (C.c_char_p * len(self.chrom_names))(*self.chrom_names)
         pos = (C.c_uint64 * len(self.chrom_pos))(*self.chrom_pos)
         return emit._call("lra_format_sam_header", version, command_line, names, pos, len(self.chrom_names))
+
+
+class HighAccMapper:
+    """MapRead_highacc behind the C boundary (lra_map_reads_highacc_batch): the -CCS / -CONTIG presets.  Reference data as LowAccMapper (the global index is
+    built on the device from index_params = (K, W, globalMaxFreq, globalWinsize, NumOfminimizersPerWindow) when idx_key is None); no local index."""
+
+    def __init__(self, ctx: Context, genome, idx_key, idx_pos, chrom_names, chrom_pos, preset="ccs", index_params=None, **overrides):
+        from . import index as _index
+        self.ctx = ctx
+        g = genome if torch.is_tensor(genome) else torch.from_numpy(np.ascontiguousarray(genome, dtype=np.uint8))
+        self.G = int(g.numel())
+        self.chrom_pos = [int(x) for x in chrom_pos]
+        self.chrom_names = [n if isinstance(n, bytes) else str(n).encode() for n in chrom_names]
+        m = MapOpts()
+        (ctx.lib.lra_map_opts_preset_contig if preset == "contig" else ctx.lib.lra_map_opts_preset_ccs)(C.byref(m))
+        for k, v in overrides.items():
+            obj = m
+            *path, leaf = k.split(".")
+            for part in path:
+                obj = getattr(obj, part)
+            setattr(obj, leaf, v)
+        self.copts = m
+        _index.load_genome(ctx, g)
+        if idx_key is None:
+            ip = index_params or ((m.globalK, m.globalW, 150, 15, 1) if preset != "contig" else (m.globalK, m.globalW, 30, 20, 1))
+            self.index_stats = _index.build_global_index(ctx, self.chrom_pos, *ip)
+        else:
+            k = np.ascontiguousarray(idx_key).view(np.uint64); p = np.ascontiguousarray(idx_pos, dtype=np.uint32)
+            ctx.check(ctx.lib.lra_ctx_load_global_index(ctx.h, C.c_void_p(k.ctypes.data), C.c_void_p(p.ctypes.data), C.c_uint64(len(k))))
+            self.index_stats = dict(n_index=len(k))
+        cp = (C.c_uint64 * len(self.chrom_pos))(*self.chrom_pos)
+        ctx.check(ctx.lib.lra_ctx_load_chromosomes(ctx.h, cp, len(self.chrom_pos) - 1))
+        self.stats = {}
+
+    def align(self, rbatch) -> MapResult:
+        ctx = self.ctx
+        res = MapResult()
+        ctx.check(ctx.lib.lra_map_reads_highacc_batch(ctx.h, rbatch.n, C.c_void_p(rbatch.seq.data_ptr()), C.c_void_p(rbatch.off.data_ptr()),
+                                                      C.c_uint64(int(rbatch.total_bases)), C.byref(self.copts), C.byref(res)))
+        c = res.counters
+        self.stats.update({n: int(getattr(c, n)) for n, _ in MapCounters._fields_})
+        self.stats.update(n_alignments=int(res.n_alignments), n_blocks=int(res.n_blocks), n_cigar_runs=int(res.n_runs))
+        return res
+
+    fetch = LowAccMapper.fetch
+    records = LowAccMapper.records
+    record_args = LowAccMapper.record_args
+    snapshot = LowAccMapper.snapshot
+    records_host = LowAccMapper.records_host

@@ -226,8 +226,16 @@ extern "C" int oracle_split_chain(int n, const uint32_t* q, const uint32_t* t, c
 // Map_lowacc.h:538-539 applies {2, 4} to the chain of the second sparse DP; LocalRefineAlignment.h:567-571 {1, 2 or 3, 4}.
 // Out: keep[] over the ORIGINAL anchors, the surviving links (linkOut, *nLink of them: RemoveSpuriousAnchors leaves the vector longer than
 // the chain, as the reference does).  Returns the number of surviving anchors.
+extern "C" int oracle_filter_chain_ex(int n, const uint32_t* q, const uint32_t* t, const int* len, const uint32_t* qend, const uint8_t* strand, const uint8_t* link,
+                                      int hasLink, const int* ops, int nOps, uint8_t* keep, uint8_t* linkOut, int* nLink);
 extern "C" int oracle_filter_chain(int n, const uint32_t* q, const uint32_t* t, const int* len, const uint8_t* strand, const uint8_t* link, int hasLink,
                                    const int* ops, int nOps, uint8_t* keep, uint8_t* linkOut, int* nLink) {
+  return oracle_filter_chain_ex(n, q, t, len, nullptr, strand, link, hasLink, ops, nOps, keep, linkOut, nLink);
+}
+// qend != NULL: the chain's qEnd(i) is qend[i] rather than q + len -- FinalChain::qEnd = Cluster_SameDiag::GetqEnd (Clustering.h:378-380), which adds the
+// merged entry's length to its LAST anchor's read position.
+extern "C" int oracle_filter_chain_ex(int n, const uint32_t* q, const uint32_t* t, const int* len, const uint32_t* qend, const uint8_t* strand, const uint8_t* link,
+                                      int hasLink, const int* ops, int nOps, uint8_t* keep, uint8_t* linkOut, int* nLink) {
   struct A { uint32_t q, t; int len; int strand; int orig; };
   std::vector<A> ch(n);
   for (int i = 0; i < n; i++) ch[i] = A{q[i], t[i], len[i], (int)strand[i], i};
@@ -235,7 +243,7 @@ extern "C" int oracle_filter_chain(int n, const uint32_t* q, const uint32_t* t, 
   if (hasLink) lk.assign(link, link + (n > 0 ? n - 1 : 0));
   auto qS = [&](int i) { return ch[i].q; };
   auto tS = [&](int i) { return ch[i].t; };
-  auto qE = [&](int i) { return ch[i].q + (uint32_t)ch[i].len; };
+  auto qE = [&](int i) { return qend ? qend[ch[i].orig] : ch[i].q + (uint32_t)ch[i].len; };
   auto tE = [&](int i) { return ch[i].t + (uint32_t)ch[i].len; };
   auto gap_of = [&](int c) -> int {
     if (ch[c].strand == 0) return (int)(((long)tS(c) - (long)qS(c)) - ((long)tS(c - 1) - (long)qS(c - 1)));

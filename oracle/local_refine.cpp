@@ -189,16 +189,31 @@ void between_anchors(Env& E, int cur, int next, int str, int inv_str, int chrom,
 // len), per chain strand / chromIndex / FirstSDPValue / NumOfAnchors0 / NumOfAnchors1; LSC = LargestSplitChain.  Out: the SegAlignments pushed
 // onto alignments.back() in order: strand, Supplymentary, ISsecondary, NumOfAnchors0/1, value, chromIndex and blocks (CSR of qPos, tPos,
 // length).  Returns the number of alignments, -1 when the reference would read outside an array, -2 when a capacity is too small.
+extern "C" int oracle_local_refine_alignment_ex(int nChains, const int* chainOff, const uint32_t* aq, const uint32_t* at, const int* alen, const uint8_t* chainStrand,
+                                                const int* chainChrom, const float* firstSdp, const int* numAnchors0, const int* numAnchors1, int LSC, int h, int minAnchors,
+                                                const char* fwd, const char* rc, uint32_t readLen, const char* genome, const uint64_t* chromPos, const oracle_lra_opts* o,
+                                                int maxSeg, int* segStrand, int* segSupp, int* segSecondary, int* segN0, int* segN1, float* segValue, int* segChrom,
+                                                int* segBlockOff, int* blocks, long blockCap);
 extern "C" int oracle_local_refine_alignment(int nChains, const int* chainOff, const uint32_t* aq, const uint32_t* at, const int* alen, const uint8_t* chainStrand,
                                              const int* chainChrom, const float* firstSdp, const int* numAnchors0, const int* numAnchors1, int LSC, int h,
                                              const char* fwd, const char* rc, uint32_t readLen, const char* genome, const uint64_t* chromPos, const oracle_lra_opts* o,
                                              int maxSeg, int* segStrand, int* segSupp, int* segSecondary, int* segN0, int* segN1, float* segValue, int* segChrom,
                                              int* segBlockOff, int* blocks, long blockCap) {
+  return oracle_local_refine_alignment_ex(nChains, chainOff, aq, at, alen, chainStrand, chainChrom, firstSdp, numAnchors0, numAnchors1, LSC, h, 2, fwd, rc, readLen, genome,
+                                          chromPos, o, maxSeg, segStrand, segSupp, segSecondary, segN0, segN1, segValue, segChrom, segBlockOff, blocks, blockCap);
+}
+// minAnchors = 1: the walk of the high-accuracy overload (LocalRefineAlignment.h:577-766; `if (ultimatechain.size() == 0) continue`, :579), whose chains st are
+// splitchains[st] (empty where the ultimatechain is empty), LSC = LargestSplitChain_dist, firstSdp / numAnchors0 = chains[h].value / NumOfAnchors0.
+extern "C" int oracle_local_refine_alignment_ex(int nChains, const int* chainOff, const uint32_t* aq, const uint32_t* at, const int* alen, const uint8_t* chainStrand,
+                                                const int* chainChrom, const float* firstSdp, const int* numAnchors0, const int* numAnchors1, int LSC, int h, int minAnchors,
+                                                const char* fwd, const char* rc, uint32_t readLen, const char* genome, const uint64_t* chromPos, const oracle_lra_opts* o,
+                                                int maxSeg, int* segStrand, int* segSupp, int* segSecondary, int* segN0, int* segN1, float* segValue, int* segChrom,
+                                                int* segBlockOff, int* blocks, long blockCap) {
   Env E; E.strands[0] = fwd; E.strands[1] = rc; E.readLen = readLen; E.genome = genome; E.chromPos = chromPos; E.o = o;
   std::vector<Aln> alns;
   for (int st = 0; st < nChains; st++) {
     const int m = chainOff[st + 1] - chainOff[st];
-    if (m <= 1) continue;
+    if (m < minAnchors) continue;
     const uint32_t* AQ = aq + chainOff[st]; const uint32_t* AT = at + chainOff[st]; const int* AL = alen + chainOff[st];
     const int start = 0, end = m - 1;
     const int str = chainStrand[st], chrom = chainChrom[st];

@@ -589,7 +589,8 @@ class LraOpts(C.Structure):
         ("gapopen", C.c_float), ("gapextend", C.c_float), ("gaproot", C.c_float), ("gapCeiling1", C.c_int), ("gapCeiling2", C.c_int)]
 
 
-def local_refine_alignment(chain_off, aq, at, alen, chain_strand, chain_chrom, first_sdp, n0, n1, h, fwd: bytes, rc: bytes, genome: bytes, chrom_pos, **kw):
+def local_refine_alignment(chain_off, aq, at, alen, chain_strand, chain_chrom, first_sdp, n0, n1, h, fwd: bytes, rc: bytes, genome: bytes, chrom_pos, lsc=None,
+                           min_anchors=2, **kw):
     """LocalRefineAlignment (LocalRefineAlignment.h:885) for one primary chain -> list of dict(strand, supp, secondary, n0, n1, value, chrom, blocks) or None (UB)."""
     L = lib()
     d = dict(localW=5, globalW=5, localMaxFreq=15, match=4, mismatch=-1, indel=-2, localBand=15, refineBySDP=1, isOnt=1, gapopen=7.0, gapextend=10.0, gaproot=1.5,
@@ -601,13 +602,14 @@ def local_refine_alignment(chain_off, aq, at, alen, chain_strand, chain_chrom, f
     a0 = np.ascontiguousarray(n0, np.int32); a1 = np.ascontiguousarray(n1, np.int32); pos = np.ascontiguousarray(chrom_pos, np.uint64)
     nch = len(cs)
     sizes = np.diff(co)
-    lsc = int(np.argmax(sizes)) if nch else 0                              # LargestSplitChain: first maximum
+    if lsc is None:
+        lsc = int(np.argmax(sizes)) if nch else 0                          # LargestSplitChain: first maximum
     max_seg = 4 * len(aq) + 8; cap = 4 * (len(aq) + len(fwd)) + 64
     seg = [np.zeros(max_seg, np.int32) for _ in range(5)]; sv = np.zeros(max_seg, np.float32); sc = np.zeros(max_seg, np.int32)
     sbo = np.zeros(max_seg + 1, np.int32); blk = np.zeros(3 * cap, np.int32)
-    L.oracle_local_refine_alignment.restype = C.c_int
-    n = L.oracle_local_refine_alignment(C.c_int(nch), _p(co, C.c_int), _p(aq, C.c_uint32), _p(at, C.c_uint32), _p(al, C.c_int), _p(cs, C.c_uint8), _p(cc, C.c_int),
-                                        _p(fs, C.c_float), _p(a0, C.c_int), _p(a1, C.c_int), C.c_int(lsc), C.c_int(int(h)), C.c_char_p(fwd), C.c_char_p(rc),
+    L.oracle_local_refine_alignment_ex.restype = C.c_int
+    n = L.oracle_local_refine_alignment_ex(C.c_int(nch), _p(co, C.c_int), _p(aq, C.c_uint32), _p(at, C.c_uint32), _p(al, C.c_int), _p(cs, C.c_uint8), _p(cc, C.c_int),
+                                        _p(fs, C.c_float), _p(a0, C.c_int), _p(a1, C.c_int), C.c_int(lsc), C.c_int(int(h)), C.c_int(int(min_anchors)), C.c_char_p(fwd), C.c_char_p(rc),
                                         C.c_uint32(len(fwd)), C.c_char_p(genome), _p(pos, C.c_uint64), C.byref(o), C.c_int(max_seg), _p(seg[0], C.c_int),
                                         _p(seg[1], C.c_int), _p(seg[2], C.c_int), _p(seg[3], C.c_int), _p(seg[4], C.c_int), _p(sv, C.c_float), _p(sc, C.c_int),
                                         _p(sbo, C.c_int), _p(blk, C.c_int), C.c_long(cap))
@@ -702,7 +704,7 @@ def refine_breakpoint(read_len, l_blocks, l_strand, l_read: bytes, l_chrom: byte
     return ret, lo[:3 * nlo.value].reshape(-1, 3).copy(), ro[:3 * nro.value].reshape(-1, 3).copy()
 
 
-def filter_chain(q, t, length, strand, link, ops):
+def filter_chain(q, t, length, strand, link, ops, qend=None):
     """Chain.h filters in the given order (1 small paired indels, 2/3 paired indels with/without refineEnds, 4 spurious anchors, 8 spurious jump).
     link=None for chain types without links.  -> (keep, surviving links)"""
     L = lib()
@@ -713,9 +715,10 @@ def filter_chain(q, t, length, strand, link, ops):
     lk = np.ascontiguousarray(link if has else np.zeros(max(n - 1, 0)), np.uint8)
     ops = np.ascontiguousarray(ops, np.int32)
     keep = np.zeros(max(1, n), np.uint8); lo = np.zeros(max(1, n), np.uint8); nl = C.c_int(0)
-    L.oracle_filter_chain.restype = C.c_int
-    L.oracle_filter_chain(C.c_int(n), _p(q, C.c_uint32), _p(t, C.c_uint32), _p(ln, C.c_int), _p(st, C.c_uint8), _p(lk, C.c_uint8), C.c_int(int(has)),
-                          _p(ops, C.c_int), C.c_int(len(ops)), _p(keep, C.c_uint8), _p(lo, C.c_uint8), C.byref(nl))
+    qe = None if qend is None else np.ascontiguousarray(qend, np.uint32)
+    L.oracle_filter_chain_ex.restype = C.c_int
+    L.oracle_filter_chain_ex(C.c_int(n), _p(q, C.c_uint32), _p(t, C.c_uint32), _p(ln, C.c_int), None if qe is None else _p(qe, C.c_uint32), _p(st, C.c_uint8),
+                             _p(lk, C.c_uint8), C.c_int(int(has)), _p(ops, C.c_int), C.c_int(len(ops)), _p(keep, C.c_uint8), _p(lo, C.c_uint8), C.byref(nl))
     return keep[:n].copy(), lo[:nl.value].copy()
 
 

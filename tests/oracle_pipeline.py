@@ -262,3 +262,185 @@ def map_reads_lowacc_mt(reads, off, first, n, genome: bytes, idx_key, idx_pos, g
     L.oracle_map_reads_lowacc_mt(r.ctypes.data_as(C.c_char_p), O._p(o_, C.c_uint64), C.c_long(first), C.c_long(n), *args, C.byref(m), C.c_int(n_threads),
                                  C.byref(sec), C.byref(bases), C.byref(nal), C.byref(cs))
     return dict(seconds=sec.value, bases=bases.value, n_alignments=nal.value, checksum=cs.value, n_reads=int(n))
+
+
+# ------------------------------------------------------------------------------------------------------------------------ MapRead_highacc
+# -CCS (lra.cpp:306-340) and -CONTIG (lra.cpp:268-305) over the defaults of Options.h:127-230
+CCS = dict(globalK=25, globalW=20, globalMaxFreq=150, localW=5, localMaxFreq=15, readType=2, refineBand=7, match=4, mismatch=-3, indel=-4, localBand=15, NumAln=2,
+           alnthres=0.7, initial_anchorbonus=10.0, second_anchorbonus=2.0, splitdist=50000, anchorstoosparse=0.005, merge_dist=100, gapopen=4.0, gapextend=15.0,
+           gaproot=1.5, gapCeiling1=2000, gapCeiling2=3000, refineBreakpoint=False, skipBandedRefine=False,
+           clean=dict(cleanMaxDiag=150, minDiagCluster=10, bypassClustering=0, cleanClustersize=100, SecondCleanMinDiagCluster=30, SecondCleanMaxDiag=100, punish_anchorfreq=10,
+                      anchorPerlength=10),
+           fine=dict(RoughClustermaxGap=500, maxDiag=500, maxGap=400, minClusterSize=10, minUniqueStretchNum=1, minUniqueStretchDist=50))
+CONTIG = dict(CCS, globalK=19, globalW=10, globalMaxFreq=30, readType=3, refineBand=50, gapextend=20.0, gapCeiling1=3000, gapCeiling2=5000, initial_anchorbonus=1.0,
+              clean=dict(CCS["clean"], minDiagCluster=30), fine=dict(CCS["fine"], maxDiag=100, maxGap=500))
+
+
+def map_read_highacc(read: bytes, genome: bytes, idx_key, idx_pos, opts=None, chrom_pos=None, stats=True):
+    """MapRead (MapRead.h:153-263) + MapRead_highacc (Map_highacc.h:37-798) for ONE read, composed from the oracle's stage functions.
+    -> (groups, unaligned, note): groups = list over the chains h of Primary_chains[0] that have clusters (dict(h=, segs=[...])), every seg as in
+    map_read_lowacc_py plus `stats` with the counters the reference's two CalculateStatistics calls leave (tdel, tins and the six size classes
+    accumulate over both, Alignment.h:440-512 / :85-86).  note = "sparse" for a read that takes the REFINEclusters branch (Map_highacc.h:429-447; not
+    composed here), "ub" where a stage reads outside an array; both come back with groups = None."""
+    o = dict(CCS)
+    if opts:
+        o.update(opts)
+    CH = [0, len(genome.rstrip(b"\0"))] if chrom_pos is None else [int(x) for x in chrom_pos]
+    gpad = genome if len(genome) >= CH[-1] + 64 else genome + b"\0" * 64
+    chrom_b = lambda c: genome[CH[c]:CH[c + 1]]
+    L = len(read); K = o["globalK"]; W = o["globalW"]
+    fwd = read; rc = revcomp_bytes(read)
+    # a1-a4 (MapRead.h:169-203): forward-strand matches first
+    keys, pos = O.store_minimizers(read, K, W)
+    sk, sp = O.sort_minimizers(keys, pos)
+    qi, ti = O.compare_lists(sk, sp, idx_key, idx_pos, o["globalMaxFreq"])
+    if len(qi) == 0:
+        return [], True, None
+    st = O.separate_strand(read, gpad, K, sp[qi], idx_pos[ti])
+    f = st == 0
+    mq = np.concatenate([sp[qi][f], sp[qi][~f]]); mt = np.concatenate([idx_pos[ti][f], idx_pos[ti][~f]]); mk = np.concatenate([sk[qi][f], sk[qi][~f]])
+    # a5 (Map_highacc.h:41-42)
+    fc, ust = O.matches_to_fine_clusters(mq, mt, mk, int(f.sum()), O.CleanOpts(globalK=K, **o["clean"]), O.FineOpts(globalK=K, **o["fine"]), CH)
+    if ust:
+        return None, False, "ub"
+    nC = len(fc["strand"])
+    if nC == 0:
+        return [], True, None
+    # a6 (:153-155), a8 SDP#C (:224-229), switchindex (:274)
+    sc = O.split_clusters(fc["box"][:, 0], fc["box"][:, 1], fc["box"][:, 2], fc["box"][:, 3], fc["strand"], fc["freq"], fc["off"], fc["q"], contig=o["readType"] == 3, K=K)
+    if len(sc["qs"]) == 0:
+        return [], True, None
+    rate = o["initial_anchorbonus"]
+    if len(sc["qs"]) // nC > 20:
+        rate = rate / 2.0
+    TRACE["rate"] = rate
+    sdp_kw = dict(NumAln=o["NumAln"], alnthres=o["alnthres"], gapopen=o["gapopen"], gapextend=o["gapextend"], gaproot=o["gaproot"], gapCeiling1=o["gapCeiling1"],
+                  gapCeiling2=o["gapCeiling2"], globalK=K)
+    first = O.sdp_chain_boxes(sc["qs"], sc["qe"], sc["ts"], sc["te"], sc["strand"], sc["val"], sc["num"], O.sdp_opts(L, rate=rate, **sdp_kw))
+    if first["status"] < 0:
+        return None, False, "ub"
+    if not first["chains"]:
+        return [], True, None
+    chains = []
+    for ch in first["chains"]:
+        sw = O.switchindex(ch["frags"], ch["link"], sc["coarse"], fc["box"][:, 0], fc["box"][:, 1])
+        if sw is None:
+            return None, False, "ub"
+        chains.append(dict(ch=[int(x) for x in sw[0]], link=[int(x) for x in sw[1]], value=ch["value"], n0=ch["num_anchors"]))
+    # clusters no chain uses are dropped, the rest renumbered (:285-318)
+    used = sorted({c for h in chains for c in h["ch"]})
+    if not used:
+        return [], True, None
+    renum = {c: i for i, c in enumerate(used)}
+    for h in chains:
+        h["ch"] = [renum[c] for c in h["ch"]]
+    cl = []
+    for c in used:
+        a, b = int(fc["off"][c]), int(fc["off"][c + 1])
+        cl.append(dict(q=fc["q"][a:b].copy(), t=fc["t"][a:b].copy(), box=fc["box"][c].astype(np.int64), strand=int(fc["strand"][c]), chrom=int(fc["chrom"][c]),
+                       freq=np.float32(fc["freq"][c])))
+    # sparse (:413-416): a cluster with at most one anchor per 100 read bases on a read of at most 50 kb
+    for c in cl:
+        if np.float32(np.float32(len(c["q"])) / np.float32(int(c["box"][1]) - int(c["box"][0]))) <= np.float32(0.01) and L <= 50000:
+            return None, False, "sparse"
+    for c in cl:                                                          # :449-460
+        off = CH[c["chrom"]]
+        c["t"] = c["t"] - np.uint32(off); c["box"][2] -= off; c["box"][3] -= off
+    if not chains:
+        return [], True, None
+    # a11 caller (:515-520)
+    moff = np.concatenate([[0], np.cumsum([len(c["q"]) for c in cl])])
+    coff = np.concatenate([[0], np.cumsum([len(h["ch"]) for h in chains])])
+    rb = O.refine_btwn_clusters_chains(moff, np.concatenate([c["q"] for c in cl]), np.concatenate([c["t"] for c in cl]), np.array([c["box"] for c in cl], np.int64),
+                                       [c["strand"] for c in cl], [c["chrom"] for c in cl], [c["freq"] for c in cl], coff, [x for h in chains for x in h["ch"]], fwd, rc, gpad, CH,
+                                       K=K, W=W, read_type=o["readType"], anchorstoosparse=o["anchorstoosparse"], match=o["match"], mismatch=o["mismatch"], indel=o["indel"],
+                                       max_freq=o["localMaxFreq"])
+    for i, c in enumerate(cl):
+        a, b = int(rb["off"][i]), int(rb["off"][i + 1])
+        c["q"] = rb["q"][a:b].copy(); c["t"] = rb["t"][a:b].copy(); c["box"] = rb["box"][i].astype(np.int64); c["freq"] = np.float32(rb["freq"][i])
+    # a7 cluster version (:573-582) and MergeMatchesSameDiag (:642)
+    ext = []
+    for h in chains:
+        h["first"] = len(ext)
+        for k, ci in enumerate(h["ch"]):
+            c = cl[ci]
+            pv = cl[h["ch"][k - 1]]["box"] if k > 0 else None
+            nx = cl[h["ch"][k + 1]]["box"] if k + 1 < len(h["ch"]) else None
+            e = O.linear_extend_cluster(c["q"], c["t"], c["strand"], c["box"], pv, nx, c["freq"], fwd, chrom_b(c["chrom"]), K=K, skiprepetitive=True, trim=True)
+            c["q"], c["t"] = e["sorted_q"], e["sorted_t"]                  # LinearExtend sorts RefinedClusters[cm]->matches in place (:201-210)
+            ext.append(dict(q=e["q"], t=e["t"], len=e["len"], overlap=e["overlap"], box=e["box"], strand=c["strand"], chrom=c["chrom"]))
+    if sum(len(c["q"]) for c in cl) == 0:
+        return [], True, None
+    for e in ext:
+        m = O.merge_same_diag(e["q"], e["t"], e["len"], e["overlap"], e["strand"], o["merge_dist"])
+        if m is None:
+            return None, False, "ub"
+        s_, e_ = m
+        last = e_ - 1
+        ln = np.where(e["q"][last].astype(np.int64) + e["len"][last] >= e["q"][s_], e["q"][last].astype(np.int64) + e["len"][last] - e["q"][s_], 0)   # Cluster_SameDiag::length
+        e["sd"] = dict(start=s_, end=e_, q=e["q"][s_], t=e["t"][s_] if e["strand"] == 0 else e["t"][last], len=ln.astype(np.int32),
+                       qend=(e["q"][last].astype(np.int64) + ln).astype(np.uint32))           # GetqStart, GettStart, length, GetqEnd (Clustering.h:366-390)
+    lra_kw = dict(localW=o["localW"], globalW=o["localW"], localMaxFreq=o["localMaxFreq"], match=o["match"], mismatch=o["mismatch"], indel=o["indel"], localBand=o["localBand"],
+                  refineBySDP=1, isOnt=0, gapopen=o["gapopen"], gapextend=o["gapextend"], gaproot=o["gaproot"], gapCeiling1=o["gapCeiling1"], gapCeiling2=o["gapCeiling2"])
+    groups = []
+    for hi, h in enumerate(chains):
+        n = len(h["ch"])
+        if n == 0:
+            continue
+        E = ext[h["first"]:h["first"] + n]
+        # a9 high-accuracy SPLITChain + LSC (:705-707)
+        sp = O.split_chain_highacc([e["strand"] for e in E], [e["chrom"] for e in E], [e["box"] for e in E], h["link"], o["splitdist"])
+        off = [0]; aq = []; at = []; al = []; cstr = []; cchr = []
+        for st_ in range(len(sp["type"])):
+            vs = sp["idx"][sp["off"][st_]:sp["off"][st_ + 1]]
+            # SDP#D + filters + SwitchToOriginalAnchors (LocalRefineAlignment.h:556-577)
+            co2 = np.concatenate([[0], np.cumsum([len(E[v]["sd"]["q"]) for v in vs])])
+            sq = np.concatenate([E[v]["sd"]["q"] for v in vs]); st2 = np.concatenate([E[v]["sd"]["t"] for v in vs]); sl = np.concatenate([E[v]["sd"]["len"] for v in vs])
+            sqe = np.concatenate([E[v]["sd"]["qend"] for v in vs])
+            e2 = O.sdp_chain(co2, [E[v]["strand"] for v in vs], sq, st2, sl, O.sdp_opts(L, mode=1, rate=o["second_anchorbonus"], **sdp_kw))
+            if e2["status"] < 0:
+                return None, False, "ub"
+            uq = []; ut = []; ul = []; ucl = []
+            if e2["chains"]:
+                ix = e2["chains"][0]["frags"].astype(np.int64)
+                which = np.searchsorted(co2, ix, side="right") - 1
+                keep, _ = O.filter_chain(sq[ix], st2[ix], sl[ix], [E[vs[w]]["strand"] for w in which], None, [1, 3, 4], qend=sqe[ix])
+                for i_, w in zip(ix[keep.astype(bool)], which[keep.astype(bool)]):
+                    v = int(vs[w]); k = int(i_ - co2[w]); e = E[v]
+                    for j in range(int(e["sd"]["end"][k]) - 1, int(e["sd"]["start"][k]) - 1, -1):
+                        uq.append(int(e["q"][j])); ut.append(int(e["t"][j])); ul.append(int(e["len"][j])); ucl.append(v)
+            aq.extend(uq); at.extend(ut); al.extend(ul); off.append(len(aq))
+            cstr.append(E[ucl[0]]["strand"] if ucl else 0); cchr.append(E[ucl[0]]["chrom"] if ucl else 0)
+        nch = len(cstr)
+        segs = O.local_refine_alignment(off, aq, at, al, cstr, cchr, [h["value"]] * nch, [h["n0"]] * nch, list(np.diff(off)), hi, fwd, rc, gpad, CH, lsc=sp["lsc"], min_anchors=1,
+                                        **lra_kw)
+        if segs is None:
+            return None, False, "ub"
+        out = []
+        for s in segs:
+            sb = fwd if s["strand"] == 0 else rc
+            cb = chrom_b(s["chrom"])
+            if o["skipBandedRefine"]:
+                refined, rst = s["blocks"], 0
+            else:
+                refined, rst = O.indel_refine(s["blocks"], sb, cb + b"\0" * 64, o["refineBand"], o["match"], o["mismatch"], o["indel"], end_align=True, read_len=L, chrom_len=len(cb))
+            d = dict(s, a13_blocks=s["blocks"], blocks=refined, refine_status=rst)
+            if stats and rst == 0 and len(refined):
+                d["stats1"] = O.calculate_statistics(refined, sb, cb + b"\0" * 64)
+            out.append(d)
+        if not o["refineBreakpoint"]:                                      # sic: `if (opts.refineBreakpoint == false)` (Map_highacc.h:723)
+            for si in range(1, len(out)):
+                l, r = out[si], out[si - 1]
+                ret, lb, rb_ = O.refine_breakpoint(L, l["blocks"], l["strand"], fwd if l["strand"] == 0 else rc, chrom_b(l["chrom"]), r["blocks"], r["strand"],
+                                                   fwd if r["strand"] == 0 else rc, chrom_b(r["chrom"]))
+                if ret >= 0:
+                    l["blocks"], r["blocks"] = lb, rb_
+                l["breakpoint"] = ret
+        for d in out:                                                      # the second CalculateStatistics (:730-732)
+            if "stats1" in d and len(d["blocks"]):
+                c2, v2, runs2, cg2 = O.calculate_statistics(d["blocks"], fwd if d["strand"] == 0 else rc, chrom_b(d["chrom"]) + b"\0" * 64)
+                for k in ("tdel", "tins", "nSmallDel", "nMedDel", "nLargeDel", "nSmallIns", "nMedIns", "nLargeIns"):
+                    c2[k] += d["stats1"][0][k]
+                d["stats"] = (c2, v2, runs2, cg2)
+        groups.append(dict(h=hi, segs=out))
+    return groups, len(groups) == 0, None

@@ -156,11 +156,16 @@ def test_hip_filter_chains_oracle(ctx):
     d = dict(off=tt(off.astype(np.int64)), q=tt(cat(0, np.int64)).to(torch.int32), t=tt(cat(1, np.int64)).to(torch.int32), ln=tt(cat(2, np.int32)),
              st=tt(cat(3, np.uint8)), lk=tt(link))
     removed = 0
-    for ops, with_link in (([2, 4], True), ([1, 2, 4], False), ([1, 3, 4], True), ([8], True), ([4, 8, 1], True), ([2], True), ([5], False), ([5, 4], True)):
-        res = chain.filter_chains_batch(ctx, len(chains), d["off"], int(off[-1]), d["q"], d["t"], d["ln"], d["st"], d["lk"] if with_link else None, ops)
+    # FinalChain's qEnd (merged entries: the length added to the LAST anchor's read position): q + len + an extra for some anchors
+    qend = cat(0, np.int64) + cat(2, np.int64) + np.where(rng.random(int(off[-1])) < 0.3, rng.integers(0, 300, int(off[-1])), 0)
+    d["qe"] = tt(qend).to(torch.int32)
+    for ops, with_link, ex in (([2, 4], True, False), ([1, 2, 4], False, False), ([1, 3, 4], True, False), ([8], True, False), ([4, 8, 1], True, False), ([2], True, False),
+                               ([5], False, False), ([5, 4], True, False), ([1, 3, 4], False, True), ([1, 2, 4], True, True)):
+        res = chain.filter_chains_batch(ctx, len(chains), d["off"], int(off[-1]), d["q"], d["t"], d["ln"], d["st"], d["lk"] if with_link else None, ops,
+                                        qend=d["qe"] if ex else None)
         out = chain.fetch_filter(ctx, res)
         for i, c in enumerate(chains):
-            keep, lk = O.filter_chain(c[0], c[1], c[2], c[3], c[4] if with_link else None, ops)
+            keep, lk = O.filter_chain(c[0], c[1], c[2], c[3], c[4] if with_link else None, ops, qend=qend[int(off[i]):int(off[i + 1])] if ex else None)
             a, b = int(off[i]), int(off[i + 1])
             assert out["keep"][a:b].tolist() == keep.tolist(), (ops, i)
             assert out["n_kept"][i] == keep.sum()

@@ -343,3 +343,86 @@ def test_oracle_split_chain_highacc_sanity(oracle):
     assert r["idx"].tolist() == [0, 2, 1, 3] and r["off"].tolist() == [0, 2, 3, 4] and r["lsc"] == 0 and [chr(int(x)) for x in r["type"]] == ["T", "T", "N"], r
     r = O.split_chain_highacc([0, 1, 0], [0, 0, 0], [[0, 500, 1000, 1500], [500, 900, 1500, 1900], [900, 2000, 1900, 3000]], [0, 0])
     assert [chr(int(x)) for x in r["type"]] == ["I", "I", "N"] and r["lsc"] == 2
+
+
+def _sv_reads(genome, rng, err, n_plain=10):
+    mix = (34, 33, 33)
+    reads, _ = synth.simulate_reads(genome, n_plain, 9000, 2500, err, mix, seed=int(rng.integers(1 << 30)))
+    sim = lambda a, n, rev=False: synth.simulate_read(rng, genome[a:a + n + 1], n, err, mix, rev)[0]
+    reads.append(np.concatenate([sim(50_000, 4000), sim(60_000, 4000)]))                                  # 6 kb deletion
+    reads.append(np.concatenate([sim(160_000, 4000), sim(164_000, 2500, True), sim(166_500, 4000)]))      # inversion
+    reads.append(np.concatenate([sim(250_000, 4500), sim(400_000, 4500, True)]))                          # translocation, second half reversed
+    reads.append(synth.revcomp(np.concatenate([sim(300_000, 3000), sim(303_200, 3000)])))                 # 200 bp deletion, read on the reverse strand
+    reads.append(np.concatenate([sim(20_000, 3000), sim(520_000, 2500), sim(23_000, 3000)]))              # insert from far away between two collinear parts
+    reads.append(sim(146_000, 14_000))                                                                    # across a tandem array
+    reads.append(sim(78_000, 16_000))                                                                     # inside the segmental duplication
+    reads.append(np.frombuffer(b"ACGT", np.uint8)[rng.integers(0, 4, 2500)].copy())                        # junk
+    return reads
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("preset", ["ccs", "ccs-bp", "ccs-k17"])
+def test_map_reads_highacc_match_oracle_pipeline(ctx, oracle, preset):
+    """lra_map_reads_highacc_batch against MapRead_highacc composed from the oracle's stage functions (tests/oracle_pipeline.map_read_highacc): every
+    SegAlignment of every chain -- strand, Supplymentary, ISsecondary, NumOfAnchors0/1, the chain's value, the refined blocks, the counters the two
+    CalculateStatistics calls leave, NV bits and CIGAR runs -- on plain reads and reads with a deletion / an inversion / a translocation / an insert,
+    reads in repeats, and a read that cannot align.  ccs-bp: --refineBreakpoints (which on this path turns RefineBreakpoint OFF, Map_highacc.h:723)."""
+    import oracle_pipeline as OP
+    from lra_amd import seed, mapread, index as I
+    g = _genome_with_repeats(19)
+    CH = [0, 250_000, len(g)]
+    rng = np.random.default_rng(8)
+    reads = _sv_reads(g, rng, 0.01)
+    over = {}
+    oo = dict(OP.CCS)
+    ip = (25, 20, 150, 15, 1)
+    if preset == "ccs-bp":
+        over["refineBreakpoint"] = 1; oo["refineBreakpoint"] = True
+    if preset == "ccs-k17":                                               # denser seeds: more clusters per read, more second chains
+        over.update({"globalK": 17, "globalW": 10, "clean.globalK": 17, "sdp.globalK": 17, "fine.globalK": 17}); oo.update(globalK=17, globalW=10); ip = (17, 10, 150, 15, 1)
+    mapper = mapread.HighAccMapper(ctx, g, None, None, [b"chrA", b"chrB"], CH, "ccs", index_params=ip, **over)
+    ik, ipos = I.global_index(ctx)
+    res = mapper.align(seed.ReadBatch(ctx, [r.tobytes() for r in reads]))
+    out = mapper.fetch(res)
+    na = int(res.num_aln)
+    gb = g.tobytes()
+    n_seg = n_supp = n_rev = n_multi = n_bp = n_sec = n_unsup = n_acc = 0
+    for r, rd in enumerate(reads):
+        exp, unaligned, note = OP.map_read_highacc(rd.tobytes(), gb, ik, ipos, oo, chrom_pos=CH)
+        if note == "sparse":
+            assert out["read_status"][r] == 32, (r, out["read_status"][r]); n_unsup += 1
+            continue
+        assert note is None and out["read_status"][r] == 0, (r, note, out["read_status"][r])
+        by_h = {G["h"]: G["segs"] for G in exp}
+        for h in range(na):
+            a0, a1 = int(out["job_aln_off"][r * na + h]), int(out["job_aln_off"][r * na + h + 1])
+            assert bool(out["job_reached"][r * na + h]) == (h in by_h), (r, h)
+            e = by_h.get(h, [])
+            assert a1 - a0 == len(e), (r, h, a1 - a0, len(e))
+            for a, s in zip(range(a0, a1), e):
+                assert (out["strand"][a], out["supp"][a], out["secondary"][a], out["n0"][a], out["n1"][a], out["chrom"][a]) == \
+                       (s["strand"], s["supp"], s["secondary"], s["n0"], s["n1"], s["chrom"]), (r, h, a)
+                assert np.float32(out["first_sdp_value"][a]).view(np.uint32) == np.float32(s["value"]).view(np.uint32), (r, h, a)
+                assert out["refine_status"][a] == s["refine_status"] == 0, (r, h, a)
+                b = out["blocks"][int(out["block_off"][a]):int(out["block_off"][a + 1])]
+                assert np.array_equal(b, s["blocks"]), (r, h, a, len(b), len(s["blocks"]))
+                ec, ev, eruns, _ = s["stats"]
+                assert out["counts"][a].tolist() == [ec[k] for k in O.STAT_NAMES], (r, h, a, out["counts"][a].tolist(), [ec[k] for k in O.STAT_NAMES])
+                assert np.float32(out["value"][a]).view(np.uint32) == np.float32(ev).view(np.uint32), (r, h, a)
+                assert np.array_equal(out["runs"][int(out["run_off"][a]):int(out["run_off"][a + 1])], eruns), (r, h, a)
+                n_seg += 1; n_supp += int(s["supp"]); n_rev += int(s["strand"]); n_bp += int(s.get("breakpoint", 0) == 1); n_sec += int(s["secondary"])
+                n_acc += int(ec["tdel"] + ec["tins"] > 0)
+            n_multi += len(e) > 1
+        if unaligned:
+            assert not any(out["job_reached"][r * na:(r + 1) * na]), r
+    assert n_seg >= len(reads) - 3 and n_supp >= 3 and n_rev >= 3 and n_multi >= 3 and n_acc >= 3, (n_seg, n_supp, n_rev, n_multi, n_acc, n_unsup)
+    assert (n_bp >= 1) == (preset != "ccs-bp"), n_bp
+    # the records: every read gets its lines (or none), supplementary segments carry SA tags, flagged reads are left out
+    names = [b"r%d" % i for i in range(len(reads))]
+    texts = mapper.records(res, names, [r.tobytes() for r in reads])
+    assert len(texts) == len(reads)
+    for r, t in enumerate(texts):
+        if out["read_status"][r]:
+            assert t == b"", r
+    assert texts[-1].split(b"\t")[1] == b"4"                              # the junk read: one unaligned record
+    assert sum(1 for t in texts if t.count(b"\n") >= 2) >= 3               # split reads: several lines
