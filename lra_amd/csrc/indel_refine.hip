@@ -183,6 +183,7 @@ __global__ void __launch_bounds__(64) ir_segment(IRArgs A) {
 struct __attribute__((aligned(16))) Row { int S, E; unsigned int C; int T; };   // window [S,E], cell offset in segment, target base
 
 constexpr int CB = 32;                // blocks per band chunk
+constexpr int MAXW = 1024;            // widest row the fill kernels take (rows of more than 64 cells: ir_fill_wide; refineBand 50 of -CONTIG gives ~100-200)
 
 struct BandArgs {
   uint64_t n_seg, n_task;
@@ -402,7 +403,7 @@ __global__ void __launch_bounds__(64) ir_band_scan(BandArgs B) {
       int len = (r < tLen) ? e - w.S + 1 : 0;
       if (r < tLen) {
         if (len < 1 || w.S < 0) status |= 1;
-        else if (len > 64) status |= 4;
+        else if (len > MAXW) status |= 4;
         width = max(width, len);
       }
       const unsigned long long l = (unsigned long long)max(len, 0);
@@ -421,10 +422,10 @@ __global__ void __launch_bounds__(64) ir_band_scan(BandArgs B) {
   }
 }
 
-// Work lists of ir_fill: width class (16 / 32 / 64 lanes per segment by the segment's widest row) x length bucket (log2 of the row
+// Work lists of ir_fill: width class (16 / 32 / 64 lanes per segment by the segment's widest row; class 3 = wider rows, ir_fill_wide) x length bucket (log2 of the row
 // count, longest first), so that the lane groups of a wave sweep segments of similar length and the long ones start first.  Bin =
 // class * 32 + (31 - log2 rows).  EMIT = false counts the bins, EMIT = true places the segments (cursor = bin start offsets).
-constexpr int FILL_BINS = 96;
+constexpr int FILL_BINS = 128;
 template <bool EMIT>
 __global__ void ir_classify(uint64_t n_seg, const int32_t* __restrict__ s_kind, const int32_t* __restrict__ s_status, const int32_t* __restrict__ s_width,
                             const uint64_t* __restrict__ s_rows, int* bins, uint32_t* list) {
@@ -434,7 +435,7 @@ __global__ void ir_classify(uint64_t n_seg, const int32_t* __restrict__ s_kind, 
   if (s < n_seg && s_kind[s] == 0 && s_status[s] == 0) {
     const int w = s_width[s];
     const uint32_t r = (uint32_t)min((unsigned long long)s_rows[s], 0x7fffffffULL);
-    bin = (w <= 16 ? 0 : w <= 32 ? 1 : 2) * 32 + (r ? __clz(r) : 31);
+    bin = (w <= 16 ? 0 : w <= 32 ? 1 : w <= 64 ? 2 : 3) * 32 + (r ? __clz(r) : 31);
   }
   const unsigned long long below = (lane == 0) ? 0ULL : (~0ULL >> (64 - lane));
   unsigned long long todo = __ballot(bin >= 0);
@@ -576,6 +577,93 @@ __global__ void __launch_bounds__(64) ir_fill(FillArgs F) {
       prevM = outM; prevD = outD; prevS = S; prevLen = len;
       ti++;
       if (ti == tLen) ti = -1;
+    }
+  }
+}
+
+
+// Rows of more than 64 cells (refineBand 50: -CONTIG): one wave per segment, a row is swept in pieces of 64 cells; the previous row's M and D
+// live in LDS (double buffered), the prefix maximum, V and M of a piece's last cell are carried into the next piece.  Same recurrence, same
+// arrows as ir_fill.
+__global__ void __launch_bounds__(64) ir_fill_wide(FillArgs F) {
+  __shared__ int sM[2][MAXW + 64], sD[2][MAXW + 64];
+  const int lane = threadIdx.x;
+  const int g = F.g, go = 2 * F.g + 1;
+  const long listEnd = F.cursor[4 + 3];
+  while (true) {
+    long x = 0;
+    if (lane == 0) x = atomicAdd(&F.cursor[3], 1);
+    x = __shfl(x, 0);
+    if (x >= listEnd) break;
+    const uint64_t s = F.list[x];
+    const int a = F.s_aln[s];
+    const long tLen = (long)F.s_rows[s];
+    const Row* rows = F.rows + F.s_row_off[s];
+    const unsigned char* qb = (const unsigned char*)F.qseq + F.q_off[a];
+    const long qLast = (long)F.q_len[a] - 1;
+    unsigned char* P = F.path + F.s_cell_off[s];
+    int prevS = 0, prevLen = 0;
+    for (long ti = 0; ti < tLen; ti++) {
+      const Row rw = rows[ti];
+      const int S = rw.S, len = rw.E - rw.S + 1, tch = rw.T;
+      const unsigned int C = rw.C;
+      const bool lastRow = (ti == tLen - 1);
+      const int off = S - prevS;
+      const int cur = (int)(ti & 1), prv = cur ^ 1;
+      int carryW = NEG, carryV = NEG, carryM = BAD;
+      for (int base = 0; base < len; base += 64) {
+        const int c = base + lane;
+        int outM, outD; unsigned char outB;
+        if (ti == 0) {                                                     // :407-431 first row
+          const bool last0 = (c == len - 1) && (tLen > 1);
+          outM = last0 ? BAD : (c == 0 ? 0 : c * g);
+          outD = BAD;
+          outB = (unsigned char)(last0 ? C_BOUND : (c == 0 ? C_DONE : C_LEFT));
+        } else {
+          const long qi = (long)S + c;
+          const int qch = qb[qi < qLast ? qi : qLast];
+          const bool interior = c >= 1 && (lastRow ? c <= len - 1 : c <= len - 2);
+          const int srcA = c + off, srcD = srcA - 1;
+          const bool aboveIn = srcA <= prevLen - 1;
+          const bool inA = srcA >= 0 && srcA < prevLen, inD = srcD >= 0 && srcD < prevLen;
+          const int aM = inA ? sM[prv][srcA] : BAD, aD = inA ? sD[prv][srcA] : BAD;
+          const int dM = inD ? sM[prv][srcD] : BAD;
+          const bool okA = aboveIn && !is_bound(ti - 1, srcA, prevLen);
+          const bool okD = aboveIn && srcD >= 0 && !is_bound(ti - 1, srcD, prevLen);
+          const int dOpen = okA ? aM + go : BAD, dExt = okA ? aD : BAD;
+          const int Dv = max(dOpen, dExt);
+          const int delOpen = (Dv == dOpen) ? 1 : 0;
+          const int mS = okD ? dM + (tch == qch ? F.match : F.mismatch) : BAD;
+          const int dS = okA ? aM + g : BAD;
+          const int V = interior ? max(mS, max(dS, Dv)) : NEG;
+          const int W = max(scan_max<64>(V), carryW);
+          int Wm1 = shr1(W, NEG), Vm1 = shr1(V, NEG);
+          if (lane == 0) { Wm1 = carryW; Vm1 = carryV; }
+          if (c == 0) { Wm1 = NEG; Vm1 = NEG; }
+          const int Iv = max(BAD, go + Wm1);
+          int M = max(max(BAD, V), max(Vm1 + g, go + Wm1));
+          if (!interior) M = BAD;
+          int Mleft = shr1(M, BAD);
+          if (lane == 0) Mleft = carryM;
+          if (c <= 1) Mleft = BAD;
+          const int iOpen = Mleft + go;
+          const int insOpen = (Iv == iOpen) ? 1 : 0;
+          const int iS = Mleft + g;
+          int code;
+          if (!interior) code = C_BOUND;
+          else if (M == mS) code = C_DIAG;
+          else if (M == iS) code = C_LEFT;
+          else if (M == dS) code = C_DOWN;
+          else if (M == Dv) code = C_DELCLOSE;
+          else code = C_INSCLOSE;
+          outM = M; outD = interior ? Dv : BAD;
+          outB = (unsigned char)(code | (delOpen << 3) | (insOpen << 4));
+          carryW = __shfl(W, 63); carryV = __shfl(V, 63); carryM = __shfl(M, 63);
+        }
+        if (c < len) { P[C + c] = outB; sM[cur][c] = outM; sD[cur][c] = outD; }
+      }
+      wave_sync();
+      prevS = S; prevLen = len;
     }
   }
 }
@@ -937,6 +1025,8 @@ extern "C" int lra_indel_refine_batch(lra_ctx* ctx, int n_aln, const int32_t* d_
     if (n16) hipLaunchKernelGGL(ir_fill<16>, dim3((unsigned)std::min<uint64_t>((n16 + 3) / 4, cap_grid)), dim3(64), 0, st, F);
     if (n32) hipLaunchKernelGGL(ir_fill<32>, dim3((unsigned)std::min<uint64_t>((n32 + 1) / 2, cap_grid)), dim3(64), 0, st, F);
     if (n64) hipLaunchKernelGGL(ir_fill<64>, dim3((unsigned)std::min<uint64_t>(n64, cap_grid)), dim3(64), 0, st, F);
+    const uint64_t nWide = (uint64_t)(h_cursor[7] - h_cursor[3]);
+    if (nWide) hipLaunchKernelGGL(ir_fill_wide, dim3((unsigned)std::min<uint64_t>(nWide, cap_grid)), dim3(64), 0, st, F);
     lra_time_end(ctx);
     TraceArgs T;
     T.n_seg = n_seg; T.s_kind = A.s_kind; T.s_tStart = A.s_tStart; T.s_rows = A.s_rows; T.s_row_off = s_row_off;

@@ -79,6 +79,9 @@ def _run_gpu(ctx, genome, reads, blocks, band, par, end_align=False):
     (20, (4, -1, -2), 0.15, (20, 30, 50), 3000, 32, False),
     (7, (4, -3, -4), 0.01, (34, 33, 33), 5000, 40, True),
     (7, (4, -1, -2), 0.10, (30, 35, 35), 30000, 6, False),
+    (50, (4, -3, -4), 0.02, (34, 33, 33), 6000, 24, True),       # -CONTIG: refineBand 50, rows of more than 64 cells (ir_fill_wide)
+    (50, (4, -3, -4), 0.08, (30, 35, 35), 4000, 16, False),
+    (33, (4, -1, -2), 0.10, (30, 35, 35), 4000, 16, False),
 ])
 def test_hip_refine_matches_oracle(ctx, oracle, band, par, err, mix, mean_len, n, end_align):
     genome = synth.make_genome(300000, seed=21)
