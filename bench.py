@@ -296,7 +296,7 @@ def main():
         traffic = None
         try:
             pmc = json.load(open(os.path.join(ROOT, "profiles", "pmc_latest.json")))["kernels"].get(dom)
-            if pmc and abs(pmc["reads_per_launch"] - args.reads / launches_per_step) < 1 and abs(pmc.get("genome_scale", 1.0) - args.genome_scale) < 1e-9:
+            if pmc and abs(pmc["reads_per_launch"] - args.reads / launches_per_step) < 1 and "genome_scale" in pmc and abs(pmc["genome_scale"] - args.genome_scale) < 1e-9 and args.lanes == 1:
                 traffic = pmc["fetch_bytes_per_launch"]
         except (OSError, ValueError, KeyError):
             pass

@@ -27,6 +27,7 @@ struct lra_ctx {
   void* aux = nullptr; size_t aux_bytes = 0;          // AffineOneGapAlign blocks of refine fallbacks
   void* out_buf = nullptr; size_t out_bytes = 0;
   uint64_t* scan_tmp = nullptr;
+  hipStream_t side = nullptr; hipEvent_t ev_fork = nullptr, ev_join = nullptr;   // lra_side_fork / lra_side_join: a second stream for a kernel that would only extend a stage's tail
   void* gbuf[192] = {};   // growable result / work buffers (lra_ensure)
   size_t gbytes[192] = {};
   // kernel timing
@@ -37,6 +38,9 @@ struct lra_ctx {
   std::vector<hipEvent_t> free_events;
 };
 
+// Fork: work queued on the returned stream starts after everything queued on ctx->stream so far; join: ctx->stream waits for it.
+hipStream_t lra_side_fork(lra_ctx* ctx);
+void lra_side_join(lra_ctx* ctx);
 void lra_time_begin(lra_ctx* ctx, const char* name);
 void lra_time_end(lra_ctx* ctx);
 void lra_seed_free(lra_ctx* ctx);

@@ -73,7 +73,25 @@ extern "C" void lra_ctx_destroy(lra_ctx* ctx) {
   for (int i = 0; i < 192; i++) if (ctx->gbuf[i]) (void)hipFree(ctx->gbuf[i]);
   for (auto& r : ctx->recs) { (void)hipEventDestroy(r.a); (void)hipEventDestroy(r.b); }
   for (auto e : ctx->free_events) (void)hipEventDestroy(e);
+  if (ctx->side) { (void)hipStreamSynchronize(ctx->side); (void)hipStreamDestroy(ctx->side); }
+  if (ctx->ev_fork) (void)hipEventDestroy(ctx->ev_fork);
+  if (ctx->ev_join) (void)hipEventDestroy(ctx->ev_join);
   delete ctx;
+}
+
+hipStream_t lra_side_fork(lra_ctx* ctx) {
+  if (!ctx->side) {
+    if (hipStreamCreateWithFlags(&ctx->side, hipStreamNonBlocking) != hipSuccess) { ctx->side = nullptr; return ctx->stream; }
+    (void)hipEventCreateWithFlags(&ctx->ev_fork, hipEventDisableTiming); (void)hipEventCreateWithFlags(&ctx->ev_join, hipEventDisableTiming);
+  }
+  (void)hipEventRecord(ctx->ev_fork, ctx->stream);
+  (void)hipStreamWaitEvent(ctx->side, ctx->ev_fork, 0);
+  return ctx->side;
+}
+void lra_side_join(lra_ctx* ctx) {
+  if (!ctx->side) return;
+  (void)hipEventRecord(ctx->ev_join, ctx->side);
+  (void)hipStreamWaitEvent(ctx->stream, ctx->ev_join, 0);
 }
 
 extern "C" int lra_ctx_set_stream(lra_ctx* ctx, void* stream) {

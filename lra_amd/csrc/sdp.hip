@@ -1495,8 +1495,11 @@ int sdp_run(lra_ctx* ctx, int n_reads, const uint64_t* d_cluster_off, const uint
         while (nbig < nsub && (long)(h_pt[r0 + ord[nbig] + 1] - h_pt[r0 + ord[nbig]]) >= big_pts) nbig++;
       }
       lra_time_begin(ctx, ctx->sdp_inner ? "sdp_inner_process" : "sdp_process");
-      if (nbig > 0) hipLaunchKernelGGL(sdp_process_wg, dim3(nbig), dim3(64 * WG_NW), 0, st, pa);
+      // the few large reads (a workgroup each) run beside the many small ones (a wave each) instead of in front of them
+      const bool forked = nbig > 0 && nsub > nbig;
+      if (nbig > 0) hipLaunchKernelGGL(sdp_process_wg, dim3(nbig), dim3(64 * WG_NW), 0, forked ? lra_side_fork(ctx) : st, pa);
       if (nsub > nbig) { ProcArgs pb = pa; pb.order = subOrder + nbig; pb.n = nsub - nbig; hipLaunchKernelGGL(sdp_process, dim3(nsub - nbig), dim3(64), 0, st, pb); }
+      if (forked) lra_side_join(ctx);
       lra_time_end(ctx);
       if (dbg) {
         (void)hipEventRecord(e1, st); (void)hipEventSynchronize(e1);
