@@ -943,8 +943,8 @@ int lra_map_reads_lowacc_batch(lra_ctx* ctx, int n_reads, const char* d_seq, con
  * when opts.bypassClustering == 0 (-CCS, -CONTIG).  Arguments and result as lra_map_reads_lowacc_batch; job j = read j / num_aln, chain h = j % num_aln of
  * Primary_chains[0] (num_aln = opts.NumAln); d_job_reached[j] = the chain has clusters and got its SegAlignmentGroup (:697-699); d_first_sdp_value =
  * Primary_chains[0].chains[h].value.  The counters of CalculateStatistics are what the reference's two calls (:721, :731) leave: tdel, tins and the six size
- * classes accumulate over both.  Needs the genome, the chromosome table and the global index (no local index).  A -CCS read that takes the REFINEclusters
- * branch (:413-447) comes back with LRA_ST_UNSUPPORTED in d_read_status.  lra_map_records / lra_map_snapshot / lra_map_pack serve both paths
+ * classes accumulate over both.  Needs the genome, the chromosome table and the global index; the genome's local index only when a read takes the REFINEclusters
+ * branch (:413-447: a second pass over those reads with K = glIndex.k, merged into the result; their d_job_reached carries bit 1).  lra_map_records / lra_map_snapshot / lra_map_pack serve both paths
  * (opts.bypassClustering tells the record stage which tail to follow).                                                                          */
 void lra_map_opts_preset_ccs(lra_map_opts* opts);          /* -CCS: lra.cpp:306-340 */
 void lra_map_opts_preset_contig(lra_map_opts* opts);       /* -CONTIG: lra.cpp:268-305 */

@@ -692,7 +692,11 @@ extern "C" int lra_map_records_host(lra_map_host* h, const lra_map_opts* o, cons
       // low-accuracy path: p == 0 left no SegAlignment (Map_lowacc.h:578-581); high-accuracy path: read.unaligned or alignments.size() == 0
       // (Map_highacc.h:778-781) = no chain of the read got its SegAlignmentGroup
       bool unaligned = nJ == 0 || jo[(size_t)r * na + 1] == jo[(size_t)r * na];
-      if (hi && nJ) { unaligned = true; for (int p = 0; p < na; p++) if (!reached.empty() && reached[(size_t)r * na + p]) unaligned = false; }
+      bool sparseRead = false;                                            // the read took the REFINEclusters branch: smallOpts.globalK = glIndex.k (Map_highacc.h:430)
+      if (hi && nJ) {
+        unaligned = true;
+        for (int p = 0; p < na; p++) if (!reached.empty() && reached[(size_t)r * na + p]) { unaligned = false; sparseRead |= (reached[(size_t)r * na + p] & 2) != 0; }
+      }
       if (!unaligned) {
         size_t total = 0;
         for (int p = 0; p < na; p++) total += (size_t)(jo[(size_t)r * na + p + 1] - jo[(size_t)r * na + p]);
@@ -758,7 +762,7 @@ extern "C" int lra_map_records_host(lra_map_host* h, const lra_map_opts* o, cons
         groups.assign(n, lra_aln_group()); index.assign(n, 0);
         if ((rc = lra_group_alignments(recs.data(), seg_off.data(), n, groups.data())) || (rc = lra_order_alignments(groups.data(), n, recs.data(), index.data(), 0)) ||
             (rc = lra_simple_mapqv(groups.data(), index.data(), n, recs.data(), o->bypassClustering, o->readType == LRA_READ_CLR, o->readType == LRA_READ_ONT,
-                                   hi ? o->globalK : o->localK)))                         // SimpleMapQV(alignmentsOrder, read, smallOpts): smallOpts.globalK = glIndex.k (Map_lowacc.h:233, :610); = opts.globalK on the high-accuracy path (Map_highacc.h:402, :736)
+                                   (hi && !sparseRead) ? o->globalK : o->localK)))                         // SimpleMapQV(alignmentsOrder, read, smallOpts): smallOpts.globalK = glIndex.k (Map_lowacc.h:233, :610); = opts.globalK on the high-accuracy path (Map_highacc.h:402, :736)
           break;
         lra_output_read(groups.data(), index.data(), n, recs.data(), o->PrintNumAln, (char)o->printFormat, o->hardClip, passthrough, 0, nullptr, nullptr, 0, &need);
         buf.resize(need + 1);

@@ -14,8 +14,9 @@
 // unused ones are dropped (:285-318), the (read, chain) -> job tables -- is done on the host from small downloads of the stage results
 // (cluster boxes, chain index lists; a few hundred bytes per read), and goes back as index arrays.
 //
-// Not built: the REFINEclusters branch (:429-447) taken by a -CCS read one of whose clusters has at most one anchor per 100 read bases
-// ("sparse", :413-416).  Such a read gets LRA_ST_UNSUPPORTED in d_read_status and no record.
+// A -CCS read one of whose clusters has at most one anchor per 100 read bases ("sparse", :413-416) takes the REFINEclusters branch (:429-447) and goes on
+// with K = glIndex.k.  Such reads are rare; they are collected by the first pass over the batch, run as a second, small batch through the same code
+// with that branch switched on, and the two results are merged on the device into one (lra_map_reads_highacc_batch at the end of this file).
 #include "common.h"
 #include "seed_state.h"
 #include "scan.h"
@@ -175,6 +176,56 @@ __global__ void k_add_counts(uint64_t nA, int32_t* counts, const int32_t* __rest
   for (int k = 4; k < 12; k++) counts[18 * a + k] += first[18 * a + k];
 }
 
+
+// ---- merging the results of two passes: job slot s of the merged result comes from slot srcSlot[s] of pass A (bit 63 clear) or pass B (bit 63 set)
+struct PassView {
+  const uint64_t* jo; const int32_t* strand; const int32_t* supp; const int32_t* sec; const int32_t* n0; const int32_t* n1; const int32_t* chrom; const float* fval;
+  const uint64_t* boff; const int32_t* blocks; const int32_t* rstat; const int32_t* counts; const float* value; const uint64_t* roff; const uint32_t* runs;
+};
+constexpr uint64_t FROM_B = 1ull << 63;
+__global__ void k_merge_count(uint64_t S, const uint64_t* __restrict__ srcSlot, PassView A, PassView B, uint32_t* nAln) {
+  const uint64_t s = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (s >= S) return;
+  const uint64_t x = srcSlot[s], j = x & ~FROM_B;
+  const PassView& V = (x & FROM_B) ? B : A;
+  nAln[s] = V.jo ? (uint32_t)(V.jo[j + 1] - V.jo[j]) : 0;
+}
+__global__ void k_merge_fields(uint64_t S, int na, const uint64_t* __restrict__ srcSlot, PassView A, PassView B, const uint64_t* __restrict__ JO, uint32_t* alnRead,
+                               int32_t* strand, int32_t* supp, int32_t* sec, int32_t* n0, int32_t* n1, int32_t* chrom, float* fval, int32_t* rstat, int32_t* counts,
+                               float* value, uint64_t* srcAln, uint32_t* nb, uint32_t* nr) {
+  const uint64_t s = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (s >= S) return;
+  const uint64_t x = srcSlot[s], j = x & ~FROM_B;
+  const PassView& V = (x & FROM_B) ? B : A;
+  const uint64_t n = JO[s + 1] - JO[s];
+  for (uint64_t i = 0; i < n; i++) {
+    const uint64_t a = V.jo[j] + i, d = JO[s] + i;
+    alnRead[d] = (uint32_t)(s / (uint64_t)na);
+    strand[d] = V.strand[a]; supp[d] = V.supp[a]; sec[d] = V.sec[a]; n0[d] = V.n0[a]; n1[d] = V.n1[a]; chrom[d] = V.chrom[a]; fval[d] = V.fval[a];
+    rstat[d] = V.rstat ? V.rstat[a] : 0; value[d] = V.value[a];
+    for (int k = 0; k < 18; k++) counts[18 * d + k] = V.counts[18 * a + k];
+    srcAln[d] = a | (x & FROM_B);
+    nb[d] = (uint32_t)(V.boff[a + 1] - V.boff[a]); nr[d] = (uint32_t)(V.roff[a + 1] - V.roff[a]);
+  }
+}
+__global__ void __launch_bounds__(64) k_merge_payload(uint64_t nA, const uint64_t* __restrict__ srcAln, PassView A, PassView B, const uint64_t* __restrict__ BO,
+                                                      const uint64_t* __restrict__ RO, int32_t* blocks, uint32_t* runs) {
+  const uint64_t d = blockIdx.x;
+  if (d >= nA) return;
+  const uint64_t x = srcAln[d], a = x & ~FROM_B;
+  const PassView& V = (x & FROM_B) ? B : A;
+  const uint64_t b0 = V.boff[a], nbk = V.boff[a + 1] - b0, r0 = V.roff[a], nrn = V.roff[a + 1] - r0;
+  for (uint64_t i = threadIdx.x; i < 3 * nbk; i += 64) blocks[3 * BO[d] + i] = V.blocks[3 * b0 + i];
+  for (uint64_t i = threadIdx.x; i < nrn; i += 64) runs[RO[d] + i] = V.runs[r0 + i];
+}
+__global__ void __launch_bounds__(64) k_gather_reads(int n, const uint32_t* __restrict__ pick, const uint64_t* __restrict__ off, const char* __restrict__ seq,
+                                                     const uint64_t* __restrict__ newOff, char* out) {
+  const int i = blockIdx.x;
+  if (i >= n) return;
+  const uint64_t a = off[pick[i]], m = off[pick[i] + 1] - a, d = newOff[i];
+  for (uint64_t k = threadIdx.x; k < m; k += 64) out[d + k] = seq[a + k];
+}
+inline size_t al256(size_t x) { return (x + 255) & ~(size_t)255; }
 }  // namespace
 
 extern "C" void lra_map_opts_preset_ccs(lra_map_opts* o) {
@@ -207,26 +258,23 @@ extern "C" void lra_map_opts_preset_contig(lra_map_opts* o) {
   o->readType = LRA_READ_CONTIG;
 }
 
-extern "C" int lra_map_reads_highacc_batch(lra_ctx* ctx, int n_reads, const char* d_seq, const uint64_t* d_read_off, uint64_t total_bases, const lra_map_opts* o,
-                                           lra_map_result* out) {
-  if (!ctx || !o || !out || n_reads < 0) return LRA_ERR_INVALID;
+// One pass over a batch.  sparse_pass = false: every read whose chains' clusters are dense enough (Map_highacc.h:413-416, sparse == 0) is taken through the path with
+// K = opts.globalK; the others are listed in *sparse_reads and left without chains.  sparse_pass = true (the batch holds such reads only): the clusters go through
+// REFINEclusters (:429-447) and the path continues with K = glIndex.k, W = glIndex.w.  h_stat / h_reached: the host copies of d_read_status / d_job_reached.
+static int highacc_core(lra_ctx* ctx, int n_reads, const char* d_seq, const uint64_t* d_read_off, uint64_t total_bases, const lra_map_opts* o, lra_map_result* out,
+                        bool sparse_pass, std::vector<int>* sparse_reads, std::vector<uint32_t>& hstat, std::vector<uint8_t>& h_reached) {
   memset(out, 0, sizeof *out);
   lra_map_state* m = ctx->map;
-  if (!m || m->chrom_pos.size() < 2 || !ctx->seed || !ctx->seed->genome || !ctx->seed->idx_key)
-    return lra_set_err(ctx, LRA_ERR_INVALID, "reference not loaded (genome, global index, chromosome table)");
-  if (o->bypassClustering) return lra_set_err(ctx, LRA_ERR_INVALID, "lra_map_reads_highacc_batch is the path of opts.bypassClustering == 0 (-CCS, -CONTIG)");
   out->n_reads = n_reads;
-  std::string().swap(m->last_text); m->last_sig = lra_map_sig{};
-  if (n_reads == 0) return LRA_OK;
-  LRA_HIP_CHECK(ctx, hipSetDevice(ctx->device));
   hipStream_t st = ctx->stream;
   const int R = n_reads, K = o->globalK, W = o->globalW;
+  const int Kt = sparse_pass ? o->localK : K, Wt = sparse_pass ? o->localW : W;   // K, W after :466-468
   const uint64_t* CH = m->chrom_pos.data();
   const int nChr = (int)m->chrom_pos.size() - 1;
   const char* genome = (const char*)ctx->seed->genome;
   const uint64_t tot = total_bases;
   int rc;
-  std::vector<uint32_t> hstat((size_t)R, 0);                              // every stage's LRA_ST_* bits per read
+  hstat.assign((size_t)R, 0);                                             // every stage's LRA_ST_* bits per read
   std::vector<uint64_t> h_read_off;
   if ((rc = dl(ctx, h_read_off, d_read_off, (size_t)R + 1))) return rc;
   // ---- a1-a4 (MapRead.h:169-203), a5 (Map_highacc.h:41-42)
@@ -339,7 +387,7 @@ extern "C" int lra_map_reads_highacc_batch(lra_ctx* ctx, int n_reads, const char
           if (newid[c] == 0) {
             const uint64_t g = c0 + c;
             const float dens = (float)(cl_moff[g + 1] - cl_moff[g]) / (cl_box[4 * g + 1] - cl_box[4 * g]);
-            if (dens <= 0.01f && L <= 50000) { hstat[r] |= LRA_ST_UNSUPPORTED; ok = false; }
+            if (dens <= 0.01f && L <= 50000 && !sparse_pass) { sparse_reads->push_back(r); ok = false; break; }
           }
       }
       if (ok) {
@@ -356,7 +404,7 @@ extern "C" int lra_map_reads_highacc_batch(lra_ctx* ctx, int n_reads, const char
   uint8_t* job_reached = (uint8_t*)lra_ensure(ctx, 82, S + 64);
   uint32_t* read_status = (uint32_t*)lra_ensure(ctx, 81, ((size_t)R + 1) * 4);
   if (!job_reached || !read_status) return LRA_ERR_NOMEM;
-  std::vector<uint8_t> h_reached(S, 0);
+  h_reached.assign(S, 0);
   lra_alignments_result ares; memset(&ares, 0, sizeof ares);
   lra_refine_result fres; memset(&fres, 0, sizeof fres);
   lra_stats_result tres; memset(&tres, 0, sizeof tres);
@@ -370,8 +418,64 @@ extern "C" int lra_map_reads_highacc_batch(lra_ctx* ctx, int n_reads, const char
     uint32_t* mq = room<uint32_t>(ctx, 113, nM); uint32_t* mt = room<uint32_t>(ctx, 114, nM); uint32_t* box = room<uint32_t>(ctx, 115, 4 * nNew);
     int32_t* strand = room<int32_t>(ctx, 116, nNew); int32_t* chrom = room<int32_t>(ctx, 117, nNew); float* freq = room<float>(ctx, 118, nNew);
     if (!d_src || !d_nmoff || !mq || !mt || !box || !strand || !chrom || !freq) return LRA_ERR_NOMEM;
-    hipLaunchKernelGGL(k_gather_clusters, dim3((unsigned)nNew), dim3(64), 0, st, nNew, d_src, fc.d_match_off, fc.d_q, fc.d_t, fc.d_box, fc.d_strand, fc.d_chrom, fc.d_anchorfreq,
-                       m->d_chrom_pos, d_nmoff, mq, mt, box, strand, chrom, freq);
+    uint64_t nMr = nM;
+    if (!sparse_pass)
+      hipLaunchKernelGGL(k_gather_clusters, dim3((unsigned)nNew), dim3(64), 0, st, nNew, d_src, fc.d_match_off, fc.d_q, fc.d_t, fc.d_box, fc.d_strand, fc.d_chrom, fc.d_anchorfreq,
+                         m->d_chrom_pos, d_nmoff, mq, mt, box, strand, chrom, freq);
+    else {
+      // ---- REFINEclusters (:429-447): the read's two local indexes (:398-402), every cluster re-seeded window by window; anchorfreq inherited (:444)
+      if (!m->gli_buf) return lra_set_err(ctx, LRA_ERR_INVALID, "a read takes the REFINEclusters branch: the genome's local index is needed (lra_ctx_build_local_index)");
+      uint64_t* off2 = (uint64_t*)lra_ensure(ctx, 58, (2 * (size_t)R + 2) * 8);
+      uint8_t* active = (uint8_t*)lra_ensure(ctx, 65, 2 * (size_t)R + 64);
+      if (!off2 || !active) return LRA_ERR_NOMEM;
+      hipLaunchKernelGGL(k_add_off2, dim3((R + 256) / 256), dim3(256), 0, st, R, d_read_off, tot, off2);
+      LRA_HIP_CHECK(ctx, hipMemsetAsync(active, 1, 2 * (size_t)R, st));
+      lra_local_index_result rli;
+      if ((rc = lra_local_index_masked_batch(ctx, 2 * R, both, off2, active, o->localK, o->localW, o->localIndexWindow, o->localMaxFreq, &rli))) return rc;
+      std::vector<uint64_t> rc_off((size_t)R + 1, 0), c_start(nNew); std::vector<uint32_t> c_cnt(nNew), bq[4]; std::vector<int32_t> c_str(nNew); std::vector<float> c_fr(nNew);
+      for (int k = 0; k < 4; k++) bq[k].resize(nNew);
+      {
+        size_t c = 0;
+        for (int r = 0; r < R; r++) { while (c < nNew && src[c] < cl_off[r + 1]) c++; rc_off[r + 1] = c; }
+      }
+      for (uint64_t c = 0; c < nNew; c++) {
+        const uint32_t g = src[c];
+        c_start[c] = cl_moff[g]; c_cnt[c] = (uint32_t)(cl_moff[g + 1] - cl_moff[g]); c_str[c] = cl_strand[g]; c_fr[c] = cl_freq[g];
+        for (int k = 0; k < 4; k++) bq[k][c] = cl_box[4 * g + k];
+      }
+      uint64_t* d_rco2 = up(ctx, 166, rc_off); uint64_t* d_cs = up(ctx, 167, c_start); uint32_t* d_cc = up(ctx, 168, c_cnt);
+      uint32_t* d_bq[4];
+      for (int k = 0; k < 4; k++) if (!(d_bq[k] = up(ctx, 100 + k, bq[k]))) return LRA_ERR_NOMEM;
+      if (!d_rco2 || !d_cs || !d_cc) return LRA_ERR_NOMEM;
+      LRA_HIP_CHECK(ctx, hipMemcpyAsync(strand, c_str.data(), nNew * 4, hipMemcpyHostToDevice, st));
+      LRA_HIP_CHECK(ctx, hipMemcpyAsync(freq, c_fr.data(), nNew * 4, hipMemcpyHostToDevice, st));
+      LRA_HIP_CHECK(ctx, hipStreamSynchronize(st));
+      lra_rsc_opts ro; ro.window = o->window; ro.smallK = o->localK; ro.K = K; ro.limitrefine = 1; ro.max_freq = o->localMaxFreq; ro.local_window = o->localIndexWindow;
+      lra_refined_clusters_result rr;
+      if ((rc = lra_refine_clusters_batch(ctx, R, d_rco2, d_cs, d_cc, strand, d_bq[0], d_bq[1], d_bq[2], d_bq[3], fc.d_q, fc.d_t, fc.n_matches, d_read_off, CH, nChr, &rli, m->n_gwin,
+                                          m->d_gso, m->gli.d_tuple_bnd, m->gli.d_tuples, &ro, &rr))) return rc;
+      std::vector<uint64_t> rmoff; std::vector<uint32_t> rst;
+      if ((rc = dl(ctx, rmoff, rr.d_match_off, nNew + 1)) || (rc = dl(ctx, rst, rr.d_status, nNew))) return rc;
+      nMr = rr.n_matches;
+      mq = room<uint32_t>(ctx, 113, nMr); mt = room<uint32_t>(ctx, 114, nMr);
+      if (!mq || !mt) return LRA_ERR_NOMEM;
+      LRA_HIP_CHECK(ctx, hipMemcpyAsync(mq, rr.d_match_q, nMr * 4, hipMemcpyDeviceToDevice, st));
+      LRA_HIP_CHECK(ctx, hipMemcpyAsync(mt, rr.d_match_t, nMr * 4, hipMemcpyDeviceToDevice, st));
+      LRA_HIP_CHECK(ctx, hipMemcpyAsync(box, rr.d_box, nNew * 16, hipMemcpyDeviceToDevice, st));
+      LRA_HIP_CHECK(ctx, hipMemcpyAsync(chrom, rr.d_chrom, nNew * 4, hipMemcpyDeviceToDevice, st));
+      LRA_HIP_CHECK(ctx, hipMemcpyAsync(d_nmoff, rmoff.data(), (nNew + 1) * 8, hipMemcpyHostToDevice, st));
+      LRA_HIP_CHECK(ctx, hipStreamSynchronize(st));
+      // clusters REFINEclusters left without matches leave the chains (:475-487; `link` keeps its length, as in the reference)
+      for (Chain& x : chains) {
+        size_t cp = 0;
+        for (size_t k = 0; k < x.ch.size(); k++) {
+          const uint32_t c = x.ch[k];
+          if (rst[c] & ~(uint32_t)LRA_ST_REJECTED) hstat[x.read] |= rst[c] & ~(uint32_t)LRA_ST_REJECTED;
+          if (rmoff[c + 1] > rmoff[c]) x.ch[cp++] = c;
+        }
+        x.ch.resize(cp);
+      }
+    }
     // chains as CSR over the new cluster numbers
     std::vector<uint64_t> rco((size_t)R + 1, 0), coff(1, 0), lkoff(1, 0); std::vector<uint32_t> chv, it_cl, it_rd; std::vector<int32_t> it_pv, it_nx; std::vector<uint8_t> lkv;
     std::vector<float> jval(nCh); std::vector<int32_t> jn0(nCh);
@@ -393,7 +497,7 @@ extern "C" int lra_map_reads_highacc_batch(lra_ctx* ctx, int n_reads, const char
     if (!d_rco || !d_coff || !d_chv) return LRA_ERR_NOMEM;
     // ---- a11 caller: RefineBtwnClusters_chain over every chain (:515-520)
     lra_btwn_clusters_result bres;
-    if ((rc = lra_refine_btwn_clusters_batch(ctx, R, d_rco, nCh, d_coff, d_chv, nNew, d_nmoff, nM, mq, mt, box, strand, chrom, freq, d_read_off, both, tot, genome, CH, nChr, K, W,
+    if ((rc = lra_refine_btwn_clusters_batch(ctx, R, d_rco, nCh, d_coff, d_chv, nNew, d_nmoff, nMr, mq, mt, box, strand, chrom, freq, d_read_off, both, tot, genome, CH, nChr, Kt, Wt,
                                              o->readType, o->anchorstoosparse, o->localMatch, o->localMismatch, o->localIndel, o->localMaxFreq, &bres))) return rc;
     cnt.n_btwn_problems = bres.n_problems; cnt.n_btwn_rounds = bres.n_rounds; cnt.n_refined_after_btwn = bres.n_matches;
     // ---- a7 cluster version: LinearExtend_chain (:573-582), then MergeMatchesSameDiag (:642)
@@ -401,7 +505,7 @@ extern "C" int lra_map_reads_highacc_batch(lra_ctx* ctx, int n_reads, const char
     if (!d_icl || !d_ipv || !d_inx || !d_ird) return LRA_ERR_NOMEM;
     lra_ext_clusters_result er;
     if ((rc = lra_linear_extend_clusters_batch(ctx, nItems, d_icl, d_ipv, d_inx, d_ird, nNew, bres.d_match_off, bres.n_matches, (uint32_t*)bres.d_q, (uint32_t*)bres.d_t, box,
-                                               strand, chrom, freq, d_seq, d_read_off, genome, CH, nChr, 1, K, 1, &er))) return rc;
+                                               strand, chrom, freq, d_seq, d_read_off, genome, CH, nChr, 1, Kt, 1, &er))) return rc;
     lra_same_diag_result sd;
     if ((rc = lra_merge_same_diag_batch(ctx, nItems, er.d_anchor_off, er.d_q, er.d_t, er.d_len, er.d_overlap, er.d_strand, o->merge_dist, &sd))) return rc;
     if ((rc = dl(ctx, st32, sd.d_status, nItems))) return rc;
@@ -559,5 +663,119 @@ extern "C" int lra_map_reads_highacc_batch(lra_ctx* ctx, int n_reads, const char
   out->d_counts = tres.d_counts; out->d_value = tres.d_value; out->d_run_off = tres.d_run_off; out->d_runs = tres.d_runs;
   out->d_strands = both; out->rc_base = tot;
   cnt.n_segments = fres.n_segments; cnt.n_rows = fres.n_rows; cnt.n_cells = fres.n_cells; cnt.n_aog = fres.n_aog;
+  return LRA_OK;
+}
+
+extern "C" int lra_map_reads_highacc_batch(lra_ctx* ctx, int n_reads, const char* d_seq, const uint64_t* d_read_off, uint64_t total_bases, const lra_map_opts* o,
+                                           lra_map_result* out) {
+  if (!ctx || !o || !out || n_reads < 0) return LRA_ERR_INVALID;
+  memset(out, 0, sizeof *out);
+  lra_map_state* m = ctx->map;
+  if (!m || m->chrom_pos.size() < 2 || !ctx->seed || !ctx->seed->genome || !ctx->seed->idx_key)
+    return lra_set_err(ctx, LRA_ERR_INVALID, "reference not loaded (genome, global index, chromosome table)");
+  if (o->bypassClustering) return lra_set_err(ctx, LRA_ERR_INVALID, "lra_map_reads_highacc_batch is the path of opts.bypassClustering == 0 (-CCS, -CONTIG)");
+  out->n_reads = n_reads;
+  std::string().swap(m->last_text); m->last_sig = lra_map_sig{};
+  if (n_reads == 0) return LRA_OK;
+  LRA_HIP_CHECK(ctx, hipSetDevice(ctx->device));
+  hipStream_t st = ctx->stream;
+  const int R = n_reads;
+  std::vector<int> sparse;
+  std::vector<uint32_t> hsA, hsB; std::vector<uint8_t> hrA, hrB;
+  int rc = highacc_core(ctx, R, d_seq, d_read_off, total_bases, o, out, false, &sparse, hsA, hrA);
+  if (rc || sparse.empty()) return rc;
+  // ---- the reads that take the REFINEclusters branch: a second, small batch
+  const int na = out->num_aln;
+  const uint64_t S = (uint64_t)R * na, nA1 = out->n_alignments, nB1 = out->n_blocks, nR1 = out->n_runs;
+  const lra_map_counters cntA = out->counters;
+  // keep pass A's per-alignment arrays (the second pass reuses the buffers they live in)
+  char* hold = (char*)lra_ensure(ctx, 170, al256((S + 2) * 8) + 9 * al256((nA1 + 2) * 4) + 2 * al256((nA1 + 2) * 8) + al256((nA1 + 1) * 72) + al256((nB1 + 1) * 12) + al256((nR1 + 1) * 4) + 4096);
+  if (!hold) return LRA_ERR_NOMEM;
+  char* hp = hold;
+  auto keep = [&](const void* srcp, size_t bytes) -> const void* {
+    char* d = hp; hp += al256(bytes + 8);
+    if (srcp && bytes) (void)hipMemcpyAsync(d, srcp, bytes, hipMemcpyDeviceToDevice, st);
+    return srcp ? d : nullptr;
+  };
+  PassView A;
+  A.jo = (const uint64_t*)keep(out->d_job_aln_off, (S + 1) * 8);
+  A.strand = (const int32_t*)keep(out->d_strand, nA1 * 4); A.supp = (const int32_t*)keep(out->d_supp, nA1 * 4); A.sec = (const int32_t*)keep(out->d_secondary, nA1 * 4);
+  A.n0 = (const int32_t*)keep(out->d_n0, nA1 * 4); A.n1 = (const int32_t*)keep(out->d_n1, nA1 * 4); A.chrom = (const int32_t*)keep(out->d_chrom, nA1 * 4);
+  A.fval = (const float*)keep(out->d_first_sdp_value, nA1 * 4); A.rstat = (const int32_t*)keep(out->d_refine_status, nA1 * 4); A.value = (const float*)keep(out->d_value, nA1 * 4);
+  A.boff = (const uint64_t*)keep(out->d_block_off, (nA1 + 1) * 8); A.roff = (const uint64_t*)keep(out->d_run_off, (nA1 + 1) * 8);
+  A.counts = (const int32_t*)keep(out->d_counts, nA1 * 72); A.blocks = (const int32_t*)keep(out->d_blocks, nB1 * 12); A.runs = (const uint32_t*)keep(out->d_runs, nR1 * 4);
+  LRA_HIP_CHECK(ctx, hipStreamSynchronize(st));
+  std::vector<uint64_t> h_off;
+  if ((rc = dl(ctx, h_off, d_read_off, (size_t)R + 1))) return rc;
+  const int R2 = (int)sparse.size();
+  std::vector<uint32_t> pick(sparse.begin(), sparse.end()); std::vector<uint64_t> off2((size_t)R2 + 1, 0);
+  for (int i = 0; i < R2; i++) off2[i + 1] = off2[i] + (h_off[sparse[i] + 1] - h_off[sparse[i]]);
+  const uint64_t tot2 = off2[R2];
+  uint32_t* d_pick = up(ctx, 173, pick); uint64_t* d_off2 = up(ctx, 174, off2);
+  char* d_seq2 = (char*)lra_ensure(ctx, 172, tot2 + 128);
+  if (!d_pick || !d_off2 || !d_seq2) return LRA_ERR_NOMEM;
+  LRA_HIP_CHECK(ctx, hipMemsetAsync(d_seq2 + tot2, 0, 64, st));
+  hipLaunchKernelGGL(k_gather_reads, dim3(R2), dim3(64), 0, st, R2, (const uint32_t*)d_pick, d_read_off, d_seq, (const uint64_t*)d_off2, d_seq2);
+  lra_map_result o2;
+  if ((rc = highacc_core(ctx, R2, d_seq2, d_off2, tot2, o, &o2, true, nullptr, hsB, hrB))) return rc;
+  if (o2.num_aln != na) return lra_set_err(ctx, LRA_ERR_INVALID, "passes disagree on NumAln");
+  // ---- merge: slot (r, h) from pass B for the reads of the second batch, from pass A otherwise
+  std::vector<uint64_t> srcSlot(S);
+  std::vector<int> inB((size_t)R, -1);
+  for (int i = 0; i < R2; i++) inB[sparse[i]] = i;
+  for (int r = 0; r < R; r++)
+    for (int h = 0; h < na; h++) {
+      const size_t s = (size_t)r * na + h;
+      if (inB[r] >= 0) { srcSlot[s] = ((uint64_t)inB[r] * na + h) | FROM_B; hrA[s] = hrB[(size_t)inB[r] * na + h] ? (uint8_t)(hrB[(size_t)inB[r] * na + h] | 2) : 0; }   // bit 1: K = glIndex.k for SimpleMapQV
+      else srcSlot[s] = s;
+    }
+  for (int i = 0; i < R2; i++) hsA[sparse[i]] = hsB[i];
+  PassView B;
+  B.jo = o2.d_job_aln_off; B.strand = o2.d_strand; B.supp = o2.d_supp; B.sec = o2.d_secondary; B.n0 = o2.d_n0; B.n1 = o2.d_n1; B.chrom = o2.d_chrom; B.fval = o2.d_first_sdp_value;
+  B.boff = o2.d_block_off; B.blocks = o2.d_blocks; B.rstat = o2.d_refine_status; B.counts = o2.d_counts; B.value = o2.d_value; B.roff = o2.d_run_off; B.runs = o2.d_runs;
+  if (nA1 == 0) A.jo = nullptr;
+  if (o2.n_alignments == 0) B.jo = nullptr;
+  const uint64_t nA = nA1 + o2.n_alignments, nBk = nB1 + o2.n_blocks, nRn = nR1 + o2.n_runs;
+  uint64_t* d_src = up(ctx, 175, srcSlot);
+  char* mg = (char*)lra_ensure(ctx, 171, 2 * al256((S + 2) * 4) + al256((S + 2) * 8) + 12 * al256((nA + 2) * 4) + 3 * al256((nA + 2) * 8) + al256((nA + 1) * 72) + al256((nBk + 1) * 12) +
+                                        al256((nRn + 1) * 4) + 8192);
+  if (!d_src || !mg) return LRA_ERR_NOMEM;
+  auto take = [&](size_t bytes) { char* r_ = mg; mg += al256(bytes + 8); return r_; };
+  uint32_t* nAln = (uint32_t*)take((S + 1) * 4); uint64_t* JO = (uint64_t*)take((S + 1) * 8); uint32_t* jstat = (uint32_t*)take((S + 1) * 4);
+  LRA_HIP_CHECK(ctx, hipMemsetAsync(jstat, 0, (S + 1) * 4, st));
+  uint32_t* alnRead = (uint32_t*)take(nA * 4); int32_t* mstrand = (int32_t*)take(nA * 4); int32_t* msupp = (int32_t*)take(nA * 4); int32_t* msec = (int32_t*)take(nA * 4);
+  int32_t* mn0 = (int32_t*)take(nA * 4); int32_t* mn1 = (int32_t*)take(nA * 4); int32_t* mchrom = (int32_t*)take(nA * 4); float* mfval = (float*)take(nA * 4);
+  int32_t* mrstat = (int32_t*)take(nA * 4); float* mvalue = (float*)take(nA * 4); uint32_t* nb = (uint32_t*)take(nA * 4); uint32_t* nr = (uint32_t*)take(nA * 4);
+  uint64_t* srcAln = (uint64_t*)take(nA * 8); uint64_t* BO = (uint64_t*)take((nA + 1) * 8); uint64_t* RO = (uint64_t*)take((nA + 1) * 8);
+  int32_t* mcounts = (int32_t*)take(nA * 72); int32_t* mblocks = (int32_t*)take(nBk * 12); uint32_t* mruns = (uint32_t*)take(nRn * 4);
+  hipLaunchKernelGGL(k_merge_count, grid(S), dim3(256), 0, st, S, (const uint64_t*)d_src, A, B, nAln);
+  if ((rc = lra_exclusive_scan<uint32_t>(ctx, (long)S, nAln, JO))) return rc;
+  hipLaunchKernelGGL(k_merge_fields, grid(S), dim3(256), 0, st, S, na, (const uint64_t*)d_src, A, B, (const uint64_t*)JO, alnRead, mstrand, msupp, msec, mn0, mn1, mchrom, mfval, mrstat,
+                     mcounts, mvalue, srcAln, nb, nr);
+  if (nA) {
+    if ((rc = lra_exclusive_scan<uint32_t>(ctx, (long)nA, nb, BO)) || (rc = lra_exclusive_scan<uint32_t>(ctx, (long)nA, nr, RO))) return rc;
+    hipLaunchKernelGGL(k_merge_payload, dim3((unsigned)nA), dim3(64), 0, st, nA, (const uint64_t*)srcAln, A, B, (const uint64_t*)BO, (const uint64_t*)RO, mblocks, mruns);
+  } else { LRA_HIP_CHECK(ctx, hipMemsetAsync(BO, 0, 8, st)); LRA_HIP_CHECK(ctx, hipMemsetAsync(RO, 0, 8, st)); }
+  // the batch's strands buffer again (the second pass overwrote it with its own reads)
+  char* both = (char*)lra_ensure(ctx, 57, 2 * total_bases + 64);
+  uint8_t* job_reached = (uint8_t*)lra_ensure(ctx, 82, S + 64);
+  uint32_t* read_status = (uint32_t*)lra_ensure(ctx, 81, ((size_t)R + 1) * 4);
+  if (!both || !job_reached || !read_status) return LRA_ERR_NOMEM;
+  LRA_HIP_CHECK(ctx, hipMemcpyAsync(both, d_seq, total_bases, hipMemcpyDeviceToDevice, st));
+  LRA_HIP_CHECK(ctx, hipMemsetAsync(both + 2 * total_bases, 0, 64, st));
+  if ((rc = lra_create_rc_batch(ctx, R, d_seq, d_read_off, both + total_bases))) return rc;
+  LRA_HIP_CHECK(ctx, hipMemcpyAsync(job_reached, hrA.data(), S, hipMemcpyHostToDevice, st));
+  LRA_HIP_CHECK(ctx, hipMemcpyAsync(read_status, hsA.data(), (size_t)R * 4, hipMemcpyHostToDevice, st));
+  LRA_HIP_CHECK(ctx, hipStreamSynchronize(st));
+  LRA_HIP_CHECK(ctx, hipGetLastError());
+  memset(out, 0, sizeof *out);
+  out->n_reads = R; out->num_aln = na; out->n_jobs = S; out->n_alignments = nA; out->n_blocks = nBk; out->n_runs = nRn;
+  out->d_job_aln_off = JO; out->d_job_status = jstat; out->d_job_reached = job_reached; out->d_read_status = read_status;
+  out->d_aln_read = alnRead; out->d_strand = mstrand; out->d_supp = msupp; out->d_secondary = msec; out->d_n0 = mn0; out->d_n1 = mn1; out->d_chrom = mchrom;
+  out->d_first_sdp_value = mfval; out->d_block_off = BO; out->d_blocks = mblocks; out->d_refine_status = mrstat; out->d_counts = mcounts; out->d_value = mvalue;
+  out->d_run_off = RO; out->d_runs = mruns; out->d_strands = both; out->rc_base = total_bases;
+  out->counters = cntA;
+  out->counters.n_clusters += o2.counters.n_clusters; out->counters.n_cells += o2.counters.n_cells; out->counters.n_rows += o2.counters.n_rows;
+  out->counters.n_segments += o2.counters.n_segments; out->counters.n_a13_blocks += o2.counters.n_a13_blocks;
   return LRA_OK;
 }

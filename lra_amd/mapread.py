@@ -469,6 +469,7 @@ class HighAccMapper:
             self.index_stats = dict(n_index=len(k))
         cp = (C.c_uint64 * len(self.chrom_pos))(*self.chrom_pos)
         ctx.check(ctx.lib.lra_ctx_load_chromosomes(ctx.h, cp, len(self.chrom_pos) - 1))
+        ctx.check(ctx.lib.lra_ctx_build_local_index(ctx.h, m.localK, m.localW, m.localIndexWindow, m.localMaxFreq))     # glIndex: only the REFINEclusters branch reads it
         self.stats = {}
 
     def align(self, rbatch) -> MapResult:
@@ -482,6 +483,7 @@ class HighAccMapper:
         return res
 
     fetch = LowAccMapper.fetch
+    fetch_local_index = LowAccMapper.fetch_local_index
     records = LowAccMapper.records
     record_args = LowAccMapper.record_args
     snapshot = LowAccMapper.snapshot

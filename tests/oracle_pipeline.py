@@ -266,7 +266,7 @@ def map_reads_lowacc_mt(reads, off, first, n, genome: bytes, idx_key, idx_pos, g
 
 # ------------------------------------------------------------------------------------------------------------------------ MapRead_highacc
 # -CCS (lra.cpp:306-340) and -CONTIG (lra.cpp:268-305) over the defaults of Options.h:127-230
-CCS = dict(globalK=25, globalW=20, globalMaxFreq=150, localW=5, localMaxFreq=15, readType=2, refineBand=7, match=4, mismatch=-3, indel=-4, localBand=15, NumAln=2,
+CCS = dict(globalK=25, globalW=20, globalMaxFreq=150, localK=7, localW=5, localMaxFreq=15, localIndexWindow=256, window=100, readType=2, refineBand=7, match=4, mismatch=-3, indel=-4, localBand=15, NumAln=2,
            alnthres=0.7, initial_anchorbonus=10.0, second_anchorbonus=2.0, splitdist=50000, anchorstoosparse=0.005, merge_dist=100, gapopen=4.0, gapextend=15.0,
            gaproot=1.5, gapCeiling1=2000, gapCeiling2=3000, refineBreakpoint=False, skipBandedRefine=False,
            clean=dict(cleanMaxDiag=150, minDiagCluster=10, bypassClustering=0, cleanClustersize=100, SecondCleanMinDiagCluster=30, SecondCleanMaxDiag=100, punish_anchorfreq=10,
@@ -276,12 +276,13 @@ CONTIG = dict(CCS, globalK=19, globalW=10, globalMaxFreq=30, readType=3, refineB
               clean=dict(CCS["clean"], minDiagCluster=30), fine=dict(CCS["fine"], maxDiag=100, maxGap=500))
 
 
-def map_read_highacc(read: bytes, genome: bytes, idx_key, idx_pos, opts=None, chrom_pos=None, stats=True):
+def map_read_highacc(read: bytes, genome: bytes, idx_key, idx_pos, opts=None, chrom_pos=None, stats=True, g_index=None):
     """MapRead (MapRead.h:153-263) + MapRead_highacc (Map_highacc.h:37-798) for ONE read, composed from the oracle's stage functions.
     -> (groups, unaligned, note): groups = list over the chains h of Primary_chains[0] that have clusters (dict(h=, segs=[...])), every seg as in
     map_read_lowacc_py plus `stats` with the counters the reference's two CalculateStatistics calls leave (tdel, tins and the six size classes
-    accumulate over both, Alignment.h:440-512 / :85-86).  note = "sparse" for a read that takes the REFINEclusters branch (Map_highacc.h:429-447; not
-    composed here), "ub" where a stage reads outside an array; both come back with groups = None."""
+    accumulate over both, Alignment.h:440-512 / :85-86).  A read that takes the REFINEclusters branch (Map_highacc.h:413-447) needs g_index = (seqOffsets,
+    tupleBoundaries, tuples) of the genome's local index (note = "sparse" and groups = None without it); TRACE["sparse"] says which branch ran.  note = "ub"
+    where a stage reads outside an array."""
     o = dict(CCS)
     if opts:
         o.update(opts)
@@ -340,12 +341,32 @@ def map_read_highacc(read: bytes, genome: bytes, idx_key, idx_pos, opts=None, ch
         cl.append(dict(q=fc["q"][a:b].copy(), t=fc["t"][a:b].copy(), box=fc["box"][c].astype(np.int64), strand=int(fc["strand"][c]), chrom=int(fc["chrom"][c]),
                        freq=np.float32(fc["freq"][c])))
     # sparse (:413-416): a cluster with at most one anchor per 100 read bases on a read of at most 50 kb
-    for c in cl:
-        if np.float32(np.float32(len(c["q"])) / np.float32(int(c["box"][1]) - int(c["box"][0]))) <= np.float32(0.01) and L <= 50000:
+    sparse = any(np.float32(np.float32(len(c["q"])) / np.float32(int(c["box"][1]) - int(c["box"][0]))) <= np.float32(0.01) and L <= 50000 for c in cl)
+    TRACE["sparse"] = sparse
+    Kg = K                                                                # opts.globalK (REFINEclusters' second options argument)
+    if sparse:                                                            # :429-447: REFINEclusters; K, W = glIndex.k, glIndex.w from here on (:466-468)
+        if g_index is None:
             return None, False, "sparse"
-    for c in cl:                                                          # :449-460
-        off = CH[c["chrom"]]
-        c["t"] = c["t"] - np.uint32(off); c["box"][2] -= off; c["box"][3] -= off
+        q_index = [None, None]
+        for c in cl:
+            sd = c["strand"]
+            if q_index[sd] is None:
+                tup, bnd = O.local_index_seq(fwd if sd == 0 else rc, o["localK"], o["localW"], o["localIndexWindow"], o["localMaxFreq"])
+                q_index[sd] = (seq_offsets(L, o["localIndexWindow"]), bnd, tup)
+            rr = O.refine_cluster(c["q"], c["t"], c["box"], sd, CH, L, q_index[sd], g_index, window=o["window"], smallK=o["localK"], K=Kg, max_freq=o["localMaxFreq"])
+            if rr is None:
+                return None, False, "ub"
+            if rr == "rejected":
+                c["q"] = np.zeros(0, np.uint32); c["t"] = np.zeros(0, np.uint32)
+            else:
+                c["q"], c["t"], c["box"], c["chrom"] = rr["q"], rr["t"], rr["box"].astype(np.int64), rr["chrom"]
+        K, W = o["localK"], o["localW"]
+        for h in chains:                                                  # :475-487 (`link` keeps its length)
+            h["ch"] = [ci for ci in h["ch"] if len(cl[ci]["q"])]
+    else:
+        for c in cl:                                                      # :449-460
+            off = CH[c["chrom"]]
+            c["t"] = c["t"] - np.uint32(off); c["box"][2] -= off; c["box"][3] -= off
     if not chains:
         return [], True, None
     # a11 caller (:515-520)
