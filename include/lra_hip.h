@@ -845,6 +845,19 @@ typedef struct lra_hsplit_result {
 int lra_split_chains_highacc_batch(lra_ctx* ctx, uint64_t n_jobs, const uint64_t* d_job_off, uint64_t n_elems, const int32_t* d_strand, const int32_t* d_chrom,
                                    const uint32_t* d_box, const uint64_t* d_link_off, const uint8_t* d_link, int splitdist, lra_hsplit_result* out);
 
+/* ---- GlobalChain / PrioritySearchTree (named by the path's description; not reachable from lra.cpp) -------------------------------------------
+ * Replaces   int GlobalChain(vector<Fragment>& fragments, vector<int>& optFragmentChainIndices, vector<Endpoint>& endpoints)   (GlobalChain.h:85-189,
+ *            PrioritySearchTree.h; called by TestGlobalChain.cpp:17 only)
+ * for n_sets independent fragment sets: set s = fragments d_off[s] .. d_off[s+1] (xl, yl, xh, yh, initial score -- TestGlobalChain.cpp:14 uses xh - xl).
+ * Output (context-owned): per fragment its final score and prev (index inside the set, -1 = none); per set the optimal chain's fragment indices
+ * d_chain[d_off[s] .. d_off[s] + d_chain_len[s]).  Synchronous.                                                                                  */
+typedef struct lra_global_chain_result {
+  uint64_t n_sets, n_fragments;
+  const int32_t* d_score; const int32_t* d_prev; const int32_t* d_chain; const uint32_t* d_chain_len;
+} lra_global_chain_result;
+int lra_global_chain_batch(lra_ctx* ctx, uint64_t n_sets, const uint64_t* d_off, uint64_t n_fragments, const int32_t* d_xl, const int32_t* d_yl, const int32_t* d_xh,
+                           const int32_t* d_yh, const int32_t* d_score, lra_global_chain_result* out);
+
 /* ---- a13 helper (high-accuracy path): SwitchToOriginalAnchors ------------------------------------------------------------------------
  * Replaces   SwitchToOriginalAnchors(finalchain, ultimatechain, ExtendClusters, extend_clusters)      (LocalRefineAlignment.h:187-199, :576)
  * for n_chains chains over Cluster_SameDiag entries: chain c = elements d_chain_off[c] .. d_chain_off[c+1], element i = entry d_elem_entry[i]

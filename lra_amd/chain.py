@@ -370,3 +370,15 @@ def fetch_hsplit(ctx: Context, res: HSplitResult):
             "sptc": ctx.to_host(res.d_sptc, ne, np.uint32), "type": ctx.to_host(res.d_piece_type, npc, np.uint8), "strand": ctx.to_host(res.d_piece_strand, npc, np.uint8),
             "box": ctx.to_host(res.d_piece_box, 4 * npc, np.uint32).reshape(-1, 4), "job": ctx.to_host(res.d_piece_job, npc, np.uint32),
             "lsc": ctx.to_host(res.d_job_lsc, nj, np.uint32)}
+
+
+class GlobalChainResult(C.Structure):
+    _fields_ = [("n_sets", C.c_uint64), ("n_fragments", C.c_uint64)] + [(n, C.c_void_p) for n in ("d_score", "d_prev", "d_chain", "d_chain_len")]
+
+
+def global_chain_batch(ctx: Context, off, xl, yl, xh, yh, score):
+    """GlobalChain (GlobalChain.h:85) over fragment sets in CSR; array arguments are device tensors (off int64, the rest int32)."""
+    res = GlobalChainResult()
+    ctx.check(ctx.lib.lra_global_chain_batch(ctx.h, C.c_uint64(int(off.numel()) - 1), ptr(off), C.c_uint64(int(xl.numel())), ptr(xl), ptr(yl), ptr(xh), ptr(yh), ptr(score),
+                                             C.byref(res)))
+    return res

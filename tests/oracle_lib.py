@@ -211,6 +211,18 @@ def split_chain_highacc(strand, chrom, box, link, splitdist=100000):
     return dict(off=off[:k + 1], idx=idx[:off[k]], type=ty[:k], strand=ss[:k], box=ob[:4 * k].reshape(-1, 4), lsc=lsc.value)
 
 
+def global_chain(fragments, score=None):
+    """GlobalChain (GlobalChain.h:85-189) on one fragment set [[xl, yl, xh, yh], ...] -> (chain, score, prev); score defaults to xh - xl (TestGlobalChain.cpp:14)"""
+    L = lib()
+    f = np.ascontiguousarray(np.asarray(fragments, np.int32).reshape(-1, 4))
+    n = len(f)
+    xl, yl, xh, yh = (np.ascontiguousarray(f[:, k]) for k in range(4))
+    sc = np.ascontiguousarray(xh - xl if score is None else score, np.int32).copy()
+    pv = np.zeros(max(1, n), np.int32); ch = np.zeros(max(1, n), np.int32)
+    k = L.oracle_global_chain(C.c_int(n), _p(xl, C.c_int), _p(yl, C.c_int), _p(xh, C.c_int), _p(yh, C.c_int), _p(sc, C.c_int), _p(pv, C.c_int), _p(ch, C.c_int))
+    return ch[:k].tolist(), sc[:n].tolist(), pv[:n].tolist()
+
+
 class FineOpts(C.Structure):
     _fields_ = [(n, C.c_int) for n in ("globalK", "RoughClustermaxGap", "maxDiag", "maxGap", "minClusterSize", "minUniqueStretchNum", "minUniqueStretchDist")]
 
