@@ -218,3 +218,34 @@ extern "C" void oracle_antiqsort(int n, uint64_t* vals_out) {
   std::sort(ptr.begin(), ptr.end(), [&](int x, int y) { return a.less(x, y); });
   for (int i = 0; i < n; i++) vals_out[i] = (uint64_t)a.val[i];
 }
+
+// The k-mer stepping of oracle_store_minimizers on its own (StoreTuple + TupleRC for the first k-mer, ShiftOne / ShiftOneRC after, the canonical key of
+// MinCount.h:60-61) and CreateRC (SeqUtils.h:151-158): PINNED to the reference's TupleOps.h / SeqUtils.h (ref_harness/tuple_ops_ref.cpp ->
+// tests/golden/tuple_ops_golden.json).  out: 3 words per k-mer (forward, reverse complement, key); rc_out: the reverse complement of seq.
+extern "C" long oracle_kmer_stream(const char* seq, long n, int k, uint64_t* out, char* rc_out) {
+  static const char* RC = nullptr;
+  static char table[256];
+  if (!RC) {
+    memset(table, 'N', 256);
+    table[(int)'A'] = 'T'; table[(int)'C'] = 'G'; table[(int)'G'] = 'C'; table[(int)'T'] = 'A';
+    table[(int)'a'] = 't'; table[(int)'c'] = 'g'; table[(int)'g'] = 'c'; table[(int)'t'] = 'a'; table[(int)'n'] = 'n';
+    RC = table;
+  }
+  for (long i = 0; i < n; i++) rc_out[n - i - 1] = RC[(unsigned char)seq[i]];
+  if (n < k) return 0;
+  const uint64_t kmask = (k >= 32) ? ~0ULL : ((1ULL << (2 * k)) - 1);
+  uint64_t cur = 0, rc = 0;
+  for (int p = 0; p < k; p++) cur = (cur << 2) + (uint64_t)oracle_code((unsigned char)seq[p]);
+  { uint64_t a = cur; for (int i = 0; i < k; i++) { rc = (rc << 2) + ((~a) & 3ULL); a >>= 2; } }
+  long m = 0;
+  for (long p = 0; p + k <= n; p++) {
+    if (p > 0) {
+      const uint64_t c = (uint64_t)oracle_code((unsigned char)seq[p + k - 1]);
+      cur = ((cur << 2) & kmask) + c;
+      rc = (rc >> 2) + (((~c) & 3ULL) << (2 * ((uint64_t)k - 1)));
+    }
+    out[3 * m] = cur; out[3 * m + 1] = rc; out[3 * m + 2] = ((cur & FOR_MASK) < (rc & FOR_MASK)) ? (cur & FOR_MASK) : (rc | REV_MASK);
+    m++;
+  }
+  return m;
+}
