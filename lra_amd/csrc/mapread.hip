@@ -12,6 +12,7 @@
 #include "seed_state.h"
 #include "scan.h"
 #include "map_state.h"
+#include <chrono>
 #include <math.h>
 #include <stdlib.h>
 #include <algorithm>
@@ -376,20 +377,30 @@ extern "C" int lra_map_reads_lowacc_batch(lra_ctx* ctx, int n_reads, const char*
   const char* genome = (const char*)ctx->seed->genome;
   const uint64_t tot = total_bases;
   int rc;
+  // LRA_STAGE_DBG=1: wall time of every stage call (device work + the host-side sizing round trips around it)
+  const bool sdbg = getenv("LRA_STAGE_DBG") != nullptr;
+  auto wall = []() { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+  double t_prev = 0;
+  if (sdbg) { (void)hipStreamSynchronize(st); t_prev = wall(); }
+  auto stage = [&](const char* name) { if (!sdbg) return; (void)hipStreamSynchronize(st); const double t = wall(); fprintf(stderr, "[stage] %-28s %8.1f ms\n", name, t - t_prev); t_prev = t; };
   // a1-a4
   lra_seed_result sres;
   if ((rc = lra_seed_batch(ctx, n_reads, d_seq, d_read_off, o->globalK, o->globalW, o->globalMaxFreq, &sres))) return rc;
+  stage("seed");
   // a5, a7
   lra_cluster_result cres;
   if ((rc = lra_clean_matches_batch(ctx, &o->clean, CH, nCh, &cres))) return rc;
+  stage("clean");
   lra_extend_result eres;
   if ((rc = lra_linear_extend_batch(ctx, o->globalK, d_seq, d_read_off, &eres))) return rc;
+  stage("linear_extend");
   // a8: the primary chains (Map_lowacc.h:184-188); match_rate = 3 for reads with a repetitive cluster (:86-89)
   const float* match_rate = nullptr;
   if ((rc = lra_match_rate_batch(ctx, &cres, o->sdp.rate, &match_rate))) return rc;
   lra_chain_result chres;
   if ((rc = lra_sparse_dp_batch(ctx, n_reads, cres.d_cluster_off, eres.d_e_start, eres.d_e_count, cres.d_c_strand, eres.d_e_qpos, eres.d_e_tpos, eres.d_e_len,
                                 d_read_off, match_rate, &o->sdp, &chres))) return rc;
+  stage("sdp#A");
   const int num_aln = chres.num_aln;
   const uint64_t n_slots = (uint64_t)n_reads * (uint64_t)num_aln;
   hipLaunchKernelGGL(k_or_status_div, grid(n_reads), dim3(256), 0, st, (uint64_t)n_reads, chres.d_status, 1, read_status);
@@ -400,6 +411,7 @@ extern "C" int lra_map_reads_lowacc_batch(lra_ctx* ctx, int n_reads, const char*
   // a9
   lra_split_result spres;
   if ((rc = lra_split_chains_batch(ctx, &chres, CH, nCh, o->splitdist, o->bypassClustering, &spres))) return rc;
+  stage("split_chains");
   hipLaunchKernelGGL(k_or_status_div, grid(n_slots), dim3(256), 0, st, n_slots, spres.d_status, num_aln, read_status);
   // a10: the reads forward, then reverse complemented, in one buffer + its local index (Map_lowacc.h:246-250)
   char* both = (char*)lra_ensure(ctx, 57, 2 * tot + 64);
@@ -417,9 +429,11 @@ extern "C" int lra_map_reads_lowacc_batch(lra_ctx* ctx, int n_reads, const char*
                      spres.d_sp_strand, spres.d_status, active);
   lra_local_index_result rli;
   if ((rc = lra_local_index_masked_batch(ctx, 2 * n_reads, both, off2, active, o->localK, o->localW, o->localIndexWindow, o->localMaxFreq, &rli))) return rc;
+  stage("read local index");
   lra_rsc_opts ro; ro.window = o->window; ro.smallK = o->localK; ro.K = o->globalK; ro.limitrefine = 1; ro.max_freq = o->localMaxFreq; ro.local_window = o->localIndexWindow;
   lra_refined_result rres;
   if ((rc = lra_refine_splitchain_batch(ctx, &chres, &spres, d_read_off, CH, nCh, &rli, m->n_gwin, m->d_gso, m->gli.d_tuple_bnd, m->gli.d_tuples, &ro, &rres))) return rc;
+  stage("refine_splitchain");
   uint64_t task_words = 0;
   if (rres.n_tasks) {
     unsigned long long* d_sum = (unsigned long long*)lra_scratch(ctx, 3, 256);
@@ -435,9 +449,11 @@ extern "C" int lra_map_reads_lowacc_batch(lra_ctx* ctx, int n_reads, const char*
   bo.match = o->localMatch; bo.mismatch = o->localMismatch; bo.indel = o->localIndel; bo.max_freq = o->localMaxFreq;
   lra_btwn_result bres;
   if ((rc = lra_refine_btwn_splitchain_batch(ctx, &chres, &spres, &rres, d_read_off, both, tot, genome, CH, nCh, &bo, &bres))) return rc;
+  stage("refine_btwn_splitchain");
   // a9 MergeChain, a7 second pass, a8 second sparse DP (Map_lowacc.h:411-540)
   lra_merge_result mres;
   if ((rc = lra_merge_extend_batch(ctx, &chres, &spres, &bres, d_seq, d_read_off, genome, CH, nCh, o->localK, &mres))) return rc;
+  stage("merge_extend");
   uint8_t* job_reached = (uint8_t*)lra_ensure(ctx, 82, n_slots + 64);
   if (!job_reached) return LRA_ERR_NOMEM;
   hipLaunchKernelGGL(k_job_reached, grid(n_slots), dim3(256), 0, st, n_slots, num_aln, chres.d_n_chains, chres.d_chain_start, spres.d_n_split, spres.d_status,
@@ -448,10 +464,12 @@ extern "C" int lra_map_reads_lowacc_batch(lra_ctx* ctx, int n_reads, const char*
   lra_chain_result ch2;
   if ((rc = lra_sparse_dp_batch(ctx, (int)mres.n_groups, mres.d_iota, mres.d_anchor_off, mres.d_count, mres.d_strand, mres.d_q, mres.d_t, mres.d_len, mres.d_iota,
                                 nullptr, &s2, &ch2))) return rc;
+  stage("sdp#2");
   if (mres.n_groups) hipLaunchKernelGGL(k_or_status_idx, grid(mres.n_groups), dim3(256), 0, st, mres.n_groups, ch2.d_status, mres.d_group_slot, num_aln, read_status);
   // a13
   lra_local_refine_inputs inp;
   if ((rc = lra_local_refine_inputs_batch(ctx, num_aln, slot_n0, &mres, &ch2, &inp))) return rc;
+  stage("local_refine_inputs");
   lra_lra_opts lo; lo.localW = o->localW; lo.globalW = o->localW; lo.localMaxFreq = o->localMaxFreq; lo.match = o->localMatch; lo.mismatch = o->localMismatch;
   lo.indel = o->localIndel; lo.localBand = o->localBand; lo.refineBySDP = 1; lo.isOnt = (o->readType == LRA_READ_ONT || o->readType == LRA_READ_CLR) ? 1 : 0;
   lo.gapopen = o->sdp.gapopen; lo.gapextend = o->sdp.gapextend; lo.gaproot = o->sdp.gaproot; lo.gapCeiling1 = o->sdp.gapCeiling1; lo.gapCeiling2 = o->sdp.gapCeiling2;
@@ -459,6 +477,7 @@ extern "C" int lra_map_reads_lowacc_batch(lra_ctx* ctx, int n_reads, const char*
   if ((rc = lra_local_refine_batch(ctx, inp.n_jobs, inp.d_job_chain_off, inp.d_job_read, inp.d_job_h, inp.n_chains, inp.d_chain_anchor_off, inp.d_chain_strand,
                                    inp.d_chain_chrom, inp.d_chain_value, inp.d_chain_n0, inp.d_chain_n1, inp.n_anchors, inp.d_q, inp.d_t, inp.d_len, d_read_off,
                                    both, tot, genome, CH, nCh, &lo, &ares))) return rc;
+  stage("local_refine");
   const uint64_t nA = ares.n_alignments, nJ = ares.n_jobs;
   if (nJ) hipLaunchKernelGGL(k_or_status_div, grid(nJ), dim3(256), 0, st, nJ, ares.d_status, num_aln, read_status);
   // a14, a16 on every SegAlignment (Map_lowacc.h:582-599)
@@ -485,8 +504,10 @@ extern "C" int lra_map_reads_lowacc_batch(lra_ctx* ctx, int n_reads, const char*
       hipLaunchKernelGGL(k_or_status_idx, grid(nA), dim3(256), 0, st, nA, (const uint32_t*)keep, aln_read, 1, read_status);
     }
     if (o->refineBreakpoint && (rc = lra_refine_breakpoints(ctx, nJ, nA, ares.d_job_aln_off, ares.d_strand, q_off, q_len, t_off, t_len, both, genome, &fres))) return rc;
+    stage("indel_refine (+breakpoints)");
     if ((rc = lra_calculate_statistics_batch(ctx, (int)nA, fres.d_blocks, fres.d_block_off, both, q_off, q_len, genome, t_off, m->lut.data(), (int)m->lut.size(), &tres)))
       return rc;
+    stage("statistics");
   }
   LRA_HIP_CHECK(ctx, hipStreamSynchronize(st));
   LRA_HIP_CHECK(ctx, hipGetLastError());

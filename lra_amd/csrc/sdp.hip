@@ -534,6 +534,7 @@ struct ProcArgs {
   const ReadArena* ra; uint32_t* poolUsed;
   uint32_t* status;
   PwlTab pwl;
+  char* wgScratch; const uint64_t* wgOff;   // sdp_process_wg: per large read, the anchors' (best predecessor, contributions) words and the points' ranks
 };
 
 // w(i, j) = -PWL_w(|j - i| + 1)   (SubRountine.h:101-129).  upper_bound over STOPS[0..24) as a count of constants <= x.
@@ -888,20 +889,21 @@ __global__ void __launch_bounds__(64) sdp_process(ProcArgs a) {
 // ---- the same for LARGE reads: one 1024-thread workgroup per read, the (family pair, level) slots spread over its 16 waves.
 // A read from a satellite array gives tens of thousands of anchors on a lattice of tied rows / columns / diagonals; with one wave per read the
 // owners of a start point's insertions take turns (phase 1b above) and every turn is a chain of dependent memory round trips: 44 k points took
-// 1.2 s, the whole launch waiting for that one wave.  Here wave w owns the slots w, w + 16, w + 32: every sub-problem still sees exactly the
-// deposits and queries it sees above, in the same order (a sub-problem belongs to one slot, a slot to one wave), the waves meet at every start
-// point for the (max value, first in visit order) reduction over the slots, and Value[] is written before anyone reads it again (an anchor's
-// end point comes after its start point).  Insertions always run wave-cooperatively (the code of phase 1b with the owner's state uniform).
+// 1.2 s, the whole launch waiting for that one wave.  Here wave w owns the slots w and w + 16: every sub-problem still sees exactly the deposits
+// and queries it sees above, in the same order (a sub-problem belongs to one slot, a slot to one wave).  The waves do NOT meet at the points:
+// each runs through all points for its own slots.  What couples them is Value[] only -- a start point's candidates from all slots are reduced
+// to (max value, first in visit order), and an end point deposits its anchor's value.  So a start point's wave folds its slots' candidates
+// into one 64-bit word per (anchor, start point) with atomicMax (value bits high, ~visit rank low: the maximum IS the reference's choice) and
+// counts itself in; an end point's wave waits until all 16 waves are counted in for the start points of that anchor that precede it (always
+// earlier in every wave's sequence, so the wave that is furthest behind never waits), then takes the value.  fval / prev are written once at
+// the end.  The critical path is the busiest wave's own work instead of (slowest wave + two barriers + a serial reduction) per point.
 struct SlotState { Node cn; uint32_t cId; int2 cTop, cLastB; int cTopOk; };
 constexpr int WG_NW = 16;
 
 __global__ void __launch_bounds__(64 * WG_NW) sdp_process_wg(ProcArgs a) {
   __shared__ float s_slope[25], s_inter[25];
   __shared__ SlotState ss[2 * LV];
-  __shared__ float s_ev[2 * LV];
-  __shared__ uint32_t s_i1[2 * LV];
-  __shared__ uint32_t s_node[2 * LV];
-  __shared__ uint32_t s_bad;
+  __shared__ volatile uint32_t s_bad;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   if (tid < 25) { s_slope[tid] = a.pwl.slope[tid]; s_inter[tid] = a.pwl.inter[tid]; }
   if (tid < 2 * LV) {
@@ -925,11 +927,35 @@ __global__ void __launch_bounds__(64 * WG_NW) sdp_process_wg(ProcArgs a) {
   const uint32_t poolPair = A.poolPair, poolPairs = A.poolPairs;
   uint32_t* poolUsed = a.poolUsed + rr;
   const uint2* visR = (const uint2*)(ab + A.visOff);
-  constexpr int SPW = (2 * LV + WG_NW - 1) / WG_NW;                       // slots per wave (3)
+  // ---- per anchor: best[2] (one word per start point: value bits << 32 | ~visit rank; 0 = no candidate), cnt[2] (waves counted in), nS, sPos[2];
+  // per point: rank = how many start points of its anchor precede it
+  const int F = (int)(a.fragOff[r + 1] - f0);
+  char* wsb = a.wgScratch + a.wgOff[blockIdx.x];
+  unsigned long long* best = (unsigned long long*)wsb;
+  uint32_t* cnt = (uint32_t*)(wsb + 16 * (size_t)F);
+  uint32_t* nS = cnt + 2 * (size_t)F;
+  uint32_t* sPos = nS + F;
+  uint8_t* rank = (uint8_t*)(sPos + 2 * (size_t)F);
+  for (int f = tid; f < F; f += 64 * WG_NW) { best[2 * f] = 0; best[2 * f + 1] = 0; cnt[2 * f] = 0; cnt[2 * f + 1] = 0; nS[f] = 0; sPos[2 * f] = 0; sPos[2 * f + 1] = 0; }
+  __syncthreads();
+  for (int pi = tid; pi < P; pi += 64 * WG_NW)
+    if (a.hfl[p0 + pi] & 1) { const uint32_t lf = a.hfr[p0 + pi]; const uint32_t k = atomicAdd(&nS[lf], 1u); if (k < 2) sPos[2 * lf + k] = (uint32_t)pi; else s_bad = LRA_ST_RANGE; }
+  __syncthreads();
+  for (int f = tid; f < F; f += 64 * WG_NW) if (nS[f] == 2 && sPos[2 * f] > sPos[2 * f + 1]) { const uint32_t t = sPos[2 * f]; sPos[2 * f] = sPos[2 * f + 1]; sPos[2 * f + 1] = t; }
+  __syncthreads();
+  for (int pi = tid; pi < P; pi += 64 * WG_NW) {
+    const uint32_t lf = a.hfr[p0 + pi];
+    int k = 0;
+    for (uint32_t x = 0; x < min(nS[lf], 2u); x++) k += sPos[2 * lf + x] < (uint32_t)pi;
+    rank[pi] = (uint8_t)k;
+  }
+  __threadfence();
+  __syncthreads();
+  constexpr int SPW = (2 * LV + WG_NW - 1) / WG_NW;                       // slots per wave
   uint2 vN[SPW]; uint8_t flN = P > 0 ? a.hfl[p0] : 0; uint32_t lfN = P > 0 ? a.hfr[p0] : 0;
 #pragma unroll
   for (int k = 0; k < SPW; k++) { const int slot = wave + k * WG_NW; vN[k] = (P > 0 && slot < 2 * LV) ? visR[slot] : make_uint2(NONE, 0); }
-  for (int pi = 0; pi < P; pi++) {
+  for (int pi = 0; pi < P && !s_bad; pi++) {
     const uint8_t fl = flN;
     const uint32_t lf = lfN;
     uint2 vv[SPW];
@@ -952,6 +978,24 @@ __global__ void __launch_bounds__(64 * WG_NW) sdp_process_wg(ProcArgs a) {
       }
     }
     wave_sync();
+    float depVal = 0.f;
+    if (!ind) {                                                          // an end point: its anchor's value, once every wave has been through its start points
+      bool any = false;
+#pragma unroll
+      for (int k = 0; k < SPW; k++) any |= act[k];
+      if (!any) continue;
+      if (lane == 0) {
+        const int need = rank[pi];
+        depVal = a.fval[f0 + lf];
+        for (int x = 0; x < need; x++) {
+          // (relaxed loads served by L2: an acquire would invalidate the CU's vector cache under all 16 waves at every end point)
+          while (__hip_atomic_load(&cnt[2 * lf + x], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < (uint32_t)WG_NW && !s_bad) __builtin_amdgcn_s_sleep(2);
+          const unsigned long long key = __hip_atomic_load(&best[2 * lf + x], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          const float v = __uint_as_float((uint32_t)(key >> 32));
+          if (key && depVal < v) depVal = v;
+        }
+      }
+    }
     if (ind) {
 #pragma unroll
       for (int k = 0; k < SPW; k++) {
@@ -965,16 +1009,17 @@ __global__ void __launch_bounds__(64 * WG_NW) sdp_process_wg(ProcArgs a) {
         }
       }
     }
+    float wBest = -2.f; int wRank = 0;                                   // this wave's best candidate of the point and its visit rank
 #pragma unroll
     for (int k = 0; k < SPW; k++) {
       const int slot = wave + k * WG_NW;
       if (slot >= 2 * LV) continue;
       const uint2 v = vv[k];
-      if (!act[k]) { if (ind && lane == 0) s_ev[slot] = -2.f; continue; }
+      if (!act[k]) continue;
       const Node nd = ss[slot].cn;
       if (ind == 0) {                                                    // PassValueToD1/D2
         if (lane == 0) {
-          const float val = a.fval[f0 + lf];
+          const float val = depVal;
           const uint32_t e = nd.dBase + v.y;
           if (ent[e].v < val) { ent[e].v = val; Ap[e] = lf; }
         }
@@ -1087,33 +1132,46 @@ __global__ void __launch_bounds__(64 * WG_NW) sdp_process_wg(ProcArgs a) {
       }
 #undef SPUSH
 #undef BPUSH
-      if (lane == 0) {
-        if (ost) atomicOr(&s_bad, ost);
-        s_ev[slot] = ev; s_i1[slot] = (uint32_t)i1; s_node[slot] = v.x;
-      }
+      if (ost && lane == 0) s_bad = s_bad | ost;
+      // Value[ii]: visits apply in the order R family deepest level first, then C family; `val < Ev` keeps the first maximum
+      const int vr = (slot / LV) * LV + (LV - 1 - slot % LV);
+      if (ev > 0.f && (ev > wBest || (ev == wBest && vr < wRank))) { wBest = ev; wRank = vr; }
     }
     wave_sync();
-    if (ind) {
-      __syncthreads();
-      // Value[ii]: visits apply in the order R family deepest level first, then C family; `val < Ev` keeps the first maximum
-      if (tid == 0 && !s_bad) {
-        float bv = -1.f; int bs = -1;
-        for (int o = 0; o < 2 * LV; o++) {
-          const int fam2 = o / LV, level = LV - 1 - (o % LV);
-          const int slot = fam2 * LV + level;
-          const float e = s_ev[slot];
-          if (e > -1.5f && e > bv) { bv = e; bs = slot; }
-        }
-        if (bs >= 0 && a.fval[f0 + lf] < bv) {
-          a.fval[f0 + lf] = bv; a.fprevNode[f0 + lf] = s_node[bs]; a.fprevInd[f0 + lf] = s_i1[bs];
-          a.fflags[f0 + lf] = (uint8_t)((bs < LV ? 1 : 0) | (inv ? 2 : 0));
-        }
+    if (ind && lane == 0) {
+      const int x = rank[pi];                                             // which start point of the anchor this is
+      // the candidate is at L2 before the wave counts itself in: the count's operand depends on the max's return value
+      uint32_t one = 1u;
+      if (wBest > 0.f) {
+        const unsigned long long was = __hip_atomic_fetch_max(&best[2 * lf + x], ((unsigned long long)__float_as_uint(wBest) << 32) | (unsigned long long)(0xFFFFFFFFu - (uint32_t)wRank),
+                                                              __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        one += (uint32_t)(was == 0xFFFFFFFFFFFFFFFFull);                   // never true: a key's low word is below 2^32 - 1 only ... (value bits of a finite float are not all ones)
       }
-      __syncthreads();
-      if (s_bad) break;
+      (void)__hip_atomic_fetch_add(&cnt[2 * lf + x], one, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
   }
-  if (tid == 0 && s_bad) atomicOr(&a.status[r], s_bad);
+  __syncthreads();
+  // Value[], prev: per anchor the start points in order, `val < Ev` (strict) at each
+  if (!s_bad) {
+    for (int f = tid; f < F; f += 64 * WG_NW) {
+      float val = a.fval[f0 + f];
+      int win = -1; unsigned long long wkey = 0;
+      for (uint32_t x = 0; x < min(nS[f], 2u); x++) {
+        const unsigned long long key = best[2 * f + x];
+        const float v = __uint_as_float((uint32_t)(key >> 32));
+        if (key && val < v) { val = v; win = (int)x; wkey = key; }
+      }
+      if (win >= 0) {
+        const int vr = (int)(0xFFFFFFFFu - (uint32_t)wkey);
+        const int slot = (vr / LV) * LV + (LV - 1 - vr % LV);
+        const uint32_t pi = sPos[2 * f + win];
+        const uint2 v = visR[(uint64_t)pi * (2 * LV) + slot];
+        a.fval[f0 + f] = val; a.fprevNode[f0 + f] = v.x; a.fprevInd[f0 + f] = v.y;
+        a.fflags[f0 + f] = (uint8_t)((slot < LV ? 1 : 0) | (((a.hfl[p0 + pi] >> 1) & 1) ? 2 : 0));
+      }
+    }
+  }
+  if (tid == 0 && s_bad) atomicOr(&a.status[r], (uint32_t)s_bad);
 #undef W
 }
 
@@ -1480,6 +1538,7 @@ int sdp_run(lra_ctx* ctx, int n_reads, const uint64_t* d_cluster_off, const uint
       if (att > 0)
         hipLaunchKernelGGL(k_reset_frags, dim3(nsub), dim3(64), 0, st, r0, subOrder, fragOff, flen, d_rate, opts->rate, fval, fprevNode, fprevInd, fflags, status);
       ProcArgs pa;
+      pa.wgScratch = nullptr; pa.wgOff = nullptr;
       pa.r0 = r0; pa.n = nsub; pa.order = subOrder; pa.ptOff = ptOff; pa.fragOff = fragOff; pa.hfl = hfl; pa.hfr = hfr; pa.flen = flen; pa.fval = fval;
       pa.fprevNode = fprevNode; pa.fprevInd = fprevInd; pa.fflags = fflags; pa.rate_in = d_rate; pa.rate = opts->rate; pa.ra = ra;
       pa.status = status; pa.pwl = pw; pa.poolUsed = poolUsed;
@@ -1496,6 +1555,21 @@ int sdp_run(lra_ctx* ctx, int n_reads, const uint64_t* d_cluster_off, const uint
       }
       lra_time_begin(ctx, ctx->sdp_inner ? "sdp_inner_process" : "sdp_process");
       // the few large reads (a workgroup each) run beside the many small ones (a wave each) instead of in front of them
+      if (nbig > 0) {                                                      // the large reads' per-anchor words (see sdp_process_wg)
+        const std::vector<uint32_t>& ord = att == 0 ? h_orderAll : h_prev;
+        std::vector<uint64_t> woff((size_t)nbig + 1, 0);
+        for (int i = 0; i < nbig; i++) {
+          const uint64_t rdx = (uint64_t)r0 + ord[i];
+          const uint64_t Fr = h_frag[rdx + 1] - h_frag[rdx], Pr = h_pt[rdx + 1] - h_pt[rdx];
+          woff[i + 1] = woff[i] + ((36 * Fr + Pr + 64 + 255) & ~(uint64_t)255);
+        }
+        char* wsc = (char*)lra_ensure(ctx, 177, woff[nbig] + 256);
+        uint64_t* dwoff = (uint64_t*)lra_ensure(ctx, 178, ((size_t)nbig + 2) * 8);
+        if (!wsc || !dwoff) return LRA_ERR_NOMEM;
+        LRA_HIP_CHECK(ctx, hipMemcpyAsync(dwoff, woff.data(), ((size_t)nbig + 1) * 8, hipMemcpyHostToDevice, st));
+        LRA_HIP_CHECK(ctx, hipStreamSynchronize(st));                      // (woff is a host temporary)
+        pa.wgScratch = wsc; pa.wgOff = dwoff;
+      }
       const bool forked = nbig > 0 && nsub > nbig;
       if (nbig > 0) hipLaunchKernelGGL(sdp_process_wg, dim3(nbig), dim3(64 * WG_NW), 0, forked ? lra_side_fork(ctx) : st, pa);
       if (nsub > nbig) { ProcArgs pb = pa; pb.order = subOrder + nbig; pb.n = nsub - nbig; hipLaunchKernelGGL(sdp_process, dim3(nsub - nbig), dim3(64), 0, st, pb); }
