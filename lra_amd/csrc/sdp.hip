@@ -236,12 +236,30 @@ struct BuildArgs {
   uint32_t* status;
 };
 
-template <bool EMIT>
-__global__ void __launch_bounds__(64, 8) sdp_build(BuildArgs a) {
-  const int rr = (int)a.order[blockIdx.x], r = a.r0 + rr, lane = threadIdx.x;
+// NW = waves per read: 1 (a wave per read) or 16 (a 1024-thread workgroup per LARGE read: every pass over the read's points is spread over the block, the
+// wave scans become block scans through LDS; the same arithmetic, the same tables).
+template <int NW>
+__device__ __forceinline__ int blk_incl_scan(int v, int lane, int wave, int* s_w, int& total) {
+  const int inc = wave_incl_scan(v, lane);
+  if (NW == 1) { total = __shfl(inc, 63); return inc; }
+  if (lane == 63) s_w[wave] = inc;
+  __syncthreads();
+  int pre = 0, tot = 0;
+#pragma unroll
+  for (int w = 0; w < NW; w++) { const int x = s_w[w]; tot += x; if (w < wave) pre += x; }
+  __syncthreads();
+  total = tot;
+  return inc + pre;
+}
+template <bool EMIT, int NW>
+__global__ void __launch_bounds__(64 * NW, NW == 1 ? 8 : 1) sdp_build(BuildArgs a) {
+  constexpr int NT = 64 * NW;
+  __shared__ int s_w[4][NW == 1 ? 1 : NW];
+  const int rr = (int)a.order[blockIdx.x], r = a.r0 + rr, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  auto SYNC = [&]() { if (NW == 1) wave_sync(); else __syncthreads(); };
   const uint64_t p0 = a.ptOff[r], pc0 = a.ptOff[a.r0];
   const int P = (int)(a.ptOff[r + 1] - p0);
-  if (P == 0) { if (!EMIT && lane == 0) { a.cntEntries[rr] = 0; a.cntNodes[rr] = 0; a.cntD[rr] = 0; a.cntV[rr] = 0; } return; }
+  if (P == 0) { if (!EMIT && tid == 0) { a.cntEntries[rr] = 0; a.cntNodes[rr] = 0; a.cntD[rr] = 0; a.cntV[rr] = 0; } return; }
   const uint32_t* hq = a.hq + p0; const uint32_t* ht = a.ht + p0; const uint32_t* h2 = a.h2 + p0;
   const uint64_t* key3 = a.key3 + p0; const uint32_t* pay3 = a.pay3 + p0;
   uint32_t* S = a.scratch + 34 * (p0 - pc0) + 64 * (uint64_t)rr;
@@ -261,29 +279,36 @@ __global__ void __launch_bounds__(64, 8) sdp_build(BuildArgs a) {
   enum { T_C1S, T_C1E, T_ND, T_NE, T_CH0, T_CH1, T_BASE, T_GID };
   // rows (GetRowInfo) and columns (GetColInfo): index of the distinct q / t of every point
   int R = 0, C = 0;
-  for (int i0 = 0; i0 < P; i0 += 64) {
-    const int i = i0 + lane;
+  for (int i0 = 0; i0 < P; i0 += NT) {
+    const int i = i0 + tid;
     const int head = (i < P) && (i == 0 || hq[i] != hq[i - 1]);
-    const int inc = wave_incl_scan(head, lane);
+    int tot; const int inc = blk_incl_scan<NW>(head, lane, wave, s_w[0], tot);
     if (i < P) rowOf[i] = R + inc - 1;
-    R += __shfl(inc, 63);
+    R += tot;
   }
-  for (int i0 = 0; i0 < P; i0 += 64) {
-    const int i = i0 + lane;
+  for (int i0 = 0; i0 < P; i0 += NT) {
+    const int i = i0 + tid;
     const int head = (i < P) && (i == 0 || ht[h2[i]] != ht[h2[i - 1]]);
-    const int inc = wave_incl_scan(head, lane);
+    int tot; const int inc = blk_incl_scan<NW>(head, lane, wave, s_w[0], tot);
     if (i < P) colOf[h2[i]] = C + inc - 1;
-    C += __shfl(inc, 63);
+    C += tot;
   }
   // class boundaries in the diagonal-sorted list
   int cOff[5];
   {
     int c0 = 0, c1 = 0, c2 = 0, c3 = 0;
-    for (int i = lane; i < P; i += 64) { const int cl = (int)(key3[i] >> 40); c0 += cl == 0; c1 += cl == 1; c2 += cl == 2; c3 += cl == 3; }
+    for (int i = tid; i < P; i += NT) { const int cl = (int)(key3[i] >> 40); c0 += cl == 0; c1 += cl == 1; c2 += cl == 2; c3 += cl == 3; }
     for (int o = 32; o > 0; o >>= 1) { c0 += __shfl_xor(c0, o); c1 += __shfl_xor(c1, o); c2 += __shfl_xor(c2, o); c3 += __shfl_xor(c3, o); }
+    if (NW > 1) {
+      if (lane == 0) { s_w[0][wave] = c0; s_w[1][wave] = c1; s_w[2][wave] = c2; s_w[3][wave] = c3; }
+      __syncthreads();
+      c0 = c1 = c2 = c3 = 0;
+      for (int w = 0; w < NW; w++) { c0 += s_w[0][w]; c1 += s_w[1][w]; c2 += s_w[2][w]; c3 += s_w[3][w]; }
+      __syncthreads();
+    }
     cOff[0] = 0; cOff[1] = c0; cOff[2] = c0 + c1; cOff[3] = c0 + c1 + c2; cOff[4] = P;
   }
-  wave_sync();
+  SYNC();
   uint32_t nEntries = 0, nNodesTot = 0, sumD = 0, nVisits = 0;
   Node* nodesR = nullptr; Ent* entR = nullptr; uint32_t* apR = nullptr; int2* stkR = nullptr; uint2* visR = nullptr;
   uint32_t blkPair = 0;
@@ -304,14 +329,14 @@ __global__ void __launch_bounds__(64, 8) sdp_build(BuildArgs a) {
     if (nS == 0 || nEn == 0) continue;
     const int fam2 = fam & 1;
     const int dSide = swapped ? 1 : 0, eSide = swapped ? 0 : 1;
-    for (int i = lane; i < Pf; i += 64) {
+    for (int i = tid; i < Pf; i += NT) {
       const uint32_t pos = pay3[cOff[sc] + i];
       lp[i] = pos; ln[i] = 0; ll[i] = lineOf[pos];
       ld[i] = back ? (long long)ht[pos] + hq[pos] : (long long)ht[pos] - hq[pos];
     }
-    if (lane == 0) { TB(0, F_LS, 0) = 0; TB(0, F_LE, 0) = nLines; TB(0, F_SB, 0) = 0; TB(0, F_SE, 0) = nS; TB(0, F_EB, 0) = nS; TB(0, F_EE, 0) = Pf; }
+    if (tid == 0) { TB(0, F_LS, 0) = 0; TB(0, F_LE, 0) = nLines; TB(0, F_SB, 0) = 0; TB(0, F_SE, 0) = nS; TB(0, F_EB, 0) = nS; TB(0, F_EE, 0) = Pf; }
     int nNodes = 1, cur = 0;
-    wave_sync();
+    SYNC();
     for (int level = 0; nNodes > 0; level++) {
       if (level >= LV) { overflow = true; break; }
       const int nxt = cur ^ 1;
@@ -321,8 +346,8 @@ __global__ void __launch_bounds__(64, 8) sdp_build(BuildArgs a) {
       // A: which elements go to the first half of their node's lines; exclusive prefix in pf
       {
         int carry = 0;
-        for (int i0 = 0; i0 < Pf; i0 += 64) {
-          const int i = i0 + lane;
+        for (int i0 = 0; i0 < Pf; i0 += NT) {
+          const int i = i0 + tid;
           int f = 0;
           if (i < Pf) {
             const uint32_t k = ln[i];
@@ -331,20 +356,20 @@ __global__ void __launch_bounds__(64, 8) sdp_build(BuildArgs a) {
               f = (e - s > 1) ? (llc[i] < ((s + e) >> 1)) : 1;
             }
           }
-          const int inc = wave_incl_scan(f, lane);
+          int tot; const int inc = blk_incl_scan<NW>(f, lane, wave, s_w[0], tot);
           if (i < Pf) pf[i] = carry + inc - f;
-          carry += __shfl(inc, 63);
+          carry += tot;
         }
-        if (lane == 0) pf[Pf] = carry;
+        if (tid == 0) pf[Pf] = carry;
       }
-      wave_sync();
-      for (int k = lane; k < nNodes; k += 64) {
+      SYNC();
+      for (int k = tid; k < nNodes; k += NT) {
         TM(T_C1S, k) = pf[TB(cur, F_SE, k)] - pf[TB(cur, F_SB, k)];
         TM(T_C1E, k) = pf[TB(cur, F_EE, k)] - pf[TB(cur, F_EB, k)];
       }
-      wave_sync();
+      SYNC();
       // C: stable partition of every node's two segments
-      for (int i = lane; i < Pf; i += 64) {
+      for (int i = tid; i < Pf; i += NT) {
         const uint32_t k = ln[i];
         if (k == NONE) { ln[P + i] = NONE; continue; }
         const bool isS = i < nS;
@@ -356,12 +381,12 @@ __global__ void __launch_bounds__(64, 8) sdp_build(BuildArgs a) {
         lpn[np_] = lpc[i]; lln[np_] = llc[i]; ldn[np_] = ldc[i];
         ln[P + np_] = 2 * k + (first ? 0 : 1);
       }
-      wave_sync();
+      SYNC();
       // D: heads of the distinct diagonals inside the D segment (ends) / E segment (starts); exclusive prefix in ph
       {
         int carry = 0;
-        for (int j0 = 0; j0 < Pf; j0 += 64) {
-          const int j = j0 + lane;
+        for (int j0 = 0; j0 < Pf; j0 += NT) {
+          const int j = j0 + tid;
           int head = 0;
           if (j < Pf) {
             const uint32_t k2 = ln[P + j];
@@ -380,17 +405,17 @@ __global__ void __launch_bounds__(64, 8) sdp_build(BuildArgs a) {
               }
             }
           }
-          const int inc = wave_incl_scan(head, lane);
+          int tot; const int inc = blk_incl_scan<NW>(head, lane, wave, s_w[0], tot);
           if (j < Pf) ph[j] = carry + inc - head;
-          carry += __shfl(inc, 63);
+          carry += tot;
         }
-        if (lane == 0) ph[Pf] = carry;
+        if (tid == 0) ph[Pf] = carry;
       }
-      wave_sync();
+      SYNC();
       // E: per node: sizes, fullness, children, next level's table
       int nNext = 0;
-      for (int k0 = 0; k0 < nNodes; k0 += 64) {
-        const int k = k0 + lane;
+      for (int k0 = 0; k0 < nNodes; k0 += NT) {
+        const int k = k0 + tid;
         uint32_t nD = 0, nE = 0, act0 = 0, act1 = 0, full = 0;
         uint32_t ls = 0, le = 0, sb = 0, se = 0, eb = 0, ee = 0, c1S = 0, c1E = 0;
         bool leaf = false;
@@ -411,8 +436,9 @@ __global__ void __launch_bounds__(64, 8) sdp_build(BuildArgs a) {
             if (dSide == 0) { act0 = goD; act1 = goE; } else { act1 = goD; act0 = goE; }
           }
         }
-        const int incF = wave_incl_scan((int)full, lane), incEnt = wave_incl_scan((int)(full ? nD + nE : 0), lane),
-                  incD = wave_incl_scan((int)(full ? nD : 0), lane), incC = wave_incl_scan((int)(act0 + act1), lane);
+        int totF, totEnt, totD, totC;
+        const int incF = blk_incl_scan<NW>((int)full, lane, wave, s_w[0], totF), incEnt = blk_incl_scan<NW>((int)(full ? nD + nE : 0), lane, wave, s_w[1], totEnt),
+                  incD = blk_incl_scan<NW>((int)(full ? nD : 0), lane, wave, s_w[2], totD), incC = blk_incl_scan<NW>((int)(act0 + act1), lane, wave, s_w[3], totC);
         if (k < nNodes) {
           const uint32_t gid = nNodesTot + incF - full, base = nEntries + incEnt - (full ? nD + nE : 0), dpre = sumD + incD - (full ? nD : 0);
           TM(T_ND, k) = nD; TM(T_NE, k) = nE; TM(T_GID, k) = full ? gid : NONE; TM(T_BASE, k) = base;
@@ -431,11 +457,11 @@ __global__ void __launch_bounds__(64, 8) sdp_build(BuildArgs a) {
             stkR[nd.stkOff] = make_int2(-1, (int)nE + 1);     // dummy pair (DivideSubByRow1.h:470)
           }
         }
-        nNodesTot += __shfl(incF, 63); nEntries += __shfl(incEnt, 63); sumD += __shfl(incD, 63); nNext += __shfl(incC, 63);
+        nNodesTot += totF; nEntries += totEnt; sumD += totD; nNext += totC;
       }
-      wave_sync();
+      SYNC();
       // F: node index of every element for the next level; emit Di / Ei and the visit records
-      for (int j = lane; j < Pf; j += 64) {
+      for (int j = tid; j < Pf; j += NT) {
         const uint32_t k2 = ln[P + j];
         if (k2 == NONE) { ln[j] = NONE; continue; }
         const uint32_t k = k2 >> 1, side = k2 & 1;
@@ -462,10 +488,10 @@ __global__ void __launch_bounds__(64, 8) sdp_build(BuildArgs a) {
           }
         }
       }
-      wave_sync();
+      SYNC();
       // G: Db / Eb in closed form (Decide_Eb_Db_*), values and back pointers zeroed
       if (EMIT) {
-        for (int j = lane; j < Pf; j += 64) {
+        for (int j = tid; j < Pf; j += NT) {
           const uint32_t k2 = ln[P + j];
           if (k2 == NONE) continue;
           const uint32_t k = k2 >> 1, side = k2 & 1;
@@ -511,11 +537,17 @@ __global__ void __launch_bounds__(64, 8) sdp_build(BuildArgs a) {
         }
       }
       nNodes = nNext; cur = nxt;
-      wave_sync();
+      SYNC();
     }
   }
   for (int o = 32; o > 0; o >>= 1) nVisits += __shfl_xor(nVisits, o);
-  if (lane == 0) {
+  if (NW > 1) {
+    if (lane == 0) s_w[0][wave] = (int)nVisits;
+    __syncthreads();
+    nVisits = 0;
+    for (int w = 0; w < NW; w++) nVisits += (uint32_t)s_w[0][w];
+  }
+  if (tid == 0) {
     if (!EMIT) { a.cntEntries[rr] = nEntries; a.cntNodes[rr] = nNodesTot; a.cntD[rr] = sumD; a.cntV[rr] = nVisits; }
     if (overflow) atomicOr(&a.status[r], (uint32_t)LRA_ST_RANGE);             // more than 2^(LV-1) distinct rows / columns
   }
@@ -966,7 +998,7 @@ __global__ void __launch_bounds__(64 * WG_NW) sdp_process_wg(ProcArgs a) {
 #pragma unroll
       for (int k = 0; k < SPW; k++) { const int slot = wave + k * WG_NW; if (slot < 2 * LV) vN[k] = visR[(uint64_t)(pi + 1) * (2 * LV) + slot]; }
     }
-    const int ind = fl & 1, inv = (fl >> 1) & 1;
+    const int ind = fl & 1;
     // phase 0 for all of this wave's slots at once (their loads are independent): sub-problem descriptor, Eb[i1], stack top, last Block pair
     Ent e0[SPW]; int2 top0[SPW], lastB0[SPW]; bool act[SPW];
 #pragma unroll
@@ -1509,7 +1541,16 @@ int sdp_run(lra_ctx* ctx, int n_reads, const uint64_t* d_cluster_off, const uint
     ba.r0 = r0; ba.n = nr; ba.ptOff = ptOff; ba.hq = hq; ba.ht = ht; ba.hfl = hfl; ba.h2 = pay2; ba.key3 = key1; ba.pay3 = pay1; ba.scratch = scratch;
     ba.cntEntries = cntE; ba.cntNodes = cntN; ba.cntD = cntD; ba.cntV = cntV; ba.status = status; ba.order = order;
     lra_time_begin(ctx, ctx->sdp_inner ? "sdp_inner_build_count" : "sdp_build_count");
-    hipLaunchKernelGGL(sdp_build<false>, dim3(nr), dim3(64), 0, st, ba);
+    {
+      // reads ordered largest first: the large ones get a 1024-thread workgroup each, beside the wave-per-read launch
+      const long big_pts = getenv("LRA_SDP_BIG_POINTS") ? atol(getenv("LRA_SDP_BIG_POINTS")) : 6000;
+      int nb0 = 0;
+      while (nb0 < nr && (long)(h_pt[r0 + h_orderAll[nb0] + 1] - h_pt[r0 + h_orderAll[nb0]]) >= big_pts) nb0++;
+      const bool forked = nb0 > 0 && nr > nb0;
+      if (nb0 > 0) hipLaunchKernelGGL((sdp_build<false, 16>), dim3(nb0), dim3(1024), 0, forked ? lra_side_fork(ctx) : st, ba);
+      if (nr > nb0) { BuildArgs bb = ba; bb.order = order + nb0; hipLaunchKernelGGL((sdp_build<false, 1>), dim3(nr - nb0), dim3(64), 0, st, bb); }
+      if (forked) lra_side_join(ctx);
+    }
     lra_time_end(ctx);
     { int rc = lra_exclusive_scan<uint32_t>(ctx, nr, cntE, entOff); if (rc) return rc; }
     uint64_t totE = 0;
@@ -1533,7 +1574,18 @@ int sdp_run(lra_ctx* ctx, int n_reads, const uint64_t* d_cluster_off, const uint
       lra_time_begin(ctx, ctx->sdp_inner ? "sdp_inner_build" : "sdp_build");
       hipLaunchKernelGGL(k_visit_clear, dim3(nsub), dim3(256), 0, st, ra, byteOff, subOrder);
       ba.ra = ra; ba.order = subOrder;
-      hipLaunchKernelGGL(sdp_build<true>, dim3(nsub), dim3(64), 0, st, ba);
+      int nbig = 0;
+      {
+        const long big_pts = getenv("LRA_SDP_BIG_POINTS") ? atol(getenv("LRA_SDP_BIG_POINTS")) : 6000;   // (tests lower it to run small reads through the workgroup kernels)
+        const std::vector<uint32_t>& ord = att == 0 ? h_orderAll : h_prev;
+        while (nbig < nsub && (long)(h_pt[r0 + ord[nbig] + 1] - h_pt[r0 + ord[nbig]]) >= big_pts) nbig++;
+      }
+      {
+        const bool forked = nbig > 0 && nsub > nbig;
+        if (nbig > 0) hipLaunchKernelGGL((sdp_build<true, 16>), dim3(nbig), dim3(1024), 0, forked ? lra_side_fork(ctx) : st, ba);
+        if (nsub > nbig) { BuildArgs bb = ba; bb.order = subOrder + nbig; hipLaunchKernelGGL((sdp_build<true, 1>), dim3(nsub - nbig), dim3(64), 0, st, bb); }
+        if (forked) lra_side_join(ctx);
+      }
       lra_time_end(ctx);
       if (att > 0)
         hipLaunchKernelGGL(k_reset_frags, dim3(nsub), dim3(64), 0, st, r0, subOrder, fragOff, flen, d_rate, opts->rate, fval, fprevNode, fprevInd, fflags, status);
@@ -1546,13 +1598,7 @@ int sdp_run(lra_ctx* ctx, int n_reads, const uint64_t* d_cluster_off, const uint
       static const bool dbg = getenv("LRA_SDP_DBG") != nullptr;
       hipEvent_t e0 = nullptr, e1 = nullptr;
       if (dbg) { (void)hipEventCreate(&e0); (void)hipEventCreate(&e1); (void)hipEventRecord(e0, st); }
-      // the reads of this attempt are ordered by their number of points, largest first: the large ones get a workgroup each
-      int nbig = 0;
-      {
-        const long big_pts = getenv("LRA_SDP_BIG_POINTS") ? atol(getenv("LRA_SDP_BIG_POINTS")) : 6000;   // (tests lower it to run small reads through the workgroup kernel)
-        const std::vector<uint32_t>& ord = att == 0 ? h_orderAll : h_prev;
-        while (nbig < nsub && (long)(h_pt[r0 + ord[nbig] + 1] - h_pt[r0 + ord[nbig]]) >= big_pts) nbig++;
-      }
+      // the reads of this attempt are ordered by their number of points, largest first: the large ones get a workgroup each (nbig, above)
       lra_time_begin(ctx, ctx->sdp_inner ? "sdp_inner_process" : "sdp_process");
       // the few large reads (a workgroup each) run beside the many small ones (a wave each) instead of in front of them
       if (nbig > 0) {                                                      // the large reads' per-anchor words (see sdp_process_wg)
