@@ -111,6 +111,14 @@ __device__ __forceinline__ void wave_sync() {
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
 }
 
+// the same for LDS traffic only: a wave's LDS instructions execute in order, so nothing has to be waited for -- in particular not the wave's outstanding
+// global stores, which wave_sync() would drain
+__device__ __forceinline__ void wave_sync_lds() {
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
 struct Problem {
   const char* q; const char* t;
   int qLen, tLen, k0, m, mm, indel;
@@ -118,7 +126,7 @@ struct Problem {
 
 template <int G, typename BytePtr>
 __device__ __forceinline__ void solve(int wlane, const Problem& pr, const Geo& g, BytePtr mem, int* out_score,
-                      int* out_nb, int* blocks, long cap, int* out_status) {
+                      int* out_nb, int* blocks, long cap, int* out_status, int* roll = nullptr) {
   const int qLen = g.qLen, tLen = g.tLen, k = g.k, R = g.R, diag = g.diag, n = g.n, nUsed = g.nUsed;
   const int m = pr.m, mm = pr.mm, indel = pr.indel;
   const int lane = wlane & (G - 1), gbase = wlane - lane;   // G lanes work on this problem
@@ -127,14 +135,25 @@ __device__ __forceinline__ void solve(int wlane, const Problem& pr, const Geo& g
   auto PI = [&](int i, int j) { return j * R + (i - j) + k + 1; };  // :12-17
   auto inb = [&](int s) { return s >= 0 && s < n; };
 #define PSET(slot, sc, ar)                                                         \
-  do { int s__ = (slot); if (inb(s__)) { if (s__ < nUsed) { w.sPre[s__] = (sc); w.pPre[s__] = (ar); } } else status |= LRA_ST_OOB_SLOT; } while (0)
+  do { int s__ = (slot); if (inb(s__)) { if (s__ < nUsed) { if (!rolling) w.sPre[s__] = (sc); w.pPre[s__] = (ar); } } else status |= LRA_ST_OOB_SLOT; } while (0)
 #define SSET(slot, sc, ar)                                                         \
   do { int s__ = (slot); if (inb(s__)) { w.sSuf[s__] = (sc); w.pSuf[s__] = (ar); } else status |= LRA_ST_OOB_SLOT; } while (0)
 
   // ---- codes + clear (:173-219)
   for (int x = lane; x <= qLen; x += G) w.qc[x] = x ? code_n((unsigned char)pr.q[x - 1]) : 0;
   for (int x = lane; x <= tLen; x += G) w.tc[x] = x ? code_n((unsigned char)pr.t[x - 1]) : 0;
-  for (int x = lane; x < nUsed; x += G) { w.sPre[x] = MISS; w.pPre[x] = -1; }
+  // roll != NULL (HBM-resident problems that only use the prefix band): the prefix SCORES live in three rotating anti-diagonal windows in LDS (a cell reads its
+  // two predecessors' anti-diagonals only, and without the suffix band nothing reads a score again but the corner's); HBM keeps the arrows.  The matrices of
+  // such a problem are ~1 MB and every cell was written twice (fill + sweep): 5 B per cell -> 1 B.
+  const bool rolling = roll != nullptr && !g.top && 2 * k + 3 <= 256 && qLen + tLen + 2 <= 4096;
+  // ... and the sequence codes sit behind the windows (roll[768 ..], one byte each), so that a sweep step touches HBM only to store its arrows
+  unsigned char* lq = (unsigned char*)(roll + 768); unsigned char* lt = lq + (qLen + 1);
+  if (rolling) {
+    for (int x = lane; x <= qLen; x += G) lq[x] = x ? code_n((unsigned char)pr.q[x - 1]) : 0;
+    for (int x = lane; x <= tLen; x += G) lt[x] = x ? code_n((unsigned char)pr.t[x - 1]) : 0;
+  }
+  if (rolling) { for (int x = lane; x < nUsed; x += G) w.pPre[x] = -1; }
+  else for (int x = lane; x < nUsed; x += G) { w.sPre[x] = MISS; w.pPre[x] = -1; }
   if (g.top)
     for (int x = lane; x < n; x += G) { w.sSuf[x] = MISS; w.pSuf[x] = -1; }
   for (int x = lane; x <= diag; x += G) { w.loMax[x] = MISS; w.loIdx[x] = 0; w.upMax[x] = MISS; w.upIdx[x] = 0; }
@@ -155,7 +174,50 @@ __device__ __forceinline__ void solve(int wlane, const Problem& pr, const Geo& g
   wave_sync();
   // ---- prefix fill by anti-diagonals s = i + j (:313-339)
   const int qB = g.qB, tB = g.tB;
-  for (int s = 2; s <= (qB - 1) + (tB - 1); s++) {
+  int rollResult = MISS;
+  if (rolling) {
+    // what the boundary / rail stores above leave in cell (i, j) before the sweep (last store wins; everything else is MISS)
+    auto pre = [&](int i, int j) -> int {
+      int v = MISS;
+      if (j == 0 && i >= 1 && i < k + 1) v = indel * i;
+      if (i == 0 && j >= 1 && j <= k + 1) v = indel * j;
+      if (i == 0 && j == 0) v = 0;
+      if (qLen >= tLen) { if (j == i + k + 1 && i <= diag - k - 1) v = MISS; if (i == j + k + 1 && j >= 1 && j < diag + k - 1) v = MISS; }
+      if (qLen <= tLen) { if (i == j + k + 1 && j < diag - 1) v = MISS; if (j == i + k + 1 && j >= 1 && j < diag + k) v = MISS; }
+      return v;
+    };
+    const int Wd = 2 * k + 3;
+    const int sLast = (qB - 1) + (tB - 1);
+    for (int s = 0; s <= max(sLast, 0); s++) {
+      int* cur = roll + (s % 3) * 256; const int* p1 = roll + ((s + 2) % 3) * 256; const int* p2 = roll + ((s + 1) % 3) * 256;
+      int jlo = max(1, max(s - qB + 1, (s - k + 1) >> 1));
+      if (s - k < 0) jlo = max(1, s - qB + 1);
+      const int jhi = min(tB - 1, min(s - 1, (s + k) >> 1));
+      for (int dd = lane; dd < Wd; dd += G) {
+        const int d = dd - k - 1;                                          // i - j
+        int v = MISS;
+        if (((s + d) & 1) == 0) {
+          const int i = (s + d) >> 1, j = s - i;
+          if (i >= 0 && j >= 0) {
+            if (s >= 2 && j >= jlo && j <= jhi && d >= -k && d <= k) {
+              const int sIns = p1[dd - 1] + indel, sDel = p1[dd + 1] + indel;
+              const int sMat = p2[dd] + (lq[i] == lt[j] ? m : mm);
+              const int best = max(sIns, max(sDel, sMat));
+              const int ar = (best == sIns) ? A_LEFT : (best == sDel) ? A_DOWN : A_DIAG;
+              v = best;
+              w.pPre[PI(i, j)] = (signed char)ar;
+            } else v = pre(i, j);
+            if (i == qB - 1 && j == tB - 1) rollResult = v;
+          }
+        }
+        cur[dd] = v;
+      }
+      wave_sync_lds();
+    }
+    wave_sync();
+    { const int ddc = (qB - 1) - (tB - 1) + k + 1; rollResult = (ddc >= 0 && ddc < Wd) ? __shfl(rollResult, gbase + (ddc % G)) : MISS; }   // the lane that owns the corner's diagonal
+  }
+  for (int s = 2; !rolling && s <= (qB - 1) + (tB - 1); s++) {
     int jlo = max(1, max(s - qB + 1, (s - k + 1) >> 1));   // ceil((s-k)/2), s-k may be < 0
     if (s - k < 0) jlo = max(1, s - qB + 1);
     int jhi = min(tB - 1, min(s - 1, (s + k) >> 1));
@@ -293,10 +355,45 @@ __device__ __forceinline__ void solve(int wlane, const Problem& pr, const Geo& g
     }
   } else {                                                                    // :582-586
     ti = qB - 1; tj = tB - 1;
-    result = w.sPre[PI(ti, tj)];
+    result = rolling ? rollResult : w.sPre[PI(ti, tj)];
   }
-  // ---- prefix trace back (:589-629), lane 0
-  if (lane == 0) {
+  // ---- prefix trace back (:589-629), lane 0 -- or, with the arrows in HBM only (rolling), all lanes in step on the same state over a window of rows staged in
+  // LDS: the walk is a chain of dependent one-byte loads a row apart (a cache line each); a window serves at least as many steps as it has rows
+  if (rolling) {
+    unsigned char* chunk = (unsigned char*)(roll + 768 + 1024);          // 8 KB
+    const int chRows = max(1, 8192 / R);
+    int cLo = 1, cHi = 0;
+    auto arrowAt = [&](int i, int j) -> int {
+      if (j < cLo || j > cHi) {
+        cHi = j; cLo = max(0, j - chRows + 1);
+        wave_sync();
+        const long base = (long)cLo * R, len = (long)(cHi - cLo + 1) * R;
+        for (long x = lane; x < len; x += G) chunk[x] = (unsigned char)w.pPre[base + x];
+        wave_sync();
+      }
+      return (int)(signed char)chunk[(j - cLo) * R + (i - j) + k + 1];
+    };
+    auto flushL = [&](int i_after, int j_after) {
+      if (run > 0) {
+        if (nb < cap) { if (lane == 0) { blocks[3 * nb] = i_after; blocks[3 * nb + 1] = j_after; blocks[3 * nb + 2] = run; } }
+        else status |= LRA_ST_CAPACITY;
+        nb++;
+        run = 0;
+      }
+    };
+    int arrow = (ti >= 0 && tj >= 0 && inb(PI(ti, tj))) ? arrowAt(ti, tj) : A_DONE;
+    long it = 0;
+    while (arrow != A_BORDER && arrow != A_DONE && ti >= 0 && tj >= 0) {
+      if (++it > iter_cap) { status |= LRA_ST_NO_TERMINATION; break; }
+      if (arrow == A_DIAG) { run++; ti--; tj--; }
+      else if (arrow == A_LEFT) { flushL(ti, tj); ti--; }
+      else if (arrow == A_DOWN) { flushL(ti, tj); tj--; }
+      else { if (arrow != A_GAPLEFT && arrow != A_GAPDOWN) status |= LRA_ST_NO_TERMINATION; break; }
+      if (ti < 0 || tj < 0) break;
+      arrow = arrowAt(ti, tj);
+    }
+    flushL(ti, tj);
+  } else if (lane == 0) {
     int arrow = (ti >= 0 && tj >= 0 && inb(PI(ti, tj))) ? w.pPre[PI(ti, tj)] : A_DONE;
     long it = 0;
     while (arrow != A_BORDER && arrow != A_DONE && ti >= 0 && tj >= 0) {
@@ -391,6 +488,7 @@ __global__ void aog_classify(BatchArgs a) {
 template <int CLS>
 __global__ void __launch_bounds__((CLS == 0 || CLS == 3 || CLS == 7) ? 256 : 64) aog_kernel(BatchArgs a) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
+  __shared__ int s_roll[CLS == 2 ? 3 * 256 + 1024 + 2048 : 1];
   constexpr int G = (CLS == 3) ? 16 : (CLS >= 7) ? 32 : 64;
   constexpr int GPW = 64 / G;
   const int lane = threadIdx.x & 63;
@@ -411,7 +509,7 @@ __global__ void __launch_bounds__((CLS == 0 || CLS == 3 || CLS == 7) ? 256 : 64)
     else if (CLS == 7) solve<32>(lane, pr, g, smem + (wave_in_wg * GPW + lane / G) * CLASS_A_BYTES, &a.score[p], &a.nblocks[p], blk, cap, &a.status[p]);
     else if (CLS == 0) solve<64>(lane, pr, g, smem + wave_in_wg * CLASS_A_BYTES, &a.score[p], &a.nblocks[p], blk, cap, &a.status[p]);
     else if (CLS == 1 || CLS == 4 || CLS == 5) solve<64>(lane, pr, g, smem, &a.score[p], &a.nblocks[p], blk, cap, &a.status[p]);
-    else solve<64>(lane, pr, g, a.gscratch + (long)(group % a.gslots) * a.gslot_bytes, &a.score[p], &a.nblocks[p], blk, cap, &a.status[p]);
+    else solve<64>(lane, pr, g, a.gscratch + (long)(group % a.gslots) * a.gslot_bytes, &a.score[p], &a.nblocks[p], blk, cap, &a.status[p], s_roll);
     wave_sync();
   }
 }
