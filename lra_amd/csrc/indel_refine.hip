@@ -997,9 +997,12 @@ extern "C" int lra_indel_refine_batch(lra_ctx* ctx, int n_aln, const int32_t* d_
     scan(ctx, (long)n_seg, s_tmpcap, s_tmp_off);
     uint64_t n_tmp = 0;
     if (d2h(ctx, &n_cells, s_cell_off + n_seg, 8) || d2h(ctx, &n_tmp, s_tmp_off + n_seg, 8)) return LRA_ERR_HIP;
-    unsigned char* path = (unsigned char*)lra_ensure(ctx, 1, n_cells + 256);
-    int32_t* tmpb = (int32_t*)lra_ensure(ctx, 2, (n_tmp + 1) * 12);
-    if (!path || !tmpb) return LRA_ERR_NOMEM;
+    // The arrows (1 B per cell) and the walk-order blocks are this stage's two large temporaries; they live in the buffer of the sparse DP's arena (slot 12):
+    // on the path the arena is dead by now (the last sparse DP ran inside LocalRefineAlignment) and this stage is over before the next batch's first one.
+    const size_t pathBytes = (n_cells + 256 + 255) & ~(size_t)255;
+    unsigned char* path = (unsigned char*)lra_ensure(ctx, 12, pathBytes + (n_tmp + 1) * 12 + 256);
+    if (!path) return LRA_ERR_NOMEM;
+    int32_t* tmpb = (int32_t*)(path + pathBytes);
     tmp_blocks = tmpb;
     int h_bins[FILL_BINS], h_start[FILL_BINS], h_cursor[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     LRA_HIP_CHECK(ctx, hipMemsetAsync(fill_counts, 0, FILL_BINS * 4, st));

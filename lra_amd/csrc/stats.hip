@@ -237,7 +237,7 @@ extern "C" int lra_calculate_statistics_batch(lra_ctx* ctx, int n_aln, const int
   uint64_t total_cap = 0;
   LRA_HIP_CHECK(ctx, hipMemcpyAsync(&total_cap, cap_off + n_aln, 8, hipMemcpyDeviceToHost, st));
   LRA_HIP_CHECK(ctx, hipStreamSynchronize(st));
-  uint32_t* tmp = (uint32_t*)lra_ensure(ctx, 2, (total_cap + 1) * 4);      // shares the refine stage's temporary block buffer slot
+  uint32_t* tmp = (uint32_t*)lra_ensure(ctx, 12, (total_cap + 1) * 4);     // shares the buffer of the sparse DP's arena / the refine stage's temporaries (all dead here)
   if (!tmp) return LRA_ERR_NOMEM;
   A.runs = tmp;
   const int grid = n_aln < ctx->num_cu * 32 ? n_aln : ctx->num_cu * 32;
