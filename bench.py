@@ -174,27 +174,22 @@ def main():
     tcv = threading.Condition()
     tails = []
 
-    def lane_loop(li, n_steps, stagger_s):
-        lane = lanes[li]
+    copy_stream = torch.cuda.Stream(device=dev_index)
+
+    def tail_thread(lane, held, ev, my_ticket):
         try:
-            if stagger_s:
-                time.sleep(stagger_s)
-            prev = None
-            for s_ in range(n_steps):
-                lane_device_side(lane)
-                if err:
-                    break
-                if args.no_records:
-                    continue
-                with tcv:
-                    while ticket[0] != s_ * len(lanes) + li:
+            torch.cuda.set_device(dev_index)
+            with torch.cuda.stream(copy_stream):
+                copy_stream.wait_event(ev)
+                with tcv:                                                  # collectives in ticket order on every rank
+                    while ticket[0] != my_ticket:
                         tcv.wait()
-                got = parallel.gather_records(lane["packed"], dst=0)          # the one exchange step: this rank's record buffer -> rank 0
+                got = parallel.gather_records(held, dst=0)                 # the one exchange step: this rank's record buffer -> rank 0
                 with tcv:
                     ticket[0] += 1
                     tcv.notify_all()
+                items = []
                 if rank == 0:
-                    items = []
                     for t in got:
                         hb = t.cpu().numpy()
                         snap = C.c_void_p()
@@ -203,10 +198,40 @@ def main():
                         # (every rank holds reads of the same shape; rank 0 formats each rank's records with its own lane's names / bases as stand-ins
                         # for the other ranks' -- the text volume and the work are the same)
                         items.append((lane, snap))
-                    if prev is not None:
-                        prev.join()
-                    prev = threading.Thread(target=host_tail, args=(items,))
-                    prev.start()
+            host_tail(items)
+        except BaseException as e:
+            err.append(e)
+
+    def lane_loop(li, n_steps, stagger_s):
+        lane = lanes[li]
+        try:
+            if stagger_s:
+                time.sleep(stagger_s)
+            prev = None
+            dbg = os.environ.get("LRA_BENCH_DBG")
+            for s_ in range(n_steps):
+                tA = time.perf_counter()
+                lane_device_side(lane)
+                tB = time.perf_counter()
+                if dbg:
+                    sys.stderr.write("[bench] step %d device side + pack %.0f ms\n" % (s_, (tB - tA) * 1e3))
+                if err:
+                    break
+                if args.no_records:
+                    continue
+                # The exchange step and everything behind it -- gather to rank 0, the copy to the host, unpacking, the record text -- belong to the step's
+                # host tail and run beside the next step's device side (the reference interleaves its output with the next reads the same way, lra.cpp:117-158).
+                # The packed buffer is context-owned (the next lra_map_pack reuses it), so the tail works on a device copy.
+                held = lane["packed"].clone()
+                ev = torch.cuda.Event()
+                ev.record(torch.cuda.current_stream())
+                if prev is not None:
+                    tC = time.perf_counter()
+                    prev.join()
+                    if dbg:
+                        sys.stderr.write("[bench] step %d waited for the previous host tail %.0f ms\n" % (s_, (time.perf_counter() - tC) * 1e3))
+                prev = threading.Thread(target=tail_thread, args=(lane, held, ev, s_ * len(lanes) + li))
+                prev.start()
             if prev is not None:
                 prev.join()
         except BaseException as e:
