@@ -436,3 +436,43 @@ def test_map_reads_highacc_match_oracle_pipeline(ctx, oracle, preset):
             assert t == b"", r
     assert texts[-1].split(b"\t")[1] == b"4"                              # the junk read: one unaligned record
     assert sum(1 for t in texts if t.count(b"\n") >= 2) >= 2               # split reads: several lines
+
+
+@pytest.mark.gpu
+def test_config0_shape_ccs_ecoli_sized(ctx, oracle):
+    """BASELINE configs[0] at its own size: a 4.6 Mb single-chromosome reference (E. coli K-12 sized) + 1000 simulated 10 kb CCS reads, -CCS: every read's
+    SegAlignments from lra_map_reads_highacc_batch against the oracle composition (the reference's CPU-runnable case)."""
+    import oracle_pipeline as OP
+    from lra_amd import seed, mapread, index as I
+    g = synth.make_genome(4_600_000, seed=101, repeat_frac=0.03, n_families=4)
+    CH = [0, len(g)]
+    reads, truth = synth.simulate_reads(g, 1000, 10000, 1500, 0.01, (34, 33, 33), seed=77)
+    mapper = mapread.HighAccMapper(ctx, g, None, None, [b"U00096.3"], CH, "ccs")
+    ik, ipos = I.global_index(ctx)
+    g_index = mapper.fetch_local_index()
+    res = mapper.align(seed.ReadBatch(ctx, [r.tobytes() for r in reads]))
+    out = mapper.fetch(res)
+    na = int(res.num_aln)
+    gb = g.tobytes()
+    n_aln = n_right = 0
+    for r, rd in enumerate(reads):
+        exp, unaligned, note = OP.map_read_highacc(rd.tobytes(), gb, ik, ipos, OP.CCS, chrom_pos=CH, g_index=g_index, stats=(r % 10 == 0))
+        assert note is None and out["read_status"][r] == 0, (r, note, out["read_status"][r])
+        by_h = {G["h"]: G["segs"] for G in exp}
+        for h in range(na):
+            a0, a1 = int(out["job_aln_off"][r * na + h]), int(out["job_aln_off"][r * na + h + 1])
+            e = by_h.get(h, [])
+            assert a1 - a0 == len(e) and bool(out["job_reached"][r * na + h]) == (h in by_h), (r, h, a1 - a0, len(e))
+            for a, s in zip(range(a0, a1), e):
+                assert (out["strand"][a], out["supp"][a], out["secondary"][a], out["n0"][a], out["n1"][a]) == (s["strand"], s["supp"], s["secondary"], s["n0"], s["n1"]), (r, h)
+                b = out["blocks"][int(out["block_off"][a]):int(out["block_off"][a + 1])]
+                assert np.array_equal(b, s["blocks"]), (r, h, len(b), len(s["blocks"]))
+                if "stats" in s:
+                    ec, ev, eruns, _ = s["stats"]
+                    assert out["counts"][a].tolist() == [ec[k] for k in O.STAT_NAMES] and np.array_equal(out["runs"][int(out["run_off"][a]):int(out["run_off"][a + 1])], eruns), (r, h)
+                n_aln += 1
+        if by_h.get(0):                                                     # the primary alignment sits where the read was drawn from
+            s0 = by_h[0][0]
+            st, ln, rev = truth[r]
+            n_right += abs(int(s0["blocks"][0][1]) - st) < 200 and s0["strand"] == int(rev)
+    assert n_aln >= 990 and n_right >= 980, (n_aln, n_right)
