@@ -231,18 +231,19 @@ inline size_t al256(size_t x) { return (x + 255) & ~(size_t)255; }
 extern "C" void lra_map_opts_preset_ccs(lra_map_opts* o) {
   if (!o) return;
   memset(o, 0, sizeof *o);
-  // -CCS (lra.cpp:306-340) over the defaults of Options.h:127-230
-  o->globalK = 25; o->globalW = 20; o->globalMaxFreq = 150;
+  // -CCS (lra.cpp:306-340) over the defaults of Options.h:127-230.  globalK: the preset says 25, but `lra align` then reads the index file, and ReadIndex
+  // overwrites opts.globalK with the K the index was built with (MMIndex.h:409, lra.cpp:623) -- 17 for `lra index -CCS` (lra.cpp:890-896); globalW stays 20.
+  o->globalK = 17; o->globalW = 20; o->globalMaxFreq = 150;
   o->localK = 7; o->localW = 5; o->localMaxFreq = 15; o->localIndexWindow = 256;
   o->refineBand = 7; o->localMatch = 4; o->localMismatch = -3; o->localIndel = -4; o->localBand = 15;
   o->refineSpaceDist = 30000; o->anchorstoosparse = 0.005f; o->splitdist = 50000; o->window = 100;
   o->second_anchorbonus = 2.0f; o->bypassClustering = 0; o->skipBandedRefine = 0; o->refineBreakpoint = 0;
-  o->clean.globalK = 25; o->clean.cleanMaxDiag = 150; o->clean.minDiagCluster = 10; o->clean.bypassClustering = 0; o->clean.cleanClustersize = 100;
+  o->clean.globalK = 17; o->clean.cleanMaxDiag = 150; o->clean.minDiagCluster = 10; o->clean.bypassClustering = 0; o->clean.cleanClustersize = 100;
   o->clean.SecondCleanMinDiagCluster = 30; o->clean.SecondCleanMaxDiag = 100; o->clean.punish_anchorfreq = 10; o->clean.anchorPerlength = 10;
   o->sdp.rate = 10.0f; o->sdp.NumAln = 2; o->sdp.alnthres = 0.7f; o->sdp.gapopen = 4.0f; o->sdp.gapextend = 15.0f; o->sdp.gaproot = 1.5f;
-  o->sdp.gapCeiling1 = 2000; o->sdp.gapCeiling2 = 3000; o->sdp.mode = 0; o->sdp.globalK = 25;
+  o->sdp.gapCeiling1 = 2000; o->sdp.gapCeiling2 = 3000; o->sdp.mode = 0; o->sdp.globalK = 17;
   o->readType = LRA_READ_CCS; o->hardClip = 1; o->PrintNumAln = 1; o->printFormat = 's';
-  o->fine.globalK = 25; o->fine.RoughClustermaxGap = 500; o->fine.maxDiag = 500; o->fine.maxGap = 400; o->fine.minClusterSize = 10; o->fine.minUniqueStretchNum = 1;
+  o->fine.globalK = 17; o->fine.RoughClustermaxGap = 500; o->fine.maxDiag = 500; o->fine.maxGap = 400; o->fine.minClusterSize = 10; o->fine.minUniqueStretchNum = 1;
   o->fine.minUniqueStretchDist = 50;
   o->merge_dist = 100;
 }
@@ -651,7 +652,7 @@ static int highacc_core(lra_ctx* ctx, int n_reads, const char* d_seq, const uint
     uint64_t* z = (uint64_t*)lra_ensure(ctx, 161, (S + 2) * 8);
     if (!z) return LRA_ERR_NOMEM;
     LRA_HIP_CHECK(ctx, hipMemsetAsync(z, 0, (S + 2) * 8, st));
-    ares.d_job_aln_off = z; ares.n_jobs = S;
+    ares.d_job_aln_off = z; ares.d_status = (const uint32_t*)z; ares.n_jobs = S;   // (zeros serve as both)
   }
   LRA_HIP_CHECK(ctx, hipStreamSynchronize(st));
   LRA_HIP_CHECK(ctx, hipGetLastError());

@@ -461,7 +461,8 @@ class HighAccMapper:
         self.copts = m
         _index.load_genome(ctx, g)
         if idx_key is None:
-            ip = index_params or ((m.globalK, m.globalW, 150, 15, 1) if preset != "contig" else (m.globalK, m.globalW, 30, 20, 1))
+            # `lra index -CCS` / `-CONTIG` (lra.cpp:884-896): K 17 / 19, W 10, maxFreq 150 / 30, window 15 / 20, one minimizer per window
+            ip = index_params or ((m.globalK, 10, 150, 15, 1) if preset != "contig" else (m.globalK, 10, 30, 20, 1))
             self.index_stats = _index.build_global_index(ctx, self.chrom_pos, *ip)
         else:
             k = np.ascontiguousarray(idx_key).view(np.uint64); p = np.ascontiguousarray(idx_pos, dtype=np.uint32)

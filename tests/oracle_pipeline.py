@@ -266,7 +266,8 @@ def map_reads_lowacc_mt(reads, off, first, n, genome: bytes, idx_key, idx_pos, g
 
 # ------------------------------------------------------------------------------------------------------------------------ MapRead_highacc
 # -CCS (lra.cpp:306-340) and -CONTIG (lra.cpp:268-305) over the defaults of Options.h:127-230
-CCS = dict(globalK=25, globalW=20, globalMaxFreq=150, localK=7, localW=5, localMaxFreq=15, localIndexWindow=256, window=100, readType=2, refineBand=7, match=4, mismatch=-3, indel=-4, localBand=15, NumAln=2,
+CCS = dict(globalK=17, globalW=20, globalMaxFreq=150,      # globalK: what ReadIndex leaves (the index's K, 17 for `lra index -CCS`), not the preset's 25
+            localK=7, localW=5, localMaxFreq=15, localIndexWindow=256, window=100, readType=2, refineBand=7, match=4, mismatch=-3, indel=-4, localBand=15, NumAln=2,
            alnthres=0.7, initial_anchorbonus=10.0, second_anchorbonus=2.0, splitdist=50000, anchorstoosparse=0.005, merge_dist=100, gapopen=4.0, gapextend=15.0,
            gaproot=1.5, gapCeiling1=2000, gapCeiling2=3000, refineBreakpoint=False, skipBandedRefine=False,
            clean=dict(cleanMaxDiag=150, minDiagCluster=10, bypassClustering=0, cleanClustersize=100, SecondCleanMinDiagCluster=30, SecondCleanMaxDiag=100, punish_anchorfreq=10,

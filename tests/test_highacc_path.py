@@ -375,7 +375,7 @@ def test_map_reads_highacc_match_oracle_pipeline(ctx, oracle, preset):
     reads = _sv_reads(g, rng, 0.01)
     over = {}
     oo = dict(OP.CCS)
-    ip = (25, 20, 150, 15, 1)
+    ip = (17, 10, 150, 15, 1)                                             # `lra index -CCS`
     if preset == "contig":                                                # -CONTIG: refineBand 50 (rows of more than 64 cells), K 19, other gap costs, contig thresholds
         oo = dict(OP.CONTIG); ip = (19, 10, 30, 20, 1)
         sim = lambda a, n, rev=False: synth.simulate_read(rng, g[a:a + n + 1], n, 0.003, (34, 33, 33), rev)[0]
@@ -385,8 +385,8 @@ def test_map_reads_highacc_match_oracle_pipeline(ctx, oracle, preset):
         over["refineBreakpoint"] = 1; oo["refineBreakpoint"] = True
     if preset == "ccs-k17":                                               # denser seeds: more clusters per read, more second chains
         over.update({"globalK": 17, "globalW": 10, "clean.globalK": 17, "sdp.globalK": 17, "fine.globalK": 17}); oo.update(globalK=17, globalW=10); ip = (17, 10, 150, 15, 1)
-    if preset == "ccs-sparse":                                            # a thin global index (one minimizer per 80 bases): clusters at ~0.01 anchors per base, so some
-        ip = (25, 20, 150, 80, 1)                                         # reads take the REFINEclusters branch (Map_highacc.h:413-447) and some do not
+    if preset == "ccs-sparse":                                            # a slightly thinner global index (one minimizer per 18 bases instead of 15; the reads are sketched with W = 20): clusters at ~0.01 anchors per base, so some
+        ip = (17, 10, 150, 18, 1)                                         # reads take the REFINEclusters branch (Map_highacc.h:413-447) and some do not
     mapper = mapread.HighAccMapper(ctx, g, None, None, [b"chrA", b"chrB"], CH, "contig" if preset == "contig" else "ccs", index_params=ip, **over)
     ik, ipos = I.global_index(ctx)
     g_index = mapper.fetch_local_index()
