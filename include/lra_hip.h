@@ -963,6 +963,22 @@ void lra_map_opts_preset_ccs(lra_map_opts* opts);          /* -CCS: lra.cpp:306-
 void lra_map_opts_preset_contig(lra_map_opts* opts);       /* -CONTIG: lra.cpp:268-305 */
 int lra_map_reads_highacc_batch(lra_ctx* ctx, int n_reads, const char* d_seq, const uint64_t* d_read_off, uint64_t total_bases, const lra_map_opts* opts,
                                 lra_map_result* out);
+/* ---- the input side ---------------------------------------------------------------------------------------------------
+ * lra_reads_open / lra_reads_next_batch / lra_reads_close replace Input::Initialize, Input::GetNext (FASTA and FASTQ) and Input::BufferedRead (Input.h:87-168,
+ * :182-283, :405-421): files are read one after the other; a batch takes reads while it holds fewer than max_bases bases (so it ends with the read that
+ * crosses the limit).  The batch's arrays are owned by the reader and valid until the next call: seq = the reads' bases, upper-cased, back to back + 64 bytes
+ * of padding; off[n_reads + 1]; names / reads / quals / read_len as lra_map_records takes them (quals[i] == NULL for FASTA reads).
+ * lra_map_reads_host is the boundary with host buffers: it copies the batch to the device and calls the driver opts->bypassClustering selects.          */
+typedef struct lra_reads lra_reads;
+typedef struct lra_read_batch {
+  int32_t n_reads; uint64_t total_bases;
+  const char* seq; const uint64_t* off; const int32_t* read_len;
+  const char* const* names; const char* const* reads; const char* const* quals;
+} lra_read_batch;
+int lra_reads_open(const char* const* files, int n_files, lra_reads** out);
+int lra_reads_next_batch(lra_reads* r, uint64_t max_bases, lra_read_batch* batch);
+void lra_reads_close(lra_reads* r);
+int lra_map_reads_host(lra_ctx* ctx, int n_reads, const char* h_seq, const uint64_t* h_off, const lra_map_opts* opts, lra_map_result* out);
 int lra_map_records(lra_ctx* ctx, const lra_map_result* res, const lra_map_opts* opts, const char* const* names, const char* const* reads,
                     const char* const* quals, const int32_t* read_len, const char* const* chrom_names, const char* passthrough, char* out, uint64_t cap,
                     uint64_t* len, uint64_t* rec_off);

@@ -51,6 +51,10 @@ SYMBOLS = {
                                                   C.c_int, C.c_int, C.c_int, C.c_int, _vp]),
     "lra_linear_extend_batch": (C.c_int, [_vp, C.c_int, _vp, _vp, _vp]),
     "lra_sparse_dp_batch": (C.c_int, [_vp, C.c_int, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "lra_reads_open": (C.c_int, [_vp, C.c_int, _vp]),
+    "lra_reads_next_batch": (C.c_int, [_vp, C.c_uint64, _vp]),
+    "lra_reads_close": (None, [_vp]),
+    "lra_map_reads_host": (C.c_int, [_vp, C.c_int, _vp, _vp, _vp, _vp]),
     "lra_global_chain_batch": (C.c_int, [_vp, C.c_uint64, _vp, C.c_uint64, _vp, _vp, _vp, _vp, _vp, _vp]),
     "lra_split_chains_highacc_batch": (C.c_int, [_vp, C.c_uint64, _vp, C.c_uint64, _vp, _vp, _vp, _vp, _vp, C.c_int, _vp]),
     "lra_split_chains_batch": (C.c_int, [_vp, _vp, _vp, C.c_int, C.c_int, C.c_int, _vp]),
