@@ -16,6 +16,24 @@
  *     library never calls exit() (the reference exit(1)s, lra.cpp:623-640);
  *   - per-item `status` words report conditions that are undefined behaviour or an
  *     endless loop in the reference (so no parity is defined for them).
+ *
+ * Lifetime of results.  Output arrays marked "context-owned" live in growable buffers of
+ * the context and stay valid until a later call reuses their buffer; a buffer that has to
+ * grow is freed and allocated again (contents are not preserved).  Which calls share
+ * buffers (copy a result out with lra_copy_device if it has to survive one of them):
+ *   - every sparse DP call (lra_sparse_dp_batch, lra_sparse_dp_boxes_batch, and the ones
+ *     inside lra_local_refine_batch / _highacc_batch) overwrites the previous sparse DP's
+ *     lra_chain_result;
+ *   - lra_indel_refine_batch and lra_calculate_statistics_batch keep their temporaries in
+ *     the sparse DP's arena: a chain result does not survive them either way, their own
+ *     results (refined blocks, counters, CIGAR runs) have buffers of their own;
+ *   - lra_indel_refine_batch's d_status lives in scratch the statistics stage reuses;
+ *   - lra_filter_chains_batch shares its buffer with lra_split_chains_batch,
+ *     lra_refine_clusters_batch with lra_refine_splitchain_batch;
+ *   - a lra_map_reads_*_batch call invalidates every result of the call before it (and a
+ *     pending two-call lra_map_records text); lra_map_snapshot / lra_map_pack take what the
+ *     record stage needs out of the context first.
+ * The two drivers are the tested orderings of these calls.
  */
 #ifndef LRA_HIP_H_
 #define LRA_HIP_H_
