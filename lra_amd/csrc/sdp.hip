@@ -566,6 +566,7 @@ struct ProcArgs {
   const ReadArena* ra; uint32_t* poolUsed;
   uint32_t* status;
   PwlTab pwl;
+  int dbg;
   char* wgScratch; const uint64_t* wgOff;   // sdp_process_wg: per large read, the anchors' (best predecessor, contributions) words and the points' ranks
 };
 
@@ -932,6 +933,16 @@ __global__ void __launch_bounds__(64) sdp_process(ProcArgs a) {
 struct SlotState { Node cn; uint32_t cId; int2 cTop, cLastB; int cTopOk; };
 constexpr int WG_NW = 16;
 
+// Which slots a wave owns.  The cost of a slot falls with its level (measured on a 47 k-point read: R0-R3 and C0-C2 ~ 350-400 M cycles each, level 8 ~ 100 M,
+// level 13+ ~ 0), so wave w takes row-family level w and column-family level 15 - w (plus the two levels beyond 15): the busiest wave carries ~ 460 M cycles
+// instead of ~ 760 M with slots w, w + 16, w + 32.
+__device__ __forceinline__ int wg_slot(int wave, int k) {
+  static_assert(LV == 18 && WG_NW == 16, "slot table written for 18 levels on 16 waves");
+  if (k == 0) return wave;                                   // R level wave
+  if (k == 1) return LV + (15 - wave);                       // C level 15 - wave
+  return wave == 0 ? 16 : wave == 1 ? 17 : wave == 15 ? LV + 16 : wave == 14 ? LV + 17 : 2 * LV;   // R16, R17, C16, C17; else none
+}
+
 __global__ void __launch_bounds__(64 * WG_NW) sdp_process_wg(ProcArgs a) {
   __shared__ float s_slope[25], s_inter[25];
   __shared__ SlotState ss[2 * LV];
@@ -983,10 +994,13 @@ __global__ void __launch_bounds__(64 * WG_NW) sdp_process_wg(ProcArgs a) {
   }
   __threadfence();
   __syncthreads();
+  // LRA_SDP_DBG: cycles per wave spent in each of its slots and waiting at end points (4 words per wave behind rank[], 8-aligned)
+  unsigned long long* dbgT = (unsigned long long*)(((uintptr_t)(rank + P) + 7) & ~(uintptr_t)7);
+  unsigned long long tSlot[4] = {0, 0, 0, 0};
   constexpr int SPW = (2 * LV + WG_NW - 1) / WG_NW;                       // slots per wave
   uint2 vN[SPW]; uint8_t flN = P > 0 ? a.hfl[p0] : 0; uint32_t lfN = P > 0 ? a.hfr[p0] : 0;
 #pragma unroll
-  for (int k = 0; k < SPW; k++) { const int slot = wave + k * WG_NW; vN[k] = (P > 0 && slot < 2 * LV) ? visR[slot] : make_uint2(NONE, 0); }
+  for (int k = 0; k < SPW; k++) { const int slot = wg_slot(wave, k); vN[k] = (P > 0 && slot < 2 * LV) ? visR[slot] : make_uint2(NONE, 0); }
   for (int pi = 0; pi < P && !s_bad; pi++) {
     const uint8_t fl = flN;
     const uint32_t lf = lfN;
@@ -996,14 +1010,14 @@ __global__ void __launch_bounds__(64 * WG_NW) sdp_process_wg(ProcArgs a) {
     if (pi + 1 < P) {                                                    // next point's rows, in flight while this one is processed
       flN = a.hfl[p0 + pi + 1]; lfN = a.hfr[p0 + pi + 1];
 #pragma unroll
-      for (int k = 0; k < SPW; k++) { const int slot = wave + k * WG_NW; if (slot < 2 * LV) vN[k] = visR[(uint64_t)(pi + 1) * (2 * LV) + slot]; }
+      for (int k = 0; k < SPW; k++) { const int slot = wg_slot(wave, k); if (slot < 2 * LV) vN[k] = visR[(uint64_t)(pi + 1) * (2 * LV) + slot]; }
     }
     const int ind = fl & 1;
     // phase 0 for all of this wave's slots at once (their loads are independent): sub-problem descriptor, Eb[i1], stack top, last Block pair
     Ent e0[SPW]; int2 top0[SPW], lastB0[SPW]; bool act[SPW];
 #pragma unroll
     for (int k = 0; k < SPW; k++) {
-      const int slot = wave + k * WG_NW;
+      const int slot = wg_slot(wave, k);
       act[k] = slot < 2 * LV && vv[k].x != NONE;
       if (act[k] && vv[k].x != ss[slot].cId) {
         if (lane == 0) { ss[slot].cn = nodes[vv[k].x]; ss[slot].cId = vv[k].x; ss[slot].cTopOk = 0; }
@@ -1016,6 +1030,7 @@ __global__ void __launch_bounds__(64 * WG_NW) sdp_process_wg(ProcArgs a) {
 #pragma unroll
       for (int k = 0; k < SPW; k++) any |= act[k];
       if (!any) continue;
+      const unsigned long long tw0 = a.dbg ? clock64() : 0;
       if (lane == 0) {
         const int need = rank[pi];
         depVal = a.fval[f0 + lf];
@@ -1027,11 +1042,12 @@ __global__ void __launch_bounds__(64 * WG_NW) sdp_process_wg(ProcArgs a) {
           if (key && depVal < v) depVal = v;
         }
       }
+      if (a.dbg) tSlot[3] += clock64() - tw0;
     }
     if (ind) {
 #pragma unroll
       for (int k = 0; k < SPW; k++) {
-        const int slot = wave + k * WG_NW;
+        const int slot = wg_slot(wave, k);
         e0[k].b = -1; e0[k].val = 0; e0[k].v = 0; top0[k] = make_int2(0, 0); lastB0[k] = make_int2(0, 0);
         if (act[k]) {
           const Node& nd = ss[slot].cn;
@@ -1044,10 +1060,11 @@ __global__ void __launch_bounds__(64 * WG_NW) sdp_process_wg(ProcArgs a) {
     float wBest = -2.f; int wRank = 0;                                   // this wave's best candidate of the point and its visit rank
 #pragma unroll
     for (int k = 0; k < SPW; k++) {
-      const int slot = wave + k * WG_NW;
+      const int slot = wg_slot(wave, k);
       if (slot >= 2 * LV) continue;
       const uint2 v = vv[k];
       if (!act[k]) continue;
+      const unsigned long long ts0 = a.dbg ? clock64() : 0;
       const Node nd = ss[slot].cn;
       if (ind == 0) {                                                    // PassValueToD1/D2
         if (lane == 0) {
@@ -1168,6 +1185,7 @@ __global__ void __launch_bounds__(64 * WG_NW) sdp_process_wg(ProcArgs a) {
       // Value[ii]: visits apply in the order R family deepest level first, then C family; `val < Ev` keeps the first maximum
       const int vr = (slot / LV) * LV + (LV - 1 - slot % LV);
       if (ev > 0.f && (ev > wBest || (ev == wBest && vr < wRank))) { wBest = ev; wRank = vr; }
+      if (a.dbg) tSlot[k] += clock64() - ts0;
     }
     wave_sync();
     if (ind && lane == 0) {
@@ -1182,6 +1200,7 @@ __global__ void __launch_bounds__(64 * WG_NW) sdp_process_wg(ProcArgs a) {
       (void)__hip_atomic_fetch_add(&cnt[2 * lf + x], one, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
   }
+  if (a.dbg && lane == 0) { for (int x = 0; x < 4; x++) dbgT[4 * wave + x] = tSlot[x]; }
   __syncthreads();
   // Value[], prev: per anchor the start points in order, `val < Ev` (strict) at each
   if (!s_bad) {
@@ -1590,7 +1609,8 @@ int sdp_run(lra_ctx* ctx, int n_reads, const uint64_t* d_cluster_off, const uint
       if (att > 0)
         hipLaunchKernelGGL(k_reset_frags, dim3(nsub), dim3(64), 0, st, r0, subOrder, fragOff, flen, d_rate, opts->rate, fval, fprevNode, fprevInd, fflags, status);
       ProcArgs pa;
-      pa.wgScratch = nullptr; pa.wgOff = nullptr;
+      pa.wgScratch = nullptr; pa.wgOff = nullptr; pa.dbg = 0;
+      uint64_t dbgOff0 = 0; char* dbgBase = nullptr;
       pa.r0 = r0; pa.n = nsub; pa.order = subOrder; pa.ptOff = ptOff; pa.fragOff = fragOff; pa.hfl = hfl; pa.hfr = hfr; pa.flen = flen; pa.fval = fval;
       pa.fprevNode = fprevNode; pa.fprevInd = fprevInd; pa.fflags = fflags; pa.rate_in = d_rate; pa.rate = opts->rate; pa.ra = ra;
       pa.status = status; pa.pwl = pw; pa.poolUsed = poolUsed;
@@ -1607,14 +1627,15 @@ int sdp_run(lra_ctx* ctx, int n_reads, const uint64_t* d_cluster_off, const uint
         for (int i = 0; i < nbig; i++) {
           const uint64_t rdx = (uint64_t)r0 + ord[i];
           const uint64_t Fr = h_frag[rdx + 1] - h_frag[rdx], Pr = h_pt[rdx + 1] - h_pt[rdx];
-          woff[i + 1] = woff[i] + ((36 * Fr + Pr + 64 + 255) & ~(uint64_t)255);
+          woff[i + 1] = woff[i] + ((36 * Fr + Pr + 64 + 8 + 64 * 8 + 255) & ~(uint64_t)255);
         }
         char* wsc = (char*)lra_ensure(ctx, 177, woff[nbig] + 256);
         uint64_t* dwoff = (uint64_t*)lra_ensure(ctx, 178, ((size_t)nbig + 2) * 8);
         if (!wsc || !dwoff) return LRA_ERR_NOMEM;
         LRA_HIP_CHECK(ctx, hipMemcpyAsync(dwoff, woff.data(), ((size_t)nbig + 1) * 8, hipMemcpyHostToDevice, st));
         LRA_HIP_CHECK(ctx, hipStreamSynchronize(st));                      // (woff is a host temporary)
-        pa.wgScratch = wsc; pa.wgOff = dwoff;
+        pa.wgScratch = wsc; pa.wgOff = dwoff; pa.dbg = dbg ? 1 : 0;
+        dbgOff0 = woff[0] + 36 * (h_frag[(uint64_t)r0 + ord[0] + 1] - h_frag[(uint64_t)r0 + ord[0]]) + (h_pt[(uint64_t)r0 + ord[0] + 1] - h_pt[(uint64_t)r0 + ord[0]]); dbgBase = wsc;
       }
       const bool forked = nbig > 0 && nsub > nbig;
       if (nbig > 0) hipLaunchKernelGGL(sdp_process_wg, dim3(nbig), dim3(64 * WG_NW), 0, forked ? lra_side_fork(ctx) : st, pa);
@@ -1629,6 +1650,13 @@ int sdp_run(lra_ctx* ctx, int n_reads, const uint64_t* d_cluster_off, const uint
         fprintf(stderr, "[sdp] mode %d inner %d att %d reads %d (of %d) points total %llu max %llu  process %.1f ms\n", opts->mode, (int)ctx->sdp_inner, att, nsub, nr,
                 (unsigned long long)tot, (unsigned long long)mx, ms);
         (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
+        if (dbgBase && nbig > 0) {                                         // the largest read's waves: cycles in each slot and waiting at end points
+          std::vector<unsigned long long> tw(64);
+          const uint64_t o8 = (dbgOff0 + 7) & ~(uint64_t)7;
+          (void)hipMemcpy(tw.data(), dbgBase + o8, 64 * 8, hipMemcpyDeviceToHost);
+          for (int w = 0; w < 16; w++)
+            fprintf(stderr, "[sdp]   wave %2d: slot cycles %10llu %10llu %10llu  waiting %10llu\n", w, tw[4 * w], tw[4 * w + 1], tw[4 * w + 2], tw[4 * w + 3]);
+        }
       }
       if (att == 2) break;
       LRA_HIP_CHECK(ctx, hipMemcpyAsync(h_status.data(), status + r0, (size_t)nr * 4, hipMemcpyDeviceToHost, st));
