@@ -1562,7 +1562,7 @@ int sdp_run(lra_ctx* ctx, int n_reads, const uint64_t* d_cluster_off, const uint
     lra_time_begin(ctx, ctx->sdp_inner ? "sdp_inner_build_count" : "sdp_build_count");
     {
       // reads ordered largest first: the large ones get a 1024-thread workgroup each, beside the wave-per-read launch
-      const long big_pts = getenv("LRA_SDP_BIG_POINTS") ? atol(getenv("LRA_SDP_BIG_POINTS")) : 6000;
+      const long big_pts = getenv("LRA_SDP_BIG_POINTS") ? atol(getenv("LRA_SDP_BIG_POINTS")) : (ctx->sdp_inner ? 1500 : 6000);
       int nb0 = 0;
       while (nb0 < nr && (long)(h_pt[r0 + h_orderAll[nb0] + 1] - h_pt[r0 + h_orderAll[nb0]]) >= big_pts) nb0++;
       const bool forked = nb0 > 0 && nr > nb0;
@@ -1595,7 +1595,7 @@ int sdp_run(lra_ctx* ctx, int n_reads, const uint64_t* d_cluster_off, const uint
       ba.ra = ra; ba.order = subOrder;
       int nbig = 0;
       {
-        const long big_pts = getenv("LRA_SDP_BIG_POINTS") ? atol(getenv("LRA_SDP_BIG_POINTS")) : 6000;   // (tests lower it to run small reads through the workgroup kernels)
+        const long big_pts = getenv("LRA_SDP_BIG_POINTS") ? atol(getenv("LRA_SDP_BIG_POINTS")) : (ctx->sdp_inner ? 1500 : 6000);   // (tests lower it to run small reads through the workgroup kernels)
         const std::vector<uint32_t>& ord = att == 0 ? h_orderAll : h_prev;
         while (nbig < nsub && (long)(h_pt[r0 + ord[nbig] + 1] - h_pt[r0 + ord[nbig]]) >= big_pts) nbig++;
       }
