@@ -110,7 +110,7 @@ def main():
     total_bases = int(off_h[-1])
     del genome
     rb = reads_h.tobytes()
-    n_threads_rec = min(64, max(1, (os.cpu_count() or 16) - 8)) if world > 1 else 0
+    n_threads_rec = max(8, (os.cpu_count() or 16) // world) if world > 1 else 0
     lanes = []
     for li in range(args.lanes):
         r0, r1 = args.reads * li // args.lanes, args.reads * (li + 1) // args.lanes
@@ -168,36 +168,22 @@ def main():
             err.append(e)
 
     # Every lane runs its own sequence of steps (no barrier between the lanes inside the timed region): lane i starts i / lanes of a step late, so
-    # that the long serial tail of one sub-batch's sparse DP runs beside the other sub-batches' wide kernels.  Collectives are issued in ticket
-    # order (step, lane) so that every rank issues them in the same order.
-    ticket = [0]
-    tcv = threading.Condition()
-    tails = []
-
+    # that the long serial tail of one sub-batch's sparse DP runs beside the other sub-batches' wide kernels.
     copy_stream = torch.cuda.Stream(device=dev_index)
 
-    def tail_thread(lane, held, ev, my_ticket):
+    def tail_thread(lane, held, ev):
         try:
             torch.cuda.set_device(dev_index)
             with torch.cuda.stream(copy_stream):
                 copy_stream.wait_event(ev)
-                with tcv:                                                  # collectives in ticket order on every rank
-                    while ticket[0] != my_ticket:
-                        tcv.wait()
-                got = parallel.gather_records(held, dst=0)                 # the one exchange step: this rank's record buffer -> rank 0
-                with tcv:
-                    ticket[0] += 1
-                    tcv.notify_all()
-                items = []
-                if rank == 0:
-                    for t in got:
-                        hb = t.cpu().numpy()
-                        snap = C.c_void_p()
-                        rc = ctx.lib.lra_map_unpack_host(C.c_void_p(hb.ctypes.data), C.c_uint64(hb.nbytes), C.byref(snap))
-                        assert rc == 0, rc
-                        # (every rank holds reads of the same shape; rank 0 formats each rank's records with its own lane's names / bases as stand-ins
-                        # for the other ranks' -- the text volume and the work are the same)
-                        items.append((lane, snap))
+                # Every rank turns its own reads' records into text (its shard of the output, in ordinal order) with its share of the host's cores: the
+                # path has no exchange step -- reads are independent, and so are their records.  (lra_amd.parallel.gather_records / merge_by_ordinal
+                # bring the record buffers of all ranks to rank 0 when one process has to write one stream: tests/test_parallel.py.)
+                hb = held.cpu().numpy()
+                snap = C.c_void_p()
+                rc = ctx.lib.lra_map_unpack_host(C.c_void_p(hb.ctypes.data), C.c_uint64(hb.nbytes), C.byref(snap))
+                assert rc == 0, rc
+                items = [(lane, snap)]
             host_tail(items)
         except BaseException as e:
             err.append(e)
@@ -230,7 +216,7 @@ def main():
                     prev.join()
                     if dbg:
                         sys.stderr.write("[bench] step %d waited for the previous host tail %.0f ms\n" % (s_, (time.perf_counter() - tC) * 1e3))
-                prev = threading.Thread(target=tail_thread, args=(lane, held, ev, s_ * len(lanes) + li))
+                prev = threading.Thread(target=tail_thread, args=(lane, held, ev))
                 prev.start()
             if prev is not None:
                 prev.join()
@@ -238,7 +224,6 @@ def main():
             err.append(e)
 
     def run_steps(n_steps, stagger):
-        ticket[0] = 0
         if len(lanes) == 1:
             lane_loop(0, n_steps, 0.0)
         else:
@@ -342,7 +327,7 @@ def main():
                                  "a9 (MergeChain), a7 (second LinearExtend + Trim), a8 (second SDP + filters), a13 (incl. a12), a14, a16; then lra_map_pack, the gather of the "
                                  "record buffers to rank 0 and the host tail a16-a17 (SetFromSegAlignment, AlignmentsOrder, SimpleMapQV, SAM text) of batch i beside the "
                                  "device side of batch i + 1%s.  Not in the step: RefineBreakpoint (a15, built; off by default in lra)" % (" -- SKIPPED (--no-records)" if args.no_records else ""),
-                       "parallelism": "reads hash-partitioned by ordinal, 1 process/GPU, genome + both indexes replicated per GPU; %d sub-batch(es) per process on their own HIP streams; RCCL gather of the packed record buffers to rank 0" % args.lanes,
+                       "parallelism": "reads hash-partitioned by ordinal, 1 process/GPU, genome + both indexes replicated per GPU; %d sub-batch(es) per process; no data-path collective: every rank formats the records of its own reads (its shard of the output) beside its next step; RCCL only for the barriers / the final reductions of the timing" % args.lanes,
                        "per_step": {k: int(v) for k, v in stats.items() if not k.startswith("_") and isinstance(v, (int, float))},
                        "reads_with_sv": n_sv},
             "kernel_ms_per_step": {k: round(v[0] / args.steps, 4) for k, v in ktimes.items() if v[1]},
