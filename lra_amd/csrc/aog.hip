@@ -25,6 +25,7 @@
 //   Slot arithmetic (:12-27) is kept exactly: the suffix matrix is addressed through a
 //   shifted origin and some out-of-band neighbour reads land on other rows' slots.
 #include "common.h"
+#include <stdlib.h>
 
 namespace {
 
@@ -443,7 +444,8 @@ struct BatchArgs {
   int32_t* score; int32_t* nblocks; int32_t* blocks; const uint64_t* block_off; int32_t* status;
   // work lists built by classify(): counts[3], lists 3 x n
   int* counts; int* lists;
-  char* gscratch; long gslot_bytes; int gslots;
+  char* gscratch; long gslot_bytes; int gslots;       // class 2: HBM work slots
+  char* gscratchB; long gslotB_bytes; int gslotsB;    // class 6: a few larger ones
 };
 
 __device__ __forceinline__ bool load_problem(const BatchArgs& a, int p, Problem& pr, Geo& g, int& range_ok) {
@@ -469,7 +471,8 @@ __global__ void aog_classify(BatchArgs a) {
       cls = need <= CLASS_A_BYTES ? 0 : need <= CLASS_M1_BYTES ? 4 : need <= CLASS_M2_BYTES ? 5 : need <= CLASS_B_BYTES ? 1 : 2;
       if (g.k + 1 <= 32) cls = cls == 0 ? 7 : cls == 4 ? 8 : cls == 5 ? 9 : cls;                              // anti-diagonals of at most 32 cells: two problems per wave
       if (need <= CLASS_S_BYTES && g.k + 1 <= 16) cls = 3;
-      if (cls == 2 && need > a.gslot_bytes) { a.score[p] = 0; a.nblocks[p] = 0; a.status[p] = LRA_ST_RANGE; cls = -1; }
+      if (cls == 2 && need > a.gslot_bytes) cls = 6;
+      if (cls == 6 && need > a.gslotB_bytes) { a.score[p] = 0; a.nblocks[p] = 0; a.status[p] = LRA_ST_RANGE; cls = -1; }
     }
   }
   // one atomic per wave and class
@@ -488,7 +491,7 @@ __global__ void aog_classify(BatchArgs a) {
 template <int CLS>
 __global__ void __launch_bounds__((CLS == 0 || CLS == 3 || CLS == 7) ? 256 : 64) aog_kernel(BatchArgs a) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  __shared__ int s_roll[CLS == 2 ? 3 * 256 + 1024 + 2048 : 1];
+  __shared__ int s_roll[(CLS == 2 || CLS == 6) ? 3 * 256 + 1024 + 2048 : 1];
   constexpr int G = (CLS == 3) ? 16 : (CLS >= 7) ? 32 : 64;
   constexpr int GPW = 64 / G;
   const int lane = threadIdx.x & 63;
@@ -509,6 +512,7 @@ __global__ void __launch_bounds__((CLS == 0 || CLS == 3 || CLS == 7) ? 256 : 64)
     else if (CLS == 7) solve<32>(lane, pr, g, smem + (wave_in_wg * GPW + lane / G) * CLASS_A_BYTES, &a.score[p], &a.nblocks[p], blk, cap, &a.status[p]);
     else if (CLS == 0) solve<64>(lane, pr, g, smem + wave_in_wg * CLASS_A_BYTES, &a.score[p], &a.nblocks[p], blk, cap, &a.status[p]);
     else if (CLS == 1 || CLS == 4 || CLS == 5) solve<64>(lane, pr, g, smem, &a.score[p], &a.nblocks[p], blk, cap, &a.status[p]);
+    else if (CLS == 6) solve<64>(lane, pr, g, a.gscratchB + (long)(group % a.gslotsB) * a.gslotB_bytes, &a.score[p], &a.nblocks[p], blk, cap, &a.status[p], s_roll);
     else solve<64>(lane, pr, g, a.gscratch + (long)(group % a.gslots) * a.gslot_bytes, &a.score[p], &a.nblocks[p], blk, cap, &a.status[p], s_roll);
     wave_sync();
   }
@@ -533,10 +537,14 @@ int lra_aog_launch_device(lra_ctx* ctx, int n, const char* d_qseq, const char* d
   char* s0 = (char*)lra_scratch(ctx, 0, list_bytes);
   if (!s0) return LRA_ERR_NOMEM;
   a.counts = (int*)s0; a.lists = (int*)(s0 + 64);
-  a.gslots = ctx->num_cu * 4;
-  a.gslot_bytes = 8L << 20;  // 8 MiB per slot: e.g. 1.5 kb x 1.5 kb at k = 60, or 5 kb x 5 kb at k = 15
-  a.gscratch = (char*)lra_scratch(ctx, 1, (size_t)a.gslots * a.gslot_bytes);
+  // class 2: 4 MiB slots, LRA_AOG_SLOTS (default 8) per CU -- with the scores of most of these problems in LDS (rolling, see solve) a wave's HBM traffic is its
+  // arrows, and a CU can keep more of them in flight; class 6: 8 MiB slots, one per CU, for the rare larger problem (1.5 kb x 1.5 kb at k = 60, 5 kb x 5 kb at k = 15)
+  const int perCu = getenv("LRA_AOG_SLOTS") ? atoi(getenv("LRA_AOG_SLOTS")) : 8;
+  a.gslots = ctx->num_cu * perCu; a.gslot_bytes = 4L << 20;
+  a.gslotsB = ctx->num_cu; a.gslotB_bytes = 8L << 20;
+  a.gscratch = (char*)lra_scratch(ctx, 1, (size_t)a.gslots * a.gslot_bytes + (size_t)a.gslotsB * a.gslotB_bytes);
   if (!a.gscratch) return LRA_ERR_NOMEM;
+  a.gscratchB = a.gscratch + (size_t)a.gslots * a.gslot_bytes;
   LRA_HIP_CHECK(ctx, hipMemsetAsync(a.counts, 0, 64, ctx->stream));
   hipLaunchKernelGGL(aog_classify, dim3((n + 255) / 256), dim3(256), 0, ctx->stream, a);
   int wgA = min((n + 3) / 4, ctx->num_cu * 5);
@@ -563,6 +571,7 @@ int lra_aog_launch_device(lra_ctx* ctx, int n, const char* d_qseq, const char* d
   lra_time_end(ctx);
   lra_time_begin(ctx, "aog_hbm");
   hipLaunchKernelGGL(aog_kernel<2>, dim3(wgC), dim3(64), 0, ctx->stream, a);
+  hipLaunchKernelGGL(aog_kernel<6>, dim3(min(n, a.gslotsB)), dim3(64), 0, ctx->stream, a);
   lra_time_end(ctx);
   LRA_HIP_CHECK(ctx, hipGetLastError());
   return LRA_OK;
