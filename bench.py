@@ -25,7 +25,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 
-def cpu_baseline(mapper, reads_h, off_h, args):
+def cpu_baseline(mapper, reads_h, off_h, args, last_res=None):
     """The oracle (CPU restatement) on the host's cores, on a bounded sample of the same batch: MapRead_lowacc read by read
     (oracle_map_reads_lowacc_mt, oracle/pipeline.cpp: the same stages in the same order as the GPU step; tests/test_mapread.py compares its
     alignments with the GPU's bit for bit) on all hardware threads."""
@@ -45,7 +45,32 @@ def cpu_baseline(mapper, reads_h, off_h, args):
     # a bounded sample: 8 reads per host thread (at most 4096), about 10-30 s of wall time
     S = int(min(len(off_h) - 1, 4096, 8 * n_threads))
     res = OP.map_reads_lowacc_mt(reads_h, off_h, 0, S, g, key, pos, g_index, opts, mapper.chrom_pos, n_threads=n_threads)
-    return {"value": res["bases"] / res["seconds"] / 1e9, "unit": "Gbp/s", "cores": n_threads, "kind": "port",
+    # The same reads' alignments as the last GPU step left them (refined blocks + the 18 counters of every SegAlignment), folded the way the oracle folds its own
+    # (oracle/pipeline.cpp: oracle_map_reads_lowacc_mt): the sample is also a parity check at the benchmark's scale.
+    parity = None
+    if last_res is not None:
+        out = mapper.fetch(last_res)
+        na = int(last_res.num_aln)
+        P = np.uint64(1099511628211)
+        total = np.uint64(0)
+        with np.errstate(over="ignore"):
+            for r in range(S):
+                a0, a1 = int(out["job_aln_off"][r * na]), int(out["job_aln_off"][(r + 1) * na])
+                if out["read_status"][r] or a1 == a0:
+                    continue
+                parts = []
+                for a in range(a0, a1):
+                    b = out["blocks"][int(out["block_off"][a]):int(out["block_off"][a + 1])]
+                    parts.append(b.reshape(-1).astype(np.uint32).astype(np.uint64)); parts.append(out["counts"][a].astype(np.int64).astype(np.uint64))
+                x = np.concatenate(parts)
+                pw = np.ones(len(x), np.uint64)
+                if len(x) > 1:
+                    pw[1:] = P
+                    pw = np.multiply.accumulate(pw)                        # P^0 .. P^(n-1), wrapping
+                h = np.sum(x * pw[::-1], dtype=np.uint64)                   # sum x_i P^(n-1-i)
+                total = total + h * np.uint64(r + 1)
+        parity = bool(int(total) == int(res["checksum"]))
+    return {"value": res["bases"] / res["seconds"] / 1e9, "unit": "Gbp/s", "cores": n_threads, "kind": "port", "sample_equals_gpu": parity,
             "sample": "first %d reads (%d bp, %d alignments) of the same batch through the oracle's MapRead_lowacc (a1-a5, a7-a11, a13 incl. a12, a14, a16: the stages of "
                       "the GPU step, oracle/pipeline.cpp) on %d host threads in %.1f s (reference data fetched from the device in %.1f s, not timed)"
                       % (res["n_reads"], res["bases"], res["n_alignments"], n_threads, res["seconds"], fetch_s)}
@@ -153,6 +178,7 @@ def main():
             lc = lane["ctx"]
             def run():
                 res = lane["mapper"].align(lane["rbatch"])
+                lane["last_res"] = res
                 if args.no_records:
                     return
                 d_buf, nb = C.c_void_p(), C.c_uint64(0)
@@ -342,7 +368,7 @@ def main():
             try:
                 for l in lanes[1:]:
                     l["ctx"].close()
-                out["cpu_baseline"] = cpu_baseline(mapper, reads_h, off_h, args)
+                out["cpu_baseline"] = cpu_baseline(mapper, reads_h, off_h, args, lanes[0].get("last_res"))
             except Exception as e:                                          # the bench line must survive a baseline problem; say what happened
                 out["cpu_baseline"] = {"value": None, "unit": "Gbp/s", "cores": os.cpu_count(), "kind": "port", "sample": "failed: %r" % (e,)}
         out["setup_s"] = {"genome": round(gen_s, 1), "index": round(index_s, 1), "reads": round(sim_s, 1)}
