@@ -44,6 +44,8 @@ def cpu_baseline(mapper, reads_h, off_h, args, last_res=None):
     n_threads = os.cpu_count() or 1
     # a bounded sample: 8 reads per host thread (at most 4096), about 10-30 s of wall time
     S = int(min(len(off_h) - 1, 4096, 8 * n_threads))
+    if os.environ.get("LRA_BENCH_CPU_SAMPLE"):                               # (a wider parity sweep: the whole batch takes ~2 minutes on 256 threads)
+        S = int(min(len(off_h) - 1, int(os.environ["LRA_BENCH_CPU_SAMPLE"])))
     res = OP.map_reads_lowacc_mt(reads_h, off_h, 0, S, g, key, pos, g_index, opts, mapper.chrom_pos, n_threads=n_threads)
     # The same reads' alignments as the last GPU step left them (refined blocks + the 18 counters of every SegAlignment), folded the way the oracle folds its own
     # (oracle/pipeline.cpp: oracle_map_reads_lowacc_mt): the sample is also a parity check at the benchmark's scale.
