@@ -26,6 +26,9 @@
 //   shifted origin and some out-of-band neighbour reads land on other rows' slots.
 #include "common.h"
 #include <stdlib.h>
+#include <algorithm>
+#include <vector>
+#include <type_traits>
 
 namespace {
 
@@ -36,6 +39,9 @@ constexpr int CLASS_A_BYTES = 10 * 1024;  // per wave, 4 waves per workgroup
 constexpr int CLASS_B_BYTES = 64 * 1024;  // per wave, 1 wave per workgroup
 constexpr int CLASS_M1_BYTES = 20 * 1024; // the same with a smaller LDS request: 8 / 5 problems per CU instead of 2
 constexpr int CLASS_M2_BYTES = 32 * 1024;
+constexpr int LN_MAX = 24, LN_ROWW = 2;
+constexpr int LN_ARROW_WORDS = LN_MAX * LN_ROWW, LN_PREV_WORDS = LN_MAX + 2, LN_CODE_BYTES = LN_MAX + 1;
+constexpr int LN_BYTES = 64 * (4 * LN_ARROW_WORDS + 4 * LN_PREV_WORDS + 2 * LN_CODE_BYTES);
 constexpr int CLASS_S_BYTES = 2560;       // per 16-lane group: 4 problems per wave, 16 per workgroup (anti-diagonals <= 16 cells)
 
 __device__ __forceinline__ int code_n(unsigned char c) {  // SeqUtils.h:42-75 (seqMapN)
@@ -125,6 +131,77 @@ struct Problem {
   int qLen, tLen, k0, m, mm, indel;
 };
 
+__device__ __forceinline__ int dpp_from_prev_lane(int v) { return __builtin_amdgcn_update_dpp(MISS, v, 0x138, 0xf, 0xf, false); }   // wave_shr:1 -- lane n reads lane n - 1
+__device__ __forceinline__ int dpp_from_next_lane(int v) { return __builtin_amdgcn_update_dpp(MISS, v, 0x130, 0xf, 0xf, false); }   // wave_shl:1 -- lane n reads lane n + 1
+
+// The sweep of solve_reg (and of solve()'s HBM-resident problems): returns the corner cell's score in every lane of the group.  P: the arrows (LDS or HBM); qc / tc: the
+// sequence codes in LDS.  Two steps per iteration (even diagonals, then odd ones, or the other way round), the codes of a lane's next cell on a diagonal loaded one
+// round ahead (a cell's successor on its diagonal is (i + 1, j + 1)), and the boundary values looked at only while an anti-diagonal can still touch row / column 0.
+template <int G, typename ArrowPtr, typename CodePtr>
+__device__ __forceinline__ int reg_fill(int lane, int gbase, const Geo& g, int m, int mm, int indel, ArrowPtr P, CodePtr qc, CodePtr tc) {
+  const int qLen = g.qLen, tLen = g.tLen, k = g.k, R = g.R, diag = g.diag, qB = g.qB, tB = g.tB;
+  // what the boundary / rail stores of solve() leave in cell (i, j) before the sweep (last store wins; everything else is MISS)
+  auto pre = [&](int i, int j) -> int {
+    int v = MISS;
+    if (j == 0 && i >= 1 && i < k + 1) v = indel * i;
+    if (i == 0 && j >= 1 && j <= k + 1) v = indel * j;
+    if (i == 0 && j == 0) v = 0;
+    if (qLen >= tLen) { if (j == i + k + 1 && i <= diag - k - 1) v = MISS; if (i == j + k + 1 && j >= 1 && j < diag + k - 1) v = MISS; }
+    if (qLen <= tLen) { if (i == j + k + 1 && j < diag - 1) v = MISS; if (j == i + k + 1 && j >= 1 && j < diag + k) v = MISS; }
+    return v;
+  };
+  const int Wd = 2 * k + 3;
+  const int sLast = max((qB - 1) + (tB - 1), 0);
+  const int ci = qB - 1, cj = tB - 1;
+  int vE = MISS, vO = MISS, corner = MISS;
+  // eq[x]: do the codes of the lane's NEXT cell on its even (x = 0) / odd (x = 1) diagonal match
+  auto codes_match = [&](int i, int j) -> bool { return i >= 0 && i <= qLen && j >= 0 && j <= tLen && qc[i] == tc[j]; };
+  const bool firstE = ((0 - k - 1) & 1) == 0;                             // step 0 is an even-diagonal step
+  bool eqE, eqO;
+  {
+    const int s0E = firstE ? 0 : 1, s0O = firstE ? 1 : 0;
+    const int dE = 2 * lane - k - 1, dO = 2 * lane + 1 - k - 1;
+    const int iE = (s0E + dE) >> 1, iO = (s0O + dO) >> 1;
+    eqE = codes_match(iE, s0E - iE); eqO = codes_match(iO, s0O - iO);
+  }
+  auto step = [&](int s, auto isE) {
+    constexpr bool E = decltype(isE)::value;
+    const int dd = 2 * lane + (E ? 0 : 1);
+    const int d = dd - k - 1;
+    const int nb1 = E ? dpp_from_prev_lane(vO) : dpp_from_next_lane(vE);   // diagonal dd - 1 (even step) resp. dd + 1 (odd step), one step ago
+    int jlo = max(1, max(s - qB + 1, (s - k + 1) >> 1));
+    if (s - k < 0) jlo = max(1, s - qB + 1);
+    const int jhi = min(tB - 1, min(s - 1, (s + k) >> 1));
+    const int i = (s + d) >> 1, j = s - i;
+    const bool eq = E ? eqE : eqO;
+    const bool nxt = codes_match(i + 1, j + 1);                           // (in flight until this lane's next step on this diagonal, two steps on)
+    int v = MISS;
+    if (dd < Wd && i >= 0 && j >= 0) {
+      if (s >= 2 && j >= jlo && j <= jhi && d >= -k && d <= k) {
+        const int sIns = (E ? nb1 : vE) + indel;                          // (i - 1, j): diagonal dd - 1
+        const int sDel = (E ? vO : nb1) + indel;                          // (i, j - 1): diagonal dd + 1
+        const int sMat = (E ? vE : vO) + (eq ? m : mm);                   // (i - 1, j - 1): this diagonal, two steps ago
+        const int best = max(sIns, max(sDel, sMat));
+        const int ar = (best == sIns) ? A_LEFT : (best == sDel) ? A_DOWN : A_DIAG;
+        v = best;
+        P[j * R + dd] = (signed char)ar;
+      } else if (s <= k + 1) v = pre(i, j);                               // (a boundary value sits in row or column 0: i + j <= k + 1; the rails hold MISS)
+      if (i == ci && j == cj) corner = v;
+    }
+    if (E) { vE = v; eqE = nxt; } else { vO = v; eqO = nxt; }
+  };
+  int s = 0;
+  if (firstE) {
+    for (; s + 1 <= sLast; s += 2) { step(s, std::true_type{}); step(s + 1, std::false_type{}); }
+    if (s <= sLast) step(s, std::true_type{});
+  } else {
+    for (; s + 1 <= sLast; s += 2) { step(s, std::false_type{}); step(s + 1, std::true_type{}); }
+    if (s <= sLast) step(s, std::false_type{});
+  }
+  const int ddc = ci - cj + k + 1;
+  return (ddc >= 0 && ddc < Wd) ? __shfl(corner, gbase + (ddc >> 1)) : MISS;
+}
+
 template <int G, typename BytePtr>
 __device__ __forceinline__ void solve(int wlane, const Problem& pr, const Geo& g, BytePtr mem, int* out_score,
                       int* out_nb, int* blocks, long cap, int* out_status, int* roll = nullptr) {
@@ -189,7 +266,9 @@ __device__ __forceinline__ void solve(int wlane, const Problem& pr, const Geo& g
     };
     const int Wd = 2 * k + 3;
     const int sLast = (qB - 1) + (tB - 1);
-    for (int s = 0; s <= max(sLast, 0); s++) {
+    const bool inRegs = k + 2 <= G;                                      // the band's diagonals fit the lanes two apiece: scores in registers (reg_fill)
+    if (inRegs) rollResult = reg_fill<G>(lane, gbase, g, m, mm, indel, w.pPre, lq, lt);
+    for (int s = 0; !inRegs && s <= max(sLast, 0); s++) {
       int* cur = roll + (s % 3) * 256; const int* p1 = roll + ((s + 2) % 3) * 256; const int* p2 = roll + ((s + 1) % 3) * 256;
       int jlo = max(1, max(s - qB + 1, (s - k + 1) >> 1));
       if (s - k < 0) jlo = max(1, s - qB + 1);
@@ -216,7 +295,7 @@ __device__ __forceinline__ void solve(int wlane, const Problem& pr, const Geo& g
       wave_sync_lds();
     }
     wave_sync();
-    { const int ddc = (qB - 1) - (tB - 1) + k + 1; rollResult = (ddc >= 0 && ddc < Wd) ? __shfl(rollResult, gbase + (ddc % G)) : MISS; }   // the lane that owns the corner's diagonal
+    if (!inRegs) { const int ddc = (qB - 1) - (tB - 1) + k + 1; rollResult = (ddc >= 0 && ddc < Wd) ? __shfl(rollResult, gbase + (ddc % G)) : MISS; }   // the lane that owns the corner's diagonal
   }
   for (int s = 2; !rolling && s <= (qB - 1) + (tB - 1); s++) {
     int jlo = max(1, max(s - qB + 1, (s - k + 1) >> 1));   // ceil((s-k)/2), s-k may be < 0
@@ -382,16 +461,27 @@ __device__ __forceinline__ void solve(int wlane, const Problem& pr, const Geo& g
         run = 0;
       }
     };
-    int arrow = (ti >= 0 && tj >= 0 && inb(PI(ti, tj))) ? arrowAt(ti, tj) : A_DONE;
-    long it = 0;
-    while (arrow != A_BORDER && arrow != A_DONE && ti >= 0 && tj >= 0) {
-      if (++it > iter_cap) { status |= LRA_ST_NO_TERMINATION; break; }
-      if (arrow == A_DIAG) { run++; ti--; tj--; }
-      else if (arrow == A_LEFT) { flushL(ti, tj); ti--; }
-      else if (arrow == A_DOWN) { flushL(ti, tj); tj--; }
-      else { if (arrow != A_GAPLEFT && arrow != A_GAPDOWN) status |= LRA_ST_NO_TERMINATION; break; }
-      if (ti < 0 || tj < 0) break;
-      arrow = arrowAt(ti, tj);
+    // lane l looks at the cell l steps down the current diagonal (inside the staged window): a run of diagonal arrows is one round
+    constexpr int A_OFF = 100, A_WIN = 101;
+    const unsigned long long gmask = (~0ULL >> (64 - G)) << gbase;
+    if (ti >= 0 && tj >= 0 && inb(PI(ti, tj))) {
+      while (true) {
+        (void)arrowAt(ti, tj);                                            // the window holds row tj now
+        const int jl = tj - lane;
+        const bool on = ti - lane >= 0 && jl >= 0;
+        const int a = !on ? A_OFF : jl < cLo ? A_WIN : (int)(signed char)chunk[(jl - cLo) * R + (ti - tj) + k + 1];
+        const unsigned long long nd = (__ballot(a != A_DIAG) & gmask) >> gbase;
+        const int f = nd ? __ffsll((long long)nd) - 1 : G;
+        run += f; ti -= f; tj -= f;
+        if (f == G) { if (ti < 0 || tj < 0) break; continue; }
+        const int af = __shfl(a, gbase + f);
+        if (af == A_WIN) continue;                                        // past the window: stage the next one
+        if (af == A_OFF) break;
+        if (af == A_LEFT) { flushL(ti, tj); ti--; }
+        else if (af == A_DOWN) { flushL(ti, tj); tj--; }
+        else { if (af != A_BORDER && af != A_DONE && af != A_GAPLEFT && af != A_GAPDOWN) status |= LRA_ST_NO_TERMINATION; break; }
+        if (ti < 0 || tj < 0) break;
+      }
     }
     flushL(ti, tj);
   } else if (lane == 0) {
@@ -435,6 +525,100 @@ __device__ __forceinline__ void solve(int wlane, const Problem& pr, const Geo& g
   }
 }
 
+// ---- the same DP for a problem that only uses the prefix band (!g.top: the common case -- the two sequences differ in length by less than the band), with the SCORES
+// in registers.  Nothing reads a prefix score again but the cell's three successors (and the corner's caller), and with lane L holding diagonals dd = 2L (even) and
+// 2L + 1 (odd) of the band (dd = i - j + k + 1), a cell's predecessors are: the same diagonal two steps ago (own register), and the two neighbouring diagonals one
+// step ago -- one in the lane's other register, one in the neighbouring lane's (a DPP wave shift).  An anti-diagonal step is then ~30 ALU instructions, one DPP move and
+// one arrow store, with no fence: the LDS version's step is a chain of LDS round trips (three score loads, the stores, a wave fence) several times as long.
+// LDS (or HBM) holds the 1-byte arrows and the sequence codes only: a fifth of the memory, so five times as many problems in flight per CU.
+// Trace back: the G lanes look at the next G cells down the current diagonal at once; a run of diagonal arrows (the common step) is taken in one round.
+// Needs (2k + 3 + 1) / 2 <= G, i.e. k + 2 <= G.  Bit-identical to solve() by construction: same cell order, same operands, same tie rules.
+template <int G, typename BytePtr>
+__device__ __forceinline__ void solve_reg(int wlane, const Problem& pr, const Geo& g, BytePtr mem, int* out_score, int* out_nb, int* blocks, long cap, int* out_status) {
+  const int qLen = g.qLen, tLen = g.tLen, k = g.k, R = g.R, diag = g.diag, n = g.n, nUsed = g.nUsed;
+  const int m = pr.m, mm = pr.mm, indel = pr.indel;
+  const int lane = wlane & (G - 1), gbase = wlane - lane;
+  auto* P = (signed char*)&mem[0];                                        // arrows [align4(nUsed)], then the codes
+  auto* qc = (unsigned char*)&mem[align4(nUsed)];
+  auto* tc = (unsigned char*)&mem[align4(nUsed) + align4(qLen + 1)];
+  int status = 0;
+  auto PI = [&](int i, int j) { return j * R + (i - j) + k + 1; };
+  auto inb = [&](int s_) { return s_ >= 0 && s_ < n; };
+#define PSETA(slot, ar) do { int s__ = (slot); if (inb(s__)) { if (s__ < nUsed) P[s__] = (ar); } else status |= LRA_ST_OOB_SLOT; } while (0)
+  for (int x = lane; x <= qLen; x += G) qc[x] = x ? code_n((unsigned char)pr.q[x - 1]) : 0;
+  for (int x = lane; x <= tLen; x += G) tc[x] = x ? code_n((unsigned char)pr.t[x - 1]) : 0;
+  { auto* P4 = (int*)&mem[0]; for (int x = lane; x < (int)(align4(nUsed) >> 2); x += G) P4[x] = -1; }
+  wave_sync();
+  // prefix boundary, then rails (the rails overwrite (0, k + 1)): the arrows of solve()'s stores, in its order
+  for (int i = 1 + lane; i < k + 1; i += G) PSETA(PI(i, 0), A_LEFT);
+  for (int j = 1 + lane; j <= k + 1; j += G) PSETA(PI(0, j), A_DOWN);
+  if (lane == 0) PSETA(PI(0, 0), A_DONE);
+  wave_sync();
+  if (qLen >= tLen) {
+    for (int i = lane; i <= diag - k - 1; i += G) PSETA(PI(i, i + k + 1), A_BORDER);
+    for (int i = 1 + lane; i < diag + k - 1; i += G) PSETA(PI(i + k + 1, i), A_BORDER);
+  }
+  if (qLen <= tLen) {
+    for (int j = lane; j < diag - 1; j += G) PSETA(PI(j + k + 1, j), A_BORDER);
+    for (int j = 1 + lane; j < diag + k; j += G) PSETA(PI(j - k - 1, j), A_BORDER);
+  }
+  wave_sync();
+#undef PSETA
+  const int qB = g.qB, tB = g.tB;
+  const int result = reg_fill<G>(lane, gbase, g, m, mm, indel, P, qc, tc);
+  wave_sync();
+  int ti = qB - 1, tj = tB - 1;
+  // ---- trace back (solve()'s prefix walk :589-629): every lane holds the walk's state; lane l looks at the cell l steps down the current diagonal
+  long nb = 0; int run = 0;
+  auto flushL = [&](int i_after, int j_after) {
+    if (run > 0) {
+      if (nb < cap) { if (lane == 0) { blocks[3 * nb] = i_after; blocks[3 * nb + 1] = j_after; blocks[3 * nb + 2] = run; } }
+      else status |= LRA_ST_CAPACITY;
+      nb++;
+      run = 0;
+    }
+  };
+  constexpr int A_OFF = 100;                                              // off the matrix: the walk stops after the move that leaves it
+  const unsigned long long gmask = (~0ULL >> (64 - G)) << gbase;
+  if (ti >= 0 && tj >= 0 && inb(PI(ti, tj))) {
+    while (true) {
+      const bool on = ti - lane >= 0 && tj - lane >= 0;
+      const int a = on ? (int)P[PI(ti, tj) - lane * R] : A_OFF;
+      const unsigned long long nd = (__ballot(a != A_DIAG) & gmask) >> gbase;
+      const int f = nd ? __ffsll((long long)nd) - 1 : G;                  // diagonal arrows before the first other one
+      run += f; ti -= f; tj -= f;
+      if (f == G) { if (ti < 0 || tj < 0) break; continue; }
+      const int af = __shfl(a, gbase + f);
+      if (af == A_OFF) break;                                             // (ti < 0 || tj < 0 after a diagonal move)
+      if (af == A_LEFT) { flushL(ti, tj); ti--; }
+      else if (af == A_DOWN) { flushL(ti, tj); tj--; }
+      else { if (af != A_BORDER && af != A_DONE && af != A_GAPLEFT && af != A_GAPDOWN) status |= LRA_ST_NO_TERMINATION; break; }
+      if (ti < 0 || tj < 0) break;
+    }
+  }
+  flushL(ti, tj);
+  // ---- publish (as solve())
+  wave_sync();
+  const long nw = min(nb, cap);
+  for (long x = lane; x < (nw + 1) / 2; x += G) {
+    const long y = nw - 1 - x;
+    const int a0 = blocks[3 * x], a1 = blocks[3 * x + 1], a2 = blocks[3 * x + 2];
+    const int b0 = blocks[3 * y], b1 = blocks[3 * y + 1], b2 = blocks[3 * y + 2];
+    blocks[3 * x] = b0 - ti; blocks[3 * x + 1] = b1 - tj; blocks[3 * x + 2] = b2;
+    if (y != x) { blocks[3 * y] = a0 - ti; blocks[3 * y + 1] = a1 - tj; blocks[3 * y + 2] = a2; }
+  }
+  for (int off = G / 2; off > 0; off >>= 1) status |= __shfl_xor(status, off);
+  if (lane == 0) {
+    int r = result;
+    if (r < -(1 << 29)) r = (int)(unsigned int)((long)INT_MIN + ((long)r - (long)MISS));
+    *out_score = r;
+    *out_nb = (int)nb;
+    *out_status = status;
+  }
+}
+__device__ __forceinline__ long need_bytes_reg(const Geo& g) { return align4(g.nUsed) + align4(g.qLen + 1) + align4(g.tLen + 1); }
+constexpr int REG_S_BYTES = 2048, REG_M_BYTES = 8192, REG_L_BYTES = 32768, REG_X_BYTES = 65536;   // classes 10 (16 lanes), 11 (32 lanes), 12, 13 (64 lanes)
+
 struct BatchArgs {
   int n;
   const char* qseq; const char* tseq;
@@ -446,6 +630,9 @@ struct BatchArgs {
   int* counts; int* lists;
   char* gscratch; long gslot_bytes; int gslots;       // class 2: HBM work slots
   char* gscratchB; long gslotB_bytes; int gslotsB;    // class 6: a few larger ones
+  int use_reg;                                        // classes 10-13 (solve_reg) in use
+  int use_lane;                                       // class 14 (aog_lane_kernel) in use
+  int regL, regX;                                     // largest arrows + codes footprint of classes 12 and 13 (above: the HBM class, whose sweep is in registers too)
 };
 
 __device__ __forceinline__ bool load_problem(const BatchArgs& a, int p, Problem& pr, Geo& g, int& range_ok) {
@@ -473,11 +660,19 @@ __global__ void aog_classify(BatchArgs a) {
       if (need <= CLASS_S_BYTES && g.k + 1 <= 16) cls = 3;
       if (cls == 2 && need > a.gslot_bytes) cls = 6;
       if (cls == 6 && need > a.gslotB_bytes) { a.score[p] = 0; a.nblocks[p] = 0; a.status[p] = LRA_ST_RANGE; cls = -1; }
+      if (cls >= 0 && !g.top && a.use_reg) {                                // prefix band only: scores in registers (solve_reg), arrows + codes in LDS
+        const long nr = need_bytes_reg(g);
+        if (a.use_lane && g.qLen <= LN_MAX && g.tLen <= LN_MAX) cls = 14;
+        else if (g.k + 2 <= 16 && nr <= REG_S_BYTES) cls = 10;
+        else if (g.k + 2 <= 32 && nr <= REG_M_BYTES) cls = 11;
+        else if (g.k + 2 <= 64 && nr <= a.regL) cls = 12;
+        else if (g.k + 2 <= 64 && nr <= a.regX) cls = 13;
+      }
     }
   }
   // one atomic per wave and class
   const unsigned long long below = (lane == 0) ? 0ULL : (~0ULL >> (64 - lane));
-  for (int c = 0; c < 10; c++) {
+  for (int c = 0; c < 15; c++) {
     const unsigned long long m = __ballot(cls == c);
     if (!m) continue;
     int base = 0;
@@ -518,6 +713,133 @@ __global__ void __launch_bounds__((CLS == 0 || CLS == 3 || CLS == 7) ? 256 : 64)
   }
 }
 
+// classes 10-13: solve_reg.  10: 16 lanes per problem, 16 problems per 256-thread workgroup; 11: 32 lanes, 4 problems per 128 threads; 12, 13: a wave per problem
+template <int CLS>
+__global__ void __launch_bounds__(CLS == 10 ? 256 : CLS == 11 ? 128 : 64) aog_reg_kernel(BatchArgs a) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  constexpr int G = CLS == 10 ? 16 : CLS == 11 ? 32 : 64;
+  constexpr int BYTES = CLS == 10 ? REG_S_BYTES : CLS == 11 ? REG_M_BYTES : CLS == 12 ? REG_L_BYTES : REG_X_BYTES;
+  constexpr int GPW = 64 / G;
+  const int lane = threadIdx.x & 63;
+  const int wave_in_wg = threadIdx.x >> 6;
+  const int waves_per_wg = blockDim.x >> 6;
+  const int group = (blockIdx.x * waves_per_wg + wave_in_wg) * GPW + lane / G;
+  const int ngroups = gridDim.x * waves_per_wg * GPW;
+  const int count = a.counts[CLS];
+  for (int x = group; x < count; x += ngroups) {
+    const int p = a.lists[(long)CLS * a.n + x];
+    Problem pr; Geo g; int ok;
+    load_problem(a, p, pr, g, ok);
+    const long cap = (long)(a.block_off[p + 1] - a.block_off[p]);
+    int* blk = a.blocks + 3 * a.block_off[p];
+    solve_reg<G>(lane, pr, g, smem + (wave_in_wg * GPW + lane / G) * BYTES, &a.score[p], &a.nblocks[p], blk, cap, &a.status[p]);
+    wave_sync();
+  }
+}
+
+
+// ---- class 14: the tiny problems (both sequences at most LN_MAX long, prefix band only) -- most of a batch's gaps between neighbouring anchors are a handful of
+// bases -- one LANE per problem.  A wave's anti-diagonal sweep spends more on a 7 x 7 problem's set-up than on its 49 cells; here 64 problems go through the wave at
+// once, each lane filling its own band row by row (the values do not depend on the order the cells are visited in): the previous row's scores in LDS (one word per
+// column, lane-interleaved, updated in place), the arrows two bits apiece (LEFT / DOWN / DIAG; two words per row), the sequence codes one byte each.  The cells the
+// sweep never computes -- row / column 0, the rails, everything off the band -- are what solve()'s boundary stores leave there: pre() for the scores, pre_arrow()
+// for the arrows.  The walk runs twice over the arrows in LDS (count the blocks and find where it ends; then store them in alignment order).
+
+__global__ void __launch_bounds__(64) aog_lane_kernel(BatchArgs a) {
+  __shared__ __attribute__((aligned(16))) char smem[LN_BYTES];
+  const int lane = threadIdx.x;
+  unsigned* AR = (unsigned*)smem;                                         // [LN_ARROW_WORDS][64]
+  int* PV = (int*)(smem + 64 * 4 * LN_ARROW_WORDS);                       // [LN_PREV_WORDS][64]
+  unsigned char* QC = (unsigned char*)(smem + 64 * 4 * (LN_ARROW_WORDS + LN_PREV_WORDS));   // [LN_CODE_BYTES][64]
+  unsigned char* TC = QC + 64 * LN_CODE_BYTES;
+  const int count = a.counts[14];
+  for (int x0 = blockIdx.x * 64; x0 < count; x0 += gridDim.x * 64) {
+    const int x = x0 + lane;
+    if (x < count) {
+      const int p = a.lists[14L * a.n + x];
+      Problem pr; Geo g; int ok;
+      load_problem(a, p, pr, g, ok);
+      const int qLen = g.qLen, tLen = g.tLen, k = g.k, diag = g.diag, qB = g.qB, tB = g.tB;
+      const int m = pr.m, mm = pr.mm, indel = pr.indel;
+      for (int i = 1; i <= qLen; i++) QC[i * 64 + lane] = (unsigned char)code_n((unsigned char)pr.q[i - 1]);
+      for (int j = 1; j <= tLen; j++) TC[j * 64 + lane] = (unsigned char)code_n((unsigned char)pr.t[j - 1]);
+      auto in_region = [&](int i, int j) { return i >= 1 && i <= qB - 1 && j >= 1 && j <= tB - 1 && i - j <= k && j - i <= k; };
+      auto pre = [&](int i, int j) -> int {
+        int v = MISS;
+        if (j == 0 && i >= 1 && i < k + 1) v = indel * i;
+        if (i == 0 && j >= 1 && j <= k + 1) v = indel * j;
+        if (i == 0 && j == 0) v = 0;
+        if (qLen >= tLen) { if (j == i + k + 1 && i <= diag - k - 1) v = MISS; if (i == j + k + 1 && j >= 1 && j < diag + k - 1) v = MISS; }
+        if (qLen <= tLen) { if (i == j + k + 1 && j < diag - 1) v = MISS; if (j == i + k + 1 && j >= 1 && j < diag + k) v = MISS; }
+        return v;
+      };
+      auto pre_arrow = [&](int i, int j) -> int {                           // the arrows of the same stores (-1: never stored)
+        int v = -1;
+        if (i < 0 || j < 0) return v;
+        if (j == 0 && i >= 1 && i < k + 1) v = A_LEFT;
+        if (i == 0 && j >= 1 && j <= k + 1) v = A_DOWN;
+        if (i == 0 && j == 0) v = A_DONE;
+        if (qLen >= tLen) { if (j == i + k + 1 && i <= diag - k - 1) v = A_BORDER; if (i == j + k + 1 && j >= 1 && j < diag + k - 1) v = A_BORDER; }
+        if (qLen <= tLen) { if (i == j + k + 1 && j < diag - 1) v = A_BORDER; if (j == i + k + 1 && j >= 1 && j < diag + k) v = A_BORDER; }
+        return v;
+      };
+      for (int j = 1; j <= tB - 1; j++) {
+        const int ilo = max(1, j - k), ihi = min(qB - 1, j + k);
+        const int tcj = TC[j * 64 + lane];
+        int left = pre(ilo - 1, j);                                        // column 0 or the lower rail
+        int dg = in_region(ilo - 1, j - 1) ? PV[(ilo - 1) * 64 + lane] : pre(ilo - 1, j - 1);
+        unsigned long long acc = 0;
+        for (int i = ilo; i <= ihi; i++) {
+          const int up = in_region(i, j - 1) ? PV[i * 64 + lane] : pre(i, j - 1);
+          const int sIns = left + indel, sDel = up + indel, sMat = dg + (QC[i * 64 + lane] == tcj ? m : mm);
+          const int best = max(sIns, max(sDel, sMat));
+          const int ar = (best == sIns) ? A_LEFT : (best == sDel) ? A_DOWN : A_DIAG;
+          acc |= (unsigned long long)ar << (2 * (i - ilo));
+          PV[i * 64 + lane] = best;
+          dg = up; left = best;
+        }
+        AR[((j - 1) * LN_ROWW) * 64 + lane] = (unsigned)acc; AR[((j - 1) * LN_ROWW + 1) * 64 + lane] = (unsigned)(acc >> 32);
+      }
+      const int ci = qB - 1, cj = tB - 1;
+      const int result = in_region(ci, cj) ? PV[ci * 64 + lane] : ((ci >= 0 && cj >= 0) ? pre(ci, cj) : MISS);
+      auto arrow_at = [&](int i, int j) -> int {
+        if (!in_region(i, j)) return pre_arrow(i, j);
+        const int sh = 2 * (i - max(1, j - k));
+        const unsigned w = AR[((j - 1) * LN_ROWW + (sh >> 5)) * 64 + lane];
+        return (int)((w >> (sh & 31)) & 3u);
+      };
+      const long cap = (long)(a.block_off[p + 1] - a.block_off[p]);
+      int* blocks = a.blocks + 3 * a.block_off[p];
+      int status = 0;
+      long nb = 0; int fi = ci, fj = cj;
+      for (int pass = 0; pass < 2; pass++) {                              // solve()'s prefix walk :589-629; pass 1 stores
+        const long nw = min(nb, cap);
+        long w = 0; int run = 0; int ti = ci, tj = cj;
+        auto flush = [&](int i_after, int j_after) {
+          if (run > 0) {
+            if (pass == 1 && w < nw) { int* b = blocks + 3 * (nw - 1 - w); b[0] = i_after - fi; b[1] = j_after - fj; b[2] = run; }
+            w++; run = 0;
+          }
+        };
+        int arrow = (ti >= 0 && tj >= 0) ? arrow_at(ti, tj) : A_DONE;
+        while (arrow != A_BORDER && arrow != A_DONE && ti >= 0 && tj >= 0) {
+          if (arrow == A_DIAG) { run++; ti--; tj--; }
+          else if (arrow == A_LEFT) { flush(ti, tj); ti--; }
+          else if (arrow == A_DOWN) { flush(ti, tj); tj--; }
+          else { if (arrow != A_GAPLEFT && arrow != A_GAPDOWN) status |= LRA_ST_NO_TERMINATION; break; }
+          if (ti < 0 || tj < 0) break;
+          arrow = arrow_at(ti, tj);
+        }
+        flush(ti, tj);
+        if (pass == 0) { nb = w; fi = ti; fj = tj; if (nb > cap) status |= LRA_ST_CAPACITY; }
+      }
+      int r = result;
+      if (r < -(1 << 29)) r = (int)(unsigned int)((long)INT_MIN + ((long)r - (long)MISS));
+      a.score[p] = r; a.nblocks[p] = (int)nb; a.status[p] = status;
+    }
+  }
+}
+
 }  // namespace
 
 int lra_aog_launch_device(lra_ctx* ctx, int n, const char* d_qseq, const char* d_tseq, const uint64_t* d_q_off,
@@ -532,8 +854,8 @@ int lra_aog_launch_device(lra_ctx* ctx, int n, const char* d_qseq, const char* d
   a.n = n; a.qseq = d_qseq; a.tseq = d_tseq; a.q_off = d_q_off; a.q_len = d_q_len; a.t_off = d_t_off; a.t_len = d_t_len;
   a.k = d_k; a.m = m; a.mm = mm; a.indel = indel;
   a.score = d_score; a.nblocks = d_nblocks; a.blocks = d_blocks; a.block_off = d_block_off; a.status = d_status;
-  // scratch slot 0: counts[16] + lists[10n];  slot 1: class-C HBM work slots
-  size_t list_bytes = 64 + sizeof(int) * 10 * (size_t)n;
+  // scratch slot 0: counts[16] + lists[15n];  slot 1: class-C HBM work slots
+  size_t list_bytes = 64 + sizeof(int) * 15 * (size_t)n;
   char* s0 = (char*)lra_scratch(ctx, 0, list_bytes);
   if (!s0) return LRA_ERR_NOMEM;
   a.counts = (int*)s0; a.lists = (int*)(s0 + 64);
@@ -545,34 +867,78 @@ int lra_aog_launch_device(lra_ctx* ctx, int n, const char* d_qseq, const char* d
   a.gscratch = (char*)lra_scratch(ctx, 1, (size_t)a.gslots * a.gslot_bytes + (size_t)a.gslotsB * a.gslotB_bytes);
   if (!a.gscratch) return LRA_ERR_NOMEM;
   a.gscratchB = a.gscratch + (size_t)a.gslots * a.gslot_bytes;
+  if (getenv("LRA_AOG_DBG")) {                                            // shapes of the batch's problems (host side, diagnostic)
+    std::vector<int32_t> hq(n), ht(n), hk(n);
+    (void)hipMemcpy(hq.data(), d_q_len, (size_t)n * 4, hipMemcpyDeviceToHost); (void)hipMemcpy(ht.data(), d_t_len, (size_t)n * 4, hipMemcpyDeviceToHost);
+    (void)hipMemcpy(hk.data(), d_k, (size_t)n * 4, hipMemcpyDeviceToHost);
+    long nTop = 0, nBigK = 0, steps = 0; long byNeed[8] = {0, 0, 0, 0, 0, 0, 0, 0}; long byK[4] = {0, 0, 0, 0}; long cellsBy[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    for (int p = 0; p < n; p++) {
+      const int q = hq[p], t = ht[p]; const int diag = std::max(1, std::min(q, t)); int k = std::min(diag, hk[p]); bool top = true;
+      if (diag + 2 * k >= std::max(q, t)) { k *= 2; top = false; }
+      const long R = 2 * k + 3, tB = std::min(diag + k, t + 1); const long nU = top ? (3 + k + diag) * R : std::min((3 + k + diag) * R, tB * R);
+      if (top) { nTop++; continue; }
+      if (k > 62) { nBigK++; continue; }
+      const long need = nU + q + t + 8;
+      const int b = need <= 2048 ? 0 : need <= 4096 ? 1 : need <= 8192 ? 2 : need <= 16384 ? 3 : need <= 32768 ? 4 : need <= 65536 ? 5 : need <= 160 * 1024 ? 6 : 7;
+      byNeed[b]++; cellsBy[b] += nU; steps += q + t;
+      byK[k <= 14 ? 0 : k <= 30 ? 1 : k <= 62 ? 2 : 3]++;
+    }
+    fprintf(stderr, "[aog] n %d top %ld k>62 %ld | arrows+codes <=2K %ld <=4K %ld <=8K %ld <=16K %ld <=32K %ld <=64K %ld <=160K %ld more %ld | cells(M) %.1f %.1f %.1f %.1f %.1f %.1f %.1f %.1f | k<=14 %ld <=30 %ld <=62 %ld | steps(M) %.1f\n",
+            n, nTop, nBigK, byNeed[0], byNeed[1], byNeed[2], byNeed[3], byNeed[4], byNeed[5], byNeed[6], byNeed[7], cellsBy[0] / 1e6, cellsBy[1] / 1e6, cellsBy[2] / 1e6, cellsBy[3] / 1e6,
+            cellsBy[4] / 1e6, cellsBy[5] / 1e6, cellsBy[6] / 1e6, cellsBy[7] / 1e6, byK[0], byK[1], byK[2], steps / 1e6);
+  }
+  a.use_reg = getenv("LRA_AOG_NOREG") ? 0 : 1;
+  a.use_lane = (a.use_reg && !getenv("LRA_AOG_NOLANE")) ? 1 : 0;
+  a.regL = getenv("LRA_AOG_REG_L") ? std::min(atoi(getenv("LRA_AOG_REG_L")), REG_L_BYTES) : 16384;
+  a.regX = getenv("LRA_AOG_REG_X") ? std::min(atoi(getenv("LRA_AOG_REG_X")), REG_X_BYTES) : 0;
+  if (a.use_reg) LRA_HIP_CHECK(ctx, hipFuncSetAttribute((const void*)aog_reg_kernel<13>, hipFuncAttributeMaxDynamicSharedMemorySize, REG_X_BYTES));
   LRA_HIP_CHECK(ctx, hipMemsetAsync(a.counts, 0, 64, ctx->stream));
   hipLaunchKernelGGL(aog_classify, dim3((n + 255) / 256), dim3(256), 0, ctx->stream, a);
   int wgA = min((n + 3) / 4, ctx->num_cu * 5);
   int wgB = min(n, ctx->num_cu * 2);
   int wgC = min(n, a.gslots);
-  lra_time_begin(ctx, "aog_lds_tiny");
-  hipLaunchKernelGGL(aog_kernel<3>, dim3(min((n + 15) / 16, ctx->num_cu * 8)), dim3(256), 16 * CLASS_S_BYTES, ctx->stream, a);
-  lra_time_end(ctx);
   LRA_HIP_CHECK(ctx, hipFuncSetAttribute((const void*)aog_kernel<7>, hipFuncAttributeMaxDynamicSharedMemorySize, 8 * CLASS_A_BYTES));
-  lra_time_begin(ctx, "aog_lds_small");
-  hipLaunchKernelGGL(aog_kernel<7>, dim3(min((n + 7) / 8, ctx->num_cu * 2)), dim3(256), 8 * CLASS_A_BYTES, ctx->stream, a);
-  hipLaunchKernelGGL(aog_kernel<0>, dim3(wgA), dim3(256), 4 * CLASS_A_BYTES, ctx->stream, a);
-  lra_time_end(ctx);
   LRA_HIP_CHECK(ctx, hipFuncSetAttribute((const void*)aog_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, CLASS_B_BYTES));
   LRA_HIP_CHECK(ctx, hipFuncSetAttribute((const void*)aog_kernel<9>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * CLASS_M2_BYTES));
-  lra_time_begin(ctx, "aog_lds_medium");
-  hipLaunchKernelGGL(aog_kernel<8>, dim3(min((n + 1) / 2, ctx->num_cu * 4)), dim3(64), 2 * CLASS_M1_BYTES, ctx->stream, a);
-  hipLaunchKernelGGL(aog_kernel<9>, dim3(min((n + 1) / 2, ctx->num_cu * 2)), dim3(64), 2 * CLASS_M2_BYTES, ctx->stream, a);
-  hipLaunchKernelGGL(aog_kernel<4>, dim3(min(n, ctx->num_cu * 8)), dim3(64), CLASS_M1_BYTES, ctx->stream, a);
-  hipLaunchKernelGGL(aog_kernel<5>, dim3(min(n, ctx->num_cu * 5)), dim3(64), CLASS_M2_BYTES, ctx->stream, a);
-  lra_time_end(ctx);
-  lra_time_begin(ctx, "aog_lds_large");
-  hipLaunchKernelGGL(aog_kernel<1>, dim3(wgB), dim3(64), CLASS_B_BYTES, ctx->stream, a);
-  lra_time_end(ctx);
+  // The classes are independent, and every class's launch ends with a few long problems on a few CUs: they run side by side on the context's side streams
+  // (the HBM class, the longest, on the context's own stream) instead of one after the other.  LRA_AOG_SERIAL=1: one stream (for comparisons).
+  static const bool serial = getenv("LRA_AOG_SERIAL") != nullptr;
+  const hipStream_t sm = ctx->stream;
+  const hipStream_t s1 = serial ? sm : lra_side_fork(ctx, 1), s2 = serial ? sm : lra_side_fork(ctx, 2), s3 = serial ? sm : lra_side_fork(ctx, 3);
+  lra_time_begin(ctx, "aog_lds_large", s1);
+  hipLaunchKernelGGL(aog_kernel<1>, dim3(wgB), dim3(64), CLASS_B_BYTES, s1, a);
+  lra_time_end(ctx, s1);
+  lra_time_begin(ctx, "aog_lds_small", s2);
+  hipLaunchKernelGGL(aog_kernel<7>, dim3(min((n + 7) / 8, ctx->num_cu * 2)), dim3(256), 8 * CLASS_A_BYTES, s2, a);
+  hipLaunchKernelGGL(aog_kernel<0>, dim3(wgA), dim3(256), 4 * CLASS_A_BYTES, s2, a);
+  lra_time_end(ctx, s2);
+  lra_time_begin(ctx, "aog_lds_tiny", s2);
+  hipLaunchKernelGGL(aog_kernel<3>, dim3(min((n + 15) / 16, ctx->num_cu * 8)), dim3(256), 16 * CLASS_S_BYTES, s2, a);
+  lra_time_end(ctx, s2);
+  lra_time_begin(ctx, "aog_lds_medium", s3);
+  hipLaunchKernelGGL(aog_kernel<8>, dim3(min((n + 1) / 2, ctx->num_cu * 4)), dim3(64), 2 * CLASS_M1_BYTES, s3, a);
+  hipLaunchKernelGGL(aog_kernel<9>, dim3(min((n + 1) / 2, ctx->num_cu * 2)), dim3(64), 2 * CLASS_M2_BYTES, s3, a);
+  hipLaunchKernelGGL(aog_kernel<4>, dim3(min(n, ctx->num_cu * 8)), dim3(64), CLASS_M1_BYTES, s3, a);
+  hipLaunchKernelGGL(aog_kernel<5>, dim3(min(n, ctx->num_cu * 5)), dim3(64), CLASS_M2_BYTES, s3, a);
+  lra_time_end(ctx, s3);
+  if (a.use_lane) {
+    lra_time_begin(ctx, "aog_lane");
+    hipLaunchKernelGGL(aog_lane_kernel, dim3(min((n + 63) / 64, ctx->num_cu * 7)), dim3(64), 0, sm, a);
+    lra_time_end(ctx);
+  }
+  if (a.use_reg) {
+    lra_time_begin(ctx, "aog_reg");
+    hipLaunchKernelGGL(aog_reg_kernel<10>, dim3(min((n + 15) / 16, ctx->num_cu * 10)), dim3(256), 16 * REG_S_BYTES, sm, a);
+    hipLaunchKernelGGL(aog_reg_kernel<11>, dim3(min((n + 3) / 4, ctx->num_cu * 10)), dim3(128), 4 * REG_M_BYTES, sm, a);
+    hipLaunchKernelGGL(aog_reg_kernel<12>, dim3(min(n, ctx->num_cu * 10)), dim3(64), a.regL, sm, a);
+    if (a.regX) hipLaunchKernelGGL(aog_reg_kernel<13>, dim3(min(n, ctx->num_cu * 4)), dim3(64), a.regX, sm, a);
+    lra_time_end(ctx);
+  }
   lra_time_begin(ctx, "aog_hbm");
-  hipLaunchKernelGGL(aog_kernel<2>, dim3(wgC), dim3(64), 0, ctx->stream, a);
-  hipLaunchKernelGGL(aog_kernel<6>, dim3(min(n, a.gslotsB)), dim3(64), 0, ctx->stream, a);
+  hipLaunchKernelGGL(aog_kernel<2>, dim3(wgC), dim3(64), 0, sm, a);
+  hipLaunchKernelGGL(aog_kernel<6>, dim3(min(n, a.gslotsB)), dim3(64), 0, sm, a);
   lra_time_end(ctx);
+  if (!serial) { lra_side_join(ctx, 1); lra_side_join(ctx, 2); lra_side_join(ctx, 3); }
   LRA_HIP_CHECK(ctx, hipGetLastError());
   return LRA_OK;
 }

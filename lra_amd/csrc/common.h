@@ -11,7 +11,7 @@
 struct lra_seed_state;
 struct lra_cluster_state;
 struct lra_map_state;
-struct lra_time_rec { const char* name; hipEvent_t a, b; };
+struct lra_time_rec { const char* name; hipEvent_t a, b; hipStream_t stream; };
 
 struct lra_ctx {
   int device = 0;
@@ -27,7 +27,9 @@ struct lra_ctx {
   void* aux = nullptr; size_t aux_bytes = 0;          // AffineOneGapAlign blocks of refine fallbacks
   void* out_buf = nullptr; size_t out_bytes = 0;
   uint64_t* scan_tmp = nullptr;
-  hipStream_t side = nullptr; hipEvent_t ev_fork = nullptr, ev_join = nullptr;   // lra_side_fork / lra_side_join: a second stream for a kernel that would only extend a stage's tail
+  // lra_side_fork / lra_side_join: further streams for kernels that would only extend a stage's tail on the context's own stream
+  static constexpr int N_SIDE = 4;
+  hipStream_t side[N_SIDE] = {}; hipEvent_t ev_fork = nullptr, ev_join[N_SIDE] = {};
   void* gbuf[192] = {};   // growable result / work buffers (lra_ensure)
   size_t gbytes[192] = {};
   // kernel timing
@@ -39,10 +41,11 @@ struct lra_ctx {
 };
 
 // Fork: work queued on the returned stream starts after everything queued on ctx->stream so far; join: ctx->stream waits for it.
-hipStream_t lra_side_fork(lra_ctx* ctx);
-void lra_side_join(lra_ctx* ctx);
-void lra_time_begin(lra_ctx* ctx, const char* name);
-void lra_time_end(lra_ctx* ctx);
+hipStream_t lra_side_fork(lra_ctx* ctx, int i = 0);
+void lra_side_join(lra_ctx* ctx, int i = 0);
+// timing records (lra_ctx_timing_get); stream = nullptr: the context's stream
+void lra_time_begin(lra_ctx* ctx, const char* name, hipStream_t stream = nullptr);
+void lra_time_end(lra_ctx* ctx, hipStream_t stream = nullptr);
 void lra_seed_free(lra_ctx* ctx);
 void lra_cluster_free(lra_ctx* ctx);
 void lra_map_free(lra_ctx* ctx);

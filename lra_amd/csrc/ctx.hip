@@ -73,25 +73,29 @@ extern "C" void lra_ctx_destroy(lra_ctx* ctx) {
   for (int i = 0; i < 192; i++) if (ctx->gbuf[i]) (void)hipFree(ctx->gbuf[i]);
   for (auto& r : ctx->recs) { (void)hipEventDestroy(r.a); (void)hipEventDestroy(r.b); }
   for (auto e : ctx->free_events) (void)hipEventDestroy(e);
-  if (ctx->side) { (void)hipStreamSynchronize(ctx->side); (void)hipStreamDestroy(ctx->side); }
+  for (int i = 0; i < lra_ctx::N_SIDE; i++) {
+    if (ctx->side[i]) { (void)hipStreamSynchronize(ctx->side[i]); (void)hipStreamDestroy(ctx->side[i]); }
+    if (ctx->ev_join[i]) (void)hipEventDestroy(ctx->ev_join[i]);
+  }
   if (ctx->ev_fork) (void)hipEventDestroy(ctx->ev_fork);
-  if (ctx->ev_join) (void)hipEventDestroy(ctx->ev_join);
   delete ctx;
 }
 
-hipStream_t lra_side_fork(lra_ctx* ctx) {
-  if (!ctx->side) {
-    if (hipStreamCreateWithFlags(&ctx->side, hipStreamNonBlocking) != hipSuccess) { ctx->side = nullptr; return ctx->stream; }
-    (void)hipEventCreateWithFlags(&ctx->ev_fork, hipEventDisableTiming); (void)hipEventCreateWithFlags(&ctx->ev_join, hipEventDisableTiming);
+hipStream_t lra_side_fork(lra_ctx* ctx, int i) {
+  if (i < 0 || i >= lra_ctx::N_SIDE) return ctx->stream;
+  if (!ctx->side[i]) {
+    if (hipStreamCreateWithFlags(&ctx->side[i], hipStreamNonBlocking) != hipSuccess) { ctx->side[i] = nullptr; return ctx->stream; }
+    if (!ctx->ev_fork) (void)hipEventCreateWithFlags(&ctx->ev_fork, hipEventDisableTiming);
+    (void)hipEventCreateWithFlags(&ctx->ev_join[i], hipEventDisableTiming);
   }
   (void)hipEventRecord(ctx->ev_fork, ctx->stream);
-  (void)hipStreamWaitEvent(ctx->side, ctx->ev_fork, 0);
-  return ctx->side;
+  (void)hipStreamWaitEvent(ctx->side[i], ctx->ev_fork, 0);
+  return ctx->side[i];
 }
-void lra_side_join(lra_ctx* ctx) {
-  if (!ctx->side) return;
-  (void)hipEventRecord(ctx->ev_join, ctx->side);
-  (void)hipStreamWaitEvent(ctx->stream, ctx->ev_join, 0);
+void lra_side_join(lra_ctx* ctx, int i) {
+  if (i < 0 || i >= lra_ctx::N_SIDE || !ctx->side[i]) return;
+  (void)hipEventRecord(ctx->ev_join[i], ctx->side[i]);
+  (void)hipStreamWaitEvent(ctx->stream, ctx->ev_join[i], 0);
 }
 
 extern "C" int lra_ctx_set_stream(lra_ctx* ctx, void* stream) {
@@ -110,16 +114,19 @@ static hipEvent_t get_event(lra_ctx* ctx) {
   return e;
 }
 
-void lra_time_begin(lra_ctx* ctx, const char* name) {
+void lra_time_begin(lra_ctx* ctx, const char* name, hipStream_t stream) {
   if (!ctx->timing) return;
-  lra_time_rec r{name, get_event(ctx), get_event(ctx)};
-  (void)hipEventRecord(r.a, ctx->stream);
+  lra_time_rec r{name, get_event(ctx), get_event(ctx), stream ? stream : ctx->stream};
+  (void)hipEventRecord(r.a, r.stream);
   ctx->recs.push_back(r);
 }
 
-void lra_time_end(lra_ctx* ctx) {
-  if (!ctx->timing || ctx->recs.empty()) return;
-  (void)hipEventRecord(ctx->recs.back().b, ctx->stream);
+// closes the last record opened on that stream
+void lra_time_end(lra_ctx* ctx, hipStream_t stream) {
+  if (!ctx->timing) return;
+  const hipStream_t s = stream ? stream : ctx->stream;
+  for (size_t i = ctx->recs.size(); i-- > 0;)
+    if (ctx->recs[i].stream == s) { (void)hipEventRecord(ctx->recs[i].b, s); return; }
 }
 
 extern "C" int lra_ctx_timing_enable(lra_ctx* ctx, int on) {
