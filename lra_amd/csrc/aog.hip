@@ -42,6 +42,7 @@ constexpr int CLASS_M2_BYTES = 32 * 1024;
 constexpr int LN_MAX = 24, LN_ROWW = 2;
 constexpr int LN_ARROW_WORDS = LN_MAX * LN_ROWW, LN_PREV_WORDS = LN_MAX + 2, LN_CODE_BYTES = LN_MAX + 1;
 constexpr int LN_BYTES = 64 * (4 * LN_ARROW_WORDS + 4 * LN_PREV_WORDS + 2 * LN_CODE_BYTES);
+constexpr int NCLS = 19;
 constexpr int CLASS_S_BYTES = 2560;       // per 16-lane group: 4 problems per wave, 16 per workgroup (anti-diagonals <= 16 cells)
 
 __device__ __forceinline__ int code_n(unsigned char c) {  // SeqUtils.h:42-75 (seqMapN)
@@ -153,53 +154,53 @@ __device__ __forceinline__ int reg_fill(int lane, int gbase, const Geo& g, int m
   const int Wd = 2 * k + 3;
   const int sLast = max((qB - 1) + (tB - 1), 0);
   const int ci = qB - 1, cj = tB - 1;
-  int vE = MISS, vO = MISS, corner = MISS;
-  // eq[x]: do the codes of the lane's NEXT cell on its even (x = 0) / odd (x = 1) diagonal match
-  auto codes_match = [&](int i, int j) -> bool { return i >= 0 && i <= qLen && j >= 0 && j <= tLen && qc[i] == tc[j]; };
+  int vE = MISS, vO = MISS;
   const bool firstE = ((0 - k - 1) & 1) == 0;                             // step 0 is an even-diagonal step
-  bool eqE, eqO;
-  {
-    const int s0E = firstE ? 0 : 1, s0O = firstE ? 1 : 0;
-    const int dE = 2 * lane - k - 1, dO = 2 * lane + 1 - k - 1;
-    const int iE = (s0E + dE) >> 1, iO = (s0O + dO) >> 1;
-    eqE = codes_match(iE, s0E - iE); eqO = codes_match(iO, s0O - iO);
-  }
+  // Per lane and parity, fixed for the whole sweep: the diagonal d, the steps [sLo, sHi] at which its cell is one the sweep computes
+  // (1 <= i <= qB - 1, 1 <= j <= tB - 1, |d| <= k: what solve()'s jlo / jhi bounds say, per diagonal), and, advanced by one per own step, the cell (i, j),
+  // its arrow's address and whether the codes of the lane's NEXT cell on the diagonal match (loaded a round ahead).
+  const int dE = 2 * lane - k - 1, dO = dE + 1;
+  const bool okE = 2 * lane < Wd && dE >= -k && dE <= k, okO = 2 * lane + 1 < Wd && dO >= -k && dO <= k;
+  const int sLoE = okE ? 2 + abs(dE) : INT_MAX, sHiE = min(2 * (qB - 1) - dE, 2 * (tB - 1) + dE);
+  const int sLoO = okO ? 2 + abs(dO) : INT_MAX, sHiO = min(2 * (qB - 1) - dO, 2 * (tB - 1) + dO);
+  const int s0E = firstE ? 0 : 1, s0O = firstE ? 1 : 0;
+  int iE = (s0E + dE) >> 1, jE = s0E - iE, iO = (s0O + dO) >> 1, jO = s0O - iO;
+  int adE = jE * R + 2 * lane, adO = jO * R + 2 * lane + 1;
+  auto codes_match = [&](int i, int j) -> bool { return qc[min(max(i, 0), qLen)] == tc[min(max(j, 0), tLen)]; };   // (a cell whose codes are used has 1 <= i <= qLen, 1 <= j <= tLen)
+  bool eqE = codes_match(iE, jE), eqO = codes_match(iO, jO);
   auto step = [&](int s, auto isE) {
     constexpr bool E = decltype(isE)::value;
-    const int dd = 2 * lane + (E ? 0 : 1);
-    const int d = dd - k - 1;
     const int nb1 = E ? dpp_from_prev_lane(vO) : dpp_from_next_lane(vE);   // diagonal dd - 1 (even step) resp. dd + 1 (odd step), one step ago
-    int jlo = max(1, max(s - qB + 1, (s - k + 1) >> 1));
-    if (s - k < 0) jlo = max(1, s - qB + 1);
-    const int jhi = min(tB - 1, min(s - 1, (s + k) >> 1));
-    const int i = (s + d) >> 1, j = s - i;
-    const bool eq = E ? eqE : eqO;
+    const int i = E ? iE : iO, j = E ? jE : jO;
     const bool nxt = codes_match(i + 1, j + 1);                           // (in flight until this lane's next step on this diagonal, two steps on)
     int v = MISS;
-    if (dd < Wd && i >= 0 && j >= 0) {
-      if (s >= 2 && j >= jlo && j <= jhi && d >= -k && d <= k) {
-        const int sIns = (E ? nb1 : vE) + indel;                          // (i - 1, j): diagonal dd - 1
-        const int sDel = (E ? vO : nb1) + indel;                          // (i, j - 1): diagonal dd + 1
-        const int sMat = (E ? vE : vO) + (eq ? m : mm);                   // (i - 1, j - 1): this diagonal, two steps ago
-        const int best = max(sIns, max(sDel, sMat));
-        const int ar = (best == sIns) ? A_LEFT : (best == sDel) ? A_DOWN : A_DIAG;
-        v = best;
-        P[j * R + dd] = (signed char)ar;
-      } else if (s <= k + 1) v = pre(i, j);                               // (a boundary value sits in row or column 0: i + j <= k + 1; the rails hold MISS)
-      if (i == ci && j == cj) corner = v;
+    if (s >= (E ? sLoE : sLoO) && s <= (E ? sHiE : sHiO)) {
+      const int sIns = (E ? nb1 : vE) + indel;                            // (i - 1, j): diagonal dd - 1
+      const int sDel = (E ? vO : nb1) + indel;                            // (i, j - 1): diagonal dd + 1
+      const int sMat = (E ? vE : vO) + ((E ? eqE : eqO) ? m : mm);        // (i - 1, j - 1): this diagonal, two steps ago
+      const int best = max(sIns, max(sDel, sMat));
+      v = best;
+      P[E ? adE : adO] = (signed char)((best == sIns) ? A_LEFT : (best == sDel) ? A_DOWN : A_DIAG);
+    } else if (s <= k + 1) {                                              // (a boundary value sits in row or column 0: i + j <= k + 1; the rails hold MISS)
+      if (2 * lane + (E ? 0 : 1) < Wd && i >= 0 && j >= 0) v = pre(i, j);
     }
-    if (E) { vE = v; eqE = nxt; } else { vO = v; eqO = nxt; }
+    if (E) { vE = v; eqE = nxt; iE++; jE++; adE += R; } else { vO = v; eqO = nxt; iO++; jO++; adO += R; }
   };
   int s = 0;
+  bool lastE;
   if (firstE) {
     for (; s + 1 <= sLast; s += 2) { step(s, std::true_type{}); step(s + 1, std::false_type{}); }
-    if (s <= sLast) step(s, std::true_type{});
+    lastE = false;
+    if (s <= sLast) { step(s, std::true_type{}); lastE = true; }
   } else {
     for (; s + 1 <= sLast; s += 2) { step(s, std::false_type{}); step(s + 1, std::true_type{}); }
-    if (s <= sLast) step(s, std::false_type{});
+    lastE = true;
+    if (s <= sLast) { step(s, std::false_type{}); lastE = false; }
   }
+  // the corner (ci, cj) is the last step's cell on diagonal ci - cj
   const int ddc = ci - cj + k + 1;
-  return (ddc >= 0 && ddc < Wd) ? __shfl(corner, gbase + (ddc >> 1)) : MISS;
+  const int corner = lastE ? vE : vO;
+  return (ci >= 0 && cj >= 0 && ddc >= 0 && ddc < Wd && ((ddc & 1) == 0) == lastE) ? __shfl(corner, gbase + (ddc >> 1)) : MISS;
 }
 
 template <int G, typename BytePtr>
@@ -223,14 +224,23 @@ __device__ __forceinline__ void solve(int wlane, const Problem& pr, const Geo& g
   // roll != NULL (HBM-resident problems that only use the prefix band): the prefix SCORES live in three rotating anti-diagonal windows in LDS (a cell reads its
   // two predecessors' anti-diagonals only, and without the suffix band nothing reads a score again but the corner's); HBM keeps the arrows.  The matrices of
   // such a problem are ~1 MB and every cell was written twice (fill + sweep): 5 B per cell -> 1 B.
-  const bool rolling = roll != nullptr && !g.top && 2 * k + 3 <= 256 && qLen + tLen + 2 <= 4096;
+  // (with the band's diagonals two to a lane the sweep keeps the scores in registers -- reg_fill -- and the codes may stay in the HBM work area when they outgrow LDS)
+  const bool codesInLds = qLen + tLen + 2 <= 4096;
+  const bool rolling = roll != nullptr && !g.top && (k + 2 <= G || (2 * k + 3 <= 256 && codesInLds));
   // ... and the sequence codes sit behind the windows (roll[768 ..], one byte each), so that a sweep step touches HBM only to store its arrows
   unsigned char* lq = (unsigned char*)(roll + 768); unsigned char* lt = lq + (qLen + 1);
-  if (rolling) {
+  if (rolling && codesInLds) {
     for (int x = lane; x <= qLen; x += G) lq[x] = x ? code_n((unsigned char)pr.q[x - 1]) : 0;
     for (int x = lane; x <= tLen; x += G) lt[x] = x ? code_n((unsigned char)pr.t[x - 1]) : 0;
   }
-  if (rolling) { for (int x = lane; x < nUsed; x += G) w.pPre[x] = -1; }
+  if (rolling) {                                                          // the arrows' "never stored" value, 16 bytes per lane and store (pPre is 4-byte aligned)
+    const long head = min((long)nUsed, (long)((16 - ((uintptr_t)&w.pPre[0] & 15)) & 15));
+    for (long x = lane; x < head; x += G) w.pPre[x] = -1;
+    const long body = (nUsed - head) >> 4;
+    int4* p16 = (int4*)(&w.pPre[0] + head);
+    for (long x = lane; x < body; x += G) p16[x] = make_int4(-1, -1, -1, -1);
+    for (long x = head + (body << 4) + lane; x < nUsed; x += G) w.pPre[x] = -1;
+  }
   else for (int x = lane; x < nUsed; x += G) { w.sPre[x] = MISS; w.pPre[x] = -1; }
   if (g.top)
     for (int x = lane; x < n; x += G) { w.sSuf[x] = MISS; w.pSuf[x] = -1; }
@@ -267,7 +277,7 @@ __device__ __forceinline__ void solve(int wlane, const Problem& pr, const Geo& g
     const int Wd = 2 * k + 3;
     const int sLast = (qB - 1) + (tB - 1);
     const bool inRegs = k + 2 <= G;                                      // the band's diagonals fit the lanes two apiece: scores in registers (reg_fill)
-    if (inRegs) rollResult = reg_fill<G>(lane, gbase, g, m, mm, indel, w.pPre, lq, lt);
+    if (inRegs) rollResult = codesInLds ? reg_fill<G>(lane, gbase, g, m, mm, indel, w.pPre, lq, lt) : reg_fill<G>(lane, gbase, g, m, mm, indel, w.pPre, w.qc, w.tc);
     for (int s = 0; !inRegs && s <= max(sLast, 0); s++) {
       int* cur = roll + (s % 3) * 256; const int* p1 = roll + ((s + 2) % 3) * 256; const int* p2 = roll + ((s + 1) % 3) * 256;
       int jlo = max(1, max(s - qB + 1, (s - k + 1) >> 1));
@@ -626,8 +636,9 @@ struct BatchArgs {
   const int32_t* k;
   int m, mm, indel;
   int32_t* score; int32_t* nblocks; int32_t* blocks; const uint64_t* block_off; int32_t* status;
-  // work lists built by classify(): counts[3], lists 3 x n
-  int* counts; int* lists;
+  // work lists: aog_classify gives every problem a class (cls8) and counts the classes; aog_scatter lays the problems out class by class in ONE list of n entries
+  // (class c at offs[c], counts[c] entries).  NCLS classes; 14 .. 18 are the lane-per-problem class cut by size, so that the 64 problems of a wave cost about the same
+  int* counts; int* offs; int* cursor; unsigned char* cls8; int* list;
   char* gscratch; long gslot_bytes; int gslots;       // class 2: HBM work slots
   char* gscratchB; long gslotB_bytes; int gslotsB;    // class 6: a few larger ones
   int use_reg;                                        // classes 10-13 (solve_reg) in use
@@ -645,41 +656,81 @@ __device__ __forceinline__ bool load_problem(const BatchArgs& a, int p, Problem&
   return range_ok;
 }
 
-__global__ void aog_classify(BatchArgs a) {
-  const int p = blockIdx.x * blockDim.x + threadIdx.x;
+// Every workgroup takes CLS_ITEMS x 1024 consecutive problems and touches the global class counters once: one atomic per wave and class on a handful of addresses
+// is 10^6 serialized L2 atomics for a batch of 2 x 10^7 problems.
+constexpr int CLS_ITEMS = 16;
+__device__ __forceinline__ int classify_one(const BatchArgs& a, int p) {
+  Problem pr; Geo g; int ok;
+  if (!load_problem(a, p, pr, g, ok)) { a.score[p] = 0; a.nblocks[p] = 0; a.status[p] = LRA_ST_RANGE; return -1; }
+  long need = need_bytes(g);
+  int cls = need <= CLASS_A_BYTES ? 0 : need <= CLASS_M1_BYTES ? 4 : need <= CLASS_M2_BYTES ? 5 : need <= CLASS_B_BYTES ? 1 : 2;
+  if (g.k + 1 <= 32) cls = cls == 0 ? 7 : cls == 4 ? 8 : cls == 5 ? 9 : cls;                              // anti-diagonals of at most 32 cells: two problems per wave
+  if (need <= CLASS_S_BYTES && g.k + 1 <= 16) cls = 3;
+  if (cls == 2 && need > a.gslot_bytes) cls = 6;
+  if (cls == 6 && need > a.gslotB_bytes) { a.score[p] = 0; a.nblocks[p] = 0; a.status[p] = LRA_ST_RANGE; return -1; }
+  if (!g.top && a.use_reg) {                                               // prefix band only: scores in registers (solve_reg), arrows + codes in LDS
+    const long nr = need_bytes_reg(g);
+    if (a.use_lane && g.qLen <= LN_MAX && g.tLen <= LN_MAX) { const int mx = max(g.qLen, g.tLen); cls = mx <= 3 ? 14 : mx <= 6 ? 15 : mx <= 10 ? 16 : mx <= 16 ? 17 : 18; }
+    else if (g.k + 2 <= 16 && nr <= REG_S_BYTES) cls = 10;
+    else if (g.k + 2 <= 32 && nr <= REG_M_BYTES) cls = 11;
+    else if (g.k + 2 <= 64 && nr <= a.regL) cls = 12;
+    else if (g.k + 2 <= 64 && nr <= a.regX) cls = 13;
+  }
+  return cls;
+}
+__global__ void __launch_bounds__(1024) aog_classify(BatchArgs a) {
+  __shared__ int s_cnt[NCLS];
   const int lane = threadIdx.x & 63;
-  int cls = -1;
-  if (p < a.n) {
-    Problem pr; Geo g; int ok;
-    if (!load_problem(a, p, pr, g, ok)) {
-      a.score[p] = 0; a.nblocks[p] = 0; a.status[p] = LRA_ST_RANGE;
-    } else {
-      long need = need_bytes(g);
-      cls = need <= CLASS_A_BYTES ? 0 : need <= CLASS_M1_BYTES ? 4 : need <= CLASS_M2_BYTES ? 5 : need <= CLASS_B_BYTES ? 1 : 2;
-      if (g.k + 1 <= 32) cls = cls == 0 ? 7 : cls == 4 ? 8 : cls == 5 ? 9 : cls;                              // anti-diagonals of at most 32 cells: two problems per wave
-      if (need <= CLASS_S_BYTES && g.k + 1 <= 16) cls = 3;
-      if (cls == 2 && need > a.gslot_bytes) cls = 6;
-      if (cls == 6 && need > a.gslotB_bytes) { a.score[p] = 0; a.nblocks[p] = 0; a.status[p] = LRA_ST_RANGE; cls = -1; }
-      if (cls >= 0 && !g.top && a.use_reg) {                                // prefix band only: scores in registers (solve_reg), arrows + codes in LDS
-        const long nr = need_bytes_reg(g);
-        if (a.use_lane && g.qLen <= LN_MAX && g.tLen <= LN_MAX) cls = 14;
-        else if (g.k + 2 <= 16 && nr <= REG_S_BYTES) cls = 10;
-        else if (g.k + 2 <= 32 && nr <= REG_M_BYTES) cls = 11;
-        else if (g.k + 2 <= 64 && nr <= a.regL) cls = 12;
-        else if (g.k + 2 <= 64 && nr <= a.regX) cls = 13;
-      }
+  if (threadIdx.x < NCLS) s_cnt[threadIdx.x] = 0;
+  __syncthreads();
+  for (int it = 0; it < CLS_ITEMS; it++) {
+    const long p = ((long)blockIdx.x * CLS_ITEMS + it) * 1024 + threadIdx.x;
+    int cls = -1;
+    if (p < a.n) { cls = classify_one(a, (int)p); a.cls8[p] = (unsigned char)cls; }
+    for (int c = 0; c < NCLS; c++) {
+      const unsigned long long m = __ballot(cls == c);
+      if (m && lane == __ffsll((long long)m) - 1) atomicAdd(&s_cnt[c], __popcll(m));
     }
   }
-  // one atomic per wave and class
+  __syncthreads();
+  if (threadIdx.x < NCLS && s_cnt[threadIdx.x]) atomicAdd(&a.counts[threadIdx.x], s_cnt[threadIdx.x]);
+}
+__global__ void aog_offsets(BatchArgs a) {
+  if (threadIdx.x == 0 && blockIdx.x == 0) { int at = 0; for (int c = 0; c < NCLS; c++) { a.offs[c] = at; at += a.counts[c]; a.cursor[c] = 0; } }
+}
+__global__ void __launch_bounds__(1024) aog_scatter(BatchArgs a) {
+  __shared__ int s_cnt[NCLS], s_base[NCLS];
+  const int lane = threadIdx.x & 63;
+  if (threadIdx.x < NCLS) s_cnt[threadIdx.x] = 0;
+  __syncthreads();
+  int mine[CLS_ITEMS];
+#pragma unroll
+  for (int it = 0; it < CLS_ITEMS; it++) {                                // how many of each class this workgroup holds
+    const long p = ((long)blockIdx.x * CLS_ITEMS + it) * 1024 + threadIdx.x;
+    const int cls = p < a.n ? (int)(signed char)a.cls8[p] : -1;
+    mine[it] = cls;
+    for (int c = 0; c < NCLS; c++) {
+      const unsigned long long m = __ballot(cls == c);
+      if (m && lane == __ffsll((long long)m) - 1) atomicAdd(&s_cnt[c], __popcll(m));
+    }
+  }
+  __syncthreads();
+  if (threadIdx.x < NCLS) { s_base[threadIdx.x] = s_cnt[threadIdx.x] ? a.offs[threadIdx.x] + atomicAdd(&a.cursor[threadIdx.x], s_cnt[threadIdx.x]) : 0; s_cnt[threadIdx.x] = 0; }
+  __syncthreads();
   const unsigned long long below = (lane == 0) ? 0ULL : (~0ULL >> (64 - lane));
-  for (int c = 0; c < 15; c++) {
-    const unsigned long long m = __ballot(cls == c);
-    if (!m) continue;
-    int base = 0;
-    const int leader = __ffsll((long long)m) - 1;
-    if (lane == leader) base = atomicAdd(&a.counts[c], __popcll(m));
-    base = __shfl(base, leader);
-    if (cls == c) a.lists[(long)c * a.n + base + __popcll(m & below)] = p;
+#pragma unroll
+  for (int it = 0; it < CLS_ITEMS; it++) {
+    const long p = ((long)blockIdx.x * CLS_ITEMS + it) * 1024 + threadIdx.x;
+    const int cls = mine[it];
+    for (int c = 0; c < NCLS; c++) {
+      const unsigned long long m = __ballot(cls == c);
+      if (!m) continue;
+      int base = 0;
+      const int leader = __ffsll((long long)m) - 1;
+      if (lane == leader) base = atomicAdd(&s_cnt[c], __popcll(m));
+      base = __shfl(base, leader);
+      if (cls == c) a.list[s_base[c] + base + __popcll(m & below)] = (int)p;
+    }
   }
 }
 
@@ -696,7 +747,7 @@ __global__ void __launch_bounds__((CLS == 0 || CLS == 3 || CLS == 7) ? 256 : 64)
   const int ngroups = gridDim.x * waves_per_wg * GPW;
   const int count = a.counts[CLS];
   for (int x = group; x < count; x += ngroups) {
-    int p = a.lists[(long)CLS * a.n + x];
+    int p = a.list[a.offs[CLS] + x];
     Problem pr; Geo g; int ok;
     load_problem(a, p, pr, g, ok);
     long cap = (long)(a.block_off[p + 1] - a.block_off[p]);
@@ -727,7 +778,7 @@ __global__ void __launch_bounds__(CLS == 10 ? 256 : CLS == 11 ? 128 : 64) aog_re
   const int ngroups = gridDim.x * waves_per_wg * GPW;
   const int count = a.counts[CLS];
   for (int x = group; x < count; x += ngroups) {
-    const int p = a.lists[(long)CLS * a.n + x];
+    const int p = a.list[a.offs[CLS] + x];
     Problem pr; Geo g; int ok;
     load_problem(a, p, pr, g, ok);
     const long cap = (long)(a.block_off[p + 1] - a.block_off[p]);
@@ -745,24 +796,29 @@ __global__ void __launch_bounds__(CLS == 10 ? 256 : CLS == 11 ? 128 : 64) aog_re
 // sweep never computes -- row / column 0, the rails, everything off the band -- are what solve()'s boundary stores leave there: pre() for the scores, pre_arrow()
 // for the arrows.  The walk runs twice over the arrows in LDS (count the blocks and find where it ends; then store them in alignment order).
 
-__global__ void __launch_bounds__(64) aog_lane_kernel(BatchArgs a) {
+__global__ void __launch_bounds__(64) aog_lane_kernel(BatchArgs a, int cls) {
   __shared__ __attribute__((aligned(16))) char smem[LN_BYTES];
   const int lane = threadIdx.x;
   unsigned* AR = (unsigned*)smem;                                         // [LN_ARROW_WORDS][64]
   int* PV = (int*)(smem + 64 * 4 * LN_ARROW_WORDS);                       // [LN_PREV_WORDS][64]
   unsigned char* QC = (unsigned char*)(smem + 64 * 4 * (LN_ARROW_WORDS + LN_PREV_WORDS));   // [LN_CODE_BYTES][64]
   unsigned char* TC = QC + 64 * LN_CODE_BYTES;
-  const int count = a.counts[14];
+  const int count = a.counts[cls];
   for (int x0 = blockIdx.x * 64; x0 < count; x0 += gridDim.x * 64) {
     const int x = x0 + lane;
     if (x < count) {
-      const int p = a.lists[14L * a.n + x];
+      const int p = a.list[a.offs[cls] + x];
       Problem pr; Geo g; int ok;
       load_problem(a, p, pr, g, ok);
       const int qLen = g.qLen, tLen = g.tLen, k = g.k, diag = g.diag, qB = g.qB, tB = g.tB;
       const int m = pr.m, mm = pr.mm, indel = pr.indel;
-      for (int i = 1; i <= qLen; i++) QC[i * 64 + lane] = (unsigned char)code_n((unsigned char)pr.q[i - 1]);
-      for (int j = 1; j <= tLen; j++) TC[j * 64 + lane] = (unsigned char)code_n((unsigned char)pr.t[j - 1]);
+      {                                                                   // (all loads in flight before the first is used)
+        unsigned char cq[LN_MAX], ct[LN_MAX];
+#pragma unroll
+        for (int i = 0; i < LN_MAX; i++) { cq[i] = i < qLen ? (unsigned char)pr.q[i] : 0; ct[i] = i < tLen ? (unsigned char)pr.t[i] : 0; }
+#pragma unroll
+        for (int i = 0; i < LN_MAX; i++) { QC[(i + 1) * 64 + lane] = (unsigned char)code_n(cq[i]); TC[(i + 1) * 64 + lane] = (unsigned char)code_n(ct[i]); }
+      }
       auto in_region = [&](int i, int j) { return i >= 1 && i <= qB - 1 && j >= 1 && j <= tB - 1 && i - j <= k && j - i <= k; };
       auto pre = [&](int i, int j) -> int {
         int v = MISS;
@@ -789,8 +845,12 @@ __global__ void __launch_bounds__(64) aog_lane_kernel(BatchArgs a) {
         int left = pre(ilo - 1, j);                                        // column 0 or the lower rail
         int dg = in_region(ilo - 1, j - 1) ? PV[(ilo - 1) * 64 + lane] : pre(ilo - 1, j - 1);
         unsigned long long acc = 0;
+        const int hi2 = j >= 2 ? min(qB - 1, j - 1 + k) : 0;              // row j - 1 holds computed cells up to column hi2 (and from at most ilo on)
         for (int i = ilo; i <= ihi; i++) {
-          const int up = in_region(i, j - 1) ? PV[i * 64 + lane] : pre(i, j - 1);
+          // (i, j - 1) off the computed region: row 0 (the boundary value), or the cell past the band's edge (column j + k: a rail or beyond, MISS)
+          int up;
+          if (i <= hi2) up = PV[i * 64 + lane];
+          else up = (j == 1 && i < k + 1) ? indel * i : MISS;
           const int sIns = left + indel, sDel = up + indel, sMat = dg + (QC[i * 64 + lane] == tcj ? m : mm);
           const int best = max(sIns, max(sDel, sMat));
           const int ar = (best == sIns) ? A_LEFT : (best == sDel) ? A_DOWN : A_DIAG;
@@ -854,11 +914,10 @@ int lra_aog_launch_device(lra_ctx* ctx, int n, const char* d_qseq, const char* d
   a.n = n; a.qseq = d_qseq; a.tseq = d_tseq; a.q_off = d_q_off; a.q_len = d_q_len; a.t_off = d_t_off; a.t_len = d_t_len;
   a.k = d_k; a.m = m; a.mm = mm; a.indel = indel;
   a.score = d_score; a.nblocks = d_nblocks; a.blocks = d_blocks; a.block_off = d_block_off; a.status = d_status;
-  // scratch slot 0: counts[16] + lists[15n];  slot 1: class-C HBM work slots
-  size_t list_bytes = 64 + sizeof(int) * 15 * (size_t)n;
-  char* s0 = (char*)lra_scratch(ctx, 0, list_bytes);
+  // scratch slot 0: counts[32] + offs[32] + cursor[32] + list[n] + cls8[n];  slot 1: class-C HBM work slots
+  char* s0 = (char*)lra_scratch(ctx, 0, 384 + sizeof(int) * (size_t)n + (size_t)n + 64);
   if (!s0) return LRA_ERR_NOMEM;
-  a.counts = (int*)s0; a.lists = (int*)(s0 + 64);
+  a.counts = (int*)s0; a.offs = a.counts + 32; a.cursor = a.counts + 64; a.list = (int*)(s0 + 384); a.cls8 = (unsigned char*)(a.list + n);
   // class 2: 4 MiB slots, LRA_AOG_SLOTS (default 8) per CU -- with the scores of most of these problems in LDS (rolling, see solve) a wave's HBM traffic is its
   // arrows, and a CU can keep more of them in flight; class 6: 8 MiB slots, one per CU, for the rare larger problem (1.5 kb x 1.5 kb at k = 60, 5 kb x 5 kb at k = 15)
   const int perCu = getenv("LRA_AOG_SLOTS") ? atoi(getenv("LRA_AOG_SLOTS")) : 8;
@@ -892,8 +951,11 @@ int lra_aog_launch_device(lra_ctx* ctx, int n, const char* d_qseq, const char* d
   a.regL = getenv("LRA_AOG_REG_L") ? std::min(atoi(getenv("LRA_AOG_REG_L")), REG_L_BYTES) : 16384;
   a.regX = getenv("LRA_AOG_REG_X") ? std::min(atoi(getenv("LRA_AOG_REG_X")), REG_X_BYTES) : 0;
   if (a.use_reg) LRA_HIP_CHECK(ctx, hipFuncSetAttribute((const void*)aog_reg_kernel<13>, hipFuncAttributeMaxDynamicSharedMemorySize, REG_X_BYTES));
-  LRA_HIP_CHECK(ctx, hipMemsetAsync(a.counts, 0, 64, ctx->stream));
-  hipLaunchKernelGGL(aog_classify, dim3((n + 255) / 256), dim3(256), 0, ctx->stream, a);
+  LRA_HIP_CHECK(ctx, hipMemsetAsync(a.counts, 0, 384, ctx->stream));
+  const int cblocks = (int)(((long)n + CLS_ITEMS * 1024 - 1) / (CLS_ITEMS * 1024));
+  hipLaunchKernelGGL(aog_classify, dim3(cblocks), dim3(1024), 0, ctx->stream, a);
+  hipLaunchKernelGGL(aog_offsets, dim3(1), dim3(64), 0, ctx->stream, a);
+  hipLaunchKernelGGL(aog_scatter, dim3(cblocks), dim3(1024), 0, ctx->stream, a);
   int wgA = min((n + 3) / 4, ctx->num_cu * 5);
   int wgB = min(n, ctx->num_cu * 2);
   int wgC = min(n, a.gslots);
@@ -923,7 +985,7 @@ int lra_aog_launch_device(lra_ctx* ctx, int n, const char* d_qseq, const char* d
   lra_time_end(ctx, s3);
   if (a.use_lane) {
     lra_time_begin(ctx, "aog_lane");
-    hipLaunchKernelGGL(aog_lane_kernel, dim3(min((n + 63) / 64, ctx->num_cu * 7)), dim3(64), 0, sm, a);
+    for (int c = 18; c >= 14; c--) hipLaunchKernelGGL(aog_lane_kernel, dim3(min((n + 63) / 64, ctx->num_cu * 7)), dim3(64), 0, sm, a, c);
     lra_time_end(ctx);
   }
   if (a.use_reg) {
