@@ -685,22 +685,51 @@ struct TraceArgs {
 // coordinates in one pass.  The forward parse is: [diag run][one run of left OR of down] -> one
 // block; seen back to front every gap run closes the block whose (possibly empty) diag run precedes
 // it, and a trailing diag run is a block of its own.
-// The walk is a chain of dependent loads; TRACE_LANES < 64 active lanes per wave spread a batch of few, long segments over more waves
-// (more SIMDs busy, fewer distinct cache lines per load instruction).
-constexpr int TRACE_LANES = 16;
-__global__ void __launch_bounds__(64) ir_trace_lane(TraceArgs T) {
-  if (threadIdx.x >= TRACE_LANES) return;
-  const uint64_t s = (uint64_t)blockIdx.x * TRACE_LANES + threadIdx.x;
+// The walk (:629-674) is a chain of dependent one-byte loads, a row apart each, ~27 k of them for a 30 kb read: one lane per segment walks at HBM latency.  Here a WAVE
+// owns a segment: the rows' descriptors and path bytes of a window of rows (as many as fit 8 KB of path, at most 256) are staged into LDS with coalesced loads,
+// and while the walk is in the match state the 64 lanes look at the next 64 cells down the current diagonal at once -- a run of diagonal arrows (the common case: a
+// 10 % error read has an indel every ~14 bases) is one round.  Everything else -- the gap states, left / down arrows, the end tests -- is the reference's step, from LDS.
+constexpr int TW_ROWS = 256, TW_PATH = 8192;
+__global__ void __launch_bounds__(64) ir_trace_wave(TraceArgs T) {
+  __shared__ Row s_rows[TW_ROWS];
+  __shared__ __attribute__((aligned(16))) unsigned char s_path[TW_PATH + 16];
+  const int lane = threadIdx.x;
+  const uint64_t s = blockIdx.x;
   if (s >= T.n_seg) return;
   if (T.s_kind[s] != 0) return;
-  if (T.s_status[s] != 0) { T.s_nblk[s] = 0; return; }
+  if (T.s_status[s] != 0) { if (lane == 0) T.s_nblk[s] = 0; return; }
   const long tLen = (long)T.s_rows[s];
   const Row* rows = T.rows + T.s_row_off[s];
   const unsigned char* P = T.path + T.s_cell_off[s];
   int32_t* ob = T.tmp_blocks + 3 * T.s_tmp_off[s];
   const long cap = (long)(T.s_tmp_off[s + 1] - T.s_tmp_off[s]);
   long ti = tLen - 1;
-  Row rw = rows[ti];
+  long rBase = 0, wLo = 1, wHi = 0; unsigned pBase = 0;                   // the staged window: rows [wLo, wHi] (descriptors from rBase on), path bytes from pBase on
+  auto stage = [&](long at) {
+    wave_sync();
+    wHi = at; rBase = max(0L, at - TW_ROWS + 1);
+    for (long x = lane; x <= at - rBase; x += 64) s_rows[x] = rows[rBase + x];
+    wave_sync();
+    const Row last = s_rows[at - rBase];
+    const unsigned end = last.C + (unsigned)max(last.E - last.S + 1, 0);
+    // the first row of the window: the smallest w with end - rows[w].C <= TW_PATH (C grows with the row)
+    long lo = rBase, hi = at;
+    while (lo < hi) { const long mid = (lo + hi) >> 1; if (end - s_rows[mid - rBase].C <= (unsigned)TW_PATH) hi = mid; else lo = mid + 1; }
+    wLo = lo; pBase = s_rows[lo - rBase].C;
+    const unsigned nbytes = min(end - pBase, (unsigned)TW_PATH);
+    // 16 bytes per lane and load: s_path[x] holds the byte at (16-byte aligned address at or below the window's first byte) + x; the bytes in front of the window
+    // belong to earlier rows / segments of the same buffer, the last, partial 16 bytes go one by one
+    const unsigned char* start = P + pBase;
+    const unsigned delta = (unsigned)((uintptr_t)start & 15);
+    const uint4* a16 = (const uint4*)(start - delta);
+    const unsigned full = (delta + nbytes) >> 4;
+    for (unsigned x = lane; x < full; x += 64) ((uint4*)s_path)[x] = a16[x];
+    for (unsigned x = (full << 4) + lane; x < delta + nbytes; x += 64) s_path[x] = (start - delta)[x];
+    pBase -= delta;                                                       // (modulo 2^32: only differences with a row's C are used)
+    wave_sync();
+  };
+  stage(ti);
+  Row rw = s_rows[ti - rBase];
   int qa = rw.E;                              // last cell of the matrix (:629)
   int mat = 0;                                // 0 match, 1 del, 2 ins
   int bad = 0;
@@ -711,10 +740,10 @@ __global__ void __launch_bounds__(64) ir_trace_lane(TraceArgs T) {
   long steps = 0;
   const long step_cap = 4 * (long)T.s_cells[s] + 64;
   auto emit_block = [&]() {
-    if (nblk < cap) { ob[3 * nblk] = (int)q; ob[3 * nblk + 1] = (int)t; ob[3 * nblk + 2] = (int)dlen; } else bad = 1;
+    if (nblk < cap) { if (lane == 0) { ob[3 * nblk] = (int)q; ob[3 * nblk + 1] = (int)t; ob[3 * nblk + 2] = (int)dlen; } } else bad = 1;
     nblk++;
   };
-  auto op = [&](int kind) {                   // kind: 0 diag, 1 left, 2 down
+  auto op = [&](int kind, long times) {       // kind: 0 diag, 1 left, 2 down
     if (kind != curKind) {
       if (curKind == -1 && kind == 0) { pending = 1; dlen = 0; }
       if (kind != 0) {
@@ -723,46 +752,67 @@ __global__ void __launch_bounds__(64) ir_trace_lane(TraceArgs T) {
       }
       curKind = kind;
     }
-    if (kind == 0) { dlen++; q--; t--; }
-    else if (kind == 1) q--;
-    else t--;
+    if (kind == 0) { dlen += times; q -= times; t -= times; }
+    else if (kind == 1) q -= times;
+    else t -= times;
   };
   while (true) {
+    if (ti < wLo || ti > wHi) stage(ti);
+    rw = s_rows[ti - rBase];
+    if (mat == 0) {
+      // lane l: the cell l steps down the diagonal; a diagonal arrow there (not in row 0: the step after it would leave the matrix) extends the run
+      const long tl = ti - lane;
+      bool fast = false;
+      if (tl >= wLo && tl >= 1) {
+        const Row r = s_rows[tl - rBase];
+        const int c = (qa - lane) - r.S;
+        if (c >= 0 && c <= r.E - r.S) fast = (s_path[r.C - pBase + (unsigned)c] & 7) == C_DIAG;
+      }
+      const unsigned long long nf = ~__ballot(fast);
+      const int f = nf ? __ffsll((long long)nf) - 1 : 64;
+      if (f > 0) {
+        steps += f;
+        if (steps > step_cap) { bad = 1; break; }
+        op(0, f); ti -= f; qa -= f;
+        continue;
+      }
+    }
     const int c = qa - rw.S;
     if (c < 0 || c > rw.E - rw.S) { bad = 1; break; }
     if (ti == 0 && c == 0) break;                                       // flat index 0 (:631)
     if (++steps > step_cap) { bad = 1; break; }
-    const unsigned char pb = P[rw.C + c];
+    const unsigned char pb = s_path[rw.C - pBase + (unsigned)c];
     long nti = ti;
     if (mat == 0) {                                                     // :632-648
       const int code = pb & 7;
       if (code == C_DELCLOSE) mat = 1;
       else if (code == C_INSCLOSE) mat = 2;
-      else if (code == C_DIAG) { op(0); nti = ti - 1; qa--; }
-      else if (code == C_LEFT) { op(1); qa--; }
-      else if (code == C_DOWN) { op(2); nti = ti - 1; }
+      else if (code == C_DIAG) { op(0, 1); nti = ti - 1; qa--; }
+      else if (code == C_LEFT) { op(1, 1); qa--; }
+      else if (code == C_DOWN) { op(2, 1); nti = ti - 1; }
       else { bad = 1; break; }                                          // boundary arrow: endless loop in the reference
     } else if (mat == 1) {                                              // :649-659
-      op(2);
+      op(2, 1);
       mat = ((pb >> 3) & 1) ? 0 : 1;
       nti = ti - 1;
     } else {                                                            // :660-671
-      op(1);
+      op(1, 1);
       mat = ((pb >> 4) & 1) ? 0 : 2;
       qa--;
     }
     if (nti != ti) {
       if (nti < 0) { bad = 1; break; }
       ti = nti;
-      rw = rows[ti];
     }
   }
   if (!bad) {
-    op(0);                                                              // the aligned first base (:674)
+    op(0, 1);                                                           // the aligned first base (:674)
     if (pending) emit_block();
   }
-  if (bad) T.s_status[s] |= 2;
-  T.s_nblk[s] = bad ? 0 : (uint32_t)nblk;
+  if (lane == 0) {
+    if (bad) T.s_status[s] |= 2;
+    T.s_nblk[s] = bad ? 0 : (uint32_t)nblk;
+  }
 }
 
 // ---------------------------------------------------------------------------------- gather
@@ -1036,7 +1086,7 @@ extern "C" int lra_indel_refine_batch(lra_ctx* ctx, int n_aln, const int32_t* d_
     T.s_cells = s_cells; T.s_cell_off = s_cell_off; T.s_status = s_status; T.rows = rows; T.path = path;
     T.s_nblk = s_nblk; T.s_tmp_off = s_tmp_off; T.tmp_blocks = tmpb;
     lra_time_begin(ctx, "ir_trace");
-    hipLaunchKernelGGL(ir_trace_lane, dim3((unsigned)((n_seg + TRACE_LANES - 1) / TRACE_LANES)), dim3(64), 0, st, T);
+    hipLaunchKernelGGL(ir_trace_wave, dim3((unsigned)n_seg), dim3(64), 0, st, T);
     lra_time_end(ctx);
     // ---- short segments -> AffineOneGapAlign (:344-357)
     if (n_aog) {
