@@ -139,6 +139,84 @@ __global__ void __launch_bounds__(64) rs_sketch(RsArgs a, int nLarge) {
   if (seqLen < (uint32_t)k) { done(); return; }
   const int span = w + k - 1;
   if (seqLen < (uint32_t)span) { done(); return; }
+  if (w >= 2 && w <= 8) {
+    // ---- the same scan, 64 positions per round (the serial machine below is what it restates; w > 8 takes the serial machine).
+    // The active minimizer's VALUE at p is the minimum of window (p - w, p]; only WHICH of several equal k-mers is active depends on the past, through the offset
+    // o = p - actP in [0, w - 1].  Step p maps o to:  p - R(p) if o = w - 1 (the active one leaves the window: the ring rescan, first minimum in ring-slot order, i.e.
+    // by (value, position mod w));  0 if k-mer p is smaller than the previous window's minimum;  o + 1 otherwise.  These maps (w entries of 4 bits) compose, so the
+    // offsets of 64 consecutive positions are one wave-wide prefix "sum" of maps applied to the offset carried in.  A tuple goes out at p when the offset was reset
+    // (either way) and the reference's validity window allows it: no N in [s, p + k - 1] with s = (last N at or before p + k - 1) + 1, p >= s + w - 1 and
+    // s < seqLen - span (the very first window's tuple, s = 0, goes out unconditionally) -- what nvStart / nvEnd / find_valid amount to position by position.
+    __shared__ uint64_t kk[128];                                           // k-mers of the last 128 positions (position & 127)
+    __shared__ unsigned char cd[128];
+    if (seqLen == (uint32_t)span) { done(); return; }                      // find_valid's strict bound: a sequence of exactly one window has no valid start
+    const long pLast = (long)seqLen - k;                                   // last k-mer position
+    uint64_t kmask = 0;
+    for (int x = 0; x < k; x++) { kmask <<= 2; kmask += 3; }
+    long lastN = -1;                                                       // last N at or before position pb + k - 2
+    { long m = -1; for (int x = lane; x < k - 1; x += 64) if (code_n(gseq[x]) > 3) m = x; for (int o2 = 32; o2 > 0; o2 >>= 1) m = max(m, __shfl_xor(m, o2)); lastN = m; }
+    int carryO = 0; uint64_t mPrev = 0;                                    // offset of the active minimizer at pb - 1; minimum of window (pb - 1 - w, pb - 1]
+    for (long pb = 0; pb <= pLast; pb += 64) {
+      const long p = pb + lane;
+      const bool act = p <= pLast;
+      // codes of positions pb .. pb + 63 + k - 1
+      rs_wave_sync();
+      for (int x = lane; x < 64 + k - 1; x += 64) { const long g = pb + x; cd[x] = g < (long)seqLen ? (unsigned char)code_n(gseq[g]) : 4; }
+      rs_wave_sync();
+      uint64_t c = 0;
+      if (act) { for (int j = 0; j < k; j++) { const int v = cd[lane + j]; c = (c << 2) + (uint64_t)(v > 3 ? 0 : v); } c &= kmask; c &= FOR_MASK; }
+      kk[p & 127] = c;
+      const bool badNew = act && cd[lane + k - 1] > 3;                      // position p + k - 1
+      rs_wave_sync();
+      // window minimum, the rescan's choice, and (first window only) the earliest minimum
+      uint64_t mWin = ~0ULL; long rPos = p, ePos = p;
+      if (act && p >= w - 1) {
+        uint64_t rVal = ~0ULL; int rSlot = 1 << 30;
+        for (int j = 0; j < w; j++) {
+          const long q = p - j; const uint64_t v = kk[q & 127]; const int slot = (int)(q % w);
+          if (v < mWin || (v == mWin && q < ePos)) { mWin = v; ePos = q; }
+          if (v < rVal || (v == rVal && slot < rSlot)) { rVal = v; rSlot = slot; rPos = q; }
+        }
+      }
+      uint64_t mP1 = __shfl_up(mWin, 1); if (lane == 0) mP1 = mPrev;        // minimum of window (p - 1 - w, p - 1]
+      const bool lt = act && p >= w && c < mP1;
+      // the step's map
+      uint32_t F = 0x76543210u;
+      if (act && p >= w) {
+        F = 0;
+        for (int o2 = 0; o2 < w; o2++) { const uint32_t to = (o2 == w - 1) ? (uint32_t)(p - rPos) : (lt ? 0u : (uint32_t)(o2 + 1)); F |= to << (4 * o2); }
+      } else if (act && p == w - 1) {                                      // the first window: whatever came in, the offset is that of the earliest minimum
+        const uint32_t to = (uint32_t)(p - ePos);
+        F = 0; for (int o2 = 0; o2 < 8; o2++) F |= to << (4 * o2);
+      }
+      uint32_t G = F;                                                      // inclusive prefix: G = F_lane o ... o F_0
+      for (int d = 1; d < 64; d <<= 1) {
+        const uint32_t E = __shfl_up(G, d);
+        if (lane >= d) { uint32_t r = 0; for (int o2 = 0; o2 < 8; o2++) { const uint32_t g1 = (E >> (4 * o2)) & 15u; r |= ((G >> (4 * g1)) & 15u) << (4 * o2); } G = r; }
+      }
+      const int oNow = (int)((G >> (4 * carryO)) & 15u);
+      int oBefore = __shfl_up(oNow, 1); if (lane == 0) oBefore = carryO;
+      const bool event = act && (p == w - 1 || (p >= w && (oBefore >= w - 1 || lt)));
+      // validity
+      long ln = badNew ? p + k - 1 : -1;
+      for (int d = 1; d < 64; d <<= 1) { const long o3 = __shfl_up(ln, d); if (lane >= d) ln = max(ln, o3); }
+      ln = max(ln, lastN);
+      const bool V = act && p >= ln + w && ln + 1 < (long)seqLen - span;     // s = ln + 1: p >= s + w - 1, and find_valid's strict bound on s
+      const bool out = event && V;
+      const unsigned long long om = __ballot(out);
+      if (out) {
+        const long ap = p - oNow;
+        const uint32_t at2 = n + (uint32_t)__popcll(om & ((lane == 0) ? 0ULL : (~0ULL >> (64 - lane))));
+        if (EMIT) { a.lkey[o + at2] = kk[ap & 127]; a.lpos[o + at2] = (uint32_t)ap; }
+      }
+      n += (uint32_t)__popcll(om);
+      // carries: the last active lane's offset, window minimum, last N
+      const int lastLane = (int)min(63L, pLast - pb);
+      carryO = __shfl(oNow, lastLane); mPrev = __shfl(mWin, lastLane); lastN = __shfl(ln, lastLane);
+    }
+    done();
+    return;
+  }
   uint64_t mask = 0;
   for (int x = 0; x < k; x++) { mask <<= 2; mask += 3; }
   long nvStart = 0, nvEnd = 0;

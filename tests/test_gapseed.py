@@ -77,6 +77,58 @@ def test_hip_refine_space_oracle(ctx):
 
 
 @pytest.mark.gpu
+def test_hip_refine_space_sketch_edges(ctx):
+    """The long-gap branch's minimizer sketch (StoreMinimizers_noncanonical, MinCount.h:182-338) seen through RefineSpace on identical spans: every tuple of
+    the query list meets its twin in the target list, so the pairs spell out the lists.  Ties (homopolymer and short tandem stretches), N runs that leave clean
+    stretches of exactly / one less / one more than w + k - 1 bases, N at either end, windows of 2 .. 9 k-mers."""
+    import torch
+    from lra_amd import gapseed
+    rng = np.random.default_rng(23)
+    probs = []
+    for i in range(220):
+        K = int(rng.choice([6, 9, 12, 15])); W = int(rng.choice([2, 3, 5, 8, 9]))
+        span = W + K - 1
+        L = int(rng.integers(1000, 1500))
+        q = np.frombuffer(b"ACGT", np.uint8)[rng.integers(0, 4, L)].copy()
+        for _ in range(int(rng.integers(0, 6))):                                        # ties: homopolymers, dinucleotide and 7-mer tandem stretches
+            a = int(rng.integers(0, L - 80)); n = int(rng.integers(5, 70)); unit = q[a:a + int(rng.choice([1, 2, 7]))].copy()
+            q[a:a + n] = np.resize(unit, n)
+        kind = i % 5
+        if kind == 1:                                                                    # scattered N
+            q[rng.integers(0, L, int(rng.integers(1, 9)))] = ord("N")
+        elif kind == 2:                                                                  # clean stretches of span - 1, span, span + 1 between N
+            at = int(rng.integers(0, 200))
+            for d in (span - 1, span, span + 1, span + 2, 2 * span):
+                q[at] = ord("N"); at += d + 1
+            q[at] = ord("N")
+        elif kind == 3:                                                                  # N at the ends; a clean tail of exactly span / span + 1
+            q[0] = ord("N"); q[L - 1 - int(rng.choice([0, span, span + 1]))] = ord("N")
+            if i % 2: q[1:int(rng.integers(2, 40))] = ord("N")
+        elif kind == 4 and i % 10 == 4:
+            q[:] = ord("A"); q[int(rng.integers(100, 900))] = ord("C")
+        qb = q.tobytes()
+        probs.append(dict(q=qb, t=qb, t_span=L, K=K, W=W, diag=int(rng.choice([5, 30])), q_add=0, t_add=0, flip=0))
+    qcat = b"".join(p["q"] for p in probs); tcat = b"".join(p["t"] for p in probs)
+    qoff = np.cumsum([0] + [len(p["q"]) for p in probs])[:-1]; toff = np.cumsum([0] + [len(p["t"]) for p in probs])[:-1]
+    dev = ctx.device
+    T = lambda a, dt: torch.tensor(np.asarray(a, dtype=dt), device=dev)
+    dq = torch.tensor(np.frombuffer(qcat + b"\0" * 64, np.uint8).copy(), device=dev); dt_ = torch.tensor(np.frombuffer(tcat + b"\0" * 64, np.uint8).copy(), device=dev)
+    res = gapseed.refine_space_batch(ctx, len(probs), dq, T(qoff, np.int64), T([len(p["q"]) for p in probs], np.int32), dt_, T(toff, np.int64),
+                                     T([len(p["t"]) for p in probs], np.int32), T([p["t_span"] for p in probs], np.int64).to(torch.int32),
+                                     T([p["K"] for p in probs], np.int32), T([p["W"] for p in probs], np.int32), T([p["diag"] for p in probs], np.int32),
+                                     T([0] * len(probs), np.int32), T([0] * len(probs), np.int32), T([0] * len(probs), np.int32), 4, -1, -2, 200)
+    out = gapseed.fetch(ctx, res)
+    total = 0
+    for i, p in enumerate(probs):
+        eq, et, ident = O.refine_space(p["q"], p["t"], p["t_span"], p["K"], p["W"], p["diag"], 4, -1, -2, 200, 0, 0, 0)
+        a, b = int(out["pair_off"][i]), int(out["pair_off"][i + 1])
+        assert b - a == len(eq), (i, p["K"], p["W"], b - a, len(eq))
+        assert np.array_equal(out["pair_q"][a:b], eq) and np.array_equal(out["pair_t"][a:b], et), (i, p["K"], p["W"])
+        total += len(eq)
+    assert total > 20000
+
+
+@pytest.mark.gpu
 def test_hip_between_anchors_oracle(ctx):
     """a13 DP leaf: RefineByLinearAlignment (LocalRefineAlignment.h:141-185) for consecutive anchor pairs"""
     import torch
