@@ -332,40 +332,72 @@ __global__ void __launch_bounds__(64) rs_compare(RsArgs a, int nLarge) {
   };
 #define Qk(x) (qk[x] & FOR_MASK)
 #define Tk(x) (tk[x] & FOR_MASK)
+  // The walk's loops, 64 list entries per round (every lane holds the same cursors; the lists are sorted, the predicates of the searches monotone):
+  // fwd(from, to, pred): the smallest x in [from, to) with !pred(x), else to  == `while (x < to && pred(x)) x++`
+  auto fwd = [&](long from, long to, auto pred) -> long {
+    long x = from;
+    while (x < to) {
+      const long idx = x + lane;
+      const unsigned long long m = __ballot(!(idx < to && pred(idx)));
+      if (m) return min(x + (long)(__ffsll((long long)m) - 1), to);
+      x += 64;
+    }
+    return to;
+  };
+  // bwd(from, stop, pred): the largest x in (stop, from] with !pred(x), else stop  == `while (x > stop && pred(x)) x--`
+  auto bwd = [&](long from, long stop, auto pred) -> long {
+    long x = from;
+    while (x > stop) {
+      const long idx = x - lane;
+      const unsigned long long m = __ballot(!(idx > stop && pred(idx)));
+      if (m) return max(x - (long)(__ffsll((long long)m) - 1), stop);
+      x -= 64;
+    }
+    return stop;
+  };
+  // lower(lo, hi, pred): the binary search `while (lo < hi) { mid; if (pred(mid)) lo = mid + 1; else hi = mid; }` for a monotone pred, 64 probes per round
+  auto lower = [&](long lo, long hi, auto pred) -> long {
+    while (hi - lo > 64) {
+      const long step = (hi - lo + 63) / 64;
+      const long idx = lo + step * (lane + 1) - 1;
+      const int c = __popcll(__ballot(idx < hi && pred(idx)));            // the probes that hold: a prefix
+      const long idxC = lo + step * (c + 1) - 1;                           // the first probe that does not (or lies past hi)
+      lo = lo + step * c; hi = min(hi, idxC);
+    }
+    return fwd(lo, hi, pred);
+  };
   if (nq > 0 && nt > 0) {
     long qs = 0, qe = nq - 1, ts = 0, te = nt;
     do {
-      while (qs <= qe && Qk(qs) < Tk(ts)) qs++;                          // :47-49
+      { const uint64_t t0 = Tk(ts); qs = fwd(qs, qe + 1, [&](long x) { return Qk(x) < t0; }); }   // :47-49
       if (qs >= qe) break;                                               // :51-53
       const uint64_t startGap = Qk(qs) - Tk(ts);
-      while (qe > qs && te > ts && Qk(qe) > Tk(te - 1)) qe--;
+      if (te > ts) { const uint64_t t1 = Tk(te - 1); qe = bwd(qe, qs, [&](long x) { return Qk(x) > t1; }); }
       const uint64_t endGap = Tk(te - 1) - Qk(qe);
       if (startGap == 0 || (startGap & FOR_MASK) > (endGap & FOR_MASK)) {
         const long tsOrig = ts, qsOrig = qs;
-        long lo = ts, hi = te;
-        while (lo < hi) { const long mid = lo + (hi - lo) / 2; if (Tk(mid) < Qk(qs)) lo = mid + 1; else hi = mid; }
-        ts = lo;
-        if (ts < te && Tk(ts) == Qk(qs)) {
-          const long tsStart = ts; long tsi = ts;
-          while (tsi != te && Qk(qs) == Tk(tsi)) tsi++;
+        const uint64_t qv = Qk(qs);
+        ts = lower(ts, te, [&](long x) { return Tk(x) < qv; });
+        if (ts < te && Tk(ts) == qv) {
+          const long tsStart = ts;
+          const long tsi = fwd(ts, te, [&](long x) { return Tk(x) == qv; });
           const long qsStart = qs;
-          while (qs < qe && Qk(qs + 1) == Qk(qs)) qs++;
+          qs = fwd(qs + 1, qe + 1, [&](long x) { return Qk(x) == qv; }) - 1;   // while (qs < qe && Qk(qs + 1) == Qk(qs)) qs++
           if (qs - qsStart < maxFreq && tsi > tsStart) rect(tsStart, tsi, qsStart, qs);   // for ti .. if (..) for qi .. emit(qi, ti)
         }
-        while (ts < te && tk[ts] == tk[tsOrig]) ts++;                    // :101 raw compare
-        while (qs < qe && qk[qs] == qk[qsOrig]) qs++;                    // :102
+        { const uint64_t r = tk[tsOrig]; ts = fwd(ts, te, [&](long x) { return tk[x] == r; }); }   // :101 raw compare
+        { const uint64_t r = qk[qsOrig]; qs = fwd(qs, qe, [&](long x) { return qk[x] == r; }); }   // :102
       } else {
-        if (te != nt && Tk(te - 1) == Qk(qe)) {
+        const uint64_t qv = Qk(qe);
+        if (te != nt && Tk(te - 1) == qv) {
         } else {
-          long lo = ts, hi = te;
-          while (lo < hi) { const long mid = lo + (hi - lo) / 2; if (!(Qk(qe) < Tk(mid))) lo = mid + 1; else hi = mid; }
-          te = lo;
+          te = lower(ts, te, [&](long x) { return !(qv < Tk(x)); });
         }
-        const long teStart = te; long tei = te;
-        while (tei > ts && Tk(tei - 1) == Qk(qe)) tei--;
+        const long teStart = te;
+        const long tei = bwd(te - 1, ts - 1, [&](long x) { return Tk(x) == qv; }) + 1;   // while (tei > ts && Tk(tei - 1) == Qk(qe)) tei--
         if (tei < teStart && teStart > 0) {
           const long qeStart = qe;
-          while (qe > qs && Qk(qe) == Qk(qe - 1)) qe--;
+          qe = bwd(qe - 1, qs - 1, [&](long x) { return Qk(x) == qv; }) + 1;             // while (qe > qs && Qk(qe) == Qk(qe - 1)) qe--
           if (qeStart - qe < maxFreq) rect(tei, teStart, qe, qeStart);
         }
         te = tei;
