@@ -58,6 +58,7 @@ typedef struct lra_ctx lra_ctx;
 #define LRA_ST_CAPACITY 8      /* caller-provided output capacity exceeded              */
 #define LRA_ST_REJECTED 16     /* the reference drops the item itself (e.g. a cluster spanning two chromosomes) */
 #define LRA_ST_UNSUPPORTED 32  /* the read takes a branch of the reference this library has not built (it gets no record) */
+#define LRA_ST_DEFERRED 64     /* internal to lra_map_reads_lowacc_batch: the read left the batch's first pass for its second one (never set in a result) */
 
 /* ---- context ---------------------------------------------------------------------- */
 int lra_ctx_create(int device_id, lra_ctx** out);
@@ -938,11 +939,13 @@ typedef struct lra_map_opts {
   lra_clean_opts clean; lra_sdp_opts sdp;
   int32_t readType, hardClip, PrintNumAln, printFormat;   /* printFormat: 's' SAM, 'p' / 'P' PAF, 'b' BED, 'a' pairwise (PrintPairwise) */
   lra_fine_opts fine; int32_t merge_dist;                 /* high-accuracy path only: MatchesToFineClusters, MergeMatchesSameDiag */
+  int32_t defer_matches;                                  /* low-accuracy path, scheduling only (results do not depend on it): a read with more refined matches than this
+                                                           * after Refine_Btwnsplitchain goes on in a second, concurrent pass; 0 = one pass (the presets) */
 } lra_map_opts;
 typedef struct lra_map_counters {
   uint64_t n_minimizers, n_matches, n_clusters, n_sdp_anchors, n_sdp_points, n_sdp_entries, n_local_tuples, n_local_tasks, n_local_task_words, n_local_pairs, n_refined_matches,
            n_btwn_problems, n_btwn_rounds, n_refined_after_btwn, n_merged_clusters, n_sdp2_anchors, n_sdp2_entries, n_a13_blocks, n_large_spaces, n_segments,
-           n_rows, n_cells, n_aog;
+           n_rows, n_cells, n_aog, n_deferred_reads;
 } lra_map_counters;
 typedef struct lra_map_result {
   int32_t n_reads, num_aln;

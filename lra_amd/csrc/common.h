@@ -38,6 +38,9 @@ struct lra_ctx {
   bool timing = false;
   std::vector<lra_time_rec> recs;
   std::vector<hipEvent_t> free_events;
+  lra_ctx* child = nullptr;                  // mapread.hip: the context of a batch's second, concurrent pass (shares this one's reference; destroyed with it)
+  bool owns_stream = false;
+  bool low_priority = false; int prio = 0;   // the second pass's streams (its side streams too) are created with the device's lowest priority
 };
 
 // Fork: work queued on the returned stream starts after everything queued on ctx->stream so far; join: ctx->stream waits for it.

@@ -60,6 +60,7 @@ extern "C" int lra_ctx_create(int device_id, lra_ctx** out) {
 
 extern "C" void lra_ctx_destroy(lra_ctx* ctx) {
   if (!ctx) return;
+  if (ctx->child) { lra_ctx_destroy(ctx->child); ctx->child = nullptr; }   // borrows this context's reference: first
   (void)hipSetDevice(ctx->device);
   (void)hipStreamSynchronize(ctx->stream);
   for (int i = 0; i < 4; i++)
@@ -78,13 +79,16 @@ extern "C" void lra_ctx_destroy(lra_ctx* ctx) {
     if (ctx->ev_join[i]) (void)hipEventDestroy(ctx->ev_join[i]);
   }
   if (ctx->ev_fork) (void)hipEventDestroy(ctx->ev_fork);
+  if (ctx->owns_stream && ctx->stream) (void)hipStreamDestroy(ctx->stream);
   delete ctx;
 }
 
 hipStream_t lra_side_fork(lra_ctx* ctx, int i) {
   if (i < 0 || i >= lra_ctx::N_SIDE) return ctx->stream;
   if (!ctx->side[i]) {
-    if (hipStreamCreateWithFlags(&ctx->side[i], hipStreamNonBlocking) != hipSuccess) { ctx->side[i] = nullptr; return ctx->stream; }
+    if ((ctx->low_priority ? hipStreamCreateWithPriority(&ctx->side[i], hipStreamNonBlocking, ctx->prio) : hipStreamCreateWithFlags(&ctx->side[i], hipStreamNonBlocking)) != hipSuccess) {
+      ctx->side[i] = nullptr; return ctx->stream;
+    }
     if (!ctx->ev_fork) (void)hipEventCreateWithFlags(&ctx->ev_fork, hipEventDisableTiming);
     (void)hipEventCreateWithFlags(&ctx->ev_join[i], hipEventDisableTiming);
   }
@@ -132,6 +136,7 @@ void lra_time_end(lra_ctx* ctx, hipStream_t stream) {
 extern "C" int lra_ctx_timing_enable(lra_ctx* ctx, int on) {
   if (!ctx) return LRA_ERR_INVALID;
   ctx->timing = on != 0;
+  if (ctx->child) ctx->child->timing = ctx->timing;
   return LRA_OK;
 }
 
@@ -140,6 +145,7 @@ extern "C" int lra_ctx_timing_reset(lra_ctx* ctx) {
   (void)hipStreamSynchronize(ctx->stream);
   for (auto& r : ctx->recs) { ctx->free_events.push_back(r.a); ctx->free_events.push_back(r.b); }
   ctx->recs.clear();
+  if (ctx->child) return lra_ctx_timing_reset(ctx->child);
   return LRA_OK;
 }
 
@@ -147,11 +153,14 @@ extern "C" int lra_ctx_timing_get(lra_ctx* ctx, const char* name, double* total_
   if (!ctx || !name) return LRA_ERR_INVALID;
   LRA_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
   double tot = 0; int n = 0;
-  for (auto& r : ctx->recs)
-    if (strcmp(r.name, name) == 0) {
-      float ms = 0;
-      if (hipEventElapsedTime(&ms, r.a, r.b) == hipSuccess) { tot += ms; n++; }
-    }
+  for (lra_ctx* c = ctx; c; c = c->child) {                               // a batch's second pass counts with the batch
+    if (c != ctx) LRA_HIP_CHECK(ctx, hipStreamSynchronize(c->stream));
+    for (auto& r : c->recs)
+      if (strcmp(r.name, name) == 0) {
+        float ms = 0;
+        if (hipEventElapsedTime(&ms, r.a, r.b) == hipSuccess) { tot += ms; n++; }
+      }
+  }
   if (total_ms) *total_ms = tot;
   if (launches) *launches = n;
   return n ? LRA_OK : lra_set_err(ctx, LRA_ERR_INVALID, "no timing records for kernel '%s'", name);

@@ -12,11 +12,13 @@
 #include "seed_state.h"
 #include "scan.h"
 #include "map_state.h"
+#include "map_merge.h"
 #include <chrono>
 #include <math.h>
 #include <stdlib.h>
 #include <algorithm>
 #include <thread>
+#include <functional>
 
 void lra_map_free(lra_ctx* ctx) {
   lra_map_state* m = ctx->map;
@@ -66,6 +68,52 @@ __global__ void k_or_status_div(uint64_t n, const uint32_t* __restrict__ status,
 __global__ void k_or_status_idx(uint64_t n, const uint32_t* __restrict__ status, const uint32_t* __restrict__ idx, int div, uint32_t* __restrict__ read_status) {
   const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i < n && status[i]) atomicOr(&read_status[idx[i] / (uint32_t)div], status[i]);
+}
+// ---- the reads whose chains are far larger than anything else in the batch (the second, concurrent pass of lra_map_reads_lowacc_batch)
+// load[r] = the number of refined matches of read r's split chains after Refine_Btwnsplitchain: what its second sparse DP will chain
+__global__ void k_read_load(uint64_t n_slots, int num_aln, const uint32_t* __restrict__ n_chains, const uint64_t* __restrict__ chain_start,
+                            const uint32_t* __restrict__ n_split, const uint32_t* __restrict__ sp_status, const uint64_t* __restrict__ match_off, uint32_t* __restrict__ load) {
+  const uint64_t s = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (s >= n_slots) return;
+  const uint64_t r = s / (uint64_t)num_aln;
+  if ((uint32_t)(s % (uint64_t)num_aln) >= n_chains[r] || sp_status[s] || !n_split[s]) return;
+  const uint64_t c0 = chain_start[s];
+  atomicAdd(&load[r], (uint32_t)(match_off[c0 + n_split[s]] - match_off[c0]));
+}
+// a read above the threshold leaves this pass: its split chains are marked (every later stage skips a marked slot), and so is its status word.  The second pass gets
+// the mirror image: sp2 (only the deferred reads' slots are on), their job_reached flags, a clean status array
+__global__ void k_mark_deferred(int n_reads, int num_aln, const uint32_t* __restrict__ load, uint32_t threshold, uint32_t* __restrict__ sp_status,
+                                uint32_t* __restrict__ read_status, uint8_t* __restrict__ deferred, uint32_t* __restrict__ sp2, uint8_t* __restrict__ reached,
+                                uint8_t* __restrict__ reached2, uint32_t* __restrict__ rstat2) {
+  const int r = blockIdx.x * blockDim.x + threadIdx.x;
+  if (r >= n_reads) return;
+  const bool d = load[r] > threshold && read_status[r] == 0;
+  deferred[r] = d ? 1 : 0;
+  rstat2[r] = 0;
+  for (int h = 0; h < num_aln; h++) {
+    const uint64_t s = (uint64_t)r * num_aln + h;
+    sp2[s] = d ? sp_status[s] : (uint32_t)LRA_ST_DEFERRED;
+    reached2[s] = d ? reached[s] : 0;
+    if (d) { sp_status[s] |= LRA_ST_DEFERRED; reached[s] = 0; }
+  }
+  if (d) read_status[r] |= LRA_ST_DEFERRED;
+}
+__global__ void k_src_slot(uint64_t S, int na, const int32_t* __restrict__ inB, uint64_t* __restrict__ src) {
+  const uint64_t s = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (s >= S) return;
+  const int b = inB[s / (uint64_t)na];
+  src[s] = b >= 0 ? (((uint64_t)b * na + s % (uint64_t)na) | lra_merge::FROM_B) : s;
+}
+__global__ void k_merge_reached(uint64_t S, const uint64_t* __restrict__ src, const uint8_t* __restrict__ A, const uint8_t* __restrict__ B, uint8_t* __restrict__ out) {
+  const uint64_t s = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (s >= S) return;
+  const uint64_t x = src[s];
+  out[s] = (x & lra_merge::FROM_B) ? B[x & ~lra_merge::FROM_B] : A[x];
+}
+__global__ void k_merge_read_status(int R, const int32_t* __restrict__ inB, const uint32_t* __restrict__ A, const uint32_t* __restrict__ B, uint32_t* __restrict__ out) {
+  const int r = blockIdx.x * blockDim.x + threadIdx.x;
+  if (r >= R) return;
+  out[r] = inB[r] >= 0 ? B[inB[r]] : A[r];
 }
 // per-split arrays live at chain_start[s] + k, k < n_split[s] (the split / refined-cluster numbering of chain_split.hip, refine_splitchain.hip, refine_btwn.hip)
 __global__ void k_or_status_split(uint64_t n_slots, int num_aln, const uint32_t* __restrict__ n_chains, const uint64_t* __restrict__ chain_start,
@@ -195,6 +243,7 @@ extern "C" void lra_map_opts_preset_ont(lra_map_opts* o) {
   o->sdp.rate = 20.0f; o->sdp.NumAln = 2; o->sdp.alnthres = 0.65f; o->sdp.gapopen = 7.0f; o->sdp.gapextend = 10.0f; o->sdp.gaproot = 1.5f;
   o->sdp.gapCeiling1 = 1500; o->sdp.gapCeiling2 = 3000; o->sdp.mode = 0; o->sdp.globalK = 17;
   o->readType = LRA_READ_ONT; o->hardClip = 1; o->PrintNumAln = 1; o->printFormat = 's';
+  o->defer_matches = 0;        // one pass (lra_map_reads_lowacc_batch: the second, concurrent pass is built and tested, and measured to be no gain on this device)
 }
 
 extern "C" void lra_map_opts_preset_clr(lra_map_opts* o) {
@@ -355,16 +404,24 @@ extern "C" int lra_match_rate_batch(lra_ctx* ctx, const lra_cluster_result* clus
   return LRA_OK;
 }
 
-extern "C" int lra_map_reads_lowacc_batch(lra_ctx* ctx, int n_reads, const char* d_seq, const uint64_t* d_read_off, uint64_t total_bases,
-                                          const lra_map_opts* o, lra_map_result* out) {
-  if (!ctx || !o || !out || n_reads < 0) return LRA_ERR_INVALID;
+// One pass of MapRead_lowacc over a batch.  defer_threshold > 0: the reads with more refined matches than that after Refine_Btwnsplitchain leave the pass there (no
+// alignments, LRA_ST_DEFERRED in their status word); *deferred lists them and on_deferred runs as soon as the list is known.
+// What the stages behind the split point need from the ones in front of it (device pointers into the first pass's buffers, which it leaves alone from there on)
+struct LowaccTailIn {
+  int n_reads = 0, num_aln = 1; uint64_t n_slots = 0, tot = 0;
+  const uint64_t* d_read_off = nullptr; const char* d_seq = nullptr; const char* both = nullptr;
+  const uint32_t* slot_n0 = nullptr;
+  lra_merge_result mres;
+  uint8_t* job_reached = nullptr; uint32_t* read_status = nullptr;
+  lra_map_counters counters;
+};
+static int lowacc_tail(lra_ctx* ctx, const LowaccTailIn& in, const lra_map_opts* o, lra_map_result* out);
+
+static int lowacc_core(lra_ctx* ctx, int n_reads, const char* d_seq, const uint64_t* d_read_off, uint64_t total_bases, const lra_map_opts* o, lra_map_result* out,
+                       uint32_t defer_threshold, std::vector<uint32_t>* deferred, lra_ctx* second, LowaccTailIn* second_in, const std::function<int()>& on_deferred) {
   memset(out, 0, sizeof *out);
   lra_map_state* m = ctx->map;
-  if (!m || !m->gli_buf || !ctx->seed || !ctx->seed->genome || !ctx->seed->idx_key)
-    return lra_set_err(ctx, LRA_ERR_INVALID, "reference not loaded (genome, global index, chromosome table, local index)");
-  if (m->gli_window != o->localIndexWindow) return lra_set_err(ctx, LRA_ERR_INVALID, "local index built with another window");
   out->n_reads = n_reads;
-  std::string().swap(m->last_text); m->last_sig = lra_map_sig{};         // a sizing call of lra_map_records for an earlier batch is void now
   if (n_reads == 0) return LRA_OK;
   LRA_HIP_CHECK(ctx, hipSetDevice(ctx->device));
   hipStream_t st = ctx->stream;
@@ -382,7 +439,7 @@ extern "C" int lra_map_reads_lowacc_batch(lra_ctx* ctx, int n_reads, const char*
   auto wall = []() { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
   double t_prev = 0;
   if (sdbg) { (void)hipStreamSynchronize(st); t_prev = wall(); }
-  auto stage = [&](const char* name) { if (!sdbg) return; (void)hipStreamSynchronize(st); const double t = wall(); fprintf(stderr, "[stage] %-28s %8.1f ms\n", name, t - t_prev); t_prev = t; };
+  auto stage = [&](const char* name) { if (!sdbg) return; (void)hipStreamSynchronize(st); const double t = wall(); fprintf(stderr, "[stage%s] %-28s %8.1f ms\n", ctx->owns_stream ? " 2nd" : "", name, t - t_prev); t_prev = t; };
   // a1-a4
   lra_seed_result sres;
   if ((rc = lra_seed_batch(ctx, n_reads, d_seq, d_read_off, o->globalK, o->globalW, o->globalMaxFreq, &sres))) return rc;
@@ -450,16 +507,80 @@ extern "C" int lra_map_reads_lowacc_batch(lra_ctx* ctx, int n_reads, const char*
   lra_btwn_result bres;
   if ((rc = lra_refine_btwn_splitchain_batch(ctx, &chres, &spres, &rres, d_read_off, both, tot, genome, CH, nCh, &bo, &bres))) return rc;
   stage("refine_btwn_splitchain");
-  // a9 MergeChain, a7 second pass, a8 second sparse DP (Map_lowacc.h:411-540)
-  lra_merge_result mres;
-  if ((rc = lra_merge_extend_batch(ctx, &chres, &spres, &bres, d_seq, d_read_off, genome, CH, nCh, o->localK, &mres))) return rc;
-  stage("merge_extend");
   uint8_t* job_reached = (uint8_t*)lra_ensure(ctx, 82, n_slots + 64);
   if (!job_reached) return LRA_ERR_NOMEM;
   hipLaunchKernelGGL(k_job_reached, grid(n_slots), dim3(256), 0, st, n_slots, num_aln, chres.d_n_chains, chres.d_chain_start, spres.d_n_split, spres.d_status,
                      bres.d_match_off, job_reached);
   if (rres.n_frags) hipLaunchKernelGGL(k_or_status_split, grid(n_slots), dim3(256), 0, st, n_slots, num_aln, chres.d_n_chains, chres.d_chain_start, spres.d_n_split,
                                        spres.d_status, rres.d_status, read_status);
+  // counters of the stages so far
+  lra_map_counters cnt0; memset(&cnt0, 0, sizeof cnt0);
+  cnt0.n_minimizers = sres.n_minimizers; cnt0.n_matches = sres.n_matches; cnt0.n_clusters = cres.n_clusters; cnt0.n_sdp_anchors = chres.n_frags; cnt0.n_sdp_points = chres.n_points;
+  cnt0.n_sdp_entries = chres.n_subproblem_entries; cnt0.n_local_tuples = rli.n_tuples; cnt0.n_local_tasks = rres.n_tasks; cnt0.n_local_task_words = task_words; cnt0.n_local_pairs = rres.n_pairs;
+  cnt0.n_refined_matches = rres.n_matches; cnt0.n_btwn_problems = bres.n_problems; cnt0.n_btwn_rounds = bres.n_rounds; cnt0.n_refined_after_btwn = bres.n_matches;
+  LowaccTailIn in;
+  in.n_reads = n_reads; in.num_aln = num_aln; in.n_slots = n_slots; in.tot = tot; in.d_read_off = d_read_off; in.d_seq = d_seq; in.both = both; in.slot_n0 = slot_n0;
+  in.job_reached = job_reached; in.read_status = read_status; in.counters = cnt0;
+  // ---- the split point: reads with more refined matches than the threshold go on in the second context (from here: MergeChain onwards), beside this pass
+  if (defer_threshold && deferred && second && second_in) {
+    uint32_t* load = (uint32_t*)lra_ensure(ctx, 181, ((size_t)n_reads + 1) * 4);
+    uint8_t* dflag = (uint8_t*)lra_ensure(ctx, 182, (size_t)n_reads + 64);
+    if (!load || !dflag) return LRA_ERR_NOMEM;
+    LRA_HIP_CHECK(ctx, hipMemsetAsync(load, 0, (size_t)n_reads * 4, st));
+    hipLaunchKernelGGL(k_read_load, grid(n_slots), dim3(256), 0, st, n_slots, num_aln, chres.d_n_chains, chres.d_chain_start, spres.d_n_split, spres.d_status, bres.d_match_off, load);
+    uint32_t* sp2 = (uint32_t*)lra_ensure(second, 183, (n_slots + 1) * 4);    // the second pass's view of the split chains: everything but the deferred reads' slots is off
+    uint8_t* reached2 = (uint8_t*)lra_ensure(second, 82, n_slots + 64);
+    uint32_t* rstat2 = (uint32_t*)lra_ensure(second, 81, ((size_t)n_reads + 1) * 4);
+    if (!sp2 || !reached2 || !rstat2) return LRA_ERR_NOMEM;
+    hipLaunchKernelGGL(k_mark_deferred, grid(n_reads), dim3(256), 0, st, n_reads, num_aln, (const uint32_t*)load, defer_threshold, (uint32_t*)spres.d_status, read_status, dflag,
+                       sp2, job_reached, reached2, rstat2);
+    std::vector<uint8_t> hf((size_t)n_reads);
+    LRA_HIP_CHECK(ctx, hipMemcpyAsync(hf.data(), dflag, (size_t)n_reads, hipMemcpyDeviceToHost, st));
+    LRA_HIP_CHECK(ctx, hipStreamSynchronize(st));
+    deferred->clear();
+    for (int r = 0; r < n_reads; r++) if (hf[r]) deferred->push_back((uint32_t)r);
+    if (!deferred->empty()) {
+      // MergeChain .. TrimOverlappedAnchors of the deferred reads' chains, into the second context's buffers but queued on THIS stream: it reads the first sparse DP's
+      // arrays, which this pass's second sparse DP is about to reuse
+      lra_split_result spB = spres; spB.d_status = sp2;
+      const hipStream_t keep = second->stream;
+      second->stream = st;
+      rc = lra_merge_extend_batch(second, &chres, &spB, &bres, d_seq, d_read_off, genome, CH, nCh, o->localK, &second_in->mres);
+      second->stream = keep;
+      if (rc) return lra_set_err(ctx, rc, "second pass, MergeChain: %s", second->err.c_str());
+      LRA_HIP_CHECK(ctx, hipStreamSynchronize(st));
+      { const lra_merge_result keepM = second_in->mres; *second_in = in; second_in->mres = keepM; second_in->job_reached = reached2; second_in->read_status = rstat2; }
+      if (on_deferred && (rc = on_deferred())) return rc;
+    }
+    stage("deferred reads");
+  }
+  // a9 MergeChain, a7 second pass (Map_lowacc.h:411-476)
+  if ((rc = lra_merge_extend_batch(ctx, &chres, &spres, &bres, d_seq, d_read_off, genome, CH, nCh, o->localK, &in.mres))) return rc;
+  stage("merge_extend");
+  return lowacc_tail(ctx, in, o, out);
+}
+
+// a8 second sparse DP, a13, a14, a16 (Map_lowacc.h:477-599) on the merged clusters of `in`
+static int lowacc_tail(lra_ctx* ctx, const LowaccTailIn& in, const lra_map_opts* o, lra_map_result* out) {
+  lra_map_state* m = ctx->map;
+  LRA_HIP_CHECK(ctx, hipSetDevice(ctx->device));
+  hipStream_t st = ctx->stream;
+  auto grid = [](uint64_t n) { return dim3((unsigned)((n + 255) / 256)); };
+  const int n_reads = in.n_reads, num_aln = in.num_aln; const uint64_t n_slots = in.n_slots, tot = in.tot;
+  const uint64_t* d_read_off = in.d_read_off; const char* both = in.both; const uint32_t* slot_n0 = in.slot_n0;
+  const lra_merge_result& mres = in.mres;
+  uint8_t* job_reached = in.job_reached; uint32_t* read_status = in.read_status;
+  const uint64_t* CH = m->chrom_pos.data();
+  const int nCh = (int)m->chrom_pos.size() - 1;
+  const char* genome = (const char*)ctx->seed->genome;
+  int rc;
+  const bool sdbg = getenv("LRA_STAGE_DBG") != nullptr;
+  auto wall = []() { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+  double t_prev = 0;
+  if (sdbg) { (void)hipStreamSynchronize(st); t_prev = wall(); }
+  auto stage = [&](const char* name) { if (!sdbg) return; (void)hipStreamSynchronize(st); const double t = wall(); fprintf(stderr, "[stage%s] %-28s %8.1f ms\n", ctx->owns_stream ? " 2nd" : "", name, t - t_prev); t_prev = t; };
+  (void)n_slots;
+  out->n_reads = n_reads;
   lra_sdp_opts s2 = o->sdp; s2.mode = 1; s2.rate = o->second_anchorbonus;      // SparseDP :2287 with opts.second_anchorbonus (Options.h:221)
   lra_chain_result ch2;
   if ((rc = lra_sparse_dp_batch(ctx, (int)mres.n_groups, mres.d_iota, mres.d_anchor_off, mres.d_count, mres.d_strand, mres.d_q, mres.d_t, mres.d_len, mres.d_iota,
@@ -526,11 +647,110 @@ extern "C" int lra_map_reads_lowacc_batch(lra_ctx* ctx, int n_reads, const char*
   }
   // counters of the batch (what bench.py prices the roofline with)
   lra_map_counters& c = out->counters;
-  c.n_minimizers = sres.n_minimizers; c.n_matches = sres.n_matches; c.n_clusters = cres.n_clusters; c.n_sdp_anchors = chres.n_frags; c.n_sdp_points = chres.n_points;
-  c.n_sdp_entries = chres.n_subproblem_entries; c.n_local_tuples = rli.n_tuples; c.n_local_tasks = rres.n_tasks; c.n_local_task_words = task_words; c.n_local_pairs = rres.n_pairs;
-  c.n_refined_matches = rres.n_matches; c.n_btwn_problems = bres.n_problems; c.n_btwn_rounds = bres.n_rounds; c.n_refined_after_btwn = bres.n_matches;
+  c = in.counters;
   c.n_merged_clusters = mres.n_groups; c.n_sdp2_anchors = mres.n_anchors; c.n_sdp2_entries = ch2.n_subproblem_entries; c.n_a13_blocks = ares.n_blocks;
   c.n_large_spaces = ares.n_big; c.n_segments = fres.n_segments; c.n_rows = fres.n_rows; c.n_cells = fres.n_cells; c.n_aog = fres.n_aog;
+  return LRA_OK;
+}
+
+// lra_map_reads_lowacc_batch: the pass above.  With opts.defer_matches > 0 the batch's most repetitive reads -- a read inside a satellite array ends up with tens of
+// thousands of refined matches where a typical 30 kb read has three thousand, and its second sparse DP keeps one workgroup busy for half a second -- leave the pass after
+// Refine_Btwnsplitchain and go on, from MergeChain, in a child context on its own lowest-priority stream and host thread BESIDE the rest of the pass; the two results
+// are merged on the device (a read's alignments do not depend on which pass computed them: tests/test_mapread.py ont-defer*).  Off in the presets: on this device it is
+// no gain at any threshold -- the repetitive reads' work is throughput that the pass's own launches already overlap, not an idle tail.
+extern "C" int lra_map_reads_lowacc_batch(lra_ctx* ctx, int n_reads, const char* d_seq, const uint64_t* d_read_off, uint64_t total_bases,
+                                          const lra_map_opts* o, lra_map_result* out) {
+  if (!ctx || !o || !out || n_reads < 0) return LRA_ERR_INVALID;
+  memset(out, 0, sizeof *out);
+  lra_map_state* m = ctx->map;
+  if (!m || !m->gli_buf || !ctx->seed || !ctx->seed->genome || !ctx->seed->idx_key)
+    return lra_set_err(ctx, LRA_ERR_INVALID, "reference not loaded (genome, global index, chromosome table, local index)");
+  if (m->gli_window != o->localIndexWindow) return lra_set_err(ctx, LRA_ERR_INVALID, "local index built with another window");
+  out->n_reads = n_reads;
+  std::string().swap(m->last_text); m->last_sig = lra_map_sig{};         // a sizing call of lra_map_records for an earlier batch is void now
+  if (n_reads == 0) return LRA_OK;
+  uint32_t threshold = o->defer_matches > 0 ? (uint32_t)o->defer_matches : 0;
+  if (const char* e = getenv("LRA_DEFER_MATCHES")) threshold = (uint32_t)std::max(0, atoi(e));
+  const std::function<int()> none;
+  if (!threshold) return lowacc_core(ctx, n_reads, d_seq, d_read_off, total_bases, o, out, 0, nullptr, nullptr, nullptr, none);
+  LRA_HIP_CHECK(ctx, hipSetDevice(ctx->device));
+  if (!ctx->child) {                                                     // the second pass's context: its own (lowest-priority) streams, this one's reference
+    lra_ctx* c = nullptr;
+    int rc = lra_ctx_create(ctx->device, &c);
+    if (rc) return lra_set_err(ctx, rc, "second-pass context");
+    if ((rc = lra_ctx_share_reference(c, ctx))) { lra_ctx_destroy(c); return lra_set_err(ctx, rc, "second-pass context: sharing the reference"); }
+    int least = 0, greatest = 0;
+    (void)hipDeviceGetStreamPriorityRange(&least, &greatest);
+    // the second pass fills the gaps the first one leaves; at equal priority the two passes' queues slow each other down far beyond the work involved (measured)
+    c->low_priority = true; c->prio = least;
+    if (hipStreamCreateWithPriority(&c->stream, hipStreamNonBlocking, least) != hipSuccess) { c->stream = nullptr; lra_ctx_destroy(c); return lra_set_err(ctx, LRA_ERR_HIP, "second-pass stream"); }
+    c->owns_stream = true; c->timing = ctx->timing;
+    ctx->child = c;
+  }
+  {                                                                      // the parent's reference may have been loaded / built again since the last batch
+    lra_ctx* c = ctx->child;
+    int rc = lra_seed_share(c, ctx);
+    if (rc) return lra_set_err(ctx, rc, "second-pass context: sharing the reference");
+    lra_map_state* d = c->map; const lra_map_state* s = ctx->map;
+    d->chrom_pos = s->chrom_pos; d->d_chrom_pos = s->d_chrom_pos; d->gli_buf = s->gli_buf; d->gli = s->gli; d->d_gso = s->d_gso; d->n_gwin = s->n_gwin;
+    d->gli_window = s->gli_window; d->lut = s->lut; d->borrowed = true;
+  }
+  std::vector<uint32_t> picked;
+  std::thread second;
+  int rc2 = LRA_OK;
+  LowaccTailIn in2;
+  lra_map_result o2; memset(&o2, 0, sizeof o2);
+  const bool ddbg = getenv("LRA_DEFER_DBG") != nullptr;
+  auto wall = []() { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+  const double t0 = wall();
+  double t_split = 0, t_second = 0;
+  auto start_second = [&]() -> int {
+    t_split = wall();
+    second = std::thread([&, c = ctx->child]() {
+      rc2 = lowacc_tail(c, in2, o, &o2);
+      t_second = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count();
+    });
+    return LRA_OK;
+  };
+  int rc = lowacc_core(ctx, n_reads, d_seq, d_read_off, total_bases, o, out, threshold, &picked, ctx->child, &in2, start_second);
+  const double t1 = wall();
+  if (second.joinable()) second.join();
+  if (ddbg) fprintf(stderr, "[defer] %d reads; split at %.0f ms, second pass done at %.0f ms, first pass done at %.0f ms\n", (int)picked.size(), t_split - t0, t_second - t0, t1 - t0);
+  if (rc) return rc;
+  if (picked.empty()) return LRA_OK;
+  if (rc2) return lra_set_err(ctx, rc2, "second pass (%d reads): %s", (int)picked.size(), ctx->child ? ctx->child->err.c_str() : "");
+  // ---- merge: the job slots of the second pass's reads from its result, every other slot from the first pass's
+  hipStream_t st = ctx->stream;
+  auto grid = [](uint64_t n) { return dim3((unsigned)((n + 255) / 256)); };
+  const int na = out->num_aln, R = n_reads, R2 = (int)picked.size();
+  if (o2.num_aln != na) return lra_set_err(ctx, LRA_ERR_INVALID, "passes disagree on NumAln");
+  const uint64_t S = (uint64_t)R * na;
+  std::vector<int32_t> inB((size_t)R, -1);
+  for (int i = 0; i < R2; i++) inB[picked[i]] = (int32_t)picked[i];    // (the second pass keeps the batch's slot numbering)
+  int32_t* d_inB = (int32_t*)lra_ensure(ctx, 173, ((size_t)R + 4) * 4);
+  uint64_t* d_src = (uint64_t*)lra_ensure(ctx, 175, (S + 4) * 8);
+  if (!d_inB || !d_src) return LRA_ERR_NOMEM;
+  LRA_HIP_CHECK(ctx, hipMemcpyAsync(d_inB, inB.data(), (size_t)R * 4, hipMemcpyHostToDevice, st));
+  hipLaunchKernelGGL(k_src_slot, grid(S), dim3(256), 0, st, S, na, (const int32_t*)d_inB, d_src);
+  const lra_map_result a = *out;
+  lra_merge::PassView A = lra_merge::view_of(a), B = lra_merge::view_of(o2);
+  char* extra = nullptr;
+  lra_map_result mo; memset(&mo, 0, sizeof mo);
+  if ((rc = lra_merge::merge_passes(ctx, 171, S, na, d_src, A, B, a.n_alignments + o2.n_alignments, a.n_blocks + o2.n_blocks, a.n_runs + o2.n_runs,
+                                    lra_merge::al256(S + 64) + ((size_t)R + 4) * 4, &extra, &mo))) return rc;
+  uint8_t* reached = (uint8_t*)extra; uint32_t* rstat = (uint32_t*)(extra + lra_merge::al256(S + 64));
+  hipLaunchKernelGGL(k_merge_reached, grid(S), dim3(256), 0, st, S, (const uint64_t*)d_src, a.d_job_reached, o2.d_job_reached, reached);
+  hipLaunchKernelGGL(k_merge_read_status, grid(R), dim3(256), 0, st, R, (const int32_t*)d_inB, a.d_read_status, o2.d_read_status, rstat);
+  LRA_HIP_CHECK(ctx, hipStreamSynchronize(st));                          // (inB is pageable; and the result is the caller's to read now)
+  LRA_HIP_CHECK(ctx, hipGetLastError());
+  *out = mo;
+  out->n_reads = R; out->num_aln = na; out->d_job_reached = reached; out->d_read_status = rstat; out->d_strands = a.d_strands; out->rc_base = a.rc_base;
+  // counters: the stages up to the split point saw every read in the first pass; the later ones saw each read in one pass only
+  lra_map_counters c = a.counters; const lra_map_counters& b = o2.counters;
+  c.n_merged_clusters += b.n_merged_clusters; c.n_sdp2_anchors += b.n_sdp2_anchors; c.n_sdp2_entries += b.n_sdp2_entries; c.n_a13_blocks += b.n_a13_blocks;
+  c.n_large_spaces += b.n_large_spaces; c.n_segments += b.n_segments; c.n_rows += b.n_rows; c.n_cells += b.n_cells; c.n_aog += b.n_aog;
+  c.n_deferred_reads = (uint64_t)R2;
+  out->counters = c;
   return LRA_OK;
 }
 

@@ -960,7 +960,7 @@ extern "C" int lra_ctx_load_global_index(lra_ctx* ctx, const uint64_t* h_key, co
 }
 
 int lra_seed_share(lra_ctx* dst, lra_ctx* src) {
-  if (dst->seed && (dst->seed->genome || dst->seed->idx_key)) return lra_set_err(dst, LRA_ERR_INVALID, "context already holds reference data");
+  if (dst->seed && !dst->seed->borrowed && (dst->seed->genome || dst->seed->idx_key)) return lra_set_err(dst, LRA_ERR_INVALID, "context already holds reference data");
   lra_seed_state* d = seed_state(dst);
   const lra_seed_state* s = src->seed;
   d->borrowed = true;

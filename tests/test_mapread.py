@@ -146,7 +146,7 @@ def test_map_reads_to_sam(ctx):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("preset", ["ont", "clr", "ont-bp", "ont-2chr", "ont-rep"])
+@pytest.mark.parametrize("preset", ["ont", "clr", "ont-bp", "ont-2chr", "ont-rep", "ont-defer", "ont-defer-all", "ont-onepass"])
 def test_map_reads_match_oracle_pipeline(ctx, oracle, preset):
     """The C boundary against the oracle's stage functions composed on the CPU (tests/oracle_pipeline.py): every SegAlignment of every
     primary chain -- strand, Supplymentary, NumOfAnchors0/1, FirstSDPValue, the refined blocks -- bit for bit, on plain reads, reads with a
@@ -157,6 +157,8 @@ def test_map_reads_match_oracle_pipeline(ctx, oracle, preset):
     O_STAT_NAMES = oracle_lib.STAT_NAMES
     genome = synth.make_genome(500_000, seed=31, repeat_frac=0.25, n_families=3)
     o = mapread.clr_options() if preset == "clr" else mapread.LowAccOptions(refineBreakpoint=(preset == "ont-bp"))     # ont-bp: --refineBreakpoints
+    # ont-defer / -all / onepass: lra_map_opts.defer_matches -- some / all / none of the reads go through the driver's second, concurrent pass; same results
+    o.deferMatches = {"ont-defer": 800, "ont-defer-all": 1, "ont-onepass": 0}.get(preset)
     oo = OP.CLR if preset == "clr" else dict(OP.ONT, refineBreakpoint=(preset == "ont-bp"))
     err, mix = (0.15, (20, 30, 50)) if preset == "clr" else (0.10, (30, 35, 35))
     ik, ip = synth.build_global_index(genome, o.globalK, o.globalW, 100)
@@ -184,6 +186,8 @@ def test_map_reads_match_oracle_pipeline(ctx, oracle, preset):
     res = mapper.align(seed.ReadBatch(ctx, [r.tobytes() for r in reads]))
     out = mapper.fetch(res)
     na = int(res.num_aln)
+    nd = mapper.stats["n_deferred_reads"]
+    assert {"ont-defer": 0 < nd < len(reads) - 1, "ont-defer-all": nd == len(reads) - 1, "ont-onepass": nd == 0}.get(preset, True), (nd, len(reads))
     g_win, g_bnd, g_tup = mapper.gli.fetch()
     g_index = (mapread.seq_offsets(CH, 256).astype(np.uint64), g_bnd, g_tup)
     gbytes = genome.tobytes() + b"\0" * 64
