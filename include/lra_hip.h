@@ -68,7 +68,7 @@ int lra_ctx_set_stream(lra_ctx* ctx, void* stream);
 const char* lra_ctx_last_error(lra_ctx* ctx);
 /* ABI version of the loaded library (tests check it against this header). */
 int lra_abi_version(void);
-#define LRA_ABI_VERSION 1
+#define LRA_ABI_VERSION 2   /* 2: lra_map_opts.defer_matches, lra_map_counters.n_deferred_reads */
 
 /* Convenience for hosts without their own HIP binding: synchronous device->host copy on the
  * context's stream (a C++ host would call hipMemcpy itself).                                */

@@ -4,7 +4,7 @@ import os
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 _LIB = None
-ABI_VERSION = 1
+ABI_VERSION = 2
 
 
 class LraError(RuntimeError):
