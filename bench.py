@@ -213,12 +213,17 @@ def main():
                 # Every rank turns its own reads' records into text (its shard of the output, in ordinal order) with its share of the host's cores: the
                 # path has no exchange step -- reads are independent, and so are their records.  (lra_amd.parallel.gather_records / merge_by_ordinal
                 # bring the record buffers of all ranks to rank 0 when one process has to write one stream: tests/test_parallel.py.)
+                tA = time.perf_counter()
                 hb = held.cpu().numpy()
+                tB = time.perf_counter()
                 snap = C.c_void_p()
                 rc = ctx.lib.lra_map_unpack_host(C.c_void_p(hb.ctypes.data), C.c_uint64(hb.nbytes), C.byref(snap))
                 assert rc == 0, rc
                 items = [(lane, snap)]
+            tC = time.perf_counter()
             host_tail(items)
+            if os.environ.get("LRA_BENCH_DBG"):
+                sys.stderr.write("[bench] host tail: copy %.0f ms (%.2f GB), unpack %.0f ms, records %.0f ms\n" % ((tB - tA) * 1e3, hb.nbytes / 1e9, (tC - tB) * 1e3, (time.perf_counter() - tC) * 1e3))
         except BaseException as e:
             err.append(e)
 

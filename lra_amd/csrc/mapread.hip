@@ -18,6 +18,7 @@
 #include <stdlib.h>
 #include <algorithm>
 #include <thread>
+#include <mutex>
 #include <functional>
 
 void lra_map_free(lra_ctx* ctx) {
@@ -667,7 +668,7 @@ extern "C" int lra_map_reads_lowacc_batch(lra_ctx* ctx, int n_reads, const char*
     return lra_set_err(ctx, LRA_ERR_INVALID, "reference not loaded (genome, global index, chromosome table, local index)");
   if (m->gli_window != o->localIndexWindow) return lra_set_err(ctx, LRA_ERR_INVALID, "local index built with another window");
   out->n_reads = n_reads;
-  std::string().swap(m->last_text); m->last_sig = lra_map_sig{};         // a sizing call of lra_map_records for an earlier batch is void now
+  m->last_text.clear(); m->last_sig = lra_map_sig{};         // a sizing call of lra_map_records for an earlier batch is void now
   if (n_reads == 0) return LRA_OK;
   uint32_t threshold = o->defer_matches > 0 ? (uint32_t)o->defer_matches : 0;
   if (const char* e = getenv("LRA_DEFER_MATCHES")) threshold = (uint32_t)std::max(0, atoi(e));
@@ -761,11 +762,12 @@ extern "C" int lra_map_reads_lowacc_batch(lra_ctx* ctx, int n_reads, const char*
 struct lra_map_host {
   int32_t n_reads = 0, num_aln = 1; uint64_t nJ = 0, nA = 0;
   std::vector<uint64_t> jo, roff, boff; std::vector<int32_t> strand, supp, sec, n0, n1, chrom, counts, blocks; std::vector<float> fval;
-  std::vector<uint32_t> runs, rstat, ends;                 // ends: per alignment first block's qPos, last block's qPos + length
+  lra_pod_buf<uint32_t> runs;                              // the CIGAR runs: 0.7 GB per 32768 reads of 30 kb
+  std::vector<uint32_t> rstat, ends;                       // ends: per alignment first block's qPos, last block's qPos + length
   std::vector<uint8_t> reached;
   std::vector<uint64_t> chrom_pos;
   std::vector<std::string> segText; std::vector<uint32_t> segStart;   // print format 'a' only
-  std::string text; std::vector<uint64_t> rec_off;         // what lra_map_records_host produced last
+  lra_text_buf text; std::vector<uint64_t> rec_off;        // what lra_map_records_host produced last
 };
 
 namespace {
@@ -785,6 +787,34 @@ __global__ void k_block_ends(uint64_t nA, const uint64_t* __restrict__ boff, con
 }  // namespace
 
 extern "C" void lra_map_host_free(lra_map_host* h) { delete h; }
+
+namespace {
+std::mutex g_pool_mu;
+struct PoolBlock { void* p; size_t cap; };
+std::vector<PoolBlock> g_pool;                                           // at most POOL_KEEP blocks, the largest ones
+constexpr size_t POOL_KEEP = 6, POOL_MIN = 8u << 20;
+}  // namespace
+void* lra_host_pool_get(size_t bytes, size_t* cap) {
+  {
+    std::lock_guard<std::mutex> lk(g_pool_mu);
+    int best = -1;
+    for (int i = 0; i < (int)g_pool.size(); i++) if (g_pool[i].cap >= bytes && (best < 0 || g_pool[i].cap < g_pool[best].cap)) best = i;
+    if (best >= 0 && g_pool[best].cap <= 2 * bytes + POOL_MIN) { void* p = g_pool[best].p; *cap = g_pool[best].cap; g_pool.erase(g_pool.begin() + best); return p; }
+  }
+  *cap = bytes;
+  return malloc(bytes);
+}
+void lra_host_pool_put(void* p, size_t cap) {
+  if (!p) return;
+  if (cap >= POOL_MIN) {
+    std::lock_guard<std::mutex> lk(g_pool_mu);
+    if (g_pool.size() < POOL_KEEP) { g_pool.push_back({p, cap}); return; }
+    int smallest = 0;
+    for (int i = 1; i < (int)g_pool.size(); i++) if (g_pool[i].cap < g_pool[smallest].cap) smallest = i;
+    if (g_pool[smallest].cap < cap) { void* q = g_pool[smallest].p; g_pool[smallest] = {p, cap}; p = q; }
+  }
+  free(p);
+}
 
 // ---- the record buffer of a batch: everything the host tail needs, packed into one device buffer (what a rank sends to rank 0)
 //   int64 header[16] = {magic, n_reads, num_aln, nJ, nA, n_blocks (0 unless with_blocks), n_runs, n_chrom, has_reached, has_rstat, ...}
@@ -860,7 +890,15 @@ extern "C" int lra_map_unpack_host(const void* h_buf, uint64_t bytes, lra_map_ho
   if (hdr[9]) get(h->rstat, 3, nR);
   get(h->jo, 4, nJ ? nJ + 1 : 0);
   get(h->strand, 5, nA); get(h->supp, 6, nA); get(h->sec, 7, nA); get(h->n0, 8, nA); get(h->n1, 9, nA); get(h->chrom, 10, nA); get(h->fval, 11, nA);
-  get(h->counts, 12, 18 * nA); get(h->boff, 13, nA ? nA + 1 : 0); get(h->ends, 14, 2 * nA); get(h->roff, 15, nA ? nA + 1 : 0); get(h->runs, 16, nRuns);
+  get(h->counts, 12, 18 * nA); get(h->boff, 13, nA ? nA + 1 : 0); get(h->ends, 14, 2 * nA); get(h->roff, 15, nA ? nA + 1 : 0);
+  if (nRuns) {                                                           // the one large array: uninitialised (pooled) memory, copied by a few threads
+    if (!h->runs.alloc(nRuns)) { delete h; return LRA_ERR_NOMEM; }
+    const char* src = b + L.off[16]; char* dst = (char*)h->runs.data(); const size_t tot = nRuns * 4;
+    const int T = tot > (64u << 20) ? 16 : 1;
+    auto cp = [&](int t) { const size_t lo = tot * t / T, hi = tot * (t + 1) / T; memcpy(dst + lo, src + lo, hi - lo); };
+    if (T == 1) cp(0);
+    else { std::vector<std::thread> th; for (int t = 0; t < T; t++) th.emplace_back(cp, t); for (auto& x : th) x.join(); }
+  }
   if (nB) { h->blocks.resize(3 * nB); memcpy(h->blocks.data(), b + L.blocks_off, 3 * nB * 4); }
   *out = h;
   return LRA_OK;
@@ -904,14 +942,14 @@ extern "C" int lra_map_records_host(lra_map_host* h, const lra_map_opts* o, cons
   const int na = h->num_aln;
   const std::vector<uint64_t>& jo = h->jo; const std::vector<uint64_t>& roff = h->roff; const std::vector<uint64_t>& boff = h->boff;
   const std::vector<int32_t>&strand = h->strand, &supp = h->supp, &sec = h->sec, &n0 = h->n0, &n1 = h->n1, &chrom = h->chrom, &counts = h->counts, &blocks = h->blocks;
-  const std::vector<float>& fval = h->fval; const std::vector<uint32_t>&runs = h->runs, &rstat = h->rstat, &ends = h->ends; const std::vector<uint8_t>& reached = h->reached;
+  const std::vector<float>& fval = h->fval; const lra_pod_buf<uint32_t>& runs = h->runs; const std::vector<uint32_t>&rstat = h->rstat, &ends = h->ends; const std::vector<uint8_t>& reached = h->reached;
   const bool pairwise = o->printFormat == 'a';
   const bool hi = !o->bypassClustering;                                   // MapRead_highacc's tail (Map_highacc.h:733-789)
   if (pairwise && h->segText.size() != h->nA) return LRA_ERR_INVALID;
   // every read is independent: host threads take contiguous ranges of reads, each builds its own text; ranges are joined in read order
   const int n_reads = h->n_reads;
   unsigned hw = std::thread::hardware_concurrency();
-  int T = n_threads > 0 ? n_threads : (int)std::min<unsigned>(hw ? hw : 1u, 16u);
+  int T = n_threads > 0 ? n_threads : (int)(hw ? hw : 1u);                 // n_threads = 0: every hardware thread (a 30 kb read's record is ~43 KB of text: 1.4 GB per 32768 reads)
   T = std::max(1, std::min(T, n_reads / 32 + 1));
   if (const char* e = getenv("LRA_RECORD_THREADS")) T = std::max(1, atoi(e));
   std::vector<std::string> part(T);
@@ -1015,27 +1053,36 @@ extern "C" int lra_map_records_host(lra_map_host* h, const lra_map_opts* o, cons
     }
     prc[tix] = rc;
   };
+  const bool rdbg = getenv("LRA_RECORD_DBG") != nullptr;
+  auto wallr = []() { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+  const double tr0 = wallr();
   if (T == 1) work(0);
   else {
     std::vector<std::thread> th;
     for (int t = 0; t < T; t++) th.emplace_back(work, t);
     for (auto& x : th) x.join();
   }
+  if (rdbg) fprintf(stderr, "[records] %d threads: per-read work %.0f ms\n", T, wallr() - tr0);
   for (int t = 0; t < T; t++) if (prc[t]) return prc[t];
-  std::string& out = h->text;
-  out.clear();
-  { size_t tot = 0; for (auto& x : part) tot += x.size(); out.reserve(tot); }
+  // the ranges' texts joined in read order: every thread copies its own part to its place (the pages of the joined text are first touched by 256 threads, not one)
+  lra_text_buf& out = h->text;
+  std::vector<size_t> pstart((size_t)T + 1, 0);
+  for (int t = 0; t < T; t++) pstart[t + 1] = pstart[t] + part[t].size();
+  out.alloc(pstart[T]);
+  if (pstart[T] && !out.data()) return LRA_ERR_NOMEM;
   h->rec_off.assign((size_t)n_reads + 1, 0);
   uint64_t at = 0; size_t r = 0;
-  for (int t = 0; t < T; t++) {
-    for (uint64_t l : plen[t]) { h->rec_off[r++] = at; at += l; }
-    out += part[t];
-    std::string().swap(part[t]);
-  }
+  for (int t = 0; t < T; t++) for (uint64_t l : plen[t]) { h->rec_off[r++] = at; at += l; }
   h->rec_off[n_reads] = at;
+  {
+    auto copy = [&](int t) { if (!part[t].empty()) memcpy(out.data() + pstart[t], part[t].data(), part[t].size()); std::string().swap(part[t]); };
+    if (T == 1) copy(0);
+    else { std::vector<std::thread> th; for (int t = 0; t < T; t++) th.emplace_back(copy, t); for (auto& x : th) x.join(); }
+  }
   *len = out.size();
   if (text) *text = out.data();
   if (rec_off) *rec_off = h->rec_off.data();
+  if (rdbg) fprintf(stderr, "[records] joined at %.0f ms (%.2f GB)\n", wallr() - tr0, out.size() / 1e9);
   return LRA_OK;
 }
 
@@ -1051,7 +1098,7 @@ extern "C" int lra_map_records(lra_ctx* ctx, const lra_map_result* res, const lr
     memcpy(out, m->last_text.data(), m->last_text.size());
     *len = m->last_text.size();
     if (rec_off) memcpy(rec_off, m->last_off.data(), m->last_off.size() * 8);
-    std::string().swap(m->last_text); m->last_sig = lra_map_sig{};
+    m->last_text.clear(); m->last_sig = lra_map_sig{};
     return LRA_OK;
   }
   lra_map_host* h = nullptr;

@@ -629,7 +629,7 @@ extern "C" int lra_map_reads_highacc_batch(lra_ctx* ctx, int n_reads, const char
     return lra_set_err(ctx, LRA_ERR_INVALID, "reference not loaded (genome, global index, chromosome table)");
   if (o->bypassClustering) return lra_set_err(ctx, LRA_ERR_INVALID, "lra_map_reads_highacc_batch is the path of opts.bypassClustering == 0 (-CCS, -CONTIG)");
   out->n_reads = n_reads;
-  std::string().swap(m->last_text); m->last_sig = lra_map_sig{};
+  m->last_text.clear(); m->last_sig = lra_map_sig{};
   if (n_reads == 0) return LRA_OK;
   LRA_HIP_CHECK(ctx, hipSetDevice(ctx->device));
   hipStream_t st = ctx->stream;
