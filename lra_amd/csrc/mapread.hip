@@ -707,6 +707,7 @@ extern "C" int lra_map_reads_lowacc_batch(lra_ctx* ctx, int n_reads, const char*
   double t_split = 0, t_second = 0;
   auto start_second = [&]() -> int {
     t_split = wall();
+    if (getenv("LRA_DEFER_DROP")) { picked.clear(); return LRA_OK; }      // (experiment: the first pass without the deferred reads, nothing else running)
     second = std::thread([&, c = ctx->child]() {
       rc2 = lowacc_tail(c, in2, o, &o2);
       t_second = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count();
