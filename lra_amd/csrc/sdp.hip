@@ -30,6 +30,7 @@
 // Roofline: integer/float bookkeeping with dependent loads, HBM-nominal; algorithmic bytes = 44 B per sub-problem entry + 269 B per
 // point (visit row + coordinates).  A launch lasts as long as its largest reads: one chunk per batch, largest first.
 #include "common.h"
+#include <type_traits>
 #include "scan.h"
 #include <algorithm>
 #include <cmath>
@@ -251,9 +252,15 @@ __device__ __forceinline__ int blk_incl_scan(int v, int lane, int wave, int* s_w
   total = tot;
   return inc + pre;
 }
-template <bool EMIT, int NW>
+// LDSV (one wave per read, at most 512 points): the per-element arrays -- 28 bytes per point with 16-bit indices and 32-bit diagonals -- live in the wave's LDS.
+// From the scratch arena every level streams them through HBM again (2.6 KB per point and build: 250 GB per step, a third of the step's traffic).
+template <bool EMIT, int NW, bool LDSV = false>
 __global__ void __launch_bounds__(64 * NW, NW == 1 ? 8 : 1) sdp_build(BuildArgs a) {
   constexpr int NT = 64 * NW;
+  using IT = typename std::conditional<LDSV, uint16_t, uint32_t>::type;   // element -> node / position / line / prefix count
+  using DT = typename std::conditional<LDSV, uint32_t, long long>::type;  // a diagonal (compared for equality only: 32 bits of it identify it inside one read)
+  constexpr IT INONE = (IT)~(IT)0;
+  extern __shared__ __attribute__((aligned(16))) char dyn_lds[];
   __shared__ int s_w[4][NW == 1 ? 1 : NW];
   const int rr = (int)a.order[blockIdx.x], r = a.r0 + rr, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   auto SYNC = [&]() { if (NW == 1) wave_sync(); else __syncthreads(); };
@@ -264,15 +271,18 @@ __global__ void __launch_bounds__(64 * NW, NW == 1 ? 8 : 1) sdp_build(BuildArgs 
   const uint64_t* key3 = a.key3 + p0; const uint32_t* pay3 = a.pay3 + p0;
   uint32_t* S = a.scratch + 34 * (p0 - pc0) + 64 * (uint64_t)rr;
   const int NCAP = P + 2;
-  uint32_t* rowOf = S; uint32_t* colOf = rowOf + P;
-  uint32_t* lp = colOf + P;                 // [2][P]
-  uint32_t* ln = lp + 2 * P;                // [2][P]: [0] node index of the element, [1] temporary 2k+side
-  uint32_t* pf = ln + 2 * P;                // [P+1]
-  uint32_t* ph = pf + P + 1;                // [P+1]
-  uint32_t* tbl = ph + P + 1;               // [2][6][NCAP]
+  // the arena's layout (34 words per point); LDSV uses its node tables only
+  uint32_t* tbl = S + 8 * P + 2;            // [2][6][NCAP]
   uint32_t* tmp = tbl + 12 * NCAP;          // [8][NCAP]
-  uint32_t* ll = tmp + 8 * NCAP;            // [2][P]  line (row / column index) of the element: travels with it, no gathers per level
-  long long* ld = (long long*)(ll + 2 * P);  // [2][P]  its diagonal (word offset 30 P + 42 from S: even, so 8-byte aligned)
+  IT* eb_ = LDSV ? (IT*)dyn_lds : (IT*)S;
+  IT* rowOf = eb_; IT* colOf = rowOf + P;
+  IT* lp = colOf + P;                       // [2][P]
+  IT* ln = lp + 2 * P;                      // [2][P]: [0] node index of the element, [1] temporary 2k+side
+  IT* pf = ln + 2 * P;                      // [P+1]
+  IT* ph = pf + P + 1;                      // [P+1]
+  IT* ll = LDSV ? ph + P + 1 : (IT*)(tmp + 8 * NCAP);   // [2][P]  line (row / column index) of the element: travels with it, no gathers per level
+  DT* ld = LDSV ? (DT*)(dyn_lds + ((((size_t)(10 * P + 2) * sizeof(IT)) + 7) & ~(size_t)7)) : (DT*)(ll + 2 * P);   // [2][P]  its diagonal (arena: word offset 30 P + 42 from S: even, so 8-byte aligned)
+  auto LN = [&](int idx) -> uint32_t { const IT v = ln[idx]; return v == INONE ? NONE : (uint32_t)v; };
 #define TB(c, f, k) tbl[((c) * 6 + (f)) * NCAP + (k)]
 #define TM(f, k) tmp[(f) * NCAP + (k)]
   enum { F_LS, F_LE, F_SB, F_SE, F_EB, F_EE };
@@ -322,7 +332,7 @@ __global__ void __launch_bounds__(64 * NW, NW == 1 ? 8 : 1) sdp_build(BuildArgs 
   for (int fam = 0; fam < 4; fam++) {
     // family switches (DivideSubBy{Row1,Col1,Row2,Col2}.h): R1, C1, R2, C2
     const bool col = fam & 1, back = fam >= 2, desc = (fam == 1 || fam == 2), swapped = (fam == 3);
-    const uint32_t* lineOf = col ? colOf : rowOf;
+    const IT* lineOf = col ? colOf : rowOf;
     const int nLines = col ? C : R;
     const int sc = back ? 2 : 0;
     const int nS = cOff[sc + 1] - cOff[sc], nEn = cOff[sc + 2] - cOff[sc + 1], Pf = nS + nEn;
@@ -331,8 +341,8 @@ __global__ void __launch_bounds__(64 * NW, NW == 1 ? 8 : 1) sdp_build(BuildArgs 
     const int dSide = swapped ? 1 : 0, eSide = swapped ? 0 : 1;
     for (int i = tid; i < Pf; i += NT) {
       const uint32_t pos = pay3[cOff[sc] + i];
-      lp[i] = pos; ln[i] = 0; ll[i] = lineOf[pos];
-      ld[i] = back ? (long long)ht[pos] + hq[pos] : (long long)ht[pos] - hq[pos];
+      lp[i] = (IT)pos; ln[i] = 0; ll[i] = lineOf[pos];
+      ld[i] = (DT)(back ? (long long)ht[pos] + hq[pos] : (long long)ht[pos] - hq[pos]);
     }
     if (tid == 0) { TB(0, F_LS, 0) = 0; TB(0, F_LE, 0) = nLines; TB(0, F_SB, 0) = 0; TB(0, F_SE, 0) = nS; TB(0, F_EB, 0) = nS; TB(0, F_EE, 0) = Pf; }
     int nNodes = 1, cur = 0;
@@ -340,9 +350,9 @@ __global__ void __launch_bounds__(64 * NW, NW == 1 ? 8 : 1) sdp_build(BuildArgs 
     for (int level = 0; nNodes > 0; level++) {
       if (level >= LV) { overflow = true; break; }
       const int nxt = cur ^ 1;
-      uint32_t* lpc = lp + cur * P; uint32_t* lpn = lp + nxt * P;
-      uint32_t* llc = ll + cur * P; uint32_t* lln = ll + nxt * P;
-      long long* ldc = ld + (size_t)cur * P; long long* ldn = ld + (size_t)nxt * P;
+      IT* lpc = lp + cur * P; IT* lpn = lp + nxt * P;
+      IT* llc = ll + cur * P; IT* lln = ll + nxt * P;
+      DT* ldc = ld + (size_t)cur * P; DT* ldn = ld + (size_t)nxt * P;
       // A: which elements go to the first half of their node's lines; exclusive prefix in pf
       {
         int carry = 0;
@@ -350,36 +360,36 @@ __global__ void __launch_bounds__(64 * NW, NW == 1 ? 8 : 1) sdp_build(BuildArgs 
           const int i = i0 + tid;
           int f = 0;
           if (i < Pf) {
-            const uint32_t k = ln[i];
+            const uint32_t k = LN(i);
             if (k != NONE) {
               const uint32_t s = TB(cur, F_LS, k), e = TB(cur, F_LE, k);
               f = (e - s > 1) ? (llc[i] < ((s + e) >> 1)) : 1;
             }
           }
           int tot; const int inc = blk_incl_scan<NW>(f, lane, wave, s_w[0], tot);
-          if (i < Pf) pf[i] = carry + inc - f;
+          if (i < Pf) pf[i] = (IT)(carry + inc - f);
           carry += tot;
         }
-        if (tid == 0) pf[Pf] = carry;
+        if (tid == 0) pf[Pf] = (IT)carry;
       }
       SYNC();
       for (int k = tid; k < nNodes; k += NT) {
-        TM(T_C1S, k) = pf[TB(cur, F_SE, k)] - pf[TB(cur, F_SB, k)];
-        TM(T_C1E, k) = pf[TB(cur, F_EE, k)] - pf[TB(cur, F_EB, k)];
+        TM(T_C1S, k) = (uint32_t)pf[TB(cur, F_SE, k)] - (uint32_t)pf[TB(cur, F_SB, k)];
+        TM(T_C1E, k) = (uint32_t)pf[TB(cur, F_EE, k)] - (uint32_t)pf[TB(cur, F_EB, k)];
       }
       SYNC();
       // C: stable partition of every node's two segments
       for (int i = tid; i < Pf; i += NT) {
-        const uint32_t k = ln[i];
-        if (k == NONE) { ln[P + i] = NONE; continue; }
+        const uint32_t k = LN(i);
+        if (k == NONE) { ln[P + i] = INONE; continue; }
         const bool isS = i < nS;
         const uint32_t sb = isS ? TB(cur, F_SB, k) : TB(cur, F_EB, k);
         const uint32_t c1 = isS ? TM(T_C1S, k) : TM(T_C1E, k);
-        const uint32_t rank1 = pf[i] - pf[sb];
-        const uint32_t first = pf[i + 1] - pf[i];
+        const uint32_t rank1 = (uint32_t)pf[i] - (uint32_t)pf[sb];
+        const uint32_t first = (uint32_t)pf[i + 1] - (uint32_t)pf[i];
         const uint32_t np_ = first ? sb + rank1 : sb + c1 + ((uint32_t)i - sb - rank1);
         lpn[np_] = lpc[i]; lln[np_] = llc[i]; ldn[np_] = ldc[i];
-        ln[P + np_] = 2 * k + (first ? 0 : 1);
+        ln[P + np_] = (IT)(2 * k + (first ? 0 : 1));
       }
       SYNC();
       // D: heads of the distinct diagonals inside the D segment (ends) / E segment (starts); exclusive prefix in ph
@@ -389,7 +399,7 @@ __global__ void __launch_bounds__(64 * NW, NW == 1 ? 8 : 1) sdp_build(BuildArgs 
           const int j = j0 + tid;
           int head = 0;
           if (j < Pf) {
-            const uint32_t k2 = ln[P + j];
+            const uint32_t k2 = LN(P + j);
             if (k2 != NONE) {
               const uint32_t k = k2 >> 1, side = k2 & 1;
               const bool isS = j < nS;
@@ -406,10 +416,10 @@ __global__ void __launch_bounds__(64 * NW, NW == 1 ? 8 : 1) sdp_build(BuildArgs 
             }
           }
           int tot; const int inc = blk_incl_scan<NW>(head, lane, wave, s_w[0], tot);
-          if (j < Pf) ph[j] = carry + inc - head;
+          if (j < Pf) ph[j] = (IT)(carry + inc - head);
           carry += tot;
         }
-        if (tid == 0) ph[Pf] = carry;
+        if (tid == 0) ph[Pf] = (IT)carry;
       }
       SYNC();
       // E: per node: sizes, fullness, children, next level's table
@@ -429,7 +439,7 @@ __global__ void __launch_bounds__(64 * NW, NW == 1 ? 8 : 1) sdp_build(BuildArgs 
             dB = dSide == 0 ? eb : eb + c1E; dE = dSide == 0 ? eb + c1E : ee;
             eB = eSide == 0 ? sb : sb + c1S; eE = eSide == 0 ? sb + c1S : se;
           }
-          nD = ph[dE] - ph[dB]; nE = ph[eE] - ph[eB];
+          nD = (uint32_t)ph[dE] - (uint32_t)ph[dB]; nE = (uint32_t)ph[eE] - (uint32_t)ph[eB];
           full = nD > 0 && nE > 0;
           if (!leaf) {                                                   // DivideSubProbBy*: which halves are explored
             const bool goD = nD > 0, goE = nE > 0;                       // both empty: none; only Di: D half; only Ei: E half; else both
@@ -462,11 +472,11 @@ __global__ void __launch_bounds__(64 * NW, NW == 1 ? 8 : 1) sdp_build(BuildArgs 
       SYNC();
       // F: node index of every element for the next level; emit Di / Ei and the visit records
       for (int j = tid; j < Pf; j += NT) {
-        const uint32_t k2 = ln[P + j];
-        if (k2 == NONE) { ln[j] = NONE; continue; }
+        const uint32_t k2 = LN(P + j);
+        if (k2 == NONE) { ln[j] = INONE; continue; }
         const uint32_t k = k2 >> 1, side = k2 & 1;
         const bool leaf = TB(cur, F_LE, k) - TB(cur, F_LS, k) == 1;
-        ln[j] = leaf ? NONE : (side == 0 ? TM(T_CH0, k) : TM(T_CH1, k));
+        ln[j] = (IT)(leaf ? NONE : (side == 0 ? TM(T_CH0, k) : TM(T_CH1, k)));
         {
           const uint32_t gid = TM(T_GID, k);
           const bool isS = j < nS;
@@ -476,13 +486,13 @@ __global__ void __launch_bounds__(64 * NW, NW == 1 ? 8 : 1) sdp_build(BuildArgs 
             else {
               uint32_t beg = isS ? TB(cur, F_SB, k) : TB(cur, F_EB, k);
               if (!leaf && side == 1) beg += isS ? TM(T_C1S, k) : TM(T_C1E, k);
-              const uint32_t head = ph[j + 1] - ph[j];
-              const uint32_t grp = ph[j] - ph[beg] + head - 1;
+              const uint32_t head = (uint32_t)ph[j + 1] - (uint32_t)ph[j];
+              const uint32_t grp = (uint32_t)ph[j] - (uint32_t)ph[beg] + head - 1;
               const uint32_t n = isS ? TM(T_NE, k) : TM(T_ND, k);
               const uint32_t idx = desc ? n - 1 - grp : grp;
               const uint32_t ent = TM(T_BASE, k) + (isS ? TM(T_ND, k) + idx : idx);
               const uint32_t pos = lpn[j];
-              if (head) entR[ent].val = ldn[j];
+              if (head) entR[ent].val = back ? (long long)ht[pos] + hq[pos] : (long long)ht[pos] - hq[pos];   // (the element's diagonal, from its point: ldn may hold 32 bits of it)
               visR[(uint64_t)pos * (2 * LV) + fam2 * LV + level] = make_uint2(gid, idx);
             }
           }
@@ -492,7 +502,7 @@ __global__ void __launch_bounds__(64 * NW, NW == 1 ? 8 : 1) sdp_build(BuildArgs 
       // G: Db / Eb in closed form (Decide_Eb_Db_*), values and back pointers zeroed
       if (EMIT) {
         for (int j = tid; j < Pf; j += NT) {
-          const uint32_t k2 = ln[P + j];
+          const uint32_t k2 = LN(P + j);
           if (k2 == NONE) continue;
           const uint32_t k = k2 >> 1, side = k2 & 1;
           const uint32_t gid = TM(T_GID, k);
@@ -503,7 +513,7 @@ __global__ void __launch_bounds__(64 * NW, NW == 1 ? 8 : 1) sdp_build(BuildArgs 
           uint32_t beg = isS ? TB(cur, F_SB, k) : TB(cur, F_EB, k);
           if (!leaf && side == 1) beg += isS ? TM(T_C1S, k) : TM(T_C1E, k);
           const uint32_t nD = TM(T_ND, k), nE = TM(T_NE, k), base = TM(T_BASE, k);
-          const uint32_t grp = ph[j] - ph[beg];
+          const uint32_t grp = (uint32_t)ph[j] - (uint32_t)ph[beg];
           const uint32_t n = isS ? nE : nD;
           const uint32_t idx = desc ? n - 1 - grp : grp;
           const uint32_t ent = base + (isS ? nD + idx : idx);
@@ -1394,6 +1404,28 @@ __global__ void __launch_bounds__(64) sdp_trace(TraceArgs a) {
 inline size_t sz(size_t n, size_t elem) { return (n * elem + 255) / 256 * 256; }
 
 // Box mode (d_qe != null): clusters are the fragments; d_c_start / d_c_count are null, d_q/d_t/d_qe/d_te/d_len(=Val)/d_c_strand are per box.
+// The one-wave-per-read builds of a launch: reads [from, to) of `order` (largest first).  Those of at most 512 points keep their element arrays in LDS
+// (three sizes of LDS request, so that small reads do not pay for large ones' occupancy); the rest work from the scratch arena.
+template <bool EMIT>
+static void launch_small_builds(lra_ctx* ctx, const BuildArgs& ba, const uint32_t* d_order, const std::vector<uint32_t>& h_order, const uint64_t* h_pt, int from, int to) {
+  static const bool noLds = getenv("LRA_SDP_BUILD_NOLDS") != nullptr;
+  hipStream_t st = ctx->stream;
+  auto pts = [&](int i) { return (long)(h_pt[h_order[i] + 1] - h_pt[h_order[i]]); };
+  int at = from;
+  // (measured: at 28 KB -- up to 1024 points -- five waves per CU are slower from LDS than 32 from the arena; up to 768 points is a wash)
+  const long caps[3] = {512, 256, 128};
+  int cut[4];                                                            // [from, cut0): arena;  [cut0, cut1): <= 512;  [cut1, cut2): <= 256;  [cut2, to): <= 128
+  for (int c = 0; c < 3; c++) { while (at < to && (noLds || pts(at) > caps[c])) at++; cut[c] = at; }
+  cut[3] = to;
+  if (cut[0] > from) { BuildArgs bb = ba; bb.order = d_order + from; hipLaunchKernelGGL((sdp_build<EMIT, 1, false>), dim3(cut[0] - from), dim3(64), 0, st, bb); }
+  for (int c = 0; c < 3; c++) {
+    const int n = cut[c + 1] - cut[c];
+    if (n <= 0) continue;
+    BuildArgs bb = ba; bb.order = d_order + cut[c];
+    hipLaunchKernelGGL((sdp_build<EMIT, 1, true>), dim3(n), dim3(64), (size_t)(28 * caps[c] + 32), st, bb);
+  }
+}
+
 int sdp_run(lra_ctx* ctx, int n_reads, const uint64_t* d_cluster_off, const uint64_t* d_c_start, const uint32_t* d_c_count,
             const int32_t* d_c_strand, const uint32_t* d_q, const uint32_t* d_t, const int32_t* d_len, const uint64_t* d_read_off,
             const float* d_rate, const lra_sdp_opts* opts, lra_chain_result* out, const uint32_t* d_qe, const uint32_t* d_te,
@@ -1567,7 +1599,7 @@ int sdp_run(lra_ctx* ctx, int n_reads, const uint64_t* d_cluster_off, const uint
       while (nb0 < nr && (long)(h_pt[r0 + h_orderAll[nb0] + 1] - h_pt[r0 + h_orderAll[nb0]]) >= big_pts) nb0++;
       const bool forked = nb0 > 0 && nr > nb0;
       if (nb0 > 0) hipLaunchKernelGGL((sdp_build<false, 16>), dim3(nb0), dim3(1024), 0, forked ? lra_side_fork(ctx) : st, ba);
-      if (nr > nb0) { BuildArgs bb = ba; bb.order = order + nb0; hipLaunchKernelGGL((sdp_build<false, 1>), dim3(nr - nb0), dim3(64), 0, st, bb); }
+      if (nr > nb0) launch_small_builds<false>(ctx, ba, order, h_orderAll, h_pt.data() + r0, nb0, nr);
       if (forked) lra_side_join(ctx);
     }
     lra_time_end(ctx);
@@ -1602,7 +1634,7 @@ int sdp_run(lra_ctx* ctx, int n_reads, const uint64_t* d_cluster_off, const uint
       {
         const bool forked = nbig > 0 && nsub > nbig;
         if (nbig > 0) hipLaunchKernelGGL((sdp_build<true, 16>), dim3(nbig), dim3(1024), 0, forked ? lra_side_fork(ctx) : st, ba);
-        if (nsub > nbig) { BuildArgs bb = ba; bb.order = subOrder + nbig; hipLaunchKernelGGL((sdp_build<true, 1>), dim3(nsub - nbig), dim3(64), 0, st, bb); }
+        if (nsub > nbig) launch_small_builds<true>(ctx, ba, subOrder, att == 0 ? h_orderAll : h_prev, h_pt.data() + r0, nbig, nsub);
         if (forked) lra_side_join(ctx);
       }
       lra_time_end(ctx);
