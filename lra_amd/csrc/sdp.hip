@@ -254,11 +254,13 @@ __device__ __forceinline__ int blk_incl_scan(int v, int lane, int wave, int* s_w
 }
 // LDSV (one wave per read, at most 512 points): the per-element arrays -- 28 bytes per point with 16-bit indices and 32-bit diagonals -- live in the wave's LDS.
 // From the scratch arena every level streams them through HBM again (2.6 KB per point and build: 250 GB per step, a third of the step's traffic).
-template <bool EMIT, int NW, bool LDSV = false>
+// MODE 2: the same narrow arrays in the arena (reads of 513 .. 16383 points: half the bytes per level, no LDS to run out of).  MODE 0: 32-bit indices, 64-bit diagonals.
+template <bool EMIT, int NW, int MODE = 0>
 __global__ void __launch_bounds__(64 * NW, NW == 1 ? 8 : 1) sdp_build(BuildArgs a) {
   constexpr int NT = 64 * NW;
-  using IT = typename std::conditional<LDSV, uint16_t, uint32_t>::type;   // element -> node / position / line / prefix count
-  using DT = typename std::conditional<LDSV, uint32_t, long long>::type;  // a diagonal (compared for equality only: 32 bits of it identify it inside one read)
+  constexpr bool LDSV = MODE == 1, NARROW = MODE != 0;
+  using IT = typename std::conditional<NARROW, uint16_t, uint32_t>::type; // element -> node / position / line / prefix count
+  using DT = typename std::conditional<NARROW, uint32_t, long long>::type; // a diagonal (compared for equality only: 32 bits of it identify it inside one read)
   constexpr IT INONE = (IT)~(IT)0;
   extern __shared__ __attribute__((aligned(16))) char dyn_lds[];
   __shared__ int s_w[4][NW == 1 ? 1 : NW];
@@ -280,8 +282,9 @@ __global__ void __launch_bounds__(64 * NW, NW == 1 ? 8 : 1) sdp_build(BuildArgs 
   IT* ln = lp + 2 * P;                      // [2][P]: [0] node index of the element, [1] temporary 2k+side
   IT* pf = ln + 2 * P;                      // [P+1]
   IT* ph = pf + P + 1;                      // [P+1]
-  IT* ll = LDSV ? ph + P + 1 : (IT*)(tmp + 8 * NCAP);   // [2][P]  line (row / column index) of the element: travels with it, no gathers per level
-  DT* ld = LDSV ? (DT*)(dyn_lds + ((((size_t)(10 * P + 2) * sizeof(IT)) + 7) & ~(size_t)7)) : (DT*)(ll + 2 * P);   // [2][P]  its diagonal (arena: word offset 30 P + 42 from S: even, so 8-byte aligned)
+  // MODE 0: ll and ld behind the tables (word offset 30 P + 42 from S: even, so ld is 8-byte aligned); narrow: ll behind ph, ld behind the tables / behind ll in LDS
+  IT* ll = NARROW ? ph + P + 1 : (IT*)(tmp + 8 * NCAP);   // [2][P]  line (row / column index) of the element: travels with it, no gathers per level
+  DT* ld = LDSV ? (DT*)(dyn_lds + ((((size_t)(10 * P + 2) * sizeof(IT)) + 7) & ~(size_t)7)) : NARROW ? (DT*)(tmp + 8 * NCAP) : (DT*)(ll + 2 * P);   // [2][P]  its diagonal
   auto LN = [&](int idx) -> uint32_t { const IT v = ln[idx]; return v == INONE ? NONE : (uint32_t)v; };
 #define TB(c, f, k) tbl[((c) * 6 + (f)) * NCAP + (k)]
 #define TM(f, k) tmp[(f) * NCAP + (k)]
@@ -1417,12 +1420,17 @@ static void launch_small_builds(lra_ctx* ctx, const BuildArgs& ba, const uint32_
   int cut[4];                                                            // [from, cut0): arena;  [cut0, cut1): <= 512;  [cut1, cut2): <= 256;  [cut2, to): <= 128
   for (int c = 0; c < 3; c++) { while (at < to && (noLds || pts(at) > caps[c])) at++; cut[c] = at; }
   cut[3] = to;
-  if (cut[0] > from) { BuildArgs bb = ba; bb.order = d_order + from; hipLaunchKernelGGL((sdp_build<EMIT, 1, false>), dim3(cut[0] - from), dim3(64), 0, st, bb); }
+  if (cut[0] > from) {                                                   // arena: 16-bit indices below 16384 points (2 x node index + side must fit)
+    int mid = from;
+    while (mid < cut[0] && pts(mid) >= 16384) mid++;
+    if (mid > from) { BuildArgs bb = ba; bb.order = d_order + from; hipLaunchKernelGGL((sdp_build<EMIT, 1, 0>), dim3(mid - from), dim3(64), 0, st, bb); }
+    if (cut[0] > mid) { BuildArgs bb = ba; bb.order = d_order + mid; hipLaunchKernelGGL((sdp_build<EMIT, 1, 2>), dim3(cut[0] - mid), dim3(64), 0, st, bb); }
+  }
   for (int c = 0; c < 3; c++) {
     const int n = cut[c + 1] - cut[c];
     if (n <= 0) continue;
     BuildArgs bb = ba; bb.order = d_order + cut[c];
-    hipLaunchKernelGGL((sdp_build<EMIT, 1, true>), dim3(n), dim3(64), (size_t)(28 * caps[c] + 32), st, bb);
+    hipLaunchKernelGGL((sdp_build<EMIT, 1, 1>), dim3(n), dim3(64), (size_t)(28 * caps[c] + 32), st, bb);
   }
 }
 
