@@ -267,14 +267,17 @@ __global__ void __launch_bounds__(STAGE_NT) local_sort_filter(uint64_t n_win, ui
   }
 }
 
+// the surviving tuples of every window, packed: a wave takes 64 windows, one after the other, its lanes side by side (coalesced both ways)
 __global__ void __launch_bounds__(64) local_compact(uint64_t n_win, uint64_t stride, const uint32_t* __restrict__ raw,
                                                     const uint64_t* __restrict__ bnd, uint32_t* __restrict__ out) {
-  const uint64_t wi = (uint64_t)blockIdx.x * 64 + threadIdx.x;
-  if (wi >= n_win) return;
-  const uint32_t* s = raw + wi * stride;
-  uint32_t* d = out + bnd[wi];
-  const long n = (long)(bnd[wi + 1] - bnd[wi]);
-  for (long x = 0; x < n; x++) d[x] = s[x];
+  const int lane = threadIdx.x;
+  const uint64_t w0 = (uint64_t)blockIdx.x * 64;
+  const uint64_t mine = w0 + lane < n_win ? bnd[w0 + lane] : 0, mineEnd = w0 + lane < n_win ? bnd[w0 + lane + 1] : 0;
+  for (int x = 0; x < 64 && w0 + x < n_win; x++) {
+    const uint64_t d0 = __shfl(mine, x), n = __shfl(mineEnd, x) - d0;
+    const uint32_t* s = raw + (w0 + x) * stride;
+    for (uint64_t i = lane; i < n; i += 64) out[d0 + i] = s[i];
+  }
 }
 
 // ---- CompareLists<LocalTuple,SmallTuple>, one lane per task
