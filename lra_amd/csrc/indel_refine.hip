@@ -669,6 +669,118 @@ __global__ void __launch_bounds__(64) ir_fill_wide(FillArgs F) {
 }
 
 // ---------------------------------------------------------------------------------- trace
+// Segments whose widest row has 17 .. 32 cells, on 16 lanes (four segments per wave instead of two): a read's rows are 15 cells wide (2 refineBand + 1) except around
+// its indels, so with 32 lanes per segment half of them idle on almost every row.  A row of more than 16 cells is done in two pieces of 16, the second one taking over
+// the first's running prefix maximum and its last cell's V / M (what the shifts by one cell read); the previous row's M and D are two registers per lane.
+__global__ void __launch_bounds__(64) ir_fill_16x2(FillArgs F) {
+  constexpr int G = 16;
+  const int lane = threadIdx.x;
+  const int c = lane % G, gbase = lane - c;
+  const int g = F.g, go = 2 * F.g + 1;
+  const long listEnd = F.cursor[4 + 1];
+  const uint32_t* list = F.list;
+  long ti = -1, tLen = 0;
+  const Row* rows = nullptr; const unsigned char* qb = nullptr; unsigned char* P = nullptr;
+  long chunkBase = 0, qLast = 0;
+  Row chunk; chunk.S = chunk.E = chunk.T = 0; chunk.C = 0;
+  int W0 = 0, q0 = 0, q1 = 0, q2 = 0, q3 = 0;                               // query bases W0 + c, + 16, + 32, + 48
+  int pM[2] = {BAD, BAD}, pD[2] = {BAD, BAD}, prevS = 0, prevLen = 0;
+  bool done = false;
+  auto ldq = [&](long idx) -> int { return qb[idx < qLast ? idx : qLast]; };
+  while (true) {
+    if (!done && ti < 0) {
+      long x = 0;
+      if (c == 0) x = atomicAdd(&F.cursor[1], 1);
+      x = __shfl(x, gbase);
+      if (x < listEnd) {
+        const uint64_t s = list[x];
+        const int a = F.s_aln[s];
+        tLen = (long)F.s_rows[s];
+        rows = F.rows + F.s_row_off[s];
+        qb = (const unsigned char*)F.qseq + F.q_off[a];
+        qLast = (long)F.q_len[a] - 1;
+        P = F.path + F.s_cell_off[s];
+        ti = 0; chunkBase = 0;
+        if (c < tLen) chunk = rows[c];
+        W0 = rows[0].S;
+        q0 = ldq((long)W0 + c); q1 = ldq((long)W0 + G + c); q2 = ldq((long)W0 + 2 * G + c); q3 = ldq((long)W0 + 3 * G + c);
+      } else done = true;
+    }
+    if (__ballot(!done) == 0ULL) break;
+    if (!done && ti - chunkBase == G) { chunkBase = ti; if (ti + c < tLen) chunk = rows[ti + c]; }
+    const int src = gbase + (int)((ti - chunkBase) & (G - 1));
+    const int S = __shfl(chunk.S, src), E = __shfl(chunk.E, src), tch = __shfl(chunk.T, src);
+    const unsigned int C = __shfl(chunk.C, src);
+    while (!done && S - W0 >= G) { W0 += G; q0 = q1; q1 = q2; q2 = q3; q3 = ldq((long)W0 + 3 * G + c); }
+    const int len = E - S + 1;
+    const bool lastRow = (ti == tLen - 1);
+    const int off = S - prevS;
+    int nM[2] = {BAD, BAD}, nD[2] = {BAD, BAD};
+    int carryW = NEG, carryV = NEG, carryM = BAD;
+    const int np = (!done && len > G) ? 2 : 1;
+    for (int p = 0; p < np; p++) {
+      const int cc = c + G * p;
+      // the query base of cell cc: position S + cc = W0 + j, j in [0, 4 G)
+      const int j = S - W0 + cc;
+      const int l = gbase + (j & (G - 1));
+      const int qa = __shfl(q0, l), qbb = __shfl(q1, l), qc = __shfl(q2, l), qd = __shfl(q3, l);
+      const int qch = (j < G) ? qa : (j < 2 * G) ? qbb : (j < 3 * G) ? qc : qd;
+      const bool interior = cc >= 1 && (lastRow ? cc <= len - 1 : cc <= len - 2);
+      const int srcA = cc + off, srcD = srcA - 1;
+      const bool aboveIn = srcA <= prevLen - 1;                            // qE[ti-1] >= q   (:491,:548,:567)
+      // the previous row's cells srcA and srcA - 1 (pieces 0 / 1 of it)
+      const int la = gbase + (srcA & (G - 1)), ld = gbase + (srcD & (G - 1));
+      const int a0 = __shfl(pM[0], la), a1 = __shfl(pM[1], la), b0 = __shfl(pD[0], la), b1 = __shfl(pD[1], la);
+      const int d0 = __shfl(pM[0], ld), d1 = __shfl(pM[1], ld);
+      const int aM = (srcA & G) ? a1 : a0, aD = (srcA & G) ? b1 : b0;
+      const int dM = (srcD & G) ? d1 : d0;
+      const bool okA = aboveIn && !is_bound(ti - 1, srcA, prevLen);
+      const bool okD = aboveIn && srcD >= 0 && !is_bound(ti - 1, srcD, prevLen);
+      const int dOpen = okA ? aM + go : BAD, dExt = okA ? aD : BAD;        // :491-502 (gapExtend = 0)
+      const int Dv = max(dOpen, dExt);
+      const int delOpen = (Dv == dOpen) ? 1 : 0;                           // :504-516
+      const int mS = okD ? dM + (tch == qch ? F.match : F.mismatch) : BAD; // :548-563
+      const int dS = okA ? aM + g : BAD;                                   // :567-574
+      const int V = interior ? max(mS, max(dS, Dv)) : NEG;
+      const int W = max(scan_max<G>(V), carryW);                           // inclusive prefix max of V over the row so far
+      int Wm1 = shr1(W, NEG), Vm1 = shr1(V, NEG);
+      if (c == 0) { Wm1 = carryW; Vm1 = carryV; }                          // (piece 0: NEG, NEG)
+      const int Iv = max(BAD, go + Wm1);
+      int M = max(max(BAD, V), max(Vm1 + g, go + Wm1));
+      if (!interior) M = BAD;
+      int Mleft = shr1(M, BAD);
+      if (c == 0) Mleft = carryM;
+      if (cc <= 1) Mleft = BAD;                                            // the row's left boundary cell (:413-418)
+      const int iOpen = Mleft + go;                                        // :523
+      const int insOpen = (Iv == iOpen) ? 1 : 0;                           // :528-540
+      const int iS = Mleft + g;                                            // :565
+      int code;
+      if (!interior) code = C_BOUND;
+      else if (M == mS) code = C_DIAG;                                     // :583-616
+      else if (M == iS) code = C_LEFT;
+      else if (M == dS) code = C_DOWN;
+      else if (M == Dv) code = C_DELCLOSE;
+      else code = C_INSCLOSE;
+      int outM = M, outD = interior ? Dv : BAD;
+      unsigned char outB = (unsigned char)(code | (delOpen << 3) | (insOpen << 4));
+      if (ti == 0) {                                                       // :407-431 first row
+        const bool last0 = (cc == len - 1) && (tLen > 1);
+        outM = last0 ? BAD : (cc == 0 ? 0 : cc * g);
+        outD = BAD;
+        outB = (unsigned char)(last0 ? C_BOUND : (cc == 0 ? C_DONE : C_LEFT));
+      }
+      if (!done && cc < len) P[C + cc] = outB;
+      nM[p] = outM; nD[p] = outD;
+      carryW = __shfl(W, gbase + G - 1); carryV = __shfl(V, gbase + G - 1); carryM = __shfl(M, gbase + G - 1);
+    }
+    if (!done) {
+      pM[0] = nM[0]; pM[1] = nM[1]; pD[0] = nD[0]; pD[1] = nD[1]; prevS = S; prevLen = len;
+      ti++;
+      if (ti == tLen) ti = -1;
+    }
+  }
+}
+
 struct TraceArgs {
   uint64_t n_seg;
   const int32_t* s_kind; const int32_t* s_tStart; const uint64_t* s_rows; const uint64_t* s_row_off;
@@ -1075,11 +1187,17 @@ extern "C" int lra_indel_refine_batch(lra_ctx* ctx, int n_aln, const int32_t* d_
     }
     lra_time_begin(ctx, "ir_fill");
     const uint64_t n16 = (uint64_t)(h_cursor[4] - h_cursor[0]), n32 = (uint64_t)(h_cursor[5] - h_cursor[1]), n64 = (uint64_t)(h_cursor[6] - h_cursor[2]);
-    if (n16) hipLaunchKernelGGL(ir_fill<16>, dim3((unsigned)std::min<uint64_t>((n16 + 3) / 4, cap_grid)), dim3(64), 0, st, F);
-    if (n32) hipLaunchKernelGGL(ir_fill<32>, dim3((unsigned)std::min<uint64_t>((n32 + 1) / 2, cap_grid)), dim3(64), 0, st, F);
-    if (n64) hipLaunchKernelGGL(ir_fill<64>, dim3((unsigned)std::min<uint64_t>(n64, cap_grid)), dim3(64), 0, st, F);
+    // a kernel's time is its longest segment's row chain, whatever the class: the classes side by side (the widest class of segments, usually the bulk, on the context's stream)
+    static const bool no16x2 = getenv("LRA_IR_NO16X2") != nullptr;
     const uint64_t nWide = (uint64_t)(h_cursor[7] - h_cursor[3]);
-    if (nWide) hipLaunchKernelGGL(ir_fill_wide, dim3((unsigned)std::min<uint64_t>(nWide, cap_grid)), dim3(64), 0, st, F);
+    if (n16) hipLaunchKernelGGL(ir_fill<16>, dim3((unsigned)std::min<uint64_t>((n16 + 3) / 4, cap_grid)), dim3(64), 0, lra_side_fork(ctx, 1), F);
+    if (n64) hipLaunchKernelGGL(ir_fill<64>, dim3((unsigned)std::min<uint64_t>(n64, cap_grid)), dim3(64), 0, lra_side_fork(ctx, 2), F);
+    if (nWide) hipLaunchKernelGGL(ir_fill_wide, dim3((unsigned)std::min<uint64_t>(nWide, cap_grid)), dim3(64), 0, lra_side_fork(ctx, 3), F);
+    if (n32 && no16x2) hipLaunchKernelGGL(ir_fill<32>, dim3((unsigned)std::min<uint64_t>((n32 + 1) / 2, cap_grid)), dim3(64), 0, st, F);
+    if (n32 && !no16x2) hipLaunchKernelGGL(ir_fill_16x2, dim3((unsigned)std::min<uint64_t>((n32 + 3) / 4, cap_grid)), dim3(64), 0, st, F);
+    if (n16) lra_side_join(ctx, 1);
+    if (n64) lra_side_join(ctx, 2);
+    if (nWide) lra_side_join(ctx, 3);
     lra_time_end(ctx);
     TraceArgs T;
     T.n_seg = n_seg; T.s_kind = A.s_kind; T.s_tStart = A.s_tStart; T.s_rows = A.s_rows; T.s_row_off = s_row_off;
