@@ -798,10 +798,10 @@ struct TraceArgs {
 // block; seen back to front every gap run closes the block whose (possibly empty) diag run precedes
 // it, and a trailing diag run is a block of its own.
 // The walk (:629-674) is a chain of dependent one-byte loads, a row apart each, ~27 k of them for a 30 kb read: one lane per segment walks at HBM latency.  Here a WAVE
-// owns a segment: the rows' descriptors and path bytes of a window of rows (as many as fit 8 KB of path, at most 256) are staged into LDS with coalesced loads,
+// owns a segment: the rows' descriptors and path bytes of a window of rows (as many as fit 4 KB of path, at most 128: more waves per CU hide more of the walk's LDS latency than longer windows save in refills) are staged into LDS with coalesced loads,
 // and while the walk is in the match state the 64 lanes look at the next 64 cells down the current diagonal at once -- a run of diagonal arrows (the common case: a
 // 10 % error read has an indel every ~14 bases) is one round.  Everything else -- the gap states, left / down arrows, the end tests -- is the reference's step, from LDS.
-constexpr int TW_ROWS = 256, TW_PATH = 8192;
+constexpr int TW_ROWS = 128, TW_PATH = 4096;
 __global__ void __launch_bounds__(64) ir_trace_wave(TraceArgs T) {
   __shared__ Row s_rows[TW_ROWS];
   __shared__ __attribute__((aligned(16))) unsigned char s_path[TW_PATH + 16];
