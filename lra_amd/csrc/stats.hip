@@ -9,6 +9,8 @@
 // identically; the log table is the caller's, i.e. the host libm's logf, LogLookUpTable.h:9-15).
 #include "common.h"
 #include "scan.h"
+#include <algorithm>
+#include <stdlib.h>
 
 namespace {
 
@@ -35,10 +37,16 @@ struct StatArgs {
 // term, :462/:491) has been added the float `value` is an exact integer, so those contributions can
 // be summed in any order (ival) -- whole 64-column chunks at a time.  From the first long gap on
 // every run is applied to the float in the reference's order.
+// GW lanes per alignment (64 / GW alignments per wave): a noisy read's blocks are ~16 columns, so a whole wave per alignment leaves three quarters of its lanes idle
+// on almost every block, and the kernel's time is (alignments / resident groups) x one alignment's chain of ~1800 dependent block steps.
+template <int GW>
 __global__ void __launch_bounds__(64) stats_kernel(StatArgs A) {
-  const int lane = threadIdx.x;
+  const int lane = threadIdx.x & (GW - 1), gbase = threadIdx.x - lane;      // lane: inside the alignment's group
   const unsigned long long below = (lane == 0) ? 0ULL : (~0ULL >> (64 - lane));
-  for (int a = blockIdx.x; a < A.n_aln; a += gridDim.x) {
+  const unsigned long long gmask = ~0ULL >> (64 - GW);
+  auto BAL = [&](bool x) -> unsigned long long { return (__ballot(x) >> gbase) & gmask; };
+  constexpr int GPW = 64 / GW;
+  for (int a = blockIdx.x * GPW + (int)threadIdx.x / GW; a < A.n_aln; a += gridDim.x * GPW) {
     const long nb = (long)(A.block_off[a + 1] - A.block_off[a]);
     const int32_t* B = A.blocks + 3 * A.block_off[a];
     const unsigned char* R = A.qseq + A.q_off[a];
@@ -87,15 +95,15 @@ __global__ void __launch_bounds__(64) stats_kernel(StatArgs A) {
     // the first 64 columns of the next block are fetched while the current block is worked on (blocks are ~16 bp on noisy reads, so
     // without this every block costs a full dependent-load latency)
     auto pairs = [&](long q, long t, long len, bool usePre, unsigned long long pm) {   // aligned pairs: '=' / 'X' by base code
-      for (long off = 0; off < len; off += 64) {
-        const int cnt = (int)min(64L, len - off);
-        const unsigned long long valid = cnt == 64 ? ~0ULL : ((1ULL << cnt) - 1);
+      for (long off = 0; off < len; off += GW) {
+        const int cnt = (int)min((long)GW, len - off);
+        const unsigned long long valid = cnt >= 64 ? ~0ULL : ((1ULL << cnt) - 1);
         unsigned long long mx;
         if (off == 0 && usePre) mx = pm & valid;
         else {
           bool x = false;
           if (lane < cnt) x = code2(R[q + off + lane]) != code2(G[t + off + lane]);
-          mx = __ballot(x) & valid;
+          mx = BAL(x) & valid;
         }
         // run starts inside the chunk: column c > 0 whose kind differs from column c-1
         const unsigned long long starts = ((mx ^ (mx << 1)) & valid) & ~1ULL;
@@ -134,21 +142,21 @@ __global__ void __launch_bounds__(64) stats_kernel(StatArgs A) {
       // block table: 64 blocks per load, handed out by shuffles.  Each lane also compares the first 64 columns of its block, so the
       // per-block loop below touches no memory for blocks of up to 64 columns (a noisy read's blocks are ~16 bp: one dependent HBM
       // round trip per block otherwise)
-      int tq = 0, tt = 0, tl = 0; unsigned long long tm = 0; long tbase = -64;
+      int tq = 0, tt = 0, tl = 0; unsigned long long tm = 0; long tbase = -GW;
       auto blk = [&](long b, int& bq, int& bt, int& bl, unsigned long long& bm) {
-        if (b >= tbase + 64 || b < tbase) {
+        if (b >= tbase + GW || b < tbase) {
           tbase = b;
           const long i = b + lane;
           tm = 0;
           if (i < nb) {
             tq = B[3 * i]; tt = B[3 * i + 1]; tl = B[3 * i + 2];
-            const int c1 = min(tl, 64);
+            const int c1 = min(tl, GW);
             const unsigned char* rp = R + tq; const unsigned char* gp = G + tt;
 #pragma unroll 8
             for (int c = 0; c < c1; c++) tm |= (unsigned long long)(code2(rp[c]) != code2(gp[c])) << c;
           }
         }
-        const int k = (int)(b - tbase);
+        const int k = gbase + (int)(b - tbase);
         bq = __shfl(tq, k); bt = __shfl(tt, k); bl = __shfl(tl, k); bm = __shfl(tm, k);
       };
       int cq, ct, cl; unsigned long long cm;
@@ -241,8 +249,11 @@ extern "C" int lra_calculate_statistics_batch(lra_ctx* ctx, int n_aln, const int
   if (!tmp) return LRA_ERR_NOMEM;
   A.runs = tmp;
   const int grid = n_aln < ctx->num_cu * 32 ? n_aln : ctx->num_cu * 32;
+  static const int statGw = getenv("LRA_STATS_GW") ? atoi(getenv("LRA_STATS_GW")) : 16;
   lra_time_begin(ctx, "stats");
-  hipLaunchKernelGGL(stats_kernel, dim3(grid), dim3(64), 0, st, A);
+  if (statGw == 64) hipLaunchKernelGGL(stats_kernel<64>, dim3(grid), dim3(64), 0, st, A);
+  else if (statGw == 32) hipLaunchKernelGGL(stats_kernel<32>, dim3(std::min((n_aln + 1) / 2, ctx->num_cu * 32)), dim3(64), 0, st, A);
+  else hipLaunchKernelGGL(stats_kernel<16>, dim3(std::min((n_aln + 3) / 4, ctx->num_cu * 32)), dim3(64), 0, st, A);
   lra_time_end(ctx);
   if (lra_exclusive_scan<uint32_t>(ctx, (long)n_aln, A.n_runs, run_off)) return LRA_ERR_HIP;
   uint64_t total = 0;
