@@ -289,22 +289,31 @@ struct CmpArgs {
   const uint64_t* out_off; uint32_t* out_qi; uint32_t* out_ti; uint32_t* counts;
 };
 
-constexpr int QCAP = 96, TCAP = 160, CSTRIDE = QCAP + TCAP + 1;   // lane-private LDS row: query list then target list
+// A block's 64 tasks share CMP_WORDS words of LDS, each task's query list then its target list packed behind the previous task's (a task of more than CMP_TASK_MAX words,
+// or one that no longer fits, is walked in HBM): a typical task has ~180 words, so 40 KB hold a block and four blocks fit a CU (fixed 257-word rows: two).
+constexpr int CMP_WORDS = 10240, CMP_TASK_MAX = 512;
 template <bool EMIT>
 __global__ void __launch_bounds__(STAGE_NT) local_compare(CmpArgs A) {
-  __shared__ uint32_t stage[64 * CSTRIDE];
+  __shared__ uint32_t stage[CMP_WORDS];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const uint64_t x0 = (uint64_t)blockIdx.x * 64;
   const uint64_t xl = x0 + lane;
   const bool live = xl < A.n_tasks;
   const uint64_t myQa = live ? A.q_lo[xl] : 0, myTa = live ? A.t_lo[xl] : 0;
   const uint64_t myQn = live ? A.q_hi[xl] - myQa : 0, myTn = live ? A.t_hi[xl] - myTa : 0;
+  // where task `lane`'s lists sit in the block's LDS (every wave computes the same prefix)
+  const uint32_t need = (myQn + myTn <= (uint64_t)CMP_TASK_MAX) ? (uint32_t)(myQn + myTn) : 0u;
+  uint32_t incl = need;
+  for (int d = 1; d < 64; d <<= 1) { const uint32_t o = __shfl_up(incl, d); if (lane >= d) incl += o; }
+  const uint32_t myOff = incl - need;
+  const bool myFits = need > 0 && incl <= (uint32_t)CMP_WORDS;
 #pragma unroll 4
   for (int i = wave; i < 64; i += STAGE_NT / 64) {                       // coalesced staging, one task per wave at a time
     const uint64_t qa = __shfl(myQa, i), qn = __shfl(myQn, i), ta = __shfl(myTa, i), tn = __shfl(myTn, i);
-    if (qn > QCAP || tn > TCAP) continue;
-    for (uint32_t p = lane; p < qn; p += 64) stage[i * CSTRIDE + p] = A.q[qa + p];
-    for (uint32_t p = lane; p < tn; p += 64) stage[i * CSTRIDE + QCAP + p] = A.t[ta + p];
+    const uint32_t so = __shfl(myOff, i);
+    if (!__shfl((int)myFits, i)) continue;
+    for (uint32_t p = lane; p < qn; p += 64) stage[so + p] = A.q[qa + p];
+    for (uint32_t p = lane; p < tn; p += 64) stage[so + (uint32_t)qn + p] = A.t[ta + p];
   }
   __syncthreads();
   // the walks diverge from task to task: every wave of the block takes 16 of its 64 tasks (16 active lanes), so the four SIMDs of the CU
@@ -312,12 +321,12 @@ __global__ void __launch_bounds__(STAGE_NT) local_compare(CmpArgs A) {
   constexpr int TPW = 64 / (STAGE_NT / 64);
   const int slot = wave * TPW + lane;                                    // the task (and its LDS row) this lane walks
   const uint64_t sQa = __shfl(myQa, slot & 63), sTa = __shfl(myTa, slot & 63), sQn = __shfl(myQn, slot & 63), sTn = __shfl(myTn, slot & 63);
+  const uint32_t sOff = __shfl(myOff, slot & 63); const bool staged = __shfl((int)myFits, slot & 63) != 0;
   if (lane >= TPW || x0 + slot >= A.n_tasks) return;
   const uint64_t x = x0 + slot;
   const long nq = (long)sQn, nt = (long)sTn;
-  const bool staged = nq <= QCAP && nt <= TCAP;
-  const uint32_t* q = staged ? stage + slot * CSTRIDE : A.q + sQa;
-  const uint32_t* t = staged ? stage + slot * CSTRIDE + QCAP : A.t + sTa;
+  const uint32_t* q = staged ? stage + sOff : A.q + sQa;
+  const uint32_t* t = staged ? stage + sOff + (uint32_t)nq : A.t + sTa;
   const int64_t maxDiag = A.maxDiag ? A.maxDiag[x] : 0, minDiag = A.minDiag ? A.minDiag[x] : 0;
   const long maxFreq = A.maxFreq;
   uint32_t* oq = EMIT ? A.out_qi + A.out_off[x] : nullptr; uint32_t* ot = EMIT ? A.out_ti + A.out_off[x] : nullptr;
