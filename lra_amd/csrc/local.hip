@@ -225,26 +225,35 @@ __device__ void w_std_sort(uint32_t* v, long n) {
 constexpr int LCAP = 160;
 constexpr int LSTRIDE = LCAP + 1;
 constexpr int STAGE_NT = 256;                                           // 4 waves stage a block's 64 lists (memory parallelism), wave 0 works on them
+// (a window holds ~45 tuples: the 64 lists of a block are packed behind one another in LS_WORDS words of LDS -- 24 KB, six blocks per CU -- instead of 64 rows of LCAP;
+// a list that no longer fits, like one above LCAP, is sorted in HBM)
+constexpr int LS_WORDS = 6144;
 __global__ void __launch_bounds__(STAGE_NT) local_sort_filter(uint64_t n_win, uint64_t stride, uint32_t* raw, int maxFreq, uint32_t* counts) {
-  __shared__ uint32_t stage[64 * LSTRIDE];
+  __shared__ uint32_t stage[LS_WORDS];
   __shared__ uint32_t kept[64];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const uint64_t w0 = (uint64_t)blockIdx.x * 64;
   const uint64_t wi = w0 + lane;
   const uint64_t myA = wi * stride, myN = wi < n_win ? counts[wi] : 0;       // raw count in, filtered count out
+  const uint32_t need = myN <= (uint64_t)LCAP ? (uint32_t)myN : 0u;
+  uint32_t incl = need;
+  for (int d = 1; d < 64; d <<= 1) { const uint32_t o = __shfl_up(incl, d); if (lane >= d) incl += o; }
+  const uint32_t myOff = incl - need;
+  const bool myFits = myN <= (uint64_t)LCAP && incl <= (uint32_t)LS_WORDS;
 #pragma unroll 4
   for (int x = wave; x < 64; x += STAGE_NT / 64) {
     const uint64_t a = __shfl(myA, x), n = __shfl(myN, x);
-    if (n > LCAP) continue;
-    for (uint32_t p = lane; p < n; p += 64) stage[x * LSTRIDE + p] = raw[a + p];
+    const uint32_t so = __shfl(myOff, x);
+    if (!__shfl((int)myFits, x)) continue;
+    for (uint32_t p = lane; p < n; p += 64) stage[so + p] = raw[a + p];
   }
   __syncthreads();
   if (wave == 0) {
     long c = 0;
     if (wi < n_win) {
       const long n = (long)myN;
-      const bool staged = n <= LCAP;
-      uint32_t* v = staged ? stage + lane * LSTRIDE : raw + myA;
+      const bool staged = myFits;
+      uint32_t* v = staged ? stage + myOff : raw + myA;
       w_std_sort(v, n);                                                  // MMIndex.h:219
       long x = 0;                                                        // RemoveFrequent MMIndex.h:69-84
       while (x < n) {
@@ -260,10 +269,11 @@ __global__ void __launch_bounds__(STAGE_NT) local_sort_filter(uint64_t n_win, ui
   __syncthreads();
   // write the surviving tuples back (coalesced, one window per wave at a time)
   for (int x = wave; x < 64; x += STAGE_NT / 64) {
-    const uint64_t a = __shfl(myA, x), n = __shfl(myN, x);
-    if (w0 + x >= n_win || n > LCAP) continue;
+    const uint64_t a = __shfl(myA, x);
+    const uint32_t so = __shfl(myOff, x);
+    if (w0 + x >= n_win || !__shfl((int)myFits, x)) continue;
     const uint32_t cx = kept[x];
-    for (uint32_t p = lane; p < cx; p += 64) raw[a + p] = stage[x * LSTRIDE + p];
+    for (uint32_t p = lane; p < cx; p += 64) raw[a + p] = stage[so + p];
   }
 }
 
