@@ -138,10 +138,7 @@ __device__ __forceinline__ int dpp_from_next_lane(int v) { return __builtin_amdg
 // The sweep of solve_reg (and of solve()'s HBM-resident problems): returns the corner cell's score in every lane of the group.  P: the arrows (LDS or HBM); qc / tc: the
 // sequence codes in LDS.  Two steps per iteration (even diagonals, then odd ones, or the other way round), the codes of a lane's next cell on a diagonal loaded one
 // round ahead (a cell's successor on its diagonal is (i + 1, j + 1)), and the boundary values looked at only while an anti-diagonal can still touch row / column 0.
-// AD: the arrows anti-diagonal by anti-diagonal -- arrow of cell (i, j) at (i + j) * (k + 2) + ((i - j + k + 1) >> 1) -- and EVERY slot of a step written by that step
-// (the computed arrow, the boundary / rail arrow solve()'s stores would have left there, or -1): one contiguous store of k + 2 bytes per step and no clearing or
-// boundary pass, where the row-major layout scatters a step's bytes over k + 2 cache lines (HBM-resident problems: 3x the bytes written).
-template <int G, bool AD = false, typename ArrowPtr, typename CodePtr>
+template <int G, typename ArrowPtr, typename CodePtr>
 __device__ __forceinline__ int reg_fill(int lane, int gbase, const Geo& g, int m, int mm, int indel, ArrowPtr P, CodePtr qc, CodePtr tc) {
   const int qLen = g.qLen, tLen = g.tLen, k = g.k, R = g.R, diag = g.diag, qB = g.qB, tB = g.tB;
   // what the boundary / rail stores of solve() leave in cell (i, j) before the sweep (last store wins; everything else is MISS)
@@ -154,16 +151,7 @@ __device__ __forceinline__ int reg_fill(int lane, int gbase, const Geo& g, int m
     if (qLen <= tLen) { if (i == j + k + 1 && j < diag - 1) v = MISS; if (j == i + k + 1 && j >= 1 && j < diag + k) v = MISS; }
     return v;
   };
-  auto pre_arrow = [&](int i, int j) -> int {                              // the arrows of the same stores (-1: never stored)
-    int v = -1;
-    if (j == 0 && i >= 1 && i < k + 1) v = A_LEFT;
-    if (i == 0 && j >= 1 && j <= k + 1) v = A_DOWN;
-    if (i == 0 && j == 0) v = A_DONE;
-    if (qLen >= tLen) { if (j == i + k + 1 && i <= diag - k - 1) v = A_BORDER; if (i == j + k + 1 && j >= 1 && j < diag + k - 1) v = A_BORDER; }
-    if (qLen <= tLen) { if (i == j + k + 1 && j < diag - 1) v = A_BORDER; if (j == i + k + 1 && j >= 1 && j < diag + k) v = A_BORDER; }
-    return v;
-  };
-  const int Wd = 2 * k + 3, W2 = k + 2;
+  const int Wd = 2 * k + 3;
   const int sLast = max((qB - 1) + (tB - 1), 0);
   const int ci = qB - 1, cj = tB - 1;
   int vE = MISS, vO = MISS;
@@ -185,19 +173,17 @@ __device__ __forceinline__ int reg_fill(int lane, int gbase, const Geo& g, int m
     const int nb1 = E ? dpp_from_prev_lane(vO) : dpp_from_next_lane(vE);   // diagonal dd - 1 (even step) resp. dd + 1 (odd step), one step ago
     const int i = E ? iE : iO, j = E ? jE : jO;
     const bool nxt = codes_match(i + 1, j + 1);                           // (in flight until this lane's next step on this diagonal, two steps on)
-    int v = MISS, arr = -1;
+    int v = MISS;
     if (s >= (E ? sLoE : sLoO) && s <= (E ? sHiE : sHiO)) {
       const int sIns = (E ? nb1 : vE) + indel;                            // (i - 1, j): diagonal dd - 1
       const int sDel = (E ? vO : nb1) + indel;                            // (i, j - 1): diagonal dd + 1
       const int sMat = (E ? vE : vO) + ((E ? eqE : eqO) ? m : mm);        // (i - 1, j - 1): this diagonal, two steps ago
       const int best = max(sIns, max(sDel, sMat));
       v = best;
-      arr = (best == sIns) ? A_LEFT : (best == sDel) ? A_DOWN : A_DIAG;
-      if (!AD) P[E ? adE : adO] = (signed char)arr;
-    } else if (AD || s <= k + 1) {                                        // (a boundary value sits in row or column 0: i + j <= k + 1; the rails hold MISS)
-      if (2 * lane + (E ? 0 : 1) < Wd && i >= 0 && j >= 0) { if (s <= k + 1) v = pre(i, j); if (AD) arr = pre_arrow(i, j); }
+      P[E ? adE : adO] = (signed char)((best == sIns) ? A_LEFT : (best == sDel) ? A_DOWN : A_DIAG);
+    } else if (s <= k + 1) {                                              // (a boundary value sits in row or column 0: i + j <= k + 1; the rails hold MISS)
+      if (2 * lane + (E ? 0 : 1) < Wd && i >= 0 && j >= 0) v = pre(i, j);
     }
-    if (AD && lane < W2) P[(long)s * W2 + lane] = (signed char)arr;
     if (E) { vE = v; eqE = nxt; iE++; jE++; adE += R; } else { vO = v; eqO = nxt; iO++; jO++; adO += R; }
   };
   int s = 0;
@@ -241,15 +227,13 @@ __device__ __forceinline__ void solve(int wlane, const Problem& pr, const Geo& g
   // (with the band's diagonals two to a lane the sweep keeps the scores in registers -- reg_fill -- and the codes may stay in the HBM work area when they outgrow LDS)
   const bool codesInLds = qLen + tLen + 2 <= 4096;
   const bool rolling = roll != nullptr && !g.top && (k + 2 <= G || (2 * k + 3 <= 256 && codesInLds));
-  // arrows anti-diagonal-major (reg_fill<AD>) in the room of the unused prefix scores, when the sweep is the register one and they fit there
-  const bool adMode = rolling && k + 2 <= G && (long)(max((g.qB - 1) + (g.tB - 1), 0) + 2) * (k + 2) <= 4L * nUsed;
   // ... and the sequence codes sit behind the windows (roll[768 ..], one byte each), so that a sweep step touches HBM only to store its arrows
   unsigned char* lq = (unsigned char*)(roll + 768); unsigned char* lt = lq + (qLen + 1);
   if (rolling && codesInLds) {
     for (int x = lane; x <= qLen; x += G) lq[x] = x ? code_n((unsigned char)pr.q[x - 1]) : 0;
     for (int x = lane; x <= tLen; x += G) lt[x] = x ? code_n((unsigned char)pr.t[x - 1]) : 0;
   }
-  if (rolling && !adMode) {                                               // the arrows' "never stored" value, 16 bytes per lane and store (pPre is 4-byte aligned)
+  if (rolling) {                                                          // the arrows' "never stored" value, 16 bytes per lane and store (pPre is 4-byte aligned)
     const long head = min((long)nUsed, (long)((16 - ((uintptr_t)&w.pPre[0] & 15)) & 15));
     for (long x = lane; x < head; x += G) w.pPre[x] = -1;
     const long body = (nUsed - head) >> 4;
@@ -263,7 +247,6 @@ __device__ __forceinline__ void solve(int wlane, const Problem& pr, const Geo& g
   for (int x = lane; x <= diag; x += G) { w.loMax[x] = MISS; w.loIdx[x] = 0; w.upMax[x] = MISS; w.upIdx[x] = 0; }
   wave_sync();
   // ---- prefix boundary (:229-241), then rails (:248-306); the rails overwrite (0,k+1)
-  if (!adMode) {
   for (int i = 1 + lane; i < k + 1; i += G) PSET(PI(i, 0), indel * i, A_LEFT);
   for (int j = 1 + lane; j <= k + 1; j += G) PSET(PI(0, j), indel * j, A_DOWN);
   if (lane == 0) PSET(PI(0, 0), 0, A_DONE);
@@ -277,7 +260,6 @@ __device__ __forceinline__ void solve(int wlane, const Problem& pr, const Geo& g
     for (int j = 1 + lane; j < diag + k; j += G) PSET(PI(j - k - 1, j), MISS, A_BORDER);
   }
   wave_sync();
-  }
   // ---- prefix fill by anti-diagonals s = i + j (:313-339)
   const int qB = g.qB, tB = g.tB;
   int rollResult = MISS;
@@ -295,9 +277,7 @@ __device__ __forceinline__ void solve(int wlane, const Problem& pr, const Geo& g
     const int Wd = 2 * k + 3;
     const int sLast = (qB - 1) + (tB - 1);
     const bool inRegs = k + 2 <= G;                                      // the band's diagonals fit the lanes two apiece: scores in registers (reg_fill)
-    if (inRegs && adMode) rollResult = codesInLds ? reg_fill<G, true>(lane, gbase, g, m, mm, indel, (signed char*)&w.sPre[0], lq, lt)
-                                                  : reg_fill<G, true>(lane, gbase, g, m, mm, indel, (signed char*)&w.sPre[0], w.qc, w.tc);
-    else if (inRegs) rollResult = codesInLds ? reg_fill<G>(lane, gbase, g, m, mm, indel, w.pPre, lq, lt) : reg_fill<G>(lane, gbase, g, m, mm, indel, w.pPre, w.qc, w.tc);
+    if (inRegs) rollResult = codesInLds ? reg_fill<G>(lane, gbase, g, m, mm, indel, w.pPre, lq, lt) : reg_fill<G>(lane, gbase, g, m, mm, indel, w.pPre, w.qc, w.tc);
     for (int s = 0; !inRegs && s <= max(sLast, 0); s++) {
       int* cur = roll + (s % 3) * 256; const int* p1 = roll + ((s + 2) % 3) * 256; const int* p2 = roll + ((s + 1) % 3) * 256;
       int jlo = max(1, max(s - qB + 1, (s - k + 1) >> 1));
@@ -471,19 +451,17 @@ __device__ __forceinline__ void solve(int wlane, const Problem& pr, const Geo& g
   // LDS: the walk is a chain of dependent one-byte loads a row apart (a cache line each); a window serves at least as many steps as it has rows
   if (rolling) {
     unsigned char* chunk = (unsigned char*)(roll + 768 + 1024);          // 8 KB
-    // the window: rows of the row-major layout, anti-diagonals of the anti-diagonal-major one ("major" coordinate mj: j resp. i + j; a diagonal step lowers it by 1 resp. 2)
-    const int strideW = adMode ? k + 2 : R;
-    const signed char* AP = adMode ? (const signed char*)&w.sPre[0] : (const signed char*)&w.pPre[0];
-    const int chRows = max(1, 8192 / strideW);
+    const int chRows = max(1, 8192 / R);
     int cLo = 1, cHi = 0;
-    auto stageAt = [&](int mj) {
-      if (mj < cLo || mj > cHi) {
-        cHi = mj; cLo = max(0, mj - chRows + 1);
+    auto arrowAt = [&](int i, int j) -> int {
+      if (j < cLo || j > cHi) {
+        cHi = j; cLo = max(0, j - chRows + 1);
         wave_sync();
-        const long base = (long)cLo * strideW, len = (long)(cHi - cLo + 1) * strideW;
-        for (long x = lane; x < len; x += G) chunk[x] = (unsigned char)AP[base + x];
+        const long base = (long)cLo * R, len = (long)(cHi - cLo + 1) * R;
+        for (long x = lane; x < len; x += G) chunk[x] = (unsigned char)w.pPre[base + x];
         wave_sync();
       }
+      return (int)(signed char)chunk[(j - cLo) * R + (i - j) + k + 1];
     };
     auto flushL = [&](int i_after, int j_after) {
       if (run > 0) {
@@ -498,12 +476,10 @@ __device__ __forceinline__ void solve(int wlane, const Problem& pr, const Geo& g
     const unsigned long long gmask = (~0ULL >> (64 - G)) << gbase;
     if (ti >= 0 && tj >= 0 && inb(PI(ti, tj))) {
       while (true) {
-        const int mj0 = adMode ? ti + tj : tj;
-        stageAt(mj0);                                                     // the window holds the walk's cell now
-        const int ml = adMode ? mj0 - 2 * lane : mj0 - lane;
-        const int minor = adMode ? ((ti - tj + k + 1) >> 1) : (ti - tj) + k + 1;
-        const bool on = ti - lane >= 0 && tj - lane >= 0;
-        const int a = !on ? A_OFF : ml < cLo ? A_WIN : (int)(signed char)chunk[(ml - cLo) * strideW + minor];
+        (void)arrowAt(ti, tj);                                            // the window holds row tj now
+        const int jl = tj - lane;
+        const bool on = ti - lane >= 0 && jl >= 0;
+        const int a = !on ? A_OFF : jl < cLo ? A_WIN : (int)(signed char)chunk[(jl - cLo) * R + (ti - tj) + k + 1];
         const unsigned long long nd = (__ballot(a != A_DIAG) & gmask) >> gbase;
         const int f = nd ? __ffsll((long long)nd) - 1 : G;
         run += f; ti -= f; tj -= f;
