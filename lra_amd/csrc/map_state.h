@@ -47,10 +47,13 @@ struct lra_map_state {
   uint64_t* d_gso = nullptr; uint64_t n_gwin = 0;  // its seqOffsets
   int gli_window = 0;
   bool borrowed = false;                           // reference data shared from another context (lra_ctx_share_reference): not freed here
+  uint64_t generation = 0;                         // bumped by every loader of this context (chromosome table, local index)
+  const lra_map_state* owner = nullptr; uint64_t owner_generation = 0;   // a borrower: whose data, at which generation (see seed_state.h)
   std::vector<float> lut;                          // LogLookUpTable.h:9-15
   lra_text_buf last_text; std::vector<uint64_t> last_off; lra_map_sig last_sig;   // lra_map_records: sizing call -> filling call
 };
 
+int lra_map_check_shared(lra_ctx* ctx);   // mapread.hip: borrowed reference data still current?
 // RefineBreakpoint over the consecutive SegAlignments of every job (Map_lowacc.h:586-596, Map_highacc.h:723-727); mapread.hip
 int lra_refine_breakpoints(lra_ctx* ctx, uint64_t nJ, uint64_t nA, const uint64_t* d_job_aln_off, const int32_t* d_strand, const uint64_t* q_off, const int32_t* q_len,
                            const uint64_t* t_off, const int64_t* t_len, const char* strands, const char* genome, lra_refine_result* fres);

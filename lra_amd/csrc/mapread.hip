@@ -40,6 +40,13 @@ lra_map_state* map_state(lra_ctx* ctx) {
   return ctx->map;
 }
 
+// a loader on a context that borrows its reference data: drop the owner's pointers, own what is loaded from here on
+void map_disown(lra_map_state* m) {
+  if (!m->borrowed) return;
+  m->d_chrom_pos = nullptr; m->gli_buf = nullptr; m->gli = lra_local_index_result{}; m->d_gso = nullptr; m->n_gwin = 0; m->gli_window = 0;
+  m->borrowed = false; m->owner = nullptr; m->owner_generation = 0;
+}
+
 __global__ void k_add_off(int n, const uint64_t* __restrict__ off, uint64_t add, uint64_t* __restrict__ out) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i <= n) out[i] = off[i];                       // [0..n]: the reads forward
@@ -261,6 +268,7 @@ extern "C" int lra_ctx_load_chromosomes(lra_ctx* ctx, const uint64_t* h_chrom_po
   if (!ctx || !h_chrom_pos || n_chrom < 1) return LRA_ERR_INVALID;
   LRA_HIP_CHECK(ctx, hipSetDevice(ctx->device));
   lra_map_state* m = map_state(ctx);
+  map_disown(m); m->generation++;
   m->chrom_pos.assign(h_chrom_pos, h_chrom_pos + n_chrom + 1);
   if (m->d_chrom_pos) (void)hipFree(m->d_chrom_pos);
   LRA_HIP_CHECK(ctx, hipMalloc((void**)&m->d_chrom_pos, (size_t)(n_chrom + 1) * 8));
@@ -274,6 +282,8 @@ extern "C" int lra_ctx_build_local_index(lra_ctx* ctx, int k, int w, int window,
   if (!ctx->seed || !ctx->seed->genome) return lra_set_err(ctx, LRA_ERR_INVALID, "load the genome first");
   LRA_HIP_CHECK(ctx, hipSetDevice(ctx->device));
   lra_map_state* m = ctx->map;
+  if (m->borrowed) return lra_set_err(ctx, LRA_ERR_INVALID, "this context shares another context's reference data: load its own chromosome table first");
+  m->generation++;
   const int n_chrom = (int)m->chrom_pos.size() - 1;
   if (m->chrom_pos[n_chrom] != ctx->seed->genome_len) return lra_set_err(ctx, LRA_ERR_INVALID, "chromosome table does not cover the genome");
   lra_local_index_result r;
@@ -315,6 +325,18 @@ extern "C" int lra_ctx_share_reference(lra_ctx* dst, lra_ctx* src) {
   const lra_map_state* s = src->map;
   m->chrom_pos = s->chrom_pos; m->d_chrom_pos = s->d_chrom_pos; m->gli_buf = s->gli_buf; m->gli = s->gli; m->d_gso = s->d_gso; m->n_gwin = s->n_gwin;
   m->gli_window = s->gli_window; m->lut = s->lut; m->borrowed = true;
+  m->owner = s->borrowed ? s->owner : s; m->owner_generation = s->borrowed ? s->owner_generation : s->generation;
+  return LRA_OK;
+}
+
+// LRA_OK, or LRA_ERR_INVALID when this context borrows reference data (lra_ctx_share_reference) that its owner has replaced since
+int lra_seed_check_shared(lra_ctx* ctx);   // seed.hip
+int lra_map_check_shared(lra_ctx* ctx) {
+  int rc = lra_seed_check_shared(ctx);
+  if (rc) return rc;
+  const lra_map_state* m = ctx->map;
+  if (m && m->borrowed && m->owner && m->owner->generation != m->owner_generation)
+    return lra_set_err(ctx, LRA_ERR_INVALID, "the context this one shares its reference data with has reloaded it: call lra_ctx_share_reference again");
   return LRA_OK;
 }
 
@@ -667,6 +689,7 @@ extern "C" int lra_map_reads_lowacc_batch(lra_ctx* ctx, int n_reads, const char*
   if (!m || !m->gli_buf || !ctx->seed || !ctx->seed->genome || !ctx->seed->idx_key)
     return lra_set_err(ctx, LRA_ERR_INVALID, "reference not loaded (genome, global index, chromosome table, local index)");
   if (m->gli_window != o->localIndexWindow) return lra_set_err(ctx, LRA_ERR_INVALID, "local index built with another window");
+  { int rcs = lra_map_check_shared(ctx); if (rcs) return rcs; }
   out->n_reads = n_reads;
   m->last_text.clear(); m->last_sig = lra_map_sig{};         // a sizing call of lra_map_records for an earlier batch is void now
   if (n_reads == 0) return LRA_OK;
@@ -695,6 +718,7 @@ extern "C" int lra_map_reads_lowacc_batch(lra_ctx* ctx, int n_reads, const char*
     lra_map_state* d = c->map; const lra_map_state* s = ctx->map;
     d->chrom_pos = s->chrom_pos; d->d_chrom_pos = s->d_chrom_pos; d->gli_buf = s->gli_buf; d->gli = s->gli; d->d_gso = s->d_gso; d->n_gwin = s->n_gwin;
     d->gli_window = s->gli_window; d->lut = s->lut; d->borrowed = true;
+    d->owner = s->borrowed ? s->owner : s; d->owner_generation = s->borrowed ? s->owner_generation : s->generation;
   }
   std::vector<uint32_t> picked;
   std::thread second;

@@ -628,6 +628,7 @@ extern "C" int lra_map_reads_highacc_batch(lra_ctx* ctx, int n_reads, const char
   if (!m || m->chrom_pos.size() < 2 || !ctx->seed || !ctx->seed->genome || !ctx->seed->idx_key)
     return lra_set_err(ctx, LRA_ERR_INVALID, "reference not loaded (genome, global index, chromosome table)");
   if (o->bypassClustering) return lra_set_err(ctx, LRA_ERR_INVALID, "lra_map_reads_highacc_batch is the path of opts.bypassClustering == 0 (-CCS, -CONTIG)");
+  { int rcs = lra_map_check_shared(ctx); if (rcs) return rcs; }
   out->n_reads = n_reads;
   m->last_text.clear(); m->last_sig = lra_map_sig{};
   if (n_reads == 0) return LRA_OK;

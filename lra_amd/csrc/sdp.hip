@@ -36,6 +36,8 @@
 #include <cmath>
 #include <cstring>
 #include <cstdlib>
+#include <string>
+#include <vector>
 #include <rocprim/rocprim.hpp>
 
 namespace {
@@ -64,16 +66,23 @@ struct Node {            // one full sub-problem (SubProblem.h:15-37), 40 bytes
   uint32_t sTop, nBlk;   // sizes of S_1 and Block
   uint32_t stkOff, blkOff;   // where they live, in pairs from the read's pair area (stacks, Blocks, then the growth pool)
   uint32_t stkCap, blkCap;   // their current capacities: 2 nD + 4 and 2 (nD + nE) + 8 pairs to begin with, doubled from the pool on demand
+  long long eLast;           // Ei[nE - 1]: the boundary diagonal of a candidate that owns the whole tail (nearly every push is (i, nE)), so that a push needs no load
 };
 
 // Everything ProcessPoint touches for one read lies in one contiguous block (sections 256-byte aligned): a wave's working set is a
 // couple of megabytes in one place instead of six arrays gigabytes apart (TLB reach).
-struct ReadArena { uint64_t base; uint32_t entOff, apOff, stkOff, visOff, blkPair, poolPair, poolPairs, pad; };   // base: device address; byte offsets; nodes at 0
+struct ReadArena { uint64_t base; uint32_t entOff, apOff, stkOff, visOff, blkPair, poolPair, poolPairs, edOff; };   // base: device address; byte offsets; nodes at 0
+// edOff: one 64-bit word per entry -- for a D entry d the diagonal Ei[Db[d]] (static), which Maximization compares every candidate at (SubRountine.h:292): stored
+// beside the entry, the candidate scan is ONE round of independent loads instead of two dependent ones
 // The pair area at stkOff holds the candidate stacks, then (from pair index blkPair) the Block lists, then (from poolPair) a pool of
 // poolPairs pairs.  Re-inserted candidates (`last` moving backwards) let a stack / Block outgrow any fixed multiple of its sub-problem, so
 // they start at 2 nD + 4 / 2 (nD + nE) + 8 pairs and double out of the pool when full; a read that exhausts its pool is re-run with 8x, 64x.
 
 __device__ __host__ inline uint32_t al256(uint64_t x) { return (uint32_t)((x + 255) & ~(uint64_t)255); }
+// A read's block is found through an address kept in a table (ReadArena::base).  A pointer made from an integer is a FLAT pointer to the compiler: every access through
+// it is a flat_load / flat_store, which counts on the LDS counter as well as on the vector-memory one -- so every LDS read (the gap-cost table inside w(), the slot state)
+// waits for all the stores in flight (a stack / Block push is followed by exactly that).  Saying that the address is in global memory gives global_load / global_store.
+__device__ __forceinline__ char* arena_ptr(uint64_t addr) { return (char*)(__attribute__((address_space(1))) char*)addr; }
 
 __global__ void k_arena_sizes(int n, int r0, const uint64_t* __restrict__ ptOff, const uint32_t* __restrict__ cntE, const uint32_t* __restrict__ cntN,
                               const uint32_t* __restrict__ cntD, ReadArena* ra, uint64_t* bytes, const uint32_t* __restrict__ order, int shift) {
@@ -82,10 +91,11 @@ __global__ void k_arena_sizes(int n, int r0, const uint64_t* __restrict__ ptOff,
   const int rr = (int)order[b];
   const uint64_t E = cntE[rr], N = cntN[rr], D = cntD[rr], P = ptOff[r0 + rr + 1] - ptOff[r0 + rr];
   ReadArena a;
-  a.base = 0; a.pad = 0;
+  a.base = 0;
   uint64_t o = al256(N * sizeof(Node));
   a.entOff = (uint32_t)o; o = al256(o + E * sizeof(Ent));
   a.apOff = (uint32_t)o; o = al256(o + E * 4);
+  a.edOff = (uint32_t)o; o = al256(o + E * 8);
   const uint64_t stkPairs = 2 * D + 4 * N + 2, blkPairs = 2 * E + 8 * N + 2, poolPairs = (2 * E + 4096) << shift;
   a.stkOff = (uint32_t)o; a.blkPair = (uint32_t)stkPairs; a.poolPair = (uint32_t)(stkPairs + blkPairs); a.poolPairs = (uint32_t)poolPairs;
   o = al256(o + (stkPairs + blkPairs + poolPairs) * 8);
@@ -100,7 +110,7 @@ __global__ void k_arena_bases(int n, const uint64_t* __restrict__ byteOff, ReadA
 __global__ void k_visit_clear(const ReadArena* __restrict__ ra, const uint64_t* __restrict__ byteOff, const uint32_t* __restrict__ order) {
   const int b = blockIdx.x;
   const ReadArena A = ra[order[b]];
-  uint4* p = (uint4*)((char*)(uintptr_t)A.base + A.visOff);
+  uint4* p = (uint4*)(arena_ptr(A.base) + A.visOff);
   const uint64_t n = (byteOff[b + 1] - byteOff[b] - A.visOff) / 16;
   for (uint64_t i = threadIdx.x; i < n; i += blockDim.x) p[i] = make_uint4(NONE, NONE, NONE, NONE);
 }
@@ -232,7 +242,7 @@ struct BuildArgs {
   const uint64_t* ptOff;
   const uint32_t* hq; const uint32_t* ht; const uint8_t* hfl; const uint32_t* h2; const uint64_t* key3; const uint32_t* pay3;
   uint32_t* scratch;                         // 34 words per point + 64 per read
-  uint32_t* cntEntries; uint32_t* cntNodes; uint32_t* cntD; uint32_t* cntV;   // [n] (count pass out)
+  uint32_t* cntEntries; uint32_t* cntNodes; uint32_t* cntD; uint32_t* cntV; uint32_t* cntRC;   // [n] (count pass out; cntRC: max(distinct rows, distinct columns))
   const ReadArena* ra;                       // emit pass: per-read blocks
   uint32_t* status;
 };
@@ -268,7 +278,7 @@ __global__ void __launch_bounds__(64 * NW, NW == 1 ? 8 : 1) sdp_build(BuildArgs 
   auto SYNC = [&]() { if (NW == 1) wave_sync(); else __syncthreads(); };
   const uint64_t p0 = a.ptOff[r], pc0 = a.ptOff[a.r0];
   const int P = (int)(a.ptOff[r + 1] - p0);
-  if (P == 0) { if (!EMIT && tid == 0) { a.cntEntries[rr] = 0; a.cntNodes[rr] = 0; a.cntD[rr] = 0; a.cntV[rr] = 0; } return; }
+  if (P == 0) { if (!EMIT && tid == 0) { a.cntEntries[rr] = 0; a.cntNodes[rr] = 0; a.cntD[rr] = 0; a.cntV[rr] = 0; a.cntRC[rr] = 0; } return; }
   const uint32_t* hq = a.hq + p0; const uint32_t* ht = a.ht + p0; const uint32_t* h2 = a.h2 + p0;
   const uint64_t* key3 = a.key3 + p0; const uint32_t* pay3 = a.pay3 + p0;
   uint32_t* S = a.scratch + 34 * (p0 - pc0) + 64 * (uint64_t)rr;
@@ -323,13 +333,14 @@ __global__ void __launch_bounds__(64 * NW, NW == 1 ? 8 : 1) sdp_build(BuildArgs 
   }
   SYNC();
   uint32_t nEntries = 0, nNodesTot = 0, sumD = 0, nVisits = 0;
-  Node* nodesR = nullptr; Ent* entR = nullptr; uint32_t* apR = nullptr; int2* stkR = nullptr; uint2* visR = nullptr;
+  Node* nodesR = nullptr; Ent* entR = nullptr; uint32_t* apR = nullptr; int2* stkR = nullptr; uint2* visR = nullptr; long long* edR = nullptr;
   uint32_t blkPair = 0;
   if (EMIT) {
     const ReadArena A = a.ra[rr];
-    char* b = (char*)(uintptr_t)A.base;
+    char* b = arena_ptr(A.base);
     blkPair = A.blkPair;
     nodesR = (Node*)b; entR = (Ent*)(b + A.entOff); apR = (uint32_t*)(b + A.apOff); stkR = (int2*)(b + A.stkOff); visR = (uint2*)(b + A.visOff);
+    edR = (long long*)(b + A.edOff);
   }
   bool overflow = false;
   for (int fam = 0; fam < 4; fam++) {
@@ -466,6 +477,7 @@ __global__ void __launch_bounds__(64 * NW, NW == 1 ? 8 : 1) sdp_build(BuildArgs 
             Node nd;
             nd.dBase = base; nd.nD = nD; nd.nE = nE; nd.last = -1; nd.sTop = 1; nd.nBlk = 0;
             nd.stkOff = 2 * dpre + 4 * gid; nd.blkOff = blkPair + 2 * base + 8 * gid; nd.stkCap = 2 * nD + 4; nd.blkCap = 2 * (nD + nE) + 8;
+            nd.eLast = 0;                                      // (written in F below, by the element that is the head of Ei[nE - 1])
             nodesR[gid] = nd;
             stkR[nd.stkOff] = make_int2(-1, (int)nE + 1);     // dummy pair (DivideSubByRow1.h:470)
           }
@@ -495,7 +507,11 @@ __global__ void __launch_bounds__(64 * NW, NW == 1 ? 8 : 1) sdp_build(BuildArgs 
               const uint32_t idx = desc ? n - 1 - grp : grp;
               const uint32_t ent = TM(T_BASE, k) + (isS ? TM(T_ND, k) + idx : idx);
               const uint32_t pos = lpn[j];
-              if (head) entR[ent].val = back ? (long long)ht[pos] + hq[pos] : (long long)ht[pos] - hq[pos];   // (the element's diagonal, from its point: ldn may hold 32 bits of it)
+              if (head) {
+                const long long dgv = back ? (long long)ht[pos] + hq[pos] : (long long)ht[pos] - hq[pos];   // (the element's diagonal, from its point: ldn may hold 32 bits of it)
+                entR[ent].val = dgv;
+                if (isS && idx == n - 1) nodesR[gid].eLast = dgv;
+              }
               visR[(uint64_t)pos * (2 * LV) + fam2 * LV + level] = make_uint2(gid, idx);
             }
           }
@@ -532,6 +548,7 @@ __global__ void __launch_bounds__(64 * NW, NW == 1 ? 8 : 1) sdp_build(BuildArgs 
             if (go) { lo = it + 1; cnt -= step + 1; } else cnt = step;
           }
           entR[ent].b = isS ? (int32_t)lo - 1 : (lo == m ? -1 : (int32_t)lo);
+          if (!isS) edR[ent] = lo == m ? 0 : opp[lo].val;                   // Ei[Db[d]]
           float v0 = 0.f;
           if (isS && lo >= 1 && lo < nD) {
             // Ev[] is written but never read by the reference (only Ep is); the slot holds Db[Eb + 1], which the flush at the end of
@@ -561,7 +578,7 @@ __global__ void __launch_bounds__(64 * NW, NW == 1 ? 8 : 1) sdp_build(BuildArgs 
     for (int w = 0; w < NW; w++) nVisits += (uint32_t)s_w[0][w];
   }
   if (tid == 0) {
-    if (!EMIT) { a.cntEntries[rr] = nEntries; a.cntNodes[rr] = nNodesTot; a.cntD[rr] = sumD; a.cntV[rr] = nVisits; }
+    if (!EMIT) { a.cntEntries[rr] = nEntries; a.cntNodes[rr] = nNodesTot; a.cntD[rr] = sumD; a.cntV[rr] = nVisits; a.cntRC[rr] = (uint32_t)max(R, C); }
     if (overflow) atomicOr(&a.status[r], (uint32_t)LRA_ST_RANGE);             // more than 2^(LV-1) distinct rows / columns
   }
 #undef TB
@@ -579,23 +596,55 @@ struct ProcArgs {
   const ReadArena* ra; uint32_t* poolUsed;
   uint32_t* status;
   PwlTab pwl;
+  const short* penTab; int penN;           // -w(|d| + 1) for d < penN (k_pen_table); penN = 0: no table
   int dbg;
   char* wgScratch; const uint64_t* wgOff;   // sdp_process_wg: per large read, the anchors' (best predecessor, contributions) words and the points' ranks
 };
 
 // w(i, j) = -PWL_w(|j - i| + 1)   (SubRountine.h:101-129).  upper_bound over STOPS[0..24) as a count of constants <= x.
+// Every visit of ProcessPoint evaluates this a handful of times and a wave runs them one after the other, so it is written for few instructions: the count of
+// stops below 1000 in nine compares, one division between 1000 and 9999, five compares beyond; 32-bit conversions wherever the values fit (the reference's
+// (long)(float) and (float)(long) give the same numbers there: both truncate / round the same value).
 __device__ __forceinline__ float pwl_w(const float* slope, const float* inter, int c1, int c2, long long i, long long j) {
   const long long x = (j > i ? j - i : i - j) + 1;
   if (x <= 2) return x == 1 ? 0.f : -0.f;
-  const int xs = x > 0x7fffffffLL ? 0x7fffffff : (int)x;
-  const int b = 1 + (xs >= 5) + (xs >= 10) + (xs >= 20) + (xs >= 40) + (xs >= 80) + (xs >= 100) + (xs >= 200) + (xs >= 300) + (xs >= 500) + (xs >= 1000) +
-                (xs >= 2000) + (xs >= 3000) + (xs >= 4000) + (xs >= 5000) + (xs >= 6000) + (xs >= 7000) + (xs >= 8000) + (xs >= 9000) + (xs >= 15000) +
-                (xs >= 20000) + (xs >= 30000) + (xs >= 40000) + (xs >= 50000);
-  long long pen = (long long)(slope[b - 1] * (float)x + inter[b - 1]);
+  int b; float xf;
+  if (x <= 0x7fffffffLL) {
+    const int xs = (int)x;
+    if (xs < 1000) b = 1 + (xs >= 5) + (xs >= 10) + (xs >= 20) + (xs >= 40) + (xs >= 80) + (xs >= 100) + (xs >= 200) + (xs >= 300) + (xs >= 500);
+    else if (xs < 10000) b = 10 + xs / 1000;                              // stops 1000, 2000, ..., 9000
+    else b = 19 + (xs >= 15000) + (xs >= 20000) + (xs >= 30000) + (xs >= 40000) + (xs >= 50000);
+    xf = (float)xs;
+  } else { b = 24; xf = (float)x; }
+  const float f = slope[b - 1] * xf + inter[b - 1];
+  if (f > -2.0e9f && f < 2.0e9f) {
+    int pen = (int)f;
+    if (pen >= c1 && pen < c2) pen = c1;
+    else if (pen > c2) pen = c2;
+    return -(float)pen;
+  }
+  long long pen = (long long)f;
   if (pen >= c1 && pen < c2) pen = c1;
   else if (pen > c2) pen = c2;
   return -(float)pen;
 }
+
+// The same through a table: -w(i, j) for |j - i| + 1 < n as 16-bit integers in LDS (every penalty is an integer: PWL_w truncates), made once per call by
+// k_pen_table with pwl_w itself.  A visit evaluates w ten times and more; from the table that is one LDS read instead of ~50 instructions and two reads.
+__device__ __forceinline__ float pwl_w_tab(const short* tab, int n, const float* slope, const float* inter, int c1, int c2, long long i, long long j) {
+  const long long d = j > i ? j - i : i - j;
+  if (d < (long long)n) { const int xi = (int)d; return xi == 0 ? 0.f : -(float)(int)tab[xi]; }   // (x == 1: w returns +0, SubRountine.h:125)
+  return pwl_w(slope, inter, c1, c2, i, j);
+}
+__global__ void k_pen_table(PwlTab pw, int n, short* tab, int* bad) {
+  const int d = blockIdx.x * blockDim.x + threadIdx.x;
+  if (d >= n) return;
+  const float w = pwl_w(pw.slope, pw.inter, pw.c1, pw.c2, 0, (long long)d);      // x = d + 1
+  const float p = -w;                                                            // the penalty: an integer
+  if (!(p >= 0.f && p <= 32767.f) || (float)(int)p != p) { atomicOr(bad, 1); tab[d] = 0; return; }
+  tab[d] = (short)(int)p;
+}
+constexpr int PEN_TAB_WG = 4096, PEN_TAB_WAVE = 2048;
 
 __device__ __forceinline__ int rl_i(int v, int src) { return __builtin_amdgcn_readlane(v, src); }           // src must be wave-uniform
 __device__ __forceinline__ float rl_f(float v, int src) { return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), src)); }
@@ -607,6 +656,19 @@ __device__ __forceinline__ long long shfl_ll(long long v, int src) {
   const int lo = __shfl((int)(v & 0xffffffffLL), src), hi = __shfl((int)(v >> 32), src);
   return (long long)(((unsigned long long)(unsigned)hi << 32) | (unsigned)lo);
 }
+
+// Wave-uniform values (every lane computes the same number): moved to scalar registers.  The sparse DP's workgroup kernel is almost entirely uniform control
+// (one visit = a serial walk the whole wave follows); left in vector registers its state overflows the 128 a wave of a 1024-thread block may hold, and a reload from
+// scratch waits behind every pending store of the walk (vector memory completes in order).  SGPRs spill into VGPR lanes instead: no memory.
+__device__ __forceinline__ int u_i(int v) { return __builtin_amdgcn_readfirstlane(v); }
+__device__ __forceinline__ uint32_t u_u(uint32_t v) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)v); }
+__device__ __forceinline__ float u_f(float v) { return __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(v))); }
+__device__ __forceinline__ long long u_ll(long long v) {
+  const unsigned lo = (unsigned)__builtin_amdgcn_readfirstlane((int)(v & 0xffffffffLL)), hi = (unsigned)__builtin_amdgcn_readfirstlane((int)(v >> 32));
+  return (long long)(((unsigned long long)hi << 32) | lo);
+}
+__device__ __forceinline__ int2 u_i2(int2 v) { return make_int2(u_i(v.x), u_i(v.y)); }
+__device__ __forceinline__ uint2 u_u2(uint2 v) { return make_uint2(u_u(v.x), u_u(v.y)); }
 
 // The literal binary search  `while (count > 0) { step = count / 2; it = first + step; if (pred(it)) { first = it + 1; count -= step + 1; }
 // else count = step; }`  (FindBoundary :245-254, UPPERbound :209-219), six levels per memory round: lane t = 1..63 evaluates the
@@ -635,6 +697,42 @@ __device__ __forceinline__ unsigned coop_search(unsigned first, unsigned count, 
     }
   }
   return first;
+}
+
+// FindValueInBlock's UPPERbound (:205-221) over Block, the same six levels per round.  The search ends at its right boundary, and the right boundary is the
+// position of its most recent probe that came out false (or the end of the list): that probe's lane still holds the pair, so Block[lo].first comes with the
+// search instead of costing one more dependent load.  Returns lo; *x = Block[lo].x when lo < count.
+__device__ __forceinline__ unsigned coop_upper_block(const int2* B, unsigned count0, int i1, int lane, int* x) {
+  unsigned first = 0, count = count0;
+  int bx = -1;
+  while (count > 0) {
+    unsigned f = first, c = count;
+    bool valid = lane >= 1;
+    if (valid) {
+      const int depth = 31 - __clz(lane);
+      for (int d = depth - 1; d >= 0; --d) {
+        if (c == 0) { valid = false; break; }
+        const unsigned step = c / 2, it = f + step;
+        if ((lane >> d) & 1) { f = it + 1; c -= step + 1; } else c = step;
+      }
+    }
+    int2 pr = make_int2(0, 0);
+    const bool live = valid && c > 0;
+    if (live) pr = B[f + c / 2];
+    const bool p = live && i1 >= pr.y;
+    const unsigned long long m = __ballot(p);
+    unsigned t = 1;
+    int lastFalse = -1;
+    while (t < 64 && count > 0) {
+      const unsigned step = count / 2, it = first + step;
+      const unsigned bit = (unsigned)((m >> t) & 1);
+      if (bit) { first = it + 1; count -= step + 1; } else { count = step; lastFalse = (int)t; }
+      t = 2 * t + bit;
+    }
+    if (lastFalse >= 0) bx = __builtin_amdgcn_readlane(pr.x, lastFalse);
+  }
+  *x = bx;
+  return u_u(first);
 }
 
 // a stack / Block that is full moves to twice the room in the read's pool (the old room is abandoned)
@@ -667,19 +765,22 @@ __device__ bool coop_grow_pairs(int2* pairs, uint32_t& off, int& cap, int used, 
 // Block stores, so each sees its own) with the next 64 Di / Dv / Db and
 // Ei[Db] prefetched one per lane, and the two binary searches (FindBoundary, FindValueInBlock's UPPERbound) probe six levels
 // per memory round.  Value[ii] is then the (max value, first in visit order) reduction the ordered `val < Ev` updates compute.
-__global__ void __launch_bounds__(64) sdp_process(ProcArgs a) {
+__global__ void __launch_bounds__(64, 4) sdp_process(ProcArgs a) {
   __shared__ float s_slope[25], s_inter[25];
+  __shared__ short s_pen[PEN_TAB_WAVE];
   const int lane = threadIdx.x;
   if (lane < 25) { s_slope[lane] = a.pwl.slope[lane]; s_inter[lane] = a.pwl.inter[lane]; }
+  const int penN = min(a.penN, PEN_TAB_WAVE);
+  for (int x = lane; x < penN; x += 64) s_pen[x] = a.penTab[x];
   __syncthreads();
   const int c1 = a.pwl.c1, c2 = a.pwl.c2;
-#define W(i, j) pwl_w(s_slope, s_inter, c1, c2, (i), (j))
+#define W(i, j) pwl_w_tab(s_pen, penN, s_slope, s_inter, c1, c2, (i), (j))
   const int rr = (int)a.order[blockIdx.x], r = a.r0 + rr;
   const uint64_t p0 = a.ptOff[r], f0 = a.fragOff[r];
   const int P = (int)(a.ptOff[r + 1] - p0);
   const float rate = a.rate_in ? a.rate_in[r] : a.rate;
   const ReadArena A = a.ra[rr];
-  char* ab = (char*)(uintptr_t)A.base;
+  char* ab = arena_ptr(A.base);
   Node* nodes = (Node*)ab;
   Ent* ent = (Ent*)(ab + A.entOff);
   uint32_t* Ap = (uint32_t*)(ab + A.apOff);
@@ -877,20 +978,20 @@ __global__ void __launch_bounds__(64) sdp_process(ProcArgs a) {
         if (!st && nBlk > 0) {
           if (i1 >= lastB.y && i1 < top.y) i2 = top.x;
           else {
-            int lo = 0, cnt = nBlk;                                       // UPPERbound :205-221, two levels per memory round
-            while (cnt > 0) {
+            int lo = 0, cnt = nBlk, bx = -1;                              // UPPERbound :205-221, two levels per memory round; the search ends at the position of its most
+            while (cnt > 0) {                                             // recent false probe (or at the end): Block[lo].first is that probe's pair, no further load
               const int step = cnt >> 1, it = lo + step;
               const int cntT = cnt - step - 1, itT = it + 1 + (cntT >> 1), itF = lo + (step >> 1);
-              const int yM = B[it].y, yT = cntT > 0 ? B[itT].y : 0, yF = step > 0 ? B[itF].y : 0;
-              if (i1 >= yM) {
+              const int2 pM = B[it], pT = cntT > 0 ? B[itT] : make_int2(0, 0), pF = step > 0 ? B[itF] : make_int2(0, 0);
+              if (i1 >= pM.y) {
                 lo = it + 1; cnt = cntT;
-                if (cnt > 0) { const int s2 = cnt >> 1; if (i1 >= yT) { lo = itT + 1; cnt -= s2 + 1; } else cnt = s2; }
+                if (cnt > 0) { const int s2 = cnt >> 1; if (i1 >= pT.y) { lo = itT + 1; cnt -= s2 + 1; } else { cnt = s2; bx = pT.x; } }
               } else {
-                cnt = step;
-                if (cnt > 0) { const int s2 = cnt >> 1; if (i1 >= yF) { lo = itF + 1; cnt -= s2 + 1; } else cnt = s2; }
+                cnt = step; bx = pM.x;
+                if (cnt > 0) { const int s2 = cnt >> 1; if (i1 >= pF.y) { lo = itF + 1; cnt -= s2 + 1; } else { cnt = s2; bx = pF.x; } }
               }
             }
-            if (lo < nBlk) i2 = B[lo].x;
+            if (lo < nBlk) i2 = bx;
           }
         }
         if (st || i2 < 0 || i2 >= m) st |= st ? st : LRA_ST_OOB_SLOT;
@@ -943,7 +1044,17 @@ __global__ void __launch_bounds__(64) sdp_process(ProcArgs a) {
 // counts itself in; an end point's wave waits until all 16 waves are counted in for the start points of that anchor that precede it (always
 // earlier in every wave's sequence, so the wave that is furthest behind never waits), then takes the value.  fval / prev are written once at
 // the end.  The critical path is the busiest wave's own work instead of (slowest wave + two barriers + a serial reduction) per point.
-struct SlotState { Node cn; uint32_t cId; int2 cTop, cLastB; int cTopOk; };
+// What a visit costs is its chain of dependent memory round trips (a 47 k-point read from a satellite array: 19 per query of a top-level sub-problem, ~0.65 us
+// each, 12 us per point).  So the slot keeps, in LDS, what the next visit will ask memory for: beside the stack top its Di / Ei[y - 1] / Dv (Dv dropped when a
+// deposit lands on that entry), the entry below the top with its Di / Ei[y - 1] (position 0 is always the dummy pair), and the sub-problem's Ei[nE - 1] (a push
+// nearly always owns the whole tail).  A pop then costs one load (the new top's Dv) instead of three dependent ones, a candidate that beats the top without
+// popping costs none, the candidate scan is one round (Ei[Db] stored beside the entries by sdp_build), and the query's E entry is in flight one point ahead.
+struct SlotState {
+  Node cn; uint32_t cId;
+  int2 cTop, cLastB; int cTopOk;                  // stack top, last Block pair (valid when cTopOk)
+  int topInfoOk, topDvOk; float topDv; long long topDi, topEi;   // of cTop: Di[x], Ei[y - 1]; Dv[x] while no deposit has touched it
+  int2 sec; int secOk, secDvOk; float secDv; long long secDi, secEi;    // the pair below the top, with its Di / Ei[y - 1] (and Dv, as for the top)
+};
 constexpr int WG_NW = 16;
 
 // Which slots a wave owns.  The cost of a slot falls with its level (measured on a 47 k-point read: R0-R3 and C0-C2 ~ 350-400 M cycles each, level 8 ~ 100 M,
@@ -956,12 +1067,19 @@ __device__ __forceinline__ int wg_slot(int wave, int k) {
   return wave == 0 ? 16 : wave == 1 ? 17 : wave == 15 ? LV + 16 : wave == 14 ? LV + 17 : 2 * LV;   // R16, R17, C16, C17; else none
 }
 
+// SPW: slots per wave -- 3 in general (36 slots on 16 waves); 2 when the launch's reads have at most 2^15 distinct rows and columns (levels 16 and 17 are empty then:
+// every array per slot is a third smaller, which is what the register file is short of)
+// DBG (LRA_SDP_DBG): cycle counters per slot and section; a separate instantiation, because the counters' registers are what the production kernel is short of
+template <int SPW, bool DBG>
 __global__ void __launch_bounds__(64 * WG_NW) sdp_process_wg(ProcArgs a) {
   __shared__ float s_slope[25], s_inter[25];
   __shared__ SlotState ss[2 * LV];
+  __shared__ short s_pen[PEN_TAB_WG];
   __shared__ volatile uint32_t s_bad;
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int tid = threadIdx.x, lane = tid & 63, wave = u_i(tid >> 6);
   if (tid < 25) { s_slope[tid] = a.pwl.slope[tid]; s_inter[tid] = a.pwl.inter[tid]; }
+  const int penN = min(a.penN, PEN_TAB_WG);
+  for (int x = tid; x < penN; x += 64 * WG_NW) s_pen[x] = a.penTab[x];
   if (tid < 2 * LV) {
     SlotState z; memset(&z, 0, sizeof z); z.cn.last = -1; z.cId = NONE;
     ss[tid] = z;
@@ -969,16 +1087,17 @@ __global__ void __launch_bounds__(64 * WG_NW) sdp_process_wg(ProcArgs a) {
   if (tid == 0) s_bad = 0;
   __syncthreads();
   const int c1 = a.pwl.c1, c2 = a.pwl.c2;
-#define W(i, j) pwl_w(s_slope, s_inter, c1, c2, (i), (j))
+#define W(i, j) pwl_w_tab(s_pen, penN, s_slope, s_inter, c1, c2, (i), (j))
   const int rr = (int)a.order[blockIdx.x], r = a.r0 + rr;
   const uint64_t p0 = a.ptOff[r], f0 = a.fragOff[r];
   const int P = (int)(a.ptOff[r + 1] - p0);
   const float rate = a.rate_in ? a.rate_in[r] : a.rate;
   const ReadArena A = a.ra[rr];
-  char* ab = (char*)(uintptr_t)A.base;
+  char* ab = arena_ptr(A.base);
   Node* nodes = (Node*)ab;
   Ent* ent = (Ent*)(ab + A.entOff);
   uint32_t* Ap = (uint32_t*)(ab + A.apOff);
+  const long long* Ed = (const long long*)(ab + A.edOff);
   int2* pairs = (int2*)(ab + A.stkOff);
   const uint32_t poolPair = A.poolPair, poolPairs = A.poolPairs;
   uint32_t* poolUsed = a.poolUsed + rr;
@@ -1009,41 +1128,42 @@ __global__ void __launch_bounds__(64 * WG_NW) sdp_process_wg(ProcArgs a) {
   __syncthreads();
   // LRA_SDP_DBG: cycles per wave spent in each of its slots and waiting at end points (4 words per wave behind rank[], 8-aligned)
   unsigned long long* dbgT = (unsigned long long*)(((uintptr_t)(rank + P) + 7) & ~(uintptr_t)7);
-  unsigned long long tSlot[4] = {0, 0, 0, 0};
-  constexpr int SPW = (2 * LV + WG_NW - 1) / WG_NW;                       // slots per wave
-  uint2 vN[SPW]; uint8_t flN = P > 0 ? a.hfl[p0] : 0; uint32_t lfN = P > 0 ? a.hfr[p0] : 0;
+  unsigned long long tRounds = 0, tEvents = 0, tStore = 0, tEvA = 0, tEvB = 0, tEvC = 0;   // event loop: choosing the candidate, up to the comparison with the top, the winner's path
+  unsigned long long tSlot[4] = {0, 0, 0, 0}, tSec[4] = {0, 0, 0, 0};   // tSec (queries only): set-up, Maximization, flush + Block search, result + state
+  static_assert(SPW == 2 || SPW == (2 * LV + WG_NW - 1) / WG_NW, "slots per wave");
+  uint2 vN[SPW]; uint32_t flN = P > 0 ? u_u(a.hfl[p0]) : 0; uint32_t lfN = P > 0 ? u_u(a.hfr[p0]) : 0;
 #pragma unroll
-  for (int k = 0; k < SPW; k++) { const int slot = wg_slot(wave, k); vN[k] = (P > 0 && slot < 2 * LV) ? visR[slot] : make_uint2(NONE, 0); }
+  for (int k = 0; k < SPW; k++) { const int slot = wg_slot(wave, k); vN[k] = (P > 0 && slot < 2 * LV) ? u_u2(visR[slot]) : make_uint2(NONE, 0); }
   for (int pi = 0; pi < P && !s_bad; pi++) {
-    const uint8_t fl = flN;
+    const uint32_t fl = flN;
     const uint32_t lf = lfN;
-    uint2 vv[SPW];
+    uint2 vv[SPW]; Ent e0[SPW];
 #pragma unroll
     for (int k = 0; k < SPW; k++) vv[k] = vN[k];
-    if (pi + 1 < P) {                                                    // next point's rows, in flight while this one is processed
-      flN = a.hfl[p0 + pi + 1]; lfN = a.hfr[p0 + pi + 1];
-#pragma unroll
-      for (int k = 0; k < SPW; k++) { const int slot = wg_slot(wave, k); if (slot < 2 * LV) vN[k] = visR[(uint64_t)(pi + 1) * (2 * LV) + slot]; }
-    }
     const int ind = fl & 1;
-    // phase 0 for all of this wave's slots at once (their loads are independent): sub-problem descriptor, Eb[i1], stack top, last Block pair
-    Ent e0[SPW]; int2 top0[SPW], lastB0[SPW]; bool act[SPW];
+    // sub-problem descriptors of this point's visits
+    bool act[SPW];
 #pragma unroll
     for (int k = 0; k < SPW; k++) {
       const int slot = wg_slot(wave, k);
       act[k] = slot < 2 * LV && vv[k].x != NONE;
-      if (act[k] && vv[k].x != ss[slot].cId) {
-        if (lane == 0) { ss[slot].cn = nodes[vv[k].x]; ss[slot].cId = vv[k].x; ss[slot].cTopOk = 0; }
+      if (act[k] && vv[k].x != u_u(ss[slot].cId)) {
+        if (lane == 0) { ss[slot].cn = nodes[vv[k].x]; ss[slot].cId = vv[k].x; ss[slot].cTopOk = 0; ss[slot].topInfoOk = 0; ss[slot].topDvOk = 0; ss[slot].secOk = 0; ss[slot].secDvOk = 0; }
       }
     }
     wave_sync();
+    if (pi + 1 < P) {                                                    // next point's rows, in flight while this one is processed
+      flN = u_u(a.hfl[p0 + pi + 1]); lfN = u_u(a.hfr[p0 + pi + 1]);
+#pragma unroll
+      for (int k = 0; k < SPW; k++) { const int slot = wg_slot(wave, k); if (slot < 2 * LV) vN[k] = u_u2(visR[(uint64_t)(pi + 1) * (2 * LV) + slot]); }
+    }
     float depVal = 0.f;
     if (!ind) {                                                          // an end point: its anchor's value, once every wave has been through its start points
       bool any = false;
 #pragma unroll
       for (int k = 0; k < SPW; k++) any |= act[k];
       if (!any) continue;
-      const unsigned long long tw0 = a.dbg ? clock64() : 0;
+      const unsigned long long tw0 = DBG ? clock64() : 0;
       if (lane == 0) {
         const int need = rank[pi];
         depVal = a.fval[f0 + lf];
@@ -1055,40 +1175,43 @@ __global__ void __launch_bounds__(64 * WG_NW) sdp_process_wg(ProcArgs a) {
           if (key && depVal < v) depVal = v;
         }
       }
-      if (a.dbg) tSlot[3] += clock64() - tw0;
+      if (DBG) tSlot[3] += clock64() - tw0;
     }
     if (ind) {
 #pragma unroll
       for (int k = 0; k < SPW; k++) {
-        const int slot = wg_slot(wave, k);
-        e0[k].b = -1; e0[k].val = 0; e0[k].v = 0; top0[k] = make_int2(0, 0); lastB0[k] = make_int2(0, 0);
-        if (act[k]) {
-          const Node& nd = ss[slot].cn;
-          e0[k] = ent[nd.dBase + nd.nD + vv[k].y];
-          top0[k] = ss[slot].cTop; lastB0[k] = ss[slot].cLastB;
-          if (!ss[slot].cTopOk && nd.sTop > 0) { top0[k] = pairs[nd.stkOff + nd.sTop - 1]; lastB0[k] = nd.nBlk > 0 ? pairs[nd.blkOff + nd.nBlk - 1] : make_int2(0, 0); }
-        }
+        e0[k].b = -1; e0[k].val = 0; e0[k].v = 0;
+        if (act[k]) { const Node& nd = ss[wg_slot(wave, k)].cn; e0[k] = ent[u_u(nd.dBase) + u_u(nd.nD) + vv[k].y]; }   // (the slots' loads are independent: one round)
       }
     }
     float wBest = -2.f; int wRank = 0;                                   // this wave's best candidate of the point and its visit rank
-#pragma unroll
+    // (one copy of the visit's code for all of the wave's slots: the kernel is several times the instruction cache as it is)
+#pragma unroll 1
     for (int k = 0; k < SPW; k++) {
       const int slot = wg_slot(wave, k);
       if (slot >= 2 * LV) continue;
-      const uint2 v = vv[k];
-      if (!act[k]) continue;
-      const unsigned long long ts0 = a.dbg ? clock64() : 0;
-      const Node nd = ss[slot].cn;
+      const uint2 v = k == 0 ? vv[0] : k == 1 ? vv[1] : vv[SPW - 1];
+      const Ent e0k = k == 0 ? e0[0] : k == 1 ? e0[1] : e0[SPW - 1];
+      if (!(k == 0 ? act[0] : k == 1 ? act[1] : act[SPW - 1])) continue;
+      const unsigned long long ts0 = DBG ? clock64() : 0;
+      SlotState& Z = ss[slot];
+      Node nd;
+      { const Node& zn = Z.cn; nd.dBase = u_u(zn.dBase); nd.nD = u_u(zn.nD); nd.nE = u_u(zn.nE); nd.last = u_i(zn.last); nd.sTop = u_u(zn.sTop); nd.nBlk = u_u(zn.nBlk); nd.stkOff = u_u(zn.stkOff);
+        nd.blkOff = u_u(zn.blkOff); nd.stkCap = u_u(zn.stkCap); nd.blkCap = u_u(zn.blkCap); nd.eLast = u_ll(zn.eLast); }
       if (ind == 0) {                                                    // PassValueToD1/D2
         if (lane == 0) {
           const float val = depVal;
           const uint32_t e = nd.dBase + v.y;
-          if (ent[e].v < val) { ent[e].v = val; Ap[e] = lf; }
+          if (ent[e].v < val) {
+            ent[e].v = val; Ap[e] = lf;
+            if (Z.cTopOk && Z.cTop.x == (int)v.y) Z.topDvOk = 0;         // the cached Dv of the stack top (of the pair below it) is stale now
+            if (Z.cTopOk && Z.secOk && Z.sec.x == (int)v.y) Z.secDvOk = 0;
+          }
         }
         continue;
       }
-      const int now = e0[k].b, dbn = __float_as_int(e0[k].v);
-      const long long ei1 = e0[k].val;
+      const int now = u_i(e0k.b), dbn = u_i(__float_as_int(e0k.v));
+      const long long ei1 = u_ll(e0k.val);
       const bool need = now != -1;
       const int m = (int)nd.nD, n = (int)nd.nE, i1 = (int)v.y;
       int oTop = (int)nd.sTop, oBlk = (int)nd.nBlk;
@@ -1097,28 +1220,50 @@ __global__ void __launch_bounds__(64 * WG_NW) sdp_process_wg(ProcArgs a) {
       int oSCap = (int)nd.stkCap, oBCap = (int)nd.blkCap;
       const Ent* oD = ent + nd.dBase;
       const Ent* oE = oD + m;
-      int2 otop = top0[k], olastB = lastB0[k];
+      const long long* oEd = Ed + nd.dBase;
+      const long long eLast = nd.eLast;
       uint32_t ost = 0;
       const int on = n;
+      // the stack top and the pair below it, with what is known about them
+      int2 otop = make_int2(0, 0), olastB = make_int2(0, 0), sec = make_int2(0, 0);
+      bool tInfo = false, tDvOk = false, secOk = false, secDvOk = false;
+      float tDv = 0.f, secDv = 0.f; long long tDi = 0, tEi = 0, secDi = 0, secEi = 0;
+      if (need) {
+        if (u_i(Z.cTopOk)) {
+          otop = u_i2(Z.cTop); olastB = u_i2(Z.cLastB); tInfo = u_i(Z.topInfoOk) != 0; tDvOk = u_i(Z.topDvOk) != 0; tDv = u_f(Z.topDv); tDi = u_ll(Z.topDi); tEi = u_ll(Z.topEi);
+          secOk = u_i(Z.secOk) != 0; sec = u_i2(Z.sec); secDi = u_ll(Z.secDi); secEi = u_ll(Z.secEi); secDvOk = u_i(Z.secDvOk) != 0; secDv = u_f(Z.secDv);
+        } else if (oTop > 0) { otop = u_i2(oS[oTop - 1]); olastB = oBlk > 0 ? u_i2(oB[oBlk - 1]) : make_int2(0, 0); }
+      }
+      // Di / Ei[y - 1] (and Dv) of a pair: the two loads are independent
+#define PAIR_INFO(pr_, di_, ei_, dv_) do { const Ent d__ = oD[(pr_).x]; long long e__ = 0; if ((pr_).y >= 1 && (pr_).y <= on) e__ = oE[(pr_).y - 1].val; (di_) = u_ll(d__.val); (dv_) = u_f(d__.v); (ei_) = u_ll(e__); } while (0)
+      // the pair at stack position oTop - 1 after a pop: the remembered second pair, the dummy at position 0, or memory
+#define NEXT_DOWN(pr_, infoOk_, di_, ei_, dv_, dvOk_) do { if (secOk) { (pr_) = sec; (di_) = secDi; (ei_) = secEi; (infoOk_) = true; (dv_) = secDv; (dvOk_) = secDvOk; secOk = false; secDvOk = false; } \
+                                               else if (oTop - 1 == 0) { (pr_) = make_int2(-1, on + 1); (infoOk_) = true; (di_) = 0; (ei_) = 0; (dvOk_) = false; } \
+                                               else { (pr_) = u_i2(oS[oTop - 1]); (infoOk_) = false; (dvOk_) = false; } } while (0)
 #define SPUSH(val_) do { const int2 v__ = (val_); if (oTop >= oSCap) { if (coop_grow_pairs(pairs, oStkOff, oSCap, oTop, poolUsed, poolPair, poolPairs, lane)) oS = pairs + oStkOff; else ost |= LRA_ST_CAPACITY; } \
-                         if (oTop < oSCap) oS[oTop] = v__; oTop++; } while (0)
+                         if (oTop < oSCap) oS[oTop] = v__; oTop++; if (DBG) { const unsigned long long t0__ = clock64(); __builtin_amdgcn_s_waitcnt(0); tStore += clock64() - t0__; } } while (0)
 #define BPUSH(val_) do { const int2 v__ = (val_); if (oBlk >= oBCap) { if (coop_grow_pairs(pairs, oBlkOff, oBCap, oBlk, poolUsed, poolPair, poolPairs, lane)) oB = pairs + oBlkOff; else ost |= LRA_ST_CAPACITY; } \
-                         if (oBlk < oBCap) oB[oBlk] = v__; oBlk++; olastB = v__; } while (0)
+                         if (oBlk < oBCap) oB[oBlk] = v__; oBlk++; olastB = v__; if (DBG) { const unsigned long long t0__ = clock64(); __builtin_amdgcn_s_waitcnt(0); tStore += clock64() - t0__; } } while (0)
+      unsigned long long tq = 0;
+      if (DBG) { __builtin_amdgcn_s_waitcnt(0); tq = clock64(); tSec[0] += tq - ts0; }
       if (need && now > nd.last) {                                       // Maximization :275-328, the whole wave
         const int olast = nd.last, onow = now;
-        bool topD = false; float tDv = 0; long long tDi = 0;
         bool stop = false;
         for (int i0 = olast + 1; i0 <= onow && !stop && !ost; i0 += 64) {
           const int j = i0 + lane;
           Ent dj; dj.val = 0; dj.b = -1; dj.v = 0;
           long long ej = 0;
-          if (j <= onow) { dj = oD[j]; if (dj.b != -1) ej = oE[dj.b].val; }
+          const unsigned long long tl0 = DBG ? clock64() : 0;
+          if (j <= onow) { dj = oD[j]; ej = oEd[j]; }                    // Di / Db / Dv and Ei[Db] of 64 candidates: one round
+          if (DBG) { __builtin_amdgcn_s_waitcnt(0); tSlot[2] += clock64() - tl0; tRounds++; }
           const int nb = min(64, onow - i0 + 1);
           int t = 0;
           while (t < nb && !ost) {
+            const unsigned long long te0 = DBG ? clock64() : 0;
             if (otop.y != on + 1) {
               if (otop.x < 0) { ost |= LRA_ST_OOB_SLOT; break; }
-              if (!topD) { const Ent e = oD[otop.x]; tDv = e.v; tDi = e.val; topD = true; }
+              if (!tInfo) { PAIR_INFO(otop, tDi, tEi, tDv); tInfo = true; tDvOk = true; }
+              else if (!tDvOk) { tDv = u_f(oD[otop.x].v); tDvOk = true; }
               bool evt = false;
               if (lane >= t && lane < nb)
                 evt = dj.b == -1 || (oTop > 1 && dj.b >= otop.y) || (dj.v + W(dj.val, ej) > tDv + W(tDi, ej));
@@ -1129,25 +1274,38 @@ __global__ void __launch_bounds__(64 * WG_NW) sdp_process_wg(ProcArgs a) {
             const int i = i0 + t;
             const int db = rl_i(dj.b, t);
             if (db == -1) { stop = true; break; }
+            unsigned long long te1 = 0;
+            if (DBG) { tEvents++; te1 = clock64(); tEvA += te1 - te0; }
             const long long di = rl_ll(dj.val, t), edb = rl_ll(ej, t);
             const float dvi = rl_f(dj.v, t);
-            if (otop.y == on + 1) { BPUSH(make_int2(-1, db)); SPUSH(make_int2(i, on)); otop = make_int2(i, on); tDv = dvi; tDi = di; topD = true; }
-            while (oTop > 1 && db >= otop.y) { BPUSH(otop); oTop--; otop = oS[oTop - 1]; topD = false; }
+            if (otop.y == on + 1) {                                      // :280-285 (the top is the dummy: position 0)
+              BPUSH(make_int2(-1, db)); SPUSH(make_int2(i, on));
+              sec = otop; secOk = true; secDi = 0; secEi = 0; secDvOk = false;
+              otop = make_int2(i, on); tDv = dvi; tDi = di; tEi = on >= 1 ? eLast : 0; tInfo = true; tDvOk = true;
+            }
+            while (oTop > 1 && db >= otop.y) {                           // :286-290
+              BPUSH(otop); oTop--;
+              NEXT_DOWN(otop, tInfo, tDi, tEi, tDv, tDvOk);
+            }
             if (otop.x < 0) { ost |= LRA_ST_OOB_SLOT; break; }
-            if (!topD) { const Ent e = oD[otop.x]; tDv = e.v; tDi = e.val; topD = true; }
-            if (dvi + W(di, edb) > tDv + W(tDi, edb)) {
+            if (!tInfo) { PAIR_INFO(otop, tDi, tEi, tDv); tInfo = true; tDvOk = true; }
+            else if (!tDvOk) { tDv = u_f(oD[otop.x].v); tDvOk = true; }
+            unsigned long long te2 = 0;
+            if (DBG) { te2 = clock64(); tEvB += te2 - te1; }
+            if (dvi + W(di, edb) > tDv + W(tDi, edb)) {                   // :292
               if (db < otop.y && oBlk > 0 && db > olastB.y) BPUSH(make_int2(otop.x, db));
-              int2 cur = otop; float cDv = tDv; long long cDi = tDi; int prevY = cur.y;
-              while (oTop > 0) {
+              int2 cur = otop; float cDv = tDv; long long cDi = tDi, cEi = tEi; bool cInfo = true, cDvOk = true; int prevY = cur.y;
+              long long prevEi = tEi;                                     // Ei[prevY - 1]: the new pair's boundary is prevY whenever the search range is empty
+              while (oTop > 0) {                                          // :299-306
                 if (cur.x < 0 || cur.y < 1) { ost |= LRA_ST_OOB_SLOT; break; }
-                const long long e = oE[cur.y - 1].val;
-                if (!(dvi + W(di, e) > cDv + W(cDi, e))) break;
-                oTop--; prevY = cur.y;
+                if (!(dvi + W(di, cEi) > cDv + W(cDi, cEi))) break;
+                oTop--; prevY = cur.y; prevEi = cEi;
                 if (oTop == 0) { ost |= LRA_ST_OOB_SLOT; break; }
-                cur = oS[oTop - 1];
+                NEXT_DOWN(cur, cInfo, cDi, cEi, cDv, cDvOk);
                 if (cur.y == on + 1) break;
                 if (cur.x < 0) { ost |= LRA_ST_OOB_SLOT; break; }
-                const Ent ce = oD[cur.x]; cDv = ce.v; cDi = ce.val;
+                if (!cInfo) { PAIR_INFO(cur, cDi, cEi, cDv); cInfo = true; cDvOk = true; }
+                else if (!cDvOk) { cDv = u_f(oD[cur.x].v); cDvOk = true; }
               }
               if (ost) break;
               unsigned h;
@@ -1156,49 +1314,61 @@ __global__ void __launch_bounds__(64 * WG_NW) sdp_process_wg(ProcArgs a) {
                 h = coop_search((unsigned)prevY, (unsigned)cur.y - (unsigned)prevY, lane,
                                 [&](unsigned it) { const long long e = oE[it].val; return dvi + W(di, e) > dvb + W(dib, e); });
               } else h = (unsigned)on;
-              SPUSH(make_int2(i, (int)h)); otop = make_int2(i, (int)h); tDv = dvi; tDi = di; topD = true;
+              SPUSH(make_int2(i, (int)h));
+              // the pair below the new top is cur; it keeps its Di / Ei[y - 1] if they are known (the dummy has none)
+              sec = cur; secOk = cur.x == -1 || cInfo; secDi = cDi; secEi = cEi; secDv = cDv; secDvOk = cur.x != -1 && cInfo && cDvOk;
+              otop = make_int2(i, (int)h); tDv = dvi; tDi = di; tInfo = true; tDvOk = true;
+              tEi = (int)h == on ? (on >= 1 ? eLast : 0) : (int)h == prevY ? prevEi : ((int)h >= 1 ? u_ll(oE[(int)h - 1].val) : 0);
             }
+            if (DBG) tEvC += clock64() - te2;
             t++;
           }
         }
       }
       // phase 2 (every lane the same values): the flush of Maximization :330-343, FindValueInBlock :224-236 with a wave-cooperative UPPERbound
       float ev = -2.f;
+      if (DBG) { __builtin_amdgcn_s_waitcnt(0); const unsigned long long t1 = clock64(); tSec[1] += t1 - tq; tq = t1; }
       if (need && !ost) {
-        if (now == m - 1) { while (oTop > 1 && otop.y != on + 1 && !ost) { BPUSH(otop); oTop--; otop = oS[oTop - 1]; } }
-        else { while (oTop > 1 && dbn >= otop.y && !ost) { BPUSH(otop); oTop--; otop = oS[oTop - 1]; } }
+        if (now == m - 1) { while (oTop > 1 && otop.y != on + 1 && !ost) { BPUSH(otop); oTop--; NEXT_DOWN(otop, tInfo, tDi, tEi, tDv, tDvOk); } }
+        else { while (oTop > 1 && dbn >= otop.y && !ost) { BPUSH(otop); oTop--; NEXT_DOWN(otop, tInfo, tDi, tEi, tDv, tDvOk); } }
         int i2 = -1;
         if (!ost && oBlk > 0) {
           if (i1 >= olastB.y && i1 < otop.y) i2 = otop.x;
           else {
-            const int2* Bc = oB;
-            const unsigned lo = coop_search(0u, (unsigned)oBlk, lane, [&](unsigned it) { return i1 >= Bc[it].y; });   // UPPERbound :205-221
-            if ((int)lo < oBlk) i2 = oB[lo].x;
+            int bx;
+            const unsigned lo = coop_upper_block(oB, (unsigned)oBlk, i1, lane, &bx);   // UPPERbound :205-221, Block[lo].first with it
+            if ((int)lo < oBlk) i2 = bx;
           }
         }
+        if (DBG) { __builtin_amdgcn_s_waitcnt(0); const unsigned long long t1 = clock64(); tSec[2] += t1 - tq; tq = t1; }
         if (ost || i2 < 0 || i2 >= m) ost |= ost ? ost : LRA_ST_OOB_SLOT;
         else {
-          const Ent d2 = oD[i2];
-          ev = d2.v + W(d2.val, ei1) + rate * a.flen[f0 + lf];
+          float d2v; long long d2d;
+          if (i2 == otop.x && tInfo && tDvOk) { d2v = tDv; d2d = tDi; }
+          else { const Ent d2 = oD[i2]; d2v = u_f(d2.v); d2d = u_ll(d2.val); if (i2 == otop.x && tInfo) { tDv = d2v; tDvOk = true; } }
+          ev = u_f(d2v + W(d2d, ei1) + rate * a.flen[f0 + lf]);
           if (lane == 0) {
             Ap[nd.dBase + nd.nD + i1] = (uint32_t)i2;
             Node* np = nodes + v.x;
             np->last = now; np->sTop = (uint32_t)oTop; np->nBlk = (uint32_t)oBlk;
             if (oStkOff != nd.stkOff) { np->stkOff = oStkOff; np->stkCap = (uint32_t)oSCap; }
             if (oBlkOff != nd.blkOff) { np->blkOff = oBlkOff; np->blkCap = (uint32_t)oBCap; }
-            SlotState& Z = ss[slot];
             Z.cn.last = now; Z.cn.sTop = (uint32_t)oTop; Z.cn.nBlk = (uint32_t)oBlk; Z.cn.stkOff = oStkOff; Z.cn.blkOff = oBlkOff; Z.cn.stkCap = (uint32_t)oSCap; Z.cn.blkCap = (uint32_t)oBCap;
             Z.cTop = otop; Z.cLastB = olastB; Z.cTopOk = 1;
+            Z.topInfoOk = tInfo ? 1 : 0; Z.topDvOk = (tInfo && tDvOk) ? 1 : 0; Z.topDv = tDv; Z.topDi = tDi; Z.topEi = tEi;
+            Z.secOk = secOk ? 1 : 0; Z.sec = sec; Z.secDi = secDi; Z.secEi = secEi; Z.secDv = secDv; Z.secDvOk = (secOk && secDvOk) ? 1 : 0;
           }
         }
       }
 #undef SPUSH
 #undef BPUSH
+#undef PAIR_INFO
+#undef NEXT_DOWN
       if (ost && lane == 0) s_bad = s_bad | ost;
       // Value[ii]: visits apply in the order R family deepest level first, then C family; `val < Ev` keeps the first maximum
       const int vr = (slot / LV) * LV + (LV - 1 - slot % LV);
       if (ev > 0.f && (ev > wBest || (ev == wBest && vr < wRank))) { wBest = ev; wRank = vr; }
-      if (a.dbg) tSlot[k] += clock64() - ts0;
+      if (DBG) { __builtin_amdgcn_s_waitcnt(0); const unsigned long long t1 = clock64(); if (k == 0) tSlot[0] += t1 - ts0; else if (k == 1) tSlot[1] += t1 - ts0; else tSlot[2] += t1 - ts0; tSec[3] += t1 - tq; }
     }
     wave_sync();
     if (ind && lane == 0) {
@@ -1213,7 +1383,7 @@ __global__ void __launch_bounds__(64 * WG_NW) sdp_process_wg(ProcArgs a) {
       (void)__hip_atomic_fetch_add(&cnt[2 * lf + x], one, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
   }
-  if (a.dbg && lane == 0) { for (int x = 0; x < 4; x++) dbgT[4 * wave + x] = tSlot[x]; }
+  if (DBG && lane == 0) { for (int x = 0; x < 4; x++) { dbgT[8 * wave + x] = tSlot[x]; dbgT[8 * wave + 4 + x] = tSec[x]; } dbgT[8 * wave + 4] = (tRounds << 32) | tEvents; dbgT[8 * wave + 7] = tStore; dbgT[8 * wave + 0] = tEvA; dbgT[8 * wave + 1] = tEvB; dbgT[8 * wave + 2] = tEvC; }
   __syncthreads();
   // Value[], prev: per anchor the start points in order, `val < Ev` (strict) at each
   if (!s_bad) {
@@ -1261,8 +1431,8 @@ __global__ void k_pred(uint64_t f0, uint64_t n, int r0, const uint32_t* __restri
   const uint32_t pn = fprevNode[g], pi = fprevInd[g];
   if (!status[r] && pn != NONE && pi != NONE) {
     const ReadArena A = ra[(int)r - r0];
-    const Node* nodesR = (const Node*)(uintptr_t)A.base;
-    const uint32_t* apR = (const uint32_t*)((const char*)(uintptr_t)A.base + A.apOff);
+    const Node* nodesR = (const Node*)arena_ptr(A.base);
+    const uint32_t* apR = (const uint32_t*)(arena_ptr(A.base) + A.apOff);
     const Node nd = nodesR[pn];
     pred = apR[nd.dBase + apR[nd.dBase + nd.nD + pi]];
   }
@@ -1463,6 +1633,18 @@ int sdp_run(lra_ctx* ctx, int n_reads, const uint64_t* d_cluster_off, const uint
     }
     pw.c1 = opts->gapCeiling1; pw.c2 = opts->gapCeiling2;
   }
+  // -w as a table for small distances (the kernels copy it to LDS); left out when a penalty does not fit 16 bits
+  short* d_penTab = (short*)lra_ensure(ctx, 190, PEN_TAB_WG * sizeof(short) + 64);
+  int penN = 0;
+  if (d_penTab) {
+    int* d_bad = (int*)(d_penTab + PEN_TAB_WG);
+    LRA_HIP_CHECK(ctx, hipMemsetAsync(d_bad, 0, 4, st));
+    hipLaunchKernelGGL(k_pen_table, dim3(PEN_TAB_WG / 256), dim3(256), 0, st, pw, PEN_TAB_WG, d_penTab, d_bad);
+    int h_bad = 1;
+    LRA_HIP_CHECK(ctx, hipMemcpyAsync(&h_bad, d_bad, 4, hipMemcpyDeviceToHost, st));
+    LRA_HIP_CHECK(ctx, hipStreamSynchronize(st));
+    if (!h_bad) penN = PEN_TAB_WG;
+  }
   std::vector<uint64_t> h_off(n1);
   LRA_HIP_CHECK(ctx, hipMemcpyAsync(h_off.data(), d_cluster_off, n1 * 8, hipMemcpyDeviceToHost, st));
   LRA_HIP_CHECK(ctx, hipStreamSynchronize(st));
@@ -1539,6 +1721,37 @@ int sdp_run(lra_ctx* ctx, int n_reads, const uint64_t* d_cluster_off, const uint
     hipLaunchKernelGGL(k_frag_read, dim3(n_reads), dim3(64), 0, st, n_reads, fragOff, fragRead);
     lra_time_end(ctx);
   }
+  if (const char* dumpPath = getenv("LRA_SDP_DUMP")) {                     // analysis hook (tools/sdp_case_stats.py): the inputs of the call's largest jobs + all job sizes
+    static int callNo = 0;
+    const int topK = getenv("LRA_SDP_DUMP_TOP") ? atoi(getenv("LRA_SDP_DUMP_TOP")) : 8;
+    LRA_HIP_CHECK(ctx, hipStreamSynchronize(st));
+    std::vector<uint32_t> idx(n_reads);
+    for (int i = 0; i < n_reads; i++) idx[i] = (uint32_t)i;
+    std::partial_sort(idx.begin(), idx.begin() + std::min(topK, n_reads), idx.end(), [&](uint32_t x, uint32_t y) { return h_frag[x + 1] - h_frag[x] > h_frag[y + 1] - h_frag[y]; });
+    std::string pth = std::string(dumpPath) + ".call" + std::to_string(callNo) + (ctx->sdp_inner ? "i" : "") + ".bin";
+    if (FILE* f = fopen(pth.c_str(), "wb")) {
+      for (int k = 0; k < std::min(topK, n_reads); k++) {
+        const uint32_t r = idx[k];
+        const uint64_t a0 = h_frag[r], n = h_frag[r + 1] - a0;
+        if (n == 0) continue;
+        std::vector<uint32_t> q(n), t(n), cl(n); std::vector<int32_t> ln(n); std::vector<uint8_t> sd(n);
+        (void)hipMemcpy(q.data(), fq + a0, n * 4, hipMemcpyDeviceToHost); (void)hipMemcpy(t.data(), ft + a0, n * 4, hipMemcpyDeviceToHost);
+        (void)hipMemcpy(ln.data(), flen + a0, n * 4, hipMemcpyDeviceToHost); (void)hipMemcpy(cl.data(), fcl + a0, n * 4, hipMemcpyDeviceToHost);
+        (void)hipMemcpy(sd.data(), fstrand + a0, n, hipMemcpyDeviceToHost);
+        std::vector<int32_t> coff; std::vector<uint8_t> cst;
+        for (uint64_t i = 0; i < n; i++) if (i == 0 || cl[i] != cl[i - 1]) { coff.push_back((int32_t)i); cst.push_back(sd[i]); }
+        coff.push_back((int32_t)n);
+        int hdr[4] = {opts->mode, (int)cst.size(), (int)n, 30000};
+        float rate = opts->rate;
+        fwrite(hdr, 4, 4, f); fwrite(&rate, 4, 1, f); fwrite(coff.data(), 4, coff.size(), f); fwrite(cst.data(), 1, cst.size(), f);
+        fwrite(q.data(), 4, n, f); fwrite(t.data(), 4, n, f); fwrite(ln.data(), 4, n, f);
+      }
+      fclose(f);
+    }
+    pth = std::string(dumpPath) + ".call" + std::to_string(callNo) + (ctx->sdp_inner ? "i" : "") + ".sizes";
+    if (FILE* f = fopen(pth.c_str(), "wb")) { fwrite(h_pt.data(), 8, n1, f); fclose(f); }
+    callNo++;
+  }
   struct Retag { lra_ctx* c; Retag(lra_ctx* x) : c(x) { c->sort_tag = c->sdp_inner ? "sdp_inner_sort" : "sdp_sort"; c->sort_fb_tag = c->sdp_inner ? "sdp_inner_sort_fallback" : "sdp_sort_fallback"; } ~Retag() { c->sort_tag = "sort"; c->sort_fb_tag = "sort_fallback"; } } retag(ctx);
   // the two point orders: (q, t, ind) / (t, q, ind) keys repeat only where two anchors share a corner, so the radix path takes nearly all lists
   { int rc = lra_sort_mostly_unique_batch(ctx, n_reads, ptOff, NP, key1, pay1, key3, pay3, 64); if (rc) return rc; }   // sort(H1, SortByRowOp)  :2171
@@ -1575,12 +1788,12 @@ int sdp_run(lra_ctx* ctx, int n_reads, const uint64_t* d_cluster_off, const uint
     const uint64_t cp = h_pt[r1] - h_pt[r0];
     if (cp == 0) { r0 = r1; continue; }
     const size_t nr1 = (size_t)nr + 1;
-    size_t needS = sz(34 * cp + 64 * (size_t)nr + 64, 4) + sz(nr1, 4) * 7 + sz(nr1 + 1, 8) * 3 + sz(nr1, sizeof(ReadArena)) + 4096;
+    size_t needS = sz(34 * cp + 64 * (size_t)nr + 64, 4) + sz(nr1, 4) * 8 + sz(nr1 + 1, 8) * 3 + sz(nr1, sizeof(ReadArena)) + 4096;
     char* ws = (char*)lra_ensure(ctx, 10, needS);
     if (!ws) return LRA_ERR_NOMEM;
     uint32_t* scratch = (uint32_t*)take(ws, 34 * cp + 64 * (size_t)nr + 64, 4);
     uint32_t* cntE = (uint32_t*)take(ws, nr1, 4); uint32_t* cntN = (uint32_t*)take(ws, nr1, 4); uint32_t* cntD = (uint32_t*)take(ws, nr1, 4);
-    uint32_t* cntV = (uint32_t*)take(ws, nr1, 4); uint32_t* order = (uint32_t*)take(ws, nr1, 4); uint32_t* order2 = (uint32_t*)take(ws, nr1, 4); uint32_t* poolUsed = (uint32_t*)take(ws, nr1, 4);
+    uint32_t* cntV = (uint32_t*)take(ws, nr1, 4); uint32_t* cntRC = (uint32_t*)take(ws, nr1, 4); uint32_t* order = (uint32_t*)take(ws, nr1, 4); uint32_t* order2 = (uint32_t*)take(ws, nr1, 4); uint32_t* poolUsed = (uint32_t*)take(ws, nr1, 4);
     std::vector<uint32_t> h_orderAll, h_prev;
     {
       std::vector<uint32_t> h_order(nr);
@@ -1598,7 +1811,7 @@ int sdp_run(lra_ctx* ctx, int n_reads, const uint64_t* d_cluster_off, const uint
     BuildArgs ba;
     memset(&ba, 0, sizeof ba);
     ba.r0 = r0; ba.n = nr; ba.ptOff = ptOff; ba.hq = hq; ba.ht = ht; ba.hfl = hfl; ba.h2 = pay2; ba.key3 = key1; ba.pay3 = pay1; ba.scratch = scratch;
-    ba.cntEntries = cntE; ba.cntNodes = cntN; ba.cntD = cntD; ba.cntV = cntV; ba.status = status; ba.order = order;
+    ba.cntEntries = cntE; ba.cntNodes = cntN; ba.cntD = cntD; ba.cntV = cntV; ba.cntRC = cntRC; ba.status = status; ba.order = order;
     lra_time_begin(ctx, ctx->sdp_inner ? "sdp_inner_build_count" : "sdp_build_count");
     {
       // reads ordered largest first: the large ones get a 1024-thread workgroup each, beside the wave-per-read launch
@@ -1614,6 +1827,13 @@ int sdp_run(lra_ctx* ctx, int n_reads, const uint64_t* d_cluster_off, const uint
     { int rc = lra_exclusive_scan<uint32_t>(ctx, nr, cntE, entOff); if (rc) return rc; }
     uint64_t totE = 0;
     LRA_HIP_CHECK(ctx, hipMemcpyAsync(&totE, entOff + nr, 8, hipMemcpyDeviceToHost, st));
+    uint32_t maxRC = 0;                                                    // over the chunk's reads: which sdp_process_wg variant serves its large reads
+    {
+      std::vector<uint32_t> h_rc(nr);
+      LRA_HIP_CHECK(ctx, hipMemcpyAsync(h_rc.data(), cntRC, (size_t)nr * 4, hipMemcpyDeviceToHost, st));
+      LRA_HIP_CHECK(ctx, hipStreamSynchronize(st));
+      for (uint32_t v : h_rc) maxRC = std::max(maxRC, v);
+    }
     // attempt 0: all reads of the chunk; attempts 1, 2: the reads whose candidate stack / Block outgrew its slots, with 8x / 64x the slots
     std::vector<uint32_t> h_status(nr), h_sub;
     uint32_t* subOrder = order;
@@ -1653,7 +1873,7 @@ int sdp_run(lra_ctx* ctx, int n_reads, const uint64_t* d_cluster_off, const uint
       uint64_t dbgOff0 = 0; char* dbgBase = nullptr;
       pa.r0 = r0; pa.n = nsub; pa.order = subOrder; pa.ptOff = ptOff; pa.fragOff = fragOff; pa.hfl = hfl; pa.hfr = hfr; pa.flen = flen; pa.fval = fval;
       pa.fprevNode = fprevNode; pa.fprevInd = fprevInd; pa.fflags = fflags; pa.rate_in = d_rate; pa.rate = opts->rate; pa.ra = ra;
-      pa.status = status; pa.pwl = pw; pa.poolUsed = poolUsed;
+      pa.status = status; pa.pwl = pw; pa.poolUsed = poolUsed; pa.penTab = d_penTab; pa.penN = penN;
       LRA_HIP_CHECK(ctx, hipMemsetAsync(poolUsed, 0, (size_t)nr * 4, st));
       static const bool dbg = getenv("LRA_SDP_DBG") != nullptr;
       hipEvent_t e0 = nullptr, e1 = nullptr;
@@ -1667,7 +1887,7 @@ int sdp_run(lra_ctx* ctx, int n_reads, const uint64_t* d_cluster_off, const uint
         for (int i = 0; i < nbig; i++) {
           const uint64_t rdx = (uint64_t)r0 + ord[i];
           const uint64_t Fr = h_frag[rdx + 1] - h_frag[rdx], Pr = h_pt[rdx + 1] - h_pt[rdx];
-          woff[i + 1] = woff[i] + ((36 * Fr + Pr + 64 + 8 + 64 * 8 + 255) & ~(uint64_t)255);
+          woff[i + 1] = woff[i] + ((36 * Fr + Pr + 64 + 8 + 128 * 8 + 255) & ~(uint64_t)255);
         }
         char* wsc = (char*)lra_ensure(ctx, 177, woff[nbig] + 256);
         uint64_t* dwoff = (uint64_t*)lra_ensure(ctx, 178, ((size_t)nbig + 2) * 8);
@@ -1678,7 +1898,12 @@ int sdp_run(lra_ctx* ctx, int n_reads, const uint64_t* d_cluster_off, const uint
         dbgOff0 = woff[0] + 36 * (h_frag[(uint64_t)r0 + ord[0] + 1] - h_frag[(uint64_t)r0 + ord[0]]) + (h_pt[(uint64_t)r0 + ord[0] + 1] - h_pt[(uint64_t)r0 + ord[0]]); dbgBase = wsc;
       }
       const bool forked = nbig > 0 && nsub > nbig;
-      if (nbig > 0) hipLaunchKernelGGL(sdp_process_wg, dim3(nbig), dim3(64 * WG_NW), 0, forked ? lra_side_fork(ctx) : st, pa);
+      if (nbig > 0) {
+        // (levels used = ceil(log2(lines)) + 1: up to 2^15 distinct rows and columns stay within levels 0..15)
+        hipStream_t ws = forked ? lra_side_fork(ctx) : st;
+        if (maxRC <= 32768) { if (dbg) hipLaunchKernelGGL((sdp_process_wg<2, true>), dim3(nbig), dim3(64 * WG_NW), 0, ws, pa); else hipLaunchKernelGGL((sdp_process_wg<2, false>), dim3(nbig), dim3(64 * WG_NW), 0, ws, pa); }
+        else { if (dbg) hipLaunchKernelGGL((sdp_process_wg<3, true>), dim3(nbig), dim3(64 * WG_NW), 0, ws, pa); else hipLaunchKernelGGL((sdp_process_wg<3, false>), dim3(nbig), dim3(64 * WG_NW), 0, ws, pa); }
+      }
       if (nsub > nbig) { ProcArgs pb = pa; pb.order = subOrder + nbig; pb.n = nsub - nbig; hipLaunchKernelGGL(sdp_process, dim3(nsub - nbig), dim3(64), 0, st, pb); }
       if (forked) lra_side_join(ctx);
       lra_time_end(ctx);
@@ -1691,11 +1916,12 @@ int sdp_run(lra_ctx* ctx, int n_reads, const uint64_t* d_cluster_off, const uint
                 (unsigned long long)tot, (unsigned long long)mx, ms);
         (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
         if (dbgBase && nbig > 0) {                                         // the largest read's waves: cycles in each slot and waiting at end points
-          std::vector<unsigned long long> tw(64);
+          std::vector<unsigned long long> tw(128);
           const uint64_t o8 = (dbgOff0 + 7) & ~(uint64_t)7;
-          (void)hipMemcpy(tw.data(), dbgBase + o8, 64 * 8, hipMemcpyDeviceToHost);
+          (void)hipMemcpy(tw.data(), dbgBase + o8, 128 * 8, hipMemcpyDeviceToHost);
           for (int w = 0; w < 16; w++)
-            fprintf(stderr, "[sdp]   wave %2d: slot cycles %10llu %10llu %10llu  waiting %10llu\n", w, tw[4 * w], tw[4 * w + 1], tw[4 * w + 2], tw[4 * w + 3]);
+            fprintf(stderr, "[sdp]   wave %2d: event loop: choose %10llu to-compare %10llu compare+win %10llu  waiting %10llu | scan rounds %8llu events %8llu maximization %10llu flush+search %10llu push-store drain %10llu\n", w,
+                    tw[8 * w], tw[8 * w + 1], tw[8 * w + 2], tw[8 * w + 3], tw[8 * w + 4] >> 32, tw[8 * w + 4] & 0xffffffffULL, tw[8 * w + 5], tw[8 * w + 6], tw[8 * w + 7]);
         }
       }
       if (att == 2) break;

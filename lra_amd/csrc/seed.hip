@@ -901,6 +901,21 @@ static bool regrow(T*& p, size_t n) {
   return hipMalloc((void**)&p, n * sizeof(T) + 64) == hipSuccess;
 }
 
+// a loader on a context that borrows its reference data: the borrowed pointers are dropped (they belong to the owner), the context owns what it loads from here on
+static void seed_disown(lra_seed_state* s) {
+  if (!s->borrowed) return;
+  s->genome = nullptr; s->genome_len = 0; s->idx_key = nullptr; s->idx_pos = nullptr; s->n_idx = 0; s->dir = nullptr; s->nbuckets = 0; s->dir_shift = 0;
+  s->borrowed = false; s->owner = nullptr; s->owner_generation = 0;
+}
+// LRA_OK, or LRA_ERR_INVALID when the context borrows reference data its owner has replaced since (lra_ctx_share_reference again)
+int lra_seed_check_shared(lra_ctx* ctx) {
+  const lra_seed_state* s = ctx->seed;
+  if (!s || !s->borrowed || !s->owner) return LRA_OK;
+  if (s->owner->generation != s->owner_generation)
+    return lra_set_err(ctx, LRA_ERR_INVALID, "the context this one shares its reference data with has reloaded it: call lra_ctx_share_reference again");
+  return LRA_OK;
+}
+
 void lra_seed_free(lra_ctx* ctx) {
   lra_seed_state* s = ctx->seed;
   if (!s) return;
@@ -916,6 +931,7 @@ extern "C" int lra_ctx_load_genome(lra_ctx* ctx, const char* h_seq, uint64_t len
   if (!ctx || (!h_seq && len)) return LRA_ERR_INVALID;
   LRA_HIP_CHECK(ctx, hipSetDevice(ctx->device));
   lra_seed_state* s = seed_state(ctx);
+  seed_disown(s); s->generation++;
   if (!regrow(s->genome, len + 64)) return lra_set_err(ctx, LRA_ERR_NOMEM, "genome alloc");
   s->genome_len = len;
   LRA_HIP_CHECK(ctx, hipMemcpy(s->genome, h_seq, len, hipMemcpyHostToDevice));
@@ -926,6 +942,7 @@ extern "C" int lra_ctx_load_genome(lra_ctx* ctx, const char* h_seq, uint64_t len
 // adopts device arrays (hipMalloc'ed, n + 1 entries at least) as the context's global index and builds the bucket directory over the key's top bits
 int lra_seed_install_index(lra_ctx* ctx, uint64_t* d_key, uint32_t* d_pos, uint64_t n) {
   lra_seed_state* s = seed_state(ctx);
+  seed_disown(s); s->generation++;
   if (s->idx_key) (void)hipFree(s->idx_key);
   if (s->idx_pos) (void)hipFree(s->idx_pos);
   s->idx_key = d_key; s->idx_pos = d_pos; s->n_idx = n;
@@ -963,7 +980,7 @@ int lra_seed_share(lra_ctx* dst, lra_ctx* src) {
   if (dst->seed && !dst->seed->borrowed && (dst->seed->genome || dst->seed->idx_key)) return lra_set_err(dst, LRA_ERR_INVALID, "context already holds reference data");
   lra_seed_state* d = seed_state(dst);
   const lra_seed_state* s = src->seed;
-  d->borrowed = true;
+  d->borrowed = true; d->owner = s->borrowed ? s->owner : s; d->owner_generation = s->borrowed ? s->owner_generation : s->generation;
   d->genome = s->genome; d->genome_len = s->genome_len; d->idx_key = s->idx_key; d->idx_pos = s->idx_pos; d->n_idx = s->n_idx;
   d->dir = s->dir; d->nbuckets = s->nbuckets; d->dir_shift = s->dir_shift;
   return LRA_OK;
@@ -983,6 +1000,7 @@ extern "C" int lra_ctx_load_genome_device(lra_ctx* ctx, const char* d_seq, uint6
   if (!ctx || (!d_seq && len)) return LRA_ERR_INVALID;
   LRA_HIP_CHECK(ctx, hipSetDevice(ctx->device));
   lra_seed_state* s = seed_state(ctx);
+  seed_disown(s); s->generation++;
   if (!regrow(s->genome, len + 64)) return lra_set_err(ctx, LRA_ERR_NOMEM, "genome alloc");
   s->genome_len = len;
   LRA_HIP_CHECK(ctx, hipMemcpyAsync(s->genome, d_seq, len, hipMemcpyDeviceToDevice, ctx->stream));
@@ -1107,6 +1125,7 @@ extern "C" int lra_seed_batch(lra_ctx* ctx, int n_reads, const char* d_seq, cons
   if (k < 1 || k > 32 || w < 1 || w > MAX_W) return lra_set_err(ctx, LRA_ERR_INVALID, "k must be 1..32 and w 1..%d", MAX_W);
   lra_seed_state* s = seed_state(ctx);
   if (!s->genome || !s->idx_key) return lra_set_err(ctx, LRA_ERR_INVALID, "load genome and global index first");
+  { int rcs = lra_seed_check_shared(ctx); if (rcs) return rcs; }
   LRA_HIP_CHECK(ctx, hipSetDevice(ctx->device));
   hipStream_t st = ctx->stream;
   memset(out, 0, sizeof(*out));

@@ -4,6 +4,12 @@
 
 struct lra_seed_state {
   bool borrowed = false;   // genome / index / directory belong to another context (lra_ctx_share_reference)
+  // Ownership tracking for shared reference data: an owner bumps `generation` whenever one of its loaders replaces the genome / index / directory;
+  // a borrower remembers whose data it holds and at which generation, and the batch entry points refuse to run on stale pointers (the owner
+  // reloaded: share again).  A loader called on a borrower first drops the borrowed pointers (nothing of the owner's is freed) and makes the
+  // context an owner of what it loads.
+  uint64_t generation = 0;
+  const lra_seed_state* owner = nullptr; uint64_t owner_generation = 0;
   unsigned char* genome = nullptr; uint64_t genome_len = 0;
   uint64_t* idx_key = nullptr; uint32_t* idx_pos = nullptr; uint64_t n_idx = 0;
   // batch buffers (grown on demand)

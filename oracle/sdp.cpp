@@ -41,6 +41,10 @@
 #include <utility>
 #include <vector>
 
+#ifndef SDP_STAT
+#define SDP_STAT(...)                      // tools/sdp_case_stats.cpp defines it to count the steps of Maximization / FindValueInBlock per level
+#endif
+
 namespace {
 
 typedef std::pair<long, long> LPair;
@@ -242,8 +246,9 @@ size_t upper_block(const std::vector<LPair>& B, unsigned int val) {     // UPPER
 // returns false on the reference's undefined behaviour (dereferencing Block.end() / index -1)
 bool find_value_in_block(const Sub& s, unsigned int i1, unsigned int& i2) {   // FindValueInBlock :224-236
   if (s.Block.empty() || s.S.empty()) return false;
-  if ((long)i1 >= s.Block.back().second && (long)i1 < s.S.back().second) i2 = (unsigned int)s.S.back().first;
+  if ((long)i1 >= s.Block.back().second && (long)i1 < s.S.back().second) { i2 = (unsigned int)s.S.back().first; SDP_STAT(fast, s, 1); }
   else {
+    SDP_STAT(bsearch, s, (long)s.Block.size());
     size_t it = upper_block(s.Block, i1);
     if (it == s.Block.size()) return false;
     i2 = (unsigned int)s.Block[it].first;
@@ -266,31 +271,36 @@ unsigned int find_boundary(unsigned int first, unsigned int last, unsigned int a
 void maximization(Sub& s, const Pwl& P) {               // Maximization :270-345 (now/last are the sub's members)
   unsigned int m = (unsigned int)s.Di.size(), n = (unsigned int)s.Ei.size();
   unsigned int now = s.now;
+  SDP_STAT(query, s, (long)now - s.last);
   for (unsigned int i = (unsigned int)(s.last + 1); i <= now; ++i) {
+    SDP_STAT(iter, s, 1);
     if (s.Db[i] == -1) break;
     if (s.S.back().second == (long)n + 1) {
       s.Block.push_back(LPair(-1, s.Db[i]));
       s.S.push_back(LPair(i, n));
     }
-    while (s.Db[i] >= s.S.back().second) { s.Block.push_back(s.S.back()); s.S.pop_back(); }
+    while (s.Db[i] >= s.S.back().second) { s.Block.push_back(s.S.back()); s.S.pop_back(); SDP_STAT(pop1, s, 1); }
     long l = s.S.back().first;
     if (s.Dv[i] + P.w(s.Di[i], s.Ei[s.Db[i]]) > s.Dv[l] + P.w(s.Di[l], s.Ei[s.Db[i]])) {
       if (s.Db[i] < s.S.back().second && !s.Block.empty() && s.Db[i] > s.Block.back().second) s.Block.push_back(LPair(s.S.back().first, s.Db[i]));
+      SDP_STAT(win, s, 1);
       LPair cur = s.S.back(), prev = s.S.back();
       while (!s.S.empty() && s.Dv[i] + P.w(s.Di[i], s.Ei[cur.second - 1]) > s.Dv[cur.first] + P.w(s.Di[cur.first], s.Ei[cur.second - 1])) {
         s.S.pop_back();
+        SDP_STAT(pop2, s, 1);
         prev = cur;
         cur = s.S.back();
         if (cur.second == (long)n + 1) break;
       }
+      SDP_STAT(fb, s, cur.first == -1 ? 0 : (long)cur.second - (long)prev.second);
       unsigned int h = find_boundary((unsigned int)prev.second, (unsigned int)cur.second, i, (unsigned int)cur.first, s, P);
       s.S.push_back(LPair(i, h));
     }
   }
   if (now == m - 1) {
-    while (s.S.back().second != (long)n + 1) { s.Block.push_back(s.S.back()); s.S.pop_back(); }
+    while (s.S.back().second != (long)n + 1) { s.Block.push_back(s.S.back()); s.S.pop_back(); SDP_STAT(pop3, s, 1); }
   } else {
-    while (s.Db[now + 1] >= s.S.back().second) { s.Block.push_back(s.S.back()); s.S.pop_back(); }
+    while (s.Db[now + 1] >= s.S.back().second) { s.Block.push_back(s.S.back()); s.S.pop_back(); SDP_STAT(pop3, s, 1); }
   }
   s.last = now;
 }
@@ -493,6 +503,18 @@ static int sdp_chain_impl(int nClusters, const int* clusterOff, const uint8_t* c
   int total = nClusters > 0 ? (o->mode == 2 ? nClusters : clusterOff[nClusters]) : 0;
   chainOff[0] = 0;
   if (total == 0) return 0;
+  if (const char* dump = getenv("ORACLE_SDP_DUMP")) {                      // analysis hook (tools/sdp_case_stats.py): the inputs of every call, appended
+    if (o->mode != 2) {
+      FILE* f = fopen(dump, "ab");
+      if (f) {
+        int hdr[4] = {o->mode, nClusters, total, o->readLen};
+        fwrite(hdr, 4, 4, f); fwrite(&o->rate, 4, 1, f);
+        fwrite(clusterOff, 4, nClusters + 1, f); fwrite(clusterStrand, 1, nClusters, f);
+        fwrite(q, 4, total, f); fwrite(t, 4, total, f); fwrite(len, 4, total, f);
+        fclose(f);
+      }
+    }
+  }
   Ctx c;
   c.pwl.init(o->gapopen, o->gapextend, o->gaproot, o->gapCeiling1, o->gapCeiling2);
   if (o->mode == 2) {                                                       // :1959-2018: four points per box, s1 e1 s2 e2

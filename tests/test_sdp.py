@@ -292,3 +292,34 @@ def test_hip_sdp_workgroup_kernel(ctx, which, monkeypatch):
     read_lens = [40000] * len(reads_in)
     res, out = _run_hip(ctx, reads_in, read_lens, kw)
     assert _compare(out, int(res.num_aln), reads_in, read_lens, kw) >= len(reads_in) - 1
+
+
+def _load_jobs(path):
+    """jobs written by LRA_SDP_DUMP (lra_amd/csrc/sdp.hip): header (mode, clusters, anchors, read length), rate, cluster offsets, strands, q, t, len"""
+    b = open(path, "rb").read(); at = 0; jobs = []
+    while at < len(b):
+        mode, nc, total, rl = (int(x) for x in np.frombuffer(b, np.int32, 4, at)); at += 16
+        rate = float(np.frombuffer(b, np.float32, 1, at)[0]); at += 4
+        off = np.frombuffer(b, np.int32, nc + 1, at).copy(); at += 4 * (nc + 1)
+        st = np.frombuffer(b, np.uint8, nc, at).copy(); at += nc
+        q = np.frombuffer(b, np.uint32, total, at).copy(); at += 4 * total
+        t = np.frombuffer(b, np.uint32, total, at).copy(); at += 4 * total
+        ln = np.frombuffer(b, np.int32, total, at).copy(); at += 4 * total
+        jobs.append((mode, rate, (off, st, q, t, ln)))
+    return jobs
+
+
+@pytest.mark.gpu
+def test_hip_sdp_heavy_jobs_of_the_bench(ctx):
+    """Jobs captured from the bench batch (tests/golden/sdp_heavy_jobs.bin, inputs only): the largest merged cluster of a read from a satellite array
+    (23390 anchors on the reverse strand: 46780 points, Block lists of 17 k pairs, `last` moving backwards in four queries of five), another one of
+    19812 anchors, the largest SDP#A read and the largest job of a13's inner sparse DP -- the workgroup kernel on real input, against the oracle."""
+    jobs = _load_jobs(os.path.join(os.path.dirname(__file__), "golden", "sdp_heavy_jobs.bin"))
+    assert len(jobs) == 4
+    for mode in (1, 0):
+        sel = [j for j in jobs if j[0] == mode]
+        reads_in = [j[2] for j in sel]
+        kw = dict(mode=1, rate=sel[0][1]) if mode == 1 else dict(rate=sel[0][1])
+        read_lens = [40000] * len(reads_in)
+        res, out = _run_hip(ctx, reads_in, read_lens, kw)
+        assert _compare(out, int(res.num_aln), reads_in, read_lens, kw) >= len(reads_in)
