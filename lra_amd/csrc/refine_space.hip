@@ -307,19 +307,21 @@ __global__ void __launch_bounds__(64) rs_compare(RsArgs a, int nLarge) {
   const int j = blockIdx.x, lane = threadIdx.x;
   if (j >= nLarge) return;
   const uint32_t i = a.largeIdx[j];
-  const uint64_t* tk = a.lkey + a.loff[2 * j]; const uint32_t* tp = a.lpos + a.loff[2 * j];
-  const uint64_t* qk = a.lkey + a.loff[2 * j + 1]; const uint32_t* qp = a.lpos + a.loff[2 * j + 1];
+  const uint64_t* tkG = a.lkey + a.loff[2 * j]; const uint32_t* tp = a.lpos + a.loff[2 * j];
+  const uint64_t* qkG = a.lkey + a.loff[2 * j + 1]; const uint32_t* qp = a.lpos + a.loff[2 * j + 1];
   const long nt = (long)(a.loff[2 * j + 1] - a.loff[2 * j]), nq = (long)(a.loff[2 * j + 2] - a.loff[2 * j + 1]);
-  if (nt + nq <= CMP_LDS_KEYS) {                                          // the two lists are adjacent in lkey: one copy
-    for (long x = lane; x < nt + nq; x += 64) skeys[x] = tk[x];
+  const bool staged = nt + nq <= CMP_LDS_KEYS;
+  if (staged) {                                                          // the two lists are adjacent in lkey: one copy
+    for (long x = lane; x < nt + nq; x += 64) skeys[x] = tkG[x];
     rs_wave_sync();
-    tk = skeys; qk = skeys + nt;
   }
   const RsBand bd = rs_band(a, i);
   const long maxFreq = a.maxFreqArr ? (long)a.maxFreqArr[i] : a.maxFreq;
   int4* rects = a.rects + a.loff[2 * j] + 2 * (uint64_t)j;               // nt + nq + 2 slots: every iteration of the walk emits at most one
   const long rcap = nt + nq + 2;
   uint32_t n = 0, nrect = 0;
+  // The walk, once for keys staged in LDS and once for keys left in HBM: through one pointer that may be either, every read would be a flat_load.
+  auto walk = [&](const uint64_t* tk, const uint64_t* qk) __attribute__((always_inline)) {
   auto rect = [&](long t0, long t1, long q0, long q1) {                   // ti in [t0, t1), qi in [q0, q1]
     if (nrect < rcap) { if (lane == 0) rects[nrect] = make_int4((int)t0, (int)t1, (int)q0, (int)q1); }
     else if (lane == 0) atomicOr(&a.status[i], (uint32_t)LRA_ST_CAPACITY);
@@ -406,6 +408,8 @@ __global__ void __launch_bounds__(64) rs_compare(RsArgs a, int nLarge) {
   }
 #undef Qk
 #undef Tk
+  };
+  if (staged) walk(skeys, skeys + nt); else walk(tkG, qkG);
   if (lane == 0) { a.cnt[i] = n; a.nrect[j] = nrect < rcap ? nrect : (uint32_t)rcap; }
 }
 
