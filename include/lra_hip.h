@@ -68,7 +68,7 @@ int lra_ctx_set_stream(lra_ctx* ctx, void* stream);
 const char* lra_ctx_last_error(lra_ctx* ctx);
 /* ABI version of the loaded library (tests check it against this header). */
 int lra_abi_version(void);
-#define LRA_ABI_VERSION 2   /* 2: lra_map_opts.defer_matches, lra_map_counters.n_deferred_reads */
+#define LRA_ABI_VERSION 3   /* 2: lra_map_opts.defer_matches, lra_map_counters.n_deferred_reads; 3: lra_map_opts.flagged_unaligned, lra_map_counters.n_flagged_reads, lra_map_host_flagged */
 
 /* Convenience for hosts without their own HIP binding: synchronous device->host copy on the
  * context's stream (a C++ host would call hipMemcpy itself).                                */
@@ -118,7 +118,8 @@ int lra_ctx_global_index(lra_ctx* ctx, const uint64_t** d_key, const uint32_t** 
  *         names, each NUL-terminated); the second call fills names, chrom_pos[n_chrom + 1], key[n], pos[n].
  *   .gli  LocalIndex::Write / Read (MMIndex.h:138-173): int32 k, w, localIndexWindow, nRegions = n_windows + 1; uint64 seqOffsets[nRegions];
  *         uint64 tupleBoundaries[nRegions]; uint64 nMin; nMin LocalTuples (uint32: t in the low 20 bits, pos in the high 12).
- *         lra_read_gli: first call with seq_offsets == NULL returns the sizes.                                                          */
+ *         lra_read_gli: first call with seq_offsets == NULL returns the sizes.  The filling calls of both readers take the values the sizing call
+ *         left in *n / *n_chrom / *names_len (*n_windows / *n_tuples) as the capacities of the caller's buffers and fail when the file holds more.      */
 int lra_write_mms(const char* path, int globalK, const char* const* chrom_names, const uint64_t* chrom_pos, int n_chrom, const uint64_t* key,
                   const uint32_t* pos, uint64_t n);
 int lra_read_mms(const char* path, int* globalK, uint64_t* n, int* n_chrom, uint64_t* names_len, char* names, uint64_t* chrom_pos, uint64_t* key,
@@ -941,11 +942,17 @@ typedef struct lra_map_opts {
   lra_fine_opts fine; int32_t merge_dist;                 /* high-accuracy path only: MatchesToFineClusters, MergeMatchesSameDiag */
   int32_t defer_matches;                                  /* low-accuracy path, scheduling only (results do not depend on it): a read with more refined matches than this
                                                            * after Refine_Btwnsplitchain goes on in a second, concurrent pass; 0 = one pass (the presets) */
+  int32_t flagged_unaligned;                              /* what lra_map_records* write for a read whose status word is non-zero (an LRA_ST_* condition in some stage: the
+                                                           * result is not known to equal the reference's): 0 (the presets) = an empty record, the caller re-runs those reads
+                                                           * elsewhere (counters.n_flagged_reads / lra_map_host_flagged say how many and which); 1 = the read's unaligned
+                                                           * record (output_unaligned, Mapping_ultility.h:457-463: a flag-4 line in SAM mode), so that the output keeps one
+                                                           * record per input read */
 } lra_map_opts;
 typedef struct lra_map_counters {
   uint64_t n_minimizers, n_matches, n_clusters, n_sdp_anchors, n_sdp_points, n_sdp_entries, n_local_tuples, n_local_tasks, n_local_task_words, n_local_pairs, n_refined_matches,
            n_btwn_problems, n_btwn_rounds, n_refined_after_btwn, n_merged_clusters, n_sdp2_anchors, n_sdp2_entries, n_a13_blocks, n_large_spaces, n_segments,
-           n_rows, n_cells, n_aog, n_deferred_reads;
+           n_rows, n_cells, n_aog, n_deferred_reads,
+           n_flagged_reads;                                  /* reads of the batch with a non-zero d_read_status (no alignment record is written for them) */
 } lra_map_counters;
 typedef struct lra_map_result {
   int32_t n_reads, num_aln;
@@ -1018,6 +1025,8 @@ int lra_map_records_host(lra_map_host* snap, const lra_map_opts* opts, const cha
                          const int32_t* read_len, const char* const* chrom_names, const char* passthrough, int n_threads, const char** text, uint64_t* len,
                          const uint64_t** rec_off);
 void lra_map_host_free(lra_map_host* snap);
+/* the reads of a snapshot whose status word is non-zero: their number; *status (optional) = the snapshot's status array [n_reads], owned by the snapshot */
+uint64_t lra_map_host_flagged(const lra_map_host* snap, const uint32_t** status);
 /* The record buffer of a batch as ONE device buffer -- what a rank sends to rank 0 in the single exchange step of the multi-GPU path (the
  * reference's ordered output, lra.cpp:145-166): lra_map_pack lays the same arrays out behind a 128-byte header in a context-owned buffer
  * (valid until the next pack on this context); lra_map_unpack_host turns a host copy of such a buffer (from any rank) into a snapshot for

@@ -4,7 +4,7 @@ import os
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 _LIB = None
-ABI_VERSION = 2
+ABI_VERSION = 3
 
 
 class LraError(RuntimeError):
@@ -106,6 +106,7 @@ SYMBOLS = {
     "lra_map_snapshot": (C.c_int, [_vp, _vp, C.c_int, _vp]),
     "lra_map_records_host": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, C.c_char_p, C.c_int, _vp, _vp, _vp]),
     "lra_map_host_free": (None, [_vp]),
+    "lra_map_host_flagged": (C.c_uint64, [_vp, _vp]),
     "lra_map_pack": (C.c_int, [_vp, _vp, C.c_int, _vp, _vp]),
     "lra_map_unpack_host": (C.c_int, [_vp, C.c_uint64, _vp]),
     "lra_map_records": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, C.c_char_p, _vp, C.c_uint64, _vp, _vp]),

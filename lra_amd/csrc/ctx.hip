@@ -89,8 +89,10 @@ hipStream_t lra_side_fork(lra_ctx* ctx, int i) {
     if ((ctx->low_priority ? hipStreamCreateWithPriority(&ctx->side[i], hipStreamNonBlocking, ctx->prio) : hipStreamCreateWithFlags(&ctx->side[i], hipStreamNonBlocking)) != hipSuccess) {
       ctx->side[i] = nullptr; return ctx->stream;
     }
-    if (!ctx->ev_fork) (void)hipEventCreateWithFlags(&ctx->ev_fork, hipEventDisableTiming);
-    (void)hipEventCreateWithFlags(&ctx->ev_join[i], hipEventDisableTiming);
+    // without its two events the side stream could not be ordered against the main one: fall back to the main stream, as when the stream itself cannot be made
+    if (!ctx->ev_fork && hipEventCreateWithFlags(&ctx->ev_fork, hipEventDisableTiming) != hipSuccess) ctx->ev_fork = nullptr;
+    if (ctx->ev_fork && hipEventCreateWithFlags(&ctx->ev_join[i], hipEventDisableTiming) != hipSuccess) ctx->ev_join[i] = nullptr;
+    if (!ctx->ev_fork || !ctx->ev_join[i]) { (void)hipStreamDestroy(ctx->side[i]); ctx->side[i] = nullptr; return ctx->stream; }
   }
   (void)hipEventRecord(ctx->ev_fork, ctx->stream);
   (void)hipStreamWaitEvent(ctx->side[i], ctx->ev_fork, 0);

@@ -525,24 +525,29 @@ extern "C" int lra_write_mms(const char* path, int globalK, const char* const* c
 extern "C" int lra_read_mms(const char* path, int* globalK, uint64_t* n, int* n_chrom, uint64_t* names_len, char* names, uint64_t* chrom_pos, uint64_t* key,
                             uint32_t* pos) {
   if (!path || !n || !n_chrom) return LRA_ERR_INVALID;
+  // the filling call (key != NULL) takes what the sizing call returned in *n / *n_chrom / *names_len as the capacities of the caller's buffers: a file that has
+  // changed in between (or is corrupt) is refused instead of written past them
+  const bool fill = key != nullptr;
+  const uint64_t capN = *n; const int capC = *n_chrom; const uint64_t capNames = names_len ? *names_len : 0;
   File f(path, "rb");
   if (!f.f) return LRA_ERR_INVALID;
   int64_t len = 0; int32_t K = 0, nc = 0;
-  if (!f.rd(&len, 8) || !f.rd(&K, 4) || !f.rd(&nc, 4) || len < 0 || nc < 0) return LRA_ERR_INVALID;
+  if (!f.rd(&len, 8) || !f.rd(&K, 4) || !f.rd(&nc, 4) || len < 0 || nc < 0 || nc > (1 << 24)) return LRA_ERR_INVALID;
+  if (fill && ((uint64_t)len > capN || nc > capC)) return LRA_ERR_INVALID;
   if (globalK) *globalK = K;
   *n = (uint64_t)len; *n_chrom = nc;
   uint64_t nl = 0;
   std::string all;
   for (int i = 0; i < nc; i++) {
     int32_t l = 0;
-    if (!f.rd(&l, 4) || l < 0) return LRA_ERR_INVALID;
+    if (!f.rd(&l, 4) || l < 0 || l > (1 << 20)) return LRA_ERR_INVALID;   // (a sequence name of a megabyte is a corrupt file)
     std::string s((size_t)l, '\0');
     if (!f.rd(&s[0], (size_t)l)) return LRA_ERR_INVALID;
     all += s; all.push_back('\0'); nl += (uint64_t)l + 1;
   }
   if (names_len) *names_len = nl;
   if (!key) return LRA_OK;
-  if (!pos || !chrom_pos || !names) return LRA_ERR_INVALID;
+  if (!pos || !chrom_pos || !names || !names_len || all.size() > capNames) return LRA_ERR_INVALID;
   memcpy(names, all.data(), all.size());
   if (!f.rd(chrom_pos, (size_t)(nc + 1) * 8)) return LRA_ERR_INVALID;
   std::vector<uint64_t> buf;
@@ -580,6 +585,8 @@ extern "C" int lra_read_gli(const char* path, int* k, int* w, int* window, uint6
   if (!f.rd(h, 16) || h[3] < 1) return LRA_ERR_INVALID;
   if (k) *k = h[0]; if (w) *w = h[1]; if (window) *window = h[2];
   const uint64_t nr = (uint64_t)h[3];
+  const uint64_t capW = *n_windows, capT = *n_tuples;                    // filling call: the sizing call's results = the capacities of the caller's buffers
+  if (seq_offsets && nr - 1 > capW) return LRA_ERR_INVALID;
   *n_windows = nr - 1;
   if (!seq_offsets) {
     if (fseek(f.f, (long)(16 + nr * 16), SEEK_SET) != 0) return LRA_ERR_INVALID;
@@ -590,7 +597,7 @@ extern "C" int lra_read_gli(const char* path, int* k, int* w, int* window, uint6
   }
   if (!tuple_bnd || !tuples) return LRA_ERR_INVALID;
   uint64_t nMin = 0;
-  if (!f.rd(seq_offsets, (size_t)nr * 8) || !f.rd(tuple_bnd, (size_t)nr * 8) || !f.rd(&nMin, 8) || !f.rd(tuples, (size_t)nMin * 4)) return LRA_ERR_INVALID;
+  if (!f.rd(seq_offsets, (size_t)nr * 8) || !f.rd(tuple_bnd, (size_t)nr * 8) || !f.rd(&nMin, 8) || nMin > capT || !f.rd(tuples, (size_t)nMin * 4)) return LRA_ERR_INVALID;
   *n_tuples = nMin;
   return LRA_OK;
 }

@@ -93,6 +93,9 @@ bool get_next(lra_reads* r, std::string& name, std::string& seq, std::string& qu
   name = first_token_behind_first_char(header);
   squeeze_upper(seq);
   squeeze(qual);
+  // the reference asserts qual.size() == seq.size() (Input.h: the FASTQ branch of GetNext); a record that breaks it ends the input here instead of handing the
+  // formatter a quality string shorter than the read (it would read past it)
+  if (qual.size() != seq.size()) { r->open_ok = false; return false; }
   return true;
 }
 

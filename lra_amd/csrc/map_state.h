@@ -53,6 +53,7 @@ struct lra_map_state {
   lra_text_buf last_text; std::vector<uint64_t> last_off; lra_map_sig last_sig;   // lra_map_records: sizing call -> filling call
 };
 
+int lra_map_count_flagged(lra_ctx* ctx, lra_map_result* out);   // mapread.hip: counters.n_flagged_reads of a finished batch
 int lra_map_check_shared(lra_ctx* ctx);   // mapread.hip: borrowed reference data still current?
 // RefineBreakpoint over the consecutive SegAlignments of every job (Map_lowacc.h:586-596, Map_highacc.h:723-727); mapread.hip
 int lra_refine_breakpoints(lra_ctx* ctx, uint64_t nJ, uint64_t nA, const uint64_t* d_job_aln_off, const int32_t* d_strand, const uint64_t* q_off, const int32_t* q_len,

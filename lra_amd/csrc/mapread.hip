@@ -251,6 +251,7 @@ extern "C" void lra_map_opts_preset_ont(lra_map_opts* o) {
   o->sdp.rate = 20.0f; o->sdp.NumAln = 2; o->sdp.alnthres = 0.65f; o->sdp.gapopen = 7.0f; o->sdp.gapextend = 10.0f; o->sdp.gaproot = 1.5f;
   o->sdp.gapCeiling1 = 1500; o->sdp.gapCeiling2 = 3000; o->sdp.mode = 0; o->sdp.globalK = 17;
   o->readType = LRA_READ_ONT; o->hardClip = 1; o->PrintNumAln = 1; o->printFormat = 's';
+  o->flagged_unaligned = 0;    // a flagged read gets an empty record (the caller re-runs it; counters.n_flagged_reads)
   o->defer_matches = 0;        // one pass (lra_map_reads_lowacc_batch: the second, concurrent pass is built and tested, and measured to be no gain on this device)
 }
 
@@ -681,8 +682,36 @@ static int lowacc_tail(lra_ctx* ctx, const LowaccTailIn& in, const lra_map_opts*
 // Refine_Btwnsplitchain and go on, from MergeChain, in a child context on its own lowest-priority stream and host thread BESIDE the rest of the pass; the two results
 // are merged on the device (a read's alignments do not depend on which pass computed them: tests/test_mapread.py ont-defer*).  Off in the presets: on this device it is
 // no gain at any threshold -- the repetitive reads' work is throughput that the pass's own launches already overlap, not an idle tail.
+namespace {
+__global__ void k_count_flagged(int n, const uint32_t* __restrict__ st, unsigned long long* out) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  const unsigned long long m = __ballot(i < n && st[i] != 0);
+  if ((threadIdx.x & 63) == 0 && m) atomicAdd(out, (unsigned long long)__popcll(m));
+}
+}  // namespace
+// counters.n_flagged_reads of a finished batch: the reads whose status word is non-zero get no alignment record (lra_map_records*), the caller must know how many
+int lra_map_count_flagged(lra_ctx* ctx, lra_map_result* out) {
+  out->counters.n_flagged_reads = 0;
+  if (!out->d_read_status || out->n_reads <= 0) return LRA_OK;
+  unsigned long long* d = (unsigned long long*)lra_ensure(ctx, 191, 64);
+  if (!d) return LRA_ERR_NOMEM;
+  LRA_HIP_CHECK(ctx, hipMemsetAsync(d, 0, 8, ctx->stream));
+  hipLaunchKernelGGL(k_count_flagged, dim3((out->n_reads + 255) / 256), dim3(256), 0, ctx->stream, out->n_reads, out->d_read_status, d);
+  unsigned long long h = 0;
+  LRA_HIP_CHECK(ctx, hipMemcpyAsync(&h, d, 8, hipMemcpyDeviceToHost, ctx->stream));
+  LRA_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+  out->counters.n_flagged_reads = h;
+  return LRA_OK;
+}
+
+static int lowacc_batch_impl(lra_ctx* ctx, int n_reads, const char* d_seq, const uint64_t* d_read_off, uint64_t total_bases, const lra_map_opts* o, lra_map_result* out);
 extern "C" int lra_map_reads_lowacc_batch(lra_ctx* ctx, int n_reads, const char* d_seq, const uint64_t* d_read_off, uint64_t total_bases,
                                           const lra_map_opts* o, lra_map_result* out) {
+  int rc = lowacc_batch_impl(ctx, n_reads, d_seq, d_read_off, total_bases, o, out);
+  if (rc == LRA_OK && out && n_reads > 0) rc = lra_map_count_flagged(ctx, out);
+  return rc;
+}
+static int lowacc_batch_impl(lra_ctx* ctx, int n_reads, const char* d_seq, const uint64_t* d_read_off, uint64_t total_bases, const lra_map_opts* o, lra_map_result* out) {
   if (!ctx || !o || !out || n_reads < 0) return LRA_ERR_INVALID;
   memset(out, 0, sizeof *out);
   lra_map_state* m = ctx->map;
@@ -812,6 +841,14 @@ __global__ void k_block_ends(uint64_t nA, const uint64_t* __restrict__ boff, con
 }  // namespace
 
 extern "C" void lra_map_host_free(lra_map_host* h) { delete h; }
+extern "C" uint64_t lra_map_host_flagged(const lra_map_host* h, const uint32_t** status) {
+  if (status) *status = nullptr;
+  if (!h) return 0;
+  uint64_t n = 0;
+  for (uint32_t v : h->rstat) n += v != 0;
+  if (status && !h->rstat.empty()) *status = h->rstat.data();
+  return n;
+}
 
 namespace {
 std::mutex g_pool_mu;
@@ -992,12 +1029,13 @@ extern "C" int lra_map_records_host(lra_map_host* h, const lra_map_opts* o, cons
     int rc = LRA_OK;
     for (int r = lo; r < hi; r++) {
       recs.clear(); cigars.clear(); seg_off.assign(1, 0); rcRead.clear();
-      if (!rstat.empty() && rstat[r]) { plen[tix].push_back(0); continue; }   // flagged read: no record (the caller routes it elsewhere; d_read_status)
+      const bool flagged = !rstat.empty() && rstat[r];
+      if (flagged && !o->flagged_unaligned) { plen[tix].push_back(0); continue; }   // flagged read: no record (the caller routes it elsewhere; d_read_status, lra_map_host_flagged)
       // low-accuracy path: p == 0 left no SegAlignment (Map_lowacc.h:578-581); high-accuracy path: read.unaligned or alignments.size() == 0
       // (Map_highacc.h:778-781) = no chain of the read got its SegAlignmentGroup
-      bool unaligned = nJ == 0 || jo[(size_t)r * na + 1] == jo[(size_t)r * na];
+      bool unaligned = flagged || nJ == 0 || jo[(size_t)r * na + 1] == jo[(size_t)r * na];   // (opts.flagged_unaligned: a flagged read is written as an unaligned one)
       bool sparseRead = false;                                            // the read took the REFINEclusters branch: smallOpts.globalK = glIndex.k (Map_highacc.h:430)
-      if (hi && nJ) {
+      if (hi && nJ && !flagged) {
         unaligned = true;
         for (int p = 0; p < na; p++) if (!reached.empty() && reached[(size_t)r * na + p]) { unaligned = false; sparseRead |= (reached[(size_t)r * na + p] & 2) != 0; }
       }

@@ -620,8 +620,14 @@ static int highacc_core(lra_ctx* ctx, int n_reads, const char* d_seq, const uint
   return LRA_OK;
 }
 
+static int highacc_batch_impl(lra_ctx* ctx, int n_reads, const char* d_seq, const uint64_t* d_read_off, uint64_t total_bases, const lra_map_opts* o, lra_map_result* out);
 extern "C" int lra_map_reads_highacc_batch(lra_ctx* ctx, int n_reads, const char* d_seq, const uint64_t* d_read_off, uint64_t total_bases, const lra_map_opts* o,
                                            lra_map_result* out) {
+  int rc = highacc_batch_impl(ctx, n_reads, d_seq, d_read_off, total_bases, o, out);
+  if (rc == LRA_OK && out && n_reads > 0) rc = lra_map_count_flagged(ctx, out);
+  return rc;
+}
+static int highacc_batch_impl(lra_ctx* ctx, int n_reads, const char* d_seq, const uint64_t* d_read_off, uint64_t total_bases, const lra_map_opts* o, lra_map_result* out) {
   if (!ctx || !o || !out || n_reads < 0) return LRA_ERR_INVALID;
   memset(out, 0, sizeof *out);
   lra_map_state* m = ctx->map;

@@ -97,14 +97,14 @@ class MapOpts(C.Structure):
                                           "localMatch", "localMismatch", "localIndel", "localBand", "refineSpaceDist")] +
                 [("anchorstoosparse", C.c_float), ("splitdist", C.c_int32), ("window", C.c_int32), ("second_anchorbonus", C.c_float),
                  ("bypassClustering", C.c_int32), ("skipBandedRefine", C.c_int32), ("refineBreakpoint", C.c_int32), ("clean", cluster.CleanOpts), ("sdp", chain.SdpOpts)] +
-                [(n, C.c_int32) for n in ("readType", "hardClip", "PrintNumAln", "printFormat")] + [("fine", cluster.FineOpts), ("merge_dist", C.c_int32), ("defer_matches", C.c_int32)])
+                [(n, C.c_int32) for n in ("readType", "hardClip", "PrintNumAln", "printFormat")] + [("fine", cluster.FineOpts), ("merge_dist", C.c_int32), ("defer_matches", C.c_int32), ("flagged_unaligned", C.c_int32)])
 
 
 class MapCounters(C.Structure):
     _fields_ = [(n, C.c_uint64) for n in ("n_minimizers", "n_matches", "n_clusters", "n_sdp_anchors", "n_sdp_points", "n_sdp_entries", "n_local_tuples",
                                           "n_local_tasks", "n_local_task_words", "n_local_pairs", "n_refined_matches", "n_btwn_problems", "n_btwn_rounds", "n_refined_after_btwn",
                                           "n_merged_clusters", "n_sdp2_anchors", "n_sdp2_entries", "n_a13_blocks", "n_large_spaces", "n_segments", "n_rows",
-                                          "n_cells", "n_aog", "n_deferred_reads")]
+                                          "n_cells", "n_aog", "n_deferred_reads", "n_flagged_reads")]
 
 
 class MapResult(C.Structure):

@@ -412,3 +412,39 @@ def test_map_reads_bench_like_properties(ctx, oracle):
             assert a1 - a0 == len(e), (r, p)
             for a, s in zip(range(a0, a1), e):
                 assert np.array_equal(out["blocks"][int(out["block_off"][a]):int(out["block_off"][a + 1])], s["blocks"]), (r, p)
+
+
+@pytest.mark.gpu
+def test_flagged_reads_are_counted_and_can_be_written_as_unaligned(ctx):
+    """A read whose status word is non-zero gets no alignment record: counters.n_flagged_reads / lra_map_host_flagged report it, and with
+    opts.flagged_unaligned the records keep one entry per input read (the read's unaligned record, output_unaligned)."""
+    import ctypes as C
+    import torch
+    from lra_amd import seed, mapread
+    genome = synth.make_genome(300_000, seed=41, repeat_frac=0.2, n_families=2)
+    o = mapread.LowAccOptions()
+    ik, ip = synth.build_global_index(genome, o.globalK, o.globalW, 100)
+    reads, _ = synth.simulate_reads(genome, 5, 5000, 1000, 0.10, seed=9)
+    mapper = mapread.LowAccMapper(ctx, genome, ik, ip, [b"chr1"], [0, len(genome)], o)
+    batch = seed.ReadBatch(ctx, [r.tobytes() for r in reads])
+    names = [b"r%d" % i for i in range(len(reads))]
+    res = mapper.align(batch)
+    assert int(res.counters.n_flagged_reads) == 0
+    base = mapper.records(res, names, [r.tobytes() for r in reads])
+    assert all(len(x) > 0 and x.split(b"\t")[1] != b"4" for x in base)
+    # flag read 2 the way a stage would (LRA_ST_CAPACITY = 8) on the device
+    one = torch.tensor([8], dtype=torch.int32, device=ctx.device)
+    ctx.check(ctx.lib.lra_copy_device(ctx.h, C.c_void_p(res.d_read_status + 2 * 4), C.c_void_p(one.data_ptr()), C.c_uint64(4)))
+    torch.cuda.synchronize()
+    snap = mapper.snapshot(res)
+    st = C.POINTER(C.c_uint32)()
+    assert ctx.lib.lra_map_host_flagged(snap, C.byref(st)) == 1 and [st[i] for i in range(5)] == [0, 0, 8, 0, 0]
+    args = mapper.record_args(names, [r.tobytes() for r in reads])
+    out0 = mapper.records_host(snap, args, free=False)
+    assert out0[2] == b"" and [out0[i] for i in (0, 1, 3, 4)] == [base[i] for i in (0, 1, 3, 4)]
+    mapper.copts.flagged_unaligned = 1
+    out1 = mapper.records_host(snap, args, free=True)
+    mapper.copts.flagged_unaligned = 0
+    f = out1[2].split(b"\t")
+    assert f[0] == b"r2" and f[1] == b"4" and out1[2].count(b"\n") == 1
+    assert [out1[i] for i in (0, 1, 3, 4)] == [base[i] for i in (0, 1, 3, 4)]
