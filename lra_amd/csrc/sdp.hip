@@ -636,6 +636,17 @@ __device__ __forceinline__ float pwl_w_tab(const short* tab, int n, const float*
   if (d < (long long)n) { const int xi = (int)d; return xi == 0 ? 0.f : -(float)(int)tab[xi]; }   // (x == 1: w returns +0, SubRountine.h:125)
   return pwl_w(slope, inter, c1, c2, i, j);
 }
+// a + w(x, e) > b + w(y, e) -- the comparison Maximization / FindBoundary make (SubRountine.h:253, :292, :299) -- with the two table reads issued together (one LDS
+// round trip instead of two: the wave walks these one after the other)
+__device__ __forceinline__ bool pwl_beats(const short* tab, int n, const float* slope, const float* inter, int c1, int c2, float a, long long x, float b, long long y, long long e) {
+  const long long d1 = e > x ? e - x : x - e, d2 = e > y ? e - y : y - e;
+  const bool in1 = d1 < (long long)n, in2 = d2 < (long long)n;
+  const int x1 = in1 ? (int)d1 : 0, x2 = in2 ? (int)d2 : 0;
+  const int p1 = tab[x1], p2 = tab[x2];
+  const float w1 = in1 ? (x1 == 0 ? 0.f : -(float)p1) : pwl_w(slope, inter, c1, c2, x, e);
+  const float w2 = in2 ? (x2 == 0 ? 0.f : -(float)p2) : pwl_w(slope, inter, c1, c2, y, e);
+  return a + w1 > b + w2;
+}
 __global__ void k_pen_table(PwlTab pw, int n, short* tab, int* bad) {
   const int d = blockIdx.x * blockDim.x + threadIdx.x;
   if (d >= n) return;
@@ -775,6 +786,7 @@ __global__ void __launch_bounds__(64, 4) sdp_process(ProcArgs a) {
   __syncthreads();
   const int c1 = a.pwl.c1, c2 = a.pwl.c2;
 #define W(i, j) pwl_w_tab(s_pen, penN, s_slope, s_inter, c1, c2, (i), (j))
+#define BEATS(a_, x_, b_, y_, e_) pwl_beats(s_pen, penN, s_slope, s_inter, c1, c2, (a_), (x_), (b_), (y_), (e_))
   const int rr = (int)a.order[blockIdx.x], r = a.r0 + rr;
   const uint64_t p0 = a.ptOff[r], f0 = a.fragOff[r];
   const int P = (int)(a.ptOff[r + 1] - p0);
@@ -854,13 +866,13 @@ __global__ void __launch_bounds__(64, 4) sdp_process(ProcArgs a) {
           while (sTop > 1 && db >= top.y) { BPUSHL(top); sTop--; top = S[sTop - 1]; topD = false; }
           if (top.x < 0) { st |= LRA_ST_OOB_SLOT; break; }
           if (!topD) { const Ent e = D[top.x]; tDv = e.v; tDi = e.val; topD = true; }
-          if (dvi + W(di, edb) > tDv + W(tDi, edb)) {
+          if (BEATS(dvi, di, tDv, tDi, edb)) {
             if (db < top.y && nBlk > 0 && db > lastB.y) BPUSHL(make_int2(top.x, db));
             int2 cur = top; float cDv = tDv; long long cDi = tDi; int prevY = cur.y;
             while (sTop > 0) {
               if (cur.x < 0 || cur.y < 1) { st |= LRA_ST_OOB_SLOT; break; }
               const long long e = E[cur.y - 1].val;
-              if (!(dvi + W(di, e) > cDv + W(cDi, e))) break;
+              if (!(BEATS(dvi, di, cDv, cDi, e))) break;
               sTop--; prevY = cur.y;
               if (sTop == 0) { st |= LRA_ST_OOB_SLOT; break; }
               cur = S[sTop - 1];
@@ -876,7 +888,7 @@ __global__ void __launch_bounds__(64, 4) sdp_process(ProcArgs a) {
               while (count > 0) {
                 const unsigned step = count / 2, it = first + step;
                 const long long e = E[it].val;
-                if (dvi + W(di, e) > cDv + W(cDi, e)) { first = it + 1; count -= step + 1; } else count = step;
+                if (BEATS(dvi, di, cDv, cDi, e)) { first = it + 1; count -= step + 1; } else count = step;
               }
             }
             SPUSHL(make_int2(i, (int)first)); top = make_int2(i, (int)first); tDv = dvi; tDi = di; topD = true;
@@ -921,7 +933,7 @@ __global__ void __launch_bounds__(64, 4) sdp_process(ProcArgs a) {
               if (!topD) { const Ent e = oD[otop.x]; tDv = e.v; tDi = e.val; topD = true; }
               bool evt = false;
               if (lane >= t && lane < nb)
-                evt = dj.b == -1 || (oTop > 1 && dj.b >= otop.y) || (dj.v + W(dj.val, ej) > tDv + W(tDi, ej));
+                evt = dj.b == -1 || (oTop > 1 && dj.b >= otop.y) || (BEATS(dj.v, dj.val, tDv, tDi, ej));
               const unsigned long long em = __ballot(evt);
               if (!em) break;
               t = __ffsll((long long)em) - 1;
@@ -935,13 +947,13 @@ __global__ void __launch_bounds__(64, 4) sdp_process(ProcArgs a) {
             while (oTop > 1 && db >= otop.y) { BPUSH(otop); oTop--; otop = oS[oTop - 1]; topD = false; }                                         // :286-290
             if (otop.x < 0) { ost |= LRA_ST_OOB_SLOT; break; }
             if (!topD) { const Ent e = oD[otop.x]; tDv = e.v; tDi = e.val; topD = true; }
-            if (dvi + W(di, edb) > tDv + W(tDi, edb)) {                   // :292
+            if (BEATS(dvi, di, tDv, tDi, edb)) {                   // :292
               if (db < otop.y && oBlk > 0 && db > olastB.y) BPUSH(make_int2(otop.x, db));
               int2 cur = otop; float cDv = tDv; long long cDi = tDi; int prevY = cur.y;
               while (oTop > 0) {                                          // :299-306
                 if (cur.x < 0 || cur.y < 1) { ost |= LRA_ST_OOB_SLOT; break; }
                 const long long e = oE[cur.y - 1].val;
-                if (!(dvi + W(di, e) > cDv + W(cDi, e))) break;
+                if (!(BEATS(dvi, di, cDv, cDi, e))) break;
                 oTop--; prevY = cur.y;
                 if (oTop == 0) { ost |= LRA_ST_OOB_SLOT; break; }
                 cur = oS[oTop - 1];
@@ -954,7 +966,7 @@ __global__ void __launch_bounds__(64, 4) sdp_process(ProcArgs a) {
               if (cur.x != -1) {
                 const float dvb = cDv; const long long dib = cDi;
                 h = coop_search((unsigned)prevY, (unsigned)cur.y - (unsigned)prevY, lane,
-                                [&](unsigned it) { const long long e = oE[it].val; return dvi + W(di, e) > dvb + W(dib, e); });
+                                [&](unsigned it) { const long long e = oE[it].val; return BEATS(dvi, di, dvb, dib, e); });
               } else h = (unsigned)on;
               SPUSH(make_int2(i, (int)h)); otop = make_int2(i, (int)h); tDv = dvi; tDi = di; topD = true;
             }
@@ -1031,6 +1043,7 @@ __global__ void __launch_bounds__(64, 4) sdp_process(ProcArgs a) {
   }
   if (lane == 0 && bad) atomicOr(&a.status[r], bad);
 #undef W
+#undef BEATS
 }
 
 // ---- the same for LARGE reads: one 1024-thread workgroup per read, the (family pair, level) slots spread over its 16 waves.
@@ -1088,6 +1101,7 @@ __global__ void __launch_bounds__(64 * WG_NW) sdp_process_wg(ProcArgs a) {
   __syncthreads();
   const int c1 = a.pwl.c1, c2 = a.pwl.c2;
 #define W(i, j) pwl_w_tab(s_pen, penN, s_slope, s_inter, c1, c2, (i), (j))
+#define BEATS(a_, x_, b_, y_, e_) pwl_beats(s_pen, penN, s_slope, s_inter, c1, c2, (a_), (x_), (b_), (y_), (e_))
   const int rr = (int)a.order[blockIdx.x], r = a.r0 + rr;
   const uint64_t p0 = a.ptOff[r], f0 = a.fragOff[r];
   const int P = (int)(a.ptOff[r + 1] - p0);
@@ -1266,7 +1280,7 @@ __global__ void __launch_bounds__(64 * WG_NW) sdp_process_wg(ProcArgs a) {
               else if (!tDvOk) { tDv = u_f(oD[otop.x].v); tDvOk = true; }
               bool evt = false;
               if (lane >= t && lane < nb)
-                evt = dj.b == -1 || (oTop > 1 && dj.b >= otop.y) || (dj.v + W(dj.val, ej) > tDv + W(tDi, ej));
+                evt = dj.b == -1 || (oTop > 1 && dj.b >= otop.y) || (BEATS(dj.v, dj.val, tDv, tDi, ej));
               const unsigned long long em = __ballot(evt);
               if (!em) break;
               t = __ffsll((long long)em) - 1;
@@ -1292,13 +1306,13 @@ __global__ void __launch_bounds__(64 * WG_NW) sdp_process_wg(ProcArgs a) {
             else if (!tDvOk) { tDv = u_f(oD[otop.x].v); tDvOk = true; }
             unsigned long long te2 = 0;
             if (DBG) { te2 = clock64(); tEvB += te2 - te1; }
-            if (dvi + W(di, edb) > tDv + W(tDi, edb)) {                   // :292
+            if (BEATS(dvi, di, tDv, tDi, edb)) {                   // :292
               if (db < otop.y && oBlk > 0 && db > olastB.y) BPUSH(make_int2(otop.x, db));
               int2 cur = otop; float cDv = tDv; long long cDi = tDi, cEi = tEi; bool cInfo = true, cDvOk = true; int prevY = cur.y;
               long long prevEi = tEi;                                     // Ei[prevY - 1]: the new pair's boundary is prevY whenever the search range is empty
               while (oTop > 0) {                                          // :299-306
                 if (cur.x < 0 || cur.y < 1) { ost |= LRA_ST_OOB_SLOT; break; }
-                if (!(dvi + W(di, cEi) > cDv + W(cDi, cEi))) break;
+                if (!(BEATS(dvi, di, cDv, cDi, cEi))) break;
                 oTop--; prevY = cur.y; prevEi = cEi;
                 if (oTop == 0) { ost |= LRA_ST_OOB_SLOT; break; }
                 NEXT_DOWN(cur, cInfo, cDi, cEi, cDv, cDvOk);
@@ -1312,7 +1326,7 @@ __global__ void __launch_bounds__(64 * WG_NW) sdp_process_wg(ProcArgs a) {
               if (cur.x != -1) {
                 const float dvb = cDv; const long long dib = cDi;
                 h = coop_search((unsigned)prevY, (unsigned)cur.y - (unsigned)prevY, lane,
-                                [&](unsigned it) { const long long e = oE[it].val; return dvi + W(di, e) > dvb + W(dib, e); });
+                                [&](unsigned it) { const long long e = oE[it].val; return BEATS(dvi, di, dvb, dib, e); });
               } else h = (unsigned)on;
               SPUSH(make_int2(i, (int)h));
               // the pair below the new top is cur; it keeps its Di / Ei[y - 1] if they are known (the dummy has none)
@@ -1407,6 +1421,7 @@ __global__ void __launch_bounds__(64 * WG_NW) sdp_process_wg(ProcArgs a) {
   }
   if (tid == 0 && s_bad) atomicOr(&a.status[r], (uint32_t)s_bad);
 #undef W
+#undef BEATS
 }
 
 // ---- value order, TraceBack, DecidePrimaryChains ------------------------------------------------------------------------
