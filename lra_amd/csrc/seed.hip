@@ -424,19 +424,20 @@ __global__ void __launch_bounds__(64) sort_kernel(int n_reads, const uint64_t* _
 // it equals a stable insertion sort of every leftover block on its own.
 constexpr int SORT_NT = 1024;
 constexpr int SORT_NW = SORT_NT / 64;
-constexpr unsigned short S_NONE = 0xFFFF;
 
-struct LdsSeg {                     // (key, original index) pairs in LDS
-  uint64_t* k; unsigned short* p;
+template <typename IT>
+struct LdsSeg {                     // (key, original index) pairs in LDS (or, for the larger size classes, in a per-workgroup global scratch)
+  uint64_t* k; IT* p;
   __device__ __forceinline__ bool lt(int a, int b) const { return (k[a] & FOR_MASK) < (k[b] & FOR_MASK); }
   __device__ __forceinline__ void swap(int a, int b) {
     uint64_t tk = k[a]; k[a] = k[b]; k[b] = tk;
-    unsigned short tp = p[a]; p[a] = p[b]; p[b] = tp;
+    IT tp = p[a]; p[a] = p[b]; p[b] = tp;
   }
   __device__ __forceinline__ void mv(int dst, int src) { k[dst] = k[src]; p[dst] = p[src]; }
 };
 
-__device__ void lds_adjust_heap(LdsSeg& s, int first, int hole, int len, uint64_t vk, unsigned short vp) {
+template <typename IT>
+__device__ void lds_adjust_heap(LdsSeg<IT>& s, int first, int hole, int len, uint64_t vk, IT vp) {
   const int top = hole;
   int child = hole;
   while (child < (len - 1) / 2) {
@@ -459,12 +460,13 @@ __device__ void lds_adjust_heap(LdsSeg& s, int first, int hole, int len, uint64_
   s.k[first + hole] = vk; s.p[first + hole] = vp;
 }
 
-__device__ void lds_heap_sort(LdsSeg& s, int first, int last) {
+template <typename IT>
+__device__ void lds_heap_sort(LdsSeg<IT>& s, int first, int last) {
   int len = last - first;
   if (len >= 2) {
     int parent = (len - 2) / 2;
     while (true) {
-      uint64_t vk = s.k[first + parent]; unsigned short vp = s.p[first + parent];
+      uint64_t vk = s.k[first + parent]; IT vp = s.p[first + parent];
       lds_adjust_heap(s, first, parent, len, vk, vp);
       if (parent == 0) break;
       parent--;
@@ -472,68 +474,89 @@ __device__ void lds_heap_sort(LdsSeg& s, int first, int last) {
   }
   while (last - first > 1) {
     --last;
-    uint64_t vk = s.k[last]; unsigned short vp = s.p[last];
+    uint64_t vk = s.k[last]; IT vp = s.p[last];
     s.mv(last, first);
     lds_adjust_heap(s, first, 0, last - first, vk, vp);
   }
 }
 
-__device__ void lds_insertion_sort(LdsSeg& s, int first, int last) {   // == __insertion_sort on an isolated block
+template <typename IT>
+__device__ void lds_insertion_sort(LdsSeg<IT>& s, int first, int last) {   // == __insertion_sort on an isolated block
   for (int i = first + 1; i < last; ++i) {
-    uint64_t vk = s.k[i]; unsigned short vp = s.p[i];
+    uint64_t vk = s.k[i]; IT vp = s.p[i];
     int j = i;
     while (j > first && (vk & FOR_MASK) < (s.k[j - 1] & FOR_MASK)) { s.mv(j, j - 1); --j; }
     s.k[j] = vk; s.p[j] = vp;
   }
 }
 
-// BIG: the same algorithm for lists of up to 65534 tuples (beyond the LDS capacity; the value order of a large read's sparse-DP fragments, the point
+// MODE 1 (BIG): the same algorithm for lists of up to 65534 tuples (beyond the LDS capacity; the value order of a large read's sparse-DP fragments, the point
 // lists of a large read, the k-mer lists of a 30 kb gap): the element arrays live in a per-workgroup global scratch, only the segment tables stay in
 // LDS; it takes the lists the LDS kernel flagged and clears the flag of those it sorted.
-template <bool BIG>
+// MODE 2 (HUGE): lists beyond that (a 1 Mb assembly contig has ~180 k minimizers; one lane per list with the literal introsort took 19.9 of the 24.3 s of a
+// 256-contig -CONTIG batch): 32-bit indices, the segment tables in the global scratch as well, the prefix counts as two 32-bit halves of a 64-bit word.
+// MODE 1 also reports what it had to leave behind (stat[0] = the longest such list, stat[1] = how many), so that the host sizes MODE 2's scratch and
+// launches it -- and the one-lane-per-list kernel behind it -- only when there is something to do.
+template <int MODE> struct SortTypes { typedef unsigned short IT; typedef uint32_t TT; };
+template <> struct SortTypes<2> { typedef uint32_t IT; typedef uint64_t TT; };
+// bytes of per-workgroup global scratch for lists of up to cap tuples (MODE 1: elements only; MODE 2: elements + tables + start bits)
+__host__ __device__ inline size_t sort_scratch_bytes(int mode, size_t cap) {
+  const size_t isz = mode == 2 ? 4 : 2, maxseg = (cap / 16 + 8 + 1) & ~(size_t)1;
+  size_t b = cap * 8 + 4 * cap * isz + 64;
+  if (mode == 2) b += 10 * maxseg * isz + (cap / 32 + 2) * 4 + 64;
+  return (b + 255) & ~(size_t)255;
+}
+template <int MODE>
 __global__ void __launch_bounds__(SORT_NT) sort_wg_kernel(int n_reads, const uint64_t* __restrict__ mm_off, uint64_t* mm_key, uint32_t* mm_pos,
-                                                        uint32_t* tscratch, int cap, int* __restrict__ fallback,
-                                                        const int* __restrict__ only, char* gscr) {
+                                                        void* tscratch, int cap, int* __restrict__ fallback,
+                                                        const int* __restrict__ only, char* gscr, int* stat) {
+  constexpr bool BIG = MODE >= 1, HUGE = MODE == 2;
+  typedef typename SortTypes<MODE>::IT IT;
+  typedef typename SortTypes<MODE>::TT TT;
+  constexpr IT S_NONE = (IT)~(IT)0;
+  constexpr int HB = HUGE ? 32 : 16;                                      // bits per half of a prefix word
+  constexpr TT HM = (TT)(((TT)1 << HB) - 1);
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int maxseg = (cap / 16 + 8 + 1) & ~1;                            // even: the word array behind the ten tables stays 4-byte aligned
-  char* ebase = BIG ? gscr + (size_t)blockIdx.x * ((size_t)cap * 16 + 64) : smem;
+  char* ebase = BIG ? gscr + (size_t)blockIdx.x * sort_scratch_bytes(MODE, (size_t)cap) : smem;
   uint64_t* key = (uint64_t*)ebase;
-  unsigned short* idx = (unsigned short*)(key + cap);
-  unsigned short* seg = idx + cap;
-  unsigned short* pa = seg + cap;
-  unsigned short* pb = pa + cap;
-  unsigned short* sF = BIG ? (unsigned short*)smem : pb + cap;            // segment tables (current)
-  unsigned short* sL = sF + maxseg;
-  unsigned short* sD = sL + maxseg;
-  unsigned short* nF = sD + maxseg;         // next level
-  unsigned short* nL = nF + maxseg;
-  unsigned short* nD = nL + maxseg;
-  unsigned short* sCut = nD + maxseg;
-  unsigned short* sLid = sCut + maxseg;
-  unsigned short* sRid = sLid + maxseg;
-  unsigned short* sM = sRid + maxseg;
+  IT* idx = (IT*)(key + cap);
+  IT* seg = idx + cap;
+  IT* pa = seg + cap;
+  IT* pb = pa + cap;
+  IT* sF = HUGE ? pb + cap : BIG ? (IT*)smem : pb + cap;                  // segment tables (current)
+  IT* sL = sF + maxseg;
+  IT* sD = sL + maxseg;
+  IT* nF = sD + maxseg;         // next level
+  IT* nL = nF + maxseg;
+  IT* nD = nL + maxseg;
+  IT* sCut = nD + maxseg;
+  IT* sLid = sCut + maxseg;
+  IT* sRid = sLid + maxseg;
+  IT* sM = sRid + maxseg;
   unsigned int* startBits = (unsigned int*)(sM + maxseg + (maxseg & 1));   // leftover-block start markers, cap/32+1 words
   __shared__ int cnt[4];                    // nseg, nnext
   __shared__ unsigned int waveTot[2 * SORT_NW];
-  uint32_t* t32 = tscratch + (size_t)blockIdx.x * (size_t)(cap + 64);
-  LdsSeg S{key, idx};
+  TT* t32 = (TT*)tscratch + (size_t)blockIdx.x * (size_t)(cap + 64);
+  LdsSeg<IT> S{key, idx};
   for (int r = blockIdx.x; r < n_reads; r += gridDim.x) {
     const long base = (long)mm_off[r];
     const int n = (int)(mm_off[r + 1] - mm_off[r]);
     if (n < 2) continue;
     if (BIG) {
-      if (!fallback[r] || n > cap) continue;                              // (every thread reads the flag before anyone clears it: the barrier below)
+      if (!fallback[r]) continue;                                         // (every thread reads the flag before anyone clears it: the barrier below)
+      if (n > cap) { if (MODE == 1 && stat && tid == 0) { atomicMax(&stat[0], n); atomicAdd(&stat[1], 1); } continue; }
     } else {
       if (only && !only[r]) continue;
       if (n > cap) { if (tid == 0) fallback[r] = 1; continue; }
     }
     __syncthreads();
     if (BIG && tid == 0) fallback[r] = 0;
-    for (int p = tid; p < n; p += SORT_NT) { key[p] = mm_key[base + p]; idx[p] = (unsigned short)p; seg[p] = 0; }
+    for (int p = tid; p < n; p += SORT_NT) { key[p] = mm_key[base + p]; idx[p] = (IT)p; seg[p] = 0; }
     for (int x = tid; x < cap / 32 + 1; x += SORT_NT) startBits[x] = 0;
     if (tid == 0) {
-      if (n > 16) { sF[0] = 0; sL[0] = (unsigned short)n; sD[0] = (unsigned short)(2 * (31 - __clz(n))); cnt[0] = 1; }
+      if (n > 16) { sF[0] = 0; sL[0] = (IT)n; sD[0] = (IT)(2 * (31 - __clz(n))); cnt[0] = 1; }
       else cnt[0] = 0;
       cnt[1] = 0;
     }
@@ -543,7 +566,7 @@ __global__ void __launch_bounds__(SORT_NT) sort_wg_kernel(int n_reads, const uin
     while (nseg > 0) {
       // (a) depth check / median of three -> pivot at `first`
       for (int s = tid; s < nseg; s += SORT_NT) {
-        const int first = sF[s], last = sL[s];
+        const int first = (int)sF[s], last = (int)sL[s];
         sM[s] = 0;
         if (sD[s] == 0) { lds_heap_sort(S, first, last); sM[s] = S_NONE; continue; }
         sD[s] = sD[s] - 1;
@@ -564,8 +587,8 @@ __global__ void __launch_bounds__(SORT_NT) sort_wg_kernel(int n_reads, const uin
       auto flags = [&](int p, bool& A, bool& B) {
         A = false; B = false;
         if (p < n) {
-          const unsigned short sg = seg[p];
-          if (sg != S_NONE && sM[sg] != S_NONE && p != sF[sg]) {
+          const IT sg = seg[p];
+          if (sg != S_NONE && sM[sg] != S_NONE && p != (int)sF[sg]) {
             const uint64_t piv = key[sF[sg]] & FOR_MASK, km = key[p] & FOR_MASK;
             A = km >= piv; B = km <= piv;
           }
@@ -585,64 +608,64 @@ __global__ void __launch_bounds__(SORT_NT) sort_wg_kernel(int n_reads, const uin
         const int p = rw * 64 + lane;
         bool A, B; flags(p, A, B);
         const unsigned long long mA = __ballot(A), mB = __ballot(B);
-        if (p <= n) t32[p] = ((baseA + __popcll(mA & below)) & 0xFFFF) | ((baseB + __popcll(mB & below)) << 16);
+        if (p <= n) t32[p] = ((TT)(baseA + __popcll(mA & below)) & HM) | ((TT)(baseB + __popcll(mB & below)) << HB);
         baseA += __popcll(mA); baseB += __popcll(mB);
       }
-      if (wave == SORT_NW - 1 && lane == 0 && (n & 63) == 0) t32[n] = (baseA & 0xFFFF) | (baseB << 16);   // prefix at n when n is a row boundary
+      if (wave == SORT_NW - 1 && lane == 0 && (n & 63) == 0) t32[n] = ((TT)baseA & HM) | ((TT)baseB << HB);   // prefix at n when n is a row boundary
       __syncthreads();
       // (c) scatter stopper positions: pa ascending, pb descending, both stored from first+1
       for (int p = tid; p < n; p += SORT_NT) {
         bool A, B; flags(p, A, B);
         if (A || B) {
-          const int sg = seg[p], b0 = sF[sg] + 1;
-          const unsigned int t = t32[p], tb = t32[b0], te = t32[sL[sg]];
-          if (A) pa[b0 + (((t & 0xFFFF) - (tb & 0xFFFF)) & 0xFFFF)] = (unsigned short)p;
-          if (B) pb[b0 + (((te >> 16) - (t >> 16) - 1) & 0xFFFF)] = (unsigned short)p;
+          const int sg = (int)seg[p], b0 = (int)sF[sg] + 1;
+          const TT t = t32[p], tb = t32[b0], te = t32[sL[sg]];
+          if (A) pa[b0 + (int)(((t & HM) - (tb & HM)) & HM)] = (IT)p;
+          if (B) pb[b0 + (int)(((te >> HB) - (t >> HB) - 1) & HM)] = (IT)p;
         }
       }
       __syncthreads();
       // (d) m = number of leading pairs with a_i < b_i
       for (int p = tid; p < n; p += SORT_NT) {
-        const unsigned short sg = seg[p];
+        const IT sg = seg[p];
         if (sg == S_NONE || sM[sg] == S_NONE) continue;
-        const int b0 = sF[sg] + 1, i = p - b0;
+        const int b0 = (int)sF[sg] + 1, i = p - b0;
         if (i < 0) continue;
-        const unsigned int tb = t32[b0], te = t32[sL[sg]];
-        const int nA = ((te & 0xFFFF) - (tb & 0xFFFF)) & 0xFFFF, nB = ((te >> 16) - (tb >> 16)) & 0xFFFF;
+        const TT tb = t32[b0], te = t32[sL[sg]];
+        const int nA = (int)(((te & HM) - (tb & HM)) & HM), nB = (int)(((te >> HB) - (tb >> HB)) & HM);
         const int lim = min(nA, nB);
-        if (i < lim && pa[b0 + i] < pb[b0 + i] && !(i + 1 < lim && pa[b0 + i + 1] < pb[b0 + i + 1])) sM[sg] = (unsigned short)(i + 1);
+        if (i < lim && pa[b0 + i] < pb[b0 + i] && !(i + 1 < lim && pa[b0 + i + 1] < pb[b0 + i + 1])) sM[sg] = (IT)(i + 1);
       }
       __syncthreads();
       // (e) the swaps
       for (int p = tid; p < n; p += SORT_NT) {
-        const unsigned short sg = seg[p];
+        const IT sg = seg[p];
         if (sg == S_NONE || sM[sg] == S_NONE) continue;
-        const int b0 = sF[sg] + 1, i = p - b0;
-        if (i >= 0 && i < sM[sg]) S.swap(pa[b0 + i], pb[b0 + i]);
+        const int b0 = (int)sF[sg] + 1, i = p - b0;
+        if (i >= 0 && i < (int)sM[sg]) S.swap(pa[b0 + i], pb[b0 + i]);
       }
       __syncthreads();
       // (f) cut -> children
       for (int s = tid; s < nseg; s += SORT_NT) {
-        const int first = sF[s], last = sL[s];
-        if (sM[s] == S_NONE) { sCut[s] = (unsigned short)last; sLid[s] = S_NONE; sRid[s] = S_NONE; continue; }   // heap sorted: finished
-        const int b0 = first + 1, m = sM[s];
-        const unsigned int tb = t32[b0], te = t32[last];
-        const int nA = ((te & 0xFFFF) - (tb & 0xFFFF)) & 0xFFFF;
+        const int first = (int)sF[s], last = (int)sL[s];
+        if (sM[s] == S_NONE) { sCut[s] = (IT)last; sLid[s] = S_NONE; sRid[s] = S_NONE; continue; }   // heap sorted: finished
+        const int b0 = first + 1, m = (int)sM[s];
+        const TT tb = t32[b0], te = t32[last];
+        const int nA = (int)(((te & HM) - (tb & HM)) & HM);
         int cut = 0x7fffffff;
         if (m < nA) cut = pa[b0 + m];
         if (m >= 1) cut = min(cut, (int)pb[b0 + m - 1]);
-        sCut[s] = (unsigned short)cut;
-        unsigned short lid = S_NONE, rid = S_NONE;
-        if (cut - first > 16) { int x = atomicAdd(&cnt[1], 1); nF[x] = (unsigned short)first; nL[x] = (unsigned short)cut; nD[x] = sD[s]; lid = (unsigned short)x; }
-        if (last - cut > 16) { int x = atomicAdd(&cnt[1], 1); nF[x] = (unsigned short)cut; nL[x] = (unsigned short)last; nD[x] = sD[s]; rid = (unsigned short)x; }
+        sCut[s] = (IT)cut;
+        IT lid = S_NONE, rid = S_NONE;
+        if (cut - first > 16) { int x = atomicAdd(&cnt[1], 1); nF[x] = (IT)first; nL[x] = (IT)cut; nD[x] = sD[s]; lid = (IT)x; }
+        if (last - cut > 16) { int x = atomicAdd(&cnt[1], 1); nF[x] = (IT)cut; nL[x] = (IT)last; nD[x] = sD[s]; rid = (IT)x; }
         atomicOr(&startBits[cut >> 5], 1u << (cut & 31));
         sLid[s] = lid; sRid[s] = rid;
       }
       __syncthreads();
       // (g) relabel elements, swap tables
       for (int p = tid; p < n; p += SORT_NT) {
-        const unsigned short sg = seg[p];
-        if (sg != S_NONE) seg[p] = (p < sCut[sg]) ? sLid[sg] : sRid[sg];
+        const IT sg = seg[p];
+        if (sg != S_NONE) seg[p] = (p < (int)sCut[sg]) ? sLid[sg] : sRid[sg];
       }
       nseg = cnt[1];
       __syncthreads();
@@ -659,7 +682,7 @@ __global__ void __launch_bounds__(SORT_NT) sort_wg_kernel(int n_reads, const uin
       }
     }
     __syncthreads();
-    uint32_t* tmp = (uint32_t*)pa;            // pa|pb = 4*cap bytes
+    uint32_t* tmp = HUGE ? (uint32_t*)seg : (uint32_t*)pa;            // pa|pb = 4*cap bytes (32-bit indices: seg, dead by now)
     for (int p = tid; p < n; p += SORT_NT) tmp[p] = mm_pos[base + idx[p]];
     __syncthreads();
     for (int p = tid; p < n; p += SORT_NT) { mm_key[base + p] = key[p]; mm_pos[base + p] = tmp[p]; }
@@ -1050,22 +1073,39 @@ static int launch_sort(lra_ctx* ctx, int n_reads, const uint64_t* mm_off, uint64
   const size_t ldsB = (size_t)maxsegB * 20 + 8 + (size_t)(capB / 32 + 2) * 4 + 64;
   const int grid = n_reads < ctx->num_cu ? n_reads : ctx->num_cu;
   const int gridB = std::min(grid, 64);
-  const size_t tszB = (size_t)gridB * (capB + 64) * 4, esz = (size_t)gridB * ((size_t)capB * 16 + 64);
+  const size_t tszB = (size_t)gridB * (capB + 64) * 4, esz = (size_t)gridB * sort_scratch_bytes(1, (size_t)capB);
   uint32_t* tscr = (uint32_t*)lra_scratch(ctx, 0, (size_t)grid * (cap + 64) * 4 + (size_t)n_reads * 4);
   char* big = (char*)lra_ensure(ctx, 85, tszB + esz + 1024);               // its own buffer: callers hold pointers into scratch 0 across a sort
-  if (!tscr || !big) return LRA_ERR_NOMEM;
+  int* stat = (int*)lra_ensure(ctx, 86, 64);
+  if (!tscr || !big || !stat) return LRA_ERR_NOMEM;
   uint32_t* tscrB = (uint32_t*)big; char* gscr = big + tszB;
   int* flags = (int*)(tscr + (size_t)grid * (cap + 64));
   LRA_HIP_CHECK(ctx, hipMemsetAsync(flags, 0, (size_t)n_reads * 4, st));
-  LRA_HIP_CHECK(ctx, hipFuncSetAttribute((const void*)sort_wg_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-  LRA_HIP_CHECK(ctx, hipFuncSetAttribute((const void*)sort_wg_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsB));
+  LRA_HIP_CHECK(ctx, hipMemsetAsync(stat, 0, 8, st));
+  LRA_HIP_CHECK(ctx, hipFuncSetAttribute((const void*)sort_wg_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  LRA_HIP_CHECK(ctx, hipFuncSetAttribute((const void*)sort_wg_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsB));
   lra_time_begin(ctx, ctx->sort_tag);
-  hipLaunchKernelGGL(sort_wg_kernel<false>, dim3(grid), dim3(SORT_NT), lds, st, n_reads, mm_off, mm_key, mm_pos, tscr, cap, flags, only, (char*)nullptr);
-  hipLaunchKernelGGL(sort_wg_kernel<true>, dim3(gridB), dim3(SORT_NT), ldsB, st, n_reads, mm_off, mm_key, mm_pos, tscrB, capB, flags, only, gscr);
+  hipLaunchKernelGGL(sort_wg_kernel<0>, dim3(grid), dim3(SORT_NT), lds, st, n_reads, mm_off, mm_key, mm_pos, (void*)tscr, cap, flags, only, (char*)nullptr, (int*)nullptr);
+  hipLaunchKernelGGL(sort_wg_kernel<1>, dim3(gridB), dim3(SORT_NT), ldsB, st, n_reads, mm_off, mm_key, mm_pos, (void*)tscrB, capB, flags, only, gscr, stat);
   lra_time_end(ctx);
-  lra_time_begin(ctx, ctx->sort_fb_tag);
-  hipLaunchKernelGGL(sort_kernel, dim3(nb), dim3(64), 0, st, n_reads, mm_off, mm_key, mm_pos, (const int*)flags);
+  // what is left: lists of more than 65534 tuples (the minimizers of a contig of several hundred kb) -- how long, how many
+  int h_stat[2] = {0, 0};
+  LRA_HIP_CHECK(ctx, hipMemcpyAsync(h_stat, stat, 8, hipMemcpyDeviceToHost, st));
+  LRA_HIP_CHECK(ctx, hipStreamSynchronize(st));
+  if (h_stat[1] == 0) return LRA_OK;
+  const int capH = std::min(h_stat[0] + 64, (1 << 26));                    // (a list beyond 2^26 tuples stays with the one-lane kernel)
+  const int gridH = std::min(h_stat[1], std::max(1, ctx->num_cu / 4));
+  const size_t eszH = sort_scratch_bytes(2, (size_t)capH), tszH = (size_t)(capH + 64) * 8;
+  char* huge = (char*)lra_ensure(ctx, 87, (size_t)gridH * (eszH + tszH) + 1024);
+  if (!huge) return LRA_ERR_NOMEM;
+  lra_time_begin(ctx, ctx->sort_tag);
+  hipLaunchKernelGGL(sort_wg_kernel<2>, dim3(gridH), dim3(SORT_NT), 0, st, n_reads, mm_off, mm_key, mm_pos, (void*)huge, capH, flags, only, huge + (size_t)gridH * tszH, (int*)nullptr);
   lra_time_end(ctx);
+  if (h_stat[0] > capH) {
+    lra_time_begin(ctx, ctx->sort_fb_tag);
+    hipLaunchKernelGGL(sort_kernel, dim3(nb), dim3(64), 0, st, n_reads, mm_off, mm_key, mm_pos, (const int*)flags);
+    lra_time_end(ctx);
+  }
   return LRA_OK;
 }
 

@@ -56,3 +56,21 @@ def test_hip_sort_big_lists(ctx, oracle):
         ek, ep = oracle.sort_minimizers(k, p)
         assert np.array_equal(got[i][0], ek), (i, len(k))
         assert np.array_equal(got[i][1], ep), (i, len(k))
+
+
+@pytest.mark.gpu
+def test_hip_sort_huge_lists(ctx, oracle):
+    """Lists beyond 65534 tuples (the minimizers of an assembly contig: ~180 k per Mb) take the workgroup sort with 32-bit indices and its tables in
+    global memory: heavy ties, few ties, the depth-limit adversary, already sorted / reversed input, two such lists beside small ones in one batch."""
+    from lra_amd import seed
+    rng = np.random.default_rng(11)
+    cs = [rng.integers(0, 1 << 34, 180000).astype(np.uint64), rng.integers(0, 3000, 131072).astype(np.uint64), oracle.antiqsort_keys(70000),
+          np.arange(90000, 0, -1).astype(np.uint64), np.arange(66000).astype(np.uint64), rng.integers(0, 1 << 34, 500).astype(np.uint64),
+          rng.integers(0, 1 << 20, 65535).astype(np.uint64), np.zeros(70001, np.uint64), rng.integers(0, 7, 300000).astype(np.uint64)]
+    cs[0] |= (rng.integers(0, 2, 180000).astype(np.uint64) << np.uint64(63))     # strand bits: not part of the order
+    pos = [np.arange(len(k), dtype=np.uint32) for k in cs]
+    got = seed.sort_minimizers_batch(ctx, cs, pos)
+    for i, (k, p) in enumerate(zip(cs, pos)):
+        ek, ep = oracle.sort_minimizers(k, p)
+        assert np.array_equal(got[i][0], ek), (i, len(k))
+        assert np.array_equal(got[i][1], ep), (i, len(k))
