@@ -807,7 +807,7 @@ __global__ void __launch_bounds__(64, 4) sdp_process(ProcArgs a) {
   Node cn; cn.dBase = 0; cn.nD = 0; cn.nE = 0; cn.last = -1; cn.sTop = 0; cn.nBlk = 0; cn.stkOff = 0; cn.blkOff = 0; cn.stkCap = 0; cn.blkCap = 0;
   uint32_t cId = NONE;
   int2 cTop = make_int2(0, 0), cLastB = make_int2(0, 0);
-  bool cTopOk = false;
+  bool cTopOk = false, cDirty = false;
   uint8_t flN = P > 0 ? a.hfl[p0] : 0;
   uint32_t lfN = P > 0 ? a.hfr[p0] : 0;
   uint2 vN = make_uint2(NONE, 0);
@@ -821,7 +821,12 @@ __global__ void __launch_bounds__(64, 4) sdp_process(ProcArgs a) {
       if (lane < 2 * LV) vN = visR[(uint64_t)(pi + 1) * (2 * LV) + lane];
     }
     const int ind = fl & 1, inv = (fl >> 1) & 1;
-    if (v.x != NONE && v.x != cId) { cn = nodes[v.x]; cId = v.x; cTopOk = false; }
+    if (v.x != NONE && v.x != cId) {
+      // (the descriptor's changing fields live in this lane's copy while the lane stays in the sub-problem; memory gets them when it leaves: a store per query
+      // would be waited for by the next point's loads -- vector memory completes in order)
+      if (cDirty) { Node* op = nodes + cId; op->last = cn.last; op->sTop = cn.sTop; op->nBlk = cn.nBlk; op->stkOff = cn.stkOff; op->stkCap = cn.stkCap; op->blkOff = cn.blkOff; op->blkCap = cn.blkCap; cDirty = false; }
+      cn = nodes[v.x]; cId = v.x; cTopOk = false;
+    }
     if (ind == 0) {                                                      // PassValueToD1/D2 (SparseDP.h:140-310)
       if (v.x != NONE) {
         const float val = a.fval[f0 + lf];
@@ -1012,10 +1017,7 @@ __global__ void __launch_bounds__(64, 4) sdp_process(ProcArgs a) {
           ev = d2.v + W(d2.val, ei1) + rate * a.flen[f0 + lf];            // :1040
           got = true;
           Ap[nd.dBase + nd.nD + i1] = (uint32_t)i2;                       // Ep[i1] (Ev[i1] is never read again)
-          Node* np = nodes + v.x;
-          np->last = now; np->sTop = (uint32_t)sTop; np->nBlk = (uint32_t)nBlk;
-          if (stkOff != nd.stkOff) { np->stkOff = stkOff; np->stkCap = (uint32_t)sCap; }
-          if (blkOff != nd.blkOff) { np->blkOff = blkOff; np->blkCap = (uint32_t)bCap; }
+          cDirty = true;
           cn.last = now; cn.sTop = (uint32_t)sTop; cn.nBlk = (uint32_t)nBlk; cn.stkOff = stkOff; cn.blkOff = blkOff; cn.stkCap = (uint32_t)sCap; cn.blkCap = (uint32_t)bCap;
           cTop = top; cLastB = lastB; cTopOk = true;
         }
@@ -1041,6 +1043,7 @@ __global__ void __launch_bounds__(64, 4) sdp_process(ProcArgs a) {
     }
     wave_sync();
   }
+  if (cDirty && cId != NONE) { Node* op = nodes + cId; op->last = cn.last; op->sTop = cn.sTop; op->nBlk = cn.nBlk; op->stkOff = cn.stkOff; op->stkCap = cn.stkCap; op->blkOff = cn.blkOff; op->blkCap = cn.blkCap; }
   if (lane == 0 && bad) atomicOr(&a.status[r], bad);
 #undef W
 #undef BEATS
@@ -1063,7 +1066,7 @@ __global__ void __launch_bounds__(64, 4) sdp_process(ProcArgs a) {
 // nearly always owns the whole tail).  A pop then costs one load (the new top's Dv) instead of three dependent ones, a candidate that beats the top without
 // popping costs none, the candidate scan is one round (Ei[Db] stored beside the entries by sdp_build), and the query's E entry is in flight one point ahead.
 struct SlotState {
-  Node cn; uint32_t cId;
+  Node cn; uint32_t cId; int dirty;                // dirty: cn's changing fields are newer than the descriptor in memory (written back when the slot leaves the sub-problem)
   int2 cTop, cLastB; int cTopOk;                  // stack top, last Block pair (valid when cTopOk)
   int topInfoOk, topDvOk; float topDv; long long topDi, topEi;   // of cTop: Di[x], Ei[y - 1]; Dv[x] while no deposit has touched it
   int2 sec; int secOk, secDvOk; float secDv; long long secDi, secEi;    // the pair below the top, with its Di / Ei[y - 1] (and Dv, as for the top)
@@ -1162,7 +1165,11 @@ __global__ void __launch_bounds__(64 * WG_NW) sdp_process_wg(ProcArgs a) {
       const int slot = wg_slot(wave, k);
       act[k] = slot < 2 * LV && vv[k].x != NONE;
       if (act[k] && vv[k].x != u_u(ss[slot].cId)) {
-        if (lane == 0) { ss[slot].cn = nodes[vv[k].x]; ss[slot].cId = vv[k].x; ss[slot].cTopOk = 0; ss[slot].topInfoOk = 0; ss[slot].topDvOk = 0; ss[slot].secOk = 0; ss[slot].secDvOk = 0; }
+        if (lane == 0) {
+          SlotState& Zs = ss[slot];
+          if (Zs.dirty) { Node* op = nodes + Zs.cId; op->last = Zs.cn.last; op->sTop = Zs.cn.sTop; op->nBlk = Zs.cn.nBlk; op->stkOff = Zs.cn.stkOff; op->stkCap = Zs.cn.stkCap; op->blkOff = Zs.cn.blkOff; op->blkCap = Zs.cn.blkCap; Zs.dirty = 0; }
+          Zs.cn = nodes[vv[k].x]; Zs.cId = vv[k].x; Zs.cTopOk = 0; Zs.topInfoOk = 0; Zs.topDvOk = 0; Zs.secOk = 0; Zs.secDvOk = 0;
+        }
       }
     }
     wave_sync();
@@ -1363,10 +1370,7 @@ __global__ void __launch_bounds__(64 * WG_NW) sdp_process_wg(ProcArgs a) {
           ev = u_f(d2v + W(d2d, ei1) + rate * a.flen[f0 + lf]);
           if (lane == 0) {
             Ap[nd.dBase + nd.nD + i1] = (uint32_t)i2;
-            Node* np = nodes + v.x;
-            np->last = now; np->sTop = (uint32_t)oTop; np->nBlk = (uint32_t)oBlk;
-            if (oStkOff != nd.stkOff) { np->stkOff = oStkOff; np->stkCap = (uint32_t)oSCap; }
-            if (oBlkOff != nd.blkOff) { np->blkOff = oBlkOff; np->blkCap = (uint32_t)oBCap; }
+            Z.dirty = 1;
             Z.cn.last = now; Z.cn.sTop = (uint32_t)oTop; Z.cn.nBlk = (uint32_t)oBlk; Z.cn.stkOff = oStkOff; Z.cn.blkOff = oBlkOff; Z.cn.stkCap = (uint32_t)oSCap; Z.cn.blkCap = (uint32_t)oBCap;
             Z.cTop = otop; Z.cLastB = olastB; Z.cTopOk = 1;
             Z.topInfoOk = tInfo ? 1 : 0; Z.topDvOk = (tInfo && tDvOk) ? 1 : 0; Z.topDv = tDv; Z.topDi = tDi; Z.topEi = tEi;
