@@ -875,7 +875,8 @@ __global__ void __launch_bounds__(64) strand_kernel(int n_reads, const unsigned 
         const unsigned char* b = genome + idx_pos[match_ti[i]];
         fwd = true;
         for (int x = 0; x < k; x++) if (a[x] != b[x]) { fwd = false; break; }
-      }
+        if (fwd) match_qi[i] |= 0x80000000u;                               // remembered for pass 2 (the same lane reads it back): the k-byte compare costs two cache
+      }                                                                    // lines of random access per match -- 12 GB per batch -- and was made twice
       nf += __popcll(__ballot(fwd));
     }
     if (lane == 0) n_forward[r] = (uint32_t)nf;
@@ -887,11 +888,10 @@ __global__ void __launch_bounds__(64) strand_kernel(int n_reads, const unsigned 
       uint32_t qp = 0, tp = 0;
       uint64_t qk = 0;
       if (in) {
-        qp = qpos_of[match_qi[i]]; tp = idx_pos[match_ti[i]]; qk = mm_key[mm_off[r] + match_qi[i]];
-        const unsigned char* a = read + qp;
-        const unsigned char* b = genome + tp;
-        fwd = true;
-        for (int x = 0; x < k; x++) if (a[x] != b[x]) { fwd = false; break; }
+        const uint32_t mq = match_qi[i], qi = mq & 0x7fffffffu;
+        fwd = (mq >> 31) != 0;
+        if (fwd) match_qi[i] = qi;
+        qp = qpos_of[qi]; tp = idx_pos[match_ti[i]]; qk = mm_key[mm_off[r] + qi];
       }
       unsigned long long mf = __ballot(in && fwd), mr = __ballot(in && !fwd);
       unsigned long long below = (lane == 0) ? 0ULL : (~0ULL >> (64 - lane));
