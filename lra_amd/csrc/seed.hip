@@ -721,8 +721,11 @@ __global__ void bounds_kernel(uint64_t total, const uint64_t* __restrict__ mm_ke
   const uint64_t hi0 = hi;
   while (lo < hi) { uint64_t mid = lo + ((hi - lo) >> 1); if ((idx_key[mid] & FOR_MASK) < q) lo = mid + 1; else hi = mid; }
   const uint64_t l = lo;
+  // the end of the equal run: it starts at l and is short (most index keys occur once), so a few forward steps replace the second binary search from scratch
+  // (the kernel is bandwidth-bound: every probe of a 1.5 GB key array is a cache line); a long run finishes with the search on what is left
   hi = hi0;
-  while (lo < hi) { uint64_t mid = lo + ((hi - lo) >> 1); if (!(q < (idx_key[mid] & FOR_MASK))) lo = mid + 1; else hi = mid; }
+  { int steps = 0; while (lo < hi && steps < 4 && (idx_key[lo] & FOR_MASK) == q) { lo++; steps++; }
+    if (steps == 4) { while (lo < hi) { uint64_t mid = lo + ((hi - lo) >> 1); if (!(q < (idx_key[mid] & FOR_MASK))) lo = mid + 1; else hi = mid; } } }
   const uint64_t u = lo;
   lb[i] = (uint32_t)l; ub[i] = (uint32_t)u;
   tk_lb[i] = (l < n_idx) ? idx_key[l] : 0;
