@@ -1068,8 +1068,8 @@ __global__ void __launch_bounds__(64, 4) sdp_process(ProcArgs a) {
 struct SlotState {
   Node cn; uint32_t cId; int dirty;                // dirty: cn's changing fields are newer than the descriptor in memory (written back when the slot leaves the sub-problem)
   int2 cTop, cLastB; int cTopOk;                  // stack top, last Block pair (valid when cTopOk)
-  int topInfoOk, topDvOk; float topDv; long long topDi, topEi;   // of cTop: Di[x], Ei[y - 1]; Dv[x] while no deposit has touched it
-  int2 sec; int secOk, secDvOk; float secDv; long long secDi, secEi;    // the pair below the top, with its Di / Ei[y - 1] (and Dv, as for the top)
+  int topInfoOk, topDvOk; float topDv, topWe; long long topDi;   // of cTop: Di[x], w(Di[x], Ei[n - 1]); Dv[x] while no deposit has touched it
+  int2 sec; int secOk, secDvOk; float secDv, secWe; long long secDi;    // the pair below the top, with the same
 };
 constexpr int WG_NW = 16;
 
@@ -1231,7 +1231,7 @@ __global__ void __launch_bounds__(64 * WG_NW) sdp_process_wg(ProcArgs a) {
         }
         continue;
       }
-      const int now = u_i(e0k.b), dbn = u_i(__float_as_int(e0k.v));
+      const int now = u_i(e0k.b);
       const long long ei1 = u_ll(e0k.val);
       const bool need = now != -1;
       const int m = (int)nd.nD, n = (int)nd.nE, i1 = (int)v.y;
@@ -1240,31 +1240,33 @@ __global__ void __launch_bounds__(64 * WG_NW) sdp_process_wg(ProcArgs a) {
       int2* oS = pairs + oStkOff; int2* oB = pairs + oBlkOff;
       int oSCap = (int)nd.stkCap, oBCap = (int)nd.blkCap;
       const Ent* oD = ent + nd.dBase;
-      const Ent* oE = oD + m;
       const long long* oEd = Ed + nd.dBase;
       const long long eLast = nd.eLast;
       uint32_t ost = 0;
       const int on = n;
-      // the stack top and the pair below it, with what is known about them
-      int2 otop = make_int2(0, 0), olastB = make_int2(0, 0), sec = make_int2(0, 0);
-      bool tInfo = false, tDvOk = false, secOk = false, secDvOk = false;
-      float tDv = 0.f, secDv = 0.f; long long tDi = 0, tEi = 0, secDi = 0, secEi = 0;
+      // EVERY pair on the stack but the dummy at position 0 has the boundary n (SubRountine.h:388-434: the first pair is pushed as (i, n); FindBoundary(prev.second,
+      // cur.second, ...) searches [n, n) or, below the dummy, returns Ei.size() -- so every later pair is (i, n) too).  Hence: `Db[i] >= top.second` (:398, :450) never
+      // holds, a candidate is compared with the stack at Ei[n - 1] only, FindBoundary never searches, and `i1 < top.second` (:326) always holds.  A pair is its D index x;
+      // what the slot keeps of the top and of the pair below it: x, Di[x], w(Di[x], Ei[n - 1]) (static) and Dv[x] (dropped when a deposit lands on x).
+      int tx = -1, sx = -1; int2 olastB = make_int2(0, 0);               // tx / sx == -1: the dummy
+      bool tInfo = false, tDvOk = false, secOk = false, sInfo = false, sDvOk = false;
+      float tDv = 0.f, tWe = 0.f, sDv = 0.f, sWe = 0.f; long long tDi = 0, sDi = 0;
       if (need) {
         if (u_i(Z.cTopOk)) {
-          otop = u_i2(Z.cTop); olastB = u_i2(Z.cLastB); tInfo = u_i(Z.topInfoOk) != 0; tDvOk = u_i(Z.topDvOk) != 0; tDv = u_f(Z.topDv); tDi = u_ll(Z.topDi); tEi = u_ll(Z.topEi);
-          secOk = u_i(Z.secOk) != 0; sec = u_i2(Z.sec); secDi = u_ll(Z.secDi); secEi = u_ll(Z.secEi); secDvOk = u_i(Z.secDvOk) != 0; secDv = u_f(Z.secDv);
-        } else if (oTop > 0) { otop = u_i2(oS[oTop - 1]); olastB = oBlk > 0 ? u_i2(oB[oBlk - 1]) : make_int2(0, 0); }
+          tx = u_i(Z.cTop.x); olastB = u_i2(Z.cLastB); tInfo = u_i(Z.topInfoOk) != 0; tDvOk = u_i(Z.topDvOk) != 0; tDv = u_f(Z.topDv); tDi = u_ll(Z.topDi); tWe = u_f(Z.topWe);
+          secOk = u_i(Z.secOk) != 0; sx = u_i(Z.sec.x); sInfo = secOk; sDi = u_ll(Z.secDi); sWe = u_f(Z.secWe); sDvOk = u_i(Z.secDvOk) != 0; sDv = u_f(Z.secDv);
+        } else if (oTop > 0) { tx = oTop == 1 ? -1 : u_i(oS[oTop - 1].x); olastB = oBlk > 0 ? u_i2(oB[oBlk - 1]) : make_int2(0, 0); }
       }
-      // Di / Ei[y - 1] (and Dv) of a pair: the two loads are independent
-#define PAIR_INFO(pr_, di_, ei_, dv_) do { const Ent d__ = oD[(pr_).x]; long long e__ = 0; if ((pr_).y >= 1 && (pr_).y <= on) e__ = oE[(pr_).y - 1].val; (di_) = u_ll(d__.val); (dv_) = u_f(d__.v); (ei_) = u_ll(e__); } while (0)
+      // Di, Dv and w(Di, Ei[n - 1]) of a pair read from memory
+#define PAIR_INFO(x_, di_, dv_, we_) do { const Ent d__ = oD[(x_)]; (di_) = u_ll(d__.val); (dv_) = u_f(d__.v); (we_) = W((di_), eLast); } while (0)
       // the pair at stack position oTop - 1 after a pop: the remembered second pair, the dummy at position 0, or memory
-#define NEXT_DOWN(pr_, infoOk_, di_, ei_, dv_, dvOk_) do { if (secOk) { (pr_) = sec; (di_) = secDi; (ei_) = secEi; (infoOk_) = true; (dv_) = secDv; (dvOk_) = secDvOk; secOk = false; secDvOk = false; } \
-                                               else if (oTop - 1 == 0) { (pr_) = make_int2(-1, on + 1); (infoOk_) = true; (di_) = 0; (ei_) = 0; (dvOk_) = false; } \
-                                               else { (pr_) = u_i2(oS[oTop - 1]); (infoOk_) = false; (dvOk_) = false; } } while (0)
+#define NEXT_DOWN(x_, infoOk_, di_, we_, dv_, dvOk_) do { if (secOk) { (x_) = sx; (di_) = sDi; (we_) = sWe; (infoOk_) = true; (dv_) = sDv; (dvOk_) = sDvOk; secOk = false; sDvOk = false; } \
+                                               else if (oTop - 1 == 0) { (x_) = -1; (infoOk_) = true; (dvOk_) = false; } \
+                                               else { (x_) = u_i(oS[oTop - 1].x); (infoOk_) = false; (dvOk_) = false; } } while (0)
 #define SPUSH(val_) do { const int2 v__ = (val_); if (oTop >= oSCap) { if (coop_grow_pairs(pairs, oStkOff, oSCap, oTop, poolUsed, poolPair, poolPairs, lane)) oS = pairs + oStkOff; else ost |= LRA_ST_CAPACITY; } \
-                         if (oTop < oSCap) oS[oTop] = v__; oTop++; if (DBG) { const unsigned long long t0__ = clock64(); __builtin_amdgcn_s_waitcnt(0); tStore += clock64() - t0__; } } while (0)
+                         if (oTop < oSCap) oS[oTop] = v__; oTop++; } while (0)
 #define BPUSH(val_) do { const int2 v__ = (val_); if (oBlk >= oBCap) { if (coop_grow_pairs(pairs, oBlkOff, oBCap, oBlk, poolUsed, poolPair, poolPairs, lane)) oB = pairs + oBlkOff; else ost |= LRA_ST_CAPACITY; } \
-                         if (oBlk < oBCap) oB[oBlk] = v__; oBlk++; olastB = v__; if (DBG) { const unsigned long long t0__ = clock64(); __builtin_amdgcn_s_waitcnt(0); tStore += clock64() - t0__; } } while (0)
+                         if (oBlk < oBCap) oB[oBlk] = v__; oBlk++; olastB = v__; } while (0)
       unsigned long long tq = 0;
       if (DBG) { __builtin_amdgcn_s_waitcnt(0); tq = clock64(); tSec[0] += tq - ts0; }
       if (need && now > nd.last) {                                       // Maximization :275-328, the whole wave
@@ -1281,13 +1283,11 @@ __global__ void __launch_bounds__(64 * WG_NW) sdp_process_wg(ProcArgs a) {
           int t = 0;
           while (t < nb && !ost) {
             const unsigned long long te0 = DBG ? clock64() : 0;
-            if (otop.y != on + 1) {
-              if (otop.x < 0) { ost |= LRA_ST_OOB_SLOT; break; }
-              if (!tInfo) { PAIR_INFO(otop, tDi, tEi, tDv); tInfo = true; tDvOk = true; }
-              else if (!tDvOk) { tDv = u_f(oD[otop.x].v); tDvOk = true; }
+            if (tx != -1) {
+              if (!tInfo) { PAIR_INFO(tx, tDi, tDv, tWe); tInfo = true; tDvOk = true; }
+              else if (!tDvOk) { tDv = u_f(oD[tx].v); tDvOk = true; }
               bool evt = false;
-              if (lane >= t && lane < nb)
-                evt = dj.b == -1 || (oTop > 1 && dj.b >= otop.y) || (BEATS(dj.v, dj.val, tDv, tDi, ej));
+              if (lane >= t && lane < nb) evt = dj.b == -1 || BEATS(dj.v, dj.val, tDv, tDi, ej);
               const unsigned long long em = __ballot(evt);
               if (!em) break;
               t = __ffsll((long long)em) - 1;
@@ -1299,62 +1299,48 @@ __global__ void __launch_bounds__(64 * WG_NW) sdp_process_wg(ProcArgs a) {
             if (DBG) { tEvents++; te1 = clock64(); tEvA += te1 - te0; }
             const long long di = rl_ll(dj.val, t), edb = rl_ll(ej, t);
             const float dvi = rl_f(dj.v, t);
-            if (otop.y == on + 1) {                                      // :280-285 (the top is the dummy: position 0)
+            bool win = true;                                             // (chosen by the ballot above: it beats the top at Ei[Db[i]] -- unless the top was the dummy)
+            if (tx == -1) {                                              // :389-395 (the stack holds the dummy only)
               BPUSH(make_int2(-1, db)); SPUSH(make_int2(i, on));
-              sec = otop; secOk = true; secDi = 0; secEi = 0; secDvOk = false;
-              otop = make_int2(i, on); tDv = dvi; tDi = di; tEi = on >= 1 ? eLast : 0; tInfo = true; tDvOk = true;
+              sx = -1; secOk = true; sInfo = true; sDvOk = false;
+              tx = i; tDv = dvi; tDi = di; tWe = W(di, eLast); tInfo = true; tDvOk = true;
+              win = BEATS(dvi, di, tDv, tDi, edb);                        // (a pair against itself, as the reference compares it: never true)
             }
-            while (oTop > 1 && db >= otop.y) {                           // :286-290
-              BPUSH(otop); oTop--;
-              NEXT_DOWN(otop, tInfo, tDi, tEi, tDv, tDvOk);
-            }
-            if (otop.x < 0) { ost |= LRA_ST_OOB_SLOT; break; }
-            if (!tInfo) { PAIR_INFO(otop, tDi, tEi, tDv); tInfo = true; tDvOk = true; }
-            else if (!tDvOk) { tDv = u_f(oD[otop.x].v); tDvOk = true; }
             unsigned long long te2 = 0;
             if (DBG) { te2 = clock64(); tEvB += te2 - te1; }
-            if (BEATS(dvi, di, tDv, tDi, edb)) {                   // :292
-              if (db < otop.y && oBlk > 0 && db > olastB.y) BPUSH(make_int2(otop.x, db));
-              int2 cur = otop; float cDv = tDv; long long cDi = tDi, cEi = tEi; bool cInfo = true, cDvOk = true; int prevY = cur.y;
-              long long prevEi = tEi;                                     // Ei[prevY - 1]: the new pair's boundary is prevY whenever the search range is empty
-              while (oTop > 0) {                                          // :299-306
-                if (cur.x < 0 || cur.y < 1) { ost |= LRA_ST_OOB_SLOT; break; }
-                if (!(BEATS(dvi, di, cDv, cDi, cEi))) break;
-                oTop--; prevY = cur.y; prevEi = cEi;
+            if (win) {                                                    // :405
+              if (oBlk > 0 && db > olastB.y) BPUSH(make_int2(tx, db));     // (Db[i] < top.second = n always)
+              const float wNew = W(di, eLast), sNew = dvi + wNew;         // the candidate at Ei[n - 1]
+              int cx = tx; float cDv = tDv, cWe = tWe; long long cDi = tDi; bool cInfo = true, cDvOk = true;
+              while (oTop > 0) {                                          // :415-422
+                if (cx < 0 || on < 1) { ost |= LRA_ST_OOB_SLOT; break; }
+                if (!(sNew > cDv + cWe)) break;
+                oTop--;
                 if (oTop == 0) { ost |= LRA_ST_OOB_SLOT; break; }
-                NEXT_DOWN(cur, cInfo, cDi, cEi, cDv, cDvOk);
-                if (cur.y == on + 1) break;
-                if (cur.x < 0) { ost |= LRA_ST_OOB_SLOT; break; }
-                if (!cInfo) { PAIR_INFO(cur, cDi, cEi, cDv); cInfo = true; cDvOk = true; }
-                else if (!cDvOk) { cDv = u_f(oD[cur.x].v); cDvOk = true; }
+                NEXT_DOWN(cx, cInfo, cDi, cWe, cDv, cDvOk);
+                if (cx == -1) break;                                      // the dummy
+                if (!cInfo) { PAIR_INFO(cx, cDi, cDv, cWe); cInfo = true; cDvOk = true; }
+                else if (!cDvOk) { cDv = u_f(oD[cx].v); cDvOk = true; }
               }
               if (ost) break;
-              unsigned h;
-              if (cur.x != -1) {
-                const float dvb = cDv; const long long dib = cDi;
-                h = coop_search((unsigned)prevY, (unsigned)cur.y - (unsigned)prevY, lane,
-                                [&](unsigned it) { const long long e = oE[it].val; return BEATS(dvi, di, dvb, dib, e); });
-              } else h = (unsigned)on;
-              SPUSH(make_int2(i, (int)h));
-              // the pair below the new top is cur; it keeps its Di / Ei[y - 1] if they are known (the dummy has none)
-              sec = cur; secOk = cur.x == -1 || cInfo; secDi = cDi; secEi = cEi; secDv = cDv; secDvOk = cur.x != -1 && cInfo && cDvOk;
-              otop = make_int2(i, (int)h); tDv = dvi; tDi = di; tInfo = true; tDvOk = true;
-              tEi = (int)h == on ? (on >= 1 ? eLast : 0) : (int)h == prevY ? prevEi : ((int)h >= 1 ? u_ll(oE[(int)h - 1].val) : 0);
+              SPUSH(make_int2(i, on));                                    // FindBoundary: n (see above)
+              sx = cx; secOk = cx == -1 || cInfo; sInfo = secOk; sDi = cDi; sWe = cWe; sDv = cDv; sDvOk = cx != -1 && cInfo && cDvOk;
+              tx = i; tDv = dvi; tDi = di; tWe = wNew; tInfo = true; tDvOk = true;
             }
             if (DBG) tEvC += clock64() - te2;
             t++;
           }
         }
       }
-      // phase 2 (every lane the same values): the flush of Maximization :330-343, FindValueInBlock :224-236 with a wave-cooperative UPPERbound
+      // phase 2 (every lane the same values): the flush of Maximization :438-453 (only its `now == m - 1` branch ever pops), FindValueInBlock :322-333 with a
+      // wave-cooperative UPPERbound
       float ev = -2.f;
       if (DBG) { __builtin_amdgcn_s_waitcnt(0); const unsigned long long t1 = clock64(); tSec[1] += t1 - tq; tq = t1; }
       if (need && !ost) {
-        if (now == m - 1) { while (oTop > 1 && otop.y != on + 1 && !ost) { BPUSH(otop); oTop--; NEXT_DOWN(otop, tInfo, tDi, tEi, tDv, tDvOk); } }
-        else { while (oTop > 1 && dbn >= otop.y && !ost) { BPUSH(otop); oTop--; NEXT_DOWN(otop, tInfo, tDi, tEi, tDv, tDvOk); } }
+        if (now == m - 1) { while (oTop > 1 && tx != -1 && !ost) { BPUSH(make_int2(tx, on)); oTop--; NEXT_DOWN(tx, tInfo, tDi, tWe, tDv, tDvOk); } }
         int i2 = -1;
         if (!ost && oBlk > 0) {
-          if (i1 >= olastB.y && i1 < otop.y) i2 = otop.x;
+          if (i1 >= olastB.y) i2 = tx;                                    // (i1 < top.second always)
           else {
             int bx;
             const unsigned lo = coop_upper_block(oB, (unsigned)oBlk, i1, lane, &bx);   // UPPERbound :205-221, Block[lo].first with it
@@ -1365,16 +1351,16 @@ __global__ void __launch_bounds__(64 * WG_NW) sdp_process_wg(ProcArgs a) {
         if (ost || i2 < 0 || i2 >= m) ost |= ost ? ost : LRA_ST_OOB_SLOT;
         else {
           float d2v; long long d2d;
-          if (i2 == otop.x && tInfo && tDvOk) { d2v = tDv; d2d = tDi; }
-          else { const Ent d2 = oD[i2]; d2v = u_f(d2.v); d2d = u_ll(d2.val); if (i2 == otop.x && tInfo) { tDv = d2v; tDvOk = true; } }
+          if (i2 == tx && tInfo && tDvOk) { d2v = tDv; d2d = tDi; }
+          else { const Ent d2 = oD[i2]; d2v = u_f(d2.v); d2d = u_ll(d2.val); if (i2 == tx && tInfo) { tDv = d2v; tDvOk = true; } }
           ev = u_f(d2v + W(d2d, ei1) + rate * a.flen[f0 + lf]);
           if (lane == 0) {
             Ap[nd.dBase + nd.nD + i1] = (uint32_t)i2;
             Z.dirty = 1;
             Z.cn.last = now; Z.cn.sTop = (uint32_t)oTop; Z.cn.nBlk = (uint32_t)oBlk; Z.cn.stkOff = oStkOff; Z.cn.blkOff = oBlkOff; Z.cn.stkCap = (uint32_t)oSCap; Z.cn.blkCap = (uint32_t)oBCap;
-            Z.cTop = otop; Z.cLastB = olastB; Z.cTopOk = 1;
-            Z.topInfoOk = tInfo ? 1 : 0; Z.topDvOk = (tInfo && tDvOk) ? 1 : 0; Z.topDv = tDv; Z.topDi = tDi; Z.topEi = tEi;
-            Z.secOk = secOk ? 1 : 0; Z.sec = sec; Z.secDi = secDi; Z.secEi = secEi; Z.secDv = secDv; Z.secDvOk = (secOk && secDvOk) ? 1 : 0;
+            Z.cTop = make_int2(tx, tx == -1 ? on + 1 : on); Z.cLastB = olastB; Z.cTopOk = 1;
+            Z.topInfoOk = tInfo ? 1 : 0; Z.topDvOk = (tInfo && tDvOk) ? 1 : 0; Z.topDv = tDv; Z.topDi = tDi; Z.topWe = tWe;
+            Z.secOk = (secOk && sInfo) ? 1 : 0; Z.sec = make_int2(sx, sx == -1 ? on + 1 : on); Z.secDi = sDi; Z.secWe = sWe; Z.secDv = sDv; Z.secDvOk = (secOk && sInfo && sDvOk) ? 1 : 0;
           }
         }
       }
