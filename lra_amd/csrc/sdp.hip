@@ -549,21 +549,9 @@ __global__ void __launch_bounds__(64 * NW, NW == 1 ? 8 : 1) sdp_build(BuildArgs 
           }
           entR[ent].b = isS ? (int32_t)lo - 1 : (lo == m ? -1 : (int32_t)lo);
           if (!isS) edR[ent] = lo == m ? 0 : opp[lo].val;                   // Ei[Db[d]]
-          float v0 = 0.f;
-          if (isS && lo >= 1 && lo < nD) {
-            // Ev[] is written but never read by the reference (only Ep is); the slot holds Db[Eb + 1], which the flush at the end of
-            // Maximization (:337) needs, so that ProcessPoint gets it with the same load as Eb
-            const long long xd = entR[base + lo].val;                       // Di[Eb + 1]
-            const Ent* ei = entR + base + nD;
-            uint32_t l2 = 0, c2 = nE;
-            while (c2 > 0) {
-              const uint32_t step = c2 >> 1, it = l2 + step;
-              const long long vv = ei[it].val;
-              if (desc ? vv >= xd : vv < xd) { l2 = it + 1; c2 -= step + 1; } else c2 = step;
-            }
-            v0 = __int_as_float(l2 == nE ? -1 : (int)l2);
-          }
-          entR[ent].v = v0; apR[ent] = 0;
+          // (Ev[] is written but never read by the reference, and Db[Eb + 1] -- which the flush at the end of Maximization tests against the top pair's boundary,
+          // :450 -- is never needed: that boundary is n or n + 1, see sdp_process_wg)
+          entR[ent].v = 0.f; apR[ent] = 0;
         }
       }
       nNodes = nNext; cur = nxt;
@@ -796,6 +784,7 @@ __global__ void __launch_bounds__(64, 4) sdp_process(ProcArgs a) {
   Node* nodes = (Node*)ab;
   Ent* ent = (Ent*)(ab + A.entOff);
   uint32_t* Ap = (uint32_t*)(ab + A.apOff);
+  const long long* Ed = (const long long*)(ab + A.edOff);
   int2* pairs = (int2*)(ab + A.stkOff);                                  // stacks, Blocks and the growth pool of this read
   const uint32_t poolPair = A.poolPair, poolPairs = A.poolPairs;
   uint32_t* poolUsed = a.poolUsed + rr;
@@ -834,12 +823,14 @@ __global__ void __launch_bounds__(64, 4) sdp_process(ProcArgs a) {
         if (ent[e].v < val) { ent[e].v = val; Ap[e] = lf; }
       }
     } else {                                                             // start point (:1025-1060)
-      // phase 0, every lane for its own sub-problem: Eb[i1] (+ Db[Eb + 1]), stack top, last Block pair
+      // Every pair on a stack but the dummy at position 0 has the boundary n (see sdp_process_wg): a pair is its D index; `Db >= top.second` never holds,
+      // candidates meet the stack at Ei[n - 1] only, FindBoundary never searches.
+      // phase 0, every lane for its own sub-problem: Eb[i1], stack top, last Block pair
       Node nd = cn;
-      if (v.x == NONE) { nd.dBase = 0; nd.nD = 0; nd.nE = 0; nd.last = -1; nd.sTop = 0; nd.nBlk = 0; nd.stkOff = 0; nd.blkOff = 0; nd.stkCap = 0; nd.blkCap = 0; }
-      int now = -1, dbn = 0;
+      if (v.x == NONE) { nd.dBase = 0; nd.nD = 0; nd.nE = 0; nd.last = -1; nd.sTop = 0; nd.nBlk = 0; nd.stkOff = 0; nd.blkOff = 0; nd.stkCap = 0; nd.blkCap = 0; nd.eLast = 0; }
+      int now = -1;
       long long ei1 = 0;
-      if (v.x != NONE) { const Ent e = ent[nd.dBase + nd.nD + v.y]; now = e.b; ei1 = e.val; dbn = __float_as_int(e.v); }
+      if (v.x != NONE) { const Ent e = ent[nd.dBase + nd.nD + v.y]; now = e.b; ei1 = e.val; }
       const bool need = now != -1;
       const int m = (int)nd.nD, n = (int)nd.nE, i1 = (int)v.y;
       int sTop = (int)nd.sTop, nBlk = (int)nd.nBlk;
@@ -847,15 +838,16 @@ __global__ void __launch_bounds__(64, 4) sdp_process(ProcArgs a) {
       int2* S = pairs + stkOff; int2* B = pairs + blkOff;
       int sCap = (int)nd.stkCap, bCap = (int)nd.blkCap;
       const Ent* D = ent + nd.dBase;
-      int2 top = cTop, lastB = cLastB;
+      const long long* Edb = Ed + nd.dBase;
+      const long long eLast = nd.eLast;
+      int tx = cTop.x; int2 lastB = cLastB;                               // tx == -1: the dummy
       uint32_t st = 0;
-      if (need && !cTopOk) { top = S[sTop - 1]; lastB = nBlk > 0 ? B[nBlk - 1] : make_int2(0, 0); }
+      if (need && !cTopOk) { tx = sTop <= 1 ? -1 : S[sTop - 1].x; lastB = nBlk > 0 ? B[nBlk - 1] : make_int2(0, 0); }
       // phase 1a, every lane for itself: short insertion runs (most queries advance `now` by a few candidates only) -- the same loop
       // as below, literal and lane-local, all lanes at once
       const int LOCAL_MAX = 6;
       const bool small = need && now > nd.last && now - nd.last <= LOCAL_MAX;
       if (small) {
-        const Ent* E = D + nd.nD;
         bool topD = false; float tDv = 0; long long tDi = 0;
 #define SPUSHL(val_) do { const int2 v__ = (val_); if (sTop >= sCap) { if (grow_pairs(pairs, stkOff, sCap, sTop, poolUsed, poolPair, poolPairs)) S = pairs + stkOff; else st |= LRA_ST_CAPACITY; } \
                           if (sTop < sCap) S[sTop] = v__; sTop++; } while (0)
@@ -866,37 +858,24 @@ __global__ void __launch_bounds__(64, 4) sdp_process(ProcArgs a) {
           const int db = di_.b;
           if (db == -1) break;
           const long long di = di_.val; const float dvi = di_.v;
-          const long long edb = E[db].val;
-          if (top.y == n + 1) { BPUSHL(make_int2(-1, db)); SPUSHL(make_int2(i, n)); top = make_int2(i, n); tDv = dvi; tDi = di; topD = true; }
-          while (sTop > 1 && db >= top.y) { BPUSHL(top); sTop--; top = S[sTop - 1]; topD = false; }
-          if (top.x < 0) { st |= LRA_ST_OOB_SLOT; break; }
-          if (!topD) { const Ent e = D[top.x]; tDv = e.v; tDi = e.val; topD = true; }
+          const long long edb = Edb[i];
+          if (tx == -1) { BPUSHL(make_int2(-1, db)); SPUSHL(make_int2(i, n)); tx = i; tDv = dvi; tDi = di; topD = true; }
+          if (!topD) { const Ent e = D[tx]; tDv = e.v; tDi = e.val; topD = true; }
           if (BEATS(dvi, di, tDv, tDi, edb)) {
-            if (db < top.y && nBlk > 0 && db > lastB.y) BPUSHL(make_int2(top.x, db));
-            int2 cur = top; float cDv = tDv; long long cDi = tDi; int prevY = cur.y;
+            if (nBlk > 0 && db > lastB.y) BPUSHL(make_int2(tx, db));
+            const float sNew = dvi + W(di, eLast);
+            int cx = tx; float cDv = tDv; long long cDi = tDi;
             while (sTop > 0) {
-              if (cur.x < 0 || cur.y < 1) { st |= LRA_ST_OOB_SLOT; break; }
-              const long long e = E[cur.y - 1].val;
-              if (!(BEATS(dvi, di, cDv, cDi, e))) break;
-              sTop--; prevY = cur.y;
+              if (cx < 0 || n < 1) { st |= LRA_ST_OOB_SLOT; break; }
+              if (!(sNew > cDv + W(cDi, eLast))) break;
+              sTop--;
               if (sTop == 0) { st |= LRA_ST_OOB_SLOT; break; }
-              cur = S[sTop - 1];
-              if (cur.y == n + 1) break;
-              if (cur.x < 0) { st |= LRA_ST_OOB_SLOT; break; }
-              const Ent ce = D[cur.x]; cDv = ce.v; cDi = ce.val;
+              cx = sTop - 1 == 0 ? -1 : S[sTop - 1].x;
+              if (cx == -1) break;
+              const Ent ce = D[cx]; cDv = ce.v; cDi = ce.val;
             }
             if (st) break;
-            unsigned first = (unsigned)n;                                 // FindBoundary :239-263
-            if (cur.x != -1) {
-              first = (unsigned)prevY;
-              unsigned count = (unsigned)cur.y - first;
-              while (count > 0) {
-                const unsigned step = count / 2, it = first + step;
-                const long long e = E[it].val;
-                if (BEATS(dvi, di, cDv, cDi, e)) { first = it + 1; count -= step + 1; } else count = step;
-              }
-            }
-            SPUSHL(make_int2(i, (int)first)); top = make_int2(i, (int)first); tDv = dvi; tDi = di; topD = true;
+            SPUSHL(make_int2(i, n)); tx = i; tDv = dvi; tDi = di; topD = true;
           }
         }
 #undef SPUSHL
@@ -908,14 +887,15 @@ __global__ void __launch_bounds__(64, 4) sdp_process(ProcArgs a) {
         const int owner = __ffsll((long long)todo) - 1;
         todo &= todo - 1;
         const Ent* oD = ent + (uint32_t)rl_i((int)nd.dBase, owner);
-        const int on = rl_i(n, owner), om = rl_i(m, owner);
-        const Ent* oE = oD + om;
+        const long long* oEd = Ed + (uint32_t)rl_i((int)nd.dBase, owner);
+        const int on = rl_i(n, owner);
+        const long long oeLast = rl_ll(eLast, owner);
         const int olast = rl_i(nd.last, owner), onow = rl_i(now, owner);
         int oTop = rl_i(sTop, owner), oBlk = rl_i(nBlk, owner);
         uint32_t oStkOff = (uint32_t)rl_i((int)stkOff, owner), oBlkOff = (uint32_t)rl_i((int)blkOff, owner);
         int2* oS = pairs + oStkOff; int2* oB = pairs + oBlkOff;
         int oSCap = rl_i(sCap, owner), oBCap = rl_i(bCap, owner);
-        int2 otop = make_int2(rl_i(top.x, owner), rl_i(top.y, owner)), olastB = make_int2(rl_i(lastB.x, owner), rl_i(lastB.y, owner));
+        int otx = rl_i(tx, owner); int2 olastB = make_int2(rl_i(lastB.x, owner), rl_i(lastB.y, owner));
         uint32_t ost = 0;
         bool topD = false; float tDv = 0; long long tDi = 0;
 #define SPUSH(val_) do { const int2 v__ = (val_); if (oTop >= oSCap) { if (coop_grow_pairs(pairs, oStkOff, oSCap, oTop, poolUsed, poolPair, poolPairs, lane)) oS = pairs + oStkOff; else ost |= LRA_ST_CAPACITY; } \
@@ -927,18 +907,16 @@ __global__ void __launch_bounds__(64, 4) sdp_process(ProcArgs a) {
           const int j = i0 + lane;
           Ent dj; dj.val = 0; dj.b = -1; dj.v = 0;
           long long ej = 0;
-          if (j <= onow) { dj = oD[j]; if (dj.b != -1) ej = oE[dj.b].val; }
+          if (j <= onow) { dj = oD[j]; ej = oEd[j]; }
           const int nb = min(64, onow - i0 + 1);
           int t = 0;
           while (t < nb && !ost) {
-            // iterations that neither stop, pop nor beat the top candidate change nothing: every lane tests its own candidate
+            // iterations that neither stop nor beat the top candidate change nothing: every lane tests its own candidate
             // against the current top and the wave jumps to the first one that does something
-            if (otop.y != on + 1) {
-              if (otop.x < 0) { ost |= LRA_ST_OOB_SLOT; break; }
-              if (!topD) { const Ent e = oD[otop.x]; tDv = e.v; tDi = e.val; topD = true; }
+            if (otx != -1) {
+              if (!topD) { const Ent e = oD[otx]; tDv = e.v; tDi = e.val; topD = true; }
               bool evt = false;
-              if (lane >= t && lane < nb)
-                evt = dj.b == -1 || (oTop > 1 && dj.b >= otop.y) || (BEATS(dj.v, dj.val, tDv, tDi, ej));
+              if (lane >= t && lane < nb) evt = dj.b == -1 || BEATS(dj.v, dj.val, tDv, tDi, ej);
               const unsigned long long em = __ballot(evt);
               if (!em) break;
               t = __ffsll((long long)em) - 1;
@@ -948,52 +926,42 @@ __global__ void __launch_bounds__(64, 4) sdp_process(ProcArgs a) {
             if (db == -1) { stop = true; break; }                         // :277
             const long long di = rl_ll(dj.val, t), edb = rl_ll(ej, t);
             const float dvi = rl_f(dj.v, t);
-            if (otop.y == on + 1) { BPUSH(make_int2(-1, db)); SPUSH(make_int2(i, on)); otop = make_int2(i, on); tDv = dvi; tDi = di; topD = true; }   // :280-285
-            while (oTop > 1 && db >= otop.y) { BPUSH(otop); oTop--; otop = oS[oTop - 1]; topD = false; }                                         // :286-290
-            if (otop.x < 0) { ost |= LRA_ST_OOB_SLOT; break; }
-            if (!topD) { const Ent e = oD[otop.x]; tDv = e.v; tDi = e.val; topD = true; }
-            if (BEATS(dvi, di, tDv, tDi, edb)) {                   // :292
-              if (db < otop.y && oBlk > 0 && db > olastB.y) BPUSH(make_int2(otop.x, db));
-              int2 cur = otop; float cDv = tDv; long long cDi = tDi; int prevY = cur.y;
-              while (oTop > 0) {                                          // :299-306
-                if (cur.x < 0 || cur.y < 1) { ost |= LRA_ST_OOB_SLOT; break; }
-                const long long e = oE[cur.y - 1].val;
-                if (!(BEATS(dvi, di, cDv, cDi, e))) break;
-                oTop--; prevY = cur.y;
+            bool win = true;                                              // (the ballot's test is the reference's, :405, unless the top was the dummy)
+            if (otx == -1) { BPUSH(make_int2(-1, db)); SPUSH(make_int2(i, on)); otx = i; tDv = dvi; tDi = di; topD = true; win = BEATS(dvi, di, tDv, tDi, edb); }   // :389-395
+            if (win) {
+              if (oBlk > 0 && db > olastB.y) BPUSH(make_int2(otx, db));
+              const float sNew = dvi + W(di, oeLast);
+              int cx = otx; float cDv = tDv; long long cDi = tDi;
+              while (oTop > 0) {                                          // :415-422
+                if (cx < 0 || on < 1) { ost |= LRA_ST_OOB_SLOT; break; }
+                if (!(sNew > cDv + W(cDi, oeLast))) break;
+                oTop--;
                 if (oTop == 0) { ost |= LRA_ST_OOB_SLOT; break; }
-                cur = oS[oTop - 1];
-                if (cur.y == on + 1) break;
-                if (cur.x < 0) { ost |= LRA_ST_OOB_SLOT; break; }
-                const Ent ce = oD[cur.x]; cDv = ce.v; cDi = ce.val;
+                cx = oTop - 1 == 0 ? -1 : oS[oTop - 1].x;
+                if (cx == -1) break;
+                const Ent ce = oD[cx]; cDv = ce.v; cDi = ce.val;
               }
               if (ost) break;
-              unsigned h;                                                 // FindBoundary :239-263
-              if (cur.x != -1) {
-                const float dvb = cDv; const long long dib = cDi;
-                h = coop_search((unsigned)prevY, (unsigned)cur.y - (unsigned)prevY, lane,
-                                [&](unsigned it) { const long long e = oE[it].val; return BEATS(dvi, di, dvb, dib, e); });
-              } else h = (unsigned)on;
-              SPUSH(make_int2(i, (int)h)); otop = make_int2(i, (int)h); tDv = dvi; tDi = di; topD = true;
+              SPUSH(make_int2(i, on)); otx = i; tDv = dvi; tDi = di; topD = true;
             }
             t++;
           }
         }
 #undef SPUSH
 #undef BPUSH
-        if (lane == owner) { sTop = oTop; nBlk = oBlk; top = otop; lastB = olastB; st |= ost; stkOff = oStkOff; blkOff = oBlkOff; sCap = oSCap; bCap = oBCap; S = oS; B = oB; }
+        if (lane == owner) { sTop = oTop; nBlk = oBlk; tx = otx; lastB = olastB; st |= ost; stkOff = oStkOff; blkOff = oBlkOff; sCap = oSCap; bCap = oBCap; S = oS; B = oB; }
       }
-      // phase 2, every lane for its own sub-problem: the flush of Maximization :330-343, FindValueInBlock :224-236, Ev / Ep
+      // phase 2, every lane for its own sub-problem: the flush of Maximization :438-453 (only its `now == m - 1` branch ever pops), FindValueInBlock :322-333, Ev / Ep
       float ev = -1.f;
       bool got = false;
       if (need && !st) {
 #define BPUSH2(val_) do { const int2 v__ = (val_); if (nBlk >= bCap) { if (grow_pairs(pairs, blkOff, bCap, nBlk, poolUsed, poolPair, poolPairs)) B = pairs + blkOff; else st |= LRA_ST_CAPACITY; } \
                           if (nBlk < bCap) B[nBlk] = v__; nBlk++; lastB = v__; } while (0)
-        if (now == m - 1) { while (sTop > 1 && top.y != n + 1 && !st) { BPUSH2(top); sTop--; top = S[sTop - 1]; } }
-        else { while (sTop > 1 && dbn >= top.y && !st) { BPUSH2(top); sTop--; top = S[sTop - 1]; } }
+        if (now == m - 1) { while (sTop > 1 && tx != -1 && !st) { BPUSH2(make_int2(tx, n)); sTop--; tx = sTop - 1 == 0 ? -1 : S[sTop - 1].x; } }
 #undef BPUSH2
         int i2 = -1;
         if (!st && nBlk > 0) {
-          if (i1 >= lastB.y && i1 < top.y) i2 = top.x;
+          if (i1 >= lastB.y) i2 = tx;                                     // (i1 < top.second always)
           else {
             int lo = 0, cnt = nBlk, bx = -1;                              // UPPERbound :205-221, two levels per memory round; the search ends at the position of its most
             while (cnt > 0) {                                             // recent false probe (or at the end): Block[lo].first is that probe's pair, no further load
@@ -1019,7 +987,7 @@ __global__ void __launch_bounds__(64, 4) sdp_process(ProcArgs a) {
           Ap[nd.dBase + nd.nD + i1] = (uint32_t)i2;                       // Ep[i1] (Ev[i1] is never read again)
           cDirty = true;
           cn.last = now; cn.sTop = (uint32_t)sTop; cn.nBlk = (uint32_t)nBlk; cn.stkOff = stkOff; cn.blkOff = blkOff; cn.stkCap = (uint32_t)sCap; cn.blkCap = (uint32_t)bCap;
-          cTop = top; cLastB = lastB; cTopOk = true;
+          cTop = make_int2(tx, tx == -1 ? n + 1 : n); cLastB = lastB; cTopOk = true;
         }
       }
       const uint32_t myI1 = v.y;
