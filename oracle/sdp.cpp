@@ -47,6 +47,8 @@
 
 namespace {
 
+long g_off_boundary = 0;      // pushes of a stack pair whose boundary is not Ei.size() (see maximization)
+
 typedef std::pair<long, long> LPair;
 
 struct Pt {                 // Point.h:9-22
@@ -294,6 +296,7 @@ void maximization(Sub& s, const Pwl& P) {               // Maximization :270-345
       }
       SDP_STAT(fb, s, cur.first == -1 ? 0 : (long)cur.second - (long)prev.second);
       unsigned int h = find_boundary((unsigned int)prev.second, (unsigned int)cur.second, i, (unsigned int)cur.first, s, P);
+      if (h != n) g_off_boundary++;                        // (never: every pair but the dummy is (i, n) -- what the HIP kernels are built on; tests/test_sdp.py checks the counter)
       s.S.push_back(LPair(i, h));
     }
   }
@@ -392,6 +395,8 @@ uint64_t fnv1a(const std::string& s) {
 }
 
 }  // namespace
+
+extern "C" long oracle_sdp_off_boundary_pushes(int reset) { const long v = g_off_boundary; if (reset) g_off_boundary = 0; return v; }
 
 // ---- test hooks for the component pinning (same canonical text as oracle/ref_harness/sdp_parts_ref.cpp) ----
 // points: q,t,ind,inv (frag/cluster/orient play no part in sorting or decomposition; frag is used to make the

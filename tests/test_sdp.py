@@ -323,3 +323,26 @@ def test_hip_sdp_heavy_jobs_of_the_bench(ctx):
         read_lens = [40000] * len(reads_in)
         res, out = _run_hip(ctx, reads_in, read_lens, kw)
         assert _compare(out, int(res.num_aln), reads_in, read_lens, kw) >= len(reads_in)
+
+
+def test_oracle_stack_pairs_all_have_the_boundary_n():
+    """What both HIP ProcessPoint kernels are built on: in the literal Maximization every pair pushed on S_1 besides the dummy is (i, Ei.size()) -- FindBoundary
+    searches an empty range or returns Ei.size() (SubRountine.h:339-354, :388-434).  Checked on the literal restatement over the pinned Maximization scripts, random
+    clusters with heavy ties, and the heavy jobs captured from the bench batch."""
+    L = O.lib()
+    L.oracle_sdp_off_boundary_pushes.restype = __import__("ctypes").c_long
+    L.oracle_sdp_off_boundary_pushes(1)
+    gold = json.load(open(GOLD))
+    for c in gold["maxim"]:
+        ops = np.array(c["ops"], dtype=np.int64).reshape(-1, 3)
+        O.sdp_maximization_script(c["params"], c["Di"], c["Ei"], [tuple(o) for o in ops])
+    rng = np.random.default_rng(5)
+    n_anchors = 0
+    for k in range(60):
+        offs, st, q, t, ln = _random_clusters(rng, int(rng.integers(1, 8)), 120, 20000, bool(k & 1))
+        O.sdp_chain(offs, st, q, t, ln, O.sdp_opts(40000))
+        n_anchors += len(q)
+    for mode, rate, job in _load_jobs(os.path.join(os.path.dirname(__file__), "golden", "sdp_heavy_jobs.bin")):
+        O.sdp_chain(*job, O.sdp_opts(40000, mode=mode, rate=rate))
+        n_anchors += len(job[2])
+    assert n_anchors > 40000 and L.oracle_sdp_off_boundary_pushes(0) == 0
