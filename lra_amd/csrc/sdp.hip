@@ -586,6 +586,7 @@ struct ProcArgs {
   PwlTab pwl;
   const short* penTab; int penN;           // -w(|d| + 1) for d < penN (k_pen_table); penN = 0: no table
   int dbg;
+  int wgNoRing;          // sdp_process_wg: keep the anchors' words at L2 whatever the spans (LRA_SDP_WG_RING=0: tests of that mode)
   char* wgScratch; const uint64_t* wgOff;   // sdp_process_wg: per large read, the anchors' (best predecessor, contributions) words and the points' ranks
 };
 
@@ -1040,6 +1041,7 @@ struct SlotState {
   int2 sec; int secOk, secDvOk; float secDv, secWe; long long secDi;    // the pair below the top, with the same
 };
 constexpr int WG_NW = 16;
+constexpr int RING_W = 2048, RING_LEAD = 1024, RING_CHECK = 32;   // window mode of sdp_process_wg
 
 // Which slots a wave owns.  The cost of a slot falls with its level (measured on a 47 k-point read: R0-R3 and C0-C2 ~ 350-400 M cycles each, level 8 ~ 100 M,
 // level 13+ ~ 0), so wave w takes row-family level w and column-family level 15 - w (plus the two levels beyond 15): the busiest wave carries ~ 460 M cycles
@@ -1059,7 +1061,12 @@ __global__ void __launch_bounds__(64 * WG_NW) sdp_process_wg(ProcArgs a) {
   __shared__ float s_slope[25], s_inter[25];
   __shared__ SlotState ss[2 * LV];
   __shared__ short s_pen[PEN_TAB_WG];
-  __shared__ volatile uint32_t s_bad;
+  // the window of anchors in progress (see below): per start point of an anchor the waves' best candidate and how many waves are counted in
+  __shared__ unsigned long long r_best[2 * RING_W];
+  __shared__ uint32_t r_cnt[2 * RING_W];
+  __shared__ int s_pos[WG_NW]; __shared__ uint32_t s_span, s_wtot[WG_NW];
+  __shared__ uint32_t s_bad;       // (read with BAD(): a volatile read is a FLAT load that waits for every outstanding store of the wave, at every point)
+#define BAD() __hip_atomic_load(&s_bad, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)
   const int tid = threadIdx.x, lane = tid & 63, wave = u_i(tid >> 6);
   if (tid < 25) { s_slope[tid] = a.pwl.slope[tid]; s_inter[tid] = a.pwl.inter[tid]; }
   const int penN = min(a.penN, PEN_TAB_WG);
@@ -1068,7 +1075,9 @@ __global__ void __launch_bounds__(64 * WG_NW) sdp_process_wg(ProcArgs a) {
     SlotState z; memset(&z, 0, sizeof z); z.cn.last = -1; z.cId = NONE;
     ss[tid] = z;
   }
-  if (tid == 0) s_bad = 0;
+  if (tid == 0) { s_bad = 0; s_span = 0; }
+  if (tid < WG_NW) s_pos[tid] = 0;
+  for (int x = tid; x < 2 * RING_W; x += 64 * WG_NW) { r_best[x] = 0; r_cnt[x] = 0; }
   __syncthreads();
   const int c1 = a.pwl.c1, c2 = a.pwl.c2;
 #define W(i, j) pwl_w_tab(s_pen, penN, s_slope, s_inter, c1, c2, (i), (j))
@@ -1088,40 +1097,100 @@ __global__ void __launch_bounds__(64 * WG_NW) sdp_process_wg(ProcArgs a) {
   uint32_t* poolUsed = a.poolUsed + rr;
   const uint2* visR = (const uint2*)(ab + A.visOff);
   // ---- per anchor: best[2] (one word per start point: value bits << 32 | ~visit rank; 0 = no candidate), cnt[2] (waves counted in), nS, sPos[2];
-  // per point: rank = how many start points of its anchor precede it
+  // per point: pm = how many start points of its anchor precede it (2 bits), and in window mode the anchor's ordinal and whether it has one start point only
+  //
+  // WINDOW MODE.  An anchor's words are in use from its first start point to its last end point, `span` points at most; a wave cannot pass an end point before all
+  // waves are through its anchor's start points, so the waves stay within a few spans of each other wherever it matters and only the anchors of a window of points are
+  // in progress at any time.  Their words then live in LDS -- entry (ordinal of the anchor among first start points) mod RING_W -- instead of at L2: counting in and
+  // asking whether all are counted in cost an LDS access instead of dependent L2 round trips.  Entries are never cleared: the count of an entry grows by 16 per
+  // generation (ordinal / RING_W; an anchor with one start point counts for both), and a candidate carries its generation above its value, so the maximum is the
+  // current generation's.  Anchor o + RING_W must not be counted in while anchor o is in progress: a wave that runs ahead where it has no end points of its own
+  // to stop at is held RING_LEAD points in front of the slowest (checked every RING_CHECK points); first start points are distinct points, so o + RING_W starts
+  // RING_W points after o at least, and RING_W >= RING_LEAD + RING_CHECK + span + 1 keeps them apart.  Reads with longer spans use the words at L2.
   const int F = (int)(a.fragOff[r + 1] - f0);
   char* wsb = a.wgScratch + a.wgOff[blockIdx.x];
   unsigned long long* best = (unsigned long long*)wsb;
   uint32_t* cnt = (uint32_t*)(wsb + 16 * (size_t)F);
   uint32_t* nS = cnt + 2 * (size_t)F;
   uint32_t* sPos = nS + F;
-  uint8_t* rank = (uint8_t*)(sPos + 2 * (size_t)F);
+  uint32_t* pm = sPos + 2 * (size_t)F;
   for (int f = tid; f < F; f += 64 * WG_NW) { best[2 * f] = 0; best[2 * f + 1] = 0; cnt[2 * f] = 0; cnt[2 * f + 1] = 0; nS[f] = 0; sPos[2 * f] = 0; sPos[2 * f + 1] = 0; }
-  __syncthreads();
-  for (int pi = tid; pi < P; pi += 64 * WG_NW)
-    if (a.hfl[p0 + pi] & 1) { const uint32_t lf = a.hfr[p0 + pi]; const uint32_t k = atomicAdd(&nS[lf], 1u); if (k < 2) sPos[2 * lf + k] = (uint32_t)pi; else s_bad = LRA_ST_RANGE; }
-  __syncthreads();
-  for (int f = tid; f < F; f += 64 * WG_NW) if (nS[f] == 2 && sPos[2 * f] > sPos[2 * f + 1]) { const uint32_t t = sPos[2 * f]; sPos[2 * f] = sPos[2 * f + 1]; sPos[2 * f + 1] = t; }
   __syncthreads();
   for (int pi = tid; pi < P; pi += 64 * WG_NW) {
     const uint32_t lf = a.hfr[p0 + pi];
-    int k = 0;
+    if (a.hfl[p0 + pi] & 1) { const uint32_t k = atomicAdd(&nS[lf], 1u); if (k < 2) sPos[2 * lf + k] = (uint32_t)pi; else atomicOr(&s_bad, (uint32_t)LRA_ST_RANGE); }
+    else atomicMax(&cnt[2 * lf], (uint32_t)pi);                            // (for now: the anchor's last end point)
+  }
+  __syncthreads();
+  for (int f = tid; f < F; f += 64 * WG_NW) {
+    if (nS[f] == 2 && sPos[2 * f] > sPos[2 * f + 1]) { const uint32_t t = sPos[2 * f]; sPos[2 * f] = sPos[2 * f + 1]; sPos[2 * f + 1] = t; }
+    if (nS[f] > 0 && cnt[2 * f] > sPos[2 * f]) atomicMax(&s_span, cnt[2 * f] - sPos[2 * f]);
+    cnt[2 * f] = 0;
+  }
+  __syncthreads();
+  const bool ring = a.wgNoRing == 0 && s_span + RING_LEAD + RING_CHECK + 1 <= (uint32_t)RING_W;
+  if (ring) {                                                              // ordinals of the anchors, in the order of their first start points -> cnt[2 f]
+    const int per = (P + 64 * WG_NW - 1) / (64 * WG_NW), b0 = min(P, tid * per), b1 = min(P, b0 + per);
+    uint32_t mine = 0;
+    for (int pi = b0; pi < b1; pi++) mine += (a.hfl[p0 + pi] & 1) && sPos[2 * a.hfr[p0 + pi]] == (uint32_t)pi;
+    uint32_t inc = mine;
+    for (int o = 1; o < 64; o <<= 1) { const uint32_t t = __shfl_up(inc, o); if (lane >= o) inc += t; }
+    if (lane == 63) s_wtot[wave] = inc;
+    __syncthreads();
+    uint32_t at = inc - mine;
+    for (int w = 0; w < wave; w++) at += s_wtot[w];
+    for (int pi = b0; pi < b1; pi++) { const uint32_t lf = a.hfr[p0 + pi]; if ((a.hfl[p0 + pi] & 1) && sPos[2 * lf] == (uint32_t)pi) cnt[2 * lf] = at++; }
+    __syncthreads();
+  }
+  for (int pi = tid; pi < P; pi += 64 * WG_NW) {
+    const uint32_t lf = a.hfr[p0 + pi];
+    uint32_t k = 0;
     for (uint32_t x = 0; x < min(nS[lf], 2u); x++) k += sPos[2 * lf + x] < (uint32_t)pi;
-    rank[pi] = (uint8_t)k;
+    pm[pi] = ring ? (cnt[2 * lf] << 3) | (nS[lf] == 1 ? 4u : 0u) | k : k;
   }
   __threadfence();
   __syncthreads();
-  // LRA_SDP_DBG: cycles per wave spent in each of its slots and waiting at end points (4 words per wave behind rank[], 8-aligned)
-  unsigned long long* dbgT = (unsigned long long*)(((uintptr_t)(rank + P) + 7) & ~(uintptr_t)7);
-  unsigned long long tRounds = 0, tEvents = 0, tStore = 0, tEvA = 0, tEvB = 0, tEvC = 0;   // event loop: choosing the candidate, up to the comparison with the top, the winner's path
+  // LRA_SDP_DBG: cycles per wave spent in each of its slots and waiting at end points (16 words per wave behind pm[], 8-aligned)
+  unsigned long long* dbgT = (unsigned long long*)(((uintptr_t)(pm + P) + 7) & ~(uintptr_t)7);
+  unsigned long long tRounds = 0, tEvents = 0, tStore = 0, tEvA = 0, tEvB = 0, tEvC = 0, tSwitch = 0, tDep = 0, tPub = 0;   // event loop: choosing the candidate, up to the comparison with the top, the winner's path
   unsigned long long tSlot[4] = {0, 0, 0, 0}, tSec[4] = {0, 0, 0, 0};   // tSec (queries only): set-up, Maximization, flush + Block search, result + state
   static_assert(SPW == 2 || SPW == (2 * LV + WG_NW - 1) / WG_NW, "slots per wave");
-  uint2 vN[SPW]; uint32_t flN = P > 0 ? u_u(a.hfl[p0]) : 0; uint32_t lfN = P > 0 ? u_u(a.hfr[p0]) : 0;
+  // The rows of the points: this point's are scalars, the next point's too (so that ITS sub-problem descriptors and its anchor's value can be asked for now), and
+  // the rows of the point after next are in flight in vector registers.  Memory returns in order: what was asked for at the top of the previous point is there
+  // by the time anything of this point has been waited for, so a point starts without a round trip of its own.
+  uint2 vN[SPW]; uint32_t flN = P > 0 ? u_u(a.hfl[p0]) : 0, lfN = P > 0 ? u_u(a.hfr[p0]) : 0, rkN = P > 0 ? u_u(pm[0]) : 0;
 #pragma unroll
   for (int k = 0; k < SPW; k++) { const int slot = wg_slot(wave, k); vN[k] = (P > 0 && slot < 2 * LV) ? u_u2(visR[slot]) : make_uint2(NONE, 0); }
-  for (int pi = 0; pi < P && !s_bad; pi++) {
-    const uint32_t fl = flN;
-    const uint32_t lf = lfN;
+  uint2 vV[SPW]; uint32_t lfV = 0, rkV = 0; uint8_t flV = 0;   // (a byte stays a byte until it is used: widening one waits for its load)
+  //                    // raw (per-lane copies of) the rows of point pi + 1 at the top of point pi
+#pragma unroll
+  for (int k = 0; k < SPW; k++) vV[k] = make_uint2(NONE, 0);
+  if (P > 1) {
+    flV = a.hfl[p0 + 1]; lfV = a.hfr[p0 + 1]; rkV = pm[1];
+#pragma unroll
+    for (int k = 0; k < SPW; k++) { const int slot = wg_slot(wave, k); if (slot < 2 * LV) vV[k] = visR[(uint64_t)(2 * LV) + slot]; }
+  }
+  uint32_t ndV[SPW], pfId[SPW]; float fvV = 0.f;                          // asked for one point ahead: lane l < 12 holds word l of the descriptor pfId[k]; the anchor's value
+#pragma unroll
+  for (int k = 0; k < SPW; k++) { ndV[k] = 0; pfId[k] = NONE; }
+  if (P > 0) fvV = a.fval[f0 + lfN];
+  constexpr int NODE_WORDS = (int)(sizeof(Node) / 4);
+  static_assert(sizeof(Node) % 4 == 0 && NODE_WORDS <= 64 && offsetof(SlotState, cn) == 0, "a descriptor is moved a word per lane");
+  const unsigned long long tAll0 = DBG ? clock64() : 0;
+  for (int pi = 0; pi < P && !BAD(); pi++) {
+    const uint32_t fl = flN, lf = lfN, rk = rkN & 3u;
+    const uint32_t re = 2 * ((rkN >> 3) & (uint32_t)(RING_W - 1)), gen = (rkN >> 3) / (uint32_t)RING_W + 1, single = (rkN >> 2) & 1u;   // window mode: the anchor's entry
+    const float fvC = fvV;
+    const unsigned long long tp0 = DBG ? clock64() : 0;
+    if (ring && (pi & (RING_CHECK - 1)) == 0 && lane == 0) {             // not further than RING_LEAD points in front of the slowest wave
+      __hip_atomic_store(&s_pos[wave], pi, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+      for (;;) {
+        int mn = pi;
+        for (int w = 0; w < WG_NW; w++) mn = min(mn, __hip_atomic_load(&s_pos[w], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP));
+        if (pi - mn <= RING_LEAD || BAD()) break;
+        __builtin_amdgcn_s_sleep(8);
+      }
+    }
     uint2 vv[SPW]; Ent e0[SPW];
 #pragma unroll
     for (int k = 0; k < SPW; k++) vv[k] = vN[k];
@@ -1133,19 +1202,38 @@ __global__ void __launch_bounds__(64 * WG_NW) sdp_process_wg(ProcArgs a) {
       const int slot = wg_slot(wave, k);
       act[k] = slot < 2 * LV && vv[k].x != NONE;
       if (act[k] && vv[k].x != u_u(ss[slot].cId)) {
-        if (lane == 0) {
-          SlotState& Zs = ss[slot];
-          if (Zs.dirty) { Node* op = nodes + Zs.cId; op->last = Zs.cn.last; op->sTop = Zs.cn.sTop; op->nBlk = Zs.cn.nBlk; op->stkOff = Zs.cn.stkOff; op->stkCap = Zs.cn.stkCap; op->blkOff = Zs.cn.blkOff; op->blkCap = Zs.cn.blkCap; Zs.dirty = 0; }
-          Zs.cn = nodes[vv[k].x]; Zs.cId = vv[k].x; Zs.cTopOk = 0; Zs.topInfoOk = 0; Zs.topDvOk = 0; Zs.secOk = 0; Zs.secDvOk = 0;
-        }
+        SlotState& Zs = ss[slot];
+        if (lane == 0 && Zs.dirty) { Node* op = nodes + Zs.cId; op->last = Zs.cn.last; op->sTop = Zs.cn.sTop; op->nBlk = Zs.cn.nBlk; op->stkOff = Zs.cn.stkOff; op->stkCap = Zs.cn.stkCap; op->blkOff = Zs.cn.blkOff; op->blkCap = Zs.cn.blkCap; Zs.dirty = 0; }
+        uint32_t w = ndV[k];
+        if (pfId[k] != vv[k].x && lane < NODE_WORDS) w = ((const uint32_t*)(nodes + vv[k].x))[lane];   // (the first point; otherwise asked for at the previous one)
+        if (lane < NODE_WORDS) ((uint32_t*)&Zs)[lane] = w;
+        if (lane == 0) { Zs.cId = vv[k].x; Zs.cTopOk = 0; Zs.topInfoOk = 0; Zs.topDvOk = 0; Zs.secOk = 0; Zs.secDvOk = 0; }
       }
     }
     wave_sync();
-    if (pi + 1 < P) {                                                    // next point's rows, in flight while this one is processed
-      flN = u_u(a.hfl[p0 + pi + 1]); lfN = u_u(a.hfr[p0 + pi + 1]);
+    if (pi + 1 < P) {                                                    // the next point's rows arrive as scalars; the rows of the one after are asked for
+      flN = u_u(flV); lfN = u_u(lfV); rkN = u_u(rkV);
 #pragma unroll
-      for (int k = 0; k < SPW; k++) { const int slot = wg_slot(wave, k); if (slot < 2 * LV) vN[k] = u_u2(visR[(uint64_t)(pi + 1) * (2 * LV) + slot]); }
+      for (int k = 0; k < SPW; k++) vN[k] = u_u2(vV[k]);
+      if (pi + 2 < P) {
+        flV = a.hfl[p0 + pi + 2]; lfV = a.hfr[p0 + pi + 2]; rkV = pm[pi + 2];
+#pragma unroll
+        for (int k = 0; k < SPW; k++) { const int slot = wg_slot(wave, k); if (slot < 2 * LV) vV[k] = visR[(uint64_t)(pi + 2) * (2 * LV) + slot]; }
+      }
+      // ... and what the next point will start with: the descriptors of the sub-problems its slots move to (never the ones the slots are in now: those are newer
+      // here than in memory; one a slot has left was written back above or earlier, ahead of this load), and its anchor's value if it is an end point
+#pragma unroll
+      for (int k = 0; k < SPW; k++) {
+        const int slot = wg_slot(wave, k);
+        pfId[k] = NONE;
+        if (slot < 2 * LV && vN[k].x != NONE && vN[k].x != u_u(ss[slot].cId)) {
+          pfId[k] = vN[k].x;
+          if (lane < NODE_WORDS) ndV[k] = ((const uint32_t*)(nodes + vN[k].x))[lane];
+        }
+      }
+      if (!(flN & 1)) fvV = a.fval[f0 + lfN];
     }
+    if (DBG) { __builtin_amdgcn_s_waitcnt(0); tSwitch += clock64() - tp0; }
     float depVal = 0.f;
     if (!ind) {                                                          // an end point: its anchor's value, once every wave has been through its start points
       bool any = false;
@@ -1154,14 +1242,23 @@ __global__ void __launch_bounds__(64 * WG_NW) sdp_process_wg(ProcArgs a) {
       if (!any) continue;
       const unsigned long long tw0 = DBG ? clock64() : 0;
       if (lane == 0) {
-        const int need = rank[pi];
-        depVal = a.fval[f0 + lf];
+        const int need = (int)rk;
+        depVal = fvC;
         for (int x = 0; x < need; x++) {
-          // (relaxed loads served by L2: an acquire would invalidate the CU's vector cache under all 16 waves at every end point)
-          while (__hip_atomic_load(&cnt[2 * lf + x], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < (uint32_t)WG_NW && !s_bad) __builtin_amdgcn_s_sleep(2);
-          const unsigned long long key = __hip_atomic_load(&best[2 * lf + x], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-          const float v = __uint_as_float((uint32_t)(key >> 32));
-          if (key && depVal < v) depVal = v;
+          if (ring) {                                                     // (LDS serves a wave's accesses in order: the count, then the candidate)
+            if (DBG) { tStore += 1ull << 32; if (__hip_atomic_load(&r_cnt[re + x], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < (uint32_t)WG_NW * gen) tStore++; }   // polls | not ready at the first
+            while (__hip_atomic_load(&r_cnt[re + x], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < (uint32_t)WG_NW * gen && !BAD()) __builtin_amdgcn_s_sleep(2);
+            const unsigned long long key = __hip_atomic_load(&r_best[re + x], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            const float v = __uint_as_float((uint32_t)(key >> 16));
+            if ((uint32_t)(key >> 48) == gen && depVal < v) depVal = v;
+          } else {
+            if (DBG) { tStore += 1ull << 32; if (__hip_atomic_load(&cnt[2 * lf + x], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < (uint32_t)WG_NW) tStore++; }
+            // (relaxed loads served by L2: an acquire would invalidate the CU's vector cache under all 16 waves at every end point)
+            while (__hip_atomic_load(&cnt[2 * lf + x], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < (uint32_t)WG_NW && !BAD()) __builtin_amdgcn_s_sleep(2);
+            const unsigned long long key = __hip_atomic_load(&best[2 * lf + x], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const float v = __uint_as_float((uint32_t)(key >> 32));
+            if (key && depVal < v) depVal = v;
+          }
         }
       }
       if (DBG) tSlot[3] += clock64() - tw0;
@@ -1197,6 +1294,7 @@ __global__ void __launch_bounds__(64 * WG_NW) sdp_process_wg(ProcArgs a) {
             if (Z.cTopOk && Z.secOk && Z.sec.x == (int)v.y) Z.secDvOk = 0;
           }
         }
+        if (DBG) { __builtin_amdgcn_s_waitcnt(0); tDep += clock64() - ts0; }
         continue;
       }
       const int now = u_i(e0k.b);
@@ -1336,15 +1434,26 @@ __global__ void __launch_bounds__(64 * WG_NW) sdp_process_wg(ProcArgs a) {
 #undef BPUSH
 #undef PAIR_INFO
 #undef NEXT_DOWN
-      if (ost && lane == 0) s_bad = s_bad | ost;
+      if (ost && lane == 0) atomicOr(&s_bad, ost);
       // Value[ii]: visits apply in the order R family deepest level first, then C family; `val < Ev` keeps the first maximum
       const int vr = (slot / LV) * LV + (LV - 1 - slot % LV);
       if (ev > 0.f && (ev > wBest || (ev == wBest && vr < wRank))) { wBest = ev; wRank = vr; }
       if (DBG) { __builtin_amdgcn_s_waitcnt(0); const unsigned long long t1 = clock64(); if (k == 0) tSlot[0] += t1 - ts0; else if (k == 1) tSlot[1] += t1 - ts0; else tSlot[2] += t1 - ts0; tSec[3] += t1 - tq; }
     }
     wave_sync();
+    const unsigned long long tb0 = DBG ? clock64() : 0;
     if (ind && lane == 0) {
-      const int x = rank[pi];                                             // which start point of the anchor this is
+      const int x = (int)rk;                                              // which start point of the anchor this is
+      if (ring) {
+        if (wBest > 0.f) (void)__hip_atomic_fetch_max(&r_best[re + x], ((unsigned long long)gen << 48) | ((unsigned long long)__float_as_uint(wBest) << 16) | (unsigned long long)(0xFFFFu - (uint32_t)wRank),
+                                                      __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        const uint32_t was = __hip_atomic_fetch_add(&r_cnt[re + x], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        if (single) (void)__hip_atomic_fetch_add(&r_cnt[re + 1], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        if (was + 1 == (uint32_t)WG_NW * gen) {                            // the last wave in: the anchor's candidate of this start point, for the pass at the end
+          const unsigned long long key = __hip_atomic_load(&r_best[re + x], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+          if ((uint32_t)(key >> 48) == gen) best[2 * lf + x] = ((key >> 16) & 0xFFFFFFFFull) << 32 | (unsigned long long)(0xFFFFFFFFu - (0xFFFFu - (uint32_t)(key & 0xFFFFu)));
+        }
+      } else {
       // the candidate is at L2 before the wave counts itself in: the count's operand depends on the max's return value
       uint32_t one = 1u;
       if (wBest > 0.f) {
@@ -1353,9 +1462,15 @@ __global__ void __launch_bounds__(64 * WG_NW) sdp_process_wg(ProcArgs a) {
         one += (uint32_t)(was == 0xFFFFFFFFFFFFFFFFull);                   // never true: a key's low word is below 2^32 - 1 only ... (value bits of a finite float are not all ones)
       }
       (void)__hip_atomic_fetch_add(&cnt[2 * lf + x], one, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
     }
+    if (DBG) { __builtin_amdgcn_s_waitcnt(0); tPub += clock64() - tb0; }
   }
-  if (DBG && lane == 0) { for (int x = 0; x < 4; x++) { dbgT[8 * wave + x] = tSlot[x]; dbgT[8 * wave + 4 + x] = tSec[x]; } dbgT[8 * wave + 4] = (tRounds << 32) | tEvents; dbgT[8 * wave + 7] = tStore; dbgT[8 * wave + 0] = tEvA; dbgT[8 * wave + 1] = tEvB; dbgT[8 * wave + 2] = tEvC; }
+  if (DBG && lane == 0) {
+    unsigned long long* o = dbgT + 16 * wave;
+    o[0] = clock64() - tAll0; o[1] = tSlot[3]; o[2] = tSwitch; o[3] = tDep; o[4] = tPub; o[5] = tSec[0]; o[6] = tSec[1]; o[7] = tSec[2]; o[8] = tSec[3];
+    o[9] = tEvA; o[10] = tEvB; o[11] = tEvC; o[12] = (tRounds << 32) | tEvents; o[13] = tStore; o[14] = tSlot[0] + tSlot[1] + tSlot[2]; o[15] = 0;
+  }
   __syncthreads();
   // Value[], prev: per anchor the start points in order, `val < Ev` (strict) at each
   if (!s_bad) {
@@ -1378,6 +1493,7 @@ __global__ void __launch_bounds__(64 * WG_NW) sdp_process_wg(ProcArgs a) {
     }
   }
   if (tid == 0 && s_bad) atomicOr(&a.status[r], (uint32_t)s_bad);
+#undef BAD
 #undef W
 #undef BEATS
 }
@@ -1842,7 +1958,7 @@ int sdp_run(lra_ctx* ctx, int n_reads, const uint64_t* d_cluster_off, const uint
       if (att > 0)
         hipLaunchKernelGGL(k_reset_frags, dim3(nsub), dim3(64), 0, st, r0, subOrder, fragOff, flen, d_rate, opts->rate, fval, fprevNode, fprevInd, fflags, status);
       ProcArgs pa;
-      pa.wgScratch = nullptr; pa.wgOff = nullptr; pa.dbg = 0;
+      pa.wgScratch = nullptr; pa.wgOff = nullptr; pa.dbg = 0; { const char* e = getenv("LRA_SDP_WG_RING"); pa.wgNoRing = (e && e[0] == '0') ? 1 : 0; }
       uint64_t dbgOff0 = 0; char* dbgBase = nullptr;
       pa.r0 = r0; pa.n = nsub; pa.order = subOrder; pa.ptOff = ptOff; pa.fragOff = fragOff; pa.hfl = hfl; pa.hfr = hfr; pa.flen = flen; pa.fval = fval;
       pa.fprevNode = fprevNode; pa.fprevInd = fprevInd; pa.fflags = fflags; pa.rate_in = d_rate; pa.rate = opts->rate; pa.ra = ra;
@@ -1860,7 +1976,7 @@ int sdp_run(lra_ctx* ctx, int n_reads, const uint64_t* d_cluster_off, const uint
         for (int i = 0; i < nbig; i++) {
           const uint64_t rdx = (uint64_t)r0 + ord[i];
           const uint64_t Fr = h_frag[rdx + 1] - h_frag[rdx], Pr = h_pt[rdx + 1] - h_pt[rdx];
-          woff[i + 1] = woff[i] + ((36 * Fr + Pr + 64 + 8 + 128 * 8 + 255) & ~(uint64_t)255);
+          woff[i + 1] = woff[i] + ((36 * Fr + 4 * Pr + 64 + 8 + 256 * 8 + 255) & ~(uint64_t)255);
         }
         char* wsc = (char*)lra_ensure(ctx, 177, woff[nbig] + 256);
         uint64_t* dwoff = (uint64_t*)lra_ensure(ctx, 178, ((size_t)nbig + 2) * 8);
@@ -1868,7 +1984,7 @@ int sdp_run(lra_ctx* ctx, int n_reads, const uint64_t* d_cluster_off, const uint
         LRA_HIP_CHECK(ctx, hipMemcpyAsync(dwoff, woff.data(), ((size_t)nbig + 1) * 8, hipMemcpyHostToDevice, st));
         LRA_HIP_CHECK(ctx, hipStreamSynchronize(st));                      // (woff is a host temporary)
         pa.wgScratch = wsc; pa.wgOff = dwoff; pa.dbg = dbg ? 1 : 0;
-        dbgOff0 = woff[0] + 36 * (h_frag[(uint64_t)r0 + ord[0] + 1] - h_frag[(uint64_t)r0 + ord[0]]) + (h_pt[(uint64_t)r0 + ord[0] + 1] - h_pt[(uint64_t)r0 + ord[0]]); dbgBase = wsc;
+        dbgOff0 = woff[0] + 36 * (h_frag[(uint64_t)r0 + ord[0] + 1] - h_frag[(uint64_t)r0 + ord[0]]) + 4 * (h_pt[(uint64_t)r0 + ord[0] + 1] - h_pt[(uint64_t)r0 + ord[0]]); dbgBase = wsc;
       }
       const bool forked = nbig > 0 && nsub > nbig;
       if (nbig > 0) {
@@ -1889,12 +2005,15 @@ int sdp_run(lra_ctx* ctx, int n_reads, const uint64_t* d_cluster_off, const uint
                 (unsigned long long)tot, (unsigned long long)mx, ms);
         (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
         if (dbgBase && nbig > 0) {                                         // the largest read's waves: cycles in each slot and waiting at end points
-          std::vector<unsigned long long> tw(128);
+          std::vector<unsigned long long> tw(256);
           const uint64_t o8 = (dbgOff0 + 7) & ~(uint64_t)7;
-          (void)hipMemcpy(tw.data(), dbgBase + o8, 128 * 8, hipMemcpyDeviceToHost);
-          for (int w = 0; w < 16; w++)
-            fprintf(stderr, "[sdp]   wave %2d: event loop: choose %10llu to-compare %10llu compare+win %10llu  waiting %10llu | scan rounds %8llu events %8llu maximization %10llu flush+search %10llu push-store drain %10llu\n", w,
-                    tw[8 * w], tw[8 * w + 1], tw[8 * w + 2], tw[8 * w + 3], tw[8 * w + 4] >> 32, tw[8 * w + 4] & 0xffffffffULL, tw[8 * w + 5], tw[8 * w + 6], tw[8 * w + 7]);
+          (void)hipMemcpy(tw.data(), dbgBase + o8, 256 * 8, hipMemcpyDeviceToHost);
+          fprintf(stderr, "[sdp]   per wave, M cycles: all | waiting  switch  deposits  publish | queries: set-up  maximization (choose, to-compare, compare+win)  flush+search  result | scan rounds  events | polls  not ready at the first\n");
+          for (int w = 0; w < 16; w++) {
+            const unsigned long long* o = tw.data() + 16 * w;
+            fprintf(stderr, "[sdp]   wave %2d: %6.1f | %6.1f %6.1f %6.1f %6.1f | %6.1f %6.1f (%5.1f %5.1f %5.1f) %6.1f %6.1f | %6llu %6llu | %6llu %6llu\n", w, o[0] * 1e-6, o[1] * 1e-6, o[2] * 1e-6, o[3] * 1e-6, o[4] * 1e-6,
+                    o[5] * 1e-6, o[6] * 1e-6, o[9] * 1e-6, o[10] * 1e-6, o[11] * 1e-6, o[7] * 1e-6, o[8] * 1e-6, o[12] >> 32, o[12] & 0xffffffffULL, o[13] >> 32, o[13] & 0xffffffffULL);
+          }
         }
       }
       if (att == 2) break;

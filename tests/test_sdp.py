@@ -269,12 +269,16 @@ def test_hip_sdp_bench_workload_flags_and_sample(ctx, oracle):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("window", ["window", "l2"])
 @pytest.mark.parametrize("which", ["clusters", "single"])
-def test_hip_sdp_workgroup_kernel(ctx, which, monkeypatch):
+def test_hip_sdp_workgroup_kernel(ctx, which, window, monkeypatch):
     """The workgroup-per-read ProcessPoint (sdp_process_wg, for reads with many points: the slots spread over 16 waves) against the oracle: the
     threshold is lowered so that the ordinary test reads go through it, plus one read of 9000 anchors on a lattice of tied rows / columns /
-    diagonals (what a read from a satellite array looks like)."""
+    diagonals (what a read from a satellite array looks like).  Both ways the waves exchange an anchor's value: the LDS window of anchors in
+    progress, and the words at L2 that reads with long anchor spans fall back to (forced here with LRA_SDP_WG_RING=0)."""
     monkeypatch.setenv("LRA_SDP_BIG_POINTS", "40")
+    if window == "l2":
+        monkeypatch.setenv("LRA_SDP_WG_RING", "0")
     rng = np.random.default_rng(23)
     if which == "clusters":
         reads_in = [_random_clusters(rng, nc, per, span, ties) for nc, per, span, ties in [(6, 80, 30000, False), (3, 150, 20000, True), (10, 30, 30000, True), (1, 5, 1000, False)]]
@@ -288,6 +292,10 @@ def test_hip_sdp_workgroup_kernel(ctx, which, monkeypatch):
         u = np.sort(u)
         o = np.lexsort((q[u], q[u].astype(np.int64) - t[u].astype(np.int64)))
         reads_in.append((np.array([0, len(u)], np.int32), np.array([0], np.uint8), q[u][o], t[u][o], np.full(len(u), 12, np.int32)))
+        # long anchors one base apart: ~1200 points between an anchor's start and its end -- more than the LDS window serves, the read takes the L2 words by itself
+        i_ = np.arange(2500); q = i_.astype(np.uint32); t = (i_ + 7000 + (i_ % 3) * 50).astype(np.uint32)
+        o = np.lexsort((q, q.astype(np.int64) - t.astype(np.int64)))
+        reads_in.append((np.array([0, 2500], np.int32), np.array([0], np.uint8), q[o], t[o], np.full(2500, 600, np.int32)))
         kw = dict(mode=1, rate=2.0)
     read_lens = [40000] * len(reads_in)
     res, out = _run_hip(ctx, reads_in, read_lens, kw)
@@ -310,10 +318,13 @@ def _load_jobs(path):
 
 
 @pytest.mark.gpu
-def test_hip_sdp_heavy_jobs_of_the_bench(ctx):
+@pytest.mark.parametrize("window", ["window", "l2"])
+def test_hip_sdp_heavy_jobs_of_the_bench(ctx, window, monkeypatch):
     """Jobs captured from the bench batch (tests/golden/sdp_heavy_jobs.bin, inputs only): the largest merged cluster of a read from a satellite array
     (23390 anchors on the reverse strand: 46780 points, Block lists of 17 k pairs, `last` moving backwards in four queries of five), another one of
     19812 anchors, the largest SDP#A read and the largest job of a13's inner sparse DP -- the workgroup kernel on real input, against the oracle."""
+    if window == "l2":
+        monkeypatch.setenv("LRA_SDP_WG_RING", "0")
     jobs = _load_jobs(os.path.join(os.path.dirname(__file__), "golden", "sdp_heavy_jobs.bin"))
     assert len(jobs) == 4
     for mode in (1, 0):
