@@ -60,6 +60,12 @@ extern "C" int lra_ctx_create(int device_id, lra_ctx** out) {
 
 extern "C" void lra_ctx_destroy(lra_ctx* ctx) {
   if (!ctx) return;
+  if (getenv("LRA_MEM_REPORT")) {                                          // analysis: what the context holds when it goes (the growable buffers by slot, the scratch slots)
+    size_t tot = 0;
+    for (int i = 0; i < 192; i++) if (ctx->gbuf[i]) { tot += ctx->gbytes[i]; if (ctx->gbytes[i] >= (size_t(256) << 20)) fprintf(stderr, "[mem] ctx %p buffer %3d: %8.2f GB\n", (void*)ctx, i, ctx->gbytes[i] / 1e9); }
+    for (int i = 0; i < 4; i++) if (ctx->scratch[i]) { tot += ctx->scratch_bytes[i]; fprintf(stderr, "[mem] ctx %p scratch %d: %8.2f GB\n", (void*)ctx, i, ctx->scratch_bytes[i] / 1e9); }
+    fprintf(stderr, "[mem] ctx %p buffers + scratch: %.2f GB (aux %.2f GB, out %.2f GB)\n", (void*)ctx, tot / 1e9, ctx->aux_bytes / 1e9, ctx->out_bytes / 1e9);
+  }
   if (ctx->child) { lra_ctx_destroy(ctx->child); ctx->child = nullptr; }   // borrows this context's reference: first
   (void)hipSetDevice(ctx->device);
   (void)hipStreamSynchronize(ctx->stream);

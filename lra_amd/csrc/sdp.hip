@@ -103,6 +103,16 @@ __global__ void k_arena_sizes(int n, int r0, const uint64_t* __restrict__ ptOff,
   ra[rr] = a;
   bytes[b] = o;
 }
+// Sizes WITHOUT the count pass: entries, sub-problems and D entries per point are narrow distributions (measured over the headline batch: 3.2 .. 9.8 entries and 0.3 .. 1.9
+// sub-problems per point, D entries 43 .. 56 % of the entries), so a read's blocks are laid out for fE / fN per point and the emit pass checks every level against them; the rare
+// read that outgrows its blocks is counted exactly and built again with the reads whose stacks outgrew theirs (attempt 1 of sdp_run).
+__global__ void k_arena_estimate(int n, int r0, const uint64_t* __restrict__ ptOff, float fE, float fN, uint32_t* cntE, uint32_t* cntN, uint32_t* cntD) {
+  int rr = blockIdx.x * blockDim.x + threadIdx.x;
+  if (rr >= n) return;
+  const uint64_t P = ptOff[r0 + rr + 1] - ptOff[r0 + rr];
+  const uint64_t E = (uint64_t)(fE * (float)P) + 64, N = (uint64_t)(fN * (float)P) + 64;
+  cntE[rr] = (uint32_t)std::min<uint64_t>(E, 0xFFFFFFFFull); cntN[rr] = (uint32_t)std::min<uint64_t>(N, 0xFFFFFFFFull); cntD[rr] = (uint32_t)std::min<uint64_t>(E * 6 / 10 + 64, 0xFFFFFFFFull);
+}
 __global__ void k_arena_bases(int n, const uint64_t* __restrict__ byteOff, ReadArena* ra, const uint32_t* __restrict__ order, char* arena) {
   int b = blockIdx.x * blockDim.x + threadIdx.x;
   if (b < n) ra[order[b]].base = (uint64_t)(uintptr_t)(arena + byteOff[b]);
@@ -342,8 +352,9 @@ __global__ void __launch_bounds__(64 * NW, NW == 1 ? 8 : 1) sdp_build(BuildArgs 
     nodesR = (Node*)b; entR = (Ent*)(b + A.entOff); apR = (uint32_t*)(b + A.apOff); stkR = (int2*)(b + A.stkOff); visR = (uint2*)(b + A.visOff);
     edR = (long long*)(b + A.edOff);
   }
-  bool overflow = false;
-  for (int fam = 0; fam < 4; fam++) {
+  bool overflow = false, outgrown = false;
+  const uint64_t capE = EMIT ? a.cntEntries[rr] : 0, capN = EMIT ? a.cntNodes[rr] : 0, capD = EMIT ? a.cntD[rr] : 0;
+  for (int fam = 0; fam < 4 && !outgrown; fam++) {
     // family switches (DivideSubBy{Row1,Col1,Row2,Col2}.h): R1, C1, R2, C2
     const bool col = fam & 1, back = fam >= 2, desc = (fam == 1 || fam == 2), swapped = (fam == 3);
     const IT* lineOf = col ? colOf : rowOf;
@@ -361,7 +372,7 @@ __global__ void __launch_bounds__(64 * NW, NW == 1 ? 8 : 1) sdp_build(BuildArgs 
     if (tid == 0) { TB(0, F_LS, 0) = 0; TB(0, F_LE, 0) = nLines; TB(0, F_SB, 0) = 0; TB(0, F_SE, 0) = nS; TB(0, F_EB, 0) = nS; TB(0, F_EE, 0) = Pf; }
     int nNodes = 1, cur = 0;
     SYNC();
-    for (int level = 0; nNodes > 0; level++) {
+    for (int level = 0; nNodes > 0 && !outgrown; level++) {
       if (level >= LV) { overflow = true; break; }
       const int nxt = cur ^ 1;
       IT* lpc = lp + cur * P; IT* lpn = lp + nxt * P;
@@ -463,6 +474,9 @@ __global__ void __launch_bounds__(64 * NW, NW == 1 ? 8 : 1) sdp_build(BuildArgs 
         int totF, totEnt, totD, totC;
         const int incF = blk_incl_scan<NW>((int)full, lane, wave, s_w[0], totF), incEnt = blk_incl_scan<NW>((int)(full ? nD + nE : 0), lane, wave, s_w[1], totEnt),
                   incD = blk_incl_scan<NW>((int)(full ? nD : 0), lane, wave, s_w[2], totD), incC = blk_incl_scan<NW>((int)(act0 + act1), lane, wave, s_w[3], totC);
+        // the read's blocks may have been laid out from an estimate (k_arena_estimate): nothing is written past them -- the level is abandoned (the levels before it are
+        // complete, and nothing points at this one yet) and the read is built again from exact counts
+        if (EMIT && ((uint64_t)nNodesTot + totF > capN || (uint64_t)nEntries + totEnt > capE || (uint64_t)sumD + totD > capD)) { outgrown = true; break; }
         if (k < nNodes) {
           const uint32_t gid = nNodesTot + incF - full, base = nEntries + incEnt - (full ? nD + nE : 0), dpre = sumD + incD - (full ? nD : 0);
           TM(T_ND, k) = nD; TM(T_NE, k) = nE; TM(T_GID, k) = full ? gid : NONE; TM(T_BASE, k) = base;
@@ -484,6 +498,7 @@ __global__ void __launch_bounds__(64 * NW, NW == 1 ? 8 : 1) sdp_build(BuildArgs 
         }
         nNodesTot += totF; nEntries += totEnt; sumD += totD; nNext += totC;
       }
+      if (outgrown) break;
       SYNC();
       // F: node index of every element for the next level; emit Di / Ei and the visit records
       for (int j = tid; j < Pf; j += NT) {
@@ -567,7 +582,9 @@ __global__ void __launch_bounds__(64 * NW, NW == 1 ? 8 : 1) sdp_build(BuildArgs 
   }
   if (tid == 0) {
     if (!EMIT) { a.cntEntries[rr] = nEntries; a.cntNodes[rr] = nNodesTot; a.cntD[rr] = sumD; a.cntV[rr] = nVisits; a.cntRC[rr] = (uint32_t)max(R, C); }
+    else { a.cntV[rr] = nEntries; a.cntRC[rr] = (uint32_t)max(R, C); }      // (what the read really has; its rows / columns for the choice of the ProcessPoint kernel)
     if (overflow) atomicOr(&a.status[r], (uint32_t)LRA_ST_RANGE);             // more than 2^(LV-1) distinct rows / columns
+    if (outgrown) atomicOr(&a.status[r], (uint32_t)LRA_ST_CAPACITY);
   }
 #undef TB
 #undef TM
@@ -777,6 +794,7 @@ __global__ void __launch_bounds__(64, 4) sdp_process(ProcArgs a) {
 #define W(i, j) pwl_w_tab(s_pen, penN, s_slope, s_inter, c1, c2, (i), (j))
 #define BEATS(a_, x_, b_, y_, e_) pwl_beats(s_pen, penN, s_slope, s_inter, c1, c2, (a_), (x_), (b_), (y_), (e_))
   const int rr = (int)a.order[blockIdx.x], r = a.r0 + rr;
+  if (a.status[r] & LRA_ST_CAPACITY) return;                             // the emit pass gave the read up (it outgrew its estimated blocks): it is built again
   const uint64_t p0 = a.ptOff[r], f0 = a.fragOff[r];
   const int P = (int)(a.ptOff[r + 1] - p0);
   const float rate = a.rate_in ? a.rate_in[r] : a.rate;
@@ -1083,6 +1101,7 @@ __global__ void __launch_bounds__(64 * WG_NW) sdp_process_wg(ProcArgs a) {
 #define W(i, j) pwl_w_tab(s_pen, penN, s_slope, s_inter, c1, c2, (i), (j))
 #define BEATS(a_, x_, b_, y_, e_) pwl_beats(s_pen, penN, s_slope, s_inter, c1, c2, (a_), (x_), (b_), (y_), (e_))
   const int rr = (int)a.order[blockIdx.x], r = a.r0 + rr;
+  if (a.status[r] & LRA_ST_CAPACITY) return;                             // (given up by the emit pass, see sdp_process)
   const uint64_t p0 = a.ptOff[r], f0 = a.fragOff[r];
   const int P = (int)(a.ptOff[r + 1] - p0);
   const float rate = a.rate_in ? a.rate_in[r] : a.rate;
@@ -1901,27 +1920,49 @@ int sdp_run(lra_ctx* ctx, int n_reads, const uint64_t* d_cluster_off, const uint
     memset(&ba, 0, sizeof ba);
     ba.r0 = r0; ba.n = nr; ba.ptOff = ptOff; ba.hq = hq; ba.ht = ht; ba.hfl = hfl; ba.h2 = pay2; ba.key3 = key1; ba.pay3 = pay1; ba.scratch = scratch;
     ba.cntEntries = cntE; ba.cntNodes = cntN; ba.cntD = cntD; ba.cntV = cntV; ba.cntRC = cntRC; ba.status = status; ba.order = order;
-    lra_time_begin(ctx, ctx->sdp_inner ? "sdp_inner_build_count" : "sdp_build_count");
-    {
+    // the count pass: the same divide as the emit pass, for the sizes of a read's blocks -- run for everything only on request (LRA_SDP_ONEPASS=0, LRA_SDP_RATIOS);
+    // otherwise the blocks are laid out from k_arena_estimate and only the reads that outgrow them are counted (attempt 1 below)
+    const bool onePassEnv = !(getenv("LRA_SDP_ONEPASS") && getenv("LRA_SDP_ONEPASS")[0] == '0');
+    const bool onePass = onePassEnv && !getenv("LRA_SDP_RATIOS");
+    auto count_pass = [&](const uint32_t* d_ord, const std::vector<uint32_t>& h_ord, int n) {
+      lra_time_begin(ctx, ctx->sdp_inner ? "sdp_inner_build_count" : "sdp_build_count");
       // reads ordered largest first: the large ones get a 1024-thread workgroup each, beside the wave-per-read launch
       const long big_pts = getenv("LRA_SDP_BIG_POINTS") ? atol(getenv("LRA_SDP_BIG_POINTS")) : (ctx->sdp_inner ? 1500 : 6000);
       int nb0 = 0;
-      while (nb0 < nr && (long)(h_pt[r0 + h_orderAll[nb0] + 1] - h_pt[r0 + h_orderAll[nb0]]) >= big_pts) nb0++;
-      const bool forked = nb0 > 0 && nr > nb0;
-      if (nb0 > 0) hipLaunchKernelGGL((sdp_build<false, 16>), dim3(nb0), dim3(1024), 0, forked ? lra_side_fork(ctx) : st, ba);
-      if (nr > nb0) launch_small_builds<false>(ctx, ba, order, h_orderAll, h_pt.data() + r0, nb0, nr);
+      while (nb0 < n && (long)(h_pt[r0 + h_ord[nb0] + 1] - h_pt[r0 + h_ord[nb0]]) >= big_pts) nb0++;
+      const bool forked = nb0 > 0 && n > nb0;
+      BuildArgs bc = ba; bc.order = d_ord; bc.n = n;
+      if (nb0 > 0) hipLaunchKernelGGL((sdp_build<false, 16>), dim3(nb0), dim3(1024), 0, forked ? lra_side_fork(ctx) : st, bc);
+      if (n > nb0) launch_small_builds<false>(ctx, bc, d_ord, h_ord, h_pt.data() + r0, nb0, n);
       if (forked) lra_side_join(ctx);
-    }
-    lra_time_end(ctx);
-    { int rc = lra_exclusive_scan<uint32_t>(ctx, nr, cntE, entOff); if (rc) return rc; }
+      lra_time_end(ctx);
+    };
     uint64_t totE = 0;
-    LRA_HIP_CHECK(ctx, hipMemcpyAsync(&totE, entOff + nr, 8, hipMemcpyDeviceToHost, st));
     uint32_t maxRC = 0;                                                    // over the chunk's reads: which sdp_process_wg variant serves its large reads
-    {
-      std::vector<uint32_t> h_rc(nr);
+    auto read_rc = [&]() -> int {                                          // ... and the entries the reads have (the count pass's cntE, or what the emit pass found: cntV)
+      std::vector<uint32_t> h_rc(nr), h_e(nr);
       LRA_HIP_CHECK(ctx, hipMemcpyAsync(h_rc.data(), cntRC, (size_t)nr * 4, hipMemcpyDeviceToHost, st));
+      LRA_HIP_CHECK(ctx, hipMemcpyAsync(h_e.data(), onePass ? cntV : cntE, (size_t)nr * 4, hipMemcpyDeviceToHost, st));
       LRA_HIP_CHECK(ctx, hipStreamSynchronize(st));
+      maxRC = 0; totE = 0;
       for (uint32_t v : h_rc) maxRC = std::max(maxRC, v);
+      for (uint32_t v : h_e) totE += v;
+      return LRA_OK;
+    };
+    if (!onePass) { count_pass(order, h_orderAll, nr); int rc = read_rc(); if (rc) return rc; }
+    else {
+      float fE = opts->mode == 0 ? 10.0f : 8.5f, fN = 2.0f;
+      if (const char* e = getenv("LRA_SDP_ESTIMATE")) { float x = 0, y = 0; if (sscanf(e, "%f,%f", &x, &y) == 2 && x > 0 && y > 0) { fE = x; fN = y; } }   // (tests: estimates that many reads outgrow)
+      hipLaunchKernelGGL(k_arena_estimate, dim3((nr + 255) / 256), dim3(256), 0, st, nr, r0, ptOff, fE, fN, cntE, cntN, cntD);
+    }
+    if (getenv("LRA_SDP_RATIOS")) {                                        // analysis: entries / nodes / D entries per point over the chunk's reads
+      std::vector<uint32_t> hE(nr), hN(nr), hD(nr);
+      (void)hipMemcpy(hE.data(), cntE, (size_t)nr * 4, hipMemcpyDeviceToHost); (void)hipMemcpy(hN.data(), cntN, (size_t)nr * 4, hipMemcpyDeviceToHost); (void)hipMemcpy(hD.data(), cntD, (size_t)nr * 4, hipMemcpyDeviceToHost);
+      std::vector<double> rE, rN, rD; double sE = 0, sP = 0;
+      for (int i = 0; i < nr; i++) { const double P = (double)(h_pt[r0 + i + 1] - h_pt[r0 + i]); if (P < 64) continue; rE.push_back(hE[i] / P); rN.push_back(hN[i] / P); rD.push_back(hD[i] / (double)std::max(1u, hE[i])); sE += hE[i]; sP += P; }
+      auto pr = [&](const char* nm, std::vector<double>& v) { if (v.empty()) return; std::sort(v.begin(), v.end()); fprintf(stderr, "[sdp ratios] %s: min %.2f p50 %.2f p90 %.2f p99 %.2f p99.9 %.2f max %.2f\n", nm, v[0], v[v.size() / 2], v[v.size() * 9 / 10], v[v.size() * 99 / 100], v[(size_t)(v.size() * 0.999)], v.back()); };
+      fprintf(stderr, "[sdp ratios] mode %d inner %d reads %d: entries per point overall %.2f\n", opts->mode, (int)ctx->sdp_inner, nr, sE / std::max(1.0, sP));
+      pr("entries / point", rE); pr("nodes / point", rN); pr("D entries / entries", rD);
     }
     // attempt 0: all reads of the chunk; attempts 1, 2: the reads whose candidate stack / Block outgrew its slots, with 8x / 64x the slots
     std::vector<uint32_t> h_status(nr), h_sub;
@@ -1930,12 +1971,12 @@ int sdp_run(lra_ctx* ctx, int n_reads, const uint64_t* d_cluster_off, const uint
     for (int att = 0; att < 3 && nsub > 0; att++) {
       const int shift = 3 * att;
       const int slot = att == 0 ? 12 : 21 + att;
+      if (onePass && att == 1) count_pass(subOrder, h_prev, nsub);         // (exact sizes for the reads that come back: some outgrew their estimated blocks)
       hipLaunchKernelGGL(k_arena_sizes, dim3((nsub + 255) / 256), dim3(256), 0, st, nsub, r0, ptOff, cntE, cntN, cntD, ra, bytes, subOrder, shift);
       { int rc = lra_exclusive_scan<uint64_t>(ctx, nsub, bytes, byteOff); if (rc) return rc; }
       uint64_t totB = 0;
       LRA_HIP_CHECK(ctx, hipMemcpyAsync(&totB, byteOff + nsub, 8, hipMemcpyDeviceToHost, st));
       LRA_HIP_CHECK(ctx, hipStreamSynchronize(st));
-      if (att == 0) totalEntries += totE;
       char* arena = (char*)lra_ensure(ctx, slot, totB + 4096);
       if (!arena) return LRA_ERR_NOMEM;
       hipLaunchKernelGGL(k_arena_bases, dim3((nsub + 255) / 256), dim3(256), 0, st, nsub, byteOff, ra, subOrder, arena);
@@ -1955,6 +1996,7 @@ int sdp_run(lra_ctx* ctx, int n_reads, const uint64_t* d_cluster_off, const uint
         if (forked) lra_side_join(ctx);
       }
       lra_time_end(ctx);
+      if (onePass && att == 0) { int rc = read_rc(); if (rc) return rc; }   // (rows / columns of the reads, known after the emit pass only)
       if (att > 0)
         hipLaunchKernelGGL(k_reset_frags, dim3(nsub), dim3(64), 0, st, r0, subOrder, fragOff, flen, d_rate, opts->rate, fval, fprevNode, fprevInd, fflags, status);
       ProcArgs pa;
@@ -2028,6 +2070,8 @@ int sdp_run(lra_ctx* ctx, int n_reads, const uint64_t* d_cluster_off, const uint
       LRA_HIP_CHECK(ctx, hipStreamSynchronize(st));
       subOrder = order2;
     }
+    if (onePass) { int rc = read_rc(); if (rc) return rc; }                 // (entries as emitted last, re-built reads included)
+    totalEntries += totE;
     const uint64_t cf0 = h_frag[r0], cfn = h_frag[r1] - h_frag[r0];
     if (cfn > 0) {
       lra_time_begin(ctx, ctx->sdp_inner ? "sdp_inner_trace" : "sdp_trace");

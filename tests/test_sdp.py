@@ -122,7 +122,14 @@ def _compare(out, num_aln, reads_in, read_lens, opts_kw):
 
 
 @pytest.mark.gpu
-def test_hip_sdp_random_clusters(ctx):
+@pytest.mark.parametrize("sizes", ["estimated", "outgrown", "counted"])
+def test_hip_sdp_random_clusters(ctx, sizes, monkeypatch):
+    """`sizes`: how a read's blocks are laid out -- from the per-point estimate (the default: no count pass), from estimates so low that most reads outgrow them and
+    are counted and built again, and from the count pass for every read (LRA_SDP_ONEPASS=0)."""
+    if sizes == "outgrown":
+        monkeypatch.setenv("LRA_SDP_ESTIMATE", "2.0,0.5")
+    if sizes == "counted":
+        monkeypatch.setenv("LRA_SDP_ONEPASS", "0")
     rng = np.random.default_rng(77)
     reads_in = []
     for k in range(160):
