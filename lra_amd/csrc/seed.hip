@@ -1120,7 +1120,7 @@ __global__ void __launch_bounds__(256) sort_adopt_kernel(int n_lists, const uint
   const int r = blockIdx.x;
   const uint64_t b = off[r], e = off[r + 1];
   int tie = 0;
-  for (uint64_t i = b + threadIdx.x; i + 1 < e; i += 256) tie |= tkey[i] == tkey[i + 1];
+  for (uint64_t i = b + threadIdx.x; i + 1 < e; i += 256) tie |= (tkey[i] & FOR_MASK) == (tkey[i + 1] & FOR_MASK);   // (what the exact sort's comparison sees: bit 63 is a flag)
   tie = __syncthreads_or(tie);
   if (tie) { if (threadIdx.x == 0) ties[r] = 1; return; }
   if (threadIdx.x == 0) ties[r] = 0;
@@ -1215,8 +1215,11 @@ extern "C" int lra_seed_batch(lra_ctx* ctx, int n_reads, const char* d_seq, cons
   hipLaunchKernelGGL(sketch_kernel<true>, dim3(nb), dim3(64), 0, st, n_reads, seq, d_read_off, k, w, s->mm_off, s->mm_key, s->mm_pos,
                      (uint32_t*)nullptr, (const int*)flagN);
   lra_time_end(ctx);
-  // ---- a2
-  { int rc = launch_sort(ctx, n_reads, s->mm_off, s->mm_key, s->mm_pos); if (rc) return rc; }
+  // ---- a2: a read outside the repeats has no k-mer twice among its minimizers, and a list without equal keys has one sorted order only: the radix path takes nearly
+  // all reads, the exact (libstdc++-identical) sort the ones with a repeated k-mer.  The temporaries are a3's outputs, not written yet.
+  static const bool exactOnly = getenv("LRA_SEED_EXACT_SORT") != nullptr;
+  if (exactOnly || total_mm == 0) { int rc = launch_sort(ctx, n_reads, s->mm_off, s->mm_key, s->mm_pos); if (rc) return rc; }
+  else { int rc = lra_sort_mostly_unique_batch(ctx, n_reads, s->mm_off, total_mm, s->mm_key, s->mm_pos, s->tk_lb, s->lb, std::min(2 * k, 63)); if (rc) return rc; }
   // ---- a3
   if (total_mm) {
     lra_time_begin(ctx, "index_bounds");
