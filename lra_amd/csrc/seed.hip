@@ -749,15 +749,14 @@ __global__ void __launch_bounds__(64) match_capacity_kernel(int n_reads, const u
 // (ii) the alternating two-ended walk of CompareLists.h:43-143, one lane per read.  T[ts] and
 // T[te-1] live in registers and are refreshed from the prefetched neighbourhood arrays whenever
 // ts / te jump to a bound; only the raw-key run skip (:101) still reads the index itself.
-constexpr int FLAT_LANES = 16;
-__global__ void __launch_bounds__(64) compare_kernel(int n_reads, const uint64_t* __restrict__ mm_off, const uint64_t* __restrict__ mm_key,
+__global__ void __launch_bounds__(64) compare_kernel(int FLAT_LANES, int n_reads, const uint64_t* __restrict__ mm_off, const uint64_t* __restrict__ mm_key,
                                                      const uint32_t* __restrict__ lbA, const uint32_t* __restrict__ ubA,
                                                      const uint64_t* __restrict__ tkLbA, const uint64_t* __restrict__ tkLbm1A,
                                                      const uint64_t* __restrict__ tkUbm1A,
                                                      const uint64_t* __restrict__ idx_key, long n_idx, long maxFreq,
                                                      const uint64_t* __restrict__ match_off, uint32_t* __restrict__ match_qi,
                                                      uint32_t* __restrict__ match_ti, uint64_t* __restrict__ counts) {
-  if (threadIdx.x >= FLAT_LANES) return;                                 // a chain of dependent loads per read: fewer lanes per wave, more waves
+  if (threadIdx.x >= FLAT_LANES) return;                                 // the walks of a wave's reads diverge: 32 reads per wave measured best (16: 39 ms, 32: 37, 64: 45)
   const int r = blockIdx.x * FLAT_LANES + threadIdx.x;
   if (r >= n_reads) return;
   const uint64_t* qk = mm_key + mm_off[r];
@@ -773,32 +772,40 @@ __global__ void __launch_bounds__(64) compare_kernel(int n_reads, const uint64_t
   const uint64_t room = match_off[r + 1] - match_off[r];
   uint64_t n = 0;
   const uint64_t M = FOR_MASK;
-#define Qm(i) (qk[(i)] & M)
   if (nq != 0 && nt != 0) {                                            // :27-30
     long qs = 0, qe = nq - 1, ts = 0, te = nt;
     uint64_t Tts = idx_key[0], Tte1 = idx_key[nt - 1];                 // raw T[ts], T[te-1]
     do {
-      while (qs <= qe && Qm(qs) < (Tts & M)) qs++;                     // :47-49
+      // Every load of a step depends on qs / qe only, which are known here: the step's tuples (three keys from each end, the bounds and index keys of qs and qe)
+      // are asked for in one go -- one memory round trip per step instead of one per basic block (~6) -- and the loops below fall back to loads beyond them.
+      const long pq = qs, eq = qe;
+      const uint64_t pK0 = qk[pq], pK1 = qk[pq + 1 < nq ? pq + 1 : pq], pK2 = qk[pq + 2 < nq ? pq + 2 : pq];
+      const uint32_t pLB = LB[pq], pUB = UB[pq]; const uint64_t pTL = TKLB[pq];
+      const uint64_t eK0 = qk[eq], eK1 = qk[eq >= 1 ? eq - 1 : eq], eK2 = qk[eq >= 2 ? eq - 2 : eq];
+      const uint32_t eLB = LB[eq], eUB = UB[eq]; const uint64_t eTU1 = TKUBM1[eq], eTL1 = TKLBM1[eq];
+      auto QF = [&](long i) -> uint64_t { const long d = i - pq; return d == 0 ? pK0 : d == 1 ? pK1 : d == 2 ? pK2 : qk[i]; };   // raw key of tuple i, front / back
+      auto QB = [&](long i) -> uint64_t { const long d = eq - i; return d == 0 ? eK0 : d == 1 ? eK1 : d == 2 ? eK2 : qk[i]; };
+      while (qs <= qe && (QF(qs) & M) < (Tts & M)) qs++;               // :47-49
       if (qs >= qe) break;                                             // :51-53
-      const uint64_t Qs = Qm(qs);
+      const uint64_t Qs = QF(qs) & M;
       uint64_t startGap = Qs - (Tts & M);
-      while (qe > qs && te > ts && Qm(qe) > (Tte1 & M)) qe--;          // :63-65
-      const uint64_t Qe = Qm(qe);
+      while (qe > qs && te > ts && (QB(qe) & M) > (Tte1 & M)) qe--;    // :63-65
+      const uint64_t Qe = QB(qe) & M;
       uint64_t endGap = (Tte1 & M) - Qe;
       if (startGap == 0 || (startGap & M) > (endGap & M)) {            // :69
         const long tsOrig = ts, qsOrig = qs;
         const uint64_t rawOrig = Tts;
-        const long lo = (long)LB[qs];                                  // lower_bound on [ts,te)  (:76)
+        const long lo = (long)(qs == pq ? pLB : LB[qs]);               // lower_bound on [ts,te)  (:76)
         if (lo > ts) {
           if (lo >= te) ts = te;
-          else { ts = lo; Tts = TKLB[qs]; }
+          else { ts = lo; Tts = (qs == pq ? pTL : TKLB[qs]); }
         }
         if (ts < te && (Tts & M) == Qs) {
           const uint32_t tsStart = (uint32_t)ts;
           uint32_t tsi = (uint32_t)ts;
-          { long e = (long)UB[qs]; e = e > te ? te : e; if (e > (long)tsi) tsi = (uint32_t)e; }   // end of the equal run inside [ts,te)
+          { long e = (long)(qs == pq ? pUB : UB[qs]); e = e > te ? te : e; if (e > (long)tsi) tsi = (uint32_t)e; }   // end of the equal run inside [ts,te)
           const uint32_t qsStart = (uint32_t)qs;
-          while (qs < qe && Qm(qs + 1) == Qs) qs++;
+          while (qs < qe && (QF(qs + 1) & M) == Qs) qs++;
           if (qs - (long)qsStart < maxFreq) {
             for (uint32_t ti = tsStart; ti != tsi; ti++)
               for (uint32_t qi = qsStart; (long)qi <= qs; qi++) {
@@ -810,26 +817,26 @@ __global__ void __launch_bounds__(64) compare_kernel(int n_reads, const uint64_t
         if (ts == tsOrig) {                                            // :101 (a jump lands on a different key: no skip)
           while (ts < te && Tts == rawOrig) { ts++; if (ts < nt) Tts = idx_key[ts]; }
         }
-        { const uint64_t raw = qk[qsOrig]; while (qs < qe && qk[qs] == raw) qs++; }             // :102
+        { const uint64_t raw = QF(qsOrig); while (qs < qe && QF(qs) == raw) qs++; }             // :102
       } else {
         if (te != nt && (Tte1 & M) == Qe) {                            // :112-114
         } else {                                                       // upper_bound on [ts,te) (:116-118)
-          const long hi = (long)UB[qe];
+          const long hi = (long)(qe == eq ? eUB : UB[qe]);
           if (hi < te) {
             if (hi <= ts) te = ts;
-            else { te = hi; Tte1 = TKUBM1[qe]; }
+            else { te = hi; Tte1 = (qe == eq ? eTU1 : TKUBM1[qe]); }
           }
         }
         const uint32_t teStart = (uint32_t)te;
         uint32_t tei = (uint32_t)te;
         if ((long)tei > ts && (Tte1 & M) == Qe) {                      // start of the equal run inside [ts,te)
-          long b = (long)LB[qe];
+          long b = (long)(qe == eq ? eLB : LB[qe]);
           if (b <= ts) tei = (uint32_t)ts;
-          else { tei = (uint32_t)b; Tte1 = TKLBM1[qe]; }
+          else { tei = (uint32_t)b; Tte1 = (qe == eq ? eTL1 : TKLBM1[qe]); }
         }
         if (tei < teStart && teStart > 0) {
           const uint32_t qeStart = (uint32_t)qe;
-          while (qe > qs && Qm(qe) == Qm(qe - 1)) qe--;
+          while (qe > qs && (QB(qe) & M) == (QB(qe - 1) & M)) qe--;
           if ((long)qeStart - qe < maxFreq) {
             for (uint32_t ti = tei; ti < teStart; ti++)
               for (uint32_t qi = (uint32_t)qe; qi <= qeStart; qi++) {
@@ -842,7 +849,6 @@ __global__ void __launch_bounds__(64) compare_kernel(int n_reads, const uint64_t
       }
     } while (qs < qe && ts < te);
   }
-#undef Qm
   counts[r] = n;
 }
 
@@ -1237,8 +1243,9 @@ extern "C" int lra_seed_batch(lra_ctx* ctx, int n_reads, const char* d_seq, cons
     if (!regrow(s->tmp_qi, c) || !regrow(s->tmp_ti, c)) return lra_set_err(ctx, LRA_ERR_NOMEM, "match walk buffers (%llu)", (unsigned long long)total_cap);
     s->cap_tmp = c;
   }
+  static const int FLAT_LANES = getenv("LRA_COMPARE_LANES") ? std::max(1, std::min(64, atoi(getenv("LRA_COMPARE_LANES")))) : 32;
   lra_time_begin(ctx, "compare");
-  hipLaunchKernelGGL(compare_kernel, dim3((n_reads + FLAT_LANES - 1) / FLAT_LANES), dim3(64), 0, st, n_reads, s->mm_off, s->mm_key, s->lb, s->ub, s->tk_lb, s->tk_lbm1, s->tk_ubm1, s->idx_key,
+  hipLaunchKernelGGL(compare_kernel, dim3((n_reads + FLAT_LANES - 1) / FLAT_LANES), dim3(64), 0, st, FLAT_LANES, n_reads, s->mm_off, s->mm_key, s->lb, s->ub, s->tk_lb, s->tk_lbm1, s->tk_ubm1, s->idx_key,
                      (long)s->n_idx, (long)max_freq, s->cap_off, s->tmp_qi, s->tmp_ti, s->counts64);
   lra_time_end(ctx);
   if (lra_exclusive_scan<uint64_t>(ctx, (long)n_reads, s->counts64, s->match_off)) return LRA_ERR_HIP;
