@@ -302,15 +302,15 @@ __device__ __forceinline__ bool rs_pass(const RsBand& bd, const uint32_t* tp, co
   }
   return true;
 }
-__global__ void __launch_bounds__(64) rs_compare(RsArgs a, int nLarge) {
-  __shared__ uint64_t skeys[CMP_LDS_KEYS];
+__global__ void __launch_bounds__(64) rs_compare(RsArgs a, int nLarge, int ldsKeys) {
+  extern __shared__ uint64_t skeys[];
   const int j = blockIdx.x, lane = threadIdx.x;
   if (j >= nLarge) return;
   const uint32_t i = a.largeIdx[j];
   const uint64_t* tkG = a.lkey + a.loff[2 * j]; const uint32_t* tp = a.lpos + a.loff[2 * j];
   const uint64_t* qkG = a.lkey + a.loff[2 * j + 1]; const uint32_t* qp = a.lpos + a.loff[2 * j + 1];
   const long nt = (long)(a.loff[2 * j + 1] - a.loff[2 * j]), nq = (long)(a.loff[2 * j + 2] - a.loff[2 * j + 1]);
-  const bool staged = nt + nq <= CMP_LDS_KEYS;
+  const bool staged = nt + nq <= ldsKeys;
   if (staged) {                                                          // the two lists are adjacent in lkey: one copy
     for (long x = lane; x < nt + nq; x += 64) skeys[x] = tkG[x];
     rs_wave_sync();
@@ -542,7 +542,8 @@ static int refine_space_impl(lra_ctx* ctx, int n, const char* d_qseq, const uint
     hipLaunchKernelGGL(rs_compact, dim3(2 * nLarge), dim3(64), 0, st, 2 * nLarge, capOff, loff, rawKey, rawPos, a.lkey, a.lpos);
     { int rc = lra_sort_minimizers_batch(ctx, 2 * nLarge, loff, a.lkey, a.lpos); if (rc) return rc; }   // sort(EndGenomeTup), sort(EndReadTup)  :306,:308
     lra_time_begin(ctx, "rs_long_compare");
-    hipLaunchKernelGGL(rs_compare, dim3(nLarge), dim3(64), 0, st, a, nLarge);
+    static const int ldsKeys = getenv("LRA_RS_LDS_KEYS") ? std::max(0, std::min(CMP_LDS_KEYS, atoi(getenv("LRA_RS_LDS_KEYS")))) : CMP_LDS_KEYS;
+    hipLaunchKernelGGL(rs_compare, dim3(nLarge), dim3(64), (size_t)ldsKeys * 8, st, a, nLarge, ldsKeys);
     lra_time_end(ctx);
   }
   // ---- pairs

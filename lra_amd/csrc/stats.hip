@@ -208,8 +208,9 @@ __global__ void __launch_bounds__(64) stats_kernel(StatArgs A) {
 //                 positions and run indices come from wave prefix sums carried from one group of 64 blocks to the next.
 //   stats_runs    a wave per alignment, a lane per RUN: length = distance to the next start, the twelve counters as wave reductions, `value` as an integer sum up to the
 //                 first gap longer than 20 and from there on as the reference's chain of float additions (:462, :491 make it a non-integer), 64 runs per step.
-// Alignments with overlapping or empty blocks (the cumulative positions of :261-330 then differ from the blocks' own) keep the serial walk.
-struct BlockPiece { int cq, ct, L, ga, gb, common; };
+// Where blocks overlap the walk's q / t leave the blocks' coordinates (:261-330 advance them by what was consumed): they are prefix sums of per-block advances,
+// taken the same way.  Alignments with gaps or blocks of 2^27 and more keep the serial walk.
+struct BlockPiece { int cq, ct, L, ga, gb, common, bl; };   // L: columns of the block's own pairs (max(bl, 0)); bl: what the walk adds to q / t after them (the block's length as given)
 __device__ __forceinline__ int col_kind(const unsigned char* R, const unsigned char* G, long q, long t) { return code2(R[q]) != code2(G[t]) ? 1 : 0; }
 // seqMap without the switch: letters by their low five bits (A 1, C 3, G 7, T 20, either case), the raw codes 0..7 by their low two bits, everything else 0
 __device__ __forceinline__ uint32_t code2b(uint32_t c) {
@@ -254,7 +255,7 @@ __device__ __forceinline__ uint32_t walk_piece(const BlockPiece& P, const unsign
   pairs(R + P.cq, G + P.ct, P.L, m1);
   if (P.ga > 0) { if (cur != 2) { if (WRITE) out[k] = (pos << 2) | 2u; k++; cur = 2; } pos += (uint32_t)P.ga; }
   if (P.gb > 0) { if (cur != 3) { if (WRITE) out[k] = (pos << 2) | 3u; k++; cur = 3; } pos += (uint32_t)P.gb; }
-  if (P.common > 0) pairs(R + P.cq + P.L + P.ga, G + P.ct + P.L + P.gb, P.common, m2);
+  if (P.common > 0) pairs(R + P.cq + P.bl + P.ga, G + P.ct + P.bl + P.gb, P.common, m2);
   return k;
 }
 
@@ -272,40 +273,56 @@ __global__ void __launch_bounds__(64) stats_starts(StatArgs A) {
     const unsigned char* G = A.tseq + A.t_off[a];
     uint32_t* out = A.runs + A.cap_off[a];
     uint32_t carryPos = 0, carryIdx = 0; int carryKind = -1; bool bad = false;
+    long carryQ = nb > 0 ? (long)B[0] : 0, carryT = nb > 0 ? (long)B[1] : 0;     // the walk's own q / t (:261-330): they leave the blocks' coordinates where blocks overlap
     for (long base = 0; base < nb; base += 64) {
       const long i = base + lane; const bool valid = i < nb;
-      BlockPiece P = {0, 0, 0, 0, 0, 0}; bool irr = false;
+      BlockPiece P = {0, 0, 0, 0, 0, 0, 0}; bool irr = false;
+      long advq = 0, advt = 0;
       if (valid) {
-        P.cq = B[3 * i]; P.ct = B[3 * i + 1]; P.L = B[3 * i + 2];
-        if (P.L <= 0) irr = true;
+        const int bq = B[3 * i], bt = B[3 * i + 1], bl = B[3 * i + 2];
+        P.L = bl > 0 ? bl : 0; P.bl = bl;
+        advq = bl; advt = bl;
         if (i + 1 < nb) {
-          const long qg = (long)B[3 * i + 3] - P.cq - P.L, tg = (long)B[3 * i + 4] - P.ct - P.L;
-          if (qg < 0 || tg < 0 || qg >= (1L << 27) || tg >= (1L << 27)) irr = true;
-          else { const long c = qg < tg ? qg : tg; P.common = (int)c; P.ga = (int)(qg - c); P.gb = (int)(tg - c); }
+          long qg = (long)B[3 * i + 3] - bq - bl, tg = (long)B[3 * i + 4] - bt - bl;
+          if (qg >= (1L << 27) || tg >= (1L << 27) || qg <= -(1L << 27) || tg <= -(1L << 27) || bl >= (1 << 27)) irr = true;
+          else if (qg > 0 || tg > 0) {
+            const long c = qg > tg ? tg : qg;
+            tg -= c; qg -= c;
+            P.ga = qg > 0 ? (int)qg : 0; P.gb = tg > 0 ? (int)tg : 0; P.common = c > 0 ? (int)c : 0;
+            advq += P.ga + P.common; advt += P.gb + P.common;
+          }
         }
       }
       if (__ballot(irr) != 0ULL) { bad = true; break; }
+      { long iq = advq, it = advt;                                         // this block's q / t: the sums of the advances before it
+        for (int d = 1; d < 64; d <<= 1) { const long yq = __shfl_up(iq, d), yt = __shfl_up(it, d); if (lane >= d) { iq += yq; it += yt; } }
+        const long q0 = carryQ + iq - advq, t0 = carryT + it - advt;
+        P.cq = (int)q0; P.ct = (int)t0;
+        carryQ += __shfl(iq, 63); carryT += __shfl(it, 63);
+      }
       unsigned long long m1 = 0, m2 = 0;
       if (valid) {
         m1 = kinds64(R + P.cq, G + P.ct, P.L < 64 ? P.L : 64);
-        if (P.common > 0) m2 = kinds64(R + P.cq + P.L + P.ga, G + P.ct + P.L + P.gb, P.common < 64 ? P.common : 64);
+        if (P.common > 0) m2 = kinds64(R + P.cq + P.bl + P.ga, G + P.ct + P.bl + P.gb, P.common < 64 ? P.common : 64);
       }
-      int lastKind = -1;
+      int lastKind = -1;                                                   // kind of the block's last column (-1: it has none)
       if (valid) {
-        if (P.common > 0) lastKind = P.common <= 64 ? (int)((m2 >> (P.common - 1)) & 1ULL) : col_kind(R, G, (long)P.cq + P.L + P.ga + P.common - 1, (long)P.ct + P.L + P.gb + P.common - 1);
+        if (P.common > 0) lastKind = P.common <= 64 ? (int)((m2 >> (P.common - 1)) & 1ULL) : col_kind(R, G, (long)P.cq + P.bl + P.ga + P.common - 1, (long)P.ct + P.bl + P.gb + P.common - 1);
         else if (P.gb > 0) lastKind = 3;
         else if (P.ga > 0) lastKind = 2;
-        else lastKind = P.L <= 64 ? (int)((m1 >> (P.L - 1)) & 1ULL) : col_kind(R, G, (long)P.cq + P.L - 1, (long)P.ct + P.L - 1);
+        else if (P.L > 0) lastKind = P.L <= 64 ? (int)((m1 >> (P.L - 1)) & 1ULL) : col_kind(R, G, (long)P.cq + P.L - 1, (long)P.ct + P.L - 1);
       }
-      int prevKind = __shfl_up(lastKind, 1);
+      int lk = lastKind;                                                   // the last column at or before this block
+      if (lane == 0 && lk < 0) lk = carryKind;
+      for (int d = 1; d < 64; d <<= 1) { const int y = __shfl_up(lk, d); if (lane >= d && lk < 0) lk = y; }
+      int prevKind = __shfl_up(lk, 1);
       if (lane == 0) prevKind = carryKind;
       const uint32_t ncols = valid ? (uint32_t)(P.L + P.ga + P.gb + P.common) : 0u;
       const uint32_t ns = valid ? walk_piece<false>(P, R, G, prevKind, 0, nullptr, m1, m2) : 0u;
       const uint32_t iPos = wave_incl_scan(ncols, lane), iIdx = wave_incl_scan(ns, lane);
       if (valid && ns) walk_piece<true>(P, R, G, prevKind, carryPos + iPos - ncols, out + (carryIdx + iIdx - ns), m1, m2);
       carryPos += __shfl(iPos, 63); carryIdx += __shfl(iIdx, 63);
-      const long lastLane = (nb - base > 64) ? 63 : (nb - base - 1);
-      carryKind = __shfl(lastKind, (int)lastLane);
+      carryKind = __shfl(lk, 63);
     }
     if (lane == 0) {
       A.serial[a] = bad ? 1 : 0;
@@ -470,6 +487,12 @@ extern "C" int lra_calculate_statistics_batch(lra_ctx* ctx, int n_aln, const int
     hipLaunchKernelGGL(stats_kernel<64>, dim3(grid), dim3(64), 0, st, A);   // the alignments with overlapping / empty blocks (normally none)
   }
   lra_time_end(ctx);
+  if (getenv("LRA_STATS_DBG")) {
+    std::vector<int32_t> h(nA); std::vector<uint64_t> bo(nA + 1);
+    (void)hipMemcpyAsync(h.data(), A.serial, nA * 4, hipMemcpyDeviceToHost, st); (void)hipMemcpyAsync(bo.data(), d_block_off, (nA + 1) * 8, hipMemcpyDeviceToHost, st); (void)hipStreamSynchronize(st);
+    long ns = 0, nbmax = 0; for (size_t i = 0; i < nA; i++) if (h[i]) { ns++; nbmax = std::max(nbmax, (long)(bo[i + 1] - bo[i])); }
+    fprintf(stderr, "[stats] %d alignments, %ld left to the serial walk (largest: %ld blocks)\n", n_aln, ns, nbmax);
+  }
   if (lra_exclusive_scan<uint32_t>(ctx, (long)n_aln, A.n_runs, run_off)) return LRA_ERR_HIP;
   uint64_t total = 0;
   LRA_HIP_CHECK(ctx, hipMemcpyAsync(&total, run_off + n_aln, 8, hipMemcpyDeviceToHost, st));

@@ -69,3 +69,61 @@ def test_hip_stats_on_refined_long_reads(ctx, oracle):
         assert cigars[i] == cigar
         assert _bits(value[i]) == _bits(val)
         assert [int(x) for x in counts[i]] == [cnt[k] for k in refine.STAT_NAMES]
+
+
+@pytest.mark.gpu
+def test_hip_stats_overlapping_and_empty_blocks(ctx, oracle):
+    """Blocks that overlap their successor in the read or the genome (negative gaps), blocks of length 0, gaps longer than 20 / 50 (the float chain of `value`):
+    the walk's own q / t then differ from the blocks' coordinates; the parallel form takes them as prefix sums of the advances."""
+    import torch
+    from lra_amd import refine
+    rng = np.random.default_rng(17)
+    n_aln = 48
+    L = 6000
+    reads = [rng.integers(0, 4, L).astype(np.uint8) for _ in range(n_aln)]
+    gens = []
+    blocks = []
+    for a in range(n_aln):
+        g = reads[a].copy()
+        mut = rng.random(L) < 0.08
+        g[mut] = (g[mut] + 1 + rng.integers(0, 3, int(mut.sum()))) % 4
+        gens.append(g)
+        q, t = int(rng.integers(0, 50)), int(rng.integers(0, 50))
+        bl = []
+        nb = int(rng.integers(1, 160))
+        for b in range(nb):
+            ln = int(rng.integers(0, 3)) if rng.random() < 0.06 else int(rng.integers(1, 90))
+            if q + ln >= L - 200 or t + ln >= L - 200:
+                break
+            bl.append((q, t, ln))
+            u = rng.random()
+            if u < 0.12:
+                dq, dt = -int(rng.integers(1, max(1, min(ln, 6)) + 1)), int(rng.integers(0, 8))          # the next block starts inside this one (read side)
+            elif u < 0.24:
+                dq, dt = int(rng.integers(0, 8)), -int(rng.integers(1, max(1, min(ln, 6)) + 1))          # ... genome side
+            elif u < 0.30:
+                dq, dt = -int(rng.integers(1, max(1, min(ln, 4)) + 1)), -int(rng.integers(1, max(1, min(ln, 4)) + 1))
+            elif u < 0.40:
+                dq, dt = int(rng.integers(21, 80)), int(rng.integers(0, 3))                        # long insertion
+            elif u < 0.50:
+                dq, dt = int(rng.integers(0, 3)), int(rng.integers(21, 80))                        # long deletion
+            else:
+                dq, dt = int(rng.integers(0, 6)), int(rng.integers(0, 6))
+            q, t = max(q + ln + dq, 0), max(t + ln + dt, 0)
+        if not bl:
+            bl = [(5, 5, 10)]
+        blocks.append(np.asarray(bl, dtype=np.int32).reshape(-1, 3))
+    to_ascii = np.frombuffer(b"ACGT", dtype=np.uint8)
+    reads = [to_ascii[r] for r in reads]; gens = [to_ascii[g] for g in gens]
+    rl = np.array([len(r) for r in reads], dtype=np.int64); gl = np.array([len(g) for g in gens], dtype=np.int64)
+    qoff = np.concatenate([[0], np.cumsum(rl)[:-1]]); toff = np.concatenate([[0], np.cumsum(gl)[:-1]])
+    qdev = torch.from_numpy(np.concatenate(reads + [np.zeros(64, np.uint8)])).to(ctx.device)
+    tdev = torch.from_numpy(np.concatenate(gens + [np.zeros(64, np.uint8)])).to(ctx.device)
+    b = refine.RefineBatch(ctx, blocks, qdev, qoff, rl.astype(np.int32), tdev, toff, gl)
+    res = refine.calculate_statistics_batch(ctx, b, oracle.log_lookup_table())
+    counts, value, cigars = refine.fetch_stats(ctx, res)
+    for i in range(n_aln):
+        cnt, val, runs, cigar = oracle.calculate_statistics(blocks[i], reads[i].tobytes(), gens[i].tobytes())
+        assert cigars[i] == cigar, i
+        assert _bits(value[i]) == _bits(val), i
+        assert [int(x) for x in counts[i]] == [cnt[k] for k in refine.STAT_NAMES], i
