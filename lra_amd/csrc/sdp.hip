@@ -160,9 +160,14 @@ struct PtArgs {
   uint64_t* key1; uint32_t* pay1; uint32_t* iq; uint32_t* it; uint8_t* ifl; uint32_t* ifr; uint32_t* ptRead;
 };
 
-// one thread per cluster: anchors -> compact fragment arrays + points in insertion order (SparseDP.h:2152-2169)
+// anchors -> compact fragment arrays + points in insertion order (SparseDP.h:2152-2169).  Box mode: one thread per cluster (= fragment).  Anchor mode: one WAVE per
+// cluster, a lane per anchor -- a merged cluster of a satellite read holds 20 k anchors, and one thread walking them kept the launch at 5-13 ms; an anchor's
+// points sit at 2 i (+ 2 behind the first anchor's second pair).
 __global__ void k_points(PtArgs a) {
-  uint64_t c = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const bool boxMode = a.qe != nullptr;
+  const uint64_t gtid = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const uint64_t c = boxMode ? gtid : (gtid >> 6);
+  const uint32_t lane = threadIdx.x & 63;
   if (c >= a.nc) return;
   const uint32_t r = a.clusRead[c];
   const int strand = a.c_strand[c];
@@ -189,7 +194,9 @@ __global__ void k_points(PtArgs a) {
   }
   const uint32_t n = a.c_count[c];
   const uint64_t src = a.c_start[c];
-  for (uint32_t i = 0; i < n; i++, g++) {
+  const uint64_t g0 = g, pc0 = p;
+  for (uint32_t i = lane; i < n; i += 64) {
+    g = g0 + i; p = pc0 + 2 * (uint64_t)i + ((!a.single && i >= 1) ? 2 : 0);
     const uint32_t q = a.q[src + i], t = a.t[src + i];
     const int len = a.len[src + i];
     const uint32_t lf = (uint32_t)(g - f0);
@@ -1825,7 +1832,8 @@ int sdp_run(lra_ctx* ctx, int n_reads, const uint64_t* d_cluster_off, const uint
     pa.qe = d_qe; pa.te = d_te; pa.fqe = fqe; pa.fte = fte;
     pa.key1 = key1; pa.pay1 = pay1; pa.iq = iq; pa.it = it; pa.ifl = ifl; pa.ifr = ifr; pa.ptRead = ptRead;
     lra_time_begin(ctx, ctx->sdp_inner ? "sdp_inner_points" : "sdp_points");
-    hipLaunchKernelGGL(k_points, dim3((unsigned)((NC + 127) / 128)), dim3(128), 0, st, pa);
+    if (pa.qe) hipLaunchKernelGGL(k_points, dim3((unsigned)((NC + 127) / 128)), dim3(128), 0, st, pa);
+    else hipLaunchKernelGGL(k_points, dim3((unsigned)((NC + 3) / 4)), dim3(256), 0, st, pa);
     hipLaunchKernelGGL(k_frag_read, dim3(n_reads), dim3(64), 0, st, n_reads, fragOff, fragRead);
     lra_time_end(ctx);
   }
