@@ -227,6 +227,186 @@ __global__ void __launch_bounds__(64) clean_kernel(CleanArgs A) {
   A.seg_ncl[seg] = ncl;
 }
 
+// ---- the same stage with a WAVE per (read, strand) segment.  clean_kernel walks a segment with one lane: every pass over its matches is a chain of dependent loads, and a
+// read out of a satellite array has tens of thousands of matches -- the launch lasted as long as its largest segment.  Every pass is a map, a scan or a reduction:
+//   * the diagonal runs (:589-722): from the ballots of the neighbour flags, 64 matches per step (runs(): calls back once per run, wave-uniformly, in order);
+//   * AVGfreq (:550-564): the run's distinct read k-mers through a compare-and-swap hash table (the run's own region of tab_key: cleared, then one CAS per probe);
+//   * SecondRoundCleanOffDiagonal (:802-868) in closed form.  Its forward pass clears the runs of neighbours that are too short, but once a run of MinDiagCluster
+//     elements has closed, `prev` stays set and every later element is flagged (the run start is never moved again, so every later run "is long enough"); the backward
+//     pass does the same downwards.  What survives both is the span from the start of the FIRST long-enough run to the closing element of the LAST one;
+//   * compaction and the clusters' boxes: ballot prefix sums and min / max reductions.
+__device__ __forceinline__ void cl_wave_sync() {
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+}
+// flag(i) for i in [lo, hi), flag(hi - 1) == 0: calls fn(ds, e) for every maximal run of set flags [ds, e - 1] (e: the element that closes it), in order.
+template <typename Flag, typename Fn>
+__device__ __forceinline__ void runs(int lo, int hi, int lane, Flag flag, Fn fn) {
+  int start = -1;                                                          // start of a run that is still open
+  for (int b = lo; b < hi; b += 64) {
+    const int i = b + lane;
+    const unsigned long long m = __ballot(i < hi && flag(i));
+    int pos = 0;
+    while (pos < 64) {
+      if (start >= 0) {
+        const unsigned long long z = ~m >> pos;                           // (bits shifted in at the top are set flags' complements of nothing: zeros of ~m are ones of m)
+        if (z == 0ULL) break;
+        const int p = pos + (__ffsll((long long)z) - 1);
+        if (p >= 64) break;
+        fn(start, b + p);
+        start = -1; pos = p + 1;
+      } else {
+        const unsigned long long o = m >> pos;
+        if (o == 0ULL) break;
+        const int p = pos + (__ffsll((long long)o) - 1);
+        start = b + p; pos = p + 1;
+      }
+    }
+  }
+}
+__device__ __forceinline__ int cl_wave_sum(int v) { for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o); return v; }
+__device__ __forceinline__ uint32_t cl_wave_min(uint32_t v) { for (int o = 32; o > 0; o >>= 1) v = min(v, (uint32_t)__shfl_xor((int)v, o)); return v; }
+__device__ __forceinline__ uint32_t cl_wave_max(uint32_t v) { for (int o = 32; o > 0; o >>= 1) v = max(v, (uint32_t)__shfl_xor((int)v, o)); return v; }
+
+__global__ void __launch_bounds__(64) clean_wave_kernel(CleanArgs A) {
+  const int lane = threadIdx.x;
+  const long seg = blockIdx.x;
+  if (seg >= 2L * A.n_reads) return;
+  const int r = (int)(seg >> 1), strand = (int)(seg & 1);
+  const uint64_t m0 = A.match_off[r], mf = m0 + A.n_forward[r], m1 = A.match_off[r + 1];
+  const uint64_t base = strand ? mf : m0;
+  const int n = (int)((strand ? m1 : mf) - base);
+  if (lane == 0) A.seg_ncl[seg] = 0;
+  if (n == 0) return;                                                    // :568-570
+  const uint32_t* q = A.sq + base; const uint32_t* t = A.st + base; const uint64_t* key = A.sk + base;
+  unsigned char* second = A.second + base;
+  int* count = A.count + base; float* freq = A.freq + base;
+  const lra_clean_opts& o = A.o;
+  for (int i = lane; i < n; i += 64) { second[i] = 0; count[i] = -1; freq[i] = 1.0f; }
+  auto onDiag = [&](int i) -> bool { return i + 1 < n && labs(diag_diff(q[i + 1], t[i + 1], q[i], t[i], strand)) < o.cleanMaxDiag; };   // :573-584
+  int largest = 0, lastStart = -1;
+  runs(0, n, lane, onDiag, [&](int ds, int e) { largest = max(largest, e - ds + 1); lastStart = ds; });                        // :589-598
+  if (lastStart < 0) return;                                             // :600-603
+  largest = max(largest, n - lastStart);
+  int minDiagCluster = largest / 10;                                     // :608-609
+  if (minDiagCluster >= o.minDiagCluster) minDiagCluster = o.minDiagCluster;
+  cl_wave_sync();
+  int counter = 0;
+  if (minDiagCluster >= 0) {
+    runs(0, n, lane, onDiag, [&](int diagStart, int i) {                 // :620-722
+      const int len = i - diagStart + 1;
+      if (len >= minDiagCluster) {
+        // AVGfreq :550-564
+        uint32_t tsz = 2; while (tsz < 2u * (uint32_t)len) tsz <<= 1;
+        unsigned long long* T = (unsigned long long*)(A.tab_key + 4 * (base + (uint64_t)diagStart));
+        for (uint32_t x = lane; x < tsz; x += 64) T[x] = ~0ULL;
+        cl_wave_sync();
+        int d = 0;
+        for (int x = diagStart + lane; x <= i; x += 64) {
+          const unsigned long long kk = key[x];
+          uint32_t h = (uint32_t)((kk * 0x9E3779B97F4A7C15ULL) >> 40) & (tsz - 1);
+          while (true) {
+            const unsigned long long old = atomicCAS(&T[h], ~0ULL, kk);
+            if (old == ~0ULL) { d++; break; }
+            if (old == kk) break;
+            h = (h + 1) & (tsz - 1);
+          }
+        }
+        const int distinct = cl_wave_sum(d);
+        const float avgfreq = (float)len / (float)distinct;
+        for (int j = diagStart + lane; j <= i; j += 64) freq[j] = avgfreq;
+        const int cc = o.cleanClustersize;
+        int MinDiagCluster = 0;
+        bool keepAll = false, secondRound = false;
+        if (o.bypassClustering) {                                        // :635-657
+          if (avgfreq >= 3.0f && len < 10) {}
+          else if (avgfreq >= 2.0f && len >= cc) {
+            MinDiagCluster = (int)((float)o.SecondCleanMinDiagCluster + floorf((avgfreq - 1.5f) / 1.0f) * (float)o.punish_anchorfreq + (float)(((len - cc) / cc) * o.anchorPerlength));
+            secondRound = true;
+          } else if (avgfreq >= 1.5f && len >= cc) {
+            MinDiagCluster = (int)((float)o.SecondCleanMinDiagCluster + floorf((avgfreq - 1.5f) / 1.5f) * (float)o.punish_anchorfreq + (float)(((len - cc) / cc) * o.anchorPerlength));
+            secondRound = true;
+          } else keepAll = true;
+        } else {                                                         // :659-693
+          if (avgfreq >= 3.0f && len < 10) {}
+          else if (avgfreq >= 4.0f && len >= cc) {
+            MinDiagCluster = (int)((float)o.SecondCleanMinDiagCluster + floorf((avgfreq - 1.5f) / 1.0f) * (float)o.punish_anchorfreq + (float)(((len - cc) / cc) * o.anchorPerlength));
+            secondRound = true;
+          } else if (avgfreq >= 1.5f && len >= cc) {
+            MinDiagCluster = (int)((float)o.SecondCleanMinDiagCluster + floorf((avgfreq - 1.5f) / 1.5f) * (float)o.punish_anchorfreq + (float)(((len - cc) / cc) * o.anchorPerlength));
+            secondRound = true;
+          } else if (avgfreq > 1.0f && len >= cc) {
+            MinDiagCluster = (int)((float)o.SecondCleanMinDiagCluster - (5.0f - floorf((avgfreq - 1.0f) / 0.1f)) * (float)(o.punish_anchorfreq / 2) + (float)(((len - cc) / cc) * (o.anchorPerlength / 2)));
+            secondRound = true;
+          } else if (avgfreq > 1.0f) {
+            MinDiagCluster = (int)((float)o.SecondCleanMinDiagCluster - (5.0f - floorf((avgfreq - 1.0f) / 0.1f)) * (float)(o.punish_anchorfreq / 2) - (float)(((cc - i + diagStart - 1) / 15) * (o.anchorPerlength / 2)));
+            secondRound = true;
+          } else keepAll = true;
+        }
+        if (secondRound) {                                               // SecondRoundCleanOffDiagonal (:802-868) on [os, oe)
+          const int os = diagStart, oe = i + 1;
+          if (MinDiagCluster >= oe - os) {}
+          else if (MinDiagCluster <= 0) keepAll = true;
+          else if (oe - os <= 1) {}
+          else {
+            const int cmd = o.SecondCleanMaxDiag;
+            int aF = 0x7fffffff, bL = -1;
+            runs(os, oe, lane, [&](int x) -> bool { return x + 1 < oe && labs(diag_diff(q[x + 1], t[x + 1], q[x], t[x], strand)) < cmd; },
+                 [&](int ds, int e) { if (e - ds + 1 >= MinDiagCluster) { aF = min(aF, ds); bL = max(bL, e); } });
+            for (int j = os + lane; j < oe; j += 64) {
+              if (j >= aF && j <= bL) { second[j] = 1; count[j] = counter; }
+              else second[j] = 0;
+            }
+          }
+        }
+        if (keepAll) for (int j = diagStart + lane; j <= i; j += 64) { second[j] = 1; count[j] = counter; }
+      }
+      counter++;
+    });
+  }
+  cl_wave_sync();
+  // compaction (:728-738) and clusters (:740-797)
+  uint32_t* oq = A.cl_q + base; uint32_t* ot = A.cl_t + base;
+  const unsigned long long below = (lane == 0) ? 0ULL : (~0ULL >> (64 - lane));
+  int c = 0;
+  for (int b = 0; b < n; b += 64) {
+    const int i = b + lane;
+    const bool keep = i < n && second[i];
+    uint32_t vq = 0, vt = 0; float vf = 0; int vc = 0;
+    if (keep) { vq = q[i]; vt = t[i]; vf = freq[i]; vc = count[i]; }
+    const unsigned long long m = __ballot(keep);
+    cl_wave_sync();                                                        // (freq / count are compacted in place: this step's reads before its writes)
+    if (keep) { const int d = c + __popcll(m & below); oq[d] = vq; ot[d] = vt; freq[d] = vf; count[d] = vc; }
+    c += __popcll(m);
+  }
+  cl_wave_sync();
+  uint32_t ncl = 0;
+  auto emit = [&](int s0, int e0) {
+    uint32_t qS = 0xFFFFFFFFu, qE = 0, tS = 0xFFFFFFFFu, tE = 0;
+    for (int b = s0 + lane; b < e0; b += 64) {
+      qS = min(qS, oq[b]); qE = max(qE, oq[b] + (uint32_t)o.globalK);
+      tS = min(tS, ot[b]); tE = max(tE, ot[b] + (uint32_t)o.globalK);
+    }
+    qS = cl_wave_min(qS); qE = cl_wave_max(qE); tS = cl_wave_min(tS); tE = cl_wave_max(tE);
+    if (lane == 0) {
+      const uint64_t x = base + ncl;
+      A.c_start[x] = base + s0; A.c_end[x] = base + e0; A.c_qs[x] = qS; A.c_qe[x] = qE; A.c_ts[x] = tS; A.c_te[x] = tE;
+      A.c_strand[x] = strand; A.c_freq[x] = freq[s0];
+      A.c_chrom[x] = header_find(A.chrom_pos, A.n_chrom + 1, tS);
+    }
+    ncl++;
+  };
+  int count_s = 0;
+  for (int b = 0; b < c; b += 64) {                                        // a cluster ends where the run counter changes
+    const int i = b + lane;
+    unsigned long long m = __ballot(i >= 1 && i < c && count[i] != count[i - 1]);
+    while (m) { const int p = __ffsll((long long)m) - 1; m &= m - 1; emit(count_s, b + p); count_s = b + p; }
+  }
+  if (c > 0 && count_s < c) emit(count_s, c);
+  if (lane == 0) A.seg_ncl[seg] = ncl;
+}
+
 // compaction of the per-segment cluster records (capacity layout: segment base = its first match)
 struct CompactArgs {
   long n_seg; const uint64_t* seg_base; const uint64_t* seg_coff;
@@ -299,7 +479,8 @@ extern "C" int lra_clean_matches_batch(lra_ctx* ctx, const lra_clean_opts* opts,
   uint64_t* seg_coff = carve<uint64_t>(w, NS);
   void* temp = (void*)w;
   LRA_HIP_CHECK(ctx, hipMemcpyAsync(d_chrom, h_chrom_pos, (size_t)(n_chrom + 1) * 8, hipMemcpyHostToDevice, st));
-  LRA_HIP_CHECK(ctx, hipMemsetAsync(A.tab_tag, 0, 4 * N * 4, st));
+  static const bool cleanSerial = getenv("LRA_CLEAN_SERIAL") != nullptr;   // the one-lane-per-segment walk (kept for comparison)
+  if (cleanSerial) LRA_HIP_CHECK(ctx, hipMemsetAsync(A.tab_tag, 0, 4 * N * 4, st));   // (its hash table's tags; clean_wave_kernel clears what it uses)
   // results: cleaned matches
   char* rbuf = (char*)lra_ensure(ctx, 4, sz(N, 4) * 2 + 4096);
   if (!rbuf) return LRA_ERR_NOMEM;
@@ -316,7 +497,8 @@ extern "C" int lra_clean_matches_batch(lra_ctx* ctx, const lra_clean_opts* opts,
   lra_time_end(ctx);
   // ---- clean
   lra_time_begin(ctx, "clean");
-  hipLaunchKernelGGL(clean_kernel, dim3((2 * n_reads + CLEAN_LANES - 1) / CLEAN_LANES), dim3(64), 0, st, A);
+  if (cleanSerial) hipLaunchKernelGGL(clean_kernel, dim3((2 * n_reads + CLEAN_LANES - 1) / CLEAN_LANES), dim3(64), 0, st, A);
+  else hipLaunchKernelGGL(clean_wave_kernel, dim3(2 * n_reads), dim3(64), 0, st, A);
   lra_time_end(ctx);
   if (lra_exclusive_scan<uint32_t>(ctx, 2L * n_reads, A.seg_ncl, seg_coff)) return LRA_ERR_HIP;
   uint64_t ncl = 0;
