@@ -990,9 +990,16 @@ int lra_aog_launch_device(lra_ctx* ctx, int n, const char* d_qseq, const char* d
   }
   if (a.use_reg) {
     lra_time_begin(ctx, "aog_reg");
+    // the three register classes side by side as well (each ends with a few long problems; one after the other they took 43 ms of the a13 call, LRA_AOG_SERIAL=1)
     hipLaunchKernelGGL(aog_reg_kernel<10>, dim3(min((n + 15) / 16, ctx->num_cu * 10)), dim3(256), 16 * REG_S_BYTES, sm, a);
-    hipLaunchKernelGGL(aog_reg_kernel<11>, dim3(min((n + 3) / 4, ctx->num_cu * 10)), dim3(128), 4 * REG_M_BYTES, sm, a);
-    hipLaunchKernelGGL(aog_reg_kernel<12>, dim3(min(n, ctx->num_cu * 10)), dim3(64), a.regL, sm, a);
+    lra_time_end(ctx);
+    lra_time_begin(ctx, "aog_reg_medium", s2);
+    hipLaunchKernelGGL(aog_reg_kernel<11>, dim3(min((n + 3) / 4, ctx->num_cu * 10)), dim3(128), 4 * REG_M_BYTES, s2, a);
+    lra_time_end(ctx, s2);
+    lra_time_begin(ctx, "aog_reg_large", s3);
+    hipLaunchKernelGGL(aog_reg_kernel<12>, dim3(min(n, ctx->num_cu * 10)), dim3(64), a.regL, s3, a);
+    lra_time_end(ctx, s3);
+    lra_time_begin(ctx, "aog_reg");
     if (a.regX) hipLaunchKernelGGL(aog_reg_kernel<13>, dim3(min(n, ctx->num_cu * 4)), dim3(64), a.regX, sm, a);
     lra_time_end(ctx);
   }
