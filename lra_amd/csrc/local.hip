@@ -12,6 +12,7 @@
 // A LocalTuple is the word  t | pos << 20  (TupleOps.h:20-25).  Windows hold ~40-80 tuples, so every
 // window / task is one lane: 7.7 M windows per 32 k-read batch keep the chip full.
 #include "common.h"
+#include <vector>
 #include "scan.h"
 #include <algorithm>
 
@@ -300,13 +301,19 @@ struct CmpArgs {
   const uint32_t* t; const uint64_t* t_lo; const uint64_t* t_hi;
   long maxFreq; const int64_t* maxDiag; const int64_t* minDiag;
   const uint64_t* out_off; uint32_t* out_qi; uint32_t* out_ti; uint32_t* counts;
+  uint16_t* capped; int* nOver;                 // MODE 2: the pairs of task x as (qi << 8 | ti) at capped[x * CMP_CAP ..], the tasks that do not fit counted
 };
+constexpr int CMP_CAP = 128;                    // pairs per task kept by the one-pass form (a task of two ~30-tuple lists yields ~20; the headline batch's largest 104)
 
 // A block's 64 tasks share CMP_WORDS words of LDS, each task's query list then its target list packed behind the previous task's (a task of more than CMP_TASK_MAX words,
 // or one that no longer fits, is walked in HBM): a typical task has ~180 words, so 40 KB hold a block and four blocks fit a CU (fixed 257-word rows: two).
 constexpr int CMP_WORDS = 10240, CMP_TASK_MAX = 512;
-template <bool EMIT>
+// MODE 0: count; 1: write the pairs at out_off (after a scan of the counts: the walk runs twice); 2: count AND keep the pairs, packed, in a fixed row per task --
+// local_compact_pairs then lays them out by the scan of the counts.  A task with a list of more than 255 tuples or more than CMP_CAP pairs sends the batch
+// through modes 0 + 1 (nOver).
+template <int MODE>
 __global__ void __launch_bounds__(STAGE_NT) local_compare(CmpArgs A) {
+  constexpr bool EMIT = MODE == 1;
   __shared__ uint32_t stage[CMP_WORDS];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const uint64_t x0 = (uint64_t)blockIdx.x * 64;
@@ -345,6 +352,7 @@ __global__ void __launch_bounds__(STAGE_NT) local_compare(CmpArgs A) {
   const int64_t maxDiag = A.maxDiag ? A.maxDiag[x] : 0, minDiag = A.minDiag ? A.minDiag[x] : 0;
   const long maxFreq = A.maxFreq;
   uint32_t* oq = EMIT ? A.out_qi + A.out_off[x] : nullptr; uint32_t* ot = EMIT ? A.out_ti + A.out_off[x] : nullptr;
+  uint16_t* cp = MODE == 2 ? A.capped + x * (uint64_t)CMP_CAP : nullptr;
   uint32_t n = 0;
   auto emit = [&](long qi, long ti) {                                    // :87-97
     if (maxDiag != 0 && minDiag != 0) {
@@ -352,6 +360,7 @@ __global__ void __launch_bounds__(STAGE_NT) local_compare(CmpArgs A) {
       if (!(d <= maxDiag && d >= minDiag)) return;
     }
     if (EMIT) { oq[n] = (uint32_t)(A.q_lo[x] + qi); ot[n] = (uint32_t)(A.t_lo[x] + ti); }
+    if (MODE == 2 && n < (uint32_t)CMP_CAP) cp[n] = (uint16_t)((qi << 8) | ti);
     n++;
   };
 #define Q(i) T_(q[(i)])
@@ -404,6 +413,18 @@ __global__ void __launch_bounds__(STAGE_NT) local_compare(CmpArgs A) {
 #undef Q
 #undef TT
   if (!EMIT) A.counts[x] = n;
+  if (MODE == 2 && (n > (uint32_t)CMP_CAP || nq > 255 || nt > 255)) atomicAdd(A.nOver, 1);
+}
+
+// the kept pairs of 4 tasks per wave (16 lanes each) to their places
+__global__ void __launch_bounds__(64) local_compact_pairs(CmpArgs A) {
+  const uint64_t x = (uint64_t)blockIdx.x * 4 + (threadIdx.x >> 4);
+  if (x >= A.n_tasks) return;
+  const int l = threadIdx.x & 15;
+  const uint32_t n = A.counts[x];
+  const uint64_t o = A.out_off[x], ql = A.q_lo[x], tl = A.t_lo[x];
+  const uint16_t* cp = A.capped + x * (uint64_t)CMP_CAP;
+  for (uint32_t p = l; p < n; p += 16) { const uint32_t v = cp[p]; A.out_qi[o + p] = (uint32_t)(ql + (v >> 8)); A.out_ti[o + p] = (uint32_t)(tl + (v & 255u)); }
 }
 
 template <typename T>
@@ -500,17 +521,32 @@ extern "C" int lra_local_compare_batch(lra_ctx* ctx, uint64_t n_tasks, const uin
   uint64_t* off = carve<uint64_t>(w, n_tasks + 1);
   A.out_off = off; A.out_qi = nullptr; A.out_ti = nullptr;
   const unsigned g = (unsigned)((n_tasks + 63) / 64);
+  static const bool twoPass = getenv("LRA_LOCAL_TWO_PASS") != nullptr;      // count, scan, walk again (kept for comparison; also what a batch with an oversized task falls back to)
+  int* nOver = (int*)lra_ensure(ctx, 94, 64);
+  A.capped = twoPass ? nullptr : (uint16_t*)lra_ensure(ctx, 95, (size_t)n_tasks * CMP_CAP * 2 + 256);
+  if (!nOver || (!twoPass && !A.capped)) return LRA_ERR_NOMEM;
+  A.nOver = nOver;
+  LRA_HIP_CHECK(ctx, hipMemsetAsync(nOver, 0, 4, st));
   lra_time_begin(ctx, "local_compare");
-  hipLaunchKernelGGL(local_compare<false>, dim3(g), dim3(STAGE_NT), 0, st, A);
+  if (twoPass) hipLaunchKernelGGL(local_compare<0>, dim3(g), dim3(STAGE_NT), 0, st, A);
+  else hipLaunchKernelGGL(local_compare<2>, dim3(g), dim3(STAGE_NT), 0, st, A);
   lra_time_end(ctx);
   if (lra_exclusive_scan<uint32_t>(ctx, (long)n_tasks, A.counts, off)) return LRA_ERR_HIP;
-  uint64_t total = 0;
+  uint64_t total = 0; int h_over = 0;
+  LRA_HIP_CHECK(ctx, hipMemcpyAsync(&h_over, nOver, 4, hipMemcpyDeviceToHost, st));
   if (d2h8(ctx, &total, off + n_tasks)) return LRA_ERR_HIP;
+  if (getenv("LRA_LOCAL_DBG")) {
+    std::vector<uint32_t> h(n_tasks); (void)hipMemcpy(h.data(), A.counts, n_tasks * 4, hipMemcpyDeviceToHost);
+    long over[6] = {0, 0, 0, 0, 0, 0}; const uint32_t lim[6] = {16, 32, 48, 64, 96, 128}; uint32_t mx = 0;
+    for (uint32_t v : h) { mx = std::max(mx, v); for (int i = 0; i < 6; i++) if (v > lim[i]) over[i]++; }
+    fprintf(stderr, "[local_compare] %llu tasks, %llu pairs, max %u, %d oversized; tasks with more than 16/32/48/64/96/128 pairs: %ld %ld %ld %ld %ld %ld\n", (unsigned long long)n_tasks, (unsigned long long)total, mx, h_over, over[0], over[1], over[2], over[3], over[4], over[5]);
+  }
   char* r = (char*)lra_scratch(ctx, 1, sz(total + 1, 4) * 2 + 4096);
   if (!r) return LRA_ERR_NOMEM;
   A.out_qi = carve<uint32_t>(r, total + 1); A.out_ti = carve<uint32_t>(r, total + 1);
   lra_time_begin(ctx, "local_compare");
-  hipLaunchKernelGGL(local_compare<true>, dim3(g), dim3(STAGE_NT), 0, st, A);
+  if (twoPass || h_over > 0) hipLaunchKernelGGL(local_compare<1>, dim3(g), dim3(STAGE_NT), 0, st, A);
+  else hipLaunchKernelGGL(local_compact_pairs, dim3((unsigned)((n_tasks + 3) / 4)), dim3(64), 0, st, A);
   lra_time_end(ctx);
   LRA_HIP_CHECK(ctx, hipGetLastError());
   LRA_HIP_CHECK(ctx, hipStreamSynchronize(st));
