@@ -137,3 +137,40 @@ def test_hip_local_compare_matches_golden_and_oracle(ctx, oracle):
         assert np.array_equal(pqi[a:b], eq + np.uint32(ql[x])) and np.array_equal(pti[a:b], et + np.uint32(tl[x])), x
         npairs += b - a
     assert npairs > 500
+
+
+@pytest.mark.gpu
+def test_hip_local_compare_oversized_tasks(ctx, oracle):
+    """Tasks that do not fit the one-pass form's row (more than 128 pairs, a list of more than 255 tuples) beside ordinary ones: the batch falls back to count + emit."""
+    import torch
+    from lra_amd import local
+    class Raw:
+        pass
+    rng = np.random.default_rng(11)
+    qs, ts, ql, qh, tl, th = [], [], [], [], [], []
+    qo = to = 0
+    for c in range(40):
+        if c % 10 == 3:                                             # few distinct k-mers, many copies: hundreds of pairs
+            nq, nt, nkeys = 60, 60, 6
+        elif c % 10 == 7:                                           # long lists
+            nq, nt, nkeys = 300, 280, 400
+        else:
+            nq, nt, nkeys = int(rng.integers(1, 40)), int(rng.integers(1, 40)), 60
+        keys = np.sort(rng.choice(1 << 20, nkeys, replace=False)).astype(np.uint32)
+        qk = np.sort(rng.choice(keys, nq)); tk = np.sort(rng.choice(keys, nt))
+        qp = rng.integers(0, 256, nq).astype(np.uint32); tp = rng.integers(0, 256, nt).astype(np.uint32)
+        qs.append(oracle.pack_local(qk, qp)); ts.append(oracle.pack_local(tk, tp))
+        ql.append(qo); qo += nq; qh.append(qo); tl.append(to); to += nt; th.append(to)
+    qa = np.concatenate(qs + [np.zeros(1, np.uint32)]); ta = np.concatenate(ts + [np.zeros(1, np.uint32)])
+    A, B = Raw(), Raw()
+    A.t_ = torch.from_numpy(qa.view(np.int32)).to(ctx.device); B.t_ = torch.from_numpy(ta.view(np.int32)).to(ctx.device)
+    A.res = local.LocalIndexResult(); B.res = local.LocalIndexResult()
+    A.res.d_tuples = A.t_.data_ptr(); B.res.d_tuples = B.t_.data_ptr()
+    off, pqi, pti = local.local_compare_batch(ctx, A, ql, qh, B, tl, th, 15)
+    big = 0
+    for x in range(len(ql)):
+        eq, et = oracle.compare_lists_local(qa[ql[x]:qh[x]], ta[tl[x]:th[x]], 15)
+        a, b = int(off[x]), int(off[x + 1])
+        assert np.array_equal(pqi[a:b], eq + np.uint32(ql[x])) and np.array_equal(pti[a:b], et + np.uint32(tl[x])), x
+        big += (b - a) > 128
+    assert big >= 2
