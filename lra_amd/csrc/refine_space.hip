@@ -542,7 +542,7 @@ static int refine_space_impl(lra_ctx* ctx, int n, const char* d_qseq, const uint
     hipLaunchKernelGGL(rs_compact, dim3(2 * nLarge), dim3(64), 0, st, 2 * nLarge, capOff, loff, rawKey, rawPos, a.lkey, a.lpos);
     { int rc = lra_sort_minimizers_batch(ctx, 2 * nLarge, loff, a.lkey, a.lpos); if (rc) return rc; }   // sort(EndGenomeTup), sort(EndReadTup)  :306,:308
     lra_time_begin(ctx, "rs_long_compare");
-    static const int ldsKeys = getenv("LRA_RS_LDS_KEYS") ? std::max(0, std::min(CMP_LDS_KEYS, atoi(getenv("LRA_RS_LDS_KEYS")))) : CMP_LDS_KEYS;
+    static const int ldsKeys = getenv("LRA_RS_LDS_KEYS") ? std::max(0, std::min(CMP_LDS_KEYS, atoi(getenv("LRA_RS_LDS_KEYS")))) : 1536;   // (measured, headline batch, lists of 2-4 k keys per gap: 7168 keys of LDS per wave 54 ms, 3072: 50, 1536: 49, 512: 52 -- the waves per CU matter more than where the keys sit)
     hipLaunchKernelGGL(rs_compare, dim3(nLarge), dim3(64), (size_t)ldsKeys * 8, st, a, nLarge, ldsKeys);
     lra_time_end(ctx);
   }
