@@ -718,24 +718,20 @@ __global__ void __launch_bounds__(64) ir_fill_16x2(FillArgs F) {
     int nM[2] = {BAD, BAD}, nD[2] = {BAD, BAD};
     int carryW = NEG, carryV = NEG, carryM = BAD;
     const int np = (!done && len > G) ? 2 : 1;
-    // narrow: no group of the wave has more than 16 cells in this row or the one above (the usual step: a read's rows are 15 cells wide away from its longer
-    // indels).  Then j < 2 G, the previous row's second piece is never a valid neighbour (aboveIn fails for srcA >= 16) and nothing is carried between pieces:
-    // eight of the step's thirteen cross-lane reads drop out.
-    const bool narrow = __ballot(!done && (len > G || prevLen > G)) == 0ULL;
     for (int p = 0; p < np; p++) {
       const int cc = c + G * p;
       // the query base of cell cc: position S + cc = W0 + j, j in [0, 4 G)
       const int j = S - W0 + cc;
       const int l = gbase + (j & (G - 1));
-      const int qa = __shfl(q0, l), qbb = __shfl(q1, l), qc = narrow ? 0 : __shfl(q2, l), qd = narrow ? 0 : __shfl(q3, l);
+      const int qa = __shfl(q0, l), qbb = __shfl(q1, l), qc = __shfl(q2, l), qd = __shfl(q3, l);
       const int qch = (j < G) ? qa : (j < 2 * G) ? qbb : (j < 3 * G) ? qc : qd;
       const bool interior = cc >= 1 && (lastRow ? cc <= len - 1 : cc <= len - 2);
       const int srcA = cc + off, srcD = srcA - 1;
       const bool aboveIn = srcA <= prevLen - 1;                            // qE[ti-1] >= q   (:491,:548,:567)
       // the previous row's cells srcA and srcA - 1 (pieces 0 / 1 of it)
       const int la = gbase + (srcA & (G - 1)), ld = gbase + (srcD & (G - 1));
-      const int a0 = __shfl(pM[0], la), a1 = narrow ? BAD : __shfl(pM[1], la), b0 = __shfl(pD[0], la), b1 = narrow ? BAD : __shfl(pD[1], la);
-      const int d0 = __shfl(pM[0], ld), d1 = narrow ? BAD : __shfl(pM[1], ld);
+      const int a0 = __shfl(pM[0], la), a1 = __shfl(pM[1], la), b0 = __shfl(pD[0], la), b1 = __shfl(pD[1], la);
+      const int d0 = __shfl(pM[0], ld), d1 = __shfl(pM[1], ld);
       const int aM = (srcA & G) ? a1 : a0, aD = (srcA & G) ? b1 : b0;
       const int dM = (srcD & G) ? d1 : d0;
       const bool okA = aboveIn && !is_bound(ti - 1, srcA, prevLen);
@@ -775,7 +771,7 @@ __global__ void __launch_bounds__(64) ir_fill_16x2(FillArgs F) {
       }
       if (!done && cc < len) P[C + cc] = outB;
       nM[p] = outM; nD[p] = outD;
-      if (!narrow) { carryW = __shfl(W, gbase + G - 1); carryV = __shfl(V, gbase + G - 1); carryM = __shfl(M, gbase + G - 1); }
+      carryW = __shfl(W, gbase + G - 1); carryV = __shfl(V, gbase + G - 1); carryM = __shfl(M, gbase + G - 1);
     }
     if (!done) {
       pM[0] = nM[0]; pM[1] = nM[1]; pD[0] = nD[0]; pD[1] = nD[1]; prevS = S; prevLen = len;
