@@ -996,7 +996,8 @@ int lra_map_reads_highacc_batch(lra_ctx* ctx, int n_reads, const char* d_seq, co
  * :182-283, :405-421): files are read one after the other; a batch takes reads while it holds fewer than max_bases bases (so it ends with the read that
  * crosses the limit).  The batch's arrays are owned by the reader and valid until the next call: seq = the reads' bases, upper-cased, back to back + 64 bytes
  * of padding; off[n_reads + 1]; names / reads / quals / read_len as lra_map_records takes them (quals[i] == NULL for FASTA reads).
- * lra_map_reads_host is the boundary with host buffers: it copies the batch to the device and calls the driver opts->bypassClustering selects.          */
+ * lra_map_reads_host is the boundary with host buffers: it copies the batch to the device and calls the driver opts->bypassClustering selects.
+ * Not supported: streamed input ("-", "stdin", "/dev/stdin": the format sniffing seeks; the reference reads those through htslib) and BAM input (htslib).  */
 typedef struct lra_reads lra_reads;
 typedef struct lra_read_batch {
   int32_t n_reads; uint64_t total_bases;
