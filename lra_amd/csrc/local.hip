@@ -62,23 +62,38 @@ constexpr int WMAX = 256;            // staged window length; longer windows rea
 constexpr int WSTRIDE = WMAX + 4;
 // One pass: window wi writes its tuples at raw + wi * stride (stride = window - k + 1 slots: a window cannot emit more tuples than it has
 // k-mer positions) and its count; the sort / filter and the compaction read the slab through (wi * stride, counts[wi]).
+__device__ __forceinline__ uint32_t spread16(uint32_t x) {            // bit i of x -> bit 2 i
+  x = (x | (x << 8)) & 0x00FF00FFu; x = (x | (x << 4)) & 0x0F0F0F0Fu; x = (x | (x << 2)) & 0x33333333u; x = (x | (x << 1)) & 0x55555555u;
+  return x;
+}
+// The serial scan of a window is a chain of LDS round trips (base, ring), so the kernel's time is that chain over the waves a CU holds: the window's bases are staged
+// as 2-bit codes + an N mask (24 words per lane instead of 260 bytes; a word serves 16 positions from a register), the ring entry is the packed tuple itself
+// (t | pos << 20) and the ring has w slots, not MAXW: ~7 KB of LDS per wave instead of 25 -- 21 waves per CU instead of 6.
 __global__ void __launch_bounds__(64) local_sketch(uint64_t n_win, const unsigned char* __restrict__ seq_all, const uint64_t* __restrict__ w_start,
                                                    const uint32_t* __restrict__ w_len, int k, int w, uint64_t stride,
                                                    uint32_t* __restrict__ raw, uint32_t* __restrict__ counts) {
   constexpr bool EMIT = true;
-  __shared__ uint32_t ringT[MAXW * 64], ringP[MAXW * 64];
-  __shared__ unsigned char stage[64 * WSTRIDE];
+  extern __shared__ uint32_t ls_lds[];
+  uint32_t* codes = ls_lds;                         // [WMAX / 16][64]: 16 codes per word, lane-interleaved
+  uint32_t* nmask = codes + (WMAX / 16) * 64;       // [WMAX / 32][64]
+  uint32_t* ring = nmask + (WMAX / 32) * 64;        // [w][64]
   const int lane = threadIdx.x;
   const uint64_t w0 = (uint64_t)blockIdx.x * 64;
   const uint64_t wi = w0 + lane;
-  // cooperative staging of the wave's windows
+  // cooperative staging of the wave's windows: 64 bases per step, packed with three ballots
   for (int x = 0; x < 64; x++) {
     const uint64_t wx = w0 + x;
     if (wx >= n_win) break;
     const uint32_t L = w_len[wx];
     if (L > WMAX) continue;
     const unsigned char* src = seq_all + w_start[wx];
-    for (uint32_t p = lane; p < L; p += 64) stage[x * WSTRIDE + p] = src[p];
+    for (uint32_t it = 0; it * 64 < L; it++) {
+      const uint32_t p = it * 64 + lane;
+      const int c = p < L ? code_n(src[p]) : 0;
+      const unsigned long long b0 = __ballot(c & 1), b1 = __ballot(c & 2), bn = __ballot(c > 3);
+      if (lane < 4) codes[(it * 4 + lane) * 64 + x] = spread16((uint32_t)(b0 >> (16 * lane)) & 0xFFFFu) | (spread16((uint32_t)(b1 >> (16 * lane)) & 0xFFFFu) << 1);
+      if (lane < 2) nmask[(it * 2 + lane) * 64 + x] = (uint32_t)(bn >> (32 * lane));
+    }
   }
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
   __builtin_amdgcn_wave_barrier();
@@ -87,8 +102,8 @@ __global__ void __launch_bounds__(64) local_sketch(uint64_t n_win, const unsigne
   const uint32_t seqLen = w_len[wi];
   const bool staged = seqLen <= WMAX;
   const unsigned char* gseq = seq_all + w_start[wi];
-  const unsigned char* lseq = stage + lane * WSTRIDE;
-  auto SEQ = [&](uint32_t p) -> unsigned char { return staged ? lseq[p] : gseq[p]; };
+  auto C2 = [&](uint32_t p) -> uint32_t { return staged ? (codes[(p >> 4) * 64 + lane] >> ((p & 15) * 2)) & 3u : code2(gseq[p]); };       // seqMap: N -> 0
+  auto ISN = [&](uint32_t p) -> bool { return staged ? ((nmask[(p >> 5) * 64 + lane] >> (p & 31)) & 1u) != 0 : code_n(gseq[p]) > 3; };
   uint32_t* out = raw + wi * stride;
   uint32_t n = 0;
 #define LS_EMIT(T__, P__) do { if (EMIT) out[n] = ((T__) & TMASK) | (((P__) & 0xFFFu) << 20); n++; } while (0)
@@ -103,41 +118,52 @@ __global__ void __launch_bounds__(64) local_sketch(uint64_t n_win, const unsigne
     while ((uint32_t)nvStart < seqLen - (uint32_t)span && !valid) {
       valid = true;
       for (long x = nvStart; valid && x < nvStart + span; x++)
-        if (code_n(SEQ((uint32_t)x)) > 3) { nvStart = x + 1; valid = false; }
+        if (ISN((uint32_t)x)) { nvStart = x + 1; valid = false; }
     }
     return valid;
   };
   if (!find_valid()) LS_DONE();
   nvEnd = nvStart + span;
   uint32_t cur = 0;
-  for (int p = 0; p < k; p++) cur = ((cur << 2) + code2(SEQ(p))) & TMASK;
-  auto shift = [&](uint32_t at) { cur = ((((cur << 2) & TMASK) & kmask) + code2(SEQ(at))) & TMASK; };
+  for (int p = 0; p < k; p++) cur = ((cur << 2) + C2(p)) & TMASK;
+  // the stream of bases the scan shifts in, position after position: a staged window's words are held in registers for 16 / 32 positions
+  uint32_t cw = 0, nw = 0;
+  auto next_base = [&](uint32_t at, uint32_t& c2, bool& isn) {
+    if (staged) {
+      if ((at & 15) == 0 || at == (uint32_t)k) cw = codes[(at >> 4) * 64 + lane];
+      if ((at & 31) == 0 || at == (uint32_t)k) nw = nmask[(at >> 5) * 64 + lane];
+      c2 = (cw >> ((at & 15) * 2)) & 3u; isn = ((nw >> (at & 31)) & 1u) != 0;
+    } else { const int c = code_n(gseq[at]); c2 = c > 3 ? 0u : (uint32_t)c; isn = c > 3; }
+  };
+  auto shift_in = [&](uint32_t c2) { cur = ((((cur << 2) & TMASK) & kmask) + c2) & TMASK; };
   uint32_t actT = cur, actP = 0;
-  ringT[lane] = actT; ringP[lane] = 0;
+  ring[lane] = actT;                                                      // (position 0 in the high bits)
   uint32_t p;
   const uint32_t nk = seqLen - k + 1;
   for (p = 1; p < (uint32_t)w && p < nk; p++) {                          // :251-270
-    shift(p + k - 1);
+    uint32_t c2; bool isn; next_base(p + k - 1, c2, isn);
+    shift_in(c2);
     if (cur < actT) { actT = cur; actP = p; }
-    ringT[(p % w) * 64 + lane] = cur; ringP[(p % w) * 64 + lane] = p;
+    ring[(p % w) * 64 + lane] = cur | (p << 20);
   }
   if (nvEnd == span) LS_EMIT(actT, actP);
   uint32_t slot = 0;                                                     // p % w for p = w
   for (p = w; p < nk; p++) {                                             // :276-337
-    shift(p + k - 1);
+    uint32_t c2; bool isn; next_base(p + k - 1, c2, isn);
+    shift_in(c2);
     if (nvEnd == (long)(p + k - 1)) {
-      if (code_n(SEQ(p + k - 1)) <= 3) nvEnd++;
+      if (!isn) nvEnd++;
       else {
         nvStart = p + k;
         if (!find_valid()) LS_DONE();
         nvEnd = nvStart + span;
       }
     }
-    ringT[slot * 64 + lane] = cur; ringP[slot * 64 + lane] = p;
+    ring[slot * 64 + lane] = cur | (p << 20);
     if (++slot == (uint32_t)w) slot = 0;
     if (p - w >= actP) {
-      actT = ringT[lane]; actP = ringP[lane];
-      for (int j = 1; j < w; j++) { uint32_t t = ringT[j * 64 + lane]; if (t < actT) { actT = t; actP = ringP[j * 64 + lane]; } }
+      { const uint32_t e = ring[lane]; actT = e & TMASK; actP = e >> 20; }
+      for (int j = 1; j < w; j++) { const uint32_t e = ring[j * 64 + lane]; if ((e & TMASK) < actT) { actT = e & TMASK; actP = e >> 20; } }
       if (nvEnd == (long)(p + k)) LS_EMIT(actT, actP);
     } else if (cur < actT) {
       actT = cur; actP = p;
@@ -476,7 +502,7 @@ extern "C" int lra_local_index_masked_batch(lra_ctx* ctx, int n_seqs, const char
   if (n_win) {
     hipLaunchKernelGGL(window_map, dim3((n_seqs + 255) / 256), dim3(256), 0, st, n_seqs, d_seq_off, window, win_off, d_active, w_seq, w_start, w_len);
     lra_time_begin(ctx, "local_sketch");
-    hipLaunchKernelGGL(local_sketch, dim3(gw), dim3(64), 0, st, n_win, seq, w_start, w_len, k, w, stride, raw, cnt);
+    hipLaunchKernelGGL(local_sketch, dim3(gw), dim3(64), (size_t)((WMAX / 16 + WMAX / 32 + w) * 64 * 4), st, n_win, seq, w_start, w_len, k, w, stride, raw, cnt);
     lra_time_end(ctx);
     lra_time_begin(ctx, "local_sort_filter");
     hipLaunchKernelGGL(local_sort_filter, dim3(gw), dim3(STAGE_NT), 0, st, n_win, stride, raw, max_freq, cnt);
