@@ -255,13 +255,17 @@ constexpr int STAGE_NT = 256;                                           // 4 wav
 // (a window holds ~45 tuples: the 64 lists of a block are packed behind one another in LS_WORDS words of LDS -- 24 KB, six blocks per CU -- instead of 64 rows of LCAP;
 // a list that no longer fits, like one above LCAP, is sorted in HBM)
 constexpr int LS_WORDS = 6144;
-__global__ void __launch_bounds__(STAGE_NT) local_sort_filter(uint64_t n_win, uint64_t stride, uint32_t* raw, int maxFreq, uint32_t* counts) {
+// sel != null: the kernel's windows are sel[0 .. *nSel) (the lists local_sort_unique left: a key twice), 64 per block as before.
+__global__ void __launch_bounds__(STAGE_NT) local_sort_filter(uint64_t n_win_all, uint64_t stride, uint32_t* raw, int maxFreq, uint32_t* counts,
+                                                              const uint32_t* __restrict__ sel, const uint64_t* __restrict__ nSel) {
   __shared__ uint32_t stage[LS_WORDS];
   __shared__ uint32_t kept[64];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const uint64_t n_win = sel ? *nSel : n_win_all;
   const uint64_t w0 = (uint64_t)blockIdx.x * 64;
-  const uint64_t wi = w0 + lane;
-  const uint64_t myA = wi * stride, myN = wi < n_win ? counts[wi] : 0;       // raw count in, filtered count out
+  if (w0 >= n_win) return;
+  const uint64_t wi = (w0 + lane < n_win) ? (sel ? (uint64_t)sel[w0 + lane] : w0 + lane) : ~0ULL;   // the window this lane sorts (~0: none)
+  const uint64_t myA = wi * stride, myN = wi != ~0ULL ? counts[wi] : 0;       // raw count in, filtered count out
   const uint32_t need = myN <= (uint64_t)LCAP ? (uint32_t)myN : 0u;
   uint32_t incl = need;
   for (int d = 1; d < 64; d <<= 1) { const uint32_t o = __shfl_up(incl, d); if (lane >= d) incl += o; }
@@ -277,7 +281,7 @@ __global__ void __launch_bounds__(STAGE_NT) local_sort_filter(uint64_t n_win, ui
   __syncthreads();
   if (wave == 0) {
     long c = 0;
-    if (wi < n_win) {
+    if (wi != ~0ULL) {
       const long n = (long)myN;
       const bool staged = myFits;
       // (once per address space, so that the list in LDS is read with ds_read and the one in HBM with global_load instead of flat_load through an either-or pointer)
@@ -305,6 +309,50 @@ __global__ void __launch_bounds__(STAGE_NT) local_sort_filter(uint64_t n_win, ui
     const uint32_t cx = kept[x];
     for (uint32_t p = lane; p < cx; p += 64) raw[a + p] = stage[so + p];
   }
+}
+
+// ---- sort(minimizers) + RemoveFrequent for the windows whose tuples have pairwise different keys -- nearly all: two equal 10-mers among a window's ~85 minimizers need a
+// repeat inside 256 bases.  Such a list has ONE sorted order (the comparison is on t only, and no two t are equal), so libstdc++'s permutation does not matter and the
+// sort is a rank count: a wave per window, a lane per tuple, rank = the tuples with a smaller key (every key read once from LDS, broadcast); nothing is removed
+// (every key occurs once, and 1 < maxFreq).  A window with a key twice, or with more than RANK_CAP tuples, is left as it is and flagged: local_sort_filter's exact
+// sort takes those (one lane per list walking LDS: the chain the whole stage used to be, 19 ms).
+constexpr int RANK_CAP = 256;
+__global__ void __launch_bounds__(256) local_sort_unique(uint64_t n_win, uint64_t stride, uint32_t* raw, const uint32_t* __restrict__ counts, uint32_t* __restrict__ flag) {
+  __shared__ uint32_t keys[4][RANK_CAP];
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const uint64_t wi = (uint64_t)blockIdx.x * 4 + wv;
+  if (wi >= n_win) return;
+  const uint32_t n = counts[wi];
+  if (n < 2) { if (lane == 0) flag[wi] = 0; return; }
+  if (n > (uint32_t)RANK_CAP) { if (lane == 0) flag[wi] = 1; return; }
+  uint32_t* v = raw + wi * stride;
+  uint32_t* K = keys[wv];
+  uint32_t e[RANK_CAP / 64];
+#pragma unroll
+  for (int c = 0; c < RANK_CAP / 64; c++) { const uint32_t i = c * 64 + lane; e[c] = i < n ? v[i] : 0xFFFFFFFFu; if (i < n) K[i] = T_(e[c]); }
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+  uint32_t rank[RANK_CAP / 64] = {}, eq[RANK_CAP / 64] = {};
+  const int nc = (int)((n + 63) / 64);
+  for (uint32_t j = 0; j < n; j++) {
+    const uint32_t tj = K[j];
+#pragma unroll
+    for (int c = 0; c < RANK_CAP / 64; c++) if (c < nc) { const uint32_t ti = T_(e[c]); rank[c] += tj < ti; eq[c] += tj == ti; }
+  }
+  bool tie = false;
+#pragma unroll
+  for (int c = 0; c < RANK_CAP / 64; c++) if (c < nc && (uint32_t)(c * 64 + lane) < n && eq[c] > 1) tie = true;
+  const bool anyTie = __ballot(tie) != 0ULL;
+  if (!anyTie) {
+#pragma unroll
+    for (int c = 0; c < RANK_CAP / 64; c++) if (c < nc && (uint32_t)(c * 64 + lane) < n) v[rank[c]] = e[c];
+  }
+  if (lane == 0) flag[wi] = anyTie ? 1u : 0u;
+}
+__global__ void local_sel(uint64_t n_win, const uint32_t* __restrict__ flag, const uint64_t* __restrict__ off, uint32_t* __restrict__ sel) {
+  const uint64_t wi = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (wi < n_win && flag[wi]) sel[off[wi]] = (uint32_t)wi;
 }
 
 // the surviving tuples of every window, packed: a wave takes 64 windows, one after the other, its lanes side by side (coalesced both ways)
@@ -504,8 +552,18 @@ extern "C" int lra_local_index_masked_batch(lra_ctx* ctx, int n_seqs, const char
     lra_time_begin(ctx, "local_sketch");
     hipLaunchKernelGGL(local_sketch, dim3(gw), dim3(64), (size_t)((WMAX / 16 + WMAX / 32 + w) * 64 * 4), st, n_win, seq, w_start, w_len, k, w, stride, raw, cnt);
     lra_time_end(ctx);
+    static const bool exactOnly = getenv("LRA_LOCAL_EXACT_SORT") != nullptr;   // every list through the exact sort (kept for comparison)
     lra_time_begin(ctx, "local_sort_filter");
-    hipLaunchKernelGGL(local_sort_filter, dim3(gw), dim3(STAGE_NT), 0, st, n_win, stride, raw, max_freq, cnt);
+    if (exactOnly || max_freq < 2 || n_win >= (1ULL << 32)) hipLaunchKernelGGL(local_sort_filter, dim3(gw), dim3(STAGE_NT), 0, st, n_win, stride, raw, max_freq, cnt, (const uint32_t*)nullptr, (const uint64_t*)nullptr);
+    else {
+      char* ws = (char*)lra_ensure(ctx, 96, sz(NW, 4) * 2 + sz(NW, 8) + 1024);
+      if (!ws) return LRA_ERR_NOMEM;
+      uint32_t* flag = carve<uint32_t>(ws, NW); uint32_t* sel = carve<uint32_t>(ws, NW); uint64_t* foff = carve<uint64_t>(ws, NW);
+      hipLaunchKernelGGL(local_sort_unique, dim3((unsigned)((n_win + 3) / 4)), dim3(256), 0, st, n_win, stride, raw, (const uint32_t*)cnt, flag);
+      if (lra_exclusive_scan<uint32_t>(ctx, (long)n_win, flag, foff)) return LRA_ERR_HIP;
+      hipLaunchKernelGGL(local_sel, dim3((unsigned)((n_win + 255) / 256)), dim3(256), 0, st, n_win, (const uint32_t*)flag, (const uint64_t*)foff, sel);
+      hipLaunchKernelGGL(local_sort_filter, dim3(gw), dim3(STAGE_NT), 0, st, n_win, stride, raw, max_freq, cnt, (const uint32_t*)sel, (const uint64_t*)(foff + n_win));
+    }
     lra_time_end(ctx);
     if (lra_exclusive_scan<uint32_t>(ctx, (long)n_win, cnt, bnd_tmp)) return LRA_ERR_HIP;
     if (d2h8(ctx, &n_tup, bnd_tmp + n_win)) return LRA_ERR_HIP;
