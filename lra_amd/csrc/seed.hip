@@ -765,26 +765,29 @@ __global__ void __launch_bounds__(64) compare_kernel(int FLAT_LANES, int n_reads
   const uint64_t* TKLB = tkLbA + mm_off[r];
   const uint64_t* TKLBM1 = tkLbm1A + mm_off[r];
   const uint64_t* TKUBM1 = tkUbm1A + mm_off[r];
-  const long nq = (long)(mm_off[r + 1] - mm_off[r]);
-  const long nt = n_idx;
+  // (32-bit cursors: a read's tuples and the index both stay below 2^32 -- lb / ub are 32-bit -- and the walk is bound by instruction issue, where every 64-bit
+  // compare or add is two)
+  const int nq = (int)(mm_off[r + 1] - mm_off[r]);
+  const uint32_t nt = (uint32_t)n_idx;
+  const int mf = maxFreq > 0x7fffffffL ? 0x7fffffff : (int)maxFreq;
   uint32_t* oq = match_qi + match_off[r];
   uint32_t* ot = match_ti + match_off[r];
   const uint64_t room = match_off[r + 1] - match_off[r];
   uint64_t n = 0;
   const uint64_t M = FOR_MASK;
   if (nq != 0 && nt != 0) {                                            // :27-30
-    long qs = 0, qe = nq - 1, ts = 0, te = nt;
+    int qs = 0, qe = nq - 1; uint32_t ts = 0, te = nt;
     uint64_t Tts = idx_key[0], Tte1 = idx_key[nt - 1];                 // raw T[ts], T[te-1]
     do {
       // Every load of a step depends on qs / qe only, which are known here: the step's tuples (three keys from each end, the bounds and index keys of qs and qe)
       // are asked for in one go -- one memory round trip per step instead of one per basic block (~6) -- and the loops below fall back to loads beyond them.
-      const long pq = qs, eq = qe;
+      const int pq = qs, eq = qe;
       const uint64_t pK0 = qk[pq], pK1 = qk[pq + 1 < nq ? pq + 1 : pq], pK2 = qk[pq + 2 < nq ? pq + 2 : pq];
       const uint32_t pLB = LB[pq], pUB = UB[pq]; const uint64_t pTL = TKLB[pq];
       const uint64_t eK0 = qk[eq], eK1 = qk[eq >= 1 ? eq - 1 : eq], eK2 = qk[eq >= 2 ? eq - 2 : eq];
       const uint32_t eLB = LB[eq], eUB = UB[eq]; const uint64_t eTU1 = TKUBM1[eq], eTL1 = TKLBM1[eq];
-      auto QF = [&](long i) -> uint64_t { const long d = i - pq; return d == 0 ? pK0 : d == 1 ? pK1 : d == 2 ? pK2 : qk[i]; };   // raw key of tuple i, front / back
-      auto QB = [&](long i) -> uint64_t { const long d = eq - i; return d == 0 ? eK0 : d == 1 ? eK1 : d == 2 ? eK2 : qk[i]; };
+      auto QF = [&](int i) -> uint64_t { const int d = i - pq; return d == 0 ? pK0 : d == 1 ? pK1 : d == 2 ? pK2 : qk[i]; };   // raw key of tuple i, front / back
+      auto QB = [&](int i) -> uint64_t { const int d = eq - i; return d == 0 ? eK0 : d == 1 ? eK1 : d == 2 ? eK2 : qk[i]; };
       while (qs <= qe && (QF(qs) & M) < (Tts & M)) qs++;               // :47-49
       if (qs >= qe) break;                                             // :51-53
       const uint64_t Qs = QF(qs) & M;
@@ -793,22 +796,22 @@ __global__ void __launch_bounds__(64) compare_kernel(int FLAT_LANES, int n_reads
       const uint64_t Qe = QB(qe) & M;
       uint64_t endGap = (Tte1 & M) - Qe;
       if (startGap == 0 || (startGap & M) > (endGap & M)) {            // :69
-        const long tsOrig = ts, qsOrig = qs;
+        const uint32_t tsOrig = ts; const int qsOrig = qs;
         const uint64_t rawOrig = Tts;
-        const long lo = (long)(qs == pq ? pLB : LB[qs]);               // lower_bound on [ts,te)  (:76)
+        const uint32_t lo = qs == pq ? pLB : LB[qs];                   // lower_bound on [ts,te)  (:76)
         if (lo > ts) {
           if (lo >= te) ts = te;
           else { ts = lo; Tts = (qs == pq ? pTL : TKLB[qs]); }
         }
         if (ts < te && (Tts & M) == Qs) {
-          const uint32_t tsStart = (uint32_t)ts;
-          uint32_t tsi = (uint32_t)ts;
-          { long e = (long)(qs == pq ? pUB : UB[qs]); e = e > te ? te : e; if (e > (long)tsi) tsi = (uint32_t)e; }   // end of the equal run inside [ts,te)
+          const uint32_t tsStart = ts;
+          uint32_t tsi = ts;
+          { uint32_t e = qs == pq ? pUB : UB[qs]; e = e > te ? te : e; if (e > tsi) tsi = e; }   // end of the equal run inside [ts,te)
           const uint32_t qsStart = (uint32_t)qs;
           while (qs < qe && (QF(qs + 1) & M) == Qs) qs++;
-          if (qs - (long)qsStart < maxFreq) {
+          if (qs - (int)qsStart < mf) {
             for (uint32_t ti = tsStart; ti != tsi; ti++)
-              for (uint32_t qi = qsStart; (long)qi <= qs; qi++) {
+              for (uint32_t qi = qsStart; qi <= (uint32_t)qs; qi++) {
                 if (n < room) { oq[n] = qi; ot[n] = ti; }
                 n++;
               }
@@ -821,23 +824,23 @@ __global__ void __launch_bounds__(64) compare_kernel(int FLAT_LANES, int n_reads
       } else {
         if (te != nt && (Tte1 & M) == Qe) {                            // :112-114
         } else {                                                       // upper_bound on [ts,te) (:116-118)
-          const long hi = (long)(qe == eq ? eUB : UB[qe]);
+          const uint32_t hi = qe == eq ? eUB : UB[qe];
           if (hi < te) {
             if (hi <= ts) te = ts;
             else { te = hi; Tte1 = (qe == eq ? eTU1 : TKUBM1[qe]); }
           }
         }
-        const uint32_t teStart = (uint32_t)te;
-        uint32_t tei = (uint32_t)te;
-        if ((long)tei > ts && (Tte1 & M) == Qe) {                      // start of the equal run inside [ts,te)
-          long b = (long)(qe == eq ? eLB : LB[qe]);
-          if (b <= ts) tei = (uint32_t)ts;
-          else { tei = (uint32_t)b; Tte1 = (qe == eq ? eTL1 : TKLBM1[qe]); }
+        const uint32_t teStart = te;
+        uint32_t tei = te;
+        if (tei > ts && (Tte1 & M) == Qe) {                      // start of the equal run inside [ts,te)
+          const uint32_t b = qe == eq ? eLB : LB[qe];
+          if (b <= ts) tei = ts;
+          else { tei = b; Tte1 = (qe == eq ? eTL1 : TKLBM1[qe]); }
         }
         if (tei < teStart && teStart > 0) {
           const uint32_t qeStart = (uint32_t)qe;
           while (qe > qs && (QB(qe) & M) == (QB(qe - 1) & M)) qe--;
-          if ((long)qeStart - qe < maxFreq) {
+          if ((int)qeStart - qe < mf) {
             for (uint32_t ti = tei; ti < teStart; ti++)
               for (uint32_t qi = (uint32_t)qe; qi <= qeStart; qi++) {
                 if (n < room) { oq[n] = qi; ot[n] = ti; }
