@@ -796,7 +796,14 @@ __global__ void __launch_bounds__(CLS == 10 ? 256 : CLS == 11 ? 128 : 64) aog_re
 // sweep never computes -- row / column 0, the rails, everything off the band -- are what solve()'s boundary stores leave there: pre() for the scores, pre_arrow()
 // for the arrows.  The walk runs twice over the arrows in LDS (count the blocks and find where it ends; then store them in alignment order).
 
+// MX: the class's largest sequence length (3, 6, 10, 16, 24).  The kernel is a chain of LDS round trips per lane, so its time is that chain over the waves a CU holds:
+// the tables are sized for the class (a row of at most 16 arrows is one word), 2.5 / 4.5 / 7 / 11 / 22 KB per wave instead of 22 for all, and a class's problems
+// load MX bases per sequence, not 24.
+template <int MX>
 __global__ void __launch_bounds__(64) aog_lane_kernel(BatchArgs a, int cls) {
+  constexpr int LN_MAX = MX, LN_ROWW = MX > 16 ? 2 : 1;
+  constexpr int LN_ARROW_WORDS = LN_MAX * LN_ROWW, LN_PREV_WORDS = LN_MAX + 2, LN_CODE_BYTES = LN_MAX + 1;
+  constexpr int LN_BYTES = 64 * (4 * LN_ARROW_WORDS + 4 * LN_PREV_WORDS + 2 * LN_CODE_BYTES);
   __shared__ __attribute__((aligned(16))) char smem[LN_BYTES];
   const int lane = threadIdx.x;
   unsigned* AR = (unsigned*)smem;                                         // [LN_ARROW_WORDS][64]
@@ -858,14 +865,14 @@ __global__ void __launch_bounds__(64) aog_lane_kernel(BatchArgs a, int cls) {
           PV[i * 64 + lane] = best;
           dg = up; left = best;
         }
-        AR[((j - 1) * LN_ROWW) * 64 + lane] = (unsigned)acc; AR[((j - 1) * LN_ROWW + 1) * 64 + lane] = (unsigned)(acc >> 32);
+        AR[((j - 1) * LN_ROWW) * 64 + lane] = (unsigned)acc; if (LN_ROWW > 1) AR[((j - 1) * LN_ROWW + 1) * 64 + lane] = (unsigned)(acc >> 32);
       }
       const int ci = qB - 1, cj = tB - 1;
       const int result = in_region(ci, cj) ? PV[ci * 64 + lane] : ((ci >= 0 && cj >= 0) ? pre(ci, cj) : MISS);
       auto arrow_at = [&](int i, int j) -> int {
         if (!in_region(i, j)) return pre_arrow(i, j);
         const int sh = 2 * (i - max(1, j - k));
-        const unsigned w = AR[((j - 1) * LN_ROWW + (sh >> 5)) * 64 + lane];
+        const unsigned w = AR[((j - 1) * LN_ROWW + (LN_ROWW > 1 ? (sh >> 5) : 0)) * 64 + lane];
         return (int)((w >> (sh & 31)) & 3u);
       };
       const long cap = (long)(a.block_off[p + 1] - a.block_off[p]);
@@ -985,7 +992,12 @@ int lra_aog_launch_device(lra_ctx* ctx, int n, const char* d_qseq, const char* d
   lra_time_end(ctx, s3);
   if (a.use_lane) {
     lra_time_begin(ctx, "aog_lane");
-    for (int c = 18; c >= 14; c--) hipLaunchKernelGGL(aog_lane_kernel, dim3(min((n + 63) / 64, ctx->num_cu * 7)), dim3(64), 0, sm, a, c);
+    const int nb64 = (n + 63) / 64;
+    hipLaunchKernelGGL(aog_lane_kernel<24>, dim3(min(nb64, ctx->num_cu * 7)), dim3(64), 0, sm, a, 18);
+    hipLaunchKernelGGL(aog_lane_kernel<16>, dim3(min(nb64, ctx->num_cu * 14)), dim3(64), 0, sm, a, 17);
+    hipLaunchKernelGGL(aog_lane_kernel<10>, dim3(min(nb64, ctx->num_cu * 22)), dim3(64), 0, sm, a, 16);
+    hipLaunchKernelGGL(aog_lane_kernel<6>, dim3(min(nb64, ctx->num_cu * 32)), dim3(64), 0, sm, a, 15);
+    hipLaunchKernelGGL(aog_lane_kernel<3>, dim3(min(nb64, ctx->num_cu * 32)), dim3(64), 0, sm, a, 14);
     lra_time_end(ctx);
   }
   if (a.use_reg) {
