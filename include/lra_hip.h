@@ -68,7 +68,7 @@ int lra_ctx_set_stream(lra_ctx* ctx, void* stream);
 const char* lra_ctx_last_error(lra_ctx* ctx);
 /* ABI version of the loaded library (tests check it against this header). */
 int lra_abi_version(void);
-#define LRA_ABI_VERSION 3   /* 2: lra_map_opts.defer_matches, lra_map_counters.n_deferred_reads; 3: lra_map_opts.flagged_unaligned, lra_map_counters.n_flagged_reads, lra_map_host_flagged */
+#define LRA_ABI_VERSION 4   /* 2: lra_map_opts.defer_matches, lra_map_counters.n_deferred_reads; 3: lra_map_opts.flagged_unaligned, lra_map_counters.n_flagged_reads, lra_map_host_flagged; 4: lra_reads_last_error, a corrupt FASTQ record is LRA_ERR_INVALID */
 
 /* Convenience for hosts without their own HIP binding: synchronous device->host copy on the
  * context's stream (a C++ host would call hipMemcpy itself).                                */
@@ -996,6 +996,8 @@ int lra_map_reads_highacc_batch(lra_ctx* ctx, int n_reads, const char* d_seq, co
  * :182-283, :405-421): files are read one after the other; a batch takes reads while it holds fewer than max_bases bases (so it ends with the read that
  * crosses the limit).  The batch's arrays are owned by the reader and valid until the next call: seq = the reads' bases, upper-cased, back to back + 64 bytes
  * of padding; off[n_reads + 1]; names / reads / quals / read_len as lra_map_records takes them (quals[i] == NULL for FASTA reads).
+ * A FASTQ record whose quality string has another length than its read (the reference asserts, Input.h:287) makes lra_reads_next_batch return LRA_ERR_INVALID
+ * on that call and on every later one: the batch of that call holds the reads in front of the record, lra_reads_last_error names the record.
  * lra_map_reads_host is the boundary with host buffers: it copies the batch to the device and calls the driver opts->bypassClustering selects.
  * Not supported: streamed input ("-", "stdin", "/dev/stdin": the format sniffing seeks; the reference reads those through htslib) and BAM input (htslib).  */
 typedef struct lra_reads lra_reads;
@@ -1006,6 +1008,7 @@ typedef struct lra_read_batch {
 } lra_read_batch;
 int lra_reads_open(const char* const* files, int n_files, lra_reads** out);
 int lra_reads_next_batch(lra_reads* r, uint64_t max_bases, lra_read_batch* batch);
+const char* lra_reads_last_error(const lra_reads* r);
 void lra_reads_close(lra_reads* r);
 int lra_map_reads_host(lra_ctx* ctx, int n_reads, const char* h_seq, const uint64_t* h_off, const lra_map_opts* opts, lra_map_result* out);
 int lra_map_records(lra_ctx* ctx, const lra_map_result* res, const lra_map_opts* opts, const char* const* names, const char* const* reads,

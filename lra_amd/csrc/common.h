@@ -3,6 +3,8 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stdio.h>
+#include <atomic>
+#include <memory>
 #include <string>
 #include <string.h>
 #include <vector>
@@ -11,6 +13,9 @@
 struct lra_seed_state;
 struct lra_cluster_state;
 struct lra_map_state;
+// The generation of a context's reference data, shared (refcounted) between the owner and every context that borrows from it, so that a borrower's staleness
+// check never reads the owner's state: `gen` is bumped by each of the owner's loaders, `dead` is set when the owner is destroyed (its device buffers are freed).
+struct lra_gen_cell { std::atomic<uint64_t> gen{0}; std::atomic<bool> dead{false}; };
 struct lra_time_rec { const char* name; hipEvent_t a, b; hipStream_t stream; };
 
 struct lra_ctx {

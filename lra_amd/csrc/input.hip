@@ -20,6 +20,7 @@ struct lra_reads {
   std::ifstream strm;
   int type = -1;                                   // 0 FASTA, 1 FASTQ
   bool open_ok = false;
+  std::string error;                               // a record the reference would abort on: lra_reads_next_batch returns LRA_ERR_INVALID from then on
   // the current batch
   std::string seq, names, quals;
   std::vector<uint64_t> off, name_off, qual_off;
@@ -93,9 +94,14 @@ bool get_next(lra_reads* r, std::string& name, std::string& seq, std::string& qu
   name = first_token_behind_first_char(header);
   squeeze_upper(seq);
   squeeze(qual);
-  // the reference asserts qual.size() == seq.size() (Input.h: the FASTQ branch of GetNext); a record that breaks it ends the input here instead of handing the
-  // formatter a quality string shorter than the read (it would read past it)
-  if (qual.size() != seq.size()) { r->open_ok = false; return false; }
+  // the reference asserts qual.size() == seq.size() (Input.h: the FASTQ branch of GetNext) and, without asserts, hands the formatter a quality string of another
+  // length than the read (it would read past it): the input ends here WITH an error -- never as a normal end of file, which would drop the rest silently
+  if (qual.size() != seq.size()) {
+    r->open_ok = false;
+    r->error = "FASTQ record '" + name + "' of " + r->files[r->cur] + ": quality string of " + std::to_string(qual.size()) + " characters for a read of " +
+               std::to_string(seq.size()) + " bases";
+    return false;
+  }
   return true;
 }
 
@@ -137,8 +143,10 @@ extern "C" int lra_reads_next_batch(lra_reads* r, uint64_t max_bases, lra_read_b
   }
   b->n_reads = (int32_t)n; b->total_bases = total; b->seq = r->seq.data(); b->off = r->off.data(); b->read_len = r->len.data();
   b->names = r->name_ptr.data(); b->reads = r->seq_ptr.data(); b->quals = r->qual_ptr.data();
-  return LRA_OK;
+  return r->error.empty() ? LRA_OK : LRA_ERR_INVALID;                      // the batch still holds the reads in front of the bad record
 }
+
+extern "C" const char* lra_reads_last_error(const lra_reads* r) { return r ? r->error.c_str() : ""; }
 
 // The boundary with host buffers: the reads of a batch (upper-case bases back to back, n_reads + 1 offsets; what lra_reads_next_batch returns) are copied to
 // the device and mapped by the driver opts->bypassClustering selects (MapRead.h:228-240).  The device copies live in context buffers.

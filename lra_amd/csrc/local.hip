@@ -138,6 +138,8 @@ __global__ void __launch_bounds__(64) local_sketch(uint64_t n_win, const unsigne
   auto shift_in = [&](uint32_t c2) { cur = ((((cur << 2) & TMASK) & kmask) + c2) & TMASK; };
   uint32_t actT = cur, actP = 0;
   ring[lane] = actT;                                                      // (position 0 in the high bits)
+  // ring entries carry p in their 12 high bits: exact because a window has at most 4096 positions (lra_local_index_masked_batch rejects window > 4096,
+  // the width of LocalTuple::pos)
   uint32_t p;
   const uint32_t nk = seqLen - k + 1;
   for (p = 1; p < (uint32_t)w && p < nk; p++) {                          // :251-270

@@ -36,8 +36,10 @@ struct lra_pod_buf {                                                     // the 
 
 struct lra_map_sig {                             // what a text of lra_map_records was made from
   const void* blocks = nullptr; const void* runs = nullptr; int32_t n_reads = 0; uint64_t n_aln = 0; int32_t fmt = 0, pna = 0, hard = 0; const char* pass = nullptr;
+  int32_t flagged_unaligned = 0; const void* status = nullptr;   // (the text of a flagged read depends on both)
   bool operator==(const lra_map_sig& o) const {
-    return blocks == o.blocks && runs == o.runs && n_reads == o.n_reads && n_aln == o.n_aln && fmt == o.fmt && pna == o.pna && hard == o.hard && pass == o.pass;
+    return blocks == o.blocks && runs == o.runs && n_reads == o.n_reads && n_aln == o.n_aln && fmt == o.fmt && pna == o.pna && hard == o.hard && pass == o.pass &&
+           flagged_unaligned == o.flagged_unaligned && status == o.status;
   }
 };
 struct lra_map_state {
@@ -47,8 +49,8 @@ struct lra_map_state {
   uint64_t* d_gso = nullptr; uint64_t n_gwin = 0;  // its seqOffsets
   int gli_window = 0;
   bool borrowed = false;                           // reference data shared from another context (lra_ctx_share_reference): not freed here
-  uint64_t generation = 0;                         // bumped by every loader of this context (chromosome table, local index)
-  const lra_map_state* owner = nullptr; uint64_t owner_generation = 0;   // a borrower: whose data, at which generation (see seed_state.h)
+  std::shared_ptr<lra_gen_cell> cell = std::make_shared<lra_gen_cell>();   // gen bumped by every loader of this context (chromosome table, local index); dead once it is destroyed
+  std::shared_ptr<lra_gen_cell> owner_cell; uint64_t owner_generation = 0;  // a borrower: whose data, at which generation (see seed_state.h)
   std::vector<float> lut;                          // LogLookUpTable.h:9-15
   lra_text_buf last_text; std::vector<uint64_t> last_off; lra_map_sig last_sig;   // lra_map_records: sizing call -> filling call
 };

@@ -25,6 +25,7 @@ void lra_map_free(lra_ctx* ctx) {
   lra_map_state* m = ctx->map;
   if (!m) return;
   if (!m->borrowed) {
+    m->cell->dead = true;                                                  // borrowers hold the cell, not this state
     if (m->d_chrom_pos) (void)hipFree(m->d_chrom_pos);
     if (m->gli_buf) (void)hipFree(m->gli_buf);
     if (m->d_gso) (void)hipFree(m->d_gso);
@@ -44,7 +45,7 @@ lra_map_state* map_state(lra_ctx* ctx) {
 void map_disown(lra_map_state* m) {
   if (!m->borrowed) return;
   m->d_chrom_pos = nullptr; m->gli_buf = nullptr; m->gli = lra_local_index_result{}; m->d_gso = nullptr; m->n_gwin = 0; m->gli_window = 0;
-  m->borrowed = false; m->owner = nullptr; m->owner_generation = 0;
+  m->borrowed = false; m->owner_cell.reset(); m->owner_generation = 0;
 }
 
 __global__ void k_add_off(int n, const uint64_t* __restrict__ off, uint64_t add, uint64_t* __restrict__ out) {
@@ -269,7 +270,7 @@ extern "C" int lra_ctx_load_chromosomes(lra_ctx* ctx, const uint64_t* h_chrom_po
   if (!ctx || !h_chrom_pos || n_chrom < 1) return LRA_ERR_INVALID;
   LRA_HIP_CHECK(ctx, hipSetDevice(ctx->device));
   lra_map_state* m = map_state(ctx);
-  map_disown(m); m->generation++;
+  map_disown(m); m->cell->gen++;
   m->chrom_pos.assign(h_chrom_pos, h_chrom_pos + n_chrom + 1);
   if (m->d_chrom_pos) (void)hipFree(m->d_chrom_pos);
   LRA_HIP_CHECK(ctx, hipMalloc((void**)&m->d_chrom_pos, (size_t)(n_chrom + 1) * 8));
@@ -284,7 +285,7 @@ extern "C" int lra_ctx_build_local_index(lra_ctx* ctx, int k, int w, int window,
   LRA_HIP_CHECK(ctx, hipSetDevice(ctx->device));
   lra_map_state* m = ctx->map;
   if (m->borrowed) return lra_set_err(ctx, LRA_ERR_INVALID, "this context shares another context's reference data: load its own chromosome table first");
-  m->generation++;
+  m->cell->gen++;
   const int n_chrom = (int)m->chrom_pos.size() - 1;
   if (m->chrom_pos[n_chrom] != ctx->seed->genome_len) return lra_set_err(ctx, LRA_ERR_INVALID, "chromosome table does not cover the genome");
   lra_local_index_result r;
@@ -326,7 +327,7 @@ extern "C" int lra_ctx_share_reference(lra_ctx* dst, lra_ctx* src) {
   const lra_map_state* s = src->map;
   m->chrom_pos = s->chrom_pos; m->d_chrom_pos = s->d_chrom_pos; m->gli_buf = s->gli_buf; m->gli = s->gli; m->d_gso = s->d_gso; m->n_gwin = s->n_gwin;
   m->gli_window = s->gli_window; m->lut = s->lut; m->borrowed = true;
-  m->owner = s->borrowed ? s->owner : s; m->owner_generation = s->borrowed ? s->owner_generation : s->generation;
+  m->owner_cell = s->borrowed ? s->owner_cell : s->cell; m->owner_generation = s->borrowed ? s->owner_generation : s->cell->gen.load();
   return LRA_OK;
 }
 
@@ -336,8 +337,9 @@ int lra_map_check_shared(lra_ctx* ctx) {
   int rc = lra_seed_check_shared(ctx);
   if (rc) return rc;
   const lra_map_state* m = ctx->map;
-  if (m && m->borrowed && m->owner && m->owner->generation != m->owner_generation)
-    return lra_set_err(ctx, LRA_ERR_INVALID, "the context this one shares its reference data with has reloaded it: call lra_ctx_share_reference again");
+  if (m && m->borrowed && m->owner_cell && (m->owner_cell->dead.load() || m->owner_cell->gen.load() != m->owner_generation))
+    return lra_set_err(ctx, LRA_ERR_INVALID, "the context this one shares its reference data with has %s: call lra_ctx_share_reference again",
+                       m->owner_cell->dead.load() ? "been destroyed" : "reloaded it");
   return LRA_OK;
 }
 
@@ -747,7 +749,7 @@ static int lowacc_batch_impl(lra_ctx* ctx, int n_reads, const char* d_seq, const
     lra_map_state* d = c->map; const lra_map_state* s = ctx->map;
     d->chrom_pos = s->chrom_pos; d->d_chrom_pos = s->d_chrom_pos; d->gli_buf = s->gli_buf; d->gli = s->gli; d->d_gso = s->d_gso; d->n_gwin = s->n_gwin;
     d->gli_window = s->gli_window; d->lut = s->lut; d->borrowed = true;
-    d->owner = s->borrowed ? s->owner : s; d->owner_generation = s->borrowed ? s->owner_generation : s->generation;
+    d->owner_cell = s->borrowed ? s->owner_cell : s->cell; d->owner_generation = s->borrowed ? s->owner_generation : s->cell->gen.load();
   }
   std::vector<uint32_t> picked;
   std::thread second;
@@ -1156,7 +1158,7 @@ extern "C" int lra_map_records(lra_ctx* ctx, const lra_map_result* res, const lr
   lra_map_state* m = ctx->map;
   if (!m) return LRA_ERR_INVALID;
   // two-call convention: the sizing call keeps its text, the filling call for the same result and format hands it over
-  const lra_map_sig sig{res->d_blocks, res->d_runs, res->n_reads, res->n_alignments, o->printFormat, o->PrintNumAln, o->hardClip, passthrough};
+  const lra_map_sig sig{res->d_blocks, res->d_runs, res->n_reads, res->n_alignments, o->printFormat, o->PrintNumAln, o->hardClip, passthrough, o->flagged_unaligned, res->d_read_status};
   if (out && m->last_sig == sig && !m->last_text.empty() && cap >= m->last_text.size()) {
     memcpy(out, m->last_text.data(), m->last_text.size());
     *len = m->last_text.size();

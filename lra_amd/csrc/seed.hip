@@ -940,14 +940,15 @@ static bool regrow(T*& p, size_t n) {
 static void seed_disown(lra_seed_state* s) {
   if (!s->borrowed) return;
   s->genome = nullptr; s->genome_len = 0; s->idx_key = nullptr; s->idx_pos = nullptr; s->n_idx = 0; s->dir = nullptr; s->nbuckets = 0; s->dir_shift = 0;
-  s->borrowed = false; s->owner = nullptr; s->owner_generation = 0;
+  s->borrowed = false; s->owner_cell.reset(); s->owner_generation = 0;
 }
 // LRA_OK, or LRA_ERR_INVALID when the context borrows reference data its owner has replaced since (lra_ctx_share_reference again)
 int lra_seed_check_shared(lra_ctx* ctx) {
   const lra_seed_state* s = ctx->seed;
-  if (!s || !s->borrowed || !s->owner) return LRA_OK;
-  if (s->owner->generation != s->owner_generation)
-    return lra_set_err(ctx, LRA_ERR_INVALID, "the context this one shares its reference data with has reloaded it: call lra_ctx_share_reference again");
+  if (!s || !s->borrowed || !s->owner_cell) return LRA_OK;
+  if (s->owner_cell->dead.load() || s->owner_cell->gen.load() != s->owner_generation)
+    return lra_set_err(ctx, LRA_ERR_INVALID, "the context this one shares its reference data with has %s: call lra_ctx_share_reference again",
+                       s->owner_cell->dead.load() ? "been destroyed" : "reloaded it");
   return LRA_OK;
 }
 
@@ -955,6 +956,7 @@ void lra_seed_free(lra_ctx* ctx) {
   lra_seed_state* s = ctx->seed;
   if (!s) return;
   if (s->borrowed) { s->genome = nullptr; s->idx_key = nullptr; s->idx_pos = nullptr; s->dir = nullptr; }
+  else s->cell->dead = true;                                               // borrowers hold the cell, not this state
   void* ptrs[] = {s->genome, s->idx_key, s->idx_pos, s->counts32, s->counts64, s->mm_off, s->match_off, s->n_forward,
                   s->mm_key, s->mm_pos, s->lb, s->ub, s->match_qi, s->match_ti, s->sep_qpos, s->sep_tpos, s->tmp_qi, s->tmp_ti, s->cap_cnt, s->cap_off, s->tk_lb, s->tk_lbm1, s->tk_ubm1, s->dir, s->sep_qkey};
   for (void* p : ptrs) if (p) (void)hipFree(p);
@@ -966,7 +968,7 @@ extern "C" int lra_ctx_load_genome(lra_ctx* ctx, const char* h_seq, uint64_t len
   if (!ctx || (!h_seq && len)) return LRA_ERR_INVALID;
   LRA_HIP_CHECK(ctx, hipSetDevice(ctx->device));
   lra_seed_state* s = seed_state(ctx);
-  seed_disown(s); s->generation++;
+  seed_disown(s); s->cell->gen++;
   if (!regrow(s->genome, len + 64)) return lra_set_err(ctx, LRA_ERR_NOMEM, "genome alloc");
   s->genome_len = len;
   LRA_HIP_CHECK(ctx, hipMemcpy(s->genome, h_seq, len, hipMemcpyHostToDevice));
@@ -977,7 +979,7 @@ extern "C" int lra_ctx_load_genome(lra_ctx* ctx, const char* h_seq, uint64_t len
 // adopts device arrays (hipMalloc'ed, n + 1 entries at least) as the context's global index and builds the bucket directory over the key's top bits
 int lra_seed_install_index(lra_ctx* ctx, uint64_t* d_key, uint32_t* d_pos, uint64_t n) {
   lra_seed_state* s = seed_state(ctx);
-  seed_disown(s); s->generation++;
+  seed_disown(s); s->cell->gen++;
   if (s->idx_key) (void)hipFree(s->idx_key);
   if (s->idx_pos) (void)hipFree(s->idx_pos);
   s->idx_key = d_key; s->idx_pos = d_pos; s->n_idx = n;
@@ -1015,7 +1017,7 @@ int lra_seed_share(lra_ctx* dst, lra_ctx* src) {
   if (dst->seed && !dst->seed->borrowed && (dst->seed->genome || dst->seed->idx_key)) return lra_set_err(dst, LRA_ERR_INVALID, "context already holds reference data");
   lra_seed_state* d = seed_state(dst);
   const lra_seed_state* s = src->seed;
-  d->borrowed = true; d->owner = s->borrowed ? s->owner : s; d->owner_generation = s->borrowed ? s->owner_generation : s->generation;
+  d->borrowed = true; d->owner_cell = s->borrowed ? s->owner_cell : s->cell; d->owner_generation = s->borrowed ? s->owner_generation : s->cell->gen.load();
   d->genome = s->genome; d->genome_len = s->genome_len; d->idx_key = s->idx_key; d->idx_pos = s->idx_pos; d->n_idx = s->n_idx;
   d->dir = s->dir; d->nbuckets = s->nbuckets; d->dir_shift = s->dir_shift;
   return LRA_OK;
@@ -1035,7 +1037,7 @@ extern "C" int lra_ctx_load_genome_device(lra_ctx* ctx, const char* d_seq, uint6
   if (!ctx || (!d_seq && len)) return LRA_ERR_INVALID;
   LRA_HIP_CHECK(ctx, hipSetDevice(ctx->device));
   lra_seed_state* s = seed_state(ctx);
-  seed_disown(s); s->generation++;
+  seed_disown(s); s->cell->gen++;
   if (!regrow(s->genome, len + 64)) return lra_set_err(ctx, LRA_ERR_NOMEM, "genome alloc");
   s->genome_len = len;
   LRA_HIP_CHECK(ctx, hipMemcpyAsync(s->genome, d_seq, len, hipMemcpyDeviceToDevice, ctx->stream));
@@ -1088,7 +1090,7 @@ static int launch_sort(lra_ctx* ctx, int n_reads, const uint64_t* mm_off, uint64
   const size_t tszB = (size_t)gridB * (capB + 64) * 4, esz = (size_t)gridB * sort_scratch_bytes(1, (size_t)capB);
   uint32_t* tscr = (uint32_t*)lra_scratch(ctx, 0, (size_t)grid * (cap + 64) * 4 + (size_t)n_reads * 4);
   char* big = (char*)lra_ensure(ctx, 85, tszB + esz + 1024);               // its own buffer: callers hold pointers into scratch 0 across a sort
-  int* stat = (int*)lra_ensure(ctx, 86, 64);
+  int* stat = (int*)lra_ensure(ctx, 97, 64);                                 // slots 97 / 98 belong to the sort alone (86 / 87 hold fine_clusters.hip's results across sorts)
   if (!tscr || !big || !stat) return LRA_ERR_NOMEM;
   uint32_t* tscrB = (uint32_t*)big; char* gscr = big + tszB;
   int* flags = (int*)(tscr + (size_t)grid * (cap + 64));
@@ -1108,7 +1110,7 @@ static int launch_sort(lra_ctx* ctx, int n_reads, const uint64_t* mm_off, uint64
   const int capH = std::min(h_stat[0] + 64, (1 << 26));                    // (a list beyond 2^26 tuples stays with the one-lane kernel)
   const int gridH = std::min(h_stat[1], std::max(1, ctx->num_cu / 4));
   const size_t eszH = sort_scratch_bytes(2, (size_t)capH), tszH = (size_t)(capH + 64) * 8;
-  char* huge = (char*)lra_ensure(ctx, 87, (size_t)gridH * (eszH + tszH) + 1024);
+  char* huge = (char*)lra_ensure(ctx, 98, (size_t)gridH * (eszH + tszH) + 1024);
   if (!huge) return LRA_ERR_NOMEM;
   lra_time_begin(ctx, ctx->sort_tag);
   hipLaunchKernelGGL(sort_wg_kernel<2>, dim3(gridH), dim3(SORT_NT), 0, st, n_reads, mm_off, mm_key, mm_pos, (void*)huge, capH, flags, only, huge + (size_t)gridH * tszH, (int*)nullptr);

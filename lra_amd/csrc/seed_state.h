@@ -8,8 +8,9 @@ struct lra_seed_state {
   // a borrower remembers whose data it holds and at which generation, and the batch entry points refuse to run on stale pointers (the owner
   // reloaded: share again).  A loader called on a borrower first drops the borrowed pointers (nothing of the owner's is freed) and makes the
   // context an owner of what it loads.
-  uint64_t generation = 0;
-  const lra_seed_state* owner = nullptr; uint64_t owner_generation = 0;
+  // The generation lives in a refcounted cell (common.h) the borrowers hold too: the check works when the owner has been destroyed (cell->dead).
+  std::shared_ptr<lra_gen_cell> cell = std::make_shared<lra_gen_cell>();
+  std::shared_ptr<lra_gen_cell> owner_cell; uint64_t owner_generation = 0;
   unsigned char* genome = nullptr; uint64_t genome_len = 0;
   uint64_t* idx_key = nullptr; uint32_t* idx_pos = nullptr; uint64_t n_idx = 0;
   // batch buffers (grown on demand)

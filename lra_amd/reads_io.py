@@ -24,14 +24,17 @@ class ReadsFile:
         """-> None at the end, else dict(names, seqs, quals (None for FASTA reads), off, raw=(ReadBatchC kept alive until the next call))"""
         b = ReadBatchC()
         rc = self.lib.lra_reads_next_batch(self.h, C.c_uint64(int(max_bases)), C.byref(b))
-        if rc != 0:
-            raise IOError("lra_reads_next_batch failed (%d)" % rc)
         n = b.n_reads
-        if n == 0:
-            return None
-        off = np.ctypeslib.as_array(b.off, shape=(n + 1,)).copy()
-        seq = C.string_at(b.seq, int(b.total_bases))
-        return dict(names=[b.names[i] for i in range(n)], seqs=[seq[int(off[i]):int(off[i + 1])] for i in range(n)], quals=[b.quals[i] for i in range(n)], off=off, raw=b)
+        out = None
+        if n:
+            off = np.ctypeslib.as_array(b.off, shape=(n + 1,)).copy()
+            seq = C.string_at(b.seq, int(b.total_bases))
+            out = dict(names=[b.names[i] for i in range(n)], seqs=[seq[int(off[i]):int(off[i + 1])] for i in range(n)], quals=[b.quals[i] for i in range(n)], off=off, raw=b)
+        if rc != 0:
+            e = IOError("lra_reads_next_batch failed (%d): %s" % (rc, (self.lib.lra_reads_last_error(self.h) or b"").decode()))
+            e.partial = out                     # the reads in front of the bad record
+            raise e
+        return out
 
     def close(self):
         if self.h:

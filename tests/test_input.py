@@ -148,14 +148,27 @@ def test_reader_matches_reference_logic(tmp_path, order, max_bases):
     exp = ref_batches(sel, max_bases)
     rf = reads_io.ReadsFile(sel)
     got = []
+    failed = None
     while True:
-        b = rf.next_batch(max_bases)
+        try:
+            b = rf.next_batch(max_bases)
+        except IOError as e:                                               # the corrupt record of e.fq: an error, never a silent end of the input
+            failed = str(e)
+            if e.partial is not None:
+                got.append([(n, s, q) for n, s, q in zip(e.partial["names"], e.partial["seqs"], e.partial["quals"])])
+            with pytest.raises(IOError):                                   # and it stays one
+                rf.next_batch(max_bases)
+            break
         if b is None:
             break
         got.append([(n, s, q) for n, s, q in zip(b["names"], b["seqs"], b["quals"])])
     rf.close()
     assert got == exp, (len(got), len(exp))
     assert sum(len(b) for b in got) >= 3
+    if 4 in order:
+        assert failed and "short_quality" in failed and "e.fq" in failed, failed
+    else:
+        assert failed is None
 
 
 @pytest.mark.gpu

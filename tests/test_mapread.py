@@ -448,3 +448,36 @@ def test_flagged_reads_are_counted_and_can_be_written_as_unaligned(ctx):
     f = out1[2].split(b"\t")
     assert f[0] == b"r2" and f[1] == b"4" and out1[2].count(b"\n") == 1
     assert [out1[i] for i in (0, 1, 3, 4)] == [base[i] for i in (0, 1, 3, 4)]
+
+
+@pytest.mark.gpu
+def test_borrowed_reference_goes_stale_when_its_owner_reloads_or_dies():
+    """lra_ctx_share_reference: a borrower's batch entry points refuse to run once the owner has reloaded its reference data, and once the owner is
+    gone altogether (the check reads a generation cell both hold, never the owner's freed state: ADVICE round 3)."""
+    from lra_amd import seed, mapread
+    from lra_amd.context import Context
+    from lra_amd._lib import LraError
+    genome = synth.make_genome(120_000, seed=4, repeat_frac=0.1, n_families=2)
+    o = mapread.LowAccOptions()
+    ik, ip = synth.build_global_index(genome, o.globalK, o.globalW, 100)
+    owner_ctx, b_ctx = Context(0), Context(0)
+    owner = mapread.LowAccMapper(owner_ctx, genome, ik, ip, [b"chr1"], [0, len(genome)], o)
+    borrower = mapread.LowAccMapper.sharing(b_ctx, owner)
+    rng = np.random.default_rng(1)
+    rd = synth.simulate_read(rng, genome[30_000:34_001], 4000, 0.10, (30, 35, 35), False)[0]
+    batch = seed.ReadBatch(b_ctx, [rd.tobytes()])
+    res = borrower.align(batch)
+    assert int(res.n_alignments) >= 1
+    import ctypes as C
+    cp = (C.c_uint64 * 2)(0, len(genome))
+    owner_ctx.check(owner_ctx.lib.lra_ctx_load_chromosomes(owner_ctx.h, cp, 1))          # a loader of the owner: the borrower's copy is stale
+    with pytest.raises(LraError, match="reloaded"):
+        borrower.align(batch)
+    b2_ctx = Context(0)
+    owner_ctx.check(owner_ctx.lib.lra_ctx_build_local_index(owner_ctx.h, o.localK, o.localW, o.localIndexWindow, o.localMaxFreq))
+    borrower2 = mapread.LowAccMapper.sharing(b2_ctx, owner)
+    assert int(borrower2.align(seed.ReadBatch(b2_ctx, [rd.tobytes()])).n_alignments) >= 1
+    owner_ctx.close()                                                                    # the owner's buffers are freed
+    with pytest.raises(LraError, match="destroyed"):
+        borrower2.align(seed.ReadBatch(b2_ctx, [rd.tobytes()]))
+    b_ctx.close(); b2_ctx.close()
