@@ -16,6 +16,7 @@ import ctypes as C
 import json
 import os
 import sys
+import contextlib
 import threading
 import time
 
@@ -95,6 +96,12 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-records", action="store_true", help="leave the host tail (SAM text) out of the step")
     ap.add_argument("--satellite-frac", type=float, default=0.03, help="fraction of every chromosome in its satellite array")
+    ap.add_argument("--defer-seed", type=int, default=int(os.environ.get("LRA_BENCH_DEFER_SEED", 6000)),
+                    help="lra_map_opts.defer_seed_matches: reads with more tier-1 matches are handed back by the batch they arrive in, pooled, and mapped as batches of "
+                         "their own inside the timed region (cost-ordered batching: every read is mapped exactly once per step either way); 0 = off")
+    ap.add_argument("--heavy-pool", type=int, default=int(os.environ.get("LRA_BENCH_HEAVY_POOL", 4096)), help="handed-back reads per batch of their own")
+    ap.add_argument("--lane-priority", type=int, default=int(os.environ.get("LRA_BENCH_LANE_PRIORITY", 1)),
+                    help="with --lanes > 1: 1 = lane 0 on a high-priority stream, the others below it (they fill what it leaves idle); 0 = all lanes alike")
     ap.add_argument("--lanes", type=int, default=int(os.environ.get("LRA_BENCH_LANES", 1)),
                     help="the batch is cut into this many sub-batches, each driven by its own context and HIP stream from its own host thread (ONE shared replica "
                          "of the reference), so that the serial tails of one sub-batch's kernels overlap the other's work")
@@ -144,18 +151,22 @@ def main():
     del genome
     rb = reads_h.tobytes()
     n_threads_rec = max(8, (os.cpu_count() or 16) // world) if world > 1 else 0
-    lanes = []
+    # A step = every sub-batch once.  With one lane that is one call on the whole batch.  With several, the sub-batches of all timed steps form one work list and
+    # every lane (a context of its own: HIP streams, work buffers; the reference data shared) takes the next item when it is free -- so a lane on a lower-priority
+    # stream, which only gets what the lane above it leaves idle, simply takes fewer of them.
+    lanes, subs = [], []
+    prio_lo, prio_hi = torch.cuda.Stream.priority_range() if hasattr(torch.cuda.Stream, "priority_range") else (0, -1)
     for li in range(args.lanes):
         r0, r1 = args.reads * li // args.lanes, args.reads * (li + 1) // args.lanes
+        stream = None
         if li == 0:
-            lctx, lmap, stream = ctx, mapper, None
+            lctx, lmap = ctx, mapper
         else:
-            stream = torch.cuda.Stream(device=dev_index)
             lctx = Context(dev_index)
             lmap = mapread.LowAccMapper.sharing(lctx, mapper)
-        if args.lanes > 1 and li == 0:
-            stream = torch.cuda.Stream(device=dev_index)
-        if stream is not None:
+        if args.lanes > 1:
+            pr = (prio_hi if li == 0 else min(prio_hi + li, prio_lo)) if args.lane_priority else 0
+            stream = torch.cuda.Stream(device=dev_index, priority=pr)
             lctx.bind_stream(stream)
         b0, b1 = int(off_h[r0]), int(off_h[r1])
         lseq = torch.cat([sim["seq"][b0:b1], torch.zeros(64, dtype=torch.uint8, device=dev)])
@@ -163,8 +174,20 @@ def main():
         rbatch = seed.read_batch_from_device(lctx, lseq, loff)
         names = [b"read%d" % i for i in range(r0, r1)]
         reads_b = [rb[int(off_h[i]):int(off_h[i + 1])] for i in range(r0, r1)]
-        lanes.append(dict(ctx=lctx, mapper=lmap, stream=stream, rbatch=rbatch, rargs=lmap.record_args(names, reads_b), packed=None))
+        subs.append(dict(rbatch=rbatch, rargs=lmap.record_args(names, reads_b), bases=b1 - b0, names=names, reads=reads_b))
+        lanes.append(dict(ctx=lctx, mapper=lmap, stream=stream, packed=None, n_items=0))
     del sim
+    # Reads handed back by their batch (opts.defer_seed_matches) are pooled and mapped as batches of their own, by a second view of lane 0's mapper with the field off
+    defer_T = args.defer_seed if args.lanes == 1 else 0
+    heavy = dict(pool=[], n=0, batches=0, reads=0)
+    if defer_T:
+        import copy
+        mapper.copts.defer_seed_matches = defer_T
+        hmap = copy.copy(mapper)
+        hmap.copts = type(mapper.copts).from_buffer_copy(mapper.copts)
+        hmap.copts.defer_seed_matches = 0
+        hmap.stats = {}
+        heavy["lane"] = dict(ctx=ctx, mapper=hmap, stream=None, packed=None, n_items=0)
     torch.cuda.synchronize()
     torch.cuda.empty_cache()
     sim_s = time.time() - t0
@@ -175,17 +198,17 @@ def main():
 
     def host_tail(items):
         try:
-            for lane, snap in items:
-                text_bytes[0] += lane["mapper"].records_host(snap, lane["rargs"], n_threads=n_threads_rec, as_list=False)
+            for lane, sub, snap in items:
+                text_bytes[0] += lane["mapper"].records_host(snap, sub["rargs"], n_threads=n_threads_rec, as_list=False)
         except BaseException as e:
             err.append(e)
 
-    def lane_device_side(lane):
+    def lane_device_side(lane, sub):
         try:
             torch.cuda.set_device(dev_index)                               # the current device is per host thread
             lc = lane["ctx"]
             def run():
-                res = lane["mapper"].align(lane["rbatch"])
+                res = lane["mapper"].align(sub["rbatch"])
                 lane["last_res"] = res
                 if args.no_records:
                     return
@@ -201,11 +224,39 @@ def main():
         except BaseException as e:                                         # surfaced by the caller: a thread's exception would vanish otherwise
             err.append(e)
 
+    def pool_handed_back(lane, j):
+        """the reads of sub-batch j that the last call handed back (LRA_ST_DEFERRED) join the pool"""
+        res = lane["last_res"]
+        st_ = lane["ctx"].to_host(res.d_read_status, int(res.n_reads), np.uint32)
+        idx = np.nonzero(st_ & 64)[0]
+        if len(idx):
+            heavy["pool"].append((j, idx)); heavy["n"] += len(idx)
+
+    def heavy_sub():
+        """the pooled reads as a batch: their bases gathered on the device, their names / sequences for the records"""
+        seqs, lens, names, rds = [], [], [], []
+        for j, idx in heavy["pool"]:
+            rb_ = subs[j]["rbatch"]
+            it = torch.from_numpy(idx.astype(np.int64)).to(dev)
+            s0 = rb_.off[it]; ln = rb_.off[it + 1] - s0
+            dst0 = torch.cumsum(ln, 0) - ln
+            src = torch.arange(int(ln.sum()), device=dev) + torch.repeat_interleave(s0 - dst0, ln)
+            seqs.append(rb_.seq[src]); lens.append(ln)
+            names += [subs[j]["names"][i] for i in idx]; rds += [subs[j]["reads"][i] for i in idx]
+        ln = torch.cat(lens)
+        off = torch.cat([torch.zeros(1, dtype=torch.int64, device=dev), torch.cumsum(ln, 0)])
+        seq = torch.cat(seqs + [torch.zeros(64, dtype=torch.uint8, device=dev)])
+        hl = heavy["lane"]
+        sub = dict(rbatch=seed.read_batch_from_device(hl["ctx"], seq, off), rargs=hl["mapper"].record_args(names, rds), bases=int(off[-1]), names=names, reads=rds)
+        heavy["batches"] += 1; heavy["reads"] += len(names)
+        heavy["pool"] = []; heavy["n"] = 0
+        return sub
+
     # Every lane runs its own sequence of steps (no barrier between the lanes inside the timed region): lane i starts i / lanes of a step late, so
     # that the long serial tail of one sub-batch's sparse DP runs beside the other sub-batches' wide kernels.
     copy_stream = torch.cuda.Stream(device=dev_index)
 
-    def tail_thread(lane, held, ev):
+    def tail_thread(lane, sub, held, ev):
         try:
             torch.cuda.set_device(dev_index)
             with torch.cuda.stream(copy_stream):
@@ -219,7 +270,7 @@ def main():
                 snap = C.c_void_p()
                 rc = ctx.lib.lra_map_unpack_host(C.c_void_p(hb.ctypes.data), C.c_uint64(hb.nbytes), C.byref(snap))
                 assert rc == 0, rc
-                items = [(lane, snap)]
+                items = [(lane, sub, snap)]
             tC = time.perf_counter()
             host_tail(items)
             if os.environ.get("LRA_BENCH_DBG"):
@@ -227,19 +278,45 @@ def main():
         except BaseException as e:
             err.append(e)
 
-    def lane_loop(li, n_steps, stagger_s):
+    work = {"items": [], "next": 0}
+    work_lock = threading.Lock()
+
+    def take_item():
+        with work_lock:
+            if work["next"] >= len(work["items"]):
+                return None
+            it = work["items"][work["next"]]
+            work["next"] += 1
+            return it
+
+    def lane_loop(li, stagger_s):
         lane = lanes[li]
         try:
             if stagger_s:
                 time.sleep(stagger_s)
             prev = None
             dbg = os.environ.get("LRA_BENCH_DBG")
-            for s_ in range(n_steps):
+            while True:
+                it = take_item()
+                if it is None:
+                    break
+                s_, sub = it[0], (subs[it[1]] if it[1] >= 0 else None)
+                if it[1] < 0:                                              # a batch of handed-back reads
+                    lane, sub = heavy["lane"], heavy_sub()
+                else:
+                    lane = lanes[li]
                 tA = time.perf_counter()
-                lane_device_side(lane)
+                lane_device_side(lane, sub)
+                lane["n_items"] += 1
+                if defer_T and it[1] >= 0 and not err:
+                    pool_handed_back(lane, it[1])
+                    last_main = work["next"] >= len(work["items"]) or all(x[1] < 0 for x in work["items"][work["next"]:])
+                    if heavy["n"] and (heavy["n"] >= args.heavy_pool or last_main):
+                        with work_lock:
+                            work["items"].insert(work["next"], (s_, -1))    # next: the pool as a batch of its own (the last step flushes what is left)
                 tB = time.perf_counter()
                 if dbg:
-                    sys.stderr.write("[bench] step %d device side + pack %.0f ms\n" % (s_, (tB - tA) * 1e3))
+                    sys.stderr.write("[bench] lane %d: step %d sub-batch %d (%d reads) device side + pack %.0f ms\n" % (li, s_, it[1], sub["rbatch"].n, (tB - tA) * 1e3))
                 if err:
                     break
                 if args.no_records:
@@ -247,15 +324,16 @@ def main():
                 # The exchange step and everything behind it -- gather to rank 0, the copy to the host, unpacking, the record text -- belong to the step's
                 # host tail and run beside the next step's device side (the reference interleaves its output with the next reads the same way, lra.cpp:117-158).
                 # The packed buffer is context-owned (the next lra_map_pack reuses it), so the tail works on a device copy.
-                held = lane["packed"].clone()
-                ev = torch.cuda.Event()
-                ev.record(torch.cuda.current_stream())
+                with torch.cuda.stream(lane["stream"]) if lane["stream"] is not None else contextlib.nullcontext():
+                    held = lane["packed"].clone()
+                    ev = torch.cuda.Event()
+                    ev.record(torch.cuda.current_stream())
                 if prev is not None:
                     tC = time.perf_counter()
                     prev.join()
                     if dbg:
-                        sys.stderr.write("[bench] step %d waited for the previous host tail %.0f ms\n" % (s_, (time.perf_counter() - tC) * 1e3))
-                prev = threading.Thread(target=tail_thread, args=(lane, held, ev))
+                        sys.stderr.write("[bench] lane %d: step %d waited for the previous host tail %.0f ms\n" % (li, s_, (time.perf_counter() - tC) * 1e3))
+                prev = threading.Thread(target=tail_thread, args=(lane, sub, held, ev))
                 prev.start()
             if prev is not None:
                 prev.join()
@@ -263,10 +341,12 @@ def main():
             err.append(e)
 
     def run_steps(n_steps, stagger):
+        work["items"] = [(s_, j) for s_ in range(n_steps) for j in range(len(subs))]
+        work["next"] = 0
         if len(lanes) == 1:
-            lane_loop(0, n_steps, 0.0)
+            lane_loop(0, 0.0)
         else:
-            ths = [threading.Thread(target=lane_loop, args=(li, n_steps, stagger * li / len(lanes))) for li in range(len(lanes))]
+            ths = [threading.Thread(target=lane_loop, args=(li, stagger * li / len(lanes))) for li in range(len(lanes))]
             for t in ths: t.start()
             for t in ths: t.join()
         if err:
@@ -277,12 +357,16 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    # (the first warm-up step allocates the contexts' work buffers -- seconds -- so the lanes' stagger is taken from the LAST warm-up step alone)
+    run_steps(max(args.warmup - 1, 0), 0.0)
     tw = time.perf_counter()
-    run_steps(args.warmup, 0.0)
-    step_guess = (time.perf_counter() - tw) / max(args.warmup, 1)
+    run_steps(min(args.warmup, 1), 0.0)
+    step_guess = (time.perf_counter() - tw) if args.warmup > 1 else 0.0
     for l in lanes:
         l["ctx"].timing(True)
         l["ctx"].timing_reset()
+        l["n_items"] = 0
+    heavy["batches"] = 0; heavy["reads"] = 0
     text_bytes[0] = 0
     sync()
     t0 = time.perf_counter()
@@ -375,10 +459,17 @@ def main():
                          "footprint_bytes_per_launch": fp, "frac_footprint": (fp / (avg_ms * 1e-3) / 1e9 / 8000.0) if avg_ms > 0 else 0.0,
                          "step_algorithmic_bytes": step_alg, "step_frac": step_alg / (ms_step * 1e-3) / 1e9 / 8000.0},
             "sam_text_gb_per_step": round(text_bytes[0] / max(args.steps, 1) / 1e9, 3),
+            "lane_items": [l["n_items"] for l in lanes],
+            "handed_back": {"defer_seed_matches": defer_T, "pool": args.heavy_pool, "reads_per_step": round(heavy["reads"] / max(args.steps, 1), 1), "batches": heavy["batches"]},
             "device_side_ms_per_step": round(t_dev / args.steps * 1e3, 1),
         }
         if world == 1 and not args.no_cpu_baseline:
             try:
+                if len(lanes) > 1 or defer_T:                              # (untimed: the sample is the head of sub-batch 0, whichever lane mapped it last -- and in ONE batch, nothing handed back)
+                    mapper.copts.defer_seed_matches = 0
+                    lane_device_side(lanes[0], subs[0])
+                    if err:
+                        raise err[0]
                 for l in lanes[1:]:
                     l["ctx"].close()
                 out["cpu_baseline"] = cpu_baseline(mapper, reads_h, off_h, args, lanes[0].get("last_res"))

@@ -58,7 +58,8 @@ typedef struct lra_ctx lra_ctx;
 #define LRA_ST_CAPACITY 8      /* caller-provided output capacity exceeded              */
 #define LRA_ST_REJECTED 16     /* the reference drops the item itself (e.g. a cluster spanning two chromosomes) */
 #define LRA_ST_UNSUPPORTED 32  /* the read takes a branch of the reference this library has not built (it gets no record) */
-#define LRA_ST_DEFERRED 64     /* internal to lra_map_reads_lowacc_batch: the read left the batch's first pass for its second one (never set in a result) */
+#define LRA_ST_DEFERRED 64     /* scheduling, not an error: with opts.defer_seed_matches the read was handed back unmapped (the caller maps it in a later batch of
+                                * its own kind; no record is written for it here).  Also used inside lra_map_reads_lowacc_batch for opts.defer_matches (never in a result) */
 
 /* ---- context ---------------------------------------------------------------------- */
 int lra_ctx_create(int device_id, lra_ctx** out);
@@ -68,7 +69,7 @@ int lra_ctx_set_stream(lra_ctx* ctx, void* stream);
 const char* lra_ctx_last_error(lra_ctx* ctx);
 /* ABI version of the loaded library (tests check it against this header). */
 int lra_abi_version(void);
-#define LRA_ABI_VERSION 4   /* 2: lra_map_opts.defer_matches, lra_map_counters.n_deferred_reads; 3: lra_map_opts.flagged_unaligned, lra_map_counters.n_flagged_reads, lra_map_host_flagged; 4: lra_reads_last_error, a corrupt FASTQ record is LRA_ERR_INVALID */
+#define LRA_ABI_VERSION 4   /* 2: lra_map_opts.defer_matches, lra_map_counters.n_deferred_reads; 3: lra_map_opts.flagged_unaligned, lra_map_counters.n_flagged_reads, lra_map_host_flagged; 4: lra_reads_last_error, a corrupt FASTQ record is LRA_ERR_INVALID; lra_map_opts.defer_seed_matches */
 
 /* Convenience for hosts without their own HIP binding: synchronous device->host copy on the
  * context's stream (a C++ host would call hipMemcpy itself).                                */
@@ -947,6 +948,13 @@ typedef struct lra_map_opts {
                                                            * elsewhere (counters.n_flagged_reads / lra_map_host_flagged say how many and which); 1 = the read's unaligned
                                                            * record (output_unaligned, Mapping_ultility.h:457-463: a flag-4 line in SAM mode), so that the output keeps one
                                                            * record per input read */
+  int32_t defer_seed_matches;                             /* low-accuracy path, scheduling only (a read's result does not depend on the batch it is mapped in): a read with
+                                                           * more tier-1 matches than this (CompareLists against the global index; a 30 kb read has ~3 k, a read from a
+                                                           * satellite array 6-10 k) is HANDED BACK: it leaves the batch behind the seed stage, d_read_status[r] has
+                                                           * LRA_ST_DEFERRED (and nothing else), counters.n_deferred_reads counts them, lra_map_records* write nothing
+                                                           * for it.  The caller collects such reads and maps them as batches of their own (with this field 0): their
+                                                           * sparse DPs are tens of times larger than a typical read's and would otherwise set the length of every
+                                                           * latency-bound launch of the batch they sit in.  0 = off (the presets) */
 } lra_map_opts;
 typedef struct lra_map_counters {
   uint64_t n_minimizers, n_matches, n_clusters, n_sdp_anchors, n_sdp_points, n_sdp_entries, n_local_tuples, n_local_tasks, n_local_task_words, n_local_pairs, n_refined_matches,

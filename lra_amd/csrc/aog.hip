@@ -205,7 +205,7 @@ __device__ __forceinline__ int reg_fill(int lane, int gbase, const Geo& g, int m
 
 template <int G, typename BytePtr>
 __device__ __forceinline__ void solve(int wlane, const Problem& pr, const Geo& g, BytePtr mem, int* out_score,
-                      int* out_nb, int* blocks, long cap, int* out_status, int* roll = nullptr) {
+                      int* out_nb, int* blocks, long cap, int* out_status, int* roll = nullptr, int chunkBytes = 8192) {
   const int qLen = g.qLen, tLen = g.tLen, k = g.k, R = g.R, diag = g.diag, n = g.n, nUsed = g.nUsed;
   const int m = pr.m, mm = pr.mm, indel = pr.indel;
   const int lane = wlane & (G - 1), gbase = wlane - lane;   // G lanes work on this problem
@@ -450,8 +450,8 @@ __device__ __forceinline__ void solve(int wlane, const Problem& pr, const Geo& g
   // ---- prefix trace back (:589-629), lane 0 -- or, with the arrows in HBM only (rolling), all lanes in step on the same state over a window of rows staged in
   // LDS: the walk is a chain of dependent one-byte loads a row apart (a cache line each); a window serves at least as many steps as it has rows
   if (rolling) {
-    unsigned char* chunk = (unsigned char*)(roll + 768 + 1024);          // 8 KB
-    const int chRows = max(1, 8192 / R);
+    unsigned char* chunk = (unsigned char*)(roll + 768 + 1024);          // chunkBytes (LRA_AOG_CHUNK: 4 KB; what a wave asks for sets how many fit a CU)
+    const int chRows = max(1, chunkBytes / R);
     int cLo = 1, cHi = 0;
     auto arrowAt = [&](int i, int j) -> int {
       if (j < cLo || j > cHi) {
@@ -641,6 +641,7 @@ struct BatchArgs {
   int* counts; int* offs; int* cursor; unsigned char* cls8; int* list;
   char* gscratch; long gslot_bytes; int gslots;       // class 2: HBM work slots
   char* gscratchB; long gslotB_bytes; int gslotsB;    // class 6: a few larger ones
+  int chunk_bytes;                                    // classes 2 / 6: the trace-back window in LDS
   int use_reg;                                        // classes 10-13 (solve_reg) in use
   int use_lane;                                       // class 14 (aog_lane_kernel) in use
   int regL, regX;                                     // largest arrows + codes footprint of classes 12 and 13 (above: the HBM class, whose sweep is in registers too)
@@ -737,7 +738,7 @@ __global__ void __launch_bounds__(1024) aog_scatter(BatchArgs a) {
 template <int CLS>
 __global__ void __launch_bounds__((CLS == 0 || CLS == 3 || CLS == 7) ? 256 : 64) aog_kernel(BatchArgs a) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  __shared__ int s_roll[(CLS == 2 || CLS == 6) ? 3 * 256 + 1024 + 2048 : 1];
+  int* s_roll = (int*)smem;                                               // classes 2 / 6 (one wave per workgroup): 3 KB of rolling scores, 4 KB of codes, the trace-back window
   constexpr int G = (CLS == 3) ? 16 : (CLS >= 7) ? 32 : 64;
   constexpr int GPW = 64 / G;
   const int lane = threadIdx.x & 63;
@@ -758,8 +759,8 @@ __global__ void __launch_bounds__((CLS == 0 || CLS == 3 || CLS == 7) ? 256 : 64)
     else if (CLS == 7) solve<32>(lane, pr, g, smem + (wave_in_wg * GPW + lane / G) * CLASS_A_BYTES, &a.score[p], &a.nblocks[p], blk, cap, &a.status[p]);
     else if (CLS == 0) solve<64>(lane, pr, g, smem + wave_in_wg * CLASS_A_BYTES, &a.score[p], &a.nblocks[p], blk, cap, &a.status[p]);
     else if (CLS == 1 || CLS == 4 || CLS == 5) solve<64>(lane, pr, g, smem, &a.score[p], &a.nblocks[p], blk, cap, &a.status[p]);
-    else if (CLS == 6) solve<64>(lane, pr, g, a.gscratchB + (long)(group % a.gslotsB) * a.gslotB_bytes, &a.score[p], &a.nblocks[p], blk, cap, &a.status[p], s_roll);
-    else solve<64>(lane, pr, g, a.gscratch + (long)(group % a.gslots) * a.gslot_bytes, &a.score[p], &a.nblocks[p], blk, cap, &a.status[p], s_roll);
+    else if (CLS == 6) solve<64>(lane, pr, g, a.gscratchB + (long)(group % a.gslotsB) * a.gslotB_bytes, &a.score[p], &a.nblocks[p], blk, cap, &a.status[p], s_roll, a.chunk_bytes);
+    else solve<64>(lane, pr, g, a.gscratch + (long)(group % a.gslots) * a.gslot_bytes, &a.score[p], &a.nblocks[p], blk, cap, &a.status[p], s_roll, a.chunk_bytes);
     wave_sync();
   }
 }
@@ -929,6 +930,7 @@ int lra_aog_launch_device(lra_ctx* ctx, int n, const char* d_qseq, const char* d
   // arrows, and a CU can keep more of them in flight; class 6: 8 MiB slots, one per CU, for the rare larger problem (1.5 kb x 1.5 kb at k = 60, 5 kb x 5 kb at k = 15)
   const int perCu = std::max(1, getenv("LRA_AOG_SLOTS") ? atoi(getenv("LRA_AOG_SLOTS")) : 8);   // (a zero or non-numeric value would leave the HBM class without a slot)
   a.gslots = ctx->num_cu * perCu; a.gslot_bytes = 4L << 20;
+  a.chunk_bytes = std::min(8192, std::max(1024, getenv("LRA_AOG_CHUNK") ? atoi(getenv("LRA_AOG_CHUNK")) : 8192)) & ~255;
   a.gslotsB = ctx->num_cu; a.gslotB_bytes = 8L << 20;
   a.gscratch = (char*)lra_scratch(ctx, 1, (size_t)a.gslots * a.gslot_bytes + (size_t)a.gslotsB * a.gslotB_bytes);
   if (!a.gscratch) return LRA_ERR_NOMEM;
@@ -1016,8 +1018,8 @@ int lra_aog_launch_device(lra_ctx* ctx, int n, const char* d_qseq, const char* d
     lra_time_end(ctx);
   }
   lra_time_begin(ctx, "aog_hbm");
-  hipLaunchKernelGGL(aog_kernel<2>, dim3(wgC), dim3(64), 0, sm, a);
-  hipLaunchKernelGGL(aog_kernel<6>, dim3(min(n, a.gslotsB)), dim3(64), 0, sm, a);
+  hipLaunchKernelGGL(aog_kernel<2>, dim3(wgC), dim3(64), (3 * 256 + 1024) * 4 + a.chunk_bytes, sm, a);
+  hipLaunchKernelGGL(aog_kernel<6>, dim3(min(n, a.gslotsB)), dim3(64), (3 * 256 + 1024) * 4 + a.chunk_bytes, sm, a);
   lra_time_end(ctx);
   if (!serial) { lra_side_join(ctx, 1); lra_side_join(ctx, 2); lra_side_join(ctx, 3); }
   LRA_HIP_CHECK(ctx, hipGetLastError());

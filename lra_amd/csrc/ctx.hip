@@ -92,12 +92,12 @@ extern "C" void lra_ctx_destroy(lra_ctx* ctx) {
 hipStream_t lra_side_fork(lra_ctx* ctx, int i) {
   if (i < 0 || i >= lra_ctx::N_SIDE) return ctx->stream;
   if (!ctx->side[i]) {
-    if ((ctx->low_priority ? hipStreamCreateWithPriority(&ctx->side[i], hipStreamNonBlocking, ctx->prio) : hipStreamCreateWithFlags(&ctx->side[i], hipStreamNonBlocking)) != hipSuccess) {
+    if (((ctx->low_priority || ctx->prio != 0) ? hipStreamCreateWithPriority(&ctx->side[i], hipStreamNonBlocking, ctx->prio) : hipStreamCreateWithFlags(&ctx->side[i], hipStreamNonBlocking)) != hipSuccess) {
       ctx->side[i] = nullptr; return ctx->stream;
     }
     // without its two events the side stream could not be ordered against the main one: fall back to the main stream, as when the stream itself cannot be made
     if (!ctx->ev_fork && hipEventCreateWithFlags(&ctx->ev_fork, hipEventDisableTiming) != hipSuccess) ctx->ev_fork = nullptr;
-    if (ctx->ev_fork && hipEventCreateWithFlags(&ctx->ev_join[i], hipEventDisableTiming) != hipSuccess) ctx->ev_join[i] = nullptr;
+    if (ctx->ev_fork && !ctx->ev_join[i] && hipEventCreateWithFlags(&ctx->ev_join[i], hipEventDisableTiming) != hipSuccess) ctx->ev_join[i] = nullptr;
     if (!ctx->ev_fork || !ctx->ev_join[i]) { (void)hipStreamDestroy(ctx->side[i]); ctx->side[i] = nullptr; return ctx->stream; }
   }
   (void)hipEventRecord(ctx->ev_fork, ctx->stream);
@@ -110,9 +110,18 @@ void lra_side_join(lra_ctx* ctx, int i) {
   (void)hipStreamWaitEvent(ctx->stream, ctx->ev_join[i], 0);
 }
 
+// The context's side streams run at the priority of the stream it is bound to: a host that maps several sub-batches at once gives each context a stream of
+// its own priority (the high one runs as if alone, the others fill what it leaves idle), and a stage's forked kernels must not jump that order.
 extern "C" int lra_ctx_set_stream(lra_ctx* ctx, void* stream) {
   if (!ctx) return LRA_ERR_INVALID;
   ctx->stream = (hipStream_t)stream;
+  int prio = 0;
+  if (ctx->low_priority || !stream || hipStreamGetPriority(ctx->stream, &prio) != hipSuccess) return LRA_OK;   // (a second-pass context keeps the priority it was made with)
+  if (prio != ctx->prio) {
+    for (int i = 0; i < lra_ctx::N_SIDE; i++)
+      if (ctx->side[i]) { (void)hipStreamSynchronize(ctx->side[i]); (void)hipStreamDestroy(ctx->side[i]); ctx->side[i] = nullptr; }
+    ctx->prio = prio;
+  }
   return LRA_OK;
 }
 

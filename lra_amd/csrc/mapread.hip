@@ -107,6 +107,14 @@ __global__ void k_mark_deferred(int n_reads, int num_aln, const uint32_t* __rest
   }
   if (d) read_status[r] |= LRA_ST_DEFERRED;
 }
+// opts.defer_seed_matches: the seed stage's flags become LRA_ST_DEFERRED in the reads' status words (no record is written for such a read)
+__global__ void k_mark_handed_back(int n_reads, const uint8_t* __restrict__ flag, uint32_t* __restrict__ read_status, unsigned long long* count) {
+  const int r = blockIdx.x * blockDim.x + threadIdx.x;
+  const bool d = r < n_reads && flag[r];
+  if (d) read_status[r] |= LRA_ST_DEFERRED;
+  const unsigned long long m = __ballot(d);
+  if ((threadIdx.x & 63) == 0 && m) atomicAdd(count, (unsigned long long)__popcll(m));
+}
 __global__ void k_src_slot(uint64_t S, int na, const int32_t* __restrict__ inB, uint64_t* __restrict__ src) {
   const uint64_t s = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (s >= S) return;
@@ -468,7 +476,23 @@ static int lowacc_core(lra_ctx* ctx, int n_reads, const char* d_seq, const uint6
   auto stage = [&](const char* name) { if (!sdbg) return; (void)hipStreamSynchronize(st); const double t = wall(); fprintf(stderr, "[stage%s] %-28s %8.1f ms\n", ctx->owns_stream ? " 2nd" : "", name, t - t_prev); t_prev = t; };
   // a1-a4
   lra_seed_result sres;
-  if ((rc = lra_seed_batch(ctx, n_reads, d_seq, d_read_off, o->globalK, o->globalW, o->globalMaxFreq, &sres))) return rc;
+  // opts.defer_seed_matches: the reads with more tier-1 matches than that are handed back (the seed stage empties their match lists: no later stage sees them)
+  const uint32_t seedT = o->defer_seed_matches > 0 ? (uint32_t)o->defer_seed_matches : 0;
+  ctx->seed->defer_T = seedT;
+  rc = lra_seed_batch(ctx, n_reads, d_seq, d_read_off, o->globalK, o->globalW, o->globalMaxFreq, &sres);
+  ctx->seed->defer_T = 0;
+  if (rc) return rc;
+  uint64_t n_handed_back = 0;
+  if (seedT) {
+    unsigned long long* dcnt = (unsigned long long*)lra_ensure(ctx, 191, 64);
+    if (!dcnt) return LRA_ERR_NOMEM;
+    LRA_HIP_CHECK(ctx, hipMemsetAsync(dcnt, 0, 8, st));
+    hipLaunchKernelGGL(k_mark_handed_back, grid((uint64_t)n_reads), dim3(256), 0, st, n_reads, (const uint8_t*)ctx->seed->defer_flag, read_status, dcnt);
+    unsigned long long h = 0;
+    LRA_HIP_CHECK(ctx, hipMemcpyAsync(&h, dcnt, 8, hipMemcpyDeviceToHost, st));
+    LRA_HIP_CHECK(ctx, hipStreamSynchronize(st));
+    n_handed_back = h;
+  }
   stage("seed");
   // a5, a7
   lra_cluster_result cres;
@@ -543,10 +567,27 @@ static int lowacc_core(lra_ctx* ctx, int n_reads, const char* d_seq, const uint6
   lra_map_counters cnt0; memset(&cnt0, 0, sizeof cnt0);
   cnt0.n_minimizers = sres.n_minimizers; cnt0.n_matches = sres.n_matches; cnt0.n_clusters = cres.n_clusters; cnt0.n_sdp_anchors = chres.n_frags; cnt0.n_sdp_points = chres.n_points;
   cnt0.n_sdp_entries = chres.n_subproblem_entries; cnt0.n_local_tuples = rli.n_tuples; cnt0.n_local_tasks = rres.n_tasks; cnt0.n_local_task_words = task_words; cnt0.n_local_pairs = rres.n_pairs;
-  cnt0.n_refined_matches = rres.n_matches; cnt0.n_btwn_problems = bres.n_problems; cnt0.n_btwn_rounds = bres.n_rounds; cnt0.n_refined_after_btwn = bres.n_matches;
+  cnt0.n_deferred_reads = n_handed_back; cnt0.n_refined_matches = rres.n_matches; cnt0.n_btwn_problems = bres.n_problems; cnt0.n_btwn_rounds = bres.n_rounds; cnt0.n_refined_after_btwn = bres.n_matches;
   LowaccTailIn in;
   in.n_reads = n_reads; in.num_aln = num_aln; in.n_slots = n_slots; in.tot = tot; in.d_read_off = d_read_off; in.d_seq = d_seq; in.both = both; in.slot_n0 = slot_n0;
   in.job_reached = job_reached; in.read_status = read_status; in.counters = cnt0;
+  if (const char* dumpPath = getenv("LRA_LOAD_DUMP")) {                  // analysis: per read, the tier-1 matches and the refined matches its second sparse DP will chain
+    uint32_t* load = (uint32_t*)lra_ensure(ctx, 181, ((size_t)n_reads + 1) * 4);
+    if (!load) return LRA_ERR_NOMEM;
+    LRA_HIP_CHECK(ctx, hipMemsetAsync(load, 0, (size_t)n_reads * 4, st));
+    hipLaunchKernelGGL(k_read_load, grid(n_slots), dim3(256), 0, st, n_slots, num_aln, chres.d_n_chains, chres.d_chain_start, spres.d_n_split, spres.d_status, bres.d_match_off, load);
+    std::vector<uint32_t> hl((size_t)n_reads), hs((size_t)n_slots); std::vector<uint64_t> hm((size_t)n_reads + 1), hq((size_t)n_reads + 1);
+    LRA_HIP_CHECK(ctx, hipMemcpyAsync(hl.data(), load, (size_t)n_reads * 4, hipMemcpyDeviceToHost, st));
+    LRA_HIP_CHECK(ctx, hipMemcpyAsync(hs.data(), spres.d_n_split, (size_t)n_slots * 4, hipMemcpyDeviceToHost, st));
+    LRA_HIP_CHECK(ctx, hipMemcpyAsync(hm.data(), sres.d_match_off, ((size_t)n_reads + 1) * 8, hipMemcpyDeviceToHost, st));
+    LRA_HIP_CHECK(ctx, hipMemcpyAsync(hq.data(), sres.d_mm_off, ((size_t)n_reads + 1) * 8, hipMemcpyDeviceToHost, st));
+    LRA_HIP_CHECK(ctx, hipStreamSynchronize(st));
+    if (FILE* f = fopen(dumpPath, "wb")) {
+      const uint32_t hdr[2] = {(uint32_t)n_reads, (uint32_t)num_aln};
+      fwrite(hdr, 4, 2, f); fwrite(hm.data(), 8, hm.size(), f); fwrite(hq.data(), 8, hq.size(), f); fwrite(hl.data(), 4, hl.size(), f); fwrite(hs.data(), 4, hs.size(), f);
+      fclose(f);
+    }
+  }
   // ---- the split point: reads with more refined matches than the threshold go on in the second context (from here: MergeChain onwards), beside this pass
   if (defer_threshold && deferred && second && second_in) {
     uint32_t* load = (uint32_t*)lra_ensure(ctx, 181, ((size_t)n_reads + 1) * 4);
@@ -687,7 +728,7 @@ static int lowacc_tail(lra_ctx* ctx, const LowaccTailIn& in, const lra_map_opts*
 namespace {
 __global__ void k_count_flagged(int n, const uint32_t* __restrict__ st, unsigned long long* out) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  const unsigned long long m = __ballot(i < n && st[i] != 0);
+  const unsigned long long m = __ballot(i < n && st[i] != 0 && st[i] != (uint32_t)LRA_ST_DEFERRED);   // (a handed-back read is not a flagged one: counters.n_deferred_reads)
   if ((threadIdx.x & 63) == 0 && m) atomicAdd(out, (unsigned long long)__popcll(m));
 }
 }  // namespace
@@ -806,7 +847,7 @@ static int lowacc_batch_impl(lra_ctx* ctx, int n_reads, const char* d_seq, const
   lra_map_counters c = a.counters; const lra_map_counters& b = o2.counters;
   c.n_merged_clusters += b.n_merged_clusters; c.n_sdp2_anchors += b.n_sdp2_anchors; c.n_sdp2_entries += b.n_sdp2_entries; c.n_a13_blocks += b.n_a13_blocks;
   c.n_large_spaces += b.n_large_spaces; c.n_segments += b.n_segments; c.n_rows += b.n_rows; c.n_cells += b.n_cells; c.n_aog += b.n_aog;
-  c.n_deferred_reads = (uint64_t)R2;
+  c.n_deferred_reads = a.counters.n_deferred_reads + (uint64_t)R2;
   out->counters = c;
   return LRA_OK;
 }
@@ -847,7 +888,7 @@ extern "C" uint64_t lra_map_host_flagged(const lra_map_host* h, const uint32_t**
   if (status) *status = nullptr;
   if (!h) return 0;
   uint64_t n = 0;
-  for (uint32_t v : h->rstat) n += v != 0;
+  for (uint32_t v : h->rstat) n += v != 0 && v != (uint32_t)LRA_ST_DEFERRED;   // (a handed-back read is not a flagged one)
   if (status && !h->rstat.empty()) *status = h->rstat.data();
   return n;
 }
@@ -1032,7 +1073,7 @@ extern "C" int lra_map_records_host(lra_map_host* h, const lra_map_opts* o, cons
     for (int r = lo; r < hi; r++) {
       recs.clear(); cigars.clear(); seg_off.assign(1, 0); rcRead.clear();
       const bool flagged = !rstat.empty() && rstat[r];
-      if (flagged && !o->flagged_unaligned) { plen[tix].push_back(0); continue; }   // flagged read: no record (the caller routes it elsewhere; d_read_status, lra_map_host_flagged)
+      if (flagged && (!o->flagged_unaligned || (rstat[r] & LRA_ST_DEFERRED))) { plen[tix].push_back(0); continue; }   // flagged read: no record (the caller routes it elsewhere; d_read_status, lra_map_host_flagged)
       // low-accuracy path: p == 0 left no SegAlignment (Map_lowacc.h:578-581); high-accuracy path: read.unaligned or alignments.size() == 0
       // (Map_highacc.h:778-781) = no chain of the read got its SegAlignmentGroup
       bool unaligned = flagged || nJ == 0 || jo[(size_t)r * na + 1] == jo[(size_t)r * na];   // (opts.flagged_unaligned: a flagged read is written as an unaligned one)

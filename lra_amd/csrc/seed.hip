@@ -735,6 +735,15 @@ __global__ void bounds_kernel(uint64_t total, const uint64_t* __restrict__ mm_ke
 
 // per-read upper bound on emitted pairs: a (query tuple, index tuple) pair with equal keys can be
 // emitted by a front step, re-emitted once by the raw-key quirk (:101-102), and once by a back step
+// opts.defer_seed_matches (scheduling only): the reads whose walk found more matches than T keep none of them -- every later stage sees a read without matches -- and are
+// flagged; the driver marks them LRA_ST_DEFERRED and the caller maps them in a later batch of their own kind
+__global__ void defer_heavy_kernel(int n_reads, uint32_t T, uint64_t* __restrict__ counts, uint8_t* __restrict__ flag) {
+  const int r = blockIdx.x * blockDim.x + threadIdx.x;
+  if (r >= n_reads) return;
+  const bool d = counts[r] > (uint64_t)T;
+  flag[r] = d ? 1 : 0;
+  if (d) counts[r] = 0;
+}
 __global__ void __launch_bounds__(64) match_capacity_kernel(int n_reads, const uint64_t* __restrict__ mm_off, const uint32_t* __restrict__ lb,
                                                             const uint32_t* __restrict__ ub, uint64_t* __restrict__ cap) {
   const int lane = threadIdx.x;
@@ -958,7 +967,7 @@ void lra_seed_free(lra_ctx* ctx) {
   if (s->borrowed) { s->genome = nullptr; s->idx_key = nullptr; s->idx_pos = nullptr; s->dir = nullptr; }
   else s->cell->dead = true;                                               // borrowers hold the cell, not this state
   void* ptrs[] = {s->genome, s->idx_key, s->idx_pos, s->counts32, s->counts64, s->mm_off, s->match_off, s->n_forward,
-                  s->mm_key, s->mm_pos, s->lb, s->ub, s->match_qi, s->match_ti, s->sep_qpos, s->sep_tpos, s->tmp_qi, s->tmp_ti, s->cap_cnt, s->cap_off, s->tk_lb, s->tk_lbm1, s->tk_ubm1, s->dir, s->sep_qkey};
+                  s->mm_key, s->mm_pos, s->lb, s->ub, s->match_qi, s->match_ti, s->sep_qpos, s->sep_tpos, s->tmp_qi, s->tmp_ti, s->cap_cnt, s->cap_off, s->tk_lb, s->tk_lbm1, s->tk_ubm1, s->dir, s->sep_qkey, s->defer_flag};
   for (void* p : ptrs) if (p) (void)hipFree(p);
   delete s;
   ctx->seed = nullptr;
@@ -1253,6 +1262,14 @@ extern "C" int lra_seed_batch(lra_ctx* ctx, int n_reads, const char* d_seq, cons
   hipLaunchKernelGGL(compare_kernel, dim3((n_reads + FLAT_LANES - 1) / FLAT_LANES), dim3(64), 0, st, FLAT_LANES, n_reads, s->mm_off, s->mm_key, s->lb, s->ub, s->tk_lb, s->tk_lbm1, s->tk_ubm1, s->idx_key,
                      (long)s->n_idx, (long)max_freq, s->cap_off, s->tmp_qi, s->tmp_ti, s->counts64);
   lra_time_end(ctx);
+  if (s->defer_T) {
+    if ((size_t)n_reads > s->cap_defer) {
+      LRA_HIP_CHECK(ctx, hipStreamSynchronize(st));
+      if (!regrow(s->defer_flag, (size_t)n_reads + n_reads / 4 + 64)) return lra_set_err(ctx, LRA_ERR_NOMEM, "defer flags");
+      s->cap_defer = (size_t)n_reads + n_reads / 4 + 64;
+    }
+    hipLaunchKernelGGL(defer_heavy_kernel, dim3((n_reads + 255) / 256), dim3(256), 0, st, n_reads, s->defer_T, s->counts64, s->defer_flag);
+  }
   if (lra_exclusive_scan<uint64_t>(ctx, (long)n_reads, s->counts64, s->match_off)) return LRA_ERR_HIP;
   uint64_t total_m = 0;
   LRA_HIP_CHECK(ctx, hipMemcpyAsync(&total_m, s->match_off + n_reads, 8, hipMemcpyDeviceToHost, st));

@@ -21,6 +21,9 @@ struct lra_seed_state {
   uint32_t* dir = nullptr; uint32_t nbuckets = 0; int dir_shift = 0;
   uint32_t* match_qi = nullptr; uint32_t* match_ti = nullptr; uint32_t* sep_qpos = nullptr; uint32_t* sep_tpos = nullptr; uint64_t* sep_qkey = nullptr; size_t cap_match = 0;
   int last_n_reads = 0; uint64_t last_n_matches = 0;   // shape of the current seed result (inputs of the clean stage)
+  // lra_map_reads_lowacc_batch with opts.defer_seed_matches: a read with more tier-1 matches than defer_T leaves the batch behind CompareLists (its match list is
+  // emptied, defer_flag[r] = 1); 0 = off.  Set by the driver around its lra_seed_batch call, never by the stage entry point itself.
+  uint32_t defer_T = 0; uint8_t* defer_flag = nullptr; size_t cap_defer = 0;
   uint32_t* tmp_qi = nullptr; uint32_t* tmp_ti = nullptr; size_t cap_tmp = 0; uint64_t* cap_cnt = nullptr; uint64_t* cap_off = nullptr;
 };
 

@@ -61,6 +61,7 @@ class LowAccOptions:
     hardClip: bool = True
     PrintNumAln: int = 1
     printFormat: str = "s"
+    deferSeedMatches: int = 0          # lra_map_opts.defer_seed_matches (scheduling only: reads with more tier-1 matches are handed back unmapped; 0 = off)
     deferMatches: int = None           # lra_map_opts.defer_matches (scheduling only; None = the preset's value, 0 = one pass)
 
 
@@ -97,7 +98,7 @@ class MapOpts(C.Structure):
                                           "localMatch", "localMismatch", "localIndel", "localBand", "refineSpaceDist")] +
                 [("anchorstoosparse", C.c_float), ("splitdist", C.c_int32), ("window", C.c_int32), ("second_anchorbonus", C.c_float),
                  ("bypassClustering", C.c_int32), ("skipBandedRefine", C.c_int32), ("refineBreakpoint", C.c_int32), ("clean", cluster.CleanOpts), ("sdp", chain.SdpOpts)] +
-                [(n, C.c_int32) for n in ("readType", "hardClip", "PrintNumAln", "printFormat")] + [("fine", cluster.FineOpts), ("merge_dist", C.c_int32), ("defer_matches", C.c_int32), ("flagged_unaligned", C.c_int32)])
+                [(n, C.c_int32) for n in ("readType", "hardClip", "PrintNumAln", "printFormat")] + [("fine", cluster.FineOpts), ("merge_dist", C.c_int32), ("defer_matches", C.c_int32), ("flagged_unaligned", C.c_int32), ("defer_seed_matches", C.c_int32)])
 
 
 class MapCounters(C.Structure):
@@ -207,6 +208,7 @@ class LowAccMapper:
         m.readType = READ_TYPES[o.read_type]; m.hardClip = int(o.hardClip); m.PrintNumAln = o.PrintNumAln; m.printFormat = ord(o.printFormat)
         if o.deferMatches is not None:
             m.defer_matches = int(o.deferMatches)
+        m.defer_seed_matches = int(o.deferSeedMatches)
         return m
 
     # ------------------------------------------------------------------------------------------------------------------ the C boundary

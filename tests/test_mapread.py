@@ -481,3 +481,46 @@ def test_borrowed_reference_goes_stale_when_its_owner_reloads_or_dies():
     with pytest.raises(LraError, match="destroyed"):
         borrower2.align(seed.ReadBatch(b2_ctx, [rd.tobytes()]))
     b_ctx.close(); b2_ctx.close()
+
+
+@pytest.mark.gpu
+def test_reads_handed_back_by_tier1_matches_map_the_same_in_a_batch_of_their_own(ctx):
+    """lra_map_opts.defer_seed_matches (scheduling only): reads with more tier-1 matches than the threshold leave the batch behind the seed stage -- status
+    LRA_ST_DEFERRED and nothing else, counted in n_deferred_reads (not in n_flagged_reads), no record -- every other read's records are unchanged, and the
+    handed-back reads mapped as a batch of their own give exactly the records they have in the one-pass batch."""
+    from lra_amd import seed, mapread
+    genome = synth.make_genome(600_000, seed=12, repeat_frac=0.3, n_families=3)
+    o = mapread.LowAccOptions()
+    ik, ip = synth.build_global_index(genome, o.globalK, o.globalW, 100)
+    reads, truth = synth.simulate_reads(genome, 24, 9000, 4000, 0.10, seed=21)
+    rng = np.random.default_rng(8)
+    reads.append(np.frombuffer(b"ACGT", dtype=np.uint8)[rng.integers(0, 4, 2000)].copy())      # junk: unaligned in both runs
+    raw = [r.tobytes() for r in reads]
+    names = [b"q%d" % i for i in range(len(reads))]
+    mapper = mapread.LowAccMapper(ctx, genome, ik, ip, [b"chr1"], [0, len(genome)], o)
+    batch = seed.ReadBatch(ctx, raw)
+    s = seed.fetch(ctx, seed.seed_batch(ctx, batch, o.globalK, o.globalW, o.globalMaxFreq))
+    per_read = np.diff(s["match_off"]).astype(np.int64)
+    T = int(np.sort(per_read)[len(per_read) * 2 // 3])                    # a third of the reads lie above it
+    res0 = mapper.align(batch)
+    assert mapper.stats["n_deferred_reads"] == 0
+    texts0 = mapper.records(res0, names, raw)
+    mapper.copts.defer_seed_matches = T
+    res1 = mapper.align(batch)
+    st1 = ctx.to_host(res1.d_read_status, len(reads), np.uint32)
+    D = np.nonzero(st1 & 64)[0]
+    assert np.array_equal(D, np.nonzero(per_read > T)[0]) and 0 < len(D) < len(reads) - 1
+    assert np.all(st1[D] == 64) and np.all(np.delete(st1, D) == 0)
+    assert mapper.stats["n_deferred_reads"] == len(D) and int(res1.counters.n_flagged_reads) == 0
+    texts1 = mapper.records(res1, names, raw)
+    for r in range(len(reads)):
+        assert texts1[r] == (b"" if r in set(D.tolist()) else texts0[r]), r
+    mapper.copts.flagged_unaligned = 1                                      # (a handed-back read is not written as an unaligned one either)
+    assert mapper.records(res1, names, raw)[int(D[0])] == b""
+    mapper.copts.flagged_unaligned = 0
+    mapper.copts.defer_seed_matches = 0
+    res2 = mapper.align(seed.ReadBatch(ctx, [raw[i] for i in D]))
+    assert mapper.stats["n_deferred_reads"] == 0
+    texts2 = mapper.records(res2, [names[i] for i in D], [raw[i] for i in D])
+    assert [texts2[k] for k in range(len(D))] == [texts0[i] for i in D]
+    assert sum(1 for t in texts2 if t and not (int(t.split(b"\t")[1]) & 4)) >= len(D) - 1
