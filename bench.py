@@ -99,6 +99,8 @@ def main():
     ap.add_argument("--defer-seed", type=int, default=int(os.environ.get("LRA_BENCH_DEFER_SEED", 6000)),
                     help="lra_map_opts.defer_seed_matches: reads with more tier-1 matches are handed back by the batch they arrive in, pooled, and mapped as batches of "
                          "their own inside the timed region (cost-ordered batching: every read is mapped exactly once per step either way); 0 = off")
+    ap.add_argument("--heavy-lane", type=int, default=int(os.environ.get("LRA_BENCH_HEAVY_LANE", 1)),
+                    help="1 = the batches of handed-back reads run on a context of their own (low-priority streams) beside the next steps; 0 = on lane 0, between steps")
     ap.add_argument("--heavy-pool", type=int, default=int(os.environ.get("LRA_BENCH_HEAVY_POOL", 4096)), help="handed-back reads per batch of their own")
     ap.add_argument("--lane-priority", type=int, default=int(os.environ.get("LRA_BENCH_LANE_PRIORITY", 1)),
                     help="with --lanes > 1: 1 = lane 0 on a high-priority stream, the others below it (they fill what it leaves idle); 0 = all lanes alike")
@@ -183,11 +185,18 @@ def main():
     if defer_T:
         import copy
         mapper.copts.defer_seed_matches = defer_T
-        hmap = copy.copy(mapper)
+        if args.heavy_lane:
+            hctx = Context(dev_index)
+            hmap = mapread.LowAccMapper.sharing(hctx, mapper)
+            hstream = torch.cuda.Stream(device=dev_index, priority=prio_lo)
+            hctx.bind_stream(hstream)
+        else:
+            hctx, hstream = ctx, None
+            hmap = copy.copy(mapper)
         hmap.copts = type(mapper.copts).from_buffer_copy(mapper.copts)
         hmap.copts.defer_seed_matches = 0
         hmap.stats = {}
-        heavy["lane"] = dict(ctx=ctx, mapper=hmap, stream=None, packed=None, n_items=0)
+        heavy["lane"] = dict(ctx=hctx, mapper=hmap, stream=hstream, packed=None, n_items=0)
     torch.cuda.synchronize()
     torch.cuda.empty_cache()
     sim_s = time.time() - t0
@@ -289,52 +298,77 @@ def main():
             work["next"] += 1
             return it
 
+    def process_item(lane, sub, prev, tag):
+        """device side + pack of one batch on `lane`, then its host tail on a thread of its own (after the previous one of this caller) -> that thread"""
+        dbg = os.environ.get("LRA_BENCH_DBG")
+        tA = time.perf_counter()
+        lane_device_side(lane, sub)
+        lane["n_items"] += 1
+        if dbg:
+            sys.stderr.write("[bench] %s (%d reads) device side + pack %.0f ms\n" % (tag, sub["rbatch"].n, (time.perf_counter() - tA) * 1e3))
+        if err or args.no_records:
+            return prev
+        # The exchange step and everything behind it -- gather to rank 0, the copy to the host, unpacking, the record text -- belong to the step's
+        # host tail and run beside the next step's device side (the reference interleaves its output with the next reads the same way, lra.cpp:117-158).
+        # The packed buffer is context-owned (the next lra_map_pack reuses it), so the tail works on a device copy.
+        with torch.cuda.stream(lane["stream"]) if lane["stream"] is not None else contextlib.nullcontext():
+            held = lane["packed"].clone()
+            ev = torch.cuda.Event()
+            ev.record(torch.cuda.current_stream())
+        if prev is not None:
+            tC = time.perf_counter()
+            prev.join()
+            if dbg:
+                sys.stderr.write("[bench] %s waited for the previous host tail %.0f ms\n" % (tag, (time.perf_counter() - tC) * 1e3))
+        th = threading.Thread(target=tail_thread, args=(lane, sub, held, ev))
+        th.start()
+        return th
+
+    import queue
+    heavy_q = queue.Queue()
+
+    def heavy_worker():
+        """the batches of handed-back reads, one after the other on their own context, beside the steps that follow the ones they came from"""
+        prev = None
+        try:
+            torch.cuda.set_device(dev_index)
+            while True:
+                sub = heavy_q.get()
+                if sub is None:
+                    break
+                if not err:
+                    prev = process_item(heavy["lane"], sub, prev, "handed-back reads")
+            if prev is not None:
+                prev.join()
+        except BaseException as e:
+            err.append(e)
+
     def lane_loop(li, stagger_s):
-        lane = lanes[li]
         try:
             if stagger_s:
                 time.sleep(stagger_s)
             prev = None
-            dbg = os.environ.get("LRA_BENCH_DBG")
             while True:
                 it = take_item()
-                if it is None:
+                if it is None or err:
                     break
-                s_, sub = it[0], (subs[it[1]] if it[1] >= 0 else None)
-                if it[1] < 0:                                              # a batch of handed-back reads
-                    lane, sub = heavy["lane"], heavy_sub()
-                else:
-                    lane = lanes[li]
-                tA = time.perf_counter()
-                lane_device_side(lane, sub)
-                lane["n_items"] += 1
-                if defer_T and it[1] >= 0 and not err:
-                    pool_handed_back(lane, it[1])
-                    last_main = work["next"] >= len(work["items"]) or all(x[1] < 0 for x in work["items"][work["next"]:])
-                    if heavy["n"] and (heavy["n"] >= args.heavy_pool or last_main):
-                        with work_lock:
-                            work["items"].insert(work["next"], (s_, -1))    # next: the pool as a batch of its own (the last step flushes what is left)
-                tB = time.perf_counter()
-                if dbg:
-                    sys.stderr.write("[bench] lane %d: step %d sub-batch %d (%d reads) device side + pack %.0f ms\n" % (li, s_, it[1], sub["rbatch"].n, (tB - tA) * 1e3))
-                if err:
-                    break
-                if args.no_records:
+                s_, j = it
+                if j < 0:                                                  # (--heavy-lane 0) a batch of handed-back reads, between two steps
+                    prev = process_item(heavy["lane"], heavy_sub(), prev, "handed-back reads")
                     continue
-                # The exchange step and everything behind it -- gather to rank 0, the copy to the host, unpacking, the record text -- belong to the step's
-                # host tail and run beside the next step's device side (the reference interleaves its output with the next reads the same way, lra.cpp:117-158).
-                # The packed buffer is context-owned (the next lra_map_pack reuses it), so the tail works on a device copy.
-                with torch.cuda.stream(lane["stream"]) if lane["stream"] is not None else contextlib.nullcontext():
-                    held = lane["packed"].clone()
-                    ev = torch.cuda.Event()
-                    ev.record(torch.cuda.current_stream())
-                if prev is not None:
-                    tC = time.perf_counter()
-                    prev.join()
-                    if dbg:
-                        sys.stderr.write("[bench] lane %d: step %d waited for the previous host tail %.0f ms\n" % (li, s_, (time.perf_counter() - tC) * 1e3))
-                prev = threading.Thread(target=tail_thread, args=(lane, sub, held, ev))
-                prev.start()
+                prev = process_item(lanes[li], subs[j], prev, "lane %d: step %d sub-batch %d" % (li, s_, j))
+                if defer_T and not err:
+                    pool_handed_back(lanes[li], j)
+                    with work_lock:
+                        last_main = work["next"] >= len(work["items"])
+                    if heavy["n"] and (heavy["n"] >= args.heavy_pool or last_main):   # the pool as a batch of its own (the last step flushes what is left)
+                        if args.heavy_lane:
+                            hs_ = heavy_sub()
+                            torch.cuda.current_stream().synchronize()      # (the gather ran on this thread's stream)
+                            heavy_q.put(hs_)
+                        else:
+                            with work_lock:
+                                work["items"].insert(work["next"], (s_, -1))
             if prev is not None:
                 prev.join()
         except BaseException as e:
@@ -343,8 +377,15 @@ def main():
     def run_steps(n_steps, stagger):
         work["items"] = [(s_, j) for s_ in range(n_steps) for j in range(len(subs))]
         work["next"] = 0
+        hw = None
+        if defer_T and args.heavy_lane:
+            hw = threading.Thread(target=heavy_worker)
+            hw.start()
         if len(lanes) == 1:
             lane_loop(0, 0.0)
+            if hw is not None:                                             # the step is over when the reads it handed back are mapped too
+                heavy_q.put(None)
+                hw.join()
         else:
             ths = [threading.Thread(target=lane_loop, args=(li, stagger * li / len(lanes))) for li in range(len(lanes))]
             for t in ths: t.start()
@@ -362,7 +403,8 @@ def main():
     tw = time.perf_counter()
     run_steps(min(args.warmup, 1), 0.0)
     step_guess = (time.perf_counter() - tw) if args.warmup > 1 else 0.0
-    for l in lanes:
+    timed = lanes + ([heavy["lane"]] if defer_T and args.heavy_lane else [])
+    for l in timed:
         l["ctx"].timing(True)
         l["ctx"].timing_reset()
         l["n_items"] = 0
@@ -390,10 +432,10 @@ def main():
                "rsc_tasks", "rsc_filter", "refine_space", "rs_long_sketch", "rs_long_compare", "btwn_plan", "btwn_apply", "merge_extend", "between_anchors", "local_refine", "sdp_inner_points", "sdp_inner_sort", "sdp_inner_build_count", "sdp_inner_build", "sdp_inner_process", "sdp_inner_trace", "chain_split", "sdp_points", "sdp_sort", "sdp_sort_fallback", "sdp_build_count", "sdp_build", "sdp_process", "sdp_trace"]
     ktimes = {}
     for k in kernels:
-        tt_ = [l["ctx"].timing_get(k) for l in lanes]
+        tt_ = [l["ctx"].timing_get(k) for l in timed]
         ktimes[k] = (sum(x[0] for x in tt_), sum(x[1] for x in tt_))
     stats = {}
-    for l in lanes:
+    for l in timed:
         l["ctx"].timing(False)
         for k, v in l["mapper"].stats.items():
             stats[k] = stats.get(k, 0) + v if isinstance(v, (int, float)) else v
@@ -470,7 +512,7 @@ def main():
                     lane_device_side(lanes[0], subs[0])
                     if err:
                         raise err[0]
-                for l in lanes[1:]:
+                for l in timed[1:]:
                     l["ctx"].close()
                 out["cpu_baseline"] = cpu_baseline(mapper, reads_h, off_h, args, lanes[0].get("last_res"))
             except Exception as e:                                          # the bench line must survive a baseline problem; say what happened

@@ -388,19 +388,25 @@ __global__ void __launch_bounds__(64 * NW, NW == 1 ? 8 : 1) sdp_build(BuildArgs 
       // A: which elements go to the first half of their node's lines; exclusive prefix in pf
       {
         int carry = 0;
-        for (int i0 = 0; i0 < Pf; i0 += NT) {
-          const int i = i0 + tid;
-          int f = 0;
-          if (i < Pf) {
-            const uint32_t k = LN(i);
-            if (k != NONE) {
-              const uint32_t s = TB(cur, F_LS, k), e = TB(cur, F_LE, k);
-              f = (e - s > 1) ? (llc[i] < ((s + e) >> 1)) : 1;
-            }
+        // (UA chunks of the pass at a time: their loads -- node of the element, the node's line range, the element's line -- are all asked for before anything is
+        // waited for or stored, so a chunk costs a third of a dependent chain instead of a whole one; the pass is a latency chain per wave, not a stream)
+        constexpr int UA = 4;
+        for (int i0 = 0; i0 < Pf; i0 += UA * NT) {
+          uint32_t kk[UA]; uint32_t ss[UA], ee[UA]; IT lv[UA]; int ff[UA];
+#pragma unroll
+          for (int u = 0; u < UA; u++) { const int i = i0 + u * NT + tid; kk[u] = i < Pf ? LN(i) : NONE; lv[u] = i < Pf ? llc[i] : (IT)0; }
+#pragma unroll
+          for (int u = 0; u < UA; u++) { ss[u] = 0; ee[u] = 0; if (kk[u] != NONE) { ss[u] = TB(cur, F_LS, kk[u]); ee[u] = TB(cur, F_LE, kk[u]); } }
+#pragma unroll
+          for (int u = 0; u < UA; u++) ff[u] = kk[u] == NONE ? 0 : (ee[u] - ss[u] > 1) ? (lv[u] < ((ss[u] + ee[u]) >> 1)) : 1;
+#pragma unroll
+          for (int u = 0; u < UA; u++) {
+            const int i = i0 + u * NT + tid;
+            if (i0 + u * NT >= Pf) break;
+            int tot; const int inc = blk_incl_scan<NW>(ff[u], lane, wave, s_w[0], tot);
+            if (i < Pf) pf[i] = (IT)(carry + inc - ff[u]);
+            carry += tot;
           }
-          int tot; const int inc = blk_incl_scan<NW>(f, lane, wave, s_w[0], tot);
-          if (i < Pf) pf[i] = (IT)(carry + inc - f);
-          carry += tot;
         }
         if (tid == 0) pf[Pf] = (IT)carry;
       }
@@ -411,45 +417,87 @@ __global__ void __launch_bounds__(64 * NW, NW == 1 ? 8 : 1) sdp_build(BuildArgs 
       }
       SYNC();
       // C: stable partition of every node's two segments
-      for (int i = tid; i < Pf; i += NT) {
-        const uint32_t k = LN(i);
-        if (k == NONE) { ln[P + i] = INONE; continue; }
-        const bool isS = i < nS;
-        const uint32_t sb = isS ? TB(cur, F_SB, k) : TB(cur, F_EB, k);
-        const uint32_t c1 = isS ? TM(T_C1S, k) : TM(T_C1E, k);
-        const uint32_t rank1 = (uint32_t)pf[i] - (uint32_t)pf[sb];
-        const uint32_t first = (uint32_t)pf[i + 1] - (uint32_t)pf[i];
-        const uint32_t np_ = first ? sb + rank1 : sb + c1 + ((uint32_t)i - sb - rank1);
-        lpn[np_] = lpc[i]; lln[np_] = llc[i]; ldn[np_] = ldc[i];
-        ln[P + np_] = (IT)(2 * k + (first ? 0 : 1));
+      {
+        // (a node's two segments are partitioned inside their own ranges, so an element's slot ln[P + .] is written either here (no node) or by the element that moves
+        // into it, never both: the chunks of a group may be read before any of them is written)
+        constexpr int UC = 2;
+        for (int i0 = 0; i0 < Pf; i0 += UC * NT) {
+          uint32_t kk[UC], pi0[UC], pi1[UC], sb[UC], c1[UC], psb[UC]; IT vlp[UC], vll[UC]; DT vld[UC];
+#pragma unroll
+          for (int u = 0; u < UC; u++) {
+            const int i = i0 + u * NT + tid;
+            kk[u] = NONE; pi0[u] = 0; pi1[u] = 0; vlp[u] = 0; vll[u] = 0; vld[u] = 0;
+            if (i < Pf) { kk[u] = LN(i); pi0[u] = (uint32_t)pf[i]; pi1[u] = (uint32_t)pf[i + 1]; vlp[u] = lpc[i]; vll[u] = llc[i]; vld[u] = ldc[i]; }
+          }
+#pragma unroll
+          for (int u = 0; u < UC; u++) {
+            const int i = i0 + u * NT + tid;
+            const bool isS = i < nS;
+            sb[u] = 0; c1[u] = 0;
+            if (kk[u] != NONE) { sb[u] = isS ? TB(cur, F_SB, kk[u]) : TB(cur, F_EB, kk[u]); c1[u] = isS ? TM(T_C1S, kk[u]) : TM(T_C1E, kk[u]); }
+          }
+#pragma unroll
+          for (int u = 0; u < UC; u++) psb[u] = kk[u] != NONE ? (uint32_t)pf[sb[u]] : 0;
+#pragma unroll
+          for (int u = 0; u < UC; u++) {
+            const int i = i0 + u * NT + tid;
+            if (i >= Pf) continue;
+            if (kk[u] == NONE) { ln[P + i] = INONE; continue; }
+            const uint32_t rank1 = pi0[u] - psb[u];
+            const uint32_t first = pi1[u] - pi0[u];
+            const uint32_t np_ = first ? sb[u] + rank1 : sb[u] + c1[u] + ((uint32_t)i - sb[u] - rank1);
+            lpn[np_] = vlp[u]; lln[np_] = vll[u]; ldn[np_] = vld[u];
+            ln[P + np_] = (IT)(2 * kk[u] + (first ? 0 : 1));
+          }
+        }
       }
       SYNC();
       // D: heads of the distinct diagonals inside the D segment (ends) / E segment (starts); exclusive prefix in ph
       {
         int carry = 0;
-        for (int j0 = 0; j0 < Pf; j0 += NT) {
-          const int j = j0 + tid;
-          int head = 0;
-          if (j < Pf) {
-            const uint32_t k2 = LN(P + j);
-            if (k2 != NONE) {
-              const uint32_t k = k2 >> 1, side = k2 & 1;
+        constexpr int UD = NW == 1 ? 4 : 2;
+        for (int j0 = 0; j0 < Pf; j0 += UD * NT) {
+          uint32_t k2v[UD], le[UD], ls[UD], bg[UD], c1[UD]; DT d0[UD], d1[UD]; int hd[UD];
+#pragma unroll
+          for (int u = 0; u < UD; u++) {
+            const int j = j0 + u * NT + tid;
+            k2v[u] = NONE; d0[u] = 0; d1[u] = 0;
+            if (j < Pf) { k2v[u] = LN(P + j); d0[u] = ldn[j]; d1[u] = j > 0 ? ldn[j - 1] : ldn[j]; }
+          }
+#pragma unroll
+          for (int u = 0; u < UD; u++) {
+            const int j = j0 + u * NT + tid;
+            const bool isS = j < nS;
+            le[u] = 0; ls[u] = 0; bg[u] = 0; c1[u] = 0;
+            if (k2v[u] != NONE) {
+              const uint32_t k = k2v[u] >> 1;
+              le[u] = TB(cur, F_LE, k); ls[u] = TB(cur, F_LS, k); bg[u] = isS ? TB(cur, F_SB, k) : TB(cur, F_EB, k); c1[u] = isS ? TM(T_C1S, k) : TM(T_C1E, k);
+            }
+          }
+#pragma unroll
+          for (int u = 0; u < UD; u++) {
+            const int j = j0 + u * NT + tid;
+            hd[u] = 0;
+            if (k2v[u] != NONE) {
+              const uint32_t side = k2v[u] & 1;
               const bool isS = j < nS;
-              const bool leaf = TB(cur, F_LE, k) - TB(cur, F_LS, k) == 1;
+              const bool leaf = le[u] - ls[u] == 1;
               const bool in = leaf || (int)side == (isS ? eSide : dSide);
               if (in) {
-                uint32_t beg = isS ? TB(cur, F_SB, k) : TB(cur, F_EB, k);
-                if (!leaf && side == 1) beg += isS ? TM(T_C1S, k) : TM(T_C1E, k);
-                if ((uint32_t)j == beg) head = 1;
-                else {
-                  head = ldn[j] != ldn[j - 1];
-                }
+                uint32_t beg = bg[u];
+                if (!leaf && side == 1) beg += c1[u];
+                hd[u] = ((uint32_t)j == beg) ? 1 : (d0[u] != d1[u]);
               }
             }
           }
-          int tot; const int inc = blk_incl_scan<NW>(head, lane, wave, s_w[0], tot);
-          if (j < Pf) ph[j] = (IT)(carry + inc - head);
-          carry += tot;
+#pragma unroll
+          for (int u = 0; u < UD; u++) {
+            const int j = j0 + u * NT + tid;
+            if (j0 + u * NT >= Pf) break;
+            int tot; const int inc = blk_incl_scan<NW>(hd[u], lane, wave, s_w[0], tot);
+            if (j < Pf) ph[j] = (IT)(carry + inc - hd[u]);
+            carry += tot;
+          }
         }
         if (tid == 0) ph[Pf] = (IT)carry;
       }
@@ -508,33 +556,71 @@ __global__ void __launch_bounds__(64 * NW, NW == 1 ? 8 : 1) sdp_build(BuildArgs 
       if (outgrown) break;
       SYNC();
       // F: node index of every element for the next level; emit Di / Ei and the visit records
-      for (int j = tid; j < Pf; j += NT) {
-        const uint32_t k2 = LN(P + j);
-        if (k2 == NONE) { ln[j] = INONE; continue; }
-        const uint32_t k = k2 >> 1, side = k2 & 1;
-        const bool leaf = TB(cur, F_LE, k) - TB(cur, F_LS, k) == 1;
-        ln[j] = (IT)(leaf ? NONE : (side == 0 ? TM(T_CH0, k) : TM(T_CH1, k)));
-        {
-          const uint32_t gid = TM(T_GID, k);
-          const bool isS = j < nS;
-          const bool in = leaf || (int)side == (isS ? eSide : dSide);
-          if (in && gid != NONE) {
-            if (!EMIT) nVisits++;
-            else {
-              uint32_t beg = isS ? TB(cur, F_SB, k) : TB(cur, F_EB, k);
-              if (!leaf && side == 1) beg += isS ? TM(T_C1S, k) : TM(T_C1E, k);
-              const uint32_t head = (uint32_t)ph[j + 1] - (uint32_t)ph[j];
-              const uint32_t grp = (uint32_t)ph[j] - (uint32_t)ph[beg] + head - 1;
-              const uint32_t n = isS ? TM(T_NE, k) : TM(T_ND, k);
-              const uint32_t idx = desc ? n - 1 - grp : grp;
-              const uint32_t ent = TM(T_BASE, k) + (isS ? TM(T_ND, k) + idx : idx);
-              const uint32_t pos = lpn[j];
-              if (head) {
-                const long long dgv = back ? (long long)ht[pos] + hq[pos] : (long long)ht[pos] - hq[pos];   // (the element's diagonal, from its point: ldn may hold 32 bits of it)
-                entR[ent].val = dgv;
-                if (isS && idx == n - 1) nodesR[gid].eLast = dgv;
+      {
+        // (the pass reads ln[P + .], the tables, ph, lpn and the points; it writes ln[.] below P, the entries and the visit rows: nothing it reads)
+        constexpr int UF = 2;
+        for (int j0 = 0; j0 < Pf; j0 += UF * NT) {
+          uint32_t k2v[UF], le[UF], ls[UF], ch[UF], gidv[UF], bg[UF], c1[UF], nNE[UF], nND[UF], bs[UF], p0v[UF], p1v[UF], pbg[UF], posv[UF], tq[UF], tt[UF];
+#pragma unroll
+          for (int u = 0; u < UF; u++) {
+            const int j = j0 + u * NT + tid;
+            k2v[u] = NONE; p0v[u] = 0; p1v[u] = 0; posv[u] = 0;
+            if (j < Pf) { k2v[u] = LN(P + j); if (EMIT) { p0v[u] = (uint32_t)ph[j]; p1v[u] = (uint32_t)ph[j + 1]; posv[u] = lpn[j]; } }
+          }
+#pragma unroll
+          for (int u = 0; u < UF; u++) {
+            const int j = j0 + u * NT + tid;
+            const bool isS = j < nS;
+            le[u] = 0; ls[u] = 0; ch[u] = 0; gidv[u] = NONE; bg[u] = 0; c1[u] = 0; nNE[u] = 0; nND[u] = 0; bs[u] = 0; tq[u] = 0; tt[u] = 0;
+            if (k2v[u] != NONE) {
+              const uint32_t k = k2v[u] >> 1, side = k2v[u] & 1;
+              le[u] = TB(cur, F_LE, k); ls[u] = TB(cur, F_LS, k); ch[u] = side == 0 ? TM(T_CH0, k) : TM(T_CH1, k); gidv[u] = TM(T_GID, k);
+              if (EMIT) {
+                bg[u] = isS ? TB(cur, F_SB, k) : TB(cur, F_EB, k); c1[u] = isS ? TM(T_C1S, k) : TM(T_C1E, k);
+                nNE[u] = TM(T_NE, k); nND[u] = TM(T_ND, k); bs[u] = TM(T_BASE, k);
+                tq[u] = hq[posv[u]]; tt[u] = ht[posv[u]];
               }
-              visR[(uint64_t)pos * (2 * LV) + fam2 * LV + level] = make_uint2(gid, idx);
+            }
+          }
+#pragma unroll
+          for (int u = 0; u < UF; u++) {
+            pbg[u] = 0;
+            if (EMIT && k2v[u] != NONE) {
+              const uint32_t side = k2v[u] & 1;
+              const bool leaf = le[u] - ls[u] == 1;
+              uint32_t beg = bg[u];
+              if (!leaf && side == 1) beg += c1[u];
+              bg[u] = beg;
+              pbg[u] = (uint32_t)ph[beg];
+            }
+          }
+#pragma unroll
+          for (int u = 0; u < UF; u++) {
+            const int j = j0 + u * NT + tid;
+            if (j >= Pf) continue;
+            if (k2v[u] == NONE) { ln[j] = INONE; continue; }
+            const uint32_t side = k2v[u] & 1;
+            const bool leaf = le[u] - ls[u] == 1;
+            ln[j] = (IT)(leaf ? NONE : ch[u]);
+            const uint32_t gid = gidv[u];
+            const bool isS = j < nS;
+            const bool in = leaf || (int)side == (isS ? eSide : dSide);
+            if (in && gid != NONE) {
+              if (!EMIT) nVisits++;
+              else {
+                const uint32_t head = p1v[u] - p0v[u];
+                const uint32_t grp = p0v[u] - pbg[u] + head - 1;
+                const uint32_t n = isS ? nNE[u] : nND[u];
+                const uint32_t idx = desc ? n - 1 - grp : grp;
+                const uint32_t ent = bs[u] + (isS ? nND[u] + idx : idx);
+                const uint32_t pos = posv[u];
+                if (head) {
+                  const long long dgv = back ? (long long)tt[u] + tq[u] : (long long)tt[u] - tq[u];   // (the element's diagonal, from its point: ldn may hold 32 bits of it)
+                  entR[ent].val = dgv;
+                  if (isS && idx == n - 1) nodesR[gid].eLast = dgv;
+                }
+                visR[(uint64_t)pos * (2 * LV) + fam2 * LV + level] = make_uint2(gid, idx);
+              }
             }
           }
         }
@@ -542,38 +628,83 @@ __global__ void __launch_bounds__(64 * NW, NW == 1 ? 8 : 1) sdp_build(BuildArgs 
       SYNC();
       // G: Db / Eb in closed form (Decide_Eb_Db_*), values and back pointers zeroed
       if (EMIT) {
-        for (int j = tid; j < Pf; j += NT) {
-          const uint32_t k2 = LN(P + j);
-          if (k2 == NONE) continue;
-          const uint32_t k = k2 >> 1, side = k2 & 1;
-          const uint32_t gid = TM(T_GID, k);
-          if (gid == NONE || ph[j + 1] == ph[j]) continue;
-          const bool isS = j < nS;
-          const bool leaf = TB(cur, F_LE, k) - TB(cur, F_LS, k) == 1;
-          if (!(leaf || (int)side == (isS ? eSide : dSide))) continue;
-          uint32_t beg = isS ? TB(cur, F_SB, k) : TB(cur, F_EB, k);
-          if (!leaf && side == 1) beg += isS ? TM(T_C1S, k) : TM(T_C1E, k);
-          const uint32_t nD = TM(T_ND, k), nE = TM(T_NE, k), base = TM(T_BASE, k);
-          const uint32_t grp = (uint32_t)ph[j] - (uint32_t)ph[beg];
-          const uint32_t n = isS ? nE : nD;
-          const uint32_t idx = desc ? n - 1 - grp : grp;
-          const uint32_t ent = base + (isS ? nD + idx : idx);
-          const long long x = entR[ent].val;
-          const Ent* opp = entR + base + (isS ? 0 : nD);
-          const uint32_t m = isS ? nD : nE;
-          uint32_t lo = 0, cnt = m;
-          // D entry: asc  #{Ei < x}   desc #{Ei >= x};   E entry: asc #{Di <= x}   desc #{Di > x}
-          while (cnt > 0) {
-            const uint32_t step = cnt >> 1, it = lo + step;
-            const long long v = opp[it].val;
-            const bool go = isS ? (desc ? v > x : v <= x) : (desc ? v >= x : v < x);
-            if (go) { lo = it + 1; cnt -= step + 1; } else cnt = step;
+        // (reads: ln[P + .], the tables, ph, the .val fields of the level's entries (written by F, above the barrier); writes: the .b / .v fields, Ei[Db], the back
+        // pointers -- so the binary searches of UG chunks run side by side, a probe of each per round)
+        constexpr int UG = 2;
+        for (int j0 = 0; j0 < Pf; j0 += UG * NT) {
+          uint32_t k2v[UG], gidv[UG], le[UG], ls[UG], bg[UG], c1[UG], nDv[UG], nEv[UG], bs[UG], p0v[UG], p1v[UG], pbg[UG];
+          bool on[UG];
+#pragma unroll
+          for (int u = 0; u < UG; u++) {
+            const int j = j0 + u * NT + tid;
+            k2v[u] = NONE; p0v[u] = 0; p1v[u] = 0;
+            if (j < Pf) { k2v[u] = LN(P + j); p0v[u] = (uint32_t)ph[j]; p1v[u] = (uint32_t)ph[j + 1]; }
           }
-          entR[ent].b = isS ? (int32_t)lo - 1 : (lo == m ? -1 : (int32_t)lo);
-          if (!isS) edR[ent] = lo == m ? 0 : opp[lo].val;                   // Ei[Db[d]]
-          // (Ev[] is written but never read by the reference, and Db[Eb + 1] -- which the flush at the end of Maximization tests against the top pair's boundary,
-          // :450 -- is never needed: that boundary is n or n + 1, see sdp_process_wg)
-          entR[ent].v = 0.f; apR[ent] = 0;
+#pragma unroll
+          for (int u = 0; u < UG; u++) {
+            const int j = j0 + u * NT + tid;
+            const bool isS = j < nS;
+            gidv[u] = NONE; le[u] = 0; ls[u] = 0; bg[u] = 0; c1[u] = 0; nDv[u] = 0; nEv[u] = 0; bs[u] = 0;
+            if (k2v[u] != NONE && p1v[u] != p0v[u]) {
+              const uint32_t k = k2v[u] >> 1;
+              gidv[u] = TM(T_GID, k); le[u] = TB(cur, F_LE, k); ls[u] = TB(cur, F_LS, k);
+              bg[u] = isS ? TB(cur, F_SB, k) : TB(cur, F_EB, k); c1[u] = isS ? TM(T_C1S, k) : TM(T_C1E, k);
+              nDv[u] = TM(T_ND, k); nEv[u] = TM(T_NE, k); bs[u] = TM(T_BASE, k);
+            }
+          }
+#pragma unroll
+          for (int u = 0; u < UG; u++) {
+            const int j = j0 + u * NT + tid;
+            const bool isS = j < nS;
+            const uint32_t side = k2v[u] & 1;
+            const bool leaf = le[u] - ls[u] == 1;
+            on[u] = k2v[u] != NONE && p1v[u] != p0v[u] && gidv[u] != NONE && (leaf || (int)side == (isS ? eSide : dSide));
+            pbg[u] = 0;
+            if (on[u]) { uint32_t beg = bg[u]; if (!leaf && side == 1) beg += c1[u]; pbg[u] = (uint32_t)ph[beg]; }
+          }
+          uint32_t entv[UG], mv[UG], lo[UG], cnt[UG]; long long xv[UG]; const Ent* opp[UG];
+#pragma unroll
+          for (int u = 0; u < UG; u++) {
+            const int j = j0 + u * NT + tid;
+            const bool isS = j < nS;
+            const uint32_t grp = p0v[u] - pbg[u];
+            const uint32_t n = isS ? nEv[u] : nDv[u];
+            const uint32_t idx = desc ? n - 1 - grp : grp;
+            entv[u] = bs[u] + (isS ? nDv[u] + idx : idx);
+            opp[u] = entR + bs[u] + (isS ? 0 : nDv[u]);
+            mv[u] = isS ? nDv[u] : nEv[u];
+            xv[u] = on[u] ? entR[entv[u]].val : 0;
+            lo[u] = 0; cnt[u] = on[u] ? mv[u] : 0;
+          }
+          // D entry: asc  #{Ei < x}   desc #{Ei >= x};   E entry: asc #{Di <= x}   desc #{Di > x}
+          while (true) {
+            bool any = false;
+#pragma unroll
+            for (int u = 0; u < UG; u++) any |= cnt[u] > 0;
+            if (!any) break;
+            long long vv[UG];
+#pragma unroll
+            for (int u = 0; u < UG; u++) vv[u] = cnt[u] > 0 ? opp[u][lo[u] + (cnt[u] >> 1)].val : 0;
+#pragma unroll
+            for (int u = 0; u < UG; u++) {
+              if (cnt[u] == 0) continue;
+              const bool isS = j0 + u * NT + tid < nS;
+              const uint32_t step = cnt[u] >> 1, it = lo[u] + step;
+              const bool go = isS ? (desc ? vv[u] > xv[u] : vv[u] <= xv[u]) : (desc ? vv[u] >= xv[u] : vv[u] < xv[u]);
+              if (go) { lo[u] = it + 1; cnt[u] -= step + 1; } else cnt[u] = step;
+            }
+          }
+#pragma unroll
+          for (int u = 0; u < UG; u++) {
+            if (!on[u]) continue;
+            const bool isS = j0 + u * NT + tid < nS;
+            const uint32_t ent = entv[u], m = mv[u];
+            entR[ent].b = isS ? (int32_t)lo[u] - 1 : (lo[u] == m ? -1 : (int32_t)lo[u]);
+            if (!isS) edR[ent] = lo[u] == m ? 0 : opp[u][lo[u]].val;        // Ei[Db[d]]
+            // (Ev[] is written but never read by the reference, and Db[Eb + 1] -- which the flush at the end of Maximization tests against the top pair's boundary,
+            // :450 -- is never needed: that boundary is n or n + 1, see sdp_process_wg)
+            entR[ent].v = 0.f; apR[ent] = 0;
+          }
         }
       }
       nNodes = nNext; cur = nxt;
@@ -2005,7 +2136,10 @@ int sdp_run(lra_ctx* ctx, int n_reads, const uint64_t* d_cluster_off, const uint
       {
         const long big_pts = getenv("LRA_SDP_BIG_POINTS") ? atol(getenv("LRA_SDP_BIG_POINTS")) : (ctx->sdp_inner ? 1500 : 6000);   // (tests lower it to run small reads through the workgroup kernels)
         const std::vector<uint32_t>& ord = att == 0 ? h_orderAll : h_prev;
-        while (nbig < nsub && (long)(h_pt[r0 + ord[nbig] + 1] - h_pt[r0 + ord[nbig]]) >= big_pts) nbig++;
+        // ... but no more of them than the device runs side by side (a workgroup holds 16 wave slots for a per-point latency a third of the wave kernel's, at 3.5 times its
+        // wave-time per point): beyond that the large reads queue up behind each other, and the ones further down the order are better off as one wave each
+        static const int maxBig = getenv("LRA_SDP_MAX_BIG") ? std::max(0, atoi(getenv("LRA_SDP_MAX_BIG"))) : (1 << 30);
+        while (nbig < nsub && nbig < maxBig && (long)(h_pt[r0 + ord[nbig] + 1] - h_pt[r0 + ord[nbig]]) >= big_pts) nbig++;
       }
       {
         const bool forked = nbig > 0 && nsub > nbig;
