@@ -152,7 +152,8 @@ def main():
     total_bases = int(off_h[-1])
     del genome
     rb = reads_h.tobytes()
-    n_threads_rec = max(8, (os.cpu_count() or 16) // world) if world > 1 else 0
+    # the record text on half of the host's hardware threads (per rank): the thread that drives the device (sizing round trips between the stages) needs a core of its own
+    n_threads_rec = max(8, (os.cpu_count() or 16) // (2 * world))
     # A step = every sub-batch once.  With one lane that is one call on the whole batch.  With several, the sub-batches of all timed steps form one work list and
     # every lane (a context of its own: HIP streams, work buffers; the reference data shared) takes the next item when it is free -- so a lane on a lower-priority
     # stream, which only gets what the lane above it leaves idle, simply takes fewer of them.
@@ -274,7 +275,14 @@ def main():
                 # path has no exchange step -- reads are independent, and so are their records.  (lra_amd.parallel.gather_records / merge_by_ordinal
                 # bring the record buffers of all ranks to rank 0 when one process has to write one stream: tests/test_parallel.py.)
                 tA = time.perf_counter()
-                hb = held.cpu().numpy()
+                # into a page-locked buffer that is kept (one per lane: a lane's tails run one after the other).  A copy into fresh pageable memory makes the runtime pin and
+                # unpin 0.7 GB of host pages per step, and the unpin stalls every queue of the process for ~50 ms (a kernel trace shows the stall on whatever kernel runs then)
+                nb_ = held.numel()
+                if lane.get("pin") is None or lane["pin"].numel() < nb_:
+                    lane["pin"] = torch.empty(int(nb_ * 1.25) + 4096, dtype=torch.uint8, pin_memory=True)
+                lane["pin"][:nb_].copy_(held, non_blocking=True)
+                copy_stream.synchronize()
+                hb = lane["pin"][:nb_].numpy()
                 tB = time.perf_counter()
                 snap = C.c_void_p()
                 rc = ctx.lib.lra_map_unpack_host(C.c_void_p(hb.ctypes.data), C.c_uint64(hb.nbytes), C.byref(snap))

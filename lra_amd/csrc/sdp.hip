@@ -282,8 +282,8 @@ __device__ __forceinline__ int blk_incl_scan(int v, int lane, int wave, int* s_w
 // LDSV (one wave per read, at most 512 points): the per-element arrays -- 28 bytes per point with 16-bit indices and 32-bit diagonals -- live in the wave's LDS.
 // From the scratch arena every level streams them through HBM again (2.6 KB per point and build: 250 GB per step, a third of the step's traffic).
 // MODE 2: the same narrow arrays in the arena (reads of 513 .. 16383 points: half the bytes per level, no LDS to run out of).  MODE 0: 32-bit indices, 64-bit diagonals.
-template <bool EMIT, int NW, int MODE = 0>
-__global__ void __launch_bounds__(64 * NW, NW == 1 ? 8 : 1) sdp_build(BuildArgs a) {
+template <bool EMIT, int NW, int MODE = 0, int OCC = 8>
+__global__ void __launch_bounds__(64 * NW, NW == 1 ? OCC : 1) sdp_build(BuildArgs a) {
   constexpr int NT = 64 * NW;
   constexpr bool LDSV = MODE == 1, NARROW = MODE != 0;
   using IT = typename std::conditional<NARROW, uint16_t, uint32_t>::type; // element -> node / position / line / prefix count
@@ -1840,7 +1840,14 @@ static void launch_small_builds(lra_ctx* ctx, const BuildArgs& ba, const uint32_
     int mid = from;
     while (mid < cut[0] && pts(mid) >= 16384) mid++;
     if (mid > from) { BuildArgs bb = ba; bb.order = d_order + from; hipLaunchKernelGGL((sdp_build<EMIT, 1, 0>), dim3(mid - from), dim3(64), 0, st, bb); }
-    if (cut[0] > mid) { BuildArgs bb = ba; bb.order = d_order + mid; hipLaunchKernelGGL((sdp_build<EMIT, 1, 2>), dim3(cut[0] - mid), dim3(64), 0, st, bb); }
+    if (cut[0] > mid) {
+      BuildArgs bb = ba; bb.order = d_order + mid;
+      static const int occ = getenv("LRA_SDP_BUILD_OCC") ? atoi(getenv("LRA_SDP_BUILD_OCC")) : 8;   // waves per SIMD the register budget is set for (tuning)
+      if (occ == 4) hipLaunchKernelGGL((sdp_build<EMIT, 1, 2, 4>), dim3(cut[0] - mid), dim3(64), 0, st, bb);
+      else if (occ == 5) hipLaunchKernelGGL((sdp_build<EMIT, 1, 2, 5>), dim3(cut[0] - mid), dim3(64), 0, st, bb);
+      else if (occ == 6) hipLaunchKernelGGL((sdp_build<EMIT, 1, 2, 6>), dim3(cut[0] - mid), dim3(64), 0, st, bb);
+      else hipLaunchKernelGGL((sdp_build<EMIT, 1, 2>), dim3(cut[0] - mid), dim3(64), 0, st, bb);
+    }
   }
   for (int c = 0; c < 3; c++) {
     const int n = cut[c + 1] - cut[c];

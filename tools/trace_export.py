@@ -8,7 +8,7 @@ import sys
 
 db = sqlite3.connect(sys.argv[1])
 cols = [r[1] for r in db.execute("pragma table_info(kernels)")]
-want = [c for c in ("start", "end", "stream_id", "queue_id", "grid_x", "grid_size_x", "workgroup_x", "workgroup_size_x", "lds_size", "name") if c in cols]
+want = [c for c in ("start", "end", "stream_id", "queue_id", "grid_x", "grid_size_x", "workgroup_x", "workgroup_size_x", "lds_size", "scratch_size", "name") if c in cols]
 rows = db.execute("select %s from kernels order by start" % ", ".join(want)).fetchall()
 t_end = max(r[1] for r in rows)
 W0 = t_end - int(float(sys.argv[2]) * 1e9)
