@@ -96,7 +96,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-records", action="store_true", help="leave the host tail (SAM text) out of the step")
     ap.add_argument("--satellite-frac", type=float, default=0.03, help="fraction of every chromosome in its satellite array")
-    ap.add_argument("--defer-seed", type=int, default=int(os.environ.get("LRA_BENCH_DEFER_SEED", 6000)),
+    ap.add_argument("--defer-seed", type=int, default=int(os.environ.get("LRA_BENCH_DEFER_SEED", 0)),
                     help="lra_map_opts.defer_seed_matches: reads with more tier-1 matches are handed back by the batch they arrive in, pooled, and mapped as batches of "
                          "their own inside the timed region (cost-ordered batching: every read is mapped exactly once per step either way); 0 = off")
     ap.add_argument("--heavy-lane", type=int, default=int(os.environ.get("LRA_BENCH_HEAVY_LANE", 1)),

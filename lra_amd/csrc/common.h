@@ -31,6 +31,7 @@ struct lra_ctx {
   lra_map_state* map = nullptr;                       // mapread.hip: chromosome table, the genome's local index
   void* aux = nullptr; size_t aux_bytes = 0;          // AffineOneGapAlign blocks of refine fallbacks
   void* out_buf = nullptr; size_t out_bytes = 0;
+  void* pin_buf = nullptr; size_t pin_bytes = 0;      // page-locked host staging of the large device-to-host copies (lra_pinned)
   uint64_t* scan_tmp = nullptr;
   // lra_side_fork / lra_side_join: further streams for kernels that would only extend a stage's tail on the context's own stream
   static constexpr int N_SIDE = 4;
@@ -62,6 +63,9 @@ int lra_set_err(lra_ctx* ctx, int code, const char* fmt, ...);
 // returns a device buffer of >= bytes (slot 0..3), growing it if needed (synchronises the
 // stream before freeing the old one)
 void* lra_scratch(lra_ctx* ctx, int slot, size_t bytes);
+// page-locked host buffer of at least `bytes`, kept by the context: the landing place of the large device-to-host copies.  A copy into pageable memory makes
+// the runtime pin and unpin the destination's pages, and the unpin stalls every queue of the process for tens of milliseconds (0.7 GB of records per batch: ~50 ms)
+void* lra_pinned(lra_ctx* ctx, size_t bytes);
 // growable buffer `idx` of at least `bytes` (contents NOT preserved on growth)
 void* lra_ensure(lra_ctx* ctx, int idx, size_t bytes);
 

@@ -31,6 +31,16 @@ void* lra_scratch(lra_ctx* ctx, int slot, size_t bytes) {
   return p;
 }
 
+void* lra_pinned(lra_ctx* ctx, size_t bytes) {
+  if (ctx->pin_buf && ctx->pin_bytes >= bytes) return ctx->pin_buf;
+  if (ctx->pin_buf) { (void)hipStreamSynchronize(ctx->stream); (void)hipHostFree(ctx->pin_buf); ctx->pin_buf = nullptr; ctx->pin_bytes = 0; }
+  const size_t want = bytes + bytes / 4 + 4096;
+  void* p = nullptr;
+  if (hipHostMalloc(&p, want, hipHostMallocDefault) != hipSuccess) { lra_set_err(ctx, LRA_ERR_NOMEM, "hipHostMalloc(%zu) failed", want); return nullptr; }
+  ctx->pin_buf = p; ctx->pin_bytes = want;
+  return p;
+}
+
 void* lra_ensure(lra_ctx* ctx, int idx, size_t bytes) {
   if (ctx->gbuf[idx] && ctx->gbytes[idx] >= bytes) return ctx->gbuf[idx];
   if (ctx->gbuf[idx]) { (void)hipStreamSynchronize(ctx->stream); (void)hipFree(ctx->gbuf[idx]); ctx->gbuf[idx] = nullptr; ctx->gbytes[idx] = 0; }
@@ -76,6 +86,7 @@ extern "C" void lra_ctx_destroy(lra_ctx* ctx) {
   lra_map_free(ctx);
   if (ctx->aux) (void)hipFree(ctx->aux);
   if (ctx->out_buf) (void)hipFree(ctx->out_buf);
+  if (ctx->pin_buf) (void)hipHostFree(ctx->pin_buf);
   if (ctx->scan_tmp) (void)hipFree(ctx->scan_tmp);
   for (int i = 0; i < 192; i++) if (ctx->gbuf[i]) (void)hipFree(ctx->gbuf[i]);
   for (auto& r : ctx->recs) { (void)hipEventDestroy(r.a); (void)hipEventDestroy(r.b); }

@@ -1015,10 +1015,12 @@ extern "C" int lra_map_snapshot(lra_ctx* ctx, const lra_map_result* res, int wit
   const void* d_buf = nullptr; uint64_t bytes = 0;
   int rc = lra_map_pack(ctx, res, with_blocks, &d_buf, &bytes);
   if (rc) return rc;
-  std::vector<char> hb(bytes);
-  LRA_HIP_CHECK(ctx, hipMemcpy(hb.data(), d_buf, bytes, hipMemcpyDeviceToHost));
+  char* hb = (char*)lra_pinned(ctx, bytes);                                // (page-locked and kept: see lra_pinned)
+  if (!hb) return LRA_ERR_NOMEM;
+  LRA_HIP_CHECK(ctx, hipMemcpyAsync(hb, d_buf, bytes, hipMemcpyDeviceToHost, ctx->stream));
+  LRA_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
   lra_map_host* h = nullptr;
-  if ((rc = lra_map_unpack_host(hb.data(), bytes, &h))) return rc;
+  if ((rc = lra_map_unpack_host(hb, bytes, &h))) return rc;
   if (with_blocks) {
     // print format 'a': the pairwise text needs the chromosome bases under every alignment (and the read on its strand)
     lra_map_state* m = ctx->map;

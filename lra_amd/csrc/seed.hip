@@ -192,12 +192,17 @@ __global__ void __launch_bounds__(64) sketch_wave_kernel(int n_reads, const unsi
     const uint32_t P0 = min((uint32_t)(2 * w), nk);
     bool hasN = false;
     uint64_t carry_m = 0; uint32_t carry_act = 0;
+    // the bases come in 64-byte pieces, one per tile, asked for two tiles ahead: piece j is tile j's own bases and (its first k - 1) the tail of tile j - 1's k-mers;
+    // a tile's step is otherwise a chain that begins with a load from HBM and nothing to do until it is back
+    unsigned char pc0 = lane < (int)seqLen ? seq[lane] : (unsigned char)'A', pc1 = 64u + lane < seqLen ? seq[64 + lane] : (unsigned char)'A';
     for (uint32_t B = 0; B < nk; B += 64) {
       // ---- keys of positions B..B+63
       const uint32_t p = B + lane;
+      const unsigned char pn = p + 128 < seqLen ? seq[p + 128] : (unsigned char)'A';
       int c0 = 0, c1 = 0;
-      if (p < seqLen) { int c = code_n(seq[p]); hasN |= c > 3; c0 = c & 3; }
-      if (lane < k - 1 && p + 64 < seqLen) { int c = code_n(seq[p + 64]); hasN |= c > 3; c1 = c > 3 ? 0 : c; }
+      if (p < seqLen) { int c = code_n(pc0); hasN |= c > 3; c0 = c & 3; }
+      if (lane < k - 1 && p + 64 < seqLen) { int c = code_n(pc1); hasN |= c > 3; c1 = c > 3 ? 0 : c; }
+      pc0 = pc1; pc1 = pn;
       const unsigned long long b0 = __ballot(c0 & 1), b1 = __ballot(c0 & 2), t0 = __ballot(c1 & 1), t1 = __ballot(c1 & 2);
       uint64_t x0 = b0 >> lane, x1 = b1 >> lane;
       if (lane) { x0 |= t0 << (64 - lane); x1 |= t1 << (64 - lane); }

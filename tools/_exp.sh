@@ -1,5 +1,5 @@
 export TMPDIR=/tmp
-python bench.py --steps 5 --warmup 2 --defer-seed 0 --no-cpu-baseline 2>/dev/null | grep -o '"ms_per_step": [0-9.]*'
-LRA_RECORD_THREADS=96 python bench.py --steps 5 --warmup 2 --defer-seed 0 --no-cpu-baseline 2>/dev/null | grep -o '"ms_per_step": [0-9.]*'
-LRA_RECORD_THREADS=32 python bench.py --steps 5 --warmup 2 --defer-seed 0 --no-cpu-baseline 2>/dev/null | grep -o '"ms_per_step": [0-9.]*'
-LRA_BENCH_DBG=1 python bench.py --steps 4 --warmup 2 --defer-seed 0 --no-cpu-baseline 2>&1 | grep "bench\]" | tail -6
+python -m pytest tests/test_seed.py tests/test_mapread.py -m gpu -x -q 2>&1 | tail -2
+python bench.py --steps 8 --warmup 3 --no-cpu-baseline --defer-seed 0 2>/dev/null | grep -o '"ms_per_step": [0-9.]*\|"sketch_count": [0-9.]*\|"sketch_emit": [0-9.]*'
+python bench.py --steps 8 --warmup 3 --no-cpu-baseline --defer-seed 0 --lanes 2 2>/dev/null | grep -o '"ms_per_step": [0-9.]*\|"lane_items": [^]]*]'
+python bench.py --steps 8 --warmup 3 --no-cpu-baseline --defer-seed 0 --lanes 2 --lane-priority 0 2>/dev/null | grep -o '"ms_per_step": [0-9.]*\|"lane_items": [^]]*]'
