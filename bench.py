@@ -26,6 +26,24 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 
+def host_cpus():
+    """(CPUs this process may use at once, hardware threads): a container's CPU bandwidth quota (cgroup cpu.max / cfs_quota_us) caps the first -- threads beyond it
+    only use the period's budget up sooner, after which the kernel throttles the whole process (the thread that drives the device included)."""
+    hw = os.cpu_count() or 1
+    try:
+        q, p_ = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if q != "max":
+            return max(1, min(hw, int(q) // int(p_))), hw
+    except Exception:
+        try:
+            q = int(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read()); p_ = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            if q > 0 and p_ > 0:
+                return max(1, min(hw, q // p_)), hw
+        except Exception:
+            pass
+    return hw, hw
+
+
 def cpu_baseline(mapper, reads_h, off_h, args, last_res=None):
     """The oracle (CPU restatement) on the host's cores, on a bounded sample of the same batch: MapRead_lowacc read by read
     (oracle_map_reads_lowacc_mt, oracle/pipeline.cpp: the same stages in the same order as the GPU step; tests/test_mapread.py compares its
@@ -42,9 +60,9 @@ def cpu_baseline(mapper, reads_h, off_h, args, last_res=None):
     g_index = mapper.fetch_local_index()
     fetch_s = time.time() - t0
     opts = dict(globalK=args.k, globalW=args.w, globalMaxFreq=args.max_freq, refineBand=args.refine_band)
-    n_threads = os.cpu_count() or 1
-    # a bounded sample: 8 reads per host thread (at most 4096), about 10-30 s of wall time
-    S = int(min(len(off_h) - 1, 4096, 8 * n_threads))
+    n_threads, hw_threads = host_cpus()                                       # the CPUs the box gives this process (its cgroup quota), not the threads it lists
+    # a bounded sample: about 10-30 s of wall time
+    S = int(min(len(off_h) - 1, 4096, max(512, 8 * n_threads)))
     if os.environ.get("LRA_BENCH_CPU_SAMPLE"):                               # (a wider parity sweep: the whole batch takes ~2 minutes on 256 threads)
         S = int(min(len(off_h) - 1, int(os.environ["LRA_BENCH_CPU_SAMPLE"])))
     res = OP.map_reads_lowacc_mt(reads_h, off_h, 0, S, g, key, pos, g_index, opts, mapper.chrom_pos, n_threads=n_threads)
@@ -75,8 +93,8 @@ def cpu_baseline(mapper, reads_h, off_h, args, last_res=None):
         parity = bool(int(total) == int(res["checksum"]))
     return {"value": res["bases"] / res["seconds"] / 1e9, "unit": "Gbp/s", "cores": n_threads, "kind": "port", "sample_equals_gpu": parity,
             "sample": "first %d reads (%d bp, %d alignments) of the same batch through the oracle's MapRead_lowacc (a1-a5, a7-a11, a13 incl. a12, a14, a16: the stages of "
-                      "the GPU step, oracle/pipeline.cpp) on %d host threads in %.1f s (reference data fetched from the device in %.1f s, not timed)"
-                      % (res["n_reads"], res["bases"], res["n_alignments"], n_threads, res["seconds"], fetch_s)}
+                      "the GPU step, oracle/pipeline.cpp) on %d host threads = the CPUs this box gives the process (cgroup CPU quota; %d hardware threads listed) in %.1f s (reference data fetched from the device in %.1f s, not timed)"
+                      % (res["n_reads"], res["bases"], res["n_alignments"], n_threads, hw_threads, res["seconds"], fetch_s)}
 
 
 def main():
@@ -153,7 +171,10 @@ def main():
     del genome
     rb = reads_h.tobytes()
     # the record text on half of the host's hardware threads (per rank): the thread that drives the device (sizing round trips between the stages) needs a core of its own
-    n_threads_rec = max(8, (os.cpu_count() or 16) // (2 * world))
+    # the record text on the host threads the library allows itself (lra_host_thread_budget: the hardware threads, capped by the container's CPU quota less two -- a
+    # burst of more runnable threads than the quota gets the whole process throttled for the rest of the scheduler period, the thread that drives the device included)
+    from lra_amd._lib import load_library
+    n_threads_rec = max(2, load_library().lra_host_thread_budget() // world)
     # A step = every sub-batch once.  With one lane that is one call on the whole batch.  With several, the sub-batches of all timed steps form one work list and
     # every lane (a context of its own: HIP streams, work buffers; the reference data shared) takes the next item when it is free -- so a lane on a lower-priority
     # stream, which only gets what the lane above it leaves idle, simply takes fewer of them.
@@ -218,13 +239,18 @@ def main():
             torch.cuda.set_device(dev_index)                               # the current device is per host thread
             lc = lane["ctx"]
             def run():
+                tA_ = time.perf_counter()
                 res = lane["mapper"].align(sub["rbatch"])
                 lane["last_res"] = res
                 if args.no_records:
                     return
                 d_buf, nb = C.c_void_p(), C.c_uint64(0)
+                tP = time.perf_counter()
                 lc.check(lc.lib.lra_map_pack(lc.h, C.byref(res), 0, C.byref(d_buf), C.byref(nb)))
                 lane["packed"] = lc.to_tensor(d_buf.value, nb.value, torch.uint8)
+                if os.environ.get("LRA_BENCH_DBG"):
+                    torch.cuda.synchronize()
+                    sys.stderr.write("[bench] align %.0f ms, pack + copy %.0f ms\n" % ((tP - tA_) * 1e3, (time.perf_counter() - tP) * 1e3))
             if lane["stream"] is not None:
                 with torch.cuda.stream(lane["stream"]):
                     run()
@@ -524,7 +550,7 @@ def main():
                     l["ctx"].close()
                 out["cpu_baseline"] = cpu_baseline(mapper, reads_h, off_h, args, lanes[0].get("last_res"))
             except Exception as e:                                          # the bench line must survive a baseline problem; say what happened
-                out["cpu_baseline"] = {"value": None, "unit": "Gbp/s", "cores": os.cpu_count(), "kind": "port", "sample": "failed: %r" % (e,)}
+                out["cpu_baseline"] = {"value": None, "unit": "Gbp/s", "cores": host_cpus()[0], "kind": "port", "sample": "failed: %r" % (e,)}
         out["setup_s"] = {"genome": round(gen_s, 1), "index": round(index_s, 1), "reads": round(sim_s, 1)}
         free_b, total_b = torch.cuda.mem_get_info(dev_index)
         out["hbm_used_gb"] = round((total_b - free_b) / 1e9, 1)               # everything resident at the end of the run: reference, reads, work buffers

@@ -55,6 +55,7 @@ SYMBOLS = {
     "lra_reads_next_batch": (C.c_int, [_vp, C.c_uint64, _vp]),
     "lra_reads_close": (None, [_vp]),
     "lra_reads_last_error": (C.c_char_p, [_vp]),
+    "lra_host_thread_budget": (C.c_int, []),
     "lra_map_reads_host": (C.c_int, [_vp, C.c_int, _vp, _vp, _vp, _vp]),
     "lra_global_chain_batch": (C.c_int, [_vp, C.c_uint64, _vp, C.c_uint64, _vp, _vp, _vp, _vp, _vp, _vp]),
     "lra_split_chains_highacc_batch": (C.c_int, [_vp, C.c_uint64, _vp, C.c_uint64, _vp, _vp, _vp, _vp, _vp, C.c_int, _vp]),

@@ -1,5 +1,7 @@
 // lra_amd/csrc/ctx.hip -- context, error reporting, scratch arenas.
 #include "common.h"
+#include <thread>
+#include <algorithm>
 #include <stdarg.h>
 
 int lra_set_err(lra_ctx* ctx, int code, const char* fmt, ...) {
@@ -30,6 +32,26 @@ void* lra_scratch(lra_ctx* ctx, int slot, size_t bytes) {
   ctx->scratch_bytes[slot] = want;
   return p;
 }
+
+int lra_host_threads() {
+  static const int cached = []() {
+    long hw = (long)std::thread::hardware_concurrency();
+    if (hw < 1) hw = 1;
+    long quota = -1, period = 100000;
+    if (FILE* f = fopen("/sys/fs/cgroup/cpu.max", "r")) {                 // cgroup v2: "<quota|max> <period>"
+      char q[64] = {0};
+      if (fscanf(f, "%63s %ld", q, &period) == 2 && strcmp(q, "max") != 0) quota = atol(q);
+      fclose(f);
+    } else {                                                               // cgroup v1
+      if (FILE* g = fopen("/sys/fs/cgroup/cpu/cpu.cfs_quota_us", "r")) { if (fscanf(g, "%ld", &quota) != 1) quota = -1; fclose(g); }
+      if (FILE* g = fopen("/sys/fs/cgroup/cpu/cpu.cfs_period_us", "r")) { if (fscanf(g, "%ld", &period) != 1) period = 100000; fclose(g); }
+    }
+    if (quota > 0 && period > 0) hw = std::min(hw, std::max(1L, quota / period - 2));
+    return (int)hw;
+  }();
+  return cached;
+}
+extern "C" int lra_host_thread_budget(void) { return lra_host_threads(); }
 
 void* lra_pinned(lra_ctx* ctx, size_t bytes) {
   if (ctx->pin_buf && ctx->pin_bytes >= bytes) return ctx->pin_buf;

@@ -999,7 +999,7 @@ extern "C" int lra_map_unpack_host(const void* h_buf, uint64_t bytes, lra_map_ho
   if (nRuns) {                                                           // the one large array: uninitialised (pooled) memory, copied by a few threads
     if (!h->runs.alloc(nRuns)) { delete h; return LRA_ERR_NOMEM; }
     const char* src = b + L.off[16]; char* dst = (char*)h->runs.data(); const size_t tot = nRuns * 4;
-    const int T = tot > (64u << 20) ? 16 : 1;
+    const int T = tot > (64u << 20) ? std::min(16, lra_host_threads()) : 1;
     auto cp = [&](int t) { const size_t lo = tot * t / T, hi = tot * (t + 1) / T; memcpy(dst + lo, src + lo, hi - lo); };
     if (T == 1) cp(0);
     else { std::vector<std::thread> th; for (int t = 0; t < T; t++) th.emplace_back(cp, t); for (auto& x : th) x.join(); }
@@ -1055,8 +1055,7 @@ extern "C" int lra_map_records_host(lra_map_host* h, const lra_map_opts* o, cons
   if (pairwise && h->segText.size() != h->nA) return LRA_ERR_INVALID;
   // every read is independent: host threads take contiguous ranges of reads, each builds its own text; ranges are joined in read order
   const int n_reads = h->n_reads;
-  unsigned hw = std::thread::hardware_concurrency();
-  int T = n_threads > 0 ? n_threads : (int)(hw ? hw : 1u);                 // n_threads = 0: every hardware thread (a 30 kb read's record is ~43 KB of text: 1.4 GB per 32768 reads)
+  int T = n_threads > 0 ? n_threads : lra_host_threads();                  // n_threads = 0: what the host allows (a 30 kb read's record is ~43 KB of text: 1.4 GB per 32768 reads)
   T = std::max(1, std::min(T, n_reads / 32 + 1));
   if (const char* e = getenv("LRA_RECORD_THREADS")) T = std::max(1, atoi(e));
   std::vector<std::string> part(T);

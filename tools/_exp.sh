@@ -1,5 +1,7 @@
 export TMPDIR=/tmp
-python -m pytest tests/test_seed.py tests/test_mapread.py -m gpu -x -q 2>&1 | tail -2
-python bench.py --steps 8 --warmup 3 --no-cpu-baseline --defer-seed 0 2>/dev/null | grep -o '"ms_per_step": [0-9.]*\|"sketch_count": [0-9.]*\|"sketch_emit": [0-9.]*'
-python bench.py --steps 8 --warmup 3 --no-cpu-baseline --defer-seed 0 --lanes 2 2>/dev/null | grep -o '"ms_per_step": [0-9.]*\|"lane_items": [^]]*]'
-python bench.py --steps 8 --warmup 3 --no-cpu-baseline --defer-seed 0 --lanes 2 --lane-priority 0 2>/dev/null | grep -o '"ms_per_step": [0-9.]*\|"lane_items": [^]]*]'
+run() { echo "$1: $(env $2 LRA_BENCH_DBG=1 python bench.py --steps 7 --warmup 2 --no-cpu-baseline $3 2>&1 | grep -o 'align [0-9]* ms' | tail -6 | tr '\n' ' ')"; }
+run norec-ish "LRA_BENCH_TAIL=copy" ""
+run base14 "X=1" ""
+run leak14 "LRA_RECORD_LEAK=1" ""
+run base128 "LRA_RECORD_THREADS=128" ""
+run leak128 "LRA_RECORD_THREADS=128 LRA_RECORD_LEAK=1" ""
