@@ -1017,7 +1017,7 @@ typedef struct lra_read_batch {
 int lra_reads_open(const char* const* files, int n_files, lra_reads** out);
 int lra_reads_next_batch(lra_reads* r, uint64_t max_bases, lra_read_batch* batch);
 const char* lra_reads_last_error(const lra_reads* r);
-int lra_host_thread_budget(void);   /* host threads lra_map_records* use when asked for 0: hardware threads, capped by the container's CPU quota (cgroup cpu.max) less two */
+int lra_host_thread_budget(void);   /* host threads lra_map_records* use when asked for 0: hardware threads, capped by the container's CPU quota (cgroup cpu.max) less four */
 void lra_reads_close(lra_reads* r);
 int lra_map_reads_host(lra_ctx* ctx, int n_reads, const char* h_seq, const uint64_t* h_off, const lra_map_opts* opts, lra_map_result* out);
 int lra_map_records(lra_ctx* ctx, const lra_map_result* res, const lra_map_opts* opts, const char* const* names, const char* const* reads,

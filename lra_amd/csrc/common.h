@@ -61,7 +61,7 @@ void lra_map_free(lra_ctx* ctx);
 
 int lra_set_err(lra_ctx* ctx, int code, const char* fmt, ...);
 // How many host threads a burst of work may use: the hardware threads, or -- inside a container with a CPU bandwidth quota (cgroup cpu.max / cfs_quota_us) -- the
-// quota's whole CPUs less two.  More runnable threads than the quota use the period's budget up in a few milliseconds and the kernel then throttles EVERY thread of the
+// quota's whole CPUs less four (the driving thread, the runtime's helper threads and a tail thread need theirs).  More runnable threads than the quota use the period's budget up in a few milliseconds and the kernel then throttles EVERY thread of the
 // process until the next period, the one that drives the device included (measured: 128 record threads on a 16-CPU quota = a 30-55 ms hole in every step)
 int lra_host_threads();
 // returns a device buffer of >= bytes (slot 0..3), growing it if needed (synchronises the

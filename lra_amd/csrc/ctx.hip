@@ -46,7 +46,7 @@ int lra_host_threads() {
       if (FILE* g = fopen("/sys/fs/cgroup/cpu/cpu.cfs_quota_us", "r")) { if (fscanf(g, "%ld", &quota) != 1) quota = -1; fclose(g); }
       if (FILE* g = fopen("/sys/fs/cgroup/cpu/cpu.cfs_period_us", "r")) { if (fscanf(g, "%ld", &period) != 1) period = 100000; fclose(g); }
     }
-    if (quota > 0 && period > 0) hw = std::min(hw, std::max(1L, quota / period - 2));
+    if (quota > 0 && period > 0) hw = std::min(hw, std::max(1L, quota / period - 4));
     return (int)hw;
   }();
   return cached;
