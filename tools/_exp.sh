@@ -1,7 +1,5 @@
 export TMPDIR=/tmp
-python bench.py --steps 20 --warmup 5 2>/dev/null | grep '^{"metric"' > gpurun_out/r04ai_bench.json
-python - <<'P'
-import json
-j=json.loads(open('gpurun_out/r04ai_bench.json').read())
-print(j['value'], j['ms_per_step'], j['cpu_baseline']['value'], j['cpu_baseline']['cores'], j['cpu_baseline'].get('sample_equals_gpu'), j['hbm_used_gb'])
-P
+bash tools/profile_bench.sh r04m --steps 10 --warmup 3 > /dev/null 2>&1
+bash tools/profile_pmc.sh r04m --steps 3 --warmup 1 > /dev/null 2>&1
+LRA_BENCH_CPU_SAMPLE=32768 python bench.py --steps 3 --warmup 1 2>/dev/null | grep '^{"metric"' > gpurun_out/r04m_full_batch_parity.json
+head -c 400 gpurun_out/r04m_bench.json; echo; head -12 gpurun_out/r04m_kernel_stats.txt | cut -c1-170; grep -o '"cpu_baseline": {[^}]*}' gpurun_out/r04m_full_batch_parity.json | cut -c1-300
