@@ -1,5 +1,5 @@
 export TMPDIR=/tmp
-bash tools/profile_bench.sh r04m --steps 10 --warmup 3 > /dev/null 2>&1
-bash tools/profile_pmc.sh r04m --steps 3 --warmup 1 > /dev/null 2>&1
-LRA_BENCH_CPU_SAMPLE=32768 python bench.py --steps 3 --warmup 1 2>/dev/null | grep '^{"metric"' > gpurun_out/r04m_full_batch_parity.json
-head -c 400 gpurun_out/r04m_bench.json; echo; head -12 gpurun_out/r04m_kernel_stats.txt | cut -c1-170; grep -o '"cpu_baseline": {[^}]*}' gpurun_out/r04m_full_batch_parity.json | cut -c1-300
+for p in ccs clr contig; do python tools/bench_presets.py --preset $p --steps 5 2>/dev/null | grep '^{"metric"' > gpurun_out/r04m_${p}_bench.json; echo $p $(grep -o '"value": [0-9.]*\|"ms_per_step": [0-9.]*\|"reads_flagged": [0-9]*\|"reads_with_an_alignment": [0-9]*' gpurun_out/r04m_${p}_bench.json | tr '\n' ' '); done
+echo lowprio $(python bench.py --steps 10 --warmup 3 --no-cpu-baseline 2>/dev/null | grep -o '"ms_per_step": [0-9.]*')
+sed -i 's|, priority=prio_lo)   # (the copy|)   # (the copy|' bench.py
+echo normal $(python bench.py --steps 10 --warmup 3 --no-cpu-baseline 2>/dev/null | grep -o '"ms_per_step": [0-9.]*')
