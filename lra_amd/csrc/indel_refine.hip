@@ -323,6 +323,8 @@ __global__ void __launch_bounds__(64) ir_band_chunk(BandArgs B) {
   long bq, bt, bl;
   sb.get(sb.b0 + from * CB, bq, bt, bl);
   bool live = (c == 0);
+  int eMin = -1;                                                        // lower bound of qE over the k rows behind tOff (-1: not known, the literal loop runs)
+  long sHi = -1;                                                        // the last row whose qS has been set
   for (long b = sb.b0 + from * CB; b <= bLast && !(status & 1); b++) {  // :232-315
     long nq2, nt2, nl2;
     const BlockStep st = block_step(sb, b, bq, bt, bl, nq2, nt2, nl2);
@@ -332,16 +334,29 @@ __global__ void __launch_bounds__(64) ir_band_chunk(BandArgs B) {
     }
     for (long bi = 0; bi < st.blockLength; bi++) {                      // :252-283
       if (tOff >= tLen) { status |= 1; break; }
+      int newE;
       {
         int lo = (int)max(q - k, qStart);
         int cs = RG(ringS, tOff), ce = RG(ringE, tOff);
         RG(ringS, tOff) = (cs == -1) ? lo : min(cs, lo);
-        if (ce == -1 || ce < q + k) RG(ringE, tOff) = (int)min(qEnd - 1, q + k);
+        newE = ce;
+        if (ce == -1 || ce < q + k) { newE = (int)min(qEnd - 1, q + k); RG(ringE, tOff) = newE; }
       }
-      for (int ki = 0; ki < k; ki++) {
-        if (tOff - ki >= 0) { if (RG(ringE, tOff - ki) < q) RG(ringE, tOff - ki) = (int)q; }
-        if (tOff + ki < tLen) { int v = RG(ringS, tOff + ki); if (v == -1 || v > q) RG(ringS, tOff + ki) = (int)q; }
+      // The reference's loop over ki = 0 .. k - 1 (:262-281) raises qE of the rows tOff - ki to q and sets qS of the rows tOff + ki to q where it is unset or larger.
+      // q never decreases (it is a running counter), so: (E) nothing changes while q <= the smallest qE of the k rows behind -- eMin is a lower bound of that
+      // minimum (a row that enters the window can only lower it, a row that leaves it is ignored), and the literal loop runs, and makes it exact, only when q gets
+      // past it: once per ~k bases inside a block instead of k reads per base; (S) a row whose qS has been set holds a value <= q for good (every value written is
+      // the q or q - k of its time), so only the rows beyond sHi, the last row set, are still unset (-1), and they take q without being read.
+      if (newE < eMin) eMin = newE;
+      if (q > eMin) {
+        int m = 0x7fffffff;
+        for (int ki = 0; ki < k; ki++)
+          if (tOff - ki >= 0) { int e = RG(ringE, tOff - ki); if (e < q) { e = (int)q; RG(ringE, tOff - ki) = e; } m = min(m, e); }
+        eMin = m;
       }
+      if (sHi < tOff) sHi = tOff;
+      for (long r = sHi + 1; r <= tOff + k - 1 && r < tLen; r++) RG(ringS, r) = (int)q;
+      if (sHi < tOff + k - 1) sHi = tOff + k - 1;
       tOff++; q++;
       flush(tOff - k);
     }
@@ -355,7 +370,10 @@ __global__ void __launch_bounds__(64) ir_band_chunk(BandArgs B) {
     if (st.btGap > st.bqGap) {                                          // :306-314
       for (int ti = 0; ti < st.btGap; ti++) {
         if (tOff >= tLen) { status |= 1; break; }
-        RG(ringS, tOff) = (int)max(q - k, qStart); RG(ringE, tOff) = (int)min(qEnd - 1, q + k);
+        const int e = (int)min(qEnd - 1, q + k);
+        RG(ringS, tOff) = (int)max(q - k, qStart); RG(ringE, tOff) = e;
+        if (e < eMin) eMin = e;
+        if (sHi < tOff) sHi = tOff;
         tOff++;
         flush(tOff - k);
       }

@@ -1,7 +1,4 @@
 export TMPDIR=/tmp
-python -m pytest tests/test_sdp.py -m gpu -x -q 2>&1 | tail -2
-for v in "X=1" "LRA_SDP_BUILD16_TWO=0"; do
-echo "$v: $(env $v LRA_STAGE_DBG=1 python bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-records 2>&1 | grep 'stage\] sdp#2\|ms_per_step' | tail -2 | sed 's/.*sdp#2 *//; s/.*"ms_per_step": \([0-9.]*\).*/step \1/' | tr '\n' ' ')"
-done
-mkdir -p /tmp/q1; rocprofv3 --kernel-trace --stats -d /tmp/q1 -o p -- python bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-records > /tmp/q1/log.txt 2>&1
-DB=$(ls /tmp/q1/*.db | head -1); python tools/trace_export.py $DB 1.4 2000 | grep -E "sdp_build|sdp_process" | awk -F'\t' '{printf "%9.1f %7.1f s%s g%s %s\n",$1,$2,$3,$5,substr($NF,1,45)}' | tail -8
+python -m pytest tests/test_refine.py tests/test_mapread.py tests/test_highacc_path.py tests/test_highacc.py -m gpu -x -q 2>&1 | tail -3
+python bench.py --steps 5 --warmup 2 2>/dev/null | grep -o '"ms_per_step": [0-9.]*\|"ir_band": [0-9.]*\|"sample_equals_gpu": [a-z]*'
+python tools/bench_presets.py --preset clr --steps 4 2>/dev/null | grep -o '"value": [0-9.]*\|"ms_per_step": [0-9.]*'
