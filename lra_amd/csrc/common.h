@@ -40,6 +40,7 @@ struct lra_ctx {
   size_t gbytes[192] = {};
   // kernel timing
   bool sdp_inner = false;                    // local_refine.hip: its small inner sparse DP is timed under "sdp_inner_*"
+  bool sort_short = false;                   // the exact sort: a launch of its own for the short lists (set by the sparse DP around its sorts: hundreds of tuples per list)
   const char* sort_tag = "sort"; const char* sort_fb_tag = "sort_fallback";   // timing names of the exact-sort kernels (sdp.hip retags them)
   bool timing = false;
   std::vector<lra_time_rec> recs;

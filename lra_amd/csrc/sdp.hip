@@ -2006,7 +2006,7 @@ int sdp_run(lra_ctx* ctx, int n_reads, const uint64_t* d_cluster_off, const uint
     if (FILE* f = fopen(pth.c_str(), "wb")) { fwrite(h_pt.data(), 8, n1, f); fclose(f); }
     callNo++;
   }
-  struct Retag { lra_ctx* c; Retag(lra_ctx* x) : c(x) { c->sort_tag = c->sdp_inner ? "sdp_inner_sort" : "sdp_sort"; c->sort_fb_tag = c->sdp_inner ? "sdp_inner_sort_fallback" : "sdp_sort_fallback"; } ~Retag() { c->sort_tag = "sort"; c->sort_fb_tag = "sort_fallback"; } } retag(ctx);
+  struct Retag { lra_ctx* c; Retag(lra_ctx* x) : c(x) { c->sort_tag = c->sdp_inner ? "sdp_inner_sort" : "sdp_sort"; c->sort_fb_tag = c->sdp_inner ? "sdp_inner_sort_fallback" : "sdp_sort_fallback"; c->sort_short = true; } ~Retag() { c->sort_tag = "sort"; c->sort_fb_tag = "sort_fallback"; c->sort_short = false; } } retag(ctx);
   // the two point orders: (q, t, ind) / (t, q, ind) keys repeat only where two anchors share a corner, so the radix path takes nearly all lists
   { int rc = lra_sort_mostly_unique_batch(ctx, n_reads, ptOff, NP, key1, pay1, key3, pay3, 64); if (rc) return rc; }   // sort(H1, SortByRowOp)  :2171
   lra_time_begin(ctx, ctx->sdp_inner ? "sdp_inner_points" : "sdp_points");

@@ -514,7 +514,7 @@ __host__ __device__ inline size_t sort_scratch_bytes(int mode, size_t cap) {
 template <int MODE>
 __global__ void __launch_bounds__(SORT_NT) sort_wg_kernel(int n_reads, const uint64_t* __restrict__ mm_off, uint64_t* mm_key, uint32_t* mm_pos,
                                                         void* tscratch, int cap, int* __restrict__ fallback,
-                                                        const int* __restrict__ only, char* gscr, int* stat) {
+                                                        const int* __restrict__ only, char* gscr, int* stat, int minLen = 0) {
   constexpr bool BIG = MODE >= 1, HUGE = MODE == 2;
   typedef typename SortTypes<MODE>::IT IT;
   typedef typename SortTypes<MODE>::TT TT;
@@ -523,6 +523,7 @@ __global__ void __launch_bounds__(SORT_NT) sort_wg_kernel(int n_reads, const uin
   constexpr TT HM = (TT)(((TT)1 << HB) - 1);
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int NT_ = (int)blockDim.x, NW_ = NT_ >> 6;                         // (1024 threads per list; 256 for the launch that takes the short lists four to a CU)
   const int maxseg = (cap / 16 + 8 + 1) & ~1;                            // even: the word array behind the ten tables stays 4-byte aligned
   char* ebase = BIG ? gscr + (size_t)blockIdx.x * sort_scratch_bytes(MODE, (size_t)cap) : smem;
   uint64_t* key = (uint64_t*)ebase;
@@ -554,12 +555,13 @@ __global__ void __launch_bounds__(SORT_NT) sort_wg_kernel(int n_reads, const uin
       if (n > cap) { if (MODE == 1 && stat && tid == 0) { atomicMax(&stat[0], n); atomicAdd(&stat[1], 1); } continue; }
     } else {
       if (only && !only[r]) continue;
-      if (n > cap) { if (tid == 0) fallback[r] = 1; continue; }
+      if (n < minLen) continue;                                           // (a shorter list was the previous launch's)
+      if (n > cap) { if (fallback && tid == 0) fallback[r] = 1; continue; }
     }
     __syncthreads();
     if (BIG && tid == 0) fallback[r] = 0;
-    for (int p = tid; p < n; p += SORT_NT) { key[p] = mm_key[base + p]; idx[p] = (IT)p; seg[p] = 0; }
-    for (int x = tid; x < cap / 32 + 1; x += SORT_NT) startBits[x] = 0;
+    for (int p = tid; p < n; p += NT_) { key[p] = mm_key[base + p]; idx[p] = (IT)p; seg[p] = 0; }
+    for (int x = tid; x < cap / 32 + 1; x += NT_) startBits[x] = 0;
     if (tid == 0) {
       if (n > 16) { sF[0] = 0; sL[0] = (IT)n; sD[0] = (IT)(2 * (31 - __clz(n))); cnt[0] = 1; }
       else cnt[0] = 0;
@@ -570,7 +572,7 @@ __global__ void __launch_bounds__(SORT_NT) sort_wg_kernel(int n_reads, const uin
     int nseg = cnt[0];
     while (nseg > 0) {
       // (a) depth check / median of three -> pivot at `first`
-      for (int s = tid; s < nseg; s += SORT_NT) {
+      for (int s = tid; s < nseg; s += NT_) {
         const int first = (int)sF[s], last = (int)sL[s];
         sM[s] = 0;
         if (sD[s] == 0) { lds_heap_sort(S, first, last); sM[s] = S_NONE; continue; }
@@ -587,7 +589,7 @@ __global__ void __launch_bounds__(SORT_NT) sort_wg_kernel(int n_reads, const uin
       __syncthreads();
       // (b) exclusive prefix counts of the two stopper flags over all positions (wave w owns a
       //     contiguous range; ballots give in-row ranks)
-      const int rows = (n + 63) / 64, rpw = (rows + SORT_NW - 1) / SORT_NW;
+      const int rows = (n + 63) / 64, rpw = (rows + NW_ - 1) / NW_;
       const int r0 = wave * rpw, r1 = min(rows, r0 + rpw);
       auto flags = [&](int p, bool& A, bool& B) {
         A = false; B = false;
@@ -604,10 +606,10 @@ __global__ void __launch_bounds__(SORT_NT) sort_wg_kernel(int n_reads, const uin
         bool A, B; flags(rw * 64 + lane, A, B);
         totA += __popcll(__ballot(A)); totB += __popcll(__ballot(B));
       }
-      if (lane == 0) { waveTot[wave] = totA; waveTot[SORT_NW + wave] = totB; }
+      if (lane == 0) { waveTot[wave] = totA; waveTot[NW_ + wave] = totB; }
       __syncthreads();
       unsigned int baseA = 0, baseB = 0;
-      for (int w = 0; w < wave; w++) { baseA += waveTot[w]; baseB += waveTot[SORT_NW + w]; }
+      for (int w = 0; w < wave; w++) { baseA += waveTot[w]; baseB += waveTot[NW_ + w]; }
       const unsigned long long below = (lane == 0) ? 0ULL : (~0ULL >> (64 - lane));
       for (int rw = r0; rw < r1; rw++) {
         const int p = rw * 64 + lane;
@@ -616,10 +618,10 @@ __global__ void __launch_bounds__(SORT_NT) sort_wg_kernel(int n_reads, const uin
         if (p <= n) t32[p] = ((TT)(baseA + __popcll(mA & below)) & HM) | ((TT)(baseB + __popcll(mB & below)) << HB);
         baseA += __popcll(mA); baseB += __popcll(mB);
       }
-      if (wave == SORT_NW - 1 && lane == 0 && (n & 63) == 0) t32[n] = ((TT)baseA & HM) | ((TT)baseB << HB);   // prefix at n when n is a row boundary
+      if (wave == NW_ - 1 && lane == 0 && (n & 63) == 0) t32[n] = ((TT)baseA & HM) | ((TT)baseB << HB);   // prefix at n when n is a row boundary
       __syncthreads();
       // (c) scatter stopper positions: pa ascending, pb descending, both stored from first+1
-      for (int p = tid; p < n; p += SORT_NT) {
+      for (int p = tid; p < n; p += NT_) {
         bool A, B; flags(p, A, B);
         if (A || B) {
           const int sg = (int)seg[p], b0 = (int)sF[sg] + 1;
@@ -630,7 +632,7 @@ __global__ void __launch_bounds__(SORT_NT) sort_wg_kernel(int n_reads, const uin
       }
       __syncthreads();
       // (d) m = number of leading pairs with a_i < b_i
-      for (int p = tid; p < n; p += SORT_NT) {
+      for (int p = tid; p < n; p += NT_) {
         const IT sg = seg[p];
         if (sg == S_NONE || sM[sg] == S_NONE) continue;
         const int b0 = (int)sF[sg] + 1, i = p - b0;
@@ -642,7 +644,7 @@ __global__ void __launch_bounds__(SORT_NT) sort_wg_kernel(int n_reads, const uin
       }
       __syncthreads();
       // (e) the swaps
-      for (int p = tid; p < n; p += SORT_NT) {
+      for (int p = tid; p < n; p += NT_) {
         const IT sg = seg[p];
         if (sg == S_NONE || sM[sg] == S_NONE) continue;
         const int b0 = (int)sF[sg] + 1, i = p - b0;
@@ -650,7 +652,7 @@ __global__ void __launch_bounds__(SORT_NT) sort_wg_kernel(int n_reads, const uin
       }
       __syncthreads();
       // (f) cut -> children
-      for (int s = tid; s < nseg; s += SORT_NT) {
+      for (int s = tid; s < nseg; s += NT_) {
         const int first = (int)sF[s], last = (int)sL[s];
         if (sM[s] == S_NONE) { sCut[s] = (IT)last; sLid[s] = S_NONE; sRid[s] = S_NONE; continue; }   // heap sorted: finished
         const int b0 = first + 1, m = (int)sM[s];
@@ -668,18 +670,18 @@ __global__ void __launch_bounds__(SORT_NT) sort_wg_kernel(int n_reads, const uin
       }
       __syncthreads();
       // (g) relabel elements, swap tables
-      for (int p = tid; p < n; p += SORT_NT) {
+      for (int p = tid; p < n; p += NT_) {
         const IT sg = seg[p];
         if (sg != S_NONE) seg[p] = (p < (int)sCut[sg]) ? sLid[sg] : sRid[sg];
       }
       nseg = cnt[1];
       __syncthreads();
-      for (int s = tid; s < nseg; s += SORT_NT) { sF[s] = nF[s]; sL[s] = nL[s]; sD[s] = nD[s]; }
+      for (int s = tid; s < nseg; s += NT_) { sF[s] = nF[s]; sL[s] = nL[s]; sD[s] = nD[s]; }
       if (tid == 0) cnt[1] = 0;
       __syncthreads();
     }
     // final insertion sort of every leftover block (blocks start at the marked positions)
-    for (int p = tid; p < n; p += SORT_NT) {
+    for (int p = tid; p < n; p += NT_) {
       if ((startBits[p >> 5] >> (p & 31)) & 1u) {
         int q = p + 1;
         while (q < n && !((startBits[q >> 5] >> (q & 31)) & 1u)) q++;
@@ -688,9 +690,9 @@ __global__ void __launch_bounds__(SORT_NT) sort_wg_kernel(int n_reads, const uin
     }
     __syncthreads();
     uint32_t* tmp = HUGE ? (uint32_t*)seg : (uint32_t*)pa;            // pa|pb = 4*cap bytes (32-bit indices: seg, dead by now)
-    for (int p = tid; p < n; p += SORT_NT) tmp[p] = mm_pos[base + idx[p]];
+    for (int p = tid; p < n; p += NT_) tmp[p] = mm_pos[base + idx[p]];
     __syncthreads();
-    for (int p = tid; p < n; p += SORT_NT) { mm_key[base + p] = key[p]; mm_pos[base + p] = tmp[p]; }
+    for (int p = tid; p < n; p += NT_) { mm_key[base + p] = key[p]; mm_pos[base + p] = tmp[p]; }
   }
 }
 
@@ -1113,7 +1115,16 @@ static int launch_sort(lra_ctx* ctx, int n_reads, const uint64_t* mm_off, uint64
   LRA_HIP_CHECK(ctx, hipFuncSetAttribute((const void*)sort_wg_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
   LRA_HIP_CHECK(ctx, hipFuncSetAttribute((const void*)sort_wg_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsB));
   lra_time_begin(ctx, ctx->sort_tag);
-  hipLaunchKernelGGL(sort_wg_kernel<0>, dim3(grid), dim3(SORT_NT), lds, st, n_reads, mm_off, mm_key, mm_pos, (void*)tscr, cap, flags, only, (char*)nullptr, (int*)nullptr);
+  // Lists of at most capS tuples first, 256 threads and ~36 KB of LDS each: four of them fit a CU where the 1024-thread / 156 KB launch holds one, and a short list's sort
+  // is a chain of barriers either way (the sparse DP's value lists: hundreds of tuples, tens of thousands of lists).  Then the rest, as before.
+  static const int capS = getenv("LRA_SORT_SMALL_CAP") ? std::max(0, std::min(cap, atoi(getenv("LRA_SORT_SMALL_CAP")))) : 2048;
+  if (capS >= 64 && ctx->sort_short) {
+    const int maxsegS = (capS / 16 + 8 + 1) & ~1;
+    const size_t ldsS = (size_t)capS * 16 + (size_t)maxsegS * 20 + 8 + (size_t)(capS / 32 + 2) * 4;
+    const int gridS = std::min(n_reads, std::min(ctx->num_cu * 4, (int)(((size_t)grid * (cap + 64)) / (size_t)(capS + 64))));
+    hipLaunchKernelGGL(sort_wg_kernel<0>, dim3(gridS), dim3(256), ldsS, st, n_reads, mm_off, mm_key, mm_pos, (void*)tscr, capS, (int*)nullptr, only, (char*)nullptr, (int*)nullptr, 0);
+  }
+  hipLaunchKernelGGL(sort_wg_kernel<0>, dim3(grid), dim3(SORT_NT), lds, st, n_reads, mm_off, mm_key, mm_pos, (void*)tscr, cap, flags, only, (char*)nullptr, (int*)nullptr, (capS >= 64 && ctx->sort_short) ? capS + 1 : 0);
   hipLaunchKernelGGL(sort_wg_kernel<1>, dim3(gridB), dim3(SORT_NT), ldsB, st, n_reads, mm_off, mm_key, mm_pos, (void*)tscrB, capB, flags, only, gscr, stat);
   lra_time_end(ctx);
   // what is left: lists of more than 65534 tuples (the minimizers of a contig of several hundred kb) -- how long, how many

@@ -1,6 +1,3 @@
 export TMPDIR=/tmp
-bash tools/profile_bench.sh r04n --steps 20 --warmup 5 > /dev/null 2>&1
-python -c "
-import json
-j=json.loads(open('gpurun_out/r04n_bench.json').read()); print(j['value'], j['ms_per_step'], j['cpu_baseline']['value'], j['cpu_baseline']['sample_equals_gpu'], j['roofline']['frac'], j['roofline']['avg_launch_ms'], j['hbm_used_gb'])"
-for p in clr ccs; do python tools/bench_presets.py --preset $p --steps 5 2>/dev/null | grep '^{"metric"' > gpurun_out/r04n_${p}_bench.json; echo $p $(grep -o '"value": [0-9.]*' gpurun_out/r04n_${p}_bench.json); done
+python -m pytest tests/test_sort.py tests/test_sdp.py tests/test_mapread.py tests/test_highacc_path.py -m gpu -x -q 2>&1 | tail -2
+python bench.py --steps 8 --warmup 2 2>/dev/null | grep -o '"ms_per_step": [0-9.]*\|"sort": [0-9.]*\|"sdp_sort": [0-9.]*\|"sdp_inner_sort": [0-9.]*\|"sample_equals_gpu": [a-z]*'
