@@ -1825,6 +1825,14 @@ inline size_t sz(size_t n, size_t elem) { return (n * elem + 255) / 256 * 256; }
 // Box mode (d_qe != null): clusters are the fragments; d_c_start / d_c_count are null, d_q/d_t/d_qe/d_te/d_len(=Val)/d_c_strand are per box.
 // The one-wave-per-read builds of a launch: reads [from, to) of `order` (largest first).  Those of at most 512 points keep their element arrays in LDS
 // (three sizes of LDS request, so that small reads do not pay for large ones' occupancy); the rest work from the scratch arena.
+// from how many points on a read gets a workgroup (the workgroup kernels' per-point latency is half the wave kernel's, at four times its wave slots): a launch is as long
+// as its largest reads' chains.  LRA_SDP_BIG_POINTS overrides all, LRA_SDP_BIG_POINTS_A the first sparse DP's (mode 0) alone
+static long sdp_big_points(const lra_ctx* ctx, int mode) {
+  if (const char* e = getenv("LRA_SDP_BIG_POINTS")) return atol(e);
+  if (ctx->sdp_inner) return 1500;
+  if (mode == 0) { if (const char* e = getenv("LRA_SDP_BIG_POINTS_A")) return atol(e); return 2500; }   // (its largest reads have ~5000 points: the top few hundred as workgroups, 93 -> 83 ms)
+  return 6000;
+}
 template <bool EMIT>
 static void launch_small_builds(lra_ctx* ctx, const BuildArgs& ba, const uint32_t* d_order, const std::vector<uint32_t>& h_order, const uint64_t* h_pt, int from, int to) {
   static const bool noLds = getenv("LRA_SDP_BUILD_NOLDS") != nullptr;
@@ -2083,7 +2091,7 @@ int sdp_run(lra_ctx* ctx, int n_reads, const uint64_t* d_cluster_off, const uint
     auto count_pass = [&](const uint32_t* d_ord, const std::vector<uint32_t>& h_ord, int n) {
       lra_time_begin(ctx, ctx->sdp_inner ? "sdp_inner_build_count" : "sdp_build_count");
       // reads ordered largest first: the large ones get a 1024-thread workgroup each, beside the wave-per-read launch
-      const long big_pts = getenv("LRA_SDP_BIG_POINTS") ? atol(getenv("LRA_SDP_BIG_POINTS")) : (ctx->sdp_inner ? 1500 : 6000);
+      const long big_pts = sdp_big_points(ctx, opts->mode);
       int nb0 = 0;
       while (nb0 < n && (long)(h_pt[r0 + h_ord[nb0] + 1] - h_pt[r0 + h_ord[nb0]]) >= big_pts) nb0++;
       const bool forked = nb0 > 0 && n > nb0;
@@ -2141,11 +2149,13 @@ int sdp_run(lra_ctx* ctx, int n_reads, const uint64_t* d_cluster_off, const uint
       ba.ra = ra; ba.order = subOrder;
       int nbig = 0;
       {
-        const long big_pts = getenv("LRA_SDP_BIG_POINTS") ? atol(getenv("LRA_SDP_BIG_POINTS")) : (ctx->sdp_inner ? 1500 : 6000);   // (tests lower it to run small reads through the workgroup kernels)
+        const long big_pts = sdp_big_points(ctx, opts->mode);   // (tests lower it to run small reads through the workgroup kernels)
         const std::vector<uint32_t>& ord = att == 0 ? h_orderAll : h_prev;
         // ... but no more of them than the device runs side by side (a workgroup holds 16 wave slots for a per-point latency a third of the wave kernel's, at 3.5 times its
         // wave-time per point): beyond that the large reads queue up behind each other, and the ones further down the order are better off as one wave each
-        static const int maxBig = getenv("LRA_SDP_MAX_BIG") ? std::max(0, atoi(getenv("LRA_SDP_MAX_BIG"))) : (1 << 30);
+        static const int maxBigAll = getenv("LRA_SDP_MAX_BIG") ? std::max(0, atoi(getenv("LRA_SDP_MAX_BIG"))) : (1 << 30);
+        static const int maxBigA = getenv("LRA_SDP_MAX_BIG_A") ? std::max(0, atoi(getenv("LRA_SDP_MAX_BIG_A"))) : 512;
+        const int maxBig = (opts->mode == 0 && !ctx->sdp_inner) ? std::min(maxBigAll, maxBigA) : maxBigAll;
         while (nbig < nsub && nbig < maxBig && (long)(h_pt[r0 + ord[nbig] + 1] - h_pt[r0 + ord[nbig]]) >= big_pts) nbig++;
       }
       {
