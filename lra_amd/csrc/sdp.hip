@@ -967,6 +967,7 @@ __global__ void __launch_bounds__(64, 4) sdp_process(ProcArgs a) {
       if (lane < 2 * LV) vN = visR[(uint64_t)(pi + 1) * (2 * LV) + lane];
     }
     const int ind = fl & 1, inv = (fl >> 1) & 1;
+    const float fvP = a.fval[f0 + lf];                                   // the anchor's value so far (asked for now: the point ends with it)
     if (v.x != NONE && v.x != cId) {
       // (the descriptor's changing fields live in this lane's copy while the lane stays in the sub-problem; memory gets them when it leaves: a store per query
       // would be waited for by the next point's loads -- vector memory completes in order)
@@ -975,7 +976,7 @@ __global__ void __launch_bounds__(64, 4) sdp_process(ProcArgs a) {
     }
     if (ind == 0) {                                                      // PassValueToD1/D2 (SparseDP.h:140-310)
       if (v.x != NONE) {
-        const float val = a.fval[f0 + lf];
+        const float val = fvP;
         const uint32_t e = cn.dBase + v.y;
         if (ent[e].v < val) { ent[e].v = val; Ap[e] = lf; }
       }
@@ -987,8 +988,6 @@ __global__ void __launch_bounds__(64, 4) sdp_process(ProcArgs a) {
       if (v.x == NONE) { nd.dBase = 0; nd.nD = 0; nd.nE = 0; nd.last = -1; nd.sTop = 0; nd.nBlk = 0; nd.stkOff = 0; nd.blkOff = 0; nd.stkCap = 0; nd.blkCap = 0; nd.eLast = 0; }
       int now = -1;
       long long ei1 = 0;
-      if (v.x != NONE) { const Ent e = ent[nd.dBase + nd.nD + v.y]; now = e.b; ei1 = e.val; }
-      const bool need = now != -1;
       const int m = (int)nd.nD, n = (int)nd.nE, i1 = (int)v.y;
       int sTop = (int)nd.sTop, nBlk = (int)nd.nBlk;
       uint32_t stkOff = nd.stkOff, blkOff = nd.blkOff;
@@ -999,7 +998,22 @@ __global__ void __launch_bounds__(64, 4) sdp_process(ProcArgs a) {
       const long long eLast = nd.eLast;
       int tx = cTop.x; int2 lastB = cLastB;                               // tx == -1: the dummy
       uint32_t st = 0;
-      if (need && !cTopOk) { tx = sTop <= 1 ? -1 : S[sTop - 1].x; lastB = nBlk > 0 ? B[nBlk - 1] : make_int2(0, 0); }
+      // what the visit asks memory for first, in ONE round: the query's E entry, the stack top and the last Block pair (when the lane has just come to the sub-problem),
+      // the first candidate and the top's D entry (used if the query inserts anything)
+      Ent pfD; pfD.val = 0; pfD.b = -1; pfD.v = 0;
+      long long pfE = 0;
+      Ent pfT; pfT.val = 0; pfT.b = 0; pfT.v = 0;
+      bool pfTok = false;
+      if (v.x != NONE) {
+        const Ent e = ent[nd.dBase + nd.nD + v.y];
+        int2 sT = make_int2(-1, 0), bL = make_int2(0, 0);
+        if (!cTopOk) { if (sTop > 1) sT = S[sTop - 1]; if (nBlk > 0) bL = B[nBlk - 1]; }
+        if (nd.last + 1 < m) { pfD = D[nd.last + 1]; pfE = Edb[nd.last + 1]; }
+        if (cTopOk && tx >= 0) { pfT = D[tx]; pfTok = true; }
+        now = e.b; ei1 = e.val;
+        if (!cTopOk) { tx = sTop <= 1 ? -1 : sT.x; lastB = bL; }
+      }
+      const bool need = now != -1;
       // phase 1a, every lane for itself: short insertion runs (most queries advance `now` by a few candidates only) -- the same loop
       // as below, literal and lane-local, all lanes at once
       const int LOCAL_MAX = 6;
@@ -1011,13 +1025,13 @@ __global__ void __launch_bounds__(64, 4) sdp_process(ProcArgs a) {
 #define BPUSHL(val_) do { const int2 v__ = (val_); if (nBlk >= bCap) { if (grow_pairs(pairs, blkOff, bCap, nBlk, poolUsed, poolPair, poolPairs)) B = pairs + blkOff; else st |= LRA_ST_CAPACITY; } \
                           if (nBlk < bCap) B[nBlk] = v__; nBlk++; lastB = v__; } while (0)
         for (int i = nd.last + 1; i <= now && !st; ++i) {
-          const Ent di_ = D[i];
+          Ent di_ = pfD; long long edb = pfE;
+          if (i != nd.last + 1) { di_ = D[i]; edb = Edb[i]; }
           const int db = di_.b;
           if (db == -1) break;
           const long long di = di_.val; const float dvi = di_.v;
-          const long long edb = Edb[i];
           if (tx == -1) { BPUSHL(make_int2(-1, db)); SPUSHL(make_int2(i, n)); tx = i; tDv = dvi; tDi = di; topD = true; }
-          if (!topD) { const Ent e = D[tx]; tDv = e.v; tDi = e.val; topD = true; }
+          if (!topD) { Ent e = pfT; if (!pfTok) e = D[tx]; tDv = e.v; tDi = e.val; topD = true; }
           if (BEATS(dvi, di, tDv, tDi, edb)) {
             if (nBlk > 0 && db > lastB.y) BPUSHL(make_int2(tx, db));
             const float sNew = dvi + W(di, eLast);
@@ -1054,7 +1068,7 @@ __global__ void __launch_bounds__(64, 4) sdp_process(ProcArgs a) {
         int oSCap = rl_i(sCap, owner), oBCap = rl_i(bCap, owner);
         int otx = rl_i(tx, owner); int2 olastB = make_int2(rl_i(lastB.x, owner), rl_i(lastB.y, owner));
         uint32_t ost = 0;
-        bool topD = false; float tDv = 0; long long tDi = 0;
+        bool topD = rl_i(pfTok ? 1 : 0, owner) != 0; float tDv = rl_f(pfT.v, owner); long long tDi = rl_ll(pfT.val, owner);   // (the owner's top, asked for above)
 #define SPUSH(val_) do { const int2 v__ = (val_); if (oTop >= oSCap) { if (coop_grow_pairs(pairs, oStkOff, oSCap, oTop, poolUsed, poolPair, poolPairs, lane)) oS = pairs + oStkOff; else ost |= LRA_ST_CAPACITY; } \
                          if (oTop < oSCap) oS[oTop] = v__; oTop++; } while (0)
 #define BPUSH(val_) do { const int2 v__ = (val_); if (oBlk >= oBCap) { if (coop_grow_pairs(pairs, oBlkOff, oBCap, oBlk, poolUsed, poolPair, poolPairs, lane)) oB = pairs + oBlkOff; else ost |= LRA_ST_CAPACITY; } \
@@ -1159,7 +1173,7 @@ __global__ void __launch_bounds__(64, 4) sdp_process(ProcArgs a) {
           if (ov > bv || (ov == bv && oo < bo)) { bv = ov; bo = oo; }
         }
         if (got && bo == ord) {
-          if (a.fval[f0 + lf] < bv) {
+          if (fvP < bv) {
             a.fval[f0 + lf] = bv; a.fprevNode[f0 + lf] = v.x; a.fprevInd[f0 + lf] = myI1;
             a.fflags[f0 + lf] = (uint8_t)((fam2 == 0 ? 1 : 0) | (inv ? 2 : 0));   // bit0 prev (row family), bit1 inv
           }
