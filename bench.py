@@ -461,7 +461,7 @@ def main():
         job_bases = total_bases
     nreads = args.reads * world
 
-    kernels = ["sketch_count", "sketch_serial", "sketch_emit", "sort", "sort_fallback", "index_bounds", "compare", "strand",
+    kernels = ["sketch_emit", "sketch_serial", "sketch_compact", "sort", "sort_fallback", "index_bounds", "compare", "strand",
                "aog_lds_tiny", "aog_lds_small", "aog_lds_medium", "aog_lds_large", "aog_lane", "aog_reg", "aog_hbm", "ir_segment", "ir_band", "ir_fill", "ir_trace", "ir_gather", "clean_sort", "clean", "linear_extend", "stats", "stats_cigar", "create_rc", "local_sketch", "local_sort_filter", "local_compare",
                "rsc_tasks", "rsc_filter", "refine_space", "rs_long_sketch", "rs_long_compare", "btwn_plan", "btwn_apply", "merge_extend", "between_anchors", "local_refine", "sdp_inner_points", "sdp_inner_sort", "sdp_inner_build_count", "sdp_inner_build", "sdp_inner_process", "sdp_inner_trace", "chain_split", "sdp_points", "sdp_sort", "sdp_sort_fallback", "sdp_build_count", "sdp_build", "sdp_process", "sdp_trace"]
     ktimes = {}
@@ -487,7 +487,7 @@ def main():
         n_q, n_m = stats.get("n_mm", 0), stats.get("n_match", 0)
         sdp_anchors = stats.get("n_sdp_anchors", 0) + stats.get("n_sdp2_anchors", 0)
         alg8d = {
-            "sketch_count": L, "sketch_emit": L + 12 * n_q, "sort": 2 * 12 * n_q, "index_bounds": n_q * (12 + 64), "compare": 12 * n_q + 16 * n_m,
+            "sketch_emit": L + 12 * n_q, "sketch_compact": 2 * 12 * n_q, "sort": 2 * 12 * n_q, "index_bounds": n_q * (12 + 64), "compare": 12 * n_q + 16 * n_m,
             "strand": 16 * n_m + 2 * args.k * n_m, "clean": 16 * n_m, "clean_sort": 2 * 16 * n_m,
             "sdp_process": 24 * sdp_anchors, "sdp_build": 16 * sdp_anchors, "sdp_build_count": 16 * sdp_anchors, "sdp_sort": 2 * 16 * sdp_anchors, "sdp_trace": 8 * sdp_anchors,
             "ir_fill": 1 * stats.get("n_cells", 0) + 2 * stats.get("n_rows", 0), "ir_band": 12 * stats.get("n_blocks", 0), "ir_trace": 1 * stats.get("n_rows", 0) + 12 * stats.get("n_blocks", 0),

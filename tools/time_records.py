@@ -28,7 +28,7 @@ print("reads %d  bases %d  align %.3f s  records %.3f s  text %.1f MB  -> record
 if os.environ.get("LRA_TIME_TAGS"):
     ctx.timing(True); ctx.timing_reset()
     mapper.align(rb)
-    tags = ["sketch_count", "sketch_emit", "sort", "index_bounds", "compare", "strand", "clean_sort", "clean", "linear_extend", "sdp_points", "sdp_sort", "sdp_build_count",
+    tags = ["sketch_emit", "sketch_compact", "sort", "index_bounds", "compare", "strand", "clean_sort", "clean", "linear_extend", "sdp_points", "sdp_sort", "sdp_build_count",
             "sdp_build", "sdp_process", "sdp_trace", "chain_split", "create_rc", "local_sketch", "local_sort_filter", "local_compare", "rsc_tasks", "rsc_filter", "refine_space",
             "rs_long_sketch", "rs_long_compare", "btwn_plan", "btwn_apply", "merge_extend", "between_anchors", "local_refine", "aog_lds_tiny", "aog_lds_small", "aog_lds_medium",
             "aog_lds_large", "aog_hbm", "ir_segment", "ir_band", "ir_fill", "ir_trace", "ir_gather", "stats", "sdp_inner_process", "sdp_inner_build", "sdp_sort_fallback", "sort_fallback"]
