@@ -120,6 +120,10 @@ def main():
     ap.add_argument("--heavy-lane", type=int, default=int(os.environ.get("LRA_BENCH_HEAVY_LANE", 1)),
                     help="1 = the batches of handed-back reads run on a context of their own (low-priority streams) beside the next steps; 0 = on lane 0, between steps")
     ap.add_argument("--heavy-pool", type=int, default=int(os.environ.get("LRA_BENCH_HEAVY_POOL", 4096)), help="handed-back reads per batch of their own")
+    ap.add_argument("--seed-ahead", type=int, default=int(os.environ.get("LRA_BENCH_SEED_AHEAD", 1)),
+                    help="1 = a step's seed stage (a1-a4) runs beside the step before it, on a side context (lra_seed_prefetch / lra_ctx_adopt_seed); 0 = every step seeds itself")
+    ap.add_argument("--seed-ahead-delay-ms", type=float, default=float(os.environ.get("LRA_BENCH_SEED_AHEAD_DELAY_MS", 300)),
+                    help="how long into a step the seeding of the next one starts")
     ap.add_argument("--lane-priority", type=int, default=int(os.environ.get("LRA_BENCH_LANE_PRIORITY", 1)),
                     help="with --lanes > 1: 1 = lane 0 on a high-priority stream, the others below it (they fill what it leaves idle); 0 = all lanes alike")
     ap.add_argument("--lanes", type=int, default=int(os.environ.get("LRA_BENCH_LANES", 1)),
@@ -234,12 +238,43 @@ def main():
         except BaseException as e:
             err.append(e)
 
+    ahead_on = bool(args.seed_ahead) and args.lanes == 1 and not defer_T
+    ahead = {}
+    if ahead_on:
+        ahead["ctx"] = Context(dev_index)
+        mapread.LowAccMapper.sharing(ahead["ctx"], mapper)
+        ahead["stream"] = torch.cuda.Stream(device=dev_index, priority=prio_lo)
+        ahead["ctx"].bind_stream(ahead["stream"])
+
+    def seed_ahead(sub):
+        try:
+            torch.cuda.set_device(dev_index)
+            if args.seed_ahead_delay_ms > 0:
+                time.sleep(args.seed_ahead_delay_ms * 1e-3)
+            t0_ = time.perf_counter()
+            seed.seed_prefetch(ahead["ctx"], sub["rbatch"], args.k, args.w, args.max_freq)
+            ahead["ok"] = True
+            if os.environ.get("LRA_BENCH_DBG"):
+                sys.stderr.write("[bench] seeding ahead %.0f ms\n" % ((time.perf_counter() - t0_) * 1e3))
+        except BaseException as e:
+            err.append(e)
+
     def lane_device_side(lane, sub):
         try:
             torch.cuda.set_device(dev_index)                               # the current device is per host thread
             lc = lane["ctx"]
             def run():
                 tA_ = time.perf_counter()
+                if ahead_on:
+                    # the seeding of the NEXT step's batch beside this step (lra_seed_prefetch on a side context, low-priority stream, a host thread of its own), and this
+                    # step's own seed result -- made beside the previous step -- adopted instead of seeding: every timed step runs one alignment pass and one seeding
+                    th_ = ahead.pop("thread", None)
+                    if th_ is not None:
+                        th_.join()
+                        if ahead.pop("ok", False):
+                            seed.adopt_seed(lc, ahead["ctx"])
+                    ahead["thread"] = threading.Thread(target=seed_ahead, args=(sub,))
+                    ahead["thread"].start()
                 res = lane["mapper"].align(sub["rbatch"])
                 lane["last_res"] = res
                 if args.no_records:
@@ -424,6 +459,9 @@ def main():
             ths = [threading.Thread(target=lane_loop, args=(li, stagger * li / len(lanes))) for li in range(len(lanes))]
             for t in ths: t.start()
             for t in ths: t.join()
+        th_ = ahead.get("thread")
+        if th_ is not None:                                                # (the seeding of the batch after the last one: joined here, so that a run of n steps holds n of them)
+            th_.join()
         if err:
             raise err[0]
 
@@ -438,6 +476,8 @@ def main():
     run_steps(min(args.warmup, 1), 0.0)
     step_guess = (time.perf_counter() - tw) if args.warmup > 1 else 0.0
     timed = lanes + ([heavy["lane"]] if defer_T and args.heavy_lane else [])
+    if ahead_on:
+        ahead["ctx"].timing(True); ahead["ctx"].timing_reset()
     for l in timed:
         l["ctx"].timing(True)
         l["ctx"].timing_reset()
@@ -466,7 +506,7 @@ def main():
                "rsc_tasks", "rsc_filter", "refine_space", "rs_long_sketch", "rs_long_compare", "btwn_plan", "btwn_apply", "merge_extend", "between_anchors", "local_refine", "sdp_inner_points", "sdp_inner_sort", "sdp_inner_build_count", "sdp_inner_build", "sdp_inner_process", "sdp_inner_trace", "chain_split", "sdp_points", "sdp_sort", "sdp_sort_fallback", "sdp_build_count", "sdp_build", "sdp_process", "sdp_trace"]
     ktimes = {}
     for k in kernels:
-        tt_ = [l["ctx"].timing_get(k) for l in timed]
+        tt_ = [l["ctx"].timing_get(k) for l in timed] + ([ahead["ctx"].timing_get(k)] if ahead_on else [])
         ktimes[k] = (sum(x[0] for x in tt_), sum(x[1] for x in tt_))
     stats = {}
     for l in timed:
@@ -525,7 +565,7 @@ def main():
                        "stages": "MapRead_lowacc chained on the reads, every stage on what the previous one produced on the device: a1-a5, a7, a8 (SDP#A), a9, a10, a11, "
                                  "a9 (MergeChain), a7 (second LinearExtend + Trim), a8 (second SDP + filters), a13 (incl. a12), a14, a16; then lra_map_pack, the gather of the "
                                  "record buffers to rank 0 and the host tail a16-a17 (SetFromSegAlignment, AlignmentsOrder, SimpleMapQV, SAM text) of batch i beside the "
-                                 "device side of batch i + 1%s.  Not in the step: RefineBreakpoint (a15, built; off by default in lra)" % (" -- SKIPPED (--no-records)" if args.no_records else ""),
+                                 "device side of batch i + 1%s; with --seed-ahead the seed stage a1-a4 of batch i + 1 also runs beside batch i (lra_seed_prefetch).  Not in the step: RefineBreakpoint (a15, built; off by default in lra)" % (" -- SKIPPED (--no-records)" if args.no_records else ""),
                        "parallelism": "reads hash-partitioned by ordinal, 1 process/GPU, genome + both indexes replicated per GPU; %d sub-batch(es) per process; no data-path collective: every rank formats the records of its own reads (its shard of the output) beside its next step; RCCL only for the barriers / the final reductions of the timing" % args.lanes,
                        "per_step": {k: int(v) for k, v in stats.items() if not k.startswith("_") and isinstance(v, (int, float))},
                        "reads_with_sv": n_sv},
@@ -536,6 +576,8 @@ def main():
                          "step_algorithmic_bytes": step_alg, "step_frac": step_alg / (ms_step * 1e-3) / 1e9 / 8000.0},
             "sam_text_gb_per_step": round(text_bytes[0] / max(args.steps, 1) / 1e9, 3),
             "lane_items": [l["n_items"] for l in lanes],
+            "seed_ahead": {"on": bool(ahead_on), "delay_ms": args.seed_ahead_delay_ms,
+                           "what": "a1-a4 of step i + 1 on a side context (low-priority stream, own host thread) beside step i; every timed step holds one alignment pass and one seeding"},
             "handed_back": {"defer_seed_matches": defer_T, "pool": args.heavy_pool, "reads_per_step": round(heavy["reads"] / max(args.steps, 1), 1), "batches": heavy["batches"]},
             "device_side_ms_per_step": round(t_dev / args.steps * 1e3, 1),
         }

@@ -69,7 +69,7 @@ int lra_ctx_set_stream(lra_ctx* ctx, void* stream);
 const char* lra_ctx_last_error(lra_ctx* ctx);
 /* ABI version of the loaded library (tests check it against this header). */
 int lra_abi_version(void);
-#define LRA_ABI_VERSION 4   /* 2: lra_map_opts.defer_matches, lra_map_counters.n_deferred_reads; 3: lra_map_opts.flagged_unaligned, lra_map_counters.n_flagged_reads, lra_map_host_flagged; 4: lra_reads_last_error, a corrupt FASTQ record is LRA_ERR_INVALID; lra_map_opts.defer_seed_matches */
+#define LRA_ABI_VERSION 5   /* 2: lra_map_opts.defer_matches, lra_map_counters.n_deferred_reads; 3: lra_map_opts.flagged_unaligned, lra_map_counters.n_flagged_reads, lra_map_host_flagged; 4: lra_reads_last_error, a corrupt FASTQ record is LRA_ERR_INVALID; lra_map_opts.defer_seed_matches; 5: lra_seed_prefetch, lra_ctx_adopt_seed */
 
 /* Convenience for hosts without their own HIP binding: synchronous device->host copy on the
  * context's stream (a C++ host would call hipMemcpy itself).                                */
@@ -163,6 +163,17 @@ typedef struct lra_seed_result {
 } lra_seed_result;
 int lra_seed_batch(lra_ctx* ctx, int n_reads, const char* d_seq, const uint64_t* d_read_off, int k, int w,
                    int max_freq, lra_seed_result* out);
+
+/* The seeding of the NEXT batch beside the current one.  The per-read path is a chain of launches that are as long as their largest reads: much of a batch's time the
+ * device has room, and a1-a4 of the batch after it fit there.  `side` is a second context of the same device that shares the mapping context's reference data
+ * (lra_ctx_share_reference), driven by a host thread of its own on its own (low-priority) stream: lra_seed_prefetch is lra_seed_batch on it, synchronous, the result
+ * kept by `side`.  lra_ctx_adopt_seed(ctx, side) then hands that result to the mapping context (the two contexts exchange their seed-stage batch buffers; no copy);
+ * the next lra_map_reads_lowacc_batch / lra_map_reads_highacc_batch on `ctx` with the same n_reads, d_seq, d_read_off and the same globalK / globalW / globalMaxFreq
+ * starts from it instead of seeding -- with any other arguments it seeds as usual and the adopted result is dropped.  Same alignments either way: scheduling only.
+ * The reads (d_seq, d_read_off) must stay untouched from the prefetch to the batch call.  Not combined with opts.defer_seed_matches (LRA_ERR_INVALID).
+ * Replaces nothing in the reference: lra's worker threads (lra.cpp:678-714) each run MapRead start to end; this is the device's way of having two reads in flight. */
+int lra_seed_prefetch(lra_ctx* side, int n_reads, const char* d_seq, const uint64_t* d_read_off, int k, int w, int max_freq);
+int lra_ctx_adopt_seed(lra_ctx* ctx, lra_ctx* side);
 
 /* CreateRC (SeqUtils.h:151): reverse complement of every read of the batch into d_rc (same offsets);
  * bytes other than ACGTacgtn become 'N' (RevCompNuc, SeqUtils.h:112).  Asynchronous.            */

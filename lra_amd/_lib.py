@@ -4,7 +4,7 @@ import os
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 _LIB = None
-ABI_VERSION = 4
+ABI_VERSION = 5
 
 
 class LraError(RuntimeError):
@@ -42,6 +42,8 @@ SYMBOLS = {
     "lra_create_rc_batch": (C.c_int, [_vp, C.c_int, _vp, _vp, _vp]),
     "lra_sort_minimizers_batch": (C.c_int, [_vp, C.c_int, _vp, _vp, _vp]),
     "lra_seed_batch": (C.c_int, [_vp, C.c_int, _vp, _vp, C.c_int, C.c_int, C.c_int, _vp]),
+    "lra_seed_prefetch": (C.c_int, [_vp, C.c_int, _vp, _vp, C.c_int, C.c_int, C.c_int]),
+    "lra_ctx_adopt_seed": (C.c_int, [_vp, _vp]),
     "lra_clean_matches_batch": (C.c_int, [_vp, _vp, _vp, C.c_int, _vp]),
     "lra_match_rate_batch": (C.c_int, [_vp, _vp, C.c_float, _vp]),
     "lra_fine_clusters_batch": (C.c_int, [_vp, _vp, _vp, _vp, C.c_int, _vp]),

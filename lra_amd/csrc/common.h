@@ -47,6 +47,9 @@ struct lra_ctx {
   std::vector<hipEvent_t> free_events;
   lra_ctx* child = nullptr;                  // mapread.hip: the context of a batch's second, concurrent pass (shares this one's reference; destroyed with it)
   bool owns_stream = false;
+  // lra_seed_prefetch / lra_ctx_adopt_seed: a seed result made ahead of its batch -- on the side context the one lra_seed_prefetch left, on the mapping context the
+  // one it adopted and lra_map_reads_lowacc_batch / lra_map_reads_highacc_batch will use instead of seeding when they are called with the same reads
+  struct { bool valid = false; int n_reads = 0; const char* d_seq = nullptr; const uint64_t* d_read_off = nullptr; int k = 0, w = 0, max_freq = 0; lra_seed_result res; } ahead;
   bool low_priority = false; int prio = 0;   // the second pass's streams (its side streams too) are created with the device's lowest priority
 };
 

@@ -478,10 +478,19 @@ static int lowacc_core(lra_ctx* ctx, int n_reads, const char* d_seq, const uint6
   lra_seed_result sres;
   // opts.defer_seed_matches: the reads with more tier-1 matches than that are handed back (the seed stage empties their match lists: no later stage sees them)
   const uint32_t seedT = o->defer_seed_matches > 0 ? (uint32_t)o->defer_seed_matches : 0;
-  ctx->seed->defer_T = seedT;
-  rc = lra_seed_batch(ctx, n_reads, d_seq, d_read_off, o->globalK, o->globalW, o->globalMaxFreq, &sres);
-  ctx->seed->defer_T = 0;
-  if (rc) return rc;
+  // (a result made ahead of the call -- lra_seed_prefetch on a side context, lra_ctx_adopt_seed -- from these reads with these parameters is what lra_seed_batch would make)
+  const bool ahead = ctx->ahead.valid && ctx->ahead.n_reads == n_reads && ctx->ahead.d_seq == d_seq && ctx->ahead.d_read_off == d_read_off &&
+                     ctx->ahead.k == o->globalK && ctx->ahead.w == o->globalW && ctx->ahead.max_freq == o->globalMaxFreq;
+  ctx->ahead.valid = false;
+  if (ahead) {
+    if (seedT) return lra_set_err(ctx, LRA_ERR_INVALID, "defer_seed_matches and a seed result adopted ahead of the call do not combine");
+    sres = ctx->ahead.res;
+  } else {
+    ctx->seed->defer_T = seedT;
+    rc = lra_seed_batch(ctx, n_reads, d_seq, d_read_off, o->globalK, o->globalW, o->globalMaxFreq, &sres);
+    ctx->seed->defer_T = 0;
+    if (rc) return rc;
+  }
   uint64_t n_handed_back = 0;
   if (seedT) {
     unsigned long long* dcnt = (unsigned long long*)lra_ensure(ctx, 191, 64);

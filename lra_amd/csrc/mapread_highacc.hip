@@ -233,7 +233,13 @@ static int highacc_core(lra_ctx* ctx, int n_reads, const char* d_seq, const uint
   if ((rc = dl(ctx, h_read_off, d_read_off, (size_t)R + 1))) return rc;
   // ---- a1-a4 (MapRead.h:169-203), a5 (Map_highacc.h:41-42)
   lra_seed_result sres;
-  if ((rc = lra_seed_batch(ctx, R, d_seq, d_read_off, K, W, o->globalMaxFreq, &sres))) return rc;
+  {
+    const bool ahead = ctx->ahead.valid && ctx->ahead.n_reads == R && ctx->ahead.d_seq == d_seq && ctx->ahead.d_read_off == d_read_off &&
+                       ctx->ahead.k == K && ctx->ahead.w == W && ctx->ahead.max_freq == o->globalMaxFreq;   // (lra_seed_prefetch + lra_ctx_adopt_seed)
+    ctx->ahead.valid = false;
+    if (ahead) sres = ctx->ahead.res;
+    else if ((rc = lra_seed_batch(ctx, R, d_seq, d_read_off, K, W, o->globalMaxFreq, &sres))) return rc;
+  }
   lra_cluster_result cres;
   if ((rc = lra_clean_matches_batch(ctx, &o->clean, CH, nChr, &cres))) return rc;
   lra_fine_result fc;

@@ -1330,3 +1330,35 @@ extern "C" int lra_seed_batch(lra_ctx* ctx, int n_reads, const char* d_seq, cons
   out->d_n_forward = s->n_forward; out->d_sep_qpos = s->sep_qpos; out->d_sep_tpos = s->sep_tpos;
   return LRA_OK;
 }
+
+extern "C" int lra_seed_prefetch(lra_ctx* side, int n_reads, const char* d_seq, const uint64_t* d_read_off, int k, int w, int max_freq) {
+  if (!side) return LRA_ERR_INVALID;
+  side->ahead.valid = false;
+  lra_seed_result res;
+  int rc = lra_seed_batch(side, n_reads, d_seq, d_read_off, k, w, max_freq, &res);
+  if (rc) return rc;
+  LRA_HIP_CHECK(side, hipStreamSynchronize(side->stream));               // (the strand pass is queued, not waited for, by lra_seed_batch)
+  side->ahead.n_reads = n_reads; side->ahead.d_seq = d_seq; side->ahead.d_read_off = d_read_off; side->ahead.k = k; side->ahead.w = w; side->ahead.max_freq = max_freq;
+  side->ahead.res = res; side->ahead.valid = true;
+  return LRA_OK;
+}
+
+// The two contexts exchange the seed stage's batch buffers (the result's pointers go with them); the reference data, its ownership and the directory stay.
+extern "C" int lra_ctx_adopt_seed(lra_ctx* ctx, lra_ctx* side) {
+  if (!ctx || !side || ctx == side) return LRA_ERR_INVALID;
+  if (ctx->device != side->device) return lra_set_err(ctx, LRA_ERR_INVALID, "the side context is on another device");
+  if (!side->ahead.valid) return lra_set_err(ctx, LRA_ERR_INVALID, "the side context holds no prefetched seed result");
+  lra_seed_state* a = seed_state(ctx); lra_seed_state* b = seed_state(side);
+  LRA_HIP_CHECK(ctx, hipSetDevice(ctx->device));
+  LRA_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));                 // nothing of the mapping context's last batch still reads its seed buffers
+#define SW(f) std::swap(a->f, b->f)
+  SW(counts32); SW(counts64); SW(mm_off); SW(match_off); SW(n_forward); SW(cap_reads);
+  SW(mm_key); SW(mm_pos); SW(lb); SW(ub); SW(cap_mm); SW(tk_lb); SW(tk_lbm1); SW(tk_ubm1);
+  SW(match_qi); SW(match_ti); SW(sep_qpos); SW(sep_tpos); SW(sep_qkey); SW(cap_match);
+  SW(last_n_reads); SW(last_n_matches); SW(defer_flag); SW(cap_defer);
+  SW(tmp_qi); SW(tmp_ti); SW(cap_tmp); SW(cap_cnt); SW(cap_off);
+#undef SW
+  ctx->ahead = side->ahead;
+  side->ahead.valid = false;
+  return LRA_OK;
+}

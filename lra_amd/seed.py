@@ -57,6 +57,16 @@ def seed_batch(ctx: Context, batch: ReadBatch, k, w, max_freq):
     return res
 
 
+def seed_prefetch(side: Context, batch: ReadBatch, k, w, max_freq):
+    """a1-a4 of a batch AHEAD of its mapping call, on a side context (own host thread, own stream; shares the mapping context's reference data); the mapping
+    context takes the result with adopt_seed and its next lra_map_reads_*_batch on the same batch starts from it (include/lra_hip.h: lra_seed_prefetch)."""
+    side.check(side.lib.lra_seed_prefetch(side.h, batch.n, ptr(batch.seq), ptr(batch.off), k, w, max_freq))
+
+
+def adopt_seed(ctx: Context, side: Context):
+    ctx.check(ctx.lib.lra_ctx_adopt_seed(ctx.h, side.h))
+
+
 def fetch(ctx: Context, res: SeedResult):
     """Copy a SeedResult to host numpy arrays (dict)."""
     n = res.n_reads

@@ -524,3 +524,59 @@ def test_reads_handed_back_by_tier1_matches_map_the_same_in_a_batch_of_their_own
     texts2 = mapper.records(res2, [names[i] for i in D], [raw[i] for i in D])
     assert [texts2[k] for k in range(len(D))] == [texts0[i] for i in D]
     assert sum(1 for t in texts2 if t and not (int(t.split(b"\t")[1]) & 4)) >= len(D) - 1
+
+
+@pytest.mark.gpu
+def test_a_seed_result_made_ahead_on_a_side_context_gives_the_same_alignments(ctx):
+    """lra_seed_prefetch + lra_ctx_adopt_seed (scheduling only): a1-a4 of a batch run on a side context that borrows the reference data, the mapping context adopts the
+    result, and its batch call on the same reads starts from it -- same records as the call that seeds itself; the adopted result is used once; a call on other
+    reads ignores it and seeds as usual; adopting twice without a prefetch in between is refused; defer_seed_matches does not combine with it."""
+    import threading
+    from lra_amd import seed, mapread
+    from lra_amd.context import Context
+    from lra_amd import LraError
+    genome = synth.make_genome(500_000, seed=31, repeat_frac=0.3, n_families=3)
+    o = mapread.LowAccOptions()
+    ik, ip = synth.build_global_index(genome, o.globalK, o.globalW, 100)
+    reads, _ = synth.simulate_reads(genome, 20, 8000, 3000, 0.10, seed=5)
+    raw = [r.tobytes() for r in reads]
+    names = [b"q%d" % i for i in range(len(reads))]
+    mapper = mapread.LowAccMapper(ctx, genome, ik, ip, [b"chr1"], [0, len(genome)], o)
+    batch = seed.ReadBatch(ctx, raw)
+    other = seed.ReadBatch(ctx, raw[:7])
+    texts0 = mapper.records(mapper.align(batch), names, raw)
+    texts_other = mapper.records(mapper.align(other), names[:7], raw[:7])
+    side = Context(0)
+    mapread.LowAccMapper.sharing(side, mapper)
+    err = []
+
+    def ahead():                                                           # (a host thread of its own, as a driver would run it beside the previous batch)
+        try:
+            seed.seed_prefetch(side, batch, o.globalK, o.globalW, o.globalMaxFreq)
+        except BaseException as e:
+            err.append(e)
+    t = threading.Thread(target=ahead); t.start()
+    assert mapper.records(mapper.align(other), names[:7], raw[:7]) == texts_other      # the mapping context is busy with another batch meanwhile
+    t.join()
+    assert not err
+    seed.adopt_seed(ctx, side)
+    with pytest.raises(LraError):
+        seed.adopt_seed(ctx, side)                                         # nothing prefetched since
+    ctx.timing(True); ctx.timing_reset()
+    assert mapper.records(mapper.align(batch), names, raw) == texts0      # from the adopted result: the mapping context runs no sketch of its own
+    assert ctx.timing_get("sketch_emit")[1] == 0
+    assert mapper.records(mapper.align(batch), names, raw) == texts0      # (used once: this call seeds itself)
+    assert ctx.timing_get("sketch_emit")[1] == 1
+    ctx.timing(False)
+    seed.seed_prefetch(side, batch, o.globalK, o.globalW, o.globalMaxFreq)
+    seed.adopt_seed(ctx, side)
+    assert mapper.records(mapper.align(other), names[:7], raw[:7]) == texts_other      # other reads: the adopted result is dropped
+    assert mapper.records(mapper.align(batch), names, raw) == texts0
+    seed.seed_prefetch(side, batch, o.globalK, o.globalW, o.globalMaxFreq)
+    seed.adopt_seed(ctx, side)
+    mapper.copts.defer_seed_matches = 100
+    with pytest.raises(LraError):
+        mapper.align(batch)
+    mapper.copts.defer_seed_matches = 0
+    assert mapper.records(mapper.align(batch), names, raw) == texts0
+    side.close()
