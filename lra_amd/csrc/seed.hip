@@ -999,7 +999,7 @@ extern "C" int lra_ctx_load_genome(lra_ctx* ctx, const char* h_seq, uint64_t len
   if (!ctx || (!h_seq && len)) return LRA_ERR_INVALID;
   LRA_HIP_CHECK(ctx, hipSetDevice(ctx->device));
   lra_seed_state* s = seed_state(ctx);
-  seed_disown(s); s->cell->gen++;
+  seed_disown(s); s->cell->gen++; ctx->ahead.valid = false;   // (a seed result adopted ahead of its batch was made from the old data)
   if (!regrow(s->genome, len + 64)) return lra_set_err(ctx, LRA_ERR_NOMEM, "genome alloc");
   s->genome_len = len;
   LRA_HIP_CHECK(ctx, hipMemcpy(s->genome, h_seq, len, hipMemcpyHostToDevice));
@@ -1010,7 +1010,7 @@ extern "C" int lra_ctx_load_genome(lra_ctx* ctx, const char* h_seq, uint64_t len
 // adopts device arrays (hipMalloc'ed, n + 1 entries at least) as the context's global index and builds the bucket directory over the key's top bits
 int lra_seed_install_index(lra_ctx* ctx, uint64_t* d_key, uint32_t* d_pos, uint64_t n) {
   lra_seed_state* s = seed_state(ctx);
-  seed_disown(s); s->cell->gen++;
+  seed_disown(s); s->cell->gen++; ctx->ahead.valid = false;   // (a seed result adopted ahead of its batch was made from the old data)
   if (s->idx_key) (void)hipFree(s->idx_key);
   if (s->idx_pos) (void)hipFree(s->idx_pos);
   s->idx_key = d_key; s->idx_pos = d_pos; s->n_idx = n;
@@ -1068,7 +1068,7 @@ extern "C" int lra_ctx_load_genome_device(lra_ctx* ctx, const char* d_seq, uint6
   if (!ctx || (!d_seq && len)) return LRA_ERR_INVALID;
   LRA_HIP_CHECK(ctx, hipSetDevice(ctx->device));
   lra_seed_state* s = seed_state(ctx);
-  seed_disown(s); s->cell->gen++;
+  seed_disown(s); s->cell->gen++; ctx->ahead.valid = false;   // (a seed result adopted ahead of its batch was made from the old data)
   if (!regrow(s->genome, len + 64)) return lra_set_err(ctx, LRA_ERR_NOMEM, "genome alloc");
   s->genome_len = len;
   LRA_HIP_CHECK(ctx, hipMemcpyAsync(s->genome, d_seq, len, hipMemcpyDeviceToDevice, ctx->stream));
@@ -1218,6 +1218,7 @@ extern "C" int lra_seed_batch(lra_ctx* ctx, int n_reads, const char* d_seq, cons
   if (!ctx || !out || n_reads < 0) return LRA_ERR_INVALID;
   if (k < 1 || k > 32 || w < 1 || w > MAX_W) return lra_set_err(ctx, LRA_ERR_INVALID, "k must be 1..32 and w 1..%d", MAX_W);
   lra_seed_state* s = seed_state(ctx);
+  ctx->ahead.valid = false;                                               // (this call overwrites the buffers of a result adopted ahead of its batch, if there is one)
   if (!s->genome || !s->idx_key) return lra_set_err(ctx, LRA_ERR_INVALID, "load genome and global index first");
   { int rcs = lra_seed_check_shared(ctx); if (rcs) return rcs; }
   LRA_HIP_CHECK(ctx, hipSetDevice(ctx->device));
@@ -1349,6 +1350,9 @@ extern "C" int lra_ctx_adopt_seed(lra_ctx* ctx, lra_ctx* side) {
   if (ctx->device != side->device) return lra_set_err(ctx, LRA_ERR_INVALID, "the side context is on another device");
   if (!side->ahead.valid) return lra_set_err(ctx, LRA_ERR_INVALID, "the side context holds no prefetched seed result");
   lra_seed_state* a = seed_state(ctx); lra_seed_state* b = seed_state(side);
+  { int rcs = lra_seed_check_shared(side); if (rcs) { side->ahead.valid = false; return lra_set_err(ctx, LRA_ERR_INVALID, "the side context's reference data is stale: share it again"); } }
+  if (a->genome != b->genome || a->idx_key != b->idx_key || a->idx_pos != b->idx_pos || a->n_idx != b->n_idx)
+    return lra_set_err(ctx, LRA_ERR_INVALID, "the side context does not hold this context's reference data (lra_ctx_share_reference)");
   LRA_HIP_CHECK(ctx, hipSetDevice(ctx->device));
   LRA_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));                 // nothing of the mapping context's last batch still reads its seed buffers
 #define SW(f) std::swap(a->f, b->f)

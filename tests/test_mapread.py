@@ -579,4 +579,21 @@ def test_a_seed_result_made_ahead_on_a_side_context_gives_the_same_alignments(ct
         mapper.align(batch)
     mapper.copts.defer_seed_matches = 0
     assert mapper.records(mapper.align(batch), names, raw) == texts0
+    # a stage call on the mapping context between the adoption and the batch call overwrites the adopted buffers: the batch call then seeds itself
+    seed.seed_prefetch(side, batch, o.globalK, o.globalW, o.globalMaxFreq)
+    seed.adopt_seed(ctx, side)
+    seed.seed_batch(ctx, other, o.globalK, o.globalW, o.globalMaxFreq)
+    ctx.timing(True); ctx.timing_reset()
+    assert mapper.records(mapper.align(batch), names, raw) == texts0
+    assert ctx.timing_get("sketch_emit")[1] == 1
+    ctx.timing(False)
+    # a context that does not share this one's reference data is refused
+    stranger = Context(0)
+    g2 = synth.make_genome(200_000, seed=77)
+    ik2, ip2 = synth.build_global_index(g2, o.globalK, o.globalW, 100)
+    mapread.LowAccMapper(stranger, g2, ik2, ip2, [b"chrS"], [0, len(g2)], o)
+    seed.seed_prefetch(stranger, seed.ReadBatch(stranger, raw[:3]), o.globalK, o.globalW, o.globalMaxFreq)
+    with pytest.raises(LraError):
+        seed.adopt_seed(ctx, stranger)
+    stranger.close()
     side.close()
