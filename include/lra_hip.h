@@ -69,7 +69,7 @@ int lra_ctx_set_stream(lra_ctx* ctx, void* stream);
 const char* lra_ctx_last_error(lra_ctx* ctx);
 /* ABI version of the loaded library (tests check it against this header). */
 int lra_abi_version(void);
-#define LRA_ABI_VERSION 5   /* 2: lra_map_opts.defer_matches, lra_map_counters.n_deferred_reads; 3: lra_map_opts.flagged_unaligned, lra_map_counters.n_flagged_reads, lra_map_host_flagged; 4: lra_reads_last_error, a corrupt FASTQ record is LRA_ERR_INVALID; lra_map_opts.defer_seed_matches; 5: lra_seed_prefetch, lra_ctx_adopt_seed */
+#define LRA_ABI_VERSION 5   /* 2: lra_map_opts.defer_matches, lra_map_counters.n_deferred_reads; 3: lra_map_opts.flagged_unaligned, lra_map_counters.n_flagged_reads, lra_map_host_flagged; 4: lra_reads_last_error, a corrupt FASTQ record is LRA_ERR_INVALID; lra_map_opts.defer_seed_matches; 5: lra_seed_prefetch, lra_ctx_adopt_seed, lra_map_reads_lowacc_front / _back, lra_map_back_release */
 
 /* Convenience for hosts without their own HIP binding: synchronous device->host copy on the
  * context's stream (a C++ host would call hipMemcpy itself).                                */
@@ -999,6 +999,21 @@ const char* lra_ctx_genome_ptr(lra_ctx* ctx);
 int lra_ctx_local_index(lra_ctx* ctx, lra_local_index_result* out, const uint64_t** d_seq_offsets);
 int lra_map_reads_lowacc_batch(lra_ctx* ctx, int n_reads, const char* d_seq, const uint64_t* d_read_off, uint64_t total_bases, const lra_map_opts* opts,
                                lra_map_result* out);
+/* Two-stage batches (low-accuracy presets): lra_map_reads_lowacc_batch in two halves, so that the FRONT half of batch i + 1 runs beside the BACK half of batch i.
+ *   front: a1 .. the second LinearExtend / TrimOverlappedAnchors (Map_lowacc.h:69-476), on `ctx` and its stream, by one host thread;
+ *   back : the second sparse DP, LocalRefineAlignment, IndelRefineAlignment, CalculateStatistics (Map_lowacc.h:477-599), on the context's companion context
+ *          (made on first use: its own stream -- priority LRA_BACK_PRIORITY, default 0 --, its own work buffers, the reference data shared), by ANOTHER host thread.
+ * lra_map_reads_lowacc_front returns when the batch is handed over; it waits, at its very end, until the batch before has been through lra_map_reads_lowacc_back
+ * AND lra_map_back_release.  lra_map_reads_lowacc_back waits for a handed-over batch, runs its back half and returns the result of the whole batch exactly as
+ * lra_map_reads_lowacc_batch would (same alignments, same counters); the result's arrays belong to *back_ctx: lra_map_pack / lra_map_snapshot / lra_map_records are
+ * called on THAT context, then lra_map_back_release(ctx) gives the back context to the next batch.  The reads (d_seq, d_read_off) stay untouched until the back half
+ * has returned.  Calls alternate strictly per batch: front(i) before back(i); back(i), release(i) before front(i + 1) returns.  Scheduling only; opts.defer_matches and
+ * opts.defer_seed_matches do not combine with it (LRA_ERR_INVALID).  The reference's counterpart is its pool of worker threads (lra.cpp:678-714): several reads in
+ * flight at different points of MapRead. */
+int lra_map_reads_lowacc_front(lra_ctx* ctx, int n_reads, const char* d_seq, const uint64_t* d_read_off, uint64_t total_bases, const lra_map_opts* opts);
+int lra_map_reads_lowacc_back(lra_ctx* ctx, const lra_map_opts* opts, lra_map_result* out, lra_ctx** back_ctx);
+int lra_map_back_release(lra_ctx* ctx);
+
 /* The same boundary for the high-accuracy presets: MapRead_highacc (Map_highacc.h:37-798) behind MapRead (MapRead.h:169-239), which the reference enters
  * when opts.bypassClustering == 0 (-CCS, -CONTIG).  Arguments and result as lra_map_reads_lowacc_batch; job j = read j / num_aln, chain h = j % num_aln of
  * Primary_chains[0] (num_aln = opts.NumAln); d_job_reached[j] = the chain has clusters and got its SegAlignmentGroup (:697-699); d_first_sdp_value =

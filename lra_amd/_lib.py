@@ -42,6 +42,9 @@ SYMBOLS = {
     "lra_create_rc_batch": (C.c_int, [_vp, C.c_int, _vp, _vp, _vp]),
     "lra_sort_minimizers_batch": (C.c_int, [_vp, C.c_int, _vp, _vp, _vp]),
     "lra_seed_batch": (C.c_int, [_vp, C.c_int, _vp, _vp, C.c_int, C.c_int, C.c_int, _vp]),
+    "lra_map_reads_lowacc_front": (C.c_int, [_vp, C.c_int, _vp, _vp, C.c_uint64, _vp]),
+    "lra_map_reads_lowacc_back": (C.c_int, [_vp, _vp, _vp, _vp]),
+    "lra_map_back_release": (C.c_int, [_vp]),
     "lra_seed_prefetch": (C.c_int, [_vp, C.c_int, _vp, _vp, C.c_int, C.c_int, C.c_int]),
     "lra_ctx_adopt_seed": (C.c_int, [_vp, _vp]),
     "lra_clean_matches_batch": (C.c_int, [_vp, _vp, _vp, C.c_int, _vp]),

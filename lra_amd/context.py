@@ -21,6 +21,13 @@ class Context:
         self.h = h
         self.bind_stream()
 
+    @classmethod
+    def borrowed(cls, handle, device):
+        """A view of a context the library owns (the companion context of two-stage batches): never destroyed from here."""
+        c = cls.__new__(cls)
+        c.lib = load_library(); c.device = device; c.h = C.c_void_p(handle); c._borrowed = True
+        return c
+
     def bind_stream(self, stream=None):
         s = stream if stream is not None else torch.cuda.current_stream(self.device)
         self.check(self.lib.lra_ctx_set_stream(self.h, C.c_void_p(s.cuda_stream)))
@@ -58,7 +65,8 @@ class Context:
 
     def close(self):
         if self.h:
-            self.lib.lra_ctx_destroy(self.h)
+            if not getattr(self, "_borrowed", False):
+                self.lib.lra_ctx_destroy(self.h)
             self.h = None
 
     def __del__(self):

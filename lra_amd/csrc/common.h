@@ -13,6 +13,8 @@
 struct lra_seed_state;
 struct lra_cluster_state;
 struct lra_map_state;
+struct lra_handover;
+void lra_handover_free(lra_ctx* ctx);   // mapread.hip
 // The generation of a context's reference data, shared (refcounted) between the owner and every context that borrows from it, so that a borrower's staleness
 // check never reads the owner's state: `gen` is bumped by each of the owner's loaders, `dead` is set when the owner is destroyed (its device buffers are freed).
 struct lra_gen_cell { std::atomic<uint64_t> gen{0}; std::atomic<bool> dead{false}; };
@@ -47,6 +49,7 @@ struct lra_ctx {
   std::vector<hipEvent_t> free_events;
   lra_ctx* child = nullptr;                  // mapread.hip: the context of a batch's second, concurrent pass (shares this one's reference; destroyed with it)
   bool owns_stream = false;
+  struct lra_handover* handover = nullptr;   // mapread.hip: lra_map_reads_lowacc_front / _back (a batch between its two halves)
   // lra_seed_prefetch / lra_ctx_adopt_seed: a seed result made ahead of its batch -- on the side context the one lra_seed_prefetch left, on the mapping context the
   // one it adopted and lra_map_reads_lowacc_batch / lra_map_reads_highacc_batch will use instead of seeding when they are called with the same reads
   struct { bool valid = false; int n_reads = 0; const char* d_seq = nullptr; const uint64_t* d_read_off = nullptr; int k = 0, w = 0, max_freq = 0; lra_seed_result res; } ahead;

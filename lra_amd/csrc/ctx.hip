@@ -98,6 +98,7 @@ extern "C" void lra_ctx_destroy(lra_ctx* ctx) {
     for (int i = 0; i < 4; i++) if (ctx->scratch[i]) { tot += ctx->scratch_bytes[i]; fprintf(stderr, "[mem] ctx %p scratch %d: %8.2f GB\n", (void*)ctx, i, ctx->scratch_bytes[i] / 1e9); }
     fprintf(stderr, "[mem] ctx %p buffers + scratch: %.2f GB (aux %.2f GB, out %.2f GB)\n", (void*)ctx, tot / 1e9, ctx->aux_bytes / 1e9, ctx->out_bytes / 1e9);
   }
+  lra_handover_free(ctx);
   if (ctx->child) { lra_ctx_destroy(ctx->child); ctx->child = nullptr; }   // borrows this context's reference: first
   (void)hipSetDevice(ctx->device);
   (void)hipStreamSynchronize(ctx->stream);

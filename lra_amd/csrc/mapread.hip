@@ -19,6 +19,7 @@
 #include <algorithm>
 #include <thread>
 #include <mutex>
+#include <condition_variable>
 #include <functional>
 
 void lra_map_free(lra_ctx* ctx) {
@@ -451,8 +452,17 @@ struct LowaccTailIn {
 };
 static int lowacc_tail(lra_ctx* ctx, const LowaccTailIn& in, const lra_map_opts* o, lra_map_result* out);
 
+// A batch between its two halves (lra_map_reads_lowacc_front / _back): what the tail needs, and whose turn it is with the back context.
+struct lra_handover {
+  std::mutex mu; std::condition_variable cv;
+  int state = 0;           // 0: the back context is free; 1: a batch is handed over, its back half not yet started; 2: the back half runs, or its result is still in use
+  LowaccTailIn in;
+};
+void lra_handover_free(lra_ctx* ctx) { delete ctx->handover; ctx->handover = nullptr; }
+
 static int lowacc_core(lra_ctx* ctx, int n_reads, const char* d_seq, const uint64_t* d_read_off, uint64_t total_bases, const lra_map_opts* o, lra_map_result* out,
-                       uint32_t defer_threshold, std::vector<uint32_t>* deferred, lra_ctx* second, LowaccTailIn* second_in, const std::function<int()>& on_deferred) {
+                       uint32_t defer_threshold, std::vector<uint32_t>* deferred, lra_ctx* second, LowaccTailIn* second_in, const std::function<int()>& on_deferred,
+                       lra_handover* H = nullptr) {
   memset(out, 0, sizeof *out);
   lra_map_state* m = ctx->map;
   out->n_reads = n_reads;
@@ -630,6 +640,26 @@ static int lowacc_core(lra_ctx* ctx, int n_reads, const char* d_seq, const uint6
     }
     stage("deferred reads");
   }
+  if (H) {
+    // The front half ends here (lra_map_reads_lowacc_front): MergeChain .. TrimOverlappedAnchors write into the BACK context's buffers (queued on this stream: they read
+    // the first sparse DP's and the refinement's arrays), and the four buffers of this half that the tail reads -- the reads with their reverse complements, the chains'
+    // NumOfAnchors0, the slots reached, the reads' status words -- change owner with the back context's (no copy).  Not before the back context is free: the batch
+    // before this one has been through its back half and its result has been released.
+    lra_ctx* b = ctx->child;
+    { std::unique_lock<std::mutex> lk(H->mu); H->cv.wait(lk, [&] { return H->state == 0; }); }
+    LRA_HIP_CHECK(ctx, hipStreamSynchronize(b->stream));
+    for (int slot : {56, 57, 81, 82}) { std::swap(ctx->gbuf[slot], b->gbuf[slot]); std::swap(ctx->gbytes[slot], b->gbytes[slot]); }
+    const hipStream_t keep = b->stream;
+    b->stream = st;
+    rc = lra_merge_extend_batch(b, &chres, &spres, &bres, d_seq, d_read_off, genome, CH, nCh, o->localK, &in.mres);
+    b->stream = keep;
+    if (rc) return lra_set_err(ctx, rc, "MergeChain into the back context: %s", b->err.c_str());
+    LRA_HIP_CHECK(ctx, hipStreamSynchronize(st));
+    stage("merge_extend");
+    { std::lock_guard<std::mutex> lk(H->mu); H->in = in; H->state = 1; }
+    H->cv.notify_all();
+    return LRA_OK;
+  }
   // a9 MergeChain, a7 second pass (Map_lowacc.h:411-476)
   if ((rc = lra_merge_extend_batch(ctx, &chres, &spres, &bres, d_seq, d_read_off, genome, CH, nCh, o->localK, &in.mres))) return rc;
   stage("merge_extend");
@@ -756,6 +786,37 @@ int lra_map_count_flagged(lra_ctx* ctx, lra_map_result* out) {
   return LRA_OK;
 }
 
+// The context's companion (a batch's second, concurrent pass; the back half of two-stage batches): a context of its own -- stream, work buffers -- that borrows this
+// one's reference data.  `lowest`: its streams at the device's lowest priority (the second pass fills the gaps the first one leaves; at equal priority the two passes'
+// queues slow each other down far beyond the work involved, measured); otherwise at LRA_BACK_PRIORITY (default 0, the default priority).
+static int ensure_child(lra_ctx* ctx, bool lowest) {
+  LRA_HIP_CHECK(ctx, hipSetDevice(ctx->device));
+  if (!ctx->child) {
+    lra_ctx* c = nullptr;
+    int rc = lra_ctx_create(ctx->device, &c);
+    if (rc) return lra_set_err(ctx, rc, "companion context");
+    if ((rc = lra_ctx_share_reference(c, ctx))) { lra_ctx_destroy(c); return lra_set_err(ctx, rc, "companion context: sharing the reference"); }
+    int least = 0, greatest = 0;
+    (void)hipDeviceGetStreamPriorityRange(&least, &greatest);
+    int prio = least;
+    if (!lowest) { prio = getenv("LRA_BACK_PRIORITY") ? atoi(getenv("LRA_BACK_PRIORITY")) : 0; prio = std::max(greatest, std::min(least, prio)); }
+    c->low_priority = true; c->prio = prio;                               // (low_priority: the context keeps the priority it was made with, lra_ctx_set_stream)
+    if (hipStreamCreateWithPriority(&c->stream, hipStreamNonBlocking, prio) != hipSuccess) { c->stream = nullptr; lra_ctx_destroy(c); return lra_set_err(ctx, LRA_ERR_HIP, "companion stream"); }
+    c->owns_stream = true; c->timing = ctx->timing;
+    ctx->child = c;
+  }
+  {                                                                      // the parent's reference may have been loaded / built again since the last batch
+    lra_ctx* c = ctx->child;
+    int rc = lra_seed_share(c, ctx);
+    if (rc) return lra_set_err(ctx, rc, "companion context: sharing the reference");
+    lra_map_state* d = c->map; const lra_map_state* s = ctx->map;
+    d->chrom_pos = s->chrom_pos; d->d_chrom_pos = s->d_chrom_pos; d->gli_buf = s->gli_buf; d->gli = s->gli; d->d_gso = s->d_gso; d->n_gwin = s->n_gwin;
+    d->gli_window = s->gli_window; d->lut = s->lut; d->borrowed = true;
+    d->owner_cell = s->borrowed ? s->owner_cell : s->cell; d->owner_generation = s->borrowed ? s->owner_generation : s->cell->gen.load();
+  }
+  return LRA_OK;
+}
+
 static int lowacc_batch_impl(lra_ctx* ctx, int n_reads, const char* d_seq, const uint64_t* d_read_off, uint64_t total_bases, const lra_map_opts* o, lra_map_result* out);
 extern "C" int lra_map_reads_lowacc_batch(lra_ctx* ctx, int n_reads, const char* d_seq, const uint64_t* d_read_off, uint64_t total_bases,
                                           const lra_map_opts* o, lra_map_result* out) {
@@ -778,29 +839,7 @@ static int lowacc_batch_impl(lra_ctx* ctx, int n_reads, const char* d_seq, const
   if (const char* e = getenv("LRA_DEFER_MATCHES")) threshold = (uint32_t)std::max(0, atoi(e));
   const std::function<int()> none;
   if (!threshold) return lowacc_core(ctx, n_reads, d_seq, d_read_off, total_bases, o, out, 0, nullptr, nullptr, nullptr, none);
-  LRA_HIP_CHECK(ctx, hipSetDevice(ctx->device));
-  if (!ctx->child) {                                                     // the second pass's context: its own (lowest-priority) streams, this one's reference
-    lra_ctx* c = nullptr;
-    int rc = lra_ctx_create(ctx->device, &c);
-    if (rc) return lra_set_err(ctx, rc, "second-pass context");
-    if ((rc = lra_ctx_share_reference(c, ctx))) { lra_ctx_destroy(c); return lra_set_err(ctx, rc, "second-pass context: sharing the reference"); }
-    int least = 0, greatest = 0;
-    (void)hipDeviceGetStreamPriorityRange(&least, &greatest);
-    // the second pass fills the gaps the first one leaves; at equal priority the two passes' queues slow each other down far beyond the work involved (measured)
-    c->low_priority = true; c->prio = least;
-    if (hipStreamCreateWithPriority(&c->stream, hipStreamNonBlocking, least) != hipSuccess) { c->stream = nullptr; lra_ctx_destroy(c); return lra_set_err(ctx, LRA_ERR_HIP, "second-pass stream"); }
-    c->owns_stream = true; c->timing = ctx->timing;
-    ctx->child = c;
-  }
-  {                                                                      // the parent's reference may have been loaded / built again since the last batch
-    lra_ctx* c = ctx->child;
-    int rc = lra_seed_share(c, ctx);
-    if (rc) return lra_set_err(ctx, rc, "second-pass context: sharing the reference");
-    lra_map_state* d = c->map; const lra_map_state* s = ctx->map;
-    d->chrom_pos = s->chrom_pos; d->d_chrom_pos = s->d_chrom_pos; d->gli_buf = s->gli_buf; d->gli = s->gli; d->d_gso = s->d_gso; d->n_gwin = s->n_gwin;
-    d->gli_window = s->gli_window; d->lut = s->lut; d->borrowed = true;
-    d->owner_cell = s->borrowed ? s->owner_cell : s->cell; d->owner_generation = s->borrowed ? s->owner_generation : s->cell->gen.load();
-  }
+  { int rcc = ensure_child(ctx, true); if (rcc) return rcc; }
   std::vector<uint32_t> picked;
   std::thread second;
   int rc2 = LRA_OK;
@@ -858,6 +897,57 @@ static int lowacc_batch_impl(lra_ctx* ctx, int n_reads, const char* d_seq, const
   c.n_large_spaces += b.n_large_spaces; c.n_segments += b.n_segments; c.n_rows += b.n_rows; c.n_cells += b.n_cells; c.n_aog += b.n_aog;
   c.n_deferred_reads = a.counters.n_deferred_reads + (uint64_t)R2;
   out->counters = c;
+  return LRA_OK;
+}
+
+// ---- two-stage batches: a batch's front half (a1 .. the second LinearExtend) on the context, its back half (second sparse DP .. statistics) on the companion
+// context, so that batch i + 1's front half runs BESIDE batch i's back half (two host threads).  The front half is short wide kernels and rounds of small latency-bound
+// launches, the back half is the sparse DP over the merged clusters and the banded refinement: side by side each fills what the other leaves idle.
+static int front_checks(lra_ctx* ctx, int n_reads, const lra_map_opts* o) {
+  if (!ctx || !o || n_reads < 0) return LRA_ERR_INVALID;
+  lra_map_state* m = ctx->map;
+  if (!m || !m->gli_buf || !ctx->seed || !ctx->seed->genome || !ctx->seed->idx_key)
+    return lra_set_err(ctx, LRA_ERR_INVALID, "reference not loaded (genome, global index, chromosome table, local index)");
+  if (m->gli_window != o->localIndexWindow) return lra_set_err(ctx, LRA_ERR_INVALID, "local index built with another window");
+  if (o->defer_matches > 0 || o->defer_seed_matches > 0 || getenv("LRA_DEFER_MATCHES")) return lra_set_err(ctx, LRA_ERR_INVALID, "two-stage batches do not combine with defer_matches / defer_seed_matches");
+  return lra_map_check_shared(ctx);
+}
+extern "C" int lra_map_reads_lowacc_front(lra_ctx* ctx, int n_reads, const char* d_seq, const uint64_t* d_read_off, uint64_t total_bases, const lra_map_opts* o) {
+  { int rc = front_checks(ctx, n_reads, o); if (rc) return rc; }
+  { int rc = ensure_child(ctx, false); if (rc) return rc; }
+  if (!ctx->handover) ctx->handover = new lra_handover();
+  lra_handover* H = ctx->handover;
+  if (n_reads == 0) {                                                     // an empty batch still takes its turn with the back context
+    { std::unique_lock<std::mutex> lk(H->mu); H->cv.wait(lk, [&] { return H->state == 0; }); H->in = LowaccTailIn(); H->in.n_reads = 0; H->state = 1; }
+    H->cv.notify_all();
+    return LRA_OK;
+  }
+  lra_map_result tmp;
+  const std::function<int()> none;
+  return lowacc_core(ctx, n_reads, d_seq, d_read_off, total_bases, o, &tmp, 0, nullptr, nullptr, nullptr, none, H);
+}
+extern "C" int lra_map_reads_lowacc_back(lra_ctx* ctx, const lra_map_opts* o, lra_map_result* out, lra_ctx** back_ctx) {
+  if (!ctx || !o || !out) return LRA_ERR_INVALID;
+  lra_handover* H = ctx->handover;
+  if (!H || !ctx->child) return lra_set_err(ctx, LRA_ERR_INVALID, "no front half has been run on this context");
+  if (back_ctx) *back_ctx = ctx->child;
+  LowaccTailIn in;
+  { std::unique_lock<std::mutex> lk(H->mu); H->cv.wait(lk, [&] { return H->state == 1; }); in = H->in; H->state = 2; }
+  memset(out, 0, sizeof *out);
+  lra_ctx* b = ctx->child;
+  b->map->last_text.clear(); b->map->last_sig = lra_map_sig{};
+  out->n_reads = in.n_reads;
+  if (in.n_reads == 0) return LRA_OK;
+  int rc = lowacc_tail(b, in, o, out);
+  if (rc == LRA_OK) rc = lra_map_count_flagged(b, out);
+  if (rc) return lra_set_err(ctx, rc, "back half: %s", b->err.c_str());
+  return LRA_OK;
+}
+extern "C" int lra_map_back_release(lra_ctx* ctx) {
+  if (!ctx || !ctx->handover) return LRA_ERR_INVALID;
+  lra_handover* H = ctx->handover;
+  { std::lock_guard<std::mutex> lk(H->mu); if (H->state != 2) return lra_set_err(ctx, LRA_ERR_INVALID, "no back half's result is held"); H->state = 0; }
+  H->cv.notify_all();
   return LRA_OK;
 }
 

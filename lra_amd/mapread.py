@@ -224,6 +224,33 @@ class LowAccMapper:
                           n_mm=int(c.n_minimizers), n_match=int(c.n_matches), n_seg=int(c.n_segments))
         return res
 
+    # ---- two-stage batches (include/lra_hip.h: lra_map_reads_lowacc_front / _back): front(i + 1) on one host thread beside back(i) on another
+    def front(self, rbatch):
+        ctx = self.ctx
+        ctx.check(ctx.lib.lra_map_reads_lowacc_front(ctx.h, rbatch.n, C.c_void_p(rbatch.seq.data_ptr()), C.c_void_p(rbatch.off.data_ptr()),
+                                                     C.c_uint64(int(rbatch.total_bases)), C.byref(self.copts)))
+
+    def back(self):
+        """-> (MapResult, the back context its arrays belong to: pack / snapshot / records / fetch through a mapper view on it, then release())"""
+        ctx = self.ctx
+        res = MapResult(); bh = C.c_void_p()
+        ctx.check(ctx.lib.lra_map_reads_lowacc_back(ctx.h, C.byref(self.copts), C.byref(res), C.byref(bh)))
+        c = res.counters
+        self.stats.update({n: int(getattr(c, n)) for n, _ in MapCounters._fields_})
+        self.stats.update(n_alignments=int(res.n_alignments), n_blocks=int(res.n_blocks), n_cigar_runs=int(res.n_runs),
+                          n_mm=int(c.n_minimizers), n_match=int(c.n_matches), n_seg=int(c.n_segments))
+        return res, Context.borrowed(bh.value, ctx.device)
+
+    def release(self):
+        self.ctx.check(self.ctx.lib.lra_map_back_release(self.ctx.h))
+
+    def on(self, ctx):
+        """This mapper's options and host-side tables bound to another context (the back context of two-stage batches)."""
+        import copy
+        m = copy.copy(self)
+        m.ctx = ctx
+        return m
+
     def fetch(self, res: MapResult):
         """Host copies of a batch result: per job the alignment range, per alignment its fields, refined blocks, counters, NV and CIGAR."""
         ctx = self.ctx

@@ -597,3 +597,68 @@ def test_a_seed_result_made_ahead_on_a_side_context_gives_the_same_alignments(ct
         seed.adopt_seed(ctx, stranger)
     stranger.close()
     side.close()
+
+
+@pytest.mark.gpu
+def test_two_stage_batches_give_the_same_records_with_the_front_half_of_the_next_batch_beside_the_back_half(ctx):
+    """lra_map_reads_lowacc_front / _back / lra_map_back_release (scheduling only): three batches through the two halves -- the front half of batch i + 1 on one host
+    thread while the back half of batch i runs on another -- give the records, counters and status words lra_map_reads_lowacc_batch gives for each of them; an empty
+    batch passes through; the handback options are refused."""
+    import threading
+    from lra_amd import seed, mapread
+    from lra_amd import LraError
+    genome = synth.make_genome(700_000, seed=41, repeat_frac=0.3, n_families=3)
+    o = mapread.LowAccOptions()
+    ik, ip = synth.build_global_index(genome, o.globalK, o.globalW, 100)
+    mapper = mapread.LowAccMapper(ctx, genome, ik, ip, [b"chr1"], [0, len(genome)], o)
+    batches = []
+    for b in range(3):
+        reads, _ = synth.simulate_reads(genome, 14 + 3 * b, 7000, 3000, 0.10, seed=50 + b)
+        if b == 1:
+            reads.append(np.frombuffer(b"ACGT", dtype=np.uint8)[np.random.default_rng(3).integers(0, 4, 1500)].copy())      # an unalignable read
+        raw = [r.tobytes() for r in reads]
+        batches.append((seed.ReadBatch(ctx, raw), [b"b%d_%d" % (b, i) for i in range(len(raw))], raw))
+    want = []
+    for rb, names, raw in batches:
+        res = mapper.align(rb)
+        want.append((mapper.records(res, names, raw), dict(mapper.stats), ctx.to_host(res.d_read_status, rb.n, np.uint32)))
+    got, err = [None] * len(batches), []
+
+    def fronts():
+        try:
+            for rb, _, _ in batches:
+                mapper.front(rb)
+        except BaseException as e:
+            err.append(e)
+
+    def backs():
+        try:
+            for i, (rb, names, raw) in enumerate(batches):
+                res, bctx = mapper.back()
+                mb = mapper.on(bctx)
+                got[i] = (mb.records(res, names, raw), dict(mapper.stats), bctx.to_host(res.d_read_status, rb.n, np.uint32))
+                mapper.release()
+        except BaseException as e:
+            err.append(e)
+    tf, tb = threading.Thread(target=fronts), threading.Thread(target=backs)
+    tf.start(); tb.start(); tf.join(); tb.join()
+    assert not err, err
+    for i in range(len(batches)):
+        assert got[i][0] == want[i][0], i
+        assert np.array_equal(got[i][2], want[i][2])
+        for k in ("n_alignments", "n_blocks", "n_cigar_runs", "n_mm", "n_match", "n_sdp_anchors", "n_sdp2_anchors", "n_refined_after_btwn", "n_segments", "n_cells", "n_flagged_reads"):
+            assert got[i][1][k] == want[i][1][k], (i, k)
+    # the one-call entry point still works on the same context afterwards, and an empty batch goes through the two halves
+    rb, names, raw = batches[0]
+    assert mapper.records(mapper.align(rb), names, raw) == want[0][0]
+    empty = seed.ReadBatch(ctx, [])
+    mapper.front(empty)
+    res, bctx = mapper.back()
+    assert int(res.n_reads) == 0 and int(res.n_alignments) == 0
+    mapper.release()
+    with pytest.raises(LraError):
+        mapper.release()                                                  # nothing held
+    mapper.copts.defer_seed_matches = 50
+    with pytest.raises(LraError):
+        mapper.front(rb)
+    mapper.copts.defer_seed_matches = 0
