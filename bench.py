@@ -120,6 +120,8 @@ def main():
     ap.add_argument("--heavy-lane", type=int, default=int(os.environ.get("LRA_BENCH_HEAVY_LANE", 1)),
                     help="1 = the batches of handed-back reads run on a context of their own (low-priority streams) beside the next steps; 0 = on lane 0, between steps")
     ap.add_argument("--heavy-pool", type=int, default=int(os.environ.get("LRA_BENCH_HEAVY_POOL", 4096)), help="handed-back reads per batch of their own")
+    ap.add_argument("--two-stage", type=int, default=int(os.environ.get("LRA_BENCH_TWO_STAGE", 1)),
+                    help="1 = two-stage batches (lra_map_reads_lowacc_front / _back): the front half of step i + 1 on one host thread beside the back half of step i on another")
     ap.add_argument("--seed-ahead", type=int, default=int(os.environ.get("LRA_BENCH_SEED_AHEAD", 1)),
                     help="1 = a step's seed stage (a1-a4) runs beside the step before it, on a side context (lra_seed_prefetch / lra_ctx_adopt_seed); 0 = every step seeds itself")
     ap.add_argument("--seed-ahead-delay-ms", type=float, default=float(os.environ.get("LRA_BENCH_SEED_AHEAD_DELAY_MS", 300)),
@@ -238,7 +240,11 @@ def main():
         except BaseException as e:
             err.append(e)
 
-    ahead_on = bool(args.seed_ahead) and args.lanes == 1 and not defer_T
+    two_stage = bool(args.two_stage) and args.lanes == 1 and not defer_T
+    ahead_on = bool(args.seed_ahead) and args.lanes == 1 and not defer_T and not two_stage
+    if two_stage:                                                          # the front halves are the work done ahead: below the back halves' priority
+        fstream_ = torch.cuda.Stream(device=dev_index, priority=prio_lo)
+        ctx.bind_stream(fstream_)
     ahead = {}
     if ahead_on:
         ahead["ctx"] = Context(dev_index)
@@ -275,6 +281,17 @@ def main():
                             seed.adopt_seed(lc, ahead["ctx"])
                     ahead["thread"] = threading.Thread(target=seed_ahead, args=(sub,))
                     ahead["thread"].start()
+                if two_stage:
+                    # this thread runs the back halves (the front halves: front_loop, a thread of its own); the result's arrays belong to the back context
+                    res, bc = lane["mapper"].back()
+                    lane["last_res"] = res
+                    if not args.no_records:
+                        d_buf, nb = C.c_void_p(), C.c_uint64(0)
+                        bc.check(bc.lib.lra_map_pack(bc.h, C.byref(res), 0, C.byref(d_buf), C.byref(nb)))
+                        lane["packed"] = bc.to_tensor(d_buf.value, nb.value, torch.uint8)
+                        bc.to_host(d_buf.value, 1, np.uint8)               # (a synchronous copy: the back context's own stream is through the pack and the copy)
+                    lane["mapper"].release()
+                    return
                 res = lane["mapper"].align(sub["rbatch"])
                 lane["last_res"] = res
                 if args.no_records:
@@ -443,9 +460,24 @@ def main():
         except BaseException as e:
             err.append(e)
 
+    def front_loop(n_steps):
+        try:
+            torch.cuda.set_device(dev_index)
+            for _ in range(n_steps):
+                for sub in subs:
+                    if err:
+                        return
+                    lanes[0]["mapper"].front(sub["rbatch"])
+        except BaseException as e:
+            err.append(e)
+
     def run_steps(n_steps, stagger):
         work["items"] = [(s_, j) for s_ in range(n_steps) for j in range(len(subs))]
         work["next"] = 0
+        ft = None
+        if two_stage and n_steps > 0:
+            ft = threading.Thread(target=front_loop, args=(n_steps,))
+            ft.start()
         hw = None
         if defer_T and args.heavy_lane:
             hw = threading.Thread(target=heavy_worker)
@@ -459,6 +491,8 @@ def main():
             ths = [threading.Thread(target=lane_loop, args=(li, stagger * li / len(lanes))) for li in range(len(lanes))]
             for t in ths: t.start()
             for t in ths: t.join()
+        if ft is not None:
+            ft.join()
         th_ = ahead.get("thread")
         if th_ is not None:                                                # (the seeding of the batch after the last one: joined here, so that a run of n steps holds n of them)
             th_.join()
@@ -576,6 +610,7 @@ def main():
                          "step_algorithmic_bytes": step_alg, "step_frac": step_alg / (ms_step * 1e-3) / 1e9 / 8000.0},
             "sam_text_gb_per_step": round(text_bytes[0] / max(args.steps, 1) / 1e9, 3),
             "lane_items": [l["n_items"] for l in lanes],
+            "two_stage": {"on": bool(two_stage), "what": "lra_map_reads_lowacc_front / _back: the front half (a1 .. the second LinearExtend) of step i + 1 on the context (low-priority stream, its own host thread) beside the back half (second sparse DP .. statistics) of step i on the companion context"},
             "seed_ahead": {"on": bool(ahead_on), "delay_ms": args.seed_ahead_delay_ms,
                            "what": "a1-a4 of step i + 1 on a side context (low-priority stream, own host thread) beside step i; every timed step holds one alignment pass and one seeding"},
             "handed_back": {"defer_seed_matches": defer_T, "pool": args.heavy_pool, "reads_per_step": round(heavy["reads"] / max(args.steps, 1), 1), "batches": heavy["batches"]},

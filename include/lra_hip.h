@@ -1002,7 +1002,7 @@ int lra_map_reads_lowacc_batch(lra_ctx* ctx, int n_reads, const char* d_seq, con
 /* Two-stage batches (low-accuracy presets): lra_map_reads_lowacc_batch in two halves, so that the FRONT half of batch i + 1 runs beside the BACK half of batch i.
  *   front: a1 .. the second LinearExtend / TrimOverlappedAnchors (Map_lowacc.h:69-476), on `ctx` and its stream, by one host thread;
  *   back : the second sparse DP, LocalRefineAlignment, IndelRefineAlignment, CalculateStatistics (Map_lowacc.h:477-599), on the context's companion context
- *          (made on first use: its own stream -- priority LRA_BACK_PRIORITY, default 0 --, its own work buffers, the reference data shared), by ANOTHER host thread.
+ *          (made on first use: its own stream -- the device's highest priority unless LRA_BACK_PRIORITY says otherwise --, its own work buffers, the reference data shared), by ANOTHER host thread.
  * lra_map_reads_lowacc_front returns when the batch is handed over; it waits, at its very end, until the batch before has been through lra_map_reads_lowacc_back
  * AND lra_map_back_release.  lra_map_reads_lowacc_back waits for a handed-over batch, runs its back half and returns the result of the whole batch exactly as
  * lra_map_reads_lowacc_batch would (same alignments, same counters); the result's arrays belong to *back_ctx: lra_map_pack / lra_map_snapshot / lra_map_records are

@@ -459,6 +459,12 @@ struct lra_handover {
   LowaccTailIn in;
 };
 void lra_handover_free(lra_ctx* ctx) { delete ctx->handover; ctx->handover = nullptr; }
+static lra_handover* handover_of(lra_ctx* ctx) {                         // (the two halves' threads may both be the first to ask)
+  static std::mutex make;
+  std::lock_guard<std::mutex> lk(make);
+  if (!ctx->handover) ctx->handover = new lra_handover();
+  return ctx->handover;
+}
 
 static int lowacc_core(lra_ctx* ctx, int n_reads, const char* d_seq, const uint64_t* d_read_off, uint64_t total_bases, const lra_map_opts* o, lra_map_result* out,
                        uint32_t defer_threshold, std::vector<uint32_t>* deferred, lra_ctx* second, LowaccTailIn* second_in, const std::function<int()>& on_deferred,
@@ -788,7 +794,7 @@ int lra_map_count_flagged(lra_ctx* ctx, lra_map_result* out) {
 
 // The context's companion (a batch's second, concurrent pass; the back half of two-stage batches): a context of its own -- stream, work buffers -- that borrows this
 // one's reference data.  `lowest`: its streams at the device's lowest priority (the second pass fills the gaps the first one leaves; at equal priority the two passes'
-// queues slow each other down far beyond the work involved, measured); otherwise at LRA_BACK_PRIORITY (default 0, the default priority).
+// queues slow each other down far beyond the work involved, measured); otherwise at LRA_BACK_PRIORITY (default: the device's highest -- the back half of a batch is the longer one, the front half of the next fills in).
 static int ensure_child(lra_ctx* ctx, bool lowest) {
   LRA_HIP_CHECK(ctx, hipSetDevice(ctx->device));
   if (!ctx->child) {
@@ -799,7 +805,7 @@ static int ensure_child(lra_ctx* ctx, bool lowest) {
     int least = 0, greatest = 0;
     (void)hipDeviceGetStreamPriorityRange(&least, &greatest);
     int prio = least;
-    if (!lowest) { prio = getenv("LRA_BACK_PRIORITY") ? atoi(getenv("LRA_BACK_PRIORITY")) : 0; prio = std::max(greatest, std::min(least, prio)); }
+    if (!lowest) { prio = getenv("LRA_BACK_PRIORITY") ? atoi(getenv("LRA_BACK_PRIORITY")) : greatest; prio = std::max(greatest, std::min(least, prio)); }
     c->low_priority = true; c->prio = prio;                               // (low_priority: the context keeps the priority it was made with, lra_ctx_set_stream)
     if (hipStreamCreateWithPriority(&c->stream, hipStreamNonBlocking, prio) != hipSuccess) { c->stream = nullptr; lra_ctx_destroy(c); return lra_set_err(ctx, LRA_ERR_HIP, "companion stream"); }
     c->owns_stream = true; c->timing = ctx->timing;
@@ -915,8 +921,7 @@ static int front_checks(lra_ctx* ctx, int n_reads, const lra_map_opts* o) {
 extern "C" int lra_map_reads_lowacc_front(lra_ctx* ctx, int n_reads, const char* d_seq, const uint64_t* d_read_off, uint64_t total_bases, const lra_map_opts* o) {
   { int rc = front_checks(ctx, n_reads, o); if (rc) return rc; }
   { int rc = ensure_child(ctx, false); if (rc) return rc; }
-  if (!ctx->handover) ctx->handover = new lra_handover();
-  lra_handover* H = ctx->handover;
+  lra_handover* H = handover_of(ctx);
   if (n_reads == 0) {                                                     // an empty batch still takes its turn with the back context
     { std::unique_lock<std::mutex> lk(H->mu); H->cv.wait(lk, [&] { return H->state == 0; }); H->in = LowaccTailIn(); H->in.n_reads = 0; H->state = 1; }
     H->cv.notify_all();
@@ -928,13 +933,12 @@ extern "C" int lra_map_reads_lowacc_front(lra_ctx* ctx, int n_reads, const char*
 }
 extern "C" int lra_map_reads_lowacc_back(lra_ctx* ctx, const lra_map_opts* o, lra_map_result* out, lra_ctx** back_ctx) {
   if (!ctx || !o || !out) return LRA_ERR_INVALID;
-  lra_handover* H = ctx->handover;
-  if (!H || !ctx->child) return lra_set_err(ctx, LRA_ERR_INVALID, "no front half has been run on this context");
-  if (back_ctx) *back_ctx = ctx->child;
+  lra_handover* H = handover_of(ctx);
   LowaccTailIn in;
-  { std::unique_lock<std::mutex> lk(H->mu); H->cv.wait(lk, [&] { return H->state == 1; }); in = H->in; H->state = 2; }
+  { std::unique_lock<std::mutex> lk(H->mu); H->cv.wait(lk, [&] { return H->state == 1; }); in = H->in; H->state = 2; }   // (waits for a front half, however long)
   memset(out, 0, sizeof *out);
-  lra_ctx* b = ctx->child;
+  lra_ctx* b = ctx->child;                                               // (made by the front half)
+  if (back_ctx) *back_ctx = b;
   b->map->last_text.clear(); b->map->last_sig = lra_map_sig{};
   out->n_reads = in.n_reads;
   if (in.n_reads == 0) return LRA_OK;

@@ -1242,9 +1242,12 @@ extern "C" int lra_seed_batch(lra_ctx* ctx, int n_reads, const char* d_seq, cons
   uint64_t total_bases = 0;
   LRA_HIP_CHECK(ctx, hipMemcpyAsync(&total_bases, d_read_off + n_reads, 8, hipMemcpyDeviceToHost, st));
   LRA_HIP_CHECK(ctx, hipStreamSynchronize(st));
-  uint64_t* wkey = (uint64_t*)lra_ensure(ctx, 99, (size_t)total_bases * 8 + 256);
-  uint32_t* wpos = (uint32_t*)lra_ensure(ctx, 100, (size_t)total_bases * 4 + 256);
-  if (!wkey || !wpos) return LRA_ERR_NOMEM;
+  // (the staging arrays -- 12 bytes per base of the batch -- live in the sparse DP's arena, slot 12: the seed stage comes first in a batch, the arena is dead until the
+  // first sparse DP, and what the batch before left there -- IndelRefine's and CalculateStatistics' arrays -- belonged to a result that ends with this call)
+  char* stg = (char*)lra_ensure(ctx, 12, (size_t)total_bases * 12 + 1024);
+  if (!stg) return LRA_ERR_NOMEM;
+  uint64_t* wkey = (uint64_t*)stg;
+  uint32_t* wpos = (uint32_t*)(stg + (((size_t)total_bases * 8 + 255) & ~(size_t)255));
   lra_time_begin(ctx, "sketch_emit");
   hipLaunchKernelGGL(sketch_wave_kernel<true>, dim3(gridW), dim3(64), 0, st, n_reads, seq, d_read_off, k, w, d_read_off, wkey, wpos, s->counts32, flagN);
   lra_time_end(ctx);

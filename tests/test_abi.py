@@ -53,7 +53,7 @@ def test_product_does_not_reference_the_oracle():
 # that outlives its call (results handed back to the caller) must never be another stage's scratch (the sort's scratch sat in
 # fine_clusters.hip's result slots).
 _SHARED_SLOTS = {
-    12: "the sparse DP arena, reused by IndelRefine / CalculateStatistics once the arena is dead (DESIGN 6b, Memory)",
+    12: "the sparse DP arena, reused by IndelRefine / CalculateStatistics once the arena is dead (DESIGN 6b, Memory) and by the minimizer sketch's staging arrays before it is alive (seed.hip)",
     **{s: "AffineOneGapAlign glue of between_anchors / refine_breakpoint: per-call scratch, dead at return" for s in (18, 19, 20, 21)},
     **{s: "tier-2 glue: refine_clusters (high-accuracy driver) / refine_splitchain (low-accuracy driver), results of the last call only" for s in (27, 28, 29)},
     **{s: "the two drivers' own buffers: one driver call per context at a time" for s in list(range(57, 66)) + [81, 82, 171, 173, 175]},
