@@ -283,14 +283,19 @@ def main():
                     ahead["thread"].start()
                 if two_stage:
                     # this thread runs the back halves (the front halves: front_loop, a thread of its own); the result's arrays belong to the back context
-                    res, bc = lane["mapper"].back()
-                    lane["last_res"] = res
-                    if not args.no_records:
-                        d_buf, nb = C.c_void_p(), C.c_uint64(0)
-                        bc.check(bc.lib.lra_map_pack(bc.h, C.byref(res), 0, C.byref(d_buf), C.byref(nb)))
-                        lane["packed"] = bc.to_tensor(d_buf.value, nb.value, torch.uint8)
-                        bc.to_host(d_buf.value, 1, np.uint8)               # (a synchronous copy: the back context's own stream is through the pack and the copy)
-                    lane["mapper"].release()
+                    try:
+                        res, bc = lane["mapper"].back()
+                        lane["last_res"] = res
+                        if not args.no_records and not err:
+                            d_buf, nb = C.c_void_p(), C.c_uint64(0)
+                            bc.check(bc.lib.lra_map_pack(bc.h, C.byref(res), 0, C.byref(d_buf), C.byref(nb)))
+                            lane["packed"] = bc.to_tensor(d_buf.value, nb.value, torch.uint8)
+                            bc.to_host(d_buf.value, 1, np.uint8)           # (a synchronous copy: the back context's own stream is through the pack and the copy)
+                    finally:
+                        try:
+                            lane["mapper"].release()                       # (whatever happened: the front thread waits for this)
+                        except BaseException:
+                            pass
                     return
                 res = lane["mapper"].align(sub["rbatch"])
                 lane["last_res"] = res
@@ -436,7 +441,7 @@ def main():
             prev = None
             while True:
                 it = take_item()
-                if it is None or err:
+                if it is None or (err and not two_stage):                  # (two-stage batches: the front thread hands over a batch per item whatever happens; each is taken)
                     break
                 s_, j = it
                 if j < 0:                                                  # (--heavy-lane 0) a batch of handed-back reads, between two steps
@@ -463,11 +468,18 @@ def main():
     def front_loop(n_steps):
         try:
             torch.cuda.set_device(dev_index)
+            done = 0
             for _ in range(n_steps):
                 for sub in subs:
-                    if err:
-                        return
-                    lanes[0]["mapper"].front(sub["rbatch"])
+                    if not err:
+                        try:
+                            lanes[0]["mapper"].front(sub["rbatch"])
+                            done += 1
+                            continue
+                        except BaseException as e:
+                            err.append(e)
+                    # after an error the back thread still waits for a batch per item: an empty one (no device work), so that the run ends and reports the error
+                    lanes[0]["mapper"].front(seed.read_batch_from_device(ctx, torch.zeros(64, dtype=torch.uint8, device=dev), torch.zeros(1, dtype=torch.int64, device=dev)))
         except BaseException as e:
             err.append(e)
 
