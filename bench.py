@@ -616,6 +616,8 @@ def main():
                        "per_step": {k: int(v) for k, v in stats.items() if not k.startswith("_") and isinstance(v, (int, float))},
                        "reads_with_sv": n_sv},
             "kernel_ms_per_step": {k: round(v[0] / args.steps, 4) for k, v in ktimes.items() if v[1]},
+            "kernel_ms_note": ("HIP-event time of each kernel family on its own stream; with two-stage batches / the seed stage ahead two contexts run side by side, so the "
+                               "families stretch each other and sum to more than the step") if (two_stage or ahead_on) else "HIP-event time of each kernel family on its stream",
             "roofline": {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": 8000.0, "unit": "GB/s", "frac": achieved / 8000.0,
                          "traffic": traffic, "avg_launch_ms": avg_ms, "algorithmic_bytes_per_launch": alg,
                          "footprint_bytes_per_launch": fp, "frac_footprint": (fp / (avg_ms * 1e-3) / 1e9 / 8000.0) if avg_ms > 0 else 0.0,
