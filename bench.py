@@ -122,6 +122,8 @@ def main():
     ap.add_argument("--heavy-pool", type=int, default=int(os.environ.get("LRA_BENCH_HEAVY_POOL", 4096)), help="handed-back reads per batch of their own")
     ap.add_argument("--two-stage", type=int, default=int(os.environ.get("LRA_BENCH_TWO_STAGE", 1)),
                     help="1 = two-stage batches (lra_map_reads_lowacc_front / _back): the front half of step i + 1 on one host thread beside the back half of step i on another")
+    ap.add_argument("--front-priority", default=os.environ.get("LRA_BENCH_FRONT_PRIORITY", "low"), choices=["low", "normal"],
+                    help="with --two-stage: the stream priority of the front halves (the back halves: LRA_BACK_PRIORITY, default the highest)")
     ap.add_argument("--seed-ahead", type=int, default=int(os.environ.get("LRA_BENCH_SEED_AHEAD", 1)),
                     help="1 = a step's seed stage (a1-a4) runs beside the step before it, on a side context (lra_seed_prefetch / lra_ctx_adopt_seed); 0 = every step seeds itself")
     ap.add_argument("--seed-ahead-delay-ms", type=float, default=float(os.environ.get("LRA_BENCH_SEED_AHEAD_DELAY_MS", 300)),
@@ -243,7 +245,7 @@ def main():
     two_stage = bool(args.two_stage) and args.lanes == 1 and not defer_T
     ahead_on = bool(args.seed_ahead) and args.lanes == 1 and not defer_T and not two_stage
     if two_stage:                                                          # the front halves are the work done ahead: below the back halves' priority
-        fstream_ = torch.cuda.Stream(device=dev_index, priority=prio_lo)
+        fstream_ = torch.cuda.Stream(device=dev_index, priority=prio_lo if args.front_priority == "low" else 0)
         ctx.bind_stream(fstream_)
     ahead = {}
     if ahead_on:

@@ -652,7 +652,9 @@ static int lowacc_core(lra_ctx* ctx, int n_reads, const char* d_seq, const uint6
     // NumOfAnchors0, the slots reached, the reads' status words -- change owner with the back context's (no copy).  Not before the back context is free: the batch
     // before this one has been through its back half and its result has been released.
     lra_ctx* b = ctx->child;
+    const double tw0 = wall();
     { std::unique_lock<std::mutex> lk(H->mu); H->cv.wait(lk, [&] { return H->state == 0; }); }
+    if (getenv("LRA_TWO_STAGE_DBG")) fprintf(stderr, "[two-stage] front half waited %.0f ms for the back context\n", wall() - tw0);
     LRA_HIP_CHECK(ctx, hipStreamSynchronize(b->stream));
     for (int slot : {56, 57, 81, 82}) { std::swap(ctx->gbuf[slot], b->gbuf[slot]); std::swap(ctx->gbytes[slot], b->gbytes[slot]); }
     const hipStream_t keep = b->stream;
@@ -935,7 +937,9 @@ extern "C" int lra_map_reads_lowacc_back(lra_ctx* ctx, const lra_map_opts* o, lr
   if (!ctx || !o || !out) return LRA_ERR_INVALID;
   lra_handover* H = handover_of(ctx);
   LowaccTailIn in;
+  const double tw0 = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count();
   { std::unique_lock<std::mutex> lk(H->mu); H->cv.wait(lk, [&] { return H->state == 1; }); in = H->in; H->state = 2; }   // (waits for a front half, however long)
+  if (getenv("LRA_TWO_STAGE_DBG")) fprintf(stderr, "[two-stage] back half waited %.0f ms for a front half\n", std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count() - tw0);
   memset(out, 0, sizeof *out);
   lra_ctx* b = ctx->child;                                               // (made by the front half)
   if (back_ctx) *back_ctx = b;
