@@ -49,6 +49,8 @@ struct lra_ctx {
   std::vector<hipEvent_t> free_events;
   lra_ctx* child = nullptr;                  // mapread.hip: the context of a batch's second, concurrent pass (shares this one's reference; destroyed with it)
   bool owns_stream = false;
+  bool pipelined = false;                    // two-stage batches (lra_map_reads_lowacc_front / _back): another batch's half runs beside this context's launches, so the
+                                             // sparse DP chooses for device time (fewer workgroup-per-read jobs: one per CU) rather than for the shortest tail
   struct lra_handover* handover = nullptr;   // mapread.hip: lra_map_reads_lowacc_front / _back (a batch between its two halves)
   // lra_seed_prefetch / lra_ctx_adopt_seed: a seed result made ahead of its batch -- on the side context the one lra_seed_prefetch left, on the mapping context the
   // one it adopted and lra_map_reads_lowacc_batch / lra_map_reads_highacc_batch will use instead of seeding when they are called with the same reads

@@ -842,6 +842,7 @@ static int lowacc_batch_impl(lra_ctx* ctx, int n_reads, const char* d_seq, const
   { int rcs = lra_map_check_shared(ctx); if (rcs) return rcs; }
   out->n_reads = n_reads;
   m->last_text.clear(); m->last_sig = lra_map_sig{};         // a sizing call of lra_map_records for an earlier batch is void now
+  ctx->pipelined = false;                                    // (the one call: nothing runs beside it)
   if (n_reads == 0) return LRA_OK;
   uint32_t threshold = o->defer_matches > 0 ? (uint32_t)o->defer_matches : 0;
   if (const char* e = getenv("LRA_DEFER_MATCHES")) threshold = (uint32_t)std::max(0, atoi(e));
@@ -923,6 +924,7 @@ static int front_checks(lra_ctx* ctx, int n_reads, const lra_map_opts* o) {
 extern "C" int lra_map_reads_lowacc_front(lra_ctx* ctx, int n_reads, const char* d_seq, const uint64_t* d_read_off, uint64_t total_bases, const lra_map_opts* o) {
   { int rc = front_checks(ctx, n_reads, o); if (rc) return rc; }
   { int rc = ensure_child(ctx, false); if (rc) return rc; }
+  ctx->pipelined = true; ctx->child->pipelined = true;
   lra_handover* H = handover_of(ctx);
   if (n_reads == 0) {                                                     // an empty batch still takes its turn with the back context
     { std::unique_lock<std::mutex> lk(H->mu); H->cv.wait(lk, [&] { return H->state == 0; }); H->in = LowaccTailIn(); H->in.n_reads = 0; H->state = 1; }

@@ -1845,7 +1845,11 @@ static long sdp_big_points(const lra_ctx* ctx, int mode) {
   if (const char* e = getenv("LRA_SDP_BIG_POINTS")) return atol(e);
   if (ctx->sdp_inner) return 1500;
   if (mode == 0) { if (const char* e = getenv("LRA_SDP_BIG_POINTS_A")) return atol(e); return 2500; }   // (its largest reads have ~5000 points: the top few hundred as workgroups, 93 -> 83 ms)
-  return 6000;
+  if (const char* e = getenv("LRA_SDP_BIG_POINTS_2")) return atol(e);
+  // Two-stage batches: the other half of another batch fills what a long tail leaves idle, and a wave per read costs a third of the device time per point that a
+  // workgroup per read does -- so only the reads that would make the wave launch far longer than everything beside it stay workgroup jobs (measured, two-stage step:
+  // 6000: 980 ms, 9000: 954, 12000: 943, 14000: 933, 16000+: up again; each with at most one job per CU, see maxBig)
+  return ctx->pipelined ? 14000 : 6000;
 }
 template <bool EMIT>
 static void launch_small_builds(lra_ctx* ctx, const BuildArgs& ba, const uint32_t* d_order, const std::vector<uint32_t>& h_order, const uint64_t* h_pt, int from, int to) {
@@ -2167,7 +2171,9 @@ int sdp_run(lra_ctx* ctx, int n_reads, const uint64_t* d_cluster_off, const uint
         const std::vector<uint32_t>& ord = att == 0 ? h_orderAll : h_prev;
         // ... but no more of them than the device runs side by side (a workgroup holds 16 wave slots for a per-point latency a third of the wave kernel's, at 3.5 times its
         // wave-time per point): beyond that the large reads queue up behind each other, and the ones further down the order are better off as one wave each
-        static const int maxBigAll = getenv("LRA_SDP_MAX_BIG") ? std::max(0, atoi(getenv("LRA_SDP_MAX_BIG"))) : (1 << 30);
+        static const int maxBigEnv = getenv("LRA_SDP_MAX_BIG") ? std::max(0, atoi(getenv("LRA_SDP_MAX_BIG"))) : -1;
+        // (two-stage batches: one round of workgroup jobs -- one per CU, all resident at once; 192: 1026 ms, 256: 933, 320: 955)
+        const int maxBigAll = maxBigEnv >= 0 ? maxBigEnv : ctx->pipelined ? ctx->num_cu : (1 << 30);
         static const int maxBigA = getenv("LRA_SDP_MAX_BIG_A") ? std::max(0, atoi(getenv("LRA_SDP_MAX_BIG_A"))) : 512;
         const int maxBig = (opts->mode == 0 && !ctx->sdp_inner) ? std::min(maxBigAll, maxBigA) : maxBigAll;
         while (nbig < nsub && nbig < maxBig && (long)(h_pt[r0 + ord[nbig] + 1] - h_pt[r0 + ord[nbig]]) >= big_pts) nbig++;
