@@ -928,7 +928,7 @@ int lra_aog_launch_device(lra_ctx* ctx, int n, const char* d_qseq, const char* d
   a.counts = (int*)s0; a.offs = a.counts + 32; a.cursor = a.counts + 64; a.list = (int*)(s0 + 384); a.cls8 = (unsigned char*)(a.list + n);
   // class 2: 4 MiB slots, LRA_AOG_SLOTS (default 8) per CU -- with the scores of most of these problems in LDS (rolling, see solve) a wave's HBM traffic is its
   // arrows, and a CU can keep more of them in flight; class 6: 8 MiB slots, one per CU, for the rare larger problem (1.5 kb x 1.5 kb at k = 60, 5 kb x 5 kb at k = 15)
-  const int perCu = std::max(1, getenv("LRA_AOG_SLOTS") ? atoi(getenv("LRA_AOG_SLOTS")) : 8);   // (a zero or non-numeric value would leave the HBM class without a slot)
+  const int perCu = std::max(1, getenv("LRA_AOG_SLOTS") ? atoi(getenv("LRA_AOG_SLOTS")) : ctx->pipelined ? 6 : 8);   // (a zero or non-numeric value would leave the HBM class without a slot; two-stage batches: 6 -- step 955 -> 939 ms)
   a.gslots = ctx->num_cu * perCu; a.gslot_bytes = 4L << 20;
   a.chunk_bytes = std::min(8192, std::max(1024, getenv("LRA_AOG_CHUNK") ? atoi(getenv("LRA_AOG_CHUNK")) : 8192)) & ~255;
   a.gslotsB = ctx->num_cu; a.gslotB_bytes = 8L << 20;

@@ -1868,7 +1868,10 @@ static void launch_small_builds(lra_ctx* ctx, const BuildArgs& ba, const uint32_
     if (mid > from) { BuildArgs bb = ba; bb.order = d_order + from; hipLaunchKernelGGL((sdp_build<EMIT, 1, 0>), dim3(mid - from), dim3(64), 0, st, bb); }
     if (cut[0] > mid) {
       BuildArgs bb = ba; bb.order = d_order + mid;
-      static const int occ = getenv("LRA_SDP_BUILD_OCC") ? atoi(getenv("LRA_SDP_BUILD_OCC")) : 8;   // waves per SIMD the register budget is set for (tuning)
+      // waves per SIMD the register budget is set for: 8; beside another batch's half (two-stage batches) 6 -- fewer, fatter waves leave the other half's launches room
+      // (two-stage step 952 -> 937 ms; in the one call 8 is the faster one)
+      static const int occEnv = getenv("LRA_SDP_BUILD_OCC") ? atoi(getenv("LRA_SDP_BUILD_OCC")) : 0;
+      const int occ = occEnv ? occEnv : ctx->pipelined ? 6 : 8;
       if (occ == 4) hipLaunchKernelGGL((sdp_build<EMIT, 1, 2, 4>), dim3(cut[0] - mid), dim3(64), 0, st, bb);
       else if (occ == 5) hipLaunchKernelGGL((sdp_build<EMIT, 1, 2, 5>), dim3(cut[0] - mid), dim3(64), 0, st, bb);
       else if (occ == 6) hipLaunchKernelGGL((sdp_build<EMIT, 1, 2, 6>), dim3(cut[0] - mid), dim3(64), 0, st, bb);
