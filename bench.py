@@ -243,7 +243,7 @@ def main():
             err.append(e)
 
     two_stage = bool(args.two_stage) and args.lanes == 1 and not defer_T
-    ahead_on = bool(args.seed_ahead) and args.lanes == 1 and not defer_T and not two_stage
+    ahead_on = bool(args.seed_ahead) and args.lanes == 1 and not defer_T and (not two_stage or args.seed_ahead == 2)   # (2: also with two-stage batches -- an experiment)
     if two_stage:                                                          # the front halves are the work done ahead: below the back halves' priority
         fstream_ = torch.cuda.Stream(device=dev_index, priority=prio_lo if args.front_priority == "low" else 0)
         ctx.bind_stream(fstream_)
@@ -273,7 +273,7 @@ def main():
             lc = lane["ctx"]
             def run():
                 tA_ = time.perf_counter()
-                if ahead_on:
+                if ahead_on and not two_stage:
                     # the seeding of the NEXT step's batch beside this step (lra_seed_prefetch on a side context, low-priority stream, a host thread of its own), and this
                     # step's own seed result -- made beside the previous step -- adopted instead of seeding: every timed step runs one alignment pass and one seeding
                     th_ = ahead.pop("thread", None)
@@ -475,6 +475,14 @@ def main():
                 for sub in subs:
                     if not err:
                         try:
+                            if ahead_on:                                   # (--seed-ahead 2: the seed stage of the front half after this one on a third context)
+                                th_ = ahead.pop("thread", None)
+                                if th_ is not None:
+                                    th_.join()
+                                    if ahead.pop("ok", False):
+                                        seed.adopt_seed(ctx, ahead["ctx"])
+                                ahead["thread"] = threading.Thread(target=seed_ahead, args=(sub,))
+                                ahead["thread"].start()
                             lanes[0]["mapper"].front(sub["rbatch"])
                             done += 1
                             continue
