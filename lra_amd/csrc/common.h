@@ -92,6 +92,14 @@ int lra_launch_linear_extend(lra_ctx* ctx, uint64_t n_clusters, int K, const uin
                              const unsigned char* seq, const uint64_t* read_off, uint32_t* e_q, uint32_t* e_t, int* e_len, uint32_t* e_count, uint32_t* box,
                              const int* c_K = nullptr);
 
+// emit.hip / rank.hip: the record text appended to a string (the C entry points lra_format_* / lra_output_read wrap these)
+int lra_format_bed_str(const lra_aln_record* r, std::string& s_);
+int lra_format_paf_str(const lra_aln_record* r, int print_cigar, std::string& s_);
+int lra_format_sam_str(const lra_aln_record* g, int n_group, int as, int hard_clip, const char* passthrough, std::string& s_);
+int lra_format_sam_simple_str(const lra_aln_record* rp, int hard_clip, const char* passthrough, std::string& s_);
+int lra_output_read_str(const lra_aln_group* groups, const int32_t* index, int n_groups, lra_aln_record* recs, int print_num_aln, char format, int hard_clip,
+                        const char* passthrough, int read_unaligned, const lra_aln_record* unaligned_rec, std::string& text);
+
 #define LRA_HIP_CHECK(ctx, call)                                                         \
   do {                                                                                   \
     hipError_t e__ = (call);                                                             \

@@ -35,16 +35,24 @@ void unaligned_record(std::ostream& o, const lra_aln_record& r) {      // :663-6
 
 }  // namespace
 
-extern "C" int lra_format_bed(const lra_aln_record* r, char* out, uint64_t cap, uint64_t* len) {
+// (the text appended to s_: the record writers build a read's records in one string, once)
+int lra_format_bed_str(const lra_aln_record* r, std::string& s_) {
   if (!r) return LRA_ERR_INVALID;
   std::ostringstream o;
   o << r->chrom << "\t" << r->t_start << "\t" << r->t_end << "\t" << (int)(unsigned char)r->mapqv << "\t" << r->read_name << "\t" << r->read_len << "\t"
     << r->q_start << "\t" << r->q_end << "\t" << r->nm << "\t" << r->nmm << "\t" << r->nins << "\t" << r->ndel << "\t" << r->value << "\t" << r->flag << "\t"
     << r->NumOfAnchors1 << "\t" << r->NumOfAnchors1 / (float)r->read_len << std::endl;
-  return deliver(o.str(), out, cap, len);
+  s_ += o.str();
+  return LRA_OK;
+}
+extern "C" int lra_format_bed(const lra_aln_record* r, char* out, uint64_t cap, uint64_t* len) {
+  std::string s_;
+  const int rc = lra_format_bed_str(r, s_);
+  return rc ? rc : deliver(s_, out, cap, len);
 }
 
-extern "C" int lra_format_paf(const lra_aln_record* r, int print_cigar, char* out, uint64_t cap, uint64_t* len) {
+// (the text appended to s_: the record writers build a read's records in one string, once)
+int lra_format_paf_str(const lra_aln_record* r, int print_cigar, std::string& s_) {
   if (!r) return LRA_ERR_INVALID;
   std::ostringstream o;
   const char strandChar = r->strand == 1 ? '-' : '+';
@@ -61,11 +69,17 @@ extern "C" int lra_format_paf(const lra_aln_record* r, int print_cigar, char* ou
   if (r->runtime > 0) o << "\tRT:i:" << r->runtime;
   if (print_cigar) { o << "\tCG:z:"; clipped_cigar(o, *r, 'S'); }
   o << std::endl;
-  return deliver(o.str(), out, cap, len);
+  s_ += o.str();
+  return LRA_OK;
+}
+extern "C" int lra_format_paf(const lra_aln_record* r, int print_cigar, char* out, uint64_t cap, uint64_t* len) {
+  std::string s_;
+  const int rc = lra_format_paf_str(r, print_cigar, s_);
+  return rc ? rc : deliver(s_, out, cap, len);
 }
 
-extern "C" int lra_format_sam(const lra_aln_record* g, int n_group, int as, int hard_clip, const char* passthrough, char* out, uint64_t cap,
-                              uint64_t* len) {
+// (the text appended to s_: the record writers build a read's records in one string, once)
+int lra_format_sam_str(const lra_aln_record* g, int n_group, int as, int hard_clip, const char* passthrough, std::string& s_) {
   if (!g || n_group < 1 || as < 0 || as >= n_group) return LRA_ERR_INVALID;
   const lra_aln_record& r = g[as];
   std::ostringstream o;
@@ -100,10 +114,18 @@ extern "C" int lra_format_sam(const lra_aln_record* g, int n_group, int as, int 
   }
   if (passthrough) o << "\t" << passthrough;
   o << std::endl;
-  return deliver(o.str(), out, cap, len);
+  s_ += o.str();
+  return LRA_OK;
+}
+extern "C" int lra_format_sam(const lra_aln_record* g, int n_group, int as, int hard_clip, const char* passthrough, char* out, uint64_t cap,
+                              uint64_t* len) {
+  std::string s_;
+  const int rc = lra_format_sam_str(g, n_group, as, hard_clip, passthrough, s_);
+  return rc ? rc : deliver(s_, out, cap, len);
 }
 
-extern "C" int lra_format_sam_simple(const lra_aln_record* rp, int hard_clip, const char* passthrough, char* out, uint64_t cap, uint64_t* len) {
+// (the text appended to s_: the record writers build a read's records in one string, once)
+int lra_format_sam_simple_str(const lra_aln_record* rp, int hard_clip, const char* passthrough, std::string& s_) {
   if (!rp) return LRA_ERR_INVALID;
   const lra_aln_record& r = *rp;
   std::ostringstream o;
@@ -131,7 +153,13 @@ extern "C" int lra_format_sam_simple(const lra_aln_record* rp, int hard_clip, co
   }
   if (passthrough) o << "\t" << passthrough;
   o << std::endl;
-  return deliver(o.str(), out, cap, len);
+  s_ += o.str();
+  return LRA_OK;
+}
+extern "C" int lra_format_sam_simple(const lra_aln_record* rp, int hard_clip, const char* passthrough, char* out, uint64_t cap, uint64_t* len) {
+  std::string s_;
+  const int rc = lra_format_sam_simple_str(rp, hard_clip, passthrough, s_);
+  return rc ? rc : deliver(s_, out, cap, len);
 }
 
 // The SAM header lra writes before the first record: "@PG" (lra.cpp:665-671) and GenomeHeader::WriteSAMHeader (Genome.h:85-89).

@@ -1249,9 +1249,9 @@ extern "C" int lra_map_records_host(lra_map_host* h, const lra_map_opts* o, cons
       else if (unaligned || recs.empty()) {
         lra_aln_record un; memset(&un, 0, sizeof un);
         un.read_name = names[r]; un.read = reads[r]; un.qual = quals ? quals[r] : nullptr; un.read_len = read_len[r];
-        lra_output_read(nullptr, nullptr, 0, nullptr, o->PrintNumAln, (char)o->printFormat, o->hardClip, passthrough, 1, &un, nullptr, 0, &need);
-        buf.resize(need + 1);
-        if ((rc = lra_output_read(nullptr, nullptr, 0, nullptr, o->PrintNumAln, (char)o->printFormat, o->hardClip, passthrough, 1, &un, buf.data(), need, &need))) break;
+        const size_t before = text.size();
+        if ((rc = lra_output_read_str(nullptr, nullptr, 0, nullptr, o->PrintNumAln, (char)o->printFormat, o->hardClip, passthrough, 1, &un, text))) break;
+        need = text.size() - before;
       } else {
         const int n = (int)seg_off.size() - 1;
         groups.assign(n, lra_aln_group()); index.assign(n, 0);
@@ -1259,12 +1259,11 @@ extern "C" int lra_map_records_host(lra_map_host* h, const lra_map_opts* o, cons
             (rc = lra_simple_mapqv(groups.data(), index.data(), n, recs.data(), o->bypassClustering, o->readType == LRA_READ_CLR, o->readType == LRA_READ_ONT,
                                    (hi && !sparseRead) ? o->globalK : o->localK)))                         // SimpleMapQV(alignmentsOrder, read, smallOpts): smallOpts.globalK = glIndex.k (Map_lowacc.h:233, :610); = opts.globalK on the high-accuracy path (Map_highacc.h:402, :736)
           break;
-        lra_output_read(groups.data(), index.data(), n, recs.data(), o->PrintNumAln, (char)o->printFormat, o->hardClip, passthrough, 0, nullptr, nullptr, 0, &need);
-        buf.resize(need + 1);
-        if ((rc = lra_output_read(groups.data(), index.data(), n, recs.data(), o->PrintNumAln, (char)o->printFormat, o->hardClip, passthrough, 0, nullptr, buf.data(), need,
-                                  &need))) break;
+        // (the records' text goes straight into the thread's part, written once: the sizing-then-filling calls of the C entry points formatted every record four times)
+        const size_t before = text.size();
+        if ((rc = lra_output_read_str(groups.data(), index.data(), n, recs.data(), o->PrintNumAln, (char)o->printFormat, o->hardClip, passthrough, 0, nullptr, text))) break;
+        need = text.size() - before;
       }
-      text.append(buf.data(), need);
       plen[tix].push_back(need);
     }
     prc[tix] = rc;

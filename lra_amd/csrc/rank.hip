@@ -137,19 +137,17 @@ extern "C" int lra_simple_mapqv(const lra_aln_group* groups, const int32_t* inde
 // OUTPUT Mapping_ultility.h:453-493 (+ output_unaligned :445-451): the first min(n_groups, PrintNumAln) alignments in order, each one's
 // segments last to first with order = size-1-s; format 's' SAM, 'b' BED, 'p' PAF, 'P' PAF with CIGAR ("pc").  unaligned_rec is used when
 // the read has no alignment and read_unaligned is set (SimplePrintSAM, format 's' only).  ('a', PrintPairwise, is not built.)
-extern "C" int lra_output_read(const lra_aln_group* groups, const int32_t* index, int n_groups, lra_aln_record* recs, int print_num_aln, char format,
-                               int hard_clip, const char* passthrough, int read_unaligned, const lra_aln_record* unaligned_rec, char* out, uint64_t cap,
-                               uint64_t* len) {
+// (every record's text is written once, straight into `text`; the sizing-call convention of the C entry point is kept by the wrapper below)
+int lra_output_read_str(const lra_aln_group* groups, const int32_t* index, int n_groups, lra_aln_record* recs, int print_num_aln, char format, int hard_clip,
+                        const char* passthrough, int read_unaligned, const lra_aln_record* unaligned_rec, std::string& text) {
   if (n_groups < 0 || (n_groups > 0 && (!groups || !index || !recs))) return LRA_ERR_INVALID;
-  std::string text;
   std::vector<char> buf;
-  auto add = [&](int rc, uint64_t n) { (void)rc; text.append(buf.data(), (size_t)n); };
-  auto call = [&](auto&& fn) {
+  auto call = [&](auto&& fn) {                                          // (the pairwise format only: its C formatter sizes, then fills)
     uint64_t n = 0;
     fn((char*)nullptr, (uint64_t)0, &n);
     buf.resize((size_t)n + 1);
     const int rc = fn(buf.data(), n, &n);
-    add(rc, n);
+    text.append(buf.data(), (size_t)n);
     return rc;
   };
   if (n_groups > 0 && groups[index[0]].count > 0) {
@@ -160,9 +158,9 @@ extern "C" int lra_output_read(const lra_aln_group* groups, const int32_t* index
       for (int s = G.count - 1; s >= 0; s--) {
         S[s].order = G.count - 1 - s;
         int rc = LRA_OK;
-        if (format == 'b') rc = call([&](char* o, uint64_t c, uint64_t* l) { return lra_format_bed(&S[s], o, c, l); });
-        else if (format == 's') rc = call([&](char* o, uint64_t c, uint64_t* l) { return lra_format_sam(S, G.count, s, hard_clip, passthrough, o, c, l); });
-        else if (format == 'p' || format == 'P') rc = call([&](char* o, uint64_t c, uint64_t* l) { return lra_format_paf(&S[s], format == 'P', o, c, l); });
+        if (format == 'b') rc = lra_format_bed_str(&S[s], text);
+        else if (format == 's') rc = lra_format_sam_str(S, G.count, s, hard_clip, passthrough, text);
+        else if (format == 'p' || format == 'P') rc = lra_format_paf_str(&S[s], format == 'P', text);
         else if (format == 'a') {                                         // PrintPairwise (Alignment.h:564-589) on CreateAlignmentStrings' strings
           const lra_aln_record& R = S[s];
           if (!R.blocks || !R.strand_read || !R.chrom_text) return LRA_ERR_INVALID;
@@ -181,10 +179,18 @@ extern "C" int lra_output_read(const lra_aln_group* groups, const int32_t* index
     }
   } else if (read_unaligned == 1) {
     if (format == 's' && unaligned_rec) {
-      const int rc = call([&](char* o, uint64_t c, uint64_t* l) { return lra_format_sam_simple(unaligned_rec, hard_clip, passthrough, o, c, l); });
+      const int rc = lra_format_sam_simple_str(unaligned_rec, hard_clip, passthrough, text);
       if (rc) return rc;
     }
   }
+  return LRA_OK;
+}
+extern "C" int lra_output_read(const lra_aln_group* groups, const int32_t* index, int n_groups, lra_aln_record* recs, int print_num_aln, char format,
+                               int hard_clip, const char* passthrough, int read_unaligned, const lra_aln_record* unaligned_rec, char* out, uint64_t cap,
+                               uint64_t* len) {
+  std::string text;
+  const int rc = lra_output_read_str(groups, index, n_groups, recs, print_num_aln, format, hard_clip, passthrough, read_unaligned, unaligned_rec, text);
+  if (rc) return rc;
   if (len) *len = text.size();
   if (!out || cap < text.size()) return text.empty() ? LRA_OK : LRA_ERR_INVALID;
   memcpy(out, text.data(), text.size());
