@@ -82,22 +82,30 @@ extern "C" int lra_format_paf(const lra_aln_record* r, int print_cigar, char* ou
 int lra_format_sam_str(const lra_aln_record* g, int n_group, int as, int hard_clip, const char* passthrough, std::string& s_) {
   if (!g || n_group < 1 || as < 0 || as >= n_group) return LRA_ERR_INVALID;
   const lra_aln_record& r = g[as];
+  // The long fields -- CIGAR, read, qualities: 40 KB of a 30 kb read's 43 KB record -- are appended to s_ as they are; the short ones go through an ostream as the
+  // reference's do (the float fields print through the same libstdc++), in pieces flushed between the long fields.
   std::ostringstream o;
+  auto flush = [&]() { s_ += o.str(); o.str(std::string()); };
+  auto cigar = [&](const lra_aln_record& x, char clipOp) {               // clipped_cigar, appended
+    if (x.pre_clip > 0) { s_ += std::to_string(x.pre_clip); s_ += clipOp; }
+    if (x.cigar) s_ += x.cigar;
+    if (x.suf_clip > 0) { s_ += std::to_string(x.suf_clip); s_ += clipOp; }
+  };
   o << r.read_name << "\t";
   if (r.n_blocks == 0) unaligned_record(o, r);
   else {
     o << (unsigned int)r.flag << "\t" << r.chrom << "\t" << (uint32_t)(r.t_start + 1) << "\t" << (unsigned int)(unsigned char)r.mapqv << "\t";
-    clipped_cigar(o, r, (r.supplementary && hard_clip) ? 'H' : 'S');
+    flush();
+    cigar(r, (r.supplementary && hard_clip) ? 'H' : 'S');
     o << "\t*\t0\t" << (uint32_t)(r.t_end - r.t_start) << "\t";
-    if (!r.supplementary) o.write(r.read, r.read_len);
-    else if (hard_clip) o.write(r.read + r.q_start, (std::streamsize)(r.q_end - r.q_start));
-    else o.write(r.read, r.read_len);
-    std::string qualStr;
-    if (r.qual == nullptr || r.qual[0] == '*') qualStr = "*";
-    else if (r.supplementary && hard_clip) qualStr = std::string(std::string(r.qual), r.first_block_qpos, r.last_block_qend - r.first_block_qpos);
-    else qualStr.assign(r.qual, (size_t)r.read_len);
-    o << "\t";
-    if (r.qual == nullptr) o << "*"; else o << qualStr;
+    flush();
+    if (!r.supplementary) s_.append(r.read, (size_t)r.read_len);
+    else if (hard_clip) s_.append(r.read + r.q_start, (size_t)(r.q_end - r.q_start));
+    else s_.append(r.read, (size_t)r.read_len);
+    s_ += "\t";
+    if (r.qual == nullptr || r.qual[0] == '*') s_ += "*";
+    else if (r.supplementary && hard_clip) s_ += std::string(std::string(r.qual), r.first_block_qpos, r.last_block_qend - r.first_block_qpos);
+    else s_.append(r.qual, (size_t)r.read_len);
     o << "\tNM:i:" << r.nmm + r.ndel + r.nins << "\tMM:i:" << r.nmm + r.ndel + r.nins << "\tNX:i:" << r.nmm << "\tND:i:" << r.ndel << "\tTD:i:" << r.tdel
       << "\tNI:i:" << r.nins << "\tTI:i:" << r.tins << "\tNV:f:" << r.value << "\tAS:i:" << (int)r.value << "\tAO:i:" << r.order
       << "\tN0:i:" << r.NumOfAnchors0 << "\tRT:i:" << r.runtime << "\tTP:A:" << tp_of(r.typeofaln)
@@ -108,13 +116,14 @@ int lra_format_sam_str(const lra_aln_record* g, int n_group, int as, int hard_cl
     for (int ag = n_group - 1; ag >= 0; ag--) {
       if (ag == as) continue;
       o << g[ag].chrom << "," << (uint32_t)(g[ag].t_start + 1) << "," << (g[ag].strand == 0 ? "+" : "-") << ",";
-      clipped_cigar(o, g[ag], 'S');
+      flush();
+      cigar(g[ag], 'S');
       o << "," << (unsigned int)(unsigned char)g[ag].mapqv << "," << (int)g[ag].nm << ";";
     }
   }
   if (passthrough) o << "\t" << passthrough;
   o << std::endl;
-  s_ += o.str();
+  flush();
   return LRA_OK;
 }
 extern "C" int lra_format_sam(const lra_aln_record* g, int n_group, int as, int hard_clip, const char* passthrough, char* out, uint64_t cap,
