@@ -1008,6 +1008,30 @@ struct PoolBlock { void* p; size_t cap; };
 std::vector<PoolBlock> g_pool;                                           // at most POOL_KEEP blocks, the largest ones
 constexpr size_t POOL_KEEP = 6, POOL_MIN = 8u << 20;
 }  // namespace
+// the record threads' parts of a batch's text (lra_map_records_host): strings kept between batches with their capacity -- a part is ~100 MB, and a fresh one is
+// 25 000 page faults and a chain of doubling reallocations
+namespace {
+std::mutex g_parts_mu;
+std::vector<std::string> g_parts;
+std::string part_take(size_t want) {
+  std::string s;
+  {
+    std::lock_guard<std::mutex> lk(g_parts_mu);
+    int best = -1;
+    for (int i = 0; i < (int)g_parts.size(); i++) if (best < 0 || g_parts[i].capacity() > g_parts[best].capacity()) best = i;
+    if (best >= 0) { s.swap(g_parts[best]); g_parts.erase(g_parts.begin() + best); }
+  }
+  s.clear();
+  if (s.capacity() < want) s.reserve(want);
+  return s;
+}
+void part_give(std::string& s) {
+  s.clear();
+  std::lock_guard<std::mutex> lk(g_parts_mu);
+  if (g_parts.size() < 64 && s.capacity() >= (8u << 20)) { g_parts.emplace_back(); g_parts.back().swap(s); }
+  else std::string().swap(s);
+}
+}  // namespace
 void* lra_host_pool_get(size_t bytes, size_t* cap) {
   {
     std::lock_guard<std::mutex> lk(g_pool_mu);
@@ -1173,6 +1197,12 @@ extern "C" int lra_map_records_host(lra_map_host* h, const lra_map_opts* o, cons
   auto work = [&](int tix) {
     const int lo = (int)((long)n_reads * tix / T), hi = (int)((long)n_reads * (tix + 1) / T);
     std::string& text = part[tix];
+    {                                                                     // room for the range's text: the reads, their CIGAR runs (~3.3 characters each), the tags
+      size_t want = 4096;
+      for (int r = lo; r < hi; r++) want += (size_t)read_len[r] + 700;
+      if (nJ && jo.size() > (size_t)hi * na) { const uint64_t a0 = jo[(size_t)lo * na], a1 = jo[(size_t)hi * na]; if (a1 < roff.size() && a0 <= a1) want += (size_t)((roff[a1] - roff[a0]) * 7 / 2) + (size_t)(a1 - a0) * 600; }
+      text = part_take(want + want / 16);
+    }
     std::vector<std::string> cigars;
     std::vector<lra_aln_record> recs;
     std::vector<int32_t> seg_off, index;
@@ -1295,7 +1325,7 @@ extern "C" int lra_map_records_host(lra_map_host* h, const lra_map_opts* o, cons
   for (int t = 0; t < T; t++) for (uint64_t l : plen[t]) { h->rec_off[r++] = at; at += l; }
   h->rec_off[n_reads] = at;
   {
-    auto copy = [&](int t) { if (!part[t].empty()) memcpy(out.data() + pstart[t], part[t].data(), part[t].size()); std::string().swap(part[t]); };
+    auto copy = [&](int t) { if (!part[t].empty()) memcpy(out.data() + pstart[t], part[t].data(), part[t].size()); part_give(part[t]); };
     if (T == 1) copy(0);
     else { std::vector<std::thread> th; for (int t = 0; t < T; t++) th.emplace_back(copy, t); for (auto& x : th) x.join(); }
   }
