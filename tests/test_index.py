@@ -33,7 +33,7 @@ def test_oracle_store_index_properties(oracle):
     a = set(zip(key.tolist(), pos.tolist())); b = set(zip(ks.tolist(), ps.tolist()))
     assert len(a ^ b) <= 0.002 * len(a)
     # every entry is a minimizer of its chromosome with that key
-    allk, allp, _ = O.store_index(g.tobytes(), CH, 17, 10, 1 << 30, 1, 1 << 30)
+    allk, allp, _ = O.store_index(g.tobytes(), CH, 17, 10, 1 << 20, 1, 1 << 30)      # (max_freq sizes CountSort's table: 2^20 keeps every key of a 300 kb genome)
     full = dict(zip(allp.tolist(), allk.tolist()))
     assert all(full.get(p) == k for k, p in zip(key.tolist(), pos.tolist()))
     # frequency filter: with max_freq 1 every surviving key is unique in the full minimizer list
