@@ -473,6 +473,7 @@ def main():
             done = 0
             for _ in range(n_steps):
                 for sub in subs:
+                    handed = False
                     if not err:
                         try:
                             if ahead_on:                                   # (--seed-ahead 2: the seed stage of the front half after this one on a third context)
@@ -483,13 +484,15 @@ def main():
                                         seed.adopt_seed(ctx, ahead["ctx"])
                                 ahead["thread"] = threading.Thread(target=seed_ahead, args=(sub,))
                                 ahead["thread"].start()
+                            handed = True                                  # (a front call that fails hands over an error batch: the back call for this item returns its code)
                             lanes[0]["mapper"].front(sub["rbatch"])
                             done += 1
                             continue
                         except BaseException as e:
                             err.append(e)
-                    # after an error the back thread still waits for a batch per item: an empty one (no device work), so that the run ends and reports the error
-                    lanes[0]["mapper"].front(seed.read_batch_from_device(ctx, torch.zeros(64, dtype=torch.uint8, device=dev), torch.zeros(1, dtype=torch.int64, device=dev)))
+                    # after an error the back thread still takes a batch per item: an empty one (no device work), so that the run ends and reports the error
+                    if not handed:
+                        lanes[0]["mapper"].front(seed.read_batch_from_device(ctx, torch.zeros(64, dtype=torch.uint8, device=dev), torch.zeros(1, dtype=torch.int64, device=dev)))
         except BaseException as e:
             err.append(e)
 

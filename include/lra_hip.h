@@ -69,7 +69,7 @@ int lra_ctx_set_stream(lra_ctx* ctx, void* stream);
 const char* lra_ctx_last_error(lra_ctx* ctx);
 /* ABI version of the loaded library (tests check it against this header). */
 int lra_abi_version(void);
-#define LRA_ABI_VERSION 5   /* 2: lra_map_opts.defer_matches, lra_map_counters.n_deferred_reads; 3: lra_map_opts.flagged_unaligned, lra_map_counters.n_flagged_reads, lra_map_host_flagged; 4: lra_reads_last_error, a corrupt FASTQ record is LRA_ERR_INVALID; lra_map_opts.defer_seed_matches; 5: lra_seed_prefetch, lra_ctx_adopt_seed, lra_map_reads_lowacc_front / _back, lra_map_back_release */
+#define LRA_ABI_VERSION 6   /* 2: lra_map_opts.defer_matches, lra_map_counters.n_deferred_reads; 3: lra_map_opts.flagged_unaligned, lra_map_counters.n_flagged_reads, lra_map_host_flagged; 4: lra_reads_last_error, a corrupt FASTQ record is LRA_ERR_INVALID; lra_map_opts.defer_seed_matches; 5: lra_seed_prefetch, lra_ctx_adopt_seed, lra_map_reads_lowacc_front / _back, lra_map_back_release; 6: a failed front half hands over an error batch (one back call per front call), separate n_handed_back_reads counter, lra_map_host_trim */
 
 /* Convenience for hosts without their own HIP binding: synchronous device->host copy on the
  * context's stream (a C++ host would call hipMemcpy itself).                                */
@@ -147,7 +147,13 @@ int lra_read_gli(const char* path, int* k, int* w, int* window, uint64_t* n_wind
  *   d_sep_*    forMatches then revMatches of each read (read pos, genome pos of each pair),
  *              d_n_forward[r] = forMatches.size()
  * Synchronous: returns after the results are complete (two host round trips size the
- * outputs).                                                                                */
+ * outputs).
+ * Lifetime of OTHER results on the same context: the sketch is staged in the context's sparse-DP
+ * arena -- the allocation that also holds the IndelRefine / CalculateStatistics arrays of the last
+ * lra_map_result.  A stage call on a context (this one, lra_sparse_dp_batch, ...) therefore ends the
+ * lifetime of the map result of an earlier batch call on THAT context: take what is needed from it
+ * first (lra_map_pack / lra_map_snapshot / lra_map_records), or seed on another context
+ * (lra_seed_prefetch).                                                                       */
 typedef struct lra_seed_result {
   int32_t n_reads;
   uint64_t n_minimizers, n_matches;
@@ -962,7 +968,7 @@ typedef struct lra_map_opts {
   int32_t defer_seed_matches;                             /* low-accuracy path, scheduling only (a read's result does not depend on the batch it is mapped in): a read with
                                                            * more tier-1 matches than this (CompareLists against the global index; a 30 kb read has ~3 k, a read from a
                                                            * satellite array 6-10 k) is HANDED BACK: it leaves the batch behind the seed stage, d_read_status[r] has
-                                                           * LRA_ST_DEFERRED (and nothing else), counters.n_deferred_reads counts them, lra_map_records* write nothing
+                                                           * LRA_ST_DEFERRED (and nothing else), counters.n_handed_back_reads counts them, lra_map_records* write nothing
                                                            * for it.  The caller collects such reads and maps them as batches of their own (with this field 0): their
                                                            * sparse DPs are tens of times larger than a typical read's and would otherwise set the length of every
                                                            * latency-bound launch of the batch they sit in.  0 = off (the presets) */
@@ -971,7 +977,10 @@ typedef struct lra_map_counters {
   uint64_t n_minimizers, n_matches, n_clusters, n_sdp_anchors, n_sdp_points, n_sdp_entries, n_local_tuples, n_local_tasks, n_local_task_words, n_local_pairs, n_refined_matches,
            n_btwn_problems, n_btwn_rounds, n_refined_after_btwn, n_merged_clusters, n_sdp2_anchors, n_sdp2_entries, n_a13_blocks, n_large_spaces, n_segments,
            n_rows, n_cells, n_aog, n_deferred_reads,
-           n_flagged_reads;                                  /* reads of the batch with a non-zero d_read_status (no alignment record is written for them) */
+           n_flagged_reads,                                  /* reads of the batch with a non-zero d_read_status (no alignment record is written for them) */
+           n_handed_back_reads;                              /* (ABI 6) reads handed back UNMAPPED by the seed stage under opts.defer_seed_matches (status LRA_ST_DEFERRED, no record):
+                                                              * what a caller sizes its pool of handed-back reads with.  n_deferred_reads counts only the reads that opts.defer_matches
+                                                              * moved to the batch's second pass -- those ARE mapped and have their records */
 } lra_map_counters;
 typedef struct lra_map_result {
   int32_t n_reads, num_aln;
@@ -1009,7 +1018,14 @@ int lra_map_reads_lowacc_batch(lra_ctx* ctx, int n_reads, const char* d_seq, con
  * called on THAT context, then lra_map_back_release(ctx) gives the back context to the next batch.  The reads (d_seq, d_read_off) stay untouched until the back half
  * has returned.  Calls alternate strictly per batch: front(i) before back(i); back(i), release(i) before front(i + 1) returns.  Scheduling only; opts.defer_matches and
  * opts.defer_seed_matches do not combine with it (LRA_ERR_INVALID).  The reference's counterpart is its pool of worker threads (lra.cpp:678-714): several reads in
- * flight at different points of MapRead. */
+ * flight at different points of MapRead.
+ * Errors (ABI 6): a front call that FAILS -- whatever the reason: reference not loaded, out of memory, a stage's error -- still hands over a batch, an ERROR batch, once
+ * the back context is free: the back call that takes it runs nothing, returns the front call's code (lra_ctx_last_error: "front half of this batch failed: ...") and frees
+ * the back context itself (NO lra_map_back_release for it: there is no result to hold; one would return LRA_ERR_INVALID).  So the contract for the two host threads is
+ * one back call per front call, whatever either returned; the thread of the back halves is never left waiting for a batch that does not come, and the next front call
+ * is not blocked by a failed one.  A back call whose own half fails returns its code with the back context still held: release it as after a success.
+ * The companion context's view of the reference data (borrowed from ctx) is refreshed by the front half only at its end, while it holds the idle back context -- never
+ * under a running back half; reloading ctx's reference between batches is seen by the next batch's back half, not by the one in flight. */
 int lra_map_reads_lowacc_front(lra_ctx* ctx, int n_reads, const char* d_seq, const uint64_t* d_read_off, uint64_t total_bases, const lra_map_opts* opts);
 int lra_map_reads_lowacc_back(lra_ctx* ctx, const lra_map_opts* opts, lra_map_result* out, lra_ctx** back_ctx);
 int lra_map_back_release(lra_ctx* ctx);
@@ -1043,6 +1059,8 @@ typedef struct lra_read_batch {
 int lra_reads_open(const char* const* files, int n_files, lra_reads** out);
 int lra_reads_next_batch(lra_reads* r, uint64_t max_bases, lra_read_batch* batch);
 const char* lra_reads_last_error(const lra_reads* r);
+uint64_t lra_map_host_trim(uint64_t keep_bytes);   /* (ABI 6) the record stage keeps its threads' text parts between batches (process-wide, at most LRA_PARTS_POOL_MB, default 4096, of
+                                                     * host memory; a fresh 100 MB part is 25 000 page faults): release them down to keep_bytes (0 = all); returns the bytes still held */
 int lra_host_thread_budget(void);   /* host threads lra_map_records* use when asked for 0: hardware threads, capped by the container's CPU quota (cgroup cpu.max) less four */
 void lra_reads_close(lra_reads* r);
 int lra_map_reads_host(lra_ctx* ctx, int n_reads, const char* h_seq, const uint64_t* h_off, const lra_map_opts* opts, lra_map_result* out);

@@ -4,7 +4,7 @@ import os
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 _LIB = None
-ABI_VERSION = 5
+ABI_VERSION = 6
 
 
 class LraError(RuntimeError):
@@ -61,6 +61,7 @@ SYMBOLS = {
     "lra_reads_close": (None, [_vp]),
     "lra_reads_last_error": (C.c_char_p, [_vp]),
     "lra_host_thread_budget": (C.c_int, []),
+    "lra_map_host_trim": (C.c_uint64, [C.c_uint64]),
     "lra_map_reads_host": (C.c_int, [_vp, C.c_int, _vp, _vp, _vp, _vp]),
     "lra_global_chain_batch": (C.c_int, [_vp, C.c_uint64, _vp, C.c_uint64, _vp, _vp, _vp, _vp, _vp, _vp]),
     "lra_split_chains_highacc_batch": (C.c_int, [_vp, C.c_uint64, _vp, C.c_uint64, _vp, _vp, _vp, _vp, _vp, C.c_int, _vp]),

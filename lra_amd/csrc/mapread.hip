@@ -114,7 +114,7 @@ __global__ void k_mark_handed_back(int n_reads, const uint8_t* __restrict__ flag
   const bool d = r < n_reads && flag[r];
   if (d) read_status[r] |= LRA_ST_DEFERRED;
   const unsigned long long m = __ballot(d);
-  if ((threadIdx.x & 63) == 0 && m) atomicAdd(count, (unsigned long long)__popcll(m));
+  if ((threadIdx.x & (warpSize - 1)) == 0 && m) atomicAdd(count, (unsigned long long)__popcll(m));
 }
 __global__ void k_src_slot(uint64_t S, int na, const int32_t* __restrict__ inB, uint64_t* __restrict__ src) {
   const uint64_t s = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -457,6 +457,8 @@ struct lra_handover {
   std::mutex mu; std::condition_variable cv;
   int state = 0;           // 0: the back context is free; 1: a batch is handed over, its back half not yet started; 2: the back half runs, or its result is still in use
   LowaccTailIn in;
+  int rc = LRA_OK;         // state 1 only: the front half of this batch FAILED with this code (nothing to run: the back call returns it and frees the context)
+  std::string err;
 };
 void lra_handover_free(lra_ctx* ctx) { delete ctx->handover; ctx->handover = nullptr; }
 static lra_handover* handover_of(lra_ctx* ctx) {                         // (the two halves' threads may both be the first to ask)
@@ -466,6 +468,7 @@ static lra_handover* handover_of(lra_ctx* ctx) {                         // (the
   return ctx->handover;
 }
 
+static int child_refresh(lra_ctx* ctx);
 static int lowacc_core(lra_ctx* ctx, int n_reads, const char* d_seq, const uint64_t* d_read_off, uint64_t total_bases, const lra_map_opts* o, lra_map_result* out,
                        uint32_t defer_threshold, std::vector<uint32_t>* deferred, lra_ctx* second, LowaccTailIn* second_in, const std::function<int()>& on_deferred,
                        lra_handover* H = nullptr) {
@@ -592,7 +595,7 @@ static int lowacc_core(lra_ctx* ctx, int n_reads, const char* d_seq, const uint6
   lra_map_counters cnt0; memset(&cnt0, 0, sizeof cnt0);
   cnt0.n_minimizers = sres.n_minimizers; cnt0.n_matches = sres.n_matches; cnt0.n_clusters = cres.n_clusters; cnt0.n_sdp_anchors = chres.n_frags; cnt0.n_sdp_points = chres.n_points;
   cnt0.n_sdp_entries = chres.n_subproblem_entries; cnt0.n_local_tuples = rli.n_tuples; cnt0.n_local_tasks = rres.n_tasks; cnt0.n_local_task_words = task_words; cnt0.n_local_pairs = rres.n_pairs;
-  cnt0.n_deferred_reads = n_handed_back; cnt0.n_refined_matches = rres.n_matches; cnt0.n_btwn_problems = bres.n_problems; cnt0.n_btwn_rounds = bres.n_rounds; cnt0.n_refined_after_btwn = bres.n_matches;
+  cnt0.n_handed_back_reads = n_handed_back; cnt0.n_refined_matches = rres.n_matches; cnt0.n_btwn_problems = bres.n_problems; cnt0.n_btwn_rounds = bres.n_rounds; cnt0.n_refined_after_btwn = bres.n_matches;
   LowaccTailIn in;
   in.n_reads = n_reads; in.num_aln = num_aln; in.n_slots = n_slots; in.tot = tot; in.d_read_off = d_read_off; in.d_seq = d_seq; in.both = both; in.slot_n0 = slot_n0;
   in.job_reached = job_reached; in.read_status = read_status; in.counters = cnt0;
@@ -655,6 +658,9 @@ static int lowacc_core(lra_ctx* ctx, int n_reads, const char* d_seq, const uint6
     const double tw0 = wall();
     { std::unique_lock<std::mutex> lk(H->mu); H->cv.wait(lk, [&] { return H->state == 0; }); }
     if (getenv("LRA_TWO_STAGE_DBG")) fprintf(stderr, "[two-stage] front half waited %.0f ms for the back context\n", wall() - tw0);
+    // (only now, with the back context idle, are its borrowed reference pointers refreshed: a back half still running on them must not see them change)
+    if ((rc = child_refresh(ctx))) return rc;
+    b->pipelined = true;
     LRA_HIP_CHECK(ctx, hipStreamSynchronize(b->stream));
     for (int slot : {56, 57, 81, 82}) { std::swap(ctx->gbuf[slot], b->gbuf[slot]); std::swap(ctx->gbytes[slot], b->gbytes[slot]); }
     const hipStream_t keep = b->stream;
@@ -775,8 +781,8 @@ static int lowacc_tail(lra_ctx* ctx, const LowaccTailIn& in, const lra_map_opts*
 namespace {
 __global__ void k_count_flagged(int n, const uint32_t* __restrict__ st, unsigned long long* out) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  const unsigned long long m = __ballot(i < n && st[i] != 0 && st[i] != (uint32_t)LRA_ST_DEFERRED);   // (a handed-back read is not a flagged one: counters.n_deferred_reads)
-  if ((threadIdx.x & 63) == 0 && m) atomicAdd(out, (unsigned long long)__popcll(m));
+  const unsigned long long m = __ballot(i < n && st[i] != 0 && st[i] != (uint32_t)LRA_ST_DEFERRED);   // (a handed-back read is not a flagged one: counters.n_handed_back_reads)
+  if ((threadIdx.x & (warpSize - 1)) == 0 && m) atomicAdd(out, (unsigned long long)__popcll(m));
 }
 }  // namespace
 // counters.n_flagged_reads of a finished batch: the reads whose status word is non-zero get no alignment record (lra_map_records*), the caller must know how many
@@ -797,7 +803,7 @@ int lra_map_count_flagged(lra_ctx* ctx, lra_map_result* out) {
 // The context's companion (a batch's second, concurrent pass; the back half of two-stage batches): a context of its own -- stream, work buffers -- that borrows this
 // one's reference data.  `lowest`: its streams at the device's lowest priority (the second pass fills the gaps the first one leaves; at equal priority the two passes'
 // queues slow each other down far beyond the work involved, measured); otherwise at LRA_BACK_PRIORITY (default: the device's highest -- the back half of a batch is the longer one, the front half of the next fills in).
-static int ensure_child(lra_ctx* ctx, bool lowest) {
+static int child_create(lra_ctx* ctx, bool lowest) {
   LRA_HIP_CHECK(ctx, hipSetDevice(ctx->device));
   if (!ctx->child) {
     lra_ctx* c = nullptr;
@@ -813,7 +819,12 @@ static int ensure_child(lra_ctx* ctx, bool lowest) {
     c->owns_stream = true; c->timing = ctx->timing;
     ctx->child = c;
   }
-  {                                                                      // the parent's reference may have been loaded / built again since the last batch
+  return LRA_OK;
+}
+// The companion's view of the parent's reference data (the parent's reference may have been loaded / built again since the last batch).  Writes the companion's
+// state: only while nothing runs on the companion (two-stage batches: the front half calls it once it holds the back context, never while a back half may be running).
+static int child_refresh(lra_ctx* ctx) {
+  {
     lra_ctx* c = ctx->child;
     int rc = lra_seed_share(c, ctx);
     if (rc) return lra_set_err(ctx, rc, "companion context: sharing the reference");
@@ -823,6 +834,10 @@ static int ensure_child(lra_ctx* ctx, bool lowest) {
     d->owner_cell = s->borrowed ? s->owner_cell : s->cell; d->owner_generation = s->borrowed ? s->owner_generation : s->cell->gen.load();
   }
   return LRA_OK;
+}
+static int ensure_child(lra_ctx* ctx, bool lowest) {
+  int rc = child_create(ctx, lowest);
+  return rc ? rc : child_refresh(ctx);
 }
 
 static int lowacc_batch_impl(lra_ctx* ctx, int n_reads, const char* d_seq, const uint64_t* d_read_off, uint64_t total_bases, const lra_map_opts* o, lra_map_result* out);
@@ -921,30 +936,51 @@ static int front_checks(lra_ctx* ctx, int n_reads, const lra_map_opts* o) {
   if (o->defer_matches > 0 || o->defer_seed_matches > 0 || getenv("LRA_DEFER_MATCHES")) return lra_set_err(ctx, LRA_ERR_INVALID, "two-stage batches do not combine with defer_matches / defer_seed_matches");
   return lra_map_check_shared(ctx);
 }
+// A front half that fails still hands over a batch -- an error batch: the back call that takes it returns the front half's code and frees the back context, so the
+// thread that runs the back halves is never left waiting for a batch that will not come (one back call per front call, whatever the front call returned).
+static int front_failed(lra_ctx* ctx, lra_handover* H, int rc) {
+  const std::string msg = ctx->err;
+  { std::unique_lock<std::mutex> lk(H->mu); H->cv.wait(lk, [&] { return H->state == 0; }); H->in = LowaccTailIn(); H->in.n_reads = 0; H->rc = rc; H->err = msg; H->state = 1; }
+  H->cv.notify_all();
+  return rc;
+}
 extern "C" int lra_map_reads_lowacc_front(lra_ctx* ctx, int n_reads, const char* d_seq, const uint64_t* d_read_off, uint64_t total_bases, const lra_map_opts* o) {
-  { int rc = front_checks(ctx, n_reads, o); if (rc) return rc; }
-  { int rc = ensure_child(ctx, false); if (rc) return rc; }
-  ctx->pipelined = true; ctx->child->pipelined = true;
+  if (!ctx) return LRA_ERR_INVALID;
   lra_handover* H = handover_of(ctx);
+  { int rc = front_checks(ctx, n_reads, o); if (rc) return front_failed(ctx, H, rc); }
+  if (!ctx->child) {                                                     // (made once, before any batch is handed over: no back half can be running)
+    int rc = ensure_child(ctx, false); if (rc) return front_failed(ctx, H, rc);
+    ctx->child->pipelined = true;
+  }
+  ctx->pipelined = true;
   if (n_reads == 0) {                                                     // an empty batch still takes its turn with the back context
-    { std::unique_lock<std::mutex> lk(H->mu); H->cv.wait(lk, [&] { return H->state == 0; }); H->in = LowaccTailIn(); H->in.n_reads = 0; H->state = 1; }
+    { std::unique_lock<std::mutex> lk(H->mu); H->cv.wait(lk, [&] { return H->state == 0; }); H->in = LowaccTailIn(); H->in.n_reads = 0; H->rc = LRA_OK; H->state = 1; }
     H->cv.notify_all();
     return LRA_OK;
   }
   lra_map_result tmp;
   const std::function<int()> none;
-  return lowacc_core(ctx, n_reads, d_seq, d_read_off, total_bases, o, &tmp, 0, nullptr, nullptr, nullptr, none, H);
+  const int rc = lowacc_core(ctx, n_reads, d_seq, d_read_off, total_bases, o, &tmp, 0, nullptr, nullptr, nullptr, none, H);
+  return rc ? front_failed(ctx, H, rc) : LRA_OK;                         // (lowacc_core hands the batch over as its last act: a failure means it has not)
 }
 extern "C" int lra_map_reads_lowacc_back(lra_ctx* ctx, const lra_map_opts* o, lra_map_result* out, lra_ctx** back_ctx) {
   if (!ctx || !o || !out) return LRA_ERR_INVALID;
   lra_handover* H = handover_of(ctx);
   LowaccTailIn in;
+  int frc = LRA_OK; std::string ferr;
   const double tw0 = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count();
-  { std::unique_lock<std::mutex> lk(H->mu); H->cv.wait(lk, [&] { return H->state == 1; }); in = H->in; H->state = 2; }   // (waits for a front half, however long)
+  {                                                                      // (waits for a front half, however long; a front half that fails hands over an error batch)
+    std::unique_lock<std::mutex> lk(H->mu);
+    H->cv.wait(lk, [&] { return H->state == 1; });
+    in = H->in; frc = H->rc; ferr = H->err; H->rc = LRA_OK; H->err.clear();
+    H->state = frc ? 0 : 2;                                              // an error batch holds nothing: the back context is free again at once
+  }
+  if (frc) H->cv.notify_all();
   if (getenv("LRA_TWO_STAGE_DBG")) fprintf(stderr, "[two-stage] back half waited %.0f ms for a front half\n", std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count() - tw0);
   memset(out, 0, sizeof *out);
+  if (back_ctx) *back_ctx = ctx->child;
+  if (frc) return lra_set_err(ctx, frc, "front half of this batch failed: %s", ferr.c_str());
   lra_ctx* b = ctx->child;                                               // (made by the front half)
-  if (back_ctx) *back_ctx = b;
   b->map->last_text.clear(); b->map->last_sig = lra_map_sig{};
   out->n_reads = in.n_reads;
   if (in.n_reads == 0) return LRA_OK;
@@ -1013,13 +1049,23 @@ constexpr size_t POOL_KEEP = 6, POOL_MIN = 8u << 20;
 namespace {
 std::mutex g_parts_mu;
 std::vector<std::string> g_parts;
+size_t g_parts_bytes = 0;                                                // capacity held by the pool
+size_t parts_cap() {                                                     // at most this much is kept between batches (LRA_PARTS_POOL_MB; lra_map_host_trim lowers what is held now)
+  static const size_t cap = [] { const char* e = getenv("LRA_PARTS_POOL_MB"); return (size_t)(e ? std::max(0, atoi(e)) : 4096) << 20; }();
+  return cap;
+}
 std::string part_take(size_t want) {
   std::string s;
   {
     std::lock_guard<std::mutex> lk(g_parts_mu);
-    int best = -1;
-    for (int i = 0; i < (int)g_parts.size(); i++) if (best < 0 || g_parts[i].capacity() > g_parts[best].capacity()) best = i;
-    if (best >= 0) { s.swap(g_parts[best]); g_parts.erase(g_parts.begin() + best); }
+    int best = -1;                                                       // the smallest string that holds `want`, else the largest there is
+    for (int i = 0; i < (int)g_parts.size(); i++) {
+      const size_t c = g_parts[i].capacity();
+      if (best < 0) { best = i; continue; }
+      const size_t b = g_parts[best].capacity();
+      if (b >= want ? (c >= want && c < b) : c > b) best = i;
+    }
+    if (best >= 0) { g_parts_bytes -= g_parts[best].capacity(); s.swap(g_parts[best]); g_parts.erase(g_parts.begin() + best); }
   }
   s.clear();
   if (s.capacity() < want) s.reserve(want);
@@ -1028,10 +1074,22 @@ std::string part_take(size_t want) {
 void part_give(std::string& s) {
   s.clear();
   std::lock_guard<std::mutex> lk(g_parts_mu);
-  if (g_parts.size() < 64 && s.capacity() >= (8u << 20)) { g_parts.emplace_back(); g_parts.back().swap(s); }
+  if (g_parts.size() < 64 && s.capacity() >= (8u << 20) && g_parts_bytes + s.capacity() <= parts_cap()) { g_parts_bytes += s.capacity(); g_parts.emplace_back(); g_parts.back().swap(s); }
   else std::string().swap(s);
 }
 }  // namespace
+// Host memory the record stage keeps between batches (the threads' text parts): released down to keep_bytes (0: all of it).  Returns the bytes still held.
+extern "C" uint64_t lra_map_host_trim(uint64_t keep_bytes) {
+  std::lock_guard<std::mutex> lk(g_parts_mu);
+  while (!g_parts.empty() && g_parts_bytes > keep_bytes) {
+    int big = 0;
+    for (int i = 1; i < (int)g_parts.size(); i++) if (g_parts[i].capacity() > g_parts[big].capacity()) big = i;
+    g_parts_bytes -= g_parts[big].capacity();
+    g_parts.erase(g_parts.begin() + big);
+  }
+  if (g_parts.empty()) std::vector<std::string>().swap(g_parts);
+  return g_parts_bytes;
+}
 void* lra_host_pool_get(size_t bytes, size_t* cap) {
   {
     std::lock_guard<std::mutex> lk(g_pool_mu);

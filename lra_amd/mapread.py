@@ -105,7 +105,7 @@ class MapCounters(C.Structure):
     _fields_ = [(n, C.c_uint64) for n in ("n_minimizers", "n_matches", "n_clusters", "n_sdp_anchors", "n_sdp_points", "n_sdp_entries", "n_local_tuples",
                                           "n_local_tasks", "n_local_task_words", "n_local_pairs", "n_refined_matches", "n_btwn_problems", "n_btwn_rounds", "n_refined_after_btwn",
                                           "n_merged_clusters", "n_sdp2_anchors", "n_sdp2_entries", "n_a13_blocks", "n_large_spaces", "n_segments", "n_rows",
-                                          "n_cells", "n_aog", "n_deferred_reads", "n_flagged_reads")]
+                                          "n_cells", "n_aog", "n_deferred_reads", "n_flagged_reads", "n_handed_back_reads")]
 
 
 class MapResult(C.Structure):

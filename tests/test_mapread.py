@@ -486,7 +486,7 @@ def test_borrowed_reference_goes_stale_when_its_owner_reloads_or_dies():
 @pytest.mark.gpu
 def test_reads_handed_back_by_tier1_matches_map_the_same_in_a_batch_of_their_own(ctx):
     """lra_map_opts.defer_seed_matches (scheduling only): reads with more tier-1 matches than the threshold leave the batch behind the seed stage -- status
-    LRA_ST_DEFERRED and nothing else, counted in n_deferred_reads (not in n_flagged_reads), no record -- every other read's records are unchanged, and the
+    LRA_ST_DEFERRED and nothing else, counted in n_handed_back_reads (not in n_flagged_reads, nor in n_deferred_reads), no record -- every other read's records are unchanged, and the
     handed-back reads mapped as a batch of their own give exactly the records they have in the one-pass batch."""
     from lra_amd import seed, mapread
     genome = synth.make_genome(600_000, seed=12, repeat_frac=0.3, n_families=3)
@@ -503,7 +503,7 @@ def test_reads_handed_back_by_tier1_matches_map_the_same_in_a_batch_of_their_own
     per_read = np.diff(s["match_off"]).astype(np.int64)
     T = int(np.sort(per_read)[len(per_read) * 2 // 3])                    # a third of the reads lie above it
     res0 = mapper.align(batch)
-    assert mapper.stats["n_deferred_reads"] == 0
+    assert mapper.stats["n_handed_back_reads"] == 0 and mapper.stats["n_deferred_reads"] == 0
     texts0 = mapper.records(res0, names, raw)
     mapper.copts.defer_seed_matches = T
     res1 = mapper.align(batch)
@@ -511,7 +511,7 @@ def test_reads_handed_back_by_tier1_matches_map_the_same_in_a_batch_of_their_own
     D = np.nonzero(st1 & 64)[0]
     assert np.array_equal(D, np.nonzero(per_read > T)[0]) and 0 < len(D) < len(reads) - 1
     assert np.all(st1[D] == 64) and np.all(np.delete(st1, D) == 0)
-    assert mapper.stats["n_deferred_reads"] == len(D) and int(res1.counters.n_flagged_reads) == 0
+    assert mapper.stats["n_handed_back_reads"] == len(D) and mapper.stats["n_deferred_reads"] == 0 and int(res1.counters.n_flagged_reads) == 0
     texts1 = mapper.records(res1, names, raw)
     for r in range(len(reads)):
         assert texts1[r] == (b"" if r in set(D.tolist()) else texts0[r]), r
@@ -520,7 +520,7 @@ def test_reads_handed_back_by_tier1_matches_map_the_same_in_a_batch_of_their_own
     mapper.copts.flagged_unaligned = 0
     mapper.copts.defer_seed_matches = 0
     res2 = mapper.align(seed.ReadBatch(ctx, [raw[i] for i in D]))
-    assert mapper.stats["n_deferred_reads"] == 0
+    assert mapper.stats["n_handed_back_reads"] == 0 and mapper.stats["n_deferred_reads"] == 0
     texts2 = mapper.records(res2, [names[i] for i in D], [raw[i] for i in D])
     assert [texts2[k] for k in range(len(D))] == [texts0[i] for i in D]
     assert sum(1 for t in texts2 if t and not (int(t.split(b"\t")[1]) & 4)) >= len(D) - 1
@@ -662,3 +662,39 @@ def test_two_stage_batches_give_the_same_records_with_the_front_half_of_the_next
     with pytest.raises(LraError):
         mapper.front(rb)
     mapper.copts.defer_seed_matches = 0
+    # a front call that fails still hands over a batch, an error batch: the back call for it returns the front's code at once, holds nothing (no release), and the
+    # next batch goes through -- the thread of the back halves is never left waiting (one back call per front call)
+    with pytest.raises(LraError, match="front half of this batch failed"):
+        mapper.back()
+    with pytest.raises(LraError):
+        mapper.release()                                                  # an error batch holds nothing
+    got2, err2, failed = [None] * 3, [], []
+
+    def fronts2():
+        for i, (rb_, _, _) in enumerate(batches):
+            mapper.copts.defer_seed_matches = 50 if i == 1 else 0         # (batch 1's front half is refused)
+            try:
+                mapper.front(rb_)
+            except LraError as e:
+                failed.append((i, str(e)))
+            except BaseException as e:
+                err2.append(e)
+        mapper.copts.defer_seed_matches = 0
+
+    def backs2():
+        for i, (rb_, names_, raw_) in enumerate(batches):
+            try:
+                res_, bctx_ = mapper.back()
+            except LraError as e:
+                got2[i] = str(e)
+                continue
+            except BaseException as e:
+                err2.append(e); return
+            got2[i] = mapper.on(bctx_).records(res_, names_, raw_)
+            mapper.release()
+    tf, tb = threading.Thread(target=fronts2), threading.Thread(target=backs2)
+    tf.start(); tb.start(); tf.join(60); tb.join(60)
+    assert not tf.is_alive() and not tb.is_alive(), "a failed front half left a thread waiting"
+    assert not err2, err2
+    assert [i for i, _ in failed] == [1]
+    assert got2[0] == want[0][0] and got2[2] == want[2][0] and isinstance(got2[1], str) and "front half of this batch failed" in got2[1]
