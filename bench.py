@@ -637,7 +637,7 @@ def main():
                          "step_algorithmic_bytes": step_alg, "step_frac": step_alg / (ms_step * 1e-3) / 1e9 / 8000.0},
             "sam_text_gb_per_step": round(text_bytes[0] / max(args.steps, 1) / 1e9, 3),
             "lane_items": [l["n_items"] for l in lanes],
-            "two_stage": {"on": bool(two_stage), "what": "lra_map_reads_lowacc_front / _back: the front half (a1 .. the second LinearExtend) of step i + 1 on the context (low-priority stream, its own host thread) beside the back half (second sparse DP .. statistics) of step i on the companion context"},
+            "two_stage": {"on": bool(two_stage), "what": "lra_map_reads_lowacc_front / _back: the front half (a1 .. the second LinearExtend) of step i + 1 on the context (low-priority stream, its own host thread) beside the back half (second sparse DP .. statistics) of step i on the companion context; a queue of one handed-over batch between them (two sets of handover buffers), so the back context goes from one batch straight to the next"},
             "seed_ahead": {"on": bool(ahead_on), "delay_ms": args.seed_ahead_delay_ms,
                            "what": "a1-a4 of step i + 1 on a side context (low-priority stream, own host thread) beside step i; every timed step holds one alignment pass and one seeding"},
             "handed_back": {"defer_seed_matches": defer_T, "pool": args.heavy_pool, "reads_per_step": round(heavy["reads"] / max(args.steps, 1), 1), "batches": heavy["batches"]},

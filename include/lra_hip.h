@@ -1012,20 +1012,22 @@ int lra_map_reads_lowacc_batch(lra_ctx* ctx, int n_reads, const char* d_seq, con
  *   front: a1 .. the second LinearExtend / TrimOverlappedAnchors (Map_lowacc.h:69-476), on `ctx` and its stream, by one host thread;
  *   back : the second sparse DP, LocalRefineAlignment, IndelRefineAlignment, CalculateStatistics (Map_lowacc.h:477-599), on the context's companion context
  *          (made on first use: its own stream -- the device's highest priority unless LRA_BACK_PRIORITY says otherwise --, its own work buffers, the reference data shared), by ANOTHER host thread.
- * lra_map_reads_lowacc_front returns when the batch is handed over; it waits, at its very end, until the batch before has been through lra_map_reads_lowacc_back
- * AND lra_map_back_release.  lra_map_reads_lowacc_back waits for a handed-over batch, runs its back half and returns the result of the whole batch exactly as
- * lra_map_reads_lowacc_batch would (same alignments, same counters); the result's arrays belong to *back_ctx: lra_map_pack / lra_map_snapshot / lra_map_records are
- * called on THAT context, then lra_map_back_release(ctx) gives the back context to the next batch.  The reads (d_seq, d_read_off) stay untouched until the back half
- * has returned.  Calls alternate strictly per batch: front(i) before back(i); back(i), release(i) before front(i + 1) returns.  Scheduling only; opts.defer_matches and
- * opts.defer_seed_matches do not combine with it (LRA_ERR_INVALID).  The reference's counterpart is its pool of worker threads (lra.cpp:678-714): several reads in
- * flight at different points of MapRead.
- * Errors (ABI 6): a front call that FAILS -- whatever the reason: reference not loaded, out of memory, a stage's error -- still hands over a batch, an ERROR batch, once
- * the back context is free: the back call that takes it runs nothing, returns the front call's code (lra_ctx_last_error: "front half of this batch failed: ...") and frees
- * the back context itself (NO lra_map_back_release for it: there is no result to hold; one would return LRA_ERR_INVALID).  So the contract for the two host threads is
- * one back call per front call, whatever either returned; the thread of the back halves is never left waiting for a batch that does not come, and the next front call
- * is not blocked by a failed one.  A back call whose own half fails returns its code with the back context still held: release it as after a success.
- * The companion context's view of the reference data (borrowed from ctx) is refreshed by the front half only at its end, while it holds the idle back context -- never
- * under a running back half; reloading ctx's reference between batches is seen by the next batch's back half, not by the one in flight. */
+ * Between the halves sits a queue of ONE batch (ABI 6; before: none -- the front half waited for the running back half): the front half writes what it hands over
+ * into one of two sets of handover buffers, taken in turn, and lra_map_reads_lowacc_front returns when the batch is handed over; it waits, at its very end, only until
+ * the batch BEFORE its own has been taken by a back call -- the back half that is running is not waited for, so the back context goes from one batch straight to the
+ * next.  lra_map_reads_lowacc_back waits for a handed-over batch, runs its back half and returns the result of the whole batch exactly as lra_map_reads_lowacc_batch
+ * would (same alignments, same counters); the result's arrays belong to *back_ctx: lra_map_pack / lra_map_snapshot / lra_map_records are called on THAT context, then
+ * lra_map_back_release(ctx) ends the result's lifetime (the next back call needs it: LRA_ERR_INVALID while a result is held).  Up to three batches are in flight (one in
+ * its back half, one handed over, one in its front half): a batch's reads (d_seq, d_read_off) stay untouched until ITS back call has returned.  Per thread the calls are
+ * in batch order: front(0), front(1), ... on one, back(0), release(0), back(1), ... on the other.  Scheduling only; opts.defer_matches and opts.defer_seed_matches do not
+ * combine with it (LRA_ERR_INVALID).  The reference's counterpart is its pool of worker threads (lra.cpp:678-714): several reads in flight at different points of MapRead.
+ * Errors (ABI 6): a front call that FAILS -- whatever the reason: reference not loaded, out of memory, a stage's error -- still hands over a batch, an ERROR batch: the
+ * back call that takes it runs nothing, returns the front call's code and holds nothing (NO lra_map_back_release for it; one would return LRA_ERR_INVALID).  So the
+ * contract for the two host threads is one back call per front call, whatever either returned; the thread of the back halves is never left waiting for a batch that
+ * does not come, and the next front call is not blocked by a failed one.  A back call whose own half fails returns its code with the result slot still held: release
+ * it as after a success.  The back calls leave their error text on the back context (lra_ctx_last_error(*back_ctx); the front thread owns ctx's).
+ * The back context's view of the reference data (borrowed from ctx) is refreshed by each back call before it runs, on its own thread; ctx's reference must not be
+ * loaded / built again while a batch is in flight (the halves in flight read it). */
 int lra_map_reads_lowacc_front(lra_ctx* ctx, int n_reads, const char* d_seq, const uint64_t* d_read_off, uint64_t total_bases, const lra_map_opts* opts);
 int lra_map_reads_lowacc_back(lra_ctx* ctx, const lra_map_opts* opts, lra_map_result* out, lra_ctx** back_ctx);
 int lra_map_back_release(lra_ctx* ctx);

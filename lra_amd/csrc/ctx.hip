@@ -187,7 +187,7 @@ void lra_time_end(lra_ctx* ctx, hipStream_t stream) {
 extern "C" int lra_ctx_timing_enable(lra_ctx* ctx, int on) {
   if (!ctx) return LRA_ERR_INVALID;
   ctx->timing = on != 0;
-  if (ctx->child) ctx->child->timing = ctx->timing;
+  for (lra_ctx* c = ctx->child; c; c = c->child) c->timing = ctx->timing;   // (the companion, and the handover contexts of two-stage batches behind it)
   return LRA_OK;
 }
 

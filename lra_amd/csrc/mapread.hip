@@ -452,12 +452,18 @@ struct LowaccTailIn {
 };
 static int lowacc_tail(lra_ctx* ctx, const LowaccTailIn& in, const lra_map_opts* o, lra_map_result* out);
 
-// A batch between its two halves (lra_map_reads_lowacc_front / _back): what the tail needs, and whose turn it is with the back context.
+// A batch between its two halves (lra_map_reads_lowacc_front / _back): what the tail needs, and a queue of ONE batch between the threads of the two halves.
+// The front half writes the batch it hands over (MergeChain .. TrimOverlappedAnchors' results, the reads with their reverse complements, the chains' NumOfAnchors0, the
+// slots reached, the status words) into one of two sets of buffers -- the handover contexts hand[0 / 1], taken in turn -- so it never waits for the back half that is
+// RUNNING, only for the batch before its own to have been taken: when batch i - 1 has been taken, batch i - 2 has been released, and set i % 2 is free.
 struct lra_handover {
   std::mutex mu; std::condition_variable cv;
-  int state = 0;           // 0: the back context is free; 1: a batch is handed over, its back half not yet started; 2: the back half runs, or its result is still in use
+  bool pending = false;    // a batch is handed over, its back half not yet started
+  bool busy = false;       // the back half runs, or its result is still in use (until lra_map_back_release)
+  uint64_t seq = 0;        // batches handed over so far (error batches do not count: they use no buffers)
+  lra_ctx* hand[2] = {nullptr, nullptr};   // owned through the companion's child chain (destroyed and timed with it)
   LowaccTailIn in;
-  int rc = LRA_OK;         // state 1 only: the front half of this batch FAILED with this code (nothing to run: the back call returns it and frees the context)
+  int rc = LRA_OK;         // pending only: the front half of this batch FAILED with this code (nothing to run: the back call returns it)
   std::string err;
 };
 void lra_handover_free(lra_ctx* ctx) { delete ctx->handover; ctx->handover = nullptr; }
@@ -650,27 +656,21 @@ static int lowacc_core(lra_ctx* ctx, int n_reads, const char* d_seq, const uint6
     stage("deferred reads");
   }
   if (H) {
-    // The front half ends here (lra_map_reads_lowacc_front): MergeChain .. TrimOverlappedAnchors write into the BACK context's buffers (queued on this stream: they read
-    // the first sparse DP's and the refinement's arrays), and the four buffers of this half that the tail reads -- the reads with their reverse complements, the chains'
-    // NumOfAnchors0, the slots reached, the reads' status words -- change owner with the back context's (no copy).  Not before the back context is free: the batch
-    // before this one has been through its back half and its result has been released.
-    lra_ctx* b = ctx->child;
+    // The front half ends here (lra_map_reads_lowacc_front): MergeChain .. TrimOverlappedAnchors write into the handover buffers of this batch's turn (queued on this
+    // stream: they read the first sparse DP's and the refinement's arrays), and the four buffers of this half that the tail reads -- the reads with their reverse
+    // complements, the chains' NumOfAnchors0, the slots reached, the reads' status words -- change owner with that set's (no copy).  Not before the batch before this one
+    // has been TAKEN by a back call (then the set's last user, the batch before that, has been released); the back half that is running is not waited for.
     const double tw0 = wall();
-    { std::unique_lock<std::mutex> lk(H->mu); H->cv.wait(lk, [&] { return H->state == 0; }); }
-    if (getenv("LRA_TWO_STAGE_DBG")) fprintf(stderr, "[two-stage] front half waited %.0f ms for the back context\n", wall() - tw0);
-    // (only now, with the back context idle, are its borrowed reference pointers refreshed: a back half still running on them must not see them change)
-    if ((rc = child_refresh(ctx))) return rc;
-    b->pipelined = true;
-    LRA_HIP_CHECK(ctx, hipStreamSynchronize(b->stream));
-    for (int slot : {56, 57, 81, 82}) { std::swap(ctx->gbuf[slot], b->gbuf[slot]); std::swap(ctx->gbytes[slot], b->gbytes[slot]); }
-    const hipStream_t keep = b->stream;
-    b->stream = st;
-    rc = lra_merge_extend_batch(b, &chres, &spres, &bres, d_seq, d_read_off, genome, CH, nCh, o->localK, &in.mres);
-    b->stream = keep;
-    if (rc) return lra_set_err(ctx, rc, "MergeChain into the back context: %s", b->err.c_str());
+    { std::unique_lock<std::mutex> lk(H->mu); H->cv.wait(lk, [&] { return !H->pending; }); }
+    if (getenv("LRA_TWO_STAGE_DBG")) fprintf(stderr, "[two-stage] front half waited %.0f ms for the batch before it to be taken\n", wall() - tw0);
+    lra_ctx* hs = H->hand[H->seq & 1];
+    for (int slot : {56, 57, 81, 82}) { std::swap(ctx->gbuf[slot], hs->gbuf[slot]); std::swap(ctx->gbytes[slot], hs->gbytes[slot]); }
+    hs->stream = st;                                                       // (a handover context has no stream of its own: its one stage runs on the front half's)
+    rc = lra_merge_extend_batch(hs, &chres, &spres, &bres, d_seq, d_read_off, genome, CH, nCh, o->localK, &in.mres);
+    if (rc) return lra_set_err(ctx, rc, "MergeChain into the handover buffers: %s", hs->err.c_str());
     LRA_HIP_CHECK(ctx, hipStreamSynchronize(st));
     stage("merge_extend");
-    { std::lock_guard<std::mutex> lk(H->mu); H->in = in; H->state = 1; }
+    { std::lock_guard<std::mutex> lk(H->mu); H->in = in; H->rc = LRA_OK; H->pending = true; H->seq++; }
     H->cv.notify_all();
     return LRA_OK;
   }
@@ -827,7 +827,7 @@ static int child_refresh(lra_ctx* ctx) {
   {
     lra_ctx* c = ctx->child;
     int rc = lra_seed_share(c, ctx);
-    if (rc) return lra_set_err(ctx, rc, "companion context: sharing the reference");
+    if (rc) return lra_set_err(c, rc, "companion context: sharing the reference");   // (on the companion: in two-stage batches this runs on the back halves' thread)
     lra_map_state* d = c->map; const lra_map_state* s = ctx->map;
     d->chrom_pos = s->chrom_pos; d->d_chrom_pos = s->d_chrom_pos; d->gli_buf = s->gli_buf; d->gli = s->gli; d->d_gso = s->d_gso; d->n_gwin = s->n_gwin;
     d->gli_window = s->gli_window; d->lut = s->lut; d->borrowed = true;
@@ -837,7 +837,9 @@ static int child_refresh(lra_ctx* ctx) {
 }
 static int ensure_child(lra_ctx* ctx, bool lowest) {
   int rc = child_create(ctx, lowest);
-  return rc ? rc : child_refresh(ctx);
+  if (rc) return rc;
+  if ((rc = child_refresh(ctx))) return lra_set_err(ctx, rc, "%s", ctx->child->err.c_str());
+  return LRA_OK;
 }
 
 static int lowacc_batch_impl(lra_ctx* ctx, int n_reads, const char* d_seq, const uint64_t* d_read_off, uint64_t total_bases, const lra_map_opts* o, lra_map_result* out);
@@ -936,25 +938,42 @@ static int front_checks(lra_ctx* ctx, int n_reads, const lra_map_opts* o) {
   if (o->defer_matches > 0 || o->defer_seed_matches > 0 || getenv("LRA_DEFER_MATCHES")) return lra_set_err(ctx, LRA_ERR_INVALID, "two-stage batches do not combine with defer_matches / defer_seed_matches");
   return lra_map_check_shared(ctx);
 }
-// A front half that fails still hands over a batch -- an error batch: the back call that takes it returns the front half's code and frees the back context, so the
+// A front half that fails still hands over a batch -- an error batch: the back call that takes it returns the front half's code and holds nothing, so the
 // thread that runs the back halves is never left waiting for a batch that will not come (one back call per front call, whatever the front call returned).
 static int front_failed(lra_ctx* ctx, lra_handover* H, int rc) {
   const std::string msg = ctx->err;
-  { std::unique_lock<std::mutex> lk(H->mu); H->cv.wait(lk, [&] { return H->state == 0; }); H->in = LowaccTailIn(); H->in.n_reads = 0; H->rc = rc; H->err = msg; H->state = 1; }
+  { std::unique_lock<std::mutex> lk(H->mu); H->cv.wait(lk, [&] { return !H->pending; }); H->in = LowaccTailIn(); H->in.n_reads = 0; H->rc = rc; H->err = msg; H->pending = true; }
   H->cv.notify_all();
   return rc;
+}
+// the back context and the two handover contexts (b -> hand[0] -> hand[1] on the child chain: destroyed with the context, timed with it); made once, by the first front call
+static int two_stage_contexts(lra_ctx* ctx, lra_handover* H) {
+  if (!ctx->child) {
+    int rc = ensure_child(ctx, false); if (rc) return rc;
+    ctx->child->pipelined = true;
+  }
+  lra_ctx* tail = ctx->child;
+  for (int i = 0; i < 2; i++) {
+    if (!H->hand[i]) {
+      if (tail->child) return lra_set_err(ctx, LRA_ERR_INVALID, "the companion context already has a companion of its own");
+      lra_ctx* c = nullptr;
+      int rc = lra_ctx_create(ctx->device, &c);
+      if (rc) return lra_set_err(ctx, rc, "handover context");
+      c->timing = ctx->timing;
+      tail->child = c; H->hand[i] = c;
+    }
+    tail = H->hand[i];
+  }
+  return LRA_OK;
 }
 extern "C" int lra_map_reads_lowacc_front(lra_ctx* ctx, int n_reads, const char* d_seq, const uint64_t* d_read_off, uint64_t total_bases, const lra_map_opts* o) {
   if (!ctx) return LRA_ERR_INVALID;
   lra_handover* H = handover_of(ctx);
   { int rc = front_checks(ctx, n_reads, o); if (rc) return front_failed(ctx, H, rc); }
-  if (!ctx->child) {                                                     // (made once, before any batch is handed over: no back half can be running)
-    int rc = ensure_child(ctx, false); if (rc) return front_failed(ctx, H, rc);
-    ctx->child->pipelined = true;
-  }
+  { int rc = two_stage_contexts(ctx, H); if (rc) return front_failed(ctx, H, rc); }
   ctx->pipelined = true;
-  if (n_reads == 0) {                                                     // an empty batch still takes its turn with the back context
-    { std::unique_lock<std::mutex> lk(H->mu); H->cv.wait(lk, [&] { return H->state == 0; }); H->in = LowaccTailIn(); H->in.n_reads = 0; H->rc = LRA_OK; H->state = 1; }
+  if (n_reads == 0) {                                                     // an empty batch still takes its turn
+    { std::unique_lock<std::mutex> lk(H->mu); H->cv.wait(lk, [&] { return !H->pending; }); H->in = LowaccTailIn(); H->in.n_reads = 0; H->rc = LRA_OK; H->pending = true; }
     H->cv.notify_all();
     return LRA_OK;
   }
@@ -971,28 +990,36 @@ extern "C" int lra_map_reads_lowacc_back(lra_ctx* ctx, const lra_map_opts* o, lr
   const double tw0 = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count();
   {                                                                      // (waits for a front half, however long; a front half that fails hands over an error batch)
     std::unique_lock<std::mutex> lk(H->mu);
-    H->cv.wait(lk, [&] { return H->state == 1; });
+    if (H->busy) return lra_set_err(ctx->child ? ctx->child : ctx, LRA_ERR_INVALID, "the result of the back half before this one is still held (lra_map_back_release)");
+    H->cv.wait(lk, [&] { return H->pending; });
     in = H->in; frc = H->rc; ferr = H->err; H->rc = LRA_OK; H->err.clear();
-    H->state = frc ? 0 : 2;                                              // an error batch holds nothing: the back context is free again at once
+    H->pending = false;
+    H->busy = frc == LRA_OK;                                             // an error batch holds nothing
   }
-  if (frc) H->cv.notify_all();
+  H->cv.notify_all();                                                    // (the front half may hand over the next batch now)
   if (getenv("LRA_TWO_STAGE_DBG")) fprintf(stderr, "[two-stage] back half waited %.0f ms for a front half\n", std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count() - tw0);
   memset(out, 0, sizeof *out);
-  if (back_ctx) *back_ctx = ctx->child;
-  if (frc) return lra_set_err(ctx, frc, "front half of this batch failed: %s", ferr.c_str());
-  lra_ctx* b = ctx->child;                                               // (made by the front half)
-  b->map->last_text.clear(); b->map->last_sig = lra_map_sig{};
-  out->n_reads = in.n_reads;
-  if (in.n_reads == 0) return LRA_OK;
-  int rc = lowacc_tail(b, in, o, out);
+  lra_ctx* b = ctx->child;                                               // (made by the first front half)
+  if (back_ctx) *back_ctx = b;
+  // (this thread's error text goes to the BACK context -- the front thread writes ctx's; without a back context the front half has failed before making one, and is not running)
+  if (frc) return lra_set_err(b ? b : ctx, frc, "front half of this batch failed: %s", ferr.c_str());
+  // The back context's view of the reference data (borrowed from ctx), refreshed here -- by the thread that owns the back context, with nothing running on it.
+  // (Reloading ctx's reference is for when no batch is in flight: the halves of the batches in flight read it.)
+  int rc = child_refresh(ctx);
+  if (rc == LRA_OK) {
+    b->map->last_text.clear(); b->map->last_sig = lra_map_sig{};
+    out->n_reads = in.n_reads;
+    if (in.n_reads == 0) return LRA_OK;
+    rc = lowacc_tail(b, in, o, out);
+  }
   if (rc == LRA_OK) rc = lra_map_count_flagged(b, out);
-  if (rc) return lra_set_err(ctx, rc, "back half: %s", b->err.c_str());
+  if (rc) { const std::string msg = b->err; return lra_set_err(b, rc, "back half: %s", msg.c_str()); }
   return LRA_OK;
 }
 extern "C" int lra_map_back_release(lra_ctx* ctx) {
   if (!ctx || !ctx->handover) return LRA_ERR_INVALID;
   lra_handover* H = ctx->handover;
-  { std::lock_guard<std::mutex> lk(H->mu); if (H->state != 2) return lra_set_err(ctx, LRA_ERR_INVALID, "no back half's result is held"); H->state = 0; }
+  { std::lock_guard<std::mutex> lk(H->mu); if (!H->busy) return lra_set_err(ctx->child ? ctx->child : ctx, LRA_ERR_INVALID, "no back half's result is held"); H->busy = false; }
   H->cv.notify_all();
   return LRA_OK;
 }

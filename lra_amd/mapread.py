@@ -234,7 +234,10 @@ class LowAccMapper:
         """-> (MapResult, the back context its arrays belong to: pack / snapshot / records / fetch through a mapper view on it, then release())"""
         ctx = self.ctx
         res = MapResult(); bh = C.c_void_p()
-        ctx.check(ctx.lib.lra_map_reads_lowacc_back(ctx.h, C.byref(self.copts), C.byref(res), C.byref(bh)))
+        rc = ctx.lib.lra_map_reads_lowacc_back(ctx.h, C.byref(self.copts), C.byref(res), C.byref(bh))
+        if rc:                                                             # (the back halves' thread leaves its error text on the back context: the front thread writes ctx's)
+            from ._lib import LraError
+            raise LraError("%d: %s" % (rc, ctx.lib.lra_ctx_last_error(C.c_void_p(bh.value) if bh.value else ctx.h).decode()))
         c = res.counters
         self.stats.update({n: int(getattr(c, n)) for n, _ in MapCounters._fields_})
         self.stats.update(n_alignments=int(res.n_alignments), n_blocks=int(res.n_blocks), n_cigar_runs=int(res.n_runs),
@@ -242,7 +245,10 @@ class LowAccMapper:
         return res, Context.borrowed(bh.value, ctx.device)
 
     def release(self):
-        self.ctx.check(self.ctx.lib.lra_map_back_release(self.ctx.h))
+        rc = self.ctx.lib.lra_map_back_release(self.ctx.h)
+        if rc:
+            from ._lib import LraError
+            raise LraError("%d: no back half's result is held" % rc)
 
     def on(self, ctx):
         """This mapper's options and host-side tables bound to another context (the back context of two-stage batches)."""
