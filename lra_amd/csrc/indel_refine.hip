@@ -799,6 +799,178 @@ __global__ void __launch_bounds__(64) ir_fill_16x2(FillArgs F) {
   }
 }
 
+// ---------------------------------------------------------------------------------- fill, anti-diagonal form
+// The same recurrence swept along anti-diagonals instead of rows: a LANE per row, eight rows of a segment in flight on the eight lanes of a group (lane of row i =
+// i mod 8), every lane two cells of its row per step.  A cell needs three cells of the row above and its own left neighbour: the left neighbour is the lane's own last
+// cell -- the row's chain M[q-1], I[q-1] is walked serially, literally, no prefix-maximum scan --, and the row above is one lane to the left, two cells per step like
+// this one.  Row i starts  1 + ceil(off / 2)  steps behind row i - 1 (off = the shift of its window, qS[i] - qS[i-1] >= 0): then the three cells above are exactly
+// among the four cells the lane to the left made in the last two steps (which two it takes depends on the parity of off), and they come over with seven DPP moves
+// (row_ror:2 -- the two groups of a 16-lane DPP row are its even and its odd lanes, so "one lane to the left, cyclically inside the group" is one rotation).
+// Nothing but the arrows and the lanes' next row descriptors / query bases touches memory; a row step of the row-wise kernels costs ~190 wave instructions for 60
+// cells (a prefix-maximum scan, thirteen cross-lane reads), a step here ~150 for ~120.
+// A lane is free for row i + 8 when that row has to start if  ceil(len_i / 2) <= sum over the eight rows between of (1 + ceil(off / 2)), which is >= 8: always for
+// rows of at most 16 cells; a segment whose wider rows break it is given up on the spot (nothing of it is used) and listed for ir_fill_16x2.
+__device__ __forceinline__ int ror2(int x) { return __builtin_amdgcn_update_dpp(0, x, 0x122, 0xf, 0xf, false); }   // lane l takes lane (l - 2) mod 16 of its DPP row
+
+__global__ void __launch_bounds__(64) ir_fill_diag(FillArgs F, int cls, uint32_t* retry, int* retryCursor) {
+  enum { ST_DONE = 0, ST_WAIT = 1, ST_RUN = 2 };
+  const int lane = threadIdx.x;
+  const int p = (lane & 15) >> 1;                                          // position in the group = row index mod 8
+  const int leader = lane & 0x31;                                          // the group's lane with p == 0
+  const unsigned long long gmask = (0x5555ULL << (lane & 1)) << (lane & 48);
+  const int g = F.g, go = 2 * F.g + 1, match = F.match, mismatch = F.mismatch;
+  const long listEnd = F.cursor[4 + cls];
+  // group state (identical on the eight lanes of a group)
+  bool segOn = false, listDone = false;
+  int tLen = 0, t = 0;
+  uint32_t segId = 0;
+  const Row* rows = nullptr; const unsigned char* qb = nullptr; unsigned char* P = nullptr;
+  long qLast = 0;
+  // lane state
+  int st = ST_DONE, row = 0, c = 0;
+  int pubRow = -1, pubT0 = 0;                                              // the row this lane started last, and when
+  Row cur; cur.S = cur.E = cur.T = 0; cur.C = 0;
+  int upS = 0, upLen = 0;                                                  // window start / length of the row above `cur`
+  Row nx = cur; int nxUpS = 0, nxUpLen = 0;                                // the same for the lane's row after this one (asked for when a row starts)
+  int Wrun = NEG, Vprev = NEG, Mprev = BAD;
+  int h1M0 = BAD, h1D0 = BAD, h1M1 = BAD, h1D1 = BAD, h2M0 = BAD, h2M1 = BAD, h2D1 = BAD;   // this lane's cells of the last step (both) and of the step before
+  int qn0 = 0, qn1 = 0;                                                    // the query bases of the lane's next two cells
+  while (true) {
+    // ---- a group without a segment takes the next one of the list
+    const bool need = !segOn && !listDone;
+    if (__ballot(need)) {
+      if (need) {
+        long x = 0;
+        if (p == 0) x = atomicAdd(&F.cursor[cls], 1);
+        x = __shfl(x, leader);
+        if (x < listEnd) {
+          segId = F.list[x];
+          const int a = F.s_aln[segId];
+          tLen = (int)F.s_rows[segId];
+          rows = F.rows + F.s_row_off[segId];
+          qb = (const unsigned char*)F.qseq + F.q_off[a];
+          qLast = (long)F.q_len[a] - 1;
+          P = F.path + F.s_cell_off[segId];
+          segOn = true; t = 0; pubRow = -1; pubT0 = 0;
+          row = p;
+          if (row < tLen) {
+            st = ST_WAIT;
+            cur = rows[row];
+            if (row > 0) { const Row u = rows[row - 1]; upS = u.S; upLen = u.E - u.S + 1; } else { upS = cur.S; upLen = 0; }
+            c = 0;
+            const long q0i = (long)cur.S, q1i = q0i + 1;
+            qn0 = qb[q0i < qLast ? q0i : qLast]; qn1 = qb[q1i < qLast ? q1i : qLast];
+          } else st = ST_DONE;
+        } else listDone = true;
+      }
+    }
+    if (__ballot(segOn) == 0ULL) break;
+    // ---- what the lane to the left has: its row, that row's first step, its cells of the last two steps
+    const int nbRow = ror2(pubRow), nbT0 = ror2(pubT0);
+    const int n1M0 = ror2(h1M0), n1D0 = ror2(h1D0), n1M1 = ror2(h1M1), n1D1 = ror2(h1D1), n2M0 = ror2(h2M0), n2M1 = ror2(h2M1), n2D1 = ror2(h2D1);
+    const int off = cur.S - upS;
+    bool conflict = false;
+    if (st == ST_WAIT) {
+      bool go_ = false;
+      if (row == 0) go_ = true;
+      else if (nbRow == row - 1) {
+        const int treq = nbT0 + 1 + ((off + 1) >> 1);
+        go_ = t == treq; conflict = t > treq;
+      }
+      if (go_) {
+        st = ST_RUN; c = 0; Wrun = NEG; Vprev = NEG; Mprev = BAD; pubRow = row; pubT0 = t;
+        if (row + 8 < tLen) { nx = rows[row + 8]; const Row u = rows[row + 7]; nxUpS = u.S; nxUpLen = u.E - u.S + 1; }
+      }
+    }
+    int o0M = BAD, o0D = BAD, o1M = BAD, o1D = BAD;
+    if (st == ST_RUN) {
+      const int len = cur.E - cur.S + 1, tch = cur.T;
+      const bool lastRow = row == tLen - 1, upNotFirst = row >= 2;
+      const bool odd = off & 1;
+      const int aM0 = odd ? n2M1 : n1M0, aD0 = odd ? n2D1 : n1D0, dM0 = odd ? n2M0 : n2M1;
+      const int aM1 = odd ? n1M0 : n1M1, aD1 = odd ? n1D0 : n1D1, dM1 = aM0;
+#define IR_CELL(cc_, aM_, aD_, dM_, qch_, oM_, oD_) do {                                                                                     \
+        const int cc = (cc_);                                                                                                                 \
+        const bool interior = cc >= 1 && (lastRow ? cc <= len - 1 : cc <= len - 2);                                                           \
+        const int srcA = cc + off, srcD = srcA - 1;                                                                                           \
+        const bool aboveIn = srcA <= upLen - 1;                              /* qE[ti-1] >= q   (:491,:548,:567) */                            \
+        const bool okA = aboveIn && !(srcA == upLen - 1 || (upNotFirst && srcA == 0));                                                         \
+        const bool okD = aboveIn && srcD >= 0 && !(srcD == upLen - 1 || (upNotFirst && srcD == 0));                                            \
+        const int dOpen = okA ? (aM_) + go : BAD, dExt = okA ? (aD_) : BAD;  /* :491-502 (gapExtend = 0) */                                    \
+        const int Dv = max(dOpen, dExt);                                                                                                      \
+        const int delOpen = (Dv == dOpen) ? 1 : 0;                           /* :504-516 */                                                    \
+        const int mS = okD ? (dM_) + (tch == (qch_) ? match : mismatch) : BAD;   /* :548-563 */                                                \
+        const int dS = okA ? (aM_) + g : BAD;                                /* :567-574 */                                                    \
+        const int V = interior ? max(mS, max(dS, Dv)) : NEG;                                                                                  \
+        const int Wm1 = Wrun, Vm1 = Vprev;                                   /* the row's prefix maximum of V and V itself, one cell to the left (cell 0: NEG) */ \
+        const int Iv = max(BAD, go + Wm1);                                                                                                    \
+        int M = max(max(BAD, V), max(Vm1 + g, go + Wm1));                                                                                     \
+        if (!interior) M = BAD;                                                                                                               \
+        int Mleft = Mprev;                                                                                                                    \
+        if (cc <= 1) Mleft = BAD;                                            /* the row's left boundary cell (:413-418) */                     \
+        const int iOpen = Mleft + go;                                        /* :523 */                                                        \
+        const int insOpen = (Iv == iOpen) ? 1 : 0;                           /* :528-540 */                                                    \
+        const int iS = Mleft + g;                                            /* :565 */                                                        \
+        int code;                                                                                                                             \
+        if (!interior) code = C_BOUND;                                                                                                        \
+        else if (M == mS) code = C_DIAG;                                     /* :583-616 */                                                    \
+        else if (M == iS) code = C_LEFT;                                                                                                      \
+        else if (M == dS) code = C_DOWN;                                                                                                      \
+        else if (M == Dv) code = C_DELCLOSE;                                                                                                  \
+        else code = C_INSCLOSE;                                                                                                               \
+        int outM = M, outD = interior ? Dv : BAD;                                                                                             \
+        unsigned char outB = (unsigned char)(code | (delOpen << 3) | (insOpen << 4));                                                         \
+        if (row == 0) {                                                      /* :407-431 first row */                                          \
+          const bool last0 = (cc == len - 1) && (tLen > 1);                                                                                   \
+          outM = last0 ? BAD : (cc == 0 ? 0 : cc * g);                                                                                        \
+          outD = BAD;                                                                                                                         \
+          outB = (unsigned char)(last0 ? C_BOUND : (cc == 0 ? C_DONE : C_LEFT));                                                              \
+        }                                                                                                                                     \
+        P[cur.C + cc] = outB;                                                                                                                 \
+        Wrun = max(Wrun, V); Vprev = V; Mprev = M;                                                                                            \
+        (oM_) = outM; (oD_) = outD;                                                                                                           \
+      } while (0)
+      IR_CELL(c, aM0, aD0, dM0, qn0, o0M, o0D);
+      if (c + 1 < len) IR_CELL(c + 1, aM1, aD1, dM1, qn1, o1M, o1D);
+#undef IR_CELL
+      c += 2;
+      if (c >= len) {                                                      // the row is through: the lane's next row is eight further on
+        row += 8;
+        if (row < tLen) { st = ST_WAIT; cur = nx; upS = nxUpS; upLen = nxUpLen; c = 0; }
+        else st = ST_DONE;
+      }
+    }
+    h2M0 = h1M0; h2M1 = h1M1; h2D1 = h1D1;
+    h1M0 = o0M; h1D0 = o0D; h1M1 = o1M; h1D1 = o1D;
+    // the bases of the lane's next two cells (a waiting lane: its row's first two)
+    if (st != ST_DONE) {
+      const long q0i = (long)cur.S + c, q1i = q0i + 1;
+      qn0 = qb[q0i < qLast ? q0i : qLast]; qn1 = qb[q1i < qLast ? q1i : qLast];   // past the read: its last base (the reference reads out of range there)
+    }
+    t++;
+    // ---- the group's segment is through (or given up)
+    const unsigned long long cf = __ballot(conflict), live = __ballot(segOn && st != ST_DONE);
+    if (segOn) {
+      if (cf & gmask) {
+        if (p == 0) retry[atomicAdd(&retryCursor[5], 1)] = segId;
+        segOn = false; st = ST_DONE;
+      } else if (!(live & gmask)) segOn = false;
+    }
+  }
+}
+
+// LRA_IR_DIAG_CHECK: the arrows of two fills of the same segments, byte for byte (a block per list entry)
+__global__ void ir_fill_compare(const uint32_t* __restrict__ list, long first, long n, const uint64_t* __restrict__ s_cell_off, const uint64_t* __restrict__ s_cells,
+                                const unsigned char* __restrict__ a, const unsigned char* __restrict__ b, unsigned long long* out) {
+  const long e = first + blockIdx.x;
+  if (e >= first + n) return;
+  const uint32_t s = list[e];
+  const uint64_t o = s_cell_off[s], m = s_cells[s];
+  unsigned long long bad = 0, firstBad = ~0ULL;
+  for (uint64_t i = threadIdx.x; i < m; i += blockDim.x) if (a[o + i] != b[o + i]) { bad++; if (i < firstBad) firstBad = i; }
+  if (bad) { atomicAdd(&out[0], bad); atomicAdd(&out[1], 1ULL); atomicMin(&out[2], ((unsigned long long)s << 32) | (firstBad & 0xffffffffULL)); }
+}
+
 struct TraceArgs {
   uint64_t n_seg;
   const int32_t* s_kind; const int32_t* s_tStart; const uint64_t* s_rows; const uint64_t* s_row_off;
@@ -1208,15 +1380,47 @@ extern "C" int lra_indel_refine_batch(lra_ctx* ctx, int n_aln, const int32_t* d_
     // a kernel's time is its longest segment's row chain, whatever the class: the classes side by side (the widest class of segments, usually the bulk, on the context's stream)
     static const bool no16x2 = getenv("LRA_IR_NO16X2") != nullptr;
     const uint64_t nWide = (uint64_t)(h_cursor[7] - h_cursor[3]);
-    if (n16) hipLaunchKernelGGL(ir_fill<16>, dim3((unsigned)std::min<uint64_t>((n16 + 3) / 4, cap_grid)), dim3(64), 0, lra_side_fork(ctx, 1), F);
+    // classes 0 and 1 (rows of at most 32 cells: nearly every segment of a read): the anti-diagonal kernel, eight segments per wave; a class-1 segment whose wide rows
+    // do not fit its schedule is listed by it and redone by ir_fill_16x2 behind it (the list's count never leaves the device).  LRA_IR_DIAG=0: the row-wise kernels.
+    static const bool diag = !(getenv("LRA_IR_DIAG") && atoi(getenv("LRA_IR_DIAG")) == 0);
+    uint32_t* retry_list = fill_lists + capSeg; int* retry_cursor = fill_counts + FILL_BINS + 8;
+    if (diag) LRA_HIP_CHECK(ctx, hipMemsetAsync(retry_cursor, 0, 32, st));
+    if (n16 && !diag) hipLaunchKernelGGL(ir_fill<16>, dim3((unsigned)std::min<uint64_t>((n16 + 3) / 4, cap_grid)), dim3(64), 0, lra_side_fork(ctx, 1), F);
+    if (n16 && diag) hipLaunchKernelGGL(ir_fill_diag, dim3((unsigned)std::min<uint64_t>((n16 + 7) / 8, cap_grid)), dim3(64), 0, lra_side_fork(ctx, 1), F, 0, retry_list, retry_cursor);
     if (n64) hipLaunchKernelGGL(ir_fill<64>, dim3((unsigned)std::min<uint64_t>(n64, cap_grid)), dim3(64), 0, lra_side_fork(ctx, 2), F);
     if (nWide) hipLaunchKernelGGL(ir_fill_wide, dim3((unsigned)std::min<uint64_t>(nWide, cap_grid)), dim3(64), 0, lra_side_fork(ctx, 3), F);
-    if (n32 && no16x2) hipLaunchKernelGGL(ir_fill<32>, dim3((unsigned)std::min<uint64_t>((n32 + 1) / 2, cap_grid)), dim3(64), 0, st, F);
-    if (n32 && !no16x2) hipLaunchKernelGGL(ir_fill_16x2, dim3((unsigned)std::min<uint64_t>((n32 + 3) / 4, cap_grid)), dim3(64), 0, st, F);
+    if (n32 && no16x2 && !diag) hipLaunchKernelGGL(ir_fill<32>, dim3((unsigned)std::min<uint64_t>((n32 + 1) / 2, cap_grid)), dim3(64), 0, st, F);
+    if (n32 && !no16x2 && !diag) hipLaunchKernelGGL(ir_fill_16x2, dim3((unsigned)std::min<uint64_t>((n32 + 3) / 4, cap_grid)), dim3(64), 0, st, F);
+    if (n32 && diag) {
+      hipLaunchKernelGGL(ir_fill_diag, dim3((unsigned)std::min<uint64_t>((n32 + 7) / 8, cap_grid)), dim3(64), 0, st, F, 1, retry_list, retry_cursor);
+      FillArgs F2 = F; F2.list = retry_list; F2.cursor = retry_cursor;
+      hipLaunchKernelGGL(ir_fill_16x2, dim3((unsigned)std::min<uint64_t>((n32 + 3) / 4, 2048)), dim3(64), 0, st, F2);
+    }
     if (n16) lra_side_join(ctx, 1);
     if (n64) lra_side_join(ctx, 2);
     if (nWide) lra_side_join(ctx, 3);
     lra_time_end(ctx);
+    if (diag && getenv("LRA_IR_DIAG_CHECK")) {                             // debugging: the row-wise kernels' arrows of the same segments beside the anti-diagonal kernel's
+      int h_retry[8];
+      if (d2h(ctx, h_retry, retry_cursor, 32)) return LRA_ERR_HIP;
+      unsigned char* path2 = nullptr; unsigned long long* d_bad = nullptr;
+      LRA_HIP_CHECK(ctx, hipMalloc((void**)&path2, n_cells + 512));
+      LRA_HIP_CHECK(ctx, hipMalloc((void**)&d_bad, 64));
+      const unsigned long long init[3] = {0, 0, ~0ULL};
+      LRA_HIP_CHECK(ctx, hipMemcpyAsync(d_bad, init, 24, hipMemcpyHostToDevice, st));
+      LRA_HIP_CHECK(ctx, hipMemcpyAsync(fill_cursor, h_cursor, 32, hipMemcpyHostToDevice, st));
+      FillArgs F3 = F; F3.path = path2;
+      if (n16) hipLaunchKernelGGL(ir_fill<16>, dim3((unsigned)std::min<uint64_t>((n16 + 3) / 4, cap_grid)), dim3(64), 0, st, F3);
+      if (n32) hipLaunchKernelGGL(ir_fill_16x2, dim3((unsigned)std::min<uint64_t>((n32 + 3) / 4, cap_grid)), dim3(64), 0, st, F3);
+      if (n16) hipLaunchKernelGGL(ir_fill_compare, dim3((unsigned)n16), dim3(256), 0, st, (const uint32_t*)fill_lists, (long)h_cursor[0], (long)n16, s_cell_off, s_cells, path, path2, d_bad);
+      if (n32) hipLaunchKernelGGL(ir_fill_compare, dim3((unsigned)n32), dim3(256), 0, st, (const uint32_t*)fill_lists, (long)h_cursor[1], (long)n32, s_cell_off, s_cells, path, path2, d_bad);
+      unsigned long long h_bad[3];
+      if (d2h(ctx, h_bad, d_bad, 24)) return LRA_ERR_HIP;
+      fprintf(stderr, "[ir diag check] segments %llu + %llu, redone row-wise %d; cells that differ %llu in %llu segments%s", (unsigned long long)n16, (unsigned long long)n32,
+              h_retry[5], h_bad[0], h_bad[1], h_bad[1] ? "" : "\n");
+      if (h_bad[1]) fprintf(stderr, "; first: segment %llu cell %llu\n", h_bad[2] >> 32, h_bad[2] & 0xffffffffULL);
+      (void)hipFree(path2); (void)hipFree(d_bad);
+    }
     TraceArgs T;
     T.n_seg = n_seg; T.s_kind = A.s_kind; T.s_tStart = A.s_tStart; T.s_rows = A.s_rows; T.s_row_off = s_row_off;
     T.s_cells = s_cells; T.s_cell_off = s_cell_off; T.s_status = s_status; T.rows = rows; T.path = path;
