@@ -124,8 +124,10 @@ def main():
                     help="1 = two-stage batches (lra_map_reads_lowacc_front / _back): the front half of step i + 1 on one host thread beside the back half of step i on another")
     ap.add_argument("--front-priority", default=os.environ.get("LRA_BENCH_FRONT_PRIORITY", "low"), choices=["low", "normal"],
                     help="with --two-stage: the stream priority of the front halves (the back halves: LRA_BACK_PRIORITY, default the highest)")
-    ap.add_argument("--seed-ahead", type=int, default=int(os.environ.get("LRA_BENCH_SEED_AHEAD", 1)),
-                    help="1 = a step's seed stage (a1-a4) runs beside the step before it, on a side context (lra_seed_prefetch / lra_ctx_adopt_seed); 0 = every step seeds itself")
+    ap.add_argument("--seed-ahead", type=int, default=int(os.environ.get("LRA_BENCH_SEED_AHEAD", -1)),
+                    help="1 = a step's seed stage (a1-a4) runs beside the step before it, on a side context (lra_seed_prefetch / lra_ctx_adopt_seed); 0 = every step seeds itself; "
+                         "2 = also with two-stage batches (the seed stage of the front half after next on a third context: ~30 GB more); -1 (default) = 2 when, after the first "
+                         "warm-up step, at least LRA_BENCH_SEED_AHEAD_FREE_GB (40) of HBM are free, else 1")
     ap.add_argument("--seed-ahead-delay-ms", type=float, default=float(os.environ.get("LRA_BENCH_SEED_AHEAD_DELAY_MS", 300)),
                     help="how long into a step the seeding of the next one starts")
     ap.add_argument("--lane-priority", type=int, default=int(os.environ.get("LRA_BENCH_LANE_PRIORITY", 1)),
@@ -243,16 +245,21 @@ def main():
             err.append(e)
 
     two_stage = bool(args.two_stage) and args.lanes == 1 and not defer_T
-    ahead_on = bool(args.seed_ahead) and args.lanes == 1 and not defer_T and (not two_stage or args.seed_ahead == 2)   # (2: also with two-stage batches -- an experiment)
+    sa_auto = args.seed_ahead < 0
+    def ahead_wanted(sa):
+        return bool(sa) and args.lanes == 1 and not defer_T and (not two_stage or sa == 2)   # (2: also with two-stage batches)
+    ahead_on = ahead_wanted(1 if sa_auto else args.seed_ahead)           # (auto: decided behind the first warm-up step, below)
     if two_stage:                                                          # the front halves are the work done ahead: below the back halves' priority
         fstream_ = torch.cuda.Stream(device=dev_index, priority=prio_lo if args.front_priority == "low" else 0)
         ctx.bind_stream(fstream_)
-    ahead = {}
-    if ahead_on:
+    ahead = {"on": ahead_on}
+    def make_ahead():
         ahead["ctx"] = Context(dev_index)
         mapread.LowAccMapper.sharing(ahead["ctx"], mapper)
         ahead["stream"] = torch.cuda.Stream(device=dev_index, priority=prio_lo)
         ahead["ctx"].bind_stream(ahead["stream"])
+    if ahead["on"]:
+        make_ahead()
 
     def seed_ahead(sub):
         try:
@@ -273,7 +280,7 @@ def main():
             lc = lane["ctx"]
             def run():
                 tA_ = time.perf_counter()
-                if ahead_on and not two_stage:
+                if ahead["on"] and not two_stage:
                     # the seeding of the NEXT step's batch beside this step (lra_seed_prefetch on a side context, low-priority stream, a host thread of its own), and this
                     # step's own seed result -- made beside the previous step -- adopted instead of seeding: every timed step runs one alignment pass and one seeding
                     th_ = ahead.pop("thread", None)
@@ -476,7 +483,7 @@ def main():
                     handed = False
                     if not err:
                         try:
-                            if ahead_on:                                   # (--seed-ahead 2: the seed stage of the front half after this one on a third context)
+                            if ahead["on"]:                               # (--seed-ahead 2: the seed stage of the front half after this one on a third context)
                                 th_ = ahead.pop("thread", None)
                                 if th_ is not None:
                                     th_.join()
@@ -530,10 +537,26 @@ def main():
         torch.cuda.synchronize()
 
     # (the first warm-up step allocates the contexts' work buffers -- seconds -- so the lanes' stagger is taken from the LAST warm-up step alone)
-    run_steps(max(args.warmup - 1, 0), 0.0)
+    n_warm = args.warmup
+    if sa_auto and two_stage and args.lanes == 1 and not defer_T and not ahead["on"] and n_warm >= 2:
+        # the third stage of the pipeline -- the seed stage of the front half after next on a context of its own -- where the device has the memory for it: every work
+        # buffer of the two halves exists after the first step, the seed context needs ~30 GB, and the warm-up steps that follow allocate it outside the timed region
+        run_steps(1, 0.0); n_warm -= 1
+        torch.cuda.synchronize()
+        free_b, _ = torch.cuda.mem_get_info(dev_index)
+        ok_ = free_b >= float(os.environ.get("LRA_BENCH_SEED_AHEAD_FREE_GB", 40)) * 1e9
+        if world > 1:                                                      # (every rank the same pipeline)
+            tf_ = torch.tensor([1 if ok_ else 0], dtype=torch.int32, device=dev)
+            dist.all_reduce(tf_, op=dist.ReduceOp.MIN)
+            ok_ = bool(tf_.item())
+        if ok_:
+            args.seed_ahead = 2
+            make_ahead(); ahead["on"] = True
+    run_steps(max(n_warm - 1, 0), 0.0)
     tw = time.perf_counter()
-    run_steps(min(args.warmup, 1), 0.0)
-    step_guess = (time.perf_counter() - tw) if args.warmup > 1 else 0.0
+    run_steps(min(n_warm, 1), 0.0)
+    step_guess = (time.perf_counter() - tw) if n_warm > 1 else 0.0
+    ahead_on = ahead["on"]
     timed = lanes + ([heavy["lane"]] if defer_T and args.heavy_lane else [])
     if ahead_on:
         ahead["ctx"].timing(True); ahead["ctx"].timing_reset()

@@ -1381,8 +1381,8 @@ extern "C" int lra_indel_refine_batch(lra_ctx* ctx, int n_aln, const int32_t* d_
     static const bool no16x2 = getenv("LRA_IR_NO16X2") != nullptr;
     const uint64_t nWide = (uint64_t)(h_cursor[7] - h_cursor[3]);
     // classes 0 and 1 (rows of at most 32 cells: nearly every segment of a read): the anti-diagonal kernel, eight segments per wave; a class-1 segment whose wide rows
-    // do not fit its schedule is listed by it and redone by ir_fill_16x2 behind it (the list's count never leaves the device).  LRA_IR_DIAG=0: the row-wise kernels.
-    static const bool diag = !(getenv("LRA_IR_DIAG") && atoi(getenv("LRA_IR_DIAG")) == 0);
+    // do not fit its schedule is listed by it and redone by ir_fill_16x2 behind it (the list's count never leaves the device).  LRA_IR_DIAG=1 switches it on.
+    static const bool diag = getenv("LRA_IR_DIAG") && atoi(getenv("LRA_IR_DIAG")) == 1;   // (off: measured slower so far -- half its lanes idle, a memory wait per step)
     uint32_t* retry_list = fill_lists + capSeg; int* retry_cursor = fill_counts + FILL_BINS + 8;
     if (diag) LRA_HIP_CHECK(ctx, hipMemsetAsync(retry_cursor, 0, 32, st));
     if (n16 && !diag) hipLaunchKernelGGL(ir_fill<16>, dim3((unsigned)std::min<uint64_t>((n16 + 3) / 4, cap_grid)), dim3(64), 0, lra_side_fork(ctx, 1), F);

@@ -666,7 +666,11 @@ static int lowacc_core(lra_ctx* ctx, int n_reads, const char* d_seq, const uint6
     lra_ctx* hs = H->hand[H->seq & 1];
     for (int slot : {56, 57, 81, 82}) { std::swap(ctx->gbuf[slot], hs->gbuf[slot]); std::swap(ctx->gbytes[slot], hs->gbytes[slot]); }
     hs->stream = st;                                                       // (a handover context has no stream of its own: its one stage runs on the front half's)
+    // (the stage's work arrays -- per refined match, dead when it returns -- and its sort's scratch are this context's, lent for the call: one set, not one per handover context)
+    auto lend = [&]() { std::swap(ctx->gbuf[100], hs->gbuf[100]); std::swap(ctx->gbytes[100], hs->gbytes[100]); std::swap(ctx->scratch[2], hs->scratch[2]); std::swap(ctx->scratch_bytes[2], hs->scratch_bytes[2]); };
+    lend();
     rc = lra_merge_extend_batch(hs, &chres, &spres, &bres, d_seq, d_read_off, genome, CH, nCh, o->localK, &in.mres);
+    lend();
     if (rc) return lra_set_err(ctx, rc, "MergeChain into the handover buffers: %s", hs->err.c_str());
     LRA_HIP_CHECK(ctx, hipStreamSynchronize(st));
     stage("merge_extend");

@@ -220,18 +220,20 @@ extern "C" int lra_merge_extend_batch(lra_ctx* ctx, const lra_chain_result* ch, 
   LRA_HIP_CHECK(ctx, hipMemcpyAsync(&NG, grBase + slots, 8, hipMemcpyDeviceToHost, st));
   LRA_HIP_CHECK(ctx, hipStreamSynchronize(st));
   out->n_groups = NG; out->d_slot_group_off = grBase;
-  char* wc = (char*)lra_ensure(ctx, 38, sz(NCL + 1, 8) * 2 + sz(NCL + 1, 4) * 5 + sz(4 * NCL + 4, 4) + sz(NG + 2, 4) * 6 + sz(4 * NG + 4, 4) + sz(NG + 2, 8) * 2 +
-                                           sz(NM + 1, 8) * 2 + sz(NM + 1, 4) * 6 + 4096);
-  if (!wc) return LRA_ERR_NOMEM;
+  // (the per-cluster / per-group arrays are part of the result; the per-match arrays -- sort keys, gathered and extended matches -- are dead when the call returns: a
+  // slot of their own, so that a caller with several result contexts can lend them ONE, lra_map_reads_lowacc_front)
+  char* wc = (char*)lra_ensure(ctx, 38, sz(NCL + 1, 8) * 2 + sz(NCL + 1, 4) * 5 + sz(4 * NCL + 4, 4) + sz(NG + 2, 4) * 6 + sz(4 * NG + 4, 4) + sz(NG + 2, 8) * 2 + 4096);
+  char* wm = (char*)lra_ensure(ctx, 100, sz(NM + 1, 8) * 2 + sz(NM + 1, 4) * 6 + 4096);
+  if (!wc || !wm) return LRA_ERR_NOMEM;
   a.cStart = (uint64_t*)take(wc, NCL + 1, 8); a.cEnd = (uint64_t*)take(wc, NCL + 1, 8);
   a.cStrand = (int*)take(wc, NCL + 1, 4); a.cChrom = (int*)take(wc, NCL + 1, 4); a.cRead = (int*)take(wc, NCL + 1, 4); a.cGroup = (uint32_t*)take(wc, NCL + 1, 4);
   uint32_t* eCount = (uint32_t*)take(wc, NCL + 1, 4); uint32_t* ebox = (uint32_t*)take(wc, 4 * NCL + 4, 4);
   a.gFirst = (uint32_t*)take(wc, NG + 2, 4); a.gLast = (uint32_t*)take(wc, NG + 2, 4); a.gSlot = (uint32_t*)take(wc, NG + 2, 4); a.gSize = (uint32_t*)take(wc, NG + 2, 4);
   a.gstrand = (int32_t*)take(wc, NG + 2, 4); a.gchrom = (int32_t*)take(wc, NG + 2, 4); a.gbox = (uint32_t*)take(wc, 4 * NG + 4, 4);
   uint64_t* anchorOff = (uint64_t*)take(wc, NG + 2, 8); uint64_t* iota = (uint64_t*)take(wc, NG + 2, 8);
-  uint64_t* key = (uint64_t*)take(wc, NM + 1, 8); uint64_t* key2 = (uint64_t*)take(wc, NM + 1, 8);
-  uint32_t* val = (uint32_t*)take(wc, NM + 1, 4); uint32_t* val2 = (uint32_t*)take(wc, NM + 1, 4); uint32_t* sq = (uint32_t*)take(wc, NM + 1, 4);
-  uint32_t* stt = (uint32_t*)take(wc, NM + 1, 4); uint32_t* eq = (uint32_t*)take(wc, NM + 1, 4); uint32_t* et = (uint32_t*)take(wc, NM + 1, 4);
+  uint64_t* key = (uint64_t*)take(wm, NM + 1, 8); uint64_t* key2 = (uint64_t*)take(wm, NM + 1, 8);
+  uint32_t* val = (uint32_t*)take(wm, NM + 1, 4); uint32_t* val2 = (uint32_t*)take(wm, NM + 1, 4); uint32_t* sq = (uint32_t*)take(wm, NM + 1, 4);
+  uint32_t* stt = (uint32_t*)take(wm, NM + 1, 4); uint32_t* eq = (uint32_t*)take(wm, NM + 1, 4); uint32_t* et = (uint32_t*)take(wm, NM + 1, 4);
   int* el = (int*)key;                                                   // the sort keys are dead once the matches are gathered
   a.eCount = eCount; a.eq = eq; a.et = et; a.el = el; a.anchorOff = anchorOff; a.scratch = key2;
   if (NCL == 0) { LRA_HIP_CHECK(ctx, hipMemsetAsync(anchorOff, 0, 16, st)); LRA_HIP_CHECK(ctx, hipStreamSynchronize(st)); out->d_anchor_off = anchorOff; return LRA_OK; }

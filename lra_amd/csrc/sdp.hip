@@ -920,7 +920,9 @@ __device__ bool coop_grow_pairs(int2* pairs, uint32_t& off, int& cap, int used, 
 // Block stores, so each sees its own) with the next 64 Di / Dv / Db and
 // Ei[Db] prefetched one per lane, and the two binary searches (FindBoundary, FindValueInBlock's UPPERbound) probe six levels
 // per memory round.  Value[ii] is then the (max value, first in visit order) reduction the ordered `val < Ev` updates compute.
-__global__ void __launch_bounds__(64, 4) sdp_process(ProcArgs a) {
+template <int FAT>
+__global__ void __launch_bounds__(64, FAT ? 2 : 4) sdp_process(ProcArgs a) {
+  if (FAT) asm volatile("v_mov_b32 v250, 0" ::: "v250");   // (experiment: the same kernel holding 256 registers per lane)
   __shared__ float s_slope[25], s_inter[25];
   __shared__ short s_pen[PEN_TAB_WAVE];
   const int lane = threadIdx.x;
@@ -2227,7 +2229,7 @@ int sdp_run(lra_ctx* ctx, int n_reads, const uint64_t* d_cluster_off, const uint
         if (maxRC <= 32768) { if (dbg) hipLaunchKernelGGL((sdp_process_wg<2, true>), dim3(nbig), dim3(64 * WG_NW), 0, ws, pa); else hipLaunchKernelGGL((sdp_process_wg<2, false>), dim3(nbig), dim3(64 * WG_NW), 0, ws, pa); }
         else { if (dbg) hipLaunchKernelGGL((sdp_process_wg<3, true>), dim3(nbig), dim3(64 * WG_NW), 0, ws, pa); else hipLaunchKernelGGL((sdp_process_wg<3, false>), dim3(nbig), dim3(64 * WG_NW), 0, ws, pa); }
       }
-      if (nsub > nbig) { ProcArgs pb = pa; pb.order = subOrder + nbig; pb.n = nsub - nbig; hipLaunchKernelGGL(sdp_process, dim3(nsub - nbig), dim3(64), 0, st, pb); }
+      if (nsub > nbig) { ProcArgs pb = pa; pb.order = subOrder + nbig; pb.n = nsub - nbig; static const int padLds = getenv("LRA_SDP_PAD_LDS") ? atoi(getenv("LRA_SDP_PAD_LDS")) : 0; static const bool fat = getenv("LRA_SDP_FAT") != nullptr; if (fat) hipLaunchKernelGGL(sdp_process<1>, dim3(nsub - nbig), dim3(64), (size_t)padLds, st, pb); else hipLaunchKernelGGL(sdp_process<0>, dim3(nsub - nbig), dim3(64), (size_t)padLds, st, pb); }
       if (forked) lra_side_join(ctx);
       lra_time_end(ctx);
       if (dbg) {
