@@ -37,7 +37,7 @@ struct lra_ctx {
   uint64_t* scan_tmp = nullptr;
   // lra_side_fork / lra_side_join: further streams for kernels that would only extend a stage's tail on the context's own stream
   static constexpr int N_SIDE = 4;
-  hipStream_t side[N_SIDE] = {}; hipEvent_t ev_fork = nullptr, ev_join[N_SIDE] = {};
+  hipStream_t side[N_SIDE] = {}; hipEvent_t ev_fork = nullptr, ev_join[N_SIDE] = {}, ev_mid = nullptr;   // ev_mid: a point on a side stream the main stream waits for (sdp.hip: the large reads' build)
   void* gbuf[192] = {};   // growable result / work buffers (lra_ensure)
   size_t gbytes[192] = {};
   // kernel timing

@@ -119,6 +119,7 @@ extern "C" void lra_ctx_destroy(lra_ctx* ctx) {
     if (ctx->ev_join[i]) (void)hipEventDestroy(ctx->ev_join[i]);
   }
   if (ctx->ev_fork) (void)hipEventDestroy(ctx->ev_fork);
+  if (ctx->ev_mid) (void)hipEventDestroy(ctx->ev_mid);
   if (ctx->owns_stream && ctx->stream) (void)hipStreamDestroy(ctx->stream);
   delete ctx;
 }

@@ -125,6 +125,25 @@ __global__ void k_visit_clear(const ReadArena* __restrict__ ra, const uint64_t* 
   for (uint64_t i = threadIdx.x; i < n; i += blockDim.x) p[i] = make_uint4(NONE, NONE, NONE, NONE);
 }
 
+// The distinct rows and columns (GetRowInfo / GetColInfo) of the reads a launch gives a workgroup each, ahead of their build: the maximum picks the sdp_process_wg
+// variant, so that the workgroup ProcessPoint launch can follow the large reads' build on its side stream without a word from the host in between.
+__global__ void k_big_lines(int r0, const uint32_t* __restrict__ order, const uint64_t* __restrict__ ptOff, const uint32_t* __restrict__ hq, const uint32_t* __restrict__ ht,
+                            const uint32_t* __restrict__ h2, uint32_t* maxLines) {
+  const int r = r0 + (int)order[blockIdx.x];
+  const uint64_t p0 = ptOff[r];
+  const int P = (int)(ptOff[r + 1] - p0);
+  const uint32_t* q = hq + p0; const uint32_t* t = ht + p0; const uint32_t* c = h2 + p0;
+  uint32_t R = 0, C = 0;
+  for (int i = threadIdx.x; i < P; i += blockDim.x) { R += (i == 0 || q[i] != q[i - 1]); C += (i == 0 || t[c[i]] != t[c[i - 1]]); }
+  for (int o = 32; o > 0; o >>= 1) { R += __shfl_xor(R, o); C += __shfl_xor(C, o); }
+  __shared__ uint32_t sR, sC;
+  if (threadIdx.x == 0) { sR = 0; sC = 0; }
+  __syncthreads();
+  if ((threadIdx.x & 63) == 0) { atomicAdd(&sR, R); atomicAdd(&sC, C); }
+  __syncthreads();
+  if (threadIdx.x == 0) atomicMax(maxLines, max(sR, sC));
+}
+
 // ---- counting / point generation ------------------------------------------------------------------------------------
 __global__ void k_cluster_counts(uint64_t nc, const uint32_t* __restrict__ c_count, uint32_t* fragCnt, uint32_t* ptCnt, int single) {
   uint64_t c = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -2159,21 +2178,12 @@ int sdp_run(lra_ctx* ctx, int n_reads, const uint64_t* d_cluster_off, const uint
       const int shift = 3 * att;
       const int slot = att == 0 ? 12 : 21 + att;
       if (onePass && att == 1) count_pass(subOrder, h_prev, nsub);         // (exact sizes for the reads that come back: some outgrew their estimated blocks)
-      hipLaunchKernelGGL(k_arena_sizes, dim3((nsub + 255) / 256), dim3(256), 0, st, nsub, r0, ptOff, cntE, cntN, cntD, ra, bytes, subOrder, shift);
-      { int rc = lra_exclusive_scan<uint64_t>(ctx, nsub, bytes, byteOff); if (rc) return rc; }
-      uint64_t totB = 0;
-      LRA_HIP_CHECK(ctx, hipMemcpyAsync(&totB, byteOff + nsub, 8, hipMemcpyDeviceToHost, st));
-      LRA_HIP_CHECK(ctx, hipStreamSynchronize(st));
-      char* arena = (char*)lra_ensure(ctx, slot, totB + 4096);
-      if (!arena) return LRA_ERR_NOMEM;
-      hipLaunchKernelGGL(k_arena_bases, dim3((nsub + 255) / 256), dim3(256), 0, st, nsub, byteOff, ra, subOrder, arena);
-      lra_time_begin(ctx, ctx->sdp_inner ? "sdp_inner_build" : "sdp_build");
-      hipLaunchKernelGGL(k_visit_clear, dim3(nsub), dim3(256), 0, st, ra, byteOff, subOrder);
-      ba.ra = ra; ba.order = subOrder;
+      static const bool dbg = getenv("LRA_SDP_DBG") != nullptr;
+      // which reads of this attempt get a workgroup each (they are ordered by their number of points, largest first)
+      const std::vector<uint32_t>& ordAtt = att == 0 ? h_orderAll : h_prev;
       int nbig = 0;
       {
         const long big_pts = sdp_big_points(ctx, opts->mode);   // (tests lower it to run small reads through the workgroup kernels)
-        const std::vector<uint32_t>& ord = att == 0 ? h_orderAll : h_prev;
         // ... but no more of them than the device runs side by side (a workgroup holds 16 wave slots for a per-point latency a third of the wave kernel's, at 3.5 times its
         // wave-time per point): beyond that the large reads queue up behind each other, and the ones further down the order are better off as one wave each
         static const int maxBigEnv = getenv("LRA_SDP_MAX_BIG") ? std::max(0, atoi(getenv("LRA_SDP_MAX_BIG"))) : -1;
@@ -2181,54 +2191,91 @@ int sdp_run(lra_ctx* ctx, int n_reads, const uint64_t* d_cluster_off, const uint
         const int maxBigAll = maxBigEnv >= 0 ? maxBigEnv : ctx->pipelined ? ctx->num_cu : (1 << 30);
         static const int maxBigA = getenv("LRA_SDP_MAX_BIG_A") ? std::max(0, atoi(getenv("LRA_SDP_MAX_BIG_A"))) : 512;
         const int maxBig = (opts->mode == 0 && !ctx->sdp_inner) ? std::min(maxBigAll, maxBigA) : maxBigAll;
-        while (nbig < nsub && nbig < maxBig && (long)(h_pt[r0 + ord[nbig] + 1] - h_pt[r0 + ord[nbig]]) >= big_pts) nbig++;
+        while (nbig < nsub && nbig < maxBig && (long)(h_pt[r0 + ordAtt[nbig] + 1] - h_pt[r0 + ordAtt[nbig]]) >= big_pts) nbig++;
       }
-      {
-        const bool forked = nbig > 0 && nsub > nbig;
+      const bool forked = nbig > 0 && nsub > nbig;
+      // LARGE READS FIRST (attempt 0, LRA_SDP_BIG_FIRST=0 switches it off).  The stage is as long as the chain build -> ProcessPoint of its largest read, and that read is one
+      // of the workgroup jobs: their build goes first, on the side stream, with nothing of this stage beside it; their ProcessPoint launch follows it on that stream at
+      // once -- what it needs from the host (the per-anchor words' offsets, the kernel variant) is made ready before the builds: the variant from the large reads' own rows /
+      // columns (k_big_lines) instead of the emit pass's counts --; the small reads' builds start behind the large reads' build and their wave-per-read ProcessPoint launch
+      // behind those, beside the workgroup launch as before.  What used to be  max(builds) + max(ProcessPoint launches)  is  build_large + max(wg, builds_small + wave).
+      static const bool bigFirstEnv = !(getenv("LRA_SDP_BIG_FIRST") && getenv("LRA_SDP_BIG_FIRST")[0] == '0');
+      const bool early = bigFirstEnv && att == 0 && onePass && forked && !dbg;
+      // the large reads' per-anchor words (see sdp_process_wg)
+      char* wsc = nullptr; uint64_t* dwoff = nullptr; uint32_t* d_maxLines = nullptr;
+      std::vector<uint64_t> woff((size_t)nbig + 1, 0);
+      if (nbig > 0) {
+        for (int i = 0; i < nbig; i++) {
+          const uint64_t rdx = (uint64_t)r0 + ordAtt[i];
+          const uint64_t Fr = h_frag[rdx + 1] - h_frag[rdx], Pr = h_pt[rdx + 1] - h_pt[rdx];
+          woff[i + 1] = woff[i] + ((36 * Fr + 4 * Pr + 64 + 8 + 256 * 8 + 255) & ~(uint64_t)255);
+        }
+        wsc = (char*)lra_ensure(ctx, 177, woff[nbig] + 256);
+        dwoff = (uint64_t*)lra_ensure(ctx, 178, ((size_t)nbig + 4) * 8);
+        if (!wsc || !dwoff) return LRA_ERR_NOMEM;
+        d_maxLines = (uint32_t*)(dwoff + nbig + 2);
+        LRA_HIP_CHECK(ctx, hipMemcpyAsync(dwoff, woff.data(), ((size_t)nbig + 1) * 8, hipMemcpyHostToDevice, st));   // (woff lives until the stream has been waited for, below)
+        if (early) {
+          LRA_HIP_CHECK(ctx, hipMemsetAsync(d_maxLines, 0, 4, st));
+          hipLaunchKernelGGL(k_big_lines, dim3(nbig), dim3(256), 0, st, r0, (const uint32_t*)subOrder, ptOff, (const uint32_t*)hq, (const uint32_t*)ht, (const uint32_t*)pay2, d_maxLines);
+        }
+      }
+      hipLaunchKernelGGL(k_arena_sizes, dim3((nsub + 255) / 256), dim3(256), 0, st, nsub, r0, ptOff, cntE, cntN, cntD, ra, bytes, subOrder, shift);
+      { int rc = lra_exclusive_scan<uint64_t>(ctx, nsub, bytes, byteOff); if (rc) return rc; }
+      uint64_t totB = 0; uint32_t bigLines = 0;
+      LRA_HIP_CHECK(ctx, hipMemcpyAsync(&totB, byteOff + nsub, 8, hipMemcpyDeviceToHost, st));
+      if (early) LRA_HIP_CHECK(ctx, hipMemcpyAsync(&bigLines, d_maxLines, 4, hipMemcpyDeviceToHost, st));
+      LRA_HIP_CHECK(ctx, hipStreamSynchronize(st));
+      char* arena = (char*)lra_ensure(ctx, slot, totB + 4096);
+      if (!arena) return LRA_ERR_NOMEM;
+      hipLaunchKernelGGL(k_arena_bases, dim3((nsub + 255) / 256), dim3(256), 0, st, nsub, byteOff, ra, subOrder, arena);
+      ProcArgs pa;
+      pa.wgScratch = wsc; pa.wgOff = dwoff; pa.dbg = (dbg && nbig > 0) ? 1 : 0; { const char* e = getenv("LRA_SDP_WG_RING"); pa.wgNoRing = (e && e[0] == '0') ? 1 : 0; }
+      uint64_t dbgOff0 = 0; char* dbgBase = nullptr;
+      if (nbig > 0) { dbgOff0 = woff[0] + 36 * (h_frag[(uint64_t)r0 + ordAtt[0] + 1] - h_frag[(uint64_t)r0 + ordAtt[0]]) + 4 * (h_pt[(uint64_t)r0 + ordAtt[0] + 1] - h_pt[(uint64_t)r0 + ordAtt[0]]); dbgBase = wsc; }
+      pa.r0 = r0; pa.n = nsub; pa.order = subOrder; pa.ptOff = ptOff; pa.fragOff = fragOff; pa.hfl = hfl; pa.hfr = hfr; pa.flen = flen; pa.fval = fval;
+      pa.fprevNode = fprevNode; pa.fprevInd = fprevInd; pa.fflags = fflags; pa.rate_in = d_rate; pa.rate = opts->rate; pa.ra = ra;
+      pa.status = status; pa.pwl = pw; pa.poolUsed = poolUsed; pa.penTab = d_penTab; pa.penN = penN;
+      // (levels used = ceil(log2(lines)) + 1: up to 2^15 distinct rows and columns stay within levels 0..15)
+      auto launch_wg = [&](hipStream_t ws, uint32_t lines) {
+        if (lines <= 32768) { if (dbg) hipLaunchKernelGGL((sdp_process_wg<2, true>), dim3(nbig), dim3(64 * WG_NW), 0, ws, pa); else hipLaunchKernelGGL((sdp_process_wg<2, false>), dim3(nbig), dim3(64 * WG_NW), 0, ws, pa); }
+        else { if (dbg) hipLaunchKernelGGL((sdp_process_wg<3, true>), dim3(nbig), dim3(64 * WG_NW), 0, ws, pa); else hipLaunchKernelGGL((sdp_process_wg<3, false>), dim3(nbig), dim3(64 * WG_NW), 0, ws, pa); }
+      };
+      if (early) LRA_HIP_CHECK(ctx, hipMemsetAsync(poolUsed, 0, (size_t)nr * 4, st));   // (in front of the fork: the workgroup launch uses its reads' pools)
+      lra_time_begin(ctx, ctx->sdp_inner ? "sdp_inner_build" : "sdp_build");
+      hipLaunchKernelGGL(k_visit_clear, dim3(nsub), dim3(256), 0, st, ra, byteOff, subOrder);
+      ba.ra = ra; ba.order = subOrder;
+      if (early) {
+        hipStream_t ws = lra_side_fork(ctx);
+        if (ws == st) {                                                  // (no side stream: the old order, everything on the one stream)
+          hipLaunchKernelGGL((sdp_build<true, 16>), dim3(nbig), dim3(1024), 0, st, ba);
+          launch_small_builds<true>(ctx, ba, subOrder, ordAtt, h_pt.data() + r0, nbig, nsub);
+          launch_wg(st, bigLines);
+        } else {
+          hipLaunchKernelGGL((sdp_build<true, 16>), dim3(nbig), dim3(1024), 0, ws, ba);
+          // the small reads' builds behind the large reads' build (an event of its own: the join event is the end of the workgroup ProcessPoint launch)
+          if (!ctx->ev_mid) (void)hipEventCreateWithFlags(&ctx->ev_mid, hipEventDisableTiming);
+          if (ctx->ev_mid) { (void)hipEventRecord(ctx->ev_mid, ws); (void)hipStreamWaitEvent(st, ctx->ev_mid, 0); }
+          lra_time_begin(ctx, ctx->sdp_inner ? "sdp_inner_process_wg" : "sdp_process_wg", ws);
+          launch_wg(ws, bigLines);
+          lra_time_end(ctx, ws);
+          launch_small_builds<true>(ctx, ba, subOrder, ordAtt, h_pt.data() + r0, nbig, nsub);
+        }
+      } else {
         if (nbig > 0) hipLaunchKernelGGL((sdp_build<true, 16>), dim3(nbig), dim3(1024), 0, forked ? lra_side_fork(ctx) : st, ba);
-        if (nsub > nbig) launch_small_builds<true>(ctx, ba, subOrder, att == 0 ? h_orderAll : h_prev, h_pt.data() + r0, nbig, nsub);
+        if (nsub > nbig) launch_small_builds<true>(ctx, ba, subOrder, ordAtt, h_pt.data() + r0, nbig, nsub);
         if (forked) lra_side_join(ctx);
       }
       lra_time_end(ctx);
       if (onePass && att == 0) { int rc = read_rc(); if (rc) return rc; }   // (rows / columns of the reads, known after the emit pass only)
       if (att > 0)
         hipLaunchKernelGGL(k_reset_frags, dim3(nsub), dim3(64), 0, st, r0, subOrder, fragOff, flen, d_rate, opts->rate, fval, fprevNode, fprevInd, fflags, status);
-      ProcArgs pa;
-      pa.wgScratch = nullptr; pa.wgOff = nullptr; pa.dbg = 0; { const char* e = getenv("LRA_SDP_WG_RING"); pa.wgNoRing = (e && e[0] == '0') ? 1 : 0; }
-      uint64_t dbgOff0 = 0; char* dbgBase = nullptr;
-      pa.r0 = r0; pa.n = nsub; pa.order = subOrder; pa.ptOff = ptOff; pa.fragOff = fragOff; pa.hfl = hfl; pa.hfr = hfr; pa.flen = flen; pa.fval = fval;
-      pa.fprevNode = fprevNode; pa.fprevInd = fprevInd; pa.fflags = fflags; pa.rate_in = d_rate; pa.rate = opts->rate; pa.ra = ra;
-      pa.status = status; pa.pwl = pw; pa.poolUsed = poolUsed; pa.penTab = d_penTab; pa.penN = penN;
-      LRA_HIP_CHECK(ctx, hipMemsetAsync(poolUsed, 0, (size_t)nr * 4, st));
-      static const bool dbg = getenv("LRA_SDP_DBG") != nullptr;
+      if (!early) LRA_HIP_CHECK(ctx, hipMemsetAsync(poolUsed, 0, (size_t)nr * 4, st));
       hipEvent_t e0 = nullptr, e1 = nullptr;
       if (dbg) { (void)hipEventCreate(&e0); (void)hipEventCreate(&e1); (void)hipEventRecord(e0, st); }
-      // the reads of this attempt are ordered by their number of points, largest first: the large ones get a workgroup each (nbig, above)
       lra_time_begin(ctx, ctx->sdp_inner ? "sdp_inner_process" : "sdp_process");
       // the few large reads (a workgroup each) run beside the many small ones (a wave each) instead of in front of them
-      if (nbig > 0) {                                                      // the large reads' per-anchor words (see sdp_process_wg)
-        const std::vector<uint32_t>& ord = att == 0 ? h_orderAll : h_prev;
-        std::vector<uint64_t> woff((size_t)nbig + 1, 0);
-        for (int i = 0; i < nbig; i++) {
-          const uint64_t rdx = (uint64_t)r0 + ord[i];
-          const uint64_t Fr = h_frag[rdx + 1] - h_frag[rdx], Pr = h_pt[rdx + 1] - h_pt[rdx];
-          woff[i + 1] = woff[i] + ((36 * Fr + 4 * Pr + 64 + 8 + 256 * 8 + 255) & ~(uint64_t)255);
-        }
-        char* wsc = (char*)lra_ensure(ctx, 177, woff[nbig] + 256);
-        uint64_t* dwoff = (uint64_t*)lra_ensure(ctx, 178, ((size_t)nbig + 2) * 8);
-        if (!wsc || !dwoff) return LRA_ERR_NOMEM;
-        LRA_HIP_CHECK(ctx, hipMemcpyAsync(dwoff, woff.data(), ((size_t)nbig + 1) * 8, hipMemcpyHostToDevice, st));
-        LRA_HIP_CHECK(ctx, hipStreamSynchronize(st));                      // (woff is a host temporary)
-        pa.wgScratch = wsc; pa.wgOff = dwoff; pa.dbg = dbg ? 1 : 0;
-        dbgOff0 = woff[0] + 36 * (h_frag[(uint64_t)r0 + ord[0] + 1] - h_frag[(uint64_t)r0 + ord[0]]) + 4 * (h_pt[(uint64_t)r0 + ord[0] + 1] - h_pt[(uint64_t)r0 + ord[0]]); dbgBase = wsc;
-      }
-      const bool forked = nbig > 0 && nsub > nbig;
-      if (nbig > 0) {
-        // (levels used = ceil(log2(lines)) + 1: up to 2^15 distinct rows and columns stay within levels 0..15)
-        hipStream_t ws = forked ? lra_side_fork(ctx) : st;
-        if (maxRC <= 32768) { if (dbg) hipLaunchKernelGGL((sdp_process_wg<2, true>), dim3(nbig), dim3(64 * WG_NW), 0, ws, pa); else hipLaunchKernelGGL((sdp_process_wg<2, false>), dim3(nbig), dim3(64 * WG_NW), 0, ws, pa); }
-        else { if (dbg) hipLaunchKernelGGL((sdp_process_wg<3, true>), dim3(nbig), dim3(64 * WG_NW), 0, ws, pa); else hipLaunchKernelGGL((sdp_process_wg<3, false>), dim3(nbig), dim3(64 * WG_NW), 0, ws, pa); }
-      }
+      if (nbig > 0 && !early) launch_wg(forked ? lra_side_fork(ctx) : st, maxRC);
       if (nsub > nbig) { ProcArgs pb = pa; pb.order = subOrder + nbig; pb.n = nsub - nbig; static const int padLds = getenv("LRA_SDP_PAD_LDS") ? atoi(getenv("LRA_SDP_PAD_LDS")) : 0; static const bool fat = getenv("LRA_SDP_FAT") != nullptr; if (fat) hipLaunchKernelGGL(sdp_process<1>, dim3(nsub - nbig), dim3(64), (size_t)padLds, st, pb); else hipLaunchKernelGGL(sdp_process<0>, dim3(nsub - nbig), dim3(64), (size_t)padLds, st, pb); }
       if (forked) lra_side_join(ctx);
       lra_time_end(ctx);
