@@ -1005,17 +1005,14 @@ __global__ void __launch_bounds__(64, FAT ? 2 : 4) sdp_process(ProcArgs a) {
       // Every pair on a stack but the dummy at position 0 has the boundary n (see sdp_process_wg): a pair is its D index; `Db >= top.second` never holds,
       // candidates meet the stack at Ei[n - 1] only, FindBoundary never searches.
       // phase 0, every lane for its own sub-problem: Eb[i1], stack top, last Block pair
-      Node nd = cn;
-      if (v.x == NONE) { nd.dBase = 0; nd.nD = 0; nd.nE = 0; nd.last = -1; nd.sTop = 0; nd.nBlk = 0; nd.stkOff = 0; nd.blkOff = 0; nd.stkCap = 0; nd.blkCap = 0; nd.eLast = 0; }
+      const Node& nd = cn;                                                 // (a lane without a visit has need == false below: nothing of nd is used)
       int now = -1;
       long long ei1 = 0;
       const int m = (int)nd.nD, n = (int)nd.nE, i1 = (int)v.y;
       int sTop = (int)nd.sTop, nBlk = (int)nd.nBlk;
       uint32_t stkOff = nd.stkOff, blkOff = nd.blkOff;
-      int2* S = pairs + stkOff; int2* B = pairs + blkOff;
+      // (stack, Block list, Di, Ei[Db] are addressed from their offsets where they are used: four 64-bit pointers per lane are eight registers)
       int sCap = (int)nd.stkCap, bCap = (int)nd.blkCap;
-      const Ent* D = ent + nd.dBase;
-      const long long* Edb = Ed + nd.dBase;
       const long long eLast = nd.eLast;
       int tx = cTop.x; int2 lastB = cLastB;                               // tx == -1: the dummy
       uint32_t st = 0;
@@ -1028,9 +1025,9 @@ __global__ void __launch_bounds__(64, FAT ? 2 : 4) sdp_process(ProcArgs a) {
       if (v.x != NONE) {
         const Ent e = ent[nd.dBase + nd.nD + v.y];
         int2 sT = make_int2(-1, 0), bL = make_int2(0, 0);
-        if (!cTopOk) { if (sTop > 1) sT = S[sTop - 1]; if (nBlk > 0) bL = B[nBlk - 1]; }
-        if (nd.last + 1 < m) { pfD = D[nd.last + 1]; pfE = Edb[nd.last + 1]; }
-        if (cTopOk && tx >= 0) { pfT = D[tx]; pfTok = true; }
+        if (!cTopOk) { if (sTop > 1) sT = (pairs + stkOff)[sTop - 1]; if (nBlk > 0) bL = (pairs + blkOff)[nBlk - 1]; }
+        if (nd.last + 1 < m) { pfD = (ent + nd.dBase)[nd.last + 1]; pfE = (Ed + nd.dBase)[nd.last + 1]; }
+        if (cTopOk && tx >= 0) { pfT = (ent + nd.dBase)[tx]; pfTok = true; }
         now = e.b; ei1 = e.val;
         if (!cTopOk) { tx = sTop <= 1 ? -1 : sT.x; lastB = bL; }
       }
@@ -1041,18 +1038,18 @@ __global__ void __launch_bounds__(64, FAT ? 2 : 4) sdp_process(ProcArgs a) {
       const bool small = need && now > nd.last && now - nd.last <= LOCAL_MAX;
       if (small) {
         bool topD = false; float tDv = 0; long long tDi = 0;
-#define SPUSHL(val_) do { const int2 v__ = (val_); if (sTop >= sCap) { if (grow_pairs(pairs, stkOff, sCap, sTop, poolUsed, poolPair, poolPairs)) S = pairs + stkOff; else st |= LRA_ST_CAPACITY; } \
-                          if (sTop < sCap) S[sTop] = v__; sTop++; } while (0)
-#define BPUSHL(val_) do { const int2 v__ = (val_); if (nBlk >= bCap) { if (grow_pairs(pairs, blkOff, bCap, nBlk, poolUsed, poolPair, poolPairs)) B = pairs + blkOff; else st |= LRA_ST_CAPACITY; } \
-                          if (nBlk < bCap) B[nBlk] = v__; nBlk++; lastB = v__; } while (0)
+#define SPUSHL(val_) do { const int2 v__ = (val_); if (sTop >= sCap) { if (!grow_pairs(pairs, stkOff, sCap, sTop, poolUsed, poolPair, poolPairs)) st |= LRA_ST_CAPACITY; } \
+                          if (sTop < sCap) (pairs + stkOff)[sTop] = v__; sTop++; } while (0)
+#define BPUSHL(val_) do { const int2 v__ = (val_); if (nBlk >= bCap) { if (!grow_pairs(pairs, blkOff, bCap, nBlk, poolUsed, poolPair, poolPairs)) st |= LRA_ST_CAPACITY; } \
+                          if (nBlk < bCap) (pairs + blkOff)[nBlk] = v__; nBlk++; lastB = v__; } while (0)
         for (int i = nd.last + 1; i <= now && !st; ++i) {
           Ent di_ = pfD; long long edb = pfE;
-          if (i != nd.last + 1) { di_ = D[i]; edb = Edb[i]; }
+          if (i != nd.last + 1) { di_ = (ent + nd.dBase)[i]; edb = (Ed + nd.dBase)[i]; }
           const int db = di_.b;
           if (db == -1) break;
           const long long di = di_.val; const float dvi = di_.v;
           if (tx == -1) { BPUSHL(make_int2(-1, db)); SPUSHL(make_int2(i, n)); tx = i; tDv = dvi; tDi = di; topD = true; }
-          if (!topD) { Ent e = pfT; if (!pfTok) e = D[tx]; tDv = e.v; tDi = e.val; topD = true; }
+          if (!topD) { Ent e = pfT; if (!pfTok) e = (ent + nd.dBase)[tx]; tDv = e.v; tDi = e.val; topD = true; }
           if (BEATS(dvi, di, tDv, tDi, edb)) {
             if (nBlk > 0 && db > lastB.y) BPUSHL(make_int2(tx, db));
             const float sNew = dvi + W(di, eLast);
@@ -1062,9 +1059,9 @@ __global__ void __launch_bounds__(64, FAT ? 2 : 4) sdp_process(ProcArgs a) {
               if (!(sNew > cDv + W(cDi, eLast))) break;
               sTop--;
               if (sTop == 0) { st |= LRA_ST_OOB_SLOT; break; }
-              cx = sTop - 1 == 0 ? -1 : S[sTop - 1].x;
+              cx = sTop - 1 == 0 ? -1 : (pairs + stkOff)[sTop - 1].x;
               if (cx == -1) break;
-              const Ent ce = D[cx]; cDv = ce.v; cDi = ce.val;
+              const Ent ce = (ent + nd.dBase)[cx]; cDv = ce.v; cDi = ce.val;
             }
             if (st) break;
             SPUSHL(make_int2(i, n)); tx = i; tDv = dvi; tDi = di; topD = true;
@@ -1141,15 +1138,15 @@ __global__ void __launch_bounds__(64, FAT ? 2 : 4) sdp_process(ProcArgs a) {
         }
 #undef SPUSH
 #undef BPUSH
-        if (lane == owner) { sTop = oTop; nBlk = oBlk; tx = otx; lastB = olastB; st |= ost; stkOff = oStkOff; blkOff = oBlkOff; sCap = oSCap; bCap = oBCap; S = oS; B = oB; }
+        if (lane == owner) { sTop = oTop; nBlk = oBlk; tx = otx; lastB = olastB; st |= ost; stkOff = oStkOff; blkOff = oBlkOff; sCap = oSCap; bCap = oBCap; }
       }
       // phase 2, every lane for its own sub-problem: the flush of Maximization :438-453 (only its `now == m - 1` branch ever pops), FindValueInBlock :322-333, Ev / Ep
       float ev = -1.f;
       bool got = false;
       if (need && !st) {
-#define BPUSH2(val_) do { const int2 v__ = (val_); if (nBlk >= bCap) { if (grow_pairs(pairs, blkOff, bCap, nBlk, poolUsed, poolPair, poolPairs)) B = pairs + blkOff; else st |= LRA_ST_CAPACITY; } \
-                          if (nBlk < bCap) B[nBlk] = v__; nBlk++; lastB = v__; } while (0)
-        if (now == m - 1) { while (sTop > 1 && tx != -1 && !st) { BPUSH2(make_int2(tx, n)); sTop--; tx = sTop - 1 == 0 ? -1 : S[sTop - 1].x; } }
+#define BPUSH2(val_) do { const int2 v__ = (val_); if (nBlk >= bCap) { if (!grow_pairs(pairs, blkOff, bCap, nBlk, poolUsed, poolPair, poolPairs)) st |= LRA_ST_CAPACITY; } \
+                          if (nBlk < bCap) (pairs + blkOff)[nBlk] = v__; nBlk++; lastB = v__; } while (0)
+        if (now == m - 1) { while (sTop > 1 && tx != -1 && !st) { BPUSH2(make_int2(tx, n)); sTop--; tx = sTop - 1 == 0 ? -1 : (pairs + stkOff)[sTop - 1].x; } }
 #undef BPUSH2
         int i2 = -1;
         if (!st && nBlk > 0) {
@@ -1159,7 +1156,7 @@ __global__ void __launch_bounds__(64, FAT ? 2 : 4) sdp_process(ProcArgs a) {
             while (cnt > 0) {                                             // recent false probe (or at the end): Block[lo].first is that probe's pair, no further load
               const int step = cnt >> 1, it = lo + step;
               const int cntT = cnt - step - 1, itT = it + 1 + (cntT >> 1), itF = lo + (step >> 1);
-              const int2 pM = B[it], pT = cntT > 0 ? B[itT] : make_int2(0, 0), pF = step > 0 ? B[itF] : make_int2(0, 0);
+              const int2 pM = (pairs + blkOff)[it], pT = cntT > 0 ? (pairs + blkOff)[itT] : make_int2(0, 0), pF = step > 0 ? (pairs + blkOff)[itF] : make_int2(0, 0);
               if (i1 >= pM.y) {
                 lo = it + 1; cnt = cntT;
                 if (cnt > 0) { const int s2 = cnt >> 1; if (i1 >= pT.y) { lo = itT + 1; cnt -= s2 + 1; } else { cnt = s2; bx = pT.x; } }
@@ -1173,7 +1170,7 @@ __global__ void __launch_bounds__(64, FAT ? 2 : 4) sdp_process(ProcArgs a) {
         }
         if (st || i2 < 0 || i2 >= m) st |= st ? st : LRA_ST_OOB_SLOT;
         else {
-          const Ent d2 = D[i2];
+          const Ent d2 = (ent + nd.dBase)[i2];
           ev = d2.v + W(d2.val, ei1) + rate * a.flen[f0 + lf];            // :1040
           got = true;
           Ap[nd.dBase + nd.nD + i1] = (uint32_t)i2;                       // Ep[i1] (Ev[i1] is never read again)
@@ -2199,7 +2196,7 @@ int sdp_run(lra_ctx* ctx, int n_reads, const uint64_t* d_cluster_off, const uint
       // once -- what it needs from the host (the per-anchor words' offsets, the kernel variant) is made ready before the builds: the variant from the large reads' own rows /
       // columns (k_big_lines) instead of the emit pass's counts --; the small reads' builds start behind the large reads' build and their wave-per-read ProcessPoint launch
       // behind those, beside the workgroup launch as before.  What used to be  max(builds) + max(ProcessPoint launches)  is  build_large + max(wg, builds_small + wave).
-      static const bool bigFirstEnv = !(getenv("LRA_SDP_BIG_FIRST") && getenv("LRA_SDP_BIG_FIRST")[0] == '0');
+      const bool bigFirstEnv = !(getenv("LRA_SDP_BIG_FIRST") && getenv("LRA_SDP_BIG_FIRST")[0] == '0');   // (read per call: the tests run both orders in one process)
       const bool early = bigFirstEnv && att == 0 && onePass && forked && !dbg;
       // the large reads' per-anchor words (see sdp_process_wg)
       char* wsc = nullptr; uint64_t* dwoff = nullptr; uint32_t* d_maxLines = nullptr;
@@ -2316,11 +2313,15 @@ int sdp_run(lra_ctx* ctx, int n_reads, const uint64_t* d_cluster_off, const uint
     const uint64_t cf0 = h_frag[r0], cfn = h_frag[r1] - h_frag[r0];
     if (cfn > 0) {
       lra_time_begin(ctx, ctx->sdp_inner ? "sdp_inner_trace" : "sdp_trace");
-      hipLaunchKernelGGL(k_valkeys, dim3((unsigned)((cfn + 255) / 256)), dim3(256), 0, st, cf0, cfn, fval, fragRead, fragOff, okey, opay);
+      // The value order (Fragment_valueOrder::Sort) is what DecidePrimaryChains walks; the single-cluster drivers (SparseDP.h:2417-2434, SparseDP_Forward.h) take the first
+      // anchor of maximal value and nothing else of it: sdp_trace finds that anchor by a scan, so the keys and the exact sort are left out there (the second sparse DP of a
+      // batch: 29 M values through the libstdc++-exact sort for nothing, 23 ms of the back half's chain)
+      const bool needOrder = opts->mode != LRA_SDP_SINGLE_CLUSTER;
+      if (needOrder) hipLaunchKernelGGL(k_valkeys, dim3((unsigned)((cfn + 255) / 256)), dim3(256), 0, st, cf0, cfn, fval, fragRead, fragOff, okey, opay);
       hipLaunchKernelGGL(k_pred, dim3((unsigned)((cfn + 255) / 256)), dim3(256), 0, st, cf0, cfn, r0, (const uint32_t*)fragRead, (const uint32_t*)fprevNode,
                          (const uint32_t*)fprevInd, (const uint32_t*)status, (const ReadArena*)ra, spare);
       lra_time_end(ctx);
-      { int rc = lra_sort_minimizers_batch(ctx, nr, fragOff + r0, okey, opay); if (rc) return rc; }   // Fragment_valueOrder::Sort (Fragment_Info.h:88)
+      if (needOrder) { int rc = lra_sort_minimizers_batch(ctx, nr, fragOff + r0, okey, opay); if (rc) return rc; }   // Fragment_valueOrder::Sort (Fragment_Info.h:88)
       TraceArgs ta;
       ta.r0 = r0; ta.n = nr; ta.numAln = opts->NumAln; ta.single = opts->mode == LRA_SDP_SINGLE_CLUSTER; ta.alnthres = opts->alnthres; ta.fragOff = fragOff; ta.read_off = d_read_off; ta.fq = fq; ta.ft = ft;
       ta.flen = flen; ta.fcl = fcl; ta.fai = fai; ta.fval = fval; ta.fpred = spare; ta.fflags = fflags; ta.opay = opay; ta.used = used;

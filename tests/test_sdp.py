@@ -276,7 +276,7 @@ def test_hip_sdp_bench_workload_flags_and_sample(ctx, oracle):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("window", ["window", "l2"])
+@pytest.mark.parametrize("window", ["window", "l2", "window-old-order"])
 @pytest.mark.parametrize("which", ["clusters", "single"])
 def test_hip_sdp_workgroup_kernel(ctx, which, window, monkeypatch):
     """The workgroup-per-read ProcessPoint (sdp_process_wg, for reads with many points: the slots spread over 16 waves) against the oracle: the
@@ -286,6 +286,9 @@ def test_hip_sdp_workgroup_kernel(ctx, which, window, monkeypatch):
     monkeypatch.setenv("LRA_SDP_BIG_POINTS", "40")
     if window == "l2":
         monkeypatch.setenv("LRA_SDP_WG_RING", "0")
+    if window == "window-old-order":
+        # the large reads' build and workgroup launch beside the small reads' (the order before round 5) instead of in front of them: both orders stay tested
+        monkeypatch.setenv("LRA_SDP_BIG_FIRST", "0")
     rng = np.random.default_rng(23)
     if which == "clusters":
         reads_in = [_random_clusters(rng, nc, per, span, ties) for nc, per, span, ties in [(6, 80, 30000, False), (3, 150, 20000, True), (10, 30, 30000, True), (1, 5, 1000, False)]]
