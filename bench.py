@@ -598,9 +598,13 @@ def main():
     if rank == 0:
         ms_step = dt / args.steps * 1e3
         gbps = job_bases * args.steps / dt / 1e9
-        dom = max(ktimes, key=lambda k: ktimes[k][0])
+        # (the workgroup ProcessPoint launch of the large reads runs on a side stream, from the end of their build: it is part of the sdp_process stage, not a family of its
+        # own -- the stage's launch duration is the longer of the two ranges, the main stream's (wave-per-read launch + the wait for the side stream) and the side stream's)
+        dom = max((k for k in ktimes if not k.endswith("_wg")), key=lambda k: ktimes[k][0])
         dom_ms, dom_n = ktimes[dom]
         avg_ms = dom_ms / max(dom_n, 1)
+        if dom == "sdp_process" and ktimes.get("sdp_process_wg", (0, 0))[1]:
+            avg_ms = max(avg_ms, ktimes["sdp_process_wg"][0] / ktimes["sdp_process_wg"][1])
         launches_per_step = max(dom_n, 1) / args.steps
         L = total_bases
         # ALGORITHMIC bytes per step of every kernel family, SURVEY.md section 8(d): 2 L (read + RC) + 12 n_q (minimizers out) + n_q (12 + 64) (sorted
