@@ -452,8 +452,7 @@ extern "C" int lra_clean_matches_batch(lra_ctx* ctx, const lra_clean_opts* opts,
   // ---- work buffers (gbuf 3) and results (gbuf 4)
   size_t temp_bytes = 0;
   if (nm) {
-    (void)rocprim::segmented_radix_sort_pairs(nullptr, temp_bytes, (uint64_t*)nullptr, (uint64_t*)nullptr, (uint32_t*)nullptr, (uint32_t*)nullptr,
-                                              (unsigned int)nm, (unsigned int)(2 * n_reads), (uint64_t*)nullptr, (uint64_t*)nullptr, 0, 64, st);
+    (void)lra_segsort_pairs(ctx, nullptr, temp_bytes, nullptr, nullptr, nullptr, nullptr, (unsigned int)nm, (unsigned int)(2 * n_reads), nullptr, nullptr, 0, 64, st);
   }
   auto sz = [](size_t n, size_t e) { return (n * e + 255) & ~(size_t)255; };
   size_t needW = sz(N, 8) * 2 + sz(N, 4) * 2 + sz(NS, 8) + sz(N, 4) * 2 + sz(N, 8) + sz(N, 1) * 4 + sz(N, 4) * 2 + sz(4 * N, 8) + sz(4 * N, 4) +
@@ -489,8 +488,7 @@ extern "C" int lra_clean_matches_batch(lra_ctx* ctx, const lra_clean_opts* opts,
   lra_time_begin(ctx, "clean_sort");
   hipLaunchKernelGGL(key_build, dim3(ctx->num_cu * 8), dim3(256), 0, st, n_reads, s->match_off, s->n_forward, s->sep_qpos, s->sep_tpos, key_in, val_in, seg_off);
   if (nm) {
-    hipError_t e = rocprim::segmented_radix_sort_pairs(temp, temp_bytes, key_in, key_out, val_in, val_out, (unsigned int)nm, (unsigned int)(2 * n_reads),
-                                                       seg_off, seg_off + 1, 0, 64, st);
+    hipError_t e = lra_segsort_pairs(ctx, temp, temp_bytes, key_in, key_out, val_in, val_out, (unsigned int)nm, (unsigned int)(2 * n_reads), seg_off, seg_off + 1, 0, 64, st);
     if (e != hipSuccess) return lra_set_err(ctx, LRA_ERR_HIP, "segmented sort: %s", hipGetErrorString(e));
     hipLaunchKernelGGL(gather_sorted, dim3((unsigned)((nm + 255) / 256)), dim3(256), 0, st, nm, val_out, s->sep_qpos, s->sep_tpos, s->sep_qkey, sq, stt, sk);
   }

@@ -61,6 +61,9 @@ struct lra_ctx {
 // Fork: work queued on the returned stream starts after everything queued on ctx->stream so far; join: ctx->stream waits for it.
 hipStream_t lra_side_fork(lra_ctx* ctx, int i = 0);
 void lra_side_join(lra_ctx* ctx, int i = 0);
+// segsort.hip: rocprim::segmented_radix_sort_pairs' interface for (uint64 key, uint32 value) pairs; segments of 257 .. 8192 pairs are sorted by one workgroup in LDS
+hipError_t lra_segsort_pairs(lra_ctx* ctx, void* temp, size_t& temp_bytes, const uint64_t* kin, uint64_t* kout, const uint32_t* vin, uint32_t* vout, unsigned int total,
+                             unsigned int nseg, const uint64_t* b, const uint64_t* e, int begin_bit, int end_bit, hipStream_t st);
 // timing records (lra_ctx_timing_get); stream = nullptr: the context's stream
 void lra_time_begin(lra_ctx* ctx, const char* name, hipStream_t stream = nullptr);
 void lra_time_end(lra_ctx* ctx, hipStream_t stream = nullptr);

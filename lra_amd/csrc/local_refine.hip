@@ -611,11 +611,10 @@ static int local_refine_impl(lra_ctx* ctx, uint64_t n_jobs, const uint64_t* d_jo
     hipLaunchKernelGGL(lr_job_pairs, dim3(gw), dim3(64), 0, st, a, key, val);
     if (nJP) {
       size_t temp_bytes = 0;
-      (void)rocprim::segmented_radix_sort_pairs(nullptr, temp_bytes, (uint64_t*)nullptr, (uint64_t*)nullptr, (uint32_t*)nullptr, (uint32_t*)nullptr, (unsigned int)nJP,
-                                                (unsigned int)nJ, (uint64_t*)nullptr, (uint64_t*)nullptr, 0, 64, st);
+      (void)lra_segsort_pairs(ctx, nullptr, temp_bytes, nullptr, nullptr, nullptr, nullptr, (unsigned int)nJP, (unsigned int)nJ, nullptr, nullptr, 0, 64, st);
       void* temp = lra_scratch(ctx, 2, temp_bytes + 256);
       if (!temp) return LRA_ERR_NOMEM;
-      hipError_t e = rocprim::segmented_radix_sort_pairs(temp, temp_bytes, key, key2, val, val2, (unsigned int)nJP, (unsigned int)nJ, a.cStart, a.cEnd, 0, 64, st);
+      hipError_t e = lra_segsort_pairs(ctx, temp, temp_bytes, key, key2, val, val2, (unsigned int)nJP, (unsigned int)nJ, a.cStart, a.cEnd, 0, 64, st);
       if (e != hipSuccess) return lra_set_err(ctx, LRA_ERR_HIP, "segmented sort: %s", hipGetErrorString(e));
       hipLaunchKernelGGL(lr_sorted, grid(nJP), dim3(256), 0, st, nJP, (const uint32_t*)val2, (const uint32_t*)a.jq, (const uint32_t*)a.jt, (const uint64_t*)key2, sq, stt);
       hipLaunchKernelGGL(lr_add_coff, dim3(gw), dim3(64), 0, st, a, stt);

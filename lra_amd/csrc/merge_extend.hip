@@ -243,13 +243,12 @@ extern "C" int lra_merge_extend_batch(lra_ctx* ctx, const lra_chain_result* ch, 
   const unsigned gw = (unsigned)std::min<uint64_t>(NCL, (uint64_t)ctx->num_cu * 32);
   if (NM > 0) {
     size_t temp_bytes = 0;
-    (void)rocprim::segmented_radix_sort_pairs(nullptr, temp_bytes, (uint64_t*)nullptr, (uint64_t*)nullptr, (uint32_t*)nullptr, (uint32_t*)nullptr, (unsigned int)NM,
-                                              (unsigned int)NCL, (uint64_t*)nullptr, (uint64_t*)nullptr, 0, 64, st);
+    (void)lra_segsort_pairs(ctx, nullptr, temp_bytes, nullptr, nullptr, nullptr, nullptr, (unsigned int)NM, (unsigned int)NCL, nullptr, nullptr, 0, 64, st);
     void* temp = lra_scratch(ctx, 2, temp_bytes + 256);
     if (!temp) return LRA_ERR_NOMEM;
     lra_time_begin(ctx, "merge_extend");
     hipLaunchKernelGGL(me_keys, dim3(gw), dim3(64), 0, st, NCL, (const uint64_t*)a.cStart, (const uint64_t*)a.cEnd, a.mq, a.mt, key, val);
-    hipError_t e = rocprim::segmented_radix_sort_pairs(temp, temp_bytes, key, key2, val, val2, (unsigned int)NM, (unsigned int)NCL, a.cStart, a.cEnd, 0, 64, st);
+    hipError_t e = lra_segsort_pairs(ctx, temp, temp_bytes, key, key2, val, val2, (unsigned int)NM, (unsigned int)NCL, a.cStart, a.cEnd, 0, 64, st);
     if (e != hipSuccess) { lra_time_end(ctx); return lra_set_err(ctx, LRA_ERR_HIP, "segmented sort: %s", hipGetErrorString(e)); }
     hipLaunchKernelGGL(me_gather_sorted, dim3(gw), dim3(64), 0, st, NCL, (const uint64_t*)a.cStart, (const uint64_t*)a.cEnd, (const int*)a.cChrom, (const uint64_t*)dpos,
                        (const uint32_t*)val2, a.mq, a.mt, sq, stt);

@@ -2065,13 +2065,11 @@ int sdp_run(lra_ctx* ctx, int n_reads, const uint64_t* d_cluster_off, const uint
   // exact introsort degenerates on the long runs of equal diagonals.  Sorted into the (now free) key1 / pay1 buffers.
   {
     size_t temp_bytes = 0;
-    (void)rocprim::segmented_radix_sort_pairs(nullptr, temp_bytes, (uint64_t*)nullptr, (uint64_t*)nullptr, (uint32_t*)nullptr, (uint32_t*)nullptr,
-                                              (unsigned int)NP, (unsigned int)n_reads, (uint64_t*)nullptr, (uint64_t*)nullptr, 0, 42, st);
+    (void)lra_segsort_pairs(ctx, nullptr, temp_bytes, nullptr, nullptr, nullptr, nullptr, (unsigned int)NP, (unsigned int)n_reads, nullptr, nullptr, 0, 42, st);
     void* temp = lra_scratch(ctx, 2, temp_bytes + 256);
     if (!temp) return LRA_ERR_NOMEM;
     lra_time_begin(ctx, ctx->sdp_inner ? "sdp_inner_sort" : "sdp_sort");
-    hipError_t e = rocprim::segmented_radix_sort_pairs(temp, temp_bytes, key3, key1, pay3, pay1, (unsigned int)NP, (unsigned int)n_reads, ptOff, ptOff + 1,
-                                                       0, 42, st);
+    hipError_t e = lra_segsort_pairs(ctx, temp, temp_bytes, key3, key1, pay3, pay1, (unsigned int)NP, (unsigned int)n_reads, ptOff, ptOff + 1, 0, 42, st);
     lra_time_end(ctx);
     if (e != hipSuccess) return lra_set_err(ctx, LRA_ERR_HIP, "segmented sort: %s", hipGetErrorString(e));
   }

@@ -1185,14 +1185,12 @@ int lra_sort_mostly_unique_batch(lra_ctx* ctx, int n_lists, const uint64_t* d_of
   if (n_lists == 0 || total == 0) return LRA_OK;
   hipStream_t st = ctx->stream;
   size_t temp_bytes = 0;
-  (void)rocprim::segmented_radix_sort_pairs(nullptr, temp_bytes, (uint64_t*)nullptr, (uint64_t*)nullptr, (uint32_t*)nullptr, (uint32_t*)nullptr,
-                                            (unsigned int)total, (unsigned int)n_lists, (uint64_t*)nullptr, (uint64_t*)nullptr, 0, end_bit, st);
+  (void)lra_segsort_pairs(ctx, nullptr, temp_bytes, nullptr, nullptr, nullptr, nullptr, (unsigned int)total, (unsigned int)n_lists, nullptr, nullptr, 0, end_bit, st);
   char* temp = (char*)lra_scratch(ctx, 2, temp_bytes + 256 + (size_t)n_lists * 4);
   if (!temp) return LRA_ERR_NOMEM;
   int* ties = (int*)(temp + ((temp_bytes + 255) & ~(size_t)255));
   lra_time_begin(ctx, ctx->sort_tag);
-  hipError_t e = rocprim::segmented_radix_sort_pairs(temp, temp_bytes, d_key, tmp_key, d_pos, tmp_pos, (unsigned int)total, (unsigned int)n_lists, d_off,
-                                                     d_off + 1, 0, end_bit, st);
+  hipError_t e = lra_segsort_pairs(ctx, temp, temp_bytes, d_key, tmp_key, d_pos, tmp_pos, (unsigned int)total, (unsigned int)n_lists, d_off, d_off + 1, 0, end_bit, st);
   if (e != hipSuccess) { lra_time_end(ctx); return lra_set_err(ctx, LRA_ERR_HIP, "segmented sort: %s", hipGetErrorString(e)); }
   hipLaunchKernelGGL(sort_adopt_kernel, dim3(n_lists), dim3(256), 0, st, n_lists, d_off, d_key, d_pos, (const uint64_t*)tmp_key, (const uint32_t*)tmp_pos, ties);
   lra_time_end(ctx);

@@ -1,0 +1,71 @@
+// lra_amd/csrc/segsort.hip -- the path's segmented sorts of (64-bit key, 32-bit value) pairs: DiagonalSort / CartesianSort of a read's (a cluster's, a job's) matches
+// (Sorting.h:50-150: any stable order by the packed key), the sparse DP's point orders where the keys of a list are all different (seed.hip: lra_sort_mostly_unique_batch),
+// its diagonal order.  gfx950 only.
+//
+// rocprim::segmented_radix_sort_pairs sorts a segment of a few thousand pairs in ~10 digit passes THROUGH MEMORY (key / value arrays read and written per pass: 10-15 G
+// pairs/s on this device, 480 bytes of traffic per pair).  Here a segment of 257 .. 8192 pairs is one workgroup's: loaded once, sorted in LDS (hipcub::BlockRadixSort, the
+// same least-significant-digit radix sort -- stable, only the bits [begin_bit, end_bit) compared --, four size classes so that a short segment does not pay for a long one's
+// padding), stored once: 21-27 G pairs/s (tools/micro/segsort.hip: identical output on 32768 segments of 640 / 1760 / 3000 / 6000 pairs).  The segments outside that range --
+// the many tiny ones (a13's jobs: rocprim's warp sorts serve them well) and the rare ones beyond a workgroup's LDS -- stay with rocprim, which is called on a copy of the
+// offsets in which every other segment is empty.  LRA_SEGSORT=0: rocprim for everything (comparisons).
+#include "common.h"
+#include <cstring>
+#include <cstdlib>
+#include <rocprim/rocprim.hpp>
+#include <hipcub/hipcub.hpp>
+
+namespace {
+
+constexpr int SEG_LO = 256, SEG_HI = 8192;     // a workgroup sorts segments of SEG_LO < n <= SEG_HI pairs
+
+__global__ void k_mask_offsets(unsigned nseg, const uint64_t* __restrict__ b, const uint64_t* __restrict__ e, uint64_t* mb, uint64_t* me) {
+  const unsigned s = blockIdx.x * blockDim.x + threadIdx.x;
+  if (s >= nseg) return;
+  const uint64_t x = b[s], y = e[s], n = y > x ? y - x : 0;
+  const bool mine = n > (uint64_t)SEG_LO && n <= (uint64_t)SEG_HI;
+  mb[s] = x; me[s] = mine ? x : y;
+}
+
+template <int NT, int IPT>
+__global__ void __launch_bounds__(NT) k_block_sort(unsigned nseg, const uint64_t* __restrict__ b, const uint64_t* __restrict__ e, const uint64_t* __restrict__ kin, uint64_t* kout,
+                                                   const uint32_t* __restrict__ vin, uint32_t* vout, int begin_bit, int end_bit, int minLen) {
+  typedef hipcub::BlockRadixSort<uint64_t, NT, IPT, uint32_t> Sort;
+  __shared__ typename Sort::TempStorage tmp;
+  for (unsigned s = blockIdx.x; s < nseg; s += gridDim.x) {
+    const uint64_t x = b[s], y = e[s];
+    const int n = y > x ? (int)std::min<uint64_t>(y - x, (uint64_t)SEG_HI + 1) : 0;
+    if (n > NT * IPT || n <= minLen) continue;                           // (another class's, or rocprim's)
+    uint64_t k[IPT]; uint32_t v[IPT];
+#pragma unroll
+    for (int i = 0; i < IPT; i++) { const int p = (int)threadIdx.x * IPT + i; k[i] = p < n ? kin[x + p] : ~0ull; v[i] = p < n ? vin[x + p] : 0u; }
+    Sort(tmp).Sort(k, v, begin_bit, end_bit);                             // (blocked arrangement in and out: position = thread * IPT + item; the padding sorts behind every pair)
+#pragma unroll
+    for (int i = 0; i < IPT; i++) { const int p = (int)threadIdx.x * IPT + i; if (p < n) { kout[x + p] = k[i]; vout[x + p] = v[i]; } }
+    __syncthreads();
+  }
+}
+
+}  // namespace
+
+// The interface of rocprim::segmented_radix_sort_pairs (temp == nullptr: temp_bytes is set to what the call needs).
+hipError_t lra_segsort_pairs(lra_ctx* ctx, void* temp, size_t& temp_bytes, const uint64_t* kin, uint64_t* kout, const uint32_t* vin, uint32_t* vout, unsigned int total,
+                             unsigned int nseg, const uint64_t* b, const uint64_t* e, int begin_bit, int end_bit, hipStream_t st) {
+  static const bool off = getenv("LRA_SEGSORT") && getenv("LRA_SEGSORT")[0] == '0';
+  size_t rb = 0;
+  hipError_t rc = rocprim::segmented_radix_sort_pairs(nullptr, rb, (uint64_t*)nullptr, (uint64_t*)nullptr, (uint32_t*)nullptr, (uint32_t*)nullptr, total, nseg, (uint64_t*)nullptr,
+                                                      (uint64_t*)nullptr, begin_bit, end_bit, st);
+  if (rc != hipSuccess) return rc;
+  const size_t rbA = (rb + 255) & ~(size_t)255, extra = 2 * ((size_t)nseg + 1) * 8 + 256;
+  if (!temp) { temp_bytes = rbA + extra; return hipSuccess; }
+  if (temp_bytes < rbA + extra) return hipErrorInvalidValue;
+  if (off || nseg == 0 || total == 0)
+    return rocprim::segmented_radix_sort_pairs(temp, rb, kin, kout, vin, vout, total, nseg, b, e, begin_bit, end_bit, st);
+  uint64_t* mb = (uint64_t*)((char*)temp + rbA); uint64_t* me = mb + nseg + 1;
+  hipLaunchKernelGGL(k_mask_offsets, dim3((nseg + 255) / 256), dim3(256), 0, st, nseg, b, e, mb, me);
+  const unsigned cu = (unsigned)ctx->num_cu;
+  hipLaunchKernelGGL((k_block_sort<256, 4>), dim3(std::min(nseg, cu * 8)), dim3(256), 0, st, nseg, b, e, kin, kout, vin, vout, begin_bit, end_bit, SEG_LO);
+  hipLaunchKernelGGL((k_block_sort<256, 8>), dim3(std::min(nseg, cu * 6)), dim3(256), 0, st, nseg, b, e, kin, kout, vin, vout, begin_bit, end_bit, 1024);
+  hipLaunchKernelGGL((k_block_sort<512, 8>), dim3(std::min(nseg, cu * 3)), dim3(512), 0, st, nseg, b, e, kin, kout, vin, vout, begin_bit, end_bit, 2048);
+  hipLaunchKernelGGL((k_block_sort<1024, 8>), dim3(std::min(nseg, cu)), dim3(1024), 0, st, nseg, b, e, kin, kout, vin, vout, begin_bit, end_bit, 4096);
+  return rocprim::segmented_radix_sort_pairs(temp, rb, kin, kout, vin, vout, total, nseg, (const uint64_t*)mb, (const uint64_t*)me, begin_bit, end_bit, st);
+}
