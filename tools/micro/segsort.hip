@@ -30,7 +30,7 @@ __global__ void __launch_bounds__(NT) k_block_sort(int nseg, const uint64_t* __r
 }
 
 int main() {
-  for (int L : {3000, 6000}) {
+  for (int L : {640, 1760, 3000, 6000}) {
     const int nseg = 32768;
     std::mt19937_64 rng(1);
     std::vector<uint64_t> off(nseg + 1, 0);
