@@ -696,21 +696,34 @@ __global__ void __launch_bounds__(64 * NW, NW == 1 ? OCC : 1) sdp_build(BuildArg
             lo[u] = 0; cnt[u] = on[u] ? mv[u] : 0;
           }
           // D entry: asc  #{Ei < x}   desc #{Ei >= x};   E entry: asc #{Di <= x}   desc #{Di > x}
+          // (the lists are sorted and the predicate holds on a prefix: two steps of the bisection per round -- the probe in the middle and the two probes its outcome can lead
+          // to are asked for together; a round is a trip to L2 and a level of the decomposition has a dozen of these searches per element group)
           while (true) {
             bool any = false;
 #pragma unroll
             for (int u = 0; u < UG; u++) any |= cnt[u] > 0;
             if (!any) break;
-            long long vv[UG];
+            long long vM[UG], vL[UG], vR[UG];
 #pragma unroll
-            for (int u = 0; u < UG; u++) vv[u] = cnt[u] > 0 ? opp[u][lo[u] + (cnt[u] >> 1)].val : 0;
+            for (int u = 0; u < UG; u++) {
+              const uint32_t step = cnt[u] >> 1, it = lo[u] + step, cntT = cnt[u] > 0 ? cnt[u] - step - 1 : 0;
+              vM[u] = cnt[u] > 0 ? opp[u][it].val : 0;
+              vL[u] = step > 0 ? opp[u][lo[u] + (step >> 1)].val : 0;
+              vR[u] = cntT > 0 ? opp[u][it + 1 + (cntT >> 1)].val : 0;
+            }
 #pragma unroll
             for (int u = 0; u < UG; u++) {
               if (cnt[u] == 0) continue;
               const bool isS = j0 + u * NT + tid < nS;
+              auto go = [&](long long v) { return isS ? (desc ? v > xv[u] : v <= xv[u]) : (desc ? v >= xv[u] : v < xv[u]); };
               const uint32_t step = cnt[u] >> 1, it = lo[u] + step;
-              const bool go = isS ? (desc ? vv[u] > xv[u] : vv[u] <= xv[u]) : (desc ? vv[u] >= xv[u] : vv[u] < xv[u]);
-              if (go) { lo[u] = it + 1; cnt[u] -= step + 1; } else cnt[u] = step;
+              if (go(vM[u])) {
+                lo[u] = it + 1; cnt[u] -= step + 1;
+                if (cnt[u] > 0) { const uint32_t s2 = cnt[u] >> 1; if (go(vR[u])) { lo[u] += s2 + 1; cnt[u] -= s2 + 1; } else cnt[u] = s2; }
+              } else {
+                cnt[u] = step;
+                if (cnt[u] > 0) { const uint32_t s2 = cnt[u] >> 1; if (go(vL[u])) { lo[u] += s2 + 1; cnt[u] -= s2 + 1; } else cnt[u] = s2; }
+              }
             }
           }
 #pragma unroll
