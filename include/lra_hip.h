@@ -69,7 +69,7 @@ int lra_ctx_set_stream(lra_ctx* ctx, void* stream);
 const char* lra_ctx_last_error(lra_ctx* ctx);
 /* ABI version of the loaded library (tests check it against this header). */
 int lra_abi_version(void);
-#define LRA_ABI_VERSION 6   /* 2: lra_map_opts.defer_matches, lra_map_counters.n_deferred_reads; 3: lra_map_opts.flagged_unaligned, lra_map_counters.n_flagged_reads, lra_map_host_flagged; 4: lra_reads_last_error, a corrupt FASTQ record is LRA_ERR_INVALID; lra_map_opts.defer_seed_matches; 5: lra_seed_prefetch, lra_ctx_adopt_seed, lra_map_reads_lowacc_front / _back, lra_map_back_release; 6: a failed front half hands over an error batch (one back call per front call), separate n_handed_back_reads counter, lra_map_host_trim */
+#define LRA_ABI_VERSION 7   /* 7: lra_sort_pairs_batch;  2: lra_map_opts.defer_matches, lra_map_counters.n_deferred_reads; 3: lra_map_opts.flagged_unaligned, lra_map_counters.n_flagged_reads, lra_map_host_flagged; 4: lra_reads_last_error, a corrupt FASTQ record is LRA_ERR_INVALID; lra_map_opts.defer_seed_matches; 5: lra_seed_prefetch, lra_ctx_adopt_seed, lra_map_reads_lowacc_front / _back, lra_map_back_release; 6: a failed front half hands over an error batch (one back call per front call), separate n_handed_back_reads counter, lra_map_host_trim */
 
 /* Convenience for hosts without their own HIP binding: synchronous device->host copy on the
  * context's stream (a C++ host would call hipMemcpy itself).                                */
@@ -190,6 +190,17 @@ int lra_create_rc_batch(lra_ctx* ctx, int n_reads, const char* d_seq, const uint
  * GenomeTuple::operator<, TupleOps.h:76) would, including the order it leaves equal keys in.
  * Asynchronous.                                                                               */
 int lra_sort_minimizers_batch(lra_ctx* ctx, int n_lists, const uint64_t* d_off, uint64_t* d_key, uint32_t* d_pos);
+
+/* The path's other sorts -- DiagonalSort / AntiDiagonalSort / CartesianSort of a read's (a cluster's, a gap's) matches (Sorting.h:50-150; called from
+ * Clustering.h:1840 CleanMatches, ChainRefine.h:767 MergeChain's LinearExtend, LocalRefineAlignment.h:364), the sparse DP's point orders where no two
+ * points of a list share a key (SparseDP.h:2171-2174), its diagonal order -- as one primitive: every segment [d_begin[i], d_end[i]) of (64-bit key,
+ * 32-bit value) pairs sorted by the key bits [begin_bit, end_bit), STABLY (pairs with equal bits keep their input order: with the packed keys the
+ * callers build, that is what std::sort leaves wherever the reference's comparator has no ties, and the callers send the lists with ties through
+ * lra_sort_minimizers_batch), from (d_key_in, d_val_in) into (d_key_out, d_val_out); segments may be empty, need not be adjacent and must not overlap.
+ * A segment of 257 .. 8192 pairs is sorted by one workgroup in LDS, the others by rocprim's segmented radix sort.  Asynchronous (the context's
+ * stream); the work buffer is the context's.                                                                                                 */
+int lra_sort_pairs_batch(lra_ctx* ctx, uint64_t n_pairs, uint64_t n_segments, const uint64_t* d_begin, const uint64_t* d_end, const uint64_t* d_key_in,
+                         uint64_t* d_key_out, const uint32_t* d_val_in, uint32_t* d_val_out, int begin_bit, int end_bit);
 
 /* ---- a5: match cleaning + diagonal clusters ----------------------------------------------
  * Replaces, per read and strand,   CleanMatches(Matches, clusters, genome, read, opts, timing, ma_strand)

@@ -4,7 +4,7 @@ import os
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 _LIB = None
-ABI_VERSION = 6
+ABI_VERSION = 7
 
 
 class LraError(RuntimeError):
@@ -41,6 +41,7 @@ SYMBOLS = {
     "lra_read_gli": (C.c_int, [C.c_char_p, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "lra_create_rc_batch": (C.c_int, [_vp, C.c_int, _vp, _vp, _vp]),
     "lra_sort_minimizers_batch": (C.c_int, [_vp, C.c_int, _vp, _vp, _vp]),
+    "lra_sort_pairs_batch": (C.c_int, [_vp, C.c_uint64, C.c_uint64, _vp, _vp, _vp, _vp, _vp, _vp, C.c_int, C.c_int]),
     "lra_seed_batch": (C.c_int, [_vp, C.c_int, _vp, _vp, C.c_int, C.c_int, C.c_int, _vp]),
     "lra_map_reads_lowacc_front": (C.c_int, [_vp, C.c_int, _vp, _vp, C.c_uint64, _vp]),
     "lra_map_reads_lowacc_back": (C.c_int, [_vp, _vp, _vp, _vp]),

@@ -69,3 +69,22 @@ hipError_t lra_segsort_pairs(lra_ctx* ctx, void* temp, size_t& temp_bytes, const
   hipLaunchKernelGGL((k_block_sort<1024, 8>), dim3(std::min(nseg, cu)), dim3(1024), 0, st, nseg, b, e, kin, kout, vin, vout, begin_bit, end_bit, 4096);
   return rocprim::segmented_radix_sort_pairs(temp, rb, kin, kout, vin, vout, total, nseg, (const uint64_t*)mb, (const uint64_t*)me, begin_bit, end_bit, st);
 }
+
+extern "C" int lra_sort_pairs_batch(lra_ctx* ctx, uint64_t n_pairs, uint64_t n_segments, const uint64_t* d_begin, const uint64_t* d_end, const uint64_t* d_key_in,
+                                    uint64_t* d_key_out, const uint32_t* d_val_in, uint32_t* d_val_out, int begin_bit, int end_bit) {
+  if (!ctx || begin_bit < 0 || end_bit > 64 || begin_bit >= end_bit) return LRA_ERR_INVALID;
+  if (n_pairs >= (1ull << 32) || n_segments >= (1ull << 32)) return lra_set_err(ctx, LRA_ERR_INVALID, "at most 2^32 - 1 pairs and segments per call");
+  if (n_pairs == 0 || n_segments == 0) return LRA_OK;
+  if (!d_begin || !d_end || !d_key_in || !d_key_out || !d_val_in || !d_val_out || d_key_in == d_key_out || d_val_in == d_val_out) return LRA_ERR_INVALID;
+  LRA_HIP_CHECK(ctx, hipSetDevice(ctx->device));
+  size_t tb = 0;
+  if (lra_segsort_pairs(ctx, nullptr, tb, nullptr, nullptr, nullptr, nullptr, (unsigned int)n_pairs, (unsigned int)n_segments, nullptr, nullptr, begin_bit, end_bit, ctx->stream) != hipSuccess)
+    return lra_set_err(ctx, LRA_ERR_HIP, "segmented sort: sizing");
+  void* temp = lra_scratch(ctx, 2, tb + 256);
+  if (!temp) return LRA_ERR_NOMEM;
+  const hipError_t e = lra_segsort_pairs(ctx, temp, tb, d_key_in, d_key_out, d_val_in, d_val_out, (unsigned int)n_pairs, (unsigned int)n_segments, d_begin, d_end, begin_bit, end_bit,
+                                         ctx->stream);
+  if (e != hipSuccess) return lra_set_err(ctx, LRA_ERR_HIP, "segmented sort: %s", hipGetErrorString(e));
+  LRA_HIP_CHECK(ctx, hipGetLastError());
+  return LRA_OK;
+}

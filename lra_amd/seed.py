@@ -101,6 +101,20 @@ def sort_minimizers_batch(ctx: Context, keys_list, pos_list):
     return [(K2[off[i]:off[i + 1]].copy(), P2[off[i]:off[i + 1]].copy()) for i in range(n)]
 
 
+def sort_pairs_batch(ctx: Context, keys, vals, begin, end, begin_bit=0, end_bit=64):
+    """lra_sort_pairs_batch: every segment [begin[i], end[i]) of (uint64 key, uint32 value) pairs sorted stably by the key bits [begin_bit, end_bit); returns
+    (keys_out, vals_out) -- positions outside every segment are left as the output buffers were (zero here)."""
+    K = np.ascontiguousarray(np.asarray(keys, dtype=np.uint64)); V = np.ascontiguousarray(np.asarray(vals, dtype=np.uint32))
+    B = np.ascontiguousarray(np.asarray(begin, dtype=np.uint64)); E = np.ascontiguousarray(np.asarray(end, dtype=np.uint64))
+    pad = lambda a, dt: np.concatenate([a, np.zeros(1, dt)])
+    dk = torch.from_numpy(pad(K, np.uint64).view(np.int64)).to(ctx.device); dv = torch.from_numpy(pad(V, np.uint32).view(np.int32)).to(ctx.device)
+    ok = torch.zeros_like(dk); ov = torch.zeros_like(dv)
+    db = torch.from_numpy(pad(B, np.uint64).view(np.int64)).to(ctx.device); de = torch.from_numpy(pad(E, np.uint64).view(np.int64)).to(ctx.device)
+    ctx.check(ctx.lib.lra_sort_pairs_batch(ctx.h, len(K), len(B), ptr(db), ptr(de), ptr(dk), ptr(ok), ptr(dv), ptr(ov), int(begin_bit), int(end_bit)))
+    torch.cuda.synchronize(ctx.device)
+    return ok.cpu().numpy().view(np.uint64)[:len(K)].copy(), ov.cpu().numpy().view(np.uint32)[:len(V)].copy()
+
+
 def create_rc(ctx: Context, batch: ReadBatch):
     """CreateRC for every read of the batch: returns a device tensor laid out like batch.seq."""
     rc = torch.zeros_like(batch.seq)

@@ -74,3 +74,34 @@ def test_hip_sort_huge_lists(ctx, oracle):
         ek, ep = oracle.sort_minimizers(k, p)
         assert np.array_equal(got[i][0], ek), (i, len(k))
         assert np.array_equal(got[i][1], ep), (i, len(k))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("bits", [(0, 64), (0, 34), (1, 42), (17, 63)])
+def test_hip_sort_pairs_segments_are_stably_sorted(ctx, bits):
+    """lra_sort_pairs_batch (segsort.hip) against numpy's stable sort on the selected key bits: segment lengths around the boundaries between its size classes (one
+    workgroup's LDS sort for 257 .. 8192 pairs: 1024 / 2048 / 4096 / 8192) and rocprim's share (<= 256, > 8192), empty segments, gaps between segments, heavy ties
+    (stability is what the callers rely on), keys that differ only outside the compared bits."""
+    from lra_amd import seed
+    rng = np.random.default_rng(5)
+    b0, b1 = bits
+    lens = [0, 1, 2, 255, 256, 257, 258, 1000, 1023, 1024, 1025, 2047, 2048, 2049, 4095, 4096, 4097, 6000, 8191, 8192, 8193, 9000, 20000, 0, 300, 700]
+    lens += [int(x) for x in rng.integers(1, 3000, size=40)]
+    begin, end, at = [], [], 5
+    for n in lens:
+        begin.append(at); end.append(at + n); at += n + int(rng.integers(0, 4))    # (a few unused positions between segments)
+    total = at + 3
+    keys = rng.integers(0, 1 << 62, size=total).astype(np.uint64)
+    for i, (b, e) in enumerate(zip(begin, end)):                                   # every third segment: few distinct keys -> long runs of ties
+        if i % 3 == 0 and e > b:
+            keys[b:e] = rng.integers(0, 7, size=e - b).astype(np.uint64) << np.uint64(b0 + 3)
+            keys[b:e] |= rng.integers(0, 1 << max(b0, 1), size=e - b).astype(np.uint64) & np.uint64((1 << b0) - 1)   # noise below begin_bit: must not matter
+    vals = np.arange(total, dtype=np.uint32)
+    ok, ov = seed.sort_pairs_batch(ctx, keys, vals, begin, end, b0, b1)
+    mask = np.uint64(((1 << b1) - 1) & ~((1 << b0) - 1)) if b1 < 64 else np.uint64((0xFFFFFFFFFFFFFFFF >> b0) << b0)
+    for b, e in zip(begin, end):
+        if e == b:
+            continue
+        o = np.argsort(keys[b:e] & mask, kind="stable")
+        assert np.array_equal(ok[b:e], keys[b:e][o]), (b, e)
+        assert np.array_equal(ov[b:e], vals[b:e][o]), (b, e)
