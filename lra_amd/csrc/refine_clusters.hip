@@ -9,6 +9,7 @@
 // lra_local_compare_batch intersects all tasks; one lane per task applies AppendValues' test (count, then emit); one wave per cluster
 // swaps reverse results back, reduces the box and refineEffiency.
 #include "common.h"
+#include "append_values.h"
 #include "scan.h"
 #include <rocprim/rocprim.hpp>
 #include <algorithm>
@@ -150,28 +151,7 @@ __global__ void rcl_tasks(RclArgs a) {
   if (!EMIT) a.taskCnt[c] = ntask;
 }
 
-struct FArgs {
-  uint64_t n_tasks;
-  const uint64_t* pairOff; const uint32_t* pqi; const uint32_t* pti; const uint32_t* qTup; const uint32_t* gTup;
-  const uint32_t* qAdd; const uint32_t* tAdd; const int64_t* mx; const int64_t* mn; const uint32_t* tbox;
-  uint32_t* cnt; const uint64_t* outOff; uint32_t* oq; uint32_t* ot;
-};
-template <bool EMIT>
-__global__ void rcl_filter(FArgs a) {                                    // AppendValues TupleOps.h:159-195
-  const uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (t >= a.n_tasks) return;
-  const uint32_t qa = a.qAdd[t], ta = a.tAdd[t];
-  const int64_t mx = a.mx[t], mn = a.mn[t];
-  const uint32_t qs = a.tbox[4 * t], qe = a.tbox[4 * t + 1], ts = a.tbox[4 * t + 2], te = a.tbox[4 * t + 3];
-  uint32_t n = 0;
-  uint64_t o = EMIT ? a.outOff[t] : 0;
-  for (uint64_t p = a.pairOff[t]; p < a.pairOff[t + 1]; p++) {
-    const uint32_t fp = (a.qTup[a.pqi[p]] >> 20) + qa, sp = (a.gTup[a.pti[p]] >> 20) + ta;
-    const int64_t diag = (int64_t)sp - (int64_t)fp;
-    if (diag >= mn && diag <= mx && fp >= qs && fp < qe && sp >= ts && sp < te) { if (EMIT) { a.oq[o] = fp; a.ot[o] = sp; o++; } n++; }
-  }
-  if (!EMIT) a.cnt[t] = n;
-}
+typedef AvArgs FArgs;                                                   // (append_values.h: a wave per 64 tasks reads their pairs 64 at a time)
 
 struct FinArgs {
   uint64_t nc; int smallK; const uint32_t* cRead; const int32_t* c_strand; const uint64_t* read_off; const uint64_t* taskOff; const uint64_t* outOff;
@@ -294,9 +274,9 @@ extern "C" int lra_refine_clusters_batch(lra_ctx* ctx, int n_reads, const uint64
     memset(&fa, 0, sizeof fa);
     fa.n_tasks = NT; fa.pairOff = pr.d_pair_off; fa.pqi = pr.d_pair_qi; fa.pti = pr.d_pair_ti; fa.qTup = read_index->d_tuples; fa.gTup = d_g_tuples;
     fa.qAdd = a.qAdd; fa.tAdd = a.tAdd; fa.mx = a.mx; fa.mn = a.mn; fa.tbox = a.tbox; fa.cnt = passCnt; fa.outOff = outOff;
-    const unsigned gt = (unsigned)((NT + 255) / 256);
+    const unsigned gt = (unsigned)((NT + 63) / 64);
     lra_time_begin(ctx, "rcl_filter");
-    hipLaunchKernelGGL(rcl_filter<false>, dim3(gt), dim3(256), 0, st, fa);
+    hipLaunchKernelGGL(av_filter<false>, dim3(gt), dim3(64), 0, st, fa);
     lra_time_end(ctx);
     { int rc = lra_exclusive_scan<uint32_t>(ctx, (long)NT, passCnt, outOff); if (rc) return rc; }
     LRA_HIP_CHECK(ctx, hipMemcpyAsync(&NMo, outOff + NT, 8, hipMemcpyDeviceToHost, st));
@@ -306,7 +286,7 @@ extern "C" int lra_refine_clusters_batch(lra_ctx* ctx, int n_reads, const uint64
     oq = (uint32_t*)take(wm, NMo + 1, 4); ot = (uint32_t*)take(wm, NMo + 1, 4);
     fa.oq = oq; fa.ot = ot;
     lra_time_begin(ctx, "rcl_filter");
-    hipLaunchKernelGGL(rcl_filter<true>, dim3(gt), dim3(256), 0, st, fa);
+    hipLaunchKernelGGL(av_filter<true>, dim3(gt), dim3(64), 0, st, fa);
     lra_time_end(ctx);
   } else {
     LRA_HIP_CHECK(ctx, hipMemsetAsync(outOff, 0, 16, st));
