@@ -1170,13 +1170,13 @@ static int launch_sort(lra_ctx* ctx, int n_reads, const uint64_t* mm_off, uint64
 // (tmp_key, tmp_pos); one block per list then looks for two equal neighbours: without any, the sorted list is copied over the input,
 // with one the input is left alone and the list is marked for the exact sort.
 __global__ void __launch_bounds__(256) sort_adopt_kernel(int n_lists, const uint64_t* __restrict__ off, uint64_t* key, uint32_t* pos,
-                                                         const uint64_t* __restrict__ tkey, const uint32_t* __restrict__ tpos, int* ties) {
+                                                         const uint64_t* __restrict__ tkey, const uint32_t* __restrict__ tpos, int* ties, int* n_ties) {
   const int r = blockIdx.x;
   const uint64_t b = off[r], e = off[r + 1];
   int tie = 0;
   for (uint64_t i = b + threadIdx.x; i + 1 < e; i += 256) tie |= (tkey[i] & FOR_MASK) == (tkey[i + 1] & FOR_MASK);   // (what the exact sort's comparison sees: bit 63 is a flag)
   tie = __syncthreads_or(tie);
-  if (tie) { if (threadIdx.x == 0) ties[r] = 1; return; }
+  if (tie) { if (threadIdx.x == 0) { ties[r] = 1; atomicAdd(n_ties, 1); } return; }
   if (threadIdx.x == 0) ties[r] = 0;
   for (uint64_t i = b + threadIdx.x; i < e; i += 256) { key[i] = tkey[i]; pos[i] = tpos[i]; }
 }
@@ -1189,14 +1189,22 @@ int lra_sort_mostly_unique_batch(lra_ctx* ctx, int n_lists, const uint64_t* d_of
   hipStream_t st = ctx->stream;
   size_t temp_bytes = 0;
   (void)lra_segsort_pairs(ctx, nullptr, temp_bytes, nullptr, nullptr, nullptr, nullptr, (unsigned int)total, (unsigned int)n_lists, nullptr, nullptr, 0, end_bit, st);
-  char* temp = (char*)lra_scratch(ctx, 2, temp_bytes + 256 + (size_t)n_lists * 4);
+  char* temp = (char*)lra_scratch(ctx, 2, temp_bytes + 512 + (size_t)n_lists * 4);
   if (!temp) return LRA_ERR_NOMEM;
   int* ties = (int*)(temp + ((temp_bytes + 255) & ~(size_t)255));
+  int* n_ties = ties + n_lists + 1;
+  LRA_HIP_CHECK(ctx, hipMemsetAsync(n_ties, 0, 4, st));
   lra_time_begin(ctx, ctx->sort_tag);
   hipError_t e = lra_segsort_pairs(ctx, temp, temp_bytes, d_key, tmp_key, d_pos, tmp_pos, (unsigned int)total, (unsigned int)n_lists, d_off, d_off + 1, 0, end_bit, st);
   if (e != hipSuccess) { lra_time_end(ctx); return lra_set_err(ctx, LRA_ERR_HIP, "segmented sort: %s", hipGetErrorString(e)); }
-  hipLaunchKernelGGL(sort_adopt_kernel, dim3(n_lists), dim3(256), 0, st, n_lists, d_off, d_key, d_pos, (const uint64_t*)tmp_key, (const uint32_t*)tmp_pos, ties);
+  hipLaunchKernelGGL(sort_adopt_kernel, dim3(n_lists), dim3(256), 0, st, n_lists, d_off, d_key, d_pos, (const uint64_t*)tmp_key, (const uint32_t*)tmp_pos, ties, n_ties);
   lra_time_end(ctx);
+  // Lists with a repeated key are rare in the sparse DP's point orders: without any, the exact sort's three launches -- workgroups that need a whole CU's LDS each, and wait
+  // for it beside another batch's half -- and their closing round trip are left out (this round trip takes its place)
+  int h_ties = 1;
+  LRA_HIP_CHECK(ctx, hipMemcpyAsync(&h_ties, n_ties, 4, hipMemcpyDeviceToHost, st));
+  LRA_HIP_CHECK(ctx, hipStreamSynchronize(st));
+  if (h_ties == 0) return LRA_OK;
   // lra_scratch slot 0 is launch_sort's own; the ties mask lives in slot 2 and stays valid through it
   int rc = launch_sort(ctx, n_lists, d_off, d_key, d_pos, ties);
   if (rc) return rc;
