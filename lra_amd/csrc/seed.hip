@@ -571,7 +571,7 @@ __global__ void __launch_bounds__(SORT_NT) sort_wg_kernel(int n_reads, const uin
     } else {
       if (only && !only[r]) continue;
       if (n < minLen) continue;                                           // (a shorter list was the previous launch's)
-      if (n > cap) { if (fallback && tid == 0) fallback[r] = 1; continue; }
+      if (n > cap) { if (fallback && tid == 0) { fallback[r] = 1; if (stat) atomicAdd(&stat[2], 1); } continue; }   // (stat[2]: lists left to the launch for large lists)
     }
     __syncthreads();
     if (BIG && tid == 0) fallback[r] = 0;
@@ -1129,7 +1129,7 @@ static int launch_sort(lra_ctx* ctx, int n_reads, const uint64_t* mm_off, uint64
   uint32_t* tscrB = (uint32_t*)big; char* gscr = big + tszB;
   int* flags = (int*)(tscr + (size_t)grid * (cap + 64));
   LRA_HIP_CHECK(ctx, hipMemsetAsync(flags, 0, (size_t)n_reads * 4, st));
-  LRA_HIP_CHECK(ctx, hipMemsetAsync(stat, 0, 8, st));
+  LRA_HIP_CHECK(ctx, hipMemsetAsync(stat, 0, 12, st));
   LRA_HIP_CHECK(ctx, hipFuncSetAttribute((const void*)sort_wg_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
   LRA_HIP_CHECK(ctx, hipFuncSetAttribute((const void*)sort_wg_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsB));
   lra_time_begin(ctx, ctx->sort_tag);
@@ -1142,7 +1142,15 @@ static int launch_sort(lra_ctx* ctx, int n_reads, const uint64_t* mm_off, uint64
     const int gridS = std::min(n_reads, std::min(ctx->num_cu * 4, (int)(((size_t)grid * (cap + 64)) / (size_t)(capS + 64))));
     hipLaunchKernelGGL(sort_wg_kernel<0>, dim3(gridS), dim3(256), ldsS, st, n_reads, mm_off, mm_key, mm_pos, (void*)tscr, capS, (int*)nullptr, only, (char*)nullptr, (int*)nullptr, 0);
   }
-  hipLaunchKernelGGL(sort_wg_kernel<0>, dim3(grid), dim3(SORT_NT), lds, st, n_reads, mm_off, mm_key, mm_pos, (void*)tscr, cap, flags, only, (char*)nullptr, (int*)nullptr, (capS >= 64 && ctx->sort_short) ? capS + 1 : 0);
+  hipLaunchKernelGGL(sort_wg_kernel<0>, dim3(grid), dim3(SORT_NT), lds, st, n_reads, mm_off, mm_key, mm_pos, (void*)tscr, cap, flags, only, (char*)nullptr, stat, (capS >= 64 && ctx->sort_short) ? capS + 1 : 0);
+  lra_time_end(ctx);
+  // the launch for lists beyond the LDS capacity (1024-thread workgroups again, 64 of them, each waiting for room beside another batch's half) only when the LDS launch left
+  // a list behind: it says how many, and the round trip that asks takes the place of the one behind the large-list launch
+  int h_left = 1;
+  LRA_HIP_CHECK(ctx, hipMemcpyAsync(&h_left, stat + 2, 4, hipMemcpyDeviceToHost, st));
+  LRA_HIP_CHECK(ctx, hipStreamSynchronize(st));
+  if (h_left == 0) return LRA_OK;
+  lra_time_begin(ctx, ctx->sort_tag);
   hipLaunchKernelGGL(sort_wg_kernel<1>, dim3(gridB), dim3(SORT_NT), ldsB, st, n_reads, mm_off, mm_key, mm_pos, (void*)tscrB, capB, flags, only, gscr, stat);
   lra_time_end(ctx);
   // what is left: lists of more than 65534 tuples (the minimizers of a contig of several hundred kb) -- how long, how many
