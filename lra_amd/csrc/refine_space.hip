@@ -139,8 +139,9 @@ __global__ void __launch_bounds__(64) rs_sketch(RsArgs a, int nLarge) {
   if (seqLen < (uint32_t)k) { done(); return; }
   const int span = w + k - 1;
   if (seqLen < (uint32_t)span) { done(); return; }
-  if (w >= 2 && w <= 8) {
-    // ---- the same scan, 64 positions per round (the serial machine below is what it restates; w > 8 takes the serial machine).
+  if (w >= 2 && w <= 16) {
+    // ---- the same scan, 64 positions per round (the serial machine below is what it restates; w > 16 takes the serial machine; the maps are 8 nibbles in a 32-bit word
+    // up to w = 8 and 16 nibbles in a 64-bit word beyond -- -CONTIG sketches its gaps with w = 10, and a 50 kb gap through the serial machine was a 26 ms launch).
     // The active minimizer's VALUE at p is the minimum of window (p - w, p]; only WHICH of several equal k-mers is active depends on the past, through the offset
     // o = p - actP in [0, w - 1].  Step p maps o to:  p - R(p) if o = w - 1 (the active one leaves the window: the ring rescan, first minimum in ring-slot order, i.e.
     // by (value, position mod w));  0 if k-mer p is smaller than the previous window's minimum;  o + 1 otherwise.  These maps (w entries of 4 bits) compose, so the
@@ -181,20 +182,38 @@ __global__ void __launch_bounds__(64) rs_sketch(RsArgs a, int nLarge) {
       uint64_t mP1 = __shfl_up(mWin, 1); if (lane == 0) mP1 = mPrev;        // minimum of window (p - 1 - w, p - 1]
       const bool lt = act && p >= w && c < mP1;
       // the step's map
-      uint32_t F = 0x76543210u;
-      if (act && p >= w) {
-        F = 0;
-        for (int o2 = 0; o2 < w; o2++) { const uint32_t to = (o2 == w - 1) ? (uint32_t)(p - rPos) : (lt ? 0u : (uint32_t)(o2 + 1)); F |= to << (4 * o2); }
-      } else if (act && p == w - 1) {                                      // the first window: whatever came in, the offset is that of the earliest minimum
-        const uint32_t to = (uint32_t)(p - ePos);
-        F = 0; for (int o2 = 0; o2 < 8; o2++) F |= to << (4 * o2);
+      int oNow;
+      if (w <= 8) {
+        uint32_t F = 0x76543210u;
+        if (act && p >= w) {
+          F = 0;
+          for (int o2 = 0; o2 < w; o2++) { const uint32_t to = (o2 == w - 1) ? (uint32_t)(p - rPos) : (lt ? 0u : (uint32_t)(o2 + 1)); F |= to << (4 * o2); }
+        } else if (act && p == w - 1) {                                    // the first window: whatever came in, the offset is that of the earliest minimum
+          const uint32_t to = (uint32_t)(p - ePos);
+          F = 0; for (int o2 = 0; o2 < 8; o2++) F |= to << (4 * o2);
+        }
+        uint32_t G = F;                                                    // inclusive prefix: G = F_lane o ... o F_0
+        for (int d = 1; d < 64; d <<= 1) {
+          const uint32_t E = __shfl_up(G, d);
+          if (lane >= d) { uint32_t r = 0; for (int o2 = 0; o2 < 8; o2++) { const uint32_t g1 = (E >> (4 * o2)) & 15u; r |= ((G >> (4 * g1)) & 15u) << (4 * o2); } G = r; }
+        }
+        oNow = (int)((G >> (4 * carryO)) & 15u);
+      } else {                                                             // the same with 16 nibbles
+        uint64_t F = 0xFEDCBA9876543210ull;
+        if (act && p >= w) {
+          F = 0;
+          for (int o2 = 0; o2 < w; o2++) { const uint64_t to = (o2 == w - 1) ? (uint64_t)(p - rPos) : (lt ? 0ull : (uint64_t)(o2 + 1)); F |= to << (4 * o2); }
+        } else if (act && p == w - 1) {
+          const uint64_t to = (uint64_t)(p - ePos);
+          F = 0; for (int o2 = 0; o2 < 16; o2++) F |= to << (4 * o2);
+        }
+        uint64_t G = F;
+        for (int d = 1; d < 64; d <<= 1) {
+          const uint64_t E = (uint64_t)__shfl_up((unsigned long long)G, d);
+          if (lane >= d) { uint64_t r = 0; for (int o2 = 0; o2 < 16; o2++) { const uint32_t g1 = (uint32_t)((E >> (4 * o2)) & 15ull); r |= ((G >> (4 * g1)) & 15ull) << (4 * o2); } G = r; }
+        }
+        oNow = (int)((G >> (4 * carryO)) & 15ull);
       }
-      uint32_t G = F;                                                      // inclusive prefix: G = F_lane o ... o F_0
-      for (int d = 1; d < 64; d <<= 1) {
-        const uint32_t E = __shfl_up(G, d);
-        if (lane >= d) { uint32_t r = 0; for (int o2 = 0; o2 < 8; o2++) { const uint32_t g1 = (E >> (4 * o2)) & 15u; r |= ((G >> (4 * g1)) & 15u) << (4 * o2); } G = r; }
-      }
-      const int oNow = (int)((G >> (4 * carryO)) & 15u);
       int oBefore = __shfl_up(oNow, 1); if (lane == 0) oBefore = carryO;
       const bool event = act && (p == w - 1 || (p >= w && (oBefore >= w - 1 || lt)));
       // validity

@@ -80,13 +80,13 @@ def test_hip_refine_space_oracle(ctx):
 def test_hip_refine_space_sketch_edges(ctx):
     """The long-gap branch's minimizer sketch (StoreMinimizers_noncanonical, MinCount.h:182-338) seen through RefineSpace on identical spans: every tuple of
     the query list meets its twin in the target list, so the pairs spell out the lists.  Ties (homopolymer and short tandem stretches), N runs that leave clean
-    stretches of exactly / one less / one more than w + k - 1 bases, N at either end, windows of 2 .. 9 k-mers."""
+    stretches of exactly / one less / one more than w + k - 1 bases, N at either end, windows of 2 .. 20 k-mers."""
     import torch
     from lra_amd import gapseed
     rng = np.random.default_rng(23)
     probs = []
-    for i in range(220):
-        K = int(rng.choice([6, 9, 12, 15])); W = int(rng.choice([2, 3, 5, 8, 9]))
+    for i in range(400):
+        K = int(rng.choice([6, 9, 12, 15, 19])); W = int(rng.choice([2, 3, 5, 8, 9, 10, 13, 16, 17, 20]))   # (w <= 8: 32-bit offset maps; 9 .. 16: 64-bit ones; beyond: the serial machine)
         span = W + K - 1
         L = int(rng.integers(1000, 1500))
         q = np.frombuffer(b"ACGT", np.uint8)[rng.integers(0, 4, L)].copy()
