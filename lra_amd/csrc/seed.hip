@@ -1159,7 +1159,9 @@ static int launch_sort(lra_ctx* ctx, int n_reads, const uint64_t* mm_off, uint64
   LRA_HIP_CHECK(ctx, hipStreamSynchronize(st));
   if (h_stat[1] == 0) return LRA_OK;
   const int capH = std::min(h_stat[0] + 64, (1 << 26));                    // (a list beyond 2^26 tuples stays with the one-lane kernel)
-  const int gridH = std::min(h_stat[1], std::max(1, ctx->num_cu / 4));
+  // (a workgroup per list beyond 65534 tuples, as many at a time as the device has CUs: a -CONTIG batch of 1024 contigs has 1024 such lists of ~180 k tuples, 7 MB of
+  // scratch each; with a quarter of the CUs the launch took 370 ms)
+  const int gridH = std::min(h_stat[1], std::max(1, ctx->num_cu));
   const size_t eszH = sort_scratch_bytes(2, (size_t)capH), tszH = (size_t)(capH + 64) * 8;
   char* huge = (char*)lra_ensure(ctx, 98, (size_t)gridH * (eszH + tszH) + 1024);
   if (!huge) return LRA_ERR_NOMEM;
