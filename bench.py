@@ -59,7 +59,7 @@ def cpu_baseline(mapper, reads_h, off_h, args, last_res=None):
     g = ctx.to_host(ctx.lib.lra_ctx_genome_ptr(ctx.h), mapper.G, np.uint8).tobytes() + b"\0" * 64
     g_index = mapper.fetch_local_index()
     fetch_s = time.time() - t0
-    opts = dict(globalK=args.k, globalW=args.w, globalMaxFreq=args.max_freq, refineBand=args.refine_band)
+    opts = dict(globalK=args.k, globalW=args.w, globalMaxFreq=args.max_freq, refineBand=args.refine_band, localIndexWindow=args.local_window)
     n_threads, hw_threads = host_cpus()                                       # the CPUs the box gives this process (its cgroup quota), not the threads it lists
     # a bounded sample: about 10-30 s of wall time
     S = int(min(len(off_h) - 1, 4096, max(512, 8 * n_threads)))
@@ -111,6 +111,8 @@ def main():
     ap.add_argument("--w", type=int, default=10)
     ap.add_argument("--max-freq", type=int, default=150)
     ap.add_argument("--refine-band", type=int, default=7)
+    ap.add_argument("--local-window", type=int, default=int(os.environ.get("LRA_BENCH_LOCAL_WINDOW", 256)),
+                    help="glIndex.localIndexWindow: 2048 = the .gli file `lra index` writes (LocalIndex(0), MMIndex.h:110-127), 256 = `lra align` without a .gli file (opts.localIndexWindow)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-records", action="store_true", help="leave the host tail (SAM text) out of the step")
     ap.add_argument("--satellite-frac", type=float, default=0.03, help="fraction of every chromosome in its satellite array")
@@ -158,7 +160,7 @@ def main():
 
     from lra_amd.context import Context
     from lra_amd import seed, parallel, mapread, synth_genome as sg
-    mopts = mapread.LowAccOptions(globalK=args.k, globalW=args.w, globalMaxFreq=args.max_freq, refineBand=args.refine_band)   # -ONT
+    mopts = mapread.LowAccOptions(globalK=args.k, globalW=args.w, globalMaxFreq=args.max_freq, refineBand=args.refine_band, localIndexWindow=args.local_window)   # -ONT
 
     # ---- reference side, once per process: genome, StoreIndex, LocalIndex (all on the device)
     t0 = time.time()

@@ -15,6 +15,7 @@
 #include <vector>
 #include "scan.h"
 #include <algorithm>
+#include <hipcub/hipcub.hpp>
 
 namespace {
 
@@ -352,6 +353,45 @@ __global__ void __launch_bounds__(256) local_sort_unique(uint64_t n_win, uint64_
   }
   if (lane == 0) flag[wi] = anyTie ? 1u : 0u;
 }
+// The same for the longer lists (windows beyond 256 bases: the .gli file `lra index` writes has windows of 2048 -- LocalIndex(0), MMIndex.h:110-127 --, ~700 tuples a
+// list, and the reads' indexes copy its window, Map_lowacc.h:246): a workgroup per window sorts the words in LDS by their low 20 bits (hipcub::BlockRadixSort, stable),
+// neighbours are compared, and a list without a repeated key -- one sorted order, nothing for RemoveFrequent to remove -- is written back; one with a repeated key is left
+// as it was, flagged, for the exact sort (the permutation libstdc++'s introsort leaves among equal keys is part of the index).  Size classes by NT * IPT; flag[wi] is 1 on
+// entry for every list above RANK_CAP (local_sort_unique).
+template <int NT, int IPT>
+__global__ void __launch_bounds__(NT) local_sort_radix(uint64_t n_win, uint64_t stride, uint32_t* raw, const uint32_t* __restrict__ counts, uint32_t* __restrict__ flag, int minLen) {
+  typedef hipcub::BlockRadixSort<uint32_t, NT, IPT> Sort;
+  __shared__ typename Sort::TempStorage tmp;
+  __shared__ uint32_t edge[NT + 1];
+  __shared__ int dup;
+  for (uint64_t wi = blockIdx.x; wi < n_win; wi += gridDim.x) {
+    const int n = (int)counts[wi];
+    if (n <= minLen || n > NT * IPT) continue;                            // (another class's; at most RANK_CAP: sorted already)
+    uint32_t* v = raw + wi * stride;
+    uint32_t k[IPT];
+#pragma unroll
+    for (int i = 0; i < IPT; i++) { const int p = (int)threadIdx.x * IPT + i; k[i] = p < n ? v[p] : 0xFFFFFFFFu; }   // (the padding: behind every tuple of its key -- the sort is stable)
+    if (threadIdx.x == 0) dup = 0;
+    Sort(tmp).Sort(k, 0, 20);
+    edge[threadIdx.x] = k[0];
+    __syncthreads();
+    bool d = false;
+#pragma unroll
+    for (int i = 0; i < IPT; i++) {
+      const int p = (int)threadIdx.x * IPT + i;
+      const uint32_t nx = i + 1 < IPT ? k[i + 1 < IPT ? i + 1 : i] : (threadIdx.x + 1 < NT ? edge[threadIdx.x + 1] : 0xFFFFFFFFu);
+      if (p + 1 < n && T_(k[i]) == T_(nx)) d = true;
+    }
+    if (d) dup = 1;
+    __syncthreads();
+    if (!dup) {
+#pragma unroll
+      for (int i = 0; i < IPT; i++) { const int p = (int)threadIdx.x * IPT + i; if (p < n) v[p] = k[i]; }
+      if (threadIdx.x == 0) flag[wi] = 0;
+    }
+    __syncthreads();
+  }
+}
 __global__ void local_sel(uint64_t n_win, const uint32_t* __restrict__ flag, const uint64_t* __restrict__ off, uint32_t* __restrict__ sel) {
   const uint64_t wi = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (wi < n_win && flag[wi]) sel[off[wi]] = (uint32_t)wi;
@@ -387,16 +427,25 @@ constexpr int CMP_WORDS = 10240, CMP_TASK_MAX = 512;
 // MODE 0: count; 1: write the pairs at out_off (after a scan of the counts: the walk runs twice); 2: count AND keep the pairs, packed, in a fixed row per task --
 // local_compact_pairs then lays them out by the scan of the counts.  A task with a list of more than 255 tuples or more than CMP_CAP pairs sends the batch
 // through modes 0 + 1 (nOver).
-template <int MODE>
+// BIG: the batch's tasks are beyond the staging (windows of 2048 bases -- the .gli file `lra index` writes -- hold ~700 tuples a list): a lane per task walks its lists
+// where they lie, every lane of the block (the 16-lanes-per-wave form exists for the LDS rows).  Its two searches start where the walk stands: lower_bound from ts
+// upwards and upper_bound from te downwards by doubling steps, then by halving inside the bracket -- the bound of a sorted range does not depend on the probes that
+// find it, and the two lists interleave, so it is one or two elements away (the literal halving of [ts, te) is ten scattered probes).
+template <int MODE, bool BIG = false>
 __global__ void __launch_bounds__(STAGE_NT) local_compare(CmpArgs A) {
   constexpr bool EMIT = MODE == 1;
-  __shared__ uint32_t stage[CMP_WORDS];
+  __shared__ uint32_t stage[BIG ? 1 : CMP_WORDS];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const uint64_t x0 = (uint64_t)blockIdx.x * 64;
-  const uint64_t xl = x0 + lane;
+  const uint64_t x0 = (uint64_t)blockIdx.x * (BIG ? STAGE_NT : 64);
+  const uint64_t xl = x0 + (BIG ? threadIdx.x : lane);
   const bool live = xl < A.n_tasks;
   const uint64_t myQa = live ? A.q_lo[xl] : 0, myTa = live ? A.t_lo[xl] : 0;
   const uint64_t myQn = live ? A.q_hi[xl] - myQa : 0, myTn = live ? A.t_hi[xl] - myTa : 0;
+  uint64_t x; long nq, nt; const uint32_t* q; const uint32_t* t;
+  if constexpr (BIG) {
+    if (!live) return;
+    x = xl; nq = (long)myQn; nt = (long)myTn; q = A.q + myQa; t = A.t + myTa;
+  } else {
   // where task `lane`'s lists sit in the block's LDS (every wave computes the same prefix)
   const uint32_t need = (myQn + myTn <= (uint64_t)CMP_TASK_MAX) ? (uint32_t)(myQn + myTn) : 0u;
   uint32_t incl = need;
@@ -419,12 +468,13 @@ __global__ void __launch_bounds__(STAGE_NT) local_compare(CmpArgs A) {
   const uint64_t sQa = __shfl(myQa, slot & 63), sTa = __shfl(myTa, slot & 63), sQn = __shfl(myQn, slot & 63), sTn = __shfl(myTn, slot & 63);
   const uint32_t sOff = __shfl(myOff, slot & 63); const bool staged = __shfl((int)myFits, slot & 63) != 0;
   if (lane >= TPW || x0 + slot >= A.n_tasks) return;
-  const uint64_t x = x0 + slot;
-  const long nq = (long)sQn, nt = (long)sTn;
+  x = x0 + slot;
+  nq = (long)sQn; nt = (long)sTn;
   // (one walk through pointers that are LDS or HBM per lane -- flat loads: a block's last tasks often do not fit its LDS, and a walk per address space makes every
   // wave that holds one of them run both, one after the other: measured 44 -> 60 ms)
-  const uint32_t* q = staged ? stage + sOff : A.q + sQa;
-  const uint32_t* t = staged ? stage + sOff + (uint32_t)nq : A.t + sTa;
+  q = staged ? stage + sOff : A.q + sQa;
+  t = staged ? stage + sOff + (uint32_t)nq : A.t + sTa;
+  }
   const int64_t maxDiag = A.maxDiag ? A.maxDiag[x] : 0, minDiag = A.minDiag ? A.minDiag[x] : 0;
   const long maxFreq = A.maxFreq;
   uint32_t* oq = EMIT ? A.out_qi + A.out_off[x] : nullptr; uint32_t* ot = EMIT ? A.out_ti + A.out_off[x] : nullptr;
@@ -452,6 +502,7 @@ __global__ void __launch_bounds__(STAGE_NT) local_compare(CmpArgs A) {
       if (startGap == 0 || startGap > endGap) {
         const long tsOrig = ts, qsOrig = qs;
         long lo = ts, hi = te;
+        if (BIG) { const uint32_t key = Q(qs); for (long s_ = 1; lo < hi; s_ <<= 1) { const long p = lo + s_ - 1; if (p >= hi) break; if (TT(p) < key) lo = p + 1; else { hi = p; break; } } }
         while (lo < hi) { long mid = lo + (hi - lo) / 2; if (TT(mid) < Q(qs)) lo = mid + 1; else hi = mid; }
         ts = lo;
         if (ts < te && TT(ts) == Q(qs)) {
@@ -469,6 +520,7 @@ __global__ void __launch_bounds__(STAGE_NT) local_compare(CmpArgs A) {
         if (te != nt && TT(te - 1) == Q(qe)) {
         } else {
           long lo = ts, hi = te;
+          if (BIG) { const uint32_t key = Q(qe); for (long s_ = 1; lo < hi; s_ <<= 1) { const long p = hi - s_; if (p < lo) break; if (!(key < TT(p))) { lo = p + 1; break; } else hi = p; } }
           while (lo < hi) { long mid = lo + (hi - lo) / 2; if (!(Q(qe) < TT(mid))) lo = mid + 1; else hi = mid; }
           te = lo;
         }
@@ -490,6 +542,14 @@ __global__ void __launch_bounds__(STAGE_NT) local_compare(CmpArgs A) {
 #undef TT
   if (!EMIT) A.counts[x] = n;
   if (MODE == 2 && (n > (uint32_t)CMP_CAP || nq > 255 || nt > 255)) atomicAdd(A.nOver, 1);
+}
+
+// the tasks whose two lists are beyond a staged row (the batch's form of the walk is chosen by their share)
+__global__ void k_big_tasks(CmpArgs A, unsigned long long* nBig) {
+  const uint64_t x = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const bool big = x < A.n_tasks && (A.q_hi[x] - A.q_lo[x]) + (A.t_hi[x] - A.t_lo[x]) > (uint64_t)CMP_TASK_MAX;
+  const unsigned long long m = __ballot(big);
+  if ((threadIdx.x & 63) == 0 && m) atomicAdd(nBig, (unsigned long long)__popcll(m));
 }
 
 // the kept pairs of 4 tasks per wave (16 lanes each) to their places
@@ -562,6 +622,13 @@ extern "C" int lra_local_index_masked_batch(lra_ctx* ctx, int n_seqs, const char
       if (!ws) return LRA_ERR_NOMEM;
       uint32_t* flag = carve<uint32_t>(ws, NW); uint32_t* sel = carve<uint32_t>(ws, NW); uint64_t* foff = carve<uint64_t>(ws, NW);
       hipLaunchKernelGGL(local_sort_unique, dim3((unsigned)((n_win + 3) / 4)), dim3(256), 0, st, n_win, stride, raw, (const uint32_t*)cnt, flag);
+      if (stride > (uint64_t)RANK_CAP) {                                  // lists beyond the rank sort: LDS radix sorts by size class (a window has at most 4096 - k + 1 tuples)
+        const unsigned cu = (unsigned)ctx->num_cu;
+        const unsigned gr = (unsigned)std::min<uint64_t>(n_win, (uint64_t)cu * 64);
+        hipLaunchKernelGGL((local_sort_radix<256, 4>), dim3(gr), dim3(256), 0, st, n_win, stride, raw, (const uint32_t*)cnt, flag, RANK_CAP);
+        if (stride > 1024) hipLaunchKernelGGL((local_sort_radix<256, 8>), dim3(gr), dim3(256), 0, st, n_win, stride, raw, (const uint32_t*)cnt, flag, 1024);
+        if (stride > 2048) hipLaunchKernelGGL((local_sort_radix<512, 8>), dim3(gr), dim3(512), 0, st, n_win, stride, raw, (const uint32_t*)cnt, flag, 2048);
+      }
       if (lra_exclusive_scan<uint32_t>(ctx, (long)n_win, flag, foff)) return LRA_ERR_HIP;
       hipLaunchKernelGGL(local_sel, dim3((unsigned)((n_win + 255) / 256)), dim3(256), 0, st, n_win, (const uint32_t*)flag, (const uint64_t*)foff, sel);
       hipLaunchKernelGGL(local_sort_filter, dim3(gw), dim3(STAGE_NT), 0, st, n_win, stride, raw, max_freq, cnt, (const uint32_t*)sel, (const uint64_t*)(foff + n_win));
@@ -609,12 +676,21 @@ extern "C" int lra_local_compare_batch(lra_ctx* ctx, uint64_t n_tasks, const uin
   const unsigned g = (unsigned)((n_tasks + 63) / 64);
   static const bool twoPass = getenv("LRA_LOCAL_TWO_PASS") != nullptr;      // count, scan, walk again (kept for comparison; also what a batch with an oversized task falls back to)
   int* nOver = (int*)lra_ensure(ctx, 94, 64);
-  A.capped = twoPass ? nullptr : (uint16_t*)lra_ensure(ctx, 95, (size_t)n_tasks * CMP_CAP * 2 + 256);
-  if (!nOver || (!twoPass && !A.capped)) return LRA_ERR_NOMEM;
+  if (!nOver) return LRA_ERR_NOMEM;
   A.nOver = nOver;
-  LRA_HIP_CHECK(ctx, hipMemsetAsync(nOver, 0, 4, st));
+  LRA_HIP_CHECK(ctx, hipMemsetAsync(nOver, 0, 16, st));
+  // the form of the walk: a batch whose tasks are mostly beyond the staged rows (the local index's windows are larger than 256 bases) is walked where its lists lie
+  static const int forceBig = getenv("LRA_LOCAL_BIG") ? atoi(getenv("LRA_LOCAL_BIG")) : -1;
+  uint64_t h_big = 0;
+  hipLaunchKernelGGL(k_big_tasks, dim3((unsigned)((n_tasks + 255) / 256)), dim3(256), 0, st, A, (unsigned long long*)(nOver + 2));
+  if (d2h8(ctx, &h_big, (const uint64_t*)(nOver + 2))) return LRA_ERR_HIP;
+  const bool big = forceBig >= 0 ? forceBig != 0 : 2 * h_big > n_tasks;
+  const unsigned gB = (unsigned)((n_tasks + STAGE_NT - 1) / STAGE_NT);
+  A.capped = (twoPass || big) ? nullptr : (uint16_t*)lra_ensure(ctx, 95, (size_t)n_tasks * CMP_CAP * 2 + 256);
+  if (!twoPass && !big && !A.capped) return LRA_ERR_NOMEM;
   lra_time_begin(ctx, "local_compare");
-  if (twoPass) hipLaunchKernelGGL(local_compare<0>, dim3(g), dim3(STAGE_NT), 0, st, A);
+  if (big) hipLaunchKernelGGL((local_compare<0, true>), dim3(gB), dim3(STAGE_NT), 0, st, A);
+  else if (twoPass) hipLaunchKernelGGL(local_compare<0>, dim3(g), dim3(STAGE_NT), 0, st, A);
   else hipLaunchKernelGGL(local_compare<2>, dim3(g), dim3(STAGE_NT), 0, st, A);
   lra_time_end(ctx);
   if (lra_exclusive_scan<uint32_t>(ctx, (long)n_tasks, A.counts, off)) return LRA_ERR_HIP;
@@ -631,7 +707,8 @@ extern "C" int lra_local_compare_batch(lra_ctx* ctx, uint64_t n_tasks, const uin
   if (!r) return LRA_ERR_NOMEM;
   A.out_qi = carve<uint32_t>(r, total + 1); A.out_ti = carve<uint32_t>(r, total + 1);
   lra_time_begin(ctx, "local_compare");
-  if (twoPass || h_over > 0) hipLaunchKernelGGL(local_compare<1>, dim3(g), dim3(STAGE_NT), 0, st, A);
+  if (big) hipLaunchKernelGGL((local_compare<1, true>), dim3(gB), dim3(STAGE_NT), 0, st, A);
+  else if (twoPass || h_over > 0) hipLaunchKernelGGL(local_compare<1>, dim3(g), dim3(STAGE_NT), 0, st, A);
   else hipLaunchKernelGGL(local_compact_pairs, dim3((unsigned)((n_tasks + 3) / 4)), dim3(64), 0, st, A);
   lra_time_end(ctx);
   LRA_HIP_CHECK(ctx, hipGetLastError());

@@ -361,7 +361,7 @@ def _sv_reads(genome, rng, err, n_plain=10):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("preset", ["ccs", "ccs-bp", "ccs-k17", "contig", "ccs-sparse"])
+@pytest.mark.parametrize("preset", ["ccs", "ccs-bp", "ccs-k17", "contig", "ccs-sparse", "ccs-gli", "contig-gli", "ccs-sparse-gli"])
 def test_map_reads_highacc_match_oracle_pipeline(ctx, oracle, preset):
     """lra_map_reads_highacc_batch against MapRead_highacc composed from the oracle's stage functions (tests/oracle_pipeline.map_read_highacc): every
     SegAlignment of every chain -- strand, Supplymentary, ISsecondary, NumOfAnchors0/1, the chain's value, the refined blocks, the counters the two
@@ -376,6 +376,8 @@ def test_map_reads_highacc_match_oracle_pipeline(ctx, oracle, preset):
     over = {}
     oo = dict(OP.CCS)
     ip = (17, 10, 150, 15, 1)                                             # `lra index -CCS`
+    gli = preset.endswith("-gli")                                         # glIndex as glIndex.Read leaves it after `lra index`: k = 10, w = 5, windows of 2048 bases (LocalIndex(0),
+    preset = preset.replace("-gli", "")                                   # MMIndex.h:110-127; RunStoreLocal keeps k = 10 under -CCS / -CONTIG, lra.cpp:785-804); without a .gli file: opts.localK = 7, 256
     if preset == "contig":                                                # -CONTIG: refineBand 50 (rows of more than 64 cells), K 19, other gap costs, contig thresholds
         oo = dict(OP.CONTIG); ip = (19, 10, 30, 20, 1)
         sim = lambda a, n, rev=False: synth.simulate_read(rng, g[a:a + n + 1], n, 0.003, (34, 33, 33), rev)[0]
@@ -387,6 +389,8 @@ def test_map_reads_highacc_match_oracle_pipeline(ctx, oracle, preset):
         over.update({"globalK": 17, "globalW": 10, "clean.globalK": 17, "sdp.globalK": 17, "fine.globalK": 17}); oo.update(globalK=17, globalW=10); ip = (17, 10, 150, 15, 1)
     if preset == "ccs-sparse":                                            # a slightly thinner global index (one minimizer per 18 bases instead of 15; the reads are sketched with W = 20): clusters at ~0.01 anchors per base, so some
         ip = (17, 10, 150, 18, 1)                                         # reads take the REFINEclusters branch (Map_highacc.h:413-447) and some do not
+    if gli:
+        over.update(localK=10, localIndexWindow=2048); oo.update(localK=10, localIndexWindow=2048)
     mapper = mapread.HighAccMapper(ctx, g, None, None, [b"chrA", b"chrB"], CH, "contig" if preset == "contig" else "ccs", index_params=ip, **over)
     ik, ipos = I.global_index(ctx)
     g_index = mapper.fetch_local_index()

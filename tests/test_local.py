@@ -57,10 +57,20 @@ def _device_seqs(ctx, seqs):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("k,w,window,mf", [(10, 5, 256, 15), (7, 5, 256, 30), (10, 5, 128, 5)])
+@pytest.mark.parametrize("k,w,window,mf", [(10, 5, 256, 15), (7, 5, 256, 30), (10, 5, 128, 5), (10, 5, 2048, 15), (10, 5, 2048, 3), (7, 5, 1000, 15), (10, 5, 4096, 15), (8, 16, 2048, 15)])
 def test_hip_local_index_matches_oracle(ctx, oracle, k, w, window, mf):
+    """window 2048 = the .gli file `lra index` writes (LocalIndex(0): 1 << (LOCAL_POS_BITS - 1), MMIndex.h:110-127) and the read indexes copied from it: ~700 tuples a
+    window, a third of the windows with a k-mer twice (the exact sort), tandem repeats whose k-mers RemoveFrequent drops; 4096 = the widest window a LocalTuple's position holds."""
     from lra_amd import local
     g, seqs = _seqs()
+    if window > 256:
+        rng = np.random.default_rng(5)
+        gl = synth.make_genome(400_000, seed=9, repeat_frac=0.4)
+        seqs = seqs + [gl[a:a + n].copy() for a, n in ((0, 30_000), (50_000, 2048), (60_000, 2049), (70_000, 4096 * 3 + 17), (100_000, 25_000), (200_000, 12_345))]
+        seqs.append(np.tile(gl[1000:1037], 200))                                                        # a tandem array: every k-mer 55 times in a 2048-base window
+        seqs.append(np.concatenate([gl[3000:4000], np.tile(np.frombuffer(b"AC", np.uint8), 700), gl[4000:5500]]))
+        seqs.append(np.frombuffer(b"ACGT", np.uint8)[rng.integers(0, 4, 9000)].copy())
+        seqs.append(np.concatenate([gl[8000:9000], np.frombuffer(b"N" * 40, np.uint8), gl[9000:12000], gl[8000:9000], gl[8200:8900]]))   # repeats inside one window: keys twice
     sd, od = _device_seqs(ctx, seqs)
     li = local.LocalIndex(ctx, sd, od, k, w, window, mf)
     win_off, bnd, tup = li.fetch()
@@ -137,6 +147,50 @@ def test_hip_local_compare_matches_golden_and_oracle(ctx, oracle):
         assert np.array_equal(pqi[a:b], eq + np.uint32(ql[x])) and np.array_equal(pti[a:b], et + np.uint32(tl[x])), x
         npairs += b - a
     assert npairs > 500
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("banded", [False, True])
+def test_hip_local_compare_large_tasks(ctx, oracle, banded):
+    """A batch whose tasks are lists of hundreds of tuples (windows of 2048 bases): the lane-per-task form of the walk (its bounds found from where the walk stands),
+    against the oracle's CompareLists -- shared keys, keys several times on either side (beyond localMaxFreq too), lists of one tuple, with and without the diagonal band."""
+    import torch
+    from lra_amd import local
+    class Raw:
+        pass
+    rng = np.random.default_rng(21 + banded)
+    qs, ts, ql, qh, tl, th, mx, mn = [], [], [], [], [], [], [], []
+    qo = to = 0
+    for c in range(300):
+        if c % 17 == 5:
+            nq, nt, nkeys = int(rng.integers(1, 4)), int(rng.integers(200, 700)), 500
+        elif c % 17 == 9:
+            nq, nt, nkeys = int(rng.integers(300, 900)), int(rng.integers(1, 3)), 500
+        elif c % 17 == 12:                                          # few distinct k-mers: long runs on both sides
+            nq, nt, nkeys = 400, 350, 30
+        else:
+            nq, nt, nkeys = int(rng.integers(250, 1000)), int(rng.integers(250, 1000)), int(rng.integers(600, 3000))
+        keys = np.sort(rng.choice(1 << 20, nkeys, replace=False)).astype(np.uint32)
+        qk = np.sort(rng.choice(keys, nq)); tk = np.sort(rng.choice(keys, nt))
+        qp = rng.integers(0, 2048, nq).astype(np.uint32); tp = rng.integers(0, 2048, nt).astype(np.uint32)
+        qs.append(oracle.pack_local(qk, qp)); ts.append(oracle.pack_local(tk, tp))
+        ql.append(qo); qo += nq; qh.append(qo); tl.append(to); to += nt; th.append(to)
+        d0 = int(rng.integers(-1500, 1500))
+        mx.append(d0 + int(rng.integers(50, 800)) if c % 5 else 0); mn.append(d0 - int(rng.integers(50, 800)) if c % 7 else 0)
+    qa = np.concatenate(qs + [np.zeros(1, np.uint32)]); ta = np.concatenate(ts + [np.zeros(1, np.uint32)])
+    A, B = Raw(), Raw()
+    A.t_ = torch.from_numpy(qa.view(np.int32)).to(ctx.device); B.t_ = torch.from_numpy(ta.view(np.int32)).to(ctx.device)
+    A.res = local.LocalIndexResult(); B.res = local.LocalIndexResult()
+    A.res.d_tuples = A.t_.data_ptr(); B.res.d_tuples = B.t_.data_ptr()
+    kw = dict(max_diag=mx, min_diag=mn) if banded else {}
+    off, pqi, pti = local.local_compare_batch(ctx, A, ql, qh, B, tl, th, 15, **kw)
+    n_pairs = 0
+    for x in range(len(ql)):
+        eq, et = oracle.compare_lists_local(qa[ql[x]:qh[x]], ta[tl[x]:th[x]], 15, *((mx[x], mn[x]) if banded else ()))
+        a, b = int(off[x]), int(off[x + 1])
+        assert np.array_equal(pqi[a:b], eq + np.uint32(ql[x])) and np.array_equal(pti[a:b], et + np.uint32(tl[x])), x
+        n_pairs += b - a
+    assert n_pairs > 5000
 
 
 @pytest.mark.gpu

@@ -146,7 +146,7 @@ def test_map_reads_to_sam(ctx):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("preset", ["ont", "clr", "ont-bp", "ont-2chr", "ont-rep", "ont-defer", "ont-defer-all", "ont-onepass"])
+@pytest.mark.parametrize("preset", ["ont", "clr", "ont-bp", "ont-2chr", "ont-rep", "ont-defer", "ont-defer-all", "ont-onepass", "ont-gli", "clr-gli", "ont-gli-2chr"])
 def test_map_reads_match_oracle_pipeline(ctx, oracle, preset):
     """The C boundary against the oracle's stage functions composed on the CPU (tests/oracle_pipeline.py): every SegAlignment of every
     primary chain -- strand, Supplymentary, NumOfAnchors0/1, FirstSDPValue, the refined blocks -- bit for bit, on plain reads, reads with a
@@ -156,10 +156,13 @@ def test_map_reads_match_oracle_pipeline(ctx, oracle, preset):
     from lra_amd import seed, mapread
     O_STAT_NAMES = oracle_lib.STAT_NAMES
     genome = synth.make_genome(500_000, seed=31, repeat_frac=0.25, n_families=3)
+    gli = preset.endswith("-gli") or "-gli-" in preset                     # the local index as `lra index` writes it and glIndex.Read hands it to the path: windows of 2048 bases
+    preset = preset.replace("-gli", "")                                    # (LocalIndex(0), MMIndex.h:110-127, lra.cpp:989); without a .gli file `lra align` builds it with opts.localIndexWindow = 256
     o = mapread.clr_options() if preset == "clr" else mapread.LowAccOptions(refineBreakpoint=(preset == "ont-bp"))     # ont-bp: --refineBreakpoints
+    o.localIndexWindow = 2048 if gli else 256
     # ont-defer / -all / onepass: lra_map_opts.defer_matches -- some / all / none of the reads go through the driver's second, concurrent pass; same results
     o.deferMatches = {"ont-defer": 800, "ont-defer-all": 1, "ont-onepass": 0}.get(preset)
-    oo = OP.CLR if preset == "clr" else dict(OP.ONT, refineBreakpoint=(preset == "ont-bp"))
+    oo = dict(OP.CLR if preset == "clr" else dict(OP.ONT, refineBreakpoint=(preset == "ont-bp")), localIndexWindow=o.localIndexWindow)
     err, mix = (0.15, (20, 30, 50)) if preset == "clr" else (0.10, (30, 35, 35))
     ik, ip = synth.build_global_index(genome, o.globalK, o.globalW, 100)
     reads, truth = synth.simulate_reads(genome, 10, 8000, 2500, err, mix, seed=11)
@@ -189,7 +192,7 @@ def test_map_reads_match_oracle_pipeline(ctx, oracle, preset):
     nd = mapper.stats["n_deferred_reads"]
     assert {"ont-defer": 0 < nd < len(reads) - 1, "ont-defer-all": nd == len(reads) - 1, "ont-onepass": nd == 0}.get(preset, True), (nd, len(reads))
     g_win, g_bnd, g_tup = mapper.gli.fetch()
-    g_index = (mapread.seq_offsets(CH, 256).astype(np.uint64), g_bnd, g_tup)
+    g_index = (mapread.seq_offsets(CH, o.localIndexWindow).astype(np.uint64), g_bnd, g_tup)
     gbytes = genome.tobytes() + b"\0" * 64
     n_seg = n_supp = n_rev = n_multi = n_bp = 0
     rates = []
