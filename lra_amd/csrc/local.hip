@@ -60,7 +60,6 @@ __global__ void window_count(int n_seqs, const uint64_t* __restrict__ seq_off, i
 // dwords apart so the per-lane byte reads spread over the banks): the serial scan then never touches
 // HBM (the unstaged version fetched ~40x the sequence bytes because 64 private streams thrash L1).
 constexpr int WMAX = 256;            // staged window length; longer windows read from HBM directly
-constexpr int WSTRIDE = WMAX + 4;
 // One pass: window wi writes its tuples at raw + wi * stride (stride = window - k + 1 slots: a window cannot emit more tuples than it has
 // k-mer positions) and its count; the sort / filter and the compaction read the slab through (wi * stride, counts[wi]).
 __device__ __forceinline__ uint32_t spread16(uint32_t x) {            // bit i of x -> bit 2 i
@@ -253,7 +252,6 @@ __device__ void w_std_sort(uint32_t* v, long n) {
 // sort + RemoveFrequent in place; counts[wi] = surviving tuples.  Lists of <= LCAP tuples are sorted in a
 // lane-private LDS row (copied in and out with coalesced accesses); longer ones in HBM.
 constexpr int LCAP = 160;
-constexpr int LSTRIDE = LCAP + 1;
 constexpr int STAGE_NT = 256;                                           // 4 waves stage a block's 64 lists (memory parallelism), wave 0 works on them
 // (a window holds ~45 tuples: the 64 lists of a block are packed behind one another in LS_WORDS words of LDS -- 24 KB, six blocks per CU -- instead of 64 rows of LCAP;
 // a list that no longer fits, like one above LCAP, is sorted in HBM)
@@ -392,6 +390,154 @@ __global__ void __launch_bounds__(NT) local_sort_radix(uint64_t n_win, uint64_t 
     __syncthreads();
   }
 }
+
+// ---- the exact sort of the long lists with a repeated key, a WAVE per list (local_sort_filter walks such a list with one lane: 52-62 ms per batch at windows of 2048
+// bases, a third of the windows).  libstdc++'s introsort is data-parallel as it stands (seed.hip, sort_wg_kernel): the segments the loop recurses into are disjoint,
+// and the unguarded Hoare partition of [first + 1, last) around *first is a closed form -- with a_0 < a_1 < .. the positions holding x >= pivot and b_0 > b_1 > .. those
+// holding x <= pivot it swaps (a_i, b_i) for i < m = #{i: a_i < b_i} and returns cut = min(a_m, b_(m-1)); the final insertion sort equals a stable insertion sort of
+// every block between two cuts.  Here the list lies in the wave's LDS; a segment is taken from a stack, its stoppers ranked by ballots into two position lists, m counted
+// (the test is true on a prefix), the swaps done side by side, the children pushed; then a lane per leftover block; then RemoveFrequent (MMIndex.h:69-84) as three
+// sweeps (run start, run end, compaction) and the list goes back in place.
+__device__ __forceinline__ void wave_sync_lds() {
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+}
+__global__ void __launch_bounds__(64) local_sort_exact_wave(uint64_t stride, uint32_t* raw, int maxFreq, uint32_t* counts, const uint32_t* __restrict__ sel,
+                                                            const uint64_t* __restrict__ nSel, int cap) {
+  extern __shared__ uint32_t xs_lds[];
+  uint32_t* v = xs_lds;
+  unsigned short* pa = (unsigned short*)(v + cap);
+  unsigned short* pb = pa + cap;
+  uint32_t* sbits = (uint32_t*)(pb + cap);                                 // block starts, cap / 32 + 1 words
+  int* stF = (int*)(sbits + cap / 32 + 1); int* stL = stF + 64; int* stD = stL + 64;
+  const int lane = threadIdx.x;
+  const unsigned long long below = lane == 0 ? 0ULL : (~0ULL >> (64 - lane));
+  const uint64_t nS = *nSel;
+  for (uint64_t bi = blockIdx.x; bi < nS; bi += gridDim.x) {
+    const uint64_t wi = sel[bi];
+    const int n = (int)counts[wi];
+    if (n > cap) continue;                                                 // (cannot happen: cap covers the stride)
+    uint32_t* g = raw + wi * stride;
+    for (int p = lane; p < n; p += 64) v[p] = g[p];
+    for (int x = lane; x < cap / 32 + 1; x += 64) sbits[x] = x == 0 ? 1u : 0u;
+    int sp = 0;
+    if (lane == 0 && n > 16) { stF[0] = 0; stL[0] = n; stD[0] = 2 * (31 - __clz(n)); }
+    if (n > 16) sp = 1;
+    wave_sync_lds();
+    while (sp > 0) {
+      --sp;
+      const int first = stF[sp], last = stL[sp]; int depth = stD[sp];
+      wave_sync_lds();                                                     // (everyone has read the entry before it is overwritten)
+      if (depth == 0) {                                                    // __partial_sort(first, last, last): heap sort, one lane
+        if (lane == 0) {
+          const long len = last - first;
+          for (long parent = (len - 2) / 2;; parent--) { w_adjust_heap(v, first, parent, len, v[first + parent]); if (parent == 0) break; }
+          long l2 = last;
+          while (l2 - first > 1) { --l2; const uint32_t val = v[l2]; v[l2] = v[first]; w_adjust_heap(v, first, 0, l2 - first, val); }
+        }
+        wave_sync_lds();
+        continue;
+      }
+      --depth;
+      {                                                                    // __move_median_to_first(first, first + 1, mid, last - 1)
+        const int a = first + 1, b = first + (last - first) / 2, c = last - 1;
+        const uint32_t ka = T_(v[a]), kb = T_(v[b]), kc = T_(v[c]);
+        int w;
+        if (ka < kb) w = kb < kc ? b : (ka < kc ? c : a);
+        else w = ka < kc ? a : (kb < kc ? c : b);
+        if (lane == 0) { const uint32_t t0 = v[first]; v[first] = v[w]; v[w] = t0; }
+      }
+      wave_sync_lds();
+      const uint32_t piv = T_(v[first]);
+      const int f1 = first + 1;
+      int nA = 0, nB = 0;
+      for (int base = f1; base < last; base += 64) {
+        const int p = base + lane;
+        const bool ok = p < last;
+        const uint32_t k = ok ? T_(v[p]) : 0u;
+        const bool A = ok && k >= piv, B = ok && k <= piv;
+        const unsigned long long mA = __ballot(A), mB = __ballot(B);
+        if (A) pa[f1 + nA + __popcll(mA & below)] = (unsigned short)p;
+        if (B) pb[f1 + nB + __popcll(mB & below)] = (unsigned short)p;
+        nA += __popcll(mA); nB += __popcll(mB);
+      }
+      wave_sync_lds();
+      const int lim = min(nA, nB);
+      int m = 0;
+      for (int i0 = 0; i0 < lim; i0 += 64) {
+        const int i = i0 + lane;
+        const bool ok = i < lim && pa[f1 + i] < pb[f1 + nB - 1 - i];
+        const unsigned long long mk = __ballot(ok);
+        m += __popcll(mk);
+        if (__popcll(mk) < min(64, lim - i0)) break;
+      }
+      for (int i0 = 0; i0 < m; i0 += 64) {
+        const int i = i0 + lane;
+        if (i < m) { const int x = pa[f1 + i], y = pb[f1 + nB - 1 - i]; const uint32_t t0 = v[x]; v[x] = v[y]; v[y] = t0; }
+      }
+      int cut = 0x7fffffff;
+      if (m < nA) cut = pa[f1 + m];
+      if (m >= 1) cut = min(cut, (int)pb[f1 + nB - m]);
+      wave_sync_lds();
+      if (lane == 0) {
+        atomicOr(&sbits[cut >> 5], 1u << (cut & 31));
+        int s2 = sp;
+        if (cut - first > 16) { stF[s2] = first; stL[s2] = cut; stD[s2] = depth; s2++; }
+        if (last - cut > 16) { stF[s2] = cut; stL[s2] = last; stD[s2] = depth; s2++; }
+      }
+      sp += (cut - first > 16) + (last - cut > 16);
+      wave_sync_lds();
+    }
+    // the final insertion sort: a lane per block between two marks
+    for (int p = lane; p < n; p += 64) {
+      if ((sbits[p >> 5] >> (p & 31)) & 1u) {
+        int q = p + 1;
+        while (q < n && !((sbits[q >> 5] >> (q & 31)) & 1u)) q++;
+        for (int i = p + 1; i < q; ++i) {
+          const uint32_t val = v[i];
+          int j = i;
+          while (j > p && T_(val) < T_(v[j - 1])) { v[j] = v[j - 1]; --j; }
+          v[j] = val;
+        }
+      }
+    }
+    wave_sync_lds();
+    // RemoveFrequent: a run of maxFreq or more equal keys goes
+    {
+      int carry = 0;
+      for (int base = 0; base < n; base += 64) {                           // run start of every position
+        const int p = base + lane;
+        const bool st = p < n && (p == 0 || T_(v[p]) != T_(v[p - 1]));
+        const unsigned long long ms = __ballot(st);
+        const unsigned long long upto = ms & (below | (1ULL << lane));
+        if (p < n) pa[p] = (unsigned short)(upto ? base + 63 - __clzll(upto) : carry);
+        if (ms) carry = base + 63 - __clzll(ms);
+      }
+      int nxt = n;
+      for (int base = ((n - 1) / 64) * 64; base >= 0; base -= 64) {        // run end (the next start) of every position
+        const int p = base + lane;
+        const bool st = p < n && (p == 0 || T_(v[p]) != T_(v[p - 1]));
+        const unsigned long long ms = __ballot(st);
+        const unsigned long long above = lane == 63 ? 0ULL : (ms & (~0ULL << (lane + 1)));
+        if (p < n) pb[p] = (unsigned short)(above ? base + __ffsll((long long)above) - 1 : nxt);
+        if (ms) nxt = base + __ffsll((long long)ms) - 1;
+      }
+      wave_sync_lds();
+      int kept = 0;
+      for (int base = 0; base < n; base += 64) {
+        const int p = base + lane;
+        const bool keep = p < n && (int)pb[p] - (int)pa[p] < maxFreq;
+        const unsigned long long mk = __ballot(keep);
+        if (keep) g[kept + __popcll(mk & below)] = v[p];
+        kept += __popcll(mk);
+      }
+      if (lane == 0) counts[wi] = (uint32_t)kept;
+    }
+    wave_sync_lds();
+  }
+}
+
 __global__ void local_sel(uint64_t n_win, const uint32_t* __restrict__ flag, const uint64_t* __restrict__ off, uint32_t* __restrict__ sel) {
   const uint64_t wi = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (wi < n_win && flag[wi]) sel[off[wi]] = (uint32_t)wi;
@@ -424,6 +570,7 @@ constexpr int CMP_CAP = 128;                    // pairs per task kept by the on
 // A block's 64 tasks share CMP_WORDS words of LDS, each task's query list then its target list packed behind the previous task's (a task of more than CMP_TASK_MAX words,
 // or one that no longer fits, is walked in HBM): a typical task has ~180 words, so 40 KB hold a block and four blocks fit a CU (fixed 257-word rows: two).
 constexpr int CMP_WORDS = 10240, CMP_TASK_MAX = 512;
+constexpr int CW_ROW = 512;                     // pairs per task kept by the one-walk form for large tasks (packed qi << 16 | ti; a task with more is walked again)
 // MODE 0: count; 1: write the pairs at out_off (after a scan of the counts: the walk runs twice); 2: count AND keep the pairs, packed, in a fixed row per task --
 // local_compact_pairs then lays them out by the scan of the counts.  A task with a list of more than 255 tuples or more than CMP_CAP pairs sends the batch
 // through modes 0 + 1 (nOver).
@@ -432,7 +579,7 @@ constexpr int CMP_WORDS = 10240, CMP_TASK_MAX = 512;
 // upwards and upper_bound from te downwards by doubling steps, then by halving inside the bracket -- the bound of a sorted range does not depend on the probes that
 // find it, and the two lists interleave, so it is one or two elements away (the literal halving of [ts, te) is ten scattered probes).
 template <int MODE, bool BIG = false>
-__global__ void __launch_bounds__(STAGE_NT) local_compare(CmpArgs A) {
+__global__ void __launch_bounds__(STAGE_NT) local_compare(CmpArgs A, uint32_t* __restrict__ rows = nullptr) {
   constexpr bool EMIT = MODE == 1;
   __shared__ uint32_t stage[BIG ? 1 : CMP_WORDS];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -444,6 +591,7 @@ __global__ void __launch_bounds__(STAGE_NT) local_compare(CmpArgs A) {
   uint64_t x; long nq, nt; const uint32_t* q; const uint32_t* t;
   if constexpr (BIG) {
     if (!live) return;
+    if (MODE == 1 && rows && A.counts[xl] <= (uint32_t)CW_ROW) return;   // (its pairs came out of its row: local_compact_rows)
     x = xl; nq = (long)myQn; nt = (long)myTn; q = A.q + myQa; t = A.t + myTa;
   } else {
   // where task `lane`'s lists sit in the block's LDS (every wave computes the same prefix)
@@ -478,7 +626,8 @@ __global__ void __launch_bounds__(STAGE_NT) local_compare(CmpArgs A) {
   const int64_t maxDiag = A.maxDiag ? A.maxDiag[x] : 0, minDiag = A.minDiag ? A.minDiag[x] : 0;
   const long maxFreq = A.maxFreq;
   uint32_t* oq = EMIT ? A.out_qi + A.out_off[x] : nullptr; uint32_t* ot = EMIT ? A.out_ti + A.out_off[x] : nullptr;
-  uint16_t* cp = MODE == 2 ? A.capped + x * (uint64_t)CMP_CAP : nullptr;
+  uint16_t* cp = (MODE == 2 && !BIG) ? A.capped + x * (uint64_t)CMP_CAP : nullptr;
+  uint32_t* row = (MODE == 2 && BIG) ? rows + x * (uint64_t)CW_ROW : nullptr;
   uint32_t n = 0;
   auto emit = [&](long qi, long ti) {                                    // :87-97
     if (maxDiag != 0 && minDiag != 0) {
@@ -486,7 +635,8 @@ __global__ void __launch_bounds__(STAGE_NT) local_compare(CmpArgs A) {
       if (!(d <= maxDiag && d >= minDiag)) return;
     }
     if (EMIT) { oq[n] = (uint32_t)(A.q_lo[x] + qi); ot[n] = (uint32_t)(A.t_lo[x] + ti); }
-    if (MODE == 2 && n < (uint32_t)CMP_CAP) cp[n] = (uint16_t)((qi << 8) | ti);
+    if (MODE == 2 && !BIG && n < (uint32_t)CMP_CAP) cp[n] = (uint16_t)((qi << 8) | ti);
+    if (MODE == 2 && BIG && n < (uint32_t)CW_ROW) row[n] = ((uint32_t)qi << 16) | (uint32_t)ti;
     n++;
   };
 #define Q(i) T_(q[(i)])
@@ -541,7 +691,128 @@ __global__ void __launch_bounds__(STAGE_NT) local_compare(CmpArgs A) {
 #undef Q
 #undef TT
   if (!EMIT) A.counts[x] = n;
-  if (MODE == 2 && (n > (uint32_t)CMP_CAP || nq > 255 || nt > 255)) atomicAdd(A.nOver, 1);
+  if (MODE == 2 && !BIG && (n > (uint32_t)CMP_CAP || nq > 255 || nt > 255)) atomicAdd(A.nOver, 1);
+  if (MODE == 2 && BIG && n > (uint32_t)CW_ROW) atomicAdd(A.nOver, 1);
+}
+
+
+// ---- CompareLists for batches of LARGE tasks (two lists of ~700 tuples: the 2048-base windows of a .gli file): the walk is a chain of dependent reads, one lane per
+// task, and with the lists where they lie every step of a wave is 64 scattered lines (142 ms per batch: each line fetched for one word and gone again before the next).
+// Here a wave takes CW_TPB tasks at a time: all its lanes copy the tasks' lists into LDS (every byte read once, coalesced), then CW_TPB lanes walk them -- the walk's
+// round trips are LDS round trips.  One walk per task: its pairs go to a row of CW_ROW packed pairs (qi << 16 | ti), local_compact_rows lays them out by the scan of
+// the counts; a task with more pairs is walked again, alone with its likes, writing at its offset (MODE 1).
+constexpr int CW_TPB = 4, CW_SLOT = 1536;
+template <int MODE>
+__global__ void __launch_bounds__(64) local_compare_wave(CmpArgs A, uint32_t* __restrict__ rows) {
+  __shared__ uint32_t stage[CW_TPB * CW_SLOT];
+  const int lane = threadIdx.x;
+  for (uint64_t g0 = (uint64_t)blockIdx.x * CW_TPB; g0 < A.n_tasks; g0 += (uint64_t)gridDim.x * CW_TPB) {
+    const uint64_t xl = g0 + (uint64_t)(lane & (CW_TPB - 1));             // lane i (and i + CW_TPB, ..) looks at task g0 + i
+    bool live = xl < A.n_tasks;
+    if (MODE == 1 && live) live = A.counts[xl] > (uint32_t)CW_ROW;
+    const uint64_t myQa = live ? A.q_lo[xl] : 0, myTa = live ? A.t_lo[xl] : 0;
+    const int myQn = live ? (int)(A.q_hi[xl] - myQa) : 0, myTn = live ? (int)(A.t_hi[xl] - myTa) : 0;
+    const bool myFits = myQn + myTn <= CW_SLOT;
+#pragma unroll
+    for (int i = 0; i < CW_TPB; i++) {
+      const uint64_t qa = __shfl(myQa, i), ta = __shfl(myTa, i);
+      const int qn = __shfl(myQn, i), tn = __shfl(myTn, i);
+      if (!__shfl((int)myFits, i)) continue;
+      uint32_t* d = stage + i * CW_SLOT;
+      for (int p = lane; p < qn; p += 64) d[p] = A.q[qa + p];
+      for (int p = lane; p < tn; p += 64) d[qn + p] = A.t[ta + p];
+    }
+    __syncthreads();
+    if (lane < CW_TPB && live) {
+      const uint64_t x = xl;
+      const int nq = myQn, nt = myTn;
+      const uint32_t* q = myFits ? stage + lane * CW_SLOT : A.q + myQa;
+      const uint32_t* t = myFits ? stage + lane * CW_SLOT + nq : A.t + myTa;
+      const int64_t maxDiag = A.maxDiag ? A.maxDiag[x] : 0, minDiag = A.minDiag ? A.minDiag[x] : 0;
+      const bool banded = maxDiag != 0 && minDiag != 0;
+      const int maxFreq = (int)A.maxFreq;
+      uint32_t* oq = MODE == 1 ? A.out_qi + A.out_off[x] : nullptr; uint32_t* ot = MODE == 1 ? A.out_ti + A.out_off[x] : nullptr;
+      uint32_t* row = rows + x * (uint64_t)CW_ROW;
+      const uint32_t qb = (uint32_t)myQa, tb = (uint32_t)myTa;
+      uint32_t n = 0;
+      auto emit = [&](int qi, int ti) {                                    // :87-97
+        if (banded) {
+          const int64_t d = (int64_t)P_(t[ti]) - (int64_t)P_(q[qi]);
+          if (!(d <= maxDiag && d >= minDiag)) return;
+        }
+        if (MODE == 1) { oq[n] = qb + (uint32_t)qi; ot[n] = tb + (uint32_t)ti; }
+        else if (n < (uint32_t)CW_ROW) row[n] = ((uint32_t)qi << 16) | (uint32_t)ti;
+        n++;
+      };
+#define Q(i) T_(q[(i)])
+#define TT(i) T_(t[(i)])
+      if (nq != 0 && nt != 0) {
+        int qs = 0, qe = nq - 1, ts = 0, te = nt;
+        do {
+          { const uint32_t k0 = TT(ts); while (qs <= qe && Q(qs) < k0) qs++; }
+          if (qs >= qe) break;
+          const uint32_t kq = Q(qs);
+          const uint32_t startGap = (kq - TT(ts)) & TMASK;
+          { const uint32_t k1 = TT(te - 1); while (qe > qs && te > ts && Q(qe) > k1) qe--; }
+          const uint32_t ke = Q(qe);
+          const uint32_t endGap = (TT(te - 1) - ke) & TMASK;
+          if (startGap == 0 || startGap > endGap) {
+            const int tsOrig = ts;
+            int lo = ts, hi = te;                                              // lower_bound(T[ts, te), Q[qs]) from ts upwards (see local_compare<.., BIG>)
+            for (int s_ = 1; lo < hi; s_ <<= 1) { const int p = lo + s_ - 1; if (p >= hi) break; if (TT(p) < kq) lo = p + 1; else { hi = p; break; } }
+            while (lo < hi) { const int mid = lo + (hi - lo) / 2; if (TT(mid) < kq) lo = mid + 1; else hi = mid; }
+            ts = lo;
+            if (ts < te && TT(ts) == kq) {
+              int tsi = ts;
+              while (tsi != te && kq == TT(tsi)) tsi++;
+              const int qsStart = qs;
+              while (qs < qe && Q(qs + 1) == kq) qs++;
+              if (qs - qsStart < maxFreq)
+                for (int ti = ts; ti != tsi; ti++)
+                  for (int qi = qsStart; qi <= qs; qi++) emit(qi, ti);
+            }
+            { const uint32_t raw = TT(tsOrig); while (ts < te && TT(ts) == raw) ts++; }
+            while (qs < qe && Q(qs) == kq) qs++;
+          } else {
+            if (te != nt && TT(te - 1) == ke) {
+            } else {
+              int lo = ts, hi = te;                                            // upper_bound(T[ts, te), Q[qe]) from te downwards
+              for (int s_ = 1; lo < hi; s_ <<= 1) { const int p = hi - s_; if (p < lo) break; if (!(ke < TT(p))) { lo = p + 1; break; } else hi = p; }
+              while (lo < hi) { const int mid = lo + (hi - lo) / 2; if (!(ke < TT(mid))) lo = mid + 1; else hi = mid; }
+              te = lo;
+            }
+            const int teStart = te;
+            int tei = te;
+            while (tei > ts && TT(tei - 1) == ke) tei--;
+            if (tei < teStart && teStart > 0) {
+              const int qeStart = qe;
+              while (qe > qs && Q(qe - 1) == ke) qe--;
+              if (qeStart - qe < maxFreq)
+                for (int ti = tei; ti < teStart; ti++)
+                  for (int qi = qe; qi <= qeStart; qi++) emit(qi, ti);
+            }
+            te = tei;
+          }
+        } while (qs < qe && ts < te);
+      }
+#undef Q
+#undef TT
+      if (MODE != 1) { A.counts[x] = n; if (n > (uint32_t)CW_ROW) atomicAdd(A.nOver, 1); }
+    }
+    __syncthreads();
+  }
+}
+// the rows' pairs to their places: a wave per task
+__global__ void __launch_bounds__(256) local_compact_rows(CmpArgs A, const uint32_t* __restrict__ rows) {
+  const uint64_t x = (uint64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (x >= A.n_tasks) return;
+  const int l = threadIdx.x & 63;
+  const uint32_t n = A.counts[x];
+  if (n > (uint32_t)CW_ROW) return;                                        // (walked again: local_compare_wave<1>)
+  const uint64_t o = A.out_off[x];
+  const uint32_t ql = (uint32_t)A.q_lo[x], tl = (uint32_t)A.t_lo[x];
+  const uint32_t* rw = rows + x * (uint64_t)CW_ROW;
+  for (uint32_t p = l; p < n; p += 64) { const uint32_t v = rw[p]; A.out_qi[o + p] = ql + (v >> 16); A.out_ti[o + p] = tl + (v & 0xFFFFu); }
 }
 
 // the tasks whose two lists are beyond a staged row (the batch's form of the walk is chosen by their share)
@@ -631,7 +902,15 @@ extern "C" int lra_local_index_masked_batch(lra_ctx* ctx, int n_seqs, const char
       }
       if (lra_exclusive_scan<uint32_t>(ctx, (long)n_win, flag, foff)) return LRA_ERR_HIP;
       hipLaunchKernelGGL(local_sel, dim3((unsigned)((n_win + 255) / 256)), dim3(256), 0, st, n_win, (const uint32_t*)flag, (const uint64_t*)foff, sel);
-      hipLaunchKernelGGL(local_sort_filter, dim3(gw), dim3(STAGE_NT), 0, st, n_win, stride, raw, max_freq, cnt, (const uint32_t*)sel, (const uint64_t*)(foff + n_win));
+      static const bool laneExact = getenv("LRA_LOCAL_EXACT_LANES") != nullptr;   // (the one-lane-per-list exact sort for the long lists as well: kept for comparison)
+      if (stride > (uint64_t)RANK_CAP && !laneExact) {
+        const int cap = (int)((stride + 63) & ~(uint64_t)63);
+        const size_t lds = (size_t)cap * 8 + ((size_t)cap / 32 + 1) * 4 + 3 * 64 * 4;
+        if (lds > 65536) LRA_HIP_CHECK(ctx, hipFuncSetAttribute((const void*)local_sort_exact_wave, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        const unsigned ge = (unsigned)std::min<uint64_t>(n_win, (uint64_t)ctx->num_cu * 32);
+        hipLaunchKernelGGL(local_sort_exact_wave, dim3(ge), dim3(64), lds, st, stride, raw, max_freq, cnt, (const uint32_t*)sel, (const uint64_t*)(foff + n_win), cap);
+      } else
+        hipLaunchKernelGGL(local_sort_filter, dim3(gw), dim3(STAGE_NT), 0, st, n_win, stride, raw, max_freq, cnt, (const uint32_t*)sel, (const uint64_t*)(foff + n_win));
     }
     lra_time_end(ctx);
     if (lra_exclusive_scan<uint32_t>(ctx, (long)n_win, cnt, bnd_tmp)) return LRA_ERR_HIP;
@@ -686,10 +965,23 @@ extern "C" int lra_local_compare_batch(lra_ctx* ctx, uint64_t n_tasks, const uin
   if (d2h8(ctx, &h_big, (const uint64_t*)(nOver + 2))) return LRA_ERR_HIP;
   const bool big = forceBig >= 0 ? forceBig != 0 : 2 * h_big > n_tasks;
   const unsigned gB = (unsigned)((n_tasks + STAGE_NT - 1) / STAGE_NT);
+  static const bool waveForm = getenv("LRA_LOCAL_BIG_WAVE") != nullptr;     // (the large tasks' lists staged in LDS, four walks per wave: measured slower -- 188 ms against 142 --, kept for comparison)
+  const bool waveBig = big && waveForm;
   A.capped = (twoPass || big) ? nullptr : (uint16_t*)lra_ensure(ctx, 95, (size_t)n_tasks * CMP_CAP * 2 + 256);
   if (!twoPass && !big && !A.capped) return LRA_ERR_NOMEM;
+  uint32_t* rows = big ? (uint32_t*)lra_ensure(ctx, 95, (size_t)n_tasks * CW_ROW * 4 + 256) : nullptr;
+  if (big && !rows) return LRA_ERR_NOMEM;
+  const unsigned gW = (unsigned)std::min<uint64_t>((n_tasks + CW_TPB - 1) / CW_TPB, (uint64_t)ctx->num_cu * 24);
+  // The lane-per-task walk of large tasks has four cursors a lane, a cache line each: with every wave slot of a CU taken (2048 walks) a line is fetched for one word and is
+  // gone before the cursor needs its next word -- the launch moves 40 x its lists.  Dynamic LDS nobody uses keeps it to two blocks (8 waves, 512 walks) per CU, whose lines
+  // stay in the CU's share of L2: 77.9 ms per batch -> 47.6 (four blocks: 55.8; one: 61.5).
+  static const size_t bigPad = getenv("LRA_LOCAL_BIG_PAD") ? (size_t)atol(getenv("LRA_LOCAL_BIG_PAD")) : 64000;
   lra_time_begin(ctx, "local_compare");
-  if (big) hipLaunchKernelGGL((local_compare<0, true>), dim3(gB), dim3(STAGE_NT), 0, st, A);
+  if (waveBig) hipLaunchKernelGGL(local_compare_wave<2>, dim3(gW), dim3(64), 0, st, A, rows);
+  else if (big) {
+    if (bigPad > 65536) LRA_HIP_CHECK(ctx, hipFuncSetAttribute((const void*)local_compare<2, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bigPad));
+    hipLaunchKernelGGL((local_compare<2, true>), dim3(gB), dim3(STAGE_NT), bigPad, st, A, rows);
+  }
   else if (twoPass) hipLaunchKernelGGL(local_compare<0>, dim3(g), dim3(STAGE_NT), 0, st, A);
   else hipLaunchKernelGGL(local_compare<2>, dim3(g), dim3(STAGE_NT), 0, st, A);
   lra_time_end(ctx);
@@ -707,7 +999,13 @@ extern "C" int lra_local_compare_batch(lra_ctx* ctx, uint64_t n_tasks, const uin
   if (!r) return LRA_ERR_NOMEM;
   A.out_qi = carve<uint32_t>(r, total + 1); A.out_ti = carve<uint32_t>(r, total + 1);
   lra_time_begin(ctx, "local_compare");
-  if (big) hipLaunchKernelGGL((local_compare<1, true>), dim3(gB), dim3(STAGE_NT), 0, st, A);
+  if (waveBig) {
+    hipLaunchKernelGGL(local_compact_rows, dim3((unsigned)((n_tasks + 3) / 4)), dim3(256), 0, st, A, (const uint32_t*)rows);
+    if (h_over > 0) hipLaunchKernelGGL(local_compare_wave<1>, dim3(gW), dim3(64), 0, st, A, rows);
+  } else if (big) {
+    hipLaunchKernelGGL(local_compact_rows, dim3((unsigned)((n_tasks + 3) / 4)), dim3(256), 0, st, A, (const uint32_t*)rows);
+    if (h_over > 0) hipLaunchKernelGGL((local_compare<1, true>), dim3(gB), dim3(STAGE_NT), std::min<size_t>(bigPad, 65536), st, A, rows);
+  }
   else if (twoPass || h_over > 0) hipLaunchKernelGGL(local_compare<1>, dim3(g), dim3(STAGE_NT), 0, st, A);
   else hipLaunchKernelGGL(local_compact_pairs, dim3((unsigned)((n_tasks + 3) / 4)), dim3(64), 0, st, A);
   lra_time_end(ctx);
