@@ -111,7 +111,7 @@ def main():
     ap.add_argument("--w", type=int, default=10)
     ap.add_argument("--max-freq", type=int, default=150)
     ap.add_argument("--refine-band", type=int, default=7)
-    ap.add_argument("--local-window", type=int, default=int(os.environ.get("LRA_BENCH_LOCAL_WINDOW", 256)),
+    ap.add_argument("--local-window", type=int, default=int(os.environ.get("LRA_BENCH_LOCAL_WINDOW", 2048)),
                     help="glIndex.localIndexWindow: 2048 = the .gli file `lra index` writes (LocalIndex(0), MMIndex.h:110-127), 256 = `lra align` without a .gli file (opts.localIndexWindow)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-records", action="store_true", help="leave the host tail (SAM text) out of the step")
@@ -649,7 +649,10 @@ def main():
                                    "strand, %.0f%% with one planted SV (deletion / insertion / inversion / tandem duplication / translocation, 50 bp-10 kb)"
                                    % (args.genome_scale, G / 1e9, args.k, args.w, args.max_freq, mapper.index_stats["n_index"], G / max(mapper.index_stats["n_index"], 1),
                                       args.reads, args.read_len, args.err * 100, args.sv_frac * 100),
-                       "preset": "-ONT (k=%d w=%d maxFreq=%d refineBand=%d match/mismatch/indel=4/-1/-2)" % (args.k, args.w, args.max_freq, args.refine_band),
+                       "preset": "-ONT (k=%d w=%d maxFreq=%d refineBand=%d match/mismatch/indel=4/-1/-2); local index k=10 w=5 maxFreq=15, windows of %d bases (%s)"
+                                 % (args.k, args.w, args.max_freq, args.refine_band, args.local_window,
+                                    "the .gli file `lra index -ONT` writes: LocalIndex(0), MMIndex.h:110-127 -- what glIndex.Read hands `lra align`" if args.local_window == 2048 else
+                                    "`lra align` without a .gli file: opts.localIndexWindow" if args.local_window == 256 else "--local-window"),
                        "stages": "MapRead_lowacc chained on the reads, every stage on what the previous one produced on the device: a1-a5, a7, a8 (SDP#A), a9, a10, a11, "
                                  "a9 (MergeChain), a7 (second LinearExtend + Trim), a8 (second SDP + filters), a13 (incl. a12), a14, a16; then lra_map_pack, the gather of the "
                                  "record buffers to rank 0 and the host tail a16-a17 (SetFromSegAlignment, AlignmentsOrder, SimpleMapQV, SAM text) of batch i beside the "

@@ -69,7 +69,7 @@ int lra_ctx_set_stream(lra_ctx* ctx, void* stream);
 const char* lra_ctx_last_error(lra_ctx* ctx);
 /* ABI version of the loaded library (tests check it against this header). */
 int lra_abi_version(void);
-#define LRA_ABI_VERSION 7   /* 7: lra_sort_pairs_batch;  2: lra_map_opts.defer_matches, lra_map_counters.n_deferred_reads; 3: lra_map_opts.flagged_unaligned, lra_map_counters.n_flagged_reads, lra_map_host_flagged; 4: lra_reads_last_error, a corrupt FASTQ record is LRA_ERR_INVALID; lra_map_opts.defer_seed_matches; 5: lra_seed_prefetch, lra_ctx_adopt_seed, lra_map_reads_lowacc_front / _back, lra_map_back_release; 6: a failed front half hands over an error batch (one back call per front call), separate n_handed_back_reads counter, lra_map_host_trim */
+#define LRA_ABI_VERSION 8   /* 8: lra_map_opts_apply_local_index, lra_ctx_local_index_params (the .gli file's k / w / window override the options', as glIndex.Read does); 7: lra_sort_pairs_batch;  2: lra_map_opts.defer_matches, lra_map_counters.n_deferred_reads; 3: lra_map_opts.flagged_unaligned, lra_map_counters.n_flagged_reads, lra_map_host_flagged; 4: lra_reads_last_error, a corrupt FASTQ record is LRA_ERR_INVALID; lra_map_opts.defer_seed_matches; 5: lra_seed_prefetch, lra_ctx_adopt_seed, lra_map_reads_lowacc_front / _back, lra_map_back_release; 6: a failed front half hands over an error batch (one back call per front call), separate n_handed_back_reads counter, lra_map_host_trim */
 
 /* Convenience for hosts without their own HIP binding: synchronous device->host copy on the
  * context's stream (a C++ host would call hipMemcpy itself).                                */
@@ -1010,6 +1010,15 @@ void lra_map_opts_preset_ont(lra_map_opts* opts);          /* -ONT: lra.cpp:386-
 void lra_map_opts_preset_clr(lra_map_opts* opts);          /* -CLR: lra.cpp:341-386 */
 int lra_ctx_load_chromosomes(lra_ctx* ctx, const uint64_t* h_chrom_pos, int n_chrom);
 int lra_ctx_build_local_index(lra_ctx* ctx, int k, int w, int window, int max_freq);
+/* glIndex's k, w and localIndexWindow belong to the INDEX, not to the options: LocalIndex::Read takes them from the .gli file (MMIndex.h:154-173, lra.cpp:627), the reads'
+ * indexes copy them (LocalIndex(LocalIndex&), MMIndex.h:128-136, Map_lowacc.h:246-247) and smallOpts.globalK / globalW are glIndex.k / w (Map_lowacc.h:233-234,
+ * Map_highacc.h:430-431).  `lra index` writes k = 10, w = 5, windows of 2048 bases under EVERY preset (`LocalIndex glIndex;` lra.cpp:989 -> LocalIndex(0): 1 <<
+ * (LOCAL_POS_BITS - 1), MMIndex.h:110-127; RunStoreLocal keeps k = 10, lra.cpp:785-817), so an `lra align` run on indexed files maps with those; only without a .gli file
+ * does it build glIndex from opts.localK (10 for -ONT / -CLR, 7 for -CCS / -CONTIG) and opts.localIndexWindow = 256 (lra.cpp:619-621, :628) -- the values the presets
+ * below hold.  lra_map_opts_apply_local_index writes an index's three values into the options (localK, localW, localIndexWindow); lra_ctx_local_index_params returns the
+ * ones the context's index was built with.  The drivers refuse options that differ from the context's index (LRA_ERR_INVALID).                                        */
+void lra_map_opts_apply_local_index(lra_map_opts* opts, int k, int w, int window);
+int lra_ctx_local_index_params(lra_ctx* ctx, int* k, int* w, int* window);
 /* The context's reference data as device pointers: the genome bytes; the genome's local index (the .gli payload: d_tuple_bnd[n_windows + 1],
  * d_tuples[n_tuples]) and its seqOffsets[n_windows + 1].  Valid until the context is destroyed or the data is loaded / built again.        */
 /* Several contexts on one GPU (sub-batches on their own HIP streams) share ONE replica of the reference: dst borrows src's genome, global

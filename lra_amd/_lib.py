@@ -4,7 +4,7 @@ import os
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 _LIB = None
-ABI_VERSION = 7
+ABI_VERSION = 8
 
 
 class LraError(RuntimeError):
@@ -107,6 +107,8 @@ SYMBOLS = {
     "lra_map_opts_preset_clr": (None, [_vp]),
     "lra_ctx_load_chromosomes": (C.c_int, [_vp, _vp, C.c_int]),
     "lra_ctx_build_local_index": (C.c_int, [_vp, C.c_int, C.c_int, C.c_int, C.c_int]),
+    "lra_map_opts_apply_local_index": (None, [_vp, C.c_int, C.c_int, C.c_int]),
+    "lra_ctx_local_index_params": (C.c_int, [_vp, _vp, _vp, _vp]),
     "lra_map_reads_lowacc_batch": (C.c_int, [_vp, C.c_int, _vp, _vp, C.c_uint64, _vp, _vp]),
     "lra_map_reads_highacc_batch": (C.c_int, [_vp, C.c_int, _vp, _vp, C.c_uint64, _vp, _vp]),
     "lra_ctx_genome_ptr": (_vp, [_vp]),

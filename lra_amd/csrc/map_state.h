@@ -47,7 +47,7 @@ struct lra_map_state {
   uint64_t* d_chrom_pos = nullptr;
   void* gli_buf = nullptr; lra_local_index_result gli{};   // the genome's LocalIndex (the .gli payload), built on the device
   uint64_t* d_gso = nullptr; uint64_t n_gwin = 0;  // its seqOffsets
-  int gli_window = 0;
+  int gli_window = 0, gli_k = 0, gli_w = 0;      // glIndex.localIndexWindow / k / w: what the genome's local index was built (or written by `lra index`) with
   bool borrowed = false;                           // reference data shared from another context (lra_ctx_share_reference): not freed here
   std::shared_ptr<lra_gen_cell> cell = std::make_shared<lra_gen_cell>();   // gen bumped by every loader of this context (chromosome table, local index); dead once it is destroyed
   std::shared_ptr<lra_gen_cell> owner_cell; uint64_t owner_generation = 0;  // a borrower: whose data, at which generation (see seed_state.h)

@@ -275,6 +275,22 @@ extern "C" void lra_map_opts_preset_clr(lra_map_opts* o) {
   o->readType = LRA_READ_CLR;
 }
 
+// What glIndex.Read leaves in the options' place (lra.cpp:627, MMIndex.h:154-173): the .gli file's k, w and localIndexWindow are the genome index's AND, through the copy
+// constructor (MMIndex.h:128-136, Map_lowacc.h:246-247), the read indexes'; smallOpts.globalK / globalW are glIndex.k / w (Map_lowacc.h:233-234, Map_highacc.h:430-431).
+// `lra index` writes k = 10, w = 5, windows of 2048 bases under every preset (LocalIndex(0): 1 << (LOCAL_POS_BITS - 1), MMIndex.h:110-127; RunStoreLocal, lra.cpp:778-850);
+// without a .gli file `lra align` builds glIndex from opts.localK / localIndexWindow = 256 (lra.cpp:619-621, :628) -- the presets' values.
+extern "C" void lra_map_opts_apply_local_index(lra_map_opts* o, int k, int w, int window) {
+  if (!o) return;
+  o->localK = k; o->localW = w; o->localIndexWindow = window;
+}
+extern "C" int lra_ctx_local_index_params(lra_ctx* ctx, int* k, int* w, int* window) {
+  if (!ctx || !ctx->map || !ctx->map->gli_window) return LRA_ERR_INVALID;
+  if (k) *k = ctx->map->gli_k;
+  if (w) *w = ctx->map->gli_w;
+  if (window) *window = ctx->map->gli_window;
+  return LRA_OK;
+}
+
 extern "C" int lra_ctx_load_chromosomes(lra_ctx* ctx, const uint64_t* h_chrom_pos, int n_chrom) {
   if (!ctx || !h_chrom_pos || n_chrom < 1) return LRA_ERR_INVALID;
   LRA_HIP_CHECK(ctx, hipSetDevice(ctx->device));
@@ -311,7 +327,7 @@ extern "C" int lra_ctx_build_local_index(lra_ctx* ctx, int k, int w, int window,
   m->gli.d_win_off = (const uint64_t*)(nb + ((const char*)r.d_win_off - ob));
   m->gli.d_tuple_bnd = (const uint64_t*)(nb + ((const char*)r.d_tuple_bnd - ob));
   m->gli.d_tuples = (const uint32_t*)(nb + ((const char*)r.d_tuples - ob));
-  m->gli_window = window;
+  m->gli_window = window; m->gli_k = k; m->gli_w = w;
   // LocalIndex::seqOffsets (MMIndex.h:200-245): window ends, restarting at each sequence
   std::vector<uint64_t> gso; gso.push_back(0);
   for (int c = 0; c < n_chrom; c++)
@@ -335,7 +351,7 @@ extern "C" int lra_ctx_share_reference(lra_ctx* dst, lra_ctx* src) {
   lra_map_state* m = map_state(dst);
   const lra_map_state* s = src->map;
   m->chrom_pos = s->chrom_pos; m->d_chrom_pos = s->d_chrom_pos; m->gli_buf = s->gli_buf; m->gli = s->gli; m->d_gso = s->d_gso; m->n_gwin = s->n_gwin;
-  m->gli_window = s->gli_window; m->lut = s->lut; m->borrowed = true;
+  m->gli_window = s->gli_window; m->gli_k = s->gli_k; m->gli_w = s->gli_w; m->lut = s->lut; m->borrowed = true;
   m->owner_cell = s->borrowed ? s->owner_cell : s->cell; m->owner_generation = s->borrowed ? s->owner_generation : s->cell->gen.load();
   return LRA_OK;
 }
@@ -834,7 +850,7 @@ static int child_refresh(lra_ctx* ctx) {
     if (rc) return lra_set_err(c, rc, "companion context: sharing the reference");   // (on the companion: in two-stage batches this runs on the back halves' thread)
     lra_map_state* d = c->map; const lra_map_state* s = ctx->map;
     d->chrom_pos = s->chrom_pos; d->d_chrom_pos = s->d_chrom_pos; d->gli_buf = s->gli_buf; d->gli = s->gli; d->d_gso = s->d_gso; d->n_gwin = s->n_gwin;
-    d->gli_window = s->gli_window; d->lut = s->lut; d->borrowed = true;
+    d->gli_window = s->gli_window; d->gli_k = s->gli_k; d->gli_w = s->gli_w; d->lut = s->lut; d->borrowed = true;
     d->owner_cell = s->borrowed ? s->owner_cell : s->cell; d->owner_generation = s->borrowed ? s->owner_generation : s->cell->gen.load();
   }
   return LRA_OK;
@@ -859,7 +875,9 @@ static int lowacc_batch_impl(lra_ctx* ctx, int n_reads, const char* d_seq, const
   lra_map_state* m = ctx->map;
   if (!m || !m->gli_buf || !ctx->seed || !ctx->seed->genome || !ctx->seed->idx_key)
     return lra_set_err(ctx, LRA_ERR_INVALID, "reference not loaded (genome, global index, chromosome table, local index)");
-  if (m->gli_window != o->localIndexWindow) return lra_set_err(ctx, LRA_ERR_INVALID, "local index built with another window");
+  if (m->gli_window != o->localIndexWindow || m->gli_k != o->localK || m->gli_w != o->localW)
+    return lra_set_err(ctx, LRA_ERR_INVALID, "the genome's local index has k = %d, w = %d, windows of %d bases; the options say %d, %d, %d (lra_map_opts_apply_local_index: glIndex.Read overrides them)",
+                       m->gli_k, m->gli_w, m->gli_window, o->localK, o->localW, o->localIndexWindow);
   { int rcs = lra_map_check_shared(ctx); if (rcs) return rcs; }
   out->n_reads = n_reads;
   m->last_text.clear(); m->last_sig = lra_map_sig{};         // a sizing call of lra_map_records for an earlier batch is void now
@@ -938,7 +956,9 @@ static int front_checks(lra_ctx* ctx, int n_reads, const lra_map_opts* o) {
   lra_map_state* m = ctx->map;
   if (!m || !m->gli_buf || !ctx->seed || !ctx->seed->genome || !ctx->seed->idx_key)
     return lra_set_err(ctx, LRA_ERR_INVALID, "reference not loaded (genome, global index, chromosome table, local index)");
-  if (m->gli_window != o->localIndexWindow) return lra_set_err(ctx, LRA_ERR_INVALID, "local index built with another window");
+  if (m->gli_window != o->localIndexWindow || m->gli_k != o->localK || m->gli_w != o->localW)
+    return lra_set_err(ctx, LRA_ERR_INVALID, "the genome's local index has k = %d, w = %d, windows of %d bases; the options say %d, %d, %d (lra_map_opts_apply_local_index: glIndex.Read overrides them)",
+                       m->gli_k, m->gli_w, m->gli_window, o->localK, o->localW, o->localIndexWindow);
   if (o->defer_matches > 0 || o->defer_seed_matches > 0 || getenv("LRA_DEFER_MATCHES")) return lra_set_err(ctx, LRA_ERR_INVALID, "two-stage batches do not combine with defer_matches / defer_seed_matches");
   return lra_map_check_shared(ctx);
 }

@@ -385,6 +385,9 @@ static int highacc_core(lra_ctx* ctx, int n_reads, const char* d_seq, const uint
     else {
       // ---- REFINEclusters (:429-447): the read's two local indexes (:398-402), every cluster re-seeded window by window; anchorfreq inherited (:444)
       if (!m->gli_buf) return lra_set_err(ctx, LRA_ERR_INVALID, "a read takes the REFINEclusters branch: the genome's local index is needed (lra_ctx_build_local_index)");
+      if (m->gli_window != o->localIndexWindow || m->gli_k != o->localK || m->gli_w != o->localW)
+        return lra_set_err(ctx, LRA_ERR_INVALID, "the genome's local index has k = %d, w = %d, windows of %d bases; the options say %d, %d, %d (lra_map_opts_apply_local_index: glIndex.Read overrides them)",
+                           m->gli_k, m->gli_w, m->gli_window, o->localK, o->localW, o->localIndexWindow);
       uint64_t* off2 = (uint64_t*)lra_ensure(ctx, 58, (2 * (size_t)R + 2) * 8);
       uint8_t* active = (uint8_t*)lra_ensure(ctx, 65, 2 * (size_t)R + 64);
       if (!off2 || !active) return LRA_ERR_NOMEM;

@@ -65,6 +65,18 @@ class LowAccOptions:
     deferMatches: int = None           # lra_map_opts.defer_matches (scheduling only; None = the preset's value, 0 = one pass)
 
 
+GLI_K, GLI_W, GLI_WINDOW = 10, 5, 2048
+"""What `lra index` writes into the .gli file under every preset (`LocalIndex glIndex;` lra.cpp:989 -> LocalIndex(0): k = 10, w = 5, windows of 1 << (LOCAL_POS_BITS - 1)
+bases, MMIndex.h:110-127) and glIndex.Read hands the path (lra.cpp:627): the genome's local index, the reads' (copied from it, Map_lowacc.h:246-247), smallOpts.globalK / W.
+The option classes' defaults are `lra align` WITHOUT a .gli file (glIndex built from opts.localK / localIndexWindow = 256, lra.cpp:619-628)."""
+
+
+def with_gli(opts, k=GLI_K, w=GLI_W, window=GLI_WINDOW):
+    """LowAccOptions after glIndex.Read of a .gli file (lra_map_opts_apply_local_index)."""
+    import dataclasses
+    return dataclasses.replace(opts, localK=k, localW=w, localIndexWindow=window)
+
+
 def clr_options(**kw):
     """The -CLR preset (lra.cpp:341-386): what differs from -ONT on this path."""
     d = dict(globalK=15, globalMaxFreq=250, refineBand=20, initial_anchorbonus=15.0, second_anchorbonus=6.0, alnthres=0.50, SecondCleanMaxDiag=120,
@@ -481,7 +493,9 @@ class HighAccMapper:
     """MapRead_highacc behind the C boundary (lra_map_reads_highacc_batch): the -CCS / -CONTIG presets.  Reference data as LowAccMapper (the global index is
     built on the device from index_params = (K, W, globalMaxFreq, globalWinsize, NumOfminimizersPerWindow) when idx_key is None); no local index."""
 
-    def __init__(self, ctx: Context, genome, idx_key, idx_pos, chrom_names, chrom_pos, preset="ccs", index_params=None, **overrides):
+    def __init__(self, ctx: Context, genome, idx_key, idx_pos, chrom_names, chrom_pos, preset="ccs", index_params=None, gli=None, **overrides):
+        """gli = (k, w, window): the genome's local index as a .gli file holds it (True: what `lra index` writes, 10 / 5 / 2048); None: built from the options, as
+        `lra align` does without a .gli file (localK = 7, windows of 256 bases)."""
         from . import index as _index
         self.ctx = ctx
         g = genome if torch.is_tensor(genome) else torch.from_numpy(np.ascontiguousarray(genome, dtype=np.uint8))
@@ -490,6 +504,8 @@ class HighAccMapper:
         self.chrom_names = [n if isinstance(n, bytes) else str(n).encode() for n in chrom_names]
         m = MapOpts()
         (ctx.lib.lra_map_opts_preset_contig if preset == "contig" else ctx.lib.lra_map_opts_preset_ccs)(C.byref(m))
+        if gli:
+            ctx.lib.lra_map_opts_apply_local_index(C.byref(m), *((GLI_K, GLI_W, GLI_WINDOW) if gli is True else gli))
         for k, v in overrides.items():
             obj = m
             *path, leaf = k.split(".")
