@@ -493,12 +493,18 @@ def main():
                                         seed.adopt_seed(ctx, ahead["ctx"])
                                 ahead["thread"] = threading.Thread(target=seed_ahead, args=(sub,))
                                 ahead["thread"].start()
-                            handed = True                                  # (a front call that fails hands over an error batch: the back call for this item returns its code)
+                            sub["_in_front"] = True                        # (set right in front of the library call: adopt_seed above raises LraError as well)
                             lanes[0]["mapper"].front(sub["rbatch"])
                             done += 1
                             continue
                         except BaseException as e:
+                            from lra_amd._lib import LraError
+                            # a front CALL that fails hands over an error batch (the back call for this item returns its code); an exception on this side of the
+                            # call (marshalling, the seed stage's adoption) has handed nothing over: the empty batch below takes the item's turn
+                            handed = isinstance(e, LraError) and sub.get("_in_front", False)
                             err.append(e)
+                        finally:
+                            sub["_in_front"] = False
                     # after an error the back thread still takes a batch per item: an empty one (no device work), so that the run ends and reports the error
                     if not handed:
                         lanes[0]["mapper"].front(seed.read_batch_from_device(ctx, torch.zeros(64, dtype=torch.uint8, device=dev), torch.zeros(1, dtype=torch.int64, device=dev)))

@@ -404,7 +404,7 @@ __device__ __forceinline__ void wave_sync_lds() {
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
 }
 __global__ void __launch_bounds__(64) local_sort_exact_wave(uint64_t stride, uint32_t* raw, int maxFreq, uint32_t* counts, const uint32_t* __restrict__ sel,
-                                                            const uint64_t* __restrict__ nSel, int cap) {
+                                                            const uint64_t* __restrict__ nSel, int cap, int minN) {
   extern __shared__ uint32_t xs_lds[];
   uint32_t* v = xs_lds;
   unsigned short* pa = (unsigned short*)(v + cap);
@@ -417,7 +417,7 @@ __global__ void __launch_bounds__(64) local_sort_exact_wave(uint64_t stride, uin
   for (uint64_t bi = blockIdx.x; bi < nS; bi += gridDim.x) {
     const uint64_t wi = sel[bi];
     const int n = (int)counts[wi];
-    if (n > cap) continue;                                                 // (cannot happen: cap covers the stride)
+    if (n > cap || n <= minN) continue;                                    // (another size class's launch: a list's LDS is its class's cap, and LDS is what limits the waves per CU)
     uint32_t* g = raw + wi * stride;
     for (int p = lane; p < n; p += 64) v[p] = g[p];
     for (int x = lane; x < cap / 32 + 1; x += 64) sbits[x] = x == 0 ? 1u : 0u;
@@ -904,11 +904,16 @@ extern "C" int lra_local_index_masked_batch(lra_ctx* ctx, int n_seqs, const char
       hipLaunchKernelGGL(local_sel, dim3((unsigned)((n_win + 255) / 256)), dim3(256), 0, st, n_win, (const uint32_t*)flag, (const uint64_t*)foff, sel);
       static const bool laneExact = getenv("LRA_LOCAL_EXACT_LANES") != nullptr;   // (the one-lane-per-list exact sort for the long lists as well: kept for comparison)
       if (stride > (uint64_t)RANK_CAP && !laneExact) {
-        const int cap = (int)((stride + 63) & ~(uint64_t)63);
-        const size_t lds = (size_t)cap * 8 + ((size_t)cap / 32 + 1) * 4 + 3 * 64 * 4;
-        if (lds > 65536) LRA_HIP_CHECK(ctx, hipFuncSetAttribute((const void*)local_sort_exact_wave, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        const int capAll = (int)((stride + 63) & ~(uint64_t)63);
         const unsigned ge = (unsigned)std::min<uint64_t>(n_win, (uint64_t)ctx->num_cu * 32);
-        hipLaunchKernelGGL(local_sort_exact_wave, dim3(ge), dim3(64), lds, st, stride, raw, max_freq, cnt, (const uint32_t*)sel, (const uint64_t*)(foff + n_win), cap);
+        int lo = 0;
+        for (int cap : {1024, capAll}) {                                   // (a 2048-base window holds ~700 tuples: the 1024 class is nearly all of them, 8.4 KB of LDS a wave)
+          cap = std::min(cap, capAll);
+          if (cap <= lo) continue;
+          const size_t lds = (size_t)cap * 8 + ((size_t)cap / 32 + 1) * 4 + 3 * 64 * 4;
+          hipLaunchKernelGGL(local_sort_exact_wave, dim3(ge), dim3(64), lds, st, stride, raw, max_freq, cnt, (const uint32_t*)sel, (const uint64_t*)(foff + n_win), cap, lo);
+          lo = cap;
+        }
       } else
         hipLaunchKernelGGL(local_sort_filter, dim3(gw), dim3(STAGE_NT), 0, st, n_win, stride, raw, max_freq, cnt, (const uint32_t*)sel, (const uint64_t*)(foff + n_win));
     }

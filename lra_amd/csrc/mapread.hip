@@ -972,9 +972,23 @@ static int front_failed(lra_ctx* ctx, lra_handover* H, int rc) {
 }
 // the back context and the two handover contexts (b -> hand[0] -> hand[1] on the child chain: destroyed with the context, timed with it); made once, by the first front call
 static int two_stage_contexts(lra_ctx* ctx, lra_handover* H) {
-  if (!ctx->child) {
-    int rc = ensure_child(ctx, false); if (rc) return rc;
-    ctx->child->pipelined = true;
+  if (!ctx->child) { int rc = ensure_child(ctx, false); if (rc) return rc; }
+  {
+    // A companion the one call's second pass made earlier (defer_matches: lowest priority, the one call's tuning) becomes the back context: the back half's priority
+    // and the choices made for device time, whoever made it.
+    lra_ctx* c = ctx->child;
+    int least = 0, greatest = 0;
+    (void)hipDeviceGetStreamPriorityRange(&least, &greatest);
+    int want = getenv("LRA_BACK_PRIORITY") ? atoi(getenv("LRA_BACK_PRIORITY")) : greatest;
+    want = std::max(greatest, std::min(least, want));
+    if (c->owns_stream && c->stream && c->prio != want && !H->hand[0]) {     // (only before the first two-stage batch: nothing of a pipeline runs on it yet)
+      LRA_HIP_CHECK(ctx, hipStreamSynchronize(c->stream));
+      hipStream_t ns = nullptr;
+      if (hipStreamCreateWithPriority(&ns, hipStreamNonBlocking, want) != hipSuccess) return lra_set_err(ctx, LRA_ERR_HIP, "companion stream");
+      (void)hipStreamDestroy(c->stream);
+      c->stream = ns; c->prio = want;
+    }
+    c->pipelined = true;
   }
   lra_ctx* tail = ctx->child;
   for (int i = 0; i < 2; i++) {

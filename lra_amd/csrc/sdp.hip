@@ -952,9 +952,7 @@ __device__ bool coop_grow_pairs(int2* pairs, uint32_t& off, int& cap, int used, 
 // Block stores, so each sees its own) with the next 64 Di / Dv / Db and
 // Ei[Db] prefetched one per lane, and the two binary searches (FindBoundary, FindValueInBlock's UPPERbound) probe six levels
 // per memory round.  Value[ii] is then the (max value, first in visit order) reduction the ordered `val < Ev` updates compute.
-template <int FAT>
-__global__ void __launch_bounds__(64, FAT ? 2 : 4) sdp_process(ProcArgs a) {
-  if (FAT) asm volatile("v_mov_b32 v250, 0" ::: "v250");   // (experiment: the same kernel holding 256 registers per lane)
+__global__ void __launch_bounds__(64, 4) sdp_process(ProcArgs a) {
   __shared__ float s_slope[25], s_inter[25];
   __shared__ short s_pen[PEN_TAB_WAVE];
   const int lane = threadIdx.x;
@@ -2229,7 +2227,7 @@ int sdp_run(lra_ctx* ctx, int n_reads, const uint64_t* d_cluster_off, const uint
         }
       }
       hipLaunchKernelGGL(k_arena_sizes, dim3((nsub + 255) / 256), dim3(256), 0, st, nsub, r0, ptOff, cntE, cntN, cntD, ra, bytes, subOrder, shift);
-      { int rc = lra_exclusive_scan<uint64_t>(ctx, nsub, bytes, byteOff); if (rc) return rc; }
+      { int rc = lra_exclusive_scan<uint64_t>(ctx, nsub, bytes, byteOff); if (rc) { (void)hipStreamSynchronize(st); return rc; } }   // (the copy out of woff may still be queued)
       uint64_t totB = 0; uint32_t bigLines = 0;
       LRA_HIP_CHECK(ctx, hipMemcpyAsync(&totB, byteOff + nsub, 8, hipMemcpyDeviceToHost, st));
       if (early) LRA_HIP_CHECK(ctx, hipMemcpyAsync(&bigLines, d_maxLines, 4, hipMemcpyDeviceToHost, st));
@@ -2284,7 +2282,7 @@ int sdp_run(lra_ctx* ctx, int n_reads, const uint64_t* d_cluster_off, const uint
       lra_time_begin(ctx, ctx->sdp_inner ? "sdp_inner_process" : "sdp_process");
       // the few large reads (a workgroup each) run beside the many small ones (a wave each) instead of in front of them
       if (nbig > 0 && !early) launch_wg(forked ? lra_side_fork(ctx) : st, maxRC);
-      if (nsub > nbig) { ProcArgs pb = pa; pb.order = subOrder + nbig; pb.n = nsub - nbig; static const int padLds = getenv("LRA_SDP_PAD_LDS") ? atoi(getenv("LRA_SDP_PAD_LDS")) : 0; static const bool fat = getenv("LRA_SDP_FAT") != nullptr; if (fat) hipLaunchKernelGGL(sdp_process<1>, dim3(nsub - nbig), dim3(64), (size_t)padLds, st, pb); else hipLaunchKernelGGL(sdp_process<0>, dim3(nsub - nbig), dim3(64), (size_t)padLds, st, pb); }
+      if (nsub > nbig) { ProcArgs pb = pa; pb.order = subOrder + nbig; pb.n = nsub - nbig; hipLaunchKernelGGL(sdp_process, dim3(nsub - nbig), dim3(64), 0, st, pb); }
       if (forked) lra_side_join(ctx);
       lra_time_end(ctx);
       if (dbg) {

@@ -18,19 +18,25 @@ namespace {
 
 constexpr int SEG_LO = 256, SEG_HI = 8192;     // a workgroup sorts segments of SEG_LO < n <= SEG_HI pairs
 
-__global__ void k_mask_offsets(unsigned nseg, const uint64_t* __restrict__ b, const uint64_t* __restrict__ e, uint64_t* mb, uint64_t* me) {
+// (also counts the segments of every size class -- (256, 1024], (1024, 2048], (2048, 4096], (4096, 8192] -- so that a class's launch with nothing to sort ends at once)
+__global__ void k_mask_offsets(unsigned nseg, const uint64_t* __restrict__ b, const uint64_t* __restrict__ e, uint64_t* mb, uint64_t* me, unsigned* classCnt) {
   const unsigned s = blockIdx.x * blockDim.x + threadIdx.x;
-  if (s >= nseg) return;
-  const uint64_t x = b[s], y = e[s], n = y > x ? y - x : 0;
-  const bool mine = n > (uint64_t)SEG_LO && n <= (uint64_t)SEG_HI;
-  mb[s] = x; me[s] = mine ? x : y;
+  int cls = -1;
+  if (s < nseg) {
+    const uint64_t x = b[s], y = e[s], n = y > x ? y - x : 0;
+    const bool mine = n > (uint64_t)SEG_LO && n <= (uint64_t)SEG_HI;
+    mb[s] = x; me[s] = mine ? x : y;
+    if (mine) cls = n <= 1024 ? 0 : n <= 2048 ? 1 : n <= 4096 ? 2 : 3;
+  }
+  for (int c = 0; c < 4; c++) { const unsigned long long m = __ballot(cls == c); if (m && (threadIdx.x & 63) == 0) atomicAdd(&classCnt[c], (unsigned)__popcll(m)); }
 }
 
 template <int NT, int IPT>
 __global__ void __launch_bounds__(NT) k_block_sort(unsigned nseg, const uint64_t* __restrict__ b, const uint64_t* __restrict__ e, const uint64_t* __restrict__ kin, uint64_t* kout,
-                                                   const uint32_t* __restrict__ vin, uint32_t* vout, int begin_bit, int end_bit, int minLen) {
+                                                   const uint32_t* __restrict__ vin, uint32_t* vout, int begin_bit, int end_bit, int minLen, const unsigned* __restrict__ classCnt) {
   typedef hipcub::BlockRadixSort<uint64_t, NT, IPT, uint32_t> Sort;
   __shared__ typename Sort::TempStorage tmp;
+  if (*classCnt == 0) return;                                              // (no segment of this size class in the call)
   for (unsigned s = blockIdx.x; s < nseg; s += gridDim.x) {
     const uint64_t x = b[s], y = e[s];
     const int n = y > x ? (int)std::min<uint64_t>(y - x, (uint64_t)SEG_HI + 1) : 0;
@@ -47,7 +53,9 @@ __global__ void __launch_bounds__(NT) k_block_sort(unsigned nseg, const uint64_t
 
 }  // namespace
 
-// The interface of rocprim::segmented_radix_sort_pairs (temp == nullptr: temp_bytes is set to what the call needs).
+// The interface of rocprim::segmented_radix_sort_pairs (temp == nullptr: temp_bytes is set to what the call needs).  As there, the segments must not overlap (each
+// workgroup reads its segment whole, then writes it: an overlapping neighbour would read half-written pairs when kin == kout is ever allowed; the entry point below
+// rejects in-place calls).
 hipError_t lra_segsort_pairs(lra_ctx* ctx, void* temp, size_t& temp_bytes, const uint64_t* kin, uint64_t* kout, const uint32_t* vin, uint32_t* vout, unsigned int total,
                              unsigned int nseg, const uint64_t* b, const uint64_t* e, int begin_bit, int end_bit, hipStream_t st) {
   static const bool off = getenv("LRA_SEGSORT") && getenv("LRA_SEGSORT")[0] == '0';
@@ -55,18 +63,20 @@ hipError_t lra_segsort_pairs(lra_ctx* ctx, void* temp, size_t& temp_bytes, const
   hipError_t rc = rocprim::segmented_radix_sort_pairs(nullptr, rb, (uint64_t*)nullptr, (uint64_t*)nullptr, (uint32_t*)nullptr, (uint32_t*)nullptr, total, nseg, (uint64_t*)nullptr,
                                                       (uint64_t*)nullptr, begin_bit, end_bit, st);
   if (rc != hipSuccess) return rc;
-  const size_t rbA = (rb + 255) & ~(size_t)255, extra = 2 * ((size_t)nseg + 1) * 8 + 256;
+  const size_t rbA = (rb + 255) & ~(size_t)255, extra = 2 * ((size_t)nseg + 1) * 8 + 256 + 64;
   if (!temp) { temp_bytes = rbA + extra; return hipSuccess; }
   if (temp_bytes < rbA + extra) return hipErrorInvalidValue;
   if (off || nseg == 0 || total == 0)
     return rocprim::segmented_radix_sort_pairs(temp, rb, kin, kout, vin, vout, total, nseg, b, e, begin_bit, end_bit, st);
   uint64_t* mb = (uint64_t*)((char*)temp + rbA); uint64_t* me = mb + nseg + 1;
-  hipLaunchKernelGGL(k_mask_offsets, dim3((nseg + 255) / 256), dim3(256), 0, st, nseg, b, e, mb, me);
+  unsigned* cc = (unsigned*)(me + nseg + 1);
+  if (hipMemsetAsync(cc, 0, 16, st) != hipSuccess) return hipErrorUnknown;
+  hipLaunchKernelGGL(k_mask_offsets, dim3((nseg + 255) / 256), dim3(256), 0, st, nseg, b, e, mb, me, cc);
   const unsigned cu = (unsigned)ctx->num_cu;
-  hipLaunchKernelGGL((k_block_sort<256, 4>), dim3(std::min(nseg, cu * 8)), dim3(256), 0, st, nseg, b, e, kin, kout, vin, vout, begin_bit, end_bit, SEG_LO);
-  hipLaunchKernelGGL((k_block_sort<256, 8>), dim3(std::min(nseg, cu * 6)), dim3(256), 0, st, nseg, b, e, kin, kout, vin, vout, begin_bit, end_bit, 1024);
-  hipLaunchKernelGGL((k_block_sort<512, 8>), dim3(std::min(nseg, cu * 3)), dim3(512), 0, st, nseg, b, e, kin, kout, vin, vout, begin_bit, end_bit, 2048);
-  hipLaunchKernelGGL((k_block_sort<1024, 8>), dim3(std::min(nseg, cu)), dim3(1024), 0, st, nseg, b, e, kin, kout, vin, vout, begin_bit, end_bit, 4096);
+  hipLaunchKernelGGL((k_block_sort<256, 4>), dim3(std::min(nseg, cu * 8)), dim3(256), 0, st, nseg, b, e, kin, kout, vin, vout, begin_bit, end_bit, SEG_LO, (const unsigned*)(cc + 0));
+  hipLaunchKernelGGL((k_block_sort<256, 8>), dim3(std::min(nseg, cu * 6)), dim3(256), 0, st, nseg, b, e, kin, kout, vin, vout, begin_bit, end_bit, 1024, (const unsigned*)(cc + 1));
+  hipLaunchKernelGGL((k_block_sort<512, 8>), dim3(std::min(nseg, cu * 3)), dim3(512), 0, st, nseg, b, e, kin, kout, vin, vout, begin_bit, end_bit, 2048, (const unsigned*)(cc + 2));
+  hipLaunchKernelGGL((k_block_sort<1024, 8>), dim3(std::min(nseg, cu)), dim3(1024), 0, st, nseg, b, e, kin, kout, vin, vout, begin_bit, end_bit, 4096, (const unsigned*)(cc + 3));
   return rocprim::segmented_radix_sort_pairs(temp, rb, kin, kout, vin, vout, total, nseg, (const uint64_t*)mb, (const uint64_t*)me, begin_bit, end_bit, st);
 }
 

@@ -24,6 +24,8 @@ def main():
     ap.add_argument("--genome-scale", type=float, default=0.0)
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--gli", type=int, default=1, help="1: the local index as `lra index` writes it (k = 10, w = 5, windows of 2048 bases: what glIndex.Read hands `lra align`); "
+                                                       "0: `lra align` without a .gli file (opts.localK, windows of 256 bases)")
     ap.add_argument("--two-stage", type=int, default=0, help="-CLR only: two-stage batches (lra_map_reads_lowacc_front / _back), as bench.py runs the headline step")
     args = ap.parse_args()
     import torch
@@ -40,10 +42,10 @@ def main():
     torch.cuda.synchronize()
     ctx = Context(0)
     if args.preset == "clr":
-        mopts = mapread.clr_options()
+        mopts = mapread.with_gli(mapread.clr_options()) if args.gli else mapread.clr_options()
         mapper = mapread.LowAccMapper(ctx, genome, None, None, chrom_names, chrom_pos, mopts, index_params=(15, 10, 250, 12, 1), staged=False)
     else:
-        mapper = mapread.HighAccMapper(ctx, genome, None, None, chrom_names, chrom_pos, args.preset)
+        mapper = mapread.HighAccMapper(ctx, genome, None, None, chrom_names, chrom_pos, args.preset, gli=bool(args.gli) or None)
     torch.cuda.synchronize()
     setup_s = time.time() - t0
     sim = sg.simulate_reads_sv(genome, chrom_pos, n_reads, read_len, read_len / 10, P["err"], P["mix"], 1000, sv_frac=0.05)
@@ -130,7 +132,8 @@ def main():
         "value": total * args.steps / dt / 1e9, "unit": "Gbp/s", "n_gpus": 1, "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
         "reads_per_s": n_reads * args.steps / dt, "higher_is_better": True, "data": "synthetic", "dtype": "int32",
         "config": {"workload": "BASELINE configs[%d]" % {"ccs": 1, "clr": 3, "contig": 4}[args.preset], "reads": n_reads, "mean_read_len": read_len, "error": P["err"],
-                   "reference_bp": int(chrom_pos[-1]), "index_entries": int(mapper.index_stats.get("n_index", 0))},
+                   "reference_bp": int(chrom_pos[-1]), "index_entries": int(mapper.index_stats.get("n_index", 0)),
+                   "local_index": "k 10, w 5, windows of 2048 bases (the .gli file `lra index` writes)" if args.gli else "the options' localK, windows of 256 bases (`lra align` without a .gli file)"},
         "reads_with_an_alignment": aligned, "reads_flagged": flagged, "n_alignments": int(res.n_alignments), "sam_text_mb": text[0] / 1e6,
         "result_sha256": hh.hexdigest(), "two_stage": two_stage, "setup_s": round(setup_s, 1), "hbm_used_gb": round((tot_b - free_b) / 1e9, 1)}))
 
