@@ -103,7 +103,9 @@ def main():
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--genome-scale", type=float, default=float(os.environ.get("LRA_BENCH_GENOME_SCALE", 1.0)), help="1.0 = GRCh38-sized (3.09 Gb)")
-    ap.add_argument("--reads", type=int, default=int(os.environ.get("LRA_BENCH_READS", 32768)), help="reads per GPU per step")
+    ap.add_argument("--reads", type=int, default=int(os.environ.get("LRA_BENCH_READS", 28672)),
+                    help="reads per GPU per step (a batch: the pipeline's granularity, not the job's size).  28672: the largest batch beside which the seed stage of the front half "
+                         "after next still has the memory for a context of its own at the .gli parameters (282 GB in use; 32768 reads: 286 GB without it, 4.6 %% slower per read)")
     ap.add_argument("--read-len", type=int, default=30000)
     ap.add_argument("--err", type=float, default=0.10)
     ap.add_argument("--sv-frac", type=float, default=0.05, help="fraction of reads carrying one planted structural variant")

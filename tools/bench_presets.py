@@ -34,7 +34,7 @@ def main():
     dev = torch.device("cuda", 0)
     torch.cuda.set_device(0)
     P = {"ccs": dict(reads=50000, read_len=15000, err=0.01, scale=64.4e6 / 3.09e9, mix=(34, 33, 33)),
-         "clr": dict(reads=32768, read_len=20000, err=0.15, scale=1.0, mix=(20, 30, 50)),
+         "clr": dict(reads=28672, read_len=20000, err=0.15, scale=1.0, mix=(20, 30, 50)),
          "contig": dict(reads=1024, read_len=1000000, err=0.002, scale=1.0, mix=(34, 33, 33))}[args.preset]
     n_reads = args.reads or P["reads"]; read_len = args.read_len or P["read_len"]; scale = args.genome_scale or P["scale"]
     t0 = time.time()
