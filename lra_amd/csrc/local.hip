@@ -815,6 +815,120 @@ __global__ void __launch_bounds__(256) local_compact_rows(CmpArgs A, const uint3
   for (uint32_t p = l; p < n; p += 64) { const uint32_t v = rw[p]; A.out_qi[o + p] = ql + (v >> 16); A.out_ti[o + p] = tl + (v & 0xFFFFu); }
 }
 
+
+// ---- CompareLists of large tasks, a lane per task with the four cursors' lines kept in LDS.  The walk reads its lists at four places that only move one way (qs up, qe
+// down, ts up, te down); read where they lie, each read is a round trip to L2 / HBM for one word of a line that is gone before the cursor needs the next one.  Here a lane
+// owns two lines of CL words per cursor in LDS (word-interleaved over the wave's lanes: bank = lane): an access is an LDS read, a cursor that crosses a line boundary
+// fetches the next line whole (two 16-byte loads), so every word of a list is fetched about once.  Probes of a search that land far from where the walk stands read the
+// list directly.
+constexpr int CL = 8;
+struct Cursor {
+  const uint32_t* arr; uint64_t off; uint32_t* row; int tag0, tag1;
+  __device__ __forceinline__ void init(const uint32_t* a, uint64_t o, uint32_t* r) { arr = a; off = o; row = r; tag0 = -1; tag1 = -1; }
+  __device__ __forceinline__ uint32_t get(int i) {
+    const uint64_t g = off + (uint64_t)(uint32_t)i;
+    const int line = (int)(g >> 3), sl = line & 1;
+    if ((sl ? tag1 : tag0) != line) {                                      // (fetching the line the cursor comes to next in the same round trip was measured: slower, 30.9 -> 34.6 ms)
+      const uint4* src = (const uint4*)(arr + ((uint64_t)(uint32_t)line << 3));
+      const uint4 a = src[0], b = src[1];
+      uint32_t* d = row + sl * CL * 64;
+      d[0] = a.x; d[64] = a.y; d[128] = a.z; d[192] = a.w; d[256] = b.x; d[320] = b.y; d[384] = b.z; d[448] = b.w;
+      if (sl) tag1 = line; else tag0 = line;
+    }
+    return row[(sl * CL + (int)(g & 7)) * 64];
+  }
+  __device__ __forceinline__ uint32_t direct(int i) const { return arr[off + (uint64_t)(uint32_t)i]; }
+};
+template <int MODE>
+__global__ void __launch_bounds__(64) local_compare_cached(CmpArgs A, uint32_t* __restrict__ rows, const uint32_t* __restrict__ overList, int nOverList) {
+  __shared__ uint32_t lines[4 * 2 * CL * 64];
+  const int lane = threadIdx.x;
+  // MODE 1: the tasks whose pairs outgrew their row, 64 of them to a wave (taken from a list: a wave of the first pass's order would walk for its one or two such tasks)
+  const uint64_t x0 = (uint64_t)blockIdx.x * 64 + lane;
+  if (MODE == 1 ? x0 >= (uint64_t)nOverList : x0 >= A.n_tasks) return;
+  const uint64_t x = MODE == 1 ? (uint64_t)overList[x0] : x0;
+  const uint64_t myQa = A.q_lo[x], myTa = A.t_lo[x];
+  const int nq = (int)(A.q_hi[x] - myQa), nt = (int)(A.t_hi[x] - myTa);
+  Cursor QF, QB, TF, TB;
+  QF.init(A.q, myQa, lines + 0 * 2 * CL * 64 + lane); QB.init(A.q, myQa, lines + 1 * 2 * CL * 64 + lane);
+  TF.init(A.t, myTa, lines + 2 * 2 * CL * 64 + lane); TB.init(A.t, myTa, lines + 3 * 2 * CL * 64 + lane);
+  const int64_t maxDiag = A.maxDiag ? A.maxDiag[x] : 0, minDiag = A.minDiag ? A.minDiag[x] : 0;
+  const bool banded = maxDiag != 0 && minDiag != 0;
+  const int maxFreq = (int)A.maxFreq;
+  uint32_t* oq = MODE == 1 ? A.out_qi + A.out_off[x] : nullptr; uint32_t* ot = MODE == 1 ? A.out_ti + A.out_off[x] : nullptr;
+  uint32_t* row = MODE == 2 ? rows + x * (uint64_t)CW_ROW : nullptr;
+  const uint32_t qb = (uint32_t)myQa, tb = (uint32_t)myTa;
+  uint32_t n = 0;
+  auto put = [&](int qi, int ti) {
+    if (MODE == 1) { oq[n] = qb + (uint32_t)qi; ot[n] = tb + (uint32_t)ti; }
+    else if (n < (uint32_t)CW_ROW) row[n] = ((uint32_t)qi << 16) | (uint32_t)ti;
+    n++;
+  };
+  if (nq != 0 && nt != 0) {
+    int qs = 0, qe = nq - 1, ts = 0, te = nt;
+    do {
+      { const uint32_t k0 = T_(TF.get(ts)); while (qs <= qe && T_(QF.get(qs)) < k0) qs++; }
+      if (qs >= qe) break;
+      const uint32_t kq = T_(QF.get(qs));
+      const uint32_t startGap = (kq - T_(TF.get(ts))) & TMASK;
+      { const uint32_t k1 = T_(TB.get(te - 1)); while (qe > qs && te > ts && T_(QB.get(qe)) > k1) qe--; }
+      const uint32_t ke = T_(QB.get(qe));
+      const uint32_t endGap = (T_(TB.get(te - 1)) - ke) & TMASK;
+      if (startGap == 0 || startGap > endGap) {
+        const int tsOrig = ts;
+        auto tf = [&](int p) -> uint32_t { return T_((unsigned)(p - tsOrig) < 12u ? TF.get(p) : TF.direct(p)); };
+        int lo = ts, hi = te;
+        for (int s_ = 1; lo < hi; s_ <<= 1) { const int p = lo + s_ - 1; if (p >= hi) break; if (tf(p) < kq) lo = p + 1; else { hi = p; break; } }
+        while (lo < hi) { const int mid = lo + (hi - lo) / 2; if (tf(mid) < kq) lo = mid + 1; else hi = mid; }
+        ts = lo;
+        if (ts < te && tf(ts) == kq) {
+          int tsi = ts;
+          while (tsi != te && kq == tf(tsi)) tsi++;
+          const int qsStart = qs;
+          while (qs < qe && T_(QF.get(qs + 1)) == kq) qs++;
+          if (qs - qsStart < maxFreq)
+            for (int ti = ts; ti != tsi; ti++) {
+              const int64_t tp = banded ? (int64_t)P_((unsigned)(ti - tsOrig) < 12u ? TF.get(ti) : TF.direct(ti)) : 0;
+              for (int qi = qsStart; qi <= qs; qi++) {
+                if (banded) { const int64_t d = tp - (int64_t)P_(QF.get(qi)); if (!(d <= maxDiag && d >= minDiag)) continue; }
+                put(qi, ti);
+              }
+            }
+        }
+        { const uint32_t raw = T_(TF.get(tsOrig)); while (ts < te && tf(ts) == raw) ts++; }
+        while (qs < qe && T_(QF.get(qs)) == kq) qs++;
+      } else {
+        const int teOrig = te;
+        auto tbk = [&](int p) -> uint32_t { return T_((unsigned)(teOrig - 1 - p) < 12u ? TB.get(p) : TB.direct(p)); };
+        if (te != nt && tbk(te - 1) == ke) {
+        } else {
+          int lo = ts, hi = te;
+          for (int s_ = 1; lo < hi; s_ <<= 1) { const int p = hi - s_; if (p < lo) break; if (!(ke < tbk(p))) { lo = p + 1; break; } else hi = p; }
+          while (lo < hi) { const int mid = lo + (hi - lo) / 2; if (!(ke < tbk(mid))) lo = mid + 1; else hi = mid; }
+          te = lo;
+        }
+        const int teStart = te;
+        int tei = te;
+        while (tei > ts && tbk(tei - 1) == ke) tei--;
+        if (tei < teStart && teStart > 0) {
+          const int qeStart = qe;
+          while (qe > qs && T_(QB.get(qe - 1)) == ke) qe--;
+          if (qeStart - qe < maxFreq)
+            for (int ti = tei; ti < teStart; ti++) {
+              const int64_t tp = banded ? (int64_t)P_((unsigned)(teOrig - 1 - ti) < 12u ? TB.get(ti) : TB.direct(ti)) : 0;
+              for (int qi = qe; qi <= qeStart; qi++) {
+                if (banded) { const int64_t d = tp - (int64_t)P_(QB.get(qi)); if (!(d <= maxDiag && d >= minDiag)) continue; }
+                put(qi, ti);
+              }
+            }
+        }
+        te = tei;
+      }
+    } while (qs < qe && ts < te);
+  }
+  if (MODE != 1) { A.counts[x] = n; if (n > (uint32_t)CW_ROW) { const int at = atomicAdd(A.nOver, 1); if (overList && at < nOverList) ((uint32_t*)overList)[at] = (uint32_t)x; } }
+}
+
 // the tasks whose two lists are beyond a staged row (the batch's form of the walk is chosen by their share)
 __global__ void k_big_tasks(CmpArgs A, unsigned long long* nBig) {
   const uint64_t x = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -974,15 +1088,19 @@ extern "C" int lra_local_compare_batch(lra_ctx* ctx, uint64_t n_tasks, const uin
   const bool waveBig = big && waveForm;
   A.capped = (twoPass || big) ? nullptr : (uint16_t*)lra_ensure(ctx, 95, (size_t)n_tasks * CMP_CAP * 2 + 256);
   if (!twoPass && !big && !A.capped) return LRA_ERR_NOMEM;
-  uint32_t* rows = big ? (uint32_t*)lra_ensure(ctx, 95, (size_t)n_tasks * CW_ROW * 4 + 256) : nullptr;
+  constexpr int OVER_CAP = 1 << 20;
+  uint32_t* rows = big ? (uint32_t*)lra_ensure(ctx, 95, (size_t)n_tasks * CW_ROW * 4 + (size_t)OVER_CAP * 4 + 512) : nullptr;
   if (big && !rows) return LRA_ERR_NOMEM;
+  uint32_t* overList = big ? rows + (((size_t)n_tasks * CW_ROW + 63) & ~(size_t)63) : nullptr;
   const unsigned gW = (unsigned)std::min<uint64_t>((n_tasks + CW_TPB - 1) / CW_TPB, (uint64_t)ctx->num_cu * 24);
   // The lane-per-task walk of large tasks has four cursors a lane, a cache line each: with every wave slot of a CU taken (2048 walks) a line is fetched for one word and is
   // gone before the cursor needs its next word -- the launch moves 40 x its lists.  Dynamic LDS nobody uses keeps it to two blocks (8 waves, 512 walks) per CU, whose lines
   // stay in the CU's share of L2: 77.9 ms per batch -> 47.6 (four blocks: 55.8; one: 61.5).
+  static const bool cachedBig = !(getenv("LRA_LOCAL_BIG_CACHED") && getenv("LRA_LOCAL_BIG_CACHED")[0] == '0');   // (0: the lists read where they lie)
   static const size_t bigPad = getenv("LRA_LOCAL_BIG_PAD") ? (size_t)atol(getenv("LRA_LOCAL_BIG_PAD")) : 64000;
   lra_time_begin(ctx, "local_compare");
   if (waveBig) hipLaunchKernelGGL(local_compare_wave<2>, dim3(gW), dim3(64), 0, st, A, rows);
+  else if (big && cachedBig) hipLaunchKernelGGL(local_compare_cached<2>, dim3((unsigned)((n_tasks + 63) / 64)), dim3(64), 0, st, A, rows, (const uint32_t*)overList, OVER_CAP);
   else if (big) {
     if (bigPad > 65536) LRA_HIP_CHECK(ctx, hipFuncSetAttribute((const void*)local_compare<2, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bigPad));
     hipLaunchKernelGGL((local_compare<2, true>), dim3(gB), dim3(STAGE_NT), bigPad, st, A, rows);
@@ -1009,7 +1127,9 @@ extern "C" int lra_local_compare_batch(lra_ctx* ctx, uint64_t n_tasks, const uin
     if (h_over > 0) hipLaunchKernelGGL(local_compare_wave<1>, dim3(gW), dim3(64), 0, st, A, rows);
   } else if (big) {
     hipLaunchKernelGGL(local_compact_rows, dim3((unsigned)((n_tasks + 3) / 4)), dim3(256), 0, st, A, (const uint32_t*)rows);
-    if (h_over > 0) hipLaunchKernelGGL((local_compare<1, true>), dim3(gB), dim3(STAGE_NT), std::min<size_t>(bigPad, 65536), st, A, rows);
+    if (h_over > 0 && cachedBig && h_over <= OVER_CAP) hipLaunchKernelGGL(local_compare_cached<1>, dim3((unsigned)((h_over + 63) / 64)), dim3(64), 0, st, A, rows, (const uint32_t*)overList, h_over);
+    else if (h_over > 0 && cachedBig) { hipLaunchKernelGGL((local_compare<1, true>), dim3(gB), dim3(STAGE_NT), std::min<size_t>(bigPad, 65536), st, A, rows); }   // (more such tasks than the list holds: every task looked at)
+    else if (h_over > 0) hipLaunchKernelGGL((local_compare<1, true>), dim3(gB), dim3(STAGE_NT), std::min<size_t>(bigPad, 65536), st, A, rows);
   }
   else if (twoPass || h_over > 0) hipLaunchKernelGGL(local_compare<1>, dim3(g), dim3(STAGE_NT), 0, st, A);
   else hipLaunchKernelGGL(local_compact_pairs, dim3((unsigned)((n_tasks + 3) / 4)), dim3(64), 0, st, A);
