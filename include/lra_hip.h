@@ -69,7 +69,7 @@ int lra_ctx_set_stream(lra_ctx* ctx, void* stream);
 const char* lra_ctx_last_error(lra_ctx* ctx);
 /* ABI version of the loaded library (tests check it against this header). */
 int lra_abi_version(void);
-#define LRA_ABI_VERSION 8   /* 8: lra_map_opts_apply_local_index, lra_ctx_local_index_params (the .gli file's k / w / window override the options', as glIndex.Read does); 7: lra_sort_pairs_batch;  2: lra_map_opts.defer_matches, lra_map_counters.n_deferred_reads; 3: lra_map_opts.flagged_unaligned, lra_map_counters.n_flagged_reads, lra_map_host_flagged; 4: lra_reads_last_error, a corrupt FASTQ record is LRA_ERR_INVALID; lra_map_opts.defer_seed_matches; 5: lra_seed_prefetch, lra_ctx_adopt_seed, lra_map_reads_lowacc_front / _back, lra_map_back_release; 6: a failed front half hands over an error batch (one back call per front call), separate n_handed_back_reads counter, lra_map_host_trim */
+#define LRA_ABI_VERSION 8   /* 8: lra_map_opts_apply_local_index, lra_ctx_local_index_params, lra_ctx_load_local_index (the .gli file's k / w / window override the options', as glIndex.Read does); 7: lra_sort_pairs_batch;  2: lra_map_opts.defer_matches, lra_map_counters.n_deferred_reads; 3: lra_map_opts.flagged_unaligned, lra_map_counters.n_flagged_reads, lra_map_host_flagged; 4: lra_reads_last_error, a corrupt FASTQ record is LRA_ERR_INVALID; lra_map_opts.defer_seed_matches; 5: lra_seed_prefetch, lra_ctx_adopt_seed, lra_map_reads_lowacc_front / _back, lra_map_back_release; 6: a failed front half hands over an error batch (one back call per front call), separate n_handed_back_reads counter, lra_map_host_trim */
 
 /* Convenience for hosts without their own HIP binding: synchronous device->host copy on the
  * context's stream (a C++ host would call hipMemcpy itself).                                */
@@ -1018,6 +1018,11 @@ int lra_ctx_build_local_index(lra_ctx* ctx, int k, int w, int window, int max_fr
  * below hold.  lra_map_opts_apply_local_index writes an index's three values into the options (localK, localW, localIndexWindow); lra_ctx_local_index_params returns the
  * ones the context's index was built with.  The drivers refuse options that differ from the context's index (LRA_ERR_INVALID).                                        */
 void lra_map_opts_apply_local_index(lra_map_opts* opts, int k, int w, int window);
+/* glIndex as LocalIndex::Read left it (MMIndex.h:154-173, lra.cpp:627): the .gli payload handed over as it is (host arrays, copied) instead of lra_ctx_build_local_index --
+ * glIndex.k / w / localIndexWindow, seqOffsets[n_windows + 1], tupleBoundaries[n_windows + 1], minimizers[n_tuples].  The seqOffsets must be those IndexSeq writes for the
+ * loaded chromosome table at this window (an index of another genome is LRA_ERR_INVALID).                                                                            */
+int lra_ctx_load_local_index(lra_ctx* ctx, int k, int w, int window, uint64_t n_windows, const uint64_t* h_seq_offsets, const uint64_t* h_tuple_bnd,
+                             uint64_t n_tuples, const uint32_t* h_tuples);
 int lra_ctx_local_index_params(lra_ctx* ctx, int* k, int* w, int* window);
 /* The context's reference data as device pointers: the genome bytes; the genome's local index (the .gli payload: d_tuple_bnd[n_windows + 1],
  * d_tuples[n_tuples]) and its seqOffsets[n_windows + 1].  Valid until the context is destroyed or the data is loaded / built again.        */

@@ -109,6 +109,7 @@ SYMBOLS = {
     "lra_ctx_build_local_index": (C.c_int, [_vp, C.c_int, C.c_int, C.c_int, C.c_int]),
     "lra_map_opts_apply_local_index": (None, [_vp, C.c_int, C.c_int, C.c_int]),
     "lra_ctx_local_index_params": (C.c_int, [_vp, _vp, _vp, _vp]),
+    "lra_ctx_load_local_index": (C.c_int, [_vp, C.c_int, C.c_int, C.c_int, C.c_uint64, _vp, _vp, C.c_uint64, _vp]),
     "lra_map_reads_lowacc_batch": (C.c_int, [_vp, C.c_int, _vp, _vp, C.c_uint64, _vp, _vp]),
     "lra_map_reads_highacc_batch": (C.c_int, [_vp, C.c_int, _vp, _vp, C.c_uint64, _vp, _vp]),
     "lra_ctx_genome_ptr": (_vp, [_vp]),

@@ -340,6 +340,50 @@ extern "C" int lra_ctx_build_local_index(lra_ctx* ctx, int k, int w, int window,
   return LRA_OK;
 }
 
+// glIndex as LocalIndex::Read left it (MMIndex.h:154-173): the .gli file's payload handed over as it is, instead of building the index again on the device.  The three
+// arrays are copied; seq_offsets must be what IndexSeq writes for the loaded chromosome table and this window (MMIndex.h:200-245: window ends, restarting at every
+// sequence) -- an index of another genome is refused.
+extern "C" int lra_ctx_load_local_index(lra_ctx* ctx, int k, int w, int window, uint64_t n_windows, const uint64_t* h_seq_offsets, const uint64_t* h_tuple_bnd,
+                                        uint64_t n_tuples, const uint32_t* h_tuples) {
+  if (!ctx || !ctx->map || ctx->map->chrom_pos.size() < 2) return ctx ? lra_set_err(ctx, LRA_ERR_INVALID, "load the chromosome table first") : LRA_ERR_INVALID;
+  if (!h_seq_offsets || !h_tuple_bnd || (n_tuples && !h_tuples)) return LRA_ERR_INVALID;
+  if (k < 1 || k > 10 || w < 1 || w > 16 || window < w + k || window > 4096) return lra_set_err(ctx, LRA_ERR_INVALID, "need 1<=k<=10 (20-bit LocalTuple), 1<=w<=16, w+k<=window<=4096");
+  LRA_HIP_CHECK(ctx, hipSetDevice(ctx->device));
+  lra_map_state* m = ctx->map;
+  if (m->borrowed) return lra_set_err(ctx, LRA_ERR_INVALID, "this context shares another context's reference data: load its own chromosome table first");
+  const int n_chrom = (int)m->chrom_pos.size() - 1;
+  std::vector<uint64_t> gso; gso.push_back(0);
+  std::vector<uint64_t> win_off((size_t)n_chrom + 1, 0);
+  for (int c = 0; c < n_chrom; c++) {
+    for (uint64_t p_ = m->chrom_pos[c]; p_ < m->chrom_pos[c + 1];) { p_ = std::min<uint64_t>(p_ + (uint64_t)window, m->chrom_pos[c + 1]); gso.push_back(p_); }
+    win_off[c + 1] = gso.size() - 1;
+  }
+  if (gso.size() != n_windows + 1 || memcmp(gso.data(), h_seq_offsets, gso.size() * 8) != 0)
+    return lra_set_err(ctx, LRA_ERR_INVALID, "the local index's seqOffsets are not those of the loaded chromosome table at windows of %d bases", window);
+  if (h_tuple_bnd[0] != 0 || h_tuple_bnd[n_windows] != n_tuples) return lra_set_err(ctx, LRA_ERR_INVALID, "tupleBoundaries do not cover the tuples");
+  for (uint64_t i = 0; i < n_windows; i++) if (h_tuple_bnd[i + 1] < h_tuple_bnd[i]) return lra_set_err(ctx, LRA_ERR_INVALID, "tupleBoundaries decrease");
+  m->cell->gen++;
+  auto sz = [](size_t n, size_t e) { return (n * e + 255) & ~(size_t)255; };
+  const size_t NW = (size_t)n_windows + 2;
+  const size_t need = sz((size_t)n_chrom + 1, 8) + sz(NW, 8) + sz((size_t)n_tuples + 1, 4);
+  if (m->gli_buf) { (void)hipFree(m->gli_buf); m->gli_buf = nullptr; }
+  LRA_HIP_CHECK(ctx, hipMalloc(&m->gli_buf, need + 256));
+  char* nb = (char*)m->gli_buf;
+  uint64_t* o_win = (uint64_t*)nb; uint64_t* o_bnd = (uint64_t*)(nb + sz((size_t)n_chrom + 1, 8)); uint32_t* o_tup = (uint32_t*)((char*)o_bnd + sz(NW, 8));
+  LRA_HIP_CHECK(ctx, hipMemcpy(o_win, win_off.data(), ((size_t)n_chrom + 1) * 8, hipMemcpyHostToDevice));
+  LRA_HIP_CHECK(ctx, hipMemcpy(o_bnd, h_tuple_bnd, ((size_t)n_windows + 1) * 8, hipMemcpyHostToDevice));
+  if (n_tuples) LRA_HIP_CHECK(ctx, hipMemcpy(o_tup, h_tuples, (size_t)n_tuples * 4, hipMemcpyHostToDevice));
+  m->gli = lra_local_index_result{};
+  m->gli.n_seqs = n_chrom; m->gli.n_windows = n_windows; m->gli.n_tuples = n_tuples; m->gli.bytes = need;
+  m->gli.d_base = nb; m->gli.d_win_off = o_win; m->gli.d_tuple_bnd = o_bnd; m->gli.d_tuples = o_tup;
+  m->gli_window = window; m->gli_k = k; m->gli_w = w;
+  if (m->d_gso) (void)hipFree(m->d_gso);
+  LRA_HIP_CHECK(ctx, hipMalloc((void**)&m->d_gso, gso.size() * 8));
+  LRA_HIP_CHECK(ctx, hipMemcpy(m->d_gso, gso.data(), gso.size() * 8, hipMemcpyHostToDevice));
+  m->n_gwin = n_windows;
+  return LRA_OK;
+}
+
 // Several contexts on one GPU (sub-batches on their own HIP streams, so that the serial tails of one sub-batch's kernels overlap the other's work)
 // share ONE replica of the reference: dst borrows src's genome, global index + directory, chromosome table and local index.  src must outlive dst.
 int lra_seed_share(lra_ctx* dst, lra_ctx* src);   // seed.hip

@@ -643,6 +643,9 @@ static int highacc_batch_impl(lra_ctx* ctx, int n_reads, const char* d_seq, cons
   if (!m || m->chrom_pos.size() < 2 || !ctx->seed || !ctx->seed->genome || !ctx->seed->idx_key)
     return lra_set_err(ctx, LRA_ERR_INVALID, "reference not loaded (genome, global index, chromosome table)");
   if (o->bypassClustering) return lra_set_err(ctx, LRA_ERR_INVALID, "lra_map_reads_highacc_batch is the path of opts.bypassClustering == 0 (-CCS, -CONTIG)");
+  if (m->gli_buf && (m->gli_window != o->localIndexWindow || m->gli_k != o->localK || m->gli_w != o->localW))    // (whether or not a read of this batch takes the branch that reads glIndex)
+    return lra_set_err(ctx, LRA_ERR_INVALID, "the genome's local index has k = %d, w = %d, windows of %d bases; the options say %d, %d, %d (lra_map_opts_apply_local_index: glIndex.Read overrides them)",
+                       m->gli_k, m->gli_w, m->gli_window, o->localK, o->localW, o->localIndexWindow);
   { int rcs = lra_map_check_shared(ctx); if (rcs) return rcs; }
   out->n_reads = n_reads;
   m->last_text.clear(); m->last_sig = lra_map_sig{};

@@ -155,3 +155,55 @@ def test_hip_index_feeds_the_path(ctx, oracle):
         qi, ti = O.compare_lists(sk, sp, ek, ep, 150)
         n_tot += len(qi)
     assert int(sres.n_matches) == n_tot and n_tot > 100
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("preset", ["ont", "ccs"])
+def test_local_index_from_a_gli_file(ctx, oracle, tmp_path, preset):
+    """glIndex handed over as LocalIndex::Read leaves it (lra_ctx_load_local_index: the .gli payload, k / w / window from the file) instead of built on the device: an
+    index built with `lra index`'s values (k 10, w 5, windows of 2048 bases), written with lra_write_gli, read back, loaded into a second context -- the same alignments
+    as on the context that built it; the options' own local values are refused until lra_map_opts_apply_local_index has overridden them; an index of another chromosome
+    table is refused."""
+    import ctypes as C
+    from lra_amd import index as I, seed, mapread
+    from lra_amd.context import Context
+    from lra_amd._lib import LraError
+    g = _genome(33, 500_000)
+    CH = [0, 230_000, 500_000]
+    reads, _ = synth.simulate_reads(g, 8, 7000, 1500, 0.10 if preset == "ont" else 0.01, seed=5)
+    names = [b"c1", b"c2"]
+    if preset == "ont":
+        a = mapread.LowAccMapper(ctx, g, None, None, names, CH, mapread.with_gli(mapread.LowAccOptions()), staged=False)
+    else:
+        a = mapread.HighAccMapper(ctx, g, None, None, names, CH, "ccs", gli=True, index_params=(17, 10, 150, 18, 1))   # (a thin index: some reads take the REFINEclusters branch)
+    so, tb, tu = a.fetch_local_index()
+    k_, w_, win_ = C.c_int(0), C.c_int(0), C.c_int(0)
+    ctx.check(ctx.lib.lra_ctx_local_index_params(ctx.h, C.byref(k_), C.byref(w_), C.byref(win_)))
+    assert (k_.value, w_.value, win_.value) == (10, 5, 2048)
+    path = tmp_path / "ref.fa.gli"
+    I.write_gli(path, 10, 5, 2048, so, tb, tu)
+    f = I.read_gli(path)
+    assert (f["k"], f["w"], f["window"]) == (10, 5, 2048) and np.array_equal(f["tuples"], tu)
+    batch = seed.ReadBatch(ctx, [r.tobytes() for r in reads])
+    ra = a.fetch(a.align(batch))
+    ik, ip = I.global_index(ctx)
+    c2 = Context(ctx.device.index or 0)
+    b = (mapread.LowAccMapper(c2, g, ik, ip, names, CH, mapread.LowAccOptions(), staged=False) if preset == "ont"
+         else mapread.HighAccMapper(c2, g, ik, ip, names, CH, "ccs"))          # the options' own values: the context builds a 256-base-window index first
+    def load(cp):
+        so_, tb_, tu_ = (np.ascontiguousarray(f[n]) for n in ("seq_offsets", "tuple_bnd", "tuples"))
+        return c2.lib.lra_ctx_load_local_index(c2.h, f["k"], f["w"], f["window"], C.c_uint64(len(so_) - 1), C.c_void_p(so_.ctypes.data), C.c_void_p(tb_.ctypes.data),
+                                               C.c_uint64(len(tu_)), C.c_void_p(tu_.ctypes.data))
+    c2.check(load(CH))
+    b2 = seed.ReadBatch(c2, [r.tobytes() for r in reads])
+    with pytest.raises(LraError):                                              # the options still say k / window of the preset: refused
+        b.align(b2)
+    c2.lib.lra_map_opts_apply_local_index(C.byref(b.copts), f["k"], f["w"], f["window"])
+    rb = b.fetch(b.align(b2))
+    assert int(ra["job_aln_off"][-1]) >= 6
+    for kk in ("job_aln_off", "strand", "chrom", "block_off", "blocks", "counts", "runs", "read_status"):
+        assert np.array_equal(ra[kk], rb[kk]), kk
+    # an index of another genome (here: the same tuples against a chromosome table cut elsewhere) is refused
+    cp = (C.c_uint64 * 3)(0, 200_000, 500_000)
+    c2.check(c2.lib.lra_ctx_load_chromosomes(c2.h, cp, 2))
+    assert load(None) != 0
