@@ -1428,15 +1428,19 @@ extern "C" int lra_map_records_host(lra_map_host* h, const lra_map_opts* o, cons
             rec.n_blocks = (int32_t)(b1 - b0);
             rec.first_block_qpos = ends[2 * a];
             rec.last_block_qend = ends[2 * a + 1];
-            if (pairwise) {
-              if (strand[a] && rcRead.empty()) {                          // CreateRC (SeqUtils.h:151)
-                const int L = read_len[r];
-                rcRead.resize((size_t)L);
-                for (int x = 0; x < L; x++) {
-                  const char ch = reads[r][L - 1 - x];
-                  rcRead[x] = ch == 'A' ? 'T' : ch == 'C' ? 'G' : ch == 'G' ? 'C' : ch == 'T' ? 'A' : ch == 'a' ? 't' : ch == 'c' ? 'g' : ch == 'g' ? 'c' : ch == 't' ? 'a' : ch == 'n' ? 'n' : 'N';
-                }
+            // Alignment::read is the strand the segment lies on: strands[str] (the constructor call Map_lowacc.h:560 / Map_highacc.h:704, UpdateParameters Alignment.h:506-507),
+            // so a reverse-strand record's SEQ is the read's reverse complement (its quality string stays as it came, Alignment.h:717-733).  Rounds 1-5 wrote the read as
+            // it came for both strands: the emitters were pinned with the read they were GIVEN, and nothing pinned which read the composition gives them.
+            if (strand[a] && rcRead.empty()) {                            // CreateRC (SeqUtils.h:151)
+              const int L = read_len[r];
+              rcRead.resize((size_t)L);
+              for (int x = 0; x < L; x++) {
+                const char ch = reads[r][L - 1 - x];
+                rcRead[x] = ch == 'A' ? 'T' : ch == 'C' ? 'G' : ch == 'G' ? 'C' : ch == 'T' ? 'A' : ch == 'a' ? 't' : ch == 'c' ? 'g' : ch == 'g' ? 'c' : ch == 't' ? 'a' : ch == 'n' ? 'n' : 'N';
               }
+            }
+            if (strand[a]) rec.read = rcRead.c_str();
+            if (pairwise) {
               rec.blocks = &blocks[3 * b0];
               rec.strand_read = strand[a] ? rcRead.c_str() : reads[r];
               rec.chrom_text = h->segText[a].data() - h->segStart[a];     // chrom_text[tPos] for the covered tPos only

@@ -132,6 +132,16 @@ class MapResult(C.Structure):
 
 READ_TYPES = {"ont": 0, "clr": 1, "ccs": 2, "contig": 3}
 
+_RC_TABLE = bytearray(b"N" * 256)
+for _a, _b in zip(b"ACGTacgtn", b"TGCAtgcan"):
+    _RC_TABLE[_a] = _b
+_RC_TABLE = bytes(_RC_TABLE)
+
+
+def create_rc(read: bytes) -> bytes:
+    """CreateRC (SeqUtils.h:151-158, RevCompNuc :112-145): what Alignment::read holds for a reverse-strand segment (strands[1])."""
+    return read.translate(_RC_TABLE)[::-1]
+
 
 class MapBatchResult:
     """What align() leaves in HBM for one batch (context-owned buffers: valid until the next align() on the same context)."""
@@ -442,6 +452,7 @@ class LowAccMapper:
         for r in range(res.n_reads):
             name = names[r] if isinstance(names[r], bytes) else str(names[r]).encode()
             rd = bytes(reads[r])
+            rd_rc = None
             ql = None if quals is None else quals[r]
             recs, seg_off = [], [0]
             unaligned = int(jo[r * na + 1] - jo[r * na]) == 0 if res.n_jobs else True                   # p == 0 left no SegAlignment (:578)
@@ -454,7 +465,10 @@ class LowAccMapper:
                     for a in range(int(jo[j]), int(jo[j + 1])):
                         c = counts[a]
                         rec = emit.AlnRecord()
-                        rec.read_name, rec.read, rec.qual, rec.read_len = name, rd, ql, len(rd)
+                        if int(al["strand"][a]) and rd_rc is None:
+                            rd_rc = create_rc(rd)
+                        # Alignment::read = strands[str] (Map_lowacc.h:560, Alignment.h:506-507): a reverse-strand record's SEQ is the reverse complement
+                        rec.read_name, rec.read, rec.qual, rec.read_len = name, (rd_rc if int(al["strand"][a]) else rd), ql, len(rd)
                         ci = int(al["chrom"][a])
                         rec.chrom = self.chrom_names[ci]
                         rec.genome_len = self.chrom_pos[ci + 1] - self.chrom_pos[ci]

@@ -1,6 +1,8 @@
 """The high-accuracy path (MapRead_highacc, Map_highacc.h:37-798; -CCS / -CONTIG): the leaves that were missing after round 1 and the path end to end.
 a5: MatchesToFineClusters (Clustering.h:1555; SplitRoughClustersWithGaps :1358, StoreFineClusters :892).
 Oracle restatements are PARITY UNPINNED (Clustering.h & co need htslib headers); CPU tests check their properties, GPU tests compare HIP with them."""
+import re
+
 import numpy as np
 import pytest
 
@@ -438,6 +440,18 @@ def test_map_reads_highacc_match_oracle_pipeline(ctx, oracle, preset):
     for r, t in enumerate(texts):
         if out["read_status"][r]:
             assert t == b"", r
+    n_rev_lines = 0
+    for r, t in enumerate(texts):                                         # SEQ = strands[str] (Map_highacc.h:704): the reverse complement for a reverse-strand record
+        for l in t.decode().split("\n"):
+            if not l or int(l.split("\t")[1]) & 4:
+                continue
+            ff = l.split("\t")
+            sread = mapread.create_rc(reads[r].tobytes()) if int(ff[1]) & 16 else reads[r].tobytes()
+            m0 = re.match(r"^(\d+)H", ff[5]); m1 = re.search(r"(\d+)H$", ff[5])
+            h0 = int(m0.group(1)) if m0 else 0; h1 = int(m1.group(1)) if m1 else 0
+            assert ff[9].encode() == sread[h0:len(sread) - h1], (r, ff[1])
+            n_rev_lines += bool(int(ff[1]) & 16)
+    assert n_rev_lines >= 3
     assert texts[-1].split(b"\t")[1] == b"4"                              # the junk read: one unaligned record
     assert sum(1 for t in texts if t.count(b"\n") >= 2) >= 2               # split reads: several lines
 

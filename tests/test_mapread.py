@@ -136,6 +136,15 @@ def test_map_reads_to_sam(ctx):
         tlen = sum(n for n, op in ops if op in "=XD")
         assert qlen == len(reads[i]), (i, qlen, len(reads[i]))
         assert f[9] == "*" or len(f[9]) == sum(n for n, op in ops if op in "=XIS")
+        # SEQ is Alignment::read = strands[str] (Map_lowacc.h:560, Alignment.h:506-507): the read as it came on the forward strand, its reverse complement on the reverse
+        # strand; a hard-clipped supplementary record carries the aligned part of THAT strand's sequence (Alignment.h:708-711)
+        for ln_ in lines:
+            ff = ln_.split("\t")
+            fl_, cg_ = int(ff[1]), _parse_cigar(ff[5])
+            sread = mapread.create_rc(reads[i].tobytes()) if fl_ & 16 else reads[i].tobytes()
+            h0 = cg_[0][0] if cg_[0][1] == "H" else 0
+            h1 = cg_[-1][0] if cg_[-1][1] == "H" else 0
+            assert ff[9].encode() == sread[h0:len(sread) - h1], (i, fl_, h0, h1)
         ok = (chrom == names[ci].decode() and bool(flag & 16) == bool(st) and abs((pos - 1 + CH[ci]) - s) < 200
               and abs(tlen - l) < 400)
         n_right += ok
