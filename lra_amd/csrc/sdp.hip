@@ -775,6 +775,7 @@ struct ProcArgs {
   int dbg;
   int wgNoRing;          // sdp_process_wg: keep the anchors' words at L2 whatever the spans (LRA_SDP_WG_RING=0: tests of that mode)
   char* wgScratch; const uint64_t* wgOff;   // sdp_process_wg: per large read, the anchors' (best predecessor, contributions) words and the points' ranks
+  unsigned long long* stat;                 // sdp_process<true> (LRA_SDP_STAT): 32 counters summed over the launch's waves
 };
 
 // w(i, j) = -PWL_w(|j - i| + 1)   (SubRountine.h:101-129).  upper_bound over STOPS[0..24) as a count of constants <= x.
@@ -833,6 +834,20 @@ __global__ void k_pen_table(PwlTab pw, int n, short* tab, int* bad) {
 }
 constexpr int PEN_TAB_WG = 4096, PEN_TAB_WAVE = 2048;
 
+// The maximum of a float over the 64 lanes, wave-uniform: four row shifts (a row = 16 lanes; lanes with nothing shifted in keep -inf), the two row broadcasts, lane 63.
+__device__ __forceinline__ float wave_max_f32(float v) {
+  constexpr int NEG_INF = (int)0xff800000u;
+  int x = __float_as_int(v);
+#define LRA_DPP_MAX(ctrl_, rmask_) x = __float_as_int(fmaxf(__int_as_float(x), __int_as_float(__builtin_amdgcn_update_dpp(NEG_INF, x, (ctrl_), (rmask_), 0xf, false))))
+  LRA_DPP_MAX(0x111, 0xf);   // row_shr:1
+  LRA_DPP_MAX(0x112, 0xf);   // row_shr:2
+  LRA_DPP_MAX(0x114, 0xf);   // row_shr:4
+  LRA_DPP_MAX(0x118, 0xf);   // row_shr:8      (lane 15 of a row: the row's maximum)
+  LRA_DPP_MAX(0x142, 0xa);   // row_bcast:15   (rows 1 and 3 take the row before them)
+  LRA_DPP_MAX(0x143, 0xc);   // row_bcast:31   (rows 2 and 3 take lane 31)
+#undef LRA_DPP_MAX
+  return __int_as_float(__builtin_amdgcn_readlane(x, 63));
+}
 __device__ __forceinline__ int rl_i(int v, int src) { return __builtin_amdgcn_readlane(v, src); }           // src must be wave-uniform
 __device__ __forceinline__ float rl_f(float v, int src) { return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), src)); }
 __device__ __forceinline__ long long rl_ll(long long v, int src) {
@@ -952,7 +967,15 @@ __device__ bool coop_grow_pairs(int2* pairs, uint32_t& off, int& cap, int used, 
 // Block stores, so each sees its own) with the next 64 Di / Dv / Db and
 // Ei[Db] prefetched one per lane, and the two binary searches (FindBoundary, FindValueInBlock's UPPERbound) probe six levels
 // per memory round.  Value[ii] is then the (max value, first in visit order) reduction the ordered `val < Ev` updates compute.
+template <bool STAT>
 __global__ void __launch_bounds__(64, 4) sdp_process(ProcArgs a) {
+  // STAT (LRA_SDP_STAT): cycles per section of a point's visit and the lengths of its loops, summed over the launch -- an instantiation of its own (the counters' registers)
+  __shared__ unsigned long long sT[STAT ? 10 : 1], sC[STAT ? 12 : 1];     // (in LDS: the production kernel's registers are what the counters would take)
+  unsigned long long tPrev = 0;
+  if (STAT) { if (threadIdx.x < 10) sT[threadIdx.x] = 0; if (threadIdx.x < 12) sC[threadIdx.x] = 0; tPrev = __builtin_amdgcn_s_memtime(); }
+#define TICK(k_) do { if (STAT) { if (a.dbg == 2) __builtin_amdgcn_s_waitcnt(0); const unsigned long long t__ = __builtin_amdgcn_s_memtime(); if (threadIdx.x == 0) sT[k_] += t__ - tPrev; tPrev = t__; } } while (0)
+#define CNT(k_, x_) do { const unsigned long long x__ = (unsigned long long)(x_); if (threadIdx.x == 0) sC[k_] += x__; } while (0)
+#define WMAX(x_) ([&]() { int m__ = (x_); for (int o__ = 32; o__ > 0; o__ >>= 1) m__ = max(m__, __shfl_xor(m__, o__)); return m__; }())
   __shared__ float s_slope[25], s_inter[25];
   __shared__ short s_pen[PEN_TAB_WAVE];
   const int lane = threadIdx.x;
@@ -1000,18 +1023,22 @@ __global__ void __launch_bounds__(64, 4) sdp_process(ProcArgs a) {
     }
     const int ind = fl & 1, inv = (fl >> 1) & 1;
     const float fvP = a.fval[f0 + lf];                                   // the anchor's value so far (asked for now: the point ends with it)
+    bool swd = false;
     if (v.x != NONE && v.x != cId) {
+      swd = true;
       // (the descriptor's changing fields live in this lane's copy while the lane stays in the sub-problem; memory gets them when it leaves: a store per query
       // would be waited for by the next point's loads -- vector memory completes in order)
       if (cDirty) { Node* op = nodes + cId; op->last = cn.last; op->sTop = cn.sTop; op->nBlk = cn.nBlk; op->stkOff = cn.stkOff; op->stkCap = cn.stkCap; op->blkOff = cn.blkOff; op->blkCap = cn.blkCap; cDirty = false; }
       cn = nodes[v.x]; cId = v.x; cTopOk = false;
     }
+    if (STAT) { const int sw = __popcll(__ballot(swd)); const int nl = __popcll(__ballot(v.x != NONE)); CNT(ind ? 1 : 0, 1); CNT(ind ? 3 : 2, sw > 0); CNT(ind ? 5 : 4, nl); TICK(ind ? 1 : 0); }
     if (ind == 0) {                                                      // PassValueToD1/D2 (SparseDP.h:140-310)
       if (v.x != NONE) {
         const float val = fvP;
         const uint32_t e = cn.dBase + v.y;
         if (ent[e].v < val) { ent[e].v = val; Ap[e] = lf; }
       }
+      TICK(2);
     } else {                                                             // start point (:1025-1060)
       // Every pair on a stack but the dummy at position 0 has the boundary n (see sdp_process_wg): a pair is its D index; `Db >= top.second` never holds,
       // candidates meet the stack at Ei[n - 1] only, FindBoundary never searches.
@@ -1043,10 +1070,12 @@ __global__ void __launch_bounds__(64, 4) sdp_process(ProcArgs a) {
         if (!cTopOk) { tx = sTop <= 1 ? -1 : sT.x; lastB = bL; }
       }
       const bool need = now != -1;
+      TICK(3);
       // phase 1a, every lane for itself: short insertion runs (most queries advance `now` by a few candidates only) -- the same loop
       // as below, literal and lane-local, all lanes at once
       const int LOCAL_MAX = 6;
       const bool small = need && now > nd.last && now - nd.last <= LOCAL_MAX;
+      int nIt = 0, nPop = 0;
       if (small) {
         bool topD = false; float tDv = 0; long long tDi = 0;
 #define SPUSHL(val_) do { const int2 v__ = (val_); if (sTop >= sCap) { if (!grow_pairs(pairs, stkOff, sCap, sTop, poolUsed, poolPair, poolPairs)) st |= LRA_ST_CAPACITY; } \
@@ -1054,6 +1083,7 @@ __global__ void __launch_bounds__(64, 4) sdp_process(ProcArgs a) {
 #define BPUSHL(val_) do { const int2 v__ = (val_); if (nBlk >= bCap) { if (!grow_pairs(pairs, blkOff, bCap, nBlk, poolUsed, poolPair, poolPairs)) st |= LRA_ST_CAPACITY; } \
                           if (nBlk < bCap) (pairs + blkOff)[nBlk] = v__; nBlk++; lastB = v__; } while (0)
         for (int i = nd.last + 1; i <= now && !st; ++i) {
+          if (STAT) nIt++;
           Ent di_ = pfD; long long edb = pfE;
           if (i != nd.last + 1) { di_ = (ent + nd.dBase)[i]; edb = (Ed + nd.dBase)[i]; }
           const int db = di_.b;
@@ -1069,6 +1099,7 @@ __global__ void __launch_bounds__(64, 4) sdp_process(ProcArgs a) {
               if (cx < 0 || n < 1) { st |= LRA_ST_OOB_SLOT; break; }
               if (!(sNew > cDv + W(cDi, eLast))) break;
               sTop--;
+              if (STAT) nPop++;
               if (sTop == 0) { st |= LRA_ST_OOB_SLOT; break; }
               cx = sTop - 1 == 0 ? -1 : (pairs + stkOff)[sTop - 1].x;
               if (cx == -1) break;
@@ -1081,8 +1112,10 @@ __global__ void __launch_bounds__(64, 4) sdp_process(ProcArgs a) {
 #undef SPUSHL
 #undef BPUSHL
       }
+      if (STAT) { const int mi = WMAX(nIt), mp = WMAX(nPop); CNT(6, mi); CNT(7, mp); CNT(8, mi > 0); TICK(4); }
       // phase 1b, one owner at a time, the whole wave: long insertion runs  for (i = last + 1; i <= now; ++i)  of Maximization :275-328
       unsigned long long todo = __ballot(need && now > nd.last && !small);
+      if (STAT) CNT(9, __popcll(todo));
       while (todo) {
         const int owner = __ffsll((long long)todo) - 1;
         todo &= todo - 1;
@@ -1151,13 +1184,15 @@ __global__ void __launch_bounds__(64, 4) sdp_process(ProcArgs a) {
 #undef BPUSH
         if (lane == owner) { sTop = oTop; nBlk = oBlk; tx = otx; lastB = olastB; st |= ost; stkOff = oStkOff; blkOff = oBlkOff; sCap = oSCap; bCap = oBCap; }
       }
+      TICK(5);
       // phase 2, every lane for its own sub-problem: the flush of Maximization :438-453 (only its `now == m - 1` branch ever pops), FindValueInBlock :322-333, Ev / Ep
       float ev = -1.f;
       bool got = false;
+      int nFl = 0, nSr = 0;
       if (need && !st) {
 #define BPUSH2(val_) do { const int2 v__ = (val_); if (nBlk >= bCap) { if (!grow_pairs(pairs, blkOff, bCap, nBlk, poolUsed, poolPair, poolPairs)) st |= LRA_ST_CAPACITY; } \
                           if (nBlk < bCap) (pairs + blkOff)[nBlk] = v__; nBlk++; lastB = v__; } while (0)
-        if (now == m - 1) { while (sTop > 1 && tx != -1 && !st) { BPUSH2(make_int2(tx, n)); sTop--; tx = sTop - 1 == 0 ? -1 : (pairs + stkOff)[sTop - 1].x; } }
+        if (now == m - 1) { while (sTop > 1 && tx != -1 && !st) { if (STAT) nFl++; BPUSH2(make_int2(tx, n)); sTop--; tx = sTop - 1 == 0 ? -1 : (pairs + stkOff)[sTop - 1].x; } }
 #undef BPUSH2
         int i2 = -1;
         if (!st && nBlk > 0) {
@@ -1165,6 +1200,7 @@ __global__ void __launch_bounds__(64, 4) sdp_process(ProcArgs a) {
           else {
             int lo = 0, cnt = nBlk, bx = -1;                              // UPPERbound :205-221, two levels per memory round; the search ends at the position of its most
             while (cnt > 0) {                                             // recent false probe (or at the end): Block[lo].first is that probe's pair, no further load
+              if (STAT) nSr++;
               const int step = cnt >> 1, it = lo + step;
               const int cntT = cnt - step - 1, itT = it + 1 + (cntT >> 1), itF = lo + (step >> 1);
               const int2 pM = (pairs + blkOff)[it], pT = cntT > 0 ? (pairs + blkOff)[itT] : make_int2(0, 0), pF = step > 0 ? (pairs + blkOff)[itF] : make_int2(0, 0);
@@ -1190,31 +1226,38 @@ __global__ void __launch_bounds__(64, 4) sdp_process(ProcArgs a) {
           cTop = make_int2(tx, tx == -1 ? n + 1 : n); cLastB = lastB; cTopOk = true;
         }
       }
+      if (STAT) { const int mf = WMAX(nFl), ms = WMAX(nSr); CNT(10, mf); CNT(11, ms); TICK(6); }
       const uint32_t myI1 = v.y;
-      for (int o = 32; o > 0; o >>= 1) st |= __shfl_xor(st, o);
+      if (__ballot(st != 0)) { for (int o = 32; o > 0; o >>= 1) st |= __shfl_xor(st, o); }   // (a status is rare: no exchange unless a lane has one)
       bad |= st;
-      // Value[ii]: visits apply in the order R family deepest level first, then C family; `val < Ev` keeps the first maximum
+      // Value[ii]: visits apply in the order R family deepest level first, then C family; `val < Ev` keeps the first maximum.  The maximum over the lanes by DPP row
+      // shifts / broadcasts (six VALU operations; a butterfly of __shfl_xor is twelve dependent trips through the LDS crossbar, a tenth of a point's time), then the
+      // first lane in visit order among those that hold it: within a family a higher lane is a deeper level, and the R family's lanes come first
       if (!bad) {
-        const int ord = fam2 * LV + (LV - 1 - level);
-        float bv = got ? ev : -1.f; int bo = got ? ord : 64;
-        for (int o = 32; o > 0; o >>= 1) {
-          const float ov = __shfl_xor(bv, o); const int oo = __shfl_xor(bo, o);
-          if (ov > bv || (ov == bv && oo < bo)) { bv = ov; bo = oo; }
-        }
-        if (got && bo == ord) {
-          if (fvP < bv) {
-            a.fval[f0 + lf] = bv; a.fprevNode[f0 + lf] = v.x; a.fprevInd[f0 + lf] = myI1;
+        const float bvM = wave_max_f32(got ? ev : -__builtin_inff());
+        const unsigned long long eq = __ballot(got && ev == bvM);
+        const unsigned long long eqR = eq & ((1ull << LV) - 1);
+        const int win = eq ? 63 - __clzll((long long)(eqR ? eqR : eq)) : -1;
+        if (lane == win) {
+          if (fvP < ev) {
+            a.fval[f0 + lf] = ev; a.fprevNode[f0 + lf] = v.x; a.fprevInd[f0 + lf] = myI1;
             a.fflags[f0 + lf] = (uint8_t)((fam2 == 0 ? 1 : 0) | (inv ? 2 : 0));   // bit0 prev (row family), bit1 inv
           }
         }
       }
+      TICK(7);
     }
     wave_sync();
+    TICK(ind ? 9 : 8);
   }
+  if (STAT && lane == 0 && a.stat) { for (int k = 0; k < 10; k++) atomicAdd(a.stat + k, sT[k]); for (int k = 0; k < 12; k++) atomicAdd(a.stat + 10 + k, sC[k]); }
   if (cDirty && cId != NONE) { Node* op = nodes + cId; op->last = cn.last; op->sTop = cn.sTop; op->nBlk = cn.nBlk; op->stkOff = cn.stkOff; op->stkCap = cn.stkCap; op->blkOff = cn.blkOff; op->blkCap = cn.blkCap; }
   if (lane == 0 && bad) atomicOr(&a.status[r], bad);
 #undef W
 #undef BEATS
+#undef TICK
+#undef CNT
+#undef WMAX
 }
 
 // ---- the same for LARGE reads: one 1024-thread workgroup per read, the (family pair, level) slots spread over its 16 waves.
@@ -2282,9 +2325,27 @@ int sdp_run(lra_ctx* ctx, int n_reads, const uint64_t* d_cluster_off, const uint
       lra_time_begin(ctx, ctx->sdp_inner ? "sdp_inner_process" : "sdp_process");
       // the few large reads (a workgroup each) run beside the many small ones (a wave each) instead of in front of them
       if (nbig > 0 && !early) launch_wg(forked ? lra_side_fork(ctx) : st, maxRC);
-      if (nsub > nbig) { ProcArgs pb = pa; pb.order = subOrder + nbig; pb.n = nsub - nbig; hipLaunchKernelGGL(sdp_process, dim3(nsub - nbig), dim3(64), 0, st, pb); }
+      static const int statEnv = getenv("LRA_SDP_STAT") ? atoi(getenv("LRA_SDP_STAT")) : 0;
+      unsigned long long* d_stat = nullptr;
+      if (nsub > nbig) {
+        ProcArgs pb = pa; pb.order = subOrder + nbig; pb.n = nsub - nbig; pb.stat = nullptr;
+        if (statEnv > 0) {
+          (void)hipMalloc((void**)&d_stat, 32 * 8); (void)hipMemsetAsync(d_stat, 0, 32 * 8, st);
+          pb.stat = d_stat; pb.dbg = statEnv;
+          hipLaunchKernelGGL(sdp_process<true>, dim3(nsub - nbig), dim3(64), 0, st, pb);
+        } else hipLaunchKernelGGL(sdp_process<false>, dim3(nsub - nbig), dim3(64), 0, st, pb);
+      }
       if (forked) lra_side_join(ctx);
       lra_time_end(ctx);
+      if (d_stat) {
+        unsigned long long hs[32];
+        (void)hipStreamSynchronize(st); (void)hipMemcpy(hs, d_stat, sizeof hs, hipMemcpyDeviceToHost); (void)hipFree(d_stat);
+        const double ne = (double)std::max<unsigned long long>(hs[10], 1), ns = (double)std::max<unsigned long long>(hs[11], 1);
+        fprintf(stderr, "[sdp-stat] mode %d inner %d reads %d: end points %llu (switch %.2f, %.1f lanes) cycles: switch %.0f deposit %.0f sync %.0f | start points %llu (switch %.2f, %.1f lanes) cycles: switch %.0f "
+                "first %.0f small %.0f coop %.0f flush+search %.0f result %.0f sync %.0f | per start point: small iters (max lane) %.2f pops %.2f with-small %.2f coop owners %.3f flush %.2f search rounds %.2f\n",
+                opts->mode, (int)ctx->sdp_inner, nsub - nbig, hs[10], hs[12] / ne, hs[14] / ne, hs[0] / ne, hs[2] / ne, hs[8] / ne, hs[11], hs[13] / ns, hs[15] / ns, hs[1] / ns, hs[3] / ns, hs[4] / ns, hs[5] / ns,
+                hs[6] / ns, hs[7] / ns, hs[9] / ns, hs[16] / ns, hs[17] / ns, hs[18] / ns, hs[19] / ns, hs[20] / ns, hs[21] / ns);
+      }
       if (dbg) {
         (void)hipEventRecord(e1, st); (void)hipEventSynchronize(e1);
         float ms = 0; (void)hipEventElapsedTime(&ms, e0, e1);
