@@ -59,7 +59,7 @@ __device__ __forceinline__ int wave_incl_scan(int v, int lane) {
 struct PwlTab { long long stops[25]; float slope[25], inter[25]; int c1, c2; };
 
 struct Ent { long long val; int b; float v; };   // one Di / Ei slot: diagonal, Db / Eb, Dv / Ev   (16 bytes)
-struct Node {            // one full sub-problem (SubProblem.h:15-37), 40 bytes
+struct Node {            // one full sub-problem (SubProblem.h:15-37), 48 bytes
   uint32_t dBase;        // entry index of Di[0] within the read's entries; Ei[0] at dBase + nD
   uint32_t nD, nE;
   int32_t last;
@@ -281,6 +281,7 @@ struct BuildArgs {
   uint32_t* cntEntries; uint32_t* cntNodes; uint32_t* cntD; uint32_t* cntV; uint32_t* cntRC;   // [n] (count pass out; cntRC: max(distinct rows, distinct columns))
   const ReadArena* ra;                       // emit pass: per-read blocks
   uint32_t* status;
+  unsigned long long* stat;                  // LRA_SDP_BUILD_STAT: cycles per pass (set-up, A, C, D, E, F, G, family set-up) summed over the launch's reads; null = off
 };
 
 // NW = waves per read: 1 (a wave per read) or 16 (a 1024-thread workgroup per LARGE read: every pass over the read's points is spread over the block, the
@@ -301,7 +302,8 @@ __device__ __forceinline__ int blk_incl_scan(int v, int lane, int wave, int* s_w
 // LDSV (one wave per read, at most 512 points): the per-element arrays -- 28 bytes per point with 16-bit indices and 32-bit diagonals -- live in the wave's LDS.
 // From the scratch arena every level streams them through HBM again (2.6 KB per point and build: 250 GB per step, a third of the step's traffic).
 // MODE 2: the same narrow arrays in the arena (reads of 513 .. 16383 points: half the bytes per level, no LDS to run out of).  MODE 0: 32-bit indices, 64-bit diagonals.
-template <bool EMIT, int NW, int MODE = 0, int OCC = 8>
+// BSTAT (LRA_SDP_BUILD_STAT): cycles per pass -- an instantiation of its own: the kernel spills as it is, and the counter's two scalars more than double what it spills
+template <bool EMIT, int NW, int MODE = 0, int OCC = 8, bool BSTAT = false>
 __global__ void __launch_bounds__(64 * NW, NW == 1 ? OCC : 1) sdp_build(BuildArgs a) {
   constexpr int NT = 64 * NW;
   constexpr bool LDSV = MODE == 1, NARROW = MODE != 0;
@@ -310,6 +312,11 @@ __global__ void __launch_bounds__(64 * NW, NW == 1 ? OCC : 1) sdp_build(BuildArg
   constexpr IT INONE = (IT)~(IT)0;
   extern __shared__ __attribute__((aligned(16))) char dyn_lds[];
   __shared__ int s_w[4][NW == 1 ? 1 : NW];
+  __shared__ unsigned long long s_bt[BSTAT ? 8 : 1];
+  unsigned long long btPrev = 0;
+  constexpr bool bstat = BSTAT;
+  if (bstat) { if (threadIdx.x < 8) s_bt[threadIdx.x] = 0; btPrev = __builtin_amdgcn_s_memtime(); }
+#define BTICK(k_) do { if (bstat) { const unsigned long long t__ = __builtin_amdgcn_s_memtime(); if (threadIdx.x == 0) s_bt[k_] += t__ - btPrev; btPrev = t__; } } while (0)
   const int rr = (int)a.order[blockIdx.x], r = a.r0 + rr, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   auto SYNC = [&]() { if (NW == 1) wave_sync(); else __syncthreads(); };
   const uint64_t p0 = a.ptOff[r], pc0 = a.ptOff[a.r0];
@@ -368,6 +375,7 @@ __global__ void __launch_bounds__(64 * NW, NW == 1 ? OCC : 1) sdp_build(BuildArg
     cOff[0] = 0; cOff[1] = c0; cOff[2] = c0 + c1; cOff[3] = c0 + c1 + c2; cOff[4] = P;
   }
   SYNC();
+  BTICK(0);
   uint32_t nEntries = 0, nNodesTot = 0, sumD = 0, nVisits = 0;
   Node* nodesR = nullptr; Ent* entR = nullptr; uint32_t* apR = nullptr; int2* stkR = nullptr; uint2* visR = nullptr; long long* edR = nullptr;
   uint32_t blkPair = 0;
@@ -398,6 +406,7 @@ __global__ void __launch_bounds__(64 * NW, NW == 1 ? OCC : 1) sdp_build(BuildArg
     if (tid == 0) { TB(0, F_LS, 0) = 0; TB(0, F_LE, 0) = nLines; TB(0, F_SB, 0) = 0; TB(0, F_SE, 0) = nS; TB(0, F_EB, 0) = nS; TB(0, F_EE, 0) = Pf; }
     int nNodes = 1, cur = 0;
     SYNC();
+    BTICK(7);
     for (int level = 0; nNodes > 0 && !outgrown; level++) {
       if (level >= LV) { overflow = true; break; }
       const int nxt = cur ^ 1;
@@ -430,6 +439,7 @@ __global__ void __launch_bounds__(64 * NW, NW == 1 ? OCC : 1) sdp_build(BuildArg
         if (tid == 0) pf[Pf] = (IT)carry;
       }
       SYNC();
+      BTICK(1);
       for (int k = tid; k < nNodes; k += NT) {
         TM(T_C1S, k) = (uint32_t)pf[TB(cur, F_SE, k)] - (uint32_t)pf[TB(cur, F_SB, k)];
         TM(T_C1E, k) = (uint32_t)pf[TB(cur, F_EE, k)] - (uint32_t)pf[TB(cur, F_EB, k)];
@@ -471,6 +481,7 @@ __global__ void __launch_bounds__(64 * NW, NW == 1 ? OCC : 1) sdp_build(BuildArg
         }
       }
       SYNC();
+      BTICK(2);
       // D: heads of the distinct diagonals inside the D segment (ends) / E segment (starts); exclusive prefix in ph
       {
         int carry = 0;
@@ -521,6 +532,7 @@ __global__ void __launch_bounds__(64 * NW, NW == 1 ? OCC : 1) sdp_build(BuildArg
         if (tid == 0) ph[Pf] = (IT)carry;
       }
       SYNC();
+      BTICK(3);
       // E: per node: sizes, fullness, children, next level's table
       int nNext = 0;
       for (int k0 = 0; k0 < nNodes; k0 += NT) {
@@ -574,6 +586,7 @@ __global__ void __launch_bounds__(64 * NW, NW == 1 ? OCC : 1) sdp_build(BuildArg
       }
       if (outgrown) break;
       SYNC();
+      BTICK(4);
       // F: node index of every element for the next level; emit Di / Ei and the visit records
       {
         // (the pass reads ln[P + .], the tables, ph, lpn and the points; it writes ln[.] below P, the entries and the visit rows: nothing it reads)
@@ -645,6 +658,7 @@ __global__ void __launch_bounds__(64 * NW, NW == 1 ? OCC : 1) sdp_build(BuildArg
         }
       }
       SYNC();
+      BTICK(5);
       // G: Db / Eb in closed form (Decide_Eb_Db_*), values and back pointers zeroed
       if (EMIT) {
         // (reads: ln[P + .], the tables, ph, the .val fields of the level's entries (written by F, above the barrier); writes: the .b / .v fields, Ei[Db], the back
@@ -741,8 +755,10 @@ __global__ void __launch_bounds__(64 * NW, NW == 1 ? OCC : 1) sdp_build(BuildArg
       }
       nNodes = nNext; cur = nxt;
       SYNC();
+      BTICK(6);
     }
   }
+  if (bstat && tid == 0) { for (int k = 0; k < 8; k++) atomicAdd(a.stat + k, s_bt[k]); atomicAdd(a.stat + 8, (unsigned long long)P); }
   for (int o = 32; o > 0; o >>= 1) nVisits += __shfl_xor(nVisits, o);
   if (NW > 1) {
     if (lane == 0) s_w[0][wave] = (int)nVisits;
@@ -758,6 +774,7 @@ __global__ void __launch_bounds__(64 * NW, NW == 1 ? OCC : 1) sdp_build(BuildArg
   }
 #undef TB
 #undef TM
+#undef BTICK
 }
 
 // ---- ProcessPoint -----------------------------------------------------------------------------------------------------
@@ -1009,28 +1026,55 @@ __global__ void __launch_bounds__(64, 4) sdp_process(ProcArgs a) {
   uint32_t cId = NONE;
   int2 cTop = make_int2(0, 0), cLastB = make_int2(0, 0);
   bool cTopOk = false, cDirty = false;
-  uint8_t flN = P > 0 ? a.hfl[p0] : 0;
-  uint32_t lfN = P > 0 ? a.hfr[p0] : 0;
-  uint2 vN = make_uint2(NONE, 0);
+  // The next point's flags and anchor are the same for every lane, and the compiler moves a wave-uniform value to a scalar register where it is MADE: a v_readfirstlane behind
+  // the load, i.e. a wait for the load -- one whole memory round trip at the top of every point (a tenth of a point pair's time), with the visit row's load queued behind
+  // it.  Read at an index the compiler cannot see through (a zero in a vector register), the two values stay in vector registers while they are in flight and become
+  // scalars where they are used, one point later.
+  int vz; asm volatile("v_mov_b32_e32 %0, 0" : "=v"(vz));
+  uint32_t flN = P > 0 ? a.hfl[p0 + vz] : 0;
+  uint32_t lfN = P > 0 ? a.hfr[p0 + vz] : 0;
+  // The visit rows run two points ahead, so that at the top of a point the NEXT point's sub-problems are known and their descriptors can be asked for: straight into LDS
+  // (global_load_lds_dwordx4: a lane's 16 bytes land at the base + 16 * lane, no vector register is held while the load is in flight -- the registers are what this
+  // kernel is short of), three loads for the 48 bytes, two buffers taken in turn.  A lane that moves to another sub-problem finds the descriptor there instead of
+  // starting a round trip (every end point's deepest lanes do); never the one the lane is in (newer in its registers than in memory), and one it has left was written back
+  // above, ahead of the load.
+  static_assert(sizeof(Node) == 48, "a descriptor is fetched as three 16-byte pieces");
+  __shared__ uint4 s_node[2][3][2 * LV];
+  uint2 vN = make_uint2(NONE, 0), vNN = make_uint2(NONE, 0);
   if (P > 0 && lane < 2 * LV) vN = visR[lane];
+  if (P > 1 && lane < 2 * LV) vNN = visR[(uint64_t)(2 * LV) + lane];
+  // (the lane is in no sub-problem yet: the first point's descriptors, asked for here)
+#define NODE_FETCH(id_, buf_) do { const char* src__ = (const char*)(nodes + (id_)); _Pragma("unroll") for (int w__ = 0; w__ < 3; w__++) \
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src__ + 16 * w__), (__attribute__((address_space(3))) void*)&s_node[(buf_)][w__][0], 16, 0, 0); } while (0)
+  if (vN.x != NONE) NODE_FETCH(vN.x, 0);
   for (int pi = 0; pi < P && !bad; pi++) {
-    const uint8_t fl = flN;
-    const uint32_t lf = lfN;
+    const uint8_t fl = (uint8_t)u_u(flN);
+    const uint32_t lf = u_u(lfN);
     const uint2 v = vN;
-    if (pi + 1 < P) {                                                    // next point's row, in flight while this one is processed
-      flN = a.hfl[p0 + pi + 1]; lfN = a.hfr[p0 + pi + 1];
-      if (lane < 2 * LV) vN = visR[(uint64_t)(pi + 1) * (2 * LV) + lane];
-    }
-    const int ind = fl & 1, inv = (fl >> 1) & 1;
-    const float fvP = a.fval[f0 + lf];                                   // the anchor's value so far (asked for now: the point ends with it)
+    vN = vNN;
+    // (whenever a lane moves, the descriptor it moves to was asked for at the point before -- or ahead of the loop --: the only source.  With a second one, a load from
+    // memory where the buffer does not hold it, the compiler either folds the two into FLAT loads through a generic pointer or waits for ALL vector memory where the two
+    // paths meet.  And the move comes FIRST in the point, the buffer read ahead of the write-back: the compiler waits for all vector memory before it reads what a
+    // load wrote to LDS, which costs nothing here -- the point before ended with everything waited for -- and a round trip behind anything asked for earlier in the point)
     bool swd = false;
     if (v.x != NONE && v.x != cId) {
       swd = true;
+      const uint4 w0 = s_node[pi & 1][0][lane], w1 = s_node[pi & 1][1][lane], w2 = s_node[pi & 1][2][lane];
       // (the descriptor's changing fields live in this lane's copy while the lane stays in the sub-problem; memory gets them when it leaves: a store per query
       // would be waited for by the next point's loads -- vector memory completes in order)
       if (cDirty) { Node* op = nodes + cId; op->last = cn.last; op->sTop = cn.sTop; op->nBlk = cn.nBlk; op->stkOff = cn.stkOff; op->stkCap = cn.stkCap; op->blkOff = cn.blkOff; op->blkCap = cn.blkCap; cDirty = false; }
-      cn = nodes[v.x]; cId = v.x; cTopOk = false;
+      cn.dBase = w0.x; cn.nD = w0.y; cn.nE = w0.z; cn.last = (int32_t)w0.w; cn.sTop = w1.x; cn.nBlk = w1.y; cn.stkOff = w1.z; cn.blkOff = w1.w; cn.stkCap = w2.x; cn.blkCap = w2.y;
+      cn.eLast = (long long)(((unsigned long long)w2.w << 32) | w2.z);
+      cId = v.x; cTopOk = false;
     }
+    if (pi + 1 < P) {                                                    // the rows of the point after next, the next point's flags: in flight while this one is processed
+      vNN = make_uint2(NONE, 0);
+      if (pi + 2 < P && lane < 2 * LV) vNN = visR[(uint64_t)(pi + 2) * (2 * LV) + lane];
+      flN = a.hfl[p0 + pi + 1 + vz]; lfN = a.hfr[p0 + pi + 1 + vz];
+    }
+    if (vN.x != NONE && vN.x != cId) NODE_FETCH(vN.x, (pi + 1) & 1);      // (lanes >= 2 * LV never have a visit: nothing is written beyond a buffer's 36 slots)
+    const int ind = fl & 1, inv = (fl >> 1) & 1;
+    const float fvP = a.fval[f0 + lf];                                   // the anchor's value so far (asked for now: the point ends with it)
     if (STAT) { const int sw = __popcll(__ballot(swd)); const int nl = __popcll(__ballot(v.x != NONE)); CNT(ind ? 1 : 0, 1); CNT(ind ? 3 : 2, sw > 0); CNT(ind ? 5 : 4, nl); TICK(ind ? 1 : 0); }
     if (ind == 0) {                                                      // PassValueToD1/D2 (SparseDP.h:140-310)
       if (v.x != NONE) {
@@ -1053,6 +1097,10 @@ __global__ void __launch_bounds__(64, 4) sdp_process(ProcArgs a) {
       int sCap = (int)nd.stkCap, bCap = (int)nd.blkCap;
       const long long eLast = nd.eLast;
       int tx = cTop.x; int2 lastB = cLastB;                               // tx == -1: the dummy
+      // sx: the D index of the pair BELOW the top (-1: the dummy is below it; SX_UNK: not known) -- what a pop or the flush would have to read the stack for.  A push makes
+      // it known (the top it covers); a pop that leaves two pairs or more above the dummy forgets it.
+      constexpr int SX_UNK = -2;
+      int sx = cTop.y;
       uint32_t st = 0;
       // what the visit asks memory for first, in ONE round: the query's E entry, the stack top and the last Block pair (when the lane has just come to the sub-problem),
       // the first candidate and the top's D entry (used if the query inserts anything)
@@ -1060,14 +1108,16 @@ __global__ void __launch_bounds__(64, 4) sdp_process(ProcArgs a) {
       long long pfE = 0;
       Ent pfT; pfT.val = 0; pfT.b = 0; pfT.v = 0;
       bool pfTok = false;
+      float pfSv = 0.f; long long pfSd = 0; int pfSx = SX_UNK;            // the D entry of the pair below the top (what the first pop compares with)
       if (v.x != NONE) {
         const Ent e = ent[nd.dBase + nd.nD + v.y];
-        int2 sT = make_int2(-1, 0), bL = make_int2(0, 0);
-        if (!cTopOk) { if (sTop > 1) sT = (pairs + stkOff)[sTop - 1]; if (nBlk > 0) bL = (pairs + blkOff)[nBlk - 1]; }
+        int2 sT = make_int2(-1, 0), sS = make_int2(-1, 0), bL = make_int2(0, 0);
+        if (!cTopOk) { if (sTop > 1) sT = (pairs + stkOff)[sTop - 1]; if (sTop > 2) sS = (pairs + stkOff)[sTop - 2]; if (nBlk > 0) bL = (pairs + blkOff)[nBlk - 1]; }
         if (nd.last + 1 < m) { pfD = (ent + nd.dBase)[nd.last + 1]; pfE = (Ed + nd.dBase)[nd.last + 1]; }
         if (cTopOk && tx >= 0) { pfT = (ent + nd.dBase)[tx]; pfTok = true; }
+        if (cTopOk && sx >= 0) { const Ent es = (ent + nd.dBase)[sx]; pfSv = es.v; pfSd = es.val; pfSx = sx; }
         now = e.b; ei1 = e.val;
-        if (!cTopOk) { tx = sTop <= 1 ? -1 : sT.x; lastB = bL; }
+        if (!cTopOk) { tx = sTop <= 1 ? -1 : sT.x; sx = sTop <= 2 ? -1 : sS.x; lastB = bL; }
       }
       const bool need = now != -1;
       TICK(3);
@@ -1089,7 +1139,7 @@ __global__ void __launch_bounds__(64, 4) sdp_process(ProcArgs a) {
           const int db = di_.b;
           if (db == -1) break;
           const long long di = di_.val; const float dvi = di_.v;
-          if (tx == -1) { BPUSHL(make_int2(-1, db)); SPUSHL(make_int2(i, n)); tx = i; tDv = dvi; tDi = di; topD = true; }
+          if (tx == -1) { BPUSHL(make_int2(-1, db)); SPUSHL(make_int2(i, n)); tx = i; sx = -1; tDv = dvi; tDi = di; topD = true; }
           if (!topD) { Ent e = pfT; if (!pfTok) e = (ent + nd.dBase)[tx]; tDv = e.v; tDi = e.val; topD = true; }
           if (BEATS(dvi, di, tDv, tDi, edb)) {
             if (nBlk > 0 && db > lastB.y) BPUSHL(make_int2(tx, db));
@@ -1101,12 +1151,14 @@ __global__ void __launch_bounds__(64, 4) sdp_process(ProcArgs a) {
               sTop--;
               if (STAT) nPop++;
               if (sTop == 0) { st |= LRA_ST_OOB_SLOT; break; }
-              cx = sTop - 1 == 0 ? -1 : (pairs + stkOff)[sTop - 1].x;
+              cx = sTop - 1 == 0 ? -1 : sx != SX_UNK ? sx : (pairs + stkOff)[sTop - 1].x;
+              sx = sTop - 1 <= 1 ? -1 : SX_UNK;
               if (cx == -1) break;
-              const Ent ce = (ent + nd.dBase)[cx]; cDv = ce.v; cDi = ce.val;
+              if (cx == pfSx) { cDv = pfSv; cDi = pfSd; }
+              else { const Ent ce = (ent + nd.dBase)[cx]; cDv = ce.v; cDi = ce.val; }
             }
             if (st) break;
-            SPUSHL(make_int2(i, n)); tx = i; tDv = dvi; tDi = di; topD = true;
+            SPUSHL(make_int2(i, n)); sx = cx; tx = i; tDv = dvi; tDi = di; topD = true;
           }
         }
 #undef SPUSHL
@@ -1128,7 +1180,7 @@ __global__ void __launch_bounds__(64, 4) sdp_process(ProcArgs a) {
         uint32_t oStkOff = (uint32_t)rl_i((int)stkOff, owner), oBlkOff = (uint32_t)rl_i((int)blkOff, owner);
         int2* oS = pairs + oStkOff; int2* oB = pairs + oBlkOff;
         int oSCap = rl_i(sCap, owner), oBCap = rl_i(bCap, owner);
-        int otx = rl_i(tx, owner); int2 olastB = make_int2(rl_i(lastB.x, owner), rl_i(lastB.y, owner));
+        int otx = rl_i(tx, owner), osx = rl_i(sx, owner); int2 olastB = make_int2(rl_i(lastB.x, owner), rl_i(lastB.y, owner));
         uint32_t ost = 0;
         bool topD = rl_i(pfTok ? 1 : 0, owner) != 0; float tDv = rl_f(pfT.v, owner); long long tDi = rl_ll(pfT.val, owner);   // (the owner's top, asked for above)
 #define SPUSH(val_) do { const int2 v__ = (val_); if (oTop >= oSCap) { if (coop_grow_pairs(pairs, oStkOff, oSCap, oTop, poolUsed, poolPair, poolPairs, lane)) oS = pairs + oStkOff; else ost |= LRA_ST_CAPACITY; } \
@@ -1160,7 +1212,7 @@ __global__ void __launch_bounds__(64, 4) sdp_process(ProcArgs a) {
             const long long di = rl_ll(dj.val, t), edb = rl_ll(ej, t);
             const float dvi = rl_f(dj.v, t);
             bool win = true;                                              // (the ballot's test is the reference's, :405, unless the top was the dummy)
-            if (otx == -1) { BPUSH(make_int2(-1, db)); SPUSH(make_int2(i, on)); otx = i; tDv = dvi; tDi = di; topD = true; win = BEATS(dvi, di, tDv, tDi, edb); }   // :389-395
+            if (otx == -1) { BPUSH(make_int2(-1, db)); SPUSH(make_int2(i, on)); otx = i; osx = -1; tDv = dvi; tDi = di; topD = true; win = BEATS(dvi, di, tDv, tDi, edb); }   // :389-395
             if (win) {
               if (oBlk > 0 && db > olastB.y) BPUSH(make_int2(otx, db));
               const float sNew = dvi + W(di, oeLast);
@@ -1170,19 +1222,20 @@ __global__ void __launch_bounds__(64, 4) sdp_process(ProcArgs a) {
                 if (!(sNew > cDv + W(cDi, oeLast))) break;
                 oTop--;
                 if (oTop == 0) { ost |= LRA_ST_OOB_SLOT; break; }
-                cx = oTop - 1 == 0 ? -1 : oS[oTop - 1].x;
+                cx = oTop - 1 == 0 ? -1 : osx != SX_UNK ? osx : oS[oTop - 1].x;
+                osx = oTop - 1 <= 1 ? -1 : SX_UNK;
                 if (cx == -1) break;
                 const Ent ce = oD[cx]; cDv = ce.v; cDi = ce.val;
               }
               if (ost) break;
-              SPUSH(make_int2(i, on)); otx = i; tDv = dvi; tDi = di; topD = true;
+              SPUSH(make_int2(i, on)); osx = cx; otx = i; tDv = dvi; tDi = di; topD = true;
             }
             t++;
           }
         }
 #undef SPUSH
 #undef BPUSH
-        if (lane == owner) { sTop = oTop; nBlk = oBlk; tx = otx; lastB = olastB; st |= ost; stkOff = oStkOff; blkOff = oBlkOff; sCap = oSCap; bCap = oBCap; }
+        if (lane == owner) { sTop = oTop; nBlk = oBlk; tx = otx; sx = osx; lastB = olastB; st |= ost; stkOff = oStkOff; blkOff = oBlkOff; sCap = oSCap; bCap = oBCap; }
       }
       TICK(5);
       // phase 2, every lane for its own sub-problem: the flush of Maximization :438-453 (only its `now == m - 1` branch ever pops), FindValueInBlock :322-333, Ev / Ep
@@ -1192,7 +1245,14 @@ __global__ void __launch_bounds__(64, 4) sdp_process(ProcArgs a) {
       if (need && !st) {
 #define BPUSH2(val_) do { const int2 v__ = (val_); if (nBlk >= bCap) { if (!grow_pairs(pairs, blkOff, bCap, nBlk, poolUsed, poolPair, poolPairs)) st |= LRA_ST_CAPACITY; } \
                           if (nBlk < bCap) (pairs + blkOff)[nBlk] = v__; nBlk++; lastB = v__; } while (0)
-        if (now == m - 1) { while (sTop > 1 && tx != -1 && !st) { if (STAT) nFl++; BPUSH2(make_int2(tx, n)); sTop--; tx = sTop - 1 == 0 ? -1 : (pairs + stkOff)[sTop - 1].x; } }
+        if (now == m - 1) {
+          while (sTop > 1 && tx != -1 && !st) {
+            if (STAT) nFl++;
+            BPUSH2(make_int2(tx, n)); sTop--;
+            tx = sTop - 1 == 0 ? -1 : sx != SX_UNK ? sx : (pairs + stkOff)[sTop - 1].x;
+            sx = sTop - 1 <= 1 ? -1 : SX_UNK;
+          }
+        }
 #undef BPUSH2
         int i2 = -1;
         if (!st && nBlk > 0) {
@@ -1223,7 +1283,7 @@ __global__ void __launch_bounds__(64, 4) sdp_process(ProcArgs a) {
           Ap[nd.dBase + nd.nD + i1] = (uint32_t)i2;                       // Ep[i1] (Ev[i1] is never read again)
           cDirty = true;
           cn.last = now; cn.sTop = (uint32_t)sTop; cn.nBlk = (uint32_t)nBlk; cn.stkOff = stkOff; cn.blkOff = blkOff; cn.stkCap = (uint32_t)sCap; cn.blkCap = (uint32_t)bCap;
-          cTop = make_int2(tx, tx == -1 ? n + 1 : n); cLastB = lastB; cTopOk = true;
+          cTop = make_int2(tx, sx); cLastB = lastB; cTopOk = true;
         }
       }
       if (STAT) { const int mf = WMAX(nFl), ms = WMAX(nSr); CNT(10, mf); CNT(11, ms); TICK(6); }
@@ -1255,6 +1315,7 @@ __global__ void __launch_bounds__(64, 4) sdp_process(ProcArgs a) {
   if (lane == 0 && bad) atomicOr(&a.status[r], bad);
 #undef W
 #undef BEATS
+#undef NODE_FETCH
 #undef TICK
 #undef CNT
 #undef WMAX
@@ -1944,7 +2005,8 @@ static void launch_small_builds(lra_ctx* ctx, const BuildArgs& ba, const uint32_
       // (two-stage step 952 -> 937 ms; in the one call 8 is the faster one)
       static const int occEnv = getenv("LRA_SDP_BUILD_OCC") ? atoi(getenv("LRA_SDP_BUILD_OCC")) : 0;
       const int occ = occEnv ? occEnv : ctx->pipelined ? 6 : 8;
-      if (occ == 4) hipLaunchKernelGGL((sdp_build<EMIT, 1, 2, 4>), dim3(cut[0] - mid), dim3(64), 0, st, bb);
+      if (bb.stat) { if (occ == 6) hipLaunchKernelGGL((sdp_build<EMIT, 1, 2, 6, true>), dim3(cut[0] - mid), dim3(64), 0, st, bb); else hipLaunchKernelGGL((sdp_build<EMIT, 1, 2, 8, true>), dim3(cut[0] - mid), dim3(64), 0, st, bb); }
+      else if (occ == 4) hipLaunchKernelGGL((sdp_build<EMIT, 1, 2, 4>), dim3(cut[0] - mid), dim3(64), 0, st, bb);
       else if (occ == 5) hipLaunchKernelGGL((sdp_build<EMIT, 1, 2, 5>), dim3(cut[0] - mid), dim3(64), 0, st, bb);
       else if (occ == 6) hipLaunchKernelGGL((sdp_build<EMIT, 1, 2, 6>), dim3(cut[0] - mid), dim3(64), 0, st, bb);
       else hipLaunchKernelGGL((sdp_build<EMIT, 1, 2>), dim3(cut[0] - mid), dim3(64), 0, st, bb);
@@ -2174,7 +2236,9 @@ int sdp_run(lra_ctx* ctx, int n_reads, const uint64_t* d_cluster_off, const uint
     BuildArgs ba;
     memset(&ba, 0, sizeof ba);
     ba.r0 = r0; ba.n = nr; ba.ptOff = ptOff; ba.hq = hq; ba.ht = ht; ba.hfl = hfl; ba.h2 = pay2; ba.key3 = key1; ba.pay3 = pay1; ba.scratch = scratch;
-    ba.cntEntries = cntE; ba.cntNodes = cntN; ba.cntD = cntD; ba.cntV = cntV; ba.cntRC = cntRC; ba.status = status; ba.order = order;
+    ba.cntEntries = cntE; ba.cntNodes = cntN; ba.cntD = cntD; ba.cntV = cntV; ba.cntRC = cntRC; ba.status = status; ba.order = order; ba.stat = nullptr;
+    static const bool buildStat = getenv("LRA_SDP_BUILD_STAT") != nullptr;
+    if (buildStat) { (void)hipMalloc((void**)&ba.stat, 16 * 8); (void)hipMemsetAsync(ba.stat, 0, 16 * 8, st); }
     // the count pass: the same divide as the emit pass, for the sizes of a read's blocks -- run for everything only on request (LRA_SDP_ONEPASS=0, LRA_SDP_RATIOS);
     // otherwise the blocks are laid out from k_arena_estimate and only the reads that outgrow them are counted (attempt 1 below)
     const bool onePassEnv = !(getenv("LRA_SDP_ONEPASS") && getenv("LRA_SDP_ONEPASS")[0] == '0');
@@ -2377,6 +2441,13 @@ int sdp_run(lra_ctx* ctx, int n_reads, const uint64_t* d_cluster_off, const uint
       LRA_HIP_CHECK(ctx, hipMemcpyAsync(order2, h_sub.data(), (size_t)nsub * 4, hipMemcpyHostToDevice, st));
       LRA_HIP_CHECK(ctx, hipStreamSynchronize(st));
       subOrder = order2;
+    }
+    if (ba.stat) {
+      unsigned long long hb[16];
+      (void)hipStreamSynchronize(st); (void)hipMemcpy(hb, ba.stat, sizeof hb, hipMemcpyDeviceToHost); (void)hipFree(ba.stat); ba.stat = nullptr;
+      const double pts = (double)std::max<unsigned long long>(hb[8], 1);
+      fprintf(stderr, "[sdp-build-stat] mode %d inner %d reads %d; the wave-per-read builds of 513 .. 16383 points, %llu points; cycles per point: set-up %.1f family %.1f | per level pass A %.1f C %.1f D %.1f E %.1f F %.1f G %.1f\n", opts->mode, (int)ctx->sdp_inner, nr,
+              hb[8], hb[0] / pts, hb[7] / pts, hb[1] / pts, hb[2] / pts, hb[3] / pts, hb[4] / pts, hb[5] / pts, hb[6] / pts);
     }
     if (onePass) { int rc = read_rc(); if (rc) return rc; }                 // (entries as emitted last, re-built reads included)
     totalEntries += totE;
