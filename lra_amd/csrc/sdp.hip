@@ -987,9 +987,9 @@ __device__ bool coop_grow_pairs(int2* pairs, uint32_t& off, int& cap, int used, 
 template <bool STAT>
 __global__ void __launch_bounds__(64, 4) sdp_process(ProcArgs a) {
   // STAT (LRA_SDP_STAT): cycles per section of a point's visit and the lengths of its loops, summed over the launch -- an instantiation of its own (the counters' registers)
-  __shared__ unsigned long long sT[STAT ? 10 : 1], sC[STAT ? 12 : 1];     // (in LDS: the production kernel's registers are what the counters would take)
+  __shared__ unsigned long long sT[STAT ? 10 : 1], sC[STAT ? 20 : 1];     // (in LDS: the production kernel's registers are what the counters would take)
   unsigned long long tPrev = 0;
-  if (STAT) { if (threadIdx.x < 10) sT[threadIdx.x] = 0; if (threadIdx.x < 12) sC[threadIdx.x] = 0; tPrev = __builtin_amdgcn_s_memtime(); }
+  if (STAT) { if (threadIdx.x < 10) sT[threadIdx.x] = 0; if (threadIdx.x < 20) sC[threadIdx.x] = 0; tPrev = __builtin_amdgcn_s_memtime(); }
 #define TICK(k_) do { if (STAT) { if (a.dbg == 2) __builtin_amdgcn_s_waitcnt(0); const unsigned long long t__ = __builtin_amdgcn_s_memtime(); if (threadIdx.x == 0) sT[k_] += t__ - tPrev; tPrev = t__; } } while (0)
 #define CNT(k_, x_) do { const unsigned long long x__ = (unsigned long long)(x_); if (threadIdx.x == 0) sC[k_] += x__; } while (0)
 #define WMAX(x_) ([&]() { int m__ = (x_); for (int o__ = 32; o__ > 0; o__ >>= 1) m__ = max(m__, __shfl_xor(m__, o__)); return m__; }())
@@ -1120,6 +1120,8 @@ __global__ void __launch_bounds__(64, 4) sdp_process(ProcArgs a) {
         if (!cTopOk) { tx = sTop <= 1 ? -1 : sT.x; sx = sTop <= 2 ? -1 : sS.x; lastB = bL; }
       }
       const bool need = now != -1;
+      const int pfTx = pfTok ? tx : SX_UNK;                               // the D index pfT was read for
+      const int nBlk0 = nBlk; const uint32_t blkOff0 = blkOff;
       TICK(3);
       // phase 1a, every lane for itself: short insertion runs (most queries advance `now` by a few candidates only) -- the same loop
       // as below, literal and lane-local, all lanes at once
@@ -1241,7 +1243,7 @@ __global__ void __launch_bounds__(64, 4) sdp_process(ProcArgs a) {
       // phase 2, every lane for its own sub-problem: the flush of Maximization :438-453 (only its `now == m - 1` branch ever pops), FindValueInBlock :322-333, Ev / Ep
       float ev = -1.f;
       bool got = false;
-      int nFl = 0, nSr = 0;
+      int nFl = 0, nSr = 0, nLd = 0, nBs = 0, nCh = 0;
       if (need && !st) {
 #define BPUSH2(val_) do { const int2 v__ = (val_); if (nBlk >= bCap) { if (!grow_pairs(pairs, blkOff, bCap, nBlk, poolUsed, poolPair, poolPairs)) st |= LRA_ST_CAPACITY; } \
                           if (nBlk < bCap) (pairs + blkOff)[nBlk] = v__; nBlk++; lastB = v__; } while (0)
@@ -1258,6 +1260,7 @@ __global__ void __launch_bounds__(64, 4) sdp_process(ProcArgs a) {
         if (!st && nBlk > 0) {
           if (i1 >= lastB.y) i2 = tx;                                     // (i1 < top.second always)
           else {
+            if (STAT) { nBs = nBlk; nCh = (nBlk != nBlk0 || blkOff != blkOff0) ? 1 : 0; }
             int lo = 0, cnt = nBlk, bx = -1;                              // UPPERbound :205-221, two levels per memory round; the search ends at the position of its most
             while (cnt > 0) {                                             // recent false probe (or at the end): Block[lo].first is that probe's pair, no further load
               if (STAT) nSr++;
@@ -1277,7 +1280,11 @@ __global__ void __launch_bounds__(64, 4) sdp_process(ProcArgs a) {
         }
         if (st || i2 < 0 || i2 >= m) st |= st ? st : LRA_ST_OOB_SLOT;
         else {
-          const Ent d2 = (ent + nd.dBase)[i2];
+          // (the answer is the stack top more often than not, and when nothing was pushed in this visit its D entry came with the visit's first loads)
+          Ent d2;
+          if (i2 == pfTx) d2 = pfT;
+          else if (i2 == pfSx) { d2.v = pfSv; d2.val = pfSd; d2.b = 0; }
+          else { d2 = (ent + nd.dBase)[i2]; if (STAT) nLd = 1; }
           ev = d2.v + W(d2.val, ei1) + rate * a.flen[f0 + lf];            // :1040
           got = true;
           Ap[nd.dBase + nd.nD + i1] = (uint32_t)i2;                       // Ep[i1] (Ev[i1] is never read again)
@@ -1286,7 +1293,7 @@ __global__ void __launch_bounds__(64, 4) sdp_process(ProcArgs a) {
           cTop = make_int2(tx, sx); cLastB = lastB; cTopOk = true;
         }
       }
-      if (STAT) { const int mf = WMAX(nFl), ms = WMAX(nSr); CNT(10, mf); CNT(11, ms); TICK(6); }
+      if (STAT) { const int mf = WMAX(nFl), ms = WMAX(nSr), ml = WMAX(nLd), mb = WMAX(nBs), mc = WMAX(nCh), m2 = WMAX(nIt >= 2 ? 1 : 0); CNT(10, mf); CNT(11, ms); CNT(12, ml); CNT(13, ms > 0); CNT(14, mc); CNT(15, mb); CNT(16, m2); TICK(6); }
       const uint32_t myI1 = v.y;
       if (__ballot(st != 0)) { for (int o = 32; o > 0; o >>= 1) st |= __shfl_xor(st, o); }   // (a status is rare: no exchange unless a lane has one)
       bad |= st;
@@ -1310,7 +1317,7 @@ __global__ void __launch_bounds__(64, 4) sdp_process(ProcArgs a) {
     wave_sync();
     TICK(ind ? 9 : 8);
   }
-  if (STAT && lane == 0 && a.stat) { for (int k = 0; k < 10; k++) atomicAdd(a.stat + k, sT[k]); for (int k = 0; k < 12; k++) atomicAdd(a.stat + 10 + k, sC[k]); }
+  if (STAT && lane == 0 && a.stat) { for (int k = 0; k < 10; k++) atomicAdd(a.stat + k, sT[k]); for (int k = 0; k < 20; k++) atomicAdd(a.stat + 10 + k, sC[k]); }
   if (cDirty && cId != NONE) { Node* op = nodes + cId; op->last = cn.last; op->sTop = cn.sTop; op->nBlk = cn.nBlk; op->stkOff = cn.stkOff; op->stkCap = cn.stkCap; op->blkOff = cn.blkOff; op->blkCap = cn.blkCap; }
   if (lane == 0 && bad) atomicOr(&a.status[r], bad);
 #undef W
@@ -2394,7 +2401,7 @@ int sdp_run(lra_ctx* ctx, int n_reads, const uint64_t* d_cluster_off, const uint
       if (nsub > nbig) {
         ProcArgs pb = pa; pb.order = subOrder + nbig; pb.n = nsub - nbig; pb.stat = nullptr;
         if (statEnv > 0) {
-          (void)hipMalloc((void**)&d_stat, 32 * 8); (void)hipMemsetAsync(d_stat, 0, 32 * 8, st);
+          (void)hipMalloc((void**)&d_stat, 40 * 8); (void)hipMemsetAsync(d_stat, 0, 40 * 8, st);
           pb.stat = d_stat; pb.dbg = statEnv;
           hipLaunchKernelGGL(sdp_process<true>, dim3(nsub - nbig), dim3(64), 0, st, pb);
         } else hipLaunchKernelGGL(sdp_process<false>, dim3(nsub - nbig), dim3(64), 0, st, pb);
@@ -2402,13 +2409,13 @@ int sdp_run(lra_ctx* ctx, int n_reads, const uint64_t* d_cluster_off, const uint
       if (forked) lra_side_join(ctx);
       lra_time_end(ctx);
       if (d_stat) {
-        unsigned long long hs[32];
+        unsigned long long hs[40];
         (void)hipStreamSynchronize(st); (void)hipMemcpy(hs, d_stat, sizeof hs, hipMemcpyDeviceToHost); (void)hipFree(d_stat);
         const double ne = (double)std::max<unsigned long long>(hs[10], 1), ns = (double)std::max<unsigned long long>(hs[11], 1);
         fprintf(stderr, "[sdp-stat] mode %d inner %d reads %d: end points %llu (switch %.2f, %.1f lanes) cycles: switch %.0f deposit %.0f sync %.0f | start points %llu (switch %.2f, %.1f lanes) cycles: switch %.0f "
-                "first %.0f small %.0f coop %.0f flush+search %.0f result %.0f sync %.0f | per start point: small iters (max lane) %.2f pops %.2f with-small %.2f coop owners %.3f flush %.2f search rounds %.2f\n",
+                "first %.0f small %.0f coop %.0f flush+search %.0f result %.0f sync %.0f | per start point: small iters (max lane) %.2f pops %.2f with-small %.2f coop owners %.3f flush %.2f search rounds %.2f | answer's entry read %.2f, a lane searches %.2f (its Block list changed in the visit %.2f, longest list %.1f), a lane with two candidates or more %.2f\n",
                 opts->mode, (int)ctx->sdp_inner, nsub - nbig, hs[10], hs[12] / ne, hs[14] / ne, hs[0] / ne, hs[2] / ne, hs[8] / ne, hs[11], hs[13] / ns, hs[15] / ns, hs[1] / ns, hs[3] / ns, hs[4] / ns, hs[5] / ns,
-                hs[6] / ns, hs[7] / ns, hs[9] / ns, hs[16] / ns, hs[17] / ns, hs[18] / ns, hs[19] / ns, hs[20] / ns, hs[21] / ns);
+                hs[6] / ns, hs[7] / ns, hs[9] / ns, hs[16] / ns, hs[17] / ns, hs[18] / ns, hs[19] / ns, hs[20] / ns, hs[21] / ns, hs[22] / ns, hs[23] / ns, hs[24] / ns, hs[25] / std::max(1.0, (double)hs[23]), hs[26] / ns);
       }
       if (dbg) {
         (void)hipEventRecord(e1, st); (void)hipEventSynchronize(e1);
