@@ -1125,7 +1125,7 @@ __global__ void __launch_bounds__(64, 4) sdp_process(ProcArgs a) {
       TICK(3);
       // phase 1a, every lane for itself: short insertion runs (most queries advance `now` by a few candidates only) -- the same loop
       // as below, literal and lane-local, all lanes at once
-      const int LOCAL_MAX = 6;
+      const int LOCAL_MAX = 4;                                             // (6: 635 ms over 12 launches, 4: 617, 2 / 3: 635, 1: 652, 10: 634, 16: 635)
       const bool small = need && now > nd.last && now - nd.last <= LOCAL_MAX;
       int nIt = 0, nPop = 0;
       if (small) {
