@@ -51,8 +51,18 @@ __device__ __forceinline__ void wave_sync() {
   __builtin_amdgcn_wave_barrier();
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
 }
+// Inclusive prefix sum over the wave: four DPP row shifts (a row = 16 lanes; nothing is shifted in across a row's start), then the two row broadcasts (rows 1 and 3 take
+// lane 15 of the row before them, rows 2 and 3 lane 31) -- six VALU operations where six __shfl_up are six dependent trips through the LDS crossbar.
 __device__ __forceinline__ int wave_incl_scan(int v, int lane) {
-  for (int d = 1; d < 64; d <<= 1) { int o = __shfl_up(v, d); if (lane >= d) v += o; }
+  (void)lane;
+#define LRA_DPP_ADD(ctrl_, rmask_) v += __builtin_amdgcn_update_dpp(0, v, (ctrl_), (rmask_), 0xf, false)
+  LRA_DPP_ADD(0x111, 0xf);   // row_shr:1
+  LRA_DPP_ADD(0x112, 0xf);   // row_shr:2
+  LRA_DPP_ADD(0x114, 0xf);   // row_shr:4
+  LRA_DPP_ADD(0x118, 0xf);   // row_shr:8
+  LRA_DPP_ADD(0x142, 0xa);   // row_bcast:15
+  LRA_DPP_ADD(0x143, 0xc);   // row_bcast:31
+#undef LRA_DPP_ADD
   return v;
 }
 
@@ -289,7 +299,7 @@ struct BuildArgs {
 template <int NW>
 __device__ __forceinline__ int blk_incl_scan(int v, int lane, int wave, int* s_w, int& total) {
   const int inc = wave_incl_scan(v, lane);
-  if (NW == 1) { total = __shfl(inc, 63); return inc; }
+  if (NW == 1) { total = __builtin_amdgcn_readlane(inc, 63); return inc; }
   if (lane == 63) s_w[wave] = inc;
   __syncthreads();
   int pre = 0, tot = 0;
