@@ -382,6 +382,9 @@ __global__ void __launch_bounds__(64 * NW, NW == 1 ? OCC : 1) sdp_build(BuildArg
       for (int w = 0; w < NW; w++) { c0 += s_w[0][w]; c1 += s_w[1][w]; c2 += s_w[2][w]; c3 += s_w[3][w]; }
       __syncthreads();
     }
+    // (the same number in every lane, but made by shuffles: said to be uniform, the class boundaries live in scalar registers -- as vector registers they are live through the
+    // whole kernel and are what the register allocator spills to scratch, to be read back inside every level)
+    c0 = __builtin_amdgcn_readfirstlane(c0); c1 = __builtin_amdgcn_readfirstlane(c1); c2 = __builtin_amdgcn_readfirstlane(c2);
     cOff[0] = 0; cOff[1] = c0; cOff[2] = c0 + c1; cOff[3] = c0 + c1 + c2; cOff[4] = P;
   }
   SYNC();
