@@ -611,7 +611,8 @@ __global__ void __launch_bounds__(64) ir_fill_wide(FillArgs F) {
   while (true) {
     long x = 0;
     if (lane == 0) x = atomicAdd(&F.cursor[3], 1);
-    x = __shfl(x, 0);
+    // (lane 0's value as a SCALAR: through a shuffle it is a vector value to the compiler, and with it the segment, its rows, every loop bound below)
+    x = (long)(((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)((unsigned long long)x >> 32)) << 32) | (unsigned)__builtin_amdgcn_readfirstlane((int)(x & 0xffffffffL)));
     if (x >= listEnd) break;
     const uint64_t s = F.list[x];
     const int a = F.s_aln[s];
