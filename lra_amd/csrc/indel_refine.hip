@@ -55,6 +55,14 @@ __device__ __forceinline__ void wave_sync() {
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
 }
 
+// The same for LDS traffic only (a wave's LDS instructions execute in order: nothing has to be waited for -- in particular not the wave's outstanding global stores,
+// which wave_sync() drains: a store-to-acknowledge round trip per call)
+__device__ __forceinline__ void wave_sync_lds() {
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
 struct IRArgs {
   int n_aln;
   const int32_t* blocks_in; const uint64_t* block_off;
@@ -681,7 +689,7 @@ __global__ void __launch_bounds__(64) ir_fill_wide(FillArgs F) {
         }
         if (c < len) { P[C + c] = outB; sM[cur][c] = outM; sD[cur][c] = outD; }
       }
-      wave_sync();
+      wave_sync_lds();                                                       // (the rows meet in sM / sD only; the arrows are written and never read here)
       prevS = S; prevLen = len;
     }
   }
