@@ -44,7 +44,7 @@ def host_cpus():
     return hw, hw
 
 
-def cpu_baseline(mapper, reads_h, off_h, args, last_res=None):
+def cpu_baseline(mapper, reads_h, off_h, args, last_res=None, opts=None, sample=None, res_mapper=None):
     """The oracle (CPU restatement) on the host's cores, on a bounded sample of the same batch: MapRead_lowacc read by read
     (oracle_map_reads_lowacc_mt, oracle/pipeline.cpp: the same stages in the same order as the GPU step; tests/test_mapread.py compares its
     alignments with the GPU's bit for bit) on all hardware threads."""
@@ -59,18 +59,21 @@ def cpu_baseline(mapper, reads_h, off_h, args, last_res=None):
     g = ctx.to_host(ctx.lib.lra_ctx_genome_ptr(ctx.h), mapper.G, np.uint8).tobytes() + b"\0" * 64
     g_index = mapper.fetch_local_index()
     fetch_s = time.time() - t0
-    opts = dict(globalK=args.k, globalW=args.w, globalMaxFreq=args.max_freq, refineBand=args.refine_band, localIndexWindow=args.local_window)
+    if opts is None:                                                        # (tools/bench_presets.py hands over another preset's options)
+        opts = dict(globalK=args.k, globalW=args.w, globalMaxFreq=args.max_freq, refineBand=args.refine_band, localIndexWindow=args.local_window)
     n_threads, hw_threads = host_cpus()                                       # the CPUs the box gives this process (its cgroup quota), not the threads it lists
     # a bounded sample: about 10-30 s of wall time
     S = int(min(len(off_h) - 1, 4096, max(512, 8 * n_threads)))
     if os.environ.get("LRA_BENCH_CPU_SAMPLE"):                               # (a wider parity sweep: the whole batch takes ~2 minutes on 256 threads)
         S = int(min(len(off_h) - 1, int(os.environ["LRA_BENCH_CPU_SAMPLE"])))
+    if sample:
+        S = int(min(len(off_h) - 1, int(sample)))
     res = OP.map_reads_lowacc_mt(reads_h, off_h, 0, S, g, key, pos, g_index, opts, mapper.chrom_pos, n_threads=n_threads)
     # The same reads' alignments as the last GPU step left them (refined blocks + the 18 counters of every SegAlignment), folded the way the oracle folds its own
     # (oracle/pipeline.cpp: oracle_map_reads_lowacc_mt): the sample is also a parity check at the benchmark's scale.
     parity = None
     if last_res is not None:
-        out = mapper.fetch(last_res)
+        out = (res_mapper or mapper).fetch(last_res)                        # (two-stage batches: the result lives on the back context)
         na = int(last_res.num_aln)
         P = np.uint64(1099511628211)
         total = np.uint64(0)

@@ -27,6 +27,8 @@ def main():
     ap.add_argument("--gli", type=int, default=1, help="1: the local index as `lra index` writes it (k = 10, w = 5, windows of 2048 bases: what glIndex.Read hands `lra align`); "
                                                        "0: `lra align` without a .gli file (opts.localK, windows of 256 bases)")
     ap.add_argument("--two-stage", type=int, default=0, help="-CLR only: two-stage batches (lra_map_reads_lowacc_front / _back), as bench.py runs the headline step")
+    ap.add_argument("--oracle-sample", type=int, default=0, help="-CLR only: the first N reads of the batch through the oracle's MapRead_lowacc on the host's cores as well "
+                                                                  "(bench.py's cpu_baseline with the -CLR options): its rate, and whether its alignments equal the last step's")
     args = ap.parse_args()
     import torch
     from lra_amd.context import Context
@@ -125,6 +127,13 @@ def main():
             hh.update(np.ascontiguousarray(out[k]).tobytes())
     aligned = int(sum(1 for r in range(n_reads) if out["job_aln_off"][r * int(res.num_aln) + int(res.num_aln)] > out["job_aln_off"][r * int(res.num_aln)]))
     free_b, tot_b = torch.cuda.mem_get_info()
+    cpu = None
+    if args.oracle_sample and args.preset == "clr":
+        sys.path.insert(0, os.path.join(ROOT, "tests"))
+        import bench
+        import oracle_pipeline as OP
+        oo = dict(OP.CLR, localIndexWindow=mopts.localIndexWindow)
+        cpu = bench.cpu_baseline(mapper, np.frombuffer(reads_h, np.uint8), off_h, None, res, opts=oo, sample=args.oracle_sample, res_mapper=last[1] if two_stage else None)
     print(json.dumps({
         "metric": "aligned Gbp/s (%s)" % {"ccs": "15 kb CCS vs a chr20-sized reference, -CCS, MapRead_highacc end to end incl. SAM text",
                                           "clr": "20 kb CLR vs the GRCh38-like reference, -CLR, MapRead_lowacc end to end incl. SAM text",
@@ -135,7 +144,7 @@ def main():
                    "reference_bp": int(chrom_pos[-1]), "index_entries": int(mapper.index_stats.get("n_index", 0)),
                    "local_index": "k 10, w 5, windows of 2048 bases (the .gli file `lra index` writes)" if args.gli else "the options' localK, windows of 256 bases (`lra align` without a .gli file)"},
         "reads_with_an_alignment": aligned, "reads_flagged": flagged, "n_alignments": int(res.n_alignments), "sam_text_mb": text[0] / 1e6,
-        "result_sha256": hh.hexdigest(), "two_stage": two_stage, "setup_s": round(setup_s, 1), "hbm_used_gb": round((tot_b - free_b) / 1e9, 1)}))
+        "cpu_baseline": cpu, "result_sha256": hh.hexdigest(), "two_stage": two_stage, "setup_s": round(setup_s, 1), "hbm_used_gb": round((tot_b - free_b) / 1e9, 1)}))
 
 
 if __name__ == "__main__":
