@@ -78,9 +78,17 @@ def cpu_baseline(mapper, reads_h, off_h, args, last_res=None, opts=None, sample=
         P = np.uint64(1099511628211)
         total = np.uint64(0)
         with np.errstate(over="ignore"):
+            reached = out.get("job_reached")
             for r in range(S):
-                a0, a1 = int(out["job_aln_off"][r * na]), int(out["job_aln_off"][(r + 1) * na])
-                if out["read_status"][r] or a1 == a0:
+                # the loop over the primary chains p as Map_lowacc.h:259-267, :486-491 run it (and lra_map_records_host reads the result): a chain that does not reach its
+                # SegAlignmentGroup ends the loop -- at p = 0 the read is unaligned whatever the later chains hold
+                a0 = int(out["job_aln_off"][r * na]); a1 = a0
+                for p_ in range(na):
+                    j = r * na + p_
+                    if reached is not None and len(reached) and not reached[j]:
+                        break
+                    a1 = int(out["job_aln_off"][j + 1])
+                if out["read_status"][r] or a1 == a0 or int(out["job_aln_off"][r * na + 1]) == a0:                       # (p = 0 without a SegAlignment: unaligned, :578-581)
                     continue
                 parts = []
                 for a in range(a0, a1):

@@ -159,6 +159,20 @@ __global__ void k_job_reached(uint64_t n_slots, int num_aln, const uint32_t* __r
   reached[s] = ok ? 1 : 0;
 }
 
+// The loop over p ENDS at the first chain that does not reach :574 (p > 0: break, :267 / :491; p == 0: the read is unaligned): the chains behind it are never mapped.
+// Their slots are switched off here (every later stage skips a marked slot, as for a deferred read), so the device's result holds no alignment the reference would not
+// have made -- lra_map_records* ends a read's loop at the same place either way.
+__global__ void k_cut_behind_unreached(int n_reads, int num_aln, uint32_t* __restrict__ sp_status, uint8_t* __restrict__ reached) {
+  const int r = blockIdx.x * blockDim.x + threadIdx.x;
+  if (r >= n_reads) return;
+  bool off = false;
+  for (int h = 0; h < num_aln; h++) {
+    const uint64_t s = (uint64_t)r * num_aln + h;
+    if (off) { if (reached[s]) { reached[s] = 0; sp_status[s] |= (uint32_t)LRA_ST_DEFERRED; } }
+    else if (!reached[s]) off = true;
+  }
+}
+
 // per alignment: which read, where its strand's bases start, where its chromosome starts and how long it is
 __global__ void k_aln_address(uint64_t n_jobs, int num_aln, const uint64_t* __restrict__ job_aln_off, const int32_t* __restrict__ strand,
                               const int32_t* __restrict__ chrom, const uint64_t* __restrict__ read_off, uint64_t rc_base,
@@ -657,6 +671,7 @@ static int lowacc_core(lra_ctx* ctx, int n_reads, const char* d_seq, const uint6
                      bres.d_match_off, job_reached);
   if (rres.n_frags) hipLaunchKernelGGL(k_or_status_split, grid(n_slots), dim3(256), 0, st, n_slots, num_aln, chres.d_n_chains, chres.d_chain_start, spres.d_n_split,
                                        spres.d_status, rres.d_status, read_status);
+  hipLaunchKernelGGL(k_cut_behind_unreached, grid((uint64_t)n_reads), dim3(256), 0, st, n_reads, num_aln, (uint32_t*)spres.d_status, job_reached);
   // counters of the stages so far
   lra_map_counters cnt0; memset(&cnt0, 0, sizeof cnt0);
   cnt0.n_minimizers = sres.n_minimizers; cnt0.n_matches = sres.n_matches; cnt0.n_clusters = cres.n_clusters; cnt0.n_sdp_anchors = chres.n_frags; cnt0.n_sdp_points = chres.n_points;
