@@ -27,6 +27,7 @@ def main():
     ap.add_argument("--gli", type=int, default=1, help="1: the local index as `lra index` writes it (k = 10, w = 5, windows of 2048 bases: what glIndex.Read hands `lra align`); "
                                                        "0: `lra align` without a .gli file (opts.localK, windows of 256 bases)")
     ap.add_argument("--two-stage", type=int, default=0, help="-CLR only: two-stage batches (lra_map_reads_lowacc_front / _back), as bench.py runs the headline step")
+    ap.add_argument("--sv-frac", type=float, default=0.05, help="fraction of reads carrying one planted structural variant")
     ap.add_argument("--oracle-sample", type=int, default=0, help="-CLR only: the first N reads of the batch through the oracle's MapRead_lowacc on the host's cores as well "
                                                                   "(bench.py's cpu_baseline with the -CLR options): its rate, and whether its alignments equal the last step's")
     args = ap.parse_args()
@@ -50,7 +51,7 @@ def main():
         mapper = mapread.HighAccMapper(ctx, genome, None, None, chrom_names, chrom_pos, args.preset, gli=bool(args.gli) or None)
     torch.cuda.synchronize()
     setup_s = time.time() - t0
-    sim = sg.simulate_reads_sv(genome, chrom_pos, n_reads, read_len, read_len / 10, P["err"], P["mix"], 1000, sv_frac=0.05)
+    sim = sg.simulate_reads_sv(genome, chrom_pos, n_reads, read_len, read_len / 10, P["err"], P["mix"], 1000, sv_frac=args.sv_frac)
     off_h = sim["off"].cpu().numpy()
     total = int(off_h[-1])
     reads_h = sim["seq"][:total].cpu().numpy().tobytes()

@@ -17,6 +17,8 @@ def main():
     ap.add_argument("--preset", choices=["ont", "clr"], default="clr")
     ap.add_argument("--reads", type=int, default=28672)
     ap.add_argument("--max-report", type=int, default=12)
+    ap.add_argument("--sv-frac", type=float, default=0.05)
+    ap.add_argument("--only-flagged", action="store_true", help="no oracle: the status words of the reads the device flagged")
     args = ap.parse_args()
     import torch
     import oracle_lib as O
@@ -33,7 +35,7 @@ def main():
         mopts = mapread.with_gli(mapread.LowAccOptions()); ip = (17, 10, 150, 12, 1); rl, err, mix = 30000, 0.10, (30, 35, 35); oo = dict(OP.ONT)
     oo["localIndexWindow"] = mopts.localIndexWindow
     mapper = mapread.LowAccMapper(ctx, genome, None, None, chrom_names, chrom_pos, mopts, index_params=ip, staged=False)
-    sim = sg.simulate_reads_sv(genome, chrom_pos, args.reads, rl, rl / 10, err, mix, 1000, sv_frac=0.05)
+    sim = sg.simulate_reads_sv(genome, chrom_pos, args.reads, rl, rl / 10, err, mix, 1000, sv_frac=args.sv_frac)
     off_h = sim["off"].cpu().numpy(); total = int(off_h[-1])
     reads_h = np.frombuffer(sim["seq"][:total].cpu().numpy().tobytes(), np.uint8)
     del genome
@@ -42,6 +44,10 @@ def main():
     res = mapper.align(rbatch)
     out = mapper.fetch(res)
     na = int(res.num_aln)
+    fl = np.nonzero(out["read_status"])[0]
+    print(json.dumps({"flagged_reads": [{"read": int(r), "status": "0x%x" % int(out["read_status"][r]), "length": int(off_h[r + 1] - off_h[r])} for r in fl[:20]]}))
+    if args.only_flagged:
+        return
     P = np.uint64(1099511628211)
     n = args.reads
     hs = np.zeros(n, np.uint64); nal = np.zeros(n, np.int64)

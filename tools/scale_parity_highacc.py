@@ -57,6 +57,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--preset", choices=["ccs", "contig"], default="ccs")
     ap.add_argument("--sample", type=int, default=1000)
+    ap.add_argument("--sv-frac", type=float, default=0.05, help="fraction of reads carrying one planted structural variant")
     ap.add_argument("--reads", type=int, default=0)
     args = ap.parse_args()
     import torch
@@ -71,7 +72,7 @@ def main():
     genome, chrom_pos, chrom_names = sg.make_grch38_like(dev, scale=P["scale"], seed=3)
     ctx = Context(0)
     mapper = mapread.HighAccMapper(ctx, genome, None, None, chrom_names, chrom_pos, args.preset, gli=True)
-    sim = sg.simulate_reads_sv(genome, chrom_pos, n_reads, P["read_len"], P["read_len"] / 10, P["err"], (34, 33, 33), 1000, sv_frac=0.05)
+    sim = sg.simulate_reads_sv(genome, chrom_pos, n_reads, P["read_len"], P["read_len"] / 10, P["err"], (34, 33, 33), 1000, sv_frac=args.sv_frac)
     off_h = sim["off"].cpu().numpy(); total = int(off_h[-1])
     reads_h = np.frombuffer(sim["seq"][:total].cpu().numpy().tobytes(), np.uint8)
     del genome
