@@ -997,7 +997,10 @@ typedef struct lra_map_result {
   int32_t n_reads, num_aln;
   uint64_t n_jobs, n_alignments, n_blocks, n_runs;
   const uint64_t* d_job_aln_off; const uint32_t* d_job_status;
-  const uint8_t* d_job_reached;     /* [n_jobs] 1: primary chain p reached Map_lowacc.h:574 (its SegAlignmentGroup exists, possibly empty) */
+  const uint8_t* d_job_reached;     /* [n_jobs] 1: primary chain p reached Map_lowacc.h:574 (its SegAlignmentGroup exists, possibly empty).  The reference's loop over p ENDS at
+                                     * the first chain that does not (p > 0: break, :267 / :491; p == 0: the read is unaligned): the low-accuracy driver maps no chain behind
+                                     * it (their flags are 0, they have no alignments).  One rule is left to the reader of these arrays, as lra_map_records* apply it: a read
+                                     * whose chain 0 reached :574 but got no SegAlignment is unaligned whatever its later chains hold (:578-581) */
   const uint32_t* d_read_status;    /* [n_reads] OR of every stage's LRA_ST_* bits for the read; non-zero = not bit-identical, no record is emitted */
   const uint32_t* d_aln_read; const int32_t* d_strand; const int32_t* d_supp; const int32_t* d_secondary; const int32_t* d_n0; const int32_t* d_n1;
   const int32_t* d_chrom; const float* d_first_sdp_value;
