@@ -27,6 +27,7 @@ def main():
     ap.add_argument("--gli", type=int, default=1, help="1: the local index as `lra index` writes it (k = 10, w = 5, windows of 2048 bases: what glIndex.Read hands `lra align`); "
                                                        "0: `lra align` without a .gli file (opts.localK, windows of 256 bases)")
     ap.add_argument("--two-stage", type=int, default=0, help="-CLR only: two-stage batches (lra_map_reads_lowacc_front / _back), as bench.py runs the headline step")
+    ap.add_argument("--err", type=float, default=0.0, help="the reads' error rate (default: the preset's)")
     ap.add_argument("--sv-frac", type=float, default=0.05, help="fraction of reads carrying one planted structural variant")
     ap.add_argument("--oracle-sample", type=int, default=0, help="-CLR only: the first N reads of the batch through the oracle's MapRead_lowacc on the host's cores as well "
                                                                   "(bench.py's cpu_baseline with the -CLR options): its rate, and whether its alignments equal the last step's")
@@ -40,6 +41,8 @@ def main():
          "clr": dict(reads=28672, read_len=20000, err=0.15, scale=1.0, mix=(20, 30, 50)),
          "contig": dict(reads=1024, read_len=1000000, err=0.002, scale=1.0, mix=(34, 33, 33))}[args.preset]
     n_reads = args.reads or P["reads"]; read_len = args.read_len or P["read_len"]; scale = args.genome_scale or P["scale"]
+    if args.err > 0:
+        P["err"] = args.err
     t0 = time.time()
     genome, chrom_pos, chrom_names = sg.make_grch38_like(dev, scale=scale, seed=3)
     torch.cuda.synchronize()

@@ -57,8 +57,10 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--preset", choices=["ccs", "contig"], default="ccs")
     ap.add_argument("--sample", type=int, default=1000)
+    ap.add_argument("--err", type=float, default=0.0, help="the reads' error rate (default: the preset's)")
     ap.add_argument("--sv-frac", type=float, default=0.05, help="fraction of reads carrying one planted structural variant")
     ap.add_argument("--reads", type=int, default=0)
+    ap.add_argument("--read-len", type=int, default=0)
     args = ap.parse_args()
     import torch
     import oracle_lib as O
@@ -69,10 +71,12 @@ def main():
     dev = torch.device("cuda", 0); torch.cuda.set_device(0)
     P = {"ccs": dict(reads=50000, read_len=15000, err=0.01, scale=64.4e6 / 3.09e9), "contig": dict(reads=1024, read_len=1000000, err=0.002, scale=1.0)}[args.preset]
     n_reads = args.reads or P["reads"]
+    if args.err > 0:
+        P["err"] = args.err
     genome, chrom_pos, chrom_names = sg.make_grch38_like(dev, scale=P["scale"], seed=3)
     ctx = Context(0)
     mapper = mapread.HighAccMapper(ctx, genome, None, None, chrom_names, chrom_pos, args.preset, gli=True)
-    sim = sg.simulate_reads_sv(genome, chrom_pos, n_reads, P["read_len"], P["read_len"] / 10, P["err"], (34, 33, 33), 1000, sv_frac=args.sv_frac)
+    sim = sg.simulate_reads_sv(genome, chrom_pos, n_reads, args.read_len or P["read_len"], (args.read_len or P["read_len"]) / 10, P["err"], (34, 33, 33), 1000, sv_frac=args.sv_frac)
     off_h = sim["off"].cpu().numpy(); total = int(off_h[-1])
     reads_h = np.frombuffer(sim["seq"][:total].cpu().numpy().tobytes(), np.uint8)
     del genome
