@@ -64,12 +64,19 @@ typedef struct lra_ctx lra_ctx;
 /* ---- context ---------------------------------------------------------------------- */
 int lra_ctx_create(int device_id, lra_ctx** out);
 void lra_ctx_destroy(lra_ctx* ctx);
+/* (ABI 9) Frees the context's growable WORK buffers -- its own, its companion contexts' (a second pass, the back half and the handover sets of two-stage batches) -- and
+ * keeps everything loaded into it (genome, chromosome table, both indexes).  The buffers grow to what the largest batch needed and are kept
+ * from call to call (a batch of 28672 reads of 30 kb holds ~250 GB of them); a caller that wants the memory back -- after a call failed with LRA_ERR_NOMEM and before it
+ * retries with a smaller batch, or between jobs -- calls this.  No batch may be in flight on the context (LRA_ERR_INVALID while a batch sits between the halves of a
+ * two-stage batch), and every result of an earlier call (lra_map_result and friends: device pointers into these buffers) is void afterwards.  The reference this
+ * boundary replaces has no counterpart: its buffers are the process heap's.  Returns the bytes freed through *bytes (may be NULL).                                  */
+int lra_ctx_release_buffers(lra_ctx* ctx, uint64_t* bytes);
 /* stream = a hipStream_t (NULL = the default stream).  All later calls launch on it. */
 int lra_ctx_set_stream(lra_ctx* ctx, void* stream);
 const char* lra_ctx_last_error(lra_ctx* ctx);
 /* ABI version of the loaded library (tests check it against this header). */
 int lra_abi_version(void);
-#define LRA_ABI_VERSION 8   /* 8: lra_map_opts_apply_local_index, lra_ctx_local_index_params, lra_ctx_load_local_index (the .gli file's k / w / window override the options', as glIndex.Read does); 7: lra_sort_pairs_batch;  2: lra_map_opts.defer_matches, lra_map_counters.n_deferred_reads; 3: lra_map_opts.flagged_unaligned, lra_map_counters.n_flagged_reads, lra_map_host_flagged; 4: lra_reads_last_error, a corrupt FASTQ record is LRA_ERR_INVALID; lra_map_opts.defer_seed_matches; 5: lra_seed_prefetch, lra_ctx_adopt_seed, lra_map_reads_lowacc_front / _back, lra_map_back_release; 6: a failed front half hands over an error batch (one back call per front call), separate n_handed_back_reads counter, lra_map_host_trim */
+#define LRA_ABI_VERSION 9   /* 9: lra_ctx_release_buffers; 8: lra_map_opts_apply_local_index, lra_ctx_local_index_params, lra_ctx_load_local_index (the .gli file's k / w / window override the options', as glIndex.Read does); 7: lra_sort_pairs_batch;  2: lra_map_opts.defer_matches, lra_map_counters.n_deferred_reads; 3: lra_map_opts.flagged_unaligned, lra_map_counters.n_flagged_reads, lra_map_host_flagged; 4: lra_reads_last_error, a corrupt FASTQ record is LRA_ERR_INVALID; lra_map_opts.defer_seed_matches; 5: lra_seed_prefetch, lra_ctx_adopt_seed, lra_map_reads_lowacc_front / _back, lra_map_back_release; 6: a failed front half hands over an error batch (one back call per front call), separate n_handed_back_reads counter, lra_map_host_trim */
 
 /* Convenience for hosts without their own HIP binding: synchronous device->host copy on the
  * context's stream (a C++ host would call hipMemcpy itself).                                */

@@ -4,7 +4,7 @@ import os
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 _LIB = None
-ABI_VERSION = 8
+ABI_VERSION = 9
 
 
 class LraError(RuntimeError):
@@ -23,6 +23,7 @@ SYMBOLS = {
     "lra_abi_version": (C.c_int, []),
     "lra_ctx_create": (C.c_int, [C.c_int, C.POINTER(_vp)]),
     "lra_ctx_destroy": (None, [_vp]),
+    "lra_ctx_release_buffers": (C.c_int, [_vp, _u64p]),
     "lra_ctx_set_stream": (C.c_int, [_vp, _vp]),
     "lra_ctx_last_error": (C.c_char_p, [_vp]),
     "lra_copy_to_host": (C.c_int, [_vp, _vp, _vp, C.c_uint64]),

@@ -63,6 +63,13 @@ class Context:
         rc = self.lib.lra_ctx_timing_get(self.h, name.encode(), C.byref(ms), C.byref(n))
         return (ms.value, n.value) if rc == 0 else (0.0, 0)
 
+    def release_buffers(self):
+        """lra_ctx_release_buffers: the context's (and its companions') growable work buffers back to the device; the reference stays loaded.  Every result of an
+        earlier call is void afterwards.  -> bytes freed"""
+        n = C.c_uint64(0)
+        self.check(self.lib.lra_ctx_release_buffers(self.h, C.byref(n)))
+        return int(n.value)
+
     def close(self):
         if self.h:
             if not getattr(self, "_borrowed", False):

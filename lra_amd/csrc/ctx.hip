@@ -11,6 +11,9 @@ int lra_set_err(lra_ctx* ctx, int code, const char* fmt, ...) {
   vsnprintf(buf, sizeof(buf), fmt, ap);
   va_end(ap);
   if (ctx) ctx->err = buf;
+  // (a failed hipMalloc leaves hipErrorOutOfMemory as the runtime's LAST ERROR; a caller that shares the process with other HIP users -- torch checks hipGetLastError
+  // after its own calls -- would be told of it long after this call has returned its own code: the library reports its errors through its return values only)
+  if (code == LRA_ERR_NOMEM) (void)hipGetLastError();
   return code;
 }
 
@@ -87,6 +90,32 @@ extern "C" int lra_ctx_create(int device_id, lra_ctx** out) {
   hipDeviceProp_t prop;
   if (hipGetDeviceProperties(&prop, device_id) == hipSuccess) c->num_cu = prop.multiProcessorCount;
   *out = c;
+  return LRA_OK;
+}
+
+bool lra_handover_idle(lra_ctx* ctx);   // mapread.hip
+void lra_seed_release_batch(lra_ctx* ctx);   // seed.hip
+extern "C" int lra_ctx_release_buffers(lra_ctx* ctx, uint64_t* bytes) {
+  if (bytes) *bytes = 0;
+  if (!ctx) return LRA_ERR_INVALID;
+  if (!lra_handover_idle(ctx)) return lra_set_err(ctx, LRA_ERR_INVALID, "lra_ctx_release_buffers: a batch is between the halves of a two-stage batch (or its result has not been released)");
+  LRA_HIP_CHECK(ctx, hipSetDevice(ctx->device));
+  uint64_t freed = 0;
+  for (lra_ctx* c = ctx; c; c = c->child) {                                // the companion contexts hang off the child chain (second pass / back half, the handover sets)
+    if (c->stream || c == ctx) (void)hipStreamSynchronize(c->stream);
+    for (int i = 0; i < lra_ctx::N_SIDE; i++) if (c->side[i]) (void)hipStreamSynchronize(c->side[i]);
+    for (int i = 0; i < 4; i++) if (c->scratch[i]) { (void)hipFree(c->scratch[i]); freed += c->scratch_bytes[i]; c->scratch[i] = nullptr; c->scratch_bytes[i] = 0; }
+    for (int i = 0; i < 192; i++) if (c->gbuf[i]) { (void)hipFree(c->gbuf[i]); freed += c->gbytes[i]; c->gbuf[i] = nullptr; c->gbytes[i] = 0; }
+    if (c->aux) { (void)hipFree(c->aux); freed += c->aux_bytes; c->aux = nullptr; c->aux_bytes = 0; }
+    if (c->out_buf) { (void)hipFree(c->out_buf); freed += c->out_bytes; c->out_buf = nullptr; c->out_bytes = 0; }
+    c->ahead.valid = false;                                                // (a seed result adopted ahead of its batch pointed into the side context's arrays: stays valid there, but the pairing is over)
+    size_t f0 = 0, f1 = 0, tot = 0;
+    (void)hipMemGetInfo(&f0, &tot);
+    lra_seed_release_batch(c);                                             // (its arrays carry no sizes: what the device says it got back)
+    (void)hipMemGetInfo(&f1, &tot);
+    if (f1 > f0) freed += f1 - f0;
+  }
+  if (bytes) *bytes = freed;
   return LRA_OK;
 }
 

@@ -541,6 +541,12 @@ struct lra_handover {
   std::string err;
 };
 void lra_handover_free(lra_ctx* ctx) { delete ctx->handover; ctx->handover = nullptr; }
+bool lra_handover_idle(lra_ctx* ctx) {                                     // lra_ctx_release_buffers: nothing handed over and not taken, no back half running or unreleased
+  lra_handover* H = ctx->handover;
+  if (!H) return true;
+  std::lock_guard<std::mutex> lk(H->mu);
+  return !H->pending && !H->busy;
+}
 static lra_handover* handover_of(lra_ctx* ctx) {                         // (the two halves' threads may both be the first to ask)
   static std::mutex make;
   std::lock_guard<std::mutex> lk(make);

@@ -986,6 +986,20 @@ int lra_seed_check_shared(lra_ctx* ctx) {
   return LRA_OK;
 }
 
+// lra_ctx_release_buffers: the seed stage's batch arrays (grown to the largest batch's minimizers / matches; the match walk's capacity-spaced buffers are the largest: three
+// slots per candidate pair) back to the device, the reference (genome, global index, bucket directory) kept.  -> bytes freed are not tracked per array: the caller reads
+// the device's free memory.
+void lra_seed_release_batch(lra_ctx* ctx) {
+  lra_seed_state* s = ctx->seed;
+  if (!s) return;
+  void** ptrs[] = {(void**)&s->counts32, (void**)&s->counts64, (void**)&s->mm_off, (void**)&s->match_off, (void**)&s->n_forward, (void**)&s->mm_key, (void**)&s->mm_pos,
+                   (void**)&s->lb, (void**)&s->ub, (void**)&s->match_qi, (void**)&s->match_ti, (void**)&s->sep_qpos, (void**)&s->sep_tpos, (void**)&s->tmp_qi, (void**)&s->tmp_ti,
+                   (void**)&s->cap_cnt, (void**)&s->cap_off, (void**)&s->tk_lb, (void**)&s->tk_lbm1, (void**)&s->tk_ubm1, (void**)&s->sep_qkey, (void**)&s->defer_flag};
+  for (void** p : ptrs) if (*p) { (void)hipFree(*p); *p = nullptr; }
+  s->cap_reads = 0; s->cap_mm = 0; s->cap_match = 0; s->cap_tmp = 0; s->cap_defer = 0;
+  s->last_n_reads = 0; s->last_n_matches = 0;
+}
+
 void lra_seed_free(lra_ctx* ctx) {
   lra_seed_state* s = ctx->seed;
   if (!s) return;
@@ -1250,7 +1264,7 @@ extern "C" int lra_seed_batch(lra_ctx* ctx, int n_reads, const char* d_seq, cons
     size_t c = (size_t)n_reads + n_reads / 4 + 64;
     if (!regrow(s->counts32, c) || !regrow(s->counts64, c) || !regrow(s->mm_off, c + 1) || !regrow(s->match_off, c + 1) ||
         !regrow(s->n_forward, c) || !regrow(s->cap_cnt, c) || !regrow(s->cap_off, c + 1))
-      return lra_set_err(ctx, LRA_ERR_NOMEM, "per-read arrays");
+      { s->cap_reads = 0; return lra_set_err(ctx, LRA_ERR_NOMEM, "per-read arrays"); }   // (capacity 0: whatever the failed group holds is re-made by the next call)
     s->cap_reads = c;
   }
   const unsigned char* seq = (const unsigned char*)d_seq;
@@ -1283,7 +1297,7 @@ extern "C" int lra_seed_batch(lra_ctx* ctx, int n_reads, const char* d_seq, cons
     size_t c = total_mm + total_mm / 4 + 1024;
     if (!regrow(s->mm_key, c) || !regrow(s->mm_pos, c) || !regrow(s->lb, c) || !regrow(s->ub, c) || !regrow(s->tk_lb, c) ||
         !regrow(s->tk_lbm1, c) || !regrow(s->tk_ubm1, c))
-      return lra_set_err(ctx, LRA_ERR_NOMEM, "minimizer arrays");
+      { s->cap_mm = 0; return lra_set_err(ctx, LRA_ERR_NOMEM, "minimizer arrays"); }
     s->cap_mm = c;
   }
   lra_time_begin(ctx, "sketch_compact");
@@ -1313,7 +1327,7 @@ extern "C" int lra_seed_batch(lra_ctx* ctx, int n_reads, const char* d_seq, cons
   LRA_HIP_CHECK(ctx, hipStreamSynchronize(st));
   if (total_cap > s->cap_tmp) {
     size_t c = total_cap + total_cap / 4 + 1024;
-    if (!regrow(s->tmp_qi, c) || !regrow(s->tmp_ti, c)) return lra_set_err(ctx, LRA_ERR_NOMEM, "match walk buffers (%llu)", (unsigned long long)total_cap);
+    if (!regrow(s->tmp_qi, c) || !regrow(s->tmp_ti, c)) { s->cap_tmp = 0; return lra_set_err(ctx, LRA_ERR_NOMEM, "match walk buffers (%llu)", (unsigned long long)total_cap); }
     s->cap_tmp = c;
   }
   // reads per wave of the walk (a lane per read): 32 for a full batch (1024 waves; more waves cost more rounds than the divergence of 32 walks costs), fewer for a small one --
@@ -1327,7 +1341,7 @@ extern "C" int lra_seed_batch(lra_ctx* ctx, int n_reads, const char* d_seq, cons
   if (s->defer_T) {
     if ((size_t)n_reads > s->cap_defer) {
       LRA_HIP_CHECK(ctx, hipStreamSynchronize(st));
-      if (!regrow(s->defer_flag, (size_t)n_reads + n_reads / 4 + 64)) return lra_set_err(ctx, LRA_ERR_NOMEM, "defer flags");
+      if (!regrow(s->defer_flag, (size_t)n_reads + n_reads / 4 + 64)) { s->cap_defer = 0; return lra_set_err(ctx, LRA_ERR_NOMEM, "defer flags"); }
       s->cap_defer = (size_t)n_reads + n_reads / 4 + 64;
     }
     hipLaunchKernelGGL(defer_heavy_kernel, dim3((n_reads + 255) / 256), dim3(256), 0, st, n_reads, s->defer_T, s->counts64, s->defer_flag);
@@ -1340,7 +1354,7 @@ extern "C" int lra_seed_batch(lra_ctx* ctx, int n_reads, const char* d_seq, cons
   if (total_m > s->cap_match) {
     size_t c = total_m + total_m / 4 + 1024;
     if (!regrow(s->match_qi, c) || !regrow(s->match_ti, c) || !regrow(s->sep_qpos, c) || !regrow(s->sep_tpos, c) || !regrow(s->sep_qkey, c))
-      return lra_set_err(ctx, LRA_ERR_NOMEM, "match arrays (%llu matches)", (unsigned long long)total_m);
+      { s->cap_match = 0; return lra_set_err(ctx, LRA_ERR_NOMEM, "match arrays (%llu matches)", (unsigned long long)total_m); }
     s->cap_match = c;
   }
   // ---- a4

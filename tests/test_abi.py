@@ -24,7 +24,7 @@ def test_library_exports_every_declared_symbol():
         assert hasattr(lib, n), "missing export: " + n
     assert sorted(SYMBOLS) == names, (sorted(set(names) ^ set(SYMBOLS)))
     L = load_library()
-    assert L.lra_abi_version() == 8
+    assert L.lra_abi_version() == 9
 
 
 def test_no_gpu_means_loud_failure():

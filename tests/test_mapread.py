@@ -710,3 +710,23 @@ def test_two_stage_batches_give_the_same_records_with_the_front_half_of_the_next
     assert not err2, err2
     assert [i for i, _ in failed] == [1]
     assert got2[0] == want[0][0] and got2[2] == want[2][0] and isinstance(got2[1], str) and "front half of this batch failed" in got2[1]
+
+
+@pytest.mark.gpu
+def test_release_buffers_keeps_the_reference(ctx):
+    """lra_ctx_release_buffers (ABI 9): the work buffers go back to the device, the reference stays loaded, the next batch maps as before."""
+    import torch
+    from lra_amd import seed, mapread
+    genome = synth.make_genome(300_000, seed=77, repeat_frac=0.2, n_families=2)
+    ik, ip = synth.build_global_index(genome, 17, 10, 100)
+    reads, _ = synth.simulate_reads(genome, 24, 9000, 2000, 0.10, (30, 35, 35), seed=5)
+    mapper = mapread.LowAccMapper(ctx, genome, ik, ip, [b"chr1"], [0, len(genome)], mapread.with_gli(mapread.LowAccOptions()))
+    batch = seed.ReadBatch(ctx, [r.tobytes() for r in reads])
+    a = mapper.fetch(mapper.align(batch))
+    free0 = torch.cuda.mem_get_info()[0]
+    freed = ctx.release_buffers()
+    assert freed > 0 and torch.cuda.mem_get_info()[0] >= free0 + freed // 2
+    b = mapper.fetch(mapper.align(batch))
+    for k in ("job_aln_off", "job_reached", "read_status", "strand", "chrom", "block_off", "blocks", "counts"):
+        assert np.array_equal(a[k], b[k]), k
+    assert ctx.release_buffers() > 0
