@@ -730,3 +730,42 @@ def test_release_buffers_keeps_the_reference(ctx):
     for k in ("job_aln_off", "job_reached", "read_status", "strand", "chrom", "block_off", "blocks", "counts"):
         assert np.array_equal(a[k], b[k]), k
     assert ctx.release_buffers() > 0
+
+
+@pytest.mark.gpu
+def test_best_chain_without_split_chain_ends_the_read(ctx):
+    """Map_lowacc.h:263-267: when SPLITChain + RemoveSpuriousSplitChain leave the FIRST primary chain no split chain the read is unaligned -- the later chains are never
+    looked at, even when one of them is the read's true alignment.  Two 19 kb -CLR reads of the bench's own workload that have the case (tests/golden/
+    clr_best_chain_spurious_reads.fa; found by tools/locate_mismatch.py: a dozen tier-1 anchors in all, the best chain three of them), against the seeded GRCh38-like
+    reference they were simulated from: no chain reaches :574, the device holds no alignment for them, and the record is the unaligned one -- as the oracle's."""
+    import os
+    import torch
+    import oracle_pipeline as OP
+    from lra_amd import seed, mapread, index as I, synth_genome as sg
+    dev = torch.device("cuda", 0)
+    genome, chrom_pos, chrom_names = sg.make_grch38_like(dev, scale=1.0, seed=3)
+    c2 = type(ctx)(0)                                                       # (a context of its own: the session's holds other tests' reference)
+    try:
+        mopts = mapread.with_gli(mapread.clr_options())
+        mapper = mapread.LowAccMapper(c2, genome, None, None, chrom_names, chrom_pos, mopts, index_params=(15, 10, 250, 12, 1), staged=False)
+        del genome
+        fa = open(os.path.join(os.path.dirname(__file__), "golden", "clr_best_chain_spurious_reads.fa")).read().split("\n")
+        reads = [fa[i + 1].encode() for i in range(0, len(fa) - 1, 2) if fa[i].startswith(">")]
+        assert len(reads) == 2
+        res = mapper.align(seed.ReadBatch(c2, reads))
+        out = mapper.fetch(res)
+        na = int(res.num_aln)
+        key, pos = I.global_index(c2)
+        g = c2.to_host(c2.lib.lra_ctx_genome_ptr(c2.h), mapper.G, np.uint8).tobytes() + b"\0" * 64
+        g_index = mapper.fetch_local_index()
+        oo = dict(OP.CLR, localIndexWindow=mopts.localIndexWindow)
+        for r, rd in enumerate(reads):
+            groups, unaligned = OP.map_read_lowacc(rd, g, key, pos, g_index, oo, chrom_pos=mapper.chrom_pos)
+            assert unaligned and sum(len(x) for x in groups) == 0, r        # the oracle: unaligned
+            assert out["read_status"][r] == 0 and not out["job_reached"][r * na:(r + 1) * na].any(), r
+            assert int(out["job_aln_off"][(r + 1) * na]) == int(out["job_aln_off"][r * na]), r
+        assert int(res.n_alignments) == 0
+        sam = mapper.records(res, [b"a", b"b"], reads)
+        assert all(t.split(b"\t")[1] == b"4" and t.count(b"\n") == 1 for t in sam)
+    finally:
+        c2.close()
