@@ -129,6 +129,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-records", action="store_true", help="leave the host tail (SAM text) out of the step")
     ap.add_argument("--satellite-frac", type=float, default=0.03, help="fraction of every chromosome in its satellite array")
+    ap.add_argument("--genome-seed", type=int, default=3, help="seed of the synthetic reference (3 = the one every recorded figure is on)")
     ap.add_argument("--defer-seed", type=int, default=int(os.environ.get("LRA_BENCH_DEFER_SEED", 0)),
                     help="lra_map_opts.defer_seed_matches: reads with more tier-1 matches are handed back by the batch they arrive in, pooled, and mapped as batches of "
                          "their own inside the timed region (cost-ordered batching: every read is mapped exactly once per step either way); 0 = off")
@@ -178,7 +179,7 @@ def main():
 
     # ---- reference side, once per process: genome, StoreIndex, LocalIndex (all on the device)
     t0 = time.time()
-    genome, chrom_pos, chrom_names = sg.make_grch38_like(dev, scale=args.genome_scale, seed=3, satellite_frac=args.satellite_frac)
+    genome, chrom_pos, chrom_names = sg.make_grch38_like(dev, scale=args.genome_scale, seed=args.genome_seed, satellite_frac=args.satellite_frac)
     torch.cuda.synchronize()
     gen_s = time.time() - t0
     ctx = Context(dev_index)
