@@ -730,6 +730,21 @@ def test_release_buffers_keeps_the_reference(ctx):
     for k in ("job_aln_off", "job_reached", "read_status", "strand", "chrom", "block_off", "blocks", "counts"):
         assert np.array_equal(a[k], b[k]), k
     assert ctx.release_buffers() > 0
+    # the same between two-stage batches: the companions' buffers (the back context's, the handover sets') go too; refused while a batch sits between the halves
+    from lra_amd import LraError
+    names = [b"r%d" % i for i in range(len(reads))]
+    raw = [r.tobytes() for r in reads]
+    want = mapper.records(mapper.align(batch), names, raw)
+    for rnd in range(2):
+        mapper.front(batch)
+        with pytest.raises(LraError):
+            ctx.release_buffers()                                          # handed over, not taken
+        res, bctx = mapper.back()
+        with pytest.raises(LraError):
+            ctx.release_buffers()                                          # taken, not released
+        assert mapper.on(bctx).records(res, names, raw) == want, rnd
+        mapper.release()
+        assert ctx.release_buffers() > 0
 
 
 @pytest.mark.gpu
