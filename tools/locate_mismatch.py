@@ -18,6 +18,7 @@ def main():
     ap.add_argument("--reads", type=int, default=28672)
     ap.add_argument("--max-report", type=int, default=12)
     ap.add_argument("--sv-frac", type=float, default=0.05)
+    ap.add_argument("--alnthres", type=float, default=0.0, help="opts.alnthres (-a): the share of the best chain's value a further primary chain needs; low values make second chains common")
     ap.add_argument("--refine-breakpoints", action="store_true", help="--refineBreakpoints (a15, off by default in lra)")
     ap.add_argument("--only-flagged", action="store_true", help="no oracle: the status words of the reads the device flagged")
     args = ap.parse_args()
@@ -35,6 +36,9 @@ def main():
     else:
         mopts = mapread.with_gli(mapread.LowAccOptions()); ip = (17, 10, 150, 12, 1); rl, err, mix = 30000, 0.10, (30, 35, 35); oo = dict(OP.ONT)
     oo["localIndexWindow"] = mopts.localIndexWindow
+    if args.alnthres > 0:
+        import dataclasses
+        mopts = dataclasses.replace(mopts, alnthres=args.alnthres); oo["alnthres"] = args.alnthres
     if args.refine_breakpoints:
         import dataclasses
         mopts = dataclasses.replace(mopts, refineBreakpoint=True); oo["refineBreakpoint"] = True
