@@ -111,8 +111,8 @@ def cpu_baseline(mapper, reads_h, off_h, args, last_res=None, opts=None, sample=
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=5)
-    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)        # (the pipeline of three contexts takes ~3 steps to fill: fewer warm-up steps time its ramp)
+    ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--genome-scale", type=float, default=float(os.environ.get("LRA_BENCH_GENOME_SCALE", 1.0)), help="1.0 = GRCh38-sized (3.09 Gb)")
     ap.add_argument("--reads", type=int, default=int(os.environ.get("LRA_BENCH_READS", 28672)),
                     help="reads per GPU per step (a batch: the pipeline's granularity, not the job's size).  28672: the largest batch beside which the seed stage of the front half "
