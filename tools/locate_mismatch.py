@@ -18,6 +18,7 @@ def main():
     ap.add_argument("--reads", type=int, default=28672)
     ap.add_argument("--max-report", type=int, default=12)
     ap.add_argument("--sv-frac", type=float, default=0.05)
+    ap.add_argument("--n-frac", type=float, default=0.0, help="this share of the reads gets a run of N (20-400 bases) and a run of lower-case bases")
     ap.add_argument("--alnthres", type=float, default=0.0, help="opts.alnthres (-a): the share of the best chain's value a further primary chain needs; low values make second chains common")
     ap.add_argument("--refine-breakpoints", action="store_true", help="--refineBreakpoints (a15, off by default in lra)")
     ap.add_argument("--only-flagged", action="store_true", help="no oracle: the status words of the reads the device flagged")
@@ -45,6 +46,17 @@ def main():
     mapper = mapread.LowAccMapper(ctx, genome, None, None, chrom_names, chrom_pos, mopts, index_params=ip, staged=False)
     sim = sg.simulate_reads_sv(genome, chrom_pos, args.reads, rl, rl / 10, err, mix, 1000, sv_frac=args.sv_frac)
     off_h = sim["off"].cpu().numpy(); total = int(off_h[-1])
+    if args.n_frac > 0:                                                       # N runs (MinCount.h skips windows with an N; IndelRefine / statistics see the bases as they are) and lower case
+        rng = np.random.default_rng(7)
+        seq = sim["seq"]
+        for r in np.nonzero(rng.random(args.reads) < args.n_frac)[0]:
+            a, b = int(off_h[r]), int(off_h[r + 1])
+            if b - a < 2000:
+                continue
+            x = a + int(rng.integers(0, b - a - 500)); ln = int(rng.integers(20, 400))
+            seq[x:x + ln] = ord("N")
+            y = a + int(rng.integers(0, b - a - 500)); l2 = int(rng.integers(20, 400))
+            seq[y:y + l2] = seq[y:y + l2] | 32
     reads_h = np.frombuffer(sim["seq"][:total].cpu().numpy().tobytes(), np.uint8)
     del genome
     lseq = torch.cat([sim["seq"][:total], torch.zeros(64, dtype=torch.uint8, device=dev)])
