@@ -22,8 +22,8 @@ def main():
     ap.add_argument("--reads", type=int, default=0)
     ap.add_argument("--read-len", type=int, default=0)
     ap.add_argument("--genome-scale", type=float, default=0.0)
-    ap.add_argument("--steps", type=int, default=3)
-    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--gli", type=int, default=1, help="1: the local index as `lra index` writes it (k = 10, w = 5, windows of 2048 bases: what glIndex.Read hands `lra align`); "
                                                        "0: `lra align` without a .gli file (opts.localK, windows of 256 bases)")
     ap.add_argument("--two-stage", type=int, default=0, help="-CLR only: two-stage batches (lra_map_reads_lowacc_front / _back), as bench.py runs the headline step")
